@@ -1,0 +1,271 @@
+/*
+ * oracle/models_oracle.c -- TEST INFRASTRUCTURE ONLY (never linked into the product).
+ *
+ * Plain-C restatement of the model library the reference's tests use:
+ *     /root/reference/test/test_utils.cpp:18-41    discrete double integrator + Jacobian
+ *     /root/reference/test/test_utils.cpp:43-82    pendulum continuous dynamics + Jacobian
+ *     /root/reference/test/test_utils.cpp:84-132   midpoint discretisation + chain-rule Jacobian
+ *     /root/reference/test/test_utils.cpp:134-238  kinematic bicycle (3 reference frames)
+ * Pinned by the reference's own model goldens (tests/golden/reference_kats.json):
+ *     test/double_integrator_test.cpp:52,59-63, test/pendulum_test.cpp:32,40,
+ *     test/bicycle_test.cpp:39,46-48.
+ *
+ * `float h`: the reference passes the time step as a C float (typedefs.hpp:31-35); the
+ * double integrator computes b = h*h/2 in float arithmetic before widening
+ * (test_utils.cpp:20).  That is reproduced here because it is visible at 1e-7.
+ */
+#include <math.h>
+#include <string.h>
+
+#define ORACLE_MODEL_DOUBLE_INTEGRATOR 0
+#define ORACLE_MODEL_PENDULUM 1
+#define ORACLE_MODEL_BICYCLE 2
+
+/* ---- double integrator (test_utils.cpp:18-41) ---------------------------------- */
+void oracle_di_dynamics(double* xnext, const double* x, const double* u, float h, int dim) {
+  double b = h * h / 2; /* float arithmetic, then widened -- as in the reference */
+  for (int i = 0; i < dim; ++i) {
+    xnext[i] = x[i] + x[i + dim] * h + u[i] * b;
+    xnext[i + dim] = x[i + dim] + u[i] * h;
+  }
+}
+
+/* jac is (2dim x 3dim) column-major = [A B] */
+void oracle_di_jacobian(double* jac, const double* x, const double* u, float h, int dim) {
+  (void)x; (void)u;
+  const int n = 2 * dim;
+  memset(jac, 0, sizeof(double) * n * 3 * dim);
+  double b = h * h / 2;
+#define J(i, j) jac[(i) + (j) * n]
+  for (int i = 0; i < dim; ++i) {
+    J(i, i) = 1.0;
+    J(i + dim, i + dim) = 1.0;
+    J(i, i + dim) = h;
+    J(i, 2 * dim + i) = b;
+    J(i + dim, 2 * dim + i) = h;
+  }
+#undef J
+}
+
+/* Variant with a true double time step (used to reproduce the golden constants, which
+ * were generated for h = 0.01 as a double: SURVEY.md section 0 item 5).              */
+void oracle_di_dynamics_hd(double* xnext, const double* x, const double* u, double h, int dim) {
+  double b = h * h / 2;
+  for (int i = 0; i < dim; ++i) {
+    xnext[i] = x[i] + x[i + dim] * h + u[i] * b;
+    xnext[i + dim] = x[i + dim] + u[i] * h;
+  }
+}
+void oracle_di_jacobian_hd(double* jac, double h, int dim) {
+  const int n = 2 * dim;
+  memset(jac, 0, sizeof(double) * n * 3 * dim);
+  double b = h * h / 2;
+  for (int i = 0; i < dim; ++i) {
+    jac[i + i * n] = 1.0;
+    jac[(i + dim) + (i + dim) * n] = 1.0;
+    jac[i + (i + dim) * n] = h;
+    jac[i + (2 * dim + i) * n] = b;
+    jac[(i + dim) + (2 * dim + i) * n] = h;
+  }
+}
+
+/* ---- pendulum (test_utils.cpp:43-82) ------------------------------------------- */
+static const double kPendulumMass = 1.0;
+static const double kPendulumLength = 0.5;
+static const double kPendulumFrictionCoeff = 0.1;
+static const double kPendulumGravity = 9.81;
+
+void oracle_pendulum_dynamics(double* xdot, const double* x, const double* u) {
+  double l = kPendulumLength, g = kPendulumGravity, b = kPendulumFrictionCoeff;
+  double m = kPendulumMass * l * l;
+  double theta = x[0], omega = x[1];
+  double omega_dot = u[0] / m - g * sin(theta) / l - b * omega / m;
+  xdot[0] = omega;
+  xdot[1] = omega_dot;
+}
+
+void oracle_pendulum_jacobian(double* jac, const double* x, const double* u) {
+  (void)u;
+  double l = kPendulumLength, g = kPendulumGravity, b = kPendulumFrictionCoeff;
+  double m = kPendulumMass * l * l;
+  jac[0] = 0.0;
+  jac[1] = -g * cos(x[0]) / l;
+  jac[2] = 1.0;
+  jac[3] = -b / m;
+  jac[4] = 0.0;
+  jac[5] = 1 / m;
+}
+
+/* ---- bicycle (test_utils.cpp:134-238; defaults test_utils.hpp:142-143) ---------- */
+typedef struct {
+  int frame;       /* 0 = CenterOfGravity, 1 = Rear, 2 = Front */
+  double length;   /* 2.7 */
+  double lr;       /* 1.5 */
+} oracle_bicycle;
+
+void oracle_bicycle_dynamics(const oracle_bicycle* mdl, double* x_dot, const double* x,
+                             const double* u) {
+  double v = u[0], delta_dot = u[1], theta = x[2], delta = x[3];
+  double beta = 0, omega = 0, stheta = 0, ctheta = 0;
+  switch (mdl->frame) {
+    case 0:
+      beta = atan2(mdl->lr * delta, mdl->length);
+      omega = v * cos(beta) * tan(delta) / mdl->length;
+      stheta = sin(theta + beta);
+      ctheta = cos(theta + beta);
+      break;
+    case 1:
+      omega = v * tan(delta) / mdl->length;
+      stheta = sin(theta);
+      ctheta = cos(theta);
+      break;
+    default:
+      omega = v * sin(delta) / mdl->length;
+      stheta = sin(theta + delta);
+      ctheta = cos(theta + delta);
+      break;
+  }
+  x_dot[0] = v * ctheta;
+  x_dot[1] = v * stheta;
+  x_dot[2] = omega;
+  x_dot[3] = delta_dot;
+}
+
+void oracle_bicycle_jacobian(const oracle_bicycle* mdl, double* jac, const double* x,
+                             const double* u) {
+  double v = u[0], theta = x[2], delta = x[3];
+  double beta = 0, dbeta_ddelta = 0, by = 0, bx = 0, domega_ddelta = 0, domega_dv = 0;
+  double stheta = 0, ctheta = 0, ds_dtheta = 0, dc_dtheta = 0, ds_ddelta = 0, dc_ddelta = 0;
+  switch (mdl->frame) {
+    case 0:
+      by = mdl->lr * delta;
+      bx = mdl->length;
+      beta = atan2(by, bx);
+      dbeta_ddelta = bx / (bx * bx + by * by) * mdl->lr;
+      domega_ddelta = v / mdl->length * (-sin(beta) * tan(delta) * dbeta_ddelta +
+                                         cos(beta) / (cos(delta) * cos(delta)));
+      domega_dv = cos(beta) * tan(delta) / mdl->length;
+      stheta = sin(theta + beta);
+      ctheta = cos(theta + beta);
+      ds_dtheta = +cos(theta + beta);
+      dc_dtheta = -sin(theta + beta);
+      ds_ddelta = +cos(theta + beta) * dbeta_ddelta;
+      dc_ddelta = -sin(theta + beta) * dbeta_ddelta;
+      break;
+    case 1:
+      domega_ddelta = v / mdl->length / (cos(delta) * cos(delta));
+      domega_dv = tan(delta) / mdl->length;
+      stheta = sin(theta);
+      ctheta = cos(theta);
+      ds_dtheta = +cos(theta);
+      dc_dtheta = -sin(theta);
+      break;
+    default:
+      domega_ddelta = v / mdl->length * cos(delta);
+      domega_dv = sin(delta) / mdl->length;
+      stheta = sin(theta + delta);
+      ctheta = cos(theta + delta);
+      ds_dtheta = +cos(theta + delta);
+      dc_dtheta = -sin(theta + delta);
+      ds_ddelta = ds_dtheta;
+      dc_ddelta = dc_dtheta;
+      break;
+  }
+  memset(jac, 0, sizeof(double) * 24);
+#define J(i, j) jac[(i) + (j) * 4]
+  J(0, 2) = v * dc_dtheta;
+  J(0, 3) = v * dc_ddelta;
+  J(0, 4) = ctheta;
+  J(1, 2) = v * ds_dtheta;
+  J(1, 3) = v * ds_ddelta;
+  J(1, 4) = stheta;
+  J(2, 3) = domega_ddelta;
+  J(2, 4) = domega_dv;
+  J(3, 5) = 1.0;
+#undef J
+}
+
+/* ---- generic continuous-model dispatch + midpoint rule (test_utils.cpp:84-132) --- */
+typedef struct {
+  int kind;            /* ORACLE_MODEL_* */
+  int dim;             /* double integrator only */
+  oracle_bicycle bike; /* bicycle only */
+} oracle_model;
+
+#define ORACLE_MAX_N 16
+#define ORACLE_MAX_M 8
+
+static void cont_dyn(const oracle_model* mdl, double* xdot, const double* x, const double* u) {
+  if (mdl->kind == ORACLE_MODEL_PENDULUM) oracle_pendulum_dynamics(xdot, x, u);
+  else oracle_bicycle_dynamics(&mdl->bike, xdot, x, u);
+}
+static void cont_jac(const oracle_model* mdl, double* jac, const double* x, const double* u) {
+  if (mdl->kind == ORACLE_MODEL_PENDULUM) oracle_pendulum_jacobian(jac, x, u);
+  else oracle_bicycle_jacobian(&mdl->bike, jac, x, u);
+}
+
+void oracle_model_dims(const oracle_model* mdl, int* n, int* m) {
+  switch (mdl->kind) {
+    case ORACLE_MODEL_DOUBLE_INTEGRATOR: *n = 2 * mdl->dim; *m = mdl->dim; break;
+    case ORACLE_MODEL_PENDULUM: *n = 2; *m = 1; break;
+    default: *n = 4; *m = 2; break;
+  }
+}
+
+/* x+ = x + h f(x + h/2 f(x,u), u)   (test_utils.cpp:85-95; `h / 2` is float arithmetic) */
+void oracle_discrete_dynamics(const oracle_model* mdl, double* xn, const double* x,
+                              const double* u, float h) {
+  if (mdl->kind == ORACLE_MODEL_DOUBLE_INTEGRATOR) {
+    oracle_di_dynamics(xn, x, u, h, mdl->dim);
+    return;
+  }
+  int n, m;
+  oracle_model_dims(mdl, &n, &m);
+  double xm[ORACLE_MAX_N];
+  cont_dyn(mdl, xm, x, u);
+  for (int i = 0; i < n; ++i) xm[i] *= h / 2;
+  for (int i = 0; i < n; ++i) xm[i] += x[i];
+  cont_dyn(mdl, xn, xm, u);
+  for (int i = 0; i < n; ++i) xn[i] = x[i] + h * xn[i];
+}
+
+/* jac (n x (n+m)) col-major:  A = I + h Am (I + h/2 A),  B = h (Am h/2 B + Bm)
+ * (test_utils.cpp:113-129)                                                          */
+void oracle_discrete_jacobian(const oracle_model* mdl, double* jac, const double* x,
+                              const double* u, float h) {
+  if (mdl->kind == ORACLE_MODEL_DOUBLE_INTEGRATOR) {
+    oracle_di_jacobian(jac, x, u, h, mdl->dim);
+    return;
+  }
+  int n, m;
+  oracle_model_dims(mdl, &n, &m);
+  double xm[ORACLE_MAX_N];
+  double J0[ORACLE_MAX_N * (ORACLE_MAX_N + ORACLE_MAX_M)];
+  double Jm[ORACLE_MAX_N * (ORACLE_MAX_N + ORACLE_MAX_M)];
+  cont_dyn(mdl, xm, x, u);
+  for (int i = 0; i < n; ++i) xm[i] = x[i] + h / 2 * xm[i];
+  cont_jac(mdl, J0, x, u);
+  cont_jac(mdl, Jm, xm, u);
+  const double* A = J0;
+  const double* B = J0 + n * n;
+  const double* Am = Jm;
+  const double* Bm = Jm + n * n;
+  /* T = I + h/2 A */
+  double T[ORACLE_MAX_N * ORACLE_MAX_N];
+  for (int j = 0; j < n; ++j)
+    for (int i = 0; i < n; ++i) T[i + j * n] = (i == j ? 1.0 : 0.0) + h / 2 * A[i + j * n];
+  /* A_d = I + (h Am) T */
+  for (int j = 0; j < n; ++j)
+    for (int i = 0; i < n; ++i) {
+      double s = 0;
+      for (int k = 0; k < n; ++k) s += (h * Am[i + k * n]) * T[k + j * n];
+      jac[i + j * n] = (i == j ? 1.0 : 0.0) + s;
+    }
+  /* B_d = h ((Am h/2) B + Bm) */
+  for (int j = 0; j < m; ++j)
+    for (int i = 0; i < n; ++i) {
+      double s = 0;
+      for (int k = 0; k < n; ++k) s += (Am[i + k * n] * (double)(h / 2)) * B[k + j * n];
+      jac[i + (n + j) * n] = h * (s + Bm[i + j * n]);
+    }
+}

@@ -1,0 +1,118 @@
+"""Seeded synthetic problem generators shared by tests and bench.py.
+
+PRNG: counter-based splitmix64(seed ^ index) -> U[0,1), seed = 20260928, so that any rank / shard
+can regenerate exactly its slice without communication.  Pure numpy (host side only).
+"""
+import numpy as np
+
+SEED = 20260928
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def splitmix64(idx, seed=SEED):
+    z = (np.asarray(idx, dtype=np.uint64) ^ np.uint64(seed)) + np.uint64(0x9E3779B97F4A7C15)
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def uniform01(shape, stream, first=0, seed=SEED):
+    """U[0,1) doubles; `stream` separates arrays, `first` is the global element offset."""
+    count = int(np.prod(shape))
+    with np.errstate(over="ignore"):
+        idx = np.arange(first, first + count, dtype=np.uint64) + (np.uint64(stream) << np.uint64(40))
+        bits = splitmix64(idx, seed)
+    return ((bits >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))).reshape(shape)
+
+
+def normal(shape, stream, first=0, seed=SEED):
+    count = int(np.prod(shape))
+    u1 = uniform01((count,), stream, 2 * first, seed)
+    u2 = uniform01((count,), stream + 1000, 2 * first, seed)
+    return (np.sqrt(-2.0 * np.log(1.0 - u1)) * np.cos(2 * np.pi * u2)).reshape(shape)
+
+
+def di_blocks(dim, h, n_inputs=None, float_h=True):
+    """[A B] and nothing else for the discrete double integrator (test_utils.cpp:18-41).
+    n_inputs < dim keeps only the first n_inputs actuated axes."""
+    n = 2 * dim
+    m = dim if n_inputs is None else n_inputs
+    if float_h:
+        hf = np.float32(h)
+        b = float(np.float32(hf * hf) / np.float32(2))
+        hd = float(hf)
+    else:
+        hd = float(h)
+        b = hd * hd / 2
+    A = np.eye(n)
+    B = np.zeros((n, m))
+    for i in range(dim):
+        A[i, i + dim] = hd
+        if i < m:
+            B[i, i] = b
+            B[i + dim, i] = hd
+    return A, B
+
+
+def tvlqr_kat_problem(kat, float_h):
+    """The reference's TVLQR known-answer problem (tvlqr_test.cpp:23-66), is_diag data."""
+    N, dim = kat["N"], kat["dim"]
+    n, m = 2 * dim, dim
+    A, B = di_blocks(dim, kat["h"], float_h=float_h)
+    xeq = np.array(kat["xeq"], dtype=float)
+    ueq = np.array(kat["ueq"], dtype=float)
+    f = A @ xeq + B @ ueq
+    Qd = np.full(n, kat["Qd"]); Rd = np.full(m, kat["Rd"]); Qfd = Qd * kat["Qf_scale"]
+    q = np.full(n, kat["q"]); r = np.full(m, kat["r"])
+    cm = lambda M: np.asarray(M).flatten(order="F")
+    out = dict(N=N, n=n, m=m,
+               A=np.tile(cm(A), (1, N, 1)), B=np.tile(cm(B), (1, N, 1)), f=np.tile(f, (1, N, 1)),
+               Qdiag=np.concatenate([np.tile(Qd, (1, N, 1)), Qfd[None, None, :]], axis=1),
+               Rdiag=np.tile(Rd, (1, N, 1)),
+               q=np.tile(q, (1, N + 1, 1)), r=np.tile(r, (1, N, 1)),
+               x0=np.array(kat["x0"], dtype=float)[None, :])
+    # dense equivalents (is_diag = false path, solver.cpp:365)
+    out["Q"] = np.stack([np.diag(v).flatten(order="F") for v in out["Qdiag"][0]])[None]
+    out["R"] = np.stack([np.diag(v).flatten(order="F") for v in out["Rdiag"][0]])[None]
+    out["H"] = np.zeros((1, N, m * n))
+    return out
+
+
+def random_ltv(batch, N, n, m, first=0, h=0.01, dtype=np.float64):
+    """Random LTV-LQ problems (SURVEY 8d, config C4 recipe): A = I + h G, B = h N(0,1),
+    Q = I + 0.1 L L^T, R = 0.1 I + 0.01 M M^T, Qf = 10 Q, q,r ~ N(0, 0.1^2), f ~ h N(0,1)."""
+    G = normal((batch, N, n, n), 1, first * N * n * n) * 0.3
+    A = np.eye(n)[None, None] + h * G
+    B = h * normal((batch, N, n, m), 3, first * N * n * m)
+    f = h * normal((batch, N, n), 5, first * N * n)
+    L = normal((batch, N + 1, n, n), 7, first * (N + 1) * n * n)
+    Q = np.eye(n)[None, None] + 0.1 * L @ np.swapaxes(L, -1, -2)
+    Q[:, N] *= 10.0
+    M = normal((batch, N, m, m), 9, first * N * m * m)
+    R = 0.1 * np.eye(m)[None, None] + 0.01 * M @ np.swapaxes(M, -1, -2)
+    H = 0.01 * normal((batch, N, m, n), 11, first * N * m * n)
+    q = 0.1 * normal((batch, N + 1, n), 13, first * (N + 1) * n)
+    r = 0.1 * normal((batch, N, m), 15, first * N * m)
+    x0 = 2.0 * uniform01((batch, n), 17, first * n) - 1.0
+    colmajor = lambda T: np.ascontiguousarray(np.swapaxes(T, -1, -2)).reshape(T.shape[0], T.shape[1], -1)
+    return dict(N=N, n=n, m=m, A=colmajor(A).astype(dtype), B=colmajor(B).astype(dtype),
+                f=f.astype(dtype), Q=colmajor(Q).astype(dtype), R=colmajor(R).astype(dtype),
+                H=colmajor(H).astype(dtype), q=q.astype(dtype), r=r.astype(dtype),
+                x0=x0.astype(dtype))
+
+
+def c1_double_integrator(batch, N=256, first=0, h=0.01):
+    """Config C1 (BASELINE.json configs[1]): DI dim=6 -> n=12, first four axes actuated -> m=4,
+    Q=I, R=1e-2 I, Qf=100 I, xref=0, x0 ~ U(-1,1); time-varying STORAGE (blocks repeated per k)."""
+    dim, n, m = 6, 12, 4
+    A, B = di_blocks(dim, h, n_inputs=m, float_h=True)
+    cm = lambda M_: np.asarray(M_).flatten(order="F")
+    Q = np.eye(n); R = 1e-2 * np.eye(m); Qf = 100.0 * np.eye(n)
+    tile = lambda v, K: np.broadcast_to(v, (batch, K) + v.shape).copy()
+    Qs = tile(cm(Q), N + 1)
+    Qs[:, N] = cm(Qf)
+    return dict(N=N, n=n, m=m, A=tile(cm(A), N), B=tile(cm(B), N), f=np.zeros((batch, N, n)),
+                Q=Qs, R=tile(cm(R), N), H=np.zeros((batch, N, m * n)),
+                q=np.zeros((batch, N + 1, n)), r=np.zeros((batch, N, m)),
+                x0=2.0 * uniform01((batch, n), 21, first * n) - 1.0)

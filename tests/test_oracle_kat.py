@@ -1,0 +1,248 @@
+"""Pins the CPU oracle against every known-answer constant the reference's tests hold for the
+hot path.  CPU only."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from tests import problems
+
+
+def _K0(kat):
+    return np.array(kat["K0_rowmajor_2x4"]).reshape(2, 4)
+
+
+@pytest.mark.parametrize("float_h,scale", [(False, 1e-6), (True, 1.0)])
+@pytest.mark.parametrize("is_diag", [True, False])
+def test_tvlqr_kat(kats, float_h, scale, is_diag):
+    """tvlqr_test.cpp:185-213 / solver_impl_test.cpp:120-148.  With h = 0.01 as a double the
+    constants are exact answers (tolerance 1e-12 .. 1e-10); with the reference's `float h`
+    plumbing they hold to the reference's own 1e-6 / 1e-5."""
+    kat = kats["tvlqr_double_integrator"]
+    pr = problems.tvlqr_kat_problem(kat, float_h)
+    if is_diag:
+        out = oracle.backward_batch(pr["A"], pr["B"], pr["f"], pr["Qdiag"], pr["Rdiag"], None,
+                                    pr["q"], pr["r"], 0.0, True)
+    else:
+        out = oracle.backward_batch(pr["A"], pr["B"], pr["f"], pr["Q"], pr["R"], pr["H"],
+                                    pr["q"], pr["r"], 0.0, False)
+    assert out["status"][0] == -1
+    n, m = pr["n"], pr["m"]
+    K0 = out["K"][0, 0].reshape(n, m).T  # column-major (m x n)
+    tol = kat["ref_tol"]
+    assert np.linalg.norm(K0 - _K0(kat)) < tol["K"] * scale
+    assert np.linalg.norm(out["d"][0, 0] - np.array(kat["d0"])) < tol["d"] * scale
+    fw = oracle.forward_batch(pr["A"], pr["B"], pr["f"], out["K"], out["d"], out["P"], out["p"], pr["x0"])
+    assert np.abs(fw["x"][0, -1] - np.array(kat["xN"])).max() < tol["xN"] * scale
+    assert np.abs(fw["y"][0, -1] - np.array(kat["yN"])).max() < tol["yN"] * max(scale, 1e-5)
+
+
+def test_total_mem_size(kats):
+    """tvlqr_test.cpp:71,167: the flat-buffer size helper."""
+    N, n, m = 10, 4, 2
+    nx = np.full(N + 1, n, dtype=np.int32)
+    nu = np.full(N, m, dtype=np.int32)
+    per_k = n + m + n + n * n + n * m + n + n + n + m + m + m * n + m + n * n + n + 2 * (n * n + m * m + m * n + n + m)
+    term = n + n + n + n + n * n + n + 2
+    assert oracle.lib().oracle_tvlqr_TotalMemSize(nx, nu, N, True) == 8 * (N * per_k + term)
+
+
+def test_cholesky_failure_returns_index():
+    """tvlqr.cpp:162-164: a non-PD Quu stops the sweep and returns that knot-point index."""
+    pr = problems.random_ltv(1, 6, 4, 2)
+    pr["R"][0, 2] = -50.0 * np.eye(2).flatten()
+    out = oracle.backward_batch(pr["A"], pr["B"], pr["f"], pr["Q"], pr["R"], pr["H"], pr["q"], pr["r"])
+    assert out["status"][0] == 2
+    reg = oracle.backward_batch(pr["A"], pr["B"], pr["f"], pr["Q"], pr["R"], pr["H"], pr["q"], pr["r"], reg=100.0)
+    assert reg["status"][0] == -1
+
+
+def test_independent_numpy_riccati():
+    """Independent float64 restatement (numpy, textbook Riccati) on a random (12,4) problem:
+    guards the 4x4 factorisation the reference's tests never pin."""
+    pr = problems.random_ltv(2, 16, 12, 4)
+    out = oracle.backward_batch(pr["A"], pr["B"], pr["f"], pr["Q"], pr["R"], pr["H"], pr["q"], pr["r"])
+    N, n, m = 16, 12, 4
+    for b in range(2):
+        M = lambda a, k, r_, c: a[b, k].reshape(c, r_).T
+        P = M(pr["Q"], N, n, n); p = pr["q"][b, N]
+        for k in range(N - 1, -1, -1):
+            A, B, f = M(pr["A"], k, n, n), M(pr["B"], k, n, m), pr["f"][b, k]
+            Qxx = M(pr["Q"], k, n, n) + A.T @ P @ A
+            Quu = M(pr["R"], k, m, m) + B.T @ P @ B
+            Qux = M(pr["H"], k, m, n) + B.T @ P @ A
+            t = p + P @ f
+            Qx = pr["q"][b, k] + A.T @ t
+            Qu = pr["r"][b, k] + B.T @ t
+            K = np.linalg.solve(Quu, Qux); d = -np.linalg.solve(Quu, Qu)
+            np.testing.assert_allclose(M(out["K"], k, m, n), K, rtol=0, atol=1e-10)
+            np.testing.assert_allclose(out["d"][b, k], d, rtol=0, atol=1e-10)
+            P = Qxx + K.T @ Quu @ K - K.T @ Qux - Qux.T @ K
+            p = Qx - K.T @ Quu @ d - K.T @ Qu + Qux.T @ d
+            np.testing.assert_allclose(M(out["P"], k, n, n), P, rtol=1e-11, atol=1e-10)
+            np.testing.assert_allclose(out["p"][b, k], p, rtol=1e-11, atol=1e-10)
+
+
+# ---------------------------------------------------------------- models
+def test_double_integrator_model(kats):
+    kat = kats["double_integrator_model"]
+    L = oracle.lib()
+    x = np.array(kat["x"]); u = np.array(kat["u"]); xn = np.zeros(4)
+    L.oracle_di_dynamics(xn, x, u, kat["h"], 2)
+    assert np.linalg.norm(xn - np.array(kat["xnext"])) < kat["tol"]
+    J = np.zeros(24)
+    L.oracle_di_jacobian(J, x, u, kat["h"], 2)
+    A, B = problems.di_blocks(2, kat["h"])
+    np.testing.assert_allclose(J.reshape(6, 4).T, np.hstack([A, B]), atol=1e-15)
+
+
+def test_pendulum_model(kats):
+    kat = kats["pendulum_model"]
+    L = oracle.lib()
+    mdl = oracle.make_model(oracle.MODEL_PENDULUM)
+    x = np.array(kat["x"]); u = np.array(kat["u"]); xn = np.zeros(2); J = np.zeros(6)
+    L.oracle_discrete_dynamics(C.byref(mdl), xn, x, u, kat["h"])
+    assert np.linalg.norm(xn - np.array(kat["xnext"])) < kat["tol"]
+    L.oracle_discrete_jacobian(C.byref(mdl), J, x, u, kat["h"])
+    assert np.linalg.norm(J.reshape(3, 2).T - np.array(kat["J_rowmajor_2x3"]).reshape(2, 3)) < kat["tol"]
+    # finite-difference check of the chain rule
+    eps = 1e-6
+    for j in range(3):
+        xp, up = x.copy(), u.copy()
+        if j < 2: xp[j] += eps
+        else: up[0] += eps
+        xq = np.zeros(2)
+        L.oracle_discrete_dynamics(C.byref(mdl), xq, xp, up, kat["h"])
+        np.testing.assert_allclose((xq - xn) / eps, J.reshape(3, 2)[j], atol=1e-5)
+
+
+def test_bicycle_model(kats):
+    kat = kats["bicycle_model"]
+    L = oracle.lib()
+    mdl = oracle.make_model(oracle.MODEL_BICYCLE)
+    xd = kat["x_deg"]
+    x = np.array([xd[0], xd[1], xd[2] * np.pi / 180.0, xd[3] * np.pi / 180.0]); u = np.array(kat["u"])
+    xdot = np.zeros(4); J = np.zeros(24)
+    L.oracle_bicycle_dynamics(C.byref(mdl.bike), xdot, x, u)
+    assert np.linalg.norm(xdot - np.array(kat["xdot"])) < kat["tol_xdot"]
+    L.oracle_bicycle_jacobian(C.byref(mdl.bike), J, x, u)
+    assert np.linalg.norm(J.reshape(6, 4).T - np.array(kat["J_rowmajor_4x6"]).reshape(4, 6)) < kat["tol_J"]
+
+
+# ---------------------------------------------------------------- merit function / solver loop
+def _di_solver(kats, float_h):
+    kat = kats["tvlqr_double_integrator"]
+    pr = problems.tvlqr_kat_problem(kat, float_h)
+    N, n, m = pr["N"], pr["n"], pr["m"]
+    s = oracle.ILQR(N, n, m, kat["h"], oracle.DYN_LINEAR, cost_kind=oracle.COST_DIAGONAL)
+    s.L.oracle_ilqr_set_linear_dynamics(s.h, pr["A"][0].copy(), pr["B"][0].copy(), pr["f"][0].ctypes.data_as(C.c_void_p))
+    for k in range(N + 1):
+        Rd = pr["Rdiag"][0, k] if k < N else None
+        r = pr["r"][0, k] if k < N else None
+        s.L.oracle_ilqr_set_diagonal_cost(s.h, k, pr["Qdiag"][0, k].copy(),
+                                          None if Rd is None else Rd.ctypes.data_as(C.c_void_p),
+                                          pr["q"][0, k].copy(),
+                                          None if r is None else r.ctypes.data_as(C.c_void_p), 0.0)
+    s.L.oracle_ilqr_set_initial_state(s.h, pr["x0"][0].copy())
+    s.L.oracle_ilqr_initialize(s.h)
+    return s, pr
+
+
+@pytest.mark.parametrize("float_h,rtol", [(False, 1e-12), (True, 1e-6)])
+def test_merit_function_kat(kats, float_h, rtol):
+    """solver_impl_test.cpp:186-271."""
+    kat = kats["merit_function_double_integrator"]
+    s, pr = _di_solver(kats, float_h)
+    N, n, m = pr["N"], pr["n"], pr["m"]
+    x0 = pr["x0"][0]; xf = np.array(kat["xf"], dtype=float)
+    for k in range(N):
+        theta = k / float(N)
+        s.L.oracle_ilqr_set_state(s.h, k, x0 + (xf - x0) * theta)
+        s.L.oracle_ilqr_set_input(s.h, k, np.full(m, theta))
+    s.L.oracle_ilqr_set_state(s.h, N, xf.copy())
+    s.L.oracle_ilqr_copy_trajectory(s.h)
+    s.L.oracle_ilqr_calc_cost_gradient(s.h)
+    s.L.oracle_ilqr_calc_dynamics_expansions(s.h)
+    s.L.oracle_ilqr_calc_expansions(s.h)
+    assert s.L.oracle_ilqr_backward_pass(s.h) == -1
+    phi1, dphi1 = s.merit(1.0)
+    assert abs(phi1 - kat["phi_alpha1"]) / abs(kat["phi_alpha1"]) < rtol
+    assert abs(dphi1 - kat["dphi_alpha1"]) / abs(kat["dphi_alpha1"]) < rtol
+    eps = 1e-6
+    phi_e, _ = s.merit(1.0 + eps, deriv=False)
+    assert abs(dphi1 - (phi_e - phi1) / eps) / abs(dphi1) < 1e-6  # :247-255
+    phi0, dphi0 = s.merit(0.0)
+    assert abs(phi0 - kat["phi_alpha0"]) / abs(kat["phi_alpha0"]) < rtol
+    assert abs(dphi0 - kat["dphi_alpha0"]) / abs(kat["dphi_alpha0"]) < rtol
+
+
+def test_tvlqr_via_solver_and_stationarity(kats):
+    """solver_impl_test.cpp:110-155: dense path through SolverImpl + stationarity < 1e-10."""
+    kat = kats["tvlqr_double_integrator"]
+    s, pr = _di_solver(kats, False)
+    assert s.L.oracle_ilqr_backward_pass(s.h) == -1
+    assert s.L.oracle_ilqr_backward_pass(s.h) == -1
+    K0 = s.get("K")[0].reshape(4, 2).T
+    assert np.linalg.norm(K0 - _K0(kat)) < 1e-12
+    s.L.oracle_ilqr_linear_rollout(s.h)
+    assert np.abs(s.get("x_cand")[-1] - np.array(kat["xN"])).max() < 1e-11
+    s.L.oracle_ilqr_calc_cost_gradient(s.h)
+    assert s.L.oracle_ilqr_stationarity(s.h) < kat["stationarity_lt"]
+
+
+def test_forward_pass_alpha_one(kats):
+    """solver_impl_test.cpp:273-316: on an LQ problem |dphi(1)| < 1e-8 and alpha == 1.0."""
+    s, pr = _di_solver(kats, True)
+    N, m = pr["N"], pr["m"]
+    for k in range(N):
+        s.L.oracle_ilqr_set_input(s.h, k, np.full(m, k / float(N)))
+    s.L.oracle_ilqr_open_loop_rollout(s.h)
+    s.L.oracle_ilqr_copy_trajectory(s.h)
+    s.L.oracle_ilqr_calc_cost_gradient(s.h)
+    s.L.oracle_ilqr_calc_dynamics_expansions(s.h)
+    s.L.oracle_ilqr_calc_expansions(s.h)
+    s.L.oracle_ilqr_backward_pass(s.h)
+    _, dphi = s.merit(1.0)
+    assert abs(dphi) < 1e-8
+    err, alpha = s.forward_pass()
+    assert err == 0 and alpha == 1.0
+
+
+def test_pendulum_solve(kats):
+    """test/pendulum_test.cpp:45-115: xN to 1e-5 in <= 10 iterations."""
+    kat = kats["pendulum_solve"]
+    N = kat["N"]; n, m = 2, 1
+    h = np.float32(np.float32(kat["tf"]) / float(N))
+    s = oracle.ILQR(N, n, m, h, oracle.DYN_MODEL, oracle.MODEL_PENDULUM, cost_kind=oracle.COST_DIAGONAL)
+    xf = np.array(kat["xf_pi"]) * np.pi
+    for k in range(N + 1):
+        Qd = np.full(n, kat["Qfd"] if k == N else kat["Qd"])
+        s.L.oracle_ilqr_set_lqr_cost(s.h, k, Qd, np.full(m, kat["Rd"]), xf.copy(), np.zeros(m))
+    s.L.oracle_ilqr_set_initial_state(s.h, np.array(kat["x0"], dtype=float))
+    s.L.oracle_ilqr_initialize(s.h)
+    for k in range(N):
+        s.L.oracle_ilqr_set_input(s.h, k, np.full(m, kat["u_init"]))
+    s.L.oracle_ilqr_set_options(s.h, 200, 1e-4, 1e-4, 1e-8, 0)
+    status, iters, log = s.solve()
+    assert status == 0
+    assert iters <= kat["max_iterations"]
+    assert np.linalg.norm(s.get("x")[-1] - np.array(kat["xN"])) < kat["tol"]
+
+
+def test_double_integrator_solve_unconstrained(kats):
+    """test/double_integrator_test.cpp:69-168: Success within iterations_max = 3."""
+    kat = kats["double_integrator_solve"]
+    N = kat["N"]; dim = 2; n, m = 4, 2
+    h = np.float32(np.float32(kat["tf"]) / np.float32(N))
+    s = oracle.ILQR(N, n, m, h, oracle.DYN_MODEL, oracle.MODEL_DI, model_dim=dim, cost_kind=oracle.COST_DIAGONAL)
+    xf = np.array(kat["xf"], dtype=float)
+    for k in range(N + 1):
+        s.L.oracle_ilqr_set_lqr_cost(s.h, k, np.full(n, kat["Q"]), np.full(m, kat["R"]), xf.copy(), np.zeros(m))
+    x0 = np.array(kat["x0"], dtype=float)
+    s.L.oracle_ilqr_set_initial_state(s.h, x0)
+    s.L.oracle_ilqr_initialize(s.h)
+    s.L.oracle_ilqr_set_options(s.h, kat["unconstrained_iterations_max"], 1e-4, 1e-4, 1e-8, 0)
+    status, iters, log = s.solve()
+    assert status == 0 and iters <= 3
+    assert np.linalg.norm(s.get("x")[-1] - xf) < np.linalg.norm(x0 - xf)
