@@ -1,0 +1,46 @@
+"""Builds altro_amd/lib/libaltro_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python -m altro_amd.build [--force]
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+LIB = os.path.join(HERE, "lib", "libaltro_hip.so")
+CSRC = os.path.join(HERE, "csrc")
+
+
+def sources():
+    out = []
+    for d, _, files in os.walk(CSRC):
+        out += [os.path.join(d, f) for f in files if f.endswith((".hip", ".h", ".hpp", ".cpp"))]
+    out += [os.path.join(ROOT, "include", "altro_hip", "altro_hip.h"),
+            os.path.join(ROOT, "include", "tvlqr", "tvlqr.h")]
+    return [s for s in out if os.path.exists(s)]
+
+
+def stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(s) > t for s in sources())
+
+
+def build(force=False, verbose=False):
+    if not (force or stale()):
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    units = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-Wno-unused-result", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + units + ["-o", LIB]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

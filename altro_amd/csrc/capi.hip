@@ -1,0 +1,773 @@
+// capi.hip -- implementation of the C ABI declared in include/altro_hip/altro_hip.h.
+// Host-side plumbing only: handle lifetime, device buffers, layout conversion launches, plan
+// dispatch, error strings.  All arithmetic lives in kernels/*.hip.  There is no CPU fallback: every
+// compute entry point needs a HIP device and says so when there is none.
+#include "altro_hip/altro_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels/pack.hip"
+#include "kernels/tvlqr_generic.hip"
+#include "kernels/tvlqr_mfma16.hip"
+
+using namespace altro_hip;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess)                                                                     \
+      return fail(ALTRO_HIP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),   \
+                  __FILE__, __LINE__);                                                        \
+  } while (0)
+
+constexpr size_t kStageBytes = size_t(256) << 20;
+
+}  // namespace
+
+struct altro_hip_batch {
+  int N = 0, n = 0, m = 0, batch = 0, dtype = 0, plan = 0, device = 0;
+  unsigned flags = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  size_t esz = 8;  // element size on the device
+  // common
+  void* x0 = nullptr;
+  void* delta_V = nullptr;
+  int* status = nullptr;
+  bool dyn_set = false, cost_set = false, x0_set = false, backward_done = false, forward_done = false;
+  int has_f = 0, is_diag = 0;
+  // plan GENERIC: reference layout on the device
+  void* g_arr[G_NUM] = {};
+  int64_t g_bstride[G_NUM] = {};
+  int64_t* g_off = nullptr;
+  int* g_nx = nullptr;
+  int* g_nu = nullptr;
+  // plan MFMA16
+  double *m_in = nullptr, *m_term = nullptr, *m_out = nullptr, *m_outn = nullptr, *m_xuy = nullptr,
+         *m_qblk = nullptr;
+  // staging for host <-> device conversion (grown lazily, never inside the hot path)
+  void* stage = nullptr;
+  size_t stage_bytes = 0;
+  size_t device_bytes = 0;
+  // profiling
+  bool prof = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int prof_launches[2] = {0, 0};
+  double prof_ms[2] = {0, 0};
+};
+
+namespace {
+
+int dmalloc(altro_hip_batch* h, void** p, size_t bytes) {
+  hipError_t e = hipMalloc(p, bytes ? bytes : 16);
+  if (e != hipSuccess) {
+    *p = nullptr;
+    return fail(ALTRO_HIP_ERR_OUT_OF_MEMORY, "hipMalloc(%zu bytes) failed: %s", bytes,
+                hipGetErrorString(e));
+  }
+  h->device_bytes += bytes;
+  return 0;
+}
+
+int ensure_stage(altro_hip_batch* h, size_t bytes) {
+  if (h->stage_bytes >= bytes) return 0;
+  if (h->stage) (void)hipFree(h->stage);
+  h->stage = nullptr;
+  h->stage_bytes = 0;
+  hipError_t e = hipMalloc(&h->stage, bytes);
+  if (e != hipSuccess)
+    return fail(ALTRO_HIP_ERR_OUT_OF_MEMORY, "staging hipMalloc(%zu) failed: %s", bytes,
+                hipGetErrorString(e));
+  h->stage_bytes = bytes;
+  return 0;
+}
+
+inline int grid_for(int64_t total, int block = 256) {
+  int64_t g = (total + block - 1) / block;
+  return (int)std::min<int64_t>(std::max<int64_t>(g, 1), 256 * 32);
+}
+
+// element counts of one knot point's block in the reference layout
+struct Dims {
+  int n, m;
+  int A() const { return n * n; }
+  int B() const { return n * m; }
+  int Q(int diag) const { return diag ? n : n * n; }
+  int R(int diag) const { return diag ? m : m * m; }
+  int H() const { return m * n; }
+};
+
+// Upload one reference-layout host array chunk by chunk and hand each chunk to `consume`.
+// host layout: [batch or 1][nk or 1][block] doubles.
+template <typename F>
+int upload_chunks(altro_hip_batch* h, const double* host, int block, int nk, int k_zero, int b_zero,
+                  int nk_host, int src_off, F consume) {
+  const int src_nk = nk_host > 0 ? nk_host : (k_zero ? 1 : nk);
+  const size_t per_problem = (size_t)src_nk * block * sizeof(double);
+  if (b_zero) {
+    int rc = ensure_stage(h, per_problem);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(h->stage, host, per_problem, hipMemcpyHostToDevice, h->stream));
+    SrcArr s{(const double*)h->stage + src_off, 0, k_zero ? 0 : (int64_t)block};
+    rc = consume(s, 0, h->batch);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+  }
+  int chunk = (int)std::max<size_t>(1, std::min<size_t>(h->batch, kStageBytes / std::max<size_t>(per_problem, 1)));
+  int rc = ensure_stage(h, per_problem * chunk);
+  if (rc) return rc;
+  for (int b0 = 0; b0 < h->batch; b0 += chunk) {
+    const int nb = std::min(chunk, h->batch - b0);
+    HIP_TRY(hipMemcpyAsync(h->stage, host + (size_t)b0 * src_nk * block, per_problem * nb,
+                           hipMemcpyHostToDevice, h->stream));
+    SrcArr s{(const double*)h->stage + src_off, (int64_t)src_nk * block, k_zero ? 0 : (int64_t)block};
+    rc = consume(s, b0, nb);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));  // the staging buffer is reused by the next chunk
+  }
+  return 0;
+}
+
+template <typename T>
+int generic_set(altro_hip_batch* h, int arr, const double* host, int block, int nk, int k_zero,
+                int b_zero, int k0 = 0, int nk_host = -1, int src_off = 0) {
+  // writes knot points [k0, k0+nk) of the device array from a host array that holds nk_host knot
+  // points per problem (default nk, or 1 when k_zero)
+  T* dst = (T*)h->g_arr[arr] + (int64_t)k0 * block;
+  const int64_t bs = h->g_bstride[arr];
+  return upload_chunks(h, host, block, nk, k_zero, b_zero, nk_host, src_off, [&](SrcArr s, int b0, int nb) {
+    const int64_t total = (int64_t)nb * nk * block;
+    hipLaunchKernelGGL(expand_copy_kernel<T>, dim3(grid_for(total)), dim3(256), 0, h->stream, dst,
+                       bs, (int64_t)block, s, block, nk, b0, nb);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "expand_copy launch: %s", hipGetErrorString(e));
+    return 0;
+  });
+}
+
+// Download: run `produce(dst_device, b0, nb)` chunk by chunk into staging, then copy to the host.
+template <typename F>
+int download_chunks(altro_hip_batch* h, double* host, int block, int nk, F produce) {
+  const size_t per_problem = (size_t)nk * block * sizeof(double);
+  int chunk = (int)std::max<size_t>(1, std::min<size_t>(h->batch, kStageBytes / std::max<size_t>(per_problem, 1)));
+  int rc = ensure_stage(h, per_problem * chunk);
+  if (rc) return rc;
+  for (int b0 = 0; b0 < h->batch; b0 += chunk) {
+    const int nb = std::min(chunk, h->batch - b0);
+    rc = produce((double*)h->stage, b0, nb);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(host + (size_t)b0 * nk * block, h->stage, per_problem * nb,
+                           hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  }
+  return 0;
+}
+
+template <typename T>
+int generic_get(altro_hip_batch* h, int arr, double* host, int block, int nk) {
+  const T* src = (const T*)h->g_arr[arr];
+  const int64_t bs = h->g_bstride[arr];
+  return download_chunks(h, host, block, nk, [&](double* dst, int b0, int nb) {
+    const int64_t total = (int64_t)nb * nk * block;
+    hipLaunchKernelGGL(gather_copy_kernel<T>, dim3(grid_for(total)), dim3(256), 0, h->stream, dst,
+                       (int64_t)nk * block, (int64_t)block, src, bs, (int64_t)block, block, nk, b0, nb);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "gather_copy launch: %s", hipGetErrorString(e));
+    return 0;
+  });
+}
+
+int mfma16_get(altro_hip_batch* h, int what, double* host, int block, int nk) {
+  return download_chunks(h, host, block, nk, [&](double* dst, int b0, int nb) {
+    const int64_t total = (int64_t)nb * nk * block;
+    hipLaunchKernelGGL(mfma16_unpack_kernel, dim3(grid_for(total)), dim3(256), 0, h->stream, dst, what,
+                       (const double*)h->m_out, (const double*)h->m_outn, (const double*)h->m_xuy,
+                       (const double*)h->m_qblk, h->N, b0, nb);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "mfma16_unpack launch: %s", hipGetErrorString(e));
+    return 0;
+  });
+}
+
+// Whole-array upload of one reference-layout source for the MFMA16 pack kernels (setup path).
+// `nk_host` = knot points per problem actually present in the host array.
+struct DevSrc {
+  void* dev = nullptr;
+  SrcArr s{nullptr, 0, 0};
+  ~DevSrc() { if (dev) (void)hipFree(dev); }
+};
+int put_src(altro_hip_batch* h, const double* src, int blk, int nk_host, int k_zero, int b_zero,
+            DevSrc* out) {
+  if (!src) return 0;
+  const size_t per_b = (size_t)nk_host * blk;
+  const size_t bytes = (size_t)(b_zero ? 1 : h->batch) * per_b * sizeof(double);
+  if (hipMalloc(&out->dev, bytes) != hipSuccess)
+    return fail(ALTRO_HIP_ERR_OUT_OF_MEMORY, "hipMalloc(%zu) failed", bytes);
+  if (hipMemcpyAsync(out->dev, src, bytes, hipMemcpyHostToDevice, h->stream) != hipSuccess)
+    return fail(ALTRO_HIP_ERR_HIP, "H2D copy failed");
+  out->s = SrcArr{(const double*)out->dev, b_zero ? 0 : (int64_t)per_b, k_zero ? 0 : (int64_t)blk};
+  return 0;
+}
+int mfma16_pack_launch(altro_hip_batch* h, int seg, SrcArr s0, SrcArr s1) {
+  const int64_t total = (int64_t)h->batch * h->N * 192;
+  hipLaunchKernelGGL(mfma16_pack_kernel, dim3(grid_for(total)), dim3(256), 0, h->stream, h->m_in,
+                     h->m_term, seg, s0, s1, h->is_diag, h->N, 0, h->batch);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "mfma16_pack launch: %s", hipGetErrorString(e));
+  return 0;
+}
+
+template <typename T>
+GenericArgs<T> generic_args(altro_hip_batch* h, double reg) {
+  GenericArgs<T> a;
+  for (int i = 0; i < G_NUM; ++i) {
+    a.base[i] = (T*)h->g_arr[i];
+    a.bstride[i] = h->g_bstride[i];
+  }
+  a.off = h->g_off;
+  a.nx = h->g_nx;
+  a.nu = h->g_nu;
+  a.x0 = (const T*)h->x0;
+  a.x0_stride = h->n;
+  a.delta_V = (T*)h->delta_V;
+  a.status = h->status;
+  a.N = h->N;
+  a.batch = h->batch;
+  a.nmax = h->n;
+  a.mmax = h->m;
+  a.reg = (T)reg;
+  a.is_diag = h->is_diag;
+  a.store_q = (h->flags & ALTRO_HIP_STORE_QBLOCKS) ? 1 : 0;
+  a.want_y = 1;
+  return a;
+}
+
+struct ProfScope {
+  altro_hip_batch* h;
+  int slot;
+  ProfScope(altro_hip_batch* h_, int slot_) : h(h_), slot(slot_) {
+    if (h->prof) (void)hipEventRecord(h->ev0, h->stream);
+  }
+  ~ProfScope() {
+    if (h->prof) {
+      (void)hipEventRecord(h->ev1, h->stream);
+      (void)hipEventSynchronize(h->ev1);
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) {
+        h->prof_ms[slot] += ms;
+        h->prof_launches[slot] += 1;
+      }
+    }
+  }
+};
+
+int launch_backward(altro_hip_batch* h, double reg) {
+  ProfScope ps(h, 0);
+  if (h->plan == ALTRO_HIP_PLAN_MFMA16) {
+    Mfma16Args a{h->m_in, h->m_term, h->m_out, h->m_outn, h->m_qblk, (const double*)h->x0, h->m_xuy,
+                 (double*)h->delta_V, h->status, h->N, h->batch, reg, h->has_f};
+    if (h->flags & ALTRO_HIP_STORE_QBLOCKS)
+      hipLaunchKernelGGL(mfma16_backward_kernel<true>, dim3(h->batch), dim3(64), 0, h->stream, a);
+    else
+      hipLaunchKernelGGL(mfma16_backward_kernel<false>, dim3(h->batch), dim3(64), 0, h->stream, a);
+  } else if (h->dtype == ALTRO_HIP_F64) {
+    auto a = generic_args<double>(h, reg);
+    size_t lds = generic_backward_lds_bytes<double>(h->n, h->m);
+    hipLaunchKernelGGL(generic_backward_kernel<double>, dim3(h->batch), dim3(64), lds, h->stream, a);
+  } else {
+    auto a = generic_args<float>(h, reg);
+    size_t lds = generic_backward_lds_bytes<float>(h->n, h->m);
+    hipLaunchKernelGGL(generic_backward_kernel<float>, dim3(h->batch), dim3(64), lds, h->stream, a);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "backward launch: %s", hipGetErrorString(e));
+  return 0;
+}
+
+int launch_forward(altro_hip_batch* h) {
+  ProfScope ps(h, 1);
+  if (h->plan == ALTRO_HIP_PLAN_MFMA16) {
+    Mfma16Args a{h->m_in, h->m_term, h->m_out, h->m_outn, h->m_qblk, (const double*)h->x0, h->m_xuy,
+                 (double*)h->delta_V, h->status, h->N, h->batch, 0.0, h->has_f};
+    hipLaunchKernelGGL(mfma16_forward_kernel, dim3(h->batch), dim3(64), 0, h->stream, a);
+  } else if (h->dtype == ALTRO_HIP_F64) {
+    auto a = generic_args<double>(h, 0.0);
+    size_t lds = (size_t)(2 * h->n + h->m) * sizeof(double) + 64;
+    hipLaunchKernelGGL(generic_forward_kernel<double>, dim3(h->batch), dim3(64), lds, h->stream, a);
+  } else {
+    auto a = generic_args<float>(h, 0.0);
+    size_t lds = (size_t)(2 * h->n + h->m) * sizeof(float) + 64;
+    hipLaunchKernelGGL(generic_forward_kernel<float>, dim3(h->batch), dim3(64), lds, h->stream, a);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "forward launch: %s", hipGetErrorString(e));
+  return 0;
+}
+
+int check(altro_hip_batch* h) {
+  if (!h) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "null handle");
+  hipError_t e = hipSetDevice(h->device);
+  if (e != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "hipSetDevice(%d): %s", h->device, hipGetErrorString(e));
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int altro_hip_version(void) { return ALTRO_HIP_VERSION; }
+const char* altro_hip_last_error(void) { return g_last_error.c_str(); }
+
+int altro_hip_device_count(void) {
+  int c = 0;
+  if (hipGetDeviceCount(&c) != hipSuccess) return 0;
+  return c;
+}
+
+int altro_hip_device_info(int device, char* name, int cap, int* compute_units, int* wave_size) {
+  if (device < 0 || device >= altro_hip_device_count())
+    return fail(ALTRO_HIP_ERR_NO_DEVICE, "no HIP device %d (count = %d)", device, altro_hip_device_count());
+  hipDeviceProp_t p;
+  HIP_TRY(hipGetDeviceProperties(&p, device));
+  if (name && cap > 0) snprintf(name, cap, "%s (%s)", p.name, p.gcnArchName);
+  if (compute_units) *compute_units = p.multiProcessorCount;
+  if (wave_size) *wave_size = p.warpSize;
+  return 0;
+}
+
+int altro_hip_batch_create(altro_hip_batch** out, int N, int n, int m, int batch, int dtype, int plan,
+                           unsigned flags, int device, void* stream) {
+  if (!out) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "out == NULL");
+  *out = nullptr;
+  if (N <= 0 || n <= 0 || m <= 0 || batch <= 0)
+    return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "N, n, m, batch must be positive (got %d %d %d %d)", N, n, m, batch);
+  if (n > 32 || m > 32) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "n, m <= 32 supported (got %d, %d)", n, m);
+  if (dtype != ALTRO_HIP_F64 && dtype != ALTRO_HIP_F32) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "bad dtype %d", dtype);
+  if (altro_hip_device_count() <= device || device < 0)
+    return fail(ALTRO_HIP_ERR_NO_DEVICE, "no HIP device %d: the altro_hip hot path has no CPU fallback", device);
+  const bool mfma_ok = (n == 12 && m == 4 && dtype == ALTRO_HIP_F64);
+  if (plan == ALTRO_HIP_PLAN_AUTO) plan = mfma_ok ? ALTRO_HIP_PLAN_MFMA16 : ALTRO_HIP_PLAN_GENERIC;
+  if (plan == ALTRO_HIP_PLAN_MFMA16 && !mfma_ok)
+    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "plan MFMA16 needs (n, m, dtype) = (12, 4, f64)");
+  if (plan == ALTRO_HIP_PLAN_LANE) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "plan LANE is not built yet");
+  if (plan != ALTRO_HIP_PLAN_MFMA16 && plan != ALTRO_HIP_PLAN_GENERIC)
+    return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "bad plan %d", plan);
+  HIP_TRY(hipSetDevice(device));
+  altro_hip_batch* h = new altro_hip_batch();
+  h->N = N; h->n = n; h->m = m; h->batch = batch; h->dtype = dtype; h->plan = plan;
+  h->flags = flags; h->device = device;
+  h->esz = dtype == ALTRO_HIP_F64 ? 8 : 4;
+  if (stream) { h->stream = (hipStream_t)stream; }
+  else {
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+      delete h;
+      return fail(ALTRO_HIP_ERR_HIP, "hipStreamCreate failed");
+    }
+    h->own_stream = true;
+  }
+  int rc = 0;
+  const size_t B = (size_t)batch, E = h->esz;
+#define ALLOC(ptr, bytes) if (!rc) rc = dmalloc(h, (void**)&(ptr), (bytes))
+  ALLOC(h->x0, B * n * E);
+  ALLOC(h->delta_V, B * 2 * E);
+  ALLOC(h->status, B * sizeof(int));
+  if (plan == ALTRO_HIP_PLAN_MFMA16) {
+    ALLOC(h->m_in, B * N * MF_IN * 8);
+    ALLOC(h->m_term, B * MF_TERM * 8);
+    ALLOC(h->m_out, B * N * MF_OUT * 8);
+    ALLOC(h->m_outn, B * MF_TERM * 8);
+    ALLOC(h->m_xuy, B * (N + 1) * 28 * 8);
+    if (flags & ALTRO_HIP_STORE_QBLOCKS) ALLOC(h->m_qblk, B * N * MF_QB * 8);
+  } else {
+    const int blk[G_NUM] = {n * n, n * m, n, n * n, m * m, m * n, n, m, m * n, m, n * n, n,
+                            n * n, m * m, m * n, n, m, n, m, n};
+    const int nks[G_NUM] = {N, N, N, N + 1, N, N, N + 1, N, N, N, N + 1, N + 1,
+                            N, N, N, N, N, N + 1, N, N + 1};
+    std::vector<int64_t> off((size_t)(N + 1) * G_NUM, 0);
+    for (int a = 0; a < G_NUM; ++a) {
+      const bool qb = (a >= G_Qxx && a <= G_Qu);
+      h->g_bstride[a] = (int64_t)nks[a] * blk[a];
+      for (int k = 0; k <= N; ++k) off[(size_t)k * G_NUM + a] = (int64_t)k * blk[a];
+      if (qb && !(flags & ALTRO_HIP_STORE_QBLOCKS)) continue;
+      ALLOC(h->g_arr[a], B * nks[a] * blk[a] * E);
+    }
+    ALLOC(h->g_off, off.size() * sizeof(int64_t));
+    ALLOC(h->g_nx, (size_t)(N + 1) * sizeof(int));
+    ALLOC(h->g_nu, (size_t)(N + 1) * sizeof(int));
+    if (!rc) {
+      std::vector<int> nx(N + 1, n), nu(N + 1, m);
+      if (hipMemcpy(h->g_off, off.data(), off.size() * sizeof(int64_t), hipMemcpyHostToDevice) != hipSuccess ||
+          hipMemcpy(h->g_nx, nx.data(), nx.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
+          hipMemcpy(h->g_nu, nu.data(), nu.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
+        rc = fail(ALTRO_HIP_ERR_HIP, "table upload failed");
+    }
+  }
+#undef ALLOC
+  if (!rc && (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess))
+    rc = fail(ALTRO_HIP_ERR_HIP, "hipEventCreate failed");
+  if (rc) {
+    altro_hip_batch_destroy(h);
+    return rc;
+  }
+  *out = h;
+  return 0;
+}
+
+void altro_hip_batch_destroy(altro_hip_batch* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  void* ptrs[] = {h->x0, h->delta_V, h->status, h->m_in, h->m_term, h->m_out, h->m_outn, h->m_xuy,
+                  h->m_qblk, h->g_off, h->g_nx, h->g_nu, h->stage};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  for (int a = 0; a < G_NUM; ++a) if (h->g_arr[a]) (void)hipFree(h->g_arr[a]);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int altro_hip_batch_plan(const altro_hip_batch* h) { return h ? h->plan : ALTRO_HIP_ERR_BAD_ARGUMENT; }
+size_t altro_hip_batch_device_bytes(const altro_hip_batch* h) { return h ? h->device_bytes : 0; }
+
+int altro_hip_set_dynamics(altro_hip_batch* h, const double* A, const double* B, const double* f,
+                           int kz, int bz) {
+  int rc = check(h);
+  if (rc) return rc;
+  if (!A || !B) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "A and B are required");
+  const int n = h->n, m = h->m, N = h->N;
+  h->has_f = f ? 1 : 0;
+  if (h->plan == ALTRO_HIP_PLAN_MFMA16) {
+    DevSrc dA, dB, df;
+    const int nkh = kz ? 1 : N;
+    rc = put_src(h, A, n * n, nkh, kz, bz, &dA);
+    if (!rc) rc = put_src(h, B, n * m, nkh, kz, bz, &dB);
+    if (!rc) rc = put_src(h, f, n, nkh, kz, bz, &df);
+    if (!rc) rc = mfma16_pack_launch(h, MSEG_Z, dA.s, dB.s);
+    if (!rc) rc = mfma16_pack_launch(h, MSEG_F, df.s, SrcArr{nullptr, 0, 0});
+    if (!rc) HIP_TRY(hipStreamSynchronize(h->stream));
+  } else if (h->dtype == ALTRO_HIP_F64) {
+    rc = generic_set<double>(h, G_A, A, n * n, N, kz, bz);
+    if (!rc) rc = generic_set<double>(h, G_B, B, n * m, N, kz, bz);
+    if (!rc) {
+      if (f) rc = generic_set<double>(h, G_f, f, n, N, kz, bz);
+      else HIP_TRY(hipMemsetAsync(h->g_arr[G_f], 0, (size_t)h->batch * N * n * h->esz, h->stream));
+    }
+  } else {
+    rc = generic_set<float>(h, G_A, A, n * n, N, kz, bz);
+    if (!rc) rc = generic_set<float>(h, G_B, B, n * m, N, kz, bz);
+    if (!rc) {
+      if (f) rc = generic_set<float>(h, G_f, f, n, N, kz, bz);
+      else HIP_TRY(hipMemsetAsync(h->g_arr[G_f], 0, (size_t)h->batch * N * n * h->esz, h->stream));
+    }
+  }
+  if (!rc) { HIP_TRY(hipStreamSynchronize(h->stream)); h->dyn_set = true; }
+  return rc;
+}
+
+int altro_hip_set_cost(altro_hip_batch* h, const double* Q, const double* R, const double* H,
+                       const double* q, const double* r, int is_diag, int kz, int bz) {
+  int rc = check(h);
+  if (rc) return rc;
+  if (!Q || !R || !q || !r) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "Q, R, q, r are required");
+  if (!is_diag && !H) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "H is required for a dense cost");
+  const int n = h->n, m = h->m, N = h->N;
+  Dims d{n, m};
+  h->is_diag = is_diag ? 1 : 0;
+  // Host Q / q hold N+1 knot points per problem; with k_stride_zero they hold TWO: the running block
+  // and the terminal block (a shared running cost with its own terminal cost is the common case).
+  const int nkQ = kz ? 2 : N + 1;
+  const int nkR = kz ? 1 : N;
+  if (h->plan == ALTRO_HIP_PLAN_MFMA16) {
+    DevSrc dQ, dR, dH, dq, dr;
+    rc = put_src(h, Q, d.Q(is_diag), nkQ, kz, bz, &dQ);
+    if (!rc) rc = put_src(h, R, d.R(is_diag), nkR, kz, bz, &dR);
+    if (!rc && !is_diag) rc = put_src(h, H, d.H(), nkR, kz, bz, &dH);
+    if (!rc) rc = put_src(h, q, n, nkQ, kz, bz, &dq);
+    if (!rc) rc = put_src(h, r, m, nkR, kz, bz, &dr);
+    SrcArr none{nullptr, 0, 0};
+    SrcArr tQ = dQ.s, tq = dq.s;  // terminal views: knot point N, or block 1 of the broadcast pair
+    if (kz) { tQ.p += d.Q(is_diag); tq.p += n; }
+    if (!rc) rc = mfma16_pack_launch(h, MSEG_Q, dQ.s, none);
+    if (!rc) rc = mfma16_pack_launch(h, MSEG_TERM_Q, tQ, none);
+    if (!rc) rc = mfma16_pack_launch(h, MSEG_HR, dH.s, dR.s);
+    if (!rc) rc = mfma16_pack_launch(h, MSEG_QR, dq.s, dr.s);
+    if (!rc) rc = mfma16_pack_launch(h, MSEG_TERM_q, tq, none);
+    if (!rc) HIP_TRY(hipStreamSynchronize(h->stream));
+  } else {
+    auto set = [&](int arr, const double* src, int blk, int nk, int k0, int nk_host, int src_off = 0) -> int {
+      if (!src) {
+        HIP_TRY(hipMemsetAsync(h->g_arr[arr], 0, (size_t)h->batch * nk * blk * h->esz, h->stream));
+        return 0;
+      }
+      return h->dtype == ALTRO_HIP_F64 ? generic_set<double>(h, arr, src, blk, nk, kz, bz, k0, nk_host, src_off)
+                                       : generic_set<float>(h, arr, src, blk, nk, kz, bz, k0, nk_host, src_off);
+    };
+    // NOTE: the device block of Q / R is always dense-sized (n*n / m*m); a diagonal cost keeps its
+    // diagonal in the head of the block, like the reference does (knotpoint_data.cpp:92-95).
+    const int qb = d.Q(is_diag), rb = d.R(is_diag);
+    h->g_bstride[G_Q] = (int64_t)(N + 1) * qb;
+    h->g_bstride[G_R] = (int64_t)N * rb;
+    {
+      std::vector<int64_t> off((size_t)(N + 1) * G_NUM);
+      HIP_TRY(hipMemcpy(off.data(), h->g_off, off.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+      for (int k = 0; k <= N; ++k) {
+        off[(size_t)k * G_NUM + G_Q] = (int64_t)k * qb;
+        off[(size_t)k * G_NUM + G_R] = (int64_t)k * rb;
+      }
+      HIP_TRY(hipMemcpy(h->g_off, off.data(), off.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    }
+    if (kz) {
+      rc = set(G_Q, Q, qb, N, 0, 2);
+      if (!rc) rc = set(G_Q, Q, qb, 1, N, 2, qb);
+      if (!rc) rc = set(G_q, q, n, N, 0, 2);
+      if (!rc) rc = set(G_q, q, n, 1, N, 2, n);
+    } else {
+      rc = set(G_Q, Q, qb, N + 1, 0, -1);
+      if (!rc) rc = set(G_q, q, n, N + 1, 0, -1);
+    }
+    if (!rc) rc = set(G_R, R, rb, N, 0, -1);
+    if (!rc) rc = set(G_H, is_diag ? nullptr : H, d.H(), N, 0, -1);
+    if (!rc) rc = set(G_r, r, m, N, 0, -1);
+  }
+  if (!rc) { HIP_TRY(hipStreamSynchronize(h->stream)); h->cost_set = true; }
+  return rc;
+}
+
+int altro_hip_set_initial_state(altro_hip_batch* h, const double* x0, int bz) {
+  int rc = check(h);
+  if (rc) return rc;
+  if (!x0) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "x0 == NULL");
+  auto consume = [&](SrcArr s, int b0, int nb) -> int {
+    const int64_t total = (int64_t)nb * h->n;
+    if (h->dtype == ALTRO_HIP_F64)
+      hipLaunchKernelGGL(expand_copy_kernel<double>, dim3(grid_for(total)), dim3(256), 0, h->stream,
+                         (double*)h->x0, (int64_t)h->n, (int64_t)h->n, s, h->n, 1, b0, nb);
+    else
+      hipLaunchKernelGGL(expand_copy_kernel<float>, dim3(grid_for(total)), dim3(256), 0, h->stream,
+                         (float*)h->x0, (int64_t)h->n, (int64_t)h->n, s, h->n, 1, b0, nb);
+    if (hipGetLastError() != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "x0 copy launch failed");
+    return 0;
+  };
+  rc = upload_chunks(h, x0, h->n, 1, 1, bz, -1, 0, consume);
+  if (!rc) h->x0_set = true;
+  return rc;
+}
+
+int altro_hip_backward(altro_hip_batch* h, double reg) {
+  int rc = check(h);
+  if (rc) return rc;
+  if (!h->dyn_set || !h->cost_set) return fail(ALTRO_HIP_ERR_NOT_SET, "set_dynamics and set_cost must precede backward");
+  rc = launch_backward(h, reg);
+  if (!rc) h->backward_done = true;
+  return rc;
+}
+
+int altro_hip_forward_ltv(altro_hip_batch* h) {
+  int rc = check(h);
+  if (rc) return rc;
+  if (!h->backward_done) return fail(ALTRO_HIP_ERR_NOT_SET, "backward must precede forward_ltv");
+  if (!h->x0_set) return fail(ALTRO_HIP_ERR_NOT_SET, "set_initial_state must precede forward_ltv");
+  rc = launch_forward(h);
+  if (!rc) h->forward_done = true;
+  return rc;
+}
+
+int altro_hip_sweep(altro_hip_batch* h, double reg) {
+  int rc = altro_hip_backward(h, reg);
+  if (!rc) rc = altro_hip_forward_ltv(h);
+  return rc;
+}
+
+int altro_hip_synchronize(altro_hip_batch* h) {
+  int rc = check(h);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+#define GETTER(NAME, GARR, MWHAT, BLOCK, NK, NEED_FWD)                                          \
+  int altro_hip_get_##NAME(altro_hip_batch* h, double* dst) {                                  \
+    int rc = check(h);                                                                          \
+    if (rc) return rc;                                                                          \
+    if (!dst) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "NULL destination");                      \
+    if (!(NEED_FWD ? h->forward_done : h->backward_done))                                       \
+      return fail(ALTRO_HIP_ERR_NOT_SET, "nothing computed yet for get_" #NAME);                \
+    if (h->plan == ALTRO_HIP_PLAN_MFMA16) return mfma16_get(h, MWHAT, dst, BLOCK, NK);          \
+    return h->dtype == ALTRO_HIP_F64 ? generic_get<double>(h, GARR, dst, BLOCK, NK)            \
+                                     : generic_get<float>(h, GARR, dst, BLOCK, NK);            \
+  }
+GETTER(K, G_K, MGET_K, h->m * h->n, h->N, false)
+GETTER(d, G_d, MGET_d, h->m, h->N, false)
+GETTER(P, G_P, MGET_P, h->n * h->n, h->N + 1, false)
+GETTER(p, G_p, MGET_p, h->n, h->N + 1, false)
+GETTER(x, G_x, MGET_x, h->n, h->N + 1, true)
+GETTER(u, G_u, MGET_u, h->m, h->N, true)
+GETTER(y, G_y, MGET_y, h->n, h->N + 1, true)
+#undef GETTER
+
+int altro_hip_get_delta_V(altro_hip_batch* h, double* dV) {
+  int rc = check(h);
+  if (rc) return rc;
+  if (!h->backward_done) return fail(ALTRO_HIP_ERR_NOT_SET, "backward has not run");
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (h->dtype == ALTRO_HIP_F64) {
+    HIP_TRY(hipMemcpy(dV, h->delta_V, (size_t)h->batch * 2 * 8, hipMemcpyDeviceToHost));
+  } else {
+    std::vector<float> tmp((size_t)h->batch * 2);
+    HIP_TRY(hipMemcpy(tmp.data(), h->delta_V, tmp.size() * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < tmp.size(); ++i) dV[i] = tmp[i];
+  }
+  return 0;
+}
+
+int altro_hip_get_status(altro_hip_batch* h, int* status) {
+  int rc = check(h);
+  if (rc) return rc;
+  if (!h->backward_done) return fail(ALTRO_HIP_ERR_NOT_SET, "backward has not run");
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(status, h->status, (size_t)h->batch * sizeof(int), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int altro_hip_get_qblocks(altro_hip_batch* h, double* dst) {
+  int rc = check(h);
+  if (rc) return rc;
+  if (!(h->flags & ALTRO_HIP_STORE_QBLOCKS)) return fail(ALTRO_HIP_ERR_NOT_SET, "handle was created without ALTRO_HIP_STORE_QBLOCKS");
+  if (!h->backward_done) return fail(ALTRO_HIP_ERR_NOT_SET, "backward has not run");
+  const int n = h->n, m = h->m, N = h->N;
+  const int per = n * n + m * m + m * n + n + m;
+  if (h->plan == ALTRO_HIP_PLAN_MFMA16) return mfma16_get(h, MGET_QBLK, dst, per, N);
+  // generic: five separate reference-layout arrays -> interleave on the host
+  std::vector<double> tmp((size_t)h->batch * N * n * n);
+  const int arrs[5] = {G_Qxx, G_Quu, G_Qux, G_Qx, G_Qu};
+  const int blks[5] = {n * n, m * m, m * n, n, m};
+  int offp = 0;
+  for (int i = 0; i < 5; ++i) {
+    rc = h->dtype == ALTRO_HIP_F64 ? generic_get<double>(h, arrs[i], tmp.data(), blks[i], N)
+                                   : generic_get<float>(h, arrs[i], tmp.data(), blks[i], N);
+    if (rc) return rc;
+    for (size_t bk = 0; bk < (size_t)h->batch * N; ++bk)
+      memcpy(dst + bk * per + offp, tmp.data() + bk * blks[i], sizeof(double) * blks[i]);
+    offp += blks[i];
+  }
+  return 0;
+}
+
+int altro_hip_stats_reduce(altro_hip_batch* h, altro_hip_stats* out) {
+  int rc = check(h);
+  if (rc) return rc;
+  if (!out) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "out == NULL");
+  if (!h->backward_done) return fail(ALTRO_HIP_ERR_NOT_SET, "backward has not run");
+  std::vector<int> st(h->batch);
+  std::vector<double> dv((size_t)h->batch * 2);
+  rc = altro_hip_get_status(h, st.data());
+  if (!rc) rc = altro_hip_get_delta_V(h, dv.data());
+  if (rc) return rc;
+  out->problems = h->batch;
+  out->cholesky_failures = 0;
+  out->sum_delta_V0 = out->sum_delta_V1 = 0.0;
+  out->max_abs_xN = 0.0;
+  for (int b = 0; b < h->batch; ++b) {
+    if (st[b] != ALTRO_HIP_TVLQR_SUCCESS) { out->cholesky_failures++; continue; }
+    out->sum_delta_V0 += dv[2 * (size_t)b];
+    out->sum_delta_V1 += dv[2 * (size_t)b + 1];
+  }
+  if (h->forward_done) {
+    std::vector<double> x((size_t)h->batch * (h->N + 1) * h->n);
+    rc = altro_hip_get_x(h, x.data());
+    if (rc) return rc;
+    for (int b = 0; b < h->batch; ++b)
+      for (int i = 0; i < h->n; ++i) {
+        double v = std::abs(x[((size_t)b * (h->N + 1) + h->N) * h->n + i]);
+        if (v > out->max_abs_xN) out->max_abs_xN = v;
+      }
+  }
+  return 0;
+}
+
+int altro_hip_profile_enable(altro_hip_batch* h, int enable) {
+  if (!h) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "null handle");
+  h->prof = enable != 0;
+  return 0;
+}
+int altro_hip_profile_reset(altro_hip_batch* h) {
+  if (!h) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "null handle");
+  h->prof_launches[0] = h->prof_launches[1] = 0;
+  h->prof_ms[0] = h->prof_ms[1] = 0.0;
+  return 0;
+}
+int altro_hip_profile_get(altro_hip_batch* h, int slot, int* launches, double* total_ms,
+                          const char** kernel_name) {
+  if (!h || slot < 0 || slot > 1) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "bad handle or slot");
+  if (launches) *launches = h->prof_launches[slot];
+  if (total_ms) *total_ms = h->prof_ms[slot];
+  if (kernel_name) {
+    static const char* names[2][2] = {{"generic_backward_kernel", "generic_forward_kernel"},
+                                      {"mfma16_backward_kernel", "mfma16_forward_kernel"}};
+    *kernel_name = names[h->plan == ALTRO_HIP_PLAN_MFMA16 ? 1 : 0][slot];
+  }
+  return 0;
+}
+
+double altro_hip_algorithmic_bytes(const altro_hip_batch* h, int slot) {
+  if (!h) return 0.0;
+  const double n = h->n, m = h->m, w = (double)h->esz;
+  // backward 3n^2+3nm+m^2+3n+2m, forward-LTV 2n^2+2nm+4n+2m elements per kp
+  const double bwd = 3 * n * n + 3 * n * m + m * m + 3 * n + 2 * m;
+  const double fwd = 2 * n * n + 2 * n * m + 4 * n + 2 * m;
+  return (slot == 0 ? bwd : fwd) * w * (double)h->N * (double)h->batch;
+}
+
+// MFMA layout self-test (tests/test_gpu_parity.py): max |D - (A B + C)| for random operands.
+double altro_hip_selftest_mfma_f64(int device) {
+  if (hipSetDevice(device) != hipSuccess) return -1.0;
+  double hA[64], hB[64], hC[256], hD[256];
+  unsigned s = 12345u;
+  auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (double)(s >> 8) / (1 << 24) - 0.5; };
+  for (double& v : hA) v = rnd();
+  for (double& v : hB) v = rnd();
+  for (double& v : hC) v = rnd();
+  double *dA, *dB, *dC, *dD;
+  if (hipMalloc(&dA, sizeof(hA)) != hipSuccess || hipMalloc(&dB, sizeof(hB)) != hipSuccess ||
+      hipMalloc(&dC, sizeof(hC)) != hipSuccess || hipMalloc(&dD, sizeof(hD)) != hipSuccess)
+    return -1.0;
+  (void)hipMemcpy(dA, hA, sizeof(hA), hipMemcpyHostToDevice);
+  (void)hipMemcpy(dB, hB, sizeof(hB), hipMemcpyHostToDevice);
+  (void)hipMemcpy(dC, hC, sizeof(hC), hipMemcpyHostToDevice);
+  hipLaunchKernelGGL(mfma16_selftest_kernel, dim3(1), dim3(64), 0, 0, dA, dB, dC, dD);
+  if (hipMemcpy(hD, dD, sizeof(hD), hipMemcpyDeviceToHost) != hipSuccess) return -1.0;
+  (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dC); (void)hipFree(dD);
+  double worst = 0.0;
+  for (int i = 0; i < 16; ++i)
+    for (int j = 0; j < 16; ++j) {
+      double ref = hC[i * 16 + j];
+      for (int k = 0; k < 4; ++k) ref += hA[i * 4 + k] * hB[k * 16 + j];
+      worst = std::max(worst, std::abs(ref - hD[i * 16 + j]));
+    }
+  return worst;
+}
+
+}  // extern "C"

@@ -1,0 +1,146 @@
+// pack.hip -- layout conversion between the reference layout ([batch][k][column-major block], what
+// the reference's callers hold: src/altro/solver/solver.cpp:63-106) and each plan's private device
+// layout.  Runs on the device so that broadcast inputs (one A for every k and every problem) are
+// expanded in HBM instead of on the host.  Setup/teardown path: never inside the timed sweep.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "tvlqr_mfma16.hip"
+
+namespace altro_hip {
+
+struct SrcArr {
+  const double* p;   // device pointer, reference layout, relative to the chunk's first problem
+  int64_t bs, ks;    // strides in elements between problems / knot points (0 = broadcast)
+};
+
+// dst[(b0+b)*dst_bs + k*dst_ks + e] = src[b*bs + k*ks + e],  e < block, k < nk, b < nb
+template <typename T>
+__global__ void expand_copy_kernel(T* dst, int64_t dst_bs, int64_t dst_ks, SrcArr src, int block,
+                                   int nk, int b0, int nb) {
+  const int64_t total = (int64_t)nb * nk * block;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int e = (int)(t % block);
+    const int k = (int)((t / block) % nk);
+    const int b = (int)(t / ((int64_t)block * nk));
+    dst[(int64_t)(b0 + b) * dst_bs + (int64_t)k * dst_ks + e] =
+        (T)src.p[(int64_t)b * src.bs + (int64_t)k * src.ks + e];
+  }
+}
+
+// out[b*bs + k*ks + e] = (double) src[(b0+b)*src_bs + k*src_ks + e]
+template <typename T>
+__global__ void gather_copy_kernel(double* out, int64_t out_bs, int64_t out_ks, const T* src,
+                                   int64_t src_bs, int64_t src_ks, int block, int nk, int b0, int nb) {
+  const int64_t total = (int64_t)nb * nk * block;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int e = (int)(t % block);
+    const int k = (int)((t / block) % nk);
+    const int b = (int)(t / ((int64_t)block * nk));
+    out[(int64_t)b * out_bs + (int64_t)k * out_ks + e] =
+        (double)src[(int64_t)(b0 + b) * src_bs + (int64_t)k * src_ks + e];
+  }
+}
+
+// ---- plan MFMA16 ------------------------------------------------------------------------------
+enum Mfma16Seg { MSEG_Z = 0, MSEG_F, MSEG_Q, MSEG_HR, MSEG_QR, MSEG_TERM_Q, MSEG_TERM_q };
+
+// One launch fills one segment of IN (or TERM) for problems [b0, b0+nb).  `s0`, `s1` are the one or
+// two reference arrays the segment draws from (Z: A,B ; HR: H,R ; QR: q,r).
+__global__ void mfma16_pack_kernel(double* in, double* term, int seg, SrcArr s0, SrcArr s1,
+                                   int is_diag, int N, int b0, int nb) {
+  int len, base;
+  switch (seg) {
+    case MSEG_Z: len = 192; base = MF_OFF_Z; break;
+    case MSEG_F: len = 12; base = MF_OFF_F; break;
+    case MSEG_Q: len = 144; base = MF_OFF_Q; break;
+    case MSEG_HR: len = 64; base = MF_OFF_HR; break;
+    case MSEG_QR: len = 16; base = MF_OFF_QR; break;
+    case MSEG_TERM_Q: len = 144; base = 0; break;
+    default: len = 12; base = 144; break;
+  }
+  const bool terminal = (seg == MSEG_TERM_Q || seg == MSEG_TERM_q);
+  const int nk = terminal ? 1 : N;
+  const int64_t total = (int64_t)nb * nk * len;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int e = (int)(t % len);
+    const int k = terminal ? N : (int)((t / len) % nk);
+    const int b = (int)(t / ((int64_t)len * nk));
+    const double* p0 = s0.p ? s0.p + (int64_t)b * s0.bs + (int64_t)k * s0.ks : nullptr;
+    const double* p1 = s1.p ? s1.p + (int64_t)b * s1.bs + (int64_t)k * s1.ks : nullptr;
+    double v = 0.0;
+    switch (seg) {
+      case MSEG_Z: {  // Zfrag[c][lane] = Z[4c + (lane>>4)][lane&15],  Z = [A B]
+        const int c = e / 64, l = e % 64, col = l & 15, row = (l >> 4) + 4 * c;
+        v = (col < 12) ? p0[row + 12 * col] : p1[row + 12 * (col - 12)];
+      } break;
+      case MSEG_F: v = p0 ? p0[e] : 0.0; break;
+      case MSEG_Q:
+      case MSEG_TERM_Q: {  // Q rows: [r][g][j] = Q[g+4r][j]
+        const int r = e / 48, g = (e % 48) / 12, jj = e % 12, row = g + 4 * r;
+        v = is_diag ? (row == jj ? p0[row] : 0.0) : p0[row + 12 * jj];
+      } break;
+      case MSEG_HR: {  // [g][j] = j < 12 ? H[g][j] : R[g][j-12]
+        const int g = e / 16, jj = e % 16;
+        if (jj < 12) v = (is_diag || !p0) ? 0.0 : p0[g + 4 * jj];
+        else v = is_diag ? (g == jj - 12 ? p1[g] : 0.0) : p1[g + 4 * (jj - 12)];
+      } break;
+      case MSEG_QR: v = (e < 12) ? p0[e] : p1[e - 12]; break;
+      default: v = p0[e]; break;  // MSEG_TERM_q
+    }
+    if (terminal) term[(int64_t)(b0 + b) * MF_TERM + base + e] = v;
+    else in[((int64_t)(b0 + b) * N + k) * MF_IN + base + e] = v;
+  }
+}
+
+enum Mfma16Get { MGET_K = 0, MGET_d, MGET_P, MGET_p, MGET_x, MGET_u, MGET_y, MGET_QBLK };
+
+// Reference-layout view of the results for problems [b0, b0+nb): dst is [nb][nk][len].
+__global__ void mfma16_unpack_kernel(double* dst, int what, const double* out, const double* outn,
+                                     const double* xuy, const double* qblk, int N, int b0, int nb) {
+  int len, nk;
+  switch (what) {
+    case MGET_K: len = 48; nk = N; break;
+    case MGET_d: len = 4; nk = N; break;
+    case MGET_P: len = 144; nk = N + 1; break;
+    case MGET_p: len = 12; nk = N + 1; break;
+    case MGET_x: len = 12; nk = N + 1; break;
+    case MGET_u: len = 4; nk = N; break;
+    case MGET_y: len = 12; nk = N + 1; break;
+    default: len = 144 + 16 + 48 + 12 + 4; nk = N; break;
+  }
+  const int64_t total = (int64_t)nb * nk * len;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int e = (int)(t % len);
+    const int k = (int)((t / len) % nk);
+    const int b = b0 + (int)(t / ((int64_t)len * nk));
+    const double* o = (k < N) ? out + ((int64_t)b * N + k) * MF_OUT : nullptr;
+    const double* pp = (k < N) ? o + MF_OFF_P : outn + (int64_t)b * MF_TERM;
+    const double* xr = xuy ? xuy + ((int64_t)b * (N + 1) + k) * 28 : nullptr;
+    double v;
+    switch (what) {
+      case MGET_K: v = o[(e % 4) * 13 + (e / 4)]; break;        // K[a + 4 j] = Kt[a][j]
+      case MGET_d: v = -o[e * 13 + 12]; break;                  // d = -Kt[:, 12]
+      case MGET_P: v = pp[(e % 12) * 13 + (e / 12)]; break;     // P[i + 12 j] = tile[i][j]
+      case MGET_p: v = pp[e * 13 + 12]; break;
+      case MGET_x: v = xr[e]; break;
+      case MGET_y: v = xr[12 + e]; break;
+      case MGET_u: v = xr[24 + e]; break;
+      default: {  // Qxx(144) | Quu(16) | Qux(48) | Qx(12) | Qu(4), column-major blocks
+        const double* q = qblk + ((int64_t)b * N + k) * MF_QB;
+        if (e < 144) v = q[(e % 12) * 16 + (e / 12)];
+        else if (e < 160) { int t2 = e - 144; v = q[(12 + t2 % 4) * 16 + 12 + t2 / 4]; }
+        else if (e < 208) { int t2 = e - 160; v = q[(12 + t2 % 4) * 16 + t2 / 4]; }
+        else v = q[256 + (e - 208)];
+      } break;
+    }
+    dst[t] = v;
+  }
+}
+
+}  // namespace altro_hip

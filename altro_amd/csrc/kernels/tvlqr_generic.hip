@@ -1,0 +1,330 @@
+// tvlqr_generic.hip -- plan GENERIC: one wavefront per problem, knot-point blocks staged in LDS.
+//
+// The catch-all implementation of the TVLQR pair for ANY (n_k, m_k) (per-knot-point dimensions
+// allowed, like the reference's `const int* nx, nu` -- src/tvlqr/tvlqr.h:17-33).  It follows the
+// operation order of src/tvlqr/tvlqr.cpp:92-192 (backward) and :208-246 (forward) one statement at
+// a time, with index-ordered dot products and no FMA contraction (this file is compiled with
+// -ffp-contract=off), so that its fp64 results agree with the CPU oracle to the last bit.  It is the
+// correctness anchor for the fast plans and the engine behind the single-problem tvlqr_* drop-in;
+// it is NOT the path bench.py measures (that is tvlqr_mfma16.hip).
+//
+// Mapping: block = 64 threads = 1 wavefront = 1 problem.  Every small product C = op(A) op(B) is
+// spread over the lanes by output element (lane e computes C[e], C[e+64], ...); operands live in LDS
+// so the broadcast reads are bank-conflict-free or same-address.  The k-recursion is serial
+// (P_{k+1} -> P_k), P_{k+1}/p_{k+1} never leave LDS.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace altro_hip {
+
+// Bit-parity with the CPU oracle: no a*b+c -> fma fusion anywhere in this file.
+#pragma clang fp contract(off)
+
+enum GArr {
+  G_A = 0, G_B, G_f, G_Q, G_R, G_H, G_q, G_r,      // inputs
+  G_K, G_d, G_P, G_p,                              // outputs
+  G_Qxx, G_Quu, G_Qux, G_Qx, G_Qu,                 // optional outputs
+  G_x, G_u, G_y,                                   // forward outputs
+  G_NUM
+};
+
+template <typename T>
+struct GenericArgs {
+  T* base[G_NUM];            // per-array base pointer
+  int64_t bstride[G_NUM];    // elements between consecutive problems
+  const int64_t* off;        // [(N+1) * G_NUM] element offset of knot point k inside a problem
+  const int* nx;             // [N+1]
+  const int* nu;             // [N+1] (nu[N] unused)
+  const T* x0;               // [batch][nx[0]]
+  int64_t x0_stride;
+  T* delta_V;                // [batch][2]
+  int* status;               // [batch]
+  int N;
+  int batch;
+  int nmax, mmax;
+  T reg;
+  int is_diag;
+  int store_q;
+  int want_y;
+};
+
+// C(mr x nc) = beta*C + alpha * op(A) op(B); operands column-major in LDS (or global for B/A reads).
+template <typename T>
+__device__ __forceinline__ void wave_gemm(int lane, int ta, int tb, int mr, int nc, int kd, T alpha,
+                                          const T* A, int lda, const T* B, int ldb, T beta, T* C,
+                                          int ldc) {
+  const int total = mr * nc;
+  for (int e = lane; e < total; e += 64) {
+    const int i = e % mr, j = e / mr;
+    T s = T(0);
+    for (int k = 0; k < kd; ++k) {
+      const T a = ta ? A[k + i * lda] : A[i + k * lda];
+      const T b = tb ? B[j + k * ldb] : B[k + j * ldb];
+      s += a * b;
+    }
+    const T c0 = (beta == T(0)) ? T(0) : beta * C[i + j * ldc];
+    C[i + j * ldc] = c0 + alpha * s;
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void wave_copy(int lane, T* dst, const T* src, int count) {
+  for (int e = lane; e < count; e += 64) dst[e] = src[e];
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void generic_backward_kernel(GenericArgs<T> a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* smem = reinterpret_cast<T*>(smem_raw);
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x;
+  if (b >= a.batch) return;
+  const int nm = a.nmax, mm = a.mmax;
+  // LDS carve
+  T* sP = smem;                 // P_{k+1}     nm*nm
+  T* sp = sP + nm * nm;         // p_{k+1}     nm
+  T* sA = sp + nm;              // A_k         nm*nm
+  T* sB = sA + nm * nm;         // B_k         nm*mm
+  T* sf = sB + nm * mm;         // f_k         nm
+  T* sQxx = sf + nm;            // nm*nm
+  T* sQuu = sQxx + nm * nm;     // mm*mm
+  T* sQux = sQuu + mm * mm;     // mm*nm
+  T* sQx = sQux + mm * nm;      // nm
+  T* sQu = sQx + nm;            // mm
+  T* sT1 = sQu + mm;            // Qxx_tmp nm*nm
+  T* sT2 = sT1 + nm * nm;       // Qux_tmp mm*nm
+  T* st = sT2 + mm * nm;        // Qx_tmp  nm
+  T* sL = st + nm;              // Quu_tmp mm*mm
+  T* sK = sL + mm * mm;         // mm*nm
+  T* sd = sK + mm * nm;         // mm
+  T* sPk = sd + mm;             // P_k nm*nm
+  T* spk = sPk + nm * nm;       // p_k nm
+  T* sw = spk + nm;             // Qu_tmp mm
+  int* s_failp = reinterpret_cast<int*>(sw + mm);  // keep ALL LDS in the one dynamic array
+#define s_fail (*s_failp)
+
+#define GPTR(arr, k) (a.base[arr] + (int64_t)b * a.bstride[arr] + a.off[(int64_t)(k) * G_NUM + arr])
+  const int N = a.N;
+  T dv0 = T(0), dv1 = T(0);
+  // terminal cost-to-go (tvlqr.cpp:81-90)
+  {
+    const int n = a.nx[N];
+    const T* Qn = GPTR(G_Q, N);
+    if (a.is_diag) {
+      for (int e = lane; e < n * n; e += 64) sP[e] = (e % n == e / n) ? Qn[e % n] : T(0);
+    } else {
+      wave_copy(lane, sP, Qn, n * n);
+    }
+    wave_copy(lane, sp, (const T*)GPTR(G_q, N), n);
+    __syncthreads();
+    wave_copy(lane, GPTR(G_P, N), (const T*)sP, n * n);
+    wave_copy(lane, GPTR(G_p, N), (const T*)sp, n);
+  }
+  if (lane == 0) s_fail = 0;
+  __syncthreads();
+
+  for (int k = N - 1; k >= 0; --k) {
+    const int n = a.nx[k], m = a.nu[k], n2 = a.nx[k + 1];
+    // stage the knot point
+    wave_copy(lane, sA, (const T*)GPTR(G_A, k), n2 * n);
+    wave_copy(lane, sB, (const T*)GPTR(G_B, k), n2 * m);
+    wave_copy(lane, sf, (const T*)GPTR(G_f, k), n2);
+    if (a.is_diag) {  // tvlqr.cpp:125-128
+      const T* Qd = GPTR(G_Q, k);
+      const T* Rd = GPTR(G_R, k);
+      for (int e = lane; e < n * n; e += 64) sQxx[e] = (e % n == e / n) ? Qd[e % n] : T(0);
+      for (int e = lane; e < m * m; e += 64) sQuu[e] = (e % m == e / m) ? Rd[e % m] : T(0);
+      for (int e = lane; e < m * n; e += 64) sQux[e] = T(0);
+    } else {  // tvlqr.cpp:129-133
+      wave_copy(lane, sQxx, (const T*)GPTR(G_Q, k), n * n);
+      wave_copy(lane, sQuu, (const T*)GPTR(G_R, k), m * m);
+      wave_copy(lane, sQux, (const T*)GPTR(G_H, k), m * n);
+    }
+    wave_copy(lane, sQx, (const T*)GPTR(G_q, k), n);
+    wave_copy(lane, sQu, (const T*)GPTR(G_r, k), m);
+    __syncthreads();
+    // Qxx_tmp = A^T P' ; Qux_tmp = B^T P' ; Qx_tmp = p' + P' f     (tvlqr.cpp:135,139,147-148)
+    wave_gemm<T>(lane, 1, 0, n, n2, n2, T(1), sA, n2, sP, n2, T(0), sT1, n);
+    wave_gemm<T>(lane, 1, 0, m, n2, n2, T(1), sB, n2, sP, n2, T(0), sT2, m);
+    wave_copy(lane, st, (const T*)sp, n2);
+    __syncthreads();
+    wave_gemm<T>(lane, 0, 0, n2, 1, n2, T(1), sP, n2, sf, n2, T(1), st, n2);
+    wave_gemm<T>(lane, 0, 0, n, n, n2, T(1), sT1, n, sA, n2, T(1), sQxx, n);   // :136
+    wave_gemm<T>(lane, 0, 0, m, m, n2, T(1), sT2, m, sB, n2, T(1), sQuu, m);   // :140
+    wave_gemm<T>(lane, 0, 0, m, n, n2, T(1), sT2, m, sA, n2, T(1), sQux, m);   // :143
+    __syncthreads();
+    wave_gemm<T>(lane, 1, 0, n, 1, n2, T(1), sA, n2, st, n2, T(1), sQx, n);    // :149-150
+    wave_gemm<T>(lane, 1, 0, m, 1, n2, T(1), sB, n2, st, n2, T(1), sQu, m);    // :151-152
+    __syncthreads();
+    // gains (tvlqr.cpp:155-166)
+    wave_copy(lane, sK, (const T*)sQux, m * n);
+    for (int e = lane; e < m; e += 64) sd[e] = -sQu[e];
+    for (int e = lane; e < m * m; e += 64) sL[e] = sQuu[e] + ((e % m == e / m) ? a.reg : T(0));
+    __syncthreads();
+    if (lane == 0) {  // unblocked lower Cholesky, fail when the pivot is <= 0 (Eigen llt_inplace)
+      int fail = 0;
+      for (int kk = 0; kk < m && !fail; ++kk) {
+        T x = sL[kk + kk * m];
+        for (int j = 0; j < kk; ++j) x -= sL[kk + j * m] * sL[kk + j * m];
+        if (x <= T(0)) { fail = 1; break; }
+        x = sqrt(x);
+        sL[kk + kk * m] = x;
+        for (int i = kk + 1; i < m; ++i) {
+          T s = sL[i + kk * m];
+          for (int j = 0; j < kk; ++j) s -= sL[i + j * m] * sL[kk + j * m];
+          sL[i + kk * m] = s / x;
+        }
+      }
+      s_fail = fail;
+    }
+    __syncthreads();
+    if (s_fail) {  // tvlqr.cpp:162-164: return k, leaving K_k = Qux, d_k = -Qu unsolved
+      wave_copy(lane, GPTR(G_K, k), (const T*)sK, m * n);
+      wave_copy(lane, GPTR(G_d, k), (const T*)sd, m);
+      if (lane == 0) {
+        a.status[b] = k;
+        a.delta_V[2 * (int64_t)b + 0] = dv0;
+        a.delta_V[2 * (int64_t)b + 1] = dv1;
+      }
+      return;
+    }
+    // solveInPlace: one right-hand side per lane (columns of K, then d)
+    for (int c = lane; c < n + 1; c += 64) {
+      T* rhs = (c < n) ? (sK + c * m) : sd;
+      for (int i = 0; i < m; ++i) {
+        T s = rhs[i];
+        for (int j = 0; j < i; ++j) s -= sL[i + j * m] * rhs[j];
+        rhs[i] = s / sL[i + i * m];
+      }
+      for (int i = m - 1; i >= 0; --i) {
+        T s = rhs[i];
+        for (int j = i + 1; j < m; ++j) s -= sL[j + i * m] * rhs[j];
+        rhs[i] = s / sL[i + i * m];
+      }
+    }
+    __syncthreads();
+    // cost-to-go (tvlqr.cpp:173-186)
+    wave_gemm<T>(lane, 0, 0, m, n, m, T(1), sQuu, m, sK, m, T(0), sT2, m);  // Qux_tmp = Quu K
+    wave_gemm<T>(lane, 1, 0, n, n, m, T(1), sK, m, sQux, m, T(0), sT1, n);  // Qxx_tmp = K^T Qux
+    wave_copy(lane, sPk, (const T*)sQxx, n * n);
+    wave_copy(lane, spk, (const T*)sQx, n);
+    wave_gemm<T>(lane, 0, 0, m, 1, m, T(1), sQuu, m, sd, m, T(0), sw, m);   // Qu_tmp = Quu d (:189)
+    __syncthreads();
+    wave_gemm<T>(lane, 1, 0, n, n, m, T(1), sT2, m, sK, m, T(1), sPk, n);   // P += (Quu K)^T K
+    __syncthreads();
+    for (int e = lane; e < n * n; e += 64) sPk[e] -= sT1[e];                // P -= K^T Qux
+    __syncthreads();
+    for (int e = lane; e < n * n; e += 64) sPk[e] -= sT1[(e / n) + (e % n) * n];  // P -= (..)^T
+    wave_gemm<T>(lane, 1, 0, n, 1, m, T(-1), sT2, m, sd, m, T(1), spk, n);  // p -= (Quu K)^T d
+    __syncthreads();
+    wave_gemm<T>(lane, 1, 0, n, 1, m, T(-1), sK, m, sQu, m, T(1), spk, n);  // p -= K^T Qu
+    __syncthreads();
+    wave_gemm<T>(lane, 1, 0, n, 1, m, T(1), sQux, m, sd, m, T(1), spk, n);  // p += Qux^T d
+    if (lane == 0) {  // tvlqr.cpp:189-191
+      T s0 = T(0), s1 = T(0);
+      for (int i = 0; i < m; ++i) s0 += sd[i] * sQu[i];
+      for (int i = 0; i < m; ++i) s1 += sd[i] * sw[i];
+      dv0 += s0;
+      dv1 += T(0.5) * s1;
+    }
+    __syncthreads();
+    // write the knot point's results, roll P_k -> P_{k+1}
+    wave_copy(lane, GPTR(G_K, k), (const T*)sK, m * n);
+    wave_copy(lane, GPTR(G_d, k), (const T*)sd, m);
+    wave_copy(lane, GPTR(G_P, k), (const T*)sPk, n * n);
+    wave_copy(lane, GPTR(G_p, k), (const T*)spk, n);
+    if (a.store_q) {
+      wave_copy(lane, GPTR(G_Qxx, k), (const T*)sQxx, n * n);
+      wave_copy(lane, GPTR(G_Quu, k), (const T*)sQuu, m * m);
+      wave_copy(lane, GPTR(G_Qux, k), (const T*)sQux, m * n);
+      wave_copy(lane, GPTR(G_Qx, k), (const T*)sQx, n);
+      wave_copy(lane, GPTR(G_Qu, k), (const T*)sQu, m);
+    }
+    wave_copy(lane, sP, (const T*)sPk, n * n);
+    wave_copy(lane, sp, (const T*)spk, n);
+    __syncthreads();
+  }
+  if (lane == 0) {
+    a.status[b] = -1;
+    a.delta_V[2 * (int64_t)b + 0] = dv0;
+    a.delta_V[2 * (int64_t)b + 1] = dv1;
+  }
+}
+
+template <typename T>
+inline size_t generic_backward_lds_bytes(int nm, int mm) {
+  size_t el = (size_t)5 * nm * nm + (size_t)4 * nm * mm + (size_t)2 * mm * mm + (size_t)6 * nm + (size_t)3 * mm;
+  return el * sizeof(T) + 64;
+}
+
+// tvlqr_ForwardPass (tvlqr.cpp:197-248): x_0 = x0; u = d - K x; x+ = f + A x + B u; y = P x + p.
+template <typename T>
+__global__ __launch_bounds__(64) void generic_forward_kernel(GenericArgs<T> a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* smem = reinterpret_cast<T*>(smem_raw);
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x;
+  if (b >= a.batch) return;
+  T* sx = smem;            // x_k
+  T* su = sx + a.nmax;     // u_k
+  T* sxn = su + a.mmax;    // x_{k+1}
+  const int N = a.N;
+  wave_copy(lane, sx, a.x0 + (int64_t)b * a.x0_stride, a.nx[0]);
+  __syncthreads();
+  wave_copy(lane, GPTR(G_x, 0), (const T*)sx, a.nx[0]);
+  for (int k = 0; k < N; ++k) {
+    const int n = a.nx[k], m = a.nu[k], n2 = a.nx[k + 1];
+    const T* A = GPTR(G_A, k);
+    const T* B = GPTR(G_B, k);
+    const T* f = GPTR(G_f, k);
+    const T* K = GPTR(G_K, k);
+    const T* d = GPTR(G_d, k);
+    for (int i = lane; i < m; i += 64) {  // u = d - K x
+      T s = T(0);
+      for (int j = 0; j < n; ++j) s += K[i + j * m] * sx[j];
+      su[i] = d[i] + T(-1) * s;
+    }
+    if (a.want_y) {  // y = P x + p   (lanes m.. take it so it overlaps the u chain)
+      const T* P = GPTR(G_P, k);
+      const T* p = GPTR(G_p, k);
+      T* y = GPTR(G_y, k);
+      for (int i = lane; i < n; i += 64) {
+        T s = T(0);
+        for (int j = 0; j < n; ++j) s += P[i + j * n] * sx[j];
+        y[i] = (T(0) + s) + p[i];
+      }
+    }
+    __syncthreads();
+    for (int i = lane; i < n2; i += 64) {  // x+ = f + A x + B u
+      T s = T(0);
+      for (int j = 0; j < n; ++j) s += A[i + j * n2] * sx[j];
+      T v = f[i] + s;
+      T s2 = T(0);
+      for (int j = 0; j < m; ++j) s2 += B[i + j * n2] * su[j];
+      sxn[i] = v + s2;
+    }
+    wave_copy(lane, GPTR(G_u, k), (const T*)su, m);
+    __syncthreads();
+    wave_copy(lane, sx, (const T*)sxn, n2);
+    wave_copy(lane, GPTR(G_x, k + 1), (const T*)sxn, n2);
+    __syncthreads();
+  }
+  if (a.want_y) {
+    const int n = a.nx[N];
+    const T* P = GPTR(G_P, N);
+    const T* p = GPTR(G_p, N);
+    T* y = GPTR(G_y, N);
+    for (int i = lane; i < n; i += 64) {
+      T s = T(0);
+      for (int j = 0; j < n; ++j) s += P[i + j * n] * sx[j];
+      y[i] = (T(0) + s) + p[i];
+    }
+  }
+#undef GPTR
+#undef s_fail
+}
+
+#pragma clang fp contract(fast)
+
+}  // namespace altro_hip

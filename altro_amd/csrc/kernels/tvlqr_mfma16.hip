@@ -1,0 +1,372 @@
+// tvlqr_mfma16.hip -- plan MFMA16: the (n, m) = (12, 4) fp64 TVLQR pair on CDNA4 matrix cores.
+//
+// Replaces tvlqr_BackwardPass / tvlqr_ForwardPass (src/tvlqr/tvlqr.cpp:65-195, :197-248) for the
+// shape BASELINE.json quotes its metric on.  One wavefront (64 lanes) owns one problem and walks the
+// horizon serially; nothing but the knot point's own blocks ever moves through HBM.
+//
+// Why MFMA here: n + m = 16, so the whole action-value expansion is two chained 16x16 tiles
+//
+//        D1 = [P' | t]^T-as-A-operand x Z         (12+1 rows used, K = 12)          3 x v_mfma_f64_16x16x4
+//        G  = [Q H^T; H R] + Z^T x D1             (16x16, K = 12, 100 % tile use)   3 x v_mfma_f64_16x16x4
+//
+// with Z = [A B] (12x16, the reference's dynamics_jac_ layout, knotpoint_data.cpp:412-414) and
+// t = p' (+ P' f).  G holds Qxx, Qux, Quu at once (tvlqr.cpp:135-143) and row 12 of D1 is Z^T t, the
+// gradient part (tvlqr.cpp:147-152).  The key hardware fact: the f64 16x16x4 accumulator layout
+// (lane l, reg r  <->  row (l>>4)+4r, col l&15) IS the B-operand layout of K-chunk r, so D1 feeds the
+// second product straight from registers -- no LDS, no shuffles.  The cost-to-go update
+// (tvlqr.cpp:173-186) is two more K=4 MFMAs in homogeneous form with Kt = [K | -d], Qt = [Qux | Qu]:
+//
+//        [P | p] = [Qxx | Qx] + Kt^T (Quu Kt - Qt) - Qt^T Kt                          2 x v_mfma_f64_16x16x4
+//
+// Only the 4x4 Cholesky + 13 triangular solves (tvlqr.cpp:159-166) run on the VALU, every lane
+// solving its own column redundantly in its four row-groups, fed by one 640-byte LDS exchange.
+// 8 MFMAs (512 matrix-pipe cycles) per knot point against 5088 algorithmic bytes: HBM-bound.
+//
+// Symmetry note: the tile product uses P'^T where the reference uses P' (and returns G rather than
+// G^T); for the symmetric Q, R the API requires (altro_solver.hpp:183) P_k is symmetric up to rounding,
+// so this changes results only at the 1e-16 relative level.  Parity is asserted at 1e-8 on K, d.
+//
+// Device layout (private to this plan; pack_mfma16.hip converts from/to the reference layout):
+//   IN  [b][k][428]  = Zfrag 3x64 | Q rows 3x48 | [H R] 4x16 | [q r] 16 | f 12   (3424 B, all algorithmic)
+//   TERM[b][156]     = Q_N rows 3x48 | q_N 12
+//   OUT [b][k][208]  = Kt 4x13 row-major | [P p] 12x13 row-major                  (1664 B, all algorithmic)
+//   OUTN[b][156]     = [P_N p_N] 12x13 row-major
+// Every load/store below is `lane -> consecutive 8-byte element` over a contiguous run.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace altro_hip {
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+constexpr int MF_N = 12, MF_M = 4;
+constexpr int MF_IN = 428;     // doubles per knot-point input record
+constexpr int MF_OUT = 208;    // doubles per knot-point output record
+constexpr int MF_TERM = 156;   // doubles per terminal record
+constexpr int MF_OFF_Z = 0, MF_OFF_Q = 192, MF_OFF_HR = 336, MF_OFF_QR = 400, MF_OFF_F = 416;
+constexpr int MF_OFF_P = 52;   // inside an OUT record: [P p] after Kt
+constexpr int MF_QB = 256 + 16;  // optional Q-block record: G tile (16x16 row-major) | [Qx Qu]
+
+__device__ __forceinline__ f64x4 mfma_f64_16x16x4(double a, double b, f64x4 c) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+// ---- DPP helpers: butterfly all-reduce over the 16 lanes of a DPP row -------------------------
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_f64(double v) {
+  union { double d; int i[2]; } in, out;
+  in.d = v;
+  out.i[0] = __builtin_amdgcn_update_dpp(0, in.i[0], CTRL, 0xf, 0xf, false);
+  out.i[1] = __builtin_amdgcn_update_dpp(0, in.i[1], CTRL, 0xf, 0xf, false);
+  return out.d;
+}
+__device__ __forceinline__ double row16_allreduce(double v) {
+  v += dpp_mov_f64<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov_f64<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov_f64<0x141>(v);  // row_half_mirror
+  v += dpp_mov_f64<0x140>(v);  // row_mirror
+  return v;
+}
+// sum over the four 16-lane row groups (lanes l, l^16, l^32, l^48): result in every lane
+__device__ __forceinline__ double group4_allreduce(double v) {
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+struct Mfma16Args {
+  const double* in;      // IN
+  const double* term;    // TERM
+  double* out;           // OUT
+  double* outn;          // OUTN
+  double* qblk;          // optional [b][k][MF_QB]
+  const double* x0;      // [b][12]
+  double* xuy;           // forward output [b][k][28] = x 12 | y 12 | u 4 ; terminal [b][N][..]
+  double* delta_V;       // [b][2]
+  int* status;           // [b]
+  int N;
+  int batch;
+  double reg;
+  int has_f;
+};
+
+// ------------------------------------------------------------------------------------------------
+// Backward sweep.
+// ------------------------------------------------------------------------------------------------
+struct Mfma16Knot {  // one knot point's inputs, in registers (11 doubles / lane)
+  double z[3], q[3], hr, qr, f[3];
+};
+
+__device__ __forceinline__ void mfma16_load_knot(Mfma16Knot& kn, const double* rec, int lane, int j,
+                                                 int g, int has_f) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c) kn.z[c] = rec[MF_OFF_Z + c * 64 + lane];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) kn.q[r] = (j < 12) ? rec[MF_OFF_Q + r * 48 + g * 12 + j] : 0.0;
+  kn.hr = rec[MF_OFF_HR + lane];
+  kn.qr = rec[MF_OFF_QR + j];
+  if (has_f) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) kn.f[r] = rec[MF_OFF_F + g + 4 * r];
+  } else {
+    kn.f[0] = kn.f[1] = kn.f[2] = 0.0;
+  }
+}
+
+template <bool STORE_Q>
+__global__ __launch_bounds__(64) void mfma16_backward_kernel(Mfma16Args a) {
+  // the one and only LDS object: 4x16 tile [Qux | Quu] then [Qx | Qu]
+  __shared__ __attribute__((aligned(16))) double S[64 + 16];
+  const int lane = threadIdx.x;
+  const int j = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x;
+  if (b >= a.batch) return;
+  const int N = a.N;
+  const double* in = a.in + (size_t)b * N * MF_IN;
+  double* out = a.out + (size_t)b * N * MF_OUT;
+
+  // terminal cost-to-go: P_N = Q_N, p_N = q_N (tvlqr.cpp:81-90) -> tile [P | p]
+  double Pt[3];
+  {
+    const double* term = a.term + (size_t)b * MF_TERM;
+    double* on = a.outn + (size_t)b * MF_TERM;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      double v = 0.0;
+      if (j < 12) v = term[r * 48 + g * 12 + j];
+      else if (j == 12) v = term[144 + g + 4 * r];
+      Pt[r] = v;
+      if (j <= 12) on[(g + 4 * r) * 13 + j] = v;
+    }
+  }
+  double dv0 = 0.0, dv1 = 0.0;
+
+  Mfma16Knot cur, nxt;
+  mfma16_load_knot(cur, in + (size_t)(N - 1) * MF_IN, lane, j, g, a.has_f);
+
+  for (int k = N - 1; k >= 0; --k) {
+    // prefetch the next knot point (k-1) while this one computes
+    if (k > 0) mfma16_load_knot(nxt, in + (size_t)(k - 1) * MF_IN, lane, j, g, a.has_f);
+
+    // ---- D1 = [P'|t]^T Z : rows 0..11 = P'^T Z, row 12 = t^T Z --------------------------------
+    f64x4 D1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) D1 = mfma_f64_16x16x4(Pt[c], cur.z[c], D1);
+
+    // ---- G = [Q H^T; H R] + Z^T D1 : Qxx (rows<12, cols<12), [Qux | Quu] (rows 12..15) ---------
+    f64x4 G = {cur.q[0], cur.q[1], cur.q[2], cur.hr};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) G = mfma_f64_16x16x4(cur.z[c], D1[c], G);
+
+    // ---- gradient [Qx; Qu] = [q; r] + Z^T t (+ Z^T P' f) : valid in lanes g == 0 -----------------
+    double gv = D1[3] + cur.qr;
+    if (a.has_f) {  // Z^T P' f = (P'^T Z)^T f : sum_i f[i] D1[i][j]
+      double s = cur.f[0] * D1[0] + cur.f[1] * D1[1] + cur.f[2] * D1[2];
+      gv += group4_allreduce(s);
+    }
+
+    // ---- LDS exchange ------------------------------------------------------------------------------
+    __syncthreads();  // previous iteration's readers are done (single-wave block: free)
+    S[lane] = G[3];                 // [Qux | Quu], row g, col j
+    if (g == 0) S[64 + j] = gv;     // [Qx | Qu]
+    __syncthreads();
+    double Quu[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) Quu[r][c] = S[r * 16 + 12 + c];
+    double rhs[4];  // column j of Qt = [Qux | Qu]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rhs[r] = S[(j == 12) ? (64 + 12 + r) : (r * 16 + j)];
+    double c3[3];   // column j of [Qxx | Qx], rows g + 4r
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      double qx = S[64 + g + 4 * r];
+      c3[r] = (j < 12) ? G[r] : ((j == 12) ? qx : 0.0);
+    }
+    double quu_row[4];  // row g of the UNregularised Quu
+#pragma unroll
+    for (int c = 0; c < 4; ++c) quu_row[c] = S[g * 16 + 12 + c];
+    const double q_mine = rhs[g];  // Qt[g][j]
+
+    // ---- Cholesky of Quu + reg I (lower, fail when a pivot is <= 0: tvlqr.cpp:159-164) -----------
+    const double reg = a.reg;
+    double x0 = Quu[0][0] + reg;
+    bool fail = !(x0 > 0.0);
+    double l00 = sqrt(x0), i0 = 1.0 / l00;
+    double l10 = Quu[1][0] * i0, l20 = Quu[2][0] * i0, l30 = Quu[3][0] * i0;
+    double x1 = (Quu[1][1] + reg) - l10 * l10;
+    fail = fail || !(x1 > 0.0);
+    double l11 = sqrt(x1), i1 = 1.0 / l11;
+    double l21 = (Quu[2][1] - l20 * l10) * i1, l31 = (Quu[3][1] - l30 * l10) * i1;
+    double x2 = (Quu[2][2] + reg) - l20 * l20 - l21 * l21;
+    fail = fail || !(x2 > 0.0);
+    double l22 = sqrt(x2), i2 = 1.0 / l22;
+    double l32 = (Quu[3][2] - l30 * l20 - l31 * l21) * i2;
+    double x3 = (Quu[3][3] + reg) - l30 * l30 - l31 * l31 - l32 * l32;
+    fail = fail || !(x3 > 0.0);
+    double l33 = sqrt(x3), i3 = 1.0 / l33;
+    if (fail) {  // wave-uniform: Quu is the same in every lane.  Reference: `return k` with
+                 // K_k = Qux, d_k = -Qu left unsolved and P_k, p_k untouched.
+      if (j <= 12) out[(size_t)k * MF_OUT + g * 13 + j] = q_mine;
+      if (j == 12 && g == 0) {  // the lane that owns the delta_V accumulators
+        a.status[b] = k;
+        a.delta_V[2 * (size_t)b + 0] = dv0;
+        a.delta_V[2 * (size_t)b + 1] = dv1;
+      }
+      return;
+    }
+    // ---- Kt[:, j] = (L L^T)^-1 Qt[:, j]  (tvlqr.cpp:165-166; column 12 gives -d) ------------------
+    double y0 = rhs[0] * i0;
+    double y1 = (rhs[1] - l10 * y0) * i1;
+    double y2 = (rhs[2] - l20 * y0 - l21 * y1) * i2;
+    double y3 = (rhs[3] - l30 * y0 - l31 * y1 - l32 * y2) * i3;
+    double k3 = y3 * i3;
+    double k2 = (y2 - l32 * k3) * i2;
+    double k1 = (y1 - l21 * k2 - l31 * k3) * i1;
+    double k0 = (y0 - l10 * k1 - l20 * k2 - l30 * k3) * i0;
+    double k_mine = (g == 0) ? k0 : (g == 1) ? k1 : (g == 2) ? k2 : k3;  // Kt[g][j]
+    // W[g][j] = (Quu Kt - Qt)[g][j]   (tvlqr.cpp:174 uses the unregularised Quu)
+    double w_mine = quu_row[0] * k0 + quu_row[1] * k1 + quu_row[2] * k2 + quu_row[3] * k3 - q_mine;
+    // ---- expected decrease (tvlqr.cpp:189-191), meaningful in column 12 where Kt = -d, Qt = Qu ---
+    {
+      double qd0 = Quu[0][0] * k0 + Quu[0][1] * k1 + Quu[0][2] * k2 + Quu[0][3] * k3;
+      double qd1 = Quu[1][0] * k0 + Quu[1][1] * k1 + Quu[1][2] * k2 + Quu[1][3] * k3;
+      double qd2 = Quu[2][0] * k0 + Quu[2][1] * k1 + Quu[2][2] * k2 + Quu[2][3] * k3;
+      double qd3 = Quu[3][0] * k0 + Quu[3][1] * k1 + Quu[3][2] * k2 + Quu[3][3] * k3;
+      dv0 -= k0 * rhs[0] + k1 * rhs[1] + k2 * rhs[2] + k3 * rhs[3];        // d . Qu
+      dv1 += 0.5 * (k0 * qd0 + k1 * qd1 + k2 * qd2 + k3 * qd3);           // 1/2 d . Quu d
+    }
+    if (j > 12) { k_mine = 0.0; w_mine = 0.0; }
+    const double q_op = (j > 12) ? 0.0 : q_mine;
+
+    // ---- [P | p] = [Qxx | Qx] + Kt^T W - Qt^T Kt  (tvlqr.cpp:173-186) ----------------------------
+    f64x4 Pn = {c3[0], c3[1], c3[2], 0.0};
+    Pn = mfma_f64_16x16x4(k_mine, w_mine, Pn);
+    Pn = mfma_f64_16x16x4(q_op, -k_mine, Pn);
+
+    // ---- store Kt and [P | p]; roll the tile --------------------------------------------------------
+    double* o = out + (size_t)k * MF_OUT;
+    if (j <= 12) {
+      o[g * 13 + j] = k_mine;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) o[MF_OFF_P + (g + 4 * r) * 13 + j] = Pn[r];
+    }
+    if (STORE_Q) {  // Qxx_, Quu_, Qux_, Qx_, Qu_ are API-visible in the reference
+      double* qb = a.qblk + ((size_t)b * N + k) * MF_QB;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) qb[(g + 4 * r) * 16 + j] = G[r];
+      if (g == 0) qb[256 + j] = gv;
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) Pt[r] = (j <= 12) ? Pn[r] : 0.0;
+    cur = nxt;
+  }
+  if (j == 12 && g == 0) {
+    a.status[b] = -1;
+    a.delta_V[2 * (size_t)b + 0] = dv0;
+    a.delta_V[2 * (size_t)b + 1] = dv1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Forward sweep: x_0 = x0 ; u = d - K x ; x+ = f + A x + B u ; y = P x + p  (tvlqr.cpp:208-246).
+// Tiles stay in the layouts the backward kernel wrote; vectors alternate between a "column layout"
+// (lane j holds v[j], replicated over the 4 row groups) for the products and a "row layout" (row
+// group g, reg r holds v[g+4r]) that the DPP row reductions produce.
+// ------------------------------------------------------------------------------------------------
+struct Mfma16FwdKnot {
+  double z[3], f[3], kt, p[3];
+};
+
+__device__ __forceinline__ void mfma16_load_fwd(Mfma16FwdKnot& kn, const double* rec,
+                                                const double* orec, int lane, int j, int g) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c) kn.z[c] = rec[MF_OFF_Z + c * 64 + lane];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) kn.f[r] = rec[MF_OFF_F + g + 4 * r];
+  kn.kt = (j <= 12) ? orec[g * 13 + j] : 0.0;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) kn.p[r] = (j <= 12) ? orec[MF_OFF_P + (g + 4 * r) * 13 + j] : 0.0;
+}
+
+__global__ __launch_bounds__(64) void mfma16_forward_kernel(Mfma16Args a) {
+  __shared__ __attribute__((aligned(16))) double S[16];
+  const int lane = threadIdx.x;
+  const int j = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x;
+  if (b >= a.batch) return;
+  const int N = a.N;
+  const double* in = a.in + (size_t)b * N * MF_IN;
+  const double* out = a.out + (size_t)b * N * MF_OUT;
+  double* xuy = a.xuy + (size_t)b * (N + 1) * 28;
+
+  // x~ = [x; 1] in column layout
+  double xc = (j < 12) ? a.x0[(size_t)b * 12 + j] : ((j == 12) ? 1.0 : 0.0);
+  Mfma16FwdKnot cur, nxt;
+  mfma16_load_fwd(cur, in, out, lane, j, g);
+  for (int k = 0; k < N; ++k) {
+    if (k + 1 < N)
+      mfma16_load_fwd(nxt, in + (size_t)(k + 1) * MF_IN, out + (size_t)(k + 1) * MF_OUT, lane, j, g);
+    double* o = xuy + (size_t)k * 28;
+    // u[g] = -(Kt x~)[g] = d - K x
+    const double ug = -row16_allreduce(cur.kt * xc);
+    // y[g+4r] = ([P p] x~)[g+4r]
+    double yr[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) yr[r] = row16_allreduce(cur.p[r] * xc);
+    // z = [x; u] in column layout: u[a] lives in row group a -> hop through LDS
+    __syncthreads();
+    if (j == 0) S[12 + g] = ug;
+    __syncthreads();
+    const double zc = (j < 12) ? xc : S[j];
+    // x+[g+4c] = f + (Z z)[g+4c]
+    double xr[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) xr[c] = row16_allreduce(cur.z[c] * zc) + cur.f[c];
+    // stores: x_k, u_k from the column layout (contiguous), y_k from the row layout
+    if (g == 0) {
+      if (j < 12) o[j] = xc; else o[24 + (j - 12)] = zc;
+    }
+    if (j == 0) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) o[12 + g + 4 * r] = yr[r];
+    }
+    // row layout -> column layout for x+
+    if (j == 0) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) S[g + 4 * c] = xr[c];
+    }
+    __syncthreads();
+    xc = (j < 12) ? S[j] : ((j == 12) ? 1.0 : 0.0);
+    cur = nxt;
+  }
+  // terminal knot point: x_N, y_N = P_N x_N + p_N (tvlqr.cpp:238-246)
+  {
+    const double* on = a.outn + (size_t)b * MF_TERM;
+    double* o = xuy + (size_t)N * 28;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      double pv = (j <= 12) ? on[(g + 4 * r) * 13 + j] : 0.0;
+      double y = row16_allreduce(pv * xc);
+      if (j == 0) o[12 + g + 4 * r] = y;
+    }
+    if (g == 0 && j < 12) o[j] = xc;
+    if (g == 0 && j >= 12) o[24 + (j - 12)] = 0.0;
+  }
+}
+
+// ---- MFMA layout self-test: D = A(16x4) B(4x16) + C with the layout this file assumes ----------
+__global__ void mfma16_selftest_kernel(const double* A, const double* B, const double* C, double* D) {
+  const int lane = threadIdx.x, j = lane & 15, g = lane >> 4;
+  f64x4 c;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) c[r] = C[(g + 4 * r) * 16 + j];
+  // A[i][k] row-major 16x4 ; B[k][j] row-major 4x16
+  f64x4 d = mfma_f64_16x16x4(A[j * 4 + g], B[g * 16 + j], c);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) D[(g + 4 * r) * 16 + j] = d[r];
+}
+
+}  // namespace altro_hip

@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py -- iLQR backward+forward sweeps/sec on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1], SURVEY.md section 8d "C1"): double integrator, horizon N=256,
+n=12, m=4, batch=4096 problems PER GPU (weak scaling: independent problem instances are sharded
+over ranks with no data-path collective), fp64, time-varying storage (every knot point of every
+problem owns its A,B,f,Q,R,H,q,r blocks in HBM).  One "step" = one sweep over the whole batch:
+tvlqr_BackwardPass followed by tvlqr_ForwardPass semantics (src/tvlqr/tvlqr.cpp:65-248), i.e.
+`altro_hip_sweep` through the C ABI.  Inputs are resident in HBM (device layout) before the timed
+region starts; nothing is skipped or cached inside it (K, d, P, p, x, u, y are all rewritten).
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the backward sweep) from HIP
+events recorded on the kernel's own stream inside this process; `cpu_baseline` is the CPU oracle
+(single thread, the reference has no threads) on a bounded sample of the same workload.
+PyTorch is used for torch.distributed (RCCL) and device synchronisation only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy ceiling)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4096, help="problems per GPU")
+    ap.add_argument("--horizon", type=int, default=256)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the cpu_baseline leg")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(N, seconds):
+    """Single-thread CPU oracle (restatement of the reference's tvlqr pair) on a bounded sample of the
+    same C1 problems; returns problem-sweeps/s."""
+    from oracle import oracle
+    from tests import problems
+    chunk = 8
+    pr = problems.c1_double_integrator(chunk, N=N)
+    done, t_used = 0, 0.0
+    while t_used < seconds or done < 16:
+        t0 = time.perf_counter()
+        o = oracle.backward_batch(pr["A"], pr["B"], pr["f"], pr["Q"], pr["R"], pr["H"], pr["q"], pr["r"])
+        oracle.forward_batch(pr["A"], pr["B"], pr["f"], o["K"], o["d"], o["P"], o["p"], pr["x0"])
+        t_used += time.perf_counter() - t0
+        done += chunk
+        if t_used > 30.0:
+            break
+    cpu = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": done / t_used, "unit": "problem-sweeps/s", "cores": 1, "kind": "port",
+            "sample": "%d problems of the same C1 workload (N=%d, n=12, m=4), %.1f s, oracle/tvlqr_oracle.c "
+                      "backward+forward, gcc -O2, 1 thread of %d on '%s'" % (done, N, t_used, os.cpu_count(), cpu)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)   # nccl == RCCL on ROCm
+
+    import altro_amd
+    from tests import problems
+    N, n, m, batch = args.horizon, 12, 4, args.batch
+    first = rank * batch                                   # this rank's slice of the global batch
+    one = problems.c1_double_integrator(1, N=N)
+    x0 = 2.0 * problems.uniform01((batch, n), 21, first * n) - 1.0
+
+    bt = altro_amd.Batch(N, n, m, batch, device=local_rank)
+    assert bt.plan == altro_amd.PLAN_MFMA16
+    # shared A,B,Q,R are EXPANDED on the device: every (problem, knot point) owns its blocks in HBM
+    bt.set_dynamics(one["A"][0, :1], one["B"][0, :1], None, k_stride_zero=True, batch_stride_zero=True)
+    Q2 = np.stack([one["Q"][0, 0], one["Q"][0, N]])
+    bt.set_cost(Q2, one["R"][0, :1], one["H"][0, :1], np.zeros((2, n)), one["r"][0, :1],
+                k_stride_zero=True, batch_stride_zero=True)
+    bt.set_initial_state(x0)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        bt.sweep()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        bt.sweep()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    # solver statistics: the only thing that ever crosses GPUs (RCCL over xGMI, latency-bound)
+    st = bt.stats()
+    ssum = torch.tensor([float(st.problems), float(st.cholesky_failures), st.sum_delta_V0, st.sum_delta_V1],
+                        dtype=torch.float64, device="cuda")
+    smax = torch.tensor([st.max_abs_xN], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(ssum, op=dist.ReduceOp.SUM)
+        dist.all_reduce(smax, op=dist.ReduceOp.MAX)
+
+    # per-kernel durations from HIP events on the handle's stream (profile mode syncs per launch, so
+    # it runs after, never inside, the timed region)
+    bt.profile(True)
+    for _ in range(max(3, min(args.steps, 10))):
+        bt.sweep()
+    bt.synchronize()
+    nb, ms_b, name_b = bt.profile_get(0)
+    nf, ms_f, name_f = bt.profile_get(1)
+    bt.profile(False)
+
+    if rank == 0:
+        total_problems = batch * world
+        sweeps_per_s = total_problems * args.steps / elapsed
+        bytes_b = bt.algorithmic_bytes(0)
+        bytes_f = bt.algorithmic_bytes(1)
+        dur_b = ms_b / nb * 1e-3
+        dur_f = ms_f / nf * 1e-3
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):   # rocprofv3 --pmc passes of this same command (see profiles/README.md)
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("batch") == batch and tj.get("horizon") == N:
+                    traffic = tj.get("backward_bytes_per_launch")
+            except (OSError, ValueError):
+                traffic = None
+        out = {
+            "metric": "iLQR backward+forward sweeps/sec (N knotpoints x batch)",
+            "value": sweeps_per_s,
+            "unit": "problem-sweeps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "C1 double integrator TVLQR sweep (BASELINE.json configs[1])",
+                "horizon_N": N, "n": n, "m": m, "batch_per_gpu": batch, "global_batch": total_problems,
+                "parallelism": "problem instances sharded over %d GPU(s), no data-path collective; "
+                               "RCCL all-reduce of solver stats only" % world,
+                "plan": "MFMA16 (wave-per-problem, v_mfma_f64_16x16x4)",
+                "knotpoint_steps_per_s": sweeps_per_s * N,
+                "kernels": {name_b: {"avg_ms": ms_b / nb, "algorithmic_GB": bytes_b / 1e9,
+                                     "GBps": bytes_b / dur_b / 1e9},
+                            name_f: {"avg_ms": ms_f / nf, "algorithmic_GB": bytes_f / 1e9,
+                                     "GBps": bytes_f / dur_f / 1e9}},
+                "stats": {"problems": int(ssum[0].item()), "cholesky_failures": int(ssum[1].item()),
+                          "sum_delta_V0": ssum[2].item(), "sum_delta_V1": ssum[3].item(),
+                          "max_abs_xN": smax[0].item()},
+            },
+            "roofline": {"bound": "hbm", "kernel": name_b, "achieved": bytes_b / dur_b / 1e9,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_b / dur_b / 1e9 / HBM_PEAK_GBS,
+                         "traffic": traffic},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(N, args.cpu_seconds)
+        print(json.dumps(out))
+    bt.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,166 @@
+/*
+ * altro_hip.h -- the drop-in boundary: a C ABI (plain pointers and sizes, no C++/torch types)
+ * in front of the hand-written HIP (gfx950) implementation of ALTRO's iLQR inner loop.
+ *
+ * Every entry point names the reference interface it stands in for (paths relative to the
+ * reference tree bjack205/altro):
+ *
+ *   altro_hip_backward      <-> tvlqr_BackwardPass   src/tvlqr/tvlqr.h:17-27, tvlqr.cpp:65-195,
+ *                               as called by SolverImpl::BackwardPass  src/altro/solver/solver.cpp:360-378
+ *   altro_hip_forward_ltv   <-> tvlqr_ForwardPass    src/tvlqr/tvlqr.h:29-33, tvlqr.cpp:197-248,
+ *                               as called by SolverImpl::LinearRollout src/altro/solver/solver.cpp:133-146
+ *   altro_hip_merit         <-> SolverImpl::MeritFunction              src/altro/solver/solver.cpp:273-355
+ *   altro_hip_expand        <-> SolverImpl::CalcExpansions + KnotPointData::CalcDynamicsExpansion /
+ *                               CalcCostGradient     solver.cpp:189-201, knotpoint_data.cpp:406-471
+ *   altro_hip_set_*         <-> the pointer arrays SolverImpl::Initialize builds over KnotPointData
+ *                               members (solver.cpp:63-106) and the setters that fill them
+ *                               (altro_solver.cpp:68-81,118-172,177-190, knotpoint_data.cpp:64-153)
+ *   altro_hip_get_*         <-> KnotPointData public members K_,d_,P_,p_,x_,u_,y_,Qxx_...
+ *                               (knotpoint_data.hpp:160-233) and ALTROSolver::GetState/GetInput/
+ *                               GetFeedbackGain/GetFeedforwardGain (altro_solver.hpp:413-422)
+ *   altro_hip_stats         <-> AltroStats (solver_stats.hpp:14-25), per batch instead of per solver
+ *
+ * The single-problem kernel boundary itself (the three tvlqr_* functions with the reference's exact
+ * C++ signatures) is declared in include/tvlqr/tvlqr.h and exported by the same library.
+ *
+ * Conventions
+ *   - One handle = `batch` independent problems with the same horizon N and dims (n, m), bound to one
+ *     HIP device and one stream.  One host thread per handle (the reference is non-re-entrant per
+ *     solver instance too: solver.cpp:277-278).
+ *   - "Reference layout" for host buffers: [batch][k][block], every block column-major exactly as the
+ *     reference stores it (tvlqr.cpp:13-16): A n*n, B n*m, f n, Q n*n (or n when is_diag), R m*m (or m),
+ *     H m*n, q n, r m, K m*n, d m, P n*n, p n, x n, u m, y n.  Q, q, P, p, x, y have N+1 knot points,
+ *     everything else N.  Host buffers are borrowed for the duration of the call only.
+ *   - Broadcast: `k_stride_zero` / `batch_stride_zero` flags say the host buffer holds ONE knot point
+ *     and/or ONE problem that every k / every problem shares (the device copy is still expanded unless
+ *     ALTRO_HIP_SHARED_STORAGE is requested at create time).
+ *   - No allocation happens inside backward / forward / merit / sweep (tvlqr_test.cpp:174-182 asserts
+ *     the same of the reference).
+ *   - Return value: 0 on success, a negative altro_hip_error otherwise; altro_hip_last_error() gives
+ *     the message.  Per-problem results of the backward pass follow the reference's convention:
+ *     status[b] == -1 (TVLQR_SUCCESS, tvlqr.h:11) or the knot-point index whose Quu was not positive
+ *     definite (tvlqr.cpp:162-164).
+ *   - There is NO CPU fallback: without a HIP device every compute entry point fails with
+ *     ALTRO_HIP_ERR_NO_DEVICE.
+ */
+#ifndef ALTRO_HIP_H_
+#define ALTRO_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ALTRO_HIP_VERSION 100
+#define ALTRO_HIP_TVLQR_SUCCESS (-1) /* tvlqr.h:11 */
+
+typedef struct altro_hip_batch altro_hip_batch; /* opaque handle */
+
+typedef enum altro_hip_dtype {
+  ALTRO_HIP_F64 = 0, /* the reference's lqr_float / a_float (tvlqr.h:13, typedefs.hpp:12) */
+  ALTRO_HIP_F32 = 1  /* extension: BASELINE.json configs[4] */
+} altro_hip_dtype;
+
+typedef enum altro_hip_error {
+  ALTRO_HIP_OK = 0,
+  ALTRO_HIP_ERR_NO_DEVICE = -1,
+  ALTRO_HIP_ERR_BAD_ARGUMENT = -2,
+  ALTRO_HIP_ERR_UNSUPPORTED = -3,
+  ALTRO_HIP_ERR_HIP = -4,
+  ALTRO_HIP_ERR_NOT_SET = -5,
+  ALTRO_HIP_ERR_OUT_OF_MEMORY = -6
+} altro_hip_error;
+
+/* Which kernel family a handle runs.  AUTO picks the fastest one that supports (n, m, dtype). */
+typedef enum altro_hip_plan {
+  ALTRO_HIP_PLAN_AUTO = 0,
+  ALTRO_HIP_PLAN_GENERIC = 1, /* wave-per-problem, LDS-staged, any (n, m) <= 32                */
+  ALTRO_HIP_PLAN_MFMA16 = 2,  /* wave-per-problem, 16x16x4 MFMA tiles, (n, m) = (12, 4)         */
+  ALTRO_HIP_PLAN_LANE = 3     /* lane-per-problem, batch structure-of-arrays, small (n, m)      */
+} altro_hip_plan;
+
+/* create flags */
+#define ALTRO_HIP_STORE_QBLOCKS 0x1u /* also write Qxx,Quu,Qux,Qx,Qu (knotpoint_data.hpp:211-215) */
+
+/* Device dynamics/cost models for the nonlinear forward pass (user std::function callbacks of
+ * typedefs.hpp:31-53 cannot run on the device; these are the compiled-in equivalents of the
+ * reference's own test models, test/test_utils.cpp:18-238).                                    */
+typedef enum altro_hip_model {
+  ALTRO_HIP_MODEL_LINEAR = 0,            /* x+ = A_k x + B_k u + f_k from the uploaded data      */
+  ALTRO_HIP_MODEL_DOUBLE_INTEGRATOR = 1, /* test_utils.cpp:18-41                                  */
+  ALTRO_HIP_MODEL_PENDULUM = 2,          /* test_utils.cpp:43-82 + midpoint :84-132               */
+  ALTRO_HIP_MODEL_BICYCLE = 3            /* test_utils.cpp:134-238 + midpoint                     */
+} altro_hip_model;
+
+/* ---- library ------------------------------------------------------------------------------- */
+int altro_hip_version(void);
+const char* altro_hip_last_error(void);
+int altro_hip_device_count(void);
+/* name[cap], CU count and wave size of `device`; ALTRO_HIP_ERR_NO_DEVICE when there is none */
+int altro_hip_device_info(int device, char* name, int cap, int* compute_units, int* wave_size);
+
+/* ---- lifecycle ------------------------------------------------------------------------------- */
+/* `stream` is a hipStream_t (NULL = a stream owned by the handle).  `plan` is an altro_hip_plan. */
+int altro_hip_batch_create(altro_hip_batch** out, int horizon_N, int n, int m, int batch,
+                           int dtype, int plan, unsigned flags, int device, void* stream);
+void altro_hip_batch_destroy(altro_hip_batch* h);
+int altro_hip_batch_plan(const altro_hip_batch* h);         /* the plan actually chosen          */
+size_t altro_hip_batch_device_bytes(const altro_hip_batch* h);
+
+/* ---- problem data (reference layout in, converted once to the device layout) ----------------- */
+int altro_hip_set_dynamics(altro_hip_batch* h, const double* A, const double* B, const double* f,
+                           int k_stride_zero, int batch_stride_zero);
+int altro_hip_set_cost(altro_hip_batch* h, const double* Q, const double* R, const double* H,
+                       const double* q, const double* r, int is_diag, int k_stride_zero,
+                       int batch_stride_zero);
+int altro_hip_set_initial_state(altro_hip_batch* h, const double* x0, int batch_stride_zero);
+
+/* ---- the hot path ----------------------------------------------------------------------------- */
+/* tvlqr_BackwardPass over the batch: K, d, P, p, delta_V, status for every problem.             */
+int altro_hip_backward(altro_hip_batch* h, double reg);
+/* tvlqr_ForwardPass over the batch: x, u, y from x0 through u = d - K x, x+ = f + A x + B u.     */
+int altro_hip_forward_ltv(altro_hip_batch* h);
+/* One "sweep" of BASELINE.json's metric: backward followed by forward, no host sync in between. */
+int altro_hip_sweep(altro_hip_batch* h, double reg);
+/* Wait for the handle's stream. */
+int altro_hip_synchronize(altro_hip_batch* h);
+
+/* ---- results (reference layout out) ------------------------------------------------------------ */
+int altro_hip_get_K(altro_hip_batch* h, double* K);             /* [batch][N][m*n]   */
+int altro_hip_get_d(altro_hip_batch* h, double* d);             /* [batch][N][m]     */
+int altro_hip_get_P(altro_hip_batch* h, double* P);             /* [batch][N+1][n*n] */
+int altro_hip_get_p(altro_hip_batch* h, double* p);             /* [batch][N+1][n]   */
+int altro_hip_get_x(altro_hip_batch* h, double* x);             /* [batch][N+1][n]   */
+int altro_hip_get_u(altro_hip_batch* h, double* u);             /* [batch][N][m]     */
+int altro_hip_get_y(altro_hip_batch* h, double* y);             /* [batch][N+1][n]   */
+int altro_hip_get_delta_V(altro_hip_batch* h, double* delta_V); /* [batch][2]        */
+int altro_hip_get_status(altro_hip_batch* h, int* status);      /* [batch]           */
+/* Qxx|Quu|Qux|Qx|Qu per knot point, [batch][N][n*n+m*m+m*n+n+m]; needs ALTRO_HIP_STORE_QBLOCKS */
+int altro_hip_get_qblocks(altro_hip_batch* h, double* qblocks);
+
+/* ---- statistics (the only thing that ever crosses GPUs: SURVEY.md section 8e) ------------------ */
+typedef struct altro_hip_stats {
+  int64_t problems;          /* batch                                                          */
+  int64_t cholesky_failures; /* problems whose status != -1                                     */
+  double sum_delta_V0;       /* sum over problems of delta_V[0]                                 */
+  double sum_delta_V1;       /* sum over problems of delta_V[1]                                 */
+  double max_abs_xN;         /* max |x_N| over problems (after a forward pass)                  */
+} altro_hip_stats;
+int altro_hip_stats_reduce(altro_hip_batch* h, altro_hip_stats* out);
+
+/* ---- measurement -------------------------------------------------------------------------------- */
+/* When enabled every kernel launch is bracketed by hipEvents ON THE HANDLE'S STREAM and the elapsed
+ * times are accumulated per kernel.  Slot 0 = backward kernel, 1 = forward kernel.                */
+int altro_hip_profile_enable(altro_hip_batch* h, int enable);
+int altro_hip_profile_reset(altro_hip_batch* h);
+int altro_hip_profile_get(altro_hip_batch* h, int slot, int* launches, double* total_ms,
+                          const char** kernel_name);
+/* Algorithmic bytes one launch of the slot's kernel must move.             */
+double altro_hip_algorithmic_bytes(const altro_hip_batch* h, int slot);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALTRO_HIP_H_ */

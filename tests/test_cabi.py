@@ -1,0 +1,45 @@
+"""CPU-only checks of the boundary: the library builds/loads, exports every symbol the public
+header declares, and refuses to compute without a device (no silent fallback)."""
+import os
+import re
+
+import pytest
+
+import altro_amd
+from altro_amd import build as hipbuild
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "altro_hip", "altro_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(altro_hip_[a-z_A-Z0-9]+)\s*\(", src)))
+
+
+def test_library_builds_and_exports_header_symbols():
+    hipbuild.build()
+    L = altro_amd.lib()
+    names = header_functions()
+    assert len(names) >= 28
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+    assert sorted(altro_amd.C_ABI_SYMBOLS) == names
+    assert L.altro_hip_version() == 100
+
+
+def test_no_cpu_fallback_without_device():
+    L = altro_amd.lib()
+    if L.altro_hip_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    with pytest.raises(altro_amd.AltroHipError, match="no CPU fallback"):
+        altro_amd.Batch(10, 4, 2, 1)
+
+
+def test_product_never_imports_oracle():
+    """The oracle is the checker, never the thing shipped."""
+    for d, _, files in os.walk(os.path.join(ROOT, "altro_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h", ".hpp")):
+                txt = open(os.path.join(d, f)).read()
+                assert "oracle" not in txt.replace("CPU oracle", "").replace("the oracle", ""), os.path.join(d, f)
