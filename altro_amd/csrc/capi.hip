@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -65,7 +66,8 @@ struct altro_hip_batch {
   int* g_nu = nullptr;
   // plan MFMA16
   double *m_in = nullptr, *m_term = nullptr, *m_out = nullptr, *m_outn = nullptr, *m_xuy = nullptr,
-         *m_qblk = nullptr;
+         *m_qblk = nullptr, *m_trash = nullptr;
+  Mfma16Strides m_st{};
   // staging for host <-> device conversion (grown lazily, never inside the hot path)
   void* stage = nullptr;
   size_t stage_bytes = 0;
@@ -204,7 +206,7 @@ int mfma16_get(altro_hip_batch* h, int what, double* host, int block, int nk) {
     const int64_t total = (int64_t)nb * nk * block;
     hipLaunchKernelGGL(mfma16_unpack_kernel, dim3(grid_for(total)), dim3(256), 0, h->stream, dst, what,
                        (const double*)h->m_out, (const double*)h->m_outn, (const double*)h->m_xuy,
-                       (const double*)h->m_qblk, h->N, b0, nb);
+                       (const double*)h->m_qblk, h->m_st, h->N, b0, nb);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "mfma16_unpack launch: %s", hipGetErrorString(e));
     return 0;
@@ -233,7 +235,7 @@ int put_src(altro_hip_batch* h, const double* src, int blk, int nk_host, int k_z
 int mfma16_pack_launch(altro_hip_batch* h, int seg, SrcArr s0, SrcArr s1) {
   const int64_t total = (int64_t)h->batch * h->N * 192;
   hipLaunchKernelGGL(mfma16_pack_kernel, dim3(grid_for(total)), dim3(256), 0, h->stream, h->m_in,
-                     h->m_term, seg, s0, s1, h->is_diag, h->N, 0, h->batch);
+                     h->m_term, h->m_st, seg, s0, s1, h->is_diag, h->N, 0, h->batch);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "mfma16_pack launch: %s", hipGetErrorString(e));
   return 0;
@@ -286,12 +288,17 @@ struct ProfScope {
 int launch_backward(altro_hip_batch* h, double reg) {
   ProfScope ps(h, 0);
   if (h->plan == ALTRO_HIP_PLAN_MFMA16) {
-    Mfma16Args a{h->m_in, h->m_term, h->m_out, h->m_outn, h->m_qblk, (const double*)h->x0, h->m_xuy,
+    Mfma16Args a{h->m_in, h->m_st.in_bs, h->m_st.in_ks, h->m_st.out_bs, h->m_st.out_ks, h->m_st.xuy_bs, h->m_st.xuy_ks, h->m_term, h->m_out, h->m_outn, h->m_qblk, h->m_trash, (const double*)h->x0, h->m_xuy,
                  (double*)h->delta_V, h->status, h->N, h->batch, reg, h->has_f};
-    if (h->flags & ALTRO_HIP_STORE_QBLOCKS)
-      hipLaunchKernelGGL(mfma16_backward_kernel<true>, dim3(h->batch), dim3(64), 0, h->stream, a);
+    const bool sq = (h->flags & ALTRO_HIP_STORE_QBLOCKS) != 0;
+    if (sq && h->has_f)
+      hipLaunchKernelGGL((mfma16_backward_kernel<true, true>), dim3(h->batch), dim3(64), 0, h->stream, a);
+    else if (sq)
+      hipLaunchKernelGGL((mfma16_backward_kernel<true, false>), dim3(h->batch), dim3(64), 0, h->stream, a);
+    else if (h->has_f)
+      hipLaunchKernelGGL((mfma16_backward_kernel<false, true>), dim3(h->batch), dim3(64), 0, h->stream, a);
     else
-      hipLaunchKernelGGL(mfma16_backward_kernel<false>, dim3(h->batch), dim3(64), 0, h->stream, a);
+      hipLaunchKernelGGL((mfma16_backward_kernel<false, false>), dim3(h->batch), dim3(64), 0, h->stream, a);
   } else if (h->dtype == ALTRO_HIP_F64) {
     auto a = generic_args<double>(h, reg);
     size_t lds = generic_backward_lds_bytes<double>(h->n, h->m);
@@ -309,7 +316,7 @@ int launch_backward(altro_hip_batch* h, double reg) {
 int launch_forward(altro_hip_batch* h) {
   ProfScope ps(h, 1);
   if (h->plan == ALTRO_HIP_PLAN_MFMA16) {
-    Mfma16Args a{h->m_in, h->m_term, h->m_out, h->m_outn, h->m_qblk, (const double*)h->x0, h->m_xuy,
+    Mfma16Args a{h->m_in, h->m_st.in_bs, h->m_st.in_ks, h->m_st.out_bs, h->m_st.out_ks, h->m_st.xuy_bs, h->m_st.xuy_ks, h->m_term, h->m_out, h->m_outn, h->m_qblk, h->m_trash, (const double*)h->x0, h->m_xuy,
                  (double*)h->delta_V, h->status, h->N, h->batch, 0.0, h->has_f};
     hipLaunchKernelGGL(mfma16_forward_kernel, dim3(h->batch), dim3(64), 0, h->stream, a);
   } else if (h->dtype == ALTRO_HIP_F64) {
@@ -395,10 +402,19 @@ int altro_hip_batch_create(altro_hip_batch** out, int N, int n, int m, int batch
   ALLOC(h->status, B * sizeof(int));
   if (plan == ALTRO_HIP_PLAN_MFMA16) {
     ALLOC(h->m_in, B * N * MF_IN * 8);
+    {
+      // default: knot-point-major slabs [k][b][record]; ALTRO_HIP_LAYOUT=bk selects problem-major
+      const char* lay = getenv("ALTRO_HIP_LAYOUT");
+      const bool kb = !(lay && lay[0] == 'b');
+      const int64_t Bq = batch;
+      h->m_st = kb ? Mfma16Strides{MF_IN, Bq * MF_IN, MF_OUT, Bq * MF_OUT, 28, Bq * 28}
+                   : Mfma16Strides{(int64_t)N * MF_IN, MF_IN, (int64_t)N * MF_OUT, MF_OUT, (int64_t)(N + 1) * 28, 28};
+    }
     ALLOC(h->m_term, B * MF_TERM * 8);
     ALLOC(h->m_out, B * N * MF_OUT * 8);
     ALLOC(h->m_outn, B * MF_TERM * 8);
     ALLOC(h->m_xuy, B * (N + 1) * 28 * 8);
+    ALLOC(h->m_trash, B * MF_OUT * 8);
     if (flags & ALTRO_HIP_STORE_QBLOCKS) ALLOC(h->m_qblk, B * N * MF_QB * 8);
   } else {
     const int blk[G_NUM] = {n * n, n * m, n, n * n, m * m, m * n, n, m, m * n, m, n * n, n,
@@ -440,7 +456,7 @@ void altro_hip_batch_destroy(altro_hip_batch* h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   void* ptrs[] = {h->x0, h->delta_V, h->status, h->m_in, h->m_term, h->m_out, h->m_outn, h->m_xuy,
-                  h->m_qblk, h->g_off, h->g_nx, h->g_nu, h->stage};
+                  h->m_qblk, h->m_trash, h->g_off, h->g_nx, h->g_nu, h->stage};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (int a = 0; a < G_NUM; ++a) if (h->g_arr[a]) (void)hipFree(h->g_arr[a]);
   if (h->ev0) (void)hipEventDestroy(h->ev0);

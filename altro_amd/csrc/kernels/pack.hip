@@ -46,12 +46,14 @@ __global__ void gather_copy_kernel(double* out, int64_t out_bs, int64_t out_ks, 
 }
 
 // ---- plan MFMA16 ------------------------------------------------------------------------------
+struct Mfma16Strides { int64_t in_bs, in_ks, out_bs, out_ks, xuy_bs, xuy_ks; };
+
 enum Mfma16Seg { MSEG_Z = 0, MSEG_F, MSEG_Q, MSEG_HR, MSEG_QR, MSEG_TERM_Q, MSEG_TERM_q };
 
 // One launch fills one segment of IN (or TERM) for problems [b0, b0+nb).  `s0`, `s1` are the one or
 // two reference arrays the segment draws from (Z: A,B ; HR: H,R ; QR: q,r).
-__global__ void mfma16_pack_kernel(double* in, double* term, int seg, SrcArr s0, SrcArr s1,
-                                   int is_diag, int N, int b0, int nb) {
+__global__ void mfma16_pack_kernel(double* in, double* term, Mfma16Strides st, int seg, SrcArr s0,
+                                   SrcArr s1, int is_diag, int N, int b0, int nb) {
   int len, base;
   switch (seg) {
     case MSEG_Z: len = 192; base = MF_OFF_Z; break;
@@ -93,7 +95,7 @@ __global__ void mfma16_pack_kernel(double* in, double* term, int seg, SrcArr s0,
       default: v = p0[e]; break;  // MSEG_TERM_q
     }
     if (terminal) term[(int64_t)(b0 + b) * MF_TERM + base + e] = v;
-    else in[((int64_t)(b0 + b) * N + k) * MF_IN + base + e] = v;
+    else in[(int64_t)(b0 + b) * st.in_bs + (int64_t)k * st.in_ks + base + e] = v;
   }
 }
 
@@ -101,7 +103,8 @@ enum Mfma16Get { MGET_K = 0, MGET_d, MGET_P, MGET_p, MGET_x, MGET_u, MGET_y, MGE
 
 // Reference-layout view of the results for problems [b0, b0+nb): dst is [nb][nk][len].
 __global__ void mfma16_unpack_kernel(double* dst, int what, const double* out, const double* outn,
-                                     const double* xuy, const double* qblk, int N, int b0, int nb) {
+                                     const double* xuy, const double* qblk, Mfma16Strides st, int N,
+                                     int b0, int nb) {
   int len, nk;
   switch (what) {
     case MGET_K: len = 48; nk = N; break;
@@ -119,9 +122,9 @@ __global__ void mfma16_unpack_kernel(double* dst, int what, const double* out, c
     const int e = (int)(t % len);
     const int k = (int)((t / len) % nk);
     const int b = b0 + (int)(t / ((int64_t)len * nk));
-    const double* o = (k < N) ? out + ((int64_t)b * N + k) * MF_OUT : nullptr;
+    const double* o = (k < N) ? out + (int64_t)b * st.out_bs + (int64_t)k * st.out_ks : nullptr;
     const double* pp = (k < N) ? o + MF_OFF_P : outn + (int64_t)b * MF_TERM;
-    const double* xr = xuy ? xuy + ((int64_t)b * (N + 1) + k) * 28 : nullptr;
+    const double* xr = xuy ? xuy + (int64_t)b * st.xuy_bs + (int64_t)k * st.xuy_ks : nullptr;
     double v;
     switch (what) {
       case MGET_K: v = o[(e % 4) * 13 + (e / 4)]; break;        // K[a + 4 j] = Kt[a][j]

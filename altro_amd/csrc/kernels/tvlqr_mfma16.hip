@@ -68,6 +68,16 @@ __device__ __forceinline__ double row16_allreduce(double v) {
   v += dpp_mov_f64<0x140>(v);  // row_mirror
   return v;
 }
+// Lanes 13..15 of every DPP row take lane 12's value (quad_perm [0,0,0,0] applied to bank 3 only);
+// all other lanes keep theirs.  Lets the three padding columns of a 16-wide tile store a duplicate of
+// column 12 to column 12's address, so that tile stores need no exec mask (and no branch).
+__device__ __forceinline__ double dpp_col12_dup(double v) {
+  union { double d; int i[2]; } in, out;
+  in.d = v;
+  out.i[0] = __builtin_amdgcn_update_dpp(in.i[0], in.i[0], 0x00, 0xf, 0x8, false);
+  out.i[1] = __builtin_amdgcn_update_dpp(in.i[1], in.i[1], 0x00, 0xf, 0x8, false);
+  return out.d;
+}
 // sum over the four 16-lane row groups (lanes l, l^16, l^32, l^48): result in every lane
 __device__ __forceinline__ double group4_allreduce(double v) {
   v += __shfl_xor(v, 16, 64);
@@ -77,10 +87,15 @@ __device__ __forceinline__ double group4_allreduce(double v) {
 
 struct Mfma16Args {
   const double* in;      // IN
+  // Element strides between problems (bs) / knot points (ks) of IN, OUT and the forward output.
+  // Knot-point-major ([k][b][record]: bs = record, ks = batch*record) keeps all the records touched at
+  // one time step in one contiguous slab of HBM (the batch structure-of-arrays picture); 0 = shared.
+  int64_t in_bs, in_ks, out_bs, out_ks, xuy_bs, xuy_ks;
   const double* term;    // TERM
   double* out;           // OUT
   double* outn;          // OUTN
   double* qblk;          // optional [b][k][MF_QB]
+  double* trash;         // [b][MF_OUT] dump record for the masked stores of failed problems
   const double* x0;      // [b][12]
   double* xuy;           // forward output [b][k][28] = x 12 | y 12 | u 4 ; terminal [b][N][..]
   double* delta_V;       // [b][2]
@@ -98,15 +113,20 @@ struct Mfma16Knot {  // one knot point's inputs, in registers (11 doubles / lane
   double z[3], q[3], hr, qr, f[3];
 };
 
-__device__ __forceinline__ void mfma16_load_knot(Mfma16Knot& kn, const double* rec, int lane, int j,
-                                                 int g, int has_f) {
+// All loads are unconditional and branch-free (lanes that have no element read a clamped, valid
+// address and discard it): exec-masked load branches make hipcc's s_waitcnt insertion collapse to
+// vmcnt(0) at the loop head, which serialises the prefetch against its own issue.
+template <bool HAS_F>
+__device__ __forceinline__ void mfma16_load_knot(Mfma16Knot& kn, const double* __restrict__ rec,
+                                                 int lane, int j, int g) {
+  const int jq = (j < 12) ? j : 11;
 #pragma unroll
   for (int c = 0; c < 3; ++c) kn.z[c] = rec[MF_OFF_Z + c * 64 + lane];
 #pragma unroll
-  for (int r = 0; r < 3; ++r) kn.q[r] = (j < 12) ? rec[MF_OFF_Q + r * 48 + g * 12 + j] : 0.0;
+  for (int r = 0; r < 3; ++r) kn.q[r] = rec[MF_OFF_Q + r * 48 + g * 12 + jq];
   kn.hr = rec[MF_OFF_HR + lane];
   kn.qr = rec[MF_OFF_QR + j];
-  if (has_f) {
+  if (HAS_F) {
 #pragma unroll
     for (int r = 0; r < 3; ++r) kn.f[r] = rec[MF_OFF_F + g + 4 * r];
   } else {
@@ -114,17 +134,42 @@ __device__ __forceinline__ void mfma16_load_knot(Mfma16Knot& kn, const double* r
   }
 }
 
-template <bool STORE_Q>
-__global__ __launch_bounds__(64) void mfma16_backward_kernel(Mfma16Args a) {
+// 1/sqrt(x) to ~1 ulp: v_rsq_f64 seed (~2^-24 relative) + ONE third-order step
+//   e = 1 - x y^2 ;  y <- y (1 + e/2 + 3 e^2 / 8)        (error ~ e^3 ~ 2^-70)
+// The Cholesky needs only the reciprocal pivots (L_kk itself is never used), so there is no sqrt
+// and no division anywhere in the sweep.
+__device__ __forceinline__ double rsqrt_nr(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  const double e = __builtin_fma(-x, y * y, 1.0);
+  const double t = __builtin_fma(0.375, e, 0.5);
+  return __builtin_fma(y * e, t, y);
+}
+
+template <bool STORE_Q, bool HAS_F>
+__global__ __launch_bounds__(64, 4) void mfma16_backward_kernel(Mfma16Args a) {
   // the one and only LDS object: 4x16 tile [Qux | Quu] then [Qx | Qu]
-  __shared__ __attribute__((aligned(16))) double S[64 + 16];
+  // S[0..63] = [Qux | Quu] (row g, col j), S[64..79] = [Qx | Qu], S[80] = 0.0 (the "zero slot" padding
+  // lanes read instead of selecting: their loop-invariant LDS addresses point here)
+  __shared__ __attribute__((aligned(16))) double S[64 + 16 + 2];
   const int lane = threadIdx.x;
   const int j = lane & 15, g = lane >> 4;
   const int b = blockIdx.x;
   if (b >= a.batch) return;
   const int N = a.N;
-  const double* in = a.in + (size_t)b * N * MF_IN;
-  double* out = a.out + (size_t)b * N * MF_OUT;
+  if (lane < 2) S[80 + lane] = 0.0;
+  // loop-invariant LDS read addresses (element indices into S)
+  int rhs_idx[4];   // column j of Qt = [Qux | Qu]; zero for the padding columns 13..15
+#pragma unroll
+  for (int r = 0; r < 4; ++r) rhs_idx[r] = (j < 12) ? (r * 16 + j) : ((j == 12) ? (64 + 12 + r) : 80);
+  const int qmine_idx = (j < 12) ? lane : ((j == 12) ? (64 + 12 + g) : 80);   // Qt[g][j]
+  int qx_idx[3];    // column 12 of [Qxx | Qx]: Qx[g + 4r]; zero for columns 13..15 (unused for j < 12)
+#pragma unroll
+  for (int r = 0; r < 3; ++r) qx_idx[r] = (j == 12) ? (64 + g + 4 * r) : 80;
+  const double* __restrict__ in = a.in + (size_t)b * a.in_bs;
+  double* __restrict__ out = a.out + (size_t)b * a.out_bs;
+  const bool col_ok = (j <= 12);
+  const int jc = col_ok ? j : 12;
+  double* __restrict__ trash = a.trash + (size_t)b * MF_OUT;
 
   // terminal cost-to-go: P_N = Q_N, p_N = q_N (tvlqr.cpp:81-90) -> tile [P | p]
   double Pt[3];
@@ -137,17 +182,23 @@ __global__ __launch_bounds__(64) void mfma16_backward_kernel(Mfma16Args a) {
       if (j < 12) v = term[r * 48 + g * 12 + j];
       else if (j == 12) v = term[144 + g + 4 * r];
       Pt[r] = v;
-      if (j <= 12) on[(g + 4 * r) * 13 + j] = v;
+      if (col_ok) on[(g + 4 * r) * 13 + j] = v;
     }
   }
+  // per-lane partial sums of the expected decrease; only column 12 is meaningful, reduced at the end
   double dv0 = 0.0, dv1 = 0.0;
+  int fail_k = -1;
 
   Mfma16Knot cur, nxt;
-  mfma16_load_knot(cur, in + (size_t)(N - 1) * MF_IN, lane, j, g, a.has_f);
+  mfma16_load_knot<HAS_F>(cur, in + (size_t)(N - 1) * a.in_ks, lane, j, g);
+  // Drain the VMEM queue before entering the loop: hipcc merges the pre-header's scoreboard into the
+  // loop header's, and a pending first load there turns into `s_waitcnt vmcnt(0)` at the top of EVERY
+  // iteration -- which would drain each step's stores before the next step may start.
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt/lgkmcnt untouched
 
   for (int k = N - 1; k >= 0; --k) {
-    // prefetch the next knot point (k-1) while this one computes
-    if (k > 0) mfma16_load_knot(nxt, in + (size_t)(k - 1) * MF_IN, lane, j, g, a.has_f);
+    // prefetch the next knot point (k-1) while this one computes (k == 0 re-reads record 0: harmless)
+    mfma16_load_knot<HAS_F>(nxt, in + (size_t)((k > 0) ? k - 1 : 0) * a.in_ks, lane, j, g);
 
     // ---- D1 = [P'|t]^T Z : rows 0..11 = P'^T Z, row 12 = t^T Z --------------------------------
     f64x4 D1 = {0.0, 0.0, 0.0, 0.0};
@@ -155,13 +206,15 @@ __global__ __launch_bounds__(64) void mfma16_backward_kernel(Mfma16Args a) {
     for (int c = 0; c < 3; ++c) D1 = mfma_f64_16x16x4(Pt[c], cur.z[c], D1);
 
     // ---- G = [Q H^T; H R] + Z^T D1 : Qxx (rows<12, cols<12), [Qux | Quu] (rows 12..15) ---------
+    // (columns 12..15 of rows 0..11 -- the Qxu block -- are never used, so the clamped Q loads of the
+    //  padding lanes need no zeroing)
     f64x4 G = {cur.q[0], cur.q[1], cur.q[2], cur.hr};
 #pragma unroll
     for (int c = 0; c < 3; ++c) G = mfma_f64_16x16x4(cur.z[c], D1[c], G);
 
     // ---- gradient [Qx; Qu] = [q; r] + Z^T t (+ Z^T P' f) : valid in lanes g == 0 -----------------
     double gv = D1[3] + cur.qr;
-    if (a.has_f) {  // Z^T P' f = (P'^T Z)^T f : sum_i f[i] D1[i][j]
+    if (HAS_F) {  // Z^T P' f = (P'^T Z)^T f : sum_i f[i] D1[i][j]
       double s = cur.f[0] * D1[0] + cur.f[1] * D1[1] + cur.f[2] * D1[2];
       gv += group4_allreduce(s);
     }
@@ -171,102 +224,100 @@ __global__ __launch_bounds__(64) void mfma16_backward_kernel(Mfma16Args a) {
     S[lane] = G[3];                 // [Qux | Quu], row g, col j
     if (g == 0) S[64 + j] = gv;     // [Qx | Qu]
     __syncthreads();
-    double Quu[4][4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) Quu[r][c] = S[r * 16 + 12 + c];
+    // lower triangle of Quu (Eigen's LLT<Lower> reads only that), same in every lane
+    const double a00 = S[0 * 16 + 12];
+    const double a10 = S[1 * 16 + 12], a11 = S[1 * 16 + 13];
+    const double a20 = S[2 * 16 + 12], a21 = S[2 * 16 + 13], a22 = S[2 * 16 + 14];
+    const double a30 = S[3 * 16 + 12], a31 = S[3 * 16 + 13], a32 = S[3 * 16 + 14], a33 = S[3 * 16 + 15];
     double rhs[4];  // column j of Qt = [Qux | Qu]
 #pragma unroll
-    for (int r = 0; r < 4; ++r) rhs[r] = S[(j == 12) ? (64 + 12 + r) : (r * 16 + j)];
-    double c3[3];   // column j of [Qxx | Qx], rows g + 4r
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      double qx = S[64 + g + 4 * r];
-      c3[r] = (j < 12) ? G[r] : ((j == 12) ? qx : 0.0);
-    }
+    for (int r = 0; r < 4; ++r) rhs[r] = S[rhs_idx[r]];
     double quu_row[4];  // row g of the UNregularised Quu
 #pragma unroll
     for (int c = 0; c < 4; ++c) quu_row[c] = S[g * 16 + 12 + c];
-    const double q_mine = rhs[g];  // Qt[g][j]
+    f64x4 Pn;           // accumulator init: column j of [Qxx | Qx], rows g + 4r
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const double qx = S[qx_idx[r]];
+      Pn[r] = (j < 12) ? G[r] : qx;
+    }
+    Pn[3] = 0.0;
+    const double q_mine = S[qmine_idx];  // Qt[g][j] (0 in the padding columns)
 
-    // ---- Cholesky of Quu + reg I (lower, fail when a pivot is <= 0: tvlqr.cpp:159-164) -----------
+    // ---- Cholesky of Quu + reg I (lower; fail when a pivot is <= 0: tvlqr.cpp:159-164) -----------
+    // Only the reciprocal pivots i_k = 1/L_kk are needed by the substitutions below.
     const double reg = a.reg;
-    double x0 = Quu[0][0] + reg;
-    bool fail = !(x0 > 0.0);
-    double l00 = sqrt(x0), i0 = 1.0 / l00;
-    double l10 = Quu[1][0] * i0, l20 = Quu[2][0] * i0, l30 = Quu[3][0] * i0;
-    double x1 = (Quu[1][1] + reg) - l10 * l10;
-    fail = fail || !(x1 > 0.0);
-    double l11 = sqrt(x1), i1 = 1.0 / l11;
-    double l21 = (Quu[2][1] - l20 * l10) * i1, l31 = (Quu[3][1] - l30 * l10) * i1;
-    double x2 = (Quu[2][2] + reg) - l20 * l20 - l21 * l21;
-    fail = fail || !(x2 > 0.0);
-    double l22 = sqrt(x2), i2 = 1.0 / l22;
-    double l32 = (Quu[3][2] - l30 * l20 - l31 * l21) * i2;
-    double x3 = (Quu[3][3] + reg) - l30 * l30 - l31 * l31 - l32 * l32;
-    fail = fail || !(x3 > 0.0);
-    double l33 = sqrt(x3), i3 = 1.0 / l33;
-    if (fail) {  // wave-uniform: Quu is the same in every lane.  Reference: `return k` with
-                 // K_k = Qux, d_k = -Qu left unsolved and P_k, p_k untouched.
-      if (j <= 12) out[(size_t)k * MF_OUT + g * 13 + j] = q_mine;
-      if (j == 12 && g == 0) {  // the lane that owns the delta_V accumulators
-        a.status[b] = k;
-        a.delta_V[2 * (size_t)b + 0] = dv0;
-        a.delta_V[2 * (size_t)b + 1] = dv1;
-      }
-      return;
-    }
+    const double x0 = a00 + reg;
+    const double i0 = rsqrt_nr(x0);
+    const double l10 = a10 * i0, l20 = a20 * i0, l30 = a30 * i0;
+    const double x1 = (a11 + reg) - l10 * l10;
+    const double i1 = rsqrt_nr(x1);
+    const double l21 = (a21 - l20 * l10) * i1, l31 = (a31 - l30 * l10) * i1;
+    const double x2 = (a22 + reg) - l20 * l20 - l21 * l21;
+    const double i2 = rsqrt_nr(x2);
+    const double l32 = (a32 - l30 * l20 - l31 * l21) * i2;
+    const double x3 = (a33 + reg) - l30 * l30 - l31 * l31 - l32 * l32;
+    const double i3 = rsqrt_nr(x3);
+    // Failure is wave-uniform (Quu is the same in every lane).  Reference: `return k` with
+    // K_k = Qux, d_k = -Qu left unsolved and P_k, p_k untouched.  To keep the loop a plain counted
+    // loop (no mid-body exits: they wreck hipcc's s_waitcnt placement) a failed problem keeps
+    // iterating on garbage with its stores masked off; failures are rare and cost nothing extra.
+    const bool fail = !(x0 > 0.0) || !(x1 > 0.0) || !(x2 > 0.0) || !(x3 > 0.0);
+    const bool was_alive = (fail_k < 0);
+    if (was_alive && fail) fail_k = k;
+    const bool alive = (fail_k < 0);
     // ---- Kt[:, j] = (L L^T)^-1 Qt[:, j]  (tvlqr.cpp:165-166; column 12 gives -d) ------------------
-    double y0 = rhs[0] * i0;
-    double y1 = (rhs[1] - l10 * y0) * i1;
-    double y2 = (rhs[2] - l20 * y0 - l21 * y1) * i2;
-    double y3 = (rhs[3] - l30 * y0 - l31 * y1 - l32 * y2) * i3;
-    double k3 = y3 * i3;
-    double k2 = (y2 - l32 * k3) * i2;
-    double k1 = (y1 - l21 * k2 - l31 * k3) * i1;
-    double k0 = (y0 - l10 * k1 - l20 * k2 - l30 * k3) * i0;
-    double k_mine = (g == 0) ? k0 : (g == 1) ? k1 : (g == 2) ? k2 : k3;  // Kt[g][j]
-    // W[g][j] = (Quu Kt - Qt)[g][j]   (tvlqr.cpp:174 uses the unregularised Quu)
-    double w_mine = quu_row[0] * k0 + quu_row[1] * k1 + quu_row[2] * k2 + quu_row[3] * k3 - q_mine;
-    // ---- expected decrease (tvlqr.cpp:189-191), meaningful in column 12 where Kt = -d, Qt = Qu ---
-    {
-      double qd0 = Quu[0][0] * k0 + Quu[0][1] * k1 + Quu[0][2] * k2 + Quu[0][3] * k3;
-      double qd1 = Quu[1][0] * k0 + Quu[1][1] * k1 + Quu[1][2] * k2 + Quu[1][3] * k3;
-      double qd2 = Quu[2][0] * k0 + Quu[2][1] * k1 + Quu[2][2] * k2 + Quu[2][3] * k3;
-      double qd3 = Quu[3][0] * k0 + Quu[3][1] * k1 + Quu[3][2] * k2 + Quu[3][3] * k3;
-      dv0 -= k0 * rhs[0] + k1 * rhs[1] + k2 * rhs[2] + k3 * rhs[3];        // d . Qu
-      dv1 += 0.5 * (k0 * qd0 + k1 * qd1 + k2 * qd2 + k3 * qd3);           // 1/2 d . Quu d
-    }
-    if (j > 12) { k_mine = 0.0; w_mine = 0.0; }
-    const double q_op = (j > 12) ? 0.0 : q_mine;
+    const double y0 = rhs[0] * i0;
+    const double y1 = (rhs[1] - l10 * y0) * i1;
+    const double y2 = (rhs[2] - l20 * y0 - l21 * y1) * i2;
+    const double y3 = (rhs[3] - l30 * y0 - l31 * y1 - l32 * y2) * i3;
+    const double k3 = y3 * i3;
+    const double k2 = (y2 - l32 * k3) * i2;
+    const double k1 = (y1 - l21 * k2 - l31 * k3) * i1;
+    const double k0 = (y0 - l10 * k1 - l20 * k2 - l30 * k3) * i0;
+    const double k_mine = (g == 0) ? k0 : (g == 1) ? k1 : (g == 2) ? k2 : k3;  // Kt[g][j]
+    // (Quu Kt)[g][j] with the UNregularised Quu (tvlqr.cpp:174), then W = Quu Kt - Qt
+    const double qk = quu_row[0] * k0 + quu_row[1] * k1 + quu_row[2] * k2 + quu_row[3] * k3;
+    const double w_mine = qk - q_mine;   // padding columns: rhs = 0 => Kt = 0, W = 0 without masking
+    // ---- expected decrease (tvlqr.cpp:189-191): in column 12 Kt = -d, Qt = Qu, so
+    //      d.Qu = -sum_g Kt[g] Qt[g]  and  1/2 d.Quu d = 1/2 sum_g Kt[g] (Quu Kt)[g]
+    dv0 = alive ? __builtin_fma(-k_mine, q_mine, dv0) : dv0;
+    dv1 = alive ? __builtin_fma(0.5 * k_mine, qk, dv1) : dv1;
 
     // ---- [P | p] = [Qxx | Qx] + Kt^T W - Qt^T Kt  (tvlqr.cpp:173-186) ----------------------------
-    f64x4 Pn = {c3[0], c3[1], c3[2], 0.0};
     Pn = mfma_f64_16x16x4(k_mine, w_mine, Pn);
-    Pn = mfma_f64_16x16x4(q_op, -k_mine, Pn);
+    Pn = mfma_f64_16x16x4(q_mine, -k_mine, Pn);
 
-    // ---- store Kt and [P | p]; roll the tile --------------------------------------------------------
-    double* o = out + (size_t)k * MF_OUT;
-    if (j <= 12) {
-      o[g * 13 + j] = k_mine;
+    // ---- roll the prefetched knot point in BEFORE the stores are issued, so that the wait for its
+    //      loads does not also have to drain this step's stores (vmcnt retires in order) ------------
+    const double k_store = alive ? k_mine : q_mine;
+    cur = nxt;
+    // ---- store Kt and [P | p] --------------------------------------------------------------------------
+    // Unconditional, branch-free stores: lanes 13..15 duplicate column 12 onto column 12's address,
+    // and a failed problem's stores are redirected to its trash record.  With no exec-masked VMEM in
+    // the loop hipcc can count the queue exactly and wait for the prefetch with vmcnt(#younger ops)
+    // instead of draining the stores too.
+    double* __restrict__ ok_ = was_alive ? out + (size_t)k * a.out_ks : trash;
+    double* __restrict__ op_ = alive ? out + (size_t)k * a.out_ks : trash;
+    ok_[g * 13 + jc] = dpp_col12_dup(k_store);
 #pragma unroll
-      for (int r = 0; r < 3; ++r) o[MF_OFF_P + (g + 4 * r) * 13 + j] = Pn[r];
-    }
-    if (STORE_Q) {  // Qxx_, Quu_, Qux_, Qx_, Qu_ are API-visible in the reference
+    for (int r = 0; r < 3; ++r) op_[MF_OFF_P + (g + 4 * r) * 13 + jc] = dpp_col12_dup(Pn[r]);
+    if (STORE_Q && was_alive) {  // Qxx_, Quu_, Qux_, Qx_, Qu_ are API-visible in the reference
       double* qb = a.qblk + ((size_t)b * N + k) * MF_QB;
 #pragma unroll
       for (int r = 0; r < 4; ++r) qb[(g + 4 * r) * 16 + j] = G[r];
       if (g == 0) qb[256 + j] = gv;
     }
 #pragma unroll
-    for (int r = 0; r < 3; ++r) Pt[r] = (j <= 12) ? Pn[r] : 0.0;
-    cur = nxt;
+    for (int r = 0; r < 3; ++r) Pt[r] = Pn[r];   // columns 13..15 are exactly 0 by construction
   }
-  if (j == 12 && g == 0) {
-    a.status[b] = -1;
-    a.delta_V[2 * (size_t)b + 0] = dv0;
-    a.delta_V[2 * (size_t)b + 1] = dv1;
+  {
+    const double t0 = group4_allreduce(dv0), t1 = group4_allreduce(dv1);
+    if (j == 12 && g == 0) {
+      a.status[b] = fail_k;   // -1 == TVLQR_SUCCESS, else the failing knot point
+      a.delta_V[2 * (size_t)b + 0] = t0;
+      a.delta_V[2 * (size_t)b + 1] = t1;
+    }
   }
 }
 
@@ -286,9 +337,14 @@ __device__ __forceinline__ void mfma16_load_fwd(Mfma16FwdKnot& kn, const double*
   for (int c = 0; c < 3; ++c) kn.z[c] = rec[MF_OFF_Z + c * 64 + lane];
 #pragma unroll
   for (int r = 0; r < 3; ++r) kn.f[r] = rec[MF_OFF_F + g + 4 * r];
-  kn.kt = (j <= 12) ? orec[g * 13 + j] : 0.0;
+  const int jc = (j <= 12) ? j : 12;   // clamped: no exec-masked load branches (see backward)
+  const double kt = orec[g * 13 + jc];
+  kn.kt = (j <= 12) ? kt : 0.0;
 #pragma unroll
-  for (int r = 0; r < 3; ++r) kn.p[r] = (j <= 12) ? orec[MF_OFF_P + (g + 4 * r) * 13 + j] : 0.0;
+  for (int r = 0; r < 3; ++r) {
+    const double pv = orec[MF_OFF_P + (g + 4 * r) * 13 + jc];
+    kn.p[r] = (j <= 12) ? pv : 0.0;
+  }
 }
 
 __global__ __launch_bounds__(64) void mfma16_forward_kernel(Mfma16Args a) {
@@ -298,18 +354,20 @@ __global__ __launch_bounds__(64) void mfma16_forward_kernel(Mfma16Args a) {
   const int b = blockIdx.x;
   if (b >= a.batch) return;
   const int N = a.N;
-  const double* in = a.in + (size_t)b * N * MF_IN;
-  const double* out = a.out + (size_t)b * N * MF_OUT;
-  double* xuy = a.xuy + (size_t)b * (N + 1) * 28;
+  const double* in = a.in + (size_t)b * a.in_bs;
+  const double* out = a.out + (size_t)b * a.out_bs;
+  double* xuy = a.xuy + (size_t)b * a.xuy_bs;
 
   // x~ = [x; 1] in column layout
   double xc = (j < 12) ? a.x0[(size_t)b * 12 + j] : ((j == 12) ? 1.0 : 0.0);
   Mfma16FwdKnot cur, nxt;
   mfma16_load_fwd(cur, in, out, lane, j, g);
   for (int k = 0; k < N; ++k) {
-    if (k + 1 < N)
-      mfma16_load_fwd(nxt, in + (size_t)(k + 1) * MF_IN, out + (size_t)(k + 1) * MF_OUT, lane, j, g);
-    double* o = xuy + (size_t)k * 28;
+    {
+      const int kn = (k + 1 < N) ? k + 1 : k;   // last step re-reads itself: harmless, branch-free
+      mfma16_load_fwd(nxt, in + (size_t)kn * a.in_ks, out + (size_t)kn * a.out_ks, lane, j, g);
+    }
+    double* o = xuy + (size_t)k * a.xuy_ks;
     // u[g] = -(Kt x~)[g] = d - K x
     const double ug = -row16_allreduce(cur.kt * xc);
     // y[g+4r] = ([P p] x~)[g+4r]
@@ -345,7 +403,7 @@ __global__ __launch_bounds__(64) void mfma16_forward_kernel(Mfma16Args a) {
   // terminal knot point: x_N, y_N = P_N x_N + p_N (tvlqr.cpp:238-246)
   {
     const double* on = a.outn + (size_t)b * MF_TERM;
-    double* o = xuy + (size_t)N * 28;
+    double* o = xuy + (size_t)N * a.xuy_ks;
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
       double pv = (j <= 12) ? on[(g + 4 * r) * 13 + j] : 0.0;

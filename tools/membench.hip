@@ -1,0 +1,107 @@
+// tools/membench.hip -- HBM streaming probes on MI355X: what bandwidth can the backward sweep's access
+// pattern reach with NO arithmetic?  (Practical roof next to the 8 TB/s datasheet number.)
+//   hipcc --offload-arch=gfx950 -O3 tools/membench.hip -o /tmp/membench && /tmp/membench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+__global__ void copy16(const double2* __restrict__ src, double2* __restrict__ dst, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+__global__ void read16(const double2* __restrict__ src, double* sink, size_t n) {
+  double acc = 0;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) { double2 v = src[i]; acc += v.x + v.y; }
+  if (acc == 1.2345) sink[0] = acc;
+}
+__global__ void write16nt(double2* __restrict__ dst, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    __builtin_nontemporal_store(1.0, &dst[i].x); __builtin_nontemporal_store(2.0, &dst[i].y);
+  }
+}
+__global__ void write8(double* __restrict__ dst, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = 1.0;
+}
+__global__ void write8nt(double* __restrict__ dst, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) __builtin_nontemporal_store(1.0, &dst[i]);
+}
+__global__ void read8(const double* __restrict__ src, double* sink, size_t n) {
+  double acc = 0;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) acc += src[i];
+  if (acc == 1.2345) sink[0] = acc;
+}
+__global__ void write16(double2* __restrict__ dst, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = make_double2(1.0, 2.0);
+}
+
+// wave-per-problem record streaming: per step read RIN doubles, write ROUT doubles, 8 B per lane,
+// software prefetch DEPTH steps ahead.  LAY = 0: [b][k], 1: [k][b].
+template <int DEPTH, int LAY, int W>
+__global__ __launch_bounds__(64) void stream_records(const double* __restrict__ in, double* __restrict__ out, int N, int batch) {
+  constexpr int RIN = 428, ROUT = 208;
+  const int lane = threadIdx.x, b = blockIdx.x;
+  const size_t in_bs = LAY ? RIN : (size_t)N * RIN, in_ks = LAY ? (size_t)batch * RIN : RIN;
+  const size_t out_bs = LAY ? ROUT : (size_t)N * ROUT, out_ks = LAY ? (size_t)batch * ROUT : ROUT;
+  const double* ip = in + b * in_bs;
+  double* op = out + b * out_bs;
+  double buf[DEPTH + 1][7];
+  auto load = [&](double* r, int k) {
+    const double* rec = ip + (size_t)k * in_ks;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) r[c] = rec[c * 64 + lane];
+    r[6] = rec[384 + (lane < 44 ? lane : 43)];
+  };
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) load(buf[d], N - 1 - d);
+  double acc = 0.0;
+  for (int k = N - 1; k >= 0; --k) {
+    int kp = k - DEPTH; if (kp < 0) kp = 0;
+    load(buf[DEPTH], kp);
+    double s = 0;
+#pragma unroll
+    for (int c = 0; c < 7; ++c) s += buf[0][c];
+    acc += s;
+    double* o = op + (size_t)k * out_ks;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { if (W) __builtin_nontemporal_store(s + c, &o[c * 64 + lane]); else o[c * 64 + lane] = s + c; }
+    if (W) __builtin_nontemporal_store(acc, &o[192 + (lane & 15)]); else o[192 + (lane & 15)] = acc;
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+      for (int c = 0; c < 7; ++c) buf[d][c] = buf[d + 1][c];
+  }
+}
+
+int main() {
+  const int N = 256, batch = 4096;
+  const size_t in_n = (size_t)batch * N * 428, out_n = (size_t)batch * N * 208;
+  double *in, *out, *sink;
+  CK(hipMalloc(&in, in_n * 8)); CK(hipMalloc(&out, out_n * 8)); CK(hipMalloc(&sink, 64));
+  CK(hipMemset(in, 0, in_n * 8)); CK(hipMemset(out, 0, out_n * 8));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  auto timeit = [&](const char* name, double bytes, auto launch) {
+    for (int i = 0; i < 3; ++i) launch();
+    hipEventRecord(e0); for (int i = 0; i < 10; ++i) launch(); hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 10;
+    printf("%-44s %8.3f ms  %8.1f GB/s\n", name, ms, bytes / ms / 1e6);
+  };
+  const size_t n16 = in_n / 2;
+  timeit("copy16 in->in2 (full 3.59 GB r + w)", 2.0 * out_n * 8, [&] { copy16<<<256 * 8, 256>>>((const double2*)in, (double2*)out, out_n / 2); });
+  timeit("read-only 16B/lane (3.59 GB)", 1.0 * in_n * 8, [&] { read16<<<256 * 8, 256>>>((const double2*)in, sink, n16); });
+  timeit("write-only 16B/lane (1.74 GB)", 1.0 * out_n * 8, [&] { write16<<<256 * 8, 256>>>((double2*)out, out_n / 2); });
+  timeit("write-only 16B/lane nontemporal", 1.0 * out_n * 8, [&] { write16nt<<<256 * 8, 256>>>((double2*)out, out_n / 2); });
+  timeit("write-only 8B/lane", 1.0 * out_n * 8, [&] { write8<<<256 * 8, 256>>>(out, out_n); });
+  timeit("write-only 8B/lane nontemporal", 1.0 * out_n * 8, [&] { write8nt<<<256 * 8, 256>>>(out, out_n); });
+  timeit("write-only 16B/lane, 64K blocks", 1.0 * out_n * 8, [&] { write16<<<65536, 256>>>((double2*)out, out_n / 2); });
+  timeit("read-only 8B/lane (3.59 GB)", 1.0 * in_n * 8, [&] { read8<<<256 * 8, 256>>>(in, sink, in_n); });
+  timeit("read-only 16B/lane, 64K blocks", 1.0 * in_n * 8, [&] { read16<<<65536, 256>>>((const double2*)in, sink, n16); });
+  const double rb = (double)in_n * 8 + (double)out_n * 8;
+  timeit("records [b][k] depth1", rb, [&] { stream_records<1, 0, 0><<<batch, 64>>>(in, out, N, batch); });
+  timeit("records [k][b] depth1", rb, [&] { stream_records<1, 1, 0><<<batch, 64>>>(in, out, N, batch); });
+  timeit("records [k][b] depth2", rb, [&] { stream_records<2, 1, 0><<<batch, 64>>>(in, out, N, batch); });
+  timeit("records [k][b] depth3", rb, [&] { stream_records<3, 1, 0><<<batch, 64>>>(in, out, N, batch); });
+  timeit("records [k][b] depth1 nt stores", rb, [&] { stream_records<1, 1, 1><<<batch, 64>>>(in, out, N, batch); });
+  timeit("records [b][k] depth1 nt stores", rb, [&] { stream_records<1, 0, 1><<<batch, 64>>>(in, out, N, batch); });
+  timeit("records [b][k] depth3", rb, [&] { stream_records<3, 0, 0><<<batch, 64>>>(in, out, N, batch); });
+  return 0;
+}
