@@ -16,6 +16,7 @@
 
 #include "kernels/pack.hip"
 #include "kernels/tvlqr_generic.hip"
+#include "kernels/tvlqr_lane.hip"
 #include "kernels/tvlqr_mfma16.hip"
 
 using namespace altro_hip;
@@ -68,6 +69,9 @@ struct altro_hip_batch {
   double *m_in = nullptr, *m_term = nullptr, *m_out = nullptr, *m_outn = nullptr, *m_xuy = nullptr,
          *m_qblk = nullptr, *m_trash = nullptr;
   Mfma16Strides m_st{};
+  // plan LANE: batch structure-of-arrays ([k][element][batch])
+  void *l_in = nullptr, *l_term = nullptr, *l_out = nullptr, *l_outn = nullptr, *l_xuy = nullptr,
+       *l_x0 = nullptr;
   // staging for host <-> device conversion (grown lazily, never inside the hot path)
   void* stage = nullptr;
   size_t stage_bytes = 0;
@@ -241,6 +245,64 @@ int mfma16_pack_launch(altro_hip_batch* h, int seg, SrcArr s0, SrcArr s1) {
   return 0;
 }
 
+
+// ---- plan LANE dispatch ---------------------------------------------------------------------------
+#define LANE_SHAPES(X) X(2, 1) X(4, 2) X(3, 1) X(6, 3)
+bool lane_supported(int n, int m) {
+#define X(N_, M_) if (n == N_ && m == M_) return true;
+  LANE_SHAPES(X)
+#undef X
+  return false;
+}
+struct LaneSizes { int e_in, e_term, e_out, e_xuy; };
+LaneSizes lane_sizes(int n, int m) {
+  return LaneSizes{2 * n * n + 2 * n * m + m * m + 2 * n + m, n * n + n, m * n + m + n * n + n, 2 * n + m};
+}
+template <typename T>
+int lane_launch(altro_hip_batch* h, bool backward, double reg) {
+  LaneArgs<T> a{(const T*)h->l_in, (const T*)h->l_term, (T*)h->l_out, (T*)h->l_outn, (const T*)h->l_x0,
+                (T*)h->l_xuy, (T*)h->delta_V, h->status, h->N, h->batch, (T)reg};
+  const dim3 grid((h->batch + 63) / 64), block(64);
+#define X(N_, M_)                                                                                     \
+  if (h->n == N_ && h->m == M_) {                                                                     \
+    if (backward) hipLaunchKernelGGL((lane_backward_kernel<N_, M_, T>), grid, block, 0, h->stream, a); \
+    else hipLaunchKernelGGL((lane_forward_kernel<N_, M_, T>), grid, block, 0, h->stream, a);           \
+  }
+  LANE_SHAPES(X)
+#undef X
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "lane kernel launch: %s", hipGetErrorString(e));
+  return 0;
+}
+// one reference-layout source -> a run of elements of the SoA records [k0, k0+nk)
+template <typename T>
+int lane_pack(altro_hip_batch* h, T* dst_base, int E, const double* host, int len, int dst_off,
+              int diag_n, int nk, int k_src0, int nk_host, int kz, int bz, int src_off = 0) {
+  DevSrc d;
+  int rc = put_src(h, host, len, nk_host, kz, bz, &d);
+  if (rc) return rc;
+  LaneSeg s{d.s.p ? d.s.p + src_off : nullptr, d.s.bs, d.s.ks, len, dst_off, diag_n};
+  const int dlen = diag_n > 0 ? diag_n * diag_n : len;
+  const int64_t total = (int64_t)h->batch * nk * dlen;
+  hipLaunchKernelGGL(lane_pack_kernel<T>, dim3(grid_for(total)), dim3(256), 0, h->stream, dst_base, E, s,
+                     nk, k_src0, h->batch);
+  if (hipGetLastError() != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "lane_pack launch failed");
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return 0;
+}
+template <typename T>
+int lane_get(altro_hip_batch* h, double* host, const void* src, const void* src_term, int E, int off,
+             int off_term, int len, int nk, int nk_main) {
+  return download_chunks(h, host, len, nk, [&](double* dst, int b0, int nb) {
+    const int64_t total = (int64_t)nb * nk * len;
+    hipLaunchKernelGGL(lane_unpack_kernel<T>, dim3(grid_for(total)), dim3(256), 0, h->stream, dst,
+                       (const T*)src, (const T*)src_term, E, off, 0, off_term, len, nk, nk_main, b0, nb,
+                       h->batch);
+    if (hipGetLastError() != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "lane_unpack launch failed");
+    return 0;
+  });
+}
+
 template <typename T>
 GenericArgs<T> generic_args(altro_hip_batch* h, double reg) {
   GenericArgs<T> a;
@@ -285,6 +347,25 @@ struct ProfScope {
   }
 };
 
+
+int lane_get_any(altro_hip_batch* h, int what, double* dst) {
+  const int n = h->n, m = h->m, N = h->N;
+  const LaneSizes z = lane_sizes(n, m);
+  const void *src, *term = nullptr;
+  int E, off, off_t = 0, len, nk, nk_main;
+  switch (what) {
+    case MGET_K: src = h->l_out; E = z.e_out; off = 0; len = m * n; nk = nk_main = N; break;
+    case MGET_d: src = h->l_out; E = z.e_out; off = m * n; len = m; nk = nk_main = N; break;
+    case MGET_P: src = h->l_out; term = h->l_outn; E = z.e_out; off = m * n + m; off_t = 0; len = n * n; nk = N + 1; nk_main = N; break;
+    case MGET_p: src = h->l_out; term = h->l_outn; E = z.e_out; off = m * n + m + n * n; off_t = n * n; len = n; nk = N + 1; nk_main = N; break;
+    case MGET_x: src = h->l_xuy; E = z.e_xuy; off = 0; len = n; nk = nk_main = N + 1; break;
+    case MGET_y: src = h->l_xuy; E = z.e_xuy; off = n; len = n; nk = nk_main = N + 1; break;
+    default: src = h->l_xuy; E = z.e_xuy; off = 2 * n; len = m; nk = nk_main = N; break;
+  }
+  return h->dtype == ALTRO_HIP_F64 ? lane_get<double>(h, dst, src, term, E, off, off_t, len, nk, nk_main)
+                                   : lane_get<float>(h, dst, src, term, E, off, off_t, len, nk, nk_main);
+}
+
 int launch_backward(altro_hip_batch* h, double reg) {
   ProfScope ps(h, 0);
   if (h->plan == ALTRO_HIP_PLAN_MFMA16) {
@@ -299,6 +380,8 @@ int launch_backward(altro_hip_batch* h, double reg) {
       hipLaunchKernelGGL((mfma16_backward_kernel<false, true>), dim3(h->batch), dim3(64), 0, h->stream, a);
     else
       hipLaunchKernelGGL((mfma16_backward_kernel<false, false>), dim3(h->batch), dim3(64), 0, h->stream, a);
+  } else if (h->plan == ALTRO_HIP_PLAN_LANE) {
+    return h->dtype == ALTRO_HIP_F64 ? lane_launch<double>(h, true, reg) : lane_launch<float>(h, true, reg);
   } else if (h->dtype == ALTRO_HIP_F64) {
     auto a = generic_args<double>(h, reg);
     size_t lds = generic_backward_lds_bytes<double>(h->n, h->m);
@@ -319,6 +402,8 @@ int launch_forward(altro_hip_batch* h) {
     Mfma16Args a{h->m_in, h->m_st.in_bs, h->m_st.in_ks, h->m_st.out_bs, h->m_st.out_ks, h->m_st.xuy_bs, h->m_st.xuy_ks, h->m_term, h->m_out, h->m_outn, h->m_qblk, h->m_trash, (const double*)h->x0, h->m_xuy,
                  (double*)h->delta_V, h->status, h->N, h->batch, 0.0, h->has_f};
     hipLaunchKernelGGL(mfma16_forward_kernel, dim3(h->batch), dim3(64), 0, h->stream, a);
+  } else if (h->plan == ALTRO_HIP_PLAN_LANE) {
+    return h->dtype == ALTRO_HIP_F64 ? lane_launch<double>(h, false, 0.0) : lane_launch<float>(h, false, 0.0);
   } else if (h->dtype == ALTRO_HIP_F64) {
     auto a = generic_args<double>(h, 0.0);
     size_t lds = (size_t)(2 * h->n + h->m) * sizeof(double) + 64;
@@ -375,11 +460,13 @@ int altro_hip_batch_create(altro_hip_batch** out, int N, int n, int m, int batch
   if (altro_hip_device_count() <= device || device < 0)
     return fail(ALTRO_HIP_ERR_NO_DEVICE, "no HIP device %d: the altro_hip hot path has no CPU fallback", device);
   const bool mfma_ok = (n == 12 && m == 4 && dtype == ALTRO_HIP_F64);
-  if (plan == ALTRO_HIP_PLAN_AUTO) plan = mfma_ok ? ALTRO_HIP_PLAN_MFMA16 : ALTRO_HIP_PLAN_GENERIC;
+  if (plan == ALTRO_HIP_PLAN_AUTO)
+    plan = mfma_ok ? ALTRO_HIP_PLAN_MFMA16 : (lane_supported(n, m) ? ALTRO_HIP_PLAN_LANE : ALTRO_HIP_PLAN_GENERIC);
   if (plan == ALTRO_HIP_PLAN_MFMA16 && !mfma_ok)
     return fail(ALTRO_HIP_ERR_UNSUPPORTED, "plan MFMA16 needs (n, m, dtype) = (12, 4, f64)");
-  if (plan == ALTRO_HIP_PLAN_LANE) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "plan LANE is not built yet");
-  if (plan != ALTRO_HIP_PLAN_MFMA16 && plan != ALTRO_HIP_PLAN_GENERIC)
+  if (plan == ALTRO_HIP_PLAN_LANE && !lane_supported(n, m))
+    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "plan LANE is instantiated for (n, m) in {(2,1), (3,1), (4,2), (6,3)}");
+  if (plan != ALTRO_HIP_PLAN_MFMA16 && plan != ALTRO_HIP_PLAN_GENERIC && plan != ALTRO_HIP_PLAN_LANE)
     return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "bad plan %d", plan);
   HIP_TRY(hipSetDevice(device));
   altro_hip_batch* h = new altro_hip_batch();
@@ -409,6 +496,7 @@ int altro_hip_batch_create(altro_hip_batch** out, int N, int n, int m, int batch
       const int64_t Bq = batch;
       h->m_st = kb ? Mfma16Strides{MF_IN, Bq * MF_IN, MF_OUT, Bq * MF_OUT, 28, Bq * 28}
                    : Mfma16Strides{(int64_t)N * MF_IN, MF_IN, (int64_t)N * MF_OUT, MF_OUT, (int64_t)(N + 1) * 28, 28};
+      if (lay && lay[0] == 's') { h->m_st.in_bs = 0; h->m_st.in_ks = 0; }   // experiment: one shared IN record
     }
     ALLOC(h->m_term, B * MF_TERM * 8);
     ALLOC(h->m_out, B * N * MF_OUT * 8);
@@ -416,6 +504,14 @@ int altro_hip_batch_create(altro_hip_batch** out, int N, int n, int m, int batch
     ALLOC(h->m_xuy, B * (N + 1) * 28 * 8);
     ALLOC(h->m_trash, B * MF_OUT * 8);
     if (flags & ALTRO_HIP_STORE_QBLOCKS) ALLOC(h->m_qblk, B * N * MF_QB * 8);
+  } else if (plan == ALTRO_HIP_PLAN_LANE) {
+    const LaneSizes z = lane_sizes(n, m);
+    ALLOC(h->l_in, B * N * z.e_in * E);
+    ALLOC(h->l_term, B * z.e_term * E);
+    ALLOC(h->l_out, B * N * z.e_out * E);
+    ALLOC(h->l_outn, B * z.e_term * E);
+    ALLOC(h->l_xuy, B * (N + 1) * z.e_xuy * E);
+    ALLOC(h->l_x0, B * n * E);
   } else {
     const int blk[G_NUM] = {n * n, n * m, n, n * n, m * m, m * n, n, m, m * n, m, n * n, n,
                             n * n, m * m, m * n, n, m, n, m, n};
@@ -456,7 +552,8 @@ void altro_hip_batch_destroy(altro_hip_batch* h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   void* ptrs[] = {h->x0, h->delta_V, h->status, h->m_in, h->m_term, h->m_out, h->m_outn, h->m_xuy,
-                  h->m_qblk, h->m_trash, h->g_off, h->g_nx, h->g_nu, h->stage};
+                  h->m_qblk, h->m_trash, h->g_off, h->g_nx, h->g_nu, h->stage,
+                  h->l_in, h->l_term, h->l_out, h->l_outn, h->l_xuy, h->l_x0};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (int a = 0; a < G_NUM; ++a) if (h->g_arr[a]) (void)hipFree(h->g_arr[a]);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -484,6 +581,17 @@ int altro_hip_set_dynamics(altro_hip_batch* h, const double* A, const double* B,
     if (!rc) rc = mfma16_pack_launch(h, MSEG_Z, dA.s, dB.s);
     if (!rc) rc = mfma16_pack_launch(h, MSEG_F, df.s, SrcArr{nullptr, 0, 0});
     if (!rc) HIP_TRY(hipStreamSynchronize(h->stream));
+  } else if (h->plan == ALTRO_HIP_PLAN_LANE) {
+    const LaneSizes z = lane_sizes(n, m);
+    const int nkh = kz ? 1 : N;
+    auto pk = [&](const double* src, int len, int off) -> int {
+      return h->dtype == ALTRO_HIP_F64
+                 ? lane_pack<double>(h, (double*)h->l_in, z.e_in, src, len, off, 0, N, 0, nkh, kz, bz)
+                 : lane_pack<float>(h, (float*)h->l_in, z.e_in, src, len, off, 0, N, 0, nkh, kz, bz);
+    };
+    rc = pk(A, n * n, 0);
+    if (!rc) rc = pk(B, n * m, n * n);
+    if (!rc) rc = pk(f, n, n * n + n * m);
   } else if (h->dtype == ALTRO_HIP_F64) {
     rc = generic_set<double>(h, G_A, A, n * n, N, kz, bz);
     if (!rc) rc = generic_set<double>(h, G_B, B, n * m, N, kz, bz);
@@ -532,6 +640,25 @@ int altro_hip_set_cost(altro_hip_batch* h, const double* Q, const double* R, con
     if (!rc) rc = mfma16_pack_launch(h, MSEG_QR, dq.s, dr.s);
     if (!rc) rc = mfma16_pack_launch(h, MSEG_TERM_q, tq, none);
     if (!rc) HIP_TRY(hipStreamSynchronize(h->stream));
+  } else if (h->plan == ALTRO_HIP_PLAN_LANE) {
+    const LaneSizes z = lane_sizes(n, m);
+    const int oQ = n * n + n * m + n, oR = oQ + n * n, oH = oR + m * m, oq = oH + m * n, or_ = oq + n;
+    auto pk = [&](void* dst, int E, const double* src, int len, int off, int diag, int nk, int k_src0,
+                  int nk_host, int src_off = 0) -> int {
+      return h->dtype == ALTRO_HIP_F64
+                 ? lane_pack<double>(h, (double*)dst, E, src, len, off, diag, nk, k_src0, nk_host, kz, bz, src_off)
+                 : lane_pack<float>(h, (float*)dst, E, src, len, off, diag, nk, k_src0, nk_host, kz, bz, src_off);
+    };
+    // terminal source knot point: index N, or block 1 of the broadcast pair (ks == 0 there, so the
+    // device source pointer is shifted by one block instead)
+    const int kt = kz ? 0 : N;
+    rc = pk(h->l_in, z.e_in, Q, d.Q(is_diag), oQ, is_diag ? n : 0, N, 0, nkQ);
+    if (!rc) rc = pk(h->l_in, z.e_in, R, d.R(is_diag), oR, is_diag ? m : 0, N, 0, nkR);
+    if (!rc) rc = pk(h->l_in, z.e_in, is_diag ? nullptr : H, d.H(), oH, 0, N, 0, nkR);
+    if (!rc) rc = pk(h->l_in, z.e_in, q, n, oq, 0, N, 0, nkQ);
+    if (!rc) rc = pk(h->l_in, z.e_in, r, m, or_, 0, N, 0, nkR);
+    if (!rc) rc = pk(h->l_term, z.e_term, Q, d.Q(is_diag), 0, is_diag ? n : 0, 1, kt, nkQ, kz ? d.Q(is_diag) : 0);
+    if (!rc) rc = pk(h->l_term, z.e_term, q, n, n * n, 0, 1, kt, nkQ, kz ? n : 0);
   } else {
     auto set = [&](int arr, const double* src, int blk, int nk, int k0, int nk_host, int src_off = 0) -> int {
       if (!src) {
@@ -588,6 +715,10 @@ int altro_hip_set_initial_state(altro_hip_batch* h, const double* x0, int bz) {
     return 0;
   };
   rc = upload_chunks(h, x0, h->n, 1, 1, bz, -1, 0, consume);
+  if (!rc && h->plan == ALTRO_HIP_PLAN_LANE)
+    rc = h->dtype == ALTRO_HIP_F64
+             ? lane_pack<double>(h, (double*)h->l_x0, h->n, x0, h->n, 0, 0, 1, 0, 1, 1, bz)
+             : lane_pack<float>(h, (float*)h->l_x0, h->n, x0, h->n, 0, 0, 1, 0, 1, 1, bz);
   if (!rc) h->x0_set = true;
   return rc;
 }
@@ -632,6 +763,7 @@ int altro_hip_synchronize(altro_hip_batch* h) {
     if (!(NEED_FWD ? h->forward_done : h->backward_done))                                       \
       return fail(ALTRO_HIP_ERR_NOT_SET, "nothing computed yet for get_" #NAME);                \
     if (h->plan == ALTRO_HIP_PLAN_MFMA16) return mfma16_get(h, MWHAT, dst, BLOCK, NK);          \
+    if (h->plan == ALTRO_HIP_PLAN_LANE) return lane_get_any(h, MWHAT, dst);                     \
     return h->dtype == ALTRO_HIP_F64 ? generic_get<double>(h, GARR, dst, BLOCK, NK)            \
                                      : generic_get<float>(h, GARR, dst, BLOCK, NK);            \
   }
@@ -676,6 +808,7 @@ int altro_hip_get_qblocks(altro_hip_batch* h, double* dst) {
   const int n = h->n, m = h->m, N = h->N;
   const int per = n * n + m * m + m * n + n + m;
   if (h->plan == ALTRO_HIP_PLAN_MFMA16) return mfma16_get(h, MGET_QBLK, dst, per, N);
+  if (h->plan == ALTRO_HIP_PLAN_LANE) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "plan LANE does not store the Q-blocks");
   // generic: five separate reference-layout arrays -> interleave on the host
   std::vector<double> tmp((size_t)h->batch * N * n * n);
   const int arrs[5] = {G_Qxx, G_Quu, G_Qux, G_Qx, G_Qu};
@@ -741,9 +874,10 @@ int altro_hip_profile_get(altro_hip_batch* h, int slot, int* launches, double* t
   if (launches) *launches = h->prof_launches[slot];
   if (total_ms) *total_ms = h->prof_ms[slot];
   if (kernel_name) {
-    static const char* names[2][2] = {{"generic_backward_kernel", "generic_forward_kernel"},
-                                      {"mfma16_backward_kernel", "mfma16_forward_kernel"}};
-    *kernel_name = names[h->plan == ALTRO_HIP_PLAN_MFMA16 ? 1 : 0][slot];
+    static const char* names[3][2] = {{"generic_backward_kernel", "generic_forward_kernel"},
+                                      {"mfma16_backward_kernel", "mfma16_forward_kernel"},
+                                      {"lane_backward_kernel", "lane_forward_kernel"}};
+    *kernel_name = names[h->plan == ALTRO_HIP_PLAN_MFMA16 ? 1 : (h->plan == ALTRO_HIP_PLAN_LANE ? 2 : 0)][slot];
   }
   return 0;
 }

@@ -57,8 +57,9 @@ template <int CTRL>
 __device__ __forceinline__ double dpp_mov_f64(double v) {
   union { double d; int i[2]; } in, out;
   in.d = v;
-  out.i[0] = __builtin_amdgcn_update_dpp(0, in.i[0], CTRL, 0xf, 0xf, false);
-  out.i[1] = __builtin_amdgcn_update_dpp(0, in.i[1], CTRL, 0xf, 0xf, false);
+  // old == src: every lane is written by these permutations, so no zero-initialising v_mov is needed
+  out.i[0] = __builtin_amdgcn_update_dpp(in.i[0], in.i[0], CTRL, 0xf, 0xf, false);
+  out.i[1] = __builtin_amdgcn_update_dpp(in.i[1], in.i[1], CTRL, 0xf, 0xf, false);
   return out.d;
 }
 __device__ __forceinline__ double row16_allreduce(double v) {
@@ -357,11 +358,15 @@ __global__ __launch_bounds__(64) void mfma16_forward_kernel(Mfma16Args a) {
   const double* in = a.in + (size_t)b * a.in_bs;
   const double* out = a.out + (size_t)b * a.out_bs;
   double* xuy = a.xuy + (size_t)b * a.xuy_bs;
+  // Every store below is executed by ALL lanes (lanes that hold a replica write the same value to the
+  // same address): no exec-masked VMEM/LDS in the loop, so hipcc can count vmcnt exactly.
+  const int xu_off = (j < 12) ? j : 24 + (j - 12);   // x_k[j] | u_k[j-12] inside a 28-double record
 
   // x~ = [x; 1] in column layout
   double xc = (j < 12) ? a.x0[(size_t)b * 12 + j] : ((j == 12) ? 1.0 : 0.0);
   Mfma16FwdKnot cur, nxt;
   mfma16_load_fwd(cur, in, out, lane, j, g);
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see the backward kernel's pre-loop drain
   for (int k = 0; k < N; ++k) {
     {
       const int kn = (k + 1 < N) ? k + 1 : k;   // last step re-reads itself: harmless, branch-free
@@ -376,42 +381,39 @@ __global__ __launch_bounds__(64) void mfma16_forward_kernel(Mfma16Args a) {
     for (int r = 0; r < 3; ++r) yr[r] = row16_allreduce(cur.p[r] * xc);
     // z = [x; u] in column layout: u[a] lives in row group a -> hop through LDS
     __syncthreads();
-    if (j == 0) S[12 + g] = ug;
+    S[12 + g] = ug;
     __syncthreads();
-    const double zc = (j < 12) ? xc : S[j];
+    const double su = S[(j < 12) ? 12 : j];
+    const double zc = (j < 12) ? xc : su;
     // x+[g+4c] = f + (Z z)[g+4c]
     double xr[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) xr[c] = row16_allreduce(cur.z[c] * zc) + cur.f[c];
-    // stores: x_k, u_k from the column layout (contiguous), y_k from the row layout
-    if (g == 0) {
-      if (j < 12) o[j] = xc; else o[24 + (j - 12)] = zc;
-    }
-    if (j == 0) {
-#pragma unroll
-      for (int r = 0; r < 3; ++r) o[12 + g + 4 * r] = yr[r];
-    }
     // row layout -> column layout for x+
-    if (j == 0) {
-#pragma unroll
-      for (int c = 0; c < 3; ++c) S[g + 4 * c] = xr[c];
-    }
     __syncthreads();
-    xc = (j < 12) ? S[j] : ((j == 12) ? 1.0 : 0.0);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) S[g + 4 * c] = xr[c];
+    __syncthreads();
+    const double sx = S[(j < 12) ? j : 0];
     cur = nxt;
+    // stores: x_k | u_k from the column layout, y_k from the row layout
+    o[xu_off] = zc;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) o[12 + g + 4 * r] = yr[r];
+    xc = (j < 12) ? sx : ((j == 12) ? 1.0 : 0.0);
   }
   // terminal knot point: x_N, y_N = P_N x_N + p_N (tvlqr.cpp:238-246)
   {
     const double* on = a.outn + (size_t)b * MF_TERM;
     double* o = xuy + (size_t)N * a.xuy_ks;
+    const int jc = (j <= 12) ? j : 12;
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-      double pv = (j <= 12) ? on[(g + 4 * r) * 13 + j] : 0.0;
-      double y = row16_allreduce(pv * xc);
-      if (j == 0) o[12 + g + 4 * r] = y;
+      const double pl = on[(g + 4 * r) * 13 + jc];
+      const double pv = (j <= 12) ? pl : 0.0;
+      o[12 + g + 4 * r] = row16_allreduce(pv * xc);
     }
-    if (g == 0 && j < 12) o[j] = xc;
-    if (g == 0 && j >= 12) o[24 + (j - 12)] = 0.0;
+    o[xu_off] = (j < 12) ? xc : 0.0;
   }
 }
 

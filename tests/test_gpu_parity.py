@@ -250,3 +250,94 @@ def test_full_size_c1_properties():
     res_N = lx[:, N] - y[:, N]
     scale = max(1.0, np.abs(y).max())
     assert max(np.abs(res_x).max(), np.abs(res_u).max(), np.abs(res_N).max()) / scale < 1e-10
+
+
+# ---------------------------------------------------------------- plan LANE (batch structure-of-arrays)
+@pytest.mark.parametrize("is_diag", [True, False])
+def test_lane_tvlqr_kat(kats, is_diag):
+    kat = kats["tvlqr_double_integrator"]
+    pr = problems.tvlqr_kat_problem(kat, float_h=False)
+    out = run_hip(pr, altro_amd.PLAN_LANE, is_diag=is_diag)
+    assert out["bt"].plan == altro_amd.PLAN_LANE
+    K0 = out["K"][0, 0].reshape(4, 2).T
+    assert np.linalg.norm(K0 - np.array(kat["K0_rowmajor_2x4"]).reshape(2, 4)) < 1e-12
+    assert np.abs(out["x"][0, -1] - np.array(kat["xN"])).max() < 1e-11
+    ref = run_oracle(pr, is_diag=is_diag)
+    for k in ("K", "d", "P", "p", "x", "u", "y"):
+        assert np.array_equal(out[k], ref[k]), k
+
+
+@pytest.mark.parametrize("n,m,N,batch", [(4, 2, 50, 200), (2, 1, 100, 131), (6, 3, 12, 70), (3, 1, 7, 64)])
+def test_lane_random_bit_exact(n, m, N, batch):
+    """Same operation order as the oracle, no FMA fusion: identical bits; batch not a multiple of 64."""
+    pr = problems.random_ltv(batch, N, n, m)
+    out = run_hip(pr, altro_amd.PLAN_AUTO)
+    assert out["bt"].plan == altro_amd.PLAN_LANE
+    ref = run_oracle(pr)
+    assert (out["status"] == -1).all()
+    for k in ("K", "d", "P", "p", "x", "u", "y"):
+        assert np.array_equal(out[k], ref[k]), k
+    assert np.array_equal(out["delta_V"], ref["dV"])
+
+
+def test_lane_failure_and_broadcast():
+    pr = problems.random_ltv(70, 10, 4, 2)
+    pr["R"][13, 4] = -50.0 * np.eye(2).flatten()
+    out = run_hip(pr, altro_amd.PLAN_LANE)
+    ref = run_oracle_each(pr)
+    assert out["status"].tolist() == ref["status"].tolist()
+    assert out["status"][13] == 4 and (np.delete(out["status"], 13) == -1).all()
+    ok = out["status"] == -1
+    assert np.array_equal(out["K"][ok], ref["K"][ok])
+    assert np.array_equal(out["K"][13, 4:], ref["K"][13, 4:])
+    assert np.array_equal(out["delta_V"][13], ref["dV"][13])
+    # broadcast (shared) inputs
+    kat_A, kat_B = problems.di_blocks(2, 0.05)
+    N, n, m, B = 30, 4, 2, 100
+    cm = lambda M: np.asarray(M).flatten(order="F")
+    bt = altro_amd.Batch(N, n, m, B, plan=altro_amd.PLAN_LANE)
+    bt.set_dynamics(cm(kat_A)[None, None], cm(kat_B)[None, None], None, k_stride_zero=True, batch_stride_zero=True)
+    Qd2 = np.stack([np.full(n, 1.0), np.full(n, 50.0)]); q2 = np.stack([np.full(n, 0.1), np.full(n, -0.2)])
+    bt.set_cost(Qd2, np.full((1, m), 0.01), None, q2, np.full((1, m), 0.03), is_diag=True,
+                k_stride_zero=True, batch_stride_zero=True)
+    x0 = 2 * problems.uniform01((B, n), 33) - 1
+    bt.set_initial_state(x0)
+    bt.sweep()
+    full = dict(N=N, n=n, m=m, A=np.tile(cm(kat_A), (B, N, 1)), B=np.tile(cm(kat_B), (B, N, 1)),
+                f=np.zeros((B, N, n)),
+                Qdiag=np.concatenate([np.tile(Qd2[0], (B, N, 1)), np.tile(Qd2[1], (B, 1, 1))], axis=1),
+                Rdiag=np.full((B, N, m), 0.01),
+                q=np.concatenate([np.tile(q2[0], (B, N, 1)), np.tile(q2[1], (B, 1, 1))], axis=1),
+                r=np.full((B, N, m), 0.03), x0=x0)
+    ref = run_oracle(full, is_diag=True)
+    for k in ("K", "d", "P", "p", "x", "u", "y"):
+        assert np.array_equal(bt.get(k), ref[k]), k
+
+
+def test_lane_f32():
+    pr = problems.random_ltv(100, 20, 4, 2)
+    bt = altro_amd.Batch(20, 4, 2, 100, dtype=altro_amd.F32)
+    assert bt.plan == altro_amd.PLAN_LANE
+    bt.set_dynamics(pr["A"], pr["B"], pr["f"]); bt.set_cost(pr["Q"], pr["R"], pr["H"], pr["q"], pr["r"])
+    bt.set_initial_state(pr["x0"]); bt.sweep()
+    ref = run_oracle(pr)
+    assert relerr(bt.get("K"), ref["K"]) < 1e-4 and relerr(bt.get("x"), ref["x"]) < 1e-4
+
+
+@pytest.mark.parametrize("name,n,m,N,batch", [("C2 pendulum-sized", 2, 1, 100, 8192), ("C3 bicycle-sized", 4, 2, 50, 65536)])
+def test_lane_full_size_shapes(name, n, m, N, batch):
+    """BASELINE.json configs[2], [3] shapes at full batch on the TVLQR pair (random LTV data):
+    every problem succeeds, a seeded sample matches the oracle bit for bit."""
+    sample = [0, 1, batch // 3, batch - 1]
+    small = problems.random_ltv(len(sample), N, n, m)
+    tile = lambda a: np.ascontiguousarray(np.broadcast_to(a[None, 0], (batch,) + a.shape[1:]))
+    pr = {k: (tile(v) if isinstance(v, np.ndarray) else v) for k, v in small.items()}
+    for i, b in enumerate(sample):            # plant the distinct sample problems
+        for k in ("A", "B", "f", "Q", "R", "H", "q", "r", "x0"):
+            pr[k][b] = small[k][i]
+    out = run_hip(pr, altro_amd.PLAN_AUTO)
+    assert out["bt"].plan == altro_amd.PLAN_LANE
+    assert (out["status"] == -1).all()
+    ref = run_oracle(small)
+    for k in ("K", "d", "P", "p", "x", "u", "y"):
+        assert np.array_equal(out[k][sample], ref[k]), k
