@@ -28,7 +28,26 @@ C_ABI_SYMBOLS = [
     "altro_hip_get_delta_V", "altro_hip_get_status", "altro_hip_get_qblocks",
     "altro_hip_stats_reduce", "altro_hip_profile_enable", "altro_hip_profile_reset",
     "altro_hip_profile_get", "altro_hip_algorithmic_bytes",
+    "altro_hip_set_model", "altro_hip_set_tracking_cost", "altro_hip_set_input_guess",
+    "altro_hip_open_loop_rollout", "altro_hip_accept", "altro_hip_expand", "altro_hip_merit",
+    "altro_hip_stationarity", "altro_hip_get_nominal", "altro_hip_get_expansion",
+    "altro_hip_default_solve_options", "altro_hip_ilqr_solve", "altro_hip_last_solve_counts",
+    "altro_hip_linesearch_host",
 ]
+
+MODEL_LINEAR, MODEL_DOUBLE_INTEGRATOR, MODEL_PENDULUM, MODEL_BICYCLE = 0, 1, 2, 3
+MERIT_FN = C.CFUNCTYPE(None, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p)
+
+
+class SolveOptions(C.Structure):
+    _fields_ = [("iterations_max", C.c_int), ("tol_stationarity", C.c_double),
+                ("tol_primal_feasibility", C.c_double), ("tol_meritfun_gradient", C.c_double),
+                ("use_backtracking_linesearch", C.c_int)]
+
+
+class SolveResult(C.Structure):
+    _fields_ = [("status", C.c_int), ("iterations", C.c_int), ("stationarity", C.c_double),
+                ("final_alpha", C.c_double), ("final_phi", C.c_double)]
 
 
 class AltroHipError(RuntimeError):
@@ -76,6 +95,22 @@ def lib():
         L.altro_hip_profile_get.argtypes = [vp, i, C.POINTER(i), C.POINTER(d), C.POINTER(C.c_char_p)]
         L.altro_hip_algorithmic_bytes.argtypes = [vp, i]
         L.altro_hip_algorithmic_bytes.restype = d
+        L.altro_hip_set_model.argtypes = [vp, i, C.c_float, i, d, d]
+        L.altro_hip_set_tracking_cost.argtypes = [vp, vp, vp, vp, vp, i, i]
+        L.altro_hip_set_input_guess.argtypes = [vp, vp, i, i]
+        for fn in ("open_loop_rollout", "accept", "expand"):
+            getattr(L, "altro_hip_" + fn).argtypes = [vp]
+        L.altro_hip_merit.argtypes = [vp, vp, i, i, vp, vp]
+        L.altro_hip_stationarity.argtypes = [vp, vp]
+        L.altro_hip_get_nominal.argtypes = [vp, vp, vp]
+        L.altro_hip_get_expansion.argtypes = [vp, vp, vp, vp, vp]
+        L.altro_hip_default_solve_options.argtypes = [C.POINTER(SolveOptions)]
+        L.altro_hip_default_solve_options.restype = None
+        L.altro_hip_ilqr_solve.argtypes = [vp, C.POINTER(SolveOptions), vp]
+        L.altro_hip_last_solve_counts.argtypes = [vp, C.POINTER(i), C.POINTER(i)]
+        L.altro_hip_linesearch_host.argtypes = [MERIT_FN, vp, d, d, d, i, i, d, d, C.POINTER(i), C.POINTER(i),
+                                                C.POINTER(d), C.POINTER(d)]
+        L.altro_hip_linesearch_host.restype = d
         L.altro_hip_selftest_mfma_f64.argtypes = [i]
         L.altro_hip_selftest_mfma_f64.restype = d
         _lib = L
@@ -168,3 +203,85 @@ class Batch:
 
     def algorithmic_bytes(self, slot):
         return self.L.altro_hip_algorithmic_bytes(self.h, slot)
+
+    # ---- the iLQR loop around the sweep (device models; plan LANE shapes) ----
+    def set_model(self, model, timestep, frame=0, length=2.7, lr=1.5):
+        _check(self.L.altro_hip_set_model(self.h, model, float(timestep), frame, length, lr))
+
+    def set_tracking_cost(self, Qd, Rd, xref, uref, k_stride_zero=False, batch_stride_zero=False):
+        keep = [_in(v) for v in (Qd, Rd, xref, uref)]
+        _check(self.L.altro_hip_set_tracking_cost(self.h, *[k[1] for k in keep], int(k_stride_zero),
+                                                  int(batch_stride_zero)))
+
+    def set_input_guess(self, u, k_stride_zero=False, batch_stride_zero=False):
+        a, pa = _in(u)
+        _check(self.L.altro_hip_set_input_guess(self.h, pa, int(k_stride_zero), int(batch_stride_zero)))
+
+    def open_loop_rollout(self):
+        _check(self.L.altro_hip_open_loop_rollout(self.h))
+
+    def accept(self):
+        _check(self.L.altro_hip_accept(self.h))
+
+    def expand(self):
+        _check(self.L.altro_hip_expand(self.h))
+
+    def merit(self, alpha, derivative=True):
+        phi = np.zeros(self.batch); dphi = np.zeros(self.batch)
+        if np.isscalar(alpha):
+            a = np.array([float(alpha)]); uniform = 1
+        else:
+            a = np.ascontiguousarray(alpha, dtype=np.float64); uniform = 0
+        _check(self.L.altro_hip_merit(self.h, a.ctypes.data_as(C.c_void_p), uniform, int(derivative),
+                                      phi.ctypes.data_as(C.c_void_p), dphi.ctypes.data_as(C.c_void_p)))
+        return phi, (dphi if derivative else None)
+
+    def stationarity(self):
+        out = np.zeros(self.batch)
+        _check(self.L.altro_hip_stationarity(self.h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def get_nominal(self):
+        x = np.zeros((self.batch, self.N + 1, self.n)); u = np.zeros((self.batch, self.N, self.m))
+        _check(self.L.altro_hip_get_nominal(self.h, x.ctypes.data_as(C.c_void_p), u.ctypes.data_as(C.c_void_p)))
+        return x, u
+
+    def get_expansion(self):
+        B, N, n, m = self.batch, self.N, self.n, self.m
+        A = np.zeros((B, N, n * n)); Bm = np.zeros((B, N, n * m)); lx = np.zeros((B, N + 1, n)); lu = np.zeros((B, N, m))
+        _check(self.L.altro_hip_get_expansion(self.h, *[v.ctypes.data_as(C.c_void_p) for v in (A, Bm, lx, lu)]))
+        return A, Bm, lx, lu
+
+    def ilqr_solve(self, iterations_max=200, tol_stationarity=1e-4, tol_meritfun_gradient=1e-8,
+                   use_backtracking=False):
+        o = SolveOptions()
+        self.L.altro_hip_default_solve_options(C.byref(o))
+        o.iterations_max, o.tol_stationarity = iterations_max, tol_stationarity
+        o.tol_meritfun_gradient, o.use_backtracking_linesearch = tol_meritfun_gradient, int(use_backtracking)
+        res = (SolveResult * self.batch)()
+        _check(self.L.altro_hip_ilqr_solve(self.h, C.byref(o), res))
+        sw, ml = C.c_int(), C.c_int()
+        self.L.altro_hip_last_solve_counts(self.h, C.byref(sw), C.byref(ml))
+        return dict(status=np.array([r.status for r in res]), iterations=np.array([r.iterations for r in res]),
+                    stationarity=np.array([r.stationarity for r in res]),
+                    alpha=np.array([r.final_alpha for r in res]), phi=np.array([r.final_phi for r in res]),
+                    sweeps=sw.value, merit_launches=ml.value)
+
+
+def linesearch_host(fn, alpha0, phi0, dphi0, try_cubic_first=False, use_backtracking=False, c1=1e-4, c2=0.9):
+    """Drives the batched solver's line-search state machine on the host with a Python merit callback."""
+    L = lib()
+    evals = []
+
+    def cb(a, phi, dphi, ctx):
+        p, dp = fn(a)
+        evals.append(a)
+        phi[0] = p
+        if dphi:
+            dphi[0] = dp
+
+    st, it, ph, dph = C.c_int(), C.c_int(), C.c_double(), C.c_double()
+    alpha = L.altro_hip_linesearch_host(MERIT_FN(cb), None, alpha0, phi0, dphi0, int(try_cubic_first),
+                                        int(use_backtracking), c1, c2, C.byref(st), C.byref(it),
+                                        C.byref(ph), C.byref(dph))
+    return dict(alpha=alpha, status=st.value, iters=it.value, phi=ph.value, dphi=dph.value, evals=evals)

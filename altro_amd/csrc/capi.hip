@@ -17,6 +17,8 @@
 #include "kernels/pack.hip"
 #include "kernels/tvlqr_generic.hip"
 #include "kernels/tvlqr_lane.hip"
+#include "kernels/ilqr_lane.hip"
+#include "linesearch_sm.h"
 #include "kernels/tvlqr_mfma16.hip"
 
 using namespace altro_hip;
@@ -72,6 +74,13 @@ struct altro_hip_batch {
   // plan LANE: batch structure-of-arrays ([k][element][batch])
   void *l_in = nullptr, *l_term = nullptr, *l_out = nullptr, *l_outn = nullptr, *l_xuy = nullptr,
        *l_x0 = nullptr;
+  // iLQR loop state (plan LANE): nominal trajectory, cost parameters, per-problem control blocks
+  void *l_nom = nullptr, *l_cost = nullptr;
+  IlqrProb* i_prob = nullptr;
+  double *i_alpha = nullptr, *i_phi = nullptr, *i_dphi = nullptr;
+  int *i_active = nullptr, *i_counters = nullptr;
+  ModelParams model{MODEL_LINEAR, 0.0f, 0, 2.7, 1.5};
+  bool model_set = false, lqr_cost_set = false, guess_set = false;
   // staging for host <-> device conversion (grown lazily, never inside the hot path)
   void* stage = nullptr;
   size_t stage_bytes = 0;
@@ -79,6 +88,7 @@ struct altro_hip_batch {
   // profiling
   bool prof = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int last_sweeps = 0, last_merit_launches = 0;
   int prof_launches[2] = {0, 0};
   double prof_ms[2] = {0, 0};
 };
@@ -93,6 +103,13 @@ int dmalloc(altro_hip_batch* h, void** p, size_t bytes) {
                 hipGetErrorString(e));
   }
   h->device_bytes += bytes;
+  return 0;
+}
+
+int check(altro_hip_batch* h) {
+  if (!h) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "null handle");
+  hipError_t e = hipSetDevice(h->device);
+  if (e != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "hipSetDevice(%d): %s", h->device, hipGetErrorString(e));
   return 0;
 }
 
@@ -366,6 +383,72 @@ int lane_get_any(altro_hip_batch* h, int what, double* dst) {
                                    : lane_get<float>(h, dst, src, term, E, off, off_t, len, nk, nk_main);
 }
 
+
+// ---- iLQR loop (plan LANE) ---------------------------------------------------------------------------
+#define ILQR_MODELS(X)                                                                      \
+  X(MODEL_PENDULUM, 2, 1) X(MODEL_BICYCLE, 4, 2) X(MODEL_DOUBLE_INTEGRATOR, 2, 1)           \
+  X(MODEL_DOUBLE_INTEGRATOR, 4, 2) X(MODEL_DOUBLE_INTEGRATOR, 6, 3)
+bool ilqr_supported(int kind, int n, int m) {
+#define X(K_, N_, M_) if (kind == K_ && n == N_ && m == M_) return true;
+  ILQR_MODELS(X)
+#undef X
+  return false;
+}
+enum IlqrKernel { IK_ROLLOUT, IK_ACCEPT, IK_EXPAND, IK_MERIT, IK_STATIONARITY };
+
+template <typename T>
+IlqrArgs<T> ilqr_args(altro_hip_batch* h, bool use_alpha, bool use_active, int want_deriv, double alpha_const) {
+  IlqrArgs<T> a;
+  a.in = (T*)h->l_in; a.term = (T*)h->l_term; a.out = (const T*)h->l_out; a.outn = (const T*)h->l_outn;
+  a.nom = (T*)h->l_nom; a.cand = (T*)h->l_xuy; a.cost = (const T*)h->l_cost; a.x0 = (const T*)h->l_x0;
+  a.alpha = use_alpha ? h->i_alpha : nullptr;
+  a.active = use_active ? h->i_active : nullptr;
+  a.phi = h->i_phi; a.dphi = h->i_dphi; a.prob = h->i_prob;
+  a.mp = h->model; a.N = h->N; a.batch = h->batch; a.want_derivative = want_deriv; a.alpha_const = alpha_const;
+  return a;
+}
+
+template <typename T>
+int ilqr_launch(altro_hip_batch* h, int which, IlqrArgs<T> a) {
+  const dim3 lanes((h->batch + 63) / 64), b64(64);
+  const int64_t total = (int64_t)h->batch * (h->N + 1);
+  const dim3 flat(grid_for(total)), b256(256);
+  bool done = false;
+#define X(K_, N_, M_)                                                                                    \
+  if (!done && h->model.kind == K_ && h->n == N_ && h->m == M_) {                                        \
+    done = true;                                                                                         \
+    switch (which) {                                                                                     \
+      case IK_ROLLOUT: hipLaunchKernelGGL((ilqr_rollout_kernel<K_, N_, M_, T>), lanes, b64, 0, h->stream, a); break; \
+      case IK_ACCEPT: hipLaunchKernelGGL((ilqr_accept_kernel<N_, M_, T>), flat, b256, 0, h->stream, a); break;       \
+      case IK_EXPAND: hipLaunchKernelGGL((ilqr_expand_kernel<K_, N_, M_, T>), flat, b256, 0, h->stream, a); break;   \
+      case IK_MERIT: hipLaunchKernelGGL((ilqr_merit_kernel<K_, N_, M_, T>), lanes, b64, 0, h->stream, a); break;     \
+      default: hipLaunchKernelGGL((ilqr_stationarity_kernel<N_, M_, T>), lanes, b64, 0, h->stream, a); break;        \
+    }                                                                                                    \
+  }
+  ILQR_MODELS(X)
+#undef X
+  if (!done) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "no device model for (kind, n, m) = (%d, %d, %d)", h->model.kind, h->n, h->m);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "iLQR kernel launch: %s", hipGetErrorString(e));
+  return 0;
+}
+int ilqr_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int want_deriv, double alpha_const) {
+  return h->dtype == ALTRO_HIP_F64
+             ? ilqr_launch<double>(h, which, ilqr_args<double>(h, use_alpha, use_active, want_deriv, alpha_const))
+             : ilqr_launch<float>(h, which, ilqr_args<float>(h, use_alpha, use_active, want_deriv, alpha_const));
+}
+int ilqr_check(altro_hip_batch* h, bool need_guess) {
+  int rc = check(h);
+  if (rc) return rc;
+  if (h->plan != ALTRO_HIP_PLAN_LANE)
+    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "the device iLQR loop is implemented for plan LANE shapes");
+  if (!h->model_set) return fail(ALTRO_HIP_ERR_NOT_SET, "altro_hip_set_model has not been called");
+  if (!h->lqr_cost_set) return fail(ALTRO_HIP_ERR_NOT_SET, "altro_hip_set_tracking_cost has not been called");
+  if (!h->x0_set) return fail(ALTRO_HIP_ERR_NOT_SET, "altro_hip_set_initial_state has not been called");
+  if (need_guess && !h->guess_set) return fail(ALTRO_HIP_ERR_NOT_SET, "altro_hip_set_input_guess has not been called");
+  return 0;
+}
+
 int launch_backward(altro_hip_batch* h, double reg) {
   ProfScope ps(h, 0);
   if (h->plan == ALTRO_HIP_PLAN_MFMA16) {
@@ -415,13 +498,6 @@ int launch_forward(altro_hip_batch* h) {
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "forward launch: %s", hipGetErrorString(e));
-  return 0;
-}
-
-int check(altro_hip_batch* h) {
-  if (!h) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "null handle");
-  hipError_t e = hipSetDevice(h->device);
-  if (e != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "hipSetDevice(%d): %s", h->device, hipGetErrorString(e));
   return 0;
 }
 
@@ -512,6 +588,16 @@ int altro_hip_batch_create(altro_hip_batch** out, int N, int n, int m, int batch
     ALLOC(h->l_outn, B * z.e_term * E);
     ALLOC(h->l_xuy, B * (N + 1) * z.e_xuy * E);
     ALLOC(h->l_x0, B * n * E);
+    ALLOC(h->l_nom, B * (N + 1) * (n + m) * E);
+    ALLOC(h->l_cost, B * (N + 1) * (2 * n + 2 * m + 1) * E);
+    ALLOC(h->i_prob, B * sizeof(IlqrProb));
+    ALLOC(h->i_alpha, B * 8);
+    ALLOC(h->i_phi, B * 8);
+    ALLOC(h->i_dphi, B * 8);
+    ALLOC(h->i_active, B * sizeof(int));
+    ALLOC(h->i_counters, 4 * sizeof(int));
+    if (!rc && hipMemset(h->l_xuy, 0, B * (N + 1) * z.e_xuy * E) != hipSuccess) rc = fail(ALTRO_HIP_ERR_HIP, "memset failed");
+    if (!rc && hipMemset(h->l_cost, 0, B * (N + 1) * (2 * n + 2 * m + 1) * E) != hipSuccess) rc = fail(ALTRO_HIP_ERR_HIP, "memset failed");
   } else {
     const int blk[G_NUM] = {n * n, n * m, n, n * n, m * m, m * n, n, m, m * n, m, n * n, n,
                             n * n, m * m, m * n, n, m, n, m, n};
@@ -553,7 +639,8 @@ void altro_hip_batch_destroy(altro_hip_batch* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   void* ptrs[] = {h->x0, h->delta_V, h->status, h->m_in, h->m_term, h->m_out, h->m_outn, h->m_xuy,
                   h->m_qblk, h->m_trash, h->g_off, h->g_nx, h->g_nu, h->stage,
-                  h->l_in, h->l_term, h->l_out, h->l_outn, h->l_xuy, h->l_x0};
+                  h->l_in, h->l_term, h->l_out, h->l_outn, h->l_xuy, h->l_x0,
+                  h->l_nom, h->l_cost, h->i_prob, h->i_alpha, h->i_phi, h->i_dphi, h->i_active, h->i_counters};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (int a = 0; a < G_NUM; ++a) if (h->g_arr[a]) (void)hipFree(h->g_arr[a]);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -889,6 +976,293 @@ double altro_hip_algorithmic_bytes(const altro_hip_batch* h, int slot) {
   const double bwd = 3 * n * n + 3 * n * m + m * m + 3 * n + 2 * m;
   const double fwd = 2 * n * n + 2 * n * m + 4 * n + 2 * m;
   return (slot == 0 ? bwd : fwd) * w * (double)h->N * (double)h->batch;
+}
+
+
+// ---- iLQR loop entry points -----------------------------------------------------------------------------
+int altro_hip_set_model(altro_hip_batch* h, int model, float timestep, int bicycle_frame,
+                        double bicycle_length, double bicycle_lr) {
+  int rc = check(h);
+  if (rc) return rc;
+  if (!(timestep > 0.0f)) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "time step must be positive (ErrorCodes::TimestepNotPositive)");
+  if (h->plan != ALTRO_HIP_PLAN_LANE || !ilqr_supported(model, h->n, h->m))
+    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "no device model %d for plan %d with (n, m) = (%d, %d)", model, h->plan, h->n, h->m);
+  h->model = ModelParams{model, timestep, bicycle_frame, bicycle_length > 0 ? bicycle_length : 2.7,
+                         bicycle_lr > 0 ? bicycle_lr : 1.5};
+  h->model_set = true;
+  return 0;
+}
+
+int altro_hip_set_tracking_cost(altro_hip_batch* h, const double* Qd, const double* Rd, const double* xref,
+                                const double* uref, int kz, int bz) {
+  // ALTROSolver::SetLQRCost (altro_solver.cpp:138-172): q = -Q xref, r = -R uref,
+  // c = 1/2 xref'Q xref (+ 1/2 uref'R uref for k < N) -> KnotPointData::SetDiagonalCost
+  int rc = check(h);
+  if (rc) return rc;
+  if (h->plan != ALTRO_HIP_PLAN_LANE) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "tracking cost needs plan LANE");
+  if (!Qd || !Rd || !xref || !uref) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "Qd, Rd, xref, uref are required");
+  const int n = h->n, m = h->m, N = h->N;
+  const int nb = bz ? 1 : h->batch, nkx = kz ? 2 : N + 1, nku = kz ? 1 : N;
+  const int E = 2 * n + 2 * m + 1;
+  // host-side arithmetic exactly as the reference's setter does it, then one upload per field
+  std::vector<double> q((size_t)nb * nkx * n), r((size_t)nb * nku * m), c((size_t)nb * nkx);
+  for (int b = 0; b < nb; ++b)
+    for (int k = 0; k < nkx; ++k) {
+      const double* Q_ = Qd + ((size_t)b * nkx + k) * n;
+      const double* x_ = xref + ((size_t)b * nkx + k) * n;
+      double cc = 0.0;
+      for (int i = 0; i < n; ++i) { q[((size_t)b * nkx + k) * n + i] = -(Q_[i] * x_[i]); cc += x_[i] * Q_[i] * x_[i]; }
+      cc *= 0.5;
+      const bool terminal = kz ? (k == 1) : (k == N);
+      if (!terminal) {
+        const int ku = kz ? 0 : k;
+        const double* R_ = Rd + ((size_t)b * nku + ku) * m;
+        const double* u_ = uref + ((size_t)b * nku + ku) * m;
+        double cu = 0.0;
+        for (int i = 0; i < m; ++i) cu += u_[i] * R_[i] * u_[i];
+        cc += 0.5 * cu;
+      }
+      c[(size_t)b * nkx + k] = cc;
+    }
+  for (int b = 0; b < nb; ++b)
+    for (int k = 0; k < nku; ++k)
+      for (int i = 0; i < m; ++i)
+        r[((size_t)b * nku + k) * m + i] = -(Rd[((size_t)b * nku + k) * m + i] * uref[((size_t)b * nku + k) * m + i]);
+  auto pk = [&](const double* src, int len, int off, int nk, int k_src0, int nk_host, int src_off) -> int {
+    return h->dtype == ALTRO_HIP_F64
+               ? lane_pack<double>(h, (double*)h->l_cost + (size_t)0, E, src, len, off, 0, nk, k_src0, nk_host, kz, bz, src_off)
+               : lane_pack<float>(h, (float*)h->l_cost + (size_t)0, E, src, len, off, 0, nk, k_src0, nk_host, kz, bz, src_off);
+  };
+  auto pk_term = [&](const double* src, int len, int off, int nk_host) -> int {   // record N of l_cost
+    const size_t base = (size_t)N * E * h->batch;
+    return h->dtype == ALTRO_HIP_F64
+               ? lane_pack<double>(h, (double*)h->l_cost + base, E, src, len, off, 0, 1, kz ? 0 : N, nk_host, kz, bz, kz ? len : 0)
+               : lane_pack<float>(h, (float*)h->l_cost + base, E, src, len, off, 0, 1, kz ? 0 : N, nk_host, kz, bz, kz ? len : 0);
+  };
+  rc = pk(Qd, n, 0, N, 0, nkx, 0);
+  if (!rc) rc = pk(Rd, m, n, N, 0, nku, 0);
+  if (!rc) rc = pk(q.data(), n, n + m, N, 0, nkx, 0);
+  if (!rc) rc = pk(r.data(), m, 2 * n + m, N, 0, nku, 0);
+  if (!rc) rc = pk(c.data(), 1, 2 * n + 2 * m, N, 0, nkx, 0);
+  if (!rc) rc = pk_term(Qd, n, 0, nkx);
+  if (!rc) rc = pk_term(q.data(), n, n + m, nkx);
+  if (!rc) rc = pk_term(c.data(), 1, 2 * n + 2 * m, nkx);
+  if (!rc) { h->lqr_cost_set = true; h->cost_set = true; h->dyn_set = true; h->is_diag = 0; h->has_f = 0; }
+  return rc;
+}
+
+int altro_hip_set_input_guess(altro_hip_batch* h, const double* u, int kz, int bz) {
+  // ALTROSolver::SetInput (altro_solver.cpp:242-251): writes the CANDIDATE inputs u_
+  int rc = check(h);
+  if (rc) return rc;
+  if (h->plan != ALTRO_HIP_PLAN_LANE) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "input guess needs plan LANE");
+  if (!u) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "u == NULL");
+  const int n = h->n, m = h->m, N = h->N;
+  rc = h->dtype == ALTRO_HIP_F64
+           ? lane_pack<double>(h, (double*)h->l_xuy, 2 * n + m, u, m, 2 * n, 0, N, 0, kz ? 1 : N, kz, bz)
+           : lane_pack<float>(h, (float*)h->l_xuy, 2 * n + m, u, m, 2 * n, 0, N, 0, kz ? 1 : N, kz, bz);
+  if (!rc) h->guess_set = true;
+  return rc;
+}
+
+int altro_hip_open_loop_rollout(altro_hip_batch* h) {
+  int rc = ilqr_check(h, true);
+  if (!rc) rc = ilqr_run(h, IK_ROLLOUT, false, false, 0, 0.0);
+  if (!rc) h->forward_done = true;
+  return rc;
+}
+int altro_hip_accept(altro_hip_batch* h) {
+  int rc = ilqr_check(h, false);
+  if (!rc) rc = ilqr_run(h, IK_ACCEPT, false, false, 0, 0.0);
+  return rc;
+}
+int altro_hip_expand(altro_hip_batch* h) {
+  int rc = ilqr_check(h, false);
+  if (!rc) rc = ilqr_run(h, IK_EXPAND, false, false, 0, 0.0);
+  return rc;
+}
+int altro_hip_merit(altro_hip_batch* h, const double* alpha, int alpha_is_uniform, int want_derivative,
+                    double* phi, double* dphi) {
+  int rc = ilqr_check(h, false);
+  if (rc) return rc;
+  if (!h->backward_done) return fail(ALTRO_HIP_ERR_NOT_SET, "backward must precede merit");
+  if (!alpha || !phi) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "alpha and phi are required");
+  if (!alpha_is_uniform)
+    HIP_TRY(hipMemcpyAsync(h->i_alpha, alpha, (size_t)h->batch * 8, hipMemcpyHostToDevice, h->stream));
+  rc = ilqr_run(h, IK_MERIT, !alpha_is_uniform, false, want_derivative, alpha[0]);
+  if (rc) return rc;
+  h->forward_done = true;
+  HIP_TRY(hipMemcpyAsync(phi, h->i_phi, (size_t)h->batch * 8, hipMemcpyDeviceToHost, h->stream));
+  if (want_derivative && dphi)
+    HIP_TRY(hipMemcpyAsync(dphi, h->i_dphi, (size_t)h->batch * 8, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return 0;
+}
+int altro_hip_stationarity(altro_hip_batch* h, double* out) {
+  int rc = ilqr_check(h, false);
+  if (rc) return rc;
+  rc = ilqr_run(h, IK_STATIONARITY, false, false, 0, 0.0);
+  if (rc) return rc;
+  std::vector<IlqrProb> pr(h->batch);
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(pr.data(), h->i_prob, pr.size() * sizeof(IlqrProb), hipMemcpyDeviceToHost));
+  for (int b = 0; b < h->batch; ++b) out[b] = pr[b].stationarity;
+  return 0;
+}
+
+int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts,
+                         altro_hip_solve_result* results) {
+  // SolverImpl::Solve (solver.cpp:414-511) for every problem of the batch at once.  The host only
+  // sequences launches and reads two counters per step; all per-problem decisions are on the device.
+  int rc = ilqr_check(h, true);
+  if (rc) return rc;
+  altro_hip_solve_options o;
+  if (opts) o = *opts;
+  else altro_hip_default_solve_options(&o);
+  IlqrLoopArgs la;
+  la.prob = h->i_prob; la.alpha = h->i_alpha; la.active = h->i_active; la.phi = h->i_phi; la.dphi = h->i_dphi;
+  la.counters = h->i_counters; la.batch = h->batch; la.iter = 0; la.iterations_max = o.iterations_max;
+  la.tol_stationarity = o.tol_stationarity; la.tol_meritfun_gradient = o.tol_meritfun_gradient;
+  la.ls = ls_default_options();
+  la.ls.try_cubic_first = 1;                                   // solver.cpp:248
+  la.ls.use_backtracking = o.use_backtracking_linesearch;      // solver.cpp:417
+  const dim3 gb((h->batch + 255) / 256), bb(256);
+  int counters[2];
+  auto read_counters = [&]() -> int {
+    HIP_TRY(hipMemcpyAsync(counters, h->i_counters, sizeof(counters), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+  };
+  auto zero_counter = [&](int idx) -> int {
+    HIP_TRY(hipMemsetAsync(h->i_counters + idx, 0, sizeof(int), h->stream));
+    return 0;
+  };
+  // initial rollout, make it the nominal trajectory, expand everything (solver.cpp:420-434)
+  hipLaunchKernelGGL(ilqr_loop_init_kernel, gb, bb, 0, h->stream, la);
+  rc = ilqr_run(h, IK_ROLLOUT, false, false, 0, 0.0);
+  if (!rc) rc = ilqr_run(h, IK_ACCEPT, false, false, 0, 0.0);
+  if (!rc) rc = ilqr_run(h, IK_EXPAND, false, false, 0, 0.0);
+  if (rc) return rc;
+  int total_merit_launches = 0, sweeps = 0;
+  for (int iter = 0; iter < o.iterations_max; ++iter) {
+    la.iter = iter;
+    hipLaunchKernelGGL(ilqr_mark_running_kernel, gb, bb, 0, h->stream, la);
+    rc = launch_backward(h, 0.0);                               // BackwardPass (reg = 0, solver.cpp:363)
+    if (rc) return rc;
+    h->backward_done = true;
+    // ForwardPass: phi(0), then the line search (solver.cpp:237-271)
+    rc = ilqr_run(h, IK_MERIT, true, true, 1, 0.0);
+    if (rc) return rc;
+    ++total_merit_launches;
+    if ((rc = zero_counter(0))) return rc;
+    hipLaunchKernelGGL(ilqr_ls_begin_kernel, gb, bb, 0, h->stream, la);
+    if ((rc = read_counters())) return rc;
+    int guard = 0;
+    while (counters[0] > 0 && guard++ < 64) {
+      rc = ilqr_run(h, IK_MERIT, true, true, 1, 0.0);
+      if (rc) return rc;
+      ++total_merit_launches;
+      if ((rc = zero_counter(0))) return rc;
+      hipLaunchKernelGGL(ilqr_ls_feed_kernel, gb, bb, 0, h->stream, la);
+      if ((rc = read_counters())) return rc;
+    }
+    // convergence criteria on the accepted candidate, then make it the nominal (solver.cpp:459-469)
+    hipLaunchKernelGGL(ilqr_mark_running_kernel, gb, bb, 0, h->stream, la);
+    rc = ilqr_run(h, IK_STATIONARITY, false, true, 0, 0.0);
+    if (!rc) rc = ilqr_run(h, IK_ACCEPT, false, true, 0, 0.0);
+    if (rc) return rc;
+    if ((rc = zero_counter(1))) return rc;
+    hipLaunchKernelGGL(ilqr_finish_iter_kernel, gb, bb, 0, h->stream, la);
+    if ((rc = read_counters())) return rc;
+    ++sweeps;
+    if (counters[1] == 0) break;
+  }
+  h->forward_done = true;
+  if (results) {
+    std::vector<IlqrProb> pr(h->batch);
+    HIP_TRY(hipMemcpy(pr.data(), h->i_prob, pr.size() * sizeof(IlqrProb), hipMemcpyDeviceToHost));
+    for (int b = 0; b < h->batch; ++b) {
+      results[b].status = pr[b].status;
+      results[b].iterations = pr[b].iterations;
+      results[b].stationarity = pr[b].stationarity;
+      results[b].final_alpha = pr[b].alpha;
+      results[b].final_phi = pr[b].ls_iters > 0 ? pr[b].ls.phi : pr[b].phi0;
+    }
+  }
+  h->last_sweeps = sweeps;
+  h->last_merit_launches = total_merit_launches;
+  return 0;
+}
+
+void altro_hip_default_solve_options(altro_hip_solve_options* o) {
+  if (!o) return;
+  o->iterations_max = 200;            // solver_options.hpp:16-39
+  o->tol_stationarity = 1e-4;
+  o->tol_primal_feasibility = 1e-4;
+  o->tol_meritfun_gradient = 1e-8;
+  o->use_backtracking_linesearch = 0;
+}
+int altro_hip_last_solve_counts(const altro_hip_batch* h, int* sweeps, int* merit_launches) {
+  if (!h) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "null handle");
+  if (sweeps) *sweeps = h->last_sweeps;
+  if (merit_launches) *merit_launches = h->last_merit_launches;
+  return 0;
+}
+int altro_hip_get_nominal(altro_hip_batch* h, double* x, double* u) {
+  int rc = check(h);
+  if (rc) return rc;
+  if (h->plan != ALTRO_HIP_PLAN_LANE) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "nominal trajectory exists for plan LANE");
+  const int n = h->n, m = h->m, N = h->N;
+  if (x) {
+    rc = h->dtype == ALTRO_HIP_F64 ? lane_get<double>(h, x, h->l_nom, nullptr, n + m, 0, 0, n, N + 1, N + 1)
+                                   : lane_get<float>(h, x, h->l_nom, nullptr, n + m, 0, 0, n, N + 1, N + 1);
+    if (rc) return rc;
+  }
+  if (u)
+    rc = h->dtype == ALTRO_HIP_F64 ? lane_get<double>(h, u, h->l_nom, nullptr, n + m, n, 0, m, N, N)
+                                   : lane_get<float>(h, u, h->l_nom, nullptr, n + m, n, 0, m, N, N);
+  return rc;
+}
+// Expansion the backward pass will consume: A | B | lx | lu (reference layout), for parity tests.
+int altro_hip_get_expansion(altro_hip_batch* h, double* A, double* B, double* lx, double* lu) {
+  int rc = check(h);
+  if (rc) return rc;
+  if (h->plan != ALTRO_HIP_PLAN_LANE) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "plan LANE only");
+  const int n = h->n, m = h->m, N = h->N;
+  const LaneSizes z = lane_sizes(n, m);
+  const int oq = 2 * n * n + 2 * n * m + m * m + n, orr = oq + n;
+  auto get = [&](double* dst, int off, int len, int nk, bool with_term, int off_term) -> int {
+    if (!dst) return 0;
+    return h->dtype == ALTRO_HIP_F64
+               ? lane_get<double>(h, dst, h->l_in, with_term ? h->l_term : nullptr, z.e_in, off, off_term, len, nk, N)
+               : lane_get<float>(h, dst, h->l_in, with_term ? h->l_term : nullptr, z.e_in, off, off_term, len, nk, N);
+  };
+  rc = get(A, 0, n * n, N, false, 0);
+  if (!rc) rc = get(B, n * n, n * m, N, false, 0);
+  if (!rc) rc = get(lx, oq, n, N + 1, true, n * n);
+  if (!rc) rc = get(lu, orr, m, N, false, 0);
+  return rc;
+}
+
+// The line-search state machine driven on the host by a callback: lets CPU-only tests pin it against
+// the real reference line search (oracle/_ref) without a GPU.
+double altro_hip_linesearch_host(altro_hip_merit_fn f, void* ctx, double alpha0, double phi0, double dphi0,
+                                 int try_cubic_first, int use_backtracking, double c1, double c2,
+                                 int* status, int* iters, double* phi, double* dphi) {
+  LsOptions o = ls_default_options();
+  o.try_cubic_first = try_cubic_first; o.use_backtracking = use_backtracking; o.c1 = c1; o.c2 = c2;
+  LsState s;
+  bool need = ls_begin(s, o, alpha0, phi0, dphi0);
+  while (need) {
+    double p = 0.0, dp = 0.0;
+    f(s.alpha, &p, s.want_derivative ? &dp : nullptr, ctx);
+    need = ls_feed(s, o, p, dp);
+  }
+  if (status) *status = s.status;
+  if (iters) *iters = s.n_iters;
+  if (phi) *phi = s.phi;
+  if (dphi) *dphi = s.dphi;
+  return s.alpha;
 }
 
 // MFMA layout self-test (tests/test_gpu_parity.py): max |D - (A B + C)| for random operands.

@@ -1,0 +1,415 @@
+// ilqr_lane.hip -- the iLQR inner loop around the TVLQR sweep for plan LANE (lane-per-problem SoA).
+//
+// Device-side counterparts of, in the reference:
+//   SolverImpl::OpenLoopRollout      src/altro/solver/solver.cpp:116-131   -> ilqr_rollout_kernel
+//   SolverImpl::CopyTrajectory       solver.cpp:148-157                    -> ilqr_accept_kernel
+//   CalcDynamicsExpansion / CalcCostGradient / CalcCostHessian (per knot point, independent in k)
+//                                    knotpoint_data.cpp:406-419, :650-708  -> ilqr_expand_kernel
+//   SolverImpl::MeritFunction        solver.cpp:273-355                    -> ilqr_merit_kernel
+//   SolverImpl::Stationarity         solver.cpp:207-222                    -> ilqr_stationarity_kernel
+//   SolverImpl::ForwardPass + CubicLineSearch + the sweep loop of Solve (solver.cpp:237-271, :447-502)
+//                                    -> ilqr_ls_begin_kernel / ilqr_ls_feed_kernel / ilqr_finish_iter_kernel
+// Unconstrained problems with a diagonal quadratic (LQR tracking) cost -- the only cost paths that work
+// in the reference -- and a compiled-in model (models.h).
+//
+// Buffers (all [..][element][batch], unit stride across lanes):
+//   in   [k][E_IN]   A B f Q R H q r : the backward pass's inputs; A,B,q(=lx),r(=lu) are rewritten by
+//                    every derivative evaluation exactly like the reference rewrites A_,B_,lx_,lu_
+//   out  [k][E_OUT]  K d P p from the backward pass ; outn = P_N p_N
+//   nom  [k][n+m]    nominal trajectory  x | u
+//   cand [k][2n+m]   candidate           x_ | y_ | u_
+//   cost [k][2n+2m+1] Qd | Rd | q | r | c     (k = N: terminal)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../linesearch_sm.h"
+#include "../models.h"
+#include "tvlqr_lane.hip"
+
+namespace altro_hip {
+
+struct IlqrProb {       // per-problem control state of the batched solve
+  int running;          // still iterating
+  int iterations;       // AltroStats::iterations (solver.cpp:506)
+  int status;           // SolveStatus: 0 Success, 1 Unsolved, 2 MaxIterations
+  int ls_failed;
+  double phi0, dphi0, alpha, stationarity;
+  int ls_iters, evaluating;
+  LsState ls;
+};
+
+template <typename T>
+struct IlqrArgs {
+  T* in;
+  T* term;
+  const T* out;
+  const T* outn;
+  T* nom;
+  T* cand;
+  const T* cost;
+  const T* x0;          // [n][batch]
+  const double* alpha;  // per problem, or nullptr -> alpha_const
+  const int* active;    // per problem, or nullptr -> all
+  double* phi;
+  double* dphi;
+  IlqrProb* prob;
+  ModelParams mp;
+  int N, batch;
+  int want_derivative;
+  double alpha_const;
+};
+
+template <int n, int m>
+struct IlqrDims {
+  static constexpr int E_NOM = n + m, E_CAND = 2 * n + m, E_COST = 2 * n + 2 * m + 1;
+  static constexpr int C_Q = 0, C_R = n, C_q = n + m, C_r = 2 * n + m, C_c = 2 * n + 2 * m;
+};
+
+#define ILQR_PROLOGUE                                                    \
+  using D = LaneDims<n, m>;                                              \
+  using I = IlqrDims<n, m>;                                              \
+  using Mdl = DiscreteModel<KIND, n, m, T>;                              \
+  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;              \
+  if (b >= a.batch) return;                                              \
+  const int64_t B = a.batch;                                             \
+  const int N = a.N;                                                     \
+  (void)N; (void)sizeof(D); (void)sizeof(I); (void)sizeof(Mdl)
+
+// x_0 = x0 ; x_{k+1} = f(x_k, u_k) on the candidate trajectory
+template <int KIND, int n, int m, typename T>
+__global__ __launch_bounds__(64) void ilqr_rollout_kernel(IlqrArgs<T> a) {
+  ILQR_PROLOGUE;
+  if (a.active && !a.active[b]) return;
+  T x[n], u[m], xn[n];
+  for (int e = 0; e < n; ++e) x[e] = a.x0[(int64_t)e * B + b];
+  for (int k = 0; k < N; ++k) {
+    T* c = a.cand + (int64_t)k * I::E_CAND * B + b;
+    for (int e = 0; e < n; ++e) c[(int64_t)e * B] = x[e];
+    for (int e = 0; e < m; ++e) u[e] = c[(int64_t)(2 * n + e) * B];
+    Mdl::dynamics(a.mp, x, u, xn);
+    for (int e = 0; e < n; ++e) x[e] = xn[e];
+  }
+  T* c = a.cand + (int64_t)N * I::E_CAND * B + b;
+  for (int e = 0; e < n; ++e) c[(int64_t)e * B] = x[e];
+}
+
+// nominal <- candidate (x, u); one thread per (problem, knot point)
+template <int n, int m, typename T>
+__global__ void ilqr_accept_kernel(IlqrArgs<T> a) {
+  using I = IlqrDims<n, m>;
+  const int64_t B = a.batch;
+  const int64_t total = B * (a.N + 1);
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = t % B;
+    const int k = (int)(t / B);
+    if (a.active && !a.active[b]) continue;
+    const T* c = a.cand + (int64_t)k * I::E_CAND * B + b;
+    T* o = a.nom + (int64_t)k * I::E_NOM * B + b;
+    for (int e = 0; e < n; ++e) o[(int64_t)e * B] = c[(int64_t)e * B];
+    if (k < a.N)
+      for (int e = 0; e < m; ++e) o[(int64_t)(n + e) * B] = c[(int64_t)(2 * n + e) * B];
+  }
+}
+
+// Expansion at the candidate point, one thread per (problem, knot point): A, B (f = 0), lxx/luu/lux,
+// lx, lu -> the backward pass's input record.  Independent in k: the reference's own TODO
+// ("do this in parallel", solver.cpp:190).
+template <int KIND, int n, int m, typename T>
+__global__ void ilqr_expand_kernel(IlqrArgs<T> a) {
+  using D = LaneDims<n, m>;
+  using I = IlqrDims<n, m>;
+  using Mdl = DiscreteModel<KIND, n, m, T>;
+  const int64_t B = a.batch;
+  const int64_t total = B * (a.N + 1);
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = t % B;
+    const int k = (int)(t / B);
+    if (a.active && !a.active[b]) continue;
+    const T* c = a.cand + (int64_t)k * I::E_CAND * B + b;
+    const T* cs = a.cost + (int64_t)k * I::E_COST * B + b;
+    T x[n], u[m];
+    for (int e = 0; e < n; ++e) x[e] = c[(int64_t)e * B];
+    if (k == a.N) {   // terminal: P_N = lxx, p_N = lx
+      for (int e = 0; e < n * n; ++e)
+        a.term[(int64_t)e * B + b] = (e % n == e / n) ? cs[(int64_t)(I::C_Q + e % n) * B] : T(0);
+      for (int e = 0; e < n; ++e)
+        a.term[(int64_t)(n * n + e) * B + b] = cs[(int64_t)(I::C_Q + e) * B] * x[e] + cs[(int64_t)(I::C_q + e) * B];
+      continue;
+    }
+    for (int e = 0; e < m; ++e) u[e] = c[(int64_t)(2 * n + e) * B];
+    T* in = a.in + (int64_t)k * D::E_IN * B + b;
+    T Am[n * n], Bm[n * m];
+    Mdl::jacobian(a.mp, x, u, Am, Bm);
+    for (int e = 0; e < n * n; ++e) in[(int64_t)(D::O_A + e) * B] = Am[e];
+    for (int e = 0; e < n * m; ++e) in[(int64_t)(D::O_B + e) * B] = Bm[e];
+    for (int e = 0; e < n; ++e) in[(int64_t)(D::O_f + e) * B] = T(0);
+    for (int e = 0; e < n * n; ++e)
+      in[(int64_t)(D::O_Q + e) * B] = (e % n == e / n) ? cs[(int64_t)(I::C_Q + e % n) * B] : T(0);
+    for (int e = 0; e < m * m; ++e)
+      in[(int64_t)(D::O_R + e) * B] = (e % m == e / m) ? cs[(int64_t)(I::C_R + e % m) * B] : T(0);
+    for (int e = 0; e < m * n; ++e) in[(int64_t)(D::O_H + e) * B] = T(0);
+    for (int e = 0; e < n; ++e)
+      in[(int64_t)(D::O_q + e) * B] = cs[(int64_t)(I::C_Q + e) * B] * x[e] + cs[(int64_t)(I::C_q + e) * B];
+    for (int e = 0; e < m; ++e)
+      in[(int64_t)(D::O_r + e) * B] = cs[(int64_t)(I::C_R + e) * B] * u[e] + cs[(int64_t)(I::C_r + e) * B];
+  }
+}
+
+// diagonal quadratic cost of one knot point (knotpoint_data.cpp:636-645)
+template <int n, int m, typename T>
+__device__ __forceinline__ T ilqr_kp_cost(const T* cs, int64_t B, const T* x, const T* u, bool terminal) {
+  using I = IlqrDims<n, m>;
+  T a1 = T(0);
+  for (int i = 0; i < n; ++i) a1 += x[i] * (cs[(int64_t)(I::C_Q + i) * B] * x[i]);
+  T J = T(0.5) * a1;
+  T b1 = T(0);
+  for (int i = 0; i < n; ++i) b1 += cs[(int64_t)(I::C_q + i) * B] * x[i];
+  J += b1;
+  if (!terminal) {
+    T a2 = T(0);
+    for (int i = 0; i < m; ++i) a2 += u[i] * (cs[(int64_t)(I::C_R + i) * B] * u[i]);
+    J += T(0.5) * a2;
+    T b2 = T(0);
+    for (int i = 0; i < m; ++i) b2 += cs[(int64_t)(I::C_r + i) * B] * u[i];
+    J += b2;
+  }
+  J += cs[(int64_t)I::C_c * B];
+  return J;
+}
+
+// MeritFunction (solver.cpp:273-355): closed-loop rollout with step alpha, total cost phi and, when
+// asked, the directional derivative dphi together with the refreshed A, B, lx, lu.
+template <int KIND, int n, int m, typename T>
+__global__ __launch_bounds__(64) void ilqr_merit_kernel(IlqrArgs<T> a) {
+  ILQR_PROLOGUE;
+  if (a.active && !a.active[b]) return;
+  const T alpha = (T)(a.alpha ? a.alpha[b] : a.alpha_const);
+  const bool deriv = a.want_derivative != 0;
+  T x[n], dxda[n], phi = T(0), dphi = T(0);
+  for (int e = 0; e < n; ++e) { x[e] = a.x0[(int64_t)e * B + b]; dxda[e] = T(0); }
+  for (int k = 0; k < N; ++k) {
+    const T* o = a.out + (int64_t)k * D::E_OUT * B + b;
+    const T* nm = a.nom + (int64_t)k * I::E_NOM * B + b;
+    const T* cs = a.cost + (int64_t)k * I::E_COST * B + b;
+    T* c = a.cand + (int64_t)k * I::E_CAND * B + b;
+    T dx[n], u[m], xn[n];
+    for (int i = 0; i < n; ++i) dx[i] = x[i] - nm[(int64_t)i * B];
+    for (int i = 0; i < m; ++i) {   // u_ = u + (-K dx + alpha d)
+      T s = T(0);
+      for (int j = 0; j < n; ++j) s += o[(int64_t)(D::O_K + i + j * m) * B] * dx[j];
+      u[i] = nm[(int64_t)(n + i) * B] + (-s + alpha * o[(int64_t)(D::O_d + i) * B]);
+    }
+    for (int i = 0; i < n; ++i) {   // y_ = P dx + p
+      T s = T(0);
+      for (int j = 0; j < n; ++j) s += o[(int64_t)(D::O_P + i + j * n) * B] * dx[j];
+      c[(int64_t)(n + i) * B] = s + o[(int64_t)(D::O_p + i) * B];
+    }
+    for (int e = 0; e < n; ++e) c[(int64_t)e * B] = x[e];
+    for (int e = 0; e < m; ++e) c[(int64_t)(2 * n + e) * B] = u[e];
+    Mdl::dynamics(a.mp, x, u, xn);
+    phi += ilqr_kp_cost<n, m, T>(cs, B, x, u, false);
+    if (deriv) {
+      T* in = a.in + (int64_t)k * D::E_IN * B + b;
+      T Am[n * n], Bm[n * m], duda[m], dxn[n], lx[n], lu[m];
+      Mdl::jacobian(a.mp, x, u, Am, Bm);
+      for (int e = 0; e < n * n; ++e) in[(int64_t)(D::O_A + e) * B] = Am[e];
+      for (int e = 0; e < n * m; ++e) in[(int64_t)(D::O_B + e) * B] = Bm[e];
+      for (int i = 0; i < m; ++i) {   // du_da = -K dx_da + d
+        T s = T(0);
+        for (int j = 0; j < n; ++j) s += o[(int64_t)(D::O_K + i + j * m) * B] * dxda[j];
+        duda[i] = -s + o[(int64_t)(D::O_d + i) * B];
+      }
+      for (int i = 0; i < n; ++i) {   // dx_da+ = A dx_da + B du_da
+        T s = T(0);
+        for (int j = 0; j < n; ++j) s += Am[i + j * n] * dxda[j];
+        T s2 = T(0);
+        for (int j = 0; j < m; ++j) s2 += Bm[i + j * n] * duda[j];
+        dxn[i] = s + s2;
+      }
+      for (int i = 0; i < n; ++i) lx[i] = cs[(int64_t)(I::C_Q + i) * B] * x[i] + cs[(int64_t)(I::C_q + i) * B];
+      for (int i = 0; i < m; ++i) lu[i] = cs[(int64_t)(I::C_R + i) * B] * u[i] + cs[(int64_t)(I::C_r + i) * B];
+      for (int e = 0; e < n; ++e) in[(int64_t)(D::O_q + e) * B] = lx[e];
+      for (int e = 0; e < m; ++e) in[(int64_t)(D::O_r + e) * B] = lu[e];
+      T s = T(0);
+      for (int i = 0; i < n; ++i) s += lx[i] * dxda[i];
+      dphi += s;
+      s = T(0);
+      for (int i = 0; i < m; ++i) s += lu[i] * duda[i];
+      dphi += s;
+      for (int e = 0; e < n; ++e) dxda[e] = dxn[e];
+    }
+    for (int e = 0; e < n; ++e) x[e] = xn[e];
+  }
+  {   // terminal knot point (solver.cpp:319-332)
+    const T* nm = a.nom + (int64_t)N * I::E_NOM * B + b;
+    const T* cs = a.cost + (int64_t)N * I::E_COST * B + b;
+    T* c = a.cand + (int64_t)N * I::E_CAND * B + b;
+    phi += ilqr_kp_cost<n, m, T>(cs, B, x, (const T*)nullptr, true);
+    T dx[n];
+    for (int i = 0; i < n; ++i) dx[i] = x[i] - nm[(int64_t)i * B];
+    for (int i = 0; i < n; ++i) {
+      T s = T(0);
+      for (int j = 0; j < n; ++j) s += a.outn[(int64_t)(i + j * n) * B + b] * dx[j];
+      c[(int64_t)(n + i) * B] = s + a.outn[(int64_t)(n * n + i) * B + b];
+    }
+    for (int e = 0; e < n; ++e) c[(int64_t)e * B] = x[e];
+    if (deriv) {
+      T s = T(0);
+      for (int i = 0; i < n; ++i) {
+        const T lx = cs[(int64_t)(I::C_Q + i) * B] * x[i] + cs[(int64_t)(I::C_q + i) * B];
+        a.term[(int64_t)(n * n + i) * B + b] = lx;
+        s += lx * dxda[i];
+      }
+      dphi += s;
+    }
+  }
+  a.phi[b] = (double)phi;
+  if (deriv) a.dphi[b] = (double)dphi;
+}
+
+// Stationarity (solver.cpp:207-222) from the candidate duals and the current expansion
+template <int n, int m, typename T>
+__global__ __launch_bounds__(64) void ilqr_stationarity_kernel(IlqrArgs<T> a) {
+  using D = LaneDims<n, m>;
+  using I = IlqrDims<n, m>;
+  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (b >= a.batch) return;
+  if (a.active && !a.active[b]) return;
+  const int64_t B = a.batch;
+  const int N = a.N;
+  T res_x = T(0), res_u = T(0);
+  for (int k = 0; k < N; ++k) {
+    const T* in = a.in + (int64_t)k * D::E_IN * B + b;
+    const T* c = a.cand + (int64_t)k * I::E_CAND * B + b;
+    const T* cn = a.cand + (int64_t)(k + 1) * I::E_CAND * B + b;
+    T yn[n];
+    for (int e = 0; e < n; ++e) yn[e] = cn[(int64_t)(n + e) * B];
+    for (int j = 0; j < n; ++j) {
+      T s = T(0);
+      for (int i = 0; i < n; ++i) s += in[(int64_t)(D::O_A + i + j * n) * B] * yn[i];
+      res_x = fmax(res_x, fabs(in[(int64_t)(D::O_q + j) * B] + s - c[(int64_t)(n + j) * B]));
+    }
+    for (int j = 0; j < m; ++j) {
+      T s = T(0);
+      for (int i = 0; i < n; ++i) s += in[(int64_t)(D::O_B + i + j * n) * B] * yn[i];
+      res_u = fmax(res_u, fabs(in[(int64_t)(D::O_r + j) * B] + s));
+    }
+  }
+  const T* c = a.cand + (int64_t)N * I::E_CAND * B + b;
+  for (int j = 0; j < n; ++j)
+    res_x = fmax(res_x, fabs(a.term[(int64_t)(n * n + j) * B + b] - c[(int64_t)(n + j) * B]));
+  a.prob[b].stationarity = (double)fmax(res_x, res_u);
+}
+
+// ---- batched line search + sweep bookkeeping (one thread per problem) ---------------------------------
+struct IlqrLoopArgs {
+  IlqrProb* prob;
+  double* alpha;      // [batch] next trial step per problem
+  int* active;        // [batch] 1 = problem takes part in the next merit evaluation
+  const double* phi;
+  const double* dphi;
+  int* counters;      // [0] = problems that still need a merit evaluation, [1] = problems still running
+  int batch;
+  int iter;
+  int iterations_max;
+  double tol_stationarity, tol_meritfun_gradient;
+  LsOptions ls;
+};
+
+__global__ void ilqr_loop_init_kernel(IlqrLoopArgs a) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.batch) return;
+  IlqrProb& p = a.prob[b];
+  p.running = 1; p.iterations = 0; p.status = 1; p.ls_failed = 0; p.evaluating = 0;
+  p.alpha = 0.0; p.stationarity = 0.0; p.ls_iters = 0;
+  a.active[b] = 1;
+  a.alpha[b] = 0.0;
+}
+
+// after merit(alpha = 0): ForwardPass's head (solver.cpp:241-249)
+__global__ void ilqr_ls_begin_kernel(IlqrLoopArgs a) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.batch) return;
+  IlqrProb& p = a.prob[b];
+  if (!p.running) { a.active[b] = 0; return; }
+  p.phi0 = a.phi[b];
+  p.dphi0 = a.dphi[b];
+  p.ls_failed = 0;
+  bool need;
+  if (fabs(p.dphi0) < a.tol_meritfun_gradient) {   // MeritFunctionGradientTooSmall: alpha = 0
+    p.alpha = 0.0;
+    p.ls_iters = 0;
+    need = false;
+  } else {
+    need = ls_begin(p.ls, a.ls, 1.0, p.phi0, p.dphi0);
+    if (!need) {   // not a descent direction
+      p.alpha = p.ls.alpha;
+      p.ls_iters = p.ls.n_iters;
+      p.ls_failed = 1;
+    }
+  }
+  p.evaluating = need ? 1 : 0;
+  a.active[b] = need ? 1 : 0;
+  if (need) {
+    a.alpha[b] = p.ls.alpha;
+    atomicAdd(&a.counters[0], 1);
+  }
+}
+
+// after merit(alpha[b]): advance every searching problem's state machine
+__global__ void ilqr_ls_feed_kernel(IlqrLoopArgs a) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.batch) return;
+  IlqrProb& p = a.prob[b];
+  if (!p.running || !p.evaluating) { a.active[b] = 0; return; }
+  const bool need = ls_feed(p.ls, a.ls, a.phi[b], a.dphi[b]);
+  if (need) {
+    a.alpha[b] = p.ls.alpha;
+    a.active[b] = 1;
+    atomicAdd(&a.counters[0], 1);
+  } else {
+    p.evaluating = 0;
+    a.active[b] = 0;
+    p.alpha = p.ls.alpha;
+    p.ls_iters = p.ls.n_iters;
+    const int st = p.ls.status;
+    // solver.cpp:264-268
+    p.ls_failed = (isnan(p.alpha) || !(st == LS_MINIMUM_FOUND || st == LS_HIT_MAX_STEPSIZE)) ? 1 : 0;
+  }
+}
+
+// end of one sweep (solver.cpp:459-502): convergence test, bookkeeping; `active` := still running
+__global__ void ilqr_finish_iter_kernel(IlqrLoopArgs a) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.batch) return;
+  IlqrProb& p = a.prob[b];
+  if (p.running) {
+    bool stop = p.ls_failed != 0;
+    if (fabs(p.stationarity) < a.tol_stationarity) {   // feasibility == 0 without constraints
+      p.status = 0;
+      stop = true;
+    }
+    p.iterations = a.iter + 1;
+    if (!stop && a.iter + 1 >= a.iterations_max) {
+      p.status = 2;   // MaxIterations; the reference reports iter + 1 after its loop ends (solver.cpp:503-506)
+      p.iterations = a.iter + 2;
+      stop = true;
+    }
+    if (stop) p.running = 0;
+  }
+  a.active[b] = p.running;
+  if (p.running) atomicAdd(&a.counters[1], 1);
+}
+
+// set `active` := running (used before the per-sweep kernels)
+__global__ void ilqr_mark_running_kernel(IlqrLoopArgs a) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.batch) return;
+  a.active[b] = a.prob[b].running;
+  a.alpha[b] = 0.0;
+}
+
+}  // namespace altro_hip

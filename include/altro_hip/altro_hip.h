@@ -140,6 +140,56 @@ int altro_hip_get_status(altro_hip_batch* h, int* status);      /* [batch]      
 /* Qxx|Quu|Qux|Qx|Qu per knot point, [batch][N][n*n+m*m+m*n+n+m]; needs ALTRO_HIP_STORE_QBLOCKS */
 int altro_hip_get_qblocks(altro_hip_batch* h, double* qblocks);
 
+
+/* ---- the iLQR loop around the sweep (plan LANE shapes: BASELINE.json configs[2], [3]) ------------- */
+/* Device model standing in for SetExplicitDynamics' host callbacks (altro_solver.cpp:68-81).        */
+int altro_hip_set_model(altro_hip_batch* h, int model, float timestep, int bicycle_frame,
+                        double bicycle_length, double bicycle_lr);
+/* ALTROSolver::SetLQRCost (altro_solver.cpp:138-172): Qd, xref [batch][N+1][n]; Rd, uref [batch][N][m];
+ * with k_stride_zero Qd/xref hold {running, terminal} and Rd/uref one knot point.                   */
+int altro_hip_set_tracking_cost(altro_hip_batch* h, const double* Qd, const double* Rd, const double* xref,
+                                const double* uref, int k_stride_zero, int batch_stride_zero);
+/* ALTROSolver::SetInput over all knot points (altro_solver.cpp:242-251): u [batch][N][m]             */
+int altro_hip_set_input_guess(altro_hip_batch* h, const double* u, int k_stride_zero, int batch_stride_zero);
+int altro_hip_open_loop_rollout(altro_hip_batch* h); /* SolverImpl::OpenLoopRollout solver.cpp:116-131 */
+int altro_hip_accept(altro_hip_batch* h);            /* SolverImpl::CopyTrajectory  solver.cpp:148-157 */
+int altro_hip_expand(altro_hip_batch* h);            /* dynamics + cost expansion at the candidate     */
+/* SolverImpl::MeritFunction (solver.cpp:273-355): alpha [batch] (or one value when alpha_is_uniform),
+ * phi / dphi [batch] out; get_x/u/y then return the candidate trajectory x_, u_, y_.               */
+int altro_hip_merit(altro_hip_batch* h, const double* alpha, int alpha_is_uniform, int want_derivative,
+                    double* phi, double* dphi);
+int altro_hip_stationarity(altro_hip_batch* h, double* stationarity); /* solver.cpp:207-222, [batch]  */
+int altro_hip_get_nominal(altro_hip_batch* h, double* x, double* u);
+int altro_hip_get_expansion(altro_hip_batch* h, double* A, double* B, double* lx, double* lu);
+
+typedef struct altro_hip_solve_options { /* AltroOptions, solver_options.hpp:16-39 */
+  int iterations_max;
+  double tol_stationarity;
+  double tol_primal_feasibility;
+  double tol_meritfun_gradient;
+  int use_backtracking_linesearch;
+} altro_hip_solve_options;
+typedef struct altro_hip_solve_result { /* AltroStats per problem, solver_stats.hpp:14-25 */
+  int status;     /* SolveStatus: 0 Success, 1 Unsolved, 2 MaxIterations (typedefs.hpp:19-27)        */
+  int iterations; /* solver.cpp:506                                                                  */
+  double stationarity;
+  double final_alpha;
+  double final_phi;
+} altro_hip_solve_result;
+void altro_hip_default_solve_options(altro_hip_solve_options* opts);
+/* SolverImpl::Solve (solver.cpp:414-511) for the whole batch; results [batch] (may be NULL).         */
+int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts,
+                         altro_hip_solve_result* results);
+int altro_hip_last_solve_counts(const altro_hip_batch* h, int* sweeps, int* merit_launches);
+
+/* The batched solver's line search is CubicLineSearch (src/linesearch/linesearch.cpp:37-412) recast as
+ * a resumable state machine (altro_amd/csrc/linesearch_sm.h).  This host entry drives that same code
+ * with a callback so that it can be pinned against the reference line search without a GPU.         */
+typedef void (*altro_hip_merit_fn)(double alpha, double* phi, double* dphi, void* ctx);
+double altro_hip_linesearch_host(altro_hip_merit_fn f, void* ctx, double alpha0, double phi0, double dphi0,
+                                 int try_cubic_first, int use_backtracking, double c1, double c2,
+                                 int* status, int* iters, double* phi, double* dphi);
+
 /* ---- statistics (the only thing that ever crosses GPUs: SURVEY.md section 8e) ------------------ */
 typedef struct altro_hip_stats {
   int64_t problems;          /* batch                                                          */
