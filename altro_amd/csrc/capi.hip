@@ -600,12 +600,13 @@ int altro_hip_batch_create(altro_hip_batch** out, int N, int n, int m, int batch
     if (!rc && hipMemset(h->l_cost, 0, B * (N + 1) * (2 * n + 2 * m + 1) * E) != hipSuccess) rc = fail(ALTRO_HIP_ERR_HIP, "memset failed");
   } else {
     const int blk[G_NUM] = {n * n, n * m, n, n * n, m * m, m * n, n, m, m * n, m, n * n, n,
-                            n * n, m * m, m * n, n, m, n, m, n};
+                            n * n, m * m, m * n, n, m, n * n, m * m, m * n, n, m, n, m, n};
     const int nks[G_NUM] = {N, N, N, N + 1, N, N, N + 1, N, N, N, N + 1, N + 1,
-                            N, N, N, N, N, N + 1, N, N + 1};
+                            N, N, N, N, N, N, N, N, N, N, N + 1, N, N + 1};
     std::vector<int64_t> off((size_t)(N + 1) * G_NUM, 0);
     for (int a = 0; a < G_NUM; ++a) {
       const bool qb = (a >= G_Qxx && a <= G_Qu);
+      if (a >= G_Qxx_tmp && a <= G_Qu_tmp) continue;   // scratch blocks: only the tvlqr_* drop-in keeps them
       h->g_bstride[a] = (int64_t)nks[a] * blk[a];
       for (int k = 0; k <= N; ++k) off[(size_t)k * G_NUM + a] = (int64_t)k * blk[a];
       if (qb && !(flags & ALTRO_HIP_STORE_QBLOCKS)) continue;

@@ -25,6 +25,7 @@ enum GArr {
   G_A = 0, G_B, G_f, G_Q, G_R, G_H, G_q, G_r,      // inputs
   G_K, G_d, G_P, G_p,                              // outputs
   G_Qxx, G_Quu, G_Qux, G_Qx, G_Qu,                 // optional outputs
+  G_Qxx_tmp, G_Quu_tmp, G_Qux_tmp, G_Qx_tmp, G_Qu_tmp,  // the reference's scratch blocks (store_q == 2)
   G_x, G_u, G_y,                                   // forward outputs
   G_NUM
 };
@@ -182,6 +183,19 @@ __global__ __launch_bounds__(64) void generic_backward_kernel(GenericArgs<T> a) 
     if (s_fail) {  // tvlqr.cpp:162-164: return k, leaving K_k = Qux, d_k = -Qu unsolved
       wave_copy(lane, GPTR(G_K, k), (const T*)sK, m * n);
       wave_copy(lane, GPTR(G_d, k), (const T*)sd, m);
+      if (a.store_q) {
+        wave_copy(lane, GPTR(G_Qxx, k), (const T*)sQxx, n * n);
+        wave_copy(lane, GPTR(G_Quu, k), (const T*)sQuu, m * m);
+        wave_copy(lane, GPTR(G_Qux, k), (const T*)sQux, m * n);
+        wave_copy(lane, GPTR(G_Qx, k), (const T*)sQx, n);
+        wave_copy(lane, GPTR(G_Qu, k), (const T*)sQu, m);
+      }
+      if (a.store_q == 2) {
+        wave_copy(lane, GPTR(G_Qxx_tmp, k), (const T*)sT1, n * n);
+        wave_copy(lane, GPTR(G_Quu_tmp, k), (const T*)sL, m * m);
+        wave_copy(lane, GPTR(G_Qux_tmp, k), (const T*)sT2, m * n);
+        wave_copy(lane, GPTR(G_Qx_tmp, k), (const T*)st, n);
+      }
       if (lane == 0) {
         a.status[b] = k;
         a.delta_V[2 * (int64_t)b + 0] = dv0;
@@ -210,6 +224,7 @@ __global__ __launch_bounds__(64) void generic_backward_kernel(GenericArgs<T> a) 
     wave_copy(lane, sPk, (const T*)sQxx, n * n);
     wave_copy(lane, spk, (const T*)sQx, n);
     wave_gemm<T>(lane, 0, 0, m, 1, m, T(1), sQuu, m, sd, m, T(0), sw, m);   // Qu_tmp = Quu d (:189)
+    if (a.store_q == 2) wave_gemm<T>(lane, 1, 0, n, 1, m, T(1), sK, m, sQu, m, T(0), st, n);  // Qx_tmp = K^T Qu (:176)
     __syncthreads();
     wave_gemm<T>(lane, 1, 0, n, n, m, T(1), sT2, m, sK, m, T(1), sPk, n);   // P += (Quu K)^T K
     __syncthreads();
@@ -240,6 +255,13 @@ __global__ __launch_bounds__(64) void generic_backward_kernel(GenericArgs<T> a) 
       wave_copy(lane, GPTR(G_Qux, k), (const T*)sQux, m * n);
       wave_copy(lane, GPTR(G_Qx, k), (const T*)sQx, n);
       wave_copy(lane, GPTR(G_Qu, k), (const T*)sQu, m);
+    }
+    if (a.store_q == 2) {
+      wave_copy(lane, GPTR(G_Qxx_tmp, k), (const T*)sT1, n * n);
+      wave_copy(lane, GPTR(G_Quu_tmp, k), (const T*)sL, m * m);
+      wave_copy(lane, GPTR(G_Qux_tmp, k), (const T*)sT2, m * n);
+      wave_copy(lane, GPTR(G_Qx_tmp, k), (const T*)st, n);
+      wave_copy(lane, GPTR(G_Qu_tmp, k), (const T*)sw, m);
     }
     wave_copy(lane, sP, (const T*)sPk, n * n);
     wave_copy(lane, sp, (const T*)spk, n);

@@ -1,0 +1,271 @@
+// tvlqr_dropin.hip -- the reference's three tvlqr_* entry points (include/tvlqr/tvlqr.h) on the GPU.
+// Pure plumbing around kernels/tvlqr_generic.hip: gather host blocks -> one H2D copy -> one launch ->
+// one D2H copy -> scatter.  One problem = one wavefront; this path exists for drop-in fidelity
+// (callers that hold a single problem as arrays of per-knot-point pointers), not for throughput --
+// batches go through include/altro_hip/altro_hip.h.
+#include "tvlqr/tvlqr.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <vector>
+
+#include "kernels/tvlqr_generic.hip"
+
+using namespace altro_hip;
+
+int tvlqr_TotalMemSize(const int* nx, const int* nu, int num_horizon, bool is_diag) {
+  // src/tvlqr/tvlqr.cpp:18-63: bytes of a flat buffer holding every per-knot-point block
+  if (!nx) return 0;
+  if (!nu) return 0;
+  long long count = 0;
+  for (int k = 0; k <= num_horizon; ++k) {
+    const long long n = nx[k];
+    count += (is_diag ? n : n * n) + n;   // Q q
+    count += n * n + n;                   // P p
+    count += n + n;                       // x y
+    if (k < num_horizon) {
+      const long long m = nu[k];
+      count += n * n + n * m + n;                              // A B f
+      count += (is_diag ? m : m * m) + (is_diag ? 0 : m * n) + m;   // R H r
+      count += m * n + m;                                      // K d
+      count += 2 * (n * n + m * m + m * n + n + m);            // Q-blocks and their scratch twins
+      count += m;                                              // u
+    }
+  }
+  count += 2;   // delta_V
+  return (int)(count * (long long)sizeof(lqr_float));
+}
+
+namespace {
+
+struct Workspace {   // cached per thread: no allocation after the first call of a given size
+  double* dev = nullptr;
+  size_t dev_elems = 0;
+  int64_t* dev_off = nullptr;
+  int* dev_dims = nullptr;
+  int* dev_status = nullptr;
+  size_t table_k = 0;
+  std::vector<double> host;
+  std::vector<int64_t> off;
+  std::vector<int> dims;
+  ~Workspace() {
+    if (dev) (void)hipFree(dev);
+    if (dev_off) (void)hipFree(dev_off);
+    if (dev_dims) (void)hipFree(dev_dims);
+    if (dev_status) (void)hipFree(dev_status);
+  }
+};
+thread_local Workspace g_ws;
+
+bool have_device() {
+  int c = 0;
+  return hipGetDeviceCount(&c) == hipSuccess && c > 0;
+}
+
+// Lays every array's knot-point blocks out in one arena; returns the arena size in elements.
+struct Layout {
+  int N;
+  std::vector<int64_t> off;   // [(N+1) * G_NUM]
+  int64_t total;
+  int nmax, mmax;
+};
+
+int64_t block_size(int arr, int n, int m, int n2, bool is_diag) {
+  switch (arr) {
+    case G_A: return (int64_t)n2 * n;
+    case G_B: return (int64_t)n2 * m;
+    case G_f: return n2;
+    case G_Q: return is_diag ? n : (int64_t)n * n;
+    case G_R: return is_diag ? m : (int64_t)m * m;
+    case G_H: case G_K: case G_Qux: case G_Qux_tmp: return (int64_t)m * n;
+    case G_q: case G_p: case G_Qx: case G_Qx_tmp: case G_x: case G_y: return n;
+    case G_r: case G_d: case G_Qu: case G_Qu_tmp: case G_u: return m;
+    case G_P: case G_Qxx: case G_Qxx_tmp: return (int64_t)n * n;
+    case G_Quu: case G_Quu_tmp: return (int64_t)m * m;
+    default: return 0;
+  }
+}
+
+Layout make_layout(const int* nx, const int* nu, int N, bool is_diag) {
+  Layout L;
+  L.N = N;
+  L.off.assign((size_t)(N + 1) * G_NUM, 0);
+  L.nmax = 0; L.mmax = 0;
+  int64_t cur = 0;
+  for (int k = 0; k <= N; ++k) {
+    const int n = nx[k], m = (k < N) ? nu[k] : 0, n2 = (k < N) ? nx[k + 1] : 0;
+    if (n > L.nmax) L.nmax = n;
+    if (m > L.mmax) L.mmax = m;
+    for (int a = 0; a < G_NUM; ++a) {
+      const bool has_terminal = (a == G_Q || a == G_q || a == G_P || a == G_p || a == G_x || a == G_y);
+      L.off[(size_t)k * G_NUM + a] = cur;
+      if (k < N || has_terminal) cur += (block_size(a, n, m, n2, is_diag) + 1) & ~int64_t(1);   // keep 16-B alignment
+    }
+  }
+  L.total = cur + 32 + 4;   // + x0 staging (<= 32) + delta_V[2] (+pad) at the end
+  return L;
+}
+
+int prepare(Workspace& w, const Layout& L, const int* nx, const int* nu) {
+  const int N = L.N;
+  if (w.dev_elems < (size_t)L.total) {
+    if (w.dev) (void)hipFree(w.dev);
+    w.dev = nullptr;
+    if (hipMalloc(&w.dev, (size_t)L.total * sizeof(double)) != hipSuccess) return -1;
+    w.dev_elems = (size_t)L.total;
+    w.host.resize((size_t)L.total);
+  }
+  if (w.table_k < (size_t)(N + 1)) {
+    if (w.dev_off) (void)hipFree(w.dev_off);
+    if (w.dev_dims) (void)hipFree(w.dev_dims);
+    if (hipMalloc(&w.dev_off, (size_t)(N + 1) * G_NUM * sizeof(int64_t)) != hipSuccess) return -1;
+    if (hipMalloc(&w.dev_dims, (size_t)(N + 1) * 2 * sizeof(int)) != hipSuccess) return -1;
+    w.table_k = (size_t)(N + 1);
+  }
+  if (!w.dev_status && hipMalloc(&w.dev_status, sizeof(int)) != hipSuccess) return -1;
+  w.dims.assign((size_t)(N + 1) * 2, 0);
+  for (int k = 0; k <= N; ++k) {
+    w.dims[k] = nx[k];
+    w.dims[(size_t)(N + 1) + k] = (k < N) ? nu[k] : 0;
+  }
+  if (hipMemcpy(w.dev_off, L.off.data(), L.off.size() * sizeof(int64_t), hipMemcpyHostToDevice) != hipSuccess) return -1;
+  if (hipMemcpy(w.dev_dims, w.dims.data(), w.dims.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return -1;
+  return 0;
+}
+
+GenericArgs<double> make_args(Workspace& w, const Layout& L, double reg, bool is_diag, int want_y) {
+  GenericArgs<double> a;
+  for (int i = 0; i < G_NUM; ++i) { a.base[i] = w.dev; a.bstride[i] = 0; }
+  a.off = w.dev_off;
+  a.nx = w.dev_dims;
+  a.nu = w.dev_dims + (L.N + 1);
+  a.x0 = w.dev + L.total - 4;   // overwritten by the forward entry point
+  a.x0_stride = 0;
+  a.delta_V = w.dev + L.total - 4;
+  a.status = w.dev_status;
+  a.N = L.N; a.batch = 1; a.nmax = L.nmax; a.mmax = L.mmax > 0 ? L.mmax : 1;
+  a.reg = reg; a.is_diag = is_diag ? 1 : 0; a.store_q = 2; a.want_y = want_y;
+  return a;
+}
+
+}  // namespace
+
+int tvlqr_BackwardPass(const int* nx, const int* nu, int num_horizon, const lqr_float* const* A,
+                       const lqr_float* const* B, const lqr_float* const* f, const lqr_float* const* Q,
+                       const lqr_float* const* R, const lqr_float* const* H, const lqr_float* const* q,
+                       const lqr_float* const* r, lqr_float reg, lqr_float** K, lqr_float** d,
+                       lqr_float** P, lqr_float** p, lqr_float* delta_V, lqr_float** Qxx, lqr_float** Quu,
+                       lqr_float** Qux, lqr_float** Qx, lqr_float** Qu, lqr_float** Qxx_tmp,
+                       lqr_float** Quu_tmp, lqr_float** Qux_tmp, lqr_float** Qx_tmp, lqr_float** Qu_tmp,
+                       bool linear_only_update, bool is_diag) {
+  (void)linear_only_update;   // accepted and ignored, like tvlqr.cpp:78
+  if (!have_device()) return TVLQR_NO_DEVICE;
+  const int N = num_horizon;
+  for (int k = 0; k <= N; ++k)
+    if (nx[k] > 32 || (k < N && nu[k] > 32)) return TVLQR_NO_DEVICE;
+  Workspace& w = g_ws;
+  const Layout L = make_layout(nx, nu, N, is_diag);
+  if (prepare(w, L, nx, nu)) return TVLQR_NO_DEVICE;
+  double* hs = w.host.data();
+  auto put = [&](int arr, int k, const double* src, int64_t cnt) {
+    if (src && cnt) memcpy(hs + L.off[(size_t)k * G_NUM + arr], src, sizeof(double) * cnt);
+  };
+  for (int k = 0; k <= N; ++k) {
+    const int n = nx[k];
+    put(G_Q, k, Q[k], is_diag ? n : (int64_t)n * n);
+    put(G_q, k, q[k], n);
+    if (k < N) {
+      const int m = nu[k], n2 = nx[k + 1];
+      put(G_A, k, A[k], (int64_t)n2 * n);
+      put(G_B, k, B[k], (int64_t)n2 * m);
+      put(G_f, k, f[k], n2);
+      put(G_R, k, R[k], is_diag ? m : (int64_t)m * m);
+      if (!is_diag) put(G_H, k, H[k], (int64_t)m * n);
+      put(G_r, k, r[k], m);
+    }
+  }
+  if (hipMemcpy(w.dev, hs, (size_t)L.total * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return TVLQR_NO_DEVICE;
+  GenericArgs<double> a = make_args(w, L, reg, is_diag, 0);
+  const size_t lds = generic_backward_lds_bytes<double>(a.nmax, a.mmax);
+  hipLaunchKernelGGL(generic_backward_kernel<double>, dim3(1), dim3(64), lds, 0, a);
+  if (hipGetLastError() != hipSuccess) return TVLQR_NO_DEVICE;
+  if (hipMemcpy(hs, w.dev, (size_t)L.total * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return TVLQR_NO_DEVICE;
+  int status = TVLQR_NO_DEVICE;
+  if (hipMemcpy(&status, w.dev_status, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return TVLQR_NO_DEVICE;
+  auto get = [&](int arr, int k, double* dst, int64_t cnt) {
+    if (dst && cnt) memcpy(dst, hs + L.off[(size_t)k * G_NUM + arr], sizeof(double) * cnt);
+  };
+  // Knot points the recursion reached: all of them on success, k >= status on failure
+  const int k_lo = (status == TVLQR_SUCCESS) ? 0 : status;
+  get(G_P, N, P[N], (int64_t)nx[N] * nx[N]);
+  get(G_p, N, p[N], nx[N]);
+  for (int k = N - 1; k >= k_lo; --k) {
+    const int n = nx[k], m = nu[k];
+    const bool failed_here = (k == status);
+    get(G_K, k, K[k], (int64_t)m * n);
+    get(G_d, k, d[k], m);
+    if (!failed_here) {
+      get(G_P, k, P[k], (int64_t)n * n);
+      get(G_p, k, p[k], n);
+    }
+    get(G_Qxx, k, Qxx[k], (int64_t)n * n);
+    get(G_Quu, k, Quu[k], (int64_t)m * m);
+    get(G_Qux, k, Qux[k], (int64_t)m * n);
+    get(G_Qx, k, Qx[k], n);
+    get(G_Qu, k, Qu[k], m);
+    get(G_Qxx_tmp, k, Qxx_tmp[k], (int64_t)n * n);
+    get(G_Quu_tmp, k, Quu_tmp[k], (int64_t)m * m);
+    get(G_Qux_tmp, k, Qux_tmp[k], (int64_t)m * n);
+    get(G_Qx_tmp, k, Qx_tmp[k], n);
+    if (!failed_here) get(G_Qu_tmp, k, Qu_tmp[k], m);
+  }
+  delta_V[0] = hs[L.total - 4];
+  delta_V[1] = hs[L.total - 3];
+  return status;
+}
+
+int tvlqr_ForwardPass(const int* nx, const int* nu, int num_horizon, const lqr_float* const* A,
+                      const lqr_float* const* B, const lqr_float* const* f, const lqr_float* const* K,
+                      const lqr_float* const* d, const lqr_float* const* P, const lqr_float* const* p,
+                      const lqr_float* x0, lqr_float** x, lqr_float** u, lqr_float** y) {
+  if (!have_device()) return TVLQR_NO_DEVICE;
+  const int N = num_horizon;
+  Workspace& w = g_ws;
+  const Layout L = make_layout(nx, nu, N, false);
+  if (prepare(w, L, nx, nu)) return TVLQR_NO_DEVICE;
+  double* hs = w.host.data();
+  auto put = [&](int arr, int k, const double* src, int64_t cnt) {
+    if (src && cnt) memcpy(hs + L.off[(size_t)k * G_NUM + arr], src, sizeof(double) * cnt);
+  };
+  for (int k = 0; k <= N; ++k) {
+    const int n = nx[k];
+    if (y) {
+      put(G_P, k, P[k], (int64_t)n * n);
+      put(G_p, k, p[k], n);
+    }
+    if (k < N) {
+      const int m = nu[k], n2 = nx[k + 1];
+      put(G_A, k, A[k], (int64_t)n2 * n);
+      put(G_B, k, B[k], (int64_t)n2 * m);
+      put(G_f, k, f[k], n2);
+      put(G_K, k, K[k], (int64_t)m * n);
+      put(G_d, k, d[k], m);
+    }
+  }
+  if (hipMemcpy(w.dev, hs, (size_t)L.total * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return TVLQR_NO_DEVICE;
+  double* dev_x0 = w.dev + L.total - 36;
+  if (hipMemcpy(dev_x0, x0, sizeof(double) * nx[0], hipMemcpyHostToDevice) != hipSuccess) return TVLQR_NO_DEVICE;
+  GenericArgs<double> a = make_args(w, L, 0.0, false, y ? 1 : 0);
+  a.x0 = dev_x0;
+  const size_t lds = (size_t)(2 * a.nmax + a.mmax) * sizeof(double) + 64;
+  hipLaunchKernelGGL(generic_forward_kernel<double>, dim3(1), dim3(64), lds, 0, a);
+  if (hipGetLastError() != hipSuccess) return TVLQR_NO_DEVICE;
+  if (hipMemcpy(hs, w.dev, (size_t)L.total * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return TVLQR_NO_DEVICE;
+  for (int k = 0; k <= N; ++k) {
+    memcpy(x[k], hs + L.off[(size_t)k * G_NUM + G_x], sizeof(double) * nx[k]);
+    if (y) memcpy(y[k], hs + L.off[(size_t)k * G_NUM + G_y], sizeof(double) * nx[k]);
+    if (k < N) memcpy(u[k], hs + L.off[(size_t)k * G_NUM + G_u], sizeof(double) * nu[k]);
+  }
+  return TVLQR_SUCCESS;
+}

@@ -45,3 +45,15 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".h", ".hpp")):
                 txt = open(os.path.join(d, f)).read()
                 assert not bad.search(txt), os.path.join(d, f)
+
+
+def test_cpp_programs_compile_and_link():
+    """The reference-signature tvlqr_* symbols resolve from libaltro_hip.so (C++ linkage) on CPU."""
+    from tests import cpp_build
+    hipbuild.build()
+    exe = cpp_build.build("tvlqr_dropin_test")
+    assert os.path.exists(exe)
+    import subprocess
+    syms = subprocess.run(["nm", "-D", "--defined-only", altro_amd.LIB_PATH], capture_output=True, text=True).stdout
+    for mangled in ("_Z18tvlqr_BackwardPass", "_Z17tvlqr_ForwardPass", "_Z18tvlqr_TotalMemSize"):
+        assert mangled in syms, mangled

@@ -1,0 +1,13 @@
+"""The C++ boundaries on the GPU: programs under tests/cpp/ re-author the reference's own C++ tests
+against our headers (include/tvlqr/tvlqr.h, include/altro/*.hpp) and link libaltro_hip.so."""
+import pytest
+
+from tests import cpp_build
+
+pytestmark = pytest.mark.gpu
+
+
+def test_tvlqr_dropin_known_answers():
+    """src/tvlqr/test/tvlqr_test.cpp re-authored: flat buffer + pointer arrays through tvlqr_*."""
+    rc, out = cpp_build.run("tvlqr_dropin_test")
+    assert rc == 0 and out.strip().endswith("OK"), out
