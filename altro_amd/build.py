@@ -34,6 +34,8 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     units = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
+    host = os.path.join(CSRC, "host")
+    units += [os.path.join(host, f) for f in sorted(os.listdir(host)) if f.endswith(".cpp")]
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-Wno-unused-result", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + units + ["-o", LIB]
     if verbose:

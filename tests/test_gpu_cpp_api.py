@@ -11,3 +11,11 @@ def test_tvlqr_dropin_known_answers():
     """src/tvlqr/test/tvlqr_test.cpp re-authored: flat buffer + pointer arrays through tvlqr_*."""
     rc, out = cpp_build.run("tvlqr_dropin_test")
     assert rc == 0 and out.strip().endswith("OK"), out
+
+
+def test_altro_solver_cpp_api_integration():
+    """test/double_integrator_test.cpp + test/pendulum_test.cpp + test/altro_api.cpp re-authored against
+    include/altro/altro.hpp: iteration counts 3 / 5 / 9, pendulum end state, error ladder."""
+    rc, out = cpp_build.run("altro_api_test")
+    print(out)
+    assert rc == 0 and out.strip().endswith("OK"), out
