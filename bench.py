@@ -90,7 +90,8 @@ def main():
     import altro_amd
     from tests import problems
     N, n, m, batch = args.horizon, 12, 4, args.batch
-    first = rank * batch                                   # this rank's slice of the global batch
+    from altro_amd import shard as _shard
+    first, _ = _shard.shard_range(batch * world, rank, world)   # this rank's slice of the global batch
     one = problems.c1_double_integrator(1, N=N)
     x0 = 2.0 * problems.uniform01((batch, n), 21, first * n) - 1.0
 
@@ -117,19 +118,11 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    from altro_amd import shard
+    elapsed = shard.max_over_ranks(elapsed, device="cuda")
 
     # solver statistics: the only thing that ever crosses GPUs (RCCL over xGMI, latency-bound)
-    st = bt.stats()
-    ssum = torch.tensor([float(st.problems), float(st.cholesky_failures), st.sum_delta_V0, st.sum_delta_V1],
-                        dtype=torch.float64, device="cuda")
-    smax = torch.tensor([st.max_abs_xN], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(ssum, op=dist.ReduceOp.SUM)
-        dist.all_reduce(smax, op=dist.ReduceOp.MAX)
+    stats = shard.reduce_stats(bt.stats(), device="cuda")
 
     # per-kernel durations from HIP events on the handle's stream (profile mode syncs per launch, so
     # it runs after, never inside, the timed region)
@@ -181,9 +174,7 @@ def main():
                                      "GBps": bytes_b / dur_b / 1e9},
                             name_f: {"avg_ms": ms_f / nf, "algorithmic_GB": bytes_f / 1e9,
                                      "GBps": bytes_f / dur_f / 1e9}},
-                "stats": {"problems": int(ssum[0].item()), "cholesky_failures": int(ssum[1].item()),
-                          "sum_delta_V0": ssum[2].item(), "sum_delta_V1": ssum[3].item(),
-                          "max_abs_xN": smax[0].item()},
+                "stats": stats,
             },
             "roofline": {"bound": "hbm", "kernel": name_b, "achieved": bytes_b / dur_b / 1e9,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_b / dur_b / 1e9 / HBM_PEAK_GBS,
