@@ -23,4 +23,4 @@ def build(name, extra_sources=()):
 def run(name, extra_sources=(), timeout=300):
     exe = build(name, extra_sources)
     p = subprocess.run([exe], capture_output=True, text=True, timeout=timeout)
-    return p.returncode, p.stdout + p.stderr
+    return p.returncode, p.stdout, p.stderr
