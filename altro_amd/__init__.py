@@ -22,7 +22,7 @@ C_ABI_SYMBOLS = [
     "altro_hip_version", "altro_hip_last_error", "altro_hip_device_count", "altro_hip_device_info",
     "altro_hip_batch_create", "altro_hip_batch_destroy", "altro_hip_batch_plan",
     "altro_hip_batch_device_bytes", "altro_hip_set_dynamics", "altro_hip_set_cost",
-    "altro_hip_set_initial_state", "altro_hip_backward", "altro_hip_forward_ltv", "altro_hip_sweep",
+    "altro_hip_set_initial_state", "altro_hip_set_host_batch", "altro_hip_backward", "altro_hip_forward_ltv", "altro_hip_sweep",
     "altro_hip_synchronize", "altro_hip_get_K", "altro_hip_get_d", "altro_hip_get_P",
     "altro_hip_get_p", "altro_hip_get_x", "altro_hip_get_u", "altro_hip_get_y",
     "altro_hip_get_delta_V", "altro_hip_get_status", "altro_hip_get_qblocks",
@@ -83,6 +83,7 @@ def lib():
         L.altro_hip_set_dynamics.argtypes = [vp, vp, vp, vp, i, i]
         L.altro_hip_set_cost.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i]
         L.altro_hip_set_initial_state.argtypes = [vp, vp, i]
+        L.altro_hip_set_host_batch.argtypes = [vp, i]
         L.altro_hip_backward.argtypes = [vp, d]
         L.altro_hip_forward_ltv.argtypes = [vp]
         L.altro_hip_sweep.argtypes = [vp, d]
@@ -158,6 +159,9 @@ class Batch:
         keep = [_in(v) for v in (Q, R, H, q, r)]
         _check(self.L.altro_hip_set_cost(self.h, *[k[1] for k in keep], int(is_diag),
                                          int(k_stride_zero), int(batch_stride_zero)))
+
+    def set_host_batch(self, host_batch):
+        _check(self.L.altro_hip_set_host_batch(self.h, int(host_batch)))
 
     def set_initial_state(self, x0, batch_stride_zero=False):
         a, pa = _in(x0)

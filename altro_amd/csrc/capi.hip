@@ -61,6 +61,7 @@ struct altro_hip_batch {
   int* status = nullptr;
   bool dyn_set = false, cost_set = false, x0_set = false, backward_done = false, forward_done = false;
   int has_f = 0, is_diag = 0;
+  int host_batch = 0;   // > 0: host arrays of the next set_* calls hold this many problems, tiled over the batch
   // plan GENERIC: reference layout on the device
   void* g_arr[G_NUM] = {};
   int64_t g_bstride[G_NUM] = {};
@@ -68,8 +69,8 @@ struct altro_hip_batch {
   int* g_nx = nullptr;
   int* g_nu = nullptr;
   // plan MFMA16
-  double *m_in = nullptr, *m_term = nullptr, *m_out = nullptr, *m_outn = nullptr, *m_xuy = nullptr,
-         *m_qblk = nullptr, *m_trash = nullptr;
+  void *m_in = nullptr, *m_term = nullptr, *m_out = nullptr, *m_outn = nullptr, *m_xuy = nullptr,
+       *m_qblk = nullptr, *m_trash = nullptr;   // element type = handle dtype (fp32 storage allowed)
   Mfma16Strides m_st{};
   // plan LANE: batch structure-of-arrays ([k][element][batch])
   void *l_in = nullptr, *l_term = nullptr, *l_out = nullptr, *l_outn = nullptr, *l_xuy = nullptr,
@@ -152,7 +153,7 @@ int upload_chunks(altro_hip_batch* h, const double* host, int block, int nk, int
     int rc = ensure_stage(h, per_problem);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(h->stage, host, per_problem, hipMemcpyHostToDevice, h->stream));
-    SrcArr s{(const double*)h->stage + src_off, 0, k_zero ? 0 : (int64_t)block};
+    SrcArr s{(const double*)h->stage + src_off, 0, k_zero ? 0 : (int64_t)block, 0};
     rc = consume(s, 0, h->batch);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -165,7 +166,7 @@ int upload_chunks(altro_hip_batch* h, const double* host, int block, int nk, int
     const int nb = std::min(chunk, h->batch - b0);
     HIP_TRY(hipMemcpyAsync(h->stage, host + (size_t)b0 * src_nk * block, per_problem * nb,
                            hipMemcpyHostToDevice, h->stream));
-    SrcArr s{(const double*)h->stage + src_off, (int64_t)src_nk * block, k_zero ? 0 : (int64_t)block};
+    SrcArr s{(const double*)h->stage + src_off, (int64_t)src_nk * block, k_zero ? 0 : (int64_t)block, 0};
     rc = consume(s, b0, nb);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));  // the staging buffer is reused by the next chunk
@@ -176,6 +177,8 @@ int upload_chunks(altro_hip_batch* h, const double* host, int block, int nk, int
 template <typename T>
 int generic_set(altro_hip_batch* h, int arr, const double* host, int block, int nk, int k_zero,
                 int b_zero, int k0 = 0, int nk_host = -1, int src_off = 0) {
+  if (h->host_batch > 0 && h->host_batch < h->batch && !b_zero)
+    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "altro_hip_set_host_batch tiling is not available on plan GENERIC");
   // writes knot points [k0, k0+nk) of the device array from a host array that holds nk_host knot
   // points per problem (default nk, or 1 when k_zero)
   T* dst = (T*)h->g_arr[arr] + (int64_t)k0 * block;
@@ -225,9 +228,14 @@ int generic_get(altro_hip_batch* h, int arr, double* host, int block, int nk) {
 int mfma16_get(altro_hip_batch* h, int what, double* host, int block, int nk) {
   return download_chunks(h, host, block, nk, [&](double* dst, int b0, int nb) {
     const int64_t total = (int64_t)nb * nk * block;
-    hipLaunchKernelGGL(mfma16_unpack_kernel, dim3(grid_for(total)), dim3(256), 0, h->stream, dst, what,
-                       (const double*)h->m_out, (const double*)h->m_outn, (const double*)h->m_xuy,
-                       (const double*)h->m_qblk, h->m_st, h->N, b0, nb);
+    if (h->dtype == ALTRO_HIP_F64)
+      hipLaunchKernelGGL(mfma16_unpack_kernel<double>, dim3(grid_for(total)), dim3(256), 0, h->stream, dst, what,
+                         (const double*)h->m_out, (const double*)h->m_outn, (const double*)h->m_xuy,
+                         (const double*)h->m_qblk, h->m_st, h->N, b0, nb);
+    else
+      hipLaunchKernelGGL(mfma16_unpack_kernel<float>, dim3(grid_for(total)), dim3(256), 0, h->stream, dst, what,
+                         (const float*)h->m_out, (const float*)h->m_outn, (const float*)h->m_xuy,
+                         (const float*)h->m_qblk, h->m_st, h->N, b0, nb);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "mfma16_unpack launch: %s", hipGetErrorString(e));
     return 0;
@@ -238,25 +246,30 @@ int mfma16_get(altro_hip_batch* h, int what, double* host, int block, int nk) {
 // `nk_host` = knot points per problem actually present in the host array.
 struct DevSrc {
   void* dev = nullptr;
-  SrcArr s{nullptr, 0, 0};
+  SrcArr s{nullptr, 0, 0, 0};
   ~DevSrc() { if (dev) (void)hipFree(dev); }
 };
 int put_src(altro_hip_batch* h, const double* src, int blk, int nk_host, int k_zero, int b_zero,
             DevSrc* out) {
   if (!src) return 0;
   const size_t per_b = (size_t)nk_host * blk;
-  const size_t bytes = (size_t)(b_zero ? 1 : h->batch) * per_b * sizeof(double);
+  const int tiled = (!b_zero && h->host_batch > 0 && h->host_batch < h->batch) ? h->host_batch : 0;
+  const size_t bytes = (size_t)(b_zero ? 1 : (tiled ? tiled : h->batch)) * per_b * sizeof(double);
   if (hipMalloc(&out->dev, bytes) != hipSuccess)
     return fail(ALTRO_HIP_ERR_OUT_OF_MEMORY, "hipMalloc(%zu) failed", bytes);
   if (hipMemcpyAsync(out->dev, src, bytes, hipMemcpyHostToDevice, h->stream) != hipSuccess)
     return fail(ALTRO_HIP_ERR_HIP, "H2D copy failed");
-  out->s = SrcArr{(const double*)out->dev, b_zero ? 0 : (int64_t)per_b, k_zero ? 0 : (int64_t)blk};
+  out->s = SrcArr{(const double*)out->dev, b_zero ? 0 : (int64_t)per_b, k_zero ? 0 : (int64_t)blk, tiled};
   return 0;
 }
 int mfma16_pack_launch(altro_hip_batch* h, int seg, SrcArr s0, SrcArr s1) {
   const int64_t total = (int64_t)h->batch * h->N * 192;
-  hipLaunchKernelGGL(mfma16_pack_kernel, dim3(grid_for(total)), dim3(256), 0, h->stream, h->m_in,
-                     h->m_term, h->m_st, seg, s0, s1, h->is_diag, h->N, 0, h->batch);
+  if (h->dtype == ALTRO_HIP_F64)
+    hipLaunchKernelGGL(mfma16_pack_kernel<double>, dim3(grid_for(total)), dim3(256), 0, h->stream, (double*)h->m_in,
+                       (double*)h->m_term, h->m_st, seg, s0, s1, h->is_diag, h->N, 0, h->batch);
+  else
+    hipLaunchKernelGGL(mfma16_pack_kernel<float>, dim3(grid_for(total)), dim3(256), 0, h->stream, (float*)h->m_in,
+                       (float*)h->m_term, h->m_st, seg, s0, s1, h->is_diag, h->N, 0, h->batch);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "mfma16_pack launch: %s", hipGetErrorString(e));
   return 0;
@@ -298,7 +311,7 @@ int lane_pack(altro_hip_batch* h, T* dst_base, int E, const double* host, int le
   DevSrc d;
   int rc = put_src(h, host, len, nk_host, kz, bz, &d);
   if (rc) return rc;
-  LaneSeg s{d.s.p ? d.s.p + src_off : nullptr, d.s.bs, d.s.ks, len, dst_off, diag_n};
+  LaneSeg s{d.s.p ? d.s.p + src_off : nullptr, d.s.bs, d.s.ks, len, dst_off, diag_n, d.s.bmod};
   const int dlen = diag_n > 0 ? diag_n * diag_n : len;
   const int64_t total = (int64_t)h->batch * nk * dlen;
   hipLaunchKernelGGL(lane_pack_kernel<T>, dim3(grid_for(total)), dim3(256), 0, h->stream, dst_base, E, s,
@@ -449,20 +462,33 @@ int ilqr_check(altro_hip_batch* h, bool need_guess) {
   return 0;
 }
 
+template <typename S>
+Mfma16Args<S> mfma16_args(altro_hip_batch* h, double reg) {
+  Mfma16Args<S> a;
+  a.in = (const S*)h->m_in;
+  a.in_bs = h->m_st.in_bs; a.in_ks = h->m_st.in_ks; a.out_bs = h->m_st.out_bs; a.out_ks = h->m_st.out_ks;
+  a.xuy_bs = h->m_st.xuy_bs; a.xuy_ks = h->m_st.xuy_ks;
+  a.term = (const S*)h->m_term; a.out = (S*)h->m_out; a.outn = (S*)h->m_outn; a.qblk = (S*)h->m_qblk;
+  a.trash = (S*)h->m_trash; a.x0 = (const S*)h->x0; a.xuy = (S*)h->m_xuy; a.delta_V = (S*)h->delta_V;
+  a.status = h->status; a.N = h->N; a.batch = h->batch; a.reg = reg; a.has_f = h->has_f;
+  return a;
+}
+template <typename S>
+void mfma16_launch_backward(altro_hip_batch* h, double reg, bool sq) {
+  auto a = mfma16_args<S>(h, reg);
+  const dim3 grid(h->batch), block(64);
+  if (sq && h->has_f) hipLaunchKernelGGL((mfma16_backward_kernel<true, true, S>), grid, block, 0, h->stream, a);
+  else if (sq) hipLaunchKernelGGL((mfma16_backward_kernel<true, false, S>), grid, block, 0, h->stream, a);
+  else if (h->has_f) hipLaunchKernelGGL((mfma16_backward_kernel<false, true, S>), grid, block, 0, h->stream, a);
+  else hipLaunchKernelGGL((mfma16_backward_kernel<false, false, S>), grid, block, 0, h->stream, a);
+}
+
 int launch_backward(altro_hip_batch* h, double reg) {
   ProfScope ps(h, 0);
   if (h->plan == ALTRO_HIP_PLAN_MFMA16) {
-    Mfma16Args a{h->m_in, h->m_st.in_bs, h->m_st.in_ks, h->m_st.out_bs, h->m_st.out_ks, h->m_st.xuy_bs, h->m_st.xuy_ks, h->m_term, h->m_out, h->m_outn, h->m_qblk, h->m_trash, (const double*)h->x0, h->m_xuy,
-                 (double*)h->delta_V, h->status, h->N, h->batch, reg, h->has_f};
     const bool sq = (h->flags & ALTRO_HIP_STORE_QBLOCKS) != 0;
-    if (sq && h->has_f)
-      hipLaunchKernelGGL((mfma16_backward_kernel<true, true>), dim3(h->batch), dim3(64), 0, h->stream, a);
-    else if (sq)
-      hipLaunchKernelGGL((mfma16_backward_kernel<true, false>), dim3(h->batch), dim3(64), 0, h->stream, a);
-    else if (h->has_f)
-      hipLaunchKernelGGL((mfma16_backward_kernel<false, true>), dim3(h->batch), dim3(64), 0, h->stream, a);
-    else
-      hipLaunchKernelGGL((mfma16_backward_kernel<false, false>), dim3(h->batch), dim3(64), 0, h->stream, a);
+    if (h->dtype == ALTRO_HIP_F64) mfma16_launch_backward<double>(h, reg, sq);
+    else mfma16_launch_backward<float>(h, reg, sq);
   } else if (h->plan == ALTRO_HIP_PLAN_LANE) {
     return h->dtype == ALTRO_HIP_F64 ? lane_launch<double>(h, true, reg) : lane_launch<float>(h, true, reg);
   } else if (h->dtype == ALTRO_HIP_F64) {
@@ -482,9 +508,13 @@ int launch_backward(altro_hip_batch* h, double reg) {
 int launch_forward(altro_hip_batch* h) {
   ProfScope ps(h, 1);
   if (h->plan == ALTRO_HIP_PLAN_MFMA16) {
-    Mfma16Args a{h->m_in, h->m_st.in_bs, h->m_st.in_ks, h->m_st.out_bs, h->m_st.out_ks, h->m_st.xuy_bs, h->m_st.xuy_ks, h->m_term, h->m_out, h->m_outn, h->m_qblk, h->m_trash, (const double*)h->x0, h->m_xuy,
-                 (double*)h->delta_V, h->status, h->N, h->batch, 0.0, h->has_f};
-    hipLaunchKernelGGL(mfma16_forward_kernel, dim3(h->batch), dim3(64), 0, h->stream, a);
+    if (h->dtype == ALTRO_HIP_F64) {
+      auto a = mfma16_args<double>(h, 0.0);
+      hipLaunchKernelGGL(mfma16_forward_kernel<double>, dim3(h->batch), dim3(64), 0, h->stream, a);
+    } else {
+      auto a = mfma16_args<float>(h, 0.0);
+      hipLaunchKernelGGL(mfma16_forward_kernel<float>, dim3(h->batch), dim3(64), 0, h->stream, a);
+    }
   } else if (h->plan == ALTRO_HIP_PLAN_LANE) {
     return h->dtype == ALTRO_HIP_F64 ? lane_launch<double>(h, false, 0.0) : lane_launch<float>(h, false, 0.0);
   } else if (h->dtype == ALTRO_HIP_F64) {
@@ -535,11 +565,11 @@ int altro_hip_batch_create(altro_hip_batch** out, int N, int n, int m, int batch
   if (dtype != ALTRO_HIP_F64 && dtype != ALTRO_HIP_F32) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "bad dtype %d", dtype);
   if (altro_hip_device_count() <= device || device < 0)
     return fail(ALTRO_HIP_ERR_NO_DEVICE, "no HIP device %d: the altro_hip hot path has no CPU fallback", device);
-  const bool mfma_ok = (n == 12 && m == 4 && dtype == ALTRO_HIP_F64);
+  const bool mfma_ok = (n == 12 && m == 4);   // fp32 handles: fp32 storage, fp64 tile arithmetic
   if (plan == ALTRO_HIP_PLAN_AUTO)
     plan = mfma_ok ? ALTRO_HIP_PLAN_MFMA16 : (lane_supported(n, m) ? ALTRO_HIP_PLAN_LANE : ALTRO_HIP_PLAN_GENERIC);
   if (plan == ALTRO_HIP_PLAN_MFMA16 && !mfma_ok)
-    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "plan MFMA16 needs (n, m, dtype) = (12, 4, f64)");
+    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "plan MFMA16 needs (n, m) = (12, 4)");
   if (plan == ALTRO_HIP_PLAN_LANE && !lane_supported(n, m))
     return fail(ALTRO_HIP_ERR_UNSUPPORTED, "plan LANE is instantiated for (n, m) in {(2,1), (3,1), (4,2), (6,3)}");
   if (plan != ALTRO_HIP_PLAN_MFMA16 && plan != ALTRO_HIP_PLAN_GENERIC && plan != ALTRO_HIP_PLAN_LANE)
@@ -564,7 +594,7 @@ int altro_hip_batch_create(altro_hip_batch** out, int N, int n, int m, int batch
   ALLOC(h->delta_V, B * 2 * E);
   ALLOC(h->status, B * sizeof(int));
   if (plan == ALTRO_HIP_PLAN_MFMA16) {
-    ALLOC(h->m_in, B * N * MF_IN * 8);
+    ALLOC(h->m_in, B * N * MF_IN * E);
     {
       // default: knot-point-major slabs [k][b][record]; ALTRO_HIP_LAYOUT=bk selects problem-major
       const char* lay = getenv("ALTRO_HIP_LAYOUT");
@@ -574,12 +604,12 @@ int altro_hip_batch_create(altro_hip_batch** out, int N, int n, int m, int batch
                    : Mfma16Strides{(int64_t)N * MF_IN, MF_IN, (int64_t)N * MF_OUT, MF_OUT, (int64_t)(N + 1) * 28, 28};
       if (lay && lay[0] == 's') { h->m_st.in_bs = 0; h->m_st.in_ks = 0; }   // experiment: one shared IN record
     }
-    ALLOC(h->m_term, B * MF_TERM * 8);
-    ALLOC(h->m_out, B * N * MF_OUT * 8);
-    ALLOC(h->m_outn, B * MF_TERM * 8);
-    ALLOC(h->m_xuy, B * (N + 1) * 28 * 8);
-    ALLOC(h->m_trash, B * MF_OUT * 8);
-    if (flags & ALTRO_HIP_STORE_QBLOCKS) ALLOC(h->m_qblk, B * N * MF_QB * 8);
+    ALLOC(h->m_term, B * MF_TERM * E);
+    ALLOC(h->m_out, B * N * MF_OUT * E);
+    ALLOC(h->m_outn, B * MF_TERM * E);
+    ALLOC(h->m_xuy, B * (N + 1) * 28 * E);
+    ALLOC(h->m_trash, B * MF_OUT * E);
+    if (flags & ALTRO_HIP_STORE_QBLOCKS) ALLOC(h->m_qblk, B * N * MF_QB * E);
   } else if (plan == ALTRO_HIP_PLAN_LANE) {
     const LaneSizes z = lane_sizes(n, m);
     ALLOC(h->l_in, B * N * z.e_in * E);
@@ -667,7 +697,7 @@ int altro_hip_set_dynamics(altro_hip_batch* h, const double* A, const double* B,
     if (!rc) rc = put_src(h, B, n * m, nkh, kz, bz, &dB);
     if (!rc) rc = put_src(h, f, n, nkh, kz, bz, &df);
     if (!rc) rc = mfma16_pack_launch(h, MSEG_Z, dA.s, dB.s);
-    if (!rc) rc = mfma16_pack_launch(h, MSEG_F, df.s, SrcArr{nullptr, 0, 0});
+    if (!rc) rc = mfma16_pack_launch(h, MSEG_F, df.s, SrcArr{nullptr, 0, 0, 0});
     if (!rc) HIP_TRY(hipStreamSynchronize(h->stream));
   } else if (h->plan == ALTRO_HIP_PLAN_LANE) {
     const LaneSizes z = lane_sizes(n, m);
@@ -719,7 +749,7 @@ int altro_hip_set_cost(altro_hip_batch* h, const double* Q, const double* R, con
     if (!rc && !is_diag) rc = put_src(h, H, d.H(), nkR, kz, bz, &dH);
     if (!rc) rc = put_src(h, q, n, nkQ, kz, bz, &dq);
     if (!rc) rc = put_src(h, r, m, nkR, kz, bz, &dr);
-    SrcArr none{nullptr, 0, 0};
+    SrcArr none{nullptr, 0, 0, 0};
     SrcArr tQ = dQ.s, tq = dq.s;  // terminal views: knot point N, or block 1 of the broadcast pair
     if (kz) { tQ.p += d.Q(is_diag); tq.p += n; }
     if (!rc) rc = mfma16_pack_launch(h, MSEG_Q, dQ.s, none);
@@ -785,6 +815,12 @@ int altro_hip_set_cost(altro_hip_batch* h, const double* Q, const double* R, con
   }
   if (!rc) { HIP_TRY(hipStreamSynchronize(h->stream)); h->cost_set = true; }
   return rc;
+}
+
+int altro_hip_set_host_batch(altro_hip_batch* h, int host_batch) {
+  if (!h || host_batch < 0) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "bad handle or host_batch");
+  h->host_batch = host_batch;
+  return 0;
 }
 
 int altro_hip_set_initial_state(altro_hip_batch* h, const double* x0, int bz) {

@@ -13,7 +13,9 @@ namespace altro_hip {
 struct SrcArr {
   const double* p;   // device pointer, reference layout, relative to the chunk's first problem
   int64_t bs, ks;    // strides in elements between problems / knot points (0 = broadcast)
+  int bmod;          // > 0: the source holds only `bmod` distinct problems, tiled over the batch
 };
+__device__ __forceinline__ int64_t src_b(const SrcArr& s, int b) { return s.bmod > 0 ? (b % s.bmod) : b; }
 
 // dst[(b0+b)*dst_bs + k*dst_ks + e] = src[b*bs + k*ks + e],  e < block, k < nk, b < nb
 template <typename T>
@@ -26,7 +28,7 @@ __global__ void expand_copy_kernel(T* dst, int64_t dst_bs, int64_t dst_ks, SrcAr
     const int k = (int)((t / block) % nk);
     const int b = (int)(t / ((int64_t)block * nk));
     dst[(int64_t)(b0 + b) * dst_bs + (int64_t)k * dst_ks + e] =
-        (T)src.p[(int64_t)b * src.bs + (int64_t)k * src.ks + e];
+        (T)src.p[(src.bmod > 0 ? src_b(src, b0 + b) : (int64_t)b) * src.bs + (int64_t)k * src.ks + e];
   }
 }
 
@@ -52,7 +54,8 @@ enum Mfma16Seg { MSEG_Z = 0, MSEG_F, MSEG_Q, MSEG_HR, MSEG_QR, MSEG_TERM_Q, MSEG
 
 // One launch fills one segment of IN (or TERM) for problems [b0, b0+nb).  `s0`, `s1` are the one or
 // two reference arrays the segment draws from (Z: A,B ; HR: H,R ; QR: q,r).
-__global__ void mfma16_pack_kernel(double* in, double* term, Mfma16Strides st, int seg, SrcArr s0,
+template <typename S>
+__global__ void mfma16_pack_kernel(S* in, S* term, Mfma16Strides st, int seg, SrcArr s0,
                                    SrcArr s1, int is_diag, int N, int b0, int nb) {
   int len, base;
   switch (seg) {
@@ -72,8 +75,8 @@ __global__ void mfma16_pack_kernel(double* in, double* term, Mfma16Strides st, i
     const int e = (int)(t % len);
     const int k = terminal ? N : (int)((t / len) % nk);
     const int b = (int)(t / ((int64_t)len * nk));
-    const double* p0 = s0.p ? s0.p + (int64_t)b * s0.bs + (int64_t)k * s0.ks : nullptr;
-    const double* p1 = s1.p ? s1.p + (int64_t)b * s1.bs + (int64_t)k * s1.ks : nullptr;
+    const double* p0 = s0.p ? s0.p + src_b(s0, b0 + b) * s0.bs + (int64_t)k * s0.ks : nullptr;
+    const double* p1 = s1.p ? s1.p + src_b(s1, b0 + b) * s1.bs + (int64_t)k * s1.ks : nullptr;
     double v = 0.0;
     switch (seg) {
       case MSEG_Z: {  // Zfrag[c][lane] = Z[4c + (lane>>4)][lane&15],  Z = [A B]
@@ -94,16 +97,17 @@ __global__ void mfma16_pack_kernel(double* in, double* term, Mfma16Strides st, i
       case MSEG_QR: v = (e < 12) ? p0[e] : p1[e - 12]; break;
       default: v = p0[e]; break;  // MSEG_TERM_q
     }
-    if (terminal) term[(int64_t)(b0 + b) * MF_TERM + base + e] = v;
-    else in[(int64_t)(b0 + b) * st.in_bs + (int64_t)k * st.in_ks + base + e] = v;
+    if (terminal) term[(int64_t)(b0 + b) * MF_TERM + base + e] = (S)v;
+    else in[(int64_t)(b0 + b) * st.in_bs + (int64_t)k * st.in_ks + base + e] = (S)v;
   }
 }
 
 enum Mfma16Get { MGET_K = 0, MGET_d, MGET_P, MGET_p, MGET_x, MGET_u, MGET_y, MGET_QBLK };
 
 // Reference-layout view of the results for problems [b0, b0+nb): dst is [nb][nk][len].
-__global__ void mfma16_unpack_kernel(double* dst, int what, const double* out, const double* outn,
-                                     const double* xuy, const double* qblk, Mfma16Strides st, int N,
+template <typename S>
+__global__ void mfma16_unpack_kernel(double* dst, int what, const S* out, const S* outn,
+                                     const S* xuy, const S* qblk, Mfma16Strides st, int N,
                                      int b0, int nb) {
   int len, nk;
   switch (what) {
@@ -122,20 +126,20 @@ __global__ void mfma16_unpack_kernel(double* dst, int what, const double* out, c
     const int e = (int)(t % len);
     const int k = (int)((t / len) % nk);
     const int b = b0 + (int)(t / ((int64_t)len * nk));
-    const double* o = (k < N) ? out + (int64_t)b * st.out_bs + (int64_t)k * st.out_ks : nullptr;
-    const double* pp = (k < N) ? o + MF_OFF_P : outn + (int64_t)b * MF_TERM;
-    const double* xr = xuy ? xuy + (int64_t)b * st.xuy_bs + (int64_t)k * st.xuy_ks : nullptr;
+    const S* o = (k < N) ? out + (int64_t)b * st.out_bs + (int64_t)k * st.out_ks : nullptr;
+    const S* pp = (k < N) ? o + MF_OFF_P : outn + (int64_t)b * MF_TERM;
+    const S* xr = xuy ? xuy + (int64_t)b * st.xuy_bs + (int64_t)k * st.xuy_ks : nullptr;
     double v;
     switch (what) {
-      case MGET_K: v = o[(e % 4) * 13 + (e / 4)]; break;        // K[a + 4 j] = Kt[a][j]
-      case MGET_d: v = -o[e * 13 + 12]; break;                  // d = -Kt[:, 12]
+      case MGET_K: v = (double)o[(e % 4) * 13 + (e / 4)]; break;        // K[a + 4 j] = Kt[a][j]
+      case MGET_d: v = -(double)o[e * 13 + 12]; break;                  // d = -Kt[:, 12]
       case MGET_P: v = pp[(e % 12) * 13 + (e / 12)]; break;     // P[i + 12 j] = tile[i][j]
       case MGET_p: v = pp[e * 13 + 12]; break;
       case MGET_x: v = xr[e]; break;
       case MGET_y: v = xr[12 + e]; break;
       case MGET_u: v = xr[24 + e]; break;
       default: {  // Qxx(144) | Quu(16) | Qux(48) | Qx(12) | Qu(4), column-major blocks
-        const double* q = qblk + ((int64_t)b * N + k) * MF_QB;
+        const S* q = qblk + ((int64_t)b * N + k) * MF_QB;
         if (e < 144) v = q[(e % 12) * 16 + (e / 12)];
         else if (e < 160) { int t2 = e - 144; v = q[(12 + t2 % 4) * 16 + 12 + t2 / 4]; }
         else if (e < 208) { int t2 = e - 160; v = q[(12 + t2 % 4) * 16 + t2 / 4]; }

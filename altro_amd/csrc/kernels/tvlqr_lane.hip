@@ -358,6 +358,7 @@ struct LaneSeg {   // one reference-layout source array -> a run of `len` elemen
   int len;         // elements per knot point in the source (n when a diagonal is expanded to n*n)
   int dst_off;     // first element index inside the destination record
   int diag_n;      // > 0: source holds a diagonal of this size, destination is the dense diag_n^2 block
+  int bmod;        // > 0: the source holds only `bmod` distinct problems, tiled over the batch
 };
 
 // dst[(k*E + dst_off + e)*batch + b]  <-  src[b*bs + k*ks + e]
@@ -368,15 +369,16 @@ __global__ void lane_pack_kernel(T* dst, int E, LaneSeg s, int nk, int k0, int b
   for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
        t += (int64_t)gridDim.x * blockDim.x) {
     const int b = (int)(t % batch);
+    const int sb = s.bmod > 0 ? (b % s.bmod) : b;
     const int e = (int)((t / batch) % dlen);
     const int k = (int)(t / ((int64_t)batch * dlen));
     double v;
     if (!s.p) v = 0.0;
     else if (s.diag_n > 0) {
       const int i = e % s.diag_n, j = e / s.diag_n;
-      v = (i == j) ? s.p[(int64_t)b * s.bs + (int64_t)(k0 + k) * s.ks + i] : 0.0;
+      v = (i == j) ? s.p[(int64_t)sb * s.bs + (int64_t)(k0 + k) * s.ks + i] : 0.0;
     } else {
-      v = s.p[(int64_t)b * s.bs + (int64_t)(k0 + k) * s.ks + e];
+      v = s.p[(int64_t)sb * s.bs + (int64_t)(k0 + k) * s.ks + e];
     }
     dst[((int64_t)k * E + s.dst_off + e) * batch + b] = (T)v;
   }

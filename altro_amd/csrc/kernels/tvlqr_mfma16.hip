@@ -86,20 +86,23 @@ __device__ __forceinline__ double group4_allreduce(double v) {
   return v;
 }
 
+// S = storage type of the HBM arrays (double, or float for ALTRO_HIP_F32 handles: fp32 storage with
+// fp64 tile arithmetic -- half the bytes, same kernels; element order and record sizes are unchanged).
+template <typename S>
 struct Mfma16Args {
-  const double* in;      // IN
+  const S* in;           // IN
   // Element strides between problems (bs) / knot points (ks) of IN, OUT and the forward output.
   // Knot-point-major ([k][b][record]: bs = record, ks = batch*record) keeps all the records touched at
   // one time step in one contiguous slab of HBM (the batch structure-of-arrays picture); 0 = shared.
   int64_t in_bs, in_ks, out_bs, out_ks, xuy_bs, xuy_ks;
-  const double* term;    // TERM
-  double* out;           // OUT
-  double* outn;          // OUTN
-  double* qblk;          // optional [b][k][MF_QB]
-  double* trash;         // [b][MF_OUT] dump record for the masked stores of failed problems
-  const double* x0;      // [b][12]
-  double* xuy;           // forward output [b][k][28] = x 12 | y 12 | u 4 ; terminal [b][N][..]
-  double* delta_V;       // [b][2]
+  const S* term;         // TERM
+  S* out;                // OUT
+  S* outn;               // OUTN
+  S* qblk;               // optional [b][k][MF_QB]
+  S* trash;              // [b][MF_OUT] dump record for the masked stores of failed problems
+  const S* x0;           // [b][12]
+  S* xuy;                // forward output [b][k][28] = x 12 | y 12 | u 4 ; terminal [b][N][..]
+  S* delta_V;            // [b][2]
   int* status;           // [b]
   int N;
   int batch;
@@ -117,19 +120,19 @@ struct Mfma16Knot {  // one knot point's inputs, in registers (11 doubles / lane
 // All loads are unconditional and branch-free (lanes that have no element read a clamped, valid
 // address and discard it): exec-masked load branches make hipcc's s_waitcnt insertion collapse to
 // vmcnt(0) at the loop head, which serialises the prefetch against its own issue.
-template <bool HAS_F>
-__device__ __forceinline__ void mfma16_load_knot(Mfma16Knot& kn, const double* __restrict__ rec,
+template <bool HAS_F, typename S>
+__device__ __forceinline__ void mfma16_load_knot(Mfma16Knot& kn, const S* __restrict__ rec,
                                                  int lane, int j, int g) {
   const int jq = (j < 12) ? j : 11;
 #pragma unroll
-  for (int c = 0; c < 3; ++c) kn.z[c] = rec[MF_OFF_Z + c * 64 + lane];
+  for (int c = 0; c < 3; ++c) kn.z[c] = (double)rec[MF_OFF_Z + c * 64 + lane];
 #pragma unroll
-  for (int r = 0; r < 3; ++r) kn.q[r] = rec[MF_OFF_Q + r * 48 + g * 12 + jq];
-  kn.hr = rec[MF_OFF_HR + lane];
-  kn.qr = rec[MF_OFF_QR + j];
+  for (int r = 0; r < 3; ++r) kn.q[r] = (double)rec[MF_OFF_Q + r * 48 + g * 12 + jq];
+  kn.hr = (double)rec[MF_OFF_HR + lane];
+  kn.qr = (double)rec[MF_OFF_QR + j];
   if (HAS_F) {
 #pragma unroll
-    for (int r = 0; r < 3; ++r) kn.f[r] = rec[MF_OFF_F + g + 4 * r];
+    for (int r = 0; r < 3; ++r) kn.f[r] = (double)rec[MF_OFF_F + g + 4 * r];
   } else {
     kn.f[0] = kn.f[1] = kn.f[2] = 0.0;
   }
@@ -146,18 +149,18 @@ __device__ __forceinline__ double rsqrt_nr(double x) {
   return __builtin_fma(y * e, t, y);
 }
 
-template <bool STORE_Q, bool HAS_F>
-__global__ __launch_bounds__(64, 4) void mfma16_backward_kernel(Mfma16Args a) {
+template <bool STORE_Q, bool HAS_F, typename S>
+__global__ __launch_bounds__(64, 4) void mfma16_backward_kernel(Mfma16Args<S> a) {
   // the one and only LDS object: 4x16 tile [Qux | Quu] then [Qx | Qu]
-  // S[0..63] = [Qux | Quu] (row g, col j), S[64..79] = [Qx | Qu], S[80] = 0.0 (the "zero slot" padding
+  // lds[0..63] = [Qux | Quu] (row g, col j), lds[64..79] = [Qx | Qu], lds[80] = 0.0 (the "zero slot" padding
   // lanes read instead of selecting: their loop-invariant LDS addresses point here)
-  __shared__ __attribute__((aligned(16))) double S[64 + 16 + 2];
+  __shared__ __attribute__((aligned(16))) double lds[64 + 16 + 2];
   const int lane = threadIdx.x;
   const int j = lane & 15, g = lane >> 4;
   const int b = blockIdx.x;
   if (b >= a.batch) return;
   const int N = a.N;
-  if (lane < 2) S[80 + lane] = 0.0;
+  if (lane < 2) lds[80 + lane] = 0.0;
   // loop-invariant LDS read addresses (element indices into S)
   int rhs_idx[4];   // column j of Qt = [Qux | Qu]; zero for the padding columns 13..15
 #pragma unroll
@@ -166,24 +169,24 @@ __global__ __launch_bounds__(64, 4) void mfma16_backward_kernel(Mfma16Args a) {
   int qx_idx[3];    // column 12 of [Qxx | Qx]: Qx[g + 4r]; zero for columns 13..15 (unused for j < 12)
 #pragma unroll
   for (int r = 0; r < 3; ++r) qx_idx[r] = (j == 12) ? (64 + g + 4 * r) : 80;
-  const double* __restrict__ in = a.in + (size_t)b * a.in_bs;
-  double* __restrict__ out = a.out + (size_t)b * a.out_bs;
+  const S* __restrict__ in = a.in + (size_t)b * a.in_bs;
+  S* __restrict__ out = a.out + (size_t)b * a.out_bs;
   const bool col_ok = (j <= 12);
   const int jc = col_ok ? j : 12;
-  double* __restrict__ trash = a.trash + (size_t)b * MF_OUT;
+  S* __restrict__ trash = a.trash + (size_t)b * MF_OUT;
 
   // terminal cost-to-go: P_N = Q_N, p_N = q_N (tvlqr.cpp:81-90) -> tile [P | p]
   double Pt[3];
   {
-    const double* term = a.term + (size_t)b * MF_TERM;
-    double* on = a.outn + (size_t)b * MF_TERM;
+    const S* term = a.term + (size_t)b * MF_TERM;
+    S* on = a.outn + (size_t)b * MF_TERM;
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
       double v = 0.0;
-      if (j < 12) v = term[r * 48 + g * 12 + j];
-      else if (j == 12) v = term[144 + g + 4 * r];
+      if (j < 12) v = (double)term[r * 48 + g * 12 + j];
+      else if (j == 12) v = (double)term[144 + g + 4 * r];
       Pt[r] = v;
-      if (col_ok) on[(g + 4 * r) * 13 + j] = v;
+      if (col_ok) on[(g + 4 * r) * 13 + j] = (S)v;
     }
   }
   // per-lane partial sums of the expected decrease; only column 12 is meaningful, reduced at the end
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(64, 4) void mfma16_backward_kernel(Mfma16Args a) {
   int fail_k = -1;
 
   Mfma16Knot cur, nxt;
-  mfma16_load_knot<HAS_F>(cur, in + (size_t)(N - 1) * a.in_ks, lane, j, g);
+  mfma16_load_knot<HAS_F, S>(cur, in + (size_t)(N - 1) * a.in_ks, lane, j, g);
   // Drain the VMEM queue before entering the loop: hipcc merges the pre-header's scoreboard into the
   // loop header's, and a pending first load there turns into `s_waitcnt vmcnt(0)` at the top of EVERY
   // iteration -- which would drain each step's stores before the next step may start.
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(64, 4) void mfma16_backward_kernel(Mfma16Args a) {
 
   for (int k = N - 1; k >= 0; --k) {
     // prefetch the next knot point (k-1) while this one computes (k == 0 re-reads record 0: harmless)
-    mfma16_load_knot<HAS_F>(nxt, in + (size_t)((k > 0) ? k - 1 : 0) * a.in_ks, lane, j, g);
+    mfma16_load_knot<HAS_F, S>(nxt, in + (size_t)((k > 0) ? k - 1 : 0) * a.in_ks, lane, j, g);
 
     // ---- D1 = [P'|t]^T Z : rows 0..11 = P'^T Z, row 12 = t^T Z --------------------------------
     f64x4 D1 = {0.0, 0.0, 0.0, 0.0};
@@ -222,28 +225,28 @@ __global__ __launch_bounds__(64, 4) void mfma16_backward_kernel(Mfma16Args a) {
 
     // ---- LDS exchange ------------------------------------------------------------------------------
     __syncthreads();  // previous iteration's readers are done (single-wave block: free)
-    S[lane] = G[3];                 // [Qux | Quu], row g, col j
-    if (g == 0) S[64 + j] = gv;     // [Qx | Qu]
+    lds[lane] = G[3];                 // [Qux | Quu], row g, col j
+    if (g == 0) lds[64 + j] = gv;     // [Qx | Qu]
     __syncthreads();
     // lower triangle of Quu (Eigen's LLT<Lower> reads only that), same in every lane
-    const double a00 = S[0 * 16 + 12];
-    const double a10 = S[1 * 16 + 12], a11 = S[1 * 16 + 13];
-    const double a20 = S[2 * 16 + 12], a21 = S[2 * 16 + 13], a22 = S[2 * 16 + 14];
-    const double a30 = S[3 * 16 + 12], a31 = S[3 * 16 + 13], a32 = S[3 * 16 + 14], a33 = S[3 * 16 + 15];
+    const double a00 = lds[0 * 16 + 12];
+    const double a10 = lds[1 * 16 + 12], a11 = lds[1 * 16 + 13];
+    const double a20 = lds[2 * 16 + 12], a21 = lds[2 * 16 + 13], a22 = lds[2 * 16 + 14];
+    const double a30 = lds[3 * 16 + 12], a31 = lds[3 * 16 + 13], a32 = lds[3 * 16 + 14], a33 = lds[3 * 16 + 15];
     double rhs[4];  // column j of Qt = [Qux | Qu]
 #pragma unroll
-    for (int r = 0; r < 4; ++r) rhs[r] = S[rhs_idx[r]];
+    for (int r = 0; r < 4; ++r) rhs[r] = lds[rhs_idx[r]];
     double quu_row[4];  // row g of the UNregularised Quu
 #pragma unroll
-    for (int c = 0; c < 4; ++c) quu_row[c] = S[g * 16 + 12 + c];
+    for (int c = 0; c < 4; ++c) quu_row[c] = lds[g * 16 + 12 + c];
     f64x4 Pn;           // accumulator init: column j of [Qxx | Qx], rows g + 4r
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-      const double qx = S[qx_idx[r]];
+      const double qx = lds[qx_idx[r]];
       Pn[r] = (j < 12) ? G[r] : qx;
     }
     Pn[3] = 0.0;
-    const double q_mine = S[qmine_idx];  // Qt[g][j] (0 in the padding columns)
+    const double q_mine = lds[qmine_idx];  // Qt[g][j] (0 in the padding columns)
 
     // ---- Cholesky of Quu + reg I (lower; fail when a pivot is <= 0: tvlqr.cpp:159-164) -----------
     // Only the reciprocal pivots i_k = 1/L_kk are needed by the substitutions below.
@@ -298,16 +301,16 @@ __global__ __launch_bounds__(64, 4) void mfma16_backward_kernel(Mfma16Args a) {
     // and a failed problem's stores are redirected to its trash record.  With no exec-masked VMEM in
     // the loop hipcc can count the queue exactly and wait for the prefetch with vmcnt(#younger ops)
     // instead of draining the stores too.
-    double* __restrict__ ok_ = was_alive ? out + (size_t)k * a.out_ks : trash;
-    double* __restrict__ op_ = alive ? out + (size_t)k * a.out_ks : trash;
-    ok_[g * 13 + jc] = dpp_col12_dup(k_store);
+    S* __restrict__ ok_ = was_alive ? out + (size_t)k * a.out_ks : trash;
+    S* __restrict__ op_ = alive ? out + (size_t)k * a.out_ks : trash;
+    ok_[g * 13 + jc] = (S)dpp_col12_dup(k_store);
 #pragma unroll
-    for (int r = 0; r < 3; ++r) op_[MF_OFF_P + (g + 4 * r) * 13 + jc] = dpp_col12_dup(Pn[r]);
+    for (int r = 0; r < 3; ++r) op_[MF_OFF_P + (g + 4 * r) * 13 + jc] = (S)dpp_col12_dup(Pn[r]);
     if (STORE_Q && was_alive) {  // Qxx_, Quu_, Qux_, Qx_, Qu_ are API-visible in the reference
-      double* qb = a.qblk + ((size_t)b * N + k) * MF_QB;
+      S* qb = a.qblk + ((size_t)b * N + k) * MF_QB;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) qb[(g + 4 * r) * 16 + j] = G[r];
-      if (g == 0) qb[256 + j] = gv;
+      for (int r = 0; r < 4; ++r) qb[(g + 4 * r) * 16 + j] = (S)G[r];
+      if (g == 0) qb[256 + j] = (S)gv;
     }
 #pragma unroll
     for (int r = 0; r < 3; ++r) Pt[r] = Pn[r];   // columns 13..15 are exactly 0 by construction
@@ -316,8 +319,8 @@ __global__ __launch_bounds__(64, 4) void mfma16_backward_kernel(Mfma16Args a) {
     const double t0 = group4_allreduce(dv0), t1 = group4_allreduce(dv1);
     if (j == 12 && g == 0) {
       a.status[b] = fail_k;   // -1 == TVLQR_SUCCESS, else the failing knot point
-      a.delta_V[2 * (size_t)b + 0] = t0;
-      a.delta_V[2 * (size_t)b + 1] = t1;
+      a.delta_V[2 * (size_t)b + 0] = (S)t0;
+      a.delta_V[2 * (size_t)b + 1] = (S)t1;
     }
   }
 }
@@ -332,38 +335,40 @@ struct Mfma16FwdKnot {
   double z[3], f[3], kt, p[3];
 };
 
-__device__ __forceinline__ void mfma16_load_fwd(Mfma16FwdKnot& kn, const double* rec,
-                                                const double* orec, int lane, int j, int g) {
+template <typename S>
+__device__ __forceinline__ void mfma16_load_fwd(Mfma16FwdKnot& kn, const S* rec, const S* orec, int lane,
+                                                int j, int g) {
 #pragma unroll
-  for (int c = 0; c < 3; ++c) kn.z[c] = rec[MF_OFF_Z + c * 64 + lane];
+  for (int c = 0; c < 3; ++c) kn.z[c] = (double)rec[MF_OFF_Z + c * 64 + lane];
 #pragma unroll
-  for (int r = 0; r < 3; ++r) kn.f[r] = rec[MF_OFF_F + g + 4 * r];
+  for (int r = 0; r < 3; ++r) kn.f[r] = (double)rec[MF_OFF_F + g + 4 * r];
   const int jc = (j <= 12) ? j : 12;   // clamped: no exec-masked load branches (see backward)
-  const double kt = orec[g * 13 + jc];
+  const double kt = (double)orec[g * 13 + jc];
   kn.kt = (j <= 12) ? kt : 0.0;
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
-    const double pv = orec[MF_OFF_P + (g + 4 * r) * 13 + jc];
+    const double pv = (double)orec[MF_OFF_P + (g + 4 * r) * 13 + jc];
     kn.p[r] = (j <= 12) ? pv : 0.0;
   }
 }
 
-__global__ __launch_bounds__(64) void mfma16_forward_kernel(Mfma16Args a) {
-  __shared__ __attribute__((aligned(16))) double S[16];
+template <typename S>
+__global__ __launch_bounds__(64) void mfma16_forward_kernel(Mfma16Args<S> a) {
+  __shared__ __attribute__((aligned(16))) double lds[16];
   const int lane = threadIdx.x;
   const int j = lane & 15, g = lane >> 4;
   const int b = blockIdx.x;
   if (b >= a.batch) return;
   const int N = a.N;
-  const double* in = a.in + (size_t)b * a.in_bs;
-  const double* out = a.out + (size_t)b * a.out_bs;
-  double* xuy = a.xuy + (size_t)b * a.xuy_bs;
+  const S* in = a.in + (size_t)b * a.in_bs;
+  const S* out = a.out + (size_t)b * a.out_bs;
+  S* xuy = a.xuy + (size_t)b * a.xuy_bs;
   // Every store below is executed by ALL lanes (lanes that hold a replica write the same value to the
   // same address): no exec-masked VMEM/LDS in the loop, so hipcc can count vmcnt exactly.
   const int xu_off = (j < 12) ? j : 24 + (j - 12);   // x_k[j] | u_k[j-12] inside a 28-double record
 
   // x~ = [x; 1] in column layout
-  double xc = (j < 12) ? a.x0[(size_t)b * 12 + j] : ((j == 12) ? 1.0 : 0.0);
+  double xc = (j < 12) ? (double)a.x0[(size_t)b * 12 + j] : ((j == 12) ? 1.0 : 0.0);
   Mfma16FwdKnot cur, nxt;
   mfma16_load_fwd(cur, in, out, lane, j, g);
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see the backward kernel's pre-loop drain
@@ -372,7 +377,7 @@ __global__ __launch_bounds__(64) void mfma16_forward_kernel(Mfma16Args a) {
       const int kn = (k + 1 < N) ? k + 1 : k;   // last step re-reads itself: harmless, branch-free
       mfma16_load_fwd(nxt, in + (size_t)kn * a.in_ks, out + (size_t)kn * a.out_ks, lane, j, g);
     }
-    double* o = xuy + (size_t)k * a.xuy_ks;
+    S* o = xuy + (size_t)k * a.xuy_ks;
     // u[g] = -(Kt x~)[g] = d - K x
     const double ug = -row16_allreduce(cur.kt * xc);
     // y[g+4r] = ([P p] x~)[g+4r]
@@ -381,9 +386,9 @@ __global__ __launch_bounds__(64) void mfma16_forward_kernel(Mfma16Args a) {
     for (int r = 0; r < 3; ++r) yr[r] = row16_allreduce(cur.p[r] * xc);
     // z = [x; u] in column layout: u[a] lives in row group a -> hop through LDS
     __syncthreads();
-    S[12 + g] = ug;
+    lds[12 + g] = ug;
     __syncthreads();
-    const double su = S[(j < 12) ? 12 : j];
+    const double su = lds[(j < 12) ? 12 : j];
     const double zc = (j < 12) ? xc : su;
     // x+[g+4c] = f + (Z z)[g+4c]
     double xr[3];
@@ -392,28 +397,28 @@ __global__ __launch_bounds__(64) void mfma16_forward_kernel(Mfma16Args a) {
     // row layout -> column layout for x+
     __syncthreads();
 #pragma unroll
-    for (int c = 0; c < 3; ++c) S[g + 4 * c] = xr[c];
+    for (int c = 0; c < 3; ++c) lds[g + 4 * c] = xr[c];
     __syncthreads();
-    const double sx = S[(j < 12) ? j : 0];
+    const double sx = lds[(j < 12) ? j : 0];
     cur = nxt;
     // stores: x_k | u_k from the column layout, y_k from the row layout
-    o[xu_off] = zc;
+    o[xu_off] = (S)zc;
 #pragma unroll
-    for (int r = 0; r < 3; ++r) o[12 + g + 4 * r] = yr[r];
+    for (int r = 0; r < 3; ++r) o[12 + g + 4 * r] = (S)yr[r];
     xc = (j < 12) ? sx : ((j == 12) ? 1.0 : 0.0);
   }
   // terminal knot point: x_N, y_N = P_N x_N + p_N (tvlqr.cpp:238-246)
   {
-    const double* on = a.outn + (size_t)b * MF_TERM;
-    double* o = xuy + (size_t)N * a.xuy_ks;
+    const S* on = a.outn + (size_t)b * MF_TERM;
+    S* o = xuy + (size_t)N * a.xuy_ks;
     const int jc = (j <= 12) ? j : 12;
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-      const double pl = on[(g + 4 * r) * 13 + jc];
+      const double pl = (double)on[(g + 4 * r) * 13 + jc];
       const double pv = (j <= 12) ? pl : 0.0;
-      o[12 + g + 4 * r] = row16_allreduce(pv * xc);
+      o[12 + g + 4 * r] = (S)row16_allreduce(pv * xc);
     }
-    o[xu_off] = (j < 12) ? xc : 0.0;
+    o[xu_off] = (S)((j < 12) ? xc : 0.0);
   }
 }
 

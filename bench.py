@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--horizon", type=int, default=256)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", default="c1", choices=["c1", "c4"],
+                    help="c1 = BASELINE.json configs[1] (the metric's config, default); c4 = configs[4] "
+                         "(random LTV n=12 m=4 N=512 batch=16384, fp32 storage) as an extra line")
     return ap.parse_args()
 
 
@@ -90,18 +93,31 @@ def main():
     import altro_amd
     from tests import problems
     N, n, m, batch = args.horizon, 12, 4, args.batch
+    c4 = args.config == "c4"
+    if c4:
+        N = 512 if args.horizon == 256 else args.horizon
+        batch = 16384 if args.batch == 4096 else args.batch
     from altro_amd import shard as _shard
     first, _ = _shard.shard_range(batch * world, rank, world)   # this rank's slice of the global batch
-    one = problems.c1_double_integrator(1, N=N)
     x0 = 2.0 * problems.uniform01((batch, n), 21, first * n) - 1.0
 
-    bt = altro_amd.Batch(N, n, m, batch, device=local_rank)
+    bt = altro_amd.Batch(N, n, m, batch, dtype=altro_amd.F32 if c4 else altro_amd.F64, device=local_rank)
     assert bt.plan == altro_amd.PLAN_MFMA16
-    # shared A,B,Q,R are EXPANDED on the device: every (problem, knot point) owns its blocks in HBM
-    bt.set_dynamics(one["A"][0, :1], one["B"][0, :1], None, k_stride_zero=True, batch_stride_zero=True)
-    Q2 = np.stack([one["Q"][0, 0], one["Q"][0, N]])
-    bt.set_cost(Q2, one["R"][0, :1], one["H"][0, :1], np.zeros((2, n)), one["r"][0, :1],
-                k_stride_zero=True, batch_stride_zero=True)
+    if c4:
+        # random time-varying LTV-LQ problems (SURVEY.md 8d "C4"): a seeded pool of 64 distinct problems is
+        # tiled over the batch ON THE DEVICE; every (problem, knot point) still owns its blocks in HBM
+        pool = problems.random_ltv(64, N, n, m)
+        bt.set_host_batch(64)
+        bt.set_dynamics(pool["A"], pool["B"], pool["f"])
+        bt.set_cost(pool["Q"], pool["R"], pool["H"], pool["q"], pool["r"])
+        bt.set_host_batch(0)
+    else:
+        one = problems.c1_double_integrator(1, N=N)
+        # shared A,B,Q,R are EXPANDED on the device: every (problem, knot point) owns its blocks in HBM
+        bt.set_dynamics(one["A"][0, :1], one["B"][0, :1], None, k_stride_zero=True, batch_stride_zero=True)
+        Q2 = np.stack([one["Q"][0, 0], one["Q"][0, N]])
+        bt.set_cost(Q2, one["R"][0, :1], one["H"][0, :1], np.zeros((2, n)), one["r"][0, :1],
+                    k_stride_zero=True, batch_stride_zero=True)
     bt.set_initial_state(x0)
 
     def barrier():
@@ -146,7 +162,7 @@ def main():
         if os.path.exists(tpath):   # rocprofv3 --pmc passes of this same command (see profiles/README.md)
             try:
                 tj = json.load(open(tpath))
-                if tj.get("batch") == batch and tj.get("horizon") == N:
+                if tj.get("batch") == batch and tj.get("horizon") == N and not c4:
                     traffic = tj.get("backward_bytes_per_launch")
             except (OSError, ValueError):
                 traffic = None
@@ -161,10 +177,11 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": "f32 storage, f64 tile arithmetic" if c4 else "f64",
             "data": "synthetic",
             "config": {
-                "workload": "C1 double integrator TVLQR sweep (BASELINE.json configs[1])",
+                "workload": ("C4 random LTV TVLQR sweep, fp32 storage (BASELINE.json configs[4])" if c4 else
+                             "C1 double integrator TVLQR sweep (BASELINE.json configs[1])"),
                 "horizon_N": N, "n": n, "m": m, "batch_per_gpu": batch, "global_batch": total_problems,
                 "parallelism": "problem instances sharded over %d GPU(s), no data-path collective; "
                                "RCCL all-reduce of solver stats only" % world,
@@ -180,7 +197,7 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_b / dur_b / 1e9 / HBM_PEAK_GBS,
                          "traffic": traffic},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not c4:
             out["cpu_baseline"] = cpu_baseline(N, args.cpu_seconds)
         print(json.dumps(out))
     bt.close()

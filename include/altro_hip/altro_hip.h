@@ -116,6 +116,10 @@ int altro_hip_set_cost(altro_hip_batch* h, const double* Q, const double* R, con
                        const double* q, const double* r, int is_diag, int k_stride_zero,
                        int batch_stride_zero);
 int altro_hip_set_initial_state(altro_hip_batch* h, const double* x0, int batch_stride_zero);
+/* Host arrays of the following set_dynamics / set_cost / set_tracking_cost / set_input_guess calls hold
+ * only `host_batch` distinct problems, tiled (b mod host_batch) over the batch on the device; 0 = off.
+ * Lets a large synthetic batch be staged without a batch-sized host copy (plans MFMA16 and LANE).   */
+int altro_hip_set_host_batch(altro_hip_batch* h, int host_batch);
 
 /* ---- the hot path ----------------------------------------------------------------------------- */
 /* tvlqr_BackwardPass over the batch: K, d, P, p, delta_V, status for every problem.             */

@@ -341,3 +341,19 @@ def test_lane_full_size_shapes(name, n, m, N, batch):
     ref = run_oracle(small)
     for k in ("K", "d", "P", "p", "x", "u", "y"):
         assert np.array_equal(out[k][sample], ref[k]), k
+
+
+def test_mfma16_fp32_storage():
+    """ALTRO_HIP_F32 on plan MFMA16: fp32 storage in HBM, fp64 tile arithmetic (BASELINE.json configs[4]
+    shape at reduced size).  Error is set by rounding the inputs/outputs to fp32: 1e-5 relative."""
+    pr = problems.random_ltv(32, 64, 12, 4)
+    bt = altro_amd.Batch(64, 12, 4, 32, dtype=altro_amd.F32)
+    assert bt.plan == altro_amd.PLAN_MFMA16
+    bt.set_dynamics(pr["A"], pr["B"], pr["f"]); bt.set_cost(pr["Q"], pr["R"], pr["H"], pr["q"], pr["r"])
+    bt.set_initial_state(pr["x0"]); bt.sweep()
+    assert (bt.get("status") == -1).all()
+    # reference: the oracle on the SAME fp32-rounded inputs
+    r32 = {k: (v.astype(np.float32).astype(np.float64) if isinstance(v, np.ndarray) else v) for k, v in pr.items()}
+    ref = run_oracle(r32)
+    for k in ("K", "d", "P", "p", "x", "u", "y"):
+        assert relerr(bt.get(k), ref[k]) < 2e-5, k
