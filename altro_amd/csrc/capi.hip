@@ -69,7 +69,7 @@ struct altro_hip_batch {
   int* g_nx = nullptr;
   int* g_nu = nullptr;
   // plan MFMA16
-  void *m_in = nullptr, *m_term = nullptr, *m_out = nullptr, *m_outn = nullptr, *m_xuy = nullptr,
+  void *m_in = nullptr, *m_cin = nullptr, *m_term = nullptr, *m_out = nullptr, *m_outn = nullptr, *m_xuy = nullptr,
        *m_qblk = nullptr, *m_trash = nullptr;   // element type = handle dtype (fp32 storage allowed)
   Mfma16Strides m_st{};
   // plan LANE: batch structure-of-arrays ([k][element][batch])
@@ -266,10 +266,10 @@ int mfma16_pack_launch(altro_hip_batch* h, int seg, SrcArr s0, SrcArr s1) {
   const int64_t total = (int64_t)h->batch * h->N * 192;
   if (h->dtype == ALTRO_HIP_F64)
     hipLaunchKernelGGL(mfma16_pack_kernel<double>, dim3(grid_for(total)), dim3(256), 0, h->stream, (double*)h->m_in,
-                       (double*)h->m_term, h->m_st, seg, s0, s1, h->is_diag, h->N, 0, h->batch);
+                       (double*)h->m_cin, (double*)h->m_term, h->m_st, seg, s0, s1, h->is_diag, h->N, 0, h->batch);
   else
     hipLaunchKernelGGL(mfma16_pack_kernel<float>, dim3(grid_for(total)), dim3(256), 0, h->stream, (float*)h->m_in,
-                       (float*)h->m_term, h->m_st, seg, s0, s1, h->is_diag, h->N, 0, h->batch);
+                       (float*)h->m_cin, (float*)h->m_term, h->m_st, seg, s0, s1, h->is_diag, h->N, 0, h->batch);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "mfma16_pack launch: %s", hipGetErrorString(e));
   return 0;
@@ -466,6 +466,8 @@ template <typename S>
 Mfma16Args<S> mfma16_args(altro_hip_batch* h, double reg) {
   Mfma16Args<S> a;
   a.in = (const S*)h->m_in;
+  a.cin = (const S*)h->m_cin;
+  a.cin_bs = h->m_st.cin_bs; a.cin_ks = h->m_st.cin_ks;
   a.in_bs = h->m_st.in_bs; a.in_ks = h->m_st.in_ks; a.out_bs = h->m_st.out_bs; a.out_ks = h->m_st.out_ks;
   a.xuy_bs = h->m_st.xuy_bs; a.xuy_ks = h->m_st.xuy_ks;
   a.term = (const S*)h->m_term; a.out = (S*)h->m_out; a.outn = (S*)h->m_outn; a.qblk = (S*)h->m_qblk;
@@ -481,6 +483,18 @@ void mfma16_launch_backward(altro_hip_batch* h, double reg, bool sq) {
   else if (sq) hipLaunchKernelGGL((mfma16_backward_kernel<true, false, S>), grid, block, 0, h->stream, a);
   else if (h->has_f) hipLaunchKernelGGL((mfma16_backward_kernel<false, true, S>), grid, block, 0, h->stream, a);
   else hipLaunchKernelGGL((mfma16_backward_kernel<false, false, S>), grid, block, 0, h->stream, a);
+}
+
+template <typename S>
+void mfma16_launch_forward(altro_hip_batch* h, const Mfma16Args<S>& a) {
+  static const int depth = [] { const char* e = getenv("ALTRO_HIP_FWD_DEPTH"); return e ? atoi(e) : 3; }();
+  const dim3 grid(h->batch), block(64);
+  switch (depth) {
+    case 1: hipLaunchKernelGGL((mfma16_forward_kernel<S, 1>), grid, block, 0, h->stream, a); break;
+    case 2: hipLaunchKernelGGL((mfma16_forward_kernel<S, 2>), grid, block, 0, h->stream, a); break;
+    case 4: hipLaunchKernelGGL((mfma16_forward_kernel<S, 4>), grid, block, 0, h->stream, a); break;
+    default: hipLaunchKernelGGL((mfma16_forward_kernel<S, 3>), grid, block, 0, h->stream, a); break;
+  }
 }
 
 int launch_backward(altro_hip_batch* h, double reg) {
@@ -510,10 +524,10 @@ int launch_forward(altro_hip_batch* h) {
   if (h->plan == ALTRO_HIP_PLAN_MFMA16) {
     if (h->dtype == ALTRO_HIP_F64) {
       auto a = mfma16_args<double>(h, 0.0);
-      hipLaunchKernelGGL(mfma16_forward_kernel<double>, dim3(h->batch), dim3(64), 0, h->stream, a);
+      mfma16_launch_forward<double>(h, a);
     } else {
       auto a = mfma16_args<float>(h, 0.0);
-      hipLaunchKernelGGL(mfma16_forward_kernel<float>, dim3(h->batch), dim3(64), 0, h->stream, a);
+      mfma16_launch_forward<float>(h, a);
     }
   } else if (h->plan == ALTRO_HIP_PLAN_LANE) {
     return h->dtype == ALTRO_HIP_F64 ? lane_launch<double>(h, false, 0.0) : lane_launch<float>(h, false, 0.0);
@@ -594,15 +608,18 @@ int altro_hip_batch_create(altro_hip_batch** out, int N, int n, int m, int batch
   ALLOC(h->delta_V, B * 2 * E);
   ALLOC(h->status, B * sizeof(int));
   if (plan == ALTRO_HIP_PLAN_MFMA16) {
-    ALLOC(h->m_in, B * N * MF_IN * E);
+    ALLOC(h->m_in, B * N * MF_DYN * E);
+    ALLOC(h->m_cin, B * N * MF_COST * E);
     {
       // default: knot-point-major slabs [k][b][record]; ALTRO_HIP_LAYOUT=bk selects problem-major
       const char* lay = getenv("ALTRO_HIP_LAYOUT");
       const bool kb = !(lay && lay[0] == 'b');
       const int64_t Bq = batch;
-      h->m_st = kb ? Mfma16Strides{MF_IN, Bq * MF_IN, MF_OUT, Bq * MF_OUT, 28, Bq * 28}
-                   : Mfma16Strides{(int64_t)N * MF_IN, MF_IN, (int64_t)N * MF_OUT, MF_OUT, (int64_t)(N + 1) * 28, 28};
-      if (lay && lay[0] == 's') { h->m_st.in_bs = 0; h->m_st.in_ks = 0; }   // experiment: one shared IN record
+      h->m_st = kb ? Mfma16Strides{MF_DYN, Bq * MF_DYN, MF_OUT, Bq * MF_OUT, 28, Bq * 28, MF_COST, Bq * MF_COST}
+                   : Mfma16Strides{(int64_t)N * MF_DYN, MF_DYN, (int64_t)N * MF_OUT, MF_OUT, (int64_t)(N + 1) * 28, 28,
+                                   (int64_t)N * MF_COST, MF_COST};
+      if (lay && lay[0] == 'x') { h->m_st.xuy_bs = (int64_t)(N + 1) * 28; h->m_st.xuy_ks = 28; }   // experiment: problem-major XUY
+      if (lay && lay[0] == 's') { h->m_st.in_bs = h->m_st.in_ks = h->m_st.cin_bs = h->m_st.cin_ks = 0; }   // experiment
     }
     ALLOC(h->m_term, B * MF_TERM * E);
     ALLOC(h->m_out, B * N * MF_OUT * E);
@@ -668,7 +685,7 @@ void altro_hip_batch_destroy(altro_hip_batch* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  void* ptrs[] = {h->x0, h->delta_V, h->status, h->m_in, h->m_term, h->m_out, h->m_outn, h->m_xuy,
+  void* ptrs[] = {h->x0, h->delta_V, h->status, h->m_in, h->m_cin, h->m_term, h->m_out, h->m_outn, h->m_xuy,
                   h->m_qblk, h->m_trash, h->g_off, h->g_nx, h->g_nu, h->stage,
                   h->l_in, h->l_term, h->l_out, h->l_outn, h->l_xuy, h->l_x0,
                   h->l_nom, h->l_cost, h->i_prob, h->i_alpha, h->i_phi, h->i_dphi, h->i_active, h->i_counters};

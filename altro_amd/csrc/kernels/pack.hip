@@ -48,14 +48,14 @@ __global__ void gather_copy_kernel(double* out, int64_t out_bs, int64_t out_ks, 
 }
 
 // ---- plan MFMA16 ------------------------------------------------------------------------------
-struct Mfma16Strides { int64_t in_bs, in_ks, out_bs, out_ks, xuy_bs, xuy_ks; };
+struct Mfma16Strides { int64_t in_bs, in_ks, out_bs, out_ks, xuy_bs, xuy_ks, cin_bs, cin_ks; };
 
 enum Mfma16Seg { MSEG_Z = 0, MSEG_F, MSEG_Q, MSEG_HR, MSEG_QR, MSEG_TERM_Q, MSEG_TERM_q };
 
 // One launch fills one segment of IN (or TERM) for problems [b0, b0+nb).  `s0`, `s1` are the one or
 // two reference arrays the segment draws from (Z: A,B ; HR: H,R ; QR: q,r).
 template <typename S>
-__global__ void mfma16_pack_kernel(S* in, S* term, Mfma16Strides st, int seg, SrcArr s0,
+__global__ void mfma16_pack_kernel(S* in, S* cin, S* term, Mfma16Strides st, int seg, SrcArr s0,
                                    SrcArr s1, int is_diag, int N, int b0, int nb) {
   int len, base;
   switch (seg) {
@@ -98,7 +98,8 @@ __global__ void mfma16_pack_kernel(S* in, S* term, Mfma16Strides st, int seg, Sr
       default: v = p0[e]; break;  // MSEG_TERM_q
     }
     if (terminal) term[(int64_t)(b0 + b) * MF_TERM + base + e] = (S)v;
-    else in[(int64_t)(b0 + b) * st.in_bs + (int64_t)k * st.in_ks + base + e] = (S)v;
+    else if (seg == MSEG_Z || seg == MSEG_F) in[(int64_t)(b0 + b) * st.in_bs + (int64_t)k * st.in_ks + base + e] = (S)v;
+    else cin[(int64_t)(b0 + b) * st.cin_bs + (int64_t)k * st.cin_ks + base + e] = (S)v;
   }
 }
 

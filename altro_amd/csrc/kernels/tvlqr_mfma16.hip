@@ -27,7 +27,8 @@
 // so this changes results only at the 1e-16 relative level.  Parity is asserted at 1e-8 on K, d.
 //
 // Device layout (private to this plan; pack_mfma16.hip converts from/to the reference layout):
-//   IN  [b][k][428]  = Zfrag 3x64 | Q rows 3x48 | [H R] 4x16 | [q r] 16 | f 12   (3424 B, all algorithmic)
+//   DYN [k][b][204]  = Z = [A B] 3x64 fragment (== row-major 12x16) | f 12        (1632 B)
+//   COST[k][b][224]  = Q rows 3x48 | [H R] 4x16 | [q r] 16                          (1792 B; 3424 B in all)
 //   TERM[b][156]     = Q_N rows 3x48 | q_N 12
 //   OUT [b][k][208]  = Kt 4x13 row-major | [P p] 12x13 row-major                  (1664 B, all algorithmic)
 //   OUTN[b][156]     = [P_N p_N] 12x13 row-major
@@ -41,10 +42,13 @@ namespace altro_hip {
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 constexpr int MF_N = 12, MF_M = 4;
-constexpr int MF_IN = 428;     // doubles per knot-point input record
+constexpr int MF_DYN = 204;    // elements per knot-point dynamics record:  Z 192 | f 12
+constexpr int MF_COST = 224;   // elements per knot-point cost record:      Q rows 144 | [H R] 64 | [q r] 16
+constexpr int MF_IN = MF_DYN + MF_COST;   // 428 = 2n^2+2nm+m^2+2n+m: every element is algorithmic
 constexpr int MF_OUT = 208;    // doubles per knot-point output record
 constexpr int MF_TERM = 156;   // doubles per terminal record
-constexpr int MF_OFF_Z = 0, MF_OFF_Q = 192, MF_OFF_HR = 336, MF_OFF_QR = 400, MF_OFF_F = 416;
+constexpr int MF_OFF_Z = 0, MF_OFF_F = 192;                  // inside a dynamics record
+constexpr int MF_OFF_Q = 0, MF_OFF_HR = 144, MF_OFF_QR = 208;  // inside a cost record
 constexpr int MF_OFF_P = 52;   // inside an OUT record: [P p] after Kt
 constexpr int MF_QB = 256 + 16;  // optional Q-block record: G tile (16x16 row-major) | [Qx Qu]
 
@@ -94,7 +98,9 @@ struct Mfma16Args {
   // Element strides between problems (bs) / knot points (ks) of IN, OUT and the forward output.
   // Knot-point-major ([k][b][record]: bs = record, ks = batch*record) keeps all the records touched at
   // one time step in one contiguous slab of HBM (the batch structure-of-arrays picture); 0 = shared.
-  int64_t in_bs, in_ks, out_bs, out_ks, xuy_bs, xuy_ks;
+  int64_t in_bs, in_ks, out_bs, out_ks, xuy_bs, xuy_ks, cin_bs, cin_ks;
+  const S* cin;          // COST records (the forward sweep never touches them: two fully-used streams
+                         // instead of one half-used one -- partial-record reads waste DRAM pages)
   const S* term;         // TERM
   S* out;                // OUT
   S* outn;               // OUTN
@@ -113,6 +119,13 @@ struct Mfma16Args {
 // ------------------------------------------------------------------------------------------------
 // Backward sweep.
 // ------------------------------------------------------------------------------------------------
+// Record loads.  Measured on MI355X (round 1): nontemporal loads (`__builtin_nontemporal_load`) make the
+// backward sweep 9 % SLOWER (1.155 vs 1.06 ms) and leave the forward sweep unchanged, so plain loads.
+template <typename S>
+__device__ __forceinline__ double ld_stream(const S* p) {
+  return (double)(*p);
+}
+
 struct Mfma16Knot {  // one knot point's inputs, in registers (11 doubles / lane)
   double z[3], q[3], hr, qr, f[3];
 };
@@ -122,17 +135,17 @@ struct Mfma16Knot {  // one knot point's inputs, in registers (11 doubles / lane
 // vmcnt(0) at the loop head, which serialises the prefetch against its own issue.
 template <bool HAS_F, typename S>
 __device__ __forceinline__ void mfma16_load_knot(Mfma16Knot& kn, const S* __restrict__ rec,
-                                                 int lane, int j, int g) {
+                                                 const S* __restrict__ crec, int lane, int j, int g) {
   const int jq = (j < 12) ? j : 11;
 #pragma unroll
-  for (int c = 0; c < 3; ++c) kn.z[c] = (double)rec[MF_OFF_Z + c * 64 + lane];
+  for (int c = 0; c < 3; ++c) kn.z[c] = ld_stream(&rec[MF_OFF_Z + c * 64 + lane]);
 #pragma unroll
-  for (int r = 0; r < 3; ++r) kn.q[r] = (double)rec[MF_OFF_Q + r * 48 + g * 12 + jq];
-  kn.hr = (double)rec[MF_OFF_HR + lane];
-  kn.qr = (double)rec[MF_OFF_QR + j];
+  for (int r = 0; r < 3; ++r) kn.q[r] = ld_stream(&crec[MF_OFF_Q + r * 48 + g * 12 + jq]);
+  kn.hr = ld_stream(&crec[MF_OFF_HR + lane]);
+  kn.qr = ld_stream(&crec[MF_OFF_QR + j]);
   if (HAS_F) {
 #pragma unroll
-    for (int r = 0; r < 3; ++r) kn.f[r] = (double)rec[MF_OFF_F + g + 4 * r];
+    for (int r = 0; r < 3; ++r) kn.f[r] = ld_stream(&rec[MF_OFF_F + g + 4 * r]);
   } else {
     kn.f[0] = kn.f[1] = kn.f[2] = 0.0;
   }
@@ -170,6 +183,7 @@ __global__ __launch_bounds__(64, 4) void mfma16_backward_kernel(Mfma16Args<S> a)
 #pragma unroll
   for (int r = 0; r < 3; ++r) qx_idx[r] = (j == 12) ? (64 + g + 4 * r) : 80;
   const S* __restrict__ in = a.in + (size_t)b * a.in_bs;
+  const S* __restrict__ cin = a.cin + (size_t)b * a.cin_bs;
   S* __restrict__ out = a.out + (size_t)b * a.out_bs;
   const bool col_ok = (j <= 12);
   const int jc = col_ok ? j : 12;
@@ -194,7 +208,7 @@ __global__ __launch_bounds__(64, 4) void mfma16_backward_kernel(Mfma16Args<S> a)
   int fail_k = -1;
 
   Mfma16Knot cur, nxt;
-  mfma16_load_knot<HAS_F, S>(cur, in + (size_t)(N - 1) * a.in_ks, lane, j, g);
+  mfma16_load_knot<HAS_F, S>(cur, in + (size_t)(N - 1) * a.in_ks, cin + (size_t)(N - 1) * a.cin_ks, lane, j, g);
   // Drain the VMEM queue before entering the loop: hipcc merges the pre-header's scoreboard into the
   // loop header's, and a pending first load there turns into `s_waitcnt vmcnt(0)` at the top of EVERY
   // iteration -- which would drain each step's stores before the next step may start.
@@ -202,7 +216,10 @@ __global__ __launch_bounds__(64, 4) void mfma16_backward_kernel(Mfma16Args<S> a)
 
   for (int k = N - 1; k >= 0; --k) {
     // prefetch the next knot point (k-1) while this one computes (k == 0 re-reads record 0: harmless)
-    mfma16_load_knot<HAS_F, S>(nxt, in + (size_t)((k > 0) ? k - 1 : 0) * a.in_ks, lane, j, g);
+    {
+      const size_t kp = (k > 0) ? k - 1 : 0;
+      mfma16_load_knot<HAS_F, S>(nxt, in + kp * a.in_ks, cin + kp * a.cin_ks, lane, j, g);
+    }
 
     // ---- D1 = [P'|t]^T Z : rows 0..11 = P'^T Z, row 12 = t^T Z --------------------------------
     f64x4 D1 = {0.0, 0.0, 0.0, 0.0};
@@ -327,98 +344,135 @@ __global__ __launch_bounds__(64, 4) void mfma16_backward_kernel(Mfma16Args<S> a)
 
 // ------------------------------------------------------------------------------------------------
 // Forward sweep: x_0 = x0 ; u = d - K x ; x+ = f + A x + B u ; y = P x + p  (tvlqr.cpp:208-246).
-// Tiles stay in the layouts the backward kernel wrote; vectors alternate between a "column layout"
-// (lane j holds v[j], replicated over the 4 row groups) for the products and a "row layout" (row
-// group g, reg r holds v[g+4r]) that the DPP row reductions produce.
+//
+// Lane-per-row with scalar-broadcast operands.  The records are row-major in HBM (Z = [A B] 12x16,
+// Kt = [K | -d] 4x13, [P | p] 12x13), so after one coalesced load -> LDS hop every lane reads ITS row
+// (16 doubles) and the state vector is broadcast from SGPRs (v_readlane), which makes each product an
+// unrolled chain of v_fma_f64 with a scalar operand: no cross-lane reductions at all.
+//   lanes  0..15 : row min(l,11) of Z          -> x+[i]   (phase A: A x, phase C: + B u + f)
+//   lanes 16..31 : row min(l-16,3) of Kt       -> u[a] = -(K x - d)
+//   lanes 32..63 : row min(l&15,11) of [P|p]   -> y[i]
+// Spare lanes replicate a neighbour (same value to the same address), so every load, LDS access and
+// store in the loop is unconditional (exact vmcnt waits, see the backward kernel).  ~85 instructions
+// per knot point instead of ~190 for the DPP-butterfly version: the kernel becomes HBM-bound.
 // ------------------------------------------------------------------------------------------------
-struct Mfma16FwdKnot {
-  double z[3], f[3], kt, p[3];
-};
+constexpr int MF_FWD_LDS = 192 + 208 + 12;   // Z | OUT record | f
 
+struct Mfma16FwdRegs {   // one knot point's coalesced loads (8 doubles / lane)
+  double z[3], o[4], f;
+};
 template <typename S>
-__device__ __forceinline__ void mfma16_load_fwd(Mfma16FwdKnot& kn, const S* rec, const S* orec, int lane,
-                                                int j, int g) {
+__device__ __forceinline__ void mfma16_fwd_load(Mfma16FwdRegs& r, const S* __restrict__ rec,
+                                                const S* __restrict__ orec, int lane) {
 #pragma unroll
-  for (int c = 0; c < 3; ++c) kn.z[c] = (double)rec[MF_OFF_Z + c * 64 + lane];
+  for (int c = 0; c < 3; ++c) r.z[c] = ld_stream(&rec[MF_OFF_Z + c * 64 + lane]);
 #pragma unroll
-  for (int r = 0; r < 3; ++r) kn.f[r] = (double)rec[MF_OFF_F + g + 4 * r];
-  const int jc = (j <= 12) ? j : 12;   // clamped: no exec-masked load branches (see backward)
-  const double kt = (double)orec[g * 13 + jc];
-  kn.kt = (j <= 12) ? kt : 0.0;
+  for (int c = 0; c < 3; ++c) r.o[c] = ld_stream(&orec[c * 64 + lane]);
+  r.o[3] = ld_stream(&orec[192 + (lane & 15)]);
+  r.f = ld_stream(&rec[MF_OFF_F + (lane < 12 ? lane : 11)]);
+}
+__device__ __forceinline__ void mfma16_fwd_stage(const Mfma16FwdRegs& r, double* __restrict__ L, int lane) {
 #pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    const double pv = (double)orec[MF_OFF_P + (g + 4 * r) * 13 + jc];
-    kn.p[r] = (j <= 12) ? pv : 0.0;
-  }
+  for (int c = 0; c < 3; ++c) L[c * 64 + lane] = r.z[c];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) L[192 + c * 64 + lane] = r.o[c];
+  L[192 + 192 + (lane & 15)] = r.o[3];
+  L[400 + (lane < 12 ? lane : 11)] = r.f;
+}
+__device__ __forceinline__ double readlane_f64(double v, int src_lane) {
+  union { double d; int i[2]; } in, out;
+  in.d = v;
+  out.i[0] = __builtin_amdgcn_readlane(in.i[0], src_lane);
+  out.i[1] = __builtin_amdgcn_readlane(in.i[1], src_lane);
+  return out.d;
 }
 
-template <typename S>
+template <typename S, int DEPTH>
 __global__ __launch_bounds__(64) void mfma16_forward_kernel(Mfma16Args<S> a) {
-  __shared__ __attribute__((aligned(16))) double lds[16];
+  __shared__ __attribute__((aligned(16))) double lds[MF_FWD_LDS + 4];
   const int lane = threadIdx.x;
-  const int j = lane & 15, g = lane >> 4;
   const int b = blockIdx.x;
   if (b >= a.batch) return;
   const int N = a.N;
-  const S* in = a.in + (size_t)b * a.in_bs;
-  const S* out = a.out + (size_t)b * a.out_bs;
-  S* xuy = a.xuy + (size_t)b * a.xuy_bs;
-  // Every store below is executed by ALL lanes (lanes that hold a replica write the same value to the
-  // same address): no exec-masked VMEM/LDS in the loop, so hipcc can count vmcnt exactly.
-  const int xu_off = (j < 12) ? j : 24 + (j - 12);   // x_k[j] | u_k[j-12] inside a 28-double record
+  const S* __restrict__ in = a.in + (size_t)b * a.in_bs;
+  const S* __restrict__ out = a.out + (size_t)b * a.out_bs;
+  S* __restrict__ xuy = a.xuy + (size_t)b * a.xuy_bs;
+  S* __restrict__ trash = a.trash + (size_t)b * MF_OUT;
+  // roles
+  const int grp = lane >> 4;
+  const int sub = lane & 15;
+  const int row = (grp == 1) ? (sub < 4 ? sub : 3) : (sub < 12 ? sub : 11);
+  const int row_base = (grp == 0) ? 16 * row : ((grp == 1) ? 192 + 13 * row : 192 + 52 + 13 * row);
+  const int out_off = (grp == 0) ? row : ((grp == 1) ? 24 + row : 12 + row);   // x | y | u inside a record
+  const bool is_x = (grp == 0), is_u = (grp == 1);
 
-  // x~ = [x; 1] in column layout
-  double xc = (j < 12) ? (double)a.x0[(size_t)b * 12 + j] : ((j == 12) ? 1.0 : 0.0);
-  Mfma16FwdKnot cur, nxt;
-  mfma16_load_fwd(cur, in, out, lane, j, g);
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see the backward kernel's pre-loop drain
-  for (int k = 0; k < N; ++k) {
-    {
-      const int kn = (k + 1 < N) ? k + 1 : k;   // last step re-reads itself: harmless, branch-free
-      mfma16_load_fwd(nxt, in + (size_t)kn * a.in_ks, out + (size_t)kn * a.out_ks, lane, j, g);
-    }
-    S* o = xuy + (size_t)k * a.xuy_ks;
-    // u[g] = -(Kt x~)[g] = d - K x
-    const double ug = -row16_allreduce(cur.kt * xc);
-    // y[g+4r] = ([P p] x~)[g+4r]
-    double yr[3];
+  double xcur = (double)a.x0[(size_t)b * 12 + row];   // meaningful in group 0: x_k[row]
+  // Register ring: knot point k + DEPTH is requested while knot point k computes, so DEPTH records
+  // (DEPTH x 3.3 KB per wave) are in flight -- the read-dominated sweep needs that to fill HBM.
+  Mfma16FwdRegs ring[DEPTH];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) yr[r] = row16_allreduce(cur.p[r] * xc);
-    // z = [x; u] in column layout: u[a] lives in row group a -> hop through LDS
-    __syncthreads();
-    lds[12 + g] = ug;
-    __syncthreads();
-    const double su = lds[(j < 12) ? 12 : j];
-    const double zc = (j < 12) ? xc : su;
-    // x+[g+4c] = f + (Z z)[g+4c]
-    double xr[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) xr[c] = row16_allreduce(cur.z[c] * zc) + cur.f[c];
-    // row layout -> column layout for x+
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < 3; ++c) lds[g + 4 * c] = xr[c];
-    __syncthreads();
-    const double sx = lds[(j < 12) ? j : 0];
-    cur = nxt;
-    // stores: x_k | u_k from the column layout, y_k from the row layout
-    o[xu_off] = (S)zc;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) o[12 + g + 4 * r] = (S)yr[r];
-    xc = (j < 12) ? sx : ((j == 12) ? 1.0 : 0.0);
+  for (int dd = 0; dd < DEPTH; ++dd) {
+    const int kk = (dd < N) ? dd : N - 1;
+    mfma16_fwd_load<S>(ring[dd], in + (size_t)kk * a.in_ks, out + (size_t)kk * a.out_ks, lane);
   }
-  // terminal knot point: x_N, y_N = P_N x_N + p_N (tvlqr.cpp:238-246)
-  {
-    const S* on = a.outn + (size_t)b * MF_TERM;
-    S* o = xuy + (size_t)N * a.xuy_ks;
-    const int jc = (j <= 12) ? j : 12;
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): drain before the loop (see the backward kernel)
+  mfma16_fwd_stage(ring[0], lds, lane);
+  __syncthreads();
+
+  const int Npad = ((N + DEPTH - 1) / DEPTH) * DEPTH;
+  for (int k0 = 0; k0 < Npad; k0 += DEPTH) {
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const double pl = (double)on[(g + 4 * r) * 13 + jc];
-      const double pv = (j <= 12) ? pl : 0.0;
-      o[12 + g + 4 * r] = (S)row16_allreduce(pv * xc);
+    for (int dd = 0; dd < DEPTH; ++dd) {
+      const int k = k0 + dd;
+      const bool live = k < N;     // padding steps (N not a multiple of DEPTH) compute on a clamped record
+      {   // slot dd held record k (already staged): refill it with record k + DEPTH (clamped, branch-free)
+        const int kn = (k + DEPTH < N) ? k + DEPTH : N - 1;
+        mfma16_fwd_load<S>(ring[dd], in + (size_t)kn * a.in_ks, out + (size_t)kn * a.out_ks, lane);
+      }
+      // this lane's row (16 doubles) and, for the x+ rows, f[row]
+      double rd[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) rd[j] = lds[row_base + j];
+      const double fi = lds[400 + row];
+      // x_k broadcast from lanes 0..11 through SGPRs
+      double xs[12];
+#pragma unroll
+      for (int j = 0; j < 12; ++j) xs[j] = readlane_f64(xcur, j);
+      // phase A: sum_j row[j] x[j]   (A x | K x | P x depending on the lane's role)
+      double acc = 0.0;
+#pragma unroll
+      for (int j = 0; j < 12; ++j) acc = __builtin_fma(rd[j], xs[j], acc);
+      // phase B: the affine column.  u = -(K x - d) ; y = P x + p
+      const double aff = acc + rd[12];
+      const double uval = -aff;
+      double us[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) us[c] = readlane_f64(uval, 16 + c);
+      // phase C: x+ = A x + B u + f
+      double xn = acc + fi;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) xn = __builtin_fma(rd[12 + c], us[c], xn);
+      // store x_k | y_k | u_k (every lane stores; replicas write identical values)
+      const double sval = is_x ? xcur : (is_u ? uval : aff);
+      __syncthreads();                       // all reads of this knot point's LDS image are done
+      mfma16_fwd_stage(ring[(dd + 1) % DEPTH], lds, lane);   // record k+1: requested DEPTH-1 steps ago
+      S* __restrict__ o = live ? xuy + (size_t)k * a.xuy_ks : trash;
+      o[out_off] = (S)sval;
+      __syncthreads();
+      xcur = live ? xn : xcur;
     }
-    o[xu_off] = (S)((j < 12) ? xc : 0.0);
+  }
+  // terminal knot point: x_N, y_N = P_N x_N + p_N (tvlqr.cpp:238-246), u slot zeroed
+  {
+    const S* __restrict__ on = a.outn + (size_t)b * MF_TERM;
+    double xs[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) xs[j] = readlane_f64(xcur, j);
+    double acc = (double)on[row * 13 + 12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) acc = __builtin_fma((double)on[row * 13 + j], xs[j], acc);
+    const double sval = is_x ? xcur : (is_u ? 0.0 : acc);
+    xuy[(size_t)N * a.xuy_ks + out_off] = (S)sval;
   }
 }
 
