@@ -2,7 +2,7 @@
  * oracle/ilqr_oracle.c -- TEST INFRASTRUCTURE ONLY (never linked into the product).
  *
  * Plain-C fp64 restatement of the reference's iLQR inner loop around the TVLQR kernel,
- * for the UNCONSTRAINED case (the AL/conic terms are SURVEY.md section 8 row f2, "next"):
+ * with the augmented-Lagrangian / conic terms of al_oracle.c:
  *     /root/reference/src/altro/solver/solver.cpp:116-131   OpenLoopRollout
  *     /root/reference/src/altro/solver/solver.cpp:148-157   CopyTrajectory
  *     /root/reference/src/altro/solver/solver.cpp:189-201   CalcExpansions
@@ -47,6 +47,29 @@ typedef struct {
 void oracle_ls_defaults(oracle_linesearch*);
 double oracle_ls_run(oracle_linesearch*, oracle_merit_fn, void*, double, double, double);
 
+/* --- AL / conic pieces (al_oracle.c) ------------------------------------------------------------ */
+#define ORACLE_MAX_CON 4
+#define ORACLE_MAX_P 8
+#define ORACLE_MAX_W 24
+typedef struct {
+  int type, p;
+  double G[ORACLE_MAX_P * ORACLE_MAX_W];
+  double g[ORACLE_MAX_P];
+  double val[ORACLE_MAX_P], z[ORACLE_MAX_P], z_est[ORACLE_MAX_P], z_proj[ORACLE_MAX_P], proj_jvp[ORACLE_MAX_P];
+  double proj_jac[ORACLE_MAX_P * ORACLE_MAX_P], proj_hess[ORACLE_MAX_P * ORACLE_MAX_P];
+  double jac_tmp[ORACLE_MAX_P * ORACLE_MAX_W], hess[ORACLE_MAX_W * ORACLE_MAX_W];
+  double rho;
+} oracle_con;
+typedef struct { int ncon; oracle_con con[ORACLE_MAX_CON]; } oracle_kp_cons;
+void oracle_al_constraints(oracle_kp_cons*, int, int, const double*, const double*);
+void oracle_al_projected_duals(oracle_kp_cons*);
+double oracle_al_cost(oracle_kp_cons*);
+void oracle_al_gradient(oracle_kp_cons*, int, int, int, double*, double*);
+void oracle_al_hessian(oracle_kp_cons*, int, int, int, double*, double*, double*);
+double oracle_al_violation(oracle_kp_cons*);
+void oracle_al_dual_update(oracle_kp_cons*);
+void oracle_al_penalty_update(oracle_kp_cons*, double, double);
+
 /* --- problem + solver state ------------------------------------------------------ */
 enum { ORACLE_DYN_LINEAR = 0, ORACLE_DYN_MODEL = 1 };
 enum { ORACLE_COST_QUADRATIC = 0, ORACLE_COST_DIAGONAL = 1 };
@@ -78,6 +101,9 @@ typedef struct {
   int ls_iters, iterations, status, backward_status;
   int n_merit_evals;
   double last_alpha, last_stationarity;
+  /* augmented Lagrangian (solver_options.hpp:27-29, solver.cpp:383-409) */
+  oracle_kp_cons* cons;   /* [N+1] */
+  double penalty_initial, penalty_scaling, penalty_max, rho, last_feasibility;
 } oracle_ilqr;
 
 static double* dalloc(size_t n) { return (double*)calloc(n ? n : 1, sizeof(double)); }
@@ -106,6 +132,8 @@ void* oracle_ilqr_create(int N, int n, int m, float h, int dyn_kind, int model_k
   s->nx = (int*)calloc(np, sizeof(int)); s->nu = (int*)calloc(np, sizeof(int));
   for (size_t k = 0; k < np; ++k) { s->nx[k] = n; s->nu[k] = m; }
   s->ptr = (double**)calloc(24 * np, sizeof(double*));
+  s->cons = (oracle_kp_cons*)calloc(np, sizeof(oracle_kp_cons));
+  s->penalty_initial = 1.0; s->penalty_scaling = 10.0; s->penalty_max = 1e8;
   s->iterations_max = 200;
   s->tol_stationarity = 1e-4;
   s->tol_primal_feasibility = 1e-4;
@@ -121,7 +149,7 @@ void oracle_ilqr_destroy(void* h) {
                    s->u, s->y, s->x_, s->u_, s->y_, s->A, s->B, s->f, s->lxx, s->luu, s->lux,
                    s->lx, s->lu, s->K, s->d, s->P, s->p, s->Qblk, s->dx_da, s->du_da};
   for (size_t i = 0; i < sizeof(all) / sizeof(all[0]); ++i) free(all[i]);
-  free(s->nx); free(s->nu); free(s->ptr); free(s);
+  free(s->nx); free(s->nu); free(s->ptr); free(s->cons); free(s);
 }
 
 void oracle_ilqr_set_options(void* h, int iterations_max, double tol_stat, double tol_feas,
@@ -257,7 +285,7 @@ static void kp_dynamics_expansion(oracle_ilqr* s, int k) {
 }
 
 /* CalcOriginalCost (:616-648) at the candidate point */
-static double kp_cost(oracle_ilqr* s, int k) {
+static double kp_original_cost(oracle_ilqr* s, int k) {
   const int n = s->n, m = s->m;
   const double *x = XK(s->x_, k), *u = UK(s->u_, k);
   const double* Q = NNK(s->Qc, k);
@@ -298,7 +326,7 @@ static double kp_cost(oracle_ilqr* s, int k) {
 }
 
 /* CalcOriginalCostGradient (:650-681) at the candidate point */
-static void kp_cost_gradient(oracle_ilqr* s, int k) {
+static void kp_original_cost_gradient(oracle_ilqr* s, int k) {
   const int n = s->n, m = s->m;
   const double *x = XK(s->x_, k), *u = UK(s->u_, k);
   double* lx = XK(s->lx, k);
@@ -327,7 +355,7 @@ static void kp_cost_gradient(oracle_ilqr* s, int k) {
 }
 
 /* CalcOriginalCostHessian (:683-708) */
-static void kp_cost_hessian(oracle_ilqr* s, int k) {
+static void kp_original_cost_hessian(oracle_ilqr* s, int k) {
   const int n = s->n, m = s->m;
   int terminal = (k == s->N);
   if (s->cost_kind == ORACLE_COST_QUADRATIC) {
@@ -349,11 +377,53 @@ static void kp_cost_hessian(oracle_ilqr* s, int k) {
   }
 }
 
+/* CalcConstraints / CalcCost / CalcCostGradient / CalcCostHessian with the AL terms (:421-448) */
+static void kp_constraints(oracle_ilqr* s, int k) {
+  oracle_al_constraints(&s->cons[k], s->n, s->m, XK(s->x_, k), UK(s->u_, k));
+}
+static double kp_cost(oracle_ilqr* s, int k) {
+  kp_constraints(s, k);
+  return kp_original_cost(s, k) + oracle_al_cost(&s->cons[k]);
+}
+static void kp_cost_gradient(oracle_ilqr* s, int k) {
+  kp_original_cost_gradient(s, k);
+  oracle_al_gradient(&s->cons[k], s->n, s->m, k == s->N, XK(s->lx, k), k < s->N ? UK(s->lu, k) : NULL);
+}
+static void kp_cost_hessian(oracle_ilqr* s, int k) {
+  kp_original_cost_hessian(s, k);
+  if (s->cons[k].ncon)
+    oracle_al_hessian(&s->cons[k], s->n, s->m, k == s->N, NNK(s->lxx, k), k < s->N ? MMK(s->luu, k) : NULL,
+                      k < s->N ? NMK(s->lux, k) : NULL);
+}
+
+/* ALTROSolver::SetConstraint with a linear function c = G [x;u] - g (G is p x (n+m), column-major) */
+int oracle_ilqr_add_linear_constraint(void* h, int k, int type, int p, const double* G, const double* g) {
+  oracle_ilqr* s = (oracle_ilqr*)h;
+  oracle_kp_cons* kc = &s->cons[k];
+  if (kc->ncon >= ORACLE_MAX_CON || p > ORACLE_MAX_P || s->n + s->m > ORACLE_MAX_W) return -1;
+  oracle_con* c = &kc->con[kc->ncon++];
+  memset(c, 0, sizeof(*c));
+  c->type = type; c->p = p; c->rho = 1.0;
+  memcpy(c->G, G, sizeof(double) * p * (s->n + s->m));
+  memcpy(c->g, g, sizeof(double) * p);
+  return kc->ncon - 1;
+}
+void oracle_ilqr_set_penalty_options(void* h, double initial, double scaling, double pmax) {
+  oracle_ilqr* s = (oracle_ilqr*)h;
+  s->penalty_initial = initial; s->penalty_scaling = scaling; s->penalty_max = pmax;
+}
+double oracle_ilqr_feasibility(void* h) { /* solver.cpp:224-231 */
+  oracle_ilqr* s = (oracle_ilqr*)h;
+  double viol = 0;
+  for (int k = 0; k <= s->N; ++k) viol = fmax(viol, oracle_al_violation(&s->cons[k]));
+  return viol;
+}
+
 /* KnotPointData::Initialize tail (:381-396) */
 void oracle_ilqr_initialize(void* h) {
   oracle_ilqr* s = (oracle_ilqr*)h;
   for (int k = 0; k <= s->N; ++k) {
-    kp_cost_hessian(s, k);
+    kp_original_cost_hessian(s, k);
     if (k == s->N) memcpy(XK(s->lx, k), XK(s->qc, k), sizeof(double) * s->n);
     if (k < s->N && s->dyn_kind == ORACLE_DYN_LINEAR) {
       memcpy(XK(s->lx, k), XK(s->qc, k), sizeof(double) * s->n);
@@ -559,9 +629,11 @@ int oracle_ilqr_solve(void* h, double* log, int log_cap) {
   oracle_ilqr_open_loop_rollout(h);
   oracle_ilqr_copy_trajectory(h);
   (void)oracle_ilqr_calc_cost(h);
+  s->rho = s->penalty_initial;
   for (int k = 0; k <= s->N; ++k) {
     if (k < s->N) kp_dynamics_expansion(s, k);
     kp_cost_gradient(s, k);
+    for (int j = 0; j < s->cons[k].ncon; ++j) s->cons[k].con[j].rho = s->penalty_initial;   /* SetPenalty (:429) */
   }
   int is_converged = 0, stop = 0, iter;
   s->status = 1;
@@ -573,12 +645,14 @@ int oracle_ilqr_solve(void* h, double* log, int log_cap) {
     int err = oracle_ilqr_forward_pass(h, &alpha);
     if (err == 2) stop = 1;
     double stationarity = oracle_ilqr_stationarity(h);
-    double feasibility = 0.0;
+    double feasibility = oracle_ilqr_feasibility(h);
+    s->last_feasibility = feasibility;
     oracle_ilqr_copy_trajectory(h);
     if (log && iter < log_cap) {
-      double* L = log + 6 * (size_t)iter;
+      double* L = log + 8 * (size_t)iter;
       L[0] = alpha; L[1] = s->phi0; L[2] = s->phi; L[3] = s->dphi0; L[4] = stationarity;
       L[5] = s->ls_iters;
+      L[6] = feasibility; L[7] = s->rho;
     }
     s->last_alpha = alpha;
     s->last_stationarity = stationarity;
@@ -588,8 +662,17 @@ int oracle_ilqr_solve(void* h, double* log, int log_cap) {
       s->status = 0;
     }
     if (stationarity < sqrt(s->tol_stationarity)) {
-      /* no constraints: DualUpdate/PenaltyUpdate are no-ops; gradients recomputed (:483-486) */
-      for (int k = 0; k <= s->N; ++k) kp_cost_gradient(s, k);
+      /* DualUpdate, PenaltyUpdate (only while infeasible), then refresh projected duals + gradients
+       * from the constraint values cached by the forward pass (solver.cpp:474-489) */
+      for (int k = 0; k <= s->N; ++k) oracle_al_dual_update(&s->cons[k]);
+      if (feasibility > s->tol_primal_feasibility) {
+        for (int k = 0; k <= s->N; ++k) oracle_al_penalty_update(&s->cons[k], s->penalty_scaling, s->penalty_max);
+        s->rho = fmin(s->rho * s->penalty_scaling, s->penalty_max);
+      }
+      for (int k = 0; k <= s->N; ++k) {
+        oracle_al_projected_duals(&s->cons[k]);
+        kp_cost_gradient(s, k);
+      }
     }
     if (stop) break;
   }

@@ -76,6 +76,13 @@ def lib():
         L.oracle_ilqr_forward_pass.restype = C.c_int
         L.oracle_ilqr_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.oracle_ilqr_solve.restype = C.c_int
+        L.oracle_ilqr_add_linear_constraint.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.oracle_ilqr_set_penalty_options.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double]
+        L.oracle_ilqr_feasibility.argtypes = [C.c_void_p]
+        L.oracle_ilqr_feasibility.restype = C.c_double
+        L.oracle_cone_projection.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.oracle_cone_jacobian.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.oracle_cone_hessian.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_ilqr_iterations.argtypes = [C.c_void_p]
         L.oracle_ilqr_merit_evals.argtypes = [C.c_void_p]
         L.oracle_ilqr_delta_V.argtypes = [C.c_void_p, C.c_int]
@@ -125,6 +132,7 @@ class Model(C.Structure):
 MODEL_DI, MODEL_PENDULUM, MODEL_BICYCLE = 0, 1, 2
 DYN_LINEAR, DYN_MODEL = 0, 1
 COST_QUADRATIC, COST_DIAGONAL = 0, 1
+CONE_EQUALITY, CONE_IDENTITY, CONE_INEQUALITY, CONE_SOC = 0, 1, 2, 3
 
 
 def make_model(kind, dim=0, frame=0, length=2.7, lr=1.5):
@@ -210,8 +218,23 @@ class ILQR:
         err = self.L.oracle_ilqr_forward_pass(self.h, C.byref(a))
         return err, a.value
 
+    def add_linear_constraint(self, k, cone, G, g):
+        """c(x,u) = G [x;u] - g in `cone` (CONE_*); G is (p, n+m) row-major numpy."""
+        G = np.asarray(G, dtype=np.float64)
+        g = np.ascontiguousarray(g, dtype=np.float64)
+        Gc = np.ascontiguousarray(G.T)   # column-major p x (n+m)
+        rc = self.L.oracle_ilqr_add_linear_constraint(self.h, int(k), int(cone), int(G.shape[0]), _p(Gc), _p(g))
+        assert rc >= 0
+        return rc
+
+    def set_penalty(self, initial=1.0, scaling=10.0, pmax=1e8):
+        self.L.oracle_ilqr_set_penalty_options(self.h, float(initial), float(scaling), float(pmax))
+
+    def feasibility(self):
+        return self.L.oracle_ilqr_feasibility(self.h)
+
     def solve(self, log_cap=256):
-        log = np.zeros((log_cap, 6))
+        log = np.zeros((log_cap, 8))   # alpha, phi0, phi, dphi0, stationarity, ls_iters, feasibility, rho
         status = self.L.oracle_ilqr_solve(self.h, _p(log), log_cap)
         it = self.L.oracle_ilqr_iterations(self.h)
         return status, it, log[:it]

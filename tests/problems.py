@@ -116,3 +116,32 @@ def c1_double_integrator(batch, N=256, first=0, h=0.01):
                 Q=Qs, R=tile(cm(R), N), H=np.zeros((batch, N, m * n)),
                 q=np.zeros((batch, N + 1, n)), r=np.zeros((batch, N, m)),
                 x0=2.0 * uniform01((batch, n), 21, first * n) - 1.0)
+
+
+# ---- constrained double integrator (test/double_integrator_test.cpp:170-493) -------------------------
+CONE_EQUALITY, CONE_IDENTITY, CONE_INEQUALITY, CONE_SOC = 0, 1, 2, 3
+
+
+def di_constraint_blocks(kind, N, n=4, m=2, xf=None, u_bnd=1.0):
+    """Linear constraint blocks c = G [x;u] - g of the reference's three constrained double-integrator
+    tests, as a list of (k_first, k_last_inclusive, cone, G[p, n+m], g[p]).
+      goal   : x_N - xf in {0}                                   (double_integrator_test.cpp:188-203,225)
+      bounds : goal + [u - ub; -ub - u] <= 0 at k = 0..N-1        (:296-317,333-334)
+      soc    : goal + [u; ub] in SOC at k = 0..N-1                (:414-432,447-448)"""
+    xf = np.zeros(n) if xf is None else np.asarray(xf, dtype=np.float64)
+    w = n + m
+    G = np.zeros((n, w)); G[:, :n] = np.eye(n)
+    blocks = [(N, N, CONE_EQUALITY, G, xf.copy())]
+    if kind == "bounds":
+        G = np.zeros((2 * m, w))
+        G[:m, n:] = np.eye(m)
+        G[m:, n:] = -np.eye(m)
+        blocks.append((0, N - 1, CONE_INEQUALITY, G, np.full(2 * m, u_bnd)))
+    elif kind == "soc":
+        G = np.zeros((m + 1, w))
+        G[:m, n:] = np.eye(m)
+        g = np.zeros(m + 1); g[m] = -u_bnd
+        blocks.append((0, N - 1, CONE_SOC, G, g))
+    else:
+        assert kind == "goal"
+    return blocks

@@ -246,3 +246,112 @@ def test_double_integrator_solve_unconstrained(kats):
     status, iters, log = s.solve()
     assert status == 0 and iters <= 3
     assert np.linalg.norm(s.get("x")[-1] - xf) < np.linalg.norm(x0 - xf)
+
+
+def _di_constrained_oracle(kats, kind, x0=None):
+    kat = kats["double_integrator_constrained"]
+    c = kat[kind]
+    N = kat["N"]; dim = kat["dim"]; n, m = 2 * dim, dim
+    h = np.float32(np.float32(kat["tf"]) / np.float32(N))
+    s = oracle.ILQR(N, n, m, h, oracle.DYN_MODEL, oracle.MODEL_DI, model_dim=dim, cost_kind=oracle.COST_DIAGONAL)
+    xf = np.array(kat["xf"], dtype=float)
+    for k in range(N + 1):
+        s.L.oracle_ilqr_set_lqr_cost(s.h, k, np.full(n, kat["Q"]), np.full(m, kat["R"]), xf.copy(), np.zeros(m))
+    x0 = np.array(c["x0"], dtype=float) if x0 is None else np.asarray(x0, dtype=float)
+    s.L.oracle_ilqr_set_initial_state(s.h, x0)
+    for (k0, k1, cone, G, g) in problems.di_constraint_blocks(kind, N, n, m, xf, kat["u_bnd"]):
+        for k in range(k0, k1 + 1):
+            s.add_linear_constraint(k, cone, G, g)
+    s.L.oracle_ilqr_initialize(s.h)
+    s.set_penalty(c["penalty_initial"], c["penalty_scaling"])
+    return s, c, xf
+
+
+@pytest.mark.parametrize("kind", ["goal", "bounds", "soc"])
+def test_double_integrator_constrained_iterations(kats, kind):
+    """test/double_integrator_test.cpp:255-256, 366-375, 482-492: the AL/conic restatement must reproduce the
+    reference's exact iteration counts (3 / 5 / 9), goal distance < 1e-4, and saturated controls."""
+    s, c, xf = _di_constrained_oracle(kats, kind)
+    status, iters, log = s.solve()
+    assert status == 0
+    assert iters == c["iterations"], log
+    assert np.linalg.norm(s.get("x")[-1] - xf) < c["goal_tol"]
+    u0 = s.get("u")[0]
+    if kind == "bounds":
+        assert np.allclose(u0, c["u0"], atol=c["u0_tol"])
+    if kind == "soc":
+        assert abs(np.linalg.norm(u0) - c["u0_norm"]) < c["u0_norm_tol"]
+
+
+def test_cone_projection_properties():
+    """cones.cpp:13-202 restatement: projection idempotent, Jacobian == finite difference of the projection,
+    Hessian == finite difference of J(x)^T b."""
+    import ctypes as C
+    L = oracle.lib()
+    rng = np.random.default_rng(5)
+    for trial in range(200):
+        dim = int(rng.integers(2, 6))
+        x = rng.normal(size=dim)
+        if trial % 3 == 0:
+            x[-1] = abs(x[-1]) * 0.3    # mostly outside the cone
+        b = rng.normal(size=dim)
+        px = np.zeros(dim); ppx = np.zeros(dim)
+        for cone in (0, 1, 2, 3):
+            L.oracle_cone_projection(cone, dim, x.ctypes.data, px.ctypes.data)
+            L.oracle_cone_projection(cone, dim, px.ctypes.data, ppx.ctypes.data)
+            assert np.allclose(px, ppx, atol=1e-12)
+            J = np.zeros((dim, dim))
+            L.oracle_cone_jacobian(cone, dim, x.ctypes.data, J.ctypes.data)
+            J = J.T   # column-major
+            eps = 1e-6
+            Jfd = np.zeros((dim, dim))
+            skip = False
+            for j in range(dim):
+                xp = x.copy(); xp[j] += eps; xm = x.copy(); xm[j] -= eps
+                a = np.zeros(dim); c = np.zeros(dim)
+                L.oracle_cone_projection(cone, dim, xp.ctypes.data, a.ctypes.data)
+                L.oracle_cone_projection(cone, dim, xm.ctypes.data, c.ctypes.data)
+                Jfd[:, j] = (a - c) / (2 * eps)
+            if cone == 2 and np.min(np.abs(x)) < 1e-4:
+                skip = True
+            if cone == 3:
+                a_ = np.linalg.norm(x[:-1])
+                if min(abs(a_ - x[-1]), abs(a_ + x[-1])) < 1e-3:
+                    skip = True
+            if not skip:
+                assert np.allclose(J, Jfd, atol=1e-6), (cone, x)
+            if cone == 3 and not skip:
+                H = np.zeros((dim, dim))
+                L.oracle_cone_hessian(cone, dim, x.ctypes.data, b.ctypes.data, H.ctypes.data)
+                Hfd = np.zeros((dim, dim))
+                for j in range(dim):
+                    xp = x.copy(); xp[j] += eps; xm = x.copy(); xm[j] -= eps
+                    Jp = np.zeros((dim, dim)); Jm = np.zeros((dim, dim))
+                    L.oracle_cone_jacobian(cone, dim, xp.ctypes.data, Jp.ctypes.data)
+                    L.oracle_cone_jacobian(cone, dim, xm.ctypes.data, Jm.ctypes.data)
+                    Hfd[:, j] = (Jp.T.T @ b - Jm.T.T @ b) / (2 * eps)   # column-major J => J^T b == Jcm @ b
+                assert np.allclose(H.T, Hfd, atol=1e-5), (x, b)
+
+
+def test_pendulum_goal_constrained(kats):
+    """test/pendulum_test.cpp:117-203: goal constraint c = xf - x (EQUALITY) at k = N; Success, distance to goal
+    < 1e-4 in <= 10 iterations."""
+    kat = kats["pendulum_goal_constrained"]
+    N = kat["N"]; n, m = 2, 1
+    h = np.float32(np.float32(kat["tf"]) / float(N))
+    s = oracle.ILQR(N, n, m, h, oracle.DYN_MODEL, oracle.MODEL_PENDULUM, cost_kind=oracle.COST_DIAGONAL)
+    xf = np.array(kat["xf_pi"]) * np.pi
+    for k in range(N + 1):
+        Qd = np.full(n, kat["Qfd"] if k == N else kat["Qd"])
+        s.L.oracle_ilqr_set_lqr_cost(s.h, k, Qd, np.full(m, kat["Rd"]), xf.copy(), np.zeros(m))
+    s.L.oracle_ilqr_set_initial_state(s.h, np.array(kat["x0"], dtype=float))
+    G = np.zeros((n, n + m)); G[:, :n] = -np.eye(n)
+    s.add_linear_constraint(N, oracle.CONE_EQUALITY, G, -xf)
+    s.L.oracle_ilqr_initialize(s.h)
+    for k in range(N):
+        s.L.oracle_ilqr_set_input(s.h, k, np.full(m, kat["u_init"]))
+    s.L.oracle_ilqr_set_options(s.h, kat["iterations_max"], 1e-4, 1e-4, 1e-8, 0)
+    status, iters, log = s.solve()
+    assert status == 0
+    assert iters <= kat["max_iterations"]
+    assert np.linalg.norm(s.get("x")[-1] - xf) < kat["goal_tol"]

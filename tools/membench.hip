@@ -72,6 +72,38 @@ __global__ __launch_bounds__(64) void stream_records(const double* __restrict__ 
   }
 }
 
+// forward-sweep pattern: per step read two fully-used records (204 + 208 doubles), write 28 doubles
+template <int DEPTH>
+__global__ __launch_bounds__(64) void stream_fwd(const double* __restrict__ dyn, const double* __restrict__ outr, double* __restrict__ xuy, int N, int batch) {
+  const int lane = threadIdx.x, b = blockIdx.x;
+  double buf[DEPTH + 1][7];
+  auto load = [&](double* r, int k) {
+    const double* d = dyn + ((size_t)k * batch + b) * 204;
+    const double* o = outr + ((size_t)k * batch + b) * 208;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) r[c] = d[c * 64 + lane];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) r[3 + c] = o[c * 64 + lane];
+    r[6] = o[192 + (lane & 15)] + d[192 + (lane < 12 ? lane : 11)];
+  };
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) load(buf[d], d);
+  double acc = 0.0;
+  for (int k = 0; k < N; ++k) {
+    int kp = k + DEPTH; if (kp >= N) kp = N - 1;
+    load(buf[DEPTH], kp);
+    double s = 0;
+#pragma unroll
+    for (int c = 0; c < 7; ++c) s += buf[0][c];
+    acc += s;
+    xuy[((size_t)k * batch + b) * 28 + (lane % 28)] = acc;
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+      for (int c = 0; c < 7; ++c) buf[d][c] = buf[d + 1][c];
+  }
+}
+
 int main() {
   const int N = 256, batch = 4096;
   const size_t in_n = (size_t)batch * N * 428, out_n = (size_t)batch * N * 208;
@@ -103,5 +135,10 @@ int main() {
   timeit("records [k][b] depth1 nt stores", rb, [&] { stream_records<1, 1, 1><<<batch, 64>>>(in, out, N, batch); });
   timeit("records [b][k] depth1 nt stores", rb, [&] { stream_records<1, 0, 1><<<batch, 64>>>(in, out, N, batch); });
   timeit("records [b][k] depth3", rb, [&] { stream_records<3, 0, 0><<<batch, 64>>>(in, out, N, batch); });
+  {
+    const double fb = (double)batch * N * (204 + 208 + 28) * 8;
+    timeit("forward pattern (412 r + 28 w) depth1", fb, [&] { stream_fwd<1><<<batch, 64>>>(in, in + (size_t)batch * N * 204, out, N, batch); });
+    timeit("forward pattern (412 r + 28 w) depth3", fb, [&] { stream_fwd<3><<<batch, 64>>>(in, in + (size_t)batch * N * 204, out, N, batch); });
+  }
   return 0;
 }
