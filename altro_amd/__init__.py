@@ -33,7 +33,10 @@ C_ABI_SYMBOLS = [
     "altro_hip_stationarity", "altro_hip_get_nominal", "altro_hip_get_expansion",
     "altro_hip_default_solve_options", "altro_hip_ilqr_solve", "altro_hip_last_solve_counts",
     "altro_hip_linesearch_host",
+    "altro_hip_add_linear_constraint", "altro_hip_clear_constraints", "altro_hip_reset_duals",
+    "altro_hip_get_duals", "altro_hip_feasibility",
 ]
+CONE_EQUALITY, CONE_IDENTITY, CONE_INEQUALITY, CONE_SOC = 0, 1, 2, 3   # ConstraintType, typedefs.hpp:29-34
 
 MODEL_LINEAR, MODEL_DOUBLE_INTEGRATOR, MODEL_PENDULUM, MODEL_BICYCLE = 0, 1, 2, 3
 MERIT_FN = C.CFUNCTYPE(None, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p)
@@ -42,12 +45,14 @@ MERIT_FN = C.CFUNCTYPE(None, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_do
 class SolveOptions(C.Structure):
     _fields_ = [("iterations_max", C.c_int), ("tol_stationarity", C.c_double),
                 ("tol_primal_feasibility", C.c_double), ("tol_meritfun_gradient", C.c_double),
-                ("use_backtracking_linesearch", C.c_int)]
+                ("use_backtracking_linesearch", C.c_int), ("penalty_initial", C.c_double),
+                ("penalty_scaling", C.c_double), ("penalty_max", C.c_double)]
 
 
 class SolveResult(C.Structure):
     _fields_ = [("status", C.c_int), ("iterations", C.c_int), ("stationarity", C.c_double),
-                ("final_alpha", C.c_double), ("final_phi", C.c_double)]
+                ("final_alpha", C.c_double), ("final_phi", C.c_double), ("primal_feasibility", C.c_double),
+                ("penalty", C.c_double), ("dual_updates", C.c_int)]
 
 
 class AltroHipError(RuntimeError):
@@ -105,6 +110,11 @@ def lib():
         L.altro_hip_stationarity.argtypes = [vp, vp]
         L.altro_hip_get_nominal.argtypes = [vp, vp, vp]
         L.altro_hip_get_expansion.argtypes = [vp, vp, vp, vp, vp]
+        L.altro_hip_add_linear_constraint.argtypes = [vp, i, i, i, i, vp, vp, i]
+        L.altro_hip_clear_constraints.argtypes = [vp]
+        L.altro_hip_reset_duals.argtypes = [vp, d]
+        L.altro_hip_get_duals.argtypes = [vp, i, i, vp]
+        L.altro_hip_feasibility.argtypes = [vp, vp]
         L.altro_hip_default_solve_options.argtypes = [C.POINTER(SolveOptions)]
         L.altro_hip_default_solve_options.restype = None
         L.altro_hip_ilqr_solve.argtypes = [vp, C.POINTER(SolveOptions), vp]
@@ -256,10 +266,45 @@ class Batch:
         _check(self.L.altro_hip_get_expansion(self.h, *[v.ctypes.data_as(C.c_void_p) for v in (A, Bm, lx, lu)]))
         return A, Bm, lx, lu
 
+    def add_linear_constraint(self, k_first, k_last, cone, G, g):
+        """c = G [x;u] - g in `cone` at knot points k_first..k_last (inclusive).  G: (p, n+m) numpy (row-major
+        here, sent column-major); g: (p,) shared by the batch or (batch, p) per problem.  Returns the block id."""
+        G = np.asarray(G, dtype=np.float64)
+        g = np.ascontiguousarray(g, dtype=np.float64)
+        Gc = np.ascontiguousarray(G.T)
+        per_problem = int(g.ndim == 2)
+        if per_problem:
+            assert g.shape == (self.batch, G.shape[0])
+        rc = self.L.altro_hip_add_linear_constraint(self.h, int(k_first), int(k_last), int(cone), int(G.shape[0]),
+                                                    Gc.ctypes.data_as(C.c_void_p), g.ctypes.data_as(C.c_void_p),
+                                                    per_problem)
+        if rc < 0:
+            _check(rc)
+        return rc
+
+    def clear_constraints(self):
+        _check(self.L.altro_hip_clear_constraints(self.h))
+
+    def reset_duals(self, penalty=1.0):
+        _check(self.L.altro_hip_reset_duals(self.h, float(penalty)))
+
+    def get_duals(self, k, slot, p):
+        out = np.zeros((self.batch, p))
+        _check(self.L.altro_hip_get_duals(self.h, int(k), int(slot), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def feasibility(self):
+        out = np.zeros(self.batch)
+        _check(self.L.altro_hip_feasibility(self.h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def ilqr_solve(self, iterations_max=200, tol_stationarity=1e-4, tol_meritfun_gradient=1e-8,
-                   use_backtracking=False):
+                   use_backtracking=False, tol_primal_feasibility=1e-4, penalty_initial=1.0, penalty_scaling=10.0,
+                   penalty_max=1e8):
         o = SolveOptions()
         self.L.altro_hip_default_solve_options(C.byref(o))
+        o.tol_primal_feasibility = tol_primal_feasibility
+        o.penalty_initial, o.penalty_scaling, o.penalty_max = penalty_initial, penalty_scaling, penalty_max
         o.iterations_max, o.tol_stationarity = iterations_max, tol_stationarity
         o.tol_meritfun_gradient, o.use_backtracking_linesearch = tol_meritfun_gradient, int(use_backtracking)
         res = (SolveResult * self.batch)()
@@ -269,6 +314,9 @@ class Batch:
         return dict(status=np.array([r.status for r in res]), iterations=np.array([r.iterations for r in res]),
                     stationarity=np.array([r.stationarity for r in res]),
                     alpha=np.array([r.final_alpha for r in res]), phi=np.array([r.final_phi for r in res]),
+                    feasibility=np.array([r.primal_feasibility for r in res]),
+                    penalty=np.array([r.penalty for r in res]),
+                    dual_updates=np.array([r.dual_updates for r in res]),
                     sweeps=sw.value, merit_launches=ml.value)
 
 

@@ -82,6 +82,17 @@ struct altro_hip_batch {
   int *i_active = nullptr, *i_counters = nullptr;
   ModelParams model{MODEL_LINEAR, 0.0f, 0, 2.7, 1.5};
   bool model_set = false, lqr_cost_set = false, guess_set = false;
+  // augmented-Lagrangian constraint blocks (plan LANE): host mirrors + device tables, uploaded lazily
+  std::vector<AlDef> al_defs;
+  std::vector<AlKnot> al_knots;
+  std::vector<double> al_G;                  // pool of G blocks, column-major p x (n+m)
+  std::vector<std::vector<double>> al_g;     // per block: [p] or [batch][p]
+  int al_rows = 0;
+  bool al_dirty = false;
+  AlDef* al_d_defs = nullptr;
+  AlKnot* al_d_knots = nullptr;
+  void *al_d_G = nullptr, *al_d_g = nullptr, *al_d_z = nullptr;
+  const int* bwd_active = nullptr;           // per-problem mask for the backward sweep inside ilqr_solve
   // staging for host <-> device conversion (grown lazily, never inside the hot path)
   void* stage = nullptr;
   size_t stage_bytes = 0;
@@ -291,7 +302,7 @@ LaneSizes lane_sizes(int n, int m) {
 template <typename T>
 int lane_launch(altro_hip_batch* h, bool backward, double reg) {
   LaneArgs<T> a{(const T*)h->l_in, (const T*)h->l_term, (T*)h->l_out, (T*)h->l_outn, (const T*)h->l_x0,
-                (T*)h->l_xuy, (T*)h->delta_V, h->status, h->N, h->batch, (T)reg};
+                (T*)h->l_xuy, (T*)h->delta_V, h->status, h->N, h->batch, (T)reg, backward ? h->bwd_active : nullptr};
   const dim3 grid((h->batch + 63) / 64), block(64);
 #define X(N_, M_)                                                                                     \
   if (h->n == N_ && h->m == M_) {                                                                     \
@@ -407,11 +418,63 @@ bool ilqr_supported(int kind, int n, int m) {
 #undef X
   return false;
 }
-enum IlqrKernel { IK_ROLLOUT, IK_ACCEPT, IK_EXPAND, IK_MERIT, IK_STATIONARITY };
+enum IlqrKernel { IK_ROLLOUT, IK_ACCEPT, IK_EXPAND, IK_MERIT, IK_STATIONARITY, IK_DUAL };
+
+// (re)build the device tables of the constraint blocks; duals restart from zero when the structure changes
+template <typename T>
+int al_upload_typed(altro_hip_batch* h) {
+  const int64_t B = h->batch;
+  for (void** p : {(void**)&h->al_d_defs, (void**)&h->al_d_knots, &h->al_d_G, &h->al_d_g, &h->al_d_z})
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+  if (h->al_defs.empty()) { h->al_rows = 0; return 0; }
+  std::vector<T> G(h->al_G.begin(), h->al_G.end());
+  std::vector<T> g;
+  std::vector<AlDef> defs = h->al_defs;
+  for (size_t i = 0; i < defs.size(); ++i) {
+    defs[i].g_off = (int64_t)g.size();
+    const std::vector<double>& src = h->al_g[i];
+    const int p = defs[i].p;
+    if (defs[i].g_per_problem) {
+      const size_t base = g.size();
+      g.resize(base + (size_t)p * B);
+      for (int64_t b = 0; b < B; ++b)
+        for (int r = 0; r < p; ++r) g[base + (size_t)r * B + b] = (T)src[(size_t)b * p + r];
+    } else {
+      for (int r = 0; r < p; ++r) g.push_back((T)src[r]);
+    }
+  }
+  int rows = 0;
+  std::vector<AlKnot> knots = h->al_knots;
+  for (auto& kn : knots)
+    for (int j = 0; j < kn.ncon; ++j) { kn.z_off[j] = rows; rows += defs[kn.def[j]].p; }
+  h->al_rows = rows;
+  int rc = 0;
+  if ((rc = dmalloc(h, (void**)&h->al_d_defs, defs.size() * sizeof(AlDef)))) return rc;
+  if ((rc = dmalloc(h, (void**)&h->al_d_knots, knots.size() * sizeof(AlKnot)))) return rc;
+  if ((rc = dmalloc(h, &h->al_d_G, G.size() * sizeof(T)))) return rc;
+  if ((rc = dmalloc(h, &h->al_d_g, g.size() * sizeof(T)))) return rc;
+  if ((rc = dmalloc(h, &h->al_d_z, (size_t)rows * B * sizeof(T)))) return rc;
+  HIP_TRY(hipMemcpy(h->al_d_defs, defs.data(), defs.size() * sizeof(AlDef), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->al_d_knots, knots.data(), knots.size() * sizeof(AlKnot), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->al_d_G, G.data(), G.size() * sizeof(T), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->al_d_g, g.data(), g.size() * sizeof(T), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(h->al_d_z, 0, (size_t)rows * B * sizeof(T)));
+  h->al_knots = knots;
+  return 0;
+}
+int al_upload(altro_hip_batch* h) {
+  if (!h->al_dirty) return 0;
+  int rc = h->dtype == ALTRO_HIP_F64 ? al_upload_typed<double>(h) : al_upload_typed<float>(h);
+  if (!rc) h->al_dirty = false;
+  return rc;
+}
 
 template <typename T>
 IlqrArgs<T> ilqr_args(altro_hip_batch* h, bool use_alpha, bool use_active, int want_deriv, double alpha_const) {
   IlqrArgs<T> a;
+  a.al.defs = h->al_d_defs; a.al.knots = h->al_d_knots; a.al.G = (const T*)h->al_d_G; a.al.g = (const T*)h->al_d_g;
+  a.al.z = (T*)h->al_d_z; a.al.enabled = h->al_defs.empty() ? 0 : 1;
+  a.mode = EXPAND_GRADIENT | EXPAND_HESSIAN;
   a.in = (T*)h->l_in; a.term = (T*)h->l_term; a.out = (const T*)h->l_out; a.outn = (const T*)h->l_outn;
   a.nom = (T*)h->l_nom; a.cand = (T*)h->l_xuy; a.cost = (const T*)h->l_cost; a.x0 = (const T*)h->l_x0;
   a.alpha = use_alpha ? h->i_alpha : nullptr;
@@ -426,6 +489,7 @@ int ilqr_launch(altro_hip_batch* h, int which, IlqrArgs<T> a) {
   const dim3 lanes((h->batch + 63) / 64), b64(64);
   const int64_t total = (int64_t)h->batch * (h->N + 1);
   const dim3 flat(grid_for(total)), b256(256);
+  const dim3 flat64((unsigned)std::min<int64_t>((total + 63) / 64, 1 << 20));
   bool done = false;
 #define X(K_, N_, M_)                                                                                    \
   if (!done && h->model.kind == K_ && h->n == N_ && h->m == M_) {                                        \
@@ -433,8 +497,9 @@ int ilqr_launch(altro_hip_batch* h, int which, IlqrArgs<T> a) {
     switch (which) {                                                                                     \
       case IK_ROLLOUT: hipLaunchKernelGGL((ilqr_rollout_kernel<K_, N_, M_, T>), lanes, b64, 0, h->stream, a); break; \
       case IK_ACCEPT: hipLaunchKernelGGL((ilqr_accept_kernel<N_, M_, T>), flat, b256, 0, h->stream, a); break;       \
-      case IK_EXPAND: hipLaunchKernelGGL((ilqr_expand_kernel<K_, N_, M_, T>), flat, b256, 0, h->stream, a); break;   \
+      case IK_EXPAND: hipLaunchKernelGGL((ilqr_expand_kernel<K_, N_, M_, T>), flat64, b64, 0, h->stream, a); break;  \
       case IK_MERIT: hipLaunchKernelGGL((ilqr_merit_kernel<K_, N_, M_, T>), lanes, b64, 0, h->stream, a); break;     \
+      case IK_DUAL: hipLaunchKernelGGL((ilqr_dual_update_kernel<N_, M_, T>), flat, b256, 0, h->stream, a); break;    \
       default: hipLaunchKernelGGL((ilqr_stationarity_kernel<N_, M_, T>), lanes, b64, 0, h->stream, a); break;        \
     }                                                                                                    \
   }
@@ -445,10 +510,18 @@ int ilqr_launch(altro_hip_batch* h, int which, IlqrArgs<T> a) {
   if (e != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "iLQR kernel launch: %s", hipGetErrorString(e));
   return 0;
 }
-int ilqr_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int want_deriv, double alpha_const) {
-  return h->dtype == ALTRO_HIP_F64
-             ? ilqr_launch<double>(h, which, ilqr_args<double>(h, use_alpha, use_active, want_deriv, alpha_const))
-             : ilqr_launch<float>(h, which, ilqr_args<float>(h, use_alpha, use_active, want_deriv, alpha_const));
+int ilqr_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int want_deriv, double alpha_const,
+             int mode = EXPAND_GRADIENT | EXPAND_HESSIAN) {
+  int rc = al_upload(h);
+  if (rc) return rc;
+  if (h->dtype == ALTRO_HIP_F64) {
+    auto a = ilqr_args<double>(h, use_alpha, use_active, want_deriv, alpha_const);
+    a.mode = mode;
+    return ilqr_launch<double>(h, which, a);
+  }
+  auto a = ilqr_args<float>(h, use_alpha, use_active, want_deriv, alpha_const);
+  a.mode = mode;
+  return ilqr_launch<float>(h, which, a);
 }
 int ilqr_check(altro_hip_batch* h, bool need_guess) {
   int rc = check(h);
@@ -643,6 +716,14 @@ int altro_hip_batch_create(altro_hip_batch** out, int N, int n, int m, int batch
     ALLOC(h->i_dphi, B * 8);
     ALLOC(h->i_active, B * sizeof(int));
     ALLOC(h->i_counters, 4 * sizeof(int));
+    if (!rc) {   // every constraint starts with penalty 1 (knotpoint_data.cpp:343)
+      std::vector<IlqrProb> pr((size_t)B);
+      std::memset(pr.data(), 0, pr.size() * sizeof(IlqrProb));
+      for (auto& q : pr) { q.rho = 1.0; q.rho_est = 1.0; q.status = 1; }
+      if (hipMemcpy(h->i_prob, pr.data(), pr.size() * sizeof(IlqrProb), hipMemcpyHostToDevice) != hipSuccess)
+        rc = fail(ALTRO_HIP_ERR_HIP, "control block upload failed");
+      h->al_knots.assign((size_t)N + 1, AlKnot{});
+    }
     if (!rc && hipMemset(h->l_xuy, 0, B * (N + 1) * z.e_xuy * E) != hipSuccess) rc = fail(ALTRO_HIP_ERR_HIP, "memset failed");
     if (!rc && hipMemset(h->l_cost, 0, B * (N + 1) * (2 * n + 2 * m + 1) * E) != hipSuccess) rc = fail(ALTRO_HIP_ERR_HIP, "memset failed");
   } else {
@@ -688,7 +769,8 @@ void altro_hip_batch_destroy(altro_hip_batch* h) {
   void* ptrs[] = {h->x0, h->delta_V, h->status, h->m_in, h->m_cin, h->m_term, h->m_out, h->m_outn, h->m_xuy,
                   h->m_qblk, h->m_trash, h->g_off, h->g_nx, h->g_nu, h->stage,
                   h->l_in, h->l_term, h->l_out, h->l_outn, h->l_xuy, h->l_x0,
-                  h->l_nom, h->l_cost, h->i_prob, h->i_alpha, h->i_phi, h->i_dphi, h->i_active, h->i_counters};
+                  h->l_nom, h->l_cost, h->i_prob, h->i_alpha, h->i_phi, h->i_dphi, h->i_active, h->i_counters,
+                  h->al_d_defs, h->al_d_knots, h->al_d_G, h->al_d_g, h->al_d_z};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (int a = 0; a < G_NUM; ++a) if (h->g_arr[a]) (void)hipFree(h->g_arr[a]);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -1163,6 +1245,98 @@ int altro_hip_stationarity(altro_hip_batch* h, double* out) {
   for (int b = 0; b < h->batch; ++b) out[b] = pr[b].stationarity;
   return 0;
 }
+int altro_hip_feasibility(altro_hip_batch* h, double* out) {
+  // SolverImpl::Feasibility (solver.cpp:224-231) of the candidate trajectory
+  int rc = ilqr_check(h, false);
+  if (rc) return rc;
+  if (!out) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "out == NULL");
+  rc = ilqr_run(h, IK_STATIONARITY, false, false, 0, 0.0);
+  if (rc) return rc;
+  std::vector<IlqrProb> pr(h->batch);
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(pr.data(), h->i_prob, pr.size() * sizeof(IlqrProb), hipMemcpyDeviceToHost));
+  for (int b = 0; b < h->batch; ++b) out[b] = pr[b].feasibility;
+  return 0;
+}
+
+int altro_hip_add_linear_constraint(altro_hip_batch* h, int k_first, int k_last, int cone, int p, const double* G,
+                                    const double* g, int g_per_problem) {
+  // ALTROSolver::SetConstraint (altro_solver.cpp:175-215) for c(x,u) = G [x;u] - g
+  int rc = check(h);
+  if (rc) return rc;
+  if (h->plan != ALTRO_HIP_PLAN_LANE) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "constraints need plan LANE");
+  if (!G || !g) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "G and g are required");
+  if (cone < CONE_EQUALITY || cone > CONE_SOC) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "unknown cone %d", cone);
+  const int pmax = cone == CONE_SOC ? AL_MAXSOC : AL_MAXP;
+  if (p < 1 || p > pmax) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "constraint dimension %d outside [1, %d]", p, pmax);
+  if (k_first < 0 || k_last > h->N || k_first > k_last)
+    return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "knot point range [%d, %d] outside [0, %d] (ErrorCodes::BadIndex)", k_first, k_last, h->N);
+  if ((int)h->al_defs.size() >= AL_MAXDEF) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "at most %d constraint blocks", AL_MAXDEF);
+  for (int k = k_first; k <= k_last; ++k)
+    if (h->al_knots[k].ncon >= AL_MAXC)
+      return fail(ALTRO_HIP_ERR_UNSUPPORTED, "at most %d constraint blocks per knot point (k = %d)", AL_MAXC, k);
+  const int w = h->n + h->m;
+  AlDef d{cone, p, g_per_problem ? 1 : 0, (int)h->al_G.size(), 0};
+  h->al_G.insert(h->al_G.end(), G, G + (size_t)p * w);
+  h->al_g.emplace_back(g, g + (size_t)p * (g_per_problem ? h->batch : 1));
+  const int id = (int)h->al_defs.size();
+  h->al_defs.push_back(d);
+  for (int k = k_first; k <= k_last; ++k) {
+    AlKnot& kn = h->al_knots[k];
+    kn.def[kn.ncon++] = id;
+  }
+  h->al_dirty = true;
+  return id;
+}
+int altro_hip_clear_constraints(altro_hip_batch* h) {
+  int rc = check(h);
+  if (rc) return rc;
+  h->al_defs.clear(); h->al_G.clear(); h->al_g.clear();
+  h->al_knots.assign((size_t)h->N + 1, AlKnot{});
+  h->al_dirty = true;
+  return al_upload(h);
+}
+int altro_hip_reset_duals(altro_hip_batch* h, double penalty) {
+  // duals back to zero and every constraint's penalty to `penalty` (what a fresh Initialize leaves: 1)
+  int rc = check(h);
+  if (rc) return rc;
+  if (h->plan != ALTRO_HIP_PLAN_LANE) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "constraints need plan LANE");
+  if (!(penalty > 0.0)) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "penalty must be positive");
+  if ((rc = al_upload(h))) return rc;
+  const size_t E = h->dtype == ALTRO_HIP_F64 ? 8 : 4;
+  if (h->al_d_z) HIP_TRY(hipMemsetAsync(h->al_d_z, 0, (size_t)h->al_rows * h->batch * E, h->stream));
+  std::vector<IlqrProb> pr(h->batch);
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(pr.data(), h->i_prob, pr.size() * sizeof(IlqrProb), hipMemcpyDeviceToHost));
+  for (auto& q : pr) { q.rho = penalty; q.rho_est = penalty; }
+  HIP_TRY(hipMemcpy(h->i_prob, pr.data(), pr.size() * sizeof(IlqrProb), hipMemcpyHostToDevice));
+  return 0;
+}
+int altro_hip_get_duals(altro_hip_batch* h, int k, int slot, double* z) {
+  // duals of constraint block `slot` of knot point k, [batch][p]
+  int rc = check(h);
+  if (rc) return rc;
+  if (h->plan != ALTRO_HIP_PLAN_LANE) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "constraints need plan LANE");
+  if ((rc = al_upload(h))) return rc;
+  if (k < 0 || k > h->N || slot < 0 || slot >= h->al_knots[k].ncon || !z)
+    return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "no constraint block %d at knot point %d", slot, k);
+  const AlKnot& kn = h->al_knots[k];
+  const int p = h->al_defs[kn.def[slot]].p;
+  const int64_t B = h->batch;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (h->dtype == ALTRO_HIP_F64) {
+    std::vector<double> t((size_t)p * B);
+    HIP_TRY(hipMemcpy(t.data(), (const double*)h->al_d_z + (size_t)kn.z_off[slot] * B, t.size() * 8, hipMemcpyDeviceToHost));
+    for (int64_t b = 0; b < B; ++b)
+      for (int r = 0; r < p; ++r) z[(size_t)b * p + r] = t[(size_t)r * B + b];
+  } else {
+    std::vector<float> t((size_t)p * B);
+    HIP_TRY(hipMemcpy(t.data(), (const float*)h->al_d_z + (size_t)kn.z_off[slot] * B, t.size() * 4, hipMemcpyDeviceToHost));
+    for (int64_t b = 0; b < B; ++b)
+      for (int r = 0; r < p; ++r) z[(size_t)b * p + r] = t[(size_t)r * B + b];
+  }
+  return 0;
+}
 
 int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts,
                          altro_hip_solve_result* results) {
@@ -1177,6 +1351,12 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
   la.prob = h->i_prob; la.alpha = h->i_alpha; la.active = h->i_active; la.phi = h->i_phi; la.dphi = h->i_dphi;
   la.counters = h->i_counters; la.batch = h->batch; la.iter = 0; la.iterations_max = o.iterations_max;
   la.tol_stationarity = o.tol_stationarity; la.tol_meritfun_gradient = o.tol_meritfun_gradient;
+  la.tol_primal_feasibility = o.tol_primal_feasibility;
+  la.penalty_initial = o.penalty_initial; la.penalty_scaling = o.penalty_scaling; la.penalty_max = o.penalty_max;
+  const bool al = !h->al_defs.empty();
+  la.al_enabled = al ? 1 : 0;
+  if (al && !(o.penalty_initial > 0.0 && o.penalty_scaling > 0.0 && o.penalty_max > 0.0))
+    return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "penalty_initial, penalty_scaling and penalty_max must be positive");
   la.ls = ls_default_options();
   la.ls.try_cubic_first = 1;                                   // solver.cpp:248
   la.ls.use_backtracking = o.use_backtracking_linesearch;      // solver.cpp:417
@@ -1195,12 +1375,24 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
   hipLaunchKernelGGL(ilqr_loop_init_kernel, gb, bb, 0, h->stream, la);
   rc = ilqr_run(h, IK_ROLLOUT, false, false, 0, 0.0);
   if (!rc) rc = ilqr_run(h, IK_ACCEPT, false, false, 0, 0.0);
-  if (!rc) rc = ilqr_run(h, IK_EXPAND, false, false, 0, 0.0);
+  // without constraints the cost Hessian is constant and is written once, here; with them the gradient is
+  // formed with the penalty the constraints carry so far and SetPenalty comes after it (solver.cpp:424-430)
+  if (!rc) rc = ilqr_run(h, IK_EXPAND, false, false, 0, 0.0, al ? EXPAND_GRADIENT : (EXPAND_GRADIENT | EXPAND_HESSIAN));
   if (rc) return rc;
+  if (al) hipLaunchKernelGGL(ilqr_set_penalty_kernel, gb, bb, 0, h->stream, la);
   int total_merit_launches = 0, sweeps = 0;
+  struct MaskGuard {   // the backward sweep skips problems that have stopped, only inside this loop
+    altro_hip_batch* h;
+    ~MaskGuard() { h->bwd_active = nullptr; }
+  } mask_guard{h};
+  h->bwd_active = h->i_active;
   for (int iter = 0; iter < o.iterations_max; ++iter) {
     la.iter = iter;
     hipLaunchKernelGGL(ilqr_mark_running_kernel, gb, bb, 0, h->stream, la);
+    if (al) {                                                   // CalcExpansions: cost Hessians (solver.cpp:448)
+      rc = ilqr_run(h, IK_EXPAND, false, true, 0, 0.0, EXPAND_HESSIAN);
+      if (rc) return rc;
+    }
     rc = launch_backward(h, 0.0);                               // BackwardPass (reg = 0, solver.cpp:363)
     if (rc) return rc;
     h->backward_done = true;
@@ -1227,6 +1419,13 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
     if (rc) return rc;
     if ((rc = zero_counter(1))) return rc;
     hipLaunchKernelGGL(ilqr_finish_iter_kernel, gb, bb, 0, h->stream, la);
+    if (al) {   // DualUpdate, PenaltyUpdate, refreshed gradients for the problems that asked (solver.cpp:470-489)
+      rc = ilqr_run(h, IK_DUAL, false, false, 0, 0.0);
+      if (rc) return rc;
+      hipLaunchKernelGGL(ilqr_penalty_update_kernel, gb, bb, 0, h->stream, la);
+      rc = ilqr_run(h, IK_EXPAND, false, true, 0, 0.0, EXPAND_GRADIENT);
+      if (rc) return rc;
+    }
     if ((rc = read_counters())) return rc;
     ++sweeps;
     if (counters[1] == 0) break;
@@ -1241,6 +1440,9 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
       results[b].stationarity = pr[b].stationarity;
       results[b].final_alpha = pr[b].alpha;
       results[b].final_phi = pr[b].ls_iters > 0 ? pr[b].ls.phi : pr[b].phi0;
+      results[b].primal_feasibility = pr[b].feasibility;
+      results[b].penalty = pr[b].rho;
+      results[b].dual_updates = pr[b].n_dual_updates;
     }
   }
   h->last_sweeps = sweeps;
@@ -1255,6 +1457,9 @@ void altro_hip_default_solve_options(altro_hip_solve_options* o) {
   o->tol_primal_feasibility = 1e-4;
   o->tol_meritfun_gradient = 1e-8;
   o->use_backtracking_linesearch = 0;
+  o->penalty_initial = 1.0;
+  o->penalty_scaling = 10.0;
+  o->penalty_max = 1e8;
 }
 int altro_hip_last_solve_counts(const altro_hip_batch* h, int* sweeps, int* merit_launches) {
   if (!h) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "null handle");

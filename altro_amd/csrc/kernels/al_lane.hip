@@ -1,0 +1,348 @@
+// al_lane.hip -- augmented-Lagrangian / conic terms for the batched iLQR loop (plan LANE).
+//
+// Device-side counterparts of, in the reference:
+//   SecondOrderConeProjection / Jacobian / Hessian   src/altro/solver/cones.cpp:13-123
+//   ConicProjection*, DualCone                       cones.cpp:125-202, cones.hpp:13-30
+//   KnotPointData::CalcViolations                    knotpoint_data.cpp:489-501
+//   DualUpdate / PenaltyUpdate                       knotpoint_data.cpp:503-517, solver.cpp:383-409
+//   CalcProjectedDuals / CalcConicJacobians / CalcConicHessians    knotpoint_data.cpp:523-570
+//   CalcConstraintCosts / ..CostGradients / ..CostHessians         knotpoint_data.cpp:572-613
+//
+// Constraints are linear blocks c(x,u) = G [x;u] - g in a cone K (every constraint of the reference's
+// tests has this form).  G (p x (n+m), column-major) is shared by all problems of the batch, so its
+// entries are wave-uniform scalar loads; g is shared or per problem.  The only per-(problem, knot point)
+// state is the dual z: constraint values, estimated/projected duals, conic Jacobians and Hessians are
+// recomputed from (x, u, z, rho) wherever they are needed instead of being stored and re-read.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace altro_hip {
+
+constexpr int AL_MAXC = 2;     // constraint blocks per knot point
+constexpr int AL_MAXP = 8;     // rows per zero / identity / orthant block
+constexpr int AL_MAXSOC = 4;   // rows per second-order-cone block
+constexpr int AL_MAXDEF = 16;  // distinct blocks per handle
+
+enum { CONE_EQUALITY = 0, CONE_IDENTITY = 1, CONE_INEQUALITY = 2, CONE_SOC = 3 };   // typedefs.hpp:29-34
+
+struct AlDef {
+  int cone, p, g_per_problem;
+  int G_off;       // into the G pool (elements)
+  int64_t g_off;   // into the g pool (elements): [p] shared, or [p][batch]
+};
+struct AlKnot {
+  int ncon;
+  int def[AL_MAXC];
+  int z_off[AL_MAXC];   // first row of this block's dual in z[rows][batch]
+};
+template <typename T>
+struct AlTable {
+  const AlDef* defs;
+  const AlKnot* knots;   // [N + 1]
+  const T* G;
+  const T* g;
+  T* z;
+  int enabled;
+};
+
+// cones.cpp:13-38 (p <= AL_MAXSOC, fully unrolled so the arrays stay in registers)
+template <typename T>
+__device__ __forceinline__ void soc_projection(int p, const T* x, T* px) {
+  const int nn = p - 1;
+  T s = T(0), a = T(0);
+#pragma unroll
+  for (int i = 0; i < AL_MAXSOC; ++i) {
+    if (i < nn) a += x[i] * x[i];
+    if (i == nn) s = x[i];
+  }
+  a = sqrt(a);
+  if (a <= -s) {
+#pragma unroll
+    for (int i = 0; i < AL_MAXSOC; ++i) px[i] = T(0);
+  } else if (a <= s) {
+#pragma unroll
+    for (int i = 0; i < AL_MAXSOC; ++i) px[i] = x[i];
+  } else {
+    const T c = T(0.5) * (T(1) + s / a);
+#pragma unroll
+    for (int i = 0; i < AL_MAXSOC; ++i) px[i] = (i < nn) ? c * x[i] : (i == nn ? c * a : T(0));
+  }
+}
+
+// cones.cpp:40-77; J is column-major with leading dimension AL_MAXSOC
+template <typename T>
+__device__ __forceinline__ void soc_jacobian(int p, const T* x, T* J) {
+  const int nn = p - 1;
+  T s = T(0), a = T(0);
+#pragma unroll
+  for (int i = 0; i < AL_MAXSOC; ++i) {
+    if (i < nn) a += x[i] * x[i];
+    if (i == nn) s = x[i];
+  }
+  a = sqrt(a);
+#pragma unroll
+  for (int i = 0; i < AL_MAXSOC * AL_MAXSOC; ++i) J[i] = T(0);
+  if (a <= -s) return;
+  if (a <= s) {
+#pragma unroll
+    for (int i = 0; i < AL_MAXSOC; ++i)
+      if (i < p) J[i + i * AL_MAXSOC] = T(1);
+    return;
+  }
+  const T c = T(0.5) * (T(1) + s / a);
+#pragma unroll
+  for (int j = 0; j < AL_MAXSOC; ++j)
+#pragma unroll
+    for (int i = 0; i < AL_MAXSOC; ++i) {
+      T v = T(0);
+      if (i < nn && j < nn) {
+        v = T(-0.5) * s / (a * a * a) * x[i] * x[j];
+        v += (i == j) ? c : T(0);
+      } else if (i < nn && j == nn) {
+        v = T(0.5) * x[i] / a;
+      } else if (i == nn && j < nn) {
+        v = ((T(-0.5) * s / (a * a)) + c / a) * x[j];
+      } else if (i == nn && j == nn) {
+        v = T(0.5);
+      }
+      J[i + j * AL_MAXSOC] = v;
+    }
+}
+
+// cones.cpp:79-123: H = d/dx [J(x)^T b]
+template <typename T>
+__device__ __forceinline__ void soc_hessian(int p, const T* x, const T* bb, T* H) {
+  const int nn = p - 1;
+  T s = T(0), bs = T(0), a = T(0), vbv = T(0);
+#pragma unroll
+  for (int i = 0; i < AL_MAXSOC; ++i) {
+    if (i < nn) { a += x[i] * x[i]; vbv += x[i] * bb[i]; }
+    if (i == nn) { s = x[i]; bs = bb[i]; }
+  }
+  a = sqrt(a);
+#pragma unroll
+  for (int i = 0; i < AL_MAXSOC * AL_MAXSOC; ++i) H[i] = T(0);
+  if (a <= -s || a <= s) return;
+#pragma unroll
+  for (int i = 0; i < AL_MAXSOC; ++i) {
+    if (i >= nn) continue;
+    T hi = T(0);
+#pragma unroll
+    for (int j = 0; j < AL_MAXSOC; ++j) {
+      if (j >= nn) continue;
+      T Hij = -x[i] * x[j] / (a * a);
+      Hij += (i == j) ? T(1) : T(0);
+      hi += Hij * bb[j];
+    }
+#pragma unroll
+    for (int r = 0; r < AL_MAXSOC; ++r)
+      if (r == nn) {
+        H[i + r * AL_MAXSOC] = hi / (T(2) * a);
+        H[r + i * AL_MAXSOC] = hi / (T(2) * a);
+      }
+#pragma unroll
+    for (int j = 0; j < AL_MAXSOC; ++j) {
+      if (j > i) continue;
+      const T vij = x[i] * x[j];
+      const T H1 = hi * x[j] * (-s / (a * a * a));
+      T H2 = vij * (T(2) * vbv) / (a * a * a * a) - x[i] * bb[j] / (a * a);
+      T H3 = -vij / (a * a);
+      if (i == j) { H2 -= vbv / (a * a); H3 += T(1); }
+      H2 *= s / a;
+      H3 *= bs / a;
+      const T v = (H1 + H2 + H3) / T(2);
+      H[i + j * AL_MAXSOC] = v;
+      H[j + i * AL_MAXSOC] = v;
+    }
+  }
+}
+
+// All AL terms of one knot point of one problem.  Returns the AL cost; subtracts the gradient terms from
+// lx / lu (GRAD), adds the Gauss-Newton (+ SOC curvature) terms to lxx / luu / lux (HESS), and tracks the
+// largest constraint violation (viol != nullptr).  rho_est is the penalty the estimated duals were formed
+// with, rho the one the Hessian is scaled by -- they differ only in the first sweep of a solve, where the
+// reference evaluates the gradient before SetPenalty (solver.cpp:424-430).  When `znew` is set the
+// projected duals are written back as the new duals (DualUpdate).
+template <int n, int m, typename T, bool GRAD, bool HESS>
+__device__ __forceinline__ T al_eval(const AlTable<T>& t, int k, int64_t b, int64_t B, const T* x, const T* u,
+                                     bool terminal, T rho_est, T rho, T* lx, T* lu, T* lxx, T* luu, T* lux,
+                                     T* viol, bool dual_update) {
+  constexpr int w = n + m;
+  const AlKnot& kn = t.knots[k];
+  T cost = T(0);
+  for (int j = 0; j < kn.ncon; ++j) {
+    const AlDef& d = t.defs[kn.def[j]];
+    const int p = d.p;
+    const int cone = d.cone;
+    const T* __restrict__ G = t.G + d.G_off;
+    const T* g = t.g + d.g_off + (d.g_per_problem ? b : 0);
+    const int64_t gs = d.g_per_problem ? B : 1;
+    T* z = t.z + (int64_t)kn.z_off[j] * B + b;
+    if (cone != CONE_SOC) {
+      // zero / identity / orthant: projection and its Jacobian are diagonal (cones.cpp:125-178)
+      T zp[AL_MAXP], msk[AL_MAXP];
+      T sq = T(0);
+#pragma unroll
+      for (int i = 0; i < AL_MAXP; ++i) {
+        zp[i] = T(0); msk[i] = T(0);
+        if (i < p) {
+          T s = T(0);
+          for (int e = 0; e < n; ++e) s += G[i + e * p] * x[e];
+          if (!terminal)
+            for (int e = 0; e < m; ++e) s += G[i + (n + e) * p] * u[e];
+          const T val = s - g[(int64_t)i * gs];
+          const T ze = z[(int64_t)i * B] - rho_est * val;
+          if (cone == CONE_EQUALITY) { zp[i] = ze; msk[i] = T(1); }                     // dual cone: identity
+          else if (cone == CONE_INEQUALITY) { zp[i] = fmin(T(0), ze); msk[i] = (ze <= T(0)) ? T(1) : T(0); }
+          // CONE_IDENTITY: dual cone is the zero cone, projection 0, Jacobian 0
+          sq += zp[i] * zp[i];
+          if (viol) {
+            T v = T(0);
+            if (cone == CONE_EQUALITY) v = fabs(val);
+            else if (cone == CONE_INEQUALITY) v = fabs(fmin(T(0), val) - val);
+            *viol = fmax(*viol, v);
+          }
+          if (dual_update) z[(int64_t)i * B] = zp[i];
+        }
+      }
+      cost += sq / (T(2) * rho_est);
+      if (GRAD) {
+        for (int e = 0; e < n; ++e) {
+          T s = T(0);
+#pragma unroll
+          for (int i = 0; i < AL_MAXP; ++i)
+            if (i < p) s += G[i + e * p] * (msk[i] * zp[i]);
+          lx[e] -= s;
+        }
+        if (!terminal)
+          for (int e = 0; e < m; ++e) {
+            T s = T(0);
+#pragma unroll
+            for (int i = 0; i < AL_MAXP; ++i)
+              if (i < p) s += G[i + (n + e) * p] * (msk[i] * zp[i]);
+            lu[e] -= s;
+          }
+      }
+      if (HESS) {
+#pragma unroll
+        for (int cb = 0; cb < w; ++cb)
+#pragma unroll
+          for (int ca = 0; ca < w; ++ca) {
+            if (ca < n && cb >= n) continue;            // the reference keeps lux only
+            if (terminal && (ca >= n || cb >= n)) continue;
+            T s = T(0);
+#pragma unroll
+            for (int i = 0; i < AL_MAXP; ++i)
+              if (i < p) s += (msk[i] * G[i + ca * p]) * (msk[i] * G[i + cb * p]);
+            s = rho * s;
+            if (ca < n) lxx[ca + cb * n] += s;
+            else if (cb >= n) luu[(ca - n) + (cb - n) * m] += s;
+            else lux[(ca - n) + cb * m] += s;
+          }
+      }
+    } else {
+      T val[AL_MAXSOC], ze[AL_MAXSOC], zp[AL_MAXSOC];
+#pragma unroll
+      for (int i = 0; i < AL_MAXSOC; ++i) {
+        val[i] = T(0); ze[i] = T(0);
+        if (i < p) {
+          T s = T(0);
+          for (int e = 0; e < n; ++e) s += G[i + e * p] * x[e];
+          if (!terminal)
+            for (int e = 0; e < m; ++e) s += G[i + (n + e) * p] * u[e];
+          val[i] = s - g[(int64_t)i * gs];
+          ze[i] = z[(int64_t)i * B] - rho_est * val[i];
+        }
+      }
+      soc_projection<T>(p, ze, zp);   // the SOC is self-dual (cones.hpp:13-30)
+      T sq = T(0);
+#pragma unroll
+      for (int i = 0; i < AL_MAXSOC; ++i)
+        if (i < p) sq += zp[i] * zp[i];
+      cost += sq / (T(2) * rho_est);
+      if (viol) {
+        T pv[AL_MAXSOC];
+        soc_projection<T>(p, val, pv);
+#pragma unroll
+        for (int i = 0; i < AL_MAXSOC; ++i)
+          if (i < p) *viol = fmax(*viol, fabs(pv[i] - val[i]));
+      }
+      if (dual_update) {
+#pragma unroll
+        for (int i = 0; i < AL_MAXSOC; ++i)
+          if (i < p) z[(int64_t)i * B] = zp[i];
+      }
+      if (GRAD || HESS) {
+        T J[AL_MAXSOC * AL_MAXSOC];
+        soc_jacobian<T>(p, ze, J);
+        if (GRAD) {
+          T jvp[AL_MAXSOC];
+#pragma unroll
+          for (int i = 0; i < AL_MAXSOC; ++i) {
+            T s = T(0);
+#pragma unroll
+            for (int r = 0; r < AL_MAXSOC; ++r) s += J[r + i * AL_MAXSOC] * zp[r];
+            jvp[i] = s;
+          }
+          for (int e = 0; e < n; ++e) {
+            T s = T(0);
+#pragma unroll
+            for (int i = 0; i < AL_MAXSOC; ++i)
+              if (i < p) s += G[i + e * p] * jvp[i];
+            lx[e] -= s;
+          }
+          if (!terminal)
+            for (int e = 0; e < m; ++e) {
+              T s = T(0);
+#pragma unroll
+              for (int i = 0; i < AL_MAXSOC; ++i)
+                if (i < p) s += G[i + (n + e) * p] * jvp[i];
+              lu[e] -= s;
+            }
+        }
+        if (HESS) {
+          T Hp[AL_MAXSOC * AL_MAXSOC];
+          soc_hessian<T>(p, ze, zp, Hp);
+          T JG[AL_MAXSOC * w], HG[AL_MAXSOC * w];   // J G and Hp G, p x w
+#pragma unroll
+          for (int e = 0; e < w; ++e)
+#pragma unroll
+            for (int i = 0; i < AL_MAXSOC; ++i) {
+              T s1 = T(0), s2 = T(0);
+#pragma unroll
+              for (int r = 0; r < AL_MAXSOC; ++r)
+                if (r < p) {
+                  const T gre = G[r + e * p];
+                  s1 += J[i + r * AL_MAXSOC] * gre;
+                  s2 += Hp[i + r * AL_MAXSOC] * gre;
+                }
+              JG[i + e * AL_MAXSOC] = s1;
+              HG[i + e * AL_MAXSOC] = s2;
+            }
+#pragma unroll
+          for (int cb = 0; cb < w; ++cb)
+#pragma unroll
+            for (int ca = 0; ca < w; ++ca) {
+              if (ca < n && cb >= n) continue;
+              if (terminal && (ca >= n || cb >= n)) continue;
+              T s1 = T(0), s2 = T(0);
+#pragma unroll
+              for (int r = 0; r < AL_MAXSOC; ++r)
+                if (r < p) {
+                  s1 += JG[r + ca * AL_MAXSOC] * JG[r + cb * AL_MAXSOC];
+                  s2 += G[r + ca * p] * HG[r + cb * AL_MAXSOC];
+                }
+              const T s = rho * s1 + rho * s2;
+              if (ca < n) lxx[ca + cb * n] += s;
+              else if (cb >= n) luu[(ca - n) + (cb - n) * m] += s;
+              else lux[(ca - n) + cb * m] += s;
+            }
+        }
+      }
+    }
+  }
+  return cost;
+}
+
+}  // namespace altro_hip

@@ -9,8 +9,9 @@
 //   SolverImpl::Stationarity         solver.cpp:207-222                    -> ilqr_stationarity_kernel
 //   SolverImpl::ForwardPass + CubicLineSearch + the sweep loop of Solve (solver.cpp:237-271, :447-502)
 //                                    -> ilqr_ls_begin_kernel / ilqr_ls_feed_kernel / ilqr_finish_iter_kernel
-// Unconstrained problems with a diagonal quadratic (LQR tracking) cost -- the only cost paths that work
-// in the reference -- and a compiled-in model (models.h).
+// A diagonal quadratic (LQR tracking) cost -- the only cost paths that work in the reference (SURVEY.md
+// section 2.1) --, a compiled-in model (models.h), and linear conic constraint blocks handled by the
+// augmented Lagrangian of al_lane.hip (duals / penalties per problem; solver.cpp:383-409, :470-489).
 //
 // Buffers (all [..][element][batch], unit stride across lanes):
 //   in   [k][E_IN]   A B f Q R H q r : the backward pass's inputs; A,B,q(=lx),r(=lu) are rewritten by
@@ -25,6 +26,7 @@
 
 #include "../linesearch_sm.h"
 #include "../models.h"
+#include "al_lane.hip"
 #include "tvlqr_lane.hip"
 
 namespace altro_hip {
@@ -37,6 +39,11 @@ struct IlqrProb {       // per-problem control state of the batched solve
   double phi0, dphi0, alpha, stationarity;
   int ls_iters, evaluating;
   LsState ls;
+  // augmented Lagrangian: rho = the constraints' penalty (KnotPointData::rho_, identical for every block
+  // of a problem), rho_est = the penalty the cached projected duals were formed with, dual = what the
+  // outer update has to do after this sweep (0 nothing, 1 duals, 2 duals + penalty)
+  double rho, rho_est, feasibility;
+  int dual, n_dual_updates;
 };
 
 template <typename T>
@@ -58,7 +65,10 @@ struct IlqrArgs {
   int N, batch;
   int want_derivative;
   double alpha_const;
+  AlTable<T> al;
+  int mode;             // expand kernel: bit 0 = dynamics Jacobians + cost gradient, bit 1 = cost Hessian
 };
+enum { EXPAND_GRADIENT = 1, EXPAND_HESSIAN = 2 };
 
 template <int n, int m>
 struct IlqrDims {
@@ -117,12 +127,13 @@ __global__ void ilqr_accept_kernel(IlqrArgs<T> a) {
 // lx, lu -> the backward pass's input record.  Independent in k: the reference's own TODO
 // ("do this in parallel", solver.cpp:190).
 template <int KIND, int n, int m, typename T>
-__global__ void ilqr_expand_kernel(IlqrArgs<T> a) {
+__global__ __launch_bounds__(64) void ilqr_expand_kernel(IlqrArgs<T> a) {
   using D = LaneDims<n, m>;
   using I = IlqrDims<n, m>;
   using Mdl = DiscreteModel<KIND, n, m, T>;
   const int64_t B = a.batch;
   const int64_t total = B * (a.N + 1);
+  const bool grad = (a.mode & EXPAND_GRADIENT) != 0, hess = (a.mode & EXPAND_HESSIAN) != 0;
   for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
        t += (int64_t)gridDim.x * blockDim.x) {
     const int64_t b = t % B;
@@ -130,31 +141,49 @@ __global__ void ilqr_expand_kernel(IlqrArgs<T> a) {
     if (a.active && !a.active[b]) continue;
     const T* c = a.cand + (int64_t)k * I::E_CAND * B + b;
     const T* cs = a.cost + (int64_t)k * I::E_COST * B + b;
+    const bool terminal = k == a.N;
     T x[n], u[m];
     for (int e = 0; e < n; ++e) x[e] = c[(int64_t)e * B];
-    if (k == a.N) {   // terminal: P_N = lxx, p_N = lx
-      for (int e = 0; e < n * n; ++e)
-        a.term[(int64_t)e * B + b] = (e % n == e / n) ? cs[(int64_t)(I::C_Q + e % n) * B] : T(0);
-      for (int e = 0; e < n; ++e)
-        a.term[(int64_t)(n * n + e) * B + b] = cs[(int64_t)(I::C_Q + e) * B] * x[e] + cs[(int64_t)(I::C_q + e) * B];
+    for (int e = 0; e < m; ++e) u[e] = terminal ? T(0) : c[(int64_t)(2 * n + e) * B];
+    T lx[n], lu[m], Qm[n * n], Rm[m * m], Hm[m * n];
+    for (int e = 0; e < n; ++e) lx[e] = cs[(int64_t)(I::C_Q + e) * B] * x[e] + cs[(int64_t)(I::C_q + e) * B];
+    for (int e = 0; e < m; ++e)
+      lu[e] = terminal ? T(0) : cs[(int64_t)(I::C_R + e) * B] * u[e] + cs[(int64_t)(I::C_r + e) * B];
+    for (int e = 0; e < n * n; ++e) Qm[e] = (e % n == e / n) ? cs[(int64_t)(I::C_Q + e % n) * B] : T(0);
+    for (int e = 0; e < m * m; ++e)
+      Rm[e] = (!terminal && e % m == e / m) ? cs[(int64_t)(I::C_R + e % m) * B] : T(0);
+    for (int e = 0; e < m * n; ++e) Hm[e] = T(0);
+    if (a.al.enabled) {
+      const T rho_est = (T)a.prob[b].rho_est, rho = (T)a.prob[b].rho;
+      if (grad && hess)
+        al_eval<n, m, T, true, true>(a.al, k, b, B, x, u, terminal, rho_est, rho, lx, lu, Qm, Rm, Hm, nullptr, false);
+      else if (grad)
+        al_eval<n, m, T, true, false>(a.al, k, b, B, x, u, terminal, rho_est, rho, lx, lu, Qm, Rm, Hm, nullptr, false);
+      else
+        al_eval<n, m, T, false, true>(a.al, k, b, B, x, u, terminal, rho_est, rho, lx, lu, Qm, Rm, Hm, nullptr, false);
+    }
+    if (terminal) {   // P_N = lxx, p_N = lx
+      if (hess)
+        for (int e = 0; e < n * n; ++e) a.term[(int64_t)e * B + b] = Qm[e];
+      if (grad)
+        for (int e = 0; e < n; ++e) a.term[(int64_t)(n * n + e) * B + b] = lx[e];
       continue;
     }
-    for (int e = 0; e < m; ++e) u[e] = c[(int64_t)(2 * n + e) * B];
     T* in = a.in + (int64_t)k * D::E_IN * B + b;
-    T Am[n * n], Bm[n * m];
-    Mdl::jacobian(a.mp, x, u, Am, Bm);
-    for (int e = 0; e < n * n; ++e) in[(int64_t)(D::O_A + e) * B] = Am[e];
-    for (int e = 0; e < n * m; ++e) in[(int64_t)(D::O_B + e) * B] = Bm[e];
-    for (int e = 0; e < n; ++e) in[(int64_t)(D::O_f + e) * B] = T(0);
-    for (int e = 0; e < n * n; ++e)
-      in[(int64_t)(D::O_Q + e) * B] = (e % n == e / n) ? cs[(int64_t)(I::C_Q + e % n) * B] : T(0);
-    for (int e = 0; e < m * m; ++e)
-      in[(int64_t)(D::O_R + e) * B] = (e % m == e / m) ? cs[(int64_t)(I::C_R + e % m) * B] : T(0);
-    for (int e = 0; e < m * n; ++e) in[(int64_t)(D::O_H + e) * B] = T(0);
-    for (int e = 0; e < n; ++e)
-      in[(int64_t)(D::O_q + e) * B] = cs[(int64_t)(I::C_Q + e) * B] * x[e] + cs[(int64_t)(I::C_q + e) * B];
-    for (int e = 0; e < m; ++e)
-      in[(int64_t)(D::O_r + e) * B] = cs[(int64_t)(I::C_R + e) * B] * u[e] + cs[(int64_t)(I::C_r + e) * B];
+    if (grad) {
+      T Am[n * n], Bm[n * m];
+      Mdl::jacobian(a.mp, x, u, Am, Bm);
+      for (int e = 0; e < n * n; ++e) in[(int64_t)(D::O_A + e) * B] = Am[e];
+      for (int e = 0; e < n * m; ++e) in[(int64_t)(D::O_B + e) * B] = Bm[e];
+      for (int e = 0; e < n; ++e) in[(int64_t)(D::O_f + e) * B] = T(0);
+      for (int e = 0; e < n; ++e) in[(int64_t)(D::O_q + e) * B] = lx[e];
+      for (int e = 0; e < m; ++e) in[(int64_t)(D::O_r + e) * B] = lu[e];
+    }
+    if (hess) {
+      for (int e = 0; e < n * n; ++e) in[(int64_t)(D::O_Q + e) * B] = Qm[e];
+      for (int e = 0; e < m * m; ++e) in[(int64_t)(D::O_R + e) * B] = Rm[e];
+      for (int e = 0; e < m * n; ++e) in[(int64_t)(D::O_H + e) * B] = Hm[e];
+    }
   }
 }
 
@@ -188,6 +217,8 @@ __global__ __launch_bounds__(64) void ilqr_merit_kernel(IlqrArgs<T> a) {
   if (a.active && !a.active[b]) return;
   const T alpha = (T)(a.alpha ? a.alpha[b] : a.alpha_const);
   const bool deriv = a.want_derivative != 0;
+  const bool al = a.al.enabled != 0;
+  const T rho = al ? (T)a.prob[b].rho : T(1);   // CalcCost refreshes the projected duals with the current penalty
   T x[n], dxda[n], phi = T(0), dphi = T(0);
   for (int e = 0; e < n; ++e) { x[e] = a.x0[(int64_t)e * B + b]; dxda[e] = T(0); }
   for (int k = 0; k < N; ++k) {
@@ -210,10 +241,18 @@ __global__ __launch_bounds__(64) void ilqr_merit_kernel(IlqrArgs<T> a) {
     for (int e = 0; e < n; ++e) c[(int64_t)e * B] = x[e];
     for (int e = 0; e < m; ++e) c[(int64_t)(2 * n + e) * B] = u[e];
     Mdl::dynamics(a.mp, x, u, xn);
-    phi += ilqr_kp_cost<n, m, T>(cs, B, x, u, false);
+    T lx[n], lu[m];
+    for (int i = 0; i < n; ++i) lx[i] = cs[(int64_t)(I::C_Q + i) * B] * x[i] + cs[(int64_t)(I::C_q + i) * B];
+    for (int i = 0; i < m; ++i) lu[i] = cs[(int64_t)(I::C_R + i) * B] * u[i] + cs[(int64_t)(I::C_r + i) * B];
+    T Jk = ilqr_kp_cost<n, m, T>(cs, B, x, u, false);
+    if (al) {
+      Jk += deriv ? al_eval<n, m, T, true, false>(a.al, k, b, B, x, u, false, rho, rho, lx, lu, nullptr, nullptr, nullptr, nullptr, false)
+                  : al_eval<n, m, T, false, false>(a.al, k, b, B, x, u, false, rho, rho, lx, lu, nullptr, nullptr, nullptr, nullptr, false);
+    }
+    phi += Jk;
     if (deriv) {
       T* in = a.in + (int64_t)k * D::E_IN * B + b;
-      T Am[n * n], Bm[n * m], duda[m], dxn[n], lx[n], lu[m];
+      T Am[n * n], Bm[n * m], duda[m], dxn[n];
       Mdl::jacobian(a.mp, x, u, Am, Bm);
       for (int e = 0; e < n * n; ++e) in[(int64_t)(D::O_A + e) * B] = Am[e];
       for (int e = 0; e < n * m; ++e) in[(int64_t)(D::O_B + e) * B] = Bm[e];
@@ -229,8 +268,6 @@ __global__ __launch_bounds__(64) void ilqr_merit_kernel(IlqrArgs<T> a) {
         for (int j = 0; j < m; ++j) s2 += Bm[i + j * n] * duda[j];
         dxn[i] = s + s2;
       }
-      for (int i = 0; i < n; ++i) lx[i] = cs[(int64_t)(I::C_Q + i) * B] * x[i] + cs[(int64_t)(I::C_q + i) * B];
-      for (int i = 0; i < m; ++i) lu[i] = cs[(int64_t)(I::C_R + i) * B] * u[i] + cs[(int64_t)(I::C_r + i) * B];
       for (int e = 0; e < n; ++e) in[(int64_t)(D::O_q + e) * B] = lx[e];
       for (int e = 0; e < m; ++e) in[(int64_t)(D::O_r + e) * B] = lu[e];
       T s = T(0);
@@ -247,7 +284,14 @@ __global__ __launch_bounds__(64) void ilqr_merit_kernel(IlqrArgs<T> a) {
     const T* nm = a.nom + (int64_t)N * I::E_NOM * B + b;
     const T* cs = a.cost + (int64_t)N * I::E_COST * B + b;
     T* c = a.cand + (int64_t)N * I::E_CAND * B + b;
-    phi += ilqr_kp_cost<n, m, T>(cs, B, x, (const T*)nullptr, true);
+    T lxN[n];
+    for (int i = 0; i < n; ++i) lxN[i] = cs[(int64_t)(I::C_Q + i) * B] * x[i] + cs[(int64_t)(I::C_q + i) * B];
+    T Jk = ilqr_kp_cost<n, m, T>(cs, B, x, (const T*)nullptr, true);
+    if (al) {
+      Jk += deriv ? al_eval<n, m, T, true, false>(a.al, N, b, B, x, (const T*)nullptr, true, rho, rho, lxN, nullptr, nullptr, nullptr, nullptr, nullptr, false)
+                  : al_eval<n, m, T, false, false>(a.al, N, b, B, x, (const T*)nullptr, true, rho, rho, lxN, nullptr, nullptr, nullptr, nullptr, nullptr, false);
+    }
+    phi += Jk;
     T dx[n];
     for (int i = 0; i < n; ++i) dx[i] = x[i] - nm[(int64_t)i * B];
     for (int i = 0; i < n; ++i) {
@@ -259,15 +303,15 @@ __global__ __launch_bounds__(64) void ilqr_merit_kernel(IlqrArgs<T> a) {
     if (deriv) {
       T s = T(0);
       for (int i = 0; i < n; ++i) {
-        const T lx = cs[(int64_t)(I::C_Q + i) * B] * x[i] + cs[(int64_t)(I::C_q + i) * B];
-        a.term[(int64_t)(n * n + i) * B + b] = lx;
-        s += lx * dxda[i];
+        a.term[(int64_t)(n * n + i) * B + b] = lxN[i];
+        s += lxN[i] * dxda[i];
       }
       dphi += s;
     }
   }
   a.phi[b] = (double)phi;
   if (deriv) a.dphi[b] = (double)dphi;
+  if (al) a.prob[b].rho_est = (double)rho;
 }
 
 // Stationarity (solver.cpp:207-222) from the candidate duals and the current expansion
@@ -302,6 +346,42 @@ __global__ __launch_bounds__(64) void ilqr_stationarity_kernel(IlqrArgs<T> a) {
   for (int j = 0; j < n; ++j)
     res_x = fmax(res_x, fabs(a.term[(int64_t)(n * n + j) * B + b] - c[(int64_t)(n + j) * B]));
   a.prob[b].stationarity = (double)fmax(res_x, res_u);
+  // Feasibility (solver.cpp:224-231): largest distance of a constraint value from its cone
+  T viol = T(0);
+  if (a.al.enabled) {
+    const T rho = (T)a.prob[b].rho;
+    for (int k = 0; k <= N; ++k) {
+      const T* ck = a.cand + (int64_t)k * I::E_CAND * B + b;
+      T x[n], u[m];
+      for (int e = 0; e < n; ++e) x[e] = ck[(int64_t)e * B];
+      for (int e = 0; e < m; ++e) u[e] = k < N ? ck[(int64_t)(2 * n + e) * B] : T(0);
+      al_eval<n, m, T, false, false>(a.al, k, b, B, x, u, k == N, rho, rho, nullptr, nullptr, nullptr, nullptr,
+                                     nullptr, &viol, false);
+    }
+  }
+  a.prob[b].feasibility = (double)viol;
+}
+
+// DualUpdate (knotpoint_data.cpp:503-510): z <- the projected duals of the accepted trajectory, one thread per
+// (problem, knot point); only problems whose sweep asked for it (IlqrProb::dual != 0).
+template <int n, int m, typename T>
+__global__ void ilqr_dual_update_kernel(IlqrArgs<T> a) {
+  using I = IlqrDims<n, m>;
+  const int64_t B = a.batch;
+  const int64_t total = B * (a.N + 1);
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = t % B;
+    const int k = (int)(t / B);
+    if (!a.prob[b].dual) continue;
+    const T* ck = a.cand + (int64_t)k * I::E_CAND * B + b;
+    T x[n], u[m];
+    for (int e = 0; e < n; ++e) x[e] = ck[(int64_t)e * B];
+    for (int e = 0; e < m; ++e) u[e] = k < a.N ? ck[(int64_t)(2 * n + e) * B] : T(0);
+    const T rho = (T)a.prob[b].rho_est;
+    al_eval<n, m, T, false, false>(a.al, k, b, B, x, u, k == a.N, rho, rho, nullptr, nullptr, nullptr, nullptr,
+                                   nullptr, nullptr, true);
+  }
 }
 
 // ---- batched line search + sweep bookkeeping (one thread per problem) ---------------------------------
@@ -315,7 +395,9 @@ struct IlqrLoopArgs {
   int batch;
   int iter;
   int iterations_max;
-  double tol_stationarity, tol_meritfun_gradient;
+  double tol_stationarity, tol_meritfun_gradient, tol_primal_feasibility;
+  double penalty_initial, penalty_scaling, penalty_max;
+  int al_enabled;
   LsOptions ls;
 };
 
@@ -325,6 +407,8 @@ __global__ void ilqr_loop_init_kernel(IlqrLoopArgs a) {
   IlqrProb& p = a.prob[b];
   p.running = 1; p.iterations = 0; p.status = 1; p.ls_failed = 0; p.evaluating = 0;
   p.alpha = 0.0; p.stationarity = 0.0; p.ls_iters = 0;
+  p.feasibility = 0.0; p.dual = 0; p.n_dual_updates = 0;
+  p.rho_est = p.rho;   // the initial gradient is formed with the penalty left by Initialize / the last solve
   a.active[b] = 1;
   a.alpha[b] = 0.0;
 }
@@ -388,9 +472,15 @@ __global__ void ilqr_finish_iter_kernel(IlqrLoopArgs a) {
   IlqrProb& p = a.prob[b];
   if (p.running) {
     bool stop = p.ls_failed != 0;
-    if (fabs(p.stationarity) < a.tol_stationarity) {   // feasibility == 0 without constraints
+    if (fabs(p.stationarity) < a.tol_stationarity && p.feasibility < a.tol_primal_feasibility) {
       p.status = 0;
       stop = true;
+    }
+    // outer AL update (solver.cpp:470-489), also on the sweep that stops
+    p.dual = 0;
+    if (a.al_enabled && p.stationarity < sqrt(a.tol_stationarity)) {
+      p.dual = p.feasibility > a.tol_primal_feasibility ? 2 : 1;
+      ++p.n_dual_updates;
     }
     p.iterations = a.iter + 1;
     if (!stop && a.iter + 1 >= a.iterations_max) {
@@ -400,8 +490,28 @@ __global__ void ilqr_finish_iter_kernel(IlqrLoopArgs a) {
     }
     if (stop) p.running = 0;
   }
+  else p.dual = 0;
   a.active[b] = p.running;
   if (p.running) atomicAdd(&a.counters[1], 1);
+}
+
+// SetPenalty (solver.cpp:429) after the initial gradient
+__global__ void ilqr_set_penalty_kernel(IlqrLoopArgs a) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.batch) return;
+  a.prob[b].rho = a.penalty_initial;
+}
+
+// PenaltyUpdate (solver.cpp:396-409) after the duals of every knot point have been updated with the old
+// penalty; then the projected duals are refreshed with the new one (solver.cpp:483-486).  `active` :=
+// problems whose cost gradients have to be recomputed.
+__global__ void ilqr_penalty_update_kernel(IlqrLoopArgs a) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.batch) return;
+  IlqrProb& p = a.prob[b];
+  a.active[b] = p.dual != 0;
+  if (p.dual == 2) p.rho = fmin(p.rho * a.penalty_scaling, a.penalty_max);
+  if (p.dual) p.rho_est = p.rho;
 }
 
 // set `active` := running (used before the per-sweep kernels)

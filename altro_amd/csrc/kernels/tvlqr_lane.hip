@@ -45,6 +45,7 @@ struct LaneArgs {
   int N;
   int batch;
   T reg;
+  const int* active;   // optional per-problem mask (the batched solver skips problems that have stopped)
 };
 
 template <int n, int m, typename T>
@@ -52,6 +53,7 @@ __global__ __launch_bounds__(64) void lane_backward_kernel(LaneArgs<T> a) {
   using D = LaneDims<n, m>;
   const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (b >= a.batch) return;
+  if (a.active && !a.active[b]) return;
   const int64_t B = a.batch;
   const int N = a.N;
   T P[n * n], p[n];

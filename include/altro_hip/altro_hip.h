@@ -166,12 +166,32 @@ int altro_hip_stationarity(altro_hip_batch* h, double* stationarity); /* solver.
 int altro_hip_get_nominal(altro_hip_batch* h, double* x, double* u);
 int altro_hip_get_expansion(altro_hip_batch* h, double* A, double* B, double* lx, double* lu);
 
+/* ---- augmented-Lagrangian constraint blocks ---------------------------
+ * ALTROSolver::SetConstraint (altro_solver.cpp:175-215) for constraints of the form
+ *     c(x_k, u_k) = G [x_k; u_k] - g   in cone K,    k = k_first .. k_last (inclusive),
+ * which covers every constraint of the reference's tests (goal, control bounds, second-order-cone bound).
+ * G: host, p x (n+m) column-major, shared by the batch.  g: host, [p] or (g_per_problem) [batch][p].
+ * cone: ConstraintType order of typedefs.hpp:29-34: 0 EQUALITY, 1 IDENTITY, 2 INEQUALITY (c <= 0),
+ * 3 SECOND_ORDER_CONE (||c[0:p-1]|| <= c[p-1]).  At most 2 blocks per knot point, p <= 8 (SOC: p <= 4).
+ * Returns the block id (>= 0) or a negative error.  Duals and penalties live on the device per problem and,
+ * like the reference's, persist from one solve to the next (warm-started MPC) until reset.             */
+int altro_hip_add_linear_constraint(altro_hip_batch* h, int k_first, int k_last, int cone, int p,
+                                    const double* G, const double* g, int g_per_problem);
+int altro_hip_clear_constraints(altro_hip_batch* h);
+int altro_hip_reset_duals(altro_hip_batch* h, double penalty);
+int altro_hip_get_duals(altro_hip_batch* h, int k, int slot, double* z /* [batch][p] */);
+/* SolverImpl::Feasibility (solver.cpp:224-231) of the candidate trajectory, [batch].                  */
+int altro_hip_feasibility(altro_hip_batch* h, double* out);
+
 typedef struct altro_hip_solve_options { /* AltroOptions, solver_options.hpp:16-39 */
   int iterations_max;
   double tol_stationarity;
   double tol_primal_feasibility;
   double tol_meritfun_gradient;
   int use_backtracking_linesearch;
+  double penalty_initial; /* solver_options.hpp:27-29; used when constraint blocks exist              */
+  double penalty_scaling;
+  double penalty_max;
 } altro_hip_solve_options;
 typedef struct altro_hip_solve_result { /* AltroStats per problem, solver_stats.hpp:14-25 */
   int status;     /* SolveStatus: 0 Success, 1 Unsolved, 2 MaxIterations (typedefs.hpp:19-27)        */
@@ -179,6 +199,9 @@ typedef struct altro_hip_solve_result { /* AltroStats per problem, solver_stats.
   double stationarity;
   double final_alpha;
   double final_phi;
+  double primal_feasibility; /* AltroStats::primal_feasibility (solver.cpp:508)                      */
+  double penalty;            /* the constraints' penalty when the problem stopped                     */
+  int dual_updates;          /* outer (dual) updates taken                                            */
 } altro_hip_solve_result;
 void altro_hip_default_solve_options(altro_hip_solve_options* opts);
 /* SolverImpl::Solve (solver.cpp:414-511) for the whole batch; results [batch] (may be NULL).         */

@@ -1,0 +1,158 @@
+"""GPU parity of the augmented-Lagrangian / conic part of the batched iLQR loop
+against the CPU oracle (oracle/al_oracle.c + ilqr_oracle.c), which is pinned to the reference's constrained
+double-integrator iteration counts 3 / 5 / 9 (tests/test_oracle_kat.py).  Constraint blocks are the ones of
+test/double_integrator_test.cpp:170-493 and test/pendulum_test.cpp:117-203."""
+import numpy as np
+import pytest
+
+import altro_amd
+from oracle import oracle
+from tests import problems
+
+pytestmark = pytest.mark.gpu
+
+
+def _di_hip(kats, kind, x0s):
+    kat = kats["double_integrator_constrained"]
+    N = kat["N"]; dim = kat["dim"]; n, m = 2 * dim, dim
+    h = np.float32(np.float32(kat["tf"]) / np.float32(N))
+    xf = np.array(kat["xf"], dtype=float)
+    bt = altro_amd.Batch(N, n, m, x0s.shape[0])
+    assert bt.plan == altro_amd.PLAN_LANE
+    bt.set_model(altro_amd.MODEL_DOUBLE_INTEGRATOR, h)
+    Qd = np.full(n, kat["Q"]); Rd = np.full(m, kat["R"])
+    bt.set_tracking_cost(np.stack([Qd, Qd]), Rd[None], np.stack([xf, xf]), np.zeros((1, m)),
+                         k_stride_zero=True, batch_stride_zero=True)
+    bt.set_initial_state(x0s)
+    bt.set_input_guess(np.zeros((1, 1, m)), k_stride_zero=True, batch_stride_zero=True)
+    for (k0, k1, cone, G, g) in problems.di_constraint_blocks(kind, N, n, m, xf, kat["u_bnd"]):
+        bt.add_linear_constraint(k0, k1, cone, G, g)
+    return bt, kat, xf
+
+
+def _di_oracle(kats, kind, x0):
+    kat = kats["double_integrator_constrained"]
+    c = kat[kind]
+    N = kat["N"]; dim = kat["dim"]; n, m = 2 * dim, dim
+    h = np.float32(np.float32(kat["tf"]) / np.float32(N))
+    s = oracle.ILQR(N, n, m, h, oracle.DYN_MODEL, oracle.MODEL_DI, model_dim=dim, cost_kind=oracle.COST_DIAGONAL)
+    xf = np.array(kat["xf"], dtype=float)
+    for k in range(N + 1):
+        s.L.oracle_ilqr_set_lqr_cost(s.h, k, np.full(n, kat["Q"]), np.full(m, kat["R"]), xf.copy(), np.zeros(m))
+    s.L.oracle_ilqr_set_initial_state(s.h, np.ascontiguousarray(x0, dtype=float))
+    for (k0, k1, cone, G, g) in problems.di_constraint_blocks(kind, N, n, m, xf, kat["u_bnd"]):
+        for k in range(k0, k1 + 1):
+            s.add_linear_constraint(k, cone, G, g)
+    s.L.oracle_ilqr_initialize(s.h)
+    s.set_penalty(c["penalty_initial"], c["penalty_scaling"])
+    return s
+
+
+@pytest.mark.parametrize("kind", ["goal", "bounds", "soc"])
+def test_reference_iteration_counts_on_device(kats, kind):
+    """double_integrator_test.cpp:255-256 / :366-375 / :482-492 through the batched device solver: Success,
+    3 / 5 / 9 iterations, goal reached, controls saturated -- for every copy in the batch."""
+    c = kats["double_integrator_constrained"][kind]
+    x0s = np.tile(np.array(c["x0"], dtype=float), (65, 1))
+    bt, kat, xf = _di_hip(kats, kind, x0s)
+    res = bt.ilqr_solve(penalty_initial=c["penalty_initial"], penalty_scaling=c["penalty_scaling"])
+    assert (res["status"] == 0).all(), res["status"]
+    assert (res["iterations"] == c["iterations"]).all(), res["iterations"]
+    x = bt.get("x"); u = bt.get("u")
+    assert (np.linalg.norm(x[:, -1] - xf, axis=1) < c["goal_tol"]).all()
+    if kind == "bounds":
+        assert np.allclose(u[:, 0], c["u0"], atol=c["u0_tol"])
+    if kind == "soc":
+        assert (np.abs(np.linalg.norm(u[:, 0], axis=1) - c["u0_norm"]) < c["u0_norm_tol"]).all()
+    assert (res["feasibility"] < 1e-4).all()
+    assert np.array_equal(x[0], x[64])
+
+
+@pytest.mark.parametrize("kind", ["goal", "bounds", "soc"])
+def test_constrained_batch_matches_per_problem_oracle(kats, kind):
+    """Heterogeneous batch: every problem follows the oracle's own iteration / dual-update path."""
+    c = kats["double_integrator_constrained"][kind]
+    batch = 80
+    base = np.array(c["x0"], dtype=float)
+    x0s = np.tile(base, (batch, 1))
+    x0s[:, 0] += 0.05 * (np.arange(batch) % 9 - 4)
+    x0s[:, 1] -= 0.04 * (np.arange(batch) % 7)
+    x0s[:, 2] += 0.02 * (np.arange(batch) % 5)
+    bt, kat, xf = _di_hip(kats, kind, x0s)
+    res = bt.ilqr_solve(penalty_initial=c["penalty_initial"], penalty_scaling=c["penalty_scaling"], iterations_max=60)
+    x = bt.get("x"); u = bt.get("u")
+    tol = 1e-8 if kind != "soc" else 1e-6
+    checked = 0
+    for b in [0, 7, 23, 42, 79]:
+        s = _di_oracle(kats, kind, x0s[b])
+        s.L.oracle_ilqr_set_options(s.h, 60, 1e-4, 1e-4, 1e-8, 0)
+        status, iters, log = s.solve()
+        assert res["status"][b] == status, (b, res["status"][b], status)
+        assert res["iterations"][b] == iters, (b, res["iterations"][b], iters)
+        if status != 0:
+            continue
+        checked += 1
+        assert abs(res["feasibility"][b] - log[iters - 1, 6]) <= 1e-9 + 1e-3 * log[iters - 1, 6]
+        np.testing.assert_allclose(x[b], s.get("x"), rtol=tol, atol=tol)
+        np.testing.assert_allclose(u[b], s.get("u"), rtol=tol * 10, atol=tol * 10)
+    assert checked >= 3
+
+
+def test_al_merit_and_expansion_parity(kats):
+    """CalcCost / CalcCostGradient / CalcCostHessian with AL terms (knotpoint_data.cpp:421-448, :572-613) at a
+    point with nonzero duals: run two sweeps on both sides, then compare phi, dphi, lx, lu."""
+    kind = "soc"
+    c = kats["double_integrator_constrained"][kind]
+    x0s = np.tile(np.array(c["x0"], dtype=float), (4, 1))
+    x0s[1] += [0.1, -0.2, 0.05, 0.0]
+    bt, kat, xf = _di_hip(kats, kind, x0s)
+    res = bt.ilqr_solve(penalty_initial=1.0, penalty_scaling=100.0, iterations_max=2)
+    for b in [0, 1]:
+        s = _di_oracle(kats, kind, x0s[b])
+        s.L.oracle_ilqr_set_options(s.h, 2, 1e-4, 1e-4, 1e-8, 0)
+        s.solve()
+        A, B, lx, lu = bt.get_expansion()
+        np.testing.assert_allclose(lx[b], s.get("lx"), rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(lu[b], s.get("lu"), rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(bt.get("x")[b], s.get("x"), rtol=1e-10, atol=1e-10)
+        assert abs(res["feasibility"][b] - s.feasibility()) < 1e-10
+        z_dev = bt.get_duals(0, 0, 3)[b]
+        assert np.isfinite(z_dev).all()
+
+
+def test_pendulum_goal_constraint_on_device(kats):
+    """test/pendulum_test.cpp:117-203: c = xf - x (EQUALITY) at k = N; Success, < 1e-4 from the goal, <= 10."""
+    kat = kats["pendulum_goal_constrained"]
+    N = kat["N"]; n, m = 2, 1
+    h = np.float32(np.float32(kat["tf"]) / float(N))
+    xf = np.array(kat["xf_pi"]) * np.pi
+    bt = altro_amd.Batch(N, n, m, 5)
+    bt.set_model(altro_amd.MODEL_PENDULUM, h)
+    bt.set_tracking_cost(np.stack([np.full(n, kat["Qd"]), np.full(n, kat["Qfd"])]), np.full((1, m), kat["Rd"]),
+                         np.stack([xf, xf]), np.zeros((1, m)), k_stride_zero=True, batch_stride_zero=True)
+    bt.set_initial_state(np.zeros((5, n)))
+    bt.set_input_guess(np.full((1, 1, m), kat["u_init"]), k_stride_zero=True, batch_stride_zero=True)
+    G = np.zeros((n, n + m)); G[:, :n] = -np.eye(n)
+    # per-problem right-hand side: the same goal for every problem, sent through the [batch][p] path
+    bt.add_linear_constraint(N, N, altro_amd.CONE_EQUALITY, G, np.tile(-xf, (5, 1)))
+    res = bt.ilqr_solve(iterations_max=kat["iterations_max"])
+    assert (res["status"] == 0).all()
+    assert (res["iterations"] <= kat["max_iterations"]).all()
+    assert (np.linalg.norm(bt.get("x")[:, -1] - xf, axis=1) < kat["goal_tol"]).all()
+
+
+def test_constraint_argument_errors(kats):
+    bt, kat, xf = _di_hip(kats, "goal", np.zeros((2, 4)))
+    G = np.zeros((3, 6))
+    with pytest.raises(altro_amd.AltroHipError):
+        bt.add_linear_constraint(0, 99, altro_amd.CONE_EQUALITY, G, np.zeros(3))     # BadIndex
+    with pytest.raises(altro_amd.AltroHipError):
+        bt.add_linear_constraint(0, 1, 7, G, np.zeros(3))                            # unknown cone
+    with pytest.raises(altro_amd.AltroHipError):
+        bt.add_linear_constraint(0, 1, altro_amd.CONE_SOC, np.zeros((5, 6)), np.zeros(5))   # SOC rows > 4
+    bt.add_linear_constraint(10, 10, altro_amd.CONE_INEQUALITY, G, np.zeros(3))
+    with pytest.raises(altro_amd.AltroHipError):
+        bt.add_linear_constraint(10, 10, altro_amd.CONE_INEQUALITY, G, np.zeros(3))  # third block at k = 10
+    bt.clear_constraints()
+    res = bt.ilqr_solve(iterations_max=5)
+    assert (res["status"] == 0).all()
