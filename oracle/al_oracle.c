@@ -233,3 +233,29 @@ void oracle_al_dual_update(oracle_kp_cons* kc) { /* :503-510 */
 void oracle_al_penalty_update(oracle_kp_cons* kc, double scaling, double pmax) { /* :512-517 */
   for (int j = 0; j < kc->ncon; ++j) kc->con[j].rho = fmin(kc->con[j].rho * scaling, pmax);
 }
+
+/* One knot point's AL terms from given (x, u, z, rho): the sequence CalcConstraints -> CalcConstraintCosts
+ * -> CalcConstraintCostGradients -> CalcConstraintCostHessians of knotpoint_data_test.cpp:233-524, used to
+ * pin this file against that test's constants.  lx/lu/lxx/luu/lux start from zero; hess is the (n+m)^2
+ * constraint_hess_ block. */
+double oracle_al_knot_eval(int type, int p, int n, int m, const double* G, const double* g, const double* x,
+                           const double* u, const double* z, double rho, double* lx, double* lu, double* lxx,
+                           double* luu, double* lux, double* hess, double* val) {
+  oracle_kp_cons kc;
+  memset(&kc, 0, sizeof(kc));
+  kc.ncon = 1;
+  oracle_con* c = &kc.con[0];
+  c->type = type; c->p = p; c->rho = rho;
+  memcpy(c->G, G, sizeof(double) * p * (n + m));
+  memcpy(c->g, g, sizeof(double) * p);
+  memcpy(c->z, z, sizeof(double) * p);
+  oracle_al_constraints(&kc, n, m, x, u);
+  double cost = oracle_al_cost(&kc);
+  memset(lx, 0, sizeof(double) * n); memset(lu, 0, sizeof(double) * m);
+  memset(lxx, 0, sizeof(double) * n * n); memset(luu, 0, sizeof(double) * m * m); memset(lux, 0, sizeof(double) * m * n);
+  oracle_al_gradient(&kc, n, m, 0, lx, lu);
+  oracle_al_hessian(&kc, n, m, 0, lxx, luu, lux);
+  memcpy(hess, c->hess, sizeof(double) * (n + m) * (n + m));
+  memcpy(val, c->val, sizeof(double) * p);
+  return cost;
+}

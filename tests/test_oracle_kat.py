@@ -355,3 +355,109 @@ def test_pendulum_goal_constrained(kats):
     assert status == 0
     assert iters <= kat["max_iterations"]
     assert np.linalg.norm(s.get("x")[-1] - xf) < kat["goal_tol"]
+
+
+def test_cone_golden_vectors(kats):
+    """src/altro/solver/test/cones_test.cpp:9-211: projection, Jacobian and Hessian constants."""
+    kat = kats["cones"]
+    L = oracle.lib()
+    tol = kat["tol"]
+    dim = 4
+    x = np.array(kat["inequality_projection"]["x"])
+    px = np.zeros(dim); J = np.zeros((dim, dim)); H = np.zeros((dim, dim))
+    L.oracle_cone_projection(oracle.CONE_EQUALITY, dim, x.ctypes.data, px.ctypes.data)
+    assert np.linalg.norm(px) < tol
+    L.oracle_cone_projection(oracle.CONE_IDENTITY, dim, x.ctypes.data, px.ctypes.data)
+    assert np.linalg.norm(px - x) < tol
+    L.oracle_cone_projection(oracle.CONE_INEQUALITY, dim, x.ctypes.data, px.ctypes.data)
+    assert np.linalg.norm(px - kat["inequality_projection"]["px"]) < tol
+    L.oracle_cone_jacobian(oracle.CONE_INEQUALITY, dim, x.ctypes.data, J.ctypes.data)
+    assert np.linalg.norm(J - np.diag(kat["inequality_projection"]["jac_diag"])) < tol
+    L.oracle_cone_jacobian(oracle.CONE_EQUALITY, dim, x.ctypes.data, J.ctypes.data)
+    assert np.linalg.norm(J) < tol
+    L.oracle_cone_jacobian(oracle.CONE_IDENTITY, dim, x.ctypes.data, J.ctypes.data)
+    assert np.linalg.norm(J - np.eye(dim)) < tol
+    b = np.array(kat["b"], dtype=float)
+    for cone in (oracle.CONE_EQUALITY, oracle.CONE_IDENTITY, oracle.CONE_INEQUALITY):
+        H[:] = 1.0
+        L.oracle_cone_hessian(cone, dim, x.ctypes.data, b.ctypes.data, H.ctypes.data)
+        assert np.linalg.norm(H) == 0.0
+    mag = np.linalg.norm(x)
+    for where, scale in kat["soc_scales"].items():
+        xs = x.copy(); xs[3] = mag * scale
+        L.oracle_cone_projection(oracle.CONE_SOC, dim, xs.ctypes.data, px.ctypes.data)
+        L.oracle_cone_jacobian(oracle.CONE_SOC, dim, xs.ctypes.data, J.ctypes.data)
+        L.oracle_cone_hessian(oracle.CONE_SOC, dim, xs.ctypes.data, b.ctypes.data, H.ctypes.data)
+        if where == "in":
+            assert np.linalg.norm(px - xs) < tol and np.linalg.norm(J - np.eye(dim)) < tol and np.linalg.norm(H) < tol
+        elif where == "below":
+            assert np.linalg.norm(px) < tol and np.linalg.norm(J) < tol and np.linalg.norm(H) < tol
+        else:
+            assert np.linalg.norm(px - kat["soc_outside_projection"]) < tol
+            assert np.linalg.norm(J.T - np.array(kat["soc_outside_jacobian"]).reshape(4, 4)) < tol
+            assert np.linalg.norm(H.T - np.array(kat["soc_outside_hessian"]).reshape(4, 4)) < tol
+            assert np.linalg.norm(H - H.T) < tol
+
+
+def _al_knot(kat, cone, z):
+    L = oracle.lib()
+    L.oracle_al_knot_eval.restype = C.c_double
+    L.oracle_al_knot_eval.argtypes = [C.c_int] * 4 + [C.c_void_p] * 5 + [C.c_double] + [C.c_void_p] * 7
+    n, m, p = kat["n"], kat["m"], kat["p"]
+    x = np.array(kat["x"], dtype=float); u = np.array(kat["u"], dtype=float)
+    J = np.array(kat["J"], dtype=float)
+    # the reference's constraint is nonlinear; the AL terms only see its value and Jacobian at (x, u)
+    g = J @ np.concatenate([x, u]) - np.array(kat["c"], dtype=float)
+    Gc = np.ascontiguousarray(J.T)
+    z = np.array(z, dtype=float)
+    lx = np.zeros(n); lu = np.zeros(m); lxx = np.zeros((n, n)); luu = np.zeros((m, m)); lux = np.zeros((n, m))
+    hess = np.zeros((n + m, n + m)); val = np.zeros(p)
+    cost = L.oracle_al_knot_eval(cone, p, n, m, Gc.ctypes.data, g.ctypes.data, x.ctypes.data, u.ctypes.data,
+                                 z.ctypes.data, kat["rho"], lx.ctypes.data, lu.ctypes.data, lxx.ctypes.data,
+                                 luu.ctypes.data, lux.ctypes.data, hess.ctypes.data, val.ctypes.data)
+    return dict(cost=cost, lx=lx, lu=lu, lxx=lxx.T, luu=luu.T, lux=lux.T, hess=hess.T, val=val)
+
+
+def test_knotpoint_al_golden_vectors(kats):
+    """src/altro/solver/test/knotpoint_data_test.cpp:233-523: AL cost, gradient and Hessian constants for the
+    orthant, zero and second-order cones (out of / below / inside the cone)."""
+    kat = kats["knotpoint_al"]
+    tol = kat["tol"]
+    rho = kat["rho"]; c = np.array(kat["c"], dtype=float)
+    # INEQUALITY
+    k = kat["inequality"]
+    r = _al_knot(kat, oracle.CONE_INEQUALITY, k["z"])
+    assert np.linalg.norm(r["val"] - c) < 1e-12
+    zt = np.minimum(np.array(k["z"]) - rho * c, 0.0)
+    assert abs(r["cost"] - zt @ zt / (2 * rho)) < tol
+    assert np.linalg.norm(r["lx"] - k["lx"]) < tol and np.linalg.norm(r["lu"] - k["lu"]) < tol
+    assert np.linalg.norm(r["lxx"]) == 0.0 and np.linalg.norm(r["lux"]) == 0.0
+    assert np.allclose(r["luu"], k["luu_const"], rtol=1e-12)
+    # EQUALITY
+    k = kat["equality"]
+    r = _al_knot(kat, oracle.CONE_EQUALITY, k["z"])
+    zt = np.array(k["z"]) - rho * c
+    assert abs(r["cost"] - zt @ zt / (2 * rho)) < tol
+    assert np.linalg.norm(r["lx"] - k["lx"]) < tol and np.linalg.norm(r["lu"] - k["lu"]) < tol
+    assert np.linalg.norm(r["lxx"] - np.array(k["lxx"]).reshape(3, 3)) < 1e-13
+    assert np.linalg.norm(r["lux"]) == 0.0 and np.allclose(r["luu"], k["luu_const"], rtol=1e-12)
+    # SOC out of cone
+    k = kat["soc_out_of_cone"]
+    r = _al_knot(kat, oracle.CONE_SOC, k["z"])
+    assert abs(r["cost"] - k["alcost"]) < tol
+    assert np.linalg.norm(r["lx"] - k["lx"]) < tol and np.linalg.norm(r["lu"] - k["lu"]) < tol
+    assert np.linalg.norm(r["hess"] - np.array(k["hess"]).reshape(5, 5)) < k["hess_tol"]
+    # SOC below the cone
+    k = kat["soc_below_cone"]
+    r = _al_knot(kat, oracle.CONE_SOC, k["z"])
+    zb = np.array(k["z"]) - rho * c
+    assert np.linalg.norm(zb[:2]) < -zb[2]
+    assert abs(r["cost"] - k["alcost"]) < tol
+    assert np.linalg.norm(r["lx"]) < tol and np.linalg.norm(r["lu"]) < tol and np.linalg.norm(r["hess"]) < 1e-6
+    # SOC in the cone
+    k = kat["soc_in_cone"]
+    r = _al_knot(kat, oracle.CONE_SOC, k["z"])
+    assert abs(r["cost"] - k["alcost"]) < tol
+    assert np.linalg.norm(r["lx"] - k["lx"]) < tol and np.linalg.norm(r["lu"] - k["lu"]) < tol
+    assert np.linalg.norm(r["lxx"] - np.array(k["lxx"]).reshape(3, 3)) < 1e-13
+    assert np.linalg.norm(r["lux"]) == 0.0 and np.allclose(r["luu"], k["luu_const"], rtol=1e-12)
