@@ -35,6 +35,7 @@ C_ABI_SYMBOLS = [
     "altro_hip_linesearch_host",
     "altro_hip_add_linear_constraint", "altro_hip_clear_constraints", "altro_hip_reset_duals",
     "altro_hip_get_duals", "altro_hip_feasibility",
+    "altro_hip_shift_trajectory", "altro_hip_update_linear_costs", "altro_hip_get_knot",
 ]
 CONE_EQUALITY, CONE_IDENTITY, CONE_INEQUALITY, CONE_SOC = 0, 1, 2, 3   # ConstraintType, typedefs.hpp:29-34
 
@@ -115,6 +116,9 @@ def lib():
         L.altro_hip_reset_duals.argtypes = [vp, d]
         L.altro_hip_get_duals.argtypes = [vp, i, i, vp]
         L.altro_hip_feasibility.argtypes = [vp, vp]
+        L.altro_hip_shift_trajectory.argtypes = [vp]
+        L.altro_hip_update_linear_costs.argtypes = [vp, vp, vp, vp, i, i, i, i]
+        L.altro_hip_get_knot.argtypes = [vp, i, vp, vp]
         L.altro_hip_default_solve_options.argtypes = [C.POINTER(SolveOptions)]
         L.altro_hip_default_solve_options.restype = None
         L.altro_hip_ilqr_solve.argtypes = [vp, C.POINTER(SolveOptions), vp]
@@ -265,6 +269,23 @@ class Batch:
         A = np.zeros((B, N, n * n)); Bm = np.zeros((B, N, n * m)); lx = np.zeros((B, N + 1, n)); lu = np.zeros((B, N, m))
         _check(self.L.altro_hip_get_expansion(self.h, *[v.ctypes.data_as(C.c_void_p) for v in (A, Bm, lx, lu)]))
         return A, Bm, lx, lu
+
+    def shift_trajectory(self):
+        _check(self.L.altro_hip_shift_trajectory(self.h))
+
+    def update_linear_costs(self, q, r, c, k_first, k_last, k_stride_zero=False, batch_stride_zero=False):
+        """q [nb, nk, n], r [nb, nk, m] or None, c [nb, nk] or None (nk = 1 / nb = 1 when the stride flags are set)."""
+        arrs = [None if a is None else np.ascontiguousarray(a, dtype=np.float64) for a in (q, r, c)]
+        ptr = [None if a is None else a.ctypes.data_as(C.c_void_p) for a in arrs]
+        _check(self.L.altro_hip_update_linear_costs(self.h, ptr[0], ptr[1], ptr[2], int(k_first), int(k_last),
+                                                    int(k_stride_zero), int(batch_stride_zero)))
+
+    def get_knot(self, k, want_u=True):
+        x = np.zeros((self.batch, self.n))
+        u = np.zeros((self.batch, self.m)) if (want_u and k < self.N) else None
+        _check(self.L.altro_hip_get_knot(self.h, int(k), x.ctypes.data_as(C.c_void_p),
+                                         u.ctypes.data_as(C.c_void_p) if u is not None else None))
+        return x, u
 
     def add_linear_constraint(self, k_first, k_last, cone, G, g):
         """c = G [x;u] - g in `cone` at knot points k_first..k_last (inclusive).  G: (p, n+m) numpy (row-major

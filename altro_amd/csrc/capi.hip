@@ -418,7 +418,7 @@ bool ilqr_supported(int kind, int n, int m) {
 #undef X
   return false;
 }
-enum IlqrKernel { IK_ROLLOUT, IK_ACCEPT, IK_EXPAND, IK_MERIT, IK_STATIONARITY, IK_DUAL };
+enum IlqrKernel { IK_ROLLOUT, IK_ACCEPT, IK_EXPAND, IK_MERIT, IK_STATIONARITY, IK_DUAL, IK_SHIFT };
 
 // (re)build the device tables of the constraint blocks; duals restart from zero when the structure changes
 template <typename T>
@@ -500,6 +500,7 @@ int ilqr_launch(altro_hip_batch* h, int which, IlqrArgs<T> a) {
       case IK_EXPAND: hipLaunchKernelGGL((ilqr_expand_kernel<K_, N_, M_, T>), flat64, b64, 0, h->stream, a); break;  \
       case IK_MERIT: hipLaunchKernelGGL((ilqr_merit_kernel<K_, N_, M_, T>), lanes, b64, 0, h->stream, a); break;     \
       case IK_DUAL: hipLaunchKernelGGL((ilqr_dual_update_kernel<N_, M_, T>), flat, b256, 0, h->stream, a); break;    \
+      case IK_SHIFT: hipLaunchKernelGGL((ilqr_shift_kernel<N_, M_, T>), dim3(grid_for((int64_t)h->batch * (N_ + M_))), b256, 0, h->stream, a); break; \
       default: hipLaunchKernelGGL((ilqr_stationarity_kernel<N_, M_, T>), lanes, b64, 0, h->stream, a); break;        \
     }                                                                                                    \
   }
@@ -1257,6 +1258,62 @@ int altro_hip_feasibility(altro_hip_batch* h, double* out) {
   HIP_TRY(hipMemcpy(pr.data(), h->i_prob, pr.size() * sizeof(IlqrProb), hipMemcpyDeviceToHost));
   for (int b = 0; b < h->batch; ++b) out[b] = pr[b].feasibility;
   return 0;
+}
+
+// ---- MPC receding-horizon operations on the resident batch -----------------
+int altro_hip_shift_trajectory(altro_hip_batch* h) {
+  int rc = ilqr_check(h, true);
+  if (!rc) rc = ilqr_run(h, IK_SHIFT, false, false, 0, 0.0);
+  return rc;
+}
+int altro_hip_update_linear_costs(altro_hip_batch* h, const double* q, const double* r, const double* c,
+                                  int k_first, int k_last, int kz, int bz) {
+  // ALTROSolver::UpdateLinearCosts (altro_solver.cpp:266-281) -> KnotPointData::UpdateLinearCosts
+  // (knotpoint_data.cpp:193-226) for knot points k_first..k_last (inclusive) of every problem
+  int rc = check(h);
+  if (rc) return rc;
+  if (h->plan != ALTRO_HIP_PLAN_LANE) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "linear cost update needs plan LANE");
+  if (!h->lqr_cost_set) return fail(ALTRO_HIP_ERR_NOT_SET, "no quadratic cost to update (ErrorCodes::CostNotQuadratic)");
+  const int n = h->n, m = h->m, N = h->N;
+  if (k_first < 0 || k_last > N || k_first > k_last)
+    return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "knot point range [%d, %d] outside [0, %d] (ErrorCodes::BadIndex)", k_first, k_last, N);
+  if (r && k_last == N)
+    return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "cannot update linear input costs at the terminal knot point "
+                                            "(ErrorCodes::InvalidOptAtTerminalKnotPoint)");
+  const int nk = k_last - k_first + 1;
+  const int E = 2 * n + 2 * m + 1;
+  const size_t base = (size_t)k_first * E * h->batch;
+  auto pk = [&](const double* src, int len, int off) -> int {
+    if (!src) return 0;
+    return h->dtype == ALTRO_HIP_F64
+               ? lane_pack<double>(h, (double*)h->l_cost + base, E, src, len, off, 0, nk, 0, kz ? 1 : nk, kz, bz)
+               : lane_pack<float>(h, (float*)h->l_cost + base, E, src, len, off, 0, nk, 0, kz ? 1 : nk, kz, bz);
+  };
+  rc = pk(q, n, n + m);
+  if (!rc) rc = pk(r, m, 2 * n + m);
+  if (!rc) rc = pk(c, 1, 2 * n + 2 * m);
+  return rc;
+}
+int altro_hip_get_knot(altro_hip_batch* h, int k, double* x, double* u) {
+  // ALTROSolver::GetState / GetInput (altro_solver.cpp:323-347) of one knot point for the whole batch:
+  // x [batch][n], u [batch][m] (u must be NULL at k = N)
+  int rc = check(h);
+  if (rc) return rc;
+  if (h->plan != ALTRO_HIP_PLAN_LANE) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "plan LANE only");
+  const int n = h->n, m = h->m, N = h->N;
+  if (k < 0 || k > N) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "knot point %d outside [0, %d] (ErrorCodes::BadIndex)", k, N);
+  if (u && k == N) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "no input at the terminal knot point");
+  const size_t E = h->dtype == ALTRO_HIP_F64 ? 8 : 4;
+  const char* rec = (const char*)h->l_nom + (size_t)k * (n + m) * h->batch * E;
+  if (x) {
+    rc = h->dtype == ALTRO_HIP_F64 ? lane_get<double>(h, x, rec, nullptr, n + m, 0, 0, n, 1, 1)
+                                   : lane_get<float>(h, x, rec, nullptr, n + m, 0, 0, n, 1, 1);
+    if (rc) return rc;
+  }
+  if (u)
+    rc = h->dtype == ALTRO_HIP_F64 ? lane_get<double>(h, u, rec, nullptr, n + m, n, 0, m, 1, 1)
+                                   : lane_get<float>(h, u, rec, nullptr, n + m, n, 0, m, 1, 1);
+  return rc;
 }
 
 int altro_hip_add_linear_constraint(altro_hip_batch* h, int k_first, int k_last, int cone, int p, const double* G,

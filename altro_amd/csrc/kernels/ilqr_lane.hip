@@ -384,6 +384,26 @@ __global__ void ilqr_dual_update_kernel(IlqrArgs<T> a) {
   }
 }
 
+// ALTROSolver::ShiftTrajectory (altro_solver.cpp:283-293): x_[k] <- x_[k+1] for k < N, u_[k] <- u_[k+1] for
+// k < N - 1, on the candidate trajectory.  One thread per (problem, element), sequential in k.
+template <int n, int m, typename T>
+__global__ void ilqr_shift_kernel(IlqrArgs<T> a) {
+  using I = IlqrDims<n, m>;
+  const int64_t B = a.batch;
+  const int64_t total = B * (n + m);
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = t % B;
+    const int e = (int)(t / B);
+    const bool is_u = e >= n;
+    const int el = is_u ? 2 * n + (e - n) : e;          // candidate record: x_ | y_ | u_
+    const int kend = is_u ? a.N - 1 : a.N;
+    T* c = a.cand + (int64_t)el * B + b;
+    const int64_t ks = (int64_t)I::E_CAND * B;
+    for (int k = 0; k < kend; ++k) c[(int64_t)k * ks] = c[(int64_t)(k + 1) * ks];
+  }
+}
+
 // ---- batched line search + sweep bookkeeping (one thread per problem) ---------------------------------
 struct IlqrLoopArgs {
   IlqrProb* prob;

@@ -183,6 +183,20 @@ int altro_hip_get_duals(altro_hip_batch* h, int k, int slot, double* z /* [batch
 /* SolverImpl::Feasibility (solver.cpp:224-231) of the candidate trajectory, [batch].                  */
 int altro_hip_feasibility(altro_hip_batch* h, double* out);
 
+/* ---- MPC receding-horizon operations on the resident batch -------------
+ * The caller pattern of test/bicycle_test.cpp:302-337: solve, read u_0, move the reference, set the new
+ * initial state, shift the trajectory -- without repacking the problem between solves.
+ *   altro_hip_shift_trajectory      ALTROSolver::ShiftTrajectory   (altro_solver.cpp:283-293)
+ *   altro_hip_update_linear_costs   ALTROSolver::UpdateLinearCosts (altro_solver.cpp:266-281): q [nb][nk][n],
+ *                                   r [nb][nk][m] or NULL, c [nb][nk] or NULL for knot points
+ *                                   k_first..k_last (inclusive); nk = 1 if kz, nb = 1 if bz
+ *   altro_hip_get_knot              ALTROSolver::GetState / GetInput (altro_solver.cpp:323-347) for the batch
+ * (altro_hip_set_initial_state is ALTROSolver::SetInitialState, altro_solver.cpp:177-190.)               */
+int altro_hip_shift_trajectory(altro_hip_batch* h);
+int altro_hip_update_linear_costs(altro_hip_batch* h, const double* q, const double* r, const double* c,
+                                  int k_first, int k_last, int kz, int bz);
+int altro_hip_get_knot(altro_hip_batch* h, int k, double* x /* [batch][n] */, double* u /* [batch][m] */);
+
 typedef struct altro_hip_solve_options { /* AltroOptions, solver_options.hpp:16-39 */
   int iterations_max;
   double tol_stationarity;

@@ -237,6 +237,24 @@ void oracle_ilqr_set_input(void* h, int k, const double* u) {
   memcpy(s->u_ + (size_t)s->m * k, u, sizeof(double) * s->m);
 }
 
+/* MPC methods: ALTROSolver::UpdateLinearCosts (altro_solver.cpp:266-281 -> knotpoint_data.cpp:193-226) and
+ * ALTROSolver::ShiftTrajectory (altro_solver.cpp:283-293, sequential in-place copy of the candidates) */
+int oracle_ilqr_update_linear_costs(void* h, int k, const double* q, const double* r, double c) {
+  oracle_ilqr* s = (oracle_ilqr*)h;
+  if (r && k == s->N) return -1;   /* InvalidOptAtTerminalKnotPoint */
+  if (q) memcpy(s->qc + (size_t)s->n * k, q, sizeof(double) * s->n);
+  if (r) memcpy(s->rc + (size_t)s->m * k, r, sizeof(double) * s->m);
+  s->cc[k] = c;
+  return 0;
+}
+void oracle_ilqr_shift_trajectory(void* h) {
+  oracle_ilqr* s = (oracle_ilqr*)h;
+  for (int k = 0; k < s->N; ++k) {
+    memcpy(s->x_ + (size_t)s->n * k, s->x_ + (size_t)s->n * (k + 1), sizeof(double) * s->n);
+    if (k < s->N - 1) memcpy(s->u_ + (size_t)s->m * k, s->u_ + (size_t)s->m * (k + 1), sizeof(double) * s->m);
+  }
+}
+
 /* --- per-knot-point methods (knotpoint_data.cpp) -------------------------------- */
 #define XK(a, k) ((a) + (size_t)s->n * (k))
 #define UK(a, k) ((a) + (size_t)s->m * (k))

@@ -83,6 +83,8 @@ def lib():
         L.oracle_cone_projection.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.oracle_cone_jacobian.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.oracle_cone_hessian.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_ilqr_update_linear_costs.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_double]
+        L.oracle_ilqr_shift_trajectory.argtypes = [C.c_void_p]
         L.oracle_ilqr_iterations.argtypes = [C.c_void_p]
         L.oracle_ilqr_merit_evals.argtypes = [C.c_void_p]
         L.oracle_ilqr_delta_V.argtypes = [C.c_void_p, C.c_int]

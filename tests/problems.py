@@ -145,3 +145,25 @@ def di_constraint_blocks(kind, N, n=4, m=2, xf=None, u_bnd=1.0):
     else:
         assert kind == "goal"
     return blocks
+
+
+# ---- bicycle tracking MPC (test/bicycle_test.cpp:140-345 with a synthetic reference, SURVEY.md 8d "C3") ----
+def bicycle_reference(steps, h=0.1, v=6.3):
+    """Seed-free synthetic reference path: the CoG bicycle (L = 2.7, lr = 1.5) rolled out with speed v and
+    steering rate 0.05 sin(0.2 t) by the explicit midpoint rule.  (The reference's own test tracks the
+    'scotty' data file, which is not copied.)  Returns x_ref [steps + 1, 4], u_ref [steps, 2]."""
+    L, lr = 2.7, 1.5
+
+    def f(x, u):
+        beta = np.arctan2(lr * x[3], L)
+        s, c = np.sin(x[2] + beta), np.cos(x[2] + beta)
+        return np.array([u[0] * c, u[0] * s, u[0] * np.cos(beta) * np.tan(x[3]) / L, u[1]])
+
+    x = np.zeros(4)
+    xs, us = [x.copy()], []
+    for i in range(steps):
+        u = np.array([v, 0.05 * np.sin(0.2 * i * h)])
+        xm = x + 0.5 * h * f(x, u)
+        x = x + h * f(xm, u)
+        xs.append(x.copy()); us.append(u)
+    return np.array(xs), np.array(us)
