@@ -41,9 +41,11 @@ def parse():
     ap.add_argument("--horizon", type=int, default=256)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--config", default="c1", choices=["c1", "c4"],
-                    help="c1 = BASELINE.json configs[1] (the metric's config, default); c4 = configs[4] "
-                         "(random LTV n=12 m=4 N=512 batch=16384, fp32 storage) as an extra line")
+    ap.add_argument("--config", default="c1", choices=["c1", "c2", "c3", "c4"],
+                    help="c1 = BASELINE.json configs[1] (the metric's config, default); extra lines: c2 = configs[2] "
+                         "(pendulum n=2 m=1 N=100 batch=8192), c3 = configs[3] (bicycle n=4 m=2 N=50 batch=65536 "
+                         "per node, with the steering bound), c4 = configs[4] (random LTV n=12 m=4 N=512 "
+                         "batch=16384, fp32 storage)")
     return ap.parse_args()
 
 
@@ -76,6 +78,96 @@ def cpu_baseline(N, seconds):
                       "backward+forward, gcc -O2, 1 thread of %d on '%s'" % (done, N, t_used, os.cpu_count(), cpu)}
 
 
+def lane_config(args, rank, local_rank, world, dist, torch):
+    """Extra lines for the small-state configs (plan LANE, lane-per-problem SoA): the same sweep metric on the
+    expansion of a nonlinear model, plus the time of one full batched AL-iLQR solve."""
+    import altro_amd
+    from altro_amd import shard
+    from tests import problems
+    c3 = args.config == "c3"
+    if c3:
+        n, m, N = 4, 2, 50 if args.horizon == 256 else args.horizon
+        batch = 65536 // 8 if args.batch == 4096 else args.batch     # configs[3]: 65536 over an 8-GPU node
+        h = np.float32(0.1)
+        x_ref, u_ref = problems.bicycle_reference(N + 1)
+    else:
+        n, m, N = 2, 1, 100 if args.horizon == 256 else args.horizon
+        batch = 8192 if args.batch == 4096 else args.batch
+        h = np.float32(0.03)
+    first, _ = shard.shard_range(batch * world, rank, world)
+    bt = altro_amd.Batch(N, n, m, batch, device=local_rank)
+    assert bt.plan == altro_amd.PLAN_LANE
+    if c3:
+        bt.set_model(altro_amd.MODEL_BICYCLE, h)
+        bt.set_tracking_cost(np.full((1, N + 1, n), 1e-2), np.full((1, N, m), 1e-3), x_ref[None, :N + 1],
+                             u_ref[None, :N], batch_stride_zero=True)
+        G = np.zeros((2, n + m)); G[0, 3] = 1.0; G[1, 3] = -1.0
+        bt.add_linear_constraint(0, N, altro_amd.CONE_INEQUALITY, G, np.full(2, np.pi / 3))
+        x0 = x_ref[0] + (problems.uniform01((batch, n), 23, first * n) - 0.5) * 0.4
+        bt.set_input_guess(np.array([[[u_ref[0][0], 0.0]]]), k_stride_zero=True, batch_stride_zero=True)
+    else:
+        bt.set_model(altro_amd.MODEL_PENDULUM, h)
+        xf = np.array([np.pi, 0.0])
+        bt.set_tracking_cost(np.array([[1e-2, 1e-2], [1.0, 1.0]]), np.array([[1e-3]]), np.stack([xf, xf]),
+                             np.zeros((1, m)), k_stride_zero=True, batch_stride_zero=True)
+        x0 = np.zeros((batch, n)); x0[:, 0] = problems.uniform01((batch,), 22, first) - 0.5
+        bt.set_input_guess(np.array([[[0.1]]]), k_stride_zero=True, batch_stride_zero=True)
+    bt.set_initial_state(x0)
+    bt.open_loop_rollout(); bt.accept(); bt.expand()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+    for _ in range(args.warmup):
+        bt.sweep()
+    barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        bt.sweep()
+    torch.cuda.synchronize(); barrier()
+    elapsed = shard.max_over_ranks(time.perf_counter() - t0, device="cuda")
+    bt.profile(True)
+    for _ in range(5):
+        bt.sweep()
+    bt.synchronize()
+    nb, ms_b, name_b = bt.profile_get(0)
+    nf, ms_f, name_f = bt.profile_get(1)
+    bt.profile(False)
+    # one full batched solve (all problems to convergence), timed on the host clock
+    bt.set_input_guess(np.array([[[u_ref[0][0], 0.0]]]) if c3 else np.array([[[0.1]]]), k_stride_zero=True,
+                       batch_stride_zero=True)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    res = bt.ilqr_solve(iterations_max=80, use_backtracking=c3)
+    torch.cuda.synchronize()
+    t_solve = time.perf_counter() - t1
+    if rank == 0:
+        bytes_b, bytes_f = bt.algorithmic_bytes(0), bt.algorithmic_bytes(1)
+        dur_b = ms_b / nb * 1e-3
+        print(json.dumps({
+            "metric": "iLQR backward+forward sweeps/sec (N knotpoints x batch)",
+            "value": batch * world * args.steps / elapsed, "unit": "problem-sweeps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": ("C3 bicycle tracking (BASELINE.json configs[3]), steering bound as an AL block"
+                                    if c3 else "C2 pendulum swing-up (BASELINE.json configs[2])"),
+                       "horizon_N": N, "n": n, "m": m, "batch_per_gpu": batch, "global_batch": batch * world,
+                       "plan": "LANE (lane-per-problem SoA)",
+                       "kernels": {name_b: {"avg_ms": ms_b / nb, "GBps": bytes_b / dur_b / 1e9},
+                                   name_f: {"avg_ms": ms_f / nf, "GBps": bytes_f / (ms_f / nf * 1e-3) / 1e9}},
+                       "full_solve": {"seconds": t_solve, "sweeps": int(res["sweeps"]),
+                                      "merit_launches": int(res["merit_launches"]),
+                                      "converged": int((res["status"] == 0).sum()),
+                                      "mean_iterations": float(res["iterations"].mean()),
+                                      "problems_per_s": batch / t_solve}},
+            "roofline": {"bound": "hbm", "kernel": name_b, "achieved": bytes_b / dur_b / 1e9, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": bytes_b / dur_b / 1e9 / HBM_PEAK_GBS, "traffic": None},
+        }))
+    bt.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -97,6 +189,8 @@ def main():
     if c4:
         N = 512 if args.horizon == 256 else args.horizon
         batch = 16384 if args.batch == 4096 else args.batch
+    if args.config in ("c2", "c3"):
+        return lane_config(args, rank, local_rank, world, dist, torch)
     from altro_amd import shard as _shard
     first, _ = _shard.shard_range(batch * world, rank, world)   # this rank's slice of the global batch
     x0 = 2.0 * problems.uniform01((batch, n), 21, first * n) - 1.0
