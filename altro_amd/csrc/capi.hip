@@ -89,7 +89,6 @@ struct altro_hip_batch {
   std::vector<std::vector<double>> al_g;     // per block: [p] or [batch][p]
   int al_rows = 0;
   bool al_dirty = false;
-  AlDef* al_d_defs = nullptr;
   AlKnot* al_d_knots = nullptr;
   void *al_d_G = nullptr, *al_d_g = nullptr, *al_d_z = nullptr;
   const int* bwd_active = nullptr;           // per-problem mask for the backward sweep inside ilqr_solve
@@ -424,7 +423,7 @@ enum IlqrKernel { IK_ROLLOUT, IK_ACCEPT, IK_EXPAND, IK_MERIT, IK_STATIONARITY, I
 template <typename T>
 int al_upload_typed(altro_hip_batch* h) {
   const int64_t B = h->batch;
-  for (void** p : {(void**)&h->al_d_defs, (void**)&h->al_d_knots, &h->al_d_G, &h->al_d_g, &h->al_d_z})
+  for (void** p : {(void**)&h->al_d_knots, &h->al_d_G, &h->al_d_g, &h->al_d_z})
     if (*p) { (void)hipFree(*p); *p = nullptr; }
   if (h->al_defs.empty()) { h->al_rows = 0; return 0; }
   std::vector<T> G(h->al_G.begin(), h->al_G.end());
@@ -446,15 +445,17 @@ int al_upload_typed(altro_hip_batch* h) {
   int rows = 0;
   std::vector<AlKnot> knots = h->al_knots;
   for (auto& kn : knots)
-    for (int j = 0; j < kn.ncon; ++j) { kn.z_off[j] = rows; rows += defs[kn.def[j]].p; }
+    for (int j = 0; j < kn.ncon; ++j) {
+      const AlDef& d = defs[kn.def[j]];
+      kn.z_off[j] = rows; rows += d.p;
+      kn.cone[j] = d.cone; kn.p[j] = d.p; kn.g_per_problem[j] = d.g_per_problem; kn.G_off[j] = d.G_off; kn.g_off[j] = d.g_off;
+    }
   h->al_rows = rows;
   int rc = 0;
-  if ((rc = dmalloc(h, (void**)&h->al_d_defs, defs.size() * sizeof(AlDef)))) return rc;
   if ((rc = dmalloc(h, (void**)&h->al_d_knots, knots.size() * sizeof(AlKnot)))) return rc;
   if ((rc = dmalloc(h, &h->al_d_G, G.size() * sizeof(T)))) return rc;
   if ((rc = dmalloc(h, &h->al_d_g, g.size() * sizeof(T)))) return rc;
   if ((rc = dmalloc(h, &h->al_d_z, (size_t)rows * B * sizeof(T)))) return rc;
-  HIP_TRY(hipMemcpy(h->al_d_defs, defs.data(), defs.size() * sizeof(AlDef), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->al_d_knots, knots.data(), knots.size() * sizeof(AlKnot), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->al_d_G, G.data(), G.size() * sizeof(T), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->al_d_g, g.data(), g.size() * sizeof(T), hipMemcpyHostToDevice));
@@ -472,7 +473,7 @@ int al_upload(altro_hip_batch* h) {
 template <typename T>
 IlqrArgs<T> ilqr_args(altro_hip_batch* h, bool use_alpha, bool use_active, int want_deriv, double alpha_const) {
   IlqrArgs<T> a;
-  a.al.defs = h->al_d_defs; a.al.knots = h->al_d_knots; a.al.G = (const T*)h->al_d_G; a.al.g = (const T*)h->al_d_g;
+  a.al.knots = h->al_d_knots; a.al.G = (const T*)h->al_d_G; a.al.g = (const T*)h->al_d_g;
   a.al.z = (T*)h->al_d_z; a.al.enabled = h->al_defs.empty() ? 0 : 1;
   a.mode = EXPAND_GRADIENT | EXPAND_HESSIAN;
   a.in = (T*)h->l_in; a.term = (T*)h->l_term; a.out = (const T*)h->l_out; a.outn = (const T*)h->l_outn;
@@ -771,7 +772,7 @@ void altro_hip_batch_destroy(altro_hip_batch* h) {
                   h->m_qblk, h->m_trash, h->g_off, h->g_nx, h->g_nu, h->stage,
                   h->l_in, h->l_term, h->l_out, h->l_outn, h->l_xuy, h->l_x0,
                   h->l_nom, h->l_cost, h->i_prob, h->i_alpha, h->i_phi, h->i_dphi, h->i_active, h->i_counters,
-                  h->al_d_defs, h->al_d_knots, h->al_d_G, h->al_d_g, h->al_d_z};
+                  h->al_d_knots, h->al_d_G, h->al_d_g, h->al_d_z};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (int a = 0; a < G_NUM; ++a) if (h->g_arr[a]) (void)hipFree(h->g_arr[a]);
   if (h->ev0) (void)hipEventDestroy(h->ev0);

@@ -17,6 +17,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "tvlqr_lane.hip"   // LaneBuf / lane_ld row access
+
 namespace altro_hip {
 
 constexpr int AL_MAXC = 2;     // constraint blocks per knot point
@@ -31,20 +33,24 @@ struct AlDef {
   int G_off;       // into the G pool (elements)
   int64_t g_off;   // into the g pool (elements): [p] shared, or [p][batch]
 };
-struct AlKnot {
+struct AlKnot {          // everything a kernel needs about knot point k in ONE wave-uniform record
   int ncon;
   int def[AL_MAXC];
   int z_off[AL_MAXC];   // first row of this block's dual in z[rows][batch]
+  int cone[AL_MAXC], p[AL_MAXC], g_per_problem[AL_MAXC], G_off[AL_MAXC];
+  int64_t g_off[AL_MAXC];
 };
 template <typename T>
 struct AlTable {
-  const AlDef* defs;
   const AlKnot* knots;   // [N + 1]
   const T* G;
   const T* g;
   T* z;
   int enabled;
 };
+// Tables and the shared G / g blocks are read through the constant address space: with a wave-uniform
+// address that is an s_load into SGPRs (scalar cache) instead of a vector load + v_readlane waterfall.
+#define ALTRO_CONST_AS __attribute__((address_space(4)))
 
 // cones.cpp:13-38 (p <= AL_MAXSOC, fully unrolled so the arrays stay in registers)
 template <typename T>
@@ -167,17 +173,18 @@ __device__ __forceinline__ void soc_hessian(int p, const T* x, const T* bb, T* H
 template <int n, int m, typename T, bool GRAD, bool HESS>
 __device__ __forceinline__ T al_eval(const AlTable<T>& t, int k, int64_t b, int64_t B, const T* x, const T* u,
                                      bool terminal, T rho_est, T rho, T* lx, T* lu, T* lxx, T* luu, T* lux,
-                                     T* viol, bool dual_update) {
+                                     T* viol, bool dual_update, const T* zpre = nullptr) {
   constexpr int w = n + m;
-  const AlKnot& kn = t.knots[k];
+  const AlKnot ALTRO_CONST_AS& kn = *(const AlKnot ALTRO_CONST_AS*)(t.knots + k);
   T cost = T(0);
-  for (int j = 0; j < kn.ncon; ++j) {
-    const AlDef& d = t.defs[kn.def[j]];
-    const int p = d.p;
-    const int cone = d.cone;
-    const T* __restrict__ G = t.G + d.G_off;
-    const T* g = t.g + d.g_off + (d.g_per_problem ? b : 0);
-    const int64_t gs = d.g_per_problem ? B : 1;
+  static_assert(AL_MAXC == 2, "the preloaded duals are selected with j == 0 ? first : second");
+  for (int j = 0; j < kn.ncon; ++j) {   // runtime loop: one copy of the block code
+    const int p = kn.p[j];
+    const int cone = kn.cone[j];
+    const bool gpp = kn.g_per_problem[j] != 0;
+    const T ALTRO_CONST_AS* G = (const T ALTRO_CONST_AS*)(t.G + kn.G_off[j]);
+    const T ALTRO_CONST_AS* gsh = (const T ALTRO_CONST_AS*)(t.g + kn.g_off[j]);   // shared right-hand side
+    const T* gpb = t.g + kn.g_off[j] + b;                                         // per-problem right-hand side
     T* z = t.z + (int64_t)kn.z_off[j] * B + b;
     if (cone != CONE_SOC) {
       // zero / identity / orthant: projection and its Jacobian are diagonal (cones.cpp:125-178)
@@ -191,8 +198,8 @@ __device__ __forceinline__ T al_eval(const AlTable<T>& t, int k, int64_t b, int6
           for (int e = 0; e < n; ++e) s += G[i + e * p] * x[e];
           if (!terminal)
             for (int e = 0; e < m; ++e) s += G[i + (n + e) * p] * u[e];
-          const T val = s - g[(int64_t)i * gs];
-          const T ze = z[(int64_t)i * B] - rho_est * val;
+          const T val = s - (gpp ? gpb[(int64_t)i * B] : gsh[i]);
+          const T ze = (zpre ? (j == 0 ? zpre[i] : zpre[AL_MAXP + i]) : z[(int64_t)i * B]) - rho_est * val;
           if (cone == CONE_EQUALITY) { zp[i] = ze; msk[i] = T(1); }                     // dual cone: identity
           else if (cone == CONE_INEQUALITY) { zp[i] = fmin(T(0), ze); msk[i] = (ze <= T(0)) ? T(1) : T(0); }
           // CONE_IDENTITY: dual cone is the zero cone, projection 0, Jacobian 0
@@ -251,8 +258,8 @@ __device__ __forceinline__ T al_eval(const AlTable<T>& t, int k, int64_t b, int6
           for (int e = 0; e < n; ++e) s += G[i + e * p] * x[e];
           if (!terminal)
             for (int e = 0; e < m; ++e) s += G[i + (n + e) * p] * u[e];
-          val[i] = s - g[(int64_t)i * gs];
-          ze[i] = z[(int64_t)i * B] - rho_est * val[i];
+          val[i] = s - (gpp ? gpb[(int64_t)i * B] : gsh[i]);
+          ze[i] = (zpre ? (j == 0 ? zpre[i] : zpre[AL_MAXP + i]) : z[(int64_t)i * B]) - rho_est * val[i];
         }
       }
       soc_projection<T>(p, ze, zp);   // the SOC is self-dual (cones.hpp:13-30)
@@ -343,6 +350,23 @@ __device__ __forceinline__ T al_eval(const AlTable<T>& t, int k, int64_t b, int6
     }
   }
   return cost;
+}
+
+// The duals of knot point k of this lane's problem into registers (zero where no row exists), so that a
+// sequential kernel can request them one knot point ahead.  `zrow` = t.z + first problem of the wave.
+template <typename T, typename BUF>
+__device__ __forceinline__ void al_load_z(const AlTable<T>& t, int k, const BUF& bz, uint32_t lane, uint32_t rowB,
+                                          T (&zv)[AL_MAXC * AL_MAXP]) {
+  const AlKnot ALTRO_CONST_AS& kn = *(const AlKnot ALTRO_CONST_AS*)(t.knots + k);
+#pragma unroll
+  for (int j = 0; j < AL_MAXC; ++j) {
+    const int p = j < kn.ncon ? kn.p[j] : 0;
+#pragma unroll
+    for (int i = 0; i < AL_MAXP; ++i) {
+      zv[j * AL_MAXP + i] = T(0);
+      if (i < p) zv[j * AL_MAXP + i] = lane_ld<T>(bz, lane, (uint32_t)(kn.z_off[j] + i) * rowB);
+    }
+  }
 }
 
 }  // namespace altro_hip

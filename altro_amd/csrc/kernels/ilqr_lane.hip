@@ -209,101 +209,183 @@ __device__ __forceinline__ T ilqr_kp_cost(const T* cs, int64_t B, const T* x, co
   return J;
 }
 
+// One knot point's merit-function operands in registers: K | d | P | p, the nominal x | u, the cost record and
+// the duals.  None of these addresses depends on the rollout, so record k + 1 is requested before knot point
+// k is evaluated (these kernels are latency-bound: one wave per 64 problems, N dependent steps).
+template <int n, int m, typename T>
+struct MeritRec {
+  using D = LaneDims<n, m>;
+  using I = IlqrDims<n, m>;
+  T out[D::E_OUT];
+  T nom[I::E_NOM];
+  T cs[I::E_COST];
+  T z[AL_MAXC * AL_MAXP];
+};
+
+template <int n, int m, typename T>
+__device__ __forceinline__ void merit_load(MeritRec<n, m, T>& r, const IlqrArgs<T>& a, int k, int64_t b0, uint32_t lane,
+                                           uint32_t rowB) {
+  using D = LaneDims<n, m>;
+  using I = IlqrDims<n, m>;
+  const int64_t B = a.batch;
+  if (k < a.N) {
+    const LaneBuf bo(a.out + b0 + (int64_t)k * D::E_OUT * B);
+#pragma unroll
+    for (int e = 0; e < D::E_OUT; ++e) r.out[e] = lane_ld<T>(bo, lane, (uint32_t)e * rowB);
+  } else {   // terminal: P_N | p_N
+    const LaneBuf bo(a.outn + b0);
+#pragma unroll
+    for (int e = 0; e < n * n + n; ++e) r.out[D::O_P + e] = lane_ld<T>(bo, lane, (uint32_t)e * rowB);
+  }
+  const LaneBuf bn(a.nom + b0 + (int64_t)k * I::E_NOM * B), bc(a.cost + b0 + (int64_t)k * I::E_COST * B);
+#pragma unroll
+  for (int e = 0; e < I::E_NOM; ++e) r.nom[e] = lane_ld<T>(bn, lane, (uint32_t)e * rowB);
+#pragma unroll
+  for (int e = 0; e < I::E_COST; ++e) r.cs[e] = lane_ld<T>(bc, lane, (uint32_t)e * rowB);
+  if (a.al.enabled) al_load_z<T>(a.al, k, LaneBuf(a.al.z + b0), lane, rowB, r.z);
+}
+
+// diagonal quadratic cost of one knot point from the register copy of its cost record (knotpoint_data.cpp:636-645)
+template <int n, int m, typename T>
+__device__ __forceinline__ T ilqr_kp_cost_reg(const T* cs, const T* x, const T* u, bool terminal) {
+  using I = IlqrDims<n, m>;
+  T a1 = T(0);
+  for (int i = 0; i < n; ++i) a1 += x[i] * (cs[I::C_Q + i] * x[i]);
+  T J = T(0.5) * a1;
+  T b1 = T(0);
+  for (int i = 0; i < n; ++i) b1 += cs[I::C_q + i] * x[i];
+  J += b1;
+  if (!terminal) {
+    T a2 = T(0);
+    for (int i = 0; i < m; ++i) a2 += u[i] * (cs[I::C_R + i] * u[i]);
+    J += T(0.5) * a2;
+    T b2 = T(0);
+    for (int i = 0; i < m; ++i) b2 += cs[I::C_r + i] * u[i];
+    J += b2;
+  }
+  J += cs[I::C_c];
+  return J;
+}
+
+// one non-terminal knot point of MeritFunction (solver.cpp:286-317)
+template <int KIND, int n, int m, typename T>
+__device__ __forceinline__ void merit_step(const MeritRec<n, m, T>& r, const IlqrArgs<T>& a, int k, int64_t b, int64_t b0,
+                                           uint32_t lane, uint32_t rowB, T alpha, T rho, bool deriv, bool al, T (&x)[n],
+                                           T (&dxda)[n], T& phi, T& dphi) {
+  using D = LaneDims<n, m>;
+  using I = IlqrDims<n, m>;
+  using Mdl = DiscreteModel<KIND, n, m, T>;
+  const int64_t B = a.batch;
+  T dx[n], u[m], xn[n], y[n];
+  for (int i = 0; i < n; ++i) dx[i] = x[i] - r.nom[i];
+  for (int i = 0; i < m; ++i) {   // u_ = u + (-K dx + alpha d)
+    T s = T(0);
+    for (int j = 0; j < n; ++j) s += r.out[D::O_K + i + j * m] * dx[j];
+    u[i] = r.nom[n + i] + (-s + alpha * r.out[D::O_d + i]);
+  }
+  for (int i = 0; i < n; ++i) {   // y_ = P dx + p
+    T s = T(0);
+    for (int j = 0; j < n; ++j) s += r.out[D::O_P + i + j * n] * dx[j];
+    y[i] = s + r.out[D::O_p + i];
+  }
+  const LaneBuf bc(a.cand + b0 + (int64_t)k * I::E_CAND * B);
+#pragma unroll
+  for (int e = 0; e < n; ++e) lane_st<T>(bc, lane, (uint32_t)e * rowB, x[e]);
+#pragma unroll
+  for (int e = 0; e < n; ++e) lane_st<T>(bc, lane, (uint32_t)(n + e) * rowB, y[e]);
+#pragma unroll
+  for (int e = 0; e < m; ++e) lane_st<T>(bc, lane, (uint32_t)(2 * n + e) * rowB, u[e]);
+  T Am[n * n], Bm[n * m];
+  if (deriv) Mdl::step(a.mp, x, u, xn, Am, Bm);
+  else Mdl::dynamics(a.mp, x, u, xn);
+  T lx[n], lu[m];
+  for (int i = 0; i < n; ++i) lx[i] = r.cs[I::C_Q + i] * x[i] + r.cs[I::C_q + i];
+  for (int i = 0; i < m; ++i) lu[i] = r.cs[I::C_R + i] * u[i] + r.cs[I::C_r + i];
+  T Jk = ilqr_kp_cost_reg<n, m, T>(r.cs, x, u, false);
+  if (al)   // one instance: the gradient terms are formed even when only phi is wanted (lx, lu are then unused)
+    Jk += al_eval<n, m, T, true, false>(a.al, k, b, B, x, u, false, rho, rho, lx, lu, nullptr, nullptr, nullptr, nullptr, false, r.z);
+  phi += Jk;
+  if (deriv) {
+    T duda[m], dxn[n];
+    const LaneBuf bi(a.in + b0 + (int64_t)k * D::E_IN * B);
+#pragma unroll
+    for (int e = 0; e < n * n; ++e) lane_st<T>(bi, lane, (uint32_t)(D::O_A + e) * rowB, Am[e]);
+#pragma unroll
+    for (int e = 0; e < n * m; ++e) lane_st<T>(bi, lane, (uint32_t)(D::O_B + e) * rowB, Bm[e]);
+    for (int i = 0; i < m; ++i) {   // du_da = -K dx_da + d
+      T s = T(0);
+      for (int j = 0; j < n; ++j) s += r.out[D::O_K + i + j * m] * dxda[j];
+      duda[i] = -s + r.out[D::O_d + i];
+    }
+    for (int i = 0; i < n; ++i) {   // dx_da+ = A dx_da + B du_da
+      T s = T(0);
+      for (int j = 0; j < n; ++j) s += Am[i + j * n] * dxda[j];
+      T s2 = T(0);
+      for (int j = 0; j < m; ++j) s2 += Bm[i + j * n] * duda[j];
+      dxn[i] = s + s2;
+    }
+#pragma unroll
+    for (int e = 0; e < n; ++e) lane_st<T>(bi, lane, (uint32_t)(D::O_q + e) * rowB, lx[e]);
+#pragma unroll
+    for (int e = 0; e < m; ++e) lane_st<T>(bi, lane, (uint32_t)(D::O_r + e) * rowB, lu[e]);
+    T s = T(0);
+    for (int i = 0; i < n; ++i) s += lx[i] * dxda[i];
+    dphi += s;
+    s = T(0);
+    for (int i = 0; i < m; ++i) s += lu[i] * duda[i];
+    dphi += s;
+    for (int e = 0; e < n; ++e) dxda[e] = dxn[e];
+  }
+  for (int e = 0; e < n; ++e) x[e] = xn[e];
+}
+
 // MeritFunction (solver.cpp:273-355): closed-loop rollout with step alpha, total cost phi and, when
 // asked, the directional derivative dphi together with the refreshed A, B, lx, lu.
 template <int KIND, int n, int m, typename T>
 __global__ __launch_bounds__(64) void ilqr_merit_kernel(IlqrArgs<T> a) {
   ILQR_PROLOGUE;
   if (a.active && !a.active[b]) return;
+  const uint32_t lane = threadIdx.x * (uint32_t)sizeof(T);
+  const uint32_t rowB = (uint32_t)B * (uint32_t)sizeof(T);
+  const int64_t b0 = (int64_t)blockIdx.x * 64;
   const T alpha = (T)(a.alpha ? a.alpha[b] : a.alpha_const);
   const bool deriv = a.want_derivative != 0;
   const bool al = a.al.enabled != 0;
   const T rho = al ? (T)a.prob[b].rho : T(1);   // CalcCost refreshes the projected duals with the current penalty
   T x[n], dxda[n], phi = T(0), dphi = T(0);
-  for (int e = 0; e < n; ++e) { x[e] = a.x0[(int64_t)e * B + b]; dxda[e] = T(0); }
-  for (int k = 0; k < N; ++k) {
-    const T* o = a.out + (int64_t)k * D::E_OUT * B + b;
-    const T* nm = a.nom + (int64_t)k * I::E_NOM * B + b;
-    const T* cs = a.cost + (int64_t)k * I::E_COST * B + b;
-    T* c = a.cand + (int64_t)k * I::E_CAND * B + b;
-    T dx[n], u[m], xn[n];
-    for (int i = 0; i < n; ++i) dx[i] = x[i] - nm[(int64_t)i * B];
-    for (int i = 0; i < m; ++i) {   // u_ = u + (-K dx + alpha d)
-      T s = T(0);
-      for (int j = 0; j < n; ++j) s += o[(int64_t)(D::O_K + i + j * m) * B] * dx[j];
-      u[i] = nm[(int64_t)(n + i) * B] + (-s + alpha * o[(int64_t)(D::O_d + i) * B]);
-    }
-    for (int i = 0; i < n; ++i) {   // y_ = P dx + p
-      T s = T(0);
-      for (int j = 0; j < n; ++j) s += o[(int64_t)(D::O_P + i + j * n) * B] * dx[j];
-      c[(int64_t)(n + i) * B] = s + o[(int64_t)(D::O_p + i) * B];
-    }
-    for (int e = 0; e < n; ++e) c[(int64_t)e * B] = x[e];
-    for (int e = 0; e < m; ++e) c[(int64_t)(2 * n + e) * B] = u[e];
-    Mdl::dynamics(a.mp, x, u, xn);
-    T lx[n], lu[m];
-    for (int i = 0; i < n; ++i) lx[i] = cs[(int64_t)(I::C_Q + i) * B] * x[i] + cs[(int64_t)(I::C_q + i) * B];
-    for (int i = 0; i < m; ++i) lu[i] = cs[(int64_t)(I::C_R + i) * B] * u[i] + cs[(int64_t)(I::C_r + i) * B];
-    T Jk = ilqr_kp_cost<n, m, T>(cs, B, x, u, false);
-    if (al) {
-      Jk += deriv ? al_eval<n, m, T, true, false>(a.al, k, b, B, x, u, false, rho, rho, lx, lu, nullptr, nullptr, nullptr, nullptr, false)
-                  : al_eval<n, m, T, false, false>(a.al, k, b, B, x, u, false, rho, rho, lx, lu, nullptr, nullptr, nullptr, nullptr, false);
-    }
-    phi += Jk;
-    if (deriv) {
-      T* in = a.in + (int64_t)k * D::E_IN * B + b;
-      T Am[n * n], Bm[n * m], duda[m], dxn[n];
-      Mdl::jacobian(a.mp, x, u, Am, Bm);
-      for (int e = 0; e < n * n; ++e) in[(int64_t)(D::O_A + e) * B] = Am[e];
-      for (int e = 0; e < n * m; ++e) in[(int64_t)(D::O_B + e) * B] = Bm[e];
-      for (int i = 0; i < m; ++i) {   // du_da = -K dx_da + d
-        T s = T(0);
-        for (int j = 0; j < n; ++j) s += o[(int64_t)(D::O_K + i + j * m) * B] * dxda[j];
-        duda[i] = -s + o[(int64_t)(D::O_d + i) * B];
-      }
-      for (int i = 0; i < n; ++i) {   // dx_da+ = A dx_da + B du_da
-        T s = T(0);
-        for (int j = 0; j < n; ++j) s += Am[i + j * n] * dxda[j];
-        T s2 = T(0);
-        for (int j = 0; j < m; ++j) s2 += Bm[i + j * n] * duda[j];
-        dxn[i] = s + s2;
-      }
-      for (int e = 0; e < n; ++e) in[(int64_t)(D::O_q + e) * B] = lx[e];
-      for (int e = 0; e < m; ++e) in[(int64_t)(D::O_r + e) * B] = lu[e];
-      T s = T(0);
-      for (int i = 0; i < n; ++i) s += lx[i] * dxda[i];
-      dphi += s;
-      s = T(0);
-      for (int i = 0; i < m; ++i) s += lu[i] * duda[i];
-      dphi += s;
-      for (int e = 0; e < n; ++e) dxda[e] = dxn[e];
-    }
-    for (int e = 0; e < n; ++e) x[e] = xn[e];
+  {
+    const LaneBuf bx(a.x0 + b0);
+#pragma unroll
+    for (int e = 0; e < n; ++e) { x[e] = lane_ld<T>(bx, lane, (uint32_t)e * rowB); dxda[e] = T(0); }
   }
-  {   // terminal knot point (solver.cpp:319-332)
-    const T* nm = a.nom + (int64_t)N * I::E_NOM * B + b;
-    const T* cs = a.cost + (int64_t)N * I::E_COST * B + b;
-    T* c = a.cand + (int64_t)N * I::E_CAND * B + b;
+  MeritRec<n, m, T> r0, r1;
+  merit_load<n, m, T>(r0, a, 0, b0, lane, rowB);
+  for (int k = 0; k < N; ++k) {   // one step instance (code size); the copy waits for record k + 1 after step k
+    merit_load<n, m, T>(r1, a, k + 1, b0, lane, rowB);      // k + 1 == N: the terminal record
+    merit_step<KIND, n, m, T>(r0, a, k, b, b0, lane, rowB, alpha, rho, deriv, al, x, dxda, phi, dphi);
+    r0 = r1;
+  }
+  {   // terminal knot point (solver.cpp:319-332); r0 holds record N
     T lxN[n];
-    for (int i = 0; i < n; ++i) lxN[i] = cs[(int64_t)(I::C_Q + i) * B] * x[i] + cs[(int64_t)(I::C_q + i) * B];
-    T Jk = ilqr_kp_cost<n, m, T>(cs, B, x, (const T*)nullptr, true);
-    if (al) {
-      Jk += deriv ? al_eval<n, m, T, true, false>(a.al, N, b, B, x, (const T*)nullptr, true, rho, rho, lxN, nullptr, nullptr, nullptr, nullptr, nullptr, false)
-                  : al_eval<n, m, T, false, false>(a.al, N, b, B, x, (const T*)nullptr, true, rho, rho, lxN, nullptr, nullptr, nullptr, nullptr, nullptr, false);
-    }
+    for (int i = 0; i < n; ++i) lxN[i] = r0.cs[I::C_Q + i] * x[i] + r0.cs[I::C_q + i];
+    T Jk = ilqr_kp_cost_reg<n, m, T>(r0.cs, x, (const T*)nullptr, true);
+    if (al)
+      Jk += al_eval<n, m, T, true, false>(a.al, N, b, B, x, (const T*)nullptr, true, rho, rho, lxN, nullptr, nullptr, nullptr, nullptr, nullptr, false, r0.z);
     phi += Jk;
     T dx[n];
-    for (int i = 0; i < n; ++i) dx[i] = x[i] - nm[(int64_t)i * B];
+    for (int i = 0; i < n; ++i) dx[i] = x[i] - r0.nom[i];
+    const LaneBuf bc(a.cand + b0 + (int64_t)N * I::E_CAND * B), bt(a.term + b0);
     for (int i = 0; i < n; ++i) {
       T s = T(0);
-      for (int j = 0; j < n; ++j) s += a.outn[(int64_t)(i + j * n) * B + b] * dx[j];
-      c[(int64_t)(n + i) * B] = s + a.outn[(int64_t)(n * n + i) * B + b];
+      for (int j = 0; j < n; ++j) s += r0.out[D::O_P + i + j * n] * dx[j];
+      lane_st<T>(bc, lane, (uint32_t)(n + i) * rowB, s + r0.out[D::O_p + i]);
     }
-    for (int e = 0; e < n; ++e) c[(int64_t)e * B] = x[e];
+#pragma unroll
+    for (int e = 0; e < n; ++e) lane_st<T>(bc, lane, (uint32_t)e * rowB, x[e]);
     if (deriv) {
       T s = T(0);
       for (int i = 0; i < n; ++i) {
-        a.term[(int64_t)(n * n + i) * B + b] = lxN[i];
+        lane_st<T>(bt, lane, (uint32_t)(n * n + i) * rowB, lxN[i]);
         s += lxN[i] * dxda[i];
       }
       dphi += s;

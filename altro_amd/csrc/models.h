@@ -119,6 +119,59 @@ ALTRO_HD void bicycle_J(const ModelParams& mp, const T* x, const T* u, T* J) {
   J[3 + 5 * 4] = T(1);
 }
 
+// f and J of the bicycle at one point with every transcendental evaluated once (the separate functions call
+// sin / cos / tan / atan2 on the same arguments up to three times each); same calls on the same arguments,
+// so the values are the ones bicycle_f / bicycle_J produce.
+template <typename T>
+ALTRO_HD void bicycle_fJ(const ModelParams& mp, const T* x, const T* u, T* xdot, T* J) {
+  const T v = u[0], delta_dot = u[1], theta = x[2], delta = x[3];
+  const T L = (T)mp.length, lr = (T)mp.lr;
+  T omega, st, ct, dbeta = T(0), domega_ddelta, domega_dv, ds_dde = T(0), dc_dde = T(0);
+  if (mp.frame == 0) {
+    const T by = lr * delta, bx = L;
+    const T beta = atan2(by, bx);
+    const T sb = sin(beta), cb = cos(beta), td = tan(delta), cd = cos(delta);
+    st = sin(theta + beta);
+    ct = cos(theta + beta);
+    omega = v * cb * td / L;
+    dbeta = bx / (bx * bx + by * by) * lr;
+    domega_ddelta = v / L * (-sb * td * dbeta + cb / (cd * cd));
+    domega_dv = cb * td / L;
+    ds_dde = ct * dbeta;
+    dc_dde = -st * dbeta;
+  } else if (mp.frame == 1) {
+    const T td = tan(delta), cd = cos(delta);
+    omega = v * td / L;
+    st = sin(theta);
+    ct = cos(theta);
+    domega_ddelta = v / L / (cd * cd);
+    domega_dv = td / L;
+  } else {
+    const T sd = sin(delta), cd = cos(delta);
+    omega = v * sd / L;
+    st = sin(theta + delta);
+    ct = cos(theta + delta);
+    domega_ddelta = v / L * cd;
+    domega_dv = sd / L;
+    ds_dde = ct;
+    dc_dde = -st;
+  }
+  xdot[0] = v * ct;
+  xdot[1] = v * st;
+  xdot[2] = omega;
+  xdot[3] = delta_dot;
+  for (int e = 0; e < 24; ++e) J[e] = T(0);
+  J[0 + 2 * 4] = v * -st;
+  J[0 + 3 * 4] = v * dc_dde;
+  J[0 + 4 * 4] = ct;
+  J[1 + 2 * 4] = v * ct;
+  J[1 + 3 * 4] = v * ds_dde;
+  J[1 + 4 * 4] = st;
+  J[2 + 3 * 4] = domega_ddelta;
+  J[2 + 4 * 4] = domega_dv;
+  J[3 + 5 * 4] = T(1);
+}
+
 // ---- discrete models -------------------------------------------------------------------------------
 // KIND is a compile-time ModelKind; n, m the dimensions (double integrator: dim = n/2, the first m
 // axes are actuated -- m == dim is the reference's model, m < dim the C1 variant of SURVEY.md 8d).
@@ -131,6 +184,45 @@ struct DiscreteModel {
   static ALTRO_HD void cont_J(const ModelParams& mp, const T* x, const T* u, T* J) {
     if (KIND == MODEL_PENDULUM) pendulum_J<T>(x, u, J);
     else bicycle_J<T>(mp, x, u, J);
+  }
+
+  static ALTRO_HD void cont_fJ(const ModelParams& mp, const T* x, const T* u, T* xdot, T* J) {
+    if (KIND == MODEL_PENDULUM) { pendulum_f<T>(x, u, xdot); pendulum_J<T>(x, u, J); }
+    else bicycle_fJ<T>(mp, x, u, xdot, J);
+  }
+
+  // dynamics() and jacobian() in one pass: f(x, u) and the midpoint are formed once and each point's
+  // transcendental functions are shared between f and J.  Values are those of the separate functions.
+  static ALTRO_HD void step(const ModelParams& mp, const T* x, const T* u, T* xn, T* A, T* B) {
+    if (KIND == MODEL_DOUBLE_INTEGRATOR) {
+      dynamics(mp, x, u, xn);
+      jacobian(mp, x, u, A, B);
+    } else {
+      const float h = mp.h;
+      T k1[n], xm[n], k2[n], J0[n * (n + m)], Jm[n * (n + m)], Tm[n * n];
+      cont_fJ(mp, x, u, k1, J0);
+      for (int i = 0; i < n; ++i) xm[i] = x[i] + (T)(h / 2) * k1[i];
+      cont_fJ(mp, xm, u, k2, Jm);
+      for (int i = 0; i < n; ++i) xn[i] = x[i] + (T)h * k2[i];
+      const T* A0 = J0;
+      const T* B0 = J0 + n * n;
+      const T* Am = Jm;
+      const T* Bm = Jm + n * n;
+      for (int j = 0; j < n; ++j)
+        for (int i = 0; i < n; ++i) Tm[i + j * n] = (i == j ? T(1) : T(0)) + (T)(h / 2) * A0[i + j * n];
+      for (int j = 0; j < n; ++j)
+        for (int i = 0; i < n; ++i) {
+          T s = T(0);
+          for (int k = 0; k < n; ++k) s += ((T)h * Am[i + k * n]) * Tm[k + j * n];
+          A[i + j * n] = (i == j ? T(1) : T(0)) + s;
+        }
+      for (int j = 0; j < m; ++j)
+        for (int i = 0; i < n; ++i) {
+          T s = T(0);
+          for (int k = 0; k < n; ++k) s += (Am[i + k * n] * (T)(h / 2)) * B0[k + j * n];
+          B[i + j * n] = (T)h * (s + Bm[i + j * n]);
+        }
+    }
   }
 
   static ALTRO_HD void dynamics(const ModelParams& mp, const T* x, const T* u, T* xn) {
