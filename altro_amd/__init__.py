@@ -47,13 +47,15 @@ class SolveOptions(C.Structure):
     _fields_ = [("iterations_max", C.c_int), ("tol_stationarity", C.c_double),
                 ("tol_primal_feasibility", C.c_double), ("tol_meritfun_gradient", C.c_double),
                 ("use_backtracking_linesearch", C.c_int), ("penalty_initial", C.c_double),
-                ("penalty_scaling", C.c_double), ("penalty_max", C.c_double)]
+                ("penalty_scaling", C.c_double), ("penalty_max", C.c_double), ("reg_initial", C.c_double),
+                ("reg_retry_max", C.c_int), ("reg_scale", C.c_double), ("reg_min", C.c_double),
+                ("reg_max", C.c_double)]
 
 
 class SolveResult(C.Structure):
     _fields_ = [("status", C.c_int), ("iterations", C.c_int), ("stationarity", C.c_double),
                 ("final_alpha", C.c_double), ("final_phi", C.c_double), ("primal_feasibility", C.c_double),
-                ("penalty", C.c_double), ("dual_updates", C.c_int)]
+                ("penalty", C.c_double), ("dual_updates", C.c_int), ("reg_retries", C.c_int)]
 
 
 class AltroHipError(RuntimeError):
@@ -321,11 +323,13 @@ class Batch:
 
     def ilqr_solve(self, iterations_max=200, tol_stationarity=1e-4, tol_meritfun_gradient=1e-8,
                    use_backtracking=False, tol_primal_feasibility=1e-4, penalty_initial=1.0, penalty_scaling=10.0,
-                   penalty_max=1e8):
+                   penalty_max=1e8, reg_initial=0.0, reg_retry_max=0, reg_scale=10.0, reg_min=1e-6, reg_max=1e8):
         o = SolveOptions()
         self.L.altro_hip_default_solve_options(C.byref(o))
         o.tol_primal_feasibility = tol_primal_feasibility
         o.penalty_initial, o.penalty_scaling, o.penalty_max = penalty_initial, penalty_scaling, penalty_max
+        o.reg_initial, o.reg_retry_max, o.reg_scale = reg_initial, reg_retry_max, reg_scale
+        o.reg_min, o.reg_max = reg_min, reg_max
         o.iterations_max, o.tol_stationarity = iterations_max, tol_stationarity
         o.tol_meritfun_gradient, o.use_backtracking_linesearch = tol_meritfun_gradient, int(use_backtracking)
         res = (SolveResult * self.batch)()
@@ -338,6 +342,7 @@ class Batch:
                     feasibility=np.array([r.primal_feasibility for r in res]),
                     penalty=np.array([r.penalty for r in res]),
                     dual_updates=np.array([r.dual_updates for r in res]),
+                    reg_retries=np.array([r.reg_retries for r in res]),
                     sweeps=sw.value, merit_launches=ml.value)
 
 

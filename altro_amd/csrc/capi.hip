@@ -92,6 +92,8 @@ struct altro_hip_batch {
   AlKnot* al_d_knots = nullptr;
   void *al_d_G = nullptr, *al_d_g = nullptr, *al_d_z = nullptr;
   const int* bwd_active = nullptr;           // per-problem mask for the backward sweep inside ilqr_solve
+  const double* bwd_reg = nullptr;           // per-problem regularisation inside ilqr_solve (retry extension)
+  double* i_reg = nullptr;
   // staging for host <-> device conversion (grown lazily, never inside the hot path)
   void* stage = nullptr;
   size_t stage_bytes = 0;
@@ -301,7 +303,8 @@ LaneSizes lane_sizes(int n, int m) {
 template <typename T>
 int lane_launch(altro_hip_batch* h, bool backward, double reg) {
   LaneArgs<T> a{(const T*)h->l_in, (const T*)h->l_term, (T*)h->l_out, (T*)h->l_outn, (const T*)h->l_x0,
-                (T*)h->l_xuy, (T*)h->delta_V, h->status, h->N, h->batch, (T)reg, backward ? h->bwd_active : nullptr};
+                (T*)h->l_xuy, (T*)h->delta_V, h->status, h->N, h->batch, (T)reg, backward ? h->bwd_active : nullptr,
+                backward ? h->bwd_reg : nullptr};
   const dim3 grid((h->batch + 63) / 64), block(64);
 #define X(N_, M_)                                                                                     \
   if (h->n == N_ && h->m == M_) {                                                                     \
@@ -704,6 +707,10 @@ int altro_hip_batch_create(altro_hip_batch** out, int N, int n, int m, int batch
     if (flags & ALTRO_HIP_STORE_QBLOCKS) ALLOC(h->m_qblk, B * N * MF_QB * E);
   } else if (plan == ALTRO_HIP_PLAN_LANE) {
     const LaneSizes z = lane_sizes(n, m);
+    // the LANE kernels address one knot point's record through a 2 GiB buffer window with 32-bit offsets
+    if (!rc && (uint64_t)B * (uint64_t)std::max(z.e_in, 2 * n + 2 * m + 1 + z.e_out) * E >= (1ull << 31))
+      rc = fail(ALTRO_HIP_ERR_UNSUPPORTED, "plan LANE: batch %d too large for one handle (record rows exceed 2 GiB); "
+                                           "split the batch over several handles", batch);
     ALLOC(h->l_in, B * N * z.e_in * E);
     ALLOC(h->l_term, B * z.e_term * E);
     ALLOC(h->l_out, B * N * z.e_out * E);
@@ -718,6 +725,7 @@ int altro_hip_batch_create(altro_hip_batch** out, int N, int n, int m, int batch
     ALLOC(h->i_dphi, B * 8);
     ALLOC(h->i_active, B * sizeof(int));
     ALLOC(h->i_counters, 4 * sizeof(int));
+    ALLOC(h->i_reg, B * 8);
     if (!rc) {   // every constraint starts with penalty 1 (knotpoint_data.cpp:343)
       std::vector<IlqrProb> pr((size_t)B);
       std::memset(pr.data(), 0, pr.size() * sizeof(IlqrProb));
@@ -772,7 +780,7 @@ void altro_hip_batch_destroy(altro_hip_batch* h) {
                   h->m_qblk, h->m_trash, h->g_off, h->g_nx, h->g_nu, h->stage,
                   h->l_in, h->l_term, h->l_out, h->l_outn, h->l_xuy, h->l_x0,
                   h->l_nom, h->l_cost, h->i_prob, h->i_alpha, h->i_phi, h->i_dphi, h->i_active, h->i_counters,
-                  h->al_d_knots, h->al_d_G, h->al_d_g, h->al_d_z};
+                  h->al_d_knots, h->al_d_G, h->al_d_g, h->al_d_z, h->i_reg};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (int a = 0; a < G_NUM; ++a) if (h->g_arr[a]) (void)hipFree(h->g_arr[a]);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -1413,13 +1421,18 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
   la.penalty_initial = o.penalty_initial; la.penalty_scaling = o.penalty_scaling; la.penalty_max = o.penalty_max;
   const bool al = !h->al_defs.empty();
   la.al_enabled = al ? 1 : 0;
+  la.reg = h->i_reg; la.bwd_status = h->status;
+  la.reg_initial = o.reg_initial; la.reg_scale = o.reg_scale; la.reg_min = o.reg_min; la.reg_max = o.reg_max;
+  const bool reg_on = o.reg_retry_max > 0 || o.reg_initial > 0.0;
+  if (o.reg_initial < 0.0 || (o.reg_retry_max > 0 && !(o.reg_scale > 1.0 && o.reg_min > 0.0 && o.reg_max >= o.reg_min)))
+    return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "regularisation retry needs reg_initial >= 0, reg_scale > 1, 0 < reg_min <= reg_max");
   if (al && !(o.penalty_initial > 0.0 && o.penalty_scaling > 0.0 && o.penalty_max > 0.0))
     return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "penalty_initial, penalty_scaling and penalty_max must be positive");
   la.ls = ls_default_options();
   la.ls.try_cubic_first = 1;                                   // solver.cpp:248
   la.ls.use_backtracking = o.use_backtracking_linesearch;      // solver.cpp:417
   const dim3 gb((h->batch + 255) / 256), bb(256);
-  int counters[2];
+  int counters[3];
   auto read_counters = [&]() -> int {
     HIP_TRY(hipMemcpyAsync(counters, h->i_counters, sizeof(counters), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1441,9 +1454,11 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
   int total_merit_launches = 0, sweeps = 0;
   struct MaskGuard {   // the backward sweep skips problems that have stopped, only inside this loop
     altro_hip_batch* h;
-    ~MaskGuard() { h->bwd_active = nullptr; }
+    ~MaskGuard() { h->bwd_active = nullptr; h->bwd_reg = nullptr; }
   } mask_guard{h};
   h->bwd_active = h->i_active;
+  h->bwd_reg = reg_on ? h->i_reg : nullptr;
+  int total_reg_retries = 0;
   for (int iter = 0; iter < o.iterations_max; ++iter) {
     la.iter = iter;
     hipLaunchKernelGGL(ilqr_mark_running_kernel, gb, bb, 0, h->stream, la);
@@ -1454,6 +1469,16 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
     rc = launch_backward(h, 0.0);                               // BackwardPass (reg = 0, solver.cpp:363)
     if (rc) return rc;
     h->backward_done = true;
+    for (int attempt = 0; attempt < o.reg_retry_max; ++attempt) {   // extension: repeat failed problems with more reg
+      if ((rc = zero_counter(2))) return rc;
+      hipLaunchKernelGGL(ilqr_reg_retry_kernel, gb, bb, 0, h->stream, la);
+      if ((rc = read_counters())) return rc;
+      if (counters[2] == 0) break;
+      total_reg_retries += counters[2];
+      rc = launch_backward(h, 0.0);
+      if (rc) return rc;
+    }
+    if (o.reg_retry_max > 0) hipLaunchKernelGGL(ilqr_mark_running_kernel, gb, bb, 0, h->stream, la);
     // ForwardPass: phi(0), then the line search (solver.cpp:237-271)
     rc = ilqr_run(h, IK_MERIT, true, true, 1, 0.0);
     if (rc) return rc;
@@ -1501,6 +1526,7 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
       results[b].primal_feasibility = pr[b].feasibility;
       results[b].penalty = pr[b].rho;
       results[b].dual_updates = pr[b].n_dual_updates;
+      results[b].reg_retries = pr[b].reg_retries;
     }
   }
   h->last_sweeps = sweeps;
@@ -1518,6 +1544,11 @@ void altro_hip_default_solve_options(altro_hip_solve_options* o) {
   o->penalty_initial = 1.0;
   o->penalty_scaling = 10.0;
   o->penalty_max = 1e8;
+  o->reg_initial = 0.0;     // the reference: reg = 0, failures ignored (solver.cpp:363, :449)
+  o->reg_retry_max = 0;
+  o->reg_scale = 10.0;
+  o->reg_min = 1e-6;
+  o->reg_max = 1e8;
 }
 int altro_hip_last_solve_counts(const altro_hip_batch* h, int* sweeps, int* merit_launches) {
   if (!h) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "null handle");

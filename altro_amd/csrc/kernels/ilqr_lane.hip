@@ -44,6 +44,7 @@ struct IlqrProb {       // per-problem control state of the batched solve
   // outer update has to do after this sweep (0 nothing, 1 duals, 2 duals + penalty)
   double rho, rho_est, feasibility;
   int dual, n_dual_updates;
+  int reg_retries;      // extension: backward passes repeated with a larger reg
 };
 
 template <typename T>
@@ -500,6 +501,10 @@ struct IlqrLoopArgs {
   double tol_stationarity, tol_meritfun_gradient, tol_primal_feasibility;
   double penalty_initial, penalty_scaling, penalty_max;
   int al_enabled;
+  // regularisation retry (extension beyond the reference, which keeps reg = 0 and ignores failures)
+  double* reg;          // [batch]
+  const int* bwd_status;  // [batch] -1 or the failing knot point of the last backward pass
+  double reg_initial, reg_scale, reg_min, reg_max;
   LsOptions ls;
 };
 
@@ -509,7 +514,8 @@ __global__ void ilqr_loop_init_kernel(IlqrLoopArgs a) {
   IlqrProb& p = a.prob[b];
   p.running = 1; p.iterations = 0; p.status = 1; p.ls_failed = 0; p.evaluating = 0;
   p.alpha = 0.0; p.stationarity = 0.0; p.ls_iters = 0;
-  p.feasibility = 0.0; p.dual = 0; p.n_dual_updates = 0;
+  p.feasibility = 0.0; p.dual = 0; p.n_dual_updates = 0; p.reg_retries = 0;
+  a.reg[b] = a.reg_initial;
   p.rho_est = p.rho;   // the initial gradient is formed with the penalty left by Initialize / the last solve
   a.active[b] = 1;
   a.alpha[b] = 0.0;
@@ -595,6 +601,28 @@ __global__ void ilqr_finish_iter_kernel(IlqrLoopArgs a) {
   else p.dual = 0;
   a.active[b] = p.running;
   if (p.running) atomicAdd(&a.counters[1], 1);
+}
+
+// Regularisation retry -- an EXTENSION: the reference passes reg = 0 and ignores a failed factorisation
+// (tvlqr.cpp:159-164, solver.cpp:363, :449).  After a backward pass, every running problem whose Cholesky
+// failed gets reg <- max(reg * scale, reg_min) and is marked for another backward pass (counters[2] counts
+// them); a problem that succeeded relaxes reg <- max(reg / scale, reg_initial) for its next sweep.
+__global__ void ilqr_reg_retry_kernel(IlqrLoopArgs a) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.batch) return;
+  IlqrProb& p = a.prob[b];
+  const bool was_active = a.active[b] != 0;
+  int again = 0;
+  if (p.running && was_active) {
+    if (a.bwd_status[b] != -1) {
+      const double r = fmax(a.reg[b] * a.reg_scale, a.reg_min);
+      if (r <= a.reg_max) { a.reg[b] = r; again = 1; ++p.reg_retries; }
+    } else {
+      a.reg[b] = fmax(a.reg[b] / a.reg_scale, a.reg_initial);
+    }
+  }
+  a.active[b] = again;
+  if (again) atomicAdd(&a.counters[2], 1);
 }
 
 // SetPenalty (solver.cpp:429) after the initial gradient

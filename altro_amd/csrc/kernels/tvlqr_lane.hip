@@ -46,6 +46,7 @@ struct LaneArgs {
   int batch;
   T reg;
   const int* active;   // optional per-problem mask (the batched solver skips problems that have stopped)
+  const double* reg_pp;  // optional per-problem regularisation (overrides reg; the solver's retry schedule)
 };
 
 // Row access for the SoA layout through buffer instructions: a wave-uniform base (the record of knot point
@@ -329,6 +330,7 @@ __global__ __launch_bounds__(64) void lane_backward_kernel(LaneArgs<T> a) {
   }
   T dv0 = T(0), dv1 = T(0);
   int fail_k = -1;
+  const T reg = a.reg_pp ? (T)a.reg_pp[b] : a.reg;
   // ping-pong: the record of knot point k - 1 is requested before knot point k is computed (addresses do
   // not depend on the recursion).  (6,3) has no registers left for a second record.
   constexpr bool kPrefetch = D::E_IN <= 64;
@@ -343,16 +345,16 @@ __global__ __launch_bounds__(64) void lane_backward_kernel(LaneArgs<T> a) {
     load(r0, k);
     for (; k >= 1; k -= 2) {
       load(r1, k - 1);
-      lane_backward_step<n, m, T>(r0, LaneBuf(pout + (int64_t)k * D::E_OUT * B), lane, rowB, a.reg, k, P, p, dv0, dv1, fail_k);
+      lane_backward_step<n, m, T>(r0, LaneBuf(pout + (int64_t)k * D::E_OUT * B), lane, rowB, reg, k, P, p, dv0, dv1, fail_k);
       load(r0, k >= 2 ? k - 2 : 0);
-      lane_backward_step<n, m, T>(r1, LaneBuf(pout + (int64_t)(k - 1) * D::E_OUT * B), lane, rowB, a.reg, k - 1, P, p, dv0, dv1, fail_k);
+      lane_backward_step<n, m, T>(r1, LaneBuf(pout + (int64_t)(k - 1) * D::E_OUT * B), lane, rowB, reg, k - 1, P, p, dv0, dv1, fail_k);
     }
     if (k == 0)
-      lane_backward_step<n, m, T>(r0, LaneBuf(pout), lane, rowB, a.reg, 0, P, p, dv0, dv1, fail_k);
+      lane_backward_step<n, m, T>(r0, LaneBuf(pout), lane, rowB, reg, 0, P, p, dv0, dv1, fail_k);
   } else {
     for (int k = N - 1; k >= 0; --k) {
       load(r0, k);
-      lane_backward_step<n, m, T>(r0, LaneBuf(pout + (int64_t)k * D::E_OUT * B), lane, rowB, a.reg, k, P, p, dv0, dv1, fail_k);
+      lane_backward_step<n, m, T>(r0, LaneBuf(pout + (int64_t)k * D::E_OUT * B), lane, rowB, reg, k, P, p, dv0, dv1, fail_k);
     }
   }
   a.status[b] = fail_k;

@@ -206,6 +206,14 @@ typedef struct altro_hip_solve_options { /* AltroOptions, solver_options.hpp:16-
   double penalty_initial; /* solver_options.hpp:27-29; used when constraint blocks exist              */
   double penalty_scaling;
   double penalty_max;
+  /* EXTENSION beyond the reference: the reference calls the backward pass with
+   * reg = 0 and ignores a failed Cholesky (tvlqr.cpp:159-164, solver.cpp:363, :449).  With reg_retry_max > 0
+   * a problem whose backward pass fails repeats it with reg <- max(reg * reg_scale, reg_min) (at most
+   * reg_retry_max times per sweep, never above reg_max) and relaxes reg by reg_scale after a success.
+   * Defaults (0, 0) reproduce the reference.                                                              */
+  double reg_initial;
+  int reg_retry_max;
+  double reg_scale, reg_min, reg_max;
 } altro_hip_solve_options;
 typedef struct altro_hip_solve_result { /* AltroStats per problem, solver_stats.hpp:14-25 */
   int status;     /* SolveStatus: 0 Success, 1 Unsolved, 2 MaxIterations (typedefs.hpp:19-27)        */
@@ -216,6 +224,7 @@ typedef struct altro_hip_solve_result { /* AltroStats per problem, solver_stats.
   double primal_feasibility; /* AltroStats::primal_feasibility (solver.cpp:508)                      */
   double penalty;            /* the constraints' penalty when the problem stopped                     */
   int dual_updates;          /* outer (dual) updates taken                                            */
+  int reg_retries;           /* extension: backward passes repeated with a larger regularisation      */
 } altro_hip_solve_result;
 void altro_hip_default_solve_options(altro_hip_solve_options* opts);
 /* SolverImpl::Solve (solver.cpp:414-511) for the whole batch; results [batch] (may be NULL).         */

@@ -156,3 +156,42 @@ def test_constraint_argument_errors(kats):
     bt.clear_constraints()
     res = bt.ilqr_solve(iterations_max=5)
     assert (res["status"] == 0).all()
+
+
+def test_regularisation_retry_extension(kats):
+    """SURVEY.md section 8 row f4 (an extension, labelled as such): the reference keeps reg = 0 and ignores a
+    failed Cholesky (tvlqr.cpp:159-164, solver.cpp:363, :449).  Default options reproduce that; with
+    reg_retry_max > 0 the failed problems repeat the backward pass with a growing reg until it succeeds."""
+    kat = kats["double_integrator_constrained"]
+    N = kat["N"]; n, m = 4, 2
+    h = np.float32(np.float32(kat["tf"]) / np.float32(N))
+    batch = 66
+    x0s = np.tile([1.0, 2.0, 0.0, 0.0], (batch, 1)) + 0.01 * np.arange(batch)[:, None]
+
+    def make(Rval):
+        bt = altro_amd.Batch(N, n, m, batch)
+        bt.set_model(altro_amd.MODEL_DOUBLE_INTEGRATOR, h)
+        Qd = np.ones(n)
+        Rd = np.full((1, m), Rval)
+        bt.set_tracking_cost(np.stack([Qd, Qd]), Rd, np.zeros((2, n)), np.zeros((1, m)), k_stride_zero=True, batch_stride_zero=True)
+        bt.set_initial_state(x0s)
+        bt.set_input_guess(np.zeros((1, 1, m)), k_stride_zero=True, batch_stride_zero=True)
+        return bt
+    # Quu = R + B'PB is indefinite with R = -0.5: the reference's behaviour is a failed backward pass that is ignored
+    bt = make(-0.5)
+    res = bt.ilqr_solve(iterations_max=2)
+    assert (res["reg_retries"] == 0).all()
+    assert (bt.get("status") != -1).all()
+    # extension: retry with reg 0.01 -> 0.1 -> 1.0
+    bt = make(-0.5)
+    res = bt.ilqr_solve(iterations_max=2, reg_retry_max=5, reg_min=0.01, reg_scale=10.0)
+    assert (res["reg_retries"] >= 3).all(), res["reg_retries"]
+    assert (bt.get("status") == -1).all()
+    assert np.isfinite(bt.get("K")).all()
+    # a well-posed problem never retries and gives the same answer as without the option
+    a = make(0.01); ra = a.ilqr_solve(iterations_max=5)
+    b = make(0.01); rb = b.ilqr_solve(iterations_max=5, reg_retry_max=5, reg_min=0.01)
+    assert (rb["reg_retries"] == 0).all()
+    assert np.array_equal(a.get("x"), b.get("x")) and np.array_equal(ra["iterations"], rb["iterations"])
+    with pytest.raises(altro_amd.AltroHipError):
+        make(0.01).ilqr_solve(reg_retry_max=2, reg_scale=0.5)
