@@ -29,17 +29,34 @@ def stale():
 
 
 def build(force=False, verbose=False):
+    """One object per translation unit, compiled in parallel (the kernel instantiations of the two element types
+    and the TVLQR plans are separate units), then one link."""
     if not (force or stale()):
         return LIB
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    objdir = os.path.join(HERE, "lib", "obj")
+    os.makedirs(objdir, exist_ok=True)
     units = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
     host = os.path.join(CSRC, "host")
     units += [os.path.join(host, f) for f in sorted(os.listdir(host)) if f.endswith(".cpp")]
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wno-unused-result", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + units + ["-o", LIB]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result",
+             "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+
+    def compile_one(src):
+        obj = os.path.join(objdir, os.path.splitext(os.path.basename(src))[0] + ".o")
+        cmd = [hipcc] + flags + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(units), os.cpu_count() or 4)) as ex:
+        objs = list(ex.map(compile_one, units))
+    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-o", LIB]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     return LIB
 

@@ -17,7 +17,7 @@
 #include "kernels/pack.hip"
 #include "kernels/tvlqr_generic.hip"
 #include "kernels/tvlqr_lane.hip"
-#include "kernels/ilqr_lane.hip"
+#include "kernels/ilqr_types.h"
 #include "linesearch_sm.h"
 #include "kernels/tvlqr_mfma16.hip"
 
@@ -411,17 +411,6 @@ int lane_get_any(altro_hip_batch* h, int what, double* dst) {
 
 
 // ---- iLQR loop (plan LANE) ---------------------------------------------------------------------------
-#define ILQR_MODELS(X)                                                                      \
-  X(MODEL_PENDULUM, 2, 1) X(MODEL_BICYCLE, 4, 2) X(MODEL_DOUBLE_INTEGRATOR, 2, 1)           \
-  X(MODEL_DOUBLE_INTEGRATOR, 4, 2) X(MODEL_DOUBLE_INTEGRATOR, 6, 3)
-bool ilqr_supported(int kind, int n, int m) {
-#define X(K_, N_, M_) if (kind == K_ && n == N_ && m == M_) return true;
-  ILQR_MODELS(X)
-#undef X
-  return false;
-}
-enum IlqrKernel { IK_ROLLOUT, IK_ACCEPT, IK_EXPAND, IK_MERIT, IK_STATIONARITY, IK_DUAL, IK_SHIFT };
-
 // (re)build the device tables of the constraint blocks; duals restart from zero when the structure changes
 template <typename T>
 int al_upload_typed(altro_hip_batch* h) {
@@ -490,29 +479,9 @@ IlqrArgs<T> ilqr_args(altro_hip_batch* h, bool use_alpha, bool use_active, int w
 
 template <typename T>
 int ilqr_launch(altro_hip_batch* h, int which, IlqrArgs<T> a) {
-  const dim3 lanes((h->batch + 63) / 64), b64(64);
-  const int64_t total = (int64_t)h->batch * (h->N + 1);
-  const dim3 flat(grid_for(total)), b256(256);
-  const dim3 flat64((unsigned)std::min<int64_t>((total + 63) / 64, 1 << 20));
-  bool done = false;
-#define X(K_, N_, M_)                                                                                    \
-  if (!done && h->model.kind == K_ && h->n == N_ && h->m == M_) {                                        \
-    done = true;                                                                                         \
-    switch (which) {                                                                                     \
-      case IK_ROLLOUT: hipLaunchKernelGGL((ilqr_rollout_kernel<K_, N_, M_, T>), lanes, b64, 0, h->stream, a); break; \
-      case IK_ACCEPT: hipLaunchKernelGGL((ilqr_accept_kernel<N_, M_, T>), flat, b256, 0, h->stream, a); break;       \
-      case IK_EXPAND: hipLaunchKernelGGL((ilqr_expand_kernel<K_, N_, M_, T>), flat64, b64, 0, h->stream, a); break;  \
-      case IK_MERIT: hipLaunchKernelGGL((ilqr_merit_kernel<K_, N_, M_, T>), lanes, b64, 0, h->stream, a); break;     \
-      case IK_DUAL: hipLaunchKernelGGL((ilqr_dual_update_kernel<N_, M_, T>), flat, b256, 0, h->stream, a); break;    \
-      case IK_SHIFT: hipLaunchKernelGGL((ilqr_shift_kernel<N_, M_, T>), dim3(grid_for((int64_t)h->batch * (N_ + M_))), b256, 0, h->stream, a); break; \
-      default: hipLaunchKernelGGL((ilqr_stationarity_kernel<N_, M_, T>), lanes, b64, 0, h->stream, a); break;        \
-    }                                                                                                    \
-  }
-  ILQR_MODELS(X)
-#undef X
-  if (!done) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "no device model for (kind, n, m) = (%d, %d, %d)", h->model.kind, h->n, h->m);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "iLQR kernel launch: %s", hipGetErrorString(e));
+  const int rc = ilqr_launch_kernel<T>(h->stream, which, h->model.kind, h->n, h->m, a);
+  if (rc == 1) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "no device model for (kind, n, m) = (%d, %d, %d)", h->model.kind, h->n, h->m);
+  if (rc) return fail(ALTRO_HIP_ERR_HIP, "iLQR kernel launch failed");
   return 0;
 }
 int ilqr_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int want_deriv, double alpha_const,
@@ -1431,7 +1400,6 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
   la.ls = ls_default_options();
   la.ls.try_cubic_first = 1;                                   // solver.cpp:248
   la.ls.use_backtracking = o.use_backtracking_linesearch;      // solver.cpp:417
-  const dim3 gb((h->batch + 255) / 256), bb(256);
   int counters[3];
   auto read_counters = [&]() -> int {
     HIP_TRY(hipMemcpyAsync(counters, h->i_counters, sizeof(counters), hipMemcpyDeviceToHost, h->stream));
@@ -1443,14 +1411,14 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
     return 0;
   };
   // initial rollout, make it the nominal trajectory, expand everything (solver.cpp:420-434)
-  hipLaunchKernelGGL(ilqr_loop_init_kernel, gb, bb, 0, h->stream, la);
+  if (ilqr_launch_loop(h->stream, ILK_LOOP_INIT, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
   rc = ilqr_run(h, IK_ROLLOUT, false, false, 0, 0.0);
   if (!rc) rc = ilqr_run(h, IK_ACCEPT, false, false, 0, 0.0);
   // without constraints the cost Hessian is constant and is written once, here; with them the gradient is
   // formed with the penalty the constraints carry so far and SetPenalty comes after it (solver.cpp:424-430)
   if (!rc) rc = ilqr_run(h, IK_EXPAND, false, false, 0, 0.0, al ? EXPAND_GRADIENT : (EXPAND_GRADIENT | EXPAND_HESSIAN));
   if (rc) return rc;
-  if (al) hipLaunchKernelGGL(ilqr_set_penalty_kernel, gb, bb, 0, h->stream, la);
+  if (al && ilqr_launch_loop(h->stream, ILK_SET_PENALTY, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
   int total_merit_launches = 0, sweeps = 0;
   struct MaskGuard {   // the backward sweep skips problems that have stopped, only inside this loop
     altro_hip_batch* h;
@@ -1461,7 +1429,7 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
   int total_reg_retries = 0;
   for (int iter = 0; iter < o.iterations_max; ++iter) {
     la.iter = iter;
-    hipLaunchKernelGGL(ilqr_mark_running_kernel, gb, bb, 0, h->stream, la);
+    if (ilqr_launch_loop(h->stream, ILK_MARK_RUNNING, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
     if (al) {                                                   // CalcExpansions: cost Hessians (solver.cpp:448)
       rc = ilqr_run(h, IK_EXPAND, false, true, 0, 0.0, EXPAND_HESSIAN);
       if (rc) return rc;
@@ -1471,20 +1439,20 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
     h->backward_done = true;
     for (int attempt = 0; attempt < o.reg_retry_max; ++attempt) {   // extension: repeat failed problems with more reg
       if ((rc = zero_counter(2))) return rc;
-      hipLaunchKernelGGL(ilqr_reg_retry_kernel, gb, bb, 0, h->stream, la);
+      if (ilqr_launch_loop(h->stream, ILK_REG_RETRY, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
       if ((rc = read_counters())) return rc;
       if (counters[2] == 0) break;
       total_reg_retries += counters[2];
       rc = launch_backward(h, 0.0);
       if (rc) return rc;
     }
-    if (o.reg_retry_max > 0) hipLaunchKernelGGL(ilqr_mark_running_kernel, gb, bb, 0, h->stream, la);
+    if (o.reg_retry_max > 0 && ilqr_launch_loop(h->stream, ILK_MARK_RUNNING, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
     // ForwardPass: phi(0), then the line search (solver.cpp:237-271)
     rc = ilqr_run(h, IK_MERIT, true, true, 1, 0.0);
     if (rc) return rc;
     ++total_merit_launches;
     if ((rc = zero_counter(0))) return rc;
-    hipLaunchKernelGGL(ilqr_ls_begin_kernel, gb, bb, 0, h->stream, la);
+    if (ilqr_launch_loop(h->stream, ILK_LS_BEGIN, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
     if ((rc = read_counters())) return rc;
     int guard = 0;
     while (counters[0] > 0 && guard++ < 64) {
@@ -1492,20 +1460,20 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
       if (rc) return rc;
       ++total_merit_launches;
       if ((rc = zero_counter(0))) return rc;
-      hipLaunchKernelGGL(ilqr_ls_feed_kernel, gb, bb, 0, h->stream, la);
+      if (ilqr_launch_loop(h->stream, ILK_LS_FEED, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
       if ((rc = read_counters())) return rc;
     }
     // convergence criteria on the accepted candidate, then make it the nominal (solver.cpp:459-469)
-    hipLaunchKernelGGL(ilqr_mark_running_kernel, gb, bb, 0, h->stream, la);
+    if (ilqr_launch_loop(h->stream, ILK_MARK_RUNNING, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
     rc = ilqr_run(h, IK_STATIONARITY, false, true, 0, 0.0);
     if (!rc) rc = ilqr_run(h, IK_ACCEPT, false, true, 0, 0.0);
     if (rc) return rc;
     if ((rc = zero_counter(1))) return rc;
-    hipLaunchKernelGGL(ilqr_finish_iter_kernel, gb, bb, 0, h->stream, la);
+    if (ilqr_launch_loop(h->stream, ILK_FINISH_ITER, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
     if (al) {   // DualUpdate, PenaltyUpdate, refreshed gradients for the problems that asked (solver.cpp:470-489)
       rc = ilqr_run(h, IK_DUAL, false, false, 0, 0.0);
       if (rc) return rc;
-      hipLaunchKernelGGL(ilqr_penalty_update_kernel, gb, bb, 0, h->stream, la);
+      if (ilqr_launch_loop(h->stream, ILK_PENALTY_UPDATE, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
       rc = ilqr_run(h, IK_EXPAND, false, true, 0, 0.0, EXPAND_GRADIENT);
       if (rc) return rc;
     }

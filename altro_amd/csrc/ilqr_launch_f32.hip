@@ -1,0 +1,42 @@
+// Kernel instantiations of the batched iLQR loop for element type float (see kernels/ilqr_types.h).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "kernels/ilqr_lane.hip"
+
+namespace altro_hip {
+
+#define ILQR_MODELS(X)                                                                      \
+  X(MODEL_PENDULUM, 2, 1) X(MODEL_BICYCLE, 4, 2) X(MODEL_DOUBLE_INTEGRATOR, 2, 1)           \
+  X(MODEL_DOUBLE_INTEGRATOR, 4, 2) X(MODEL_DOUBLE_INTEGRATOR, 6, 3)
+
+template <>
+int ilqr_launch_kernel<float>(hipStream_t stream, int which, int kind, int n, int m, const IlqrArgs<float>& a) {
+  using T = float;
+  const dim3 lanes((a.batch + 63) / 64), b64(64), b256(256);
+  const int64_t total = (int64_t)a.batch * (a.N + 1);
+  const dim3 flat((unsigned)std::min<int64_t>((total + 255) / 256, 1 << 20));
+  const dim3 flat64((unsigned)std::min<int64_t>((total + 63) / 64, 1 << 20));
+  bool done = false;
+#define X(K_, N_, M_)                                                                                         \
+  if (!done && kind == K_ && n == N_ && m == M_) {                                                            \
+    done = true;                                                                                              \
+    const dim3 shift((unsigned)std::min<int64_t>(((int64_t)a.batch * (N_ + M_) + 255) / 256, 1 << 20));       \
+    switch (which) {                                                                                          \
+      case IK_ROLLOUT: hipLaunchKernelGGL((ilqr_rollout_kernel<K_, N_, M_, T>), lanes, b64, 0, stream, a); break;   \
+      case IK_ACCEPT: hipLaunchKernelGGL((ilqr_accept_kernel<N_, M_, T>), flat, b256, 0, stream, a); break;         \
+      case IK_EXPAND: hipLaunchKernelGGL((ilqr_expand_kernel<K_, N_, M_, T>), flat64, b64, 0, stream, a); break;    \
+      case IK_MERIT: hipLaunchKernelGGL((ilqr_merit_kernel<K_, N_, M_, T>), lanes, b64, 0, stream, a); break;       \
+      case IK_DUAL: hipLaunchKernelGGL((ilqr_dual_update_kernel<N_, M_, T>), flat, b256, 0, stream, a); break;      \
+      case IK_SHIFT: hipLaunchKernelGGL((ilqr_shift_kernel<N_, M_, T>), shift, b256, 0, stream, a); break;          \
+      default: hipLaunchKernelGGL((ilqr_stationarity_kernel<N_, M_, T>), lanes, b64, 0, stream, a); break;          \
+    }                                                                                                         \
+  }
+  ILQR_MODELS(X)
+#undef X
+  if (!done) return 1;
+  return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+}  // namespace altro_hip

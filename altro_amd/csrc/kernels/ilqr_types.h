@@ -1,0 +1,85 @@
+// ilqr_types.h -- plain argument / state types of the batched iLQR loop (shared by the kernels and by the host
+// code of the C ABI).  No kernels here: this header may be included by any translation unit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../linesearch_sm.h"
+#include "../models.h"
+#include "al_types.h"
+
+namespace altro_hip {
+
+struct IlqrProb {       // per-problem control state of the batched solve
+  int running;          // still iterating
+  int iterations;       // AltroStats::iterations (solver.cpp:506)
+  int status;           // SolveStatus: 0 Success, 1 Unsolved, 2 MaxIterations
+  int ls_failed;
+  double phi0, dphi0, alpha, stationarity;
+  int ls_iters, evaluating;
+  LsState ls;
+  // augmented Lagrangian: rho = the constraints' penalty (KnotPointData::rho_, identical for every block
+  // of a problem), rho_est = the penalty the cached projected duals were formed with, dual = what the
+  // outer update has to do after this sweep (0 nothing, 1 duals, 2 duals + penalty)
+  double rho, rho_est, feasibility;
+  int dual, n_dual_updates;
+  int reg_retries;      // extension: backward passes repeated with a larger reg
+};
+
+template <typename T>
+struct IlqrArgs {
+  T* in;
+  T* term;
+  const T* out;
+  const T* outn;
+  T* nom;
+  T* cand;
+  const T* cost;
+  const T* x0;          // [n][batch]
+  const double* alpha;  // per problem, or nullptr -> alpha_const
+  const int* active;    // per problem, or nullptr -> all
+  double* phi;
+  double* dphi;
+  IlqrProb* prob;
+  ModelParams mp;
+  int N, batch;
+  int want_derivative;
+  double alpha_const;
+  AlTable<T> al;
+  int mode;             // expand kernel: bit 0 = dynamics Jacobians + cost gradient, bit 1 = cost Hessian
+};
+enum { EXPAND_GRADIENT = 1, EXPAND_HESSIAN = 2 };
+
+struct IlqrLoopArgs {
+  IlqrProb* prob;
+  double* alpha;      // [batch] next trial step per problem
+  int* active;        // [batch] 1 = problem takes part in the next merit evaluation
+  const double* phi;
+  const double* dphi;
+  int* counters;      // [0] = problems that still need a merit evaluation, [1] = problems still running
+  int batch;
+  int iter;
+  int iterations_max;
+  double tol_stationarity, tol_meritfun_gradient, tol_primal_feasibility;
+  double penalty_initial, penalty_scaling, penalty_max;
+  int al_enabled;
+  // regularisation retry (extension beyond the reference, which keeps reg = 0 and ignores failures)
+  double* reg;          // [batch]
+  const int* bwd_status;  // [batch] -1 or the failing knot point of the last backward pass
+  double reg_initial, reg_scale, reg_min, reg_max;
+  LsOptions ls;
+};
+
+enum IlqrKernel { IK_ROLLOUT, IK_ACCEPT, IK_EXPAND, IK_MERIT, IK_STATIONARITY, IK_DUAL, IK_SHIFT };
+enum IlqrLoopKernel { ILK_LOOP_INIT, ILK_LS_BEGIN, ILK_LS_FEED, ILK_FINISH_ITER, ILK_MARK_RUNNING, ILK_SET_PENALTY,
+                      ILK_PENALTY_UPDATE, ILK_REG_RETRY };
+
+// Launchers (ilqr_launch_f64.hip / ilqr_launch_f32.hip hold the kernel instantiations, so that the kernels of
+// the two element types compile in parallel with the rest of the library).  Return 0, 1 = no device model for
+// (kind, n, m), 2 = launch error (hipGetLastError has the reason).
+bool ilqr_supported(int kind, int n, int m);
+template <typename T>
+int ilqr_launch_kernel(hipStream_t stream, int which, int kind, int n, int m, const IlqrArgs<T>& a);
+int ilqr_launch_loop(hipStream_t stream, int which, const IlqrLoopArgs& a);
+
+}  // namespace altro_hip
