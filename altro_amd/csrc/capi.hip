@@ -20,6 +20,7 @@
 #include "kernels/ilqr_types.h"
 #include "linesearch_sm.h"
 #include "kernels/tvlqr_mfma16.hip"
+#include "kernels/tvlqr_mfma16_f32.hip"
 
 using namespace altro_hip;
 
@@ -534,14 +535,8 @@ void mfma16_launch_backward(altro_hip_batch* h, double reg, bool sq) {
 
 template <typename S>
 void mfma16_launch_forward(altro_hip_batch* h, const Mfma16Args<S>& a) {
-  static const int depth = [] { const char* e = getenv("ALTRO_HIP_FWD_DEPTH"); return e ? atoi(e) : 3; }();
-  const dim3 grid(h->batch), block(64);
-  switch (depth) {
-    case 1: hipLaunchKernelGGL((mfma16_forward_kernel<S, 1>), grid, block, 0, h->stream, a); break;
-    case 2: hipLaunchKernelGGL((mfma16_forward_kernel<S, 2>), grid, block, 0, h->stream, a); break;
-    case 4: hipLaunchKernelGGL((mfma16_forward_kernel<S, 4>), grid, block, 0, h->stream, a); break;
-    default: hipLaunchKernelGGL((mfma16_forward_kernel<S, 3>), grid, block, 0, h->stream, a); break;
-  }
+  // register-ring depth 3: depths 1..4 were measured, 3 is the knee
+  hipLaunchKernelGGL((mfma16_forward_kernel<S, 3>), dim3(h->batch), dim3(64), 0, h->stream, a);
 }
 
 int launch_backward(altro_hip_batch* h, double reg) {
@@ -549,7 +544,12 @@ int launch_backward(altro_hip_batch* h, double reg) {
   if (h->plan == ALTRO_HIP_PLAN_MFMA16) {
     const bool sq = (h->flags & ALTRO_HIP_STORE_QBLOCKS) != 0;
     if (h->dtype == ALTRO_HIP_F64) mfma16_launch_backward<double>(h, reg, sq);
-    else mfma16_launch_backward<float>(h, reg, sq);
+    else if (sq || !(h->flags & ALTRO_HIP_F32_PURE)) mfma16_launch_backward<float>(h, reg, sq);   // fp32 storage, fp64 tiles
+    else {   // opt-in: pure fp32 on v_mfma_f32_16x16x4_f32
+      auto a = mfma16_args<float>(h, reg);
+      if (h->has_f) hipLaunchKernelGGL((mfma16_backward_f32_kernel<true, 3>), dim3(h->batch), dim3(64), 0, h->stream, a);
+      else hipLaunchKernelGGL((mfma16_backward_f32_kernel<false, 3>), dim3(h->batch), dim3(64), 0, h->stream, a);
+    }
   } else if (h->plan == ALTRO_HIP_PLAN_LANE) {
     return h->dtype == ALTRO_HIP_F64 ? lane_launch<double>(h, true, reg) : lane_launch<float>(h, true, reg);
   } else if (h->dtype == ALTRO_HIP_F64) {
@@ -658,15 +658,9 @@ int altro_hip_batch_create(altro_hip_batch** out, int N, int n, int m, int batch
     ALLOC(h->m_in, B * N * MF_DYN * E);
     ALLOC(h->m_cin, B * N * MF_COST * E);
     {
-      // default: knot-point-major slabs [k][b][record]; ALTRO_HIP_LAYOUT=bk selects problem-major
-      const char* lay = getenv("ALTRO_HIP_LAYOUT");
-      const bool kb = !(lay && lay[0] == 'b');
+      // knot-point-major slabs [k][b][record] (problem-major [b][k] measured the same)
       const int64_t Bq = batch;
-      h->m_st = kb ? Mfma16Strides{MF_DYN, Bq * MF_DYN, MF_OUT, Bq * MF_OUT, 28, Bq * 28, MF_COST, Bq * MF_COST}
-                   : Mfma16Strides{(int64_t)N * MF_DYN, MF_DYN, (int64_t)N * MF_OUT, MF_OUT, (int64_t)(N + 1) * 28, 28,
-                                   (int64_t)N * MF_COST, MF_COST};
-      if (lay && lay[0] == 'x') { h->m_st.xuy_bs = (int64_t)(N + 1) * 28; h->m_st.xuy_ks = 28; }   // experiment: problem-major XUY
-      if (lay && lay[0] == 's') { h->m_st.in_bs = h->m_st.in_ks = h->m_st.cin_bs = h->m_st.cin_ks = 0; }   // experiment
+      h->m_st = Mfma16Strides{MF_DYN, Bq * MF_DYN, MF_OUT, Bq * MF_OUT, 28, Bq * 28, MF_COST, Bq * MF_COST};
     }
     ALLOC(h->m_term, B * MF_TERM * E);
     ALLOC(h->m_out, B * N * MF_OUT * E);

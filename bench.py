@@ -46,6 +46,9 @@ def parse():
                          "(pendulum n=2 m=1 N=100 batch=8192), c3 = configs[3] (bicycle n=4 m=2 N=50 batch=65536 "
                          "per node, with the steering bound), c4 = configs[4] (random LTV n=12 m=4 N=512 "
                          "batch=16384, fp32 storage)")
+    ap.add_argument("--c4-pure", action="store_true",
+                    help="config c4: backward sweep in pure fp32 (ALTRO_HIP_F32_PURE, v_mfma_f32_16x16x4_f32) "
+                         "instead of fp32 storage with fp64 tile arithmetic")
     return ap.parse_args()
 
 
@@ -195,7 +198,8 @@ def main():
     first, _ = _shard.shard_range(batch * world, rank, world)   # this rank's slice of the global batch
     x0 = 2.0 * problems.uniform01((batch, n), 21, first * n) - 1.0
 
-    bt = altro_amd.Batch(N, n, m, batch, dtype=altro_amd.F32 if c4 else altro_amd.F64, device=local_rank)
+    bt = altro_amd.Batch(N, n, m, batch, dtype=altro_amd.F32 if c4 else altro_amd.F64, device=local_rank,
+                         flags=altro_amd.F32_PURE if (c4 and args.c4_pure) else 0)
     assert bt.plan == altro_amd.PLAN_MFMA16
     if c4:
         # random time-varying LTV-LQ problems (SURVEY.md 8d "C4"): a seeded pool of 64 distinct problems is
@@ -271,7 +275,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32 storage, f64 tile arithmetic" if c4 else "f64",
+            "dtype": ("f32" if args.c4_pure else "f32 storage, f64 tile arithmetic") if c4 else "f64",
             "data": "synthetic",
             "config": {
                 "workload": ("C4 random LTV TVLQR sweep, fp32 storage (BASELINE.json configs[4])" if c4 else

@@ -83,6 +83,10 @@ typedef enum altro_hip_plan {
 
 /* create flags */
 #define ALTRO_HIP_STORE_QBLOCKS 0x1u /* also write Qxx,Quu,Qux,Qx,Qu (knotpoint_data.hpp:211-215) */
+#define ALTRO_HIP_F32_PURE 0x2u      /* ALTRO_HIP_F32 on plan MFMA16: backward sweep in pure fp32 on
+                                        v_mfma_f32_16x16x4_f32 (cost-to-go carried in fp32: ~5e-4 relative).
+                                        Default for F32 is fp32 storage with fp64 tile arithmetic (2e-5): on
+                                        MI355X both are bound by the same fp32 record traffic */
 
 /* Device dynamics/cost models for the nonlinear forward pass (user std::function callbacks of
  * typedefs.hpp:31-53 cannot run on the device; these are the compiled-in equivalents of the
