@@ -158,3 +158,20 @@ def test_fp32_lane_solver_tracks_fp64():
     ok = r32["status"] == 0
     err = np.abs(b32.get("x")[ok, -1] - b64.get("x")[ok, -1]).max()
     assert err < 1e-2, err
+
+
+@pytest.mark.parametrize("N", [1, 2, 3])
+@pytest.mark.parametrize("name", ["pendulum", "double_integrator"])
+def test_shortest_horizons_solve(name, N):
+    """Horizons shorter than the kernels' record prefetch depth: same path as the oracle."""
+    c = CASES[name]
+    x0s = c["x0"](5)
+    bt = make_hip(c["model"], N, c["n"], c["m"], c["h"], c["Qd"], c["Rd"], c["Qfd"], c["xf"], x0s, c["u0"])
+    res = bt.ilqr_solve(iterations_max=25)
+    x = bt.get("x")
+    for b in [0, 4]:
+        s = make_oracle(c["okind"], N, c["n"], c["m"], c["h"], c["Qd"], c["Rd"], c["Qfd"], c["xf"], x0s[b], c["u0"], c["dim"])
+        s.L.oracle_ilqr_set_options(s.h, 25, 1e-4, 1e-4, 1e-8, 0)
+        status, iters, log = s.solve()
+        assert res["status"][b] == status and res["iterations"][b] == iters
+        np.testing.assert_allclose(x[b], s.get("x"), rtol=1e-9, atol=1e-9)

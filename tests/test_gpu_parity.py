@@ -384,3 +384,24 @@ def test_mfma16_fp32_no_affine_and_failure():
     bt.backward()
     st = bt.get("status")
     assert st[3] == 7 and (np.delete(st, 3) == -1).all()
+
+
+@pytest.mark.parametrize("n,m,plan", [(12, 4, altro_amd.PLAN_MFMA16), (4, 2, altro_amd.PLAN_LANE), (2, 1, altro_amd.PLAN_LANE),
+                                      (6, 3, altro_amd.PLAN_LANE), (3, 1, altro_amd.PLAN_LANE), (5, 2, altro_amd.PLAN_GENERIC),
+                                      (12, 4, altro_amd.PLAN_GENERIC)])
+@pytest.mark.parametrize("N", [1, 2, 3, 5])
+@pytest.mark.parametrize("batch", [1, 65])
+def test_shortest_horizons_and_single_problem(n, m, plan, N, batch):
+    """Edge shapes: horizons shorter than every prefetch / ping-pong depth (N = 1, 2, 3, odd N), a single problem,
+    and a batch one past a wavefront.  reg > 0 rides along."""
+    pr = problems.random_ltv(batch, N, n, m)
+    out = run_hip(pr, altro_amd.PLAN_AUTO if plan != altro_amd.PLAN_GENERIC else plan, reg=1e-3)
+    assert out["bt"].plan == plan
+    ref = run_oracle(pr, reg=1e-3)
+    assert (out["status"] == -1).all()
+    for k in ("K", "d", "P", "p", "x", "u", "y"):
+        if plan == altro_amd.PLAN_MFMA16:
+            assert relerr(out[k], ref[k]) < 1e-11, k
+        else:
+            assert np.array_equal(out[k], ref[k]), k
+    assert relerr(out["delta_V"], ref["dV"]) < 1e-11
