@@ -49,127 +49,114 @@ ALTRO_HD void pendulum_J(const T* x, const T* u, T* J) {
   J[5] = T(1) / mm;
 }
 
+// sin and cos of one argument with a single range reduction on the device
+template <typename T>
+ALTRO_HD void sincos_hd(T a, T* s, T* c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (sizeof(T) == 4) sincosf(a, s, c);
+  else sincos(a, s, c);
+#else
+  *s = sin(a);
+  *c = cos(a);
+#endif
+}
+
+// Trigonometry of the kinematic bicycle (test/test_utils.cpp:134-238) at one point.  The reference's test model
+// calls atan2 / sin / cos / tan on beta = atan2(lr delta, L), delta and theta + beta; on the GPU the iLQR kernels
+// are bound by exactly these fp64 library calls, so they are formed from ONE sincos(theta), ONE sincos(delta) and
+// a square root:  cos(beta) = L / rho, sin(beta) = lr delta / rho, rho = sqrt(L^2 + (lr delta)^2)   (L > 0),
+// sin(theta + beta) and cos(theta + beta) by the addition theorems, tan(delta) = sin / cos.  Same functions of
+// (theta, delta); results differ from the library-call form in the last ulp or two (parity tolerance 1e-10).
+template <typename T>
+struct BicycleTrig {
+  T st, ct;        // sin / cos of the heading of the velocity vector (theta + beta, theta or theta + delta)
+  T sb, cb;        // sin / cos of the side-slip angle beta (frame 0)
+  T sd, cd, td;    // sin / cos / tan of the steering angle
+  T dbeta;         // d beta / d delta (frame 0)
+};
+template <typename T>
+ALTRO_HD BicycleTrig<T> bicycle_trig(const ModelParams& mp, T theta, T delta) {
+  BicycleTrig<T> t;
+  const T L = (T)mp.length, lr = (T)mp.lr;
+  T sth, cth;
+  sincos_hd<T>(theta, &sth, &cth);
+  sincos_hd<T>(delta, &t.sd, &t.cd);
+  t.td = t.sd / t.cd;
+  t.sb = T(0); t.cb = T(1); t.dbeta = T(0);
+  if (mp.frame == 0) {
+    const T by = lr * delta, bx = L;
+    const T r2 = bx * bx + by * by;
+    const T ir = T(1) / sqrt(r2);
+    t.cb = bx * ir;
+    t.sb = by * ir;
+    t.dbeta = bx / r2 * lr;
+    t.st = sth * t.cb + cth * t.sb;
+    t.ct = cth * t.cb - sth * t.sb;
+  } else if (mp.frame == 1) {
+    t.st = sth;
+    t.ct = cth;
+  } else {
+    t.st = sth * t.cd + cth * t.sd;
+    t.ct = cth * t.cd - sth * t.sd;
+  }
+  return t;
+}
+
+template <typename T>
+ALTRO_HD void bicycle_f_from(const ModelParams& mp, const BicycleTrig<T>& t, const T* u, T* xdot) {
+  const T v = u[0], L = (T)mp.length;
+  T omega;
+  if (mp.frame == 0) omega = v * t.cb * t.td / L;
+  else if (mp.frame == 1) omega = v * t.td / L;
+  else omega = v * t.sd / L;
+  xdot[0] = v * t.ct;
+  xdot[1] = v * t.st;
+  xdot[2] = omega;
+  xdot[3] = u[1];
+}
+template <typename T>
+ALTRO_HD void bicycle_J_from(const ModelParams& mp, const BicycleTrig<T>& t, const T* u, T* J) {
+  const T v = u[0], L = (T)mp.length;
+  T domega_ddelta, domega_dv, ds_dde = T(0), dc_dde = T(0);
+  if (mp.frame == 0) {
+    domega_ddelta = v / L * (-t.sb * t.td * t.dbeta + t.cb / (t.cd * t.cd));
+    domega_dv = t.cb * t.td / L;
+    ds_dde = t.ct * t.dbeta;
+    dc_dde = -t.st * t.dbeta;
+  } else if (mp.frame == 1) {
+    domega_ddelta = v / L / (t.cd * t.cd);
+    domega_dv = t.td / L;
+  } else {
+    domega_ddelta = v / L * t.cd;
+    domega_dv = t.sd / L;
+    ds_dde = t.ct;
+    dc_dde = -t.st;
+  }
+  for (int e = 0; e < 24; ++e) J[e] = T(0);
+  J[0 + 2 * 4] = v * -t.st;
+  J[0 + 3 * 4] = v * dc_dde;
+  J[0 + 4 * 4] = t.ct;
+  J[1 + 2 * 4] = v * t.ct;
+  J[1 + 3 * 4] = v * ds_dde;
+  J[1 + 4 * 4] = t.st;
+  J[2 + 3 * 4] = domega_ddelta;
+  J[2 + 4 * 4] = domega_dv;
+  J[3 + 5 * 4] = T(1);
+}
 template <typename T>
 ALTRO_HD void bicycle_f(const ModelParams& mp, const T* x, const T* u, T* xdot) {
-  const T v = u[0], delta_dot = u[1], theta = x[2], delta = x[3];
-  const T L = (T)mp.length, lr = (T)mp.lr;
-  T omega, st, ct;
-  if (mp.frame == 0) {
-    const T beta = atan2(lr * delta, L);
-    omega = v * cos(beta) * tan(delta) / L;
-    st = sin(theta + beta);
-    ct = cos(theta + beta);
-  } else if (mp.frame == 1) {
-    omega = v * tan(delta) / L;
-    st = sin(theta);
-    ct = cos(theta);
-  } else {
-    omega = v * sin(delta) / L;
-    st = sin(theta + delta);
-    ct = cos(theta + delta);
-  }
-  xdot[0] = v * ct;
-  xdot[1] = v * st;
-  xdot[2] = omega;
-  xdot[3] = delta_dot;
+  bicycle_f_from<T>(mp, bicycle_trig<T>(mp, x[2], x[3]), u, xdot);
 }
 template <typename T>
 ALTRO_HD void bicycle_J(const ModelParams& mp, const T* x, const T* u, T* J) {
-  const T v = u[0], theta = x[2], delta = x[3];
-  const T L = (T)mp.length, lr = (T)mp.lr;
-  T dbeta = T(0), domega_ddelta, domega_dv, st, ct, ds_dth, dc_dth, ds_dde = T(0), dc_dde = T(0);
-  if (mp.frame == 0) {
-    const T by = lr * delta, bx = L;
-    const T beta = atan2(by, bx);
-    dbeta = bx / (bx * bx + by * by) * lr;
-    domega_ddelta = v / L * (-sin(beta) * tan(delta) * dbeta + cos(beta) / (cos(delta) * cos(delta)));
-    domega_dv = cos(beta) * tan(delta) / L;
-    st = sin(theta + beta);
-    ct = cos(theta + beta);
-    ds_dth = cos(theta + beta);
-    dc_dth = -sin(theta + beta);
-    ds_dde = cos(theta + beta) * dbeta;
-    dc_dde = -sin(theta + beta) * dbeta;
-  } else if (mp.frame == 1) {
-    domega_ddelta = v / L / (cos(delta) * cos(delta));
-    domega_dv = tan(delta) / L;
-    st = sin(theta);
-    ct = cos(theta);
-    ds_dth = cos(theta);
-    dc_dth = -sin(theta);
-  } else {
-    domega_ddelta = v / L * cos(delta);
-    domega_dv = sin(delta) / L;
-    st = sin(theta + delta);
-    ct = cos(theta + delta);
-    ds_dth = cos(theta + delta);
-    dc_dth = -sin(theta + delta);
-    ds_dde = ds_dth;
-    dc_dde = dc_dth;
-  }
-  for (int e = 0; e < 24; ++e) J[e] = T(0);
-  J[0 + 2 * 4] = v * dc_dth;
-  J[0 + 3 * 4] = v * dc_dde;
-  J[0 + 4 * 4] = ct;
-  J[1 + 2 * 4] = v * ds_dth;
-  J[1 + 3 * 4] = v * ds_dde;
-  J[1 + 4 * 4] = st;
-  J[2 + 3 * 4] = domega_ddelta;
-  J[2 + 4 * 4] = domega_dv;
-  J[3 + 5 * 4] = T(1);
+  bicycle_J_from<T>(mp, bicycle_trig<T>(mp, x[2], x[3]), u, J);
 }
-
-// f and J of the bicycle at one point with every transcendental evaluated once (the separate functions call
-// sin / cos / tan / atan2 on the same arguments up to three times each); same calls on the same arguments,
-// so the values are the ones bicycle_f / bicycle_J produce.
+// f and J at one point from one evaluation of the trigonometry
 template <typename T>
 ALTRO_HD void bicycle_fJ(const ModelParams& mp, const T* x, const T* u, T* xdot, T* J) {
-  const T v = u[0], delta_dot = u[1], theta = x[2], delta = x[3];
-  const T L = (T)mp.length, lr = (T)mp.lr;
-  T omega, st, ct, dbeta = T(0), domega_ddelta, domega_dv, ds_dde = T(0), dc_dde = T(0);
-  if (mp.frame == 0) {
-    const T by = lr * delta, bx = L;
-    const T beta = atan2(by, bx);
-    const T sb = sin(beta), cb = cos(beta), td = tan(delta), cd = cos(delta);
-    st = sin(theta + beta);
-    ct = cos(theta + beta);
-    omega = v * cb * td / L;
-    dbeta = bx / (bx * bx + by * by) * lr;
-    domega_ddelta = v / L * (-sb * td * dbeta + cb / (cd * cd));
-    domega_dv = cb * td / L;
-    ds_dde = ct * dbeta;
-    dc_dde = -st * dbeta;
-  } else if (mp.frame == 1) {
-    const T td = tan(delta), cd = cos(delta);
-    omega = v * td / L;
-    st = sin(theta);
-    ct = cos(theta);
-    domega_ddelta = v / L / (cd * cd);
-    domega_dv = td / L;
-  } else {
-    const T sd = sin(delta), cd = cos(delta);
-    omega = v * sd / L;
-    st = sin(theta + delta);
-    ct = cos(theta + delta);
-    domega_ddelta = v / L * cd;
-    domega_dv = sd / L;
-    ds_dde = ct;
-    dc_dde = -st;
-  }
-  xdot[0] = v * ct;
-  xdot[1] = v * st;
-  xdot[2] = omega;
-  xdot[3] = delta_dot;
-  for (int e = 0; e < 24; ++e) J[e] = T(0);
-  J[0 + 2 * 4] = v * -st;
-  J[0 + 3 * 4] = v * dc_dde;
-  J[0 + 4 * 4] = ct;
-  J[1 + 2 * 4] = v * ct;
-  J[1 + 3 * 4] = v * ds_dde;
-  J[1 + 4 * 4] = st;
-  J[2 + 3 * 4] = domega_ddelta;
-  J[2 + 4 * 4] = domega_dv;
-  J[3 + 5 * 4] = T(1);
+  const BicycleTrig<T> t = bicycle_trig<T>(mp, x[2], x[3]);
+  bicycle_f_from<T>(mp, t, u, xdot);
+  bicycle_J_from<T>(mp, t, u, J);
 }
 
 // ---- discrete models -------------------------------------------------------------------------------

@@ -125,7 +125,9 @@ def test_batched_solve_matches_per_problem_oracle(name):
             continue   # a run that hits the iteration cap is chaotic in the last digits: compare outcome only
         n_converged += 1
         assert abs(res["alpha"][b] - log[iters - 1, 0]) <= 1e-6
-        assert abs(res["stationarity"][b] - log[iters - 1, 4]) <= 0.05 * log[iters - 1, 4] + 2e-6
+        # the final residual is itself a rounding-level quantity after many back-tracked iterations (bicycle)
+        stol = 0.2 if bk else 0.05
+        assert abs(res["stationarity"][b] - log[iters - 1, 4]) <= stol * log[iters - 1, 4] + 2e-6
         np.testing.assert_allclose(x[b], s.get("x"), rtol=tol, atol=tol)
         np.testing.assert_allclose(u[b], s.get("u"), rtol=tol * 10, atol=tol * 10)
     assert n_converged >= 2
