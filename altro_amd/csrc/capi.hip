@@ -94,6 +94,10 @@ struct altro_hip_batch {
   void *al_d_G = nullptr, *al_d_g = nullptr, *al_d_z = nullptr;
   const int* bwd_active = nullptr;           // per-problem mask for the backward sweep inside ilqr_solve
   const double* bwd_reg = nullptr;           // per-problem regularisation inside ilqr_solve (retry extension)
+  // iLQR loop on plan MFMA16 (dynamics given as data): nominal trajectory + cost parameters, allocated by
+  // altro_hip_set_tracking_cost; ilqr_linear = the backward sweep ignores the affine term (knotpoint_data.cpp:416)
+  void *m_nom = nullptr, *m_costp = nullptr;
+  bool ilqr_linear = false;
   double* i_reg = nullptr;
   // staging for host <-> device conversion (grown lazily, never inside the hot path)
   void* stage = nullptr;
@@ -202,6 +206,32 @@ int generic_set(altro_hip_batch* h, int arr, const double* host, int block, int 
                        bs, (int64_t)block, s, block, nk, b0, nb);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "expand_copy launch: %s", hipGetErrorString(e));
+    return 0;
+  });
+}
+
+// One reference-layout host array ([batch or 1][nk_host][block]) into `block` consecutive elements of AoS device
+// records: dst[b * dst_bs + k * dst_ks + e], k = 0..nk-1.
+template <typename T>
+int aos_set(altro_hip_batch* h, T* dst, int64_t dst_bs, int64_t dst_ks, const double* host, int block, int nk,
+            int k_zero, int b_zero, int nk_host = -1, int src_off = 0) {
+  return upload_chunks(h, host, block, nk, k_zero, b_zero, nk_host, src_off, [&](SrcArr s, int b0, int nb) {
+    const int64_t total = (int64_t)nb * nk * block;
+    hipLaunchKernelGGL(expand_copy_kernel<T>, dim3(grid_for(total)), dim3(256), 0, h->stream, dst, dst_bs, dst_ks, s,
+                       block, nk, b0, nb);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "expand_copy launch: %s", hipGetErrorString(e));
+    return 0;
+  });
+}
+template <typename T>
+int aos_get(altro_hip_batch* h, double* host, const T* src, int64_t src_bs, int64_t src_ks, int block, int nk) {
+  return download_chunks(h, host, block, nk, [&](double* dst, int b0, int nb) {
+    const int64_t total = (int64_t)nb * nk * block;
+    hipLaunchKernelGGL(gather_copy_kernel<T>, dim3(grid_for(total)), dim3(256), 0, h->stream, dst,
+                       (int64_t)nk * block, (int64_t)block, src, src_bs, src_ks, block, nk, b0, nb);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "gather_copy launch: %s", hipGetErrorString(e));
     return 0;
   });
 }
@@ -485,8 +515,27 @@ int ilqr_launch(altro_hip_batch* h, int which, IlqrArgs<T> a) {
   if (rc) return fail(ALTRO_HIP_ERR_HIP, "iLQR kernel launch failed");
   return 0;
 }
+template <typename S>
+int wave_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int want_deriv, double alpha_const) {
+  IlqrWaveArgs<S> a;
+  a.dyn = (const S*)h->m_in; a.dyn_bs = h->m_st.in_bs; a.dyn_ks = h->m_st.in_ks;
+  a.cin = (S*)h->m_cin; a.cin_bs = h->m_st.cin_bs; a.cin_ks = h->m_st.cin_ks;
+  a.term = (S*)h->m_term; a.out = (const S*)h->m_out; a.out_bs = h->m_st.out_bs; a.out_ks = h->m_st.out_ks;
+  a.outn = (const S*)h->m_outn; a.nom = (S*)h->m_nom; a.cand = (S*)h->m_xuy; a.xuy_bs = h->m_st.xuy_bs;
+  a.xuy_ks = h->m_st.xuy_ks; a.costp = (const S*)h->m_costp; a.x0 = (const S*)h->x0;
+  a.alpha = use_alpha ? h->i_alpha : nullptr; a.active = use_active ? h->i_active : nullptr;
+  a.phi = h->i_phi; a.dphi = h->i_dphi; a.prob = h->i_prob; a.N = h->N; a.batch = h->batch;
+  a.want_derivative = want_deriv; a.alpha_const = alpha_const;
+  const int rc = ilqr_wave_launch_kernel<S>(h->stream, which, a);
+  if (rc == 1) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "operation %d is not available on plan MFMA16 (constraints are a plan-LANE feature)", which);
+  if (rc) return fail(ALTRO_HIP_ERR_HIP, "iLQR kernel launch failed");
+  return 0;
+}
 int ilqr_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int want_deriv, double alpha_const,
              int mode = EXPAND_GRADIENT | EXPAND_HESSIAN) {
+  if (h->plan == ALTRO_HIP_PLAN_MFMA16)   // linear dynamics, constant cost Hessian: "expand" = the cost gradient
+    return h->dtype == ALTRO_HIP_F64 ? wave_run<double>(h, which, use_alpha, use_active, want_deriv, alpha_const)
+                                     : wave_run<float>(h, which, use_alpha, use_active, want_deriv, alpha_const);
   int rc = al_upload(h);
   if (rc) return rc;
   if (h->dtype == ALTRO_HIP_F64) {
@@ -501,9 +550,13 @@ int ilqr_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int
 int ilqr_check(altro_hip_batch* h, bool need_guess) {
   int rc = check(h);
   if (rc) return rc;
-  if (h->plan != ALTRO_HIP_PLAN_LANE)
-    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "the device iLQR loop is implemented for plan LANE shapes");
-  if (!h->model_set) return fail(ALTRO_HIP_ERR_NOT_SET, "altro_hip_set_model has not been called");
+  if (h->plan == ALTRO_HIP_PLAN_MFMA16) {   // dynamics are data (altro_hip_set_dynamics), no device model
+    if (!h->dyn_set) return fail(ALTRO_HIP_ERR_NOT_SET, "altro_hip_set_dynamics has not been called");
+  } else if (h->plan != ALTRO_HIP_PLAN_LANE) {
+    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "the device iLQR loop is implemented for plans LANE and MFMA16");
+  } else if (!h->model_set) {
+    return fail(ALTRO_HIP_ERR_NOT_SET, "altro_hip_set_model has not been called");
+  }
   if (!h->lqr_cost_set) return fail(ALTRO_HIP_ERR_NOT_SET, "altro_hip_set_tracking_cost has not been called");
   if (!h->x0_set) return fail(ALTRO_HIP_ERR_NOT_SET, "altro_hip_set_initial_state has not been called");
   if (need_guess && !h->guess_set) return fail(ALTRO_HIP_ERR_NOT_SET, "altro_hip_set_input_guess has not been called");
@@ -520,16 +573,16 @@ Mfma16Args<S> mfma16_args(altro_hip_batch* h, double reg) {
   a.xuy_bs = h->m_st.xuy_bs; a.xuy_ks = h->m_st.xuy_ks;
   a.term = (const S*)h->m_term; a.out = (S*)h->m_out; a.outn = (S*)h->m_outn; a.qblk = (S*)h->m_qblk;
   a.trash = (S*)h->m_trash; a.x0 = (const S*)h->x0; a.xuy = (S*)h->m_xuy; a.delta_V = (S*)h->delta_V;
-  a.status = h->status; a.N = h->N; a.batch = h->batch; a.reg = reg; a.has_f = h->has_f;
+  a.status = h->status; a.N = h->N; a.batch = h->batch; a.reg = reg; a.has_f = h->has_f && !h->ilqr_linear;
   return a;
 }
 template <typename S>
 void mfma16_launch_backward(altro_hip_batch* h, double reg, bool sq) {
   auto a = mfma16_args<S>(h, reg);
   const dim3 grid(h->batch), block(64);
-  if (sq && h->has_f) hipLaunchKernelGGL((mfma16_backward_kernel<true, true, S>), grid, block, 0, h->stream, a);
+  if (sq && a.has_f) hipLaunchKernelGGL((mfma16_backward_kernel<true, true, S>), grid, block, 0, h->stream, a);
   else if (sq) hipLaunchKernelGGL((mfma16_backward_kernel<true, false, S>), grid, block, 0, h->stream, a);
-  else if (h->has_f) hipLaunchKernelGGL((mfma16_backward_kernel<false, true, S>), grid, block, 0, h->stream, a);
+  else if (a.has_f) hipLaunchKernelGGL((mfma16_backward_kernel<false, true, S>), grid, block, 0, h->stream, a);
   else hipLaunchKernelGGL((mfma16_backward_kernel<false, false, S>), grid, block, 0, h->stream, a);
 }
 
@@ -547,7 +600,7 @@ int launch_backward(altro_hip_batch* h, double reg) {
     else if (sq || !(h->flags & ALTRO_HIP_F32_PURE)) mfma16_launch_backward<float>(h, reg, sq);   // fp32 storage, fp64 tiles
     else {   // opt-in: pure fp32 on v_mfma_f32_16x16x4_f32
       auto a = mfma16_args<float>(h, reg);
-      if (h->has_f) hipLaunchKernelGGL((mfma16_backward_f32_kernel<true, 3>), dim3(h->batch), dim3(64), 0, h->stream, a);
+      if (a.has_f) hipLaunchKernelGGL((mfma16_backward_f32_kernel<true, 3>), dim3(h->batch), dim3(64), 0, h->stream, a);
       else hipLaunchKernelGGL((mfma16_backward_f32_kernel<false, 3>), dim3(h->batch), dim3(64), 0, h->stream, a);
     }
   } else if (h->plan == ALTRO_HIP_PLAN_LANE) {
@@ -682,21 +735,7 @@ int altro_hip_batch_create(altro_hip_batch** out, int N, int n, int m, int batch
     ALLOC(h->l_x0, B * n * E);
     ALLOC(h->l_nom, B * (N + 1) * (n + m) * E);
     ALLOC(h->l_cost, B * (N + 1) * (2 * n + 2 * m + 1) * E);
-    ALLOC(h->i_prob, B * sizeof(IlqrProb));
-    ALLOC(h->i_alpha, B * 8);
-    ALLOC(h->i_phi, B * 8);
-    ALLOC(h->i_dphi, B * 8);
-    ALLOC(h->i_active, B * sizeof(int));
-    ALLOC(h->i_counters, 4 * sizeof(int));
-    ALLOC(h->i_reg, B * 8);
-    if (!rc) {   // every constraint starts with penalty 1 (knotpoint_data.cpp:343)
-      std::vector<IlqrProb> pr((size_t)B);
-      std::memset(pr.data(), 0, pr.size() * sizeof(IlqrProb));
-      for (auto& q : pr) { q.rho = 1.0; q.rho_est = 1.0; q.status = 1; }
-      if (hipMemcpy(h->i_prob, pr.data(), pr.size() * sizeof(IlqrProb), hipMemcpyHostToDevice) != hipSuccess)
-        rc = fail(ALTRO_HIP_ERR_HIP, "control block upload failed");
-      h->al_knots.assign((size_t)N + 1, AlKnot{});
-    }
+    if (!rc) h->al_knots.assign((size_t)N + 1, AlKnot{});
     if (!rc && hipMemset(h->l_xuy, 0, B * (N + 1) * z.e_xuy * E) != hipSuccess) rc = fail(ALTRO_HIP_ERR_HIP, "memset failed");
     if (!rc && hipMemset(h->l_cost, 0, B * (N + 1) * (2 * n + 2 * m + 1) * E) != hipSuccess) rc = fail(ALTRO_HIP_ERR_HIP, "memset failed");
   } else {
@@ -724,6 +763,22 @@ int altro_hip_batch_create(altro_hip_batch** out, int N, int n, int m, int batch
         rc = fail(ALTRO_HIP_ERR_HIP, "table upload failed");
     }
   }
+  if (plan == ALTRO_HIP_PLAN_LANE || plan == ALTRO_HIP_PLAN_MFMA16) {   // per-problem control blocks of the iLQR loop
+    ALLOC(h->i_prob, B * sizeof(IlqrProb));
+    ALLOC(h->i_alpha, B * 8);
+    ALLOC(h->i_phi, B * 8);
+    ALLOC(h->i_dphi, B * 8);
+    ALLOC(h->i_active, B * sizeof(int));
+    ALLOC(h->i_counters, 4 * sizeof(int));
+    ALLOC(h->i_reg, B * 8);
+    if (!rc) {   // every constraint starts with penalty 1 (knotpoint_data.cpp:343)
+      std::vector<IlqrProb> pr((size_t)B);
+      std::memset(pr.data(), 0, pr.size() * sizeof(IlqrProb));
+      for (auto& q : pr) { q.rho = 1.0; q.rho_est = 1.0; q.status = 1; }
+      if (hipMemcpy(h->i_prob, pr.data(), pr.size() * sizeof(IlqrProb), hipMemcpyHostToDevice) != hipSuccess)
+        rc = fail(ALTRO_HIP_ERR_HIP, "control block upload failed");
+    }
+  }
 #undef ALLOC
   if (!rc && (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess))
     rc = fail(ALTRO_HIP_ERR_HIP, "hipEventCreate failed");
@@ -743,7 +798,7 @@ void altro_hip_batch_destroy(altro_hip_batch* h) {
                   h->m_qblk, h->m_trash, h->g_off, h->g_nx, h->g_nu, h->stage,
                   h->l_in, h->l_term, h->l_out, h->l_outn, h->l_xuy, h->l_x0,
                   h->l_nom, h->l_cost, h->i_prob, h->i_alpha, h->i_phi, h->i_dphi, h->i_active, h->i_counters,
-                  h->al_d_knots, h->al_d_G, h->al_d_g, h->al_d_z, h->i_reg};
+                  h->al_d_knots, h->al_d_G, h->al_d_g, h->al_d_z, h->i_reg, h->m_nom, h->m_costp};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (int a = 0; a < G_NUM; ++a) if (h->g_arr[a]) (void)hipFree(h->g_arr[a]);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -1108,7 +1163,8 @@ int altro_hip_set_tracking_cost(altro_hip_batch* h, const double* Qd, const doub
   // c = 1/2 xref'Q xref (+ 1/2 uref'R uref for k < N) -> KnotPointData::SetDiagonalCost
   int rc = check(h);
   if (rc) return rc;
-  if (h->plan != ALTRO_HIP_PLAN_LANE) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "tracking cost needs plan LANE");
+  if (h->plan != ALTRO_HIP_PLAN_LANE && h->plan != ALTRO_HIP_PLAN_MFMA16)
+    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "tracking cost needs plan LANE or MFMA16");
   if (!Qd || !Rd || !xref || !uref) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "Qd, Rd, xref, uref are required");
   const int n = h->n, m = h->m, N = h->N;
   const int nb = bz ? 1 : h->batch, nkx = kz ? 2 : N + 1, nku = kz ? 1 : N;
@@ -1137,6 +1193,47 @@ int altro_hip_set_tracking_cost(altro_hip_batch* h, const double* Qd, const doub
     for (int k = 0; k < nku; ++k)
       for (int i = 0; i < m; ++i)
         r[((size_t)b * nku + k) * m + i] = -(Rd[((size_t)b * nku + k) * m + i] * uref[((size_t)b * nku + k) * m + i]);
+  if (h->plan == ALTRO_HIP_PLAN_MFMA16) {
+    // (a) the backward sweep's blocks: lxx = diag(Qd), luu = diag(Rd), lux = 0; lx, lu are refreshed by the loop
+    rc = altro_hip_set_cost(h, Qd, Rd, nullptr, q.data(), r.data(), 1, kz, bz);
+    if (rc) return rc;
+    // (b) the cost parameters the merit function needs: [k][b][36] = Qd | Rd | q | r | c
+    const size_t Ez = h->dtype == ALTRO_HIP_F64 ? 8 : 4;
+    const int64_t B = h->batch;
+    if (!h->m_costp) {
+      if ((rc = dmalloc(h, &h->m_costp, (size_t)B * (N + 1) * MF_COSTP * Ez))) return rc;
+      if ((rc = dmalloc(h, &h->m_nom, (size_t)B * (N + 1) * MF_NOM * Ez))) return rc;
+      HIP_TRY(hipMemset(h->m_costp, 0, (size_t)B * (N + 1) * MF_COSTP * Ez));
+      HIP_TRY(hipMemset(h->m_nom, 0, (size_t)B * (N + 1) * MF_NOM * Ez));
+    }
+    auto put = [&](const double* src, int len, int off, int k0, int nk, int nk_host, int src_off) -> int {
+      // records k0..k0+nk-1; with kz the host holds {running, terminal} and src_off selects which
+      if (h->dtype == ALTRO_HIP_F64)
+        return aos_set<double>(h, (double*)h->m_costp + (size_t)k0 * B * MF_COSTP + off, MF_COSTP, B * MF_COSTP, src, len, nk,
+                               kz, bz, nk_host, src_off);
+      return aos_set<float>(h, (float*)h->m_costp + (size_t)k0 * B * MF_COSTP + off, MF_COSTP, B * MF_COSTP, src, len, nk, kz,
+                            bz, nk_host, src_off);
+    };
+    rc = put(Qd, n, 0, 0, N, nkx, 0);
+    if (!rc) rc = put(Rd, m, 12, 0, N, nku, 0);
+    if (!rc) rc = put(q.data(), n, 16, 0, N, nkx, 0);
+    if (!rc) rc = put(r.data(), m, 28, 0, N, nku, 0);
+    if (!rc) rc = put(c.data(), 1, 32, 0, N, nkx, 0);
+    // terminal record N: element N of a full host array, or the second entry of a {running, terminal} pair
+    auto put_term = [&](const double* src, int len, int off) -> int {
+      const double* base = kz ? src : src;   // per problem the host holds nkx knot points
+      if (h->dtype == ALTRO_HIP_F64)
+        return aos_set<double>(h, (double*)h->m_costp + (size_t)N * B * MF_COSTP + off, MF_COSTP, B * MF_COSTP, base, len, 1, 1,
+                               bz, nkx, (kz ? 1 : N) * len);
+      return aos_set<float>(h, (float*)h->m_costp + (size_t)N * B * MF_COSTP + off, MF_COSTP, B * MF_COSTP, base, len, 1, 1, bz,
+                            nkx, (kz ? 1 : N) * len);
+    };
+    if (!rc) rc = put_term(Qd, n, 0);
+    if (!rc) rc = put_term(q.data(), n, 16);
+    if (!rc) rc = put_term(c.data(), 1, 32);
+    if (!rc) { h->lqr_cost_set = true; h->ilqr_linear = true; }
+    return rc;
+  }
   auto pk = [&](const double* src, int len, int off, int nk, int k_src0, int nk_host, int src_off) -> int {
     return h->dtype == ALTRO_HIP_F64
                ? lane_pack<double>(h, (double*)h->l_cost + (size_t)0, E, src, len, off, 0, nk, k_src0, nk_host, kz, bz, src_off)
@@ -1164,9 +1261,17 @@ int altro_hip_set_input_guess(altro_hip_batch* h, const double* u, int kz, int b
   // ALTROSolver::SetInput (altro_solver.cpp:242-251): writes the CANDIDATE inputs u_
   int rc = check(h);
   if (rc) return rc;
-  if (h->plan != ALTRO_HIP_PLAN_LANE) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "input guess needs plan LANE");
+  if (h->plan != ALTRO_HIP_PLAN_LANE && h->plan != ALTRO_HIP_PLAN_MFMA16)
+    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "input guess needs plan LANE or MFMA16");
   if (!u) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "u == NULL");
   const int n = h->n, m = h->m, N = h->N;
+  if (h->plan == ALTRO_HIP_PLAN_MFMA16) {   // candidate records [k][b][28] = x | y | u
+    rc = h->dtype == ALTRO_HIP_F64
+             ? aos_set<double>(h, (double*)h->m_xuy + 24, h->m_st.xuy_bs, h->m_st.xuy_ks, u, m, N, kz, bz)
+             : aos_set<float>(h, (float*)h->m_xuy + 24, h->m_st.xuy_bs, h->m_st.xuy_ks, u, m, N, kz, bz);
+    if (!rc) h->guess_set = true;
+    return rc;
+  }
   rc = h->dtype == ALTRO_HIP_F64
            ? lane_pack<double>(h, (double*)h->l_xuy, 2 * n + m, u, m, 2 * n, 0, N, 0, kz ? 1 : N, kz, bz)
            : lane_pack<float>(h, (float*)h->l_xuy, 2 * n + m, u, m, 2 * n, 0, N, 0, kz ? 1 : N, kz, bz);
@@ -1244,7 +1349,8 @@ int altro_hip_update_linear_costs(altro_hip_batch* h, const double* q, const dou
   // (knotpoint_data.cpp:193-226) for knot points k_first..k_last (inclusive) of every problem
   int rc = check(h);
   if (rc) return rc;
-  if (h->plan != ALTRO_HIP_PLAN_LANE) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "linear cost update needs plan LANE");
+  if (h->plan != ALTRO_HIP_PLAN_LANE && h->plan != ALTRO_HIP_PLAN_MFMA16)
+    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "linear cost update needs plan LANE or MFMA16");
   if (!h->lqr_cost_set) return fail(ALTRO_HIP_ERR_NOT_SET, "no quadratic cost to update (ErrorCodes::CostNotQuadratic)");
   const int n = h->n, m = h->m, N = h->N;
   if (k_first < 0 || k_last > N || k_first > k_last)
@@ -1253,6 +1359,21 @@ int altro_hip_update_linear_costs(altro_hip_batch* h, const double* q, const dou
     return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "cannot update linear input costs at the terminal knot point "
                                             "(ErrorCodes::InvalidOptAtTerminalKnotPoint)");
   const int nk = k_last - k_first + 1;
+  if (h->plan == ALTRO_HIP_PLAN_MFMA16) {
+    const int64_t B = h->batch;
+    auto put = [&](const double* src, int len, int off) -> int {
+      if (!src) return 0;
+      if (h->dtype == ALTRO_HIP_F64)
+        return aos_set<double>(h, (double*)h->m_costp + (size_t)k_first * B * MF_COSTP + off, MF_COSTP, B * MF_COSTP, src, len,
+                               nk, kz, bz);
+      return aos_set<float>(h, (float*)h->m_costp + (size_t)k_first * B * MF_COSTP + off, MF_COSTP, B * MF_COSTP, src, len, nk,
+                            kz, bz);
+    };
+    rc = put(q, n, 16);
+    if (!rc) rc = put(r, m, 28);
+    if (!rc) rc = put(c, 1, 32);
+    return rc;
+  }
   const int E = 2 * n + 2 * m + 1;
   const size_t base = (size_t)k_first * E * h->batch;
   auto pk = [&](const double* src, int len, int off) -> int {
@@ -1387,6 +1508,8 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
   la.reg = h->i_reg; la.bwd_status = h->status;
   la.reg_initial = o.reg_initial; la.reg_scale = o.reg_scale; la.reg_min = o.reg_min; la.reg_max = o.reg_max;
   const bool reg_on = o.reg_retry_max > 0 || o.reg_initial > 0.0;
+  if (reg_on && h->plan != ALTRO_HIP_PLAN_LANE)
+    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "the regularisation schedule is a plan-LANE feature");
   if (o.reg_initial < 0.0 || (o.reg_retry_max > 0 && !(o.reg_scale > 1.0 && o.reg_min > 0.0 && o.reg_max >= o.reg_min)))
     return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "regularisation retry needs reg_initial >= 0, reg_scale > 1, 0 < reg_min <= reg_max");
   if (al && !(o.penalty_initial > 0.0 && o.penalty_scaling > 0.0 && o.penalty_max > 0.0))
@@ -1521,8 +1644,21 @@ int altro_hip_last_solve_counts(const altro_hip_batch* h, int* sweeps, int* meri
 int altro_hip_get_nominal(altro_hip_batch* h, double* x, double* u) {
   int rc = check(h);
   if (rc) return rc;
-  if (h->plan != ALTRO_HIP_PLAN_LANE) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "nominal trajectory exists for plan LANE");
   const int n = h->n, m = h->m, N = h->N;
+  if (h->plan == ALTRO_HIP_PLAN_MFMA16) {
+    if (!h->m_nom) return fail(ALTRO_HIP_ERR_NOT_SET, "altro_hip_set_tracking_cost has not been called");
+    const int64_t B = h->batch;
+    if (x) {
+      rc = h->dtype == ALTRO_HIP_F64 ? aos_get<double>(h, x, (const double*)h->m_nom, MF_NOM, B * MF_NOM, n, N + 1)
+                                     : aos_get<float>(h, x, (const float*)h->m_nom, MF_NOM, B * MF_NOM, n, N + 1);
+      if (rc) return rc;
+    }
+    if (u)
+      rc = h->dtype == ALTRO_HIP_F64 ? aos_get<double>(h, u, (const double*)h->m_nom + 12, MF_NOM, B * MF_NOM, m, N)
+                                     : aos_get<float>(h, u, (const float*)h->m_nom + 12, MF_NOM, B * MF_NOM, m, N);
+    return rc;
+  }
+  if (h->plan != ALTRO_HIP_PLAN_LANE) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "nominal trajectory exists for plans LANE and MFMA16");
   if (x) {
     rc = h->dtype == ALTRO_HIP_F64 ? lane_get<double>(h, x, h->l_nom, nullptr, n + m, 0, 0, n, N + 1, N + 1)
                                    : lane_get<float>(h, x, h->l_nom, nullptr, n + m, 0, 0, n, N + 1, N + 1);

@@ -1,0 +1,31 @@
+// Kernel instantiations of the iLQR loop for plan MFMA16 (see kernels/ilqr_mfma16.hip, kernels/ilqr_types.h).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "kernels/ilqr_mfma16.hip"
+
+namespace altro_hip {
+
+template <typename S>
+static int wave_launch(hipStream_t stream, int which, const IlqrWaveArgs<S>& a) {
+  const dim3 waves(a.batch), b64(64), b256(256);
+  const int64_t flat_n = (int64_t)a.batch * (a.N + 1) * 16;
+  const dim3 flat((unsigned)std::min<int64_t>((flat_n + 255) / 256, 1 << 20));
+  switch (which) {
+    case IK_ROLLOUT: hipLaunchKernelGGL(wave_rollout_kernel<S>, waves, b64, 0, stream, a); break;
+    case IK_ACCEPT: hipLaunchKernelGGL(wave_accept_kernel<S>, flat, b256, 0, stream, a); break;
+    case IK_EXPAND: hipLaunchKernelGGL(wave_gradient_kernel<S>, flat, b256, 0, stream, a); break;
+    case IK_MERIT: hipLaunchKernelGGL(wave_merit_kernel<S>, waves, b64, 0, stream, a); break;
+    case IK_STATIONARITY: hipLaunchKernelGGL(wave_stationarity_kernel<S>, waves, b64, 0, stream, a); break;
+    case IK_SHIFT: hipLaunchKernelGGL(wave_shift_kernel<S>, dim3((a.batch * 16 + 255) / 256), b256, 0, stream, a); break;
+    default: return 1;   // no constraint kernels on this plan
+  }
+  return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+template <>
+int ilqr_wave_launch_kernel<double>(hipStream_t stream, int which, const IlqrWaveArgs<double>& a) { return wave_launch<double>(stream, which, a); }
+template <>
+int ilqr_wave_launch_kernel<float>(hipStream_t stream, int which, const IlqrWaveArgs<float>& a) { return wave_launch<float>(stream, which, a); }
+
+}  // namespace altro_hip

@@ -70,6 +70,33 @@ struct IlqrLoopArgs {
   LsOptions ls;
 };
 
+// ---- plan MFMA16 ((12, 4), wave per problem, dynamics given as data): kernels/ilqr_mfma16.hip ----------------
+constexpr int MF_NOM = 16;     // nominal record: x 12 | u 4
+constexpr int MF_COSTP = 36;   // cost-parameter record: Qd 12 | Rd 4 | q 12 | r 4 | c 1 | pad 3
+
+template <typename S>
+struct IlqrWaveArgs {
+  const S* dyn;   int64_t dyn_bs, dyn_ks;    // DYN records: Z 192 | f 12
+  S* cin;         int64_t cin_bs, cin_ks;    // COST records: Q 144 | [H R] 64 | [q r] 16
+  S* term;                                   // [b][156]: Q_N 144 | q_N 12
+  const S* out;   int64_t out_bs, out_ks;    // OUT records: Kt 52 | [P p] 156
+  const S* outn;                             // [b][156]
+  S* nom;                                    // [k][b][16]
+  S* cand;        int64_t xuy_bs, xuy_ks;    // [k][b][28]: x 12 | y 12 | u 4
+  const S* costp;                            // [k][b][36]
+  const S* x0;                               // [b][12]
+  const double* alpha;
+  const int* active;
+  double* phi;
+  double* dphi;
+  IlqrProb* prob;
+  int N, batch, want_derivative;
+  double alpha_const;
+};
+
+template <typename S>
+int ilqr_wave_launch_kernel(hipStream_t stream, int which, const IlqrWaveArgs<S>& a);   // ilqr_launch_mfma16.hip
+
 enum IlqrKernel { IK_ROLLOUT, IK_ACCEPT, IK_EXPAND, IK_MERIT, IK_STATIONARITY, IK_DUAL, IK_SHIFT };
 enum IlqrLoopKernel { ILK_LOOP_INIT, ILK_LS_BEGIN, ILK_LS_FEED, ILK_FINISH_ITER, ILK_MARK_RUNNING, ILK_SET_PENALTY,
                       ILK_PENALTY_UPDATE, ILK_REG_RETRY };

@@ -1,0 +1,134 @@
+"""The iLQR loop on plan MFMA16 ((n, m) = (12, 4), wave per problem) for dynamics given as data
+(x+ = A_k x + B_k u + f_k, the reference's SetLinearDynamics path) with the diagonal tracking cost, against the
+oracle's restatement of SolverImpl with ORACLE_DYN_LINEAR.  An LQ problem: the reference converges in one or two
+sweeps with alpha = 1 (solver_impl_test.cpp:309-315, double_integrator_test.cpp:129-132)."""
+import numpy as np
+import pytest
+
+import altro_amd
+from oracle import oracle
+from tests import problems
+
+pytestmark = pytest.mark.gpu
+
+N, n, m = 24, 12, 4
+
+
+def make_problem(batch, with_f):
+    pr = problems.random_ltv(batch, N, n, m)
+    A, B = pr["A"], pr["B"]
+    f = pr["f"] if with_f else None
+    rng_q = 1.0 + problems.uniform01((batch, N + 1, n), 71)
+    rng_r = 0.1 + 0.2 * problems.uniform01((batch, N, m), 72)
+    xref = problems.normal((batch, N + 1, n), 73) * 0.3
+    uref = problems.normal((batch, N, m), 74) * 0.1
+    x0 = problems.normal((batch, n), 75)
+    u0 = problems.normal((batch, N, m), 76) * 0.2
+    return dict(A=A, B=B, f=f, Qd=rng_q, Rd=rng_r, xref=xref, uref=uref, x0=x0, u0=u0)
+
+
+def make_hip(p):
+    batch = p["x0"].shape[0]
+    bt = altro_amd.Batch(N, n, m, batch)
+    assert bt.plan == altro_amd.PLAN_MFMA16
+    bt.set_dynamics(p["A"], p["B"], p["f"])
+    bt.set_tracking_cost(p["Qd"], p["Rd"], p["xref"], p["uref"])
+    bt.set_initial_state(p["x0"])
+    bt.set_input_guess(p["u0"])
+    return bt
+
+
+def make_oracle(p, b):
+    s = oracle.ILQR(N, n, m, 0.01, oracle.DYN_LINEAR, cost_kind=oracle.COST_DIAGONAL)
+    f = p["f"][b] if p["f"] is not None else None
+    s.L.oracle_ilqr_set_linear_dynamics(s.h, np.ascontiguousarray(p["A"][b]), np.ascontiguousarray(p["B"][b]),
+                                        None if f is None else np.ascontiguousarray(f).ctypes.data)
+    for k in range(N + 1):
+        s.L.oracle_ilqr_set_lqr_cost(s.h, k, np.ascontiguousarray(p["Qd"][b, k]), np.ascontiguousarray(p["Rd"][b, min(k, N - 1)]),
+                                     np.ascontiguousarray(p["xref"][b, k]), np.ascontiguousarray(p["uref"][b, min(k, N - 1)]))
+    s.L.oracle_ilqr_set_initial_state(s.h, np.ascontiguousarray(p["x0"][b]))
+    s.L.oracle_ilqr_initialize(s.h)
+    for k in range(N):
+        s.L.oracle_ilqr_set_input(s.h, k, np.ascontiguousarray(p["u0"][b, k]))
+    return s
+
+
+@pytest.mark.parametrize("with_f", [False, True])
+def test_merit_function_parity_mfma16(with_f):
+    """solver.cpp:273-355 on the device for (12, 4): phi, dphi, candidate x_/u_/y_, refreshed lx, lu."""
+    batch = 9
+    p = make_problem(batch, with_f)
+    bt = make_hip(p)
+    bt.open_loop_rollout(); bt.accept(); bt.expand(); bt.backward()
+    assert (bt.get("status") == -1).all()
+    alphas = np.linspace(0.0, 1.2, batch)
+    phi, dphi = bt.merit(alphas)
+    xc, uc, yc = bt.get("x"), bt.get("u"), bt.get("y")
+    st = bt.stationarity()
+    for b in [0, 4, 8]:
+        s = make_oracle(p, b)
+        s.L.oracle_ilqr_open_loop_rollout(s.h); s.L.oracle_ilqr_copy_trajectory(s.h)
+        s.L.oracle_ilqr_calc_dynamics_expansions(s.h); s.L.oracle_ilqr_calc_cost_gradient(s.h)
+        s.L.oracle_ilqr_calc_expansions(s.h)
+        assert s.L.oracle_ilqr_backward_pass(s.h) == -1
+        np.testing.assert_allclose(bt.get("K")[b], s.get("K"), rtol=1e-9, atol=1e-9)
+        p_ref, dp_ref = s.merit(alphas[b])
+        assert abs(phi[b] - p_ref) <= 1e-11 * max(1.0, abs(p_ref))
+        assert abs(dphi[b] - dp_ref) <= 1e-9 * max(1.0, abs(dp_ref))
+        np.testing.assert_allclose(xc[b], s.get("x_cand"), rtol=1e-10, atol=1e-10)
+        np.testing.assert_allclose(uc[b], s.get("u_cand"), rtol=1e-10, atol=1e-10)
+        np.testing.assert_allclose(yc[b], s.get("y_cand"), rtol=1e-9, atol=1e-9)
+        assert abs(st[b] - s.L.oracle_ilqr_stationarity(s.h)) <= 1e-8 * max(1.0, st[b])
+
+
+@pytest.mark.parametrize("with_f", [False, True])
+def test_batched_lq_solve_mfma16(with_f):
+    """Whole solves: same status / iterations as the oracle per problem (an LQ problem: alpha = 1, <= 3 sweeps),
+    same trajectories."""
+    batch = 70
+    p = make_problem(batch, with_f)
+    bt = make_hip(p)
+    res = bt.ilqr_solve(iterations_max=10)
+    assert (res["status"] == 0).all()
+    assert (res["iterations"] <= 3).all()
+    assert (np.abs(res["alpha"] - 1.0) < 1e-12).all()
+    x, u = bt.get_nominal()
+    for b in [0, 33, 69]:
+        s = make_oracle(p, b)
+        s.L.oracle_ilqr_set_options(s.h, 10, 1e-4, 1e-4, 1e-8, 0)
+        status, iters, log = s.solve()
+        assert status == 0 and iters == res["iterations"][b]
+        np.testing.assert_allclose(x[b], s.get("x"), rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(u[b], s.get("u"), rtol=1e-8, atol=1e-8)
+
+
+def test_c1_double_integrator_ilqr():
+    """BASELINE.json configs[1] as an iLQR solve: the C1 double integrator (n = 12, m = 4) converges in <= 3
+    sweeps (double_integrator_test.cpp:129-132) and beats the open-loop cost."""
+    batch = 130
+    one = problems.c1_double_integrator(1, N=64)
+    bt = altro_amd.Batch(64, 12, 4, batch)
+    bt.set_dynamics(one["A"][0, :1], one["B"][0, :1], None, k_stride_zero=True, batch_stride_zero=True)
+    Qd = np.stack([np.ones(12), 100.0 * np.ones(12)])
+    bt.set_tracking_cost(Qd, np.full((1, 4), 1e-2), np.zeros((2, 12)), np.zeros((1, 4)), k_stride_zero=True, batch_stride_zero=True)
+    x0 = 2.0 * problems.uniform01((batch, 12), 21) - 1.0
+    bt.set_initial_state(x0)
+    bt.set_input_guess(np.zeros((1, 1, 4)), k_stride_zero=True, batch_stride_zero=True)
+    res = bt.ilqr_solve(iterations_max=10)
+    assert (res["status"] == 0).all() and (res["iterations"] <= 3).all()
+    x, u = bt.get_nominal()
+    for b in [0, 129]:
+        s = oracle.ILQR(64, 12, 4, 0.01, oracle.DYN_LINEAR, cost_kind=oracle.COST_DIAGONAL)
+        s.L.oracle_ilqr_set_linear_dynamics(s.h, np.ascontiguousarray(np.tile(one["A"][0, :1], (64, 1))),
+                                            np.ascontiguousarray(np.tile(one["B"][0, :1], (64, 1))), None)
+        for k in range(65):
+            s.L.oracle_ilqr_set_lqr_cost(s.h, k, np.ascontiguousarray(Qd[1 if k == 64 else 0]), np.full(4, 1e-2), np.zeros(12), np.zeros(4))
+        s.L.oracle_ilqr_set_initial_state(s.h, np.ascontiguousarray(x0[b]))
+        s.L.oracle_ilqr_initialize(s.h)
+        s.L.oracle_ilqr_set_options(s.h, 10, 1e-4, 1e-4, 1e-8, 0)
+        status, iters, log = s.solve()
+        assert status == 0 and iters == res["iterations"][b]
+        np.testing.assert_allclose(x[b], s.get("x"), rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(u[b], s.get("u"), rtol=1e-8, atol=1e-8)
+    with pytest.raises(altro_amd.AltroHipError):
+        bt.add_linear_constraint(0, 1, altro_amd.CONE_EQUALITY, np.zeros((1, 16)), np.zeros(1))   # plan-LANE feature
