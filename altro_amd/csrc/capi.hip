@@ -482,7 +482,8 @@ int al_upload_typed(altro_hip_batch* h) {
   HIP_TRY(hipMemcpy(h->al_d_knots, knots.data(), knots.size() * sizeof(AlKnot), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->al_d_G, G.data(), G.size() * sizeof(T), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->al_d_g, g.data(), g.size() * sizeof(T), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemset(h->al_d_z, 0, (size_t)rows * B * sizeof(T)));
+  // (memsets go on the handle's own stream: it is non-blocking, so a null-stream memset would race the kernels)
+  HIP_TRY(hipMemsetAsync(h->al_d_z, 0, (size_t)rows * B * sizeof(T), h->stream));
   h->al_knots = knots;
   return 0;
 }
@@ -736,8 +737,9 @@ int altro_hip_batch_create(altro_hip_batch** out, int N, int n, int m, int batch
     ALLOC(h->l_nom, B * (N + 1) * (n + m) * E);
     ALLOC(h->l_cost, B * (N + 1) * (2 * n + 2 * m + 1) * E);
     if (!rc) h->al_knots.assign((size_t)N + 1, AlKnot{});
-    if (!rc && hipMemset(h->l_xuy, 0, B * (N + 1) * z.e_xuy * E) != hipSuccess) rc = fail(ALTRO_HIP_ERR_HIP, "memset failed");
-    if (!rc && hipMemset(h->l_cost, 0, B * (N + 1) * (2 * n + 2 * m + 1) * E) != hipSuccess) rc = fail(ALTRO_HIP_ERR_HIP, "memset failed");
+    // on the handle's own (non-blocking) stream: a null-stream memset would race the first kernels launched on it
+    if (!rc && hipMemsetAsync(h->l_xuy, 0, B * (N + 1) * z.e_xuy * E, h->stream) != hipSuccess) rc = fail(ALTRO_HIP_ERR_HIP, "memset failed");
+    if (!rc && hipMemsetAsync(h->l_cost, 0, B * (N + 1) * (2 * n + 2 * m + 1) * E, h->stream) != hipSuccess) rc = fail(ALTRO_HIP_ERR_HIP, "memset failed");
   } else {
     const int blk[G_NUM] = {n * n, n * m, n, n * n, m * m, m * n, n, m, m * n, m, n * n, n,
                             n * n, m * m, m * n, n, m, n * n, m * m, m * n, n, m, n, m, n};
@@ -1203,8 +1205,8 @@ int altro_hip_set_tracking_cost(altro_hip_batch* h, const double* Qd, const doub
     if (!h->m_costp) {
       if ((rc = dmalloc(h, &h->m_costp, (size_t)B * (N + 1) * MF_COSTP * Ez))) return rc;
       if ((rc = dmalloc(h, &h->m_nom, (size_t)B * (N + 1) * MF_NOM * Ez))) return rc;
-      HIP_TRY(hipMemset(h->m_costp, 0, (size_t)B * (N + 1) * MF_COSTP * Ez));
-      HIP_TRY(hipMemset(h->m_nom, 0, (size_t)B * (N + 1) * MF_NOM * Ez));
+      HIP_TRY(hipMemsetAsync(h->m_costp, 0, (size_t)B * (N + 1) * MF_COSTP * Ez, h->stream));
+      HIP_TRY(hipMemsetAsync(h->m_nom, 0, (size_t)B * (N + 1) * MF_NOM * Ez, h->stream));
     }
     auto put = [&](const double* src, int len, int off, int k0, int nk, int nk_host, int src_off) -> int {
       // records k0..k0+nk-1; with kz the host holds {running, terminal} and src_off selects which

@@ -248,6 +248,22 @@ def main():
     nf, ms_f, name_f = bt.profile_get(1)
     bt.profile(False)
 
+    # the same batch as a full iLQR solve (rollout, expansion, backward sweep, merit-function line search,
+    # convergence test; an LQ problem, so <= 3 sweeps), outside the timed region
+    full_solve = None
+    if not c4:
+        Qd2 = np.stack([np.ones(n), 100.0 * np.ones(n)])
+        bt.set_tracking_cost(Qd2, np.full((1, m), 1e-2), np.zeros((2, n)), np.zeros((1, m)), k_stride_zero=True,
+                             batch_stride_zero=True)
+        bt.set_input_guess(np.zeros((1, 1, m)), k_stride_zero=True, batch_stride_zero=True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        res = bt.ilqr_solve(iterations_max=10)
+        torch.cuda.synchronize()
+        t_solve = time.perf_counter() - t1
+        full_solve = {"seconds": t_solve, "sweeps": int(res["sweeps"]), "merit_launches": int(res["merit_launches"]),
+                      "converged": int((res["status"] == 0).sum()), "problems_per_s": batch / t_solve}
+
     if rank == 0:
         total_problems = batch * world
         sweeps_per_s = total_problems * args.steps / elapsed
@@ -290,6 +306,7 @@ def main():
                             name_f: {"avg_ms": ms_f / nf, "algorithmic_GB": bytes_f / 1e9,
                                      "GBps": bytes_f / dur_f / 1e9}},
                 "stats": stats,
+                "ilqr_full_solve": full_solve,
             },
             "roofline": {"bound": "hbm", "kernel": name_b, "achieved": bytes_b / dur_b / 1e9,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_b / dur_b / 1e9 / HBM_PEAK_GBS,

@@ -132,3 +132,24 @@ def test_c1_double_integrator_ilqr():
         np.testing.assert_allclose(u[b], s.get("u"), rtol=1e-8, atol=1e-8)
     with pytest.raises(altro_amd.AltroHipError):
         bt.add_linear_constraint(0, 1, altro_amd.CONE_EQUALITY, np.zeros((1, 16)), np.zeros(1))   # plan-LANE feature
+
+
+def test_full_size_c1_ilqr_solve():
+    """BASELINE.json configs[1] at full size (N = 256, batch = 4096) as an iLQR solve: every problem converges in
+    one sweep with alpha = 1 and a stationarity at rounding level.  (Regression: a null-stream memset of the
+    freshly allocated cost-parameter records raced the upload kernels on the handle's non-blocking stream and
+    zeroed the first problems' parameters.)"""
+    Nf, batch = 256, 4096
+    one = problems.c1_double_integrator(1, N=Nf)
+    bt = altro_amd.Batch(Nf, 12, 4, batch)
+    bt.set_dynamics(one["A"][0, :1], one["B"][0, :1], None, k_stride_zero=True, batch_stride_zero=True)
+    Qd = np.stack([np.ones(12), 100.0 * np.ones(12)])
+    bt.set_tracking_cost(Qd, np.full((1, 4), 1e-2), np.zeros((2, 12)), np.zeros((1, 4)), k_stride_zero=True, batch_stride_zero=True)
+    bt.set_initial_state(2.0 * problems.uniform01((batch, 12), 21) - 1.0)
+    bt.set_input_guess(np.zeros((1, 1, 4)), k_stride_zero=True, batch_stride_zero=True)
+    res = bt.ilqr_solve(iterations_max=10)
+    assert (res["status"] == 0).all()
+    assert (res["iterations"] == 1).all()
+    assert (res["alpha"] == 1.0).all()
+    assert res["stationarity"].max() < 1e-10
+    assert res["sweeps"] == 1
