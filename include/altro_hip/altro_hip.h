@@ -149,7 +149,14 @@ int altro_hip_get_status(altro_hip_batch* h, int* status);      /* [batch]      
 int altro_hip_get_qblocks(altro_hip_batch* h, double* qblocks);
 
 
-/* ---- the iLQR loop around the sweep (plan LANE shapes: BASELINE.json configs[2], [3]) ------------- */
+/* ---- the iLQR loop around the sweep ------------------------------------------------------------------
+ * Plan LANE (n <= 6: BASELINE.json configs[2], [3]): nonlinear dynamics from a compiled-in device model
+ * (altro_hip_set_model), constraint blocks, MPC operations.
+ * Plan MFMA16 ((n, m) = (12, 4): configs[1], [4]): dynamics are DATA -- the A, B, f given to
+ * altro_hip_set_dynamics, the reference's SetLinearDynamics path (knotpoint_data.cpp:123-142, :406-419,
+ * :710-719) -- with the tracking cost below; no altro_hip_set_model.  From altro_hip_set_tracking_cost on, the
+ * backward sweep of such a handle ignores f, as the reference's expansion does (f_.setZero(), :416), while the
+ * rollout keeps it.  Constraints and the regularisation schedule are plan-LANE features.               */
 /* Device model standing in for SetExplicitDynamics' host callbacks (altro_solver.cpp:68-81).        */
 int altro_hip_set_model(altro_hip_batch* h, int model, float timestep, int bicycle_frame,
                         double bicycle_length, double bicycle_lr);
