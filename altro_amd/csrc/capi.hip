@@ -517,8 +517,11 @@ int ilqr_launch(altro_hip_batch* h, int which, IlqrArgs<T> a) {
   return 0;
 }
 template <typename S>
-int wave_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int want_deriv, double alpha_const) {
+int wave_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int want_deriv, double alpha_const, int mode) {
   IlqrWaveArgs<S> a;
+  a.al.knots = h->al_d_knots; a.al.G = (const S*)h->al_d_G; a.al.g = (const S*)h->al_d_g; a.al.z = (S*)h->al_d_z;
+  a.al.enabled = h->al_defs.empty() ? 0 : 1;
+  a.mode = mode;
   a.dyn = (const S*)h->m_in; a.dyn_bs = h->m_st.in_bs; a.dyn_ks = h->m_st.in_ks;
   a.cin = (S*)h->m_cin; a.cin_bs = h->m_st.cin_bs; a.cin_ks = h->m_st.cin_ks;
   a.term = (S*)h->m_term; a.out = (const S*)h->m_out; a.out_bs = h->m_st.out_bs; a.out_ks = h->m_st.out_ks;
@@ -528,17 +531,17 @@ int wave_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int
   a.phi = h->i_phi; a.dphi = h->i_dphi; a.prob = h->i_prob; a.N = h->N; a.batch = h->batch;
   a.want_derivative = want_deriv; a.alpha_const = alpha_const;
   const int rc = ilqr_wave_launch_kernel<S>(h->stream, which, a);
-  if (rc == 1) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "operation %d is not available on plan MFMA16 (constraints are a plan-LANE feature)", which);
+  if (rc == 1) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "operation %d is not available on plan MFMA16", which);
   if (rc) return fail(ALTRO_HIP_ERR_HIP, "iLQR kernel launch failed");
   return 0;
 }
 int ilqr_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int want_deriv, double alpha_const,
              int mode = EXPAND_GRADIENT | EXPAND_HESSIAN) {
-  if (h->plan == ALTRO_HIP_PLAN_MFMA16)   // linear dynamics, constant cost Hessian: "expand" = the cost gradient
-    return h->dtype == ALTRO_HIP_F64 ? wave_run<double>(h, which, use_alpha, use_active, want_deriv, alpha_const)
-                                     : wave_run<float>(h, which, use_alpha, use_active, want_deriv, alpha_const);
   int rc = al_upload(h);
   if (rc) return rc;
+  if (h->plan == ALTRO_HIP_PLAN_MFMA16)   // linear dynamics: "expand" = cost gradient (+ AL Hessian terms when constrained)
+    return h->dtype == ALTRO_HIP_F64 ? wave_run<double>(h, which, use_alpha, use_active, want_deriv, alpha_const, mode)
+                                     : wave_run<float>(h, which, use_alpha, use_active, want_deriv, alpha_const, mode);
   if (h->dtype == ALTRO_HIP_F64) {
     auto a = ilqr_args<double>(h, use_alpha, use_active, want_deriv, alpha_const);
     a.mode = mode;
@@ -736,7 +739,6 @@ int altro_hip_batch_create(altro_hip_batch** out, int N, int n, int m, int batch
     ALLOC(h->l_x0, B * n * E);
     ALLOC(h->l_nom, B * (N + 1) * (n + m) * E);
     ALLOC(h->l_cost, B * (N + 1) * (2 * n + 2 * m + 1) * E);
-    if (!rc) h->al_knots.assign((size_t)N + 1, AlKnot{});
     // on the handle's own (non-blocking) stream: a null-stream memset would race the first kernels launched on it
     if (!rc && hipMemsetAsync(h->l_xuy, 0, B * (N + 1) * z.e_xuy * E, h->stream) != hipSuccess) rc = fail(ALTRO_HIP_ERR_HIP, "memset failed");
     if (!rc && hipMemsetAsync(h->l_cost, 0, B * (N + 1) * (2 * n + 2 * m + 1) * E, h->stream) != hipSuccess) rc = fail(ALTRO_HIP_ERR_HIP, "memset failed");
@@ -766,6 +768,7 @@ int altro_hip_batch_create(altro_hip_batch** out, int N, int n, int m, int batch
     }
   }
   if (plan == ALTRO_HIP_PLAN_LANE || plan == ALTRO_HIP_PLAN_MFMA16) {   // per-problem control blocks of the iLQR loop
+    if (!rc) h->al_knots.assign((size_t)N + 1, AlKnot{});
     ALLOC(h->i_prob, B * sizeof(IlqrProb));
     ALLOC(h->i_alpha, B * 8);
     ALLOC(h->i_phi, B * 8);
@@ -1416,9 +1419,12 @@ int altro_hip_add_linear_constraint(altro_hip_batch* h, int k_first, int k_last,
   // ALTROSolver::SetConstraint (altro_solver.cpp:175-215) for c(x,u) = G [x;u] - g
   int rc = check(h);
   if (rc) return rc;
-  if (h->plan != ALTRO_HIP_PLAN_LANE) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "constraints need plan LANE");
+  if (h->plan != ALTRO_HIP_PLAN_LANE && h->plan != ALTRO_HIP_PLAN_MFMA16)
+    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "constraints need plan LANE or MFMA16");
   if (!G || !g) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "G and g are required");
   if (cone < CONE_EQUALITY || cone > CONE_SOC) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "unknown cone %d", cone);
+  if (cone == CONE_SOC && h->plan != ALTRO_HIP_PLAN_LANE)
+    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "second-order-cone blocks are a plan-LANE feature");
   const int pmax = cone == CONE_SOC ? AL_MAXSOC : AL_MAXP;
   if (p < 1 || p > pmax) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "constraint dimension %d outside [1, %d]", p, pmax);
   if (k_first < 0 || k_last > h->N || k_first > k_last)
@@ -1452,7 +1458,7 @@ int altro_hip_reset_duals(altro_hip_batch* h, double penalty) {
   // duals back to zero and every constraint's penalty to `penalty` (what a fresh Initialize leaves: 1)
   int rc = check(h);
   if (rc) return rc;
-  if (h->plan != ALTRO_HIP_PLAN_LANE) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "constraints need plan LANE");
+  if (h->plan != ALTRO_HIP_PLAN_LANE && h->plan != ALTRO_HIP_PLAN_MFMA16) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "constraints need plan LANE or MFMA16");
   if (!(penalty > 0.0)) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "penalty must be positive");
   if ((rc = al_upload(h))) return rc;
   const size_t E = h->dtype == ALTRO_HIP_F64 ? 8 : 4;
@@ -1468,7 +1474,7 @@ int altro_hip_get_duals(altro_hip_batch* h, int k, int slot, double* z) {
   // duals of constraint block `slot` of knot point k, [batch][p]
   int rc = check(h);
   if (rc) return rc;
-  if (h->plan != ALTRO_HIP_PLAN_LANE) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "constraints need plan LANE");
+  if (h->plan != ALTRO_HIP_PLAN_LANE && h->plan != ALTRO_HIP_PLAN_MFMA16) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "constraints need plan LANE or MFMA16");
   if ((rc = al_upload(h))) return rc;
   if (k < 0 || k > h->N || slot < 0 || slot >= h->al_knots[k].ncon || !z)
     return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "no constraint block %d at knot point %d", slot, k);

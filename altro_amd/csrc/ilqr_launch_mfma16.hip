@@ -15,11 +15,12 @@ static int wave_launch(hipStream_t stream, int which, const IlqrWaveArgs<S>& a) 
   switch (which) {
     case IK_ROLLOUT: hipLaunchKernelGGL(wave_rollout_kernel<S>, waves, b64, 0, stream, a); break;
     case IK_ACCEPT: hipLaunchKernelGGL(wave_accept_kernel<S>, flat, b256, 0, stream, a); break;
-    case IK_EXPAND: hipLaunchKernelGGL(wave_gradient_kernel<S>, flat, b256, 0, stream, a); break;
+    case IK_EXPAND: hipLaunchKernelGGL(wave_expand_kernel<S>, dim3((unsigned)((int64_t)a.batch * (a.N + 1))), b64, 0, stream, a); break;
+    case IK_DUAL: hipLaunchKernelGGL(wave_dual_update_kernel<S>, dim3((unsigned)((int64_t)a.batch * (a.N + 1))), b64, 0, stream, a); break;
     case IK_MERIT: hipLaunchKernelGGL(wave_merit_kernel<S>, waves, b64, 0, stream, a); break;
     case IK_STATIONARITY: hipLaunchKernelGGL(wave_stationarity_kernel<S>, waves, b64, 0, stream, a); break;
     case IK_SHIFT: hipLaunchKernelGGL(wave_shift_kernel<S>, dim3((a.batch * 16 + 255) / 256), b256, 0, stream, a); break;
-    default: return 1;   // no constraint kernels on this plan
+    default: return 1;
   }
   return hipGetLastError() == hipSuccess ? 0 : 2;
 }

@@ -8,7 +8,9 @@
 //   SolverImpl::MeritFunction     solver.cpp:273-355   -> wave_merit_kernel
 //   SolverImpl::Stationarity      solver.cpp:207-222   -> wave_stationarity_kernel
 // The line search, convergence logic and sweep sequencing are the plan-independent kernels of
-// ilqr_loop_kernels.hip driven by altro_hip_ilqr_solve.  Constraints (al_lane.hip) are a plan-LANE feature.
+// ilqr_loop_kernels.hip driven by altro_hip_ilqr_solve.  Linear constraint blocks c = G [x;u] - g in the zero /
+// identity / orthant cones (knotpoint_data.cpp:489-613 restricted to cones whose projection is diagonal) are
+// evaluated by lanes 48..55 (one constraint row each); second-order cones are a plan-LANE feature.
 //
 // The linear dynamics make the expansion trivial -- A, B are the data, and the reference zeroes the affine term
 // of the EXPANSION (f_.setZero(), knotpoint_data.cpp:416) while the rollout keeps it -- so the backward sweep runs
@@ -38,6 +40,61 @@ __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
   return v;
+}
+
+// Constraint rows of knot point k for this wave's problem.  Lane `row_lane` (48 + i, i < 8) owns row i of each of
+// the (at most two) blocks: value, estimated / projected dual, AL cost share, violation; it publishes
+//   jv[c * 8 + i] = mask * z_proj   (gradient factor J^T z_proj, cones.cpp:153-178 are diagonal here)
+//   mk[c * 8 + i] = mask            (Gauss-Newton factor)
+// to LDS for the lanes that own gradient / Hessian entries.  xs / us: the point, in LDS.  With dual_update the
+// projected dual becomes the dual (knotpoint_data.cpp:503-510).  Must be called by all lanes (no barrier inside).
+template <typename S>
+__device__ __forceinline__ void wave_al_rows(const AlTable<S>& t, int k, int b, int64_t B, const double* xs, const double* us,
+                                             bool terminal, double rho_est, int lane, double* jv, double* mk, double& cost,
+                                             double& viol, bool dual_update) {
+  const AlKnot ALTRO_CONST_AS& kn = *(const AlKnot ALTRO_CONST_AS*)(t.knots + k);
+  const int i = lane - 48;
+  const bool row_lane = (i >= 0 && i < AL_MAXP);
+#pragma unroll
+  for (int c = 0; c < AL_MAXC; ++c) {
+    double jvv = 0.0, mkv = 0.0;
+    if (c < kn.ncon && row_lane && i < kn.p[c]) {
+      const int p = kn.p[c], cone = kn.cone[c];
+      const S* G = t.G + kn.G_off[c];
+      double s = 0.0;
+#pragma unroll
+      for (int e = 0; e < 12; ++e) s += (double)G[i + e * p] * xs[e];
+      if (!terminal) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += (double)G[i + (12 + e) * p] * us[e];
+      }
+      const double gi = kn.g_per_problem[c] ? (double)t.g[kn.g_off[c] + (int64_t)i * B + b] : (double)t.g[kn.g_off[c] + i];
+      const double val = s - gi;
+      S* zp_ = t.z + (int64_t)(kn.z_off[c] + i) * B + b;
+      const double ze = (double)*zp_ - rho_est * val;
+      double zp = 0.0;
+      if (cone == CONE_EQUALITY) { zp = ze; mkv = 1.0; viol = fmax(viol, fabs(val)); }
+      else if (cone == CONE_INEQUALITY) { zp = fmin(0.0, ze); mkv = (ze <= 0.0) ? 1.0 : 0.0; viol = fmax(viol, fabs(fmin(0.0, val) - val)); }
+      cost += zp * zp / (2.0 * rho_est);
+      jvv = mkv * zp;
+      if (dual_update) *zp_ = (S)zp;
+    }
+    if (row_lane) { jv[c * AL_MAXP + i] = jvv; mk[c * AL_MAXP + i] = mkv; }
+  }
+}
+// sum_c sum_i G_c[i][e] * w[c * 8 + i]  for column e of the constraint Jacobians of knot point k
+template <typename S>
+__device__ __forceinline__ double wave_al_col(const AlTable<S>& t, int k, int e, const double* w) {
+  const AlKnot ALTRO_CONST_AS& kn = *(const AlKnot ALTRO_CONST_AS*)(t.knots + k);
+  double s = 0.0;
+#pragma unroll
+  for (int c = 0; c < AL_MAXC; ++c)
+    if (c < kn.ncon) {
+      const int p = kn.p[c];
+      const S* G = t.G + kn.G_off[c];
+      for (int i = 0; i < p; ++i) s += (double)G[i + e * p] * w[c * AL_MAXP + i];
+    }
+  return s;
 }
 
 // x_0 = x0 ; x_{k+1} = A x + B u + f on the candidate trajectory (u_ is the guess already stored there)
@@ -86,47 +143,104 @@ __global__ void wave_accept_kernel(IlqrWaveArgs<S> a) {
   }
 }
 
-// lx, lu at the candidate point into the backward sweep's [q r] slot (and q_N of TERM)
+// Expansion at the candidate point, one wave per (problem, knot point).
+//   EXPAND_GRADIENT: lx, lu (+ AL terms) into the backward sweep's [q r] slot (q_N of TERM at k = N)
+//   EXPAND_HESSIAN : [Q H^T; H R] = diag(Qd, Rd) + rho G^T M G  (M = the projection's diagonal Jacobian) into the
+//                    Q rows / [H R] slots -- only launched when constraint blocks exist; without them the blocks
+//                    set by altro_hip_set_tracking_cost stay as they are.
 template <typename S>
-__global__ void wave_gradient_kernel(IlqrWaveArgs<S> a) {
-  const int64_t total = (int64_t)a.batch * (a.N + 1) * 16;
-  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-    const int e = (int)(t % 16);
-    const int64_t r = t / 16;
-    const int b = (int)(r % a.batch);
-    const int k = (int)(r / a.batch);
-    if (a.active && !a.active[b]) continue;
-    const S* c = a.cand + (size_t)b * a.xuy_bs + (size_t)k * a.xuy_ks;
-    const S* cp = a.costp + ((size_t)k * a.batch + b) * MF_COSTP;
+__global__ __launch_bounds__(64) void wave_expand_kernel(IlqrWaveArgs<S> a) {
+  __shared__ double xs[12], us[4], jv[AL_MAXC * AL_MAXP], mk[AL_MAXC * AL_MAXP];
+  const int lane = threadIdx.x;
+  const int64_t wk = blockIdx.x;
+  const int b = (int)(wk % a.batch), k = (int)(wk / a.batch);
+  if (k > a.N) return;
+  if (a.active && !a.active[b]) return;
+  const bool terminal = k == a.N;
+  const bool grad = (a.mode & EXPAND_GRADIENT) != 0, hess = (a.mode & EXPAND_HESSIAN) != 0;
+  const S* c = a.cand + (size_t)b * a.xuy_bs + (size_t)k * a.xuy_ks;
+  const S* cp = a.costp + ((size_t)k * a.batch + b) * MF_COSTP;
+  if (lane < 12) xs[lane] = (double)c[lane];
+  if (lane >= 12 && lane < 16) us[lane - 12] = terminal ? 0.0 : (double)c[24 + lane - 12];
+  __syncthreads();
+  const bool al = a.al.enabled != 0;
+  if (al) {
+    double cost = 0.0, viol = 0.0;
+    wave_al_rows<S>(a.al, k, b, a.batch, xs, us, terminal, a.prob[b].rho_est, lane, jv, mk, cost, viol, false);
+  }
+  __syncthreads();
+  if (grad && lane < 16) {
+    const int e = lane;
     if (e < 12) {
-      const double lx = (double)cp[e] * (double)c[e] + (double)cp[16 + e];
-      if (k < a.N) a.cin[(size_t)b * a.cin_bs + (size_t)k * a.cin_ks + MF_OFF_QR + e] = (S)lx;
+      double lx = (double)cp[e] * xs[e] + (double)cp[16 + e];
+      if (al) lx -= wave_al_col<S>(a.al, k, e, jv);
+      if (!terminal) a.cin[(size_t)b * a.cin_bs + (size_t)k * a.cin_ks + MF_OFF_QR + e] = (S)lx;
       else a.term[(size_t)b * MF_TERM + 144 + e] = (S)lx;
-    } else if (k < a.N) {
-      const int cidx = e - 12;
-      const double lu = (double)cp[12 + cidx] * (double)c[24 + cidx] + (double)cp[28 + cidx];
+    } else if (!terminal) {
+      double lu = (double)cp[e] * us[e - 12] + (double)cp[16 + e];
+      if (al) lu -= wave_al_col<S>(a.al, k, e, jv);
       a.cin[(size_t)b * a.cin_bs + (size_t)k * a.cin_ks + MF_OFF_QR + e] = (S)lu;
+    }
+  }
+  if (hess && al) {   // 16 x 16 tile, 4 entries per lane: row r = lane / 4 (+ 0), columns 4 (lane % 4) + 0..3 ... plain loop
+    const double rho = a.prob[b].rho;
+    const AlKnot ALTRO_CONST_AS& kn = *(const AlKnot ALTRO_CONST_AS*)(a.al.knots + k);
+    for (int t = lane; t < 256; t += 64) {
+      const int r = t / 16, cc = t % 16;
+      if (terminal && (r >= 12 || cc >= 12)) continue;
+      if (r < 12 && cc >= 12) continue;     // the H^T block is not stored
+      double v = (r == cc) ? (double)cp[r] : 0.0;   // costp[0..15] = Qd | Rd
+      double s = 0.0;
+      for (int cidx = 0; cidx < kn.ncon; ++cidx) {
+        const int p = kn.p[cidx];
+        const S* G = a.al.G + kn.G_off[cidx];
+        for (int i = 0; i < p; ++i) s += (mk[cidx * AL_MAXP + i] * (double)G[i + r * p]) * (mk[cidx * AL_MAXP + i] * (double)G[i + cc * p]);
+      }
+      v += rho * s;
+      if (terminal) a.term[(size_t)b * MF_TERM + r * 12 + cc] = (S)v;
+      else if (r < 12) a.cin[(size_t)b * a.cin_bs + (size_t)k * a.cin_ks + MF_OFF_Q + r * 12 + cc] = (S)v;
+      else a.cin[(size_t)b * a.cin_bs + (size_t)k * a.cin_ks + MF_OFF_HR + (r - 12) * 16 + cc] = (S)v;
     }
   }
 }
 
-// MeritFunction (solver.cpp:273-355) for linear dynamics and the diagonal tracking cost
+// DualUpdate (knotpoint_data.cpp:503-510) for the problems whose sweep asked for it, one wave per (problem, knot point)
+template <typename S>
+__global__ __launch_bounds__(64) void wave_dual_update_kernel(IlqrWaveArgs<S> a) {
+  __shared__ double xs[12], us[4], jv[AL_MAXC * AL_MAXP], mk[AL_MAXC * AL_MAXP];
+  const int lane = threadIdx.x;
+  const int64_t wk = blockIdx.x;
+  const int b = (int)(wk % a.batch), k = (int)(wk / a.batch);
+  if (k > a.N || !a.al.enabled) return;
+  if (!a.prob[b].dual) return;
+  const bool terminal = k == a.N;
+  const S* c = a.cand + (size_t)b * a.xuy_bs + (size_t)k * a.xuy_ks;
+  if (lane < 12) xs[lane] = (double)c[lane];
+  if (lane >= 12 && lane < 16) us[lane - 12] = terminal ? 0.0 : (double)c[24 + lane - 12];
+  __syncthreads();
+  double cost = 0.0, viol = 0.0;
+  wave_al_rows<S>(a.al, k, b, a.batch, xs, us, terminal, a.prob[b].rho_est, lane, jv, mk, cost, viol, true);
+}
+
+// MeritFunction (solver.cpp:273-355) for linear dynamics and the diagonal tracking cost (+ AL terms)
 template <typename S>
 __global__ __launch_bounds__(64) void wave_merit_kernel(IlqrWaveArgs<S> a) {
-  __shared__ double xs[12], dxs[12], das[12], us[4], dus[4];
+  __shared__ double xs[12], dxs[12], das[12], us[4], dus[4], jv[AL_MAXC * AL_MAXP], mk[AL_MAXC * AL_MAXP];
   const int b = blockIdx.x, lane = threadIdx.x;
   if (b >= a.batch) return;
   if (a.active && !a.active[b]) return;
   const int N = a.N;
   const double alpha = a.alpha ? a.alpha[b] : a.alpha_const;
   const bool deriv = a.want_derivative != 0;
+  const bool al = a.al.enabled != 0;
+  const double rho = al ? a.prob[b].rho : 1.0;   // CalcCost refreshes the projected duals with the current penalty
   const int grp = lane >> 4, sub = lane & 15;
   const bool is_x = lane < 12, is_u = (grp == 1 && sub < 4), is_y = (grp == 2 && sub < 12);
   const int i = sub < 12 ? sub : 11;       // row of Z / [P|p]
   const int ia = sub < 4 ? sub : 3;        // row of Kt
   double x = (double)a.x0[(size_t)b * 12 + i];
   double dxda = 0.0;
-  double J = 0.0, dJ = 0.0;                // per-lane partial sums of phi and dphi
+  double J = 0.0, dJ = 0.0, viol = 0.0;    // per-lane partial sums of phi and dphi
   for (int k = 0; k < N; ++k) {
     const S* z = a.dyn + (size_t)b * a.dyn_bs + (size_t)k * a.dyn_ks;
     const S* o = a.out + (size_t)b * a.out_bs + (size_t)k * a.out_ks;
@@ -147,11 +261,6 @@ __global__ __launch_bounds__(64) void wave_merit_kernel(IlqrWaveArgs<S> a) {
       c[24 + ia] = (S)u;
       const double Rd = (double)cp[12 + ia], rr = (double)cp[28 + ia];
       J += 0.5 * (u * (Rd * u)) + rr * u;
-      if (deriv) {
-        const double lu = Rd * u + rr;
-        ci[MF_OFF_QR + 12 + ia] = (S)lu;
-        dJ += lu * du;
-      }
     }
     if (is_y) {   // y_ = P dx + p
       double s = 0.0;
@@ -172,11 +281,16 @@ __global__ __launch_bounds__(64) void wave_merit_kernel(IlqrWaveArgs<S> a) {
       const double Qd = (double)cp[i], q = (double)cp[16 + i];
       J += 0.5 * (x * (Qd * x)) + q * x;
       if (lane == 0) J += (double)cp[32];
-      if (deriv) {
-        const double lx = Qd * x + q;
-        ci[MF_OFF_QR + i] = (S)lx;
-        dJ += lx * dxda;
-      }
+    }
+    if (al) wave_al_rows<S>(a.al, k, b, a.batch, xs, us, false, rho, lane, jv, mk, J, viol, false);
+    __syncthreads();
+    if (deriv && lane < 16) {   // lx (lanes 0..11) and lu (lanes 12..15) with the AL terms; dphi
+      const int e = lane;
+      const double pt = e < 12 ? x : us[e - 12];
+      double l = (double)cp[e] * pt + (double)cp[16 + e];       // costp: Qd | Rd | q | r line up with [x; u]
+      if (al) l -= wave_al_col<S>(a.al, k, e, jv);
+      ci[MF_OFF_QR + e] = (S)l;
+      dJ += l * (e < 12 ? dxda : dus[e - 12]);
     }
     __syncthreads();
     if (is_x) { x = xn; dxda = dxn; }
@@ -187,29 +301,34 @@ __global__ __launch_bounds__(64) void wave_merit_kernel(IlqrWaveArgs<S> a) {
     const S* on = a.outn + (size_t)b * MF_TERM;
     S* c = a.cand + (size_t)b * a.xuy_bs + (size_t)N * a.xuy_ks;
     if (is_x) {
+      xs[lane] = x;
       dxs[lane] = x - (double)nm[lane];
       c[lane] = (S)x;
       const double Qd = (double)cp[i], q = (double)cp[16 + i];
       J += 0.5 * (x * (Qd * x)) + q * x;
       if (lane == 0) J += (double)cp[32];
-      if (deriv) {
-        const double lx = Qd * x + q;
-        a.term[(size_t)b * MF_TERM + 144 + i] = (S)lx;
-        dJ += lx * dxda;
-      }
     }
     __syncthreads();
+    if (al) wave_al_rows<S>(a.al, N, b, a.batch, xs, us, true, rho, lane, jv, mk, J, viol, false);
     if (is_y) {
       double s = 0.0;
 #pragma unroll
       for (int j = 0; j < 12; ++j) s += (double)on[i * 13 + j] * dxs[j];
       c[12 + i] = (S)(s + (double)on[i * 13 + 12]);
     }
+    __syncthreads();
+    if (deriv && is_x) {
+      double lx = (double)cp[i] * x + (double)cp[16 + i];
+      if (al) lx -= wave_al_col<S>(a.al, N, i, jv);
+      a.term[(size_t)b * MF_TERM + 144 + i] = (S)lx;
+      dJ += lx * dxda;
+    }
   }
   const double phi = wave_sum(J), dphi = wave_sum(dJ);
   if (lane == 0) {
     a.phi[b] = phi;
     if (deriv) a.dphi[b] = dphi;
+    if (al) a.prob[b].rho_est = rho;
   }
 }
 
@@ -238,7 +357,23 @@ __global__ __launch_bounds__(64) void wave_stationarity_kernel(IlqrWaveArgs<S> a
     res = fmax(res, fabs((double)a.term[(size_t)b * MF_TERM + 144 + lane] -
                          (double)a.cand[(size_t)b * a.xuy_bs + (size_t)N * a.xuy_ks + 12 + lane]));
   res = wave_max(res);
-  if (lane == 0) { a.prob[b].stationarity = res; a.prob[b].feasibility = 0.0; }
+  // Feasibility (solver.cpp:224-231) of the candidate trajectory
+  double viol = 0.0;
+  if (a.al.enabled) {
+    __shared__ double xs[12], us[4], jv[AL_MAXC * AL_MAXP], mk[AL_MAXC * AL_MAXP];
+    const double rho = a.prob[b].rho;
+    for (int k = 0; k <= N; ++k) {
+      const S* c = a.cand + (size_t)b * a.xuy_bs + (size_t)k * a.xuy_ks;
+      __syncthreads();
+      if (lane < 12) xs[lane] = (double)c[lane];
+      if (lane >= 12 && lane < 16) us[lane - 12] = k < N ? (double)c[24 + lane - 12] : 0.0;
+      __syncthreads();
+      double cost = 0.0;
+      wave_al_rows<S>(a.al, k, b, a.batch, xs, us, k == N, rho, lane, jv, mk, cost, viol, false);
+    }
+    viol = wave_max(viol);
+  }
+  if (lane == 0) { a.prob[b].stationarity = res; a.prob[b].feasibility = viol; }
 }
 
 // ALTROSolver::ShiftTrajectory (altro_solver.cpp:283-293) on the candidate records

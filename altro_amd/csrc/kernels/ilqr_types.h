@@ -92,6 +92,8 @@ struct IlqrWaveArgs {
   IlqrProb* prob;
   int N, batch, want_derivative;
   double alpha_const;
+  AlTable<S> al;
+  int mode;                                  // expand kernel: EXPAND_GRADIENT | EXPAND_HESSIAN
 };
 
 template <typename S>

@@ -130,8 +130,6 @@ def test_c1_double_integrator_ilqr():
         assert status == 0 and iters == res["iterations"][b]
         np.testing.assert_allclose(x[b], s.get("x"), rtol=1e-9, atol=1e-9)
         np.testing.assert_allclose(u[b], s.get("u"), rtol=1e-8, atol=1e-8)
-    with pytest.raises(altro_amd.AltroHipError):
-        bt.add_linear_constraint(0, 1, altro_amd.CONE_EQUALITY, np.zeros((1, 16)), np.zeros(1))   # plan-LANE feature
 
 
 def test_full_size_c1_ilqr_solve():
@@ -153,3 +151,52 @@ def test_full_size_c1_ilqr_solve():
     assert (res["alpha"] == 1.0).all()
     assert res["stationarity"].max() < 1e-10
     assert res["sweeps"] == 1
+
+
+def _constrained_problem(batch):
+    p = make_problem(batch, True)
+    w = n + m
+    Gb = np.zeros((2 * m, w)); Gb[:m, n:] = np.eye(m); Gb[m:, n:] = -np.eye(m)      # |u| <= 0.3 at every k < N
+    Gs = np.zeros((2, w)); Gs[0, 1] = 1.0; Gs[1, 2] = -1.0                            # x1 <= 1.2, -x2 <= 1.2 at 1 <= k < N
+    Ge = np.zeros((1, w)); Ge[0, 12] = 1.0                                            # u_0[0] == 0.05
+    blocks = [(0, N - 1, problems.CONE_INEQUALITY, Gb, np.full(2 * m, 0.3)),
+              (1, N - 1, problems.CONE_INEQUALITY, Gs, np.array([1.2, 1.2])),
+              (0, 0, problems.CONE_EQUALITY, Ge, np.array([0.05]))]
+    return p, blocks
+
+
+def test_constrained_lq_solve_mfma16():
+    """Linear MPC-style problem at (12, 4): input bounds + state half-spaces (INEQUALITY) and an EQUALITY block on
+    the first input, through the AL loop on plan MFMA16, against the oracle per problem: same status / iterations / number of
+    dual updates / feasibility, same trajectory."""
+    batch = 40
+    p, blocks = _constrained_problem(batch)
+    bt = make_hip(p)
+    for (k0, k1, cone, G, g) in blocks:
+        bt.add_linear_constraint(k0, k1, cone, G, g)
+    with pytest.raises(altro_amd.AltroHipError):
+        bt.add_linear_constraint(0, 0, altro_amd.CONE_SOC, np.zeros((3, 16)), np.zeros(3))   # SOC: plan LANE only
+    res = bt.ilqr_solve(iterations_max=60, penalty_initial=1.0, penalty_scaling=10.0)
+    x, u = bt.get_nominal()
+    nconv = 0
+    for b in [0, 17, 39]:
+        s = make_oracle(p, b)
+        for (k0, k1, cone, G, g) in blocks:
+            for k in range(k0, k1 + 1):
+                s.add_linear_constraint(k, cone, G, g)
+        s.L.oracle_ilqr_initialize(s.h)
+        for k in range(N):
+            s.L.oracle_ilqr_set_input(s.h, k, np.ascontiguousarray(p["u0"][b, k]))
+        s.set_penalty(1.0, 10.0)
+        s.L.oracle_ilqr_set_options(s.h, 60, 1e-4, 1e-4, 1e-8, 0)
+        status, iters, log = s.solve()
+        assert res["status"][b] == status and res["iterations"][b] == iters, (b, res["status"][b], status, res["iterations"][b], iters)
+        if status != 0:
+            continue
+        nconv += 1
+        assert abs(res["feasibility"][b] - log[iters - 1, 6]) <= 1e-9 + 1e-3 * log[iters - 1, 6]
+        np.testing.assert_allclose(x[b], s.get("x"), rtol=1e-7, atol=1e-7)
+        np.testing.assert_allclose(u[b], s.get("u"), rtol=1e-6, atol=1e-6)
+        assert np.abs(u[b]).max() <= 0.3 + 2e-4 and abs(u[b][0, 0] - 0.05) < 2e-4
+    assert nconv >= 2
+    assert (res["dual_updates"] > 0).all()
