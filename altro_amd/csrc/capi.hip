@@ -1397,10 +1397,25 @@ int altro_hip_get_knot(altro_hip_batch* h, int k, double* x, double* u) {
   // x [batch][n], u [batch][m] (u must be NULL at k = N)
   int rc = check(h);
   if (rc) return rc;
-  if (h->plan != ALTRO_HIP_PLAN_LANE) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "plan LANE only");
   const int n = h->n, m = h->m, N = h->N;
   if (k < 0 || k > N) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "knot point %d outside [0, %d] (ErrorCodes::BadIndex)", k, N);
   if (u && k == N) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "no input at the terminal knot point");
+  if (h->plan == ALTRO_HIP_PLAN_MFMA16) {
+    if (!h->m_nom) return fail(ALTRO_HIP_ERR_NOT_SET, "altro_hip_set_tracking_cost has not been called");
+    const int64_t B = h->batch;
+    if (x) {
+      rc = h->dtype == ALTRO_HIP_F64
+               ? aos_get<double>(h, x, (const double*)h->m_nom + (size_t)k * B * MF_NOM, MF_NOM, B * MF_NOM, n, 1)
+               : aos_get<float>(h, x, (const float*)h->m_nom + (size_t)k * B * MF_NOM, MF_NOM, B * MF_NOM, n, 1);
+      if (rc) return rc;
+    }
+    if (u)
+      rc = h->dtype == ALTRO_HIP_F64
+               ? aos_get<double>(h, u, (const double*)h->m_nom + (size_t)k * B * MF_NOM + 12, MF_NOM, B * MF_NOM, m, 1)
+               : aos_get<float>(h, u, (const float*)h->m_nom + (size_t)k * B * MF_NOM + 12, MF_NOM, B * MF_NOM, m, 1);
+    return rc;
+  }
+  if (h->plan != ALTRO_HIP_PLAN_LANE) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "plans LANE and MFMA16 only");
   const size_t E = h->dtype == ALTRO_HIP_F64 ? 8 : 4;
   const char* rec = (const char*)h->l_nom + (size_t)k * (n + m) * h->batch * E;
   if (x) {

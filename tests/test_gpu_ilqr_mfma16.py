@@ -200,3 +200,47 @@ def test_constrained_lq_solve_mfma16():
         assert np.abs(u[b]).max() <= 0.3 + 2e-4 and abs(u[b][0, 0] - 0.05) < 2e-4
     assert nconv >= 2
     assert (res["dual_updates"] > 0).all()
+
+
+def test_receding_horizon_ops_mfma16():
+    """The MPC caller pattern of test/bicycle_test.cpp:302-337 on the (12, 4) plan: solve, take u_0, move the linear
+    cost terms (UpdateLinearCosts), SetInitialState, ShiftTrajectory -- with input bounds -- against the oracle
+    running each problem alone."""
+    batch, nsim = 6, 3
+    p, blocks = _constrained_problem(batch)
+    blocks = blocks[:1]                       # input bounds only
+    bt = make_hip(p)
+    for (k0, k1, cone, G, g) in blocks:
+        bt.add_linear_constraint(k0, k1, cone, G, g)
+    ors = []
+    for b in range(batch):
+        s = make_oracle(p, b)
+        for (k0, k1, cone, G, g) in blocks:
+            for k in range(k0, k1 + 1):
+                s.add_linear_constraint(k, cone, G, g)
+        s.L.oracle_ilqr_initialize(s.h)
+        for k in range(N):
+            s.L.oracle_ilqr_set_input(s.h, k, np.ascontiguousarray(p["u0"][b, k]))
+        s.set_penalty(1.0, 10.0)
+        s.L.oracle_ilqr_set_options(s.h, 60, 1e-4, 1e-4, 1e-8, 0)
+        ors.append(s)
+    xs = p["x0"].copy()
+    for it in range(nsim):
+        res = bt.ilqr_solve(iterations_max=60, penalty_initial=1.0, penalty_scaling=10.0)
+        xk, u0 = bt.get_knot(0)
+        x1, _ = bt.get_knot(1)
+        qnew = -(p["Qd"] * (p["xref"] + 0.05 * (it + 1)))          # a moving reference: q = -Qd xref'
+        cnew = 0.1 * (it + 1) * np.ones((batch, N + 1))
+        for b in range(batch):
+            s = ors[b]
+            status, iters, log = s.solve()
+            assert res["status"][b] == status and res["iterations"][b] == iters, (it, b)
+            np.testing.assert_allclose(u0[b], s.get("u")[0], rtol=1e-6, atol=1e-6)
+            np.testing.assert_allclose(x1[b], s.get("x")[1], rtol=1e-7, atol=1e-7)
+            for k in range(N + 1):
+                s.L.oracle_ilqr_update_linear_costs(s.h, k, np.ascontiguousarray(qnew[b, k]).ctypes.data, None, float(cnew[b, k]))
+            s.L.oracle_ilqr_set_initial_state(s.h, np.ascontiguousarray(x1[b]))
+            s.L.oracle_ilqr_shift_trajectory(s.h)
+        bt.update_linear_costs(qnew, None, cnew, 0, N)
+        bt.set_initial_state(x1)
+        bt.shift_trajectory()
