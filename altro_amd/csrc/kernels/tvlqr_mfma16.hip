@@ -347,7 +347,13 @@ __global__ __launch_bounds__(64, 4) void mfma16_backward_kernel(Mfma16Args<S> a)
 // store in the loop is unconditional (exact vmcnt waits, see the backward kernel).  ~85 instructions
 // per knot point instead of ~190 for the DPP-butterfly version: the kernel becomes HBM-bound.
 // ------------------------------------------------------------------------------------------------
-constexpr int MF_FWD_LDS = 192 + 208 + 12;   // Z | OUT record | f
+// LDS image of one knot point: Z with its rows padded to 17 doubles | OUT record | f.  Unpadded, the 12 lanes that
+// each read one row of Z (stride 16 doubles = 128 B = all 32 banks) would hit the same bank pair: a 12-way conflict
+// on every ds_read_b64; the 13-double rows of Kt / [P|p] are conflict-free as they are.
+constexpr int MF_FWD_ZLD = 17;
+constexpr int MF_FWD_OUT0 = 12 * MF_FWD_ZLD;          // 204
+constexpr int MF_FWD_F0 = MF_FWD_OUT0 + 208;          // 412
+constexpr int MF_FWD_LDS = MF_FWD_F0 + 12;
 
 struct Mfma16FwdRegs {   // one knot point's coalesced loads (8 doubles / lane)
   double z[3], o[4], f;
@@ -364,11 +370,11 @@ __device__ __forceinline__ void mfma16_fwd_load(Mfma16FwdRegs& r, const S* __res
 }
 __device__ __forceinline__ void mfma16_fwd_stage(const Mfma16FwdRegs& r, double* __restrict__ L, int lane) {
 #pragma unroll
-  for (int c = 0; c < 3; ++c) L[c * 64 + lane] = r.z[c];
+  for (int c = 0; c < 3; ++c) L[c * 4 * MF_FWD_ZLD + (lane >> 4) * MF_FWD_ZLD + (lane & 15)] = r.z[c];   // row 4c + lane/16
 #pragma unroll
-  for (int c = 0; c < 3; ++c) L[192 + c * 64 + lane] = r.o[c];
-  L[192 + 192 + (lane & 15)] = r.o[3];
-  L[400 + (lane < 12 ? lane : 11)] = r.f;
+  for (int c = 0; c < 3; ++c) L[MF_FWD_OUT0 + c * 64 + lane] = r.o[c];
+  L[MF_FWD_OUT0 + 192 + (lane & 15)] = r.o[3];
+  L[MF_FWD_F0 + (lane < 12 ? lane : 11)] = r.f;
 }
 __device__ __forceinline__ double readlane_f64(double v, int src_lane) {
   union { double d; int i[2]; } in, out;
@@ -393,7 +399,7 @@ __global__ __launch_bounds__(64) void mfma16_forward_kernel(Mfma16Args<S> a) {
   const int grp = lane >> 4;
   const int sub = lane & 15;
   const int row = (grp == 1) ? (sub < 4 ? sub : 3) : (sub < 12 ? sub : 11);
-  const int row_base = (grp == 0) ? 16 * row : ((grp == 1) ? 192 + 13 * row : 192 + 52 + 13 * row);
+  const int row_base = (grp == 0) ? MF_FWD_ZLD * row : ((grp == 1) ? MF_FWD_OUT0 + 13 * row : MF_FWD_OUT0 + 52 + 13 * row);
   const int out_off = (grp == 0) ? row : ((grp == 1) ? 24 + row : 12 + row);   // x | y | u inside a record
   const bool is_x = (grp == 0), is_u = (grp == 1);
 
@@ -424,7 +430,7 @@ __global__ __launch_bounds__(64) void mfma16_forward_kernel(Mfma16Args<S> a) {
       double rd[16];
 #pragma unroll
       for (int j = 0; j < 16; ++j) rd[j] = lds[row_base + j];
-      const double fi = lds[400 + row];
+      const double fi = lds[MF_FWD_F0 + row];
       // x_k broadcast from lanes 0..11 through SGPRs
       double xs[12];
 #pragma unroll
