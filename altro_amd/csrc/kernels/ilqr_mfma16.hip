@@ -222,10 +222,47 @@ __global__ __launch_bounds__(64) void wave_dual_update_kernel(IlqrWaveArgs<S> a)
   wave_al_rows<S>(a.al, k, b, a.batch, xs, us, terminal, a.prob[b].rho_est, lane, jv, mk, cost, viol, true);
 }
 
-// MeritFunction (solver.cpp:273-355) for linear dynamics and the diagonal tracking cost (+ AL terms)
+// One knot point's merit-function operands, loaded coalesced (lane -> consecutive element) and staged into an LDS
+// image: Z rows padded to 17 (bank conflicts, see the forward sweep) | OUT record | f | nominal | cost parameters.
+constexpr int MW_ZLD = 17;
+constexpr int MW_OUT0 = 12 * MW_ZLD;       // 204
+constexpr int MW_F0 = MW_OUT0 + 208;       // 412
+constexpr int MW_NOM0 = MW_F0 + 12;        // 424
+constexpr int MW_CP0 = MW_NOM0 + 16;       // 440
+constexpr int MW_IMG = MW_CP0 + MF_COSTP;  // 476
+struct MeritWaveRegs { double z[3], o[4], f, nm, cp; };
+template <typename S>
+__device__ __forceinline__ void merit_wave_load(MeritWaveRegs& r, const S* __restrict__ z, const S* __restrict__ o,
+                                                const S* __restrict__ nm, const S* __restrict__ cp, int lane) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c) r.z[c] = (double)z[MF_OFF_Z + c * 64 + lane];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) r.o[c] = (double)o[c * 64 + lane];
+  r.o[3] = (double)o[192 + (lane & 15)];
+  r.f = (double)z[MF_OFF_F + (lane < 12 ? lane : 11)];
+  r.nm = (double)nm[lane & 15];
+  r.cp = (double)cp[lane < MF_COSTP ? lane : MF_COSTP - 1];
+}
+__device__ __forceinline__ void merit_wave_stage(const MeritWaveRegs& r, double* __restrict__ L, int lane) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c) L[c * 4 * MW_ZLD + (lane >> 4) * MW_ZLD + (lane & 15)] = r.z[c];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) L[MW_OUT0 + c * 64 + lane] = r.o[c];
+  L[MW_OUT0 + 192 + (lane & 15)] = r.o[3];
+  L[MW_F0 + (lane < 12 ? lane : 11)] = r.f;
+  L[MW_NOM0 + (lane & 15)] = r.nm;
+  L[MW_CP0 + (lane < MF_COSTP ? lane : MF_COSTP - 1)] = r.cp;
+}
+
+// MeritFunction (solver.cpp:273-355) for linear dynamics and the diagonal tracking cost (+ AL terms).
+// Records are requested DEPTH knot points ahead (register ring, loop unrolled DEPTH times), every lane's loads and
+// stores in the loop are unconditional (replica lanes re-read / re-write the same element): see the forward sweep.
 template <typename S>
 __global__ __launch_bounds__(64) void wave_merit_kernel(IlqrWaveArgs<S> a) {
+  constexpr int DEPTH = 2;
+  __shared__ double img[MW_IMG + 4];
   __shared__ double xs[12], dxs[12], das[12], us[4], dus[4], jv[AL_MAXC * AL_MAXP], mk[AL_MAXC * AL_MAXP];
+  __shared__ double crec[28], qrec[16];     // candidate record x | y | u and [lx lu], gathered for one coalesced store
   const int b = blockIdx.x, lane = threadIdx.x;
   if (b >= a.batch) return;
   if (a.active && !a.active[b]) return;
@@ -238,68 +275,108 @@ __global__ __launch_bounds__(64) void wave_merit_kernel(IlqrWaveArgs<S> a) {
   const bool is_x = lane < 12, is_u = (grp == 1 && sub < 4), is_y = (grp == 2 && sub < 12);
   const int i = sub < 12 ? sub : 11;       // row of Z / [P|p]
   const int ia = sub < 4 ? sub : 3;        // row of Kt
+  const int l27 = lane < 28 ? lane : 27;
+  const S* __restrict__ dynb = a.dyn + (size_t)b * a.dyn_bs;
+  const S* __restrict__ outb = a.out + (size_t)b * a.out_bs;
+  const S* __restrict__ nomb = a.nom + (size_t)b * MF_NOM;
+  const S* __restrict__ cpb = a.costp + (size_t)b * MF_COSTP;
+  const size_t nom_ks = (size_t)a.batch * MF_NOM, cp_ks = (size_t)a.batch * MF_COSTP;
   double x = (double)a.x0[(size_t)b * 12 + i];
   double dxda = 0.0;
   double J = 0.0, dJ = 0.0, viol = 0.0;    // per-lane partial sums of phi and dphi
-  for (int k = 0; k < N; ++k) {
-    const S* z = a.dyn + (size_t)b * a.dyn_bs + (size_t)k * a.dyn_ks;
-    const S* o = a.out + (size_t)b * a.out_bs + (size_t)k * a.out_ks;
-    const S* nm = a.nom + ((size_t)k * a.batch + b) * MF_NOM;
-    const S* cp = a.costp + ((size_t)k * a.batch + b) * MF_COSTP;
-    S* c = a.cand + (size_t)b * a.xuy_bs + (size_t)k * a.xuy_ks;
-    S* ci = a.cin + (size_t)b * a.cin_bs + (size_t)k * a.cin_ks;
-    if (is_x) { xs[lane] = x; dxs[lane] = x - (double)nm[lane]; das[lane] = dxda; c[lane] = (S)x; }
+  MeritWaveRegs ring[DEPTH];
+#pragma unroll
+  for (int dd = 0; dd < DEPTH; ++dd) {
+    const size_t kk = dd < N ? dd : N - 1;
+    merit_wave_load<S>(ring[dd], dynb + kk * a.dyn_ks, outb + kk * a.out_ks, nomb + kk * nom_ks, cpb + kk * cp_ks, lane);
+  }
+  const int Npad = ((N + DEPTH - 1) / DEPTH) * DEPTH;
+  for (int k0 = 0; k0 < Npad; k0 += DEPTH) {
+#pragma unroll
+   for (int dd = 0; dd < DEPTH; ++dd) {
+    const int k = k0 + dd;
+    const bool live = k < N;     // padding steps (N odd) run on a clamped record and change nothing
+    const int kc = live ? k : N - 1;
+    __syncthreads();             // readers of the previous image are done
+    merit_wave_stage(ring[dd], img, lane);
+    {
+      const size_t kn = (k + DEPTH < N) ? k + DEPTH : N - 1;
+      merit_wave_load<S>(ring[dd], dynb + kn * a.dyn_ks, outb + kn * a.out_ks, nomb + kn * nom_ks, cpb + kn * cp_ks, lane);
+    }
+    if (is_x) { xs[lane] = x; das[lane] = dxda; crec[lane] = x; }
     __syncthreads();
+    if (is_x) dxs[lane] = x - img[MW_NOM0 + lane];
+    __syncthreads();
+    double uval = 0.0, duval = 0.0;
     if (is_u) {   // u_ = u + (-K dx + alpha d) ; du_da = -K dx_da + d        (Kt = [K | -d])
       double s = 0.0, s2 = 0.0;
 #pragma unroll
-      for (int j = 0; j < 12; ++j) { const double kij = (double)o[ia * 13 + j]; s += kij * dxs[j]; s2 += kij * das[j]; }
-      const double d = -(double)o[ia * 13 + 12];
-      const double u = (double)nm[12 + ia] + (-s + alpha * d);
-      const double du = -s2 + d;
-      us[ia] = u; dus[ia] = du;
-      c[24 + ia] = (S)u;
-      const double Rd = (double)cp[12 + ia], rr = (double)cp[28 + ia];
-      J += 0.5 * (u * (Rd * u)) + rr * u;
+      for (int j = 0; j < 12; ++j) { const double kij = img[MW_OUT0 + ia * 13 + j]; s += kij * dxs[j]; s2 += kij * das[j]; }
+      const double d = -img[MW_OUT0 + ia * 13 + 12];
+      uval = img[MW_NOM0 + 12 + ia] + (-s + alpha * d);
+      duval = -s2 + d;
+      us[ia] = uval; dus[ia] = duval;
+      crec[24 + ia] = uval;
+      const double Rd = img[MW_CP0 + 12 + ia], rr = img[MW_CP0 + 28 + ia];
+      if (live) J += 0.5 * (uval * (Rd * uval)) + rr * uval;
     }
     if (is_y) {   // y_ = P dx + p
       double s = 0.0;
 #pragma unroll
-      for (int j = 0; j < 12; ++j) s += (double)o[MF_OFF_P + i * 13 + j] * dxs[j];
-      c[12 + i] = (S)(s + (double)o[MF_OFF_P + i * 13 + 12]);
+      for (int j = 0; j < 12; ++j) s += img[MW_OUT0 + MF_OFF_P + i * 13 + j] * dxs[j];
+      crec[12 + i] = s + img[MW_OUT0 + MF_OFF_P + i * 13 + 12];
     }
     __syncthreads();
     double xn = 0.0, dxn = 0.0;
     if (is_x) {   // x+ = A x + B u + f ; dx+/da = A dx_da + B du_da ; state cost
       double s = 0.0, s2 = 0.0, t = 0.0, t2 = 0.0;
 #pragma unroll
-      for (int j = 0; j < 12; ++j) { const double aij = (double)z[i * 16 + j]; s += aij * xs[j]; t += aij * das[j]; }
+      for (int j = 0; j < 12; ++j) { const double aij = img[i * MW_ZLD + j]; s += aij * xs[j]; t += aij * das[j]; }
 #pragma unroll
-      for (int cc = 0; cc < 4; ++cc) { const double bic = (double)z[i * 16 + 12 + cc]; s2 += bic * us[cc]; t2 += bic * dus[cc]; }
-      xn = (s + s2) + (double)z[MF_OFF_F + i];
+      for (int cc = 0; cc < 4; ++cc) { const double bic = img[i * MW_ZLD + 12 + cc]; s2 += bic * us[cc]; t2 += bic * dus[cc]; }
+      xn = (s + s2) + img[MW_F0 + i];
       dxn = t + t2;
-      const double Qd = (double)cp[i], q = (double)cp[16 + i];
-      J += 0.5 * (x * (Qd * x)) + q * x;
-      if (lane == 0) J += (double)cp[32];
+      const double Qd = img[MW_CP0 + i], q = img[MW_CP0 + 16 + i];
+      if (live) {
+        J += 0.5 * (x * (Qd * x)) + q * x;
+        if (lane == 0) J += img[MW_CP0 + 32];
+      }
     }
-    if (al) wave_al_rows<S>(a.al, k, b, a.batch, xs, us, false, rho, lane, jv, mk, J, viol, false);
+    if (al) {
+      double Jal = 0.0;
+      wave_al_rows<S>(a.al, kc, b, a.batch, xs, us, false, rho, lane, jv, mk, Jal, viol, false);
+      if (live) J += Jal;
+    }
     __syncthreads();
     if (deriv && lane < 16) {   // lx (lanes 0..11) and lu (lanes 12..15) with the AL terms; dphi
       const int e = lane;
       const double pt = e < 12 ? x : us[e - 12];
-      double l = (double)cp[e] * pt + (double)cp[16 + e];       // costp: Qd | Rd | q | r line up with [x; u]
-      if (al) l -= wave_al_col<S>(a.al, k, e, jv);
-      ci[MF_OFF_QR + e] = (S)l;
-      dJ += l * (e < 12 ? dxda : dus[e - 12]);
+      double l = img[MW_CP0 + e] * pt + img[MW_CP0 + 16 + e];       // costp: Qd | Rd | q | r line up with [x; u]
+      if (al) l -= wave_al_col<S>(a.al, kc, e, jv);
+      qrec[e] = l;
+      if (live) dJ += l * (e < 12 ? dxda : dus[e - 12]);
     }
     __syncthreads();
-    if (is_x) { x = xn; dxda = dxn; }
+    {   // one coalesced store of the candidate record (and of [lx lu]).  A padding step's record goes to the terminal
+        // slot, which the terminal block below rewrites (x is already x_N there)
+      S* c = a.cand + (size_t)b * a.xuy_bs + (size_t)(live ? k : N) * a.xuy_ks;
+      c[l27] = (S)crec[l27];
+      if (deriv) {
+        S* ci = a.cin + (size_t)b * a.cin_bs + (size_t)kc * a.cin_ks;
+        const double qv = qrec[sub];
+        if (live) ci[MF_OFF_QR + sub] = (S)qv;
+      }
+    }
+    if (is_x && live) { x = xn; dxda = dxn; }
+   }
   }
+  __syncthreads();
   {   // terminal knot point (solver.cpp:319-332)
     const S* nm = a.nom + ((size_t)N * a.batch + b) * MF_NOM;
     const S* cp = a.costp + ((size_t)N * a.batch + b) * MF_COSTP;
     const S* on = a.outn + (size_t)b * MF_TERM;
     S* c = a.cand + (size_t)b * a.xuy_bs + (size_t)N * a.xuy_ks;
+    if (is_u) c[24 + ia] = S(0);
     if (is_x) {
       xs[lane] = x;
       dxs[lane] = x - (double)nm[lane];
