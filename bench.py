@@ -29,6 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+RED_DEVICE = "cuda"     # where the scalar reductions live (RCCL needs device tensors)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy ceiling)
 
 
@@ -128,7 +129,7 @@ def lane_config(args, rank, local_rank, world, dist, torch):
     for _ in range(args.steps):
         bt.sweep()
     torch.cuda.synchronize(); barrier()
-    elapsed = shard.max_over_ranks(time.perf_counter() - t0, device="cuda")
+    elapsed = shard.max_over_ranks(time.perf_counter() - t0, device=RED_DEVICE)
     bt.profile(True)
     for _ in range(5):
         bt.sweep()
@@ -180,10 +181,17 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP hot path has no CPU fallback")
+    # One rank per GPU.  (ALTRO_BENCH_BACKEND=gloo is a test hook: it lets a 1-GPU box execute the multi-rank code
+    # path with every rank on GPU 0 and the scalar reductions on the CPU; the driver's runs use nccl == RCCL.)
+    backend = os.environ.get("ALTRO_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
+    global RED_DEVICE
+    RED_DEVICE = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)   # nccl == RCCL on ROCm
+        dist.init_process_group(backend, rank=rank, world_size=world)
 
     import altro_amd
     from tests import problems
@@ -233,10 +241,10 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     from altro_amd import shard
-    elapsed = shard.max_over_ranks(elapsed, device="cuda")
+    elapsed = shard.max_over_ranks(elapsed, device=RED_DEVICE)
 
     # solver statistics: the only thing that ever crosses GPUs (RCCL over xGMI, latency-bound)
-    stats = shard.reduce_stats(bt.stats(), device="cuda")
+    stats = shard.reduce_stats(bt.stats(), device=RED_DEVICE)
 
     # per-kernel durations from HIP events on the handle's stream (profile mode syncs per launch, so
     # it runs after, never inside, the timed region)
