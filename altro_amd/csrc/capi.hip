@@ -86,6 +86,7 @@ struct altro_hip_batch {
   // augmented-Lagrangian constraint blocks (plan LANE): host mirrors + device tables, uploaded lazily
   std::vector<AlDef> al_defs;
   std::vector<AlKnot> al_knots;
+  int al_uniform = 0, al_rows_per_knot = 0;  // knot points 0..N-1 carry the same blocks (kernels/al_types.h)
   std::vector<double> al_G;                  // pool of G blocks, column-major p x (n+m)
   std::vector<std::vector<double>> al_g;     // per block: [p] or [batch][p]
   int al_rows = 0;
@@ -472,8 +473,33 @@ int al_upload_typed(altro_hip_batch* h) {
       const AlDef& d = defs[kn.def[j]];
       kn.z_off[j] = rows; rows += d.p;
       kn.cone[j] = d.cone; kn.p[j] = d.p; kn.g_per_problem[j] = d.g_per_problem; kn.G_off[j] = d.G_off; kn.g_off[j] = d.g_off;
+      // bound-type block: every row of G is +-e_idx
+      const int w = h->n + h->m;
+      bool sel = d.cone != CONE_SOC;
+      for (int r = 0; r < d.p && sel; ++r) {
+        int nz = 0, at = -1;
+        for (int e = 0; e < w; ++e) {
+          const double v = h->al_G[(size_t)d.G_off + r + (size_t)e * d.p];
+          if (v != 0.0) { ++nz; at = e; if (v != 1.0 && v != -1.0) sel = false; }
+        }
+        if (nz != 1) sel = false;
+        else kn.sidx[j][r] = h->al_G[(size_t)d.G_off + r + (size_t)at * d.p] > 0 ? at + 1 : -(at + 1);
+      }
+      kn.sel[j] = sel ? 1 : 0;
     }
   h->al_rows = rows;
+  {   // uniform running knot points?  (then the dual rows of knot point k start k * rows_per_knot after those of 0)
+    const AlKnot& k0 = knots[0];
+    int r0 = 0;
+    for (int j = 0; j < k0.ncon; ++j) r0 += defs[k0.def[j]].p;
+    bool uni = h->N >= 1 && k0.ncon > 0;
+    for (int k = 1; k < h->N && uni; ++k) {
+      uni = knots[k].ncon == k0.ncon;
+      for (int j = 0; j < k0.ncon && uni; ++j) uni = knots[k].def[j] == k0.def[j] && knots[k].z_off[j] == k0.z_off[j] + k * r0;
+    }
+    h->al_uniform = uni ? 1 : 0;
+    h->al_rows_per_knot = r0;
+  }
   int rc = 0;
   if ((rc = dmalloc(h, (void**)&h->al_d_knots, knots.size() * sizeof(AlKnot)))) return rc;
   if ((rc = dmalloc(h, &h->al_d_G, G.size() * sizeof(T)))) return rc;
@@ -499,6 +525,7 @@ IlqrArgs<T> ilqr_args(altro_hip_batch* h, bool use_alpha, bool use_active, int w
   IlqrArgs<T> a;
   a.al.knots = h->al_d_knots; a.al.G = (const T*)h->al_d_G; a.al.g = (const T*)h->al_d_g;
   a.al.z = (T*)h->al_d_z; a.al.enabled = h->al_defs.empty() ? 0 : 1;
+  a.al.uniform = h->al_uniform; a.al.rows_per_knot = h->al_rows_per_knot; a.al.N = h->N;
   a.mode = EXPAND_GRADIENT | EXPAND_HESSIAN;
   a.in = (T*)h->l_in; a.term = (T*)h->l_term; a.out = (const T*)h->l_out; a.outn = (const T*)h->l_outn;
   a.nom = (T*)h->l_nom; a.cand = (T*)h->l_xuy; a.cost = (const T*)h->l_cost; a.x0 = (const T*)h->l_x0;
@@ -521,6 +548,7 @@ int wave_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int
   IlqrWaveArgs<S> a;
   a.al.knots = h->al_d_knots; a.al.G = (const S*)h->al_d_G; a.al.g = (const S*)h->al_d_g; a.al.z = (S*)h->al_d_z;
   a.al.enabled = h->al_defs.empty() ? 0 : 1;
+  a.al.uniform = h->al_uniform; a.al.rows_per_knot = h->al_rows_per_knot; a.al.N = h->N;
   a.mode = mode;
   a.dyn = (const S*)h->m_in; a.dyn_bs = h->m_st.in_bs; a.dyn_ks = h->m_st.in_ks;
   a.cin = (S*)h->m_cin; a.cin_bs = h->m_st.cin_bs; a.cin_ks = h->m_st.cin_ks;

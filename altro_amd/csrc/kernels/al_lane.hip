@@ -145,7 +145,8 @@ __device__ __forceinline__ T al_eval(const AlTable<T>& t, int k, int64_t b, int6
                                      bool terminal, T rho_est, T rho, T* lx, T* lu, T* lxx, T* luu, T* lux,
                                      T* viol, bool dual_update, const T* zpre = nullptr) {
   constexpr int w = n + m;
-  const AlKnot ALTRO_CONST_AS& kn = *(const AlKnot ALTRO_CONST_AS*)(t.knots + k);
+  int zshift;
+  const AlKnot ALTRO_CONST_AS& kn = al_knot<T>(t, k, zshift);
   T cost = T(0);
   static_assert(AL_MAXC == 2, "the preloaded duals are selected with j == 0 ? first : second");
   for (int j = 0; j < kn.ncon; ++j) {   // runtime loop: one copy of the block code
@@ -155,8 +156,76 @@ __device__ __forceinline__ T al_eval(const AlTable<T>& t, int k, int64_t b, int6
     const T ALTRO_CONST_AS* G = (const T ALTRO_CONST_AS*)(t.G + kn.G_off[j]);
     const T ALTRO_CONST_AS* gsh = (const T ALTRO_CONST_AS*)(t.g + kn.g_off[j]);   // shared right-hand side
     const T* gpb = t.g + kn.g_off[j] + b;                                         // per-problem right-hand side
-    T* z = t.z + (int64_t)kn.z_off[j] * B + b;
-    if (cone != CONE_SOC) {
+    T* z = t.z + (int64_t)(kn.z_off[j] + zshift) * B + b;
+    if (cone != CONE_SOC && kn.sel[j]) {
+      // Bound-type block (rows +-e_idx): the same arithmetic as the general branch below with the zero terms of
+      // the dot products left out -- adding +-0 never changes a sum, so the results are bit-identical -- and
+      // without a single load from G.
+      T jvp[AL_MAXP], msk[AL_MAXP], sg[AL_MAXP];
+      int idx[AL_MAXP];
+      T sq = T(0);
+#pragma unroll
+      for (int i = 0; i < AL_MAXP; ++i) {
+        jvp[i] = T(0); msk[i] = T(0); sg[i] = T(0); idx[i] = -1;
+        if (i < p) {
+          const int code = kn.sidx[j][i];
+          idx[i] = (code < 0 ? -code : code) - 1;
+          sg[i] = code < 0 ? T(-1) : T(1);
+          T v = T(0);
+#pragma unroll
+          for (int e = 0; e < n; ++e) v = (idx[i] == e) ? x[e] : v;
+          if (!terminal) {
+#pragma unroll
+            for (int e = 0; e < m; ++e) v = (idx[i] == n + e) ? u[e] : v;
+          }
+          const T val = sg[i] * v - (gpp ? gpb[(int64_t)i * B] : gsh[i]);
+          const T ze = (zpre ? (j == 0 ? zpre[i] : zpre[AL_MAXP + i]) : z[(int64_t)i * B]) - rho_est * val;
+          T zpi = T(0);
+          if (cone == CONE_EQUALITY) { zpi = ze; msk[i] = T(1); }
+          else if (cone == CONE_INEQUALITY) { zpi = fmin(T(0), ze); msk[i] = (ze <= T(0)) ? T(1) : T(0); }
+          sq += zpi * zpi;
+          jvp[i] = msk[i] * zpi;
+          if (viol) {
+            T vv = T(0);
+            if (cone == CONE_EQUALITY) vv = fabs(val);
+            else if (cone == CONE_INEQUALITY) vv = fabs(fmin(T(0), val) - val);
+            *viol = fmax(*viol, vv);
+          }
+          if (dual_update) z[(int64_t)i * B] = zpi;
+        }
+      }
+      cost += sq / (T(2) * rho_est);
+      if (GRAD) {
+#pragma unroll
+        for (int e = 0; e < n; ++e) {
+          T s = T(0);
+#pragma unroll
+          for (int i = 0; i < AL_MAXP; ++i) s += (idx[i] == e) ? sg[i] * jvp[i] : T(0);
+          lx[e] -= s;
+        }
+        if (!terminal) {
+#pragma unroll
+          for (int e = 0; e < m; ++e) {
+            T s = T(0);
+#pragma unroll
+            for (int i = 0; i < AL_MAXP; ++i) s += (idx[i] == n + e) ? sg[i] * jvp[i] : T(0);
+            lu[e] -= s;
+          }
+        }
+      }
+      if (HESS) {
+#pragma unroll
+        for (int e = 0; e < w; ++e) {
+          if (terminal && e >= n) continue;
+          T s = T(0);
+#pragma unroll
+          for (int i = 0; i < AL_MAXP; ++i) s += (idx[i] == e) ? (msk[i] * sg[i]) * (msk[i] * sg[i]) : T(0);
+          s = rho * s;
+          if (e < n) lxx[e + e * n] += s;
+          else luu[(e - n) + (e - n) * m] += s;
+        }
+      }
+    } else if (cone != CONE_SOC) {
       // zero / identity / orthant: projection and its Jacobian are diagonal (cones.cpp:125-178)
       T zp[AL_MAXP], msk[AL_MAXP];
       T sq = T(0);
@@ -327,14 +396,15 @@ __device__ __forceinline__ T al_eval(const AlTable<T>& t, int k, int64_t b, int6
 template <typename T, typename BUF>
 __device__ __forceinline__ void al_load_z(const AlTable<T>& t, int k, const BUF& bz, uint32_t lane, uint32_t rowB,
                                           T (&zv)[AL_MAXC * AL_MAXP]) {
-  const AlKnot ALTRO_CONST_AS& kn = *(const AlKnot ALTRO_CONST_AS*)(t.knots + k);
+  int zshift;
+  const AlKnot ALTRO_CONST_AS& kn = al_knot<T>(t, k, zshift);
 #pragma unroll
   for (int j = 0; j < AL_MAXC; ++j) {
     const int p = j < kn.ncon ? kn.p[j] : 0;
 #pragma unroll
     for (int i = 0; i < AL_MAXP; ++i) {
       zv[j * AL_MAXP + i] = T(0);
-      if (i < p) zv[j * AL_MAXP + i] = lane_ld<T>(bz, lane, (uint32_t)(kn.z_off[j] + i) * rowB);
+      if (i < p) zv[j * AL_MAXP + i] = lane_ld<T>(bz, lane, (uint32_t)(kn.z_off[j] + zshift + i) * rowB);
     }
   }
 }

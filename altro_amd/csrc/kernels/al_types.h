@@ -23,6 +23,10 @@ struct AlKnot {          // everything a kernel needs about knot point k in ONE 
   int z_off[AL_MAXC];   // first row of this block's dual in z[rows][batch]
   int cone[AL_MAXC], p[AL_MAXC], g_per_problem[AL_MAXC], G_off[AL_MAXC];
   int64_t g_off[AL_MAXC];
+  // Bound-type blocks: every row of G is +-e_idx (control / state bounds, goal pins -- most constraints of an MPC
+  // problem).  sel != 0 marks such a block; sidx[row] = +(idx + 1) or -(idx + 1).  The kernels then skip G.
+  int sel[AL_MAXC];
+  int sidx[AL_MAXC][AL_MAXP];
 };
 template <typename T>
 struct AlTable {
@@ -31,9 +35,20 @@ struct AlTable {
   const T* g;
   T* z;
   int enabled;
+  // uniform != 0: knot points 0 .. N-1 carry the same blocks (the usual MPC problem), so the kernels read the table
+  // entry of knot point 0 at every step -- the same constant-memory address, a scalar-cache hit instead of a fresh
+  // miss per step -- and offset the duals by k * rows_per_knot.
+  int uniform, rows_per_knot, N;
 };
+#define ALTRO_CONST_AS __attribute__((address_space(4)))
+// table entry and dual-row shift for knot point k
+template <typename T>
+__device__ __forceinline__ const AlKnot ALTRO_CONST_AS& al_knot(const AlTable<T>& t, int k, int& zshift) {
+  const bool u = t.uniform != 0 && k < t.N;
+  zshift = u ? k * t.rows_per_knot : 0;
+  return *(const AlKnot ALTRO_CONST_AS*)(t.knots + (u ? 0 : k));
+}
 // Tables and the shared G / g blocks are read through the constant address space: with a wave-uniform
 // address that is an s_load into SGPRs (scalar cache) instead of a vector load + v_readlane waterfall.
-#define ALTRO_CONST_AS __attribute__((address_space(4)))
 
 }  // namespace altro_hip

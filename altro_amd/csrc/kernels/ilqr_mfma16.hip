@@ -52,7 +52,8 @@ template <typename S>
 __device__ __forceinline__ void wave_al_rows(const AlTable<S>& t, int k, int b, int64_t B, const double* xs, const double* us,
                                              bool terminal, double rho_est, int lane, double* jv, double* mk, double& cost,
                                              double& viol, bool dual_update) {
-  const AlKnot ALTRO_CONST_AS& kn = *(const AlKnot ALTRO_CONST_AS*)(t.knots + k);
+  int zshift;
+  const AlKnot ALTRO_CONST_AS& kn = al_knot<S>(t, k, zshift);
   const int i = lane - 48;
   const bool row_lane = (i >= 0 && i < AL_MAXP);
 #pragma unroll
@@ -70,7 +71,7 @@ __device__ __forceinline__ void wave_al_rows(const AlTable<S>& t, int k, int b, 
       }
       const double gi = kn.g_per_problem[c] ? (double)t.g[kn.g_off[c] + (int64_t)i * B + b] : (double)t.g[kn.g_off[c] + i];
       const double val = s - gi;
-      S* zp_ = t.z + (int64_t)(kn.z_off[c] + i) * B + b;
+      S* zp_ = t.z + (int64_t)(kn.z_off[c] + zshift + i) * B + b;
       const double ze = (double)*zp_ - rho_est * val;
       double zp = 0.0;
       if (cone == CONE_EQUALITY) { zp = ze; mkv = 1.0; viol = fmax(viol, fabs(val)); }
@@ -85,7 +86,8 @@ __device__ __forceinline__ void wave_al_rows(const AlTable<S>& t, int k, int b, 
 // sum_c sum_i G_c[i][e] * w[c * 8 + i]  for column e of the constraint Jacobians of knot point k
 template <typename S>
 __device__ __forceinline__ double wave_al_col(const AlTable<S>& t, int k, int e, const double* w) {
-  const AlKnot ALTRO_CONST_AS& kn = *(const AlKnot ALTRO_CONST_AS*)(t.knots + k);
+  int zshift;
+  const AlKnot ALTRO_CONST_AS& kn = al_knot<S>(t, k, zshift);
   double s = 0.0;
 #pragma unroll
   for (int c = 0; c < AL_MAXC; ++c)
@@ -184,7 +186,8 @@ __global__ __launch_bounds__(64) void wave_expand_kernel(IlqrWaveArgs<S> a) {
   }
   if (hess && al) {   // 16 x 16 tile, 4 entries per lane: row r = lane / 4 (+ 0), columns 4 (lane % 4) + 0..3 ... plain loop
     const double rho = a.prob[b].rho;
-    const AlKnot ALTRO_CONST_AS& kn = *(const AlKnot ALTRO_CONST_AS*)(a.al.knots + k);
+    int zshift;
+    const AlKnot ALTRO_CONST_AS& kn = al_knot<S>(a.al, k, zshift);
     for (int t = lane; t < 256; t += 64) {
       const int r = t / 16, cc = t % 16;
       if (terminal && (r >= 12 || cc >= 12)) continue;
