@@ -488,6 +488,8 @@ int al_upload_typed(altro_hip_batch* h) {
       kn.sel[j] = sel ? 1 : 0;
     }
   h->al_rows = rows;
+  if (h->plan == ALTRO_HIP_PLAN_LANE && (uint64_t)rows * (uint64_t)B * sizeof(T) >= (1ull << 31))
+    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "plan LANE: %d dual rows x batch %d exceed the 2 GiB buffer window; split the batch", rows, h->batch);
   {   // uniform running knot points?  (then the dual rows of knot point k start k * rows_per_knot after those of 0)
     const AlKnot& k0 = knots[0];
     int r0 = 0;
