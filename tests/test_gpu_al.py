@@ -195,3 +195,31 @@ def test_regularisation_retry_extension(kats):
     assert np.array_equal(a.get("x"), b.get("x")) and np.array_equal(ra["iterations"], rb["iterations"])
     with pytest.raises(altro_amd.AltroHipError):
         make(0.01).ilqr_solve(reg_retry_max=2, reg_scale=0.5)
+
+
+def test_full_size_c3_constrained_tracking_batch():
+    """BASELINE.json configs[3] at full size on one GPU (bicycle, N = 50, 65536 vehicles, steering bound as an
+    INEQUALITY block at every knot point): size-independent properties of the batched solve -- nearly every vehicle
+    converges, converged ones are feasible and stationary, copies of one problem give identical bits."""
+    from tests import mpc_common as M
+    N, n, m, batch = 50, 4, 2, 65536
+    x_ref, u_ref = problems.bicycle_reference(N + 1)
+    bt = altro_amd.Batch(N, n, m, batch)
+    bt.set_model(altro_amd.MODEL_BICYCLE, np.float32(0.1))
+    bt.set_tracking_cost(np.full((1, N + 1, n), 1e-2), np.full((1, N, m), 1e-3), x_ref[None, :N + 1], u_ref[None, :N],
+                         batch_stride_zero=True)
+    cone, G, g = M.steering_block()
+    bt.add_linear_constraint(0, N, cone, G, g)
+    x0 = x_ref[0] + (problems.uniform01((batch, n), 23) - 0.5) * 0.4
+    x0[batch // 2] = x0[0]            # two copies of one problem, far apart in the batch
+    bt.set_initial_state(x0)
+    bt.set_input_guess(np.array([[[u_ref[0][0], 0.0]]]), k_stride_zero=True, batch_stride_zero=True)
+    res = bt.ilqr_solve(iterations_max=40, use_backtracking=True)
+    ok = res["status"] == 0
+    assert ok.mean() > 0.995, ok.mean()
+    assert (res["feasibility"][ok] < 1e-4).all() and (res["stationarity"][ok] < 1e-4).all()
+    assert set(np.unique(res["status"])) <= {0, 1, 2}
+    x, u = bt.get_nominal()
+    assert np.abs(x[ok][:, :, 3]).max() <= M.DELTA_MAX + 1e-4
+    assert np.array_equal(x[0], x[batch // 2]) and res["iterations"][0] == res["iterations"][batch // 2]
+    assert np.isfinite(x).all()

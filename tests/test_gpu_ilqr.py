@@ -177,3 +177,25 @@ def test_shortest_horizons_solve(name, N):
         status, iters, log = s.solve()
         assert res["status"][b] == status and res["iterations"][b] == iters
         np.testing.assert_allclose(x[b], s.get("x"), rtol=1e-9, atol=1e-9)
+
+
+def test_full_size_c2_pendulum_batch():
+    """BASELINE.json configs[2] at full size (pendulum, N = 100, 8192 problems): every swing-up converges within the
+    reference's iteration budget scale, reaches the upright goal region, and equal problems give equal bits."""
+    N, batch = 100, 8192
+    xf = np.array([np.pi, 0.0])
+    bt = altro_amd.Batch(N, 2, 1, batch)
+    bt.set_model(altro_amd.MODEL_PENDULUM, np.float32(0.03))
+    bt.set_tracking_cost(np.array([[1e-2, 1e-2], [1.0, 1.0]]), np.array([[1e-3]]), np.stack([xf, xf]), np.zeros((1, 1)),
+                         k_stride_zero=True, batch_stride_zero=True)
+    from tests import problems
+    x0 = np.zeros((batch, 2)); x0[:, 0] = problems.uniform01((batch,), 22) - 0.5
+    x0[4097] = x0[3]
+    bt.set_initial_state(x0)
+    bt.set_input_guess(np.array([[[0.1]]]), k_stride_zero=True, batch_stride_zero=True)
+    res = bt.ilqr_solve(iterations_max=30)
+    assert (res["status"] == 0).all()
+    assert res["iterations"].max() <= 20
+    x, u = bt.get_nominal()
+    assert np.abs(x[:, -1, 0] - np.pi).max() < 0.2
+    assert np.array_equal(x[3], x[4097])
