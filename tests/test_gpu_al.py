@@ -223,3 +223,36 @@ def test_full_size_c3_constrained_tracking_batch():
     assert np.abs(x[ok][:, :, 3]).max() <= M.DELTA_MAX + 1e-4
     assert np.array_equal(x[0], x[batch // 2]) and res["iterations"][0] == res["iterations"][batch // 2]
     assert np.isfinite(x).all()
+
+
+def test_per_problem_bounds_match_oracle(kats):
+    """Per-problem right-hand sides (g_per_problem): every problem of the batch has its own control bound; each must
+    follow the oracle solving it alone with that bound."""
+    kat = kats["double_integrator_constrained"]
+    c = kat["bounds"]
+    N = kat["N"]; n, m = 4, 2
+    batch = 48
+    x0s = np.tile(np.array(c["x0"], dtype=float), (batch, 1))
+    x0s[:, 0] += 0.03 * (np.arange(batch) % 11 - 5)
+    ubs = 0.8 + 0.05 * (np.arange(batch) % 9)                     # 0.8 .. 1.2
+    bt, _, xf = _di_hip(kats, "goal", x0s)                        # goal block at k = N
+    Gb = np.zeros((2 * m, n + m)); Gb[:m, n:] = np.eye(m); Gb[m:, n:] = -np.eye(m)
+    bt.add_linear_constraint(0, N - 1, altro_amd.CONE_INEQUALITY, Gb, np.repeat(ubs[:, None], 2 * m, axis=1))
+    res = bt.ilqr_solve(penalty_initial=c["penalty_initial"], penalty_scaling=c["penalty_scaling"], iterations_max=60)
+    x, u = bt.get("x"), bt.get("u")
+    checked = 0
+    for b in [0, 8, 13, 30, 47]:
+        s = _di_oracle(kats, "goal", x0s[b])
+        for k in range(N):
+            s.add_linear_constraint(k, oracle.CONE_INEQUALITY, Gb, np.full(2 * m, ubs[b]))
+        s.L.oracle_ilqr_initialize(s.h)
+        s.set_penalty(c["penalty_initial"], c["penalty_scaling"])
+        s.L.oracle_ilqr_set_options(s.h, 60, 1e-4, 1e-4, 1e-8, 0)
+        status, iters, log = s.solve()
+        assert res["status"][b] == status and res["iterations"][b] == iters, (b, res["status"][b], status, res["iterations"][b], iters)
+        if status != 0:
+            continue
+        checked += 1
+        np.testing.assert_allclose(x[b], s.get("x"), rtol=1e-8, atol=1e-8)
+        assert np.abs(u[b]).max() <= ubs[b] + 2e-4
+    assert checked >= 3
