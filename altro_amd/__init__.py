@@ -37,6 +37,7 @@ C_ABI_SYMBOLS = [
     "altro_hip_add_linear_constraint", "altro_hip_clear_constraints", "altro_hip_reset_duals",
     "altro_hip_get_duals", "altro_hip_feasibility",
     "altro_hip_shift_trajectory", "altro_hip_update_linear_costs", "altro_hip_get_knot",
+    "altro_hip_set_pointer_mode",
 ]
 CONE_EQUALITY, CONE_IDENTITY, CONE_INEQUALITY, CONE_SOC = 0, 1, 2, 3   # ConstraintType, typedefs.hpp:29-34
 
@@ -119,6 +120,7 @@ def lib():
         L.altro_hip_reset_duals.argtypes = [vp, d]
         L.altro_hip_get_duals.argtypes = [vp, i, i, vp]
         L.altro_hip_feasibility.argtypes = [vp, vp]
+        L.altro_hip_set_pointer_mode.argtypes = [vp, i]
         L.altro_hip_shift_trajectory.argtypes = [vp]
         L.altro_hip_update_linear_costs.argtypes = [vp, vp, vp, vp, i, i, i, i]
         L.altro_hip_get_knot.argtypes = [vp, i, vp, vp]
@@ -157,6 +159,12 @@ class Batch:
         _check(self.L.altro_hip_batch_create(C.byref(self.h), N, n, m, batch, dtype, plan, flags,
                                              device, stream))
         self.plan = self.L.altro_hip_batch_plan(self.h)
+
+    def set_pointer_mode(self, device_pointers):
+        """device_pointers=True: the bulk arrays handed to the raw C entry points are device pointers (see
+        altro_hip.h).  The numpy-based helpers of this class always pass host arrays; use `self.L` + `self.h` with
+        your own device pointers (e.g. torch tensors' data_ptr()) while the mode is on."""
+        _check(self.L.altro_hip_set_pointer_mode(self.h, int(bool(device_pointers))))
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h:

@@ -63,6 +63,7 @@ struct altro_hip_batch {
   bool dyn_set = false, cost_set = false, x0_set = false, backward_done = false, forward_done = false;
   int has_f = 0, is_diag = 0;
   int host_batch = 0;   // > 0: host arrays of the next set_* calls hold this many problems, tiled over the batch
+  bool dev_ptrs = false;   // altro_hip_set_pointer_mode: bulk arrays of set_* / get_* are device pointers
   // plan GENERIC: reference layout on the device
   void* g_arr[G_NUM] = {};
   int64_t g_bstride[G_NUM] = {};
@@ -167,6 +168,13 @@ int upload_chunks(altro_hip_batch* h, const double* host, int block, int nk, int
                   int nk_host, int src_off, F consume) {
   const int src_nk = nk_host > 0 ? nk_host : (k_zero ? 1 : nk);
   const size_t per_problem = (size_t)src_nk * block * sizeof(double);
+  if (h->dev_ptrs) {   // the caller's array already lives in HBM: no staging, one pass over the whole batch
+    SrcArr s{host + src_off, b_zero ? 0 : (int64_t)src_nk * block, k_zero ? 0 : (int64_t)block, 0};
+    int rc = consume(s, 0, h->batch);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));   // the caller may reuse its buffer on return
+    return 0;
+  }
   if (b_zero) {
     int rc = ensure_stage(h, per_problem);
     if (rc) return rc;
@@ -241,6 +249,12 @@ int aos_get(altro_hip_batch* h, double* host, const T* src, int64_t src_bs, int6
 template <typename F>
 int download_chunks(altro_hip_batch* h, double* host, int block, int nk, F produce) {
   const size_t per_problem = (size_t)nk * block * sizeof(double);
+  if (h->dev_ptrs) {   // write straight into the caller's device array
+    int rc = produce(host, 0, h->batch);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+  }
   int chunk = (int)std::max<size_t>(1, std::min<size_t>(h->batch, kStageBytes / std::max<size_t>(per_problem, 1)));
   int rc = ensure_stage(h, per_problem * chunk);
   if (rc) return rc;
@@ -299,6 +313,10 @@ int put_src(altro_hip_batch* h, const double* src, int blk, int nk_host, int k_z
   const size_t per_b = (size_t)nk_host * blk;
   const int tiled = (!b_zero && h->host_batch > 0 && h->host_batch < h->batch) ? h->host_batch : 0;
   const size_t bytes = (size_t)(b_zero ? 1 : (tiled ? tiled : h->batch)) * per_b * sizeof(double);
+  if (h->dev_ptrs) {   // device pointer: use it in place
+    out->s = SrcArr{src, b_zero ? 0 : (int64_t)per_b, k_zero ? 0 : (int64_t)blk, tiled};
+    return 0;
+  }
   if (hipMalloc(&out->dev, bytes) != hipSuccess)
     return fail(ALTRO_HIP_ERR_OUT_OF_MEMORY, "hipMalloc(%zu) failed", bytes);
   if (hipMemcpyAsync(out->dev, src, bytes, hipMemcpyHostToDevice, h->stream) != hipSuccess)
@@ -1009,6 +1027,13 @@ int altro_hip_set_initial_state(altro_hip_batch* h, const double* x0, int bz) {
   return rc;
 }
 
+int altro_hip_set_pointer_mode(altro_hip_batch* h, int device_pointers) {
+  int rc = check(h);
+  if (rc) return rc;
+  h->dev_ptrs = device_pointers != 0;
+  return 0;
+}
+
 int altro_hip_backward(altro_hip_batch* h, double reg) {
   int rc = check(h);
   if (rc) return rc;
@@ -1201,6 +1226,9 @@ int altro_hip_set_tracking_cost(altro_hip_batch* h, const double* Qd, const doub
   if (h->plan != ALTRO_HIP_PLAN_LANE && h->plan != ALTRO_HIP_PLAN_MFMA16)
     return fail(ALTRO_HIP_ERR_UNSUPPORTED, "tracking cost needs plan LANE or MFMA16");
   if (!Qd || !Rd || !xref || !uref) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "Qd, Rd, xref, uref are required");
+  if (h->dev_ptrs)
+    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "altro_hip_set_tracking_cost forms q = -Q xref on the host: pass host arrays "
+                                           "(altro_hip_set_pointer_mode(h, 0))");
   const int n = h->n, m = h->m, N = h->N;
   const int nb = bz ? 1 : h->batch, nkx = kz ? 2 : N + 1, nku = kz ? 1 : N;
   const int E = 2 * n + 2 * m + 1;

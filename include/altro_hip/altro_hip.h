@@ -120,6 +120,13 @@ int altro_hip_set_cost(altro_hip_batch* h, const double* Q, const double* R, con
                        const double* q, const double* r, int is_diag, int k_stride_zero,
                        int batch_stride_zero);
 int altro_hip_set_initial_state(altro_hip_batch* h, const double* x0, int batch_stride_zero);
+/* Pointer mode of the BULK arrays: with device_pointers != 0 the A, B, f, Q, R, H, q, r, x0, u arguments of
+ * altro_hip_set_dynamics / set_cost / set_initial_state / set_input_guess / update_linear_costs and the outputs of
+ * altro_hip_get_K .. get_y / get_nominal / get_knot are DEVICE pointers (fp64, the same reference layout) on the
+ * handle's device: kernels on the handle's stream read / write them in place, no staging copy -- for callers whose
+ * linearisation already lives in HBM.  Everything else (status, delta_V, alpha / phi, results, duals, tracking-cost
+ * arguments) stays in host memory.  Default 0.                                                            */
+int altro_hip_set_pointer_mode(altro_hip_batch* h, int device_pointers);
 /* Host arrays of the following set_dynamics / set_cost / set_tracking_cost / set_input_guess calls hold
  * only `host_batch` distinct problems, tiled (b mod host_batch) over the batch on the device; 0 = off.
  * Lets a large synthetic batch be staged without a batch-sized host copy (plans MFMA16 and LANE).   */

@@ -435,3 +435,37 @@ def test_generic_and_lane_shape_fuzz():
         assert (out["status"] == -1).all(), (n, m, N, batch)
         for k in ("K", "d", "P", "p", "x", "u", "y"):
             assert np.array_equal(out[k], ref[k]), (k, n, m, N, batch, plan)
+
+
+@pytest.mark.parametrize("n,m,plan", [(12, 4, altro_amd.PLAN_MFMA16), (4, 2, altro_amd.PLAN_LANE), (5, 2, altro_amd.PLAN_GENERIC)])
+def test_device_pointer_mode(n, m, plan):
+    """altro_hip_set_pointer_mode: inputs taken from / outputs written to caller-owned device arrays (torch tensors
+    here, as plain device memory) give the same bits as the host-pointer path."""
+    import ctypes as C
+    import torch
+    N, batch = 17, 70
+    pr = problems.random_ltv(batch, N, n, m)
+    ref = run_hip(pr, altro_amd.PLAN_AUTO if plan != altro_amd.PLAN_GENERIC else plan)
+    bt = altro_amd.Batch(N, n, m, batch, plan=altro_amd.PLAN_AUTO if plan != altro_amd.PLAN_GENERIC else plan)
+    assert bt.plan == plan
+    dev = {k: torch.from_numpy(np.ascontiguousarray(pr[k])).cuda() for k in ("A", "B", "f", "Q", "R", "H", "q", "r", "x0")}
+    p = lambda t: C.c_void_p(t.data_ptr())
+    bt.set_pointer_mode(True)
+    L, h = bt.L, bt.h
+    assert L.altro_hip_set_dynamics(h, p(dev["A"]), p(dev["B"]), p(dev["f"]), 0, 0) == 0
+    assert L.altro_hip_set_cost(h, p(dev["Q"]), p(dev["R"]), p(dev["H"]), p(dev["q"]), p(dev["r"]), 0, 0, 0) == 0
+    assert L.altro_hip_set_initial_state(h, p(dev["x0"]), 0) == 0
+    assert L.altro_hip_sweep(h, 0.0) == 0
+    shapes = {"K": (batch, N, m * n), "d": (batch, N, m), "P": (batch, N + 1, n * n), "p": (batch, N + 1, n),
+              "x": (batch, N + 1, n), "u": (batch, N, m), "y": (batch, N + 1, n)}
+    for k, shp in shapes.items():
+        out = torch.full(shp, float("nan"), dtype=torch.float64, device="cuda")
+        assert getattr(L, "altro_hip_get_" + k)(h, p(out)) == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), ref[k]), k
+    # tracking-cost arithmetic happens on the host: refused in device mode; host mode again works
+    if plan != altro_amd.PLAN_GENERIC:
+        with pytest.raises(altro_amd.AltroHipError):
+            bt.set_tracking_cost(np.ones((batch, N + 1, n)), np.ones((batch, N, m)), np.zeros((batch, N + 1, n)), np.zeros((batch, N, m)))
+    bt.set_pointer_mode(False)
+    assert np.array_equal(bt.get("K"), ref["K"])
