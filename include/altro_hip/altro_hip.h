@@ -125,7 +125,9 @@ int altro_hip_set_initial_state(altro_hip_batch* h, const double* x0, int batch_
  * altro_hip_get_K .. get_y / get_nominal / get_knot are DEVICE pointers (fp64, the same reference layout) on the
  * handle's device: kernels on the handle's stream read / write them in place, no staging copy -- for callers whose
  * linearisation already lives in HBM.  Everything else (status, delta_V, alpha / phi, results, duals, tracking-cost
- * arguments) stays in host memory.  Default 0.                                                            */
+ * arguments) stays in host memory.  Default 0.  Stream ordering is the caller's: the handle works on its own
+ * stream, so work other streams still have pending on those arrays must be complete before the call; on return
+ * the call's own reads / writes are complete (it synchronises its stream).                                */
 int altro_hip_set_pointer_mode(altro_hip_batch* h, int device_pointers);
 /* Host arrays of the following set_dynamics / set_cost / set_tracking_cost / set_input_guess calls hold
  * only `host_batch` distinct problems, tiled (b mod host_batch) over the batch on the device; 0 = off.

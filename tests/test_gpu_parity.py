@@ -450,6 +450,7 @@ def test_device_pointer_mode(n, m, plan):
     assert bt.plan == plan
     dev = {k: torch.from_numpy(np.ascontiguousarray(pr[k])).cuda() for k in ("A", "B", "f", "Q", "R", "H", "q", "r", "x0")}
     p = lambda t: C.c_void_p(t.data_ptr())
+    torch.cuda.synchronize()    # the handle works on its own stream: the caller's arrays must be complete
     bt.set_pointer_mode(True)
     L, h = bt.L, bt.h
     assert L.altro_hip_set_dynamics(h, p(dev["A"]), p(dev["B"]), p(dev["f"]), 0, 0) == 0
@@ -460,6 +461,7 @@ def test_device_pointer_mode(n, m, plan):
               "x": (batch, N + 1, n), "u": (batch, N, m), "y": (batch, N + 1, n)}
     for k, shp in shapes.items():
         out = torch.full(shp, float("nan"), dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()    # (the fill runs on torch's stream)
         assert getattr(L, "altro_hip_get_" + k)(h, p(out)) == 0
         torch.cuda.synchronize()
         assert np.array_equal(out.cpu().numpy(), ref[k]), k
