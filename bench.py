@@ -59,10 +59,11 @@ def _cpu_worker(args):
     from oracle import oracle
     from tests import problems
     pr = problems.c1_double_integrator(4, N=N)
+    L, _ = oracle.timing_lib()
     done, t0 = 0, time.perf_counter()
     while time.perf_counter() - t0 < seconds:
-        o = oracle.backward_batch(pr["A"], pr["B"], pr["f"], pr["Q"], pr["R"], pr["H"], pr["q"], pr["r"])
-        oracle.forward_batch(pr["A"], pr["B"], pr["f"], o["K"], o["d"], o["P"], o["p"], pr["x0"])
+        o = oracle.backward_batch(pr["A"], pr["B"], pr["f"], pr["Q"], pr["R"], pr["H"], pr["q"], pr["r"], L=L)
+        oracle.forward_batch(pr["A"], pr["B"], pr["f"], o["K"], o["d"], o["P"], o["p"], pr["x0"], L=L)
         done += 4
     return done, time.perf_counter() - t0
 
@@ -88,11 +89,12 @@ def cpu_baseline(N, seconds):
     from tests import problems
     chunk = 8
     pr = problems.c1_double_integrator(chunk, N=N)
+    L, flags = oracle.timing_lib()      # the same C sources at -O3 -march=native of THIS host (results unchanged)
     done, t_used = 0, 0.0
     while t_used < seconds or done < 16:
         t0 = time.perf_counter()
-        o = oracle.backward_batch(pr["A"], pr["B"], pr["f"], pr["Q"], pr["R"], pr["H"], pr["q"], pr["r"])
-        oracle.forward_batch(pr["A"], pr["B"], pr["f"], o["K"], o["d"], o["P"], o["p"], pr["x0"])
+        o = oracle.backward_batch(pr["A"], pr["B"], pr["f"], pr["Q"], pr["R"], pr["H"], pr["q"], pr["r"], L=L)
+        oracle.forward_batch(pr["A"], pr["B"], pr["f"], o["K"], o["d"], o["P"], o["p"], pr["x0"], L=L)
         t_used += time.perf_counter() - t0
         done += chunk
         if t_used > 30.0:
@@ -107,7 +109,7 @@ def cpu_baseline(N, seconds):
         pass
     return {"value": done / t_used, "unit": "problem-sweeps/s", "cores": 1, "kind": "port",
             "sample": "%d problems of the same C1 workload (N=%d, n=12, m=4), %.1f s, oracle/tvlqr_oracle.c "
-                      "backward+forward, gcc -O2, 1 thread of %d on '%s'" % (done, N, t_used, os.cpu_count(), cpu)}
+                      "backward+forward, %s, 1 thread of %d on '%s'" % (done, N, t_used, flags, os.cpu_count(), cpu)}
 
 
 def lane_config(args, rank, local_rank, world, dist, torch):

@@ -30,6 +30,33 @@ def build(force=False):
         subprocess.check_call(["make", "-C", _HERE, "-s", "ref"], stdout=subprocess.DEVNULL)
 
 
+def timing_lib():
+    """The same C sources built `-O3 -march=native` (still `-ffp-contract=off`: same algorithm, same results) for
+    bench.py's cpu_baseline leg, so that the CPU side is timed at its best.  Host-specific, hence built on the
+    machine that runs it and named after its CPU; falls back to the portable build when that fails."""
+    import hashlib
+    try:
+        cpu = "".join(l for l in open("/proc/cpuinfo") if l.startswith(("model name", "flags")))[:4096]
+    except OSError:
+        cpu = "unknown"
+    tag = hashlib.sha1(cpu.encode()).hexdigest()[:10]
+    path = os.path.join(_HERE, "_build", "liboracle_native_%s.so" % tag)
+    srcs = [os.path.join(_HERE, f) for f in ("tvlqr_oracle.c",)]
+    try:
+        if not os.path.exists(path) or any(os.path.getmtime(x) > os.path.getmtime(path) for x in srcs):
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            subprocess.check_call(["gcc", "-O3", "-march=native", "-ffp-contract=off", "-fPIC", "-std=c11", "-shared", "-o", path]
+                                  + srcs + ["-lm"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        L = C.CDLL(path)
+        L.oracle_backward_batch.argtypes = [C.c_int] * 4 + [C.c_void_p] * 8 + [C.c_double, C.c_int] + [C.c_void_p] * 6
+        L.oracle_backward_batch.restype = None
+        L.oracle_forward_batch.argtypes = [C.c_int] * 4 + [C.c_void_p] * 11
+        L.oracle_forward_batch.restype = None
+        return L, "gcc -O3 -march=native"
+    except (OSError, subprocess.CalledProcessError):
+        return lib(), "gcc -O2"
+
+
 _lib = None
 
 
@@ -156,11 +183,11 @@ def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
-def backward_batch(A, B, f, Q, R, H, q, r, reg=0.0, is_diag=False):
+def backward_batch(A, B, f, Q, R, H, q, r, reg=0.0, is_diag=False, L=None):
     """Arrays are [batch, k, ...] in the reference's column-major blocks, flattened:
     A [b,N,n*n], B [b,N,n*m], f [b,N,n], Q [b,N+1,n*n or n], R [b,N,m*m or m], H [b,N,m*n],
     q [b,N+1,n], r [b,N,m]. Returns dict(K,d,P,p,dV,status)."""
-    L = lib()
+    L = L or lib()
     batch, N = A.shape[0], A.shape[1]
     n = f.shape[2]
     m = r.shape[2]
@@ -174,8 +201,8 @@ def backward_batch(A, B, f, Q, R, H, q, r, reg=0.0, is_diag=False):
     return dict(K=K, d=d, P=P, p=p, dV=dV, status=status)
 
 
-def forward_batch(A, B, f, K, d, P, p, x0, want_y=True):
-    L = lib()
+def forward_batch(A, B, f, K, d, P, p, x0, want_y=True, L=None):
+    L = L or lib()
     batch, N = A.shape[0], A.shape[1]
     n = f.shape[2]
     m = d.shape[2]
