@@ -53,6 +53,7 @@ def test_cpp_programs_compile_and_link():
     hipbuild.build()
     exe = cpp_build.build("tvlqr_dropin_test")
     assert os.path.exists(exe)
+    assert os.path.exists(cpp_build.build("batch_solver_test"))   # include/altro_hip/altro_hip.hpp: header-only C++ wrapper
     import subprocess
     syms = subprocess.run(["nm", "-D", "--defined-only", altro_amd.LIB_PATH], capture_output=True, text=True).stdout
     for mangled in ("_Z18tvlqr_BackwardPass", "_Z17tvlqr_ForwardPass", "_Z18tvlqr_TotalMemSize"):

@@ -20,3 +20,10 @@ def test_altro_solver_cpp_api_integration():
     print(out)
     assert rc == 0 and out.strip().endswith("OK"), out + err
     assert "iterations = 3, dist" in out and "iterations = 5, dist" in out and "iterations = 9, dist" in out
+
+
+def test_batch_solver_cpp_wrapper():
+    """include/altro_hip/altro_hip.hpp (header-only C++ over the C ABI): the constrained double integrator of
+    test/double_integrator_test.cpp:258-376 for a batch of 100 -- 5 iterations, goal reached, controls saturated."""
+    rc, out, err = cpp_build.run("batch_solver_test")
+    assert rc == 0 and out.strip().endswith("PASS"), out + err
