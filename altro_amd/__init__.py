@@ -345,13 +345,11 @@ class Batch:
         _check(self.L.altro_hip_ilqr_solve(self.h, C.byref(o), res))
         sw, ml = C.c_int(), C.c_int()
         self.L.altro_hip_last_solve_counts(self.h, C.byref(sw), C.byref(ml))
-        return dict(status=np.array([r.status for r in res]), iterations=np.array([r.iterations for r in res]),
-                    stationarity=np.array([r.stationarity for r in res]),
-                    alpha=np.array([r.final_alpha for r in res]), phi=np.array([r.final_phi for r in res]),
-                    feasibility=np.array([r.primal_feasibility for r in res]),
-                    penalty=np.array([r.penalty for r in res]),
-                    dual_updates=np.array([r.dual_updates for r in res]),
-                    reg_retries=np.array([r.reg_retries for r in res]),
+        rec = np.frombuffer(res, dtype=np.dtype(SolveResult))     # one view instead of 9 Python loops over the batch
+        return dict(status=rec["status"].copy(), iterations=rec["iterations"].copy(),
+                    stationarity=rec["stationarity"].copy(), alpha=rec["final_alpha"].copy(), phi=rec["final_phi"].copy(),
+                    feasibility=rec["primal_feasibility"].copy(), penalty=rec["penalty"].copy(),
+                    dual_updates=rec["dual_updates"].copy(), reg_retries=rec["reg_retries"].copy(),
                     sweeps=sw.value, merit_launches=ml.value)
 
 
