@@ -30,6 +30,18 @@ struct ModelParams {
   double lr;       // bicycle CoG -> rear axle (1.5)
 };
 
+// sin and cos of one argument with a single range reduction on the device
+template <typename T>
+ALTRO_HD void sincos_hd(T a, T* s, T* c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (sizeof(T) == 4) sincosf(a, s, c);
+  else sincos(a, s, c);
+#else
+  *s = sin(a);
+  *c = cos(a);
+#endif
+}
+
 // ---- continuous models: xdot = f(x, u), J = [df/dx df/du] column-major (n x (n+m)) ----------------
 template <typename T>
 ALTRO_HD void pendulum_f(const T* x, const T* u, T* xdot) {
@@ -47,18 +59,6 @@ ALTRO_HD void pendulum_J(const T* x, const T* u, T* J) {
   J[3] = -b / mm;
   J[4] = T(0);
   J[5] = T(1) / mm;
-}
-
-// sin and cos of one argument with a single range reduction on the device
-template <typename T>
-ALTRO_HD void sincos_hd(T a, T* s, T* c) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  if constexpr (sizeof(T) == 4) sincosf(a, s, c);
-  else sincos(a, s, c);
-#else
-  *s = sin(a);
-  *c = cos(a);
-#endif
 }
 
 // Trigonometry of the kinematic bicycle (test/test_utils.cpp:134-238) at one point.  The reference's test model
@@ -174,7 +174,14 @@ struct DiscreteModel {
   }
 
   static ALTRO_HD void cont_fJ(const ModelParams& mp, const T* x, const T* u, T* xdot, T* J) {
-    if (KIND == MODEL_PENDULUM) { pendulum_f<T>(x, u, xdot); pendulum_J<T>(x, u, J); }
+    if (KIND == MODEL_PENDULUM) {   // one sincos for f (sin) and J (cos)
+      const T l = T(0.5), g = T(9.81), b = T(0.1), mm = T(1.0) * l * l;
+      T sn, cs;
+      sincos_hd<T>(x[0], &sn, &cs);
+      xdot[0] = x[1];
+      xdot[1] = u[0] / mm - g * sn / l - b * x[1] / mm;
+      J[0] = T(0); J[1] = -g * cs / l; J[2] = T(1); J[3] = -b / mm; J[4] = T(0); J[5] = T(1) / mm;
+    }
     else bicycle_fJ<T>(mp, x, u, xdot, J);
   }
 
