@@ -1651,6 +1651,13 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
     ++total_merit_launches;
     if ((rc = zero_counter(0))) return rc;
     if (ilqr_launch_loop(h->stream, ILK_LS_BEGIN, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
+    // The first trial step is launched without asking the device whether any problem needs it: the masks make it a
+    // no-op when none does, and it saves one host read-back per sweep (these loops are latency-bound).
+    rc = ilqr_run(h, IK_MERIT, true, true, 1, 0.0);
+    if (rc) return rc;
+    ++total_merit_launches;
+    if ((rc = zero_counter(0))) return rc;
+    if (ilqr_launch_loop(h->stream, ILK_LS_FEED, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
     if ((rc = read_counters())) return rc;
     int guard = 0;
     while (counters[0] > 0 && guard++ < 64) {
