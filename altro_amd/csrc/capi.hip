@@ -1496,8 +1496,6 @@ int altro_hip_add_linear_constraint(altro_hip_batch* h, int k_first, int k_last,
     return fail(ALTRO_HIP_ERR_UNSUPPORTED, "constraints need plan LANE or MFMA16");
   if (!G || !g) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "G and g are required");
   if (cone < CONE_EQUALITY || cone > CONE_SOC) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "unknown cone %d", cone);
-  if (cone == CONE_SOC && h->plan != ALTRO_HIP_PLAN_LANE)
-    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "second-order-cone blocks are a plan-LANE feature");
   const int pmax = cone == CONE_SOC ? AL_MAXSOC : AL_MAXP;
   if (p < 1 || p > pmax) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "constraint dimension %d outside [1, %d]", p, pmax);
   if (k_first < 0 || k_last > h->N || k_first > k_last)

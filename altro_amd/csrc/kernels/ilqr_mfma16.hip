@@ -8,9 +8,9 @@
 //   SolverImpl::MeritFunction     solver.cpp:273-355   -> wave_merit_kernel
 //   SolverImpl::Stationarity      solver.cpp:207-222   -> wave_stationarity_kernel
 // The line search, convergence logic and sweep sequencing are the plan-independent kernels of
-// ilqr_loop_kernels.hip driven by altro_hip_ilqr_solve.  Linear constraint blocks c = G [x;u] - g in the zero /
-// identity / orthant cones (knotpoint_data.cpp:489-613 restricted to cones whose projection is diagonal) are
-// evaluated by lanes 48..55 (one constraint row each); second-order cones are a plan-LANE feature.
+// ilqr_loop_kernels.hip driven by altro_hip_ilqr_solve.  Linear constraint blocks c = G [x;u] - g
+// (knotpoint_data.cpp:489-613) are evaluated by lanes 48..55, one constraint row each (a second-order-cone block
+// as a whole by lane 48).
 //
 // The linear dynamics make the expansion trivial -- A, B are the data, and the reference zeroes the affine term
 // of the EXPANSION (f_.setZero(), knotpoint_data.cpp:416) while the rollout keeps it -- so the backward sweep runs
@@ -28,6 +28,7 @@
 
 #include "ilqr_types.h"
 #include "mfma16_layout.h"
+#include "al_lane.hip"   // soc_projection / soc_jacobian / soc_hessian
 
 namespace altro_hip {
 
@@ -42,45 +43,101 @@ __device__ __forceinline__ double wave_max(double v) {
   return v;
 }
 
-// Constraint rows of knot point k for this wave's problem.  Lane `row_lane` (48 + i, i < 8) owns row i of each of
-// the (at most two) blocks: value, estimated / projected dual, AL cost share, violation; it publishes
-//   jv[c * 8 + i] = mask * z_proj   (gradient factor J^T z_proj, cones.cpp:153-178 are diagonal here)
-//   mk[c * 8 + i] = mask            (Gauss-Newton factor)
-// to LDS for the lanes that own gradient / Hessian entries.  xs / us: the point, in LDS.  With dual_update the
+// Constraint rows of knot point k for this wave's problem.  Lane 48 + i (i < 8) owns row i of each of the (at most
+// two) blocks -- value, estimated / projected dual, AL cost share, violation -- and publishes to LDS, for the lanes
+// that own gradient / Hessian entries,
+//   jv[c * 8 + i]        = (J^T z_proj)_i                      gradient factor (cones.cpp:153-178)
+//   Jm[c * 64 + i * 8 + r] = J_ir  (projection Jacobian, p x p)  Gauss-Newton factor        (Jm may be nullptr)
+//   Hm[c * 16 + i * 4 + r] = (d/dz J^T z_proj)_ir               second-order-cone curvature  (Hm may be nullptr)
+// For the zero / identity / orthant cones J is diagonal and the curvature vanishes.  A second-order-cone block
+// (p <= 4, cones.cpp:13-123) is evaluated as a whole by lane 48.  xs / us: the point, in LDS.  With dual_update the
 // projected dual becomes the dual (knotpoint_data.cpp:503-510).  Must be called by all lanes (no barrier inside).
 template <typename S>
 __device__ __forceinline__ void wave_al_rows(const AlTable<S>& t, int k, int b, int64_t B, const double* xs, const double* us,
-                                             bool terminal, double rho_est, int lane, double* jv, double* mk, double& cost,
-                                             double& viol, bool dual_update) {
+                                             bool terminal, double rho_est, int lane, double* jv, double* Jm, double* Hm,
+                                             double& cost, double& viol, bool dual_update) {
   int zshift;
   const AlKnot ALTRO_CONST_AS& kn = al_knot<S>(t, k, zshift);
   const int i = lane - 48;
   const bool row_lane = (i >= 0 && i < AL_MAXP);
 #pragma unroll
   for (int c = 0; c < AL_MAXC; ++c) {
-    double jvv = 0.0, mkv = 0.0;
-    if (c < kn.ncon && row_lane && i < kn.p[c]) {
-      const int p = kn.p[c], cone = kn.cone[c];
-      const S* G = t.G + kn.G_off[c];
-      double s = 0.0;
-#pragma unroll
-      for (int e = 0; e < 12; ++e) s += (double)G[i + e * p] * xs[e];
-      if (!terminal) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) s += (double)G[i + (12 + e) * p] * us[e];
-      }
-      const double gi = kn.g_per_problem[c] ? (double)t.g[kn.g_off[c] + (int64_t)i * B + b] : (double)t.g[kn.g_off[c] + i];
-      const double val = s - gi;
-      S* zp_ = t.z + (int64_t)(kn.z_off[c] + zshift + i) * B + b;
-      const double ze = (double)*zp_ - rho_est * val;
-      double zp = 0.0;
-      if (cone == CONE_EQUALITY) { zp = ze; mkv = 1.0; viol = fmax(viol, fabs(val)); }
-      else if (cone == CONE_INEQUALITY) { zp = fmin(0.0, ze); mkv = (ze <= 0.0) ? 1.0 : 0.0; viol = fmax(viol, fabs(fmin(0.0, val) - val)); }
-      cost += zp * zp / (2.0 * rho_est);
-      jvv = mkv * zp;
-      if (dual_update) *zp_ = (S)zp;
+    const bool has = c < kn.ncon;
+    const int p = has ? kn.p[c] : 0, cone = has ? kn.cone[c] : CONE_IDENTITY;
+    const S* G = t.G + (has ? kn.G_off[c] : 0);
+    if (row_lane) {   // clear this lane's row of the published matrices
+      jv[c * AL_MAXP + i] = 0.0;
+      if (Jm)
+        for (int r = 0; r < AL_MAXP; ++r) Jm[c * 64 + i * 8 + r] = 0.0;
+      if (Hm && i < AL_MAXSOC)
+        for (int r = 0; r < AL_MAXSOC; ++r) Hm[c * 16 + i * 4 + r] = 0.0;
     }
-    if (row_lane) { jv[c * AL_MAXP + i] = jvv; mk[c * AL_MAXP + i] = mkv; }
+    if (!has) continue;
+    if (cone != CONE_SOC) {
+      if (row_lane && i < p) {
+        double s = 0.0;
+#pragma unroll
+        for (int e = 0; e < 12; ++e) s += (double)G[i + e * p] * xs[e];
+        if (!terminal) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) s += (double)G[i + (12 + e) * p] * us[e];
+        }
+        const double gi = kn.g_per_problem[c] ? (double)t.g[kn.g_off[c] + (int64_t)i * B + b] : (double)t.g[kn.g_off[c] + i];
+        const double val = s - gi;
+        S* zp_ = t.z + (int64_t)(kn.z_off[c] + zshift + i) * B + b;
+        const double ze = (double)*zp_ - rho_est * val;
+        double zp = 0.0, mkv = 0.0;
+        if (cone == CONE_EQUALITY) { zp = ze; mkv = 1.0; viol = fmax(viol, fabs(val)); }
+        else if (cone == CONE_INEQUALITY) { zp = fmin(0.0, ze); mkv = (ze <= 0.0) ? 1.0 : 0.0; viol = fmax(viol, fabs(fmin(0.0, val) - val)); }
+        cost += zp * zp / (2.0 * rho_est);
+        jv[c * AL_MAXP + i] = mkv * zp;
+        if (Jm) Jm[c * 64 + i * 8 + i] = mkv;
+        if (dual_update) *zp_ = (S)zp;
+      }
+    } else if (i == 0) {   // the whole second-order-cone block on one lane
+      double val[AL_MAXSOC], ze[AL_MAXSOC], zp[AL_MAXSOC], pv[AL_MAXSOC];
+#pragma unroll
+      for (int r = 0; r < AL_MAXSOC; ++r) {
+        val[r] = 0.0; ze[r] = 0.0;
+        if (r < p) {
+          double s = 0.0;
+          for (int e = 0; e < 12; ++e) s += (double)G[r + e * p] * xs[e];
+          if (!terminal)
+            for (int e = 0; e < 4; ++e) s += (double)G[r + (12 + e) * p] * us[e];
+          const double gi = kn.g_per_problem[c] ? (double)t.g[kn.g_off[c] + (int64_t)r * B + b] : (double)t.g[kn.g_off[c] + r];
+          val[r] = s - gi;
+          ze[r] = (double)t.z[(int64_t)(kn.z_off[c] + zshift + r) * B + b] - rho_est * val[r];
+        }
+      }
+      soc_projection<double>(p, ze, zp);
+      soc_projection<double>(p, val, pv);
+      double sq = 0.0;
+#pragma unroll
+      for (int r = 0; r < AL_MAXSOC; ++r)
+        if (r < p) { sq += zp[r] * zp[r]; viol = fmax(viol, fabs(pv[r] - val[r])); }
+      cost += sq / (2.0 * rho_est);
+      double J[AL_MAXSOC * AL_MAXSOC];
+      soc_jacobian<double>(p, ze, J);
+#pragma unroll
+      for (int r = 0; r < AL_MAXSOC; ++r) {
+        if (r >= p) continue;
+        double sj = 0.0;
+#pragma unroll
+        for (int q = 0; q < AL_MAXSOC; ++q) sj += J[q + r * AL_MAXSOC] * zp[q];     // (J^T z_proj)_r
+        jv[c * AL_MAXP + r] = sj;
+        if (Jm)
+          for (int q = 0; q < AL_MAXSOC; ++q) Jm[c * 64 + r * 8 + q] = J[r + q * AL_MAXSOC];
+        if (dual_update) t.z[(int64_t)(kn.z_off[c] + zshift + r) * B + b] = (S)zp[r];
+      }
+      if (Hm) {
+        double Hp[AL_MAXSOC * AL_MAXSOC];
+        soc_hessian<double>(p, ze, zp, Hp);
+#pragma unroll
+        for (int r = 0; r < AL_MAXSOC; ++r)
+#pragma unroll
+          for (int q = 0; q < AL_MAXSOC; ++q) Hm[c * 16 + r * 4 + q] = Hp[r + q * AL_MAXSOC];
+      }
+    }
   }
 }
 // sum_c sum_i G_c[i][e] * w[c * 8 + i]  for column e of the constraint Jacobians of knot point k
@@ -152,7 +209,7 @@ __global__ void wave_accept_kernel(IlqrWaveArgs<S> a) {
 //                    set by altro_hip_set_tracking_cost stay as they are.
 template <typename S>
 __global__ __launch_bounds__(64) void wave_expand_kernel(IlqrWaveArgs<S> a) {
-  __shared__ double xs[12], us[4], jv[AL_MAXC * AL_MAXP], mk[AL_MAXC * AL_MAXP];
+  __shared__ double xs[12], us[4], jv[AL_MAXC * AL_MAXP], Jm[AL_MAXC * 64], Hm[AL_MAXC * 16];
   const int lane = threadIdx.x;
   const int64_t wk = blockIdx.x;
   const int b = (int)(wk % a.batch), k = (int)(wk / a.batch);
@@ -168,7 +225,7 @@ __global__ __launch_bounds__(64) void wave_expand_kernel(IlqrWaveArgs<S> a) {
   const bool al = a.al.enabled != 0;
   if (al) {
     double cost = 0.0, viol = 0.0;
-    wave_al_rows<S>(a.al, k, b, a.batch, xs, us, terminal, a.prob[b].rho_est, lane, jv, mk, cost, viol, false);
+    wave_al_rows<S>(a.al, k, b, a.batch, xs, us, terminal, a.prob[b].rho_est, lane, jv, Jm, Hm, cost, viol, false);
   }
   __syncthreads();
   if (grad && lane < 16) {
@@ -197,7 +254,20 @@ __global__ __launch_bounds__(64) void wave_expand_kernel(IlqrWaveArgs<S> a) {
       for (int cidx = 0; cidx < kn.ncon; ++cidx) {
         const int p = kn.p[cidx];
         const S* G = a.al.G + kn.G_off[cidx];
-        for (int i = 0; i < p; ++i) s += (mk[cidx * AL_MAXP + i] * (double)G[i + r * p]) * (mk[cidx * AL_MAXP + i] * (double)G[i + cc * p]);
+        const double* Jc = Jm + cidx * 64;
+        for (int i = 0; i < p; ++i) {   // (J G)_{i r} (J G)_{i cc}
+          double jr = 0.0, jc = 0.0;
+          for (int q = 0; q < p; ++q) { jr += Jc[i * 8 + q] * (double)G[q + r * p]; jc += Jc[i * 8 + q] * (double)G[q + cc * p]; }
+          s += jr * jc;
+        }
+        if (kn.cone[cidx] == CONE_SOC) {   // + G^T (d/dz J^T z_proj) G   (knotpoint_data.cpp:561-567)
+          const double* Hc = Hm + cidx * 16;
+          for (int i = 0; i < p; ++i) {
+            double hc = 0.0;
+            for (int q = 0; q < p; ++q) hc += Hc[i * 4 + q] * (double)G[q + cc * p];
+            s += (double)G[i + r * p] * hc;
+          }
+        }
       }
       v += rho * s;
       if (terminal) a.term[(size_t)b * MF_TERM + r * 12 + cc] = (S)v;
@@ -210,7 +280,7 @@ __global__ __launch_bounds__(64) void wave_expand_kernel(IlqrWaveArgs<S> a) {
 // DualUpdate (knotpoint_data.cpp:503-510) for the problems whose sweep asked for it, one wave per (problem, knot point)
 template <typename S>
 __global__ __launch_bounds__(64) void wave_dual_update_kernel(IlqrWaveArgs<S> a) {
-  __shared__ double xs[12], us[4], jv[AL_MAXC * AL_MAXP], mk[AL_MAXC * AL_MAXP];
+  __shared__ double xs[12], us[4], jv[AL_MAXC * AL_MAXP], Jm[AL_MAXC * 64], Hm[AL_MAXC * 16];
   const int lane = threadIdx.x;
   const int64_t wk = blockIdx.x;
   const int b = (int)(wk % a.batch), k = (int)(wk / a.batch);
@@ -222,7 +292,7 @@ __global__ __launch_bounds__(64) void wave_dual_update_kernel(IlqrWaveArgs<S> a)
   if (lane >= 12 && lane < 16) us[lane - 12] = terminal ? 0.0 : (double)c[24 + lane - 12];
   __syncthreads();
   double cost = 0.0, viol = 0.0;
-  wave_al_rows<S>(a.al, k, b, a.batch, xs, us, terminal, a.prob[b].rho_est, lane, jv, mk, cost, viol, true);
+  wave_al_rows<S>(a.al, k, b, a.batch, xs, us, terminal, a.prob[b].rho_est, lane, jv, nullptr, nullptr, cost, viol, true);
 }
 
 // One knot point's merit-function operands, loaded coalesced (lane -> consecutive element) and staged into an LDS
@@ -264,7 +334,7 @@ template <typename S>
 __global__ __launch_bounds__(64) void wave_merit_kernel(IlqrWaveArgs<S> a) {
   constexpr int DEPTH = 2;
   __shared__ double img[MW_IMG + 4];
-  __shared__ double xs[12], dxs[12], das[12], us[4], dus[4], jv[AL_MAXC * AL_MAXP], mk[AL_MAXC * AL_MAXP];
+  __shared__ double xs[12], dxs[12], das[12], us[4], dus[4], jv[AL_MAXC * AL_MAXP];
   __shared__ double crec[28], qrec[16];     // candidate record x | y | u and [lx lu], gathered for one coalesced store
   const int b = blockIdx.x, lane = threadIdx.x;
   if (b >= a.batch) return;
@@ -347,7 +417,7 @@ __global__ __launch_bounds__(64) void wave_merit_kernel(IlqrWaveArgs<S> a) {
     }
     if (al) {
       double Jal = 0.0;
-      wave_al_rows<S>(a.al, kc, b, a.batch, xs, us, false, rho, lane, jv, mk, Jal, viol, false);
+      wave_al_rows<S>(a.al, kc, b, a.batch, xs, us, false, rho, lane, jv, nullptr, nullptr, Jal, viol, false);
       if (live) J += Jal;
     }
     __syncthreads();
@@ -389,7 +459,7 @@ __global__ __launch_bounds__(64) void wave_merit_kernel(IlqrWaveArgs<S> a) {
       if (lane == 0) J += (double)cp[32];
     }
     __syncthreads();
-    if (al) wave_al_rows<S>(a.al, N, b, a.batch, xs, us, true, rho, lane, jv, mk, J, viol, false);
+    if (al) wave_al_rows<S>(a.al, N, b, a.batch, xs, us, true, rho, lane, jv, nullptr, nullptr, J, viol, false);
     if (is_y) {
       double s = 0.0;
 #pragma unroll
@@ -440,7 +510,7 @@ __global__ __launch_bounds__(64) void wave_stationarity_kernel(IlqrWaveArgs<S> a
   // Feasibility (solver.cpp:224-231) of the candidate trajectory
   double viol = 0.0;
   if (a.al.enabled) {
-    __shared__ double xs[12], us[4], jv[AL_MAXC * AL_MAXP], mk[AL_MAXC * AL_MAXP];
+    __shared__ double xs[12], us[4], jv[AL_MAXC * AL_MAXP], Jm[AL_MAXC * 64], Hm[AL_MAXC * 16];
     const double rho = a.prob[b].rho;
     for (int k = 0; k <= N; ++k) {
       const S* c = a.cand + (size_t)b * a.xuy_bs + (size_t)k * a.xuy_ks;
@@ -449,7 +519,7 @@ __global__ __launch_bounds__(64) void wave_stationarity_kernel(IlqrWaveArgs<S> a
       if (lane >= 12 && lane < 16) us[lane - 12] = k < N ? (double)c[24 + lane - 12] : 0.0;
       __syncthreads();
       double cost = 0.0;
-      wave_al_rows<S>(a.al, k, b, a.batch, xs, us, k == N, rho, lane, jv, mk, cost, viol, false);
+      wave_al_rows<S>(a.al, k, b, a.batch, xs, us, k == N, rho, lane, jv, nullptr, nullptr, cost, viol, false);
     }
     viol = wave_max(viol);
   }

@@ -165,8 +165,8 @@ int altro_hip_get_qblocks(altro_hip_batch* h, double* qblocks);
  * altro_hip_set_dynamics, the reference's SetLinearDynamics path (knotpoint_data.cpp:123-142, :406-419,
  * :710-719) -- with the tracking cost below; no altro_hip_set_model.  From altro_hip_set_tracking_cost on, the
  * backward sweep of such a handle ignores f, as the reference's expansion does (f_.setZero(), :416), while the
- * rollout keeps it.  Constraint blocks in the zero / identity / orthant cones work on both plans (second-order
- * cones and the regularisation schedule are plan-LANE features).                                       */
+ * rollout keeps it.  Constraint blocks (all four cones) work on both plans; the regularisation schedule is a
+ * plan-LANE feature.                                                                                    */
 /* Device model standing in for SetExplicitDynamics' host callbacks (altro_solver.cpp:68-81).        */
 int altro_hip_set_model(altro_hip_batch* h, int model, float timestep, int bicycle_frame,
                         double bicycle_length, double bicycle_lr);
@@ -193,8 +193,7 @@ int altro_hip_get_expansion(altro_hip_batch* h, double* A, double* B, double* lx
  * which covers every constraint of the reference's tests (goal, control bounds, second-order-cone bound).
  * G: host, p x (n+m) column-major, shared by the batch.  g: host, [p] or (g_per_problem) [batch][p].
  * cone: ConstraintType order of typedefs.hpp:29-34: 0 EQUALITY, 1 IDENTITY, 2 INEQUALITY (c <= 0),
- * 3 SECOND_ORDER_CONE (||c[0:p-1]|| <= c[p-1], plan LANE only).  At most 2 blocks per knot point, p <= 8
- * (SOC: p <= 4).
+ * 3 SECOND_ORDER_CONE (||c[0:p-1]|| <= c[p-1]).  At most 2 blocks per knot point, p <= 8 (SOC: p <= 4).
  * Returns the block id (>= 0) or a negative error.  Duals and penalties live on the device per problem and,
  * like the reference's, persist from one solve to the next (warm-started MPC) until reset.             */
 int altro_hip_add_linear_constraint(altro_hip_batch* h, int k_first, int k_last, int cone, int p,

@@ -174,8 +174,6 @@ def test_constrained_lq_solve_mfma16():
     bt = make_hip(p)
     for (k0, k1, cone, G, g) in blocks:
         bt.add_linear_constraint(k0, k1, cone, G, g)
-    with pytest.raises(altro_amd.AltroHipError):
-        bt.add_linear_constraint(0, 0, altro_amd.CONE_SOC, np.zeros((3, 16)), np.zeros(3))   # SOC: plan LANE only
     res = bt.ilqr_solve(iterations_max=60, penalty_initial=1.0, penalty_scaling=10.0)
     x, u = bt.get_nominal()
     nconv = 0
@@ -244,3 +242,36 @@ def test_receding_horizon_ops_mfma16():
         bt.update_linear_costs(qnew, None, cnew, 0, N)
         bt.set_initial_state(x1)
         bt.shift_trajectory()
+
+
+def test_second_order_cone_block_mfma16():
+    """A second-order-cone block on the (12, 4) plan: || (u0, u1, u2) || <= 0.35 at every k < N (the form of
+    double_integrator_test.cpp:414-448), against the oracle per problem."""
+    batch = 12
+    p = make_problem(batch, False)
+    w = n + m
+    Gs = np.zeros((4, w)); Gs[0, 12] = 1.0; Gs[1, 13] = 1.0; Gs[2, 14] = 1.0
+    gs = np.array([0.0, 0.0, 0.0, -0.35])
+    bt = make_hip(p)
+    bt.add_linear_constraint(0, N - 1, altro_amd.CONE_SOC, Gs, gs)
+    res = bt.ilqr_solve(iterations_max=80, penalty_initial=1.0, penalty_scaling=10.0)
+    x, u = bt.get_nominal()
+    nconv = 0
+    for b in [0, 5, 11]:
+        s = make_oracle(p, b)
+        for k in range(N):
+            s.add_linear_constraint(k, oracle.CONE_SOC, Gs, gs)
+        s.L.oracle_ilqr_initialize(s.h)
+        for k in range(N):
+            s.L.oracle_ilqr_set_input(s.h, k, np.ascontiguousarray(p["u0"][b, k]))
+        s.set_penalty(1.0, 10.0)
+        s.L.oracle_ilqr_set_options(s.h, 80, 1e-4, 1e-4, 1e-8, 0)
+        status, iters, log = s.solve()
+        assert res["status"][b] == status and res["iterations"][b] == iters, (b, res["status"][b], status, res["iterations"][b], iters)
+        if status != 0:
+            continue
+        nconv += 1
+        np.testing.assert_allclose(x[b], s.get("x"), rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(u[b], s.get("u"), rtol=1e-5, atol=1e-5)
+        assert np.linalg.norm(u[b][:, :3], axis=1).max() <= 0.35 + 2e-4
+    assert nconv >= 2
