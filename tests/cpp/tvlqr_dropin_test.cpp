@@ -2,6 +2,7 @@
 // known-answer problem pushed through the three tvlqr_* entry points with the reference's calling
 // convention (arrays of per-knot-point pointers into ONE flat buffer sized by tvlqr_TotalMemSize).
 // Links against libaltro_hip.so; needs an MI355X.  Prints "OK" and returns 0 on success.
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -89,6 +90,16 @@ int main() {
   res = tvlqr_BackwardPass(nx, nu, N, A, B, f, Q, R, H, q, r, 2e6, K, d, P, p, delta_V, Qxx, Quu, Qux,
                            Qx, Qu, Qxx_t, Quu_t, Qux_t, Qx_t, Qu_t, false, is_diag);
   CHECK(res == TVLQR_SUCCESS);
+  {   // latency of ONE call through the kernel boundary (informative: the boundary is for compatibility, the
+      // throughput comes from the batched C ABI)
+    const auto t0 = std::chrono::steady_clock::now();
+    const int reps = 200;
+    for (int i = 0; i < reps; ++i)
+      tvlqr_BackwardPass(nx, nu, N, A, B, f, Q, R, H, q, r, 2e6, K, d, P, p, delta_V, Qxx, Quu, Qux, Qx, Qu, Qxx_t, Quu_t,
+                         Qux_t, Qx_t, Qu_t, false, is_diag);
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps;
+    std::printf("tvlqr_BackwardPass (N = %d, n = %d, m = %d) through the drop-in: %.1f us per call\n", N, n, m, us);
+  }
   std::printf("OK\n");
   return 0;
 }
