@@ -471,3 +471,32 @@ def test_device_pointer_mode(n, m, plan):
             bt.set_tracking_cost(np.ones((batch, N + 1, n)), np.ones((batch, N, m)), np.zeros((batch, N + 1, n)), np.zeros((batch, N, m)))
     bt.set_pointer_mode(False)
     assert np.array_equal(bt.get("K"), ref["K"])
+
+
+def test_large_batch_c1_uses_the_hbm():
+    """Eight times the metric's batch on one GPU (32768 problems x 256 knot points: ~45 GB of records -- the layouts
+    are sized for 288 GB).  Size-independent checks: all factorizations succeed, identical problems give identical
+    bits across the whole batch, and the first / last problems equal the same problems solved in a small batch."""
+    batch, N, n, m = 32768, 256, 12, 4
+    one = problems.c1_double_integrator(1, N=N)
+    x0 = 2.0 * problems.uniform01((batch, n), 21) - 1.0
+    x0[batch - 1] = x0[0]
+
+    def run(bsz, x0s):
+        bt = altro_amd.Batch(N, n, m, bsz)
+        bt.set_dynamics(one["A"][0, :1], one["B"][0, :1], None, k_stride_zero=True, batch_stride_zero=True)
+        Q2 = np.stack([one["Q"][0, 0], one["Q"][0, N]])
+        bt.set_cost(Q2, one["R"][0, :1], one["H"][0, :1], np.zeros((2, n)), one["r"][0, :1], k_stride_zero=True,
+                    batch_stride_zero=True)
+        bt.set_initial_state(x0s)
+        bt.sweep()
+        return bt
+    big = run(batch, x0)
+    assert big.L.altro_hip_batch_device_bytes(big.h) > 40e9
+    assert (big.get("status") == -1).all()
+    x_last = big.get("x")[:, -1]          # [batch, n] slice of a 800 MB download
+    assert np.array_equal(x_last[0], x_last[batch - 1])
+    small = run(3, x0[[0, 12345, batch - 1]])
+    assert np.array_equal(small.get("x")[:, -1], x_last[[0, 12345, batch - 1]])
+    dV = big.get("delta_V")
+    assert np.isfinite(dV).all() and np.isfinite(x_last).all()
