@@ -915,6 +915,7 @@ int altro_hip_set_cost(altro_hip_batch* h, const double* Q, const double* R, con
   if (rc) return rc;
   if (!Q || !R || !q || !r) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "Q, R, q, r are required");
   if (!is_diag && !H) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "H is required for a dense cost");
+  h->ilqr_linear = false;   // explicit cost blocks = TVLQR semantics again (altro_hip_set_tracking_cost sets it back)
   const int n = h->n, m = h->m, N = h->N;
   Dims d{n, m};
   h->is_diag = is_diag ? 1 : 0;
