@@ -70,6 +70,27 @@ class Stats(C.Structure):
                 ("max_abs_xN", C.c_double)]
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch wheels bundle their own libamdhip64 with the same SONAME (libamdhip64.so.7) as /opt/rocm's.  Whichever
+    copy a process loads first serves every later request for that SONAME -- but torch asks for it by file name, so a
+    process that loaded the system copy through libaltro_hip.so and imports torch afterwards ends up with TWO HIP
+    runtimes, and torch may then fail to find the GPU.  When torch is installed (it need not be imported), load its
+    copy first so that this library and a later `import torch` share one runtime.  ALTRO_HIP_SYSTEM_RUNTIME=1 opts out."""
+    import sys
+    if "torch" in sys.modules or os.environ.get("ALTRO_HIP_SYSTEM_RUNTIME"):
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(path):
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except (OSError, ImportError, ValueError):
+        pass
+
+
 _lib = None
 
 
@@ -80,6 +101,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise AltroHipError("%s is missing: run `python -m altro_amd.build` (hipcc, gfx950). "
                                 "There is no CPU fallback." % LIB_PATH)
+        _share_hip_runtime_with_torch()
         L = C.CDLL(LIB_PATH)
         vp, i, d = C.c_void_p, C.c_int, C.c_double
         L.altro_hip_last_error.restype = C.c_char_p
