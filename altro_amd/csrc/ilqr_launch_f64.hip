@@ -31,7 +31,10 @@ int ilqr_launch_kernel<double>(hipStream_t stream, int which, int kind, int n, i
       case IK_MERIT: hipLaunchKernelGGL((ilqr_merit_kernel<K_, N_, M_, T>), lanes, b64, 0, stream, a); break;       \
       case IK_DUAL: hipLaunchKernelGGL((ilqr_dual_update_kernel<N_, M_, T>), flat, b256, 0, stream, a); break;      \
       case IK_SHIFT: hipLaunchKernelGGL((ilqr_shift_kernel<N_, M_, T>), shift, b256, 0, stream, a); break;          \
-      default: hipLaunchKernelGGL((ilqr_stationarity_kernel<N_, M_, T>), lanes, b64, 0, stream, a); break;          \
+      default:                                                                                                \
+        hipLaunchKernelGGL(ilqr_zero_residuals_kernel<T>, dim3((a.batch + 255) / 256), b256, 0, stream, a);    \
+        hipLaunchKernelGGL((ilqr_stationarity_kernel<N_, M_, T>), flat64, b64, 0, stream, a);                   \
+        break;                                                                                                \
     }                                                                                                         \
   }
   ILQR_MODELS(X)

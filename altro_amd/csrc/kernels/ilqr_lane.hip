@@ -358,52 +358,63 @@ __global__ __launch_bounds__(64) void ilqr_merit_kernel(IlqrArgs<T> a) {
   if (al) a.prob[b].rho_est = (double)rho;
 }
 
-// Stationarity (solver.cpp:207-222) from the candidate duals and the current expansion
+// Stationarity (solver.cpp:207-222) and Feasibility (solver.cpp:224-231) of the candidate trajectory: maxima over
+// knot points of independent per-knot-point residuals, so one thread per (problem, knot point) and an atomic max per
+// problem (non-negative doubles order like their bit patterns) -- not an N-step loop per problem, which would be
+// one more latency chain in every sweep.  ilqr_zero_residuals_kernel runs first.
+template <typename T>
+__global__ void ilqr_zero_residuals_kernel(IlqrArgs<T> a) {
+  const int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (b >= a.batch) return;
+  if (a.active && !a.active[b]) return;
+  a.prob[b].stationarity = 0.0;
+  a.prob[b].feasibility = 0.0;
+}
 template <int n, int m, typename T>
 __global__ __launch_bounds__(64) void ilqr_stationarity_kernel(IlqrArgs<T> a) {
   using D = LaneDims<n, m>;
   using I = IlqrDims<n, m>;
-  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
-  if (b >= a.batch) return;
-  if (a.active && !a.active[b]) return;
   const int64_t B = a.batch;
   const int N = a.N;
-  T res_x = T(0), res_u = T(0);
-  for (int k = 0; k < N; ++k) {
-    const T* in = a.in + (int64_t)k * D::E_IN * B + b;
+  const int64_t total = B * (N + 1);
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = t % B;
+    const int k = (int)(t / B);
+    if (a.active && !a.active[b]) continue;
     const T* c = a.cand + (int64_t)k * I::E_CAND * B + b;
-    const T* cn = a.cand + (int64_t)(k + 1) * I::E_CAND * B + b;
-    T yn[n];
-    for (int e = 0; e < n; ++e) yn[e] = cn[(int64_t)(n + e) * B];
-    for (int j = 0; j < n; ++j) {
-      T s = T(0);
-      for (int i = 0; i < n; ++i) s += in[(int64_t)(D::O_A + i + j * n) * B] * yn[i];
-      res_x = fmax(res_x, fabs(in[(int64_t)(D::O_q + j) * B] + s - c[(int64_t)(n + j) * B]));
+    T res = T(0);
+    if (k < N) {
+      const T* in = a.in + (int64_t)k * D::E_IN * B + b;
+      const T* cn = a.cand + (int64_t)(k + 1) * I::E_CAND * B + b;
+      T yn[n];
+      for (int e = 0; e < n; ++e) yn[e] = cn[(int64_t)(n + e) * B];
+      for (int j = 0; j < n; ++j) {
+        T s = T(0);
+        for (int i = 0; i < n; ++i) s += in[(int64_t)(D::O_A + i + j * n) * B] * yn[i];
+        res = fmax(res, fabs(in[(int64_t)(D::O_q + j) * B] + s - c[(int64_t)(n + j) * B]));
+      }
+      for (int j = 0; j < m; ++j) {
+        T s = T(0);
+        for (int i = 0; i < n; ++i) s += in[(int64_t)(D::O_B + i + j * n) * B] * yn[i];
+        res = fmax(res, fabs(in[(int64_t)(D::O_r + j) * B] + s));
+      }
+    } else {
+      for (int j = 0; j < n; ++j)
+        res = fmax(res, fabs(a.term[(int64_t)(n * n + j) * B + b] - c[(int64_t)(n + j) * B]));
     }
-    for (int j = 0; j < m; ++j) {
-      T s = T(0);
-      for (int i = 0; i < n; ++i) s += in[(int64_t)(D::O_B + i + j * n) * B] * yn[i];
-      res_u = fmax(res_u, fabs(in[(int64_t)(D::O_r + j) * B] + s));
+    atomicMax(reinterpret_cast<unsigned long long*>(&a.prob[b].stationarity),
+              (unsigned long long)__double_as_longlong((double)res));
+    if (a.al.enabled) {
+      const T rho = (T)a.prob[b].rho;
+      T x[n], u[m], viol = T(0);
+      for (int e = 0; e < n; ++e) x[e] = c[(int64_t)e * B];
+      for (int e = 0; e < m; ++e) u[e] = k < N ? c[(int64_t)(2 * n + e) * B] : T(0);
+      al_eval<n, m, T, false, false>(a.al, k, b, B, x, u, k == N, rho, rho, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                     &viol, false);
+      atomicMax(reinterpret_cast<unsigned long long*>(&a.prob[b].feasibility),
+                (unsigned long long)__double_as_longlong((double)viol));
     }
   }
-  const T* c = a.cand + (int64_t)N * I::E_CAND * B + b;
-  for (int j = 0; j < n; ++j)
-    res_x = fmax(res_x, fabs(a.term[(int64_t)(n * n + j) * B + b] - c[(int64_t)(n + j) * B]));
-  a.prob[b].stationarity = (double)fmax(res_x, res_u);
-  // Feasibility (solver.cpp:224-231): largest distance of a constraint value from its cone
-  T viol = T(0);
-  if (a.al.enabled) {
-    const T rho = (T)a.prob[b].rho;
-    for (int k = 0; k <= N; ++k) {
-      const T* ck = a.cand + (int64_t)k * I::E_CAND * B + b;
-      T x[n], u[m];
-      for (int e = 0; e < n; ++e) x[e] = ck[(int64_t)e * B];
-      for (int e = 0; e < m; ++e) u[e] = k < N ? ck[(int64_t)(2 * n + e) * B] : T(0);
-      al_eval<n, m, T, false, false>(a.al, k, b, B, x, u, k == N, rho, rho, nullptr, nullptr, nullptr, nullptr,
-                                     nullptr, &viol, false);
-    }
-  }
-  a.prob[b].feasibility = (double)viol;
 }
 
 // DualUpdate (knotpoint_data.cpp:503-510): z <- the projected duals of the accepted trajectory, one thread per
