@@ -356,10 +356,13 @@ int lane_launch(altro_hip_batch* h, bool backward, double reg) {
                 (T*)h->l_xuy, (T*)h->delta_V, h->status, h->N, h->batch, (T)reg, backward ? h->bwd_active : nullptr,
                 backward ? h->bwd_reg : nullptr};
   const dim3 grid((h->batch + 63) / 64), block(64);
-#define X(N_, M_)                                                                                     \
-  if (h->n == N_ && h->m == M_) {                                                                     \
-    if (backward) hipLaunchKernelGGL((lane_backward_kernel<N_, M_, T>), grid, block, 0, h->stream, a); \
-    else hipLaunchKernelGGL((lane_forward_kernel<N_, M_, T>), grid, block, 0, h->stream, a);           \
+  const bool fused = (h->flags & ALTRO_HIP_LANE_FUSED) != 0;
+#define X(N_, M_)                                                                                              \
+  if (h->n == N_ && h->m == M_) {                                                                              \
+    if (backward && fused) hipLaunchKernelGGL((lane_backward_kernel_fused<N_, M_, T>), grid, block, 0, h->stream, a); \
+    else if (backward) hipLaunchKernelGGL((lane_backward_kernel<N_, M_, T>), grid, block, 0, h->stream, a);    \
+    else if (fused) hipLaunchKernelGGL((lane_forward_kernel_fused<N_, M_, T>), grid, block, 0, h->stream, a);  \
+    else hipLaunchKernelGGL((lane_forward_kernel<N_, M_, T>), grid, block, 0, h->stream, a);                   \
   }
   LANE_SHAPES(X)
 #undef X

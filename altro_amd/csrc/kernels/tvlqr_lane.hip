@@ -19,7 +19,6 @@
 
 namespace altro_hip {
 
-#pragma clang fp contract(off)
 
 template <int n, int m>
 struct LaneDims {
@@ -79,289 +78,6 @@ __device__ __forceinline__ void lane_st(const LaneBuf& bf, uint32_t lane_off, ui
   }
 }
 
-// One knot point of the backward recursion (tvlqr.cpp:92-192) on a record already in registers.
-template <int n, int m, typename T>
-__device__ __forceinline__ void lane_backward_step(const T (&cur)[LaneDims<n, m>::E_IN], const LaneBuf& bo, uint32_t lane,
-                                                   uint32_t rowB, T reg, int k, T (&P)[n * n], T (&p)[n], T& dv0,
-                                                   T& dv1, int& fail_k) {
-  using D = LaneDims<n, m>;
-  T A[n * n], Bm[n * m], f[n], Qxx[n * n], Quu[m * m], Qux[m * n], Qx[n], Qu[m];
-#pragma unroll
-  for (int e = 0; e < n * n; ++e) A[e] = cur[D::O_A + e];
-#pragma unroll
-  for (int e = 0; e < n * m; ++e) Bm[e] = cur[D::O_B + e];
-#pragma unroll
-  for (int e = 0; e < n; ++e) f[e] = cur[D::O_f + e];
-#pragma unroll
-  for (int e = 0; e < n * n; ++e) Qxx[e] = cur[D::O_Q + e];
-#pragma unroll
-  for (int e = 0; e < m * m; ++e) Quu[e] = cur[D::O_R + e];
-#pragma unroll
-  for (int e = 0; e < m * n; ++e) Qux[e] = cur[D::O_H + e];
-#pragma unroll
-  for (int e = 0; e < n; ++e) Qx[e] = cur[D::O_q + e];
-#pragma unroll
-  for (int e = 0; e < m; ++e) Qu[e] = cur[D::O_r + e];
-
-  // Qxx_tmp = A^T P' ; Qux_tmp = B^T P' ; Qx_tmp = p' + P' f        (tvlqr.cpp:135,139,147-148)
-  T T1[n * n], T2[m * n], t[n];
-#pragma unroll
-  for (int j = 0; j < n; ++j)
-#pragma unroll
-    for (int i = 0; i < n; ++i) {
-      T s = T(0);
-#pragma unroll
-      for (int kk = 0; kk < n; ++kk) s += A[kk + i * n] * P[kk + j * n];
-      T1[i + j * n] = T(0) + s;
-    }
-#pragma unroll
-  for (int j = 0; j < n; ++j)
-#pragma unroll
-    for (int i = 0; i < m; ++i) {
-      T s = T(0);
-#pragma unroll
-      for (int kk = 0; kk < n; ++kk) s += Bm[kk + i * n] * P[kk + j * n];
-      T2[i + j * m] = T(0) + s;
-    }
-#pragma unroll
-  for (int i = 0; i < n; ++i) {
-    T s = T(0);
-#pragma unroll
-    for (int kk = 0; kk < n; ++kk) s += P[i + kk * n] * f[kk];
-    t[i] = p[i] + s;
-  }
-  // Qxx += Qxx_tmp A ; Quu += Qux_tmp B ; Qux += Qux_tmp A             (tvlqr.cpp:136,140,143)
-#pragma unroll
-  for (int j = 0; j < n; ++j)
-#pragma unroll
-    for (int i = 0; i < n; ++i) {
-      T s = T(0);
-#pragma unroll
-      for (int kk = 0; kk < n; ++kk) s += T1[i + kk * n] * A[kk + j * n];
-      Qxx[i + j * n] = Qxx[i + j * n] + s;
-    }
-#pragma unroll
-  for (int j = 0; j < m; ++j)
-#pragma unroll
-    for (int i = 0; i < m; ++i) {
-      T s = T(0);
-#pragma unroll
-      for (int kk = 0; kk < n; ++kk) s += T2[i + kk * m] * Bm[kk + j * n];
-      Quu[i + j * m] = Quu[i + j * m] + s;
-    }
-#pragma unroll
-  for (int j = 0; j < n; ++j)
-#pragma unroll
-    for (int i = 0; i < m; ++i) {
-      T s = T(0);
-#pragma unroll
-      for (int kk = 0; kk < n; ++kk) s += T2[i + kk * m] * A[kk + j * n];
-      Qux[i + j * m] = Qux[i + j * m] + s;
-    }
-  // Qx = q + A^T Qx_tmp ; Qu = r + B^T Qx_tmp                           (tvlqr.cpp:149-152)
-#pragma unroll
-  for (int i = 0; i < n; ++i) {
-    T s = T(0);
-#pragma unroll
-    for (int kk = 0; kk < n; ++kk) s += A[kk + i * n] * t[kk];
-    Qx[i] = Qx[i] + s;
-  }
-#pragma unroll
-  for (int i = 0; i < m; ++i) {
-    T s = T(0);
-#pragma unroll
-    for (int kk = 0; kk < n; ++kk) s += Bm[kk + i * n] * t[kk];
-    Qu[i] = Qu[i] + s;
-  }
-  // gains: K = Qux, d = -Qu, LL^T = Quu + reg I                          (tvlqr.cpp:155-166)
-  T K[m * n], d[m], L[m * m];
-#pragma unroll
-  for (int e = 0; e < m * n; ++e) K[e] = Qux[e];
-#pragma unroll
-  for (int e = 0; e < m; ++e) d[e] = -Qu[e];
-#pragma unroll
-  for (int e = 0; e < m * m; ++e) L[e] = Quu[e] + ((e % m == e / m) ? reg : T(0));
-  bool fail = false;
-#pragma unroll
-  for (int kk = 0; kk < m; ++kk) {
-    T x = L[kk + kk * m];
-#pragma unroll
-    for (int j = 0; j < kk; ++j) x -= L[kk + j * m] * L[kk + j * m];
-    if (x <= T(0)) fail = true;
-    x = sqrt(x);
-    L[kk + kk * m] = x;
-#pragma unroll
-    for (int i = kk + 1; i < m; ++i) {
-      T s = L[i + kk * m];
-#pragma unroll
-      for (int j = 0; j < kk; ++j) s -= L[i + j * m] * L[kk + j * m];
-      L[i + kk * m] = s / x;
-    }
-  }
-  const bool was_alive = fail_k < 0;
-  if (was_alive && fail) fail_k = k;
-  const bool alive = fail_k < 0;
-  if (was_alive && !alive) {  // tvlqr.cpp:162-164: K_k = Qux, d_k = -Qu stay unsolved; stop here
-#pragma unroll
-    for (int e = 0; e < m * n; ++e) lane_st<T>(bo, lane, (uint32_t)(D::O_K + e) * rowB, K[e]);
-#pragma unroll
-    for (int e = 0; e < m; ++e) lane_st<T>(bo, lane, (uint32_t)(D::O_d + e) * rowB, d[e]);
-  }
-  if (!alive) return;   // (lane-divergent only when a problem failed: rare)
-#pragma unroll
-  for (int c = 0; c < n + 1; ++c) {
-    T* rhs = (c < n) ? (K + c * m) : d;
-#pragma unroll
-    for (int i = 0; i < m; ++i) {
-      T s = rhs[i];
-#pragma unroll
-      for (int j = 0; j < i; ++j) s -= L[i + j * m] * rhs[j];
-      rhs[i] = s / L[i + i * m];
-    }
-#pragma unroll
-    for (int i = m - 1; i >= 0; --i) {
-      T s = rhs[i];
-#pragma unroll
-      for (int j = i + 1; j < m; ++j) s -= L[j + i * m] * rhs[j];
-      rhs[i] = s / L[i + i * m];
-    }
-  }
-  // cost-to-go                                                             (tvlqr.cpp:173-186)
-  T U[m * n], V[n * n], w[m];
-#pragma unroll
-  for (int j = 0; j < n; ++j)
-#pragma unroll
-    for (int i = 0; i < m; ++i) {
-      T s = T(0);
-#pragma unroll
-      for (int kk = 0; kk < m; ++kk) s += Quu[i + kk * m] * K[kk + j * m];
-      U[i + j * m] = T(0) + s;   // Qux_tmp = Quu K
-    }
-#pragma unroll
-  for (int j = 0; j < n; ++j)
-#pragma unroll
-    for (int i = 0; i < n; ++i) {
-      T s = T(0);
-#pragma unroll
-      for (int kk = 0; kk < m; ++kk) s += K[kk + i * m] * Qux[kk + j * m];
-      V[i + j * n] = T(0) + s;   // Qxx_tmp = K^T Qux
-    }
-#pragma unroll
-  for (int i = 0; i < m; ++i) {
-    T s = T(0);
-#pragma unroll
-    for (int kk = 0; kk < m; ++kk) s += Quu[i + kk * m] * d[kk];
-    w[i] = T(0) + s;             // Qu_tmp = Quu d
-  }
-  T Pk[n * n], pk[n];
-#pragma unroll
-  for (int j = 0; j < n; ++j)
-#pragma unroll
-    for (int i = 0; i < n; ++i) {
-      T s = T(0);
-#pragma unroll
-      for (int kk = 0; kk < m; ++kk) s += U[kk + i * m] * K[kk + j * m];
-      Pk[i + j * n] = Qxx[i + j * n] + s;
-    }
-#pragma unroll
-  for (int e = 0; e < n * n; ++e) Pk[e] -= V[e];
-#pragma unroll
-  for (int j = 0; j < n; ++j)
-#pragma unroll
-    for (int i = 0; i < n; ++i) Pk[i + j * n] -= V[j + i * n];
-#pragma unroll
-  for (int i = 0; i < n; ++i) {
-    T s = T(0);
-#pragma unroll
-    for (int kk = 0; kk < m; ++kk) s += U[kk + i * m] * d[kk];
-    T v = Qx[i] + T(-1) * s;
-    T s2 = T(0);
-#pragma unroll
-    for (int kk = 0; kk < m; ++kk) s2 += K[kk + i * m] * Qu[kk];
-    v = v + T(-1) * s2;
-    T s3 = T(0);
-#pragma unroll
-    for (int kk = 0; kk < m; ++kk) s3 += Qux[kk + i * m] * d[kk];
-    pk[i] = v + s3;
-  }
-  {  // tvlqr.cpp:189-191
-    T s0 = T(0), s1 = T(0);
-#pragma unroll
-    for (int i = 0; i < m; ++i) s0 += d[i] * Qu[i];
-#pragma unroll
-    for (int i = 0; i < m; ++i) s1 += d[i] * w[i];
-    dv0 += s0;
-    dv1 += T(0.5) * s1;
-  }
-#pragma unroll
-  for (int e = 0; e < m * n; ++e) lane_st<T>(bo, lane, (uint32_t)(D::O_K + e) * rowB, K[e]);
-#pragma unroll
-  for (int e = 0; e < m; ++e) lane_st<T>(bo, lane, (uint32_t)(D::O_d + e) * rowB, d[e]);
-#pragma unroll
-  for (int e = 0; e < n * n; ++e) { lane_st<T>(bo, lane, (uint32_t)(D::O_P + e) * rowB, Pk[e]); P[e] = Pk[e]; }
-#pragma unroll
-  for (int e = 0; e < n; ++e) { lane_st<T>(bo, lane, (uint32_t)(D::O_p + e) * rowB, pk[e]); p[e] = pk[e]; }
-}
-
-template <int n, int m, typename T>
-__global__ __launch_bounds__(64) void lane_backward_kernel(LaneArgs<T> a) {
-  using D = LaneDims<n, m>;
-  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
-  if (b >= a.batch) return;
-  if (a.active && !a.active[b]) return;
-  const int64_t B = a.batch;
-  const int N = a.N;
-  const uint32_t lane = threadIdx.x * (uint32_t)sizeof(T);
-  const uint32_t rowB = (uint32_t)B * (uint32_t)sizeof(T);
-  const int64_t b0 = (int64_t)blockIdx.x * 64;
-  const T* __restrict__ pin = a.in + b0;
-  T* __restrict__ pout = a.out + b0;
-  T P[n * n], p[n];
-  {   // all loads first, then all stores: interleaved they serialise into n*n + n round trips
-    const LaneBuf bt(a.term + b0), bn(a.outn + b0);
-#pragma unroll
-    for (int e = 0; e < n * n; ++e) P[e] = lane_ld<T>(bt, lane, (uint32_t)e * rowB);
-#pragma unroll
-    for (int e = 0; e < n; ++e) p[e] = lane_ld<T>(bt, lane, (uint32_t)(n * n + e) * rowB);
-#pragma unroll
-    for (int e = 0; e < n * n; ++e) lane_st<T>(bn, lane, (uint32_t)e * rowB, P[e]);
-#pragma unroll
-    for (int e = 0; e < n; ++e) lane_st<T>(bn, lane, (uint32_t)(n * n + e) * rowB, p[e]);
-  }
-  T dv0 = T(0), dv1 = T(0);
-  int fail_k = -1;
-  const T reg = a.reg_pp ? (T)a.reg_pp[b] : a.reg;
-  // ping-pong: the record of knot point k - 1 is requested before knot point k is computed (addresses do
-  // not depend on the recursion).  (6,3) has no registers left for a second record.
-  constexpr bool kPrefetch = D::E_IN <= 64;
-  T r0[D::E_IN], r1[kPrefetch ? D::E_IN : 1];
-  auto load = [&](T* r, int k) {
-    const LaneBuf bi(pin + (int64_t)k * D::E_IN * B);
-#pragma unroll
-    for (int e = 0; e < D::E_IN; ++e) r[e] = lane_ld<T>(bi, lane, (uint32_t)e * rowB);
-  };
-  if constexpr (kPrefetch) {
-    int k = N - 1;
-    load(r0, k);
-    for (; k >= 1; k -= 2) {
-      load(r1, k - 1);
-      lane_backward_step<n, m, T>(r0, LaneBuf(pout + (int64_t)k * D::E_OUT * B), lane, rowB, reg, k, P, p, dv0, dv1, fail_k);
-      load(r0, k >= 2 ? k - 2 : 0);
-      lane_backward_step<n, m, T>(r1, LaneBuf(pout + (int64_t)(k - 1) * D::E_OUT * B), lane, rowB, reg, k - 1, P, p, dv0, dv1, fail_k);
-    }
-    if (k == 0)
-      lane_backward_step<n, m, T>(r0, LaneBuf(pout), lane, rowB, reg, 0, P, p, dv0, dv1, fail_k);
-  } else {
-    for (int k = N - 1; k >= 0; --k) {
-      load(r0, k);
-      lane_backward_step<n, m, T>(r0, LaneBuf(pout + (int64_t)k * D::E_OUT * B), lane, rowB, reg, k, P, p, dv0, dv1, fail_k);
-    }
-  }
-  a.status[b] = fail_k;
-  a.delta_V[2 * b + 0] = dv0;
-  a.delta_V[2 * b + 1] = dv1;
-}
-
 // One knot point's forward-pass operands in registers: A | B | f and K | d | P | p.  The addresses never
 // depend on the state, so the record of step k + DEPTH is requested before step k is computed: these
 // shapes are latency-bound (one wave per 64 problems, N dependent steps) and an un-prefetched step costs
@@ -383,93 +99,15 @@ struct LaneFwdRec {
   }
 };
 
-template <int n, int m, typename T>
-__device__ __forceinline__ void lane_forward_step(const LaneFwdRec<n, m, T>& r, T* __restrict__ orow, uint32_t rowB,
-                                                  uint32_t lane, T (&x)[n]) {
-  using D = LaneDims<n, m>;
-  T u[m], xn[n], y[n];
-#pragma unroll
-  for (int i = 0; i < m; ++i) {   // u = d - K x
-    T s = T(0);
-#pragma unroll
-    for (int j = 0; j < n; ++j) s += r.out[D::O_K + i + j * m] * x[j];
-    u[i] = r.out[D::O_d + i] + T(-1) * s;
-  }
-#pragma unroll
-  for (int i = 0; i < n; ++i) {   // y = P x + p
-    T s = T(0);
-#pragma unroll
-    for (int j = 0; j < n; ++j) s += r.out[D::O_P + i + j * n] * x[j];
-    y[i] = (T(0) + s) + r.out[D::O_p + i];
-  }
-#pragma unroll
-  for (int i = 0; i < n; ++i) {   // x+ = f + A x + B u
-    T s = T(0);
-#pragma unroll
-    for (int j = 0; j < n; ++j) s += r.in[i + j * n] * x[j];
-    T v = r.in[n * n + n * m + i] + s;
-    T s2 = T(0);
-#pragma unroll
-    for (int j = 0; j < m; ++j) s2 += r.in[n * n + i + j * n] * u[j];
-    xn[i] = v + s2;
-  }
-  const LaneBuf bx(orow);
-#pragma unroll
-  for (int e = 0; e < n; ++e) lane_st<T>(bx, lane, (uint32_t)e * rowB, x[e]);
-#pragma unroll
-  for (int e = 0; e < n; ++e) lane_st<T>(bx, lane, (uint32_t)(n + e) * rowB, y[e]);
-#pragma unroll
-  for (int e = 0; e < m; ++e) lane_st<T>(bx, lane, (uint32_t)(2 * n + e) * rowB, u[e]);
-#pragma unroll
-  for (int e = 0; e < n; ++e) x[e] = xn[e];
-}
-
-template <int n, int m, typename T>
-__global__ __launch_bounds__(64) void lane_forward_kernel(LaneArgs<T> a) {
-  using D = LaneDims<n, m>;
-  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
-  if (b >= a.batch) return;
-  const int64_t B = a.batch;
-  const int N = a.N;
-  const uint32_t lane = threadIdx.x * (uint32_t)sizeof(T);   // byte offset of this lane inside a 64-problem row
-  const int64_t b0 = (int64_t)blockIdx.x * 64;               // wave-uniform first problem of this wave
-  const T* __restrict__ pin = a.in + b0;
-  const T* __restrict__ pout = a.out + b0;
-  T* __restrict__ pxuy = a.xuy + b0;
-  T x[n];
-#pragma unroll
-  for (int e = 0; e < n; ++e) x[e] = a.x0[(int64_t)e * B + b];
-  T PN[n * n + n];
-#pragma unroll
-  for (int e = 0; e < n * n + n; ++e) PN[e] = a.outn[(int64_t)e * B + b];
-  // ping-pong: the record of step k + 1 is in flight while step k runs
-  LaneFwdRec<n, m, T> r0, r1;
-  const int last = N - 1;
-  const uint32_t rowB = (uint32_t)B * (uint32_t)sizeof(T);
-  r0.load(pin, pout, B, 0, lane, rowB);
-  int k = 0;
-  for (; k + 1 < N; k += 2) {
-    r1.load(pin, pout, B, k + 1, lane, rowB);
-    lane_forward_step<n, m, T>(r0, pxuy + (int64_t)k * D::E_XUY * B, rowB, lane, x);
-    r0.load(pin, pout, B, k + 2 < N ? k + 2 : last, lane, rowB);
-    lane_forward_step<n, m, T>(r1, pxuy + (int64_t)(k + 1) * D::E_XUY * B, rowB, lane, x);
-  }
-  if (k < N) lane_forward_step<n, m, T>(r0, pxuy + (int64_t)k * D::E_XUY * B, rowB, lane, x);
-  {
-    T* o = a.xuy + (int64_t)N * D::E_XUY * B + b;
-#pragma unroll
-    for (int i = 0; i < n; ++i) {
-      T s = T(0);
-#pragma unroll
-      for (int j = 0; j < n; ++j) s += PN[i + j * n] * x[j];
-      o[(int64_t)(n + i) * B] = (T(0) + s) + PN[n * n + i];
-    }
-#pragma unroll
-    for (int e = 0; e < n; ++e) o[(int64_t)e * B] = x[e];
-#pragma unroll
-    for (int e = 0; e < m; ++e) o[(int64_t)(2 * n + e) * B] = T(0);
-  }
-}
+// ---- the kernels, in two arithmetic flavours (see tvlqr_lane_body.inc) ---------------------------------------------
+#pragma clang fp contract(off)
+#define LANE_FN(x) x
+#include "tvlqr_lane_body.inc"
+#undef LANE_FN
+#pragma clang fp contract(fast)
+#define LANE_FN(x) x##_fused
+#include "tvlqr_lane_body.inc"
+#undef LANE_FN
 
 #pragma clang fp contract(fast)
 

@@ -47,6 +47,8 @@ def parse():
                          "(pendulum n=2 m=1 N=100 batch=8192), c3 = configs[3] (bicycle n=4 m=2 N=50 batch=65536 "
                          "per node, with the steering bound), c4 = configs[4] (random LTV n=12 m=4 N=512 "
                          "batch=16384, fp32 storage)")
+    ap.add_argument("--lane-fused", action="store_true",
+                    help="configs c2 / c3: FMA-fused LANE kernels (ALTRO_HIP_LANE_FUSED; not bit-identical to the CPU path)")
     ap.add_argument("--c4-pure", action="store_true",
                     help="config c4: backward sweep in pure fp32 (ALTRO_HIP_F32_PURE, v_mfma_f32_16x16x4_f32) "
                          "instead of fp32 storage with fp64 tile arithmetic")
@@ -129,7 +131,7 @@ def lane_config(args, rank, local_rank, world, dist, torch):
         batch = 8192 if args.batch == 4096 else args.batch
         h = np.float32(0.03)
     first, _ = shard.shard_range(batch * world, rank, world)
-    bt = altro_amd.Batch(N, n, m, batch, device=local_rank)
+    bt = altro_amd.Batch(N, n, m, batch, device=local_rank, flags=altro_amd.LANE_FUSED if args.lane_fused else 0)
     assert bt.plan == altro_amd.PLAN_LANE
     if c3:
         bt.set_model(altro_amd.MODEL_BICYCLE, h)

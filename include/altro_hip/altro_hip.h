@@ -88,6 +88,11 @@ typedef enum altro_hip_plan {
                                         Default for F32 is fp32 storage with fp64 tile arithmetic (2e-5): on
                                         MI355X both are bound by the same fp32 record traffic */
 
+#define ALTRO_HIP_LANE_FUSED 0x4u    /* plan LANE: let the TVLQR kernels fuse a * b + c into one FMA.  Default off: the
+                                        unfused kernels repeat the CPU path operation for operation and give
+                                        bit-identical results; fused ones differ in the last bits (1e-12 relative)
+                                        and are ~20 % faster where the sweep is instruction-bound (small batches)  */
+
 /* Device dynamics/cost models for the nonlinear forward pass (user std::function callbacks of
  * typedefs.hpp:31-53 cannot run on the device; these are the compiled-in equivalents of the
  * reference's own test models, test/test_utils.cpp:18-238).                                    */

@@ -480,3 +480,16 @@ def test_large_batch_c1_uses_the_hbm():
     assert np.array_equal(small.get("x")[:, -1], x_last[[0, 12345, batch - 1]])
     dV = big.get("delta_V")
     assert np.isfinite(dV).all() and np.isfinite(x_last).all()
+
+
+@pytest.mark.parametrize("n,m", [(4, 2), (2, 1), (6, 3), (3, 1)])
+def test_lane_fused_flag(n, m):
+    """ALTRO_HIP_LANE_FUSED: FMA-fused LANE kernels agree with the oracle to 1e-12 relative (the default, unfused
+    kernels are bit-identical: test_lane_random_bit_exact)."""
+    pr = problems.random_ltv(97, 31, n, m)
+    out = run_hip(pr, altro_amd.PLAN_AUTO, flags=altro_amd.LANE_FUSED)
+    assert out["bt"].plan == altro_amd.PLAN_LANE
+    ref = run_oracle(pr)
+    assert (out["status"] == -1).all()
+    for k in ("K", "d", "P", "p", "x", "u", "y"):
+        assert relerr(out[k], ref[k]) < 1e-12, k
