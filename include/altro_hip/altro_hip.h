@@ -18,6 +18,11 @@
  *   altro_hip_get_*         <-> KnotPointData public members K_,d_,P_,p_,x_,u_,y_,Qxx_...
  *                               (knotpoint_data.hpp:160-233) and ALTROSolver::GetState/GetInput/
  *                               GetFeedbackGain/GetFeedforwardGain (altro_solver.hpp:413-422)
+ *   altro_hip_ilqr_solve    <-> SolverImpl::Solve incl. ForwardPass + CubicLineSearch and the outer dual / penalty
+ *                               updates (solver.cpp:237-271, 383-409, 414-511; linesearch.cpp:37-412), per problem
+ *   altro_hip_add_linear_constraint <-> ALTROSolver::SetConstraint (altro_solver.cpp:192-223) with the AL / conic
+ *                               terms of knotpoint_data.cpp:489-613 and cones.cpp:13-202
+ *   altro_hip_shift_trajectory / update_linear_costs / get_knot <-> the MPC methods (altro_solver.cpp:266-293, 323-347)
  *   altro_hip_stats         <-> AltroStats (solver_stats.hpp:14-25), per batch instead of per solver
  *
  * The single-problem kernel boundary itself (the three tvlqr_* functions with the reference's exact
@@ -32,8 +37,8 @@
  *     H m*n, q n, r m, K m*n, d m, P n*n, p n, x n, u m, y n.  Q, q, P, p, x, y have N+1 knot points,
  *     everything else N.  Host buffers are borrowed for the duration of the call only.
  *   - Broadcast: `k_stride_zero` / `batch_stride_zero` flags say the host buffer holds ONE knot point
- *     and/or ONE problem that every k / every problem shares (the device copy is still expanded unless
- *     ALTRO_HIP_SHARED_STORAGE is requested at create time).
+ *     and/or ONE problem that every k / every problem shares (the device copy is still expanded: every
+ *     (problem, knot point) owns its blocks in HBM, the general time-varying case).
  *   - No allocation happens inside backward / forward / merit / sweep (tvlqr_test.cpp:174-182 asserts
  *     the same of the reference).
  *   - Return value: 0 on success, a negative altro_hip_error otherwise; altro_hip_last_error() gives
