@@ -256,3 +256,54 @@ def test_per_problem_bounds_match_oracle(kats):
         np.testing.assert_allclose(x[b], s.get("x"), rtol=1e-8, atol=1e-8)
         assert np.abs(u[b]).max() <= ubs[b] + 2e-4
     assert checked >= 3
+
+
+@pytest.mark.parametrize("dim", [1, 3])
+def test_constrained_double_integrator_other_dims(dim):
+    """The LANE AL path at its smallest and largest shapes, (2, 1) and (6, 3): goal (EQUALITY) + control bounds
+    (INEQUALITY) + a second-order-cone bound on (6, 3), against the oracle per problem."""
+    n, m, N = 2 * dim, dim, 12
+    h = np.float32(0.4)
+    batch = 66
+    x0s = np.zeros((batch, n)); x0s[:, :dim] = 1.5 + 0.02 * (np.arange(batch) % 13)[:, None]
+    bt = altro_amd.Batch(N, n, m, batch)
+    assert bt.plan == altro_amd.PLAN_LANE
+    bt.set_model(altro_amd.MODEL_DOUBLE_INTEGRATOR, h)
+    Qd = np.ones(n); Rd = np.full(m, 1e-2)
+    bt.set_tracking_cost(np.stack([Qd, Qd]), Rd[None], np.zeros((2, n)), np.zeros((1, m)), k_stride_zero=True, batch_stride_zero=True)
+    bt.set_initial_state(x0s)
+    bt.set_input_guess(np.zeros((1, 1, m)), k_stride_zero=True, batch_stride_zero=True)
+    w = n + m
+    Gg = np.zeros((n, w)); Gg[:, :n] = np.eye(n)
+    blocks = [(N, N, problems.CONE_EQUALITY, Gg, np.zeros(n))]
+    if dim == 3:
+        Gs = np.zeros((m + 1, w)); Gs[:m, n:] = np.eye(m)
+        gs = np.zeros(m + 1); gs[m] = -1.2
+        blocks.append((0, N - 1, problems.CONE_SOC, Gs, gs))
+    else:
+        Gb = np.zeros((2 * m, w)); Gb[:m, n:] = np.eye(m); Gb[m:, n:] = -np.eye(m)
+        blocks.append((0, N - 1, problems.CONE_INEQUALITY, Gb, np.full(2 * m, 0.9)))
+    for (k0, k1, cone, G, g) in blocks:
+        bt.add_linear_constraint(k0, k1, cone, G, g)
+    res = bt.ilqr_solve(iterations_max=80, penalty_initial=1.0, penalty_scaling=100.0)
+    x, u = bt.get("x"), bt.get("u")
+    checked = 0
+    for b in [0, 31, 65]:
+        s = oracle.ILQR(N, n, m, h, oracle.DYN_MODEL, oracle.MODEL_DI, model_dim=dim, cost_kind=oracle.COST_DIAGONAL)
+        for k in range(N + 1):
+            s.L.oracle_ilqr_set_lqr_cost(s.h, k, Qd.copy(), Rd.copy(), np.zeros(n), np.zeros(m))
+        s.L.oracle_ilqr_set_initial_state(s.h, np.ascontiguousarray(x0s[b]))
+        for (k0, k1, cone, G, g) in blocks:
+            for k in range(k0, k1 + 1):
+                s.add_linear_constraint(k, cone, G, g)
+        s.L.oracle_ilqr_initialize(s.h)
+        s.set_penalty(1.0, 100.0)
+        s.L.oracle_ilqr_set_options(s.h, 80, 1e-4, 1e-4, 1e-8, 0)
+        status, iters, log = s.solve()
+        assert res["status"][b] == status and res["iterations"][b] == iters, (dim, b, res["status"][b], status, res["iterations"][b], iters)
+        if status != 0:
+            continue
+        checked += 1
+        tol = 1e-6 if dim == 3 else 1e-8
+        np.testing.assert_allclose(x[b], s.get("x"), rtol=tol, atol=tol)
+    assert checked >= 2
