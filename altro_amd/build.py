@@ -16,9 +16,9 @@ def sources():
     out = []
     for d, _, files in os.walk(CSRC):
         out += [os.path.join(d, f) for f in files if f.endswith((".hip", ".h", ".hpp", ".cpp"))]
-    out += [os.path.join(ROOT, "include", "altro_hip", "altro_hip.h"),
-            os.path.join(ROOT, "include", "tvlqr", "tvlqr.h")]
-    return [s for s in out if os.path.exists(s)]
+    for d, _, files in os.walk(os.path.join(ROOT, "include")):
+        out += [os.path.join(d, f) for f in files if f.endswith((".h", ".hpp"))]
+    return out
 
 
 def stale():

@@ -25,35 +25,13 @@ using Vec = std::vector<double>;
 
 // ---- error strings (exceptions.cpp:12-98 in the reference) ----------------------------------------
 const char* ErrorCodeToString(ErrorCodes err) {
-  switch (err) {
-    case ErrorCodes::NoError: return "no error";
-    case ErrorCodes::StateDimUnknown: return "state dimension unknown";
-    case ErrorCodes::InputDimUnknown: return "input dimension unknown";
-    case ErrorCodes::NextStateDimUnknown: return "next state dimension unknown";
-    case ErrorCodes::DimensionUnknown: return "dimension unknown";
-    case ErrorCodes::BadIndex: return "bad knot point index";
-    case ErrorCodes::DimensionMismatch: return "dimension mismatch";
-    case ErrorCodes::SolverNotInitialized: return "solver not initialized";
-    case ErrorCodes::SolverAlreadyInitialized: return "solver already initialized";
-    case ErrorCodes::NonPositive: return "expected a positive value";
-    case ErrorCodes::TimestepNotPositive: return "time step not positive";
-    case ErrorCodes::CostFunNotSet: return "cost function not set";
-    case ErrorCodes::DynamicsFunNotSet: return "dynamics function not set";
-    case ErrorCodes::InvalidOptAtTerminalKnotPoint: return "invalid operation at the terminal knot point";
-    case ErrorCodes::MaxConstraintsExceeded: return "maximum number of constraints exceeded";
-    case ErrorCodes::InvalidConstraintDim: return "invalid constraint dimension";
-    case ErrorCodes::CholeskyFailed: return "Cholesky factorization failed";
-    case ErrorCodes::OpOnlyValidAtTerminalKnotPoint: return "operation only valid at the terminal knot point";
-    case ErrorCodes::InvalidPointer: return "invalid pointer";
-    case ErrorCodes::BackwardPassFailed: return "backward pass failed (try increasing regularization)";
-    case ErrorCodes::LineSearchFailed: return "line search failed to find a point satisfying the strong Wolfe conditions";
-    case ErrorCodes::MeritFunctionGradientTooSmall: return "merit function gradient under tolerance";
-    case ErrorCodes::InvalidBoundConstraint: return "invalid bound constraint";
-    case ErrorCodes::NonPositivePenalty: return "penalty must be strictly positive";
-    case ErrorCodes::CostNotQuadratic: return "cost function not quadratic";
-    case ErrorCodes::FileError: return "file error";
-  }
-  return "unknown error";
+  static const char* const kMessages[] = {
+#define ALTRO_ERROR_MESSAGE(code, message) message,
+      ALTRO_ERROR_TABLE(ALTRO_ERROR_MESSAGE)
+#undef ALTRO_ERROR_MESSAGE
+  };
+  const int i = static_cast<int>(err);
+  return i >= 0 && i < static_cast<int>(sizeof(kMessages) / sizeof(kMessages[0])) ? kMessages[i] : "unknown error";
 }
 void PrintErrorCode(ErrorCodes err) {
   std::fprintf(stderr, "Got error code %d: %s\n", static_cast<int>(err), ErrorCodeToString(err));

@@ -11,14 +11,15 @@ namespace altro {
 
 struct AltroStats {
   using millisd = std::chrono::duration<double, std::milli>;
-  SolveStatus status = SolveStatus::Unsolved;
-  millisd solve_time{0.0};
-  int iterations = 0;
-  int outer_iterations = 0;
-  double objective_value = 0.0;
-  double stationarity = 0.0;
-  double primal_feasibility = 0.0;
-  double complimentarity = 0.0;
+
+  SolveStatus status = SolveStatus::Unsolved;  // why Solve() stopped
+  int iterations = 0;                          // iLQR iterations, over all outer loops
+  int outer_iterations = 0;                    // declared by the API; left at 0 (as upstream)
+  millisd solve_time{0.0};                     // wall clock of Solve(), host side
+  double objective_value = 0.0;                // merit value phi at the accepted step of the last iteration
+  double stationarity = 0.0;                   // last value compared with tol_stationarity
+  double primal_feasibility = 0.0;             // last value compared with tol_primal_feasibility
+  double complimentarity = 0.0;                // declared by the API (spelling included); never computed
 };
 
 }  // namespace altro

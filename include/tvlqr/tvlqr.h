@@ -19,27 +19,60 @@
 
 #include <stdbool.h>
 
-#define TVLQR_SUCCESS -1
-#define TVLQR_NO_DEVICE -2
+#define TVLQR_SUCCESS -1   /* both passes: no knot point failed */
+#define TVLQR_NO_DEVICE -2 /* this library only: no usable HIP device (the reference has no such case) */
 
 typedef double lqr_float;
 
+/* One pointer per knot point, each to a column-major block owned by the caller.  The aliases spell the same
+ * types the reference spells out, so the C++-mangled names are unchanged. */
+typedef const lqr_float *const *tvlqr_blocks_in; /* read by the pass  */
+typedef lqr_float **tvlqr_blocks_out;            /* written by the pass */
+
+/* Bytes a caller would need to hold every block of one problem (inputs, gains, cost-to-go, Q blocks and
+ * scratch); `is_diag` sizes Q, R as diagonals. */
 int tvlqr_TotalMemSize(const int *nx, const int *nu, int num_horizon, bool is_diag);
 
-int tvlqr_BackwardPass(const int *nx, const int *nu, int num_horizon,
-                       const lqr_float *const *A, const lqr_float *const *B, const lqr_float *const *f,
-                       const lqr_float *const *Q, const lqr_float *const *R, const lqr_float *const* H,
-                       const lqr_float *const *q, const lqr_float *const *r, lqr_float reg,
-                       lqr_float **K, lqr_float **d,
-                       lqr_float **P, lqr_float **p, lqr_float *delta_V,
-                       lqr_float **Qxx, lqr_float **Quu, lqr_float **Qux,
-                       lqr_float **Qx, lqr_float **Qu,
-                       lqr_float **Qxx_tmp, lqr_float **Quu_tmp, lqr_float **Qux_tmp,
-                       lqr_float **Qx_tmp, lqr_float **Qu_tmp,
-                       bool linear_only_update, bool is_diag);
+/* Riccati recursion k = num_horizon .. 0 over x+ = A x + B u + f with stage cost
+ * 1/2 x'Qx + 1/2 u'Ru + u'Hx + q'x + r'u.  Returns TVLQR_SUCCESS or the failing knot point. */
+int tvlqr_BackwardPass(
+    const int *nx,           /* [num_horizon + 1] state dimensions   */
+    const int *nu,           /* [num_horizon + 1] input dimensions   */
+    int num_horizon,         /* N: knot points 0..N                  */
+    tvlqr_blocks_in A,       /* [N]   nx[k+1] x nx[k]                */
+    tvlqr_blocks_in B,       /* [N]   nx[k+1] x nu[k]                */
+    tvlqr_blocks_in f,       /* [N]   nx[k+1]                        */
+    tvlqr_blocks_in Q,       /* [N+1] nx x nx, or nx if is_diag      */
+    tvlqr_blocks_in R,       /* [N]   nu x nu, or nu if is_diag      */
+    tvlqr_blocks_in H,       /* [N]   nu x nx                        */
+    tvlqr_blocks_in q,       /* [N+1] nx                             */
+    tvlqr_blocks_in r,       /* [N]   nu                             */
+    lqr_float reg,           /* added to the diagonal of Quu         */
+    tvlqr_blocks_out K,      /* [N]   nu x nx feedback gain          */
+    tvlqr_blocks_out d,      /* [N]   nu feedforward                 */
+    tvlqr_blocks_out P,      /* [N+1] nx x nx cost-to-go Hessian     */
+    tvlqr_blocks_out p,      /* [N+1] nx cost-to-go gradient         */
+    lqr_float *delta_V,      /* [2]   sum d'Qu, sum 1/2 d'Quu d       */
+    tvlqr_blocks_out Qxx,    /* [N+1] action-value expansion ...     */
+    tvlqr_blocks_out Quu,    /* [N]                                  */
+    tvlqr_blocks_out Qux,    /* [N]                                  */
+    tvlqr_blocks_out Qx,     /* [N+1]                                */
+    tvlqr_blocks_out Qu,     /* [N]                                  */
+    tvlqr_blocks_out Qxx_tmp, /* [N+1] ... and the scratch blocks    */
+    tvlqr_blocks_out Quu_tmp, /* [N]   (Quu_tmp holds the factor)    */
+    tvlqr_blocks_out Qux_tmp, /* [N]                                 */
+    tvlqr_blocks_out Qx_tmp,  /* [N+1]                               */
+    tvlqr_blocks_out Qu_tmp,  /* [N]                                 */
+    bool linear_only_update, /* accepted, unused (as upstream)       */
+    bool is_diag);
 
-int tvlqr_ForwardPass(const int *nx, const int *nu, int num_horizon,
-                      const lqr_float *const *A, const lqr_float *const *B, const lqr_float *const *f,
-                      const lqr_float *const *K, const lqr_float *const *d,
-                      const lqr_float *const *P, const lqr_float *const *p,
-                      const lqr_float *x0, lqr_float **x, lqr_float **u, lqr_float **y);
+/* Closed-loop rollout u = d - K x, x+ = A x + B u + f from x0, with co-states y = P x + p (skipped when y is NULL). */
+int tvlqr_ForwardPass(
+    const int *nx, const int *nu, int num_horizon,
+    tvlqr_blocks_in A, tvlqr_blocks_in B, tvlqr_blocks_in f, /* dynamics, as above     */
+    tvlqr_blocks_in K, tvlqr_blocks_in d,                    /* gains from the backward pass */
+    tvlqr_blocks_in P, tvlqr_blocks_in p,                    /* cost-to-go from the backward pass */
+    const lqr_float *x0,                                     /* nx[0] initial state    */
+    tvlqr_blocks_out x,                                      /* [N+1] states           */
+    tvlqr_blocks_out u,                                      /* [N]   inputs           */
+    tvlqr_blocks_out y);                                     /* [N+1] co-states        */
