@@ -453,6 +453,21 @@ def test_device_pointer_mode():
     assert r.returncode == 0 and "device pointer mode OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_rccl_and_the_hip_library_share_a_process():
+    """bench.py's N>1 launch form on the one GPU a test box has: `python -m torch.distributed.run --nproc-per-node 1`,
+    backend nccl (RCCL), with the all-reduce and barrier forced to run -- RCCL's communicator, its kernels and
+    libaltro_hip.so's streams in one process on one device (tests/rccl_rank_check.py)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", "29533",
+                        os.path.join(root, "tests", "rccl_rank_check.py")], capture_output=True, text=True, timeout=600,
+                       cwd=root, env=env)
+    assert r.returncode == 0 and "rccl rank check OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
 def test_large_batch_c1_uses_the_hbm():
     """Eight times the metric's batch on one GPU (32768 problems x 256 knot points: ~45 GB of records -- the layouts
     are sized for 288 GB).  Size-independent checks: all factorizations succeed, identical problems give identical
