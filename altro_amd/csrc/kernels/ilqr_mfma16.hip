@@ -249,6 +249,7 @@ __global__ __launch_bounds__(64) void wave_expand_kernel(IlqrWaveArgs<S> a) {
       const int r = t / 16, cc = t % 16;
       if (terminal && (r >= 12 || cc >= 12)) continue;
       if (r < 12 && cc >= 12) continue;     // the H^T block is not stored
+      if (!terminal && r < 12 && cc < r) continue;   // nor is the lower triangle of Q (cost records hold triu(Q))
       double v = (r == cc) ? (double)cp[r] : 0.0;   // costp[0..15] = Qd | Rd
       double s = 0.0;
       for (int cidx = 0; cidx < kn.ncon; ++cidx) {
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(64) void wave_expand_kernel(IlqrWaveArgs<S> a) {
       }
       v += rho * s;
       if (terminal) a.term[(size_t)b * MF_TERM + r * 12 + cc] = (S)v;
-      else if (r < 12) a.cin[(size_t)b * a.cin_bs + (size_t)k * a.cin_ks + MF_OFF_Q + r * 12 + cc] = (S)v;
+      else if (r < 12) a.cin[(size_t)b * a.cin_bs + (size_t)k * a.cin_ks + MF_OFF_Q + mf_sym(r, cc)] = (S)v;
       else a.cin[(size_t)b * a.cin_bs + (size_t)k * a.cin_ks + MF_OFF_HR + (r - 12) * 16 + cc] = (S)v;
     }
   }
@@ -299,19 +300,19 @@ __global__ __launch_bounds__(64) void wave_dual_update_kernel(IlqrWaveArgs<S> a)
 // image: Z rows padded to 17 (bank conflicts, see the forward sweep) | OUT record | f | nominal | cost parameters.
 constexpr int MW_ZLD = 17;
 constexpr int MW_OUT0 = 12 * MW_ZLD;       // 204
-constexpr int MW_F0 = MW_OUT0 + 208;       // 412
-constexpr int MW_NOM0 = MW_F0 + 12;        // 424
-constexpr int MW_CP0 = MW_NOM0 + 16;       // 440
-constexpr int MW_IMG = MW_CP0 + MF_COSTP;  // 476
-struct MeritWaveRegs { double z[3], o[4], f, nm, cp; };
+constexpr int MW_F0 = MW_OUT0 + MF_OUT;    // 348
+constexpr int MW_NOM0 = MW_F0 + 12;        // 360
+constexpr int MW_CP0 = MW_NOM0 + 16;       // 376
+constexpr int MW_IMG = MW_CP0 + MF_COSTP;  // 412
+struct MeritWaveRegs { double z[3], o[3], f, nm, cp; };
 template <typename S>
 __device__ __forceinline__ void merit_wave_load(MeritWaveRegs& r, const S* __restrict__ z, const S* __restrict__ o,
                                                 const S* __restrict__ nm, const S* __restrict__ cp, int lane) {
 #pragma unroll
   for (int c = 0; c < 3; ++c) r.z[c] = (double)z[MF_OFF_Z + c * 64 + lane];
 #pragma unroll
-  for (int c = 0; c < 3; ++c) r.o[c] = (double)o[c * 64 + lane];
-  r.o[3] = (double)o[192 + (lane & 15)];
+  for (int c = 0; c < 2; ++c) r.o[c] = (double)o[c * 64 + lane];
+  r.o[2] = (double)o[128 + (lane & 15)];
   r.f = (double)z[MF_OFF_F + (lane < 12 ? lane : 11)];
   r.nm = (double)nm[lane & 15];
   r.cp = (double)cp[lane < MF_COSTP ? lane : MF_COSTP - 1];
@@ -320,8 +321,8 @@ __device__ __forceinline__ void merit_wave_stage(const MeritWaveRegs& r, double*
 #pragma unroll
   for (int c = 0; c < 3; ++c) L[c * 4 * MW_ZLD + (lane >> 4) * MW_ZLD + (lane & 15)] = r.z[c];
 #pragma unroll
-  for (int c = 0; c < 3; ++c) L[MW_OUT0 + c * 64 + lane] = r.o[c];
-  L[MW_OUT0 + 192 + (lane & 15)] = r.o[3];
+  for (int c = 0; c < 2; ++c) L[MW_OUT0 + c * 64 + lane] = r.o[c];
+  L[MW_OUT0 + 128 + (lane & 15)] = r.o[2];
   L[MW_F0 + (lane < 12 ? lane : 11)] = r.f;
   L[MW_NOM0 + (lane & 15)] = r.nm;
   L[MW_CP0 + (lane < MF_COSTP ? lane : MF_COSTP - 1)] = r.cp;
@@ -348,6 +349,9 @@ __global__ __launch_bounds__(64) void wave_merit_kernel(IlqrWaveArgs<S> a) {
   const bool is_x = lane < 12, is_u = (grp == 1 && sub < 4), is_y = (grp == 2 && sub < 12);
   const int i = sub < 12 ? sub : 11;       // row of Z / [P|p]
   const int ia = sub < 4 ? sub : 3;        // row of Kt
+  int prow[12];                            // image offsets of row i of P, gathered from its packed upper triangle
+#pragma unroll
+  for (int j = 0; j < 12; ++j) prow[j] = MW_OUT0 + MF_OFF_P + mf_sym(i, j);
   const int l27 = lane < 28 ? lane : 27;
   const S* __restrict__ dynb = a.dyn + (size_t)b * a.dyn_bs;
   const S* __restrict__ outb = a.out + (size_t)b * a.out_bs;
@@ -396,8 +400,8 @@ __global__ __launch_bounds__(64) void wave_merit_kernel(IlqrWaveArgs<S> a) {
     if (is_y) {   // y_ = P dx + p
       double s = 0.0;
 #pragma unroll
-      for (int j = 0; j < 12; ++j) s += img[MW_OUT0 + MF_OFF_P + i * 13 + j] * dxs[j];
-      crec[12 + i] = s + img[MW_OUT0 + MF_OFF_P + i * 13 + 12];
+      for (int j = 0; j < 12; ++j) s += img[prow[j]] * dxs[j];
+      crec[12 + i] = s + img[MW_OUT0 + MF_OFF_p + i];
     }
     __syncthreads();
     double xn = 0.0, dxn = 0.0;

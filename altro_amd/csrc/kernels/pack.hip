@@ -61,7 +61,7 @@ __global__ void mfma16_pack_kernel(S* in, S* cin, S* term, Mfma16Strides st, int
   switch (seg) {
     case MSEG_Z: len = 192; base = MF_OFF_Z; break;
     case MSEG_F: len = 12; base = MF_OFF_F; break;
-    case MSEG_Q: len = 144; base = MF_OFF_Q; break;
+    case MSEG_Q: len = MF_TRI; base = MF_OFF_Q; break;
     case MSEG_HR: len = 64; base = MF_OFF_HR; break;
     case MSEG_QR: len = 16; base = MF_OFF_QR; break;
     case MSEG_TERM_Q: len = 144; base = 0; break;
@@ -84,9 +84,14 @@ __global__ void mfma16_pack_kernel(S* in, S* cin, S* term, Mfma16Strides st, int
         v = (col < 12) ? p0[row + 12 * col] : p1[row + 12 * (col - 12)];
       } break;
       case MSEG_F: v = p0 ? p0[e] : 0.0; break;
-      case MSEG_Q:
-      case MSEG_TERM_Q: {  // Q rows: [r][g][j] = Q[g+4r][j]
-        const int r = e / 48, g = (e % 48) / 12, jj = e % 12, row = g + 4 * r;
+      case MSEG_Q: {  // upper triangle of the (symmetric) Q, row-major packed: e <-> (row, jj >= row)
+        int row = 0, rem = e;
+        while (rem >= 12 - row) { rem -= 12 - row; ++row; }
+        const int jj = row + rem;
+        v = is_diag ? (row == jj ? p0[row] : 0.0) : p0[row + 12 * jj];
+      } break;
+      case MSEG_TERM_Q: {  // Q_N rows, full: [row][jj]
+        const int row = e / 12, jj = e % 12;
         v = is_diag ? (row == jj ? p0[row] : 0.0) : p0[row + 12 * jj];
       } break;
       case MSEG_HR: {  // [g][j] = j < 12 ? H[g][j] : R[g][j-12]
@@ -128,14 +133,16 @@ __global__ void mfma16_unpack_kernel(double* dst, int what, const S* out, const 
     const int k = (int)((t / len) % nk);
     const int b = b0 + (int)(t / ((int64_t)len * nk));
     const S* o = (k < N) ? out + (int64_t)b * st.out_bs + (int64_t)k * st.out_ks : nullptr;
-    const S* pp = (k < N) ? o + MF_OFF_P : outn + (int64_t)b * MF_TERM;
+    const S* pn = outn + (int64_t)b * MF_TERM;   // [P_N p_N] 12x13 (k == N)
     const S* xr = xuy ? xuy + (int64_t)b * st.xuy_bs + (int64_t)k * st.xuy_ks : nullptr;
     double v;
     switch (what) {
       case MGET_K: v = (double)o[(e % 4) * 13 + (e / 4)]; break;        // K[a + 4 j] = Kt[a][j]
       case MGET_d: v = -(double)o[e * 13 + 12]; break;                  // d = -Kt[:, 12]
-      case MGET_P: v = pp[(e % 12) * 13 + (e / 12)]; break;     // P[i + 12 j] = tile[i][j]
-      case MGET_p: v = pp[e * 13 + 12]; break;
+      case MGET_P:   // P[i + 12 j]: both halves from the stored upper triangle (k < N) / tile[i][j] (k == N)
+        v = (k < N) ? (double)o[MF_OFF_P + mf_sym(e % 12, e / 12)] : (double)pn[(e % 12) * 13 + (e / 12)];
+        break;
+      case MGET_p: v = (k < N) ? (double)o[MF_OFF_p + e] : (double)pn[e * 13 + 12]; break;
       case MGET_x: v = xr[e]; break;
       case MGET_y: v = xr[12 + e]; break;
       case MGET_u: v = xr[24 + e]; break;

@@ -26,12 +26,14 @@
 // G^T); for the symmetric Q, R the API requires (altro_solver.hpp:183) P_k is symmetric up to rounding,
 // so this changes results only at the 1e-16 relative level.  Parity is asserted at 1e-8 on K, d.
 //
-// Device layout (private to this plan; pack_mfma16.hip converts from/to the reference layout):
-//   DYN [k][b][204]  = Z = [A B] 3x64 fragment (== row-major 12x16) | f 12        (1632 B)
-//   COST[k][b][224]  = Q rows 3x48 | [H R] 4x16 | [q r] 16                          (1792 B; 3424 B in all)
-//   TERM[b][156]     = Q_N rows 3x48 | q_N 12
-//   OUT [b][k][208]  = Kt 4x13 row-major | [P p] 12x13 row-major                  (1664 B, all algorithmic)
+// Device layout (private to this plan; pack_mfma16.hip converts from/to the reference layout).  Q and P are symmetric
+// (altro_solver.hpp:183 requires it of Q; P inherits it up to rounding): only their upper triangles go through HBM.
+//   DYN [k][b][204]  = Z = [A B] 3x64 fragment (== row-major 12x16) | f 12                       (1632 B)
+//   COST[k][b][160]  = triu(Q) 78 row-major packed | pad 2 | [H R] 4x16 | [q r] 16               (1280 B; 2912 B in all)
+//   TERM[b][156]     = Q_N rows 12x12 | q_N 12
+//   OUT [k][b][144]  = Kt 4x13 row-major | triu(P) 78 | p 12 | pad 2                             (1152 B)
 //   OUTN[b][156]     = [P_N p_N] 12x13 row-major
+// 508 elements per knot point move instead of the 636 the full blocks would take (mfma16_layout.h).
 // Every load/store below is `lane -> consecutive 8-byte element` over a contiguous run.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -120,18 +122,28 @@ __device__ __forceinline__ double ld_stream(const S* p) {
 struct Mfma16Knot {  // one knot point's inputs, in registers (11 doubles / lane)
   double z[3], q[3], hr, qr, f[3];
 };
+// Element offsets, inside a cost record, of the three entries Q[g + 4r][j] of this lane's G-tile registers: a gather
+// from the packed upper triangle (the 64 lanes of one load touch the same ten cache lines the triangle occupies).
+struct Mfma16QOff { int o[3]; };
+__device__ __forceinline__ Mfma16QOff mfma16_q_offsets(int j, int g) {
+  const int jq = (j < 12) ? j : 11;
+  Mfma16QOff q;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) q.o[r] = MF_OFF_Q + mf_sym(g + 4 * r, jq);
+  return q;
+}
 
 // All loads are unconditional and branch-free (lanes that have no element read a clamped, valid
 // address and discard it): exec-masked load branches make hipcc's s_waitcnt insertion collapse to
 // vmcnt(0) at the loop head, which serialises the prefetch against its own issue.
 template <bool HAS_F, typename S>
 __device__ __forceinline__ void mfma16_load_knot(Mfma16Knot& kn, const S* __restrict__ rec,
-                                                 const S* __restrict__ crec, int lane, int j, int g) {
-  const int jq = (j < 12) ? j : 11;
+                                                 const S* __restrict__ crec, int lane, int j, int g,
+                                                 const Mfma16QOff& qo) {
 #pragma unroll
   for (int c = 0; c < 3; ++c) kn.z[c] = ld_stream(&rec[MF_OFF_Z + c * 64 + lane]);
 #pragma unroll
-  for (int r = 0; r < 3; ++r) kn.q[r] = ld_stream(&crec[MF_OFF_Q + r * 48 + g * 12 + jq]);
+  for (int r = 0; r < 3; ++r) kn.q[r] = ld_stream(&crec[qo.o[r]]);
   kn.hr = ld_stream(&crec[MF_OFF_HR + lane]);
   kn.qr = ld_stream(&crec[MF_OFF_QR + j]);
   if (HAS_F) {
@@ -179,6 +191,16 @@ __global__ __launch_bounds__(64, 4) void mfma16_backward_kernel(Mfma16Args<S> a)
   const bool col_ok = (j <= 12);
   const int jc = col_ok ? j : 12;
   S* __restrict__ trash = a.trash + (size_t)b * MF_OUT;
+  const Mfma16QOff qo = mfma16_q_offsets(j, g);
+  // where this lane's three [P | p] registers (rows g + 4r, column j) go inside an OUT record: the packed upper
+  // triangle, the p block, or -- for the entries below the diagonal and the padding columns -- the record's two
+  // spare slots (garbage nobody reads; same cache lines, so no extra traffic and no exec-masked store)
+  int p_off[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const int row = g + 4 * r;
+    p_off[r] = (j == 12) ? MF_OFF_p + row : ((j < 12 && j >= row) ? MF_OFF_P + mf_sym(row, j) : MF_OFF_PAD + (j > 12 ? 1 : 0));
+  }
 
   // terminal cost-to-go: P_N = Q_N, p_N = q_N (tvlqr.cpp:81-90) -> tile [P | p]
   double Pt[3];
@@ -199,7 +221,7 @@ __global__ __launch_bounds__(64, 4) void mfma16_backward_kernel(Mfma16Args<S> a)
   int fail_k = -1;
 
   Mfma16Knot cur, nxt;
-  mfma16_load_knot<HAS_F, S>(cur, in + (size_t)(N - 1) * a.in_ks, cin + (size_t)(N - 1) * a.cin_ks, lane, j, g);
+  mfma16_load_knot<HAS_F, S>(cur, in + (size_t)(N - 1) * a.in_ks, cin + (size_t)(N - 1) * a.cin_ks, lane, j, g, qo);
   // Drain the VMEM queue before entering the loop: hipcc merges the pre-header's scoreboard into the
   // loop header's, and a pending first load there turns into `s_waitcnt vmcnt(0)` at the top of EVERY
   // iteration -- which would drain each step's stores before the next step may start.
@@ -209,7 +231,7 @@ __global__ __launch_bounds__(64, 4) void mfma16_backward_kernel(Mfma16Args<S> a)
     // prefetch the next knot point (k-1) while this one computes (k == 0 re-reads record 0: harmless)
     {
       const size_t kp = (k > 0) ? k - 1 : 0;
-      mfma16_load_knot<HAS_F, S>(nxt, in + kp * a.in_ks, cin + kp * a.cin_ks, lane, j, g);
+      mfma16_load_knot<HAS_F, S>(nxt, in + kp * a.in_ks, cin + kp * a.cin_ks, lane, j, g, qo);
     }
 
     // ---- D1 = [P'|t]^T Z : rows 0..11 = P'^T Z, row 12 = t^T Z --------------------------------
@@ -313,7 +335,7 @@ __global__ __launch_bounds__(64, 4) void mfma16_backward_kernel(Mfma16Args<S> a)
     S* __restrict__ op_ = alive ? out + (size_t)k * a.out_ks : trash;
     ok_[g * 13 + jc] = (S)dpp_col12_dup(k_store);
 #pragma unroll
-    for (int r = 0; r < 3; ++r) op_[MF_OFF_P + (g + 4 * r) * 13 + jc] = (S)dpp_col12_dup(Pn[r]);
+    for (int r = 0; r < 3; ++r) op_[p_off[r]] = (S)Pn[r];
     if (STORE_Q && was_alive) {  // Qxx_, Quu_, Qux_, Qx_, Qu_ are API-visible in the reference
       S* qb = a.qblk + ((size_t)b * N + k) * MF_QB;
 #pragma unroll
@@ -352,11 +374,11 @@ __global__ __launch_bounds__(64, 4) void mfma16_backward_kernel(Mfma16Args<S> a)
 // on every ds_read_b64; the 13-double rows of Kt / [P|p] are conflict-free as they are.
 constexpr int MF_FWD_ZLD = 17;
 constexpr int MF_FWD_OUT0 = 12 * MF_FWD_ZLD;          // 204
-constexpr int MF_FWD_F0 = MF_FWD_OUT0 + 208;          // 412
+constexpr int MF_FWD_F0 = MF_FWD_OUT0 + MF_OUT;       // 348
 constexpr int MF_FWD_LDS = MF_FWD_F0 + 12;
 
-struct Mfma16FwdRegs {   // one knot point's coalesced loads (8 doubles / lane)
-  double z[3], o[4], f;
+struct Mfma16FwdRegs {   // one knot point's coalesced loads (7 doubles / lane)
+  double z[3], o[3], f;
 };
 template <typename S>
 __device__ __forceinline__ void mfma16_fwd_load(Mfma16FwdRegs& r, const S* __restrict__ rec,
@@ -364,16 +386,16 @@ __device__ __forceinline__ void mfma16_fwd_load(Mfma16FwdRegs& r, const S* __res
 #pragma unroll
   for (int c = 0; c < 3; ++c) r.z[c] = ld_stream(&rec[MF_OFF_Z + c * 64 + lane]);
 #pragma unroll
-  for (int c = 0; c < 3; ++c) r.o[c] = ld_stream(&orec[c * 64 + lane]);
-  r.o[3] = ld_stream(&orec[192 + (lane & 15)]);
+  for (int c = 0; c < 2; ++c) r.o[c] = ld_stream(&orec[c * 64 + lane]);
+  r.o[2] = ld_stream(&orec[128 + (lane & 15)]);
   r.f = ld_stream(&rec[MF_OFF_F + (lane < 12 ? lane : 11)]);
 }
 __device__ __forceinline__ void mfma16_fwd_stage(const Mfma16FwdRegs& r, double* __restrict__ L, int lane) {
 #pragma unroll
   for (int c = 0; c < 3; ++c) L[c * 4 * MF_FWD_ZLD + (lane >> 4) * MF_FWD_ZLD + (lane & 15)] = r.z[c];   // row 4c + lane/16
 #pragma unroll
-  for (int c = 0; c < 3; ++c) L[MF_FWD_OUT0 + c * 64 + lane] = r.o[c];
-  L[MF_FWD_OUT0 + 192 + (lane & 15)] = r.o[3];
+  for (int c = 0; c < 2; ++c) L[MF_FWD_OUT0 + c * 64 + lane] = r.o[c];
+  L[MF_FWD_OUT0 + 128 + (lane & 15)] = r.o[2];
   L[MF_FWD_F0 + (lane < 12 ? lane : 11)] = r.f;
 }
 __device__ __forceinline__ double readlane_f64(double v, int src_lane) {
@@ -399,7 +421,13 @@ __global__ __launch_bounds__(64) void mfma16_forward_kernel(Mfma16Args<S> a) {
   const int grp = lane >> 4;
   const int sub = lane & 15;
   const int row = (grp == 1) ? (sub < 4 ? sub : 3) : (sub < 12 ? sub : 11);
-  const int row_base = (grp == 0) ? MF_FWD_ZLD * row : ((grp == 1) ? MF_FWD_OUT0 + 13 * row : MF_FWD_OUT0 + 52 + 13 * row);
+  const int row_base = (grp == 0) ? MF_FWD_ZLD * row : MF_FWD_OUT0 + 13 * (grp == 1 ? row : 0);
+  // LDS addresses of this lane's row: linear for the rows of Z and Kt; the rows of [P | p] are gathered from the
+  // packed upper triangle (entries left of the diagonal are the transposed ones) and the p block
+  int ra[13];
+#pragma unroll
+  for (int jj = 0; jj < 12; ++jj) ra[jj] = (grp >= 2) ? MF_FWD_OUT0 + MF_OFF_P + mf_sym(row, jj) : row_base + jj;
+  ra[12] = (grp >= 2) ? MF_FWD_OUT0 + MF_OFF_p + row : row_base + 12;
   const int out_off = (grp == 0) ? row : ((grp == 1) ? 24 + row : 12 + row);   // x | y | u inside a record
   const bool is_x = (grp == 0), is_u = (grp == 1);
 
@@ -429,7 +457,9 @@ __global__ __launch_bounds__(64) void mfma16_forward_kernel(Mfma16Args<S> a) {
       // this lane's row (16 doubles) and, for the x+ rows, f[row]
       double rd[16];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) rd[j] = lds[row_base + j];
+      for (int j = 0; j < 13; ++j) rd[j] = lds[ra[j]];
+#pragma unroll
+      for (int j = 13; j < 16; ++j) rd[j] = lds[row_base + j];   // columns of B: meaningful in the rows of Z only
       const double fi = lds[MF_FWD_F0 + row];
       // x_k broadcast from lanes 0..11 through SGPRs
       double xs[12];

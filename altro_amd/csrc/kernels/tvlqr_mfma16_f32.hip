@@ -51,12 +51,12 @@ struct Mfma16KnotF32 {   // one knot point's inputs, in registers (13 floats / l
 // Unconditional, branch-free loads (clamped addresses for lanes without an element, see the fp64 kernel)
 template <bool HAS_F>
 __device__ __forceinline__ void mfma16_load_knot_f32(Mfma16KnotF32& kn, const float* __restrict__ rec,
-                                                     const float* __restrict__ crec, int zoff, int qoff, int qstride,
+                                                     const float* __restrict__ crec, int zoff, const int (&qo)[4],
                                                      int foff, int j) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) kn.z[r] = rec[MF_OFF_Z + zoff + r * 16];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) kn.q[r] = crec[qoff + r * qstride];
+  for (int r = 0; r < 4; ++r) kn.q[r] = crec[qo[r]];
   kn.qr = crec[MF_OFF_QR + j];
   if (HAS_F) {
 #pragma unroll
@@ -93,8 +93,9 @@ __global__ __launch_bounds__(64, 4) void mfma16_backward_f32_kernel(Mfma16Args<f
   const int jq = (j < 12) ? j : 11;
   const int gz = g3 ? 0 : g;                                   // group 3 re-reads group 0's rows and zeroes them
   const int zoff = (4 * gz) * 16 + j;                          // Z[4g + r][j], r -> + 16 r
-  const int qoff = g3 ? (MF_OFF_HR + j) : (MF_OFF_Q + (4 * g) * 12 + jq);   // G-tile init: Q rows | [H R] rows
-  const int qstride = g3 ? 16 : 12;
+  int qo[4];   // G-tile init: Q[4g + r][j] gathered from the packed upper triangle | [H R] rows (group 3)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) qo[r] = g3 ? (MF_OFF_HR + j + 16 * r) : (MF_OFF_Q + mf_sym(4 * g + r, jq));
   const int foff = 4 * gz;
   const float* __restrict__ in = a.in + (size_t)b * a.in_bs;
   const float* __restrict__ cin = a.cin + (size_t)b * a.cin_bs;
@@ -102,7 +103,13 @@ __global__ __launch_bounds__(64, 4) void mfma16_backward_f32_kernel(Mfma16Args<f
   const bool col_ok = (j <= 12);
   const int jc = col_ok ? j : 12;
   float* __restrict__ trash = a.trash + (size_t)b * MF_OUT;
-  const int prow = 4 * gz;                                     // first row of this lane's [P | p] slice
+  // where this lane's [P | p] registers (rows 4g + r, column j) go inside an OUT record (see the fp64 kernel)
+  int p_off[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = 4 * gz + r;
+    p_off[r] = (j == 12) ? MF_OFF_p + row : ((j < 12 && j >= row) ? MF_OFF_P + mf_sym(row, j) : MF_OFF_PAD + (j > 12 ? 1 : 0));
+  }
   const int w_idx = g3 ? j : 82 + lane, w_stride = g3 ? 16 : 64, gv_idx = g3 ? 64 + j : 82 + 4 * 64 + lane;
   const float g_keep = (j < 12 && !g3) ? 1.0f : 0.0f;          // lanes whose G registers are entries of Qxx
 
@@ -130,7 +137,7 @@ __global__ __launch_bounds__(64, 4) void mfma16_backward_f32_kernel(Mfma16Args<f
 #pragma unroll
   for (int dd = 0; dd < DEPTH; ++dd) {
     const size_t kk = (N - 1 - dd > 0) ? N - 1 - dd : 0;
-    mfma16_load_knot_f32<HAS_F>(ring[dd], in + kk * a.in_ks, cin + kk * a.cin_ks, zoff, qoff, qstride, foff, j);
+    mfma16_load_knot_f32<HAS_F>(ring[dd], in + kk * a.in_ks, cin + kk * a.cin_ks, zoff, qo, foff, j);
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): drain before the loop (see the fp64 kernel)
 
@@ -144,7 +151,7 @@ __global__ __launch_bounds__(64, 4) void mfma16_backward_f32_kernel(Mfma16Args<f
     const Mfma16KnotF32 cur = ring[dd];
     {   // slot dd is consumed: refill it with the record DEPTH knot points further down (clamped, branch-free)
       const size_t kp = (k - DEPTH > 0) ? k - DEPTH : 0;
-      mfma16_load_knot_f32<HAS_F>(ring[dd], in + kp * a.in_ks, cin + kp * a.cin_ks, zoff, qoff, qstride, foff, j);
+      mfma16_load_knot_f32<HAS_F>(ring[dd], in + kp * a.in_ks, cin + kp * a.cin_ks, zoff, qo, foff, j);
     }
     float z[4];
 #pragma unroll
@@ -231,7 +238,7 @@ __global__ __launch_bounds__(64, 4) void mfma16_backward_f32_kernel(Mfma16Args<f
     float* __restrict__ op_ = (alive && !g3) ? out + (size_t)k * a.out_ks : trash;
     ok_[g * 13 + jc] = dpp_col12_dup_f32(k_store);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) op_[MF_OFF_P + (prow + r) * 13 + jc] = dpp_col12_dup_f32(Pn[r]);
+    for (int r = 0; r < 4; ++r) op_[p_off[r]] = Pn[r];
 #pragma unroll
     for (int r = 0; r < 4; ++r) Pt[r] = !live ? Pt[r] : (g3 ? 0.0f : Pn[r]);   // rows 12..15 are not part of [P | p]
    }

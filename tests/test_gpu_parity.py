@@ -469,7 +469,7 @@ def test_rccl_and_the_hip_library_share_a_process():
 
 
 def test_large_batch_c1_uses_the_hbm():
-    """Eight times the metric's batch on one GPU (32768 problems x 256 knot points: ~45 GB of records -- the layouts
+    """Eight times the metric's batch on one GPU (32768 problems x 256 knot points: ~36 GB of records -- the layouts
     are sized for 288 GB).  Size-independent checks: all factorizations succeed, identical problems give identical
     bits across the whole batch, and the first / last problems equal the same problems solved in a small batch."""
     batch, N, n, m = 32768, 256, 12, 4
@@ -487,7 +487,7 @@ def test_large_batch_c1_uses_the_hbm():
         bt.sweep()
         return bt
     big = run(batch, x0)
-    assert big.L.altro_hip_batch_device_bytes(big.h) > 40e9
+    assert big.L.altro_hip_batch_device_bytes(big.h) > 32e9
     assert (big.get("status") == -1).all()
     x_last = big.get("x")[:, -1]          # [batch, n] slice of a 800 MB download
     assert np.array_equal(x_last[0], x_last[batch - 1])

@@ -104,6 +104,35 @@ __global__ __launch_bounds__(64) void stream_fwd(const double* __restrict__ dyn,
   }
 }
 
+
+// generic record streaming, [k][b] layout: per step read RIN doubles and write ROUT doubles (8 B per lane, unit
+// stride), prefetch one step ahead.  Used to price symmetric-packed record layouts before building them.
+template <int RIN, int ROUT>
+__global__ __launch_bounds__(64) void stream_generic(const double* __restrict__ in, double* __restrict__ out, int N, int batch) {
+  constexpr int LI = (RIN + 63) / 64, LO = (ROUT + 63) / 64;
+  const int lane = threadIdx.x, b = blockIdx.x;
+  double cur[LI], nxt[LI];
+  auto load = [&](double* r, int k) {
+    const double* rec = in + ((size_t)k * batch + b) * RIN;
+#pragma unroll
+    for (int c = 0; c < LI; ++c) { int e = c * 64 + lane; r[c] = rec[e < RIN ? e : RIN - 1]; }
+  };
+  load(cur, N - 1);
+  double acc = 0.0;
+  for (int k = N - 1; k >= 0; --k) {
+    load(nxt, k > 0 ? k - 1 : 0);
+    double s = 0;
+#pragma unroll
+    for (int c = 0; c < LI; ++c) s += cur[c];
+    acc += s;
+    double* o = out + ((size_t)k * batch + b) * ROUT;
+#pragma unroll
+    for (int c = 0; c < LO; ++c) { int e = c * 64 + lane; o[e < ROUT ? e : ROUT - 1] = acc + c; }
+#pragma unroll
+    for (int c = 0; c < LI; ++c) cur[c] = nxt[c];
+  }
+}
+
 int main() {
   const int N = 256, batch = 4096;
   const size_t in_n = (size_t)batch * N * 428, out_n = (size_t)batch * N * 208;
@@ -139,6 +168,17 @@ int main() {
     const double fb = (double)batch * N * (204 + 208 + 28) * 8;
     timeit("forward pattern (412 r + 28 w) depth1", fb, [&] { stream_fwd<1><<<batch, 64>>>(in, in + (size_t)batch * N * 204, out, N, batch); });
     timeit("forward pattern (412 r + 28 w) depth3", fb, [&] { stream_fwd<3><<<batch, 64>>>(in, in + (size_t)batch * N * 204, out, N, batch); });
+  }
+  {
+    auto gen = [&](const char* name, int rin, int rout, auto launch) {
+      timeit(name, (double)batch * N * (rin + rout) * 8, launch);
+    };
+    gen("generic 428 r + 208 w (today's backward)", 428, 208, [&] { stream_generic<428, 208><<<batch, 64>>>(in, out, N, batch); });
+    gen("generic 428 r + 144 w (P packed)", 428, 144, [&] { stream_generic<428, 144><<<batch, 64>>>(in, out, N, batch); });
+    gen("generic 364 r + 144 w (Q and P packed)", 364, 144, [&] { stream_generic<364, 144><<<batch, 64>>>(in, out, N, batch); });
+    gen("generic 360 r + 144 w (Q, R and P packed)", 360, 144, [&] { stream_generic<360, 144><<<batch, 64>>>(in, out, N, batch); });
+    gen("generic 412 r + 28 w (today's forward)", 412, 28, [&] { stream_generic<412, 28><<<batch, 64>>>(in, out, N, batch); });
+    gen("generic 348 r + 28 w (forward, P packed)", 348, 28, [&] { stream_generic<348, 28><<<batch, 64>>>(in, out, N, batch); });
   }
   return 0;
 }
