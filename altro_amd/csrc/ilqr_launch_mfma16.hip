@@ -15,7 +15,14 @@ static int wave_launch(hipStream_t stream, int which, const IlqrWaveArgs<S>& a) 
   switch (which) {
     case IK_ROLLOUT: hipLaunchKernelGGL(wave_rollout_kernel<S>, waves, b64, 0, stream, a); break;
     case IK_ACCEPT: hipLaunchKernelGGL(wave_accept_kernel<S>, flat, b256, 0, stream, a); break;
-    case IK_EXPAND: hipLaunchKernelGGL(wave_expand_kernel<S>, dim3((unsigned)((int64_t)a.batch * (a.N + 1))), b64, 0, stream, a); break;
+    case IK_EXPAND:
+      if (a.al.enabled) {
+        hipLaunchKernelGGL(wave_expand_kernel<S>, dim3((unsigned)((int64_t)a.batch * (a.N + 1))), b64, 0, stream, a);
+      } else if (a.mode & EXPAND_GRADIENT) {   // no constraint blocks: the Hessian is constant, the gradient is 16 entries
+        const int64_t blocks = ((int64_t)a.batch * (a.N + 1) * 16 + 255) / 256;
+        hipLaunchKernelGGL(wave_expand_grad_kernel<S>, dim3((unsigned)(blocks < 262144 ? blocks : 262144)), dim3(256), 0, stream, a);
+      }
+      break;
     case IK_DUAL: hipLaunchKernelGGL(wave_dual_update_kernel<S>, dim3((unsigned)((int64_t)a.batch * (a.N + 1))), b64, 0, stream, a); break;
     case IK_MERIT: hipLaunchKernelGGL(wave_merit_kernel<S>, waves, b64, 0, stream, a); break;
     case IK_STATIONARITY: hipLaunchKernelGGL(wave_stationarity_kernel<S>, waves, b64, 0, stream, a); break;

@@ -202,6 +202,28 @@ __global__ void wave_accept_kernel(IlqrWaveArgs<S> a) {
   }
 }
 
+// Cost gradient of an UNconstrained problem: lx = Qd x + q, lu = Rd u + r, one thread per (knot point, problem,
+// entry) in the order the records lie in HBM.  (The wave-per-knot-point kernel below is for the AL terms; without
+// them it would spend a million 64-lane workgroups on 16 multiply-adds each.)
+template <typename S>
+__global__ void wave_expand_grad_kernel(IlqrWaveArgs<S> a) {
+  const int64_t total = (int64_t)(a.N + 1) * a.batch * 16;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int e = (int)(t & 15);
+    const int b = (int)((t >> 4) % a.batch);
+    const int k = (int)((t >> 4) / a.batch);
+    if (a.active && !a.active[b]) continue;
+    const bool terminal = k == a.N;
+    if (terminal && e >= 12) continue;
+    const S* c = a.cand + (size_t)b * a.xuy_bs + (size_t)k * a.xuy_ks;
+    const S* cp = a.costp + ((size_t)k * a.batch + b) * MF_COSTP;
+    const double z = (double)c[e < 12 ? e : 12 + e];   // x | (y) | u inside a candidate record
+    const double l = (double)cp[e] * z + (double)cp[16 + e];
+    if (terminal) a.term[(size_t)b * MF_TERM + 144 + e] = (S)l;
+    else a.cin[(size_t)b * a.cin_bs + (size_t)k * a.cin_ks + MF_OFF_QR + e] = (S)l;
+  }
+}
+
 // Expansion at the candidate point, one wave per (problem, knot point).
 //   EXPAND_GRADIENT: lx, lu (+ AL terms) into the backward sweep's [q r] slot (q_N of TERM at k = N)
 //   EXPAND_HESSIAN : [Q H^T; H R] = diag(Qd, Rd) + rho G^T M G  (M = the projection's diagonal Jacobian) into the

@@ -133,6 +133,34 @@ __global__ __launch_bounds__(64) void stream_generic(const double* __restrict__ 
   }
 }
 
+// the same with 16 bytes per lane (double2 loads and stores; RIN, ROUT multiples of 2)
+template <int RIN, int ROUT>
+__global__ __launch_bounds__(64) void stream_generic16(const double* __restrict__ in, double* __restrict__ out, int N, int batch) {
+  constexpr int PI = RIN / 2, PO = ROUT / 2;
+  constexpr int LI = (PI + 63) / 64, LO = (PO + 63) / 64;
+  const int lane = threadIdx.x, b = blockIdx.x;
+  double2 cur[LI], nxt[LI];
+  auto load = [&](double2* r, int k) {
+    const double2* rec = (const double2*)(in + ((size_t)k * batch + b) * RIN);
+#pragma unroll
+    for (int c = 0; c < LI; ++c) { int e = c * 64 + lane; r[c] = rec[e < PI ? e : PI - 1]; }
+  };
+  load(cur, N - 1);
+  double acc = 0.0;
+  for (int k = N - 1; k >= 0; --k) {
+    load(nxt, k > 0 ? k - 1 : 0);
+    double s = 0;
+#pragma unroll
+    for (int c = 0; c < LI; ++c) s += cur[c].x + cur[c].y;
+    acc += s;
+    double2* o = (double2*)(out + ((size_t)k * batch + b) * ROUT);
+#pragma unroll
+    for (int c = 0; c < LO; ++c) { int e = c * 64 + lane; o[e < PO ? e : PO - 1] = make_double2(acc + c, acc); }
+#pragma unroll
+    for (int c = 0; c < LI; ++c) cur[c] = nxt[c];
+  }
+}
+
 int main() {
   const int N = 256, batch = 4096;
   const size_t in_n = (size_t)batch * N * 428, out_n = (size_t)batch * N * 208;
@@ -179,6 +207,10 @@ int main() {
     gen("generic 360 r + 144 w (Q, R and P packed)", 360, 144, [&] { stream_generic<360, 144><<<batch, 64>>>(in, out, N, batch); });
     gen("generic 412 r + 28 w (today's forward)", 412, 28, [&] { stream_generic<412, 28><<<batch, 64>>>(in, out, N, batch); });
     gen("generic 348 r + 28 w (forward, P packed)", 348, 28, [&] { stream_generic<348, 28><<<batch, 64>>>(in, out, N, batch); });
+    gen("16 B/lane: 364 r + 144 w", 364, 144, [&] { stream_generic16<364, 144><<<batch, 64>>>(in, out, N, batch); });
+    gen("16 B/lane: 348 r + 28 w", 348, 28, [&] { stream_generic16<348, 28><<<batch, 64>>>(in, out, N, batch); });
+    gen("8 B/lane again: 364 r + 144 w", 364, 144, [&] { stream_generic<364, 144><<<batch, 64>>>(in, out, N, batch); });
+    gen("8 B/lane again: 348 r + 28 w", 348, 28, [&] { stream_generic<348, 28><<<batch, 64>>>(in, out, N, batch); });
   }
   return 0;
 }
