@@ -126,6 +126,9 @@ size_t altro_hip_batch_device_bytes(const altro_hip_batch* h);
 /* ---- problem data (reference layout in, converted once to the device layout) ----------------- */
 int altro_hip_set_dynamics(altro_hip_batch* h, const double* A, const double* B, const double* f,
                            int k_stride_zero, int batch_stride_zero);
+/* Q, R symmetric, as the reference requires (altro_solver.hpp:183).  Plan MFMA16 stores the symmetric blocks once:
+ * of Q_0..Q_{N-1} only the upper triangle is read, and altro_hip_get_P returns P_0..P_{N-1} mirrored from the upper
+ * triangle the sweep keeps (exactly symmetric, within rounding of the reference's P). */
 int altro_hip_set_cost(altro_hip_batch* h, const double* Q, const double* R, const double* H,
                        const double* q, const double* r, int is_diag, int k_stride_zero,
                        int batch_stride_zero);

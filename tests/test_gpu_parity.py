@@ -133,6 +133,29 @@ def test_mfma16_random(with_f):
     assert relerr(out["delta_V"], ref["dV"]) < 1e-9
 
 
+def test_mfma16_symmetric_blocks_are_stored_once():
+    """Plan MFMA16 keeps only the upper triangles of Q and P in HBM (kernels/mfma16_layout.h).  Consequences pinned here:
+    get_P is exactly symmetric and within rounding of the oracle's P (whose two halves differ at the 1e-16 level); the
+    strict lower triangle of the caller's Q is never read; and y = P x + p built from the mirrored triangle stays
+    within the parity tolerance."""
+    pr = problems.random_ltv(8, 24, 12, 4)
+    ref = run_oracle(pr)
+    out = run_hip(pr, altro_amd.PLAN_MFMA16)
+    N = 24
+    P = out["P"].reshape(8, N + 1, 12, 12)
+    assert np.array_equal(P[:, :N], np.swapaxes(P[:, :N], -1, -2))          # stored once -> bitwise symmetric
+    assert relerr(out["P"], ref["P"]) < 1e-12 and relerr(out["y"], ref["y"]) < 1e-10
+    # garbage below the diagonal of Q changes nothing (Q is column-major [i + 12 j]: i > j is the lower triangle)
+    pr2 = dict(pr)
+    Q = pr["Q"].copy().reshape(8, N + 1, 12, 12)                              # [.., j, i]
+    jj, ii = np.meshgrid(np.arange(12), np.arange(12), indexing="ij")
+    Q[:, :N, jj < ii] = 1e6                                                   # knot points 0..N-1 only (Q_N is stored full)
+    pr2["Q"] = Q.reshape(pr["Q"].shape)
+    out2 = run_hip(pr2, altro_amd.PLAN_MFMA16)
+    for k in ("K", "d", "P", "p", "x", "u", "y"):
+        assert np.array_equal(out2[k], out[k]), k
+
+
 def test_mfma16_no_f_pointer():
     pr = problems.random_ltv(3, 8, 12, 4)
     pr["f"] = np.zeros_like(pr["f"])
