@@ -20,7 +20,8 @@
 //
 // Only the 4x4 Cholesky + 13 triangular solves (tvlqr.cpp:159-166) run on the VALU, every lane
 // solving its own column redundantly in its four row-groups, fed by one 640-byte LDS exchange.
-// 8 MFMAs (512 matrix-pipe cycles) per knot point against 5088 algorithmic bytes: HBM-bound.
+// 8 MFMAs (512 matrix-pipe cycles) per knot point against 5088 algorithmic bytes (4064 after storing the symmetric
+// blocks once, see below): HBM-bound.
 //
 // Symmetry note: the tile product uses P'^T where the reference uses P' (and returns G rather than
 // G^T); for the symmetric Q, R the API requires (altro_solver.hpp:183) P_k is symmetric up to rounding,
