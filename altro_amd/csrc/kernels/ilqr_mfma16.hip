@@ -357,7 +357,9 @@ template <typename S>
 __global__ __launch_bounds__(64) void wave_merit_kernel(IlqrWaveArgs<S> a) {
   constexpr int DEPTH = 2;
   __shared__ double img[MW_IMG + 4];
-  __shared__ double xs[12], dxs[12], das[12], us[4], dus[4], jv[AL_MAXC * AL_MAXP];
+  __shared__ double vec[24], das[12], us[4], dus[4], jv[AL_MAXC * AL_MAXP];   // vec = x | dx
+  double* const xs = vec;
+  double* const dxs = vec + 12;
   __shared__ double crec[28], qrec[16];     // candidate record x | y | u and [lx lu], gathered for one coalesced store
   const int b = blockIdx.x, lane = threadIdx.x;
   if (b >= a.batch) return;
@@ -371,9 +373,14 @@ __global__ __launch_bounds__(64) void wave_merit_kernel(IlqrWaveArgs<S> a) {
   const bool is_x = lane < 12, is_u = (grp == 1 && sub < 4), is_y = (grp == 2 && sub < 12);
   const int i = sub < 12 ? sub : 11;       // row of Z / [P|p]
   const int ia = sub < 4 ? sub : 3;        // row of Kt
-  int prow[12];                            // image offsets of row i of P, gathered from its packed upper triangle
+  // image offsets of this lane's row: a row of Z (lanes 0..15), of Kt (16..31) or of [P | p] (32..63; P gathered from
+  // its packed upper triangle), plus the affine column
+  int ra[13];
 #pragma unroll
-  for (int j = 0; j < 12; ++j) prow[j] = MW_OUT0 + MF_OFF_P + mf_sym(i, j);
+  for (int j = 0; j < 12; ++j)
+    ra[j] = (grp == 0) ? i * MW_ZLD + j : (grp == 1) ? MW_OUT0 + ia * 13 + j : MW_OUT0 + MF_OFF_P + mf_sym(i, j);
+  ra[12] = (grp == 0) ? i * MW_ZLD + 12 : (grp == 1) ? MW_OUT0 + ia * 13 + 12 : MW_OUT0 + MF_OFF_p + i;
+  const int vbase = (grp == 0) ? 0 : 12;   // rows of Z multiply x, the others dx: vec = xs | dxs
   const int l27 = lane < 28 ? lane : 27;
   const S* __restrict__ dynb = a.dyn + (size_t)b * a.dyn_bs;
   const S* __restrict__ outb = a.out + (size_t)b * a.out_bs;
@@ -398,43 +405,43 @@ __global__ __launch_bounds__(64) void wave_merit_kernel(IlqrWaveArgs<S> a) {
     const int kc = live ? k : N - 1;
     __syncthreads();             // readers of the previous image are done
     merit_wave_stage(ring[dd], img, lane);
+    // the three vectors every row product below needs: x, dx = x - x_nominal (its record entry is already in this
+    // lane's registers) and dx/dalpha
+    if (is_x) { xs[lane] = x; dxs[lane] = x - ring[dd].nm; das[lane] = dxda; crec[lane] = x; }
     {
       const size_t kn = (k + DEPTH < N) ? k + DEPTH : N - 1;
       merit_wave_load<S>(ring[dd], dynb + kn * a.dyn_ks, outb + kn * a.out_ks, nomb + kn * nom_ks, cpb + kn * cp_ks, lane);
     }
-    if (is_x) { xs[lane] = x; das[lane] = dxda; crec[lane] = x; }
     __syncthreads();
-    if (is_x) dxs[lane] = x - img[MW_NOM0 + lane];
-    __syncthreads();
+    // Phase A, all 64 lanes at once: this lane's row (of Z, of Kt or of [P | p]) times x (rows of Z) or dx (the
+    // others), and times dx/dalpha.  Same accumulation order as the per-role loops this replaces.
+    double acc = 0.0, acc2 = 0.0;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+      const double rj = img[ra[j]];
+      acc += rj * vec[vbase + j];
+      acc2 += rj * das[j];
+    }
+    const double aff = img[ra[12]];          // -d (rows of Kt), p (rows of [P | p]), B[.][0] (rows of Z)
     double uval = 0.0, duval = 0.0;
     if (is_u) {   // u_ = u + (-K dx + alpha d) ; du_da = -K dx_da + d        (Kt = [K | -d])
-      double s = 0.0, s2 = 0.0;
-#pragma unroll
-      for (int j = 0; j < 12; ++j) { const double kij = img[MW_OUT0 + ia * 13 + j]; s += kij * dxs[j]; s2 += kij * das[j]; }
-      const double d = -img[MW_OUT0 + ia * 13 + 12];
-      uval = img[MW_NOM0 + 12 + ia] + (-s + alpha * d);
-      duval = -s2 + d;
+      const double d = -aff;
+      uval = img[MW_NOM0 + 12 + ia] + (-acc + alpha * d);
+      duval = -acc2 + d;
       us[ia] = uval; dus[ia] = duval;
       crec[24 + ia] = uval;
       const double Rd = img[MW_CP0 + 12 + ia], rr = img[MW_CP0 + 28 + ia];
       if (live) J += 0.5 * (uval * (Rd * uval)) + rr * uval;
     }
-    if (is_y) {   // y_ = P dx + p
-      double s = 0.0;
-#pragma unroll
-      for (int j = 0; j < 12; ++j) s += img[prow[j]] * dxs[j];
-      crec[12 + i] = s + img[MW_OUT0 + MF_OFF_p + i];
-    }
+    if (is_y) crec[12 + i] = acc + aff;      // y_ = P dx + p
     __syncthreads();
     double xn = 0.0, dxn = 0.0;
     if (is_x) {   // x+ = A x + B u + f ; dx+/da = A dx_da + B du_da ; state cost
-      double s = 0.0, s2 = 0.0, t = 0.0, t2 = 0.0;
-#pragma unroll
-      for (int j = 0; j < 12; ++j) { const double aij = img[i * MW_ZLD + j]; s += aij * xs[j]; t += aij * das[j]; }
+      double s2 = 0.0, t2 = 0.0;
 #pragma unroll
       for (int cc = 0; cc < 4; ++cc) { const double bic = img[i * MW_ZLD + 12 + cc]; s2 += bic * us[cc]; t2 += bic * dus[cc]; }
-      xn = (s + s2) + img[MW_F0 + i];
-      dxn = t + t2;
+      xn = (acc + s2) + img[MW_F0 + i];
+      dxn = acc2 + t2;
       const double Qd = img[MW_CP0 + i], q = img[MW_CP0 + 16 + i];
       if (live) {
         J += 0.5 * (x * (Qd * x)) + q * x;
