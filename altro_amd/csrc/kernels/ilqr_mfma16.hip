@@ -156,30 +156,46 @@ __device__ __forceinline__ double wave_al_col(const AlTable<S>& t, int k, int e,
   return s;
 }
 
-// x_0 = x0 ; x_{k+1} = A x + B u + f on the candidate trajectory (u_ is the guess already stored there)
+// x_0 = x0 ; x_{k+1} = A x + B u + f on the candidate trajectory (u_ is the guess already stored there).
+// The DYN record is loaded coalesced, one knot point ahead, and staged in LDS with its rows padded to 17 (bank
+// conflicts, see the forward sweep); lanes 0..11 then read their row.
 template <typename S>
 __global__ __launch_bounds__(64) void wave_rollout_kernel(IlqrWaveArgs<S> a) {
-  __shared__ double xs[12], us[4];
+  constexpr int ZLD = 17;
+  __shared__ double zimg[12 * ZLD + 12], xs[12], us[4];
   const int b = blockIdx.x, lane = threadIdx.x;
   if (b >= a.batch) return;
   if (a.active && !a.active[b]) return;
+  const int N = a.N;
   const int i = lane < 12 ? lane : 11;
+  const S* __restrict__ dynb = a.dyn + (size_t)b * a.dyn_bs;
+  S* __restrict__ candb = a.cand + (size_t)b * a.xuy_bs;
   double x = (double)a.x0[(size_t)b * 12 + i];
-  for (int k = 0; k < a.N; ++k) {
-    S* c = a.cand + (size_t)b * a.xuy_bs + (size_t)k * a.xuy_ks;
-    const S* z = a.dyn + (size_t)b * a.dyn_bs + (size_t)k * a.dyn_ks;
-    if (lane < 12) { xs[lane] = x; c[lane] = (S)x; }
-    if (lane >= 16 && lane < 20) us[lane - 16] = (double)c[24 + lane - 16];
+  double zr[3], fr, ur;
+  auto load = [&](int k) {
+    const S* z = dynb + (size_t)k * a.dyn_ks;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) zr[c] = (double)z[MF_OFF_Z + c * 64 + lane];
+    fr = (double)z[MF_OFF_F + i];
+    ur = (double)candb[(size_t)k * a.xuy_ks + 24 + (lane & 3)];
+  };
+  load(0);
+  for (int k = 0; k < N; ++k) {
+    __syncthreads();   // readers of the previous image are done
+#pragma unroll
+    for (int c = 0; c < 3; ++c) zimg[(4 * c + (lane >> 4)) * ZLD + (lane & 15)] = zr[c];
+    zimg[12 * ZLD + i] = fr;
+    if (lane < 4) us[lane] = ur;
+    if (lane < 12) { xs[lane] = x; candb[(size_t)k * a.xuy_ks + lane] = (S)x; }
+    load(k + 1 < N ? k + 1 : N - 1);
     __syncthreads();
     double acc = 0.0;
 #pragma unroll
-    for (int j = 0; j < 12; ++j) acc += (double)z[i * 16 + j] * xs[j];
+    for (int j = 0; j < 12; ++j) acc += zimg[i * ZLD + j] * xs[j];
     double acc2 = 0.0;
 #pragma unroll
-    for (int cc = 0; cc < 4; ++cc) acc2 += (double)z[i * 16 + 12 + cc] * us[cc];
-    const double xn = (acc + acc2) + (double)z[MF_OFF_F + i];
-    __syncthreads();
-    x = xn;
+    for (int cc = 0; cc < 4; ++cc) acc2 += zimg[i * ZLD + 12 + cc] * us[cc];
+    x = (acc + acc2) + zimg[12 * ZLD + i];
   }
   if (lane < 12) a.cand[(size_t)b * a.xuy_bs + (size_t)a.N * a.xuy_ks + lane] = (S)x;
 }
