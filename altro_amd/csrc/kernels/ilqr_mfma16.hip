@@ -294,10 +294,19 @@ __global__ __launch_bounds__(64) void wave_expand_kernel(IlqrWaveArgs<S> a) {
         const int p = kn.p[cidx];
         const S* G = a.al.G + kn.G_off[cidx];
         const double* Jc = Jm + cidx * 64;
-        for (int i = 0; i < p; ++i) {   // (J G)_{i r} (J G)_{i cc}
-          double jr = 0.0, jc = 0.0;
-          for (int q = 0; q < p; ++q) { jr += Jc[i * 8 + q] * (double)G[q + r * p]; jc += Jc[i * 8 + q] * (double)G[q + cc * p]; }
-          s += jr * jc;
+        if (kn.cone[cidx] != CONE_SOC) {   // diagonal projection Jacobian: (J G)_{i r} = J_ii G_ir -- the terms left out
+          for (int i = 0; i < p; ++i) {    // of the full sums below are exact zeros, so the bits are the same
+            const double jii = Jc[i * 8 + i];
+            double jr = 0.0, jc = 0.0;
+            jr += jii * (double)G[i + r * p]; jc += jii * (double)G[i + cc * p];
+            s += jr * jc;
+          }
+        } else {
+          for (int i = 0; i < p; ++i) {   // (J G)_{i r} (J G)_{i cc}
+            double jr = 0.0, jc = 0.0;
+            for (int q = 0; q < p; ++q) { jr += Jc[i * 8 + q] * (double)G[q + r * p]; jc += Jc[i * 8 + q] * (double)G[q + cc * p]; }
+            s += jr * jc;
+          }
         }
         if (kn.cone[cidx] == CONE_SOC) {   // + G^T (d/dz J^T z_proj) G   (knotpoint_data.cpp:561-567)
           const double* Hc = Hm + cidx * 16;
