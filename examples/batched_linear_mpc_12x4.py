@@ -15,6 +15,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import altro_amd  # noqa: E402
 
 
+# the reference's MPC caller uses the backtracking line search (test/bicycle_test.cpp:282); BACKTRACK=0 selects the cubic one
+BACKTRACK = bool(int(os.environ.get("BACKTRACK", "1")))
+
+
 def main():
     batch = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
@@ -43,7 +47,7 @@ def main():
     t_solve = 0.0
     for t in range(steps):
         t0 = time.perf_counter()
-        res = bt.ilqr_solve(iterations_max=60)
+        res = bt.ilqr_solve(iterations_max=60, use_backtracking=BACKTRACK)
         t_solve += time.perf_counter() - t0
         _, u = bt.get_knot(0)
         x = x @ A.T + u @ B.T                                                    # the plant: the same linear model
