@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import altro_amd  # noqa: E402
 
 
-# the reference's MPC caller uses the backtracking line search (test/bicycle_test.cpp:282); BACKTRACK=0 selects the cubic one
+# the reference's MPC caller uses the backtracking line search (test/bicycle_test.cpp:291); BACKTRACK=0 selects the cubic one
 BACKTRACK = bool(int(os.environ.get("BACKTRACK", "1")))
 
 
