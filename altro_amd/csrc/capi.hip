@@ -82,6 +82,11 @@ struct altro_hip_batch {
   IlqrProb* i_prob = nullptr;
   double *i_alpha = nullptr, *i_phi = nullptr, *i_dphi = nullptr;
   int *i_active = nullptr, *i_counters = nullptr;
+  // speculative backtracking (altro_hip_ilqr_solve): spare candidate trajectories, allocated on first use
+  void* i_cand_spec = nullptr;
+  int *i_spec_sel = nullptr, *i_spec_refresh = nullptr;
+  int spec_trials = 1;            // trials per merit launch of the CURRENT launch (1 = no speculation)
+  int spec_pre = 0;               // the current launch is phi(0) fused with the first trial step
   ModelParams model{MODEL_LINEAR, 0.0f, 0, 2.7, 1.5};
   bool model_set = false, lqr_cost_set = false, guess_set = false;
   // augmented-Lagrangian constraint blocks (plan LANE): host mirrors + device tables, uploaded lazily
@@ -556,6 +561,11 @@ IlqrArgs<T> ilqr_args(altro_hip_batch* h, bool use_alpha, bool use_active, int w
   a.active = use_active ? h->i_active : nullptr;
   a.phi = h->i_phi; a.dphi = h->i_dphi; a.prob = h->i_prob;
   a.mp = h->model; a.N = h->N; a.batch = h->batch; a.want_derivative = want_deriv; a.alpha_const = alpha_const;
+  a.cand_spec = (T*)h->i_cand_spec; a.spec_trials = h->i_cand_spec ? h->spec_trials : 1; a.spec_sel = h->i_spec_sel;
+  a.spec_pre = h->i_cand_spec ? h->spec_pre : 0;
+  a.spec_stride = (int64_t)h->batch * (h->N + 1) * lane_sizes(h->n, h->m).e_xuy;
+  const LsOptions lo = ls_default_options();
+  a.ls_beta = lo.beta_decrease; a.ls_max_iters = lo.max_iters;
   return a;
 }
 
@@ -581,6 +591,11 @@ int wave_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int
   a.alpha = use_alpha ? h->i_alpha : nullptr; a.active = use_active ? h->i_active : nullptr;
   a.phi = h->i_phi; a.dphi = h->i_dphi; a.prob = h->i_prob; a.N = h->N; a.batch = h->batch;
   a.want_derivative = want_deriv; a.alpha_const = alpha_const;
+  a.cand_spec = (S*)h->i_cand_spec; a.spec_trials = h->i_cand_spec ? h->spec_trials : 1; a.spec_sel = h->i_spec_sel;
+  a.spec_pre = h->i_cand_spec ? h->spec_pre : 0;
+  a.spec_stride = (int64_t)h->batch * (h->N + 1) * 28;
+  const LsOptions lo = ls_default_options();
+  a.ls_beta = lo.beta_decrease; a.ls_max_iters = lo.max_iters;
   const int rc = ilqr_wave_launch_kernel<S>(h->stream, which, a);
   if (rc == 1) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "operation %d is not available on plan MFMA16", which);
   if (rc) return fail(ALTRO_HIP_ERR_HIP, "iLQR kernel launch failed");
@@ -822,8 +837,10 @@ int altro_hip_batch_create(altro_hip_batch** out, int N, int n, int m, int batch
     if (!rc) h->al_knots.assign((size_t)N + 1, AlKnot{});
     ALLOC(h->i_prob, B * sizeof(IlqrProb));
     ALLOC(h->i_alpha, B * 8);
-    ALLOC(h->i_phi, B * 8);
-    ALLOC(h->i_dphi, B * 8);
+    ALLOC(h->i_phi, B * 8 * ILQR_SPEC_TRIALS);
+    ALLOC(h->i_spec_sel, B * sizeof(int));
+    ALLOC(h->i_spec_refresh, B * sizeof(int));
+    ALLOC(h->i_dphi, B * 8 * 2);
     ALLOC(h->i_active, B * sizeof(int));
     ALLOC(h->i_counters, 4 * sizeof(int));
     ALLOC(h->i_reg, B * 8);
@@ -854,7 +871,8 @@ void altro_hip_batch_destroy(altro_hip_batch* h) {
                   h->m_qblk, h->m_trash, h->g_off, h->g_nx, h->g_nu, h->stage,
                   h->l_in, h->l_term, h->l_out, h->l_outn, h->l_xuy, h->l_x0,
                   h->l_nom, h->l_cost, h->i_prob, h->i_alpha, h->i_phi, h->i_dphi, h->i_active, h->i_counters,
-                  h->al_d_knots, h->al_d_G, h->al_d_g, h->al_d_z, h->i_reg, h->m_nom, h->m_costp};
+                  h->al_d_knots, h->al_d_G, h->al_d_g, h->al_d_z, h->i_reg, h->m_nom, h->m_costp,
+                  h->i_cand_spec, h->i_spec_sel, h->i_spec_refresh};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (int a = 0; a < G_NUM; ++a) if (h->g_arr[a]) (void)hipFree(h->g_arr[a]);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -1589,6 +1607,7 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
   const bool al = !h->al_defs.empty();
   la.al_enabled = al ? 1 : 0;
   la.reg = h->i_reg; la.bwd_status = h->status;
+  la.spec_trials = 1; la.spec_pre = 0; la.spec_sel = h->i_spec_sel; la.spec_refresh = h->i_spec_refresh;
   la.reg_initial = o.reg_initial; la.reg_scale = o.reg_scale; la.reg_min = o.reg_min; la.reg_max = o.reg_max;
   const bool reg_on = o.reg_retry_max > 0 || o.reg_initial > 0.0;
   if (reg_on && h->plan != ALTRO_HIP_PLAN_LANE)
@@ -1620,6 +1639,17 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
   if (rc) return rc;
   if (al && ilqr_launch_loop(h->stream, ILK_SET_PENALTY, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
   int total_merit_launches = 0, sweeps = 0;
+  // speculative backtracking: how much of the chip the searching problems occupy, and how much there is
+  const bool spec_all_on = std::getenv("ALTRO_HIP_NO_SPECULATION") == nullptr;
+  const bool spec_on = o.use_backtracking_linesearch != 0 && spec_all_on;
+  int running = h->batch;   // problems still iterating (counters[1] of the previous sweep)
+  const bool lane_plan = h->plan == ALTRO_HIP_PLAN_LANE;
+  auto spec_units = [&](int searching) -> int {   // wavefronts one merit launch keeps busy
+    return lane_plan ? (h->batch + 63) / 64 : searching;   // LANE: the searching lanes are scattered over all waves
+  };
+  const int64_t spec_capacity = lane_plan ? 512 : 4096;    // two waves per CU (LANE: latency-bound; more slow each other down) / four per SIMD (MFMA16)
+  const int64_t cand_elems = (int64_t)h->batch * (h->N + 1) * (lane_plan ? lane_sizes(h->n, h->m).e_xuy : 28);
+  h->spec_trials = 1;
   struct MaskGuard {   // the backward sweep skips problems that have stopped, only inside this loop
     altro_hip_batch* h;
     ~MaskGuard() { h->bwd_active = nullptr; h->bwd_reg = nullptr; }
@@ -1647,28 +1677,74 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
       if (rc) return rc;
     }
     if (o.reg_retry_max > 0 && ilqr_launch_loop(h->stream, ILK_MARK_RUNNING, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
-    // ForwardPass: phi(0), then the line search (solver.cpp:237-271)
+    // ForwardPass: phi(0), then the line search (solver.cpp:237-271).  While the running problems leave half of the
+    // chip idle, the first step the search will ask for (alpha0 = 1, known in advance) rides in the same launch as
+    // phi(0) -- phi, phi' and the trajectory go to spare row / buffer 0 -- and ILK_LS_BEGIN consumes it at once.
+    bool refreshed = false;
+    const bool pre = spec_all_on && (int64_t)spec_units(running) * 2 <= spec_capacity;
+    if (pre && !h->i_cand_spec) {
+      const size_t bytes = (size_t)(ILQR_SPEC_TRIALS - 1) * cand_elems * h->esz;
+      if ((rc = dmalloc(h, &h->i_cand_spec, bytes))) return rc;
+    }
+    h->spec_trials = pre ? 2 : 1; h->spec_pre = pre ? 1 : 0;
     rc = ilqr_run(h, IK_MERIT, true, true, 1, 0.0);
+    h->spec_trials = 1; h->spec_pre = 0;
     if (rc) return rc;
     ++total_merit_launches;
     if ((rc = zero_counter(0))) return rc;
+    la.spec_pre = pre ? 1 : 0;
     if (ilqr_launch_loop(h->stream, ILK_LS_BEGIN, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
-    // The first trial step is launched without asking the device whether any problem needs it: the masks make it a
-    // no-op when none does, and it saves one host read-back per sweep (these loops are latency-bound).
-    rc = ilqr_run(h, IK_MERIT, true, true, 1, 0.0);
-    if (rc) return rc;
-    ++total_merit_launches;
-    if ((rc = zero_counter(0))) return rc;
-    if (ilqr_launch_loop(h->stream, ILK_LS_FEED, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
-    if ((rc = read_counters())) return rc;
-    int guard = 0;
-    while (counters[0] > 0 && guard++ < 64) {
+    la.spec_pre = 0;
+    if (pre) {
+      rc = ilqr_run(h, IK_SPEC_SELECT, false, false, 0, 0.0);
+      if (rc) return rc;
+      refreshed = true;
+    } else {
+      // The first trial step is launched without asking the device whether any problem needs it: the masks make it
+      // a no-op when none does, and it saves one host read-back per sweep (these loops are latency-bound).
       rc = ilqr_run(h, IK_MERIT, true, true, 1, 0.0);
       if (rc) return rc;
       ++total_merit_launches;
       if ((rc = zero_counter(0))) return rc;
       if (ilqr_launch_loop(h->stream, ILK_LS_FEED, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
+    }
+    if ((rc = read_counters())) return rc;
+    int guard = 0;
+    while (counters[0] > 0 && guard++ < 64) {
+      // Speculative backtracking: once the problems still searching leave most of the chip idle, one launch
+      // evaluates the next 2, 4 or 8 steps of the (known) sequence alpha beta^j for each of them; the feed
+      // kernel consumes them in order, so every decision is the sequential one (kernels/ilqr_types.h).
+      int trials = 1;
+      if (spec_on)
+        while (trials < ILQR_SPEC_TRIALS && (int64_t)spec_units(counters[0]) * trials * 2 <= spec_capacity) trials *= 2;
+      const bool spec = trials > 1;
+      if (spec && !h->i_cand_spec) {
+        const size_t bytes = (size_t)(ILQR_SPEC_TRIALS - 1) * cand_elems * h->esz;
+        if ((rc = dmalloc(h, &h->i_cand_spec, bytes))) return rc;
+      }
+      h->spec_trials = trials;
+      la.spec_trials = h->spec_trials;
+      rc = ilqr_run(h, IK_MERIT, true, true, 1, 0.0);
+      if (rc) return rc;
+      ++total_merit_launches;
+      if ((rc = zero_counter(0))) return rc;
+      if (ilqr_launch_loop(h->stream, ILK_LS_FEED, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
+      if (spec) {
+        rc = ilqr_run(h, IK_SPEC_SELECT, false, false, 0, 0.0);
+        if (rc) return rc;
+        refreshed = true;
+      }
+      h->spec_trials = 1;
+      la.spec_trials = 1;
       if ((rc = read_counters())) return rc;
+    }
+    if (refreshed) {   // steps accepted from a speculative trial carry no phi' pass: redo their expansion (what the
+                       // derivative pass of a sequential trial would have left behind)
+      int* keep = h->i_active;
+      h->i_active = h->i_spec_refresh;
+      rc = ilqr_run(h, IK_EXPAND, false, true, 0, 0.0, EXPAND_GRADIENT);
+      h->i_active = keep;
+      if (rc) return rc;
     }
     // convergence criteria on the accepted candidate, then make it the nominal (solver.cpp:459-469)
     if (ilqr_launch_loop(h->stream, ILK_MARK_RUNNING, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
@@ -1687,6 +1763,7 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
     if ((rc = read_counters())) return rc;
     ++sweeps;
     if (counters[1] == 0) break;
+    running = counters[1];
   }
   h->forward_done = true;
   if (results) {

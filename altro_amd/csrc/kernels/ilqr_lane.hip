@@ -231,8 +231,8 @@ __device__ __forceinline__ T ilqr_kp_cost_reg(const T* cs, const T* x, const T* 
 
 // one non-terminal knot point of MeritFunction (solver.cpp:286-317)
 template <int KIND, int n, int m, typename T>
-__device__ __forceinline__ void merit_step(const MeritRec<n, m, T>& r, const IlqrArgs<T>& a, int k, int64_t b, int64_t b0,
-                                           uint32_t lane, uint32_t rowB, T alpha, T rho, bool deriv, bool al, T (&x)[n],
+__device__ __forceinline__ void merit_step(const MeritRec<n, m, T>& r, const IlqrArgs<T>& a, T* cand, int k, int64_t b, int64_t b0,
+                                           uint32_t lane, uint32_t rowB, T alpha, T rho, bool deriv, bool store, bool al, T (&x)[n],
                                            T (&dxda)[n], T& phi, T& dphi) {
   using D = LaneDims<n, m>;
   using I = IlqrDims<n, m>;
@@ -250,7 +250,7 @@ __device__ __forceinline__ void merit_step(const MeritRec<n, m, T>& r, const Ilq
     for (int j = 0; j < n; ++j) s += r.out[D::O_P + i + j * n] * dx[j];
     y[i] = s + r.out[D::O_p + i];
   }
-  const LaneBuf bc(a.cand + b0 + (int64_t)k * I::E_CAND * B);
+  const LaneBuf bc(cand + b0 + (int64_t)k * I::E_CAND * B);
 #pragma unroll
   for (int e = 0; e < n; ++e) lane_st<T>(bc, lane, (uint32_t)e * rowB, x[e]);
 #pragma unroll
@@ -271,9 +271,9 @@ __device__ __forceinline__ void merit_step(const MeritRec<n, m, T>& r, const Ilq
     T duda[m], dxn[n];
     const LaneBuf bi(a.in + b0 + (int64_t)k * D::E_IN * B);
 #pragma unroll
-    for (int e = 0; e < n * n; ++e) lane_st<T>(bi, lane, (uint32_t)(D::O_A + e) * rowB, Am[e]);
+    for (int e = 0; e < n * n; ++e) if (store) lane_st<T>(bi, lane, (uint32_t)(D::O_A + e) * rowB, Am[e]);
 #pragma unroll
-    for (int e = 0; e < n * m; ++e) lane_st<T>(bi, lane, (uint32_t)(D::O_B + e) * rowB, Bm[e]);
+    for (int e = 0; e < n * m; ++e) if (store) lane_st<T>(bi, lane, (uint32_t)(D::O_B + e) * rowB, Bm[e]);
     for (int i = 0; i < m; ++i) {   // du_da = -K dx_da + d
       T s = T(0);
       for (int j = 0; j < n; ++j) s += r.out[D::O_K + i + j * m] * dxda[j];
@@ -287,9 +287,9 @@ __device__ __forceinline__ void merit_step(const MeritRec<n, m, T>& r, const Ilq
       dxn[i] = s + s2;
     }
 #pragma unroll
-    for (int e = 0; e < n; ++e) lane_st<T>(bi, lane, (uint32_t)(D::O_q + e) * rowB, lx[e]);
+    for (int e = 0; e < n; ++e) if (store) lane_st<T>(bi, lane, (uint32_t)(D::O_q + e) * rowB, lx[e]);
 #pragma unroll
-    for (int e = 0; e < m; ++e) lane_st<T>(bi, lane, (uint32_t)(D::O_r + e) * rowB, lu[e]);
+    for (int e = 0; e < m; ++e) if (store) lane_st<T>(bi, lane, (uint32_t)(D::O_r + e) * rowB, lu[e]);
     T s = T(0);
     for (int i = 0; i < n; ++i) s += lx[i] * dxda[i];
     dphi += s;
@@ -310,8 +310,30 @@ __global__ __launch_bounds__(64) void ilqr_merit_kernel(IlqrArgs<T> a) {
   const uint32_t lane = threadIdx.x * (uint32_t)sizeof(T);
   const uint32_t rowB = (uint32_t)B * (uint32_t)sizeof(T);
   const int64_t b0 = (int64_t)blockIdx.x * 64;
-  const T alpha = (T)(a.alpha ? a.alpha[b] : a.alpha_const);
-  const bool deriv = a.want_derivative != 0;
+  double alpha_d = a.alpha ? a.alpha[b] : a.alpha_const;
+  T* cand = a.cand;
+  const int trial = blockIdx.y;   // > 0: a speculative backtracking trial (IlqrArgs::spec_trials)
+  bool store = true;              // a derivative pass also leaves A, B, lx, lu behind -- except the fused first trial
+  if (trial > 0 && a.spec_pre) {  // next to phi(0): the step alpha0 = 1 the search will ask for first, phi and phi'
+    if (trial > 1) return;
+    alpha_d = 1.0;
+    cand = a.cand_spec;
+    store = false;
+  } else if (trial > 0) {
+    const LsState& ls = a.prob[b].ls;
+    if (ls.stage == LS_STAGE_BACKTRACK) {          // pending: alpha beta^0 with bt_iter = t; trial j is bt_iter = t + j
+      if (ls.bt_iter + trial >= a.ls_max_iters) return;
+    } else if (ls.stage == LS_STAGE_CUBIC) {       // pending: the cubic guess; if it is rejected the backtracking
+      if (trial >= a.ls_max_iters) return;         // sequence starts at alpha0 beta with bt_iter = 1 (linesearch.cpp:138)
+      alpha_d = ls.alpha0;
+    } else {
+      return;
+    }
+    for (int t = 0; t < trial; ++t) alpha_d = alpha_d * a.ls_beta;   // the state machine's own sequence of products
+    cand = a.cand_spec + (int64_t)(trial - 1) * a.spec_stride;
+  }
+  const T alpha = (T)alpha_d;
+  const bool deriv = a.want_derivative != 0 && (trial == 0 || a.spec_pre);   // backtracking trials never ask for phi'
   const bool al = a.al.enabled != 0;
   const T rho = al ? (T)a.prob[b].rho : T(1);   // CalcCost refreshes the projected duals with the current penalty
   T x[n], dxda[n], phi = T(0), dphi = T(0);
@@ -324,7 +346,7 @@ __global__ __launch_bounds__(64) void ilqr_merit_kernel(IlqrArgs<T> a) {
   merit_load<n, m, T>(r0, a, 0, b0, lane, rowB);
   for (int k = 0; k < N; ++k) {   // one step instance (code size); the copy waits for record k + 1 after step k
     merit_load<n, m, T>(r1, a, k + 1, b0, lane, rowB);      // k + 1 == N: the terminal record
-    merit_step<KIND, n, m, T>(r0, a, k, b, b0, lane, rowB, alpha, rho, deriv, al, x, dxda, phi, dphi);
+    merit_step<KIND, n, m, T>(r0, a, cand, k, b, b0, lane, rowB, alpha, rho, deriv, store, al, x, dxda, phi, dphi);
     r0 = r1;
   }
   {   // terminal knot point (solver.cpp:319-332); r0 holds record N
@@ -336,7 +358,7 @@ __global__ __launch_bounds__(64) void ilqr_merit_kernel(IlqrArgs<T> a) {
     phi += Jk;
     T dx[n];
     for (int i = 0; i < n; ++i) dx[i] = x[i] - r0.nom[i];
-    const LaneBuf bc(a.cand + b0 + (int64_t)N * I::E_CAND * B), bt(a.term + b0);
+    const LaneBuf bc(cand + b0 + (int64_t)N * I::E_CAND * B), bt(a.term + b0);
     for (int i = 0; i < n; ++i) {
       T s = T(0);
       for (int j = 0; j < n; ++j) s += r0.out[D::O_P + i + j * n] * dx[j];
@@ -347,15 +369,28 @@ __global__ __launch_bounds__(64) void ilqr_merit_kernel(IlqrArgs<T> a) {
     if (deriv) {
       T s = T(0);
       for (int i = 0; i < n; ++i) {
-        lane_st<T>(bt, lane, (uint32_t)(n * n + i) * rowB, lxN[i]);
+        if (store) lane_st<T>(bt, lane, (uint32_t)(n * n + i) * rowB, lxN[i]);
         s += lxN[i] * dxda[i];
       }
       dphi += s;
     }
   }
-  a.phi[b] = (double)phi;
-  if (deriv) a.dphi[b] = (double)dphi;
+  a.phi[(int64_t)trial * B + b] = (double)phi;
+  if (deriv) a.dphi[(int64_t)trial * B + b] = (double)dphi;
   if (al) a.prob[b].rho_est = (double)rho;
+}
+
+// Speculative backtracking: the problems that just ended their search on spare trajectory spec_sel[b] - 1 get it
+// copied over their candidate trajectory (rows x | y | u of every knot point).
+template <int n, int m, typename T>
+__global__ void ilqr_spec_select_kernel(IlqrArgs<T> a) {
+  using I = IlqrDims<n, m>;
+  const int64_t B = a.batch;
+  const int64_t total = (int64_t)(a.N + 1) * I::E_CAND * B;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int s = a.spec_sel[t % B];
+    if (s > 0) a.cand[t] = a.cand_spec[(int64_t)(s - 1) * a.spec_stride + t];
+  }
 }
 
 // Stationarity (solver.cpp:207-222) and Feasibility (solver.cpp:224-231) of the candidate trajectory: maxima over

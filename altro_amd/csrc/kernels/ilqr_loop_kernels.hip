@@ -27,6 +27,8 @@ __global__ void ilqr_ls_begin_kernel(IlqrLoopArgs a) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= a.batch) return;
   IlqrProb& p = a.prob[b];
+  a.spec_sel[b] = 0;
+  a.spec_refresh[b] = 0;
   if (!p.running) { a.active[b] = 0; return; }
   p.phi0 = a.phi[b];
   p.dphi0 = a.dphi[b];
@@ -44,6 +46,19 @@ __global__ void ilqr_ls_begin_kernel(IlqrLoopArgs a) {
       p.ls_failed = 1;
     }
   }
+  // Fused first trial (IlqrLoopArgs::spec_pre): the merit launch that produced phi(0) also evaluated the first step
+  // alpha0 = 1 the search asks for (into phi / dphi row 1 and spare candidate 0), so it is consumed right here.
+  if (need && a.spec_pre) {
+    need = ls_feed(p.ls, a.ls, a.phi[(size_t)a.batch + b], a.dphi[(size_t)a.batch + b]);
+    if (!need) {   // the search ended on that step (same bookkeeping as ilqr_ls_feed_kernel)
+      p.alpha = p.ls.alpha;
+      p.ls_iters = p.ls.n_iters;
+      const int st = p.ls.status;
+      p.ls_failed = (isnan(p.alpha) || !(st == LS_MINIMUM_FOUND || st == LS_HIT_MAX_STEPSIZE)) ? 1 : 0;
+      a.spec_sel[b] = 1;
+      a.spec_refresh[b] = 1;
+    }
+  }
   p.evaluating = need ? 1 : 0;
   a.active[b] = need ? 1 : 0;
   if (need) {
@@ -57,8 +72,20 @@ __global__ void ilqr_ls_feed_kernel(IlqrLoopArgs a) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= a.batch) return;
   IlqrProb& p = a.prob[b];
-  if (!p.running || !p.evaluating) { a.active[b] = 0; return; }
-  const bool need = ls_feed(p.ls, a.ls, a.phi[b], a.dphi[b]);
+  if (!p.running || !p.evaluating) { a.active[b] = 0; a.spec_sel[b] = 0; return; }
+  // Speculative backtracking: the merit launch also evaluated alpha beta^j, j = 1 .. spec_trials - 1, for the problems
+  // that were in the backtracking stage or about to enter it (cubic first guess pending).  Feeding them in order reproduces the sequential search exactly; "need" after
+  // trial j - 1 is precisely the condition under which trial j exists (bt_iter below max_iters).
+  const int stage0 = p.ls.stage;
+  bool need = ls_feed(p.ls, a.ls, a.phi[b], a.dphi[b]);
+  int last = 0;
+  if (stage0 == LS_STAGE_BACKTRACK || stage0 == LS_STAGE_CUBIC)   // (a rejected cubic guess is followed by alpha0 beta^j, j >= 1)
+    for (int j = 1; j < a.spec_trials && need && p.ls.stage == LS_STAGE_BACKTRACK; ++j) {
+      need = ls_feed(p.ls, a.ls, a.phi[(size_t)j * a.batch + b], 0.0);
+      last = j;
+    }
+  a.spec_sel[b] = need ? 0 : last;          // the trajectory of the last trial fed is the one the search ends on
+  if (!need && last > 0) a.spec_refresh[b] = 1;
   if (need) {
     a.alpha[b] = p.ls.alpha;
     a.active[b] = 1;

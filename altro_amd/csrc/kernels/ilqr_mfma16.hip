@@ -218,6 +218,22 @@ __global__ void wave_accept_kernel(IlqrWaveArgs<S> a) {
   }
 }
 
+// Speculative backtracking: copy spare candidate trajectory spec_sel[b] - 1 over the candidate of problem b
+template <typename S>
+__global__ void wave_spec_select_kernel(IlqrWaveArgs<S> a) {
+  const int64_t total = (int64_t)a.batch * (a.N + 1) * 28;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int e = (int)(t % 28);
+    const int64_t r = t / 28;
+    const int b = (int)(r % a.batch);
+    const int k = (int)(r / a.batch);
+    const int sl = a.spec_sel[b];
+    if (sl <= 0) continue;
+    const size_t off = (size_t)b * a.xuy_bs + (size_t)k * a.xuy_ks + e;
+    a.cand[off] = a.cand_spec[(size_t)(sl - 1) * a.spec_stride + off];
+  }
+}
+
 // Cost gradient of an UNconstrained problem: lx = Qd x + q, lu = Rd u + r, one thread per (knot point, problem,
 // entry) in the order the records lie in HBM.  (The wave-per-knot-point kernel below is for the AL terms; without
 // them it would spend a million 64-lane workgroups on 16 multiply-adds each.)
@@ -390,8 +406,29 @@ __global__ __launch_bounds__(64) void wave_merit_kernel(IlqrWaveArgs<S> a) {
   if (b >= a.batch) return;
   if (a.active && !a.active[b]) return;
   const int N = a.N;
-  const double alpha = a.alpha ? a.alpha[b] : a.alpha_const;
-  const bool deriv = a.want_derivative != 0;
+  double alpha = a.alpha ? a.alpha[b] : a.alpha_const;
+  S* __restrict__ candb = a.cand + (size_t)b * a.xuy_bs;
+  const int trial = blockIdx.y;   // > 0: a speculative backtracking trial (IlqrArgs::spec_trials)
+  bool store = true;              // see ilqr_merit_kernel
+  if (trial > 0 && a.spec_pre) {
+    if (trial > 1) return;
+    alpha = 1.0;
+    candb = a.cand_spec + (size_t)b * a.xuy_bs;
+    store = false;
+  } else if (trial > 0) {
+    const LsState& ls = a.prob[b].ls;
+    if (ls.stage == LS_STAGE_BACKTRACK) {
+      if (ls.bt_iter + trial >= a.ls_max_iters) return;
+    } else if (ls.stage == LS_STAGE_CUBIC) {       // see ilqr_merit_kernel
+      if (trial >= a.ls_max_iters) return;
+      alpha = ls.alpha0;
+    } else {
+      return;
+    }
+    for (int t = 0; t < trial; ++t) alpha = alpha * a.ls_beta;
+    candb = a.cand_spec + (size_t)(trial - 1) * a.spec_stride + (size_t)b * a.xuy_bs;
+  }
+  const bool deriv = a.want_derivative != 0 && (trial == 0 || a.spec_pre);
   const bool al = a.al.enabled != 0;
   const double rho = al ? a.prob[b].rho : 1.0;   // CalcCost refreshes the projected duals with the current penalty
   const int grp = lane >> 4, sub = lane & 15;
@@ -490,12 +527,12 @@ __global__ __launch_bounds__(64) void wave_merit_kernel(IlqrWaveArgs<S> a) {
     __syncthreads();
     {   // one coalesced store of the candidate record (and of [lx lu]).  A padding step's record goes to the terminal
         // slot, which the terminal block below rewrites (x is already x_N there)
-      S* c = a.cand + (size_t)b * a.xuy_bs + (size_t)(live ? k : N) * a.xuy_ks;
+      S* c = candb + (size_t)(live ? k : N) * a.xuy_ks;
       c[l27] = (S)crec[l27];
       if (deriv) {
         S* ci = a.cin + (size_t)b * a.cin_bs + (size_t)kc * a.cin_ks;
         const double qv = qrec[sub];
-        if (live) ci[MF_OFF_QR + sub] = (S)qv;
+        if (live && store) ci[MF_OFF_QR + sub] = (S)qv;
       }
     }
     if (is_x && live) { x = xn; dxda = dxn; }
@@ -506,7 +543,7 @@ __global__ __launch_bounds__(64) void wave_merit_kernel(IlqrWaveArgs<S> a) {
     const S* nm = a.nom + ((size_t)N * a.batch + b) * MF_NOM;
     const S* cp = a.costp + ((size_t)N * a.batch + b) * MF_COSTP;
     const S* on = a.outn + (size_t)b * MF_TERM;
-    S* c = a.cand + (size_t)b * a.xuy_bs + (size_t)N * a.xuy_ks;
+    S* c = candb + (size_t)N * a.xuy_ks;
     if (is_u) c[24 + ia] = S(0);
     if (is_x) {
       xs[lane] = x;
@@ -528,14 +565,14 @@ __global__ __launch_bounds__(64) void wave_merit_kernel(IlqrWaveArgs<S> a) {
     if (deriv && is_x) {
       double lx = (double)cp[i] * x + (double)cp[16 + i];
       if (al) lx -= wave_al_col<S>(a.al, N, i, jv);
-      a.term[(size_t)b * MF_TERM + 144 + i] = (S)lx;
+      if (store) a.term[(size_t)b * MF_TERM + 144 + i] = (S)lx;
       dJ += lx * dxda;
     }
   }
   const double phi = wave_sum(J), dphi = wave_sum(dJ);
   if (lane == 0) {
-    a.phi[b] = phi;
-    if (deriv) a.dphi[b] = dphi;
+    a.phi[(size_t)trial * a.batch + b] = phi;
+    if (deriv) a.dphi[(size_t)trial * a.batch + b] = dphi;
     if (al) a.prob[b].rho_est = rho;
   }
 }

@@ -47,6 +47,18 @@ struct IlqrArgs {
   double alpha_const;
   AlTable<T> al;
   int mode;             // expand kernel: bit 0 = dynamics Jacobians + cost gradient, bit 1 = cost Hessian
+  // Speculative backtracking (merit kernel, gridDim.y = spec_trials): block row j > 0 evaluates, for the problems
+  // that are in the backtracking stage, the step the state machine WILL ask for after j more failures -- the sequence
+  // alpha beta^j is known in advance (linesearch.cpp:385-413) -- into phi[j * batch + b] and the j-th spare
+  // candidate trajectory; ilqr_ls_feed_kernel consumes the results in order, so decisions are unchanged.
+  T* cand_spec;         // [spec_trials - 1][same shape as cand]
+  int64_t spec_stride;  // elements between two spare candidate trajectories
+  int spec_trials;      // 1 = no speculation
+  int spec_pre;         // 1: this is the phi(0) launch and block row 1 evaluates the search's first step alpha0 = 1
+                        //    (phi and phi' into row 1, no expansion stores, spare candidate 0)
+  const int* spec_sel;  // [batch] IK_SPEC_SELECT: copy spare candidate spec_sel[b] - 1 over the candidate of problem b
+  double ls_beta;       // CubicLineSearch::beta_decrease
+  int ls_max_iters;
 };
 enum { EXPAND_GRADIENT = 1, EXPAND_HESSIAN = 2 };
 
@@ -57,6 +69,10 @@ struct IlqrLoopArgs {
   const double* phi;
   const double* dphi;
   int* counters;      // [0] = problems that still need a merit evaluation, [1] = problems still running
+  int spec_trials;    // trials evaluated by the last merit launch (phi holds spec_trials x batch values)
+  int spec_pre;       // ILK_LS_BEGIN: row 1 of phi / dphi holds the first trial step (see IlqrArgs::spec_pre)
+  int* spec_sel;      // [batch] 1 + the spare candidate trajectory a problem that JUST finished its search took (0: none)
+  int* spec_refresh;  // [batch] 1: the accepted step came from a speculative trial (no phi' pass): expansion to be redone
   int batch;
   int iter;
   int iterations_max;
@@ -77,9 +93,9 @@ constexpr int MF_COSTP = 36;   // cost-parameter record: Qd 12 | Rd 4 | q 12 | r
 template <typename S>
 struct IlqrWaveArgs {
   const S* dyn;   int64_t dyn_bs, dyn_ks;    // DYN records: Z 192 | f 12
-  S* cin;         int64_t cin_bs, cin_ks;    // COST records: Q 144 | [H R] 64 | [q r] 16
+  S* cin;         int64_t cin_bs, cin_ks;    // COST records: triu(Q) 78 | pad 2 | [H R] 64 | [q r] 16
   S* term;                                   // [b][156]: Q_N 144 | q_N 12
-  const S* out;   int64_t out_bs, out_ks;    // OUT records: Kt 52 | [P p] 156
+  const S* out;   int64_t out_bs, out_ks;    // OUT records: Kt 52 | triu(P) 78 | p 12 | pad 2
   const S* outn;                             // [b][156]
   S* nom;                                    // [k][b][16]
   S* cand;        int64_t xuy_bs, xuy_ks;    // [k][b][28]: x 12 | y 12 | u 4
@@ -87,6 +103,8 @@ struct IlqrWaveArgs {
   const S* x0;                               // [b][12]
   const double* alpha;
   const int* active;
+  S* cand_spec; int64_t spec_stride; int spec_trials; int spec_pre; double ls_beta; int ls_max_iters;   // see IlqrArgs
+  const int* spec_sel;
   double* phi;
   double* dphi;
   IlqrProb* prob;
@@ -99,7 +117,9 @@ struct IlqrWaveArgs {
 template <typename S>
 int ilqr_wave_launch_kernel(hipStream_t stream, int which, const IlqrWaveArgs<S>& a);   // ilqr_launch_mfma16.hip
 
-enum IlqrKernel { IK_ROLLOUT, IK_ACCEPT, IK_EXPAND, IK_MERIT, IK_STATIONARITY, IK_DUAL, IK_SHIFT };
+// Speculative backtracking: most trials one merit launch evaluates (the host picks 1, 2, 4 or 8 by how idle the chip is)
+constexpr int ILQR_SPEC_TRIALS = 8;
+enum IlqrKernel { IK_ROLLOUT, IK_ACCEPT, IK_EXPAND, IK_MERIT, IK_STATIONARITY, IK_DUAL, IK_SHIFT, IK_SPEC_SELECT };
 enum IlqrLoopKernel { ILK_LOOP_INIT, ILK_LS_BEGIN, ILK_LS_FEED, ILK_FINISH_ITER, ILK_MARK_RUNNING, ILK_SET_PENALTY,
                       ILK_PENALTY_UPDATE, ILK_REG_RETRY };
 

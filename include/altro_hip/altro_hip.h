@@ -261,7 +261,12 @@ typedef struct altro_hip_solve_result { /* AltroStats per problem, solver_stats.
   int reg_retries;           /* extension: backward passes repeated with a larger regularisation      */
 } altro_hip_solve_result;
 void altro_hip_default_solve_options(altro_hip_solve_options* opts);
-/* SolverImpl::Solve (solver.cpp:414-511) for the whole batch; results [batch] (may be NULL).         */
+/* SolverImpl::Solve (solver.cpp:414-511) for the whole batch; results [batch] (may be NULL).
+ * While the problems still searching leave part of the GPU idle, line-search steps that are known in advance are
+ * evaluated speculatively -- the first step (alpha = 1) in the launch that evaluates phi(0), the backtracking steps
+ * alpha beta^j several per launch -- and consumed by the search in its own order: every result is bit-identical to
+ * the one-step-per-launch sequence, only altro_hip_last_solve_counts' merit_launches drops.  Setting the environment
+ * variable ALTRO_HIP_NO_SPECULATION (any value) restores one step per launch. */
 int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts,
                          altro_hip_solve_result* results);
 int altro_hip_last_solve_counts(const altro_hip_batch* h, int* sweeps, int* merit_launches);
