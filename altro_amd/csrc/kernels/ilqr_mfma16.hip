@@ -310,7 +310,18 @@ __global__ __launch_bounds__(64) void wave_expand_kernel(IlqrWaveArgs<S> a) {
         const int p = kn.p[cidx];
         const S* G = a.al.G + kn.G_off[cidx];
         const double* Jc = Jm + cidx * 64;
-        if (kn.cone[cidx] != CONE_SOC) {   // diagonal projection Jacobian: (J G)_{i r} = J_ii G_ir -- the terms left out
+        if (kn.cone[cidx] != CONE_SOC && kn.sel[cidx]) {
+          // bound-type block (rows +-e_idx, al_types.h): G^T J^T J G is diagonal, entry (r, r) collects the rows that
+          // select variable r.  Everything skipped is an exact zero in the sums below: same bits, O(p) instead of
+          // O(p^2) per entry and no loads from G.
+          if (r == cc)
+            for (int i = 0; i < p; ++i) {
+              const int code = kn.sidx[cidx][i];
+              if ((code < 0 ? -code : code) - 1 != r) continue;
+              const double jg = Jc[i * 8 + i] * (code < 0 ? -1.0 : 1.0);
+              s += jg * jg;
+            }
+        } else if (kn.cone[cidx] != CONE_SOC) {   // diagonal projection Jacobian: (J G)_{i r} = J_ii G_ir -- the terms left out
           for (int i = 0; i < p; ++i) {    // of the full sums below are exact zeros, so the bits are the same
             const double jii = Jc[i * 8 + i];
             double jr = 0.0, jc = 0.0;
