@@ -87,6 +87,7 @@ struct altro_hip_batch {
   int *i_spec_sel = nullptr, *i_spec_refresh = nullptr;
   int spec_trials = 1;            // trials per merit launch of the CURRENT launch (1 = no speculation)
   int spec_pre = 0;               // the current launch is phi(0) fused with the first trial step
+  bool spec_no_memory = false;    // the spare trajectories could not be allocated: no speculation on this handle
   ModelParams model{MODEL_LINEAR, 0.0f, 0, 2.7, 1.5};
   bool model_set = false, lqr_cost_set = false, guess_set = false;
   // augmented-Lagrangian constraint blocks (plan LANE): host mirrors + device tables, uploaded lazily
@@ -1649,6 +1650,7 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
   };
   const int64_t spec_capacity = lane_plan ? 512 : 4096;    // two waves per CU (LANE: latency-bound; more slow each other down) / four per SIMD (MFMA16)
   const int64_t cand_elems = (int64_t)h->batch * (h->N + 1) * (lane_plan ? lane_sizes(h->n, h->m).e_xuy : 28);
+  const size_t spare_bytes = (size_t)(ILQR_SPEC_TRIALS - 1) * cand_elems * h->esz;   // spare candidate trajectories
   h->spec_trials = 1;
   struct MaskGuard {   // the backward sweep skips problems that have stopped, only inside this loop
     altro_hip_batch* h;
@@ -1681,10 +1683,11 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
     // chip idle, the first step the search will ask for (alpha0 = 1, known in advance) rides in the same launch as
     // phi(0) -- phi, phi' and the trajectory go to spare row / buffer 0 -- and ILK_LS_BEGIN consumes it at once.
     bool refreshed = false;
-    const bool pre = spec_all_on && (int64_t)spec_units(running) * 2 <= spec_capacity;
-    if (pre && !h->i_cand_spec) {
-      const size_t bytes = (size_t)(ILQR_SPEC_TRIALS - 1) * cand_elems * h->esz;
-      if ((rc = dmalloc(h, &h->i_cand_spec, bytes))) return rc;
+    bool pre = spec_all_on && !h->spec_no_memory && (int64_t)spec_units(running) * 2 <= spec_capacity;
+    if (pre && !h->i_cand_spec && dmalloc(h, &h->i_cand_spec, spare_bytes)) {
+      (void)hipGetLastError();    // an optimisation only: carry on one step per launch
+      h->spec_no_memory = true;
+      pre = false;
     }
     h->spec_trials = pre ? 2 : 1; h->spec_pre = pre ? 1 : 0;
     rc = ilqr_run(h, IK_MERIT, true, true, 1, 0.0);
@@ -1715,13 +1718,14 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
       // evaluates the next 2, 4 or 8 steps of the (known) sequence alpha beta^j for each of them; the feed
       // kernel consumes them in order, so every decision is the sequential one (kernels/ilqr_types.h).
       int trials = 1;
-      if (spec_on)
+      if (spec_on && !h->spec_no_memory)
         while (trials < ILQR_SPEC_TRIALS && (int64_t)spec_units(counters[0]) * trials * 2 <= spec_capacity) trials *= 2;
-      const bool spec = trials > 1;
-      if (spec && !h->i_cand_spec) {
-        const size_t bytes = (size_t)(ILQR_SPEC_TRIALS - 1) * cand_elems * h->esz;
-        if ((rc = dmalloc(h, &h->i_cand_spec, bytes))) return rc;
+      if (trials > 1 && !h->i_cand_spec && dmalloc(h, &h->i_cand_spec, spare_bytes)) {
+        (void)hipGetLastError();
+        h->spec_no_memory = true;
+        trials = 1;
       }
+      const bool spec = trials > 1;
       h->spec_trials = trials;
       la.spec_trials = h->spec_trials;
       rc = ilqr_run(h, IK_MERIT, true, true, 1, 0.0);
