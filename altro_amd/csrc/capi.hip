@@ -650,7 +650,7 @@ Mfma16Args<S> mfma16_args(altro_hip_batch* h, double reg) {
 template <typename S>
 void mfma16_launch_backward(altro_hip_batch* h, double reg, bool sq) {
   auto a = mfma16_args<S>(h, reg);
-  const dim3 grid(h->batch), block(64);
+  const dim3 grid(mf_grid(h->batch)), block(64);
   if (sq && a.has_f) hipLaunchKernelGGL((mfma16_backward_kernel<true, true, S>), grid, block, 0, h->stream, a);
   else if (sq) hipLaunchKernelGGL((mfma16_backward_kernel<true, false, S>), grid, block, 0, h->stream, a);
   else if (a.has_f) hipLaunchKernelGGL((mfma16_backward_kernel<false, true, S>), grid, block, 0, h->stream, a);
@@ -660,7 +660,7 @@ void mfma16_launch_backward(altro_hip_batch* h, double reg, bool sq) {
 template <typename S>
 void mfma16_launch_forward(altro_hip_batch* h, const Mfma16Args<S>& a) {
   // register-ring depth 3: depths 1..4 were measured, 3 is the knee
-  hipLaunchKernelGGL((mfma16_forward_kernel<S, 3>), dim3(h->batch), dim3(64), 0, h->stream, a);
+  hipLaunchKernelGGL((mfma16_forward_kernel<S, 3>), dim3(mf_grid(h->batch)), dim3(64), 0, h->stream, a);
 }
 
 int launch_backward(altro_hip_batch* h, double reg) {
@@ -671,8 +671,8 @@ int launch_backward(altro_hip_batch* h, double reg) {
     else if (sq || !(h->flags & ALTRO_HIP_F32_PURE)) mfma16_launch_backward<float>(h, reg, sq);   // fp32 storage, fp64 tiles
     else {   // opt-in: pure fp32 on v_mfma_f32_16x16x4_f32
       auto a = mfma16_args<float>(h, reg);
-      if (a.has_f) hipLaunchKernelGGL((mfma16_backward_f32_kernel<true, 3>), dim3(h->batch), dim3(64), 0, h->stream, a);
-      else hipLaunchKernelGGL((mfma16_backward_f32_kernel<false, 3>), dim3(h->batch), dim3(64), 0, h->stream, a);
+      if (a.has_f) hipLaunchKernelGGL((mfma16_backward_f32_kernel<true, 3>), dim3(mf_grid(h->batch)), dim3(64), 0, h->stream, a);
+      else hipLaunchKernelGGL((mfma16_backward_f32_kernel<false, 3>), dim3(mf_grid(h->batch)), dim3(64), 0, h->stream, a);
     }
   } else if (h->plan == ALTRO_HIP_PLAN_LANE) {
     return h->dtype == ALTRO_HIP_F64 ? lane_launch<double>(h, true, reg) : lane_launch<float>(h, true, reg);

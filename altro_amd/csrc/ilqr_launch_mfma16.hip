@@ -9,7 +9,7 @@ namespace altro_hip {
 
 template <typename S>
 static int wave_launch(hipStream_t stream, int which, const IlqrWaveArgs<S>& a) {
-  const dim3 waves(a.batch), b64(64), b256(256);
+  const dim3 waves(mf_grid(a.batch)), b64(64), b256(256);   // XCD-aware problem mapping: kernels/mfma16_layout.h
   const int64_t flat_n = (int64_t)a.batch * (a.N + 1) * 16;
   const dim3 flat((unsigned)std::min<int64_t>((flat_n + 255) / 256, 1 << 20));
   switch (which) {

@@ -163,7 +163,7 @@ template <typename S>
 __global__ __launch_bounds__(64) void wave_rollout_kernel(IlqrWaveArgs<S> a) {
   constexpr int ZLD = 17;
   __shared__ double zimg[12 * ZLD + 12], xs[12], us[4];
-  const int b = blockIdx.x, lane = threadIdx.x;
+  const int b = mf_problem(blockIdx.x, a.batch), lane = threadIdx.x;
   if (b >= a.batch) return;
   if (a.active && !a.active[b]) return;
   const int N = a.N;
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(64) void wave_merit_kernel(IlqrWaveArgs<S> a) {
   double* const xs = vec;
   double* const dxs = vec + 12;
   __shared__ double crec[28], qrec[16];     // candidate record x | y | u and [lx lu], gathered for one coalesced store
-  const int b = blockIdx.x, lane = threadIdx.x;
+  const int b = mf_problem(blockIdx.x, a.batch), lane = threadIdx.x;
   if (b >= a.batch) return;
   if (a.active && !a.active[b]) return;
   const int N = a.N;
@@ -591,7 +591,7 @@ __global__ __launch_bounds__(64) void wave_merit_kernel(IlqrWaveArgs<S> a) {
 // Stationarity (solver.cpp:207-222): max_k |lx + A^T y+ - y|, max_k |lu + B^T y+|
 template <typename S>
 __global__ __launch_bounds__(64) void wave_stationarity_kernel(IlqrWaveArgs<S> a) {
-  const int b = blockIdx.x, lane = threadIdx.x;
+  const int b = mf_problem(blockIdx.x, a.batch), lane = threadIdx.x;
   if (b >= a.batch) return;
   if (a.active && !a.active[b]) return;
   const int N = a.N;

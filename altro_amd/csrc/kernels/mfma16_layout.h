@@ -29,4 +29,15 @@ __host__ __device__ constexpr int mf_sym(int i, int j) {
 static_assert(mf_sym(11, 11) == MF_TRI - 1, "packed triangle size");
 static_assert(MF_COST % 8 == 0 && MF_OUT % 8 == 0, "records are whole 64-byte lines");
 
+// XCD-aware block -> problem mapping of the wave-per-problem kernels.  Workgroups are dealt round-robin to the eight
+// XCDs, each with its own L2: with problem = blockIdx the records one XCD touches at a time are every eighth record of
+// the [k][b] slab.  Here XCD x takes the contiguous eighth [x * chunk, (x + 1) * chunk) of the batch instead, so each
+// L2 streams one contiguous run per slab (measured on C1: backward 0.83-0.85 -> 0.80 ms, forward 0.63-0.65 -> 0.61 ms).
+// Launch mf_grid(batch) blocks; blocks past the end of a ragged eighth return at once.
+constexpr int MF_XCDS = 8;
+__host__ __device__ constexpr int mf_grid(int batch) { return MF_XCDS * ((batch + MF_XCDS - 1) / MF_XCDS); }
+__host__ __device__ constexpr int mf_problem(int block, int batch) {
+  return (block % MF_XCDS) * ((batch + MF_XCDS - 1) / MF_XCDS) + block / MF_XCDS;
+}
+
 }  // namespace altro_hip

@@ -174,7 +174,7 @@ __global__ __launch_bounds__(64, 4) void mfma16_backward_kernel(Mfma16Args<S> a)
   __shared__ __attribute__((aligned(16))) double lds[64 + 16 + 2];
   const int lane = threadIdx.x;
   const int j = lane & 15, g = lane >> 4;
-  const int b = blockIdx.x;
+  const int b = mf_problem(blockIdx.x, a.batch);
   if (b >= a.batch) return;
   const int N = a.N;
   if (lane < 2) lds[80 + lane] = 0.0;
@@ -411,7 +411,7 @@ template <typename S, int DEPTH>
 __global__ __launch_bounds__(64) void mfma16_forward_kernel(Mfma16Args<S> a) {
   __shared__ __attribute__((aligned(16))) double lds[MF_FWD_LDS + 4];
   const int lane = threadIdx.x;
-  const int b = blockIdx.x;
+  const int b = mf_problem(blockIdx.x, a.batch);
   if (b >= a.batch) return;
   const int N = a.N;
   const S* __restrict__ in = a.in + (size_t)b * a.in_bs;

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(64, 4) void mfma16_backward_f32_kernel(Mfma16Args<f
   __shared__ __attribute__((aligned(16))) float lds[64 + 16 + 2 + 5 * 64];
   const int lane = threadIdx.x;
   const int j = lane & 15, g = lane >> 4;
-  const int b = blockIdx.x;
+  const int b = mf_problem(blockIdx.x, a.batch);
   if (b >= a.batch) return;
   const int N = a.N;
   const bool g3 = (g == 3);          // lane group 3 holds rows 12..15: no rows of Z / Q / P
