@@ -361,7 +361,7 @@ int lane_launch(altro_hip_batch* h, bool backward, double reg) {
   LaneArgs<T> a{(const T*)h->l_in, (const T*)h->l_term, (T*)h->l_out, (T*)h->l_outn, (const T*)h->l_x0,
                 (T*)h->l_xuy, (T*)h->delta_V, h->status, h->N, h->batch, (T)reg, backward ? h->bwd_active : nullptr,
                 backward ? h->bwd_reg : nullptr};
-  const dim3 grid((h->batch + 63) / 64), block(64);
+  const dim3 grid(8 * (((h->batch + 63) / 64 + 7) / 8)), block(64);
   const bool fused = (h->flags & ALTRO_HIP_LANE_FUSED) != 0;
 #define X(N_, M_)                                                                                              \
   if (h->n == N_ && h->m == M_) {                                                                              \
