@@ -161,6 +161,36 @@ __global__ __launch_bounds__(64) void stream_generic16(const double* __restrict_
   }
 }
 
+// generic record streaming with (MAP) the XCD-aware block -> problem mapping and WPB waves (adjacent problems) per block
+template <int RIN, int ROUT, int MAP, int WPB>
+__global__ __launch_bounds__(64 * WPB) void stream_mapped(const double* __restrict__ in, double* __restrict__ out, int N, int batch) {
+  constexpr int LI = (RIN + 63) / 64, LO = (ROUT + 63) / 64;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int nblk = batch / WPB, chunk = nblk / 8;
+  const int blk = MAP ? (int)((blockIdx.x & 7) * chunk + (blockIdx.x >> 3)) : (int)blockIdx.x;
+  const int b = blk * WPB + wv;
+  double cur[LI], nxt[LI];
+  auto load = [&](double* r, int k) {
+    const double* rec = in + ((size_t)k * batch + b) * RIN;
+#pragma unroll
+    for (int c = 0; c < LI; ++c) { int e = c * 64 + lane; r[c] = rec[e < RIN ? e : RIN - 1]; }
+  };
+  load(cur, N - 1);
+  double acc = 0.0;
+  for (int k = N - 1; k >= 0; --k) {
+    load(nxt, k > 0 ? k - 1 : 0);
+    double s = 0;
+#pragma unroll
+    for (int c = 0; c < LI; ++c) s += cur[c];
+    acc += s;
+    double* o = out + ((size_t)k * batch + b) * ROUT;
+#pragma unroll
+    for (int c = 0; c < LO; ++c) { int e = c * 64 + lane; o[e < ROUT ? e : ROUT - 1] = acc + c; }
+#pragma unroll
+    for (int c = 0; c < LI; ++c) cur[c] = nxt[c];
+  }
+}
+
 int main() {
   const int N = 256, batch = 4096;
   const size_t in_n = (size_t)batch * N * 428, out_n = (size_t)batch * N * 208;
@@ -211,6 +241,12 @@ int main() {
     gen("16 B/lane: 348 r + 28 w", 348, 28, [&] { stream_generic16<348, 28><<<batch, 64>>>(in, out, N, batch); });
     gen("8 B/lane again: 364 r + 144 w", 364, 144, [&] { stream_generic<364, 144><<<batch, 64>>>(in, out, N, batch); });
     gen("8 B/lane again: 348 r + 28 w", 348, 28, [&] { stream_generic<348, 28><<<batch, 64>>>(in, out, N, batch); });
+    gen("364 r + 144 w, plain, 1 wave/block", 364, 144, [&] { stream_mapped<364, 144, 0, 1><<<batch, 64>>>(in, out, N, batch); });
+    gen("364 r + 144 w, XCD map, 1 wave/block", 364, 144, [&] { stream_mapped<364, 144, 1, 1><<<batch, 64>>>(in, out, N, batch); });
+    gen("364 r + 144 w, XCD map, 2 waves/block", 364, 144, [&] { stream_mapped<364, 144, 1, 2><<<batch / 2, 128>>>(in, out, N, batch); });
+    gen("364 r + 144 w, XCD map, 4 waves/block", 364, 144, [&] { stream_mapped<364, 144, 1, 4><<<batch / 4, 256>>>(in, out, N, batch); });
+    gen("364 r + 144 w, plain, 4 waves/block", 364, 144, [&] { stream_mapped<364, 144, 0, 4><<<batch / 4, 256>>>(in, out, N, batch); });
+    gen("364 r + 144 w, XCD map, 8 waves/block", 364, 144, [&] { stream_mapped<364, 144, 1, 8><<<batch / 8, 512>>>(in, out, N, batch); });
   }
   return 0;
 }
