@@ -161,30 +161,33 @@ __device__ __forceinline__ T al_eval(const AlTable<T>& t, int k, int64_t b, int6
       // Bound-type block (rows +-e_idx): the same arithmetic as the general branch below with the zero terms of
       // the dot products left out -- adding +-0 never changes a sum, so the results are bit-identical -- and
       // without a single load from G.
-      T jvp[AL_MAXP], msk[AL_MAXP], sg[AL_MAXP];
-      int idx[AL_MAXP];
+      // Per-variable sums of the gradient / Gauss-Newton terms, accumulated row by row in the order the full
+      // products take them (rows past p contribute nothing and are skipped by a wave-uniform branch).
+      T sx[n], su[m], hx[n], hu[m];
+#pragma unroll
+      for (int e = 0; e < n; ++e) { sx[e] = T(0); hx[e] = T(0); }
+#pragma unroll
+      for (int e = 0; e < m; ++e) { su[e] = T(0); hu[e] = T(0); }
       T sq = T(0);
 #pragma unroll
       for (int i = 0; i < AL_MAXP; ++i) {
-        jvp[i] = T(0); msk[i] = T(0); sg[i] = T(0); idx[i] = -1;
         if (i < p) {
           const int code = kn.sidx[j][i];
-          idx[i] = (code < 0 ? -code : code) - 1;
-          sg[i] = code < 0 ? T(-1) : T(1);
+          const int idx = (code < 0 ? -code : code) - 1;
+          const T sgn = code < 0 ? T(-1) : T(1);
           T v = T(0);
 #pragma unroll
-          for (int e = 0; e < n; ++e) v = (idx[i] == e) ? x[e] : v;
+          for (int e = 0; e < n; ++e) v = (idx == e) ? x[e] : v;
           if (!terminal) {
 #pragma unroll
-            for (int e = 0; e < m; ++e) v = (idx[i] == n + e) ? u[e] : v;
+            for (int e = 0; e < m; ++e) v = (idx == n + e) ? u[e] : v;
           }
-          const T val = sg[i] * v - (gpp ? gpb[(int64_t)i * B] : gsh[i]);
+          const T val = sgn * v - (gpp ? gpb[(int64_t)i * B] : gsh[i]);
           const T ze = (zpre ? (j == 0 ? zpre[i] : zpre[AL_MAXP + i]) : z[(int64_t)i * B]) - rho_est * val;
-          T zpi = T(0);
-          if (cone == CONE_EQUALITY) { zpi = ze; msk[i] = T(1); }
-          else if (cone == CONE_INEQUALITY) { zpi = fmin(T(0), ze); msk[i] = (ze <= T(0)) ? T(1) : T(0); }
+          T zpi = T(0), mski = T(0);
+          if (cone == CONE_EQUALITY) { zpi = ze; mski = T(1); }
+          else if (cone == CONE_INEQUALITY) { zpi = fmin(T(0), ze); mski = (ze <= T(0)) ? T(1) : T(0); }
           sq += zpi * zpi;
-          jvp[i] = msk[i] * zpi;
           if (viol) {
             T vv = T(0);
             if (cone == CONE_EQUALITY) vv = fabs(val);
@@ -192,37 +195,41 @@ __device__ __forceinline__ T al_eval(const AlTable<T>& t, int k, int64_t b, int6
             *viol = fmax(*viol, vv);
           }
           if (dual_update) z[(int64_t)i * B] = zpi;
+          if (GRAD) {
+            const T t = sgn * (mski * zpi);
+#pragma unroll
+            for (int e = 0; e < n; ++e) sx[e] += (idx == e) ? t : T(0);
+            if (!terminal) {
+#pragma unroll
+              for (int e = 0; e < m; ++e) su[e] += (idx == n + e) ? t : T(0);
+            }
+          }
+          if (HESS) {
+            const T hh = (mski * sgn) * (mski * sgn);
+#pragma unroll
+            for (int e = 0; e < n; ++e) hx[e] += (idx == e) ? hh : T(0);
+            if (!terminal) {
+#pragma unroll
+              for (int e = 0; e < m; ++e) hu[e] += (idx == n + e) ? hh : T(0);
+            }
+          }
         }
       }
       cost += sq / (T(2) * rho_est);
       if (GRAD) {
 #pragma unroll
-        for (int e = 0; e < n; ++e) {
-          T s = T(0);
-#pragma unroll
-          for (int i = 0; i < AL_MAXP; ++i) s += (idx[i] == e) ? sg[i] * jvp[i] : T(0);
-          lx[e] -= s;
-        }
+        for (int e = 0; e < n; ++e) lx[e] -= sx[e];
         if (!terminal) {
 #pragma unroll
-          for (int e = 0; e < m; ++e) {
-            T s = T(0);
-#pragma unroll
-            for (int i = 0; i < AL_MAXP; ++i) s += (idx[i] == n + e) ? sg[i] * jvp[i] : T(0);
-            lu[e] -= s;
-          }
+          for (int e = 0; e < m; ++e) lu[e] -= su[e];
         }
       }
       if (HESS) {
 #pragma unroll
-        for (int e = 0; e < w; ++e) {
-          if (terminal && e >= n) continue;
-          T s = T(0);
+        for (int e = 0; e < n; ++e) lxx[e + e * n] += rho * hx[e];
+        if (!terminal) {
 #pragma unroll
-          for (int i = 0; i < AL_MAXP; ++i) s += (idx[i] == e) ? (msk[i] * sg[i]) * (msk[i] * sg[i]) : T(0);
-          s = rho * s;
-          if (e < n) lxx[e + e * n] += s;
-          else luu[(e - n) + (e - n) * m] += s;
+          for (int e = 0; e < m; ++e) luu[e + e * m] += rho * hu[e];
         }
       }
     } else if (cone != CONE_SOC) {
