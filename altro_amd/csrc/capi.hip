@@ -88,6 +88,8 @@ struct altro_hip_batch {
   int spec_trials = 1;            // trials per merit launch of the CURRENT launch (1 = no speculation)
   int spec_pre = 0;               // the current launch is phi(0) fused with the first trial step
   bool spec_no_memory = false;    // the spare trajectories could not be allocated: no speculation on this handle
+  double spec_beta = 0.5;         // the running solve's LsOptions::beta_decrease / max_iters (what the merit kernels
+  int spec_max_iters = 25;        // need to reproduce the state machine's step sequence)
   ModelParams model{MODEL_LINEAR, 0.0f, 0, 2.7, 1.5};
   bool model_set = false, lqr_cost_set = false, guess_set = false;
   // augmented-Lagrangian constraint blocks (plan LANE): host mirrors + device tables, uploaded lazily
@@ -565,8 +567,7 @@ IlqrArgs<T> ilqr_args(altro_hip_batch* h, bool use_alpha, bool use_active, int w
   a.cand_spec = (T*)h->i_cand_spec; a.spec_trials = h->i_cand_spec ? h->spec_trials : 1; a.spec_sel = h->i_spec_sel;
   a.spec_pre = h->i_cand_spec ? h->spec_pre : 0;
   a.spec_stride = (int64_t)h->batch * (h->N + 1) * lane_sizes(h->n, h->m).e_xuy;
-  const LsOptions lo = ls_default_options();
-  a.ls_beta = lo.beta_decrease; a.ls_max_iters = lo.max_iters;
+  a.ls_beta = h->spec_beta; a.ls_max_iters = h->spec_max_iters;
   return a;
 }
 
@@ -595,8 +596,7 @@ int wave_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int
   a.cand_spec = (S*)h->i_cand_spec; a.spec_trials = h->i_cand_spec ? h->spec_trials : 1; a.spec_sel = h->i_spec_sel;
   a.spec_pre = h->i_cand_spec ? h->spec_pre : 0;
   a.spec_stride = (int64_t)h->batch * (h->N + 1) * 28;
-  const LsOptions lo = ls_default_options();
-  a.ls_beta = lo.beta_decrease; a.ls_max_iters = lo.max_iters;
+  a.ls_beta = h->spec_beta; a.ls_max_iters = h->spec_max_iters;
   const int rc = ilqr_wave_launch_kernel<S>(h->stream, which, a);
   if (rc == 1) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "operation %d is not available on plan MFMA16", which);
   if (rc) return fail(ALTRO_HIP_ERR_HIP, "iLQR kernel launch failed");
@@ -1620,6 +1620,7 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
   la.ls = ls_default_options();
   la.ls.try_cubic_first = 1;                                   // solver.cpp:248
   la.ls.use_backtracking = o.use_backtracking_linesearch;      // solver.cpp:417
+  h->spec_beta = la.ls.beta_decrease; h->spec_max_iters = la.ls.max_iters;
   int counters[3];
   auto read_counters = [&]() -> int {
     HIP_TRY(hipMemcpyAsync(counters, h->i_counters, sizeof(counters), hipMemcpyDeviceToHost, h->stream));
