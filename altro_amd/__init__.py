@@ -28,7 +28,9 @@ C_ABI_SYMBOLS = [
     "altro_hip_synchronize", "altro_hip_get_K", "altro_hip_get_d", "altro_hip_get_P",
     "altro_hip_get_p", "altro_hip_get_x", "altro_hip_get_u", "altro_hip_get_y",
     "altro_hip_get_delta_V", "altro_hip_get_status", "altro_hip_get_qblocks",
-    "altro_hip_stats_reduce", "altro_hip_profile_enable", "altro_hip_profile_reset",
+    "altro_hip_stats_reduce", "altro_hip_comm_unique_id", "altro_hip_comm_create", "altro_hip_comm_create_all",
+    "altro_hip_comm_destroy", "altro_hip_stats_allreduce", "altro_hip_stats_allreduce_multi",
+    "altro_hip_profile_enable", "altro_hip_profile_reset",
     "altro_hip_profile_get", "altro_hip_algorithmic_bytes",
     "altro_hip_set_model", "altro_hip_set_tracking_cost", "altro_hip_set_input_guess",
     "altro_hip_open_loop_rollout", "altro_hip_accept", "altro_hip_expand", "altro_hip_merit",
@@ -66,9 +68,19 @@ class AltroHipError(RuntimeError):
 
 
 class Stats(C.Structure):
-    _fields_ = [("problems", C.c_int64), ("cholesky_failures", C.c_int64),
+    """altro_hip_stats: what SolverImpl::Solve reports, reduced over a batch (and over GPUs)."""
+    _fields_ = [("problems", C.c_int64), ("cholesky_failures", C.c_int64), ("converged", C.c_int64),
+                ("iterations", C.c_int64), ("sum_cost", C.c_double),
                 ("sum_delta_V0", C.c_double), ("sum_delta_V1", C.c_double),
-                ("max_abs_xN", C.c_double)]
+                ("max_stationarity", C.c_double), ("max_feasibility", C.c_double), ("max_abs_xN", C.c_double)]
+    SUM_FIELDS = ("problems", "cholesky_failures", "converged", "iterations", "sum_cost", "sum_delta_V0", "sum_delta_V1")
+    MAX_FIELDS = ("max_stationarity", "max_feasibility", "max_abs_xN")
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+COMM_ID_BYTES = 128
 
 
 def _share_hip_runtime_with_torch():
@@ -124,6 +136,13 @@ def lib():
         for g in ("K", "d", "P", "p", "x", "u", "y", "delta_V", "status", "qblocks"):
             getattr(L, "altro_hip_get_" + g).argtypes = [vp, vp]
         L.altro_hip_stats_reduce.argtypes = [vp, C.POINTER(Stats)]
+        L.altro_hip_comm_unique_id.argtypes = [vp]
+        L.altro_hip_comm_create.argtypes = [C.POINTER(vp), i, i, i, vp]
+        L.altro_hip_comm_create_all.argtypes = [C.POINTER(vp), i, C.POINTER(i)]
+        L.altro_hip_comm_destroy.argtypes = [vp]
+        L.altro_hip_comm_destroy.restype = None
+        L.altro_hip_stats_allreduce.argtypes = [vp, vp, C.POINTER(Stats)]
+        L.altro_hip_stats_allreduce_multi.argtypes = [C.POINTER(vp), C.POINTER(vp), i, C.POINTER(Stats)]
         L.altro_hip_profile_enable.argtypes = [vp, i]
         L.altro_hip_profile_reset.argtypes = [vp]
         L.altro_hip_profile_get.argtypes = [vp, i, C.POINTER(i), C.POINTER(d), C.POINTER(C.c_char_p)]
@@ -239,9 +258,13 @@ class Batch:
         _check(getattr(self.L, "altro_hip_get_" + name)(self.h, out.ctypes.data_as(C.c_void_p)))
         return out
 
-    def stats(self):
+    def stats(self, comm=None):
+        """This handle's statistics (device-side reduction); with a Comm, the global ones (two RCCL all-reduces)."""
         s = Stats()
-        _check(self.L.altro_hip_stats_reduce(self.h, C.byref(s)))
+        if comm is None:
+            _check(self.L.altro_hip_stats_reduce(self.h, C.byref(s)))
+        else:
+            _check(self.L.altro_hip_stats_allreduce(self.h, comm.c, C.byref(s)))
         return s
 
     def profile(self, enable=True):
@@ -374,6 +397,31 @@ class Batch:
                     feasibility=rec["primal_feasibility"].copy(), penalty=rec["penalty"].copy(),
                     dual_updates=rec["dual_updates"].copy(), reg_retries=rec["reg_retries"].copy(),
                     sweeps=sw.value, merit_launches=ml.value)
+
+
+class Comm:
+    """One RCCL communicator rank (altro_hip_comm).  `unique_id()` on rank 0, hand the 128 bytes to every rank by any
+    channel (bench.py: a torch.distributed broadcast), then Comm(device, rank, world, id) on every rank."""
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_char * COMM_ID_BYTES)()
+        _check(lib().altro_hip_comm_unique_id(C.cast(buf, C.c_void_p)))
+        return bytes(buf)
+
+    def __init__(self, device, rank, world, uid):
+        self.L = lib()
+        self.c = C.c_void_p()
+        assert len(uid) == COMM_ID_BYTES
+        buf = (C.c_char * COMM_ID_BYTES).from_buffer_copy(uid)
+        _check(self.L.altro_hip_comm_create(C.byref(self.c), int(device), int(rank), int(world), C.cast(buf, C.c_void_p)))
+
+    def close(self):
+        if getattr(self, "c", None) is not None and self.c:
+            self.L.altro_hip_comm_destroy(self.c)
+            self.c = None
+
+    __del__ = close
 
 
 def linesearch_host(fn, alpha0, phi0, dphi0, try_cubic_first=False, use_backtracking=False, c1=1e-4, c2=0.9):

@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 def sources():
     out = []
     for d, _, files in os.walk(CSRC):
-        out += [os.path.join(d, f) for f in files if f.endswith((".hip", ".h", ".hpp", ".cpp"))]
+        out += [os.path.join(d, f) for f in files if f.endswith((".hip", ".h", ".hpp", ".cpp", ".inc"))]
     for d, _, files in os.walk(os.path.join(ROOT, "include")):
         out += [os.path.join(d, f) for f in files if f.endswith((".h", ".hpp"))]
     return out
@@ -45,7 +45,8 @@ def build(force=False, verbose=False):
              "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
     def compile_one(src):
-        obj = os.path.join(objdir, os.path.splitext(os.path.basename(src))[0] + ".o")
+        # object names follow the path below csrc/ (host/x.cpp and x.hip must not collide)
+        obj = os.path.join(objdir, os.path.splitext(os.path.relpath(src, CSRC))[0].replace(os.sep, "__") + ".o")
         cmd = [hipcc] + flags + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)

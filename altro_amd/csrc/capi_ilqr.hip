@@ -1,0 +1,836 @@
+// capi_ilqr.hip -- C ABI: the batched AL-iLQR loop around the sweep (SolverImpl::Solve per problem), the device models' entry
+// points, augmented-Lagrangian constraint blocks and the MPC receding-horizon operations.  The host sequences launches;
+// every per-problem decision is taken on the device (kernels/ilqr_loop_kernels.hip).
+#include "capi_internal.h"
+
+using namespace altro_hip;
+using namespace altro_hip::capi;
+
+namespace {
+
+// ---- iLQR loop (plan LANE) ---------------------------------------------------------------------------
+// (re)build the device tables of the constraint blocks; duals restart from zero when the structure changes
+template <typename T>
+int al_upload_typed(altro_hip_batch* h) {
+  const int64_t B = h->batch;
+  for (void** p : {(void**)&h->al_d_knots, &h->al_d_G, &h->al_d_g, &h->al_d_z})
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+  if (h->al_defs.empty()) { h->al_rows = 0; return 0; }
+  std::vector<T> G(h->al_G.begin(), h->al_G.end());
+  std::vector<T> g;
+  std::vector<AlDef> defs = h->al_defs;
+  for (size_t i = 0; i < defs.size(); ++i) {
+    defs[i].g_off = (int64_t)g.size();
+    const std::vector<double>& src = h->al_g[i];
+    const int p = defs[i].p;
+    if (defs[i].g_per_problem) {
+      const size_t base = g.size();
+      g.resize(base + (size_t)p * B);
+      for (int64_t b = 0; b < B; ++b)
+        for (int r = 0; r < p; ++r) g[base + (size_t)r * B + b] = (T)src[(size_t)b * p + r];
+    } else {
+      for (int r = 0; r < p; ++r) g.push_back((T)src[r]);
+    }
+  }
+  int rows = 0;
+  std::vector<AlKnot> knots = h->al_knots;
+  for (auto& kn : knots)
+    for (int j = 0; j < kn.ncon; ++j) {
+      const AlDef& d = defs[kn.def[j]];
+      kn.z_off[j] = rows; rows += d.p;
+      kn.cone[j] = d.cone; kn.p[j] = d.p; kn.g_per_problem[j] = d.g_per_problem; kn.G_off[j] = d.G_off; kn.g_off[j] = d.g_off;
+      // bound-type block: every row of G is +-e_idx
+      const int w = h->n + h->m;
+      bool sel = d.cone != CONE_SOC;
+      for (int r = 0; r < d.p && sel; ++r) {
+        int nz = 0, at = -1;
+        for (int e = 0; e < w; ++e) {
+          const double v = h->al_G[(size_t)d.G_off + r + (size_t)e * d.p];
+          if (v != 0.0) { ++nz; at = e; if (v != 1.0 && v != -1.0) sel = false; }
+        }
+        if (nz != 1) sel = false;
+        else kn.sidx[j][r] = h->al_G[(size_t)d.G_off + r + (size_t)at * d.p] > 0 ? at + 1 : -(at + 1);
+      }
+      kn.sel[j] = sel ? 1 : 0;
+    }
+  h->al_rows = rows;
+  if (h->plan == ALTRO_HIP_PLAN_LANE && (uint64_t)rows * (uint64_t)B * sizeof(T) >= (1ull << 31))
+    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "plan LANE: %d dual rows x batch %d exceed the 2 GiB buffer window; split the batch", rows, h->batch);
+  {   // uniform running knot points?  (then the dual rows of knot point k start k * rows_per_knot after those of 0)
+    const AlKnot& k0 = knots[0];
+    int r0 = 0;
+    for (int j = 0; j < k0.ncon; ++j) r0 += defs[k0.def[j]].p;
+    bool uni = h->N >= 1 && k0.ncon > 0;
+    for (int k = 1; k < h->N && uni; ++k) {
+      uni = knots[k].ncon == k0.ncon;
+      for (int j = 0; j < k0.ncon && uni; ++j) uni = knots[k].def[j] == k0.def[j] && knots[k].z_off[j] == k0.z_off[j] + k * r0;
+    }
+    h->al_uniform = uni ? 1 : 0;
+    h->al_rows_per_knot = r0;
+  }
+  int rc = 0;
+  if ((rc = dmalloc(h, (void**)&h->al_d_knots, knots.size() * sizeof(AlKnot)))) return rc;
+  if ((rc = dmalloc(h, &h->al_d_G, G.size() * sizeof(T)))) return rc;
+  if ((rc = dmalloc(h, &h->al_d_g, g.size() * sizeof(T)))) return rc;
+  if ((rc = dmalloc(h, &h->al_d_z, (size_t)rows * B * sizeof(T)))) return rc;
+  HIP_TRY(hipMemcpy(h->al_d_knots, knots.data(), knots.size() * sizeof(AlKnot), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->al_d_G, G.data(), G.size() * sizeof(T), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->al_d_g, g.data(), g.size() * sizeof(T), hipMemcpyHostToDevice));
+  // (memsets go on the handle's own stream: it is non-blocking, so a null-stream memset would race the kernels)
+  HIP_TRY(hipMemsetAsync(h->al_d_z, 0, (size_t)rows * B * sizeof(T), h->stream));
+  h->al_knots = knots;
+  return 0;
+}
+int al_upload(altro_hip_batch* h) {
+  if (!h->al_dirty) return 0;
+  int rc = h->dtype == ALTRO_HIP_F64 ? al_upload_typed<double>(h) : al_upload_typed<float>(h);
+  if (!rc) h->al_dirty = false;
+  return rc;
+}
+
+template <typename T>
+IlqrArgs<T> ilqr_args(altro_hip_batch* h, bool use_alpha, bool use_active, int want_deriv, double alpha_const) {
+  IlqrArgs<T> a;
+  a.al.knots = h->al_d_knots; a.al.G = (const T*)h->al_d_G; a.al.g = (const T*)h->al_d_g;
+  a.al.z = (T*)h->al_d_z; a.al.enabled = h->al_defs.empty() ? 0 : 1;
+  a.al.uniform = h->al_uniform; a.al.rows_per_knot = h->al_rows_per_knot; a.al.N = h->N;
+  a.mode = EXPAND_GRADIENT | EXPAND_HESSIAN;
+  a.in = (T*)h->l_in; a.term = (T*)h->l_term; a.out = (const T*)h->l_out; a.outn = (const T*)h->l_outn;
+  a.nom = (T*)h->l_nom; a.cand = (T*)h->l_xuy; a.cost = (const T*)h->l_cost; a.x0 = (const T*)h->l_x0;
+  a.alpha = use_alpha ? h->i_alpha : nullptr;
+  a.active = use_active ? h->i_active : nullptr;
+  a.phi = h->i_phi; a.dphi = h->i_dphi; a.prob = h->i_prob;
+  a.mp = h->model; a.N = h->N; a.batch = h->batch; a.want_derivative = want_deriv; a.alpha_const = alpha_const;
+  a.cand_spec = (T*)h->i_cand_spec; a.spec_trials = h->i_cand_spec ? h->spec_trials : 1; a.spec_sel = h->i_spec_sel;
+  a.spec_pre = h->i_cand_spec ? h->spec_pre : 0;
+  a.spec_stride = (int64_t)h->batch * (h->N + 1) * lane_sizes(h->n, h->m).e_xuy;
+  a.ls_beta = h->spec_beta; a.ls_max_iters = h->spec_max_iters;
+  return a;
+}
+
+template <typename T>
+int ilqr_launch(altro_hip_batch* h, int which, IlqrArgs<T> a) {
+  const int rc = ilqr_launch_kernel<T>(h->stream, which, h->model.kind, h->n, h->m, a);
+  if (rc == 1) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "no device model for (kind, n, m) = (%d, %d, %d)", h->model.kind, h->n, h->m);
+  if (rc) return fail(ALTRO_HIP_ERR_HIP, "iLQR kernel launch failed");
+  return 0;
+}
+template <typename S>
+int wave_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int want_deriv, double alpha_const, int mode) {
+  IlqrWaveArgs<S> a;
+  a.al.knots = h->al_d_knots; a.al.G = (const S*)h->al_d_G; a.al.g = (const S*)h->al_d_g; a.al.z = (S*)h->al_d_z;
+  a.al.enabled = h->al_defs.empty() ? 0 : 1;
+  a.al.uniform = h->al_uniform; a.al.rows_per_knot = h->al_rows_per_knot; a.al.N = h->N;
+  a.mode = mode;
+  a.dyn = (const S*)h->m_in; a.dyn_bs = h->m_st.in_bs; a.dyn_ks = h->m_st.in_ks;
+  a.cin = (S*)h->m_cin; a.cin_bs = h->m_st.cin_bs; a.cin_ks = h->m_st.cin_ks;
+  a.term = (S*)h->m_term; a.out = (const S*)h->m_out; a.out_bs = h->m_st.out_bs; a.out_ks = h->m_st.out_ks;
+  a.outn = (const S*)h->m_outn; a.nom = (S*)h->m_nom; a.cand = (S*)h->m_xuy; a.xuy_bs = h->m_st.xuy_bs;
+  a.xuy_ks = h->m_st.xuy_ks; a.costp = (const S*)h->m_costp; a.x0 = (const S*)h->x0;
+  a.alpha = use_alpha ? h->i_alpha : nullptr; a.active = use_active ? h->i_active : nullptr;
+  a.phi = h->i_phi; a.dphi = h->i_dphi; a.prob = h->i_prob; a.N = h->N; a.batch = h->batch;
+  a.want_derivative = want_deriv; a.alpha_const = alpha_const;
+  a.cand_spec = (S*)h->i_cand_spec; a.spec_trials = h->i_cand_spec ? h->spec_trials : 1; a.spec_sel = h->i_spec_sel;
+  a.spec_pre = h->i_cand_spec ? h->spec_pre : 0;
+  a.spec_stride = (int64_t)h->batch * (h->N + 1) * 28;
+  a.ls_beta = h->spec_beta; a.ls_max_iters = h->spec_max_iters;
+  const int rc = ilqr_wave_launch_kernel<S>(h->stream, which, a);
+  if (rc == 1) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "operation %d is not available on plan MFMA16", which);
+  if (rc) return fail(ALTRO_HIP_ERR_HIP, "iLQR kernel launch failed");
+  return 0;
+}
+int ilqr_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int want_deriv, double alpha_const,
+             int mode = EXPAND_GRADIENT | EXPAND_HESSIAN) {
+  int rc = al_upload(h);
+  if (rc) return rc;
+  if (h->plan == ALTRO_HIP_PLAN_MFMA16)   // linear dynamics: "expand" = cost gradient (+ AL Hessian terms when constrained)
+    return h->dtype == ALTRO_HIP_F64 ? wave_run<double>(h, which, use_alpha, use_active, want_deriv, alpha_const, mode)
+                                     : wave_run<float>(h, which, use_alpha, use_active, want_deriv, alpha_const, mode);
+  if (h->dtype == ALTRO_HIP_F64) {
+    auto a = ilqr_args<double>(h, use_alpha, use_active, want_deriv, alpha_const);
+    a.mode = mode;
+    return ilqr_launch<double>(h, which, a);
+  }
+  auto a = ilqr_args<float>(h, use_alpha, use_active, want_deriv, alpha_const);
+  a.mode = mode;
+  return ilqr_launch<float>(h, which, a);
+}
+int ilqr_check(altro_hip_batch* h, bool need_guess) {
+  int rc = check(h);
+  if (rc) return rc;
+  if (h->plan == ALTRO_HIP_PLAN_MFMA16) {   // dynamics are data (altro_hip_set_dynamics), no device model
+    if (!h->dyn_set) return fail(ALTRO_HIP_ERR_NOT_SET, "altro_hip_set_dynamics has not been called");
+  } else if (h->plan != ALTRO_HIP_PLAN_LANE) {
+    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "the device iLQR loop is implemented for plans LANE and MFMA16");
+  } else if (!h->model_set) {
+    return fail(ALTRO_HIP_ERR_NOT_SET, "altro_hip_set_model has not been called");
+  }
+  if (!h->lqr_cost_set) return fail(ALTRO_HIP_ERR_NOT_SET, "altro_hip_set_tracking_cost has not been called");
+  if (!h->x0_set) return fail(ALTRO_HIP_ERR_NOT_SET, "altro_hip_set_initial_state has not been called");
+  if (need_guess && !h->guess_set) return fail(ALTRO_HIP_ERR_NOT_SET, "altro_hip_set_input_guess has not been called");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+// ---- iLQR loop entry points -----------------------------------------------------------------------------
+int altro_hip_set_model(altro_hip_batch* h, int model, float timestep, int bicycle_frame,
+                        double bicycle_length, double bicycle_lr) {
+  int rc = check(h);
+  if (rc) return rc;
+  if (!(timestep > 0.0f)) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "time step must be positive (ErrorCodes::TimestepNotPositive)");
+  if (h->plan != ALTRO_HIP_PLAN_LANE || !ilqr_supported(model, h->n, h->m))
+    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "no device model %d for plan %d with (n, m) = (%d, %d)", model, h->plan, h->n, h->m);
+  h->model = ModelParams{model, timestep, bicycle_frame, bicycle_length > 0 ? bicycle_length : 2.7,
+                         bicycle_lr > 0 ? bicycle_lr : 1.5};
+  h->model_set = true;
+  return 0;
+}
+
+int altro_hip_set_tracking_cost(altro_hip_batch* h, const double* Qd, const double* Rd, const double* xref,
+                                const double* uref, int kz, int bz) {
+  // ALTROSolver::SetLQRCost (altro_solver.cpp:138-172): q = -Q xref, r = -R uref,
+  // c = 1/2 xref'Q xref (+ 1/2 uref'R uref for k < N) -> KnotPointData::SetDiagonalCost
+  int rc = check(h);
+  if (rc) return rc;
+  if (h->plan != ALTRO_HIP_PLAN_LANE && h->plan != ALTRO_HIP_PLAN_MFMA16)
+    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "tracking cost needs plan LANE or MFMA16");
+  if (!Qd || !Rd || !xref || !uref) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "Qd, Rd, xref, uref are required");
+  if (h->dev_ptrs)
+    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "altro_hip_set_tracking_cost forms q = -Q xref on the host: pass host arrays "
+                                           "(altro_hip_set_pointer_mode(h, 0))");
+  const int n = h->n, m = h->m, N = h->N;
+  const int nb = bz ? 1 : h->batch, nkx = kz ? 2 : N + 1, nku = kz ? 1 : N;
+  const int E = 2 * n + 2 * m + 1;
+  // host-side arithmetic exactly as the reference's setter does it, then one upload per field
+  std::vector<double> q((size_t)nb * nkx * n), r((size_t)nb * nku * m), c((size_t)nb * nkx);
+  for (int b = 0; b < nb; ++b)
+    for (int k = 0; k < nkx; ++k) {
+      const double* Q_ = Qd + ((size_t)b * nkx + k) * n;
+      const double* x_ = xref + ((size_t)b * nkx + k) * n;
+      double cc = 0.0;
+      for (int i = 0; i < n; ++i) { q[((size_t)b * nkx + k) * n + i] = -(Q_[i] * x_[i]); cc += x_[i] * Q_[i] * x_[i]; }
+      cc *= 0.5;
+      const bool terminal = kz ? (k == 1) : (k == N);
+      if (!terminal) {
+        const int ku = kz ? 0 : k;
+        const double* R_ = Rd + ((size_t)b * nku + ku) * m;
+        const double* u_ = uref + ((size_t)b * nku + ku) * m;
+        double cu = 0.0;
+        for (int i = 0; i < m; ++i) cu += u_[i] * R_[i] * u_[i];
+        cc += 0.5 * cu;
+      }
+      c[(size_t)b * nkx + k] = cc;
+    }
+  for (int b = 0; b < nb; ++b)
+    for (int k = 0; k < nku; ++k)
+      for (int i = 0; i < m; ++i)
+        r[((size_t)b * nku + k) * m + i] = -(Rd[((size_t)b * nku + k) * m + i] * uref[((size_t)b * nku + k) * m + i]);
+  if (h->plan == ALTRO_HIP_PLAN_MFMA16) {
+    // (a) the backward sweep's blocks: lxx = diag(Qd), luu = diag(Rd), lux = 0; lx, lu are refreshed by the loop
+    rc = altro_hip_set_cost(h, Qd, Rd, nullptr, q.data(), r.data(), 1, kz, bz);
+    if (rc) return rc;
+    // (b) the cost parameters the merit function needs: [k][b][36] = Qd | Rd | q | r | c
+    const size_t Ez = h->dtype == ALTRO_HIP_F64 ? 8 : 4;
+    const int64_t B = h->batch;
+    if (!h->m_costp) {
+      if ((rc = dmalloc(h, &h->m_costp, (size_t)B * (N + 1) * MF_COSTP * Ez))) return rc;
+      if ((rc = dmalloc(h, &h->m_nom, (size_t)B * (N + 1) * MF_NOM * Ez))) return rc;
+      HIP_TRY(hipMemsetAsync(h->m_costp, 0, (size_t)B * (N + 1) * MF_COSTP * Ez, h->stream));
+      HIP_TRY(hipMemsetAsync(h->m_nom, 0, (size_t)B * (N + 1) * MF_NOM * Ez, h->stream));
+    }
+    auto put = [&](const double* src, int len, int off, int k0, int nk, int nk_host, int src_off) -> int {
+      // records k0..k0+nk-1; with kz the host holds {running, terminal} and src_off selects which
+      if (h->dtype == ALTRO_HIP_F64)
+        return aos_set<double>(h, (double*)h->m_costp + (size_t)k0 * B * MF_COSTP + off, MF_COSTP, B * MF_COSTP, src, len, nk,
+                               kz, bz, nk_host, src_off);
+      return aos_set<float>(h, (float*)h->m_costp + (size_t)k0 * B * MF_COSTP + off, MF_COSTP, B * MF_COSTP, src, len, nk, kz,
+                            bz, nk_host, src_off);
+    };
+    rc = put(Qd, n, 0, 0, N, nkx, 0);
+    if (!rc) rc = put(Rd, m, 12, 0, N, nku, 0);
+    if (!rc) rc = put(q.data(), n, 16, 0, N, nkx, 0);
+    if (!rc) rc = put(r.data(), m, 28, 0, N, nku, 0);
+    if (!rc) rc = put(c.data(), 1, 32, 0, N, nkx, 0);
+    // terminal record N: element N of a full host array, or the second entry of a {running, terminal} pair
+    auto put_term = [&](const double* src, int len, int off) -> int {
+      const double* base = kz ? src : src;   // per problem the host holds nkx knot points
+      if (h->dtype == ALTRO_HIP_F64)
+        return aos_set<double>(h, (double*)h->m_costp + (size_t)N * B * MF_COSTP + off, MF_COSTP, B * MF_COSTP, base, len, 1, 1,
+                               bz, nkx, (kz ? 1 : N) * len);
+      return aos_set<float>(h, (float*)h->m_costp + (size_t)N * B * MF_COSTP + off, MF_COSTP, B * MF_COSTP, base, len, 1, 1, bz,
+                            nkx, (kz ? 1 : N) * len);
+    };
+    if (!rc) rc = put_term(Qd, n, 0);
+    if (!rc) rc = put_term(q.data(), n, 16);
+    if (!rc) rc = put_term(c.data(), 1, 32);
+    if (!rc) { h->lqr_cost_set = true; h->ilqr_linear = true; }
+    return rc;
+  }
+  auto pk = [&](const double* src, int len, int off, int nk, int k_src0, int nk_host, int src_off) -> int {
+    return h->dtype == ALTRO_HIP_F64
+               ? lane_pack<double>(h, (double*)h->l_cost + (size_t)0, E, src, len, off, 0, nk, k_src0, nk_host, kz, bz, src_off)
+               : lane_pack<float>(h, (float*)h->l_cost + (size_t)0, E, src, len, off, 0, nk, k_src0, nk_host, kz, bz, src_off);
+  };
+  auto pk_term = [&](const double* src, int len, int off, int nk_host) -> int {   // record N of l_cost
+    const size_t base = (size_t)N * E * h->batch;
+    return h->dtype == ALTRO_HIP_F64
+               ? lane_pack<double>(h, (double*)h->l_cost + base, E, src, len, off, 0, 1, kz ? 0 : N, nk_host, kz, bz, kz ? len : 0)
+               : lane_pack<float>(h, (float*)h->l_cost + base, E, src, len, off, 0, 1, kz ? 0 : N, nk_host, kz, bz, kz ? len : 0);
+  };
+  rc = pk(Qd, n, 0, N, 0, nkx, 0);
+  if (!rc) rc = pk(Rd, m, n, N, 0, nku, 0);
+  if (!rc) rc = pk(q.data(), n, n + m, N, 0, nkx, 0);
+  if (!rc) rc = pk(r.data(), m, 2 * n + m, N, 0, nku, 0);
+  if (!rc) rc = pk(c.data(), 1, 2 * n + 2 * m, N, 0, nkx, 0);
+  if (!rc) rc = pk_term(Qd, n, 0, nkx);
+  if (!rc) rc = pk_term(q.data(), n, n + m, nkx);
+  if (!rc) rc = pk_term(c.data(), 1, 2 * n + 2 * m, nkx);
+  if (!rc) { h->lqr_cost_set = true; h->cost_set = true; h->dyn_set = true; h->is_diag = 0; h->has_f = 0; }
+  return rc;
+}
+
+int altro_hip_set_input_guess(altro_hip_batch* h, const double* u, int kz, int bz) {
+  // ALTROSolver::SetInput (altro_solver.cpp:242-251): writes the CANDIDATE inputs u_
+  int rc = check(h);
+  if (rc) return rc;
+  if (h->plan != ALTRO_HIP_PLAN_LANE && h->plan != ALTRO_HIP_PLAN_MFMA16)
+    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "input guess needs plan LANE or MFMA16");
+  if (!u) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "u == NULL");
+  const int n = h->n, m = h->m, N = h->N;
+  if (h->plan == ALTRO_HIP_PLAN_MFMA16) {   // candidate records [k][b][28] = x | y | u
+    rc = h->dtype == ALTRO_HIP_F64
+             ? aos_set<double>(h, (double*)h->m_xuy + 24, h->m_st.xuy_bs, h->m_st.xuy_ks, u, m, N, kz, bz)
+             : aos_set<float>(h, (float*)h->m_xuy + 24, h->m_st.xuy_bs, h->m_st.xuy_ks, u, m, N, kz, bz);
+    if (!rc) h->guess_set = true;
+    return rc;
+  }
+  rc = h->dtype == ALTRO_HIP_F64
+           ? lane_pack<double>(h, (double*)h->l_xuy, 2 * n + m, u, m, 2 * n, 0, N, 0, kz ? 1 : N, kz, bz)
+           : lane_pack<float>(h, (float*)h->l_xuy, 2 * n + m, u, m, 2 * n, 0, N, 0, kz ? 1 : N, kz, bz);
+  if (!rc) h->guess_set = true;
+  return rc;
+}
+
+int altro_hip_open_loop_rollout(altro_hip_batch* h) {
+  int rc = ilqr_check(h, true);
+  if (!rc) rc = ilqr_run(h, IK_ROLLOUT, false, false, 0, 0.0);
+  if (!rc) h->forward_done = true;
+  return rc;
+}
+int altro_hip_accept(altro_hip_batch* h) {
+  int rc = ilqr_check(h, false);
+  if (!rc) rc = ilqr_run(h, IK_ACCEPT, false, false, 0, 0.0);
+  return rc;
+}
+int altro_hip_expand(altro_hip_batch* h) {
+  int rc = ilqr_check(h, false);
+  if (!rc) rc = ilqr_run(h, IK_EXPAND, false, false, 0, 0.0);
+  return rc;
+}
+int altro_hip_merit(altro_hip_batch* h, const double* alpha, int alpha_is_uniform, int want_derivative,
+                    double* phi, double* dphi) {
+  int rc = ilqr_check(h, false);
+  if (rc) return rc;
+  if (!h->backward_done) return fail(ALTRO_HIP_ERR_NOT_SET, "backward must precede merit");
+  if (!alpha || !phi) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "alpha and phi are required");
+  if (!alpha_is_uniform)
+    HIP_TRY(hipMemcpyAsync(h->i_alpha, alpha, (size_t)h->batch * 8, hipMemcpyHostToDevice, h->stream));
+  rc = ilqr_run(h, IK_MERIT, !alpha_is_uniform, false, want_derivative, alpha[0]);
+  if (rc) return rc;
+  h->forward_done = true;
+  HIP_TRY(hipMemcpyAsync(phi, h->i_phi, (size_t)h->batch * 8, hipMemcpyDeviceToHost, h->stream));
+  if (want_derivative && dphi)
+    HIP_TRY(hipMemcpyAsync(dphi, h->i_dphi, (size_t)h->batch * 8, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return 0;
+}
+int altro_hip_stationarity(altro_hip_batch* h, double* out) {
+  int rc = ilqr_check(h, false);
+  if (rc) return rc;
+  rc = ilqr_run(h, IK_STATIONARITY, false, false, 0, 0.0);
+  if (rc) return rc;
+  std::vector<IlqrProb> pr(h->batch);
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(pr.data(), h->i_prob, pr.size() * sizeof(IlqrProb), hipMemcpyDeviceToHost));
+  for (int b = 0; b < h->batch; ++b) out[b] = pr[b].stationarity;
+  return 0;
+}
+int altro_hip_feasibility(altro_hip_batch* h, double* out) {
+  // SolverImpl::Feasibility (solver.cpp:224-231) of the candidate trajectory
+  int rc = ilqr_check(h, false);
+  if (rc) return rc;
+  if (!out) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "out == NULL");
+  rc = ilqr_run(h, IK_STATIONARITY, false, false, 0, 0.0);
+  if (rc) return rc;
+  std::vector<IlqrProb> pr(h->batch);
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(pr.data(), h->i_prob, pr.size() * sizeof(IlqrProb), hipMemcpyDeviceToHost));
+  for (int b = 0; b < h->batch; ++b) out[b] = pr[b].feasibility;
+  return 0;
+}
+
+// ---- MPC receding-horizon operations on the resident batch -----------------
+int altro_hip_shift_trajectory(altro_hip_batch* h) {
+  int rc = ilqr_check(h, true);
+  if (!rc) rc = ilqr_run(h, IK_SHIFT, false, false, 0, 0.0);
+  return rc;
+}
+int altro_hip_update_linear_costs(altro_hip_batch* h, const double* q, const double* r, const double* c,
+                                  int k_first, int k_last, int kz, int bz) {
+  // ALTROSolver::UpdateLinearCosts (altro_solver.cpp:266-281) -> KnotPointData::UpdateLinearCosts
+  // (knotpoint_data.cpp:193-226) for knot points k_first..k_last (inclusive) of every problem
+  int rc = check(h);
+  if (rc) return rc;
+  if (h->plan != ALTRO_HIP_PLAN_LANE && h->plan != ALTRO_HIP_PLAN_MFMA16)
+    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "linear cost update needs plan LANE or MFMA16");
+  if (!h->lqr_cost_set) return fail(ALTRO_HIP_ERR_NOT_SET, "no quadratic cost to update (ErrorCodes::CostNotQuadratic)");
+  const int n = h->n, m = h->m, N = h->N;
+  if (k_first < 0 || k_last > N || k_first > k_last)
+    return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "knot point range [%d, %d] outside [0, %d] (ErrorCodes::BadIndex)", k_first, k_last, N);
+  if (r && k_last == N)
+    return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "cannot update linear input costs at the terminal knot point "
+                                            "(ErrorCodes::InvalidOptAtTerminalKnotPoint)");
+  const int nk = k_last - k_first + 1;
+  if (h->plan == ALTRO_HIP_PLAN_MFMA16) {
+    const int64_t B = h->batch;
+    auto put = [&](const double* src, int len, int off) -> int {
+      if (!src) return 0;
+      if (h->dtype == ALTRO_HIP_F64)
+        return aos_set<double>(h, (double*)h->m_costp + (size_t)k_first * B * MF_COSTP + off, MF_COSTP, B * MF_COSTP, src, len,
+                               nk, kz, bz);
+      return aos_set<float>(h, (float*)h->m_costp + (size_t)k_first * B * MF_COSTP + off, MF_COSTP, B * MF_COSTP, src, len, nk,
+                            kz, bz);
+    };
+    rc = put(q, n, 16);
+    if (!rc) rc = put(r, m, 28);
+    if (!rc) rc = put(c, 1, 32);
+    return rc;
+  }
+  const int E = 2 * n + 2 * m + 1;
+  const size_t base = (size_t)k_first * E * h->batch;
+  auto pk = [&](const double* src, int len, int off) -> int {
+    if (!src) return 0;
+    return h->dtype == ALTRO_HIP_F64
+               ? lane_pack<double>(h, (double*)h->l_cost + base, E, src, len, off, 0, nk, 0, kz ? 1 : nk, kz, bz)
+               : lane_pack<float>(h, (float*)h->l_cost + base, E, src, len, off, 0, nk, 0, kz ? 1 : nk, kz, bz);
+  };
+  rc = pk(q, n, n + m);
+  if (!rc) rc = pk(r, m, 2 * n + m);
+  if (!rc) rc = pk(c, 1, 2 * n + 2 * m);
+  return rc;
+}
+int altro_hip_get_knot(altro_hip_batch* h, int k, double* x, double* u) {
+  // ALTROSolver::GetState / GetInput (altro_solver.cpp:323-347) of one knot point for the whole batch:
+  // x [batch][n], u [batch][m] (u must be NULL at k = N)
+  int rc = check(h);
+  if (rc) return rc;
+  const int n = h->n, m = h->m, N = h->N;
+  if (k < 0 || k > N) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "knot point %d outside [0, %d] (ErrorCodes::BadIndex)", k, N);
+  if (u && k == N) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "no input at the terminal knot point");
+  if (h->plan == ALTRO_HIP_PLAN_MFMA16) {
+    if (!h->m_nom) return fail(ALTRO_HIP_ERR_NOT_SET, "altro_hip_set_tracking_cost has not been called");
+    const int64_t B = h->batch;
+    if (x) {
+      rc = h->dtype == ALTRO_HIP_F64
+               ? aos_get<double>(h, x, (const double*)h->m_nom + (size_t)k * B * MF_NOM, MF_NOM, B * MF_NOM, n, 1)
+               : aos_get<float>(h, x, (const float*)h->m_nom + (size_t)k * B * MF_NOM, MF_NOM, B * MF_NOM, n, 1);
+      if (rc) return rc;
+    }
+    if (u)
+      rc = h->dtype == ALTRO_HIP_F64
+               ? aos_get<double>(h, u, (const double*)h->m_nom + (size_t)k * B * MF_NOM + 12, MF_NOM, B * MF_NOM, m, 1)
+               : aos_get<float>(h, u, (const float*)h->m_nom + (size_t)k * B * MF_NOM + 12, MF_NOM, B * MF_NOM, m, 1);
+    return rc;
+  }
+  if (h->plan != ALTRO_HIP_PLAN_LANE) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "plans LANE and MFMA16 only");
+  const size_t E = h->dtype == ALTRO_HIP_F64 ? 8 : 4;
+  const char* rec = (const char*)h->l_nom + (size_t)k * (n + m) * h->batch * E;
+  if (x) {
+    rc = h->dtype == ALTRO_HIP_F64 ? lane_get<double>(h, x, rec, nullptr, n + m, 0, 0, n, 1, 1)
+                                   : lane_get<float>(h, x, rec, nullptr, n + m, 0, 0, n, 1, 1);
+    if (rc) return rc;
+  }
+  if (u)
+    rc = h->dtype == ALTRO_HIP_F64 ? lane_get<double>(h, u, rec, nullptr, n + m, n, 0, m, 1, 1)
+                                   : lane_get<float>(h, u, rec, nullptr, n + m, n, 0, m, 1, 1);
+  return rc;
+}
+
+int altro_hip_add_linear_constraint(altro_hip_batch* h, int k_first, int k_last, int cone, int p, const double* G,
+                                    const double* g, int g_per_problem) {
+  // ALTROSolver::SetConstraint (altro_solver.cpp:175-215) for c(x,u) = G [x;u] - g
+  int rc = check(h);
+  if (rc) return rc;
+  if (h->plan != ALTRO_HIP_PLAN_LANE && h->plan != ALTRO_HIP_PLAN_MFMA16)
+    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "constraints need plan LANE or MFMA16");
+  if (!G || !g) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "G and g are required");
+  if (cone < CONE_EQUALITY || cone > CONE_SOC) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "unknown cone %d", cone);
+  const int pmax = cone == CONE_SOC ? AL_MAXSOC : AL_MAXP;
+  if (p < 1 || p > pmax) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "constraint dimension %d outside [1, %d]", p, pmax);
+  if (k_first < 0 || k_last > h->N || k_first > k_last)
+    return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "knot point range [%d, %d] outside [0, %d] (ErrorCodes::BadIndex)", k_first, k_last, h->N);
+  if ((int)h->al_defs.size() >= AL_MAXDEF) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "at most %d constraint blocks", AL_MAXDEF);
+  for (int k = k_first; k <= k_last; ++k)
+    if (h->al_knots[k].ncon >= AL_MAXC)
+      return fail(ALTRO_HIP_ERR_UNSUPPORTED, "at most %d constraint blocks per knot point (k = %d)", AL_MAXC, k);
+  const int w = h->n + h->m;
+  AlDef d{cone, p, g_per_problem ? 1 : 0, (int)h->al_G.size(), 0};
+  h->al_G.insert(h->al_G.end(), G, G + (size_t)p * w);
+  h->al_g.emplace_back(g, g + (size_t)p * (g_per_problem ? h->batch : 1));
+  const int id = (int)h->al_defs.size();
+  h->al_defs.push_back(d);
+  for (int k = k_first; k <= k_last; ++k) {
+    AlKnot& kn = h->al_knots[k];
+    kn.def[kn.ncon++] = id;
+  }
+  h->al_dirty = true;
+  return id;
+}
+int altro_hip_clear_constraints(altro_hip_batch* h) {
+  int rc = check(h);
+  if (rc) return rc;
+  h->al_defs.clear(); h->al_G.clear(); h->al_g.clear();
+  h->al_knots.assign((size_t)h->N + 1, AlKnot{});
+  h->al_dirty = true;
+  return al_upload(h);
+}
+int altro_hip_reset_duals(altro_hip_batch* h, double penalty) {
+  // duals back to zero and every constraint's penalty to `penalty` (what a fresh Initialize leaves: 1)
+  int rc = check(h);
+  if (rc) return rc;
+  if (h->plan != ALTRO_HIP_PLAN_LANE && h->plan != ALTRO_HIP_PLAN_MFMA16) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "constraints need plan LANE or MFMA16");
+  if (!(penalty > 0.0)) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "penalty must be positive");
+  if ((rc = al_upload(h))) return rc;
+  const size_t E = h->dtype == ALTRO_HIP_F64 ? 8 : 4;
+  if (h->al_d_z) HIP_TRY(hipMemsetAsync(h->al_d_z, 0, (size_t)h->al_rows * h->batch * E, h->stream));
+  std::vector<IlqrProb> pr(h->batch);
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(pr.data(), h->i_prob, pr.size() * sizeof(IlqrProb), hipMemcpyDeviceToHost));
+  for (auto& q : pr) { q.rho = penalty; q.rho_est = penalty; }
+  HIP_TRY(hipMemcpy(h->i_prob, pr.data(), pr.size() * sizeof(IlqrProb), hipMemcpyHostToDevice));
+  return 0;
+}
+int altro_hip_get_duals(altro_hip_batch* h, int k, int slot, double* z) {
+  // duals of constraint block `slot` of knot point k, [batch][p]
+  int rc = check(h);
+  if (rc) return rc;
+  if (h->plan != ALTRO_HIP_PLAN_LANE && h->plan != ALTRO_HIP_PLAN_MFMA16) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "constraints need plan LANE or MFMA16");
+  if ((rc = al_upload(h))) return rc;
+  if (k < 0 || k > h->N || slot < 0 || slot >= h->al_knots[k].ncon || !z)
+    return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "no constraint block %d at knot point %d", slot, k);
+  const AlKnot& kn = h->al_knots[k];
+  const int p = h->al_defs[kn.def[slot]].p;
+  const int64_t B = h->batch;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (h->dtype == ALTRO_HIP_F64) {
+    std::vector<double> t((size_t)p * B);
+    HIP_TRY(hipMemcpy(t.data(), (const double*)h->al_d_z + (size_t)kn.z_off[slot] * B, t.size() * 8, hipMemcpyDeviceToHost));
+    for (int64_t b = 0; b < B; ++b)
+      for (int r = 0; r < p; ++r) z[(size_t)b * p + r] = t[(size_t)r * B + b];
+  } else {
+    std::vector<float> t((size_t)p * B);
+    HIP_TRY(hipMemcpy(t.data(), (const float*)h->al_d_z + (size_t)kn.z_off[slot] * B, t.size() * 4, hipMemcpyDeviceToHost));
+    for (int64_t b = 0; b < B; ++b)
+      for (int r = 0; r < p; ++r) z[(size_t)b * p + r] = t[(size_t)r * B + b];
+  }
+  return 0;
+}
+
+int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts,
+                         altro_hip_solve_result* results) {
+  // SolverImpl::Solve (solver.cpp:414-511) for every problem of the batch at once.  The host only
+  // sequences launches and reads two counters per step; all per-problem decisions are on the device.
+  int rc = ilqr_check(h, true);
+  if (rc) return rc;
+  altro_hip_solve_options o;
+  if (opts) o = *opts;
+  else altro_hip_default_solve_options(&o);
+  IlqrLoopArgs la;
+  la.prob = h->i_prob; la.alpha = h->i_alpha; la.active = h->i_active; la.phi = h->i_phi; la.dphi = h->i_dphi;
+  la.counters = h->i_counters; la.batch = h->batch; la.iter = 0; la.iterations_max = o.iterations_max;
+  la.tol_stationarity = o.tol_stationarity; la.tol_meritfun_gradient = o.tol_meritfun_gradient;
+  la.tol_primal_feasibility = o.tol_primal_feasibility;
+  la.penalty_initial = o.penalty_initial; la.penalty_scaling = o.penalty_scaling; la.penalty_max = o.penalty_max;
+  const bool al = !h->al_defs.empty();
+  la.al_enabled = al ? 1 : 0;
+  la.reg = h->i_reg; la.bwd_status = h->status;
+  la.spec_trials = 1; la.spec_pre = 0; la.spec_sel = h->i_spec_sel; la.spec_refresh = h->i_spec_refresh;
+  la.reg_initial = o.reg_initial; la.reg_scale = o.reg_scale; la.reg_min = o.reg_min; la.reg_max = o.reg_max;
+  const bool reg_on = o.reg_retry_max > 0 || o.reg_initial > 0.0;
+  if (reg_on && h->plan != ALTRO_HIP_PLAN_LANE)
+    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "the regularisation schedule is a plan-LANE feature");
+  if (o.reg_initial < 0.0 || (o.reg_retry_max > 0 && !(o.reg_scale > 1.0 && o.reg_min > 0.0 && o.reg_max >= o.reg_min)))
+    return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "regularisation retry needs reg_initial >= 0, reg_scale > 1, 0 < reg_min <= reg_max");
+  if (al && !(o.penalty_initial > 0.0 && o.penalty_scaling > 0.0 && o.penalty_max > 0.0))
+    return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "penalty_initial, penalty_scaling and penalty_max must be positive");
+  la.ls = ls_default_options();
+  la.ls.try_cubic_first = 1;                                   // solver.cpp:248
+  la.ls.use_backtracking = o.use_backtracking_linesearch;      // solver.cpp:417
+  h->spec_beta = la.ls.beta_decrease; h->spec_max_iters = la.ls.max_iters;
+  int counters[3];
+  auto read_counters = [&]() -> int {
+    HIP_TRY(hipMemcpyAsync(counters, h->i_counters, sizeof(counters), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+  };
+  auto zero_counter = [&](int idx) -> int {
+    HIP_TRY(hipMemsetAsync(h->i_counters + idx, 0, sizeof(int), h->stream));
+    return 0;
+  };
+  // initial rollout, make it the nominal trajectory, expand everything (solver.cpp:420-434)
+  if (ilqr_launch_loop(h->stream, ILK_LOOP_INIT, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
+  rc = ilqr_run(h, IK_ROLLOUT, false, false, 0, 0.0);
+  if (!rc) rc = ilqr_run(h, IK_ACCEPT, false, false, 0, 0.0);
+  // without constraints the cost Hessian is constant and is written once, here; with them the gradient is
+  // formed with the penalty the constraints carry so far and SetPenalty comes after it (solver.cpp:424-430)
+  if (!rc) rc = ilqr_run(h, IK_EXPAND, false, false, 0, 0.0, al ? EXPAND_GRADIENT : (EXPAND_GRADIENT | EXPAND_HESSIAN));
+  if (rc) return rc;
+  if (al && ilqr_launch_loop(h->stream, ILK_SET_PENALTY, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
+  int total_merit_launches = 0, sweeps = 0;
+  // speculative backtracking: how much of the chip the searching problems occupy, and how much there is
+  const bool spec_all_on = std::getenv("ALTRO_HIP_NO_SPECULATION") == nullptr;
+  const bool spec_on = o.use_backtracking_linesearch != 0 && spec_all_on;
+  int running = h->batch;   // problems still iterating (counters[1] of the previous sweep)
+  const bool lane_plan = h->plan == ALTRO_HIP_PLAN_LANE;
+  auto spec_units = [&](int searching) -> int {   // wavefronts one merit launch keeps busy
+    return lane_plan ? (h->batch + 63) / 64 : searching;   // LANE: the searching lanes are scattered over all waves
+  };
+  const int64_t spec_capacity = lane_plan ? 512 : 4096;    // two waves per CU (LANE: latency-bound; more slow each other down) / four per SIMD (MFMA16)
+  const int64_t cand_elems = (int64_t)h->batch * (h->N + 1) * (lane_plan ? lane_sizes(h->n, h->m).e_xuy : 28);
+  const size_t spare_bytes = (size_t)(ILQR_SPEC_TRIALS - 1) * cand_elems * h->esz;   // spare candidate trajectories
+  h->spec_trials = 1;
+  struct MaskGuard {   // the backward sweep skips problems that have stopped, only inside this loop
+    altro_hip_batch* h;
+    ~MaskGuard() { h->bwd_active = nullptr; h->bwd_reg = nullptr; }
+  } mask_guard{h};
+  h->bwd_active = h->i_active;
+  h->bwd_reg = reg_on ? h->i_reg : nullptr;
+  int total_reg_retries = 0;
+  for (int iter = 0; iter < o.iterations_max; ++iter) {
+    la.iter = iter;
+    if (ilqr_launch_loop(h->stream, ILK_MARK_RUNNING, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
+    if (al) {                                                   // CalcExpansions: cost Hessians (solver.cpp:448)
+      rc = ilqr_run(h, IK_EXPAND, false, true, 0, 0.0, EXPAND_HESSIAN);
+      if (rc) return rc;
+    }
+    rc = launch_backward(h, 0.0);                               // BackwardPass (reg = 0, solver.cpp:363)
+    if (rc) return rc;
+    h->backward_done = true;
+    for (int attempt = 0; attempt < o.reg_retry_max; ++attempt) {   // extension: repeat failed problems with more reg
+      if ((rc = zero_counter(2))) return rc;
+      if (ilqr_launch_loop(h->stream, ILK_REG_RETRY, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
+      if ((rc = read_counters())) return rc;
+      if (counters[2] == 0) break;
+      total_reg_retries += counters[2];
+      rc = launch_backward(h, 0.0);
+      if (rc) return rc;
+    }
+    if (o.reg_retry_max > 0 && ilqr_launch_loop(h->stream, ILK_MARK_RUNNING, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
+    // ForwardPass: phi(0), then the line search (solver.cpp:237-271).  While the running problems leave half of the
+    // chip idle, the first step the search will ask for (alpha0 = 1, known in advance) rides in the same launch as
+    // phi(0) -- phi, phi' and the trajectory go to spare row / buffer 0 -- and ILK_LS_BEGIN consumes it at once.
+    bool refreshed = false;
+    bool pre = spec_all_on && !h->spec_no_memory && (int64_t)spec_units(running) * 2 <= spec_capacity;
+    if (pre && !h->i_cand_spec && dmalloc(h, &h->i_cand_spec, spare_bytes)) {
+      (void)hipGetLastError();    // an optimisation only: carry on one step per launch
+      h->spec_no_memory = true;
+      pre = false;
+    }
+    h->spec_trials = pre ? 2 : 1; h->spec_pre = pre ? 1 : 0;
+    rc = ilqr_run(h, IK_MERIT, true, true, 1, 0.0);
+    h->spec_trials = 1; h->spec_pre = 0;
+    if (rc) return rc;
+    ++total_merit_launches;
+    if ((rc = zero_counter(0))) return rc;
+    la.spec_pre = pre ? 1 : 0;
+    if (ilqr_launch_loop(h->stream, ILK_LS_BEGIN, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
+    la.spec_pre = 0;
+    if (pre) {
+      rc = ilqr_run(h, IK_SPEC_SELECT, false, false, 0, 0.0);
+      if (rc) return rc;
+      refreshed = true;
+    } else {
+      // The first trial step is launched without asking the device whether any problem needs it: the masks make it
+      // a no-op when none does, and it saves one host read-back per sweep (these loops are latency-bound).
+      rc = ilqr_run(h, IK_MERIT, true, true, 1, 0.0);
+      if (rc) return rc;
+      ++total_merit_launches;
+      if ((rc = zero_counter(0))) return rc;
+      if (ilqr_launch_loop(h->stream, ILK_LS_FEED, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
+    }
+    if ((rc = read_counters())) return rc;
+    int guard = 0;
+    while (counters[0] > 0 && guard++ < 64) {
+      // Speculative backtracking: once the problems still searching leave most of the chip idle, one launch
+      // evaluates the next 2, 4 or 8 steps of the (known) sequence alpha beta^j for each of them; the feed
+      // kernel consumes them in order, so every decision is the sequential one (kernels/ilqr_types.h).
+      int trials = 1;
+      if (spec_on && !h->spec_no_memory)
+        while (trials < ILQR_SPEC_TRIALS && (int64_t)spec_units(counters[0]) * trials * 2 <= spec_capacity) trials *= 2;
+      if (trials > 1 && !h->i_cand_spec && dmalloc(h, &h->i_cand_spec, spare_bytes)) {
+        (void)hipGetLastError();
+        h->spec_no_memory = true;
+        trials = 1;
+      }
+      const bool spec = trials > 1;
+      h->spec_trials = trials;
+      la.spec_trials = h->spec_trials;
+      rc = ilqr_run(h, IK_MERIT, true, true, 1, 0.0);
+      if (rc) return rc;
+      ++total_merit_launches;
+      if ((rc = zero_counter(0))) return rc;
+      if (ilqr_launch_loop(h->stream, ILK_LS_FEED, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
+      if (spec) {
+        rc = ilqr_run(h, IK_SPEC_SELECT, false, false, 0, 0.0);
+        if (rc) return rc;
+        refreshed = true;
+      }
+      h->spec_trials = 1;
+      la.spec_trials = 1;
+      if ((rc = read_counters())) return rc;
+    }
+    if (refreshed) {   // steps accepted from a speculative trial carry no phi' pass: redo their expansion (what the
+                       // derivative pass of a sequential trial would have left behind)
+      int* keep = h->i_active;
+      h->i_active = h->i_spec_refresh;
+      rc = ilqr_run(h, IK_EXPAND, false, true, 0, 0.0, EXPAND_GRADIENT);
+      h->i_active = keep;
+      if (rc) return rc;
+    }
+    // convergence criteria on the accepted candidate, then make it the nominal (solver.cpp:459-469)
+    if (ilqr_launch_loop(h->stream, ILK_MARK_RUNNING, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
+    rc = ilqr_run(h, IK_STATIONARITY, false, true, 0, 0.0);
+    if (!rc) rc = ilqr_run(h, IK_ACCEPT, false, true, 0, 0.0);
+    if (rc) return rc;
+    if ((rc = zero_counter(1))) return rc;
+    if (ilqr_launch_loop(h->stream, ILK_FINISH_ITER, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
+    if (al) {   // DualUpdate, PenaltyUpdate, refreshed gradients for the problems that asked (solver.cpp:470-489)
+      rc = ilqr_run(h, IK_DUAL, false, false, 0, 0.0);
+      if (rc) return rc;
+      if (ilqr_launch_loop(h->stream, ILK_PENALTY_UPDATE, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
+      rc = ilqr_run(h, IK_EXPAND, false, true, 0, 0.0, EXPAND_GRADIENT);
+      if (rc) return rc;
+    }
+    if ((rc = read_counters())) return rc;
+    ++sweeps;
+    if (counters[1] == 0) break;
+    running = counters[1];
+  }
+  h->forward_done = true;
+  h->solve_done = true;
+  if (results) {
+    std::vector<IlqrProb> pr(h->batch);
+    HIP_TRY(hipMemcpy(pr.data(), h->i_prob, pr.size() * sizeof(IlqrProb), hipMemcpyDeviceToHost));
+    for (int b = 0; b < h->batch; ++b) {
+      results[b].status = pr[b].status;
+      results[b].iterations = pr[b].iterations;
+      results[b].stationarity = pr[b].stationarity;
+      results[b].final_alpha = pr[b].alpha;
+      results[b].final_phi = pr[b].ls_iters > 0 ? pr[b].ls.phi : pr[b].phi0;
+      results[b].primal_feasibility = pr[b].feasibility;
+      results[b].penalty = pr[b].rho;
+      results[b].dual_updates = pr[b].n_dual_updates;
+      results[b].reg_retries = pr[b].reg_retries;
+    }
+  }
+  h->last_sweeps = sweeps;
+  h->last_merit_launches = total_merit_launches;
+  return 0;
+}
+
+void altro_hip_default_solve_options(altro_hip_solve_options* o) {
+  if (!o) return;
+  o->iterations_max = 200;            // solver_options.hpp:16-39
+  o->tol_stationarity = 1e-4;
+  o->tol_primal_feasibility = 1e-4;
+  o->tol_meritfun_gradient = 1e-8;
+  o->use_backtracking_linesearch = 0;
+  o->penalty_initial = 1.0;
+  o->penalty_scaling = 10.0;
+  o->penalty_max = 1e8;
+  o->reg_initial = 0.0;     // the reference: reg = 0, failures ignored (solver.cpp:363, :449)
+  o->reg_retry_max = 0;
+  o->reg_scale = 10.0;
+  o->reg_min = 1e-6;
+  o->reg_max = 1e8;
+}
+int altro_hip_last_solve_counts(const altro_hip_batch* h, int* sweeps, int* merit_launches) {
+  if (!h) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "null handle");
+  if (sweeps) *sweeps = h->last_sweeps;
+  if (merit_launches) *merit_launches = h->last_merit_launches;
+  return 0;
+}
+int altro_hip_get_nominal(altro_hip_batch* h, double* x, double* u) {
+  int rc = check(h);
+  if (rc) return rc;
+  const int n = h->n, m = h->m, N = h->N;
+  if (h->plan == ALTRO_HIP_PLAN_MFMA16) {
+    if (!h->m_nom) return fail(ALTRO_HIP_ERR_NOT_SET, "altro_hip_set_tracking_cost has not been called");
+    const int64_t B = h->batch;
+    if (x) {
+      rc = h->dtype == ALTRO_HIP_F64 ? aos_get<double>(h, x, (const double*)h->m_nom, MF_NOM, B * MF_NOM, n, N + 1)
+                                     : aos_get<float>(h, x, (const float*)h->m_nom, MF_NOM, B * MF_NOM, n, N + 1);
+      if (rc) return rc;
+    }
+    if (u)
+      rc = h->dtype == ALTRO_HIP_F64 ? aos_get<double>(h, u, (const double*)h->m_nom + 12, MF_NOM, B * MF_NOM, m, N)
+                                     : aos_get<float>(h, u, (const float*)h->m_nom + 12, MF_NOM, B * MF_NOM, m, N);
+    return rc;
+  }
+  if (h->plan != ALTRO_HIP_PLAN_LANE) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "nominal trajectory exists for plans LANE and MFMA16");
+  if (x) {
+    rc = h->dtype == ALTRO_HIP_F64 ? lane_get<double>(h, x, h->l_nom, nullptr, n + m, 0, 0, n, N + 1, N + 1)
+                                   : lane_get<float>(h, x, h->l_nom, nullptr, n + m, 0, 0, n, N + 1, N + 1);
+    if (rc) return rc;
+  }
+  if (u)
+    rc = h->dtype == ALTRO_HIP_F64 ? lane_get<double>(h, u, h->l_nom, nullptr, n + m, n, 0, m, N, N)
+                                   : lane_get<float>(h, u, h->l_nom, nullptr, n + m, n, 0, m, N, N);
+  return rc;
+}
+// Expansion the backward pass will consume: A | B | lx | lu (reference layout), for parity tests.
+int altro_hip_get_expansion(altro_hip_batch* h, double* A, double* B, double* lx, double* lu) {
+  int rc = check(h);
+  if (rc) return rc;
+  if (h->plan != ALTRO_HIP_PLAN_LANE) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "plan LANE only");
+  const int n = h->n, m = h->m, N = h->N;
+  const LaneSizes z = lane_sizes(n, m);
+  const int oq = 2 * n * n + 2 * n * m + m * m + n, orr = oq + n;
+  auto get = [&](double* dst, int off, int len, int nk, bool with_term, int off_term) -> int {
+    if (!dst) return 0;
+    return h->dtype == ALTRO_HIP_F64
+               ? lane_get<double>(h, dst, h->l_in, with_term ? h->l_term : nullptr, z.e_in, off, off_term, len, nk, N)
+               : lane_get<float>(h, dst, h->l_in, with_term ? h->l_term : nullptr, z.e_in, off, off_term, len, nk, N);
+  };
+  rc = get(A, 0, n * n, N, false, 0);
+  if (!rc) rc = get(B, n * n, n * m, N, false, 0);
+  if (!rc) rc = get(lx, oq, n, N + 1, true, n * n);
+  if (!rc) rc = get(lu, orr, m, N, false, 0);
+  return rc;
+}
+
+// The line-search state machine driven on the host by a callback: lets CPU-only tests pin it against
+// the real reference line search (oracle/_ref) without a GPU.
+double altro_hip_linesearch_host(altro_hip_merit_fn f, void* ctx, double alpha0, double phi0, double dphi0,
+                                 int try_cubic_first, int use_backtracking, double c1, double c2,
+                                 int* status, int* iters, double* phi, double* dphi) {
+  LsOptions o = ls_default_options();
+  o.try_cubic_first = try_cubic_first; o.use_backtracking = use_backtracking; o.c1 = c1; o.c2 = c2;
+  LsState s;
+  bool need = ls_begin(s, o, alpha0, phi0, dphi0);
+  while (need) {
+    double p = 0.0, dp = 0.0;
+    f(s.alpha, &p, s.want_derivative ? &dp : nullptr, ctx);
+    need = ls_feed(s, o, p, dp);
+  }
+  if (status) *status = s.status;
+  if (iters) *iters = s.n_iters;
+  if (phi) *phi = s.phi;
+  if (dphi) *dphi = s.dphi;
+  return s.alpha;
+}
+
+}  // extern "C"

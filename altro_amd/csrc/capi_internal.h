@@ -1,0 +1,393 @@
+// capi_internal.h -- the handle behind include/altro_hip/altro_hip.h and the host-side helpers its translation units share
+// (capi_core.hip: lifetime, setters, getters; capi_tvlqr.hip: the sweep launchers; capi_ilqr.hip: the iLQR loop, constraint
+// blocks and MPC operations; capi_stats.hip: statistics reduction and the multi-device runner).  Host-side plumbing only:
+// all arithmetic lives in kernels/*.hip.  There is no CPU fallback anywhere behind this header.
+#pragma once
+#include "altro_hip/altro_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels/pack.hip"
+#include "kernels/tvlqr_generic.hip"
+#include "kernels/tvlqr_lane.hip"
+#include "kernels/ilqr_types.h"
+#include "kernels/mfma16_layout.h"
+#include "linesearch_sm.h"
+
+namespace altro_hip {
+namespace capi {
+
+// records the message altro_hip_last_error() returns (thread-local, capi_core.hip) and passes `code` through
+int fail(int code, const char* fmt, ...);
+
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess)                                                                     \
+      return ::altro_hip::capi::fail(ALTRO_HIP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                  __FILE__, __LINE__);                                                        \
+  } while (0)
+
+constexpr size_t kStageBytes = size_t(256) << 20;
+
+}  // namespace capi
+}  // namespace altro_hip
+
+using namespace altro_hip;   // internal header: the handle below names the kernels' argument types directly
+
+struct altro_hip_batch {
+  int N = 0, n = 0, m = 0, batch = 0, dtype = 0, plan = 0, device = 0;
+  unsigned flags = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  size_t esz = 8;  // element size on the device
+  // common
+  void* x0 = nullptr;
+  void* delta_V = nullptr;
+  int* status = nullptr;
+  bool dyn_set = false, cost_set = false, x0_set = false, backward_done = false, forward_done = false;
+  int has_f = 0, is_diag = 0;
+  int host_batch = 0;   // > 0: host arrays of the next set_* calls hold this many problems, tiled over the batch
+  bool dev_ptrs = false;   // altro_hip_set_pointer_mode: bulk arrays of set_* / get_* are device pointers
+  // plan GENERIC: reference layout on the device
+  void* g_arr[G_NUM] = {};
+  int64_t g_bstride[G_NUM] = {};
+  int64_t* g_off = nullptr;
+  int* g_nx = nullptr;
+  int* g_nu = nullptr;
+  // plan MFMA16
+  void *m_in = nullptr, *m_cin = nullptr, *m_term = nullptr, *m_out = nullptr, *m_outn = nullptr, *m_xuy = nullptr,
+       *m_qblk = nullptr, *m_trash = nullptr;   // element type = handle dtype (fp32 storage allowed)
+  Mfma16Strides m_st{};
+  // plan LANE: batch structure-of-arrays ([k][element][batch])
+  void *l_in = nullptr, *l_term = nullptr, *l_out = nullptr, *l_outn = nullptr, *l_xuy = nullptr,
+       *l_x0 = nullptr;
+  // iLQR loop state (plan LANE): nominal trajectory, cost parameters, per-problem control blocks
+  void *l_nom = nullptr, *l_cost = nullptr;
+  IlqrProb* i_prob = nullptr;
+  double *i_alpha = nullptr, *i_phi = nullptr, *i_dphi = nullptr;
+  int *i_active = nullptr, *i_counters = nullptr;
+  // speculative backtracking (altro_hip_ilqr_solve): spare candidate trajectories, allocated on first use
+  void* i_cand_spec = nullptr;
+  int *i_spec_sel = nullptr, *i_spec_refresh = nullptr;
+  int spec_trials = 1;            // trials per merit launch of the CURRENT launch (1 = no speculation)
+  int spec_pre = 0;               // the current launch is phi(0) fused with the first trial step
+  bool spec_no_memory = false;    // the spare trajectories could not be allocated: no speculation on this handle
+  double spec_beta = 0.5;         // the running solve's LsOptions::beta_decrease / max_iters (what the merit kernels
+  int spec_max_iters = 25;        // need to reproduce the state machine's step sequence)
+  ModelParams model{MODEL_LINEAR, 0.0f, 0, 2.7, 1.5};
+  bool model_set = false, lqr_cost_set = false, guess_set = false;
+  // augmented-Lagrangian constraint blocks (plan LANE): host mirrors + device tables, uploaded lazily
+  std::vector<AlDef> al_defs;
+  std::vector<AlKnot> al_knots;
+  int al_uniform = 0, al_rows_per_knot = 0;  // knot points 0..N-1 carry the same blocks (kernels/al_types.h)
+  std::vector<double> al_G;                  // pool of G blocks, column-major p x (n+m)
+  std::vector<std::vector<double>> al_g;     // per block: [p] or [batch][p]
+  int al_rows = 0;
+  bool al_dirty = false;
+  AlKnot* al_d_knots = nullptr;
+  void *al_d_G = nullptr, *al_d_g = nullptr, *al_d_z = nullptr;
+  const int* bwd_active = nullptr;           // per-problem mask for the backward sweep inside ilqr_solve
+  const double* bwd_reg = nullptr;           // per-problem regularisation inside ilqr_solve (retry extension)
+  // iLQR loop on plan MFMA16 (dynamics given as data): nominal trajectory + cost parameters, allocated by
+  // altro_hip_set_tracking_cost; ilqr_linear = the backward sweep ignores the affine term (knotpoint_data.cpp:416)
+  void *m_nom = nullptr, *m_costp = nullptr;
+  bool ilqr_linear = false;
+  double* i_reg = nullptr;
+  // staging for host <-> device conversion (grown lazily, never inside the hot path)
+  void* stage = nullptr;
+  size_t stage_bytes = 0;
+  size_t device_bytes = 0;
+  // statistics reduction (capi_stats.hip): per-block partials and the reduced vector, on the device
+  double *st_partial = nullptr, *st_red = nullptr;
+  bool solve_done = false;   // altro_hip_ilqr_solve has run: the per-problem control blocks hold AltroStats
+  // profiling
+  bool prof = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int last_sweeps = 0, last_merit_launches = 0;
+  int prof_launches[2] = {0, 0};
+  double prof_ms[2] = {0, 0};
+};
+
+namespace altro_hip {
+namespace capi {
+
+inline int dmalloc(altro_hip_batch* h, void** p, size_t bytes) {
+  hipError_t e = hipMalloc(p, bytes ? bytes : 16);
+  if (e != hipSuccess) {
+    *p = nullptr;
+    return fail(ALTRO_HIP_ERR_OUT_OF_MEMORY, "hipMalloc(%zu bytes) failed: %s", bytes,
+                hipGetErrorString(e));
+  }
+  h->device_bytes += bytes;
+  return 0;
+}
+
+inline int check(altro_hip_batch* h) {
+  if (!h) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "null handle");
+  hipError_t e = hipSetDevice(h->device);
+  if (e != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "hipSetDevice(%d): %s", h->device, hipGetErrorString(e));
+  return 0;
+}
+
+inline int ensure_stage(altro_hip_batch* h, size_t bytes) {
+  if (h->stage_bytes >= bytes) return 0;
+  if (h->stage) (void)hipFree(h->stage);
+  h->stage = nullptr;
+  h->stage_bytes = 0;
+  hipError_t e = hipMalloc(&h->stage, bytes);
+  if (e != hipSuccess)
+    return fail(ALTRO_HIP_ERR_OUT_OF_MEMORY, "staging hipMalloc(%zu) failed: %s", bytes,
+                hipGetErrorString(e));
+  h->stage_bytes = bytes;
+  return 0;
+}
+
+inline int grid_for(int64_t total, int block = 256) {
+  int64_t g = (total + block - 1) / block;
+  return (int)std::min<int64_t>(std::max<int64_t>(g, 1), 256 * 32);
+}
+
+// element counts of one knot point's block in the reference layout
+struct Dims {
+  int n, m;
+  int A() const { return n * n; }
+  int B() const { return n * m; }
+  int Q(int diag) const { return diag ? n : n * n; }
+  int R(int diag) const { return diag ? m : m * m; }
+  int H() const { return m * n; }
+};
+
+// Upload one reference-layout host array chunk by chunk and hand each chunk to `consume`.
+// host layout: [batch or 1][nk or 1][block] doubles.
+template <typename F>
+inline int upload_chunks(altro_hip_batch* h, const double* host, int block, int nk, int k_zero, int b_zero,
+                  int nk_host, int src_off, F consume) {
+  const int src_nk = nk_host > 0 ? nk_host : (k_zero ? 1 : nk);
+  const size_t per_problem = (size_t)src_nk * block * sizeof(double);
+  if (h->dev_ptrs) {   // the caller's array already lives in HBM: no staging, one pass over the whole batch
+    SrcArr s{host + src_off, b_zero ? 0 : (int64_t)src_nk * block, k_zero ? 0 : (int64_t)block, 0};
+    int rc = consume(s, 0, h->batch);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));   // the caller may reuse its buffer on return
+    return 0;
+  }
+  if (b_zero) {
+    int rc = ensure_stage(h, per_problem);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(h->stage, host, per_problem, hipMemcpyHostToDevice, h->stream));
+    SrcArr s{(const double*)h->stage + src_off, 0, k_zero ? 0 : (int64_t)block, 0};
+    rc = consume(s, 0, h->batch);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+  }
+  int chunk = (int)std::max<size_t>(1, std::min<size_t>(h->batch, kStageBytes / std::max<size_t>(per_problem, 1)));
+  int rc = ensure_stage(h, per_problem * chunk);
+  if (rc) return rc;
+  for (int b0 = 0; b0 < h->batch; b0 += chunk) {
+    const int nb = std::min(chunk, h->batch - b0);
+    HIP_TRY(hipMemcpyAsync(h->stage, host + (size_t)b0 * src_nk * block, per_problem * nb,
+                           hipMemcpyHostToDevice, h->stream));
+    SrcArr s{(const double*)h->stage + src_off, (int64_t)src_nk * block, k_zero ? 0 : (int64_t)block, 0};
+    rc = consume(s, b0, nb);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));  // the staging buffer is reused by the next chunk
+  }
+  return 0;
+}
+
+template <typename T>
+inline int generic_set(altro_hip_batch* h, int arr, const double* host, int block, int nk, int k_zero,
+                int b_zero, int k0 = 0, int nk_host = -1, int src_off = 0) {
+  if (h->host_batch > 0 && h->host_batch < h->batch && !b_zero)
+    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "altro_hip_set_host_batch tiling is not available on plan GENERIC");
+  // writes knot points [k0, k0+nk) of the device array from a host array that holds nk_host knot
+  // points per problem (default nk, or 1 when k_zero)
+  T* dst = (T*)h->g_arr[arr] + (int64_t)k0 * block;
+  const int64_t bs = h->g_bstride[arr];
+  return upload_chunks(h, host, block, nk, k_zero, b_zero, nk_host, src_off, [&](SrcArr s, int b0, int nb) {
+    const int64_t total = (int64_t)nb * nk * block;
+    hipLaunchKernelGGL(expand_copy_kernel<T>, dim3(grid_for(total)), dim3(256), 0, h->stream, dst,
+                       bs, (int64_t)block, s, block, nk, b0, nb);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "expand_copy launch: %s", hipGetErrorString(e));
+    return 0;
+  });
+}
+
+// One reference-layout host array ([batch or 1][nk_host][block]) into `block` consecutive elements of AoS device
+// records: dst[b * dst_bs + k * dst_ks + e], k = 0..nk-1.
+template <typename T>
+inline int aos_set(altro_hip_batch* h, T* dst, int64_t dst_bs, int64_t dst_ks, const double* host, int block, int nk,
+            int k_zero, int b_zero, int nk_host = -1, int src_off = 0) {
+  return upload_chunks(h, host, block, nk, k_zero, b_zero, nk_host, src_off, [&](SrcArr s, int b0, int nb) {
+    const int64_t total = (int64_t)nb * nk * block;
+    hipLaunchKernelGGL(expand_copy_kernel<T>, dim3(grid_for(total)), dim3(256), 0, h->stream, dst, dst_bs, dst_ks, s,
+                       block, nk, b0, nb);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "expand_copy launch: %s", hipGetErrorString(e));
+    return 0;
+  });
+}
+// Download: run `produce(dst_device, b0, nb)` chunk by chunk into staging, then copy to the host.
+template <typename F>
+inline int download_chunks(altro_hip_batch* h, double* host, int block, int nk, F produce) {
+  const size_t per_problem = (size_t)nk * block * sizeof(double);
+  if (h->dev_ptrs) {   // write straight into the caller's device array
+    int rc = produce(host, 0, h->batch);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+  }
+  int chunk = (int)std::max<size_t>(1, std::min<size_t>(h->batch, kStageBytes / std::max<size_t>(per_problem, 1)));
+  int rc = ensure_stage(h, per_problem * chunk);
+  if (rc) return rc;
+  for (int b0 = 0; b0 < h->batch; b0 += chunk) {
+    const int nb = std::min(chunk, h->batch - b0);
+    rc = produce((double*)h->stage, b0, nb);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(host + (size_t)b0 * nk * block, h->stage, per_problem * nb,
+                           hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  }
+  return 0;
+}
+
+template <typename T>
+inline int aos_get(altro_hip_batch* h, double* host, const T* src, int64_t src_bs, int64_t src_ks, int block, int nk) {
+  return download_chunks(h, host, block, nk, [&](double* dst, int b0, int nb) {
+    const int64_t total = (int64_t)nb * nk * block;
+    hipLaunchKernelGGL(gather_copy_kernel<T>, dim3(grid_for(total)), dim3(256), 0, h->stream, dst,
+                       (int64_t)nk * block, (int64_t)block, src, src_bs, src_ks, block, nk, b0, nb);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "gather_copy launch: %s", hipGetErrorString(e));
+    return 0;
+  });
+}
+
+template <typename T>
+inline int generic_get(altro_hip_batch* h, int arr, double* host, int block, int nk) {
+  const T* src = (const T*)h->g_arr[arr];
+  const int64_t bs = h->g_bstride[arr];
+  return download_chunks(h, host, block, nk, [&](double* dst, int b0, int nb) {
+    const int64_t total = (int64_t)nb * nk * block;
+    hipLaunchKernelGGL(gather_copy_kernel<T>, dim3(grid_for(total)), dim3(256), 0, h->stream, dst,
+                       (int64_t)nk * block, (int64_t)block, src, bs, (int64_t)block, block, nk, b0, nb);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "gather_copy launch: %s", hipGetErrorString(e));
+    return 0;
+  });
+}
+
+inline int mfma16_get(altro_hip_batch* h, int what, double* host, int block, int nk) {
+  return download_chunks(h, host, block, nk, [&](double* dst, int b0, int nb) {
+    const int64_t total = (int64_t)nb * nk * block;
+    if (h->dtype == ALTRO_HIP_F64)
+      hipLaunchKernelGGL(mfma16_unpack_kernel<double>, dim3(grid_for(total)), dim3(256), 0, h->stream, dst, what,
+                         (const double*)h->m_out, (const double*)h->m_outn, (const double*)h->m_xuy,
+                         (const double*)h->m_qblk, h->m_st, h->N, b0, nb);
+    else
+      hipLaunchKernelGGL(mfma16_unpack_kernel<float>, dim3(grid_for(total)), dim3(256), 0, h->stream, dst, what,
+                         (const float*)h->m_out, (const float*)h->m_outn, (const float*)h->m_xuy,
+                         (const float*)h->m_qblk, h->m_st, h->N, b0, nb);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "mfma16_unpack launch: %s", hipGetErrorString(e));
+    return 0;
+  });
+}
+
+// Whole-array upload of one reference-layout source for the MFMA16 pack kernels (setup path).
+// `nk_host` = knot points per problem actually present in the host array.
+struct DevSrc {
+  void* dev = nullptr;
+  SrcArr s{nullptr, 0, 0, 0};
+  ~DevSrc() { if (dev) (void)hipFree(dev); }
+};
+inline int put_src(altro_hip_batch* h, const double* src, int blk, int nk_host, int k_zero, int b_zero,
+            DevSrc* out) {
+  if (!src) return 0;
+  const size_t per_b = (size_t)nk_host * blk;
+  const int tiled = (!b_zero && h->host_batch > 0 && h->host_batch < h->batch) ? h->host_batch : 0;
+  const size_t bytes = (size_t)(b_zero ? 1 : (tiled ? tiled : h->batch)) * per_b * sizeof(double);
+  if (h->dev_ptrs) {   // device pointer: use it in place
+    out->s = SrcArr{src, b_zero ? 0 : (int64_t)per_b, k_zero ? 0 : (int64_t)blk, tiled};
+    return 0;
+  }
+  if (hipMalloc(&out->dev, bytes) != hipSuccess)
+    return fail(ALTRO_HIP_ERR_OUT_OF_MEMORY, "hipMalloc(%zu) failed", bytes);
+  if (hipMemcpyAsync(out->dev, src, bytes, hipMemcpyHostToDevice, h->stream) != hipSuccess)
+    return fail(ALTRO_HIP_ERR_HIP, "H2D copy failed");
+  out->s = SrcArr{(const double*)out->dev, b_zero ? 0 : (int64_t)per_b, k_zero ? 0 : (int64_t)blk, tiled};
+  return 0;
+}
+inline int mfma16_pack_launch(altro_hip_batch* h, int seg, SrcArr s0, SrcArr s1) {
+  const int64_t total = (int64_t)h->batch * h->N * 192;
+  if (h->dtype == ALTRO_HIP_F64)
+    hipLaunchKernelGGL(mfma16_pack_kernel<double>, dim3(grid_for(total)), dim3(256), 0, h->stream, (double*)h->m_in,
+                       (double*)h->m_cin, (double*)h->m_term, h->m_st, seg, s0, s1, h->is_diag, h->N, 0, h->batch);
+  else
+    hipLaunchKernelGGL(mfma16_pack_kernel<float>, dim3(grid_for(total)), dim3(256), 0, h->stream, (float*)h->m_in,
+                       (float*)h->m_cin, (float*)h->m_term, h->m_st, seg, s0, s1, h->is_diag, h->N, 0, h->batch);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "mfma16_pack launch: %s", hipGetErrorString(e));
+  return 0;
+}
+
+// ---- plan LANE dispatch ---------------------------------------------------------------------------
+#define LANE_SHAPES(X) X(2, 1) X(4, 2) X(3, 1) X(6, 3)
+inline bool lane_supported(int n, int m) {
+#define X(N_, M_) if (n == N_ && m == M_) return true;
+  LANE_SHAPES(X)
+#undef X
+  return false;
+}
+struct LaneSizes { int e_in, e_term, e_out, e_xuy; };
+inline LaneSizes lane_sizes(int n, int m) {
+  return LaneSizes{2 * n * n + 2 * n * m + m * m + 2 * n + m, n * n + n, m * n + m + n * n + n, 2 * n + m};
+}
+// one reference-layout source -> a run of elements of the SoA records [k0, k0+nk)
+template <typename T>
+inline int lane_pack(altro_hip_batch* h, T* dst_base, int E, const double* host, int len, int dst_off,
+              int diag_n, int nk, int k_src0, int nk_host, int kz, int bz, int src_off = 0) {
+  DevSrc d;
+  int rc = put_src(h, host, len, nk_host, kz, bz, &d);
+  if (rc) return rc;
+  LaneSeg s{d.s.p ? d.s.p + src_off : nullptr, d.s.bs, d.s.ks, len, dst_off, diag_n, d.s.bmod};
+  const int dlen = diag_n > 0 ? diag_n * diag_n : len;
+  const int64_t total = (int64_t)h->batch * nk * dlen;
+  hipLaunchKernelGGL(lane_pack_kernel<T>, dim3(grid_for(total)), dim3(256), 0, h->stream, dst_base, E, s,
+                     nk, k_src0, h->batch);
+  if (hipGetLastError() != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "lane_pack launch failed");
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return 0;
+}
+template <typename T>
+inline int lane_get(altro_hip_batch* h, double* host, const void* src, const void* src_term, int E, int off,
+             int off_term, int len, int nk, int nk_main) {
+  return download_chunks(h, host, len, nk, [&](double* dst, int b0, int nb) {
+    const int64_t total = (int64_t)nb * nk * len;
+    hipLaunchKernelGGL(lane_unpack_kernel<T>, dim3(grid_for(total)), dim3(256), 0, h->stream, dst,
+                       (const T*)src, (const T*)src_term, E, off, 0, off_term, len, nk, nk_main, b0, nb,
+                       h->batch);
+    if (hipGetLastError() != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "lane_unpack launch failed");
+    return 0;
+  });
+}
+
+constexpr int kStatsBlocks = 1024, kStatsStride = 16;   // capi_stats.hip: partials [kStatsBlocks][kStatsStride]
+
+// the sweep launchers (capi_tvlqr.hip), also used by the iLQR loop
+int launch_backward(altro_hip_batch* h, double reg);
+int launch_forward(altro_hip_batch* h);
+
+}  // namespace capi
+}  // namespace altro_hip

@@ -1,0 +1,225 @@
+// capi_tvlqr.hip -- C ABI: the TVLQR sweep (altro_hip_backward / forward_ltv / sweep) and its per-plan kernel launchers.
+// This unit instantiates the sweep kernels of all three plans (GENERIC, LANE, MFMA16 in fp64 / fp32 storage / pure fp32).
+#include "capi_internal.h"
+
+#include "kernels/tvlqr_mfma16.hip"
+#include "kernels/tvlqr_mfma16_f32.hip"
+
+using namespace altro_hip;
+using namespace altro_hip::capi;
+
+namespace {
+
+template <typename T>
+int lane_launch(altro_hip_batch* h, bool backward, double reg) {
+  LaneArgs<T> a{(const T*)h->l_in, (const T*)h->l_term, (T*)h->l_out, (T*)h->l_outn, (const T*)h->l_x0,
+                (T*)h->l_xuy, (T*)h->delta_V, h->status, h->N, h->batch, (T)reg, backward ? h->bwd_active : nullptr,
+                backward ? h->bwd_reg : nullptr};
+  const dim3 grid(8 * (((h->batch + 63) / 64 + 7) / 8)), block(64);
+  const bool fused = (h->flags & ALTRO_HIP_LANE_FUSED) != 0;
+#define X(N_, M_)                                                                                              \
+  if (h->n == N_ && h->m == M_) {                                                                              \
+    if (backward && fused) hipLaunchKernelGGL((lane_backward_kernel_fused<N_, M_, T>), grid, block, 0, h->stream, a); \
+    else if (backward) hipLaunchKernelGGL((lane_backward_kernel<N_, M_, T>), grid, block, 0, h->stream, a);    \
+    else if (fused) hipLaunchKernelGGL((lane_forward_kernel_fused<N_, M_, T>), grid, block, 0, h->stream, a);  \
+    else hipLaunchKernelGGL((lane_forward_kernel<N_, M_, T>), grid, block, 0, h->stream, a);                   \
+  }
+  LANE_SHAPES(X)
+#undef X
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "lane kernel launch: %s", hipGetErrorString(e));
+  return 0;
+}
+
+template <typename T>
+GenericArgs<T> generic_args(altro_hip_batch* h, double reg) {
+  GenericArgs<T> a;
+  for (int i = 0; i < G_NUM; ++i) {
+    a.base[i] = (T*)h->g_arr[i];
+    a.bstride[i] = h->g_bstride[i];
+  }
+  a.off = h->g_off;
+  a.nx = h->g_nx;
+  a.nu = h->g_nu;
+  a.x0 = (const T*)h->x0;
+  a.x0_stride = h->n;
+  a.delta_V = (T*)h->delta_V;
+  a.status = h->status;
+  a.N = h->N;
+  a.batch = h->batch;
+  a.nmax = h->n;
+  a.mmax = h->m;
+  a.reg = (T)reg;
+  a.is_diag = h->is_diag;
+  a.store_q = (h->flags & ALTRO_HIP_STORE_QBLOCKS) ? 1 : 0;
+  a.want_y = 1;
+  return a;
+}
+
+struct ProfScope {
+  altro_hip_batch* h;
+  int slot;
+  ProfScope(altro_hip_batch* h_, int slot_) : h(h_), slot(slot_) {
+    if (h->prof) (void)hipEventRecord(h->ev0, h->stream);
+  }
+  ~ProfScope() {
+    if (h->prof) {
+      (void)hipEventRecord(h->ev1, h->stream);
+      (void)hipEventSynchronize(h->ev1);
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) {
+        h->prof_ms[slot] += ms;
+        h->prof_launches[slot] += 1;
+      }
+    }
+  }
+};
+
+
+template <typename S>
+Mfma16Args<S> mfma16_args(altro_hip_batch* h, double reg) {
+  Mfma16Args<S> a;
+  a.in = (const S*)h->m_in;
+  a.cin = (const S*)h->m_cin;
+  a.cin_bs = h->m_st.cin_bs; a.cin_ks = h->m_st.cin_ks;
+  a.in_bs = h->m_st.in_bs; a.in_ks = h->m_st.in_ks; a.out_bs = h->m_st.out_bs; a.out_ks = h->m_st.out_ks;
+  a.xuy_bs = h->m_st.xuy_bs; a.xuy_ks = h->m_st.xuy_ks;
+  a.term = (const S*)h->m_term; a.out = (S*)h->m_out; a.outn = (S*)h->m_outn; a.qblk = (S*)h->m_qblk;
+  a.trash = (S*)h->m_trash; a.x0 = (const S*)h->x0; a.xuy = (S*)h->m_xuy; a.delta_V = (S*)h->delta_V;
+  a.status = h->status; a.N = h->N; a.batch = h->batch; a.reg = reg; a.has_f = h->has_f && !h->ilqr_linear;
+  return a;
+}
+template <typename S>
+void mfma16_launch_backward(altro_hip_batch* h, double reg, bool sq) {
+  auto a = mfma16_args<S>(h, reg);
+  const dim3 grid(mf_grid(h->batch)), block(64);
+  if (sq && a.has_f) hipLaunchKernelGGL((mfma16_backward_kernel<true, true, S>), grid, block, 0, h->stream, a);
+  else if (sq) hipLaunchKernelGGL((mfma16_backward_kernel<true, false, S>), grid, block, 0, h->stream, a);
+  else if (a.has_f) hipLaunchKernelGGL((mfma16_backward_kernel<false, true, S>), grid, block, 0, h->stream, a);
+  else hipLaunchKernelGGL((mfma16_backward_kernel<false, false, S>), grid, block, 0, h->stream, a);
+}
+
+template <typename S>
+void mfma16_launch_forward(altro_hip_batch* h, const Mfma16Args<S>& a) {
+  // register-ring depth 3: depths 1..4 were measured, 3 is the knee
+  hipLaunchKernelGGL((mfma16_forward_kernel<S, 3>), dim3(mf_grid(h->batch)), dim3(64), 0, h->stream, a);
+}
+
+}  // namespace
+
+namespace altro_hip {
+namespace capi {
+
+int launch_backward(altro_hip_batch* h, double reg) {
+  ProfScope ps(h, 0);
+  if (h->plan == ALTRO_HIP_PLAN_MFMA16) {
+    const bool sq = (h->flags & ALTRO_HIP_STORE_QBLOCKS) != 0;
+    if (h->dtype == ALTRO_HIP_F64) mfma16_launch_backward<double>(h, reg, sq);
+    else if (sq || !(h->flags & ALTRO_HIP_F32_PURE)) mfma16_launch_backward<float>(h, reg, sq);   // fp32 storage, fp64 tiles
+    else {   // opt-in: pure fp32 on v_mfma_f32_16x16x4_f32
+      auto a = mfma16_args<float>(h, reg);
+      if (a.has_f) hipLaunchKernelGGL((mfma16_backward_f32_kernel<true, 3>), dim3(mf_grid(h->batch)), dim3(64), 0, h->stream, a);
+      else hipLaunchKernelGGL((mfma16_backward_f32_kernel<false, 3>), dim3(mf_grid(h->batch)), dim3(64), 0, h->stream, a);
+    }
+  } else if (h->plan == ALTRO_HIP_PLAN_LANE) {
+    return h->dtype == ALTRO_HIP_F64 ? lane_launch<double>(h, true, reg) : lane_launch<float>(h, true, reg);
+  } else if (h->dtype == ALTRO_HIP_F64) {
+    auto a = generic_args<double>(h, reg);
+    size_t lds = generic_backward_lds_bytes<double>(h->n, h->m);
+    hipLaunchKernelGGL(generic_backward_kernel<double>, dim3(h->batch), dim3(64), lds, h->stream, a);
+  } else {
+    auto a = generic_args<float>(h, reg);
+    size_t lds = generic_backward_lds_bytes<float>(h->n, h->m);
+    hipLaunchKernelGGL(generic_backward_kernel<float>, dim3(h->batch), dim3(64), lds, h->stream, a);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "backward launch: %s", hipGetErrorString(e));
+  return 0;
+}
+
+int launch_forward(altro_hip_batch* h) {
+  ProfScope ps(h, 1);
+  if (h->plan == ALTRO_HIP_PLAN_MFMA16) {
+    if (h->dtype == ALTRO_HIP_F64) {
+      auto a = mfma16_args<double>(h, 0.0);
+      mfma16_launch_forward<double>(h, a);
+    } else {
+      auto a = mfma16_args<float>(h, 0.0);
+      mfma16_launch_forward<float>(h, a);
+    }
+  } else if (h->plan == ALTRO_HIP_PLAN_LANE) {
+    return h->dtype == ALTRO_HIP_F64 ? lane_launch<double>(h, false, 0.0) : lane_launch<float>(h, false, 0.0);
+  } else if (h->dtype == ALTRO_HIP_F64) {
+    auto a = generic_args<double>(h, 0.0);
+    size_t lds = (size_t)(2 * h->n + h->m) * sizeof(double) + 64;
+    hipLaunchKernelGGL(generic_forward_kernel<double>, dim3(h->batch), dim3(64), lds, h->stream, a);
+  } else {
+    auto a = generic_args<float>(h, 0.0);
+    size_t lds = (size_t)(2 * h->n + h->m) * sizeof(float) + 64;
+    hipLaunchKernelGGL(generic_forward_kernel<float>, dim3(h->batch), dim3(64), lds, h->stream, a);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "forward launch: %s", hipGetErrorString(e));
+  return 0;
+}
+
+}  // namespace capi
+}  // namespace altro_hip
+
+extern "C" {
+
+int altro_hip_backward(altro_hip_batch* h, double reg) {
+  int rc = check(h);
+  if (rc) return rc;
+  if (!h->dyn_set || !h->cost_set) return fail(ALTRO_HIP_ERR_NOT_SET, "set_dynamics and set_cost must precede backward");
+  rc = launch_backward(h, reg);
+  if (!rc) h->backward_done = true;
+  return rc;
+}
+
+int altro_hip_forward_ltv(altro_hip_batch* h) {
+  int rc = check(h);
+  if (rc) return rc;
+  if (!h->backward_done) return fail(ALTRO_HIP_ERR_NOT_SET, "backward must precede forward_ltv");
+  if (!h->x0_set) return fail(ALTRO_HIP_ERR_NOT_SET, "set_initial_state must precede forward_ltv");
+  rc = launch_forward(h);
+  if (!rc) h->forward_done = true;
+  return rc;
+}
+
+int altro_hip_sweep(altro_hip_batch* h, double reg) {
+  int rc = altro_hip_backward(h, reg);
+  if (!rc) rc = altro_hip_forward_ltv(h);
+  return rc;
+}
+
+// MFMA layout self-test (tests/test_gpu_parity.py): max |D - (A B + C)| for random operands.
+double altro_hip_selftest_mfma_f64(int device) {
+  if (hipSetDevice(device) != hipSuccess) return -1.0;
+  double hA[64], hB[64], hC[256], hD[256];
+  unsigned s = 12345u;
+  auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (double)(s >> 8) / (1 << 24) - 0.5; };
+  for (double& v : hA) v = rnd();
+  for (double& v : hB) v = rnd();
+  for (double& v : hC) v = rnd();
+  double *dA, *dB, *dC, *dD;
+  if (hipMalloc(&dA, sizeof(hA)) != hipSuccess || hipMalloc(&dB, sizeof(hB)) != hipSuccess ||
+      hipMalloc(&dC, sizeof(hC)) != hipSuccess || hipMalloc(&dD, sizeof(hD)) != hipSuccess)
+    return -1.0;
+  (void)hipMemcpy(dA, hA, sizeof(hA), hipMemcpyHostToDevice);
+  (void)hipMemcpy(dB, hB, sizeof(hB), hipMemcpyHostToDevice);
+  (void)hipMemcpy(dC, hC, sizeof(hC), hipMemcpyHostToDevice);
+  hipLaunchKernelGGL(mfma16_selftest_kernel, dim3(1), dim3(64), 0, 0, dA, dB, dC, dD);
+  if (hipMemcpy(hD, dD, sizeof(hD), hipMemcpyDeviceToHost) != hipSuccess) return -1.0;
+  (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dC); (void)hipFree(dD);
+  double worst = 0.0;
+  for (int i = 0; i < 16; ++i)
+    for (int j = 0; j < 16; ++j) {
+      double ref = hC[i * 16 + j];
+      for (int k = 0; k < 4; ++k) ref += hA[i * 4 + k] * hB[k * 16 + j];
+      worst = std::max(worst, std::abs(ref - hD[i * 16 + j]));
+    }
+  return worst;
+}
+
+}  // extern "C"

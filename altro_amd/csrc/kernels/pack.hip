@@ -6,7 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "tvlqr_mfma16.hip"
+#include "mfma16_layout.h"
 
 namespace altro_hip {
 

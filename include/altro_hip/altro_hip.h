@@ -23,7 +23,8 @@
  *   altro_hip_add_linear_constraint <-> ALTROSolver::SetConstraint (altro_solver.cpp:192-223) with the AL / conic
  *                               terms of knotpoint_data.cpp:489-613 and cones.cpp:13-202
  *   altro_hip_shift_trajectory / update_linear_costs / get_knot <-> the MPC methods (altro_solver.cpp:266-293, 323-347)
- *   altro_hip_stats         <-> AltroStats (solver_stats.hpp:14-25), per batch instead of per solver
+ *   altro_hip_stats_*       <-> AltroStats (solver_stats.hpp:14-25) as SolverImpl::Solve fills it (solver.cpp:464-469,
+ *                               :492-509), reduced per batch on the device and across GPUs by RCCL
  *
  * The single-problem kernel boundary itself (the three tvlqr_* functions with the reference's exact
  * C++ signatures) is declared in include/tvlqr/tvlqr.h and exported by the same library.
@@ -58,7 +59,7 @@
 extern "C" {
 #endif
 
-#define ALTRO_HIP_VERSION 100
+#define ALTRO_HIP_VERSION 200
 #define ALTRO_HIP_TVLQR_SUCCESS (-1) /* tvlqr.h:11 */
 
 typedef struct altro_hip_batch altro_hip_batch; /* opaque handle */
@@ -279,15 +280,44 @@ double altro_hip_linesearch_host(altro_hip_merit_fn f, void* ctx, double alpha0,
                                  int try_cubic_first, int use_backtracking, double c1, double c2,
                                  int* status, int* iters, double* phi, double* dphi);
 
-/* ---- statistics (the only thing that ever crosses GPUs: SURVEY.md section 8e) ------------------ */
+/* ---- statistics: the only thing that ever crosses GPUs ---------------------
+ * What SolverImpl::Solve reports per solver (solver.cpp:464-469, :492-509; AltroStats, solver_stats.hpp:14-25),
+ * reduced over the problems of a batch ON THE DEVICE (one deterministic two-stage reduction kernel pair; nothing
+ * but this struct travels to the host), and -- across GPUs -- by two in-place ncclAllReduce calls (RCCL over
+ * xGMI) on the handle's stream: the sums as one ncclSum over doubles (counts are exact below 2^53), the maxima
+ * as one ncclMax.  Problem instances are sharded; there is no other collective on the path.                  */
 typedef struct altro_hip_stats {
-  int64_t problems;          /* batch                                                          */
-  int64_t cholesky_failures; /* problems whose status != -1                                     */
-  double sum_delta_V0;       /* sum over problems of delta_V[0]                                 */
-  double sum_delta_V1;       /* sum over problems of delta_V[1]                                 */
-  double max_abs_xN;         /* max |x_N| over problems (after a forward pass)                  */
+  int64_t problems;          /* problems reduced over (batch, or the global batch after an all-reduce)       */
+  int64_t cholesky_failures; /* problems whose last backward pass failed (status != -1, tvlqr.cpp:162-164)   */
+  int64_t converged;         /* SolveStatus::Success after the last altro_hip_ilqr_solve (0 before any)      */
+  int64_t iterations;        /* sum of AltroStats::iterations (solver.cpp:506)                               */
+  double sum_cost;           /* sum of the final merit value phi (AltroStats::objective_value)               */
+  double sum_delta_V0;       /* sum of delta_V[0] over the problems whose backward pass succeeded            */
+  double sum_delta_V1;       /* sum of delta_V[1]                                                            */
+  double max_stationarity;   /* max over problems (solver.cpp:207-222)                                       */
+  double max_feasibility;    /* max over problems (solver.cpp:224-231)                                       */
+  double max_abs_xN;         /* max |x_N| over problems (after a forward pass / solve)                       */
 } altro_hip_stats;
+/* this handle's problems only */
 int altro_hip_stats_reduce(altro_hip_batch* h, altro_hip_stats* out);
+
+/* One communicator rank per GPU.  RCCL is resolved at run time (dlopen of the librccl.so.1 the process already
+ * uses, else the system one): the library has no link-time dependency on it.
+ *   one process per GPU (the launch model of bench.py / torchrun / mpirun): rank 0 calls altro_hip_comm_unique_id,
+ *     the host program hands the 128 bytes to every rank by whatever channel it has, every rank calls
+ *     altro_hip_comm_create (ncclCommInitRank);
+ *   one process driving several GPUs: altro_hip_comm_create_all (ncclCommInitAll), then
+ *     altro_hip_stats_allreduce_multi with one handle per device (the calls are grouped, ncclGroupStart/End). */
+typedef struct altro_hip_comm altro_hip_comm;
+#define ALTRO_HIP_COMM_ID_BYTES 128
+int altro_hip_comm_unique_id(void* id /* [ALTRO_HIP_COMM_ID_BYTES] out */);
+int altro_hip_comm_create(altro_hip_comm** out, int device, int rank, int world, const void* id);
+int altro_hip_comm_create_all(altro_hip_comm** out /* [ndev] */, int ndev, const int* devices);
+void altro_hip_comm_destroy(altro_hip_comm* c);
+/* local device-side reduction, then the two all-reduces on h's stream; `out` holds the global statistics on every rank */
+int altro_hip_stats_allreduce(altro_hip_batch* h, altro_hip_comm* comm, altro_hip_stats* out);
+int altro_hip_stats_allreduce_multi(altro_hip_batch* const* handles, altro_hip_comm* const* comms, int n,
+                                    altro_hip_stats* out);
 
 /* ---- measurement -------------------------------------------------------------------------------- */
 /* When enabled every kernel launch is bracketed by hipEvents ON THE HANDLE'S STREAM and the elapsed

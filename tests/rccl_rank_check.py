@@ -41,6 +41,14 @@ def main():
     assert t[0].item() == batch and t[1].item() == st.sum_delta_V0
     red = shard.reduce_stats(st, device="cuda")
     assert red["problems"] == batch * world and red["cholesky_failures"] == 0
+    # the C ABI's own collective: a communicator built from an id that travelled over torch.distributed, two
+    # ncclAllReduce calls on the handle's stream (altro_hip_stats_allreduce)
+    comm = shard.make_comm(local_rank, rank, world)
+    glob = bt.stats(comm)
+    assert glob.problems == batch * world and glob.cholesky_failures == 0
+    assert abs(glob.sum_delta_V0 - red["sum_delta_V0"]) <= 1e-12 * abs(red["sum_delta_V0"])
+    assert glob.max_abs_xN == red["max_abs_xN"]
+    comm.close()
     assert shard.max_over_ranks(1.5 + rank, device="cuda") == 1.5 + (world - 1)
     assert np.array_equal(bt.get("K"), before)
     bt.close()

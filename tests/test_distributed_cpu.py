@@ -27,6 +27,12 @@ class _Stats:
         self.sum_delta_V0 = float(x0[:, 1].sum())
         self.sum_delta_V1 = float((x0[:, 2] ** 2).sum())
         self.max_abs_xN = float(np.abs(x0).max())
+        # the quantities SolverImpl::Solve reports, synthesised from the same slice
+        self.converged = int((x0[:, 3] > 0).sum())
+        self.iterations = int((np.abs(x0[:, 4]) * 10).astype(int).sum())
+        self.sum_cost = float((x0[:, 5] ** 2).sum())
+        self.max_stationarity = float(np.abs(x0[:, 6]).max())
+        self.max_feasibility = float(np.abs(x0[:, 7]).max())
 
 
 def _worker(rank, world, port, global_batch, n, out):
@@ -68,6 +74,10 @@ def test_sharding_and_stats_reduction_gloo():
         assert abs(red["sum_delta_V0"] - serial.sum_delta_V0) < 1e-9
         assert abs(red["sum_delta_V1"] - serial.sum_delta_V1) < 1e-9
         assert red["max_abs_xN"] == serial.max_abs_xN
+        assert red["converged"] == serial.converged and red["iterations"] == serial.iterations
+        assert abs(red["sum_cost"] - serial.sum_cost) < 1e-9
+        assert red["max_stationarity"] == serial.max_stationarity
+        assert red["max_feasibility"] == serial.max_feasibility
         assert r[4] == 2.0                                                       # max over ranks
 
 
