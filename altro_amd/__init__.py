@@ -31,7 +31,7 @@ C_ABI_SYMBOLS = [
     "altro_hip_stats_reduce", "altro_hip_comm_unique_id", "altro_hip_comm_create", "altro_hip_comm_create_all",
     "altro_hip_comm_destroy", "altro_hip_stats_allreduce", "altro_hip_stats_allreduce_multi",
     "altro_hip_profile_enable", "altro_hip_profile_reset",
-    "altro_hip_profile_get", "altro_hip_algorithmic_bytes",
+    "altro_hip_profile_get", "altro_hip_profile_get_range", "altro_hip_algorithmic_bytes",
     "altro_hip_set_model", "altro_hip_set_tracking_cost", "altro_hip_set_input_guess",
     "altro_hip_open_loop_rollout", "altro_hip_accept", "altro_hip_expand", "altro_hip_merit",
     "altro_hip_stationarity", "altro_hip_get_nominal", "altro_hip_get_expansion",
@@ -146,6 +146,7 @@ def lib():
         L.altro_hip_profile_enable.argtypes = [vp, i]
         L.altro_hip_profile_reset.argtypes = [vp]
         L.altro_hip_profile_get.argtypes = [vp, i, C.POINTER(i), C.POINTER(d), C.POINTER(C.c_char_p)]
+        L.altro_hip_profile_get_range.argtypes = [vp, i, C.POINTER(d), C.POINTER(d)]
         L.altro_hip_algorithmic_bytes.argtypes = [vp, i]
         L.altro_hip_algorithmic_bytes.restype = d
         L.altro_hip_set_model.argtypes = [vp, i, C.c_float, i, d, d]
@@ -268,8 +269,14 @@ class Batch:
         return s
 
     def profile(self, enable=True):
+        """True / 1: hipEvents + a wait per launch; 2: events only (read by profile_get), for use inside a timed region."""
         _check(self.L.altro_hip_profile_enable(self.h, int(enable)))
         _check(self.L.altro_hip_profile_reset(self.h))
+
+    def profile_range(self, slot):
+        lo, hi = C.c_double(), C.c_double()
+        _check(self.L.altro_hip_profile_get_range(self.h, slot, C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
 
     def profile_get(self, slot):
         n, ms, name = C.c_int(), C.c_double(), C.c_char_p()

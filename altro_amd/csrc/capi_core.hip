@@ -207,6 +207,7 @@ void altro_hip_batch_destroy(altro_hip_batch* h) {
   for (int a = 0; a < G_NUM; ++a) if (h->g_arr[a]) (void)hipFree(h->g_arr[a]);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
+  for (hipEvent_t e : h->prof_ev) if (e) (void)hipEventDestroy(e);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -464,19 +465,60 @@ int altro_hip_get_qblocks(altro_hip_batch* h, double* dst) {
 }
 
 int altro_hip_profile_enable(altro_hip_batch* h, int enable) {
-  if (!h) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "null handle");
-  h->prof = enable != 0;
+  int rc = check(h);
+  if (rc) return rc;
+  if (enable < 0 || enable > 2) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "profile mode %d (0 off, 1 per-launch sync, 2 events only)", enable);
+  if (enable == 2 && h->prof_ev.empty()) {
+    constexpr int kLaunches = 4096;   // launches one asynchronous window can hold (later ones go unrecorded)
+    h->prof_ev.resize(2 * kLaunches, nullptr);
+    h->prof_slot.assign(kLaunches, 0);
+    for (auto& e : h->prof_ev)
+      if (hipEventCreate(&e) != hipSuccess) {
+        for (auto& d : h->prof_ev) if (d) (void)hipEventDestroy(d);
+        h->prof_ev.clear();
+        return fail(ALTRO_HIP_ERR_HIP, "hipEventCreate failed");
+      }
+  }
+  if (h->prof == 2 && enable != 2) {   // leave nothing half-recorded behind
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->prof_n = 0;
+  }
+  h->prof = enable;
   return 0;
 }
 int altro_hip_profile_reset(altro_hip_batch* h) {
   if (!h) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "null handle");
+  if (h->prof == 2) { (void)hipSetDevice(h->device); (void)hipStreamSynchronize(h->stream); }
+  h->prof_n = 0;
   h->prof_launches[0] = h->prof_launches[1] = 0;
   h->prof_ms[0] = h->prof_ms[1] = 0.0;
+  h->prof_min[0] = h->prof_min[1] = h->prof_max[0] = h->prof_max[1] = 0.0;
   return 0;
 }
+namespace {
+int profile_drain(altro_hip_batch* h) {   // mode 2: turn the recorded event pairs into per-slot totals
+  if (h->prof_n == 0) return 0;
+  int rc = check(h);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  for (int i = 0; i < h->prof_n; ++i) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, h->prof_ev[2 * i], h->prof_ev[2 * i + 1]) != hipSuccess) continue;
+    const int slot = h->prof_slot[i];
+    h->prof_min[slot] = h->prof_launches[slot] ? std::min(h->prof_min[slot], (double)ms) : (double)ms;
+    h->prof_max[slot] = std::max(h->prof_max[slot], (double)ms);
+    h->prof_ms[slot] += ms;
+    h->prof_launches[slot] += 1;
+  }
+  h->prof_n = 0;
+  return 0;
+}
+}  // namespace
 int altro_hip_profile_get(altro_hip_batch* h, int slot, int* launches, double* total_ms,
                           const char** kernel_name) {
   if (!h || slot < 0 || slot > 1) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "bad handle or slot");
+  int rc = profile_drain(h);
+  if (rc) return rc;
   if (launches) *launches = h->prof_launches[slot];
   if (total_ms) *total_ms = h->prof_ms[slot];
   if (kernel_name) {
@@ -485,6 +527,14 @@ int altro_hip_profile_get(altro_hip_batch* h, int slot, int* launches, double* t
                                       {"lane_backward_kernel", "lane_forward_kernel"}};
     *kernel_name = names[h->plan == ALTRO_HIP_PLAN_MFMA16 ? 1 : (h->plan == ALTRO_HIP_PLAN_LANE ? 2 : 0)][slot];
   }
+  return 0;
+}
+int altro_hip_profile_get_range(altro_hip_batch* h, int slot, double* min_ms, double* max_ms) {
+  if (!h || slot < 0 || slot > 1) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "bad handle or slot");
+  int rc = profile_drain(h);
+  if (rc) return rc;
+  if (min_ms) *min_ms = h->prof_min[slot];
+  if (max_ms) *max_ms = h->prof_max[slot];
   return 0;
 }
 

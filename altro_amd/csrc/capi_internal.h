@@ -109,8 +109,13 @@ struct altro_hip_batch {
   // statistics reduction (capi_stats.hip): per-block partials and the reduced vector, on the device
   double *st_partial = nullptr, *st_red = nullptr;
   bool solve_done = false;   // altro_hip_ilqr_solve has run: the per-problem control blocks hold AltroStats
-  // profiling
-  bool prof = false;
+  // profiling: 0 off, 1 = events + a synchronisation per launch, 2 = events only (resolved by profile_get), so that
+  // the launches of a timed region can be bracketed without stalling the stream between them
+  int prof = 0;
+  std::vector<hipEvent_t> prof_ev;    // mode 2: pairs of events, one pair per recorded launch
+  std::vector<int> prof_slot;
+  int prof_n = 0;
+  double prof_min[2] = {0, 0}, prof_max[2] = {0, 0};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int last_sweeps = 0, last_merit_launches = 0;
   int prof_launches[2] = {0, 0};

@@ -56,21 +56,31 @@ GenericArgs<T> generic_args(altro_hip_batch* h, double reg) {
   return a;
 }
 
-struct ProfScope {
+struct ProfScope {   // brackets one kernel launch with hipEvents ON THE HANDLE'S STREAM (altro_hip_profile_enable)
   altro_hip_batch* h;
-  int slot;
+  int slot, idx = -1;
+  static void add(altro_hip_batch* h, int slot, float ms) {
+    h->prof_min[slot] = h->prof_launches[slot] ? std::min(h->prof_min[slot], (double)ms) : (double)ms;
+    h->prof_max[slot] = std::max(h->prof_max[slot], (double)ms);
+    h->prof_ms[slot] += ms;
+    h->prof_launches[slot] += 1;
+  }
   ProfScope(altro_hip_batch* h_, int slot_) : h(h_), slot(slot_) {
-    if (h->prof) (void)hipEventRecord(h->ev0, h->stream);
+    if (h->prof == 1) (void)hipEventRecord(h->ev0, h->stream);
+    else if (h->prof == 2 && 2 * (h->prof_n + 1) <= (int)h->prof_ev.size()) {
+      idx = h->prof_n++;
+      h->prof_slot[idx] = slot;
+      (void)hipEventRecord(h->prof_ev[2 * idx], h->stream);
+    }
   }
   ~ProfScope() {
-    if (h->prof) {
+    if (h->prof == 1) {
       (void)hipEventRecord(h->ev1, h->stream);
       (void)hipEventSynchronize(h->ev1);
       float ms = 0.f;
-      if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) {
-        h->prof_ms[slot] += ms;
-        h->prof_launches[slot] += 1;
-      }
+      if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) add(h, slot, ms);
+    } else if (idx >= 0) {
+      (void)hipEventRecord(h->prof_ev[2 * idx + 1], h->stream);   // no wait: altro_hip_profile_get reads them
     }
   }
 };

@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--horizon", type=int, default=256)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--repeat-seconds", type=float, default=2.0,
+                    help="after the K timed steps: this many seconds of back-to-back sweeps, min / median / max per step")
     ap.add_argument("--config", default="c1", choices=["c1", "c2", "c3", "c4"],
                     help="c1 = BASELINE.json configs[1] (the metric's config, default); extra lines: c2 = configs[2] "
                          "(pendulum n=2 m=1 N=100 batch=8192), c3 = configs[3] (bicycle n=4 m=2 N=50 batch=65536 "
@@ -114,6 +116,116 @@ def cpu_baseline(N, seconds):
                       "backward+forward, %s, 1 thread of %d on '%s'" % (done, N, t_used, flags, os.cpu_count(), cpu)}
 
 
+def eigen_probe():
+    """the reference's own CPU path needs Eigen >= 3.4 (deps/CMakeLists.txt:15-19), which is not
+    part of this image.  Probe for it so that the line SAYS which CPU path was timed."""
+    import shutil
+    import subprocess
+    import tempfile
+    gxx = shutil.which("g++")
+    if not gxx:
+        return "g++ not found: Eigen not probed; reference CPU path stated by restatement (oracle/, kind 'port')"
+    with tempfile.TemporaryDirectory() as td:
+        src = os.path.join(td, "p.cpp")
+        with open(src, "w") as f:
+            f.write("#include <Eigen/Dense>\n#if !EIGEN_VERSION_AT_LEAST(3, 4, 0)\n#error old\n#endif\nint main() { return 0; }\n")
+        for inc in ([], ["-I/usr/include/eigen3"], ["-I/usr/local/include/eigen3"], ["-I/opt/conda/include/eigen3"]):
+            r = subprocess.run([gxx, "-std=c++17", "-fsyntax-only"] + inc + [src], capture_output=True)
+            if r.returncode == 0:
+                return ("Eigen >= 3.4 found (%s) but no Eigen harness is shipped: the image this repo is built and tested on has "
+                        "no Eigen, so one could not be validated; CPU path = restatement (oracle/, kind 'port')" % (inc or ["default path"]))
+    return "Eigen not available on this host -- reference CPU path stated by restatement (oracle/tvlqr_oracle.c, kind 'port')"
+
+
+def timed_region(bt, args, world, dist, torch, shard):
+    """The contract's timing: W untimed sweeps, then EXACTLY K sweeps bracketed by barrier + synchronize on both sides,
+    max over ranks.  Every launch inside the region is bracketed by hipEvents on the handle's own stream without any
+    wait in between (profile mode 2), so the per-kernel durations belong to the same sweeps as the headline number."""
+    def barrier():
+        if world > 1:
+            dist.barrier()
+    for _ in range(args.warmup):
+        bt.sweep()
+    bt.profile(2)              # events only; reset after the warm-up
+    barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        bt.sweep()
+    torch.cuda.synchronize(); barrier()
+    elapsed = shard.max_over_ranks(time.perf_counter() - t0, device=RED_DEVICE)
+    kern = {}
+    for slot in (0, 1):
+        nl, ms, name = bt.profile_get(slot)
+        lo, hi = bt.profile_range(slot)
+        kern[slot] = {"name": name, "launches": nl, "avg_ms": ms / max(nl, 1), "min_ms": lo, "max_ms": hi}
+    bt.profile(0)
+    return elapsed, kern
+
+
+def repeat_block(bt, torch, ms_per_step, seconds):
+    """>= `seconds` of back-to-back sweeps AFTER the contract's K steps (which last only tens of milliseconds), without
+    events, timed in blocks on the host clock: the run-to-run spread of a sweep, in the line itself."""
+    if seconds <= 0:
+        return None
+    per_block = max(10, int(0.05 / max(ms_per_step * 1e-3, 1e-6)))     # ~50 ms per block
+    blocks, t_all = [], time.perf_counter()
+    while time.perf_counter() - t_all < seconds or len(blocks) < 5:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(per_block):
+            bt.sweep()
+        torch.cuda.synchronize()
+        blocks.append((time.perf_counter() - t0) / per_block * 1e3)
+        if len(blocks) >= 400:
+            break
+    blocks.sort()
+    return {"sweeps": per_block * len(blocks), "seconds": time.perf_counter() - t_all, "block_sweeps": per_block,
+            "ms_per_step": {"min": blocks[0], "median": blocks[len(blocks) // 2], "max": blocks[-1]},
+            "note": "host clock around blocks of back-to-back sweeps, no events, after the timed region"}
+
+
+def global_stats(bt, local_rank, rank, world, shard):
+    """the statistics reduction is the path's only collective.  Under RCCL (backend nccl) it is
+    the C ABI's own entry -- device-side reduction + two ncclAllReduce on the handle's stream; under the single-box
+    gloo test hook the same device-side reduction followed by the two torch.distributed calls."""
+    if RED_DEVICE == "cuda":
+        comm = shard.make_comm(local_rank, rank, world)
+        st = bt.stats(comm).as_dict()
+        comm.close()
+        st["reduced_by"] = "altro_hip_stats_allreduce (device-side reduction + 2 x ncclAllReduce, RCCL, world %d)" % world
+        return st
+    st = shard.reduce_stats(bt.stats(), device="cpu")
+    st["reduced_by"] = "altro_hip_stats_reduce (device) + torch.distributed gloo all_reduce (test hook)"
+    return st
+
+
+def roofline_block(cfg_key, batch, N, name_b, bytes_b, dur_b):
+    """`achieved` / `frac` follow the contract: SURVEY 8(d) ALGORITHMIC bytes per launch / measured duration / 8 TB/s.
+    `traffic` is the PMC byte count of a tracked earlier rocprofv3 run of the same command (profiles/pmc_traffic.json),
+    NOT a live counter read; `frac_traffic` prices those physical bytes against the same peak."""
+    traffic, source = None, None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        tj = json.load(open(tpath)).get(cfg_key) or {}
+        if tj.get("batch") == batch and tj.get("horizon") == N and tj.get("calibrated", True):
+            traffic = tj.get("backward_bytes_per_launch")
+            source = "profiles/pmc_traffic.json[%s] <- %s (tracked rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an " \
+                     "earlier run of this command; not measured in this run)" % (cfg_key, tj.get("profile"))
+    except (OSError, ValueError):
+        pass
+    ach = bytes_b / dur_b / 1e9
+    return {"bound": "hbm", "kernel": name_b, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": ach / HBM_PEAK_GBS, "frac_algorithmic": ach / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_source": source,
+            "traffic_GBps": (traffic / dur_b / 1e9) if traffic else None,
+            "frac_traffic": (traffic / dur_b / 1e9 / HBM_PEAK_GBS) if traffic else None,
+            "duration_ms": dur_b * 1e3,
+            "duration_source": "hipEvents on the handle's stream around every launch of the timed region (no wait between launches)",
+            "note": "frac = frac_algorithmic = SURVEY 8(d) bytes of the full n x n blocks / kernel time / 8 TB/s; the records "
+                    "hold the symmetric Q and P blocks as triangles, so the bytes that move (traffic) are fewer and "
+                    "frac_traffic is the physical HBM utilisation"}
+
+
 def lane_config(args, rank, local_rank, world, dist, torch):
     """Extra lines for the small-state configs (plan LANE, lane-per-problem SoA): the same sweep metric on the
     expansion of a nonlinear model, plus the time of one full batched AL-iLQR solve."""
@@ -151,24 +263,10 @@ def lane_config(args, rank, local_rank, world, dist, torch):
     bt.set_initial_state(x0)
     bt.open_loop_rollout(); bt.accept(); bt.expand()
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-    for _ in range(args.warmup):
-        bt.sweep()
-    barrier(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        bt.sweep()
-    torch.cuda.synchronize(); barrier()
-    elapsed = shard.max_over_ranks(time.perf_counter() - t0, device=RED_DEVICE)
-    bt.profile(True)
-    for _ in range(5):
-        bt.sweep()
-    bt.synchronize()
-    nb, ms_b, name_b = bt.profile_get(0)
-    nf, ms_f, name_f = bt.profile_get(1)
-    bt.profile(False)
+    elapsed, kern = timed_region(bt, args, world, dist, torch, shard)
+    rep = repeat_block(bt, torch, elapsed / args.steps * 1e3, args.repeat_seconds)
+    ms_b, nb, name_b = kern[0]["avg_ms"], 1, kern[0]["name"]
+    ms_f, nf, name_f = kern[1]["avg_ms"], 1, kern[1]["name"]
     # one full batched solve (all problems to convergence), timed on the host clock
     bt.set_input_guess(np.array([[[u_ref[0][0], 0.0]]]) if c3 else np.array([[[0.1]]]), k_stride_zero=True,
                        batch_stride_zero=True)
@@ -177,6 +275,7 @@ def lane_config(args, rank, local_rank, world, dist, torch):
     res = bt.ilqr_solve(iterations_max=80, use_backtracking=c3)
     torch.cuda.synchronize()
     t_solve = time.perf_counter() - t1
+    stats = global_stats(bt, local_rank, rank, world, shard)     # after the solve: the quantities Solve reports
     if rank == 0:
         bytes_b, bytes_f = bt.algorithmic_bytes(0), bt.algorithmic_bytes(1)
         dur_b = ms_b / nb * 1e-3
@@ -189,15 +288,15 @@ def lane_config(args, rank, local_rank, world, dist, torch):
                                     if c3 else "C2 pendulum swing-up (BASELINE.json configs[2])"),
                        "horizon_N": N, "n": n, "m": m, "batch_per_gpu": batch, "global_batch": batch * world,
                        "plan": "LANE (lane-per-problem SoA)",
-                       "kernels": {name_b: {"avg_ms": ms_b / nb, "GBps": bytes_b / dur_b / 1e9},
-                                   name_f: {"avg_ms": ms_f / nf, "GBps": bytes_f / (ms_f / nf * 1e-3) / 1e9}},
+                       "kernels": {name_b: dict(kern[0], GBps=bytes_b / dur_b / 1e9),
+                                   name_f: dict(kern[1], GBps=bytes_f / (ms_f / nf * 1e-3) / 1e9)},
+                       "repeat": rep, "stats": stats,
                        "full_solve": {"seconds": t_solve, "sweeps": int(res["sweeps"]),
                                       "merit_launches": int(res["merit_launches"]),
                                       "converged": int((res["status"] == 0).sum()),
                                       "mean_iterations": float(res["iterations"].mean()),
                                       "problems_per_s": batch / t_solve}},
-            "roofline": {"bound": "hbm", "kernel": name_b, "achieved": bytes_b / dur_b / 1e9, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": bytes_b / dur_b / 1e9 / HBM_PEAK_GBS, "traffic": None},
+            "roofline": roofline_block("c3" if c3 else "c2", batch, N, name_b, bytes_b, dur_b),
         }))
     bt.close()
     if world > 1:
@@ -214,6 +313,7 @@ def main():
     if world == 1 and not args.no_cpu_baseline and args.config == "c1":
         cpu_leg = cpu_baseline(args.horizon, args.cpu_seconds)
         cpu_leg["all_cores"] = cpu_all_cores(args.horizon)
+        cpu_leg["eigen"] = eigen_probe()
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -263,35 +363,11 @@ def main():
                     k_stride_zero=True, batch_stride_zero=True)
     bt.set_initial_state(x0)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-
-    for _ in range(args.warmup):
-        bt.sweep()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        bt.sweep()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
     from altro_amd import shard
-    elapsed = shard.max_over_ranks(elapsed, device=RED_DEVICE)
-
-    # solver statistics: the only thing that ever crosses GPUs (RCCL over xGMI, latency-bound)
-    stats = shard.reduce_stats(bt.stats(), device=RED_DEVICE)
-
-    # per-kernel durations from HIP events on the handle's stream (profile mode syncs per launch, so
-    # it runs after, never inside, the timed region)
-    bt.profile(True)
-    for _ in range(max(3, min(args.steps, 10))):
-        bt.sweep()
-    bt.synchronize()
-    nb, ms_b, name_b = bt.profile_get(0)
-    nf, ms_f, name_f = bt.profile_get(1)
-    bt.profile(False)
+    elapsed, kern = timed_region(bt, args, world, dist, torch, shard)
+    rep = repeat_block(bt, torch, elapsed / args.steps * 1e3, args.repeat_seconds)
+    ms_b, nb, name_b = kern[0]["avg_ms"], 1, kern[0]["name"]
+    ms_f, nf, name_f = kern[1]["avg_ms"], 1, kern[1]["name"]
 
     # the same batch as a full iLQR solve (rollout, expansion, backward sweep, merit-function line search,
     # convergence test; an LQ problem, so <= 3 sweeps), outside the timed region
@@ -310,6 +386,10 @@ def main():
         full_solve = {"seconds": t_solve, "sweeps": int(res["sweeps"]), "merit_launches": int(res["merit_launches"]),
                       "converged": int((res["status"] == 0).sum()), "problems_per_s": batch / t_solve}
 
+    # solver statistics -- the only thing that ever crosses GPUs (RCCL over xGMI, latency-bound) -- after the solve,
+    # so that the quantities SolverImpl::Solve reports are all populated (for c4: the sweep's quantities only)
+    stats = global_stats(bt, local_rank, rank, world, shard)
+
     if rank == 0:
         total_problems = batch * world
         sweeps_per_s = total_problems * args.steps / elapsed
@@ -317,15 +397,6 @@ def main():
         bytes_f = bt.algorithmic_bytes(1)
         dur_b = ms_b / nb * 1e-3
         dur_f = ms_f / nf * 1e-3
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):   # rocprofv3 --pmc passes of this same command (see profiles/README.md)
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("batch") == batch and tj.get("horizon") == N and not c4:
-                    traffic = tj.get("backward_bytes_per_launch")
-            except (OSError, ValueError):
-                traffic = None
         out = {
             "metric": "iLQR backward+forward sweeps/sec (N knotpoints x batch)",
             "value": sweeps_per_s,
@@ -347,21 +418,13 @@ def main():
                                "RCCL all-reduce of solver stats only" % world,
                 "plan": "MFMA16 (wave-per-problem, v_mfma_f64_16x16x4)",
                 "knotpoint_steps_per_s": sweeps_per_s * N,
-                "kernels": {name_b: {"avg_ms": ms_b / nb, "algorithmic_GB": bytes_b / 1e9,
-                                     "GBps": bytes_b / dur_b / 1e9},
-                            name_f: {"avg_ms": ms_f / nf, "algorithmic_GB": bytes_f / 1e9,
-                                     "GBps": bytes_f / dur_f / 1e9}},
+                "kernels": {name_b: dict(kern[0], algorithmic_GB=bytes_b / 1e9, GBps=bytes_b / dur_b / 1e9),
+                            name_f: dict(kern[1], algorithmic_GB=bytes_f / 1e9, GBps=bytes_f / dur_f / 1e9)},
+                "repeat": rep,
                 "stats": stats,
                 "ilqr_full_solve": full_solve,
             },
-            "roofline": {"bound": "hbm", "kernel": name_b, "achieved": bytes_b / dur_b / 1e9,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_b / dur_b / 1e9 / HBM_PEAK_GBS,
-                         "traffic": traffic,
-                         # the records hold only the upper triangles of the symmetric Q and P blocks, so the bytes
-                         # that actually move (PMC) are fewer than SURVEY 8(d)'s algorithmic count of full blocks
-                         "traffic_GBps": (traffic / dur_b / 1e9) if traffic else None,
-                         "note": "achieved = SURVEY 8(d) algorithmic bytes (full n x n blocks) / kernel time; "
-                                 "traffic = PMC bytes of the symmetric-packed records"},
+            "roofline": roofline_block(("c4pure" if args.c4_pure else "c4") if c4 else "c1", batch, N, name_b, bytes_b, dur_b),
         }
         if cpu_leg is not None:
             out["cpu_baseline"] = cpu_leg

@@ -320,12 +320,16 @@ int altro_hip_stats_allreduce_multi(altro_hip_batch* const* handles, altro_hip_c
                                     altro_hip_stats* out);
 
 /* ---- measurement -------------------------------------------------------------------------------- */
-/* When enabled every kernel launch is bracketed by hipEvents ON THE HANDLE'S STREAM and the elapsed
- * times are accumulated per kernel.  Slot 0 = backward kernel, 1 = forward kernel.                */
+/* Every launch of the sweep kernels is bracketed by hipEvents ON THE HANDLE'S STREAM (torch.cuda.Event would only see
+ * torch's current stream) and the elapsed times are accumulated per kernel: slot 0 = backward kernel, 1 = forward
+ * kernel.  enable = 1: the call waits for each launch (use outside timed regions); enable = 2: events only -- nothing
+ * waits between launches, altro_hip_profile_get / _get_range synchronise the stream and read up to 4096 recorded
+ * launches -- so the launches of a timed region are measured where they run; 0 = off.                           */
 int altro_hip_profile_enable(altro_hip_batch* h, int enable);
 int altro_hip_profile_reset(altro_hip_batch* h);
 int altro_hip_profile_get(altro_hip_batch* h, int slot, int* launches, double* total_ms,
                           const char** kernel_name);
+int altro_hip_profile_get_range(altro_hip_batch* h, int slot, double* min_ms, double* max_ms);
 /* Algorithmic bytes one launch of the slot's kernel must move.             */
 double altro_hip_algorithmic_bytes(const altro_hip_batch* h, int slot);
 
