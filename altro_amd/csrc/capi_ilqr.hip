@@ -604,8 +604,13 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
   h->spec_trials = 1;
   struct MaskGuard {   // the backward sweep skips problems that have stopped, only inside this loop
     altro_hip_batch* h;
-    ~MaskGuard() { h->bwd_active = nullptr; h->bwd_reg = nullptr; }
-  } mask_guard{h};
+    int* active0;
+    ~MaskGuard() {   // whatever path leaves the solve: no speculation state, mask or swapped pointer survives it
+      h->bwd_active = nullptr; h->bwd_reg = nullptr;
+      h->spec_trials = 1; h->spec_pre = 0;
+      h->i_active = active0;
+    }
+  } mask_guard{h, h->i_active};
   h->bwd_active = h->i_active;
   h->bwd_reg = reg_on ? h->i_reg : nullptr;
   int total_reg_retries = 0;
@@ -721,6 +726,7 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
   }
   h->forward_done = true;
   h->solve_done = true;
+  HIP_TRY(hipStreamSynchronize(h->stream));   // (iterations_max <= 0 reaches this point with kernels still in flight)
   if (results) {
     std::vector<IlqrProb> pr(h->batch);
     HIP_TRY(hipMemcpy(pr.data(), h->i_prob, pr.size() * sizeof(IlqrProb), hipMemcpyDeviceToHost));

@@ -550,7 +550,17 @@ ErrorCodes SolverImpl::Solve() {   // solver.cpp:414-511
   int iter;
   for (iter = 0; iter < opts.iterations_max; ++iter) {
     for (auto& kp : data) kp.CostHessian_();   // CalcExpansions
-    BackwardPass();                            // return value ignored, as solver.cpp:449 does
+    BackwardPass();                            // a Cholesky failure (k >= 0) is ignored, as solver.cpp:449 does
+    if (backward_status < TVLQR_SUCCESS) {     // ... but "the device pass did not run" is not a reference case: K, d, P, p
+      // were never written, and iterating on them would spin to iterations_max with alpha = 0 and no diagnostic
+      std::fprintf(stderr, "altro: tvlqr_BackwardPass did not run (%s); the HIP path has no CPU fallback\n",
+                   backward_status == TVLQR_NO_DEVICE ? "no usable HIP device or a device allocation / copy failed"
+                                                      : "a state or input dimension exceeds 32");
+      stats.status = SolveStatus::Unsolved;
+      stats.iterations = iter;
+      stats.solve_time = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start);
+      return ErrorCodes::BackwardPassFailed;
+    }
     ErrorCodes err = ForwardPass(&alpha);
     if (!(err == ErrorCodes::NoError || err == ErrorCodes::MeritFunctionGradientTooSmall)) {
       PrintErrorCode(err);

@@ -7,6 +7,7 @@
 #pragma once
 #include <algorithm>
 #include <cmath>
+#include <vector>
 
 #include "altro/solver/typedefs.hpp"
 
@@ -73,15 +74,17 @@ inline void ProjectionJacobian(ConstraintType cone, int dim, const double* x, do
         for (int i = 0; i < dim; ++i) J[i + (size_t)i * dim] = 1.0;
         break;
       }
-      const double c = 0.5 * (1 + s / a);
-      for (int j = 0; j < nv; ++j)
-        for (int i = 0; i < nv; ++i) {
-          double v = -0.5 * s / (a * a * a) * x[i] * x[j];
-          v += (i == j) ? c : 0;
-          J[i + (size_t)j * dim] = v;
-        }
-      for (int i = 0; i < nv; ++i) J[i + (size_t)nv * dim] = 0.5 * x[i] / a;
-      for (int j = 0; j < nv; ++j) J[nv + (size_t)j * dim] = ((-0.5 * s / (a * a)) + c / a) * x[j];
+      // outside: P(v, s) = ((a + s) / 2) (u, 1) with u = v / a, hence
+      //   J = 1/2 [ I + (s/a) (I - u u^T)   u ]
+      //           [ u^T                     1 ]
+      std::vector<double> u((size_t)nv);
+      const double inv_a = 1.0 / a, t = s * inv_a;
+      for (int i = 0; i < nv; ++i) u[i] = x[i] * inv_a;
+      for (int j = 0; j < nv; ++j) {
+        for (int i = 0; i < nv; ++i) J[i + (size_t)j * dim] = 0.5 * (((i == j) ? 1.0 + t : 0.0) - t * u[i] * u[j]);
+        J[nv + (size_t)j * dim] = 0.5 * u[j];
+        J[j + (size_t)nv * dim] = 0.5 * u[j];
+      }
       J[nv + (size_t)nv * dim] = 0.5;
     } break;
   }
@@ -91,33 +94,25 @@ inline void ProjectionJacobian(ConstraintType cone, int dim, const double* x, do
 inline void ProjectionHessian(ConstraintType cone, int dim, const double* x, const double* b, double* H) {
   std::fill(H, H + (size_t)dim * dim, 0.0);
   if (cone != ConstraintType::SECOND_ORDER_CONE) return;
+  // Second derivative of g(x) = b^T P(x) outside the cone, P(v, s) = ((a + s) / 2) (u, 1), a = |v|, u = v / a.
+  // With Pi = I - u u^T, gamma = u^T b_v and w = Pi b_v (the part of b_v orthogonal to v):
+  //   d2g/dv dv^T = 1/(2a) [ (b_s - (s/a) gamma) Pi - (s/a) (w u^T + u w^T) ]
+  //   d2g/dv ds   = w / (2a),        d2g/ds ds = 0
+  // (the u u^T terms of the individual pieces cancel); inside or below the cone P is linear and the Hessian vanishes.
   const int nv = dim - 1;
-  const double s = x[nv], bs = b[nv];
-  double vbv = 0.0, a = 0.0;
-  for (int i = 0; i < nv; ++i) { a += x[i] * x[i]; vbv += x[i] * b[i]; }
-  a = std::sqrt(a);
+  const double s = x[nv], a = soc_norm(nv, x);
   if (a <= -s || a <= s) return;
-  for (int i = 0; i < nv; ++i) {
-    double hi = 0.0;
-    for (int j = 0; j < nv; ++j) {
-      double Hij = -x[i] * x[j] / (a * a);
-      Hij += (i == j) ? 1 : 0;
-      hi += Hij * b[j];
-    }
-    H[i + (size_t)nv * dim] = hi / (2 * a);
-    H[nv + (size_t)i * dim] = hi / (2 * a);
-    for (int j = 0; j <= i; ++j) {
-      const double vij = x[i] * x[j];
-      const double H1 = hi * x[j] * (-s / (a * a * a));
-      double H2 = vij * (2 * vbv) / (a * a * a * a) - x[i] * b[j] / (a * a);
-      double H3 = -vij / (a * a);
-      if (i == j) { H2 -= vbv / (a * a); H3 += 1; }
-      H2 *= s / a;
-      H3 *= bs / a;
-      const double v = (H1 + H2 + H3) / 2.0;
-      H[i + (size_t)j * dim] = v;
-      H[j + (size_t)i * dim] = v;
-    }
+  std::vector<double> u((size_t)nv), w((size_t)nv);
+  const double inv_a = 1.0 / a, half = 0.5 * inv_a, t = s * inv_a;
+  double gamma = 0.0;
+  for (int i = 0; i < nv; ++i) { u[i] = x[i] * inv_a; gamma += u[i] * b[i]; }
+  for (int i = 0; i < nv; ++i) w[i] = b[i] - gamma * u[i];
+  const double kappa = b[nv] - t * gamma;
+  for (int j = 0; j < nv; ++j) {
+    for (int i = 0; i < nv; ++i)
+      H[i + (size_t)j * dim] = half * (kappa * (((i == j) ? 1.0 : 0.0) - u[i] * u[j]) - t * (w[i] * u[j] + u[i] * w[j]));
+    H[nv + (size_t)j * dim] = half * w[j];
+    H[j + (size_t)nv * dim] = half * w[j];
   }
 }
 

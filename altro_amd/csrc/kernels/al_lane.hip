@@ -66,72 +66,62 @@ __device__ __forceinline__ void soc_jacobian(int p, const T* x, T* J) {
       if (i < p) J[i + i * AL_MAXSOC] = T(1);
     return;
   }
-  const T c = T(0.5) * (T(1) + s / a);
+  // outside: P(v, s) = ((a + s) / 2) (u, 1), u = v / a  =>  J = 1/2 [ I + (s/a)(I - u u^T), u ; u^T, 1 ]
+  const T inv_a = T(1) / a, t = s * inv_a;
+  T u[AL_MAXSOC];
+#pragma unroll
+  for (int i = 0; i < AL_MAXSOC; ++i) u[i] = (i < nn) ? x[i] * inv_a : T(0);
 #pragma unroll
   for (int j = 0; j < AL_MAXSOC; ++j)
 #pragma unroll
     for (int i = 0; i < AL_MAXSOC; ++i) {
       T v = T(0);
-      if (i < nn && j < nn) {
-        v = T(-0.5) * s / (a * a * a) * x[i] * x[j];
-        v += (i == j) ? c : T(0);
-      } else if (i < nn && j == nn) {
-        v = T(0.5) * x[i] / a;
-      } else if (i == nn && j < nn) {
-        v = ((T(-0.5) * s / (a * a)) + c / a) * x[j];
-      } else if (i == nn && j == nn) {
-        v = T(0.5);
-      }
+      if (i < nn && j < nn) v = T(0.5) * (((i == j) ? T(1) + t : T(0)) - t * u[i] * u[j]);
+      else if (i < nn && j == nn) v = T(0.5) * u[i];
+      else if (i == nn && j < nn) v = T(0.5) * u[j];
+      else if (i == nn && j == nn) v = T(0.5);
       J[i + j * AL_MAXSOC] = v;
     }
 }
 
-// cones.cpp:79-123: H = d/dx [J(x)^T b]
+// H = d2/dx2 [b^T P(x)] (what cones.cpp:79-123 returns), from the closed form: outside the cone, with a = |v|, u = v / a,
+// Pi = I - u u^T, gamma = u^T b_v, w = Pi b_v:
+//   Hvv = 1/(2a) [ (b_s - (s/a) gamma) Pi - (s/a)(w u^T + u w^T) ],   Hvs = w / (2a),   Hss = 0;
+// zero inside and below the cone (P is linear there).  Column-major, leading dimension AL_MAXSOC.
 template <typename T>
 __device__ __forceinline__ void soc_hessian(int p, const T* x, const T* bb, T* H) {
   const int nn = p - 1;
-  T s = T(0), bs = T(0), a = T(0), vbv = T(0);
+  T s = T(0), bs = T(0), a = T(0);
 #pragma unroll
   for (int i = 0; i < AL_MAXSOC; ++i) {
-    if (i < nn) { a += x[i] * x[i]; vbv += x[i] * bb[i]; }
+    if (i < nn) a += x[i] * x[i];
     if (i == nn) { s = x[i]; bs = bb[i]; }
   }
   a = sqrt(a);
 #pragma unroll
   for (int i = 0; i < AL_MAXSOC * AL_MAXSOC; ++i) H[i] = T(0);
   if (a <= -s || a <= s) return;
+  const T inv_a = T(1) / a, half = T(0.5) * inv_a, t = s * inv_a;
+  T u[AL_MAXSOC], w[AL_MAXSOC];
+  T gamma = T(0);
 #pragma unroll
   for (int i = 0; i < AL_MAXSOC; ++i) {
-    if (i >= nn) continue;
-    T hi = T(0);
-#pragma unroll
-    for (int j = 0; j < AL_MAXSOC; ++j) {
-      if (j >= nn) continue;
-      T Hij = -x[i] * x[j] / (a * a);
-      Hij += (i == j) ? T(1) : T(0);
-      hi += Hij * bb[j];
-    }
-#pragma unroll
-    for (int r = 0; r < AL_MAXSOC; ++r)
-      if (r == nn) {
-        H[i + r * AL_MAXSOC] = hi / (T(2) * a);
-        H[r + i * AL_MAXSOC] = hi / (T(2) * a);
-      }
-#pragma unroll
-    for (int j = 0; j < AL_MAXSOC; ++j) {
-      if (j > i) continue;
-      const T vij = x[i] * x[j];
-      const T H1 = hi * x[j] * (-s / (a * a * a));
-      T H2 = vij * (T(2) * vbv) / (a * a * a * a) - x[i] * bb[j] / (a * a);
-      T H3 = -vij / (a * a);
-      if (i == j) { H2 -= vbv / (a * a); H3 += T(1); }
-      H2 *= s / a;
-      H3 *= bs / a;
-      const T v = (H1 + H2 + H3) / T(2);
-      H[i + j * AL_MAXSOC] = v;
-      H[j + i * AL_MAXSOC] = v;
-    }
+    u[i] = (i < nn) ? x[i] * inv_a : T(0);
+    gamma += u[i] * ((i < nn) ? bb[i] : T(0));
   }
+#pragma unroll
+  for (int i = 0; i < AL_MAXSOC; ++i) w[i] = (i < nn) ? bb[i] - gamma * u[i] : T(0);
+  const T kappa = bs - t * gamma;
+#pragma unroll
+  for (int j = 0; j < AL_MAXSOC; ++j)
+#pragma unroll
+    for (int i = 0; i < AL_MAXSOC; ++i) {
+      T v = T(0);
+      if (i < nn && j < nn) v = half * (kappa * (((i == j) ? T(1) : T(0)) - u[i] * u[j]) - t * (w[i] * u[j] + u[i] * w[j]));
+      else if (i < nn && j == nn) v = half * w[i];
+      else if (i == nn && j < nn) v = half * w[j];
+      H[i + j * AL_MAXSOC] = v;
+    }
 }
 
 // All AL terms of one knot point of one problem.  Returns the AL cost; subtracts the gradient terms from

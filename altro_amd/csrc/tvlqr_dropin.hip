@@ -50,6 +50,8 @@ struct Workspace {   // cached per thread: no allocation after the first call of
   std::vector<int64_t> off;
   std::vector<int> dims;
   ~Workspace() {
+    int c = 0;   // thread / process teardown: the HIP runtime may already be gone -- then there is nothing left to free
+    if (hipGetDeviceCount(&c) != hipSuccess || c <= 0) return;
     if (dev) (void)hipFree(dev);
     if (dev_off) (void)hipFree(dev_off);
     if (dev_dims) (void)hipFree(dev_dims);
@@ -61,6 +63,13 @@ thread_local Workspace g_ws;
 bool have_device() {
   int c = 0;
   return hipGetDeviceCount(&c) == hipSuccess && c > 0;
+}
+
+// the GENERIC kernels stage every block through fixed LDS images: state / input dimensions up to 32
+bool dims_supported(const int* nx, const int* nu, int N) {
+  for (int k = 0; k <= N; ++k)
+    if (nx[k] < 0 || nx[k] > 32 || (k < N && (nu[k] < 0 || nu[k] > 32))) return false;
+  return true;
 }
 
 // Lays every array's knot-point blocks out in one arena; returns the arena size in elements.
@@ -112,15 +121,17 @@ int prepare(Workspace& w, const Layout& L, const int* nx, const int* nu) {
   if (w.dev_elems < (size_t)L.total) {
     if (w.dev) (void)hipFree(w.dev);
     w.dev = nullptr;
-    if (hipMalloc(&w.dev, (size_t)L.total * sizeof(double)) != hipSuccess) return -1;
+    w.dev_elems = 0;
+    if (hipMalloc(&w.dev, (size_t)L.total * sizeof(double)) != hipSuccess) { w.dev = nullptr; return -1; }
     w.dev_elems = (size_t)L.total;
     w.host.resize((size_t)L.total);
   }
   if (w.table_k < (size_t)(N + 1)) {
     if (w.dev_off) (void)hipFree(w.dev_off);
     if (w.dev_dims) (void)hipFree(w.dev_dims);
-    if (hipMalloc(&w.dev_off, (size_t)(N + 1) * G_NUM * sizeof(int64_t)) != hipSuccess) return -1;
-    if (hipMalloc(&w.dev_dims, (size_t)(N + 1) * 2 * sizeof(int)) != hipSuccess) return -1;
+    w.dev_off = nullptr; w.dev_dims = nullptr; w.table_k = 0;   // nothing dangling if an allocation below fails
+    if (hipMalloc(&w.dev_off, (size_t)(N + 1) * G_NUM * sizeof(int64_t)) != hipSuccess) { w.dev_off = nullptr; return -1; }
+    if (hipMalloc(&w.dev_dims, (size_t)(N + 1) * 2 * sizeof(int)) != hipSuccess) { w.dev_dims = nullptr; return -1; }
     w.table_k = (size_t)(N + 1);
   }
   if (!w.dev_status && hipMalloc(&w.dev_status, sizeof(int)) != hipSuccess) return -1;
@@ -162,8 +173,7 @@ int tvlqr_BackwardPass(const int* nx, const int* nu, int num_horizon, const lqr_
   (void)linear_only_update;   // accepted and ignored, like tvlqr.cpp:78
   if (!have_device()) return TVLQR_NO_DEVICE;
   const int N = num_horizon;
-  for (int k = 0; k <= N; ++k)
-    if (nx[k] > 32 || (k < N && nu[k] > 32)) return TVLQR_NO_DEVICE;
+  if (!dims_supported(nx, nu, N)) return TVLQR_UNSUPPORTED_SIZE;
   Workspace& w = g_ws;
   const Layout L = make_layout(nx, nu, N, is_diag);
   if (prepare(w, L, nx, nu)) return TVLQR_NO_DEVICE;
@@ -231,6 +241,7 @@ int tvlqr_ForwardPass(const int* nx, const int* nu, int num_horizon, const lqr_f
                       const lqr_float* x0, lqr_float** x, lqr_float** u, lqr_float** y) {
   if (!have_device()) return TVLQR_NO_DEVICE;
   const int N = num_horizon;
+  if (!dims_supported(nx, nu, N)) return TVLQR_UNSUPPORTED_SIZE;   // x0 staging and the kernels' LDS images assume <= 32
   Workspace& w = g_ws;
   const Layout L = make_layout(nx, nu, N, false);
   if (prepare(w, L, nx, nu)) return TVLQR_NO_DEVICE;
