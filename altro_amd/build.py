@@ -55,7 +55,7 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=min(len(units), os.cpu_count() or 4)) as ex:
         objs = list(ex.map(compile_one, units))
-    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-o", LIB]
+    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-Wl,-soname,libaltro_hip.so"] + objs + ["-o", LIB]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
