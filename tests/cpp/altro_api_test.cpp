@@ -123,6 +123,34 @@ static void test_di_unconstrained() {
   std::printf("   iterations = %d, |xN - xf| = %.3e, solve time %.2f ms\n", s.GetIterations(), dist(xN, p.xf), s.GetSolveTimeMs());
 }
 
+// BASELINE.json configs[0] names the double integrator at N = 50 (the reference's own test uses N = 10,
+// double_integrator_test.cpp:69-85; SURVEY.md 4.2: "support both").  Same problem, 50 steps of h = tf / 50: one LQ
+// iteration, and the end state / first input the CPU oracle gives for it (tests/golden/dense_fixtures.npz, solve_di_n50).
+static void test_di_unconstrained_n50() {
+  std::printf("[double integrator] unconstrained, N = 50 (BASELINE.json configs[0])\n");
+  DIProblem p; p.N = 50; p.h = (float)(5.0f / 50.0f); p.x0 = {1.0, 2.0, 0.0, 0.0};
+  ALTROSolver s(p.N);
+  di_setup(s, p);
+  EXPECT(s.Initialize() == ErrorCodes::NoError);
+  di_guess(s, p);
+  AltroOptions o; o.iterations_max = 3;
+  s.SetOptions(o);
+  EXPECT(s.Solve() == SolveStatus::Success);
+  EXPECT(s.GetIterations() == 1);
+  std::vector<double> xN(4), u0(2);
+  s.GetState(xN.data(), p.N);
+  s.GetInput(u0.data(), 0);
+  const double xN_ref[4] = {0.01395607778542234, 0.02791215557084468, -0.0015793690701396, -0.0031587381402792};
+  const double u0_ref[2] = {-5.893250749690505, -11.78650149938101};
+  double e = 0;
+  for (int i = 0; i < 4; ++i) e = std::fmax(e, std::fabs(xN[i] - xN_ref[i]));
+  for (int i = 0; i < 2; ++i) e = std::fmax(e, std::fabs(u0[i] - u0_ref[i]));
+  std::printf("   iterations = %d, |xN - xf| = %.3e, max deviation from the oracle's fixture %.2e\n", s.GetIterations(),
+              dist(xN, p.xf), e);
+  EXPECT(e < 1e-10);
+  EXPECT(dist(xN, p.xf) < dist(p.x0, p.xf) && dist(xN, p.xf) > 1e-3);   // double_integrator_test.cpp:165-166
+}
+
 static void test_di_goal() {
   std::printf("[double integrator] terminal goal constraint (EQUALITY)\n");
   DIProblem p; p.x0 = {1.0, 2.0, 0.0, 0.0};
@@ -276,6 +304,7 @@ static void test_pendulum(bool constrained) {
 int main() {
   test_constructor_and_errors();
   test_di_unconstrained();
+  test_di_unconstrained_n50();
   test_di_goal();
   test_di_bounds();
   test_di_soc();
