@@ -97,6 +97,7 @@ Mfma16Args<S> mfma16_args(altro_hip_batch* h, double reg) {
   a.term = (const S*)h->m_term; a.out = (S*)h->m_out; a.outn = (S*)h->m_outn; a.qblk = (S*)h->m_qblk;
   a.trash = (S*)h->m_trash; a.x0 = (const S*)h->x0; a.xuy = (S*)h->m_xuy; a.delta_V = (S*)h->delta_V;
   a.status = h->status; a.N = h->N; a.batch = h->batch; a.reg = reg; a.has_f = h->has_f && !h->ilqr_linear;
+  a.active = h->bwd_active; a.reg_pp = h->bwd_reg;   // set only inside altro_hip_ilqr_solve
   return a;
 }
 template <typename S>

@@ -108,6 +108,8 @@ struct Mfma16Args {
   int batch;
   double reg;
   int has_f;
+  const int* active;     // optional per-problem mask: the batched solver skips problems that have stopped (backward only)
+  const double* reg_pp;  // optional per-problem regularisation (overrides reg): the solver's retry schedule
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -176,6 +178,7 @@ __global__ __launch_bounds__(64, 4) void mfma16_backward_kernel(Mfma16Args<S> a)
   const int j = lane & 15, g = lane >> 4;
   const int b = mf_problem(blockIdx.x, a.batch);
   if (b >= a.batch) return;
+  if (a.active && !a.active[b]) return;   // wave-uniform: the whole problem is skipped, its outputs stay as they are
   const int N = a.N;
   if (lane < 2) lds[80 + lane] = 0.0;
   // loop-invariant LDS read addresses (element indices into S)
@@ -220,6 +223,7 @@ __global__ __launch_bounds__(64, 4) void mfma16_backward_kernel(Mfma16Args<S> a)
   // per-lane partial sums of the expected decrease; only column 12 is meaningful, reduced at the end
   double dv0 = 0.0, dv1 = 0.0;
   int fail_k = -1;
+  const double reg = a.reg_pp ? a.reg_pp[b] : a.reg;
 
   Mfma16Knot cur, nxt;
   mfma16_load_knot<HAS_F, S>(cur, in + (size_t)(N - 1) * a.in_ks, cin + (size_t)(N - 1) * a.cin_ks, lane, j, g, qo);
@@ -281,7 +285,6 @@ __global__ __launch_bounds__(64, 4) void mfma16_backward_kernel(Mfma16Args<S> a)
 
     // ---- Cholesky of Quu + reg I (lower; fail when a pivot is <= 0: tvlqr.cpp:159-164) -----------
     // Only the reciprocal pivots i_k = 1/L_kk are needed by the substitutions below.
-    const double reg = a.reg;
     const double x0 = a00 + reg;
     const double i0 = rsqrt_nr(x0);
     const double l10 = a10 * i0, l20 = a20 * i0, l30 = a30 * i0;

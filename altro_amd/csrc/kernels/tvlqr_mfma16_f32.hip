@@ -79,6 +79,7 @@ __global__ __launch_bounds__(64, 4) void mfma16_backward_f32_kernel(Mfma16Args<f
   const int j = lane & 15, g = lane >> 4;
   const int b = mf_problem(blockIdx.x, a.batch);
   if (b >= a.batch) return;
+  if (a.active && !a.active[b]) return;
   const int N = a.N;
   const bool g3 = (g == 3);          // lane group 3 holds rows 12..15: no rows of Z / Q / P
   if (lane < 2) lds[80 + lane] = 0.0f;
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(64, 4) void mfma16_backward_f32_kernel(Mfma16Args<f
   }
   float dv0 = 0.0f, dv1 = 0.0f;
   int fail_k = -1;
-  const float reg = (float)a.reg;
+  const float reg = (float)(a.reg_pp ? a.reg_pp[b] : a.reg);
 
   Mfma16KnotF32 ring[DEPTH];
 #pragma unroll

@@ -179,8 +179,7 @@ int altro_hip_get_qblocks(altro_hip_batch* h, double* qblocks);
  * altro_hip_set_dynamics, the reference's SetLinearDynamics path (knotpoint_data.cpp:123-142, :406-419,
  * :710-719) -- with the tracking cost below; no altro_hip_set_model.  From altro_hip_set_tracking_cost on, the
  * backward sweep of such a handle ignores f, as the reference's expansion does (f_.setZero(), :416), while the
- * rollout keeps it.  Constraint blocks (all four cones) work on both plans; the regularisation schedule is a
- * plan-LANE feature.                                                                                    */
+ * rollout keeps it.  Constraint blocks (all four cones) and the regularisation schedule work on both plans.  */
 /* Device model standing in for SetExplicitDynamics' host callbacks (altro_solver.cpp:68-81).        */
 int altro_hip_set_model(altro_hip_batch* h, int model, float timestep, int bicycle_frame,
                         double bicycle_length, double bicycle_lr);

@@ -275,3 +275,27 @@ def test_second_order_cone_block_mfma16():
         np.testing.assert_allclose(u[b], s.get("u"), rtol=1e-5, atol=1e-5)
         assert np.linalg.norm(u[b][:, :3], axis=1).max() <= 0.35 + 2e-4
     assert nconv >= 2
+
+
+def test_regularisation_retry_on_plan_mfma16():
+    """SURVEY.md section 8 row f4 on the metric's own shape: the reference keeps reg = 0 and ignores
+    a failed Cholesky (tvlqr.cpp:159-164, solver.cpp:363, :373-377) -- the default -- and with reg_retry_max > 0 the
+    problems whose Quu is indefinite repeat the wave-per-problem backward sweep with a growing per-problem reg while
+    the others keep reg = 0 and their bits."""
+    batch = 40
+    p = make_problem(batch, True)
+    bad = np.arange(batch) % 5 == 2                      # every fifth problem: R = -0.3 I  ->  Quu indefinite
+    p["Rd"] = p["Rd"].copy(); p["Rd"][bad] = -0.3
+    bt = make_hip(p)
+    res = bt.ilqr_solve(iterations_max=2)                # reference behaviour: failures ignored, no retry
+    st = bt.get("status")
+    assert (res["reg_retries"] == 0).all() and (st[bad] != -1).all() and (st[~bad] == -1).all()
+    good_x = bt.get_nominal()[0][~bad].copy()
+    bt2 = make_hip(p)
+    res2 = bt2.ilqr_solve(iterations_max=2, reg_retry_max=6, reg_min=0.01, reg_scale=10.0)
+    st2 = bt2.get("status")
+    assert (st2 == -1).all(), st2
+    assert (res2["reg_retries"][bad] >= 2).all() and (res2["reg_retries"][~bad] == 0).all(), res2["reg_retries"]
+    assert np.isfinite(bt2.get("K")).all() and np.isfinite(bt2.get_nominal()[0]).all()
+    assert np.array_equal(bt2.get_nominal()[0][~bad], good_x)     # well-posed problems are untouched by the option
+    bt.close(); bt2.close()
