@@ -279,7 +279,7 @@ def lane_config(args, rank, local_rank, world, dist, torch):
     if rank == 0:
         bytes_b, bytes_f = bt.algorithmic_bytes(0), bt.algorithmic_bytes(1)
         dur_b = ms_b / nb * 1e-3
-        print(json.dumps({
+        emit(({
             "metric": "iLQR backward+forward sweeps/sec (N knotpoints x batch)",
             "value": batch * world * args.steps / elapsed, "unit": "problem-sweeps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -303,8 +303,27 @@ def lane_config(args, rank, local_rank, world, dist, torch):
         dist.destroy_process_group()
 
 
+_JSON_OUT = None
+
+
+def _claim_stdout():
+    """The contract: rank 0 prints ONE JSON line on stdout.  Native libraries write there too (RCCL prints a version
+    banner on its first communicator), so fd 1 is pointed at stderr for the life of the process and the line goes to
+    a private duplicate of the original stdout."""
+    global _JSON_OUT
+    sys.stdout.flush()
+    _JSON_OUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
+
+def emit(obj):
+    _JSON_OUT.write(json.dumps(obj) + "\n")
+    _JSON_OUT.flush()
+
+
 def main():
     args = parse()
+    _claim_stdout()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -428,7 +447,7 @@ def main():
         }
         if cpu_leg is not None:
             out["cpu_baseline"] = cpu_leg
-        print(json.dumps(out))
+        emit(out)
     bt.close()
     if world > 1:
         dist.destroy_process_group()
