@@ -176,6 +176,8 @@ def lib():
         L.altro_hip_linesearch_host.restype = d
         L.altro_hip_selftest_mfma_f64.argtypes = [i]
         L.altro_hip_selftest_mfma_f64.restype = d
+        L.altro_hip_selftest_mfma_f32_4b.argtypes = [i]
+        L.altro_hip_selftest_mfma_f32_4b.restype = d
         _lib = L
     return _lib
 

@@ -4,6 +4,7 @@
 
 #include "kernels/tvlqr_mfma16.hip"
 #include "kernels/tvlqr_mfma16_f32.hip"
+#include "kernels/tvlqr_mfma16_f32x4.hip"
 
 using namespace altro_hip;
 using namespace altro_hip::capi;
@@ -129,7 +130,29 @@ int launch_backward(altro_hip_batch* h, double reg) {
     else if (sq || !(h->flags & ALTRO_HIP_F32_PURE)) mfma16_launch_backward<float>(h, reg, sq);   // fp32 storage, fp64 tiles
     else {   // opt-in: pure fp32 on v_mfma_f32_16x16x4_f32
       auto a = mfma16_args<float>(h, reg);
-      if (a.has_f) hipLaunchKernelGGL((mfma16_backward_f32_kernel<true, 3>), dim3(mf_grid(h->batch)), dim3(64), 0, h->stream, a);
+      // four problems per wave (kernels/tvlqr_mfma16_f32x4.hip) whenever the batch allows it; the one-problem kernel
+      // stays for ragged batches and, under ALTRO_HIP_F32_PURE_V1, for A/B measurements
+      static const bool v1 = std::getenv("ALTRO_HIP_F32_PURE_V1") != nullptr;
+      if (h->batch % 4 == 0 && !v1) {
+        const dim3 grid(mf_grid(h->batch / 4));
+        // (ring depth, waves per SIMD): measured on C4 (profiles/r02f_c4_quad_variants.txt: 3.40 ms for (2, 2), 4.1-4.4 ms for
+        // the others and for the one-problem kernel); ALTRO_HIP_F32X4 = "DW" overrides
+        static const int variant = std::getenv("ALTRO_HIP_F32X4") ? std::atoi(std::getenv("ALTRO_HIP_F32X4")) : 22;
+#define MFQ_LAUNCH(D, W)                                                                                               \
+  do {                                                                                                                 \
+    if (a.has_f) hipLaunchKernelGGL((mfma16_backward_f32x4_kernel<true, D, W>), grid, dim3(64), 0, h->stream, a);       \
+    else hipLaunchKernelGGL((mfma16_backward_f32x4_kernel<false, D, W>), grid, dim3(64), 0, h->stream, a);              \
+  } while (0)
+        switch (variant) {
+          case 13: MFQ_LAUNCH(1, 3); break;
+          case 12: MFQ_LAUNCH(1, 2); break;
+          case 32: MFQ_LAUNCH(3, 2); break;
+          case 31: MFQ_LAUNCH(3, 1); break;
+          case 41: MFQ_LAUNCH(4, 1); break;
+          default: MFQ_LAUNCH(2, 2); break;
+        }
+#undef MFQ_LAUNCH
+      } else if (a.has_f) hipLaunchKernelGGL((mfma16_backward_f32_kernel<true, 3>), dim3(mf_grid(h->batch)), dim3(64), 0, h->stream, a);
       else hipLaunchKernelGGL((mfma16_backward_f32_kernel<false, 3>), dim3(mf_grid(h->batch)), dim3(64), 0, h->stream, a);
     }
   } else if (h->plan == ALTRO_HIP_PLAN_LANE) {
@@ -230,6 +253,36 @@ double altro_hip_selftest_mfma_f64(int device) {
       for (int k = 0; k < 4; ++k) ref += hA[i * 4 + k] * hB[k * 16 + j];
       worst = std::max(worst, std::abs(ref - hD[i * 16 + j]));
     }
+  return worst;
+}
+
+// 4-block layout self-test (tests/test_gpu_parity.py): max |D_b - (A_b B_b + C_b)| over the four blocks of
+// v_mfma_f32_16x16x1_4b_f32 with the layout kernels/tvlqr_mfma16_f32x4.hip assumes.
+double altro_hip_selftest_mfma_f32_4b(int device) {
+  if (hipSetDevice(device) != hipSuccess) return -1.0;
+  float hA[64], hB[64], hC[1024], hD[1024];
+  unsigned s = 2468u;
+  auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (float)(s >> 8) / (1 << 24) - 0.5f; };
+  for (float& v : hA) v = rnd();
+  for (float& v : hB) v = rnd();
+  for (float& v : hC) v = rnd();
+  float *dA, *dB, *dC, *dD;
+  if (hipMalloc(&dA, sizeof(hA)) != hipSuccess || hipMalloc(&dB, sizeof(hB)) != hipSuccess ||
+      hipMalloc(&dC, sizeof(hC)) != hipSuccess || hipMalloc(&dD, sizeof(hD)) != hipSuccess)
+    return -1.0;
+  (void)hipMemcpy(dA, hA, sizeof(hA), hipMemcpyHostToDevice);
+  (void)hipMemcpy(dB, hB, sizeof(hB), hipMemcpyHostToDevice);
+  (void)hipMemcpy(dC, hC, sizeof(hC), hipMemcpyHostToDevice);
+  hipLaunchKernelGGL(mfma16_selftest_4b_kernel, dim3(1), dim3(64), 0, 0, dA, dB, dC, dD);
+  if (hipMemcpy(hD, dD, sizeof(hD), hipMemcpyDeviceToHost) != hipSuccess) return -1.0;
+  (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dC); (void)hipFree(dD);
+  double worst = 0.0;
+  for (int b = 0; b < 4; ++b)
+    for (int i = 0; i < 16; ++i)
+      for (int j = 0; j < 16; ++j) {
+        const double ref = (double)hC[b * 256 + i * 16 + j] + (double)hA[16 * b + i] * (double)hB[16 * b + j];
+        worst = std::max(worst, std::abs(ref - (double)hD[b * 256 + i * 16 + j]));
+      }
   return worst;
 }
 

@@ -65,6 +65,12 @@ def test_mfma_f64_layout_assumption():
     assert 0.0 <= altro_amd.lib().altro_hip_selftest_mfma_f64(0) < 1e-15
 
 
+def test_mfma_f32_4block_layout_assumption():
+    """tvlqr_mfma16_f32x4.hip assumes, for v_mfma_f32_16x16x1_4b_f32: block b takes A / B from lanes 16 b .. 16 b + 15 and
+    returns D_b in registers 4 b + r with lane 16 g + j <-> row 4 g + r, column j."""
+    assert 0.0 <= altro_amd.lib().altro_hip_selftest_mfma_f32_4b(0) < 1e-6
+
+
 @pytest.mark.parametrize("is_diag", [True, False])
 def test_generic_tvlqr_kat(kats, is_diag):
     """The reference's own known answers (tvlqr_test.cpp:185-213) through the HIP path."""
