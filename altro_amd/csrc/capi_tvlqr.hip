@@ -135,7 +135,7 @@ int launch_backward(altro_hip_batch* h, double reg) {
       static const bool v1 = std::getenv("ALTRO_HIP_F32_PURE_V1") != nullptr;
       if (h->batch % 4 == 0 && !v1) {
         const dim3 grid(mf_grid(h->batch / 4));
-        // (ring depth, waves per SIMD): measured on C4 (profiles/r02f_c4_quad_variants.txt: 3.40 ms for (2, 2), 4.1-4.4 ms for
+        // (ring depth, waves per SIMD): measured on C4 (profiles/r02g_c4_quad_variants.txt: 3.40 ms for (2, 2), 4.1-4.4 ms for
         // the others and for the one-problem kernel); ALTRO_HIP_F32X4 = "DW" overrides
         static const int variant = std::getenv("ALTRO_HIP_F32X4") ? std::atoi(std::getenv("ALTRO_HIP_F32X4")) : 22;
 #define MFQ_LAUNCH(D, W)                                                                                               \

@@ -51,9 +51,10 @@ def parse():
                          "batch=16384, fp32 storage)")
     ap.add_argument("--lane-fused", action="store_true",
                     help="configs c2 / c3: FMA-fused LANE kernels (ALTRO_HIP_LANE_FUSED; not bit-identical to the CPU path)")
-    ap.add_argument("--c4-pure", action="store_true",
-                    help="config c4: backward sweep in pure fp32 (ALTRO_HIP_F32_PURE, v_mfma_f32_16x16x4_f32) "
-                         "instead of fp32 storage with fp64 tile arithmetic")
+    ap.add_argument("--c4-pure", action="store_true", help="(default for config c4; kept for older command lines)")
+    ap.add_argument("--c4-mixed", action="store_true",
+                    help="config c4: fp32 storage with fp64 tile arithmetic (the ALTRO_HIP_F32 default of the C ABI) instead of "
+                         "the pure-fp32 backward sweep (ALTRO_HIP_F32_PURE: v_mfma_f32_16x16x4_f32, four problems per wave)")
     return ap.parse_args()
 
 
@@ -353,6 +354,7 @@ def main():
     from tests import problems
     N, n, m, batch = args.horizon, 12, 4, args.batch
     c4 = args.config == "c4"
+    args.c4_pure = c4 and not args.c4_mixed
     if c4:
         N = 512 if args.horizon == 256 else args.horizon
         batch = 16384 if args.batch == 4096 else args.batch
@@ -435,7 +437,8 @@ def main():
                 "horizon_N": N, "n": n, "m": m, "batch_per_gpu": batch, "global_batch": total_problems,
                 "parallelism": "problem instances sharded over %d GPU(s), no data-path collective; "
                                "RCCL all-reduce of solver stats only" % world,
-                "plan": "MFMA16 (wave-per-problem, v_mfma_f64_16x16x4)",
+                "plan": ("MFMA16, pure fp32: four problems per wave, v_mfma_f32_16x16x4 + v_mfma_f32_16x16x1_4b" if args.c4_pure else
+                         "MFMA16 (wave-per-problem, v_mfma_f64_16x16x4)"),
                 "knotpoint_steps_per_s": sweeps_per_s * N,
                 "kernels": {name_b: dict(kern[0], algorithmic_GB=bytes_b / 1e9, GBps=bytes_b / dur_b / 1e9),
                             name_f: dict(kern[1], algorithmic_GB=bytes_f / 1e9, GBps=bytes_f / dur_f / 1e9)},
@@ -443,7 +446,7 @@ def main():
                 "stats": stats,
                 "ilqr_full_solve": full_solve,
             },
-            "roofline": roofline_block(("c4pure" if args.c4_pure else "c4") if c4 else "c1", batch, N, name_b, bytes_b, dur_b),
+            "roofline": roofline_block(("c4pure" if args.c4_pure else "c4mixed") if c4 else "c1", batch, N, name_b, bytes_b, dur_b),
         }
         if cpu_leg is not None:
             out["cpu_baseline"] = cpu_leg

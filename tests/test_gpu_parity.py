@@ -559,14 +559,14 @@ def _c4_errors(flags, batch=48, N=512):
 def test_c4_full_horizon_sample_vs_oracle(mixed):
     """configs[4] at N = 512 (the fp32 accuracy claim was only tested at N = 64): a seeded sample of random
     LTV problems against the fp64 oracle on the SAME fp32-rounded inputs.  The Riccati recursion is contractive for
-    these problems, so the fp32 error does not accumulate over the horizon: the tolerances of the N = 64 test hold.
-    mixed (fp32 storage, fp64 tiles): 2e-5 relative; pure fp32 (v_mfma_f32_16x16x4_f32): 5e-4 relative."""
+    these problems, so the fp32 error does not accumulate over the horizon.  Measured on MI355X (round 2): mixed (fp32
+    storage, fp64 tiles) 3e-8 .. 7e-8 relative -- the rounding of the stored outputs; pure fp32 (four problems per wave,
+    v_mfma_f32_16x16x4_f32 / _16x16x1_4b) 6e-7 .. 2.2e-6.  Asserted with a margin of ~8: 5e-7 and 2e-5."""
     errs = _c4_errors(0 if mixed else altro_amd.F32_PURE)
     print("C4 N=512", "mixed" if mixed else "pure", errs)
-    tol = 2e-5 if mixed else 5e-4
-    for k in ("K", "d", "P", "p", "x", "u", "y"):
+    tol = 5e-7 if mixed else 2e-5
+    for k in ("K", "d", "P", "p", "x", "u", "y", "dV"):
         assert errs[k] < tol, (k, errs)
-    assert errs["dV"] < (1e-4 if mixed else 2e-3), errs
 
 
 @pytest.mark.parametrize("mixed", [True, False])
