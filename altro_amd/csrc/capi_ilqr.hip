@@ -612,7 +612,39 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
   h->bwd_active = h->i_active;
   h->bwd_reg = reg_on ? h->i_reg : nullptr;
   int total_reg_retries = 0;
-  for (int iter = 0; iter < o.iterations_max; ++iter) {
+  // Plan LANE: the sweeps run fused, whole sweeps per launch with no host in between (kernels/ilqr_fused.hip).  With the
+  // cubic line search that is the whole solve; with the backtracking search the first sweeps -- where nearly every
+  // problem converges -- and the stragglers then continue below, where several backtracking steps ride one launch.
+  // Bit-identical either way (tests/test_gpu_fused.py).  ALTRO_HIP_NO_FUSED (any value) keeps everything below;
+  // ALTRO_HIP_FUSED_SWEEPS=n sets the hand-over point.
+  int iter0 = 0;
+  if (lane_plan && std::getenv("ALTRO_HIP_NO_FUSED") == nullptr && o.iterations_max > 0) {
+    int fused_sweeps = o.use_backtracking_linesearch ? std::min(o.iterations_max, 12) : o.iterations_max;
+    if (const char* e = std::getenv("ALTRO_HIP_FUSED_SWEEPS")) fused_sweeps = std::max(1, std::min(o.iterations_max, std::atoi(e)));
+    HIP_TRY(hipMemsetAsync(h->i_counters, 0, 4 * sizeof(int), h->stream));
+    IlqrFusedArgs fa{0, fused_sweeps, o.reg_retry_max, reg_on ? 1 : 0, h->i_counters};
+    int frc;
+    if (h->dtype == ALTRO_HIP_F64) {
+      LaneArgs<double> ba{(const double*)h->l_in, (const double*)h->l_term, (double*)h->l_out, (double*)h->l_outn,
+                          (const double*)h->l_x0, (double*)h->l_xuy, (double*)h->delta_V, h->status, h->N, h->batch, 0.0,
+                          nullptr, nullptr};
+      frc = ilqr_launch_fused<double>(h->stream, h->model.kind, h->n, h->m, ilqr_args<double>(h, false, false, 1, 0.0), la, ba, fa);
+    } else {
+      LaneArgs<float> ba{(const float*)h->l_in, (const float*)h->l_term, (float*)h->l_out, (float*)h->l_outn,
+                         (const float*)h->l_x0, (float*)h->l_xuy, (float*)h->delta_V, h->status, h->N, h->batch, 0.0f,
+                         nullptr, nullptr};
+      frc = ilqr_launch_fused<float>(h->stream, h->model.kind, h->n, h->m, ilqr_args<float>(h, false, false, 1, 0.0), la, ba, fa);
+    }
+    if (frc) return fail(ALTRO_HIP_ERR_HIP, "fused iLQR kernel launch failed");
+    h->backward_done = true;
+    int c4[4];
+    HIP_TRY(hipMemcpyAsync(c4, h->i_counters, sizeof(c4), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    sweeps = c4[3];
+    running = c4[1];
+    iter0 = running > 0 ? fused_sweeps : o.iterations_max;
+  }
+  for (int iter = iter0; iter < o.iterations_max; ++iter) {
     la.iter = iter;
     if (ilqr_launch_loop(h->stream, ILK_MARK_RUNNING, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
     if (al) {                                                   // CalcExpansions: cost Hessians (solver.cpp:448)

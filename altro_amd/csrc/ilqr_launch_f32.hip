@@ -4,6 +4,7 @@
 #include <algorithm>
 
 #include "kernels/ilqr_lane.hip"
+#include "kernels/ilqr_fused.hip"
 
 namespace altro_hip {
 
@@ -36,6 +37,23 @@ int ilqr_launch_kernel<float>(hipStream_t stream, int which, int kind, int n, in
         hipLaunchKernelGGL((ilqr_stationarity_kernel<N_, M_, T>), flat64, b64, 0, stream, a);                   \
         break;                                                                                                \
     }                                                                                                         \
+  }
+  ILQR_MODELS(X)
+#undef X
+  if (!done) return 1;
+  return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+template <>
+int ilqr_launch_fused<float>(hipStream_t stream, int kind, int n, int m, const IlqrArgs<float>& a, const IlqrLoopArgs& la,
+                          const LaneArgs<float>& ba, const IlqrFusedArgs& fa) {
+  using T = float;
+  const dim3 grid(8 * (((a.batch + 63) / 64 + 7) / 8)), block(64);   // the sweep kernels' XCD-aware wave mapping
+  bool done = false;
+#define X(K_, N_, M_)                                                                                              \
+  if (!done && kind == K_ && n == N_ && m == M_) {                                                                 \
+    done = true;                                                                                                   \
+    hipLaunchKernelGGL((ilqr_fused_sweeps_kernel<K_, N_, M_, T>), grid, block, 0, stream, a, la, ba, fa);           \
   }
   ILQR_MODELS(X)
 #undef X

@@ -50,9 +50,11 @@ struct IlqrDims {
 
 // x_0 = x0 ; x_{k+1} = f(x_k, u_k) on the candidate trajectory
 template <int KIND, int n, int m, typename T>
-__global__ __launch_bounds__(64) void ilqr_rollout_kernel(IlqrArgs<T> a) {
-  ILQR_PROLOGUE;
-  if (a.active && !a.active[b]) return;
+__device__ __forceinline__ void ilqr_rollout_lane(const IlqrArgs<T>& a, int64_t b) {
+  using I = IlqrDims<n, m>;
+  using Mdl = DiscreteModel<KIND, n, m, T>;
+  const int64_t B = a.batch;
+  const int N = a.N;
   T x[n], u[m], xn[n];
   for (int e = 0; e < n; ++e) x[e] = a.x0[(int64_t)e * B + b];
   for (int k = 0; k < N; ++k) {
@@ -65,11 +67,27 @@ __global__ __launch_bounds__(64) void ilqr_rollout_kernel(IlqrArgs<T> a) {
   T* c = a.cand + (int64_t)N * I::E_CAND * B + b;
   for (int e = 0; e < n; ++e) c[(int64_t)e * B] = x[e];
 }
+template <int KIND, int n, int m, typename T>
+__global__ __launch_bounds__(64) void ilqr_rollout_kernel(IlqrArgs<T> a) {
+  ILQR_PROLOGUE;
+  if (a.active && !a.active[b]) return;
+  ilqr_rollout_lane<KIND, n, m, T>(a, b);
+}
 
-// nominal <- candidate (x, u); one thread per (problem, knot point)
+// nominal <- candidate (x, u) of one knot point
+template <int n, int m, typename T>
+__device__ __forceinline__ void ilqr_accept_point(const IlqrArgs<T>& a, int64_t b, int k) {
+  using I = IlqrDims<n, m>;
+  const int64_t B = a.batch;
+  const T* c = a.cand + (int64_t)k * I::E_CAND * B + b;
+  T* o = a.nom + (int64_t)k * I::E_NOM * B + b;
+  for (int e = 0; e < n; ++e) o[(int64_t)e * B] = c[(int64_t)e * B];
+  if (k < a.N)
+    for (int e = 0; e < m; ++e) o[(int64_t)(n + e) * B] = c[(int64_t)(2 * n + e) * B];
+}
+// one thread per (problem, knot point)
 template <int n, int m, typename T>
 __global__ void ilqr_accept_kernel(IlqrArgs<T> a) {
-  using I = IlqrDims<n, m>;
   const int64_t B = a.batch;
   const int64_t total = B * (a.N + 1);
   for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
@@ -77,22 +95,67 @@ __global__ void ilqr_accept_kernel(IlqrArgs<T> a) {
     const int64_t b = t % B;
     const int k = (int)(t / B);
     if (a.active && !a.active[b]) continue;
-    const T* c = a.cand + (int64_t)k * I::E_CAND * B + b;
-    T* o = a.nom + (int64_t)k * I::E_NOM * B + b;
-    for (int e = 0; e < n; ++e) o[(int64_t)e * B] = c[(int64_t)e * B];
-    if (k < a.N)
-      for (int e = 0; e < m; ++e) o[(int64_t)(n + e) * B] = c[(int64_t)(2 * n + e) * B];
+    ilqr_accept_point<n, m, T>(a, b, k);
   }
 }
 
-// Expansion at the candidate point, one thread per (problem, knot point): A, B (f = 0), lxx/luu/lux,
-// lx, lu -> the backward pass's input record.  Independent in k: the reference's own TODO
-// ("do this in parallel", solver.cpp:190).
+// Expansion at the candidate point of ONE knot point: A, B (f = 0), lxx/luu/lux, lx, lu -> the backward pass's input
+// record.  Independent in k: the reference's own TODO ("do this in parallel", solver.cpp:190).
 template <int KIND, int n, int m, typename T>
-__global__ __launch_bounds__(64) void ilqr_expand_kernel(IlqrArgs<T> a) {
+__device__ __forceinline__ void ilqr_expand_point(const IlqrArgs<T>& a, int64_t b, int k, bool grad, bool hess) {
   using D = LaneDims<n, m>;
   using I = IlqrDims<n, m>;
   using Mdl = DiscreteModel<KIND, n, m, T>;
+  const int64_t B = a.batch;
+  const T* c = a.cand + (int64_t)k * I::E_CAND * B + b;
+  const T* cs = a.cost + (int64_t)k * I::E_COST * B + b;
+  const bool terminal = k == a.N;
+  T x[n], u[m];
+  for (int e = 0; e < n; ++e) x[e] = c[(int64_t)e * B];
+  for (int e = 0; e < m; ++e) u[e] = terminal ? T(0) : c[(int64_t)(2 * n + e) * B];
+  T lx[n], lu[m], Qm[n * n], Rm[m * m], Hm[m * n];
+  for (int e = 0; e < n; ++e) lx[e] = cs[(int64_t)(I::C_Q + e) * B] * x[e] + cs[(int64_t)(I::C_q + e) * B];
+  for (int e = 0; e < m; ++e)
+    lu[e] = terminal ? T(0) : cs[(int64_t)(I::C_R + e) * B] * u[e] + cs[(int64_t)(I::C_r + e) * B];
+  for (int e = 0; e < n * n; ++e) Qm[e] = (e % n == e / n) ? cs[(int64_t)(I::C_Q + e % n) * B] : T(0);
+  for (int e = 0; e < m * m; ++e)
+    Rm[e] = (!terminal && e % m == e / m) ? cs[(int64_t)(I::C_R + e % m) * B] : T(0);
+  for (int e = 0; e < m * n; ++e) Hm[e] = T(0);
+  if (a.al.enabled) {
+    const T rho_est = (T)a.prob[b].rho_est, rho = (T)a.prob[b].rho;
+    if (grad && hess)
+      al_eval<n, m, T, true, true>(a.al, k, b, B, x, u, terminal, rho_est, rho, lx, lu, Qm, Rm, Hm, nullptr, false);
+    else if (grad)
+      al_eval<n, m, T, true, false>(a.al, k, b, B, x, u, terminal, rho_est, rho, lx, lu, Qm, Rm, Hm, nullptr, false);
+    else
+      al_eval<n, m, T, false, true>(a.al, k, b, B, x, u, terminal, rho_est, rho, lx, lu, Qm, Rm, Hm, nullptr, false);
+  }
+  if (terminal) {   // P_N = lxx, p_N = lx
+    if (hess)
+      for (int e = 0; e < n * n; ++e) a.term[(int64_t)e * B + b] = Qm[e];
+    if (grad)
+      for (int e = 0; e < n; ++e) a.term[(int64_t)(n * n + e) * B + b] = lx[e];
+    return;
+  }
+  T* in = a.in + (int64_t)k * D::E_IN * B + b;
+  if (grad) {
+    T Am[n * n], Bm[n * m];
+    Mdl::jacobian(a.mp, x, u, Am, Bm);
+    for (int e = 0; e < n * n; ++e) in[(int64_t)(D::O_A + e) * B] = Am[e];
+    for (int e = 0; e < n * m; ++e) in[(int64_t)(D::O_B + e) * B] = Bm[e];
+    for (int e = 0; e < n; ++e) in[(int64_t)(D::O_f + e) * B] = T(0);
+    for (int e = 0; e < n; ++e) in[(int64_t)(D::O_q + e) * B] = lx[e];
+    for (int e = 0; e < m; ++e) in[(int64_t)(D::O_r + e) * B] = lu[e];
+  }
+  if (hess) {
+    for (int e = 0; e < n * n; ++e) in[(int64_t)(D::O_Q + e) * B] = Qm[e];
+    for (int e = 0; e < m * m; ++e) in[(int64_t)(D::O_R + e) * B] = Rm[e];
+    for (int e = 0; e < m * n; ++e) in[(int64_t)(D::O_H + e) * B] = Hm[e];
+  }
+}
+// one thread per (problem, knot point)
+template <int KIND, int n, int m, typename T>
+__global__ __launch_bounds__(64) void ilqr_expand_kernel(IlqrArgs<T> a) {
   const int64_t B = a.batch;
   const int64_t total = B * (a.N + 1);
   const bool grad = (a.mode & EXPAND_GRADIENT) != 0, hess = (a.mode & EXPAND_HESSIAN) != 0;
@@ -101,51 +164,7 @@ __global__ __launch_bounds__(64) void ilqr_expand_kernel(IlqrArgs<T> a) {
     const int64_t b = t % B;
     const int k = (int)(t / B);
     if (a.active && !a.active[b]) continue;
-    const T* c = a.cand + (int64_t)k * I::E_CAND * B + b;
-    const T* cs = a.cost + (int64_t)k * I::E_COST * B + b;
-    const bool terminal = k == a.N;
-    T x[n], u[m];
-    for (int e = 0; e < n; ++e) x[e] = c[(int64_t)e * B];
-    for (int e = 0; e < m; ++e) u[e] = terminal ? T(0) : c[(int64_t)(2 * n + e) * B];
-    T lx[n], lu[m], Qm[n * n], Rm[m * m], Hm[m * n];
-    for (int e = 0; e < n; ++e) lx[e] = cs[(int64_t)(I::C_Q + e) * B] * x[e] + cs[(int64_t)(I::C_q + e) * B];
-    for (int e = 0; e < m; ++e)
-      lu[e] = terminal ? T(0) : cs[(int64_t)(I::C_R + e) * B] * u[e] + cs[(int64_t)(I::C_r + e) * B];
-    for (int e = 0; e < n * n; ++e) Qm[e] = (e % n == e / n) ? cs[(int64_t)(I::C_Q + e % n) * B] : T(0);
-    for (int e = 0; e < m * m; ++e)
-      Rm[e] = (!terminal && e % m == e / m) ? cs[(int64_t)(I::C_R + e % m) * B] : T(0);
-    for (int e = 0; e < m * n; ++e) Hm[e] = T(0);
-    if (a.al.enabled) {
-      const T rho_est = (T)a.prob[b].rho_est, rho = (T)a.prob[b].rho;
-      if (grad && hess)
-        al_eval<n, m, T, true, true>(a.al, k, b, B, x, u, terminal, rho_est, rho, lx, lu, Qm, Rm, Hm, nullptr, false);
-      else if (grad)
-        al_eval<n, m, T, true, false>(a.al, k, b, B, x, u, terminal, rho_est, rho, lx, lu, Qm, Rm, Hm, nullptr, false);
-      else
-        al_eval<n, m, T, false, true>(a.al, k, b, B, x, u, terminal, rho_est, rho, lx, lu, Qm, Rm, Hm, nullptr, false);
-    }
-    if (terminal) {   // P_N = lxx, p_N = lx
-      if (hess)
-        for (int e = 0; e < n * n; ++e) a.term[(int64_t)e * B + b] = Qm[e];
-      if (grad)
-        for (int e = 0; e < n; ++e) a.term[(int64_t)(n * n + e) * B + b] = lx[e];
-      continue;
-    }
-    T* in = a.in + (int64_t)k * D::E_IN * B + b;
-    if (grad) {
-      T Am[n * n], Bm[n * m];
-      Mdl::jacobian(a.mp, x, u, Am, Bm);
-      for (int e = 0; e < n * n; ++e) in[(int64_t)(D::O_A + e) * B] = Am[e];
-      for (int e = 0; e < n * m; ++e) in[(int64_t)(D::O_B + e) * B] = Bm[e];
-      for (int e = 0; e < n; ++e) in[(int64_t)(D::O_f + e) * B] = T(0);
-      for (int e = 0; e < n; ++e) in[(int64_t)(D::O_q + e) * B] = lx[e];
-      for (int e = 0; e < m; ++e) in[(int64_t)(D::O_r + e) * B] = lu[e];
-    }
-    if (hess) {
-      for (int e = 0; e < n * n; ++e) in[(int64_t)(D::O_Q + e) * B] = Qm[e];
-      for (int e = 0; e < m * m; ++e) in[(int64_t)(D::O_R + e) * B] = Rm[e];
-      for (int e = 0; e < m * n; ++e) in[(int64_t)(D::O_H + e) * B] = Hm[e];
-    }
+    ilqr_expand_point<KIND, n, m, T>(a, b, k, grad, hess);
   }
 }
 
@@ -301,39 +320,15 @@ __device__ __forceinline__ void merit_step(const MeritRec<n, m, T>& r, const Ilq
   for (int e = 0; e < n; ++e) x[e] = xn[e];
 }
 
-// MeritFunction (solver.cpp:273-355): closed-loop rollout with step alpha, total cost phi and, when
-// asked, the directional derivative dphi together with the refreshed A, B, lx, lu.
+// MeritFunction (solver.cpp:273-355) for one problem: closed-loop rollout with step alpha, total cost phi and, when
+// asked, the directional derivative dphi together with the refreshed A, B, lx, lu (`store`).  Leaves rho_est = rho.
 template <int KIND, int n, int m, typename T>
-__global__ __launch_bounds__(64) void ilqr_merit_kernel(IlqrArgs<T> a) {
-  ILQR_PROLOGUE;
-  if (a.active && !a.active[b]) return;
-  const uint32_t lane = threadIdx.x * (uint32_t)sizeof(T);
-  const uint32_t rowB = (uint32_t)B * (uint32_t)sizeof(T);
-  const int64_t b0 = (int64_t)blockIdx.x * 64;
-  double alpha_d = a.alpha ? a.alpha[b] : a.alpha_const;
-  T* cand = a.cand;
-  const int trial = blockIdx.y;   // > 0: a speculative backtracking trial (IlqrArgs::spec_trials)
-  bool store = true;              // a derivative pass also leaves A, B, lx, lu behind -- except the fused first trial
-  if (trial > 0 && a.spec_pre) {  // next to phi(0): the step alpha0 = 1 the search will ask for first, phi and phi'
-    if (trial > 1) return;
-    alpha_d = 1.0;
-    cand = a.cand_spec;
-    store = false;
-  } else if (trial > 0) {
-    const LsState& ls = a.prob[b].ls;
-    if (ls.stage == LS_STAGE_BACKTRACK) {          // pending: alpha beta^0 with bt_iter = t; trial j is bt_iter = t + j
-      if (ls.bt_iter + trial >= a.ls_max_iters) return;
-    } else if (ls.stage == LS_STAGE_CUBIC) {       // pending: the cubic guess; if it is rejected the backtracking
-      if (trial >= a.ls_max_iters) return;         // sequence starts at alpha0 beta with bt_iter = 1 (linesearch.cpp:138)
-      alpha_d = ls.alpha0;
-    } else {
-      return;
-    }
-    for (int t = 0; t < trial; ++t) alpha_d = alpha_d * a.ls_beta;   // the state machine's own sequence of products
-    cand = a.cand_spec + (int64_t)(trial - 1) * a.spec_stride;
-  }
-  const T alpha = (T)alpha_d;
-  const bool deriv = a.want_derivative != 0 && (trial == 0 || a.spec_pre);   // backtracking trials never ask for phi'
+__device__ __forceinline__ void ilqr_merit_lane(const IlqrArgs<T>& a, int64_t b, int64_t b0, uint32_t lane, uint32_t rowB,
+                                                T alpha, bool deriv, bool store, T* cand, T& phi_out, T& dphi_out) {
+  using D = LaneDims<n, m>;
+  using I = IlqrDims<n, m>;
+  const int64_t B = a.batch;
+  const int N = a.N;
   const bool al = a.al.enabled != 0;
   const T rho = al ? (T)a.prob[b].rho : T(1);   // CalcCost refreshes the projected duals with the current penalty
   T x[n], dxda[n], phi = T(0), dphi = T(0);
@@ -375,9 +370,46 @@ __global__ __launch_bounds__(64) void ilqr_merit_kernel(IlqrArgs<T> a) {
       dphi += s;
     }
   }
+  phi_out = phi;
+  dphi_out = dphi;
+  if (al) a.prob[b].rho_est = (double)rho;
+}
+
+// One launch = one merit evaluation per problem (and, with gridDim.y > 1, the speculative trials of IlqrArgs).
+template <int KIND, int n, int m, typename T>
+__global__ __launch_bounds__(64) void ilqr_merit_kernel(IlqrArgs<T> a) {
+  ILQR_PROLOGUE;
+  if (a.active && !a.active[b]) return;
+  const uint32_t lane = threadIdx.x * (uint32_t)sizeof(T);
+  const uint32_t rowB = (uint32_t)B * (uint32_t)sizeof(T);
+  const int64_t b0 = (int64_t)blockIdx.x * 64;
+  double alpha_d = a.alpha ? a.alpha[b] : a.alpha_const;
+  T* cand = a.cand;
+  const int trial = blockIdx.y;   // > 0: a speculative backtracking trial (IlqrArgs::spec_trials)
+  bool store = true;              // a derivative pass also leaves A, B, lx, lu behind -- except the fused first trial
+  if (trial > 0 && a.spec_pre) {  // next to phi(0): the step alpha0 = 1 the search will ask for first, phi and phi'
+    if (trial > 1) return;
+    alpha_d = 1.0;
+    cand = a.cand_spec;
+    store = false;
+  } else if (trial > 0) {
+    const LsState& ls = a.prob[b].ls;
+    if (ls.stage == LS_STAGE_BACKTRACK) {          // pending: alpha beta^0 with bt_iter = t; trial j is bt_iter = t + j
+      if (ls.bt_iter + trial >= a.ls_max_iters) return;
+    } else if (ls.stage == LS_STAGE_CUBIC) {       // pending: the cubic guess; if it is rejected the backtracking
+      if (trial >= a.ls_max_iters) return;         // sequence starts at alpha0 beta with bt_iter = 1 (linesearch.cpp:138)
+      alpha_d = ls.alpha0;
+    } else {
+      return;
+    }
+    for (int t = 0; t < trial; ++t) alpha_d = alpha_d * a.ls_beta;   // the state machine's own sequence of products
+    cand = a.cand_spec + (int64_t)(trial - 1) * a.spec_stride;
+  }
+  const bool deriv = a.want_derivative != 0 && (trial == 0 || a.spec_pre);   // backtracking trials never ask for phi'
+  T phi, dphi;
+  ilqr_merit_lane<KIND, n, m, T>(a, b, b0, lane, rowB, (T)alpha_d, deriv, store, cand, phi, dphi);
   a.phi[(int64_t)trial * B + b] = (double)phi;
   if (deriv) a.dphi[(int64_t)trial * B + b] = (double)dphi;
-  if (al) a.prob[b].rho_est = (double)rho;
 }
 
 // Speculative backtracking: the problems that just ended their search on spare trajectory spec_sel[b] - 1 get it
@@ -405,58 +437,78 @@ __global__ void ilqr_zero_residuals_kernel(IlqrArgs<T> a) {
   a.prob[b].stationarity = 0.0;
   a.prob[b].feasibility = 0.0;
 }
+// residuals of ONE knot point: stationarity (solver.cpp:207-222) and, with constraints, the violation (solver.cpp:224-231)
 template <int n, int m, typename T>
-__global__ __launch_bounds__(64) void ilqr_stationarity_kernel(IlqrArgs<T> a) {
+__device__ __forceinline__ void ilqr_stationarity_point(const IlqrArgs<T>& a, int64_t b, int k, T& res, T& viol) {
   using D = LaneDims<n, m>;
   using I = IlqrDims<n, m>;
   const int64_t B = a.batch;
   const int N = a.N;
-  const int64_t total = B * (N + 1);
+  const T* c = a.cand + (int64_t)k * I::E_CAND * B + b;
+  res = T(0);
+  viol = T(0);
+  if (k < N) {
+    const T* in = a.in + (int64_t)k * D::E_IN * B + b;
+    const T* cn = a.cand + (int64_t)(k + 1) * I::E_CAND * B + b;
+    T yn[n];
+    for (int e = 0; e < n; ++e) yn[e] = cn[(int64_t)(n + e) * B];
+    for (int j = 0; j < n; ++j) {
+      T s = T(0);
+      for (int i = 0; i < n; ++i) s += in[(int64_t)(D::O_A + i + j * n) * B] * yn[i];
+      res = fmax(res, fabs(in[(int64_t)(D::O_q + j) * B] + s - c[(int64_t)(n + j) * B]));
+    }
+    for (int j = 0; j < m; ++j) {
+      T s = T(0);
+      for (int i = 0; i < n; ++i) s += in[(int64_t)(D::O_B + i + j * n) * B] * yn[i];
+      res = fmax(res, fabs(in[(int64_t)(D::O_r + j) * B] + s));
+    }
+  } else {
+    for (int j = 0; j < n; ++j)
+      res = fmax(res, fabs(a.term[(int64_t)(n * n + j) * B + b] - c[(int64_t)(n + j) * B]));
+  }
+  if (a.al.enabled) {
+    const T rho = (T)a.prob[b].rho;
+    T x[n], u[m];
+    for (int e = 0; e < n; ++e) x[e] = c[(int64_t)e * B];
+    for (int e = 0; e < m; ++e) u[e] = k < N ? c[(int64_t)(2 * n + e) * B] : T(0);
+    al_eval<n, m, T, false, false>(a.al, k, b, B, x, u, k == N, rho, rho, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                   &viol, false);
+  }
+}
+template <int n, int m, typename T>
+__global__ __launch_bounds__(64) void ilqr_stationarity_kernel(IlqrArgs<T> a) {
+  const int64_t B = a.batch;
+  const int64_t total = B * (a.N + 1);
   for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
     const int64_t b = t % B;
     const int k = (int)(t / B);
     if (a.active && !a.active[b]) continue;
-    const T* c = a.cand + (int64_t)k * I::E_CAND * B + b;
-    T res = T(0);
-    if (k < N) {
-      const T* in = a.in + (int64_t)k * D::E_IN * B + b;
-      const T* cn = a.cand + (int64_t)(k + 1) * I::E_CAND * B + b;
-      T yn[n];
-      for (int e = 0; e < n; ++e) yn[e] = cn[(int64_t)(n + e) * B];
-      for (int j = 0; j < n; ++j) {
-        T s = T(0);
-        for (int i = 0; i < n; ++i) s += in[(int64_t)(D::O_A + i + j * n) * B] * yn[i];
-        res = fmax(res, fabs(in[(int64_t)(D::O_q + j) * B] + s - c[(int64_t)(n + j) * B]));
-      }
-      for (int j = 0; j < m; ++j) {
-        T s = T(0);
-        for (int i = 0; i < n; ++i) s += in[(int64_t)(D::O_B + i + j * n) * B] * yn[i];
-        res = fmax(res, fabs(in[(int64_t)(D::O_r + j) * B] + s));
-      }
-    } else {
-      for (int j = 0; j < n; ++j)
-        res = fmax(res, fabs(a.term[(int64_t)(n * n + j) * B + b] - c[(int64_t)(n + j) * B]));
-    }
+    T res, viol;
+    ilqr_stationarity_point<n, m, T>(a, b, k, res, viol);
     atomicMax(reinterpret_cast<unsigned long long*>(&a.prob[b].stationarity),
               (unsigned long long)__double_as_longlong((double)res));
-    if (a.al.enabled) {
-      const T rho = (T)a.prob[b].rho;
-      T x[n], u[m], viol = T(0);
-      for (int e = 0; e < n; ++e) x[e] = c[(int64_t)e * B];
-      for (int e = 0; e < m; ++e) u[e] = k < N ? c[(int64_t)(2 * n + e) * B] : T(0);
-      al_eval<n, m, T, false, false>(a.al, k, b, B, x, u, k == N, rho, rho, nullptr, nullptr, nullptr, nullptr, nullptr,
-                                     &viol, false);
+    if (a.al.enabled)
       atomicMax(reinterpret_cast<unsigned long long*>(&a.prob[b].feasibility),
                 (unsigned long long)__double_as_longlong((double)viol));
-    }
   }
 }
 
-// DualUpdate (knotpoint_data.cpp:503-510): z <- the projected duals of the accepted trajectory, one thread per
-// (problem, knot point); only problems whose sweep asked for it (IlqrProb::dual != 0).
+// DualUpdate (knotpoint_data.cpp:503-510) of ONE knot point: z <- the projected duals of the accepted trajectory
+template <int n, int m, typename T>
+__device__ __forceinline__ void ilqr_dual_point(const IlqrArgs<T>& a, int64_t b, int k) {
+  using I = IlqrDims<n, m>;
+  const int64_t B = a.batch;
+  const T* ck = a.cand + (int64_t)k * I::E_CAND * B + b;
+  T x[n], u[m];
+  for (int e = 0; e < n; ++e) x[e] = ck[(int64_t)e * B];
+  for (int e = 0; e < m; ++e) u[e] = k < a.N ? ck[(int64_t)(2 * n + e) * B] : T(0);
+  const T rho = (T)a.prob[b].rho_est;
+  al_eval<n, m, T, false, false>(a.al, k, b, B, x, u, k == a.N, rho, rho, nullptr, nullptr, nullptr, nullptr,
+                                 nullptr, nullptr, true);
+}
+// one thread per (problem, knot point); only problems whose sweep asked for it (IlqrProb::dual != 0)
 template <int n, int m, typename T>
 __global__ void ilqr_dual_update_kernel(IlqrArgs<T> a) {
-  using I = IlqrDims<n, m>;
   const int64_t B = a.batch;
   const int64_t total = B * (a.N + 1);
   for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
@@ -464,13 +516,7 @@ __global__ void ilqr_dual_update_kernel(IlqrArgs<T> a) {
     const int64_t b = t % B;
     const int k = (int)(t / B);
     if (!a.prob[b].dual) continue;
-    const T* ck = a.cand + (int64_t)k * I::E_CAND * B + b;
-    T x[n], u[m];
-    for (int e = 0; e < n; ++e) x[e] = ck[(int64_t)e * B];
-    for (int e = 0; e < m; ++e) u[e] = k < a.N ? ck[(int64_t)(2 * n + e) * B] : T(0);
-    const T rho = (T)a.prob[b].rho_est;
-    al_eval<n, m, T, false, false>(a.al, k, b, B, x, u, k == a.N, rho, rho, nullptr, nullptr, nullptr, nullptr,
-                                   nullptr, nullptr, true);
+    ilqr_dual_point<n, m, T>(a, b, k);
   }
 }
 

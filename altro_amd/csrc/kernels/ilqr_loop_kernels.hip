@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "ilqr_loop_logic.h"
 #include "ilqr_types.h"
 
 namespace altro_hip {
@@ -13,11 +14,8 @@ __global__ void ilqr_loop_init_kernel(IlqrLoopArgs a) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= a.batch) return;
   IlqrProb& p = a.prob[b];
-  p.running = 1; p.iterations = 0; p.status = 1; p.ls_failed = 0; p.evaluating = 0;
-  p.alpha = 0.0; p.stationarity = 0.0; p.ls_iters = 0;
-  p.feasibility = 0.0; p.dual = 0; p.n_dual_updates = 0; p.reg_retries = 0;
+  ilqr_prob_init(p);
   a.reg[b] = a.reg_initial;
-  p.rho_est = p.rho;   // the initial gradient is formed with the penalty left by Initialize / the last solve
   a.active[b] = 1;
   a.alpha[b] = 0.0;
 }
@@ -30,31 +28,13 @@ __global__ void ilqr_ls_begin_kernel(IlqrLoopArgs a) {
   a.spec_sel[b] = 0;
   a.spec_refresh[b] = 0;
   if (!p.running) { a.active[b] = 0; return; }
-  p.phi0 = a.phi[b];
-  p.dphi0 = a.dphi[b];
-  p.ls_failed = 0;
-  bool need;
-  if (fabs(p.dphi0) < a.tol_meritfun_gradient) {   // MeritFunctionGradientTooSmall: alpha = 0
-    p.alpha = 0.0;
-    p.ls_iters = 0;
-    need = false;
-  } else {
-    need = ls_begin(p.ls, a.ls, 1.0, p.phi0, p.dphi0);
-    if (!need) {   // not a descent direction
-      p.alpha = p.ls.alpha;
-      p.ls_iters = p.ls.n_iters;
-      p.ls_failed = 1;
-    }
-  }
+  bool need = ilqr_ls_begin_logic(p, a.ls, a.tol_meritfun_gradient, a.phi[b], a.dphi[b]);
   // Fused first trial (IlqrLoopArgs::spec_pre): the merit launch that produced phi(0) also evaluated the first step
   // alpha0 = 1 the search asks for (into phi / dphi row 1 and spare candidate 0), so it is consumed right here.
   if (need && a.spec_pre) {
     need = ls_feed(p.ls, a.ls, a.phi[(size_t)a.batch + b], a.dphi[(size_t)a.batch + b]);
     if (!need) {   // the search ended on that step (same bookkeeping as ilqr_ls_feed_kernel)
-      p.alpha = p.ls.alpha;
-      p.ls_iters = p.ls.n_iters;
-      const int st = p.ls.status;
-      p.ls_failed = (isnan(p.alpha) || !(st == LS_MINIMUM_FOUND || st == LS_HIT_MAX_STEPSIZE)) ? 1 : 0;
+      ilqr_ls_end_logic(p);
       a.spec_sel[b] = 1;
       a.spec_refresh[b] = 1;
     }
@@ -93,11 +73,7 @@ __global__ void ilqr_ls_feed_kernel(IlqrLoopArgs a) {
   } else {
     p.evaluating = 0;
     a.active[b] = 0;
-    p.alpha = p.ls.alpha;
-    p.ls_iters = p.ls.n_iters;
-    const int st = p.ls.status;
-    // solver.cpp:264-268
-    p.ls_failed = (isnan(p.alpha) || !(st == LS_MINIMUM_FOUND || st == LS_HIT_MAX_STEPSIZE)) ? 1 : 0;
+    ilqr_ls_end_logic(p);
   }
 }
 
@@ -106,26 +82,7 @@ __global__ void ilqr_finish_iter_kernel(IlqrLoopArgs a) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= a.batch) return;
   IlqrProb& p = a.prob[b];
-  if (p.running) {
-    bool stop = p.ls_failed != 0;
-    if (fabs(p.stationarity) < a.tol_stationarity && p.feasibility < a.tol_primal_feasibility) {
-      p.status = 0;
-      stop = true;
-    }
-    // outer AL update (solver.cpp:470-489), also on the sweep that stops
-    p.dual = 0;
-    if (a.al_enabled && p.stationarity < sqrt(a.tol_stationarity)) {
-      p.dual = p.feasibility > a.tol_primal_feasibility ? 2 : 1;
-      ++p.n_dual_updates;
-    }
-    p.iterations = a.iter + 1;
-    if (!stop && a.iter + 1 >= a.iterations_max) {
-      p.status = 2;   // MaxIterations; the reference reports iter + 1 after its loop ends (solver.cpp:503-506)
-      p.iterations = a.iter + 2;
-      stop = true;
-    }
-    if (stop) p.running = 0;
-  }
+  if (p.running) ilqr_finish_iter_logic(p, a, a.iter);
   else p.dual = 0;
   a.active[b] = p.running;
   if (p.running) atomicAdd(&a.counters[1], 1);
@@ -141,14 +98,7 @@ __global__ void ilqr_reg_retry_kernel(IlqrLoopArgs a) {
   IlqrProb& p = a.prob[b];
   const bool was_active = a.active[b] != 0;
   int again = 0;
-  if (p.running && was_active) {
-    if (a.bwd_status[b] != -1) {
-      const double r = fmax(a.reg[b] * a.reg_scale, a.reg_min);
-      if (r <= a.reg_max) { a.reg[b] = r; again = 1; ++p.reg_retries; }
-    } else {
-      a.reg[b] = fmax(a.reg[b] / a.reg_scale, a.reg_initial);
-    }
-  }
+  if (p.running && was_active) again = ilqr_reg_retry_logic(p, a, a.reg[b], a.bwd_status[b]) ? 1 : 0;
   a.active[b] = again;
   if (again) atomicAdd(&a.counters[2], 1);
 }
@@ -167,9 +117,7 @@ __global__ void ilqr_penalty_update_kernel(IlqrLoopArgs a) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= a.batch) return;
   IlqrProb& p = a.prob[b];
-  a.active[b] = p.dual != 0;
-  if (p.dual == 2) p.rho = fmin(p.rho * a.penalty_scaling, a.penalty_max);
-  if (p.dual) p.rho_est = p.rho;
+  a.active[b] = ilqr_penalty_update_logic(p, a) ? 1 : 0;
 }
 
 // set `active` := running (used before the per-sweep kernels)

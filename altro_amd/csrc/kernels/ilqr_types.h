@@ -126,6 +126,20 @@ enum IlqrLoopKernel { ILK_LOOP_INIT, ILK_LS_BEGIN, ILK_LS_FEED, ILK_FINISH_ITER,
 // Launchers (ilqr_launch_f64.hip / ilqr_launch_f32.hip hold the kernel instantiations, so that the kernels of
 // the two element types compile in parallel with the rest of the library).  Return 0, 1 = no device model for
 // (kind, n, m), 2 = launch error (hipGetLastError has the reason).
+// plan LANE: whole sweeps in one launch (kernels/ilqr_fused.hip)
+template <typename T>
+struct LaneArgs;   // kernels/tvlqr_lane.hip
+struct IlqrFusedArgs {
+  int first_iter;     // index of the first sweep this launch runs (0 right after the initial rollout / expansion)
+  int max_sweeps;     // sweeps to run at most in this launch
+  int reg_retry_max;  // altro_hip_solve_options::reg_retry_max
+  int use_reg;        // per-problem regularisation in force (reg_initial > 0 or retries enabled)
+  int* counters;      // [1] += problems still running when the launch ends; [3] = max sweeps any wave ran (atomicMax)
+};
+template <typename T>
+int ilqr_launch_fused(hipStream_t stream, int kind, int n, int m, const IlqrArgs<T>& a, const IlqrLoopArgs& la,
+                      const LaneArgs<T>& ba, const IlqrFusedArgs& fa);
+
 bool ilqr_supported(int kind, int n, int m);
 template <typename T>
 int ilqr_launch_kernel(hipStream_t stream, int which, int kind, int n, int m, const IlqrArgs<T>& a);

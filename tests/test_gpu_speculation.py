@@ -16,6 +16,7 @@ pytestmark = pytest.mark.gpu
 
 def _solve_both(make, **opts):
     out = []
+    os.environ["ALTRO_HIP_NO_FUSED"] = "1"    # speculation belongs to the launch-sequenced loop: test it there, alone
     for off in (True, False):
         if off:
             os.environ["ALTRO_HIP_NO_SPECULATION"] = "1"
@@ -28,6 +29,7 @@ def _solve_both(make, **opts):
             out.append((res, x, u, bt))
         finally:
             os.environ.pop("ALTRO_HIP_NO_SPECULATION", None)
+    os.environ.pop("ALTRO_HIP_NO_FUSED", None)
     return out
 
 
