@@ -81,14 +81,19 @@ __global__ __launch_bounds__(64) void ilqr_fused_sweeps_kernel(IlqrArgs<T> a, Il
     // convergence criteria on the accepted candidate, then make it the nominal (solver.cpp:459-469)
     {
       T stat = T(0), feas = T(0);
+      // (reads only: unrolled so that the operand loads of four knot points are in flight at once -- one lane walks its
+      //  own problem's knot points here, where the stand-alone kernel has a thread per (problem, knot point))
+#pragma unroll 4
       for (int k = 0; k <= N; ++k)
         if (run) {
           T r, v;
           ilqr_stationarity_point<n, m, T>(a, b, k, r, v);
           stat = fmax(stat, r);
           feas = fmax(feas, v);
-          ilqr_accept_point<n, m, T>(a, b, k);
         }
+#pragma unroll 4
+      for (int k = 0; k <= N; ++k)
+        if (run) ilqr_accept_point<n, m, T>(a, b, k);
       if (run) {
         pp->stationarity = (double)stat;
         pp->feasibility = (double)feas;

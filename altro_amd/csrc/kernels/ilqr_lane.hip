@@ -30,6 +30,9 @@
 #include "al_lane.hip"
 #include "tvlqr_lane.hip"
 
+#if defined(__clang__)
+#pragma clang fp contract(on)   // single-expression a * b + c only: the same rounding in every kernel these functions are inlined into (see models.h)
+#endif
 namespace altro_hip {
 
 template <int n, int m>
@@ -79,11 +82,19 @@ template <int n, int m, typename T>
 __device__ __forceinline__ void ilqr_accept_point(const IlqrArgs<T>& a, int64_t b, int k) {
   using I = IlqrDims<n, m>;
   const int64_t B = a.batch;
-  const T* c = a.cand + (int64_t)k * I::E_CAND * B + b;
-  T* o = a.nom + (int64_t)k * I::E_NOM * B + b;
-  for (int e = 0; e < n; ++e) o[(int64_t)e * B] = c[(int64_t)e * B];
-  if (k < a.N)
-    for (int e = 0; e < m; ++e) o[(int64_t)(n + e) * B] = c[(int64_t)(2 * n + e) * B];
+  const T* __restrict__ c = a.cand + (int64_t)k * I::E_CAND * B + b;
+  T* __restrict__ o = a.nom + (int64_t)k * I::E_NOM * B + b;
+  T x[n], u[m];
+#pragma unroll
+  for (int e = 0; e < n; ++e) x[e] = c[(int64_t)e * B];
+#pragma unroll
+  for (int e = 0; e < m; ++e) u[e] = k < a.N ? c[(int64_t)(2 * n + e) * B] : T(0);
+#pragma unroll
+  for (int e = 0; e < n; ++e) o[(int64_t)e * B] = x[e];
+  if (k < a.N) {
+#pragma unroll
+    for (int e = 0; e < m; ++e) o[(int64_t)(n + e) * B] = u[e];
+  }
 }
 // one thread per (problem, knot point)
 template <int n, int m, typename T>
@@ -444,23 +455,40 @@ __device__ __forceinline__ void ilqr_stationarity_point(const IlqrArgs<T>& a, in
   using I = IlqrDims<n, m>;
   const int64_t B = a.batch;
   const int N = a.N;
-  const T* c = a.cand + (int64_t)k * I::E_CAND * B + b;
+  const T* __restrict__ c = a.cand + (int64_t)k * I::E_CAND * B + b;
   res = T(0);
   viol = T(0);
   if (k < N) {
-    const T* in = a.in + (int64_t)k * D::E_IN * B + b;
-    const T* cn = a.cand + (int64_t)(k + 1) * I::E_CAND * B + b;
-    T yn[n];
+    // every operand first, then the arithmetic: the loads of one knot point (and, in the fused solve kernel's loop over k,
+    // of the next ones) are in flight together instead of one exposed round trip per element
+    const T* __restrict__ in = a.in + (int64_t)k * D::E_IN * B + b;
+    const T* __restrict__ cn = a.cand + (int64_t)(k + 1) * I::E_CAND * B + b;
+    T yn[n], Am[n * n], Bm[n * m], lx[n], lu[m], y[n];
+#pragma unroll
     for (int e = 0; e < n; ++e) yn[e] = cn[(int64_t)(n + e) * B];
+#pragma unroll
+    for (int e = 0; e < n * n; ++e) Am[e] = in[(int64_t)(D::O_A + e) * B];
+#pragma unroll
+    for (int e = 0; e < n * m; ++e) Bm[e] = in[(int64_t)(D::O_B + e) * B];
+#pragma unroll
+    for (int e = 0; e < n; ++e) lx[e] = in[(int64_t)(D::O_q + e) * B];
+#pragma unroll
+    for (int e = 0; e < m; ++e) lu[e] = in[(int64_t)(D::O_r + e) * B];
+#pragma unroll
+    for (int e = 0; e < n; ++e) y[e] = c[(int64_t)(n + e) * B];
+#pragma unroll
     for (int j = 0; j < n; ++j) {
       T s = T(0);
-      for (int i = 0; i < n; ++i) s += in[(int64_t)(D::O_A + i + j * n) * B] * yn[i];
-      res = fmax(res, fabs(in[(int64_t)(D::O_q + j) * B] + s - c[(int64_t)(n + j) * B]));
+#pragma unroll
+      for (int i = 0; i < n; ++i) s += Am[i + j * n] * yn[i];
+      res = fmax(res, fabs(lx[j] + s - y[j]));
     }
+#pragma unroll
     for (int j = 0; j < m; ++j) {
       T s = T(0);
-      for (int i = 0; i < n; ++i) s += in[(int64_t)(D::O_B + i + j * n) * B] * yn[i];
-      res = fmax(res, fabs(in[(int64_t)(D::O_r + j) * B] + s));
+#pragma unroll
+      for (int i = 0; i < n; ++i) s += Bm[i + j * n] * yn[i];
+      res = fmax(res, fabs(lu[j] + s));
     }
   } else {
     for (int j = 0; j < n; ++j)
@@ -541,3 +569,6 @@ __global__ void ilqr_shift_kernel(IlqrArgs<T> a) {
 }
 
 }  // namespace altro_hip
+#if defined(__clang__)
+#pragma clang fp contract(fast)
+#endif

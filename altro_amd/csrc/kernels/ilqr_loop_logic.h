@@ -7,6 +7,9 @@
 
 #include "ilqr_types.h"
 
+#if defined(__clang__)
+#pragma clang fp contract(on)   // single-expression a * b + c only: the same rounding in every kernel these functions are inlined into (see models.h)
+#endif
 namespace altro_hip {
 
 // start of a solve (what a fresh Solve() call resets)
@@ -90,3 +93,6 @@ __device__ __forceinline__ bool ilqr_penalty_update_logic(IlqrProb& p, const Ilq
 }
 
 }  // namespace altro_hip
+#if defined(__clang__)
+#pragma clang fp contract(fast)
+#endif

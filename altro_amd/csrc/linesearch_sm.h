@@ -17,6 +17,9 @@
 #define ALTRO_LS_HD inline
 #endif
 
+#if defined(__clang__)
+#pragma clang fp contract(on)   // single-expression a * b + c only: the same rounding in every kernel these functions are inlined into (see models.h)
+#endif
 namespace altro_hip {
 
 enum LsStatus {   // linesearch.hpp:16-25
@@ -257,3 +260,6 @@ ALTRO_LS_HD bool ls_feed(LsState& s, const LsOptions& o, double phi, double dphi
 }
 
 }  // namespace altro_hip
+#if defined(__clang__)
+#pragma clang fp contract(fast)
+#endif

@@ -18,6 +18,14 @@
 #define ALTRO_HD inline
 #endif
 
+#if defined(__clang__)
+// Contraction: `on` = a * b + c is fused where it is ONE source expression, and nowhere else.  Unlike `fast`, which lets
+// the optimiser fuse across statements depending on what surrounds the code, this does not depend on the kernel a
+// function is inlined into -- the launch-sequenced solve and the fused solve kernel (ilqr_fused.hip) therefore round
+// identically, bit for bit.
+#pragma clang fp contract(on)
+#endif
+
 namespace altro_hip {
 
 enum ModelKind { MODEL_LINEAR = 0, MODEL_DOUBLE_INTEGRATOR = 1, MODEL_PENDULUM = 2, MODEL_BICYCLE = 3 };
@@ -230,12 +238,13 @@ struct DiscreteModel {
         xn[i + dim] = x[i + dim] + ui * (T)h;
       }
     } else {
-      T xm[n];
-      cont_f(mp, x, u, xm);
-      for (int i = 0; i < n; ++i) xm[i] *= (T)(h / 2);
-      for (int i = 0; i < n; ++i) xm[i] += x[i];
-      cont_f(mp, xm, u, xn);
-      for (int i = 0; i < n; ++i) xn[i] = x[i] + (T)h * xn[i];
+      // (the SAME expressions as step() below: under `fp contract(on)` identical source rounds identically, which is what
+      //  makes a derivative-free merit pass -- a speculative line-search trial -- land on the bits of a full one)
+      T k1[n], xm[n], k2[n];
+      cont_f(mp, x, u, k1);
+      for (int i = 0; i < n; ++i) xm[i] = x[i] + (T)(h / 2) * k1[i];
+      cont_f(mp, xm, u, k2);
+      for (int i = 0; i < n; ++i) xn[i] = x[i] + (T)h * k2[i];
     }
   }
 
@@ -285,3 +294,7 @@ struct DiscreteModel {
 };
 
 }  // namespace altro_hip
+
+#if defined(__clang__)
+#pragma clang fp contract(fast)
+#endif

@@ -268,14 +268,18 @@ def lane_config(args, rank, local_rank, world, dist, torch):
     rep = repeat_block(bt, torch, elapsed / args.steps * 1e3, args.repeat_seconds)
     ms_b, nb, name_b = kern[0]["avg_ms"], 1, kern[0]["name"]
     ms_f, nf, name_f = kern[1]["avg_ms"], 1, kern[1]["name"]
-    # one full batched solve (all problems to convergence), timed on the host clock
-    bt.set_input_guess(np.array([[[u_ref[0][0], 0.0]]]) if c3 else np.array([[[0.1]]]), k_stride_zero=True,
-                       batch_stride_zero=True)
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    res = bt.ilqr_solve(iterations_max=80, use_backtracking=c3)
-    torch.cuda.synchronize()
-    t_solve = time.perf_counter() - t1
+    # one full batched solve (all problems to convergence), timed on the host clock; one untimed solve first (the first
+    # launch of each kernel loads its code object), duals and penalties reset in between so that both start alike
+    for timed in (False, True):
+        if c3:
+            bt.reset_duals(1.0)
+        bt.set_input_guess(np.array([[[u_ref[0][0], 0.0]]]) if c3 else np.array([[[0.1]]]), k_stride_zero=True,
+                           batch_stride_zero=True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        res = bt.ilqr_solve(iterations_max=80, use_backtracking=c3)
+        torch.cuda.synchronize()
+        t_solve = time.perf_counter() - t1
     stats = global_stats(bt, local_rank, rank, world, shard)     # after the solve: the quantities Solve reports
     if rank == 0:
         bytes_b, bytes_f = bt.algorithmic_bytes(0), bt.algorithmic_bytes(1)
