@@ -103,6 +103,7 @@ IlqrArgs<T> ilqr_args(altro_hip_batch* h, bool use_alpha, bool use_active, int w
   a.mp = h->model; a.N = h->N; a.batch = h->batch; a.want_derivative = want_deriv; a.alpha_const = alpha_const;
   a.cand_spec = (T*)h->i_cand_spec; a.spec_trials = h->i_cand_spec ? h->spec_trials : 1; a.spec_sel = h->i_spec_sel;
   a.spec_pre = h->i_cand_spec ? h->spec_pre : 0;
+  a.spec_flip = 0;
   a.spec_stride = (int64_t)h->batch * (h->N + 1) * lane_sizes(h->n, h->m).e_xuy;
   a.ls_beta = h->spec_beta; a.ls_max_iters = h->spec_max_iters;
   return a;
@@ -612,14 +613,29 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
   h->bwd_active = h->i_active;
   h->bwd_reg = reg_on ? h->i_reg : nullptr;
   int total_reg_retries = 0;
-  // Plan LANE: the sweeps run fused, whole sweeps per launch with no host in between (kernels/ilqr_fused.hip).  With the
-  // cubic line search that is the whole solve; with the backtracking search the first sweeps -- where nearly every
-  // problem converges -- and the stragglers then continue below, where several backtracking steps ride one launch.
-  // Bit-identical either way (tests/test_gpu_fused.py).  ALTRO_HIP_NO_FUSED (any value) keeps everything below;
-  // ALTRO_HIP_FUSED_SWEEPS=n sets the hand-over point.
+  // Plan LANE: the sweeps run fused -- whole sweeps per launch, a workgroup of four waves per 64 problems sequencing itself
+  // with no host in between (kernels/ilqr_fused.hip); bit-identical to the loop below (tests/test_gpu_fused.py).
+  // Which of the two runs is a measured choice (tools/solve_ab.py, DESIGN.md "Fused solve"): POLICY below.
+  // ALTRO_HIP_FUSED=1 / =0 forces one or the other (ALTRO_HIP_NO_FUSED, any value, = the latter);
+  // ALTRO_HIP_FUSED_SWEEPS=n hands the problems still running after n sweeps over to the loop below (a test hook: the
+  // hand-over is exact at any sweep).
   int iter0 = 0;
-  if (lane_plan && std::getenv("ALTRO_HIP_NO_FUSED") == nullptr && o.iterations_max > 0) {
-    int fused_sweeps = o.use_backtracking_linesearch ? std::min(o.iterations_max, 12) : o.iterations_max;
+  // (n <= 4: the shapes the fused kernel is instantiated for, ilqr_launch_f64.hip)
+  bool fused_can = lane_plan && h->n <= 4 && o.iterations_max > 0 && !h->spec_no_memory;
+  // POLICY (MI355X, batch 8192, 80 sweeps): pendulum 3.29 against 3.73 ms (cubic) and 3.41 against 3.82 ms (backtracking);
+  // bicycle + steering bound 105 against 187 ms (cubic), but 72.5 against 68.6 ms with backtracking, where the loop below
+  // evaluates up to eight steps per launch on otherwise idle CUs and the fused bicycle body spills (368 B / lane).
+  bool fused_want = !(o.use_backtracking_linesearch && h->n > 2);
+  if (const char* e = std::getenv("ALTRO_HIP_FUSED")) fused_want = std::atoi(e) != 0;
+  if (std::getenv("ALTRO_HIP_NO_FUSED") != nullptr) fused_want = false;
+  bool fused = fused_can && fused_want;
+  if (fused && !h->i_cand_spec && dmalloc(h, &h->i_cand_spec, spare_bytes)) {   // the waves' speculative steps need the spare
+    (void)hipGetLastError();                                                    // trajectories; without them: sequenced loop
+    h->spec_no_memory = true;
+    fused = false;
+  }
+  if (fused) {
+    int fused_sweeps = o.iterations_max;
     if (const char* e = std::getenv("ALTRO_HIP_FUSED_SWEEPS")) fused_sweeps = std::max(1, std::min(o.iterations_max, std::atoi(e)));
     HIP_TRY(hipMemsetAsync(h->i_counters, 0, 4 * sizeof(int), h->stream));
     IlqrFusedArgs fa{0, fused_sweeps, o.reg_retry_max, reg_on ? 1 : 0, h->i_counters};

@@ -1,18 +1,22 @@
 // ilqr_fused.hip -- plan LANE: whole sweeps of SolverImpl::Solve (solver.cpp:447-502) in ONE kernel launch.
 //
-// On plan LANE a problem lives in one lane from the first knot point to the last, and no kernel of the loop ever reads
-// another problem's data: the launch boundaries of the launch-sequenced solve (capi_ilqr.hip) carry no dependency, only
-// cost -- ~13 launches and two or three host read-backs per sweep, a third of the wall time of a small solve
-// (profiles/r02a_c2_rocprofv3.txt: 2.95 ms of kernels in a 4.5 ms solve).  Here a wave runs its 64 problems through
-//     [AL Hessians] -> backward sweep (+ regularisation retries) -> merit(0) -> line search (a merit pass per trial step)
-//     -> stationarity / feasibility -> accept -> convergence test -> [dual / penalty update, gradient refresh]
-// sweep after sweep with no launch and no host in between, and retires as soon as its own problems have stopped (a
-// straggler holds its own wave, not the batch).  The arithmetic is the SAME device functions the sequenced path's kernels
-// call (ilqr_lane.hip, tvlqr_lane_body.inc, ilqr_loop_logic.h, linesearch_sm.h), in the order the sequenced path runs them
-// without speculation, so every result is bit-identical to it (tests/test_gpu_fused.py); the per-(problem, knot point)
-// kernels become loops over k inside the lane.  What this path does not have is the speculative evaluation of several
-// backtracking steps per launch: the host hands problems that are still running after `max_sweeps` sweeps back to the
-// sequenced loop, which has it (capi_ilqr.hip).
+// On plan LANE no kernel of the loop ever reads another problem's data, so the launch boundaries of the
+// launch-sequenced solve (capi_ilqr.hip) carry no dependency, only cost: ~13 launches and two or three host read-backs
+// per sweep.  Here a WORKGROUP of W = 4 wavefronts owns 64 problems (lane t of every wave <-> problem b0 + t) and runs
+// the very sequence the host loop enqueues, with `__syncthreads()` where the host has a launch boundary and
+// `__syncthreads_count()` where it reads a counter back:
+//   * the serial chains -- backward sweep, merit rollout -- run in one wave per pass, and the waves that would idle
+//     evaluate the line search's steps that are known in advance, exactly like the speculative launches of the host
+//     loop (gridDim.y there, the wave index here): wave 1 takes the first step alpha0 = 1 next to wave 0's phi(0), and
+//     in the backtracking stage the four waves take alpha beta^0..3 at once;
+//   * what is independent in k -- expansions, stationarity / feasibility, accept, dual updates, the copy of a spare
+//     candidate -- is dealt round-robin over the four waves (knot point k to wave k mod 4), the same point functions the
+//     (problem, knot point)-parallel kernels call.
+// Every function called is the body of a kernel of the sequenced path (ilqr_lane.hip, tvlqr_lane_body.inc,
+// ilqr_loop_logic.h), on the same per-batch arrays, in the same order: results are bit-identical to it with and without
+// its speculation (tests/test_gpu_fused.py).  A workgroup retires as soon as its 64 problems have stopped: a
+// straggler holds its own four waves, not the batch.  All waves of a workgroup sit on one CU and share its vector L1,
+// which is what makes a `__syncthreads()` enough between a store of one wave and a load of another.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -21,102 +25,139 @@
 
 namespace altro_hip {
 
+constexpr int ILQR_FUSED_WAVES = 4;
+
+// (Calling the heavy phases instead of inlining them -- to keep the bicycle's merit rollout, backward sweep and
+//  expansions from sharing one register allocation, 256 VGPRs + 256 AGPRs + 368 bytes of scratch against 256 + 140 for
+//  the stand-alone merit kernel -- was measured and is far worse: C2 6.4 ms against 3.3 ms, the by-reference argument
+//  blocks go through scratch.)
 template <int KIND, int n, int m, typename T>
-__global__ __launch_bounds__(64) void ilqr_fused_sweeps_kernel(IlqrArgs<T> a, IlqrLoopArgs la, LaneArgs<T> ba, IlqrFusedArgs fa) {
-  // the same wave -> problems mapping as the sweep kernels (XCD-aware, tvlqr_lane_body.inc)
+__global__ __launch_bounds__(64 * ILQR_FUSED_WAVES) void ilqr_fused_sweeps_kernel(IlqrArgs<T> a, IlqrLoopArgs la, LaneArgs<T> ba,
+                                                                                   IlqrFusedArgs fa) {
+  constexpr int W = ILQR_FUSED_WAVES;
+  // the same wave -> problems mapping as the sweep kernels (XCD-aware, tvlqr_lane_body.inc), one workgroup per 64 problems
   const int nwv = (a.batch + 63) / 64, chk = (nwv + 7) / 8;
   const int wv = (int)((blockIdx.x & 7) * chk + (blockIdx.x >> 3));
   if (wv >= nwv) return;
-  const int tid = threadIdx.x;
+  const int w = threadIdx.x >> 6, t = threadIdx.x & 63;
   const int64_t b0 = (int64_t)wv * 64;
-  const int64_t b = b0 + tid;
+  const int64_t b = b0 + t;
   const int64_t B = a.batch;
   const bool valid = b < B;
+  const int bi = (int)(valid ? b : b0);           // (lanes past the batch never dereference it)
   const int N = a.N;
-  const uint32_t lane = (uint32_t)tid * (uint32_t)sizeof(T);
+  const uint32_t lane = (uint32_t)t * (uint32_t)sizeof(T);
   const uint32_t rowB = (uint32_t)B * (uint32_t)sizeof(T);
   const bool al = a.al.enabled != 0;
-  IlqrProb* pp = a.prob + (valid ? b : 0);
+  const bool lead = w == 0 && valid;              // wave 0 keeps the per-problem books
   int sweeps = 0;
 
+  // one knot point in W of every (problem, knot point)-parallel step
+#define FUSED_FOR_K(MASKED, CALL)                      \
+  for (int k = w; k <= N; k += W)                       \
+    if (valid && (MASKED)) { CALL; }
+
   for (int it = fa.first_iter; it < fa.first_iter + fa.max_sweeps; ++it) {
-    const bool run = valid && pp->running != 0;
-    if (__ballot(run) == 0ull) break;
+    la.iter = it;
+    if (__syncthreads_count(lead && la.prob[bi].running != 0) == 0) break;
     ++sweeps;
+    if (lead) ilqr_mark_running_body(la, bi);
+    __syncthreads();
     // CalcExpansions: the cost Hessians change only through the constraints' terms (solver.cpp:448)
-    if (al)
-      for (int k = 0; k <= N; ++k)
-        if (run) ilqr_expand_point<KIND, n, m, T>(a, b, k, false, true);
+    if (al) {
+      FUSED_FOR_K(la.active[bi], (ilqr_expand_point<KIND, n, m, T>(a, b, k, false, true)));
+      __syncthreads();
+    }
     // BackwardPass (reg = 0 in the reference, solver.cpp:363); extension: repeat with a growing per-problem reg
-    {
-      bool again = run;
-      for (int attempt = 0; attempt <= fa.reg_retry_max; ++attempt) {
-        if (__ballot(again) == 0ull) break;
-        int status = -1;
-        if (again) {
-          const T reg = fa.use_reg ? (T)la.reg[b] : T(0);
-          status = lane_backward_lane<n, m, T>(ba, b0, tid, reg);
-        }
-        if (attempt == fa.reg_retry_max) break;
-        again = again && ilqr_reg_retry_logic(*pp, la, la.reg[b], status);
-      }
+    if (lead && la.active[bi]) (void)lane_backward_lane<n, m, T>(ba, b0, t, fa.use_reg ? (T)la.reg[bi] : T(0));
+    for (int attempt = 0; attempt < fa.reg_retry_max; ++attempt) {
+      __syncthreads();
+      const bool again = lead && ilqr_reg_retry_body(la, bi);
+      if (__syncthreads_count(again) == 0) break;
+      if (again) (void)lane_backward_lane<n, m, T>(ba, b0, t, (T)la.reg[bi]);
     }
-    // ForwardPass: phi(0) and phi'(0), then the line search, one merit pass per trial step (solver.cpp:237-271)
-    bool need = false;
-    {
-      T phi = T(0), dphi = T(0);
-      if (run) {
-        ilqr_merit_lane<KIND, n, m, T>(a, b, b0, lane, rowB, T(0), true, true, a.cand, phi, dphi);
-        need = ilqr_ls_begin_logic(*pp, la.ls, la.tol_meritfun_gradient, (double)phi, (double)dphi);
-        pp->evaluating = need ? 1 : 0;
-      }
-      while (__ballot(need) != 0ull) {
-        if (need) {
-          ilqr_merit_lane<KIND, n, m, T>(a, b, b0, lane, rowB, (T)pp->ls.alpha, true, true, a.cand, phi, dphi);
-          need = ls_feed(pp->ls, la.ls, (double)phi, (double)dphi);
-          if (!need) { pp->evaluating = 0; ilqr_ls_end_logic(*pp); }
-        }
-      }
+    if (fa.reg_retry_max > 0) {
+      __syncthreads();
+      if (lead) ilqr_mark_running_body(la, bi);
     }
+    __syncthreads();
+    // ForwardPass: phi(0) in wave 0 and, next to it, the first step the search will ask for (alpha0 = 1) in wave 1
+    {
+      IlqrArgs<T> am = a;
+      // (roles swapped, IlqrArgs::spec_flip: the alpha0 = 1 pass writes the candidate and the expansion, phi(0) -- whose
+      //  trajectory is the nominal one and whose expansion is the one already in place -- goes to spare candidate 0)
+      am.alpha = la.alpha; am.want_derivative = 1; am.spec_trials = 2; am.spec_pre = 1; am.spec_flip = 1;
+      if (w < 2 && valid && la.active[bi]) ilqr_merit_body<KIND, n, m, T>(am, b, b0, lane, rowB, w);
+    }
+    __syncthreads();
+    la.spec_pre = 1;
+    bool need0 = false;
+    if (lead) {
+      const bool was_running = la.prob[bi].running != 0;
+      need0 = ilqr_ls_begin_body(la, bi);
+      // what the swap changes afterwards: a search that ended ON the first step has its trajectory and expansion in place
+      // already; one that ended WITHOUT it (phi' too small, not a descent direction: alpha = 0) takes the phi(0)
+      // trajectory back from the spare and has its expansion redone
+      if (la.spec_sel[bi] == 1) { la.spec_sel[bi] = 0; la.spec_refresh[bi] = 0; }
+      else if (was_running && !need0) { la.spec_sel[bi] = 1; la.spec_refresh[bi] = 1; }
+    }
+    int searching = __syncthreads_count(need0);
+    la.spec_pre = 0;
+    FUSED_FOR_K(true, (ilqr_spec_select_point<n, m, T>(a, b, k)));
+    // the line search: one round = one merit evaluation per searching problem; in the backtracking stage the four waves
+    // take the next four steps of the (known) sequence alpha beta^j at once
+    while (searching > 0) {
+      __syncthreads();
+      const int trials = la.ls.use_backtracking ? W : 1;
+      {
+        IlqrArgs<T> am = a;
+        am.alpha = la.alpha; am.want_derivative = 1; am.spec_trials = trials; am.spec_pre = 0;
+        if (w < trials && valid && la.active[bi]) ilqr_merit_body<KIND, n, m, T>(am, b, b0, lane, rowB, w);
+      }
+      __syncthreads();
+      la.spec_trials = trials;
+      searching = __syncthreads_count(lead && ilqr_ls_feed_body(la, bi));
+      la.spec_trials = 1;
+      if (trials > 1) FUSED_FOR_K(true, (ilqr_spec_select_point<n, m, T>(a, b, k)));
+    }
+    __syncthreads();
+    // steps accepted from a speculative trial carry no phi' pass: redo their expansion (what the derivative pass of a
+    // sequential trial would have left behind)
+    FUSED_FOR_K(la.spec_refresh[bi], (ilqr_expand_point<KIND, n, m, T>(a, b, k, true, false)));
+    __syncthreads();
     // convergence criteria on the accepted candidate, then make it the nominal (solver.cpp:459-469)
-    {
-      T stat = T(0), feas = T(0);
-      // (reads only: unrolled so that the operand loads of four knot points are in flight at once -- one lane walks its
-      //  own problem's knot points here, where the stand-alone kernel has a thread per (problem, knot point))
-#pragma unroll 4
-      for (int k = 0; k <= N; ++k)
-        if (run) {
-          T r, v;
-          ilqr_stationarity_point<n, m, T>(a, b, k, r, v);
-          stat = fmax(stat, r);
-          feas = fmax(feas, v);
-        }
-#pragma unroll 4
-      for (int k = 0; k <= N; ++k)
-        if (run) ilqr_accept_point<n, m, T>(a, b, k);
-      if (run) {
-        pp->stationarity = (double)stat;
-        pp->feasibility = (double)feas;
-        ilqr_finish_iter_logic(*pp, la, it);
-      }
+    if (lead) {
+      ilqr_mark_running_body(la, bi);
+      if (la.prob[bi].running) { la.prob[bi].stationarity = 0.0; la.prob[bi].feasibility = 0.0; }
     }
+    __syncthreads();
+    for (int k = w; k <= N; k += W)
+      if (valid && la.active[bi]) {
+        T res, viol;
+        ilqr_stationarity_point<n, m, T>(a, b, k, res, viol);
+        atomicMax(reinterpret_cast<unsigned long long*>(&a.prob[b].stationarity), (unsigned long long)__double_as_longlong((double)res));
+        if (al)
+          atomicMax(reinterpret_cast<unsigned long long*>(&a.prob[b].feasibility), (unsigned long long)__double_as_longlong((double)viol));
+        ilqr_accept_point<n, m, T>(a, b, k);
+      }
+    __syncthreads();
+    if (lead) (void)ilqr_finish_iter_body(la, bi);
+    __syncthreads();
     // DualUpdate, PenaltyUpdate, refreshed cost gradients for the problems that asked (solver.cpp:470-489)
     if (al) {
-      const bool dual = run && pp->dual != 0;
-      if (__ballot(dual) != 0ull) {
-        for (int k = 0; k <= N; ++k)
-          if (dual) ilqr_dual_point<n, m, T>(a, b, k);
-        if (dual) (void)ilqr_penalty_update_logic(*pp, la);
-        for (int k = 0; k <= N; ++k)
-          if (dual) ilqr_expand_point<KIND, n, m, T>(a, b, k, true, false);
-      }
+      FUSED_FOR_K(la.prob[bi].dual, (ilqr_dual_point<n, m, T>(a, b, k)));
+      __syncthreads();
+      if (lead) ilqr_penalty_update_body(la, bi);
+      __syncthreads();
+      FUSED_FOR_K(la.active[bi], (ilqr_expand_point<KIND, n, m, T>(a, b, k, true, false)));
+      __syncthreads();
     }
   }
-  // hand-back: how many problems the launch leaves running, how many sweeps its slowest wave took
-  const bool still = valid && pp->running != 0;
-  const unsigned long long m64 = __ballot(still);
-  if (tid == 0) {
-    if (m64) atomicAdd(&fa.counters[1], __popcll(m64));
+#undef FUSED_FOR_K
+  // hand-back: how many problems the launch leaves running, how many sweeps its slowest workgroup took
+  const int still = __syncthreads_count(lead && la.prob[bi].running != 0);
+  if (threadIdx.x == 0) {
+    if (still) atomicAdd(&fa.counters[1], still);
     atomicMax(&fa.counters[3], sweeps);
   }
 }

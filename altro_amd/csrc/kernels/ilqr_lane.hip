@@ -386,21 +386,19 @@ __device__ __forceinline__ void ilqr_merit_lane(const IlqrArgs<T>& a, int64_t b,
   if (al) a.prob[b].rho_est = (double)rho;
 }
 
-// One launch = one merit evaluation per problem (and, with gridDim.y > 1, the speculative trials of IlqrArgs).
+// One merit evaluation of problem b: trial 0 is the step the search asked for (alpha[b]); trial > 0 a speculative one
+// (IlqrArgs::spec_trials / spec_pre) into its own phi row and spare candidate trajectory.
 template <int KIND, int n, int m, typename T>
-__global__ __launch_bounds__(64) void ilqr_merit_kernel(IlqrArgs<T> a) {
-  ILQR_PROLOGUE;
-  if (a.active && !a.active[b]) return;
-  const uint32_t lane = threadIdx.x * (uint32_t)sizeof(T);
-  const uint32_t rowB = (uint32_t)B * (uint32_t)sizeof(T);
-  const int64_t b0 = (int64_t)blockIdx.x * 64;
+__device__ __forceinline__ void ilqr_merit_body(const IlqrArgs<T>& a, int64_t b, int64_t b0, uint32_t lane, uint32_t rowB, int trial) {
+  const int64_t B = a.batch;
   double alpha_d = a.alpha ? a.alpha[b] : a.alpha_const;
   T* cand = a.cand;
-  const int trial = blockIdx.y;   // > 0: a speculative backtracking trial (IlqrArgs::spec_trials)
   bool store = true;              // a derivative pass also leaves A, B, lx, lu behind -- except the fused first trial
   if (trial > 0 && a.spec_pre) {  // next to phi(0): the step alpha0 = 1 the search will ask for first, phi and phi'
     if (trial > 1) return;
     alpha_d = 1.0;
+    if (!a.spec_flip) { cand = a.cand_spec; store = false; }
+  } else if (trial == 0 && a.spec_pre && a.spec_flip) {   // (fused solve kernel) the phi(0) pass steps aside
     cand = a.cand_spec;
     store = false;
   } else if (trial > 0) {
@@ -422,9 +420,32 @@ __global__ __launch_bounds__(64) void ilqr_merit_kernel(IlqrArgs<T> a) {
   a.phi[(int64_t)trial * B + b] = (double)phi;
   if (deriv) a.dphi[(int64_t)trial * B + b] = (double)dphi;
 }
+// one launch = one merit evaluation per problem; gridDim.y > 1: the speculative trials ride along
+template <int KIND, int n, int m, typename T>
+__global__ __launch_bounds__(64) void ilqr_merit_kernel(IlqrArgs<T> a) {
+  ILQR_PROLOGUE;
+  if (a.active && !a.active[b]) return;
+  ilqr_merit_body<KIND, n, m, T>(a, b, (int64_t)blockIdx.x * 64, threadIdx.x * (uint32_t)sizeof(T),
+                                 (uint32_t)B * (uint32_t)sizeof(T), (int)blockIdx.y);
+}
 
-// Speculative backtracking: the problems that just ended their search on spare trajectory spec_sel[b] - 1 get it
-// copied over their candidate trajectory (rows x | y | u of every knot point).
+// Speculative backtracking: a problem that just ended its search on spare trajectory spec_sel[b] - 1 gets it copied
+// over its candidate trajectory (rows x | y | u); this is one knot point of that copy.
+template <int n, int m, typename T>
+__device__ __forceinline__ void ilqr_spec_select_point(const IlqrArgs<T>& a, int64_t b, int k) {
+  using I = IlqrDims<n, m>;
+  const int s = a.spec_sel[b];
+  if (s <= 0) return;
+  const int64_t B = a.batch;
+  const int64_t row0 = (int64_t)k * I::E_CAND * B + b;
+  const T* __restrict__ src = a.cand_spec + (int64_t)(s - 1) * a.spec_stride + row0;
+  T* __restrict__ dst = a.cand + row0;
+  T v[I::E_CAND];
+#pragma unroll
+  for (int e = 0; e < I::E_CAND; ++e) v[e] = src[(int64_t)e * B];
+#pragma unroll
+  for (int e = 0; e < I::E_CAND; ++e) dst[(int64_t)e * B] = v[e];
+}
 template <int n, int m, typename T>
 __global__ void ilqr_spec_select_kernel(IlqrArgs<T> a) {
   using I = IlqrDims<n, m>;

@@ -92,6 +92,91 @@ __device__ __forceinline__ bool ilqr_penalty_update_logic(IlqrProb& p, const Ilq
   return p.dual != 0;
 }
 
+// ---- one problem's share of each bookkeeping step, on the per-batch arrays of IlqrLoopArgs: the bodies of the
+//      one-thread-per-problem kernels (ilqr_loop_kernels.hip), also called by the fused solve kernel -----------------------
+
+// set `active` := running (used before the per-sweep kernels)
+__device__ __forceinline__ void ilqr_mark_running_body(const IlqrLoopArgs& a, int b) {
+  a.active[b] = a.prob[b].running;
+  a.alpha[b] = 0.0;
+}
+
+// after merit(alpha = 0): ForwardPass's head (solver.cpp:241-249); returns whether problem b needs a merit evaluation
+__device__ __forceinline__ bool ilqr_ls_begin_body(const IlqrLoopArgs& a, int b) {
+  IlqrProb& p = a.prob[b];
+  a.spec_sel[b] = 0;
+  a.spec_refresh[b] = 0;
+  if (!p.running) { a.active[b] = 0; return false; }
+  bool need = ilqr_ls_begin_logic(p, a.ls, a.tol_meritfun_gradient, a.phi[b], a.dphi[b]);
+  // Fused first trial (IlqrLoopArgs::spec_pre): the merit launch that produced phi(0) also evaluated the first step
+  // alpha0 = 1 the search asks for (into phi / dphi row 1 and spare candidate 0), so it is consumed right here.
+  if (need && a.spec_pre) {
+    need = ls_feed(p.ls, a.ls, a.phi[(size_t)a.batch + b], a.dphi[(size_t)a.batch + b]);
+    if (!need) {   // the search ended on that step (same bookkeeping as ilqr_ls_feed_body)
+      ilqr_ls_end_logic(p);
+      a.spec_sel[b] = 1;
+      a.spec_refresh[b] = 1;
+    }
+  }
+  p.evaluating = need ? 1 : 0;
+  a.active[b] = need ? 1 : 0;
+  if (need) a.alpha[b] = p.ls.alpha;
+  return need;
+}
+
+// after merit(alpha[b]): advance the state machine of problem b; returns whether it needs another evaluation
+__device__ __forceinline__ bool ilqr_ls_feed_body(const IlqrLoopArgs& a, int b) {
+  IlqrProb& p = a.prob[b];
+  if (!p.running || !p.evaluating) { a.active[b] = 0; a.spec_sel[b] = 0; return false; }
+  // Speculative backtracking: the merit launch also evaluated alpha beta^j, j = 1 .. spec_trials - 1, for the problems
+  // that were in the backtracking stage or about to enter it (cubic first guess pending).  Feeding them in order
+  // reproduces the sequential search exactly; "need" after trial j - 1 is precisely the condition under which trial j
+  // exists (bt_iter below max_iters).
+  const int stage0 = p.ls.stage;
+  bool need = ls_feed(p.ls, a.ls, a.phi[b], a.dphi[b]);
+  int last = 0;
+  if (stage0 == LS_STAGE_BACKTRACK || stage0 == LS_STAGE_CUBIC)   // (a rejected cubic guess is followed by alpha0 beta^j, j >= 1)
+    for (int j = 1; j < a.spec_trials && need && p.ls.stage == LS_STAGE_BACKTRACK; ++j) {
+      need = ls_feed(p.ls, a.ls, a.phi[(size_t)j * a.batch + b], 0.0);
+      last = j;
+    }
+  a.spec_sel[b] = need ? 0 : last;          // the trajectory of the last trial fed is the one the search ends on
+  if (!need && last > 0) a.spec_refresh[b] = 1;
+  if (need) {
+    a.alpha[b] = p.ls.alpha;
+    a.active[b] = 1;
+  } else {
+    p.evaluating = 0;
+    a.active[b] = 0;
+    ilqr_ls_end_logic(p);
+  }
+  return need;
+}
+
+// end of one sweep (solver.cpp:459-502); `active` := still running; returns that
+__device__ __forceinline__ bool ilqr_finish_iter_body(const IlqrLoopArgs& a, int b) {
+  IlqrProb& p = a.prob[b];
+  if (p.running) ilqr_finish_iter_logic(p, a, a.iter);
+  else p.dual = 0;
+  a.active[b] = p.running;
+  return p.running != 0;
+}
+
+// regularisation retry after a backward pass (extension); `active` := repeat the backward pass; returns that
+__device__ __forceinline__ bool ilqr_reg_retry_body(const IlqrLoopArgs& a, int b) {
+  IlqrProb& p = a.prob[b];
+  const bool was_active = a.active[b] != 0;
+  bool again = false;
+  if (p.running && was_active) again = ilqr_reg_retry_logic(p, a, a.reg[b], a.bwd_status[b]);
+  a.active[b] = again ? 1 : 0;
+  return again;
+}
+
+// PenaltyUpdate; `active` := problems whose cost gradients have to be recomputed
+__device__ __forceinline__ void ilqr_penalty_update_body(const IlqrLoopArgs& a, int b) {
+  a.active[b] = ilqr_penalty_update_logic(a.prob[b], a) ? 1 : 0;
+}
+
 }  // namespace altro_hip
 #if defined(__clang__)
 #pragma clang fp contract(fast)

@@ -56,6 +56,9 @@ struct IlqrArgs {
   int spec_trials;      // 1 = no speculation
   int spec_pre;         // 1: this is the phi(0) launch and block row 1 evaluates the search's first step alpha0 = 1
                         //    (phi and phi' into row 1, no expansion stores, spare candidate 0)
+  int spec_flip;        // with spec_pre (fused solve kernel only): the roles are swapped -- the alpha0 = 1 pass writes the
+                        //    candidate trajectory and the expansion, the phi(0) pass goes to spare candidate 0 and stores
+                        //    nothing: the step that is nearly always accepted needs no copy and no re-expansion afterwards
   const int* spec_sel;  // [batch] IK_SPEC_SELECT: copy spare candidate spec_sel[b] - 1 over the candidate of problem b
   double ls_beta;       // CubicLineSearch::beta_decrease
   int ls_max_iters;

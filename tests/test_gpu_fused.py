@@ -17,7 +17,7 @@ KEYS = ("status", "iterations", "stationarity", "alpha", "phi", "feasibility", "
 
 
 def _solve(make, env, **opts):
-    saved = {k: os.environ.get(k) for k in ("ALTRO_HIP_NO_FUSED", "ALTRO_HIP_FUSED_SWEEPS", "ALTRO_HIP_NO_SPECULATION")}
+    saved = {k: os.environ.get(k) for k in ("ALTRO_HIP_NO_FUSED", "ALTRO_HIP_FUSED", "ALTRO_HIP_FUSED_SWEEPS", "ALTRO_HIP_NO_SPECULATION")}
     for k in saved:
         os.environ.pop(k, None)
     os.environ.update(env)
@@ -101,10 +101,10 @@ def _di_cones(kind, batch):
 ])
 def test_fused_solve_is_bit_identical_to_the_sequenced_loop(name, make, opts, duals):
     seq = _solve(make, {"ALTRO_HIP_NO_FUSED": "1", "ALTRO_HIP_NO_SPECULATION": "1"}, **opts)
-    fused = _solve(make, {"ALTRO_HIP_FUSED_SWEEPS": "1000"}, **opts)        # the whole solve in one launch
+    fused = _solve(make, {"ALTRO_HIP_FUSED": "1", "ALTRO_HIP_FUSED_SWEEPS": "1000"}, **opts)        # the whole solve in one launch
     _same(seq, fused)
     assert int(fused[0]["merit_launches"]) == 0 and int(seq[0]["merit_launches"]) > 0
-    hand = _solve(make, {"ALTRO_HIP_FUSED_SWEEPS": "2"}, **opts)            # two sweeps fused, the rest sequenced + speculative
+    hand = _solve(make, {"ALTRO_HIP_FUSED": "1", "ALTRO_HIP_FUSED_SWEEPS": "2"}, **opts)            # two sweeps fused, the rest sequenced + speculative
     _same(seq, hand)
     for (k, slot, p) in duals:   # the duals went the same way too
         z = seq[5].get_duals(k, slot, p)
@@ -125,7 +125,7 @@ def test_fused_regularisation_retry_matches_sequenced():
         return bt
     opts = dict(iterations_max=2, reg_retry_max=5, reg_min=0.01, reg_scale=10.0)
     seq = _solve(make, {"ALTRO_HIP_NO_FUSED": "1"}, **opts)
-    fused = _solve(make, {}, **opts)
+    fused = _solve(make, {"ALTRO_HIP_FUSED": "1"}, **opts)
     _same(seq, fused)
     assert (fused[0]["reg_retries"] >= 3).all() and (fused[5].get("status") == -1).all()
 
@@ -133,5 +133,5 @@ def test_fused_regularisation_retry_matches_sequenced():
 def test_fused_ragged_batch_and_short_horizon():
     for batch, N in ((1, 3), (65, 1), (130, 7)):
         seq = _solve(_pendulum(batch, N), {"ALTRO_HIP_NO_FUSED": "1"}, iterations_max=15)
-        fused = _solve(_pendulum(batch, N), {}, iterations_max=15)
+        fused = _solve(_pendulum(batch, N), {"ALTRO_HIP_FUSED": "1"}, iterations_max=15)
         _same(seq, fused)
