@@ -106,7 +106,23 @@ IlqrArgs<T> ilqr_args(altro_hip_batch* h, bool use_alpha, bool use_active, int w
   a.spec_flip = 0;
   a.spec_stride = (int64_t)h->batch * (h->N + 1) * lane_sizes(h->n, h->m).e_xuy;
   a.ls_beta = h->spec_beta; a.ls_max_iters = h->spec_max_iters;
+  a.merit_jk = h->merit_split == 1 ? (T*)h->i_merit_jk : nullptr;
+  a.spec_jac = (T*)h->i_spec_jac;
   return a;
+}
+// The buffers of the three-launch merit evaluation (first use).  No memory for them: the one-launch kernel, for good.
+void merit_split_prepare(altro_hip_batch* h) {
+  if (h->merit_split >= 0) return;
+  const char* e = std::getenv("ALTRO_HIP_MERIT_SPLIT");
+  h->merit_split = (e && std::atoi(e) == 0) ? 0 : 1;
+  if (!h->merit_split) return;
+  const size_t jk = (size_t)ILQR_SPEC_TRIALS * (h->N + 1) * h->batch * h->esz;
+  const size_t jac = ((size_t)h->N * (h->n * h->n + h->n * h->m + h->n + h->m) + h->n) * h->batch * h->esz;
+  if (dmalloc(h, &h->i_merit_jk, jk) || dmalloc(h, &h->i_spec_jac, jac)) {
+    (void)hipGetLastError();
+    if (h->i_merit_jk) { (void)hipFree(h->i_merit_jk); h->i_merit_jk = nullptr; }
+    h->merit_split = 0;
+  }
 }
 
 template <typename T>
@@ -147,6 +163,7 @@ int ilqr_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int
   if (h->plan == ALTRO_HIP_PLAN_MFMA16)   // linear dynamics: "expand" = cost gradient (+ AL Hessian terms when constrained)
     return h->dtype == ALTRO_HIP_F64 ? wave_run<double>(h, which, use_alpha, use_active, want_deriv, alpha_const, mode)
                                      : wave_run<float>(h, which, use_alpha, use_active, want_deriv, alpha_const, mode);
+  if (which == IK_MERIT) merit_split_prepare(h);
   if (h->dtype == ALTRO_HIP_F64) {
     auto a = ilqr_args<double>(h, use_alpha, use_active, want_deriv, alpha_const);
     a.mode = mode;

@@ -78,6 +78,10 @@ struct altro_hip_batch {
   // speculative backtracking (altro_hip_ilqr_solve): spare candidate trajectories, allocated on first use
   void* i_cand_spec = nullptr;
   int *i_spec_sel = nullptr, *i_spec_refresh = nullptr;
+  // MeritFunction in three launches (plan LANE, kernels/ilqr_lane.hip): per-knot-point costs of every trial and the
+  // spare A | B | lx | lu block; allocated on the first merit evaluation, merit_split = 0 keeps the one-launch kernel
+  void *i_merit_jk = nullptr, *i_spec_jac = nullptr;
+  int merit_split = -1;           // -1: not decided yet (ALTRO_HIP_MERIT_SPLIT, default on)
   int spec_trials = 1;            // trials per merit launch of the CURRENT launch (1 = no speculation)
   int spec_pre = 0;               // the current launch is phi(0) fused with the first trial step
   bool spec_no_memory = false;    // the spare trajectories could not be allocated: no speculation on this handle

@@ -28,7 +28,17 @@ int ilqr_launch_kernel<float>(hipStream_t stream, int which, int kind, int n, in
       case IK_ROLLOUT: hipLaunchKernelGGL((ilqr_rollout_kernel<K_, N_, M_, T>), lanes, b64, 0, stream, a); break;   \
       case IK_ACCEPT: hipLaunchKernelGGL((ilqr_accept_kernel<N_, M_, T>), flat, b256, 0, stream, a); break;         \
       case IK_EXPAND: hipLaunchKernelGGL((ilqr_expand_kernel<K_, N_, M_, T>), flat64, b64, 0, stream, a); break;    \
-      case IK_MERIT: hipLaunchKernelGGL((ilqr_merit_kernel<K_, N_, M_, T>), dim3(lanes.x, a.spec_trials > 1 ? a.spec_trials : 1), b64, 0, stream, a); break; \
+      case IK_MERIT: {                                                                                        \
+        const unsigned trials = a.spec_trials > 1 ? a.spec_trials : 1;                                        \
+        if (a.merit_jk) {   /* rollout | per-knot-point terms on the whole chip | sums and phi' */            \
+          hipLaunchKernelGGL((ilqr_merit_roll_kernel<K_, N_, M_, T>), dim3(lanes.x, trials), b64, 0, stream, a);   \
+          hipLaunchKernelGGL((ilqr_merit_point_kernel<K_, N_, M_, T>), dim3(flat64.x, trials), b64, 0, stream, a); \
+          hipLaunchKernelGGL((ilqr_merit_sum_kernel<K_, N_, M_, T>), dim3(lanes.x, trials), b64, 0, stream, a);    \
+        } else {                                                                                              \
+          hipLaunchKernelGGL((ilqr_merit_kernel<K_, N_, M_, T>), dim3(lanes.x, trials), b64, 0, stream, a);    \
+        }                                                                                                     \
+        break;                                                                                                \
+      }                                                                                                       \
       case IK_SPEC_SELECT: hipLaunchKernelGGL((ilqr_spec_select_kernel<N_, M_, T>), flat, b256, 0, stream, a); break; \
       case IK_DUAL: hipLaunchKernelGGL((ilqr_dual_update_kernel<N_, M_, T>), flat, b256, 0, stream, a); break;      \
       case IK_SHIFT: hipLaunchKernelGGL((ilqr_shift_kernel<N_, M_, T>), shift, b256, 0, stream, a); break;          \

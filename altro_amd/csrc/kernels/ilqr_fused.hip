@@ -39,7 +39,7 @@ __global__ __launch_bounds__(64 * ILQR_FUSED_WAVES) void ilqr_fused_sweeps_kerne
   const int nwv = (a.batch + 63) / 64, chk = (nwv + 7) / 8;
   const int wv = (int)((blockIdx.x & 7) * chk + (blockIdx.x >> 3));
   if (wv >= nwv) return;
-  const int w = threadIdx.x >> 6, t = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), t = threadIdx.x & 63;   // (w: provably wave-uniform)
   const int64_t b0 = (int64_t)wv * 64;
   const int64_t b = b0 + t;
   const int64_t B = a.batch;

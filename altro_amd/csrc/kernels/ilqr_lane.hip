@@ -386,39 +386,57 @@ __device__ __forceinline__ void ilqr_merit_lane(const IlqrArgs<T>& a, int64_t b,
   if (al) a.prob[b].rho_est = (double)rho;
 }
 
-// One merit evaluation of problem b: trial 0 is the step the search asked for (alpha[b]); trial > 0 a speculative one
-// (IlqrArgs::spec_trials / spec_pre) into its own phi row and spare candidate trajectory.
-template <int KIND, int n, int m, typename T>
-__device__ __forceinline__ void ilqr_merit_body(const IlqrArgs<T>& a, int64_t b, int64_t b0, uint32_t lane, uint32_t rowB, int trial) {
-  const int64_t B = a.batch;
-  double alpha_d = a.alpha ? a.alpha[b] : a.alpha_const;
-  T* cand = a.cand;
-  bool store = true;              // a derivative pass also leaves A, B, lx, lu behind -- except the fused first trial
+// Which step trial `trial` of problem b evaluates, where its trajectory goes and what it leaves behind: trial 0 is the step
+// the search asked for (alpha[b]); trial > 0 a speculative one (IlqrArgs::spec_trials / spec_pre) into its own phi row and
+// spare candidate trajectory.
+template <typename T>
+struct MeritTrial {
+  // the same for every problem of a launch row (kept free of per-lane control flow, so that the buffer descriptors built on
+  // `cand` stay in scalar registers)
+  T* cand;
+  bool deriv;   // phi' wanted (backtracking trials never ask for it)
+  bool store;   // a derivative pass also leaves A, B, lx, lu behind -- except the fused first trial
+  // per problem
+  double alpha;
+  bool run;     // false: nothing to evaluate for this (problem, trial)
+};
+template <typename T>
+__device__ __forceinline__ MeritTrial<T> ilqr_merit_trial(const IlqrArgs<T>& a, int64_t b, int trial) {
+  MeritTrial<T> tr;
+  tr.deriv = a.want_derivative != 0 && (trial == 0 || a.spec_pre);
+  const bool aside = a.spec_pre && (a.spec_flip ? trial == 0 : trial > 0);   // spare candidate 0, no expansion stores
+  tr.store = !aside;
+  tr.cand = aside ? a.cand_spec : (trial > 0 && !a.spec_pre) ? a.cand_spec + (int64_t)(trial - 1) * a.spec_stride : a.cand;
+  tr.alpha = a.alpha ? a.alpha[b] : a.alpha_const;
+  tr.run = false;
   if (trial > 0 && a.spec_pre) {  // next to phi(0): the step alpha0 = 1 the search will ask for first, phi and phi'
-    if (trial > 1) return;
-    alpha_d = 1.0;
-    if (!a.spec_flip) { cand = a.cand_spec; store = false; }
-  } else if (trial == 0 && a.spec_pre && a.spec_flip) {   // (fused solve kernel) the phi(0) pass steps aside
-    cand = a.cand_spec;
-    store = false;
+    if (trial > 1) return tr;
+    tr.alpha = 1.0;
   } else if (trial > 0) {
     const LsState& ls = a.prob[b].ls;
     if (ls.stage == LS_STAGE_BACKTRACK) {          // pending: alpha beta^0 with bt_iter = t; trial j is bt_iter = t + j
-      if (ls.bt_iter + trial >= a.ls_max_iters) return;
+      if (ls.bt_iter + trial >= a.ls_max_iters) return tr;
     } else if (ls.stage == LS_STAGE_CUBIC) {       // pending: the cubic guess; if it is rejected the backtracking
-      if (trial >= a.ls_max_iters) return;         // sequence starts at alpha0 beta with bt_iter = 1 (linesearch.cpp:138)
-      alpha_d = ls.alpha0;
+      if (trial >= a.ls_max_iters) return tr;      // sequence starts at alpha0 beta with bt_iter = 1 (linesearch.cpp:138)
+      tr.alpha = ls.alpha0;
     } else {
-      return;
+      return tr;
     }
-    for (int t = 0; t < trial; ++t) alpha_d = alpha_d * a.ls_beta;   // the state machine's own sequence of products
-    cand = a.cand_spec + (int64_t)(trial - 1) * a.spec_stride;
+    for (int t = 0; t < trial; ++t) tr.alpha = tr.alpha * a.ls_beta;   // the state machine's own sequence of products
   }
-  const bool deriv = a.want_derivative != 0 && (trial == 0 || a.spec_pre);   // backtracking trials never ask for phi'
+  tr.run = true;
+  return tr;
+}
+// One merit evaluation of problem b in one lane: rollout, costs, phi' and the expansion, knot point after knot point.
+template <int KIND, int n, int m, typename T>
+__device__ __forceinline__ void ilqr_merit_body(const IlqrArgs<T>& a, int64_t b, int64_t b0, uint32_t lane, uint32_t rowB, int trial) {
+  const int64_t B = a.batch;
+  const MeritTrial<T> tr = ilqr_merit_trial<T>(a, b, trial);
+  if (!tr.run) return;
   T phi, dphi;
-  ilqr_merit_lane<KIND, n, m, T>(a, b, b0, lane, rowB, (T)alpha_d, deriv, store, cand, phi, dphi);
+  ilqr_merit_lane<KIND, n, m, T>(a, b, b0, lane, rowB, (T)tr.alpha, tr.deriv, tr.store, tr.cand, phi, dphi);
   a.phi[(int64_t)trial * B + b] = (double)phi;
-  if (deriv) a.dphi[(int64_t)trial * B + b] = (double)dphi;
+  if (tr.deriv) a.dphi[(int64_t)trial * B + b] = (double)dphi;
 }
 // one launch = one merit evaluation per problem; gridDim.y > 1: the speculative trials ride along
 template <int KIND, int n, int m, typename T>
@@ -427,6 +445,285 @@ __global__ __launch_bounds__(64) void ilqr_merit_kernel(IlqrArgs<T> a) {
   if (a.active && !a.active[b]) return;
   ilqr_merit_body<KIND, n, m, T>(a, b, (int64_t)blockIdx.x * 64, threadIdx.x * (uint32_t)sizeof(T),
                                  (uint32_t)B * (uint32_t)sizeof(T), (int)blockIdx.y);
+}
+
+// ---- MeritFunction in three launches ---------------------------------------------------------------------------------
+// Of everything ilqr_merit_lane does per knot point only two things are serial in k: the closed-loop rollout
+// x+ = f(x, u + alpha d - K dx) and the sensitivity dx/dalpha behind phi'.  Costs, constraint terms, dynamics Jacobians
+// and cost gradients depend on k through (x_k, u_k) alone.  So:
+//   1. ilqr_merit_roll_kernel   lane per (problem, trial): the rollout, nothing else -- the latency chain of the launch
+//   2. ilqr_merit_point_kernel  thread per (problem, knot point, trial), the whole chip: y, J_k (+ constraint terms),
+//                               A, B, lx, lu (into the backward pass's input record, or -- a speculative first step --
+//                               into the spare block a.spec_jac), J_k into a.merit_jk
+//   3. ilqr_merit_sum_kernel    lane per (problem, trial): phi = sum J_k in k order, the dx/dalpha recursion and phi'
+// Same expressions, same summation order as ilqr_merit_lane (the fused solve kernel still uses that): bit-identical
+// (tests/test_gpu_fused.py, tests/test_gpu_merit_split.py).
+template <int n, int m, typename T>
+struct MeritJac {   // where a derivative pass leaves A | B | lx | lu of knot point k and lx of the terminal one
+  T* p; int E, oA, oB, oq, orr;
+  T* term; int oterm;
+};
+template <int n, int m, typename T>
+__device__ __forceinline__ MeritJac<n, m, T> ilqr_merit_jac(const IlqrArgs<T>& a, bool store) {
+  using D = LaneDims<n, m>;
+  MeritJac<n, m, T> j;
+  if (store) {
+    j.p = a.in; j.E = D::E_IN; j.oA = D::O_A; j.oB = D::O_B; j.oq = D::O_q; j.orr = D::O_r; j.term = a.term; j.oterm = n * n;
+  } else {
+    j.p = a.spec_jac; j.E = n * n + n * m + n + m; j.oA = 0; j.oB = n * n; j.oq = n * n + n * m; j.orr = n * n + n * m + n;
+    j.term = a.spec_jac + (int64_t)a.N * j.E * a.batch; j.oterm = 0;
+  }
+  return j;
+}
+
+// depth of the prefetch rings of the serial kernels: about 48 loads in flight per wave, at most 4 records
+#define MERIT_RING(LOADS) ((LOADS) <= 12 ? 4 : (LOADS) <= 16 ? 3 : 2)
+template <int n, int m, typename T>
+struct RollRec {
+  T K[n * m], d[m], nom[n + m];
+};
+template <int n, int m, typename T>
+__device__ __forceinline__ void roll_load(RollRec<n, m, T>& r, const IlqrArgs<T>& a, int k, int64_t b0, uint32_t lane, uint32_t rowB) {
+  using D = LaneDims<n, m>;
+  using I = IlqrDims<n, m>;
+  const int64_t B = a.batch;
+  const LaneBuf bo(a.out + b0 + (int64_t)k * D::E_OUT * B), bn(a.nom + b0 + (int64_t)k * I::E_NOM * B);
+#pragma unroll
+  for (int e = 0; e < n * m; ++e) r.K[e] = lane_ld<T>(bo, lane, (uint32_t)(D::O_K + e) * rowB);
+#pragma unroll
+  for (int e = 0; e < m; ++e) r.d[e] = lane_ld<T>(bo, lane, (uint32_t)(D::O_d + e) * rowB);
+#pragma unroll
+  for (int e = 0; e < n + m; ++e) r.nom[e] = lane_ld<T>(bn, lane, (uint32_t)e * rowB);
+}
+template <int KIND, int n, int m, typename T>
+__global__ __launch_bounds__(64) void ilqr_merit_roll_kernel(IlqrArgs<T> a) {
+  ILQR_PROLOGUE;
+  if (a.active && !a.active[b]) return;
+  const MeritTrial<T> tr = ilqr_merit_trial<T>(a, b, (int)blockIdx.y);
+  if (!tr.run) return;
+  const int64_t b0 = (int64_t)blockIdx.x * 64;
+  const uint32_t lane = threadIdx.x * (uint32_t)sizeof(T), rowB = (uint32_t)B * (uint32_t)sizeof(T);
+  const T alpha = (T)tr.alpha;
+  T x[n], u[m], xn[n], dx[n];
+  {
+    const LaneBuf bx(a.x0 + b0);
+#pragma unroll
+    for (int e = 0; e < n; ++e) x[e] = lane_ld<T>(bx, lane, (uint32_t)e * rowB);
+  }
+  // None of the records' addresses depends on the rollout: they are requested RD knot points ahead (a ring of registers,
+  // statically indexed through the unrolled inner loop).  With one wave per SIMD the loop is otherwise paced by the
+  // latency of one record's loads (~0.5 us each knot point), not by the arithmetic.  The refills are UNCONDITIONAL (index
+  // clamped to the last record): a load under a branch lands in a temporary, and the copy into the ring waits for it.
+  constexpr int RD = MERIT_RING(n * m + 2 * m + n);
+  RollRec<n, m, T> ring[RD];
+  const int last = N > 0 ? N - 1 : 0;
+#pragma unroll
+  for (int d = 0; d < RD; ++d) roll_load<n, m, T>(ring[d], a, d < last ? d : last, b0, lane, rowB);
+  auto step = [&](RollRec<n, m, T>& r0, int k, bool refill) {
+    for (int i = 0; i < n; ++i) dx[i] = x[i] - r0.nom[i];
+    for (int i = 0; i < m; ++i) {   // u_ = u + (-K dx + alpha d)
+      T s = T(0);
+      for (int j = 0; j < n; ++j) s += r0.K[i + j * m] * dx[j];
+      u[i] = r0.nom[n + i] + (-s + alpha * r0.d[i]);
+    }
+    if (refill) roll_load<n, m, T>(r0, a, k + RD < last ? k + RD : last, b0, lane, rowB);
+    const LaneBuf bc(tr.cand + b0 + (int64_t)k * I::E_CAND * B);
+#pragma unroll
+    for (int e = 0; e < n; ++e) lane_st<T>(bc, lane, (uint32_t)e * rowB, x[e]);
+#pragma unroll
+    for (int e = 0; e < m; ++e) lane_st<T>(bc, lane, (uint32_t)(2 * n + e) * rowB, u[e]);
+    Mdl::dynamics(a.mp, x, u, xn);
+    for (int e = 0; e < n; ++e) x[e] = xn[e];
+  };
+  int k = 0;
+  for (; k + RD <= N; k += RD) {   // whole groups: nothing conditional between the loads
+#pragma unroll
+    for (int d = 0; d < RD; ++d) step(ring[d], k + d, true);
+  }
+#pragma unroll
+  for (int d = 0; d < RD; ++d)     // the last N mod RD knot points are in the ring already
+    if (k + d < N) step(ring[d], k + d, false);
+  const LaneBuf bc(tr.cand + b0 + (int64_t)N * I::E_CAND * B);
+#pragma unroll
+  for (int e = 0; e < n; ++e) lane_st<T>(bc, lane, (uint32_t)e * rowB, x[e]);
+}
+
+// everything of MeritFunction at ONE knot point of a rolled-out trial (solver.cpp:286-332 without the two recursions)
+template <int KIND, int n, int m, typename T>
+__device__ __forceinline__ void ilqr_merit_point(const IlqrArgs<T>& a, int64_t b, int k, int trial, const MeritTrial<T>& tr) {
+  using D = LaneDims<n, m>;
+  using I = IlqrDims<n, m>;
+  using Mdl = DiscreteModel<KIND, n, m, T>;
+  const int64_t B = a.batch;
+  const int N = a.N;
+  const bool terminal = k == N;
+  const bool al = a.al.enabled != 0;
+  T* c = tr.cand + (int64_t)k * I::E_CAND * B + b;
+  const T* cs_ = a.cost + (int64_t)k * I::E_COST * B + b;
+  const T* nm = a.nom + (int64_t)k * I::E_NOM * B + b;
+  const T* Pp = terminal ? a.outn + b : a.out + (int64_t)k * D::E_OUT * B + (int64_t)D::O_P * B + b;   // P | p
+  T x[n], u[m], dx[n], cs[I::E_COST], P[n * n + n];
+  for (int e = 0; e < n; ++e) x[e] = c[(int64_t)e * B];
+  for (int e = 0; e < m; ++e) u[e] = terminal ? T(0) : c[(int64_t)(2 * n + e) * B];
+  for (int e = 0; e < n; ++e) dx[e] = nm[(int64_t)e * B];
+  for (int e = 0; e < I::E_COST; ++e) cs[e] = cs_[(int64_t)e * B];
+  for (int e = 0; e < n * n + n; ++e) P[e] = Pp[(int64_t)e * B];
+  const T rho = al ? (T)a.prob[b].rho : T(1);
+  for (int e = 0; e < n; ++e) dx[e] = x[e] - dx[e];
+  for (int i = 0; i < n; ++i) {   // y_ = P dx + p
+    T s = T(0);
+    for (int j = 0; j < n; ++j) s += P[i + j * n] * dx[j];
+    c[(int64_t)(n + i) * B] = s + P[n * n + i];
+  }
+  static_assert(D::O_p == D::O_P + n * n, "P | p are adjacent in the backward pass's output record");
+  const MeritJac<n, m, T> jd = ilqr_merit_jac<n, m, T>(a, tr.store);
+  T lx[n], lu[m];
+  for (int i = 0; i < n; ++i) lx[i] = cs[I::C_Q + i] * x[i] + cs[I::C_q + i];
+  T Jk;
+  if (!terminal) {
+    for (int i = 0; i < m; ++i) lu[i] = cs[I::C_R + i] * u[i] + cs[I::C_r + i];
+    Jk = ilqr_kp_cost_reg<n, m, T>(cs, x, u, false);
+    if (al) Jk += al_eval<n, m, T, true, false>(a.al, k, b, B, x, u, false, rho, rho, lx, lu, nullptr, nullptr, nullptr, nullptr, false);
+    if (tr.deriv) {
+      T Am[n * n], Bm[n * m];
+      Mdl::jacobian(a.mp, x, u, Am, Bm);
+      T* j = jd.p + (int64_t)k * jd.E * B + b;
+      for (int e = 0; e < n * n; ++e) j[(int64_t)(jd.oA + e) * B] = Am[e];
+      for (int e = 0; e < n * m; ++e) j[(int64_t)(jd.oB + e) * B] = Bm[e];
+      for (int e = 0; e < n; ++e) j[(int64_t)(jd.oq + e) * B] = lx[e];
+      for (int e = 0; e < m; ++e) j[(int64_t)(jd.orr + e) * B] = lu[e];
+    }
+  } else {
+    Jk = ilqr_kp_cost_reg<n, m, T>(cs, x, (const T*)nullptr, true);
+    if (al) Jk += al_eval<n, m, T, true, false>(a.al, N, b, B, x, (const T*)nullptr, true, rho, rho, lx, nullptr, nullptr, nullptr, nullptr, nullptr, false);
+    if (tr.deriv)
+      for (int e = 0; e < n; ++e) jd.term[(int64_t)(jd.oterm + e) * B + b] = lx[e];
+  }
+  a.merit_jk[((int64_t)trial * (N + 1) + k) * B + b] = Jk;
+}
+template <int KIND, int n, int m, typename T>
+__global__ __launch_bounds__(64) void ilqr_merit_point_kernel(IlqrArgs<T> a) {
+  const int64_t B = a.batch;
+  const int64_t total = B * (a.N + 1);
+  const int trial = (int)blockIdx.y;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = t % B;
+    const int k = (int)(t / B);
+    if (a.active && !a.active[b]) continue;
+    const MeritTrial<T> tr = ilqr_merit_trial<T>(a, b, trial);
+    if (!tr.run) continue;
+    ilqr_merit_point<KIND, n, m, T>(a, b, k, trial, tr);
+  }
+}
+
+template <int n, int m, typename T>
+struct SumRec {
+  T K[n * m], d[m], A[n * n], Bm[n * m], lx[n], lu[m], J;
+};
+template <int n, int m, bool DERIV, typename T>
+__device__ __forceinline__ void sum_load(SumRec<n, m, T>& r, const IlqrArgs<T>& a, const MeritJac<n, m, T>& jd, const T* jk, int k,
+                                         int64_t b0, uint32_t lane, uint32_t rowB) {
+  using D = LaneDims<n, m>;
+  const int64_t B = a.batch;
+  r.J = lane_ld<T>(LaneBuf(jk + b0 + (int64_t)k * B), lane, 0u);
+  if constexpr (DERIV) {
+    const LaneBuf bo(a.out + b0 + (int64_t)k * D::E_OUT * B), bj(jd.p + b0 + (int64_t)k * jd.E * B);
+#pragma unroll
+    for (int e = 0; e < n * m; ++e) r.K[e] = lane_ld<T>(bo, lane, (uint32_t)(D::O_K + e) * rowB);
+#pragma unroll
+    for (int e = 0; e < m; ++e) r.d[e] = lane_ld<T>(bo, lane, (uint32_t)(D::O_d + e) * rowB);
+#pragma unroll
+    for (int e = 0; e < n * n; ++e) r.A[e] = lane_ld<T>(bj, lane, (uint32_t)(jd.oA + e) * rowB);
+#pragma unroll
+    for (int e = 0; e < n * m; ++e) r.Bm[e] = lane_ld<T>(bj, lane, (uint32_t)(jd.oB + e) * rowB);
+#pragma unroll
+    for (int e = 0; e < n; ++e) r.lx[e] = lane_ld<T>(bj, lane, (uint32_t)(jd.oq + e) * rowB);
+#pragma unroll
+    for (int e = 0; e < m; ++e) r.lu[e] = lane_ld<T>(bj, lane, (uint32_t)(jd.orr + e) * rowB);
+  }
+}
+// phi (and phi') of one (problem, trial) from the per-knot-point terms: the sums in k order, the dx/dalpha recursion
+template <int n, int m, bool DERIV, typename T>
+__device__ __forceinline__ void ilqr_merit_sum_lane(const IlqrArgs<T>& a, const MeritJac<n, m, T>& jd, const T* jk, int64_t b0,
+                                                    uint32_t lane, uint32_t rowB, T& phi_out, T& dphi_out) {
+  const int64_t B = a.batch;
+  const int N = a.N;
+  T dxda[n], phi = T(0), dphi = T(0);
+  for (int e = 0; e < n; ++e) dxda[e] = T(0);
+  // terminal record first (it is needed last, its loads are in flight for the whole loop); ring of RD records, refilled
+  // unconditionally (see ilqr_merit_roll_kernel)
+  T JN = lane_ld<T>(LaneBuf(jk + b0 + (int64_t)N * B), lane, 0u), lxN[n];
+  if constexpr (DERIV) {
+    const LaneBuf bt(jd.term + b0);
+#pragma unroll
+    for (int e = 0; e < n; ++e) lxN[e] = lane_ld<T>(bt, lane, (uint32_t)(jd.oterm + e) * rowB);
+  }
+  constexpr int RD = DERIV ? MERIT_RING(2 * n * m + 2 * m + n * n + n + 1) : 4;
+  SumRec<n, m, T> ring[RD];
+  const int last = N > 0 ? N - 1 : 0;
+#pragma unroll
+  for (int d = 0; d < RD; ++d) sum_load<n, m, DERIV, T>(ring[d], a, jd, jk, d < last ? d : last, b0, lane, rowB);
+  auto step = [&](SumRec<n, m, T>& r0, int k, bool refill) {
+    phi += r0.J;
+    if constexpr (DERIV) {
+      T duda[m], dxn[n];
+      for (int i = 0; i < m; ++i) {   // du_da = -K dx_da + d
+        T s = T(0);
+        for (int j = 0; j < n; ++j) s += r0.K[i + j * m] * dxda[j];
+        duda[i] = -s + r0.d[i];
+      }
+      for (int i = 0; i < n; ++i) {   // dx_da+ = A dx_da + B du_da
+        T s = T(0);
+        for (int j = 0; j < n; ++j) s += r0.A[i + j * n] * dxda[j];
+        T s2 = T(0);
+        for (int j = 0; j < m; ++j) s2 += r0.Bm[i + j * n] * duda[j];
+        dxn[i] = s + s2;
+      }
+      T s = T(0);
+      for (int i = 0; i < n; ++i) s += r0.lx[i] * dxda[i];
+      dphi += s;
+      s = T(0);
+      for (int i = 0; i < m; ++i) s += r0.lu[i] * duda[i];
+      dphi += s;
+      for (int e = 0; e < n; ++e) dxda[e] = dxn[e];
+    }
+    if (refill) sum_load<n, m, DERIV, T>(r0, a, jd, jk, k + RD < last ? k + RD : last, b0, lane, rowB);
+  };
+  int k = 0;
+  for (; k + RD <= N; k += RD) {
+#pragma unroll
+    for (int d = 0; d < RD; ++d) step(ring[d], k + d, true);
+  }
+#pragma unroll
+  for (int d = 0; d < RD; ++d)
+    if (k + d < N) step(ring[d], k + d, false);
+  phi += JN;
+  if constexpr (DERIV) {
+    T s = T(0);
+    for (int i = 0; i < n; ++i) s += lxN[i] * dxda[i];
+    dphi += s;
+  }
+  phi_out = phi;
+  dphi_out = dphi;
+}
+template <int KIND, int n, int m, typename T>
+__global__ __launch_bounds__(64) void ilqr_merit_sum_kernel(IlqrArgs<T> a) {
+  ILQR_PROLOGUE;
+  if (a.active && !a.active[b]) return;
+  const int trial = (int)blockIdx.y;
+  const MeritTrial<T> tr = ilqr_merit_trial<T>(a, b, trial);
+  if (!tr.run) return;
+  const int64_t b0 = (int64_t)blockIdx.x * 64;
+  const uint32_t lane = threadIdx.x * (uint32_t)sizeof(T), rowB = (uint32_t)B * (uint32_t)sizeof(T);
+  const MeritJac<n, m, T> jd = ilqr_merit_jac<n, m, T>(a, tr.store);
+  const T* jk = a.merit_jk + (int64_t)trial * (N + 1) * B;
+  const bool deriv = tr.deriv;
+  T phi, dphi;
+  if (deriv) ilqr_merit_sum_lane<n, m, true, T>(a, jd, jk, b0, lane, rowB, phi, dphi);
+  else ilqr_merit_sum_lane<n, m, false, T>(a, jd, jk, b0, lane, rowB, phi, dphi);
+  a.phi[(int64_t)trial * B + b] = (double)phi;
+  if (deriv) a.dphi[(int64_t)trial * B + b] = (double)dphi;
+  if (a.al.enabled) a.prob[b].rho_est = (double)(T)a.prob[b].rho;
 }
 
 // Speculative backtracking: a problem that just ended its search on spare trajectory spec_sel[b] - 1 gets it copied

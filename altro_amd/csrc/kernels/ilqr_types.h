@@ -62,6 +62,10 @@ struct IlqrArgs {
   const int* spec_sel;  // [batch] IK_SPEC_SELECT: copy spare candidate spec_sel[b] - 1 over the candidate of problem b
   double ls_beta;       // CubicLineSearch::beta_decrease
   int ls_max_iters;
+  // MeritFunction in three launches (kernels/ilqr_lane.hip): per-knot-point costs of every trial, and the A | B | lx | lu
+  // block of a derivative pass that must not touch the backward pass's input record.  nullptr: the one-launch kernel.
+  T* merit_jk;          // [spec_trials][N + 1][batch]
+  T* spec_jac;          // [N][n n + n m + n + m][batch] then [n][batch]
 };
 enum { EXPAND_GRADIENT = 1, EXPAND_HESSIAN = 2 };
 

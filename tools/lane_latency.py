@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-kernel latency of the LANE iLQR kernels on the C3 bicycle problem (run under rocprofv3 --kernel-trace):
-    python tools/lane_latency.py BATCH DERIV(0|1) AL(0|1) [N]"""
+    python tools/lane_latency.py BATCH DERIV(0|1) AL(0|1) [N] [pendulum]"""
 import os
 import sys
 import numpy as np
@@ -10,6 +10,22 @@ from tests import problems
 
 batch, deriv, al = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 N = int(sys.argv[4]) if len(sys.argv) > 4 else 50
+if len(sys.argv) > 5 and sys.argv[5] == "pendulum":
+    bt = altro_amd.Batch(N, 2, 1, batch)
+    bt.set_model(altro_amd.MODEL_PENDULUM, np.float32(0.03))
+    xf = np.array([np.pi, 0.0])
+    bt.set_tracking_cost(np.array([[1e-2, 1e-2], [1.0, 1.0]]), np.array([[1e-3]]), np.stack([xf, xf]), np.zeros((1, 1)),
+                         k_stride_zero=True, batch_stride_zero=True)
+    x0 = np.zeros((batch, 2)); x0[:, 0] = problems.uniform01((batch,), 22) - 0.5
+    bt.set_initial_state(x0)
+    bt.set_input_guess(np.array([[[0.1]]]), k_stride_zero=True, batch_stride_zero=True)
+    bt.open_loop_rollout(); bt.accept(); bt.expand()
+    for _ in range(10):
+        bt.backward(); bt.forward_ltv()
+        bt.merit(1.0, derivative=bool(deriv))
+        bt.expand()
+    bt.synchronize()
+    sys.exit(0)
 n, m, h = 4, 2, np.float32(0.1)
 x_ref, u_ref = problems.bicycle_reference(N + 1)
 bt = altro_amd.Batch(N, n, m, batch)
