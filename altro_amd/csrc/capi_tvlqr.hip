@@ -18,6 +18,19 @@ int lane_launch(altro_hip_batch* h, bool backward, double reg) {
                 backward ? h->bwd_reg : nullptr};
   const dim3 grid(8 * (((h->batch + 63) / 64 + 7) / 8)), block(64);
   const bool fused = (h->flags & ALTRO_HIP_LANE_FUSED) != 0;
+  // (4, 2): four lanes per problem (kernels/tvlqr_quad_body.inc), same records, bit-identical results; ALTRO_HIP_LANE_QUAD=0
+  // keeps the lane-per-problem sweep
+  const char* qe = std::getenv("ALTRO_HIP_LANE_QUAD");
+  const bool quad_on = !(qe && std::atoi(qe) == 0);
+  if (backward) h->bwd_quad = quad_on && h->n == 4 && h->m == 2;
+  if (backward && h->bwd_quad) {
+    const dim3 qgrid(8 * (((h->batch + 15) / 16 + 7) / 8));
+    if (fused) hipLaunchKernelGGL((quad_backward_kernel_fused<2, T>), qgrid, block, 0, h->stream, a);
+    else hipLaunchKernelGGL((quad_backward_kernel<2, T>), qgrid, block, 0, h->stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "quad kernel launch: %s", hipGetErrorString(e));
+    return 0;
+  }
 #define X(N_, M_)                                                                                              \
   if (h->n == N_ && h->m == M_) {                                                                              \
     if (backward && fused) hipLaunchKernelGGL((lane_backward_kernel_fused<N_, M_, T>), grid, block, 0, h->stream, a); \

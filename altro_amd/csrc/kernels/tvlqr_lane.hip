@@ -78,6 +78,20 @@ __device__ __forceinline__ void lane_st(const LaneBuf& bf, uint32_t lane_off, ui
   }
 }
 
+// The value lane S of this lane's quad holds (DPP quad_perm:[S,S,S,S]; all four lanes of the quad must be active).
+template <int S, typename T>
+__device__ __forceinline__ T quad_bcast(T v) {
+  constexpr int ctrl = S | (S << 2) | (S << 4) | (S << 6);
+  if constexpr (sizeof(T) == 8) {
+    lane_v2u w = __builtin_bit_cast(lane_v2u, v);
+    w.x = (unsigned)__builtin_amdgcn_update_dpp(0, (int)w.x, ctrl, 0xf, 0xf, true);
+    w.y = (unsigned)__builtin_amdgcn_update_dpp(0, (int)w.y, ctrl, 0xf, 0xf, true);
+    return __builtin_bit_cast(T, w);
+  } else {
+    return __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, true));
+  }
+}
+
 // One knot point's forward-pass operands in registers: A | B | f and K | d | P | p.  The addresses never
 // depend on the state, so the record of step k + DEPTH is requested before step k is computed: these
 // shapes are latency-bound (one wave per 64 problems, N dependent steps) and an un-prefetched step costs
@@ -103,10 +117,12 @@ struct LaneFwdRec {
 #pragma clang fp contract(off)
 #define LANE_FN(x) x
 #include "tvlqr_lane_body.inc"
+#include "tvlqr_quad_body.inc"
 #undef LANE_FN
 #pragma clang fp contract(fast)
 #define LANE_FN(x) x##_fused
 #include "tvlqr_lane_body.inc"
+#include "tvlqr_quad_body.inc"
 #undef LANE_FN
 
 #pragma clang fp contract(fast)
