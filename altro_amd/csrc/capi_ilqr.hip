@@ -638,7 +638,11 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
   // hand-over is exact at any sweep).
   int iter0 = 0;
   // (n <= 4: the shapes the fused kernel is instantiated for, ilqr_launch_f64.hip)
-  bool fused_can = lane_plan && h->n <= 4 && o.iterations_max > 0 && !h->spec_no_memory;
+  // (the kernel works on the buffers of the three-launch merit evaluation; ALTRO_HIP_LANE_FUSED -- FMA-contracted sweeps --
+  //  is a property of the launch-sequenced kernels only)
+  if (lane_plan) merit_split_prepare(h);
+  bool fused_can = lane_plan && h->n <= 4 && o.iterations_max > 0 && !h->spec_no_memory && h->merit_split == 1 &&
+                   !(h->flags & ALTRO_HIP_LANE_FUSED);
   // POLICY (MI355X, batch 8192, 80 sweeps): pendulum 3.29 against 3.73 ms (cubic) and 3.41 against 3.82 ms (backtracking);
   // bicycle + steering bound 105 against 187 ms (cubic), but 72.5 against 68.6 ms with backtracking, where the loop below
   // evaluates up to eight steps per launch on otherwise idle CUs and the fused bicycle body spills (368 B / lane).
@@ -655,7 +659,14 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
     int fused_sweeps = o.iterations_max;
     if (const char* e = std::getenv("ALTRO_HIP_FUSED_SWEEPS")) fused_sweeps = std::max(1, std::min(o.iterations_max, std::atoi(e)));
     HIP_TRY(hipMemsetAsync(h->i_counters, 0, 4 * sizeof(int), h->stream));
-    IlqrFusedArgs fa{0, fused_sweeps, o.reg_retry_max, reg_on ? 1 : 0, h->i_counters};
+    IlqrFusedArgs fa{0, fused_sweeps, o.reg_retry_max, reg_on ? 1 : 0, h->i_counters, nullptr};
+    const int clk_G = h->batch <= 8 * 256 ? 8 : 32;   // (ilqr_launch_fused)
+    const int clk_groups = (h->batch + clk_G - 1) / clk_G;
+    unsigned long long* clk = nullptr;     // ALTRO_HIP_FUSED_CLOCK: per-phase time of the kernel, printed to stderr
+    if (std::getenv("ALTRO_HIP_FUSED_CLOCK") != nullptr) {
+      const size_t bytes = (size_t)clk_groups * ILQR_FUSED_PHASES * sizeof(unsigned long long);
+      if (hipMalloc((void**)&clk, bytes) == hipSuccess) { (void)hipMemsetAsync(clk, 0, bytes, h->stream); fa.clk = clk; }
+    }
     int frc;
     if (h->dtype == ALTRO_HIP_F64) {
       LaneArgs<double> ba{(const double*)h->l_in, (const double*)h->l_term, (double*)h->l_out, (double*)h->l_outn,
@@ -675,6 +686,25 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
     HIP_TRY(hipStreamSynchronize(h->stream));
     sweeps = c4[3];
     running = c4[1];
+    if (clk) {
+      std::vector<unsigned long long> hc((size_t)clk_groups * ILQR_FUSED_PHASES);
+      (void)hipMemcpy(hc.data(), clk, hc.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+      (void)hipFree(clk);
+      static const char* names[ILQR_FUSED_PHASES] = {"hessians", "backward", "pre:roll", "pre:points", "pre:sums", "ls logic+select",
+                                                     "ls:roll", "ls:points", "ls:sums", "re-expand", "stationarity+accept", "duals+gradients"};
+      int slow = 0;
+      unsigned long long slow_t = 0;
+      std::vector<double> mean(ILQR_FUSED_PHASES, 0.0);
+      for (int g = 0; g < clk_groups; ++g) {
+        unsigned long long tot = 0;
+        for (int p = 0; p < ILQR_FUSED_PHASES; ++p) { tot += hc[(size_t)g * ILQR_FUSED_PHASES + p]; mean[p] += (double)hc[(size_t)g * ILQR_FUSED_PHASES + p]; }
+        if (tot > slow_t) { slow_t = tot; slow = g; }
+      }
+      std::fprintf(stderr, "[altro_hip] fused solve phase clock, us (mean over %d workgroups | slowest workgroup %d), %d sweeps max\n", clk_groups, slow, sweeps);
+      for (int p = 0; p < ILQR_FUSED_PHASES; ++p)
+        std::fprintf(stderr, "  %-22s %10.1f | %10.1f\n", names[p], mean[p] / clk_groups * 0.01, (double)hc[(size_t)slow * ILQR_FUSED_PHASES + p] * 0.01);
+      std::fprintf(stderr, "  %-22s %10s | %10.1f\n", "total", "", (double)slow_t * 0.01);
+    }
     iter0 = running > 0 ? fused_sweeps : o.iterations_max;
   }
   for (int iter = iter0; iter < o.iterations_max; ++iter) {

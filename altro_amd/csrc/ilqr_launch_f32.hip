@@ -58,18 +58,22 @@ template <>
 int ilqr_launch_fused<float>(hipStream_t stream, int kind, int n, int m, const IlqrArgs<float>& a, const IlqrLoopArgs& la,
                           const LaneArgs<float>& ba, const IlqrFusedArgs& fa) {
   using T = float;
-  // one workgroup of ILQR_FUSED_WAVES waves per 64 problems, dealt to the XCDs like the sweep kernels' waves
-  const dim3 grid(8 * (((a.batch + 63) / 64 + 7) / 8)), block(64 * ILQR_FUSED_WAVES);
+  // Problems per workgroup (of four waves): as few as keeps every workgroup resident at once, one per CU -- the fewer, the
+  // more knot points each wave takes at once in the (problem, knot point)-parallel steps (ilqr_fused.hip, KS).
+  const int G = a.batch <= 8 * 256 ? 8 : 32;
+  const dim3 grid(8 * (((a.batch + G - 1) / G + 7) / 8)), block(256);
   bool done = false;
-  // (6, 3) is not instantiated: its backward sweep alone fills the register file, and the fused kernel around it makes
-  // hipcc 7.2 emit an illegal spill reload (odd-aligned 64-bit VGPR pair); that shape keeps the launch-sequenced loop
+  // (6, 3) is not instantiated: hipcc 7.2 emits an illegal spill reload (odd-aligned 64-bit VGPR pair) for it; that shape
+  // keeps the launch-sequenced loop
 #define X(K_, N_, M_)                                                                                              \
   if (!done && kind == K_ && n == N_ && m == M_) {                                                                 \
     done = true;                                                                                                   \
-    if constexpr (N_ <= 4)                                                                                         \
-      hipLaunchKernelGGL((ilqr_fused_sweeps_kernel<K_, N_, M_, T>), grid, block, 0, stream, a, la, ba, fa);         \
-    else                                                                                                           \
+    if constexpr (N_ <= 4) {                                                                                       \
+      if (G == 8) hipLaunchKernelGGL((ilqr_fused_sweeps_kernel<K_, N_, M_, T, 8>), grid, block, 0, stream, a, la, ba, fa);   \
+      else hipLaunchKernelGGL((ilqr_fused_sweeps_kernel<K_, N_, M_, T, 32>), grid, block, 0, stream, a, la, ba, fa);          \
+    } else {                                                                                                       \
       return 1;                                                                                                    \
+    }                                                                                                              \
   }
   ILQR_MODELS(X)
 #undef X

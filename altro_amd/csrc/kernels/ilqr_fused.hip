@@ -25,37 +25,90 @@
 
 namespace altro_hip {
 
-constexpr int ILQR_FUSED_WAVES = 4;
-
-// (Calling the heavy phases instead of inlining them -- to keep the bicycle's merit rollout, backward sweep and
-//  expansions from sharing one register allocation, 256 VGPRs + 256 AGPRs + 368 bytes of scratch against 256 + 140 for
-//  the stand-alone merit kernel -- was measured and is far worse: C2 6.4 ms against 3.3 ms, the by-reference argument
-//  blocks go through scratch.)
-template <int KIND, int n, int m, typename T>
-__global__ __launch_bounds__(64 * ILQR_FUSED_WAVES) void ilqr_fused_sweeps_kernel(IlqrArgs<T> a, IlqrLoopArgs la, LaneArgs<T> ba,
-                                                                                   IlqrFusedArgs fa) {
-  constexpr int W = ILQR_FUSED_WAVES;
-  // the same wave -> problems mapping as the sweep kernels (XCD-aware, tvlqr_lane_body.inc), one workgroup per 64 problems
-  const int nwv = (a.batch + 63) / 64, chk = (nwv + 7) / 8;
-  const int wv = (int)((blockIdx.x & 7) * chk + (blockIdx.x >> 3));
-  if (wv >= nwv) return;
+// (Calling the heavy phases instead of inlining them was measured and is far worse -- C2 6.4 ms against 3.3 ms: the
+//  by-reference argument blocks go through scratch.  What keeps the register file in check instead is that no phase is
+//  monolithic any more: the merit evaluation is the three-phase one of ilqr_lane.hip, the (4, 2) backward sweep the
+//  four-lanes-per-problem one of tvlqr_quad_body.inc.)
+template <int KIND, int n, int m, typename T, int G>
+__global__ __launch_bounds__(256) void ilqr_fused_sweeps_kernel(IlqrArgs<T> a, IlqrLoopArgs la, LaneArgs<T> ba, IlqrFusedArgs fa) {
+  static_assert(G == 64 || G == 32 || G == 16 || G == 8, "problems per workgroup");
+  constexpr int W = 4;                        // waves per workgroup: one per SIMD, each with the whole register file
+  constexpr int KS = 64 / G;                  // knot points a wave takes at once in the (problem, knot point)-parallel steps
+  constexpr bool QUAD = n == 4 && m == 2;     // the shapes tvlqr_quad_body.inc is instantiated for
+  // workgroup -> problems: contiguous runs per XCD like the sweep kernels' waves (tvlqr_lane_body.inc)
+  const int nwg = (a.batch + G - 1) / G, chk = (nwg + 7) / 8;
+  const int wg = (int)((blockIdx.x & 7) * chk + (blockIdx.x >> 3));
+  if (wg >= nwg) return;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), t = threadIdx.x & 63;   // (w: provably wave-uniform)
-  const int64_t b0 = (int64_t)wv * 64;
-  const int64_t b = b0 + t;
+  const int pt = t % G, ks = t / G;           // lane = (problem slot, knot-point slot)
+  const int64_t b0 = (int64_t)wg * G;
+  const int64_t b = b0 + pt;
   const int64_t B = a.batch;
   const bool valid = b < B;
   const int bi = (int)(valid ? b : b0);           // (lanes past the batch never dereference it)
   const int N = a.N;
-  const uint32_t lane = (uint32_t)t * (uint32_t)sizeof(T);
+  const uint32_t lane = (uint32_t)pt * (uint32_t)sizeof(T);
   const uint32_t rowB = (uint32_t)B * (uint32_t)sizeof(T);
   const bool al = a.al.enabled != 0;
-  const bool lead = w == 0 && valid;              // wave 0 keeps the per-problem books
+  const bool serial = ks == 0 && valid;           // the lanes of a wave that run a lane-per-problem chain
+  const bool lead = w == 0 && serial;             // wave 0 keeps the per-problem books
   int sweeps = 0;
+  // optional phase clock (ALTRO_HIP_FUSED_CLOCK, a tuning aid): 100 MHz ticks per phase and workgroup
+  unsigned long long tick = fa.clk ? wall_clock64() : 0ull;
+  auto lap = [&](int phase) {
+    if (fa.clk && threadIdx.x == 0) {
+      const unsigned long long now = wall_clock64();
+      fa.clk[(int64_t)wg * ILQR_FUSED_PHASES + phase] += now - tick;
+      tick = now;
+    }
+  };
+  __shared__ int s_again[G];                      // regularisation retry: which problems repeat their backward sweep
 
-  // one knot point in W of every (problem, knot point)-parallel step
-#define FUSED_FOR_K(MASKED, CALL)                      \
-  for (int k = w; k <= N; k += W)                       \
+  // W * KS knot points at once in every (problem, knot point)-parallel step
+#define FUSED_FOR_K(MASKED, CALL)                                  \
+  for (int k = w * KS + ks; k <= N; k += W * KS)                   \
     if (valid && (MASKED)) { CALL; }
+
+  // BackwardPass of the workgroup's problems: lane t of wave 0 <-> problem b0 + t, or -- (4, 2) -- four lanes per problem,
+  // 16 problems in each of the waves 0..3.  `pick`: which problems (all the active ones, or the retrying ones).
+  auto backward = [&](bool retry) {
+    if constexpr (QUAD) {
+      if (w < (G + 15) / 16) {
+        const int q = 16 * w + (t >> 2);
+        const int64_t bq = b0 + q;
+        if (q < G && bq < B && (retry ? s_again[q] != 0 : la.active[bq] != 0))
+          (void)quad_backward_wave<m, T>(ba, b0 + 16 * w, t, (retry || fa.use_reg) ? (T)la.reg[bq] : T(0));
+      }
+    } else {
+      if (lead && (retry ? s_again[pt] != 0 : la.active[bi] != 0))
+        (void)lane_backward_lane<n, m, T>(ba, b0, pt, (retry || fa.use_reg) ? (T)la.reg[bi] : T(0));
+    }
+  };
+  // One merit launch of the sequenced loop (ilqr_launch_kernel, IK_MERIT) inside the workgroup: the rollouts of the
+  // `trials` steps in one wave each, their per-knot-point terms dealt over all waves, the sums in one wave each.
+  auto merit = [&](const IlqrArgs<T>& am, int trials, int ph) {
+    if (w < trials && serial && la.active[bi]) {
+      const MeritTrial<T> tr = ilqr_merit_trial<T>(am, b, w);
+      if (tr.run) ilqr_merit_roll_lane<KIND, n, m, T>(am, tr, b0, lane, rowB);
+    }
+    __syncthreads();
+    lap(ph);
+    for (int idx = w * KS + ks; idx < trials * (N + 1); idx += W * KS) {
+      const int trial = idx / (N + 1), k = idx - trial * (N + 1);
+      if (valid && la.active[bi]) {
+        const MeritTrial<T> tr = ilqr_merit_trial<T>(am, b, trial);
+        if (tr.run) ilqr_merit_point<KIND, n, m, T>(am, b, k, trial, tr);
+      }
+    }
+    __syncthreads();
+    lap(ph + 1);
+    if (w < trials && serial && la.active[bi]) {
+      const MeritTrial<T> tr = ilqr_merit_trial<T>(am, b, w);
+      if (tr.run) ilqr_merit_sum_body<n, m, T>(am, tr, b, b0, lane, rowB, w);
+    }
+    __syncthreads();
+    lap(ph + 2);
+  };
 
   for (int it = fa.first_iter; it < fa.first_iter + fa.max_sweeps; ++it) {
     la.iter = it;
@@ -68,28 +121,30 @@ __global__ __launch_bounds__(64 * ILQR_FUSED_WAVES) void ilqr_fused_sweeps_kerne
       FUSED_FOR_K(la.active[bi], (ilqr_expand_point<KIND, n, m, T>(a, b, k, false, true)));
       __syncthreads();
     }
+    lap(0);
     // BackwardPass (reg = 0 in the reference, solver.cpp:363); extension: repeat with a growing per-problem reg
-    if (lead && la.active[bi]) (void)lane_backward_lane<n, m, T>(ba, b0, t, fa.use_reg ? (T)la.reg[bi] : T(0));
+    backward(false);
     for (int attempt = 0; attempt < fa.reg_retry_max; ++attempt) {
       __syncthreads();
       const bool again = lead && ilqr_reg_retry_body(la, bi);
+      if (w == 0 && ks == 0) s_again[pt] = again ? 1 : 0;
       if (__syncthreads_count(again) == 0) break;
-      if (again) (void)lane_backward_lane<n, m, T>(ba, b0, t, (T)la.reg[bi]);
+      backward(true);
     }
     if (fa.reg_retry_max > 0) {
       __syncthreads();
       if (lead) ilqr_mark_running_body(la, bi);
     }
     __syncthreads();
-    // ForwardPass: phi(0) in wave 0 and, next to it, the first step the search will ask for (alpha0 = 1) in wave 1
+    lap(1);
+    // ForwardPass: phi(0) and, next to it, the first step the search will ask for (alpha0 = 1)
     {
       IlqrArgs<T> am = a;
       // (roles swapped, IlqrArgs::spec_flip: the alpha0 = 1 pass writes the candidate and the expansion, phi(0) -- whose
       //  trajectory is the nominal one and whose expansion is the one already in place -- goes to spare candidate 0)
-      am.alpha = la.alpha; am.want_derivative = 1; am.spec_trials = 2; am.spec_pre = 1; am.spec_flip = 1;
-      if (w < 2 && valid && la.active[bi]) ilqr_merit_body<KIND, n, m, T>(am, b, b0, lane, rowB, w);
+      am.alpha = la.alpha; am.active = la.active; am.want_derivative = 1; am.spec_trials = 2; am.spec_pre = 1; am.spec_flip = 1;
+      merit(am, 2, 2);
     }
-    __syncthreads();
     la.spec_pre = 1;
     bool need0 = false;
     if (lead) {
@@ -104,17 +159,17 @@ __global__ __launch_bounds__(64 * ILQR_FUSED_WAVES) void ilqr_fused_sweeps_kerne
     int searching = __syncthreads_count(need0);
     la.spec_pre = 0;
     FUSED_FOR_K(true, (ilqr_spec_select_point<n, m, T>(a, b, k)));
-    // the line search: one round = one merit evaluation per searching problem; in the backtracking stage the four waves
-    // take the next four steps of the (known) sequence alpha beta^j at once
+    lap(5);
+    // the line search: one round = one merit evaluation per searching problem; in the backtracking stage the next four
+    // steps of the (known) sequence alpha beta^j at once
     while (searching > 0) {
       __syncthreads();
-      const int trials = la.ls.use_backtracking ? W : 1;
+      const int trials = la.ls.use_backtracking ? 4 : 1;
       {
         IlqrArgs<T> am = a;
-        am.alpha = la.alpha; am.want_derivative = 1; am.spec_trials = trials; am.spec_pre = 0;
-        if (w < trials && valid && la.active[bi]) ilqr_merit_body<KIND, n, m, T>(am, b, b0, lane, rowB, w);
+        am.alpha = la.alpha; am.active = la.active; am.want_derivative = 1; am.spec_trials = trials; am.spec_pre = 0;
+        merit(am, trials, 6);
       }
-      __syncthreads();
       la.spec_trials = trials;
       searching = __syncthreads_count(lead && ilqr_ls_feed_body(la, bi));
       la.spec_trials = 1;
@@ -123,15 +178,17 @@ __global__ __launch_bounds__(64 * ILQR_FUSED_WAVES) void ilqr_fused_sweeps_kerne
     __syncthreads();
     // steps accepted from a speculative trial carry no phi' pass: redo their expansion (what the derivative pass of a
     // sequential trial would have left behind)
+    lap(5);
     FUSED_FOR_K(la.spec_refresh[bi], (ilqr_expand_point<KIND, n, m, T>(a, b, k, true, false)));
     __syncthreads();
+    lap(9);
     // convergence criteria on the accepted candidate, then make it the nominal (solver.cpp:459-469)
     if (lead) {
       ilqr_mark_running_body(la, bi);
       if (la.prob[bi].running) { la.prob[bi].stationarity = 0.0; la.prob[bi].feasibility = 0.0; }
     }
     __syncthreads();
-    for (int k = w; k <= N; k += W)
+    for (int k = w * KS + ks; k <= N; k += W * KS)
       if (valid && la.active[bi]) {
         T res, viol;
         ilqr_stationarity_point<n, m, T>(a, b, k, res, viol);
@@ -141,6 +198,7 @@ __global__ __launch_bounds__(64 * ILQR_FUSED_WAVES) void ilqr_fused_sweeps_kerne
         ilqr_accept_point<n, m, T>(a, b, k);
       }
     __syncthreads();
+    lap(10);
     if (lead) (void)ilqr_finish_iter_body(la, bi);
     __syncthreads();
     // DualUpdate, PenaltyUpdate, refreshed cost gradients for the problems that asked (solver.cpp:470-489)
@@ -152,6 +210,7 @@ __global__ __launch_bounds__(64 * ILQR_FUSED_WAVES) void ilqr_fused_sweeps_kerne
       FUSED_FOR_K(la.active[bi], (ilqr_expand_point<KIND, n, m, T>(a, b, k, true, false)));
       __syncthreads();
     }
+    lap(11);
   }
 #undef FUSED_FOR_K
   // hand-back: how many problems the launch leaves running, how many sweeps its slowest workgroup took

@@ -495,14 +495,14 @@ __device__ __forceinline__ void roll_load(RollRec<n, m, T>& r, const IlqrArgs<T>
 #pragma unroll
   for (int e = 0; e < n + m; ++e) r.nom[e] = lane_ld<T>(bn, lane, (uint32_t)e * rowB);
 }
+// the closed-loop rollout of one (problem, trial) into the trial's candidate trajectory (x_, u_)
 template <int KIND, int n, int m, typename T>
-__global__ __launch_bounds__(64) void ilqr_merit_roll_kernel(IlqrArgs<T> a) {
-  ILQR_PROLOGUE;
-  if (a.active && !a.active[b]) return;
-  const MeritTrial<T> tr = ilqr_merit_trial<T>(a, b, (int)blockIdx.y);
-  if (!tr.run) return;
-  const int64_t b0 = (int64_t)blockIdx.x * 64;
-  const uint32_t lane = threadIdx.x * (uint32_t)sizeof(T), rowB = (uint32_t)B * (uint32_t)sizeof(T);
+__device__ __forceinline__ void ilqr_merit_roll_lane(const IlqrArgs<T>& a, const MeritTrial<T>& tr, int64_t b0, uint32_t lane,
+                                                     uint32_t rowB) {
+  using I = IlqrDims<n, m>;
+  using Mdl = DiscreteModel<KIND, n, m, T>;
+  const int64_t B = a.batch;
+  const int N = a.N;
   const T alpha = (T)tr.alpha;
   T x[n], u[m], xn[n], dx[n];
   {
@@ -546,6 +546,15 @@ __global__ __launch_bounds__(64) void ilqr_merit_roll_kernel(IlqrArgs<T> a) {
   const LaneBuf bc(tr.cand + b0 + (int64_t)N * I::E_CAND * B);
 #pragma unroll
   for (int e = 0; e < n; ++e) lane_st<T>(bc, lane, (uint32_t)e * rowB, x[e]);
+}
+template <int KIND, int n, int m, typename T>
+__global__ __launch_bounds__(64) void ilqr_merit_roll_kernel(IlqrArgs<T> a) {
+  ILQR_PROLOGUE;
+  if (a.active && !a.active[b]) return;
+  const MeritTrial<T> tr = ilqr_merit_trial<T>(a, b, (int)blockIdx.y);
+  if (!tr.run) return;
+  ilqr_merit_roll_lane<KIND, n, m, T>(a, tr, (int64_t)blockIdx.x * 64, threadIdx.x * (uint32_t)sizeof(T),
+                                      (uint32_t)B * (uint32_t)sizeof(T));
 }
 
 // everything of MeritFunction at ONE knot point of a rolled-out trial (solver.cpp:286-332 without the two recursions)
@@ -706,6 +715,20 @@ __device__ __forceinline__ void ilqr_merit_sum_lane(const IlqrArgs<T>& a, const 
   phi_out = phi;
   dphi_out = dphi;
 }
+// phi / phi' of one (problem, trial) into its row of a.phi / a.dphi
+template <int n, int m, typename T>
+__device__ __forceinline__ void ilqr_merit_sum_body(const IlqrArgs<T>& a, const MeritTrial<T>& tr, int64_t b, int64_t b0, uint32_t lane,
+                                                    uint32_t rowB, int trial) {
+  const int64_t B = a.batch;
+  const MeritJac<n, m, T> jd = ilqr_merit_jac<n, m, T>(a, tr.store);
+  const T* jk = a.merit_jk + (int64_t)trial * (a.N + 1) * B;
+  T phi, dphi;
+  if (tr.deriv) ilqr_merit_sum_lane<n, m, true, T>(a, jd, jk, b0, lane, rowB, phi, dphi);
+  else ilqr_merit_sum_lane<n, m, false, T>(a, jd, jk, b0, lane, rowB, phi, dphi);
+  a.phi[(int64_t)trial * B + b] = (double)phi;
+  if (tr.deriv) a.dphi[(int64_t)trial * B + b] = (double)dphi;
+  if (a.al.enabled) a.prob[b].rho_est = (double)(T)a.prob[b].rho;
+}
 template <int KIND, int n, int m, typename T>
 __global__ __launch_bounds__(64) void ilqr_merit_sum_kernel(IlqrArgs<T> a) {
   ILQR_PROLOGUE;
@@ -713,17 +736,8 @@ __global__ __launch_bounds__(64) void ilqr_merit_sum_kernel(IlqrArgs<T> a) {
   const int trial = (int)blockIdx.y;
   const MeritTrial<T> tr = ilqr_merit_trial<T>(a, b, trial);
   if (!tr.run) return;
-  const int64_t b0 = (int64_t)blockIdx.x * 64;
-  const uint32_t lane = threadIdx.x * (uint32_t)sizeof(T), rowB = (uint32_t)B * (uint32_t)sizeof(T);
-  const MeritJac<n, m, T> jd = ilqr_merit_jac<n, m, T>(a, tr.store);
-  const T* jk = a.merit_jk + (int64_t)trial * (N + 1) * B;
-  const bool deriv = tr.deriv;
-  T phi, dphi;
-  if (deriv) ilqr_merit_sum_lane<n, m, true, T>(a, jd, jk, b0, lane, rowB, phi, dphi);
-  else ilqr_merit_sum_lane<n, m, false, T>(a, jd, jk, b0, lane, rowB, phi, dphi);
-  a.phi[(int64_t)trial * B + b] = (double)phi;
-  if (deriv) a.dphi[(int64_t)trial * B + b] = (double)dphi;
-  if (a.al.enabled) a.prob[b].rho_est = (double)(T)a.prob[b].rho;
+  ilqr_merit_sum_body<n, m, T>(a, tr, b, (int64_t)blockIdx.x * 64, threadIdx.x * (uint32_t)sizeof(T),
+                               (uint32_t)B * (uint32_t)sizeof(T), trial);
 }
 
 // Speculative backtracking: a problem that just ended its search on spare trajectory spec_sel[b] - 1 gets it copied

@@ -136,12 +136,14 @@ enum IlqrLoopKernel { ILK_LOOP_INIT, ILK_LS_BEGIN, ILK_LS_FEED, ILK_FINISH_ITER,
 // plan LANE: whole sweeps in one launch (kernels/ilqr_fused.hip)
 template <typename T>
 struct LaneArgs;   // kernels/tvlqr_lane.hip
+constexpr int ILQR_FUSED_PHASES = 12;   // IlqrFusedArgs::clk
 struct IlqrFusedArgs {
   int first_iter;     // index of the first sweep this launch runs (0 right after the initial rollout / expansion)
   int max_sweeps;     // sweeps to run at most in this launch
   int reg_retry_max;  // altro_hip_solve_options::reg_retry_max
   int use_reg;        // per-problem regularisation in force (reg_initial > 0 or retries enabled)
   int* counters;      // [1] += problems still running when the launch ends; [3] = max sweeps any wave ran (atomicMax)
+  unsigned long long* clk;   // optional [workgroups][ILQR_FUSED_PHASES] phase clock (100 MHz ticks), a tuning aid
 };
 template <typename T>
 int ilqr_launch_fused(hipStream_t stream, int kind, int n, int m, const IlqrArgs<T>& a, const IlqrLoopArgs& la,
