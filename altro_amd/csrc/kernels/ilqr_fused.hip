@@ -85,17 +85,44 @@ __global__ __launch_bounds__(256) void ilqr_fused_sweeps_kernel(IlqrArgs<T> a, I
     }
   };
   // One merit launch of the sequenced loop (ilqr_launch_kernel, IK_MERIT) inside the workgroup: the rollouts of the
-  // `trials` steps in one wave each, their per-knot-point terms dealt over all waves, the sums in one wave each.
-  auto merit = [&](const IlqrArgs<T>& am, int trials, int ph) {
-    if (w < trials && serial && la.active[bi]) {
-      const MeritTrial<T> tr = ilqr_merit_trial<T>(am, b, w);
-      if (tr.run) ilqr_merit_roll_lane<KIND, n, m, T>(am, tr, b0, lane, rowB);
+  // `trials` steps in one wave each; their per-knot-point terms follow BEHIND the rollouts as a wave front -- the rolling
+  // waves publish how far they are (s_prog, every other ring group), the other waves, and the rolling ones once they
+  // are through, draw chunks of KS (knot point, trial) pairs in k order (s_next) and evaluate them as soon as every
+  // trial has passed the chunk's last knot point --; then the sums in one wave each.
+  __shared__ int s_prog[4];                      // knot points rolled out so far, per trial
+  __shared__ int s_next;                         // next chunk of per-knot-point work
+  struct Publish {
+    int* slot;
+    __device__ __forceinline__ void operator()(int count) const {
+      // release at workgroup scope: the stores of the knot points counted are visible to the workgroup before the counter is
+      __hip_atomic_store(slot, count, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
+  };
+  auto merit = [&](const IlqrArgs<T>& am, int trials, int ph) {
+    if (threadIdx.x < 4) s_prog[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_next = 0;
     __syncthreads();
+    if (w < trials) {
+      if (serial && la.active[bi]) {
+        const MeritTrial<T> tr = ilqr_merit_trial<T>(am, b, w);
+        if (tr.run) ilqr_merit_roll_lane<KIND, n, m, T, Publish>(am, tr, b0, lane, rowB, Publish{&s_prog[w]});
+      }
+      Publish{&s_prog[w]}(N + 1);               // (also when no problem of this workgroup takes this step)
+    }
     lap(ph);
-    for (int idx = w * KS + ks; idx < trials * (N + 1); idx += W * KS) {
-      const int trial = idx / (N + 1), k = idx - trial * (N + 1);
-      if (valid && la.active[bi]) {
+    const int total = trials * (N + 1), nchunks = (total + KS - 1) / KS;
+    for (;;) {
+      int c = 0;
+      if (t == 0) c = atomicAdd(&s_next, 1);
+      c = __builtin_amdgcn_readfirstlane(c);
+      if (c >= nchunks) break;
+      const int last_idx = (c + 1) * KS - 1 < total ? (c + 1) * KS - 1 : total - 1;
+      const int kmax = last_idx / trials;
+      for (int tt = 0; tt < trials; ++tt)
+        while (__hip_atomic_load(&s_prog[tt], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= kmax) __builtin_amdgcn_s_sleep(2);
+      const int idx = c * KS + ks;
+      if (idx < total && valid && la.active[bi]) {
+        const int k = idx / trials, trial = idx - k * trials;
         const MeritTrial<T> tr = ilqr_merit_trial<T>(am, b, trial);
         if (tr.run) ilqr_merit_point<KIND, n, m, T>(am, b, k, trial, tr);
       }

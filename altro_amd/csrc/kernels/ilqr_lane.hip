@@ -495,10 +495,13 @@ __device__ __forceinline__ void roll_load(RollRec<n, m, T>& r, const IlqrArgs<T>
 #pragma unroll
   for (int e = 0; e < n + m; ++e) r.nom[e] = lane_ld<T>(bn, lane, (uint32_t)e * rowB);
 }
-// the closed-loop rollout of one (problem, trial) into the trial's candidate trajectory (x_, u_)
-template <int KIND, int n, int m, typename T>
+// The closed-loop rollout of one (problem, trial) into the trial's candidate trajectory (x_, u_).  `pub(c)`, called every
+// other group of the loop and once at the end (c = N + 1), tells a consumer that knot points 0 .. c - 1 are stored (the
+// fused solve kernel evaluates their per-knot-point terms in other waves while the rollout goes on).
+struct RollNoPublish { __device__ __forceinline__ void operator()(int) const {} };
+template <int KIND, int n, int m, typename T, class Pub = RollNoPublish>
 __device__ __forceinline__ void ilqr_merit_roll_lane(const IlqrArgs<T>& a, const MeritTrial<T>& tr, int64_t b0, uint32_t lane,
-                                                     uint32_t rowB) {
+                                                     uint32_t rowB, const Pub& pub = Pub()) {
   using I = IlqrDims<n, m>;
   using Mdl = DiscreteModel<KIND, n, m, T>;
   const int64_t B = a.batch;
@@ -539,6 +542,7 @@ __device__ __forceinline__ void ilqr_merit_roll_lane(const IlqrArgs<T>& a, const
   for (; k + RD <= N; k += RD) {   // whole groups: nothing conditional between the loads
 #pragma unroll
     for (int d = 0; d < RD; ++d) step(ring[d], k + d, true);
+    if ((k / RD) & 1) pub(k + RD);
   }
 #pragma unroll
   for (int d = 0; d < RD; ++d)     // the last N mod RD knot points are in the ring already
@@ -546,6 +550,7 @@ __device__ __forceinline__ void ilqr_merit_roll_lane(const IlqrArgs<T>& a, const
   const LaneBuf bc(tr.cand + b0 + (int64_t)N * I::E_CAND * B);
 #pragma unroll
   for (int e = 0; e < n; ++e) lane_st<T>(bc, lane, (uint32_t)e * rowB, x[e]);
+  pub(N + 1);
 }
 template <int KIND, int n, int m, typename T>
 __global__ __launch_bounds__(64) void ilqr_merit_roll_kernel(IlqrArgs<T> a) {

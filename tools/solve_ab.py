@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import altro_amd                      # noqa: E402
 from tests import problems            # noqa: E402
 
-R = int(sys.argv[1]) if len(sys.argv) > 1 else 7
+R = int(sys.argv[1]) if len(sys.argv) > 1 and __name__ == "__main__" else 7
 
 
 def c2(backtracking=False):
@@ -44,23 +44,24 @@ def c3(backtracking=True, N=50, batch=8192):
     return bt, guess, dict(iterations_max=80, use_backtracking=backtracking)
 
 
-CASES = (("C2 pendulum N=100 batch=8192, cubic search", c2, False), ("C2 pendulum, backtracking search", c2, True),
-         ("C3 bicycle N=50 batch=8192, backtracking search", c3, True), ("C3 bicycle, cubic search", c3, False))
-for name, make, backtracking in CASES:
-    bt, guess, opts = make(backtracking)
-    times = {"fused": [], "sequenced": []}
-    for rep in range(R + 1):
-        for mode in ("fused", "sequenced"):
-            os.environ["ALTRO_HIP_FUSED"] = "0" if mode == "sequenced" else "1"
-            guess()
-            bt.synchronize()
-            t0 = time.perf_counter()
-            res = bt.ilqr_solve(**opts)
-            dt = time.perf_counter() - t0
-            if rep:                      # the first pair loads the kernels' code objects
-                times[mode].append(dt)
-    os.environ.pop("ALTRO_HIP_FUSED", None)
-    for mode, ts in times.items():
-        ts = np.sort(ts) * 1e3
-        print("%-50s %-9s  min %.3f ms  median %.3f ms  max %.3f ms   (sweeps %d, converged %d)" % (
-            name, mode, ts[0], ts[len(ts) // 2], ts[-1], int(res["sweeps"]), int((res["status"] == 0).sum())))
+if __name__ == "__main__":
+    CASES = (("C2 pendulum N=100 batch=8192, cubic search", c2, False), ("C2 pendulum, backtracking search", c2, True),
+             ("C3 bicycle N=50 batch=8192, backtracking search", c3, True), ("C3 bicycle, cubic search", c3, False))
+    for name, make, backtracking in CASES:
+        bt, guess, opts = make(backtracking)
+        times = {"fused": [], "sequenced": []}
+        for rep in range(R + 1):
+            for mode in ("fused", "sequenced"):
+                os.environ["ALTRO_HIP_FUSED"] = "0" if mode == "sequenced" else "1"
+                guess()
+                bt.synchronize()
+                t0 = time.perf_counter()
+                res = bt.ilqr_solve(**opts)
+                dt = time.perf_counter() - t0
+                if rep:                      # the first pair loads the kernels' code objects
+                    times[mode].append(dt)
+        os.environ.pop("ALTRO_HIP_FUSED", None)
+        for mode, ts in times.items():
+            ts = np.sort(ts) * 1e3
+            print("%-50s %-9s  min %.3f ms  median %.3f ms  max %.3f ms   (sweeps %d, converged %d)" % (
+                name, mode, ts[0], ts[len(ts) // 2], ts[-1], int(res["sweeps"]), int((res["status"] == 0).sum())))
