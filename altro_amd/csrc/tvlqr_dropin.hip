@@ -39,15 +39,18 @@ int tvlqr_TotalMemSize(const int* nx, const int* nu, int num_horizon, bool is_di
 
 namespace {
 
-struct Workspace {   // cached per thread: no allocation after the first call of a given size
+// Cached per thread: no allocation after the first call of a given size, and -- a solver calls these entries with the same
+// dimensions iteration after iteration -- no table upload after the first call of a given layout.  One call is one
+// host-to-device copy of the arena (from pinned memory), one single-wave kernel and one copy back; the status word and
+// the forward pass's x0 travel inside the arena.
+struct Workspace {
   double* dev = nullptr;
   size_t dev_elems = 0;
   int64_t* dev_off = nullptr;
   int* dev_dims = nullptr;
-  int* dev_status = nullptr;
   size_t table_k = 0;
-  std::vector<double> host;
-  std::vector<int64_t> off;
+  double* host = nullptr;         // pinned staging arena (hipHostMalloc), same size as dev
+  std::vector<int64_t> off;       // the tables the device holds right now
   std::vector<int> dims;
   ~Workspace() {
     int c = 0;   // thread / process teardown: the HIP runtime may already be gone -- then there is nothing left to free
@@ -55,7 +58,7 @@ struct Workspace {   // cached per thread: no allocation after the first call of
     if (dev) (void)hipFree(dev);
     if (dev_off) (void)hipFree(dev_off);
     if (dev_dims) (void)hipFree(dev_dims);
-    if (dev_status) (void)hipFree(dev_status);
+    if (host) (void)hipHostFree(host);
   }
 };
 thread_local Workspace g_ws;
@@ -122,9 +125,13 @@ int prepare(Workspace& w, const Layout& L, const int* nx, const int* nu) {
     if (w.dev) (void)hipFree(w.dev);
     w.dev = nullptr;
     w.dev_elems = 0;
+    if (w.host) (void)hipHostFree(w.host);
+    w.host = nullptr;
     if (hipMalloc(&w.dev, (size_t)L.total * sizeof(double)) != hipSuccess) { w.dev = nullptr; return -1; }
+    if (hipHostMalloc((void**)&w.host, (size_t)L.total * sizeof(double), hipHostMallocDefault) != hipSuccess) {
+      (void)hipFree(w.dev); w.dev = nullptr; w.host = nullptr; return -1;
+    }
     w.dev_elems = (size_t)L.total;
-    w.host.resize((size_t)L.total);
   }
   if (w.table_k < (size_t)(N + 1)) {
     if (w.dev_off) (void)hipFree(w.dev_off);
@@ -133,15 +140,20 @@ int prepare(Workspace& w, const Layout& L, const int* nx, const int* nu) {
     if (hipMalloc(&w.dev_off, (size_t)(N + 1) * G_NUM * sizeof(int64_t)) != hipSuccess) { w.dev_off = nullptr; return -1; }
     if (hipMalloc(&w.dev_dims, (size_t)(N + 1) * 2 * sizeof(int)) != hipSuccess) { w.dev_dims = nullptr; return -1; }
     w.table_k = (size_t)(N + 1);
+    w.off.clear(); w.dims.clear();
   }
-  if (!w.dev_status && hipMalloc(&w.dev_status, sizeof(int)) != hipSuccess) return -1;
-  w.dims.assign((size_t)(N + 1) * 2, 0);
+  std::vector<int> dims((size_t)(N + 1) * 2, 0);
   for (int k = 0; k <= N; ++k) {
-    w.dims[k] = nx[k];
-    w.dims[(size_t)(N + 1) + k] = (k < N) ? nu[k] : 0;
+    dims[k] = nx[k];
+    dims[(size_t)(N + 1) + k] = (k < N) ? nu[k] : 0;
   }
-  if (hipMemcpy(w.dev_off, L.off.data(), L.off.size() * sizeof(int64_t), hipMemcpyHostToDevice) != hipSuccess) return -1;
-  if (hipMemcpy(w.dev_dims, w.dims.data(), w.dims.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return -1;
+  if (dims != w.dims || L.off != w.off) {   // a new layout: upload its tables (the usual call finds them in place)
+    w.off.clear(); w.dims.clear();
+    if (hipMemcpy(w.dev_off, L.off.data(), L.off.size() * sizeof(int64_t), hipMemcpyHostToDevice) != hipSuccess) return -1;
+    if (hipMemcpy(w.dev_dims, dims.data(), dims.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return -1;
+    w.off = L.off;
+    w.dims = dims;
+  }
   return 0;
 }
 
@@ -154,7 +166,7 @@ GenericArgs<double> make_args(Workspace& w, const Layout& L, double reg, bool is
   a.x0 = w.dev + L.total - 4;   // overwritten by the forward entry point
   a.x0_stride = 0;
   a.delta_V = w.dev + L.total - 4;
-  a.status = w.dev_status;
+  a.status = reinterpret_cast<int*>(w.dev + L.total - 2);   // the arena's last two elements are padding: the status word rides back with it
   a.N = L.N; a.batch = 1; a.nmax = L.nmax; a.mmax = L.mmax > 0 ? L.mmax : 1;
   a.reg = reg; a.is_diag = is_diag ? 1 : 0; a.store_q = 2; a.want_y = want_y;
   return a;
@@ -177,9 +189,11 @@ int tvlqr_BackwardPass(const int* nx, const int* nu, int num_horizon, const lqr_
   Workspace& w = g_ws;
   const Layout L = make_layout(nx, nu, N, is_diag);
   if (prepare(w, L, nx, nu)) return TVLQR_NO_DEVICE;
-  double* hs = w.host.data();
+  double* hs = w.host;
   auto put = [&](int arr, int k, const double* src, int64_t cnt) {
-    if (src && cnt) memcpy(hs + L.off[(size_t)k * G_NUM + arr], src, sizeof(double) * cnt);
+    if (!cnt) return;
+    if (src) memcpy(hs + L.off[(size_t)k * G_NUM + arr], src, sizeof(double) * cnt);
+    else memset(hs + L.off[(size_t)k * G_NUM + arr], 0, sizeof(double) * cnt);   // an absent block is a zero block
   };
   for (int k = 0; k <= N; ++k) {
     const int n = nx[k];
@@ -201,8 +215,8 @@ int tvlqr_BackwardPass(const int* nx, const int* nu, int num_horizon, const lqr_
   hipLaunchKernelGGL(generic_backward_kernel<double>, dim3(1), dim3(64), lds, 0, a);
   if (hipGetLastError() != hipSuccess) return TVLQR_NO_DEVICE;
   if (hipMemcpy(hs, w.dev, (size_t)L.total * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return TVLQR_NO_DEVICE;
-  int status = TVLQR_NO_DEVICE;
-  if (hipMemcpy(&status, w.dev_status, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return TVLQR_NO_DEVICE;
+  int status;
+  memcpy(&status, hs + L.total - 2, sizeof(int));
   auto get = [&](int arr, int k, double* dst, int64_t cnt) {
     if (dst && cnt) memcpy(dst, hs + L.off[(size_t)k * G_NUM + arr], sizeof(double) * cnt);
   };
@@ -245,9 +259,11 @@ int tvlqr_ForwardPass(const int* nx, const int* nu, int num_horizon, const lqr_f
   Workspace& w = g_ws;
   const Layout L = make_layout(nx, nu, N, false);
   if (prepare(w, L, nx, nu)) return TVLQR_NO_DEVICE;
-  double* hs = w.host.data();
+  double* hs = w.host;
   auto put = [&](int arr, int k, const double* src, int64_t cnt) {
-    if (src && cnt) memcpy(hs + L.off[(size_t)k * G_NUM + arr], src, sizeof(double) * cnt);
+    if (!cnt) return;
+    if (src) memcpy(hs + L.off[(size_t)k * G_NUM + arr], src, sizeof(double) * cnt);
+    else memset(hs + L.off[(size_t)k * G_NUM + arr], 0, sizeof(double) * cnt);   // an absent block is a zero block
   };
   for (int k = 0; k <= N; ++k) {
     const int n = nx[k];
@@ -264,9 +280,9 @@ int tvlqr_ForwardPass(const int* nx, const int* nu, int num_horizon, const lqr_f
       put(G_d, k, d[k], m);
     }
   }
+  memcpy(hs + L.total - 36, x0, sizeof(double) * nx[0]);
   if (hipMemcpy(w.dev, hs, (size_t)L.total * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return TVLQR_NO_DEVICE;
   double* dev_x0 = w.dev + L.total - 36;
-  if (hipMemcpy(dev_x0, x0, sizeof(double) * nx[0], hipMemcpyHostToDevice) != hipSuccess) return TVLQR_NO_DEVICE;
   GenericArgs<double> a = make_args(w, L, 0.0, false, y ? 1 : 0);
   a.x0 = dev_x0;
   const size_t lds = (size_t)(2 * a.nmax + a.mmax) * sizeof(double) + 64;
