@@ -190,11 +190,22 @@ def global_stats(bt, local_rank, rank, world, shard):
     the C ABI's own entry -- device-side reduction + two ncclAllReduce on the handle's stream; under the single-box
     gloo test hook the same device-side reduction followed by the two torch.distributed calls."""
     if RED_DEVICE == "cuda":
-        comm = shard.make_comm(local_rank, rank, world)
-        st = bt.stats(comm).as_dict()
-        comm.close()
-        st["reduced_by"] = "altro_hip_stats_allreduce (device-side reduction + 2 x ncclAllReduce, RCCL, world %d)" % world
-        return st
+        try:
+            comm = shard.make_comm(local_rank, rank, world)
+            st = bt.stats(comm).as_dict()
+            comm.close()
+            st["reduced_by"] = "altro_hip_stats_allreduce (device-side reduction + 2 x ncclAllReduce, RCCL, world %d)" % world
+            return st
+        except Exception as e:   # the statistics are outside the timed region: a collective that fails must not cost the line
+            print("[bench] altro_hip_stats_allreduce failed on rank %d (%s); falling back to torch.distributed" % (rank, e),
+                  file=sys.stderr)
+            if world == 1:
+                st = bt.stats().as_dict()
+                st["reduced_by"] = "altro_hip_stats_reduce (device); no collective (world 1)"
+                return st
+            st = shard.reduce_stats(bt.stats(), device="cuda:%d" % local_rank)
+            st["reduced_by"] = "altro_hip_stats_reduce (device) + torch.distributed nccl all_reduce (fallback: %s)" % e
+            return st
     st = shard.reduce_stats(bt.stats(), device="cpu")
     st["reduced_by"] = "altro_hip_stats_reduce (device) + torch.distributed gloo all_reduce (test hook)"
     return st
