@@ -643,10 +643,11 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
   if (lane_plan) merit_split_prepare(h);
   bool fused_can = lane_plan && h->n <= 4 && o.iterations_max > 0 && !h->spec_no_memory && h->merit_split == 1 &&
                    !(h->flags & ALTRO_HIP_LANE_FUSED);
-  // POLICY (MI355X, batch 8192, 80 sweeps): pendulum 3.29 against 3.73 ms (cubic) and 3.41 against 3.82 ms (backtracking);
-  // bicycle + steering bound 105 against 187 ms (cubic), but 72.5 against 68.6 ms with backtracking, where the loop below
-  // evaluates up to eight steps per launch on otherwise idle CUs and the fused bicycle body spills (368 B / lane).
-  bool fused_want = !(o.use_backtracking_linesearch && h->n > 2);
+  // POLICY: fused wherever the kernel exists.  Measured on MI355X (tools/solve_batches.py, tools/solve_ab.py; bicycle +
+  // steering bound, N = 50, median wall ms fused / sequenced): backtracking search 6.6 / 7.6 at 256 problems, 22 / 31 at
+  // 2048, 31 / 35 at 4096, 44 / 45 at 8192, 66 / 70 at 16384; cubic search 24 / 36, 29 / 63, 36 / 86, 52 / 110, 61 / 162;
+  // pendulum, 8192 problems: 2.8 / 4.1 (cubic), 3.2 / 4.3 (backtracking).
+  bool fused_want = true;
   if (const char* e = std::getenv("ALTRO_HIP_FUSED")) fused_want = std::atoi(e) != 0;
   if (std::getenv("ALTRO_HIP_NO_FUSED") != nullptr) fused_want = false;
   bool fused = fused_can && fused_want;
@@ -660,7 +661,7 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
     if (const char* e = std::getenv("ALTRO_HIP_FUSED_SWEEPS")) fused_sweeps = std::max(1, std::min(o.iterations_max, std::atoi(e)));
     HIP_TRY(hipMemsetAsync(h->i_counters, 0, 4 * sizeof(int), h->stream));
     IlqrFusedArgs fa{0, fused_sweeps, o.reg_retry_max, reg_on ? 1 : 0, h->i_counters, nullptr};
-    const int clk_G = h->batch <= 8 * 256 ? 8 : 32;   // (ilqr_launch_fused)
+    const int clk_G = ilqr_fused_group(h->batch);
     const int clk_groups = (h->batch + clk_G - 1) / clk_G;
     unsigned long long* clk = nullptr;     // ALTRO_HIP_FUSED_CLOCK: per-phase time of the kernel, printed to stderr
     if (std::getenv("ALTRO_HIP_FUSED_CLOCK") != nullptr) {

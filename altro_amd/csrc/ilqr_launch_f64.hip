@@ -4,7 +4,6 @@
 #include <algorithm>
 
 #include "kernels/ilqr_lane.hip"
-#include "kernels/ilqr_fused.hip"
 #include "kernels/ilqr_loop_kernels.hip"
 
 namespace altro_hip {
@@ -48,33 +47,6 @@ int ilqr_launch_kernel<double>(hipStream_t stream, int which, int kind, int n, i
         hipLaunchKernelGGL((ilqr_stationarity_kernel<N_, M_, T>), flat64, b64, 0, stream, a);                   \
         break;                                                                                                \
     }                                                                                                         \
-  }
-  ILQR_MODELS(X)
-#undef X
-  if (!done) return 1;
-  return hipGetLastError() == hipSuccess ? 0 : 2;
-}
-
-template <>
-int ilqr_launch_fused<double>(hipStream_t stream, int kind, int n, int m, const IlqrArgs<double>& a, const IlqrLoopArgs& la,
-                          const LaneArgs<double>& ba, const IlqrFusedArgs& fa) {
-  using T = double;
-  // Problems per workgroup (of four waves): as few as keeps every workgroup resident at once, one per CU -- the fewer, the
-  // more knot points each wave takes at once in the (problem, knot point)-parallel steps (ilqr_fused.hip, KS).
-  const int G = a.batch <= 8 * 256 ? 8 : 32;
-  const dim3 grid(8 * (((a.batch + G - 1) / G + 7) / 8)), block(256);
-  bool done = false;
-  // (6, 3) is not instantiated: hipcc 7.2 emits an illegal spill reload (odd-aligned 64-bit VGPR pair) for it; that shape
-  // keeps the launch-sequenced loop
-#define X(K_, N_, M_)                                                                                              \
-  if (!done && kind == K_ && n == N_ && m == M_) {                                                                 \
-    done = true;                                                                                                   \
-    if constexpr (N_ <= 4) {                                                                                       \
-      if (G == 8) hipLaunchKernelGGL((ilqr_fused_sweeps_kernel<K_, N_, M_, T, 8>), grid, block, 0, stream, a, la, ba, fa);   \
-      else hipLaunchKernelGGL((ilqr_fused_sweeps_kernel<K_, N_, M_, T, 32>), grid, block, 0, stream, a, la, ba, fa);          \
-    } else {                                                                                                       \
-      return 1;                                                                                                    \
-    }                                                                                                              \
   }
   ILQR_MODELS(X)
 #undef X

@@ -145,9 +145,20 @@ struct IlqrFusedArgs {
   int* counters;      // [1] += problems still running when the launch ends; [3] = max sweeps any wave ran (atomicMax)
   unsigned long long* clk;   // optional [workgroups][ILQR_FUSED_PHASES] phase clock (100 MHz ticks), a tuning aid
 };
+template <typename T, int G>   // G problems per workgroup: one translation unit each (ilqr_fused_unit.inc)
+int ilqr_launch_fused_g(hipStream_t stream, int kind, int n, int m, const IlqrArgs<T>& a, const IlqrLoopArgs& la,
+                        const LaneArgs<T>& ba, const IlqrFusedArgs& fa);
+// Problems per workgroup (of four waves): as few as keeps every workgroup resident at once, one per CU -- the fewer, the more
+// knot points each wave takes at once in the (problem, knot point)-parallel steps (ilqr_fused.hip, KS).
+inline int ilqr_fused_group(int batch) { return batch <= 8 * 256 ? 8 : batch <= 16 * 256 ? 16 : 32; }
 template <typename T>
-int ilqr_launch_fused(hipStream_t stream, int kind, int n, int m, const IlqrArgs<T>& a, const IlqrLoopArgs& la,
-                      const LaneArgs<T>& ba, const IlqrFusedArgs& fa);
+inline int ilqr_launch_fused(hipStream_t stream, int kind, int n, int m, const IlqrArgs<T>& a, const IlqrLoopArgs& la,
+                             const LaneArgs<T>& ba, const IlqrFusedArgs& fa) {
+  const int G = ilqr_fused_group(a.batch);
+  return G == 8    ? ilqr_launch_fused_g<T, 8>(stream, kind, n, m, a, la, ba, fa)
+         : G == 16 ? ilqr_launch_fused_g<T, 16>(stream, kind, n, m, a, la, ba, fa)
+                   : ilqr_launch_fused_g<T, 32>(stream, kind, n, m, a, la, ba, fa);
+}
 
 bool ilqr_supported(int kind, int n, int m);
 template <typename T>

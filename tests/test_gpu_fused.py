@@ -135,3 +135,15 @@ def test_fused_ragged_batch_and_short_horizon():
         seq = _solve(_pendulum(batch, N), {"ALTRO_HIP_NO_FUSED": "1"}, iterations_max=15)
         fused = _solve(_pendulum(batch, N), {"ALTRO_HIP_FUSED": "1"}, iterations_max=15)
         _same(seq, fused)
+
+
+@pytest.mark.parametrize("batch", [2100, 4200])
+def test_fused_workgroup_sizes(batch):
+    """8 / 16 / 32 problems per workgroup (ilqr_fused_group: batch <= 2048 / <= 4096 / larger): the other tests run the
+    8-problem kernels; these batches the 16- and 32-problem ones, ragged last workgroup included"""
+    for make, opts in ((_pendulum(batch, 24), dict(iterations_max=12)),
+                       (_bicycle(batch, 16), dict(iterations_max=10, use_backtracking=True))):
+        seq = _solve(make, {"ALTRO_HIP_NO_FUSED": "1"}, **opts)
+        fused = _solve(make, {"ALTRO_HIP_FUSED": "1"}, **opts)
+        _same(seq, fused)
+        assert int(fused[0]["merit_launches"]) == 0
