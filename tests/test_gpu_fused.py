@@ -147,3 +147,25 @@ def test_fused_workgroup_sizes(batch):
         fused = _solve(make, {"ALTRO_HIP_FUSED": "1"}, **opts)
         _same(seq, fused)
         assert int(fused[0]["merit_launches"]) == 0
+
+
+def test_fused_f32_storage():
+    """the same kernels instantiated for float: fused and sequenced still agree bit for bit"""
+    N, n, m, batch = 30, 4, 2, 150
+    x_ref, u_ref = problems.bicycle_reference(N + 1)
+
+    def make():
+        bt = altro_amd.Batch(N, n, m, batch, dtype=altro_amd.F32)
+        bt.set_model(altro_amd.MODEL_BICYCLE, np.float32(0.1))
+        bt.set_tracking_cost(np.full((1, N + 1, n), 1e-2), np.full((1, N, m), 1e-3), x_ref[None, :N + 1], u_ref[None, :N],
+                             batch_stride_zero=True)
+        G = np.zeros((2, n + m)); G[0, 3] = 1.0; G[1, 3] = -1.0
+        bt.add_linear_constraint(0, N, altro_amd.CONE_INEQUALITY, G, np.full(2, np.pi / 3))
+        bt.set_initial_state(x_ref[0] + (problems.uniform01((batch, n), 23, 0) - 0.5) * 0.5)
+        bt.set_input_guess(np.array([[[u_ref[0][0], 0.0]]]), k_stride_zero=True, batch_stride_zero=True)
+        return bt
+    for opts in (dict(iterations_max=15, use_backtracking=True), dict(iterations_max=15)):
+        seq = _solve(make, {"ALTRO_HIP_NO_FUSED": "1"}, **opts)
+        fused = _solve(make, {"ALTRO_HIP_FUSED": "1"}, **opts)
+        _same(seq, fused)
+        assert int(fused[0]["merit_launches"]) == 0
