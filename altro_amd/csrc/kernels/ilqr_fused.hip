@@ -1,22 +1,26 @@
 // ilqr_fused.hip -- plan LANE: whole sweeps of SolverImpl::Solve (solver.cpp:447-502) in ONE kernel launch.
 //
 // On plan LANE no kernel of the loop ever reads another problem's data, so the launch boundaries of the
-// launch-sequenced solve (capi_ilqr.hip) carry no dependency, only cost: ~13 launches and two or three host read-backs
-// per sweep.  Here a WORKGROUP of W = 4 wavefronts owns 64 problems (lane t of every wave <-> problem b0 + t) and runs
+// launch-sequenced solve (capi_ilqr.hip) carry no dependency, only cost: ~20 launches and two or three host read-backs
+// per sweep.  Here a WORKGROUP of four wavefronts owns G = 8, 16 or 32 problems (as few as keeps every workgroup
+// resident at once, one per CU; lane = (problem slot, knot-point slot), 64 / G knot points per wave at once) and runs
 // the very sequence the host loop enqueues, with `__syncthreads()` where the host has a launch boundary and
 // `__syncthreads_count()` where it reads a counter back:
-//   * the serial chains -- backward sweep, merit rollout -- run in one wave per pass, and the waves that would idle
-//     evaluate the line search's steps that are known in advance, exactly like the speculative launches of the host
-//     loop (gridDim.y there, the wave index here): wave 1 takes the first step alpha0 = 1 next to wave 0's phi(0), and
-//     in the backtracking stage the four waves take alpha beta^0..3 at once;
-//   * what is independent in k -- expansions, stationarity / feasibility, accept, dual updates, the copy of a spare
-//     candidate -- is dealt round-robin over the four waves (knot point k to wave k mod 4), the same point functions the
-//     (problem, knot point)-parallel kernels call.
+//   * the serial chains run in one wave per chain: the backward sweep (for (4, 2) four lanes per problem, 16 problems
+//     per wave: tvlqr_quad_body.inc), and of the merit evaluation (three phases, ilqr_lane.hip) the rollouts and the
+//     sums -- one wave per line-search step evaluated, exactly the speculative launches of the host loop (gridDim.y
+//     there, the wave index here): the first step alpha0 = 1 next to phi(0), alpha beta^0..3 in the backtracking stage;
+//   * the per-knot-point terms of a merit evaluation follow the rollouts as a wave front (progress counters in LDS),
+//     drawn chunk by chunk by whichever wave is free;
+//   * what else is independent in k -- expansions, stationarity / feasibility, accept, dual updates, the copy of a
+//     spare candidate -- is dealt round-robin over the four waves, the same point functions the (problem, knot
+//     point)-parallel kernels call.
 // Every function called is the body of a kernel of the sequenced path (ilqr_lane.hip, tvlqr_lane_body.inc,
-// ilqr_loop_logic.h), on the same per-batch arrays, in the same order: results are bit-identical to it with and without
-// its speculation (tests/test_gpu_fused.py).  A workgroup retires as soon as its 64 problems have stopped: a
-// straggler holds its own four waves, not the batch.  All waves of a workgroup sit on one CU and share its vector L1,
-// which is what makes a `__syncthreads()` enough between a store of one wave and a load of another.
+// tvlqr_quad_body.inc, ilqr_loop_logic.h), on the same per-batch arrays, in the same order: results are bit-identical
+// to it with and without its speculation (tests/test_gpu_fused.py).  A workgroup retires as soon as its problems have
+// stopped: a straggler holds its own four waves, not the batch.  All waves of a workgroup sit on one CU and share its
+// vector L1, which is what makes a `__syncthreads()` (or a workgroup-scope release / acquire pair) enough between a
+// store of one wave and a load of another.
 #pragma once
 #include <hip/hip_runtime.h>
 

@@ -456,8 +456,8 @@ __global__ __launch_bounds__(64) void ilqr_merit_kernel(IlqrArgs<T> a) {
 //                               A, B, lx, lu (into the backward pass's input record, or -- a speculative first step --
 //                               into the spare block a.spec_jac), J_k into a.merit_jk
 //   3. ilqr_merit_sum_kernel    lane per (problem, trial): phi = sum J_k in k order, the dx/dalpha recursion and phi'
-// Same expressions, same summation order as ilqr_merit_lane (the fused solve kernel still uses that): bit-identical
-// (tests/test_gpu_fused.py, tests/test_gpu_merit_split.py).
+// Same expressions, same summation order as the one-launch ilqr_merit_kernel (ALTRO_HIP_MERIT_SPLIT=0 keeps it): bit-identical
+// (tests/test_gpu_merit_split.py).  The fused solve kernel (ilqr_fused.hip) runs the same three phases inside a workgroup.
 template <int n, int m, typename T>
 struct MeritJac {   // where a derivative pass leaves A | B | lx | lu of knot point k and lx of the terminal one
   T* p; int E, oA, oB, oq, orr;
