@@ -33,10 +33,17 @@ namespace altro_hip {
 //  by-reference argument blocks go through scratch.  What keeps the register file in check instead is that no phase is
 //  monolithic any more: the merit evaluation is the three-phase one of ilqr_lane.hip, the (4, 2) backward sweep the
 //  four-lanes-per-problem one of tvlqr_quad_body.inc.)
+// Waves per workgroup: four = one per SIMD, each with the whole register file; eight (two per SIMD, 256 registers each)
+// where hipcc 7.2 can build it -- the 2-state shapes in fp64.  For the 4-state shapes and for float it emits an illegal
+// spill reload ("requires even aligned vector registers") as soon as the kernel is held to 256 registers.
+template <int n, typename T>
+constexpr int ilqr_fused_waves() { return (n <= 2 && sizeof(T) == 8) ? 8 : 4; }
+
 template <int KIND, int n, int m, typename T, int G>
-__global__ __launch_bounds__(256) void ilqr_fused_sweeps_kernel(IlqrArgs<T> a, IlqrLoopArgs la, LaneArgs<T> ba, IlqrFusedArgs fa) {
+__global__ __launch_bounds__((64 * ilqr_fused_waves<n, T>())) void ilqr_fused_sweeps_kernel(IlqrArgs<T> a, IlqrLoopArgs la,
+                                                                                           LaneArgs<T> ba, IlqrFusedArgs fa) {
   static_assert(G == 64 || G == 32 || G == 16 || G == 8, "problems per workgroup");
-  constexpr int W = 4;                        // waves per workgroup: one per SIMD, each with the whole register file
+  constexpr int W = ilqr_fused_waves<n, T>();
   constexpr int KS = 64 / G;                  // knot points a wave takes at once in the (problem, knot point)-parallel steps
   constexpr bool QUAD = n == 4 && m == 2;     // the shapes tvlqr_quad_body.inc is instantiated for
   // workgroup -> problems: contiguous runs per XCD like the sweep kernels' waves (tvlqr_lane_body.inc)
@@ -219,15 +226,26 @@ __global__ __launch_bounds__(256) void ilqr_fused_sweeps_kernel(IlqrArgs<T> a, I
       if (la.prob[bi].running) { la.prob[bi].stationarity = 0.0; la.prob[bi].feasibility = 0.0; }
     }
     __syncthreads();
-    for (int k = w * KS + ks; k <= N; k += W * KS)
-      if (valid && la.active[bi]) {
-        T res, viol;
-        ilqr_stationarity_point<n, m, T>(a, b, k, res, viol);
-        atomicMax(reinterpret_cast<unsigned long long*>(&a.prob[b].stationarity), (unsigned long long)__double_as_longlong((double)res));
-        if (al)
-          atomicMax(reinterpret_cast<unsigned long long*>(&a.prob[b].feasibility), (unsigned long long)__double_as_longlong((double)viol));
-        ilqr_accept_point<n, m, T>(a, b, k);
+    {   // (the maxima over this lane's knot points first, then ONE atomic per lane: 101 atomics on one word serialise)
+      // (maxima of the bit patterns, exactly what a sequence of atomicMax calls on the same word computes, NaNs included)
+      unsigned long long res_max = 0ull, viol_max = 0ull;
+      bool any = false;
+      for (int k = w * KS + ks; k <= N; k += W * KS)
+        if (valid && la.active[bi]) {
+          T res, viol;
+          ilqr_stationarity_point<n, m, T>(a, b, k, res, viol);
+          const unsigned long long rb = (unsigned long long)__double_as_longlong((double)res);
+          const unsigned long long vb = (unsigned long long)__double_as_longlong((double)viol);
+          res_max = rb > res_max ? rb : res_max;
+          viol_max = vb > viol_max ? vb : viol_max;
+          any = true;
+          ilqr_accept_point<n, m, T>(a, b, k);
+        }
+      if (any) {
+        atomicMax(reinterpret_cast<unsigned long long*>(&a.prob[b].stationarity), res_max);
+        if (al) atomicMax(reinterpret_cast<unsigned long long*>(&a.prob[b].feasibility), viol_max);
       }
+    }
     __syncthreads();
     lap(10);
     if (lead) (void)ilqr_finish_iter_body(la, bi);
