@@ -18,15 +18,18 @@ int lane_launch(altro_hip_batch* h, bool backward, double reg) {
                 backward ? h->bwd_reg : nullptr};
   const dim3 grid(8 * (((h->batch + 63) / 64 + 7) / 8)), block(64);
   const bool fused = (h->flags & ALTRO_HIP_LANE_FUSED) != 0;
-  // (4, 2): four lanes per problem (kernels/tvlqr_quad_body.inc), same records, bit-identical results; ALTRO_HIP_LANE_QUAD=0
-  // keeps the lane-per-problem sweep
+  // (4, 2) and (2, 1): four lanes per problem (kernels/tvlqr_quad_body.inc, tvlqr_quad2_body.inc), same records, bit-identical
+  // results; ALTRO_HIP_LANE_QUAD=0 keeps the lane-per-problem sweep
   const char* qe = std::getenv("ALTRO_HIP_LANE_QUAD");
   const bool quad_on = !(qe && std::atoi(qe) == 0);
-  if (backward) h->bwd_quad = quad_on && h->n == 4 && h->m == 2;
+  const bool q42 = h->n == 4 && h->m == 2, q21 = h->n == 2 && h->m == 1;
+  if (backward) h->bwd_quad = quad_on && (q42 || q21);
   if (backward && h->bwd_quad) {
     const dim3 qgrid(8 * (((h->batch + 15) / 16 + 7) / 8));
-    if (fused) hipLaunchKernelGGL((quad_backward_kernel_fused<2, T>), qgrid, block, 0, h->stream, a);
-    else hipLaunchKernelGGL((quad_backward_kernel<2, T>), qgrid, block, 0, h->stream, a);
+    if (q42 && fused) hipLaunchKernelGGL((quad_backward_kernel_fused<2, T>), qgrid, block, 0, h->stream, a);
+    else if (q42) hipLaunchKernelGGL((quad_backward_kernel<2, T>), qgrid, block, 0, h->stream, a);
+    else if (fused) hipLaunchKernelGGL((quad2_backward_kernel_fused<T>), qgrid, block, 0, h->stream, a);
+    else hipLaunchKernelGGL((quad2_backward_kernel<T>), qgrid, block, 0, h->stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "quad kernel launch: %s", hipGetErrorString(e));
     return 0;

@@ -45,7 +45,7 @@ __global__ __launch_bounds__((64 * ilqr_fused_waves<n, T>())) void ilqr_fused_sw
   static_assert(G == 64 || G == 32 || G == 16 || G == 8, "problems per workgroup");
   constexpr int W = ilqr_fused_waves<n, T>();
   constexpr int KS = 64 / G;                  // knot points a wave takes at once in the (problem, knot point)-parallel steps
-  constexpr bool QUAD = n == 4 && m == 2;     // the shapes tvlqr_quad_body.inc is instantiated for
+  constexpr bool QUAD = (n == 4 && m == 2) || (n == 2 && m == 1);   // four lanes per problem: tvlqr_quad_body.inc, tvlqr_quad2_body.inc
   // workgroup -> problems: contiguous runs per XCD like the sweep kernels' waves (tvlqr_lane_body.inc)
   const int nwg = (a.batch + G - 1) / G, chk = (nwg + 7) / 8;
   const int wg = (int)((blockIdx.x & 7) * chk + (blockIdx.x >> 3));
@@ -87,8 +87,11 @@ __global__ __launch_bounds__((64 * ilqr_fused_waves<n, T>())) void ilqr_fused_sw
       if (w < (G + 15) / 16) {
         const int q = 16 * w + (t >> 2);
         const int64_t bq = b0 + q;
-        if (q < G && bq < B && (retry ? s_again[q] != 0 : la.active[bq] != 0))
-          (void)quad_backward_wave<m, T>(ba, b0 + 16 * w, t, (retry || fa.use_reg) ? (T)la.reg[bq] : T(0));
+        if (q < G && bq < B && (retry ? s_again[q] != 0 : la.active[bq] != 0)) {
+          const T rg = (retry || fa.use_reg) ? (T)la.reg[bq] : T(0);
+          if constexpr (n == 4) (void)quad_backward_wave<m, T>(ba, b0 + 16 * w, t, rg);
+          else (void)quad2_backward_wave<T>(ba, b0 + 16 * w, t, rg);
+        }
       }
     } else {
       if (lead && (retry ? s_again[pt] != 0 : la.active[bi] != 0))

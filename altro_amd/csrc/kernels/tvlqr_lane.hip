@@ -92,6 +92,20 @@ __device__ __forceinline__ T quad_bcast(T v) {
   }
 }
 
+// Lane l of a quad gets the value of lane {A, B, C, D}[l] of the same quad (DPP quad_perm:[A,B,C,D])
+template <int A, int B, int C, int D, typename T>
+__device__ __forceinline__ T quad_shuf(T v) {
+  constexpr int ctrl = A | (B << 2) | (C << 4) | (D << 6);
+  if constexpr (sizeof(T) == 8) {
+    lane_v2u w = __builtin_bit_cast(lane_v2u, v);
+    w.x = (unsigned)__builtin_amdgcn_update_dpp(0, (int)w.x, ctrl, 0xf, 0xf, true);
+    w.y = (unsigned)__builtin_amdgcn_update_dpp(0, (int)w.y, ctrl, 0xf, 0xf, true);
+    return __builtin_bit_cast(T, w);
+  } else {
+    return __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, true));
+  }
+}
+
 // One knot point's forward-pass operands in registers: A | B | f and K | d | P | p.  The addresses never
 // depend on the state, so the record of step k + DEPTH is requested before step k is computed: these
 // shapes are latency-bound (one wave per 64 problems, N dependent steps) and an un-prefetched step costs
@@ -118,11 +132,13 @@ struct LaneFwdRec {
 #define LANE_FN(x) x
 #include "tvlqr_lane_body.inc"
 #include "tvlqr_quad_body.inc"
+#include "tvlqr_quad2_body.inc"
 #undef LANE_FN
 #pragma clang fp contract(fast)
 #define LANE_FN(x) x##_fused
 #include "tvlqr_lane_body.inc"
 #include "tvlqr_quad_body.inc"
+#include "tvlqr_quad2_body.inc"
 #undef LANE_FN
 
 #pragma clang fp contract(fast)
