@@ -74,11 +74,20 @@ __global__ __launch_bounds__((64 * ilqr_fused_waves<n, T>())) void ilqr_fused_sw
     }
   };
   __shared__ int s_again[G];                      // regularisation retry: which problems repeat their backward sweep
+  // The (problem, knot point)-parallel steps run on the COMPACTED list of the workgroup's running problems: with na of them
+  // left, a wave takes 64 / Gd knot points at once, Gd = the power of two >= na.  The tail of a batched solve -- a few
+  // stragglers per workgroup for most of the sweeps -- gets the whole wave per problem there (memory accesses are then one
+  // cache line per lane: irrelevant for a handful of problems).  The serial chains keep the fixed lane <-> problem mapping.
+  __shared__ int s_list[G];
+  __shared__ int s_na;
+  int KSd = KS, ksd = ks, bik = bi;
+  int64_t bk = b;
+  bool validk = valid;
 
   // W * KS knot points at once in every (problem, knot point)-parallel step
 #define FUSED_FOR_K(MASKED, CALL)                                  \
-  for (int k = w * KS + ks; k <= N; k += W * KS)                   \
-    if (valid && (MASKED)) { CALL; }
+  for (int k = w * KSd + ksd; k <= N; k += W * KSd)                \
+    if (validk && (MASKED)) { CALL; }
 
   // BackwardPass of the workgroup's problems: lane t of wave 0 <-> problem b0 + t, or -- (4, 2) -- four lanes per problem,
   // 16 problems in each of the waves 0..3.  `pick`: which problems (all the active ones, or the retrying ones).
@@ -124,21 +133,21 @@ __global__ __launch_bounds__((64 * ilqr_fused_waves<n, T>())) void ilqr_fused_sw
       Publish{&s_prog[w]}(N + 1);               // (also when no problem of this workgroup takes this step)
     }
     lap(ph);
-    const int total = trials * (N + 1), nchunks = (total + KS - 1) / KS;
+    const int total = trials * (N + 1), nchunks = (total + KSd - 1) / KSd;
     for (;;) {
       int c = 0;
       if (t == 0) c = atomicAdd(&s_next, 1);
       c = __builtin_amdgcn_readfirstlane(c);
       if (c >= nchunks) break;
-      const int last_idx = (c + 1) * KS - 1 < total ? (c + 1) * KS - 1 : total - 1;
+      const int last_idx = (c + 1) * KSd - 1 < total ? (c + 1) * KSd - 1 : total - 1;
       const int kmax = last_idx / trials;
       for (int tt = 0; tt < trials; ++tt)
         while (__hip_atomic_load(&s_prog[tt], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= kmax) __builtin_amdgcn_s_sleep(2);
-      const int idx = c * KS + ks;
-      if (idx < total && valid && la.active[bi]) {
+      const int idx = c * KSd + ksd;
+      if (idx < total && validk && la.active[bik]) {
         const int k = idx / trials, trial = idx - k * trials;
-        const MeritTrial<T> tr = ilqr_merit_trial<T>(am, b, trial);
-        if (tr.run) ilqr_merit_point<KIND, n, m, T>(am, b, k, trial, tr);
+        const MeritTrial<T> tr = ilqr_merit_trial<T>(am, bk, trial);
+        if (tr.run) ilqr_merit_point<KIND, n, m, T>(am, bk, k, trial, tr);
       }
     }
     __syncthreads();
@@ -157,9 +166,25 @@ __global__ __launch_bounds__((64 * ilqr_fused_waves<n, T>())) void ilqr_fused_sw
     ++sweeps;
     if (lead) ilqr_mark_running_body(la, bi);
     __syncthreads();
+    {   // the running problems of this workgroup, compacted (a problem that stops during the sweep stays listed: masks apply)
+      const bool act = lead && la.active[bi] != 0;
+      const unsigned long long mask = __ballot(act);
+      if (act) s_list[__popcll(mask & ((1ull << t) - 1ull))] = pt;
+      if (threadIdx.x == 0) s_na = __popcll(mask);
+      __syncthreads();
+      const int na = s_na;
+      int Gd = 1;
+      while (Gd < na) Gd <<= 1;
+      KSd = 64 / Gd;
+      const int slot = t & (Gd - 1);
+      ksd = t >> __builtin_ctz(Gd);
+      validk = slot < na;
+      bik = validk ? (int)b0 + s_list[slot] : (int)b0;
+      bk = bik;
+    }
     // CalcExpansions: the cost Hessians change only through the constraints' terms (solver.cpp:448)
     if (al) {
-      FUSED_FOR_K(la.active[bi], (ilqr_expand_point<KIND, n, m, T>(a, b, k, false, true)));
+      FUSED_FOR_K(la.active[bik], (ilqr_expand_point<KIND, n, m, T>(a, bk, k, false, true)));
       __syncthreads();
     }
     lap(0);
@@ -199,7 +224,7 @@ __global__ __launch_bounds__((64 * ilqr_fused_waves<n, T>())) void ilqr_fused_sw
     }
     int searching = __syncthreads_count(need0);
     la.spec_pre = 0;
-    FUSED_FOR_K(true, (ilqr_spec_select_point<n, m, T>(a, b, k)));
+    FUSED_FOR_K(true, (ilqr_spec_select_point<n, m, T>(a, bk, k)));
     lap(5);
     // the line search: one round = one merit evaluation per searching problem; in the backtracking stage the next four
     // steps of the (known) sequence alpha beta^j at once
@@ -214,13 +239,13 @@ __global__ __launch_bounds__((64 * ilqr_fused_waves<n, T>())) void ilqr_fused_sw
       la.spec_trials = trials;
       searching = __syncthreads_count(lead && ilqr_ls_feed_body(la, bi));
       la.spec_trials = 1;
-      if (trials > 1) FUSED_FOR_K(true, (ilqr_spec_select_point<n, m, T>(a, b, k)));
+      if (trials > 1) FUSED_FOR_K(true, (ilqr_spec_select_point<n, m, T>(a, bk, k)));
     }
     __syncthreads();
     // steps accepted from a speculative trial carry no phi' pass: redo their expansion (what the derivative pass of a
     // sequential trial would have left behind)
     lap(5);
-    FUSED_FOR_K(la.spec_refresh[bi], (ilqr_expand_point<KIND, n, m, T>(a, b, k, true, false)));
+    FUSED_FOR_K(la.spec_refresh[bik], (ilqr_expand_point<KIND, n, m, T>(a, bk, k, true, false)));
     __syncthreads();
     lap(9);
     // convergence criteria on the accepted candidate, then make it the nominal (solver.cpp:459-469)
@@ -233,20 +258,20 @@ __global__ __launch_bounds__((64 * ilqr_fused_waves<n, T>())) void ilqr_fused_sw
       // (maxima of the bit patterns, exactly what a sequence of atomicMax calls on the same word computes, NaNs included)
       unsigned long long res_max = 0ull, viol_max = 0ull;
       bool any = false;
-      for (int k = w * KS + ks; k <= N; k += W * KS)
-        if (valid && la.active[bi]) {
+      for (int k = w * KSd + ksd; k <= N; k += W * KSd)
+        if (validk && la.active[bik]) {
           T res, viol;
-          ilqr_stationarity_point<n, m, T>(a, b, k, res, viol);
+          ilqr_stationarity_point<n, m, T>(a, bk, k, res, viol);
           const unsigned long long rb = (unsigned long long)__double_as_longlong((double)res);
           const unsigned long long vb = (unsigned long long)__double_as_longlong((double)viol);
           res_max = rb > res_max ? rb : res_max;
           viol_max = vb > viol_max ? vb : viol_max;
           any = true;
-          ilqr_accept_point<n, m, T>(a, b, k);
+          ilqr_accept_point<n, m, T>(a, bk, k);
         }
       if (any) {
-        atomicMax(reinterpret_cast<unsigned long long*>(&a.prob[b].stationarity), res_max);
-        if (al) atomicMax(reinterpret_cast<unsigned long long*>(&a.prob[b].feasibility), viol_max);
+        atomicMax(reinterpret_cast<unsigned long long*>(&a.prob[bk].stationarity), res_max);
+        if (al) atomicMax(reinterpret_cast<unsigned long long*>(&a.prob[bk].feasibility), viol_max);
       }
     }
     __syncthreads();
@@ -255,11 +280,11 @@ __global__ __launch_bounds__((64 * ilqr_fused_waves<n, T>())) void ilqr_fused_sw
     __syncthreads();
     // DualUpdate, PenaltyUpdate, refreshed cost gradients for the problems that asked (solver.cpp:470-489)
     if (al) {
-      FUSED_FOR_K(la.prob[bi].dual, (ilqr_dual_point<n, m, T>(a, b, k)));
+      FUSED_FOR_K(la.prob[bik].dual, (ilqr_dual_point<n, m, T>(a, bk, k)));
       __syncthreads();
       if (lead) ilqr_penalty_update_body(la, bi);
       __syncthreads();
-      FUSED_FOR_K(la.active[bi], (ilqr_expand_point<KIND, n, m, T>(a, b, k, true, false)));
+      FUSED_FOR_K(la.active[bik], (ilqr_expand_point<KIND, n, m, T>(a, bk, k, true, false)));
       __syncthreads();
     }
     lap(11);
