@@ -402,6 +402,34 @@ __device__ __forceinline__ void mfma16_fwd_stage(const Mfma16FwdRegs& r, double*
   L[MF_FWD_OUT0 + 128 + (lane & 15)] = r.o[2];
   L[MF_FWD_F0 + (lane < 12 ? lane : 11)] = r.f;
 }
+// fp32 storage: the two records of a knot point (DYN 816 B, OUT 576 B, both 16-byte multiples at 16-byte-aligned addresses)
+// as ONE 16-byte-per-lane load each -- 51 and 36 lanes' worth, the other lanes repeat the last chunk -- instead of seven
+// 4-byte-per-lane loads: the sweep is paid per vector-memory instruction and per request size, not per byte.
+// The LDS image built from them is the same, element for element.
+typedef float mf_f32x4 __attribute__((ext_vector_type(4)));
+struct Mfma16FwdRegsF32 {
+  mf_f32x4 dyn, out;
+};
+__device__ __forceinline__ void mfma16_fwd_load(Mfma16FwdRegsF32& r, const float* __restrict__ rec, const float* __restrict__ orec,
+                                                int lane) {
+  static_assert(MF_DYN % 4 == 0 && MF_OUT % 4 == 0 && MF_OFF_F % 4 == 0, "16-byte chunks never straddle a block");
+  const int cd = lane < MF_DYN / 4 ? lane : MF_DYN / 4 - 1, co = lane < MF_OUT / 4 ? lane : MF_OUT / 4 - 1;
+  r.dyn = *reinterpret_cast<const mf_f32x4*>(rec + 4 * cd);
+  r.out = *reinterpret_cast<const mf_f32x4*>(orec + 4 * co);
+}
+__device__ __forceinline__ void mfma16_fwd_stage(const Mfma16FwdRegsF32& r, double* __restrict__ L, int lane) {
+  const int cd = lane < MF_DYN / 4 ? lane : MF_DYN / 4 - 1, co = lane < MF_OUT / 4 ? lane : MF_OUT / 4 - 1;
+  const int e = 4 * cd;                       // elements e .. e + 3 of the DYN record: a row of Z (16 wide) or f
+  const int base = e < MF_OFF_F ? (e >> 4) * MF_FWD_ZLD + (e & 15) : MF_FWD_F0 + (e - MF_OFF_F);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) L[base + q] = (double)r.dyn[q];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) L[MF_FWD_OUT0 + 4 * co + q] = (double)r.out[q];
+}
+template <typename S>
+struct Mfma16FwdRing { using type = Mfma16FwdRegs; };
+template <>
+struct Mfma16FwdRing<float> { using type = Mfma16FwdRegsF32; };
 __device__ __forceinline__ double readlane_f64(double v, int src_lane) {
   union { double d; int i[2]; } in, out;
   in.d = v;
@@ -438,11 +466,11 @@ __global__ __launch_bounds__(64) void mfma16_forward_kernel(Mfma16Args<S> a) {
   double xcur = (double)a.x0[(size_t)b * 12 + row];   // meaningful in group 0: x_k[row]
   // Register ring: knot point k + DEPTH is requested while knot point k computes, so DEPTH records
   // (DEPTH x 3.3 KB per wave) are in flight -- the read-dominated sweep needs that to fill HBM.
-  Mfma16FwdRegs ring[DEPTH];
+  typename Mfma16FwdRing<S>::type ring[DEPTH];
 #pragma unroll
   for (int dd = 0; dd < DEPTH; ++dd) {
     const int kk = (dd < N) ? dd : N - 1;
-    mfma16_fwd_load<S>(ring[dd], in + (size_t)kk * a.in_ks, out + (size_t)kk * a.out_ks, lane);
+    mfma16_fwd_load(ring[dd], in + (size_t)kk * a.in_ks, out + (size_t)kk * a.out_ks, lane);
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): drain before the loop (see the backward kernel)
   mfma16_fwd_stage(ring[0], lds, lane);
@@ -456,7 +484,7 @@ __global__ __launch_bounds__(64) void mfma16_forward_kernel(Mfma16Args<S> a) {
       const bool live = k < N;     // padding steps (N not a multiple of DEPTH) compute on a clamped record
       {   // slot dd held record k (already staged): refill it with record k + DEPTH (clamped, branch-free)
         const int kn = (k + DEPTH < N) ? k + DEPTH : N - 1;
-        mfma16_fwd_load<S>(ring[dd], in + (size_t)kn * a.in_ks, out + (size_t)kn * a.out_ks, lane);
+        mfma16_fwd_load(ring[dd], in + (size_t)kn * a.in_ks, out + (size_t)kn * a.out_ks, lane);
       }
       // this lane's row (16 doubles) and, for the x+ rows, f[row]
       double rd[16];
