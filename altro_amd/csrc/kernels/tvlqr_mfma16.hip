@@ -441,6 +441,7 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane) {
 template <typename S, int DEPTH>
 __global__ __launch_bounds__(64) void mfma16_forward_kernel(Mfma16Args<S> a) {
   __shared__ __attribute__((aligned(16))) double lds[MF_FWD_LDS + 4];
+  __shared__ double xu_lds[16];   // x_k | u_k: broadcast reads (fp32 storage: the sweep is issue-bound, 32 v_readlane cost more)
   const int lane = threadIdx.x;
   const int b = mf_problem(blockIdx.x, a.batch);
   if (b >= a.batch) return;
@@ -495,8 +496,15 @@ __global__ __launch_bounds__(64) void mfma16_forward_kernel(Mfma16Args<S> a) {
       const double fi = lds[MF_FWD_F0 + row];
       // x_k broadcast from lanes 0..11 through SGPRs
       double xs[12];
+      if constexpr (sizeof(S) == 4) {
+        if (lane < 12) xu_lds[lane] = xcur;
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): one wave, in-order LDS: the write is visible to the reads below
 #pragma unroll
-      for (int j = 0; j < 12; ++j) xs[j] = readlane_f64(xcur, j);
+        for (int j = 0; j < 12; ++j) xs[j] = xu_lds[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 12; ++j) xs[j] = readlane_f64(xcur, j);
+      }
       // phase A: sum_j row[j] x[j]   (A x | K x | P x depending on the lane's role)
       double acc = 0.0;
 #pragma unroll
@@ -505,8 +513,15 @@ __global__ __launch_bounds__(64) void mfma16_forward_kernel(Mfma16Args<S> a) {
       const double aff = acc + rd[12];
       const double uval = -aff;
       double us[4];
+      if constexpr (sizeof(S) == 4) {
+        if (lane >= 16 && lane < 20) xu_lds[lane - 4] = uval;
+        __builtin_amdgcn_s_waitcnt(0xC07F);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) us[c] = readlane_f64(uval, 16 + c);
+        for (int c = 0; c < 4; ++c) us[c] = xu_lds[12 + c];
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) us[c] = readlane_f64(uval, 16 + c);
+      }
       // phase C: x+ = A x + B u + f
       double xn = acc + fi;
 #pragma unroll
