@@ -178,6 +178,8 @@ def lib():
         L.altro_hip_selftest_mfma_f64.restype = d
         L.altro_hip_selftest_mfma_f32_4b.argtypes = [i]
         L.altro_hip_selftest_mfma_f32_4b.restype = d
+        L.altro_hip_selftest_sincos.argtypes = [i, vp, i, vp, vp]
+        L.altro_hip_selftest_sincos.restype = i
         _lib = L
     return _lib
 

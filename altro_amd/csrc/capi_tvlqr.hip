@@ -1,6 +1,7 @@
 // capi_tvlqr.hip -- C ABI: the TVLQR sweep (altro_hip_backward / forward_ltv / sweep) and its per-plan kernel launchers.
 // This unit instantiates the sweep kernels of all three plans (GENERIC, LANE, MFMA16 in fp64 / fp32 storage / pure fp32).
 #include "capi_internal.h"
+#include "models.h"
 
 #include "kernels/tvlqr_mfma16.hip"
 #include "kernels/tvlqr_mfma16_f32.hip"
@@ -244,6 +245,32 @@ int altro_hip_sweep(altro_hip_batch* h, double reg) {
 }
 
 // MFMA layout self-test (tests/test_gpu_parity.py): max |D - (A B + C)| for random operands.
+namespace {
+__global__ void sincos_selftest_kernel(const double* x, int n, double* s, double* c) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) sincos_hd<double>(x[i], &s[i], &c[i]);
+}
+}  // namespace
+// the device's fp64 sincos (models.h) on n arguments: the accuracy test of tests/test_gpu_trig.py
+int altro_hip_selftest_sincos(int device, const double* x, int n, double* s, double* c) {
+  if (!x || !s || !c || n <= 0) return ALTRO_HIP_ERR_BAD_ARGUMENT;
+  if (hipSetDevice(device) != hipSuccess) return ALTRO_HIP_ERR_NO_DEVICE;
+  double *dx = nullptr, *ds = nullptr, *dc = nullptr;
+  const size_t bytes = (size_t)n * sizeof(double);
+  int rc = 0;
+  if (hipMalloc((void**)&dx, bytes) != hipSuccess || hipMalloc((void**)&ds, bytes) != hipSuccess ||
+      hipMalloc((void**)&dc, bytes) != hipSuccess) rc = ALTRO_HIP_ERR_OUT_OF_MEMORY;
+  if (!rc && hipMemcpy(dx, x, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = ALTRO_HIP_ERR_HIP;
+  if (!rc) {
+    hipLaunchKernelGGL(sincos_selftest_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, dx, n, ds, dc);
+    if (hipMemcpy(s, ds, bytes, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(c, dc, bytes, hipMemcpyDeviceToHost) != hipSuccess)
+      rc = ALTRO_HIP_ERR_HIP;
+  }
+  if (dx) (void)hipFree(dx);
+  if (ds) (void)hipFree(ds);
+  if (dc) (void)hipFree(dc);
+  return rc;
+}
 double altro_hip_selftest_mfma_f64(int device) {
   if (hipSetDevice(device) != hipSuccess) return -1.0;
   double hA[64], hB[64], hC[256], hD[256];

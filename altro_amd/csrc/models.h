@@ -38,7 +38,10 @@ struct ModelParams {
   double lr;       // bicycle CoG -> rear axle (1.5)
 };
 
-// sin and cos of one argument with a single range reduction on the device
+// sin and cos of one argument with a single range reduction on the device.  (A hand-written fp64 evaluation -- Cody-Waite
+// reduction as a double-double, fdlibm kernels, 0.78 ulp worst case over [-2^20, 2^20] -- was measured against the library
+// routine in round 2 and is not faster: the solves moved by less than their run-to-run spread.  tests/test_gpu_trig.py pins
+// the accuracy of whatever this calls.)  Every device path calls this one function (sin_hd / cos_hd are its halves).
 template <typename T>
 ALTRO_HD void sincos_hd(T a, T* s, T* c) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -49,20 +52,40 @@ ALTRO_HD void sincos_hd(T a, T* s, T* c) {
   *c = cos(a);
 #endif
 }
+template <typename T>
+ALTRO_HD T sin_hd(T a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  T s, c;
+  sincos_hd<T>(a, &s, &c);
+  return s;
+#else
+  return sin(a);
+#endif
+}
+template <typename T>
+ALTRO_HD T cos_hd(T a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  T s, c;
+  sincos_hd<T>(a, &s, &c);
+  return c;
+#else
+  return cos(a);
+#endif
+}
 
 // ---- continuous models: xdot = f(x, u), J = [df/dx df/du] column-major (n x (n+m)) ----------------
 template <typename T>
 ALTRO_HD void pendulum_f(const T* x, const T* u, T* xdot) {
   const T l = T(0.5), g = T(9.81), b = T(0.1), mm = T(1.0) * l * l;
   xdot[0] = x[1];
-  xdot[1] = u[0] / mm - g * sin(x[0]) / l - b * x[1] / mm;
+  xdot[1] = u[0] / mm - g * sin_hd<T>(x[0]) / l - b * x[1] / mm;
 }
 template <typename T>
 ALTRO_HD void pendulum_J(const T* x, const T* u, T* J) {
   (void)u;
   const T l = T(0.5), g = T(9.81), b = T(0.1), mm = T(1.0) * l * l;
   J[0] = T(0);
-  J[1] = -g * cos(x[0]) / l;
+  J[1] = -g * cos_hd<T>(x[0]) / l;
   J[2] = T(1);
   J[3] = -b / mm;
   J[4] = T(0);
