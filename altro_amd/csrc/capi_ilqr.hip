@@ -643,10 +643,10 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
   if (lane_plan) merit_split_prepare(h);
   bool fused_can = lane_plan && h->n <= 4 && o.iterations_max > 0 && !h->spec_no_memory && h->merit_split == 1 &&
                    !(h->flags & ALTRO_HIP_LANE_FUSED);
-  // POLICY: fused wherever the kernel exists.  Measured on MI355X (tools/solve_batches.py, tools/solve_ab.py; bicycle +
-  // steering bound, N = 50, median wall ms fused / sequenced): backtracking search 6.6 / 7.6 at 256 problems, 22 / 31 at
-  // 2048, 31 / 35 at 4096, 44 / 45 at 8192, 66 / 70 at 16384; cubic search 24 / 36, 29 / 63, 36 / 86, 52 / 110, 61 / 162;
-  // pendulum, 8192 problems: 2.8 / 4.1 (cubic), 3.2 / 4.3 (backtracking).
+  // POLICY: fused wherever the kernel exists.  Measured on MI355X (tools/solve_batches.py, profiles/r02p_solve_batches.txt;
+  // bicycle + steering bound, N = 50, median wall ms fused / sequenced): backtracking search 5.5 / 7.4 at 256 problems,
+  // 20 / 31 at 2048, 24 / 44 at 8192, 76 / 173 at 65536; cubic search 25 / 33, 28 / 61, 36 / 106, 99 / 316; pendulum, 8192
+  // problems: 2.4 / 4.1 (cubic), 2.6 / 4.3 (backtracking).
   bool fused_want = true;
   if (const char* e = std::getenv("ALTRO_HIP_FUSED")) fused_want = std::atoi(e) != 0;
   if (std::getenv("ALTRO_HIP_NO_FUSED") != nullptr) fused_want = false;

@@ -12,7 +12,7 @@ from tools.solve_ab import c2, c3      # noqa: E402
 
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 for name, mk in (("C3 bicycle, backtracking", lambda B: c3(True, 50, B)), ("C3 bicycle, cubic", lambda B: c3(False, 50, B))):
-    for B in (256, 1024, 2048, 4096, 8192, 16384):
+    for B in [int(v) for v in os.environ.get("SOLVE_BATCHES", "256,1024,2048,4096,8192,16384").split(",")]:
         bt, guess, opts = mk(B)
         med = {}
         for mode in ("1", "0"):
