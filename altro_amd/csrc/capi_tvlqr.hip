@@ -25,6 +25,14 @@ int lane_launch(altro_hip_batch* h, bool backward, double reg) {
   const bool quad_on = !(qe && std::atoi(qe) == 0);
   const bool q42 = h->n == 4 && h->m == 2, q21 = h->n == 2 && h->m == 1;
   if (backward) h->bwd_quad = quad_on && (q42 || q21);
+  if (!backward && quad_on && q42) {   // forward sweep of (4, 2): four lanes per problem as well
+    const dim3 qgrid(8 * (((h->batch + 15) / 16 + 7) / 8));
+    if (fused) hipLaunchKernelGGL((quad_forward_kernel_fused<2, T>), qgrid, block, 0, h->stream, a);
+    else hipLaunchKernelGGL((quad_forward_kernel<2, T>), qgrid, block, 0, h->stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "quad kernel launch: %s", hipGetErrorString(e));
+    return 0;
+  }
   if (backward && h->bwd_quad) {
     const dim3 qgrid(8 * (((h->batch + 15) / 16 + 7) / 8));
     if (q42 && fused) hipLaunchKernelGGL((quad_backward_kernel_fused<2, T>), qgrid, block, 0, h->stream, a);

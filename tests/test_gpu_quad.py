@@ -49,8 +49,9 @@ def test_quad_profile_names_the_kernel_it_ran(n, m, name):
     bt = run_hip(pr, altro_amd.PLAN_LANE)["bt"]
     bt.profile(1); bt.backward(); bt.synchronize()
     assert bt.profile_get(0)[2] == name
+    assert bt.profile_get(1)[2] == ("quad_forward_kernel" if n == 4 else "lane_forward_kernel")   # (4, 2): the forward sweep too
     bt2 = _lane(lambda: run_hip(pr, altro_amd.PLAN_LANE)["bt"])
-    assert bt2.profile_get(0)[2] == "lane_backward_kernel"
+    assert bt2.profile_get(0)[2] == "lane_backward_kernel" and bt2.profile_get(1)[2] == "lane_forward_kernel"
 
 
 @pytest.mark.parametrize("n,m", [(4, 2), (2, 1)])
