@@ -3,6 +3,8 @@
 // every per-problem decision is taken on the device (kernels/ilqr_loop_kernels.hip).
 #include "capi_internal.h"
 
+#include <cstring>
+
 using namespace altro_hip;
 using namespace altro_hip::capi;
 
@@ -821,20 +823,18 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
   h->forward_done = true;
   h->solve_done = true;
   HIP_TRY(hipStreamSynchronize(h->stream));   // (iterations_max <= 0 reaches this point with kernels still in flight)
-  if (results) {
-    std::vector<IlqrProb> pr(h->batch);
-    HIP_TRY(hipMemcpy(pr.data(), h->i_prob, pr.size() * sizeof(IlqrProb), hipMemcpyDeviceToHost));
-    for (int b = 0; b < h->batch; ++b) {
-      results[b].status = pr[b].status;
-      results[b].iterations = pr[b].iterations;
-      results[b].stationarity = pr[b].stationarity;
-      results[b].final_alpha = pr[b].alpha;
-      results[b].final_phi = pr[b].ls_iters > 0 ? pr[b].ls.phi : pr[b].phi0;
-      results[b].primal_feasibility = pr[b].feasibility;
-      results[b].penalty = pr[b].rho;
-      results[b].dual_updates = pr[b].n_dual_updates;
-      results[b].reg_retries = pr[b].reg_retries;
+  if (results) {   // gathered on the device into the struct's own layout: 56 bytes per problem cross PCIe, through pinned memory
+    static_assert(sizeof(IlqrResult) == sizeof(altro_hip_solve_result), "IlqrResult mirrors altro_hip_solve_result");
+    const size_t bytes = (size_t)h->batch * sizeof(IlqrResult);
+    if (!h->i_results) {
+      if ((rc = dmalloc(h, &h->i_results, bytes))) return rc;
+      if (hipHostMalloc(&h->i_results_host, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); h->i_results_host = nullptr; }
     }
+    if (ilqr_launch_results(h->stream, h->i_prob, (IlqrResult*)h->i_results, h->batch)) return fail(ALTRO_HIP_ERR_HIP, "results kernel launch failed");
+    void* stage = h->i_results_host ? h->i_results_host : (void*)results;
+    HIP_TRY(hipMemcpyAsync(stage, h->i_results, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (stage != (void*)results) std::memcpy(results, stage, bytes);
   }
   h->last_sweeps = sweeps;
   h->last_merit_launches = total_merit_launches;

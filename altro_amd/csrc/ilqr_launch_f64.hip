@@ -61,6 +61,11 @@ bool ilqr_supported(int kind, int n, int m) {
   return false;
 }
 
+int ilqr_launch_results(hipStream_t stream, const IlqrProb* prob, IlqrResult* out, int batch) {
+  hipLaunchKernelGGL(ilqr_results_kernel, dim3((batch + 255) / 256), dim3(256), 0, stream, prob, out, batch);
+  return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
 int ilqr_launch_loop(hipStream_t stream, int which, const IlqrLoopArgs& a) {
   const dim3 gb((a.batch + 255) / 256), bb(256);
   switch (which) {

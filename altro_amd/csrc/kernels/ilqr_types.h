@@ -164,5 +164,13 @@ bool ilqr_supported(int kind, int n, int m);
 template <typename T>
 int ilqr_launch_kernel(hipStream_t stream, int which, int kind, int n, int m, const IlqrArgs<T>& a);
 int ilqr_launch_loop(hipStream_t stream, int which, const IlqrLoopArgs& a);
+// What a solve reports per problem, gathered on the device in the layout of altro_hip_solve_result (altro_hip.h): the host
+// copies 56 bytes per problem instead of the 280-byte control blocks.
+struct IlqrResult {
+  int status, iterations;
+  double stationarity, final_alpha, final_phi, primal_feasibility, penalty;
+  int dual_updates, reg_retries;
+};
+int ilqr_launch_results(hipStream_t stream, const IlqrProb* prob, IlqrResult* out, int batch);
 
 }  // namespace altro_hip
