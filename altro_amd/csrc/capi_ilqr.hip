@@ -598,27 +598,54 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
     HIP_TRY(hipMemsetAsync(h->i_counters + idx, 0, sizeof(int), h->stream));
     return 0;
   };
-  // initial rollout, make it the nominal trajectory, expand everything (solver.cpp:420-434)
-  if (ilqr_launch_loop(h->stream, ILK_LOOP_INIT, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
-  rc = ilqr_run(h, IK_ROLLOUT, false, false, 0, 0.0);
-  if (!rc) rc = ilqr_run(h, IK_ACCEPT, false, false, 0, 0.0);
-  // without constraints the cost Hessian is constant and is written once, here; with them the gradient is
-  // formed with the penalty the constraints carry so far and SetPenalty comes after it (solver.cpp:424-430)
-  if (!rc) rc = ilqr_run(h, IK_EXPAND, false, false, 0, 0.0, al ? EXPAND_GRADIENT : (EXPAND_GRADIENT | EXPAND_HESSIAN));
-  if (rc) return rc;
-  if (al && ilqr_launch_loop(h->stream, ILK_SET_PENALTY, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
+  const bool lane_plan = h->plan == ALTRO_HIP_PLAN_LANE;
+  const int64_t cand_elems = (int64_t)h->batch * (h->N + 1) * (lane_plan ? lane_sizes(h->n, h->m).e_xuy : 28);
+  const size_t spare_bytes = (size_t)(ILQR_SPEC_TRIALS - 1) * cand_elems * h->esz;   // spare candidate trajectories
+  // (n <= 4: the shapes the fused kernel is instantiated for, ilqr_launch_f64.hip)
+  // (the kernel works on the buffers of the three-launch merit evaluation; ALTRO_HIP_LANE_FUSED -- FMA-contracted sweeps --
+  //  is a property of the launch-sequenced kernels only)
+  if (lane_plan) merit_split_prepare(h);
+  bool fused_can = lane_plan && h->n <= 4 && o.iterations_max > 0 && !h->spec_no_memory && h->merit_split == 1 &&
+                   !(h->flags & ALTRO_HIP_LANE_FUSED);
+  // POLICY: fused wherever the kernel exists.  Measured on MI355X (tools/solve_batches.py, profiles/r02p_solve_batches.txt;
+  // bicycle + steering bound, N = 50, median wall ms fused / sequenced): backtracking search 5.5 / 7.4 at 256 problems,
+  // 20 / 31 at 2048, 24 / 44 at 8192, 76 / 173 at 65536; cubic search 25 / 33, 28 / 61, 36 / 106, 99 / 316; pendulum, 8192
+  // problems: 2.4 / 4.1 (cubic), 2.6 / 4.3 (backtracking).
+  bool fused_want = true;
+  if (const char* e = std::getenv("ALTRO_HIP_FUSED")) fused_want = std::atoi(e) != 0;
+  if (std::getenv("ALTRO_HIP_NO_FUSED") != nullptr) fused_want = false;
+  bool fused = fused_can && fused_want;
+  if (fused && !h->i_cand_spec && dmalloc(h, &h->i_cand_spec, spare_bytes)) {   // the waves' speculative steps need the spare
+    (void)hipGetLastError();                                                    // trajectories; without them: sequenced loop
+    h->spec_no_memory = true;
+    fused = false;
+  }
+  // initial rollout, make it the nominal trajectory, expand everything (solver.cpp:420-434) -- inside the fused kernel when
+  // that runs (IlqrFusedArgs::prologue), five launches otherwise
+  // (not for the 2-state shapes: their eight-wave kernel lives on 256 registers and spills; with the prologue's code in it
+  //  the pendulum solve loses 0.11 ms, the bicycle's MPC step gains 0.03 ms)
+  const bool fused_prologue = fused && h->n > 2;
+  if (!fused_prologue) {
+    if (ilqr_launch_loop(h->stream, ILK_LOOP_INIT, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
+    rc = ilqr_run(h, IK_ROLLOUT, false, false, 0, 0.0);
+    if (!rc) rc = ilqr_run(h, IK_ACCEPT, false, false, 0, 0.0);
+    // without constraints the cost Hessian is constant and is written once, here; with them the gradient is
+    // formed with the penalty the constraints carry so far and SetPenalty comes after it (solver.cpp:424-430)
+    if (!rc) rc = ilqr_run(h, IK_EXPAND, false, false, 0, 0.0, al ? EXPAND_GRADIENT : (EXPAND_GRADIENT | EXPAND_HESSIAN));
+    if (rc) return rc;
+    if (al && ilqr_launch_loop(h->stream, ILK_SET_PENALTY, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
+  } else if ((rc = al_upload(h))) {   // (what ilqr_run does before any launch)
+    return rc;
+  }
   int total_merit_launches = 0, sweeps = 0;
   // speculative backtracking: how much of the chip the searching problems occupy, and how much there is
   const bool spec_all_on = std::getenv("ALTRO_HIP_NO_SPECULATION") == nullptr;
   const bool spec_on = o.use_backtracking_linesearch != 0 && spec_all_on;
   int running = h->batch;   // problems still iterating (counters[1] of the previous sweep)
-  const bool lane_plan = h->plan == ALTRO_HIP_PLAN_LANE;
   auto spec_units = [&](int searching) -> int {   // wavefronts one merit launch keeps busy
     return lane_plan ? (h->batch + 63) / 64 : searching;   // LANE: the searching lanes are scattered over all waves
   };
   const int64_t spec_capacity = lane_plan ? 512 : 4096;    // two waves per CU (LANE: latency-bound; more slow each other down) / four per SIMD (MFMA16)
-  const int64_t cand_elems = (int64_t)h->batch * (h->N + 1) * (lane_plan ? lane_sizes(h->n, h->m).e_xuy : 28);
-  const size_t spare_bytes = (size_t)(ILQR_SPEC_TRIALS - 1) * cand_elems * h->esz;   // spare candidate trajectories
   h->spec_trials = 1;
   struct MaskGuard {   // the backward sweep skips problems that have stopped, only inside this loop
     altro_hip_batch* h;
@@ -639,30 +666,11 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
   // ALTRO_HIP_FUSED_SWEEPS=n hands the problems still running after n sweeps over to the loop below (a test hook: the
   // hand-over is exact at any sweep).
   int iter0 = 0;
-  // (n <= 4: the shapes the fused kernel is instantiated for, ilqr_launch_f64.hip)
-  // (the kernel works on the buffers of the three-launch merit evaluation; ALTRO_HIP_LANE_FUSED -- FMA-contracted sweeps --
-  //  is a property of the launch-sequenced kernels only)
-  if (lane_plan) merit_split_prepare(h);
-  bool fused_can = lane_plan && h->n <= 4 && o.iterations_max > 0 && !h->spec_no_memory && h->merit_split == 1 &&
-                   !(h->flags & ALTRO_HIP_LANE_FUSED);
-  // POLICY: fused wherever the kernel exists.  Measured on MI355X (tools/solve_batches.py, profiles/r02p_solve_batches.txt;
-  // bicycle + steering bound, N = 50, median wall ms fused / sequenced): backtracking search 5.5 / 7.4 at 256 problems,
-  // 20 / 31 at 2048, 24 / 44 at 8192, 76 / 173 at 65536; cubic search 25 / 33, 28 / 61, 36 / 106, 99 / 316; pendulum, 8192
-  // problems: 2.4 / 4.1 (cubic), 2.6 / 4.3 (backtracking).
-  bool fused_want = true;
-  if (const char* e = std::getenv("ALTRO_HIP_FUSED")) fused_want = std::atoi(e) != 0;
-  if (std::getenv("ALTRO_HIP_NO_FUSED") != nullptr) fused_want = false;
-  bool fused = fused_can && fused_want;
-  if (fused && !h->i_cand_spec && dmalloc(h, &h->i_cand_spec, spare_bytes)) {   // the waves' speculative steps need the spare
-    (void)hipGetLastError();                                                    // trajectories; without them: sequenced loop
-    h->spec_no_memory = true;
-    fused = false;
-  }
   if (fused) {
     int fused_sweeps = o.iterations_max;
     if (const char* e = std::getenv("ALTRO_HIP_FUSED_SWEEPS")) fused_sweeps = std::max(1, std::min(o.iterations_max, std::atoi(e)));
     HIP_TRY(hipMemsetAsync(h->i_counters, 0, 4 * sizeof(int), h->stream));
-    IlqrFusedArgs fa{0, fused_sweeps, o.reg_retry_max, reg_on ? 1 : 0, h->i_counters, nullptr};
+    IlqrFusedArgs fa{0, fused_sweeps, o.reg_retry_max, reg_on ? 1 : 0, h->i_counters, nullptr, fused_prologue ? 1 : 0};
     const int clk_G = ilqr_fused_group(h->batch);
     const int clk_groups = (h->batch + clk_G - 1) / clk_G;
     unsigned long long* clk = nullptr;     // ALTRO_HIP_FUSED_CLOCK: per-phase time of the kernel, printed to stderr

@@ -160,6 +160,26 @@ __global__ __launch_bounds__((64 * ilqr_fused_waves<n, T>())) void ilqr_fused_sw
     lap(ph + 2);
   };
 
+  if constexpr (n > 2) if (fa.prologue) {   // the head of Solve (solver.cpp:420-434), in the order the host loop launches it
+                                             // (compiled for the 4-state shapes only: see capi_ilqr.hip)
+    if (lead) {                                   // ilqr_loop_init_kernel
+      ilqr_prob_init(la.prob[bi]);
+      la.reg[bi] = la.reg_initial;
+      la.active[bi] = 1;
+      la.alpha[bi] = 0.0;
+    }
+    __syncthreads();
+    if (w == 0 && serial) ilqr_rollout_lane<KIND, n, m, T>(a, b);          // initial rollout on the candidate trajectory
+    __syncthreads();
+    FUSED_FOR_K(true, (ilqr_accept_point<n, m, T>(a, bk, k)));             // ... which becomes the nominal one
+    __syncthreads();
+    // without constraints the cost Hessian is constant and is written once, here; with them the gradient is formed with
+    // the penalty the constraints carry so far and SetPenalty comes after it (solver.cpp:424-430)
+    FUSED_FOR_K(true, (ilqr_expand_point<KIND, n, m, T>(a, bk, k, true, !al)));
+    __syncthreads();
+    if (al && lead) la.prob[bi].rho = la.penalty_initial;                   // ilqr_set_penalty_kernel
+    __syncthreads();
+  }
   for (int it = fa.first_iter; it < fa.first_iter + fa.max_sweeps; ++it) {
     la.iter = it;
     if (__syncthreads_count(lead && la.prob[bi].running != 0) == 0) break;

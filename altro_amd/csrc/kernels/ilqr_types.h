@@ -144,6 +144,8 @@ struct IlqrFusedArgs {
   int use_reg;        // per-problem regularisation in force (reg_initial > 0 or retries enabled)
   int* counters;      // [1] += problems still running when the launch ends; [3] = max sweeps any wave ran (atomicMax)
   unsigned long long* clk;   // optional [workgroups][ILQR_FUSED_PHASES] phase clock (100 MHz ticks), a tuning aid
+  int prologue;       // 1: the launch starts with the head of Solve (solver.cpp:420-434): control blocks, initial rollout,
+                      //    accept, first expansion, SetPenalty -- what the host enqueues as five launches otherwise
 };
 template <typename T, int G>   // G problems per workgroup: one translation unit each (ilqr_fused_unit.inc)
 int ilqr_launch_fused_g(hipStream_t stream, int kind, int n, int m, const IlqrArgs<T>& a, const IlqrLoopArgs& la,
