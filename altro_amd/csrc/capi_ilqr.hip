@@ -601,7 +601,12 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
   const bool lane_plan = h->plan == ALTRO_HIP_PLAN_LANE;
   const int64_t cand_elems = (int64_t)h->batch * (h->N + 1) * (lane_plan ? lane_sizes(h->n, h->m).e_xuy : 28);
   const size_t spare_bytes = (size_t)(ILQR_SPEC_TRIALS - 1) * cand_elems * h->esz;   // spare candidate trajectories
-  // (n <= 4: the shapes the fused kernel is instantiated for, ilqr_launch_f64.hip)
+  // Plan LANE: whole solves run in ONE launch -- a workgroup of four (eight) waves per 8 / 16 / 32 problems sequencing itself with
+  // no host in between (kernels/ilqr_fused.hip) -- bit-identical to the launch-sequenced loop further down
+  // (tests/test_gpu_fused.py, tools/fuzz_fused.py).  ALTRO_HIP_FUSED=1 / =0 forces one or the other (ALTRO_HIP_NO_FUSED, any
+  // value, = the latter); ALTRO_HIP_FUSED_SWEEPS=n hands the problems still running after n sweeps over to the loop (a test
+  // hook: the hand-over is exact at any sweep).
+  // (n <= 4: the shapes the fused kernel is instantiated for, ilqr_fused_unit.inc)
   // (the kernel works on the buffers of the three-launch merit evaluation; ALTRO_HIP_LANE_FUSED -- FMA-contracted sweeps --
   //  is a property of the launch-sequenced kernels only)
   if (lane_plan) merit_split_prepare(h);
@@ -659,12 +664,6 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
   h->bwd_active = h->i_active;
   h->bwd_reg = reg_on ? h->i_reg : nullptr;
   int total_reg_retries = 0;
-  // Plan LANE: the sweeps run fused -- whole sweeps per launch, a workgroup of four waves per 64 problems sequencing itself
-  // with no host in between (kernels/ilqr_fused.hip); bit-identical to the loop below (tests/test_gpu_fused.py).
-  // Which of the two runs is a measured choice (tools/solve_ab.py, DESIGN.md "Fused solve"): POLICY below.
-  // ALTRO_HIP_FUSED=1 / =0 forces one or the other (ALTRO_HIP_NO_FUSED, any value, = the latter);
-  // ALTRO_HIP_FUSED_SWEEPS=n hands the problems still running after n sweeps over to the loop below (a test hook: the
-  // hand-over is exact at any sweep).
   int iter0 = 0;
   if (fused) {
     int fused_sweeps = o.iterations_max;
