@@ -606,11 +606,10 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
   // (tests/test_gpu_fused.py, tools/fuzz_fused.py).  ALTRO_HIP_FUSED=1 / =0 forces one or the other (ALTRO_HIP_NO_FUSED, any
   // value, = the latter); ALTRO_HIP_FUSED_SWEEPS=n hands the problems still running after n sweeps over to the loop (a test
   // hook: the hand-over is exact at any sweep).
-  // (n <= 4: the shapes the fused kernel is instantiated for, ilqr_fused_unit.inc)
   // (the kernel works on the buffers of the three-launch merit evaluation; ALTRO_HIP_LANE_FUSED -- FMA-contracted sweeps --
   //  is a property of the launch-sequenced kernels only)
   if (lane_plan) merit_split_prepare(h);
-  bool fused_can = lane_plan && h->n <= 4 && o.iterations_max > 0 && !h->spec_no_memory && h->merit_split == 1 &&
+  bool fused_can = lane_plan && o.iterations_max > 0 && !h->spec_no_memory && h->merit_split == 1 &&
                    !(h->flags & ALTRO_HIP_LANE_FUSED);
   // POLICY: fused wherever the kernel exists.  Measured on MI355X (tools/solve_batches.py, profiles/r02p_solve_batches.txt;
   // bicycle + steering bound, N = 50, median wall ms fused / sequenced): backtracking search 5.5 / 7.4 at 256 problems,

@@ -169,3 +169,31 @@ def test_fused_f32_storage():
         fused = _solve(make, {"ALTRO_HIP_FUSED": "1"}, **opts)
         _same(seq, fused)
         assert int(fused[0]["merit_launches"]) == 0
+
+
+def test_fused_six_state_double_integrator():
+    """(6, 3): the shape whose fused kernel hipcc could not build before the merit evaluation was split"""
+    N, n, m, batch = 25, 6, 3, 150
+
+    def make(constrained):
+        def mk():
+            bt = altro_amd.Batch(N, n, m, batch)
+            assert bt.plan == altro_amd.PLAN_LANE
+            bt.set_model(altro_amd.MODEL_DOUBLE_INTEGRATOR, np.float32(0.2))
+            bt.set_tracking_cost(np.ones((2, n)), np.full((1, m), 1e-2), np.zeros((2, n)), np.zeros((1, m)), k_stride_zero=True,
+                                 batch_stride_zero=True)
+            if constrained:
+                G = np.zeros((2 * m, n + m)); G[:m, n:] = np.eye(m); G[m:, n:] = -np.eye(m)
+                bt.add_linear_constraint(0, N - 1, altro_amd.CONE_INEQUALITY, G, np.full(2 * m, 0.6))
+            bt.set_initial_state(2.0 * (problems.uniform01((batch, n), 57, 0) - 0.5))
+            bt.set_input_guess(np.zeros((1, 1, m)), k_stride_zero=True, batch_stride_zero=True)
+            return bt
+        return mk
+    for constrained, opts in ((False, dict(iterations_max=5)), (True, dict(iterations_max=25, penalty_scaling=10.0, use_backtracking=True)),
+                              (True, dict(iterations_max=25, penalty_scaling=100.0))):
+        seq = _solve(make(constrained), {"ALTRO_HIP_NO_FUSED": "1"}, **opts)
+        fused = _solve(make(constrained), {"ALTRO_HIP_FUSED": "1"}, **opts)
+        hand = _solve(make(constrained), {"ALTRO_HIP_FUSED": "1", "ALTRO_HIP_FUSED_SWEEPS": "2"}, **opts)
+        _same(seq, fused)
+        _same(seq, hand)
+        assert int(fused[0]["merit_launches"]) == 0

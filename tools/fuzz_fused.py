@@ -17,7 +17,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
 
 
 def make_case():
-    model = rng.choice(["pendulum", "bicycle", "di2", "di4"])
+    model = rng.choice(["pendulum", "bicycle", "di2", "di4", "di6"])
     N = int(rng.integers(1, 70))
     batch = int(rng.choice([1, 7, 33, 64, 65, 200, 777, 2048, 2049, 3000, 4097, 6000]))
     dtype = altro_amd.F32 if rng.random() < 0.25 else altro_amd.F64
@@ -51,7 +51,7 @@ def make_case():
             bt.set_initial_state(x_ref[0] + (problems.uniform01((batch, n), seed, 0) - 0.5) * spread)
             bt.set_input_guess(np.array([[[u_ref[0][0], 0.0]]]), k_stride_zero=True, batch_stride_zero=True)
         else:
-            dim = 1 if model == "di2" else 2
+            dim = {"di2": 1, "di4": 2, "di6": 3}[model]
             n, m = 2 * dim, dim
             bt = altro_amd.Batch(N, n, m, batch, dtype=dtype)
             bt.set_model(altro_amd.MODEL_DOUBLE_INTEGRATOR, np.float32(0.2))
