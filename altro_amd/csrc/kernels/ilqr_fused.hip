@@ -34,10 +34,10 @@ namespace altro_hip {
 //  monolithic any more: the merit evaluation is the three-phase one of ilqr_lane.hip, the (4, 2) backward sweep the
 //  four-lanes-per-problem one of tvlqr_quad_body.inc.)
 // Waves per workgroup: four = one per SIMD, each with the whole register file; eight (two per SIMD, 256 registers each)
-// where hipcc 7.2 can build it -- the 2-state shapes in fp64.  For the 4-state shapes and for float it emits an illegal
-// spill reload ("requires even aligned vector registers") as soon as the kernel is held to 256 registers.
+// where hipcc 7.2 can build it -- the 2-state shapes.  For the 4- and 6-state shapes it emits an illegal spill reload
+// ("requires even aligned vector registers") as soon as the kernel is held to 256 registers.
 template <int n, typename T>
-constexpr int ilqr_fused_waves() { return (n <= 2 && sizeof(T) == 8) ? 8 : 4; }
+constexpr int ilqr_fused_waves() { return n <= 2 ? 8 : 4; }
 
 template <int KIND, int n, int m, typename T, int G>
 __global__ __launch_bounds__((64 * ilqr_fused_waves<n, T>())) void ilqr_fused_sweeps_kernel(IlqrArgs<T> a, IlqrLoopArgs la,
