@@ -116,7 +116,8 @@ struct Mfma16Args {
 // Backward sweep.
 // ------------------------------------------------------------------------------------------------
 // Record loads.  Measured on MI355X (round 1): nontemporal loads (`__builtin_nontemporal_load`) make the
-// backward sweep 9 % SLOWER (1.155 vs 1.06 ms) and leave the forward sweep unchanged, so plain loads.
+// backward sweep 9 % SLOWER (1.155 vs 1.06 ms) and leave the forward sweep unchanged, so plain loads.  Nontemporal STORES
+// of the OUT records (round 2, same-box A/B, three pairs): 0.8424 vs 0.8428 ms -- no difference, plain stores.
 template <typename S>
 __device__ __forceinline__ double ld_stream(const S* p) {
   return (double)(*p);
