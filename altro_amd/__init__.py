@@ -29,9 +29,9 @@ C_ABI_SYMBOLS = [
     "altro_hip_get_p", "altro_hip_get_x", "altro_hip_get_u", "altro_hip_get_y",
     "altro_hip_get_delta_V", "altro_hip_get_status", "altro_hip_get_qblocks",
     "altro_hip_stats_reduce", "altro_hip_comm_unique_id", "altro_hip_comm_create", "altro_hip_comm_create_all",
-    "altro_hip_comm_destroy", "altro_hip_stats_allreduce", "altro_hip_stats_allreduce_multi",
+    "altro_hip_comm_destroy", "altro_hip_comm_rank", "altro_hip_comm_world", "altro_hip_comm_device", "altro_hip_stats_allreduce", "altro_hip_stats_allreduce_multi",
     "altro_hip_profile_enable", "altro_hip_profile_reset",
-    "altro_hip_profile_get", "altro_hip_profile_get_range", "altro_hip_algorithmic_bytes",
+    "altro_hip_profile_get", "altro_hip_profile_get_range", "altro_hip_profile_dropped", "altro_hip_algorithmic_bytes",
     "altro_hip_set_model", "altro_hip_set_tracking_cost", "altro_hip_set_input_guess",
     "altro_hip_open_loop_rollout", "altro_hip_accept", "altro_hip_expand", "altro_hip_merit",
     "altro_hip_stationarity", "altro_hip_get_nominal", "altro_hip_get_expansion",
@@ -72,8 +72,10 @@ class Stats(C.Structure):
     _fields_ = [("problems", C.c_int64), ("cholesky_failures", C.c_int64), ("converged", C.c_int64),
                 ("iterations", C.c_int64), ("sum_cost", C.c_double),
                 ("sum_delta_V0", C.c_double), ("sum_delta_V1", C.c_double),
-                ("max_stationarity", C.c_double), ("max_feasibility", C.c_double), ("max_abs_xN", C.c_double)]
-    SUM_FIELDS = ("problems", "cholesky_failures", "converged", "iterations", "sum_cost", "sum_delta_V0", "sum_delta_V1")
+                ("max_stationarity", C.c_double), ("max_feasibility", C.c_double), ("max_abs_xN", C.c_double),
+                ("non_finite", C.c_int64)]
+    SUM_FIELDS = ("problems", "cholesky_failures", "converged", "iterations", "sum_cost", "sum_delta_V0", "sum_delta_V1",
+                  "non_finite")
     MAX_FIELDS = ("max_stationarity", "max_feasibility", "max_abs_xN")
 
     def as_dict(self):
@@ -141,12 +143,15 @@ def lib():
         L.altro_hip_comm_create_all.argtypes = [C.POINTER(vp), i, C.POINTER(i)]
         L.altro_hip_comm_destroy.argtypes = [vp]
         L.altro_hip_comm_destroy.restype = None
+        for fn in ("rank", "world", "device"):
+            getattr(L, "altro_hip_comm_" + fn).argtypes = [vp]
         L.altro_hip_stats_allreduce.argtypes = [vp, vp, C.POINTER(Stats)]
         L.altro_hip_stats_allreduce_multi.argtypes = [C.POINTER(vp), C.POINTER(vp), i, C.POINTER(Stats)]
         L.altro_hip_profile_enable.argtypes = [vp, i]
         L.altro_hip_profile_reset.argtypes = [vp]
         L.altro_hip_profile_get.argtypes = [vp, i, C.POINTER(i), C.POINTER(d), C.POINTER(C.c_char_p)]
         L.altro_hip_profile_get_range.argtypes = [vp, i, C.POINTER(d), C.POINTER(d)]
+        L.altro_hip_profile_dropped.argtypes = [vp, i]
         L.altro_hip_algorithmic_bytes.argtypes = [vp, i]
         L.altro_hip_algorithmic_bytes.restype = d
         L.altro_hip_set_model.argtypes = [vp, i, C.c_float, i, d, d]
@@ -281,6 +286,9 @@ class Batch:
         lo, hi = C.c_double(), C.c_double()
         _check(self.L.altro_hip_profile_get_range(self.h, slot, C.byref(lo), C.byref(hi)))
         return lo.value, hi.value
+
+    def profile_dropped(self, slot):
+        return self.L.altro_hip_profile_dropped(self.h, slot)
 
     def profile_get(self, slot):
         n, ms, name = C.c_int(), C.c_double(), C.c_char_p()
@@ -426,6 +434,15 @@ class Comm:
         assert len(uid) == COMM_ID_BYTES
         buf = (C.c_char * COMM_ID_BYTES).from_buffer_copy(uid)
         _check(self.L.altro_hip_comm_create(C.byref(self.c), int(device), int(rank), int(world), C.cast(buf, C.c_void_p)))
+
+    @property
+    def rank(self):
+        return self.L.altro_hip_comm_rank(self.c)
+
+    @property
+    def world(self):
+        """Number of ranks (= GPUs) the communicator was built over: what a bench line reports as n_gpus."""
+        return self.L.altro_hip_comm_world(self.c)
 
     def close(self):
         if getattr(self, "c", None) is not None and self.c:

@@ -44,10 +44,25 @@ def build(force=False, verbose=False):
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result",
              "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
+    def fresh(obj, dep):
+        """An object is reused when neither its source nor any header its last compile read (-MMD) is newer."""
+        if force or not (os.path.exists(obj) and os.path.exists(dep)):
+            return False
+        t = os.path.getmtime(obj)
+        try:
+            words = open(dep).read().replace("\\\n", " ").split()
+        except OSError:
+            return False
+        files = [w for w in words[1:] if not w.endswith(":")]
+        return all(os.path.exists(f) and os.path.getmtime(f) <= t for f in files) and bool(files)
+
     def compile_one(src):
         # object names follow the path below csrc/ (host/x.cpp and x.hip must not collide)
         obj = os.path.join(objdir, os.path.splitext(os.path.relpath(src, CSRC))[0].replace(os.sep, "__") + ".o")
-        cmd = [hipcc] + flags + ["-c", src, "-o", obj]
+        dep = obj[:-2] + ".d"
+        if fresh(obj, dep):
+            return obj
+        cmd = [hipcc] + flags + ["-MMD", "-MF", dep, "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

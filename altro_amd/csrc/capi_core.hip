@@ -170,9 +170,10 @@ int altro_hip_batch_create(altro_hip_batch** out, int N, int n, int m, int batch
     ALLOC(h->i_phi, B * 8 * ILQR_SPEC_TRIALS);
     ALLOC(h->i_spec_sel, B * sizeof(int));
     ALLOC(h->i_spec_refresh, B * sizeof(int));
+    ALLOC(h->i_stat_done, B * sizeof(int));
     ALLOC(h->i_dphi, B * 8 * 2);
     ALLOC(h->i_active, B * sizeof(int));
-    ALLOC(h->i_counters, 4 * sizeof(int));
+    ALLOC(h->i_counters, 8 * sizeof(int));
     ALLOC(h->i_reg, B * 8);
     if (!rc) {   // every constraint starts with penalty 1 (knotpoint_data.cpp:343)
       std::vector<IlqrProb> pr((size_t)B);
@@ -202,7 +203,7 @@ void altro_hip_batch_destroy(altro_hip_batch* h) {
                   h->l_in, h->l_term, h->l_out, h->l_outn, h->l_xuy, h->l_x0,
                   h->l_nom, h->l_cost, h->i_prob, h->i_alpha, h->i_phi, h->i_dphi, h->i_active, h->i_counters,
                   h->al_d_knots, h->al_d_G, h->al_d_g, h->al_d_z, h->i_reg, h->m_nom, h->m_costp,
-                  h->i_cand_spec, h->i_spec_sel, h->i_spec_refresh, h->st_partial, h->st_red, h->i_merit_jk, h->i_spec_jac, h->i_results};
+                  h->i_cand_spec, h->i_spec_sel, h->i_spec_refresh, h->i_stat_done, h->st_partial, h->st_red, h->i_merit_jk, h->i_spec_jac, h->i_results};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->i_results_host) (void)hipHostFree(h->i_results_host);
   for (int a = 0; a < G_NUM; ++a) if (h->g_arr[a]) (void)hipFree(h->g_arr[a]);
@@ -492,6 +493,7 @@ int altro_hip_profile_reset(altro_hip_batch* h) {
   if (h->prof == 2) { (void)hipSetDevice(h->device); (void)hipStreamSynchronize(h->stream); }
   h->prof_n = 0;
   h->prof_launches[0] = h->prof_launches[1] = 0;
+  h->prof_dropped[0] = h->prof_dropped[1] = 0;
   h->prof_ms[0] = h->prof_ms[1] = 0.0;
   h->prof_min[0] = h->prof_min[1] = h->prof_max[0] = h->prof_max[1] = 0.0;
   return 0;
@@ -535,6 +537,10 @@ int altro_hip_profile_get(altro_hip_batch* h, int slot, int* launches, double* t
                                                                                     : "mfma16_backward_f32_kernel";
   }
   return 0;
+}
+int altro_hip_profile_dropped(altro_hip_batch* h, int slot) {
+  if (!h || slot < 0 || slot > 1) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "bad handle or slot");
+  return h->prof_dropped[slot];
 }
 int altro_hip_profile_get_range(altro_hip_batch* h, int slot, double* min_ms, double* max_ms) {
   if (!h || slot < 0 || slot > 1) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "bad handle or slot");

@@ -153,6 +153,7 @@ int wave_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int
   a.spec_pre = h->i_cand_spec ? h->spec_pre : 0;
   a.spec_stride = (int64_t)h->batch * (h->N + 1) * 28;
   a.ls_beta = h->spec_beta; a.ls_max_iters = h->spec_max_iters;
+  a.skip = which == IK_STATIONARITY ? h->stat_skip : nullptr;
   const int rc = ilqr_wave_launch_kernel<S>(h->stream, which, a);
   if (rc == 1) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "operation %d is not available on plan MFMA16", which);
   if (rc) return fail(ALTRO_HIP_ERR_HIP, "iLQR kernel launch failed");
@@ -588,7 +589,7 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
   la.ls.try_cubic_first = 1;                                   // solver.cpp:248
   la.ls.use_backtracking = o.use_backtracking_linesearch;      // solver.cpp:417
   h->spec_beta = la.ls.beta_decrease; h->spec_max_iters = la.ls.max_iters;
-  int counters[3];
+  int counters[5];
   auto read_counters = [&]() -> int {
     HIP_TRY(hipMemcpyAsync(counters, h->i_counters, sizeof(counters), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -629,13 +630,23 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
   // (not for the 2-state shapes: their eight-wave kernel lives on 256 registers and spills; with the prologue's code in it
   //  the pendulum solve loses 0.11 ms, the bicycle's MPC step gains 0.03 ms)
   const bool fused_prologue = fused && h->n > 2;
+  // Plan MFMA16: phi(0) and the line search's first step from one pass over the records (wave_merit2_kernel), the
+  // candidate's stationarity / feasibility from that same pass, and -- without constraint blocks -- the head of Solve as
+  // one pass too (ROLLOUT_INIT).  ALTRO_HIP_MERIT2=0 keeps the one-evaluation-per-launch sequence (the comparison the
+  // tests hold this one against).
+  bool dual = !lane_plan;
+  if (const char* e = std::getenv("ALTRO_HIP_MERIT2")) dual = dual && std::atoi(e) != 0;
   if (!fused_prologue) {
     if (ilqr_launch_loop(h->stream, ILK_LOOP_INIT, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
-    rc = ilqr_run(h, IK_ROLLOUT, false, false, 0, 0.0);
-    if (!rc) rc = ilqr_run(h, IK_ACCEPT, false, false, 0, 0.0);
-    // without constraints the cost Hessian is constant and is written once, here; with them the gradient is
-    // formed with the penalty the constraints carry so far and SetPenalty comes after it (solver.cpp:424-430)
-    if (!rc) rc = ilqr_run(h, IK_EXPAND, false, false, 0, 0.0, al ? EXPAND_GRADIENT : (EXPAND_GRADIENT | EXPAND_HESSIAN));
+    if (dual && !al) {
+      rc = ilqr_run(h, IK_ROLLOUT, false, false, 0, 0.0, ROLLOUT_INIT);
+    } else {
+      rc = ilqr_run(h, IK_ROLLOUT, false, false, 0, 0.0);
+      if (!rc) rc = ilqr_run(h, IK_ACCEPT, false, false, 0, 0.0);
+      // without constraints the cost Hessian is constant and is written once, here; with them the gradient is
+      // formed with the penalty the constraints carry so far and SetPenalty comes after it (solver.cpp:424-430)
+      if (!rc) rc = ilqr_run(h, IK_EXPAND, false, false, 0, 0.0, al ? EXPAND_GRADIENT : (EXPAND_GRADIENT | EXPAND_HESSIAN));
+    }
     if (rc) return rc;
     if (al && ilqr_launch_loop(h->stream, ILK_SET_PENALTY, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
   } else if ((rc = al_upload(h))) {   // (what ilqr_run does before any launch)
@@ -655,7 +666,7 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
     altro_hip_batch* h;
     int* active0;
     ~MaskGuard() {   // whatever path leaves the solve: no speculation state, mask or swapped pointer survives it
-      h->bwd_active = nullptr; h->bwd_reg = nullptr;
+      h->bwd_active = nullptr; h->bwd_reg = nullptr; h->stat_skip = nullptr;
       h->spec_trials = 1; h->spec_pre = 0;
       h->i_active = active0;
     }
@@ -740,22 +751,37 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
     // chip idle, the first step the search will ask for (alpha0 = 1, known in advance) rides in the same launch as
     // phi(0) -- phi, phi' and the trajectory go to spare row / buffer 0 -- and ILK_LS_BEGIN consumes it at once.
     bool refreshed = false;
-    bool pre = spec_all_on && !h->spec_no_memory && (int64_t)spec_units(running) * 2 <= spec_capacity;
+    bool stat_needed = true;
+    bool pre = !dual && spec_all_on && !h->spec_no_memory && (int64_t)spec_units(running) * 2 <= spec_capacity;
     if (pre && !h->i_cand_spec && dmalloc(h, &h->i_cand_spec, spare_bytes)) {
       (void)hipGetLastError();    // an optimisation only: carry on one step per launch
       h->spec_no_memory = true;
       pre = false;
     }
     h->spec_trials = pre ? 2 : 1; h->spec_pre = pre ? 1 : 0;
-    rc = ilqr_run(h, IK_MERIT, true, true, 1, 0.0);
+    rc = ilqr_run(h, dual ? IK_MERIT2 : IK_MERIT, true, true, 1, 0.0);
     h->spec_trials = 1; h->spec_pre = 0;
     if (rc) return rc;
     ++total_merit_launches;
     if ((rc = zero_counter(0))) return rc;
-    la.spec_pre = pre ? 1 : 0;
+    if (dual) HIP_TRY(hipMemsetAsync(h->i_counters + 3, 0, 2 * sizeof(int), h->stream));
+    la.spec_pre = (pre || dual) ? 1 : 0;
+    la.spec_flip = dual ? 1 : 0; la.stat_done = h->i_stat_done; la.stat_inline = h->dtype == ALTRO_HIP_F64 ? 1 : 0;
     if (ilqr_launch_loop(h->stream, ILK_LS_BEGIN, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
-    la.spec_pre = 0;
-    if (pre) {
+    la.spec_pre = 0; la.spec_flip = 0;
+    if (dual) {
+      if ((rc = read_counters())) return rc;
+      if (counters[3] > 0) {   // searches that ended WITHOUT the first step (phi' too small, not a descent direction): their
+                               // candidate is the alpha = 0 evaluation's, redone by the single-step kernel for them alone
+        int* keep = h->i_active;
+        h->i_active = h->i_spec_refresh;
+        rc = ilqr_run(h, IK_MERIT, true, true, 1, 0.0);
+        h->i_active = keep;
+        if (rc) return rc;
+        ++total_merit_launches;
+      }
+      stat_needed = counters[4] > 0;
+    } else if (pre) {
       rc = ilqr_run(h, IK_SPEC_SELECT, false, false, 0, 0.0);
       if (rc) return rc;
       refreshed = true;
@@ -768,7 +794,7 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
       if ((rc = zero_counter(0))) return rc;
       if (ilqr_launch_loop(h->stream, ILK_LS_FEED, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
     }
-    if ((rc = read_counters())) return rc;
+    if (!dual && (rc = read_counters())) return rc;
     int guard = 0;
     while (counters[0] > 0 && guard++ < 64) {
       // Speculative backtracking: once the problems still searching leave most of the chip idle, one launch
@@ -809,7 +835,11 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
     }
     // convergence criteria on the accepted candidate, then make it the nominal (solver.cpp:459-469)
     if (ilqr_launch_loop(h->stream, ILK_MARK_RUNNING, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
-    rc = ilqr_run(h, IK_STATIONARITY, false, true, 0, 0.0);
+    if (stat_needed) {   // (dual: only the problems whose step was not the one wave_merit2_kernel evaluated)
+      h->stat_skip = dual ? h->i_stat_done : nullptr;
+      rc = ilqr_run(h, IK_STATIONARITY, false, true, 0, 0.0);
+      h->stat_skip = nullptr;
+    }
     if (!rc) rc = ilqr_run(h, IK_ACCEPT, false, true, 0, 0.0);
     if (rc) return rc;
     if ((rc = zero_counter(1))) return rc;

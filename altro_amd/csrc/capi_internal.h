@@ -78,6 +78,8 @@ struct altro_hip_batch {
   // speculative backtracking (altro_hip_ilqr_solve): spare candidate trajectories, allocated on first use
   void* i_cand_spec = nullptr;
   int *i_spec_sel = nullptr, *i_spec_refresh = nullptr;
+  int* i_stat_done = nullptr;     // plan MFMA16's dual merit evaluation (IlqrLoopArgs::stat_done)
+  const int* stat_skip = nullptr; // set while a solve's IK_STATIONARITY launches may skip those problems
   // MeritFunction in three launches (plan LANE, kernels/ilqr_lane.hip): per-knot-point costs of every trial and the
   // spare A | B | lx | lu block; allocated on the first merit evaluation, merit_split = 0 keeps the one-launch kernel
   void *i_merit_jk = nullptr, *i_spec_jac = nullptr;
@@ -125,6 +127,7 @@ struct altro_hip_batch {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int last_sweeps = 0, last_merit_launches = 0;
   int prof_launches[2] = {0, 0};
+  int prof_dropped[2] = {0, 0};   // mode 2: launches issued after the event ring was full (not in the averages)
   double prof_ms[2] = {0, 0};
 };
 

@@ -3,7 +3,8 @@
 // problem instances are sharded over the GPUs of a node and never talk during sweeps; the
 // only thing that crosses GPUs is what SolverImpl::Solve reports (solver.cpp:464-469, :492-509; AltroStats,
 // solver_stats.hpp:14-25), summed / maximised over the problems:
-//     ncclSum over {problems, Cholesky failures, converged, iterations, cost, delta_V0, delta_V1}   (7 doubles)
+//     ncclSum over {problems, Cholesky failures, converged, iterations, cost, delta_V0, delta_V1,
+//                   problems with a non-finite result}                                              (8 doubles)
 //     ncclMax over {stationarity, feasibility, |x_N|}                                               (3 doubles)
 // Per GPU the reduction is a deterministic two-stage kernel pair (fixed tree order: the result does not depend on
 // scheduling), so nothing but 16 doubles ever goes to the host.  RCCL is resolved with dlopen at first use -- the
@@ -12,6 +13,8 @@
 #include "capi_internal.h"
 
 #include <dlfcn.h>
+#include <mutex>
+#include <string>
 #include <rccl/rccl.h>   // types and prototypes only; every call goes through the table below
 
 using namespace altro_hip;
@@ -20,7 +23,7 @@ using namespace altro_hip::capi;
 namespace {
 
 // positions inside the reduced vector (device, kStatsStride doubles)
-enum { ST_PROBLEMS = 0, ST_CHOL, ST_CONVERGED, ST_ITERATIONS, ST_COST, ST_DV0, ST_DV1, ST_NSUM,
+enum { ST_PROBLEMS = 0, ST_CHOL, ST_CONVERGED, ST_ITERATIONS, ST_COST, ST_DV0, ST_DV1, ST_NONFINITE, ST_NSUM,
        ST_MAX0 = 8, ST_MAX_STAT = 8, ST_MAX_FEAS, ST_MAX_XN, ST_NMAX = 3 };
 
 struct StatsIn {
@@ -32,6 +35,10 @@ struct StatsIn {
   int n, batch;
   int have_bwd, have_fwd, have_solve;
 };
+
+// max that keeps a NaN (fmax drops it): a diverged problem must show in the batch's maxima, as it does in the
+// per-problem results and in sum_cost
+__device__ __forceinline__ double nanmax(double a, double b) { return (a != a || b != b) ? (a + b) : fmax(a, b); }
 
 template <typename T>
 __global__ __launch_bounds__(256) void stats_partial_kernel(StatsIn a, double* __restrict__ partial) {
@@ -49,20 +56,25 @@ __global__ __launch_bounds__(256) void stats_partial_kernel(StatsIn a, double* _
         acc[ST_DV1] += (double)((const T*)a.delta_V)[2 * (size_t)b + 1];
       }
     }
+    bool bad = false;   // any non-finite number among this problem's reported quantities
     if (a.have_solve) {
       const IlqrProb& p = a.prob[b];
       if (p.status == 0) acc[ST_CONVERGED] += 1.0;
       acc[ST_ITERATIONS] += (double)p.iterations;
-      acc[ST_COST] += p.ls_iters > 0 ? p.ls.phi : p.phi0;
-      acc[7 + 0] = fmax(acc[7 + 0], fabs(p.stationarity));
-      acc[7 + 1] = fmax(acc[7 + 1], p.feasibility);
+      const double cost = p.ls_iters > 0 ? p.ls.phi : p.phi0;
+      acc[ST_COST] += cost;
+      acc[ST_MAX_STAT] = nanmax(acc[ST_MAX_STAT], fabs(p.stationarity));
+      acc[ST_MAX_FEAS] = nanmax(acc[ST_MAX_FEAS], p.feasibility);
+      bad = !isfinite(cost) || !isfinite(p.stationarity) || !isfinite(p.feasibility);
     }
     if (a.have_fwd) {
       const T* x = (const T*)a.xN + (size_t)b * a.x_bs;
       double mx = 0.0;
-      for (int i = 0; i < a.n; ++i) mx = fmax(mx, fabs((double)x[(size_t)i * a.x_is]));
-      acc[7 + 2] = fmax(acc[7 + 2], mx);
+      for (int i = 0; i < a.n; ++i) mx = nanmax(mx, fabs((double)x[(size_t)i * a.x_is]));
+      acc[ST_MAX_XN] = nanmax(acc[ST_MAX_XN], mx);
+      bad = bad || !isfinite(mx);
     }
+    if (bad) acc[ST_NONFINITE] += 1.0;
   }
 #pragma unroll
   for (int i = 0; i < 11; ++i) sh[threadIdx.x][i] = acc[i];
@@ -70,13 +82,13 @@ __global__ __launch_bounds__(256) void stats_partial_kernel(StatsIn a, double* _
   for (int s = 128; s > 0; s >>= 1) {
     if ((int)threadIdx.x < s) {
 #pragma unroll
-      for (int i = 0; i < 7; ++i) sh[threadIdx.x][i] += sh[threadIdx.x + s][i];
+      for (int i = 0; i < ST_NSUM; ++i) sh[threadIdx.x][i] += sh[threadIdx.x + s][i];
 #pragma unroll
-      for (int i = 7; i < 10; ++i) sh[threadIdx.x][i] = fmax(sh[threadIdx.x][i], sh[threadIdx.x + s][i]);
+      for (int i = ST_MAX0; i < ST_MAX0 + ST_NMAX; ++i) sh[threadIdx.x][i] = nanmax(sh[threadIdx.x][i], sh[threadIdx.x + s][i]);
     }
     __syncthreads();
   }
-  if (threadIdx.x < 10) partial[(size_t)blockIdx.x * kStatsStride + threadIdx.x] = sh[0][threadIdx.x];
+  if (threadIdx.x < 11) partial[(size_t)blockIdx.x * kStatsStride + threadIdx.x] = sh[0][threadIdx.x];
 }
 
 __global__ __launch_bounds__(64) void stats_final_kernel(const double* __restrict__ partial, int nblk,
@@ -84,9 +96,9 @@ __global__ __launch_bounds__(64) void stats_final_kernel(const double* __restric
   const int i = threadIdx.x;
   if (i >= kStatsStride) return;
   double v = 0.0;
-  if (i < 7) for (int k = 0; k < nblk; ++k) v += partial[(size_t)k * kStatsStride + i];          // in block order
+  if (i < ST_NSUM) for (int k = 0; k < nblk; ++k) v += partial[(size_t)k * kStatsStride + i];    // in block order
   else if (i >= ST_MAX0 && i < ST_MAX0 + ST_NMAX)
-    for (int k = 0; k < nblk; ++k) v = fmax(v, partial[(size_t)k * kStatsStride + i - 1]);
+    for (int k = 0; k < nblk; ++k) v = nanmax(v, partial[(size_t)k * kStatsStride + i]);
   red[i] = v;
 }
 
@@ -129,6 +141,7 @@ int stats_read(altro_hip_batch* h, altro_hip_stats* out) {
   out->max_stationarity = v[ST_MAX_STAT];
   out->max_feasibility = v[ST_MAX_FEAS];
   out->max_abs_xN = v[ST_MAX_XN];
+  out->non_finite = (int64_t)llround(v[ST_NONFINITE]);
   return 0;
 }
 
@@ -146,10 +159,11 @@ struct Rccl {
 };
 
 int rccl(const Rccl** out) {
+  // resolved once per process, whichever host thread gets here first (one thread per GPU may call comm_create at once)
   static Rccl r;
-  static bool tried = false;
-  if (!tried) {
-    tried = true;
+  static std::string why = "symbols missing";
+  static std::once_flag once;
+  std::call_once(once, [] {
     const char* env = std::getenv("ALTRO_HIP_RCCL");
     void* lib = env ? dlopen(env, RTLD_NOW | RTLD_GLOBAL) : nullptr;
     // the copy this process already uses (a communicator must be driven by the library that made it) ...
@@ -157,20 +171,25 @@ int rccl(const Rccl** out) {
       if (!lib) lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
     // ... else the system one
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
-      if (!lib) lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-    if (lib) {
-      r.lib = lib;
-#define SYM(field, name) r.field = (decltype(r.field))dlsym(lib, name)
-      SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommInitAll, "ncclCommInitAll");
-      SYM(CommDestroy, "ncclCommDestroy"); SYM(AllReduce, "ncclAllReduce"); SYM(GroupStart, "ncclGroupStart");
-      SYM(GroupEnd, "ncclGroupEnd"); SYM(GetErrorString, "ncclGetErrorString");
+      if (!lib) {
+        lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) {
+          const char* err = dlerror();   // read ONCE: the call clears the message
+          if (err) why = err;
+        }
+      }
+    if (!lib) return;
+    const char* missing = nullptr;
+#define SYM(field, name) \
+  do { r.field = (decltype(r.field))dlsym(lib, name); if (!r.field && !missing) missing = name; } while (0)
+    SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommInitAll, "ncclCommInitAll");
+    SYM(CommDestroy, "ncclCommDestroy"); SYM(AllReduce, "ncclAllReduce"); SYM(GroupStart, "ncclGroupStart");
+    SYM(GroupEnd, "ncclGroupEnd"); SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
-      if (!r.GetUniqueId || !r.CommInitRank || !r.CommInitAll || !r.CommDestroy || !r.AllReduce || !r.GroupStart ||
-          !r.GroupEnd || !r.GetErrorString)
-        r.lib = nullptr;
-    }
-  }
-  if (!r.lib) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "RCCL (librccl.so.1) could not be loaded: %s", dlerror() ? dlerror() : "symbols missing");
+    if (missing) why = std::string("symbol ") + missing + " not found in the RCCL library that was loaded";
+    else r.lib = lib;
+  });
+  if (!r.lib) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "RCCL (librccl.so.1) could not be loaded: %s", why.c_str());
   *out = &r;
   return 0;
 }
@@ -262,6 +281,10 @@ int altro_hip_comm_create_all(altro_hip_comm** out, int ndev, const int* devices
   }
   return 0;
 }
+
+int altro_hip_comm_rank(const altro_hip_comm* c) { return c ? c->rank : ALTRO_HIP_ERR_BAD_ARGUMENT; }
+int altro_hip_comm_world(const altro_hip_comm* c) { return c ? c->world : ALTRO_HIP_ERR_BAD_ARGUMENT; }
+int altro_hip_comm_device(const altro_hip_comm* c) { return c ? c->device : ALTRO_HIP_ERR_BAD_ARGUMENT; }
 
 void altro_hip_comm_destroy(altro_hip_comm* c) {
   if (!c) return;

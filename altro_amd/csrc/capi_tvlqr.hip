@@ -93,10 +93,14 @@ struct ProfScope {   // brackets one kernel launch with hipEvents ON THE HANDLE'
   }
   ProfScope(altro_hip_batch* h_, int slot_) : h(h_), slot(slot_) {
     if (h->prof == 1) (void)hipEventRecord(h->ev0, h->stream);
-    else if (h->prof == 2 && 2 * (h->prof_n + 1) <= (int)h->prof_ev.size()) {
-      idx = h->prof_n++;
-      h->prof_slot[idx] = slot;
-      (void)hipEventRecord(h->prof_ev[2 * idx], h->stream);
+    else if (h->prof == 2) {
+      if (2 * (h->prof_n + 1) <= (int)h->prof_ev.size()) {
+        idx = h->prof_n++;
+        h->prof_slot[idx] = slot;
+        (void)hipEventRecord(h->prof_ev[2 * idx], h->stream);
+      } else {
+        h->prof_dropped[slot] += 1;   // the ring is full: say so instead of averaging over a silent prefix
+      }
     }
   }
   ~ProfScope() {

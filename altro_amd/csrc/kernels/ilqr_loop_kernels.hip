@@ -42,7 +42,12 @@ __global__ void ilqr_loop_init_kernel(IlqrLoopArgs a) {
 __global__ void ilqr_ls_begin_kernel(IlqrLoopArgs a) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= a.batch) return;
+  const bool was_running = a.prob[b].running != 0;
   if (ilqr_ls_begin_body(a, b)) atomicAdd(&a.counters[0], 1);
+  if (a.spec_flip && was_running) {
+    if (a.spec_refresh[b]) atomicAdd(&a.counters[3], 1);
+    if (!a.stat_done[b]) atomicAdd(&a.counters[4], 1);
+  }
 }
 
 // after merit(alpha[b]): advance every searching problem's state machine

@@ -118,6 +118,12 @@ __device__ __forceinline__ bool ilqr_ls_begin_body(const IlqrLoopArgs& a, int b)
       a.spec_refresh[b] = 1;
     }
   }
+  if (a.spec_flip) {   // (IlqrLoopArgs::spec_flip) the first step's pass wrote the candidate and the expansion itself
+    const bool on_first = a.spec_sel[b] == 1;
+    a.spec_sel[b] = 0;
+    a.spec_refresh[b] = (!on_first && !need) ? 1 : 0;
+    a.stat_done[b] = (on_first && a.stat_inline) ? 1 : 0;
+  }
   p.evaluating = need ? 1 : 0;
   a.active[b] = need ? 1 : 0;
   if (need) a.alpha[b] = p.ls.alpha;

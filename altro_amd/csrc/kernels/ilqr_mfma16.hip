@@ -168,16 +168,26 @@ __global__ __launch_bounds__(64) void wave_rollout_kernel(IlqrWaveArgs<S> a) {
   if (a.active && !a.active[b]) return;
   const int N = a.N;
   const int i = lane < 12 ? lane : 11;
+  // ROLLOUT_INIT (the head of Solve for an unconstrained problem, solver.cpp:420-434): the same pass also makes the
+  // trajectory the nominal one (CopyTrajectory, what wave_accept_kernel does) and forms the cost gradient lx = Qd x + q,
+  // lu = Rd u + r at it (what wave_expand_grad_kernel does) -- the values and expressions of those two kernels, from the
+  // x and u this wave already holds, instead of two more passes over the trajectory.
+  const bool init = (a.mode & ROLLOUT_INIT) != 0;
+  const int e16 = lane & 15;
   const S* __restrict__ dynb = a.dyn + (size_t)b * a.dyn_bs;
   S* __restrict__ candb = a.cand + (size_t)b * a.xuy_bs;
   double x = (double)a.x0[(size_t)b * 12 + i];
-  double zr[3], fr, ur;
+  double zr[3], fr, ur, cq = 0.0, cl = 0.0;
   auto load = [&](int k) {
     const S* z = dynb + (size_t)k * a.dyn_ks;
 #pragma unroll
     for (int c = 0; c < 3; ++c) zr[c] = (double)z[MF_OFF_Z + c * 64 + lane];
     fr = (double)z[MF_OFF_F + i];
     ur = (double)candb[(size_t)k * a.xuy_ks + 24 + (lane & 3)];
+    if (init) {
+      const S* cp = a.costp + ((size_t)k * a.batch + b) * MF_COSTP;
+      cq = (double)cp[e16]; cl = (double)cp[16 + e16];
+    }
   };
   load(0);
   for (int k = 0; k < N; ++k) {
@@ -187,8 +197,14 @@ __global__ __launch_bounds__(64) void wave_rollout_kernel(IlqrWaveArgs<S> a) {
     zimg[12 * ZLD + i] = fr;
     if (lane < 4) us[lane] = ur;
     if (lane < 12) { xs[lane] = x; candb[(size_t)k * a.xuy_ks + lane] = (S)x; }
+    const double cqk = cq, clk = cl;
     load(k + 1 < N ? k + 1 : N - 1);
     __syncthreads();
+    if (init && lane < 16) {
+      const double z = (double)(S)(lane < 12 ? x : us[lane - 12]);     // as the stored trajectory holds it
+      a.nom[((size_t)k * a.batch + b) * MF_NOM + lane] = (S)z;
+      a.cin[(size_t)b * a.cin_bs + (size_t)k * a.cin_ks + MF_OFF_QR + lane] = (S)(cqk * z + clk);
+    }
     double acc = 0.0;
 #pragma unroll
     for (int j = 0; j < 12; ++j) acc += zimg[i * ZLD + j] * xs[j];
@@ -198,6 +214,12 @@ __global__ __launch_bounds__(64) void wave_rollout_kernel(IlqrWaveArgs<S> a) {
     x = (acc + acc2) + zimg[12 * ZLD + i];
   }
   if (lane < 12) a.cand[(size_t)b * a.xuy_bs + (size_t)a.N * a.xuy_ks + lane] = (S)x;
+  if (init && lane < 16) {
+    const S* cp = a.costp + ((size_t)N * a.batch + b) * MF_COSTP;
+    const double z = (double)(S)x;
+    a.nom[((size_t)N * a.batch + b) * MF_NOM + lane] = lane < 12 ? (S)z : S(0);
+    if (lane < 12) a.term[(size_t)b * MF_TERM + 144 + lane] = (S)((double)cp[lane] * z + (double)cp[16 + lane]);
+  }
 }
 
 // nominal <- candidate (x, u)
@@ -588,12 +610,236 @@ __global__ __launch_bounds__(64) void wave_merit_kernel(IlqrWaveArgs<S> a) {
   }
 }
 
+// phi(0) AND the line search's first step alpha0 = 1 (linesearch.cpp: the search always starts there) in ONE pass over
+// the records: the two evaluations of SolverImpl::MeritFunction (solver.cpp:273-355) that every sweep makes stream the
+// same DYN / OUT / nominal / cost-parameter records, so "trial 0" (alpha = a.alpha[b], 0 in the solve loop) and "trial 1"
+// (alpha = 1) ride the same loads and the same LDS image -- each lane forms its row product against both trials' vectors
+// (interleaved in LDS: one 16-byte broadcast read per pair).  Expressions and accumulation order per trial are those of
+// wave_merit_kernel.  Outputs: phi / dphi rows 0 and 1; the candidate trajectory x_, u_, y_ and the expansion lx, lu
+// are TRIAL 1's (IlqrLoopArgs::spec_flip: the step that is nearly always accepted needs no copy and no second pass).
+// For fp64 storage the kernel also leaves trial 1's stationarity (solver.cpp:207-222, with a one-knot-point lag:
+// |lx_k + A_k^T y_{k+1} - y_k| needs the NEXT step's y, so the previous record image, gradient and y stay in LDS)
+// and feasibility (solver.cpp:224-231) in the control block -- the values wave_stationarity_kernel would compute from
+// the stored candidate, without its two further passes over DYN.
+template <typename S>
+__global__ __launch_bounds__(64) void wave_merit2_kernel(IlqrWaveArgs<S> a) {
+  constexpr int DEPTH = 2;                          // also the image ping-pong: parity of k == dd
+  constexpr bool kStat = sizeof(S) == 8;            // stored values == computed values only without a rounding store
+  __shared__ double img[2][MW_IMG + 4];
+  __shared__ __attribute__((aligned(16))) double vec2[24 * 2];   // x | dx, [entry][trial]
+  __shared__ __attribute__((aligned(16))) double das2[12 * 2];
+  __shared__ __attribute__((aligned(16))) double us2[4 * 2];
+  __shared__ __attribute__((aligned(16))) double dus2[4 * 2];
+  __shared__ double xsA[2][12], usA[2][4], jv[2][AL_MAXC * AL_MAXP];   // contiguous copies for the AL rows
+  __shared__ double crec[2][28], qrec[2][16], yN[12], lxN[12];
+  const int b = mf_problem(blockIdx.x, a.batch), lane = threadIdx.x;
+  if (b >= a.batch) return;
+  if (a.active && !a.active[b]) return;
+  const int N = a.N;
+  const double alpha0 = a.alpha ? a.alpha[b] : a.alpha_const;
+  S* __restrict__ candb = a.cand + (size_t)b * a.xuy_bs;
+  const bool al = a.al.enabled != 0;
+  const double rho = al ? a.prob[b].rho : 1.0;
+  const int grp = lane >> 4, sub = lane & 15;
+  const bool is_x = lane < 12, is_u = (grp == 1 && sub < 4), is_y = (grp == 2 && sub < 12);
+  const int i = sub < 12 ? sub : 11;
+  const int ia = sub < 4 ? sub : 3;
+  int ra[13];
+#pragma unroll
+  for (int j = 0; j < 12; ++j)
+    ra[j] = (grp == 0) ? i * MW_ZLD + j : (grp == 1) ? MW_OUT0 + ia * 13 + j : MW_OUT0 + MF_OFF_P + mf_sym(i, j);
+  ra[12] = (grp == 0) ? i * MW_ZLD + 12 : (grp == 1) ? MW_OUT0 + ia * 13 + 12 : MW_OUT0 + MF_OFF_p + i;
+  const int vbase = (grp == 0) ? 0 : 12;
+  const int l27 = lane < 28 ? lane : 27;
+  const S* __restrict__ dynb = a.dyn + (size_t)b * a.dyn_bs;
+  const S* __restrict__ outb = a.out + (size_t)b * a.out_bs;
+  const S* __restrict__ nomb = a.nom + (size_t)b * MF_NOM;
+  const S* __restrict__ cpb = a.costp + (size_t)b * MF_COSTP;
+  const size_t nom_ks = (size_t)a.batch * MF_NOM, cp_ks = (size_t)a.batch * MF_COSTP;
+  double x0 = (double)a.x0[(size_t)b * 12 + i], x1 = x0;
+  double dx0 = 0.0, dx1 = 0.0;               // dx/dalpha of the two trials
+  double J0 = 0.0, J1 = 0.0, dJ0 = 0.0, dJ1 = 0.0, viol = 0.0, viol0 = 0.0, res = 0.0;
+  MeritWaveRegs ring[DEPTH];
+#pragma unroll
+  for (int dd = 0; dd < DEPTH; ++dd) {
+    const size_t kk = dd < N ? dd : N - 1;
+    merit_wave_load<S>(ring[dd], dynb + kk * a.dyn_ks, outb + kk * a.out_ks, nomb + kk * nom_ks, cpb + kk * cp_ks, lane);
+  }
+  const int Npad = ((N + DEPTH - 1) / DEPTH) * DEPTH;
+  for (int k0 = 0; k0 < Npad; k0 += DEPTH) {
+#pragma unroll
+   for (int dd = 0; dd < DEPTH; ++dd) {
+    const int k = k0 + dd;
+    const bool live = k < N;
+    const int kc = live ? k : N - 1;
+    double* const L = img[dd];
+    // (no barrier here: the image, the candidate record and the gradient are double-buffered, and every lane has passed
+    //  the last barrier of the previous step before anything single-buffered is rewritten)
+    merit_wave_stage(ring[dd], L, lane);
+    if (is_x) {
+      const double nm = ring[dd].nm;
+      vec2[lane * 2] = x0; vec2[lane * 2 + 1] = x1;
+      vec2[(12 + lane) * 2] = x0 - nm; vec2[(12 + lane) * 2 + 1] = x1 - nm;
+      das2[lane * 2] = dx0; das2[lane * 2 + 1] = dx1;
+      crec[dd][lane] = x1;
+      if (al) { xsA[0][lane] = x0; xsA[1][lane] = x1; }
+    }
+    {
+      const size_t kn = (k + DEPTH < N) ? k + DEPTH : N - 1;
+      merit_wave_load<S>(ring[dd], dynb + kn * a.dyn_ks, outb + kn * a.out_ks, nomb + kn * nom_ks, cpb + kn * cp_ks, lane);
+    }
+    __syncthreads();
+    double acc0 = 0.0, acc1 = 0.0, acd0 = 0.0, acd1 = 0.0;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+      const double rj = L[ra[j]];
+      const double2 v = *reinterpret_cast<const double2*>(&vec2[(vbase + j) * 2]);
+      const double2 d = *reinterpret_cast<const double2*>(&das2[j * 2]);
+      acc0 += rj * v.x; acc1 += rj * v.y;
+      acd0 += rj * d.x; acd1 += rj * d.y;
+    }
+    const double aff = L[ra[12]];
+    if (is_u) {
+      const double d = -aff, un = L[MW_NOM0 + 12 + ia];
+      const double u0 = un + (-acc0 + alpha0 * d), u1 = un + (-acc1 + 1.0 * d);
+      const double du0 = -acd0 + d, du1 = -acd1 + d;
+      us2[ia * 2] = u0; us2[ia * 2 + 1] = u1; dus2[ia * 2] = du0; dus2[ia * 2 + 1] = du1;
+      crec[dd][24 + ia] = u1;
+      if (al) { usA[0][ia] = u0; usA[1][ia] = u1; }
+      const double Rd = L[MW_CP0 + 12 + ia], rr = L[MW_CP0 + 28 + ia];
+      if (live) { J0 += 0.5 * (u0 * (Rd * u0)) + rr * u0; J1 += 0.5 * (u1 * (Rd * u1)) + rr * u1; }
+    }
+    if (is_y) crec[dd][12 + i] = acc1 + aff;
+    __syncthreads();
+    double xn0 = 0.0, xn1 = 0.0, dxn0 = 0.0, dxn1 = 0.0;
+    if (is_x) {
+      double s0 = 0.0, s1 = 0.0, t0 = 0.0, t1 = 0.0;
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        const double bic = L[i * MW_ZLD + 12 + cc];
+        const double2 u = *reinterpret_cast<const double2*>(&us2[cc * 2]);
+        const double2 du = *reinterpret_cast<const double2*>(&dus2[cc * 2]);
+        s0 += bic * u.x; s1 += bic * u.y; t0 += bic * du.x; t1 += bic * du.y;
+      }
+      const double f = L[MW_F0 + i];
+      xn0 = (acc0 + s0) + f; xn1 = (acc1 + s1) + f;
+      dxn0 = acd0 + t0; dxn1 = acd1 + t1;
+      const double Qd = L[MW_CP0 + i], q = L[MW_CP0 + 16 + i];
+      if (live) {
+        J0 += 0.5 * (x0 * (Qd * x0)) + q * x0;
+        J1 += 0.5 * (x1 * (Qd * x1)) + q * x1;
+        if (lane == 0) { J0 += L[MW_CP0 + 32]; J1 += L[MW_CP0 + 32]; }
+      }
+    }
+    if (kStat && grp == 1 && live && k >= 1) {   // stationarity at knot point k - 1 now that y_k is known (trial 1)
+      const double* const Lp = img[dd ^ 1];
+      double sy = 0.0;
+#pragma unroll
+      for (int r = 0; r < 12; ++r) sy += Lp[r * MW_ZLD + sub] * crec[dd][12 + r];
+      const double g = qrec[dd ^ 1][sub] + sy;
+      res = fmax(res, fabs(sub < 12 ? g - crec[dd ^ 1][12 + sub] : g));
+    }
+    if (al) {
+      double Ja = 0.0, Jb = 0.0;
+      wave_al_rows<S>(a.al, kc, b, a.batch, xsA[0], usA[0], false, rho, lane, jv[0], nullptr, nullptr, Ja, viol0, false);
+      wave_al_rows<S>(a.al, kc, b, a.batch, xsA[1], usA[1], false, rho, lane, jv[1], nullptr, nullptr, Jb, viol, false);
+      if (live) { J0 += Ja; J1 += Jb; }
+    }
+    __syncthreads();
+    if (lane < 16) {
+      const int e = lane;
+      const double p0 = e < 12 ? x0 : us2[(e - 12) * 2], p1 = e < 12 ? x1 : us2[(e - 12) * 2 + 1];
+      double l0 = L[MW_CP0 + e] * p0 + L[MW_CP0 + 16 + e];
+      double l1 = L[MW_CP0 + e] * p1 + L[MW_CP0 + 16 + e];
+      if (al) { l0 -= wave_al_col<S>(a.al, kc, e, jv[0]); l1 -= wave_al_col<S>(a.al, kc, e, jv[1]); }
+      qrec[dd][e] = l1;
+      if (live) {
+        dJ0 += l0 * (e < 12 ? dx0 : dus2[(e - 12) * 2]);
+        dJ1 += l1 * (e < 12 ? dx1 : dus2[(e - 12) * 2 + 1]);
+      }
+    }
+    __syncthreads();
+    {
+      S* c = candb + (size_t)(live ? k : N) * a.xuy_ks;
+      c[l27] = (S)crec[dd][l27];
+      S* ci = a.cin + (size_t)b * a.cin_bs + (size_t)kc * a.cin_ks;
+      const double qv = qrec[dd][sub];
+      if (live) ci[MF_OFF_QR + sub] = (S)qv;
+    }
+    if (is_x && live) { x0 = xn0; x1 = xn1; dx0 = dxn0; dx1 = dxn1; }
+   }
+  }
+  __syncthreads();
+  {   // terminal knot point (solver.cpp:319-332), both trials
+    const S* nm = a.nom + ((size_t)N * a.batch + b) * MF_NOM;
+    const S* cp = a.costp + ((size_t)N * a.batch + b) * MF_COSTP;
+    const S* on = a.outn + (size_t)b * MF_TERM;
+    S* c = candb + (size_t)N * a.xuy_ks;
+    if (is_u) c[24 + ia] = S(0);
+    if (is_x) {
+      const double nmv = (double)nm[lane];
+      vec2[lane * 2] = x0; vec2[lane * 2 + 1] = x1;
+      vec2[(12 + lane) * 2] = x0 - nmv; vec2[(12 + lane) * 2 + 1] = x1 - nmv;
+      if (al) { xsA[0][lane] = x0; xsA[1][lane] = x1; }
+      c[lane] = (S)x1;
+      const double Qd = (double)cp[i], q = (double)cp[16 + i];
+      J0 += 0.5 * (x0 * (Qd * x0)) + q * x0;
+      J1 += 0.5 * (x1 * (Qd * x1)) + q * x1;
+      if (lane == 0) { J0 += (double)cp[32]; J1 += (double)cp[32]; }
+    }
+    __syncthreads();
+    if (al) {
+      wave_al_rows<S>(a.al, N, b, a.batch, xsA[0], usA[0], true, rho, lane, jv[0], nullptr, nullptr, J0, viol0, false);
+      wave_al_rows<S>(a.al, N, b, a.batch, xsA[1], usA[1], true, rho, lane, jv[1], nullptr, nullptr, J1, viol, false);
+    }
+    if (is_y) {
+      double sacc = 0.0;
+#pragma unroll
+      for (int j = 0; j < 12; ++j) sacc += (double)on[i * 13 + j] * vec2[(12 + j) * 2 + 1];
+      const double y = sacc + (double)on[i * 13 + 12];
+      c[12 + i] = (S)y;
+      yN[i] = y;
+    }
+    __syncthreads();
+    if (is_x) {
+      double lx0 = (double)cp[i] * x0 + (double)cp[16 + i];
+      double lx1 = (double)cp[i] * x1 + (double)cp[16 + i];
+      if (al) { lx0 -= wave_al_col<S>(a.al, N, i, jv[0]); lx1 -= wave_al_col<S>(a.al, N, i, jv[1]); }
+      a.term[(size_t)b * MF_TERM + 144 + i] = (S)lx1;
+      lxN[i] = lx1;
+      dJ0 += lx0 * dx0;
+      dJ1 += lx1 * dx1;
+    }
+    if (kStat) {
+      __syncthreads();
+      const int pl = (N - 1) & 1;      // the last LIVE step's buffers (a padding step writes the other parity)
+      if (grp == 1) {
+        double sy = 0.0;
+#pragma unroll
+        for (int r = 0; r < 12; ++r) sy += img[pl][r * MW_ZLD + sub] * yN[r];
+        const double g = qrec[pl][sub] + sy;
+        res = fmax(res, fabs(sub < 12 ? g - crec[pl][12 + sub] : g));
+      }
+      if (lane < 12) res = fmax(res, fabs(lxN[lane] - yN[lane]));
+    }
+  }
+  const double phi0 = wave_sum(J0), dphi0 = wave_sum(dJ0), phi1 = wave_sum(J1), dphi1 = wave_sum(dJ1);
+  if (kStat) { res = wave_max(res); if (al) viol = wave_max(viol); }
+  if (lane == 0) {
+    a.phi[b] = phi0; a.dphi[b] = dphi0;
+    a.phi[(size_t)a.batch + b] = phi1; a.dphi[(size_t)a.batch + b] = dphi1;
+    if (al) a.prob[b].rho_est = rho;
+    if (kStat) { a.prob[b].stationarity = res; a.prob[b].feasibility = viol; }
+  }
+}
+
 // Stationarity (solver.cpp:207-222): max_k |lx + A^T y+ - y|, max_k |lu + B^T y+|
 template <typename S>
 __global__ __launch_bounds__(64) void wave_stationarity_kernel(IlqrWaveArgs<S> a) {
   const int b = mf_problem(blockIdx.x, a.batch), lane = threadIdx.x;
   if (b >= a.batch) return;
   if (a.active && !a.active[b]) return;
+  if (a.skip && a.skip[b]) return;   // wave_merit2_kernel left this candidate's values in the control block already
   const int N = a.N;
   const int j = lane & 15;
   double res = 0.0;

@@ -75,11 +75,23 @@ struct IlqrLoopArgs {
   int* active;        // [batch] 1 = problem takes part in the next merit evaluation
   const double* phi;
   const double* dphi;
-  int* counters;      // [0] = problems that still need a merit evaluation, [1] = problems still running
+  int* counters;      // [0] = problems that still need a merit evaluation, [1] = problems still running; [3], [4]: spec_flip
   int spec_trials;    // trials evaluated by the last merit launch (phi holds spec_trials x batch values)
   int spec_pre;       // ILK_LS_BEGIN: row 1 of phi / dphi holds the first trial step (see IlqrArgs::spec_pre)
   int* spec_sel;      // [batch] 1 + the spare candidate trajectory a problem that JUST finished its search took (0: none)
   int* spec_refresh;  // [batch] 1: the accepted step came from a speculative trial (no phi' pass): expansion to be redone
+  // Plan MFMA16's dual evaluation (wave_merit2_kernel: phi(0) and the step alpha0 = 1 from ONE stream of the records, the
+  // alpha0 = 1 pass being the one that writes the candidate trajectory and the expansion).  ILK_LS_BEGIN then consumes
+  // row 1 like spec_pre and sorts the running problems three ways:
+  //   ended ON the first step   -> nothing to copy or redo; stat_done[b] = stat_inline (the kernel already left the
+  //                                candidate's stationarity / feasibility in the control block)
+  //   ended WITHOUT it          -> spec_refresh[b] = 1, counters[3]++: the alpha = 0 evaluation is repeated by the
+  //                                single-step kernel for these (phi' too small, not a descent direction: rare)
+  //   still searching           -> the ordinary rounds follow
+  // counters[4] counts the running problems whose stationarity still has to be computed by IK_STATIONARITY.
+  int spec_flip = 0;
+  int stat_inline = 0;
+  int* stat_done = nullptr;   // [batch]
   int batch;
   int iter;
   int iterations_max;
@@ -118,15 +130,19 @@ struct IlqrWaveArgs {
   int N, batch, want_derivative;
   double alpha_const;
   AlTable<S> al;
-  int mode;                                  // expand kernel: EXPAND_GRADIENT | EXPAND_HESSIAN
+  int mode;                                  // expand kernel: EXPAND_GRADIENT | EXPAND_HESSIAN; rollout kernel: ROLLOUT_INIT
+  const int* skip = nullptr;                 // stationarity kernel: problems whose value wave_merit2_kernel already left
 };
+constexpr int ROLLOUT_INIT = 4;   // wave_rollout_kernel also writes the nominal record and the cost gradient (the head of
+                                  // Solve for an unconstrained problem: rollout + CopyTrajectory + expansion in one pass)
 
 template <typename S>
 int ilqr_wave_launch_kernel(hipStream_t stream, int which, const IlqrWaveArgs<S>& a);   // ilqr_launch_mfma16.hip
 
 // Speculative backtracking: most trials one merit launch evaluates (the host picks 1, 2, 4 or 8 by how idle the chip is)
 constexpr int ILQR_SPEC_TRIALS = 8;
-enum IlqrKernel { IK_ROLLOUT, IK_ACCEPT, IK_EXPAND, IK_MERIT, IK_STATIONARITY, IK_DUAL, IK_SHIFT, IK_SPEC_SELECT };
+enum IlqrKernel { IK_ROLLOUT, IK_ACCEPT, IK_EXPAND, IK_MERIT, IK_STATIONARITY, IK_DUAL, IK_SHIFT, IK_SPEC_SELECT,
+                  IK_MERIT2 /* plan MFMA16: phi(0) and the first step in one pass */ };
 enum IlqrLoopKernel { ILK_LOOP_INIT, ILK_LS_BEGIN, ILK_LS_FEED, ILK_FINISH_ITER, ILK_MARK_RUNNING, ILK_SET_PENALTY,
                       ILK_PENALTY_UPDATE, ILK_REG_RETRY };
 

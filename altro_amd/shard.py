@@ -28,7 +28,7 @@ def reduce_stats(stats, device=None, group=None):
         dist.all_reduce(smax, op=dist.ReduceOp.MAX, group=group)
     out = {}
     for k, v in zip(Stats.SUM_FIELDS, ssum.tolist()):
-        out[k] = int(round(v)) if k in ("problems", "cholesky_failures", "converged", "iterations") else v
+        out[k] = int(round(v)) if k in ("problems", "cholesky_failures", "converged", "iterations", "non_finite") else v
     out.update(zip(Stats.MAX_FIELDS, smax.tolist()))
     return out
 

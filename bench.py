@@ -4,6 +4,11 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Both forms run N ranks, one per GPU: started plainly with --gpus N > 1 (no WORLD_SIZE in the environment) this script
+becomes the launcher and re-executes itself under torch.distributed.run; it refuses to start when fewer than N HIP
+devices are visible, and when the launcher's WORLD_SIZE disagrees with --gpus.  `n_gpus` in the line is the number of
+ranks of the RCCL communicator the statistics were reduced over, not an argument or an environment variable.
+
 Workload (BASELINE.json configs[1], SURVEY.md section 8d "C1"): double integrator, horizon N=256,
 n=12, m=4, batch=4096 problems PER GPU (weak scaling: independent problem instances are sharded
 over ranks with no data-path collective), fp64, time-varying storage (every knot point of every
@@ -38,11 +43,16 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=4096, help="problems per GPU")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="problems PER GPU (weak scaling).  Default: c1 4096, c2 8192, c4 16384 per GPU (weak); c3 has a "
+                         "GLOBAL default instead, see --global-batch")
+    ap.add_argument("--global-batch", type=int, default=None,
+                    help="problems over ALL GPUs, sharded contiguously over the ranks (strong scaling).  Default for c3: "
+                         "65536 (BASELINE.json configs[3]: 65536 initial states sharded across the GPUs of a node)")
     ap.add_argument("--horizon", type=int, default=256)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--repeat-seconds", type=float, default=2.0,
+    ap.add_argument("--repeat-seconds", type=float, default=6.5,
                     help="after the K timed steps: this many seconds of back-to-back sweeps, min / median / max per step")
     ap.add_argument("--config", default="c1", choices=["c1", "c2", "c3", "c4"],
                     help="c1 = BASELINE.json configs[1] (the metric's config, default); extra lines: c2 = configs[2] "
@@ -56,6 +66,47 @@ def parse():
                     help="config c4: fp32 storage with fp64 tile arithmetic (the ALTRO_HIP_F32 default of the C ABI) instead of "
                          "the pure-fp32 backward sweep (ALTRO_HIP_F32_PURE: v_mfma_f32_16x16x4_f32, four problems per wave)")
     return ap.parse_args()
+
+
+def relaunch_if_needed(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: become the launcher (one process per GPU, the
+    contract's form).  Fails loudly rather than running fewer ranks than asked for."""
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is not None:
+        if int(env_world) != args.gpus:
+            raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks; refusing to report a "
+                             "line for a different number of GPUs than asked for" % (args.gpus, env_world))
+        return
+    if args.gpus <= 1:
+        return
+    import socket
+    import altro_amd
+    have = altro_amd.lib().altro_hip_device_count()
+    test_hook = os.environ.get("ALTRO_BENCH_BACKEND", "nccl") != "nccl"
+    if have < args.gpus and not test_hook:
+        raise SystemExit("bench.py: --gpus %d but only %d HIP device(s) are visible" % (args.gpus, have))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] --gpus %d: re-executing as %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    os.execv(sys.executable, cmd)
+
+
+def resolve_batch(args, default_per_gpu, rank, world, default_global=None):
+    """-> (problems of this rank, index of its first problem in the global batch, global batch, "weak" | "strong").
+    --batch B: B problems per GPU (weak).  --global-batch G, or a config whose BASELINE entry names a node-wide batch
+    (c3): the contiguous shard [lo, hi) of G (strong; ragged when world does not divide G)."""
+    from altro_amd import shard
+    glob = args.global_batch if args.global_batch is not None else (default_global if args.batch is None else None)
+    if glob is not None:
+        if glob < world:
+            raise SystemExit("bench.py: global batch %d < %d ranks" % (glob, world))
+        lo, hi = shard.shard_range(glob, rank, world)
+        return hi - lo, lo, glob, "strong"
+    per = args.batch if args.batch is not None else default_per_gpu
+    return per, rank * per, per * world, "weak"
 
 
 def _cpu_worker(args):
@@ -158,7 +209,8 @@ def timed_region(bt, args, world, dist, torch, shard):
     for slot in (0, 1):
         nl, ms, name = bt.profile_get(slot)
         lo, hi = bt.profile_range(slot)
-        kern[slot] = {"name": name, "launches": nl, "avg_ms": ms / max(nl, 1), "min_ms": lo, "max_ms": hi}
+        kern[slot] = {"name": name, "launches": nl, "launches_not_recorded": bt.profile_dropped(slot),
+                      "avg_ms": ms / max(nl, 1), "min_ms": lo, "max_ms": hi}
     bt.profile(0)
     return elapsed, kern
 
@@ -185,60 +237,80 @@ def repeat_block(bt, torch, ms_per_step, seconds):
             "note": "host clock around blocks of back-to-back sweeps, no events, after the timed region"}
 
 
-def global_stats(bt, local_rank, rank, world, shard):
-    """the statistics reduction is the path's only collective.  Under RCCL (backend nccl) it is
-    the C ABI's own entry -- device-side reduction + two ncclAllReduce on the handle's stream; under the single-box
-    gloo test hook the same device-side reduction followed by the two torch.distributed calls."""
-    if RED_DEVICE == "cuda":
-        try:
-            comm = shard.make_comm(local_rank, rank, world)
-            st = bt.stats(comm).as_dict()
-            comm.close()
-            st["reduced_by"] = "altro_hip_stats_allreduce (device-side reduction + 2 x ncclAllReduce, RCCL, world %d)" % world
-            return st
-        except Exception as e:   # the statistics are outside the timed region: a collective that fails must not cost the line
-            print("[bench] altro_hip_stats_allreduce failed on rank %d (%s); falling back to torch.distributed" % (rank, e),
-                  file=sys.stderr)
-            if world == 1:
-                st = bt.stats().as_dict()
-                st["reduced_by"] = "altro_hip_stats_reduce (device); no collective (world 1)"
-                return st
-            st = shard.reduce_stats(bt.stats(), device="cuda:%d" % local_rank)
-            st["reduced_by"] = "altro_hip_stats_reduce (device) + torch.distributed nccl all_reduce (fallback: %s)" % e
-            return st
-    st = shard.reduce_stats(bt.stats(), device="cpu")
-    st["reduced_by"] = "altro_hip_stats_reduce (device) + torch.distributed gloo all_reduce (test hook)"
-    return st
+class StatsChannel:
+    """the statistics reduction is the path's only collective.  Under RCCL (backend nccl) it is the
+    C ABI's own entry -- device-side reduction + two ncclAllReduce on the handle's stream over a communicator the
+    library opens itself; under the single-box gloo test hook (ALTRO_BENCH_BACKEND=gloo: every rank on the box's one GPU,
+    where RCCL refuses to put two ranks on one device) the same device-side reduction followed by the same two
+    all-reduces through torch.distributed.  `world` -- the line's n_gpus -- is what the channel itself reports."""
+
+    def __init__(self, local_rank, rank, env_world, shard, dist):
+        self.shard, self.local_rank, self.rank = shard, local_rank, rank
+        self.comm, self.note = None, None
+        if RED_DEVICE == "cuda":
+            try:
+                self.comm = shard.make_comm(local_rank, rank, env_world)
+                self.world = self.comm.world           # altro_hip_comm_world: ranks of the RCCL communicator
+                self.how = "altro_hip_stats_allreduce (device-side reduction + 2 x ncclAllReduce, RCCL, world %d)" % self.world
+                return
+            except Exception as e:   # noqa: BLE001 -- statistics are outside the timed region: never cost the line
+                print("[bench] RCCL communicator failed on rank %d (%s); falling back to torch.distributed" % (rank, e),
+                      file=sys.stderr)
+                self.note = str(e)
+        self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        if RED_DEVICE == "cuda":
+            self.how = ("altro_hip_stats_reduce (device) + torch.distributed nccl all_reduce, world %d (fallback: %s)"
+                        % (self.world, self.note)) if self.world > 1 else \
+                       "altro_hip_stats_reduce (device); no collective (world 1; RCCL unavailable: %s)" % self.note
+        else:
+            self.how = "altro_hip_stats_reduce (device) + torch.distributed gloo all_reduce, world %d (test hook)" % self.world
+
+    def reduce(self, bt):
+        if self.comm is not None:
+            st = bt.stats(self.comm).as_dict()
+        elif self.world == 1:
+            st = bt.stats().as_dict()
+        else:
+            st = self.shard.reduce_stats(bt.stats(), device=("cuda:%d" % self.local_rank) if RED_DEVICE == "cuda" else "cpu")
+        st["reduced_by"] = self.how
+        return st
+
+    def close(self):
+        if self.comm is not None:
+            self.comm.close()
+            self.comm = None
 
 
-def roofline_block(cfg_key, batch, N, name_b, bytes_b, dur_b):
+def roofline_block(cfg_key, batch, N, name, alg_bytes, dur, slot=0):
     """`achieved` / `frac` follow the contract: SURVEY 8(d) ALGORITHMIC bytes per launch / measured duration / 8 TB/s.
     `traffic` is the PMC byte count of a tracked earlier rocprofv3 run of the same command (profiles/pmc_traffic.json),
-    NOT a live counter read; `frac_traffic` prices those physical bytes against the same peak."""
+    NOT a live counter read; `frac_traffic` prices those physical bytes against the same peak.  slot 0 = the backward
+    sweep (the dominant kernel: `roofline`), slot 1 = the forward sweep (`roofline_forward`)."""
     traffic, source = None, None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         tj = json.load(open(tpath)).get(cfg_key) or {}
         if tj.get("batch") == batch and tj.get("horizon") == N and tj.get("calibrated", True):
-            traffic = tj.get("backward_bytes_per_launch")
-            source = "profiles/pmc_traffic.json[%s] <- %s (tracked rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an " \
-                     "earlier run of this command; not measured in this run)" % (cfg_key, tj.get("profile"))
+            traffic = tj.get("backward_bytes_per_launch" if slot == 0 else "forward_bytes_per_launch")
+            if traffic:
+                source = "profiles/pmc_traffic.json[%s] <- %s (tracked rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an " \
+                         "earlier run of this command; not measured in this run)" % (cfg_key, tj.get("profile"))
     except (OSError, ValueError):
         pass
-    ach = bytes_b / dur_b / 1e9
-    return {"bound": "hbm", "kernel": name_b, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    ach = alg_bytes / dur / 1e9
+    return {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": ach / HBM_PEAK_GBS, "frac_algorithmic": ach / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": source,
-            "traffic_GBps": (traffic / dur_b / 1e9) if traffic else None,
-            "frac_traffic": (traffic / dur_b / 1e9 / HBM_PEAK_GBS) if traffic else None,
-            "duration_ms": dur_b * 1e3,
+            "traffic_GBps": (traffic / dur / 1e9) if traffic else None,
+            "frac_traffic": (traffic / dur / 1e9 / HBM_PEAK_GBS) if traffic else None,
+            "duration_ms": dur * 1e3,
             "duration_source": "hipEvents on the handle's stream around every launch of the timed region (no wait between launches)",
             "note": "frac = frac_algorithmic = SURVEY 8(d) bytes of the full n x n blocks / kernel time / 8 TB/s; the records "
                     "hold the symmetric Q and P blocks as triangles, so the bytes that move (traffic) are fewer and "
                     "frac_traffic is the physical HBM utilisation"}
 
 
-def lane_config(args, rank, local_rank, world, dist, torch):
+def lane_config(args, rank, local_rank, world, dist, torch, chan):
     """Extra lines for the small-state configs (plan LANE, lane-per-problem SoA): the same sweep metric on the
     expansion of a nonlinear model, plus the time of one full batched AL-iLQR solve."""
     import altro_amd
@@ -247,14 +319,15 @@ def lane_config(args, rank, local_rank, world, dist, torch):
     c3 = args.config == "c3"
     if c3:
         n, m, N = 4, 2, 50 if args.horizon == 256 else args.horizon
-        batch = 65536 // 8 if args.batch == 4096 else args.batch     # configs[3]: 65536 over an 8-GPU node
+        # configs[3]: 65536 random initial states sharded over the GPUs of the node (8192 each at 8 GPUs, all of them
+        # on the one GPU of an N=1 run); --batch B makes it B per GPU instead (the tracked profiles use 8192)
+        batch, first, global_batch, scaling = resolve_batch(args, None, rank, world, default_global=65536)
         h = np.float32(0.1)
         x_ref, u_ref = problems.bicycle_reference(N + 1)
     else:
         n, m, N = 2, 1, 100 if args.horizon == 256 else args.horizon
-        batch = 8192 if args.batch == 4096 else args.batch
+        batch, first, global_batch, scaling = resolve_batch(args, 8192, rank, world)
         h = np.float32(0.03)
-    first, _ = shard.shard_range(batch * world, rank, world)
     bt = altro_amd.Batch(N, n, m, batch, device=local_rank, flags=altro_amd.LANE_FUSED if args.lane_fused else 0)
     assert bt.plan == altro_amd.PLAN_LANE
     if c3:
@@ -294,18 +367,21 @@ def lane_config(args, rank, local_rank, world, dist, torch):
         if timed:
             t_solves.append(time.perf_counter() - t1)
     t_solve = sorted(t_solves)[1]
-    stats = global_stats(bt, local_rank, rank, world, shard)     # after the solve: the quantities Solve reports
+    stats = chan.reduce(bt)     # after the solve: the quantities Solve reports
     if rank == 0:
         bytes_b, bytes_f = bt.algorithmic_bytes(0), bt.algorithmic_bytes(1)
         dur_b = ms_b / nb * 1e-3
         emit(({
             "metric": "iLQR backward+forward sweeps/sec (N knotpoints x batch)",
-            "value": batch * world * args.steps / elapsed, "unit": "problem-sweeps/s", "n_gpus": world,
+            "value": global_batch * args.steps / elapsed, "unit": "problem-sweeps/s", "n_gpus": chan.world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": ("C3 bicycle tracking (BASELINE.json configs[3]), steering bound as an AL block"
                                     if c3 else "C2 pendulum swing-up (BASELINE.json configs[2])"),
-                       "horizon_N": N, "n": n, "m": m, "batch_per_gpu": batch, "global_batch": batch * world,
+                       "horizon_N": N, "n": n, "m": m, "batch_per_gpu": batch, "global_batch": global_batch,
+                       "sharding": ("global batch %d split into contiguous per-rank ranges (strong scaling: rank 0 holds "
+                                    "%d problems)" % (global_batch, batch)) if scaling == "strong" else
+                                   ("%d problems per GPU x %d GPU(s) (weak scaling)" % (batch, chan.world)),
                        "plan": "LANE (lane-per-problem SoA)",
                        "kernels": {name_b: dict(kern[0], GBps=bytes_b / dur_b / 1e9),
                                    name_f: dict(kern[1], GBps=bytes_f / (ms_f / nf * 1e-3) / 1e9)},
@@ -316,10 +392,32 @@ def lane_config(args, rank, local_rank, world, dist, torch):
                                       "mean_iterations": float(res["iterations"].mean()),
                                       "problems_per_s": batch / t_solve}},
             "roofline": roofline_block("c3" if c3 else "c2", batch, N, name_b, bytes_b, dur_b),
+            "roofline_forward": roofline_block("c3" if c3 else "c2", batch, N, name_f, bytes_f, ms_f / nf * 1e-3, slot=1),
         }))
     bt.close()
+    chan.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def ilqr_sweep_time(bt, torch, reps=5):
+    """one iLQR sweep = expansion + BackwardPass + one forward evaluation with derivative (alpha = 1), i.e.
+    CalcExpansions / BackwardPass / MeritFunction of solver.cpp:447-456, on the C1 batch (outside the timed region; host
+    clock around the three C-ABI calls with the stream drained, median of `reps`)."""
+    ts = {"expand": [], "backward": [], "merit": [], "total": []}
+    for _ in range(reps + 1):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter(); bt.expand(); bt.synchronize()
+        t1 = time.perf_counter(); bt.backward(); bt.synchronize()
+        t2 = time.perf_counter(); bt.merit(1.0, derivative=True)
+        t3 = time.perf_counter()
+        for k, v in (("expand", t1 - t0), ("backward", t2 - t1), ("merit", t3 - t2), ("total", t3 - t0)):
+            ts[k].append(v * 1e3)
+    med = {k: sorted(v[1:])[len(v[1:]) // 2] for k, v in ts.items()}      # the first round is untimed
+    return {"ms": med["total"], "expand_ms": med["expand"], "backward_ms": med["backward"],
+            "merit_with_derivative_ms": med["merit"],
+            "what": "altro_hip_expand + altro_hip_backward + altro_hip_merit(alpha = 1, phi and dphi): SURVEY 8(d)'s sweep "
+                    "(expansion + BackwardPass + one forward evaluation with derivative), host clock, median of %d" % reps}
 
 
 _JSON_OUT = None
@@ -342,6 +440,7 @@ def emit(obj):
 
 def main():
     args = parse()
+    relaunch_if_needed(args)
     _claim_stdout()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -369,18 +468,22 @@ def main():
         dist.init_process_group(backend, rank=rank, world_size=world)
 
     import altro_amd
+    from altro_amd import shard
     from tests import problems
-    N, n, m, batch = args.horizon, 12, 4, args.batch
+    if backend == "nccl" and torch.cuda.device_count() < world:
+        raise SystemExit("bench.py: %d ranks but only %d HIP device(s) are visible" % (world, torch.cuda.device_count()))
+    chan = StatsChannel(local_rank, rank, world, shard, dist)      # the RCCL communicator, opened before anything is timed
+    if chan.world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the communicator has %d rank(s)" % (args.gpus, chan.world))
+    N, n, m = args.horizon, 12, 4
     c4 = args.config == "c4"
     args.c4_pure = c4 and not args.c4_mixed
     if c4:
         N = 512 if args.horizon == 256 else args.horizon
-        batch = 16384 if args.batch == 4096 else args.batch
     if args.config in ("c2", "c3"):
-        return lane_config(args, rank, local_rank, world, dist, torch)
-    from altro_amd import shard as _shard
-    first, _ = _shard.shard_range(batch * world, rank, world)   # this rank's slice of the global batch
-    x0 = 2.0 * problems.uniform01((batch, n), 21, first * n) - 1.0
+        return lane_config(args, rank, local_rank, world, dist, torch, chan)
+    batch, first, global_batch, scaling = resolve_batch(args, 16384 if c4 else 4096, rank, world)
+    x0 = 2.0 * problems.uniform01((batch, n), 21, first * n) - 1.0   # this rank's slice of the global batch
 
     bt = altro_amd.Batch(N, n, m, batch, dtype=altro_amd.F32 if c4 else altro_amd.F64, device=local_rank,
                          flags=altro_amd.F32_PURE if (c4 and args.c4_pure) else 0)
@@ -402,7 +505,6 @@ def main():
                     k_stride_zero=True, batch_stride_zero=True)
     bt.set_initial_state(x0)
 
-    from altro_amd import shard
     elapsed, kern = timed_region(bt, args, world, dist, torch, shard)
     rep = repeat_block(bt, torch, elapsed / args.steps * 1e3, args.repeat_seconds)
     ms_b, nb, name_b = kern[0]["avg_ms"], 1, kern[0]["name"]
@@ -410,7 +512,7 @@ def main():
 
     # the same batch as a full iLQR solve (rollout, expansion, backward sweep, merit-function line search,
     # convergence test; an LQ problem, so <= 3 sweeps), outside the timed region
-    full_solve = None
+    full_solve, ilqr_sweep = None, None
     if not c4:
         Qd2 = np.stack([np.ones(n), 100.0 * np.ones(n)])
         bt.set_tracking_cost(Qd2, np.full((1, m), 1e-2), np.zeros((2, n)), np.zeros((1, m)), k_stride_zero=True,
@@ -424,13 +526,14 @@ def main():
             t_solve = time.perf_counter() - t1
         full_solve = {"seconds": t_solve, "sweeps": int(res["sweeps"]), "merit_launches": int(res["merit_launches"]),
                       "converged": int((res["status"] == 0).sum()), "problems_per_s": batch / t_solve}
+        ilqr_sweep = ilqr_sweep_time(bt, torch)
 
     # solver statistics -- the only thing that ever crosses GPUs (RCCL over xGMI, latency-bound) -- after the solve,
     # so that the quantities SolverImpl::Solve reports are all populated (for c4: the sweep's quantities only)
-    stats = global_stats(bt, local_rank, rank, world, shard)
+    stats = chan.reduce(bt)
 
     if rank == 0:
-        total_problems = batch * world
+        total_problems = global_batch
         sweeps_per_s = total_problems * args.steps / elapsed
         bytes_b = bt.algorithmic_bytes(0)
         bytes_f = bt.algorithmic_bytes(1)
@@ -440,12 +543,12 @@ def main():
             "metric": "iLQR backward+forward sweeps/sec (N knotpoints x batch)",
             "value": sweeps_per_s,
             "unit": "problem-sweeps/s",
-            "n_gpus": world,
+            "n_gpus": chan.world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": ("f32" if args.c4_pure else "f32 storage, f64 tile arithmetic") if c4 else "f64",
             "data": "synthetic",
@@ -454,7 +557,9 @@ def main():
                              "C1 double integrator TVLQR sweep (BASELINE.json configs[1])"),
                 "horizon_N": N, "n": n, "m": m, "batch_per_gpu": batch, "global_batch": total_problems,
                 "parallelism": "problem instances sharded over %d GPU(s), no data-path collective; "
-                               "RCCL all-reduce of solver stats only" % world,
+                               "RCCL all-reduce of solver stats only" % chan.world,
+                "sharding": ("global batch %d split into contiguous per-rank ranges (strong scaling)" % global_batch)
+                            if scaling == "strong" else "%d problems per GPU x %d GPU(s) (weak scaling)" % (batch, chan.world),
                 "plan": ("MFMA16, pure fp32: four problems per wave, v_mfma_f32_16x16x4 + v_mfma_f32_16x16x1_4b" if args.c4_pure else
                          "MFMA16 (wave-per-problem, v_mfma_f64_16x16x4)"),
                 "knotpoint_steps_per_s": sweeps_per_s * N,
@@ -463,13 +568,25 @@ def main():
                 "repeat": rep,
                 "stats": stats,
                 "ilqr_full_solve": full_solve,
+                "ilqr_sweep": ilqr_sweep,
             },
             "roofline": roofline_block(("c4pure" if args.c4_pure else "c4mixed") if c4 else "c1", batch, N, name_b, bytes_b, dur_b),
+            "roofline_forward": roofline_block(("c4pure" if args.c4_pure else "c4mixed") if c4 else "c1", batch, N, name_f,
+                                               bytes_f, dur_f, slot=1),
         }
+        if c4:
+            out["config"]["c4_numerics"] = {
+                "default": "pure fp32 (ALTRO_HIP_F32_PURE): fp32 records, fp32 MFMA arithmetic -- configs[4] says fp32" if args.c4_pure
+                           else "fp32 records, fp64 tile arithmetic (the C ABI's ALTRO_HIP_F32 default)",
+                "accuracy_vs_fp64_oracle": "K, d, P, p relative to the fp64 oracle on the same fp32-rounded inputs through all "
+                                           "512 knot points: 2e-5 pure fp32, 5e-7 fp64 tile arithmetic "
+                                           "(tests/test_gpu_parity.py::test_c4_full_horizon_sample_vs_oracle holds both)",
+                "other_variant": "--c4-mixed" if args.c4_pure else "(default) pure fp32"}
         if cpu_leg is not None:
             out["cpu_baseline"] = cpu_leg
         emit(out)
     bt.close()
+    chan.close()
     if world > 1:
         dist.destroy_process_group()
 

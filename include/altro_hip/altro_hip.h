@@ -296,7 +296,11 @@ typedef struct altro_hip_stats {
   double max_stationarity;   /* max over problems (solver.cpp:207-222)                                       */
   double max_feasibility;    /* max over problems (solver.cpp:224-231)                                       */
   double max_abs_xN;         /* max |x_N| over problems (after a forward pass / solve)                       */
+  int64_t non_finite;        /* problems whose cost, stationarity, feasibility or x_N is NaN / Inf (summed over
+                                GPUs like the other counts: ncclMax need not carry a NaN, this count does)       */
 } altro_hip_stats;
+/* Within a batch a NaN in any problem's stationarity / feasibility / x_N makes the corresponding maximum NaN (it is
+ * not dropped, matching the per-problem results); across GPUs rely on non_finite.                                  */
 /* this handle's problems only */
 int altro_hip_stats_reduce(altro_hip_batch* h, altro_hip_stats* out);
 
@@ -313,6 +317,10 @@ int altro_hip_comm_unique_id(void* id /* [ALTRO_HIP_COMM_ID_BYTES] out */);
 int altro_hip_comm_create(altro_hip_comm** out, int device, int rank, int world, const void* id);
 int altro_hip_comm_create_all(altro_hip_comm** out /* [ndev] */, int ndev, const int* devices);
 void altro_hip_comm_destroy(altro_hip_comm* c);
+/* what the communicator itself was built with: rank, number of ranks (= GPUs taking part), HIP device */
+int altro_hip_comm_rank(const altro_hip_comm* c);
+int altro_hip_comm_world(const altro_hip_comm* c);
+int altro_hip_comm_device(const altro_hip_comm* c);
 /* local device-side reduction, then the two all-reduces on h's stream; `out` holds the global statistics on every rank */
 int altro_hip_stats_allreduce(altro_hip_batch* h, altro_hip_comm* comm, altro_hip_stats* out);
 int altro_hip_stats_allreduce_multi(altro_hip_batch* const* handles, altro_hip_comm* const* comms, int n,
@@ -329,6 +337,9 @@ int altro_hip_profile_reset(altro_hip_batch* h);
 int altro_hip_profile_get(altro_hip_batch* h, int slot, int* launches, double* total_ms,
                           const char** kernel_name);
 int altro_hip_profile_get_range(altro_hip_batch* h, int slot, double* min_ms, double* max_ms);
+/* enable = 2: launches of the slot's kernel issued after the 4096-launch event window was full since the last reset
+ * (they ran, but are not part of the totals above); 0 means the averages cover every launch.                        */
+int altro_hip_profile_dropped(altro_hip_batch* h, int slot);
 /* Algorithmic bytes one launch of the slot's kernel must move.             */
 double altro_hip_algorithmic_bytes(const altro_hip_batch* h, int slot);
 

@@ -58,3 +58,21 @@ def test_cpp_programs_compile_and_link():
     syms = subprocess.run(["nm", "-D", "--defined-only", altro_amd.LIB_PATH], capture_output=True, text=True).stdout
     for mangled in ("_Z18tvlqr_BackwardPass", "_Z17tvlqr_ForwardPass", "_Z18tvlqr_TotalMemSize"):
         assert mangled in syms, mangled
+
+
+def test_bench_refuses_to_run_fewer_gpus_than_asked_for():
+    """bench.py --gpus N must not quietly report one GPU: without N visible devices (none in this container) or with a
+    launcher that started a different number of ranks it stops with a message."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "ALTRO_BENCH_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8"], env=env, capture_output=True,
+                       text=True, timeout=120)
+    if r.returncode == 0 or "HIP device(s) are visible" not in r.stderr:
+        # a box that really has 8 GPUs would run; anything else must have refused
+        import altro_amd
+        assert altro_amd.lib().altro_hip_device_count() >= 8, r.stderr[-2000:]
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8"], env=dict(env, WORLD_SIZE="1", RANK="0"),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and "--gpus 8" in r.stderr

@@ -1,0 +1,120 @@
+"""Plan MFMA16: phi(0) and the line search's first step from ONE pass over the records (wave_merit2_kernel), the
+candidate's stationarity / feasibility from that same pass, the head of Solve as one pass (ROLLOUT_INIT) -- against the
+one-evaluation-per-launch sequence they replace (ALTRO_HIP_MERIT2=0: wave_merit_kernel twice, wave_stationarity_kernel,
+rollout + accept + expand), which tests/test_gpu_ilqr_mfma16.py pins to the oracle.  Same expressions in the same
+order per trial: the results are compared bit for bit; where the compiler contracts a product-sum differently in the
+two kernels a tolerance of 1e-12 relative would still hold, and the test says which it was.
+Needs an MI355X."""
+import os
+
+import numpy as np
+import pytest
+
+import altro_amd
+from tests import problems
+from tests.test_gpu_ilqr_mfma16 import _constrained_problem, make_problem
+
+pytestmark = pytest.mark.gpu
+
+n, m = 12, 4
+
+
+def _solve(p, N, blocks, dual, dtype=altro_amd.F64, **kw):
+    batch = p["x0"].shape[0]
+    bt = altro_amd.Batch(N, n, m, batch, dtype=dtype)
+    bt.set_dynamics(p["A"], p["B"], p["f"])
+    bt.set_tracking_cost(p["Qd"], p["Rd"], p["xref"], p["uref"])
+    bt.set_initial_state(p["x0"])
+    bt.set_input_guess(p["u0"])
+    for (k0, k1, cone, G, g) in blocks:
+        bt.add_linear_constraint(k0, k1, cone, G, g)
+    old = os.environ.get("ALTRO_HIP_MERIT2")
+    os.environ["ALTRO_HIP_MERIT2"] = "1" if dual else "0"
+    try:
+        res = bt.ilqr_solve(**kw)
+    finally:
+        if old is None:
+            del os.environ["ALTRO_HIP_MERIT2"]
+        else:
+            os.environ["ALTRO_HIP_MERIT2"] = old
+    out = dict(res)
+    out["x"], out["u"] = bt.get_nominal()
+    out["xc"], out["uc"], out["yc"] = bt.get("x"), bt.get("u"), bt.get("y")
+    out["K"], out["d"] = bt.get("K"), bt.get("d")
+    bt.close()
+    return out
+
+
+def _same(a, b, what):
+    exact = True
+    for k in ("status", "iterations", "dual_updates", "reg_retries"):
+        assert np.array_equal(a[k], b[k]), (what, k)
+    for k in ("phi", "stationarity", "feasibility", "alpha", "penalty", "x", "u", "xc", "uc", "yc", "K", "d"):
+        if not np.array_equal(a[k], b[k]):
+            exact = False
+            scale = max(1.0, float(np.abs(b[k]).max()))
+            assert np.abs(a[k] - b[k]).max() <= 1e-12 * scale, (what, k, float(np.abs(a[k] - b[k]).max()), scale)
+    return exact
+
+
+def _problem(batch, N, with_f):
+    import tests.test_gpu_ilqr_mfma16 as t
+    keep = t.N
+    t.N = N
+    try:
+        return make_problem(batch, with_f)
+    finally:
+        t.N = keep
+
+
+@pytest.mark.parametrize("N,with_f", [(24, True), (25, False), (1, True), (2, True), (3, False)])
+def test_dual_evaluation_matches_the_sequence_lq(N, with_f):
+    """Unconstrained LQ solves, even and odd horizons (the two-deep record ring has a padding step when N is odd;
+    the stationarity lag ends on the last LIVE step's buffers)."""
+    p = _problem(67, N, with_f)
+    a = _solve(p, N, [], True, iterations_max=6)
+    b = _solve(p, N, [], False, iterations_max=6)
+    assert (a["status"] == 0).all() and a["sweeps"] == b["sweeps"]
+    assert a["merit_launches"] < b["merit_launches"]           # one pass where the sequence takes two
+    exact = _same(a, b, "lq N=%d" % N)
+    print("dual vs sequence, N = %d: %s" % (N, "bit-identical" if exact else "within 1e-12"))
+
+
+def test_dual_evaluation_matches_the_sequence_constrained():
+    """Input bounds + state half-spaces + an equality block (the AL rows ride both trials), many sweeps, dual updates,
+    line searches that go past the first step (those problems fall back to the single-step kernel and to
+    wave_stationarity_kernel): same decisions, same numbers."""
+    p, blocks = _constrained_problem(40)
+    kw = dict(iterations_max=60, penalty_initial=1.0, penalty_scaling=10.0)
+    a = _solve(p, 24, blocks, True, **kw)
+    b = _solve(p, 24, blocks, False, **kw)
+    assert (a["dual_updates"] > 0).all() and (a["iterations"] > 3).any()
+    exact = _same(a, b, "constrained")
+    print("dual vs sequence, constrained: %s" % ("bit-identical" if exact else "within 1e-12"))
+
+
+def test_dual_evaluation_backtracking_and_early_out():
+    """(a) a search that ends WITHOUT the first step: a problem already at its optimum has |phi'(0)| below the
+    tolerance in its second sweep ... forced here by a huge tol_meritfun_gradient so every problem takes that path in
+    its first sweep (alpha = 0, candidate = the alpha = 0 evaluation); (b) the backtracking search."""
+    p = _problem(33, 24, True)
+    a = _solve(p, 24, [], True, iterations_max=3, tol_meritfun_gradient=1e30)
+    b = _solve(p, 24, [], False, iterations_max=3, tol_meritfun_gradient=1e30)
+    assert (a["alpha"] == 0.0).all()
+    assert _same(a, b, "early-out") in (True, False)
+    a = _solve(p, 24, [], True, iterations_max=6, use_backtracking=True)
+    b = _solve(p, 24, [], False, iterations_max=6, use_backtracking=True)
+    assert (a["status"] == 0).all()
+    _same(a, b, "backtracking")
+
+
+def test_dual_evaluation_fp32_storage():
+    """fp32 records: the stationarity comes from wave_stationarity_kernel (stored values are rounded ones), the rest
+    is the dual pass."""
+    p = _problem(48, 24, True)
+    a = _solve(p, 24, [], True, dtype=altro_amd.F32, iterations_max=6)
+    b = _solve(p, 24, [], False, dtype=altro_amd.F32, iterations_max=6)
+    assert np.array_equal(a["status"], b["status"]) and np.array_equal(a["iterations"], b["iterations"])
+    for k in ("phi", "stationarity", "x", "u"):
+        scale = max(1.0, float(np.abs(b[k]).max()))
+        assert np.abs(a[k] - b[k]).max() <= 1e-12 * scale, k

@@ -108,3 +108,25 @@ def test_rccl_allreduce_entry_points_on_one_rank():
     L.altro_hip_comm_destroy(cm[0])
     comm.close()
     bt.close()
+
+
+def test_a_diverged_problem_shows_in_the_statistics():
+    """fmax drops a NaN; the reduction must not: one problem with a NaN trajectory makes max_abs_xN NaN (as the
+    per-problem results say) and is counted in non_finite -- the count is what survives an ncclMax across GPUs."""
+    batch = 700
+    pr = problems.random_ltv(batch, 12, 4, 2)
+    x0 = pr["x0"].copy()
+    x0[333, 1] = np.nan
+    bt = altro_amd.Batch(12, 4, 2, batch)
+    bt.set_dynamics(pr["A"], pr["B"], pr["f"])
+    bt.set_cost(pr["Q"], pr["R"], pr["H"], pr["q"], pr["r"])
+    bt.set_initial_state(x0)
+    bt.sweep()
+    s = bt.stats()
+    assert np.isnan(bt.get("x")[333, -1]).any()
+    assert np.isnan(s.max_abs_xN) and s.non_finite == 1 and s.problems == batch
+    bt.set_initial_state(pr["x0"])
+    bt.sweep()
+    s = bt.stats()
+    assert s.non_finite == 0 and s.max_abs_xN == np.abs(bt.get("x")[:, -1]).max()
+    bt.close()
