@@ -634,7 +634,7 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
   // candidate's stationarity / feasibility from that same pass, and -- without constraint blocks -- the head of Solve as
   // one pass too (ROLLOUT_INIT).  ALTRO_HIP_MERIT2=0 keeps the one-evaluation-per-launch sequence (the comparison the
   // tests hold this one against).
-  bool dual = !lane_plan;
+  bool dual = !lane_plan && std::getenv("ALTRO_HIP_NO_SPECULATION") == nullptr;   // (the first step rides before it is asked for)
   if (const char* e = std::getenv("ALTRO_HIP_MERIT2")) dual = dual && std::atoi(e) != 0;
   if (!fused_prologue) {
     if (ilqr_launch_loop(h->stream, ILK_LOOP_INIT, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");

@@ -24,8 +24,14 @@ static int wave_launch(hipStream_t stream, int which, const IlqrWaveArgs<S>& a) 
       }
       break;
     case IK_DUAL: hipLaunchKernelGGL(wave_dual_update_kernel<S>, dim3((unsigned)((int64_t)a.batch * (a.N + 1))), b64, 0, stream, a); break;
-    case IK_MERIT: hipLaunchKernelGGL(wave_merit_kernel<S>, dim3(waves.x, a.spec_trials > 1 ? a.spec_trials : 1), b64, 0, stream, a); break;
-    case IK_MERIT2: hipLaunchKernelGGL(wave_merit2_kernel<S>, waves, b64, 0, stream, a); break;
+    case IK_MERIT:
+      if (a.al.enabled) hipLaunchKernelGGL((wave_merit_kernel<S, true>), dim3(waves.x, a.spec_trials > 1 ? a.spec_trials : 1), b64, 0, stream, a);
+      else hipLaunchKernelGGL((wave_merit_kernel<S, false>), dim3(waves.x, a.spec_trials > 1 ? a.spec_trials : 1), b64, 0, stream, a);
+      break;
+    case IK_MERIT2:
+      if (a.al.enabled) hipLaunchKernelGGL((wave_merit2_kernel<S, true>), waves, b64, 0, stream, a);
+      else hipLaunchKernelGGL((wave_merit2_kernel<S, false>), waves, b64, 0, stream, a);
+      break;
     case IK_SPEC_SELECT: {
       const int64_t blocks = ((int64_t)a.batch * (a.N + 1) * 28 + 255) / 256;
       hipLaunchKernelGGL(wave_spec_select_kernel<S>, dim3((unsigned)(blocks < 262144 ? blocks : 262144)), b256, 0, stream, a);

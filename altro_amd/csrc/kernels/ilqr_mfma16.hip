@@ -427,7 +427,9 @@ __device__ __forceinline__ void merit_wave_stage(const MeritWaveRegs& r, double*
 // MeritFunction (solver.cpp:273-355) for linear dynamics and the diagonal tracking cost (+ AL terms).
 // Records are requested DEPTH knot points ahead (register ring, loop unrolled DEPTH times), every lane's loads and
 // stores in the loop are unconditional (replica lanes re-read / re-write the same element): see the forward sweep.
-template <typename S>
+// (AL: constraint blocks exist.  A separate instantiation, not a run-time branch: the unconstrained kernel then fits 128
+//  registers -- four waves per SIMD, C1's 4096 waves all resident -- where the common one needed 177.)
+template <typename S, bool AL>
 __global__ __launch_bounds__(64) void wave_merit_kernel(IlqrWaveArgs<S> a) {
   constexpr int DEPTH = 2;
   __shared__ double img[MW_IMG + 4];
@@ -462,7 +464,7 @@ __global__ __launch_bounds__(64) void wave_merit_kernel(IlqrWaveArgs<S> a) {
     candb = a.cand_spec + (size_t)(trial - 1) * a.spec_stride + (size_t)b * a.xuy_bs;
   }
   const bool deriv = a.want_derivative != 0 && (trial == 0 || a.spec_pre);
-  const bool al = a.al.enabled != 0;
+  constexpr bool al = AL;
   const double rho = al ? a.prob[b].rho : 1.0;   // CalcCost refreshes the projected duals with the current penalty
   const int grp = lane >> 4, sub = lane & 15;
   const bool is_x = lane < 12, is_u = (grp == 1 && sub < 4), is_y = (grp == 2 && sub < 12);
@@ -621,7 +623,7 @@ __global__ __launch_bounds__(64) void wave_merit_kernel(IlqrWaveArgs<S> a) {
 // |lx_k + A_k^T y_{k+1} - y_k| needs the NEXT step's y, so the previous record image, gradient and y stay in LDS)
 // and feasibility (solver.cpp:224-231) in the control block -- the values wave_stationarity_kernel would compute from
 // the stored candidate, without its two further passes over DYN.
-template <typename S>
+template <typename S, bool AL>
 __global__ __launch_bounds__(64) void wave_merit2_kernel(IlqrWaveArgs<S> a) {
   constexpr int DEPTH = 2;                          // also the image ping-pong: parity of k == dd
   constexpr bool kStat = sizeof(S) == 8;            // stored values == computed values only without a rounding store
@@ -638,7 +640,7 @@ __global__ __launch_bounds__(64) void wave_merit2_kernel(IlqrWaveArgs<S> a) {
   const int N = a.N;
   const double alpha0 = a.alpha ? a.alpha[b] : a.alpha_const;
   S* __restrict__ candb = a.cand + (size_t)b * a.xuy_bs;
-  const bool al = a.al.enabled != 0;
+  constexpr bool al = AL;
   const double rho = al ? a.prob[b].rho : 1.0;
   const int grp = lane >> 4, sub = lane & 15;
   const bool is_x = lane < 12, is_u = (grp == 1 && sub < 4), is_y = (grp == 2 && sub < 12);

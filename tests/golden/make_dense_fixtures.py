@@ -19,7 +19,8 @@ from oracle import oracle          # noqa: E402
 from tests import problems         # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden", "dense_fixtures.npz")
-from tests.golden_cases import P_KNOTS, SOLVES, TVLQR, checksum, solve_case, tvlqr_problem   # noqa: E402,F401
+from tests.golden_cases import (AL_KINDS, MERIT_ALPHAS, P_KNOTS, REG_CASE, SOLVES, TVLQR, al_case, checksum, load_kats,   # noqa: E402,F401
+                                lq12_case, merit_case, mpc_case, mpc_linear_costs, solve_case, tvlqr_problem)
 
 OKIND = {"double_integrator": oracle.MODEL_DI, "pendulum": oracle.MODEL_PENDULUM, "bicycle": oracle.MODEL_BICYCLE}
 
@@ -54,6 +55,150 @@ def oracle_solve(name):
     return dict(x=np.stack(xs), u=np.stack(us), iterations=np.array(its), status=np.array(sts))
 
 
+# ---- round 3: constrained solves (f2), MPC (f3), the (12, 4) iLQR loop, merit / expansion / stationarity (a5, a7-a11), reg (f4)
+def oracle_al(kind):
+    c = al_case(load_kats(), kind)
+    out = dict(x=[], u=[], status=[], iterations=[], feasibility=[])
+    for x0 in c["x0s"]:
+        s = oracle.ILQR(c["N"], c["n"], c["m"], c["h"], oracle.DYN_MODEL, oracle.MODEL_DI, model_dim=c["dim"], cost_kind=oracle.COST_DIAGONAL)
+        for k in range(c["N"] + 1):
+            s.L.oracle_ilqr_set_lqr_cost(s.h, k, np.full(c["n"], c["Q"]), np.full(c["m"], c["R"]), c["xf"].copy(), np.zeros(c["m"]))
+        s.L.oracle_ilqr_set_initial_state(s.h, np.ascontiguousarray(x0))
+        for (k0, k1, cone, G, g) in c["blocks"]:
+            for k in range(k0, k1 + 1):
+                s.add_linear_constraint(k, cone, G, g)
+        s.L.oracle_ilqr_initialize(s.h)
+        s.set_penalty(c["penalty_initial"], c["penalty_scaling"])
+        s.L.oracle_ilqr_set_options(s.h, c["itmax"], 1e-4, 1e-4, 1e-8, 0)
+        status, iters, log = s.solve()
+        out["x"].append(s.get("x")); out["u"].append(s.get("u")); out["status"].append(status); out["iterations"].append(iters)
+        out["feasibility"].append(log[iters - 1, 6] if iters > 0 else 0.0)
+    return {k: np.array(v) for k, v in out.items()}
+
+
+def oracle_mpc():
+    import ctypes as C
+    c = mpc_case()
+    N, n, m = c["N"], c["n"], c["m"]
+    mdl = oracle.make_model(oracle.MODEL_BICYCLE)
+    L = oracle.lib()
+    its, u0s, xs, sts = [], [], [], []
+    for x0 in c["x0s"]:
+        s = oracle.ILQR(N, n, m, c["h"], oracle.DYN_MODEL, oracle.MODEL_BICYCLE, cost_kind=oracle.COST_DIAGONAL)
+        for k in range(N + 1):
+            s.L.oracle_ilqr_set_lqr_cost(s.h, k, np.full(n, c["QD"]), np.full(m, c["RD"]), np.ascontiguousarray(c["x_ref"][k]),
+                                         np.ascontiguousarray(c["u_ref"][min(k, len(c["u_ref"]) - 1)]))
+        for k in range(N + 1):
+            s.add_linear_constraint(k, oracle.CONE_INEQUALITY, c["G"], c["g"])
+        s.L.oracle_ilqr_set_initial_state(s.h, np.ascontiguousarray(x0))
+        s.L.oracle_ilqr_initialize(s.h)
+        for k in range(N):
+            s.L.oracle_ilqr_set_input(s.h, k, c["u0"])
+        s.L.oracle_ilqr_set_options(s.h, 80, 1e-4, 1e-4, 1e-8, 1)
+        x = np.array(x0, dtype=float)
+        row = ([], [], [], [])
+        for it in range(c["nsim"]):
+            status, iters, _ = s.solve()
+            u = s.get("u")[0].copy()
+            xn = np.zeros(n)
+            L.oracle_discrete_dynamics(C.byref(mdl), xn, np.ascontiguousarray(x), np.ascontiguousarray(u), c["h"])
+            x = xn
+            row[0].append(iters); row[1].append(u); row[2].append(x.copy()); row[3].append(status)
+            q, cc = mpc_linear_costs(c, it + 1)
+            for k in range(N + 1):
+                s.L.oracle_ilqr_update_linear_costs(s.h, k, q[k].ctypes.data, None, float(cc[k]))
+            s.L.oracle_ilqr_set_initial_state(s.h, x)
+            s.L.oracle_ilqr_shift_trajectory(s.h)
+        its.append(row[0]); u0s.append(row[1]); xs.append(row[2]); sts.append(row[3])
+    return dict(iterations=np.array(its), u0=np.array(u0s), x_next=np.array(xs), status=np.array(sts))
+
+
+def _lq12_oracle(c, b):
+    p, N = c["p"], c["N"]
+    s = oracle.ILQR(N, 12, 4, 0.01, oracle.DYN_LINEAR, cost_kind=oracle.COST_DIAGONAL)
+    s.L.oracle_ilqr_set_linear_dynamics(s.h, np.ascontiguousarray(p["A"][b]), np.ascontiguousarray(p["B"][b]),
+                                        np.ascontiguousarray(p["f"][b]).ctypes.data)
+    for k in range(N + 1):
+        s.L.oracle_ilqr_set_lqr_cost(s.h, k, np.ascontiguousarray(p["Qd"][b, k]), np.ascontiguousarray(p["Rd"][b, min(k, N - 1)]),
+                                     np.ascontiguousarray(p["xref"][b, k]), np.ascontiguousarray(p["uref"][b, min(k, N - 1)]))
+    s.L.oracle_ilqr_set_initial_state(s.h, np.ascontiguousarray(p["x0"][b]))
+    for (k0, k1, cone, G, g) in c["blocks"]:
+        for k in range(k0, k1 + 1):
+            s.add_linear_constraint(k, cone, G, g)
+    s.L.oracle_ilqr_initialize(s.h)
+    for k in range(N):
+        s.L.oracle_ilqr_set_input(s.h, k, np.ascontiguousarray(p["u0"][b, k]))
+    return s
+
+
+def oracle_lq12(constrained):
+    c = lq12_case(constrained)
+    out = dict(x=[], u=[], status=[], iterations=[], feasibility=[])
+    for b in range(c["p"]["x0"].shape[0]):
+        s = _lq12_oracle(c, b)
+        if constrained:
+            s.set_penalty(1.0, 10.0)
+        s.L.oracle_ilqr_set_options(s.h, c["itmax"], 1e-4, 1e-4, 1e-8, 0)
+        status, iters, log = s.solve()
+        out["x"].append(s.get("x")); out["u"].append(s.get("u")); out["status"].append(status); out["iterations"].append(iters)
+        out["feasibility"].append(log[iters - 1, 6] if iters > 0 else 0.0)
+    return {k: np.array(v) for k, v in out.items()}
+
+
+def _merit_rows(make, nprob):
+    """For every problem and every alpha of MERIT_ALPHAS (problem-major): phi, phi', candidate, expansion at it, stationarity."""
+    keys = ("phi", "dphi", "x", "u", "y", "lx", "lu", "A", "B", "stationarity", "K")
+    out = {k: [] for k in keys}
+    for b in range(nprob):
+        for al in MERIT_ALPHAS:
+            s = make(b)
+            s.L.oracle_ilqr_open_loop_rollout(s.h); s.L.oracle_ilqr_copy_trajectory(s.h)
+            s.L.oracle_ilqr_calc_dynamics_expansions(s.h); s.L.oracle_ilqr_calc_cost_gradient(s.h)
+            s.L.oracle_ilqr_calc_expansions(s.h)
+            assert s.L.oracle_ilqr_backward_pass(s.h) == -1
+            out["K"].append(s.get("K"))
+            phi, dphi = s.merit(al)
+            out["phi"].append(phi); out["dphi"].append(dphi)
+            out["x"].append(s.get("x_cand")); out["u"].append(s.get("u_cand")); out["y"].append(s.get("y_cand"))
+            out["lx"].append(s.get("lx")); out["lu"].append(s.get("lu")); out["A"].append(s.get("A")); out["B"].append(s.get("B"))
+            out["stationarity"].append(s.L.oracle_ilqr_stationarity(s.h))
+    return {k: np.array(v) for k, v in out.items()}
+
+
+def oracle_merit(name):
+    if name == "lq12":
+        c = lq12_case(False)
+        return _merit_rows(lambda b: _lq12_oracle(c, b), c["p"]["x0"].shape[0])
+    c = merit_case(name)
+
+    def make(b):
+        s = oracle.ILQR(c["N"], c["n"], c["m"], c["h"], oracle.DYN_MODEL, OKIND[c["model_name"]], model_dim=c["dim"],
+                        cost_kind=oracle.COST_DIAGONAL)
+        for k in range(c["N"] + 1):
+            s.L.oracle_ilqr_set_lqr_cost(s.h, k, np.ascontiguousarray(c["Qfd"] if k == c["N"] else c["Qd"], dtype=float),
+                                         np.ascontiguousarray(c["Rd"], dtype=float), np.ascontiguousarray(c["xf"], dtype=float),
+                                         np.zeros(c["m"]))
+        s.L.oracle_ilqr_set_initial_state(s.h, np.ascontiguousarray(c["x0s"][b], dtype=float))
+        s.L.oracle_ilqr_initialize(s.h)
+        for k in range(c["N"]):
+            s.L.oracle_ilqr_set_input(s.h, k, np.ascontiguousarray(c["u0"], dtype=float))
+        return s
+    return _merit_rows(make, len(c["x0s"]))
+
+
+def oracle_reg():
+    """tvlqr_BackwardPass's reg argument (tvlqr.cpp:159-164): a positive reg on well-posed problems, and indefinite R blocks
+    that fail without it (the failing knot point is the status) and pass with it."""
+    pr = tvlqr_problem(REG_CASE["name"])
+    o = oracle.backward_batch(pr["A"], pr["B"], pr["f"], pr["Q"], pr["R"], pr["H"], pr["q"], pr["r"], reg=REG_CASE["reg"])
+    out = {"reg_" + k: o[k] for k in ("K", "d", "P", "p", "dV", "status")}
+    R = pr["R"].copy(); R[1] *= -1.0                       # problem 1: R negative definite
+    bad = oracle.backward_batch(pr["A"], pr["B"], pr["f"], pr["Q"], R, pr["H"], pr["q"], pr["r"], reg=0.0)
+    out["bad_status"] = bad["status"]
+    out["bad_K0"] = bad["K"][0]
+    return out
+
+
 def generate():
     data = {}
     for name in TVLQR:
@@ -62,6 +207,19 @@ def generate():
     for name in SOLVES:
         for k, v in oracle_solve(name).items():
             data["solve_%s_%s" % (name, k)] = v
+    for kind in AL_KINDS:
+        for k, v in oracle_al(kind).items():
+            data["al_%s_%s" % (kind, k)] = v
+    for k, v in oracle_mpc().items():
+        data["mpc_%s" % k] = v
+    for constrained in (False, True):
+        for k, v in oracle_lq12(constrained).items():
+            data["lq12_%s_%s" % ("al" if constrained else "lq", k)] = v
+    for name in ("pendulum", "bicycle", "lq12"):
+        for k, v in oracle_merit(name).items():
+            data["merit_%s_%s" % (name, k)] = v
+    for k, v in oracle_reg().items():
+        data["tvlqr_%s" % k] = v
     return data
 
 

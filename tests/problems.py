@@ -167,3 +167,24 @@ def bicycle_reference(steps, h=0.1, v=6.3):
         x = x + h * f(xm, u)
         xs.append(x.copy()); us.append(u)
     return np.array(xs), np.array(us)
+
+
+# ---- (12, 4) iLQR problems with dynamics given as data (plan MFMA16; tests/test_gpu_ilqr_mfma16.py) --------------------
+def ilqr12x4_problem(batch, N, with_f, n=12, m=4):
+    """Random LTV dynamics + a diagonal tracking cost with per-problem, per-knot-point weights and references."""
+    pr = random_ltv(batch, N, n, m)
+    return dict(A=pr["A"], B=pr["B"], f=pr["f"] if with_f else None,
+                Qd=1.0 + uniform01((batch, N + 1, n), 71), Rd=0.1 + 0.2 * uniform01((batch, N, m), 72),
+                xref=normal((batch, N + 1, n), 73) * 0.3, uref=normal((batch, N, m), 74) * 0.1,
+                x0=normal((batch, n), 75), u0=normal((batch, N, m), 76) * 0.2)
+
+
+def ilqr12x4_constraint_blocks(N, n=12, m=4):
+    """|u| <= 0.3 at every k < N, x1 <= 1.2 and -x2 <= 1.2 at 1 <= k < N (INEQUALITY), u_0[0] == 0.05 (EQUALITY)."""
+    w = n + m
+    Gb = np.zeros((2 * m, w)); Gb[:m, n:] = np.eye(m); Gb[m:, n:] = -np.eye(m)
+    Gs = np.zeros((2, w)); Gs[0, 1] = 1.0; Gs[1, 2] = -1.0
+    Ge = np.zeros((1, w)); Ge[0, 12] = 1.0
+    return [(0, N - 1, CONE_INEQUALITY, Gb, np.full(2 * m, 0.3)),
+            (1, N - 1, CONE_INEQUALITY, Gs, np.array([1.2, 1.2])),
+            (0, 0, CONE_EQUALITY, Ge, np.array([0.05]))]

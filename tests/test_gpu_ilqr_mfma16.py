@@ -15,16 +15,7 @@ N, n, m = 24, 12, 4
 
 
 def make_problem(batch, with_f):
-    pr = problems.random_ltv(batch, N, n, m)
-    A, B = pr["A"], pr["B"]
-    f = pr["f"] if with_f else None
-    rng_q = 1.0 + problems.uniform01((batch, N + 1, n), 71)
-    rng_r = 0.1 + 0.2 * problems.uniform01((batch, N, m), 72)
-    xref = problems.normal((batch, N + 1, n), 73) * 0.3
-    uref = problems.normal((batch, N, m), 74) * 0.1
-    x0 = problems.normal((batch, n), 75)
-    u0 = problems.normal((batch, N, m), 76) * 0.2
-    return dict(A=A, B=B, f=f, Qd=rng_q, Rd=rng_r, xref=xref, uref=uref, x0=x0, u0=u0)
+    return problems.ilqr12x4_problem(batch, N, with_f)
 
 
 def make_hip(p):
@@ -154,15 +145,7 @@ def test_full_size_c1_ilqr_solve():
 
 
 def _constrained_problem(batch):
-    p = make_problem(batch, True)
-    w = n + m
-    Gb = np.zeros((2 * m, w)); Gb[:m, n:] = np.eye(m); Gb[m:, n:] = -np.eye(m)      # |u| <= 0.3 at every k < N
-    Gs = np.zeros((2, w)); Gs[0, 1] = 1.0; Gs[1, 2] = -1.0                            # x1 <= 1.2, -x2 <= 1.2 at 1 <= k < N
-    Ge = np.zeros((1, w)); Ge[0, 12] = 1.0                                            # u_0[0] == 0.05
-    blocks = [(0, N - 1, problems.CONE_INEQUALITY, Gb, np.full(2 * m, 0.3)),
-              (1, N - 1, problems.CONE_INEQUALITY, Gs, np.array([1.2, 1.2])),
-              (0, 0, problems.CONE_EQUALITY, Ge, np.array([0.05]))]
-    return p, blocks
+    return make_problem(batch, True), problems.ilqr12x4_constraint_blocks(N)
 
 
 def test_constrained_lq_solve_mfma16():
