@@ -402,6 +402,7 @@ constexpr int kStatsBlocks = 1024, kStatsStride = 16;   // capi_stats.hip: parti
 // the sweep launchers (capi_tvlqr.hip), also used by the iLQR loop
 int launch_backward(altro_hip_batch* h, double reg);
 int launch_forward(altro_hip_batch* h);
+bool mfma16_forward_is_x4(const altro_hip_batch* h);   // the forward sweep runs four problems per wave (pure fp32)
 
 }  // namespace capi
 }  // namespace altro_hip

@@ -6,6 +6,7 @@
 #include "kernels/tvlqr_mfma16.hip"
 #include "kernels/tvlqr_mfma16_f32.hip"
 #include "kernels/tvlqr_mfma16_f32x4.hip"
+#include "kernels/tvlqr_mfma16_fwd_f32x4.hip"
 
 using namespace altro_hip;
 using namespace altro_hip::capi;
@@ -200,6 +201,12 @@ int launch_backward(altro_hip_batch* h, double reg) {
   return 0;
 }
 
+// the pure-fp32 forward sweep with four problems per wave: fp32 records, fp32 arithmetic asked for, a batch of whole quads
+bool mfma16_forward_is_x4(const altro_hip_batch* h) {
+  static const bool v1 = std::getenv("ALTRO_HIP_F32_PURE_FWD_V1") != nullptr;   // A/B: the one-problem fp64-arithmetic kernel
+  return h->plan == ALTRO_HIP_PLAN_MFMA16 && h->dtype == ALTRO_HIP_F32 && (h->flags & ALTRO_HIP_F32_PURE) && h->batch % 4 == 0 && !v1;
+}
+
 int launch_forward(altro_hip_batch* h) {
   ProfScope ps(h, 1);
   if (h->plan == ALTRO_HIP_PLAN_MFMA16) {
@@ -208,7 +215,26 @@ int launch_forward(altro_hip_batch* h) {
       mfma16_launch_forward<double>(h, a);
     } else {
       auto a = mfma16_args<float>(h, 0.0);
-      mfma16_launch_forward<float>(h, a);
+      if (mfma16_forward_is_x4(h)) {   // pure fp32, four problems per wave (kernels/tvlqr_mfma16_fwd_f32x4.hip)
+        const dim3 grid(mf_grid(h->batch / 4));
+        // (ring depth, waves per SIMD): measured on C4 on two boxes (profiles/r03e_ / r03f_c4_fwd_variants.txt): (2, 2) 2.47 / 2.375 ms,
+        // (3, 2) 2.43 / 2.405, (4, 2) 2.49 / 2.39, (1, 4) 2.63 / 2.44, (2, 4) 2.61 / 2.42 (spills), the one-problem kernel
+        // 2.84 / 2.81; ALTRO_HIP_F32X4_FWD = "DW" overrides (tools/c4_fwd_ab.sh)
+        static const int variant = std::getenv("ALTRO_HIP_F32X4_FWD") ? std::atoi(std::getenv("ALTRO_HIP_F32X4_FWD")) : 22;
+        switch (variant) {
+          case 14: hipLaunchKernelGGL((mfma16_forward_f32x4_kernel<1, 4>), grid, dim3(64), 0, h->stream, a); break;
+          case 34: hipLaunchKernelGGL((mfma16_forward_f32x4_kernel<3, 4>), grid, dim3(64), 0, h->stream, a); break;
+          case 32: hipLaunchKernelGGL((mfma16_forward_f32x4_kernel<3, 2>), grid, dim3(64), 0, h->stream, a); break;
+          case 42: hipLaunchKernelGGL((mfma16_forward_f32x4_kernel<4, 2>), grid, dim3(64), 0, h->stream, a); break;
+          case 24: hipLaunchKernelGGL((mfma16_forward_f32x4_kernel<2, 4>), grid, dim3(64), 0, h->stream, a); break;
+          case 23: hipLaunchKernelGGL((mfma16_forward_f32x4_kernel<2, 3>), grid, dim3(64), 0, h->stream, a); break;
+          case 33: hipLaunchKernelGGL((mfma16_forward_f32x4_kernel<3, 3>), grid, dim3(64), 0, h->stream, a); break;
+          case 32: hipLaunchKernelGGL((mfma16_forward_f32x4_kernel<3, 2>), grid, dim3(64), 0, h->stream, a); break;
+          default: hipLaunchKernelGGL((mfma16_forward_f32x4_kernel<2, 2>), grid, dim3(64), 0, h->stream, a); break;
+        }
+      } else {
+        mfma16_launch_forward<float>(h, a);
+      }
     }
   } else if (h->plan == ALTRO_HIP_PLAN_LANE) {
     return h->dtype == ALTRO_HIP_F64 ? lane_launch<double>(h, false, 0.0) : lane_launch<float>(h, false, 0.0);
