@@ -229,7 +229,6 @@ int launch_forward(altro_hip_batch* h) {
           case 24: hipLaunchKernelGGL((mfma16_forward_f32x4_kernel<2, 4>), grid, dim3(64), 0, h->stream, a); break;
           case 23: hipLaunchKernelGGL((mfma16_forward_f32x4_kernel<2, 3>), grid, dim3(64), 0, h->stream, a); break;
           case 33: hipLaunchKernelGGL((mfma16_forward_f32x4_kernel<3, 3>), grid, dim3(64), 0, h->stream, a); break;
-          case 32: hipLaunchKernelGGL((mfma16_forward_f32x4_kernel<3, 2>), grid, dim3(64), 0, h->stream, a); break;
           default: hipLaunchKernelGGL((mfma16_forward_f32x4_kernel<2, 2>), grid, dim3(64), 0, h->stream, a); break;
         }
       } else {
