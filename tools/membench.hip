@@ -191,7 +191,54 @@ __global__ __launch_bounds__(64 * WPB) void stream_mapped(const double* __restri
   }
 }
 
-int main() {
+// P adjacent problems per wave ([k][b] slabs: their records are one contiguous run of P * RIN doubles), V doubles per lane
+// and access (8 or 16 bytes), records requested DEPTH knot points ahead, XCD-aware block -> problem mapping.  Prices the
+// "two problems per wave, two doubles per lane" form of the fp64 backward sweep before it is built.
+template <int RIN, int ROUT, int P, int V, int DEPTH>
+__global__ __launch_bounds__(64) void stream_multi(const double* __restrict__ in, double* __restrict__ out, int N, int batch) {
+  constexpr int EI = P * RIN / V, EO = P * ROUT / V;            // V-wide elements per knot point
+  constexpr int LI = (EI + 63) / 64, LO = (EO + 63) / 64;
+  typedef double vec __attribute__((ext_vector_type(V)));
+  const int lane = threadIdx.x;
+  const int nblk = batch / P, chunk = nblk / 8;
+  const int blk = (int)((blockIdx.x & 7) * chunk + (blockIdx.x >> 3));
+  const size_t b0 = (size_t)blk * P;
+  vec ring[DEPTH][LI];
+  auto load = [&](vec* r, int k) {
+    const vec* rec = (const vec*)(in + ((size_t)k * batch + b0) * RIN);
+#pragma unroll
+    for (int c = 0; c < LI; ++c) { int e = c * 64 + lane; r[c] = rec[e < EI ? e : EI - 1]; }
+  };
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) load(ring[d], N - 1 - d > 0 ? N - 1 - d : 0);
+  double acc = 0.0;
+  for (int k0 = N - 1; k0 >= 0; k0 -= DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      const int k = k0 - d;
+      if (k < 0) break;
+      double s = 0;
+#pragma unroll
+      for (int c = 0; c < LI; ++c)
+#pragma unroll
+        for (int v = 0; v < V; ++v) s += ring[d][c][v];
+      acc += s;
+      load(ring[d], k - DEPTH > 0 ? k - DEPTH : 0);
+      vec* o = (vec*)(out + ((size_t)k * batch + b0) * ROUT);
+#pragma unroll
+      for (int c = 0; c < LO; ++c) {
+        int e = c * 64 + lane;
+        vec w;
+#pragma unroll
+        for (int v = 0; v < V; ++v) w[v] = acc + c + v;
+        o[e < EO ? e : EO - 1] = w;
+      }
+    }
+  }
+}
+
+int main(int argc, char** argv) {
+  const bool only_multi = argc > 1;   // any argument: just the problems-per-wave table
   const int N = 256, batch = 4096;
   const size_t in_n = (size_t)batch * N * 428, out_n = (size_t)batch * N * 208;
   double *in, *out, *sink;
@@ -204,6 +251,26 @@ int main() {
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 10;
     printf("%-44s %8.3f ms  %8.1f GB/s\n", name, ms, bytes / ms / 1e6);
   };
+  if (only_multi) {
+    auto gen = [&](const char* name, auto launch) { timeit(name, (double)batch * N * (364 + 144) * 8, launch); };
+    printf("# backward-sweep record set (364 r + 144 w doubles per knot point and problem, 4.26 GB), [k][b] slabs, XCD-aware mapping:\n"
+           "# problems per wave x bytes per lane x prefetch depth (no arithmetic)\n");
+    for (int rep = 0; rep < 2; ++rep) {
+      gen("1 problem/wave,  8 B/lane, depth 1", [&] { stream_multi<364, 144, 1, 1, 1><<<batch, 64>>>(in, out, N, batch); });
+      gen("1 problem/wave,  8 B/lane, depth 2", [&] { stream_multi<364, 144, 1, 1, 2><<<batch, 64>>>(in, out, N, batch); });
+      gen("1 problem/wave, 16 B/lane, depth 1", [&] { stream_multi<364, 144, 1, 2, 1><<<batch, 64>>>(in, out, N, batch); });
+      gen("1 problem/wave, 16 B/lane, depth 2", [&] { stream_multi<364, 144, 1, 2, 2><<<batch, 64>>>(in, out, N, batch); });
+      gen("2 problems/wave,  8 B/lane, depth 1", [&] { stream_multi<364, 144, 2, 1, 1><<<batch / 2, 64>>>(in, out, N, batch); });
+      gen("2 problems/wave,  8 B/lane, depth 2", [&] { stream_multi<364, 144, 2, 1, 2><<<batch / 2, 64>>>(in, out, N, batch); });
+      gen("2 problems/wave, 16 B/lane, depth 1", [&] { stream_multi<364, 144, 2, 2, 1><<<batch / 2, 64>>>(in, out, N, batch); });
+      gen("2 problems/wave, 16 B/lane, depth 2", [&] { stream_multi<364, 144, 2, 2, 2><<<batch / 2, 64>>>(in, out, N, batch); });
+      gen("2 problems/wave, 16 B/lane, depth 3", [&] { stream_multi<364, 144, 2, 2, 3><<<batch / 2, 64>>>(in, out, N, batch); });
+      gen("4 problems/wave, 16 B/lane, depth 1", [&] { stream_multi<364, 144, 4, 2, 1><<<batch / 4, 64>>>(in, out, N, batch); });
+      gen("4 problems/wave, 16 B/lane, depth 2", [&] { stream_multi<364, 144, 4, 2, 2><<<batch / 4, 64>>>(in, out, N, batch); });
+      gen("today: stream_mapped 1/wave 8 B depth 1", [&] { stream_mapped<364, 144, 1, 1><<<batch, 64>>>(in, out, N, batch); });
+    }
+    return 0;
+  }
   const size_t n16 = in_n / 2;
   timeit("copy16 in->in2 (full 3.59 GB r + w)", 2.0 * out_n * 8, [&] { copy16<<<256 * 8, 256>>>((const double2*)in, (double2*)out, out_n / 2); });
   timeit("read-only 16B/lane (3.59 GB)", 1.0 * in_n * 8, [&] { read16<<<256 * 8, 256>>>((const double2*)in, sink, n16); });
