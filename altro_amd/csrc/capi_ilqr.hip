@@ -112,13 +112,35 @@ IlqrArgs<T> ilqr_args(altro_hip_batch* h, bool use_alpha, bool use_active, int w
   a.spec_jac = (T*)h->i_spec_jac;
   return a;
 }
+// Most line-search steps one merit launch of this handle can ever evaluate: the sequenced loop speculates 2 / 4 / 8 wide only
+// while wavefronts x trials x 2 stays below what the chip holds (plan LANE: 512 wavefronts; the scattered searching lanes
+// occupy every wave of the batch), the fused solve kernel never goes beyond 4.  The spare trajectories and the per-trial cost
+// array are sized to THIS, not to ILQR_SPEC_TRIALS: at 65536 bicycles that is 3 spares instead of 7 (0.8 GB instead of 1.9).
+int spec_trials_cap(const altro_hip_batch* h) {
+  if (h->plan != ALTRO_HIP_PLAN_LANE) return ILQR_SPEC_TRIALS;   // MFMA16: the searching problems alone decide
+  const int64_t units = (h->batch + 63) / 64;
+  int t = ILQR_SPEC_TRIALS;
+  while (t > 4 && units * t * 2 > 512) t /= 2;
+  return t;
+}
+// `count` spare candidate trajectories (grown on demand, never shrunk); false = no memory for them (nothing is changed)
+bool ensure_spares(altro_hip_batch* h, int count, size_t bytes_each) {
+  if (h->spare_count >= count) return true;
+  void* fresh = nullptr;
+  if (hipMalloc(&fresh, (size_t)count * bytes_each) != hipSuccess) { (void)hipGetLastError(); return false; }
+  if (h->i_cand_spec) { (void)hipStreamSynchronize(h->stream); (void)hipFree(h->i_cand_spec); h->device_bytes -= (size_t)h->spare_count * bytes_each; }
+  h->i_cand_spec = fresh;
+  h->spare_count = count;
+  h->device_bytes += (size_t)count * bytes_each;
+  return true;
+}
 // The buffers of the three-launch merit evaluation (first use).  No memory for them: the one-launch kernel, for good.
 void merit_split_prepare(altro_hip_batch* h) {
   if (h->merit_split >= 0) return;
   const char* e = std::getenv("ALTRO_HIP_MERIT_SPLIT");
   h->merit_split = (e && std::atoi(e) == 0) ? 0 : 1;
   if (!h->merit_split) return;
-  const size_t jk = (size_t)ILQR_SPEC_TRIALS * (h->N + 1) * h->batch * h->esz;
+  const size_t jk = (size_t)spec_trials_cap(h) * (h->N + 1) * h->batch * h->esz;
   const size_t jac = ((size_t)h->N * (h->n * h->n + h->n * h->m + h->n + h->m) + h->n) * h->batch * h->esz;
   if (dmalloc(h, &h->i_merit_jk, jk) || dmalloc(h, &h->i_spec_jac, jac)) {
     (void)hipGetLastError();
@@ -601,7 +623,8 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
   };
   const bool lane_plan = h->plan == ALTRO_HIP_PLAN_LANE;
   const int64_t cand_elems = (int64_t)h->batch * (h->N + 1) * (lane_plan ? lane_sizes(h->n, h->m).e_xuy : 28);
-  const size_t spare_bytes = (size_t)(ILQR_SPEC_TRIALS - 1) * cand_elems * h->esz;   // spare candidate trajectories
+  const size_t spare_each = (size_t)cand_elems * h->esz;   // one spare candidate trajectory
+  const int trials_cap = spec_trials_cap(h);
   // Plan LANE: whole solves run in ONE launch -- a workgroup of four (eight) waves per 8 / 16 / 32 problems sequencing itself with
   // no host in between (kernels/ilqr_fused.hip) -- bit-identical to the launch-sequenced loop further down
   // (tests/test_gpu_fused.py, tools/fuzz_fused.py).  ALTRO_HIP_FUSED=1 / =0 forces one or the other (ALTRO_HIP_NO_FUSED, any
@@ -620,11 +643,8 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
   if (const char* e = std::getenv("ALTRO_HIP_FUSED")) fused_want = std::atoi(e) != 0;
   if (std::getenv("ALTRO_HIP_NO_FUSED") != nullptr) fused_want = false;
   bool fused = fused_can && fused_want;
-  if (fused && !h->i_cand_spec && dmalloc(h, &h->i_cand_spec, spare_bytes)) {   // the waves' speculative steps need the spare
-    (void)hipGetLastError();                                                    // trajectories; without them: sequenced loop
-    h->spec_no_memory = true;
-    fused = false;
-  }
+  if (fused && !ensure_spares(h, 3, spare_each))   // the waves' speculative steps (at most four per evaluation) need three
+    fused = false;                                 // spare trajectories; without them THIS solve runs the sequenced loop
   // initial rollout, make it the nominal trajectory, expand everything (solver.cpp:420-434) -- inside the fused kernel when
   // that runs (IlqrFusedArgs::prologue), five launches otherwise
   // (not for the 2-state shapes: their eight-wave kernel lives on 256 registers and spills; with the prologue's code in it
@@ -753,8 +773,7 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
     bool refreshed = false;
     bool stat_needed = true;
     bool pre = !dual && spec_all_on && !h->spec_no_memory && (int64_t)spec_units(running) * 2 <= spec_capacity;
-    if (pre && !h->i_cand_spec && dmalloc(h, &h->i_cand_spec, spare_bytes)) {
-      (void)hipGetLastError();    // an optimisation only: carry on one step per launch
+    if (pre && !ensure_spares(h, 1, spare_each)) {   // an optimisation only: carry on one step per launch
       h->spec_no_memory = true;
       pre = false;
     }
@@ -802,11 +821,10 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
       // kernel consumes them in order, so every decision is the sequential one (kernels/ilqr_types.h).
       int trials = 1;
       if (spec_on && !h->spec_no_memory)
-        while (trials < ILQR_SPEC_TRIALS && (int64_t)spec_units(counters[0]) * trials * 2 <= spec_capacity) trials *= 2;
-      if (trials > 1 && !h->i_cand_spec && dmalloc(h, &h->i_cand_spec, spare_bytes)) {
-        (void)hipGetLastError();
-        h->spec_no_memory = true;
-        trials = 1;
+        while (trials < trials_cap && (int64_t)spec_units(counters[0]) * trials * 2 <= spec_capacity) trials *= 2;
+      if (trials > 1 && !ensure_spares(h, trials_cap - 1, spare_each)) {
+        while (trials > 1 && trials - 1 > h->spare_count) trials /= 2;   // as wide as the spares there are
+        if (trials == 1 && h->spare_count == 0) h->spec_no_memory = true;
       }
       const bool spec = trials > 1;
       h->spec_trials = trials;

@@ -77,6 +77,7 @@ struct altro_hip_batch {
   int *i_active = nullptr, *i_counters = nullptr;
   // speculative backtracking (altro_hip_ilqr_solve): spare candidate trajectories, allocated on first use
   void* i_cand_spec = nullptr;
+  int spare_count = 0;            // spare candidate trajectories i_cand_spec holds (sized to the path in use, see spec_trials_cap)
   int *i_spec_sel = nullptr, *i_spec_refresh = nullptr;
   int* i_stat_done = nullptr;     // plan MFMA16's dual merit evaluation (IlqrLoopArgs::stat_done)
   const int* stat_skip = nullptr; // set while a solve's IK_STATIONARITY launches may skip those problems

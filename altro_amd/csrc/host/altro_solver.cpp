@@ -6,6 +6,7 @@
 // computed here: they go through tvlqr_BackwardPass / tvlqr_ForwardPass (include/tvlqr/tvlqr.h),
 // which this library implements on the MI355X.  No Eigen: blocks are std::vector<double>,
 // column-major like the reference's (internal_types.hpp:13-14).
+#define ALTRO_TU_FP_CONTRACT 1   // a host C++ unit: clang's default (on); the shared headers restore THIS mode (fp_contract.h)
 #include "altro/altro_solver.hpp"
 
 #include <algorithm>

@@ -20,9 +20,8 @@
 #include "al_types.h"
 #include "tvlqr_lane.hip"   // LaneBuf / lane_ld row access
 
-#if defined(__clang__)
-#pragma clang fp contract(on)   // single-expression a * b + c only: the same rounding in every kernel these functions are inlined into (see models.h)
-#endif
+#include "../fp_contract.h"
+ALTRO_FP_REGION_ON   // single-expression a * b + c only: the same rounding in every kernel these functions are inlined into (see models.h)
 namespace altro_hip {
 
 // cones.cpp:13-38 (p <= AL_MAXSOC, fully unrolled so the arrays stay in registers)
@@ -410,6 +409,4 @@ __device__ __forceinline__ void al_load_z(const AlTable<T>& t, int k, const BUF&
 }
 
 }  // namespace altro_hip
-#if defined(__clang__)
-#pragma clang fp contract(fast)
-#endif
+ALTRO_FP_REGION_END   // back to the including translation unit's own mode (fp_contract.h)

@@ -22,6 +22,7 @@
 // vector L1, which is what makes a `__syncthreads()` (or a workgroup-scope release / acquire pair) enough between a
 // store of one wave and a load of another.
 #pragma once
+#include "../fp_contract.h"
 #include <hip/hip_runtime.h>
 
 #include "ilqr_lane.hip"
@@ -39,6 +40,10 @@ namespace altro_hip {
 template <int n, typename T>
 constexpr int ilqr_fused_waves() { return n <= 2 ? 8 : 4; }
 
+// (The kernel body holds no floating-point arithmetic of its own -- every expression lives in the shared device functions,
+//  which carry their own contract(on) regions -- but it is put under the same mode explicitly so that an expression added
+//  here later cannot round differently from the launch-sequenced path by accident.)
+ALTRO_FP_REGION_ON
 template <int KIND, int n, int m, typename T, int G>
 __global__ __launch_bounds__((64 * ilqr_fused_waves<n, T>())) void ilqr_fused_sweeps_kernel(IlqrArgs<T> a, IlqrLoopArgs la,
                                                                                            LaneArgs<T> ba, IlqrFusedArgs fa) {
@@ -317,5 +322,7 @@ __global__ __launch_bounds__((64 * ilqr_fused_waves<n, T>())) void ilqr_fused_sw
     atomicMax(&fa.counters[3], sweeps);
   }
 }
+
+ALTRO_FP_REGION_END
 
 }  // namespace altro_hip

@@ -30,9 +30,8 @@
 #include "al_lane.hip"
 #include "tvlqr_lane.hip"
 
-#if defined(__clang__)
-#pragma clang fp contract(on)   // single-expression a * b + c only: the same rounding in every kernel these functions are inlined into (see models.h)
-#endif
+#include "../fp_contract.h"
+ALTRO_FP_REGION_ON   // single-expression a * b + c only: the same rounding in every kernel these functions are inlined into (see models.h)
 namespace altro_hip {
 
 template <int n, int m>
@@ -906,6 +905,4 @@ __global__ void ilqr_shift_kernel(IlqrArgs<T> a) {
 }
 
 }  // namespace altro_hip
-#if defined(__clang__)
-#pragma clang fp contract(fast)
-#endif
+ALTRO_FP_REGION_END   // back to the including translation unit's own mode (fp_contract.h)

@@ -7,9 +7,8 @@
 
 #include "ilqr_types.h"
 
-#if defined(__clang__)
-#pragma clang fp contract(on)   // single-expression a * b + c only: the same rounding in every kernel these functions are inlined into (see models.h)
-#endif
+#include "../fp_contract.h"
+ALTRO_FP_REGION_ON   // single-expression a * b + c only: the same rounding in every kernel these functions are inlined into (see models.h)
 namespace altro_hip {
 
 // start of a solve (what a fresh Solve() call resets)
@@ -184,6 +183,4 @@ __device__ __forceinline__ void ilqr_penalty_update_body(const IlqrLoopArgs& a, 
 }
 
 }  // namespace altro_hip
-#if defined(__clang__)
-#pragma clang fp contract(fast)
-#endif
+ALTRO_FP_REGION_END   // back to the including translation unit's own mode (fp_contract.h)

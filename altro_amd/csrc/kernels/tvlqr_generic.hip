@@ -13,13 +13,14 @@
 // so the broadcast reads are bank-conflict-free or same-address.  The k-recursion is serial
 // (P_{k+1} -> P_k), P_{k+1}/p_{k+1} never leave LDS.
 #pragma once
+#include "../fp_contract.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace altro_hip {
 
 // Bit-parity with the CPU oracle: no a*b+c -> fma fusion anywhere in this file.
-#pragma clang fp contract(off)
+ALTRO_FP_REGION_OFF
 
 enum GArr {
   G_A = 0, G_B, G_f, G_Q, G_R, G_H, G_q, G_r,      // inputs
@@ -347,6 +348,6 @@ __global__ __launch_bounds__(64) void generic_forward_kernel(GenericArgs<T> a) {
 #undef s_fail
 }
 
-#pragma clang fp contract(fast)
+ALTRO_FP_REGION_END   // back to the including translation unit's own mode (fp_contract.h)
 
 }  // namespace altro_hip

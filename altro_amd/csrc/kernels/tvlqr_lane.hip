@@ -14,6 +14,7 @@
 // These shapes (BASELINE.json configs[2], [3]) are latency-bound, not HBM-bound: N dependent steps of
 // a few hundred flops each.  Occupancy comes from the batch; nothing here tries to look like a GEMM.
 #pragma once
+#include "../fp_contract.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -128,20 +129,20 @@ struct LaneFwdRec {
 };
 
 // ---- the kernels, in two arithmetic flavours (see tvlqr_lane_body.inc) ---------------------------------------------
-#pragma clang fp contract(off)
+ALTRO_FP_REGION_OFF
 #define LANE_FN(x) x
 #include "tvlqr_lane_body.inc"
 #include "tvlqr_quad_body.inc"
 #include "tvlqr_quad2_body.inc"
 #undef LANE_FN
-#pragma clang fp contract(fast)
+ALTRO_FP_REGION_FAST
 #define LANE_FN(x) x##_fused
 #include "tvlqr_lane_body.inc"
 #include "tvlqr_quad_body.inc"
 #include "tvlqr_quad2_body.inc"
 #undef LANE_FN
 
-#pragma clang fp contract(fast)
+ALTRO_FP_REGION_END   // back to the including translation unit's own mode (fp_contract.h)
 
 // ---- layout conversion for plan LANE ------------------------------------------------------------
 struct LaneSeg {   // one reference-layout source array -> a run of `len` elements of a SoA record

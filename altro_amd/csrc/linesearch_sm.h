@@ -17,9 +17,8 @@
 #define ALTRO_LS_HD inline
 #endif
 
-#if defined(__clang__)
-#pragma clang fp contract(on)   // single-expression a * b + c only: the same rounding in every kernel these functions are inlined into (see models.h)
-#endif
+#include "fp_contract.h"
+ALTRO_FP_REGION_ON   // single-expression a * b + c only: the same rounding in every kernel these functions are inlined into (see models.h)
 namespace altro_hip {
 
 enum LsStatus {   // linesearch.hpp:16-25
@@ -260,6 +259,4 @@ ALTRO_LS_HD bool ls_feed(LsState& s, const LsOptions& o, double phi, double dphi
 }
 
 }  // namespace altro_hip
-#if defined(__clang__)
-#pragma clang fp contract(fast)
-#endif
+ALTRO_FP_REGION_END   // back to the including translation unit's own mode (fp_contract.h)

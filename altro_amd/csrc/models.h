@@ -18,13 +18,12 @@
 #define ALTRO_HD inline
 #endif
 
-#if defined(__clang__)
+#include "fp_contract.h"
 // Contraction: `on` = a * b + c is fused where it is ONE source expression, and nowhere else.  Unlike `fast`, which lets
 // the optimiser fuse across statements depending on what surrounds the code, this does not depend on the kernel a
 // function is inlined into -- the launch-sequenced solve and the fused solve kernel (ilqr_fused.hip) therefore round
 // identically, bit for bit.
-#pragma clang fp contract(on)
-#endif
+ALTRO_FP_REGION_ON
 
 namespace altro_hip {
 
@@ -318,6 +317,4 @@ struct DiscreteModel {
 
 }  // namespace altro_hip
 
-#if defined(__clang__)
-#pragma clang fp contract(fast)
-#endif
+ALTRO_FP_REGION_END   // back to the including translation unit's own mode (fp_contract.h)
