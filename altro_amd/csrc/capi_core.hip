@@ -77,13 +77,18 @@ int altro_hip_batch_create(altro_hip_batch** out, int N, int n, int m, int batch
   if (dtype != ALTRO_HIP_F64 && dtype != ALTRO_HIP_F32) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "bad dtype %d", dtype);
   if (altro_hip_device_count() <= device || device < 0)
     return fail(ALTRO_HIP_ERR_NO_DEVICE, "no HIP device %d: the altro_hip hot path has no CPU fallback", device);
-  const bool mfma_ok = (n == 12 && m == 4);   // fp32 handles: fp32 storage, fp64 tile arithmetic
+  // Plan MFMA16 works on the (12, 4) tile; any n <= 12, m <= 4 rides it zero-padded (kernels/pack.hip): no shape next to a
+  // fast one falls off a cliff (the reference is dimension-generic, tvlqr.cpp:92-121).  AUTO: the exact tile shape first,
+  // then the lane-per-problem plan where it is instantiated (n <= 6, m <= 3: a whole knot point fits one lane's registers),
+  // then the padded tile, and GENERIC for everything larger.  (fp32 handles: fp32 storage, fp64 tile arithmetic.)
+  const bool mfma_ok = (n <= 12 && m <= 4);
   if (plan == ALTRO_HIP_PLAN_AUTO)
-    plan = mfma_ok ? ALTRO_HIP_PLAN_MFMA16 : (lane_supported(n, m) ? ALTRO_HIP_PLAN_LANE : ALTRO_HIP_PLAN_GENERIC);
+    plan = (n == 12 && m == 4) ? ALTRO_HIP_PLAN_MFMA16
+           : lane_supported(n, m) ? ALTRO_HIP_PLAN_LANE : (mfma_ok ? ALTRO_HIP_PLAN_MFMA16 : ALTRO_HIP_PLAN_GENERIC);
   if (plan == ALTRO_HIP_PLAN_MFMA16 && !mfma_ok)
-    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "plan MFMA16 needs (n, m) = (12, 4)");
+    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "plan MFMA16 needs n <= 12 and m <= 4 (got %d, %d)", n, m);
   if (plan == ALTRO_HIP_PLAN_LANE && !lane_supported(n, m))
-    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "plan LANE is instantiated for (n, m) in {(2,1), (3,1), (4,2), (6,3)}");
+    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "plan LANE is instantiated for n <= 6, m <= 3 (got %d, %d)", n, m);
   if (plan != ALTRO_HIP_PLAN_MFMA16 && plan != ALTRO_HIP_PLAN_GENERIC && plan != ALTRO_HIP_PLAN_LANE)
     return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "bad plan %d", plan);
   HIP_TRY(hipSetDevice(device));
@@ -102,7 +107,8 @@ int altro_hip_batch_create(altro_hip_batch** out, int N, int n, int m, int batch
   int rc = 0;
   const size_t B = (size_t)batch, E = h->esz;
 #define ALLOC(ptr, bytes) if (!rc) rc = dmalloc(h, (void**)&(ptr), (bytes))
-  ALLOC(h->x0, B * n * E);
+  h->x0_stride = plan == ALTRO_HIP_PLAN_MFMA16 ? MF_N : n;      // plan MFMA16 keeps x0 in tile rows of 12
+  ALLOC(h->x0, B * h->x0_stride * E);
   ALLOC(h->delta_V, B * 2 * E);
   ALLOC(h->status, B * sizeof(int));
   ALLOC(h->st_partial, (size_t)kStatsBlocks * kStatsStride * sizeof(double));
@@ -121,6 +127,13 @@ int altro_hip_batch_create(altro_hip_batch** out, int N, int n, int m, int batch
     ALLOC(h->m_xuy, B * (N + 1) * 28 * E);
     ALLOC(h->m_trash, B * MF_OUT * E);
     if (flags & ALTRO_HIP_STORE_QBLOCKS) ALLOC(h->m_qblk, B * N * MF_QB * E);
+    if (!rc && (n < MF_N || m < MF_M)) {   // padded shape: whatever no setter writes must read as zero
+      (void)hipMemsetAsync(h->x0, 0, B * MF_N * E, h->stream);
+      (void)hipMemsetAsync(h->m_xuy, 0, B * (N + 1) * 28 * E, h->stream);
+      (void)hipMemsetAsync(h->m_in, 0, B * N * MF_DYN * E, h->stream);
+      (void)hipMemsetAsync(h->m_cin, 0, B * N * MF_COST * E, h->stream);
+      (void)hipMemsetAsync(h->m_term, 0, B * MF_TERM * E, h->stream);
+    }
   } else if (plan == ALTRO_HIP_PLAN_LANE) {
     const LaneSizes z = lane_sizes(n, m);
     // the LANE kernels address one knot point's record through a 2 GiB buffer window with 32-bit offsets
@@ -366,10 +379,10 @@ int altro_hip_set_initial_state(altro_hip_batch* h, const double* x0, int bz) {
     const int64_t total = (int64_t)nb * h->n;
     if (h->dtype == ALTRO_HIP_F64)
       hipLaunchKernelGGL(expand_copy_kernel<double>, dim3(grid_for(total)), dim3(256), 0, h->stream,
-                         (double*)h->x0, (int64_t)h->n, (int64_t)h->n, s, h->n, 1, b0, nb);
+                         (double*)h->x0, (int64_t)h->x0_stride, (int64_t)h->x0_stride, s, h->n, 1, b0, nb);
     else
       hipLaunchKernelGGL(expand_copy_kernel<float>, dim3(grid_for(total)), dim3(256), 0, h->stream,
-                         (float*)h->x0, (int64_t)h->n, (int64_t)h->n, s, h->n, 1, b0, nb);
+                         (float*)h->x0, (int64_t)h->x0_stride, (int64_t)h->x0_stride, s, h->n, 1, b0, nb);
     if (hipGetLastError() != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "x0 copy launch failed");
     return 0;
   };

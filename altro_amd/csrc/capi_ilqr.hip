@@ -18,7 +18,20 @@ int al_upload_typed(altro_hip_batch* h) {
   for (void** p : {(void**)&h->al_d_knots, &h->al_d_G, &h->al_d_g, &h->al_d_z})
     if (*p) { (void)hipFree(*p); *p = nullptr; }
   if (h->al_defs.empty()) { h->al_rows = 0; return 0; }
-  std::vector<T> G(h->al_G.begin(), h->al_G.end());
+  // G on the device: p x (n + m) column-major as given on plan LANE; on plan MFMA16 p x 16 in the tile's own column order
+  // (states in columns 0..11, inputs in 12..15), so that a padded shape's blocks address the padded [x; u] correctly
+  const bool tile = h->plan == ALTRO_HIP_PLAN_MFMA16;
+  const int w_log = h->n + h->m, w_dev = tile ? MF_N + MF_M : w_log;
+  auto dev_col = [&](int e) { return (tile && e >= h->n) ? MF_N + (e - h->n) : e; };
+  std::vector<T> G;
+  std::vector<int> G_off_dev(h->al_defs.size(), 0);
+  for (size_t i = 0; i < h->al_defs.size(); ++i) {
+    const AlDef& d0 = h->al_defs[i];
+    G_off_dev[i] = (int)G.size();
+    G.resize(G.size() + (size_t)d0.p * w_dev, (T)0);
+    for (int e = 0; e < w_log; ++e)
+      for (int r = 0; r < d0.p; ++r) G[(size_t)G_off_dev[i] + r + (size_t)dev_col(e) * d0.p] = (T)h->al_G[(size_t)d0.G_off + r + (size_t)e * d0.p];
+  }
   std::vector<T> g;
   std::vector<AlDef> defs = h->al_defs;
   for (size_t i = 0; i < defs.size(); ++i) {
@@ -40,7 +53,7 @@ int al_upload_typed(altro_hip_batch* h) {
     for (int j = 0; j < kn.ncon; ++j) {
       const AlDef& d = defs[kn.def[j]];
       kn.z_off[j] = rows; rows += d.p;
-      kn.cone[j] = d.cone; kn.p[j] = d.p; kn.g_per_problem[j] = d.g_per_problem; kn.G_off[j] = d.G_off; kn.g_off[j] = d.g_off;
+      kn.cone[j] = d.cone; kn.p[j] = d.p; kn.g_per_problem[j] = d.g_per_problem; kn.G_off[j] = G_off_dev[kn.def[j]]; kn.g_off[j] = d.g_off;
       // bound-type block: every row of G is +-e_idx
       const int w = h->n + h->m;
       bool sel = d.cone != CONE_SOC;
@@ -51,7 +64,7 @@ int al_upload_typed(altro_hip_batch* h) {
           if (v != 0.0) { ++nz; at = e; if (v != 1.0 && v != -1.0) sel = false; }
         }
         if (nz != 1) sel = false;
-        else kn.sidx[j][r] = h->al_G[(size_t)d.G_off + r + (size_t)at * d.p] > 0 ? at + 1 : -(at + 1);
+        else kn.sidx[j][r] = h->al_G[(size_t)d.G_off + r + (size_t)at * d.p] > 0 ? dev_col(at) + 1 : -(dev_col(at) + 1);
       }
       kn.sel[j] = sel ? 1 : 0;
     }
@@ -204,9 +217,12 @@ int ilqr_check(altro_hip_batch* h, bool need_guess) {
   if (h->plan == ALTRO_HIP_PLAN_MFMA16) {   // dynamics are data (altro_hip_set_dynamics), no device model
     if (!h->dyn_set) return fail(ALTRO_HIP_ERR_NOT_SET, "altro_hip_set_dynamics has not been called");
   } else if (h->plan != ALTRO_HIP_PLAN_LANE) {
-    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "the device iLQR loop is implemented for plans LANE and MFMA16");
+    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "the device iLQR loop runs on plans MFMA16 (n <= 12, m <= 4, dynamics given as data) and "
+                                           "LANE (n <= 6, m <= 3, device models); plan GENERIC (n = %d, m = %d) has the TVLQR sweep only",
+                h->n, h->m);
   } else if (!h->model_set) {
-    return fail(ALTRO_HIP_ERR_NOT_SET, "altro_hip_set_model has not been called");
+    return fail(ALTRO_HIP_ERR_NOT_SET, "altro_hip_set_model has not been called (plan LANE runs device models; for dynamics given as "
+                                       "data -- altro_hip_set_dynamics -- create the handle with ALTRO_HIP_PLAN_MFMA16)");
   }
   if (!h->lqr_cost_set) return fail(ALTRO_HIP_ERR_NOT_SET, "altro_hip_set_tracking_cost has not been called");
   if (!h->x0_set) return fail(ALTRO_HIP_ERR_NOT_SET, "altro_hip_set_initial_state has not been called");
@@ -297,6 +313,12 @@ int altro_hip_set_tracking_cost(altro_hip_batch* h, const double* Qd, const doub
     if (!rc) rc = put(q.data(), n, 16, 0, N, nkx, 0);
     if (!rc) rc = put(r.data(), m, 28, 0, N, nku, 0);
     if (!rc) rc = put(c.data(), 1, 32, 0, N, nkx, 0);
+    if (!rc && m < MF_M) {   // padded inputs: Rd = 1 keeps their diagonal of Quu positive (they stay at exactly 0: K, d rows are 0)
+      const double ones[MF_M] = {1.0, 1.0, 1.0, 1.0};
+      rc = h->dtype == ALTRO_HIP_F64
+               ? aos_set<double>(h, (double*)h->m_costp + 12 + m, MF_COSTP, B * MF_COSTP, ones, MF_M - m, N, 1, 1, 1, 0)
+               : aos_set<float>(h, (float*)h->m_costp + 12 + m, MF_COSTP, B * MF_COSTP, ones, MF_M - m, N, 1, 1, 1, 0);
+    }
     // terminal record N: element N of a full host array, or the second entry of a {running, terminal} pair
     auto put_term = [&](const double* src, int len, int off) -> int {
       const double* base = kz ? src : src;   // per problem the host holds nkx knot points

@@ -77,6 +77,7 @@ struct altro_hip_batch {
   int *i_active = nullptr, *i_counters = nullptr;
   // speculative backtracking (altro_hip_ilqr_solve): spare candidate trajectories, allocated on first use
   void* i_cand_spec = nullptr;
+  int x0_stride = 0;              // elements between two problems' x0 on the device (12 on plan MFMA16, else n)
   int spare_count = 0;            // spare candidate trajectories i_cand_spec holds (sized to the path in use, see spec_trials_cap)
   int *i_spec_sel = nullptr, *i_spec_refresh = nullptr;
   int* i_stat_done = nullptr;     // plan MFMA16's dual merit evaluation (IlqrLoopArgs::stat_done)
@@ -309,11 +310,11 @@ inline int mfma16_get(altro_hip_batch* h, int what, double* host, int block, int
     if (h->dtype == ALTRO_HIP_F64)
       hipLaunchKernelGGL(mfma16_unpack_kernel<double>, dim3(grid_for(total)), dim3(256), 0, h->stream, dst, what,
                          (const double*)h->m_out, (const double*)h->m_outn, (const double*)h->m_xuy,
-                         (const double*)h->m_qblk, h->m_st, h->N, b0, nb);
+                         (const double*)h->m_qblk, h->m_st, h->N, b0, nb, h->n, h->m);
     else
       hipLaunchKernelGGL(mfma16_unpack_kernel<float>, dim3(grid_for(total)), dim3(256), 0, h->stream, dst, what,
                          (const float*)h->m_out, (const float*)h->m_outn, (const float*)h->m_xuy,
-                         (const float*)h->m_qblk, h->m_st, h->N, b0, nb);
+                         (const float*)h->m_qblk, h->m_st, h->N, b0, nb, h->n, h->m);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "mfma16_unpack launch: %s", hipGetErrorString(e));
     return 0;
@@ -348,17 +349,21 @@ inline int mfma16_pack_launch(altro_hip_batch* h, int seg, SrcArr s0, SrcArr s1)
   const int64_t total = (int64_t)h->batch * h->N * 192;
   if (h->dtype == ALTRO_HIP_F64)
     hipLaunchKernelGGL(mfma16_pack_kernel<double>, dim3(grid_for(total)), dim3(256), 0, h->stream, (double*)h->m_in,
-                       (double*)h->m_cin, (double*)h->m_term, h->m_st, seg, s0, s1, h->is_diag, h->N, 0, h->batch);
+                       (double*)h->m_cin, (double*)h->m_term, h->m_st, seg, s0, s1, h->is_diag, h->N, 0, h->batch, h->n, h->m);
   else
     hipLaunchKernelGGL(mfma16_pack_kernel<float>, dim3(grid_for(total)), dim3(256), 0, h->stream, (float*)h->m_in,
-                       (float*)h->m_cin, (float*)h->m_term, h->m_st, seg, s0, s1, h->is_diag, h->N, 0, h->batch);
+                       (float*)h->m_cin, (float*)h->m_term, h->m_st, seg, s0, s1, h->is_diag, h->N, 0, h->batch, h->n, h->m);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "mfma16_pack launch: %s", hipGetErrorString(e));
   return 0;
 }
 
 // ---- plan LANE dispatch ---------------------------------------------------------------------------
-#define LANE_SHAPES(X) X(2, 1) X(4, 2) X(3, 1) X(6, 3)
+// every (n, m) with n <= 6, m <= 3 (the reference is dimension-generic, tvlqr.cpp:92-121: a shape one off a fast one must not
+// fall back to plan GENERIC); (2, 1) and (4, 2) additionally have their several-lanes-per-problem sweeps
+#define LANE_SHAPES(X)                                                                                   \
+  X(1, 1) X(2, 1) X(3, 1) X(4, 1) X(5, 1) X(6, 1) X(1, 2) X(2, 2) X(3, 2) X(4, 2) X(5, 2) X(6, 2) X(1, 3) \
+  X(2, 3) X(3, 3) X(4, 3) X(5, 3) X(6, 3)
 inline bool lane_supported(int n, int m) {
 #define X(N_, M_) if (n == N_ && m == M_) return true;
   LANE_SHAPES(X)

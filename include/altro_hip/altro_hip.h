@@ -79,12 +79,14 @@ typedef enum altro_hip_error {
   ALTRO_HIP_ERR_OUT_OF_MEMORY = -6
 } altro_hip_error;
 
-/* Which kernel family a handle runs.  AUTO picks the fastest one that supports (n, m, dtype). */
+/* Which kernel family a handle runs.  AUTO: (12, 4) -> MFMA16; n <= 6, m <= 3 -> LANE; other n <= 12, m <= 4 -> MFMA16
+ * (padded); anything larger (<= 32) -> GENERIC (TVLQR sweep only). */
 typedef enum altro_hip_plan {
   ALTRO_HIP_PLAN_AUTO = 0,
   ALTRO_HIP_PLAN_GENERIC = 1, /* wave-per-problem, LDS-staged, any (n, m) <= 32                */
-  ALTRO_HIP_PLAN_MFMA16 = 2,  /* wave-per-problem, 16x16x4 MFMA tiles, (n, m) = (12, 4)         */
-  ALTRO_HIP_PLAN_LANE = 3     /* lane-per-problem, batch structure-of-arrays, small (n, m)      */
+  ALTRO_HIP_PLAN_MFMA16 = 2,  /* wave-per-problem, 16x16x4 MFMA tiles: (n, m) = (12, 4), and any n <= 12,
+                                 m <= 4 on zero-padded records (same results, the (12, 4) cost)        */
+  ALTRO_HIP_PLAN_LANE = 3     /* lane-per-problem, batch structure-of-arrays, n <= 6 and m <= 3         */
 } altro_hip_plan;
 
 /* create flags */

@@ -282,3 +282,57 @@ def test_regularisation_retry_on_plan_mfma16():
     assert np.isfinite(bt2.get("K")).all() and np.isfinite(bt2.get_nominal()[0]).all()
     assert np.array_equal(bt2.get_nominal()[0][~bad], good_x)     # well-posed problems are untouched by the option
     bt.close(); bt2.close()
+
+
+@pytest.mark.parametrize("nn,mm,constrained", [(9, 3, False), (9, 3, True), (12, 2, True), (7, 4, False)])
+def test_padded_shape_ilqr_solve_mfma16(nn, mm, constrained):
+    """The iLQR loop of plan MFMA16 for n <= 12, m <= 4 (zero-padded tile records): whole solves --
+    with input bounds and a state half-space when `constrained` -- against the oracle per problem, at the (12, 4)
+    tolerances.  The constraint blocks are given over the problem's own [x; u] (n + m columns)."""
+    Nh, batch = 17, 20
+    p = problems.ilqr12x4_problem(batch, Nh, True, n=nn, m=mm)
+    blocks = []
+    if constrained:
+        w = nn + mm
+        Gb = np.zeros((2 * mm, w)); Gb[:mm, nn:] = np.eye(mm); Gb[mm:, nn:] = -np.eye(mm)
+        Gs = np.zeros((1, w)); Gs[0, 1] = 1.0
+        blocks = [(0, Nh - 1, problems.CONE_INEQUALITY, Gb, np.full(2 * mm, 0.3)), (1, Nh - 1, problems.CONE_INEQUALITY, Gs, np.array([1.2]))]
+    bt = altro_amd.Batch(Nh, nn, mm, batch, plan=altro_amd.PLAN_MFMA16)
+    bt.set_dynamics(p["A"], p["B"], p["f"])
+    bt.set_tracking_cost(p["Qd"], p["Rd"], p["xref"], p["uref"])
+    bt.set_initial_state(p["x0"])
+    bt.set_input_guess(p["u0"])
+    for (k0, k1, cone, G, g) in blocks:
+        bt.add_linear_constraint(k0, k1, cone, G, g)
+    res = bt.ilqr_solve(iterations_max=60, penalty_initial=1.0, penalty_scaling=10.0)
+    x, u = bt.get_nominal()
+    assert x.shape == (batch, Nh + 1, nn) and u.shape == (batch, Nh, mm)
+    nconv = 0
+    for b in [0, 9, 19]:
+        s = oracle.ILQR(Nh, nn, mm, 0.01, oracle.DYN_LINEAR, cost_kind=oracle.COST_DIAGONAL)
+        s.L.oracle_ilqr_set_linear_dynamics(s.h, np.ascontiguousarray(p["A"][b]), np.ascontiguousarray(p["B"][b]),
+                                            np.ascontiguousarray(p["f"][b]).ctypes.data)
+        for k in range(Nh + 1):
+            s.L.oracle_ilqr_set_lqr_cost(s.h, k, np.ascontiguousarray(p["Qd"][b, k]), np.ascontiguousarray(p["Rd"][b, min(k, Nh - 1)]),
+                                         np.ascontiguousarray(p["xref"][b, k]), np.ascontiguousarray(p["uref"][b, min(k, Nh - 1)]))
+        s.L.oracle_ilqr_set_initial_state(s.h, np.ascontiguousarray(p["x0"][b]))
+        for (k0, k1, cone, G, g) in blocks:
+            for k in range(k0, k1 + 1):
+                s.add_linear_constraint(k, cone, G, g)
+        s.L.oracle_ilqr_initialize(s.h)
+        for k in range(Nh):
+            s.L.oracle_ilqr_set_input(s.h, k, np.ascontiguousarray(p["u0"][b, k]))
+        s.set_penalty(1.0, 10.0)
+        s.L.oracle_ilqr_set_options(s.h, 60, 1e-4, 1e-4, 1e-8, 0)
+        status, iters, log = s.solve()
+        assert res["status"][b] == status and res["iterations"][b] == iters, (b, res["status"][b], status, res["iterations"][b], iters)
+        if status != 0:
+            continue
+        nconv += 1
+        tol = 1e-7 if constrained else 1e-9
+        np.testing.assert_allclose(x[b], s.get("x"), rtol=tol, atol=tol)
+        np.testing.assert_allclose(u[b], s.get("u"), rtol=tol * 10, atol=tol * 10)
+        if constrained:
+            assert np.abs(u[b]).max() <= 0.3 + 2e-4
+    assert nconv >= 2
+    bt.close()

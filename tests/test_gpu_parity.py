@@ -447,9 +447,10 @@ def test_generic_and_lane_shape_fuzz():
     for _ in range(14):
         cases.append((int(rng.integers(1, 17)), int(rng.integers(1, 9)), int(rng.integers(1, 40)), int(rng.integers(1, 9)),
                       altro_amd.PLAN_GENERIC))
-    for (n, m) in [(2, 1), (3, 1), (4, 2), (6, 3)]:
-        for batch in (63, 64, 129):
-            cases.append((n, m, int(rng.integers(1, 60)), batch, altro_amd.PLAN_LANE))
+    for n in range(1, 7):           # plan LANE: every n <= 6, m <= 3 (round 3: no shape cliff next to the four original shapes)
+        for m in range(1, 4):
+            for batch in ((63, 64, 129) if (n, m) in [(2, 1), (3, 1), (4, 2), (6, 3)] else (int(rng.integers(1, 200)),)):
+                cases.append((n, m, int(rng.integers(1, 60)), batch, altro_amd.PLAN_LANE))
     for idx, (n, m, N, batch, plan) in enumerate(cases):
         if n == 12 and m == 4:
             continue
@@ -466,6 +467,55 @@ def test_generic_and_lane_shape_fuzz():
         assert (out["status"] == -1).all(), (n, m, N, batch)
         for k in ("K", "d", "P", "p", "x", "u", "y"):
             assert np.array_equal(out[k], ref[k]), (k, n, m, N, batch, plan)
+
+
+def test_padded_mfma16_shapes_vs_oracle():
+    """Plan MFMA16 for any n <= 12, m <= 4: the (12, 4) tile's records zero-padded, R padded with the
+    identity.  AUTO picks it for every shape plan LANE does not cover; the results are the (n, m) problem's own, at the
+    plan's tolerance (K, d 1e-8 absolute, everything 1e-9 relative), including reg > 0, a missing affine term, the Q-block
+    write-back, fp32 storage and the pure-fp32 kernels (four problems per wave: batch % 4 == 0)."""
+    rng = np.random.default_rng(20260929)
+    shapes = [(12, 3), (10, 4), (7, 1), (9, 2), (11, 4), (8, 3), (12, 1), (7, 4), (3, 4), (1, 4), (5, 2)]
+    for idx, (n, m) in enumerate(shapes):
+        N, batch = int(rng.integers(1, 40)), int(rng.integers(1, 70))
+        pr = problems.random_ltv(batch, N, n, m)
+        if idx % 3 == 0:
+            pr["f"] = None
+        reg = 0.0 if idx % 2 else 1e-2
+        auto = altro_amd.PLAN_AUTO if not (n <= 6 and m <= 3) else altro_amd.PLAN_MFMA16
+        out = run_hip(pr, auto, reg=reg)
+        assert out["bt"].plan == altro_amd.PLAN_MFMA16, (n, m)
+        ref_pr = dict(pr)
+        if ref_pr["f"] is None:
+            ref_pr["f"] = np.zeros((batch, N, n))
+        ref = run_oracle(ref_pr, reg=reg)
+        assert (out["status"] == -1).all(), (n, m, N, batch)
+        assert np.abs(out["K"] - ref["K"]).max() < 1e-8 and np.abs(out["d"] - ref["d"]).max() < 1e-8, (n, m)
+        for k in ("K", "d", "P", "p", "x", "u", "y"):
+            assert out[k].shape == ref[k].shape and relerr(out[k], ref[k]) < 1e-9, (k, n, m, N, batch, relerr(out[k], ref[k]))
+        assert relerr(out["delta_V"], ref["dV"]) < 1e-9
+    # Q-block write-back at the problem's own dimensions, and the fp32 variants
+    n, m, N, batch = 10, 3, 9, 8
+    pr = problems.random_ltv(batch, N, n, m)
+    ref = run_oracle(pr)
+    bt = altro_amd.Batch(N, n, m, batch, flags=altro_amd.STORE_QBLOCKS)
+    assert bt.plan == altro_amd.PLAN_MFMA16
+    bt.set_dynamics(pr["A"], pr["B"], pr["f"]); bt.set_cost(pr["Q"], pr["R"], pr["H"], pr["q"], pr["r"])
+    bt.set_initial_state(pr["x0"]); bt.sweep()
+    qb = bt.get("qblocks")
+    assert qb.shape == (batch, N, n * n + m * m + m * n + n + m) and np.isfinite(qb).all()
+    Quu = qb[:, :, n * n:n * n + m * m].reshape(batch, N, m, m)
+    assert np.abs(Quu - np.swapaxes(Quu, -1, -2)).max() < 1e-10 and (np.linalg.eigvalsh(Quu) > 0).all()
+    assert relerr(bt.get("K"), ref["K"]) < 1e-9
+    bt.close()
+    for flags, tol in ((0, 2e-6), (altro_amd.F32_PURE, 2e-4)):
+        bt = altro_amd.Batch(N, n, m, batch, dtype=altro_amd.F32, flags=flags)
+        bt.set_dynamics(pr["A"], pr["B"], pr["f"]); bt.set_cost(pr["Q"], pr["R"], pr["H"], pr["q"], pr["r"])
+        bt.set_initial_state(pr["x0"]); bt.sweep()
+        assert (bt.get("status") == -1).all()
+        for k in ("K", "d", "P", "p", "x", "u", "y"):
+            assert relerr(bt.get(k), ref[k]) < tol, (k, flags, relerr(bt.get(k), ref[k]))
+        bt.close()
 
 
 def test_device_pointer_mode():
