@@ -32,7 +32,7 @@ C_ABI_SYMBOLS = [
     "altro_hip_comm_destroy", "altro_hip_comm_rank", "altro_hip_comm_world", "altro_hip_comm_device", "altro_hip_stats_allreduce", "altro_hip_stats_allreduce_multi",
     "altro_hip_profile_enable", "altro_hip_profile_reset",
     "altro_hip_profile_get", "altro_hip_profile_get_range", "altro_hip_profile_dropped", "altro_hip_algorithmic_bytes",
-    "altro_hip_set_model", "altro_hip_set_tracking_cost", "altro_hip_set_input_guess",
+    "altro_hip_set_model", "altro_hip_set_model_source", "altro_hip_set_tracking_cost", "altro_hip_set_input_guess",
     "altro_hip_open_loop_rollout", "altro_hip_accept", "altro_hip_expand", "altro_hip_merit",
     "altro_hip_stationarity", "altro_hip_get_nominal", "altro_hip_get_expansion",
     "altro_hip_default_solve_options", "altro_hip_ilqr_solve", "altro_hip_last_solve_counts",
@@ -44,7 +44,7 @@ C_ABI_SYMBOLS = [
 ]
 CONE_EQUALITY, CONE_IDENTITY, CONE_INEQUALITY, CONE_SOC = 0, 1, 2, 3   # ConstraintType, typedefs.hpp:29-34
 
-MODEL_LINEAR, MODEL_DOUBLE_INTEGRATOR, MODEL_PENDULUM, MODEL_BICYCLE = 0, 1, 2, 3
+MODEL_LINEAR, MODEL_DOUBLE_INTEGRATOR, MODEL_PENDULUM, MODEL_BICYCLE, MODEL_USER = 0, 1, 2, 3, 4
 MERIT_FN = C.CFUNCTYPE(None, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p)
 
 
@@ -155,6 +155,7 @@ def lib():
         L.altro_hip_algorithmic_bytes.argtypes = [vp, i]
         L.altro_hip_algorithmic_bytes.restype = d
         L.altro_hip_set_model.argtypes = [vp, i, C.c_float, i, d, d]
+        L.altro_hip_set_model_source.argtypes = [vp, C.c_char_p, C.c_float]
         L.altro_hip_set_tracking_cost.argtypes = [vp, vp, vp, vp, vp, i, i]
         L.altro_hip_set_input_guess.argtypes = [vp, vp, i, i]
         for fn in ("open_loop_rollout", "accept", "expand"):
@@ -301,6 +302,10 @@ class Batch:
     # ---- the iLQR loop around the sweep (device models; plan LANE shapes) ----
     def set_model(self, model, timestep, frame=0, length=2.7, lr=1.5):
         _check(self.L.altro_hip_set_model(self.h, model, float(timestep), frame, length, lr))
+
+    def set_model_source(self, source, timestep):
+        """The caller's own continuous dynamics + Jacobian as HIP source (altro_hip_set_model_source), compiled at run time."""
+        _check(self.L.altro_hip_set_model_source(self.h, source.encode(), float(timestep)))
 
     def set_tracking_cost(self, Qd, Rd, xref, uref, k_stride_zero=False, batch_stride_zero=False):
         keep = [_in(v) for v in (Qd, Rd, xref, uref)]

@@ -164,6 +164,7 @@ void merit_split_prepare(altro_hip_batch* h) {
 
 template <typename T>
 int ilqr_launch(altro_hip_batch* h, int which, IlqrArgs<T> a) {
+  if (h->model.kind == MODEL_USER) return rtc_launch<T>(h, which, a);   // the caller's own dynamics, compiled at run time (capi_rtc.hip)
   const int rc = ilqr_launch_kernel<T>(h->stream, which, h->model.kind, h->n, h->m, a);
   if (rc == 1) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "no device model for (kind, n, m) = (%d, %d, %d)", h->model.kind, h->n, h->m);
   if (rc) return fail(ALTRO_HIP_ERR_HIP, "iLQR kernel launch failed");
@@ -656,7 +657,7 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
   //  is a property of the launch-sequenced kernels only)
   if (lane_plan) merit_split_prepare(h);
   bool fused_can = lane_plan && o.iterations_max > 0 && !h->spec_no_memory && h->merit_split == 1 &&
-                   !(h->flags & ALTRO_HIP_LANE_FUSED);
+                   !(h->flags & ALTRO_HIP_LANE_FUSED) && h->model.kind != MODEL_USER;   // (run-time models: sequenced loop)
   // POLICY: fused wherever the kernel exists.  Measured on MI355X (tools/solve_batches.py, profiles/r02p_solve_batches.txt;
   // bicycle + steering bound, N = 50, median wall ms fused / sequenced): backtracking search 5.5 / 7.4 at 256 problems,
   // 20 / 31 at 2048, 24 / 44 at 8192, 76 / 173 at 65536; cubic search 25 / 33, 28 / 61, 36 / 106, 99 / 316; pendulum, 8192

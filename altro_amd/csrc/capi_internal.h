@@ -77,6 +77,7 @@ struct altro_hip_batch {
   int *i_active = nullptr, *i_counters = nullptr;
   // speculative backtracking (altro_hip_ilqr_solve): spare candidate trajectories, allocated on first use
   void* i_cand_spec = nullptr;
+  void* rtc = nullptr;            // run-time compiled model (capi_rtc.hip: RtcModule, shared through a per-process cache)
   int x0_stride = 0;              // elements between two problems' x0 on the device (12 on plan MFMA16, else n)
   int spare_count = 0;            // spare candidate trajectories i_cand_spec holds (sized to the path in use, see spec_trials_cap)
   int *i_spec_sel = nullptr, *i_spec_refresh = nullptr;
@@ -404,6 +405,12 @@ inline int lane_get(altro_hip_batch* h, double* host, const void* src, const voi
 }
 
 constexpr int kStatsBlocks = 1024, kStatsStride = 16;   // capi_stats.hip: partials [kStatsBlocks][kStatsStride]
+
+// run-time compiled user models (capi_rtc.hip): the kernels of the launch-sequenced loop, in this order in RtcModule::fn
+enum RtcKernel { RTC_ROLLOUT = 0, RTC_ACCEPT, RTC_EXPAND, RTC_MERIT, RTC_MERIT_ROLL, RTC_MERIT_POINT, RTC_MERIT_SUM, RTC_SPEC_SELECT,
+                 RTC_ZERO_RESIDUALS, RTC_STATIONARITY, RTC_DUAL, RTC_SHIFT, RTC_NUM };
+template <typename T>
+int rtc_launch(altro_hip_batch* h, int which, const IlqrArgs<T>& a);
 
 // the sweep launchers (capi_tvlqr.hip), also used by the iLQR loop
 int launch_backward(altro_hip_batch* h, double reg);

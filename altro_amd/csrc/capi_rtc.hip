@@ -1,0 +1,271 @@
+// capi_rtc.hip -- C ABI: caller-supplied dynamics in the batched AL-iLQR loop (plan LANE), compiled at run time.
+//
+// ALTROSolver::SetExplicitDynamics (altro_solver.cpp:68-81) takes two host callbacks (typedefs.hpp:31-53); a std::function
+// cannot run on the device, so the batched path offers the device-side equivalent: the caller hands the SOURCE of the
+// continuous dynamics and of its Jacobian -- hand-written HIP, two function templates -- and the library compiles its own
+// lane-per-problem iLQR kernels (kernels/ilqr_lane.hip) around them with hiprtc, once per (source, n, m, element type) and
+// process.  The kernels are the very ones the compiled-in models use (MODEL_PENDULUM, MODEL_BICYCLE ...): the pendulum
+// supplied as source solves to the same bits as MODEL_PENDULUM (tests/test_gpu_user_model.py).  The library's own sources
+// travel inside libaltro_hip.so (.incbin below); hiprtc is resolved with dlopen at first use, so the library keeps its one
+// link-time dependency (the HIP runtime).  Whole solves of such a handle run on the launch-sequenced loop (the one-launch
+// fused kernel is not compiled at run time: it is the library's longest compile).
+#include "capi_internal.h"
+
+#include <dlfcn.h>
+#include <hip/hiprtc.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+
+using namespace altro_hip;
+using namespace altro_hip::capi;
+
+// ---- the sources hiprtc needs, embedded at build time (paths relative to the -I of csrc) ------------------------------------
+#if !defined(__HIP_DEVICE_COMPILE__)
+#define ALTRO_EMBED(sym, path)                                                                                       \
+  __asm__(".pushsection .rodata\n.global " #sym "\n" #sym ":\n.incbin \"" path "\"\n.byte 0\n.popsection\n"); \
+  extern "C" const char sym[];
+#else
+#define ALTRO_EMBED(sym, path) extern "C" const char sym[];
+#endif
+ALTRO_EMBED(altro_rtc_src_rtc_compat, "rtc_compat.h")
+ALTRO_EMBED(altro_rtc_src_fp_contract, "fp_contract.h")
+ALTRO_EMBED(altro_rtc_src_models, "models.h")
+ALTRO_EMBED(altro_rtc_src_linesearch, "linesearch_sm.h")
+ALTRO_EMBED(altro_rtc_src_ilqr_types, "kernels/ilqr_types.h")
+ALTRO_EMBED(altro_rtc_src_al_types, "kernels/al_types.h")
+ALTRO_EMBED(altro_rtc_src_al_lane, "kernels/al_lane.hip")
+ALTRO_EMBED(altro_rtc_src_tvlqr_lane, "kernels/tvlqr_lane.hip")
+ALTRO_EMBED(altro_rtc_src_lane_body, "kernels/tvlqr_lane_body.inc")
+ALTRO_EMBED(altro_rtc_src_quad_body, "kernels/tvlqr_quad_body.inc")
+ALTRO_EMBED(altro_rtc_src_quad2_body, "kernels/tvlqr_quad2_body.inc")
+ALTRO_EMBED(altro_rtc_src_ilqr_lane, "kernels/ilqr_lane.hip")
+
+namespace {
+
+struct Hiprtc {
+  void* lib = nullptr;
+  decltype(&hiprtcCreateProgram) CreateProgram = nullptr;
+  decltype(&hiprtcCompileProgram) CompileProgram = nullptr;
+  decltype(&hiprtcDestroyProgram) DestroyProgram = nullptr;
+  decltype(&hiprtcAddNameExpression) AddNameExpression = nullptr;
+  decltype(&hiprtcGetLoweredName) GetLoweredName = nullptr;
+  decltype(&hiprtcGetCodeSize) GetCodeSize = nullptr;
+  decltype(&hiprtcGetCode) GetCode = nullptr;
+  decltype(&hiprtcGetProgramLogSize) GetProgramLogSize = nullptr;
+  decltype(&hiprtcGetProgramLog) GetProgramLog = nullptr;
+  decltype(&hiprtcGetErrorString) GetErrorString = nullptr;
+};
+
+int hiprtc_api(const Hiprtc** out) {
+  static Hiprtc r;
+  static std::string why = "symbols missing";
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const char* env = std::getenv("ALTRO_HIP_HIPRTC");
+    void* lib = env ? dlopen(env, RTLD_NOW | RTLD_GLOBAL) : nullptr;
+    for (const char* name : {"libhiprtc.so.7", "libhiprtc.so"})
+      if (!lib) lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD);       // a copy the process already has
+    for (const char* name : {"libhiprtc.so.7", "libhiprtc.so", "/opt/rocm/lib/libhiprtc.so"})
+      if (!lib) {
+        lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) { const char* e = dlerror(); if (e) why = e; }
+      }
+    if (!lib) return;
+    const char* missing = nullptr;
+#define SYM(field, name) \
+  do { r.field = (decltype(r.field))dlsym(lib, name); if (!r.field && !missing) missing = name; } while (0)
+    SYM(CreateProgram, "hiprtcCreateProgram"); SYM(CompileProgram, "hiprtcCompileProgram"); SYM(DestroyProgram, "hiprtcDestroyProgram");
+    SYM(AddNameExpression, "hiprtcAddNameExpression"); SYM(GetLoweredName, "hiprtcGetLoweredName"); SYM(GetCodeSize, "hiprtcGetCodeSize");
+    SYM(GetCode, "hiprtcGetCode"); SYM(GetProgramLogSize, "hiprtcGetProgramLogSize"); SYM(GetProgramLog, "hiprtcGetProgramLog");
+    SYM(GetErrorString, "hiprtcGetErrorString");
+#undef SYM
+    if (missing) why = std::string("symbol ") + missing + " not found in libhiprtc";
+    else r.lib = lib;
+  });
+  if (!r.lib) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "hiprtc (libhiprtc.so) could not be loaded: %s", why.c_str());
+  *out = &r;
+  return 0;
+}
+
+// the kernels of the launch-sequenced loop that depend on (model, n, m, T): ilqr_launch_f64.hip's list, by name
+const char* const kKernelExpr[RTC_NUM] = {
+    "altro_hip::ilqr_rollout_kernel<altro_hip::MODEL_USER, %d, %d, %s>",
+    "altro_hip::ilqr_accept_kernel<%d, %d, %s>",
+    "altro_hip::ilqr_expand_kernel<altro_hip::MODEL_USER, %d, %d, %s>",
+    "altro_hip::ilqr_merit_kernel<altro_hip::MODEL_USER, %d, %d, %s>",
+    "altro_hip::ilqr_merit_roll_kernel<altro_hip::MODEL_USER, %d, %d, %s>",
+    "altro_hip::ilqr_merit_point_kernel<altro_hip::MODEL_USER, %d, %d, %s>",
+    "altro_hip::ilqr_merit_sum_kernel<altro_hip::MODEL_USER, %d, %d, %s>",
+    "altro_hip::ilqr_spec_select_kernel<%d, %d, %s>",
+    "altro_hip::ilqr_zero_residuals_kernel<%s>",
+    "altro_hip::ilqr_stationarity_kernel<%d, %d, %s>",
+    "altro_hip::ilqr_dual_update_kernel<%d, %d, %s>",
+    "altro_hip::ilqr_shift_kernel<%d, %d, %s>",
+};
+
+std::string kernel_expr(int which, int n, int m, const char* T) {
+  char buf[256];
+  if (which == RTC_ZERO_RESIDUALS) std::snprintf(buf, sizeof(buf), kKernelExpr[which], T);
+  else std::snprintf(buf, sizeof(buf), kKernelExpr[which], n, m, T);
+  return buf;
+}
+
+}  // namespace
+
+namespace altro_hip {
+namespace capi {
+
+struct RtcModule {
+  hipModule_t module = nullptr;
+  hipFunction_t fn[RTC_NUM] = {};
+  int device = -1;
+};
+
+// Compile (or fetch) the module for (source, n, m, dtype) on the handle's device; nullptr + last_error on failure.
+static int rtc_module_for(altro_hip_batch* h, const std::string& user_src, RtcModule** out) {
+  *out = nullptr;
+  static std::mutex mu;
+  static std::map<std::string, RtcModule*> cache;
+  const char* T = h->dtype == ALTRO_HIP_F64 ? "double" : "float";
+  const std::string key = std::to_string(h->device) + "|" + std::to_string(h->n) + "|" + std::to_string(h->m) + "|" + T + "|" + user_src;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = cache.find(key);
+  if (it != cache.end()) { *out = it->second; return 0; }
+  const Hiprtc* R;
+  int rc = hiprtc_api(&R);
+  if (rc) return rc;
+  // the unit: the caller's two templates under contract(on) (like every device function the solve paths share), the
+  // library's kernels, and explicit instantiations of the ones this shape needs
+  std::string src = "#define ALTRO_HIP_USER_MODEL 1\n#include \"rtc_compat.h\"\n#include \"fp_contract.h\"\nALTRO_FP_REGION_ON\n";
+  src += "#line 1 \"user_model\"\n" + user_src + "\nALTRO_FP_REGION_END\n#include \"kernels/ilqr_lane.hip\"\nnamespace altro_hip {\n";
+  for (int w = 0; w < RTC_NUM; ++w) {
+    std::string e = kernel_expr(w, h->n, h->m, T);
+    e.erase(0, std::strlen("altro_hip::"));
+    for (size_t p; (p = e.find("altro_hip::")) != std::string::npos;) e.erase(p, std::strlen("altro_hip::"));
+    src += "template __global__ void " + e + "(IlqrArgs<" + T + ">);\n";
+  }
+  src += "}\n";
+  const char* hdr_src[] = {altro_rtc_src_rtc_compat, altro_rtc_src_fp_contract, altro_rtc_src_models, altro_rtc_src_linesearch,
+                           altro_rtc_src_ilqr_types, altro_rtc_src_al_types, altro_rtc_src_al_lane, altro_rtc_src_tvlqr_lane,
+                           altro_rtc_src_lane_body, altro_rtc_src_quad_body, altro_rtc_src_quad2_body, altro_rtc_src_ilqr_lane};
+  const char* hdr_name[] = {"rtc_compat.h", "fp_contract.h", "models.h", "linesearch_sm.h", "kernels/ilqr_types.h", "kernels/al_types.h",
+                            "kernels/al_lane.hip", "kernels/tvlqr_lane.hip", "kernels/tvlqr_lane_body.inc", "kernels/tvlqr_quad_body.inc",
+                            "kernels/tvlqr_quad2_body.inc", "kernels/ilqr_lane.hip"};
+  hiprtcProgram prog = nullptr;
+  hiprtcResult rr = R->CreateProgram(&prog, src.c_str(), "altro_user_model.hip", 12, hdr_src, hdr_name);
+  if (rr != HIPRTC_SUCCESS) return fail(ALTRO_HIP_ERR_HIP, "hiprtcCreateProgram: %s", R->GetErrorString(rr));
+  std::vector<std::string> exprs;
+  for (int w = 0; w < RTC_NUM; ++w) {
+    exprs.push_back(kernel_expr(w, h->n, h->m, T));
+    R->AddNameExpression(prog, exprs.back().c_str());
+  }
+  hipDeviceProp_t prop;
+  std::string arch = "--offload-arch=gfx950";
+  if (hipGetDeviceProperties(&prop, h->device) == hipSuccess) arch = std::string("--offload-arch=") + prop.gcnArchName;
+  const char* opts[] = {arch.c_str(), "-O3", "-std=c++17"};
+  rr = R->CompileProgram(prog, 3, opts);
+  if (rr != HIPRTC_SUCCESS) {
+    size_t ls = 0;
+    R->GetProgramLogSize(prog, &ls);
+    std::string log(ls, '\0');
+    if (ls) R->GetProgramLog(prog, &log[0]);
+    if (log.size() > 1800) log.resize(1800);
+    R->DestroyProgram(&prog);
+    return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "the model source does not compile (hiprtc: %s):\n%s", R->GetErrorString(rr), log.c_str());
+  }
+  size_t cs = 0;
+  R->GetCodeSize(prog, &cs);
+  std::vector<char> code(cs);
+  R->GetCode(prog, code.data());
+  RtcModule* m = new RtcModule();
+  m->device = h->device;
+  if (hipModuleLoadData(&m->module, code.data()) != hipSuccess) {
+    R->DestroyProgram(&prog);
+    delete m;
+    return fail(ALTRO_HIP_ERR_HIP, "hipModuleLoadData of the compiled model failed: %s", hipGetErrorString(hipGetLastError()));
+  }
+  for (int w = 0; w < RTC_NUM; ++w) {
+    const char* lowered = nullptr;
+    if (R->GetLoweredName(prog, exprs[w].c_str(), &lowered) != HIPRTC_SUCCESS || !lowered ||
+        hipModuleGetFunction(&m->fn[w], m->module, lowered) != hipSuccess) {
+      rc = fail(ALTRO_HIP_ERR_HIP, "kernel %s missing from the compiled model", exprs[w].c_str());
+      R->DestroyProgram(&prog);
+      (void)hipModuleUnload(m->module);
+      delete m;
+      return rc;
+    }
+  }
+  R->DestroyProgram(&prog);
+  cache[key] = m;
+  *out = m;
+  return 0;
+}
+
+// One kernel of the launch-sequenced loop from the handle's run-time module: the grids of ilqr_launch_kernel (ilqr_launch_f64.hip).
+template <typename T>
+int rtc_launch(altro_hip_batch* h, int which, const IlqrArgs<T>& a) {
+  RtcModule* mod = (RtcModule*)h->rtc;
+  if (!mod) return fail(ALTRO_HIP_ERR_NOT_SET, "altro_hip_set_model_source has not been called");
+  IlqrArgs<T> args = a;
+  void* params[] = {&args};
+  const unsigned lanes = (unsigned)((a.batch + 63) / 64);
+  const int64_t total = (int64_t)a.batch * (a.N + 1);
+  const unsigned flat = (unsigned)std::min<int64_t>((total + 255) / 256, 1 << 20);
+  const unsigned flat64 = (unsigned)std::min<int64_t>((total + 63) / 64, 1 << 20);
+  const unsigned trials = a.spec_trials > 1 ? a.spec_trials : 1;
+  auto go = [&](int w, unsigned gx, unsigned gy, unsigned bx) -> int {
+    const hipError_t e = hipModuleLaunchKernel(mod->fn[w], gx, gy, 1, bx, 1, 1, 0, h->stream, params, nullptr);
+    if (e != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "launch of %s failed: %s", kKernelExpr[w], hipGetErrorString(e));
+    return 0;
+  };
+  switch (which) {
+    case IK_ROLLOUT: return go(RTC_ROLLOUT, lanes, 1, 64);
+    case IK_ACCEPT: return go(RTC_ACCEPT, flat, 1, 256);
+    case IK_EXPAND: return go(RTC_EXPAND, flat64, 1, 64);
+    case IK_MERIT:
+      if (a.merit_jk) {
+        int rc = go(RTC_MERIT_ROLL, lanes, trials, 64);
+        if (!rc) rc = go(RTC_MERIT_POINT, flat64, trials, 64);
+        if (!rc) rc = go(RTC_MERIT_SUM, lanes, trials, 64);
+        return rc;
+      }
+      return go(RTC_MERIT, lanes, trials, 64);
+    case IK_SPEC_SELECT: return go(RTC_SPEC_SELECT, flat, 1, 256);
+    case IK_DUAL: return go(RTC_DUAL, flat, 1, 256);
+    case IK_SHIFT: return go(RTC_SHIFT, (unsigned)std::min<int64_t>(((int64_t)a.batch * (h->n + h->m) + 255) / 256, 1 << 20), 1, 256);
+    case IK_STATIONARITY: {
+      int rc = go(RTC_ZERO_RESIDUALS, (unsigned)((a.batch + 255) / 256), 1, 256);
+      if (!rc) rc = go(RTC_STATIONARITY, flat64, 1, 64);
+      return rc;
+    }
+    default: return fail(ALTRO_HIP_ERR_UNSUPPORTED, "operation %d has no run-time compiled kernel", which);
+  }
+}
+template int rtc_launch<double>(altro_hip_batch*, int, const IlqrArgs<double>&);
+template int rtc_launch<float>(altro_hip_batch*, int, const IlqrArgs<float>&);
+
+}  // namespace capi
+}  // namespace altro_hip
+
+extern "C" {
+
+int altro_hip_set_model_source(altro_hip_batch* h, const char* source, float timestep) {
+  int rc = check(h);
+  if (rc) return rc;
+  if (!source) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "source == NULL");
+  if (!(timestep > 0.0f)) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "time step must be positive (ErrorCodes::TimestepNotPositive)");
+  if (h->plan != ALTRO_HIP_PLAN_LANE)
+    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "run-time compiled models run on plan LANE (n <= 6, m <= 3); this handle is on plan %d with "
+                                           "(n, m) = (%d, %d)", h->plan, h->n, h->m);
+  HIP_TRY(hipSetDevice(h->device));
+  RtcModule* m = nullptr;
+  if ((rc = rtc_module_for(h, source, &m))) return rc;   // (altro_hip_last_error has the compiler's log)
+  h->rtc = m;
+  h->model = ModelParams{MODEL_USER, timestep, 0, 2.7, 1.5};
+  h->model_set = true;
+  return 0;
+}
+
+}  // extern "C"

@@ -14,8 +14,7 @@
 // state is the dual z: constraint values, estimated/projected duals, conic Jacobians and Hessians are
 // recomputed from (x, u, z, rho) wherever they are needed instead of being stored and re-read.
 #pragma once
-#include <hip/hip_runtime.h>
-#include <stdint.h>
+#include "../rtc_compat.h"
 
 #include "al_types.h"
 #include "tvlqr_lane.hip"   // LaneBuf / lane_ld row access

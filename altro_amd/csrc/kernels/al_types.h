@@ -1,7 +1,7 @@
 // al_types.h -- plain types of the augmented-Lagrangian constraint tables (shared by the kernels in
 // al_lane.hip and the host code of the C ABI, which fills them).
 #pragma once
-#include <stdint.h>
+#include "../rtc_compat.h"
 
 namespace altro_hip {
 

@@ -21,8 +21,7 @@
 //   cand [k][2n+m]   candidate           x_ | y_ | u_
 //   cost [k][2n+2m+1] Qd | Rd | q | r | c     (k = N: terminal)
 #pragma once
-#include <hip/hip_runtime.h>
-#include <stdint.h>
+#include "../rtc_compat.h"
 
 #include "../linesearch_sm.h"
 #include "../models.h"

@@ -1,8 +1,7 @@
 // ilqr_types.h -- plain argument / state types of the batched iLQR loop (shared by the kernels and by the host
 // code of the C ABI).  No kernels here: this header may be included by any translation unit.
 #pragma once
-#include <hip/hip_runtime.h>
-#include <stdint.h>
+#include "../rtc_compat.h"
 
 #include "../linesearch_sm.h"
 #include "../models.h"

@@ -15,8 +15,7 @@
 // a few hundred flops each.  Occupancy comes from the batch; nothing here tries to look like a GEMM.
 #pragma once
 #include "../fp_contract.h"
-#include <hip/hip_runtime.h>
-#include <stdint.h>
+#include "../rtc_compat.h"
 
 namespace altro_hip {
 

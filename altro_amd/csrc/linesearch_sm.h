@@ -9,7 +9,7 @@
 // exactly the trial steps the reference does (tests/test_linesearch_sm.py checks this against the
 // real reference code compiled into oracle/_ref).
 #pragma once
-#include <math.h>
+#include "rtc_compat.h"
 
 #if defined(__HIPCC__)
 #define ALTRO_LS_HD __host__ __device__ inline

@@ -10,7 +10,7 @@
 // `float h`: the reference passes the step as a C float; h/2 and (for the double integrator) h*h/2
 // are formed in float arithmetic before widening, which is reproduced here.
 #pragma once
-#include <math.h>
+#include "rtc_compat.h"
 
 #if defined(__HIPCC__)
 #define ALTRO_HD __host__ __device__ __forceinline__
@@ -27,7 +27,8 @@ ALTRO_FP_REGION_ON
 
 namespace altro_hip {
 
-enum ModelKind { MODEL_LINEAR = 0, MODEL_DOUBLE_INTEGRATOR = 1, MODEL_PENDULUM = 2, MODEL_BICYCLE = 3 };
+enum ModelKind { MODEL_LINEAR = 0, MODEL_DOUBLE_INTEGRATOR = 1, MODEL_PENDULUM = 2, MODEL_BICYCLE = 3,
+                 MODEL_USER = 4 /* altro_hip_set_model_source: the caller's own continuous dynamics, compiled at run time */ };
 
 struct ModelParams {
   int kind;
@@ -194,16 +195,32 @@ ALTRO_HD void bicycle_fJ(const ModelParams& mp, const T* x, const T* u, T* xdot,
 // axes are actuated -- m == dim is the reference's model, m < dim the C1 variant of SURVEY.md 8d).
 template <int KIND, int n, int m, typename T>
 struct DiscreteModel {
+  // MODEL_USER exists only in the unit hiprtc compiles for altro_hip_set_model_source (capi_rtc.hip): the caller's source --
+  // ahead of this header there -- defines, for T = double and float,
+  //     template <typename T> __device__ void altro_user_dynamics(const T* x, const T* u, T* xdot);     xdot = f(x, u)
+  //     template <typename T> __device__ void altro_user_jacobian(const T* x, const T* u, T* J);        J = [df/dx df/du],
+  // J column-major n x (n + m): what ALTROSolver::SetExplicitDynamics' two callbacks compute (altro_solver.cpp:68-81,
+  // typedefs.hpp:31-53) for a continuous model; the explicit-midpoint discretisation and its chain rule below are the
+  // reference's test harness (test/test_utils.cpp:84-132).
   static ALTRO_HD void cont_f(const ModelParams& mp, const T* x, const T* u, T* xdot) {
     if (KIND == MODEL_PENDULUM) pendulum_f<T>(x, u, xdot);
+#if defined(ALTRO_HIP_USER_MODEL)
+    else if (KIND == MODEL_USER) altro_user_dynamics<T>(x, u, xdot);
+#endif
     else bicycle_f<T>(mp, x, u, xdot);
   }
   static ALTRO_HD void cont_J(const ModelParams& mp, const T* x, const T* u, T* J) {
     if (KIND == MODEL_PENDULUM) pendulum_J<T>(x, u, J);
+#if defined(ALTRO_HIP_USER_MODEL)
+    else if (KIND == MODEL_USER) altro_user_jacobian<T>(x, u, J);
+#endif
     else bicycle_J<T>(mp, x, u, J);
   }
 
   static ALTRO_HD void cont_fJ(const ModelParams& mp, const T* x, const T* u, T* xdot, T* J) {
+#if defined(ALTRO_HIP_USER_MODEL)
+    if (KIND == MODEL_USER) { altro_user_dynamics<T>(x, u, xdot); altro_user_jacobian<T>(x, u, J); return; }
+#endif
     if (KIND == MODEL_PENDULUM) {   // one sincos for f (sin) and J (cos)
       const T l = T(0.5), g = T(9.81), b = T(0.1), mm = T(1.0) * l * l;
       T sn, cs;

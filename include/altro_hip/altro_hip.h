@@ -185,6 +185,18 @@ int altro_hip_get_qblocks(altro_hip_batch* h, double* qblocks);
 /* Device model standing in for SetExplicitDynamics' host callbacks (altro_solver.cpp:68-81).        */
 int altro_hip_set_model(altro_hip_batch* h, int model, float timestep, int bicycle_frame,
                         double bicycle_length, double bicycle_lr);
+/* ALTROSolver::SetExplicitDynamics (altro_solver.cpp:68-81) for the batched path, for dynamics the library does not ship:
+ * the caller's host callbacks (typedefs.hpp:31-53) cannot run on the device, so the caller hands their device-side SOURCE
+ * instead -- hand-written HIP, compiled with hiprtc into the library's own lane-per-problem kernels, once per (source, n, m,
+ * dtype) and process (plan LANE: n <= 6, m <= 3).  `source` must define, for T = double and T = float,
+ *     template <typename T> __device__ void altro_user_dynamics(const T* x, const T* u, T* xdot);   // xdot = f(x, u)
+ *     template <typename T> __device__ void altro_user_jacobian(const T* x, const T* u, T* J);      // J = [df/dx df/du],
+ * J column-major n x (n + m); the discretisation is the explicit midpoint rule with `timestep` (and its chain rule for
+ * A, B), as in the reference's own test models (test/test_utils.cpp:84-132).  No system headers: the HIP device API and
+ * the math functions (sin, cos, sincos, sqrt, ...) are built in.  A source that does not compile gives
+ * ALTRO_HIP_ERR_BAD_ARGUMENT with the compiler's log in altro_hip_last_error().  Whole solves of such a handle run on the
+ * launch-sequenced loop.                                                                                              */
+int altro_hip_set_model_source(altro_hip_batch* h, const char* source, float timestep);
 /* ALTROSolver::SetLQRCost (altro_solver.cpp:138-172): Qd, xref [batch][N+1][n]; Rd, uref [batch][N][m];
  * with k_stride_zero Qd/xref hold {running, terminal} and Rd/uref one knot point.                   */
 int altro_hip_set_tracking_cost(altro_hip_batch* h, const double* Qd, const double* Rd, const double* xref,
