@@ -37,7 +37,7 @@ C_ABI_SYMBOLS = [
     "altro_hip_stationarity", "altro_hip_get_nominal", "altro_hip_get_expansion",
     "altro_hip_default_solve_options", "altro_hip_ilqr_solve", "altro_hip_last_solve_counts",
     "altro_hip_linesearch_host",
-    "altro_hip_add_linear_constraint", "altro_hip_clear_constraints", "altro_hip_reset_duals",
+    "altro_hip_add_linear_constraint", "altro_hip_add_user_constraint", "altro_hip_clear_constraints", "altro_hip_reset_duals",
     "altro_hip_get_duals", "altro_hip_feasibility",
     "altro_hip_shift_trajectory", "altro_hip_update_linear_costs", "altro_hip_get_knot",
     "altro_hip_set_pointer_mode",
@@ -165,6 +165,7 @@ def lib():
         L.altro_hip_get_nominal.argtypes = [vp, vp, vp]
         L.altro_hip_get_expansion.argtypes = [vp, vp, vp, vp, vp]
         L.altro_hip_add_linear_constraint.argtypes = [vp, i, i, i, i, vp, vp, i]
+        L.altro_hip_add_user_constraint.argtypes = [vp, i, i, i, i, i]
         L.altro_hip_clear_constraints.argtypes = [vp]
         L.altro_hip_reset_duals.argtypes = [vp, d]
         L.altro_hip_get_duals.argtypes = [vp, i, i, vp]
@@ -380,6 +381,13 @@ class Batch:
         rc = self.L.altro_hip_add_linear_constraint(self.h, int(k_first), int(k_last), int(cone), int(G.shape[0]),
                                                     Gc.ctypes.data_as(C.c_void_p), g.ctypes.data_as(C.c_void_p),
                                                     per_problem)
+        if rc < 0:
+            _check(rc)
+        return rc
+
+    def add_user_constraint(self, k_first, k_last, cone, p, cid):
+        """Block `cid` of the constraints the run-time compiled source defines (altro_hip_add_user_constraint)."""
+        rc = self.L.altro_hip_add_user_constraint(self.h, int(k_first), int(k_last), int(cone), int(p), int(cid))
         if rc < 0:
             _check(rc)
         return rc

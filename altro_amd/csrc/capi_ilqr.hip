@@ -54,6 +54,7 @@ int al_upload_typed(altro_hip_batch* h) {
       const AlDef& d = defs[kn.def[j]];
       kn.z_off[j] = rows; rows += d.p;
       kn.cone[j] = d.cone; kn.p[j] = d.p; kn.g_per_problem[j] = d.g_per_problem; kn.G_off[j] = G_off_dev[kn.def[j]]; kn.g_off[j] = d.g_off;
+      kn.user[j] = d.user;
       // bound-type block: every row of G is +-e_idx
       const int w = h->n + h->m;
       bool sel = d.cone != CONE_SOC;
@@ -554,6 +555,22 @@ int altro_hip_add_linear_constraint(altro_hip_batch* h, int k_first, int k_last,
   }
   h->al_dirty = true;
   return id;
+}
+int altro_hip_add_user_constraint(altro_hip_batch* h, int k_first, int k_last, int cone, int p, int id) {
+  // ALTROSolver::SetConstraint with a general callback pair (altro_solver.cpp:192-223): value and Jacobian of block `id` come
+  // from the source given to altro_hip_set_model_source (altro_user_constraint / altro_user_constraint_jacobian)
+  int rc = check(h);
+  if (rc) return rc;
+  if (h->plan != ALTRO_HIP_PLAN_LANE || h->model.kind != MODEL_USER || !h->rtc_has_constraints)
+    return fail(ALTRO_HIP_ERR_NOT_SET, "altro_hip_set_model_source must come first, with a source that defines "
+                                       "altro_user_constraint and altro_user_constraint_jacobian (plan LANE)");
+  if (id < 0) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "constraint id %d", id);
+  std::vector<double> G((size_t)std::max(p, 0) * (h->n + h->m), 0.0), g((size_t)std::max(p, 0), 0.0);   // placeholders: never read
+  rc = altro_hip_add_linear_constraint(h, k_first, k_last, cone, p, G.data(), g.data(), 0);
+  if (rc < 0) return rc;
+  h->al_defs[rc].user = id + 1;
+  h->al_dirty = true;
+  return rc;
 }
 int altro_hip_clear_constraints(altro_hip_batch* h) {
   int rc = check(h);

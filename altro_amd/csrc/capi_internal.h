@@ -77,6 +77,7 @@ struct altro_hip_batch {
   int *i_active = nullptr, *i_counters = nullptr;
   // speculative backtracking (altro_hip_ilqr_solve): spare candidate trajectories, allocated on first use
   void* i_cand_spec = nullptr;
+  bool rtc_has_constraints = false;   // ... whose source also defines altro_user_constraint / _jacobian
   void* rtc = nullptr;            // run-time compiled model (capi_rtc.hip: RtcModule, shared through a per-process cache)
   int x0_stride = 0;              // elements between two problems' x0 on the device (12 on plan MFMA16, else n)
   int spare_count = 0;            // spare candidate trajectories i_cand_spec holds (sized to the path in use, see spec_trials_cap)

@@ -138,7 +138,9 @@ static int rtc_module_for(altro_hip_batch* h, const std::string& user_src, RtcMo
   if (rc) return rc;
   // the unit: the caller's two templates under contract(on) (like every device function the solve paths share), the
   // library's kernels, and explicit instantiations of the ones this shape needs
-  std::string src = "#define ALTRO_HIP_USER_MODEL 1\n#include \"rtc_compat.h\"\n#include \"fp_contract.h\"\nALTRO_FP_REGION_ON\n";
+  std::string src = "#define ALTRO_HIP_USER_MODEL 1\n";
+  if (user_src.find("altro_user_constraint_jacobian") != std::string::npos) src += "#define ALTRO_HIP_USER_CONSTRAINTS 1\n";
+  src += "#include \"rtc_compat.h\"\n#include \"fp_contract.h\"\nALTRO_FP_REGION_ON\n";
   src += "#line 1 \"user_model\"\n" + user_src + "\nALTRO_FP_REGION_END\n#include \"kernels/ilqr_lane.hip\"\nnamespace altro_hip {\n";
   for (int w = 0; w < RTC_NUM; ++w) {
     std::string e = kernel_expr(w, h->n, h->m, T);
@@ -263,6 +265,7 @@ int altro_hip_set_model_source(altro_hip_batch* h, const char* source, float tim
   RtcModule* m = nullptr;
   if ((rc = rtc_module_for(h, source, &m))) return rc;   // (altro_hip_last_error has the compiler's log)
   h->rtc = m;
+  h->rtc_has_constraints = std::string(source).find("altro_user_constraint_jacobian") != std::string::npos;
   h->model = ModelParams{MODEL_USER, timestep, 0, 2.7, 1.5};
   h->model_set = true;
   return 0;

@@ -125,6 +125,17 @@ __device__ __forceinline__ void soc_hessian(int p, const T* x, const T* bb, T* H
     }
 }
 
+// A block's Jacobian entry (row i, column col) and value: the shared G / the product G [x;u], or -- only in the unit hiprtc
+// compiles around a caller's source that defines them (capi_rtc.hip) -- the caller's own c(x, u) and dc/d[x;u]
+// (knotpoint_data.cpp:489-567 treats a general constraint exactly so: Gauss-Newton in its Jacobian).
+#if defined(ALTRO_HIP_USER_MODEL) && defined(ALTRO_HIP_USER_CONSTRAINTS)
+#define AL_G(i, col) (uid ? Guser[(i) + (col) * p] : (T)G[(i) + (col) * p])
+#define AL_CVAL(i, lin) (uid ? cuser[i] : (lin))
+#else
+#define AL_G(i, col) G[(i) + (col) * p]
+#define AL_CVAL(i, lin) (lin)
+#endif
+
 // All AL terms of one knot point of one problem.  Returns the AL cost; subtracts the gradient terms from
 // lx / lu (GRAD), adds the Gauss-Newton (+ SOC curvature) terms to lxx / luu / lux (HESS), and tracks the
 // largest constraint violation (viol != nullptr).  rho_est is the penalty the estimated duals were formed
@@ -148,6 +159,17 @@ __device__ __forceinline__ T al_eval(const AlTable<T>& t, int k, int64_t b, int6
     const T ALTRO_CONST_AS* gsh = (const T ALTRO_CONST_AS*)(t.g + kn.g_off[j]);   // shared right-hand side
     const T* gpb = t.g + kn.g_off[j] + b;                                         // per-problem right-hand side
     T* z = t.z + (int64_t)(kn.z_off[j] + zshift) * B + b;
+#if defined(ALTRO_HIP_USER_MODEL) && defined(ALTRO_HIP_USER_CONSTRAINTS)
+    const int uid = kn.user[j];
+    T Guser[AL_MAXP * w], cuser[AL_MAXP];
+    if (uid) {
+      T uu[m];
+#pragma unroll
+      for (int e = 0; e < m; ++e) uu[e] = terminal ? T(0) : u[e];
+      altro_user_constraint<T>(uid - 1, x, uu, cuser);
+      altro_user_constraint_jacobian<T>(uid - 1, x, uu, Guser);
+    }
+#endif
     if (cone != CONE_SOC && kn.sel[j]) {
       // Bound-type block (rows +-e_idx): the same arithmetic as the general branch below with the zero terms of
       // the dot products left out -- adding +-0 never changes a sum, so the results are bit-identical -- and
@@ -232,10 +254,10 @@ __device__ __forceinline__ T al_eval(const AlTable<T>& t, int k, int64_t b, int6
         zp[i] = T(0); msk[i] = T(0);
         if (i < p) {
           T s = T(0);
-          for (int e = 0; e < n; ++e) s += G[i + e * p] * x[e];
+          for (int e = 0; e < n; ++e) s += AL_G(i, e) * x[e];
           if (!terminal)
-            for (int e = 0; e < m; ++e) s += G[i + (n + e) * p] * u[e];
-          const T val = s - (gpp ? gpb[(int64_t)i * B] : gsh[i]);
+            for (int e = 0; e < m; ++e) s += AL_G(i, n + e) * u[e];
+          const T val = AL_CVAL(i, s) - (gpp ? gpb[(int64_t)i * B] : gsh[i]);
           const T ze = (zpre ? (j == 0 ? zpre[i] : zpre[AL_MAXP + i]) : z[(int64_t)i * B]) - rho_est * val;
           if (cone == CONE_EQUALITY) { zp[i] = ze; msk[i] = T(1); }                     // dual cone: identity
           else if (cone == CONE_INEQUALITY) { zp[i] = fmin(T(0), ze); msk[i] = (ze <= T(0)) ? T(1) : T(0); }
@@ -256,7 +278,7 @@ __device__ __forceinline__ T al_eval(const AlTable<T>& t, int k, int64_t b, int6
           T s = T(0);
 #pragma unroll
           for (int i = 0; i < AL_MAXP; ++i)
-            if (i < p) s += G[i + e * p] * (msk[i] * zp[i]);
+            if (i < p) s += AL_G(i, e) * (msk[i] * zp[i]);
           lx[e] -= s;
         }
         if (!terminal)
@@ -264,7 +286,7 @@ __device__ __forceinline__ T al_eval(const AlTable<T>& t, int k, int64_t b, int6
             T s = T(0);
 #pragma unroll
             for (int i = 0; i < AL_MAXP; ++i)
-              if (i < p) s += G[i + (n + e) * p] * (msk[i] * zp[i]);
+              if (i < p) s += AL_G(i, n + e) * (msk[i] * zp[i]);
             lu[e] -= s;
           }
       }
@@ -278,7 +300,7 @@ __device__ __forceinline__ T al_eval(const AlTable<T>& t, int k, int64_t b, int6
             T s = T(0);
 #pragma unroll
             for (int i = 0; i < AL_MAXP; ++i)
-              if (i < p) s += (msk[i] * G[i + ca * p]) * (msk[i] * G[i + cb * p]);
+              if (i < p) s += (msk[i] * AL_G(i, ca)) * (msk[i] * AL_G(i, cb));
             s = rho * s;
             if (ca < n) lxx[ca + cb * n] += s;
             else if (cb >= n) luu[(ca - n) + (cb - n) * m] += s;
@@ -292,10 +314,10 @@ __device__ __forceinline__ T al_eval(const AlTable<T>& t, int k, int64_t b, int6
         val[i] = T(0); ze[i] = T(0);
         if (i < p) {
           T s = T(0);
-          for (int e = 0; e < n; ++e) s += G[i + e * p] * x[e];
+          for (int e = 0; e < n; ++e) s += AL_G(i, e) * x[e];
           if (!terminal)
-            for (int e = 0; e < m; ++e) s += G[i + (n + e) * p] * u[e];
-          val[i] = s - (gpp ? gpb[(int64_t)i * B] : gsh[i]);
+            for (int e = 0; e < m; ++e) s += AL_G(i, n + e) * u[e];
+          val[i] = AL_CVAL(i, s) - (gpp ? gpb[(int64_t)i * B] : gsh[i]);
           ze[i] = (zpre ? (j == 0 ? zpre[i] : zpre[AL_MAXP + i]) : z[(int64_t)i * B]) - rho_est * val[i];
         }
       }
@@ -333,7 +355,7 @@ __device__ __forceinline__ T al_eval(const AlTable<T>& t, int k, int64_t b, int6
             T s = T(0);
 #pragma unroll
             for (int i = 0; i < AL_MAXSOC; ++i)
-              if (i < p) s += G[i + e * p] * jvp[i];
+              if (i < p) s += AL_G(i, e) * jvp[i];
             lx[e] -= s;
           }
           if (!terminal)
@@ -341,7 +363,7 @@ __device__ __forceinline__ T al_eval(const AlTable<T>& t, int k, int64_t b, int6
               T s = T(0);
 #pragma unroll
               for (int i = 0; i < AL_MAXSOC; ++i)
-                if (i < p) s += G[i + (n + e) * p] * jvp[i];
+                if (i < p) s += AL_G(i, n + e) * jvp[i];
               lu[e] -= s;
             }
         }
@@ -357,7 +379,7 @@ __device__ __forceinline__ T al_eval(const AlTable<T>& t, int k, int64_t b, int6
 #pragma unroll
               for (int r = 0; r < AL_MAXSOC; ++r)
                 if (r < p) {
-                  const T gre = G[r + e * p];
+                  const T gre = AL_G(r, e);
                   s1 += J[i + r * AL_MAXSOC] * gre;
                   s2 += Hp[i + r * AL_MAXSOC] * gre;
                 }
@@ -375,7 +397,7 @@ __device__ __forceinline__ T al_eval(const AlTable<T>& t, int k, int64_t b, int6
               for (int r = 0; r < AL_MAXSOC; ++r)
                 if (r < p) {
                   s1 += JG[r + ca * AL_MAXSOC] * JG[r + cb * AL_MAXSOC];
-                  s2 += G[r + ca * p] * HG[r + cb * AL_MAXSOC];
+                  s2 += AL_G(r, ca) * HG[r + cb * AL_MAXSOC];
                 }
               const T s = rho * s1 + rho * s2;
               if (ca < n) lxx[ca + cb * n] += s;

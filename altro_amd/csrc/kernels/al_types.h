@@ -16,6 +16,7 @@ struct AlDef {
   int cone, p, g_per_problem;
   int G_off;       // into the G pool (elements)
   int64_t g_off;   // into the g pool (elements): [p] shared, or [p][batch]
+  int user;        // 0: c = G [x;u] - g;  id + 1: rows and Jacobian come from the caller's run-time compiled source
 };
 struct AlKnot {          // everything a kernel needs about knot point k in ONE wave-uniform record
   int ncon;
@@ -27,6 +28,9 @@ struct AlKnot {          // everything a kernel needs about knot point k in ONE 
   // problem).  sel != 0 marks such a block; sidx[row] = +(idx + 1) or -(idx + 1).  The kernels then skip G.
   int sel[AL_MAXC];
   int sidx[AL_MAXC][AL_MAXP];
+  // id + 1 of a block whose value c(x, u) and Jacobian dc/d[x;u] the caller's source computes (altro_hip_add_user_constraint:
+  // ALTROSolver::SetConstraint with a general callback pair, altro_solver.cpp:192-223); 0 for c = G [x;u] - g
+  int user[AL_MAXC];
 };
 template <typename T>
 struct AlTable {

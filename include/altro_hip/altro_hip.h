@@ -197,6 +197,14 @@ int altro_hip_set_model(altro_hip_batch* h, int model, float timestep, int bicyc
  * ALTRO_HIP_ERR_BAD_ARGUMENT with the compiler's log in altro_hip_last_error().  Whole solves of such a handle run on the
  * launch-sequenced loop.                                                                                              */
 int altro_hip_set_model_source(altro_hip_batch* h, const char* source, float timestep);
+/* ALTROSolver::SetConstraint with a general (nonlinear) callback pair (altro_solver.cpp:192-223, typedefs.hpp:41-53): when
+ * the source above also defines
+ *     template <typename T> __device__ void altro_user_constraint(int id, const T* x, const T* u, T* c);            // c[p]
+ *     template <typename T> __device__ void altro_user_constraint_jacobian(int id, const T* x, const T* u, T* J);   // p x (n+m)
+ * (J column-major; u is zero at the terminal knot point), this registers block `id` of them -- p rows in `cone` at knot
+ * points k_first..k_last -- next to the linear blocks; the AL terms treat it as the reference treats any constraint
+ * (knotpoint_data.cpp:489-613: projected duals, Gauss-Newton in the Jacobian).  Returns the block id or a negative error. */
+int altro_hip_add_user_constraint(altro_hip_batch* h, int k_first, int k_last, int cone, int p, int id);
 /* ALTROSolver::SetLQRCost (altro_solver.cpp:138-172): Qd, xref [batch][N+1][n]; Rd, uref [batch][N][m];
  * with k_stride_zero Qd/xref hold {running, terminal} and Rd/uref one knot point.                   */
 int altro_hip_set_tracking_cost(altro_hip_batch* h, const double* Qd, const double* Rd, const double* xref,

@@ -162,3 +162,92 @@ def test_a_source_that_does_not_compile_says_why():
     with pytest.raises(altro_amd.AltroHipError):
         big.set_model_source(PENDULUM_SRC, 0.1)       # plan MFMA16: dynamics are data there
     bt.close(); big.close()
+
+
+GOAL_SRC = PENDULUM_SRC + r"""
+// block 0: the goal pin c = x - (pi, 0) (pendulum_test.cpp:117-203 writes it as a callback pair too)
+template <typename T> __device__ void altro_user_constraint(int id, const T* x, const T* u, T* c) {
+  (void)id; (void)u;
+  c[0] = x[0] - T(3.141592653589793);
+  c[1] = x[1];
+}
+template <typename T> __device__ void altro_user_constraint_jacobian(int id, const T* x, const T* u, T* J) {   // 2 x 3
+  (void)id; (void)x; (void)u;
+  J[0] = T(1); J[1] = T(0); J[2] = T(0); J[3] = T(1); J[4] = T(0); J[5] = T(0);
+}
+"""
+
+OBSTACLE_SRC = UNICYCLE_SRC + r"""
+// block 0: stay outside a disc of radius 0.4 around (1.0, 0.45):  r^2 - |p - c|^2 <= 0   (nonlinear, INEQUALITY)
+template <typename T> __device__ void altro_user_constraint(int id, const T* x, const T* u, T* c) {
+  (void)id; (void)u;
+  const T dx = x[0] - T(1.0), dy = x[1] - T(0.45);
+  c[0] = T(0.16) - dx * dx - dy * dy;
+}
+template <typename T> __device__ void altro_user_constraint_jacobian(int id, const T* x, const T* u, T* J) {   // 1 x 5
+  (void)id; (void)u;
+  J[0] = -T(2) * (x[0] - T(1.0)); J[1] = -T(2) * (x[1] - T(0.45)); J[2] = T(0); J[3] = T(0); J[4] = T(0);
+}
+"""
+
+
+def test_user_constraint_that_is_linear_matches_the_linear_block():
+    """The pendulum's goal pin as a run-time compiled constraint against the same pin as a linear block: same decisions,
+    same trajectory (the linear one goes through the bound-type fast path, the compiled one through the general rows)."""
+    batch = 70
+    out = []
+    for user in (True, False):
+        N, n, m = 50, 2, 1
+        h = np.float32(np.float32(3.0) / 50.0)
+        bt = altro_amd.Batch(N, n, m, batch)
+        bt.set_model_source(GOAL_SRC if user else PENDULUM_SRC, h)
+        xf = np.array([np.pi, 0.0])
+        bt.set_tracking_cost(np.array([[1e-2, 1e-2], [1.0, 1.0]]), np.array([[1e-3]]), np.stack([xf, xf]), np.zeros((1, m)),
+                             k_stride_zero=True, batch_stride_zero=True)
+        x0 = np.zeros((batch, n)); x0[:, 0] = problems.uniform01((batch,), 41) - 0.5
+        bt.set_initial_state(x0)
+        bt.set_input_guess(np.array([[[0.1]]]), k_stride_zero=True, batch_stride_zero=True)
+        if user:
+            bt.add_user_constraint(N, N, altro_amd.CONE_EQUALITY, 2, 0)
+        else:
+            G = np.zeros((2, 3)); G[0, 0] = 1.0; G[1, 1] = 1.0
+            bt.add_linear_constraint(N, N, altro_amd.CONE_EQUALITY, G, xf)
+        res = bt.ilqr_solve(iterations_max=40)
+        out.append((res, bt.get_nominal()))
+        bt.close()
+    (ra, (xa, ua)), (rb, (xb, ub)) = out
+    assert np.array_equal(ra["status"], rb["status"]) and np.array_equal(ra["iterations"], rb["iterations"])
+    assert np.array_equal(ra["dual_updates"], rb["dual_updates"])
+    assert np.abs(xa - xb).max() < 1e-9 and np.abs(ua - ub).max() < 1e-8
+    ok = ra["status"] == 0
+    assert ok.sum() > batch // 2 and (ra["feasibility"][ok] < 1e-4).all()
+
+
+def test_nonlinear_user_constraint_obstacle():
+    """A nonlinear inequality (a disc to stay out of) on the unicycle: the batch converges, every converged trajectory
+    clears the disc to the feasibility tolerance, and the unconstrained solve of the same problems does cut through it."""
+    N, n, m, batch = 40, 3, 2, 64
+    h = np.float32(0.1)
+    xf = np.array([2.0, 1.0, 0.0])
+    x0 = np.zeros((batch, n)); x0[:, 1] = (problems.uniform01((batch,), 47) - 0.5) * 0.2
+    worst = []
+    for constrained in (False, True):
+        bt = altro_amd.Batch(N, n, m, batch)
+        bt.set_model_source(OBSTACLE_SRC, h)
+        bt.set_tracking_cost(np.array([[1e-2] * 3, [50.0] * 3]), np.array([[1e-2, 1e-2]]), np.stack([xf, xf]), np.zeros((1, m)),
+                             k_stride_zero=True, batch_stride_zero=True)
+        bt.set_initial_state(x0)
+        bt.set_input_guess(np.array([[[0.5, 0.1]]]), k_stride_zero=True, batch_stride_zero=True)
+        if constrained:
+            bt.add_user_constraint(1, N, altro_amd.CONE_INEQUALITY, 1, 0)
+        res = bt.ilqr_solve(iterations_max=150, penalty_initial=10.0)
+        x, _ = bt.get_nominal()
+        clear = np.sqrt((x[:, :, 0] - 1.0) ** 2 + (x[:, :, 1] - 0.45) ** 2).min(axis=1)
+        ok = res["status"] == 0
+        assert ok.sum() >= batch - 6, (constrained, int(ok.sum()))
+        worst.append(clear[ok].min())
+        if constrained:
+            assert (res["feasibility"][ok] < 1e-4).all()
+            assert np.abs(x[ok][:, -1] - xf).max() < 0.15
+        bt.close()
+    assert worst[0] < 0.3 and worst[1] > 0.4 - 2e-3, worst
