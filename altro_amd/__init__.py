@@ -36,6 +36,7 @@ C_ABI_SYMBOLS = [
     "altro_hip_open_loop_rollout", "altro_hip_accept", "altro_hip_expand", "altro_hip_merit",
     "altro_hip_stationarity", "altro_hip_get_nominal", "altro_hip_get_expansion",
     "altro_hip_default_solve_options", "altro_hip_ilqr_solve", "altro_hip_last_solve_counts",
+    "altro_hip_ilqr_solve_async", "altro_hip_ilqr_poll", "altro_hip_ilqr_wait",
     "altro_hip_linesearch_host",
     "altro_hip_add_linear_constraint", "altro_hip_add_user_constraint", "altro_hip_clear_constraints", "altro_hip_reset_duals",
     "altro_hip_get_duals", "altro_hip_feasibility",
@@ -61,6 +62,11 @@ class SolveResult(C.Structure):
     _fields_ = [("status", C.c_int), ("iterations", C.c_int), ("stationarity", C.c_double),
                 ("final_alpha", C.c_double), ("final_phi", C.c_double), ("primal_feasibility", C.c_double),
                 ("penalty", C.c_double), ("dual_updates", C.c_int), ("reg_retries", C.c_int)]
+
+
+class PollRecord(C.Structure):
+    """altro_hip_poll_record: one problem's results + first input, published by the solve kernel when the problem stops."""
+    _fields_ = [("result", SolveResult), ("u0", C.c_double * 4), ("done", C.c_int), ("reserved", C.c_int)]
 
 
 class AltroHipError(RuntimeError):
@@ -178,6 +184,9 @@ def lib():
         L.altro_hip_default_solve_options.restype = None
         L.altro_hip_ilqr_solve.argtypes = [vp, C.POINTER(SolveOptions), vp]
         L.altro_hip_last_solve_counts.argtypes = [vp, C.POINTER(i), C.POINTER(i)]
+        L.altro_hip_ilqr_solve_async.argtypes = [vp, C.POINTER(SolveOptions)]
+        L.altro_hip_ilqr_poll.argtypes = [vp, C.POINTER(i), C.POINTER(C.POINTER(PollRecord))]
+        L.altro_hip_ilqr_wait.argtypes = [vp, vp]
         L.altro_hip_linesearch_host.argtypes = [MERIT_FN, vp, d, d, d, i, i, d, d, C.POINTER(i), C.POINTER(i),
                                                 C.POINTER(d), C.POINTER(d)]
         L.altro_hip_linesearch_host.restype = d
@@ -408,9 +417,9 @@ class Batch:
         _check(self.L.altro_hip_feasibility(self.h, out.ctypes.data_as(C.c_void_p)))
         return out
 
-    def ilqr_solve(self, iterations_max=200, tol_stationarity=1e-4, tol_meritfun_gradient=1e-8,
-                   use_backtracking=False, tol_primal_feasibility=1e-4, penalty_initial=1.0, penalty_scaling=10.0,
-                   penalty_max=1e8, reg_initial=0.0, reg_retry_max=0, reg_scale=10.0, reg_min=1e-6, reg_max=1e8):
+    def _solve_options(self, iterations_max=200, tol_stationarity=1e-4, tol_meritfun_gradient=1e-8,
+                       use_backtracking=False, tol_primal_feasibility=1e-4, penalty_initial=1.0, penalty_scaling=10.0,
+                       penalty_max=1e8, reg_initial=0.0, reg_retry_max=0, reg_scale=10.0, reg_min=1e-6, reg_max=1e8):
         o = SolveOptions()
         self.L.altro_hip_default_solve_options(C.byref(o))
         o.tol_primal_feasibility = tol_primal_feasibility
@@ -419,16 +428,43 @@ class Batch:
         o.reg_min, o.reg_max = reg_min, reg_max
         o.iterations_max, o.tol_stationarity = iterations_max, tol_stationarity
         o.tol_meritfun_gradient, o.use_backtracking_linesearch = tol_meritfun_gradient, int(use_backtracking)
+        return o
+
+    @staticmethod
+    def _results(rec, sweeps, merit_launches):
+        return dict(status=rec["status"].copy(), iterations=rec["iterations"].copy(),
+                    stationarity=rec["stationarity"].copy(), alpha=rec["final_alpha"].copy(), phi=rec["final_phi"].copy(),
+                    feasibility=rec["primal_feasibility"].copy(), penalty=rec["penalty"].copy(),
+                    dual_updates=rec["dual_updates"].copy(), reg_retries=rec["reg_retries"].copy(),
+                    sweeps=sweeps, merit_launches=merit_launches)
+
+    def ilqr_solve(self, **options):
+        o = self._solve_options(**options)
         res = (SolveResult * self.batch)()
         _check(self.L.altro_hip_ilqr_solve(self.h, C.byref(o), res))
         sw, ml = C.c_int(), C.c_int()
         self.L.altro_hip_last_solve_counts(self.h, C.byref(sw), C.byref(ml))
         rec = np.frombuffer(res, dtype=np.dtype(SolveResult))     # one view instead of 9 Python loops over the batch
-        return dict(status=rec["status"].copy(), iterations=rec["iterations"].copy(),
-                    stationarity=rec["stationarity"].copy(), alpha=rec["final_alpha"].copy(), phi=rec["final_phi"].copy(),
-                    feasibility=rec["primal_feasibility"].copy(), penalty=rec["penalty"].copy(),
-                    dual_updates=rec["dual_updates"].copy(), reg_retries=rec["reg_retries"].copy(),
-                    sweeps=sw.value, merit_launches=ml.value)
+        return self._results(rec, sw.value, ml.value)
+
+    def ilqr_solve_async(self, **options):
+        """Start the solve and return at once (altro_hip_ilqr_solve_async); follow with poll() / wait()."""
+        o = self._solve_options(**options)
+        _check(self.L.altro_hip_ilqr_solve_async(self.h, C.byref(o)))
+
+    def poll(self):
+        """(records published so far, numpy view [batch] of the pinned altro_hip_poll_record array -- fields result.*, u0, done)."""
+        n, recs = C.c_int(), C.POINTER(PollRecord)()
+        _check(self.L.altro_hip_ilqr_poll(self.h, C.byref(n), C.byref(recs)))
+        buf = (PollRecord * self.batch).from_address(C.addressof(recs.contents))
+        return n.value, np.frombuffer(buf, dtype=np.dtype(PollRecord))
+
+    def wait(self):
+        res = (SolveResult * self.batch)()
+        _check(self.L.altro_hip_ilqr_wait(self.h, res))
+        sw, ml = C.c_int(), C.c_int()
+        self.L.altro_hip_last_solve_counts(self.h, C.byref(sw), C.byref(ml))
+        return self._results(np.frombuffer(res, dtype=np.dtype(SolveResult)), sw.value, ml.value)
 
 
 class Comm:

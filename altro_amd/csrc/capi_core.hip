@@ -219,6 +219,8 @@ void altro_hip_batch_destroy(altro_hip_batch* h) {
                   h->i_cand_spec, h->i_spec_sel, h->i_spec_refresh, h->i_stat_done, h->st_partial, h->st_red, h->i_merit_jk, h->i_spec_jac, h->i_results};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->i_results_host) (void)hipHostFree(h->i_results_host);
+  if (h->poll_host) (void)hipHostFree(h->poll_host);
+  if (h->poll_count_host) (void)hipHostFree(h->poll_count_host);
   for (int a = 0; a < G_NUM; ++a) if (h->g_arr[a]) (void)hipFree(h->g_arr[a]);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);

@@ -622,12 +622,64 @@ int altro_hip_get_duals(altro_hip_batch* h, int k, int slot, double* z) {
   return 0;
 }
 
+// per-problem results gathered on the device into the struct's own layout: 56 bytes per problem cross PCIe, through pinned memory
+static int ilqr_gather_results(altro_hip_batch* h, altro_hip_solve_result* results) {
+  static_assert(sizeof(IlqrResult) == sizeof(altro_hip_solve_result), "IlqrResult mirrors altro_hip_solve_result");
+  static_assert(sizeof(IlqrPollRec) == sizeof(altro_hip_poll_record), "IlqrPollRec mirrors altro_hip_poll_record");
+  int rc;
+  const size_t bytes = (size_t)h->batch * sizeof(IlqrResult);
+  if (!h->i_results) {
+    if ((rc = dmalloc(h, &h->i_results, bytes))) return rc;
+    if (hipHostMalloc(&h->i_results_host, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); h->i_results_host = nullptr; }
+  }
+  if (ilqr_launch_results(h->stream, h->i_prob, (IlqrResult*)h->i_results, h->batch)) return fail(ALTRO_HIP_ERR_HIP, "results kernel launch failed");
+  void* stage = h->i_results_host ? h->i_results_host : (void*)results;
+  HIP_TRY(hipMemcpyAsync(stage, h->i_results, bytes, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (stage != (void*)results) std::memcpy(results, stage, bytes);
+  return 0;
+}
+
+int altro_hip_ilqr_solve_async(altro_hip_batch* h, const altro_hip_solve_options* opts) {
+  if (!h) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "null handle");
+  h->async_request = true;
+  const int rc = altro_hip_ilqr_solve(h, opts, nullptr);
+  h->async_request = false;
+  return rc;
+}
+int altro_hip_ilqr_poll(altro_hip_batch* h, int* n_done, const altro_hip_poll_record** records) {
+  if (!h) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "null handle");
+  if (!h->poll_host) return fail(ALTRO_HIP_ERR_NOT_SET, "altro_hip_ilqr_solve_async has not been called");
+  if (n_done) *n_done = __atomic_load_n(h->poll_count_host, __ATOMIC_ACQUIRE);
+  if (records) *records = (const altro_hip_poll_record*)h->poll_host;
+  return 0;
+}
+int altro_hip_ilqr_wait(altro_hip_batch* h, altro_hip_solve_result* results) {
+  int rc = check(h);
+  if (rc) return rc;
+  if (!h->poll_host) return fail(ALTRO_HIP_ERR_NOT_SET, "altro_hip_ilqr_solve_async has not been called");
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  h->async_pending = false;
+  int c4[4];
+  HIP_TRY(hipMemcpy(c4, h->i_counters, sizeof(c4), hipMemcpyDeviceToHost));
+  h->last_sweeps = c4[3];
+  h->last_merit_launches = 0;
+  if (results) return ilqr_gather_results(h, results);
+  return 0;
+}
+
 int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts,
                          altro_hip_solve_result* results) {
   // SolverImpl::Solve (solver.cpp:414-511) for every problem of the batch at once.  The host only
   // sequences launches and reads two counters per step; all per-problem decisions are on the device.
   int rc = ilqr_check(h, true);
   if (rc) return rc;
+  const bool async = h->async_request;
+  h->async_request = false;
+  if (h->async_pending) {   // a solve started with altro_hip_ilqr_solve_async is still out: finish it first
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->async_pending = false;
+  }
   altro_hip_solve_options o;
   if (opts) o = *opts;
   else altro_hip_default_solve_options(&o);
@@ -685,6 +737,21 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
   bool fused = fused_can && fused_want;
   if (fused && !ensure_spares(h, 3, spare_each))   // the waves' speculative steps (at most four per evaluation) need three
     fused = false;                                 // spare trajectories; without them THIS solve runs the sequenced loop
+  if (async) {   // results while the solve runs: only the one-launch path can publish them
+    if (!fused || std::getenv("ALTRO_HIP_FUSED_SWEEPS") != nullptr)
+      return fail(ALTRO_HIP_ERR_UNSUPPORTED, "altro_hip_ilqr_solve_async needs the one-launch solve kernel (plan LANE with a compiled-in "
+                                             "device model, default environment); use altro_hip_ilqr_solve");
+    const size_t bytes = (size_t)h->batch * sizeof(IlqrPollRec);
+    if (!h->poll_host) {
+      if (hipHostMalloc(&h->poll_host, bytes, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+          hipHostMalloc((void**)&h->poll_count_host, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(ALTRO_HIP_ERR_OUT_OF_MEMORY, "pinned host memory for %d poll records", h->batch);
+      }
+    }
+    std::memset(h->poll_host, 0, bytes);
+    *h->poll_count_host = 0;
+  }
   // initial rollout, make it the nominal trajectory, expand everything (solver.cpp:420-434) -- inside the fused kernel when
   // that runs (IlqrFusedArgs::prologue), five launches otherwise
   // (not for the 2-state shapes: their eight-wave kernel lives on 256 registers and spills; with the prologue's code in it
@@ -740,6 +807,12 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
     if (const char* e = std::getenv("ALTRO_HIP_FUSED_SWEEPS")) fused_sweeps = std::max(1, std::min(o.iterations_max, std::atoi(e)));
     HIP_TRY(hipMemsetAsync(h->i_counters, 0, 4 * sizeof(int), h->stream));
     IlqrFusedArgs fa{0, fused_sweeps, o.reg_retry_max, reg_on ? 1 : 0, h->i_counters, nullptr, fused_prologue ? 1 : 0};
+    if (async) {
+      void *dp = nullptr, *dc = nullptr;
+      HIP_TRY(hipHostGetDevicePointer(&dp, h->poll_host, 0));
+      HIP_TRY(hipHostGetDevicePointer(&dc, h->poll_count_host, 0));
+      fa.poll = (IlqrPollRec*)dp; fa.poll_count = (int*)dc;
+    }
     const int clk_G = ilqr_fused_group(h->batch);
     const int clk_groups = (h->batch + clk_G - 1) / clk_G;
     unsigned long long* clk = nullptr;     // ALTRO_HIP_FUSED_CLOCK: per-phase time of the kernel, printed to stderr
@@ -761,6 +834,12 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
     }
     if (frc) return fail(ALTRO_HIP_ERR_HIP, "fused iLQR kernel launch failed");
     h->backward_done = true;
+    if (async) {   // the caller polls; altro_hip_ilqr_wait finishes the bookkeeping
+      h->async_pending = true;
+      h->forward_done = true;
+      h->solve_done = true;
+      return 0;
+    }
     int c4[4];
     HIP_TRY(hipMemcpyAsync(c4, h->i_counters, sizeof(c4), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -917,19 +996,7 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
   h->forward_done = true;
   h->solve_done = true;
   HIP_TRY(hipStreamSynchronize(h->stream));   // (iterations_max <= 0 reaches this point with kernels still in flight)
-  if (results) {   // gathered on the device into the struct's own layout: 56 bytes per problem cross PCIe, through pinned memory
-    static_assert(sizeof(IlqrResult) == sizeof(altro_hip_solve_result), "IlqrResult mirrors altro_hip_solve_result");
-    const size_t bytes = (size_t)h->batch * sizeof(IlqrResult);
-    if (!h->i_results) {
-      if ((rc = dmalloc(h, &h->i_results, bytes))) return rc;
-      if (hipHostMalloc(&h->i_results_host, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); h->i_results_host = nullptr; }
-    }
-    if (ilqr_launch_results(h->stream, h->i_prob, (IlqrResult*)h->i_results, h->batch)) return fail(ALTRO_HIP_ERR_HIP, "results kernel launch failed");
-    void* stage = h->i_results_host ? h->i_results_host : (void*)results;
-    HIP_TRY(hipMemcpyAsync(stage, h->i_results, bytes, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    if (stage != (void*)results) std::memcpy(results, stage, bytes);
-  }
+  if (results && (rc = ilqr_gather_results(h, results))) return rc;
   h->last_sweeps = sweeps;
   h->last_merit_launches = total_merit_launches;
   return 0;

@@ -77,6 +77,9 @@ struct altro_hip_batch {
   int *i_active = nullptr, *i_counters = nullptr;
   // speculative backtracking (altro_hip_ilqr_solve): spare candidate trajectories, allocated on first use
   void* i_cand_spec = nullptr;
+  // altro_hip_ilqr_solve_async / _poll / _wait: pinned records the fused kernel publishes into while it runs
+  void* poll_host = nullptr; int* poll_count_host = nullptr;
+  bool async_request = false, async_pending = false;
   bool rtc_has_constraints = false;   // ... whose source also defines altro_user_constraint / _jacobian
   void* rtc = nullptr;            // run-time compiled model (capi_rtc.hip: RtcModule, shared through a per-process cache)
   int x0_stride = 0;              // elements between two problems' x0 on the device (12 on plan MFMA16, else n)

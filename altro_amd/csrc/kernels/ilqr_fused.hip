@@ -69,6 +69,7 @@ __global__ __launch_bounds__((64 * ilqr_fused_waves<n, T>())) void ilqr_fused_sw
   const bool serial = ks == 0 && valid;           // the lanes of a wave that run a lane-per-problem chain
   const bool lead = w == 0 && serial;             // wave 0 keeps the per-problem books
   int sweeps = 0;
+  bool published = false;                         // (lead lanes) this problem's record has gone out to the host (fa.poll)
   // optional phase clock (ALTRO_HIP_FUSED_CLOCK, a tuning aid): 100 MHz ticks per phase and workgroup
   unsigned long long tick = fa.clk ? wall_clock64() : 0ull;
   auto lap = [&](int phase) {
@@ -313,6 +314,18 @@ __global__ __launch_bounds__((64 * ilqr_fused_waves<n, T>())) void ilqr_fused_sw
       __syncthreads();
     }
     lap(11);
+    // altro_hip_ilqr_solve_async: a problem that stopped in this sweep goes out NOW -- its results and the first input of its
+    // solution into the caller's pinned record, then the flag, then the count -- while the rest of the batch keeps iterating
+    if (fa.poll && lead && !published && !la.prob[bi].running) {
+      IlqrPollRec* rec = fa.poll + bi;
+      rec->result = ilqr_result_of(la.prob[bi]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) rec->u0[e] = e < m ? (double)a.nom[((int64_t)n + e) * B + b] : 0.0;
+      __threadfence_system();
+      __hip_atomic_store(&rec->done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_fetch_add(fa.poll_count, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      published = true;
+    }
   }
 #undef FUSED_FOR_K
   // hand-back: how many problems the launch leaves running, how many sweeps its slowest workgroup took

@@ -13,18 +13,7 @@ namespace altro_hip {
 __global__ void ilqr_results_kernel(const IlqrProb* __restrict__ prob, IlqrResult* __restrict__ out, int batch) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= batch) return;
-  const IlqrProb& p = prob[b];
-  IlqrResult r;
-  r.status = p.status;
-  r.iterations = p.iterations;
-  r.stationarity = p.stationarity;
-  r.final_alpha = p.alpha;
-  r.final_phi = p.ls_iters > 0 ? p.ls.phi : p.phi0;
-  r.primal_feasibility = p.feasibility;
-  r.penalty = p.rho;
-  r.dual_updates = p.n_dual_updates;
-  r.reg_retries = p.reg_retries;
-  out[b] = r;
+  out[b] = ilqr_result_of(prob[b]);
 }
 
 // ---- batched line search + sweep bookkeeping (one thread per problem) ---------------------------------

@@ -91,6 +91,21 @@ __device__ __forceinline__ bool ilqr_penalty_update_logic(IlqrProb& p, const Ilq
   return p.dual != 0;
 }
 
+// AltroStats of one problem (solver.cpp:503-509) in the layout the C ABI hands out
+__device__ __forceinline__ IlqrResult ilqr_result_of(const IlqrProb& p) {
+  IlqrResult r;
+  r.status = p.status;
+  r.iterations = p.iterations;
+  r.stationarity = p.stationarity;
+  r.final_alpha = p.alpha;
+  r.final_phi = p.ls_iters > 0 ? p.ls.phi : p.phi0;
+  r.primal_feasibility = p.feasibility;
+  r.penalty = p.rho;
+  r.dual_updates = p.n_dual_updates;
+  r.reg_retries = p.reg_retries;
+  return r;
+}
+
 // ---- one problem's share of each bookkeeping step, on the per-batch arrays of IlqrLoopArgs: the bodies of the
 //      one-thread-per-problem kernels (ilqr_loop_kernels.hip), also called by the fused solve kernel -----------------------
 

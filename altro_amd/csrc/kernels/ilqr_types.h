@@ -152,6 +152,20 @@ enum IlqrLoopKernel { ILK_LOOP_INIT, ILK_LS_BEGIN, ILK_LS_FEED, ILK_FINISH_ITER,
 template <typename T>
 struct LaneArgs;   // kernels/tvlqr_lane.hip
 constexpr int ILQR_FUSED_PHASES = 12;   // IlqrFusedArgs::clk
+// What a solve reports per problem, gathered on the device in the layout of altro_hip_solve_result (altro_hip.h): the host
+// copies 56 bytes per problem instead of the 280-byte control blocks.
+struct IlqrResult {
+  int status, iterations;
+  double stationarity, final_alpha, final_phi, primal_feasibility, penalty;
+  int dual_updates, reg_retries;
+};
+// altro_hip_ilqr_solve_async / _poll: one record per problem in pinned host memory, published by the fused solve kernel the
+// moment the problem stops (mirror of altro_hip_poll_record, altro_hip.h)
+struct IlqrPollRec {
+  IlqrResult result;
+  double u0[4];        // the first input of the solution (what a receding-horizon caller applies)
+  int done, reserved;
+};
 struct IlqrFusedArgs {
   int first_iter;     // index of the first sweep this launch runs (0 right after the initial rollout / expansion)
   int max_sweeps;     // sweeps to run at most in this launch
@@ -161,6 +175,8 @@ struct IlqrFusedArgs {
   unsigned long long* clk;   // optional [workgroups][ILQR_FUSED_PHASES] phase clock (100 MHz ticks), a tuning aid
   int prologue;       // 1: the launch starts with the head of Solve (solver.cpp:420-434): control blocks, initial rollout,
                       //    accept, first expansion, SetPenalty -- what the host enqueues as five launches otherwise
+  IlqrPollRec* poll = nullptr;   // optional [batch], pinned host memory: results published while the launch still runs
+  int* poll_count = nullptr;     // optional, pinned: number of records published so far
 };
 template <typename T, int G>   // G problems per workgroup: one translation unit each (ilqr_fused_unit.inc)
 int ilqr_launch_fused_g(hipStream_t stream, int kind, int n, int m, const IlqrArgs<T>& a, const IlqrLoopArgs& la,
@@ -181,13 +197,6 @@ bool ilqr_supported(int kind, int n, int m);
 template <typename T>
 int ilqr_launch_kernel(hipStream_t stream, int which, int kind, int n, int m, const IlqrArgs<T>& a);
 int ilqr_launch_loop(hipStream_t stream, int which, const IlqrLoopArgs& a);
-// What a solve reports per problem, gathered on the device in the layout of altro_hip_solve_result (altro_hip.h): the host
-// copies 56 bytes per problem instead of the 280-byte control blocks.
-struct IlqrResult {
-  int status, iterations;
-  double stationarity, final_alpha, final_phi, primal_feasibility, penalty;
-  int dual_updates, reg_retries;
-};
 int ilqr_launch_results(hipStream_t stream, const IlqrProb* prob, IlqrResult* out, int batch);
 
 }  // namespace altro_hip

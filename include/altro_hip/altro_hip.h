@@ -293,6 +293,26 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
                          altro_hip_solve_result* results);
 int altro_hip_last_solve_counts(const altro_hip_batch* h, int* sweeps, int* merit_launches);
 
+/* Results WHILE the batch still solves.  A batched solve lasts as long as its slowest problem (8192 steering-bounded bicycles:
+ * 3.3 sweeps on average, a handful run all 80), but an MPC caller can use every problem the moment it stops.  On the
+ * one-launch path (plan LANE with a compiled-in device model) the solve kernel publishes each problem into a record in
+ * pinned host memory when it stops: its AltroStats and the first input of its solution.
+ *   altro_hip_ilqr_solve_async  starts the solve and returns at once (ALTRO_HIP_ERR_UNSUPPORTED where only the
+ *                               launch-sequenced loop can run: use altro_hip_ilqr_solve there)
+ *   altro_hip_ilqr_poll         never blocks: *n_done = records published so far, *records = the [batch] array (valid until
+ *                               the handle's next solve or its destruction); record b is complete once records[b].done != 0
+ *   altro_hip_ilqr_wait         blocks until the launch has ended; results [batch] as altro_hip_ilqr_solve fills them (may be
+ *                               NULL).  Any other call on the handle waits for the launch as well.                          */
+typedef struct altro_hip_poll_record {
+  altro_hip_solve_result result;
+  double u0[4];      /* u_0 of the solution (entries >= m are 0): what a receding-horizon loop applies (bicycle_test.cpp:313) */
+  int done;          /* set last (release order) */
+  int reserved;
+} altro_hip_poll_record;
+int altro_hip_ilqr_solve_async(altro_hip_batch* h, const altro_hip_solve_options* opts);
+int altro_hip_ilqr_poll(altro_hip_batch* h, int* n_done, const altro_hip_poll_record** records);
+int altro_hip_ilqr_wait(altro_hip_batch* h, altro_hip_solve_result* results);
+
 /* The batched solver's line search is CubicLineSearch (src/linesearch/linesearch.cpp:37-412) recast as
  * a resumable state machine (altro_amd/csrc/linesearch_sm.h).  This host entry drives that same code
  * with a callback so that it can be pinned against the reference line search without a GPU.         */
