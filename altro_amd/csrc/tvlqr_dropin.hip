@@ -40,11 +40,15 @@ int tvlqr_TotalMemSize(const int* nx, const int* nu, int num_horizon, bool is_di
 namespace {
 
 // Cached per thread: no allocation after the first call of a given size, and -- a solver calls these entries with the same
-// dimensions iteration after iteration -- no table upload after the first call of a given layout.  One call is one
-// host-to-device copy of the arena (from pinned memory), one single-wave kernel and one copy back; the status word and
-// the forward pass's x0 travel inside the arena.
+// dimensions iteration after iteration -- no table upload after the first call of a given layout.  One call is ONE
+// asynchronous host-to-device copy of the INPUT blocks (the arena's prefix, from pinned memory), one single-wave kernel
+// that writes its OUTPUT blocks, the status word and delta_V straight into the pinned arena (mapped into the device's
+// address space: posted PCIe writes, nobody waits on them) and one wait on a private stream -- round 2 copied the whole
+// arena both ways with two blocking copies.
 struct Workspace {
   double* dev = nullptr;
+  double* host_dev = nullptr;     // the pinned arena as the device sees it
+  hipStream_t stream = nullptr;
   size_t dev_elems = 0;
   int64_t* dev_off = nullptr;
   int* dev_dims = nullptr;
@@ -59,6 +63,7 @@ struct Workspace {
     if (dev_off) (void)hipFree(dev_off);
     if (dev_dims) (void)hipFree(dev_dims);
     if (host) (void)hipHostFree(host);
+    if (stream) (void)hipStreamDestroy(stream);
   }
 };
 thread_local Workspace g_ws;
@@ -80,6 +85,7 @@ struct Layout {
   int N;
   std::vector<int64_t> off;   // [(N+1) * G_NUM]
   int64_t total;
+  int64_t group_end[4];       // arena offset where each group of arrays ends
   int nmax, mmax;
 };
 
@@ -99,21 +105,29 @@ int64_t block_size(int arr, int n, int m, int n2, bool is_diag) {
   }
 }
 
+// Arena order: [A B f of every k] [Q R H q r of every k] [K d P p of every k] [everything else] [x0 | delta_V | status].
+// The backward pass's inputs are the first two groups, the forward pass's the first three: one contiguous copy each.
 Layout make_layout(const int* nx, const int* nu, int N, bool is_diag) {
   Layout L;
   L.N = N;
   L.off.assign((size_t)(N + 1) * G_NUM, 0);
   L.nmax = 0; L.mmax = 0;
   int64_t cur = 0;
-  for (int k = 0; k <= N; ++k) {
-    const int n = nx[k], m = (k < N) ? nu[k] : 0, n2 = (k < N) ? nx[k + 1] : 0;
-    if (n > L.nmax) L.nmax = n;
-    if (m > L.mmax) L.mmax = m;
-    for (int a = 0; a < G_NUM; ++a) {
-      const bool has_terminal = (a == G_Q || a == G_q || a == G_P || a == G_p || a == G_x || a == G_y);
-      L.off[(size_t)k * G_NUM + a] = cur;
-      if (k < N || has_terminal) cur += (block_size(a, n, m, n2, is_diag) + 1) & ~int64_t(1);   // keep 16-B alignment
+  auto group_of = [](int a) { return (a == G_A || a == G_B || a == G_f) ? 0 : (a == G_Q || a == G_R || a == G_H || a == G_q || a == G_r) ? 1
+                                     : (a == G_K || a == G_d || a == G_P || a == G_p) ? 2 : 3; };
+  for (int g = 0; g < 4; ++g) {
+    for (int k = 0; k <= N; ++k) {
+      const int n = nx[k], m = (k < N) ? nu[k] : 0, n2 = (k < N) ? nx[k + 1] : 0;
+      if (n > L.nmax) L.nmax = n;
+      if (m > L.mmax) L.mmax = m;
+      for (int a = 0; a < G_NUM; ++a) {
+        if (group_of(a) != g) continue;
+        const bool has_terminal = (a == G_Q || a == G_q || a == G_P || a == G_p || a == G_x || a == G_y);
+        L.off[(size_t)k * G_NUM + a] = cur;
+        if (k < N || has_terminal) cur += (block_size(a, n, m, n2, is_diag) + 1) & ~int64_t(1);   // keep 16-B alignment
+      }
     }
+    L.group_end[g] = cur;
   }
   L.total = cur + 32 + 4;   // + x0 staging (<= 32) + delta_V[2] (+pad) at the end
   return L;
@@ -128,11 +142,15 @@ int prepare(Workspace& w, const Layout& L, const int* nx, const int* nu) {
     if (w.host) (void)hipHostFree(w.host);
     w.host = nullptr;
     if (hipMalloc(&w.dev, (size_t)L.total * sizeof(double)) != hipSuccess) { w.dev = nullptr; return -1; }
-    if (hipHostMalloc((void**)&w.host, (size_t)L.total * sizeof(double), hipHostMallocDefault) != hipSuccess) {
-      (void)hipFree(w.dev); w.dev = nullptr; w.host = nullptr; return -1;
+    if (hipHostMalloc((void**)&w.host, (size_t)L.total * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&w.host_dev, w.host, 0) != hipSuccess) {
+      (void)hipFree(w.dev); w.dev = nullptr;
+      if (w.host) (void)hipHostFree(w.host);
+      w.host = nullptr; return -1;
     }
     w.dev_elems = (size_t)L.total;
   }
+  if (!w.stream && hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking) != hipSuccess) { w.stream = nullptr; return -1; }
   if (w.table_k < (size_t)(N + 1)) {
     if (w.dev_off) (void)hipFree(w.dev_off);
     if (w.dev_dims) (void)hipFree(w.dev_dims);
@@ -157,16 +175,18 @@ int prepare(Workspace& w, const Layout& L, const int* nx, const int* nu) {
   return 0;
 }
 
-GenericArgs<double> make_args(Workspace& w, const Layout& L, double reg, bool is_diag, int want_y) {
+// `inputs_end`: arrays laid out below this arena offset are read from the device copy, everything else -- outputs, scratch
+// twins, delta_V, the status word, the forward pass's x0 -- lives in the pinned arena itself
+GenericArgs<double> make_args(Workspace& w, const Layout& L, double reg, bool is_diag, int want_y, int64_t inputs_end) {
   GenericArgs<double> a;
-  for (int i = 0; i < G_NUM; ++i) { a.base[i] = w.dev; a.bstride[i] = 0; }
+  for (int i = 0; i < G_NUM; ++i) { a.base[i] = (L.off[i] < inputs_end) ? w.dev : w.host_dev; a.bstride[i] = 0; }
   a.off = w.dev_off;
   a.nx = w.dev_dims;
   a.nu = w.dev_dims + (L.N + 1);
-  a.x0 = w.dev + L.total - 4;   // overwritten by the forward entry point
+  a.x0 = w.host_dev + L.total - 36;
   a.x0_stride = 0;
-  a.delta_V = w.dev + L.total - 4;
-  a.status = reinterpret_cast<int*>(w.dev + L.total - 2);   // the arena's last two elements are padding: the status word rides back with it
+  a.delta_V = w.host_dev + L.total - 4;
+  a.status = reinterpret_cast<int*>(w.host_dev + L.total - 2);   // the arena's last two elements are padding: the status word lives there
   a.N = L.N; a.batch = 1; a.nmax = L.nmax; a.mmax = L.mmax > 0 ? L.mmax : 1;
   a.reg = reg; a.is_diag = is_diag ? 1 : 0; a.store_q = 2; a.want_y = want_y;
   return a;
@@ -209,12 +229,12 @@ int tvlqr_BackwardPass(const int* nx, const int* nu, int num_horizon, const lqr_
       put(G_r, k, r[k], m);
     }
   }
-  if (hipMemcpy(w.dev, hs, (size_t)L.total * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return TVLQR_NO_DEVICE;
-  GenericArgs<double> a = make_args(w, L, reg, is_diag, 0);
+  if (hipMemcpyAsync(w.dev, hs, (size_t)L.group_end[1] * sizeof(double), hipMemcpyHostToDevice, w.stream) != hipSuccess) return TVLQR_NO_DEVICE;
+  GenericArgs<double> a = make_args(w, L, reg, is_diag, 0, L.group_end[1]);
   const size_t lds = generic_backward_lds_bytes<double>(a.nmax, a.mmax);
-  hipLaunchKernelGGL(generic_backward_kernel<double>, dim3(1), dim3(64), lds, 0, a);
+  hipLaunchKernelGGL(generic_backward_kernel<double>, dim3(1), dim3(64), lds, w.stream, a);
   if (hipGetLastError() != hipSuccess) return TVLQR_NO_DEVICE;
-  if (hipMemcpy(hs, w.dev, (size_t)L.total * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return TVLQR_NO_DEVICE;
+  if (hipStreamSynchronize(w.stream) != hipSuccess) return TVLQR_NO_DEVICE;
   int status;
   memcpy(&status, hs + L.total - 2, sizeof(int));
   auto get = [&](int arr, int k, double* dst, int64_t cnt) {
@@ -281,14 +301,12 @@ int tvlqr_ForwardPass(const int* nx, const int* nu, int num_horizon, const lqr_f
     }
   }
   memcpy(hs + L.total - 36, x0, sizeof(double) * nx[0]);
-  if (hipMemcpy(w.dev, hs, (size_t)L.total * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return TVLQR_NO_DEVICE;
-  double* dev_x0 = w.dev + L.total - 36;
-  GenericArgs<double> a = make_args(w, L, 0.0, false, y ? 1 : 0);
-  a.x0 = dev_x0;
+  if (hipMemcpyAsync(w.dev, hs, (size_t)L.group_end[2] * sizeof(double), hipMemcpyHostToDevice, w.stream) != hipSuccess) return TVLQR_NO_DEVICE;
+  GenericArgs<double> a = make_args(w, L, 0.0, false, y ? 1 : 0, L.group_end[2]);
   const size_t lds = (size_t)(2 * a.nmax + a.mmax) * sizeof(double) + 64;
-  hipLaunchKernelGGL(generic_forward_kernel<double>, dim3(1), dim3(64), lds, 0, a);
+  hipLaunchKernelGGL(generic_forward_kernel<double>, dim3(1), dim3(64), lds, w.stream, a);
   if (hipGetLastError() != hipSuccess) return TVLQR_NO_DEVICE;
-  if (hipMemcpy(hs, w.dev, (size_t)L.total * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return TVLQR_NO_DEVICE;
+  if (hipStreamSynchronize(w.stream) != hipSuccess) return TVLQR_NO_DEVICE;
   for (int k = 0; k <= N; ++k) {
     memcpy(x[k], hs + L.off[(size_t)k * G_NUM + G_x], sizeof(double) * nx[k]);
     if (y) memcpy(y[k], hs + L.off[(size_t)k * G_NUM + G_y], sizeof(double) * nx[k]);
