@@ -21,9 +21,14 @@ int lane_launch(altro_hip_batch* h, bool backward, double reg) {
   const dim3 grid(8 * (((h->batch + 63) / 64 + 7) / 8)), block(64);
   const bool fused = (h->flags & ALTRO_HIP_LANE_FUSED) != 0;
   // (4, 2) and (2, 1): four lanes per problem (kernels/tvlqr_quad_body.inc, tvlqr_quad2_body.inc), same records, bit-identical
-  // results; ALTRO_HIP_LANE_QUAD=0 keeps the lane-per-problem sweep
+  // results -- while the batch leaves the chip idle.  Measured on MI355X (tools/c3_quad_ab.sh, profiles/r03i_quad_ab.txt,
+  // backward + forward ms, quad / lane-per-problem): (4, 2) 0.12 / 0.21 at 4096 problems, 0.16 / 0.23 at 8192, 0.28 / 0.27 at
+  // 16384, 0.56 / 0.44 at 32768, 1.10 / 0.84 at 65536; (2, 1) 0.10 / 0.12, 0.11 / 0.12, 0.16 / 0.14, 0.31 / 0.25, 0.60 / 0.49.
+  // The quad form shortens the chain of one wave (what bounds small batches); once every SIMD has its waves the sweep is
+  // HBM-bound and the lane-per-problem form's 512-byte runs stream better than the quad's four 128-byte segments.
+  // ALTRO_HIP_LANE_QUAD=0 / 1 forces one or the other.
   const char* qe = std::getenv("ALTRO_HIP_LANE_QUAD");
-  const bool quad_on = !(qe && std::atoi(qe) == 0);
+  const bool quad_on = qe ? std::atoi(qe) != 0 : h->batch <= 12288;
   const bool q42 = h->n == 4 && h->m == 2, q21 = h->n == 2 && h->m == 1;
   if (backward) h->bwd_quad = quad_on && (q42 || q21);
   if (!backward && quad_on && q42) {   // forward sweep of (4, 2): four lanes per problem as well

@@ -1,0 +1,17 @@
+#!/bin/bash
+# quad (four lanes per problem) against lane-per-problem sweeps of the (4, 2) and (2, 1) shapes over the batch size
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/${1:-r03i}_quad_ab.txt
+echo "# bench.py --config c3|c2 --batch B, ALTRO_HIP_LANE_QUAD=1|0: (backward, forward) kernel ms per launch" > $O
+for cfg in c3 c2; do
+for B in 4096 8192 16384 32768 65536 131072; do
+  for Q in 1 0; do
+    ALTRO_HIP_LANE_QUAD=$Q python bench.py --config $cfg --batch $B --repeat-seconds 0 --steps 20 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['config']['kernels']
+print('$cfg batch %6d quad=$Q  ms/step %.4f  ' % ($B, d['ms_per_step']), {n:round(v['avg_ms'],4) for n,v in k.items()})
+" >> $O
+  done
+done
+done
+cat $O
