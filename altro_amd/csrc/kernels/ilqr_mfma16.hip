@@ -623,44 +623,61 @@ __global__ __launch_bounds__(64) void wave_merit_kernel(IlqrWaveArgs<S> a) {
 // |lx_k + A_k^T y_{k+1} - y_k| needs the NEXT step's y, so the previous record image, gradient and y stay in LDS)
 // and feasibility (solver.cpp:224-231) in the control block -- the values wave_stationarity_kernel would compute from
 // the stored candidate, without its two further passes over DYN.
+// sum over the 32 lanes of this lane's half of the wave: offsets 16 .. 1 of the butterfly wave_sum runs over 64 lanes (whose
+// first step, offset 32, only ever adds the exact zeros of the other half: the order of the additions that matter is kept)
+__device__ __forceinline__ double half_sum(double v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Lane roles: ONE TRIAL PER HALF WAVE.  Half h = lane / 32 evaluates trial h (0: alpha = a.alpha[b], 1: alpha = 1); within a
+// half, r = lane % 32:
+//   r  0..11 : row r of Z = [A B]        -> x+[r], dx+/dalpha[r], state cost terms, lx[r]
+//   r 16..19 : row r - 16 of Kt = [K|-d] -> u, du/dalpha, input cost terms                     (lu: lanes r 12..15, like the
+//   r 12..15, 20..27 : rows 0..3, 4..11 of [P | p] -> y                                          single-trial kernel's 12..15)
+// i.e. the single-trial kernel's lanes 0..11 / 16..19 keep their places inside a half, so the per-trial sums are taken in
+// its order.  Each lane reads ITS trial's vectors (8-byte broadcast reads): 36 LDS reads per lane and knot point for both
+// trials together, where the first version of this kernel (every lane against both trials' interleaved vectors) needed 36
+// at twice the width -- the kernel is bound by the LDS pipe, not by HBM.
 template <typename S, bool AL>
 __global__ __launch_bounds__(64) void wave_merit2_kernel(IlqrWaveArgs<S> a) {
   constexpr int DEPTH = 2;                          // also the image ping-pong: parity of k == dd
   constexpr bool kStat = sizeof(S) == 8;            // stored values == computed values only without a rounding store
   __shared__ double img[2][MW_IMG + 4];
-  __shared__ __attribute__((aligned(16))) double vec2[24 * 2];   // x | dx, [entry][trial]
-  __shared__ __attribute__((aligned(16))) double das2[12 * 2];
-  __shared__ __attribute__((aligned(16))) double us2[4 * 2];
-  __shared__ __attribute__((aligned(16))) double dus2[4 * 2];
-  __shared__ double xsA[2][12], usA[2][4], jv[2][AL_MAXC * AL_MAXP];   // contiguous copies for the AL rows
+  __shared__ double vec[2][24], das[2][12], us[2][4], dus[2][4];   // [trial]: x | dx, dx/dalpha, u, du/dalpha
+  __shared__ double jv[2][AL_MAXC * AL_MAXP];
   __shared__ double crec[2][28], qrec[2][16], yN[12], lxN[12];
   const int b = mf_problem(blockIdx.x, a.batch), lane = threadIdx.x;
   if (b >= a.batch) return;
   if (a.active && !a.active[b]) return;
   const int N = a.N;
-  const double alpha0 = a.alpha ? a.alpha[b] : a.alpha_const;
+  const int h = lane >> 5, r = lane & 31;           // trial, role
+  const double alpha = h ? 1.0 : (a.alpha ? a.alpha[b] : a.alpha_const);
   S* __restrict__ candb = a.cand + (size_t)b * a.xuy_bs;
   constexpr bool al = AL;
   const double rho = al ? a.prob[b].rho : 1.0;
-  const int grp = lane >> 4, sub = lane & 15;
-  const bool is_x = lane < 12, is_u = (grp == 1 && sub < 4), is_y = (grp == 2 && sub < 12);
-  const int i = sub < 12 ? sub : 11;
-  const int ia = sub < 4 ? sub : 3;
+  const bool is_x = r < 12, is_u = (r >= 16 && r < 20), is_y = (r >= 12 && r < 16) || (r >= 20 && r < 28);
+  const bool cand = h == 1;                         // trial 1 writes the candidate trajectory and the expansion
+  const int i = is_x ? r : (r < 16 ? r - 12 : (r < 20 ? 11 : (r < 28 ? r - 16 : 11)));   // row of Z / of [P | p]
+  const int ia = is_u ? r - 16 : 3;                 // row of Kt
   int ra[13];
 #pragma unroll
   for (int j = 0; j < 12; ++j)
-    ra[j] = (grp == 0) ? i * MW_ZLD + j : (grp == 1) ? MW_OUT0 + ia * 13 + j : MW_OUT0 + MF_OFF_P + mf_sym(i, j);
-  ra[12] = (grp == 0) ? i * MW_ZLD + 12 : (grp == 1) ? MW_OUT0 + ia * 13 + 12 : MW_OUT0 + MF_OFF_p + i;
-  const int vbase = (grp == 0) ? 0 : 12;
+    ra[j] = is_x ? i * MW_ZLD + j : is_u ? MW_OUT0 + ia * 13 + j : MW_OUT0 + MF_OFF_P + mf_sym(i, j);
+  ra[12] = is_x ? i * MW_ZLD + 12 : is_u ? MW_OUT0 + ia * 13 + 12 : MW_OUT0 + MF_OFF_p + i;
+  const double* const vrow = is_x ? &vec[h][0] : &vec[h][12];   // rows of Z multiply x, the others dx
   const int l27 = lane < 28 ? lane : 27;
+  const int sub = lane & 15;
   const S* __restrict__ dynb = a.dyn + (size_t)b * a.dyn_bs;
   const S* __restrict__ outb = a.out + (size_t)b * a.out_bs;
   const S* __restrict__ nomb = a.nom + (size_t)b * MF_NOM;
   const S* __restrict__ cpb = a.costp + (size_t)b * MF_COSTP;
   const size_t nom_ks = (size_t)a.batch * MF_NOM, cp_ks = (size_t)a.batch * MF_COSTP;
-  double x0 = (double)a.x0[(size_t)b * 12 + i], x1 = x0;
-  double dx0 = 0.0, dx1 = 0.0;               // dx/dalpha of the two trials
-  double J0 = 0.0, J1 = 0.0, dJ0 = 0.0, dJ1 = 0.0, viol = 0.0, viol0 = 0.0, res = 0.0;
+  double x = (double)a.x0[(size_t)b * 12 + (is_x ? r : 11)];
+  double dxda = 0.0;
+  double J = 0.0, Jal = 0.0, dJ = 0.0, viol = 0.0, res = 0.0;   // (Jal: the AL rows' cost shares, summed apart like the
+                                                                 //  single-trial kernel's lanes 48..55 do)
   MeritWaveRegs ring[DEPTH];
 #pragma unroll
   for (int dd = 0; dd < DEPTH; ++dd) {
@@ -678,97 +695,82 @@ __global__ __launch_bounds__(64) void wave_merit2_kernel(IlqrWaveArgs<S> a) {
     // (no barrier here: the image, the candidate record and the gradient are double-buffered, and every lane has passed
     //  the last barrier of the previous step before anything single-buffered is rewritten)
     merit_wave_stage(ring[dd], L, lane);
-    if (is_x) {
-      const double nm = ring[dd].nm;
-      vec2[lane * 2] = x0; vec2[lane * 2 + 1] = x1;
-      vec2[(12 + lane) * 2] = x0 - nm; vec2[(12 + lane) * 2 + 1] = x1 - nm;
-      das2[lane * 2] = dx0; das2[lane * 2 + 1] = dx1;
-      crec[dd][lane] = x1;
-      if (al) { xsA[0][lane] = x0; xsA[1][lane] = x1; }
+    if (is_x) {   // (ring.nm is the nominal record's element lane % 16 = r)
+      vec[h][r] = x; vec[h][12 + r] = x - ring[dd].nm; das[h][r] = dxda;
+      if (cand) crec[dd][r] = x;
     }
     {
       const size_t kn = (k + DEPTH < N) ? k + DEPTH : N - 1;
       merit_wave_load<S>(ring[dd], dynb + kn * a.dyn_ks, outb + kn * a.out_ks, nomb + kn * nom_ks, cpb + kn * cp_ks, lane);
     }
     __syncthreads();
-    double acc0 = 0.0, acc1 = 0.0, acd0 = 0.0, acd1 = 0.0;
+    // this lane's row (of Z, of Kt or of [P | p]) times x (rows of Z) or dx (the others), and times dx/dalpha
+    double acc = 0.0, acc2 = 0.0;
 #pragma unroll
     for (int j = 0; j < 12; ++j) {
       const double rj = L[ra[j]];
-      const double2 v = *reinterpret_cast<const double2*>(&vec2[(vbase + j) * 2]);
-      const double2 d = *reinterpret_cast<const double2*>(&das2[j * 2]);
-      acc0 += rj * v.x; acc1 += rj * v.y;
-      acd0 += rj * d.x; acd1 += rj * d.y;
+      acc += rj * vrow[j];
+      acc2 += rj * das[h][j];
     }
-    const double aff = L[ra[12]];
-    if (is_u) {
-      const double d = -aff, un = L[MW_NOM0 + 12 + ia];
-      const double u0 = un + (-acc0 + alpha0 * d), u1 = un + (-acc1 + 1.0 * d);
-      const double du0 = -acd0 + d, du1 = -acd1 + d;
-      us2[ia * 2] = u0; us2[ia * 2 + 1] = u1; dus2[ia * 2] = du0; dus2[ia * 2 + 1] = du1;
-      crec[dd][24 + ia] = u1;
-      if (al) { usA[0][ia] = u0; usA[1][ia] = u1; }
+    const double aff = L[ra[12]];          // -d (rows of Kt), p (rows of [P | p]), B[.][0] (rows of Z)
+    if (is_u) {   // u_ = u + (-K dx + alpha d) ; du_da = -K dx_da + d        (Kt = [K | -d])
+      const double d = -aff;
+      const double uval = L[MW_NOM0 + 12 + ia] + (-acc + alpha * d);
+      const double duval = -acc2 + d;
+      us[h][ia] = uval; dus[h][ia] = duval;
+      if (cand) crec[dd][24 + ia] = uval;
       const double Rd = L[MW_CP0 + 12 + ia], rr = L[MW_CP0 + 28 + ia];
-      if (live) { J0 += 0.5 * (u0 * (Rd * u0)) + rr * u0; J1 += 0.5 * (u1 * (Rd * u1)) + rr * u1; }
+      if (live) J += 0.5 * (uval * (Rd * uval)) + rr * uval;
     }
-    if (is_y) crec[dd][12 + i] = acc1 + aff;
+    if (is_y && cand) crec[dd][12 + i] = acc + aff;      // y_ = P dx + p
     __syncthreads();
-    double xn0 = 0.0, xn1 = 0.0, dxn0 = 0.0, dxn1 = 0.0;
-    if (is_x) {
-      double s0 = 0.0, s1 = 0.0, t0 = 0.0, t1 = 0.0;
+    double xn = 0.0, dxn = 0.0;
+    if (is_x) {   // x+ = A x + B u + f ; dx+/da = A dx_da + B du_da ; state cost
+      double s2 = 0.0, t2 = 0.0;
 #pragma unroll
-      for (int cc = 0; cc < 4; ++cc) {
-        const double bic = L[i * MW_ZLD + 12 + cc];
-        const double2 u = *reinterpret_cast<const double2*>(&us2[cc * 2]);
-        const double2 du = *reinterpret_cast<const double2*>(&dus2[cc * 2]);
-        s0 += bic * u.x; s1 += bic * u.y; t0 += bic * du.x; t1 += bic * du.y;
-      }
-      const double f = L[MW_F0 + i];
-      xn0 = (acc0 + s0) + f; xn1 = (acc1 + s1) + f;
-      dxn0 = acd0 + t0; dxn1 = acd1 + t1;
+      for (int cc = 0; cc < 4; ++cc) { const double bic = L[i * MW_ZLD + 12 + cc]; s2 += bic * us[h][cc]; t2 += bic * dus[h][cc]; }
+      xn = (acc + s2) + L[MW_F0 + i];
+      dxn = acc2 + t2;
       const double Qd = L[MW_CP0 + i], q = L[MW_CP0 + 16 + i];
       if (live) {
-        J0 += 0.5 * (x0 * (Qd * x0)) + q * x0;
-        J1 += 0.5 * (x1 * (Qd * x1)) + q * x1;
-        if (lane == 0) { J0 += L[MW_CP0 + 32]; J1 += L[MW_CP0 + 32]; }
+        J += 0.5 * (x * (Qd * x)) + q * x;
+        if (r == 0) J += L[MW_CP0 + 32];
       }
     }
-    if (kStat && grp == 1 && live && k >= 1) {   // stationarity at knot point k - 1 now that y_k is known (trial 1)
+    if (kStat && lane >= 48 && live && k >= 1) {   // stationarity at knot point k - 1 now that y_k is known (trial 1's lanes 48..63)
       const double* const Lp = img[dd ^ 1];
       double sy = 0.0;
 #pragma unroll
-      for (int r = 0; r < 12; ++r) sy += Lp[r * MW_ZLD + sub] * crec[dd][12 + r];
+      for (int rr = 0; rr < 12; ++rr) sy += Lp[rr * MW_ZLD + sub] * crec[dd][12 + rr];
       const double g = qrec[dd ^ 1][sub] + sy;
       res = fmax(res, fabs(sub < 12 ? g - crec[dd ^ 1][12 + sub] : g));
     }
     if (al) {
-      double Ja = 0.0, Jb = 0.0;
-      wave_al_rows<S>(a.al, kc, b, a.batch, xsA[0], usA[0], false, rho, lane, jv[0], nullptr, nullptr, Ja, viol0, false);
-      wave_al_rows<S>(a.al, kc, b, a.batch, xsA[1], usA[1], false, rho, lane, jv[1], nullptr, nullptr, Jb, viol, false);
-      if (live) { J0 += Ja; J1 += Jb; }
+      double Ja = 0.0, Jb = 0.0, v0 = 0.0;
+      wave_al_rows<S>(a.al, kc, b, a.batch, &vec[0][0], &us[0][0], false, rho, lane, jv[0], nullptr, nullptr, Ja, v0, false);
+      wave_al_rows<S>(a.al, kc, b, a.batch, &vec[1][0], &us[1][0], false, rho, lane, jv[1], nullptr, nullptr, Jb, viol, false);
+      // (the rows' cost shares land in lanes 48..55 = trial 1's half: trial 0's go to the same place of its own half)
+      Ja = __shfl(Ja, (lane + 32) & 63, 64);
+      if (live) Jal += h ? Jb : Ja;
     }
     __syncthreads();
-    if (lane < 16) {
-      const int e = lane;
-      const double p0 = e < 12 ? x0 : us2[(e - 12) * 2], p1 = e < 12 ? x1 : us2[(e - 12) * 2 + 1];
-      double l0 = L[MW_CP0 + e] * p0 + L[MW_CP0 + 16 + e];
-      double l1 = L[MW_CP0 + e] * p1 + L[MW_CP0 + 16 + e];
-      if (al) { l0 -= wave_al_col<S>(a.al, kc, e, jv[0]); l1 -= wave_al_col<S>(a.al, kc, e, jv[1]); }
-      qrec[dd][e] = l1;
-      if (live) {
-        dJ0 += l0 * (e < 12 ? dx0 : dus2[(e - 12) * 2]);
-        dJ1 += l1 * (e < 12 ? dx1 : dus2[(e - 12) * 2 + 1]);
-      }
+    if (r < 16) {   // lx (r 0..11) and lu (r 12..15) with the AL terms; dphi
+      const int e = r;
+      const double pt = e < 12 ? x : us[h][e - 12];
+      double l = L[MW_CP0 + e] * pt + L[MW_CP0 + 16 + e];       // costp: Qd | Rd | q | r line up with [x; u]
+      if (al) l -= wave_al_col<S>(a.al, kc, e, jv[h]);
+      if (cand) qrec[dd][e] = l;
+      if (live) dJ += l * (e < 12 ? dxda : dus[h][e - 12]);
     }
     __syncthreads();
-    {
+    {   // one coalesced store of trial 1's candidate record and of its [lx lu]
       S* c = candb + (size_t)(live ? k : N) * a.xuy_ks;
       c[l27] = (S)crec[dd][l27];
       S* ci = a.cin + (size_t)b * a.cin_bs + (size_t)kc * a.cin_ks;
       const double qv = qrec[dd][sub];
       if (live) ci[MF_OFF_QR + sub] = (S)qv;
     }
-    if (is_x && live) { x0 = xn0; x1 = xn1; dx0 = dxn0; dx1 = dxn1; }
+    if (is_x && live) { x = xn; dxda = dxn; }
    }
   }
   __syncthreads();
@@ -777,59 +779,57 @@ __global__ __launch_bounds__(64) void wave_merit2_kernel(IlqrWaveArgs<S> a) {
     const S* cp = a.costp + ((size_t)N * a.batch + b) * MF_COSTP;
     const S* on = a.outn + (size_t)b * MF_TERM;
     S* c = candb + (size_t)N * a.xuy_ks;
-    if (is_u) c[24 + ia] = S(0);
+    if (is_u && cand) c[24 + ia] = S(0);
     if (is_x) {
-      const double nmv = (double)nm[lane];
-      vec2[lane * 2] = x0; vec2[lane * 2 + 1] = x1;
-      vec2[(12 + lane) * 2] = x0 - nmv; vec2[(12 + lane) * 2 + 1] = x1 - nmv;
-      if (al) { xsA[0][lane] = x0; xsA[1][lane] = x1; }
-      c[lane] = (S)x1;
+      vec[h][r] = x; vec[h][12 + r] = x - (double)nm[r];
+      if (cand) c[r] = (S)x;
       const double Qd = (double)cp[i], q = (double)cp[16 + i];
-      J0 += 0.5 * (x0 * (Qd * x0)) + q * x0;
-      J1 += 0.5 * (x1 * (Qd * x1)) + q * x1;
-      if (lane == 0) { J0 += (double)cp[32]; J1 += (double)cp[32]; }
+      J += 0.5 * (x * (Qd * x)) + q * x;
+      if (r == 0) J += (double)cp[32];
     }
     __syncthreads();
     if (al) {
-      wave_al_rows<S>(a.al, N, b, a.batch, xsA[0], usA[0], true, rho, lane, jv[0], nullptr, nullptr, J0, viol0, false);
-      wave_al_rows<S>(a.al, N, b, a.batch, xsA[1], usA[1], true, rho, lane, jv[1], nullptr, nullptr, J1, viol, false);
+      double Ja = 0.0, Jb = 0.0, v0 = 0.0;
+      wave_al_rows<S>(a.al, N, b, a.batch, &vec[0][0], &us[0][0], true, rho, lane, jv[0], nullptr, nullptr, Ja, v0, false);
+      wave_al_rows<S>(a.al, N, b, a.batch, &vec[1][0], &us[1][0], true, rho, lane, jv[1], nullptr, nullptr, Jb, viol, false);
+      Ja = __shfl(Ja, (lane + 32) & 63, 64);
+      Jal += h ? Jb : Ja;
     }
-    if (is_y) {
+    if (is_y && cand) {
       double sacc = 0.0;
 #pragma unroll
-      for (int j = 0; j < 12; ++j) sacc += (double)on[i * 13 + j] * vec2[(12 + j) * 2 + 1];
+      for (int j = 0; j < 12; ++j) sacc += (double)on[i * 13 + j] * vec[1][12 + j];
       const double y = sacc + (double)on[i * 13 + 12];
       c[12 + i] = (S)y;
       yN[i] = y;
     }
     __syncthreads();
     if (is_x) {
-      double lx0 = (double)cp[i] * x0 + (double)cp[16 + i];
-      double lx1 = (double)cp[i] * x1 + (double)cp[16 + i];
-      if (al) { lx0 -= wave_al_col<S>(a.al, N, i, jv[0]); lx1 -= wave_al_col<S>(a.al, N, i, jv[1]); }
-      a.term[(size_t)b * MF_TERM + 144 + i] = (S)lx1;
-      lxN[i] = lx1;
-      dJ0 += lx0 * dx0;
-      dJ1 += lx1 * dx1;
+      double lx = (double)cp[i] * x + (double)cp[16 + i];
+      if (al) lx -= wave_al_col<S>(a.al, N, i, jv[h]);
+      if (cand) { a.term[(size_t)b * MF_TERM + 144 + i] = (S)lx; lxN[i] = lx; }
+      dJ += lx * dxda;
     }
     if (kStat) {
       __syncthreads();
       const int pl = (N - 1) & 1;      // the last LIVE step's buffers (a padding step writes the other parity)
-      if (grp == 1) {
+      if (lane >= 48) {
         double sy = 0.0;
 #pragma unroll
-        for (int r = 0; r < 12; ++r) sy += img[pl][r * MW_ZLD + sub] * yN[r];
+        for (int rr = 0; rr < 12; ++rr) sy += img[pl][rr * MW_ZLD + sub] * yN[rr];
         const double g = qrec[pl][sub] + sy;
         res = fmax(res, fabs(sub < 12 ? g - crec[pl][12 + sub] : g));
       }
-      if (lane < 12) res = fmax(res, fabs(lxN[lane] - yN[lane]));
+      if (cand && is_x) res = fmax(res, fabs(lxN[r] - yN[r]));
     }
   }
-  const double phi0 = wave_sum(J0), dphi0 = wave_sum(dJ0), phi1 = wave_sum(J1), dphi1 = wave_sum(dJ1);
+  const double phi = half_sum(J + Jal), dphi = half_sum(dJ);   // (J + Jal: the 64-lane butterfly's first step, lane l + lane l + 32)
   if (kStat) { res = wave_max(res); if (al) viol = wave_max(viol); }
+  if (r == 0) {
+    a.phi[(size_t)h * a.batch + b] = phi;
+    a.dphi[(size_t)h * a.batch + b] = dphi;
+  }
   if (lane == 0) {
-    a.phi[b] = phi0; a.dphi[b] = dphi0;
-    a.phi[(size_t)a.batch + b] = phi1; a.dphi[(size_t)a.batch + b] = dphi1;
     if (al) a.prob[b].rho_est = rho;
     if (kStat) { a.prob[b].stationarity = res; a.prob[b].feasibility = viol; }
   }

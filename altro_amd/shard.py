@@ -35,17 +35,44 @@ def reduce_stats(stats, device=None, group=None):
 
 def make_comm(device, rank, world):
     """One RCCL communicator rank for altro_hip_stats_allreduce: rank 0 draws the unique id, torch.distributed
-    (already initialised by the launcher's rendezvous) carries its 128 bytes to the other ranks."""
+    (already initialised by the launcher's rendezvous) carries its 128 bytes to the other ranks.  Every step that can
+    fail on one rank only is followed by an agreement over torch.distributed, so that either ALL ranks hold a
+    communicator or all of them raise -- never some inside ncclCommInitRank while others have given up."""
     import torch
     import torch.distributed as dist
     import altro_amd
-    uid = altro_amd.Comm.unique_id() if rank == 0 else bytes(altro_amd.COMM_ID_BYTES)
-    if world > 1:
+    multi = world > 1
+    on = None
+    if multi:
         on = "cuda" if dist.get_backend() == "nccl" else "cpu"
-        t = torch.tensor(list(uid), dtype=torch.uint8, device=on)
+    ok, uid, err = 1, bytes(altro_amd.COMM_ID_BYTES), None
+    if rank == 0:
+        try:
+            uid = altro_amd.Comm.unique_id()
+        except Exception as e:   # noqa: BLE001 -- e.g. librccl cannot be loaded: tell the other ranks instead of leaving them waiting
+            ok, err = 0, e
+    if multi:
+        t = torch.tensor([ok] + list(uid), dtype=torch.uint8, device=on)
         dist.broadcast(t, src=0)
-        uid = bytes(t.cpu().tolist())
-    return altro_amd.Comm(device, rank, world, uid)
+        vals = t.cpu().tolist()
+        ok, uid = vals[0], bytes(vals[1:])
+    if not ok:
+        raise altro_amd.AltroHipError("rank 0 could not draw an RCCL unique id%s" % ((": %s" % err) if err else ""))
+    comm, err = None, None
+    try:
+        comm = altro_amd.Comm(device, rank, world, uid)
+    except Exception as e:   # noqa: BLE001
+        err = e
+    if multi:
+        flag = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=on)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if comm is not None:
+                comm.close()
+            raise altro_amd.AltroHipError("ncclCommInitRank failed on at least one rank%s" % ((": %s" % err) if err else ""))
+    elif comm is None:
+        raise err
+    return comm
 
 
 def max_over_ranks(value, device=None, group=None):
