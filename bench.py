@@ -59,6 +59,10 @@ def parse():
                          "(pendulum n=2 m=1 N=100 batch=8192), c3 = configs[3] (bicycle n=4 m=2 N=50 batch=65536 "
                          "per node, with the steering bound), c4 = configs[4] (random LTV n=12 m=4 N=512 "
                          "batch=16384, fp32 storage)")
+    ap.add_argument("--live-traffic", action="store_true",
+                    help="measure roofline.traffic in THIS run: two short rocprofv3 passes of this same command (--kernel-trace "
+                         "--pmc FETCH_SIZE, then WRITE_SIZE; each counter in its own pass, nothing else traced) before the timed "
+                         "region, ~1 minute.  Default: the tracked figure of profiles/pmc_traffic.json, labelled as such")
     ap.add_argument("--lane-fused", action="store_true",
                     help="configs c2 / c3: FMA-fused LANE kernels (ALTRO_HIP_LANE_FUSED; not bit-identical to the CPU path)")
     ap.add_argument("--c4-pure", action="store_true", help="(default for config c4; kept for older command lines)")
@@ -281,6 +285,49 @@ class StatsChannel:
             self.comm = None
 
 
+_LIVE_TRAFFIC = None   # {kernel name prefix: bytes per launch}, filled by live_traffic() on rank 0 when --live-traffic is given
+
+
+def live_traffic(args):
+    """HBM bytes per launch of the sweep kernels from two rocprofv3 PMC passes of this very command (steps 3, no CPU leg, no
+    repeat block), exactly as MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE each in its own pass with
+    --kernel-trace only, values in KiB, FETCH_SIZE doubled on gfx950.  Returns {kernel name: bytes} or None."""
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        print("[bench] --live-traffic: rocprofv3 not found", file=sys.stderr)
+        return None
+    child = [sys.executable, os.path.abspath(__file__), "--config", args.config, "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+             "--repeat-seconds", "0", "--horizon", str(args.horizon)]
+    if args.batch is not None:
+        child += ["--batch", str(args.batch)]
+    if args.global_batch is not None:
+        child += ["--global-batch", str(args.global_batch)]
+    if args.c4_mixed:
+        child += ["--c4-mixed"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["TMPDIR"] = "/tmp"
+    sums = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        with tempfile.TemporaryDirectory(dir="/tmp") as td:
+            r = subprocess.run([prof, "--kernel-trace", "--pmc", ctr, "-d", td, "-o", "t", "--"] + child, cwd="/tmp", env=env,
+                               capture_output=True, text=True, timeout=600)
+            dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(td) for f in fs if f.endswith(".db")]
+            if r.returncode != 0 or not dbs:
+                print("[bench] --live-traffic: the %s pass failed (rc %d)" % (ctr, r.returncode), file=sys.stderr)
+                return None
+            con = sqlite3.connect(dbs[0])
+            rows = con.execute("select kernel_name, avg(v) from (select kernel_name, dispatch_id, sum(value) as v from counters_collection "
+                               "where counter_name = ? group by kernel_name, dispatch_id) group by kernel_name", (ctr,)).fetchall()
+            con.close()
+            for name, kib in rows:
+                sums.setdefault(name, {})[ctr] = kib
+    return {name: 2.0 * 1024.0 * v.get("FETCH_SIZE", 0.0) + 1024.0 * v.get("WRITE_SIZE", 0.0) for name, v in sums.items()}
+
+
 def roofline_block(cfg_key, batch, N, name, alg_bytes, dur, slot=0):
     """`achieved` / `frac` follow the contract: SURVEY 8(d) ALGORITHMIC bytes per launch / measured duration / 8 TB/s.
     `traffic` is the PMC byte count of a tracked earlier rocprofv3 run of the same command (profiles/pmc_traffic.json),
@@ -297,6 +344,12 @@ def roofline_block(cfg_key, batch, N, name, alg_bytes, dur, slot=0):
                          "earlier run of this command; not measured in this run)" % (cfg_key, tj.get("profile"))
     except (OSError, ValueError):
         pass
+    if _LIVE_TRAFFIC:   # measured in this run: the kernel whose (demangled) name contains the profiled slot's name
+        hit = [v for k, v in _LIVE_TRAFFIC.items() if name in k]
+        if hit:
+            traffic = max(hit)
+            source = "LIVE: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE passes of this command run by this process " \
+                     "(bytes = 2 * 1024 * FETCH_SIZE + 1024 * WRITE_SIZE per launch, MI355X_MICROARCH.md)"
     ach = alg_bytes / dur / 1e9
     return {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": ach / HBM_PEAK_GBS, "frac_algorithmic": ach / HBM_PEAK_GBS,
@@ -451,6 +504,12 @@ def main():
         cpu_leg = cpu_baseline(args.horizon, args.cpu_seconds)
         cpu_leg["all_cores"] = cpu_all_cores(args.horizon)
         cpu_leg["eigen"] = eigen_probe()
+    if args.live_traffic and rank == 0 and world == 1:   # before this process touches the GPU: the passes are child processes
+        global _LIVE_TRAFFIC
+        try:
+            _LIVE_TRAFFIC = live_traffic(args)
+        except Exception as e:   # noqa: BLE001 -- a measurement extra must never take the bench line down
+            print("[bench] --live-traffic failed: %s" % e, file=sys.stderr)
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
