@@ -52,13 +52,15 @@ __device__ __forceinline__ double wave_max(double v) {
 // For the zero / identity / orthant cones J is diagonal and the curvature vanishes.  A second-order-cone block
 // (p <= 4, cones.cpp:13-123) is evaluated as a whole by lane 48.  xs / us: the point, in LDS.  With dual_update the
 // projected dual becomes the dual (knotpoint_data.cpp:503-510).  Must be called by all lanes (no barrier inside).
-template <typename S>
+// (ROW0: the lane that owns row 0 -- 48 everywhere but in the two-trial kernel, where each half of the wave evaluates its
+//  own trial's rows in its lanes 16..23 and passes lane % 32 with ROW0 = 16.)
+template <typename S, int ROW0 = 48>
 __device__ __forceinline__ void wave_al_rows(const AlTable<S>& t, int k, int b, int64_t B, const double* xs, const double* us,
                                              bool terminal, double rho_est, int lane, double* jv, double* Jm, double* Hm,
                                              double& cost, double& viol, bool dual_update) {
   int zshift;
   const AlKnot ALTRO_CONST_AS& kn = al_knot<S>(t, k, zshift);
-  const int i = lane - 48;
+  const int i = lane - ROW0;
   const bool row_lane = (i >= 0 && i < AL_MAXP);
 #pragma unroll
   for (int c = 0; c < AL_MAXC; ++c) {
@@ -746,12 +748,12 @@ __global__ __launch_bounds__(64) void wave_merit2_kernel(IlqrWaveArgs<S> a) {
       res = fmax(res, fabs(sub < 12 ? g - crec[dd ^ 1][12 + sub] : g));
     }
     if (al) {
-      double Ja = 0.0, Jb = 0.0, v0 = 0.0;
-      wave_al_rows<S>(a.al, kc, b, a.batch, &vec[0][0], &us[0][0], false, rho, lane, jv[0], nullptr, nullptr, Ja, v0, false);
-      wave_al_rows<S>(a.al, kc, b, a.batch, &vec[1][0], &us[1][0], false, rho, lane, jv[1], nullptr, nullptr, Jb, viol, false);
-      // (the rows' cost shares land in lanes 48..55 = trial 1's half: trial 0's go to the same place of its own half)
-      Ja = __shfl(Ja, (lane + 32) & 63, 64);
-      if (live) Jal += h ? Jb : Ja;
+      // both trials' constraint rows at once: lanes r = 16..23 of each half own the rows of their trial (trial 1's are
+      // lanes 48..55, where the single-trial kernel has them); the feasibility that counts is the candidate's (trial 1)
+      double Ja = 0.0, vv = 0.0;
+      wave_al_rows<S, 16>(a.al, kc, b, a.batch, &vec[h][0], &us[h][0], false, rho, r, jv[h], nullptr, nullptr, Ja, vv, false);
+      if (live) Jal += Ja;
+      if (cand) viol = fmax(viol, vv);
     }
     __syncthreads();
     if (r < 16) {   // lx (r 0..11) and lu (r 12..15) with the AL terms; dphi
@@ -789,11 +791,10 @@ __global__ __launch_bounds__(64) void wave_merit2_kernel(IlqrWaveArgs<S> a) {
     }
     __syncthreads();
     if (al) {
-      double Ja = 0.0, Jb = 0.0, v0 = 0.0;
-      wave_al_rows<S>(a.al, N, b, a.batch, &vec[0][0], &us[0][0], true, rho, lane, jv[0], nullptr, nullptr, Ja, v0, false);
-      wave_al_rows<S>(a.al, N, b, a.batch, &vec[1][0], &us[1][0], true, rho, lane, jv[1], nullptr, nullptr, Jb, viol, false);
-      Ja = __shfl(Ja, (lane + 32) & 63, 64);
-      Jal += h ? Jb : Ja;
+      double Ja = 0.0, vv = 0.0;
+      wave_al_rows<S, 16>(a.al, N, b, a.batch, &vec[h][0], &us[h][0], true, rho, r, jv[h], nullptr, nullptr, Ja, vv, false);
+      Jal += Ja;
+      if (cand) viol = fmax(viol, vv);
     }
     if (is_y && cand) {
       double sacc = 0.0;
