@@ -897,7 +897,14 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
       pre = false;
     }
     h->spec_trials = pre ? 2 : 1; h->spec_pre = pre ? 1 : 0;
-    rc = ilqr_run(h, dual ? IK_MERIT2 : IK_MERIT, true, true, 1, 0.0);
+    // (mode 1 on IK_MERIT2: the matrix-core form of the two-trial evaluation, wave_merit2_mfma_kernel -- unconstrained problems,
+    //  fp64 records.  Opt-in, ALTRO_HIP_MERIT2_MFMA=1: correct to 1e-12 but, as built, 0.99 ms where the LDS-broadcast form
+    //  takes 0.86 on C1 -- 222 registers, two waves per SIMD under a chain of 13 dependent-issue MFMAs per knot point;
+    //  DESIGN.md 4.11)
+    const char* mm = std::getenv("ALTRO_HIP_MERIT2_MFMA");
+    const bool merit_mfma = mm != nullptr && std::atoi(mm) != 0;
+    rc = dual ? ilqr_run(h, IK_MERIT2, true, true, 1, 0.0, (merit_mfma && !al && h->dtype == ALTRO_HIP_F64) ? 1 : 0)
+              : ilqr_run(h, IK_MERIT, true, true, 1, 0.0);
     h->spec_trials = 1; h->spec_pre = 0;
     if (rc) return rc;
     ++total_merit_launches;

@@ -836,6 +836,215 @@ __global__ __launch_bounds__(64) void wave_merit2_kernel(IlqrWaveArgs<S> a) {
   }
 }
 
+// ---- the same two-trial evaluation on the matrix cores ------------------------------------------------------------------------
+// wave_merit2_kernel is bound by the LDS pipe, and what it moves through LDS is operand broadcast: every lane re-reads the
+// vectors x, dx, dx/dalpha its row multiplies.  MFMA removes exactly that (the backward sweep's reason to use it).  Here the
+// state of both trials and their sensitivities are four COLUMNS of the 16 x 16 B operand of v_mfma_f64_16x16x4 --
+//     column 0: [x; u] of trial 0      column 2: d[x; u]/dalpha of trial 0
+//     column 1: [x; u] of trial 1      column 3: d[x; u]/dalpha of trial 1          (columns 4..15: zero)
+// -- with [x; u] in the rows: lane (g, t) = (lane / 16, lane % 16) holds row 4 c + g of column t in register c (c = 0..2: x,
+// c = 3: u).  The accumulator layout of the instruction (register r <-> row g + 4 r, column t) IS this B-operand layout, so
+//     K dx           (A operand: the rows of Kt)                                            3 MFMA
+//     Z [x; u]       (A operand: Z read transposed from the LDS image)  -> the next state   4 MFMA
+//     P dx           (A operand: P gathered from its packed triangle)   -> y                3 MFMA
+//     Z^T y+         (A operand: Z's own fragment registers, one knot point late)  -> the stationarity residual   3 MFMA
+// hand their results to the next product in registers: the recursion never goes through LDS.  Sums are taken in the MFMA's
+// order, not in wave_merit_kernel's: results agree to rounding (1e-12 relative asserted), not bit for bit.  Unconstrained
+// problems, fp64 records (the default for those); everything else runs wave_merit2_kernel.
+typedef double mw_f64x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ mw_f64x4 mw_mfma(double a, double b, mw_f64x4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ double mw_from_lane_plus2(double v) { return __shfl_down(v, 2, 64); }
+
+template <typename S>
+__global__ __launch_bounds__(64) void wave_merit2_mfma_kernel(IlqrWaveArgs<S> a) {
+  constexpr int DEPTH = 2;
+  __shared__ double img[2][MW_IMG + 4];
+  __shared__ double crec[2][28], qrec[2][16];
+  const int b = mf_problem(blockIdx.x, a.batch), lane = threadIdx.x;
+  if (b >= a.batch) return;
+  if (a.active && !a.active[b]) return;
+  const int N = a.N;
+  const int g = lane >> 4, t = lane & 15;
+  const bool xcol = t < 2;                      // a column that holds a trial's [x; u] (2, 3: its sensitivities)
+  const bool live_col = t < 4;
+  const bool cand = t == 1;                     // trial 1 writes the candidate trajectory and the expansion
+  const double alpha = (t == 0) ? (a.alpha ? a.alpha[b] : a.alpha_const) : 1.0;
+  S* __restrict__ candb = a.cand + (size_t)b * a.xuy_bs;
+  const int tr = t < 12 ? t : 11;               // row of Z / of [P | p] this lane supplies as A operand (rows 12..15: zeroed)
+  const int ta = t < 4 ? t : 3;                 // row of Kt
+  int aZ[4], aK[3], aP[3];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) aZ[c] = tr * MW_ZLD + 4 * c + g;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { aK[c] = MW_OUT0 + ta * 13 + 4 * c + g; aP[c] = MW_OUT0 + MF_OFF_P + mf_sym(tr, 4 * c + g); }
+  const int l27 = lane < 28 ? lane : 27;
+  const S* __restrict__ dynb = a.dyn + (size_t)b * a.dyn_bs;
+  const S* __restrict__ outb = a.out + (size_t)b * a.out_bs;
+  const S* __restrict__ nomb = a.nom + (size_t)b * MF_NOM;
+  const S* __restrict__ cpb = a.costp + (size_t)b * MF_COSTP;
+  const size_t nom_ks = (size_t)a.batch * MF_NOM, cp_ks = (size_t)a.batch * MF_COSTP;
+  // the state: V[c] = row 4 c + g of this lane's column; columns 0, 1 start at x0, the sensitivities at 0
+  double V[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) V[c] = xcol ? (double)a.x0[(size_t)b * 12 + 4 * c + g] : 0.0;
+  double J = 0.0, dJ = 0.0, res = 0.0;
+  double lxp[3] = {0.0, 0.0, 0.0}, lup = 0.0, yp[3] = {0.0, 0.0, 0.0}, zprev[3] = {0.0, 0.0, 0.0};   // knot point k - 1 (the lag)
+  MeritWaveRegs ring[DEPTH];
+#pragma unroll
+  for (int dd = 0; dd < DEPTH; ++dd) {
+    const size_t kk = dd < N ? dd : N - 1;
+    merit_wave_load<S>(ring[dd], dynb + kk * a.dyn_ks, outb + kk * a.out_ks, nomb + kk * nom_ks, cpb + kk * cp_ks, lane);
+  }
+  const int Npad = ((N + DEPTH - 1) / DEPTH) * DEPTH;
+  for (int k0 = 0; k0 < Npad; k0 += DEPTH) {
+#pragma unroll
+   for (int dd = 0; dd < DEPTH; ++dd) {
+    const int k = k0 + dd;
+    const bool live = k < N;
+    const int kc = live ? k : N - 1;
+    double* const L = img[dd];
+    merit_wave_stage(ring[dd], L, lane);
+    double zf[3];                               // Z_k in fragment order: lane (g, t) holds Z[4 c + g][t] = (Z^T)[t][4 c + g]
+#pragma unroll
+    for (int c = 0; c < 3; ++c) zf[c] = ring[dd].z[c];
+    {
+      const size_t kn = (k + DEPTH < N) ? k + DEPTH : N - 1;
+      merit_wave_load<S>(ring[dd], dynb + kn * a.dyn_ks, outb + kn * a.out_ks, nomb + kn * nom_ks, cpb + kn * cp_ks, lane);
+    }
+    __syncthreads();
+    // dx = x - x_nominal in the trial columns; the sensitivity columns go through unchanged
+    double W[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) W[c] = V[c] - (xcol ? L[MW_NOM0 + 4 * c + g] : 0.0);
+    // K dx | K dx/dalpha: rows 0..3 of the product = register 0 of lane (g, t)
+    mw_f64x4 DK = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) DK = mw_mfma(t < 4 ? L[aK[c]] : 0.0, W[c], DK);
+    const double d = L[MW_OUT0 + g * 13 + 12] * -1.0;      // d[g] = -Kt[g][12]
+    // u_ = u + (-K dx + alpha d) ; du_da = -K dx_da + d
+    const double U = xcol ? L[MW_NOM0 + 12 + g] + (-DK[0] + alpha * d) : (live_col ? -DK[0] + d : 0.0);
+    // y_ = P dx + p  (P dx/dalpha in the sensitivity columns is not needed, it rides along)
+    mw_f64x4 DY = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) DY = mw_mfma(t < 12 ? L[aP[c]] : 0.0, W[c], DY);
+    double y[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) y[c] = DY[c] + L[MW_OUT0 + MF_OFF_p + 4 * c + g];
+    // costs and their gradient at (x_k, u_k), in the trial columns
+    double lx[3], lu;
+    {
+      double Jk = 0.0;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const double Qd = L[MW_CP0 + 4 * c + g], q = L[MW_CP0 + 16 + 4 * c + g];
+        Jk += 0.5 * (V[c] * (Qd * V[c])) + q * V[c];
+        lx[c] = Qd * V[c] + q;
+      }
+      const double Rd = L[MW_CP0 + 12 + g], rr = L[MW_CP0 + 28 + g];
+      Jk += 0.5 * (U * (Rd * U)) + rr * U;
+      lu = Rd * U + rr;
+      if (g == 0) Jk += L[MW_CP0 + 32];
+      if (live && xcol) J += Jk;
+      // dphi: the sensitivities of trial t sit two columns to the right
+      double dk = lu * mw_from_lane_plus2(U);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) dk += lx[c] * mw_from_lane_plus2(V[c]);
+      if (live && xcol) dJ += dk;
+    }
+    // stationarity at knot point k - 1 now that y_k is known: Z_{k-1}^T y_k in fragment registers, trial 1's column
+    if (k >= 1 && live) {
+      mw_f64x4 DS = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int c = 0; c < 3; ++c) DS = mw_mfma(zprev[c], y[c], DS);
+      if (cand) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) res = fmax(res, fabs((lxp[c] + DS[c]) - yp[c]));
+        res = fmax(res, fabs(lup + DS[3]));
+      }
+    }
+    // the candidate record x_ | y_ | u_ and [lx lu] of trial 1, gathered for one coalesced store each
+    if (cand) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { crec[dd][4 * c + g] = V[c]; crec[dd][12 + 4 * c + g] = y[c]; qrec[dd][4 * c + g] = lx[c]; }
+      crec[dd][24 + g] = U;
+      qrec[dd][12 + g] = lu;
+    }
+    if (live) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { lxp[c] = lx[c]; yp[c] = y[c]; zprev[c] = zf[c]; }
+      lup = lu;
+    }
+    // the next state: Z [x; u] (+ f in the trial columns)
+    mw_f64x4 DX = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) DX = mw_mfma(t < 12 ? L[aZ[c]] : 0.0, V[c], DX);
+    DX = mw_mfma(t < 12 ? L[aZ[3]] : 0.0, U, DX);
+    if (live) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) V[c] = DX[c] + (xcol ? L[MW_F0 + 4 * c + g] : 0.0);
+    }
+    __syncthreads();
+    {
+      S* c = candb + (size_t)(live ? k : N) * a.xuy_ks;
+      c[l27] = (S)crec[dd][l27];
+      S* ci = a.cin + (size_t)b * a.cin_bs + (size_t)kc * a.cin_ks;
+      const double qv = qrec[dd][t];
+      if (live) ci[MF_OFF_QR + t] = (S)qv;
+    }
+   }
+  }
+  {   // terminal knot point (solver.cpp:319-332), both trials
+    const S* nm = a.nom + ((size_t)N * a.batch + b) * MF_NOM;
+    const S* cp = a.costp + ((size_t)N * a.batch + b) * MF_COSTP;
+    const S* on = a.outn + (size_t)b * MF_TERM;
+    S* cN = candb + (size_t)N * a.xuy_ks;
+    double W[3], lxN[3];
+    {
+      double Jk = 0.0, dk = 0.0;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        W[c] = V[c] - (xcol ? (double)nm[4 * c + g] : 0.0);
+        const double Qd = (double)cp[4 * c + g], q = (double)cp[16 + 4 * c + g];
+        Jk += 0.5 * (V[c] * (Qd * V[c])) + q * V[c];
+        lxN[c] = Qd * V[c] + q;
+        dk += lxN[c] * mw_from_lane_plus2(V[c]);
+      }
+      if (g == 0) Jk += (double)cp[32];
+      if (xcol) { J += Jk; dJ += dk; }
+    }
+    mw_f64x4 DY = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) DY = mw_mfma(t < 12 ? (double)on[tr * 13 + 4 * c + g] : 0.0, W[c], DY);
+    double yN[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) yN[c] = DY[c] + (double)on[(4 * c + g) * 13 + 12];
+    mw_f64x4 DS = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) DS = mw_mfma(zprev[c], yN[c], DS);
+    if (cand) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        res = fmax(res, fabs((lxp[c] + DS[c]) - yp[c]));
+        res = fmax(res, fabs(lxN[c] - yN[c]));
+        cN[4 * c + g] = (S)V[c];
+        cN[12 + 4 * c + g] = (S)yN[c];
+        a.term[(size_t)b * MF_TERM + 144 + 4 * c + g] = (S)lxN[c];
+      }
+      res = fmax(res, fabs(lup + DS[3]));
+      cN[24 + g] = S(0);
+    }
+  }
+  // per-column sums over the four lane groups; columns 0 and 1 are the trials
+  J += __shfl_xor(J, 16, 64); J += __shfl_xor(J, 32, 64);
+  dJ += __shfl_xor(dJ, 16, 64); dJ += __shfl_xor(dJ, 32, 64);
+  res = wave_max(res);
+  if (lane < 2) {
+    a.phi[(size_t)lane * a.batch + b] = J;
+    a.dphi[(size_t)lane * a.batch + b] = dJ;
+  }
+  if (lane == 0) { a.prob[b].stationarity = res; a.prob[b].feasibility = 0.0; }
+}
+
 // Stationarity (solver.cpp:207-222): max_k |lx + A^T y+ - y|, max_k |lu + B^T y+|
 template <typename S>
 __global__ __launch_bounds__(64) void wave_stationarity_kernel(IlqrWaveArgs<S> a) {

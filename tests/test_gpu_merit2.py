@@ -112,3 +112,19 @@ def test_dual_evaluation_fp32_storage():
     for k in ("phi", "stationarity", "x", "u"):
         scale = max(1.0, float(np.abs(b[k]).max()))
         assert np.abs(a[k] - b[k]).max() <= 2e-6 * scale, k
+
+
+def test_matrix_core_form_of_the_dual_evaluation():
+    """wave_merit2_mfma_kernel (opt-in, ALTRO_HIP_MERIT2_MFMA=1): the two trials and their sensitivities as columns of the
+    MFMA B operand, K dx / Z [x; u] / P dx / Z^T y+ as 13 v_mfma_f64_16x16x4 per knot point, the recursion in registers.
+    Sums in the MFMA's order: same decisions, values within 1e-12 of the two-launch sequence."""
+    for N, with_f in ((24, True), (25, False), (1, True), (2, False)):
+        p = _problem(50, N, with_f)
+        os.environ["ALTRO_HIP_MERIT2_MFMA"] = "1"
+        try:
+            a = _solve(p, N, [], True, iterations_max=6)
+        finally:
+            del os.environ["ALTRO_HIP_MERIT2_MFMA"]
+        b = _solve(p, N, [], False, iterations_max=6)
+        assert (a["status"] == 0).all()
+        _same(a, b, "mfma N=%d" % N)
