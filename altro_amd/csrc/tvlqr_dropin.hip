@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "kernels/tvlqr_generic.hip"
+#include "kernels/tvlqr_lane.hip"   // plan LANE's sweeps: a single small problem rides one lane (four for (4, 2) and (2, 1))
 
 using namespace altro_hip;
 
@@ -192,6 +193,199 @@ GenericArgs<double> make_args(Workspace& w, const Layout& L, double reg, bool is
   return a;
 }
 
+
+// ---- fast path for ONE small problem with uniform dimensions (n <= 6, m <= 3) ----------------------------------------------------
+// The single-wave GENERIC kernel stages every block through LDS and takes 7-10 us per knot point; the lane-per-problem
+// sweeps of the batched ABI keep a knot point in registers: 3 us per knot point in one lane, 1.6 us with four lanes per
+// problem.  So: pack the inputs as a batch of ONE in plan LANE's record layout, run its backward sweep (K, d, P, p, delta_V,
+// status into device memory), then ONE more launch -- a thread per knot point, nothing serial -- recomputes what the seam's
+// signature carries besides (Qxx, Quu, Qux, Qx, Qu and the final contents of their scratch twins, tvlqr.cpp:125-191) from the
+// inputs and the sweep's results with the sweep's own expressions, and writes everything into the mapped pinned arena at the
+// GENERIC layout's offsets, where the scatter code below picks it up.  A failed factorisation (rare) repeats the call on the
+// GENERIC path, whose partial outputs follow the reference's early return to the letter.
+ALTRO_FP_REGION_OFF
+template <int n, int m>
+__global__ void dropin_qblocks_kernel(const double* __restrict__ in, const double* __restrict__ term, const double* __restrict__ out,
+                                      const double* __restrict__ outn, const double* __restrict__ dV, const int* __restrict__ status,
+                                      int N, double reg, double* __restrict__ host, const int64_t* __restrict__ off, int64_t total) {
+  using D = LaneDims<n, m>;
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k > N) return;
+  auto at = [&](int arr) -> double* { return host + off[(size_t)k * G_NUM + arr]; };
+  if (k == N) {
+    double* Ph = at(G_P); double* ph = at(G_p);
+    for (int e = 0; e < n * n; ++e) Ph[e] = outn[e];
+    for (int e = 0; e < n; ++e) ph[e] = outn[n * n + e];
+    host[total - 4] = dV[0]; host[total - 3] = dV[1];
+    *reinterpret_cast<int*>(host + total - 2) = status[0];
+    (void)term;
+    return;
+  }
+  const double* rec = in + (size_t)k * D::E_IN;
+  const double* o = out + (size_t)k * D::E_OUT;
+  const double* Pn = (k + 1 < N) ? out + (size_t)(k + 1) * D::E_OUT + D::O_P : outn;
+  const double* pn = (k + 1 < N) ? out + (size_t)(k + 1) * D::E_OUT + D::O_p : outn + n * n;
+  double A[n * n], Bm[n * m], f[n], Qxx[n * n], Quu[m * m], Qux[m * n], Qx[n], Qu[m], P[n * n], pp[n], K[m * n], d[m];
+  for (int e = 0; e < n * n; ++e) { A[e] = rec[D::O_A + e]; Qxx[e] = rec[D::O_Q + e]; P[e] = Pn[e]; }
+  for (int e = 0; e < n * m; ++e) { Bm[e] = rec[D::O_B + e]; Qux[e] = rec[D::O_H + e]; K[e] = o[D::O_K + e]; }
+  for (int e = 0; e < n; ++e) { f[e] = rec[D::O_f + e]; Qx[e] = rec[D::O_q + e]; pp[e] = pn[e]; }
+  for (int e = 0; e < m * m; ++e) Quu[e] = rec[D::O_R + e];
+  for (int e = 0; e < m; ++e) { Qu[e] = rec[D::O_r + e]; d[e] = o[D::O_d + e]; }
+  // the expressions of lane_backward_step (kernels/tvlqr_lane_body.inc), index-ordered dot products, no contraction
+  double T1[n * n], T2[m * n], t[n];
+  for (int j = 0; j < n; ++j)
+    for (int i = 0; i < n; ++i) { double s = 0.0; for (int kk = 0; kk < n; ++kk) s += A[kk + i * n] * P[kk + j * n]; T1[i + j * n] = 0.0 + s; }
+  for (int j = 0; j < n; ++j)
+    for (int i = 0; i < m; ++i) { double s = 0.0; for (int kk = 0; kk < n; ++kk) s += Bm[kk + i * n] * P[kk + j * n]; T2[i + j * m] = 0.0 + s; }
+  for (int i = 0; i < n; ++i) { double s = 0.0; for (int kk = 0; kk < n; ++kk) s += P[i + kk * n] * f[kk]; t[i] = pp[i] + s; }
+  for (int j = 0; j < n; ++j)
+    for (int i = 0; i < n; ++i) { double s = 0.0; for (int kk = 0; kk < n; ++kk) s += T1[i + kk * n] * A[kk + j * n]; Qxx[i + j * n] = Qxx[i + j * n] + s; }
+  for (int j = 0; j < m; ++j)
+    for (int i = 0; i < m; ++i) { double s = 0.0; for (int kk = 0; kk < n; ++kk) s += T2[i + kk * m] * Bm[kk + j * n]; Quu[i + j * m] = Quu[i + j * m] + s; }
+  for (int j = 0; j < n; ++j)
+    for (int i = 0; i < m; ++i) { double s = 0.0; for (int kk = 0; kk < n; ++kk) s += T2[i + kk * m] * A[kk + j * n]; Qux[i + j * m] = Qux[i + j * m] + s; }
+  for (int i = 0; i < n; ++i) { double s = 0.0; for (int kk = 0; kk < n; ++kk) s += A[kk + i * n] * t[kk]; Qx[i] = Qx[i] + s; }
+  for (int i = 0; i < m; ++i) { double s = 0.0; for (int kk = 0; kk < n; ++kk) s += Bm[kk + i * n] * t[kk]; Qu[i] = Qu[i] + s; }
+  // the scratch twins as the reference leaves them: chol(Quu + reg I) in place, Quu K, K^T Qux, K^T Qu, Quu d
+  double L[m * m], QuuK[m * n], KtQux[n * n], KtQu[n], Quud[m];
+  for (int e = 0; e < m * m; ++e) L[e] = Quu[e] + ((e % m == e / m) ? reg : 0.0);
+  for (int kk = 0; kk < m; ++kk) {
+    double x = L[kk + kk * m];
+    for (int j = 0; j < kk; ++j) x -= L[kk + j * m] * L[kk + j * m];
+    x = sqrt(x);
+    L[kk + kk * m] = x;
+    for (int i = kk + 1; i < m; ++i) {
+      double s = L[i + kk * m];
+      for (int j = 0; j < kk; ++j) s -= L[i + j * m] * L[kk + j * m];
+      L[i + kk * m] = s / x;
+    }
+  }
+  for (int j = 0; j < n; ++j)
+    for (int i = 0; i < m; ++i) { double s = 0.0; for (int kk = 0; kk < m; ++kk) s += Quu[i + kk * m] * K[kk + j * m]; QuuK[i + j * m] = 0.0 + s; }
+  for (int j = 0; j < n; ++j)
+    for (int i = 0; i < n; ++i) { double s = 0.0; for (int kk = 0; kk < m; ++kk) s += K[kk + i * m] * Qux[kk + j * m]; KtQux[i + j * n] = 0.0 + s; }
+  for (int i = 0; i < n; ++i) { double s = 0.0; for (int kk = 0; kk < m; ++kk) s += K[kk + i * m] * Qu[kk]; KtQu[i] = 0.0 + s; }
+  for (int i = 0; i < m; ++i) { double s = 0.0; for (int kk = 0; kk < m; ++kk) s += Quu[i + kk * m] * d[kk]; Quud[i] = 0.0 + s; }
+  double* h;
+  h = at(G_K); for (int e = 0; e < m * n; ++e) h[e] = K[e];
+  h = at(G_d); for (int e = 0; e < m; ++e) h[e] = d[e];
+  h = at(G_P); for (int e = 0; e < n * n; ++e) h[e] = o[D::O_P + e];
+  h = at(G_p); for (int e = 0; e < n; ++e) h[e] = o[D::O_p + e];
+  h = at(G_Qxx); for (int e = 0; e < n * n; ++e) h[e] = Qxx[e];
+  h = at(G_Quu); for (int e = 0; e < m * m; ++e) h[e] = Quu[e];
+  h = at(G_Qux); for (int e = 0; e < m * n; ++e) h[e] = Qux[e];
+  h = at(G_Qx); for (int e = 0; e < n; ++e) h[e] = Qx[e];
+  h = at(G_Qu); for (int e = 0; e < m; ++e) h[e] = Qu[e];
+  h = at(G_Qxx_tmp); for (int e = 0; e < n * n; ++e) h[e] = KtQux[e];
+  h = at(G_Quu_tmp); for (int e = 0; e < m * m; ++e) h[e] = L[e];
+  h = at(G_Qux_tmp); for (int e = 0; e < m * n; ++e) h[e] = QuuK[e];
+  h = at(G_Qx_tmp); for (int e = 0; e < n; ++e) h[e] = KtQu[e];
+  h = at(G_Qu_tmp); for (int e = 0; e < m; ++e) h[e] = Quud[e];
+}
+ALTRO_FP_REGION_END
+
+#define DROPIN_SHAPES(X)                                                                                 \
+  X(1, 1) X(2, 1) X(3, 1) X(4, 1) X(5, 1) X(6, 1) X(1, 2) X(2, 2) X(3, 2) X(4, 2) X(5, 2) X(6, 2) X(1, 3) \
+  X(2, 3) X(3, 3) X(4, 3) X(5, 3) X(6, 3)
+
+struct FastWs {           // device + pinned staging of the batch-of-one LANE records (per thread, grown on demand)
+  double* dev = nullptr;
+  double* host = nullptr;
+  size_t elems = 0;
+  ~FastWs() {
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess || c <= 0) return;
+    if (dev) (void)hipFree(dev);
+    if (host) (void)hipHostFree(host);
+  }
+};
+thread_local FastWs g_fast;
+
+bool fast_shape(const int* nx, const int* nu, int N, int* n_out, int* m_out) {
+  if (N < 1) return false;
+  const int n = nx[0], m = nu[0];
+  if (n < 1 || n > 6 || m < 1 || m > 3) return false;
+  for (int k = 0; k <= N; ++k)
+    if (nx[k] != n || (k < N && nu[k] != m)) return false;
+  *n_out = n; *m_out = m;
+  return true;
+}
+
+// returns 0 when the fast path ran to completion (outputs and status in the pinned arena w.host), 1 to fall back
+int fast_backward(Workspace& w, const Layout& L, int n, int m, int N, const double* const* A, const double* const* B,
+                  const double* const* f, const double* const* Q, const double* const* R, const double* const* H,
+                  const double* const* q, const double* const* r, double reg, bool is_diag) {
+  if (std::getenv("ALTRO_TVLQR_DROPIN_GENERIC") != nullptr) return 1;   // A/B hook: always the GENERIC kernel
+  const int e_in = 2 * n * n + 2 * n * m + m * m + 2 * n + m, e_term = n * n + n, e_out = m * n + m + n * n + n;
+  const size_t in_elems = (size_t)N * e_in + e_term;
+  const size_t total = in_elems + (size_t)N * e_out + e_term + 4;
+  FastWs& fw = g_fast;
+  if (fw.elems < total) {
+    if (fw.dev) (void)hipFree(fw.dev);
+    if (fw.host) (void)hipHostFree(fw.host);
+    fw.dev = nullptr; fw.host = nullptr; fw.elems = 0;
+    if (hipMalloc(&fw.dev, total * sizeof(double)) != hipSuccess) { fw.dev = nullptr; return 1; }
+    if (hipHostMalloc((void**)&fw.host, in_elems * sizeof(double) + 64, hipHostMallocDefault) != hipSuccess) {
+      (void)hipFree(fw.dev); fw.dev = nullptr; fw.host = nullptr; return 1;
+    }
+    fw.elems = total;
+  }
+  // plan LANE's record of one knot point: A | B | f | Q | R | H | q | r (kernels/tvlqr_lane.hip, LaneDims)
+  const int oB = n * n, of = oB + n * m, oQ = of + n, oR = oQ + n * n, oH = oR + m * m, oq = oH + m * n, orr = oq + n;
+  auto put = [](double* dst, const double* src, int cnt) {
+    if (src) memcpy(dst, src, sizeof(double) * cnt);
+    else memset(dst, 0, sizeof(double) * cnt);
+  };
+  auto put_sym = [&](double* dst, const double* src, int dim) {   // a diagonal block (is_diag) expanded to the dense one
+    if (!is_diag) { put(dst, src, dim * dim); return; }
+    memset(dst, 0, sizeof(double) * dim * dim);
+    for (int i = 0; i < dim; ++i) dst[i + i * dim] = src[i];
+  };
+  for (int k = 0; k < N; ++k) {
+    double* rec = fw.host + (size_t)k * e_in;
+    put(rec, A[k], n * n); put(rec + oB, B[k], n * m); put(rec + of, f[k], n);
+    put_sym(rec + oQ, Q[k], n); put_sym(rec + oR, R[k], m);
+    put(rec + oH, is_diag ? nullptr : H[k], m * n);
+    put(rec + oq, q[k], n); put(rec + orr, r[k], m);
+  }
+  {
+    double* tr = fw.host + (size_t)N * e_in;
+    put_sym(tr, Q[N], n); put(tr + n * n, q[N], n);
+  }
+  double* d_in = fw.dev;
+  double* d_term = d_in + (size_t)N * e_in;
+  double* d_out = d_term + e_term;
+  double* d_outn = d_out + (size_t)N * e_out;
+  double* d_dv = d_outn + e_term;
+  int* d_status = reinterpret_cast<int*>(d_dv + 2);
+  if (hipMemcpyAsync(d_in, fw.host, in_elems * sizeof(double), hipMemcpyHostToDevice, w.stream) != hipSuccess) return 1;
+  LaneArgs<double> a{d_in, d_term, d_out, d_outn, nullptr, nullptr, d_dv, d_status, N, 1, reg, nullptr, nullptr};
+  bool done = false;
+  if (n == 4 && m == 2) { hipLaunchKernelGGL((quad_backward_kernel<2, double>), dim3(8), dim3(64), 0, w.stream, a); done = true; }
+  else if (n == 2 && m == 1) { hipLaunchKernelGGL((quad2_backward_kernel<double>), dim3(8), dim3(64), 0, w.stream, a); done = true; }
+#define X(N_, M_)                                                                                                     \
+  if (!done && n == N_ && m == M_) { hipLaunchKernelGGL((lane_backward_kernel<N_, M_, double>), dim3(8), dim3(64), 0, w.stream, a); done = true; }
+  DROPIN_SHAPES(X)
+#undef X
+  if (!done || hipGetLastError() != hipSuccess) return 1;
+  const dim3 qgrid((N + 1 + 63) / 64), qblock(64);
+  done = false;
+#define X(N_, M_)                                                                                                     \
+  if (!done && n == N_ && m == M_) {                                                                                  \
+    hipLaunchKernelGGL((dropin_qblocks_kernel<N_, M_>), qgrid, qblock, 0, w.stream, (const double*)d_in, (const double*)d_term,     \
+                       (const double*)d_out, (const double*)d_outn, (const double*)d_dv, (const int*)d_status, N, reg, w.host_dev,  \
+                       (const int64_t*)w.dev_off, (int64_t)L.total);                                                  \
+    done = true;                                                                                                      \
+  }
+  DROPIN_SHAPES(X)
+#undef X
+  if (!done || hipGetLastError() != hipSuccess) return 1;
+  if (hipStreamSynchronize(w.stream) != hipSuccess) return 1;
+  int status;
+  memcpy(&status, w.host + L.total - 2, sizeof(int));
+  return status == TVLQR_SUCCESS ? 0 : 1;   // a failed factorisation: the GENERIC path reproduces the reference's early return
+}
+
 }  // namespace
 
 int tvlqr_BackwardPass(const int* nx, const int* nu, int num_horizon, const lqr_float* const* A,
@@ -210,11 +404,14 @@ int tvlqr_BackwardPass(const int* nx, const int* nu, int num_horizon, const lqr_
   const Layout L = make_layout(nx, nu, N, is_diag);
   if (prepare(w, L, nx, nu)) return TVLQR_NO_DEVICE;
   double* hs = w.host;
+  int fn = 0, fm = 0;
+  const bool fast = fast_shape(nx, nu, N, &fn, &fm) && fast_backward(w, L, fn, fm, N, A, B, f, Q, R, H, q, r, reg, is_diag) == 0;
   auto put = [&](int arr, int k, const double* src, int64_t cnt) {
     if (!cnt) return;
     if (src) memcpy(hs + L.off[(size_t)k * G_NUM + arr], src, sizeof(double) * cnt);
     else memset(hs + L.off[(size_t)k * G_NUM + arr], 0, sizeof(double) * cnt);   // an absent block is a zero block
   };
+  if (!fast) {
   for (int k = 0; k <= N; ++k) {
     const int n = nx[k];
     put(G_Q, k, Q[k], is_diag ? n : (int64_t)n * n);
@@ -235,6 +432,7 @@ int tvlqr_BackwardPass(const int* nx, const int* nu, int num_horizon, const lqr_
   hipLaunchKernelGGL(generic_backward_kernel<double>, dim3(1), dim3(64), lds, w.stream, a);
   if (hipGetLastError() != hipSuccess) return TVLQR_NO_DEVICE;
   if (hipStreamSynchronize(w.stream) != hipSuccess) return TVLQR_NO_DEVICE;
+  }
   int status;
   memcpy(&status, hs + L.total - 2, sizeof(int));
   auto get = [&](int arr, int k, double* dst, int64_t cnt) {
