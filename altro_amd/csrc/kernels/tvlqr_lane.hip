@@ -128,18 +128,55 @@ struct LaneFwdRec {
 };
 
 // ---- the kernels, in two arithmetic flavours (see tvlqr_lane_body.inc) ---------------------------------------------
+// Division and square root of the gain solve.  The exact flavour uses the IEEE operations (what keeps the CPU path's bits and
+// what the chain of a small sweep mostly waits for: ~350 cycles per knot point for (2, 1)); the fused flavour
+// (ALTRO_HIP_LANE_FUSED, already 1e-12 rather than bit-identical) uses v_rcp_f64 / v_rsq_f64 with two Newton steps and one
+// correction -- within an ulp or two of the IEEE result, a fraction of its latency.
+template <typename T>
+__device__ __forceinline__ T lane_fast_div(T a, T b) {
+  if constexpr (sizeof(T) == 8) {
+    double r = __builtin_amdgcn_rcp(b);
+    r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+    const double q = a * r;
+    return __builtin_fma(__builtin_fma(-b, q, a), r, q);
+  } else {
+    return a / b;
+  }
+}
+template <typename T>
+__device__ __forceinline__ T lane_fast_sqrt(T x) {
+  if constexpr (sizeof(T) == 8) {
+    if (!(x > 0.0)) return sqrt(x);              // zero, negative, NaN: the library's answer (the caller tests x <= 0 first)
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * __builtin_fma(__builtin_fma(-x * y, y, 1.0), 0.5, 1.0);
+    y = y * __builtin_fma(__builtin_fma(-x * y, y, 1.0), 0.5, 1.0);
+    const double s = x * y;
+    return __builtin_fma(__builtin_fma(-s, s, x), 0.5 * y, s);
+  } else {
+    return sqrt(x);
+  }
+}
 ALTRO_FP_REGION_OFF
 #define LANE_FN(x) x
+#define LANE_DIV(a, b) ((a) / (b))
+#define LANE_SQRT(x) sqrt(x)
 #include "tvlqr_lane_body.inc"
 #include "tvlqr_quad_body.inc"
 #include "tvlqr_quad2_body.inc"
 #undef LANE_FN
+#undef LANE_DIV
+#undef LANE_SQRT
 ALTRO_FP_REGION_FAST
 #define LANE_FN(x) x##_fused
+#define LANE_DIV(a, b) lane_fast_div((a), (b))
+#define LANE_SQRT(x) lane_fast_sqrt(x)
 #include "tvlqr_lane_body.inc"
 #include "tvlqr_quad_body.inc"
 #include "tvlqr_quad2_body.inc"
 #undef LANE_FN
+#undef LANE_DIV
+#undef LANE_SQRT
 
 ALTRO_FP_REGION_END   // back to the including translation unit's own mode (fp_contract.h)
 
