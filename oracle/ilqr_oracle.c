@@ -96,6 +96,7 @@ typedef struct {
   int iterations_max;
   double tol_stationarity, tol_primal_feasibility, tol_meritfun_gradient;
   int use_backtracking;
+  double ls_c1, ls_c2; /* CubicLineSearch::SetOptimalityTolerances (linesearch.cpp), defaults 1e-4 / 0.9 */
   /* results */
   double phi0, dphi0, phi, dphi;
   int ls_iters, iterations, status, backward_status;
@@ -139,6 +140,7 @@ void* oracle_ilqr_create(int N, int n, int m, float h, int dyn_kind, int model_k
   s->tol_primal_feasibility = 1e-4;
   s->tol_meritfun_gradient = 1e-8;
   s->use_backtracking = 0;
+  s->ls_c1 = 1e-4; s->ls_c2 = 0.9;
   return s;
 }
 
@@ -626,6 +628,7 @@ int oracle_ilqr_forward_pass(void* h, double* alpha) {
   oracle_ls_defaults(&ls);
   ls.try_cubic_first = 1;
   ls.use_backtracking = s->use_backtracking;
+  ls.c1 = s->ls_c1; ls.c2 = s->ls_c2;
   *alpha = oracle_ls_run(&ls, merit_cb, h, 1.0, s->phi0, s->dphi0);
   s->phi = ls.phi;
   s->dphi = ls.dphi;
@@ -722,6 +725,34 @@ GETTER(lu, lu, (size_t)s->m * s->N)
 GETTER(lxx, lxx, (size_t)s->n * s->n * (s->N + 1))
 GETTER(luu, luu, (size_t)s->m * s->m * s->N)
 GETTER(lux, lux, (size_t)s->n * s->m * s->N)
+/* --- the pieces solver/test/alilqr_test.cpp:112-215 sequences by hand ------------- */
+/* solver.ls_.SetOptimalityTolerances(c1, c2) (the solver's own line search object persists between passes) */
+void oracle_ilqr_set_linesearch_tolerances(void* h, double c1, double c2) {
+  oracle_ilqr* s = (oracle_ilqr*)h;
+  s->ls_c1 = c1; s->ls_c2 = c2;
+}
+void oracle_ilqr_dual_update(void* h) { /* solver.cpp:383-388 */
+  oracle_ilqr* s = (oracle_ilqr*)h;
+  for (int k = 0; k <= s->N; ++k) oracle_al_dual_update(&s->cons[k]);
+}
+void oracle_ilqr_penalty_update(void* h) { /* solver.cpp:390-395 */
+  oracle_ilqr* s = (oracle_ilqr*)h;
+  for (int k = 0; k <= s->N; ++k) oracle_al_penalty_update(&s->cons[k], s->penalty_scaling, s->penalty_max);
+  s->rho = fmin(s->rho * s->penalty_scaling, s->penalty_max);
+}
+/* the per-knot-point refresh the test runs before each block of iterations (alilqr_test.cpp:126-133):
+ * CalcDynamicsExpansion, CalcConstraints, CalcConstraintJacobians, CalcProjectedDuals, CalcConicJacobians,
+ * CalcCostGradient -- on the candidate trajectory (x_, u_), which equals the nominal one after CopyTrajectory */
+void oracle_ilqr_refresh_expansions(void* h) {
+  oracle_ilqr* s = (oracle_ilqr*)h;
+  for (int k = 0; k <= s->N; ++k) {
+    if (k < s->N) kp_dynamics_expansion(s, k);
+    kp_constraints(s, k);
+    oracle_al_projected_duals(&s->cons[k]);
+    kp_cost_gradient(s, k);
+  }
+}
+
 int oracle_ilqr_iterations(void* h) { return ((oracle_ilqr*)h)->iterations; }
 int oracle_ilqr_merit_evals(void* h) { return ((oracle_ilqr*)h)->n_merit_evals; }
 double oracle_ilqr_delta_V(void* h, int i) { return ((oracle_ilqr*)h)->delta_V[i]; }

@@ -106,6 +106,10 @@ def lib():
         L.oracle_ilqr_add_linear_constraint.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.oracle_ilqr_set_penalty_options.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double]
         L.oracle_ilqr_feasibility.argtypes = [C.c_void_p]
+        L.oracle_ilqr_set_linesearch_tolerances.argtypes = [C.c_void_p, C.c_double, C.c_double]
+        for name in ("dual_update", "penalty_update", "refresh_expansions"):
+            getattr(L, "oracle_ilqr_" + name).argtypes = [C.c_void_p]
+            getattr(L, "oracle_ilqr_" + name).restype = None
         L.oracle_ilqr_feasibility.restype = C.c_double
         L.oracle_cone_projection.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.oracle_cone_jacobian.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]

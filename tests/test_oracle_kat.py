@@ -461,3 +461,57 @@ def test_knotpoint_al_golden_vectors(kats):
     assert np.linalg.norm(r["lx"] - k["lx"]) < tol and np.linalg.norm(r["lu"] - k["lu"]) < tol
     assert np.linalg.norm(r["lxx"] - np.array(k["lxx"]).reshape(3, 3)) < 1e-13
     assert np.linalg.norm(r["lux"]) == 0.0 and np.allclose(r["luu"], k["luu_const"], rtol=1e-12)
+
+
+def test_pendulum_alilqr_hand_sequenced(kats):
+    """solver/test/alilqr_test.cpp:112-215: the reference's own AL-iLQR test drives SolverImpl by hand -- phi(0) of
+    the open-loop rollout (AL terms included) = 10.632455092693577, six iterations with the line search at
+    (c1, c2) = (1e-4, 0.1) leave the pendulum 0.04186387 from the goal, a dual + penalty update and six more shrink
+    that more than five-fold, a dual + two penalty updates and six more bring it under 1e-4."""
+    kat = kats["pendulum_alilqr_hand_sequenced"]
+    N = kat["N"]; n, m = 2, 1
+    h = np.float32(np.float32(kat["tf"]) / float(N))
+    s = oracle.ILQR(N, n, m, h, oracle.DYN_MODEL, oracle.MODEL_PENDULUM, cost_kind=oracle.COST_DIAGONAL)
+    L = s.L
+    xf = np.array(kat["xf_pi"]) * np.pi
+    for k in range(N + 1):
+        Qd = np.full(n, kat["Qfd"] if k == N else kat["Qd"])
+        L.oracle_ilqr_set_lqr_cost(s.h, k, Qd, np.full(m, kat["Rd"]), xf.copy(), np.zeros(m))
+    L.oracle_ilqr_set_initial_state(s.h, np.array(kat["x0"], dtype=float))
+    G = np.zeros((n, n + m)); G[:, :n] = -np.eye(n)
+    s.add_linear_constraint(N, oracle.CONE_EQUALITY, G, -xf)
+    L.oracle_ilqr_initialize(s.h)
+    for k in range(N):
+        L.oracle_ilqr_set_input(s.h, k, np.full(m, kat["u_init"]))
+    L.oracle_ilqr_open_loop_rollout(s.h)
+    L.oracle_ilqr_copy_trajectory(s.h)
+    phi0, _ = s.merit(0.0, deriv=False)
+    assert abs(phi0 - kat["phi0"]) < kat["phi0_tol"]
+
+    L.oracle_ilqr_set_linesearch_tolerances(s.h, kat["ls_c1"], kat["ls_c2"])
+
+    def block():
+        L.oracle_ilqr_refresh_expansions(s.h)
+        dist = None
+        for _ in range(kat["iterations_per_block"]):
+            L.oracle_ilqr_calc_expansions(s.h)
+            L.oracle_ilqr_backward_pass(s.h)
+            err, alpha = s.forward_pass()
+            if err == 1:      # MeritFunctionGradientTooSmall: the reference's later blocks break here
+                break
+            assert err == 0
+            dist = np.linalg.norm(s.get("x_cand")[-1] - xf)
+            L.oracle_ilqr_copy_trajectory(s.h)
+        return dist if dist is not None else np.linalg.norm(s.get("x")[-1] - xf)
+
+    d1 = block()
+    assert abs(d1 - kat["dist_after_block1"]) < kat["dist_after_block1_tol"], d1
+    L.oracle_ilqr_dual_update(s.h)
+    L.oracle_ilqr_penalty_update(s.h)
+    d2 = block()
+    assert d2 < d1 / kat["block2_ratio"], (d1, d2)
+    L.oracle_ilqr_dual_update(s.h)
+    L.oracle_ilqr_penalty_update(s.h)
+    L.oracle_ilqr_penalty_update(s.h)
+    d3 = block()
+    assert d3 < kat["final_dist_tol"], d3
