@@ -101,6 +101,19 @@ def test_pendulum_solve_reference_pin(kats):
     assert np.array_equal(xN[0], xN[2])
 
 
+def test_bicycle_turn90_reference_pin(kats):
+    """test/bicycle_test.cpp:53-138 through the batched device solver: from rest, backtracking line search, at most 30
+    iterations, the car ends within 1e-2 of (1, 2, pi/2, 0)."""
+    kat = kats["bicycle_turn90"]
+    c = CASES["bicycle"]
+    bt = make_hip(c["model"], c["N"], 4, 2, c["h"], c["Qd"], c["Rd"], c["Qfd"], c["xf"], np.zeros((3, 4)), c["u0"])
+    res = bt.ilqr_solve(iterations_max=kat["iterations_max"], use_backtracking=True)
+    xN = bt.get("x")[:, -1]
+    assert np.linalg.norm(xN[0] - np.asarray(c["xf"], dtype=float)) < kat["goal_tol"]
+    assert np.array_equal(xN[0], xN[2])
+    assert (res["iterations"] <= kat["iterations_max"] + 1).all()
+
+
 @pytest.mark.parametrize("name", list(CASES))
 def test_solve_agrees_iteration_by_iteration(name):
     """Where the arithmetic is the same the comparison is tight: stop the device solve and the oracle after 1, 2, 3, 4

@@ -515,3 +515,23 @@ def test_pendulum_alilqr_hand_sequenced(kats):
     L.oracle_ilqr_penalty_update(s.h)
     d3 = block()
     assert d3 < kat["final_dist_tol"], d3
+
+
+def test_bicycle_turn90(kats):
+    """test/bicycle_test.cpp:53-138: the unconstrained 90-degree turn with the backtracking line search ends within
+    1e-2 of the goal."""
+    kat = kats["bicycle_turn90"]
+    N = kat["N"]; n, m = 4, 2
+    h = np.float32(np.float32(kat["tf"]) / float(N))
+    s = oracle.ILQR(N, n, m, h, oracle.DYN_MODEL, oracle.MODEL_BICYCLE, cost_kind=oracle.COST_DIAGONAL)
+    xf = np.array([1.0, 2.0, np.pi / 2, 0.0])
+    for k in range(N + 1):
+        Qd = np.full(n, kat["Qfd"] if k == N else kat["Qd"])
+        s.L.oracle_ilqr_set_lqr_cost(s.h, k, Qd, np.full(m, kat["Rd"]), xf.copy(), np.zeros(m))
+    s.L.oracle_ilqr_set_initial_state(s.h, np.array(kat["x0"], dtype=float))
+    s.L.oracle_ilqr_initialize(s.h)
+    for k in range(N):
+        s.L.oracle_ilqr_set_input(s.h, k, np.array(kat["u_init"], dtype=float))
+    s.L.oracle_ilqr_set_options(s.h, kat["iterations_max"], 1e-4, 1e-4, 1e-8, kat["use_backtracking"])
+    status, iters, log = s.solve()
+    assert np.linalg.norm(s.get("x")[-1] - xf) < kat["goal_tol"]
