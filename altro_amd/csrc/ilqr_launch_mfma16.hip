@@ -4,6 +4,7 @@
 #include <algorithm>
 
 #include "kernels/ilqr_mfma16.hip"
+#include "kernels/ilqr_merit2_dpp.hip"
 
 namespace altro_hip {
 
@@ -30,6 +31,7 @@ static int wave_launch(hipStream_t stream, int which, const IlqrWaveArgs<S>& a) 
       break;
     case IK_MERIT2:
       if (a.al.enabled) hipLaunchKernelGGL((wave_merit2_kernel<S, true>), waves, b64, 0, stream, a);
+      else if (a.mode == 2) hipLaunchKernelGGL((wave_merit2_dpp_kernel<S>), dim3(mf_grid((a.batch + 1) / 2)), b64, 0, stream, a);   // two problems per wave
       else if (sizeof(S) == 8 && a.mode == 1) hipLaunchKernelGGL((wave_merit2_mfma_kernel<S>), waves, b64, 0, stream, a);   // mode 1: asked for by altro_hip_ilqr_solve
       else hipLaunchKernelGGL((wave_merit2_kernel<S, false>), waves, b64, 0, stream, a);
       break;

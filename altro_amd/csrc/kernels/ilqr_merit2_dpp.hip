@@ -1,0 +1,281 @@
+// kernels/ilqr_merit2_dpp.hip -- wave_merit2_kernel's two-trial merit evaluation (SolverImpl::MeritFunction,
+// solver.cpp:273-355, for phi(0) and the line search's first step alpha0 = 1 in one pass over the records) with the operand
+// broadcast moved from the LDS pipe to the VALU's data-parallel primitives, and TWO PROBLEMS PER WAVE.
+//
+// wave_merit2_kernel is bound by the LDS pipe: ~100 LDS instructions per knot point, most of them every
+// lane re-reading the vector its row multiplies.  tools/ldsbench.hip prices an LDS wave instruction at 1.2-2.1 ns of the
+// CU's one pipe (whatever the width, broadcast or not, 16 lanes active or 64) and `v_fmac_f64_dpp ... row_newbcast:c` --
+// acc += (lane c of my row of 16 lanes) * coefficient, gfx90a+ -- at the price of a plain v_fma_f64 on the SIMD's own VALU.
+// So a trial lives in ONE ROW OF 16 LANES:
+//     lane j < 12 : x_j, dx_j/dalpha           -- row j of Z = [A B] (next state), row j of [P | p] (y)
+//     lane 12 + i : u_i, du_i/dalpha           -- row i of Kt = [K | -d]
+// the vector [x; u] IS the row's registers, every product is sixteen (twelve) DPP multiply-adds, and nothing of the
+// recursion goes through LDS.  A wave has four such rows: two problems x two trials (lane = 32 * slot + 16 * trial + j).
+// What still crosses LDS is the transposition of the records -- loaded coalesced, 16 bytes per lane, each half wave its own
+// problem's; read back as rows of coefficients -- and one column read of Z per knot point for the stationarity.
+//
+// Per trial every sum is taken in wave_merit2_kernel's order with its expressions (same FMA contraction), and the final
+// wave sums are taken over the same 32-entry arrangement, so phi, dphi, the candidate trajectory, the gradient and the
+// stationarity are BIT-IDENTICAL to that kernel's (tests/test_gpu_merit2.py).  Unconstrained problems (no AL rows: those
+// need lanes of their own); everything else runs wave_merit2_kernel.
+#pragma once
+
+namespace altro_hip {
+
+constexpr int MD_ZLD = 18;                   // Z rows padded to 18: rows stay 16-byte aligned, 16 lanes reading a column hit 16 bank pairs
+constexpr int MD_OUT0 = 12 * MD_ZLD;         // 216
+constexpr int MD_F0 = MD_OUT0 + MF_OUT;      // 360
+constexpr int MD_NOM0 = MD_F0 + 12;          // 372
+constexpr int MD_CP0 = MD_NOM0 + MF_NOM;     // 388
+constexpr int MD_IMG = MD_CP0 + MF_COSTP;    // 424
+static_assert(MF_DYN % 2 == 0 && MF_OUT % 2 == 0 && MF_NOM % 2 == 0 && MF_COSTP % 2 == 0 && MD_IMG % 2 == 0, "records move as pairs");
+
+typedef double md_d2 __attribute__((ext_vector_type(2)));
+typedef float md_f2 __attribute__((ext_vector_type(2)));
+template <typename S> struct md_pair_of;
+template <> struct md_pair_of<double> { typedef md_d2 type; };
+template <> struct md_pair_of<float> { typedef md_f2 type; };
+template <typename S>
+__device__ __forceinline__ md_d2 md_ld(const S* __restrict__ p, int pair) {
+  const typename md_pair_of<S>::type v = *reinterpret_cast<const typename md_pair_of<S>::type*>(p + 2 * pair);
+  return md_d2{(double)v[0], (double)v[1]};
+}
+struct MeritPairRegs { md_d2 z[3], f, o[3], nm, cp; };   // one knot point's records of one problem, spread over 32 lanes
+template <typename S>
+__device__ __forceinline__ void merit_pair_load(MeritPairRegs& r, const S* __restrict__ z, const S* __restrict__ o,
+                                                const S* __restrict__ nm, const S* __restrict__ cp, int hl) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c) r.z[c] = md_ld<S>(z, c * 32 + hl);           // Z: 96 pairs
+  r.f = md_ld<S>(z, 96 + (hl < 6 ? hl : 5));                               // f: 6 pairs
+#pragma unroll
+  for (int c = 0; c < 2; ++c) r.o[c] = md_ld<S>(o, c * 32 + hl);           // OUT: 72 pairs
+  r.o[2] = md_ld<S>(o, 64 + (hl & 7));
+  r.nm = md_ld<S>(nm, hl & 7);                                             // nominal: 8 pairs
+  r.cp = md_ld<S>(cp, hl < 18 ? hl : 17);                                  // cost parameters: 18 pairs
+}
+__device__ __forceinline__ void merit_pair_stage(const MeritPairRegs& r, double* __restrict__ L, int hl) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int pi = c * 32 + hl;
+    *reinterpret_cast<md_d2*>(L + (pi >> 3) * MD_ZLD + (pi & 7) * 2) = r.z[c];
+  }
+  *reinterpret_cast<md_d2*>(L + MD_F0 + 2 * (hl < 6 ? hl : 5)) = r.f;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) *reinterpret_cast<md_d2*>(L + MD_OUT0 + 2 * (c * 32 + hl)) = r.o[c];
+  *reinterpret_cast<md_d2*>(L + MD_OUT0 + 2 * (64 + (hl & 7))) = r.o[2];
+  *reinterpret_cast<md_d2*>(L + MD_NOM0 + 2 * (hl & 7)) = r.nm;
+  *reinterpret_cast<md_d2*>(L + MD_CP0 + 2 * (hl < 18 ? hl : 17)) = r.cp;
+}
+
+// acc += (lane N of this lane's row of 16 lanes of v) * coef.  The hazard recogniser does not look inside inline assembly:
+// a DPP read needs 2 wait states after a VALU write of its source (5 after a VALU write of EXEC) -- every block of these
+// instructions therefore starts with `s_nop 4`, and no block reads a register that the block itself writes through DPP.
+// (volatile: a block must stay where the whole wave executes it -- sunk into a branch only some lanes take, its broadcasts
+//  would read lanes that are switched off.)
+#define MD_BC(N) " row_newbcast:" #N " row_mask:0xf bank_mask:0xf\n"
+// block A: %0 += bc(%2) * coef, %1 += bc(%3) * coef      (two sums against the same twelve coefficients %4 .. %15)
+#define MD_A(N, OP) "v_fmac_f64_dpp %0, %2, %" #OP MD_BC(N) "v_fmac_f64_dpp %1, %3, %" #OP MD_BC(N)
+__device__ __forceinline__ void md_rows12(double& acc, double& acc2, double v, double v2, const double (&c)[13]) {
+  asm volatile("s_nop 4\n" MD_A(0, 4) MD_A(1, 5) MD_A(2, 6) MD_A(3, 7) MD_A(4, 8) MD_A(5, 9) MD_A(6, 10) MD_A(7, 11) MD_A(8, 12) MD_A(9, 13)
+      MD_A(10, 14) MD_A(11, 15)
+      : "+v"(acc), "+v"(acc2)
+      : "v"(v), "v"(v2), "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5]), "v"(c[6]), "v"(c[7]), "v"(c[8]), "v"(c[9]),
+        "v"(c[10]), "v"(c[11]));
+}
+// block B: rows of Z = [A B] against [x; u] (%4) and its sensitivity (%5): the A part into %0 / %1, the B part into %2 / %3
+#define MD_B(N, OP) "v_fmac_f64_dpp %0, %4, %" #OP MD_BC(N) "v_fmac_f64_dpp %1, %5, %" #OP MD_BC(N)
+#define MD_BU(N, OP) "v_fmac_f64_dpp %2, %4, %" #OP MD_BC(N) "v_fmac_f64_dpp %3, %5, %" #OP MD_BC(N)
+__device__ __forceinline__ void md_rows16(double& acc, double& acc2, double& s2, double& t2, double w, double dw, const double (&c)[16]) {
+  asm volatile("s_nop 4\n" MD_B(0, 6) MD_B(1, 7) MD_B(2, 8) MD_B(3, 9) MD_B(4, 10) MD_B(5, 11) MD_B(6, 12) MD_B(7, 13) MD_B(8, 14) MD_B(9, 15)
+      MD_B(10, 16) MD_B(11, 17) MD_BU(12, 18) MD_BU(13, 19) MD_BU(14, 20) MD_BU(15, 21)
+      : "+v"(acc), "+v"(acc2), "+v"(s2), "+v"(t2)
+      : "v"(w), "v"(dw), "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5]), "v"(c[6]), "v"(c[7]), "v"(c[8]), "v"(c[9]),
+        "v"(c[10]), "v"(c[11]), "v"(c[12]), "v"(c[13]), "v"(c[14]), "v"(c[15]));
+}
+// block C: one sum against twelve coefficients
+#define MD_C(N, OP) "v_fmac_f64_dpp %0, %1, %" #OP MD_BC(N)
+__device__ __forceinline__ void md_col12(double& acc, double v, const double (&c)[12]) {
+  asm volatile("s_nop 4\n" MD_C(0, 2) MD_C(1, 3) MD_C(2, 4) MD_C(3, 5) MD_C(4, 6) MD_C(5, 7) MD_C(6, 8) MD_C(7, 9) MD_C(8, 10) MD_C(9, 11)
+      MD_C(10, 12) MD_C(11, 13)
+      : "+v"(acc)
+      : "v"(v), "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5]), "v"(c[6]), "v"(c[7]), "v"(c[8]), "v"(c[9]), "v"(c[10]),
+        "v"(c[11]));
+}
+
+template <typename S>
+__global__ __launch_bounds__(64) void wave_merit2_dpp_kernel(IlqrWaveArgs<S> a) {
+  constexpr int DEPTH = 2;                          // also the image ping-pong: parity of k == dd
+  constexpr bool kStat = sizeof(S) == 8;            // stored values == computed values only without a rounding store
+  __shared__ double img[2][2][MD_IMG];              // [parity][slot]
+  __shared__ double red[2][4][32];                  // the final sums, in wave_merit2_kernel's lane arrangement
+  const int lane = threadIdx.x;
+  const int npairs = (a.batch + 1) >> 1;
+  const int pr = mf_problem(blockIdx.x, npairs);
+  if (pr >= npairs) return;
+  const int slot = lane >> 5, h = (lane >> 4) & 1, j = lane & 15, hl = lane & 31;
+  const int b_own = 2 * pr + slot, b_oth = 2 * pr + (1 - slot);
+  const bool ok_own = b_own < a.batch && !(a.active && !a.active[b_own]);
+  const bool ok_oth = b_oth < a.batch && !(a.active && !a.active[b_oth]);
+  if (!ok_own && !ok_oth) return;                   // (the same two answers in every lane: wave-uniform)
+  const int b = ok_own ? b_own : b_oth;             // a slot without a problem shadows the other one and stores nothing
+  const bool wr = ok_own;
+  const int N = a.N;
+  const double alpha = h ? 1.0 : (a.alpha ? a.alpha[b] : a.alpha_const);
+  const bool isx = j < 12;
+  const bool cand = h == 1 && wr;                   // trial 1 writes the candidate trajectory and the expansion
+  const int jr = isx ? j : 11;                      // a valid row for the lanes that own none
+  S* __restrict__ candb = a.cand + (size_t)b * a.xuy_bs;
+  const S* __restrict__ dynb = a.dyn + (size_t)b * a.dyn_bs;
+  const S* __restrict__ outb = a.out + (size_t)b * a.out_bs;
+  const S* __restrict__ nomb = a.nom + (size_t)b * MF_NOM;
+  const S* __restrict__ cpb = a.costp + (size_t)b * MF_COSTP;
+  const size_t nom_ks = (size_t)a.batch * MF_NOM, cp_ks = (size_t)a.batch * MF_COSTP;
+  // where this lane's coefficients sit in the image: row j of [P | p] (lanes < 12) or row j - 12 of Kt (lanes 12..15)
+  int ra[13];
+#pragma unroll
+  for (int c = 0; c < 12; ++c) ra[c] = isx ? MD_OUT0 + MF_OFF_P + mf_sym(j, c) : MD_OUT0 + (j - 12) * 13 + c;
+  ra[12] = isx ? MD_OUT0 + MF_OFF_p + j : MD_OUT0 + (j - 12) * 13 + 12;
+  double x = isx ? (double)a.x0[(size_t)b * 12 + j] : 0.0;
+  double dxda = 0.0;
+  double J = 0.0, dJ = 0.0, res = 0.0;
+  double lprev = 0.0, yprev = 0.0;                  // gradient and y of knot point k - 1 (the stationarity's lag)
+  MeritPairRegs ring[DEPTH];
+#pragma unroll
+  for (int dd = 0; dd < DEPTH; ++dd) {
+    const size_t kk = dd < N ? dd : N - 1;
+    merit_pair_load<S>(ring[dd], dynb + kk * a.dyn_ks, outb + kk * a.out_ks, nomb + kk * nom_ks, cpb + kk * cp_ks, hl);
+  }
+  const int Npad = ((N + DEPTH - 1) / DEPTH) * DEPTH;
+  for (int k0 = 0; k0 < Npad; k0 += DEPTH) {
+#pragma unroll
+   for (int dd = 0; dd < DEPTH; ++dd) {
+    const int k = k0 + dd;
+    const bool live = k < N;
+    const int kc = live ? k : N - 1;
+    double* const L = img[dd][slot];
+    merit_pair_stage(ring[dd], L, hl);
+    {
+      const size_t kn = (k + DEPTH < N) ? k + DEPTH : N - 1;
+      merit_pair_load<S>(ring[dd], dynb + kn * a.dyn_ks, outb + kn * a.out_ks, nomb + kn * nom_ks, cpb + kn * cp_ks, hl);
+    }
+    __syncthreads();
+    // (1) rows of [P | p] and of Kt against dx and dx/dalpha
+    double cA[13];
+#pragma unroll
+    for (int c = 0; c < 13; ++c) cA[c] = L[ra[c]];
+    const double wnom = L[MD_NOM0 + j];                      // nominal x_j | u_(j-12)
+    const double cq = L[MD_CP0 + j], cl = L[MD_CP0 + 16 + j];   // Qd | Rd and q | r line up with [x; u]
+    const double dx = x - wnom;
+    double acc = 0.0, acc2 = 0.0;
+    md_rows12(acc, acc2, dx, dxda, cA);
+    const double aff = cA[12];                               // p_j | -d_i
+    const double d = -aff;
+    const double uval = wnom + (-acc + alpha * d);           // u_ = u + (-K dx + alpha d)        (lanes 12..15)
+    const double duval = -acc2 + d;                          // du/dalpha = -K dx/dalpha + d
+    const double y = acc + aff;                              // y_ = P dx + p                     (lanes 0..11)
+    const double w = isx ? x : uval, dw = isx ? dxda : duval;
+    // (2) the stationarity at knot point k - 1 now that y_k is known: column j of Z_(k-1) against y_k
+    if (kStat && live && k >= 1) {
+      const double* const Lp = img[dd ^ 1][slot];
+      double cZ[12];
+#pragma unroll
+      for (int rr = 0; rr < 12; ++rr) cZ[rr] = Lp[rr * MD_ZLD + j];
+      double sy = 0.0;
+      md_col12(sy, y, cZ);
+      const double g = lprev + sy;
+      if (cand) res = fmax(res, fabs(isx ? g - yprev : g));
+    }
+    // (3) rows of Z against [x; u] and its sensitivity; costs, gradient, dphi
+    double cR[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) cR[c] = L[jr * MD_ZLD + c];
+    double zacc = 0.0, zacc2 = 0.0, s2 = 0.0, t2 = 0.0;
+    md_rows16(zacc, zacc2, s2, t2, w, dw, cR);
+    const double xn = (zacc + s2) + L[MD_F0 + jr];           // x+ = A x + B u + f
+    const double dxn = zacc2 + t2;                           // dx+/dalpha = A dx/dalpha + B du/dalpha
+    if (live) {
+      J += 0.5 * (w * (cq * w)) + cl * w;
+      if (j == 0) J += L[MD_CP0 + 32];
+    }
+    // (an explicit fma: cq * w also feeds the cost above, and a product with two uses is not contracted -- wave_merit2_kernel
+    //  forms this gradient from its own loads, where it is)
+    const double l = __builtin_fma(cq, w, cl);               // lx_j | lu_(j-12)
+    if (live) dJ += l * dw;
+    if (cand) {   // trial 1's candidate record x | y | u and its [lx lu]
+      S* c = candb + (size_t)(live ? k : N) * a.xuy_ks;
+      if (isx) c[j] = (S)x;
+      c[12 + j] = (S)(isx ? y : uval);
+      if (live) a.cin[(size_t)b * a.cin_bs + (size_t)kc * a.cin_ks + MF_OFF_QR + j] = (S)l;
+    }
+    if (live) { lprev = l; yprev = y; if (isx) { x = xn; dxda = dxn; } }
+   }
+  }
+  {   // terminal knot point (solver.cpp:319-332), both trials
+    const S* nm = a.nom + ((size_t)N * a.batch + b) * MF_NOM;
+    const S* cp = a.costp + ((size_t)N * a.batch + b) * MF_COSTP;
+    const S* on = a.outn + (size_t)b * MF_TERM;
+    S* c = candb + (size_t)N * a.xuy_ks;
+    const double dxN = x - (double)nm[jr];
+    const double Qd = (double)cp[jr], q = (double)cp[16 + jr];
+    if (isx) {
+      J += 0.5 * (x * (Qd * x)) + q * x;
+      if (j == 0) J += (double)cp[32];
+    }
+    double cP[13];
+#pragma unroll
+    for (int cc = 0; cc < 13; ++cc) cP[cc] = (double)on[jr * 13 + cc];
+    double sacc = 0.0, unused = 0.0;
+    md_rows12(sacc, unused, dxN, dxda, cP);
+    const double yN = sacc + cP[12];
+    const double lx = __builtin_fma(Qd, x, q);
+    if (isx) dJ += lx * dxda;
+    if (cand) {
+      if (isx) {
+        c[j] = (S)x;
+        c[12 + j] = (S)yN;
+        a.term[(size_t)b * MF_TERM + 144 + j] = (S)lx;
+      } else {
+        c[12 + j] = S(0);
+      }
+    }
+    if (kStat) {
+      const double* const Lp = img[(N - 1) & 1][slot];     // the last LIVE step's image (a padding step writes the other parity)
+      double cZ[12];
+#pragma unroll
+      for (int rr = 0; rr < 12; ++rr) cZ[rr] = Lp[rr * MD_ZLD + j];
+      double sy = 0.0;
+      md_col12(sy, yN, cZ);
+      const double g = lprev + sy;
+      if (cand) {
+        res = fmax(res, fabs(isx ? g - yprev : g));
+        if (isx) res = fmax(res, fabs(lx - yN));
+      }
+    }
+  }
+  // the sums, over wave_merit2_kernel's arrangement of the addends: a trial's 32 entries hold the state terms at 0..11, the
+  // input terms at 16..19 (dphi: 12..15), zeros elsewhere, and are added by the butterfly of offsets 16 .. 1
+  __syncthreads();
+  for (int e = lane; e < 2 * 4 * 32; e += 64) (&red[0][0][0])[e] = 0.0;
+  __syncthreads();
+  red[0][lane >> 4][isx ? j : j + 4] = J;
+  red[1][lane >> 4][j] = dJ;
+  __syncthreads();
+#pragma unroll
+  for (int sl = 0; sl < 2; ++sl) {
+    const int trial = lane >> 5, e = lane & 31;
+    const double phi = half_sum(red[0][2 * sl + trial][e]), dphi = half_sum(red[1][2 * sl + trial][e]);
+    const int bs = 2 * pr + sl;
+    const bool oks = sl == slot ? ok_own : ok_oth;
+    if (e == 0 && oks) {
+      a.phi[(size_t)trial * a.batch + bs] = phi;
+      a.dphi[(size_t)trial * a.batch + bs] = dphi;
+    }
+  }
+  if (kStat) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) res = fmax(res, __shfl_xor(res, o, 64));   // over this slot's 32 lanes
+    if (hl == 0 && wr) { a.prob[b].stationarity = res; a.prob[b].feasibility = 0.0; }
+  }
+}
+
+}  // namespace altro_hip

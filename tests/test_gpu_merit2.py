@@ -128,3 +128,39 @@ def test_matrix_core_form_of_the_dual_evaluation():
         b = _solve(p, N, [], False, iterations_max=6)
         assert (a["status"] == 0).all()
         _same(a, b, "mfma N=%d" % N)
+
+
+def _with_env(name, value, fn):
+    old = os.environ.get(name)
+    os.environ[name] = value
+    try:
+        return fn()
+    finally:
+        if old is None:
+            del os.environ[name]
+        else:
+            os.environ[name] = old
+
+
+@pytest.mark.parametrize("batch,N,with_f", [(67, 24, True), (1, 7, True), (2, 1, False), (130, 25, False), (64, 2, True)])
+def test_dpp_form_is_bit_identical_to_the_lds_form(batch, N, with_f):
+    """wave_merit2_dpp_kernel (the default for unconstrained problems: broadcasts by `v_fmac_f64_dpp row_newbcast`, two problems
+    per wave) against wave_merit2_kernel (ALTRO_HIP_MERIT2_DPP=0): same sums in the same order -- bit for bit, for odd batches
+    (a wave with one problem), odd horizons (the padding step) and a batch where a third of the problems start at their optimum and drop
+    out of the second sweep (a wave whose two problems are not both running)."""
+    p = _problem(batch, N, with_f)
+    if batch >= 3 and not with_f:
+        p["x0"][::3] = 0.0
+    a = _with_env("ALTRO_HIP_MERIT2_DPP", "1", lambda: _solve(p, N, [], True, iterations_max=6))
+    b = _with_env("ALTRO_HIP_MERIT2_DPP", "0", lambda: _solve(p, N, [], True, iterations_max=6))
+    assert (a["status"] == 0).all()
+    for k in ("status", "iterations", "phi", "stationarity", "feasibility", "alpha", "x", "u", "xc", "uc", "yc", "K", "d"):
+        assert np.array_equal(a[k], b[k]), (k, float(np.abs(np.asarray(a[k], dtype=float) - np.asarray(b[k], dtype=float)).max()))
+
+
+def test_dpp_form_fp32_storage_is_bit_identical_to_the_lds_form():
+    p = _problem(45, 24, True)
+    a = _with_env("ALTRO_HIP_MERIT2_DPP", "1", lambda: _solve(p, 24, [], True, dtype=altro_amd.F32, iterations_max=6))
+    b = _with_env("ALTRO_HIP_MERIT2_DPP", "0", lambda: _solve(p, 24, [], True, dtype=altro_amd.F32, iterations_max=6))
+    for k in ("status", "iterations", "phi", "stationarity", "alpha", "x", "u", "xc", "uc", "yc"):
+        assert np.array_equal(a[k], b[k]), k
