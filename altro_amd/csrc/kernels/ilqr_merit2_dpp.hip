@@ -278,4 +278,8 @@ __global__ __launch_bounds__(64) void wave_merit2_dpp_kernel(IlqrWaveArgs<S> a) 
   }
 }
 
+// (The open-loop rollout was built the same way -- one problem per row of 16 lanes, two per wave -- and measured against
+//  wave_rollout_kernel in alternation on one box: 0.579 vs 0.564 ms on C1.  That kernel's LDS traffic is a third of the merit
+//  evaluation's and it already runs at the record stream's rate, so the LDS form stays; profiles/r03r_rollout_ab.txt.)
+
 }  // namespace altro_hip

@@ -164,3 +164,4 @@ def test_dpp_form_fp32_storage_is_bit_identical_to_the_lds_form():
     b = _with_env("ALTRO_HIP_MERIT2_DPP", "0", lambda: _solve(p, 24, [], True, dtype=altro_amd.F32, iterations_max=6))
     for k in ("status", "iterations", "phi", "stationarity", "alpha", "x", "u", "xc", "uc", "yc"):
         assert np.array_equal(a[k], b[k]), k
+

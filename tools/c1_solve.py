@@ -2,7 +2,7 @@
 """C1 (BASELINE.json configs[1]: N = 256, n = 12, m = 4, 4096 problems) as whole iLQR solves on plan MFMA16: wall time per
 altro_hip_ilqr_solve (host clock, stream drained), for A/B runs (ALTRO_HIP_MERIT2=0/1) and for rocprofv3 --kernel-trace.
 
-    python tools/c1_solve.py [solves] [batch] [horizon] [--al]
+    python tools/c1_solve.py [solves] [batch] [horizon] [--al] [--alternate=ENV_SWITCH]
 """
 import os
 import sys
@@ -32,8 +32,11 @@ def main():
     if al:   # input bounds as an INEQUALITY block: the AL path of the same shape
         G = np.zeros((2 * m, n + m)); G[:m, n:] = np.eye(m); G[m:, n:] = -np.eye(m)
         bt.add_linear_constraint(0, N - 1, altro_amd.CONE_INEQUALITY, G, np.full(2 * m, 2.0))
+    alternate = [a.split("=")[1] for a in sys.argv if a.startswith("--alternate=")]   # an environment switch flipped 1 / 0 per solve
     ts = []
     for i in range(solves + 1):
+        if alternate:
+            os.environ[alternate[0]] = str(i & 1)
         bt.set_input_guess(np.zeros((1, 1, m)), k_stride_zero=True, batch_stride_zero=True)
         if al:
             bt.reset_duals(1.0)
