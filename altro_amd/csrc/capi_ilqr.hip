@@ -907,7 +907,7 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
     //  kernels/ilqr_merit2_dpp.hip -- unconstrained problems, bit-identical; ALTRO_HIP_MERIT2_DPP=0 keeps the LDS form)
     const char* md = std::getenv("ALTRO_HIP_MERIT2_DPP");
     const bool merit_dpp = md == nullptr || std::atoi(md) != 0;
-    const int merit2_mode = al ? 0 : (merit_mfma && h->dtype == ALTRO_HIP_F64) ? 1 : merit_dpp ? 2 : 0;
+    const int merit2_mode = (merit_mfma && !al && h->dtype == ALTRO_HIP_F64) ? 1 : merit_dpp ? 2 : 0;
     rc = dual ? ilqr_run(h, IK_MERIT2, true, true, 1, 0.0, merit2_mode)
               : ilqr_run(h, IK_MERIT, true, true, 1, 0.0);
     h->spec_trials = 1; h->spec_pre = 0;

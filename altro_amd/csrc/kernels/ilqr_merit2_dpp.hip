@@ -16,8 +16,7 @@
 //
 // Per trial every sum is taken in wave_merit2_kernel's order with its expressions (same FMA contraction), and the final
 // wave sums are taken over the same 32-entry arrangement, so phi, dphi, the candidate trajectory, the gradient and the
-// stationarity are BIT-IDENTICAL to that kernel's (tests/test_gpu_merit2.py).  Unconstrained problems (no AL rows: those
-// need lanes of their own); everything else runs wave_merit2_kernel.
+// stationarity are BIT-IDENTICAL to that kernel's (tests/test_gpu_merit2.py).  Constraint blocks ride in the same rows (dpp_al_rows below).
 #pragma once
 
 namespace altro_hip {
@@ -102,8 +101,112 @@ __device__ __forceinline__ void md_col12(double& acc, double v, const double (&c
         "v"(c[11]));
 }
 
+// ---- constraint blocks in the row layout ------------------------------------------------------------------------------------------
+// wave_al_rows / wave_al_col (ilqr_mfma16.hip) with the point [x; u] in the row's registers: lane i < 8 of the row owns
+// row i of each of the (at most two) blocks -- c_i = G_i [x; u] - g_i is one more 16-term DPP chain, its coefficients the
+// lane's row of G --, forms the estimated / projected dual, the AL cost share, the violation and (J^T z_proj)_i, which STAYS in
+// the lane; the gradient's column sums  sum_c sum_i G_c[i][e] (J^T z_proj)_i  are a 16-term chain in lane e against those.  A
+// second-order-cone block (p <= 4) is evaluated by every lane of the row from the four row values (broadcast), as the one
+// lane of wave_al_rows does.  Same expressions, same order of the sums (terms that do not exist enter as exact zeros).
+#define MD_K(N, OP) "v_fmac_f64_dpp %0, %1, %" #OP MD_BC(N)
+__device__ __forceinline__ void md_chain16(double& acc, double v, const double (&c)[16]) {
+  asm volatile("s_nop 4\n" MD_K(0, 2) MD_K(1, 3) MD_K(2, 4) MD_K(3, 5) MD_K(4, 6) MD_K(5, 7) MD_K(6, 8) MD_K(7, 9) MD_K(8, 10) MD_K(9, 11)
+      MD_K(10, 12) MD_K(11, 13) MD_K(12, 14) MD_K(13, 15) MD_K(14, 16) MD_K(15, 17)
+      : "+v"(acc)
+      : "v"(v), "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5]), "v"(c[6]), "v"(c[7]), "v"(c[8]), "v"(c[9]), "v"(c[10]),
+        "v"(c[11]), "v"(c[12]), "v"(c[13]), "v"(c[14]), "v"(c[15]));
+}
+__device__ __forceinline__ void md_chain8(double& acc, double v, const double (&c)[8]) {
+  asm volatile("s_nop 4\n" MD_K(0, 2) MD_K(1, 3) MD_K(2, 4) MD_K(3, 5) MD_K(4, 6) MD_K(5, 7) MD_K(6, 8) MD_K(7, 9)
+      : "+v"(acc)
+      : "v"(v), "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5]), "v"(c[6]), "v"(c[7]));
+}
+// lanes 0..3 of the row, to every lane of the row
+__device__ __forceinline__ void md_gather4(double v, double (&o)[4]) {
+  asm volatile("s_nop 4\n"
+               "v_mov_b64_dpp %0, %4" MD_BC(0) "v_mov_b64_dpp %1, %4" MD_BC(1) "v_mov_b64_dpp %2, %4" MD_BC(2) "v_mov_b64_dpp %3, %4" MD_BC(3)
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3])
+      : "v"(v));
+}
 template <typename S>
-__global__ __launch_bounds__(64) void wave_merit2_dpp_kernel(IlqrWaveArgs<S> a) {
+__device__ __forceinline__ void dpp_al_rows(const AlTable<S>& t, int k, int b, int64_t B, double w, bool terminal, double rho_est, int j,
+                                            double (&jvr)[AL_MAXC], double& cost, double& viol) {
+  int zshift;
+  const AlKnot ALTRO_CONST_AS& kn = al_knot<S>(t, k, zshift);
+#pragma unroll
+  for (int c = 0; c < AL_MAXC; ++c) {
+    jvr[c] = 0.0;
+    if (c >= kn.ncon) continue;                     // (wave-uniform: the table is the handle's)
+    const int p = kn.p[c], cone = kn.cone[c];
+    const S* G = t.G + kn.G_off[c];
+    const bool rl = j < p;                          // this lane owns a row of the block
+    const int jr = rl ? j : 0;
+    double cG[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const double ge = (double)G[jr + e * p];
+      cG[e] = (rl && !(terminal && e >= 12)) ? ge : 0.0;
+    }
+    double sacc = 0.0;
+    md_chain16(sacc, w, cG);
+    const double gi = rl ? (kn.g_per_problem[c] ? (double)t.g[kn.g_off[c] + (int64_t)jr * B + b] : (double)t.g[kn.g_off[c] + jr]) : 0.0;
+    const double val = sacc - gi;
+    const double zi = (double)t.z[(int64_t)(kn.z_off[c] + zshift + jr) * B + b];
+    const double ze = rl ? zi - rho_est * val : 0.0;
+    if (cone != CONE_SOC) {
+      if (rl) {
+        double zp = 0.0, mkv = 0.0;
+        if (cone == CONE_EQUALITY) { zp = ze; mkv = 1.0; viol = fmax(viol, fabs(val)); }
+        else if (cone == CONE_INEQUALITY) { zp = fmin(0.0, ze); mkv = (ze <= 0.0) ? 1.0 : 0.0; viol = fmax(viol, fabs(fmin(0.0, val) - val)); }
+        cost += zp * zp / (2.0 * rho_est);
+        jvr[c] = mkv * zp;
+      }
+    } else {
+      double valv[AL_MAXSOC], zev[AL_MAXSOC], zpv[AL_MAXSOC], pv[AL_MAXSOC];
+      md_gather4(val, valv);
+      md_gather4(ze, zev);
+      soc_projection<double>(p, zev, zpv);
+      soc_projection<double>(p, valv, pv);
+      double sq = 0.0;
+#pragma unroll
+      for (int r = 0; r < AL_MAXSOC; ++r)
+        if (r < p) { sq += zpv[r] * zpv[r]; viol = fmax(viol, fabs(pv[r] - valv[r])); }
+      if (j == 0) cost += sq / (2.0 * rho_est);
+      double Jc[AL_MAXSOC * AL_MAXSOC];
+      soc_jacobian<double>(p, zev, Jc);
+#pragma unroll
+      for (int r = 0; r < AL_MAXSOC; ++r) {
+        double sj = 0.0;
+#pragma unroll
+        for (int q = 0; q < AL_MAXSOC; ++q) sj += Jc[q + r * AL_MAXSOC] * zpv[q];     // (J^T z_proj)_r
+        if (r < p && j == r) jvr[c] = sj;
+      }
+    }
+  }
+}
+template <typename S>
+__device__ __forceinline__ double dpp_al_col(const AlTable<S>& t, int k, int j, const double (&jvr)[AL_MAXC]) {
+  int zshift;
+  const AlKnot ALTRO_CONST_AS& kn = al_knot<S>(t, k, zshift);
+  double s = 0.0;
+#pragma unroll
+  for (int c = 0; c < AL_MAXC; ++c) {
+    if (c >= kn.ncon) continue;
+    const int p = kn.p[c];
+    const S* G = t.G + kn.G_off[c];
+    double cC[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const double gi = (double)G[(i < p ? i : 0) + j * p];
+      cC[i] = i < p ? gi : 0.0;
+    }
+    md_chain8(s, jvr[c], cC);
+  }
+  return s;
+}
+
+template <typename S, bool AL>
+__global__ __launch_bounds__(64, 2) void wave_merit2_dpp_kernel(IlqrWaveArgs<S> a) {
   constexpr int DEPTH = 2;                          // also the image ping-pong: parity of k == dd
   constexpr bool kStat = sizeof(S) == 8;            // stored values == computed values only without a rounding store
   __shared__ double img[2][2][MD_IMG];              // [parity][slot]
@@ -121,6 +224,8 @@ __global__ __launch_bounds__(64) void wave_merit2_dpp_kernel(IlqrWaveArgs<S> a) 
   const bool wr = ok_own;
   const int N = a.N;
   const double alpha = h ? 1.0 : (a.alpha ? a.alpha[b] : a.alpha_const);
+  constexpr bool al = AL;
+  const double rho = al ? a.prob[b].rho : 1.0;
   const bool isx = j < 12;
   const bool cand = h == 1 && wr;                   // trial 1 writes the candidate trajectory and the expansion
   const int jr = isx ? j : 11;                      // a valid row for the lanes that own none
@@ -137,7 +242,8 @@ __global__ __launch_bounds__(64) void wave_merit2_dpp_kernel(IlqrWaveArgs<S> a) 
   ra[12] = isx ? MD_OUT0 + MF_OFF_p + j : MD_OUT0 + (j - 12) * 13 + 12;
   double x = isx ? (double)a.x0[(size_t)b * 12 + j] : 0.0;
   double dxda = 0.0;
-  double J = 0.0, dJ = 0.0, res = 0.0;
+  double J = 0.0, Jal = 0.0, dJ = 0.0, res = 0.0, viol = 0.0;   // (Jal: the constraint rows' cost shares, lanes 0..7)
+  double jvr[AL_MAXC] = {0.0, 0.0};
   double lprev = 0.0, yprev = 0.0;                  // gradient and y of knot point k - 1 (the stationarity's lag)
   MeritPairRegs ring[DEPTH];
 #pragma unroll
@@ -174,6 +280,12 @@ __global__ __launch_bounds__(64) void wave_merit2_dpp_kernel(IlqrWaveArgs<S> a) 
     const double duval = -acc2 + d;                          // du/dalpha = -K dx/dalpha + d
     const double y = acc + aff;                              // y_ = P dx + p                     (lanes 0..11)
     const double w = isx ? x : uval, dw = isx ? dxda : duval;
+    if (al) {   // both trials' constraint rows at the candidate point [x; u]; the feasibility that counts is trial 1's
+      double Ja = 0.0, vv = 0.0;
+      dpp_al_rows<S>(a.al, kc, b, a.batch, w, false, rho, j, jvr, Ja, vv);
+      if (live) Jal += Ja;
+      if (cand) viol = fmax(viol, vv);
+    }
     // (2) the stationarity at knot point k - 1 now that y_k is known: column j of Z_(k-1) against y_k
     if (kStat && live && k >= 1) {
       const double* const Lp = img[dd ^ 1][slot];
@@ -199,7 +311,8 @@ __global__ __launch_bounds__(64) void wave_merit2_dpp_kernel(IlqrWaveArgs<S> a) 
     }
     // (an explicit fma: cq * w also feeds the cost above, and a product with two uses is not contracted -- wave_merit2_kernel
     //  forms this gradient from its own loads, where it is)
-    const double l = __builtin_fma(cq, w, cl);               // lx_j | lu_(j-12)
+    double l = __builtin_fma(cq, w, cl);                     // lx_j | lu_(j-12)
+    if (al) l -= dpp_al_col<S>(a.al, kc, j, jvr);
     if (live) dJ += l * dw;
     if (cand) {   // trial 1's candidate record x | y | u and its [lx lu]
       S* c = candb + (size_t)(live ? k : N) * a.xuy_ks;
@@ -221,13 +334,20 @@ __global__ __launch_bounds__(64) void wave_merit2_dpp_kernel(IlqrWaveArgs<S> a) 
       J += 0.5 * (x * (Qd * x)) + q * x;
       if (j == 0) J += (double)cp[32];
     }
+    if (al) {
+      double Ja = 0.0, vv = 0.0;
+      dpp_al_rows<S>(a.al, N, b, a.batch, isx ? x : 0.0, true, rho, j, jvr, Ja, vv);
+      Jal += Ja;
+      if (cand) viol = fmax(viol, vv);
+    }
     double cP[13];
 #pragma unroll
     for (int cc = 0; cc < 13; ++cc) cP[cc] = (double)on[jr * 13 + cc];
     double sacc = 0.0, unused = 0.0;
     md_rows12(sacc, unused, dxN, dxda, cP);
     const double yN = sacc + cP[12];
-    const double lx = __builtin_fma(Qd, x, q);
+    double lx = __builtin_fma(Qd, x, q);
+    if (al) lx -= dpp_al_col<S>(a.al, N, jr, jvr);
     if (isx) dJ += lx * dxda;
     if (cand) {
       if (isx) {
@@ -260,6 +380,10 @@ __global__ __launch_bounds__(64) void wave_merit2_dpp_kernel(IlqrWaveArgs<S> a) 
   red[0][lane >> 4][isx ? j : j + 4] = J;
   red[1][lane >> 4][j] = dJ;
   __syncthreads();
+  if (al) {   // wave_merit2_kernel's row lanes are entries 16..23: (J + Jal) there
+    if (j < AL_MAXP) red[0][lane >> 4][16 + j] += Jal;
+    __syncthreads();
+  }
 #pragma unroll
   for (int sl = 0; sl < 2; ++sl) {
     const int trial = lane >> 5, e = lane & 31;
@@ -274,8 +398,13 @@ __global__ __launch_bounds__(64) void wave_merit2_dpp_kernel(IlqrWaveArgs<S> a) 
   if (kStat) {
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) res = fmax(res, __shfl_xor(res, o, 64));   // over this slot's 32 lanes
-    if (hl == 0 && wr) { a.prob[b].stationarity = res; a.prob[b].feasibility = 0.0; }
+    if (al) {
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) viol = fmax(viol, __shfl_xor(viol, o, 64));
+    }
+    if (hl == 0 && wr) { a.prob[b].stationarity = res; a.prob[b].feasibility = viol; }
   }
+  if (al && hl == 0 && wr) a.prob[b].rho_est = rho;
 }
 
 // (The open-loop rollout was built the same way -- one problem per row of 16 lanes, two per wave -- and measured against

@@ -165,3 +165,30 @@ def test_dpp_form_fp32_storage_is_bit_identical_to_the_lds_form():
     for k in ("status", "iterations", "phi", "stationarity", "alpha", "x", "u", "xc", "uc", "yc"):
         assert np.array_equal(a[k], b[k]), k
 
+
+
+def _soc_and_terminal_blocks(N):
+    """A second-order-cone block on the inputs at every k < N, an input-bound block beside it, and a terminal half-space block."""
+    w = n + m
+    Gs = np.zeros((4, w)); Gs[0, 12] = 1.0; Gs[1, 13] = 1.0; Gs[2, 14] = 1.0
+    Gb = np.zeros((2 * m, w)); Gb[:m, n:] = np.eye(m); Gb[m:, n:] = -np.eye(m)
+    Gt = np.zeros((3, w)); Gt[0, 0] = 1.0; Gt[1, 1] = -1.0; Gt[2, 5] = 1.0
+    return [(0, N - 1, altro_amd.CONE_SOC, Gs, np.array([0.0, 0.0, 0.0, -0.35])),
+            (0, N - 1, altro_amd.CONE_INEQUALITY, Gb, np.full(2 * m, 0.3)),
+            (N, N, altro_amd.CONE_INEQUALITY, Gt, np.array([0.4, 0.4, 0.2]))]
+
+
+@pytest.mark.parametrize("which,batch,N,dtype", [("bounds", 41, 24, altro_amd.F64), ("bounds", 6, 5, altro_amd.F64), ("soc", 23, 12, altro_amd.F64),
+                                                 ("bounds", 17, 8, altro_amd.F32)])
+def test_dpp_form_with_constraint_blocks_is_bit_identical_to_the_lds_form(which, batch, N, dtype):
+    """The constraint rows in the row layout (dpp_al_rows / dpp_al_col) against wave_merit2_kernel<S, true>: inequality and
+    equality blocks, two blocks per knot point, a second-order cone, a terminal block; whole solves with dual updates and
+    searches that go past the first step -- bit for bit."""
+    p = problems.ilqr12x4_problem(batch, N, True)
+    blocks = problems.ilqr12x4_constraint_blocks(N) if which == "bounds" else _soc_and_terminal_blocks(N)
+    kw = dict(iterations_max=40, penalty_initial=1.0, penalty_scaling=10.0)
+    a = _with_env("ALTRO_HIP_MERIT2_DPP", "1", lambda: _solve(p, N, blocks, True, dtype=dtype, **kw))
+    b = _with_env("ALTRO_HIP_MERIT2_DPP", "0", lambda: _solve(p, N, blocks, True, dtype=dtype, **kw))
+    assert (a["dual_updates"] > 0).any()
+    for k in ("status", "iterations", "dual_updates", "phi", "stationarity", "feasibility", "alpha", "penalty", "x", "u", "xc", "uc", "yc", "K", "d"):
+        assert np.array_equal(a[k], b[k]), (k, float(np.abs(np.asarray(a[k], dtype=float) - np.asarray(b[k], dtype=float)).max()))
