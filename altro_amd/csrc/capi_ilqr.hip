@@ -178,6 +178,10 @@ int wave_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int
   a.al.enabled = h->al_defs.empty() ? 0 : 1;
   a.al.uniform = h->al_uniform; a.al.rows_per_knot = h->al_rows_per_knot; a.al.N = h->N;
   a.mode = mode;
+  if (which == IK_MERIT) {   // a line-search round: the DPP form of the merit evaluation unless ALTRO_HIP_MERIT_DPP=0 keeps the LDS form
+    const char* e = std::getenv("ALTRO_HIP_MERIT_DPP");
+    a.mode = (e != nullptr && std::atoi(e) == 0) ? 0 : 2;
+  }
   a.dyn = (const S*)h->m_in; a.dyn_bs = h->m_st.in_bs; a.dyn_ks = h->m_st.in_ks;
   a.cin = (S*)h->m_cin; a.cin_bs = h->m_st.cin_bs; a.cin_ks = h->m_st.cin_ks;
   a.term = (S*)h->m_term; a.out = (const S*)h->m_out; a.out_bs = h->m_st.out_bs; a.out_ks = h->m_st.out_ks;

@@ -26,12 +26,16 @@ static int wave_launch(hipStream_t stream, int which, const IlqrWaveArgs<S>& a) 
       break;
     case IK_DUAL: hipLaunchKernelGGL(wave_dual_update_kernel<S>, dim3((unsigned)((int64_t)a.batch * (a.N + 1))), b64, 0, stream, a); break;
     case IK_MERIT:
-      if (a.al.enabled) hipLaunchKernelGGL((wave_merit_kernel<S, true>), dim3(waves.x, a.spec_trials > 1 ? a.spec_trials : 1), b64, 0, stream, a);
+      if (a.mode == 2) {   // the DPP form: two problems per wave, two trials per problem (kernels/ilqr_merit2_dpp.hip)
+        const dim3 grid(mf_grid((a.batch + 1) / 2), ((a.spec_trials > 1 ? a.spec_trials : 1) + 1) / 2);
+        if (a.al.enabled) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, true, false>), grid, b64, 0, stream, a);
+        else hipLaunchKernelGGL((wave_merit_dpp_kernel<S, false, false>), grid, b64, 0, stream, a);
+      } else if (a.al.enabled) hipLaunchKernelGGL((wave_merit_kernel<S, true>), dim3(waves.x, a.spec_trials > 1 ? a.spec_trials : 1), b64, 0, stream, a);
       else hipLaunchKernelGGL((wave_merit_kernel<S, false>), dim3(waves.x, a.spec_trials > 1 ? a.spec_trials : 1), b64, 0, stream, a);
       break;
     case IK_MERIT2:
-      if (a.mode == 2 && a.al.enabled) hipLaunchKernelGGL((wave_merit2_dpp_kernel<S, true>), dim3(mf_grid((a.batch + 1) / 2)), b64, 0, stream, a);
-      else if (a.mode == 2) hipLaunchKernelGGL((wave_merit2_dpp_kernel<S, false>), dim3(mf_grid((a.batch + 1) / 2)), b64, 0, stream, a);   // two problems per wave
+      if (a.mode == 2 && a.al.enabled) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, true, true>), dim3(mf_grid((a.batch + 1) / 2)), b64, 0, stream, a);
+      else if (a.mode == 2) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, false, true>), dim3(mf_grid((a.batch + 1) / 2)), b64, 0, stream, a);   // two problems per wave
       else if (a.al.enabled) hipLaunchKernelGGL((wave_merit2_kernel<S, true>), waves, b64, 0, stream, a);
       else if (sizeof(S) == 8 && a.mode == 1) hipLaunchKernelGGL((wave_merit2_mfma_kernel<S>), waves, b64, 0, stream, a);   // mode 1: asked for by altro_hip_ilqr_solve
       else hipLaunchKernelGGL((wave_merit2_kernel<S, false>), waves, b64, 0, stream, a);

@@ -205,12 +205,17 @@ __device__ __forceinline__ double dpp_al_col(const AlTable<S>& t, int k, int j, 
   return s;
 }
 
-template <typename S, bool AL>
-__global__ __launch_bounds__(64, 2) void wave_merit2_dpp_kernel(IlqrWaveArgs<S> a) {
+// DUAL: the two rows of a problem are trial 0 (alpha = a.alpha[b]) and trial 1 (alpha = 1) of wave_merit2_kernel (IK_MERIT2).
+// !DUAL: wave_merit_kernel (IK_MERIT, a line-search round): the rows are the speculative trials 2 blockIdx.y and 2 blockIdx.y + 1
+// of IlqrArgs::spec_trials (trial 0 = the step the search asked for), every row with its own step, candidate buffer and
+// outputs; a row without a trial computes along and stores nothing.  The wave sums are then taken over that kernel's 64-entry
+// arrangement (state terms 0..11, input terms 16..19, constraint rows 48..55) by the butterfly it uses.
+template <typename S, bool AL, bool DUAL>
+__global__ __launch_bounds__(64, 2) void wave_merit_dpp_kernel(IlqrWaveArgs<S> a) {
   constexpr int DEPTH = 2;                          // also the image ping-pong: parity of k == dd
   constexpr bool kStat = sizeof(S) == 8;            // stored values == computed values only without a rounding store
   __shared__ double img[2][2][MD_IMG];              // [parity][slot]
-  __shared__ double red[2][4][32];                  // the final sums, in wave_merit2_kernel's lane arrangement
+  __shared__ double red[2][4][64];                  // the final sums, in the LDS-form kernels' lane arrangement
   const int lane = threadIdx.x;
   const int npairs = (a.batch + 1) >> 1;
   const int pr = mf_problem(blockIdx.x, npairs);
@@ -223,13 +228,43 @@ __global__ __launch_bounds__(64, 2) void wave_merit2_dpp_kernel(IlqrWaveArgs<S> 
   const int b = ok_own ? b_own : b_oth;             // a slot without a problem shadows the other one and stores nothing
   const bool wr = ok_own;
   const int N = a.N;
-  const double alpha = h ? 1.0 : (a.alpha ? a.alpha[b] : a.alpha_const);
+  // this row's trial: its step, where its candidate goes, what it stores
+  int trial = h;
+  double alpha = a.alpha ? a.alpha[b] : a.alpha_const;
+  bool store = true, deriv = true, row_on = wr;
+  S* __restrict__ candb = a.cand + (size_t)b * a.xuy_bs;
+  if constexpr (DUAL) {
+    if (h) alpha = 1.0;
+  } else {
+    trial = 2 * (int)blockIdx.y + h;
+    row_on = wr && trial < (a.spec_trials > 1 ? a.spec_trials : 1);
+    if (trial > 0 && a.spec_pre) {                  // (see wave_merit_kernel)
+      if (trial > 1) row_on = false;
+      alpha = 1.0;
+      candb = a.cand_spec + (size_t)b * a.xuy_bs;
+      store = false;
+    } else if (trial > 0) {
+      const LsState& ls = a.prob[b].ls;
+      if (ls.stage == LS_STAGE_BACKTRACK) {
+        if (ls.bt_iter + trial >= a.ls_max_iters) row_on = false;
+      } else if (ls.stage == LS_STAGE_CUBIC) {
+        if (trial >= a.ls_max_iters) row_on = false;
+        alpha = ls.alpha0;
+      } else {
+        row_on = false;
+      }
+      for (int t = 0; t < trial; ++t) alpha = alpha * a.ls_beta;
+      candb = a.cand_spec + (size_t)(trial - 1) * a.spec_stride + (size_t)b * a.xuy_bs;
+    }
+    deriv = a.want_derivative != 0 && (trial == 0 || a.spec_pre);
+    if (!__any(row_on)) return;
+  }
   constexpr bool al = AL;
   const double rho = al ? a.prob[b].rho : 1.0;
   const bool isx = j < 12;
-  const bool cand = h == 1 && wr;                   // trial 1 writes the candidate trajectory and the expansion
+  const bool cand = DUAL ? (h == 1 && wr) : row_on; // DUAL: trial 1 writes the candidate trajectory and the expansion
+  const bool wqr = DUAL ? cand : (row_on && deriv && store);
   const int jr = isx ? j : 11;                      // a valid row for the lanes that own none
-  S* __restrict__ candb = a.cand + (size_t)b * a.xuy_bs;
   const S* __restrict__ dynb = a.dyn + (size_t)b * a.dyn_bs;
   const S* __restrict__ outb = a.out + (size_t)b * a.out_bs;
   const S* __restrict__ nomb = a.nom + (size_t)b * MF_NOM;
@@ -287,7 +322,7 @@ __global__ __launch_bounds__(64, 2) void wave_merit2_dpp_kernel(IlqrWaveArgs<S> 
       if (cand) viol = fmax(viol, vv);
     }
     // (2) the stationarity at knot point k - 1 now that y_k is known: column j of Z_(k-1) against y_k
-    if (kStat && live && k >= 1) {
+    if (DUAL && kStat && live && k >= 1) {
       const double* const Lp = img[dd ^ 1][slot];
       double cZ[12];
 #pragma unroll
@@ -318,7 +353,7 @@ __global__ __launch_bounds__(64, 2) void wave_merit2_dpp_kernel(IlqrWaveArgs<S> 
       S* c = candb + (size_t)(live ? k : N) * a.xuy_ks;
       if (isx) c[j] = (S)x;
       c[12 + j] = (S)(isx ? y : uval);
-      if (live) a.cin[(size_t)b * a.cin_bs + (size_t)kc * a.cin_ks + MF_OFF_QR + j] = (S)l;
+      if (live && wqr) a.cin[(size_t)b * a.cin_bs + (size_t)kc * a.cin_ks + MF_OFF_QR + j] = (S)l;
     }
     if (live) { lprev = l; yprev = y; if (isx) { x = xn; dxda = dxn; } }
    }
@@ -336,8 +371,12 @@ __global__ __launch_bounds__(64, 2) void wave_merit2_dpp_kernel(IlqrWaveArgs<S> 
     }
     if (al) {
       double Ja = 0.0, vv = 0.0;
-      dpp_al_rows<S>(a.al, N, b, a.batch, isx ? x : 0.0, true, rho, j, jvr, Ja, vv);
-      Jal += Ja;
+      if constexpr (DUAL) {
+        dpp_al_rows<S>(a.al, N, b, a.batch, isx ? x : 0.0, true, rho, j, jvr, Ja, vv);
+        Jal += Ja;
+      } else {   // (wave_merit_kernel adds the terminal blocks' shares to its running sum one by one)
+        dpp_al_rows<S>(a.al, N, b, a.batch, isx ? x : 0.0, true, rho, j, jvr, Jal, vv);
+      }
       if (cand) viol = fmax(viol, vv);
     }
     double cP[13];
@@ -353,12 +392,12 @@ __global__ __launch_bounds__(64, 2) void wave_merit2_dpp_kernel(IlqrWaveArgs<S> 
       if (isx) {
         c[j] = (S)x;
         c[12 + j] = (S)yN;
-        a.term[(size_t)b * MF_TERM + 144 + j] = (S)lx;
+        if (wqr) a.term[(size_t)b * MF_TERM + 144 + j] = (S)lx;
       } else {
         c[12 + j] = S(0);
       }
     }
-    if (kStat) {
+    if (DUAL && kStat) {
       const double* const Lp = img[(N - 1) & 1][slot];     // the last LIVE step's image (a padding step writes the other parity)
       double cZ[12];
 #pragma unroll
@@ -372,39 +411,53 @@ __global__ __launch_bounds__(64, 2) void wave_merit2_dpp_kernel(IlqrWaveArgs<S> 
       }
     }
   }
-  // the sums, over wave_merit2_kernel's arrangement of the addends: a trial's 32 entries hold the state terms at 0..11, the
-  // input terms at 16..19 (dphi: 12..15), zeros elsewhere, and are added by the butterfly of offsets 16 .. 1
+  // the sums, over the LDS-form kernels' arrangement of the addends.  DUAL: a trial's 32 entries hold the state terms at 0..11,
+  // the input terms at 16..19 (dphi: 12..15), the constraint rows' at 16..23, and are added by the butterfly of offsets 16 .. 1
   __syncthreads();
-  for (int e = lane; e < 2 * 4 * 32; e += 64) (&red[0][0][0])[e] = 0.0;
+  for (int e = lane; e < 2 * 4 * 64; e += 64) (&red[0][0][0])[e] = 0.0;
   __syncthreads();
   red[0][lane >> 4][isx ? j : j + 4] = J;
   red[1][lane >> 4][j] = dJ;
   __syncthreads();
-  if (al) {   // wave_merit2_kernel's row lanes are entries 16..23: (J + Jal) there
-    if (j < AL_MAXP) red[0][lane >> 4][16 + j] += Jal;
+  if (al) {   // the row lanes of wave_merit2_kernel are entries 16..23 ((J + Jal) there), of wave_merit_kernel 48..55
+    if (j < AL_MAXP) red[0][lane >> 4][(DUAL ? 16 : 48) + j] += Jal;
     __syncthreads();
   }
+  if constexpr (DUAL) {
 #pragma unroll
-  for (int sl = 0; sl < 2; ++sl) {
-    const int trial = lane >> 5, e = lane & 31;
-    const double phi = half_sum(red[0][2 * sl + trial][e]), dphi = half_sum(red[1][2 * sl + trial][e]);
-    const int bs = 2 * pr + sl;
-    const bool oks = sl == slot ? ok_own : ok_oth;
-    if (e == 0 && oks) {
-      a.phi[(size_t)trial * a.batch + bs] = phi;
-      a.dphi[(size_t)trial * a.batch + bs] = dphi;
+    for (int sl = 0; sl < 2; ++sl) {
+      const int tr = lane >> 5, e = lane & 31;
+      const double phi = half_sum(red[0][2 * sl + tr][e]), dphi = half_sum(red[1][2 * sl + tr][e]);
+      const int bs = 2 * pr + sl;
+      const bool oks = sl == slot ? ok_own : ok_oth;
+      if (e == 0 && oks) {
+        a.phi[(size_t)tr * a.batch + bs] = phi;
+        a.dphi[(size_t)tr * a.batch + bs] = dphi;
+      }
     }
-  }
-  if (kStat) {
+    if (kStat) {
 #pragma unroll
-    for (int o = 16; o > 0; o >>= 1) res = fmax(res, __shfl_xor(res, o, 64));   // over this slot's 32 lanes
-    if (al) {
+      for (int o = 16; o > 0; o >>= 1) res = fmax(res, __shfl_xor(res, o, 64));   // over this slot's 32 lanes
+      if (al) {
 #pragma unroll
-      for (int o = 16; o > 0; o >>= 1) viol = fmax(viol, __shfl_xor(viol, o, 64));
+        for (int o = 16; o > 0; o >>= 1) viol = fmax(viol, __shfl_xor(viol, o, 64));
+      }
+      if (hl == 0 && wr) { a.prob[b].stationarity = res; a.prob[b].feasibility = viol; }
     }
-    if (hl == 0 && wr) { a.prob[b].stationarity = res; a.prob[b].feasibility = viol; }
+    if (al && hl == 0 && wr) a.prob[b].rho_est = rho;
+  } else {
+    const unsigned long long on_mask = __ballot(row_on);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                     // row q of the wave: slot q / 2, trial 2 blockIdx.y + q % 2
+      const double phi = wave_sum(red[0][q][lane]), dphi = wave_sum(red[1][q][lane]);
+      const int tq = 2 * (int)blockIdx.y + (q & 1), bs = 2 * pr + (q >> 1);
+      if (lane == 0 && ((on_mask >> (16 * q)) & 1ull)) {
+        a.phi[(size_t)tq * a.batch + bs] = phi;
+        if (a.want_derivative != 0 && (tq == 0 || a.spec_pre)) a.dphi[(size_t)tq * a.batch + bs] = dphi;
+      }
+    }
+    if (al && j == 0 && row_on) a.prob[b].rho_est = rho;
   }
-  if (al && hl == 0 && wr) a.prob[b].rho_est = rho;
 }
 
 // (The open-loop rollout was built the same way -- one problem per row of 16 lanes, two per wave -- and measured against

@@ -192,3 +192,57 @@ def test_dpp_form_with_constraint_blocks_is_bit_identical_to_the_lds_form(which,
     assert (a["dual_updates"] > 0).any()
     for k in ("status", "iterations", "dual_updates", "phi", "stationarity", "feasibility", "alpha", "penalty", "x", "u", "xc", "uc", "yc", "K", "d"):
         assert np.array_equal(a[k], b[k]), (k, float(np.abs(np.asarray(a[k], dtype=float) - np.asarray(b[k], dtype=float)).max()))
+
+
+def _merit_direct(p, N, blocks, dtype=altro_amd.F64):
+    """altro_hip_merit (IK_MERIT) at per-problem steps after one expansion + backward pass: phi, phi', candidate, gradient."""
+    batch = p["x0"].shape[0]
+    bt = altro_amd.Batch(N, n, m, batch, dtype=dtype)
+    bt.set_dynamics(p["A"], p["B"], p["f"])
+    bt.set_tracking_cost(p["Qd"], p["Rd"], p["xref"], p["uref"])
+    bt.set_initial_state(p["x0"])
+    bt.set_input_guess(p["u0"])
+    for (k0, k1, cone, G, g) in blocks:
+        bt.add_linear_constraint(k0, k1, cone, G, g)
+    bt.open_loop_rollout(); bt.accept(); bt.expand(); bt.backward()
+    alphas = np.linspace(0.0, 1.4, batch)
+    phi, dphi = bt.merit(alphas)
+    out = dict(phi=phi, dphi=dphi, x=bt.get("x"), u=bt.get("u"), y=bt.get("y"))
+    out["stationarity"] = bt.stationarity()      # reads the gradient the evaluation left in the cost records
+    bt.backward()
+    out["d"] = bt.get("d")                       # ... and so does the next backward pass
+    phi1, _ = bt.merit(0.6, derivative=False)
+    out["phi_noderiv"], out["x2"] = phi1, bt.get("x")
+    bt.close()
+    return out
+
+
+@pytest.mark.parametrize("which,batch,N,dtype", [("none", 35, 24, altro_amd.F64), ("none", 1, 5, altro_amd.F64), ("bounds", 22, 9, altro_amd.F64),
+                                                 ("soc", 9, 12, altro_amd.F64), ("bounds", 12, 8, altro_amd.F32)])
+def test_dpp_single_step_form_is_bit_identical_to_the_lds_form(which, batch, N, dtype):
+    """wave_merit_dpp_kernel<.., DUAL = false> (the line-search rounds and altro_hip_merit; default) against wave_merit_kernel
+    (ALTRO_HIP_MERIT_DPP=0): one evaluation per problem at its own step, with and without the derivative."""
+    p = problems.ilqr12x4_problem(batch, N, True)
+    blocks = [] if which == "none" else problems.ilqr12x4_constraint_blocks(N) if which == "bounds" else _soc_and_terminal_blocks(N)
+    a = _with_env("ALTRO_HIP_MERIT_DPP", "1", lambda: _merit_direct(p, N, blocks, dtype))
+    b = _with_env("ALTRO_HIP_MERIT_DPP", "0", lambda: _merit_direct(p, N, blocks, dtype))
+    for k in a:
+        assert np.array_equal(a[k], b[k]), (k, float(np.abs(np.asarray(a[k], dtype=float) - np.asarray(b[k], dtype=float)).max()))
+    assert np.isfinite(a["phi"]).all() and np.abs(a["dphi"]).max() > 0
+
+
+@pytest.mark.parametrize("dual", [True, False])
+@pytest.mark.parametrize("which,batch,N,kw", [("bounds", 41, 24, dict()), ("soc", 14, 12, dict()), ("bounds", 19, 10, dict(use_backtracking=True)),
+                                              ("none", 30, 16, dict(use_backtracking=True))])
+def test_dpp_line_search_rounds_are_bit_identical_to_the_lds_form(which, batch, N, kw, dual):
+    """Whole solves whose searches go past the first step (speculative trials in the rounds, the spec_pre launch of the
+    one-evaluation-per-launch sequence with dual = False): the same numbers with the rounds on either form."""
+    p = problems.ilqr12x4_problem(batch, N, True)
+    blocks = [] if which == "none" else problems.ilqr12x4_constraint_blocks(N) if which == "bounds" else _soc_and_terminal_blocks(N)
+    opts = dict(iterations_max=40, penalty_initial=1.0, penalty_scaling=10.0, **kw)
+    a = _with_env("ALTRO_HIP_MERIT_DPP", "1", lambda: _solve(p, N, blocks, dual, **opts))
+    b = _with_env("ALTRO_HIP_MERIT_DPP", "0", lambda: _solve(p, N, blocks, dual, **opts))
+    if which != "none":
+        assert a["merit_launches"] > 2 * a["sweeps"]        # the rounds did run
+    for k in ("status", "iterations", "dual_updates", "phi", "stationarity", "feasibility", "alpha", "penalty", "x", "u", "xc", "uc", "yc", "K", "d"):
+        assert np.array_equal(a[k], b[k]), (k, float(np.abs(np.asarray(a[k], dtype=float) - np.asarray(b[k], dtype=float)).max()))
