@@ -180,7 +180,7 @@ int wave_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int
   a.mode = mode;
   if (which == IK_MERIT) {   // a line-search round: the DPP form of the merit evaluation unless ALTRO_HIP_MERIT_DPP=0 keeps the LDS form
     const char* e = std::getenv("ALTRO_HIP_MERIT_DPP");
-    a.mode = (e != nullptr && std::atoi(e) == 0) ? 0 : 2;
+    a.mode = e == nullptr ? 2 : std::atoi(e) == 0 ? 0 : std::atoi(e) == 2 ? 3 : 2;   // (2: the DPP form whatever the launcher's rule)
   }
   a.dyn = (const S*)h->m_in; a.dyn_bs = h->m_st.in_bs; a.dyn_ks = h->m_st.in_ks;
   a.cin = (S*)h->m_cin; a.cin_bs = h->m_st.cin_bs; a.cin_ks = h->m_st.cin_ks;

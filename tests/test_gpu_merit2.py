@@ -224,7 +224,7 @@ def test_dpp_single_step_form_is_bit_identical_to_the_lds_form(which, batch, N, 
     (ALTRO_HIP_MERIT_DPP=0): one evaluation per problem at its own step, with and without the derivative."""
     p = problems.ilqr12x4_problem(batch, N, True)
     blocks = [] if which == "none" else problems.ilqr12x4_constraint_blocks(N) if which == "bounds" else _soc_and_terminal_blocks(N)
-    a = _with_env("ALTRO_HIP_MERIT_DPP", "1", lambda: _merit_direct(p, N, blocks, dtype))
+    a = _with_env("ALTRO_HIP_MERIT_DPP", "2", lambda: _merit_direct(p, N, blocks, dtype))      # 2: also where the launcher would not
     b = _with_env("ALTRO_HIP_MERIT_DPP", "0", lambda: _merit_direct(p, N, blocks, dtype))
     for k in a:
         assert np.array_equal(a[k], b[k]), (k, float(np.abs(np.asarray(a[k], dtype=float) - np.asarray(b[k], dtype=float)).max()))
@@ -240,9 +240,11 @@ def test_dpp_line_search_rounds_are_bit_identical_to_the_lds_form(which, batch, 
     p = problems.ilqr12x4_problem(batch, N, True)
     blocks = [] if which == "none" else problems.ilqr12x4_constraint_blocks(N) if which == "bounds" else _soc_and_terminal_blocks(N)
     opts = dict(iterations_max=40, penalty_initial=1.0, penalty_scaling=10.0, **kw)
-    a = _with_env("ALTRO_HIP_MERIT_DPP", "1", lambda: _solve(p, N, blocks, dual, **opts))
+    a = _with_env("ALTRO_HIP_MERIT_DPP", "2", lambda: _solve(p, N, blocks, dual, **opts))
     b = _with_env("ALTRO_HIP_MERIT_DPP", "0", lambda: _solve(p, N, blocks, dual, **opts))
+    c = _solve(p, N, blocks, dual, **opts)                    # the default rule (DPP form where it is the faster one)
     if which != "none":
         assert a["merit_launches"] > 2 * a["sweeps"]        # the rounds did run
     for k in ("status", "iterations", "dual_updates", "phi", "stationarity", "feasibility", "alpha", "penalty", "x", "u", "xc", "uc", "yc", "K", "d"):
         assert np.array_equal(a[k], b[k]), (k, float(np.abs(np.asarray(a[k], dtype=float) - np.asarray(b[k], dtype=float)).max()))
+        assert np.array_equal(c[k], b[k]), k
