@@ -178,6 +178,10 @@ int wave_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int
   a.al.enabled = h->al_defs.empty() ? 0 : 1;
   a.al.uniform = h->al_uniform; a.al.rows_per_knot = h->al_rows_per_knot; a.al.N = h->N;
   a.mode = mode;
+  if (which == IK_EXPAND) {
+    const char* e = std::getenv("ALTRO_HIP_EXPAND_DPP");
+    if (e != nullptr && std::atoi(e) == 0) a.mode |= EXPAND_LDS;
+  }
   if (which == IK_MERIT) {   // a line-search round: the DPP form of the merit evaluation unless ALTRO_HIP_MERIT_DPP=0 keeps the LDS form
     const char* e = std::getenv("ALTRO_HIP_MERIT_DPP");
     a.mode = e == nullptr ? 2 : std::atoi(e) == 0 ? 0 : std::atoi(e) == 2 ? 3 : 2;   // (2: the DPP form whatever the launcher's rule)

@@ -17,7 +17,9 @@ static int wave_launch(hipStream_t stream, int which, const IlqrWaveArgs<S>& a) 
     case IK_ROLLOUT: hipLaunchKernelGGL(wave_rollout_kernel<S>, waves, b64, 0, stream, a); break;
     case IK_ACCEPT: hipLaunchKernelGGL(wave_accept_kernel<S>, flat, b256, 0, stream, a); break;
     case IK_EXPAND:
-      if (a.al.enabled) {
+      if (a.al.enabled && (a.mode & EXPAND_LDS) == 0) {   // four (problem, knot point) pairs per wave, kernels/ilqr_merit2_dpp.hip
+        hipLaunchKernelGGL(wave_expand_dpp_kernel<S>, dim3((unsigned)((int64_t)((a.batch + 3) / 4) * (a.N + 1))), b64, 0, stream, a);
+      } else if (a.al.enabled) {
         hipLaunchKernelGGL(wave_expand_kernel<S>, dim3((unsigned)((int64_t)a.batch * (a.N + 1))), b64, 0, stream, a);
       } else if (a.mode & EXPAND_GRADIENT) {   // no constraint blocks: the Hessian is constant, the gradient is 16 entries
         const int64_t blocks = ((int64_t)a.batch * (a.N + 1) * 16 + 255) / 256;

@@ -69,6 +69,8 @@ __device__ __forceinline__ void merit_pair_stage(const MeritPairRegs& r, double*
 // acc += (lane N of this lane's row of 16 lanes of v) * coef.  The hazard recogniser does not look inside inline assembly:
 // a DPP read needs 2 wait states after a VALU write of its source (5 after a VALU write of EXEC) -- every block of these
 // instructions therefore starts with `s_nop 4`, and no block reads a register that the block itself writes through DPP.
+// (Accumulators are early-clobber operands: a block writes them before it has read all its inputs, so an input that happens to
+//  hold the same value -- a literal zero next to a sum that starts at zero -- must not be given the accumulator's register.)
 // (volatile: a block must stay where the whole wave executes it -- sunk into a branch only some lanes take, its broadcasts
 //  would read lanes that are switched off.)
 #define MD_BC(N) " row_newbcast:" #N " row_mask:0xf bank_mask:0xf\n"
@@ -77,7 +79,7 @@ __device__ __forceinline__ void merit_pair_stage(const MeritPairRegs& r, double*
 __device__ __forceinline__ void md_rows12(double& acc, double& acc2, double v, double v2, const double (&c)[13]) {
   asm volatile("s_nop 4\n" MD_A(0, 4) MD_A(1, 5) MD_A(2, 6) MD_A(3, 7) MD_A(4, 8) MD_A(5, 9) MD_A(6, 10) MD_A(7, 11) MD_A(8, 12) MD_A(9, 13)
       MD_A(10, 14) MD_A(11, 15)
-      : "+v"(acc), "+v"(acc2)
+      : "+&v"(acc), "+&v"(acc2)
       : "v"(v), "v"(v2), "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5]), "v"(c[6]), "v"(c[7]), "v"(c[8]), "v"(c[9]),
         "v"(c[10]), "v"(c[11]));
 }
@@ -87,7 +89,7 @@ __device__ __forceinline__ void md_rows12(double& acc, double& acc2, double v, d
 __device__ __forceinline__ void md_rows16(double& acc, double& acc2, double& s2, double& t2, double w, double dw, const double (&c)[16]) {
   asm volatile("s_nop 4\n" MD_B(0, 6) MD_B(1, 7) MD_B(2, 8) MD_B(3, 9) MD_B(4, 10) MD_B(5, 11) MD_B(6, 12) MD_B(7, 13) MD_B(8, 14) MD_B(9, 15)
       MD_B(10, 16) MD_B(11, 17) MD_BU(12, 18) MD_BU(13, 19) MD_BU(14, 20) MD_BU(15, 21)
-      : "+v"(acc), "+v"(acc2), "+v"(s2), "+v"(t2)
+      : "+&v"(acc), "+&v"(acc2), "+&v"(s2), "+&v"(t2)
       : "v"(w), "v"(dw), "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5]), "v"(c[6]), "v"(c[7]), "v"(c[8]), "v"(c[9]),
         "v"(c[10]), "v"(c[11]), "v"(c[12]), "v"(c[13]), "v"(c[14]), "v"(c[15]));
 }
@@ -96,7 +98,7 @@ __device__ __forceinline__ void md_rows16(double& acc, double& acc2, double& s2,
 __device__ __forceinline__ void md_col12(double& acc, double v, const double (&c)[12]) {
   asm volatile("s_nop 4\n" MD_C(0, 2) MD_C(1, 3) MD_C(2, 4) MD_C(3, 5) MD_C(4, 6) MD_C(5, 7) MD_C(6, 8) MD_C(7, 9) MD_C(8, 10) MD_C(9, 11)
       MD_C(10, 12) MD_C(11, 13)
-      : "+v"(acc)
+      : "+&v"(acc)
       : "v"(v), "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5]), "v"(c[6]), "v"(c[7]), "v"(c[8]), "v"(c[9]), "v"(c[10]),
         "v"(c[11]));
 }
@@ -112,13 +114,13 @@ __device__ __forceinline__ void md_col12(double& acc, double v, const double (&c
 __device__ __forceinline__ void md_chain16(double& acc, double v, const double (&c)[16]) {
   asm volatile("s_nop 4\n" MD_K(0, 2) MD_K(1, 3) MD_K(2, 4) MD_K(3, 5) MD_K(4, 6) MD_K(5, 7) MD_K(6, 8) MD_K(7, 9) MD_K(8, 10) MD_K(9, 11)
       MD_K(10, 12) MD_K(11, 13) MD_K(12, 14) MD_K(13, 15) MD_K(14, 16) MD_K(15, 17)
-      : "+v"(acc)
+      : "+&v"(acc)
       : "v"(v), "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5]), "v"(c[6]), "v"(c[7]), "v"(c[8]), "v"(c[9]), "v"(c[10]),
         "v"(c[11]), "v"(c[12]), "v"(c[13]), "v"(c[14]), "v"(c[15]));
 }
 __device__ __forceinline__ void md_chain8(double& acc, double v, const double (&c)[8]) {
   asm volatile("s_nop 4\n" MD_K(0, 2) MD_K(1, 3) MD_K(2, 4) MD_K(3, 5) MD_K(4, 6) MD_K(5, 7) MD_K(6, 8) MD_K(7, 9)
-      : "+v"(acc)
+      : "+&v"(acc)
       : "v"(v), "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5]), "v"(c[6]), "v"(c[7]));
 }
 // lanes 0..3 of the row, to every lane of the row
@@ -457,6 +459,182 @@ __global__ __launch_bounds__(64, 2) void wave_merit_dpp_kernel(IlqrWaveArgs<S> a
       }
     }
     if (al && j == 0 && row_on) a.prob[b].rho_est = rho;
+  }
+}
+
+// ---- the expansion with constraint blocks (wave_expand_kernel) in the row layout ------------------------------------------------
+// One (problem, knot point) per row of 16 lanes, four per wave (wave_expand_kernel spends a whole wave on one).  Lane j holds
+// [x; u]_j and column j of every constraint Jacobian: the rows' values are 16-term DPP chains (dpp_al_rows' arithmetic), the
+// gradient's column sums 8-term ones, and the Gauss-Newton block  rho G^T J^T J G  is built row by row as outer products
+//     tile[r][j] += (J G)_(i r) (J G)_(i j) = bcast_r(a_i) * a_i ,   a_i = lane j's entry of row i of J G ,
+// 8 DPP multiply-adds per tile row and block (second-order cones: J G with the cone's full 4 x 4 Jacobian, plus the curvature
+// term  G^T (d/dz J^T z_proj) G  the same way).  Same expressions and order of the sums as wave_expand_kernel: bit-identical.
+template <int R>
+__device__ __forceinline__ void md_outer8(double& acc, const double (&v)[8]) {
+  asm volatile("s_nop 4\n"
+               "v_fmac_f64_dpp %0, %1, %1 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n v_fmac_f64_dpp %0, %2, %2 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n"
+               "v_fmac_f64_dpp %0, %3, %3 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n v_fmac_f64_dpp %0, %4, %4 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n"
+               "v_fmac_f64_dpp %0, %5, %5 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n v_fmac_f64_dpp %0, %6, %6 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n"
+               "v_fmac_f64_dpp %0, %7, %7 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n v_fmac_f64_dpp %0, %8, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf"
+      : "+&v"(acc)
+      : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "n"(R));
+}
+// acc += bcast_R(g_i) * h_i, i = 0..3   (the second-order cone's curvature term)
+template <int R>
+__device__ __forceinline__ void md_cross4(double& acc, const double (&g)[8], const double (&hc)[4]) {
+  asm volatile("s_nop 4\n"
+               "v_fmac_f64_dpp %0, %1, %5 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n v_fmac_f64_dpp %0, %2, %6 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n"
+               "v_fmac_f64_dpp %0, %3, %7 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n v_fmac_f64_dpp %0, %4, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf"
+      : "+&v"(acc)
+      : "v"(g[0]), "v"(g[1]), "v"(g[2]), "v"(g[3]), "v"(hc[0]), "v"(hc[1]), "v"(hc[2]), "v"(hc[3]), "n"(R));
+}
+__device__ __forceinline__ void md_gather8(double v, double (&o)[8]) {
+  asm volatile("s_nop 4\n"
+               "v_mov_b64_dpp %0, %8" MD_BC(0) "v_mov_b64_dpp %1, %8" MD_BC(1) "v_mov_b64_dpp %2, %8" MD_BC(2) "v_mov_b64_dpp %3, %8" MD_BC(3)
+               "v_mov_b64_dpp %4, %8" MD_BC(4) "v_mov_b64_dpp %5, %8" MD_BC(5) "v_mov_b64_dpp %6, %8" MD_BC(6) "v_mov_b64_dpp %7, %8" MD_BC(7)
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
+      : "v"(v));
+}
+template <int R>
+__device__ __forceinline__ void md_outer_rows(double (&tile)[16], const double (&ai)[8]) {
+  md_outer8<R>(tile[R], ai);
+  if constexpr (R + 1 < 16) md_outer_rows<R + 1>(tile, ai);
+}
+template <int R>
+__device__ __forceinline__ void md_cross_rows(double (&tile)[16], const double (&g)[8], const double (&hc)[4]) {
+  md_cross4<R>(tile[R], g, hc);
+  if constexpr (R + 1 < 16) md_cross_rows<R + 1>(tile, g, hc);
+}
+
+template <typename S>
+__global__ __launch_bounds__(64) void wave_expand_dpp_kernel(IlqrWaveArgs<S> a) {
+  const int lane = threadIdx.x, j = lane & 15;
+  // four problems of ONE knot point per wave (the constraint table entry is the knot point's: wave-uniform control flow)
+  const int wpk = (a.batch + 3) >> 2;
+  const int k = (int)(blockIdx.x / wpk), b0 = (int)(blockIdx.x % wpk) * 4, b_own = b0 + (lane >> 4);
+  if (k > a.N) return;
+  // a row without a problem of its own (past the end of the batch, or one that is not taking part) shadows the wave's first
+  // live row and stores nothing: the DPP blocks below need every lane switched on
+  bool on = b_own < a.batch;
+  if (on && a.active && !a.active[b_own]) on = false;
+  const unsigned long long onm = __ballot(on);
+  if (onm == 0ull) return;
+  const int b = on ? b_own : b0 + (__builtin_ctzll(onm) >> 4);
+  const bool terminal = k == a.N;
+  const bool grad = (a.mode & EXPAND_GRADIENT) != 0, hess = (a.mode & EXPAND_HESSIAN) != 0;
+  const S* c = a.cand + (size_t)b * a.xuy_bs + (size_t)k * a.xuy_ks;
+  const S* cp = a.costp + ((size_t)k * a.batch + b) * MF_COSTP;
+  const double w = j < 12 ? (double)c[j] : (terminal ? 0.0 : (double)c[12 + j]);      // x_j | u_(j-12)   (c[24 + j - 12])
+  const double cq = (double)cp[j], cl = (double)cp[16 + j];
+  const double rho_est = a.prob[b].rho_est, rho = a.prob[b].rho;
+  int zshift;
+  const AlKnot ALTRO_CONST_AS& kn = al_knot<S>(a.al, k, zshift);
+  double tile[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) tile[r] = 0.0;
+  double scol = 0.0;
+#pragma unroll
+  for (int cidx = 0; cidx < AL_MAXC; ++cidx) {
+    if (cidx >= kn.ncon) continue;
+    const int p = kn.p[cidx], cone = kn.cone[cidx];
+    const S* G = a.al.G + kn.G_off[cidx];
+    const bool rl = j < p;
+    const int jr = rl ? j : 0;
+    double cG[16], cC[8];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const double ge = (double)G[jr + e * p];
+      cG[e] = (rl && !(terminal && e >= 12)) ? ge : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const double gi = (double)G[(i < p ? i : 0) + j * p];
+      cC[i] = i < p ? gi : 0.0;
+    }
+    double sacc = 0.0;
+    md_chain16(sacc, w, cG);
+    const double gi = rl ? (kn.g_per_problem[cidx] ? (double)a.al.g[kn.g_off[cidx] + (int64_t)jr * a.batch + b] : (double)a.al.g[kn.g_off[cidx] + jr]) : 0.0;
+    const double val = sacc - gi;
+    const double zi = (double)a.al.z[(int64_t)(kn.z_off[cidx] + zshift + jr) * a.batch + b];
+    const double ze = rl ? zi - rho_est * val : 0.0;
+    double jv = 0.0;
+    if (cone != CONE_SOC) {
+      double mkv = 0.0;
+      if (rl) {
+        double zp = 0.0;
+        if (cone == CONE_EQUALITY) { zp = ze; mkv = 1.0; }
+        else if (cone == CONE_INEQUALITY) { zp = fmin(0.0, ze); mkv = (ze <= 0.0) ? 1.0 : 0.0; }
+        jv = mkv * zp;
+      }
+      if (grad) md_chain8(scol, jv, cC);
+      if (hess) {
+        double mk[8], ai[8];
+        md_gather8(mkv, mk);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ai[i] = mk[i] * cC[i];      // (J G)_(i j): the projection's Jacobian is diagonal
+        md_outer_rows<0>(tile, ai);
+      }
+    } else {
+      double valv[AL_MAXSOC], zev[AL_MAXSOC], zpv[AL_MAXSOC];
+      md_gather4(val, valv);
+      md_gather4(ze, zev);
+      soc_projection<double>(p, zev, zpv);
+      double Jc[AL_MAXSOC * AL_MAXSOC];
+      soc_jacobian<double>(p, zev, Jc);
+#pragma unroll
+      for (int r = 0; r < AL_MAXSOC; ++r) {
+        double sj = 0.0;
+#pragma unroll
+        for (int q = 0; q < AL_MAXSOC; ++q) sj += Jc[q + r * AL_MAXSOC] * zpv[q];
+        if (r < p && j == r) jv = sj;
+      }
+      if (grad) md_chain8(scol, jv, cC);
+      if (hess) {
+        double ai[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          double jr2 = 0.0;
+          if (i < AL_MAXSOC) {
+#pragma unroll
+            for (int q = 0; q < AL_MAXSOC; ++q)
+              if (q < p) jr2 += Jc[i + q * AL_MAXSOC] * cC[q];
+          }
+          ai[i] = (i < p) ? jr2 : 0.0;
+        }
+        md_outer_rows<0>(tile, ai);
+        double Hp[AL_MAXSOC * AL_MAXSOC], hc[4];
+        soc_hessian<double>(p, zev, zpv, Hp);
+#pragma unroll
+        for (int i = 0; i < AL_MAXSOC; ++i) {
+          double hh = 0.0;
+#pragma unroll
+          for (int q = 0; q < AL_MAXSOC; ++q)
+            if (q < p) hh += Hp[i + q * AL_MAXSOC] * cC[q];
+          hc[i] = (i < p) ? hh : 0.0;
+        }
+        md_cross_rows<0>(tile, cC, hc);
+      }
+    }
+  }
+  if (!on) return;
+  if (grad) {
+    double l = cq * w + cl;
+    l -= scol;
+    if (!terminal) a.cin[(size_t)b * a.cin_bs + (size_t)k * a.cin_ks + MF_OFF_QR + j] = (S)l;
+    else if (j < 12) a.term[(size_t)b * MF_TERM + 144 + j] = (S)l;
+  }
+  if (hess) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (terminal && (r >= 12 || j >= 12)) continue;
+      if (r < 12 && j >= 12) continue;             // the H^T block is not stored
+      if (!terminal && r < 12 && j < r) continue;  // nor is the lower triangle of Q
+      double v = (r == j) ? cq : 0.0;
+      v += rho * tile[r];
+      if (terminal) a.term[(size_t)b * MF_TERM + r * 12 + j] = (S)v;
+      else if (r < 12) a.cin[(size_t)b * a.cin_bs + (size_t)k * a.cin_ks + MF_OFF_Q + mf_sym(r, j)] = (S)v;
+      else a.cin[(size_t)b * a.cin_bs + (size_t)k * a.cin_ks + MF_OFF_HR + (r - 12) * 16 + j] = (S)v;
+    }
   }
 }
 

@@ -66,7 +66,7 @@ struct IlqrArgs {
   T* merit_jk;          // [spec_trials][N + 1][batch]
   T* spec_jac;          // [N][n n + n m + n + m][batch] then [n][batch]
 };
-enum { EXPAND_GRADIENT = 1, EXPAND_HESSIAN = 2 };
+enum { EXPAND_GRADIENT = 1, EXPAND_HESSIAN = 2, EXPAND_LDS = 16 /* plan MFMA16: wave_expand_kernel instead of the DPP form (A/B, tests) */ };
 
 struct IlqrLoopArgs {
   IlqrProb* prob;

@@ -248,3 +248,38 @@ def test_dpp_line_search_rounds_are_bit_identical_to_the_lds_form(which, batch, 
     for k in ("status", "iterations", "dual_updates", "phi", "stationarity", "feasibility", "alpha", "penalty", "x", "u", "xc", "uc", "yc", "K", "d"):
         assert np.array_equal(a[k], b[k]), (k, float(np.abs(np.asarray(a[k], dtype=float) - np.asarray(b[k], dtype=float)).max()))
         assert np.array_equal(c[k], b[k]), k
+
+
+@pytest.mark.parametrize("which,batch,N,dtype", [("bounds", 41, 24, altro_amd.F64), ("bounds", 6, 5, altro_amd.F64), ("soc", 23, 12, altro_amd.F64),
+                                                 ("soc", 3, 4, altro_amd.F64), ("bounds", 17, 8, altro_amd.F32)])
+def test_dpp_expansion_is_bit_identical_to_the_lds_form(which, batch, N, dtype):
+    """wave_expand_dpp_kernel (four (problem, knot point) pairs per wave; the Gauss-Newton block as DPP outer products) against
+    wave_expand_kernel (ALTRO_HIP_EXPAND_DPP=0): first the backward pass right after one expansion (K, d read every entry of the
+    cost records), then whole solves -- batches that are not multiples of four, problems that drop out, second-order cones with
+    their curvature term, a terminal block."""
+    p = problems.ilqr12x4_problem(batch, N, True)
+    blocks = problems.ilqr12x4_constraint_blocks(N) if which == "bounds" else _soc_and_terminal_blocks(N)
+
+    def one_expansion():
+        bt = altro_amd.Batch(N, n, m, batch, dtype=dtype)
+        bt.set_dynamics(p["A"], p["B"], p["f"])
+        bt.set_tracking_cost(p["Qd"], p["Rd"], p["xref"], p["uref"])
+        bt.set_initial_state(p["x0"])
+        bt.set_input_guess(p["u0"])
+        for (k0, k1, cone, G, g) in blocks:
+            bt.add_linear_constraint(k0, k1, cone, G, g)
+        bt.open_loop_rollout(); bt.accept(); bt.expand(); bt.backward()
+        out = bt.get("K"), bt.get("d"), bt.get("P"), bt.get("p")
+        bt.close()
+        return out
+
+    ea = _with_env("ALTRO_HIP_EXPAND_DPP", "1", one_expansion)
+    eb = _with_env("ALTRO_HIP_EXPAND_DPP", "0", one_expansion)
+    for x, y in zip(ea, eb):
+        assert np.array_equal(x, y)
+    kw = dict(iterations_max=40, penalty_initial=1.0, penalty_scaling=10.0)
+    a = _with_env("ALTRO_HIP_EXPAND_DPP", "1", lambda: _solve(p, N, blocks, True, dtype=dtype, **kw))
+    b = _with_env("ALTRO_HIP_EXPAND_DPP", "0", lambda: _solve(p, N, blocks, True, dtype=dtype, **kw))
+    assert (a["dual_updates"] > 0).any()
+    for k in ("status", "iterations", "dual_updates", "phi", "stationarity", "feasibility", "alpha", "penalty", "x", "u", "xc", "uc", "yc", "K", "d"):
+        assert np.array_equal(a[k], b[k]), (k, float(np.abs(np.asarray(a[k], dtype=float) - np.asarray(b[k], dtype=float)).max()))
