@@ -178,6 +178,10 @@ int wave_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int
   a.al.enabled = h->al_defs.empty() ? 0 : 1;
   a.al.uniform = h->al_uniform; a.al.rows_per_knot = h->al_rows_per_knot; a.al.N = h->N;
   a.mode = mode;
+  if (which == IK_STATIONARITY || which == IK_DUAL) {   // constraint rows in the DPP form unless ALTRO_HIP_ALROWS_DPP=0
+    const char* e = std::getenv("ALTRO_HIP_ALROWS_DPP");
+    a.mode = (e != nullptr && std::atoi(e) == 0) ? 0 : STAT_NO_FEAS;
+  }
   if (which == IK_EXPAND) {
     const char* e = std::getenv("ALTRO_HIP_EXPAND_DPP");
     if (e != nullptr && std::atoi(e) == 0) a.mode |= EXPAND_LDS;

@@ -26,7 +26,10 @@ static int wave_launch(hipStream_t stream, int which, const IlqrWaveArgs<S>& a) 
         hipLaunchKernelGGL(wave_expand_grad_kernel<S>, dim3((unsigned)(blocks < 262144 ? blocks : 262144)), dim3(256), 0, stream, a);
       }
       break;
-    case IK_DUAL: hipLaunchKernelGGL(wave_dual_update_kernel<S>, dim3((unsigned)((int64_t)a.batch * (a.N + 1))), b64, 0, stream, a); break;
+    case IK_DUAL:
+      if (a.mode & STAT_NO_FEAS) hipLaunchKernelGGL(wave_dual_update_dpp_kernel<S>, dim3((unsigned)((int64_t)((a.batch + 3) / 4) * (a.N + 1))), b64, 0, stream, a);
+      else hipLaunchKernelGGL(wave_dual_update_kernel<S>, dim3((unsigned)((int64_t)a.batch * (a.N + 1))), b64, 0, stream, a);
+      break;
     case IK_MERIT:
       // the DPP form: two problems per wave, two trials per problem (kernels/ilqr_merit2_dpp.hip).  With constraint blocks
       // and ONE trial per problem its second rows idle: on long horizons the LDS form is then the faster one (C1 + input
@@ -50,7 +53,16 @@ static int wave_launch(hipStream_t stream, int which, const IlqrWaveArgs<S>& a) 
       const int64_t blocks = ((int64_t)a.batch * (a.N + 1) * 28 + 255) / 256;
       hipLaunchKernelGGL(wave_spec_select_kernel<S>, dim3((unsigned)(blocks < 262144 ? blocks : 262144)), b256, 0, stream, a);
     } break;
-    case IK_STATIONARITY: hipLaunchKernelGGL(wave_stationarity_kernel<S>, waves, b64, 0, stream, a); break;
+    case IK_STATIONARITY:
+      if (a.al.enabled && (a.mode & STAT_NO_FEAS)) {   // the residual here, the constraint rows four problems per wave
+        hipLaunchKernelGGL(wave_stationarity_kernel<S>, waves, b64, 0, stream, a);
+        hipLaunchKernelGGL(wave_feasibility_dpp_kernel<S>, dim3((a.batch + 3) / 4), b64, 0, stream, a);
+      } else {
+        IlqrWaveArgs<S> a2 = a;
+        a2.mode &= ~STAT_NO_FEAS;
+        hipLaunchKernelGGL(wave_stationarity_kernel<S>, waves, b64, 0, stream, a2);
+      }
+      break;
     case IK_SHIFT: hipLaunchKernelGGL(wave_shift_kernel<S>, dim3((a.batch * 16 + 255) / 256), b256, 0, stream, a); break;
     default: return 1;
   }

@@ -130,9 +130,10 @@ __device__ __forceinline__ void md_gather4(double v, double (&o)[4]) {
       : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3])
       : "v"(v));
 }
-template <typename S>
+// (DU: DualUpdate, knotpoint_data.cpp:503-510 -- the projected dual becomes the dual; `store`: this row has a problem of its own)
+template <typename S, bool DU = false>
 __device__ __forceinline__ void dpp_al_rows(const AlTable<S>& t, int k, int b, int64_t B, double w, bool terminal, double rho_est, int j,
-                                            double (&jvr)[AL_MAXC], double& cost, double& viol) {
+                                            double (&jvr)[AL_MAXC], double& cost, double& viol, bool store = false) {
   int zshift;
   const AlKnot ALTRO_CONST_AS& kn = al_knot<S>(t, k, zshift);
 #pragma unroll
@@ -153,7 +154,8 @@ __device__ __forceinline__ void dpp_al_rows(const AlTable<S>& t, int k, int b, i
     md_chain16(sacc, w, cG);
     const double gi = rl ? (kn.g_per_problem[c] ? (double)t.g[kn.g_off[c] + (int64_t)jr * B + b] : (double)t.g[kn.g_off[c] + jr]) : 0.0;
     const double val = sacc - gi;
-    const double zi = (double)t.z[(int64_t)(kn.z_off[c] + zshift + jr) * B + b];
+    S* const zp_ = t.z + (int64_t)(kn.z_off[c] + zshift + jr) * B + b;
+    const double zi = (double)*zp_;
     const double ze = rl ? zi - rho_est * val : 0.0;
     if (cone != CONE_SOC) {
       if (rl) {
@@ -162,6 +164,7 @@ __device__ __forceinline__ void dpp_al_rows(const AlTable<S>& t, int k, int b, i
         else if (cone == CONE_INEQUALITY) { zp = fmin(0.0, ze); mkv = (ze <= 0.0) ? 1.0 : 0.0; viol = fmax(viol, fabs(fmin(0.0, val) - val)); }
         cost += zp * zp / (2.0 * rho_est);
         jvr[c] = mkv * zp;
+        if (DU && store) *zp_ = (S)zp;
       }
     } else {
       double valv[AL_MAXSOC], zev[AL_MAXSOC], zpv[AL_MAXSOC], pv[AL_MAXSOC];
@@ -174,6 +177,13 @@ __device__ __forceinline__ void dpp_al_rows(const AlTable<S>& t, int k, int b, i
       for (int r = 0; r < AL_MAXSOC; ++r)
         if (r < p) { sq += zpv[r] * zpv[r]; viol = fmax(viol, fabs(pv[r] - valv[r])); }
       if (j == 0) cost += sq / (2.0 * rho_est);
+      if (DU && store && rl) {
+        double zown = 0.0;
+#pragma unroll
+        for (int r = 0; r < AL_MAXSOC; ++r)
+          if (j == r) zown = zpv[r];
+        *zp_ = (S)zown;
+      }
       double Jc[AL_MAXSOC * AL_MAXSOC];
       soc_jacobian<double>(p, zev, Jc);
 #pragma unroll
@@ -636,6 +646,55 @@ __global__ __launch_bounds__(64) void wave_expand_dpp_kernel(IlqrWaveArgs<S> a) 
       else a.cin[(size_t)b * a.cin_bs + (size_t)k * a.cin_ks + MF_OFF_HR + (r - 12) * 16 + j] = (S)v;
     }
   }
+}
+
+// DualUpdate (wave_dual_update_kernel) and the candidate's feasibility (the second half of wave_stationarity_kernel) in the row
+// layout: four problems per wave, the rows' values by DPP, no LDS and no barriers.  wave_dual_update_kernel spends a wave per
+// (problem, knot point); the feasibility loop of wave_stationarity_kernel a wave per problem with eight lanes at work and two
+// barriers per knot point.  Maxima and stores only: bit-identical by construction.
+template <typename S>
+__global__ __launch_bounds__(64) void wave_dual_update_dpp_kernel(IlqrWaveArgs<S> a) {
+  const int lane = threadIdx.x, j = lane & 15;
+  const int wpk = (a.batch + 3) >> 2;
+  const int k = (int)(blockIdx.x / wpk), b0 = (int)(blockIdx.x % wpk) * 4, b_own = b0 + (lane >> 4);
+  if (k > a.N || !a.al.enabled) return;
+  const bool on = b_own < a.batch && a.prob[b_own < a.batch ? b_own : 0].dual != 0;
+  const unsigned long long onm = __ballot(on);
+  if (onm == 0ull) return;
+  const int b = on ? b_own : b0 + (__builtin_ctzll(onm) >> 4);
+  const bool terminal = k == a.N;
+  const S* c = a.cand + (size_t)b * a.xuy_bs + (size_t)k * a.xuy_ks;
+  const double w = j < 12 ? (double)c[j] : (terminal ? 0.0 : (double)c[12 + j]);
+  double jvr[AL_MAXC], cost = 0.0, viol = 0.0;
+  dpp_al_rows<S, true>(a.al, k, b, a.batch, w, terminal, a.prob[b].rho_est, j, jvr, cost, viol, on);
+}
+template <typename S>
+__global__ __launch_bounds__(64) void wave_feasibility_dpp_kernel(IlqrWaveArgs<S> a) {
+  const int lane = threadIdx.x, j = lane & 15;
+  const int b0 = (int)blockIdx.x * 4, b_own = b0 + (lane >> 4);
+  bool on = b_own < a.batch;
+  if (on && a.active && !a.active[b_own]) on = false;
+  if (on && a.skip && a.skip[b_own]) on = false;
+  const unsigned long long onm = __ballot(on);
+  if (onm == 0ull) return;
+  const int b = on ? b_own : b0 + (__builtin_ctzll(onm) >> 4);
+  const int N = a.N;
+  const double rho = a.prob[b].rho;
+  const S* cb = a.cand + (size_t)b * a.xuy_bs;
+  double viol = 0.0;
+  double wn = j < 12 ? (double)cb[j] : (N > 0 ? (double)cb[12 + j] : 0.0);
+  for (int k = 0; k <= N; ++k) {
+    const double w = wn;
+    if (k < N) {
+      const S* c = cb + (size_t)(k + 1) * a.xuy_ks;
+      wn = j < 12 ? (double)c[j] : (k + 1 < N ? (double)c[12 + j] : 0.0);
+    }
+    double jvr[AL_MAXC], cost = 0.0;
+    dpp_al_rows<S>(a.al, k, b, a.batch, w, k == N, rho, j, jvr, cost, viol);
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) viol = fmax(viol, __shfl_xor(viol, o, 64));
+  if (j == 0 && on) a.prob[b].feasibility = viol;
 }
 
 // (The open-loop rollout was built the same way -- one problem per row of 16 lanes, two per wave -- and measured against

@@ -1071,9 +1071,10 @@ __global__ __launch_bounds__(64) void wave_stationarity_kernel(IlqrWaveArgs<S> a
     res = fmax(res, fabs((double)a.term[(size_t)b * MF_TERM + 144 + lane] -
                          (double)a.cand[(size_t)b * a.xuy_bs + (size_t)N * a.xuy_ks + 12 + lane]));
   res = wave_max(res);
-  // Feasibility (solver.cpp:224-231) of the candidate trajectory
+  // Feasibility (solver.cpp:224-231) of the candidate trajectory (STAT_NO_FEAS: wave_feasibility_dpp_kernel computes it)
   double viol = 0.0;
-  if (a.al.enabled) {
+  const bool feas_here = (a.mode & STAT_NO_FEAS) == 0;
+  if (a.al.enabled && feas_here) {
     __shared__ double xs[12], us[4], jv[AL_MAXC * AL_MAXP], Jm[AL_MAXC * 64], Hm[AL_MAXC * 16];
     const double rho = a.prob[b].rho;
     for (int k = 0; k <= N; ++k) {
@@ -1087,7 +1088,7 @@ __global__ __launch_bounds__(64) void wave_stationarity_kernel(IlqrWaveArgs<S> a
     }
     viol = wave_max(viol);
   }
-  if (lane == 0) { a.prob[b].stationarity = res; a.prob[b].feasibility = viol; }
+  if (lane == 0) { a.prob[b].stationarity = res; if (feas_here) a.prob[b].feasibility = viol; }
 }
 
 // ALTROSolver::ShiftTrajectory (altro_solver.cpp:283-293) on the candidate records

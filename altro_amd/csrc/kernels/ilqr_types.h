@@ -66,6 +66,7 @@ struct IlqrArgs {
   T* merit_jk;          // [spec_trials][N + 1][batch]
   T* spec_jac;          // [N][n n + n m + n + m][batch] then [n][batch]
 };
+constexpr int STAT_NO_FEAS = 32;   // IK_STATIONARITY / IK_DUAL on plan MFMA16: the constraint rows in the DPP form (ilqr_merit2_dpp.hip)
 enum { EXPAND_GRADIENT = 1, EXPAND_HESSIAN = 2, EXPAND_LDS = 16 /* plan MFMA16: wave_expand_kernel instead of the DPP form (A/B, tests) */ };
 
 struct IlqrLoopArgs {

@@ -283,3 +283,19 @@ def test_dpp_expansion_is_bit_identical_to_the_lds_form(which, batch, N, dtype):
     assert (a["dual_updates"] > 0).any()
     for k in ("status", "iterations", "dual_updates", "phi", "stationarity", "feasibility", "alpha", "penalty", "x", "u", "xc", "uc", "yc", "K", "d"):
         assert np.array_equal(a[k], b[k]), (k, float(np.abs(np.asarray(a[k], dtype=float) - np.asarray(b[k], dtype=float)).max()))
+
+
+@pytest.mark.parametrize("which,batch,N,dtype", [("bounds", 41, 24, altro_amd.F64), ("soc", 23, 12, altro_amd.F64), ("soc", 3, 4, altro_amd.F64),
+                                                 ("bounds", 17, 8, altro_amd.F32)])
+def test_dpp_dual_update_and_feasibility_are_bit_identical_to_the_lds_form(which, batch, N, dtype):
+    """wave_dual_update_dpp_kernel and wave_feasibility_dpp_kernel (four problems per wave) against wave_dual_update_kernel and
+    the feasibility loop of wave_stationarity_kernel (ALTRO_HIP_ALROWS_DPP=0): whole solves, the duals included."""
+    p = problems.ilqr12x4_problem(batch, N, True)
+    blocks = problems.ilqr12x4_constraint_blocks(N) if which == "bounds" else _soc_and_terminal_blocks(N)
+    kw = dict(iterations_max=40, penalty_initial=1.0, penalty_scaling=10.0)
+    for dual in (True, False):       # (False: the one-evaluation-per-launch sequence, where every sweep runs IK_STATIONARITY)
+        a = _with_env("ALTRO_HIP_ALROWS_DPP", "1", lambda: _solve(p, N, blocks, dual, dtype=dtype, **kw))
+        b = _with_env("ALTRO_HIP_ALROWS_DPP", "0", lambda: _solve(p, N, blocks, dual, dtype=dtype, **kw))
+        assert (a["dual_updates"] > 0).any()
+        for k in ("status", "iterations", "dual_updates", "phi", "stationarity", "feasibility", "alpha", "penalty", "x", "u", "xc", "uc", "yc", "K", "d"):
+            assert np.array_equal(a[k], b[k]), (dual, k)
