@@ -56,7 +56,7 @@ static int wave_launch(hipStream_t stream, int which, const IlqrWaveArgs<S>& a) 
     case IK_STATIONARITY:
       if (a.al.enabled && (a.mode & STAT_NO_FEAS)) {   // the residual here, the constraint rows four problems per wave
         hipLaunchKernelGGL(wave_stationarity_kernel<S>, waves, b64, 0, stream, a);
-        hipLaunchKernelGGL(wave_feasibility_dpp_kernel<S>, dim3((a.batch + 3) / 4), b64, 0, stream, a);
+        hipLaunchKernelGGL(wave_feasibility_dpp_kernel<S>, dim3((unsigned)((int64_t)((a.batch + 3) / 4) * (a.N + 1))), b64, 0, stream, a);
       } else {
         IlqrWaveArgs<S> a2 = a;
         a2.mode &= ~STAT_NO_FEAS;

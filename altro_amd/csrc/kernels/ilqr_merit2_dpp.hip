@@ -668,33 +668,30 @@ __global__ __launch_bounds__(64) void wave_dual_update_dpp_kernel(IlqrWaveArgs<S
   double jvr[AL_MAXC], cost = 0.0, viol = 0.0;
   dpp_al_rows<S, true>(a.al, k, b, a.batch, w, terminal, a.prob[b].rho_est, j, jvr, cost, viol, on);
 }
+// One wave per (four problems, knot point), like the dual update; the maximum over the knot points is an atomic maximum on the
+// bit pattern (violations are non-negative doubles, whose order is their bit patterns' order as unsigned integers) into the
+// control block, which wave_stationarity_kernel -- launched just before, same stream -- has set to zero (STAT_NO_FEAS).
 template <typename S>
 __global__ __launch_bounds__(64) void wave_feasibility_dpp_kernel(IlqrWaveArgs<S> a) {
   const int lane = threadIdx.x, j = lane & 15;
-  const int b0 = (int)blockIdx.x * 4, b_own = b0 + (lane >> 4);
+  const int wpk = (a.batch + 3) >> 2;
+  const int k = (int)(blockIdx.x / wpk), b0 = (int)(blockIdx.x % wpk) * 4, b_own = b0 + (lane >> 4);
+  if (k > a.N) return;
   bool on = b_own < a.batch;
   if (on && a.active && !a.active[b_own]) on = false;
   if (on && a.skip && a.skip[b_own]) on = false;
   const unsigned long long onm = __ballot(on);
   if (onm == 0ull) return;
   const int b = on ? b_own : b0 + (__builtin_ctzll(onm) >> 4);
-  const int N = a.N;
-  const double rho = a.prob[b].rho;
-  const S* cb = a.cand + (size_t)b * a.xuy_bs;
-  double viol = 0.0;
-  double wn = j < 12 ? (double)cb[j] : (N > 0 ? (double)cb[12 + j] : 0.0);
-  for (int k = 0; k <= N; ++k) {
-    const double w = wn;
-    if (k < N) {
-      const S* c = cb + (size_t)(k + 1) * a.xuy_ks;
-      wn = j < 12 ? (double)c[j] : (k + 1 < N ? (double)c[12 + j] : 0.0);
-    }
-    double jvr[AL_MAXC], cost = 0.0;
-    dpp_al_rows<S>(a.al, k, b, a.batch, w, k == N, rho, j, jvr, cost, viol);
-  }
+  const bool terminal = k == a.N;
+  const S* c = a.cand + (size_t)b * a.xuy_bs + (size_t)k * a.xuy_ks;
+  const double w = j < 12 ? (double)c[j] : (terminal ? 0.0 : (double)c[12 + j]);
+  double jvr[AL_MAXC], cost = 0.0, viol = 0.0;
+  dpp_al_rows<S>(a.al, k, b, a.batch, w, terminal, a.prob[b].rho, j, jvr, cost, viol);
 #pragma unroll
   for (int o = 8; o > 0; o >>= 1) viol = fmax(viol, __shfl_xor(viol, o, 64));
-  if (j == 0 && on) a.prob[b].feasibility = viol;
+  if (j == 0 && on && viol > 0.0)
+    atomicMax(reinterpret_cast<unsigned long long*>(&a.prob[b].feasibility), (unsigned long long)__double_as_longlong(viol));
 }
 
 // (The open-loop rollout was built the same way -- one problem per row of 16 lanes, two per wave -- and measured against

@@ -1088,7 +1088,7 @@ __global__ __launch_bounds__(64) void wave_stationarity_kernel(IlqrWaveArgs<S> a
     }
     viol = wave_max(viol);
   }
-  if (lane == 0) { a.prob[b].stationarity = res; if (feas_here) a.prob[b].feasibility = viol; }
+  if (lane == 0) { a.prob[b].stationarity = res; a.prob[b].feasibility = viol; }   // (STAT_NO_FEAS: 0, the start of the atomic maximum)
 }
 
 // ALTROSolver::ShiftTrajectory (altro_solver.cpp:283-293) on the candidate records
