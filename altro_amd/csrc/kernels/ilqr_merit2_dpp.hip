@@ -1,6 +1,14 @@
-// kernels/ilqr_merit2_dpp.hip -- wave_merit2_kernel's two-trial merit evaluation (SolverImpl::MeritFunction,
-// solver.cpp:273-355, for phi(0) and the line search's first step alpha0 = 1 in one pass over the records) with the operand
-// broadcast moved from the LDS pipe to the VALU's data-parallel primitives, and TWO PROBLEMS PER WAVE.
+// kernels/ilqr_merit2_dpp.hip -- plan MFMA16's iLQR kernels in the ROW LAYOUT: the point [x; u] of a (problem, trial) lives in the
+// registers of one row of 16 lanes and every product against it is a chain of `v_fmac_f64_dpp ... row_newbcast` instructions.
+//   wave_merit_dpp_kernel<S, AL, DUAL>   MeritFunction (solver.cpp:273-355): the two-trial pass and the line-search rounds
+//   wave_expand_dpp_kernel               CalcExpansions with constraint blocks (solver.cpp:189-201, knotpoint_data.cpp:537-613)
+//   wave_dual_update_dpp_kernel          DualUpdate (solver.cpp:383-388, knotpoint_data.cpp:503-510)
+//   wave_feasibility_dpp_kernel          Feasibility (solver.cpp:224-231)
+// Each replaces an LDS-form kernel of ilqr_mfma16.hip and is bit-identical to it (tests/test_gpu_merit2.py, tools/fuzz_dpp.py).
+//
+// The first of them: wave_merit2_kernel's two-trial merit evaluation (phi(0) and the line search's first step alpha0 = 1 in one
+// pass over the records) with the operand broadcast moved from the LDS pipe to the VALU's data-parallel primitives, and TWO
+// PROBLEMS PER WAVE.
 //
 // wave_merit2_kernel is bound by the LDS pipe: ~100 LDS instructions per knot point, most of them every
 // lane re-reading the vector its row multiplies.  tools/ldsbench.hip prices an LDS wave instruction at 1.2-2.1 ns of the
