@@ -916,7 +916,7 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
     const char* mm = std::getenv("ALTRO_HIP_MERIT2_MFMA");
     const bool merit_mfma = mm != nullptr && std::atoi(mm) != 0;
     // (mode 2: the same evaluation with the broadcasts on the VALU's DPP path and two problems per wave,
-    //  kernels/ilqr_merit2_dpp.hip -- unconstrained problems, bit-identical; ALTRO_HIP_MERIT2_DPP=0 keeps the LDS form)
+    //  kernels/ilqr_merit2_dpp.hip -- with or without constraint blocks, bit-identical; ALTRO_HIP_MERIT2_DPP=0 keeps the LDS form)
     const char* md = std::getenv("ALTRO_HIP_MERIT2_DPP");
     const bool merit_dpp = md == nullptr || std::atoi(md) != 0;
     const int merit2_mode = (merit_mfma && !al && h->dtype == ALTRO_HIP_F64) ? 1 : merit_dpp ? 2 : 0;
