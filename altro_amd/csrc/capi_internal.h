@@ -6,6 +6,7 @@
 #include "altro_hip/altro_hip.h"
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cstdarg>
@@ -132,6 +133,7 @@ struct altro_hip_batch {
   int prof_n = 0;
   double prof_min[2] = {0, 0}, prof_max[2] = {0, 0};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t launch_ev0 = nullptr, launch_ev1 = nullptr;   // the events the NEXT profiled launch carries (ProfScope, capi_tvlqr.hip)
   int last_sweeps = 0, last_merit_launches = 0;
   int prof_launches[2] = {0, 0};
   int prof_dropped[2] = {0, 0};   // mode 2: launches issued after the event ring was full (not in the averages)

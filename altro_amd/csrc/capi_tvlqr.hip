@@ -11,6 +11,10 @@
 using namespace altro_hip;
 using namespace altro_hip::capi;
 
+// a launch that carries the profiling events of the enclosing ProfScope (null events: a plain launch)
+#define PROF_LAUNCH(kernel, grid, block, lds, stream, ...) \
+  hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, h->launch_ev0, h->launch_ev1, 0, __VA_ARGS__)
+
 namespace {
 
 template <typename T>
@@ -33,28 +37,28 @@ int lane_launch(altro_hip_batch* h, bool backward, double reg) {
   if (backward) h->bwd_quad = quad_on && (q42 || q21);
   if (!backward && quad_on && q42) {   // forward sweep of (4, 2): four lanes per problem as well
     const dim3 qgrid(8 * (((h->batch + 15) / 16 + 7) / 8));
-    if (fused) hipLaunchKernelGGL((quad_forward_kernel_fused<2, T>), qgrid, block, 0, h->stream, a);
-    else hipLaunchKernelGGL((quad_forward_kernel<2, T>), qgrid, block, 0, h->stream, a);
+    if (fused) PROF_LAUNCH((quad_forward_kernel_fused<2, T>), qgrid, block, 0, h->stream, a);
+    else PROF_LAUNCH((quad_forward_kernel<2, T>), qgrid, block, 0, h->stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "quad kernel launch: %s", hipGetErrorString(e));
     return 0;
   }
   if (backward && h->bwd_quad) {
     const dim3 qgrid(8 * (((h->batch + 15) / 16 + 7) / 8));
-    if (q42 && fused) hipLaunchKernelGGL((quad_backward_kernel_fused<2, T>), qgrid, block, 0, h->stream, a);
-    else if (q42) hipLaunchKernelGGL((quad_backward_kernel<2, T>), qgrid, block, 0, h->stream, a);
-    else if (fused) hipLaunchKernelGGL((quad2_backward_kernel_fused<T>), qgrid, block, 0, h->stream, a);
-    else hipLaunchKernelGGL((quad2_backward_kernel<T>), qgrid, block, 0, h->stream, a);
+    if (q42 && fused) PROF_LAUNCH((quad_backward_kernel_fused<2, T>), qgrid, block, 0, h->stream, a);
+    else if (q42) PROF_LAUNCH((quad_backward_kernel<2, T>), qgrid, block, 0, h->stream, a);
+    else if (fused) PROF_LAUNCH((quad2_backward_kernel_fused<T>), qgrid, block, 0, h->stream, a);
+    else PROF_LAUNCH((quad2_backward_kernel<T>), qgrid, block, 0, h->stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "quad kernel launch: %s", hipGetErrorString(e));
     return 0;
   }
 #define X(N_, M_)                                                                                              \
   if (h->n == N_ && h->m == M_) {                                                                              \
-    if (backward && fused) hipLaunchKernelGGL((lane_backward_kernel_fused<N_, M_, T>), grid, block, 0, h->stream, a); \
-    else if (backward) hipLaunchKernelGGL((lane_backward_kernel<N_, M_, T>), grid, block, 0, h->stream, a);    \
-    else if (fused) hipLaunchKernelGGL((lane_forward_kernel_fused<N_, M_, T>), grid, block, 0, h->stream, a);  \
-    else hipLaunchKernelGGL((lane_forward_kernel<N_, M_, T>), grid, block, 0, h->stream, a);                   \
+    if (backward && fused) PROF_LAUNCH((lane_backward_kernel_fused<N_, M_, T>), grid, block, 0, h->stream, a); \
+    else if (backward) PROF_LAUNCH((lane_backward_kernel<N_, M_, T>), grid, block, 0, h->stream, a);    \
+    else if (fused) PROF_LAUNCH((lane_forward_kernel_fused<N_, M_, T>), grid, block, 0, h->stream, a);  \
+    else PROF_LAUNCH((lane_forward_kernel<N_, M_, T>), grid, block, 0, h->stream, a);                   \
   }
   LANE_SHAPES(X)
 #undef X
@@ -88,7 +92,11 @@ GenericArgs<T> generic_args(altro_hip_batch* h, double reg) {
   return a;
 }
 
-struct ProfScope {   // brackets one kernel launch with hipEvents ON THE HANDLE'S STREAM (altro_hip_profile_enable)
+// One profiled kernel launch (altro_hip_profile_enable).  The launch itself carries the two events -- hipExtLaunchKernelGGL
+// stamps them from the dispatch's own completion signal -- instead of two hipEventRecord calls around it: those are marker
+// packets with barriers on the handle's stream, 15 us per sweep of a timed region whose sweeps take 1.45 ms
+// (profiles/r03zc_event_overhead.txt), and they time the packets' turnaround along with the kernel.
+struct ProfScope {
   altro_hip_batch* h;
   int slot, idx = -1;
   static void add(altro_hip_batch* h, int slot, float ms) {
@@ -98,26 +106,25 @@ struct ProfScope {   // brackets one kernel launch with hipEvents ON THE HANDLE'
     h->prof_launches[slot] += 1;
   }
   ProfScope(altro_hip_batch* h_, int slot_) : h(h_), slot(slot_) {
-    if (h->prof == 1) (void)hipEventRecord(h->ev0, h->stream);
+    h->launch_ev0 = nullptr; h->launch_ev1 = nullptr;
+    if (h->prof == 1) { h->launch_ev0 = h->ev0; h->launch_ev1 = h->ev1; }
     else if (h->prof == 2) {
       if (2 * (h->prof_n + 1) <= (int)h->prof_ev.size()) {
         idx = h->prof_n++;
         h->prof_slot[idx] = slot;
-        (void)hipEventRecord(h->prof_ev[2 * idx], h->stream);
+        h->launch_ev0 = h->prof_ev[2 * idx]; h->launch_ev1 = h->prof_ev[2 * idx + 1];
       } else {
         h->prof_dropped[slot] += 1;   // the ring is full: say so instead of averaging over a silent prefix
       }
     }
   }
   ~ProfScope() {
-    if (h->prof == 1) {
-      (void)hipEventRecord(h->ev1, h->stream);
+    if (h->prof == 1 && h->launch_ev1) {
       (void)hipEventSynchronize(h->ev1);
       float ms = 0.f;
       if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) add(h, slot, ms);
-    } else if (idx >= 0) {
-      (void)hipEventRecord(h->prof_ev[2 * idx + 1], h->stream);   // no wait: altro_hip_profile_get reads them
     }
+    h->launch_ev0 = nullptr; h->launch_ev1 = nullptr;   // (mode 2: altro_hip_profile_get reads the pairs, no wait here)
   }
 };
 
@@ -140,16 +147,16 @@ template <typename S>
 void mfma16_launch_backward(altro_hip_batch* h, double reg, bool sq) {
   auto a = mfma16_args<S>(h, reg);
   const dim3 grid(mf_grid(h->batch)), block(64);
-  if (sq && a.has_f) hipLaunchKernelGGL((mfma16_backward_kernel<true, true, S>), grid, block, 0, h->stream, a);
-  else if (sq) hipLaunchKernelGGL((mfma16_backward_kernel<true, false, S>), grid, block, 0, h->stream, a);
-  else if (a.has_f) hipLaunchKernelGGL((mfma16_backward_kernel<false, true, S>), grid, block, 0, h->stream, a);
-  else hipLaunchKernelGGL((mfma16_backward_kernel<false, false, S>), grid, block, 0, h->stream, a);
+  if (sq && a.has_f) PROF_LAUNCH((mfma16_backward_kernel<true, true, S>), grid, block, 0, h->stream, a);
+  else if (sq) PROF_LAUNCH((mfma16_backward_kernel<true, false, S>), grid, block, 0, h->stream, a);
+  else if (a.has_f) PROF_LAUNCH((mfma16_backward_kernel<false, true, S>), grid, block, 0, h->stream, a);
+  else PROF_LAUNCH((mfma16_backward_kernel<false, false, S>), grid, block, 0, h->stream, a);
 }
 
 template <typename S>
 void mfma16_launch_forward(altro_hip_batch* h, const Mfma16Args<S>& a) {
   // register-ring depth 3: depths 1..4 were measured, 3 is the knee
-  hipLaunchKernelGGL((mfma16_forward_kernel<S, 3>), dim3(mf_grid(h->batch)), dim3(64), 0, h->stream, a);
+  PROF_LAUNCH((mfma16_forward_kernel<S, 3>), dim3(mf_grid(h->batch)), dim3(64), 0, h->stream, a);
 }
 
 }  // namespace
@@ -175,8 +182,8 @@ int launch_backward(altro_hip_batch* h, double reg) {
         static const int variant = std::getenv("ALTRO_HIP_F32X4") ? std::atoi(std::getenv("ALTRO_HIP_F32X4")) : 22;
 #define MFQ_LAUNCH(D, W)                                                                                               \
   do {                                                                                                                 \
-    if (a.has_f) hipLaunchKernelGGL((mfma16_backward_f32x4_kernel<true, D, W>), grid, dim3(64), 0, h->stream, a);       \
-    else hipLaunchKernelGGL((mfma16_backward_f32x4_kernel<false, D, W>), grid, dim3(64), 0, h->stream, a);              \
+    if (a.has_f) PROF_LAUNCH((mfma16_backward_f32x4_kernel<true, D, W>), grid, dim3(64), 0, h->stream, a);       \
+    else PROF_LAUNCH((mfma16_backward_f32x4_kernel<false, D, W>), grid, dim3(64), 0, h->stream, a);              \
   } while (0)
         switch (variant) {
           case 13: MFQ_LAUNCH(1, 3); break;
@@ -187,19 +194,19 @@ int launch_backward(altro_hip_batch* h, double reg) {
           default: MFQ_LAUNCH(2, 2); break;
         }
 #undef MFQ_LAUNCH
-      } else if (a.has_f) hipLaunchKernelGGL((mfma16_backward_f32_kernel<true, 3>), dim3(mf_grid(h->batch)), dim3(64), 0, h->stream, a);
-      else hipLaunchKernelGGL((mfma16_backward_f32_kernel<false, 3>), dim3(mf_grid(h->batch)), dim3(64), 0, h->stream, a);
+      } else if (a.has_f) PROF_LAUNCH((mfma16_backward_f32_kernel<true, 3>), dim3(mf_grid(h->batch)), dim3(64), 0, h->stream, a);
+      else PROF_LAUNCH((mfma16_backward_f32_kernel<false, 3>), dim3(mf_grid(h->batch)), dim3(64), 0, h->stream, a);
     }
   } else if (h->plan == ALTRO_HIP_PLAN_LANE) {
     return h->dtype == ALTRO_HIP_F64 ? lane_launch<double>(h, true, reg) : lane_launch<float>(h, true, reg);
   } else if (h->dtype == ALTRO_HIP_F64) {
     auto a = generic_args<double>(h, reg);
     size_t lds = generic_backward_lds_bytes<double>(h->n, h->m);
-    hipLaunchKernelGGL(generic_backward_kernel<double>, dim3(h->batch), dim3(64), lds, h->stream, a);
+    PROF_LAUNCH(generic_backward_kernel<double>, dim3(h->batch), dim3(64), lds, h->stream, a);
   } else {
     auto a = generic_args<float>(h, reg);
     size_t lds = generic_backward_lds_bytes<float>(h->n, h->m);
-    hipLaunchKernelGGL(generic_backward_kernel<float>, dim3(h->batch), dim3(64), lds, h->stream, a);
+    PROF_LAUNCH(generic_backward_kernel<float>, dim3(h->batch), dim3(64), lds, h->stream, a);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "backward launch: %s", hipGetErrorString(e));
@@ -227,14 +234,14 @@ int launch_forward(altro_hip_batch* h) {
         // 2.84 / 2.81; ALTRO_HIP_F32X4_FWD = "DW" overrides (tools/c4_fwd_ab.sh)
         static const int variant = std::getenv("ALTRO_HIP_F32X4_FWD") ? std::atoi(std::getenv("ALTRO_HIP_F32X4_FWD")) : 22;
         switch (variant) {
-          case 14: hipLaunchKernelGGL((mfma16_forward_f32x4_kernel<1, 4>), grid, dim3(64), 0, h->stream, a); break;
-          case 34: hipLaunchKernelGGL((mfma16_forward_f32x4_kernel<3, 4>), grid, dim3(64), 0, h->stream, a); break;
-          case 32: hipLaunchKernelGGL((mfma16_forward_f32x4_kernel<3, 2>), grid, dim3(64), 0, h->stream, a); break;
-          case 42: hipLaunchKernelGGL((mfma16_forward_f32x4_kernel<4, 2>), grid, dim3(64), 0, h->stream, a); break;
-          case 24: hipLaunchKernelGGL((mfma16_forward_f32x4_kernel<2, 4>), grid, dim3(64), 0, h->stream, a); break;
-          case 23: hipLaunchKernelGGL((mfma16_forward_f32x4_kernel<2, 3>), grid, dim3(64), 0, h->stream, a); break;
-          case 33: hipLaunchKernelGGL((mfma16_forward_f32x4_kernel<3, 3>), grid, dim3(64), 0, h->stream, a); break;
-          default: hipLaunchKernelGGL((mfma16_forward_f32x4_kernel<2, 2>), grid, dim3(64), 0, h->stream, a); break;
+          case 14: PROF_LAUNCH((mfma16_forward_f32x4_kernel<1, 4>), grid, dim3(64), 0, h->stream, a); break;
+          case 34: PROF_LAUNCH((mfma16_forward_f32x4_kernel<3, 4>), grid, dim3(64), 0, h->stream, a); break;
+          case 32: PROF_LAUNCH((mfma16_forward_f32x4_kernel<3, 2>), grid, dim3(64), 0, h->stream, a); break;
+          case 42: PROF_LAUNCH((mfma16_forward_f32x4_kernel<4, 2>), grid, dim3(64), 0, h->stream, a); break;
+          case 24: PROF_LAUNCH((mfma16_forward_f32x4_kernel<2, 4>), grid, dim3(64), 0, h->stream, a); break;
+          case 23: PROF_LAUNCH((mfma16_forward_f32x4_kernel<2, 3>), grid, dim3(64), 0, h->stream, a); break;
+          case 33: PROF_LAUNCH((mfma16_forward_f32x4_kernel<3, 3>), grid, dim3(64), 0, h->stream, a); break;
+          default: PROF_LAUNCH((mfma16_forward_f32x4_kernel<2, 2>), grid, dim3(64), 0, h->stream, a); break;
         }
       } else {
         mfma16_launch_forward<float>(h, a);
@@ -245,11 +252,11 @@ int launch_forward(altro_hip_batch* h) {
   } else if (h->dtype == ALTRO_HIP_F64) {
     auto a = generic_args<double>(h, 0.0);
     size_t lds = (size_t)(2 * h->n + h->m) * sizeof(double) + 64;
-    hipLaunchKernelGGL(generic_forward_kernel<double>, dim3(h->batch), dim3(64), lds, h->stream, a);
+    PROF_LAUNCH(generic_forward_kernel<double>, dim3(h->batch), dim3(64), lds, h->stream, a);
   } else {
     auto a = generic_args<float>(h, 0.0);
     size_t lds = (size_t)(2 * h->n + h->m) * sizeof(float) + 64;
-    hipLaunchKernelGGL(generic_forward_kernel<float>, dim3(h->batch), dim3(64), lds, h->stream, a);
+    PROF_LAUNCH(generic_forward_kernel<float>, dim3(h->batch), dim3(64), lds, h->stream, a);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "forward launch: %s", hipGetErrorString(e));
