@@ -799,7 +799,15 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
   auto spec_units = [&](int searching) -> int {   // wavefronts one merit launch keeps busy
     return lane_plan ? (h->batch + 63) / 64 : searching;   // LANE: the searching lanes are scattered over all waves
   };
-  const int64_t spec_capacity = lane_plan ? 512 : 4096;    // two waves per CU (LANE: latency-bound; more slow each other down) / four per SIMD (MFMA16)
+  const char* mrd = std::getenv("ALTRO_HIP_MERIT_DPP");
+  const bool merit_rounds_dpp = mrd == nullptr || std::atoi(mrd) != 0;
+  // wavefronts a round of `trials` steps per searching problem launches: a wave per (problem, trial) in the LDS form, a wave per
+  // two problems and two trials in the DPP form (which keeps two waves per SIMD, not four: see the capacity below)
+  auto spec_waves = [&](int searching, int trials) -> int64_t {
+    if (lane_plan || !merit_rounds_dpp) return (int64_t)spec_units(searching) * trials;
+    return (int64_t)((searching + 1) / 2) * ((trials + 1) / 2);
+  };
+  const int64_t spec_capacity = lane_plan ? 512 : (merit_rounds_dpp ? 2048 : 4096);    // two waves per CU (LANE: latency-bound; more slow each other down) / four per SIMD (MFMA16)
   h->spec_trials = 1;
   struct MaskGuard {   // the backward sweep skips problems that have stopped, only inside this loop
     altro_hip_batch* h;
@@ -903,7 +911,7 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
     // phi(0) -- phi, phi' and the trajectory go to spare row / buffer 0 -- and ILK_LS_BEGIN consumes it at once.
     bool refreshed = false;
     bool stat_needed = true;
-    bool pre = !dual && spec_all_on && !h->spec_no_memory && (int64_t)spec_units(running) * 2 <= spec_capacity;
+    bool pre = !dual && spec_all_on && !h->spec_no_memory && spec_waves(running, 2) * 2 <= spec_capacity * (lane_plan || !merit_rounds_dpp ? 2 : 1);
     if (pre && !ensure_spares(h, 1, spare_each)) {   // an optimisation only: carry on one step per launch
       h->spec_no_memory = true;
       pre = false;
@@ -964,7 +972,10 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
       // kernel consumes them in order, so every decision is the sequential one (kernels/ilqr_types.h).
       int trials = 1;
       if (spec_on && !h->spec_no_memory)
-        while (trials < trials_cap && (int64_t)spec_units(counters[0]) * trials * 2 <= spec_capacity) trials *= 2;
+        while (trials < trials_cap && spec_waves(counters[0], trials * 2) * 2 <= spec_capacity) trials *= 2;
+      // plan MFMA16's rounds in the DPP form evaluate two trials per problem in the lanes one trial would leave idle
+      // (kernels/ilqr_merit2_dpp.hip): the second step of the known sequence rides along whatever the occupancy
+      if (spec_on && !lane_plan && !h->spec_no_memory && trials < 2 && merit_rounds_dpp) trials = 2;
       if (trials > 1 && !ensure_spares(h, trials_cap - 1, spare_each)) {
         while (trials > 1 && trials - 1 > h->spare_count) trials /= 2;   // as wide as the spares there are
         if (trials == 1 && h->spare_count == 0) h->spec_no_memory = true;
