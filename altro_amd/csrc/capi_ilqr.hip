@@ -886,10 +886,11 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
     }
     iter0 = running > 0 ? fused_sweeps : o.iterations_max;
   }
+  bool hessians_ready = false;   // the previous sweep's last expansion left the cost Hessians of this one
   for (int iter = iter0; iter < o.iterations_max; ++iter) {
     la.iter = iter;
     if (ilqr_launch_loop(h->stream, ILK_MARK_RUNNING, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
-    if (al) {                                                   // CalcExpansions: cost Hessians (solver.cpp:448)
+    if (al && !hessians_ready) {                                // CalcExpansions: cost Hessians (solver.cpp:448)
       rc = ilqr_run(h, IK_EXPAND, false, true, 0, 0.0, EXPAND_HESSIAN);
       if (rc) return rc;
     }
@@ -1020,8 +1021,14 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
       rc = ilqr_run(h, IK_DUAL, false, false, 0, 0.0);
       if (rc) return rc;
       if (ilqr_launch_loop(h->stream, ILK_PENALTY_UPDATE, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
-      rc = ilqr_run(h, IK_EXPAND, false, true, 0, 0.0, EXPAND_GRADIENT);
+      // ... and, in the same pass over the constraint rows, the cost Hessians the NEXT sweep's CalcExpansions would form:
+      // nothing they depend on (trajectory, duals, penalties) changes between here and there
+      // (plan MFMA16, DPP form: gradient for the problems whose duals changed, Hessians for every problem still running)
+      const char* ed = std::getenv("ALTRO_HIP_EXPAND_DPP");
+      const bool merged = !lane_plan && !(ed != nullptr && std::atoi(ed) == 0);
+      rc = ilqr_run(h, IK_EXPAND, false, true, 0, 0.0, merged ? (EXPAND_GRADIENT | EXPAND_HESSIAN | EXPAND_NEXT) : EXPAND_GRADIENT);
       if (rc) return rc;
+      hessians_ready = merged;
     }
     if ((rc = read_counters())) return rc;
     ++sweeps;

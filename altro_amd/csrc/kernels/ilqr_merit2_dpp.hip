@@ -533,8 +533,10 @@ __global__ __launch_bounds__(64) void wave_expand_dpp_kernel(IlqrWaveArgs<S> a) 
   if (k > a.N) return;
   // a row without a problem of its own (past the end of the batch, or one that is not taking part) shadows the wave's first
   // live row and stores nothing: the DPP blocks below need every lane switched on
-  bool on = b_own < a.batch;
-  if (on && a.active && !a.active[b_own]) on = false;
+  const bool in_batch = b_own < a.batch;
+  const bool on_g = in_batch && !(a.active && !a.active[b_own]);                    // stores the gradient
+  const bool on_h = (a.mode & EXPAND_NEXT) ? (in_batch && a.prob[b_own].running != 0) : on_g;   // stores the Hessian blocks
+  const bool on = on_g || on_h;
   const unsigned long long onm = __ballot(on);
   if (onm == 0ull) return;
   const int b = on ? b_own : b0 + (__builtin_ctzll(onm) >> 4);
@@ -635,13 +637,13 @@ __global__ __launch_bounds__(64) void wave_expand_dpp_kernel(IlqrWaveArgs<S> a) 
     }
   }
   if (!on) return;
-  if (grad) {
+  if (grad && on_g) {
     double l = cq * w + cl;
     l -= scol;
     if (!terminal) a.cin[(size_t)b * a.cin_bs + (size_t)k * a.cin_ks + MF_OFF_QR + j] = (S)l;
     else if (j < 12) a.term[(size_t)b * MF_TERM + 144 + j] = (S)l;
   }
-  if (hess) {
+  if (hess && on_h) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       if (terminal && (r >= 12 || j >= 12)) continue;

@@ -67,7 +67,9 @@ struct IlqrArgs {
   T* spec_jac;          // [N][n n + n m + n + m][batch] then [n][batch]
 };
 constexpr int STAT_NO_FEAS = 32;   // IK_STATIONARITY / IK_DUAL on plan MFMA16: the constraint rows in the DPP form (ilqr_merit2_dpp.hip)
-enum { EXPAND_GRADIENT = 1, EXPAND_HESSIAN = 2, EXPAND_LDS = 16 /* plan MFMA16: wave_expand_kernel instead of the DPP form (A/B, tests) */ };
+enum { EXPAND_GRADIENT = 1, EXPAND_HESSIAN = 2, EXPAND_LDS = 16 /* plan MFMA16: wave_expand_kernel instead of the DPP form (A/B, tests) */,
+       EXPAND_NEXT = 64 /* wave_expand_dpp_kernel at the end of a sweep: the gradient for the problems of the active mask (those whose
+                           duals changed), the cost Hessians of the NEXT sweep for every problem still running (IlqrProb::running) */ };
 
 struct IlqrLoopArgs {
   IlqrProb* prob;
