@@ -95,6 +95,7 @@ int al_upload_typed(altro_hip_batch* h) {
   // (memsets go on the handle's own stream: it is non-blocking, so a null-stream memset would race the kernels)
   HIP_TRY(hipMemsetAsync(h->al_d_z, 0, (size_t)rows * B * sizeof(T), h->stream));
   h->al_knots = knots;
+  h->al_G_count = (int)G.size();
   return 0;
 }
 int al_upload(altro_hip_batch* h) {
@@ -109,7 +110,7 @@ IlqrArgs<T> ilqr_args(altro_hip_batch* h, bool use_alpha, bool use_active, int w
   IlqrArgs<T> a;
   a.al.knots = h->al_d_knots; a.al.G = (const T*)h->al_d_G; a.al.g = (const T*)h->al_d_g;
   a.al.z = (T*)h->al_d_z; a.al.enabled = h->al_defs.empty() ? 0 : 1;
-  a.al.uniform = h->al_uniform; a.al.rows_per_knot = h->al_rows_per_knot; a.al.N = h->N;
+  a.al.uniform = h->al_uniform; a.al.rows_per_knot = h->al_rows_per_knot; a.al.N = h->N; a.al.G_count = h->al_G_count;
   a.mode = EXPAND_GRADIENT | EXPAND_HESSIAN;
   a.in = (T*)h->l_in; a.term = (T*)h->l_term; a.out = (const T*)h->l_out; a.outn = (const T*)h->l_outn;
   a.nom = (T*)h->l_nom; a.cand = (T*)h->l_xuy; a.cost = (const T*)h->l_cost; a.x0 = (const T*)h->l_x0;
@@ -176,7 +177,7 @@ int wave_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int
   IlqrWaveArgs<S> a;
   a.al.knots = h->al_d_knots; a.al.G = (const S*)h->al_d_G; a.al.g = (const S*)h->al_d_g; a.al.z = (S*)h->al_d_z;
   a.al.enabled = h->al_defs.empty() ? 0 : 1;
-  a.al.uniform = h->al_uniform; a.al.rows_per_knot = h->al_rows_per_knot; a.al.N = h->N;
+  a.al.uniform = h->al_uniform; a.al.rows_per_knot = h->al_rows_per_knot; a.al.N = h->N; a.al.G_count = h->al_G_count;
   a.mode = mode;
   if (which == IK_STATIONARITY || which == IK_DUAL) {   // constraint rows in the DPP form unless ALTRO_HIP_ALROWS_DPP=0
     const char* e = std::getenv("ALTRO_HIP_ALROWS_DPP");

@@ -43,6 +43,7 @@ struct AlTable {
   // entry of knot point 0 at every step -- the same constant-memory address, a scalar-cache hit instead of a fresh
   // miss per step -- and offset the duals by k * rows_per_knot.
   int uniform, rows_per_knot, N;
+  int G_count;           // elements of the G pool (kernels that keep it in LDS: kernels/ilqr_merit2_dpp.hip)
 };
 #define ALTRO_CONST_AS __attribute__((address_space(4)))
 // table entry and dual-row shift for knot point k

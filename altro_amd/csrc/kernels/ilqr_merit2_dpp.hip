@@ -35,6 +35,7 @@ constexpr int MD_F0 = MD_OUT0 + MF_OUT;      // 360
 constexpr int MD_NOM0 = MD_F0 + 12;          // 372
 constexpr int MD_CP0 = MD_NOM0 + MF_NOM;     // 388
 constexpr int MD_IMG = MD_CP0 + MF_COSTP;    // 424
+constexpr int MD_GPOOL = 512;                // doubles of LDS for the constraint Jacobians (four blocks of 8 x 16)
 static_assert(MF_DYN % 2 == 0 && MF_OUT % 2 == 0 && MF_NOM % 2 == 0 && MF_COSTP % 2 == 0 && MD_IMG % 2 == 0, "records move as pairs");
 
 typedef double md_d2 __attribute__((ext_vector_type(2)));
@@ -141,7 +142,8 @@ __device__ __forceinline__ void md_gather4(double v, double (&o)[4]) {
 // (DU: DualUpdate, knotpoint_data.cpp:503-510 -- the projected dual becomes the dual; `store`: this row has a problem of its own)
 template <typename S, bool DU = false>
 __device__ __forceinline__ void dpp_al_rows(const AlTable<S>& t, int k, int b, int64_t B, double w, bool terminal, double rho_est, int j,
-                                            double (&jvr)[AL_MAXC], double& cost, double& viol, bool store = false) {
+                                            double (&jvr)[AL_MAXC], double& cost, double& viol, bool store = false,
+                                            const double* Gl = nullptr) {   // Gl: the G pool in LDS (the sweeps keep it there)
   int zshift;
   const AlKnot ALTRO_CONST_AS& kn = al_knot<S>(t, k, zshift);
 #pragma unroll
@@ -153,10 +155,19 @@ __device__ __forceinline__ void dpp_al_rows(const AlTable<S>& t, int k, int b, i
     const bool rl = j < p;                          // this lane owns a row of the block
     const int jr = rl ? j : 0;
     double cG[16];
+    if (Gl) {
+      const double* Gc = Gl + kn.G_off[c];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const double ge = (double)G[jr + e * p];
-      cG[e] = (rl && !(terminal && e >= 12)) ? ge : 0.0;
+      for (int e = 0; e < 16; ++e) {
+        const double ge = Gc[jr + e * p];
+        cG[e] = (rl && !(terminal && e >= 12)) ? ge : 0.0;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const double ge = (double)G[jr + e * p];
+        cG[e] = (rl && !(terminal && e >= 12)) ? ge : 0.0;
+      }
     }
     double sacc = 0.0;
     md_chain16(sacc, w, cG);
@@ -205,7 +216,7 @@ __device__ __forceinline__ void dpp_al_rows(const AlTable<S>& t, int k, int b, i
   }
 }
 template <typename S>
-__device__ __forceinline__ double dpp_al_col(const AlTable<S>& t, int k, int j, const double (&jvr)[AL_MAXC]) {
+__device__ __forceinline__ double dpp_al_col(const AlTable<S>& t, int k, int j, const double (&jvr)[AL_MAXC], const double* Gl = nullptr) {
   int zshift;
   const AlKnot ALTRO_CONST_AS& kn = al_knot<S>(t, k, zshift);
   double s = 0.0;
@@ -215,10 +226,19 @@ __device__ __forceinline__ double dpp_al_col(const AlTable<S>& t, int k, int j, 
     const int p = kn.p[c];
     const S* G = t.G + kn.G_off[c];
     double cC[8];
+    if (Gl) {
+      const double* Gc = Gl + kn.G_off[c];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const double gi = (double)G[(i < p ? i : 0) + j * p];
-      cC[i] = i < p ? gi : 0.0;
+      for (int i = 0; i < 8; ++i) {
+        const double gi = Gc[(i < p ? i : 0) + j * p];
+        cC[i] = i < p ? gi : 0.0;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const double gi = (double)G[(i < p ? i : 0) + j * p];
+        cC[i] = i < p ? gi : 0.0;
+      }
     }
     md_chain8(s, jvr[c], cC);
   }
@@ -234,8 +254,8 @@ template <typename S, bool AL, bool DUAL>
 __global__ __launch_bounds__(64, 2) void wave_merit_dpp_kernel(IlqrWaveArgs<S> a) {
   constexpr int DEPTH = 2;                          // also the image ping-pong: parity of k == dd
   constexpr bool kStat = sizeof(S) == 8;            // stored values == computed values only without a rounding store
-  __shared__ double img[2][2][MD_IMG];              // [parity][slot]
-  __shared__ double red[2][4][64];                  // the final sums, in the LDS-form kernels' lane arrangement
+  __shared__ double img[2][2][MD_IMG];              // [parity][slot]; after the sweep: the final sums (red, below)
+  __shared__ double Gpool[AL ? MD_GPOOL : 1];       // the constraint Jacobians, read at every knot point: kept here when they fit
   const int lane = threadIdx.x;
   const int npairs = (a.batch + 1) >> 1;
   const int pr = mf_problem(blockIdx.x, npairs);
@@ -281,6 +301,11 @@ __global__ __launch_bounds__(64, 2) void wave_merit_dpp_kernel(IlqrWaveArgs<S> a
   }
   constexpr bool al = AL;
   const double rho = al ? a.prob[b].rho : 1.0;
+  const double* Gl = nullptr;
+  if (al && a.al.G_count <= MD_GPOOL) {             // (the first barrier of the sweep below orders these stores before their readers)
+    for (int e = lane; e < a.al.G_count; e += 64) Gpool[e] = (double)a.al.G[e];
+    Gl = Gpool;
+  }
   const bool isx = j < 12;
   const bool cand = DUAL ? (h == 1 && wr) : row_on; // DUAL: trial 1 writes the candidate trajectory and the expansion
   const bool wqr = DUAL ? cand : (row_on && deriv && store);
@@ -337,7 +362,7 @@ __global__ __launch_bounds__(64, 2) void wave_merit_dpp_kernel(IlqrWaveArgs<S> a
     const double w = isx ? x : uval, dw = isx ? dxda : duval;
     if (al) {   // both trials' constraint rows at the candidate point [x; u]; the feasibility that counts is trial 1's
       double Ja = 0.0, vv = 0.0;
-      dpp_al_rows<S>(a.al, kc, b, a.batch, w, false, rho, j, jvr, Ja, vv);
+      dpp_al_rows<S>(a.al, kc, b, a.batch, w, false, rho, j, jvr, Ja, vv, false, Gl);
       if (live) Jal += Ja;
       if (cand) viol = fmax(viol, vv);
     }
@@ -367,7 +392,7 @@ __global__ __launch_bounds__(64, 2) void wave_merit_dpp_kernel(IlqrWaveArgs<S> a
     // (an explicit fma: cq * w also feeds the cost above, and a product with two uses is not contracted -- wave_merit2_kernel
     //  forms this gradient from its own loads, where it is)
     double l = __builtin_fma(cq, w, cl);                     // lx_j | lu_(j-12)
-    if (al) l -= dpp_al_col<S>(a.al, kc, j, jvr);
+    if (al) l -= dpp_al_col<S>(a.al, kc, j, jvr, Gl);
     if (live) dJ += l * dw;
     if (cand) {   // trial 1's candidate record x | y | u and its [lx lu]
       S* c = candb + (size_t)(live ? k : N) * a.xuy_ks;
@@ -392,10 +417,10 @@ __global__ __launch_bounds__(64, 2) void wave_merit_dpp_kernel(IlqrWaveArgs<S> a
     if (al) {
       double Ja = 0.0, vv = 0.0;
       if constexpr (DUAL) {
-        dpp_al_rows<S>(a.al, N, b, a.batch, isx ? x : 0.0, true, rho, j, jvr, Ja, vv);
+        dpp_al_rows<S>(a.al, N, b, a.batch, isx ? x : 0.0, true, rho, j, jvr, Ja, vv, false, Gl);
         Jal += Ja;
       } else {   // (wave_merit_kernel adds the terminal blocks' shares to its running sum one by one)
-        dpp_al_rows<S>(a.al, N, b, a.batch, isx ? x : 0.0, true, rho, j, jvr, Jal, vv);
+        dpp_al_rows<S>(a.al, N, b, a.batch, isx ? x : 0.0, true, rho, j, jvr, Jal, vv, false, Gl);
       }
       if (cand) viol = fmax(viol, vv);
     }
@@ -406,7 +431,7 @@ __global__ __launch_bounds__(64, 2) void wave_merit_dpp_kernel(IlqrWaveArgs<S> a
     md_rows12(sacc, unused, dxN, dxda, cP);
     const double yN = sacc + cP[12];
     double lx = __builtin_fma(Qd, x, q);
-    if (al) lx -= dpp_al_col<S>(a.al, N, jr, jvr);
+    if (al) lx -= dpp_al_col<S>(a.al, N, jr, jvr, Gl);
     if (isx) dJ += lx * dxda;
     if (cand) {
       if (isx) {
@@ -434,6 +459,8 @@ __global__ __launch_bounds__(64, 2) void wave_merit_dpp_kernel(IlqrWaveArgs<S> a
   // the sums, over the LDS-form kernels' arrangement of the addends.  DUAL: a trial's 32 entries hold the state terms at 0..11,
   // the input terms at 16..19 (dphi: 12..15), the constraint rows' at 16..23, and are added by the butterfly of offsets 16 .. 1
   __syncthreads();
+  static_assert(2 * 2 * MD_IMG >= 2 * 4 * 64, "the final sums reuse the record images");
+  double (*red)[4][64] = reinterpret_cast<double (*)[4][64]>(&img[0][0][0]);   // the final sums, in the LDS-form kernels' lane arrangement
   for (int e = lane; e < 2 * 4 * 64; e += 64) (&red[0][0][0])[e] = 0.0;
   __syncthreads();
   red[0][lane >> 4][isx ? j : j + 4] = J;
