@@ -32,10 +32,9 @@ static int wave_launch(hipStream_t stream, int which, const IlqrWaveArgs<S>& a) 
       break;
     case IK_MERIT:
       // the DPP form: two problems per wave, two trials per problem (kernels/ilqr_merit2_dpp.hip).  With constraint blocks
-      // and ONE trial per problem its second rows idle: on long horizons the LDS form is then the faster one (C1 + input
-      // bounds, N = 256, rounds of one trial: 0.48 vs 0.51 ms per launch, the solve 136.6 vs 140.2 ms), on short ones its
-      // half as many waves still win (the (12, 4) MPC example, N = 40: 13.6 vs 14.1 ms per step; 15.0 with the LDS form throughout)
-      if (a.mode == 3 || (a.mode == 2 && (a.spec_trials > 1 || !a.al.enabled || a.N <= 96))) {   // (3: forced, ALTRO_HIP_MERIT_DPP=2 -- tests)
+      // and ONE trial per problem its second rows idle; on long horizons the LDS form (four waves per SIMD) is then the faster
+      // one -- C1 + input bounds as whole solves, cubic search: N = 48: 48.7 (DPP) vs 49.0 ms, N = 128: 72.2 vs 72.8, N = 256: 111.6 vs 108.9
+      if (a.mode == 3 || (a.mode == 2 && (a.spec_trials > 1 || !a.al.enabled || a.N <= 160))) {   // (3: forced, ALTRO_HIP_MERIT_DPP=2 -- tests)
         const dim3 grid(mf_grid((a.batch + 1) / 2), ((a.spec_trials > 1 ? a.spec_trials : 1) + 1) / 2);
         if (a.al.enabled) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, true, false>), grid, b64, 0, stream, a);
         else hipLaunchKernelGGL((wave_merit_dpp_kernel<S, false, false>), grid, b64, 0, stream, a);
