@@ -143,7 +143,8 @@ __device__ __forceinline__ void md_gather4(double v, double (&o)[4]) {
 template <typename S, bool DU = false>
 __device__ __forceinline__ void dpp_al_rows(const AlTable<S>& t, int k, int b, int64_t B, double w, bool terminal, double rho_est, int j,
                                             double (&jvr)[AL_MAXC], double& cost, double& viol, bool store = false,
-                                            const double* Gl = nullptr) {   // Gl: the G pool in LDS (the sweeps keep it there)
+                                            const double* Gl = nullptr,     // Gl: the G pool in LDS (the sweeps keep it there)
+                                            const double (*pre)[2] = nullptr) {   // pre: this knot point's (z_i, g_i), fetched a step ahead
   int zshift;
   const AlKnot ALTRO_CONST_AS& kn = al_knot<S>(t, k, zshift);
 #pragma unroll
@@ -171,10 +172,14 @@ __device__ __forceinline__ void dpp_al_rows(const AlTable<S>& t, int k, int b, i
     }
     double sacc = 0.0;
     md_chain16(sacc, w, cG);
-    const double gi = rl ? (kn.g_per_problem[c] ? (double)t.g[kn.g_off[c] + (int64_t)jr * B + b] : (double)t.g[kn.g_off[c] + jr]) : 0.0;
-    const double val = sacc - gi;
     S* const zp_ = t.z + (int64_t)(kn.z_off[c] + zshift + jr) * B + b;
-    const double zi = (double)*zp_;
+    double gi, zi;
+    if (pre) { zi = pre[c][0]; gi = pre[c][1]; }
+    else {
+      gi = rl ? (kn.g_per_problem[c] ? (double)t.g[kn.g_off[c] + (int64_t)jr * B + b] : (double)t.g[kn.g_off[c] + jr]) : 0.0;
+      zi = (double)*zp_;
+    }
+    const double val = sacc - gi;
     const double ze = rl ? zi - rho_est * val : 0.0;
     if (cone != CONE_SOC) {
       if (rl) {
@@ -213,6 +218,23 @@ __device__ __forceinline__ void dpp_al_rows(const AlTable<S>& t, int k, int b, i
         if (r < p && j == r) jvr[c] = sj;
       }
     }
+  }
+}
+// (z_i, g_i) of knot point k for dpp_al_rows: the duals sit in [row][batch] arrays, a fresh line per knot point and row -- the sweeps
+// fetch them one step ahead so that the row's chain does not wait for them at every knot point
+template <typename S>
+__device__ __forceinline__ void dpp_al_fetch(const AlTable<S>& t, int k, int b, int64_t B, int j, double (&zg)[AL_MAXC][2]) {
+  int zshift;
+  const AlKnot ALTRO_CONST_AS& kn = al_knot<S>(t, k, zshift);
+#pragma unroll
+  for (int c = 0; c < AL_MAXC; ++c) {
+    zg[c][0] = 0.0; zg[c][1] = 0.0;
+    if (c >= kn.ncon) continue;
+    const int p = kn.p[c];
+    const bool rl = j < p;
+    const int jr = rl ? j : 0;
+    zg[c][0] = (double)t.z[(int64_t)(kn.z_off[c] + zshift + jr) * B + b];
+    zg[c][1] = rl ? (kn.g_per_problem[c] ? (double)t.g[kn.g_off[c] + (int64_t)jr * B + b] : (double)t.g[kn.g_off[c] + jr]) : 0.0;
   }
 }
 template <typename S>
@@ -324,6 +346,8 @@ __global__ __launch_bounds__(64, 2) void wave_merit_dpp_kernel(IlqrWaveArgs<S> a
   double dxda = 0.0;
   double J = 0.0, Jal = 0.0, dJ = 0.0, res = 0.0, viol = 0.0;   // (Jal: the constraint rows' cost shares, lanes 0..7)
   double jvr[AL_MAXC] = {0.0, 0.0};
+  double zg[AL_MAXC][2] = {{0.0, 0.0}, {0.0, 0.0}};   // (z_i, g_i) of the knot point in hand
+  if (al) dpp_al_fetch<S>(a.al, 0, b, a.batch, j, zg);
   double lprev = 0.0, yprev = 0.0;                  // gradient and y of knot point k - 1 (the stationarity's lag)
   MeritPairRegs ring[DEPTH];
 #pragma unroll
@@ -362,8 +386,16 @@ __global__ __launch_bounds__(64, 2) void wave_merit_dpp_kernel(IlqrWaveArgs<S> a
     const double w = isx ? x : uval, dw = isx ? dxda : duval;
     if (al) {   // both trials' constraint rows at the candidate point [x; u]; the feasibility that counts is trial 1's
       double Ja = 0.0, vv = 0.0;
-      dpp_al_rows<S>(a.al, kc, b, a.batch, w, false, rho, j, jvr, Ja, vv, false, Gl);
-      if (live) Jal += Ja;
+      if (live) {
+        double zgn[AL_MAXC][2];
+        dpp_al_fetch<S>(a.al, k + 1, b, a.batch, j, zgn);     // (k + 1 <= N: the terminal knot point's too)
+        dpp_al_rows<S>(a.al, kc, b, a.batch, w, false, rho, j, jvr, Ja, vv, false, Gl, zg);
+#pragma unroll
+        for (int c = 0; c < AL_MAXC; ++c) { zg[c][0] = zgn[c][0]; zg[c][1] = zgn[c][1]; }
+        Jal += Ja;
+      } else {
+        dpp_al_rows<S>(a.al, kc, b, a.batch, w, false, rho, j, jvr, Ja, vv, false, Gl);   // a padding step: knot point N - 1 again, discarded
+      }
       if (cand) viol = fmax(viol, vv);
     }
     // (2) the stationarity at knot point k - 1 now that y_k is known: column j of Z_(k-1) against y_k
@@ -417,10 +449,10 @@ __global__ __launch_bounds__(64, 2) void wave_merit_dpp_kernel(IlqrWaveArgs<S> a
     if (al) {
       double Ja = 0.0, vv = 0.0;
       if constexpr (DUAL) {
-        dpp_al_rows<S>(a.al, N, b, a.batch, isx ? x : 0.0, true, rho, j, jvr, Ja, vv, false, Gl);
+        dpp_al_rows<S>(a.al, N, b, a.batch, isx ? x : 0.0, true, rho, j, jvr, Ja, vv, false, Gl, zg);
         Jal += Ja;
       } else {   // (wave_merit_kernel adds the terminal blocks' shares to its running sum one by one)
-        dpp_al_rows<S>(a.al, N, b, a.batch, isx ? x : 0.0, true, rho, j, jvr, Jal, vv, false, Gl);
+        dpp_al_rows<S>(a.al, N, b, a.batch, isx ? x : 0.0, true, rho, j, jvr, Jal, vv, false, Gl, zg);
       }
       if (cand) viol = fmax(viol, vv);
     }
