@@ -179,6 +179,7 @@ int wave_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int
   a.al.enabled = h->al_defs.empty() ? 0 : 1;
   a.al.uniform = h->al_uniform; a.al.rows_per_knot = h->al_rows_per_knot; a.al.N = h->N; a.al.G_count = h->al_G_count;
   a.mode = mode;
+  a.penalty_scaling = h->expand_penalty_scaling; a.penalty_max = h->expand_penalty_max;
   if (which == IK_STATIONARITY || which == IK_DUAL) {   // constraint rows in the DPP form unless ALTRO_HIP_ALROWS_DPP=0
     const char* e = std::getenv("ALTRO_HIP_ALROWS_DPP");
     a.mode = (e != nullptr && std::atoi(e) == 0) ? 0 : STAT_NO_FEAS;
@@ -1019,6 +1020,23 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
     if ((rc = zero_counter(1))) return rc;
     if (ilqr_launch_loop(h->stream, ILK_FINISH_ITER, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
     if (al) {   // DualUpdate, PenaltyUpdate, refreshed gradients for the problems that asked (solver.cpp:470-489)
+      // (plan MFMA16, DPP forms: ONE pass over the constraint rows does the dual update, the gradients and the next sweep's
+      //  Hessians -- EXPAND_DUAL | EXPAND_NEXT -- and PenaltyUpdate's bookkeeping follows it)
+      const char* ed0 = std::getenv("ALTRO_HIP_EXPAND_DPP");
+      const char* ar0 = std::getenv("ALTRO_HIP_ALROWS_DPP");
+      const bool fused_end = !lane_plan && !(ed0 != nullptr && std::atoi(ed0) == 0) && !(ar0 != nullptr && std::atoi(ar0) == 0);
+      if (fused_end) {
+        h->expand_penalty_scaling = o.penalty_scaling; h->expand_penalty_max = o.penalty_max;
+        rc = ilqr_run(h, IK_EXPAND, false, true, 0, 0.0, EXPAND_GRADIENT | EXPAND_HESSIAN | EXPAND_NEXT | EXPAND_DUAL);
+        if (rc) return rc;
+        if (ilqr_launch_loop(h->stream, ILK_PENALTY_UPDATE, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
+        hessians_ready = true;
+        if ((rc = read_counters())) return rc;
+        ++sweeps;
+        if (counters[1] == 0) break;
+        running = counters[1];
+        continue;
+      }
       rc = ilqr_run(h, IK_DUAL, false, false, 0, 0.0);
       if (rc) return rc;
       if (ilqr_launch_loop(h->stream, ILK_PENALTY_UPDATE, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");

@@ -48,10 +48,7 @@ static int wave_launch(hipStream_t stream, int which, const IlqrWaveArgs<S>& a) 
       else if (sizeof(S) == 8 && a.mode == 1) hipLaunchKernelGGL((wave_merit2_mfma_kernel<S>), waves, b64, 0, stream, a);   // mode 1: asked for by altro_hip_ilqr_solve
       else hipLaunchKernelGGL((wave_merit2_kernel<S, false>), waves, b64, 0, stream, a);
       break;
-    case IK_SPEC_SELECT: {
-      const int64_t blocks = ((int64_t)a.batch * (a.N + 1) * 28 + 255) / 256;
-      hipLaunchKernelGGL(wave_spec_select_kernel<S>, dim3((unsigned)(blocks < 262144 ? blocks : 262144)), b256, 0, stream, a);
-    } break;
+    case IK_SPEC_SELECT: hipLaunchKernelGGL(wave_spec_select_kernel<S>, dim3(a.batch), b64, 0, stream, a); break;
     case IK_STATIONARITY:
       if (a.al.enabled && (a.mode & STAT_NO_FEAS)) {   // the residual here, the constraint rows four problems per wave
         hipLaunchKernelGGL(wave_stationarity_kernel<S>, waves, b64, 0, stream, a);

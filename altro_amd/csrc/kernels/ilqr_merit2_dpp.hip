@@ -593,7 +593,12 @@ __global__ __launch_bounds__(64) void wave_expand_dpp_kernel(IlqrWaveArgs<S> a) 
   // a row without a problem of its own (past the end of the batch, or one that is not taking part) shadows the wave's first
   // live row and stores nothing: the DPP blocks below need every lane switched on
   const bool in_batch = b_own < a.batch;
-  const bool on_g = in_batch && !(a.active && !a.active[b_own]);                    // stores the gradient
+  // EXPAND_DUAL: this launch is also the sweep's DualUpdate (wave_dual_update_dpp_kernel) and looks ahead of its PenaltyUpdate
+  // (ilqr_penalty_update_logic, which runs AFTER it): a problem whose sweep asked for the update (IlqrProb::dual) gets its
+  // projected duals stored, and its gradient / Hessians are formed from those and from the penalty the update will leave
+  const bool du = (a.mode & EXPAND_DUAL) != 0;
+  const int dual_own = (du && in_batch) ? a.prob[b_own].dual : 0;
+  const bool on_g = du ? dual_own != 0 : (in_batch && !(a.active && !a.active[b_own]));   // stores the gradient
   const bool on_h = (a.mode & EXPAND_NEXT) ? (in_batch && a.prob[b_own].running != 0) : on_g;   // stores the Hessian blocks
   const bool on = on_g || on_h;
   const unsigned long long onm = __ballot(on);
@@ -605,7 +610,10 @@ __global__ __launch_bounds__(64) void wave_expand_dpp_kernel(IlqrWaveArgs<S> a) 
   const S* cp = a.costp + ((size_t)k * a.batch + b) * MF_COSTP;
   const double w = j < 12 ? (double)c[j] : (terminal ? 0.0 : (double)c[12 + j]);      // x_j | u_(j-12)   (c[24 + j - 12])
   const double cq = (double)cp[j], cl = (double)cp[16 + j];
-  const double rho_est = a.prob[b].rho_est, rho = a.prob[b].rho;
+  const int dual = du ? a.prob[b].dual : 0;
+  const double rho_est0 = a.prob[b].rho_est, rho0 = a.prob[b].rho;
+  const double rho = (dual == 2) ? fmin(rho0 * a.penalty_scaling, a.penalty_max) : rho0;   // (what PenaltyUpdate will set)
+  const double rho_est = dual ? rho : rho_est0;
   int zshift;
   const AlKnot ALTRO_CONST_AS& kn = al_knot<S>(a.al, k, zshift);
   double tile[16];
@@ -634,7 +642,27 @@ __global__ __launch_bounds__(64) void wave_expand_dpp_kernel(IlqrWaveArgs<S> a) 
     md_chain16(sacc, w, cG);
     const double gi = rl ? (kn.g_per_problem[cidx] ? (double)a.al.g[kn.g_off[cidx] + (int64_t)jr * a.batch + b] : (double)a.al.g[kn.g_off[cidx] + jr]) : 0.0;
     const double val = sacc - gi;
-    const double zi = (double)a.al.z[(int64_t)(kn.z_off[cidx] + zshift + jr) * a.batch + b];
+    S* const zp_ = a.al.z + (int64_t)(kn.z_off[cidx] + zshift + jr) * a.batch + b;
+    double zi = (double)*zp_;
+    if (du) {   // DualUpdate (knotpoint_data.cpp:503-510): the projected dual, formed with the penalty in force, becomes the dual.
+                // (`du` and `cone` are the wave's; the problems' own `dual` flags only select at the end -- the cone's gathers are DPP)
+      const double ze0 = rl ? zi - rho_est0 * val : 0.0;
+      double znew = 0.0;
+      if (cone == CONE_EQUALITY) znew = ze0;
+      else if (cone == CONE_INEQUALITY) znew = fmin(0.0, ze0);
+      else {
+        double zev0[AL_MAXSOC], zpv0[AL_MAXSOC];
+        md_gather4(ze0, zev0);
+        soc_projection<double>(p, zev0, zpv0);
+#pragma unroll
+        for (int r = 0; r < AL_MAXSOC; ++r)
+          if (j == r) znew = zpv0[r];
+      }
+      if (dual != 0 && rl) {
+        if (on && on_g) *zp_ = (S)znew;
+        zi = (double)(S)znew;                      // (what a later pass would read back)
+      }
+    }
     const double ze = rl ? zi - rho_est * val : 0.0;
     double jv = 0.0;
     if (cone != CONE_SOC) {

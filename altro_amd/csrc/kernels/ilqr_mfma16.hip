@@ -242,19 +242,21 @@ __global__ void wave_accept_kernel(IlqrWaveArgs<S> a) {
   }
 }
 
-// Speculative backtracking: copy spare candidate trajectory spec_sel[b] - 1 over the candidate of problem b
+// Speculative backtracking: copy spare candidate trajectory spec_sel[b] - 1 over the candidate of problem b.  A wave per
+// problem: most rounds select a spare for few problems or none, and those waves leave after one load.
 template <typename S>
-__global__ void wave_spec_select_kernel(IlqrWaveArgs<S> a) {
-  const int64_t total = (int64_t)a.batch * (a.N + 1) * 28;
-  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-    const int e = (int)(t % 28);
-    const int64_t r = t / 28;
-    const int b = (int)(r % a.batch);
-    const int k = (int)(r / a.batch);
-    const int sl = a.spec_sel[b];
-    if (sl <= 0) continue;
-    const size_t off = (size_t)b * a.xuy_bs + (size_t)k * a.xuy_ks + e;
-    a.cand[off] = a.cand_spec[(size_t)(sl - 1) * a.spec_stride + off];
+__global__ __launch_bounds__(64) void wave_spec_select_kernel(IlqrWaveArgs<S> a) {
+  const int b = blockIdx.x;
+  if (b >= a.batch) return;
+  const int sl = a.spec_sel[b];
+  if (sl <= 0) return;
+  const int total = (a.N + 1) * 28;
+  const S* __restrict__ src = a.cand_spec + (size_t)(sl - 1) * a.spec_stride + (size_t)b * a.xuy_bs;
+  S* __restrict__ dst = a.cand + (size_t)b * a.xuy_bs;
+  for (int t = threadIdx.x; t < total; t += 64) {
+    const int k = t / 28, e = t - 28 * k;
+    const size_t off = (size_t)k * a.xuy_ks + e;
+    dst[off] = src[off];
   }
 }
 

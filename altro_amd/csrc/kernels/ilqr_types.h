@@ -69,7 +69,8 @@ struct IlqrArgs {
 constexpr int STAT_NO_FEAS = 32;   // IK_STATIONARITY / IK_DUAL on plan MFMA16: the constraint rows in the DPP form (ilqr_merit2_dpp.hip)
 enum { EXPAND_GRADIENT = 1, EXPAND_HESSIAN = 2, EXPAND_LDS = 16 /* plan MFMA16: wave_expand_kernel instead of the DPP form (A/B, tests) */,
        EXPAND_NEXT = 64 /* wave_expand_dpp_kernel at the end of a sweep: the gradient for the problems of the active mask (those whose
-                           duals changed), the cost Hessians of the NEXT sweep for every problem still running (IlqrProb::running) */ };
+                           duals changed), the cost Hessians of the NEXT sweep for every problem still running (IlqrProb::running) */,
+       EXPAND_DUAL = 128 /* ... and the sweep's DualUpdate in the same pass (IlqrProb::dual instead of the active mask) */ };
 
 struct IlqrLoopArgs {
   IlqrProb* prob;
@@ -133,6 +134,7 @@ struct IlqrWaveArgs {
   double alpha_const;
   AlTable<S> al;
   int mode;                                  // expand kernel: EXPAND_GRADIENT | EXPAND_HESSIAN; rollout kernel: ROLLOUT_INIT
+  double penalty_scaling = 10.0, penalty_max = 1e8;   // EXPAND_DUAL: PenaltyUpdate's parameters (solver_options.hpp:27-29)
   const int* skip = nullptr;                 // stationarity kernel: problems whose value wave_merit2_kernel already left
 };
 constexpr int ROLLOUT_INIT = 4;   // wave_rollout_kernel also writes the nominal record and the cost gradient (the head of
