@@ -31,10 +31,11 @@ static int wave_launch(hipStream_t stream, int which, const IlqrWaveArgs<S>& a) 
       else hipLaunchKernelGGL(wave_dual_update_kernel<S>, dim3((unsigned)((int64_t)a.batch * (a.N + 1))), b64, 0, stream, a);
       break;
     case IK_MERIT:
-      // the DPP form: two problems per wave, two trials per problem (kernels/ilqr_merit2_dpp.hip).  With constraint blocks
-      // and ONE trial per problem its second rows idle; on long horizons the LDS form (four waves per SIMD) is then the faster
-      // one -- C1 + input bounds as whole solves, cubic search: N = 48: 48.7 (DPP) vs 49.0 ms, N = 128: 72.2 vs 72.8, N = 256: 111.6 vs 108.9
-      if (a.mode == 3 || (a.mode == 2 && (a.spec_trials > 1 || !a.al.enabled || a.N <= 160))) {   // (3: forced, ALTRO_HIP_MERIT_DPP=2 -- tests)
+      // the DPP form: two problems per wave, two trials per problem (kernels/ilqr_merit2_dpp.hip).  (With constraint blocks and
+      // ONE trial per problem its second rows idle; while the constraint Jacobians came from global memory the LDS form won
+      // those rounds on long horizons.  With G in LDS and the duals fetched a step ahead the DPP form wins them too -- C1 + input
+      // bounds, cubic search, whole solves: N = 192: 69.7 vs 70.9 ms, N = 256: 105.2 vs 108.9.)
+      if (a.mode == 3 || a.mode == 2) {   // (3: ALTRO_HIP_MERIT_DPP=2, kept for the tests that force the form)
         const dim3 grid(mf_grid((a.batch + 1) / 2), ((a.spec_trials > 1 ? a.spec_trials : 1) + 1) / 2);
         if (a.al.enabled) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, true, false>), grid, b64, 0, stream, a);
         else hipLaunchKernelGGL((wave_merit_dpp_kernel<S, false, false>), grid, b64, 0, stream, a);
