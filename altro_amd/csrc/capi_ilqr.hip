@@ -914,7 +914,7 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
     // phi(0) -- phi, phi' and the trajectory go to spare row / buffer 0 -- and ILK_LS_BEGIN consumes it at once.
     bool refreshed = false;
     bool stat_needed = true;
-    bool pre = !dual && spec_all_on && !h->spec_no_memory && spec_waves(running, 2) * 2 <= spec_capacity * (lane_plan || !merit_rounds_dpp ? 2 : 1);
+    bool pre = !dual && spec_all_on && !h->spec_no_memory && spec_waves(running, 2) <= spec_capacity;
     if (pre && !ensure_spares(h, 1, spare_each)) {   // an optimisation only: carry on one step per launch
       h->spec_no_memory = true;
       pre = false;
@@ -975,7 +975,7 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
       // kernel consumes them in order, so every decision is the sequential one (kernels/ilqr_types.h).
       int trials = 1;
       if (spec_on && !h->spec_no_memory)
-        while (trials < trials_cap && spec_waves(counters[0], trials * 2) * 2 <= spec_capacity) trials *= 2;
+        while (trials < trials_cap && spec_waves(counters[0], trials * 2) <= spec_capacity) trials *= 2;   // as wide as leaves the launch within the capacity
       // plan MFMA16's rounds in the DPP form evaluate two trials per problem in the lanes one trial would leave idle
       // (kernels/ilqr_merit2_dpp.hip): the second step of the known sequence rides along whatever the occupancy
       if (spec_on && !lane_plan && !h->spec_no_memory && trials < 2 && merit_rounds_dpp) trials = 2;
