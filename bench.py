@@ -591,6 +591,28 @@ def main():
     # so that the quantities SolverImpl::Solve reports are all populated (for c4: the sweep's quantities only)
     stats = chan.reduce(bt)
 
+    # ... and, after the statistics (they describe the unconstrained solve), the same batch with input bounds |u| <= 2 as a whole
+    # AL-iLQR solve: constraint rows, dual and penalty updates, line searches past the first step -- the AL half of the path
+    # (SURVEY section 8 row f2), outside the timed region like the solve above
+    constrained = None
+    if not c4:
+        import altro_amd
+        Gb = np.zeros((2 * m, n + m)); Gb[:m, n:] = np.eye(m); Gb[m:, n:] = -np.eye(m)
+        bt.add_linear_constraint(0, N - 1, altro_amd.CONE_INEQUALITY, Gb, np.full(2 * m, 2.0))
+        for timed in (False, True):
+            bt.set_input_guess(np.zeros((1, 1, m)), k_stride_zero=True, batch_stride_zero=True)
+            bt.reset_duals(1.0)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            resc = bt.ilqr_solve(iterations_max=40)
+            torch.cuda.synchronize()
+            t_con = time.perf_counter() - t1
+        constrained = {"seconds": t_con, "sweeps": int(resc["sweeps"]), "merit_launches": int(resc["merit_launches"]),
+                       "converged": int((resc["status"] == 0).sum()), "dual_updates_max": int(resc["dual_updates"].max()),
+                       "max_feasibility": float(np.abs(resc["feasibility"]).max()),
+                       "what": "the C1 batch with input bounds |u| <= 2 (an INEQUALITY block at every k < N) as one altro_hip_ilqr_solve: "
+                               "AL-iLQR, cubic line search, iterations_max 40 (host clock, second of two solves)"}
+
     if rank == 0:
         total_problems = global_batch
         sweeps_per_s = total_problems * args.steps / elapsed
@@ -628,6 +650,7 @@ def main():
                 "stats": stats,
                 "ilqr_full_solve": full_solve,
                 "ilqr_sweep": ilqr_sweep,
+                "ilqr_constrained_solve": constrained,
             },
             "roofline": roofline_block(("c4pure" if args.c4_pure else "c4mixed") if c4 else "c1", batch, N, name_b, bytes_b, dur_b),
             "roofline_forward": roofline_block(("c4pure" if args.c4_pure else "c4mixed") if c4 else "c1", batch, N, name_f,
