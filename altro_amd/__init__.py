@@ -32,7 +32,8 @@ C_ABI_SYMBOLS = [
     "altro_hip_comm_destroy", "altro_hip_comm_rank", "altro_hip_comm_world", "altro_hip_comm_device", "altro_hip_stats_allreduce", "altro_hip_stats_allreduce_multi",
     "altro_hip_profile_enable", "altro_hip_profile_reset",
     "altro_hip_profile_get", "altro_hip_profile_get_range", "altro_hip_profile_dropped", "altro_hip_algorithmic_bytes",
-    "altro_hip_set_model", "altro_hip_set_model_source", "altro_hip_set_tracking_cost", "altro_hip_set_input_guess",
+    "altro_hip_set_model", "altro_hip_set_model_source", "altro_hip_set_tracking_cost", "altro_hip_set_quadratic_cost",
+    "altro_hip_set_input_guess",
     "altro_hip_open_loop_rollout", "altro_hip_accept", "altro_hip_expand", "altro_hip_merit",
     "altro_hip_stationarity", "altro_hip_get_nominal", "altro_hip_get_expansion",
     "altro_hip_default_solve_options", "altro_hip_ilqr_solve", "altro_hip_last_solve_counts",
@@ -163,6 +164,7 @@ def lib():
         L.altro_hip_set_model.argtypes = [vp, i, C.c_float, i, d, d]
         L.altro_hip_set_model_source.argtypes = [vp, C.c_char_p, C.c_float]
         L.altro_hip_set_tracking_cost.argtypes = [vp, vp, vp, vp, vp, i, i]
+        L.altro_hip_set_quadratic_cost.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i]
         L.altro_hip_set_input_guess.argtypes = [vp, vp, i, i]
         for fn in ("open_loop_rollout", "accept", "expand"):
             getattr(L, "altro_hip_" + fn).argtypes = [vp]
@@ -321,6 +323,14 @@ class Batch:
         keep = [_in(v) for v in (Qd, Rd, xref, uref)]
         _check(self.L.altro_hip_set_tracking_cost(self.h, *[k[1] for k in keep], int(k_stride_zero),
                                                   int(batch_stride_zero)))
+
+    def set_quadratic_cost(self, Q, R, H, q, r, c=None, k_stride_zero=False, batch_stride_zero=False):
+        """ALTROSolver::SetQuadraticCost for the device iLQR loop: Q [.][N+1][n*n], R [.][N][m*m], H [.][N][m*n] column-major
+        blocks, q [.][N+1][n], r [.][N][m], c [.][N+1] (None: zero); k_stride_zero: {running, terminal} / one knot point."""
+        keep = [_in(v) for v in (Q, R, H, q, r)]
+        kc = _in(c) if c is not None else (None, None)
+        _check(self.L.altro_hip_set_quadratic_cost(self.h, *[k[1] for k in keep], kc[1], int(k_stride_zero),
+                                                   int(batch_stride_zero)))
 
     def set_input_guess(self, u, k_stride_zero=False, batch_stride_zero=False):
         a, pa = _in(u)

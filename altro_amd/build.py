@@ -3,6 +3,7 @@
     python -m altro_amd.build [--force]
 """
 import os
+import re
 import subprocess
 import sys
 
@@ -44,8 +45,18 @@ def build(force=False, verbose=False):
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result",
              "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
-    def fresh(obj, dep):
-        """An object is reused when neither its source nor any header its last compile read (-MMD) is newer."""
+    def embedded(src):
+        """Files a unit pulls in with .incbin (ALTRO_EMBED in capi_rtc.hip: the sources handed to hiprtc).  The assembler
+        reads them, not the preprocessor, so -MMD never lists them: they are dependencies all the same."""
+        try:
+            text = open(src).read()
+        except OSError:
+            return []
+        return [os.path.join(CSRC, m) for m in re.findall(r'^ALTRO_EMBED\(\s*\w+\s*,\s*"([^"]+)"\s*\)', text, re.M)]
+
+    def fresh(src, obj, dep):
+        """An object is reused when neither its source, nor any header its last compile read (-MMD), nor any file it
+        embeds with .incbin is newer."""
         if force or not (os.path.exists(obj) and os.path.exists(dep)):
             return False
         t = os.path.getmtime(obj)
@@ -53,14 +64,14 @@ def build(force=False, verbose=False):
             words = open(dep).read().replace("\\\n", " ").split()
         except OSError:
             return False
-        files = [w for w in words[1:] if not w.endswith(":")]
+        files = [w for w in words[1:] if not w.endswith(":")] + embedded(src)
         return all(os.path.exists(f) and os.path.getmtime(f) <= t for f in files) and bool(files)
 
     def compile_one(src):
         # object names follow the path below csrc/ (host/x.cpp and x.hip must not collide)
         obj = os.path.join(objdir, os.path.splitext(os.path.relpath(src, CSRC))[0].replace(os.sep, "__") + ".o")
         dep = obj[:-2] + ".d"
-        if fresh(obj, dep):
+        if fresh(src, obj, dep):
             return obj
         cmd = [hipcc] + flags + ["-MMD", "-MF", dep, "-c", src, "-o", obj]
         if verbose:

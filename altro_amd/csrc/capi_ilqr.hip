@@ -113,7 +113,8 @@ IlqrArgs<T> ilqr_args(altro_hip_batch* h, bool use_alpha, bool use_active, int w
   a.al.uniform = h->al_uniform; a.al.rows_per_knot = h->al_rows_per_knot; a.al.N = h->N; a.al.G_count = h->al_G_count;
   a.mode = EXPAND_GRADIENT | EXPAND_HESSIAN;
   a.in = (T*)h->l_in; a.term = (T*)h->l_term; a.out = (const T*)h->l_out; a.outn = (const T*)h->l_outn;
-  a.nom = (T*)h->l_nom; a.cand = (T*)h->l_xuy; a.cost = (const T*)h->l_cost; a.x0 = (const T*)h->l_x0;
+  a.nom = (T*)h->l_nom; a.cand = (T*)h->l_xuy; a.x0 = (const T*)h->l_x0;
+  a.cost = (const T*)(h->cost_dense ? h->l_costq : h->l_cost); a.cost_kind = h->cost_dense ? 1 : 0;
   a.alpha = use_alpha ? h->i_alpha : nullptr;
   a.active = use_active ? h->i_active : nullptr;
   a.phi = h->i_phi; a.dphi = h->i_dphi; a.prob = h->i_prob;
@@ -186,8 +187,9 @@ int wave_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int
   }
   if (which == IK_EXPAND) {
     const char* e = std::getenv("ALTRO_HIP_EXPAND_DPP");
-    if (e != nullptr && std::atoi(e) == 0) a.mode |= EXPAND_LDS;
+    if (e != nullptr && std::atoi(e) == 0 && !h->cost_dense) a.mode |= EXPAND_LDS;   // (the dense cost lives in the row-layout kernels only)
   }
+  a.costd = (const S*)h->m_costd; a.costd_term = (const S*)h->m_costd_term; a.cost_dense = h->cost_dense ? 1 : 0;
   if (which == IK_MERIT) {   // a line-search round: the DPP form of the merit evaluation unless ALTRO_HIP_MERIT_DPP=0 keeps the LDS form
     const char* e = std::getenv("ALTRO_HIP_MERIT_DPP");
     a.mode = e == nullptr ? 2 : std::atoi(e) == 0 ? 0 : std::atoi(e) == 2 ? 3 : 2;   // (2: the DPP form whatever the launcher's rule)
@@ -240,7 +242,7 @@ int ilqr_check(altro_hip_batch* h, bool need_guess) {
     return fail(ALTRO_HIP_ERR_NOT_SET, "altro_hip_set_model has not been called (plan LANE runs device models; for dynamics given as "
                                        "data -- altro_hip_set_dynamics -- create the handle with ALTRO_HIP_PLAN_MFMA16)");
   }
-  if (!h->lqr_cost_set) return fail(ALTRO_HIP_ERR_NOT_SET, "altro_hip_set_tracking_cost has not been called");
+  if (!h->lqr_cost_set) return fail(ALTRO_HIP_ERR_NOT_SET, "neither altro_hip_set_tracking_cost nor altro_hip_set_quadratic_cost has been called");
   if (!h->x0_set) return fail(ALTRO_HIP_ERR_NOT_SET, "altro_hip_set_initial_state has not been called");
   if (need_guess && !h->guess_set) return fail(ALTRO_HIP_ERR_NOT_SET, "altro_hip_set_input_guess has not been called");
   return 0;
@@ -347,7 +349,7 @@ int altro_hip_set_tracking_cost(altro_hip_batch* h, const double* Qd, const doub
     if (!rc) rc = put_term(Qd, n, 0);
     if (!rc) rc = put_term(q.data(), n, 16);
     if (!rc) rc = put_term(c.data(), 1, 32);
-    if (!rc) { h->lqr_cost_set = true; h->ilqr_linear = true; }
+    if (!rc) { h->lqr_cost_set = true; h->ilqr_linear = true; h->cost_dense = false; }
     return rc;
   }
   auto pk = [&](const double* src, int len, int off, int nk, int k_src0, int nk_host, int src_off) -> int {
@@ -369,7 +371,110 @@ int altro_hip_set_tracking_cost(altro_hip_batch* h, const double* Qd, const doub
   if (!rc) rc = pk_term(Qd, n, 0, nkx);
   if (!rc) rc = pk_term(q.data(), n, n + m, nkx);
   if (!rc) rc = pk_term(c.data(), 1, 2 * n + 2 * m, nkx);
-  if (!rc) { h->lqr_cost_set = true; h->cost_set = true; h->dyn_set = true; h->is_diag = 0; h->has_f = 0; }
+  if (!rc) { h->lqr_cost_set = true; h->cost_set = true; h->dyn_set = true; h->is_diag = 0; h->has_f = 0; h->cost_dense = false; }
+  return rc;
+}
+
+int altro_hip_set_quadratic_cost(altro_hip_batch* h, const double* Q, const double* R, const double* H, const double* q,
+                                 const double* r, const double* c, int kz, int bz) {
+  // ALTROSolver::SetQuadraticCost (altro_solver.cpp:118-136) -> KnotPointData::SetQuadraticCost (knotpoint_data.cpp:64-85) for the
+  // device iLQR loop: the cost 1/2 x'Qx + 1/2 u'Ru + u'Hx + q'x + r'u + c per knot point, stored dense and evaluated as
+  // CalcOriginalCost / Gradient / Hessian do (knotpoint_data.cpp:624-634, :659-668, :691-698).
+  int rc = check(h);
+  if (rc) return rc;
+  if (h->plan != ALTRO_HIP_PLAN_LANE && h->plan != ALTRO_HIP_PLAN_MFMA16)
+    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "the device iLQR loop (and its costs) needs plan LANE or MFMA16");
+  if (!Q || !R || !H || !q || !r) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "Q, R, H, q, r are required (c may be NULL: zero)");
+  const int n = h->n, m = h->m, N = h->N;
+  const int nkx = kz ? 2 : N + 1, nku = kz ? 1 : N;
+  const size_t Ez = h->esz;
+  const int64_t B = h->batch;
+  if (h->plan == ALTRO_HIP_PLAN_MFMA16) {
+    // (a) the backward sweep's blocks: lxx = Q, luu = R, lux = H; lx, lu are refreshed by the loop
+    rc = altro_hip_set_cost(h, Q, R, H, q, r, 0, kz, bz);
+    if (rc) return rc;
+    // (b) the cost's own record, in the COST / TERM layout, for the merit function and the expansion
+    if (!h->m_costd) {
+      if ((rc = dmalloc(h, &h->m_costd, (size_t)B * (N + 1) * MF_COST * Ez))) return rc;
+      if ((rc = dmalloc(h, &h->m_costd_term, (size_t)B * MF_TERM * Ez))) return rc;
+      HIP_TRY(hipMemsetAsync(h->m_costd, 0, (size_t)B * (N + 1) * MF_COST * Ez, h->stream));
+      HIP_TRY(hipMemsetAsync(h->m_costd_term, 0, (size_t)B * MF_TERM * Ez, h->stream));
+    }
+    if (!h->m_nom) {
+      if ((rc = dmalloc(h, &h->m_nom, (size_t)B * (N + 1) * MF_NOM * Ez))) return rc;
+      HIP_TRY(hipMemsetAsync(h->m_nom, 0, (size_t)B * (N + 1) * MF_NOM * Ez, h->stream));
+    }
+    {
+      Dims d{n, m};
+      DevSrc dQ, dR, dH, dq, dr;
+      rc = put_src(h, Q, d.Q(0), nkx, kz, bz, &dQ);
+      if (!rc) rc = put_src(h, R, d.R(0), nku, kz, bz, &dR);
+      if (!rc) rc = put_src(h, H, d.H(), nku, kz, bz, &dH);
+      if (!rc) rc = put_src(h, q, n, nkx, kz, bz, &dq);
+      if (!rc) rc = put_src(h, r, m, nku, kz, bz, &dr);
+      SrcArr none{nullptr, 0, 0, 0};
+      SrcArr tQ = dQ.s, tq = dq.s;   // terminal views: knot point N, or block 1 of the {running, terminal} pair
+      if (kz) { tQ.p += d.Q(0); tq.p += n; }
+      if (!rc) rc = mfma16_pack_launch(h, MSEG_Q, dQ.s, none, h->m_costd, h->m_costd_term, 0);
+      if (!rc) rc = mfma16_pack_launch(h, MSEG_TERM_Q, tQ, none, h->m_costd, h->m_costd_term, 0);
+      if (!rc) rc = mfma16_pack_launch(h, MSEG_HR, dH.s, dR.s, h->m_costd, h->m_costd_term, 0);
+      if (!rc) rc = mfma16_pack_launch(h, MSEG_QR, dq.s, dr.s, h->m_costd, h->m_costd_term, 0);
+      if (!rc) rc = mfma16_pack_launch(h, MSEG_TERM_q, tq, none, h->m_costd, h->m_costd_term, 0);
+      if (!rc) HIP_TRY(hipStreamSynchronize(h->stream));   // (the sources are freed on leaving this block)
+    }
+    if (!rc && c) {   // c_k into the record's spare slot, k = 0 .. N (record N holds nothing else)
+      auto putc = [&](int k0, int nk, int src_off) -> int {
+        if (h->dtype == ALTRO_HIP_F64)
+          return aos_set<double>(h, (double*)h->m_costd + (size_t)k0 * B * MF_COST + MF_COSTD_C, MF_COST, B * MF_COST, c, 1, nk, kz, bz, nkx, src_off);
+        return aos_set<float>(h, (float*)h->m_costd + (size_t)k0 * B * MF_COST + MF_COSTD_C, MF_COST, B * MF_COST, c, 1, nk, kz, bz, nkx, src_off);
+      };
+      rc = putc(0, N, 0);
+      if (!rc) {   // record N: element N of a full host array, or the second entry of a {running, terminal} pair
+        if (h->dtype == ALTRO_HIP_F64)
+          rc = aos_set<double>(h, (double*)h->m_costd + (size_t)N * B * MF_COST + MF_COSTD_C, MF_COST, B * MF_COST, c, 1, 1, 1, bz, nkx, kz ? 1 : N);
+        else
+          rc = aos_set<float>(h, (float*)h->m_costd + (size_t)N * B * MF_COST + MF_COSTD_C, MF_COST, B * MF_COST, c, 1, 1, 1, bz, nkx, kz ? 1 : N);
+      }
+    } else if (!rc) {   // c == NULL: zero (a handle that carried another cost before)
+      const double zero = 0.0;
+      struct HostPtrs { altro_hip_batch* h; bool keep; ~HostPtrs() { h->dev_ptrs = keep; } } host_ptrs{h, h->dev_ptrs};
+      h->dev_ptrs = false;   // (`zero` lives on the host whatever the caller's pointer mode)
+      rc = h->dtype == ALTRO_HIP_F64
+               ? aos_set<double>(h, (double*)h->m_costd + MF_COSTD_C, MF_COST, B * MF_COST, &zero, 1, N + 1, 1, 1, 1, 0)
+               : aos_set<float>(h, (float*)h->m_costd + MF_COSTD_C, MF_COST, B * MF_COST, &zero, 1, N + 1, 1, 1, 1, 0);
+    }
+    if (!rc) { h->lqr_cost_set = true; h->ilqr_linear = true; h->cost_dense = true; }
+    return rc;
+  }
+  // plan LANE: [k][Q n n | R m m | H m n | q n | r m | c][batch], column-major blocks as given (IlqrDims<n, m, 1>)
+  const int E = n * n + m * m + m * n + n + m + 1;
+  const int oR = n * n, oH = oR + m * m, oq = oH + m * n, or_ = oq + n, oc = or_ + m;
+  if ((uint64_t)B * (uint64_t)E * Ez >= (1ull << 31))
+    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "plan LANE: batch %d too large for one handle (dense cost rows exceed 2 GiB)", h->batch);
+  if (!h->l_costq) {
+    if ((rc = dmalloc(h, &h->l_costq, (size_t)B * (N + 1) * E * Ez))) return rc;
+    HIP_TRY(hipMemsetAsync(h->l_costq, 0, (size_t)B * (N + 1) * E * Ez, h->stream));
+  }
+  auto pk = [&](const double* src, int len, int off, int nk_host) -> int {   // knot points 0 .. N - 1  (src == NULL: zeros)
+    return h->dtype == ALTRO_HIP_F64 ? lane_pack<double>(h, (double*)h->l_costq, E, src, len, off, 0, N, 0, nk_host, kz, bz, 0)
+                                     : lane_pack<float>(h, (float*)h->l_costq, E, src, len, off, 0, N, 0, nk_host, kz, bz, 0);
+  };
+  auto pk_term = [&](const double* src, int len, int off) -> int {           // record N
+    const size_t base = (size_t)N * E * h->batch;
+    return h->dtype == ALTRO_HIP_F64
+               ? lane_pack<double>(h, (double*)h->l_costq + base, E, src, len, off, 0, 1, kz ? 0 : N, nkx, kz, bz, kz ? len : 0)
+               : lane_pack<float>(h, (float*)h->l_costq + base, E, src, len, off, 0, 1, kz ? 0 : N, nkx, kz, bz, kz ? len : 0);
+  };
+  rc = pk(Q, n * n, 0, nkx);
+  if (!rc) rc = pk(R, m * m, oR, nku);
+  if (!rc) rc = pk(H, m * n, oH, nku);
+  if (!rc) rc = pk(q, n, oq, nkx);
+  if (!rc) rc = pk(r, m, or_, nku);
+  if (!rc) rc = pk(c, 1, oc, nkx);
+  if (!rc) rc = pk_term(Q, n * n, 0);
+  if (!rc) rc = pk_term(q, n, oq);
+  if (!rc) rc = pk_term(c, 1, oc);
+  if (!rc) { h->lqr_cost_set = true; h->cost_set = true; h->dyn_set = true; h->is_diag = 0; h->has_f = 0; h->cost_dense = true; }
   return rc;
 }
 
@@ -475,6 +580,23 @@ int altro_hip_update_linear_costs(altro_hip_batch* h, const double* q, const dou
     return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "cannot update linear input costs at the terminal knot point "
                                             "(ErrorCodes::InvalidOptAtTerminalKnotPoint)");
   const int nk = k_last - k_first + 1;
+  if (h->plan == ALTRO_HIP_PLAN_MFMA16 && h->cost_dense) {
+    // the dense cost's record: [q r] at MF_OFF_QR, c in the spare slot; the terminal knot point's q_N lives in costd_term
+    const int64_t B = h->batch;
+    const int nkr = k_last == N ? nk - 1 : nk;    // running knot points in the range
+    auto put = [&](void* base, int64_t bs, int64_t ks, const double* src, int len, int nkp, int src_off) -> int {
+      if (!src || nkp <= 0) return 0;
+      if (h->dtype == ALTRO_HIP_F64) return aos_set<double>(h, (double*)base, bs, ks, src, len, nkp, kz, bz, kz ? 1 : nk, src_off);
+      return aos_set<float>(h, (float*)base, bs, ks, src, len, nkp, kz, bz, kz ? 1 : nk, src_off);
+    };
+    char* cd = (char*)h->m_costd + (size_t)k_first * B * MF_COST * h->esz;
+    rc = put(cd + (size_t)MF_OFF_QR * h->esz, MF_COST, B * MF_COST, q, n, nkr, 0);
+    if (!rc) rc = put(cd + (size_t)(MF_OFF_QR + 12) * h->esz, MF_COST, B * MF_COST, r, m, nkr, 0);
+    if (!rc) rc = put(cd + (size_t)MF_COSTD_C * h->esz, MF_COST, B * MF_COST, c, 1, nk, 0);
+    if (!rc && k_last == N)   // q_N: the last knot point of the host range (or the one shared entry)
+      rc = put((char*)h->m_costd_term + (size_t)144 * h->esz, MF_TERM, 0, q, n, 1, kz ? 0 : (nk - 1) * n);
+    return rc;
+  }
   if (h->plan == ALTRO_HIP_PLAN_MFMA16) {
     const int64_t B = h->batch;
     auto put = [&](const double* src, int len, int off) -> int {
@@ -490,17 +612,20 @@ int altro_hip_update_linear_costs(altro_hip_batch* h, const double* q, const dou
     if (!rc) rc = put(c, 1, 32);
     return rc;
   }
-  const int E = 2 * n + 2 * m + 1;
+  const bool dense = h->cost_dense;
+  const int E = dense ? n * n + m * m + m * n + n + m + 1 : 2 * n + 2 * m + 1;
+  const int oq = dense ? n * n + m * m + m * n : n + m;
+  void* cost = dense ? h->l_costq : h->l_cost;
   const size_t base = (size_t)k_first * E * h->batch;
   auto pk = [&](const double* src, int len, int off) -> int {
     if (!src) return 0;
     return h->dtype == ALTRO_HIP_F64
-               ? lane_pack<double>(h, (double*)h->l_cost + base, E, src, len, off, 0, nk, 0, kz ? 1 : nk, kz, bz)
-               : lane_pack<float>(h, (float*)h->l_cost + base, E, src, len, off, 0, nk, 0, kz ? 1 : nk, kz, bz);
+               ? lane_pack<double>(h, (double*)cost + base, E, src, len, off, 0, nk, 0, kz ? 1 : nk, kz, bz)
+               : lane_pack<float>(h, (float*)cost + base, E, src, len, off, 0, nk, 0, kz ? 1 : nk, kz, bz);
   };
-  rc = pk(q, n, n + m);
-  if (!rc) rc = pk(r, m, 2 * n + m);
-  if (!rc) rc = pk(c, 1, 2 * n + 2 * m);
+  rc = pk(q, n, oq);
+  if (!rc) rc = pk(r, m, oq + n);
+  if (!rc) rc = pk(c, 1, oq + n + m);
   return rc;
 }
 int altro_hip_get_knot(altro_hip_batch* h, int k, double* x, double* u) {
@@ -740,7 +865,8 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
   //  is a property of the launch-sequenced kernels only)
   if (lane_plan) merit_split_prepare(h);
   bool fused_can = lane_plan && o.iterations_max > 0 && !h->spec_no_memory && h->merit_split == 1 &&
-                   !(h->flags & ALTRO_HIP_LANE_FUSED) && h->model.kind != MODEL_USER;   // (run-time models: sequenced loop)
+                   !(h->flags & ALTRO_HIP_LANE_FUSED) && h->model.kind != MODEL_USER &&   // (run-time models: sequenced loop)
+                   !h->cost_dense;   // (the one-launch kernel is instantiated for the diagonal cost: a dense one runs sequenced)
   // POLICY: fused wherever the kernel exists.  Measured on MI355X (tools/solve_batches.py, profiles/r02p_solve_batches.txt;
   // bicycle + steering bound, N = 50, median wall ms fused / sequenced): backtracking search 5.5 / 7.4 at 256 problems,
   // 20 / 31 at 2048, 24 / 44 at 8192, 76 / 173 at 65536; cubic search 25 / 33, 28 / 61, 36 / 106, 99 / 316; pendulum, 8192
@@ -779,7 +905,7 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
   if (const char* e = std::getenv("ALTRO_HIP_MERIT2")) dual = dual && std::atoi(e) != 0;
   if (!fused_prologue) {
     if (ilqr_launch_loop(h->stream, ILK_LOOP_INIT, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
-    if (dual && !al) {
+    if (dual && !al && !h->cost_dense) {   // (ROLLOUT_INIT forms the diagonal cost's gradient)
       rc = ilqr_run(h, IK_ROLLOUT, false, false, 0, 0.0, ROLLOUT_INIT);
     } else {
       rc = ilqr_run(h, IK_ROLLOUT, false, false, 0, 0.0);
@@ -802,7 +928,7 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
     return lane_plan ? (h->batch + 63) / 64 : searching;   // LANE: the searching lanes are scattered over all waves
   };
   const char* mrd = std::getenv("ALTRO_HIP_MERIT_DPP");
-  const bool merit_rounds_dpp = mrd == nullptr || std::atoi(mrd) != 0;
+  const bool merit_rounds_dpp = mrd == nullptr || std::atoi(mrd) != 0 || h->cost_dense;   // (a dense cost: row-layout kernels only)
   // wavefronts a round of `trials` steps per searching problem launches: a wave per (problem, trial) in the LDS form, a wave per
   // two problems and two trials in the DPP form (which keeps two waves per SIMD, not four: see the capacity below)
   auto spec_waves = [&](int searching, int trials) -> int64_t {

@@ -83,6 +83,8 @@ struct altro_hip_batch {
   bool async_request = false, async_pending = false;
   bool rtc_has_constraints = false;   // ... whose source also defines altro_user_constraint / _jacobian
   void* rtc = nullptr;            // run-time compiled model (capi_rtc.hip: RtcModule, shared through a per-process cache)
+  std::string rtc_source;         // ... its source, and the cost kind (IlqrArgs::cost_kind) its cost-reading kernels were instantiated for
+  int rtc_ck = 0;
   int x0_stride = 0;              // elements between two problems' x0 on the device (12 on plan MFMA16, else n)
   int spare_count = 0;            // spare candidate trajectories i_cand_spec holds (sized to the path in use, see spec_trials_cap)
   int *i_spec_sel = nullptr, *i_spec_refresh = nullptr;
@@ -119,6 +121,11 @@ struct altro_hip_batch {
   // altro_hip_set_tracking_cost; ilqr_linear = the backward sweep ignores the affine term (knotpoint_data.cpp:416)
   void *m_nom = nullptr, *m_costp = nullptr;
   bool ilqr_linear = false;
+  // the dense quadratic cost of altro_hip_set_quadratic_cost (ALTROSolver::SetQuadraticCost): plan MFMA16 keeps the cost's own
+  // blocks in COST-record layout next to the records the loop rewrites (IlqrWaveArgs::costd / costd_term); plan LANE keeps
+  // Q | R | H | q | r | c records in l_costq (IlqrArgs::cost with cost_kind = 1)
+  void *m_costd = nullptr, *m_costd_term = nullptr, *l_costq = nullptr;
+  bool cost_dense = false;
   double* i_reg = nullptr;
   // staging for host <-> device conversion (grown lazily, never inside the hot path)
   void* stage = nullptr;
@@ -354,14 +361,20 @@ inline int put_src(altro_hip_batch* h, const double* src, int blk, int nk_host, 
   out->s = SrcArr{(const double*)out->dev, b_zero ? 0 : (int64_t)per_b, k_zero ? 0 : (int64_t)blk, tiled};
   return 0;
 }
-inline int mfma16_pack_launch(altro_hip_batch* h, int seg, SrcArr s0, SrcArr s1) {
+// (cin / term: the COST and TERM records to fill -- the handle's own, or the dense cost's copies m_costd / m_costd_term, which
+//  have the same layout and strides)
+inline int mfma16_pack_launch(altro_hip_batch* h, int seg, SrcArr s0, SrcArr s1, void* cin = nullptr, void* term = nullptr,
+                              int is_diag = -1) {
   const int64_t total = (int64_t)h->batch * h->N * 192;
+  if (!cin) cin = h->m_cin;
+  if (!term) term = h->m_term;
+  if (is_diag < 0) is_diag = h->is_diag;
   if (h->dtype == ALTRO_HIP_F64)
     hipLaunchKernelGGL(mfma16_pack_kernel<double>, dim3(grid_for(total)), dim3(256), 0, h->stream, (double*)h->m_in,
-                       (double*)h->m_cin, (double*)h->m_term, h->m_st, seg, s0, s1, h->is_diag, h->N, 0, h->batch, h->n, h->m);
+                       (double*)cin, (double*)term, h->m_st, seg, s0, s1, is_diag, h->N, 0, h->batch, h->n, h->m);
   else
     hipLaunchKernelGGL(mfma16_pack_kernel<float>, dim3(grid_for(total)), dim3(256), 0, h->stream, (float*)h->m_in,
-                       (float*)h->m_cin, (float*)h->m_term, h->m_st, seg, s0, s1, h->is_diag, h->N, 0, h->batch, h->n, h->m);
+                       (float*)cin, (float*)term, h->m_st, seg, s0, s1, is_diag, h->N, 0, h->batch, h->n, h->m);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "mfma16_pack launch: %s", hipGetErrorString(e));
   return 0;

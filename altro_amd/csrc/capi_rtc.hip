@@ -11,6 +11,8 @@
 // fused kernel is not compiled at run time: it is the library's longest compile).
 #include "capi_internal.h"
 
+#include <cctype>
+
 #include <dlfcn.h>
 #include <hip/hiprtc.h>
 
@@ -105,11 +107,32 @@ const char* const kKernelExpr[RTC_NUM] = {
     "altro_hip::ilqr_shift_kernel<%d, %d, %s>",
 };
 
-std::string kernel_expr(int which, int n, int m, const char* T) {
+// ck: IlqrArgs::cost_kind -- the kernels that read the cost record take it as their last template argument (kernels/ilqr_lane.hip)
+std::string kernel_expr(int which, int n, int m, const char* T, int ck) {
   char buf[256];
   if (which == RTC_ZERO_RESIDUALS) std::snprintf(buf, sizeof(buf), kKernelExpr[which], T);
   else std::snprintf(buf, sizeof(buf), kKernelExpr[which], n, m, T);
-  return buf;
+  std::string e = buf;
+  if (ck && (which == RTC_EXPAND || which == RTC_MERIT || which == RTC_MERIT_POINT)) e.insert(e.size() - 1, ", " + std::to_string(ck));
+  return e;
+}
+// does `src` define a function of this name?  (the identifier followed by an opening parenthesis, outside // comments)
+bool defines_function(const std::string& src, const char* name) {
+  const size_t len = std::strlen(name);
+  for (size_t p = src.find(name); p != std::string::npos; p = src.find(name, p + 1)) {
+    if (p > 0 && (std::isalnum((unsigned char)src[p - 1]) || src[p - 1] == '_')) continue;
+    size_t q = p + len;
+    while (q < src.size() && std::isspace((unsigned char)src[q])) ++q;
+    if (q >= src.size() || src[q] != '(') continue;
+    const size_t line = src.rfind('\n', p);
+    const size_t cmt = src.rfind("//", p);
+    if (cmt != std::string::npos && (line == std::string::npos || cmt > line)) continue;   // inside a line comment
+    return true;
+  }
+  return false;
+}
+bool source_has_constraints(const std::string& src) {
+  return defines_function(src, "altro_user_constraint") && defines_function(src, "altro_user_constraint_jacobian");
 }
 
 }  // namespace
@@ -124,12 +147,12 @@ struct RtcModule {
 };
 
 // Compile (or fetch) the module for (source, n, m, dtype) on the handle's device; nullptr + last_error on failure.
-static int rtc_module_for(altro_hip_batch* h, const std::string& user_src, RtcModule** out) {
+static int rtc_module_for(altro_hip_batch* h, const std::string& user_src, int ck, RtcModule** out) {
   *out = nullptr;
   static std::mutex mu;
   static std::map<std::string, RtcModule*> cache;
   const char* T = h->dtype == ALTRO_HIP_F64 ? "double" : "float";
-  const std::string key = std::to_string(h->device) + "|" + std::to_string(h->n) + "|" + std::to_string(h->m) + "|" + T + "|" + user_src;
+  const std::string key = std::to_string(h->device) + "|" + std::to_string(h->n) + "|" + std::to_string(h->m) + "|" + T + "|" + std::to_string(ck) + "|" + user_src;
   std::lock_guard<std::mutex> lock(mu);
   auto it = cache.find(key);
   if (it != cache.end()) { *out = it->second; return 0; }
@@ -139,11 +162,11 @@ static int rtc_module_for(altro_hip_batch* h, const std::string& user_src, RtcMo
   // the unit: the caller's two templates under contract(on) (like every device function the solve paths share), the
   // library's kernels, and explicit instantiations of the ones this shape needs
   std::string src = "#define ALTRO_HIP_USER_MODEL 1\n";
-  if (user_src.find("altro_user_constraint_jacobian") != std::string::npos) src += "#define ALTRO_HIP_USER_CONSTRAINTS 1\n";
+  if (source_has_constraints(user_src)) src += "#define ALTRO_HIP_USER_CONSTRAINTS 1\n";
   src += "#include \"rtc_compat.h\"\n#include \"fp_contract.h\"\nALTRO_FP_REGION_ON\n";
   src += "#line 1 \"user_model\"\n" + user_src + "\nALTRO_FP_REGION_END\n#include \"kernels/ilqr_lane.hip\"\nnamespace altro_hip {\n";
   for (int w = 0; w < RTC_NUM; ++w) {
-    std::string e = kernel_expr(w, h->n, h->m, T);
+    std::string e = kernel_expr(w, h->n, h->m, T, ck);
     e.erase(0, std::strlen("altro_hip::"));
     for (size_t p; (p = e.find("altro_hip::")) != std::string::npos;) e.erase(p, std::strlen("altro_hip::"));
     src += "template __global__ void " + e + "(IlqrArgs<" + T + ">);\n";
@@ -160,7 +183,7 @@ static int rtc_module_for(altro_hip_batch* h, const std::string& user_src, RtcMo
   if (rr != HIPRTC_SUCCESS) return fail(ALTRO_HIP_ERR_HIP, "hiprtcCreateProgram: %s", R->GetErrorString(rr));
   std::vector<std::string> exprs;
   for (int w = 0; w < RTC_NUM; ++w) {
-    exprs.push_back(kernel_expr(w, h->n, h->m, T));
+    exprs.push_back(kernel_expr(w, h->n, h->m, T, ck));
     R->AddNameExpression(prog, exprs.back().c_str());
   }
   hipDeviceProp_t prop;
@@ -183,10 +206,10 @@ static int rtc_module_for(altro_hip_batch* h, const std::string& user_src, RtcMo
   R->GetCode(prog, code.data());
   RtcModule* m = new RtcModule();
   m->device = h->device;
-  if (hipModuleLoadData(&m->module, code.data()) != hipSuccess) {
+  if (const hipError_t le = hipModuleLoadData(&m->module, code.data()); le != hipSuccess) {
     R->DestroyProgram(&prog);
     delete m;
-    return fail(ALTRO_HIP_ERR_HIP, "hipModuleLoadData of the compiled model failed: %s", hipGetErrorString(hipGetLastError()));
+    return fail(ALTRO_HIP_ERR_HIP, "hipModuleLoadData of the compiled model failed: %s", hipGetErrorString(le));
   }
   for (int w = 0; w < RTC_NUM; ++w) {
     const char* lowered = nullptr;
@@ -208,8 +231,14 @@ static int rtc_module_for(altro_hip_batch* h, const std::string& user_src, RtcMo
 // One kernel of the launch-sequenced loop from the handle's run-time module: the grids of ilqr_launch_kernel (ilqr_launch_f64.hip).
 template <typename T>
 int rtc_launch(altro_hip_batch* h, int which, const IlqrArgs<T>& a) {
+  if (!h->rtc) return fail(ALTRO_HIP_ERR_NOT_SET, "altro_hip_set_model_source has not been called");
+  if (h->rtc_ck != a.cost_kind) {   // the handle's cost changed kind since the module was built: the instantiations for this one
+    RtcModule* m2 = nullptr;
+    int rc = rtc_module_for(h, h->rtc_source, a.cost_kind, &m2);
+    if (rc) return rc;
+    h->rtc = m2; h->rtc_ck = a.cost_kind;
+  }
   RtcModule* mod = (RtcModule*)h->rtc;
-  if (!mod) return fail(ALTRO_HIP_ERR_NOT_SET, "altro_hip_set_model_source has not been called");
   IlqrArgs<T> args = a;
   void* params[] = {&args};
   const unsigned lanes = (unsigned)((a.batch + 63) / 64);
@@ -263,9 +292,15 @@ int altro_hip_set_model_source(altro_hip_batch* h, const char* source, float tim
                                            "(n, m) = (%d, %d)", h->plan, h->n, h->m);
   HIP_TRY(hipSetDevice(h->device));
   RtcModule* m = nullptr;
-  if ((rc = rtc_module_for(h, source, &m))) return rc;   // (altro_hip_last_error has the compiler's log)
-  h->rtc = m;
-  h->rtc_has_constraints = std::string(source).find("altro_user_constraint_jacobian") != std::string::npos;
+  const std::string src(source);
+  const bool c_val = defines_function(src, "altro_user_constraint"), c_jac = defines_function(src, "altro_user_constraint_jacobian");
+  if (c_val != c_jac)
+    return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "the model source defines %s but not %s: constraint blocks need both",
+                c_val ? "altro_user_constraint" : "altro_user_constraint_jacobian", c_val ? "altro_user_constraint_jacobian" : "altro_user_constraint");
+  const int ck = h->cost_dense ? 1 : 0;
+  if ((rc = rtc_module_for(h, src, ck, &m))) return rc;   // (altro_hip_last_error has the compiler's log)
+  h->rtc = m; h->rtc_ck = ck; h->rtc_source = src;
+  h->rtc_has_constraints = c_val && c_jac;
   h->model = ModelParams{MODEL_USER, timestep, 0, 2.7, 1.5};
   h->model_set = true;
   return 0;

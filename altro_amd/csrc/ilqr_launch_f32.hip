@@ -26,13 +26,19 @@ int ilqr_launch_kernel<float>(hipStream_t stream, int which, int kind, int n, in
     switch (which) {                                                                                          \
       case IK_ROLLOUT: hipLaunchKernelGGL((ilqr_rollout_kernel<K_, N_, M_, T>), lanes, b64, 0, stream, a); break;   \
       case IK_ACCEPT: hipLaunchKernelGGL((ilqr_accept_kernel<N_, M_, T>), flat, b256, 0, stream, a); break;         \
-      case IK_EXPAND: hipLaunchKernelGGL((ilqr_expand_kernel<K_, N_, M_, T>), flat64, b64, 0, stream, a); break;    \
+      case IK_EXPAND:   /* (a.cost_kind: the instantiation for the dense quadratic cost, kernels/ilqr_lane.hip) */  \
+        if (a.cost_kind) hipLaunchKernelGGL((ilqr_expand_kernel<K_, N_, M_, T, 1>), flat64, b64, 0, stream, a);       \
+        else hipLaunchKernelGGL((ilqr_expand_kernel<K_, N_, M_, T>), flat64, b64, 0, stream, a);                      \
+        break;                                                                                                \
       case IK_MERIT: {                                                                                        \
         const unsigned trials = a.spec_trials > 1 ? a.spec_trials : 1;                                        \
         if (a.merit_jk) {   /* rollout | per-knot-point terms on the whole chip | sums and phi' */            \
           hipLaunchKernelGGL((ilqr_merit_roll_kernel<K_, N_, M_, T>), dim3(lanes.x, trials), b64, 0, stream, a);   \
-          hipLaunchKernelGGL((ilqr_merit_point_kernel<K_, N_, M_, T>), dim3(flat64.x, trials), b64, 0, stream, a); \
+          if (a.cost_kind) hipLaunchKernelGGL((ilqr_merit_point_kernel<K_, N_, M_, T, 1>), dim3(flat64.x, trials), b64, 0, stream, a); \
+          else hipLaunchKernelGGL((ilqr_merit_point_kernel<K_, N_, M_, T>), dim3(flat64.x, trials), b64, 0, stream, a); \
           hipLaunchKernelGGL((ilqr_merit_sum_kernel<K_, N_, M_, T>), dim3(lanes.x, trials), b64, 0, stream, a);    \
+        } else if (a.cost_kind) {                                                                             \
+          hipLaunchKernelGGL((ilqr_merit_kernel<K_, N_, M_, T, 1>), dim3(lanes.x, trials), b64, 0, stream, a); \
         } else {                                                                                              \
           hipLaunchKernelGGL((ilqr_merit_kernel<K_, N_, M_, T>), dim3(lanes.x, trials), b64, 0, stream, a);    \
         }                                                                                                     \

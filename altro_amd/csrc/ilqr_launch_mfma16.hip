@@ -17,8 +17,12 @@ static int wave_launch(hipStream_t stream, int which, const IlqrWaveArgs<S>& a) 
     case IK_ROLLOUT: hipLaunchKernelGGL(wave_rollout_kernel<S>, waves, b64, 0, stream, a); break;
     case IK_ACCEPT: hipLaunchKernelGGL(wave_accept_kernel<S>, flat, b256, 0, stream, a); break;
     case IK_EXPAND:
-      if (a.al.enabled && (a.mode & EXPAND_LDS) == 0) {   // four (problem, knot point) pairs per wave, kernels/ilqr_merit2_dpp.hip
-        hipLaunchKernelGGL(wave_expand_dpp_kernel<S>, dim3((unsigned)((int64_t)((a.batch + 3) / 4) * (a.N + 1))), b64, 0, stream, a);
+      if (a.cost_dense) {   // the dense quadratic cost: row-layout kernels only (capi_ilqr.hip keeps EXPAND_LDS off)
+        const int64_t blocks = ((int64_t)a.batch * (a.N + 1) * 16 + 255) / 256;
+        if (a.al.enabled) hipLaunchKernelGGL((wave_expand_dpp_kernel<S, true>), dim3((unsigned)((int64_t)((a.batch + 3) / 4) * (a.N + 1))), b64, 0, stream, a);
+        else if (a.mode & EXPAND_GRADIENT) hipLaunchKernelGGL(wave_expand_grad_dense_kernel<S>, dim3((unsigned)(blocks < 262144 ? blocks : 262144)), dim3(256), 0, stream, a);
+      } else if (a.al.enabled && (a.mode & EXPAND_LDS) == 0) {   // four (problem, knot point) pairs per wave, kernels/ilqr_merit2_dpp.hip
+        hipLaunchKernelGGL((wave_expand_dpp_kernel<S, false>), dim3((unsigned)((int64_t)((a.batch + 3) / 4) * (a.N + 1))), b64, 0, stream, a);
       } else if (a.al.enabled) {
         hipLaunchKernelGGL(wave_expand_kernel<S>, dim3((unsigned)((int64_t)a.batch * (a.N + 1))), b64, 0, stream, a);
       } else if (a.mode & EXPAND_GRADIENT) {   // no constraint blocks: the Hessian is constant, the gradient is 16 entries
@@ -35,7 +39,11 @@ static int wave_launch(hipStream_t stream, int which, const IlqrWaveArgs<S>& a) 
       // ONE trial per problem its second rows idle; while the constraint Jacobians came from global memory the LDS form won
       // those rounds on long horizons.  With G in LDS and the duals fetched a step ahead the DPP form wins them too -- C1 + input
       // bounds, cubic search, whole solves: N = 192: 69.7 vs 70.9 ms, N = 256: 105.2 vs 108.9.)
-      if (a.mode == 3 || a.mode == 2) {   // (3: ALTRO_HIP_MERIT_DPP=2, kept for the tests that force the form)
+      if (a.cost_dense) {   // the dense quadratic cost lives in the row-layout kernel only
+        const dim3 grid(mf_grid((a.batch + 1) / 2), ((a.spec_trials > 1 ? a.spec_trials : 1) + 1) / 2);
+        if (a.al.enabled) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, true, false, true>), grid, b64, 0, stream, a);
+        else hipLaunchKernelGGL((wave_merit_dpp_kernel<S, false, false, true>), grid, b64, 0, stream, a);
+      } else if (a.mode == 3 || a.mode == 2) {   // (3: ALTRO_HIP_MERIT_DPP=2, kept for the tests that force the form)
         const dim3 grid(mf_grid((a.batch + 1) / 2), ((a.spec_trials > 1 ? a.spec_trials : 1) + 1) / 2);
         if (a.al.enabled) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, true, false>), grid, b64, 0, stream, a);
         else hipLaunchKernelGGL((wave_merit_dpp_kernel<S, false, false>), grid, b64, 0, stream, a);
@@ -43,7 +51,9 @@ static int wave_launch(hipStream_t stream, int which, const IlqrWaveArgs<S>& a) 
       else hipLaunchKernelGGL((wave_merit_kernel<S, false>), dim3(waves.x, a.spec_trials > 1 ? a.spec_trials : 1), b64, 0, stream, a);
       break;
     case IK_MERIT2:
-      if (a.mode == 2 && a.al.enabled) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, true, true>), dim3(mf_grid((a.batch + 1) / 2)), b64, 0, stream, a);
+      if (a.cost_dense && a.al.enabled) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, true, true, true>), dim3(mf_grid((a.batch + 1) / 2)), b64, 0, stream, a);
+      else if (a.cost_dense) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, false, true, true>), dim3(mf_grid((a.batch + 1) / 2)), b64, 0, stream, a);
+      else if (a.mode == 2 && a.al.enabled) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, true, true>), dim3(mf_grid((a.batch + 1) / 2)), b64, 0, stream, a);
       else if (a.mode == 2) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, false, true>), dim3(mf_grid((a.batch + 1) / 2)), b64, 0, stream, a);   // two problems per wave
       else if (a.al.enabled) hipLaunchKernelGGL((wave_merit2_kernel<S, true>), waves, b64, 0, stream, a);
       else if (sizeof(S) == 8 && a.mode == 1) hipLaunchKernelGGL((wave_merit2_mfma_kernel<S>), waves, b64, 0, stream, a);   // mode 1: asked for by altro_hip_ilqr_solve

@@ -19,7 +19,10 @@
 //   out  [k][E_OUT]  K d P p from the backward pass ; outn = P_N p_N
 //   nom  [k][n+m]    nominal trajectory  x | u
 //   cand [k][2n+m]   candidate           x_ | y_ | u_
-//   cost [k][2n+2m+1] Qd | Rd | q | r | c     (k = N: terminal)
+//   cost [k][2n+2m+1] Qd | Rd | q | r | c     (k = N: terminal)   -- the diagonal cost (CK = 0: KnotPointData::SetDiagonalCost)
+//        [k][n n + m m + m n + n + m + 1]  Q | R | H | q | r | c (column-major blocks, as given)
+//                                                               -- the dense quadratic cost (CK = 1: KnotPointData::SetQuadraticCost,
+//                                                                  knotpoint_data.cpp:64-85; value / gradient / Hessian :616-708)
 #pragma once
 #include "../rtc_compat.h"
 
@@ -33,11 +36,118 @@
 ALTRO_FP_REGION_ON   // single-expression a * b + c only: the same rounding in every kernel these functions are inlined into (see models.h)
 namespace altro_hip {
 
-template <int n, int m>
+// CK: the cost the handle carries (IlqrArgs::cost_kind) -- 0 the diagonal tracking cost of ALTROSolver::SetLQRCost, 1 the dense
+// quadratic cost of ALTROSolver::SetQuadraticCost (altro_solver.cpp:118-136).  A template parameter of the kernels that read
+// the cost record (expansion, merit evaluation), not a run-time branch: the diagonal instantiations are the ones the fused
+// solve kernel is built from, and they stay exactly as they were.
+template <int n, int m, int CK = 0>
 struct IlqrDims {
-  static constexpr int E_NOM = n + m, E_CAND = 2 * n + m, E_COST = 2 * n + 2 * m + 1;
-  static constexpr int C_Q = 0, C_R = n, C_q = n + m, C_r = 2 * n + m, C_c = 2 * n + 2 * m;
+  static constexpr int E_NOM = n + m, E_CAND = 2 * n + m;
+  static constexpr int E_COST = CK ? n * n + m * m + m * n + n + m + 1 : 2 * n + 2 * m + 1;
+  static constexpr int C_Q = 0, C_R = CK ? n * n : n, C_H = n * n + m * m /* CK = 1 only */;
+  static constexpr int C_q = CK ? n * n + m * m + m * n : n + m, C_r = C_q + n, C_c = C_r + m;
 };
+
+// ---- the cost of one knot point from a register copy of its record ------------------------------------------------------------
+// CalcOriginalCost (knotpoint_data.cpp:616-648)
+template <int n, int m, int CK, typename T>
+__device__ __forceinline__ T ilqr_cost_value(const T* cs, const T* x, const T* u, bool terminal) {
+  using I = IlqrDims<n, m, CK>;
+  T J;
+  if constexpr (CK == 0) {   // diagonal (:636-645)
+    T a1 = T(0);
+    for (int i = 0; i < n; ++i) a1 += x[i] * (cs[I::C_Q + i] * x[i]);
+    J = T(0.5) * a1;
+    T b1 = T(0);
+    for (int i = 0; i < n; ++i) b1 += cs[I::C_q + i] * x[i];
+    J += b1;
+    if (!terminal) {
+      T a2 = T(0);
+      for (int i = 0; i < m; ++i) a2 += u[i] * (cs[I::C_R + i] * u[i]);
+      J += T(0.5) * a2;
+      T b2 = T(0);
+      for (int i = 0; i < m; ++i) b2 += cs[I::C_r + i] * u[i];
+      J += b2;
+    }
+  } else {                   // dense (:624-634): 1/2 x'Qx + q'x + 1/2 u'Ru + r'u + u'Hx
+    T a1 = T(0);
+    for (int i = 0; i < n; ++i) {
+      T t = T(0);
+      for (int j = 0; j < n; ++j) t += cs[I::C_Q + i + j * n] * x[j];
+      a1 += x[i] * t;
+    }
+    J = T(0.5) * a1;
+    T b1 = T(0);
+    for (int i = 0; i < n; ++i) b1 += cs[I::C_q + i] * x[i];
+    J += b1;
+    if (!terminal) {
+      T a2 = T(0);
+      for (int i = 0; i < m; ++i) {
+        T t = T(0);
+        for (int j = 0; j < m; ++j) t += cs[I::C_R + i + j * m] * u[j];
+        a2 += u[i] * t;
+      }
+      J += T(0.5) * a2;
+      T b2 = T(0);
+      for (int i = 0; i < m; ++i) b2 += cs[I::C_r + i] * u[i];
+      J += b2;
+      T b3 = T(0);
+      for (int i = 0; i < m; ++i) {
+        T t = T(0);
+        for (int j = 0; j < n; ++j) t += cs[I::C_H + i + j * m] * x[j];
+        b3 += u[i] * t;
+      }
+      J += b3;
+    }
+  }
+  J += cs[I::C_c];
+  return J;
+}
+// CalcOriginalCostGradient (knotpoint_data.cpp:650-681); lu untouched at the terminal knot point
+template <int n, int m, int CK, typename T>
+__device__ __forceinline__ void ilqr_cost_gradient(const T* cs, const T* x, const T* u, bool terminal, T* lx, T* lu) {
+  using I = IlqrDims<n, m, CK>;
+  if constexpr (CK == 0) {
+    for (int i = 0; i < n; ++i) lx[i] = cs[I::C_Q + i] * x[i] + cs[I::C_q + i];
+    if (!terminal)
+      for (int i = 0; i < m; ++i) lu[i] = cs[I::C_R + i] * u[i] + cs[I::C_r + i];
+  } else {                   // lx = Q x; lx += q; lu = R u; lu += r; lu += H x; lx += H'u   (:659-668)
+    for (int i = 0; i < n; ++i) {
+      T t = T(0);
+      for (int j = 0; j < n; ++j) t += cs[I::C_Q + i + j * n] * x[j];
+      lx[i] = t + cs[I::C_q + i];
+    }
+    if (!terminal) {
+      for (int i = 0; i < m; ++i) {
+        T t = T(0);
+        for (int j = 0; j < m; ++j) t += cs[I::C_R + i + j * m] * u[j];
+        T l = t + cs[I::C_r + i];
+        T hx = T(0);
+        for (int j = 0; j < n; ++j) hx += cs[I::C_H + i + j * m] * x[j];
+        lu[i] = l + hx;
+      }
+      for (int j = 0; j < n; ++j) {
+        T t = T(0);
+        for (int i = 0; i < m; ++i) t += cs[I::C_H + i + j * m] * u[i];
+        lx[j] = lx[j] + t;
+      }
+    }
+  }
+}
+// CalcOriginalCostHessian (knotpoint_data.cpp:683-708): lxx n x n, luu m x m, lux m x n, column-major
+template <int n, int m, int CK, typename T>
+__device__ __forceinline__ void ilqr_cost_hessian(const T* cs, bool terminal, T* Qm, T* Rm, T* Hm) {
+  using I = IlqrDims<n, m, CK>;
+  if constexpr (CK == 0) {
+    for (int e = 0; e < n * n; ++e) Qm[e] = (e % n == e / n) ? cs[I::C_Q + e % n] : T(0);
+    for (int e = 0; e < m * m; ++e) Rm[e] = (!terminal && e % m == e / m) ? cs[I::C_R + e % m] : T(0);
+    for (int e = 0; e < m * n; ++e) Hm[e] = T(0);
+  } else {
+    for (int e = 0; e < n * n; ++e) Qm[e] = cs[I::C_Q + e];
+    for (int e = 0; e < m * m; ++e) Rm[e] = terminal ? T(0) : cs[I::C_R + e];
+    for (int e = 0; e < m * n; ++e) Hm[e] = terminal ? T(0) : cs[I::C_H + e];
+  }
+}
 
 #define ILQR_PROLOGUE                                                    \
   using D = LaneDims<n, m>;                                              \
@@ -110,10 +220,10 @@ __global__ void ilqr_accept_kernel(IlqrArgs<T> a) {
 
 // Expansion at the candidate point of ONE knot point: A, B (f = 0), lxx/luu/lux, lx, lu -> the backward pass's input
 // record.  Independent in k: the reference's own TODO ("do this in parallel", solver.cpp:190).
-template <int KIND, int n, int m, typename T>
+template <int KIND, int n, int m, typename T, int CK = 0>
 __device__ __forceinline__ void ilqr_expand_point(const IlqrArgs<T>& a, int64_t b, int k, bool grad, bool hess) {
   using D = LaneDims<n, m>;
-  using I = IlqrDims<n, m>;
+  using I = IlqrDims<n, m, CK>;
   using Mdl = DiscreteModel<KIND, n, m, T>;
   const int64_t B = a.batch;
   const T* c = a.cand + (int64_t)k * I::E_CAND * B + b;
@@ -123,13 +233,21 @@ __device__ __forceinline__ void ilqr_expand_point(const IlqrArgs<T>& a, int64_t 
   for (int e = 0; e < n; ++e) x[e] = c[(int64_t)e * B];
   for (int e = 0; e < m; ++e) u[e] = terminal ? T(0) : c[(int64_t)(2 * n + e) * B];
   T lx[n], lu[m], Qm[n * n], Rm[m * m], Hm[m * n];
-  for (int e = 0; e < n; ++e) lx[e] = cs[(int64_t)(I::C_Q + e) * B] * x[e] + cs[(int64_t)(I::C_q + e) * B];
-  for (int e = 0; e < m; ++e)
-    lu[e] = terminal ? T(0) : cs[(int64_t)(I::C_R + e) * B] * u[e] + cs[(int64_t)(I::C_r + e) * B];
-  for (int e = 0; e < n * n; ++e) Qm[e] = (e % n == e / n) ? cs[(int64_t)(I::C_Q + e % n) * B] : T(0);
-  for (int e = 0; e < m * m; ++e)
-    Rm[e] = (!terminal && e % m == e / m) ? cs[(int64_t)(I::C_R + e % m) * B] : T(0);
-  for (int e = 0; e < m * n; ++e) Hm[e] = T(0);
+  if constexpr (CK == 0) {
+    for (int e = 0; e < n; ++e) lx[e] = cs[(int64_t)(I::C_Q + e) * B] * x[e] + cs[(int64_t)(I::C_q + e) * B];
+    for (int e = 0; e < m; ++e)
+      lu[e] = terminal ? T(0) : cs[(int64_t)(I::C_R + e) * B] * u[e] + cs[(int64_t)(I::C_r + e) * B];
+    for (int e = 0; e < n * n; ++e) Qm[e] = (e % n == e / n) ? cs[(int64_t)(I::C_Q + e % n) * B] : T(0);
+    for (int e = 0; e < m * m; ++e)
+      Rm[e] = (!terminal && e % m == e / m) ? cs[(int64_t)(I::C_R + e % m) * B] : T(0);
+    for (int e = 0; e < m * n; ++e) Hm[e] = T(0);
+  } else {   // dense quadratic cost: the record first, then the reference's expressions (knotpoint_data.cpp:650-708)
+    T cr[I::E_COST];
+    for (int e = 0; e < I::E_COST; ++e) cr[e] = cs[(int64_t)e * B];
+    for (int e = 0; e < m; ++e) lu[e] = T(0);
+    ilqr_cost_gradient<n, m, CK, T>(cr, x, u, terminal, lx, lu);
+    ilqr_cost_hessian<n, m, CK, T>(cr, terminal, Qm, Rm, Hm);
+  }
   if (a.al.enabled) {
     const T rho_est = (T)a.prob[b].rho_est, rho = (T)a.prob[b].rho;
     if (grad && hess)
@@ -163,7 +281,7 @@ __device__ __forceinline__ void ilqr_expand_point(const IlqrArgs<T>& a, int64_t 
   }
 }
 // one thread per (problem, knot point)
-template <int KIND, int n, int m, typename T>
+template <int KIND, int n, int m, typename T, int CK = 0>
 __global__ __launch_bounds__(64) void ilqr_expand_kernel(IlqrArgs<T> a) {
   const int64_t B = a.batch;
   const int64_t total = B * (a.N + 1);
@@ -173,50 +291,28 @@ __global__ __launch_bounds__(64) void ilqr_expand_kernel(IlqrArgs<T> a) {
     const int64_t b = t % B;
     const int k = (int)(t / B);
     if (a.active && !a.active[b]) continue;
-    ilqr_expand_point<KIND, n, m, T>(a, b, k, grad, hess);
+    ilqr_expand_point<KIND, n, m, T, CK>(a, b, k, grad, hess);
   }
-}
-
-// diagonal quadratic cost of one knot point (knotpoint_data.cpp:636-645)
-template <int n, int m, typename T>
-__device__ __forceinline__ T ilqr_kp_cost(const T* cs, int64_t B, const T* x, const T* u, bool terminal) {
-  using I = IlqrDims<n, m>;
-  T a1 = T(0);
-  for (int i = 0; i < n; ++i) a1 += x[i] * (cs[(int64_t)(I::C_Q + i) * B] * x[i]);
-  T J = T(0.5) * a1;
-  T b1 = T(0);
-  for (int i = 0; i < n; ++i) b1 += cs[(int64_t)(I::C_q + i) * B] * x[i];
-  J += b1;
-  if (!terminal) {
-    T a2 = T(0);
-    for (int i = 0; i < m; ++i) a2 += u[i] * (cs[(int64_t)(I::C_R + i) * B] * u[i]);
-    J += T(0.5) * a2;
-    T b2 = T(0);
-    for (int i = 0; i < m; ++i) b2 += cs[(int64_t)(I::C_r + i) * B] * u[i];
-    J += b2;
-  }
-  J += cs[(int64_t)I::C_c * B];
-  return J;
 }
 
 // One knot point's merit-function operands in registers: K | d | P | p, the nominal x | u, the cost record and
 // the duals.  None of these addresses depends on the rollout, so record k + 1 is requested before knot point
 // k is evaluated (these kernels are latency-bound: one wave per 64 problems, N dependent steps).
-template <int n, int m, typename T>
+template <int n, int m, typename T, int CK = 0>
 struct MeritRec {
   using D = LaneDims<n, m>;
-  using I = IlqrDims<n, m>;
+  using I = IlqrDims<n, m, CK>;
   T out[D::E_OUT];
   T nom[I::E_NOM];
   T cs[I::E_COST];
   T z[AL_MAXC * AL_MAXP];
 };
 
-template <int n, int m, typename T>
-__device__ __forceinline__ void merit_load(MeritRec<n, m, T>& r, const IlqrArgs<T>& a, int k, int64_t b0, uint32_t lane,
+template <int n, int m, typename T, int CK>
+__device__ __forceinline__ void merit_load(MeritRec<n, m, T, CK>& r, const IlqrArgs<T>& a, int k, int64_t b0, uint32_t lane,
                                            uint32_t rowB) {
   using D = LaneDims<n, m>;
-  using I = IlqrDims<n, m>;
+  using I = IlqrDims<n, m, CK>;
   const int64_t B = a.batch;
   if (k < a.N) {
     const LaneBuf bo(a.out + b0 + (int64_t)k * D::E_OUT * B);
@@ -235,35 +331,13 @@ __device__ __forceinline__ void merit_load(MeritRec<n, m, T>& r, const IlqrArgs<
   if (a.al.enabled) al_load_z<T>(a.al, k, LaneBuf(a.al.z + b0), lane, rowB, r.z);
 }
 
-// diagonal quadratic cost of one knot point from the register copy of its cost record (knotpoint_data.cpp:636-645)
-template <int n, int m, typename T>
-__device__ __forceinline__ T ilqr_kp_cost_reg(const T* cs, const T* x, const T* u, bool terminal) {
-  using I = IlqrDims<n, m>;
-  T a1 = T(0);
-  for (int i = 0; i < n; ++i) a1 += x[i] * (cs[I::C_Q + i] * x[i]);
-  T J = T(0.5) * a1;
-  T b1 = T(0);
-  for (int i = 0; i < n; ++i) b1 += cs[I::C_q + i] * x[i];
-  J += b1;
-  if (!terminal) {
-    T a2 = T(0);
-    for (int i = 0; i < m; ++i) a2 += u[i] * (cs[I::C_R + i] * u[i]);
-    J += T(0.5) * a2;
-    T b2 = T(0);
-    for (int i = 0; i < m; ++i) b2 += cs[I::C_r + i] * u[i];
-    J += b2;
-  }
-  J += cs[I::C_c];
-  return J;
-}
-
 // one non-terminal knot point of MeritFunction (solver.cpp:286-317)
-template <int KIND, int n, int m, typename T>
-__device__ __forceinline__ void merit_step(const MeritRec<n, m, T>& r, const IlqrArgs<T>& a, T* cand, int k, int64_t b, int64_t b0,
+template <int KIND, int n, int m, typename T, int CK>
+__device__ __forceinline__ void merit_step(const MeritRec<n, m, T, CK>& r, const IlqrArgs<T>& a, T* cand, int k, int64_t b, int64_t b0,
                                            uint32_t lane, uint32_t rowB, T alpha, T rho, bool deriv, bool store, bool al, T (&x)[n],
                                            T (&dxda)[n], T& phi, T& dphi) {
   using D = LaneDims<n, m>;
-  using I = IlqrDims<n, m>;
+  using I = IlqrDims<n, m, CK>;
   using Mdl = DiscreteModel<KIND, n, m, T>;
   const int64_t B = a.batch;
   T dx[n], u[m], xn[n], y[n];
@@ -289,9 +363,8 @@ __device__ __forceinline__ void merit_step(const MeritRec<n, m, T>& r, const Ilq
   if (deriv) Mdl::step(a.mp, x, u, xn, Am, Bm);
   else Mdl::dynamics(a.mp, x, u, xn);
   T lx[n], lu[m];
-  for (int i = 0; i < n; ++i) lx[i] = r.cs[I::C_Q + i] * x[i] + r.cs[I::C_q + i];
-  for (int i = 0; i < m; ++i) lu[i] = r.cs[I::C_R + i] * u[i] + r.cs[I::C_r + i];
-  T Jk = ilqr_kp_cost_reg<n, m, T>(r.cs, x, u, false);
+  ilqr_cost_gradient<n, m, CK, T>(r.cs, x, u, false, lx, lu);
+  T Jk = ilqr_cost_value<n, m, CK, T>(r.cs, x, u, false);
   if (al)   // one instance: the gradient terms are formed even when only phi is wanted (lx, lu are then unused)
     Jk += al_eval<n, m, T, true, false>(a.al, k, b, B, x, u, false, rho, rho, lx, lu, nullptr, nullptr, nullptr, nullptr, false, r.z);
   phi += Jk;
@@ -331,11 +404,11 @@ __device__ __forceinline__ void merit_step(const MeritRec<n, m, T>& r, const Ilq
 
 // MeritFunction (solver.cpp:273-355) for one problem: closed-loop rollout with step alpha, total cost phi and, when
 // asked, the directional derivative dphi together with the refreshed A, B, lx, lu (`store`).  Leaves rho_est = rho.
-template <int KIND, int n, int m, typename T>
+template <int KIND, int n, int m, typename T, int CK = 0>
 __device__ __forceinline__ void ilqr_merit_lane(const IlqrArgs<T>& a, int64_t b, int64_t b0, uint32_t lane, uint32_t rowB,
                                                 T alpha, bool deriv, bool store, T* cand, T& phi_out, T& dphi_out) {
   using D = LaneDims<n, m>;
-  using I = IlqrDims<n, m>;
+  using I = IlqrDims<n, m, CK>;
   const int64_t B = a.batch;
   const int N = a.N;
   const bool al = a.al.enabled != 0;
@@ -346,17 +419,17 @@ __device__ __forceinline__ void ilqr_merit_lane(const IlqrArgs<T>& a, int64_t b,
 #pragma unroll
     for (int e = 0; e < n; ++e) { x[e] = lane_ld<T>(bx, lane, (uint32_t)e * rowB); dxda[e] = T(0); }
   }
-  MeritRec<n, m, T> r0, r1;
-  merit_load<n, m, T>(r0, a, 0, b0, lane, rowB);
+  MeritRec<n, m, T, CK> r0, r1;
+  merit_load<n, m, T, CK>(r0, a, 0, b0, lane, rowB);
   for (int k = 0; k < N; ++k) {   // one step instance (code size); the copy waits for record k + 1 after step k
-    merit_load<n, m, T>(r1, a, k + 1, b0, lane, rowB);      // k + 1 == N: the terminal record
-    merit_step<KIND, n, m, T>(r0, a, cand, k, b, b0, lane, rowB, alpha, rho, deriv, store, al, x, dxda, phi, dphi);
+    merit_load<n, m, T, CK>(r1, a, k + 1, b0, lane, rowB);      // k + 1 == N: the terminal record
+    merit_step<KIND, n, m, T, CK>(r0, a, cand, k, b, b0, lane, rowB, alpha, rho, deriv, store, al, x, dxda, phi, dphi);
     r0 = r1;
   }
   {   // terminal knot point (solver.cpp:319-332); r0 holds record N
     T lxN[n];
-    for (int i = 0; i < n; ++i) lxN[i] = r0.cs[I::C_Q + i] * x[i] + r0.cs[I::C_q + i];
-    T Jk = ilqr_kp_cost_reg<n, m, T>(r0.cs, x, (const T*)nullptr, true);
+    ilqr_cost_gradient<n, m, CK, T>(r0.cs, x, (const T*)nullptr, true, lxN, (T*)nullptr);
+    T Jk = ilqr_cost_value<n, m, CK, T>(r0.cs, x, (const T*)nullptr, true);
     if (al)
       Jk += al_eval<n, m, T, true, false>(a.al, N, b, B, x, (const T*)nullptr, true, rho, rho, lxN, nullptr, nullptr, nullptr, nullptr, nullptr, false, r0.z);
     phi += Jk;
@@ -426,22 +499,22 @@ __device__ __forceinline__ MeritTrial<T> ilqr_merit_trial(const IlqrArgs<T>& a, 
   return tr;
 }
 // One merit evaluation of problem b in one lane: rollout, costs, phi' and the expansion, knot point after knot point.
-template <int KIND, int n, int m, typename T>
+template <int KIND, int n, int m, typename T, int CK = 0>
 __device__ __forceinline__ void ilqr_merit_body(const IlqrArgs<T>& a, int64_t b, int64_t b0, uint32_t lane, uint32_t rowB, int trial) {
   const int64_t B = a.batch;
   const MeritTrial<T> tr = ilqr_merit_trial<T>(a, b, trial);
   if (!tr.run) return;
   T phi, dphi;
-  ilqr_merit_lane<KIND, n, m, T>(a, b, b0, lane, rowB, (T)tr.alpha, tr.deriv, tr.store, tr.cand, phi, dphi);
+  ilqr_merit_lane<KIND, n, m, T, CK>(a, b, b0, lane, rowB, (T)tr.alpha, tr.deriv, tr.store, tr.cand, phi, dphi);
   a.phi[(int64_t)trial * B + b] = (double)phi;
   if (tr.deriv) a.dphi[(int64_t)trial * B + b] = (double)dphi;
 }
 // one launch = one merit evaluation per problem; gridDim.y > 1: the speculative trials ride along
-template <int KIND, int n, int m, typename T>
+template <int KIND, int n, int m, typename T, int CK = 0>
 __global__ __launch_bounds__(64) void ilqr_merit_kernel(IlqrArgs<T> a) {
   ILQR_PROLOGUE;
   if (a.active && !a.active[b]) return;
-  ilqr_merit_body<KIND, n, m, T>(a, b, (int64_t)blockIdx.x * 64, threadIdx.x * (uint32_t)sizeof(T),
+  ilqr_merit_body<KIND, n, m, T, CK>(a, b, (int64_t)blockIdx.x * 64, threadIdx.x * (uint32_t)sizeof(T),
                                  (uint32_t)B * (uint32_t)sizeof(T), (int)blockIdx.y);
 }
 
@@ -561,10 +634,10 @@ __global__ __launch_bounds__(64) void ilqr_merit_roll_kernel(IlqrArgs<T> a) {
 }
 
 // everything of MeritFunction at ONE knot point of a rolled-out trial (solver.cpp:286-332 without the two recursions)
-template <int KIND, int n, int m, typename T>
+template <int KIND, int n, int m, typename T, int CK = 0>
 __device__ __forceinline__ void ilqr_merit_point(const IlqrArgs<T>& a, int64_t b, int k, int trial, const MeritTrial<T>& tr) {
   using D = LaneDims<n, m>;
-  using I = IlqrDims<n, m>;
+  using I = IlqrDims<n, m, CK>;
   using Mdl = DiscreteModel<KIND, n, m, T>;
   const int64_t B = a.batch;
   const int N = a.N;
@@ -590,11 +663,10 @@ __device__ __forceinline__ void ilqr_merit_point(const IlqrArgs<T>& a, int64_t b
   static_assert(D::O_p == D::O_P + n * n, "P | p are adjacent in the backward pass's output record");
   const MeritJac<n, m, T> jd = ilqr_merit_jac<n, m, T>(a, tr.store);
   T lx[n], lu[m];
-  for (int i = 0; i < n; ++i) lx[i] = cs[I::C_Q + i] * x[i] + cs[I::C_q + i];
+  ilqr_cost_gradient<n, m, CK, T>(cs, x, u, terminal, lx, lu);
   T Jk;
   if (!terminal) {
-    for (int i = 0; i < m; ++i) lu[i] = cs[I::C_R + i] * u[i] + cs[I::C_r + i];
-    Jk = ilqr_kp_cost_reg<n, m, T>(cs, x, u, false);
+    Jk = ilqr_cost_value<n, m, CK, T>(cs, x, u, false);
     if (al) Jk += al_eval<n, m, T, true, false>(a.al, k, b, B, x, u, false, rho, rho, lx, lu, nullptr, nullptr, nullptr, nullptr, false);
     if (tr.deriv) {
       T Am[n * n], Bm[n * m];
@@ -606,14 +678,14 @@ __device__ __forceinline__ void ilqr_merit_point(const IlqrArgs<T>& a, int64_t b
       for (int e = 0; e < m; ++e) j[(int64_t)(jd.orr + e) * B] = lu[e];
     }
   } else {
-    Jk = ilqr_kp_cost_reg<n, m, T>(cs, x, (const T*)nullptr, true);
+    Jk = ilqr_cost_value<n, m, CK, T>(cs, x, (const T*)nullptr, true);
     if (al) Jk += al_eval<n, m, T, true, false>(a.al, N, b, B, x, (const T*)nullptr, true, rho, rho, lx, nullptr, nullptr, nullptr, nullptr, nullptr, false);
     if (tr.deriv)
       for (int e = 0; e < n; ++e) jd.term[(int64_t)(jd.oterm + e) * B + b] = lx[e];
   }
   a.merit_jk[((int64_t)trial * (N + 1) + k) * B + b] = Jk;
 }
-template <int KIND, int n, int m, typename T>
+template <int KIND, int n, int m, typename T, int CK = 0>
 __global__ __launch_bounds__(64) void ilqr_merit_point_kernel(IlqrArgs<T> a) {
   const int64_t B = a.batch;
   const int64_t total = B * (a.N + 1);
@@ -624,7 +696,7 @@ __global__ __launch_bounds__(64) void ilqr_merit_point_kernel(IlqrArgs<T> a) {
     if (a.active && !a.active[b]) continue;
     const MeritTrial<T> tr = ilqr_merit_trial<T>(a, b, trial);
     if (!tr.run) continue;
-    ilqr_merit_point<KIND, n, m, T>(a, b, k, trial, tr);
+    ilqr_merit_point<KIND, n, m, T, CK>(a, b, k, trial, tr);
   }
 }
 

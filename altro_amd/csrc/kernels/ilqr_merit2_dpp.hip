@@ -35,6 +35,7 @@ constexpr int MD_F0 = MD_OUT0 + MF_OUT;      // 360
 constexpr int MD_NOM0 = MD_F0 + 12;          // 372
 constexpr int MD_CP0 = MD_NOM0 + MF_NOM;     // 388
 constexpr int MD_IMG = MD_CP0 + MF_COSTP;    // 424
+constexpr int MD_IMG_DENSE = MD_CP0 + MF_COST;   // 548: a dense quadratic cost's record (IlqrWaveArgs::costd) instead of the 36 parameters
 constexpr int MD_GPOOL = 512;                // doubles of LDS for the constraint Jacobians (four blocks of 8 x 16)
 static_assert(MF_DYN % 2 == 0 && MF_OUT % 2 == 0 && MF_NOM % 2 == 0 && MF_COSTP % 2 == 0 && MD_IMG % 2 == 0, "records move as pairs");
 
@@ -48,9 +49,11 @@ __device__ __forceinline__ md_d2 md_ld(const S* __restrict__ p, int pair) {
   const typename md_pair_of<S>::type v = *reinterpret_cast<const typename md_pair_of<S>::type*>(p + 2 * pair);
   return md_d2{(double)v[0], (double)v[1]};
 }
-struct MeritPairRegs { md_d2 z[3], f, o[3], nm, cp; };   // one knot point's records of one problem, spread over 32 lanes
-template <typename S>
-__device__ __forceinline__ void merit_pair_load(MeritPairRegs& r, const S* __restrict__ z, const S* __restrict__ o,
+// one knot point's records of one problem, spread over 32 lanes  (DENSE: the 160-element dense cost record, 80 pairs)
+template <bool DENSE = false>
+struct MeritPairRegs { md_d2 z[3], f, o[3], nm, cp[DENSE ? 3 : 1]; };
+template <typename S, bool DENSE = false>
+__device__ __forceinline__ void merit_pair_load(MeritPairRegs<DENSE>& r, const S* __restrict__ z, const S* __restrict__ o,
                                                 const S* __restrict__ nm, const S* __restrict__ cp, int hl) {
 #pragma unroll
   for (int c = 0; c < 3; ++c) r.z[c] = md_ld<S>(z, c * 32 + hl);           // Z: 96 pairs
@@ -59,9 +62,14 @@ __device__ __forceinline__ void merit_pair_load(MeritPairRegs& r, const S* __res
   for (int c = 0; c < 2; ++c) r.o[c] = md_ld<S>(o, c * 32 + hl);           // OUT: 72 pairs
   r.o[2] = md_ld<S>(o, 64 + (hl & 7));
   r.nm = md_ld<S>(nm, hl & 7);                                             // nominal: 8 pairs
-  r.cp = md_ld<S>(cp, hl < 18 ? hl : 17);                                  // cost parameters: 18 pairs
+  if constexpr (DENSE) {                                                   // dense cost record: 80 pairs
+    r.cp[0] = md_ld<S>(cp, hl); r.cp[1] = md_ld<S>(cp, 32 + hl); r.cp[2] = md_ld<S>(cp, 64 + (hl & 15));
+  } else {
+    r.cp[0] = md_ld<S>(cp, hl < 18 ? hl : 17);                             // cost parameters: 18 pairs
+  }
 }
-__device__ __forceinline__ void merit_pair_stage(const MeritPairRegs& r, double* __restrict__ L, int hl) {
+template <bool DENSE>
+__device__ __forceinline__ void merit_pair_stage(const MeritPairRegs<DENSE>& r, double* __restrict__ L, int hl) {
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     const int pi = c * 32 + hl;
@@ -72,7 +80,13 @@ __device__ __forceinline__ void merit_pair_stage(const MeritPairRegs& r, double*
   for (int c = 0; c < 2; ++c) *reinterpret_cast<md_d2*>(L + MD_OUT0 + 2 * (c * 32 + hl)) = r.o[c];
   *reinterpret_cast<md_d2*>(L + MD_OUT0 + 2 * (64 + (hl & 7))) = r.o[2];
   *reinterpret_cast<md_d2*>(L + MD_NOM0 + 2 * (hl & 7)) = r.nm;
-  *reinterpret_cast<md_d2*>(L + MD_CP0 + 2 * (hl < 18 ? hl : 17)) = r.cp;
+  if constexpr (DENSE) {
+    *reinterpret_cast<md_d2*>(L + MD_CP0 + 2 * hl) = r.cp[0];
+    *reinterpret_cast<md_d2*>(L + MD_CP0 + 2 * (32 + hl)) = r.cp[1];
+    *reinterpret_cast<md_d2*>(L + MD_CP0 + 2 * (64 + (hl & 15))) = r.cp[2];
+  } else {
+    *reinterpret_cast<md_d2*>(L + MD_CP0 + 2 * (hl < 18 ? hl : 17)) = r.cp[0];
+  }
 }
 
 // acc += (lane N of this lane's row of 16 lanes of v) * coef.  The hazard recogniser does not look inside inline assembly:
@@ -272,11 +286,16 @@ __device__ __forceinline__ double dpp_al_col(const AlTable<S>& t, int k, int j, 
 // of IlqrArgs::spec_trials (trial 0 = the step the search asked for), every row with its own step, candidate buffer and
 // outputs; a row without a trial computes along and stores nothing.  The wave sums are then taken over that kernel's 64-entry
 // arrangement (state terms 0..11, input terms 16..19, constraint rows 48..55) by the butterfly it uses.
-template <typename S, bool AL, bool DUAL>
+// DENSE: the cost is the dense quadratic one of ALTROSolver::SetQuadraticCost (knotpoint_data.cpp:616-708) -- lane j of a row also
+// owns row j of W = [Q H^T; H R] (staged with the other records: IlqrWaveArgs::costd), (W [x; u])_j is one more 16-term DPP chain,
+// the cost share 1/2 w_j (W [x; u])_j + [q r]_j w_j and the gradient (W [x; u])_j + [q r]_j.
+template <typename S, bool AL, bool DUAL, bool DENSE = false>
 __global__ __launch_bounds__(64, 2) void wave_merit_dpp_kernel(IlqrWaveArgs<S> a) {
   constexpr int DEPTH = 2;                          // also the image ping-pong: parity of k == dd
   constexpr bool kStat = sizeof(S) == 8;            // stored values == computed values only without a rounding store
-  __shared__ double img[2][2][MD_IMG];              // [parity][slot]; after the sweep: the final sums (red, below)
+  constexpr int IMG = DENSE ? MD_IMG_DENSE : MD_IMG;
+  constexpr int CPE = DENSE ? MF_COST : MF_COSTP;   // elements of a knot point's cost record
+  __shared__ double img[2][2][IMG];                 // [parity][slot]; after the sweep: the final sums (red, below)
   __shared__ double Gpool[AL ? MD_GPOOL : 1];       // the constraint Jacobians, read at every knot point: kept here when they fit
   const int lane = threadIdx.x;
   const int npairs = (a.batch + 1) >> 1;
@@ -335,13 +354,20 @@ __global__ __launch_bounds__(64, 2) void wave_merit_dpp_kernel(IlqrWaveArgs<S> a
   const S* __restrict__ dynb = a.dyn + (size_t)b * a.dyn_bs;
   const S* __restrict__ outb = a.out + (size_t)b * a.out_bs;
   const S* __restrict__ nomb = a.nom + (size_t)b * MF_NOM;
-  const S* __restrict__ cpb = a.costp + (size_t)b * MF_COSTP;
-  const size_t nom_ks = (size_t)a.batch * MF_NOM, cp_ks = (size_t)a.batch * MF_COSTP;
+  const S* __restrict__ cpb = (DENSE ? a.costd : a.costp) + (size_t)b * CPE;
+  const size_t nom_ks = (size_t)a.batch * MF_NOM, cp_ks = (size_t)a.batch * CPE;
   // where this lane's coefficients sit in the image: row j of [P | p] (lanes < 12) or row j - 12 of Kt (lanes 12..15)
   int ra[13];
 #pragma unroll
   for (int c = 0; c < 12; ++c) ra[c] = isx ? MD_OUT0 + MF_OFF_P + mf_sym(j, c) : MD_OUT0 + (j - 12) * 13 + c;
   ra[12] = isx ? MD_OUT0 + MF_OFF_p + j : MD_OUT0 + (j - 12) * 13 + 12;
+  // DENSE: row j of W = [Q H^T; H R] inside the staged cost record (triu(Q) | c | pad | [H R] | [q r])
+  int rw[DENSE ? 16 : 1];
+  if constexpr (DENSE) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+      rw[c] = MD_CP0 + (isx ? (c < 12 ? MF_OFF_Q + mf_sym(j, c) : MF_OFF_HR + (c - 12) * 16 + j) : MF_OFF_HR + (j - 12) * 16 + c);
+  }
   double x = isx ? (double)a.x0[(size_t)b * 12 + j] : 0.0;
   double dxda = 0.0;
   double J = 0.0, Jal = 0.0, dJ = 0.0, res = 0.0, viol = 0.0;   // (Jal: the constraint rows' cost shares, lanes 0..7)
@@ -349,11 +375,11 @@ __global__ __launch_bounds__(64, 2) void wave_merit_dpp_kernel(IlqrWaveArgs<S> a
   double zg[AL_MAXC][2] = {{0.0, 0.0}, {0.0, 0.0}};   // (z_i, g_i) of the knot point in hand
   if (al) dpp_al_fetch<S>(a.al, 0, b, a.batch, j, zg);
   double lprev = 0.0, yprev = 0.0;                  // gradient and y of knot point k - 1 (the stationarity's lag)
-  MeritPairRegs ring[DEPTH];
+  MeritPairRegs<DENSE> ring[DEPTH];
 #pragma unroll
   for (int dd = 0; dd < DEPTH; ++dd) {
     const size_t kk = dd < N ? dd : N - 1;
-    merit_pair_load<S>(ring[dd], dynb + kk * a.dyn_ks, outb + kk * a.out_ks, nomb + kk * nom_ks, cpb + kk * cp_ks, hl);
+    merit_pair_load<S, DENSE>(ring[dd], dynb + kk * a.dyn_ks, outb + kk * a.out_ks, nomb + kk * nom_ks, cpb + kk * cp_ks, hl);
   }
   const int Npad = ((N + DEPTH - 1) / DEPTH) * DEPTH;
   for (int k0 = 0; k0 < Npad; k0 += DEPTH) {
@@ -363,10 +389,10 @@ __global__ __launch_bounds__(64, 2) void wave_merit_dpp_kernel(IlqrWaveArgs<S> a
     const bool live = k < N;
     const int kc = live ? k : N - 1;
     double* const L = img[dd][slot];
-    merit_pair_stage(ring[dd], L, hl);
+    merit_pair_stage<DENSE>(ring[dd], L, hl);
     {
       const size_t kn = (k + DEPTH < N) ? k + DEPTH : N - 1;
-      merit_pair_load<S>(ring[dd], dynb + kn * a.dyn_ks, outb + kn * a.out_ks, nomb + kn * nom_ks, cpb + kn * cp_ks, hl);
+      merit_pair_load<S, DENSE>(ring[dd], dynb + kn * a.dyn_ks, outb + kn * a.out_ks, nomb + kn * nom_ks, cpb + kn * cp_ks, hl);
     }
     __syncthreads();
     // (1) rows of [P | p] and of Kt against dx and dx/dalpha
@@ -374,7 +400,8 @@ __global__ __launch_bounds__(64, 2) void wave_merit_dpp_kernel(IlqrWaveArgs<S> a
 #pragma unroll
     for (int c = 0; c < 13; ++c) cA[c] = L[ra[c]];
     const double wnom = L[MD_NOM0 + j];                      // nominal x_j | u_(j-12)
-    const double cq = L[MD_CP0 + j], cl = L[MD_CP0 + 16 + j];   // Qd | Rd and q | r line up with [x; u]
+    const double cq = DENSE ? 0.0 : L[MD_CP0 + j];           // Qd | Rd and q | r line up with [x; u]
+    const double cl = L[MD_CP0 + (DENSE ? MF_OFF_QR : 16) + j];
     const double dx = x - wnom;
     double acc = 0.0, acc2 = 0.0;
     md_rows12(acc, acc2, dx, dxda, cA);
@@ -417,13 +444,27 @@ __global__ __launch_bounds__(64, 2) void wave_merit_dpp_kernel(IlqrWaveArgs<S> a
     md_rows16(zacc, zacc2, s2, t2, w, dw, cR);
     const double xn = (zacc + s2) + L[MD_F0 + jr];           // x+ = A x + B u + f
     const double dxn = zacc2 + t2;                           // dx+/dalpha = A dx/dalpha + B du/dalpha
-    if (live) {
-      J += 0.5 * (w * (cq * w)) + cl * w;
-      if (j == 0) J += L[MD_CP0 + 32];
+    double l;                                                // lx_j | lu_(j-12)
+    if constexpr (DENSE) {   // (W [x; u])_j: this lane's row of W against the row's registers (knotpoint_data.cpp:624-634, :659-668)
+      double cW[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) cW[c] = L[rw[c]];
+      double g = 0.0;
+      md_chain16(g, w, cW);
+      if (live) {
+        J += 0.5 * (w * g) + cl * w;
+        if (j == 0) J += L[MD_CP0 + MF_COSTD_C];
+      }
+      l = g + cl;
+    } else {
+      if (live) {
+        J += 0.5 * (w * (cq * w)) + cl * w;
+        if (j == 0) J += L[MD_CP0 + 32];
+      }
+      // (an explicit fma: cq * w also feeds the cost above, and a product with two uses is not contracted -- wave_merit2_kernel
+      //  forms this gradient from its own loads, where it is)
+      l = __builtin_fma(cq, w, cl);
     }
-    // (an explicit fma: cq * w also feeds the cost above, and a product with two uses is not contracted -- wave_merit2_kernel
-    //  forms this gradient from its own loads, where it is)
-    double l = __builtin_fma(cq, w, cl);                     // lx_j | lu_(j-12)
     if (al) l -= dpp_al_col<S>(a.al, kc, j, jvr, Gl);
     if (live) dJ += l * dw;
     if (cand) {   // trial 1's candidate record x | y | u and its [lx lu]
@@ -437,14 +478,28 @@ __global__ __launch_bounds__(64, 2) void wave_merit_dpp_kernel(IlqrWaveArgs<S> a
   }
   {   // terminal knot point (solver.cpp:319-332), both trials
     const S* nm = a.nom + ((size_t)N * a.batch + b) * MF_NOM;
-    const S* cp = a.costp + ((size_t)N * a.batch + b) * MF_COSTP;
     const S* on = a.outn + (size_t)b * MF_TERM;
     S* c = candb + (size_t)N * a.xuy_ks;
     const double dxN = x - (double)nm[jr];
-    const double Qd = (double)cp[jr], q = (double)cp[16 + jr];
-    if (isx) {
-      J += 0.5 * (x * (Qd * x)) + q * x;
-      if (j == 0) J += (double)cp[32];
+    double Qd = 0.0, q, gN = 0.0;                            // (gN: DENSE, (Q_N x)_j)
+    if constexpr (DENSE) {
+      const S* cT = a.costd_term + (size_t)b * MF_TERM;      // Q_N rows | q_N
+      double cQ[12];
+#pragma unroll
+      for (int cc = 0; cc < 12; ++cc) cQ[cc] = (double)cT[jr * 12 + cc];
+      q = (double)cT[144 + jr];
+      md_col12(gN, isx ? x : 0.0, cQ);
+      if (isx) {
+        J += 0.5 * (x * gN) + q * x;
+        if (j == 0) J += (double)a.costd[((size_t)N * a.batch + b) * MF_COST + MF_COSTD_C];
+      }
+    } else {
+      const S* cp = a.costp + ((size_t)N * a.batch + b) * MF_COSTP;
+      Qd = (double)cp[jr]; q = (double)cp[16 + jr];
+      if (isx) {
+        J += 0.5 * (x * (Qd * x)) + q * x;
+        if (j == 0) J += (double)cp[32];
+      }
     }
     if (al) {
       double Ja = 0.0, vv = 0.0;
@@ -462,7 +517,7 @@ __global__ __launch_bounds__(64, 2) void wave_merit_dpp_kernel(IlqrWaveArgs<S> a
     double sacc = 0.0, unused = 0.0;
     md_rows12(sacc, unused, dxN, dxda, cP);
     const double yN = sacc + cP[12];
-    double lx = __builtin_fma(Qd, x, q);
+    double lx = DENSE ? gN + q : __builtin_fma(Qd, x, q);
     if (al) lx -= dpp_al_col<S>(a.al, N, jr, jvr, Gl);
     if (isx) dJ += lx * dxda;
     if (cand) {
@@ -491,7 +546,7 @@ __global__ __launch_bounds__(64, 2) void wave_merit_dpp_kernel(IlqrWaveArgs<S> a
   // the sums, over the LDS-form kernels' arrangement of the addends.  DUAL: a trial's 32 entries hold the state terms at 0..11,
   // the input terms at 16..19 (dphi: 12..15), the constraint rows' at 16..23, and are added by the butterfly of offsets 16 .. 1
   __syncthreads();
-  static_assert(2 * 2 * MD_IMG >= 2 * 4 * 64, "the final sums reuse the record images");
+  static_assert(2 * 2 * IMG >= 2 * 4 * 64, "the final sums reuse the record images");
   double (*red)[4][64] = reinterpret_cast<double (*)[4][64]>(&img[0][0][0]);   // the final sums, in the LDS-form kernels' lane arrangement
   for (int e = lane; e < 2 * 4 * 64; e += 64) (&red[0][0][0])[e] = 0.0;
   __syncthreads();
@@ -583,7 +638,10 @@ __device__ __forceinline__ void md_cross_rows(double (&tile)[16], const double (
   if constexpr (R + 1 < 16) md_cross_rows<R + 1>(tile, g, hc);
 }
 
-template <typename S>
+// DENSE: the cost's own Hessian is W = [Q H^T; H R] of ALTROSolver::SetQuadraticCost instead of diag(Qd, Rd) and its gradient
+// W [x; u] + [q r] (knotpoint_data.cpp:659-668, :691-698); lane j reads row j of W (= column j: W is symmetric) from the dense
+// cost record, the gradient is one more 16-term chain.
+template <typename S, bool DENSE = false>
 __global__ __launch_bounds__(64) void wave_expand_dpp_kernel(IlqrWaveArgs<S> a) {
   const int lane = threadIdx.x, j = lane & 15;
   // four problems of ONE knot point per wave (the constraint table entry is the knot point's: wave-uniform control flow)
@@ -607,9 +665,32 @@ __global__ __launch_bounds__(64) void wave_expand_dpp_kernel(IlqrWaveArgs<S> a) 
   const bool terminal = k == a.N;
   const bool grad = (a.mode & EXPAND_GRADIENT) != 0, hess = (a.mode & EXPAND_HESSIAN) != 0;
   const S* c = a.cand + (size_t)b * a.xuy_bs + (size_t)k * a.xuy_ks;
-  const S* cp = a.costp + ((size_t)k * a.batch + b) * MF_COSTP;
   const double w = j < 12 ? (double)c[j] : (terminal ? 0.0 : (double)c[12 + j]);      // x_j | u_(j-12)   (c[24 + j - 12])
-  const double cq = (double)cp[j], cl = (double)cp[16 + j];
+  double cq = 0.0, cl, cW[DENSE ? 16 : 1];
+  if constexpr (DENSE) {
+    if (!terminal) {
+      const S* cd = a.costd + ((size_t)k * a.batch + b) * MF_COST;
+#pragma unroll
+      for (int cc = 0; cc < 16; ++cc)
+        cW[cc] = (double)cd[j < 12 ? (cc < 12 ? MF_OFF_Q + mf_sym(j, cc) : MF_OFF_HR + (cc - 12) * 16 + j) : MF_OFF_HR + (j - 12) * 16 + cc];
+      cl = (double)cd[MF_OFF_QR + j];
+    } else {
+      const S* cT = a.costd_term + (size_t)b * MF_TERM;      // Q_N rows | q_N
+      const int jr = j < 12 ? j : 11;
+#pragma unroll
+      for (int cc = 0; cc < 16; ++cc) {
+        const double v = (double)cT[jr * 12 + (cc < 12 ? cc : 11)];
+        cW[cc] = (j < 12 && cc < 12) ? v : 0.0;
+      }
+      const double qv = (double)cT[144 + jr];
+      cl = j < 12 ? qv : 0.0;
+    }
+  } else {
+    const S* cp = a.costp + ((size_t)k * a.batch + b) * MF_COSTP;
+    cq = (double)cp[j]; cl = (double)cp[16 + j];
+  }
+  double gW = 0.0;                                           // DENSE: (W [x; u])_j
+  if constexpr (DENSE) md_chain16(gW, w, cW);
   const int dual = du ? a.prob[b].dual : 0;
   const double rho_est0 = a.prob[b].rho_est, rho0 = a.prob[b].rho;
   const double rho = (dual == 2) ? fmin(rho0 * a.penalty_scaling, a.penalty_max) : rho0;   // (what PenaltyUpdate will set)
@@ -725,7 +806,7 @@ __global__ __launch_bounds__(64) void wave_expand_dpp_kernel(IlqrWaveArgs<S> a) 
   }
   if (!on) return;
   if (grad && on_g) {
-    double l = cq * w + cl;
+    double l = DENSE ? gW + cl : cq * w + cl;
     l -= scol;
     if (!terminal) a.cin[(size_t)b * a.cin_bs + (size_t)k * a.cin_ks + MF_OFF_QR + j] = (S)l;
     else if (j < 12) a.term[(size_t)b * MF_TERM + 144 + j] = (S)l;
@@ -736,7 +817,7 @@ __global__ __launch_bounds__(64) void wave_expand_dpp_kernel(IlqrWaveArgs<S> a) 
       if (terminal && (r >= 12 || j >= 12)) continue;
       if (r < 12 && j >= 12) continue;             // the H^T block is not stored
       if (!terminal && r < 12 && j < r) continue;  // nor is the lower triangle of Q
-      double v = (r == j) ? cq : 0.0;
+      double v = DENSE ? cW[r] : ((r == j) ? cq : 0.0);
       v += rho * tile[r];
       if (terminal) a.term[(size_t)b * MF_TERM + r * 12 + j] = (S)v;
       else if (r < 12) a.cin[(size_t)b * a.cin_bs + (size_t)k * a.cin_ks + MF_OFF_Q + mf_sym(r, j)] = (S)v;

@@ -282,6 +282,43 @@ __global__ void wave_expand_grad_kernel(IlqrWaveArgs<S> a) {
   }
 }
 
+// The same for the dense quadratic cost of ALTROSolver::SetQuadraticCost (knotpoint_data.cpp:659-668): lx = Q x + H^T u + q,
+// lu = R u + H x + r, i.e. entry e of W [x; u] + [q r] with W = [Q H^T; H R] read from the dense cost record
+// (IlqrWaveArgs::costd).  The sum runs over [x; u] in order as a chain of fused multiply-adds from zero, then + [q r]_e: the
+// order and operations of the row-layout kernels' DPP chain (kernels/ilqr_merit2_dpp.hip), so the gradient a merit pass
+// leaves behind and this kernel's are the same bits.
+template <typename S>
+__global__ void wave_expand_grad_dense_kernel(IlqrWaveArgs<S> a) {
+  const int64_t total = (int64_t)(a.N + 1) * a.batch * 16;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int e = (int)(t & 15);
+    const int b = (int)((t >> 4) % a.batch);
+    const int k = (int)((t >> 4) / a.batch);
+    if (a.active && !a.active[b]) continue;
+    const bool terminal = k == a.N;
+    if (terminal && e >= 12) continue;
+    const S* c = a.cand + (size_t)b * a.xuy_bs + (size_t)k * a.xuy_ks;
+    double acc = 0.0, lin;
+    if (!terminal) {
+      const S* cd = a.costd + ((size_t)k * a.batch + b) * MF_COST;
+#pragma unroll
+      for (int cc = 0; cc < 16; ++cc) {
+        const double wv = (double)cd[e < 12 ? (cc < 12 ? MF_OFF_Q + mf_sym(e, cc) : MF_OFF_HR + (cc - 12) * 16 + e) : MF_OFF_HR + (e - 12) * 16 + cc];
+        acc = __builtin_fma((double)c[cc < 12 ? cc : 12 + cc], wv, acc);
+      }
+      lin = (double)cd[MF_OFF_QR + e];
+    } else {
+      const S* cT = a.costd_term + (size_t)b * MF_TERM;
+#pragma unroll
+      for (int cc = 0; cc < 12; ++cc) acc = __builtin_fma((double)c[cc], (double)cT[e * 12 + cc], acc);
+      lin = (double)cT[144 + e];
+    }
+    const double l = acc + lin;
+    if (terminal) a.term[(size_t)b * MF_TERM + 144 + e] = (S)l;
+    else a.cin[(size_t)b * a.cin_bs + (size_t)k * a.cin_ks + MF_OFF_QR + e] = (S)l;
+  }
+}
+
 // Expansion at the candidate point, one wave per (problem, knot point).
 //   EXPAND_GRADIENT: lx, lu (+ AL terms) into the backward sweep's [q r] slot (q_N of TERM at k = N)
 //   EXPAND_HESSIAN : [Q H^T; H R] = diag(Qd, Rd) + rho G^T M G  (M = the projection's diagonal Jacobian) into the

@@ -65,6 +65,9 @@ struct IlqrArgs {
   // block of a derivative pass that must not touch the backward pass's input record.  nullptr: the one-launch kernel.
   T* merit_jk;          // [spec_trials][N + 1][batch]
   T* spec_jac;          // [N][n n + n m + n + m][batch] then [n][batch]
+  // 0: `cost` holds the diagonal cost records Qd | Rd | q | r | c (ALTROSolver::SetLQRCost); 1: the dense quadratic ones
+  // Q | R | H | q | r | c (ALTROSolver::SetQuadraticCost, altro_solver.cpp:118-136) -- selects the kernels' CK instantiation
+  int cost_kind = 0;
 };
 constexpr int STAT_NO_FEAS = 32;   // IK_STATIONARITY / IK_DUAL on plan MFMA16: the constraint rows in the DPP form (ilqr_merit2_dpp.hip)
 enum { EXPAND_GRADIENT = 1, EXPAND_HESSIAN = 2, EXPAND_LDS = 16 /* plan MFMA16: wave_expand_kernel instead of the DPP form (A/B, tests) */,
@@ -136,7 +139,16 @@ struct IlqrWaveArgs {
   int mode;                                  // expand kernel: EXPAND_GRADIENT | EXPAND_HESSIAN; rollout kernel: ROLLOUT_INIT
   double penalty_scaling = 10.0, penalty_max = 1e8;   // EXPAND_DUAL: PenaltyUpdate's parameters (solver_options.hpp:27-29)
   const int* skip = nullptr;                 // stationarity kernel: problems whose value wave_merit2_kernel already left
+  // The dense quadratic cost of ALTROSolver::SetQuadraticCost (altro_solver.cpp:118-136, knotpoint_data.cpp:64-85): the cost's own
+  // W = [Q H^T; H R], [q r] and c in the layout of a COST record -- triu(Q) 78 | c | pad | [H R] 64 | [q r] 16 -- for knot points
+  // 0 .. N - 1 (record N: only c_N), and Q_N rows | q_N like TERM.  (The COST records themselves cannot serve: the loop rewrites
+  // their [q r] slot with the gradient, and with constraint blocks their Q / [H R] with the Gauss-Newton Hessian.)  Read by the
+  // row-layout kernels (kernels/ilqr_merit2_dpp.hip) instead of costp when cost_dense != 0.
+  const S* costd = nullptr;                  // [k][b][160]
+  const S* costd_term = nullptr;             // [b][156]
+  int cost_dense = 0;
 };
+constexpr int MF_COSTD_C = 78;    // the constant term c inside a dense cost record (the first pad slot of the COST layout)
 constexpr int ROLLOUT_INIT = 4;   // wave_rollout_kernel also writes the nominal record and the cost gradient (the head of
                                   // Solve for an unconstrained problem: rollout + CopyTrajectory + expansion in one pass)
 

@@ -209,6 +209,16 @@ int altro_hip_add_user_constraint(altro_hip_batch* h, int k_first, int k_last, i
  * with k_stride_zero Qd/xref hold {running, terminal} and Rd/uref one knot point.                   */
 int altro_hip_set_tracking_cost(altro_hip_batch* h, const double* Qd, const double* Rd, const double* xref,
                                 const double* uref, int k_stride_zero, int batch_stride_zero);
+/* ALTROSolver::SetQuadraticCost (altro_solver.cpp:118-136 -> KnotPointData::SetQuadraticCost, knotpoint_data.cpp:64-85) for the
+ * device iLQR loop: the dense cost  1/2 x'Q x + 1/2 u'R u + u'H x + q'x + r'u + c  per knot point, evaluated as
+ * CalcOriginalCost / CalcOriginalCostGradient / CalcOriginalCostHessian do (knotpoint_data.cpp:624-634, :659-668, :691-698:
+ * lx = Q x + H'u + q, lu = R u + H x + r, lxx = Q, luu = R, lux = H).  Column-major blocks as the reference takes them:
+ * Q [batch][N+1][n*n] (symmetric, altro_solver.hpp:183), R [batch][N][m*m], H [batch][N][m*n], q [batch][N+1][n],
+ * r [batch][N][m], c [batch][N+1] or NULL (zero); with k_stride_zero Q / q / c hold {running, terminal} and R / H / r one
+ * knot point.  Replaces a tracking cost set before (and vice versa); altro_hip_update_linear_costs then updates q, r, c of
+ * this cost.  Plans LANE (device models and run-time compiled ones; whole solves run on the launch-sequenced loop) and MFMA16.  */
+int altro_hip_set_quadratic_cost(altro_hip_batch* h, const double* Q, const double* R, const double* H, const double* q,
+                                 const double* r, const double* c, int k_stride_zero, int batch_stride_zero);
 /* ALTROSolver::SetInput over all knot points (altro_solver.cpp:242-251): u [batch][N][m]             */
 int altro_hip_set_input_guess(altro_hip_batch* h, const double* u, int k_stride_zero, int batch_stride_zero);
 int altro_hip_open_loop_rollout(altro_hip_batch* h); /* SolverImpl::OpenLoopRollout solver.cpp:116-131 */

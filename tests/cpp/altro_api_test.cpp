@@ -301,8 +301,57 @@ static void test_pendulum(bool constrained) {
   }
 }
 
+// ALTROSolver::SetQuadraticCost (altro_solver.cpp:118-136) -- a DENSE cost with a cross term,
+// 1/2 x'Qx + 1/2 u'Ru + u'Hx + q'x + r'u + c, on the double integrator (with and without the goal constraint).  The blocks are
+// small closed forms so that tests/test_gpu_cpp_api.py can hand the very same numbers to the oracle
+// (oracle.ILQR(cost_kind = COST_QUADRATIC)) and compare the line printed here: iterations, end state, first input.
+static void quad_blocks(std::vector<double>& Q, std::vector<double>& R, std::vector<double>& H, std::vector<double>& q, std::vector<double>& r) {
+  const double v[4] = {1.0, -1.0, 0.5, 0.25};
+  Q.assign(16, 0.0); R.assign(4, 0.0); H.assign(8, 0.0);
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) Q[i + 4 * j] = (i == j ? 1.0 : 0.0) + 0.1 * v[i] * v[j];
+  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j) R[i + 2 * j] = (i == j ? 1e-2 : 0.0) + 0.005;
+  const double Hr[2][4] = {{0.02, 0.0, -0.02, 0.01}, {0.0, 0.02, 0.01, -0.02}};
+  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 4; ++j) H[i + 2 * j] = Hr[i][j];
+  q = {-0.2, 0.1, 0.05, -0.03};
+  r = {0.01, -0.02};
+}
+static void test_di_quadratic_cost(bool goal) {
+  std::printf("[double integrator] dense quadratic cost (SetQuadraticCost)%s\n", goal ? " + goal constraint" : "");
+  DIProblem p; p.x0 = {1.0, 2.0, 0.0, 0.0};
+  ALTROSolver s(p.N);
+  EXPECT(s.SetDimension(p.n, p.m, 0, LastIndex) == ErrorCodes::NoError);
+  EXPECT(s.SetTimeStep(p.h, 0, LastIndex) == ErrorCodes::NoError);
+  EXPECT(s.SetExplicitDynamics(di_dyn, di_jac, 0, LastIndex) == ErrorCodes::NoError);
+  std::vector<double> Q, R, H, q, r;
+  quad_blocks(Q, R, H, q, r);
+  EXPECT(s.SetQuadraticCost(3, 2, Q.data(), R.data(), H.data(), q.data(), r.data(), 0.3, 0, p.N) == ErrorCodes::DimensionMismatch);
+  EXPECT(s.SetQuadraticCost(p.n, p.m, Q.data(), R.data(), H.data(), q.data(), r.data(), 0.3, 0, p.N) == ErrorCodes::NoError);   // [0, N)
+  std::vector<double> QN(Q);
+  for (double& e : QN) e *= 10.0;
+  EXPECT(s.SetQuadraticCost(p.n, p.m, QN.data(), R.data(), H.data(), q.data(), r.data(), 0.1, p.N) == ErrorCodes::NoError);      // terminal
+  EXPECT(s.SetInitialState(p.x0.data(), p.n) == ErrorCodes::NoError);
+  if (goal) di_goal(s, p);
+  EXPECT(s.Initialize() == ErrorCodes::NoError);
+  di_guess(s, p);
+  AltroOptions o; o.iterations_max = 20;
+  s.SetOptions(o);
+  const SolveStatus st = s.Solve();
+  EXPECT(st == SolveStatus::Success);
+  std::vector<double> xN(4), u0(2);
+  s.GetState(xN.data(), p.N);
+  s.GetInput(u0.data(), 0);
+  std::printf("   quadratic%s: status %d iterations %d xN %.17g %.17g %.17g %.17g u0 %.17g %.17g objective %.17g\n", goal ? "_goal" : "", (int)st,
+              s.GetIterations(), xN[0], xN[1], xN[2], xN[3], u0[0], u0[1], (double)s.GetFinalObjective());
+  if (goal) EXPECT(dist(xN, p.xf) < 1e-4);
+}
+
 int main() {
   test_constructor_and_errors();
+  test_di_quadratic_cost(false);
+  test_di_quadratic_cost(true);
   test_di_unconstrained();
   test_di_unconstrained_n50();
   test_di_goal();

@@ -20,7 +20,7 @@ from tests import problems         # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden", "dense_fixtures.npz")
 from tests.golden_cases import (AL_KINDS, MERIT_ALPHAS, P_KNOTS, REG_CASE, SOLVES, TVLQR, al_case, checksum, load_kats,   # noqa: E402,F401
-                                lq12_case, merit_case, mpc_case, mpc_linear_costs, solve_case, tvlqr_problem)
+                                lq12_case, merit_case, mpc_case, mpc_linear_costs, quad12_case, quad4_case, solve_case, tvlqr_problem)
 
 OKIND = {"double_integrator": oracle.MODEL_DI, "pendulum": oracle.MODEL_PENDULUM, "bicycle": oracle.MODEL_BICYCLE}
 
@@ -145,6 +145,67 @@ def oracle_lq12(constrained):
     return {k: np.array(v) for k, v in out.items()}
 
 
+# ---- round 4: the dense quadratic cost of ALTROSolver::SetQuadraticCost in the iLQR loop (row a9) -----------------------------
+def _set_quadratic(s, cost, b, N):
+    for k in range(N + 1):
+        kk = min(k, N - 1)
+        s.L.oracle_ilqr_set_quadratic_cost(s.h, k, np.ascontiguousarray(cost["Q"][b, k]), np.ascontiguousarray(cost["R"][b, kk]).ctypes.data,
+                                           np.ascontiguousarray(cost["H"][b, kk]).ctypes.data, np.ascontiguousarray(cost["q"][b, k]),
+                                           np.ascontiguousarray(cost["r"][b, kk]).ctypes.data, float(cost["c"][b, k]))
+
+
+def _quad12_oracle(c, b):
+    p, N = c["p"], c["N"]
+    s = oracle.ILQR(N, 12, 4, 0.01, oracle.DYN_LINEAR, cost_kind=oracle.COST_QUADRATIC)
+    s.L.oracle_ilqr_set_linear_dynamics(s.h, np.ascontiguousarray(p["A"][b]), np.ascontiguousarray(p["B"][b]),
+                                        np.ascontiguousarray(p["f"][b]).ctypes.data)
+    _set_quadratic(s, p, b, N)
+    s.L.oracle_ilqr_set_initial_state(s.h, np.ascontiguousarray(p["x0"][b]))
+    for (k0, k1, cone, G, g) in c["blocks"]:
+        for k in range(k0, k1 + 1):
+            s.add_linear_constraint(k, cone, G, g)
+    s.L.oracle_ilqr_initialize(s.h)
+    for k in range(N):
+        s.L.oracle_ilqr_set_input(s.h, k, np.ascontiguousarray(p["u0"][b, k]))
+    return s
+
+
+def _solve_rows(make, nprob, constrained, itmax):
+    out = dict(x=[], u=[], status=[], iterations=[], feasibility=[])
+    for b in range(nprob):
+        s = make(b)
+        if constrained:
+            s.set_penalty(1.0, 10.0)
+        s.L.oracle_ilqr_set_options(s.h, itmax, 1e-4, 1e-4, 1e-8, 0)
+        status, iters, log = s.solve()
+        out["x"].append(s.get("x")); out["u"].append(s.get("u")); out["status"].append(status); out["iterations"].append(iters)
+        out["feasibility"].append(log[iters - 1, 6] if iters > 0 else 0.0)
+    return {k: np.array(v) for k, v in out.items()}
+
+
+def oracle_quad12(constrained):
+    c = quad12_case(constrained)
+    return _solve_rows(lambda b: _quad12_oracle(c, b), c["p"]["x0"].shape[0], constrained, c["itmax"])
+
+
+def _quad4_oracle(c, b):
+    s = oracle.ILQR(c["N"], c["n"], c["m"], c["h"], oracle.DYN_MODEL, OKIND[c["model_name"]], model_dim=c["dim"], cost_kind=oracle.COST_QUADRATIC)
+    _set_quadratic(s, c["cost"], b, c["N"])
+    s.L.oracle_ilqr_set_initial_state(s.h, np.ascontiguousarray(c["x0s"][b], dtype=float))
+    for (k0, k1, cone, G, g) in c["blocks"]:
+        for k in range(k0, k1 + 1):
+            s.add_linear_constraint(k, cone, G, g)
+    s.L.oracle_ilqr_initialize(s.h)
+    for k in range(c["N"]):
+        s.L.oracle_ilqr_set_input(s.h, k, np.ascontiguousarray(c["u0"], dtype=float))
+    return s
+
+
+def oracle_quad4(constrained):
+    c = quad4_case(constrained)
+    return _solve_rows(lambda b: _quad4_oracle(c, b), len(c["x0s"]), constrained, c["itmax"])
+
+
 def _merit_rows(make, nprob):
     """For every problem and every alpha of MERIT_ALPHAS (problem-major): phi, phi', candidate, expansion at it, stationarity."""
     keys = ("phi", "dphi", "x", "u", "y", "lx", "lu", "A", "B", "stationarity", "K")
@@ -166,6 +227,12 @@ def _merit_rows(make, nprob):
 
 
 def oracle_merit(name):
+    if name == "quad12":
+        c = quad12_case(False)
+        return _merit_rows(lambda b: _quad12_oracle(c, b), c["p"]["x0"].shape[0])
+    if name == "quad4":
+        c = quad4_case(False)
+        return _merit_rows(lambda b: _quad4_oracle(c, b), len(c["x0s"]))
     if name == "lq12":
         c = lq12_case(False)
         return _merit_rows(lambda b: _lq12_oracle(c, b), c["p"]["x0"].shape[0])
@@ -220,6 +287,14 @@ def generate():
             data["merit_%s_%s" % (name, k)] = v
     for k, v in oracle_reg().items():
         data["tvlqr_%s" % k] = v
+    for constrained in (False, True):
+        for k, v in oracle_quad12(constrained).items():
+            data["quad12_%s_%s" % ("al" if constrained else "lq", k)] = v
+        for k, v in oracle_quad4(constrained).items():
+            data["quad4_%s_%s" % ("al" if constrained else "lq", k)] = v
+    for name in ("quad12", "quad4"):
+        for k, v in oracle_merit(name).items():
+            data["merit_%s_%s" % (name, k)] = v
     return data
 
 

@@ -109,6 +109,26 @@ def lq12_case(constrained):
     return dict(N=N, p=p, blocks=problems.ilqr12x4_constraint_blocks(N) if constrained else [], itmax=60 if constrained else 10)
 
 
+def quad12_case(constrained):
+    """Row a9 on plan MFMA16: the same (12, 4) problems with the DENSE quadratic cost of ALTROSolver::SetQuadraticCost
+    (Q, R, H != 0, q, r, c per problem and knot point: problems.quadratic_cost) instead of the tracking cost."""
+    c = lq12_case(constrained)
+    c["p"] = dict(c["p"], **problems.quadratic_cost(4, c["N"], 12, 4))
+    return c
+
+
+def quad4_case(constrained):
+    """Row a9 on plan LANE: the bicycle (4, 2) with the dense quadratic cost, with and without input bounds |u| <= 0.4."""
+    N, n, m = 20, 4, 2
+    x0s = 0.02 * (np.arange(3 * 4).reshape(3, 4) % 7 - 3) / 3.0
+    blocks = []
+    if constrained:
+        Gb = np.zeros((2 * m, n + m)); Gb[:m, n:] = np.eye(m); Gb[m:, n:] = -np.eye(m)
+        blocks = [(0, N - 1, problems.CONE_INEQUALITY, Gb, np.full(2 * m, 0.4))]
+    return dict(N=N, n=n, m=m, h=np.float32(0.1), model=3, model_name="bicycle", dim=0, u0=[0.5, 0.0], x0s=x0s,
+                cost=problems.quadratic_cost(3, N, n, m), blocks=blocks, itmax=40)
+
+
 MERIT_ALPHAS = (0.0, 0.35, 1.0)
 
 

@@ -188,3 +188,18 @@ def ilqr12x4_constraint_blocks(N, n=12, m=4):
     return [(0, N - 1, CONE_INEQUALITY, Gb, np.full(2 * m, 0.3)),
             (1, N - 1, CONE_INEQUALITY, Gs, np.array([1.2, 1.2])),
             (0, 0, CONE_EQUALITY, Ge, np.array([0.05]))]
+
+
+def quadratic_cost(batch, N, n, m, stream=81):
+    """A dense quadratic cost per problem and knot point, in the blocks ALTROSolver::SetQuadraticCost takes
+    (altro_solver.cpp:118-136, column-major): Q = I + 0.1 L L^T (n x n, symmetric positive definite), R = 0.1 I + 0.02 M M^T,
+    H = 0.03 N(0, 1) (m x n: small enough that [Q H^T; H R] stays positive definite), q, r ~ N(0, 0.3^2), c ~ U(0, 1).
+    Shapes: Q [batch][N+1][n*n], R [batch][N][m*m], H [batch][N][m*n], q [batch][N+1][n], r [batch][N][m], c [batch][N+1]."""
+    L = normal((batch, N + 1, n, n), stream)
+    Q = np.eye(n) + 0.1 * L @ np.swapaxes(L, -1, -2)
+    M = normal((batch, N, m, m), stream + 1)
+    R = 0.1 * np.eye(m) + 0.02 * M @ np.swapaxes(M, -1, -2)
+    H = 0.03 * normal((batch, N, m, n), stream + 2)
+    col = lambda X: np.ascontiguousarray(np.swapaxes(X, -1, -2)).reshape(X.shape[0], X.shape[1], -1)   # column-major blocks
+    return dict(Q=col(Q), R=col(R), H=col(H), q=0.3 * normal((batch, N + 1, n), stream + 3), r=0.3 * normal((batch, N, m), stream + 4),
+                c=uniform01((batch, N + 1), stream + 5))

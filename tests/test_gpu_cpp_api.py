@@ -30,6 +30,45 @@ def test_altro_solver_cpp_api_integration():
     assert "iterations = 3, dist" in out and "iterations = 5, dist" in out and "iterations = 9, dist" in out
 
 
+def test_altro_solver_set_quadratic_cost_matches_the_oracle():
+    """SURVEY.md section 8 row a9 through the public C++ class: ALTROSolver::SetQuadraticCost (altro_solver.cpp:118-136) with a cross
+    term H != 0 on the double integrator, with and without the goal constraint -- tests/cpp/altro_api_test.cpp prints iterations,
+    end state and first input; the same blocks go to oracle.ILQR(cost_kind = COST_QUADRATIC) here."""
+    import numpy as np
+    from oracle import oracle
+    rc, out, err = cpp_build.run("altro_api_test")
+    assert rc == 0, out + err
+    v = np.array([1.0, -1.0, 0.5, 0.25])
+    Q = np.eye(4) + 0.1 * np.outer(v, v)
+    R = 1e-2 * np.eye(2) + 0.005
+    H = np.array([[0.02, 0.0, -0.02, 0.01], [0.0, 0.02, 0.01, -0.02]])
+    q, r = np.array([-0.2, 0.1, 0.05, -0.03]), np.array([0.01, -0.02])
+    N, h = 10, np.float32(0.5)
+    col = lambda M: np.ascontiguousarray(M.T).ravel()
+    for goal in (False, True):
+        tag = "quadratic_goal:" if goal else "quadratic:"
+        line = [l for l in out.splitlines() if l.strip().startswith(tag)]
+        assert len(line) == 1, out
+        w = line[0].split()
+        status, iters = int(w[2]), int(w[4])
+        xN, u0 = np.array([float(t) for t in w[6:10]]), np.array([float(t) for t in w[11:13]])
+        s = oracle.ILQR(N, 4, 2, h, oracle.DYN_MODEL, oracle.MODEL_DI, model_dim=2, cost_kind=oracle.COST_QUADRATIC)
+        for k in range(N + 1):
+            s.L.oracle_ilqr_set_quadratic_cost(s.h, k, col(10.0 * Q if k == N else Q), col(R).ctypes.data, col(H).ctypes.data,
+                                               np.ascontiguousarray(q), np.ascontiguousarray(r).ctypes.data, 0.1 if k == N else 0.3)
+        s.L.oracle_ilqr_set_initial_state(s.h, np.array([1.0, 2.0, 0.0, 0.0]))
+        if goal:
+            s.add_linear_constraint(N, oracle.CONE_EQUALITY, np.hstack([np.eye(4), np.zeros((4, 2))]), np.zeros(4))
+        s.L.oracle_ilqr_initialize(s.h)
+        for k in range(N):
+            s.L.oracle_ilqr_set_input(s.h, k, np.zeros(2))
+        s.L.oracle_ilqr_set_options(s.h, 20, 1e-4, 1e-4, 1e-8, 0)
+        st_o, it_o, log = s.solve()
+        assert status == st_o == 0 and iters == it_o, (goal, status, st_o, iters, it_o)
+        np.testing.assert_allclose(xN, s.get("x")[N], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(u0, s.get("u")[0], rtol=1e-8, atol=1e-8)
+
+
 def test_batch_solver_cpp_wrapper():
     """include/altro_hip/altro_hip.hpp (header-only C++ over the C ABI): the constrained double integrator of
     test/double_integrator_test.cpp:258-376 for a batch of 100 -- 5 iterations, goal reached, controls saturated."""

@@ -219,6 +219,77 @@ def test_merit_expansion_stationarity_against_dense_fixture(mk, dense, name):
     bt.close()
 
 
+def _quad_batch(mk, name, constrained, repeat=1):
+    if name == "quad12":
+        c = mk.quad12_case(constrained)
+        p = {k: (np.repeat(v, repeat, axis=0) if v is not None else None) for k, v in c["p"].items()}
+        bt = altro_amd.Batch(c["N"], 12, 4, p["x0"].shape[0])
+        assert bt.plan == altro_amd.PLAN_MFMA16
+        bt.set_dynamics(p["A"], p["B"], p["f"])
+        bt.set_quadratic_cost(p["Q"], p["R"], p["H"], p["q"], p["r"], p["c"])
+        bt.set_initial_state(p["x0"]); bt.set_input_guess(p["u0"])
+        nprob = c["p"]["x0"].shape[0]
+    else:
+        c = mk.quad4_case(constrained)
+        cost = {k: np.repeat(v, repeat, axis=0) for k, v in c["cost"].items()}
+        x0s = np.repeat(np.asarray(c["x0s"], dtype=float), repeat, axis=0)
+        bt = altro_amd.Batch(c["N"], c["n"], c["m"], x0s.shape[0])
+        assert bt.plan == altro_amd.PLAN_LANE
+        bt.set_model(c["model"], c["h"])
+        bt.set_quadratic_cost(cost["Q"], cost["R"], cost["H"], cost["q"], cost["r"], cost["c"])
+        bt.set_initial_state(x0s)
+        bt.set_input_guess(np.asarray(c["u0"], dtype=float)[None, None], k_stride_zero=True, batch_stride_zero=True)
+        nprob = len(c["x0s"])
+    for (k0, k1, cone, G, g) in c["blocks"]:
+        bt.add_linear_constraint(k0, k1, cone, G, g)
+    return bt, c, nprob
+
+
+@pytest.mark.parametrize("name", ["quad12", "quad4"])
+@pytest.mark.parametrize("constrained", [False, True])
+def test_dense_quadratic_cost_solves_against_dense_fixture(mk, dense, name, constrained):
+    """Row a9 (knotpoint_data.cpp:616-708 in the device loop): whole solves with the dense cost Q, R, H != 0 of
+    ALTROSolver::SetQuadraticCost, plan MFMA16 at (12, 4) and plan LANE at (4, 2), with and without constraint blocks."""
+    bt, c, nprob = _quad_batch(mk, name, constrained)
+    res = bt.ilqr_solve(iterations_max=c["itmax"], penalty_initial=1.0, penalty_scaling=10.0)
+    tag = "%s_%s" % (name, "al" if constrained else "lq")
+    assert res["status"].tolist() == dense[tag + "_status"].tolist()
+    assert res["iterations"].tolist() == dense[tag + "_iterations"].tolist()
+    x, u = bt.get_nominal()
+    tol = (1e-7 if constrained else 1e-9) if name == "quad12" else 2e-7
+    assert np.abs(x - dense[tag + "_x"]).max() < tol
+    assert np.abs(u - dense[tag + "_u"]).max() < tol * 10
+    if constrained:
+        ref = dense[tag + "_feasibility"]
+        assert (np.abs(res["feasibility"] - ref) <= 1e-9 + 1e-3 * ref).all()
+    bt.close()
+
+
+@pytest.mark.parametrize("name", ["quad12", "quad4"])
+def test_dense_quadratic_cost_merit_rows_against_dense_fixture(mk, dense, name):
+    """Row a9 in one merit evaluation with derivative at alpha = 0, 0.35, 1: phi (with u'Hx), phi', candidates, the refreshed
+    lx = Qx + H'u + q and lu = Ru + Hx + r (plan LANE: read back; plan MFMA16: through the stationarity), gains from lux = H."""
+    na = len(mk.MERIT_ALPHAS)
+    bt, c, nprob = _quad_batch(mk, name, False, repeat=na)
+    tol = 1e-9 if name == "quad12" else 1e-10
+    bt.open_loop_rollout(); bt.accept(); bt.expand(); bt.backward()
+    assert (bt.get("status") == -1).all()
+    assert relerr(bt.get("K"), dense["merit_%s_K" % name]) < tol * 10
+    phi, dphi = bt.merit(np.tile(np.array(mk.MERIT_ALPHAS), nprob))
+    assert relerr(phi, dense["merit_%s_phi" % name]) < tol * 10
+    assert relerr(dphi, dense["merit_%s_dphi" % name]) < tol * 100
+    for k in ("x", "u", "y"):
+        assert relerr(bt.get(k), dense["merit_%s_%s" % (name, k)]) < tol * 10, k
+    if name == "quad4":
+        A, B, lx, lu = bt.get_expansion()
+        for k, v in (("A", A), ("B", B), ("lx", lx), ("lu", lu)):
+            assert relerr(v, dense["merit_%s_%s" % (name, k)]) < tol * 10, k
+    st = bt.stationarity()
+    ref = dense["merit_%s_stationarity" % name]
+    assert (np.abs(st - ref) <= 1e-8 * np.maximum(1.0, np.abs(ref))).all()
+    bt.close()
+
+
 def test_regularised_backward_pass_against_dense_fixture(mk, dense):
     """Row f4 / a1's reg argument (tvlqr.cpp:159-164): reg > 0 on plan LANE (bit-identical), and the failing knot point of
     an indefinite R as the status."""

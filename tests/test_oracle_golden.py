@@ -39,6 +39,24 @@ def test_solve_fixture_is_what_the_oracle_computes(dense, name):
         assert out["status"].tolist() == [0] and out["iterations"][0] <= 3
 
 
+def test_round4_dense_cost_fixtures_are_what_the_oracle_computes(dense):
+    """Row a9: the dense quadratic cost (ALTROSolver::SetQuadraticCost) in whole solves on both plans' shapes and in the
+    merit / expansion rows, regenerated and compared."""
+    for constrained in (False, True):
+        tag = "al" if constrained else "lq"
+        for name, fn in (("quad12", mk.oracle_quad12), ("quad4", mk.oracle_quad4)):
+            out = fn(constrained)
+            assert (out["status"] == 0).all()
+            for k, v in out.items():
+                ref = dense["%s_%s_%s" % (name, tag, k)]
+                assert np.abs(np.asarray(v, dtype=float) - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max()), (name, constrained, k)
+    for name in ("quad12", "quad4"):
+        out = mk.oracle_merit(name)
+        for k, v in out.items():
+            ref = dense["merit_%s_%s" % (name, k)]
+            assert np.abs(v - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max()), (name, k)
+
+
 @pytest.mark.parametrize("group", ["al", "mpc", "lq12", "merit", "reg"])
 def test_round3_fixtures_are_what_the_oracle_computes(dense, group):
     """The constrained solves (3 / 5 / 9 iterations for the reference's own start), the MPC loop, the (12, 4) iLQR solves, the
