@@ -21,7 +21,7 @@ TVLQR_SUCCESS = -1
 
 # every symbol include/altro_hip/altro_hip.h declares (tests check the .so exports all of them)
 C_ABI_SYMBOLS = [
-    "altro_hip_version", "altro_hip_last_error", "altro_hip_device_count", "altro_hip_device_info",
+    "altro_hip_version", "altro_hip_last_error", "altro_hip_device_count", "altro_hip_device_info", "altro_hip_device_pci_bus_id",
     "altro_hip_batch_create", "altro_hip_batch_destroy", "altro_hip_batch_plan",
     "altro_hip_batch_device_bytes", "altro_hip_set_dynamics", "altro_hip_set_cost",
     "altro_hip_set_initial_state", "altro_hip_set_host_batch", "altro_hip_backward", "altro_hip_forward_ltv", "altro_hip_sweep",
@@ -128,6 +128,7 @@ def lib():
         vp, i, d = C.c_void_p, C.c_int, C.c_double
         L.altro_hip_last_error.restype = C.c_char_p
         L.altro_hip_device_info.argtypes = [i, C.c_char_p, i, C.POINTER(i), C.POINTER(i)]
+        L.altro_hip_device_pci_bus_id.argtypes = [i, C.c_char_p, i]
         L.altro_hip_batch_create.argtypes = [C.POINTER(vp), i, i, i, i, i, i, C.c_uint, i, vp]
         L.altro_hip_batch_destroy.argtypes = [vp]
         L.altro_hip_batch_destroy.restype = None
@@ -205,6 +206,16 @@ def lib():
 def _check(rc):
     if rc != 0:
         raise AltroHipError("altro_hip error %d: %s" % (rc, lib().altro_hip_last_error().decode()))
+
+
+def device_info(device=0):
+    """-> (name, compute units, PCI bus id) of a HIP device."""
+    L = lib()
+    name, pci = C.create_string_buffer(256), C.create_string_buffer(64)
+    cus, ws = C.c_int(), C.c_int()
+    _check(L.altro_hip_device_info(int(device), name, 256, C.byref(cus), C.byref(ws)))
+    _check(L.altro_hip_device_pci_bus_id(int(device), pci, 64))
+    return name.value.decode(), cus.value, pci.value.decode()
 
 
 def _in(a):

@@ -67,6 +67,14 @@ int altro_hip_device_info(int device, char* name, int cap, int* compute_units, i
   return 0;
 }
 
+int altro_hip_device_pci_bus_id(int device, char* buf, int cap) {
+  if (device < 0 || device >= altro_hip_device_count())
+    return fail(ALTRO_HIP_ERR_NO_DEVICE, "no HIP device %d (count = %d)", device, altro_hip_device_count());
+  if (!buf || cap < 16) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "buf == NULL or cap < 16");
+  HIP_TRY(hipDeviceGetPCIBusId(buf, cap, device));
+  return 0;
+}
+
 int altro_hip_batch_create(altro_hip_batch** out, int N, int n, int m, int batch, int dtype, int plan,
                            unsigned flags, int device, void* stream) {
   if (!out) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "out == NULL");

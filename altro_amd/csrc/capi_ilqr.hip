@@ -136,14 +136,15 @@ int spec_trials_cap(const altro_hip_batch* h) {
   if (h->plan != ALTRO_HIP_PLAN_LANE) return ILQR_SPEC_TRIALS;   // MFMA16: the searching problems alone decide
   const int64_t units = (h->batch + 63) / 64;
   int t = ILQR_SPEC_TRIALS;
-  while (t > 4 && units * t * 2 > 512) t /= 2;
+  while (t > 4 && units * t > 512) t /= 2;   // the solve loop widens while units * (2 * trials) <= 512: the widest launch is units * t
   return t;
 }
 // `count` spare candidate trajectories (grown on demand, never shrunk); false = no memory for them (nothing is changed)
 bool ensure_spares(altro_hip_batch* h, int count, size_t bytes_each) {
   if (h->spare_count >= count) return true;
+  if (h->spare_failed > 0 && count >= h->spare_failed) return false;   // this size did not fit before: do not ask again
   void* fresh = nullptr;
-  if (hipMalloc(&fresh, (size_t)count * bytes_each) != hipSuccess) { (void)hipGetLastError(); return false; }
+  if (hipMalloc(&fresh, (size_t)count * bytes_each) != hipSuccess) { (void)hipGetLastError(); h->spare_failed = count; return false; }
   if (h->i_cand_spec) { (void)hipStreamSynchronize(h->stream); (void)hipFree(h->i_cand_spec); h->device_bytes -= (size_t)h->spare_count * bytes_each; }
   h->i_cand_spec = fresh;
   h->spare_count = count;
@@ -798,11 +799,13 @@ int altro_hip_ilqr_wait(altro_hip_batch* h, altro_hip_solve_result* results) {
   if (rc) return rc;
   if (!h->poll_host) return fail(ALTRO_HIP_ERR_NOT_SET, "altro_hip_ilqr_solve_async has not been called");
   HIP_TRY(hipStreamSynchronize(h->stream));
-  h->async_pending = false;
-  int c4[4];
-  HIP_TRY(hipMemcpy(c4, h->i_counters, sizeof(c4), hipMemcpyDeviceToHost));
-  h->last_sweeps = c4[3];
-  h->last_merit_launches = 0;
+  if (h->async_pending) {   // the books of THAT solve: a later synchronous solve, or a second wait, keeps its own counts
+    h->async_pending = false;
+    int c4[4];
+    HIP_TRY(hipMemcpy(c4, h->i_counters, sizeof(c4), hipMemcpyDeviceToHost));
+    h->last_sweeps = c4[3];
+    h->last_merit_launches = 0;
+  }
   if (results) return ilqr_gather_results(h, results);
   return 0;
 }
@@ -964,7 +967,7 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
     const int clk_G = ilqr_fused_group(h->batch);
     const int clk_groups = (h->batch + clk_G - 1) / clk_G;
     unsigned long long* clk = nullptr;     // ALTRO_HIP_FUSED_CLOCK: per-phase time of the kernel, printed to stderr
-    if (std::getenv("ALTRO_HIP_FUSED_CLOCK") != nullptr) {
+    if (std::getenv("ALTRO_HIP_FUSED_CLOCK") != nullptr && !async) {   // (an async solve returns before the clock could be read or freed)
       const size_t bytes = (size_t)clk_groups * ILQR_FUSED_PHASES * sizeof(unsigned long long);
       if (hipMalloc((void**)&clk, bytes) == hipSuccess) { (void)hipMemsetAsync(clk, 0, bytes, h->stream); fa.clk = clk; }
     }

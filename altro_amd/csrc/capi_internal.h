@@ -87,6 +87,7 @@ struct altro_hip_batch {
   int rtc_ck = 0;
   int x0_stride = 0;              // elements between two problems' x0 on the device (12 on plan MFMA16, else n)
   int spare_count = 0;            // spare candidate trajectories i_cand_spec holds (sized to the path in use, see spec_trials_cap)
+  int spare_failed = 0;           // > 0: an allocation of this many spares failed on this handle (no retry at this size or above)
   int *i_spec_sel = nullptr, *i_spec_refresh = nullptr;
   int* i_stat_done = nullptr;     // plan MFMA16's dual merit evaluation (IlqrLoopArgs::stat_done)
   const int* stat_skip = nullptr; // set while a solve's IK_STATIONARITY launches may skip those problems

@@ -3,9 +3,10 @@
 // problem instances are sharded over the GPUs of a node and never talk during sweeps; the
 // only thing that crosses GPUs is what SolverImpl::Solve reports (solver.cpp:464-469, :492-509; AltroStats,
 // solver_stats.hpp:14-25), summed / maximised over the problems:
-//     ncclSum over {problems, Cholesky failures, converged, iterations, cost, delta_V0, delta_V1,
-//                   problems with a non-finite result}                                              (8 doubles)
-//     ncclMax over {stationarity, feasibility, |x_N|}                                               (3 doubles)
+//     ncclSum, ncclInt64  over {problems, Cholesky failures, converged, iterations, problems with a non-finite result}
+//     ncclSum, ncclDouble over {cost, delta_V0, delta_V1}
+//     ncclMax, ncclDouble over {stationarity, feasibility, |x_N|}
+// (the counts travel as the 64-bit integers SURVEY 8(e) names: the reduced vector holds their bit patterns in its first five slots)
 // Per GPU the reduction is a deterministic two-stage kernel pair (fixed tree order: the result does not depend on
 // scheduling), so nothing but 16 doubles ever goes to the host.  RCCL is resolved with dlopen at first use -- the
 // copy the process already has (torch's, an MPI program's) if there is one -- so libaltro_hip.so itself links only
@@ -13,8 +14,12 @@
 #include "capi_internal.h"
 
 #include <dlfcn.h>
+#include <chrono>
+#include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <rccl/rccl.h>   // types and prototypes only; every call goes through the table below
 
 using namespace altro_hip;
@@ -23,7 +28,8 @@ using namespace altro_hip::capi;
 namespace {
 
 // positions inside the reduced vector (device, kStatsStride doubles)
-enum { ST_PROBLEMS = 0, ST_CHOL, ST_CONVERGED, ST_ITERATIONS, ST_COST, ST_DV0, ST_DV1, ST_NONFINITE, ST_NSUM,
+enum { ST_PROBLEMS = 0, ST_CHOL, ST_CONVERGED, ST_ITERATIONS, ST_NONFINITE, ST_NINT /* the counts */,
+       ST_COST = 5, ST_DV0, ST_DV1, ST_NSUM /* end of the sums */,
        ST_MAX0 = 8, ST_MAX_STAT = 8, ST_MAX_FEAS, ST_MAX_XN, ST_NMAX = 3 };
 
 struct StatsIn {
@@ -99,7 +105,9 @@ __global__ __launch_bounds__(64) void stats_final_kernel(const double* __restric
   if (i < ST_NSUM) for (int k = 0; k < nblk; ++k) v += partial[(size_t)k * kStatsStride + i];    // in block order
   else if (i >= ST_MAX0 && i < ST_MAX0 + ST_NMAX)
     for (int k = 0; k < nblk; ++k) v = nanmax(v, partial[(size_t)k * kStatsStride + i]);
-  red[i] = v;
+  // the counts leave as 64-bit integers (exact: they were whole numbers below 2^53 all along)
+  if (i < ST_NINT) reinterpret_cast<long long*>(red)[i] = (long long)llrint(v);
+  else red[i] = v;
 }
 
 // enqueue the local reduction of h on its stream; h->st_red then holds the vector
@@ -131,17 +139,19 @@ int stats_read(altro_hip_batch* h, altro_hip_stats* out) {
   double v[kStatsStride];
   HIP_TRY(hipMemcpyAsync(v, h->st_red, sizeof(v), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
-  out->problems = (int64_t)llround(v[ST_PROBLEMS]);
-  out->cholesky_failures = (int64_t)llround(v[ST_CHOL]);
-  out->converged = (int64_t)llround(v[ST_CONVERGED]);
-  out->iterations = (int64_t)llround(v[ST_ITERATIONS]);
+  int64_t cnt[ST_NINT];
+  std::memcpy(cnt, v, sizeof(cnt));
+  out->problems = cnt[ST_PROBLEMS];
+  out->cholesky_failures = cnt[ST_CHOL];
+  out->converged = cnt[ST_CONVERGED];
+  out->iterations = cnt[ST_ITERATIONS];
   out->sum_cost = v[ST_COST];
   out->sum_delta_V0 = v[ST_DV0];
   out->sum_delta_V1 = v[ST_DV1];
   out->max_stationarity = v[ST_MAX_STAT];
   out->max_feasibility = v[ST_MAX_FEAS];
   out->max_abs_xN = v[ST_MAX_XN];
-  out->non_finite = (int64_t)llround(v[ST_NONFINITE]);
+  out->non_finite = cnt[ST_NONFINITE];
   return 0;
 }
 
@@ -209,7 +219,8 @@ struct altro_hip_comm {
 
 namespace {
 int enqueue_allreduce(const Rccl* R, altro_hip_batch* h, altro_hip_comm* c) {
-  RCCL_TRY(R, R->AllReduce(h->st_red, h->st_red, ST_NSUM, ncclDouble, ncclSum, c->comm, h->stream));
+  RCCL_TRY(R, R->AllReduce(h->st_red, h->st_red, ST_NINT, ncclInt64, ncclSum, c->comm, h->stream));
+  RCCL_TRY(R, R->AllReduce(h->st_red + ST_NINT, h->st_red + ST_NINT, ST_NSUM - ST_NINT, ncclDouble, ncclSum, c->comm, h->stream));
   RCCL_TRY(R, R->AllReduce(h->st_red + ST_MAX0, h->st_red + ST_MAX0, ST_NMAX, ncclDouble, ncclMax, c->comm, h->stream));
   return 0;
 }
@@ -250,13 +261,31 @@ int altro_hip_comm_create(altro_hip_comm** out, int device, int rank, int world,
   HIP_TRY(hipSetDevice(device));
   ncclUniqueId u;
   std::memcpy(&u, id, sizeof(u));
-  altro_hip_comm* c = new altro_hip_comm();
-  c->device = device; c->rank = rank; c->world = world;
-  ncclResult_t r = R->CommInitRank(&c->comm, world, u, rank);
-  if (r != ncclSuccess) {
-    delete c;
-    return fail(ALTRO_HIP_ERR_HIP, "ncclCommInitRank(rank %d of %d, device %d) failed: %s", rank, world, device, R->GetErrorString(r));
+  // ncclCommInitRank blocks until every rank of the world has called it: a rank that never arrives (died at start-up, bound to
+  // the wrong device, a unique id that was not the one rank 0 made) would hang the others for good.  It runs on a helper thread
+  // and this call gives up after ALTRO_HIP_COMM_TIMEOUT_S seconds (default 120) with a message that says what was waited for.
+  struct InitState { std::mutex mu; std::condition_variable cv; bool done = false; ncclResult_t res = ncclSuccess; ncclComm_t comm = nullptr; };
+  auto st = std::make_shared<InitState>();
+  double timeout_s = 120.0;
+  if (const char* e = std::getenv("ALTRO_HIP_COMM_TIMEOUT_S")) { const double v = std::atof(e); if (v > 0.0) timeout_s = v; }
+  std::thread([st, R, world, u, rank, device]() {
+    ncclComm_t cm = nullptr;
+    ncclResult_t r = (hipSetDevice(device) == hipSuccess) ? R->CommInitRank(&cm, world, u, rank) : ncclUnhandledCudaError;
+    std::lock_guard<std::mutex> lock(st->mu);
+    st->res = r; st->comm = cm; st->done = true;
+    st->cv.notify_all();
+  }).detach();
+  {
+    std::unique_lock<std::mutex> lock(st->mu);
+    if (!st->cv.wait_for(lock, std::chrono::duration<double>(timeout_s), [&] { return st->done; }))
+      return fail(ALTRO_HIP_ERR_HIP, "ncclCommInitRank(rank %d of %d, device %d) did not return within %.0f s: not every rank of the world "
+                                     "joined (a rank that died, a wrong device binding or unique id); ALTRO_HIP_COMM_TIMEOUT_S changes the limit",
+                  rank, world, device, timeout_s);
   }
+  if (st->res != ncclSuccess)
+    return fail(ALTRO_HIP_ERR_HIP, "ncclCommInitRank(rank %d of %d, device %d) failed: %s", rank, world, device, R->GetErrorString(st->res));
+  altro_hip_comm* c = new altro_hip_comm();
+  c->device = device; c->rank = rank; c->world = world; c->comm = st->comm;
   *out = c;
   return 0;
 }

@@ -59,10 +59,18 @@ def parse():
                          "(pendulum n=2 m=1 N=100 batch=8192), c3 = configs[3] (bicycle n=4 m=2 N=50 batch=65536 "
                          "per node, with the steering bound), c4 = configs[4] (random LTV n=12 m=4 N=512 "
                          "batch=16384, fp32 storage)")
-    ap.add_argument("--live-traffic", action="store_true",
-                    help="measure roofline.traffic in THIS run: two short rocprofv3 passes of this same command (--kernel-trace "
-                         "--pmc FETCH_SIZE, then WRITE_SIZE; each counter in its own pass, nothing else traced) before the timed "
-                         "region, ~1 minute.  Default: the tracked figure of profiles/pmc_traffic.json, labelled as such")
+    ap.add_argument("--live-traffic", action="store_true", help="(the default at one GPU; kept for older command lines)")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not measure roofline.traffic in this run.  By default (one GPU, rocprofv3 present) the C1 line's traffic "
+                         "comes from two short rocprofv3 passes of this same command (--kernel-trace --pmc FETCH_SIZE, then WRITE_SIZE; "
+                         "each counter in its own pass, nothing else traced) run as child processes before the timed region, ~1 minute; "
+                         "with this flag, or when a pass fails, the tracked figure of profiles/pmc_traffic.json is used and labelled")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="config c1 at one GPU also runs short timed regions of configs[2], [3] (8192 and 65536 problems) and [4] "
+                         "after its own and reports them under config.other_configs; this flag leaves them out")
+    ap.add_argument("--other-steps", type=int, default=10, help="timed sweeps per entry of config.other_configs")
+    ap.add_argument("--sweeps-only", action="store_true",
+                    help="c1: the timed sweeps and nothing after them (no iLQR solves, no other configs): what the PMC passes run")
     ap.add_argument("--lane-fused", action="store_true",
                     help="configs c2 / c3: FMA-fused LANE kernels (ALTRO_HIP_LANE_FUSED; not bit-identical to the CPU path)")
     ap.add_argument("--c4-pure", action="store_true", help="(default for config c4; kept for older command lines)")
@@ -207,7 +215,10 @@ def timed_region(bt, args, world, dist, torch, shard):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         bt.sweep()
-    torch.cuda.synchronize(); barrier()
+    torch.cuda.synchronize()
+    global _ELAPSED_LOCAL
+    _ELAPSED_LOCAL = time.perf_counter() - t0      # this rank's own K steps (before the closing barrier): the per-rank table
+    barrier()
     elapsed = shard.max_over_ranks(time.perf_counter() - t0, device=RED_DEVICE)
     kern = {}
     for slot in (0, 1):
@@ -217,6 +228,38 @@ def timed_region(bt, args, world, dist, torch, shard):
                       "avg_ms": ms / max(nl, 1), "min_ms": lo, "max_ms": hi}
     bt.profile(0)
     return elapsed, kern
+
+
+_ELAPSED_LOCAL = None
+
+
+def elapsed_local():
+    return _ELAPSED_LOCAL
+
+
+def rank_table(elapsed, steps, local_rank, rank, world, dist, torch):
+    """config.ranks: per rank its HIP device, that device's PCI bus id and name, and the time of ITS K steps -- gathered with
+    torch.distributed after the timed region (an object gather: nothing of the data path).  Lets a reader of a multi-GPU line
+    see a straggler, or two ranks bound to one device."""
+    import altro_amd
+    row = {"rank": rank, "local_rank": local_rank, "device": local_rank, "pid": os.getpid(),
+           "ms_per_step_own": None if elapsed is None else elapsed / steps * 1e3}
+    try:
+        name, cus, pci = altro_amd.device_info(local_rank)
+        row.update({"name": name, "compute_units": cus, "pci_bus_id": pci})
+    except Exception as e:   # noqa: BLE001
+        row["device_info_error"] = str(e)
+    if world == 1:
+        return [row]
+    rows = [None] * world
+    try:
+        dist.all_gather_object(rows, row)
+    except Exception as e:   # noqa: BLE001
+        return [dict(row, gather_error=str(e))]
+    devs = [r.get("pci_bus_id") for r in rows if r]
+    if len(set(devs)) != len(devs):
+        print("[bench] WARNING: two ranks report the same PCI bus id: %s" % devs, file=sys.stderr)
+    return rows
 
 
 def repeat_block(bt, torch, ms_per_step, seconds):
@@ -285,7 +328,8 @@ class StatsChannel:
             self.comm = None
 
 
-_LIVE_TRAFFIC = None   # {kernel name prefix: bytes per launch}, filled by live_traffic() on rank 0 when --live-traffic is given
+_LIVE_TRAFFIC = None   # {kernel name: bytes per launch}, filled by live_traffic() on rank 0 of a one-GPU run
+_LIVE_TRAFFIC_NOTE = None
 
 
 def live_traffic(args):
@@ -301,7 +345,7 @@ def live_traffic(args):
         print("[bench] --live-traffic: rocprofv3 not found", file=sys.stderr)
         return None
     child = [sys.executable, os.path.abspath(__file__), "--config", args.config, "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
-             "--repeat-seconds", "0", "--horizon", str(args.horizon)]
+             "--no-live-traffic", "--no-other-configs", "--sweeps-only", "--repeat-seconds", "0", "--horizon", str(args.horizon)]
     if args.batch is not None:
         child += ["--batch", str(args.batch)]
     if args.global_batch is not None:
@@ -363,6 +407,156 @@ def roofline_block(cfg_key, batch, N, name, alg_bytes, dur, slot=0):
                     "frac_traffic is the physical HBM utilisation"}
 
 
+def cpu_sweep_rate(N, n, m, seconds, dtype_note=""):
+    """Single-thread CPU oracle on TVLQR problems of the shape (N, n, m): backward + forward per problem (the sweep's cost on a
+    CPU does not depend on the values, so seeded random LTV-LQ problems of the shape stand for the config's own)."""
+    from oracle import oracle
+    from tests import problems
+    chunk = 8
+    pr = problems.random_ltv(chunk, N, n, m)
+    L, flags = oracle.timing_lib()
+    done, t_used = 0, 0.0
+    while t_used < seconds or done < 16:
+        t0 = time.perf_counter()
+        o = oracle.backward_batch(pr["A"], pr["B"], pr["f"], pr["Q"], pr["R"], pr["H"], pr["q"], pr["r"], L=L)
+        oracle.forward_batch(pr["A"], pr["B"], pr["f"], o["K"], o["d"], o["P"], o["p"], pr["x0"], L=L)
+        t_used += time.perf_counter() - t0
+        done += chunk
+    return {"value": done / t_used, "unit": "problem-sweeps/s", "cores": 1, "kind": "port",
+            "sample": "%d seeded random LTV-LQ problems of this shape (N=%d, n=%d, m=%d), %.1f s, oracle/tvlqr_oracle.c backward+forward "
+                      "in fp64%s, %s, 1 thread" % (done, N, n, m, t_used, dtype_note, flags)}
+
+
+def make_lane_batch(cfg, batch, first, N, device, lane_fused=False):
+    """configs[2] (pendulum) / configs[3] (bicycle tracking with the steering bound) on plan LANE: the handle with its model, cost,
+    constraint block, initial states (this rank's slice of the global batch) and input guess, expanded at the initial rollout.
+    -> (handle, callable that restores the input guess)"""
+    import altro_amd
+    from tests import problems
+    c3 = cfg == "c3"
+    n, m = (4, 2) if c3 else (2, 1)
+    bt = altro_amd.Batch(N, n, m, batch, device=device, flags=altro_amd.LANE_FUSED if lane_fused else 0)
+    assert bt.plan == altro_amd.PLAN_LANE
+    if c3:
+        x_ref, u_ref = problems.bicycle_reference(N + 1)
+        bt.set_model(altro_amd.MODEL_BICYCLE, np.float32(0.1))
+        bt.set_tracking_cost(np.full((1, N + 1, n), 1e-2), np.full((1, N, m), 1e-3), x_ref[None, :N + 1],
+                             u_ref[None, :N], batch_stride_zero=True)
+        G = np.zeros((2, n + m)); G[0, 3] = 1.0; G[1, 3] = -1.0
+        bt.add_linear_constraint(0, N, altro_amd.CONE_INEQUALITY, G, np.full(2, np.pi / 3))
+        x0 = x_ref[0] + (problems.uniform01((batch, n), 23, first * n) - 0.5) * 0.4
+        guess = np.array([[[u_ref[0][0], 0.0]]])
+    else:
+        bt.set_model(altro_amd.MODEL_PENDULUM, np.float32(0.03))
+        xf = np.array([np.pi, 0.0])
+        bt.set_tracking_cost(np.array([[1e-2, 1e-2], [1.0, 1.0]]), np.array([[1e-3]]), np.stack([xf, xf]),
+                             np.zeros((1, m)), k_stride_zero=True, batch_stride_zero=True)
+        x0 = np.zeros((batch, n)); x0[:, 0] = problems.uniform01((batch,), 22, first) - 0.5
+        guess = np.array([[[0.1]]])
+
+    def set_guess():
+        bt.set_input_guess(guess, k_stride_zero=True, batch_stride_zero=True)
+    set_guess()
+    bt.set_initial_state(x0)
+    bt.open_loop_rollout(); bt.accept(); bt.expand()
+    return bt, set_guess
+
+
+def make_mfma_batch(c4, c4_pure, batch, first, N, device):
+    """configs[1] (C1 double integrator, fp64) / configs[4] (random LTV, fp32) on plan MFMA16, data resident in HBM."""
+    import altro_amd
+    from tests import problems
+    n, m = 12, 4
+    x0 = 2.0 * problems.uniform01((batch, n), 21, first * n) - 1.0   # this rank's slice of the global batch
+    bt = altro_amd.Batch(N, n, m, batch, dtype=altro_amd.F32 if c4 else altro_amd.F64, device=device,
+                         flags=altro_amd.F32_PURE if (c4 and c4_pure) else 0)
+    assert bt.plan == altro_amd.PLAN_MFMA16
+    if c4:
+        # random time-varying LTV-LQ problems (SURVEY.md 8d "C4"): a seeded pool of 64 distinct problems is
+        # tiled over the batch ON THE DEVICE; every (problem, knot point) still owns its blocks in HBM
+        pool = problems.random_ltv(64, N, n, m)
+        bt.set_host_batch(64)
+        bt.set_dynamics(pool["A"], pool["B"], pool["f"])
+        bt.set_cost(pool["Q"], pool["R"], pool["H"], pool["q"], pool["r"])
+        bt.set_host_batch(0)
+    else:
+        one = problems.c1_double_integrator(1, N=N)
+        # shared A,B,Q,R are EXPANDED on the device: every (problem, knot point) owns its blocks in HBM
+        bt.set_dynamics(one["A"][0, :1], one["B"][0, :1], None, k_stride_zero=True, batch_stride_zero=True)
+        Q2 = np.stack([one["Q"][0, 0], one["Q"][0, N]])
+        bt.set_cost(Q2, one["R"][0, :1], one["H"][0, :1], np.zeros((2, n)), one["r"][0, :1],
+                    k_stride_zero=True, batch_stride_zero=True)
+    bt.set_initial_state(x0)
+    return bt
+
+
+def other_config_entry(key, device, steps, torch, cpu_seconds=2.0):
+    """One entry of config.other_configs: a short timed region (3 untimed sweeps, then `steps` sweeps between two device
+    synchronisations; per-kernel hipEvents inside it) of another BASELINE.json config on this GPU, with the roofline fraction
+    of its backward sweep, the tracked PMC traffic where it is calibrated, and a bounded single-thread CPU figure."""
+    cfg, batch = {"c2": ("c2", 8192), "c3_8192": ("c3", 8192), "c3_65536": ("c3", 65536), "c4": ("c4", 16384)}[key]
+    N = {"c2": 100, "c3": 50, "c4": 512}[cfg]
+    n, m = {"c2": (2, 1), "c3": (4, 2), "c4": (12, 4)}[cfg]
+    t_setup = time.perf_counter()
+    set_guess = None
+    if cfg == "c4":
+        bt = make_mfma_batch(True, True, batch, 0, N, device)
+    else:
+        bt, set_guess = make_lane_batch(cfg, batch, 0, N, device)
+    for _ in range(3):
+        bt.sweep()
+    bt.profile(2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        bt.sweep()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kern = {}
+    for slot in (0, 1):
+        nl, ms, name = bt.profile_get(slot)
+        kern[slot] = {"name": name, "launches": nl, "avg_ms": ms / max(nl, 1)}
+    bt.profile(0)
+    bytes_b, bytes_f = bt.algorithmic_bytes(0), bt.algorithmic_bytes(1)
+    dur_b, dur_f = kern[0]["avg_ms"] * 1e-3, kern[1]["avg_ms"] * 1e-3
+    cfg_key = "c4pure" if cfg == "c4" else cfg
+    roof = roofline_block(cfg_key, batch, N, kern[0]["name"], bytes_b, dur_b)
+    roof_f = roofline_block(cfg_key, batch, N, kern[1]["name"], bytes_f, dur_f, slot=1)
+    for r in (roof, roof_f):
+        r.pop("note", None); r.pop("duration_source", None)
+    if cfg != "c4" and batch <= 8192:
+        roof["bound_in_practice"] = ("dependent-issue latency, not HBM: %d waves on 1024 SIMDs walk N = %d dependent steps; one wave's chain "
+                                    "issues an instruction every ~6.5 cycles with SQ_WAIT_INST_ANY ~ 0 (profiles/r01l_lane_pmc_one_wave.txt), "
+                                    "so `frac` is reported for reference only" % ((batch + 15) // 16 if n == 4 else (batch + 15) // 16, N))
+    out = {"workload": {"c2": "C2 pendulum swing-up (BASELINE.json configs[2]): TVLQR sweep on the expansion at the initial rollout",
+                        "c3": "C3 bicycle tracking + steering bound (BASELINE.json configs[3]): TVLQR sweep on the expansion at the initial rollout",
+                        "c4": "C4 random LTV TVLQR sweep, pure fp32 (BASELINE.json configs[4])"}[cfg],
+           "horizon_N": N, "n": n, "m": m, "batch": batch, "dtype": "f32" if cfg == "c4" else "f64", "steps": steps,
+           "ms_per_step": elapsed / steps * 1e3, "value": batch * steps / elapsed, "unit": "problem-sweeps/s",
+           "kernels": {kern[0]["name"]: dict(kern[0], algorithmic_GB=bytes_b / 1e9, GBps=bytes_b / dur_b / 1e9),
+                       kern[1]["name"]: dict(kern[1], algorithmic_GB=bytes_f / 1e9, GBps=bytes_f / dur_f / 1e9)},
+           "roofline": roof, "roofline_forward": roof_f}
+    if set_guess is not None:   # the same batch as one whole AL-iLQR solve (second of two: the first loads the kernels' code)
+        c3 = cfg == "c3"
+        for timed in (False, True):
+            if c3:
+                bt.reset_duals(1.0)
+            set_guess()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            res = bt.ilqr_solve(iterations_max=80, use_backtracking=c3)
+            torch.cuda.synchronize()
+            t_solve = time.perf_counter() - t1
+        out["full_solve"] = {"ms": t_solve * 1e3, "sweeps": int(res["sweeps"]), "converged": int((res["status"] == 0).sum()),
+                             "mean_iterations": float(res["iterations"].mean())}
+    bt.close()
+    if cpu_seconds > 0:
+        out["cpu_baseline"] = cpu_sweep_rate(N, n, m, cpu_seconds, " (the GPU line: fp32)" if cfg == "c4" else "")
+        out["vs_cpu_single_thread"] = out["value"] / out["cpu_baseline"]["value"]
+    out["seconds_total"] = time.perf_counter() - t_setup
+    return out
+
+
 def lane_config(args, rank, local_rank, world, dist, torch, chan):
     """Extra lines for the small-state configs (plan LANE, lane-per-problem SoA): the same sweep metric on the
     expansion of a nonlinear model, plus the time of one full batched AL-iLQR solve."""
@@ -375,31 +569,10 @@ def lane_config(args, rank, local_rank, world, dist, torch, chan):
         # configs[3]: 65536 random initial states sharded over the GPUs of the node (8192 each at 8 GPUs, all of them
         # on the one GPU of an N=1 run); --batch B makes it B per GPU instead (the tracked profiles use 8192)
         batch, first, global_batch, scaling = resolve_batch(args, None, rank, world, default_global=65536)
-        h = np.float32(0.1)
-        x_ref, u_ref = problems.bicycle_reference(N + 1)
     else:
         n, m, N = 2, 1, 100 if args.horizon == 256 else args.horizon
         batch, first, global_batch, scaling = resolve_batch(args, 8192, rank, world)
-        h = np.float32(0.03)
-    bt = altro_amd.Batch(N, n, m, batch, device=local_rank, flags=altro_amd.LANE_FUSED if args.lane_fused else 0)
-    assert bt.plan == altro_amd.PLAN_LANE
-    if c3:
-        bt.set_model(altro_amd.MODEL_BICYCLE, h)
-        bt.set_tracking_cost(np.full((1, N + 1, n), 1e-2), np.full((1, N, m), 1e-3), x_ref[None, :N + 1],
-                             u_ref[None, :N], batch_stride_zero=True)
-        G = np.zeros((2, n + m)); G[0, 3] = 1.0; G[1, 3] = -1.0
-        bt.add_linear_constraint(0, N, altro_amd.CONE_INEQUALITY, G, np.full(2, np.pi / 3))
-        x0 = x_ref[0] + (problems.uniform01((batch, n), 23, first * n) - 0.5) * 0.4
-        bt.set_input_guess(np.array([[[u_ref[0][0], 0.0]]]), k_stride_zero=True, batch_stride_zero=True)
-    else:
-        bt.set_model(altro_amd.MODEL_PENDULUM, h)
-        xf = np.array([np.pi, 0.0])
-        bt.set_tracking_cost(np.array([[1e-2, 1e-2], [1.0, 1.0]]), np.array([[1e-3]]), np.stack([xf, xf]),
-                             np.zeros((1, m)), k_stride_zero=True, batch_stride_zero=True)
-        x0 = np.zeros((batch, n)); x0[:, 0] = problems.uniform01((batch,), 22, first) - 0.5
-        bt.set_input_guess(np.array([[[0.1]]]), k_stride_zero=True, batch_stride_zero=True)
-    bt.set_initial_state(x0)
-    bt.open_loop_rollout(); bt.accept(); bt.expand()
+    bt, set_guess = make_lane_batch(args.config, batch, first, N, local_rank, args.lane_fused)
 
     elapsed, kern = timed_region(bt, args, world, dist, torch, shard)
     rep = repeat_block(bt, torch, elapsed / args.steps * 1e3, args.repeat_seconds)
@@ -411,8 +584,7 @@ def lane_config(args, rank, local_rank, world, dist, torch, chan):
     for timed in (False, True, True, True):     # (median of three timed solves)
         if c3:
             bt.reset_duals(1.0)
-        bt.set_input_guess(np.array([[[u_ref[0][0], 0.0]]]) if c3 else np.array([[[0.1]]]), k_stride_zero=True,
-                           batch_stride_zero=True)
+        set_guess()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         res = bt.ilqr_solve(iterations_max=80, use_backtracking=c3)
@@ -504,12 +676,20 @@ def main():
         cpu_leg = cpu_baseline(args.horizon, args.cpu_seconds)
         cpu_leg["all_cores"] = cpu_all_cores(args.horizon)
         cpu_leg["eigen"] = eigen_probe()
-    if args.live_traffic and rank == 0 and world == 1:   # before this process touches the GPU: the passes are child processes
-        global _LIVE_TRAFFIC
+    # roofline.traffic of THIS run: two short PMC passes of the same command as child processes, before this process touches the
+    # GPU (one GPU only: the driver's multi-GPU runs keep the tracked figure)
+    global _LIVE_TRAFFIC, _LIVE_TRAFFIC_NOTE
+    if not args.no_live_traffic and rank == 0 and world == 1:
+        t_live = time.perf_counter()
         try:
             _LIVE_TRAFFIC = live_traffic(args)
+            _LIVE_TRAFFIC_NOTE = ("measured in this run (%.0f s)" % (time.perf_counter() - t_live)) if _LIVE_TRAFFIC else \
+                "the live PMC passes failed or rocprofv3 is absent: tracked figure"
         except Exception as e:   # noqa: BLE001 -- a measurement extra must never take the bench line down
-            print("[bench] --live-traffic failed: %s" % e, file=sys.stderr)
+            print("[bench] live traffic failed: %s" % e, file=sys.stderr)
+            _LIVE_TRAFFIC_NOTE = "the live PMC passes failed (%s): tracked figure" % e
+    else:
+        _LIVE_TRAFFIC_NOTE = "--no-live-traffic" if args.no_live_traffic else "more than one rank: tracked figure"
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -542,27 +722,7 @@ def main():
     if args.config in ("c2", "c3"):
         return lane_config(args, rank, local_rank, world, dist, torch, chan)
     batch, first, global_batch, scaling = resolve_batch(args, 16384 if c4 else 4096, rank, world)
-    x0 = 2.0 * problems.uniform01((batch, n), 21, first * n) - 1.0   # this rank's slice of the global batch
-
-    bt = altro_amd.Batch(N, n, m, batch, dtype=altro_amd.F32 if c4 else altro_amd.F64, device=local_rank,
-                         flags=altro_amd.F32_PURE if (c4 and args.c4_pure) else 0)
-    assert bt.plan == altro_amd.PLAN_MFMA16
-    if c4:
-        # random time-varying LTV-LQ problems (SURVEY.md 8d "C4"): a seeded pool of 64 distinct problems is
-        # tiled over the batch ON THE DEVICE; every (problem, knot point) still owns its blocks in HBM
-        pool = problems.random_ltv(64, N, n, m)
-        bt.set_host_batch(64)
-        bt.set_dynamics(pool["A"], pool["B"], pool["f"])
-        bt.set_cost(pool["Q"], pool["R"], pool["H"], pool["q"], pool["r"])
-        bt.set_host_batch(0)
-    else:
-        one = problems.c1_double_integrator(1, N=N)
-        # shared A,B,Q,R are EXPANDED on the device: every (problem, knot point) owns its blocks in HBM
-        bt.set_dynamics(one["A"][0, :1], one["B"][0, :1], None, k_stride_zero=True, batch_stride_zero=True)
-        Q2 = np.stack([one["Q"][0, 0], one["Q"][0, N]])
-        bt.set_cost(Q2, one["R"][0, :1], one["H"][0, :1], np.zeros((2, n)), one["r"][0, :1],
-                    k_stride_zero=True, batch_stride_zero=True)
-    bt.set_initial_state(x0)
+    bt = make_mfma_batch(c4, args.c4_pure, batch, first, N, local_rank)
 
     elapsed, kern = timed_region(bt, args, world, dist, torch, shard)
     rep = repeat_block(bt, torch, elapsed / args.steps * 1e3, args.repeat_seconds)
@@ -571,8 +731,10 @@ def main():
 
     # the same batch as a full iLQR solve (rollout, expansion, backward sweep, merit-function line search,
     # convergence test; an LQ problem, so <= 3 sweeps), outside the timed region
+    # who ran what: one row per rank (device, PCI bus id, its own K-step time) so that a straggler or a mis-bound rank shows
+    ranks = rank_table(elapsed_local(), args.steps, local_rank, rank, world, dist, torch)
     full_solve, ilqr_sweep = None, None
-    if not c4:
+    if not c4 and not args.sweeps_only:
         Qd2 = np.stack([np.ones(n), 100.0 * np.ones(n)])
         bt.set_tracking_cost(Qd2, np.full((1, m), 1e-2), np.zeros((2, n)), np.zeros((1, m)), k_stride_zero=True,
                              batch_stride_zero=True)
@@ -595,7 +757,7 @@ def main():
     # AL-iLQR solve: constraint rows, dual and penalty updates, line searches past the first step -- the AL half of the path
     # (SURVEY section 8 row f2), outside the timed region like the solve above
     constrained = None
-    if not c4:
+    if not c4 and not args.sweeps_only:
         import altro_amd
         Gb = np.zeros((2 * m, n + m)); Gb[:m, n:] = np.eye(m); Gb[m:, n:] = -np.eye(m)
         bt.add_linear_constraint(0, N - 1, altro_amd.CONE_INEQUALITY, Gb, np.full(2 * m, 2.0))
@@ -613,11 +775,26 @@ def main():
                        "what": "the C1 batch with input bounds |u| <= 2 (an INEQUALITY block at every k < N) as one altro_hip_ilqr_solve: "
                                "AL-iLQR, cubic line search, iterations_max 40 (host clock, second of two solves)"}
 
+    # the other single-GPU configs of BASELINE.json, each a short timed region of its own on this GPU (one-GPU runs of the
+    # default config only; the C1 handle is released first: C4 alone holds 18 GB)
+    others = None
+    if not c4 and world == 1 and not args.no_other_configs and not args.sweeps_only:
+        bytes_keep = (bt.algorithmic_bytes(0), bt.algorithmic_bytes(1))
+        bt.close()
+        bt = None
+        others = {}
+        for key in ("c2", "c3_8192", "c3_65536", "c4"):
+            try:
+                others[key] = other_config_entry(key, local_rank, args.other_steps, torch, 0.0 if args.no_cpu_baseline else 2.0)
+            except Exception as e:   # noqa: BLE001 -- an extra must never take the metric's own line down
+                others[key] = {"error": str(e)}
+    else:
+        bytes_keep = (bt.algorithmic_bytes(0), bt.algorithmic_bytes(1))
+
     if rank == 0:
         total_problems = global_batch
         sweeps_per_s = total_problems * args.steps / elapsed
-        bytes_b = bt.algorithmic_bytes(0)
-        bytes_f = bt.algorithmic_bytes(1)
+        bytes_b, bytes_f = bytes_keep
         dur_b = ms_b / nb * 1e-3
         dur_f = ms_f / nf * 1e-3
         out = {
@@ -651,6 +828,8 @@ def main():
                 "ilqr_full_solve": full_solve,
                 "ilqr_sweep": ilqr_sweep,
                 "ilqr_constrained_solve": constrained,
+                "ranks": ranks,
+                "other_configs": others,
             },
             "roofline": roofline_block(("c4pure" if args.c4_pure else "c4mixed") if c4 else "c1", batch, N, name_b, bytes_b, dur_b),
             "roofline_forward": roofline_block(("c4pure" if args.c4_pure else "c4mixed") if c4 else "c1", batch, N, name_f,
@@ -664,10 +843,16 @@ def main():
                                            "512 knot points: 2e-5 pure fp32, 5e-7 fp64 tile arithmetic "
                                            "(tests/test_gpu_parity.py::test_c4_full_horizon_sample_vs_oracle holds both)",
                 "other_variant": "--c4-mixed" if args.c4_pure else "(default) pure fp32"}
+        out["roofline"]["has_f"] = bool(c4)
+        out["roofline"]["has_f_note"] = ("the batch carries no affine term f (set_dynamics(f = None)): the kernel timed is the HAS_F = false "
+                                         "instantiation, so the 96 B per knot point SURVEY 8(d) counts for f (of 5088) are not read"
+                                         if not c4 else "the batch carries f")
+        out["roofline"]["traffic_live"] = _LIVE_TRAFFIC_NOTE
         if cpu_leg is not None:
             out["cpu_baseline"] = cpu_leg
         emit(out)
-    bt.close()
+    if bt is not None:
+        bt.close()
     chan.close()
     if world > 1:
         dist.destroy_process_group()

@@ -117,6 +117,9 @@ const char* altro_hip_last_error(void);
 int altro_hip_device_count(void);
 /* name[cap], CU count and wave size of `device`; ALTRO_HIP_ERR_NO_DEVICE when there is none */
 int altro_hip_device_info(int device, char* name, int cap, int* compute_units, int* wave_size);
+/* "domain:bus:device.function" of a HIP device (hipDeviceGetPCIBusId): which physical GPU a rank of a multi-GPU run is
+ * bound to -- bench.py prints it per rank.  cap >= 16.                                                                */
+int altro_hip_device_pci_bus_id(int device, char* buf, int cap);
 
 /* ---- lifecycle ------------------------------------------------------------------------------- */
 /* `stream` is a hipStream_t (NULL = a stream owned by the handle).  `plan` is an altro_hip_plan. */

@@ -4,6 +4,8 @@ reduction of the per-problem results, on every plan, and the RCCL all-reduce ent
 still goes through ncclCommInitRank / ncclAllReduce on the handle's stream.  Needs an MI355X."""
 import ctypes as C
 
+import os
+
 import numpy as np
 import pytest
 
@@ -108,6 +110,61 @@ def test_rccl_allreduce_entry_points_on_one_rank():
     L.altro_hip_comm_destroy(cm[0])
     comm.close()
     bt.close()
+
+
+def test_rccl_all_devices_of_the_box_in_one_process():
+    """altro_hip_comm_create_all (ncclCommInitAll) + altro_hip_stats_allreduce_multi (grouped all-reduces: int64 counts, double sums,
+    double maxima) over EVERY device this box has, one handle per device: the reduced vector is the sum / maximum of the local
+    ones.  The first execution of the multi-rank RCCL code on a multi-GPU node must not be the driver's scaling run -- on the
+    1-GPU test boxes this is skipped."""
+    import torch  # noqa: F401
+    L = altro_amd.lib()
+    ndev = L.altro_hip_device_count()
+    if ndev < 2:
+        pytest.skip("one HIP device: the one-rank form is covered by test_rccl_allreduce_entry_points_on_one_rank")
+    bts, locals_ = [], []
+    for d in range(ndev):
+        pr = problems.random_ltv(96 + 32 * d, 24, 12, 4, first=1000 * d)
+        bt = altro_amd.Batch(24, 12, 4, 96 + 32 * d, device=d)
+        bt.set_dynamics(pr["A"], pr["B"], pr["f"]); bt.set_cost(pr["Q"], pr["R"], pr["H"], pr["q"], pr["r"])
+        bt.set_initial_state(pr["x0"]); bt.sweep()
+        bts.append(bt); locals_.append(bt.stats().as_dict())
+    cm = (C.c_void_p * ndev)()
+    assert L.altro_hip_comm_create_all(cm, ndev, None) == 0, L.altro_hip_last_error()
+    hs = (C.c_void_p * ndev)(*[bt.h for bt in bts])
+    out = altro_amd.Stats()
+    assert L.altro_hip_stats_allreduce_multi(hs, cm, ndev, C.byref(out)) == 0, L.altro_hip_last_error()
+    red = out.as_dict()
+    for k in ("problems", "cholesky_failures", "converged", "iterations", "non_finite"):
+        assert red[k] == sum(l[k] for l in locals_), k
+    for k in ("sum_cost", "sum_delta_V0", "sum_delta_V1"):
+        ref = sum(l[k] for l in locals_)
+        assert abs(red[k] - ref) <= 1e-12 * max(1.0, abs(ref)), k
+    for k in ("max_stationarity", "max_feasibility", "max_abs_xN"):
+        assert red[k] == max(l[k] for l in locals_), k
+    for i in range(ndev):
+        L.altro_hip_comm_destroy(cm[i])
+    for bt in bts:
+        bt.close()
+
+
+def test_comm_create_gives_up_when_a_rank_never_joins():
+    """ncclCommInitRank waits for every rank of the world; altro_hip_comm_create gives up after ALTRO_HIP_COMM_TIMEOUT_S with a
+    message instead of hanging (here: rank 0 of a world of 2 whose rank 1 never starts).  Run in a child process: the helper
+    thread stays blocked inside RCCL until the process ends."""
+    import subprocess
+    import sys
+    code = ("import os, torch, altro_amd\n"
+            "os.environ['ALTRO_HIP_COMM_TIMEOUT_S'] = '3'\n"
+            "try:\n"
+            "    altro_amd.Comm(0, 0, 2, altro_amd.Comm.unique_id())\n"
+            "    print('JOINED')\n"
+            "except Exception as e:\n"
+            "    print('ERR', e)\n"
+            "os._exit(0)\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert "ERR" in r.stdout and "did not return within 3 s" in r.stdout, r.stdout + r.stderr
 
 
 def test_a_diverged_problem_shows_in_the_statistics():
