@@ -46,7 +46,7 @@ C_ABI_SYMBOLS = [
 ]
 CONE_EQUALITY, CONE_IDENTITY, CONE_INEQUALITY, CONE_SOC = 0, 1, 2, 3   # ConstraintType, typedefs.hpp:29-34
 
-MODEL_LINEAR, MODEL_DOUBLE_INTEGRATOR, MODEL_PENDULUM, MODEL_BICYCLE, MODEL_USER = 0, 1, 2, 3, 4
+MODEL_LINEAR, MODEL_DOUBLE_INTEGRATOR, MODEL_PENDULUM, MODEL_BICYCLE, MODEL_USER, MODEL_QUADROTOR = 0, 1, 2, 3, 4, 5
 MERIT_FN = C.CFUNCTYPE(None, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p)
 
 

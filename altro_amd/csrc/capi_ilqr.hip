@@ -191,6 +191,10 @@ int wave_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int
     if (e != nullptr && std::atoi(e) == 0 && !h->cost_dense) a.mode |= EXPAND_LDS;   // (the dense cost lives in the row-layout kernels only)
   }
   a.costd = (const S*)h->m_costd; a.costd_term = (const S*)h->m_costd_term; a.cost_dense = h->cost_dense ? 1 : 0;
+  if (h->model_set) {   // a device model: the dynamics expansion rides with every gradient expansion of a stored trajectory
+    a.mp = h->model;    // (not with the end-of-sweep refresh, EXPAND_NEXT: the merit pass that made the candidate left Z already)
+    if (which == IK_EXPAND && (a.mode & EXPAND_GRADIENT) && !(a.mode & EXPAND_NEXT)) a.mode |= EXPAND_DYN;
+  }
   if (which == IK_MERIT) {   // a line-search round: the DPP form of the merit evaluation unless ALTRO_HIP_MERIT_DPP=0 keeps the LDS form
     const char* e = std::getenv("ALTRO_HIP_MERIT_DPP");
     a.mode = e == nullptr ? 2 : std::atoi(e) == 0 ? 0 : std::atoi(e) == 2 ? 3 : 2;   // (2: the DPP form whatever the launcher's rule)
@@ -233,8 +237,9 @@ int ilqr_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int
 int ilqr_check(altro_hip_batch* h, bool need_guess) {
   int rc = check(h);
   if (rc) return rc;
-  if (h->plan == ALTRO_HIP_PLAN_MFMA16) {   // dynamics are data (altro_hip_set_dynamics), no device model
-    if (!h->dyn_set) return fail(ALTRO_HIP_ERR_NOT_SET, "altro_hip_set_dynamics has not been called");
+  if (h->plan == ALTRO_HIP_PLAN_MFMA16) {   // dynamics are data (altro_hip_set_dynamics) or a device model of the tile plan
+    if (!h->dyn_set && !h->model_set)
+      return fail(ALTRO_HIP_ERR_NOT_SET, "neither altro_hip_set_dynamics nor altro_hip_set_model has been called");
   } else if (h->plan != ALTRO_HIP_PLAN_LANE) {
     return fail(ALTRO_HIP_ERR_UNSUPPORTED, "the device iLQR loop runs on plans MFMA16 (n <= 12, m <= 4, dynamics given as data) and "
                                            "LANE (n <= 6, m <= 3, device models); plan GENERIC (n = %d, m = %d) has the TVLQR sweep only",
@@ -259,11 +264,18 @@ int altro_hip_set_model(altro_hip_batch* h, int model, float timestep, int bicyc
   int rc = check(h);
   if (rc) return rc;
   if (!(timestep > 0.0f)) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "time step must be positive (ErrorCodes::TimestepNotPositive)");
-  if (h->plan != ALTRO_HIP_PLAN_LANE || !ilqr_supported(model, h->n, h->m))
+  const bool tile = h->plan == ALTRO_HIP_PLAN_MFMA16 && ilqr_tile_model_supported(model, h->n, h->m);   // kernels/ilqr_tile_model.hip
+  if (tile && h->dtype != ALTRO_HIP_F64)
+    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "device models on plan MFMA16 run on fp64 records (create the handle with ALTRO_HIP_F64)");
+  if (!tile && (h->plan != ALTRO_HIP_PLAN_LANE || !ilqr_supported(model, h->n, h->m)))
     return fail(ALTRO_HIP_ERR_UNSUPPORTED, "no device model %d for plan %d with (n, m) = (%d, %d)", model, h->plan, h->n, h->m);
   h->model = ModelParams{model, timestep, bicycle_frame, bicycle_length > 0 ? bicycle_length : 2.7,
                          bicycle_lr > 0 ? bicycle_lr : 1.5};
   h->model_set = true;
+  if (tile) {   // the DYN records are the EXPANSION's from now on (Z = [A B] written by the expansion / merit kernels, f = 0)
+    HIP_TRY(hipMemsetAsync(h->m_in, 0, (size_t)h->batch * h->N * MF_DYN * h->esz, h->stream));
+    h->dyn_set = true; h->has_f = 0;
+  }
   return 0;
 }
 
@@ -908,7 +920,7 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
   if (const char* e = std::getenv("ALTRO_HIP_MERIT2")) dual = dual && std::atoi(e) != 0;
   if (!fused_prologue) {
     if (ilqr_launch_loop(h->stream, ILK_LOOP_INIT, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
-    if (dual && !al && !h->cost_dense) {   // (ROLLOUT_INIT forms the diagonal cost's gradient)
+    if (dual && !al && !h->cost_dense && !h->model_set) {   // (ROLLOUT_INIT: linear dynamics as data, the diagonal cost's gradient)
       rc = ilqr_run(h, IK_ROLLOUT, false, false, 0, 0.0, ROLLOUT_INIT);
     } else {
       rc = ilqr_run(h, IK_ROLLOUT, false, false, 0, 0.0);
@@ -931,7 +943,7 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
     return lane_plan ? (h->batch + 63) / 64 : searching;   // LANE: the searching lanes are scattered over all waves
   };
   const char* mrd = std::getenv("ALTRO_HIP_MERIT_DPP");
-  const bool merit_rounds_dpp = mrd == nullptr || std::atoi(mrd) != 0 || h->cost_dense;   // (a dense cost: row-layout kernels only)
+  const bool merit_rounds_dpp = mrd == nullptr || std::atoi(mrd) != 0 || h->cost_dense || h->model_set;   // (a dense cost, a device model: row-layout kernels only)
   // wavefronts a round of `trials` steps per searching problem launches: a wave per (problem, trial) in the LDS form, a wave per
   // two problems and two trials in the DPP form (which keeps two waves per SIMD, not four: see the capacity below)
   auto spec_waves = [&](int searching, int trials) -> int64_t {
@@ -1246,8 +1258,42 @@ int altro_hip_get_nominal(altro_hip_batch* h, double* x, double* u) {
 int altro_hip_get_expansion(altro_hip_batch* h, double* A, double* B, double* lx, double* lu) {
   int rc = check(h);
   if (rc) return rc;
-  if (h->plan != ALTRO_HIP_PLAN_LANE) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "plan LANE only");
   const int n = h->n, m = h->m, N = h->N;
+  if (h->plan == ALTRO_HIP_PLAN_MFMA16) {   // Z = [A B] rows of the DYN records, [lx lu] of the COST records, lx_N of TERM
+    if (h->dev_ptrs) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "altro_hip_get_expansion on plan MFMA16 writes host arrays");
+    const int64_t B_ = h->batch;
+    std::vector<double> raw;
+    auto fetch = [&](const void* src, int64_t bs, int64_t ks, int off, int block, int nk) -> int {
+      raw.assign((size_t)B_ * nk * block, 0.0);
+      return h->dtype == ALTRO_HIP_F64 ? aos_get<double>(h, raw.data(), (const double*)src + off, bs, ks, block, nk)
+                                       : aos_get<float>(h, raw.data(), (const float*)src + off, bs, ks, block, nk);
+    };
+    if (A || B) {
+      if ((rc = fetch(h->m_in, h->m_st.in_bs, h->m_st.in_ks, MF_OFF_Z, 192, N))) return rc;
+      for (int64_t b = 0; b < B_; ++b)
+        for (int k = 0; k < N; ++k) {
+          const double* zr = raw.data() + ((size_t)b * N + k) * 192;
+          if (A) for (int j = 0; j < n; ++j) for (int i = 0; i < n; ++i) A[((size_t)b * N + k) * n * n + i + (size_t)n * j] = zr[i * 16 + j];
+          if (B) for (int j = 0; j < m; ++j) for (int i = 0; i < n; ++i) B[((size_t)b * N + k) * n * m + i + (size_t)n * j] = zr[i * 16 + 12 + j];
+        }
+    }
+    if (lx || lu) {
+      if ((rc = fetch(h->m_cin, h->m_st.cin_bs, h->m_st.cin_ks, MF_OFF_QR, 16, N))) return rc;
+      for (int64_t b = 0; b < B_; ++b)
+        for (int k = 0; k < N; ++k) {
+          const double* qr = raw.data() + ((size_t)b * N + k) * 16;
+          if (lx) for (int i = 0; i < n; ++i) lx[((size_t)b * (N + 1) + k) * n + i] = qr[i];
+          if (lu) for (int i = 0; i < m; ++i) lu[((size_t)b * N + k) * m + i] = qr[12 + i];
+        }
+      if (lx) {
+        if ((rc = fetch(h->m_term, MF_TERM, 0, 144, 12, 1))) return rc;
+        for (int64_t b = 0; b < B_; ++b)
+          for (int i = 0; i < n; ++i) lx[((size_t)b * (N + 1) + N) * n + i] = raw[(size_t)b * 12 + i];
+      }
+    }
+    return 0;
+  }
+  if (h->plan != ALTRO_HIP_PLAN_LANE) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "plans LANE and MFMA16 only");
   const LaneSizes z = lane_sizes(n, m);
   const int oq = 2 * n * n + 2 * n * m + m * m + n, orr = oq + n;
   auto get = [&](double* dst, int off, int len, int nk, bool with_term, int off_term) -> int {

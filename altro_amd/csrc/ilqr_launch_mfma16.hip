@@ -13,6 +13,13 @@ static int wave_launch(hipStream_t stream, int which, const IlqrWaveArgs<S>& a) 
   const dim3 waves(mf_grid(a.batch)), b64(64), b256(256);   // XCD-aware problem mapping: kernels/mfma16_layout.h
   const int64_t flat_n = (int64_t)a.batch * (a.N + 1) * 16;
   const dim3 flat((unsigned)std::min<int64_t>((flat_n + 255) / 256, 1 << 20));
+  if (a.mp.kind != MODEL_LINEAR) {   // a device model instead of dynamics as data: kernels/ilqr_tile_model.hip
+    if (which == IK_ROLLOUT || which == IK_MERIT || which == IK_MERIT2) return ilqr_wave_launch_model<S>(stream, which, a);
+    if (which == IK_EXPAND && (a.mode & EXPAND_DYN)) {
+      const int rc = ilqr_wave_launch_model<S>(stream, IK_EXPAND, a);
+      if (rc) return rc;
+    }
+  }
   switch (which) {
     case IK_ROLLOUT: hipLaunchKernelGGL(wave_rollout_kernel<S>, waves, b64, 0, stream, a); break;
     case IK_ACCEPT: hipLaunchKernelGGL(wave_accept_kernel<S>, flat, b256, 0, stream, a); break;

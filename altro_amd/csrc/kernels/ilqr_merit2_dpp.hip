@@ -52,12 +52,15 @@ __device__ __forceinline__ md_d2 md_ld(const S* __restrict__ p, int pair) {
 // one knot point's records of one problem, spread over 32 lanes  (DENSE: the 160-element dense cost record, 80 pairs)
 template <bool DENSE = false>
 struct MeritPairRegs { md_d2 z[3], f, o[3], nm, cp[DENSE ? 3 : 1]; };
-template <typename S, bool DENSE = false>
+// (MODEL: the dynamics come from a device model, kernels/ilqr_tile_model.hip -- Z and f are neither loaded nor staged)
+template <typename S, bool DENSE = false, bool MODEL = false>
 __device__ __forceinline__ void merit_pair_load(MeritPairRegs<DENSE>& r, const S* __restrict__ z, const S* __restrict__ o,
                                                 const S* __restrict__ nm, const S* __restrict__ cp, int hl) {
+  if constexpr (!MODEL) {
 #pragma unroll
-  for (int c = 0; c < 3; ++c) r.z[c] = md_ld<S>(z, c * 32 + hl);           // Z: 96 pairs
-  r.f = md_ld<S>(z, 96 + (hl < 6 ? hl : 5));                               // f: 6 pairs
+    for (int c = 0; c < 3; ++c) r.z[c] = md_ld<S>(z, c * 32 + hl);         // Z: 96 pairs
+    r.f = md_ld<S>(z, 96 + (hl < 6 ? hl : 5));                             // f: 6 pairs
+  }
 #pragma unroll
   for (int c = 0; c < 2; ++c) r.o[c] = md_ld<S>(o, c * 32 + hl);           // OUT: 72 pairs
   r.o[2] = md_ld<S>(o, 64 + (hl & 7));
@@ -68,14 +71,16 @@ __device__ __forceinline__ void merit_pair_load(MeritPairRegs<DENSE>& r, const S
     r.cp[0] = md_ld<S>(cp, hl < 18 ? hl : 17);                             // cost parameters: 18 pairs
   }
 }
-template <bool DENSE>
+template <bool DENSE, bool MODEL = false>
 __device__ __forceinline__ void merit_pair_stage(const MeritPairRegs<DENSE>& r, double* __restrict__ L, int hl) {
+  if constexpr (!MODEL) {
 #pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    const int pi = c * 32 + hl;
-    *reinterpret_cast<md_d2*>(L + (pi >> 3) * MD_ZLD + (pi & 7) * 2) = r.z[c];
+    for (int c = 0; c < 3; ++c) {
+      const int pi = c * 32 + hl;
+      *reinterpret_cast<md_d2*>(L + (pi >> 3) * MD_ZLD + (pi & 7) * 2) = r.z[c];
+    }
+    *reinterpret_cast<md_d2*>(L + MD_F0 + 2 * (hl < 6 ? hl : 5)) = r.f;
   }
-  *reinterpret_cast<md_d2*>(L + MD_F0 + 2 * (hl < 6 ? hl : 5)) = r.f;
 #pragma unroll
   for (int c = 0; c < 2; ++c) *reinterpret_cast<md_d2*>(L + MD_OUT0 + 2 * (c * 32 + hl)) = r.o[c];
   *reinterpret_cast<md_d2*>(L + MD_OUT0 + 2 * (64 + (hl & 7))) = r.o[2];
@@ -281,6 +286,10 @@ __device__ __forceinline__ double dpp_al_col(const AlTable<S>& t, int k, int j, 
   return s;
 }
 
+}  // namespace altro_hip
+#include "ilqr_tile_model.hip"   // nonlinear device models in this layout: tile_model_step (uses the DPP blocks above)
+namespace altro_hip {
+
 // DUAL: the two rows of a problem are trial 0 (alpha = a.alpha[b]) and trial 1 (alpha = 1) of wave_merit2_kernel (IK_MERIT2).
 // !DUAL: wave_merit_kernel (IK_MERIT, a line-search round): the rows are the speculative trials 2 blockIdx.y and 2 blockIdx.y + 1
 // of IlqrArgs::spec_trials (trial 0 = the step the search asked for), every row with its own step, candidate buffer and
@@ -289,8 +298,12 @@ __device__ __forceinline__ double dpp_al_col(const AlTable<S>& t, int k, int j, 
 // DENSE: the cost is the dense quadratic one of ALTROSolver::SetQuadraticCost (knotpoint_data.cpp:616-708) -- lane j of a row also
 // owns row j of W = [Q H^T; H R] (staged with the other records: IlqrWaveArgs::costd), (W [x; u])_j is one more 16-term DPP chain,
 // the cost share 1/2 w_j (W [x; u])_j + [q r]_j w_j and the gradient (W [x; u])_j + [q r]_j.
-template <typename S, bool AL, bool DUAL, bool DENSE = false>
-__global__ __launch_bounds__(64, 2) void wave_merit_dpp_kernel(IlqrWaveArgs<S> a) {
+// MK != 0: the dynamics are the device model MK (models.h) instead of the DYN records' data -- every knot point steps the model
+// from the row's registers and, where phi' is wanted, forms row j of Z = [A B] at the point (tile_model_step,
+// ilqr_tile_model.hip); a pass that stores the expansion leaves those rows in the DYN records for the next backward sweep
+// (what KnotPointData::CalcDynamicsExpansion leaves in A_, B_: knotpoint_data.cpp:406-419).  Z and f are then not loaded.
+template <typename S, bool AL, bool DUAL, bool DENSE = false, int MK = 0>
+__global__ __launch_bounds__(64, (MK != 0 ? 1 : 2)) void wave_merit_dpp_kernel(IlqrWaveArgs<S> a) {
   constexpr int DEPTH = 2;                          // also the image ping-pong: parity of k == dd
   constexpr bool kStat = sizeof(S) == 8;            // stored values == computed values only without a rounding store
   constexpr int IMG = DENSE ? MD_IMG_DENSE : MD_IMG;
@@ -379,7 +392,7 @@ __global__ __launch_bounds__(64, 2) void wave_merit_dpp_kernel(IlqrWaveArgs<S> a
 #pragma unroll
   for (int dd = 0; dd < DEPTH; ++dd) {
     const size_t kk = dd < N ? dd : N - 1;
-    merit_pair_load<S, DENSE>(ring[dd], dynb + kk * a.dyn_ks, outb + kk * a.out_ks, nomb + kk * nom_ks, cpb + kk * cp_ks, hl);
+    merit_pair_load<S, DENSE, MK != 0>(ring[dd], dynb + kk * a.dyn_ks, outb + kk * a.out_ks, nomb + kk * nom_ks, cpb + kk * cp_ks, hl);
   }
   const int Npad = ((N + DEPTH - 1) / DEPTH) * DEPTH;
   for (int k0 = 0; k0 < Npad; k0 += DEPTH) {
@@ -389,10 +402,10 @@ __global__ __launch_bounds__(64, 2) void wave_merit_dpp_kernel(IlqrWaveArgs<S> a
     const bool live = k < N;
     const int kc = live ? k : N - 1;
     double* const L = img[dd][slot];
-    merit_pair_stage<DENSE>(ring[dd], L, hl);
+    merit_pair_stage<DENSE, MK != 0>(ring[dd], L, hl);
     {
       const size_t kn = (k + DEPTH < N) ? k + DEPTH : N - 1;
-      merit_pair_load<S, DENSE>(ring[dd], dynb + kn * a.dyn_ks, outb + kn * a.out_ks, nomb + kn * nom_ks, cpb + kn * cp_ks, hl);
+      merit_pair_load<S, DENSE, MK != 0>(ring[dd], dynb + kn * a.dyn_ks, outb + kn * a.out_ks, nomb + kn * nom_ks, cpb + kn * cp_ks, hl);
     }
     __syncthreads();
     // (1) rows of [P | p] and of Kt against dx and dx/dalpha
@@ -438,11 +451,33 @@ __global__ __launch_bounds__(64, 2) void wave_merit_dpp_kernel(IlqrWaveArgs<S> a
     }
     // (3) rows of Z against [x; u] and its sensitivity; costs, gradient, dphi
     double cR[16];
-#pragma unroll
-    for (int c = 0; c < 16; ++c) cR[c] = L[jr * MD_ZLD + c];
     double zacc = 0.0, zacc2 = 0.0, s2 = 0.0, t2 = 0.0;
-    md_rows16(zacc, zacc2, s2, t2, w, dw, cR);
-    const double xn = (zacc + s2) + L[MD_F0 + jr];           // x+ = A x + B u + f
+    double xn;
+    if constexpr (MK != 0) {   // a device model: x+ = F(x, u), and row j of Z = [A B] at (x, u) where phi' is wanted
+      if (DUAL || deriv) {
+        tile_model_step<MK, true>(a.mp, w, jr, xn, cR);
+      } else {
+        tile_model_step<MK, false>(a.mp, w, jr, xn, cR);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) cR[c] = 0.0;
+      }
+      md_rows16(zacc, zacc2, s2, t2, w, dw, cR);
+      if (DUAL && kStat && cand && isx) {                    // the candidate's Z for the stationarity of the next step (column reads)
+#pragma unroll
+        for (int c = 0; c < 16; ++c) L[jr * MD_ZLD + c] = cR[c];
+      }
+      if (live && wqr && isx) {                              // CalcDynamicsExpansion's A_, B_ for the next backward sweep (f = 0)
+        S* zd = const_cast<S*>(a.dyn) + (size_t)b * a.dyn_bs + (size_t)kc * a.dyn_ks;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) zd[MF_OFF_Z + j * 16 + c] = (S)cR[c];
+        zd[MF_OFF_F + j] = S(0);
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) cR[c] = L[jr * MD_ZLD + c];
+      md_rows16(zacc, zacc2, s2, t2, w, dw, cR);
+      xn = (zacc + s2) + L[MD_F0 + jr];                      // x+ = A x + B u + f
+    }
     const double dxn = zacc2 + t2;                           // dx+/dalpha = A dx/dalpha + B du/dalpha
     double l;                                                // lx_j | lu_(j-12)
     if constexpr (DENSE) {   // (W [x; u])_j: this lane's row of W against the row's registers (knotpoint_data.cpp:624-634, :659-668)

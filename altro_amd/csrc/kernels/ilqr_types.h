@@ -73,7 +73,10 @@ constexpr int STAT_NO_FEAS = 32;   // IK_STATIONARITY / IK_DUAL on plan MFMA16: 
 enum { EXPAND_GRADIENT = 1, EXPAND_HESSIAN = 2, EXPAND_LDS = 16 /* plan MFMA16: wave_expand_kernel instead of the DPP form (A/B, tests) */,
        EXPAND_NEXT = 64 /* wave_expand_dpp_kernel at the end of a sweep: the gradient for the problems of the active mask (those whose
                            duals changed), the cost Hessians of the NEXT sweep for every problem still running (IlqrProb::running) */,
-       EXPAND_DUAL = 128 /* ... and the sweep's DualUpdate in the same pass (IlqrProb::dual instead of the active mask) */ };
+       EXPAND_DUAL = 128 /* ... and the sweep's DualUpdate in the same pass (IlqrProb::dual instead of the active mask) */,
+       EXPAND_DYN = 256 /* plan MFMA16 with a device model: also the dynamics Jacobians Z = [A B] of the stored candidate trajectory
+                           (wave_expand_dyn_kernel) -- the head of Solve and the re-expansion after a speculative step; a merit pass
+                           with derivative leaves them itself */ };
 
 struct IlqrLoopArgs {
   IlqrProb* prob;
@@ -147,6 +150,9 @@ struct IlqrWaveArgs {
   const S* costd = nullptr;                  // [k][b][160]
   const S* costd_term = nullptr;             // [b][156]
   int cost_dense = 0;
+  // A device model instead of dynamics given as data (altro_hip_set_model on plan MFMA16, kernels/ilqr_tile_model.hip): the
+  // rollout and the merit evaluation step the model, the expansion writes Z = [A B] into the DYN records (mp.kind != MODEL_LINEAR)
+  ModelParams mp{MODEL_LINEAR, 0.0f, 0, 2.7, 1.5};
 };
 constexpr int MF_COSTD_C = 78;    // the constant term c inside a dense cost record (the first pad slot of the COST layout)
 constexpr int ROLLOUT_INIT = 4;   // wave_rollout_kernel also writes the nominal record and the cost gradient (the head of
@@ -154,6 +160,9 @@ constexpr int ROLLOUT_INIT = 4;   // wave_rollout_kernel also writes the nominal
 
 template <typename S>
 int ilqr_wave_launch_kernel(hipStream_t stream, int which, const IlqrWaveArgs<S>& a);   // ilqr_launch_mfma16.hip
+template <typename S>
+int ilqr_wave_launch_model(hipStream_t stream, int which, const IlqrWaveArgs<S>& a);    // ilqr_launch_mfma16_model.hip (a.mp.kind)
+bool ilqr_tile_model_supported(int kind, int n, int m);                                 // device models of the (12, 4) tile plan
 
 // Speculative backtracking: most trials one merit launch evaluates (the host picks 1, 2, 4 or 8 by how idle the chip is)
 constexpr int ILQR_SPEC_TRIALS = 8;

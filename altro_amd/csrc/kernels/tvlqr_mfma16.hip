@@ -26,6 +26,12 @@
 // Symmetry note: the tile product uses P'^T where the reference uses P' (and returns G rather than
 // G^T); for the symmetric Q, R the API requires (altro_solver.hpp:183) P_k is symmetric up to rounding,
 // so this changes results only at the 1e-16 relative level.  Parity is asserted at 1e-8 on K, d.
+// The cost-to-go the recursion CARRIES is the one it STORES: after every step the lower triangle of the
+// new P is replaced by the mirrored upper one (one LDS transposition per knot point).  Without it the
+// antisymmetric part of P -- pure rounding noise, 1e-16 -- is propagated by the recursion, and that
+// propagation is not the contracting closed-loop map the symmetric part sees: on a 12-state quadrotor
+// linearisation (N = 40) it doubles every step and reached 2e-6 in K_0 (round 4, tests/test_gpu_tile_model.py);
+// the double integrator and the random LTV problems of the benchmark configs never showed it.
 //
 // Device layout (private to this plan; pack_mfma16.hip converts from/to the reference layout).  Q and P are symmetric
 // (altro_solver.hpp:183 requires it of Q; P inherits it up to rounding): only their upper triangles go through HBM.
@@ -123,6 +129,8 @@ __device__ __forceinline__ double ld_stream(const S* p) {
   return (double)(*p);
 }
 
+constexpr int MF_PT_LD = 17;   // row pitch of the [P | p] exchange tile: 16 columns + 1 (a column read hits 16 different bank pairs)
+
 struct Mfma16Knot {  // one knot point's inputs, in registers (11 doubles / lane)
   double z[3], q[3], hr, qr, f[3];
 };
@@ -175,6 +183,7 @@ __global__ __launch_bounds__(64, 4) void mfma16_backward_kernel(Mfma16Args<S> a)
   // lds[0..63] = [Qux | Quu] (row g, col j), lds[64..79] = [Qx | Qu], lds[80] = 0.0 (the "zero slot" padding
   // lanes read instead of selecting: their loop-invariant LDS addresses point here)
   __shared__ __attribute__((aligned(16))) double lds[64 + 16 + 2];
+  __shared__ double ptile[12 * MF_PT_LD];   // the new [P | p] tile, written row-major and read back mirrored (see the symmetry note)
   const int lane = threadIdx.x;
   const int j = lane & 15, g = lane >> 4;
   const int b = mf_problem(blockIdx.x, a.batch);
@@ -205,6 +214,17 @@ __global__ __launch_bounds__(64, 4) void mfma16_backward_kernel(Mfma16Args<S> a)
   for (int r = 0; r < 3; ++r) {
     const int row = g + 4 * r;
     p_off[r] = (j == 12) ? MF_OFF_p + row : ((j < 12 && j >= row) ? MF_OFF_P + mf_sym(row, j) : MF_OFF_PAD + (j > 12 ? 1 : 0));
+  }
+
+  // the tile exchange that keeps the carried P symmetric: every lane writes its three entries (row g + 4r, column j) and reads
+  // them back -- the entries BELOW the diagonal from the mirrored position above it, every other one from its own slot (no
+  // selects, no masked accesses)
+  int pt_wr[3], pt_rd[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const int row = g + 4 * r;
+    pt_wr[r] = row * MF_PT_LD + j;
+    pt_rd[r] = (j < 12 && j < row) ? j * MF_PT_LD + row : pt_wr[r];
   }
 
   // terminal cost-to-go: P_N = Q_N, p_N = q_N (tvlqr.cpp:81-90) -> tile [P | p]
@@ -326,6 +346,12 @@ __global__ __launch_bounds__(64, 4) void mfma16_backward_kernel(Mfma16Args<S> a)
     // ---- [P | p] = [Qxx | Qx] + Kt^T W - Qt^T Kt  (tvlqr.cpp:173-186) ----------------------------
     Pn = mfma_f64_16x16x4(k_mine, w_mine, Pn);
     Pn = mfma_f64_16x16x4(q_mine, -k_mine, Pn);
+    // ---- the carried P is the stored P: lower triangle <- mirrored upper triangle ------------------
+#pragma unroll
+    for (int r = 0; r < 3; ++r) ptile[pt_wr[r]] = Pn[r];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 3; ++r) Pn[r] = ptile[pt_rd[r]];
 
     // ---- roll the prefetched knot point in BEFORE the stores are issued, so that the wait for its
     //      loads does not also have to drain this step's stores (vmcnt retires in order) ------------

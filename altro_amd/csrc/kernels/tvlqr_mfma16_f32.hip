@@ -75,6 +75,7 @@ __global__ __launch_bounds__(64, 4) void mfma16_backward_f32_kernel(Mfma16Args<f
   // lds[82 + ...] = dump area: lanes outside group 3 write their (unused) G rows there, so that the exchange
   // has no exec-masked region -- any branch in this loop degrades hipcc's s_waitcnt placement for the ring
   __shared__ __attribute__((aligned(16))) float lds[64 + 16 + 2 + 5 * 64];
+  __shared__ float ptile[12 * 17];   // the new [P | p] tile, written row-major and read back mirrored (symmetry note, tvlqr_mfma16.hip)
   const int lane = threadIdx.x;
   const int j = lane & 15, g = lane >> 4;
   const int b = mf_problem(blockIdx.x, a.batch);
@@ -110,6 +111,13 @@ __global__ __launch_bounds__(64, 4) void mfma16_backward_f32_kernel(Mfma16Args<f
   for (int r = 0; r < 4; ++r) {
     const int row = 4 * gz + r;
     p_off[r] = (j == 12) ? MF_OFF_p + row : ((j < 12 && j >= row) ? MF_OFF_P + mf_sym(row, j) : MF_OFF_PAD + (j > 12 ? 1 : 0));
+  }
+  int pt_wr[4], pt_rd[4];     // the exchange that keeps the carried P symmetric (rows 4 gz + r; group 3 shadows group 0's slots)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = 4 * gz + r;
+    pt_wr[r] = row * 17 + j;
+    pt_rd[r] = (j < 12 && j < row) ? j * 17 + row : pt_wr[r];
   }
   const int w_idx = g3 ? j : 82 + lane, w_stride = g3 ? 16 : 64, gv_idx = g3 ? 64 + j : 82 + 4 * 64 + lane;
   const float g_keep = (j < 12 && !g3) ? 1.0f : 0.0f;          // lanes whose G registers are entries of Qxx
@@ -232,6 +240,14 @@ __global__ __launch_bounds__(64, 4) void mfma16_backward_f32_kernel(Mfma16Args<f
     // ---- [P | p] = [Qxx | Qx] + Kt^T W - Qt^T Kt -------------------------------------------------------------
     Pn = mfma_f32_16x16x4(k_mine, w_mine, Pn);
     Pn = mfma_f32_16x16x4(q_mine, -k_mine, Pn);
+    // the carried P is the stored P: lower triangle <- mirrored upper triangle (group 3 holds no rows: it stays out)
+    if (!g3) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ptile[pt_wr[r]] = Pn[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Pn[r] = g3 ? Pn[r] : ptile[pt_rd[r]];
 
     const float k_store = alive ? k_mine : q_mine;
     // ---- stores: branch-free; group 3 (no rows of [P | p]) and failed problems write to the trash record --

@@ -88,6 +88,8 @@ struct MfqLanes {     // loop-invariant per-lane LDS addresses (float indices) a
   int qt_w[4], ps_w, gv_w;        // exchange: writes
   int quu_r, ps_r, rhs_r, qx_r;   // exchange: reads
   int k_w, k_stride, p_w[4];      // OUT image: Kt[r][j] of problem g (+ k_stride r), [P | p] entries of a tile (+ p x 144)
+  int p_m[4];                     // ... and where the entries BELOW the diagonal read their mirror image back (else -1): the P the
+                                  //     recursion carries is the P it stores (see the symmetry note of the fp64 kernel)
   uint32_t st_off[3];             // global offset of this lane's 16 bytes in each of the three store sweeps (or out of window)
   int st_sel[3];                  // bit position in the ballot masks of the problem those 16 bytes belong to, + 64 for the Kt part
 };
@@ -222,6 +224,14 @@ __device__ __forceinline__ void mfq_back(const Mfma16Args<float>& a, float* __re
 #pragma unroll
     for (int r = 0; r < 4; ++r) lds[L.p_w[r] + p * MF_OUT] = Pn[4 * p + r];
   __syncthreads();
+  // the carried P is the stored P: entries below the diagonal <- their mirror image in the records just assembled
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float mv = lds[(L.p_m[r] >= 0 ? L.p_m[r] : MFQ_ZERO) + (L.p_m[r] >= 0 ? p * MF_OUT : 0)];
+      Pn[4 * p + r] = L.p_m[r] >= 0 ? mv : Pn[4 * p + r];
+    }
   {
     // which problems may store: Kt of those alive BEFORE this knot point, [P | p] of those still alive after it
     const unsigned long long was_mask = __ballot(was_alive), alive_mask = __ballot(alive);
@@ -289,6 +299,7 @@ __global__ __launch_bounds__(64, WAVES) void mfma16_backward_f32x4_kernel(Mfma16
     const bool has = !g3 && (j == 12 || (j < 12 && j >= row));
     // entries below the diagonal, the padding columns and group 3 go to each record's two spare slots (nobody reads them)
     L.p_w[r] = MFQ_OUT + (has ? ((j == 12) ? (MF_OFF_p + row) : (MF_OFF_P + mf_sym(row, j))) : (MF_OFF_PAD + (lane & 1)));
+    L.p_m[r] = (!g3 && j < 12 && j < row) ? MFQ_OUT + MF_OFF_P + mf_sym(row, j) : -1;
   }
 #pragma unroll
   for (int i = 0; i < 3; ++i) {

@@ -28,7 +28,8 @@ ALTRO_FP_REGION_ON
 namespace altro_hip {
 
 enum ModelKind { MODEL_LINEAR = 0, MODEL_DOUBLE_INTEGRATOR = 1, MODEL_PENDULUM = 2, MODEL_BICYCLE = 3,
-                 MODEL_USER = 4 /* altro_hip_set_model_source: the caller's own continuous dynamics, compiled at run time */ };
+                 MODEL_USER = 4 /* altro_hip_set_model_source: the caller's own continuous dynamics, compiled at run time */,
+                 MODEL_QUADROTOR = 5 /* 12 states, 4 inputs: the nonlinear model of the (12, 4) tile plan (not a reference model) */ };
 
 struct ModelParams {
   int kind;
@@ -190,6 +191,71 @@ ALTRO_HD void bicycle_fJ(const ModelParams& mp, const T* x, const T* u, T* xdot,
   bicycle_J_from<T>(mp, t, u, J);
 }
 
+// ---- quadrotor, 12 states, 4 inputs ------------------------------------------------------------------
+// NOT one of the reference's test models (those stop at 4 states): a quaternion-free rigid-body quadrotor, the nonlinear model
+// the (12, 4) tile plan ships so that ALTROSolver::SetExplicitDynamics-style dynamics (altro_solver.cpp:68-81) can be iterated
+// on the device at the shape BASELINE.json calls "quadrotor-sized".  Same equations as oracle/models_oracle.c (written apart):
+//   x = [p (3) | roll phi, pitch theta, yaw psi | v (3, world) | omega (3, body)],  u = [thrust F | torques tau (3)]
+//   pdot = v ;  [phi; theta; psi]' = W(phi, theta) omega ;  vdot = -g e3 + F / mass R e3 ;  omegadot = I^-1 (tau - omega x I omega)
+template <typename T>
+struct QuadTrig { T sp, cp, st, ct, ss, cs; };
+template <typename T>
+ALTRO_HD QuadTrig<T> quadrotor_trig(const T* x) {
+  QuadTrig<T> t;
+  sincos_hd<T>(x[3], &t.sp, &t.cp);
+  sincos_hd<T>(x[4], &t.st, &t.ct);
+  sincos_hd<T>(x[5], &t.ss, &t.cs);
+  return t;
+}
+constexpr double kQuadMass = 0.5, kQuadG = 9.81, kQuadIx = 0.0023, kQuadIy = 0.0023, kQuadIz = 0.004;
+template <typename T>
+ALTRO_HD void quadrotor_f_from(const QuadTrig<T>& t, const T* x, const T* u, T* xd) {
+  const T tt = t.st / t.ct;
+  const T wx = x[9], wy = x[10], wz = x[11];
+  xd[0] = x[6]; xd[1] = x[7]; xd[2] = x[8];
+  xd[3] = wx + t.sp * tt * wy + t.cp * tt * wz;
+  xd[4] = t.cp * wy - t.sp * wz;
+  xd[5] = (t.sp * wy + t.cp * wz) / t.ct;
+  const T a = u[0] / T(kQuadMass);
+  xd[6] = a * (t.cp * t.st * t.cs + t.sp * t.ss);
+  xd[7] = a * (t.cp * t.st * t.ss - t.sp * t.cs);
+  xd[8] = a * (t.cp * t.ct) - T(kQuadG);
+  xd[9] = (u[1] - T(kQuadIz - kQuadIy) * wy * wz) / T(kQuadIx);
+  xd[10] = (u[2] - T(kQuadIx - kQuadIz) * wz * wx) / T(kQuadIy);
+  xd[11] = (u[3] - T(kQuadIy - kQuadIx) * wx * wy) / T(kQuadIz);
+}
+template <typename T>
+ALTRO_HD void quadrotor_J_from(const QuadTrig<T>& t, const T* x, const T* u, T* J) {   // 12 x 16, column-major
+#pragma unroll
+  for (int e = 0; e < 192; ++e) J[e] = T(0);   // (unrolled: the array must dissolve into registers / constants where it is used)
+  const T tt = t.st / t.ct, sec2 = T(1) / (t.ct * t.ct);
+  const T wx = x[9], wy = x[10], wz = x[11];
+  J[0 + 6 * 12] = T(1); J[1 + 7 * 12] = T(1); J[2 + 8 * 12] = T(1);
+  J[3 + 3 * 12] = t.cp * tt * wy - t.sp * tt * wz;
+  J[3 + 4 * 12] = (t.sp * wy + t.cp * wz) * sec2;
+  J[3 + 9 * 12] = T(1); J[3 + 10 * 12] = t.sp * tt; J[3 + 11 * 12] = t.cp * tt;
+  J[4 + 3 * 12] = -t.sp * wy - t.cp * wz;
+  J[4 + 10 * 12] = t.cp; J[4 + 11 * 12] = -t.sp;
+  J[5 + 3 * 12] = (t.cp * wy - t.sp * wz) / t.ct;
+  J[5 + 4 * 12] = (t.sp * wy + t.cp * wz) * t.st * sec2;
+  J[5 + 10 * 12] = t.sp / t.ct; J[5 + 11 * 12] = t.cp / t.ct;
+  const T a = u[0] / T(kQuadMass);
+  J[6 + 3 * 12] = a * (-t.sp * t.st * t.cs + t.cp * t.ss);
+  J[6 + 4 * 12] = a * (t.cp * t.ct * t.cs);
+  J[6 + 5 * 12] = a * (-t.cp * t.st * t.ss + t.sp * t.cs);
+  J[6 + 12 * 12] = (t.cp * t.st * t.cs + t.sp * t.ss) / T(kQuadMass);
+  J[7 + 3 * 12] = a * (-t.sp * t.st * t.ss - t.cp * t.cs);
+  J[7 + 4 * 12] = a * (t.cp * t.ct * t.ss);
+  J[7 + 5 * 12] = a * (t.cp * t.st * t.cs + t.sp * t.ss);
+  J[7 + 12 * 12] = (t.cp * t.st * t.ss - t.sp * t.cs) / T(kQuadMass);
+  J[8 + 3 * 12] = a * (-t.sp * t.ct);
+  J[8 + 4 * 12] = a * (-t.cp * t.st);
+  J[8 + 12 * 12] = (t.cp * t.ct) / T(kQuadMass);
+  J[9 + 10 * 12] = -T(kQuadIz - kQuadIy) * wz / T(kQuadIx); J[9 + 11 * 12] = -T(kQuadIz - kQuadIy) * wy / T(kQuadIx); J[9 + 13 * 12] = T(1) / T(kQuadIx);
+  J[10 + 9 * 12] = -T(kQuadIx - kQuadIz) * wz / T(kQuadIy); J[10 + 11 * 12] = -T(kQuadIx - kQuadIz) * wx / T(kQuadIy); J[10 + 14 * 12] = T(1) / T(kQuadIy);
+  J[11 + 9 * 12] = -T(kQuadIy - kQuadIx) * wy / T(kQuadIz); J[11 + 10 * 12] = -T(kQuadIy - kQuadIx) * wx / T(kQuadIz); J[11 + 15 * 12] = T(1) / T(kQuadIz);
+}
+
 // ---- discrete models -------------------------------------------------------------------------------
 // KIND is a compile-time ModelKind; n, m the dimensions (double integrator: dim = n/2, the first m
 // axes are actuated -- m == dim is the reference's model, m < dim the C1 variant of SURVEY.md 8d).
@@ -207,6 +273,7 @@ struct DiscreteModel {
 #if defined(ALTRO_HIP_USER_MODEL)
     else if (KIND == MODEL_USER) altro_user_dynamics<T>(x, u, xdot);
 #endif
+    else if (KIND == MODEL_QUADROTOR) quadrotor_f_from<T>(quadrotor_trig<T>(x), x, u, xdot);
     else bicycle_f<T>(mp, x, u, xdot);
   }
   static ALTRO_HD void cont_J(const ModelParams& mp, const T* x, const T* u, T* J) {
@@ -214,6 +281,7 @@ struct DiscreteModel {
 #if defined(ALTRO_HIP_USER_MODEL)
     else if (KIND == MODEL_USER) altro_user_jacobian<T>(x, u, J);
 #endif
+    else if (KIND == MODEL_QUADROTOR) quadrotor_J_from<T>(quadrotor_trig<T>(x), x, u, J);
     else bicycle_J<T>(mp, x, u, J);
   }
 
@@ -221,6 +289,12 @@ struct DiscreteModel {
 #if defined(ALTRO_HIP_USER_MODEL)
     if (KIND == MODEL_USER) { altro_user_dynamics<T>(x, u, xdot); altro_user_jacobian<T>(x, u, J); return; }
 #endif
+    if (KIND == MODEL_QUADROTOR) {   // one set of sincos for f and J
+      const QuadTrig<T> t = quadrotor_trig<T>(x);
+      quadrotor_f_from<T>(t, x, u, xdot);
+      quadrotor_J_from<T>(t, x, u, J);
+      return;
+    }
     if (KIND == MODEL_PENDULUM) {   // one sincos for f (sin) and J (cos)
       const T l = T(0.5), g = T(9.81), b = T(0.1), mm = T(1.0) * l * l;
       T sn, cs;

@@ -108,7 +108,9 @@ typedef enum altro_hip_model {
   ALTRO_HIP_MODEL_LINEAR = 0,            /* x+ = A_k x + B_k u + f_k from the uploaded data      */
   ALTRO_HIP_MODEL_DOUBLE_INTEGRATOR = 1, /* test_utils.cpp:18-41                                  */
   ALTRO_HIP_MODEL_PENDULUM = 2,          /* test_utils.cpp:43-82 + midpoint :84-132               */
-  ALTRO_HIP_MODEL_BICYCLE = 3            /* test_utils.cpp:134-238 + midpoint                     */
+  ALTRO_HIP_MODEL_BICYCLE = 3,           /* test_utils.cpp:134-238 + midpoint                     */
+  ALTRO_HIP_MODEL_USER = 4,              /* set by altro_hip_set_model_source (not a value to pass) */
+  ALTRO_HIP_MODEL_QUADROTOR = 5          /* 12 states, 4 inputs, plan MFMA16 (csrc/models.h) + midpoint; not a reference model */
 } altro_hip_model;
 
 /* ---- library ------------------------------------------------------------------------------- */
@@ -185,7 +187,11 @@ int altro_hip_get_qblocks(altro_hip_batch* h, double* qblocks);
  * :710-719) -- with the tracking cost below; no altro_hip_set_model.  From altro_hip_set_tracking_cost on, the
  * backward sweep of such a handle ignores f, as the reference's expansion does (f_.setZero(), :416), while the
  * rollout keeps it.  Constraint blocks (all four cones) and the regularisation schedule work on both plans.  */
-/* Device model standing in for SetExplicitDynamics' host callbacks (altro_solver.cpp:68-81).        */
+/* Device model standing in for SetExplicitDynamics' host callbacks (altro_solver.cpp:68-81).  Plan LANE: ALTRO_HIP_MODEL_DOUBLE_INTEGRATOR,
+ * _PENDULUM, _BICYCLE (the reference's test models).  Plan MFMA16 with (n, m) = (12, 4) and fp64 records: ALTRO_HIP_MODEL_QUADROTOR
+ * (12-state rigid-body quadrotor, csrc/models.h; not a reference model) -- NONLINEAR dynamics on the tile plan: rollout and merit
+ * evaluation step the model (explicit midpoint, test/test_utils.cpp:84-132), the expansion writes A, B into the records the backward
+ * sweep reads (knotpoint_data.cpp:406-419); no altro_hip_set_dynamics then.                                                      */
 int altro_hip_set_model(altro_hip_batch* h, int model, float timestep, int bicycle_frame,
                         double bicycle_length, double bicycle_lr);
 /* ALTROSolver::SetExplicitDynamics (altro_solver.cpp:68-81) for the batched path, for dynamics the library does not ship:

@@ -20,6 +20,7 @@
 #define ORACLE_MODEL_DOUBLE_INTEGRATOR 0
 #define ORACLE_MODEL_PENDULUM 1
 #define ORACLE_MODEL_BICYCLE 2
+#define ORACLE_MODEL_QUADROTOR 3   /* NOT from the reference: this repo's own 12-state test model, see below */
 
 /* ---- double integrator (test_utils.cpp:18-41) ---------------------------------- */
 void oracle_di_dynamics(double* xnext, const double* x, const double* u, float h, int dim) {
@@ -185,6 +186,73 @@ void oracle_bicycle_jacobian(const oracle_bicycle* mdl, double* jac, const doubl
 #undef J
 }
 
+/* ---- quadrotor, 12 states, 4 inputs -----------------------------------------------------------
+ * NOT a model of the reference (its tests stop at 4 states): a quaternion-free rigid-body quadrotor used to exercise
+ * ALTROSolver::SetExplicitDynamics-style NONLINEAR dynamics at the (12, 4) shape BASELINE.json calls "quadrotor-sized".
+ * It enters the solver exactly as the reference's models do -- continuous f and its Jacobian through the midpoint rule
+ * below -- and its Jacobian is checked against central differences in tests/test_oracle_kat.py.
+ *   x = [p (3) | roll phi, pitch theta, yaw psi | v (3, world) | omega (3, body)],  u = [thrust F | torques tau (3)]
+ *   pdot = v ;  [phi; theta; psi]' = W(phi, theta) omega ;  vdot = -g e3 + F/mass R(phi, theta, psi) e3 ;
+ *   omegadot = I^-1 (tau - omega x I omega),  I = diag(Ix, Iy, Iz)                                            */
+#define QUAD_MASS 0.5
+#define QUAD_G 9.81
+#define QUAD_IX 0.0023
+#define QUAD_IY 0.0023
+#define QUAD_IZ 0.004
+void oracle_quadrotor_dynamics(double* xd, const double* x, const double* u) {
+  const double sp = sin(x[3]), cp = cos(x[3]), st = sin(x[4]), ct = cos(x[4]), ss = sin(x[5]), cs = cos(x[5]);
+  const double tt = st / ct;
+  const double wx = x[9], wy = x[10], wz = x[11];
+  xd[0] = x[6]; xd[1] = x[7]; xd[2] = x[8];
+  xd[3] = wx + sp * tt * wy + cp * tt * wz;
+  xd[4] = cp * wy - sp * wz;
+  xd[5] = (sp * wy + cp * wz) / ct;
+  const double a = u[0] / QUAD_MASS;
+  xd[6] = a * (cp * st * cs + sp * ss);
+  xd[7] = a * (cp * st * ss - sp * cs);
+  xd[8] = a * (cp * ct) - QUAD_G;
+  xd[9] = (u[1] - (QUAD_IZ - QUAD_IY) * wy * wz) / QUAD_IX;
+  xd[10] = (u[2] - (QUAD_IX - QUAD_IZ) * wz * wx) / QUAD_IY;
+  xd[11] = (u[3] - (QUAD_IY - QUAD_IX) * wx * wy) / QUAD_IZ;
+}
+/* jac (12 x 16) column-major = [df/dx df/du] */
+void oracle_quadrotor_jacobian(double* jac, const double* x, const double* u) {
+  const int n = 12;
+  memset(jac, 0, sizeof(double) * 12 * 16);
+#define J(i, j) jac[(i) + (j) * n]
+  const double sp = sin(x[3]), cp = cos(x[3]), st = sin(x[4]), ct = cos(x[4]), ss = sin(x[5]), cs = cos(x[5]);
+  const double tt = st / ct, sec2 = 1.0 / (ct * ct);
+  const double wx = x[9], wy = x[10], wz = x[11];
+  J(0, 6) = 1.0; J(1, 7) = 1.0; J(2, 8) = 1.0;
+  /* Euler-angle rates */
+  J(3, 3) = cp * tt * wy - sp * tt * wz;
+  J(3, 4) = (sp * wy + cp * wz) * sec2;
+  J(3, 9) = 1.0; J(3, 10) = sp * tt; J(3, 11) = cp * tt;
+  J(4, 3) = -sp * wy - cp * wz;
+  J(4, 10) = cp; J(4, 11) = -sp;
+  J(5, 3) = (cp * wy - sp * wz) / ct;
+  J(5, 4) = (sp * wy + cp * wz) * st * sec2;
+  J(5, 10) = sp / ct; J(5, 11) = cp / ct;
+  /* translational acceleration */
+  const double a = u[0] / QUAD_MASS;
+  J(6, 3) = a * (-sp * st * cs + cp * ss);
+  J(6, 4) = a * (cp * ct * cs);
+  J(6, 5) = a * (-cp * st * ss + sp * cs);
+  J(6, 12) = (cp * st * cs + sp * ss) / QUAD_MASS;
+  J(7, 3) = a * (-sp * st * ss - cp * cs);
+  J(7, 4) = a * (cp * ct * ss);
+  J(7, 5) = a * (cp * st * cs + sp * ss);
+  J(7, 12) = (cp * st * ss - sp * cs) / QUAD_MASS;
+  J(8, 3) = a * (-sp * ct);
+  J(8, 4) = a * (-cp * st);
+  J(8, 12) = (cp * ct) / QUAD_MASS;
+  /* body rates */
+  J(9, 10) = -(QUAD_IZ - QUAD_IY) * wz / QUAD_IX; J(9, 11) = -(QUAD_IZ - QUAD_IY) * wy / QUAD_IX; J(9, 13) = 1.0 / QUAD_IX;
+  J(10, 9) = -(QUAD_IX - QUAD_IZ) * wz / QUAD_IY; J(10, 11) = -(QUAD_IX - QUAD_IZ) * wx / QUAD_IY; J(10, 14) = 1.0 / QUAD_IY;
+  J(11, 9) = -(QUAD_IY - QUAD_IX) * wy / QUAD_IZ; J(11, 10) = -(QUAD_IY - QUAD_IX) * wx / QUAD_IZ; J(11, 15) = 1.0 / QUAD_IZ;
+#undef J
+}
+
 /* ---- generic continuous-model dispatch + midpoint rule (test_utils.cpp:84-132) --- */
 typedef struct {
   int kind;            /* ORACLE_MODEL_* */
@@ -197,10 +265,12 @@ typedef struct {
 
 static void cont_dyn(const oracle_model* mdl, double* xdot, const double* x, const double* u) {
   if (mdl->kind == ORACLE_MODEL_PENDULUM) oracle_pendulum_dynamics(xdot, x, u);
+  else if (mdl->kind == ORACLE_MODEL_QUADROTOR) oracle_quadrotor_dynamics(xdot, x, u);
   else oracle_bicycle_dynamics(&mdl->bike, xdot, x, u);
 }
 static void cont_jac(const oracle_model* mdl, double* jac, const double* x, const double* u) {
   if (mdl->kind == ORACLE_MODEL_PENDULUM) oracle_pendulum_jacobian(jac, x, u);
+  else if (mdl->kind == ORACLE_MODEL_QUADROTOR) oracle_quadrotor_jacobian(jac, x, u);
   else oracle_bicycle_jacobian(&mdl->bike, jac, x, u);
 }
 
@@ -208,6 +278,7 @@ void oracle_model_dims(const oracle_model* mdl, int* n, int* m) {
   switch (mdl->kind) {
     case ORACLE_MODEL_DOUBLE_INTEGRATOR: *n = 2 * mdl->dim; *m = mdl->dim; break;
     case ORACLE_MODEL_PENDULUM: *n = 2; *m = 1; break;
+    case ORACLE_MODEL_QUADROTOR: *n = 12; *m = 4; break;
     default: *n = 4; *m = 2; break;
   }
 }

@@ -203,3 +203,27 @@ def quadratic_cost(batch, N, n, m, stream=81):
     col = lambda X: np.ascontiguousarray(np.swapaxes(X, -1, -2)).reshape(X.shape[0], X.shape[1], -1)   # column-major blocks
     return dict(Q=col(Q), R=col(R), H=col(H), q=0.3 * normal((batch, N + 1, n), stream + 3), r=0.3 * normal((batch, N, m), stream + 4),
                 c=uniform01((batch, N + 1), stream + 5))
+
+
+def quadrotor_ltv(batch, N, h=0.02, seed_stream=131):
+    """Time-varying LQ problems from linearisations of the 12-state quadrotor test model (oracle/models_oracle.c) along seeded random
+    states near hover: A_k, B_k of the explicit midpoint rule, a dense cost with a cross term.  Chains of integrators (torque ->
+    rate -> angle -> velocity -> position): the problem class on which an UNSYMMETRISED cost-to-go recursion lets the antisymmetric
+    rounding noise of P double every step (tests/test_gpu_parity.py::test_backward_sweep_keeps_p_symmetric)."""
+    import ctypes as C
+    from oracle import oracle
+    L = oracle.lib()
+    mdl = oracle.make_model(oracle.MODEL_QUADROTOR)
+    n, m = 12, 4
+    xs = 0.3 * normal((batch, N, n), seed_stream)
+    us = np.array([0.5 * 9.81, 0, 0, 0]) + normal((batch, N, m), seed_stream + 1) * np.array([0.5, 0.01, 0.01, 0.01])
+    A = np.zeros((batch, N, n * n)); B = np.zeros((batch, N, n * m))
+    J = np.zeros(n * (n + m))
+    for b in range(batch):
+        for k in range(N):
+            L.oracle_discrete_jacobian(C.byref(mdl), J, np.ascontiguousarray(xs[b, k]), np.ascontiguousarray(us[b, k]), np.float32(h))
+            A[b, k] = J[:n * n]; B[b, k] = J[n * n:]
+    cost = quadratic_cost(batch, N, n, m, stream=seed_stream + 2)
+    R = cost["R"] + np.diag([0.0, 20.0, 20.0, 20.0]).reshape(-1)
+    return dict(N=N, n=n, m=m, A=A, B=B, f=np.zeros((batch, N, n)), Q=cost["Q"], R=R, H=cost["H"], q=cost["q"], r=cost["r"],
+                x0=normal((batch, n), seed_stream + 8))

@@ -336,3 +336,104 @@ def test_padded_shape_ilqr_solve_mfma16(nn, mm, constrained):
             assert np.abs(u[b]).max() <= 0.3 + 2e-4
     assert nconv >= 2
     bt.close()
+
+
+def _c1_bounded(x0, itmax):
+    """bench.py's constrained C1 workload for the initial states x0: device handle solved with iterations_max = itmax."""
+    Nf = 256
+    one = problems.c1_double_integrator(1, N=Nf)
+    bt = altro_amd.Batch(Nf, 12, 4, x0.shape[0])
+    bt.set_dynamics(one["A"][0, :1], one["B"][0, :1], None, k_stride_zero=True, batch_stride_zero=True)
+    Qd = np.stack([np.ones(12), 100.0 * np.ones(12)])
+    bt.set_tracking_cost(Qd, np.full((1, 4), 1e-2), np.zeros((2, 12)), np.zeros((1, 4)), k_stride_zero=True, batch_stride_zero=True)
+    bt.set_initial_state(x0)
+    bt.set_input_guess(np.zeros((1, 1, 4)), k_stride_zero=True, batch_stride_zero=True)
+    Gb = np.zeros((8, 16)); Gb[:4, 12:] = np.eye(4); Gb[4:, 12:] = -np.eye(4)
+    bt.add_linear_constraint(0, Nf - 1, altro_amd.CONE_INEQUALITY, Gb, np.full(8, 2.0))
+    res = bt.ilqr_solve(iterations_max=itmax)
+    x, u = bt.get_nominal()
+    bt.close()
+    return res, x, u
+
+
+def _c1_bounded_oracle(x0b, itmax):
+    Nf = 256
+    one = problems.c1_double_integrator(1, N=Nf)
+    A = np.ascontiguousarray(np.tile(one["A"][0, :1], (Nf, 1))); B = np.ascontiguousarray(np.tile(one["B"][0, :1], (Nf, 1)))
+    Gb = np.zeros((8, 16)); Gb[:4, 12:] = np.eye(4); Gb[4:, 12:] = -np.eye(4)
+    s = oracle.ILQR(Nf, 12, 4, 0.01, oracle.DYN_LINEAR, cost_kind=oracle.COST_DIAGONAL)
+    s.L.oracle_ilqr_set_linear_dynamics(s.h, A, B, None)
+    for k in range(Nf + 1):
+        s.L.oracle_ilqr_set_lqr_cost(s.h, k, np.ascontiguousarray(100.0 * np.ones(12) if k == Nf else np.ones(12)), np.full(4, 1e-2), np.zeros(12), np.zeros(4))
+    s.L.oracle_ilqr_set_initial_state(s.h, np.ascontiguousarray(x0b))
+    for k in range(Nf):
+        s.add_linear_constraint(k, oracle.CONE_INEQUALITY, Gb, np.full(8, 2.0))
+    s.L.oracle_ilqr_initialize(s.h)
+    s.set_penalty(1.0, 10.0)
+    s.L.oracle_ilqr_set_options(s.h, itmax, 1e-4, 1e-4, 1e-8, 0)
+    status, iters, log = s.solve()
+    return s, status, iters, log
+
+
+def test_bench_constrained_workload_sample_vs_oracle():
+    """bench.py's `config.ilqr_constrained_solve` at its own size: the C1 batch -- 4096 double integrators,
+    N = 256, x0 ~ U(-1, 1)^12 -- with input bounds |u| <= 2 as one AL-iLQR solve (cubic line search, iterations_max 40).  A seeded
+    sample of 32 problems INCLUDING the batch's stragglers (the problems that did not end in Success, the ones with the most
+    iterations and dual updates) goes through oracle.ILQR one by one.
+
+    What the batch's non-converged problems are (tools/straggler_trace.py prints the iterations): after a penalty update one
+    sweep's line search works at the resolution of the merit function itself -- e.g. phi(0) = 125.5648687, phi'(0) = -1.3e-3,
+    accepted step ~1.5e-3 after 16 evaluations, i.e. a sufficient-decrease margin c1 alpha phi' ~ 2e-10 against values of 1e2 whose
+    last digits (1e-13 relative) differ between any two orders of summation.  Device and oracle then resolve the search
+    differently (one ends it `Success`, the other with a line-search failure, which by solver.cpp:450-453 stops the solve as
+    `Unsolved`).  So: a problem either agrees outright -- status, iterations, dual updates, final step, feasibility, stationarity,
+    trajectory 1e-7 -- or (1) it agrees with the oracle, trajectory included, up to the sweep before the first difference and
+    (2) that sweep's line search is such a rounding-limited one in the oracle's own log (>= 8 evaluations or a step below 1e-2)."""
+    Nf, batch = 256, 4096
+    x0 = 2.0 * problems.uniform01((batch, 12), 21) - 1.0
+    res, x, u = _c1_bounded(x0, 40)
+    stragglers = np.flatnonzero(res["status"] != 0)
+    order_it = np.argsort(-res["iterations"], kind="stable")
+    order_du = np.argsort(-res["dual_updates"], kind="stable")
+    rng = np.random.default_rng(20260929)
+    pick = list(stragglers[:8]) + list(order_it[:6]) + list(order_du[:4]) + list(rng.choice(batch, size=64, replace=False))
+    sample = []
+    for b in pick:
+        if int(b) not in sample:
+            sample.append(int(b))
+        if len(sample) == 32:
+            break
+    n_strag = sum(1 for b in sample if res["status"][b] != 0)
+    assert len(stragglers) == 0 or n_strag >= min(4, len(stragglers))
+    same, differ = 0, []
+    for b in sample:
+        s, status, iters, log = _c1_bounded_oracle(x0[b], 40)
+        last = log[iters - 1]      # alpha, phi0, phi, dphi0, stationarity, ls_iters, feasibility, rho
+        outright = (res["status"][b] == status and res["iterations"][b] == iters and
+                    abs(res["alpha"][b] - last[0]) <= 1e-9 * max(1.0, abs(last[0])))
+        if outright:
+            assert abs(res["feasibility"][b] - last[6]) <= 1e-9 + 1e-5 * last[6], (b, res["feasibility"][b], last[6])
+            assert abs(res["stationarity"][b] - last[4]) <= 1e-8 + 1e-4 * abs(last[4]), (b, res["stationarity"][b], last[4])
+            assert abs(res["penalty"][b] - last[7]) <= 1e-12 * last[7]
+            np.testing.assert_allclose(x[b], s.get("x"), rtol=1e-7, atol=1e-7)
+            np.testing.assert_allclose(u[b], s.get("u"), rtol=1e-6, atol=1e-6)
+            same += 1
+        else:
+            differ.append((b, int(res["status"][b]), int(res["iterations"][b]), status, iters, log))
+    print("constrained C1 batch: %d of %d converged, %d stragglers; sample of 32 with %d of them: %d agree outright, %d differ at a "
+          "rounding-limited line search" % ((res["status"] == 0).sum(), batch, len(stragglers), n_strag, same, len(differ)))
+    assert same >= 16, (same, [(d[0], d[1], d[2], d[3], d[4]) for d in differ])
+    for (b, st_d, it_d, st_o, it_o, log) in differ:
+        upto = min(it_d, it_o)
+        hard = [i for i in range(upto) if log[i][5] >= 8 or log[i][0] < 2e-2]      # sweeps (0-based) with a rounding-limited search
+        assert hard, ("problem %d differs (device %d / %d, oracle %d / %d) without a rounding-limited line search" % (b, st_d, it_d, st_o, it_o),
+                      log[:upto, [0, 5]])
+        i_first = hard[0] + 1                         # 1-based: everything before this sweep must be identical
+        if i_first >= 2:
+            rd, xd, ud = _c1_bounded(x0[b:b + 1], i_first - 1)
+            so, st2, it2, log2 = _c1_bounded_oracle(x0[b], i_first - 1)
+            assert rd["iterations"][0] == it2 and rd["status"][0] == st2, (b, i_first, rd["iterations"][0], it2)
+            np.testing.assert_allclose(xd[0], so.get("x"), rtol=1e-7, atol=1e-7)
+            np.testing.assert_allclose(ud[0], so.get("u"), rtol=1e-6, atol=1e-6)
+            ref_phi = log2[i_first - 2][2]          # (the log holds one row per sweep run: i_first - 1 of them)
+            assert abs(rd["phi"][0] - ref_phi) <= 1e-10 * max(1.0, abs(ref_phi)), (b, rd["phi"][0], ref_phi)

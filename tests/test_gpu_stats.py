@@ -158,9 +158,9 @@ def test_comm_create_gives_up_when_a_rank_never_joins():
             "os.environ['ALTRO_HIP_COMM_TIMEOUT_S'] = '3'\n"
             "try:\n"
             "    altro_amd.Comm(0, 0, 2, altro_amd.Comm.unique_id())\n"
-            "    print('JOINED')\n"
+            "    print('JOINED', flush=True)\n"
             "except Exception as e:\n"
-            "    print('ERR', e)\n"
+            "    print('ERR', e, flush=True)\n"
             "os._exit(0)\n")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

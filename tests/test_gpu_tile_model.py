@@ -1,0 +1,156 @@
+"""NONLINEAR dynamics on the (12, 4) tile plan (missing #2): altro_hip_set_model on plan MFMA16 -- the rollout and the
+merit evaluation step a device model (explicit midpoint rule, test/test_utils.cpp:84-132), the expansion leaves A, B in the
+records the backward sweep reads (KnotPointData::CalcDynamicsExpansion, knotpoint_data.cpp:406-419) -- against the oracle running
+the same model through its restatement of SolverImpl.  The model is the 12-state quadrotor of csrc/models.h / oracle/models_oracle.c
+(this repo's own test model: the reference ships none that large; its Jacobian is pinned by central differences in
+tests/test_oracle_kat.py).
+
+Tolerances: one merit evaluation phi 1e-10, phi' 1e-8 relative, candidates 2e-9 / 2e-8 (device vs glibc sin / cos differ in the
+last ulp, the tile's sums are reassociated, and 40 closed-loop steps of a quadrotor with gains of order 1e2 amplify both: the first
+run measured 1.7e-10 on one entry of 492); whole solves: same status and iterations per problem, trajectories 1e-6."""
+import numpy as np
+import pytest
+
+import altro_amd
+from oracle import oracle
+from tests import problems
+
+pytestmark = pytest.mark.gpu
+
+N, n, m = 40, 12, 4
+H = np.float32(0.02)
+HOVER = np.array([0.5 * 9.81, 0.0, 0.0, 0.0])
+
+
+def make_case(batch, dense):
+    """Fly from a perturbed state to hover at the origin: tracking cost (or the same as dense blocks + a cross term)."""
+    x0 = np.zeros((batch, n))
+    x0[:, :3] = 0.8 * problems.normal((batch, 3), 91)
+    x0[:, 3:6] = 0.15 * problems.normal((batch, 3), 92)
+    x0[:, 6:9] = 0.3 * problems.normal((batch, 3), 93)
+    x0[:, 9:] = 0.2 * problems.normal((batch, 3), 94)
+    Qd = np.concatenate([np.full(3, 2.0), np.full(3, 1.0), np.full(3, 0.5), np.full(3, 0.1)])
+    Rd = np.array([0.05, 20.0, 20.0, 20.0])
+    c = dict(x0=x0, Qd=Qd, Qfd=20.0 * Qd, Rd=Rd, xref=np.zeros(n), uref=HOVER, u0=HOVER.copy())
+    if dense:
+        c.update(problems.quadratic_cost(batch, N, n, m, stream=121))
+        c["R"] = c["R"] + np.diag([0.0, 20.0, 20.0, 20.0]).T.reshape(-1)     # torques are tiny numbers: weigh them like the tracking cost
+        c["r"] = c["r"] * 0.0 - (c["R"].reshape(batch, N, m, m) @ HOVER)      # minimum at the hover input
+        c["q"] = c["q"] * 0.1
+    return c
+
+
+def make_hip(c, dense):
+    bt = altro_amd.Batch(N, n, m, c["x0"].shape[0])
+    assert bt.plan == altro_amd.PLAN_MFMA16
+    bt.set_model(altro_amd.MODEL_QUADROTOR, H)
+    if dense:
+        bt.set_quadratic_cost(c["Q"], c["R"], c["H"], c["q"], c["r"], c["c"])
+    else:
+        bt.set_tracking_cost(np.stack([c["Qd"], c["Qfd"]]), c["Rd"][None], np.stack([c["xref"], c["xref"]]), c["uref"][None],
+                             k_stride_zero=True, batch_stride_zero=True)
+    bt.set_initial_state(c["x0"])
+    bt.set_input_guess(c["u0"][None, None], k_stride_zero=True, batch_stride_zero=True)
+    return bt
+
+
+def make_oracle(c, b, dense, blocks=()):
+    s = oracle.ILQR(N, n, m, H, oracle.DYN_MODEL, oracle.MODEL_QUADROTOR, cost_kind=oracle.COST_QUADRATIC if dense else oracle.COST_DIAGONAL)
+    for k in range(N + 1):
+        kk = min(k, N - 1)
+        if dense:
+            s.L.oracle_ilqr_set_quadratic_cost(s.h, k, np.ascontiguousarray(c["Q"][b, k]), np.ascontiguousarray(c["R"][b, kk]).ctypes.data,
+                                               np.ascontiguousarray(c["H"][b, kk]).ctypes.data, np.ascontiguousarray(c["q"][b, k]),
+                                               np.ascontiguousarray(c["r"][b, kk]).ctypes.data, float(c["c"][b, k]))
+        else:
+            s.L.oracle_ilqr_set_lqr_cost(s.h, k, np.ascontiguousarray(c["Qfd"] if k == N else c["Qd"]), np.ascontiguousarray(c["Rd"]),
+                                         np.ascontiguousarray(c["xref"]), np.ascontiguousarray(c["uref"]))
+    s.L.oracle_ilqr_set_initial_state(s.h, np.ascontiguousarray(c["x0"][b]))
+    for (k0, k1, cone, G, g) in blocks:
+        for k in range(k0, k1 + 1):
+            s.add_linear_constraint(k, cone, G, g)
+    s.L.oracle_ilqr_initialize(s.h)
+    for k in range(N):
+        s.L.oracle_ilqr_set_input(s.h, k, np.ascontiguousarray(c["u0"]))
+    return s
+
+
+@pytest.mark.parametrize("dense", [False, True])
+def test_merit_expansion_stationarity(dense):
+    """Rollout, expansion (A, B through the gains of the backward sweep), one merit evaluation per problem at its own alpha:
+    phi, phi', candidate x_ / u_ / y_, and the candidate's stationarity (which reads the Z rows the pass left in the records)."""
+    batch = 9
+    c = make_case(batch, dense)
+    bt = make_hip(c, dense)
+    bt.open_loop_rollout(); bt.accept(); bt.expand()
+    A0, B0, lx0, lu0 = bt.get_expansion()             # the expansion at the rolled-out trajectory (before any merit pass)
+    bt.backward()
+    assert (bt.get("status") == -1).all()
+    alphas = np.linspace(0.0, 1.0, batch)
+    phi, dphi = bt.merit(alphas)
+    xc, uc, yc = bt.get("x"), bt.get("u"), bt.get("y")
+    st = bt.stationarity()
+    K = bt.get("K")
+    for b in [0, 3, 8]:
+        s = make_oracle(c, b, dense)
+        s.L.oracle_ilqr_open_loop_rollout(s.h); s.L.oracle_ilqr_copy_trajectory(s.h)
+        s.L.oracle_ilqr_calc_dynamics_expansions(s.h); s.L.oracle_ilqr_calc_cost_gradient(s.h)
+        s.L.oracle_ilqr_calc_expansions(s.h)
+        np.testing.assert_allclose(A0[b], s.get("A"), rtol=1e-12, atol=1e-12)    # CalcDynamicsExpansion: A, B of the midpoint rule
+        np.testing.assert_allclose(B0[b], s.get("B"), rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(lx0[b], s.get("lx"), rtol=1e-11, atol=1e-11)
+        np.testing.assert_allclose(lu0[b], s.get("lu"), rtol=1e-11, atol=1e-11)
+        assert s.L.oracle_ilqr_backward_pass(s.h) == -1
+        Kr = s.get("K")
+        assert np.abs(K[b] - Kr).max() <= 1e-8 * max(1.0, np.abs(Kr).max())          # gains: A, B, lxx, luu, lux all entered
+        p_ref, dp_ref = s.merit(alphas[b])
+        assert abs(phi[b] - p_ref) <= 1e-10 * max(1.0, abs(p_ref)), (b, phi[b], p_ref)
+        assert abs(dphi[b] - dp_ref) <= 1e-8 * max(1.0, abs(dp_ref)), (b, dphi[b], dp_ref)
+        np.testing.assert_allclose(xc[b], s.get("x_cand"), rtol=2e-9, atol=2e-9)
+        np.testing.assert_allclose(uc[b], s.get("u_cand"), rtol=2e-8, atol=2e-8)
+        np.testing.assert_allclose(yc[b], s.get("y_cand"), rtol=1e-7, atol=1e-7)
+        ref_st = s.L.oracle_ilqr_stationarity(s.h)
+        assert abs(st[b] - ref_st) <= 1e-7 * max(1.0, ref_st), (b, st[b], ref_st)
+
+
+@pytest.mark.parametrize("dense,constrained,backtracking", [(False, False, False), (False, True, False), (True, False, False),
+                                                             (False, False, True), (True, True, False)])
+def test_whole_solves(dense, constrained, backtracking):
+    """Whole (AL-)iLQR solves of the nonlinear 12-state problem on the tile plan: status, iterations, trajectories per problem;
+    with thrust / torque bounds as an INEQUALITY block when `constrained`."""
+    batch = 21
+    c = make_case(batch, dense)
+    bt = make_hip(c, dense)
+    blocks = []
+    if constrained:
+        Gb = np.zeros((2, n + m)); Gb[0, 12] = 1.0; Gb[1, 12] = -1.0
+        blocks = [(0, N - 1, altro_amd.CONE_INEQUALITY, Gb, np.array([1.25 * HOVER[0], -0.6 * HOVER[0]]))]
+        for (k0, k1, cone, G, g) in blocks:
+            bt.add_linear_constraint(k0, k1, cone, G, g)
+    # (tol_stationarity 1e-3: at the default 1e-4 most of these stall just above it -- phi' below tol_meritfun_gradient, step 0,
+    #  the reference's own behaviour -- and run into the iteration limit, device and oracle alike)
+    res = bt.ilqr_solve(iterations_max=50, use_backtracking=backtracking, tol_stationarity=1e-3)
+    x, u = bt.get_nominal()
+    nconv = 0
+    for b in [0, 10, 20]:
+        s = make_oracle(c, b, dense, blocks)
+        if blocks:
+            s.set_penalty(1.0, 10.0)
+        s.L.oracle_ilqr_set_options(s.h, 50, 1e-3, 1e-4, 1e-8, 1 if backtracking else 0)
+        status, iters, log = s.solve()
+        assert res["status"][b] == status and res["iterations"][b] == iters, (b, res["status"][b], status, res["iterations"][b], iters)
+        if status != 0:
+            continue
+        nconv += 1
+        np.testing.assert_allclose(x[b], s.get("x"), rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(u[b], s.get("u"), rtol=1e-5, atol=1e-5)
+    assert nconv >= 2
+
+
+def test_model_needs_the_tile_shape_and_fp64():
+    bt = altro_amd.Batch(N, 9, 3, 4, plan=altro_amd.PLAN_MFMA16)
+    with pytest.raises(altro_amd.AltroHipError):
+        bt.set_model(altro_amd.MODEL_QUADROTOR, H)
+    bt = altro_amd.Batch(N, 12, 4, 4, dtype=altro_amd.F32)
+    with pytest.raises(altro_amd.AltroHipError):
+        bt.set_model(altro_amd.MODEL_QUADROTOR, H)

@@ -535,3 +535,47 @@ def test_bicycle_turn90(kats):
     s.L.oracle_ilqr_set_options(s.h, kat["iterations_max"], 1e-4, 1e-4, 1e-8, kat["use_backtracking"])
     status, iters, log = s.solve()
     assert np.linalg.norm(s.get("x")[-1] - xf) < kat["goal_tol"]
+
+
+def test_quadrotor_test_model_jacobian_by_central_differences():
+    """The 12-state quadrotor (oracle/models_oracle.c) is this repo's own test model for NONLINEAR dynamics at the (12, 4)
+    shape -- the reference ships none that large -- so nothing of the reference pins it: its analytic Jacobian is checked here
+    against central differences of its own dynamics, continuous and discretised (midpoint rule + chain rule, the reference's
+    test_utils.cpp:84-132), and a hover input keeps the hovering state a fixed point."""
+    import ctypes as C
+    L = oracle.lib()
+    L.oracle_quadrotor_dynamics.argtypes = [C.c_void_p] * 3
+    L.oracle_quadrotor_jacobian.argtypes = [C.c_void_p] * 3
+    rng = np.random.default_rng(7)
+    mdl = oracle.make_model(oracle.MODEL_QUADROTOR)
+    h = np.float32(0.02)
+    for trial in range(5):
+        x = rng.normal(size=12) * 0.4
+        u = np.array([0.5 * 9.81, 0.0, 0.0, 0.0]) + rng.normal(size=4) * np.array([1.0, 0.01, 0.01, 0.01])
+
+        def f(z):
+            out = np.zeros(12)
+            xx, uu = np.ascontiguousarray(z[:12]), np.ascontiguousarray(z[12:])
+            L.oracle_quadrotor_dynamics(out.ctypes.data, xx.ctypes.data, uu.ctypes.data)
+            return out
+
+        def F(z):
+            out = np.zeros(12)
+            L.oracle_discrete_dynamics(C.byref(mdl), out, np.ascontiguousarray(z[:12]), np.ascontiguousarray(z[12:]), h)
+            return out
+        z = np.concatenate([x, u])
+        J = np.zeros(12 * 16)
+        L.oracle_quadrotor_jacobian(J.ctypes.data, x.ctypes.data, u.ctypes.data)
+        Jd = np.zeros(12 * 16)
+        L.oracle_discrete_jacobian(C.byref(mdl), Jd, x, u, h)
+        for (fun, Jan) in ((f, J.reshape(16, 12).T), (F, Jd.reshape(16, 12).T)):
+            num = np.zeros((12, 16))
+            for c in range(16):
+                e = np.zeros(16); e[c] = 1e-6 * max(1.0, abs(z[c]))
+                num[:, c] = (fun(z + e) - fun(z - e)) / (2 * e[c])
+            assert np.abs(num - Jan).max() <= 2e-7 * max(1.0, np.abs(Jan).max()), (trial, np.abs(num - Jan).max())
+    hover_x = np.zeros(12); hover_x[:3] = [1.0, -2.0, 3.0]
+    hover_u = np.array([0.5 * 9.81, 0, 0, 0.0])
+    out = np.zeros(12)
+    L.oracle_discrete_dynamics(C.byref(mdl), out, hover_x, hover_u, h)
+    assert np.abs(out - hover_x).max() < 1e-15
