@@ -212,6 +212,16 @@ int wave_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int
   a.spec_stride = (int64_t)h->batch * (h->N + 1) * 28;
   a.ls_beta = h->spec_beta; a.ls_max_iters = h->spec_max_iters;
   a.skip = which == IK_STATIONARITY ? h->stat_skip : nullptr;
+  if (h->model_set && h->model.kind == MODEL_USER) {   // the caller's own model, compiled at run time (capi_rtc.hip): fp64 handles only
+    if constexpr (sizeof(S) == 8) {
+      if (which == IK_ROLLOUT || which == IK_MERIT || which == IK_MERIT2) return rtc_tile_launch(h, which, a);
+      if (which == IK_EXPAND && (a.mode & EXPAND_DYN)) {
+        const int rcm = rtc_tile_launch(h, IK_EXPAND, a);
+        if (rcm) return rcm;
+      }
+    }
+    a.mp.kind = MODEL_LINEAR;   // (what follows are the cost kernels: none of them steps the dynamics)
+  }
   const int rc = ilqr_wave_launch_kernel<S>(h->stream, which, a);
   if (rc == 1) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "operation %d is not available on plan MFMA16", which);
   if (rc) return fail(ALTRO_HIP_ERR_HIP, "iLQR kernel launch failed");

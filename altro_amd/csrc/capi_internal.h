@@ -433,6 +433,7 @@ enum RtcKernel { RTC_ROLLOUT = 0, RTC_ACCEPT, RTC_EXPAND, RTC_MERIT, RTC_MERIT_R
                  RTC_ZERO_RESIDUALS, RTC_STATIONARITY, RTC_DUAL, RTC_SHIFT, RTC_NUM };
 template <typename T>
 int rtc_launch(altro_hip_batch* h, int which, const IlqrArgs<T>& a);
+int rtc_tile_launch(altro_hip_batch* h, int which, const IlqrWaveArgs<double>& a);   // plan MFMA16: the model kernels of a caller's source
 
 // the sweep launchers (capi_tvlqr.hip), also used by the iLQR loop
 int launch_backward(altro_hip_batch* h, double reg);

@@ -43,6 +43,11 @@ ALTRO_EMBED(altro_rtc_src_lane_body, "kernels/tvlqr_lane_body.inc")
 ALTRO_EMBED(altro_rtc_src_quad_body, "kernels/tvlqr_quad_body.inc")
 ALTRO_EMBED(altro_rtc_src_quad2_body, "kernels/tvlqr_quad2_body.inc")
 ALTRO_EMBED(altro_rtc_src_ilqr_lane, "kernels/ilqr_lane.hip")
+// ... and of the tile plan's row-layout kernels (a caller's model on plan MFMA16)
+ALTRO_EMBED(altro_rtc_src_mfma16_layout, "kernels/mfma16_layout.h")
+ALTRO_EMBED(altro_rtc_src_ilqr_mfma16, "kernels/ilqr_mfma16.hip")
+ALTRO_EMBED(altro_rtc_src_merit2_dpp, "kernels/ilqr_merit2_dpp.hip")
+ALTRO_EMBED(altro_rtc_src_tile_model, "kernels/ilqr_tile_model.hip")
 
 namespace {
 
@@ -228,6 +233,121 @@ static int rtc_module_for(altro_hip_batch* h, const std::string& user_src, int c
   return 0;
 }
 
+// ---- the same for plan MFMA16: the caller's model inside the tile plan's row-layout kernels (kernels/ilqr_tile_model.hip) ------
+// One module per (source, n, m, constraint blocks?, dense cost?): the rollout, the dynamics expansion and the two merit kernels
+// (line-search round / two-trial pass) of that combination -- four kernels instead of ten, the merit kernels being the library's
+// heaviest compiles.
+enum RtcTileKernel { RTT_ROLLOUT = 0, RTT_EXPAND_DYN, RTT_MERIT, RTT_MERIT2, RTT_NUM };
+struct RtcTileModule {
+  hipModule_t module = nullptr;
+  hipFunction_t fn[RTT_NUM] = {};
+};
+static int rtc_tile_module_for(altro_hip_batch* h, int al, int dense, RtcTileModule** out) {
+  *out = nullptr;
+  static std::mutex mu;
+  static std::map<std::string, RtcTileModule*> cache;
+  const std::string& user_src = h->rtc_source;
+  const std::string key = std::to_string(h->device) + "|" + std::to_string(h->n) + "|" + std::to_string(h->m) + "|" + std::to_string(al) + "|" +
+                          std::to_string(dense) + "|" + user_src;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = cache.find(key);
+  if (it != cache.end()) { *out = it->second; return 0; }
+  const Hiprtc* R;
+  int rc = hiprtc_api(&R);
+  if (rc) return rc;
+  const char* B_[2] = {"false", "true"};
+  std::string exprs[RTT_NUM];
+  exprs[RTT_ROLLOUT] = "altro_hip::wave_rollout_model_kernel<double, altro_hip::MODEL_USER>";
+  exprs[RTT_EXPAND_DYN] = "altro_hip::wave_expand_dyn_kernel<double, altro_hip::MODEL_USER>";
+  exprs[RTT_MERIT] = std::string("altro_hip::wave_merit_dpp_kernel<double, ") + B_[al] + ", false, " + B_[dense] + ", altro_hip::MODEL_USER>";
+  exprs[RTT_MERIT2] = std::string("altro_hip::wave_merit_dpp_kernel<double, ") + B_[al] + ", true, " + B_[dense] + ", altro_hip::MODEL_USER>";
+  std::string src = "#define ALTRO_HIP_USER_MODEL 1\n#define ALTRO_HIP_TILE_N " + std::to_string(h->n) + "\n#define ALTRO_HIP_TILE_M " +
+                    std::to_string(h->m) + "\n";
+  src += "#include \"rtc_compat.h\"\n#include \"fp_contract.h\"\nALTRO_FP_REGION_ON\n";
+  src += "#line 1 \"user_model\"\n" + user_src + "\nALTRO_FP_REGION_END\n#include \"kernels/ilqr_mfma16.hip\"\n#include \"kernels/ilqr_merit2_dpp.hip\"\n"
+         "namespace altro_hip {\n";
+  for (int w = 0; w < RTT_NUM; ++w) {
+    std::string e = exprs[w];
+    for (size_t p; (p = e.find("altro_hip::")) != std::string::npos;) e.erase(p, std::strlen("altro_hip::"));
+    src += "template __global__ void " + e + "(IlqrWaveArgs<double>);\n";
+  }
+  src += "}\n";
+  const char* hdr_src[] = {altro_rtc_src_rtc_compat, altro_rtc_src_fp_contract, altro_rtc_src_models, altro_rtc_src_linesearch,
+                           altro_rtc_src_ilqr_types, altro_rtc_src_al_types, altro_rtc_src_al_lane, altro_rtc_src_tvlqr_lane,
+                           altro_rtc_src_lane_body, altro_rtc_src_quad_body, altro_rtc_src_quad2_body, altro_rtc_src_mfma16_layout,
+                           altro_rtc_src_ilqr_mfma16, altro_rtc_src_merit2_dpp, altro_rtc_src_tile_model};
+  const char* hdr_name[] = {"rtc_compat.h", "fp_contract.h", "models.h", "linesearch_sm.h", "kernels/ilqr_types.h", "kernels/al_types.h",
+                            "kernels/al_lane.hip", "kernels/tvlqr_lane.hip", "kernels/tvlqr_lane_body.inc", "kernels/tvlqr_quad_body.inc",
+                            "kernels/tvlqr_quad2_body.inc", "kernels/mfma16_layout.h", "kernels/ilqr_mfma16.hip",
+                            "kernels/ilqr_merit2_dpp.hip", "kernels/ilqr_tile_model.hip"};
+  hiprtcProgram prog = nullptr;
+  hiprtcResult rr = R->CreateProgram(&prog, src.c_str(), "altro_user_tile_model.hip", 15, hdr_src, hdr_name);
+  if (rr != HIPRTC_SUCCESS) return fail(ALTRO_HIP_ERR_HIP, "hiprtcCreateProgram: %s", R->GetErrorString(rr));
+  for (int w = 0; w < RTT_NUM; ++w) R->AddNameExpression(prog, exprs[w].c_str());
+  hipDeviceProp_t prop;
+  std::string arch = "--offload-arch=gfx950";
+  if (hipGetDeviceProperties(&prop, h->device) == hipSuccess) arch = std::string("--offload-arch=") + prop.gcnArchName;
+  const char* opts[] = {arch.c_str(), "-O3", "-std=c++17"};
+  rr = R->CompileProgram(prog, 3, opts);
+  if (rr != HIPRTC_SUCCESS) {
+    size_t ls = 0;
+    R->GetProgramLogSize(prog, &ls);
+    std::string log(ls, '\0');
+    if (ls) R->GetProgramLog(prog, &log[0]);
+    if (log.size() > 1800) log.resize(1800);
+    R->DestroyProgram(&prog);
+    return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "the model source does not compile for the tile plan (hiprtc: %s):\n%s", R->GetErrorString(rr), log.c_str());
+  }
+  size_t cs = 0;
+  R->GetCodeSize(prog, &cs);
+  std::vector<char> code(cs);
+  R->GetCode(prog, code.data());
+  RtcTileModule* m = new RtcTileModule();
+  if (const hipError_t le = hipModuleLoadData(&m->module, code.data()); le != hipSuccess) {
+    R->DestroyProgram(&prog);
+    delete m;
+    return fail(ALTRO_HIP_ERR_HIP, "hipModuleLoadData of the compiled tile model failed: %s", hipGetErrorString(le));
+  }
+  for (int w = 0; w < RTT_NUM; ++w) {
+    const char* lowered = nullptr;
+    if (R->GetLoweredName(prog, exprs[w].c_str(), &lowered) != HIPRTC_SUCCESS || !lowered ||
+        hipModuleGetFunction(&m->fn[w], m->module, lowered) != hipSuccess) {
+      rc = fail(ALTRO_HIP_ERR_HIP, "kernel %s missing from the compiled tile model", exprs[w].c_str());
+      R->DestroyProgram(&prog);
+      (void)hipModuleUnload(m->module);
+      delete m;
+      return rc;
+    }
+  }
+  R->DestroyProgram(&prog);
+  cache[key] = m;
+  *out = m;
+  return 0;
+}
+
+// A model kernel of plan MFMA16's loop from the handle's run-time module: the grids of ilqr_launch_mfma16_model.hip.
+int rtc_tile_launch(altro_hip_batch* h, int which, const IlqrWaveArgs<double>& a) {
+  if (h->rtc_source.empty()) return fail(ALTRO_HIP_ERR_NOT_SET, "altro_hip_set_model_source has not been called");
+  RtcTileModule* mod = nullptr;
+  int rc = rtc_tile_module_for(h, a.al.enabled ? 1 : 0, a.cost_dense ? 1 : 0, &mod);
+  if (rc) return rc;
+  IlqrWaveArgs<double> args = a;
+  void* params[] = {&args};
+  auto go = [&](int w, unsigned gx, unsigned gy) -> int {
+    const hipError_t e = hipModuleLaunchKernel(mod->fn[w], gx, gy, 1, 64, 1, 1, 0, h->stream, params, nullptr);
+    if (e != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "launch of the run-time compiled tile kernel %d failed: %s", w, hipGetErrorString(e));
+    return 0;
+  };
+  const unsigned pairs = (unsigned)mf_grid((a.batch + 1) / 2);
+  switch (which) {
+    case IK_ROLLOUT: return go(RTT_ROLLOUT, (unsigned)((a.batch + 3) / 4), 1);
+    case IK_EXPAND: return go(RTT_EXPAND_DYN, (unsigned)((int64_t)((a.batch + 3) / 4) * a.N), 1);
+    case IK_MERIT: return go(RTT_MERIT, pairs, (unsigned)(((a.spec_trials > 1 ? a.spec_trials : 1) + 1) / 2));
+    case IK_MERIT2: return go(RTT_MERIT2, pairs, 1);
+    default: return fail(ALTRO_HIP_ERR_UNSUPPORTED, "operation %d has no run-time compiled tile kernel", which);
+  }
+}
+
 // One kernel of the launch-sequenced loop from the handle's run-time module: the grids of ilqr_launch_kernel (ilqr_launch_f64.hip).
 template <typename T>
 int rtc_launch(altro_hip_batch* h, int which, const IlqrArgs<T>& a) {
@@ -287,10 +407,26 @@ int altro_hip_set_model_source(altro_hip_batch* h, const char* source, float tim
   if (rc) return rc;
   if (!source) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "source == NULL");
   if (!(timestep > 0.0f)) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "time step must be positive (ErrorCodes::TimestepNotPositive)");
-  if (h->plan != ALTRO_HIP_PLAN_LANE)
-    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "run-time compiled models run on plan LANE (n <= 6, m <= 3); this handle is on plan %d with "
-                                           "(n, m) = (%d, %d)", h->plan, h->n, h->m);
+  if (h->plan != ALTRO_HIP_PLAN_LANE && h->plan != ALTRO_HIP_PLAN_MFMA16)
+    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "run-time compiled models run on plans LANE (n <= 6, m <= 3) and MFMA16 (n <= 12, m <= 4); this "
+                                           "handle is on plan %d with (n, m) = (%d, %d)", h->plan, h->n, h->m);
   HIP_TRY(hipSetDevice(h->device));
+  if (h->plan == ALTRO_HIP_PLAN_MFMA16) {   // the tile plan's row-layout kernels around the caller's model (kernels/ilqr_tile_model.hip)
+    if (h->dtype != ALTRO_HIP_F64)
+      return fail(ALTRO_HIP_ERR_UNSUPPORTED, "device models on plan MFMA16 run on fp64 records (create the handle with ALTRO_HIP_F64)");
+    const std::string tsrc(source);
+    if (defines_function(tsrc, "altro_user_constraint") || defines_function(tsrc, "altro_user_constraint_jacobian"))
+      return fail(ALTRO_HIP_ERR_UNSUPPORTED, "nonlinear constraint blocks from source are a plan LANE feature; plan MFMA16 takes the model's "
+                                             "two functions and linear blocks (altro_hip_add_linear_constraint)");
+    h->rtc_source = tsrc;
+    h->model = ModelParams{MODEL_USER, timestep, 0, 2.7, 1.5};
+    RtcTileModule* tm = nullptr;   // compile now: a source that does not build must fail HERE, with the compiler's log
+    if ((rc = rtc_tile_module_for(h, h->al_defs.empty() ? 0 : 1, h->cost_dense ? 1 : 0, &tm))) { h->rtc_source.clear(); return rc; }
+    h->model_set = true; h->rtc_has_constraints = false;
+    HIP_TRY(hipMemsetAsync(h->m_in, 0, (size_t)h->batch * h->N * MF_DYN * h->esz, h->stream));
+    h->dyn_set = true; h->has_f = 0;
+    return 0;
+  }
   RtcModule* m = nullptr;
   const std::string src(source);
   const bool c_val = defines_function(src, "altro_user_constraint"), c_jac = defines_function(src, "altro_user_constraint_jacobian");

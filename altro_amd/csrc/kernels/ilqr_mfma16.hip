@@ -23,8 +23,7 @@
 //   lanes 32..43 : row i of [P | p]     -> y[i]
 // Vectors are exchanged through LDS (broadcast reads).
 #pragma once
-#include <hip/hip_runtime.h>
-#include <stdint.h>
+#include "../rtc_compat.h"   // (also compiled at run time: a caller's own model on the tile plan, capi_rtc.hip)
 
 #include "ilqr_types.h"
 #include "mfma16_layout.h"

@@ -256,6 +256,36 @@ ALTRO_HD void quadrotor_J_from(const QuadTrig<T>& t, const T* x, const T* u, T* 
   J[11 + 9 * 12] = -T(kQuadIy - kQuadIx) * wy / T(kQuadIz); J[11 + 10 * 12] = -T(kQuadIy - kQuadIx) * wx / T(kQuadIz); J[11 + 15 * 12] = T(1) / T(kQuadIz);
 }
 
+#if defined(ALTRO_HIP_USER_MODEL) && defined(ALTRO_HIP_TILE_N)
+// A caller's model on the (12, 4) tile plan (capi_rtc.hip compiles this unit with ALTRO_HIP_TILE_N / _M = the problem's own
+// dimensions n <= 12, m <= 4): the tile's vectors are [x; 0] (12) and [u; 0] (4), its Jacobian 12 x 16 column-major with the
+// inputs in columns 12..15.  Padding states have xdot = 0 (they stay at 0; their rows of A are the identity's), padding inputs
+// no effect.
+template <typename T>
+ALTRO_HD void altro_tile_user_f(const T* x, const T* u, T* xdot) {
+  T xd[ALTRO_HIP_TILE_N];
+  altro_user_dynamics<T>(x, u, xd);
+#pragma unroll
+  for (int i = 0; i < 12; ++i) xdot[i] = T(0);
+#pragma unroll
+  for (int i = 0; i < ALTRO_HIP_TILE_N; ++i) xdot[i] = xd[i];
+}
+template <typename T>
+ALTRO_HD void altro_tile_user_J(const T* x, const T* u, T* J) {
+  T Ju[ALTRO_HIP_TILE_N * (ALTRO_HIP_TILE_N + ALTRO_HIP_TILE_M)];
+#pragma unroll
+  for (int e = 0; e < ALTRO_HIP_TILE_N * (ALTRO_HIP_TILE_N + ALTRO_HIP_TILE_M); ++e) Ju[e] = T(0);
+  altro_user_jacobian<T>(x, u, Ju);
+#pragma unroll
+  for (int e = 0; e < 192; ++e) J[e] = T(0);
+#pragma unroll
+  for (int c = 0; c < ALTRO_HIP_TILE_N + ALTRO_HIP_TILE_M; ++c)
+#pragma unroll
+    for (int i = 0; i < ALTRO_HIP_TILE_N; ++i)
+      J[i + 12 * (c < ALTRO_HIP_TILE_N ? c : 12 + (c - ALTRO_HIP_TILE_N))] = Ju[i + ALTRO_HIP_TILE_N * c];
+}
+#endif
+
 // ---- discrete models -------------------------------------------------------------------------------
 // KIND is a compile-time ModelKind; n, m the dimensions (double integrator: dim = n/2, the first m
 // axes are actuated -- m == dim is the reference's model, m < dim the C1 variant of SURVEY.md 8d).
@@ -270,7 +300,9 @@ struct DiscreteModel {
   // reference's test harness (test/test_utils.cpp:84-132).
   static ALTRO_HD void cont_f(const ModelParams& mp, const T* x, const T* u, T* xdot) {
     if (KIND == MODEL_PENDULUM) pendulum_f<T>(x, u, xdot);
-#if defined(ALTRO_HIP_USER_MODEL)
+#if defined(ALTRO_HIP_USER_MODEL) && defined(ALTRO_HIP_TILE_N)
+    else if (KIND == MODEL_USER) altro_tile_user_f<T>(x, u, xdot);
+#elif defined(ALTRO_HIP_USER_MODEL)
     else if (KIND == MODEL_USER) altro_user_dynamics<T>(x, u, xdot);
 #endif
     else if (KIND == MODEL_QUADROTOR) quadrotor_f_from<T>(quadrotor_trig<T>(x), x, u, xdot);
@@ -278,7 +310,9 @@ struct DiscreteModel {
   }
   static ALTRO_HD void cont_J(const ModelParams& mp, const T* x, const T* u, T* J) {
     if (KIND == MODEL_PENDULUM) pendulum_J<T>(x, u, J);
-#if defined(ALTRO_HIP_USER_MODEL)
+#if defined(ALTRO_HIP_USER_MODEL) && defined(ALTRO_HIP_TILE_N)
+    else if (KIND == MODEL_USER) altro_tile_user_J<T>(x, u, J);
+#elif defined(ALTRO_HIP_USER_MODEL)
     else if (KIND == MODEL_USER) altro_user_jacobian<T>(x, u, J);
 #endif
     else if (KIND == MODEL_QUADROTOR) quadrotor_J_from<T>(quadrotor_trig<T>(x), x, u, J);
@@ -286,7 +320,9 @@ struct DiscreteModel {
   }
 
   static ALTRO_HD void cont_fJ(const ModelParams& mp, const T* x, const T* u, T* xdot, T* J) {
-#if defined(ALTRO_HIP_USER_MODEL)
+#if defined(ALTRO_HIP_USER_MODEL) && defined(ALTRO_HIP_TILE_N)
+    if (KIND == MODEL_USER) { altro_tile_user_f<T>(x, u, xdot); altro_tile_user_J<T>(x, u, J); return; }
+#elif defined(ALTRO_HIP_USER_MODEL)
     if (KIND == MODEL_USER) { altro_user_dynamics<T>(x, u, xdot); altro_user_jacobian<T>(x, u, J); return; }
 #endif
     if (KIND == MODEL_QUADROTOR) {   // one set of sincos for f and J

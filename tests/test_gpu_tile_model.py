@@ -154,3 +154,136 @@ def test_model_needs_the_tile_shape_and_fp64():
     bt = altro_amd.Batch(N, 12, 4, 4, dtype=altro_amd.F32)
     with pytest.raises(altro_amd.AltroHipError):
         bt.set_model(altro_amd.MODEL_QUADROTOR, H)
+
+
+QUADROTOR_SRC = r"""
+// the caller's own 12-state quadrotor (the equations of csrc/models.h's MODEL_QUADROTOR, written as a user would hand them over)
+template <typename T> __device__ void altro_user_dynamics(const T* x, const T* u, T* xd) {
+  const T mass = T(0.5), g = T(9.81), Ix = T(0.0023), Iy = T(0.0023), Iz = T(0.004);
+  T sp, cp, st, ct, ss, cs;
+  sincos(x[3], &sp, &cp); sincos(x[4], &st, &ct); sincos(x[5], &ss, &cs);
+  const T tt = st / ct, wx = x[9], wy = x[10], wz = x[11];
+  xd[0] = x[6]; xd[1] = x[7]; xd[2] = x[8];
+  xd[3] = wx + sp * tt * wy + cp * tt * wz;
+  xd[4] = cp * wy - sp * wz;
+  xd[5] = (sp * wy + cp * wz) / ct;
+  const T a = u[0] / mass;
+  xd[6] = a * (cp * st * cs + sp * ss);
+  xd[7] = a * (cp * st * ss - sp * cs);
+  xd[8] = a * (cp * ct) - g;
+  xd[9] = (u[1] - (Iz - Iy) * wy * wz) / Ix;
+  xd[10] = (u[2] - (Ix - Iz) * wz * wx) / Iy;
+  xd[11] = (u[3] - (Iy - Ix) * wx * wy) / Iz;
+}
+template <typename T> __device__ void altro_user_jacobian(const T* x, const T* u, T* J) {
+  const T mass = T(0.5), Ix = T(0.0023), Iy = T(0.0023), Iz = T(0.004);
+  T sp, cp, st, ct, ss, cs;
+  sincos(x[3], &sp, &cp); sincos(x[4], &st, &ct); sincos(x[5], &ss, &cs);
+  const T tt = st / ct, sec2 = T(1) / (ct * ct), wx = x[9], wy = x[10], wz = x[11];
+  for (int e = 0; e < 192; ++e) J[e] = T(0);
+  J[0 + 6 * 12] = T(1); J[1 + 7 * 12] = T(1); J[2 + 8 * 12] = T(1);
+  J[3 + 3 * 12] = cp * tt * wy - sp * tt * wz; J[3 + 4 * 12] = (sp * wy + cp * wz) * sec2;
+  J[3 + 9 * 12] = T(1); J[3 + 10 * 12] = sp * tt; J[3 + 11 * 12] = cp * tt;
+  J[4 + 3 * 12] = -sp * wy - cp * wz; J[4 + 10 * 12] = cp; J[4 + 11 * 12] = -sp;
+  J[5 + 3 * 12] = (cp * wy - sp * wz) / ct; J[5 + 4 * 12] = (sp * wy + cp * wz) * st * sec2;
+  J[5 + 10 * 12] = sp / ct; J[5 + 11 * 12] = cp / ct;
+  const T a = u[0] / mass;
+  J[6 + 3 * 12] = a * (-sp * st * cs + cp * ss); J[6 + 4 * 12] = a * (cp * ct * cs); J[6 + 5 * 12] = a * (-cp * st * ss + sp * cs);
+  J[6 + 12 * 12] = (cp * st * cs + sp * ss) / mass;
+  J[7 + 3 * 12] = a * (-sp * st * ss - cp * cs); J[7 + 4 * 12] = a * (cp * ct * ss); J[7 + 5 * 12] = a * (cp * st * cs + sp * ss);
+  J[7 + 12 * 12] = (cp * st * ss - sp * cs) / mass;
+  J[8 + 3 * 12] = a * (-sp * ct); J[8 + 4 * 12] = a * (-cp * st); J[8 + 12 * 12] = (cp * ct) / mass;
+  J[9 + 10 * 12] = -(Iz - Iy) * wz / Ix; J[9 + 11 * 12] = -(Iz - Iy) * wy / Ix; J[9 + 13 * 12] = T(1) / Ix;
+  J[10 + 9 * 12] = -(Ix - Iz) * wz / Iy; J[10 + 11 * 12] = -(Ix - Iz) * wx / Iy; J[10 + 14 * 12] = T(1) / Iy;
+  J[11 + 9 * 12] = -(Iy - Ix) * wy / Iz; J[11 + 10 * 12] = -(Iy - Ix) * wx / Iz; J[11 + 15 * 12] = T(1) / Iz;
+}
+"""
+
+
+@pytest.mark.parametrize("constrained", [False, True])
+def test_user_source_on_the_tile_plan(constrained):
+    """altro_hip_set_model_source on plan MFMA16: the caller's own 12-state dynamics + Jacobian as HIP source, compiled by hiprtc into
+    the tile plan's row-layout kernels.  The quadrotor handed over as source solves like the compiled-in MODEL_QUADROTOR (same
+    equations, same kernels around them: status, iterations, trajectories 1e-10) and like the oracle."""
+    batch = 13
+    c = make_case(batch, False)
+    blocks = []
+    if constrained:
+        Gb = np.zeros((2, n + m)); Gb[0, 12] = 1.0; Gb[1, 12] = -1.0
+        blocks = [(0, N - 1, altro_amd.CONE_INEQUALITY, Gb, np.array([1.25 * HOVER[0], -0.6 * HOVER[0]]))]
+
+    def run(source):
+        bt = altro_amd.Batch(N, n, m, batch)
+        for (k0, k1, cone, G, g) in blocks:
+            bt.add_linear_constraint(k0, k1, cone, G, g)
+        if source:
+            bt.set_model_source(QUADROTOR_SRC, H)
+        else:
+            bt.set_model(altro_amd.MODEL_QUADROTOR, H)
+        bt.set_tracking_cost(np.stack([c["Qd"], c["Qfd"]]), c["Rd"][None], np.stack([c["xref"], c["xref"]]), c["uref"][None],
+                             k_stride_zero=True, batch_stride_zero=True)
+        bt.set_initial_state(c["x0"])
+        bt.set_input_guess(c["u0"][None, None], k_stride_zero=True, batch_stride_zero=True)
+        res = bt.ilqr_solve(iterations_max=50, tol_stationarity=1e-3)
+        return res, bt.get_nominal()
+    r_src, (x_src, u_src) = run(True)
+    r_mod, (x_mod, u_mod) = run(False)
+    assert np.array_equal(r_src["status"], r_mod["status"]) and np.array_equal(r_src["iterations"], r_mod["iterations"])
+    np.testing.assert_allclose(x_src, x_mod, rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(u_src, u_mod, rtol=1e-9, atol=1e-9)
+    s = make_oracle(c, 0, False, blocks)      # (problem 0: one of those test_whole_solves holds against the oracle)
+    if blocks:
+        s.set_penalty(1.0, 10.0)
+    s.L.oracle_ilqr_set_options(s.h, 50, 1e-3, 1e-4, 1e-8, 0)
+    status, iters, log = s.solve()
+    assert r_src["status"][0] == status and r_src["iterations"][0] == iters
+    np.testing.assert_allclose(x_src[0], s.get("x"), rtol=1e-6, atol=1e-6)
+
+
+PLANAR_SRC = r"""
+// planar quadrotor: x = [px, pz, theta, vx, vz, omega], u = [left thrust, right thrust]
+template <typename T> __device__ void altro_user_dynamics(const T* x, const T* u, T* xd) {
+  const T mass = T(1.0), g = T(9.81), l = T(0.25), I = T(0.05);
+  const T s = sin(x[2]), c = cos(x[2]), F = u[0] + u[1];
+  xd[0] = x[3]; xd[1] = x[4]; xd[2] = x[5];
+  xd[3] = -F * s / mass; xd[4] = F * c / mass - g; xd[5] = l * (u[1] - u[0]) / I;
+}
+template <typename T> __device__ void altro_user_jacobian(const T* x, const T* u, T* J) {
+  const T mass = T(1.0), l = T(0.25), I = T(0.05);
+  const T s = sin(x[2]), c = cos(x[2]), F = u[0] + u[1];
+  for (int e = 0; e < 48; ++e) J[e] = T(0);
+  J[0 + 3 * 6] = T(1); J[1 + 4 * 6] = T(1); J[2 + 5 * 6] = T(1);
+  J[3 + 2 * 6] = -F * c / mass; J[4 + 2 * 6] = -F * s / mass;
+  J[3 + 6 * 6] = -s / mass; J[3 + 7 * 6] = -s / mass;
+  J[4 + 6 * 6] = c / mass; J[4 + 7 * 6] = c / mass;
+  J[5 + 6 * 6] = -l / I; J[5 + 7 * 6] = l / I;
+}
+"""
+
+
+def test_padded_user_model_tile_plan_equals_plan_lane():
+    """A caller's (6, 2) model rides the (12, 4) tile zero-padded (the shim of models.h re-lays its Jacobian into the tile's
+    columns): the same source solved on plan MFMA16 and on plan LANE (lane-per-problem kernels, compared with the oracle in
+    tests/test_gpu_user_model.py) gives the same iterations and trajectories."""
+    batch, Np, nn, mm = 17, 30, 6, 2
+    hp = np.float32(0.05)
+    x0 = np.zeros((batch, nn)); x0[:, :2] = 0.6 * problems.normal((batch, 2), 141); x0[:, 2] = 0.2 * problems.normal((batch,), 142)
+    Qd = np.array([2.0, 2.0, 1.0, 0.3, 0.3, 0.1]); Rd = np.array([0.1, 0.1]); uh = np.full(2, 0.5 * 9.81)
+    out = []
+    for plan in (altro_amd.PLAN_MFMA16, altro_amd.PLAN_LANE):
+        bt = altro_amd.Batch(Np, nn, mm, batch, plan=plan)
+        assert bt.plan == plan
+        bt.set_model_source(PLANAR_SRC, hp)
+        bt.set_tracking_cost(np.stack([Qd, 30.0 * Qd]), Rd[None], np.zeros((2, nn)), uh[None], k_stride_zero=True, batch_stride_zero=True)
+        bt.set_initial_state(x0)
+        bt.set_input_guess(uh[None, None], k_stride_zero=True, batch_stride_zero=True)
+        res = bt.ilqr_solve(iterations_max=60, tol_stationarity=1e-3)
+        x, u = bt.get_nominal()
+        assert x.shape == (batch, Np + 1, nn) and u.shape == (batch, Np, mm)
+        out.append((res, x, u))
+    (ra, xa, ua), (rb, xb, ub) = out
+    assert (ra["status"] == 0).sum() >= batch - 2
+    same = ra["iterations"] == rb["iterations"]
+    assert same.sum() >= batch - 1, (ra["iterations"], rb["iterations"])     # (a convergence test at rounding level may move by one sweep)
+    np.testing.assert_allclose(xa[same], xb[same], rtol=1e-7, atol=1e-7)
+    np.testing.assert_allclose(ua[same], ub[same], rtol=1e-6, atol=1e-6)

@@ -158,10 +158,17 @@ def test_a_source_that_does_not_compile_says_why():
     with pytest.raises(altro_amd.AltroHipError) as e:
         bt.set_model_source("template <typename T> __device__ void altro_user_dynamics(const T* x, const T* u, T* xdot) { xdot[0] = y; }", 0.1)
     assert "error" in str(e.value) and "user_model" in str(e.value)
-    big = altro_amd.Batch(10, 12, 4, 4)
+    big = altro_amd.Batch(10, 20, 4, 4)
     with pytest.raises(altro_amd.AltroHipError):
-        big.set_model_source(PENDULUM_SRC, 0.1)       # plan MFMA16: dynamics are data there
-    bt.close(); big.close()
+        big.set_model_source(PENDULUM_SRC, 0.1)       # plan GENERIC: the TVLQR sweep only
+    f32 = altro_amd.Batch(10, 12, 4, 4, dtype=altro_amd.F32)
+    with pytest.raises(altro_amd.AltroHipError):
+        f32.set_model_source(PENDULUM_SRC, 0.1)       # plan MFMA16 takes models on fp64 records (tests/test_gpu_tile_model.py)
+    tile = altro_amd.Batch(10, 12, 4, 4)
+    with pytest.raises(altro_amd.AltroHipError) as e2:
+        tile.set_model_source("template <typename T> __device__ void altro_user_dynamics(const T* x, const T* u, T* xdot) { xdot[0] = y; }", 0.1)
+    assert "error" in str(e2.value) and "user_model" in str(e2.value)
+    bt.close(); big.close(); f32.close(); tile.close()
 
 
 GOAL_SRC = PENDULUM_SRC + r"""
