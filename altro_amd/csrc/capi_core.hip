@@ -194,7 +194,8 @@ int altro_hip_batch_create(altro_hip_batch** out, int N, int n, int m, int batch
     ALLOC(h->i_stat_done, B * sizeof(int));
     ALLOC(h->i_dphi, B * 8 * 2);
     ALLOC(h->i_active, B * sizeof(int));
-    ALLOC(h->i_counters, 8 * sizeof(int));
+    ALLOC(h->i_counters, (size_t)kCounterSlots * 8 * sizeof(int));
+    if (!rc && hipMemsetAsync(h->i_counters, 0, (size_t)kCounterSlots * 8 * sizeof(int), h->stream) != hipSuccess) rc = fail(ALTRO_HIP_ERR_HIP, "memset failed");
     ALLOC(h->i_reg, B * 8);
     if (!rc) {   // every constraint starts with penalty 1 (knotpoint_data.cpp:343)
       std::vector<IlqrProb> pr((size_t)B);
@@ -230,6 +231,8 @@ void altro_hip_batch_destroy(altro_hip_batch* h) {
   if (h->i_results_host) (void)hipHostFree(h->i_results_host);
   if (h->poll_host) (void)hipHostFree(h->poll_host);
   if (h->poll_count_host) (void)hipHostFree(h->poll_count_host);
+  if (h->cnt_host) (void)hipHostFree(h->cnt_host);
+  for (hipEvent_t e : h->cnt_ev) if (e) (void)hipEventDestroy(e);
   for (int a = 0; a < G_NUM; ++a) if (h->g_arr[a]) (void)hipFree(h->g_arr[a]);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);

@@ -867,14 +867,42 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
   la.ls.try_cubic_first = 1;                                   // solver.cpp:248
   la.ls.use_backtracking = o.use_backtracking_linesearch;      // solver.cpp:417
   h->spec_beta = la.ls.beta_decrease; h->spec_max_iters = la.ls.max_iters;
-  int counters[5];
-  auto read_counters = [&]() -> int {
-    HIP_TRY(hipMemcpyAsync(counters, h->i_counters, sizeof(counters), hipMemcpyDeviceToHost, h->stream));
+  // Counters without traffic on the stream: every counting launch (ILK_LS_BEGIN / _LS_FEED / _FINISH_ITER / _REG_RETRY) gets a
+  // fresh, zeroed 8-int slot of i_counters and publishes it into host-mapped memory itself (ilqr_publish_counters); an event
+  // behind the launch tells the host when to look.  No hipMemsetAsync / hipMemcpyAsync between the phases of a solve, and the
+  // host can enqueue AHEAD of a verdict it has not read yet (below).
+  if (!h->cnt_host) {
+    if (hipHostMalloc((void**)&h->cnt_host, (size_t)kCounterSlots * 8 * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+      (void)hipGetLastError();
+      return fail(ALTRO_HIP_ERR_OUT_OF_MEMORY, "pinned host memory for the solve loop's counters");
+    }
+    void* dp = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&dp, h->cnt_host, 0));
+    h->cnt_host_dev = (int*)dp;
+    for (hipEvent_t& e : h->cnt_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  int slot = 0;   // slot 0 belongs to the one-launch solve kernel
+  bool slots_dirty = false;
+  auto reset_slots = [&]() -> int {   // start of a solve (and, should a solve ever use them up, in the middle of one)
     HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemsetAsync(h->i_counters, 0, (size_t)kCounterSlots * 8 * sizeof(int), h->stream));
+    slot = 0; slots_dirty = false;
     return 0;
   };
-  auto zero_counter = [&](int idx) -> int {
-    HIP_TRY(hipMemsetAsync(h->i_counters + idx, 0, sizeof(int), h->stream));
+  // launch a counting loop kernel on a fresh slot; returns the slot (< 0: error code negated)
+  auto counted = [&](int which_kernel) -> int {
+    if (slot + 1 >= kCounterSlots) { int rc_ = reset_slots(); if (rc_) return -1; }
+    ++slot; slots_dirty = true;
+    la.counters = h->i_counters + 8 * slot;
+    la.counters_pub = h->cnt_host_dev + 8 * slot;
+    if (ilqr_launch_loop(h->stream, which_kernel, la)) { (void)fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed"); return -1; }
+    if (hipEventRecord(h->cnt_ev[slot & 15], h->stream) != hipSuccess) { (void)fail(ALTRO_HIP_ERR_HIP, "hipEventRecord failed"); return -1; }
+    la.counters_pub = nullptr;
+    return slot;
+  };
+  auto verdict = [&](int s, int idx, int* out) -> int {   // wait for slot s's launch and read its counter idx
+    HIP_TRY(hipEventSynchronize(h->cnt_ev[s & 15]));
+    *out = ((volatile int*)h->cnt_host)[8 * s + idx];
     return 0;
   };
   const bool lane_plan = h->plan == ALTRO_HIP_PLAN_LANE;
@@ -1040,7 +1068,24 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
     iter0 = running > 0 ? fused_sweeps : o.iterations_max;
   }
   bool hessians_ready = false;   // the previous sweep's last expansion left the cost Hessians of this one
-  for (int iter = iter0; iter < o.iterations_max; ++iter) {
+  // ---- the launch-sequenced loop, with the host running AHEAD of the device's verdicts -------------------------------------------
+  // Every kernel of a sweep masks itself (running / active / the line search's own state), so a launch made for problems that
+  // turn out not to need it is a no-op.  The host therefore does not wait for a count before it enqueues what follows when the
+  // solve's own history says the work will be needed: the next line-search round goes out before the previous round's count is
+  // read (as many rounds ahead as the last sweep took), and from the second sweep on the next sweep's head goes out before
+  // the count of problems still running is read.  A verdict that says "nobody" stops the enqueueing; what is already queued runs
+  // on empty masks.  The stream never drains inside a solve, and no memset or copy rides on it (counter slots, above).  Results
+  // are those of the wait-then-launch loop bit for bit: the same kernels see the same masks in the same order.
+  // (ALTRO_HIP_NO_RUNAHEAD: wait for every verdict before enqueueing on -- the comparison the tests hold this against)
+  const char* nra = std::getenv("ALTRO_HIP_NO_RUNAHEAD");
+  const bool run_ahead = nra == nullptr || std::atoi(nra) == 0;
+  if (iter0 < o.iterations_max)   // the one memset of the solve: every slot but the one-launch kernel's starts from zero
+    HIP_TRY(hipMemsetAsync(h->i_counters + 8, 0, (size_t)(kCounterSlots - 1) * 8 * sizeof(int), h->stream));
+  int pend_finish = -1;          // slot of the previous sweep's ILK_FINISH_ITER whose count has not been read yet
+  bool multi_sweep = false;      // a second sweep was needed: from now on the next sweep's head is enqueued ahead
+  int rounds_last = 0;           // line-search rounds the previous sweep needed (beyond the dual / first evaluation)
+  bool stop = false;
+  for (int iter = iter0; iter < o.iterations_max && !stop; ++iter) {
     la.iter = iter;
     if (ilqr_launch_loop(h->stream, ILK_MARK_RUNNING, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
     if (al && !hessians_ready) {                                // CalcExpansions: cost Hessians (solver.cpp:448)
@@ -1051,11 +1096,12 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
     if (rc) return rc;
     h->backward_done = true;
     for (int attempt = 0; attempt < o.reg_retry_max; ++attempt) {   // extension: repeat failed problems with more reg
-      if ((rc = zero_counter(2))) return rc;
-      if (ilqr_launch_loop(h->stream, ILK_REG_RETRY, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
-      if ((rc = read_counters())) return rc;
-      if (counters[2] == 0) break;
-      total_reg_retries += counters[2];
+      const int sr = counted(ILK_REG_RETRY);
+      if (sr < 0) return ALTRO_HIP_ERR_HIP;
+      int again = 0;
+      if ((rc = verdict(sr, 2, &again))) return rc;
+      if (again == 0) break;
+      total_reg_retries += again;
       rc = launch_backward(h, 0.0);
       if (rc) return rc;
     }
@@ -1064,7 +1110,6 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
     // chip idle, the first step the search will ask for (alpha0 = 1, known in advance) rides in the same launch as
     // phi(0) -- phi, phi' and the trajectory go to spare row / buffer 0 -- and ILK_LS_BEGIN consumes it at once.
     bool refreshed = false;
-    bool stat_needed = true;
     bool pre = !dual && spec_all_on && !h->spec_no_memory && spec_waves(running, 2) <= spec_capacity;
     if (pre && !ensure_spares(h, 1, spare_each)) {   // an optimisation only: carry on one step per launch
       h->spec_no_memory = true;
@@ -1086,25 +1131,21 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
               : ilqr_run(h, IK_MERIT, true, true, 1, 0.0);
     h->spec_trials = 1; h->spec_pre = 0;
     if (rc) return rc;
-    ++total_merit_launches;
-    if ((rc = zero_counter(0))) return rc;
-    if (dual) HIP_TRY(hipMemsetAsync(h->i_counters + 3, 0, 2 * sizeof(int), h->stream));
+    int sweep_merit_launches = 1;
     la.spec_pre = (pre || dual) ? 1 : 0;
     la.spec_flip = dual ? 1 : 0; la.stat_done = h->i_stat_done; la.stat_inline = h->dtype == ALTRO_HIP_F64 ? 1 : 0;
-    if (ilqr_launch_loop(h->stream, ILK_LS_BEGIN, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
+    int prev = counted(ILK_LS_BEGIN);      // the slot whose [0] says whether another evaluation is needed
+    if (prev < 0) return ALTRO_HIP_ERR_HIP;
     la.spec_pre = 0; la.spec_flip = 0;
     if (dual) {
-      if ((rc = read_counters())) return rc;
-      if (counters[3] > 0) {   // searches that ended WITHOUT the first step (phi' too small, not a descent direction): their
-                               // candidate is the alpha = 0 evaluation's, redone by the single-step kernel for them alone
-        int* keep = h->i_active;
-        h->i_active = h->i_spec_refresh;
-        rc = ilqr_run(h, IK_MERIT, true, true, 1, 0.0);
-        h->i_active = keep;
-        if (rc) return rc;
-        ++total_merit_launches;
-      }
-      stat_needed = counters[4] > 0;
+      // searches that ended WITHOUT the first step (phi' too small, not a descent direction): their candidate is the alpha = 0
+      // evaluation's, redone by the single-step kernel for them alone -- launched on their mask whether or not there are any
+      // (counted only when there were: the verdict is read with the first round's)
+      int* keep = h->i_active;
+      h->i_active = h->i_spec_refresh;
+      rc = ilqr_run(h, IK_MERIT, true, true, 1, 0.0);
+      h->i_active = keep;
+      if (rc) return rc;
     } else if (pre) {
       rc = ilqr_run(h, IK_SPEC_SELECT, false, false, 0, 0.0);
       if (rc) return rc;
@@ -1114,19 +1155,35 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
       // a no-op when none does, and it saves one host read-back per sweep (these loops are latency-bound).
       rc = ilqr_run(h, IK_MERIT, true, true, 1, 0.0);
       if (rc) return rc;
-      ++total_merit_launches;
-      if ((rc = zero_counter(0))) return rc;
-      if (ilqr_launch_loop(h->stream, ILK_LS_FEED, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
+      ++sweep_merit_launches;
+      prev = counted(ILK_LS_FEED);
+      if (prev < 0) return ALTRO_HIP_ERR_HIP;
     }
-    if (!dual && (rc = read_counters())) return rc;
-    int guard = 0;
-    while (counters[0] > 0 && guard++ < 64) {
+    const int begin_slot = dual ? prev : -1;
+    // the previous sweep's verdict, now that this sweep's head keeps the device busy
+    if (pend_finish >= 0) {
+      int still = 0;
+      if ((rc = verdict(pend_finish, 1, &still))) return rc;
+      pend_finish = -1;
+      ++sweeps;                                   // (the previous sweep)
+      if (still == 0) { stop = true; break; }     // nobody was running: what this sweep enqueued ran on empty masks
+      running = still;
+    }
+    int searching = -1;            // the last count read (the speculation width follows it)
+    int rounds = 0;
+    for (int guard = 0; guard < 64; ++guard) {
+      const bool ahead = run_ahead && rounds < rounds_last;    // history says this round will be needed: enqueue it first
+      if (!ahead) {
+        if ((rc = verdict(prev, 0, &searching))) return rc;
+        if (searching == 0) break;
+      }
       // Speculative backtracking: once the problems still searching leave most of the chip idle, one launch
       // evaluates the next 2, 4 or 8 steps of the (known) sequence alpha beta^j for each of them; the feed
       // kernel consumes them in order, so every decision is the sequential one (kernels/ilqr_types.h).
+      const int width_for = searching > 0 ? searching : running;
       int trials = 1;
       if (spec_on && !h->spec_no_memory)
-        while (trials < trials_cap && spec_waves(counters[0], trials * 2) <= spec_capacity) trials *= 2;   // as wide as leaves the launch within the capacity
+        while (trials < trials_cap && spec_waves(width_for, trials * 2) <= spec_capacity) trials *= 2;   // as wide as leaves the launch within the capacity
       // plan MFMA16's rounds in the DPP form evaluate two trials per problem in the lanes one trial would leave idle
       // (kernels/ilqr_merit2_dpp.hip): the second step of the known sequence rides along whatever the occupancy
       if (spec_on && !lane_plan && !h->spec_no_memory && trials < 2 && merit_rounds_dpp) trials = 2;
@@ -1139,18 +1196,29 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
       la.spec_trials = h->spec_trials;
       rc = ilqr_run(h, IK_MERIT, true, true, 1, 0.0);
       if (rc) return rc;
-      ++total_merit_launches;
-      if ((rc = zero_counter(0))) return rc;
-      if (ilqr_launch_loop(h->stream, ILK_LS_FEED, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
+      const int sf = counted(ILK_LS_FEED);
+      if (sf < 0) return ALTRO_HIP_ERR_HIP;
       if (spec) {
         rc = ilqr_run(h, IK_SPEC_SELECT, false, false, 0, 0.0);
         if (rc) return rc;
-        refreshed = true;
       }
       h->spec_trials = 1;
       la.spec_trials = 1;
-      if ((rc = read_counters())) return rc;
+      if (ahead) {
+        if ((rc = verdict(prev, 0, &searching))) return rc;
+        if (searching == 0) break;      // the round just enqueued was not needed: it ran on empty masks (not counted)
+      }
+      ++sweep_merit_launches; ++rounds;
+      if (spec) refreshed = true;
+      prev = sf;
     }
+    rounds_last = rounds;
+    if (begin_slot >= 0) {   // (the verdicts of ILK_LS_BEGIN's launch are in: it was waited for above)
+      int redone = 0;
+      if ((rc = verdict(begin_slot, 3, &redone))) return rc;
+      if (redone > 0) ++sweep_merit_launches;
+    }
+    total_merit_launches += sweep_merit_launches;
     if (refreshed) {   // steps accepted from a speculative trial carry no phi' pass: redo their expansion (what the
                        // derivative pass of a sequential trial would have left behind)
       int* keep = h->i_active;
@@ -1161,15 +1229,15 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
     }
     // convergence criteria on the accepted candidate, then make it the nominal (solver.cpp:459-469)
     if (ilqr_launch_loop(h->stream, ILK_MARK_RUNNING, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
-    if (stat_needed) {   // (dual: only the problems whose step was not the one wave_merit2_kernel evaluated)
+    {   // (dual: only the problems whose step was not the one the two-trial pass evaluated -- the skip mask; most waves leave at once)
       h->stat_skip = dual ? h->i_stat_done : nullptr;
       rc = ilqr_run(h, IK_STATIONARITY, false, true, 0, 0.0);
       h->stat_skip = nullptr;
     }
     if (!rc) rc = ilqr_run(h, IK_ACCEPT, false, true, 0, 0.0);
     if (rc) return rc;
-    if ((rc = zero_counter(1))) return rc;
-    if (ilqr_launch_loop(h->stream, ILK_FINISH_ITER, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
+    const int fin = counted(ILK_FINISH_ITER);
+    if (fin < 0) return ALTRO_HIP_ERR_HIP;
     if (al) {   // DualUpdate, PenaltyUpdate, refreshed gradients for the problems that asked (solver.cpp:470-489)
       // (plan MFMA16, DPP forms: ONE pass over the constraint rows does the dual update, the gradients and the next sweep's
       //  Hessians -- EXPAND_DUAL | EXPAND_NEXT -- and PenaltyUpdate's bookkeeping follows it)
@@ -1182,28 +1250,37 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
         if (rc) return rc;
         if (ilqr_launch_loop(h->stream, ILK_PENALTY_UPDATE, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
         hessians_ready = true;
-        if ((rc = read_counters())) return rc;
-        ++sweeps;
-        if (counters[1] == 0) break;
-        running = counters[1];
-        continue;
+      } else {
+        rc = ilqr_run(h, IK_DUAL, false, false, 0, 0.0);
+        if (rc) return rc;
+        if (ilqr_launch_loop(h->stream, ILK_PENALTY_UPDATE, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
+        // ... and, in the same pass over the constraint rows, the cost Hessians the NEXT sweep's CalcExpansions would form:
+        // nothing they depend on (trajectory, duals, penalties) changes between here and there
+        // (plan MFMA16, DPP form: gradient for the problems whose duals changed, Hessians for every problem still running)
+        const char* ed = std::getenv("ALTRO_HIP_EXPAND_DPP");
+        const bool merged = !lane_plan && !(ed != nullptr && std::atoi(ed) == 0);
+        rc = ilqr_run(h, IK_EXPAND, false, true, 0, 0.0, merged ? (EXPAND_GRADIENT | EXPAND_HESSIAN | EXPAND_NEXT) : EXPAND_GRADIENT);
+        if (rc) return rc;
+        hessians_ready = merged;
       }
-      rc = ilqr_run(h, IK_DUAL, false, false, 0, 0.0);
-      if (rc) return rc;
-      if (ilqr_launch_loop(h->stream, ILK_PENALTY_UPDATE, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
-      // ... and, in the same pass over the constraint rows, the cost Hessians the NEXT sweep's CalcExpansions would form:
-      // nothing they depend on (trajectory, duals, penalties) changes between here and there
-      // (plan MFMA16, DPP form: gradient for the problems whose duals changed, Hessians for every problem still running)
-      const char* ed = std::getenv("ALTRO_HIP_EXPAND_DPP");
-      const bool merged = !lane_plan && !(ed != nullptr && std::atoi(ed) == 0);
-      rc = ilqr_run(h, IK_EXPAND, false, true, 0, 0.0, merged ? (EXPAND_GRADIENT | EXPAND_HESSIAN | EXPAND_NEXT) : EXPAND_GRADIENT);
-      if (rc) return rc;
-      hessians_ready = merged;
     }
-    if ((rc = read_counters())) return rc;
+    // how many problems still run: read now -- or, once the solve has shown that it takes several sweeps, after the next sweep's
+    // head has been enqueued
+    if (run_ahead && multi_sweep && iter + 1 < o.iterations_max) {
+      pend_finish = fin;
+      continue;
+    }
+    int still = 0;
+    if ((rc = verdict(fin, 1, &still))) return rc;
     ++sweeps;
-    if (counters[1] == 0) break;
-    running = counters[1];
+    if (still == 0) break;
+    running = still;
+    multi_sweep = true;
+  }
+  if (pend_finish >= 0) {   // (the last sweep the iteration limit allowed)
+    int still = 0;
+    if ((rc = verdict(pend_finish, 1, &still))) return rc;
+    ++sweeps;
   }
   h->forward_done = true;
   h->solve_done = true;

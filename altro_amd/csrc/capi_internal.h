@@ -75,7 +75,10 @@ struct altro_hip_batch {
   void *l_nom = nullptr, *l_cost = nullptr;
   IlqrProb* i_prob = nullptr;
   double *i_alpha = nullptr, *i_phi = nullptr, *i_dphi = nullptr;
-  int *i_active = nullptr, *i_counters = nullptr;
+  int *i_active = nullptr, *i_counters = nullptr;   // i_counters: kCounterSlots slots of 8 ints (slot 0: the one-launch solve kernel's)
+  int* cnt_host = nullptr;        // the sequenced loop's view of the counters: host-mapped pinned memory, one slot per counting launch
+  int* cnt_host_dev = nullptr;    // ... its device address
+  hipEvent_t cnt_ev[16] = {};     // events recorded behind the counting launches (ring: at most a few are ever in flight)
   // speculative backtracking (altro_hip_ilqr_solve): spare candidate trajectories, allocated on first use
   void* i_cand_spec = nullptr;
   // altro_hip_ilqr_solve_async / _poll / _wait: pinned records the fused kernel publishes into while it runs
@@ -426,6 +429,7 @@ inline int lane_get(altro_hip_batch* h, double* host, const void* src, const voi
   });
 }
 
+constexpr int kCounterSlots = 2048;   // counter slots of one handle (altro_hip_batch::i_counters)
 constexpr int kStatsBlocks = 1024, kStatsStride = 16;   // capi_stats.hip: partials [kStatsBlocks][kStatsStride]
 
 // run-time compiled user models (capi_rtc.hip): the kernels of the launch-sequenced loop, in this order in RtcModule::fn

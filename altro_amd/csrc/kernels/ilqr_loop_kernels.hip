@@ -16,6 +16,25 @@ __global__ void ilqr_results_kernel(const IlqrProb* __restrict__ prob, IlqrResul
   out[b] = ilqr_result_of(prob[b]);
 }
 
+// The counters of a counting kernel, handed to the host without a copy on the stream: the block that finishes last (a ticket in
+// counters[7]) stores counters[0..6] into the launch's slot of host-mapped memory; the host reads it after the event it recorded
+// behind the launch.  Called by every thread of the kernel (no early exits before it).
+__device__ __forceinline__ void ilqr_publish_counters(const IlqrLoopArgs& a) {
+  if (!a.counters_pub) return;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    const int ticket = atomicAdd(&a.counters[7], 1);
+    if (ticket == (int)gridDim.x - 1) {
+      __threadfence();
+#pragma unroll
+      for (int i = 0; i < 7; ++i)
+        __hip_atomic_store(&a.counters_pub[i], __hip_atomic_load(&a.counters[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
 // ---- batched line search + sweep bookkeeping (one thread per problem) ---------------------------------
 __global__ void ilqr_loop_init_kernel(IlqrLoopArgs a) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -30,27 +49,29 @@ __global__ void ilqr_loop_init_kernel(IlqrLoopArgs a) {
 // after merit(alpha = 0): ForwardPass's head (solver.cpp:241-249)
 __global__ void ilqr_ls_begin_kernel(IlqrLoopArgs a) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= a.batch) return;
-  const bool was_running = a.prob[b].running != 0;
-  if (ilqr_ls_begin_body(a, b)) atomicAdd(&a.counters[0], 1);
-  if (a.spec_flip && was_running) {
-    if (a.spec_refresh[b]) atomicAdd(&a.counters[3], 1);
-    if (!a.stat_done[b]) atomicAdd(&a.counters[4], 1);
+  if (b < a.batch) {
+    const bool was_running = a.prob[b].running != 0;
+    if (ilqr_ls_begin_body(a, b)) atomicAdd(&a.counters[0], 1);
+    if (a.spec_flip && was_running) {
+      if (a.spec_refresh[b]) atomicAdd(&a.counters[3], 1);
+      if (!a.stat_done[b]) atomicAdd(&a.counters[4], 1);
+    }
   }
+  ilqr_publish_counters(a);
 }
 
 // after merit(alpha[b]): advance every searching problem's state machine
 __global__ void ilqr_ls_feed_kernel(IlqrLoopArgs a) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= a.batch) return;
-  if (ilqr_ls_feed_body(a, b)) atomicAdd(&a.counters[0], 1);
+  if (b < a.batch && ilqr_ls_feed_body(a, b)) atomicAdd(&a.counters[0], 1);
+  ilqr_publish_counters(a);
 }
 
 // end of one sweep (solver.cpp:459-502): convergence test, bookkeeping; `active` := still running
 __global__ void ilqr_finish_iter_kernel(IlqrLoopArgs a) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= a.batch) return;
-  if (ilqr_finish_iter_body(a, b)) atomicAdd(&a.counters[1], 1);
+  if (b < a.batch && ilqr_finish_iter_body(a, b)) atomicAdd(&a.counters[1], 1);
+  ilqr_publish_counters(a);
 }
 
 // Regularisation retry -- an EXTENSION: the reference passes reg = 0 and ignores a failed factorisation
@@ -59,8 +80,8 @@ __global__ void ilqr_finish_iter_kernel(IlqrLoopArgs a) {
 // them); a problem that succeeded relaxes reg <- max(reg / scale, reg_initial) for its next sweep.
 __global__ void ilqr_reg_retry_kernel(IlqrLoopArgs a) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= a.batch) return;
-  if (ilqr_reg_retry_body(a, b)) atomicAdd(&a.counters[2], 1);
+  if (b < a.batch && ilqr_reg_retry_body(a, b)) atomicAdd(&a.counters[2], 1);
+  ilqr_publish_counters(a);
 }
 
 // SetPenalty (solver.cpp:429) after the initial gradient

@@ -84,7 +84,11 @@ struct IlqrLoopArgs {
   int* active;        // [batch] 1 = problem takes part in the next merit evaluation
   const double* phi;
   const double* dphi;
-  int* counters;      // [0] = problems that still need a merit evaluation, [1] = problems still running; [3], [4]: spec_flip
+  int* counters;      // [0] = problems that still need a merit evaluation, [1] = problems still running; [3], [4]: spec_flip;
+                      // [7] = blocks of the counting kernel that are through (see counters_pub)
+  int* counters_pub = nullptr;   // optional, host-mapped pinned memory [7]: the last block of a counting kernel (ILK_LS_BEGIN, _LS_FEED,
+                                 // _FINISH_ITER, _REG_RETRY) copies counters[0..6] there, so the host reads them after an event with no
+                                 // copy or memset on the stream -- every such launch gets a fresh zeroed slot of counters (capi_ilqr.hip)
   int spec_trials;    // trials evaluated by the last merit launch (phi holds spec_trials x batch values)
   int spec_pre;       // ILK_LS_BEGIN: row 1 of phi / dphi holds the first trial step (see IlqrArgs::spec_pre)
   int* spec_sel;      // [batch] 1 + the spare candidate trajectory a problem that JUST finished its search took (0: none)
