@@ -248,6 +248,7 @@ int altro_hip_set_dynamics(altro_hip_batch* h, const double* A, const double* B,
                            int kz, int bz) {
   int rc = check(h);
   if (rc) return rc;
+  h->expansion_current = false;
   if (!A || !B) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "A and B are required");
   const int n = h->n, m = h->m, N = h->N;
   h->has_f = f ? 1 : 0;
@@ -294,6 +295,7 @@ int altro_hip_set_cost(altro_hip_batch* h, const double* Q, const double* R, con
                        const double* q, const double* r, int is_diag, int kz, int bz) {
   int rc = check(h);
   if (rc) return rc;
+  h->expansion_current = false;
   if (!Q || !R || !q || !r) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "Q, R, q, r are required");
   if (!is_diag && !H) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "H is required for a dense cost");
   h->ilqr_linear = false;   // explicit cost blocks = TVLQR semantics again (altro_hip_set_tracking_cost sets it back)
@@ -388,6 +390,7 @@ int altro_hip_set_host_batch(altro_hip_batch* h, int host_batch) {
 int altro_hip_set_initial_state(altro_hip_batch* h, const double* x0, int bz) {
   int rc = check(h);
   if (rc) return rc;
+  h->expansion_current = false;
   if (!x0) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "x0 == NULL");
   auto consume = [&](SrcArr s, int b0, int nb) -> int {
     const int64_t total = (int64_t)nb * h->n;

@@ -231,9 +231,14 @@ int ilqr_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int
              int mode = EXPAND_GRADIENT | EXPAND_HESSIAN) {
   int rc = al_upload(h);
   if (rc) return rc;
-  if (h->plan == ALTRO_HIP_PLAN_MFMA16)   // linear dynamics: "expand" = cost gradient (+ AL Hessian terms when constrained)
-    return h->dtype == ALTRO_HIP_F64 ? wave_run<double>(h, which, use_alpha, use_active, want_deriv, alpha_const, mode)
-                                     : wave_run<float>(h, which, use_alpha, use_active, want_deriv, alpha_const, mode);
+  if (h->plan == ALTRO_HIP_PLAN_MFMA16) {   // linear dynamics: "expand" = cost gradient (+ AL Hessian terms when constrained)
+    rc = h->dtype == ALTRO_HIP_F64 ? wave_run<double>(h, which, use_alpha, use_active, want_deriv, alpha_const, mode)
+                                   : wave_run<float>(h, which, use_alpha, use_active, want_deriv, alpha_const, mode);
+    // (altro_hip_batch::expansion_current) who writes the candidate trajectory, and who leaves its expansion behind
+    if (which == IK_MERIT) h->expansion_current = !rc && want_deriv && !use_active && h->spec_trials == 1 && !h->spec_pre && h->al_defs.empty();
+    else if (which == IK_ROLLOUT || which == IK_SHIFT || which == IK_SPEC_SELECT || which == IK_MERIT2 || which == IK_DUAL) h->expansion_current = false;
+    return rc;
+  }
   if (which == IK_MERIT) merit_split_prepare(h);
   if (h->dtype == ALTRO_HIP_F64) {
     auto a = ilqr_args<double>(h, use_alpha, use_active, want_deriv, alpha_const);
@@ -273,6 +278,7 @@ int altro_hip_set_model(altro_hip_batch* h, int model, float timestep, int bicyc
                         double bicycle_length, double bicycle_lr) {
   int rc = check(h);
   if (rc) return rc;
+  h->expansion_current = false;
   if (!(timestep > 0.0f)) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "time step must be positive (ErrorCodes::TimestepNotPositive)");
   const bool tile = h->plan == ALTRO_HIP_PLAN_MFMA16 && ilqr_tile_model_supported(model, h->n, h->m);   // kernels/ilqr_tile_model.hip
   if (tile && h->dtype != ALTRO_HIP_F64)
@@ -295,6 +301,7 @@ int altro_hip_set_tracking_cost(altro_hip_batch* h, const double* Qd, const doub
   // c = 1/2 xref'Q xref (+ 1/2 uref'R uref for k < N) -> KnotPointData::SetDiagonalCost
   int rc = check(h);
   if (rc) return rc;
+  h->expansion_current = false;
   if (h->plan != ALTRO_HIP_PLAN_LANE && h->plan != ALTRO_HIP_PLAN_MFMA16)
     return fail(ALTRO_HIP_ERR_UNSUPPORTED, "tracking cost needs plan LANE or MFMA16");
   if (!Qd || !Rd || !xref || !uref) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "Qd, Rd, xref, uref are required");
@@ -405,6 +412,7 @@ int altro_hip_set_quadratic_cost(altro_hip_batch* h, const double* Q, const doub
   // CalcOriginalCost / Gradient / Hessian do (knotpoint_data.cpp:624-634, :659-668, :691-698).
   int rc = check(h);
   if (rc) return rc;
+  h->expansion_current = false;
   if (h->plan != ALTRO_HIP_PLAN_LANE && h->plan != ALTRO_HIP_PLAN_MFMA16)
     return fail(ALTRO_HIP_ERR_UNSUPPORTED, "the device iLQR loop (and its costs) needs plan LANE or MFMA16");
   if (!Q || !R || !H || !q || !r) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "Q, R, H, q, r are required (c may be NULL: zero)");
@@ -505,6 +513,7 @@ int altro_hip_set_input_guess(altro_hip_batch* h, const double* u, int kz, int b
   // ALTROSolver::SetInput (altro_solver.cpp:242-251): writes the CANDIDATE inputs u_
   int rc = check(h);
   if (rc) return rc;
+  h->expansion_current = false;
   if (h->plan != ALTRO_HIP_PLAN_LANE && h->plan != ALTRO_HIP_PLAN_MFMA16)
     return fail(ALTRO_HIP_ERR_UNSUPPORTED, "input guess needs plan LANE or MFMA16");
   if (!u) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "u == NULL");
@@ -536,8 +545,12 @@ int altro_hip_accept(altro_hip_batch* h) {
 }
 int altro_hip_expand(altro_hip_batch* h) {
   int rc = ilqr_check(h, false);
-  if (!rc) rc = ilqr_run(h, IK_EXPAND, false, false, 0, 0.0);
-  return rc;
+  if (rc) return rc;
+  // CalcExpansions (solver.cpp:189-201) right after a merit evaluation with derivative of an unconstrained problem: the pass left
+  // lx, lu (A, B for a device model) of this very candidate, and the cost's Hessian blocks are the constants the setter stored
+  // (knotpoint_data.cpp:691-705 copies them afresh each sweep) -- nothing to launch
+  if (h->plan == ALTRO_HIP_PLAN_MFMA16 && h->expansion_current && h->al_defs.empty()) return 0;
+  return ilqr_run(h, IK_EXPAND, false, false, 0, 0.0);
 }
 int altro_hip_merit(altro_hip_batch* h, const double* alpha, int alpha_is_uniform, int want_derivative,
                     double* phi, double* dphi) {
@@ -593,6 +606,7 @@ int altro_hip_update_linear_costs(altro_hip_batch* h, const double* q, const dou
   // (knotpoint_data.cpp:193-226) for knot points k_first..k_last (inclusive) of every problem
   int rc = check(h);
   if (rc) return rc;
+  h->expansion_current = false;
   if (h->plan != ALTRO_HIP_PLAN_LANE && h->plan != ALTRO_HIP_PLAN_MFMA16)
     return fail(ALTRO_HIP_ERR_UNSUPPORTED, "linear cost update needs plan LANE or MFMA16");
   if (!h->lqr_cost_set) return fail(ALTRO_HIP_ERR_NOT_SET, "no quadratic cost to update (ErrorCodes::CostNotQuadratic)");
@@ -693,6 +707,7 @@ int altro_hip_add_linear_constraint(altro_hip_batch* h, int k_first, int k_last,
   // ALTROSolver::SetConstraint (altro_solver.cpp:175-215) for c(x,u) = G [x;u] - g
   int rc = check(h);
   if (rc) return rc;
+  h->expansion_current = false;
   if (h->plan != ALTRO_HIP_PLAN_LANE && h->plan != ALTRO_HIP_PLAN_MFMA16)
     return fail(ALTRO_HIP_ERR_UNSUPPORTED, "constraints need plan LANE or MFMA16");
   if (!G || !g) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "G and g are required");
@@ -737,6 +752,7 @@ int altro_hip_add_user_constraint(altro_hip_batch* h, int k_first, int k_last, i
 int altro_hip_clear_constraints(altro_hip_batch* h) {
   int rc = check(h);
   if (rc) return rc;
+  h->expansion_current = false;
   h->al_defs.clear(); h->al_G.clear(); h->al_g.clear();
   h->al_knots.assign((size_t)h->N + 1, AlKnot{});
   h->al_dirty = true;
@@ -746,6 +762,7 @@ int altro_hip_reset_duals(altro_hip_batch* h, double penalty) {
   // duals back to zero and every constraint's penalty to `penalty` (what a fresh Initialize leaves: 1)
   int rc = check(h);
   if (rc) return rc;
+  h->expansion_current = false;
   if (h->plan != ALTRO_HIP_PLAN_LANE && h->plan != ALTRO_HIP_PLAN_MFMA16) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "constraints need plan LANE or MFMA16");
   if (!(penalty > 0.0)) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "penalty must be positive");
   if ((rc = al_upload(h))) return rc;
@@ -838,6 +855,7 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
   // sequences launches and reads two counters per step; all per-problem decisions are on the device.
   int rc = ilqr_check(h, true);
   if (rc) return rc;
+  h->expansion_current = false;
   const bool async = h->async_request;
   h->async_request = false;
   if (h->async_pending) {   // a solve started with altro_hip_ilqr_solve_async is still out: finish it first

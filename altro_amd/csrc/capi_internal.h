@@ -130,6 +130,11 @@ struct altro_hip_batch {
   // Q | R | H | q | r | c records in l_costq (IlqrArgs::cost with cost_kind = 1)
   void *m_costd = nullptr, *m_costd_term = nullptr, *l_costq = nullptr;
   bool cost_dense = false;
+  // plan MFMA16, no constraint blocks: the last thing that touched the candidate trajectory was a merit evaluation WITH derivative
+  // over the whole batch -- which leaves lx, lu (and, with a device model, A, B) of that candidate in the records, while the
+  // quadratic cost's Hessian blocks never change: altro_hip_expand then has nothing to do.  Cleared by everything that changes
+  // the candidate, the cost or the dynamics.
+  bool expansion_current = false;
   double* i_reg = nullptr;
   // staging for host <-> device conversion (grown lazily, never inside the hot path)
   void* stage = nullptr;

@@ -405,6 +405,7 @@ extern "C" {
 int altro_hip_set_model_source(altro_hip_batch* h, const char* source, float timestep) {
   int rc = check(h);
   if (rc) return rc;
+  h->expansion_current = false;
   if (!source) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "source == NULL");
   if (!(timestep > 0.0f)) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "time step must be positive (ErrorCodes::TimestepNotPositive)");
   if (h->plan != ALTRO_HIP_PLAN_LANE && h->plan != ALTRO_HIP_PLAN_MFMA16)

@@ -338,6 +338,30 @@ def test_padded_shape_ilqr_solve_mfma16(nn, mm, constrained):
     bt.close()
 
 
+def test_expand_after_a_derivative_pass_has_nothing_to_do():
+    """CalcExpansions right after MeritFunction with derivative (solver.cpp:448 after :455): the merit pass left lx, lu of its
+    candidate in the records, so altro_hip_expand launches nothing -- and what it would have written is what is there, bit for
+    bit (forced by touching the input guess, which invalidates the shortcut)."""
+    batch = 11
+    p = make_problem(batch, True)
+    bt = make_hip(p)
+    bt.open_loop_rollout(); bt.accept(); bt.expand(); bt.backward()
+    bt.merit(np.linspace(0.1, 1.0, batch))
+    _, _, lx1, lu1 = bt.get_expansion()
+    bt.expand()                                       # no launch
+    _, _, lx2, lu2 = bt.get_expansion()
+    assert np.array_equal(lx1, lx2) and np.array_equal(lu1, lu2)
+    bt.set_input_guess(bt.get("u"))                   # the same inputs again: the shortcut is off, the gradient pass runs
+    bt.expand()
+    _, _, lx3, lu3 = bt.get_expansion()
+    assert np.array_equal(lx1, lx3) and np.array_equal(lu1, lu3)
+    bt.merit(0.5, derivative=False)                   # a pass without derivative moves the candidate and leaves no expansion
+    bt.expand()
+    _, _, lx4, _ = bt.get_expansion()
+    assert not np.array_equal(lx1, lx4)
+    bt.close()
+
+
 def _c1_bounded(x0, itmax):
     """bench.py's constrained C1 workload for the initial states x0: device handle solved with iterations_max = itmax."""
     Nf = 256
