@@ -184,7 +184,7 @@ int altro_hip_batch_create(altro_hip_batch** out, int N, int n, int m, int batch
         rc = fail(ALTRO_HIP_ERR_HIP, "table upload failed");
     }
   }
-  if (plan == ALTRO_HIP_PLAN_LANE || plan == ALTRO_HIP_PLAN_MFMA16) {   // per-problem control blocks of the iLQR loop
+  {   // per-problem control blocks of the iLQR loop (every plan: GENERIC runs it through kernels/ilqr_generic.hip)
     if (!rc) h->al_knots.assign((size_t)N + 1, AlKnot{});
     ALLOC(h->i_prob, B * sizeof(IlqrProb));
     ALLOC(h->i_alpha, B * 8);
@@ -226,7 +226,7 @@ void altro_hip_batch_destroy(altro_hip_batch* h) {
                   h->l_nom, h->l_cost, h->i_prob, h->i_alpha, h->i_phi, h->i_dphi, h->i_active, h->i_counters,
                   h->al_d_knots, h->al_d_G, h->al_d_g, h->al_d_z, h->i_reg, h->m_nom, h->m_costp,
                   h->i_cand_spec, h->i_spec_sel, h->i_spec_refresh, h->i_stat_done, h->st_partial, h->st_red, h->i_merit_jk, h->i_spec_jac, h->i_results,
-                  h->m_costd, h->m_costd_term, h->l_costq};
+                  h->m_costd, h->m_costd_term, h->l_costq, h->g_xn, h->g_un, h->g_cQ, h->g_cR, h->g_cH, h->g_cq, h->g_cr, h->g_cc};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->i_results_host) (void)hipHostFree(h->i_results_host);
   if (h->poll_host) (void)hipHostFree(h->poll_host);

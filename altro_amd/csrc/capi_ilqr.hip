@@ -227,8 +227,37 @@ int wave_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int
   if (rc) return fail(ALTRO_HIP_ERR_HIP, "iLQR kernel launch failed");
   return 0;
 }
+// plan GENERIC: any (n, m) up to 32, dynamics as data, quadratic cost, no constraint blocks (kernels/ilqr_generic.hip)
+template <typename T>
+int gen_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int want_deriv, double alpha_const, int mode) {
+  const int n = h->n, m = h->m, N = h->N;
+  IlqrGenArgs<T> a;
+  a.A = (const T*)h->g_arr[G_A]; a.A_bs = h->g_bstride[G_A]; a.B = (const T*)h->g_arr[G_B]; a.B_bs = h->g_bstride[G_B];
+  a.f = (const T*)h->g_arr[G_f]; a.f_bs = h->g_bstride[G_f];
+  a.Q = (T*)h->g_arr[G_Q]; a.Q_bs = h->g_bstride[G_Q]; a.R = (T*)h->g_arr[G_R]; a.R_bs = h->g_bstride[G_R];
+  a.H = (T*)h->g_arr[G_H]; a.H_bs = h->g_bstride[G_H]; a.q = (T*)h->g_arr[G_q]; a.q_bs = h->g_bstride[G_q];
+  a.r = (T*)h->g_arr[G_r]; a.r_bs = h->g_bstride[G_r];
+  a.K = (const T*)h->g_arr[G_K]; a.K_bs = h->g_bstride[G_K]; a.d = (const T*)h->g_arr[G_d]; a.d_bs = h->g_bstride[G_d];
+  a.P = (const T*)h->g_arr[G_P]; a.P_bs = h->g_bstride[G_P]; a.p = (const T*)h->g_arr[G_p]; a.p_bs = h->g_bstride[G_p];
+  a.x = (T*)h->g_arr[G_x]; a.x_bs = h->g_bstride[G_x]; a.u = (T*)h->g_arr[G_u]; a.u_bs = h->g_bstride[G_u];
+  a.y = (T*)h->g_arr[G_y]; a.y_bs = h->g_bstride[G_y];
+  a.xn = (T*)h->g_xn; a.un = (T*)h->g_un;
+  a.cQ = (const T*)h->g_cQ; a.cR = (const T*)h->g_cR; a.cH = (const T*)h->g_cH; a.cq = (const T*)h->g_cq; a.cr = (const T*)h->g_cr;
+  a.cc = (const T*)h->g_cc;
+  a.x0 = (const T*)h->x0; a.x0_stride = h->x0_stride;
+  a.alpha = use_alpha ? h->i_alpha : nullptr; a.active = use_active ? h->i_active : nullptr; a.alpha_const = alpha_const;
+  a.phi = h->i_phi; a.dphi = h->i_dphi; a.prob = h->i_prob;
+  a.N = N; a.n = n; a.m = m; a.batch = h->batch; a.want_derivative = want_deriv; a.mode = mode;
+  const int rc = ilqr_generic_launch<T>(h->stream, which, a);
+  if (rc == 1) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "operation %d is not available on plan GENERIC", which);
+  if (rc) return fail(ALTRO_HIP_ERR_HIP, "iLQR kernel launch failed");
+  return 0;
+}
 int ilqr_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int want_deriv, double alpha_const,
              int mode = EXPAND_GRADIENT | EXPAND_HESSIAN) {
+  if (h->plan == ALTRO_HIP_PLAN_GENERIC)
+    return h->dtype == ALTRO_HIP_F64 ? gen_run<double>(h, which, use_alpha, use_active, want_deriv, alpha_const, mode)
+                                     : gen_run<float>(h, which, use_alpha, use_active, want_deriv, alpha_const, mode);
   int rc = al_upload(h);
   if (rc) return rc;
   if (h->plan == ALTRO_HIP_PLAN_MFMA16) {   // linear dynamics: "expand" = cost gradient (+ AL Hessian terms when constrained)
@@ -249,16 +278,58 @@ int ilqr_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int
   a.mode = mode;
   return ilqr_launch<float>(h, which, a);
 }
+
+// plan GENERIC: the cost's own dense blocks (what the merit function and the expansion evaluate) next to the backward sweep's
+// inputs, which altro_hip_set_cost fills; nominal trajectory allocated on first use.  Host arrays: Q [nb][nkx][n n], R [nb][nku][m m],
+// H [nb][nku][m n], q [nb][nkx][n], r [nb][nku][m], c [nb][nkx] or NULL.
+template <typename T>
+int generic_cost_def(altro_hip_batch* h, const double* Q, const double* R, const double* H, const double* q, const double* r,
+                     const double* c, int kz, int bz) {
+  const int n = h->n, m = h->m, N = h->N;
+  const int nkx = kz ? 2 : N + 1, nku = kz ? 1 : N;
+  const size_t B = h->batch, E = h->esz;
+  int rc = 0;
+  if (!h->g_cQ) {
+    if ((rc = dmalloc(h, &h->g_cQ, B * (N + 1) * n * n * E)) || (rc = dmalloc(h, &h->g_cR, B * N * m * m * E)) ||
+        (rc = dmalloc(h, &h->g_cH, B * N * m * n * E)) || (rc = dmalloc(h, &h->g_cq, B * (N + 1) * n * E)) ||
+        (rc = dmalloc(h, &h->g_cr, B * N * m * E)) || (rc = dmalloc(h, &h->g_cc, B * (N + 1) * E)) ||
+        (rc = dmalloc(h, &h->g_xn, B * (N + 1) * n * E)) || (rc = dmalloc(h, &h->g_un, B * N * m * E)))
+      return rc;
+    HIP_TRY(hipMemsetAsync(h->g_xn, 0, B * (N + 1) * n * E, h->stream));
+    HIP_TRY(hipMemsetAsync(h->g_un, 0, B * N * m * E, h->stream));
+    HIP_TRY(hipMemsetAsync(h->g_arr[G_u], 0, B * N * m * E, h->stream));
+  }
+  auto put = [&](void* dst, int blk, int nk_total, const double* src, int nk_host, bool with_terminal) -> int {
+    if (!src) { HIP_TRY(hipMemsetAsync(dst, 0, B * nk_total * blk * E, h->stream)); return 0; }
+    int r_ = aos_set<T>(h, (T*)dst, (int64_t)nk_total * blk, (int64_t)blk, src, blk, N, kz, bz, nk_host, 0);
+    if (!r_ && with_terminal)   // knot point N: element N of a full host array, or the second entry of a {running, terminal} pair
+      r_ = aos_set<T>(h, (T*)dst + (size_t)N * blk, (int64_t)nk_total * blk, (int64_t)blk, src, blk, 1, 1, bz, nk_host, (kz ? 1 : N) * blk);
+    return r_;
+  };
+  rc = put(h->g_cQ, n * n, N + 1, Q, nkx, true);
+  if (!rc) rc = put(h->g_cR, m * m, N, R, nku, false);
+  if (!rc) rc = put(h->g_cH, m * n, N, H, nku, false);
+  if (!rc) rc = put(h->g_cq, n, N + 1, q, nkx, true);
+  if (!rc) rc = put(h->g_cr, m, N, r, nku, false);
+  if (!rc) rc = put(h->g_cc, 1, N + 1, c, nkx, true);
+  return rc;
+}
+int generic_cost(altro_hip_batch* h, const double* Q, const double* R, const double* H, const double* q, const double* r,
+                 const double* c, int kz, int bz) {
+  int rc = altro_hip_set_cost(h, Q, R, H, q, r, 0, kz, bz);   // the backward sweep's blocks: lxx = Q, luu = R, lux = H (lx, lu refreshed by the loop)
+  if (rc) return rc;
+  rc = h->dtype == ALTRO_HIP_F64 ? generic_cost_def<double>(h, Q, R, H, q, r, c, kz, bz) : generic_cost_def<float>(h, Q, R, H, q, r, c, kz, bz);
+  if (!rc) { h->lqr_cost_set = true; h->ilqr_linear = true; h->cost_dense = true; h->spec_no_memory = true; /* one step per launch on this plan */ }
+  return rc;
+}
 int ilqr_check(altro_hip_batch* h, bool need_guess) {
   int rc = check(h);
   if (rc) return rc;
   if (h->plan == ALTRO_HIP_PLAN_MFMA16) {   // dynamics are data (altro_hip_set_dynamics) or a device model of the tile plan
     if (!h->dyn_set && !h->model_set)
       return fail(ALTRO_HIP_ERR_NOT_SET, "neither altro_hip_set_dynamics nor altro_hip_set_model has been called");
-  } else if (h->plan != ALTRO_HIP_PLAN_LANE) {
-    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "the device iLQR loop runs on plans MFMA16 (n <= 12, m <= 4, dynamics given as data) and "
-                                           "LANE (n <= 6, m <= 3, device models); plan GENERIC (n = %d, m = %d) has the TVLQR sweep only",
-                h->n, h->m);
+  } else if (h->plan == ALTRO_HIP_PLAN_GENERIC) {   // any (n, m) up to 32: dynamics as data, a quadratic cost, no constraint blocks
+    if (!h->dyn_set) return fail(ALTRO_HIP_ERR_NOT_SET, "altro_hip_set_dynamics has not been called");
   } else if (!h->model_set) {
     return fail(ALTRO_HIP_ERR_NOT_SET, "altro_hip_set_model has not been called (plan LANE runs device models; for dynamics given as "
                                        "data -- altro_hip_set_dynamics -- create the handle with ALTRO_HIP_PLAN_MFMA16)");
@@ -302,8 +373,8 @@ int altro_hip_set_tracking_cost(altro_hip_batch* h, const double* Qd, const doub
   int rc = check(h);
   if (rc) return rc;
   h->expansion_current = false;
-  if (h->plan != ALTRO_HIP_PLAN_LANE && h->plan != ALTRO_HIP_PLAN_MFMA16)
-    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "tracking cost needs plan LANE or MFMA16");
+  if (h->plan != ALTRO_HIP_PLAN_LANE && h->plan != ALTRO_HIP_PLAN_MFMA16 && h->plan != ALTRO_HIP_PLAN_GENERIC)
+    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "unknown plan");
   if (!Qd || !Rd || !xref || !uref) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "Qd, Rd, xref, uref are required");
   if (h->dev_ptrs)
     return fail(ALTRO_HIP_ERR_UNSUPPORTED, "altro_hip_set_tracking_cost forms q = -Q xref on the host: pass host arrays "
@@ -335,6 +406,14 @@ int altro_hip_set_tracking_cost(altro_hip_batch* h, const double* Qd, const doub
     for (int k = 0; k < nku; ++k)
       for (int i = 0; i < m; ++i)
         r[((size_t)b * nku + k) * m + i] = -(Rd[((size_t)b * nku + k) * m + i] * uref[((size_t)b * nku + k) * m + i]);
+  if (h->plan == ALTRO_HIP_PLAN_GENERIC) {   // the diagonal cost as dense blocks (H = 0): what kernels/ilqr_generic.hip evaluates
+    std::vector<double> Qf((size_t)nb * nkx * n * n, 0.0), Rf((size_t)nb * nku * m * m, 0.0), Hf((size_t)nb * nku * m * n, 0.0);
+    for (size_t t = 0; t < (size_t)nb * nkx; ++t)
+      for (int i = 0; i < n; ++i) Qf[t * n * n + i + (size_t)n * i] = Qd[t * n + i];
+    for (size_t t = 0; t < (size_t)nb * nku; ++t)
+      for (int i = 0; i < m; ++i) Rf[t * m * m + i + (size_t)m * i] = Rd[t * m + i];
+    return generic_cost(h, Qf.data(), Rf.data(), Hf.data(), q.data(), r.data(), c.data(), kz, bz);
+  }
   if (h->plan == ALTRO_HIP_PLAN_MFMA16) {
     // (a) the backward sweep's blocks: lxx = diag(Qd), luu = diag(Rd), lux = 0; lx, lu are refreshed by the loop
     rc = altro_hip_set_cost(h, Qd, Rd, nullptr, q.data(), r.data(), 1, kz, bz);
@@ -413,9 +492,8 @@ int altro_hip_set_quadratic_cost(altro_hip_batch* h, const double* Q, const doub
   int rc = check(h);
   if (rc) return rc;
   h->expansion_current = false;
-  if (h->plan != ALTRO_HIP_PLAN_LANE && h->plan != ALTRO_HIP_PLAN_MFMA16)
-    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "the device iLQR loop (and its costs) needs plan LANE or MFMA16");
   if (!Q || !R || !H || !q || !r) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "Q, R, H, q, r are required (c may be NULL: zero)");
+  if (h->plan == ALTRO_HIP_PLAN_GENERIC) return generic_cost(h, Q, R, H, q, r, c, kz, bz);
   const int n = h->n, m = h->m, N = h->N;
   const int nkx = kz ? 2 : N + 1, nku = kz ? 1 : N;
   const size_t Ez = h->esz;
@@ -514,10 +592,13 @@ int altro_hip_set_input_guess(altro_hip_batch* h, const double* u, int kz, int b
   int rc = check(h);
   if (rc) return rc;
   h->expansion_current = false;
-  if (h->plan != ALTRO_HIP_PLAN_LANE && h->plan != ALTRO_HIP_PLAN_MFMA16)
-    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "input guess needs plan LANE or MFMA16");
   if (!u) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "u == NULL");
   const int n = h->n, m = h->m, N = h->N;
+  if (h->plan == ALTRO_HIP_PLAN_GENERIC) {   // candidate inputs: the forward sweep's u array, reference layout
+    rc = h->dtype == ALTRO_HIP_F64 ? generic_set<double>(h, G_u, u, m, N, kz, bz) : generic_set<float>(h, G_u, u, m, N, kz, bz);
+    if (!rc) h->guess_set = true;
+    return rc;
+  }
   if (h->plan == ALTRO_HIP_PLAN_MFMA16) {   // candidate records [k][b][28] = x | y | u
     rc = h->dtype == ALTRO_HIP_F64
              ? aos_set<double>(h, (double*)h->m_xuy + 24, h->m_st.xuy_bs, h->m_st.xuy_ks, u, m, N, kz, bz)
@@ -607,8 +688,6 @@ int altro_hip_update_linear_costs(altro_hip_batch* h, const double* q, const dou
   int rc = check(h);
   if (rc) return rc;
   h->expansion_current = false;
-  if (h->plan != ALTRO_HIP_PLAN_LANE && h->plan != ALTRO_HIP_PLAN_MFMA16)
-    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "linear cost update needs plan LANE or MFMA16");
   if (!h->lqr_cost_set) return fail(ALTRO_HIP_ERR_NOT_SET, "no quadratic cost to update (ErrorCodes::CostNotQuadratic)");
   const int n = h->n, m = h->m, N = h->N;
   if (k_first < 0 || k_last > N || k_first > k_last)
@@ -617,6 +696,19 @@ int altro_hip_update_linear_costs(altro_hip_batch* h, const double* q, const dou
     return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "cannot update linear input costs at the terminal knot point "
                                             "(ErrorCodes::InvalidOptAtTerminalKnotPoint)");
   const int nk = k_last - k_first + 1;
+  if (h->plan == ALTRO_HIP_PLAN_GENERIC) {   // the cost's own q, r, c blocks (dense [b][k][block])
+    auto put = [&](void* base, int blk, int nk_total, const double* src, int nkp) -> int {
+      if (!src || nkp <= 0) return 0;
+      char* dst = (char*)base + (size_t)k_first * blk * h->esz;
+      return h->dtype == ALTRO_HIP_F64
+                 ? aos_set<double>(h, (double*)dst, (int64_t)nk_total * blk, (int64_t)blk, src, blk, nkp, kz, bz, kz ? 1 : nk, 0)
+                 : aos_set<float>(h, (float*)dst, (int64_t)nk_total * blk, (int64_t)blk, src, blk, nkp, kz, bz, kz ? 1 : nk, 0);
+    };
+    rc = put(h->g_cq, n, N + 1, q, nk);
+    if (!rc) rc = put(h->g_cr, m, N, r, nk);
+    if (!rc) rc = put(h->g_cc, 1, N + 1, c, nk);
+    return rc;
+  }
   if (h->plan == ALTRO_HIP_PLAN_MFMA16 && h->cost_dense) {
     // the dense cost's record: [q r] at MF_OFF_QR, c in the spare slot; the terminal knot point's q_N lives in costd_term
     const int64_t B = h->batch;
@@ -688,7 +780,18 @@ int altro_hip_get_knot(altro_hip_batch* h, int k, double* x, double* u) {
                : aos_get<float>(h, u, (const float*)h->m_nom + (size_t)k * B * MF_NOM + 12, MF_NOM, B * MF_NOM, m, 1);
     return rc;
   }
-  if (h->plan != ALTRO_HIP_PLAN_LANE) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "plans LANE and MFMA16 only");
+  if (h->plan == ALTRO_HIP_PLAN_GENERIC) {
+    if (!h->g_xn) return fail(ALTRO_HIP_ERR_NOT_SET, "no cost has been set for the iLQR loop");
+    if (x) {
+      rc = h->dtype == ALTRO_HIP_F64 ? aos_get<double>(h, x, (const double*)h->g_xn + (size_t)k * n, (int64_t)(N + 1) * n, n, n, 1)
+                                     : aos_get<float>(h, x, (const float*)h->g_xn + (size_t)k * n, (int64_t)(N + 1) * n, n, n, 1);
+      if (rc) return rc;
+    }
+    if (u)
+      rc = h->dtype == ALTRO_HIP_F64 ? aos_get<double>(h, u, (const double*)h->g_un + (size_t)k * m, (int64_t)N * m, m, m, 1)
+                                     : aos_get<float>(h, u, (const float*)h->g_un + (size_t)k * m, (int64_t)N * m, m, m, 1);
+    return rc;
+  }
   const size_t E = h->dtype == ALTRO_HIP_F64 ? 8 : 4;
   const char* rec = (const char*)h->l_nom + (size_t)k * (n + m) * h->batch * E;
   if (x) {
@@ -972,7 +1075,9 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
   // candidate's stationarity / feasibility from that same pass, and -- without constraint blocks -- the head of Solve as
   // one pass too (ROLLOUT_INIT).  ALTRO_HIP_MERIT2=0 keeps the one-evaluation-per-launch sequence (the comparison the
   // tests hold this one against).
-  bool dual = !lane_plan && std::getenv("ALTRO_HIP_NO_SPECULATION") == nullptr;   // (the first step rides before it is asked for)
+  if (h->plan == ALTRO_HIP_PLAN_GENERIC && o.reg_retry_max > 0)
+    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "the regularisation retry is built for plans LANE and MFMA16 (plan GENERIC: reg_retry_max = 0)");
+  bool dual = h->plan == ALTRO_HIP_PLAN_MFMA16 && std::getenv("ALTRO_HIP_NO_SPECULATION") == nullptr;   // (the first step rides before it is asked for)
   if (const char* e = std::getenv("ALTRO_HIP_MERIT2")) dual = dual && std::atoi(e) != 0;
   if (!fused_prologue) {
     if (ilqr_launch_loop(h->stream, ILK_LOOP_INIT, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
@@ -1348,7 +1453,18 @@ int altro_hip_get_nominal(altro_hip_batch* h, double* x, double* u) {
                                      : aos_get<float>(h, u, (const float*)h->m_nom + 12, MF_NOM, B * MF_NOM, m, N);
     return rc;
   }
-  if (h->plan != ALTRO_HIP_PLAN_LANE) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "nominal trajectory exists for plans LANE and MFMA16");
+  if (h->plan == ALTRO_HIP_PLAN_GENERIC) {
+    if (!h->g_xn) return fail(ALTRO_HIP_ERR_NOT_SET, "no cost has been set for the iLQR loop");
+    if (x) {
+      rc = h->dtype == ALTRO_HIP_F64 ? aos_get<double>(h, x, (const double*)h->g_xn, (int64_t)(N + 1) * n, n, n, N + 1)
+                                     : aos_get<float>(h, x, (const float*)h->g_xn, (int64_t)(N + 1) * n, n, n, N + 1);
+      if (rc) return rc;
+    }
+    if (u)
+      rc = h->dtype == ALTRO_HIP_F64 ? aos_get<double>(h, u, (const double*)h->g_un, (int64_t)N * m, m, m, N)
+                                     : aos_get<float>(h, u, (const float*)h->g_un, (int64_t)N * m, m, m, N);
+    return rc;
+  }
   if (x) {
     rc = h->dtype == ALTRO_HIP_F64 ? lane_get<double>(h, x, h->l_nom, nullptr, n + m, 0, 0, n, N + 1, N + 1)
                                    : lane_get<float>(h, x, h->l_nom, nullptr, n + m, 0, 0, n, N + 1, N + 1);
@@ -1398,7 +1514,17 @@ int altro_hip_get_expansion(altro_hip_batch* h, double* A, double* B, double* lx
     }
     return 0;
   }
-  if (h->plan != ALTRO_HIP_PLAN_LANE) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "plans LANE and MFMA16 only");
+  if (h->plan == ALTRO_HIP_PLAN_GENERIC) {   // reference layout already: A, B as given, lx / lu the backward sweep's q / r
+    auto get = [&](double* dst, int arr, int blk, int nk) -> int {
+      if (!dst) return 0;
+      return h->dtype == ALTRO_HIP_F64 ? generic_get<double>(h, arr, dst, blk, nk) : generic_get<float>(h, arr, dst, blk, nk);
+    };
+    rc = get(A, G_A, n * n, N);
+    if (!rc) rc = get(B, G_B, n * m, N);
+    if (!rc) rc = get(lx, G_q, n, N + 1);
+    if (!rc) rc = get(lu, G_r, m, N);
+    return rc;
+  }
   const LaneSizes z = lane_sizes(n, m);
   const int oq = 2 * n * n + 2 * n * m + m * m + n, orr = oq + n;
   auto get = [&](double* dst, int off, int len, int nk, bool with_term, int off_term) -> int {

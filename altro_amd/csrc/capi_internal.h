@@ -20,6 +20,7 @@
 #include "kernels/tvlqr_generic.hip"
 #include "kernels/tvlqr_lane.hip"
 #include "kernels/ilqr_types.h"
+#include "kernels/ilqr_generic.hip"
 #include "kernels/mfma16_layout.h"
 #include "linesearch_sm.h"
 
@@ -135,6 +136,8 @@ struct altro_hip_batch {
   // quadratic cost's Hessian blocks never change: altro_hip_expand then has nothing to do.  Cleared by everything that changes
   // the candidate, the cost or the dynamics.
   bool expansion_current = false;
+  // iLQR loop on plan GENERIC (kernels/ilqr_generic.hip): nominal trajectory and the cost's own blocks, dense [b][k][block]
+  void *g_xn = nullptr, *g_un = nullptr, *g_cQ = nullptr, *g_cR = nullptr, *g_cH = nullptr, *g_cq = nullptr, *g_cr = nullptr, *g_cc = nullptr;
   double* i_reg = nullptr;
   // staging for host <-> device conversion (grown lazily, never inside the hot path)
   void* stage = nullptr;

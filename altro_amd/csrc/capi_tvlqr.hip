@@ -89,6 +89,7 @@ GenericArgs<T> generic_args(altro_hip_batch* h, double reg) {
   a.is_diag = h->is_diag;
   a.store_q = (h->flags & ALTRO_HIP_STORE_QBLOCKS) ? 1 : 0;
   a.want_y = 1;
+  a.no_f = h->ilqr_linear ? 1 : 0;
   return a;
 }
 

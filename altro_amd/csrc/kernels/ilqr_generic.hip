@@ -1,0 +1,293 @@
+// ilqr_generic.hip -- the iLQR loop around the TVLQR sweep for plan GENERIC: any (n, m) up to 32, dynamics given as DATA
+// (x+ = A_k x + B_k u + f_k: the reference's SetLinearDynamics path, knotpoint_data.cpp:123-142, :406-419, :710-719) and a
+// quadratic cost (tracking or dense).  The correctness-first companion of kernels/ilqr_mfma16.hip for the shapes the tile plan
+// does not cover (n > 12 or m > 4): one wavefront per problem, vectors exchanged through LDS, the blocks read from the
+// reference layout on the device (column-major, lane i <-> row i, so every load is a unit-stride run).  Device-side counterparts of
+//   SolverImpl::OpenLoopRollout   solver.cpp:116-131        -> generic_rollout_kernel
+//   SolverImpl::CopyTrajectory    solver.cpp:148-157        -> generic_accept_kernel
+//   CalcCostGradient / Hessian    knotpoint_data.cpp:650-708 -> generic_expand_kernel
+//   SolverImpl::MeritFunction     solver.cpp:273-355        -> generic_merit_kernel
+//   SolverImpl::Stationarity      solver.cpp:207-222        -> generic_stationarity_kernel
+// The line search, convergence logic and sweep sequencing are the plan-independent kernels of ilqr_loop_kernels.hip.
+// Sums are taken per lane and reduced over the wave: results agree with the oracle to rounding (1e-12 relative), not bit for bit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ilqr_types.h"
+
+namespace altro_hip {
+
+constexpr int GEN_MAX = 32;   // n, m <= 32: lanes 0..31 own state rows, lanes 32..63 input rows
+
+template <typename T>
+struct IlqrGenArgs {
+  // dynamics (data) and the backward sweep's inputs / outputs, reference layout [b][k][block]
+  const T *A, *B, *f;  int64_t A_bs, B_bs, f_bs;
+  T *Q, *R, *H, *q, *r; int64_t Q_bs, R_bs, H_bs, q_bs, r_bs;      // lxx [N+1] | luu | lux | lx [N+1] | lu
+  const T *K, *d, *P, *p; int64_t K_bs, d_bs, P_bs, p_bs;
+  T *x, *u, *y;        int64_t x_bs, u_bs, y_bs;                    // candidate trajectory x_ [N+1] | u_ [N] | y_ [N+1]
+  T *xn, *un;                                                       // nominal, dense: [b][N+1][n], [b][N][m]
+  const T *cQ, *cR, *cH, *cq, *cr, *cc;                             // the cost's own blocks, dense: Q [b][N+1][n n], R, H [b][N][..], q, r, c
+  const T* x0; int64_t x0_stride;
+  const double* alpha; const int* active; double alpha_const;
+  double* phi; double* dphi; IlqrProb* prob;
+  int N, n, m, batch, want_derivative, mode;
+};
+
+__device__ __forceinline__ double gen_wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double gen_wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// x_0 = x0 ; x_{k+1} = A x + B u + f on the candidate trajectory (u_ is the guess already stored there)
+template <typename T>
+__global__ __launch_bounds__(64) void generic_rollout_kernel(IlqrGenArgs<T> a) {
+  __shared__ double xs[GEN_MAX], us[GEN_MAX];
+  const int b = blockIdx.x, lane = threadIdx.x;
+  if (a.active && !a.active[b]) return;
+  const int n = a.n, m = a.m, N = a.N;
+  const int i = lane < n ? lane : 0;
+  double x = (double)a.x0[(int64_t)b * a.x0_stride + i];
+  for (int k = 0; k < N; ++k) {
+    __syncthreads();
+    if (lane < n) { xs[lane] = x; a.x[(int64_t)b * a.x_bs + (int64_t)k * n + lane] = (T)x; }
+    if (lane < m) us[lane] = (double)a.u[(int64_t)b * a.u_bs + (int64_t)k * m + lane];
+    __syncthreads();
+    const T* Ak = a.A + (int64_t)b * a.A_bs + (int64_t)k * n * n;
+    const T* Bk = a.B + (int64_t)b * a.B_bs + (int64_t)k * n * m;
+    double s = 0.0, s2 = 0.0;
+    for (int j = 0; j < n; ++j) s += (double)Ak[i + j * n] * xs[j];
+    for (int j = 0; j < m; ++j) s2 += (double)Bk[i + j * n] * us[j];
+    x = (s + s2) + (double)a.f[(int64_t)b * a.f_bs + (int64_t)k * n + i];
+  }
+  if (lane < n) a.x[(int64_t)b * a.x_bs + (int64_t)N * n + lane] = (T)x;
+}
+
+// nominal <- candidate (x, u)
+template <typename T>
+__global__ void generic_accept_kernel(IlqrGenArgs<T> a) {
+  const int n = a.n, m = a.m, N = a.N;
+  const int64_t per = (int64_t)(N + 1) * n + (int64_t)N * m, total = per * a.batch;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(t / per);
+    const int64_t e = t % per;
+    if (a.active && !a.active[b]) continue;
+    if (e < (int64_t)(N + 1) * n) a.xn[(int64_t)b * (N + 1) * n + e] = a.x[(int64_t)b * a.x_bs + e];
+    else a.un[(int64_t)b * N * m + (e - (int64_t)(N + 1) * n)] = a.u[(int64_t)b * a.u_bs + (e - (int64_t)(N + 1) * n)];
+  }
+}
+
+// Expansion at the candidate point, one thread per (problem, knot point, entry of [x; u]):
+//   EXPAND_GRADIENT: lx = Q x + H^T u + q, lu = R u + H x + r  (knotpoint_data.cpp:659-668) into the backward sweep's q / r
+//   EXPAND_HESSIAN : lxx = Q, luu = R, lux = H (knotpoint_data.cpp:691-698) into its Q / R / H -- a copy of the cost's own blocks
+template <typename T>
+__global__ void generic_expand_kernel(IlqrGenArgs<T> a) {
+  const int n = a.n, m = a.m, N = a.N, w = n + m;
+  const bool grad = (a.mode & EXPAND_GRADIENT) != 0, hess = (a.mode & EXPAND_HESSIAN) != 0;
+  const int64_t total = (int64_t)a.batch * (N + 1) * w;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int e = (int)(t % w);
+    const int k = (int)((t / w) % (N + 1));
+    const int b = (int)(t / ((int64_t)w * (N + 1)));
+    if (a.active && !a.active[b]) continue;
+    const bool terminal = k == N;
+    if (terminal && e >= n) continue;
+    const T* xk = a.x + (int64_t)b * a.x_bs + (int64_t)k * n;
+    const T* uk = a.u + (int64_t)b * a.u_bs + (int64_t)k * m;
+    if (grad) {
+      double s;
+      if (e < n) {
+        const T* Qk = a.cQ + ((int64_t)b * (N + 1) + k) * n * n;
+        s = 0.0;
+        for (int j = 0; j < n; ++j) s += (double)Qk[e + j * n] * (double)xk[j];
+        s += (double)a.cq[((int64_t)b * (N + 1) + k) * n + e];
+        if (!terminal) {
+          const T* Hk = a.cH + ((int64_t)b * N + k) * m * n;
+          double t2 = 0.0;
+          for (int i = 0; i < m; ++i) t2 += (double)Hk[i + e * m] * (double)uk[i];
+          s += t2;
+        }
+        a.q[(int64_t)b * a.q_bs + (int64_t)k * n + e] = (T)s;
+      } else {
+        const int i = e - n;
+        const T* Rk = a.cR + ((int64_t)b * N + k) * m * m;
+        const T* Hk = a.cH + ((int64_t)b * N + k) * m * n;
+        s = 0.0;
+        for (int j = 0; j < m; ++j) s += (double)Rk[i + j * m] * (double)uk[j];
+        s += (double)a.cr[((int64_t)b * N + k) * m + i];
+        double t2 = 0.0;
+        for (int j = 0; j < n; ++j) t2 += (double)Hk[i + j * m] * (double)xk[j];
+        s += t2;
+        a.r[(int64_t)b * a.r_bs + (int64_t)k * m + i] = (T)s;
+      }
+    }
+    if (hess) {
+      if (e < n) {
+        const T* Qk = a.cQ + ((int64_t)b * (N + 1) + k) * n * n;
+        for (int j = 0; j < n; ++j) a.Q[(int64_t)b * a.Q_bs + (int64_t)k * n * n + e + j * n] = Qk[e + j * n];
+      } else {
+        const int i = e - n;
+        const T* Rk = a.cR + ((int64_t)b * N + k) * m * m;
+        const T* Hk = a.cH + ((int64_t)b * N + k) * m * n;
+        for (int j = 0; j < m; ++j) a.R[(int64_t)b * a.R_bs + (int64_t)k * m * m + i + j * m] = Rk[i + j * m];
+        for (int j = 0; j < n; ++j) a.H[(int64_t)b * a.H_bs + (int64_t)k * m * n + i + j * m] = Hk[i + j * m];
+      }
+    }
+  }
+}
+
+// MeritFunction (solver.cpp:273-355): closed-loop rollout with step alpha, total cost phi and -- when asked -- the directional
+// derivative phi' with the refreshed lx, lu.  Lanes 0..31: state rows, lanes 32..63: input rows.
+template <typename T>
+__global__ __launch_bounds__(64) void generic_merit_kernel(IlqrGenArgs<T> a) {
+  __shared__ double xs[GEN_MAX], dxs[GEN_MAX], das[GEN_MAX], us[GEN_MAX], dus[GEN_MAX];
+  const int b = blockIdx.x, lane = threadIdx.x;
+  if (a.active && !a.active[b]) return;
+  const int n = a.n, m = a.m, N = a.N;
+  const double alpha = a.alpha ? a.alpha[b] : a.alpha_const;
+  const bool deriv = a.want_derivative != 0;
+  const bool isx = lane < n, isu = lane >= 32 && lane - 32 < m;
+  const int i = isx ? lane : 0, iu = isu ? lane - 32 : 0;
+  double x = (double)a.x0[(int64_t)b * a.x0_stride + i], dxda = 0.0;
+  double J = 0.0, dJ = 0.0;
+  for (int k = 0; k < N; ++k) {
+    __syncthreads();
+    if (isx) {
+      xs[lane] = x; dxs[lane] = x - (double)a.xn[((int64_t)b * (N + 1) + k) * n + lane]; das[lane] = dxda;
+      a.x[(int64_t)b * a.x_bs + (int64_t)k * n + lane] = (T)x;
+    }
+    __syncthreads();
+    if (isu) {   // u_ = u + (-K dx + alpha d) ; du_da = -K dx_da + d
+      const T* Kk = a.K + (int64_t)b * a.K_bs + (int64_t)k * m * n;
+      double s = 0.0, s2 = 0.0;
+      for (int j = 0; j < n; ++j) { const double kj = (double)Kk[iu + j * m]; s += kj * dxs[j]; s2 += kj * das[j]; }
+      const double dk = (double)a.d[(int64_t)b * a.d_bs + (int64_t)k * m + iu];
+      const double uv = (double)a.un[((int64_t)b * N + k) * m + iu] + (-s + alpha * dk);
+      us[iu] = uv; dus[iu] = -s2 + dk;
+      a.u[(int64_t)b * a.u_bs + (int64_t)k * m + iu] = (T)uv;
+    }
+    if (isx) {   // y_ = P dx + p
+      const T* Pk = a.P + (int64_t)b * a.P_bs + (int64_t)k * n * n;
+      double s = 0.0;
+      for (int j = 0; j < n; ++j) s += (double)Pk[i + j * n] * dxs[j];
+      a.y[(int64_t)b * a.y_bs + (int64_t)k * n + i] = (T)(s + (double)a.p[(int64_t)b * a.p_bs + (int64_t)k * n + i]);
+    }
+    __syncthreads();
+    const T* Qk = a.cQ + ((int64_t)b * (N + 1) + k) * n * n;
+    const T* Rk = a.cR + ((int64_t)b * N + k) * m * m;
+    const T* Hk = a.cH + ((int64_t)b * N + k) * m * n;
+    double xn = 0.0, dxn = 0.0;
+    if (isx) {   // state row: cost share, lx, next state
+      double qx = 0.0, htu = 0.0;
+      for (int j = 0; j < n; ++j) qx += (double)Qk[i + j * n] * xs[j];
+      for (int j = 0; j < m; ++j) htu += (double)Hk[j + i * m] * us[j];
+      const double ql = (double)a.cq[((int64_t)b * (N + 1) + k) * n + i];
+      J += x * (0.5 * qx + ql);
+      if (lane == 0) J += (double)a.cc[(int64_t)b * (N + 1) + k];
+      const double lx = (qx + htu) + ql;
+      if (deriv) { dJ += lx * dxda; a.q[(int64_t)b * a.q_bs + (int64_t)k * n + i] = (T)lx; }
+      const T* Ak = a.A + (int64_t)b * a.A_bs + (int64_t)k * n * n;
+      const T* Bk = a.B + (int64_t)b * a.B_bs + (int64_t)k * n * m;
+      double s = 0.0, s2 = 0.0, t = 0.0, t2 = 0.0;
+      for (int j = 0; j < n; ++j) { const double aj = (double)Ak[i + j * n]; s += aj * xs[j]; t += aj * das[j]; }
+      for (int j = 0; j < m; ++j) { const double bj = (double)Bk[i + j * n]; s2 += bj * us[j]; t2 += bj * dus[j]; }
+      xn = (s + s2) + (double)a.f[(int64_t)b * a.f_bs + (int64_t)k * n + i];
+      dxn = t + t2;
+    }
+    if (isu) {   // input row: cost share (with the cross term u'Hx), lu
+      double ru = 0.0, hx = 0.0;
+      for (int j = 0; j < m; ++j) ru += (double)Rk[iu + j * m] * us[j];
+      for (int j = 0; j < n; ++j) hx += (double)Hk[iu + j * m] * xs[j];
+      const double rl = (double)a.cr[((int64_t)b * N + k) * m + iu];
+      const double uv = us[iu];
+      J += uv * ((0.5 * ru + rl) + hx);
+      const double lu = (ru + hx) + rl;
+      if (deriv) { dJ += lu * dus[iu]; a.r[(int64_t)b * a.r_bs + (int64_t)k * m + iu] = (T)lu; }
+    }
+    if (isx) { x = xn; dxda = dxn; }
+  }
+  __syncthreads();
+  {   // terminal knot point (solver.cpp:319-332)
+    if (isx) { xs[lane] = x; dxs[lane] = x - (double)a.xn[((int64_t)b * (N + 1) + N) * n + lane]; a.x[(int64_t)b * a.x_bs + (int64_t)N * n + lane] = (T)x; }
+    __syncthreads();
+    if (isx) {
+      const T* Qk = a.cQ + ((int64_t)b * (N + 1) + N) * n * n;
+      const T* Pk = a.P + (int64_t)b * a.P_bs + (int64_t)N * n * n;
+      double qx = 0.0, s = 0.0;
+      for (int j = 0; j < n; ++j) { qx += (double)Qk[i + j * n] * xs[j]; s += (double)Pk[i + j * n] * dxs[j]; }
+      const double ql = (double)a.cq[((int64_t)b * (N + 1) + N) * n + i];
+      J += x * (0.5 * qx + ql);
+      if (lane == 0) J += (double)a.cc[(int64_t)b * (N + 1) + N];
+      a.y[(int64_t)b * a.y_bs + (int64_t)N * n + i] = (T)(s + (double)a.p[(int64_t)b * a.p_bs + (int64_t)N * n + i]);
+      const double lx = qx + ql;
+      if (deriv) { dJ += lx * dxda; a.q[(int64_t)b * a.q_bs + (int64_t)N * n + i] = (T)lx; }
+    }
+  }
+  const double phi = gen_wave_sum(J), dphi = gen_wave_sum(dJ);
+  if (lane == 0) {
+    a.phi[b] = phi;
+    if (deriv) a.dphi[b] = dphi;
+  }
+}
+
+// Stationarity (solver.cpp:207-222): max_k |lx + A^T y+ - y|, max_k |lu + B^T y+| on the candidate trajectory; feasibility 0
+// (constraint blocks are not part of this plan's loop)
+template <typename T>
+__global__ __launch_bounds__(64) void generic_stationarity_kernel(IlqrGenArgs<T> a) {
+  __shared__ double yn[GEN_MAX];
+  const int b = blockIdx.x, lane = threadIdx.x;
+  if (a.active && !a.active[b]) return;
+  const int n = a.n, m = a.m, N = a.N;
+  const bool isx = lane < n, isu = lane >= 32 && lane - 32 < m;
+  const int j = isx ? lane : (isu ? lane - 32 : 0);
+  double res = 0.0;
+  for (int k = 0; k < N; ++k) {
+    __syncthreads();
+    if (lane < n) yn[lane] = (double)a.y[(int64_t)b * a.y_bs + (int64_t)(k + 1) * n + lane];
+    __syncthreads();
+    if (isx) {
+      const T* Ak = a.A + (int64_t)b * a.A_bs + (int64_t)k * n * n;
+      double s = 0.0;
+      for (int i = 0; i < n; ++i) s += (double)Ak[i + j * n] * yn[i];
+      res = fmax(res, fabs(((double)a.q[(int64_t)b * a.q_bs + (int64_t)k * n + j] + s) - (double)a.y[(int64_t)b * a.y_bs + (int64_t)k * n + j]));
+    } else if (isu) {
+      const T* Bk = a.B + (int64_t)b * a.B_bs + (int64_t)k * n * m;
+      double s = 0.0;
+      for (int i = 0; i < n; ++i) s += (double)Bk[i + j * n] * yn[i];
+      res = fmax(res, fabs((double)a.r[(int64_t)b * a.r_bs + (int64_t)k * m + j] + s));
+    }
+  }
+  if (isx) res = fmax(res, fabs((double)a.q[(int64_t)b * a.q_bs + (int64_t)N * n + j] - (double)a.y[(int64_t)b * a.y_bs + (int64_t)N * n + j]));
+  res = gen_wave_max(res);
+  if (lane == 0) { a.prob[b].stationarity = res; a.prob[b].feasibility = 0.0; }
+}
+
+// ALTROSolver::ShiftTrajectory (altro_solver.cpp:283-293) on the candidate trajectory
+template <typename T>
+__global__ void generic_shift_kernel(IlqrGenArgs<T> a) {
+  const int n = a.n, m = a.m, N = a.N;
+  const int64_t total = (int64_t)a.batch * (n + m);
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int e = (int)(t % (n + m));
+    const int b = (int)(t / (n + m));
+    if (e < n) {
+      T* c = a.x + (int64_t)b * a.x_bs + e;
+      for (int k = 0; k < N; ++k) c[(int64_t)k * n] = c[(int64_t)(k + 1) * n];
+    } else {
+      T* c = a.u + (int64_t)b * a.u_bs + (e - n);
+      for (int k = 0; k < N - 1; ++k) c[(int64_t)k * m] = c[(int64_t)(k + 1) * m];
+    }
+  }
+}
+
+template <typename T>
+int ilqr_generic_launch(hipStream_t stream, int which, const IlqrGenArgs<T>& a);   // ilqr_launch_generic.hip
+
+}  // namespace altro_hip

@@ -49,6 +49,7 @@ struct GenericArgs {
   int is_diag;
   int store_q;
   int want_y;
+  int no_f = 0;              // backward sweep: treat f as zero (altro_hip_batch::ilqr_linear: the expansion of the iLQR loop)
 };
 
 // C(mr x nc) = beta*C + alpha * op(A) op(B); operands column-major in LDS (or global for B/A reads).
@@ -131,7 +132,8 @@ __global__ __launch_bounds__(64) void generic_backward_kernel(GenericArgs<T> a) 
     // stage the knot point
     wave_copy(lane, sA, (const T*)GPTR(G_A, k), n2 * n);
     wave_copy(lane, sB, (const T*)GPTR(G_B, k), n2 * m);
-    wave_copy(lane, sf, (const T*)GPTR(G_f, k), n2);
+    if (a.no_f) { for (int e = lane; e < n2; e += 64) sf[e] = T(0); }   // the iLQR loop's expansion carries no affine term (knotpoint_data.cpp:416)
+    else wave_copy(lane, sf, (const T*)GPTR(G_f, k), n2);
     if (a.is_diag) {  // tvlqr.cpp:125-128
       const T* Qd = GPTR(G_Q, k);
       const T* Rd = GPTR(G_R, k);

@@ -80,7 +80,8 @@ typedef enum altro_hip_error {
 } altro_hip_error;
 
 /* Which kernel family a handle runs.  AUTO: (12, 4) -> MFMA16; n <= 6, m <= 3 -> LANE; other n <= 12, m <= 4 -> MFMA16
- * (padded); anything larger (<= 32) -> GENERIC (TVLQR sweep only). */
+ * (padded); anything larger (<= 32) -> GENERIC (the TVLQR sweep and the iLQR loop for dynamics given as data with a quadratic
+ * cost, kernels/ilqr_generic.hip: correctness first; no device models, no constraint blocks, no regularisation retry). */
 typedef enum altro_hip_plan {
   ALTRO_HIP_PLAN_AUTO = 0,
   ALTRO_HIP_PLAN_GENERIC = 1, /* wave-per-problem, LDS-staged, any (n, m) <= 32                */
@@ -180,6 +181,8 @@ int altro_hip_get_qblocks(altro_hip_batch* h, double* qblocks);
 
 
 /* ---- the iLQR loop around the sweep ------------------------------------------------------------------
+ * Plan GENERIC (n or m beyond the tile, up to 32): dynamics are DATA, tracking or dense quadratic cost, MPC operations; one wave per
+ * problem (kernels/ilqr_generic.hip).  Constraint blocks, device models and the regularisation retry: plans LANE / MFMA16.
  * Plan LANE (n <= 6: BASELINE.json configs[2], [3]): nonlinear dynamics from a compiled-in device model
  * (altro_hip_set_model), constraint blocks, MPC operations.
  * Plan MFMA16 ((n, m) = (12, 4): configs[1], [4]): dynamics are DATA -- the A, B, f given to

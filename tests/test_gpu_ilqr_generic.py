@@ -1,0 +1,140 @@
+"""The iLQR loop on plan GENERIC (missing #3): shapes beyond the (12, 4) tile -- any n, m up to 32 -- with dynamics
+given as data and a quadratic cost (tracking or dense), through kernels/ilqr_generic.hip, against the oracle's restatement of
+SolverImpl with ORACLE_DYN_LINEAR.  Correctness-first plan: one wave per problem, sums reduced over the wave -- results agree to
+rounding (merit phi 1e-11, phi' 1e-9, candidates 1e-10; whole LQ solves: same status / iterations, trajectories 1e-9)."""
+import numpy as np
+import pytest
+
+import altro_amd
+from oracle import oracle
+from tests import problems
+
+pytestmark = pytest.mark.gpu
+
+
+def make(batch, N, n, m, dense, with_f=True):
+    p = problems.ilqr12x4_problem(batch, N, with_f, n=n, m=m)      # random LTV dynamics + tracking cost of any shape
+    if dense:
+        p.update(problems.quadratic_cost(batch, N, n, m))
+    bt = altro_amd.Batch(N, n, m, batch)
+    assert bt.plan == altro_amd.PLAN_GENERIC
+    bt.set_dynamics(p["A"], p["B"], p["f"])
+    if dense:
+        bt.set_quadratic_cost(p["Q"], p["R"], p["H"], p["q"], p["r"], p["c"])
+    else:
+        bt.set_tracking_cost(p["Qd"], p["Rd"], p["xref"], p["uref"])
+    bt.set_initial_state(p["x0"])
+    bt.set_input_guess(p["u0"])
+    return p, bt
+
+
+def make_oracle(p, b, N, n, m, dense):
+    s = oracle.ILQR(N, n, m, 0.01, oracle.DYN_LINEAR, cost_kind=oracle.COST_QUADRATIC if dense else oracle.COST_DIAGONAL)
+    f = p["f"][b] if p["f"] is not None else None
+    s.L.oracle_ilqr_set_linear_dynamics(s.h, np.ascontiguousarray(p["A"][b]), np.ascontiguousarray(p["B"][b]),
+                                        None if f is None else np.ascontiguousarray(f).ctypes.data)
+    for k in range(N + 1):
+        kk = min(k, N - 1)
+        if dense:
+            s.L.oracle_ilqr_set_quadratic_cost(s.h, k, np.ascontiguousarray(p["Q"][b, k]), np.ascontiguousarray(p["R"][b, kk]).ctypes.data,
+                                               np.ascontiguousarray(p["H"][b, kk]).ctypes.data, np.ascontiguousarray(p["q"][b, k]),
+                                               np.ascontiguousarray(p["r"][b, kk]).ctypes.data, float(p["c"][b, k]))
+        else:
+            s.L.oracle_ilqr_set_lqr_cost(s.h, k, np.ascontiguousarray(p["Qd"][b, k]), np.ascontiguousarray(p["Rd"][b, kk]),
+                                         np.ascontiguousarray(p["xref"][b, k]), np.ascontiguousarray(p["uref"][b, kk]))
+    s.L.oracle_ilqr_set_initial_state(s.h, np.ascontiguousarray(p["x0"][b]))
+    s.L.oracle_ilqr_initialize(s.h)
+    for k in range(N):
+        s.L.oracle_ilqr_set_input(s.h, k, np.ascontiguousarray(p["u0"][b, k]))
+    return s
+
+
+@pytest.mark.parametrize("n,m,dense", [(16, 5, False), (16, 5, True), (13, 4, True), (32, 8, False), (12, 6, True)])
+def test_merit_expansion_stationarity_generic(n, m, dense):
+    N, batch = 14, 7
+    p, bt = make(batch, N, n, m, dense)
+    bt.open_loop_rollout(); bt.accept(); bt.expand(); bt.backward()
+    assert (bt.get("status") == -1).all()
+    A0, B0, lx0, lu0 = bt.get_expansion()
+    alphas = np.linspace(0.0, 1.2, batch)
+    phi, dphi = bt.merit(alphas)
+    xc, uc, yc = bt.get("x"), bt.get("u"), bt.get("y")
+    st = bt.stationarity()
+    for b in [0, 3, 6]:
+        s = make_oracle(p, b, N, n, m, dense)
+        s.L.oracle_ilqr_open_loop_rollout(s.h); s.L.oracle_ilqr_copy_trajectory(s.h)
+        s.L.oracle_ilqr_calc_dynamics_expansions(s.h); s.L.oracle_ilqr_calc_cost_gradient(s.h)
+        s.L.oracle_ilqr_calc_expansions(s.h)
+        np.testing.assert_allclose(lx0[b], s.get("lx"), rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(lu0[b], s.get("lu"), rtol=1e-12, atol=1e-12)
+        assert s.L.oracle_ilqr_backward_pass(s.h) == -1
+        assert np.array_equal(bt.get("K")[b], s.get("K"))           # plan GENERIC's sweep is the oracle's bit for bit
+        p_ref, dp_ref = s.merit(alphas[b])
+        assert abs(phi[b] - p_ref) <= 1e-11 * max(1.0, abs(p_ref)), (b, phi[b], p_ref)
+        assert abs(dphi[b] - dp_ref) <= 1e-9 * max(1.0, abs(dp_ref)), (b, dphi[b], dp_ref)
+        np.testing.assert_allclose(xc[b], s.get("x_cand"), rtol=1e-10, atol=1e-10)
+        np.testing.assert_allclose(uc[b], s.get("u_cand"), rtol=1e-10, atol=1e-10)
+        np.testing.assert_allclose(yc[b], s.get("y_cand"), rtol=1e-9, atol=1e-9)
+        ref_st = s.L.oracle_ilqr_stationarity(s.h)
+        assert abs(st[b] - ref_st) <= 1e-8 * max(1.0, ref_st)
+
+
+@pytest.mark.parametrize("n,m,dense,dtype", [(16, 5, False, altro_amd.F64), (20, 7, True, altro_amd.F64), (32, 8, True, altro_amd.F64),
+                                              (16, 5, True, altro_amd.F32)])
+def test_whole_lq_solves_generic(n, m, dense, dtype):
+    """Whole solves of an LQ problem (alpha = 1, <= 3 sweeps) on plan GENERIC; MPC operations on the resident batch afterwards
+    (UpdateLinearCosts, SetInitialState, ShiftTrajectory: bicycle_test.cpp:302-337's pattern) and a second solve."""
+    N, batch = 18, 11
+    p = problems.ilqr12x4_problem(batch, N, True, n=n, m=m)
+    if dense:
+        p.update(problems.quadratic_cost(batch, N, n, m))
+    bt = altro_amd.Batch(N, n, m, batch, dtype=dtype)
+    assert bt.plan == altro_amd.PLAN_GENERIC
+    bt.set_dynamics(p["A"], p["B"], p["f"])
+    if dense:
+        bt.set_quadratic_cost(p["Q"], p["R"], p["H"], p["q"], p["r"], p["c"])
+    else:
+        bt.set_tracking_cost(p["Qd"], p["Rd"], p["xref"], p["uref"])
+    bt.set_initial_state(p["x0"]); bt.set_input_guess(p["u0"])
+    f32 = dtype == altro_amd.F32
+    res = bt.ilqr_solve(iterations_max=10, tol_stationarity=1e-2 if f32 else 1e-4)
+    assert (res["status"] == 0).all() and (res["iterations"] <= 3).all()
+    x, u = bt.get_nominal()
+    tol = 2e-4 if f32 else 1e-9
+    ors = {}
+    for b in [0, 5, 10]:
+        s = make_oracle(p, b, N, n, m, dense)
+        s.L.oracle_ilqr_set_options(s.h, 10, 1e-4, 1e-4, 1e-8, 0)
+        status, iters, log = s.solve()
+        assert status == 0 and (f32 or iters == res["iterations"][b])
+        np.testing.assert_allclose(x[b], s.get("x"), rtol=tol, atol=tol)
+        np.testing.assert_allclose(u[b], s.get("u"), rtol=tol * 10, atol=tol * 10)
+        ors[b] = s
+    if f32:
+        return
+    # receding horizon: move the linear cost terms, take x_1 as the new initial state, shift, solve again
+    qbase = p["q"] if dense else -(p["Qd"] * p["xref"])
+    qnew = qbase + 0.05
+    x1, _ = bt.get_knot(1)
+    bt.update_linear_costs(qnew, None, np.zeros((batch, N + 1)), 0, N)
+    bt.set_initial_state(x1)
+    bt.shift_trajectory()
+    res2 = bt.ilqr_solve(iterations_max=10)
+    x2, u2 = bt.get_nominal()
+    for b, s in ors.items():
+        for k in range(N + 1):
+            s.L.oracle_ilqr_update_linear_costs(s.h, k, np.ascontiguousarray(qnew[b, k]).ctypes.data, None, 0.0)
+        s.L.oracle_ilqr_set_initial_state(s.h, np.ascontiguousarray(x1[b]))
+        s.L.oracle_ilqr_shift_trajectory(s.h)
+        status, iters, log = s.solve()
+        assert res2["status"][b] == status and res2["iterations"][b] == iters
+        np.testing.assert_allclose(x2[b], s.get("x"), rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(u2[b], s.get("u"), rtol=1e-8, atol=1e-8)
+
+
+def test_generic_plan_says_what_it_does_not_do():
+    bt = altro_amd.Batch(10, 16, 5, 4)
+    with pytest.raises(altro_amd.AltroHipError):
+        bt.add_linear_constraint(0, 9, altro_amd.CONE_INEQUALITY, np.zeros((2, 21)), np.zeros(2))   # constraint blocks: LANE / MFMA16
+    with pytest.raises(altro_amd.AltroHipError):
+        bt.set_model(altro_amd.MODEL_BICYCLE, 0.1)
