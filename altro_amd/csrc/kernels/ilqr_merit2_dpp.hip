@@ -303,7 +303,7 @@ namespace altro_hip {
 // ilqr_tile_model.hip); a pass that stores the expansion leaves those rows in the DYN records for the next backward sweep
 // (what KnotPointData::CalcDynamicsExpansion leaves in A_, B_: knotpoint_data.cpp:406-419).  Z and f are then not loaded.
 template <typename S, bool AL, bool DUAL, bool DENSE = false, int MK = 0>
-__global__ __launch_bounds__(64, (MK != 0 ? 1 : 2)) void wave_merit_dpp_kernel(IlqrWaveArgs<S> a) {
+__global__ __launch_bounds__(64, ((MK != 0 || (AL && DENSE && sizeof(S) == 8)) ? 1 : 2)) void wave_merit_dpp_kernel(IlqrWaveArgs<S> a) {
   constexpr int DEPTH = 2;                          // also the image ping-pong: parity of k == dd
   constexpr bool kStat = sizeof(S) == 8;            // stored values == computed values only without a rounding store
   constexpr int IMG = DENSE ? MD_IMG_DENSE : MD_IMG;

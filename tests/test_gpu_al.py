@@ -307,3 +307,28 @@ def test_constrained_double_integrator_other_dims(dim):
         tol = 1e-6 if dim == 3 else 1e-8
         np.testing.assert_allclose(x[b], s.get("x"), rtol=tol, atol=tol)
     assert checked >= 2
+
+
+def test_constraint_capacity_is_stated_and_enforced():
+    """The reference appends constraints without limit (knotpoint_data.cpp:155-178); the device tables hold at most 2 blocks per
+    knot point, 8 rows per block (4 for a second-order cone) and 16 block definitions per handle (kernels/al_types.h, stated in
+    altro_hip.h next to altro_hip_add_linear_constraint).  Going past a limit is an error that says which one -- never a silent
+    truncation; rows of the same cone can be stacked into one block (two 4-row bound blocks == one 8-row block)."""
+    N, n, m = 10, 4, 2
+    bt = altro_amd.Batch(N, n, m, 3)
+    w = n + m
+    G1 = np.zeros((1, w)); G1[0, 4] = 1.0
+    bt.add_linear_constraint(0, N - 1, altro_amd.CONE_INEQUALITY, G1, np.array([1.0]))
+    bt.add_linear_constraint(0, N - 1, altro_amd.CONE_INEQUALITY, -G1, np.array([1.0]))
+    with pytest.raises(altro_amd.AltroHipError, match="at most 2 constraint blocks per knot point"):
+        bt.add_linear_constraint(3, 3, altro_amd.CONE_EQUALITY, G1, np.array([0.0]))
+    with pytest.raises(altro_amd.AltroHipError, match=r"constraint dimension 9 outside \[1, 8\]"):
+        bt.add_linear_constraint(N, N, altro_amd.CONE_INEQUALITY, np.zeros((9, w)), np.zeros(9))
+    with pytest.raises(altro_amd.AltroHipError, match=r"constraint dimension 5 outside \[1, 4\]"):
+        bt.add_linear_constraint(N, N, altro_amd.CONE_SOC, np.zeros((5, w)), np.zeros(5))
+    bt2 = altro_amd.Batch(40, n, m, 3)
+    for k in range(16):
+        bt2.add_linear_constraint(k, k, altro_amd.CONE_INEQUALITY, G1, np.array([1.0]))
+    with pytest.raises(altro_amd.AltroHipError, match="at most 16 constraint blocks"):
+        bt2.add_linear_constraint(20, 20, altro_amd.CONE_INEQUALITY, G1, np.array([1.0]))
+    bt.close(); bt2.close()

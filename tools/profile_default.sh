@@ -3,7 +3,7 @@
 # WRITE_SIZE in their own passes (kernel-trace only, each pass bounded); summary in gpurun_out/<tag>_default_rocprofv3.txt
 TAG=${1:-r02z}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-CMD="python bench.py --no-cpu-baseline"
+CMD="python bench.py --no-cpu-baseline --no-live-traffic"
 OUT=gpurun_out/prof_${TAG}_default; rm -rf $OUT; mkdir -p $OUT
 SUM=gpurun_out/${TAG}_default_rocprofv3.txt
 echo "# $CMD  (= the default bench command without its CPU leg; rocprofv3, MI355X; one pass per counter set, --kernel-trace only)" > $SUM
