@@ -44,6 +44,7 @@ struct AlTable {
   // miss per step -- and offset the duals by k * rows_per_knot.
   int uniform, rows_per_knot, N;
   int G_count;           // elements of the G pool (kernels that keep it in LDS: kernels/ilqr_merit2_dpp.hip)
+  int has_soc;           // some block is a second-order cone (kernels instantiated without the cone's code serve handles that have none)
 };
 #define ALTRO_CONST_AS __attribute__((address_space(4)))
 // table entry and dual-row shift for knot point k

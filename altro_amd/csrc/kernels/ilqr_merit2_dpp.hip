@@ -159,7 +159,7 @@ __device__ __forceinline__ void md_gather4(double v, double (&o)[4]) {
       : "v"(v));
 }
 // (DU: DualUpdate, knotpoint_data.cpp:503-510 -- the projected dual becomes the dual; `store`: this row has a problem of its own)
-template <typename S, bool DU = false>
+template <typename S, bool DU = false, bool SOC = true>
 __device__ __forceinline__ void dpp_al_rows(const AlTable<S>& t, int k, int b, int64_t B, double w, bool terminal, double rho_est, int j,
                                             double (&jvr)[AL_MAXC], double& cost, double& viol, bool store = false,
                                             const double* Gl = nullptr,     // Gl: the G pool in LDS (the sweeps keep it there)
@@ -200,7 +200,7 @@ __device__ __forceinline__ void dpp_al_rows(const AlTable<S>& t, int k, int b, i
     }
     const double val = sacc - gi;
     const double ze = rl ? zi - rho_est * val : 0.0;
-    if (cone != CONE_SOC) {
+    if (!SOC || cone != CONE_SOC) {   // (!SOC: the handle has no second-order cone -- al.has_soc -- and the cone's code is not in the kernel)
       if (rl) {
         double zp = 0.0, mkv = 0.0;
         if (cone == CONE_EQUALITY) { zp = ze; mkv = 1.0; viol = fmax(viol, fabs(val)); }
@@ -302,7 +302,7 @@ namespace altro_hip {
 // from the row's registers and, where phi' is wanted, forms row j of Z = [A B] at the point (tile_model_step,
 // ilqr_tile_model.hip); a pass that stores the expansion leaves those rows in the DYN records for the next backward sweep
 // (what KnotPointData::CalcDynamicsExpansion leaves in A_, B_: knotpoint_data.cpp:406-419).  Z and f are then not loaded.
-template <typename S, bool AL, bool DUAL, bool DENSE = false, int MK = 0>
+template <typename S, bool AL, bool DUAL, bool DENSE = false, int MK = 0, bool SOC = true>
 __global__ __launch_bounds__(64, ((MK != 0 || (AL && DENSE && sizeof(S) == 8)) ? 1 : 2)) void wave_merit_dpp_kernel(IlqrWaveArgs<S> a) {
   constexpr int DEPTH = 2;                          // also the image ping-pong: parity of k == dd
   constexpr bool kStat = sizeof(S) == 8;            // stored values == computed values only without a rounding store
@@ -429,12 +429,12 @@ __global__ __launch_bounds__(64, ((MK != 0 || (AL && DENSE && sizeof(S) == 8)) ?
       if (live) {
         double zgn[AL_MAXC][2];
         dpp_al_fetch<S>(a.al, k + 1, b, a.batch, j, zgn);     // (k + 1 <= N: the terminal knot point's too)
-        dpp_al_rows<S>(a.al, kc, b, a.batch, w, false, rho, j, jvr, Ja, vv, false, Gl, zg);
+        dpp_al_rows<S, false, SOC>(a.al, kc, b, a.batch, w, false, rho, j, jvr, Ja, vv, false, Gl, zg);
 #pragma unroll
         for (int c = 0; c < AL_MAXC; ++c) { zg[c][0] = zgn[c][0]; zg[c][1] = zgn[c][1]; }
         Jal += Ja;
       } else {
-        dpp_al_rows<S>(a.al, kc, b, a.batch, w, false, rho, j, jvr, Ja, vv, false, Gl);   // a padding step: knot point N - 1 again, discarded
+        dpp_al_rows<S, false, SOC>(a.al, kc, b, a.batch, w, false, rho, j, jvr, Ja, vv, false, Gl);   // a padding step: knot point N - 1 again, discarded
       }
       if (cand) viol = fmax(viol, vv);
     }
@@ -539,10 +539,10 @@ __global__ __launch_bounds__(64, ((MK != 0 || (AL && DENSE && sizeof(S) == 8)) ?
     if (al) {
       double Ja = 0.0, vv = 0.0;
       if constexpr (DUAL) {
-        dpp_al_rows<S>(a.al, N, b, a.batch, isx ? x : 0.0, true, rho, j, jvr, Ja, vv, false, Gl, zg);
+        dpp_al_rows<S, false, SOC>(a.al, N, b, a.batch, isx ? x : 0.0, true, rho, j, jvr, Ja, vv, false, Gl, zg);
         Jal += Ja;
       } else {   // (wave_merit_kernel adds the terminal blocks' shares to its running sum one by one)
-        dpp_al_rows<S>(a.al, N, b, a.batch, isx ? x : 0.0, true, rho, j, jvr, Jal, vv, false, Gl, zg);
+        dpp_al_rows<S, false, SOC>(a.al, N, b, a.batch, isx ? x : 0.0, true, rho, j, jvr, Jal, vv, false, Gl, zg);
       }
       if (cand) viol = fmax(viol, vv);
     }
