@@ -15,7 +15,8 @@ namespace {
 template <typename T>
 int al_upload_typed(altro_hip_batch* h) {
   const int64_t B = h->batch;
-  for (void** p : {(void**)&h->al_d_knots, &h->al_d_G, &h->al_d_g, &h->al_d_z})
+  h->al_Gpad_count = 0;
+  for (void** p : {(void**)&h->al_d_knots, &h->al_d_G, &h->al_d_Gpad, &h->al_d_g, &h->al_d_z})
     if (*p) { (void)hipFree(*p); *p = nullptr; }
   if (h->al_defs.empty()) { h->al_rows = 0; return 0; }
   // G on the device: p x (n + m) column-major as given on plan LANE; on plan MFMA16 p x 16 in the tile's own column order
@@ -31,6 +32,17 @@ int al_upload_typed(altro_hip_batch* h) {
     G.resize(G.size() + (size_t)d0.p * w_dev, (T)0);
     for (int e = 0; e < w_log; ++e)
       for (int r = 0; r < d0.p; ++r) G[(size_t)G_off_dev[i] + r + (size_t)dev_col(e) * d0.p] = (T)h->al_G[(size_t)d0.G_off + r + (size_t)e * d0.p];
+  }
+  std::vector<T> Gpad;   // the same blocks zero-padded for the row-layout kernels (al_types.h: AL_GP_DEF)
+  if (tile) {
+    Gpad.assign(h->al_defs.size() * (size_t)AL_GP_DEF, (T)0);
+    for (size_t i = 0; i < h->al_defs.size(); ++i) {
+      const AlDef& d0 = h->al_defs[i];
+      if (d0.user) continue;
+      for (int e = 0; e < w_log; ++e)
+        for (int r = 0; r < d0.p && r < AL_MAXP; ++r)
+          Gpad[i * (size_t)AL_GP_DEF + (size_t)r * AL_GP_LD + dev_col(e)] = (T)h->al_G[(size_t)d0.G_off + r + (size_t)e * d0.p];
+    }
   }
   std::vector<T> g;
   std::vector<AlDef> defs = h->al_defs;
@@ -55,6 +67,7 @@ int al_upload_typed(altro_hip_batch* h) {
       kn.z_off[j] = rows; rows += d.p;
       kn.cone[j] = d.cone; kn.p[j] = d.p; kn.g_per_problem[j] = d.g_per_problem; kn.G_off[j] = G_off_dev[kn.def[j]]; kn.g_off[j] = d.g_off;
       kn.user[j] = d.user;
+      kn.Gp_off[j] = kn.def[j] * AL_GP_DEF;
       // bound-type block: every row of G is +-e_idx
       const int w = h->n + h->m;
       bool sel = d.cone != CONE_SOC;
@@ -91,6 +104,11 @@ int al_upload_typed(altro_hip_batch* h) {
   if ((rc = dmalloc(h, &h->al_d_z, (size_t)rows * B * sizeof(T)))) return rc;
   HIP_TRY(hipMemcpy(h->al_d_knots, knots.data(), knots.size() * sizeof(AlKnot), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->al_d_G, G.data(), G.size() * sizeof(T), hipMemcpyHostToDevice));
+  if (!Gpad.empty()) {
+    if ((rc = dmalloc(h, &h->al_d_Gpad, Gpad.size() * sizeof(T)))) return rc;
+    HIP_TRY(hipMemcpy(h->al_d_Gpad, Gpad.data(), Gpad.size() * sizeof(T), hipMemcpyHostToDevice));
+    h->al_Gpad_count = (int)Gpad.size();
+  }
   HIP_TRY(hipMemcpy(h->al_d_g, g.data(), g.size() * sizeof(T), hipMemcpyHostToDevice));
   // (memsets go on the handle's own stream: it is non-blocking, so a null-stream memset would race the kernels)
   HIP_TRY(hipMemsetAsync(h->al_d_z, 0, (size_t)rows * B * sizeof(T), h->stream));
@@ -112,7 +130,7 @@ IlqrArgs<T> ilqr_args(altro_hip_batch* h, bool use_alpha, bool use_active, int w
   IlqrArgs<T> a;
   a.al.knots = h->al_d_knots; a.al.G = (const T*)h->al_d_G; a.al.g = (const T*)h->al_d_g;
   a.al.z = (T*)h->al_d_z; a.al.enabled = h->al_defs.empty() ? 0 : 1;
-  a.al.uniform = h->al_uniform; a.al.rows_per_knot = h->al_rows_per_knot; a.al.N = h->N; a.al.G_count = h->al_G_count; a.al.has_soc = h->al_has_soc;
+  a.al.uniform = h->al_uniform; a.al.rows_per_knot = h->al_rows_per_knot; a.al.N = h->N; a.al.G_count = h->al_G_count; a.al.has_soc = h->al_has_soc; a.al.Gpad = (decltype(a.al.Gpad))h->al_d_Gpad; a.al.Gpad_count = h->al_Gpad_count;
   a.mode = EXPAND_GRADIENT | EXPAND_HESSIAN;
   a.in = (T*)h->l_in; a.term = (T*)h->l_term; a.out = (const T*)h->l_out; a.outn = (const T*)h->l_outn;
   a.nom = (T*)h->l_nom; a.cand = (T*)h->l_xuy; a.x0 = (const T*)h->l_x0;
@@ -181,7 +199,7 @@ int wave_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int
   IlqrWaveArgs<S> a;
   a.al.knots = h->al_d_knots; a.al.G = (const S*)h->al_d_G; a.al.g = (const S*)h->al_d_g; a.al.z = (S*)h->al_d_z;
   a.al.enabled = h->al_defs.empty() ? 0 : 1;
-  a.al.uniform = h->al_uniform; a.al.rows_per_knot = h->al_rows_per_knot; a.al.N = h->N; a.al.G_count = h->al_G_count; a.al.has_soc = h->al_has_soc;
+  a.al.uniform = h->al_uniform; a.al.rows_per_knot = h->al_rows_per_knot; a.al.N = h->N; a.al.G_count = h->al_G_count; a.al.has_soc = h->al_has_soc; a.al.Gpad = (decltype(a.al.Gpad))h->al_d_Gpad; a.al.Gpad_count = h->al_Gpad_count;
   a.mode = mode;
   a.penalty_scaling = h->expand_penalty_scaling; a.penalty_max = h->expand_penalty_max;
   if (which == IK_STATIONARITY || which == IK_DUAL) {   // constraint rows in the DPP form unless ALTRO_HIP_ALROWS_DPP=0

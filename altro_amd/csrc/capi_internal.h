@@ -118,6 +118,8 @@ struct altro_hip_batch {
   bool al_dirty = false;
   AlKnot* al_d_knots = nullptr;
   void *al_d_G = nullptr, *al_d_g = nullptr, *al_d_z = nullptr;
+  void* al_d_Gpad = nullptr;                 // AlTable::Gpad (plan MFMA16)
+  int al_Gpad_count = 0;
   int al_G_count = 0;                        // elements of the device G pool
   int al_has_soc = 0;                        // some block is a second-order cone
   double expand_penalty_scaling = 10.0, expand_penalty_max = 1e8;   // what EXPAND_DUAL's look-ahead of PenaltyUpdate needs

@@ -333,8 +333,9 @@ int rtc_tile_launch(altro_hip_batch* h, int which, const IlqrWaveArgs<double>& a
   if (rc) return rc;
   IlqrWaveArgs<double> args = a;
   void* params[] = {&args};
+  const unsigned gsh = a.al.enabled ? (unsigned)a.al.Gpad_count * 8u : 0u;   // the merit kernels' dynamic LDS (padded constraint Jacobians)
   auto go = [&](int w, unsigned gx, unsigned gy) -> int {
-    const hipError_t e = hipModuleLaunchKernel(mod->fn[w], gx, gy, 1, 64, 1, 1, 0, h->stream, params, nullptr);
+    const hipError_t e = hipModuleLaunchKernel(mod->fn[w], gx, gy, 1, 64, 1, 1, (w == RTT_MERIT || w == RTT_MERIT2) ? gsh : 0u, h->stream, params, nullptr);
     if (e != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "launch of the run-time compiled tile kernel %d failed: %s", w, hipGetErrorString(e));
     return 0;
   };

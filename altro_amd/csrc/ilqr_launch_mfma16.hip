@@ -11,6 +11,7 @@ namespace altro_hip {
 template <typename S>
 static int wave_launch(hipStream_t stream, int which, const IlqrWaveArgs<S>& a) {
   const dim3 waves(mf_grid(a.batch)), b64(64), b256(256);   // XCD-aware problem mapping: kernels/mfma16_layout.h
+  const unsigned gsh = a.al.enabled ? (unsigned)a.al.Gpad_count * 8u : 0u;   // wave_merit_dpp_kernel's dynamic LDS: the padded constraint Jacobians
   const int64_t flat_n = (int64_t)a.batch * (a.N + 1) * 16;
   const dim3 flat((unsigned)std::min<int64_t>((flat_n + 255) / 256, 1 << 20));
   if (a.mp.kind != MODEL_LINEAR) {   // a device model instead of dynamics as data: kernels/ilqr_tile_model.hip
@@ -48,24 +49,24 @@ static int wave_launch(hipStream_t stream, int which, const IlqrWaveArgs<S>& a) 
       // bounds, cubic search, whole solves: N = 192: 69.7 vs 70.9 ms, N = 256: 105.2 vs 108.9.)
       if (a.cost_dense) {   // the dense quadratic cost lives in the row-layout kernel only
         const dim3 grid(mf_grid((a.batch + 1) / 2), ((a.spec_trials > 1 ? a.spec_trials : 1) + 1) / 2);
-        if (a.al.enabled && !a.al.has_soc) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, true, false, true, 0, false>), grid, b64, 0, stream, a);
-        else if (a.al.enabled) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, true, false, true>), grid, b64, 0, stream, a);
-        else hipLaunchKernelGGL((wave_merit_dpp_kernel<S, false, false, true>), grid, b64, 0, stream, a);
+        if (a.al.enabled && !a.al.has_soc) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, true, false, true, 0, false>), grid, b64, gsh, stream, a);
+        else if (a.al.enabled) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, true, false, true>), grid, b64, gsh, stream, a);
+        else hipLaunchKernelGGL((wave_merit_dpp_kernel<S, false, false, true>), grid, b64, gsh, stream, a);
       } else if (a.mode == 3 || a.mode == 2) {   // (3: ALTRO_HIP_MERIT_DPP=2, kept for the tests that force the form)
         const dim3 grid(mf_grid((a.batch + 1) / 2), ((a.spec_trials > 1 ? a.spec_trials : 1) + 1) / 2);
-        if (a.al.enabled && !a.al.has_soc) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, true, false, false, 0, false>), grid, b64, 0, stream, a);
-        else if (a.al.enabled) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, true, false>), grid, b64, 0, stream, a);
-        else hipLaunchKernelGGL((wave_merit_dpp_kernel<S, false, false>), grid, b64, 0, stream, a);
+        if (a.al.enabled && !a.al.has_soc) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, true, false, false, 0, false>), grid, b64, gsh, stream, a);
+        else if (a.al.enabled) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, true, false>), grid, b64, gsh, stream, a);
+        else hipLaunchKernelGGL((wave_merit_dpp_kernel<S, false, false>), grid, b64, gsh, stream, a);
       } else if (a.al.enabled) hipLaunchKernelGGL((wave_merit_kernel<S, true>), dim3(waves.x, a.spec_trials > 1 ? a.spec_trials : 1), b64, 0, stream, a);
       else hipLaunchKernelGGL((wave_merit_kernel<S, false>), dim3(waves.x, a.spec_trials > 1 ? a.spec_trials : 1), b64, 0, stream, a);
       break;
     case IK_MERIT2:
-      if (a.cost_dense && a.al.enabled && !a.al.has_soc) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, true, true, true, 0, false>), dim3(mf_grid((a.batch + 1) / 2)), b64, 0, stream, a);
-      else if (a.cost_dense && a.al.enabled) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, true, true, true>), dim3(mf_grid((a.batch + 1) / 2)), b64, 0, stream, a);
-      else if (a.cost_dense) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, false, true, true>), dim3(mf_grid((a.batch + 1) / 2)), b64, 0, stream, a);
-      else if (a.mode == 2 && a.al.enabled && !a.al.has_soc) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, true, true, false, 0, false>), dim3(mf_grid((a.batch + 1) / 2)), b64, 0, stream, a);
-      else if (a.mode == 2 && a.al.enabled) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, true, true>), dim3(mf_grid((a.batch + 1) / 2)), b64, 0, stream, a);
-      else if (a.mode == 2) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, false, true>), dim3(mf_grid((a.batch + 1) / 2)), b64, 0, stream, a);   // two problems per wave
+      if (a.cost_dense && a.al.enabled && !a.al.has_soc) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, true, true, true, 0, false>), dim3(mf_grid((a.batch + 1) / 2)), b64, gsh, stream, a);
+      else if (a.cost_dense && a.al.enabled) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, true, true, true>), dim3(mf_grid((a.batch + 1) / 2)), b64, gsh, stream, a);
+      else if (a.cost_dense) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, false, true, true>), dim3(mf_grid((a.batch + 1) / 2)), b64, gsh, stream, a);
+      else if (a.mode == 2 && a.al.enabled && !a.al.has_soc) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, true, true, false, 0, false>), dim3(mf_grid((a.batch + 1) / 2)), b64, gsh, stream, a);
+      else if (a.mode == 2 && a.al.enabled) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, true, true>), dim3(mf_grid((a.batch + 1) / 2)), b64, gsh, stream, a);
+      else if (a.mode == 2) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, false, true>), dim3(mf_grid((a.batch + 1) / 2)), b64, gsh, stream, a);   // two problems per wave
       else if (a.al.enabled) hipLaunchKernelGGL((wave_merit2_kernel<S, true>), waves, b64, 0, stream, a);
       else if (sizeof(S) == 8 && a.mode == 1) hipLaunchKernelGGL((wave_merit2_mfma_kernel<S>), waves, b64, 0, stream, a);   // mode 1: asked for by altro_hip_ilqr_solve
       else hipLaunchKernelGGL((wave_merit2_kernel<S, false>), waves, b64, 0, stream, a);

@@ -23,6 +23,7 @@ template <>
 int ilqr_wave_launch_model<double>(hipStream_t stream, int which, const IlqrWaveArgs<double>& a) {
   using S = double;
   const dim3 b64(64);
+  const unsigned gsh = a.al.enabled ? (unsigned)a.al.Gpad_count * 8u : 0u;   // wave_merit_dpp_kernel's dynamic LDS: the padded constraint Jacobians
   const dim3 rows4((unsigned)((a.batch + 3) / 4));
   const dim3 pairs(mf_grid((a.batch + 1) / 2), which == IK_MERIT ? ((a.spec_trials > 1 ? a.spec_trials : 1) + 1) / 2 : 1);
   bool done = false;
@@ -35,16 +36,16 @@ int ilqr_wave_launch_model<double>(hipStream_t stream, int which, const IlqrWave
         hipLaunchKernelGGL((wave_expand_dyn_kernel<S, K_>), dim3((unsigned)((int64_t)((a.batch + 3) / 4) * a.N)), b64, 0, stream, a); \
         break;                                                                                                                  \
       case IK_MERIT:                                                                                                            \
-        if (a.cost_dense && a.al.enabled) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, true, false, true, K_>), pairs, b64, 0, stream, a);   \
-        else if (a.cost_dense) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, false, false, true, K_>), pairs, b64, 0, stream, a);             \
-        else if (a.al.enabled) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, true, false, false, K_>), pairs, b64, 0, stream, a);             \
-        else hipLaunchKernelGGL((wave_merit_dpp_kernel<S, false, false, false, K_>), pairs, b64, 0, stream, a);                              \
+        if (a.cost_dense && a.al.enabled) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, true, false, true, K_>), pairs, b64, gsh, stream, a);   \
+        else if (a.cost_dense) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, false, false, true, K_>), pairs, b64, gsh, stream, a);             \
+        else if (a.al.enabled) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, true, false, false, K_>), pairs, b64, gsh, stream, a);             \
+        else hipLaunchKernelGGL((wave_merit_dpp_kernel<S, false, false, false, K_>), pairs, b64, gsh, stream, a);                              \
         break;                                                                                                                  \
       case IK_MERIT2:                                                                                                           \
-        if (a.cost_dense && a.al.enabled) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, true, true, true, K_>), pairs, b64, 0, stream, a);    \
-        else if (a.cost_dense) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, false, true, true, K_>), pairs, b64, 0, stream, a);              \
-        else if (a.al.enabled) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, true, true, false, K_>), pairs, b64, 0, stream, a);              \
-        else hipLaunchKernelGGL((wave_merit_dpp_kernel<S, false, true, false, K_>), pairs, b64, 0, stream, a);                               \
+        if (a.cost_dense && a.al.enabled) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, true, true, true, K_>), pairs, b64, gsh, stream, a);    \
+        else if (a.cost_dense) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, false, true, true, K_>), pairs, b64, gsh, stream, a);              \
+        else if (a.al.enabled) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, true, true, false, K_>), pairs, b64, gsh, stream, a);              \
+        else hipLaunchKernelGGL((wave_merit_dpp_kernel<S, false, true, false, K_>), pairs, b64, gsh, stream, a);                               \
         break;                                                                                                                  \
       default: return 1;                                                                                                        \
     }                                                                                                                           \

@@ -9,6 +9,9 @@ constexpr int AL_MAXC = 2;     // constraint blocks per knot point
 constexpr int AL_MAXP = 8;     // rows per zero / identity / orthant block
 constexpr int AL_MAXSOC = 4;   // rows per second-order-cone block
 constexpr int AL_MAXDEF = 16;  // distinct blocks per handle
+// AlTable::Gpad: every block as 9 rows x 16 tile columns, rows padded to 18 (16-byte aligned, eight lanes reading one column hit
+// eight bank groups): rows >= p and row 8 are zero, so a lane reads `its` row (min(lane, 8)) or any column without a select
+constexpr int AL_GP_LD = 18, AL_GP_DEF = 9 * AL_GP_LD;
 
 enum { CONE_EQUALITY = 0, CONE_IDENTITY = 1, CONE_INEQUALITY = 2, CONE_SOC = 3 };   // typedefs.hpp:29-34
 
@@ -31,6 +34,8 @@ struct AlKnot {          // everything a kernel needs about knot point k in ONE 
   // id + 1 of a block whose value c(x, u) and Jacobian dc/d[x;u] the caller's source computes (altro_hip_add_user_constraint:
   // ALTROSolver::SetConstraint with a general callback pair, altro_solver.cpp:192-223); 0 for c = G [x;u] - g
   int user[AL_MAXC];
+  // the block's Jacobian in the zero-padded pool AlTable::Gpad (plan MFMA16's row-layout kernels): def index * AL_GP_DEF
+  int Gp_off[AL_MAXC];
 };
 template <typename T>
 struct AlTable {
@@ -44,6 +49,8 @@ struct AlTable {
   // miss per step -- and offset the duals by k * rows_per_knot.
   int uniform, rows_per_knot, N;
   int G_count;           // elements of the G pool (kernels that keep it in LDS: kernels/ilqr_merit2_dpp.hip)
+  const T* Gpad;         // [def][9][AL_GP_LD], see AL_GP_DEF (plan MFMA16 only; else null)
+  int Gpad_count;        // its elements
   int has_soc;           // some block is a second-order cone (kernels instantiated without the cone's code serve handles that have none)
 };
 #define ALTRO_CONST_AS __attribute__((address_space(4)))

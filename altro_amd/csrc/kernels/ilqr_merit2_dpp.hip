@@ -286,6 +286,103 @@ __device__ __forceinline__ double dpp_al_col(const AlTable<S>& t, int k, int j, 
   return s;
 }
 
+
+// ---- the same rows for the sweeps of wave_merit_dpp_kernel: what a knot point's chain does not have to wait for, it does not ----
+// * the table entry of a knot point (AlKnot, constant address space) is read ONCE per knot point into scalar registers (AlpKnot)
+//   and handed to the three users (duals a step ahead, rows, gradient columns) -- for the usual uniform table once per sweep;
+// * the Jacobians come from the zero-padded pool AlTable::Gpad (al_types.h: AL_GP_DEF) in LDS: a lane reads row min(lane, 8) --
+//   rows >= p and row 8 are zero -- as eight 16-byte reads, and any column as eight 8-byte ones, with no select per element;
+// * a lane that owns no row carries exact zeros through the same arithmetic instead of branching around it (val = ze = 0:
+//   cost share + 0, violation max(., 0), J^T z_proj = 0).
+// Same values, same expressions, same order of the sums as dpp_al_rows / dpp_al_col: bit-identical (tests/test_gpu_merit2.py).
+struct AlpKnot {
+  int ncon, p[AL_MAXC], cone[AL_MAXC], gp_off[AL_MAXC], z_off[AL_MAXC], gpp[AL_MAXC];
+  int64_t g_off[AL_MAXC];
+};
+template <typename S>
+__device__ __forceinline__ void alp_knot(const AlTable<S>& t, int k, AlpKnot& s) {
+  const AlKnot ALTRO_CONST_AS& kn = *(const AlKnot ALTRO_CONST_AS*)(t.knots + k);
+  s.ncon = kn.ncon;
+#pragma unroll
+  for (int c = 0; c < AL_MAXC; ++c) {
+    s.p[c] = kn.p[c]; s.cone[c] = kn.cone[c]; s.gp_off[c] = kn.Gp_off[c]; s.z_off[c] = kn.z_off[c]; s.gpp[c] = kn.g_per_problem[c];
+    s.g_off[c] = kn.g_off[c];
+  }
+}
+// (z_i, g_i) of the knot point whose entry is s (zshift: al_knot's, for uniform tables)
+template <typename S>
+__device__ __forceinline__ void alp_fetch(const AlTable<S>& t, const AlpKnot& s, int zshift, int b, int64_t B, int j, double (&zg)[AL_MAXC][2]) {
+#pragma unroll
+  for (int c = 0; c < AL_MAXC; ++c) {
+    zg[c][0] = 0.0; zg[c][1] = 0.0;
+    if (c >= s.ncon) continue;
+    const bool rl = j < s.p[c];
+    const int jr = rl ? j : 0;
+    zg[c][0] = (double)t.z[(int64_t)(s.z_off[c] + zshift + jr) * B + b];
+    zg[c][1] = rl ? (s.gpp[c] ? (double)t.g[s.g_off[c] + (int64_t)jr * B + b] : (double)t.g[s.g_off[c] + jr]) : 0.0;
+  }
+}
+// rowb: min(lane of the row, 8) * AL_GP_LD;  pre: this knot point's (z_i, g_i)
+template <bool SOC>
+__device__ __forceinline__ void alp_rows(const AlpKnot& s, double w, double rho_est, int j, int rowb, double (&jvr)[AL_MAXC], double& cost,
+                                         double& viol, const double* Gp, const double (&pre)[AL_MAXC][2]) {
+#pragma unroll
+  for (int c = 0; c < AL_MAXC; ++c) {
+    jvr[c] = 0.0;
+    if (c >= s.ncon) continue;                      // (wave-uniform)
+    const int p = s.p[c], cone = s.cone[c];
+    const md_d2* Gr = reinterpret_cast<const md_d2*>(Gp + s.gp_off[c] + rowb);
+    double cG[16];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const md_d2 v = Gr[e]; cG[2 * e] = v[0]; cG[2 * e + 1] = v[1]; }
+    double sacc = 0.0;
+    md_chain16(sacc, w, cG);
+    const bool rl = j < p;
+    const double val = sacc - pre[c][1];
+    const double ze = rl ? pre[c][0] - rho_est * val : 0.0;
+    if (!SOC || cone != CONE_SOC) {
+      double zp = 0.0, mkv = 0.0;
+      if (cone == CONE_EQUALITY) { zp = ze; mkv = 1.0; viol = fmax(viol, fabs(val)); }
+      else if (cone == CONE_INEQUALITY) { zp = fmin(0.0, ze); mkv = (ze <= 0.0) ? 1.0 : 0.0; viol = fmax(viol, fabs(fmin(0.0, val) - val)); }
+      cost += zp * zp / (2.0 * rho_est);
+      jvr[c] = mkv * zp;
+    } else {
+      double valv[AL_MAXSOC], zev[AL_MAXSOC], zpv[AL_MAXSOC], pv[AL_MAXSOC];
+      md_gather4(val, valv);
+      md_gather4(ze, zev);
+      soc_projection<double>(p, zev, zpv);
+      soc_projection<double>(p, valv, pv);
+      double sq = 0.0;
+#pragma unroll
+      for (int r = 0; r < AL_MAXSOC; ++r)
+        if (r < p) { sq += zpv[r] * zpv[r]; viol = fmax(viol, fabs(pv[r] - valv[r])); }
+      if (j == 0) cost += sq / (2.0 * rho_est);
+      double Jc[AL_MAXSOC * AL_MAXSOC];
+      soc_jacobian<double>(p, zev, Jc);
+#pragma unroll
+      for (int r = 0; r < AL_MAXSOC; ++r) {
+        double sj = 0.0;
+#pragma unroll
+        for (int q = 0; q < AL_MAXSOC; ++q) sj += Jc[q + r * AL_MAXSOC] * zpv[q];     // (J^T z_proj)_r
+        if (r < p && j == r) jvr[c] = sj;
+      }
+    }
+  }
+}
+__device__ __forceinline__ double alp_col(const AlpKnot& s, int j, const double (&jvr)[AL_MAXC], const double* Gp) {
+  double sum = 0.0;
+#pragma unroll
+  for (int c = 0; c < AL_MAXC; ++c) {
+    if (c >= s.ncon) continue;
+    const double* Gc = Gp + s.gp_off[c] + j;
+    double cC[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) cC[i] = Gc[i * AL_GP_LD];
+    md_chain8(sum, jvr[c], cC);
+  }
+  return sum;
+}
+
 }  // namespace altro_hip
 #include "ilqr_tile_model.hip"   // nonlinear device models in this layout: tile_model_step (uses the DPP blocks above)
 namespace altro_hip {
@@ -309,7 +406,7 @@ __global__ __launch_bounds__(64, ((MK != 0 || (AL && DENSE && sizeof(S) == 8)) ?
   constexpr int IMG = DENSE ? MD_IMG_DENSE : MD_IMG;
   constexpr int CPE = DENSE ? MF_COST : MF_COSTP;   // elements of a knot point's cost record
   __shared__ double img[2][2][IMG];                 // [parity][slot]; after the sweep: the final sums (red, below)
-  __shared__ double Gpool[AL ? MD_GPOOL : 1];       // the constraint Jacobians, read at every knot point: kept here when they fit
+  extern __shared__ double Gdyn[];                  // AlTable::Gpad as doubles: the constraint Jacobians, read at every knot point (the launchers pass Gpad_count * 8 bytes)
   const int lane = threadIdx.x;
   const int npairs = (a.batch + 1) >> 1;
   const int pr = mf_problem(blockIdx.x, npairs);
@@ -355,11 +452,11 @@ __global__ __launch_bounds__(64, ((MK != 0 || (AL && DENSE && sizeof(S) == 8)) ?
   }
   constexpr bool al = AL;
   const double rho = al ? a.prob[b].rho : 1.0;
-  const double* Gl = nullptr;
-  if (al && a.al.G_count <= MD_GPOOL) {             // (the first barrier of the sweep below orders these stores before their readers)
-    for (int e = lane; e < a.al.G_count; e += 64) Gpool[e] = (double)a.al.G[e];
-    Gl = Gpool;
-  }
+  if (al)                                           // (the first barrier of the sweep below orders these stores before their readers)
+    for (int e = lane; e < a.al.Gpad_count; e += 64) Gdyn[e] = (double)a.al.Gpad[e];
+  const bool al_uni = al && a.al.uniform != 0;
+  const int rowb = (j < 8 ? j : 8) * AL_GP_LD;
+  AlpKnot kc_s, kn_s;                               // the table entries of the knot point in hand and of the next (scalar registers)
   const bool isx = j < 12;
   const bool cand = DUAL ? (h == 1 && wr) : row_on; // DUAL: trial 1 writes the candidate trajectory and the expansion
   const bool wqr = DUAL ? cand : (row_on && deriv && store);
@@ -386,7 +483,7 @@ __global__ __launch_bounds__(64, ((MK != 0 || (AL && DENSE && sizeof(S) == 8)) ?
   double J = 0.0, Jal = 0.0, dJ = 0.0, res = 0.0, viol = 0.0;   // (Jal: the constraint rows' cost shares, lanes 0..7)
   double jvr[AL_MAXC] = {0.0, 0.0};
   double zg[AL_MAXC][2] = {{0.0, 0.0}, {0.0, 0.0}};   // (z_i, g_i) of the knot point in hand
-  if (al) dpp_al_fetch<S>(a.al, 0, b, a.batch, j, zg);
+  if (al) { alp_knot<S>(a.al, 0, kc_s); kn_s = kc_s; alp_fetch<S>(a.al, kc_s, 0, b, a.batch, j, zg); }
   double lprev = 0.0, yprev = 0.0;                  // gradient and y of knot point k - 1 (the stationarity's lag)
   MeritPairRegs<DENSE> ring[DEPTH];
 #pragma unroll
@@ -428,15 +525,17 @@ __global__ __launch_bounds__(64, ((MK != 0 || (AL && DENSE && sizeof(S) == 8)) ?
       double Ja = 0.0, vv = 0.0;
       if (live) {
         double zgn[AL_MAXC][2];
-        dpp_al_fetch<S>(a.al, k + 1, b, a.batch, j, zgn);     // (k + 1 <= N: the terminal knot point's too)
-        dpp_al_rows<S, false, SOC>(a.al, kc, b, a.batch, w, false, rho, j, jvr, Ja, vv, false, Gl, zg);
+        if (k + 1 >= N) alp_knot<S>(a.al, N, kn_s);           // (k + 1 <= N: the terminal knot point's too)
+        else if (!al_uni) alp_knot<S>(a.al, k + 1, kn_s);
+        alp_fetch<S>(a.al, kn_s, (al_uni && k + 1 < N) ? (k + 1) * a.al.rows_per_knot : 0, b, a.batch, j, zgn);
+        alp_rows<SOC>(kc_s, w, rho, j, rowb, jvr, Ja, vv, Gdyn, zg);
 #pragma unroll
         for (int c = 0; c < AL_MAXC; ++c) { zg[c][0] = zgn[c][0]; zg[c][1] = zgn[c][1]; }
         Jal += Ja;
       } else {
-        dpp_al_rows<S, false, SOC>(a.al, kc, b, a.batch, w, false, rho, j, jvr, Ja, vv, false, Gl);   // a padding step: knot point N - 1 again, discarded
+        alp_rows<SOC>(kc_s, w, rho, j, rowb, jvr, Ja, vv, Gdyn, zg);   // a padding step: discarded
       }
-      if (cand) viol = fmax(viol, vv);
+      if (cand && live) viol = fmax(viol, vv);               // (live: a padding step's point is not on the trajectory)
     }
     // (2) the stationarity at knot point k - 1 now that y_k is known: column j of Z_(k-1) against y_k
     if (DUAL && kStat && live && k >= 1) {
@@ -500,7 +599,7 @@ __global__ __launch_bounds__(64, ((MK != 0 || (AL && DENSE && sizeof(S) == 8)) ?
       //  forms this gradient from its own loads, where it is)
       l = __builtin_fma(cq, w, cl);
     }
-    if (al) l -= dpp_al_col<S>(a.al, kc, j, jvr, Gl);
+    if (al) { l -= alp_col(kc_s, j, jvr, Gdyn); if (live) kc_s = kn_s; }
     if (live) dJ += l * dw;
     if (cand) {   // trial 1's candidate record x | y | u and its [lx lu]
       S* c = candb + (size_t)(live ? k : N) * a.xuy_ks;
@@ -539,10 +638,10 @@ __global__ __launch_bounds__(64, ((MK != 0 || (AL && DENSE && sizeof(S) == 8)) ?
     if (al) {
       double Ja = 0.0, vv = 0.0;
       if constexpr (DUAL) {
-        dpp_al_rows<S, false, SOC>(a.al, N, b, a.batch, isx ? x : 0.0, true, rho, j, jvr, Ja, vv, false, Gl, zg);
+        alp_rows<SOC>(kc_s, isx ? x : 0.0, rho, j, rowb, jvr, Ja, vv, Gdyn, zg);
         Jal += Ja;
       } else {   // (wave_merit_kernel adds the terminal blocks' shares to its running sum one by one)
-        dpp_al_rows<S, false, SOC>(a.al, N, b, a.batch, isx ? x : 0.0, true, rho, j, jvr, Jal, vv, false, Gl, zg);
+        alp_rows<SOC>(kc_s, isx ? x : 0.0, rho, j, rowb, jvr, Jal, vv, Gdyn, zg);
       }
       if (cand) viol = fmax(viol, vv);
     }
@@ -553,7 +652,7 @@ __global__ __launch_bounds__(64, ((MK != 0 || (AL && DENSE && sizeof(S) == 8)) ?
     md_rows12(sacc, unused, dxN, dxda, cP);
     const double yN = sacc + cP[12];
     double lx = DENSE ? gN + q : __builtin_fma(Qd, x, q);
-    if (al) lx -= dpp_al_col<S>(a.al, N, jr, jvr, Gl);
+    if (al) lx -= alp_col(kc_s, jr, jvr, Gdyn);
     if (isx) dJ += lx * dxda;
     if (cand) {
       if (isx) {

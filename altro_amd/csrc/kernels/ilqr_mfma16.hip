@@ -791,7 +791,7 @@ __global__ __launch_bounds__(64) void wave_merit2_kernel(IlqrWaveArgs<S> a) {
       double Ja = 0.0, vv = 0.0;
       wave_al_rows<S, 16>(a.al, kc, b, a.batch, &vec[h][0], &us[h][0], false, rho, r, jv[h], nullptr, nullptr, Ja, vv, false);
       if (live) Jal += Ja;
-      if (cand) viol = fmax(viol, vv);
+      if (cand && live) viol = fmax(viol, vv);   // (live: a padding step's point is not on the trajectory)
     }
     __syncthreads();
     if (r < 16) {   // lx (r 0..11) and lu (r 12..15) with the AL terms; dphi

@@ -299,3 +299,24 @@ def test_dpp_dual_update_and_feasibility_are_bit_identical_to_the_lds_form(which
         assert (a["dual_updates"] > 0).any()
         for k in ("status", "iterations", "dual_updates", "phi", "stationarity", "feasibility", "alpha", "penalty", "x", "u", "xc", "uc", "yc", "K", "d"):
             assert np.array_equal(a[k], b[k]), (dual, k)
+
+
+@pytest.mark.parametrize("N", [5, 6, 7, 9])
+def test_reported_feasibility_is_the_trajectorys_own(N):
+    """AltroStats::primal_feasibility of a solve (written by the two-trial pass for the accepted step) against the constraint
+    violation recomputed from the returned trajectory -- in particular for ODD horizons, where the sweep's padding step (the
+    horizon is walked two knot points per trip) evaluates knot point N - 1 a second time on a point that is not on the
+    trajectory: nothing of that step may reach the maximum."""
+    batch = 24
+    p = problems.ilqr12x4_problem(batch, N, True)
+    blocks = problems.ilqr12x4_constraint_blocks(N)
+    r = _solve(p, N, blocks, True, iterations_max=40, penalty_initial=1.0, penalty_scaling=10.0)
+    x, u = r["x"], r["u"]
+    viol = np.zeros(batch)
+    for (k0, k1, cone, G, g) in blocks:
+        for k in range(k0, k1 + 1):
+            w = np.concatenate([x[:, k], u[:, k] if k < N else np.zeros((batch, m))], axis=1)
+            c = w @ G.T - g
+            v = np.abs(c) if cone == altro_amd.CONE_EQUALITY else np.maximum(c, 0.0)
+            viol = np.maximum(viol, v.max(axis=1))
+    np.testing.assert_allclose(r["feasibility"], viol, rtol=1e-9, atol=1e-12)

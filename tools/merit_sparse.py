@@ -4,7 +4,7 @@ of problems that take part, in the row-layout (DPP) form and in the LDS form (a 
 bounds.  The late rounds of a constrained solve run for a handful of problems: their cost is one wave's dependent chain, and the
 form with the shorter chain wins there whatever it does at full batch.
 
-    python tools/merit_sparse.py [horizon]
+    python tools/merit_sparse.py [horizon] [batch,batch,...]
 """
 import os
 import sys
@@ -30,8 +30,9 @@ def med(f, reps=25):
 
 
 print(f"# tools/merit_sparse.py: one merit evaluation (phi only) with two input-bound blocks, N = {N}, (12, 4), fp64; median of 25, host clock, ms")
-print(f"{'problems':>9s} {'DPP form':>10s} {'LDS form':>10s} {'with derivative: DPP':>21s} {'LDS':>8s}")
-for batch in (2, 8, 32, 128, 512, 1024, 2048, 4096):
+print(f"{'problems':>9s} {'DPP form':>10s} {'LDS form':>10s} {'with derivative: DPP':>21s} {'LDS':>8s} {'no constraints: DPP':>20s} {'LDS':>8s}")
+BATCHES = [int(v) for v in sys.argv[2].split(',')] if len(sys.argv) > 2 else [2, 8, 32, 128, 512, 1024, 2048, 4096]
+for batch in BATCHES:
     one = problems.c1_double_integrator(1, N=N)
     bt = altro_amd.Batch(N, n, m, batch)
     bt.set_dynamics(one["A"][0, :1], one["B"][0, :1], None, k_stride_zero=True, batch_stride_zero=True)
@@ -49,6 +50,11 @@ for batch in (2, 8, 32, 128, 512, 1024, 2048, 4096):
         for form in ("1", "0"):
             os.environ["ALTRO_HIP_MERIT_DPP"] = form
             out.append(med(lambda: bt.merit(alpha, deriv)))
+    bt.clear_constraints()
+    bt.open_loop_rollout(); bt.accept(); bt.expand(); bt.backward()
+    for form in ("1", "0"):
+        os.environ["ALTRO_HIP_MERIT_DPP"] = form
+        out.append(med(lambda: bt.merit(alpha, False)))
     os.environ.pop("ALTRO_HIP_MERIT_DPP")
-    print(f"{batch:9d} {out[0]:10.3f} {out[1]:10.3f} {out[2]:21.3f} {out[3]:8.3f}", flush=True)
+    print(f"{batch:9d} {out[0]:10.3f} {out[1]:10.3f} {out[2]:21.3f} {out[3]:8.3f} {out[4]:20.3f} {out[5]:8.3f}", flush=True)
     bt.close()
