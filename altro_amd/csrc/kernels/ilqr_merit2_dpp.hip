@@ -835,24 +835,21 @@ __global__ __launch_bounds__(64) void wave_expand_dpp_kernel(IlqrWaveArgs<S> a) 
 #pragma unroll
   for (int r = 0; r < 16; ++r) tile[r] = 0.0;
   double scol = 0.0;
+  bool tile_counts = true;
 #pragma unroll
   for (int cidx = 0; cidx < AL_MAXC; ++cidx) {
     if (cidx >= kn.ncon) continue;
     const int p = kn.p[cidx], cone = kn.cone[cidx];
-    const S* G = a.al.G + kn.G_off[cidx];
+    // row min(j, 8) and column j of the block from the zero-padded pool (al_types.h: AL_GP_DEF; rows >= p are zero, and at the
+    // terminal knot point the input lanes of w are): no select per element
+    const S* Gp = a.al.Gpad + kn.Gp_off[cidx];
     const bool rl = j < p;
     const int jr = rl ? j : 0;
     double cG[16], cC[8];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const double ge = (double)G[jr + e * p];
-      cG[e] = (rl && !(terminal && e >= 12)) ? ge : 0.0;
-    }
+    for (int e = 0; e < 8; ++e) { const md_d2 v = md_ld<S>(Gp + (j < 8 ? j : 8) * AL_GP_LD, e); cG[2 * e] = v[0]; cG[2 * e + 1] = v[1]; }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const double gi = (double)G[(i < p ? i : 0) + j * p];
-      cC[i] = i < p ? gi : 0.0;
-    }
+    for (int i = 0; i < 8; ++i) cC[i] = (double)Gp[i * AL_GP_LD + j];
     double sacc = 0.0;
     md_chain16(sacc, w, cG);
     const double gi = rl ? (kn.g_per_problem[cidx] ? (double)a.al.g[kn.g_off[cidx] + (int64_t)jr * a.batch + b] : (double)a.al.g[kn.g_off[cidx] + jr]) : 0.0;
@@ -890,11 +887,28 @@ __global__ __launch_bounds__(64) void wave_expand_dpp_kernel(IlqrWaveArgs<S> a) 
       }
       if (grad) md_chain8(scol, jv, cC);
       if (hess) {
-        double mk[8], ai[8];
+        double mk[8];
         md_gather8(mkv, mk);
+        if (kn.sel[cidx] && tile_counts) {
+          // a bound-type block (every row of G is +-e_idx: AlKnot::sel): (J G)^T (J G) is diagonal, entry idx = the number of
+          // its rows that are active there -- the 128 multiply-adds below would add exactly these ones and zeros, one by one
+          // (tile_counts: the tile holds such counts only so far, so adding them in one go rounds nowhere)
+          double dsum = 0.0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) ai[i] = mk[i] * cC[i];      // (J G)_(i j): the projection's Jacobian is diagonal
-        md_outer_rows<0>(tile, ai);
+          for (int i = 0; i < 8; ++i)
+            if (i < p) {
+              const int sx = kn.sidx[cidx][i];
+              dsum += (j == (sx < 0 ? -sx : sx) - 1) ? mk[i] * mk[i] : 0.0;
+            }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) tile[r] += (r == j) ? dsum : 0.0;
+        } else {
+          double ai[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) ai[i] = mk[i] * cC[i];      // (J G)_(i j): the projection's Jacobian is diagonal
+          md_outer_rows<0>(tile, ai);
+          tile_counts = false;
+        }
       }
     } else {
       double valv[AL_MAXSOC], zev[AL_MAXSOC], zpv[AL_MAXSOC];
@@ -924,6 +938,7 @@ __global__ __launch_bounds__(64) void wave_expand_dpp_kernel(IlqrWaveArgs<S> a) 
           ai[i] = (i < p) ? jr2 : 0.0;
         }
         md_outer_rows<0>(tile, ai);
+        tile_counts = false;
         double Hp[AL_MAXSOC * AL_MAXSOC], hc[4];
         soc_hessian<double>(p, zev, zpv, Hp);
 #pragma unroll
