@@ -56,7 +56,7 @@ class SolveOptions(C.Structure):
                 ("use_backtracking_linesearch", C.c_int), ("penalty_initial", C.c_double),
                 ("penalty_scaling", C.c_double), ("penalty_max", C.c_double), ("reg_initial", C.c_double),
                 ("reg_retry_max", C.c_int), ("reg_scale", C.c_double), ("reg_min", C.c_double),
-                ("reg_max", C.c_double)]
+                ("reg_max", C.c_double), ("stop_when_running_at_most", C.c_int)]
 
 
 class SolveResult(C.Structure):
@@ -440,13 +440,15 @@ class Batch:
 
     def _solve_options(self, iterations_max=200, tol_stationarity=1e-4, tol_meritfun_gradient=1e-8,
                        use_backtracking=False, tol_primal_feasibility=1e-4, penalty_initial=1.0, penalty_scaling=10.0,
-                       penalty_max=1e8, reg_initial=0.0, reg_retry_max=0, reg_scale=10.0, reg_min=1e-6, reg_max=1e8):
+                       penalty_max=1e8, reg_initial=0.0, reg_retry_max=0, reg_scale=10.0, reg_min=1e-6, reg_max=1e8,
+                       stop_when_running_at_most=0):
         o = SolveOptions()
         self.L.altro_hip_default_solve_options(C.byref(o))
         o.tol_primal_feasibility = tol_primal_feasibility
         o.penalty_initial, o.penalty_scaling, o.penalty_max = penalty_initial, penalty_scaling, penalty_max
         o.reg_initial, o.reg_retry_max, o.reg_scale = reg_initial, reg_retry_max, reg_scale
         o.reg_min, o.reg_max = reg_min, reg_max
+        o.stop_when_running_at_most = int(stop_when_running_at_most)
         o.iterations_max, o.tol_stationarity = iterations_max, tol_stationarity
         o.tol_meritfun_gradient, o.use_backtracking_linesearch = tol_meritfun_gradient, int(use_backtracking)
         return o

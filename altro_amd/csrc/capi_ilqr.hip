@@ -1060,7 +1060,8 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
   if (lane_plan) merit_split_prepare(h);
   bool fused_can = lane_plan && o.iterations_max > 0 && !h->spec_no_memory && h->merit_split == 1 &&
                    !(h->flags & ALTRO_HIP_LANE_FUSED) && h->model.kind != MODEL_USER &&   // (run-time models: sequenced loop)
-                   !h->cost_dense;   // (the one-launch kernel is instantiated for the diagonal cost: a dense one runs sequenced)
+                   !h->cost_dense &&   // (the one-launch kernel is instantiated for the diagonal cost: a dense one runs sequenced)
+                   o.stop_when_running_at_most <= 0;   // (the batch-level early return is the sequenced loop's)
   // POLICY: fused wherever the kernel exists.  Measured on MI355X (tools/solve_batches.py, profiles/r02p_solve_batches.txt;
   // bicycle + steering bound, N = 50, median wall ms fused / sequenced): backtracking search 5.5 / 7.4 at 256 problems,
   // 20 / 31 at 2048, 24 / 44 at 8192, 76 / 173 at 65536; cubic search 25 / 33, 28 / 61, 36 / 106, 99 / 316; pendulum, 8192
@@ -1224,6 +1225,7 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
   const bool run_ahead = nra == nullptr || std::atoi(nra) == 0;
   if (iter0 < o.iterations_max)   // the one memset of the solve: every slot but the one-launch kernel's starts from zero
     HIP_TRY(hipMemsetAsync(h->i_counters + 8, 0, (size_t)(kCounterSlots - 1) * 8 * sizeof(int), h->stream));
+  const int stop_at = o.stop_when_running_at_most > 0 ? o.stop_when_running_at_most : 0;
   int pend_finish = -1;          // slot of the previous sweep's ILK_FINISH_ITER whose count has not been read yet
   bool multi_sweep = false;      // a second sweep was needed: from now on the next sweep's head is enqueued ahead
   int rounds_last = 0;           // line-search rounds the previous sweep needed (beyond the dual / first evaluation)
@@ -1409,14 +1411,14 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
     }
     // how many problems still run: read now -- or, once the solve has shown that it takes several sweeps, after the next sweep's
     // head has been enqueued
-    if (run_ahead && multi_sweep && iter + 1 < o.iterations_max) {
+    if (run_ahead && multi_sweep && iter + 1 < o.iterations_max && stop_at == 0) {
       pend_finish = fin;
       continue;
     }
     int still = 0;
     if ((rc = verdict(fin, 1, &still))) return rc;
     ++sweeps;
-    if (still == 0) break;
+    if (still <= stop_at) break;   // (stop_at = 0: nobody runs any more; > 0: altro_hip_solve_options::stop_when_running_at_most)
     running = still;
     multi_sweep = true;
   }
@@ -1449,6 +1451,7 @@ void altro_hip_default_solve_options(altro_hip_solve_options* o) {
   o->reg_scale = 10.0;
   o->reg_min = 1e-6;
   o->reg_max = 1e8;
+  o->stop_when_running_at_most = 0;   // (extension: every problem to its own end)
 }
 int altro_hip_last_solve_counts(const altro_hip_batch* h, int* sweeps, int* merit_launches) {
   if (!h) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "null handle");

@@ -3,7 +3,10 @@
 (position, velocity, acceleration per axis; jerk inputs) follow a moving set-point under input bounds.  Dynamics are
 given as data (the reference's SetLinearDynamics path), so the whole AL-iLQR loop runs on the matrix-core plan MFMA16.
 
-    python examples/batched_linear_mpc_12x4.py [batch] [steps]
+    python examples/batched_linear_mpc_12x4.py [batch] [steps] [stop-when-running-at-most]
+
+The third argument is altro_hip_solve_options::stop_when_running_at_most (default 0 = every problem to its own end, like the
+reference): a batched call lasts as long as its slowest problem, and here 99.9 % of the systems need one sweep per step.
 """
 import os
 import sys
@@ -22,6 +25,7 @@ BACKTRACK = bool(int(os.environ.get("BACKTRACK", "1")))
 def main():
     batch = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+    stop_at = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     N, n, m, h = 40, 12, 4, 0.05
     I4, Z4 = np.eye(4), np.zeros((4, 4))
     A = np.block([[I4, h * I4, 0.5 * h * h * I4], [Z4, I4, h * I4], [Z4, Z4, I4]])
@@ -47,20 +51,21 @@ def main():
     t_solve = 0.0
     for t in range(steps):
         t0 = time.perf_counter()
-        res = bt.ilqr_solve(iterations_max=60, use_backtracking=BACKTRACK)
+        res = bt.ilqr_solve(iterations_max=60, use_backtracking=BACKTRACK, stop_when_running_at_most=stop_at)
         t_solve += time.perf_counter() - t0
         _, u = bt.get_knot(0)
         x = x @ A.T + u @ B.T                                                    # the plant: the same linear model
         if t % 10 == 0 or t == steps - 1:
             err = np.linalg.norm(x[:, :4] - goal((t + 1) * h)[:4], axis=1)
-            print("step %3d: %5d/%d converged, mean iterations %.2f, max |u| %.3f, position error mean %.3e"
-                  % (t, int((res["status"] == 0).sum()), batch, res["iterations"].mean(), np.abs(u).max(), err.mean()))
+            print("step %3d: %5d/%d converged, iterations mean %.2f max %d (%d sweeps, %d merit launches), max |u| %.3f, position error mean %.3e"
+                  % (t, int((res["status"] == 0).sum()), batch, res["iterations"].mean(), res["iterations"].max(), res["sweeps"],
+                     res["merit_launches"], np.abs(u).max(), err.mean()))
         xr = np.stack([goal((t + 1 + k) * h) for k in range(N + 1)])             # the set-point moves on
         bt.update_linear_costs(-(Qd * xr)[None], None, (0.5 * (Qd * xr * xr).sum(1))[None], 0, N, batch_stride_zero=True)
         bt.set_initial_state(x)
         bt.shift_trajectory()
-    print("%d MPC steps x %d systems (n=12, m=4, N=%d): %.2f ms per step in the solver (%.0f solves/s)"
-          % (steps, batch, N, t_solve / steps * 1e3, steps * batch / t_solve))
+    print("%d MPC steps x %d systems (n=12, m=4, N=%d%s): %.2f ms per step in the solver (%.0f solves/s)"
+          % (steps, batch, N, ", return when <= %d still run" % stop_at if stop_at else "", t_solve / steps * 1e3, steps * batch / t_solve))
 
 
 if __name__ == "__main__":

@@ -292,6 +292,13 @@ typedef struct altro_hip_solve_options { /* AltroOptions, solver_options.hpp:16-
   double reg_initial;
   int reg_retry_max;
   double reg_scale, reg_min, reg_max;
+  /* EXTENSION beyond the reference, for batches: a batched solve lasts as long as its slowest problem (the reference solves one
+   * problem per call and has no such notion).  With stop_when_running_at_most = k > 0 the call returns after the first sweep
+   * that leaves at most k problems running; those keep their latest accepted iterate and report status 1 (Unsolved) with the
+   * iterations they took.  Every problem that stopped on its own is untouched by this: its result is bit for bit the one of
+   * the full solve.  Honoured by the launch-sequenced loop (plans MFMA16 and GENERIC; plan LANE runs that loop instead of its
+   * one-launch kernel when k > 0).  Default 0: solve every problem to its own end, like the reference.                        */
+  int stop_when_running_at_most;
 } altro_hip_solve_options;
 typedef struct altro_hip_solve_result { /* AltroStats per problem, solver_stats.hpp:14-25 */
   int status;     /* SolveStatus: 0 Success, 1 Unsolved, 2 MaxIterations (typedefs.hpp:19-27)        */

@@ -461,3 +461,41 @@ def test_bench_constrained_workload_sample_vs_oracle():
             np.testing.assert_allclose(ud[0], so.get("u"), rtol=1e-6, atol=1e-6)
             ref_phi = log2[i_first - 2][2]          # (the log holds one row per sweep run: i_first - 1 of them)
             assert abs(rd["phi"][0] - ref_phi) <= 1e-10 * max(1.0, abs(ref_phi)), (b, rd["phi"][0], ref_phi)
+
+
+def test_batch_level_early_return_leaves_finished_problems_untouched():
+    """altro_hip_solve_options::stop_when_running_at_most (an extension for batches: the call returns after the first sweep that
+    leaves at most k problems running).  512 input-bounded (12, 4) problems, N = 64: the early return takes fewer sweeps; every
+    problem that stopped on its own reports bit for bit what the full solve reports (per-problem iterations are independent of the
+    batch); the problems cut off report status 1 (Unsolved) with the iterations they took, and there are at most k of them more
+    than in the full solve."""
+    batch, Nf, k_stop = 512, 64, 12
+    x0 = 2.0 * problems.uniform01((batch, 12), 77) - 1.0
+    one = problems.c1_double_integrator(1, N=Nf)
+
+    def solve(**kw):
+        bt = altro_amd.Batch(Nf, 12, 4, batch)
+        bt.set_dynamics(one["A"][0, :1], one["B"][0, :1], None, k_stride_zero=True, batch_stride_zero=True)
+        bt.set_tracking_cost(np.stack([np.ones(12), 100.0 * np.ones(12)]), np.full((1, 4), 1e-2), np.zeros((2, 12)), np.zeros((1, 4)),
+                             k_stride_zero=True, batch_stride_zero=True)
+        bt.set_initial_state(x0)
+        bt.set_input_guess(np.zeros((1, 1, 4)), k_stride_zero=True, batch_stride_zero=True)
+        Gb = np.zeros((8, 16)); Gb[:4, 12:] = np.eye(4); Gb[4:, 12:] = -np.eye(4)
+        bt.add_linear_constraint(0, Nf - 1, altro_amd.CONE_INEQUALITY, Gb, np.full(8, 4.0))
+        res = bt.ilqr_solve(iterations_max=40, **kw)
+        x, u = bt.get_nominal()
+        bt.close()
+        return res, x, u
+
+    full, xf, uf = solve()
+    early, xe, ue = solve(stop_when_running_at_most=k_stop)
+    assert early["sweeps"] < full["sweeps"], (early["sweeps"], full["sweeps"])
+    done = early["status"] == 0
+    assert done.sum() >= batch - k_stop - int((full["status"] != 0).sum())
+    assert np.array_equal(full["status"][done], early["status"][done])
+    for key in ("iterations", "stationarity", "feasibility", "phi", "alpha", "dual_updates"):
+        assert np.array_equal(full[key][done], early[key][done]), key
+    assert np.array_equal(xf[done], xe[done]) and np.array_equal(uf[done], ue[done])
+    cut = ~done & (full["status"] == 0)
+    assert cut.sum() <= k_stop and (early["status"][cut] == 1).all()
+    assert (early["iterations"][cut] <= early["sweeps"]).all() and (early["iterations"][cut] >= 1).all()
