@@ -550,6 +550,27 @@ def other_config_entry(key, device, steps, torch, cpu_seconds=2.0):
         out["full_solve"] = {"ms": t_solve * 1e3, "sweeps": int(res["sweeps"]), "converged": int((res["status"] == 0).sum()),
                              "mean_iterations": float(res["iterations"].mean())}
     bt.close()
+    if cfg != "c4" and batch <= 8192:
+        # What bit-identity with the CPU path costs at this latency-bound size: the same sweeps with ALTRO_HIP_LANE_FUSED (the kernels
+        # may contract a * b + c into one FMA: 1e-12 relative instead of bit-identical; an opt-in flag of altro_hip_batch_create, NOT
+        # what the numbers above ran)
+        bf, _ = make_lane_batch(cfg, batch, 0, N, device, lane_fused=True)
+        for _ in range(3):
+            bf.sweep()
+        bf.profile(2)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(steps):
+            bf.sweep()
+        torch.cuda.synchronize()
+        el2 = time.perf_counter() - t2
+        nl0, ms0, name0 = bf.profile_get(0)
+        nl1, ms1, name1 = bf.profile_get(1)
+        bf.profile(0)
+        bf.close()
+        out["fma_contracted_variant"] = {"flag": "ALTRO_HIP_LANE_FUSED (opt-in; not bit-identical to the CPU path: 1e-12 relative)",
+                                         "ms_per_step": el2 / steps * 1e3, name0: {"avg_ms": ms0 / max(nl0, 1)}, name1: {"avg_ms": ms1 / max(nl1, 1)},
+                                         "backward_frac": bytes_b / (ms0 / max(nl0, 1) * 1e-3) / 8e12}
     if cpu_seconds > 0:
         out["cpu_baseline"] = cpu_sweep_rate(N, n, m, cpu_seconds, " (the GPU line: fp32)" if cfg == "c4" else "")
         out["vs_cpu_single_thread"] = out["value"] / out["cpu_baseline"]["value"]
