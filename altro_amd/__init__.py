@@ -22,7 +22,7 @@ TVLQR_SUCCESS = -1
 # every symbol include/altro_hip/altro_hip.h declares (tests check the .so exports all of them)
 C_ABI_SYMBOLS = [
     "altro_hip_version", "altro_hip_last_error", "altro_hip_device_count", "altro_hip_device_info", "altro_hip_device_pci_bus_id",
-    "altro_hip_batch_create", "altro_hip_batch_destroy", "altro_hip_batch_plan",
+    "altro_hip_batch_create", "altro_hip_batch_create_dims", "altro_hip_batch_destroy", "altro_hip_batch_plan",
     "altro_hip_batch_device_bytes", "altro_hip_set_dynamics", "altro_hip_set_cost",
     "altro_hip_set_initial_state", "altro_hip_set_host_batch", "altro_hip_backward", "altro_hip_forward_ltv", "altro_hip_sweep",
     "altro_hip_synchronize", "altro_hip_get_K", "altro_hip_get_d", "altro_hip_get_P",
@@ -130,6 +130,7 @@ def lib():
         L.altro_hip_device_info.argtypes = [i, C.c_char_p, i, C.POINTER(i), C.POINTER(i)]
         L.altro_hip_device_pci_bus_id.argtypes = [i, C.c_char_p, i]
         L.altro_hip_batch_create.argtypes = [C.POINTER(vp), i, i, i, i, i, i, C.c_uint, i, vp]
+        L.altro_hip_batch_create_dims.argtypes = [C.POINTER(vp), i, vp, vp, i, i, C.c_uint, i, vp]
         L.altro_hip_batch_destroy.argtypes = [vp]
         L.altro_hip_batch_destroy.restype = None
         L.altro_hip_batch_plan.argtypes = [vp]
@@ -236,6 +237,26 @@ class Batch:
                                              device, stream))
         self.plan = self.L.altro_hip_batch_plan(self.h)
 
+    @classmethod
+    def with_dims(cls, nx, nu, batch, dtype=F64, flags=0, device=0, stream=None):
+        """altro_hip_batch_create_dims: per-knot-point dimensions nx[0..N], nu[0..N-1] (plan GENERIC, TVLQR sweeps).  Bulk arrays
+        are flat per problem, [batch, sum_k block_k]; `get` returns them like that (split with `offsets`)."""
+        self = cls.__new__(cls)
+        self.L = lib()
+        self.nx = np.ascontiguousarray(nx, dtype=np.int32); self.nu = np.ascontiguousarray(nu, dtype=np.int32)
+        self.N, self.n, self.m, self.batch = len(self.nu), int(self.nx.max()), int(self.nu.max()), batch
+        assert len(self.nx) == self.N + 1
+        self.h = C.c_void_p()
+        _check(self.L.altro_hip_batch_create_dims(C.byref(self.h), self.N, self.nx.ctypes.data_as(C.c_void_p),
+                                                  self.nu.ctypes.data_as(C.c_void_p), batch, dtype, flags, device, stream))
+        self.plan = self.L.altro_hip_batch_plan(self.h)
+        return self
+
+    def _ragged_len(self, name):
+        nx, nu, N = self.nx.astype(np.int64), self.nu.astype(np.int64), self.N
+        return {"K": int((nu * nx[:N]).sum()), "d": int(nu.sum()), "P": int((nx * nx).sum()), "p": int(nx.sum()),
+                "x": int(nx.sum()), "u": int(nu.sum()), "y": int(nx.sum())}[name]
+
     def set_pointer_mode(self, device_pointers):
         """device_pointers=True: the bulk arrays handed to the raw C entry points are device pointers (see
         altro_hip.h).  The numpy-based helpers of this class always pass host arrays; use `self.L` + `self.h` with
@@ -287,6 +308,8 @@ class Batch:
                  "qblocks": (B, N, n * n + m * m + m * n + n + m)}
         if name == "status":
             out = np.zeros(B, dtype=np.int32)
+        elif getattr(self, "nx", None) is not None and name in ("K", "d", "P", "p", "x", "u", "y"):
+            out = np.zeros((B, self._ragged_len(name)), dtype=np.float64)
         else:
             out = np.zeros(shape[name], dtype=np.float64)
         _check(getattr(self.L, "altro_hip_get_" + name)(self.h, out.ctypes.data_as(C.c_void_p)))

@@ -75,8 +75,9 @@ int altro_hip_device_pci_bus_id(int device, char* buf, int cap) {
   return 0;
 }
 
-int altro_hip_batch_create(altro_hip_batch** out, int N, int n, int m, int batch, int dtype, int plan,
-                           unsigned flags, int device, void* stream) {
+// (nx_k, nu_k: per-knot-point dimensions -- altro_hip_batch_create_dims -- or null for the uniform n, m)
+static int batch_create_impl(altro_hip_batch** out, int N, int n, int m, int batch, int dtype, int plan,
+                             unsigned flags, int device, void* stream, const int* nx_k, const int* nu_k) {
   if (!out) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "out == NULL");
   *out = nullptr;
   if (N <= 0 || n <= 0 || m <= 0 || batch <= 0)
@@ -103,6 +104,7 @@ int altro_hip_batch_create(altro_hip_batch** out, int N, int n, int m, int batch
   altro_hip_batch* h = new altro_hip_batch();
   h->N = N; h->n = n; h->m = m; h->batch = batch; h->dtype = dtype; h->plan = plan;
   h->flags = flags; h->device = device;
+  if (nx_k) { h->ragged = true; h->nxv.assign(nx_k, nx_k + N + 1); h->nuv.assign(nu_k, nu_k + N); }
   h->esz = dtype == ALTRO_HIP_F64 ? 8 : 4;
   if (stream) { h->stream = (hipStream_t)stream; }
   else {
@@ -160,24 +162,31 @@ int altro_hip_batch_create(altro_hip_batch** out, int N, int n, int m, int batch
     if (!rc && hipMemsetAsync(h->l_xuy, 0, B * (N + 1) * z.e_xuy * E, h->stream) != hipSuccess) rc = fail(ALTRO_HIP_ERR_HIP, "memset failed");
     if (!rc && hipMemsetAsync(h->l_cost, 0, B * (N + 1) * (2 * n + 2 * m + 1) * E, h->stream) != hipSuccess) rc = fail(ALTRO_HIP_ERR_HIP, "memset failed");
   } else {
-    const int blk[G_NUM] = {n * n, n * m, n, n * n, m * m, m * n, n, m, m * n, m, n * n, n,
-                            n * n, m * m, m * n, n, m, n * n, m * m, m * n, n, m, n, m, n};
+    // block sizes of knot point k (tvlqr.cpp:92-121: A_k is nx[k+1] x nx[k], B_k nx[k+1] x nu[k], K_k nu[k] x nx[k], ...)
+    std::vector<int> nx(N + 1, n), nu(N + 1, m);
+    if (h->ragged) { nx = h->nxv; for (int k = 0; k < N; ++k) nu[k] = h->nuv[k]; }
+    auto blk_at = [&](int a, int k) -> int {
+      const int nk = nx[k], mk = nu[k], n2 = nx[k < N ? k + 1 : N];
+      const int v[G_NUM] = {n2 * nk, n2 * mk, n2, nk * nk, mk * mk, mk * nk, nk, mk, mk * nk, mk, nk * nk, nk,
+                            nk * nk, mk * mk, mk * nk, nk, mk, nk * nk, mk * mk, mk * nk, nk, mk, nk, mk, nk};
+      return v[a];
+    };
     const int nks[G_NUM] = {N, N, N, N + 1, N, N, N + 1, N, N, N, N + 1, N + 1,
                             N, N, N, N, N, N, N, N, N, N, N + 1, N, N + 1};
     std::vector<int64_t> off((size_t)(N + 1) * G_NUM, 0);
     for (int a = 0; a < G_NUM; ++a) {
       const bool qb = (a >= G_Qxx && a <= G_Qu);
       if (a >= G_Qxx_tmp && a <= G_Qu_tmp) continue;   // scratch blocks: only the tvlqr_* drop-in keeps them
-      h->g_bstride[a] = (int64_t)nks[a] * blk[a];
-      for (int k = 0; k <= N; ++k) off[(size_t)k * G_NUM + a] = (int64_t)k * blk[a];
+      int64_t at = 0;
+      for (int k = 0; k <= N; ++k) { off[(size_t)k * G_NUM + a] = at; if (k < nks[a]) at += blk_at(a, k); }
+      h->g_bstride[a] = at;
       if (qb && !(flags & ALTRO_HIP_STORE_QBLOCKS)) continue;
-      ALLOC(h->g_arr[a], B * nks[a] * blk[a] * E);
+      ALLOC(h->g_arr[a], B * (size_t)at * E);
     }
     ALLOC(h->g_off, off.size() * sizeof(int64_t));
     ALLOC(h->g_nx, (size_t)(N + 1) * sizeof(int));
     ALLOC(h->g_nu, (size_t)(N + 1) * sizeof(int));
     if (!rc) {
-      std::vector<int> nx(N + 1, n), nu(N + 1, m);
       if (hipMemcpy(h->g_off, off.data(), off.size() * sizeof(int64_t), hipMemcpyHostToDevice) != hipSuccess ||
           hipMemcpy(h->g_nx, nx.data(), nx.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
           hipMemcpy(h->g_nu, nu.data(), nu.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
@@ -214,6 +223,28 @@ int altro_hip_batch_create(altro_hip_batch** out, int N, int n, int m, int batch
   }
   *out = h;
   return 0;
+}
+
+int altro_hip_batch_create(altro_hip_batch** out, int N, int n, int m, int batch, int dtype, int plan,
+                           unsigned flags, int device, void* stream) {
+  return batch_create_impl(out, N, n, m, batch, dtype, plan, flags, device, stream, nullptr, nullptr);
+}
+
+int altro_hip_batch_create_dims(altro_hip_batch** out, int N, const int* nx, const int* nu, int batch, int dtype,
+                                unsigned flags, int device, void* stream) {
+  if (!out) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "out == NULL");
+  *out = nullptr;
+  if (N <= 0 || !nx || !nu) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "N must be positive, nx and nu non-null");
+  int nmax = 0, mmax = 0;
+  for (int k = 0; k <= N; ++k) {
+    if (nx[k] <= 0 || nx[k] > 32) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "nx[%d] = %d outside [1, 32]", k, nx[k]);
+    nmax = std::max(nmax, nx[k]);
+    if (k < N) {
+      if (nu[k] <= 0 || nu[k] > 32) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "nu[%d] = %d outside [1, 32]", k, nu[k]);
+      mmax = std::max(mmax, nu[k]);
+    }
+  }
+  return batch_create_impl(out, N, nmax, mmax, batch, dtype, ALTRO_HIP_PLAN_GENERIC, flags, device, stream, nx, nu);
 }
 
 void altro_hip_batch_destroy(altro_hip_batch* h) {
@@ -272,6 +303,16 @@ int altro_hip_set_dynamics(altro_hip_batch* h, const double* A, const double* B,
     rc = pk(A, n * n, 0);
     if (!rc) rc = pk(B, n * m, n * n);
     if (!rc) rc = pk(f, n, n * n + n * m);
+  } else if (h->ragged) {   // per-knot-point dimensions: the caller's packed [b][k][block_k] IS the device layout, one block per problem
+    if (kz) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "k_stride_zero needs uniform dimensions");
+    auto whole = [&](int arr, const double* src) -> int {
+      if (!src) { HIP_TRY(hipMemsetAsync(h->g_arr[arr], 0, (size_t)h->batch * h->g_bstride[arr] * h->esz, h->stream)); return 0; }
+      return h->dtype == ALTRO_HIP_F64 ? generic_set<double>(h, arr, src, (int)h->g_bstride[arr], 1, 0, bz)
+                                       : generic_set<float>(h, arr, src, (int)h->g_bstride[arr], 1, 0, bz);
+    };
+    rc = whole(G_A, A);
+    if (!rc) rc = whole(G_B, B);
+    if (!rc) rc = whole(G_f, f);
   } else if (h->dtype == ALTRO_HIP_F64) {
     rc = generic_set<double>(h, G_A, A, n * n, N, kz, bz);
     if (!rc) rc = generic_set<double>(h, G_B, B, n * m, N, kz, bz);
@@ -341,6 +382,30 @@ int altro_hip_set_cost(altro_hip_batch* h, const double* Q, const double* R, con
     if (!rc) rc = pk(h->l_in, z.e_in, r, m, or_, 0, N, 0, nkR);
     if (!rc) rc = pk(h->l_term, z.e_term, Q, d.Q(is_diag), 0, is_diag ? n : 0, 1, kt, nkQ, kz ? d.Q(is_diag) : 0);
     if (!rc) rc = pk(h->l_term, z.e_term, q, n, n * n, 0, 1, kt, nkQ, kz ? n : 0);
+  } else if (h->ragged) {   // per-knot-point dimensions: every array moves as one packed block per problem
+    if (kz) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "k_stride_zero needs uniform dimensions");
+    {   // where Q_k / R_k start: n_k (m_k) entries for a diagonal cost, n_k^2 (m_k^2) for a dense one, packed in the allocated blocks
+      std::vector<int64_t> off((size_t)(N + 1) * G_NUM);
+      HIP_TRY(hipMemcpy(off.data(), h->g_off, off.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+      int64_t aq = 0, ar = 0;
+      for (int k = 0; k <= N; ++k) {
+        off[(size_t)k * G_NUM + G_Q] = aq; off[(size_t)k * G_NUM + G_R] = ar;
+        aq += is_diag ? h->nxv[k] : h->nxv[k] * h->nxv[k];
+        if (k < N) ar += is_diag ? h->nuv[k] : h->nuv[k] * h->nuv[k];
+      }
+      h->g_bstride[G_Q] = aq; h->g_bstride[G_R] = ar;
+      HIP_TRY(hipMemcpy(h->g_off, off.data(), off.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    }
+    auto whole = [&](int arr, const double* src) -> int {
+      if (!src) { HIP_TRY(hipMemsetAsync(h->g_arr[arr], 0, (size_t)h->batch * h->g_bstride[arr] * h->esz, h->stream)); return 0; }
+      return h->dtype == ALTRO_HIP_F64 ? generic_set<double>(h, arr, src, (int)h->g_bstride[arr], 1, 0, bz)
+                                       : generic_set<float>(h, arr, src, (int)h->g_bstride[arr], 1, 0, bz);
+    };
+    rc = whole(G_Q, Q);
+    if (!rc) rc = whole(G_q, q);
+    if (!rc) rc = whole(G_R, R);
+    if (!rc) rc = whole(G_H, is_diag ? nullptr : H);
+    if (!rc) rc = whole(G_r, r);
   } else {
     auto set = [&](int arr, const double* src, int blk, int nk, int k0, int nk_host, int src_off = 0) -> int {
       if (!src) {
@@ -392,18 +457,19 @@ int altro_hip_set_initial_state(altro_hip_batch* h, const double* x0, int bz) {
   if (rc) return rc;
   h->expansion_current = false;
   if (!x0) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "x0 == NULL");
+  const int n0 = h->ragged ? h->nxv[0] : h->n;   // (per-knot-point dimensions: x0 has nx[0] entries per problem)
   auto consume = [&](SrcArr s, int b0, int nb) -> int {
-    const int64_t total = (int64_t)nb * h->n;
+    const int64_t total = (int64_t)nb * n0;
     if (h->dtype == ALTRO_HIP_F64)
       hipLaunchKernelGGL(expand_copy_kernel<double>, dim3(grid_for(total)), dim3(256), 0, h->stream,
-                         (double*)h->x0, (int64_t)h->x0_stride, (int64_t)h->x0_stride, s, h->n, 1, b0, nb);
+                         (double*)h->x0, (int64_t)h->x0_stride, (int64_t)h->x0_stride, s, n0, 1, b0, nb);
     else
       hipLaunchKernelGGL(expand_copy_kernel<float>, dim3(grid_for(total)), dim3(256), 0, h->stream,
-                         (float*)h->x0, (int64_t)h->x0_stride, (int64_t)h->x0_stride, s, h->n, 1, b0, nb);
+                         (float*)h->x0, (int64_t)h->x0_stride, (int64_t)h->x0_stride, s, n0, 1, b0, nb);
     if (hipGetLastError() != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "x0 copy launch failed");
     return 0;
   };
-  rc = upload_chunks(h, x0, h->n, 1, 1, bz, -1, 0, consume);
+  rc = upload_chunks(h, x0, n0, 1, 1, bz, -1, 0, consume);
   if (!rc && h->plan == ALTRO_HIP_PLAN_LANE)
     rc = h->dtype == ALTRO_HIP_F64
              ? lane_pack<double>(h, (double*)h->l_x0, h->n, x0, h->n, 0, 0, 1, 0, 1, 1, bz)
@@ -435,6 +501,9 @@ int altro_hip_synchronize(altro_hip_batch* h) {
       return fail(ALTRO_HIP_ERR_NOT_SET, "nothing computed yet for get_" #NAME);                \
     if (h->plan == ALTRO_HIP_PLAN_MFMA16) return mfma16_get(h, MWHAT, dst, BLOCK, NK);          \
     if (h->plan == ALTRO_HIP_PLAN_LANE) return lane_get_any(h, MWHAT, dst);                     \
+    if (h->ragged) /* per-knot-point dimensions: the packed array of a problem as one block */   \
+      return h->dtype == ALTRO_HIP_F64 ? generic_get<double>(h, GARR, dst, (int)h->g_bstride[GARR], 1)   \
+                                       : generic_get<float>(h, GARR, dst, (int)h->g_bstride[GARR], 1);   \
     return h->dtype == ALTRO_HIP_F64 ? generic_get<double>(h, GARR, dst, BLOCK, NK)            \
                                      : generic_get<float>(h, GARR, dst, BLOCK, NK);            \
   }
@@ -480,6 +549,7 @@ int altro_hip_get_qblocks(altro_hip_batch* h, double* dst) {
   const int per = n * n + m * m + m * n + n + m;
   if (h->plan == ALTRO_HIP_PLAN_MFMA16) return mfma16_get(h, MGET_QBLK, dst, per, N);
   if (h->plan == ALTRO_HIP_PLAN_LANE) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "plan LANE does not store the Q-blocks");
+  if (h->ragged) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "altro_hip_get_qblocks interleaves uniform blocks; not available with per-knot-point dimensions");
   // generic: five separate reference-layout arrays -> interleave on the host
   std::vector<double> tmp((size_t)h->batch * N * n * n);
   const int arrs[5] = {G_Qxx, G_Quu, G_Qux, G_Qx, G_Qu};

@@ -343,7 +343,7 @@ int generic_cost(altro_hip_batch* h, const double* Q, const double* R, const dou
   return rc;
 }
 int ilqr_check(altro_hip_batch* h, bool need_guess) {
-  int rc = check(h);
+  int rc = loop_entry(h);
   if (rc) return rc;
   if (h->plan == ALTRO_HIP_PLAN_MFMA16) {   // dynamics are data (altro_hip_set_dynamics) or a device model of the tile plan
     if (!h->dyn_set && !h->model_set)
@@ -367,7 +367,7 @@ extern "C" {
 // ---- iLQR loop entry points -----------------------------------------------------------------------------
 int altro_hip_set_model(altro_hip_batch* h, int model, float timestep, int bicycle_frame,
                         double bicycle_length, double bicycle_lr) {
-  int rc = check(h);
+  int rc = loop_entry(h);
   if (rc) return rc;
   h->expansion_current = false;
   if (!(timestep > 0.0f)) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "time step must be positive (ErrorCodes::TimestepNotPositive)");
@@ -390,7 +390,7 @@ int altro_hip_set_tracking_cost(altro_hip_batch* h, const double* Qd, const doub
                                 const double* uref, int kz, int bz) {
   // ALTROSolver::SetLQRCost (altro_solver.cpp:138-172): q = -Q xref, r = -R uref,
   // c = 1/2 xref'Q xref (+ 1/2 uref'R uref for k < N) -> KnotPointData::SetDiagonalCost
-  int rc = check(h);
+  int rc = loop_entry(h);
   if (rc) return rc;
   h->expansion_current = false;
   if (h->plan != ALTRO_HIP_PLAN_LANE && h->plan != ALTRO_HIP_PLAN_MFMA16 && h->plan != ALTRO_HIP_PLAN_GENERIC)
@@ -509,7 +509,7 @@ int altro_hip_set_quadratic_cost(altro_hip_batch* h, const double* Q, const doub
   // ALTROSolver::SetQuadraticCost (altro_solver.cpp:118-136) -> KnotPointData::SetQuadraticCost (knotpoint_data.cpp:64-85) for the
   // device iLQR loop: the cost 1/2 x'Qx + 1/2 u'Ru + u'Hx + q'x + r'u + c per knot point, stored dense and evaluated as
   // CalcOriginalCost / Gradient / Hessian do (knotpoint_data.cpp:624-634, :659-668, :691-698).
-  int rc = check(h);
+  int rc = loop_entry(h);
   if (rc) return rc;
   h->expansion_current = false;
   if (!Q || !R || !H || !q || !r) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "Q, R, H, q, r are required (c may be NULL: zero)");
@@ -609,7 +609,7 @@ int altro_hip_set_quadratic_cost(altro_hip_batch* h, const double* Q, const doub
 
 int altro_hip_set_input_guess(altro_hip_batch* h, const double* u, int kz, int bz) {
   // ALTROSolver::SetInput (altro_solver.cpp:242-251): writes the CANDIDATE inputs u_
-  int rc = check(h);
+  int rc = loop_entry(h);
   if (rc) return rc;
   h->expansion_current = false;
   if (!u) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "u == NULL");
@@ -705,7 +705,7 @@ int altro_hip_update_linear_costs(altro_hip_batch* h, const double* q, const dou
                                   int k_first, int k_last, int kz, int bz) {
   // ALTROSolver::UpdateLinearCosts (altro_solver.cpp:266-281) -> KnotPointData::UpdateLinearCosts
   // (knotpoint_data.cpp:193-226) for knot points k_first..k_last (inclusive) of every problem
-  int rc = check(h);
+  int rc = loop_entry(h);
   if (rc) return rc;
   h->expansion_current = false;
   if (!h->lqr_cost_set) return fail(ALTRO_HIP_ERR_NOT_SET, "no quadratic cost to update (ErrorCodes::CostNotQuadratic)");
@@ -780,7 +780,7 @@ int altro_hip_update_linear_costs(altro_hip_batch* h, const double* q, const dou
 int altro_hip_get_knot(altro_hip_batch* h, int k, double* x, double* u) {
   // ALTROSolver::GetState / GetInput (altro_solver.cpp:323-347) of one knot point for the whole batch:
   // x [batch][n], u [batch][m] (u must be NULL at k = N)
-  int rc = check(h);
+  int rc = loop_entry(h);
   if (rc) return rc;
   const int n = h->n, m = h->m, N = h->N;
   if (k < 0 || k > N) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "knot point %d outside [0, %d] (ErrorCodes::BadIndex)", k, N);
@@ -828,7 +828,7 @@ int altro_hip_get_knot(altro_hip_batch* h, int k, double* x, double* u) {
 int altro_hip_add_linear_constraint(altro_hip_batch* h, int k_first, int k_last, int cone, int p, const double* G,
                                     const double* g, int g_per_problem) {
   // ALTROSolver::SetConstraint (altro_solver.cpp:175-215) for c(x,u) = G [x;u] - g
-  int rc = check(h);
+  int rc = loop_entry(h);
   if (rc) return rc;
   h->expansion_current = false;
   if (h->plan != ALTRO_HIP_PLAN_LANE && h->plan != ALTRO_HIP_PLAN_MFMA16)
@@ -859,7 +859,7 @@ int altro_hip_add_linear_constraint(altro_hip_batch* h, int k_first, int k_last,
 int altro_hip_add_user_constraint(altro_hip_batch* h, int k_first, int k_last, int cone, int p, int id) {
   // ALTROSolver::SetConstraint with a general callback pair (altro_solver.cpp:192-223): value and Jacobian of block `id` come
   // from the source given to altro_hip_set_model_source (altro_user_constraint / altro_user_constraint_jacobian)
-  int rc = check(h);
+  int rc = loop_entry(h);
   if (rc) return rc;
   if (h->plan != ALTRO_HIP_PLAN_LANE || h->model.kind != MODEL_USER || !h->rtc_has_constraints)
     return fail(ALTRO_HIP_ERR_NOT_SET, "altro_hip_set_model_source must come first, with a source that defines "
@@ -873,7 +873,7 @@ int altro_hip_add_user_constraint(altro_hip_batch* h, int k_first, int k_last, i
   return rc;
 }
 int altro_hip_clear_constraints(altro_hip_batch* h) {
-  int rc = check(h);
+  int rc = loop_entry(h);
   if (rc) return rc;
   h->expansion_current = false;
   h->al_defs.clear(); h->al_G.clear(); h->al_g.clear();
@@ -883,7 +883,7 @@ int altro_hip_clear_constraints(altro_hip_batch* h) {
 }
 int altro_hip_reset_duals(altro_hip_batch* h, double penalty) {
   // duals back to zero and every constraint's penalty to `penalty` (what a fresh Initialize leaves: 1)
-  int rc = check(h);
+  int rc = loop_entry(h);
   if (rc) return rc;
   h->expansion_current = false;
   if (h->plan != ALTRO_HIP_PLAN_LANE && h->plan != ALTRO_HIP_PLAN_MFMA16) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "constraints need plan LANE or MFMA16");
@@ -900,7 +900,7 @@ int altro_hip_reset_duals(altro_hip_batch* h, double penalty) {
 }
 int altro_hip_get_duals(altro_hip_batch* h, int k, int slot, double* z) {
   // duals of constraint block `slot` of knot point k, [batch][p]
-  int rc = check(h);
+  int rc = loop_entry(h);
   if (rc) return rc;
   if (h->plan != ALTRO_HIP_PLAN_LANE && h->plan != ALTRO_HIP_PLAN_MFMA16) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "constraints need plan LANE or MFMA16");
   if ((rc = al_upload(h))) return rc;
@@ -957,7 +957,7 @@ int altro_hip_ilqr_poll(altro_hip_batch* h, int* n_done, const altro_hip_poll_re
   return 0;
 }
 int altro_hip_ilqr_wait(altro_hip_batch* h, altro_hip_solve_result* results) {
-  int rc = check(h);
+  int rc = loop_entry(h);
   if (rc) return rc;
   if (!h->poll_host) return fail(ALTRO_HIP_ERR_NOT_SET, "altro_hip_ilqr_solve_async has not been called");
   HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1460,7 +1460,7 @@ int altro_hip_last_solve_counts(const altro_hip_batch* h, int* sweeps, int* meri
   return 0;
 }
 int altro_hip_get_nominal(altro_hip_batch* h, double* x, double* u) {
-  int rc = check(h);
+  int rc = loop_entry(h);
   if (rc) return rc;
   const int n = h->n, m = h->m, N = h->N;
   if (h->plan == ALTRO_HIP_PLAN_MFMA16) {
@@ -1500,7 +1500,7 @@ int altro_hip_get_nominal(altro_hip_batch* h, double* x, double* u) {
 }
 // Expansion the backward pass will consume: A | B | lx | lu (reference layout), for parity tests.
 int altro_hip_get_expansion(altro_hip_batch* h, double* A, double* B, double* lx, double* lu) {
-  int rc = check(h);
+  int rc = loop_entry(h);
   if (rc) return rc;
   const int n = h->n, m = h->m, N = h->N;
   if (h->plan == ALTRO_HIP_PLAN_MFMA16) {   // Z = [A B] rows of the DYN records, [lx lu] of the COST records, lx_N of TERM

@@ -62,6 +62,8 @@ struct altro_hip_batch {
   // plan GENERIC: reference layout on the device
   void* g_arr[G_NUM] = {};
   int64_t g_bstride[G_NUM] = {};
+  bool ragged = false;                       // per-knot-point dimensions (altro_hip_batch_create_dims): plan GENERIC, TVLQR sweeps only
+  std::vector<int> nxv, nuv;                 // nx[0..N], nu[0..N-1] of a ragged handle (n, m hold the maxima)
   int64_t* g_off = nullptr;
   int* g_nx = nullptr;
   int* g_nu = nullptr;
@@ -182,6 +184,16 @@ inline int check(altro_hip_batch* h) {
   if (!h) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "null handle");
   hipError_t e = hipSetDevice(h->device);
   if (e != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "hipSetDevice(%d): %s", h->device, hipGetErrorString(e));
+  return 0;
+}
+
+// entry of the iLQR-loop family of calls: a handle with per-knot-point dimensions serves the TVLQR sweeps only
+inline int loop_entry(altro_hip_batch* h) {
+  int rc = check(h);
+  if (rc) return rc;
+  if (h->ragged)
+    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "a handle with per-knot-point dimensions (altro_hip_batch_create_dims) serves altro_hip_backward / "
+                                           "_forward_ltv / _sweep and their setters and getters; the iLQR loop needs uniform dimensions");
   return 0;
 }
 

@@ -404,7 +404,7 @@ template int rtc_launch<float>(altro_hip_batch*, int, const IlqrArgs<float>&);
 extern "C" {
 
 int altro_hip_set_model_source(altro_hip_batch* h, const char* source, float timestep) {
-  int rc = check(h);
+  int rc = loop_entry(h);
   if (rc) return rc;
   h->expansion_current = false;
   if (!source) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "source == NULL");

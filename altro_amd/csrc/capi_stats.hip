@@ -122,7 +122,9 @@ int stats_local_launch(altro_hip_batch* h) {
   } else if (h->plan == ALTRO_HIP_PLAN_LANE) {     // [k][element][batch], elements x n | y n | u m
     a.xN = (const char*)h->l_xuy + (size_t)h->N * (2 * h->n + h->m) * h->batch * h->esz; a.x_bs = 1; a.x_is = h->batch;
   } else {                                         // reference layout [b][N+1][n]
-    a.xN = (const char*)h->g_arr[G_x] + (size_t)h->N * h->n * h->esz; a.x_bs = h->g_bstride[G_x]; a.x_is = 1;
+    const int64_t xN_at = h->ragged ? h->g_bstride[G_x] - h->nxv[h->N] : (int64_t)h->N * h->n;
+    if (h->ragged) a.n = h->nxv[h->N];
+    a.xN = (const char*)h->g_arr[G_x] + (size_t)xN_at * h->esz; a.x_bs = h->g_bstride[G_x]; a.x_is = 1;
   }
   const int nblk = std::min(kStatsBlocks, (h->batch + 255) / 256);
   if (h->dtype == ALTRO_HIP_F64)

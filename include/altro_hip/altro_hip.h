@@ -128,6 +128,14 @@ int altro_hip_device_pci_bus_id(int device, char* buf, int cap);
 /* `stream` is a hipStream_t (NULL = a stream owned by the handle).  `plan` is an altro_hip_plan. */
 int altro_hip_batch_create(altro_hip_batch** out, int horizon_N, int n, int m, int batch,
                            int dtype, int plan, unsigned flags, int device, void* stream);
+/* The same with PER-KNOT-POINT dimensions nx[0..N], nu[0..N-1] (ALTROSolver::SetDimension per range, altro_solver.cpp:26-47; the
+ * kernel boundary takes nx[k], nu[k] throughout, tvlqr.cpp:65-248: A_k is nx[k+1] x nx[k], B_k nx[k+1] x nu[k], K_k nu[k] x nx[k]).
+ * Plan GENERIC, every dimension in [1, 32].  Such a handle serves the TVLQR sweeps -- altro_hip_set_dynamics / _set_cost /
+ * _set_initial_state, altro_hip_backward / _forward_ltv / _sweep, the getters, the statistics -- with every bulk array packed
+ * [b][k][block_k] (block_k column-major with knot point k's own dimensions: the reference's per-knot-point blocks end to end);
+ * k_stride_zero is refused, batch_stride_zero works; the iLQR-loop calls need uniform dimensions and say so.                     */
+int altro_hip_batch_create_dims(altro_hip_batch** out, int horizon_N, const int* nx, const int* nu, int batch, int dtype,
+                                unsigned flags, int device, void* stream);
 void altro_hip_batch_destroy(altro_hip_batch* h);
 int altro_hip_batch_plan(const altro_hip_batch* h);         /* the plan actually chosen          */
 size_t altro_hip_batch_device_bytes(const altro_hip_batch* h);

@@ -7,7 +7,7 @@ CPP = os.path.join(ROOT, "tests", "cpp")
 LIBDIR = os.path.join(ROOT, "altro_amd", "lib")
 
 
-def build(name, extra_sources=()):
+def build(name, extra_sources=(), extra_link=()):
     src = os.path.join(CPP, name + ".cpp")
     out = os.path.join(CPP, name + ".bin")
     deps = [src, os.path.join(LIBDIR, "libaltro_hip.so")] + [os.path.join(ROOT, s) for s in extra_sources]
@@ -15,12 +15,12 @@ def build(name, extra_sources=()):
         return out
     cmd = ["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"), src] + \
           [os.path.join(ROOT, s) for s in extra_sources] + \
-          ["-L" + LIBDIR, "-laltro_hip", "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,$ORIGIN/../../altro_amd/lib", "-o", out]
+          ["-L" + LIBDIR, "-laltro_hip", "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,$ORIGIN/../../altro_amd/lib"] + list(extra_link) + ["-o", out]
     subprocess.check_call(cmd)
     return out
 
 
-def run(name, extra_sources=(), timeout=300):
-    exe = build(name, extra_sources)
+def run(name, extra_sources=(), timeout=300, extra_link=()):
+    exe = build(name, extra_sources, extra_link)
     p = subprocess.run([exe], capture_output=True, text=True, timeout=timeout)
     return p.returncode, p.stdout, p.stderr

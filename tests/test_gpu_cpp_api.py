@@ -21,6 +21,22 @@ def test_tvlqr_dropin_fast_path_equals_the_generic_path():
     assert rc == 0 and out.strip().endswith("OK"), out + err
 
 
+def test_tvlqr_dropin_per_knot_point_dimensions_match_the_oracle():
+    """tvlqr.cpp:65-248 takes nx[k], nu[k] per knot point; the reference's own tests pass uniform ones only.  A random problem with
+    a state dimension that shrinks 6 -> 2 along the horizon and an input dimension that changes every step (tests/cpp/
+    tvlqr_dropin_varying_test.cpp) through the device drop-in and through oracle/tvlqr_oracle.c on the same pointer tables: every
+    output array bit for bit, dense and diagonal cost, and the failure convention."""
+    import os
+    from oracle import oracle
+    oracle.lib()   # builds oracle/_build/liboracle.so when it is not there
+    libdir = os.path.dirname(oracle._LIB)
+    rc, out, err = cpp_build.run("tvlqr_dropin_varying_test",
+                                 extra_link=["-L" + libdir, "-l:" + os.path.basename(oracle._LIB), "-Wl,-rpath," + libdir])
+    print(out)
+    assert rc == 0 and out.strip().endswith("OK"), out + err
+    assert out.count("bit-identical") == 4
+
+
 def test_altro_solver_cpp_api_integration():
     """test/double_integrator_test.cpp + test/pendulum_test.cpp + test/altro_api.cpp re-authored against
     include/altro/altro.hpp: iteration counts 3 / 5 / 9, pendulum end state, error ladder."""
