@@ -116,6 +116,9 @@ int al_upload_typed(altro_hip_batch* h) {
   h->al_G_count = (int)G.size();
   h->al_has_soc = 0;
   for (const AlDef& d : defs) if (d.cone == CONE_SOC) h->al_has_soc = 1;
+  h->al_all_sel = 1;
+  for (const AlKnot& kn : knots)
+    for (int j = 0; j < kn.ncon; ++j) if (!kn.sel[j]) h->al_all_sel = 0;
   return 0;
 }
 int al_upload(altro_hip_batch* h) {
@@ -130,7 +133,7 @@ IlqrArgs<T> ilqr_args(altro_hip_batch* h, bool use_alpha, bool use_active, int w
   IlqrArgs<T> a;
   a.al.knots = h->al_d_knots; a.al.G = (const T*)h->al_d_G; a.al.g = (const T*)h->al_d_g;
   a.al.z = (T*)h->al_d_z; a.al.enabled = h->al_defs.empty() ? 0 : 1;
-  a.al.uniform = h->al_uniform; a.al.rows_per_knot = h->al_rows_per_knot; a.al.N = h->N; a.al.G_count = h->al_G_count; a.al.has_soc = h->al_has_soc; a.al.Gpad = (decltype(a.al.Gpad))h->al_d_Gpad; a.al.Gpad_count = h->al_Gpad_count;
+  a.al.uniform = h->al_uniform; a.al.rows_per_knot = h->al_rows_per_knot; a.al.N = h->N; a.al.G_count = h->al_G_count; a.al.has_soc = h->al_has_soc; a.al.all_sel = h->al_all_sel; a.al.Gpad = (decltype(a.al.Gpad))h->al_d_Gpad; a.al.Gpad_count = h->al_Gpad_count;
   a.mode = EXPAND_GRADIENT | EXPAND_HESSIAN;
   a.in = (T*)h->l_in; a.term = (T*)h->l_term; a.out = (const T*)h->l_out; a.outn = (const T*)h->l_outn;
   a.nom = (T*)h->l_nom; a.cand = (T*)h->l_xuy; a.x0 = (const T*)h->l_x0;
@@ -199,7 +202,7 @@ int wave_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int
   IlqrWaveArgs<S> a;
   a.al.knots = h->al_d_knots; a.al.G = (const S*)h->al_d_G; a.al.g = (const S*)h->al_d_g; a.al.z = (S*)h->al_d_z;
   a.al.enabled = h->al_defs.empty() ? 0 : 1;
-  a.al.uniform = h->al_uniform; a.al.rows_per_knot = h->al_rows_per_knot; a.al.N = h->N; a.al.G_count = h->al_G_count; a.al.has_soc = h->al_has_soc; a.al.Gpad = (decltype(a.al.Gpad))h->al_d_Gpad; a.al.Gpad_count = h->al_Gpad_count;
+  a.al.uniform = h->al_uniform; a.al.rows_per_knot = h->al_rows_per_knot; a.al.N = h->N; a.al.G_count = h->al_G_count; a.al.has_soc = h->al_has_soc; a.al.all_sel = h->al_all_sel; a.al.Gpad = (decltype(a.al.Gpad))h->al_d_Gpad; a.al.Gpad_count = h->al_Gpad_count;
   a.mode = mode;
   a.penalty_scaling = h->expand_penalty_scaling; a.penalty_max = h->expand_penalty_max;
   if (which == IK_STATIONARITY || which == IK_DUAL) {   // constraint rows in the DPP form unless ALTRO_HIP_ALROWS_DPP=0
@@ -1225,6 +1228,10 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
   const bool run_ahead = nra == nullptr || std::atoi(nra) == 0;
   if (iter0 < o.iterations_max)   // the one memset of the solve: every slot but the one-launch kernel's starts from zero
     HIP_TRY(hipMemsetAsync(h->i_counters + 8, 0, (size_t)(kCounterSlots - 1) * 8 * sizeof(int), h->stream));
+  // Plan MFMA16, diagonal cost, bound-type blocks only: the Hessian blocks differ from sweep to sweep on their diagonal alone, so
+  // after this solve's first (full) Hessian expansion the later ones store 16 values per knot point instead of 158 (EXPAND_DIAG)
+  bool hessian_stored = false;
+  const int diag_mode = (h->plan == ALTRO_HIP_PLAN_MFMA16 && al && !h->cost_dense && h->al_all_sel && std::getenv("ALTRO_HIP_NO_EXPAND_DIAG") == nullptr) ? EXPAND_DIAG : 0;
   const int stop_at = o.stop_when_running_at_most > 0 ? o.stop_when_running_at_most : 0;
   int pend_finish = -1;          // slot of the previous sweep's ILK_FINISH_ITER whose count has not been read yet
   bool multi_sweep = false;      // a second sweep was needed: from now on the next sweep's head is enqueued ahead
@@ -1234,8 +1241,9 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
     la.iter = iter;
     if (ilqr_launch_loop(h->stream, ILK_MARK_RUNNING, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
     if (al && !hessians_ready) {                                // CalcExpansions: cost Hessians (solver.cpp:448)
-      rc = ilqr_run(h, IK_EXPAND, false, true, 0, 0.0, EXPAND_HESSIAN);
+      rc = ilqr_run(h, IK_EXPAND, false, true, 0, 0.0, EXPAND_HESSIAN | (hessian_stored ? diag_mode : 0));
       if (rc) return rc;
+      hessian_stored = true;
     }
     rc = launch_backward(h, 0.0);                               // BackwardPass (reg = 0, solver.cpp:363)
     if (rc) return rc;
@@ -1391,7 +1399,7 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
       const bool fused_end = !lane_plan && !(ed0 != nullptr && std::atoi(ed0) == 0) && !(ar0 != nullptr && std::atoi(ar0) == 0);
       if (fused_end) {
         h->expand_penalty_scaling = o.penalty_scaling; h->expand_penalty_max = o.penalty_max;
-        rc = ilqr_run(h, IK_EXPAND, false, true, 0, 0.0, EXPAND_GRADIENT | EXPAND_HESSIAN | EXPAND_NEXT | EXPAND_DUAL);
+        rc = ilqr_run(h, IK_EXPAND, false, true, 0, 0.0, EXPAND_GRADIENT | EXPAND_HESSIAN | EXPAND_NEXT | EXPAND_DUAL | (hessian_stored ? diag_mode : 0));
         if (rc) return rc;
         if (ilqr_launch_loop(h->stream, ILK_PENALTY_UPDATE, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
         hessians_ready = true;
@@ -1404,7 +1412,7 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
         // (plan MFMA16, DPP form: gradient for the problems whose duals changed, Hessians for every problem still running)
         const char* ed = std::getenv("ALTRO_HIP_EXPAND_DPP");
         const bool merged = !lane_plan && !(ed != nullptr && std::atoi(ed) == 0);
-        rc = ilqr_run(h, IK_EXPAND, false, true, 0, 0.0, merged ? (EXPAND_GRADIENT | EXPAND_HESSIAN | EXPAND_NEXT) : EXPAND_GRADIENT);
+        rc = ilqr_run(h, IK_EXPAND, false, true, 0, 0.0, merged ? (EXPAND_GRADIENT | EXPAND_HESSIAN | EXPAND_NEXT | (hessian_stored ? diag_mode : 0)) : EXPAND_GRADIENT);
         if (rc) return rc;
         hessians_ready = merged;
       }

@@ -124,6 +124,7 @@ struct altro_hip_batch {
   int al_Gpad_count = 0;
   int al_G_count = 0;                        // elements of the device G pool
   int al_has_soc = 0;                        // some block is a second-order cone
+  int al_all_sel = 0;                        // every block is bound-type (rows +-e_idx: AlKnot::sel)
   double expand_penalty_scaling = 10.0, expand_penalty_max = 1e8;   // what EXPAND_DUAL's look-ahead of PenaltyUpdate needs
   const int* bwd_active = nullptr;           // per-problem mask for the backward sweep inside ilqr_solve
   const double* bwd_reg = nullptr;           // per-problem regularisation inside ilqr_solve (retry extension)

@@ -30,7 +30,8 @@ static int wave_launch(hipStream_t stream, int which, const IlqrWaveArgs<S>& a) 
         if (a.al.enabled) hipLaunchKernelGGL((wave_expand_dpp_kernel<S, true>), dim3((unsigned)((int64_t)((a.batch + 3) / 4) * (a.N + 1))), b64, 0, stream, a);
         else if (a.mode & EXPAND_GRADIENT) hipLaunchKernelGGL(wave_expand_grad_dense_kernel<S>, dim3((unsigned)(blocks < 262144 ? blocks : 262144)), dim3(256), 0, stream, a);
       } else if (a.al.enabled && (a.mode & EXPAND_LDS) == 0) {   // four (problem, knot point) pairs per wave, kernels/ilqr_merit2_dpp.hip
-        hipLaunchKernelGGL((wave_expand_dpp_kernel<S, false>), dim3((unsigned)((int64_t)((a.batch + 3) / 4) * (a.N + 1))), b64, 0, stream, a);
+        if (a.al.all_sel) hipLaunchKernelGGL((wave_expand_dpp_kernel<S, false, true>), dim3((unsigned)((int64_t)((a.batch + 3) / 4) * (a.N + 1))), b64, 0, stream, a);
+        else hipLaunchKernelGGL((wave_expand_dpp_kernel<S, false>), dim3((unsigned)((int64_t)((a.batch + 3) / 4) * (a.N + 1))), b64, 0, stream, a);
       } else if (a.al.enabled) {
         hipLaunchKernelGGL(wave_expand_kernel<S>, dim3((unsigned)((int64_t)a.batch * (a.N + 1))), b64, 0, stream, a);
       } else if (a.mode & EXPAND_GRADIENT) {   // no constraint blocks: the Hessian is constant, the gradient is 16 entries

@@ -51,6 +51,7 @@ struct AlTable {
   int G_count;           // elements of the G pool (kernels that keep it in LDS: kernels/ilqr_merit2_dpp.hip)
   const T* Gpad;         // [def][9][AL_GP_LD], see AL_GP_DEF (plan MFMA16 only; else null)
   int Gpad_count;        // its elements
+  int all_sel;           // every block is bound-type (AlKnot::sel): the Gauss-Newton blocks are diagonal
   int has_soc;           // some block is a second-order cone (kernels instantiated without the cone's code serve handles that have none)
 };
 #define ALTRO_CONST_AS __attribute__((address_space(4)))

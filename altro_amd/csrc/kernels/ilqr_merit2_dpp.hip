@@ -775,8 +775,12 @@ __device__ __forceinline__ void md_cross_rows(double (&tile)[16], const double (
 // DENSE: the cost's own Hessian is W = [Q H^T; H R] of ALTROSolver::SetQuadraticCost instead of diag(Qd, Rd) and its gradient
 // W [x; u] + [q r] (knotpoint_data.cpp:659-668, :691-698); lane j reads row j of W (= column j: W is symmetric) from the dense
 // cost record, the gradient is one more 16-term chain.
-template <typename S, bool DENSE = false>
+// BOUNDS: every block of the handle is bound-type (rows +-e_idx: AlTable::all_sel) and the cost is diagonal -- the Hessian blocks
+// are then diagonal: diag(Qd, Rd) + rho * (active rows per variable).  No 16 x 16 tile is formed; and once a solve has stored the
+// full blocks, later expansions store the diagonal only (EXPAND_DIAG: what is off it cannot have changed).
+template <typename S, bool DENSE = false, bool BOUNDS = false>
 __global__ __launch_bounds__(64) void wave_expand_dpp_kernel(IlqrWaveArgs<S> a) {
+  static_assert(!(DENSE && BOUNDS), "the diagonal form is the diagonal cost's");
   const int lane = threadIdx.x, j = lane & 15;
   // four problems of ONE knot point per wave (the constraint table entry is the knot point's: wave-uniform control flow)
   const int wpk = (a.batch + 3) >> 2;
@@ -831,9 +835,10 @@ __global__ __launch_bounds__(64) void wave_expand_dpp_kernel(IlqrWaveArgs<S> a) 
   const double rho_est = dual ? rho : rho_est0;
   int zshift;
   const AlKnot ALTRO_CONST_AS& kn = al_knot<S>(a.al, k, zshift);
-  double tile[16];
+  double tile[BOUNDS ? 1 : 16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) tile[r] = 0.0;
+  for (int r = 0; r < (BOUNDS ? 1 : 16); ++r) tile[r] = 0.0;
+  double dacc = 0.0;                                // BOUNDS: this lane's diagonal entry of (J G)^T (J G), summed over the blocks
   double scol = 0.0;
   bool tile_counts = true;
 #pragma unroll
@@ -862,7 +867,7 @@ __global__ __launch_bounds__(64) void wave_expand_dpp_kernel(IlqrWaveArgs<S> a) 
       double znew = 0.0;
       if (cone == CONE_EQUALITY) znew = ze0;
       else if (cone == CONE_INEQUALITY) znew = fmin(0.0, ze0);
-      else {
+      else if constexpr (!BOUNDS) {
         double zev0[AL_MAXSOC], zpv0[AL_MAXSOC];
         md_gather4(ze0, zev0);
         soc_projection<double>(p, zev0, zpv0);
@@ -877,7 +882,7 @@ __global__ __launch_bounds__(64) void wave_expand_dpp_kernel(IlqrWaveArgs<S> a) 
     }
     const double ze = rl ? zi - rho_est * val : 0.0;
     double jv = 0.0;
-    if (cone != CONE_SOC) {
+    if (BOUNDS || cone != CONE_SOC) {
       double mkv = 0.0;
       if (rl) {
         double zp = 0.0;
@@ -889,7 +894,14 @@ __global__ __launch_bounds__(64) void wave_expand_dpp_kernel(IlqrWaveArgs<S> a) 
       if (hess) {
         double mk[8];
         md_gather8(mkv, mk);
-        if (kn.sel[cidx] && tile_counts) {
+        if constexpr (BOUNDS) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+            if (i < p) {
+              const int sx = kn.sidx[cidx][i];
+              dacc += (j == (sx < 0 ? -sx : sx) - 1) ? mk[i] * mk[i] : 0.0;
+            }
+        } else if (kn.sel[cidx] && tile_counts) {
           // a bound-type block (every row of G is +-e_idx: AlKnot::sel): (J G)^T (J G) is diagonal, entry idx = the number of
           // its rows that are active there -- the 128 multiply-adds below would add exactly these ones and zeros, one by one
           // (tile_counts: the tile holds such counts only so far, so adding them in one go rounds nowhere)
@@ -910,7 +922,7 @@ __global__ __launch_bounds__(64) void wave_expand_dpp_kernel(IlqrWaveArgs<S> a) 
           tile_counts = false;
         }
       }
-    } else {
+    } else if constexpr (!BOUNDS) {
       double valv[AL_MAXSOC], zev[AL_MAXSOC], zpv[AL_MAXSOC];
       md_gather4(val, valv);
       md_gather4(ze, zev);
@@ -961,13 +973,16 @@ __global__ __launch_bounds__(64) void wave_expand_dpp_kernel(IlqrWaveArgs<S> a) 
     else if (j < 12) a.term[(size_t)b * MF_TERM + 144 + j] = (S)l;
   }
   if (hess && on_h) {
+    const bool diag_only = BOUNDS && (a.mode & EXPAND_DIAG) != 0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       if (terminal && (r >= 12 || j >= 12)) continue;
       if (r < 12 && j >= 12) continue;             // the H^T block is not stored
       if (!terminal && r < 12 && j < r) continue;  // nor is the lower triangle of Q
+      if (diag_only && r != j) continue;           // (stored by this solve's full expansion; cannot have changed)
       double v = DENSE ? cW[r] : ((r == j) ? cq : 0.0);
-      v += rho * tile[r];
+      if constexpr (BOUNDS) v += rho * ((r == j) ? dacc : 0.0);   // (the tile's entry: the count on the diagonal, an exact zero off it)
+      else v += rho * tile[r];
       if (terminal) a.term[(size_t)b * MF_TERM + r * 12 + j] = (S)v;
       else if (r < 12) a.cin[(size_t)b * a.cin_bs + (size_t)k * a.cin_ks + MF_OFF_Q + mf_sym(r, j)] = (S)v;
       else a.cin[(size_t)b * a.cin_bs + (size_t)k * a.cin_ks + MF_OFF_HR + (r - 12) * 16 + j] = (S)v;

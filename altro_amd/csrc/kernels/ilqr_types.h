@@ -76,7 +76,9 @@ enum { EXPAND_GRADIENT = 1, EXPAND_HESSIAN = 2, EXPAND_LDS = 16 /* plan MFMA16: 
        EXPAND_DUAL = 128 /* ... and the sweep's DualUpdate in the same pass (IlqrProb::dual instead of the active mask) */,
        EXPAND_DYN = 256 /* plan MFMA16 with a device model: also the dynamics Jacobians Z = [A B] of the stored candidate trajectory
                            (wave_expand_dyn_kernel) -- the head of Solve and the re-expansion after a speculative step; a merit pass
-                           with derivative leaves them itself */ };
+                           with derivative leaves them itself */,
+       EXPAND_DIAG = 512 /* wave_expand_dpp_kernel<.., BOUNDS>: only the DIAGONAL of the Hessian blocks is stored -- the rest was
+                            stored by a full expansion of this solve and cannot have changed (diagonal cost, bound-type blocks) */ };
 
 struct IlqrLoopArgs {
   IlqrProb* prob;
