@@ -236,7 +236,8 @@ int altro_hip_set_tracking_cost(altro_hip_batch* h, const double* Qd, const doub
  * Q [batch][N+1][n*n] (symmetric, altro_solver.hpp:183), R [batch][N][m*m], H [batch][N][m*n], q [batch][N+1][n],
  * r [batch][N][m], c [batch][N+1] or NULL (zero); with k_stride_zero Q / q / c hold {running, terminal} and R / H / r one
  * knot point.  Replaces a tracking cost set before (and vice versa); altro_hip_update_linear_costs then updates q, r, c of
- * this cost.  Plans LANE (device models and run-time compiled ones; whole solves run on the launch-sequenced loop) and MFMA16.  */
+ * this cost.  Every plan: LANE (device models and run-time compiled ones; whole solves run on the launch-sequenced loop), MFMA16,
+ * GENERIC.                                                                                                                          */
 int altro_hip_set_quadratic_cost(altro_hip_batch* h, const double* Q, const double* R, const double* H, const double* q,
                                  const double* r, const double* c, int k_stride_zero, int batch_stride_zero);
 /* ALTROSolver::SetInput over all knot points (altro_solver.cpp:242-251): u [batch][N][m]             */

@@ -72,6 +72,14 @@ class BatchSolver {
                   bool shared_over_batch = false) {
     Check(altro_hip_set_tracking_cost(h_, Qd, Rd, xref, uref, shared_over_k, shared_over_batch));
   }
+  // ALTROSolver::SetQuadraticCost (altro_solver.cpp:118-136) for all knot points: the general quadratic cost with the cross term
+  // u^T H x.  Q [batch][N+1][n*n], R [batch][N][m*m], H [batch][N][m*n] (column-major blocks), q, r, c likewise (c may be null)
+  void SetQuadraticCost(const double* Q, const double* R, const double* H, const double* q, const double* r, const double* c,
+                        bool shared_over_k = false, bool shared_over_batch = false) {
+    Check(altro_hip_set_quadratic_cost(h_, Q, R, H, q, r, c, shared_over_k, shared_over_batch));
+  }
+  // SetExplicitDynamics with the caller's own continuous model as HIP source, compiled at run time (altro_hip_set_model_source)
+  void SetModelSource(const char* source, float timestep) { Check(altro_hip_set_model_source(h_, source, timestep)); }
   void SetInitialState(const double* x0, bool shared_over_batch = false) {
     Check(altro_hip_set_initial_state(h_, x0, shared_over_batch));
   }

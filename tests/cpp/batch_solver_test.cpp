@@ -51,6 +51,29 @@ int main() {
     EXPECT(std::sqrt(dist) < 1e-4);
     EXPECT(std::fabs(u[b * N * m + 0] + 1.0) < 1e-4 && std::fabs(u[b * N * m + 1] + 1.0) < 1e-4);   // saturated
   }
+  {   // the same problems with the cost handed over as dense blocks (SetQuadraticCost; H = 0, diagonal Q and R): the same solves, bit for bit
+    BatchSolver dense(N, n, m, batch);
+    dense.SetModel(ALTRO_HIP_MODEL_DOUBLE_INTEGRATOR, h);
+    double Q[2 * 16] = {0}, R[4] = {0}, H[8] = {0}, q[2 * 4] = {0}, r[2] = {0}, c[2] = {0};
+    for (int i = 0; i < 4; ++i) { Q[i + 4 * i] = 1.0; Q[16 + i + 4 * i] = 1.0; }
+    R[0] = R[3] = 1e-2;
+    dense.SetQuadraticCost(Q, R, H, q, r, c, true, true);
+    dense.SetInitialState(x0.data());
+    dense.SetInput(u0, true, true);
+    dense.SetConstraint(N, N, Cone::Equality, 4, Gg, gg);
+    dense.SetConstraint(0, N - 1, Cone::Inequality, 4, Gb, gb);
+    dense.opts.penalty_initial = 100;
+    dense.opts.penalty_scaling = 100;
+    auto rd = dense.Solve();
+    EXPECT(rd.NumConverged() == batch);
+    std::vector<double> xd(batch * (N + 1) * n), ud(batch * N * m);
+    dense.GetTrajectory(xd.data(), ud.data());
+    bool same = true;
+    for (size_t i = 0; i < xd.size(); ++i) same = same && xd[i] == x[i];
+    for (size_t i = 0; i < ud.size(); ++i) same = same && ud[i] == u[i];
+    for (int b = 0; b < batch; ++b) same = same && rd.problems[b].iterations == res.problems[b].iterations;
+    EXPECT(same);
+  }
   bool threw = false;
   try { solver.SetConstraint(0, 99, Cone::Equality, 4, Gg, gg); } catch (const std::runtime_error&) { threw = true; }
   EXPECT(threw);
