@@ -250,7 +250,7 @@ int wave_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int
   if (rc) return fail(ALTRO_HIP_ERR_HIP, "iLQR kernel launch failed");
   return 0;
 }
-// plan GENERIC: any (n, m) up to 32, dynamics as data, quadratic cost, no constraint blocks (kernels/ilqr_generic.hip)
+// plan GENERIC: any (n, m) up to 32, dynamics as data, quadratic cost, linear constraint blocks (kernels/ilqr_generic.hip)
 template <typename T>
 int gen_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int want_deriv, double alpha_const, int mode) {
   const int n = h->n, m = h->m, N = h->N;
@@ -271,6 +271,10 @@ int gen_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int 
   a.alpha = use_alpha ? h->i_alpha : nullptr; a.active = use_active ? h->i_active : nullptr; a.alpha_const = alpha_const;
   a.phi = h->i_phi; a.dphi = h->i_dphi; a.prob = h->i_prob;
   a.N = N; a.n = n; a.m = m; a.batch = h->batch; a.want_derivative = want_deriv; a.mode = mode;
+  a.al.knots = h->al_d_knots; a.al.G = (const T*)h->al_d_G; a.al.g = (const T*)h->al_d_g; a.al.z = (T*)h->al_d_z;
+  a.al.enabled = h->al_defs.empty() ? 0 : 1;
+  a.al.uniform = h->al_uniform; a.al.rows_per_knot = h->al_rows_per_knot; a.al.N = h->N; a.al.G_count = h->al_G_count;
+  a.al.has_soc = h->al_has_soc; a.al.all_sel = h->al_all_sel; a.al.Gpad = nullptr; a.al.Gpad_count = 0;
   const int rc = ilqr_generic_launch<T>(h->stream, which, a);
   if (rc == 1) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "operation %d is not available on plan GENERIC", which);
   if (rc) return fail(ALTRO_HIP_ERR_HIP, "iLQR kernel launch failed");
@@ -278,11 +282,11 @@ int gen_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int 
 }
 int ilqr_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int want_deriv, double alpha_const,
              int mode = EXPAND_GRADIENT | EXPAND_HESSIAN) {
+  int rc = al_upload(h);
+  if (rc) return rc;
   if (h->plan == ALTRO_HIP_PLAN_GENERIC)
     return h->dtype == ALTRO_HIP_F64 ? gen_run<double>(h, which, use_alpha, use_active, want_deriv, alpha_const, mode)
                                      : gen_run<float>(h, which, use_alpha, use_active, want_deriv, alpha_const, mode);
-  int rc = al_upload(h);
-  if (rc) return rc;
   if (h->plan == ALTRO_HIP_PLAN_MFMA16) {   // linear dynamics: "expand" = cost gradient (+ AL Hessian terms when constrained)
     rc = h->dtype == ALTRO_HIP_F64 ? wave_run<double>(h, which, use_alpha, use_active, want_deriv, alpha_const, mode)
                                    : wave_run<float>(h, which, use_alpha, use_active, want_deriv, alpha_const, mode);
@@ -351,7 +355,7 @@ int ilqr_check(altro_hip_batch* h, bool need_guess) {
   if (h->plan == ALTRO_HIP_PLAN_MFMA16) {   // dynamics are data (altro_hip_set_dynamics) or a device model of the tile plan
     if (!h->dyn_set && !h->model_set)
       return fail(ALTRO_HIP_ERR_NOT_SET, "neither altro_hip_set_dynamics nor altro_hip_set_model has been called");
-  } else if (h->plan == ALTRO_HIP_PLAN_GENERIC) {   // any (n, m) up to 32: dynamics as data, a quadratic cost, no constraint blocks
+  } else if (h->plan == ALTRO_HIP_PLAN_GENERIC) {   // any (n, m) up to 32: dynamics as data, a quadratic cost
     if (!h->dyn_set) return fail(ALTRO_HIP_ERR_NOT_SET, "altro_hip_set_dynamics has not been called");
   } else if (!h->model_set) {
     return fail(ALTRO_HIP_ERR_NOT_SET, "altro_hip_set_model has not been called (plan LANE runs device models; for dynamics given as "
@@ -834,8 +838,6 @@ int altro_hip_add_linear_constraint(altro_hip_batch* h, int k_first, int k_last,
   int rc = loop_entry(h);
   if (rc) return rc;
   h->expansion_current = false;
-  if (h->plan != ALTRO_HIP_PLAN_LANE && h->plan != ALTRO_HIP_PLAN_MFMA16)
-    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "constraints need plan LANE or MFMA16");
   if (!G || !g) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "G and g are required");
   if (cone < CONE_EQUALITY || cone > CONE_SOC) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "unknown cone %d", cone);
   const int pmax = cone == CONE_SOC ? AL_MAXSOC : AL_MAXP;
@@ -889,7 +891,6 @@ int altro_hip_reset_duals(altro_hip_batch* h, double penalty) {
   int rc = loop_entry(h);
   if (rc) return rc;
   h->expansion_current = false;
-  if (h->plan != ALTRO_HIP_PLAN_LANE && h->plan != ALTRO_HIP_PLAN_MFMA16) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "constraints need plan LANE or MFMA16");
   if (!(penalty > 0.0)) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "penalty must be positive");
   if ((rc = al_upload(h))) return rc;
   const size_t E = h->dtype == ALTRO_HIP_F64 ? 8 : 4;
@@ -905,7 +906,6 @@ int altro_hip_get_duals(altro_hip_batch* h, int k, int slot, double* z) {
   // duals of constraint block `slot` of knot point k, [batch][p]
   int rc = loop_entry(h);
   if (rc) return rc;
-  if (h->plan != ALTRO_HIP_PLAN_LANE && h->plan != ALTRO_HIP_PLAN_MFMA16) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "constraints need plan LANE or MFMA16");
   if ((rc = al_upload(h))) return rc;
   if (k < 0 || k > h->N || slot < 0 || slot >= h->al_knots[k].ncon || !z)
     return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "no constraint block %d at knot point %d", slot, k);
@@ -1050,6 +1050,7 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
     return 0;
   };
   const bool lane_plan = h->plan == ALTRO_HIP_PLAN_LANE;
+  const bool generic_plan = h->plan == ALTRO_HIP_PLAN_GENERIC;   // (constraint rows in their one-wave-per-knot-point form: no merged end pass)
   const int64_t cand_elems = (int64_t)h->batch * (h->N + 1) * (lane_plan ? lane_sizes(h->n, h->m).e_xuy : 28);
   const size_t spare_each = (size_t)cand_elems * h->esz;   // one spare candidate trajectory
   const int trials_cap = spec_trials_cap(h);
@@ -1121,7 +1122,7 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
   }
   int total_merit_launches = 0, sweeps = 0;
   // speculative backtracking: how much of the chip the searching problems occupy, and how much there is
-  const bool spec_all_on = std::getenv("ALTRO_HIP_NO_SPECULATION") == nullptr;
+  const bool spec_all_on = std::getenv("ALTRO_HIP_NO_SPECULATION") == nullptr && !generic_plan;   // (plan GENERIC evaluates one step per launch)
   const bool spec_on = o.use_backtracking_linesearch != 0 && spec_all_on;
   int running = h->batch;   // problems still iterating (counters[1] of the previous sweep)
   auto spec_units = [&](int searching) -> int {   // wavefronts one merit launch keeps busy
@@ -1396,7 +1397,7 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
       //  Hessians -- EXPAND_DUAL | EXPAND_NEXT -- and PenaltyUpdate's bookkeeping follows it)
       const char* ed0 = std::getenv("ALTRO_HIP_EXPAND_DPP");
       const char* ar0 = std::getenv("ALTRO_HIP_ALROWS_DPP");
-      const bool fused_end = !lane_plan && !(ed0 != nullptr && std::atoi(ed0) == 0) && !(ar0 != nullptr && std::atoi(ar0) == 0);
+      const bool fused_end = !lane_plan && !generic_plan && !(ed0 != nullptr && std::atoi(ed0) == 0) && !(ar0 != nullptr && std::atoi(ar0) == 0);
       if (fused_end) {
         h->expand_penalty_scaling = o.penalty_scaling; h->expand_penalty_max = o.penalty_max;
         rc = ilqr_run(h, IK_EXPAND, false, true, 0, 0.0, EXPAND_GRADIENT | EXPAND_HESSIAN | EXPAND_NEXT | EXPAND_DUAL | (hessian_stored ? diag_mode : 0));
@@ -1411,7 +1412,7 @@ int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts
         // nothing they depend on (trajectory, duals, penalties) changes between here and there
         // (plan MFMA16, DPP form: gradient for the problems whose duals changed, Hessians for every problem still running)
         const char* ed = std::getenv("ALTRO_HIP_EXPAND_DPP");
-        const bool merged = !lane_plan && !(ed != nullptr && std::atoi(ed) == 0);
+        const bool merged = !lane_plan && !generic_plan && !(ed != nullptr && std::atoi(ed) == 0);
         rc = ilqr_run(h, IK_EXPAND, false, true, 0, 0.0, merged ? (EXPAND_GRADIENT | EXPAND_HESSIAN | EXPAND_NEXT | (hessian_stored ? diag_mode : 0)) : EXPAND_GRADIENT);
         if (rc) return rc;
         hessians_ready = merged;

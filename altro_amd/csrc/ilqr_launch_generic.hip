@@ -15,7 +15,11 @@ static int gen_launch(hipStream_t stream, int which, const IlqrGenArgs<T>& a) {
   switch (which) {
     case IK_ROLLOUT: hipLaunchKernelGGL(generic_rollout_kernel<T>, waves, b64, 0, stream, a); break;
     case IK_ACCEPT: hipLaunchKernelGGL(generic_accept_kernel<T>, flat, b256, 0, stream, a); break;
-    case IK_EXPAND: hipLaunchKernelGGL(generic_expand_kernel<T>, flat, b256, 0, stream, a); break;
+    case IK_EXPAND:
+      if (a.al.enabled) hipLaunchKernelGGL(generic_expand_al_kernel<T>, dim3((unsigned)((int64_t)a.batch * (a.N + 1))), b64, 0, stream, a);
+      else hipLaunchKernelGGL(generic_expand_kernel<T>, flat, b256, 0, stream, a);
+      break;
+    case IK_DUAL: hipLaunchKernelGGL(generic_dual_update_kernel<T>, dim3((unsigned)((int64_t)a.batch * (a.N + 1))), b64, 0, stream, a); break;
     case IK_MERIT: hipLaunchKernelGGL(generic_merit_kernel<T>, waves, b64, 0, stream, a); break;
     case IK_STATIONARITY: hipLaunchKernelGGL(generic_stationarity_kernel<T>, waves, b64, 0, stream, a); break;
     case IK_SHIFT: hipLaunchKernelGGL(generic_shift_kernel<T>, dim3((unsigned)(((int64_t)a.batch * (a.n + a.m) + 255) / 256)), b256, 0, stream, a); break;

@@ -15,6 +15,7 @@
 #include <stdint.h>
 
 #include "ilqr_types.h"
+#include "al_lane.hip"   // soc_projection / soc_jacobian / soc_hessian
 
 namespace altro_hip {
 
@@ -33,6 +34,7 @@ struct IlqrGenArgs {
   const double* alpha; const int* active; double alpha_const;
   double* phi; double* dphi; IlqrProb* prob;
   int N, n, m, batch, want_derivative, mode;
+  AlTable<T> al;                                                    // constraint blocks (G: p x (n + m), column-major)
 };
 
 __device__ __forceinline__ double gen_wave_sum(double v) {
@@ -44,6 +46,112 @@ __device__ __forceinline__ double gen_wave_max(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
   return v;
+}
+
+
+// ---- constraint blocks (augmented-Lagrangian terms, knotpoint_data.cpp:489-613; cones.cpp:13-202) for this plan ---------------------
+// wave_al_rows / wave_al_col of kernels/ilqr_mfma16.hip with the problem's own dimensions: lane i < 8 owns row i of each of the (at most
+// two) blocks of knot point k -- value c_i = G_i [x; u] - g_i, estimated / projected dual, AL cost share, violation -- and publishes
+//   jv[c * 8 + i] = (J^T z_proj)_i,  Jm[c * 64 + i * 8 + r] = J_ir (projection Jacobian),  Hm[c * 16 + i * 4 + r] (cone curvature)
+// to LDS for the lanes that own gradient / Hessian entries.  A second-order-cone block (p <= 4) is evaluated whole by lane 0.
+// xs / us: the point, in LDS (us ignored at the terminal knot point).  Must be called by all lanes; no barrier inside.
+template <typename T>
+__device__ __forceinline__ void gen_al_rows(const AlTable<T>& t, int k, int b, int64_t B, int n, int m, const double* xs, const double* us,
+                                            bool terminal, double rho_est, int lane, double* jv, double* Jm, double* Hm, double& cost,
+                                            double& viol, bool dual_update) {
+  int zshift;
+  const AlKnot ALTRO_CONST_AS& kn = al_knot<T>(t, k, zshift);
+  const int i = lane;
+  const bool row_lane = i < AL_MAXP;
+#pragma unroll
+  for (int c = 0; c < AL_MAXC; ++c) {
+    const bool has = c < kn.ncon;
+    const int p = has ? kn.p[c] : 0, cone = has ? kn.cone[c] : CONE_IDENTITY;
+    const T* G = t.G + (has ? kn.G_off[c] : 0);
+    if (row_lane) {
+      jv[c * AL_MAXP + i] = 0.0;
+      if (Jm)
+        for (int r = 0; r < AL_MAXP; ++r) Jm[c * 64 + i * 8 + r] = 0.0;
+      if (Hm && i < AL_MAXSOC)
+        for (int r = 0; r < AL_MAXSOC; ++r) Hm[c * 16 + i * 4 + r] = 0.0;
+    }
+    if (!has) continue;
+    auto value = [&](int r) -> double {
+      double s = 0.0;
+      for (int e = 0; e < n; ++e) s += (double)G[r + e * p] * xs[e];
+      if (!terminal)
+        for (int e = 0; e < m; ++e) s += (double)G[r + (n + e) * p] * us[e];
+      const double gi = kn.g_per_problem[c] ? (double)t.g[kn.g_off[c] + (int64_t)r * B + b] : (double)t.g[kn.g_off[c] + r];
+      return s - gi;
+    };
+    if (cone != CONE_SOC) {
+      if (row_lane && i < p) {
+        const double val = value(i);
+        T* zp_ = t.z + (int64_t)(kn.z_off[c] + zshift + i) * B + b;
+        const double ze = (double)*zp_ - rho_est * val;
+        double zp = 0.0, mkv = 0.0;
+        if (cone == CONE_EQUALITY) { zp = ze; mkv = 1.0; viol = fmax(viol, fabs(val)); }
+        else if (cone == CONE_INEQUALITY) { zp = fmin(0.0, ze); mkv = (ze <= 0.0) ? 1.0 : 0.0; viol = fmax(viol, fabs(fmin(0.0, val) - val)); }
+        cost += zp * zp / (2.0 * rho_est);
+        jv[c * AL_MAXP + i] = mkv * zp;
+        if (Jm) Jm[c * 64 + i * 8 + i] = mkv;
+        if (dual_update) *zp_ = (T)zp;
+      }
+    } else if (i == 0) {
+      double val[AL_MAXSOC], ze[AL_MAXSOC], zp[AL_MAXSOC], pv[AL_MAXSOC];
+#pragma unroll
+      for (int r = 0; r < AL_MAXSOC; ++r) {
+        val[r] = 0.0; ze[r] = 0.0;
+        if (r < p) {
+          val[r] = value(r);
+          ze[r] = (double)t.z[(int64_t)(kn.z_off[c] + zshift + r) * B + b] - rho_est * val[r];
+        }
+      }
+      soc_projection<double>(p, ze, zp);
+      soc_projection<double>(p, val, pv);
+      double sq = 0.0;
+#pragma unroll
+      for (int r = 0; r < AL_MAXSOC; ++r)
+        if (r < p) { sq += zp[r] * zp[r]; viol = fmax(viol, fabs(pv[r] - val[r])); }
+      cost += sq / (2.0 * rho_est);
+      double J[AL_MAXSOC * AL_MAXSOC];
+      soc_jacobian<double>(p, ze, J);
+#pragma unroll
+      for (int r = 0; r < AL_MAXSOC; ++r) {
+        if (r >= p) continue;
+        double sj = 0.0;
+#pragma unroll
+        for (int q = 0; q < AL_MAXSOC; ++q) sj += J[q + r * AL_MAXSOC] * zp[q];
+        jv[c * AL_MAXP + r] = sj;
+        if (Jm)
+          for (int q = 0; q < AL_MAXSOC; ++q) Jm[c * 64 + r * 8 + q] = J[r + q * AL_MAXSOC];
+        if (dual_update) t.z[(int64_t)(kn.z_off[c] + zshift + r) * B + b] = (T)zp[r];
+      }
+      if (Hm) {
+        double Hp[AL_MAXSOC * AL_MAXSOC];
+        soc_hessian<double>(p, ze, zp, Hp);
+#pragma unroll
+        for (int r = 0; r < AL_MAXSOC; ++r)
+#pragma unroll
+          for (int q = 0; q < AL_MAXSOC; ++q) Hm[c * 16 + r * 4 + q] = Hp[r + q * AL_MAXSOC];
+      }
+    }
+  }
+}
+// sum_c sum_i G_c[i][e] * w[c * 8 + i]  for column e of [x; u] of the constraint Jacobians of knot point k
+template <typename T>
+__device__ __forceinline__ double gen_al_col(const AlTable<T>& t, int k, int e, const double* w) {
+  int zshift;
+  const AlKnot ALTRO_CONST_AS& kn = al_knot<T>(t, k, zshift);
+  double s = 0.0;
+#pragma unroll
+  for (int c = 0; c < AL_MAXC; ++c)
+    if (c < kn.ncon) {
+      const int p = kn.p[c];
+      const T* G = t.G + kn.G_off[c];
+      for (int i = 0; i < p; ++i) s += (double)G[i + e * p] * w[c * AL_MAXP + i];
+    }
+  return s;
 }
 
 // x_0 = x0 ; x_{k+1} = A x + B u + f on the candidate trajectory (u_ is the guess already stored there)
@@ -147,10 +255,13 @@ __global__ void generic_expand_kernel(IlqrGenArgs<T> a) {
 // derivative phi' with the refreshed lx, lu.  Lanes 0..31: state rows, lanes 32..63: input rows.
 template <typename T>
 __global__ __launch_bounds__(64) void generic_merit_kernel(IlqrGenArgs<T> a) {
-  __shared__ double xs[GEN_MAX], dxs[GEN_MAX], das[GEN_MAX], us[GEN_MAX], dus[GEN_MAX];
+  __shared__ double xs[GEN_MAX], dxs[GEN_MAX], das[GEN_MAX], us[GEN_MAX], dus[GEN_MAX], jv[AL_MAXC * AL_MAXP];
   const int b = blockIdx.x, lane = threadIdx.x;
   if (a.active && !a.active[b]) return;
   const int n = a.n, m = a.m, N = a.N;
+  const bool al = a.al.enabled != 0;
+  const double rho = al ? a.prob[b].rho : 1.0;
+  double viol = 0.0;
   const double alpha = a.alpha ? a.alpha[b] : a.alpha_const;
   const bool deriv = a.want_derivative != 0;
   const bool isx = lane < n, isu = lane >= 32 && lane - 32 < m;
@@ -180,6 +291,12 @@ __global__ __launch_bounds__(64) void generic_merit_kernel(IlqrGenArgs<T> a) {
       a.y[(int64_t)b * a.y_bs + (int64_t)k * n + i] = (T)(s + (double)a.p[(int64_t)b * a.p_bs + (int64_t)k * n + i]);
     }
     __syncthreads();
+    if (al) {   // the constraint rows' cost shares at the candidate point; (J^T z_proj) for the gradient below
+      double Jal = 0.0;
+      gen_al_rows<T>(a.al, k, b, a.batch, n, m, xs, us, false, rho, lane, jv, nullptr, nullptr, Jal, viol, false);
+      J += Jal;
+      __syncthreads();
+    }
     const T* Qk = a.cQ + ((int64_t)b * (N + 1) + k) * n * n;
     const T* Rk = a.cR + ((int64_t)b * N + k) * m * m;
     const T* Hk = a.cH + ((int64_t)b * N + k) * m * n;
@@ -191,7 +308,8 @@ __global__ __launch_bounds__(64) void generic_merit_kernel(IlqrGenArgs<T> a) {
       const double ql = (double)a.cq[((int64_t)b * (N + 1) + k) * n + i];
       J += x * (0.5 * qx + ql);
       if (lane == 0) J += (double)a.cc[(int64_t)b * (N + 1) + k];
-      const double lx = (qx + htu) + ql;
+      double lx = (qx + htu) + ql;
+      if (al && deriv) lx -= gen_al_col<T>(a.al, k, i, jv);
       if (deriv) { dJ += lx * dxda; a.q[(int64_t)b * a.q_bs + (int64_t)k * n + i] = (T)lx; }
       const T* Ak = a.A + (int64_t)b * a.A_bs + (int64_t)k * n * n;
       const T* Bk = a.B + (int64_t)b * a.B_bs + (int64_t)k * n * m;
@@ -208,7 +326,8 @@ __global__ __launch_bounds__(64) void generic_merit_kernel(IlqrGenArgs<T> a) {
       const double rl = (double)a.cr[((int64_t)b * N + k) * m + iu];
       const double uv = us[iu];
       J += uv * ((0.5 * ru + rl) + hx);
-      const double lu = (ru + hx) + rl;
+      double lu = (ru + hx) + rl;
+      if (al && deriv) lu -= gen_al_col<T>(a.al, k, n + iu, jv);
       if (deriv) { dJ += lu * dus[iu]; a.r[(int64_t)b * a.r_bs + (int64_t)k * m + iu] = (T)lu; }
     }
     if (isx) { x = xn; dxda = dxn; }
@@ -217,6 +336,10 @@ __global__ __launch_bounds__(64) void generic_merit_kernel(IlqrGenArgs<T> a) {
   {   // terminal knot point (solver.cpp:319-332)
     if (isx) { xs[lane] = x; dxs[lane] = x - (double)a.xn[((int64_t)b * (N + 1) + N) * n + lane]; a.x[(int64_t)b * a.x_bs + (int64_t)N * n + lane] = (T)x; }
     __syncthreads();
+    if (al) {
+      gen_al_rows<T>(a.al, N, b, a.batch, n, m, xs, us, true, rho, lane, jv, nullptr, nullptr, J, viol, false);
+      __syncthreads();
+    }
     if (isx) {
       const T* Qk = a.cQ + ((int64_t)b * (N + 1) + N) * n * n;
       const T* Pk = a.P + (int64_t)b * a.P_bs + (int64_t)N * n * n;
@@ -226,7 +349,8 @@ __global__ __launch_bounds__(64) void generic_merit_kernel(IlqrGenArgs<T> a) {
       J += x * (0.5 * qx + ql);
       if (lane == 0) J += (double)a.cc[(int64_t)b * (N + 1) + N];
       a.y[(int64_t)b * a.y_bs + (int64_t)N * n + i] = (T)(s + (double)a.p[(int64_t)b * a.p_bs + (int64_t)N * n + i]);
-      const double lx = qx + ql;
+      double lx = qx + ql;
+      if (al && deriv) lx -= gen_al_col<T>(a.al, N, i, jv);
       if (deriv) { dJ += lx * dxda; a.q[(int64_t)b * a.q_bs + (int64_t)N * n + i] = (T)lx; }
     }
   }
@@ -234,11 +358,11 @@ __global__ __launch_bounds__(64) void generic_merit_kernel(IlqrGenArgs<T> a) {
   if (lane == 0) {
     a.phi[b] = phi;
     if (deriv) a.dphi[b] = dphi;
+    if (al) a.prob[b].rho_est = rho;
   }
 }
 
-// Stationarity (solver.cpp:207-222): max_k |lx + A^T y+ - y|, max_k |lu + B^T y+| on the candidate trajectory; feasibility 0
-// (constraint blocks are not part of this plan's loop)
+// Stationarity (solver.cpp:207-222): max_k |lx + A^T y+ - y|, max_k |lu + B^T y+| on the candidate trajectory, and its feasibility
 template <typename T>
 __global__ __launch_bounds__(64) void generic_stationarity_kernel(IlqrGenArgs<T> a) {
   __shared__ double yn[GEN_MAX];
@@ -266,7 +390,130 @@ __global__ __launch_bounds__(64) void generic_stationarity_kernel(IlqrGenArgs<T>
   }
   if (isx) res = fmax(res, fabs((double)a.q[(int64_t)b * a.q_bs + (int64_t)N * n + j] - (double)a.y[(int64_t)b * a.y_bs + (int64_t)N * n + j]));
   res = gen_wave_max(res);
-  if (lane == 0) { a.prob[b].stationarity = res; a.prob[b].feasibility = 0.0; }
+  double viol = 0.0;   // Feasibility (solver.cpp:224-231) of the candidate trajectory
+  if (a.al.enabled) {
+    __shared__ double xs[GEN_MAX], us[GEN_MAX], jv[AL_MAXC * AL_MAXP];
+    const double rho = a.prob[b].rho;
+    for (int k = 0; k <= N; ++k) {
+      __syncthreads();
+      if (lane < n) xs[lane] = (double)a.x[(int64_t)b * a.x_bs + (int64_t)k * n + lane];
+      if (lane >= 32 && lane - 32 < m) us[lane - 32] = k < N ? (double)a.u[(int64_t)b * a.u_bs + (int64_t)k * m + lane - 32] : 0.0;
+      __syncthreads();
+      double cost = 0.0;
+      gen_al_rows<T>(a.al, k, b, a.batch, n, m, xs, us, k == N, rho, lane, jv, nullptr, nullptr, cost, viol, false);
+    }
+    viol = gen_wave_max(viol);
+  }
+  if (lane == 0) { a.prob[b].stationarity = res; a.prob[b].feasibility = viol; }
+}
+
+// The expansion with constraint blocks, one wave per (problem, knot point) (wave_expand_kernel of kernels/ilqr_mfma16.hip with the
+// problem's own dimensions):  EXPAND_GRADIENT  lx, lu with the AL terms (knotpoint_data.cpp:583-595) into the sweep's q / r;
+// EXPAND_HESSIAN  [lxx lux^T; lux luu] = the cost's blocks + rho G^T (J^T J + curvature) G (knotpoint_data.cpp:597-613) into Q / R / H.
+template <typename T>
+__global__ __launch_bounds__(64) void generic_expand_al_kernel(IlqrGenArgs<T> a) {
+  __shared__ double xs[GEN_MAX], us[GEN_MAX], jv[AL_MAXC * AL_MAXP], Jm[AL_MAXC * 64], Hm[AL_MAXC * 16];
+  const int lane = threadIdx.x;
+  const int64_t wk = blockIdx.x;
+  const int b = (int)(wk % a.batch), k = (int)(wk / a.batch);
+  const int n = a.n, m = a.m, N = a.N, w = n + m;
+  if (k > N) return;
+  if (a.active && !a.active[b]) return;
+  const bool terminal = k == N;
+  const bool grad = (a.mode & EXPAND_GRADIENT) != 0, hess = (a.mode & EXPAND_HESSIAN) != 0;
+  if (lane < n) xs[lane] = (double)a.x[(int64_t)b * a.x_bs + (int64_t)k * n + lane];
+  if (lane >= 32 && lane - 32 < m) us[lane - 32] = terminal ? 0.0 : (double)a.u[(int64_t)b * a.u_bs + (int64_t)k * m + lane - 32];
+  __syncthreads();
+  {
+    double cost = 0.0, viol = 0.0;
+    gen_al_rows<T>(a.al, k, b, a.batch, n, m, xs, us, terminal, a.prob[b].rho_est, lane, jv, Jm, Hm, cost, viol, false);
+  }
+  __syncthreads();
+  const T* Qk = a.cQ + ((int64_t)b * (N + 1) + k) * n * n;
+  const T* Rk = terminal ? nullptr : a.cR + ((int64_t)b * N + k) * m * m;
+  const T* Hk = terminal ? nullptr : a.cH + ((int64_t)b * N + k) * m * n;
+  if (grad) {
+    if (lane < n) {
+      const int e = lane;
+      double s = 0.0;
+      for (int j = 0; j < n; ++j) s += (double)Qk[e + j * n] * xs[j];
+      s += (double)a.cq[((int64_t)b * (N + 1) + k) * n + e];
+      if (!terminal) {
+        double t2 = 0.0;
+        for (int i = 0; i < m; ++i) t2 += (double)Hk[i + e * m] * us[i];
+        s += t2;
+      }
+      s -= gen_al_col<T>(a.al, k, e, jv);
+      a.q[(int64_t)b * a.q_bs + (int64_t)k * n + e] = (T)s;
+    } else if (!terminal && lane >= 32 && lane - 32 < m) {
+      const int i = lane - 32;
+      double s = 0.0;
+      for (int j = 0; j < m; ++j) s += (double)Rk[i + j * m] * us[j];
+      s += (double)a.cr[((int64_t)b * N + k) * m + i];
+      double t2 = 0.0;
+      for (int j = 0; j < n; ++j) t2 += (double)Hk[i + j * m] * xs[j];
+      s += t2;
+      s -= gen_al_col<T>(a.al, k, n + i, jv);
+      a.r[(int64_t)b * a.r_bs + (int64_t)k * m + i] = (T)s;
+    }
+  }
+  if (hess) {
+    const double rho = a.prob[b].rho;
+    int zshift;
+    const AlKnot ALTRO_CONST_AS& kn = al_knot<T>(a.al, k, zshift);
+    const int wt = terminal ? n : w;
+    for (int t = lane; t < wt * wt; t += 64) {
+      const int r = t % wt, cc = t / wt;          // entry (r, cc) of the (n + m) x (n + m) block, column-major walk
+      if (r < n && cc >= n) continue;             // the lux^T block is not stored
+      double v = r < n ? (double)Qk[r + cc * n] : (cc < n ? (double)Hk[(r - n) + cc * m] : (double)Rk[(r - n) + (cc - n) * m]);
+      double s = 0.0;
+      for (int cidx = 0; cidx < kn.ncon; ++cidx) {
+        const int p = kn.p[cidx];
+        const T* G = a.al.G + kn.G_off[cidx];
+        const double* Jc = Jm + cidx * 64;
+        if (kn.cone[cidx] != CONE_SOC) {          // diagonal projection Jacobian: (J G)_(i r) = J_ii G_ir
+          for (int i = 0; i < p; ++i) {
+            const double jii = Jc[i * 8 + i];
+            s += (jii * (double)G[i + r * p]) * (jii * (double)G[i + cc * p]);
+          }
+        } else {
+          for (int i = 0; i < p; ++i) {
+            double jr = 0.0, jc = 0.0;
+            for (int q = 0; q < p; ++q) { jr += Jc[i * 8 + q] * (double)G[q + r * p]; jc += Jc[i * 8 + q] * (double)G[q + cc * p]; }
+            s += jr * jc;
+          }
+          const double* Hc = Hm + cidx * 16;       // + G^T (d/dz J^T z_proj) G   (knotpoint_data.cpp:561-567)
+          for (int i = 0; i < p; ++i) {
+            double hc = 0.0;
+            for (int q = 0; q < p; ++q) hc += Hc[i * 4 + q] * (double)G[q + cc * p];
+            s += (double)G[i + r * p] * hc;
+          }
+        }
+      }
+      v += rho * s;
+      if (r < n) a.Q[(int64_t)b * a.Q_bs + (int64_t)k * n * n + r + cc * n] = (T)v;
+      else if (cc < n) a.H[(int64_t)b * a.H_bs + (int64_t)k * m * n + (r - n) + cc * m] = (T)v;
+      else a.R[(int64_t)b * a.R_bs + (int64_t)k * m * m + (r - n) + (cc - n) * m] = (T)v;
+    }
+  }
+}
+
+// DualUpdate (knotpoint_data.cpp:503-510) for the problems whose sweep asked for it, one wave per (problem, knot point)
+template <typename T>
+__global__ __launch_bounds__(64) void generic_dual_update_kernel(IlqrGenArgs<T> a) {
+  __shared__ double xs[GEN_MAX], us[GEN_MAX], jv[AL_MAXC * AL_MAXP];
+  const int lane = threadIdx.x;
+  const int64_t wk = blockIdx.x;
+  const int b = (int)(wk % a.batch), k = (int)(wk / a.batch);
+  const int n = a.n, m = a.m, N = a.N;
+  if (k > N || !a.al.enabled) return;
+  if (!a.prob[b].dual) return;
+  const bool terminal = k == N;
+  if (lane < n) xs[lane] = (double)a.x[(int64_t)b * a.x_bs + (int64_t)k * n + lane];
+  if (lane >= 32 && lane - 32 < m) us[lane - 32] = terminal ? 0.0 : (double)a.u[(int64_t)b * a.u_bs + (int64_t)k * m + lane - 32];
+  __syncthreads();
+  double cost = 0.0, viol = 0.0;
+  gen_al_rows<T>(a.al, k, b, a.batch, n, m, xs, us, terminal, a.prob[b].rho_est, lane, jv, nullptr, nullptr, cost, viol, true);
 }
 
 // ALTROSolver::ShiftTrajectory (altro_solver.cpp:283-293) on the candidate trajectory

@@ -261,7 +261,8 @@ int altro_hip_get_expansion(altro_hip_batch* h, double* A, double* B, double* lx
  * cone: ConstraintType order of typedefs.hpp:29-34: 0 EQUALITY, 1 IDENTITY, 2 INEQUALITY (c <= 0),
  * 3 SECOND_ORDER_CONE (||c[0:p-1]|| <= c[p-1]).  At most 2 blocks per knot point, p <= 8 (SOC: p <= 4).
  * Returns the block id (>= 0) or a negative error.  Duals and penalties live on the device per problem and,
- * like the reference's, persist from one solve to the next (warm-started MPC) until reset.             */
+ * like the reference's, persist from one solve to the next (warm-started MPC) until reset.  Every plan (GENERIC since round 4:
+ * any n, m <= 32, one wave per knot point).                                                              */
 int altro_hip_add_linear_constraint(altro_hip_batch* h, int k_first, int k_last, int cone, int p,
                                     const double* G, const double* g, int g_per_problem);
 int altro_hip_clear_constraints(altro_hip_batch* h);

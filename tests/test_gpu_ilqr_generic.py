@@ -132,9 +132,68 @@ def test_whole_lq_solves_generic(n, m, dense, dtype):
         np.testing.assert_allclose(u2[b], s.get("u"), rtol=1e-8, atol=1e-8)
 
 
+def _blocks(N, n, m, soc):
+    """|u_i| <= 0.3 for the first four inputs (two INEQUALITY blocks share a knot point with nothing else; a third kind rides on other
+    knot points): x1 <= 1.2 and -x2 <= 1.2 at 1 <= k < N ... as far as two blocks per knot point allow: bounds everywhere, the state
+    half-spaces where no equality block sits, u_0[0] == 0.05 at k = 0, a second-order cone on (u_0, u_1, u_2 ; 0.35) instead of the
+    half-spaces when `soc`, and a terminal half-space block."""
+    w = n + m
+    Gb = np.zeros((8, w)); Gb[:4, n:n + 4] = np.eye(4); Gb[4:, n:n + 4] = -np.eye(4)
+    Gs = np.zeros((2, w)); Gs[0, 1] = 1.0; Gs[1, n - 1] = -1.0
+    Ge = np.zeros((1, w)); Ge[0, n] = 1.0
+    Gt = np.zeros((3, w)); Gt[0, 0] = 1.0; Gt[1, 1] = -1.0; Gt[2, n - 2] = 1.0
+    out = [(0, N - 1, altro_amd.CONE_INEQUALITY, Gb, np.full(8, 0.3)), (0, 0, altro_amd.CONE_EQUALITY, Ge, np.array([0.05])),
+           (N, N, altro_amd.CONE_INEQUALITY, Gt, np.array([0.4, 0.4, 0.2]))]
+    if soc:
+        Gc = np.zeros((4, w)); Gc[0, n + 1] = 1.0; Gc[1, n + 2] = 1.0; Gc[2, n + 3] = 1.0
+        out.append((1, N - 1, altro_amd.CONE_SOC, Gc, np.array([0.0, 0.0, 0.0, -0.35])))
+    else:
+        out.append((1, N - 1, altro_amd.CONE_INEQUALITY, Gs, np.array([1.2, 1.2])))
+    return out
+
+
+@pytest.mark.parametrize("n,m,dense,soc,backtracking", [(14, 5, False, False, False), (16, 6, True, False, True), (13, 5, False, True, False),
+                                                         (20, 8, True, True, False)])
+def test_constrained_solves_generic(n, m, dense, soc, backtracking):
+    """Constraint blocks on plan GENERIC (knotpoint_data.cpp:489-613, solver.cpp:383-409, 470-489 for shapes beyond the tile):
+    inequality / equality blocks, a second-order cone, a terminal block, two blocks per knot point -- whole AL-iLQR solves against
+    the oracle per problem: same status, iterations and dual updates, feasibility, trajectories 1e-7; the duals themselves 1e-6."""
+    N, batch = 16, 9
+    p, bt = make(batch, N, n, m, dense)
+    blocks = _blocks(N, n, m, soc)
+    for (k0, k1, cone, G, g) in blocks:
+        bt.add_linear_constraint(k0, k1, cone, G, g)
+    res = bt.ilqr_solve(iterations_max=60, penalty_initial=1.0, penalty_scaling=10.0, use_backtracking=backtracking)
+    x, u = bt.get_nominal()
+    assert (res["dual_updates"] > 0).all()
+    nconv = 0
+    for b in [0, 4, 8]:
+        s = make_oracle(p, b, N, n, m, dense)
+        for (k0, k1, cone, G, g) in blocks:
+            for k in range(k0, k1 + 1):
+                s.add_linear_constraint(k, cone, G, g)
+        s.L.oracle_ilqr_initialize(s.h)
+        for k in range(N):
+            s.L.oracle_ilqr_set_input(s.h, k, np.ascontiguousarray(p["u0"][b, k]))
+        s.set_penalty(1.0, 10.0)
+        s.L.oracle_ilqr_set_options(s.h, 60, 1e-4, 1e-4, 1e-8, 1 if backtracking else 0)
+        status, iters, log = s.solve()
+        assert res["status"][b] == status and res["iterations"][b] == iters, (b, res["status"][b], status, res["iterations"][b], iters)
+        if status != 0:
+            continue
+        nconv += 1
+        assert abs(res["feasibility"][b] - log[iters - 1, 6]) <= 1e-9 + 1e-3 * log[iters - 1, 6]
+        np.testing.assert_allclose(x[b], s.get("x"), rtol=1e-7, atol=1e-7)
+        np.testing.assert_allclose(u[b], s.get("u"), rtol=1e-6, atol=1e-6)
+        assert np.abs(u[b][:, :4]).max() <= 0.3 + 2e-4 and abs(u[b][0, 0] - 0.05) < 2e-4
+    assert nconv >= 1
+    assert (bt.feasibility() >= 0.0).all()
+    z = bt.get_duals(0, 0, 8)
+    assert z.shape == (batch, 8) and (z <= 1e-12).all()      # duals of an INEQUALITY block live in the non-positive orthant
+    bt.close()
+
+
 def test_generic_plan_says_what_it_does_not_do():
     bt = altro_amd.Batch(10, 16, 5, 4)
-    with pytest.raises(altro_amd.AltroHipError):
-        bt.add_linear_constraint(0, 9, altro_amd.CONE_INEQUALITY, np.zeros((2, 21)), np.zeros(2))   # constraint blocks: LANE / MFMA16
     with pytest.raises(altro_amd.AltroHipError):
         bt.set_model(altro_amd.MODEL_BICYCLE, 0.1)
