@@ -36,7 +36,6 @@ constexpr int MD_NOM0 = MD_F0 + 12;          // 372
 constexpr int MD_CP0 = MD_NOM0 + MF_NOM;     // 388
 constexpr int MD_IMG = MD_CP0 + MF_COSTP;    // 424
 constexpr int MD_IMG_DENSE = MD_CP0 + MF_COST;   // 548: a dense quadratic cost's record (IlqrWaveArgs::costd) instead of the 36 parameters
-constexpr int MD_GPOOL = 512;                // doubles of LDS for the constraint Jacobians (four blocks of 8 x 16)
 static_assert(MF_DYN % 2 == 0 && MF_OUT % 2 == 0 && MF_NOM % 2 == 0 && MF_COSTP % 2 == 0 && MD_IMG % 2 == 0, "records move as pairs");
 
 typedef double md_d2 __attribute__((ext_vector_type(2)));
@@ -161,9 +160,7 @@ __device__ __forceinline__ void md_gather4(double v, double (&o)[4]) {
 // (DU: DualUpdate, knotpoint_data.cpp:503-510 -- the projected dual becomes the dual; `store`: this row has a problem of its own)
 template <typename S, bool DU = false, bool SOC = true>
 __device__ __forceinline__ void dpp_al_rows(const AlTable<S>& t, int k, int b, int64_t B, double w, bool terminal, double rho_est, int j,
-                                            double (&jvr)[AL_MAXC], double& cost, double& viol, bool store = false,
-                                            const double* Gl = nullptr,     // Gl: the G pool in LDS (the sweeps keep it there)
-                                            const double (*pre)[2] = nullptr) {   // pre: this knot point's (z_i, g_i), fetched a step ahead
+                                            double (&jvr)[AL_MAXC], double& cost, double& viol, bool store = false) {
   int zshift;
   const AlKnot ALTRO_CONST_AS& kn = al_knot<S>(t, k, zshift);
 #pragma unroll
@@ -175,29 +172,16 @@ __device__ __forceinline__ void dpp_al_rows(const AlTable<S>& t, int k, int b, i
     const bool rl = j < p;                          // this lane owns a row of the block
     const int jr = rl ? j : 0;
     double cG[16];
-    if (Gl) {
-      const double* Gc = Gl + kn.G_off[c];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const double ge = Gc[jr + e * p];
-        cG[e] = (rl && !(terminal && e >= 12)) ? ge : 0.0;
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const double ge = (double)G[jr + e * p];
-        cG[e] = (rl && !(terminal && e >= 12)) ? ge : 0.0;
-      }
+    for (int e = 0; e < 16; ++e) {
+      const double ge = (double)G[jr + e * p];
+      cG[e] = (rl && !(terminal && e >= 12)) ? ge : 0.0;
     }
     double sacc = 0.0;
     md_chain16(sacc, w, cG);
     S* const zp_ = t.z + (int64_t)(kn.z_off[c] + zshift + jr) * B + b;
-    double gi, zi;
-    if (pre) { zi = pre[c][0]; gi = pre[c][1]; }
-    else {
-      gi = rl ? (kn.g_per_problem[c] ? (double)t.g[kn.g_off[c] + (int64_t)jr * B + b] : (double)t.g[kn.g_off[c] + jr]) : 0.0;
-      zi = (double)*zp_;
-    }
+    const double gi = rl ? (kn.g_per_problem[c] ? (double)t.g[kn.g_off[c] + (int64_t)jr * B + b] : (double)t.g[kn.g_off[c] + jr]) : 0.0;
+    const double zi = (double)*zp_;
     const double val = sacc - gi;
     const double ze = rl ? zi - rho_est * val : 0.0;
     if (!SOC || cone != CONE_SOC) {   // (!SOC: the handle has no second-order cone -- al.has_soc -- and the cone's code is not in the kernel)
@@ -239,54 +223,6 @@ __device__ __forceinline__ void dpp_al_rows(const AlTable<S>& t, int k, int b, i
     }
   }
 }
-// (z_i, g_i) of knot point k for dpp_al_rows: the duals sit in [row][batch] arrays, a fresh line per knot point and row -- the sweeps
-// fetch them one step ahead so that the row's chain does not wait for them at every knot point
-template <typename S>
-__device__ __forceinline__ void dpp_al_fetch(const AlTable<S>& t, int k, int b, int64_t B, int j, double (&zg)[AL_MAXC][2]) {
-  int zshift;
-  const AlKnot ALTRO_CONST_AS& kn = al_knot<S>(t, k, zshift);
-#pragma unroll
-  for (int c = 0; c < AL_MAXC; ++c) {
-    zg[c][0] = 0.0; zg[c][1] = 0.0;
-    if (c >= kn.ncon) continue;
-    const int p = kn.p[c];
-    const bool rl = j < p;
-    const int jr = rl ? j : 0;
-    zg[c][0] = (double)t.z[(int64_t)(kn.z_off[c] + zshift + jr) * B + b];
-    zg[c][1] = rl ? (kn.g_per_problem[c] ? (double)t.g[kn.g_off[c] + (int64_t)jr * B + b] : (double)t.g[kn.g_off[c] + jr]) : 0.0;
-  }
-}
-template <typename S>
-__device__ __forceinline__ double dpp_al_col(const AlTable<S>& t, int k, int j, const double (&jvr)[AL_MAXC], const double* Gl = nullptr) {
-  int zshift;
-  const AlKnot ALTRO_CONST_AS& kn = al_knot<S>(t, k, zshift);
-  double s = 0.0;
-#pragma unroll
-  for (int c = 0; c < AL_MAXC; ++c) {
-    if (c >= kn.ncon) continue;
-    const int p = kn.p[c];
-    const S* G = t.G + kn.G_off[c];
-    double cC[8];
-    if (Gl) {
-      const double* Gc = Gl + kn.G_off[c];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const double gi = Gc[(i < p ? i : 0) + j * p];
-        cC[i] = i < p ? gi : 0.0;
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const double gi = (double)G[(i < p ? i : 0) + j * p];
-        cC[i] = i < p ? gi : 0.0;
-      }
-    }
-    md_chain8(s, jvr[c], cC);
-  }
-  return s;
-}
-
-
 // ---- the same rows for the sweeps of wave_merit_dpp_kernel: what a knot point's chain does not have to wait for, it does not ----
 // * the table entry of a knot point (AlKnot, constant address space) is read ONCE per knot point into scalar registers (AlpKnot)
 //   and handed to the three users (duals a step ahead, rows, gradient columns) -- for the usual uniform table once per sweep;
@@ -294,7 +230,8 @@ __device__ __forceinline__ double dpp_al_col(const AlTable<S>& t, int k, int j, 
 //   rows >= p and row 8 are zero -- as eight 16-byte reads, and any column as eight 8-byte ones, with no select per element;
 // * a lane that owns no row carries exact zeros through the same arithmetic instead of branching around it (val = ze = 0:
 //   cost share + 0, violation max(., 0), J^T z_proj = 0).
-// Same values, same expressions, same order of the sums as dpp_al_rows / dpp_al_col: bit-identical (tests/test_gpu_merit2.py).
+// Same values, same expressions, same order of the sums as dpp_al_rows (and as wave_al_rows / wave_al_col of the LDS form):
+// bit-identical (tests/test_gpu_merit2.py).
 struct AlpKnot {
   int ncon, p[AL_MAXC], cone[AL_MAXC], gp_off[AL_MAXC], z_off[AL_MAXC], gpp[AL_MAXC];
   int64_t g_off[AL_MAXC];
