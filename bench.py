@@ -525,9 +525,10 @@ def other_config_entry(key, device, steps, torch, cpu_seconds=2.0):
     for r in (roof, roof_f):
         r.pop("note", None); r.pop("duration_source", None)
     if cfg != "c4" and batch <= 8192:
-        roof["bound_in_practice"] = ("dependent-issue latency, not HBM: %d waves on 1024 SIMDs walk N = %d dependent steps; one wave's chain "
-                                    "issues an instruction every ~6.5 cycles with SQ_WAIT_INST_ANY ~ 0 (profiles/r01l_lane_pmc_one_wave.txt), "
-                                    "so `frac` is reported for reference only" % ((batch + 15) // 16 if n == 4 else (batch + 15) // 16, N))
+        roof["bound_in_practice"] = ("instruction issue of one wave per SIMD, not HBM: %d waves on 1024 SIMDs walk N = %d dependent steps; "
+                                    "SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES = 0.72-0.75, SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES = 0.05-0.12 "
+                                    "(profiles/r04zf_quad_pmc.txt: 559 VALU instructions per knot point and wave for (4, 2)), half the SIMDs idle -- "
+                                    "so `frac` is reported for reference only" % ((batch + 15) // 16, N))
     out = {"workload": {"c2": "C2 pendulum swing-up (BASELINE.json configs[2]): TVLQR sweep on the expansion at the initial rollout",
                         "c3": "C3 bicycle tracking + steering bound (BASELINE.json configs[3]): TVLQR sweep on the expansion at the initial rollout",
                         "c4": "C4 random LTV TVLQR sweep, pure fp32 (BASELINE.json configs[4])"}[cfg],
