@@ -375,3 +375,72 @@ def test_dense_cost_equals_tracking_cost_when_diagonal():
     assert np.array_equal(ra["iterations"], rd["iterations"])
     np.testing.assert_allclose(d.get_nominal()[0], a.get_nominal()[0], rtol=1e-11, atol=1e-11)
     np.testing.assert_allclose(d.get_nominal()[1], a.get_nominal()[1], rtol=1e-10, atol=1e-10)
+
+
+n12, m4 = 12, 4
+
+
+def test_full_size_c1_dense_cost_properties():
+    """BASELINE.json configs[1] at full size (N = 256, n = 12, m = 4, 4096 problems) with the general quadratic cost in the device loop:
+    size-independent checks.  (1) an LQ problem with a dense cost converges in one sweep with alpha = 1 for every problem, and its
+    KKT residual |lx + A^T y+ - y|, |lu + B^T y+| with lx = Q x + H^T u + q, lu = R u + H x + r (knotpoint_data.cpp:659-668), recomputed
+    in numpy from the returned trajectory and duals, vanishes; (2) a seeded sample of problems against the oracle; (3) with diagonal
+    Q, R and H = 0 the solve is the tracking cost's, bit for bit, for all 4096 problems."""
+    batch, Nf = 4096, 256
+    one = problems.c1_double_integrator(1, N=Nf)
+    x0 = 2.0 * problems.uniform01((batch, n12), 21) - 1.0
+    c = problems.quadratic_cost(1, Nf, n12, m4, stream=311)
+
+    def handle():
+        bt = altro_amd.Batch(Nf, n12, m4, batch)
+        assert bt.plan == altro_amd.PLAN_MFMA16
+        bt.set_dynamics(one["A"][0, :1], one["B"][0, :1], None, k_stride_zero=True, batch_stride_zero=True)
+        bt.set_initial_state(x0)
+        bt.set_input_guess(np.zeros((1, 1, m4)), k_stride_zero=True, batch_stride_zero=True)
+        return bt
+
+    bt = handle()
+    bt.set_quadratic_cost(c["Q"], c["R"], c["H"], c["q"], c["r"], c["c"], batch_stride_zero=True)
+    res = bt.ilqr_solve(iterations_max=10)
+    assert (res["status"] == 0).all() and (res["iterations"] == 1).all() and (res["alpha"] == 1.0).all()
+    x, u = bt.get_nominal()
+    y = bt.get("y")
+    A = one["A"][0, 0].reshape(n12, n12).T; B = one["B"][0, 0].reshape(m4, n12).T
+    Q = c["Q"][0].reshape(Nf + 1, n12, n12).transpose(0, 2, 1); R = c["R"][0].reshape(Nf, m4, m4).transpose(0, 2, 1)
+    H = c["H"][0].reshape(Nf, n12, m4).transpose(0, 2, 1)                      # [k][m][n]
+    lx = np.einsum("kij,bkj->bki", Q, x) + c["q"][0][None]
+    lx[:, :Nf] += np.einsum("kij,bki->bkj", H, u)
+    lu = np.einsum("kij,bkj->bki", R, u) + np.einsum("kij,bkj->bki", H, x[:, :Nf]) + c["r"][0][None]
+    res_x = lx[:, :Nf] + y[:, 1:] @ A - y[:, :Nf]
+    res_u = lu + y[:, 1:] @ B
+    res_N = lx[:, Nf] - y[:, Nf]
+    scale = max(1.0, float(np.abs(y).max()))
+    assert max(np.abs(res_x).max(), np.abs(res_u).max(), np.abs(res_N).max()) / scale < 1e-9
+    for b in (0, 2222, 4095):
+        s = oracle.ILQR(Nf, n12, m4, 0.01, oracle.DYN_LINEAR, cost_kind=oracle.COST_QUADRATIC)
+        s.L.oracle_ilqr_set_linear_dynamics(s.h, np.ascontiguousarray(np.tile(one["A"][0, :1], (Nf, 1))), np.ascontiguousarray(np.tile(one["B"][0, :1], (Nf, 1))), None)
+        for k in range(Nf + 1):
+            kk = min(k, Nf - 1)
+            s.L.oracle_ilqr_set_quadratic_cost(s.h, k, np.ascontiguousarray(c["Q"][0, k]), np.ascontiguousarray(c["R"][0, kk]).ctypes.data,
+                                               np.ascontiguousarray(c["H"][0, kk]).ctypes.data, np.ascontiguousarray(c["q"][0, k]),
+                                               np.ascontiguousarray(c["r"][0, kk]).ctypes.data, float(c["c"][0, k]))
+        s.L.oracle_ilqr_set_initial_state(s.h, np.ascontiguousarray(x0[b]))
+        s.L.oracle_ilqr_initialize(s.h)
+        for k in range(Nf):
+            s.L.oracle_ilqr_set_input(s.h, k, np.zeros(m4))
+        s.L.oracle_ilqr_set_options(s.h, 10, 1e-4, 1e-4, 1e-8, 0)
+        status, iters, log = s.solve()
+        assert status == 0 and iters == 1
+        np.testing.assert_allclose(x[b], s.get("x"), rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(u[b], s.get("u"), rtol=1e-8, atol=1e-8)
+    bt.close()
+    # (3) diagonal blocks: the tracking cost's solve
+    Qd = np.stack([np.ones(n12), 100.0 * np.ones(n12)]); Rd = np.full((1, m4), 1e-2)
+    bt1 = handle()
+    bt1.set_tracking_cost(Qd, Rd, np.zeros((2, n12)), np.zeros((1, m4)), k_stride_zero=True, batch_stride_zero=True)
+    r1 = bt1.ilqr_solve(iterations_max=10); x1, u1 = bt1.get_nominal(); bt1.close()
+    bt2 = handle()
+    bt2.set_quadratic_cost(np.stack([np.diag(Qd[0]).reshape(-1), np.diag(Qd[1]).reshape(-1)]), np.diag(Rd[0]).reshape(1, -1), np.zeros((1, m4 * n12)),
+                           np.zeros((2, n12)), np.zeros((1, m4)), np.zeros(2), k_stride_zero=True, batch_stride_zero=True)
+    r2 = bt2.ilqr_solve(iterations_max=10); x2, u2 = bt2.get_nominal(); bt2.close()
+    assert np.array_equal(r1["iterations"], r2["iterations"]) and np.array_equal(x1, x2) and np.array_equal(u1, u2)
