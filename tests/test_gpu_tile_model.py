@@ -287,3 +287,54 @@ def test_padded_user_model_tile_plan_equals_plan_lane():
     assert same.sum() >= batch - 1, (ra["iterations"], rb["iterations"])     # (a convergence test at rounding level may move by one sweep)
     np.testing.assert_allclose(xa[same], xb[same], rtol=1e-7, atol=1e-7)
     np.testing.assert_allclose(ua[same], ub[same], rtol=1e-6, atol=1e-6)
+
+
+def test_full_size_quadrotor_rollout_and_expansion():
+    """The tile plan's device model at BASELINE.json configs[1]'s size (4096 problems, N = 256): size-independent checks.  The open-loop
+    rollout of every problem is finite and, for a seeded sample, equals the explicit-midpoint integration of the same equations in numpy
+    (1e-11); the expansion's A_k, B_k equal central differences of that numpy step (1e-6) at sampled knot points."""
+    batch, Nf = 4096, 256
+    mass, grav, ix, iy, iz = 0.5, 9.81, 0.0023, 0.0023, 0.004
+
+    def f_cont(x, u):
+        sp, cp, st, ct, ss, cs = np.sin(x[3]), np.cos(x[3]), np.sin(x[4]), np.cos(x[4]), np.sin(x[5]), np.cos(x[5])
+        tt = st / ct
+        wx, wy, wz = x[9], x[10], x[11]
+        a = u[0] / mass
+        return np.array([x[6], x[7], x[8], wx + sp * tt * wy + cp * tt * wz, cp * wy - sp * wz, (sp * wy + cp * wz) / ct,
+                         a * (cp * st * cs + sp * ss), a * (cp * st * ss - sp * cs), a * (cp * ct) - grav,
+                         (u[1] - (iz - iy) * wy * wz) / ix, (u[2] - (ix - iz) * wz * wx) / iy, (u[3] - (iy - ix) * wx * wy) / iz])
+
+    hd = float(np.float32(0.01)); h2 = float(np.float32(0.01) / np.float32(2))
+    step = lambda x, u: x + hd * f_cont(x + h2 * f_cont(x, u), u)   # noqa: E731
+    x0 = np.zeros((batch, n))
+    x0[:, :3] = 0.5 * problems.normal((batch, 3), 191)
+    x0[:, 3:6] = 0.1 * problems.normal((batch, 3), 192)
+    x0[:, 6:9] = 0.2 * problems.normal((batch, 3), 193)
+    x0[:, 9:] = 0.1 * problems.normal((batch, 3), 194)
+    u = HOVER[None, None] + np.array([0.3, 0.002, 0.002, 0.002]) * problems.normal((batch, Nf, m), 195)
+    bt = altro_amd.Batch(Nf, n, m, batch)
+    bt.set_model(altro_amd.MODEL_QUADROTOR, np.float32(0.01))
+    Qd = np.ones(n)
+    bt.set_tracking_cost(np.stack([Qd, Qd]), np.ones((1, m)), np.zeros((2, n)), HOVER[None], k_stride_zero=True, batch_stride_zero=True)
+    bt.set_initial_state(x0)
+    bt.set_input_guess(u)
+    bt.open_loop_rollout(); bt.accept(); bt.expand()
+    x, _ = bt.get_nominal()
+    assert np.isfinite(x).all()
+    A, B, _, _ = bt.get_expansion()
+    for b in (0, 1234, 4095):
+        xr = np.zeros((Nf + 1, n)); xr[0] = x0[b]
+        for k in range(Nf):
+            xr[k + 1] = step(xr[k], u[b, k])
+        np.testing.assert_allclose(x[b], xr, rtol=1e-11, atol=1e-11)
+        for k in (0, 100, 255):
+            Ak = A[b, k].reshape(n, n).T; Bk = B[b, k].reshape(m, n).T
+            eps = 1e-6
+            for j in range(n):
+                e = np.zeros(n); e[j] = eps
+                np.testing.assert_allclose(Ak[:, j], (step(xr[k] + e, u[b, k]) - step(xr[k] - e, u[b, k])) / (2 * eps), rtol=1e-6, atol=1e-6)
+            for j in range(m):
+                e = np.zeros(m); e[j] = eps
+                np.testing.assert_allclose(Bk[:, j], (step(xr[k], u[b, k] + e) - step(xr[k], u[b, k] - e)) / (2 * eps), rtol=1e-6, atol=1e-6)
+    bt.close()
