@@ -3,14 +3,14 @@
 right-hand sides, terminal blocks, both line searches) against the oracle's restatement of SolverImpl, problem by problem: status,
 iterations, dual updates; trajectories where both converged.
 
-    python tools/fuzz_generic_al.py [cases] [seed]
+    python tests/soak/fuzz_generic_al.py [cases] [seed]
 """
 import os
 import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import altro_amd  # noqa: E402
 from oracle import oracle  # noqa: E402
 from tests import problems  # noqa: E402

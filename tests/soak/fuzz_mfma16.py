@@ -2,7 +2,7 @@
 """One-off soak: plan MFMA16 (packed symmetric records, XCD-aware mapping) against the oracle on random shapes."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import altro_amd
 from tests import problems
 from tests.test_gpu_parity import run_hip, run_oracle, relerr

@@ -1,7 +1,7 @@
 """The merit function of the sweep in which a straggler of bench.py's constrained C1 workload leaves the oracle's path:
 phi(alpha), phi'(alpha) on the device and in the oracle at the same steps, from the same state (both after `it` sweeps).
 
-    PYTHONPATH=. python tools/straggler_merit.py 118 7
+    PYTHONPATH=. python tests/soak/straggler_merit.py 118 7
 """
 import sys
 

@@ -1,6 +1,6 @@
 """Iteration-by-iteration trace of problems of bench.py's constrained C1 workload (|u| <= 2) on the device against the oracle.
 
-    python tools/straggler_trace.py 118 [more problem indices]
+    python tests/soak/straggler_trace.py 118 [more problem indices]
 
 For every i = 1 .. the device solve is repeated from scratch with iterations_max = i (duals reset), so that the state after
 i iterations can be read from the per-problem results; the oracle's log has one row per iteration.

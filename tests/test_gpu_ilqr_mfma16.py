@@ -405,7 +405,7 @@ def test_bench_constrained_workload_sample_vs_oracle():
     sample of 32 problems INCLUDING the batch's stragglers (the problems that did not end in Success, the ones with the most
     iterations and dual updates) goes through oracle.ILQR one by one.
 
-    What the batch's non-converged problems are (tools/straggler_trace.py prints the iterations): after a penalty update one
+    What the batch's non-converged problems are (tests/soak/straggler_trace.py prints the iterations): after a penalty update one
     sweep's line search works at the resolution of the merit function itself -- e.g. phi(0) = 125.5648687, phi'(0) = -1.3e-3,
     accepted step ~1.5e-3 after 16 evaluations, i.e. a sufficient-decrease margin c1 alpha phi' ~ 2e-10 against values of 1e2 whose
     last digits (1e-13 relative) differ between any two orders of summation.  Device and oracle then resolve the search
