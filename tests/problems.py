@@ -151,7 +151,8 @@ def di_constraint_blocks(kind, N, n=4, m=2, xf=None, u_bnd=1.0):
 def bicycle_reference(steps, h=0.1, v=6.3):
     """Seed-free synthetic reference path: the CoG bicycle (L = 2.7, lr = 1.5) rolled out with speed v and
     steering rate 0.05 sin(0.2 t) by the explicit midpoint rule.  (The reference's own test tracks the
-    'scotty' data file, which is not copied.)  Returns x_ref [steps + 1, 4], u_ref [steps, 2]."""
+    'scotty' path: tests/golden/scotty_reference.json, `scotty()` below, tracked by tests/test_oracle_mpc.py and
+    tests/test_gpu_scotty.py.)  Returns x_ref [steps + 1, 4], u_ref [steps, 2]."""
     L, lr = 2.7, 1.5
 
     def f(x, u):
@@ -167,6 +168,22 @@ def bicycle_reference(steps, h=0.1, v=6.3):
         x = x + h * f(xm, u)
         xs.append(x.copy()); us.append(u)
     return np.array(xs), np.array(us)
+
+
+def scotty():
+    """The reference's own MPC scenario as data (tests/golden/make_scotty_fixtures.py): the path of test/scotty.json
+    (501 points, spacing 0.1 s) and what test/bicycle_test.cpp:266-359 saved after tracking it for 200 receding-horizon
+    steps.  Returns x_ref [501, 4], u_ref [501, 2], expected {solve_iters, state_trajectory, input_trajectory,
+    tracking_error} as arrays."""
+    import json
+    import os
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    with open(os.path.join(g, "scotty_reference.json")) as f:
+        ref = json.load(f)
+    with open(os.path.join(g, "scotty_mpc_expected.json")) as f:
+        mpc = json.load(f)
+    exp = {k: np.array(mpc[k]) for k in ("solve_iters", "state_trajectory", "input_trajectory", "tracking_error")}
+    return np.array(ref["state_trajectory"]), np.array(ref["input_trajectory"]), exp
 
 
 # ---- (12, 4) iLQR problems with dynamics given as data (plan MFMA16; tests/test_gpu_ilqr_mfma16.py) --------------------
