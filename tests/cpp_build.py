@@ -20,7 +20,7 @@ def build(name, extra_sources=(), extra_link=()):
     return out
 
 
-def run(name, extra_sources=(), timeout=300, extra_link=()):
+def run(name, extra_sources=(), timeout=300, extra_link=(), args=()):
     exe = build(name, extra_sources, extra_link)
-    p = subprocess.run([exe], capture_output=True, text=True, timeout=timeout)
+    p = subprocess.run([exe] + [str(a) for a in args], capture_output=True, text=True, timeout=timeout)
     return p.returncode, p.stdout, p.stderr
