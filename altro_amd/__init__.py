@@ -33,7 +33,7 @@ C_ABI_SYMBOLS = [
     "altro_hip_profile_enable", "altro_hip_profile_reset",
     "altro_hip_profile_get", "altro_hip_profile_get_range", "altro_hip_profile_dropped", "altro_hip_algorithmic_bytes",
     "altro_hip_set_model", "altro_hip_set_model_source", "altro_hip_set_tracking_cost", "altro_hip_set_quadratic_cost",
-    "altro_hip_set_input_guess",
+    "altro_hip_set_input_guess", "altro_hip_set_state_guess",
     "altro_hip_open_loop_rollout", "altro_hip_accept", "altro_hip_expand", "altro_hip_merit",
     "altro_hip_stationarity", "altro_hip_get_nominal", "altro_hip_get_expansion",
     "altro_hip_default_solve_options", "altro_hip_ilqr_solve", "altro_hip_last_solve_counts",
@@ -168,6 +168,7 @@ def lib():
         L.altro_hip_set_tracking_cost.argtypes = [vp, vp, vp, vp, vp, i, i]
         L.altro_hip_set_quadratic_cost.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i]
         L.altro_hip_set_input_guess.argtypes = [vp, vp, i, i]
+        L.altro_hip_set_state_guess.argtypes = [vp, vp, i, i]
         for fn in ("open_loop_rollout", "accept", "expand"):
             getattr(L, "altro_hip_" + fn).argtypes = [vp]
         L.altro_hip_merit.argtypes = [vp, vp, i, i, vp, vp]
@@ -369,6 +370,11 @@ class Batch:
     def set_input_guess(self, u, k_stride_zero=False, batch_stride_zero=False):
         a, pa = _in(u)
         _check(self.L.altro_hip_set_input_guess(self.h, pa, int(k_stride_zero), int(batch_stride_zero)))
+
+    def set_state_guess(self, x, k_stride_zero=False, batch_stride_zero=False):
+        """ALTROSolver::SetState: x [.][N+1][n] into the candidate states."""
+        a, pa = _in(x)
+        _check(self.L.altro_hip_set_state_guess(self.h, pa, int(k_stride_zero), int(batch_stride_zero)))
 
     def open_loop_rollout(self):
         _check(self.L.altro_hip_open_loop_rollout(self.h))

@@ -182,6 +182,9 @@ static int batch_create_impl(altro_hip_batch** out, int N, int n, int m, int bat
       h->g_bstride[a] = at;
       if (qb && !(flags & ALTRO_HIP_STORE_QBLOCKS)) continue;
       ALLOC(h->g_arr[a], B * (size_t)at * E);
+      // candidate trajectory: defined (zero) from the start, so altro_hip_set_input_guess / _set_state_guess may come in any order with the cost
+      if (!rc && (a == G_u || a == G_x || a == G_y) && hipMemsetAsync(h->g_arr[a], 0, B * (size_t)at * E, h->stream) != hipSuccess)
+        rc = fail(ALTRO_HIP_ERR_HIP, "memset failed");
     }
     ALLOC(h->g_off, off.size() * sizeof(int64_t));
     ALLOC(h->g_nx, (size_t)(N + 1) * sizeof(int));
@@ -386,6 +389,9 @@ int altro_hip_set_cost(altro_hip_batch* h, const double* Q, const double* R, con
     if (kz) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "k_stride_zero needs uniform dimensions");
     {   // where Q_k / R_k start: n_k (m_k) entries for a diagonal cost, n_k^2 (m_k^2) for a dense one, packed in the allocated blocks
       std::vector<int64_t> off((size_t)(N + 1) * G_NUM);
+      // a sweep enqueued by an earlier asynchronous altro_hip_backward still reads the table: the handle's stream is non-blocking, so
+      // the null-stream copies below would not wait for it
+      HIP_TRY(hipStreamSynchronize(h->stream));
       HIP_TRY(hipMemcpy(off.data(), h->g_off, off.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
       int64_t aq = 0, ar = 0;
       for (int k = 0; k <= N; ++k) {

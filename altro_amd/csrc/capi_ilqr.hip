@@ -316,15 +316,19 @@ int generic_cost_def(altro_hip_batch* h, const double* Q, const double* R, const
   const int nkx = kz ? 2 : N + 1, nku = kz ? 1 : N;
   const size_t B = h->batch, E = h->esz;
   int rc = 0;
-  if (!h->g_cQ) {
-    if ((rc = dmalloc(h, &h->g_cQ, B * (N + 1) * n * n * E)) || (rc = dmalloc(h, &h->g_cR, B * N * m * m * E)) ||
-        (rc = dmalloc(h, &h->g_cH, B * N * m * n * E)) || (rc = dmalloc(h, &h->g_cq, B * (N + 1) * n * E)) ||
-        (rc = dmalloc(h, &h->g_cr, B * N * m * E)) || (rc = dmalloc(h, &h->g_cc, B * (N + 1) * E)) ||
-        (rc = dmalloc(h, &h->g_xn, B * (N + 1) * n * E)) || (rc = dmalloc(h, &h->g_un, B * N * m * E)))
-      return rc;
-    HIP_TRY(hipMemsetAsync(h->g_xn, 0, B * (N + 1) * n * E, h->stream));
-    HIP_TRY(hipMemsetAsync(h->g_un, 0, B * N * m * E, h->stream));
-    HIP_TRY(hipMemsetAsync(h->g_arr[G_u], 0, B * N * m * E, h->stream));
+  {   // every array has its own guard: a failed allocation in the middle leaves the later pointers null and the next call retries them
+    // (one `if (!h->g_cQ)` around all eight skipped the retry and handed null arrays to the kernels)
+    struct { void** p; size_t bytes; bool zero; } want[] = {
+        {&h->g_cQ, B * (N + 1) * n * n * E, false}, {&h->g_cR, B * N * m * m * E, false}, {&h->g_cH, B * N * m * n * E, false},
+        {&h->g_cq, B * (N + 1) * n * E, false},     {&h->g_cr, B * N * m * E, false},     {&h->g_cc, B * (N + 1) * E, false},
+        {&h->g_xn, B * (N + 1) * n * E, true},      {&h->g_un, B * N * m * E, true}};
+    for (auto& w : want) {
+      if (*w.p) continue;
+      if ((rc = dmalloc(h, w.p, w.bytes))) return rc;
+      if (w.zero) HIP_TRY(hipMemsetAsync(*w.p, 0, w.bytes, h->stream));
+    }
+    // the candidate inputs (g_arr[G_u]) are NOT touched here: altro_hip_set_input_guess may come before the cost, like the reference's
+    // SetInput may; they are zeroed once, when the handle is created
   }
   auto put = [&](void* dst, int blk, int nk_total, const double* src, int nk_host, bool with_terminal) -> int {
     if (!src) { HIP_TRY(hipMemsetAsync(dst, 0, B * nk_total * blk * E, h->stream)); return 0; }
@@ -638,6 +642,23 @@ int altro_hip_set_input_guess(altro_hip_batch* h, const double* u, int kz, int b
            : lane_pack<float>(h, (float*)h->l_xuy, 2 * n + m, u, m, 2 * n, 0, N, 0, kz ? 1 : N, kz, bz);
   if (!rc) h->guess_set = true;
   return rc;
+}
+
+int altro_hip_set_state_guess(altro_hip_batch* h, const double* x, int kz, int bz) {
+  // ALTROSolver::SetState (altro_solver.cpp:229-240): writes the CANDIDATE states x_
+  int rc = loop_entry(h);
+  if (rc) return rc;
+  h->expansion_current = false;
+  if (!x) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "x == NULL");
+  const int n = h->n, m = h->m, N = h->N;
+  const bool f64 = h->dtype == ALTRO_HIP_F64;
+  if (h->plan == ALTRO_HIP_PLAN_GENERIC)
+    return f64 ? generic_set<double>(h, G_x, x, n, N + 1, kz, bz) : generic_set<float>(h, G_x, x, n, N + 1, kz, bz);
+  if (h->plan == ALTRO_HIP_PLAN_MFMA16)
+    return f64 ? aos_set<double>(h, (double*)h->m_xuy, h->m_st.xuy_bs, h->m_st.xuy_ks, x, n, N + 1, kz, bz)
+               : aos_set<float>(h, (float*)h->m_xuy, h->m_st.xuy_bs, h->m_st.xuy_ks, x, n, N + 1, kz, bz);
+  return f64 ? lane_pack<double>(h, (double*)h->l_xuy, 2 * n + m, x, n, 0, 0, N + 1, 0, kz ? 1 : N + 1, kz, bz)
+             : lane_pack<float>(h, (float*)h->l_xuy, 2 * n + m, x, n, 0, 0, N + 1, 0, kz ? 1 : N + 1, kz, bz);
 }
 
 int altro_hip_open_loop_rollout(altro_hip_batch* h) {

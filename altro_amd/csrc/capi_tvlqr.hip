@@ -222,6 +222,7 @@ bool mfma16_forward_is_x4(const altro_hip_batch* h) {
 
 int launch_forward(altro_hip_batch* h) {
   ProfScope ps(h, 1);
+  h->expansion_current = false;   // the sweep writes the candidate trajectory: whatever expansion a merit pass left is not of this point
   if (h->plan == ALTRO_HIP_PLAN_MFMA16) {
     if (h->dtype == ALTRO_HIP_F64) {
       auto a = mfma16_args<double>(h, 0.0);

@@ -81,7 +81,8 @@ typedef enum altro_hip_error {
 
 /* Which kernel family a handle runs.  AUTO: (12, 4) -> MFMA16; n <= 6, m <= 3 -> LANE; other n <= 12, m <= 4 -> MFMA16
  * (padded); anything larger (<= 32) -> GENERIC (the TVLQR sweep and the iLQR loop for dynamics given as data with a quadratic
- * cost, kernels/ilqr_generic.hip: correctness first; no device models, no constraint blocks, no regularisation retry). */
+ * cost and linear constraint blocks in every cone, kernels/ilqr_generic.hip: correctness first; no device models, no regularisation
+ * retry). */
 typedef enum altro_hip_plan {
   ALTRO_HIP_PLAN_AUTO = 0,
   ALTRO_HIP_PLAN_GENERIC = 1, /* wave-per-problem, LDS-staged, any (n, m) <= 32                */
@@ -190,7 +191,8 @@ int altro_hip_get_qblocks(altro_hip_batch* h, double* qblocks);
 
 /* ---- the iLQR loop around the sweep ------------------------------------------------------------------
  * Plan GENERIC (n or m beyond the tile, up to 32): dynamics are DATA, tracking or dense quadratic cost, MPC operations; one wave per
- * problem (kernels/ilqr_generic.hip).  Constraint blocks, device models and the regularisation retry: plans LANE / MFMA16.
+ * problem (kernels/ilqr_generic.hip), linear constraint blocks in every cone (round 4).  Device models and the regularisation retry:
+ * plans LANE / MFMA16.
  * Plan LANE (n <= 6: BASELINE.json configs[2], [3]): nonlinear dynamics from a compiled-in device model
  * (altro_hip_set_model), constraint blocks, MPC operations.
  * Plan MFMA16 ((n, m) = (12, 4): configs[1], [4]): dynamics are DATA -- the A, B, f given to
@@ -242,6 +244,10 @@ int altro_hip_set_quadratic_cost(altro_hip_batch* h, const double* Q, const doub
                                  const double* r, const double* c, int k_stride_zero, int batch_stride_zero);
 /* ALTROSolver::SetInput over all knot points (altro_solver.cpp:242-251): u [batch][N][m]             */
 int altro_hip_set_input_guess(altro_hip_batch* h, const double* u, int k_stride_zero, int batch_stride_zero);
+/* ALTROSolver::SetState over all knot points (altro_solver.cpp:229-240): x [batch][N+1][n] into the CANDIDATE states x_.  A whole
+ * solve overwrites them with its initial rollout (solver.cpp:421), so this matters to callers who sequence the phases themselves
+ * (accept / expand / backward / merit on a state trajectory that is not a rollout: solver_impl_test.cpp:186-271 does exactly that). */
+int altro_hip_set_state_guess(altro_hip_batch* h, const double* x, int k_stride_zero, int batch_stride_zero);
 int altro_hip_open_loop_rollout(altro_hip_batch* h); /* SolverImpl::OpenLoopRollout solver.cpp:116-131 */
 int altro_hip_accept(altro_hip_batch* h);            /* SolverImpl::CopyTrajectory  solver.cpp:148-157 */
 int altro_hip_expand(altro_hip_batch* h);            /* dynamics + cost expansion at the candidate     */
@@ -285,6 +291,9 @@ int altro_hip_update_linear_costs(altro_hip_batch* h, const double* q, const dou
                                   int k_first, int k_last, int kz, int bz);
 int altro_hip_get_knot(altro_hip_batch* h, int k, double* x /* [batch][n] */, double* u /* [batch][m] */);
 
+/* ALWAYS start from altro_hip_default_solve_options(&o) and change fields afterwards: the struct grows at its END between library
+ * versions (altro_hip_version(); stop_when_running_at_most came with version 200), and a caller that fills it field by field leaves
+ * the new fields uninitialised.                                                                                                  */
 typedef struct altro_hip_solve_options { /* AltroOptions, solver_options.hpp:16-39 */
   int iterations_max;
   double tol_stationarity;

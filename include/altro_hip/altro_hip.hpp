@@ -86,6 +86,9 @@ class BatchSolver {
   void SetInput(const double* u, bool shared_over_k = false, bool shared_over_batch = false) {
     Check(altro_hip_set_input_guess(h_, u, shared_over_k, shared_over_batch));
   }
+  void SetState(const double* x, bool shared_over_k = false, bool shared_over_batch = false) {
+    Check(altro_hip_set_state_guess(h_, x, shared_over_k, shared_over_batch));
+  }
   // ALTROSolver::SetConstraint for c = G [x;u] - g in `cone` at knot points k_start .. k_stop (inclusive);
   // G is p x (n+m) column-major; returns the block id
   int SetConstraint(int k_start, int k_stop, Cone cone, int p, const double* G, const double* g, bool g_per_problem = false) {

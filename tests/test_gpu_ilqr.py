@@ -255,3 +255,12 @@ def test_full_size_c2_pendulum_batch():
     x, u = bt.get_nominal()
     assert np.abs(x[:, -1, 0] - np.pi).max() < 0.2
     assert np.array_equal(x[3], x[4097])
+    # eight seeded problems of the full batch against the oracle solving each alone: status, iteration
+    # count, the whole trajectory at the solve tolerance of this file (2e-7: device vs glibc sin/cos through up to 20 sweeps)
+    for b in [0, 3, 1023, 4096, 4097, 5000, 7777, 8191]:
+        s = make_oracle(oracle.MODEL_PENDULUM, N, 2, 1, np.float32(0.03), [1e-2, 1e-2], [1e-3], [1.0, 1.0], xf, x0[b], [0.1])
+        s.L.oracle_ilqr_set_options(s.h, 30, 1e-4, 1e-4, 1e-8, 0)
+        status, iters, _ = s.solve()
+        assert res["status"][b] == status and res["iterations"][b] == iters, (b, res["status"][b], status, res["iterations"][b], iters)
+        np.testing.assert_allclose(x[b], s.get("x"), rtol=0, atol=2e-7)
+        np.testing.assert_allclose(u[b], s.get("u"), rtol=0, atol=2e-7)

@@ -197,3 +197,37 @@ def test_generic_plan_says_what_it_does_not_do():
     bt = altro_amd.Batch(10, 16, 5, 4)
     with pytest.raises(altro_amd.AltroHipError):
         bt.set_model(altro_amd.MODEL_BICYCLE, 0.1)
+
+
+@pytest.mark.parametrize("dense", [False, True])
+def test_input_guess_before_the_cost_is_kept(dense):
+    """the reference allows SetInput at any time (altro_solver.cpp:242-251); on plan GENERIC the first cost
+    setter used to zero the candidate inputs, so a guess given BEFORE the cost was lost and the solve started from u = 0."""
+    N, n, m, batch = 9, 14, 5, 4
+    p = problems.ilqr12x4_problem(batch, N, True, n=n, m=m)
+    if dense:
+        p.update(problems.quadratic_cost(batch, N, n, m))
+
+    def build(guess_first):
+        bt = altro_amd.Batch(N, n, m, batch)
+        assert bt.plan == altro_amd.PLAN_GENERIC
+        bt.set_dynamics(p["A"], p["B"], p["f"])
+        bt.set_initial_state(p["x0"])
+        if guess_first:
+            bt.set_input_guess(p["u0"])
+        if dense:
+            bt.set_quadratic_cost(p["Q"], p["R"], p["H"], p["q"], p["r"], p["c"])
+        else:
+            bt.set_tracking_cost(p["Qd"], p["Rd"], p["xref"], p["uref"])
+        if not guess_first:
+            bt.set_input_guess(p["u0"])
+        return bt
+    a, b = build(True), build(False)
+    assert np.abs(p["u0"]).max() > 0
+    np.testing.assert_array_equal(a.get("u"), p["u0"])
+    a.open_loop_rollout(); b.open_loop_rollout()
+    np.testing.assert_array_equal(a.get("x"), b.get("x"))
+    ra, rb = a.ilqr_solve(iterations_max=10), b.ilqr_solve(iterations_max=10)
+    assert np.array_equal(ra["iterations"], rb["iterations"])
+    xa, ua = a.get_nominal(); xb, ub = b.get_nominal()
+    np.testing.assert_array_equal(xa, xb); np.testing.assert_array_equal(ua, ub)
