@@ -224,8 +224,8 @@ def test_input_guess_before_the_cost_is_kept(dense):
         return bt
     a, b = build(True), build(False)
     assert np.abs(p["u0"]).max() > 0
-    np.testing.assert_array_equal(a.get("u"), p["u0"])
     a.open_loop_rollout(); b.open_loop_rollout()
+    np.testing.assert_array_equal(a.get("u"), p["u0"])
     np.testing.assert_array_equal(a.get("x"), b.get("x"))
     ra, rb = a.ilqr_solve(iterations_max=10), b.ilqr_solve(iterations_max=10)
     assert np.array_equal(ra["iterations"], rb["iterations"])
