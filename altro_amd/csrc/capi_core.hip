@@ -635,7 +635,6 @@ int altro_hip_profile_get(altro_hip_batch* h, int slot, int* launches, double* t
                                       {"mfma16_backward_kernel", "mfma16_forward_kernel"},
                                       {"lane_backward_kernel", "lane_forward_kernel"}};
     *kernel_name = names[h->plan == ALTRO_HIP_PLAN_MFMA16 ? 1 : (h->plan == ALTRO_HIP_PLAN_LANE ? 2 : 0)][slot];
-    if (slot == 0 && h->plan == ALTRO_HIP_PLAN_LANE && h->bwd_hex) *kernel_name = "hex_backward_kernel";
     if (slot == 0 && h->plan == ALTRO_HIP_PLAN_LANE && h->bwd_quad) *kernel_name = h->n == 4 ? "quad_backward_kernel" : "quad2_backward_kernel";
     if (slot == 1 && h->plan == ALTRO_HIP_PLAN_LANE && h->fwd_quad) *kernel_name = "quad_forward_kernel";
     if (slot == 1 && mfma16_forward_is_x4(h)) *kernel_name = "mfma16_forward_f32x4_kernel";

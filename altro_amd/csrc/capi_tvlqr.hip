@@ -1,7 +1,6 @@
 // capi_tvlqr.hip -- C ABI: the TVLQR sweep (altro_hip_backward / forward_ltv / sweep) and its per-plan kernel launchers.
 // This unit instantiates the sweep kernels of all three plans (GENERIC, LANE, MFMA16 in fp64 / fp32 storage / pure fp32).
 #include "capi_internal.h"
-#include <type_traits>
 #include "models.h"
 
 #include "kernels/tvlqr_mfma16.hip"
@@ -36,26 +35,6 @@ int lane_launch(altro_hip_batch* h, bool backward, double reg) {
   const bool quad_on = qe ? std::atoi(qe) != 0 : h->batch <= 12288;
   const bool q42 = h->n == 4 && h->m == 2, q21 = h->n == 2 && h->m == 1;
   if (backward) h->bwd_quad = quad_on && (q42 || q21);
-  // sixteen (n <= 2: eight) lanes per problem, records staged through LDS (kernels/tvlqr_hex.hip; fp64, exact flavour, n <= 4):
-  // the backward sweep while the batch leaves SIMDs idle.  ALTRO_HIP_LANE_HEX=0 / 1 forces it off / on.
-  if (backward) h->bwd_hex = false;
-  if constexpr (std::is_same<T, double>::value) {
-    const char* he = std::getenv("ALTRO_HIP_LANE_HEX");
-    const bool hex_on = !fused && h->n <= 4 && (he ? std::atoi(he) != 0 : false);   // opt-in: measured slower than the quad sweeps (profiles/r05f_hex_backward_ab.txt)
-    if (backward && hex_on) {
-      h->bwd_hex = true; h->bwd_quad = false;
-#define X(N_, M_)                                                                                                      \
-  if (h->n == N_ && h->m == M_) {                                                                                      \
-    const int ppw = HexDims<N_, M_>::PPW;                                                                              \
-    PROF_LAUNCH((hex_backward_kernel<N_, M_>), dim3(8 * (((h->batch + ppw - 1) / ppw + 7) / 8)), block, 0, h->stream, a); \
-  }
-      X(1, 1) X(2, 1) X(3, 1) X(4, 1) X(1, 2) X(2, 2) X(3, 2) X(4, 2) X(1, 3) X(2, 3) X(3, 3) X(4, 3)
-#undef X
-      hipError_t e = hipGetLastError();
-      if (e != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "hex kernel launch: %s", hipGetErrorString(e));
-      return 0;
-    }
-  }
   if (!backward) h->fwd_quad = quad_on && q42;
   if (!backward && quad_on && q42) {   // forward sweep of (4, 2): four lanes per problem as well
     const dim3 qgrid(8 * (((h->batch + 15) / 16 + 7) / 8));

@@ -164,11 +164,6 @@ ALTRO_FP_REGION_OFF
 #include "tvlqr_lane_body.inc"
 #include "tvlqr_quad_body.inc"
 #include "tvlqr_quad2_body.inc"
-#ifndef __HIPCC_RTC__   // (the run-time compiled user-model kernels of capi_rtc.hip never launch the sweep kernels: not embedded there)
-}  // namespace altro_hip
-#include "tvlqr_hex.hip"   // sixteen lanes per problem (fp64, exact flavour only)
-namespace altro_hip {
-#endif
 #undef LANE_FN
 #undef LANE_DIV
 #undef LANE_SQRT
