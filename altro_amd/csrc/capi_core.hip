@@ -82,7 +82,7 @@ static int batch_create_impl(altro_hip_batch** out, int N, int n, int m, int bat
   *out = nullptr;
   if (N <= 0 || n <= 0 || m <= 0 || batch <= 0)
     return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "N, n, m, batch must be positive (got %d %d %d %d)", N, n, m, batch);
-  if (n > 32 || m > 32) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "n, m <= 32 supported (got %d, %d)", n, m);
+  if (n > kGenericMaxDim || m > kGenericMaxDim) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "n, m <= %d supported (got %d, %d)", kGenericMaxDim, n, m);
   if (dtype != ALTRO_HIP_F64 && dtype != ALTRO_HIP_F32) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "bad dtype %d", dtype);
   if (altro_hip_device_count() <= device || device < 0)
     return fail(ALTRO_HIP_ERR_NO_DEVICE, "no HIP device %d: the altro_hip hot path has no CPU fallback", device);
@@ -240,10 +240,10 @@ int altro_hip_batch_create_dims(altro_hip_batch** out, int N, const int* nx, con
   if (N <= 0 || !nx || !nu) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "N must be positive, nx and nu non-null");
   int nmax = 0, mmax = 0;
   for (int k = 0; k <= N; ++k) {
-    if (nx[k] <= 0 || nx[k] > 32) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "nx[%d] = %d outside [1, 32]", k, nx[k]);
+    if (nx[k] <= 0 || nx[k] > kGenericMaxDim) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "nx[%d] = %d outside [1, %d]", k, nx[k], kGenericMaxDim);
     nmax = std::max(nmax, nx[k]);
     if (k < N) {
-      if (nu[k] <= 0 || nu[k] > 32) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "nu[%d] = %d outside [1, 32]", k, nu[k]);
+      if (nu[k] <= 0 || nu[k] > kGenericMaxDim) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "nu[%d] = %d outside [1, %d]", k, nu[k], kGenericMaxDim);
       mmax = std::max(mmax, nu[k]);
     }
   }
@@ -257,7 +257,7 @@ void altro_hip_batch_destroy(altro_hip_batch* h) {
   void* ptrs[] = {h->x0, h->delta_V, h->status, h->m_in, h->m_cin, h->m_term, h->m_out, h->m_outn, h->m_xuy,
                   h->m_qblk, h->m_trash, h->g_off, h->g_nx, h->g_nu, h->stage,
                   h->l_in, h->l_term, h->l_out, h->l_outn, h->l_xuy, h->l_x0,
-                  h->l_nom, h->l_cost, h->i_prob, h->i_alpha, h->i_phi, h->i_dphi, h->i_active, h->i_counters,
+                  h->l_nom, h->l_cost, h->g_ws, h->i_prob, h->i_alpha, h->i_phi, h->i_dphi, h->i_active, h->i_counters,
                   h->al_d_knots, h->al_d_G, h->al_d_Gpad, h->al_d_g, h->al_d_z, h->i_reg, h->m_nom, h->m_costp,
                   h->i_cand_spec, h->i_spec_sel, h->i_spec_refresh, h->i_stat_done, h->st_partial, h->st_red, h->i_merit_jk, h->i_spec_jac, h->i_results,
                   h->m_costd, h->m_costd_term, h->l_costq, h->g_xn, h->g_un, h->g_cQ, h->g_cR, h->g_cH, h->g_cq, h->g_cr, h->g_cc};

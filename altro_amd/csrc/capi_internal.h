@@ -102,6 +102,7 @@ struct altro_hip_batch {
   void *i_merit_jk = nullptr, *i_spec_jac = nullptr;
   int merit_split = -1;           // -1: not decided yet (ALTRO_HIP_MERIT_SPLIT, default on)
   void *i_results = nullptr, *i_results_host = nullptr;   // per-problem solve results: device gather + pinned staging (first solve)
+  void* g_ws = nullptr;           // plan GENERIC, blocks beyond 64 KB of LDS: the backward sweep's per-problem work blocks (first use)
   bool fwd_quad = false;          // the last LANE forward sweep ran four lanes per problem
   bool bwd_quad = false;          // the last LANE backward sweep ran four lanes per problem (kernels/tvlqr_quad_body.inc)
   int spec_trials = 1;            // trials per merit launch of the CURRENT launch (1 = no speculation)

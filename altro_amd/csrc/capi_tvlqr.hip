@@ -201,14 +201,25 @@ int launch_backward(altro_hip_batch* h, double reg) {
     }
   } else if (h->plan == ALTRO_HIP_PLAN_LANE) {
     return h->dtype == ALTRO_HIP_F64 ? lane_launch<double>(h, true, reg) : lane_launch<float>(h, true, reg);
-  } else if (h->dtype == ALTRO_HIP_F64) {
-    auto a = generic_args<double>(h, reg);
-    size_t lds = generic_backward_lds_bytes<double>(h->n, h->m);
-    PROF_LAUNCH(generic_backward_kernel<double>, dim3(h->batch), dim3(64), lds, h->stream, a);
   } else {
-    auto a = generic_args<float>(h, reg);
-    size_t lds = generic_backward_lds_bytes<float>(h->n, h->m);
-    PROF_LAUNCH(generic_backward_kernel<float>, dim3(h->batch), dim3(64), lds, h->stream, a);
+    // blocks beyond 64 KB of LDS per problem (n, m past ~32 in fp64): the same kernel on a per-problem work block in global memory
+    const size_t lds = h->dtype == ALTRO_HIP_F64 ? generic_backward_lds_bytes<double>(h->n, h->m) : generic_backward_lds_bytes<float>(h->n, h->m);
+    const bool big = lds > kGenericLdsLimit;
+    if (big && !h->g_ws) {
+      int rc = dmalloc(h, &h->g_ws, (size_t)h->batch * ((lds + 15) / 16 * 16));
+      if (rc) return rc;
+    }
+    if (h->dtype == ALTRO_HIP_F64) {
+      auto a = generic_args<double>(h, reg);
+      a.ws = (double*)h->g_ws; a.ws_stride = (int64_t)((lds + 15) / 16 * 16 / sizeof(double));
+      if (big) PROF_LAUNCH((generic_backward_kernel<double, true>), dim3(h->batch), dim3(64), 0, h->stream, a);
+      else PROF_LAUNCH((generic_backward_kernel<double, false>), dim3(h->batch), dim3(64), lds, h->stream, a);
+    } else {
+      auto a = generic_args<float>(h, reg);
+      a.ws = (float*)h->g_ws; a.ws_stride = (int64_t)((lds + 15) / 16 * 16 / sizeof(float));
+      if (big) PROF_LAUNCH((generic_backward_kernel<float, true>), dim3(h->batch), dim3(64), 0, h->stream, a);
+      else PROF_LAUNCH((generic_backward_kernel<float, false>), dim3(h->batch), dim3(64), lds, h->stream, a);
+    }
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "backward launch: %s", hipGetErrorString(e));

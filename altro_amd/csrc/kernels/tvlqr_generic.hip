@@ -22,6 +22,9 @@ namespace altro_hip {
 // Bit-parity with the CPU oracle: no a*b+c -> fma fusion anywhere in this file.
 ALTRO_FP_REGION_OFF
 
+constexpr size_t kGenericLdsLimit = 64 * 1024;   // dynamic LDS a launch gets without asking for more; beyond it plan GENERIC works in global memory
+constexpr int kGenericMaxDim = 256;              // n, m accepted by plan GENERIC (a bound on the work blocks, not of the algorithm)
+
 enum GArr {
   G_A = 0, G_B, G_f, G_Q, G_R, G_H, G_q, G_r,      // inputs
   G_K, G_d, G_P, G_p,                              // outputs
@@ -50,6 +53,8 @@ struct GenericArgs {
   int store_q;
   int want_y;
   int no_f = 0;              // backward sweep: treat f as zero (altro_hip_batch::ilqr_linear: the expansion of the iLQR loop)
+  T* ws = nullptr;           // generic_backward_kernel<T, true>: per-problem work blocks in global memory instead of LDS
+  int64_t ws_stride = 0;     // elements between consecutive problems' work blocks (>= generic_backward_lds_bytes / sizeof(T))
 };
 
 // C(mr x nc) = beta*C + alpha * op(A) op(B); operands column-major in LDS (or global for B/A reads).
@@ -76,13 +81,17 @@ __device__ __forceinline__ void wave_copy(int lane, T* dst, const T* src, int co
   for (int e = lane; e < count; e += 64) dst[e] = src[e];
 }
 
-template <typename T>
+// BIG = false: the knot point's blocks live in LDS (what fits 64 KB: n, m up to ~32 in fp64).  BIG = true: the same code on a
+// per-problem work block in GLOBAL memory (args.ws) -- any dimensions, as the reference takes them (tvlqr.cpp:92-121 sizes every
+// block from nx[k], nu[k]); slow (every operand is a cached global load), which is the point: refusing n = 33 is worse.  A workgroup
+// is one wave and __syncthreads() orders its global accesses at workgroup scope, so the phases stay as they are.
+template <typename T, bool BIG = false>
 __global__ __launch_bounds__(64) void generic_backward_kernel(GenericArgs<T> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* smem = reinterpret_cast<T*>(smem_raw);
   const int lane = threadIdx.x;
   const int b = blockIdx.x;
   if (b >= a.batch) return;
+  T* smem = BIG ? a.ws + (int64_t)b * a.ws_stride : reinterpret_cast<T*>(smem_raw);
   const int nm = a.nmax, mm = a.mmax;
   // LDS carve
   T* sP = smem;                 // P_{k+1}     nm*nm

@@ -54,6 +54,8 @@ struct Workspace {
   int64_t* dev_off = nullptr;
   int* dev_dims = nullptr;
   size_t table_k = 0;
+  double* big = nullptr;          // the backward kernel's work block when a knot point does not fit 64 KB of LDS
+  size_t big_bytes = 0;
   double* host = nullptr;         // pinned staging arena (hipHostMalloc), same size as dev
   std::vector<int64_t> off;       // the tables the device holds right now
   std::vector<int> dims;
@@ -61,6 +63,7 @@ struct Workspace {
     int c = 0;   // thread / process teardown: the HIP runtime may already be gone -- then there is nothing left to free
     if (hipGetDeviceCount(&c) != hipSuccess || c <= 0) return;
     if (dev) (void)hipFree(dev);
+    if (big) (void)hipFree(big);
     if (dev_off) (void)hipFree(dev_off);
     if (dev_dims) (void)hipFree(dev_dims);
     if (host) (void)hipHostFree(host);
@@ -74,10 +77,11 @@ bool have_device() {
   return hipGetDeviceCount(&c) == hipSuccess && c > 0;
 }
 
-// the GENERIC kernels stage every block through fixed LDS images: state / input dimensions up to 32
+// any dimensions, like the reference (tvlqr.cpp:92-121): blocks that do not fit 64 KB of LDS are worked on in global memory
+// (generic_backward_kernel<T, true>); kGenericMaxDim only bounds that work block
 bool dims_supported(const int* nx, const int* nu, int N) {
   for (int k = 0; k <= N; ++k)
-    if (nx[k] < 0 || nx[k] > 32 || (k < N && (nu[k] < 0 || nu[k] > 32))) return false;
+    if (nx[k] < 0 || nx[k] > kGenericMaxDim || (k < N && (nu[k] < 0 || nu[k] > kGenericMaxDim))) return false;
   return true;
 }
 
@@ -88,6 +92,7 @@ struct Layout {
   int64_t total;
   int64_t group_end[4];       // arena offset where each group of arrays ends
   int nmax, mmax;
+  int xstage;                 // elements reserved for the forward pass's x0 in front of delta_V at the arena's end
 };
 
 int64_t block_size(int arr, int n, int m, int n2, bool is_diag) {
@@ -130,7 +135,8 @@ Layout make_layout(const int* nx, const int* nu, int N, bool is_diag) {
     }
     L.group_end[g] = cur;
   }
-  L.total = cur + 32 + 4;   // + x0 staging (<= 32) + delta_V[2] (+pad) at the end
+  L.xstage = std::max(32, (L.nmax + 3) & ~3);
+  L.total = cur + L.xstage + 4;   // + x0 staging + delta_V[2] (+pad) at the end
   return L;
 }
 
@@ -184,7 +190,7 @@ GenericArgs<double> make_args(Workspace& w, const Layout& L, double reg, bool is
   a.off = w.dev_off;
   a.nx = w.dev_dims;
   a.nu = w.dev_dims + (L.N + 1);
-  a.x0 = w.host_dev + L.total - 36;
+  a.x0 = w.host_dev + L.total - 4 - L.xstage;
   a.x0_stride = 0;
   a.delta_V = w.host_dev + L.total - 4;
   a.status = reinterpret_cast<int*>(w.host_dev + L.total - 2);   // the arena's last two elements are padding: the status word lives there
@@ -429,7 +435,18 @@ int tvlqr_BackwardPass(const int* nx, const int* nu, int num_horizon, const lqr_
   if (hipMemcpyAsync(w.dev, hs, (size_t)L.group_end[1] * sizeof(double), hipMemcpyHostToDevice, w.stream) != hipSuccess) return TVLQR_NO_DEVICE;
   GenericArgs<double> a = make_args(w, L, reg, is_diag, 0, L.group_end[1]);
   const size_t lds = generic_backward_lds_bytes<double>(a.nmax, a.mmax);
-  hipLaunchKernelGGL(generic_backward_kernel<double>, dim3(1), dim3(64), lds, w.stream, a);
+  if (lds > kGenericLdsLimit) {
+    if (w.big_bytes < lds) {
+      if (w.big) (void)hipFree(w.big);
+      w.big = nullptr; w.big_bytes = 0;
+      if (hipMalloc((void**)&w.big, lds) != hipSuccess) { w.big = nullptr; return TVLQR_NO_DEVICE; }
+      w.big_bytes = lds;
+    }
+    a.ws = w.big; a.ws_stride = 0;
+    hipLaunchKernelGGL((generic_backward_kernel<double, true>), dim3(1), dim3(64), 0, w.stream, a);
+  } else {
+    hipLaunchKernelGGL((generic_backward_kernel<double, false>), dim3(1), dim3(64), lds, w.stream, a);
+  }
   if (hipGetLastError() != hipSuccess) return TVLQR_NO_DEVICE;
   if (hipStreamSynchronize(w.stream) != hipSuccess) return TVLQR_NO_DEVICE;
   }
@@ -473,7 +490,7 @@ int tvlqr_ForwardPass(const int* nx, const int* nu, int num_horizon, const lqr_f
                       const lqr_float* x0, lqr_float** x, lqr_float** u, lqr_float** y) {
   if (!have_device()) return TVLQR_NO_DEVICE;
   const int N = num_horizon;
-  if (!dims_supported(nx, nu, N)) return TVLQR_UNSUPPORTED_SIZE;   // x0 staging and the kernels' LDS images assume <= 32
+  if (!dims_supported(nx, nu, N)) return TVLQR_UNSUPPORTED_SIZE;
   Workspace& w = g_ws;
   const Layout L = make_layout(nx, nu, N, false);
   if (prepare(w, L, nx, nu)) return TVLQR_NO_DEVICE;
@@ -498,7 +515,7 @@ int tvlqr_ForwardPass(const int* nx, const int* nu, int num_horizon, const lqr_f
       put(G_d, k, d[k], m);
     }
   }
-  memcpy(hs + L.total - 36, x0, sizeof(double) * nx[0]);
+  memcpy(hs + L.total - 4 - L.xstage, x0, sizeof(double) * nx[0]);
   if (hipMemcpyAsync(w.dev, hs, (size_t)L.group_end[2] * sizeof(double), hipMemcpyHostToDevice, w.stream) != hipSuccess) return TVLQR_NO_DEVICE;
   GenericArgs<double> a = make_args(w, L, 0.0, false, y ? 1 : 0, L.group_end[2]);
   const size_t lds = (size_t)(2 * a.nmax + a.mmax) * sizeof(double) + 64;

@@ -80,12 +80,13 @@ typedef enum altro_hip_error {
 } altro_hip_error;
 
 /* Which kernel family a handle runs.  AUTO: (12, 4) -> MFMA16; n <= 6, m <= 3 -> LANE; other n <= 12, m <= 4 -> MFMA16
- * (padded); anything larger (<= 32) -> GENERIC (the TVLQR sweep and the iLQR loop for dynamics given as data with a quadratic
+ * (padded); anything larger (<= 256) -> GENERIC (the TVLQR sweep and the iLQR loop for dynamics given as data with a quadratic
  * cost and linear constraint blocks in every cone, kernels/ilqr_generic.hip: correctness first; no device models, no regularisation
  * retry). */
 typedef enum altro_hip_plan {
   ALTRO_HIP_PLAN_AUTO = 0,
-  ALTRO_HIP_PLAN_GENERIC = 1, /* wave-per-problem, LDS-staged, any (n, m) <= 32                */
+  ALTRO_HIP_PLAN_GENERIC = 1, /* wave-per-problem, any (n, m) <= 256: blocks staged in LDS, or (past ~32) worked on in global memory;
+                                 the iLQR loop of this plan: n, m <= 32                            */
   ALTRO_HIP_PLAN_MFMA16 = 2,  /* wave-per-problem, 16x16x4 MFMA tiles: (n, m) = (12, 4), and any n <= 12,
                                  m <= 4 on zero-padded records (same results, the (12, 4) cost)        */
   ALTRO_HIP_PLAN_LANE = 3     /* lane-per-problem, batch structure-of-arrays, n <= 6 and m <= 3         */

@@ -21,7 +21,7 @@
 
 #define TVLQR_SUCCESS -1   /* both passes: no knot point failed */
 #define TVLQR_NO_DEVICE -2 /* this library only: no usable HIP device (the reference has no such case) */
-#define TVLQR_UNSUPPORTED_SIZE -3 /* this library only: some nx[k] or nu[k] exceeds 32 (the reference has no limit) */
+#define TVLQR_UNSUPPORTED_SIZE -3 /* this library only: some nx[k] or nu[k] exceeds 256 (the reference has no limit; up to round 4: 32) */
 
 typedef double lqr_float;
 

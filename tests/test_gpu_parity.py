@@ -96,8 +96,11 @@ def test_generic_tvlqr_kat(kats, is_diag):
         assert relerr(out[k], ref[key]) < 1e-13, k
 
 
-@pytest.mark.parametrize("n,m,N,batch", [(12, 4, 16, 8), (4, 2, 50, 5), (2, 1, 100, 3), (7, 3, 9, 4), (1, 1, 5, 2)])
+@pytest.mark.parametrize("n,m,N,batch", [(12, 4, 16, 8), (4, 2, 50, 5), (2, 1, 100, 3), (7, 3, 9, 4), (1, 1, 5, 2),
+                                         (32, 32, 5, 3), (33, 7, 6, 3), (40, 10, 8, 3), (64, 16, 6, 2), (20, 48, 4, 2)])
 def test_generic_random(n, m, N, batch):
+    # (n or m beyond 32 -- round 5: the knot point's blocks no longer fit 64 KB of LDS and the same kernel works on a per-problem
+    #  block in global memory, generic_backward_kernel<T, true>; the reference is dimension-generic, tvlqr.cpp:92-121)
     pr = problems.random_ltv(batch, N, n, m)
     out = run_hip(pr, altro_amd.PLAN_GENERIC)
     ref = run_oracle(pr)
