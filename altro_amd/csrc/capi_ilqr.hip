@@ -16,7 +16,7 @@ template <typename T>
 int al_upload_typed(altro_hip_batch* h) {
   const int64_t B = h->batch;
   h->al_Gpad_count = 0;
-  for (void** p : {(void**)&h->al_d_knots, &h->al_d_G, &h->al_d_Gpad, &h->al_d_g, &h->al_d_z})
+  for (void** p : {(void**)&h->al_d_knots, (void**)&h->al_d_big, &h->al_d_G, &h->al_d_Gpad, &h->al_d_g, &h->al_d_z})
     if (*p) { (void)hipFree(*p); *p = nullptr; }
   if (h->al_defs.empty()) { h->al_rows = 0; return 0; }
   // G on the device: p x (n + m) column-major as given on plan LANE; on plan MFMA16 p x 16 in the tile's own column order
@@ -60,11 +60,19 @@ int al_upload_typed(altro_hip_batch* h) {
     }
   }
   int rows = 0;
-  std::vector<AlKnot> knots = h->al_knots;
-  for (auto& kn : knots)
-    for (int j = 0; j < kn.ncon; ++j) {
-      const AlDef& d = defs[kn.def[j]];
-      kn.z_off[j] = rows; rows += d.p;
+  const bool gen = h->plan == ALTRO_HIP_PLAN_GENERIC;
+  std::vector<AlKnotBig> big = h->al_knots;
+  std::vector<AlKnot> knots(gen ? 0 : big.size(), AlKnot{});
+  for (size_t k = 0; k < big.size(); ++k) {
+    AlKnotBig& bk = big[k];
+    for (int j = 0; j < bk.ncon; ++j) {
+      const AlDef& d = defs[bk.def[j]];
+      bk.z_off[j] = rows; rows += d.p;
+      bk.cone[j] = d.cone; bk.p[j] = d.p; bk.g_per_problem[j] = d.g_per_problem; bk.G_off[j] = G_off_dev[bk.def[j]]; bk.g_off[j] = d.g_off;
+      if (gen) continue;
+      AlKnot& kn = knots[k];
+      kn.ncon = bk.ncon; kn.def[j] = bk.def[j];
+      kn.z_off[j] = bk.z_off[j];
       kn.cone[j] = d.cone; kn.p[j] = d.p; kn.g_per_problem[j] = d.g_per_problem; kn.G_off[j] = G_off_dev[kn.def[j]]; kn.g_off[j] = d.g_off;
       kn.user[j] = d.user;
       kn.Gp_off[j] = kn.def[j] * AL_GP_DEF;
@@ -82,27 +90,32 @@ int al_upload_typed(altro_hip_batch* h) {
       }
       kn.sel[j] = sel ? 1 : 0;
     }
+  }
   h->al_rows = rows;
   if (h->plan == ALTRO_HIP_PLAN_LANE && (uint64_t)rows * (uint64_t)B * sizeof(T) >= (1ull << 31))
     return fail(ALTRO_HIP_ERR_UNSUPPORTED, "plan LANE: %d dual rows x batch %d exceed the 2 GiB buffer window; split the batch", rows, h->batch);
   {   // uniform running knot points?  (then the dual rows of knot point k start k * rows_per_knot after those of 0)
-    const AlKnot& k0 = knots[0];
+    const AlKnotBig& k0 = big[0];
     int r0 = 0;
     for (int j = 0; j < k0.ncon; ++j) r0 += defs[k0.def[j]].p;
     bool uni = h->N >= 1 && k0.ncon > 0;
     for (int k = 1; k < h->N && uni; ++k) {
-      uni = knots[k].ncon == k0.ncon;
-      for (int j = 0; j < k0.ncon && uni; ++j) uni = knots[k].def[j] == k0.def[j] && knots[k].z_off[j] == k0.z_off[j] + k * r0;
+      uni = big[k].ncon == k0.ncon;
+      for (int j = 0; j < k0.ncon && uni; ++j) uni = big[k].def[j] == k0.def[j] && big[k].z_off[j] == k0.z_off[j] + k * r0;
     }
     h->al_uniform = uni ? 1 : 0;
     h->al_rows_per_knot = r0;
   }
   int rc = 0;
-  if ((rc = dmalloc(h, (void**)&h->al_d_knots, knots.size() * sizeof(AlKnot)))) return rc;
+  if (gen) {
+    if ((rc = dmalloc(h, (void**)&h->al_d_big, big.size() * sizeof(AlKnotBig)))) return rc;
+    HIP_TRY(hipMemcpy(h->al_d_big, big.data(), big.size() * sizeof(AlKnotBig), hipMemcpyHostToDevice));
+  }
+  if ((rc = dmalloc(h, (void**)&h->al_d_knots, std::max<size_t>(knots.size(), 1) * sizeof(AlKnot)))) return rc;
   if ((rc = dmalloc(h, &h->al_d_G, G.size() * sizeof(T)))) return rc;
   if ((rc = dmalloc(h, &h->al_d_g, g.size() * sizeof(T)))) return rc;
   if ((rc = dmalloc(h, &h->al_d_z, (size_t)rows * B * sizeof(T)))) return rc;
-  HIP_TRY(hipMemcpy(h->al_d_knots, knots.data(), knots.size() * sizeof(AlKnot), hipMemcpyHostToDevice));
+  if (!knots.empty()) HIP_TRY(hipMemcpy(h->al_d_knots, knots.data(), knots.size() * sizeof(AlKnot), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->al_d_G, G.data(), G.size() * sizeof(T), hipMemcpyHostToDevice));
   if (!Gpad.empty()) {
     if ((rc = dmalloc(h, &h->al_d_Gpad, Gpad.size() * sizeof(T)))) return rc;
@@ -112,11 +125,11 @@ int al_upload_typed(altro_hip_batch* h) {
   HIP_TRY(hipMemcpy(h->al_d_g, g.data(), g.size() * sizeof(T), hipMemcpyHostToDevice));
   // (memsets go on the handle's own stream: it is non-blocking, so a null-stream memset would race the kernels)
   HIP_TRY(hipMemsetAsync(h->al_d_z, 0, (size_t)rows * B * sizeof(T), h->stream));
-  h->al_knots = knots;
+  h->al_knots = big;
   h->al_G_count = (int)G.size();
   h->al_has_soc = 0;
   for (const AlDef& d : defs) if (d.cone == CONE_SOC) h->al_has_soc = 1;
-  h->al_all_sel = 1;
+  h->al_all_sel = gen ? 0 : 1;
   for (const AlKnot& kn : knots)
     for (int j = 0; j < kn.ncon; ++j) if (!kn.sel[j]) h->al_all_sel = 0;
   return 0;
@@ -275,6 +288,7 @@ int gen_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int 
   a.al.enabled = h->al_defs.empty() ? 0 : 1;
   a.al.uniform = h->al_uniform; a.al.rows_per_knot = h->al_rows_per_knot; a.al.N = h->N; a.al.G_count = h->al_G_count;
   a.al.has_soc = h->al_has_soc; a.al.all_sel = h->al_all_sel; a.al.Gpad = nullptr; a.al.Gpad_count = 0;
+  a.al.big = h->al_d_big;
   const int rc = ilqr_generic_launch<T>(h->stream, which, a);
   if (rc == 1) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "operation %d is not available on plan GENERIC", which);
   if (rc) return fail(ALTRO_HIP_ERR_HIP, "iLQR kernel launch failed");
@@ -864,14 +878,20 @@ int altro_hip_add_linear_constraint(altro_hip_batch* h, int k_first, int k_last,
   h->expansion_current = false;
   if (!G || !g) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "G and g are required");
   if (cone < CONE_EQUALITY || cone > CONE_SOC) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "unknown cone %d", cone);
-  const int pmax = cone == CONE_SOC ? AL_MAXSOC : AL_MAXP;
-  if (p < 1 || p > pmax) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "constraint dimension %d outside [1, %d]", p, pmax);
+  // capacities (stated in altro_hip.h): plan GENERIC loops over the blocks with one lane per row, plans LANE / MFMA16 unroll two blocks
+  const bool gen = h->plan == ALTRO_HIP_PLAN_GENERIC;
+  const int pmax = cone == CONE_SOC ? AL_MAXSOC : (gen ? GEN_MAXP : AL_MAXP);
+  const int cmax = gen ? GEN_MAXC : AL_MAXC, dmax = gen ? GEN_MAXDEF : AL_MAXDEF;
+  if (p < 1 || p > pmax)
+    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "constraint dimension %d outside [1, %d]%s", p, pmax,
+                gen || cone == CONE_SOC ? "" : " on this plan (ALTRO_HIP_PLAN_GENERIC takes up to 64 rows per block and 8 blocks per knot point)");
   if (k_first < 0 || k_last > h->N || k_first > k_last)
     return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "knot point range [%d, %d] outside [0, %d] (ErrorCodes::BadIndex)", k_first, k_last, h->N);
-  if ((int)h->al_defs.size() >= AL_MAXDEF) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "at most %d constraint blocks", AL_MAXDEF);
+  if ((int)h->al_defs.size() >= dmax) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "at most %d constraint blocks", dmax);
   for (int k = k_first; k <= k_last; ++k)
-    if (h->al_knots[k].ncon >= AL_MAXC)
-      return fail(ALTRO_HIP_ERR_UNSUPPORTED, "at most %d constraint blocks per knot point (k = %d)", AL_MAXC, k);
+    if (h->al_knots[k].ncon >= cmax)
+      return fail(ALTRO_HIP_ERR_UNSUPPORTED, "at most %d constraint blocks per knot point on this plan (k = %d)%s", cmax, k,
+                  gen ? "" : ": ALTRO_HIP_PLAN_GENERIC takes 8");
   const int w = h->n + h->m;
   AlDef d{cone, p, g_per_problem ? 1 : 0, (int)h->al_G.size(), 0};
   h->al_G.insert(h->al_G.end(), G, G + (size_t)p * w);
@@ -879,7 +899,7 @@ int altro_hip_add_linear_constraint(altro_hip_batch* h, int k_first, int k_last,
   const int id = (int)h->al_defs.size();
   h->al_defs.push_back(d);
   for (int k = k_first; k <= k_last; ++k) {
-    AlKnot& kn = h->al_knots[k];
+    AlKnotBig& kn = h->al_knots[k];
     kn.def[kn.ncon++] = id;
   }
   h->al_dirty = true;
@@ -906,7 +926,7 @@ int altro_hip_clear_constraints(altro_hip_batch* h) {
   if (rc) return rc;
   h->expansion_current = false;
   h->al_defs.clear(); h->al_G.clear(); h->al_g.clear();
-  h->al_knots.assign((size_t)h->N + 1, AlKnot{});
+  h->al_knots.assign((size_t)h->N + 1, AlKnotBig{});
   h->al_dirty = true;
   return al_upload(h);
 }
@@ -933,7 +953,7 @@ int altro_hip_get_duals(altro_hip_batch* h, int k, int slot, double* z) {
   if ((rc = al_upload(h))) return rc;
   if (k < 0 || k > h->N || slot < 0 || slot >= h->al_knots[k].ncon || !z)
     return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "no constraint block %d at knot point %d", slot, k);
-  const AlKnot& kn = h->al_knots[k];
+  const AlKnotBig& kn = h->al_knots[k];
   const int p = h->al_defs[kn.def[slot]].p;
   const int64_t B = h->batch;
   HIP_TRY(hipStreamSynchronize(h->stream));

@@ -114,13 +114,14 @@ struct altro_hip_batch {
   bool model_set = false, lqr_cost_set = false, guess_set = false;
   // augmented-Lagrangian constraint blocks (plan LANE): host mirrors + device tables, uploaded lazily
   std::vector<AlDef> al_defs;
-  std::vector<AlKnot> al_knots;
+  std::vector<AlKnotBig> al_knots;       // (the device table is AlKnot for plans LANE / MFMA16, AlKnotBig for plan GENERIC)
   int al_uniform = 0, al_rows_per_knot = 0;  // knot points 0..N-1 carry the same blocks (kernels/al_types.h)
   std::vector<double> al_G;                  // pool of G blocks, column-major p x (n+m)
   std::vector<std::vector<double>> al_g;     // per block: [p] or [batch][p]
   int al_rows = 0;
   bool al_dirty = false;
   AlKnot* al_d_knots = nullptr;
+  AlKnotBig* al_d_big = nullptr;
   void *al_d_G = nullptr, *al_d_g = nullptr, *al_d_z = nullptr;
   void* al_d_Gpad = nullptr;                 // AlTable::Gpad (plan MFMA16)
   int al_Gpad_count = 0;

@@ -13,6 +13,12 @@ constexpr int AL_MAXDEF = 16;  // distinct blocks per handle
 // eight bank groups): rows >= p and row 8 are zero, so a lane reads `its` row (min(lane, 8)) or any column without a select
 constexpr int AL_GP_LD = 18, AL_GP_DEF = 9 * AL_GP_LD;
 
+// Plan GENERIC has its own, larger table (kernels/ilqr_generic.hip loops over the blocks instead of unrolling two of them, one lane per
+// row): the reference takes any number of constraints of any dimension per knot point (knotpoint_data.hpp:16, knotpoint_data.cpp:155-161)
+constexpr int GEN_MAXC = 8;     // constraint blocks per knot point on plan GENERIC
+constexpr int GEN_MAXP = 64;    // rows per zero / identity / orthant block on plan GENERIC: one lane each, so up to n + m = 64
+constexpr int GEN_MAXDEF = 64;  // distinct blocks per handle on plan GENERIC
+
 enum { CONE_EQUALITY = 0, CONE_IDENTITY = 1, CONE_INEQUALITY = 2, CONE_SOC = 3 };   // typedefs.hpp:29-34
 
 struct AlDef {
@@ -37,9 +43,17 @@ struct AlKnot {          // everything a kernel needs about knot point k in ONE 
   // the block's Jacobian in the zero-padded pool AlTable::Gpad (plan MFMA16's row-layout kernels): def index * AL_GP_DEF
   int Gp_off[AL_MAXC];
 };
+struct AlKnotBig {       // the host's record of a knot point on every plan, and plan GENERIC's device table entry
+  int ncon;
+  int def[GEN_MAXC];
+  int z_off[GEN_MAXC];
+  int cone[GEN_MAXC], p[GEN_MAXC], g_per_problem[GEN_MAXC], G_off[GEN_MAXC];
+  int64_t g_off[GEN_MAXC];
+};
 template <typename T>
 struct AlTable {
-  const AlKnot* knots;   // [N + 1]
+  const AlKnot* knots;   // [N + 1]   (plans LANE, MFMA16)
+  const AlKnotBig* big = nullptr;   // [N + 1]   (plan GENERIC)
   const T* G;
   const T* g;
   T* z;

@@ -50,32 +50,33 @@ __device__ __forceinline__ double gen_wave_max(double v) {
 
 
 // ---- constraint blocks (augmented-Lagrangian terms, knotpoint_data.cpp:489-613; cones.cpp:13-202) for this plan ---------------------
-// wave_al_rows / wave_al_col of kernels/ilqr_mfma16.hip with the problem's own dimensions: lane i < 8 owns row i of each of the (at most
-// two) blocks of knot point k -- value c_i = G_i [x; u] - g_i, estimated / projected dual, AL cost share, violation -- and publishes
-//   jv[c * 8 + i] = (J^T z_proj)_i,  Jm[c * 64 + i * 8 + r] = J_ir (projection Jacobian),  Hm[c * 16 + i * 4 + r] (cone curvature)
-// to LDS for the lanes that own gradient / Hessian entries.  A second-order-cone block (p <= 4) is evaluated whole by lane 0.
+// Up to GEN_MAXC blocks per knot point, a zero / identity / orthant block of up to GEN_MAXP = 64 rows (the reference takes any number of
+// any dimension, knotpoint_data.cpp:155-161).  Lane i owns row i of EVERY block of knot point k -- value c_i = G_i [x; u] - g_i,
+// estimated / projected dual, AL cost share, violation -- and publishes to LDS, for the lanes that own gradient / Hessian entries,
+//   jv[c * GEN_MAXP + i] = (J^T z_proj)_i     jd[c * GEN_MAXP + i] = J_ii  (the projection Jacobian of those cones is diagonal)
+// A second-order-cone block (p <= AL_MAXSOC) is evaluated whole by lane 0: Jm[c * 16 + i * 4 + r] = J_ir, Hm[c * 16 + i * 4 + r] its curvature.
 // xs / us: the point, in LDS (us ignored at the terminal knot point).  Must be called by all lanes; no barrier inside.
+constexpr int GEN_AL_JV = GEN_MAXC * GEN_MAXP, GEN_AL_SOC = GEN_MAXC * AL_MAXSOC * AL_MAXSOC;
+template <typename T>
+__device__ __forceinline__ const AlKnotBig ALTRO_CONST_AS& gen_knot(const AlTable<T>& t, int k, int& zshift) {
+  const bool u = t.uniform != 0 && k < t.N;
+  zshift = u ? k * t.rows_per_knot : 0;
+  return *(const AlKnotBig ALTRO_CONST_AS*)(t.big + (u ? 0 : k));
+}
 template <typename T>
 __device__ __forceinline__ void gen_al_rows(const AlTable<T>& t, int k, int b, int64_t B, int n, int m, const double* xs, const double* us,
-                                            bool terminal, double rho_est, int lane, double* jv, double* Jm, double* Hm, double& cost,
-                                            double& viol, bool dual_update) {
+                                            bool terminal, double rho_est, int lane, double* jv, double* jd, double* Jm, double* Hm,
+                                            double& cost, double& viol, bool dual_update) {
   int zshift;
-  const AlKnot ALTRO_CONST_AS& kn = al_knot<T>(t, k, zshift);
+  const AlKnotBig ALTRO_CONST_AS& kn = gen_knot<T>(t, k, zshift);
   const int i = lane;
-  const bool row_lane = i < AL_MAXP;
-#pragma unroll
-  for (int c = 0; c < AL_MAXC; ++c) {
-    const bool has = c < kn.ncon;
-    const int p = has ? kn.p[c] : 0, cone = has ? kn.cone[c] : CONE_IDENTITY;
-    const T* G = t.G + (has ? kn.G_off[c] : 0);
-    if (row_lane) {
-      jv[c * AL_MAXP + i] = 0.0;
-      if (Jm)
-        for (int r = 0; r < AL_MAXP; ++r) Jm[c * 64 + i * 8 + r] = 0.0;
-      if (Hm && i < AL_MAXSOC)
-        for (int r = 0; r < AL_MAXSOC; ++r) Hm[c * 16 + i * 4 + r] = 0.0;
-    }
-    if (!has) continue;
+  const int ncon = kn.ncon;
+  for (int c = 0; c < ncon; ++c) {
+    const int p = kn.p[c], cone = kn.cone[c];
+    const T* G = t.G + kn.G_off[c];
+    jv[c * GEN_MAXP + i] = 0.0;
+    if (jd) jd[c * GEN_MAXP + i] = 0.0;
+    if (Jm && i < AL_MAXSOC * AL_MAXSOC) { Jm[c * 16 + i] = 0.0; Hm[c * 16 + i] = 0.0; }
     auto value = [&](int r) -> double {
       double s = 0.0;
       for (int e = 0; e < n; ++e) s += (double)G[r + e * p] * xs[e];
@@ -85,7 +86,7 @@ __device__ __forceinline__ void gen_al_rows(const AlTable<T>& t, int k, int b, i
       return s - gi;
     };
     if (cone != CONE_SOC) {
-      if (row_lane && i < p) {
+      if (i < p) {
         const double val = value(i);
         T* zp_ = t.z + (int64_t)(kn.z_off[c] + zshift + i) * B + b;
         const double ze = (double)*zp_ - rho_est * val;
@@ -93,8 +94,8 @@ __device__ __forceinline__ void gen_al_rows(const AlTable<T>& t, int k, int b, i
         if (cone == CONE_EQUALITY) { zp = ze; mkv = 1.0; viol = fmax(viol, fabs(val)); }
         else if (cone == CONE_INEQUALITY) { zp = fmin(0.0, ze); mkv = (ze <= 0.0) ? 1.0 : 0.0; viol = fmax(viol, fabs(fmin(0.0, val) - val)); }
         cost += zp * zp / (2.0 * rho_est);
-        jv[c * AL_MAXP + i] = mkv * zp;
-        if (Jm) Jm[c * 64 + i * 8 + i] = mkv;
+        jv[c * GEN_MAXP + i] = mkv * zp;
+        if (jd) jd[c * GEN_MAXP + i] = mkv;
         if (dual_update) *zp_ = (T)zp;
       }
     } else if (i == 0) {
@@ -122,9 +123,9 @@ __device__ __forceinline__ void gen_al_rows(const AlTable<T>& t, int k, int b, i
         double sj = 0.0;
 #pragma unroll
         for (int q = 0; q < AL_MAXSOC; ++q) sj += J[q + r * AL_MAXSOC] * zp[q];
-        jv[c * AL_MAXP + r] = sj;
+        jv[c * GEN_MAXP + r] = sj;
         if (Jm)
-          for (int q = 0; q < AL_MAXSOC; ++q) Jm[c * 64 + r * 8 + q] = J[r + q * AL_MAXSOC];
+          for (int q = 0; q < AL_MAXSOC; ++q) Jm[c * 16 + r * 4 + q] = J[r + q * AL_MAXSOC];
         if (dual_update) t.z[(int64_t)(kn.z_off[c] + zshift + r) * B + b] = (T)zp[r];
       }
       if (Hm) {
@@ -138,19 +139,18 @@ __device__ __forceinline__ void gen_al_rows(const AlTable<T>& t, int k, int b, i
     }
   }
 }
-// sum_c sum_i G_c[i][e] * w[c * 8 + i]  for column e of [x; u] of the constraint Jacobians of knot point k
+// sum_c sum_i G_c[i][e] * w[c * GEN_MAXP + i]  for column e of [x; u] of the constraint Jacobians of knot point k
 template <typename T>
 __device__ __forceinline__ double gen_al_col(const AlTable<T>& t, int k, int e, const double* w) {
   int zshift;
-  const AlKnot ALTRO_CONST_AS& kn = al_knot<T>(t, k, zshift);
+  const AlKnotBig ALTRO_CONST_AS& kn = gen_knot<T>(t, k, zshift);
   double s = 0.0;
-#pragma unroll
-  for (int c = 0; c < AL_MAXC; ++c)
-    if (c < kn.ncon) {
-      const int p = kn.p[c];
-      const T* G = t.G + kn.G_off[c];
-      for (int i = 0; i < p; ++i) s += (double)G[i + e * p] * w[c * AL_MAXP + i];
-    }
+  const int ncon = kn.ncon;
+  for (int c = 0; c < ncon; ++c) {
+    const int p = kn.p[c];
+    const T* G = t.G + kn.G_off[c];
+    for (int i = 0; i < p; ++i) s += (double)G[i + e * p] * w[c * GEN_MAXP + i];
+  }
   return s;
 }
 
@@ -255,7 +255,7 @@ __global__ void generic_expand_kernel(IlqrGenArgs<T> a) {
 // derivative phi' with the refreshed lx, lu.  Lanes 0..31: state rows, lanes 32..63: input rows.
 template <typename T>
 __global__ __launch_bounds__(64) void generic_merit_kernel(IlqrGenArgs<T> a) {
-  __shared__ double xs[GEN_MAX], dxs[GEN_MAX], das[GEN_MAX], us[GEN_MAX], dus[GEN_MAX], jv[AL_MAXC * AL_MAXP];
+  __shared__ double xs[GEN_MAX], dxs[GEN_MAX], das[GEN_MAX], us[GEN_MAX], dus[GEN_MAX], jv[GEN_AL_JV];
   const int b = blockIdx.x, lane = threadIdx.x;
   if (a.active && !a.active[b]) return;
   const int n = a.n, m = a.m, N = a.N;
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(64) void generic_merit_kernel(IlqrGenArgs<T> a) {
     __syncthreads();
     if (al) {   // the constraint rows' cost shares at the candidate point; (J^T z_proj) for the gradient below
       double Jal = 0.0;
-      gen_al_rows<T>(a.al, k, b, a.batch, n, m, xs, us, false, rho, lane, jv, nullptr, nullptr, Jal, viol, false);
+      gen_al_rows<T>(a.al, k, b, a.batch, n, m, xs, us, false, rho, lane, jv, nullptr, nullptr, nullptr, Jal, viol, false);
       J += Jal;
       __syncthreads();
     }
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(64) void generic_merit_kernel(IlqrGenArgs<T> a) {
     if (isx) { xs[lane] = x; dxs[lane] = x - (double)a.xn[((int64_t)b * (N + 1) + N) * n + lane]; a.x[(int64_t)b * a.x_bs + (int64_t)N * n + lane] = (T)x; }
     __syncthreads();
     if (al) {
-      gen_al_rows<T>(a.al, N, b, a.batch, n, m, xs, us, true, rho, lane, jv, nullptr, nullptr, J, viol, false);
+      gen_al_rows<T>(a.al, N, b, a.batch, n, m, xs, us, true, rho, lane, jv, nullptr, nullptr, nullptr, J, viol, false);
       __syncthreads();
     }
     if (isx) {
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(64) void generic_stationarity_kernel(IlqrGenArgs<T>
   res = gen_wave_max(res);
   double viol = 0.0;   // Feasibility (solver.cpp:224-231) of the candidate trajectory
   if (a.al.enabled) {
-    __shared__ double xs[GEN_MAX], us[GEN_MAX], jv[AL_MAXC * AL_MAXP];
+    __shared__ double xs[GEN_MAX], us[GEN_MAX], jv[GEN_AL_JV];
     const double rho = a.prob[b].rho;
     for (int k = 0; k <= N; ++k) {
       __syncthreads();
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(64) void generic_stationarity_kernel(IlqrGenArgs<T>
       if (lane >= 32 && lane - 32 < m) us[lane - 32] = k < N ? (double)a.u[(int64_t)b * a.u_bs + (int64_t)k * m + lane - 32] : 0.0;
       __syncthreads();
       double cost = 0.0;
-      gen_al_rows<T>(a.al, k, b, a.batch, n, m, xs, us, k == N, rho, lane, jv, nullptr, nullptr, cost, viol, false);
+      gen_al_rows<T>(a.al, k, b, a.batch, n, m, xs, us, k == N, rho, lane, jv, nullptr, nullptr, nullptr, cost, viol, false);
     }
     viol = gen_wave_max(viol);
   }
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(64) void generic_stationarity_kernel(IlqrGenArgs<T>
 // EXPAND_HESSIAN  [lxx lux^T; lux luu] = the cost's blocks + rho G^T (J^T J + curvature) G (knotpoint_data.cpp:597-613) into Q / R / H.
 template <typename T>
 __global__ __launch_bounds__(64) void generic_expand_al_kernel(IlqrGenArgs<T> a) {
-  __shared__ double xs[GEN_MAX], us[GEN_MAX], jv[AL_MAXC * AL_MAXP], Jm[AL_MAXC * 64], Hm[AL_MAXC * 16];
+  __shared__ double xs[GEN_MAX], us[GEN_MAX], jv[GEN_AL_JV], jd[GEN_AL_JV], Jm[GEN_AL_SOC], Hm[GEN_AL_SOC];
   const int lane = threadIdx.x;
   const int64_t wk = blockIdx.x;
   const int b = (int)(wk % a.batch), k = (int)(wk / a.batch);
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(64) void generic_expand_al_kernel(IlqrGenArgs<T> a)
   __syncthreads();
   {
     double cost = 0.0, viol = 0.0;
-    gen_al_rows<T>(a.al, k, b, a.batch, n, m, xs, us, terminal, a.prob[b].rho_est, lane, jv, Jm, Hm, cost, viol, false);
+    gen_al_rows<T>(a.al, k, b, a.batch, n, m, xs, us, terminal, a.prob[b].rho_est, lane, jv, jd, Jm, Hm, cost, viol, false);
   }
   __syncthreads();
   const T* Qk = a.cQ + ((int64_t)b * (N + 1) + k) * n * n;
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(64) void generic_expand_al_kernel(IlqrGenArgs<T> a)
   if (hess) {
     const double rho = a.prob[b].rho;
     int zshift;
-    const AlKnot ALTRO_CONST_AS& kn = al_knot<T>(a.al, k, zshift);
+    const AlKnotBig ALTRO_CONST_AS& kn = gen_knot<T>(a.al, k, zshift);
     const int wt = terminal ? n : w;
     for (int t = lane; t < wt * wt; t += 64) {
       const int r = t % wt, cc = t / wt;          // entry (r, cc) of the (n + m) x (n + m) block, column-major walk
@@ -470,16 +470,16 @@ __global__ __launch_bounds__(64) void generic_expand_al_kernel(IlqrGenArgs<T> a)
       for (int cidx = 0; cidx < kn.ncon; ++cidx) {
         const int p = kn.p[cidx];
         const T* G = a.al.G + kn.G_off[cidx];
-        const double* Jc = Jm + cidx * 64;
+        const double* Jc = Jm + cidx * 16;
         if (kn.cone[cidx] != CONE_SOC) {          // diagonal projection Jacobian: (J G)_(i r) = J_ii G_ir
           for (int i = 0; i < p; ++i) {
-            const double jii = Jc[i * 8 + i];
+            const double jii = jd[cidx * GEN_MAXP + i];
             s += (jii * (double)G[i + r * p]) * (jii * (double)G[i + cc * p]);
           }
         } else {
           for (int i = 0; i < p; ++i) {
             double jr = 0.0, jc = 0.0;
-            for (int q = 0; q < p; ++q) { jr += Jc[i * 8 + q] * (double)G[q + r * p]; jc += Jc[i * 8 + q] * (double)G[q + cc * p]; }
+            for (int q = 0; q < p; ++q) { jr += Jc[i * 4 + q] * (double)G[q + r * p]; jc += Jc[i * 4 + q] * (double)G[q + cc * p]; }
             s += jr * jc;
           }
           const double* Hc = Hm + cidx * 16;       // + G^T (d/dz J^T z_proj) G   (knotpoint_data.cpp:561-567)
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(64) void generic_expand_al_kernel(IlqrGenArgs<T> a)
 // DualUpdate (knotpoint_data.cpp:503-510) for the problems whose sweep asked for it, one wave per (problem, knot point)
 template <typename T>
 __global__ __launch_bounds__(64) void generic_dual_update_kernel(IlqrGenArgs<T> a) {
-  __shared__ double xs[GEN_MAX], us[GEN_MAX], jv[AL_MAXC * AL_MAXP];
+  __shared__ double xs[GEN_MAX], us[GEN_MAX], jv[GEN_AL_JV];
   const int lane = threadIdx.x;
   const int64_t wk = blockIdx.x;
   const int b = (int)(wk % a.batch), k = (int)(wk / a.batch);
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(64) void generic_dual_update_kernel(IlqrGenArgs<T> 
   if (lane >= 32 && lane - 32 < m) us[lane - 32] = terminal ? 0.0 : (double)a.u[(int64_t)b * a.u_bs + (int64_t)k * m + lane - 32];
   __syncthreads();
   double cost = 0.0, viol = 0.0;
-  gen_al_rows<T>(a.al, k, b, a.batch, n, m, xs, us, terminal, a.prob[b].rho_est, lane, jv, nullptr, nullptr, cost, viol, true);
+  gen_al_rows<T>(a.al, k, b, a.batch, n, m, xs, us, terminal, a.prob[b].rho_est, lane, jv, nullptr, nullptr, nullptr, cost, viol, true);
 }
 
 // ALTROSolver::ShiftTrajectory (altro_solver.cpp:283-293) on the candidate trajectory

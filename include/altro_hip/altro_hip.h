@@ -266,10 +266,16 @@ int altro_hip_get_expansion(altro_hip_batch* h, double* A, double* B, double* lx
  * which covers every constraint of the reference's tests (goal, control bounds, second-order-cone bound).
  * G: host, p x (n+m) column-major, shared by the batch.  g: host, [p] or (g_per_problem) [batch][p].
  * cone: ConstraintType order of typedefs.hpp:29-34: 0 EQUALITY, 1 IDENTITY, 2 INEQUALITY (c <= 0),
- * 3 SECOND_ORDER_CONE (||c[0:p-1]|| <= c[p-1]).  At most 2 blocks per knot point, p <= 8 (SOC: p <= 4).
+ * 3 SECOND_ORDER_CONE (||c[0:p-1]|| <= c[p-1]).
+ * Capacity (the reference appends constraints without limit, knotpoint_data.cpp:155-161; going past a limit here is an error that
+ * names it, never a truncation):
+ *   plan GENERIC       8 blocks per knot point, p <= 64 rows per block (SOC: p <= 4), 64 blocks per handle -- e.g. a (12, 4) problem
+ *                      with an input box (8 rows), a state box (24 rows) and more; create the handle with ALTRO_HIP_PLAN_GENERIC;
+ *   plans LANE, MFMA16 2 blocks per knot point, p <= 8 (SOC: p <= 4), 16 blocks per handle (the blocks ride fixed lanes / registers of
+ *                      the fast kernels); rows of one cone can be stacked into one block.
  * Returns the block id (>= 0) or a negative error.  Duals and penalties live on the device per problem and,
- * like the reference's, persist from one solve to the next (warm-started MPC) until reset.  Every plan (GENERIC since round 4:
- * any n, m <= 32, one wave per knot point).                                                              */
+ * like the reference's, persist from one solve to the next (warm-started MPC) until reset.  Every plan (GENERIC: n, m <= 32,
+ * one wave per knot point).                                                                              */
 int altro_hip_add_linear_constraint(altro_hip_batch* h, int k_first, int k_last, int cone, int p,
                                     const double* G, const double* g, int g_per_problem);
 int altro_hip_clear_constraints(altro_hip_batch* h);

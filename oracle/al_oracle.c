@@ -18,8 +18,8 @@
 #include <string.h>
 
 enum { ORACLE_CONE_EQUALITY = 0, ORACLE_CONE_IDENTITY = 1, ORACLE_CONE_INEQUALITY = 2, ORACLE_CONE_SOC = 3 };
-#define ORACLE_MAX_CON 4
-#define ORACLE_MAX_P 8
+#define ORACLE_MAX_CON 8
+#define ORACLE_MAX_P 32
 #define ORACLE_MAX_W 64   /* n + m up to 32 + 32 (plan GENERIC's shapes) */
 
 typedef struct {

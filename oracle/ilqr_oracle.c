@@ -48,8 +48,8 @@ void oracle_ls_defaults(oracle_linesearch*);
 double oracle_ls_run(oracle_linesearch*, oracle_merit_fn, void*, double, double, double);
 
 /* --- AL / conic pieces (al_oracle.c) ------------------------------------------------------------ */
-#define ORACLE_MAX_CON 4
-#define ORACLE_MAX_P 8
+#define ORACLE_MAX_CON 8
+#define ORACLE_MAX_P 32
 #define ORACLE_MAX_W 64   /* n + m up to 32 + 32 (plan GENERIC's shapes) */
 typedef struct {
   int type, p;
