@@ -89,3 +89,70 @@ def test_shard_range_covers_everything():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+# ---- shard.make_comm: either ALL ranks hold a communicator or all of them raise ---------------------------------
+class _FakeComm:
+    """Stands in for altro_amd.Comm (an RCCL communicator rank) on a box without GPUs: records what make_comm hands it."""
+    fail_id = False          # rank 0 cannot draw a unique id (librccl missing, ...)
+    fail_init_on = None      # this rank's ncclCommInitRank fails (wrong device, ...)
+    closed = 0
+
+    @staticmethod
+    def unique_id():
+        if _FakeComm.fail_id:
+            raise RuntimeError("librccl.so not found")
+        return bytes(range(128))
+
+    def __init__(self, device, rank, world, uid):
+        if _FakeComm.fail_init_on == rank:
+            raise RuntimeError("ncclCommInitRank: invalid device on rank %d" % rank)
+        self.device, self.rank, self.world, self.uid = device, rank, world, uid
+
+    def close(self):
+        _FakeComm.closed += 1
+
+
+def _comm_worker(rank, world, port, scenario, out):
+    import altro_amd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    altro_amd.Comm = _FakeComm
+    _FakeComm.fail_id = scenario == "id"
+    _FakeComm.fail_init_on = 1 if scenario == "init" else None
+    try:
+        c = shard.make_comm(rank, rank, world)
+        out.put((rank, "ok", c.world, c.uid == bytes(range(128)), _FakeComm.closed))
+    except altro_amd.AltroHipError as e:
+        out.put((rank, "raised", str(e), None, _FakeComm.closed))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("scenario", ["fine", "id", "init"])
+def test_make_comm_all_ranks_agree(scenario):
+    """The unique-id broadcast and the agreement after ncclCommInitRank of shard.make_comm over gloo, world 2, with a stand-in for
+    the RCCL communicator: every rank gets rank 0's 128 bytes; when rank 0 cannot draw an id, or ONE rank's init fails, BOTH ranks
+    raise (and the rank whose init succeeded closes its communicator) -- nobody is left inside a collective the other never joins."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_comm_worker, args=(r, world, port, scenario, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=150) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    if scenario == "fine":
+        assert [r[1] for r in res] == ["ok", "ok"] and all(r[2] == world and r[3] for r in res)
+    else:
+        assert [r[1] for r in res] == ["raised", "raised"], res
+        if scenario == "id":
+            assert all("unique id" in r[2] for r in res)
+        else:
+            assert all("ncclCommInitRank failed on at least one rank" in r[2] for r in res)
+            assert res[0][4] == 1 and res[1][4] == 0        # rank 0's communicator (which did come up) was closed again
