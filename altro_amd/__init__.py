@@ -236,7 +236,12 @@ class Batch:
         self.h = C.c_void_p()
         _check(self.L.altro_hip_batch_create(C.byref(self.h), N, n, m, batch, dtype, plan, flags,
                                              device, stream))
-        self.plan = self.L.altro_hip_batch_plan(self.h)
+
+    @property
+    def plan(self):
+        """The plan the handle runs NOW (a small-shape handle created with PLAN_AUTO moves from the padded tile to LANE when a LANE-only
+        device model is set on it)."""
+        return self.L.altro_hip_batch_plan(self.h)
 
     @classmethod
     def with_dims(cls, nx, nu, batch, dtype=F64, flags=0, device=0, stream=None):
@@ -250,7 +255,6 @@ class Batch:
         self.h = C.c_void_p()
         _check(self.L.altro_hip_batch_create_dims(C.byref(self.h), self.N, self.nx.ctypes.data_as(C.c_void_p),
                                                   self.nu.ctypes.data_as(C.c_void_p), batch, dtype, flags, device, stream))
-        self.plan = self.L.altro_hip_batch_plan(self.h)
         return self
 
     def _ragged_len(self, name):

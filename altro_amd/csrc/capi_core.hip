@@ -91,9 +91,19 @@ static int batch_create_impl(altro_hip_batch** out, int N, int n, int m, int bat
   // then the lane-per-problem plan where it is instantiated (n <= 6, m <= 3: a whole knot point fits one lane's registers),
   // then the padded tile, and GENERIC for everything larger.  (fp32 handles: fp32 storage, fp64 tile arithmetic.)
   const bool mfma_ok = (n <= 12 && m <= 4);
-  if (plan == ALTRO_HIP_PLAN_AUTO)
+  const bool was_auto = plan == ALTRO_HIP_PLAN_AUTO;
+  if (plan == ALTRO_HIP_PLAN_AUTO) {
+    // By measured cost of a sweep (tools/shape_cliff.py, profiles/r05i_shape_cliff*.txt; N = 128, fp64, ms at 4096 / 16384 problems):
+    //   (6,3) LANE 2.07 / 2.43, tile 0.77 / 2.97    (6,2) 1.40 / 1.73    (5,3) 1.33 / 1.61    (5,2) 1.23 / 1.46    (6,1) 0.87 / 1.13
+    //   (5,1) 0.55, (4,3) 0.71, (4,2) 0.26 ... : LANE below the tile's 0.77 at every batch
+    // A lane carries the whole 5 x 5 / 6 x 6 blocks, so below one wave per SIMD LANE is a long single-wave chain, while the padded tile
+    // costs the (12, 4) sweep whatever the shape and grows linearly past 4096 problems.  Hence: n >= 5 with m >= 2 rides the padded tile
+    // up to 6144 problems ((6, 3): 8192), LANE beyond.  A LANE-only compiled-in device model arriving later moves the (still empty)
+    // handle to LANE (altro_hip_set_model).
+    const bool small_tile = lane_supported(n, m) && dtype == ALTRO_HIP_F64 && n >= 5 && m >= 2 && batch <= ((n == 6 && m == 3) ? 8192 : 6144);
     plan = (n == 12 && m == 4) ? ALTRO_HIP_PLAN_MFMA16
-           : lane_supported(n, m) ? ALTRO_HIP_PLAN_LANE : (mfma_ok ? ALTRO_HIP_PLAN_MFMA16 : ALTRO_HIP_PLAN_GENERIC);
+           : (lane_supported(n, m) && !small_tile) ? ALTRO_HIP_PLAN_LANE : (mfma_ok ? ALTRO_HIP_PLAN_MFMA16 : ALTRO_HIP_PLAN_GENERIC);
+  }
   if (plan == ALTRO_HIP_PLAN_MFMA16 && !mfma_ok)
     return fail(ALTRO_HIP_ERR_UNSUPPORTED, "plan MFMA16 needs n <= 12 and m <= 4 (got %d, %d)", n, m);
   if (plan == ALTRO_HIP_PLAN_LANE && !lane_supported(n, m))
@@ -103,7 +113,7 @@ static int batch_create_impl(altro_hip_batch** out, int N, int n, int m, int bat
   HIP_TRY(hipSetDevice(device));
   altro_hip_batch* h = new altro_hip_batch();
   h->N = N; h->n = n; h->m = m; h->batch = batch; h->dtype = dtype; h->plan = plan;
-  h->flags = flags; h->device = device;
+  h->flags = flags; h->device = device; h->auto_plan = was_auto; h->user_stream = stream != nullptr;
   if (nx_k) { h->ragged = true; h->nxv.assign(nx_k, nx_k + N + 1); h->nuv.assign(nu_k, nu_k + N); }
   h->esz = dtype == ALTRO_HIP_F64 ? 8 : 4;
   if (stream) { h->stream = (hipStream_t)stream; }
@@ -182,8 +192,10 @@ static int batch_create_impl(altro_hip_batch** out, int N, int n, int m, int bat
       h->g_bstride[a] = at;
       if (qb && !(flags & ALTRO_HIP_STORE_QBLOCKS)) continue;
       ALLOC(h->g_arr[a], B * (size_t)at * E);
-      // candidate trajectory: defined (zero) from the start, so altro_hip_set_input_guess / _set_state_guess may come in any order with the cost
-      if (!rc && (a == G_u || a == G_x || a == G_y) && hipMemsetAsync(h->g_arr[a], 0, B * (size_t)at * E, h->stream) != hipSuccess)
+      // everything defined (zero) from the start: the candidate trajectory, so that altro_hip_set_input_guess / _set_state_guess may come
+      // in any order with the cost; the gains, so that the forward sweep of a problem whose backward sweep stopped at a failed
+      // factorisation (its K, d below the failing knot point are never written) rolls out finite numbers
+      if (!rc && hipMemsetAsync(h->g_arr[a], 0, B * (size_t)at * E, h->stream) != hipSuccess)
         rc = fail(ALTRO_HIP_ERR_HIP, "memset failed");
     }
     ALLOC(h->g_off, off.size() * sizeof(int64_t));
@@ -232,6 +244,26 @@ int altro_hip_batch_create(altro_hip_batch** out, int N, int n, int m, int batch
                            unsigned flags, int device, void* stream) {
   return batch_create_impl(out, N, n, m, batch, dtype, plan, flags, device, stream, nullptr, nullptr);
 }
+
+extern "C++" {
+namespace altro_hip { namespace capi {
+// A handle created with ALTRO_HIP_PLAN_AUTO that nothing has been set on yet becomes a handle of `plan` in place (same address):
+// a fresh handle is created and the two exchange their contents.
+int replan_empty_handle(altro_hip_batch* h, int plan) {
+  if (!h->auto_plan || h->dyn_set || h->cost_set || h->x0_set || h->model_set || h->lqr_cost_set || h->guess_set || !h->al_defs.empty())
+    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "this handle runs plan %d; create it with plan %d (or call altro_hip_set_model before anything else "
+                                           "on a handle created with ALTRO_HIP_PLAN_AUTO)", h->plan, plan);
+  altro_hip_batch* fresh = nullptr;
+  int rc = batch_create_impl(&fresh, h->N, h->n, h->m, h->batch, h->dtype, plan, h->flags, h->device, h->user_stream ? (void*)h->stream : nullptr,
+                             nullptr, nullptr);
+  if (rc) return rc;
+  std::swap(*h, *fresh);
+  h->auto_plan = false;
+  altro_hip_batch_destroy(fresh);   // (the old buffers; a caller-supplied stream is shared and not destroyed: own_stream is false on both)
+  return 0;
+}
+} }
+}  // extern "C++"
 
 int altro_hip_batch_create_dims(altro_hip_batch** out, int N, const int* nx, const int* nu, int batch, int dtype,
                                 unsigned flags, int device, void* stream) {

@@ -399,6 +399,12 @@ int altro_hip_set_model(altro_hip_batch* h, int model, float timestep, int bicyc
   if (rc) return rc;
   h->expansion_current = false;
   if (!(timestep > 0.0f)) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "time step must be positive (ErrorCodes::TimestepNotPositive)");
+  // plan AUTO put a small shape on the padded tile (cheaper sweeps below ~6000 problems, capi_core.hip); a compiled-in model that only
+  // plan LANE carries moves the still-empty handle there
+  if (h->plan == ALTRO_HIP_PLAN_MFMA16 && !ilqr_tile_model_supported(model, h->n, h->m) && ilqr_supported(model, h->n, h->m) &&
+      lane_supported(h->n, h->m)) {
+    if ((rc = replan_empty_handle(h, ALTRO_HIP_PLAN_LANE))) return rc;
+  }
   const bool tile = h->plan == ALTRO_HIP_PLAN_MFMA16 && ilqr_tile_model_supported(model, h->n, h->m);   // kernels/ilqr_tile_model.hip
   if (tile && h->dtype != ALTRO_HIP_F64)
     return fail(ALTRO_HIP_ERR_UNSUPPORTED, "device models on plan MFMA16 run on fp64 records (create the handle with ALTRO_HIP_F64)");

@@ -112,6 +112,8 @@ struct altro_hip_batch {
   int spec_max_iters = 25;        // need to reproduce the state machine's step sequence)
   ModelParams model{MODEL_LINEAR, 0.0f, 0, 2.7, 1.5};
   bool model_set = false, lqr_cost_set = false, guess_set = false;
+  bool auto_plan = false;         // created with ALTRO_HIP_PLAN_AUTO (the plan may still move to LANE when a LANE-only device model arrives)
+  bool user_stream = false;
   // augmented-Lagrangian constraint blocks (plan LANE): host mirrors + device tables, uploaded lazily
   std::vector<AlDef> al_defs;
   std::vector<AlKnotBig> al_knots;       // (the device table is AlKnot for plans LANE / MFMA16, AlKnotBig for plan GENERIC)
@@ -467,6 +469,7 @@ int rtc_launch(altro_hip_batch* h, int which, const IlqrArgs<T>& a);
 int rtc_tile_launch(altro_hip_batch* h, int which, const IlqrWaveArgs<double>& a);   // plan MFMA16: the model kernels of a caller's source
 
 // the sweep launchers (capi_tvlqr.hip), also used by the iLQR loop
+int replan_empty_handle(altro_hip_batch* h, int plan);   // capi_core.hip
 int launch_backward(altro_hip_batch* h, double reg);
 int launch_forward(altro_hip_batch* h);
 bool mfma16_forward_is_x4(const altro_hip_batch* h);   // the forward sweep runs four problems per wave (pure fp32)

@@ -79,10 +79,13 @@ typedef enum altro_hip_error {
   ALTRO_HIP_ERR_OUT_OF_MEMORY = -6
 } altro_hip_error;
 
-/* Which kernel family a handle runs.  AUTO: (12, 4) -> MFMA16; n <= 6, m <= 3 -> LANE; other n <= 12, m <= 4 -> MFMA16
- * (padded); anything larger (<= 256) -> GENERIC (the TVLQR sweep and the iLQR loop for dynamics given as data with a quadratic
- * cost and linear constraint blocks in every cone, kernels/ilqr_generic.hip: correctness first; no device models, no regularisation
- * retry). */
+/* Which kernel family a handle runs.  AUTO picks by measured sweep cost (tools/shape_cliff.py, profiles/r05i_shape_cliff*.txt):
+ * (12, 4) -> MFMA16; n <= 6, m <= 3 -> LANE, except n >= 5 with m >= 2 below 6144 problems ((6, 3): 8192), where a lane carrying
+ * whole 5 x 5 / 6 x 6 blocks is a long single-wave chain and the zero-padded tile is up to 2.7 x faster -> MFMA16 (such a handle moves
+ * to LANE by itself when altro_hip_set_model names a compiled-in model only LANE carries, provided nothing else was set on it yet);
+ * other n <= 12, m <= 4 -> MFMA16 (padded); anything larger (<= 256) -> GENERIC (the TVLQR sweep for any size; the iLQR loop for
+ * n, m <= 32 with dynamics given as data, a quadratic cost and linear constraint blocks in every cone, kernels/ilqr_generic.hip:
+ * correctness first; no device models, no regularisation retry). */
 typedef enum altro_hip_plan {
   ALTRO_HIP_PLAN_AUTO = 0,
   ALTRO_HIP_PLAN_GENERIC = 1, /* wave-per-problem, any (n, m) <= 256: blocks staged in LDS, or (past ~32) worked on in global memory;

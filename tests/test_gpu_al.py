@@ -288,8 +288,8 @@ def test_constrained_double_integrator_other_dims(dim):
     batch = 66
     x0s = np.zeros((batch, n)); x0s[:, :dim] = 1.5 + 0.02 * (np.arange(batch) % 13)[:, None]
     bt = altro_amd.Batch(N, n, m, batch)
-    assert bt.plan == altro_amd.PLAN_LANE
     bt.set_model(altro_amd.MODEL_DOUBLE_INTEGRATOR, h)
+    assert bt.plan == altro_amd.PLAN_LANE      # ((6, 3) under plan AUTO: the padded tile until a LANE-only model arrives)
     Qd = np.ones(n); Rd = np.full(m, 1e-2)
     bt.set_tracking_cost(np.stack([Qd, Qd]), Rd[None], np.zeros((2, n)), np.zeros((1, m)), k_stride_zero=True, batch_stride_zero=True)
     bt.set_initial_state(x0s)

@@ -39,13 +39,24 @@ def sweep_ms(N, n, m, batch, plan):
 
 
 def main():
-    N, batch = 128, 4096
-    print("# sweep (backward + forward) ms, N = %d, batch = %d, fp64, random LTV problems; plan AUTO vs plan GENERIC" % (N, batch))
-    print("%-8s %-8s %10s %10s %8s" % ("(n, m)", "AUTO ->", "AUTO ms", "GENERIC ms", "ratio"))
-    for (n, m) in [(12, 4), (12, 3), (11, 4), (10, 4), (8, 2), (7, 3), (6, 3), (6, 2), (5, 3), (5, 1), (4, 2), (4, 3), (3, 2), (2, 1), (1, 1)]:
-        a, used = sweep_ms(N, n, m, batch, altro_amd.PLAN_AUTO)
-        g, _ = sweep_ms(N, n, m, batch, altro_amd.PLAN_GENERIC)
-        print("%-8s %-8s %10.3f %10.3f %8.1f" % ("(%d, %d)" % (n, m), PLAN[used], a, g, g / a))
+    N = 128
+    batches = [int(b) for b in sys.argv[1:]] or [4096]
+    for batch in batches:
+        print("# sweep (backward + forward) ms, N = %d, batch = %d, fp64, random LTV problems; every plan that takes the shape" % (N, batch))
+        print("%-8s %-8s %10s %10s %10s %10s %8s" % ("(n, m)", "AUTO ->", "AUTO ms", "LANE ms", "MFMA16 ms", "GENERIC ms", "worst/AUTO"))
+        shapes = [(16, 4), (14, 7), (13, 4), (12, 4), (12, 3), (11, 4), (10, 4), (8, 2), (7, 3), (6, 3), (6, 2), (6, 1), (5, 3), (5, 2), (5, 1),
+                  (4, 3), (4, 2), (4, 1), (3, 3), (3, 2), (2, 1), (1, 1)]
+        for (n, m) in shapes:
+            if batch > 8192 and (n > 12 or m > 4):
+                continue
+            a, used = sweep_ms(N, n, m, batch, altro_amd.PLAN_AUTO)
+            row = {}
+            for name, plan, ok in (("LANE", altro_amd.PLAN_LANE, n <= 6 and m <= 3), ("MFMA16", altro_amd.PLAN_MFMA16, n <= 12 and m <= 4),
+                                   ("GENERIC", altro_amd.PLAN_GENERIC, batch <= 8192)):
+                row[name] = sweep_ms(N, n, m, batch, plan)[0] if ok else None
+            f = lambda v: ("%10.3f" % v) if v is not None else "%10s" % "-"
+            best = min([v for v in row.values() if v is not None] + [a])
+            print("%-8s %-8s %10.3f %s %s %s %8.2f" % ("(%d, %d)" % (n, m), PLAN[used], a, f(row["LANE"]), f(row["MFMA16"]), f(row["GENERIC"]), a / best))
 
 
 if __name__ == "__main__":
