@@ -672,7 +672,7 @@ int altro_hip_profile_get(altro_hip_batch* h, int slot, int* launches, double* t
     if (slot == 1 && mfma16_forward_is_x4(h)) *kernel_name = "mfma16_forward_f32x4_kernel";
     if (slot == 0 && h->plan == ALTRO_HIP_PLAN_MFMA16 && h->dtype == ALTRO_HIP_F32 && (h->flags & ALTRO_HIP_F32_PURE) &&
         !(h->flags & ALTRO_HIP_STORE_QBLOCKS))
-      *kernel_name = (h->batch % 4 == 0 && !std::getenv("ALTRO_HIP_F32_PURE_V1")) ? "mfma16_backward_f32x4_kernel"
+      *kernel_name = (h->batch % 4 == 0) ? "mfma16_backward_f32x4_kernel"
                                                                                     : "mfma16_backward_f32_kernel";
   }
   return 0;

@@ -8,7 +8,8 @@
 using namespace altro_hip;
 using namespace altro_hip::capi;
 
-namespace {
+namespace altro_hip {
+namespace capi {   // (external linkage: capi_solve.hip drives these)
 
 // ---- iLQR loop (plan LANE) ---------------------------------------------------------------------------
 // (re)build the device tables of the constraint blocks; duals restart from zero when the structure changes
@@ -294,8 +295,7 @@ int gen_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int 
   if (rc) return fail(ALTRO_HIP_ERR_HIP, "iLQR kernel launch failed");
   return 0;
 }
-int ilqr_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int want_deriv, double alpha_const,
-             int mode = EXPAND_GRADIENT | EXPAND_HESSIAN) {
+int ilqr_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int want_deriv, double alpha_const, int mode) {
   int rc = al_upload(h);
   if (rc) return rc;
   if (h->plan == ALTRO_HIP_PLAN_GENERIC)
@@ -388,7 +388,10 @@ int ilqr_check(altro_hip_batch* h, bool need_guess) {
   return 0;
 }
 
-}  // namespace
+template IlqrArgs<double> ilqr_args<double>(altro_hip_batch*, bool, bool, int, double);
+template IlqrArgs<float> ilqr_args<float>(altro_hip_batch*, bool, bool, int, double);
+}  // namespace capi
+}  // namespace altro_hip
 
 extern "C" {
 
@@ -978,7 +981,8 @@ int altro_hip_get_duals(altro_hip_batch* h, int k, int slot, double* z) {
 }
 
 // per-problem results gathered on the device into the struct's own layout: 56 bytes per problem cross PCIe, through pinned memory
-static int ilqr_gather_results(altro_hip_batch* h, altro_hip_solve_result* results) {
+}  // extern "C"
+int altro_hip::capi::ilqr_gather_results(altro_hip_batch* h, altro_hip_solve_result* results) {
   static_assert(sizeof(IlqrResult) == sizeof(altro_hip_solve_result), "IlqrResult mirrors altro_hip_solve_result");
   static_assert(sizeof(IlqrPollRec) == sizeof(altro_hip_poll_record), "IlqrPollRec mirrors altro_hip_poll_record");
   int rc;
@@ -994,6 +998,7 @@ static int ilqr_gather_results(altro_hip_batch* h, altro_hip_solve_result* resul
   if (stage != (void*)results) std::memcpy(results, stage, bytes);
   return 0;
 }
+extern "C" {
 
 int altro_hip_ilqr_solve_async(altro_hip_batch* h, const altro_hip_solve_options* opts) {
   if (!h) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "null handle");
@@ -1025,475 +1030,7 @@ int altro_hip_ilqr_wait(altro_hip_batch* h, altro_hip_solve_result* results) {
   return 0;
 }
 
-int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts,
-                         altro_hip_solve_result* results) {
-  // SolverImpl::Solve (solver.cpp:414-511) for every problem of the batch at once.  The host only
-  // sequences launches and reads two counters per step; all per-problem decisions are on the device.
-  int rc = ilqr_check(h, true);
-  if (rc) return rc;
-  h->expansion_current = false;
-  const bool async = h->async_request;
-  h->async_request = false;
-  if (h->async_pending) {   // a solve started with altro_hip_ilqr_solve_async is still out: finish it first
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    h->async_pending = false;
-  }
-  altro_hip_solve_options o;
-  if (opts) o = *opts;
-  else altro_hip_default_solve_options(&o);
-  IlqrLoopArgs la;
-  la.prob = h->i_prob; la.alpha = h->i_alpha; la.active = h->i_active; la.phi = h->i_phi; la.dphi = h->i_dphi;
-  la.counters = h->i_counters; la.batch = h->batch; la.iter = 0; la.iterations_max = o.iterations_max;
-  la.tol_stationarity = o.tol_stationarity; la.tol_meritfun_gradient = o.tol_meritfun_gradient;
-  la.tol_primal_feasibility = o.tol_primal_feasibility;
-  la.penalty_initial = o.penalty_initial; la.penalty_scaling = o.penalty_scaling; la.penalty_max = o.penalty_max;
-  const bool al = !h->al_defs.empty();
-  la.al_enabled = al ? 1 : 0;
-  la.reg = h->i_reg; la.bwd_status = h->status;
-  la.spec_trials = 1; la.spec_pre = 0; la.spec_sel = h->i_spec_sel; la.spec_refresh = h->i_spec_refresh;
-  la.reg_initial = o.reg_initial; la.reg_scale = o.reg_scale; la.reg_min = o.reg_min; la.reg_max = o.reg_max;
-  const bool reg_on = o.reg_retry_max > 0 || o.reg_initial > 0.0;
-  if (o.reg_initial < 0.0 || (o.reg_retry_max > 0 && !(o.reg_scale > 1.0 && o.reg_min > 0.0 && o.reg_max >= o.reg_min)))
-    return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "regularisation retry needs reg_initial >= 0, reg_scale > 1, 0 < reg_min <= reg_max");
-  if (al && !(o.penalty_initial > 0.0 && o.penalty_scaling > 0.0 && o.penalty_max > 0.0))
-    return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "penalty_initial, penalty_scaling and penalty_max must be positive");
-  la.ls = ls_default_options();
-  la.ls.try_cubic_first = 1;                                   // solver.cpp:248
-  la.ls.use_backtracking = o.use_backtracking_linesearch;      // solver.cpp:417
-  h->spec_beta = la.ls.beta_decrease; h->spec_max_iters = la.ls.max_iters;
-  // Counters without traffic on the stream: every counting launch (ILK_LS_BEGIN / _LS_FEED / _FINISH_ITER / _REG_RETRY) gets a
-  // fresh, zeroed 8-int slot of i_counters and publishes it into host-mapped memory itself (ilqr_publish_counters); an event
-  // behind the launch tells the host when to look.  No hipMemsetAsync / hipMemcpyAsync between the phases of a solve, and the
-  // host can enqueue AHEAD of a verdict it has not read yet (below).
-  if (!h->cnt_host) {
-    if (hipHostMalloc((void**)&h->cnt_host, (size_t)kCounterSlots * 8 * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
-      (void)hipGetLastError();
-      return fail(ALTRO_HIP_ERR_OUT_OF_MEMORY, "pinned host memory for the solve loop's counters");
-    }
-    void* dp = nullptr;
-    HIP_TRY(hipHostGetDevicePointer(&dp, h->cnt_host, 0));
-    h->cnt_host_dev = (int*)dp;
-    for (hipEvent_t& e : h->cnt_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  }
-  int slot = 0;   // slot 0 belongs to the one-launch solve kernel
-  bool slots_dirty = false;
-  auto reset_slots = [&]() -> int {   // start of a solve (and, should a solve ever use them up, in the middle of one)
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    HIP_TRY(hipMemsetAsync(h->i_counters, 0, (size_t)kCounterSlots * 8 * sizeof(int), h->stream));
-    slot = 0; slots_dirty = false;
-    return 0;
-  };
-  // launch a counting loop kernel on a fresh slot; returns the slot (< 0: error code negated)
-  auto counted = [&](int which_kernel) -> int {
-    if (slot + 1 >= kCounterSlots) { int rc_ = reset_slots(); if (rc_) return -1; }
-    ++slot; slots_dirty = true;
-    la.counters = h->i_counters + 8 * slot;
-    la.counters_pub = h->cnt_host_dev + 8 * slot;
-    if (ilqr_launch_loop(h->stream, which_kernel, la)) { (void)fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed"); return -1; }
-    if (hipEventRecord(h->cnt_ev[slot & 15], h->stream) != hipSuccess) { (void)fail(ALTRO_HIP_ERR_HIP, "hipEventRecord failed"); return -1; }
-    la.counters_pub = nullptr;
-    return slot;
-  };
-  auto verdict = [&](int s, int idx, int* out) -> int {   // wait for slot s's launch and read its counter idx
-    HIP_TRY(hipEventSynchronize(h->cnt_ev[s & 15]));
-    *out = ((volatile int*)h->cnt_host)[8 * s + idx];
-    return 0;
-  };
-  const bool lane_plan = h->plan == ALTRO_HIP_PLAN_LANE;
-  const bool generic_plan = h->plan == ALTRO_HIP_PLAN_GENERIC;   // (constraint rows in their one-wave-per-knot-point form: no merged end pass)
-  const int64_t cand_elems = (int64_t)h->batch * (h->N + 1) * (lane_plan ? lane_sizes(h->n, h->m).e_xuy : 28);
-  const size_t spare_each = (size_t)cand_elems * h->esz;   // one spare candidate trajectory
-  const int trials_cap = spec_trials_cap(h);
-  // Plan LANE: whole solves run in ONE launch -- a workgroup of four (eight) waves per 8 / 16 / 32 problems sequencing itself with
-  // no host in between (kernels/ilqr_fused.hip) -- bit-identical to the launch-sequenced loop further down
-  // (tests/test_gpu_fused.py, tools/fuzz_fused.py).  ALTRO_HIP_FUSED=1 / =0 forces one or the other (ALTRO_HIP_NO_FUSED, any
-  // value, = the latter); ALTRO_HIP_FUSED_SWEEPS=n hands the problems still running after n sweeps over to the loop (a test
-  // hook: the hand-over is exact at any sweep).
-  // (the kernel works on the buffers of the three-launch merit evaluation; ALTRO_HIP_LANE_FUSED -- FMA-contracted sweeps --
-  //  is a property of the launch-sequenced kernels only)
-  if (lane_plan) merit_split_prepare(h);
-  bool fused_can = lane_plan && o.iterations_max > 0 && !h->spec_no_memory && h->merit_split == 1 &&
-                   !(h->flags & ALTRO_HIP_LANE_FUSED) && h->model.kind != MODEL_USER &&   // (run-time models: sequenced loop)
-                   !h->cost_dense &&   // (the one-launch kernel is instantiated for the diagonal cost: a dense one runs sequenced)
-                   o.stop_when_running_at_most <= 0;   // (the batch-level early return is the sequenced loop's)
-  // POLICY: fused wherever the kernel exists.  Measured on MI355X (tools/solve_batches.py, profiles/r02p_solve_batches.txt;
-  // bicycle + steering bound, N = 50, median wall ms fused / sequenced): backtracking search 5.5 / 7.4 at 256 problems,
-  // 20 / 31 at 2048, 24 / 44 at 8192, 76 / 173 at 65536; cubic search 25 / 33, 28 / 61, 36 / 106, 99 / 316; pendulum, 8192
-  // problems: 2.4 / 4.1 (cubic), 2.6 / 4.3 (backtracking).
-  bool fused_want = true;
-  if (const char* e = std::getenv("ALTRO_HIP_FUSED")) fused_want = std::atoi(e) != 0;
-  if (std::getenv("ALTRO_HIP_NO_FUSED") != nullptr) fused_want = false;
-  bool fused = fused_can && fused_want;
-  if (fused && !ensure_spares(h, 3, spare_each))   // the waves' speculative steps (at most four per evaluation) need three
-    fused = false;                                 // spare trajectories; without them THIS solve runs the sequenced loop
-  if (async) {   // results while the solve runs: only the one-launch path can publish them
-    if (!fused || std::getenv("ALTRO_HIP_FUSED_SWEEPS") != nullptr)
-      return fail(ALTRO_HIP_ERR_UNSUPPORTED, "altro_hip_ilqr_solve_async needs the one-launch solve kernel (plan LANE with a compiled-in "
-                                             "device model, default environment); use altro_hip_ilqr_solve");
-    const size_t bytes = (size_t)h->batch * sizeof(IlqrPollRec);
-    if (!h->poll_host) {
-      if (hipHostMalloc(&h->poll_host, bytes, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
-          hipHostMalloc((void**)&h->poll_count_host, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
-        (void)hipGetLastError();
-        return fail(ALTRO_HIP_ERR_OUT_OF_MEMORY, "pinned host memory for %d poll records", h->batch);
-      }
-    }
-    std::memset(h->poll_host, 0, bytes);
-    *h->poll_count_host = 0;
-  }
-  // initial rollout, make it the nominal trajectory, expand everything (solver.cpp:420-434) -- inside the fused kernel when
-  // that runs (IlqrFusedArgs::prologue), five launches otherwise
-  // (not for the 2-state shapes: their eight-wave kernel lives on 256 registers and spills; with the prologue's code in it
-  //  the pendulum solve loses 0.11 ms, the bicycle's MPC step gains 0.03 ms)
-  const bool fused_prologue = fused && h->n > 2;
-  // Plan MFMA16: phi(0) and the line search's first step from one pass over the records (wave_merit2_kernel), the
-  // candidate's stationarity / feasibility from that same pass, and -- without constraint blocks -- the head of Solve as
-  // one pass too (ROLLOUT_INIT).  ALTRO_HIP_MERIT2=0 keeps the one-evaluation-per-launch sequence (the comparison the
-  // tests hold this one against).
-  if (h->plan == ALTRO_HIP_PLAN_GENERIC && o.reg_retry_max > 0)
-    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "the regularisation retry is built for plans LANE and MFMA16 (plan GENERIC: reg_retry_max = 0)");
-  bool dual = h->plan == ALTRO_HIP_PLAN_MFMA16 && std::getenv("ALTRO_HIP_NO_SPECULATION") == nullptr;   // (the first step rides before it is asked for)
-  if (const char* e = std::getenv("ALTRO_HIP_MERIT2")) dual = dual && std::atoi(e) != 0;
-  if (!fused_prologue) {
-    if (ilqr_launch_loop(h->stream, ILK_LOOP_INIT, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
-    if (dual && !al && !h->cost_dense && !h->model_set) {   // (ROLLOUT_INIT: linear dynamics as data, the diagonal cost's gradient)
-      rc = ilqr_run(h, IK_ROLLOUT, false, false, 0, 0.0, ROLLOUT_INIT);
-    } else {
-      rc = ilqr_run(h, IK_ROLLOUT, false, false, 0, 0.0);
-      if (!rc) rc = ilqr_run(h, IK_ACCEPT, false, false, 0, 0.0);
-      // without constraints the cost Hessian is constant and is written once, here; with them the gradient is
-      // formed with the penalty the constraints carry so far and SetPenalty comes after it (solver.cpp:424-430)
-      if (!rc) rc = ilqr_run(h, IK_EXPAND, false, false, 0, 0.0, al ? EXPAND_GRADIENT : (EXPAND_GRADIENT | EXPAND_HESSIAN));
-    }
-    if (rc) return rc;
-    if (al && ilqr_launch_loop(h->stream, ILK_SET_PENALTY, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
-  } else if ((rc = al_upload(h))) {   // (what ilqr_run does before any launch)
-    return rc;
-  }
-  int total_merit_launches = 0, sweeps = 0;
-  // speculative backtracking: how much of the chip the searching problems occupy, and how much there is
-  const bool spec_all_on = std::getenv("ALTRO_HIP_NO_SPECULATION") == nullptr && !generic_plan;   // (plan GENERIC evaluates one step per launch)
-  const bool spec_on = o.use_backtracking_linesearch != 0 && spec_all_on;
-  int running = h->batch;   // problems still iterating (counters[1] of the previous sweep)
-  auto spec_units = [&](int searching) -> int {   // wavefronts one merit launch keeps busy
-    return lane_plan ? (h->batch + 63) / 64 : searching;   // LANE: the searching lanes are scattered over all waves
-  };
-  const char* mrd = std::getenv("ALTRO_HIP_MERIT_DPP");
-  const bool merit_rounds_dpp = mrd == nullptr || std::atoi(mrd) != 0 || h->cost_dense || h->model_set;   // (a dense cost, a device model: row-layout kernels only)
-  // wavefronts a round of `trials` steps per searching problem launches: a wave per (problem, trial) in the LDS form, a wave per
-  // two problems and two trials in the DPP form (which keeps two waves per SIMD, not four: see the capacity below)
-  auto spec_waves = [&](int searching, int trials) -> int64_t {
-    if (lane_plan || !merit_rounds_dpp) return (int64_t)spec_units(searching) * trials;
-    return (int64_t)((searching + 1) / 2) * ((trials + 1) / 2);
-  };
-  const int64_t spec_capacity = lane_plan ? 512 : (merit_rounds_dpp ? 2048 : 4096);    // two waves per CU (LANE: latency-bound; more slow each other down) / four per SIMD (MFMA16)
-  h->spec_trials = 1;
-  struct MaskGuard {   // the backward sweep skips problems that have stopped, only inside this loop
-    altro_hip_batch* h;
-    int* active0;
-    ~MaskGuard() {   // whatever path leaves the solve: no speculation state, mask or swapped pointer survives it
-      h->bwd_active = nullptr; h->bwd_reg = nullptr; h->stat_skip = nullptr;
-      h->spec_trials = 1; h->spec_pre = 0;
-      h->i_active = active0;
-    }
-  } mask_guard{h, h->i_active};
-  h->bwd_active = h->i_active;
-  h->bwd_reg = reg_on ? h->i_reg : nullptr;
-  int total_reg_retries = 0;
-  int iter0 = 0;
-  if (fused) {
-    int fused_sweeps = o.iterations_max;
-    if (const char* e = std::getenv("ALTRO_HIP_FUSED_SWEEPS")) fused_sweeps = std::max(1, std::min(o.iterations_max, std::atoi(e)));
-    HIP_TRY(hipMemsetAsync(h->i_counters, 0, 4 * sizeof(int), h->stream));
-    IlqrFusedArgs fa{0, fused_sweeps, o.reg_retry_max, reg_on ? 1 : 0, h->i_counters, nullptr, fused_prologue ? 1 : 0};
-    if (async) {
-      void *dp = nullptr, *dc = nullptr;
-      HIP_TRY(hipHostGetDevicePointer(&dp, h->poll_host, 0));
-      HIP_TRY(hipHostGetDevicePointer(&dc, h->poll_count_host, 0));
-      fa.poll = (IlqrPollRec*)dp; fa.poll_count = (int*)dc;
-    }
-    const int clk_G = ilqr_fused_group(h->batch);
-    const int clk_groups = (h->batch + clk_G - 1) / clk_G;
-    unsigned long long* clk = nullptr;     // ALTRO_HIP_FUSED_CLOCK: per-phase time of the kernel, printed to stderr
-    if (std::getenv("ALTRO_HIP_FUSED_CLOCK") != nullptr && !async) {   // (an async solve returns before the clock could be read or freed)
-      const size_t bytes = (size_t)clk_groups * ILQR_FUSED_PHASES * sizeof(unsigned long long);
-      if (hipMalloc((void**)&clk, bytes) == hipSuccess) { (void)hipMemsetAsync(clk, 0, bytes, h->stream); fa.clk = clk; }
-    }
-    int frc;
-    if (h->dtype == ALTRO_HIP_F64) {
-      LaneArgs<double> ba{(const double*)h->l_in, (const double*)h->l_term, (double*)h->l_out, (double*)h->l_outn,
-                          (const double*)h->l_x0, (double*)h->l_xuy, (double*)h->delta_V, h->status, h->N, h->batch, 0.0,
-                          nullptr, nullptr};
-      frc = ilqr_launch_fused<double>(h->stream, h->model.kind, h->n, h->m, ilqr_args<double>(h, false, false, 1, 0.0), la, ba, fa);
-    } else {
-      LaneArgs<float> ba{(const float*)h->l_in, (const float*)h->l_term, (float*)h->l_out, (float*)h->l_outn,
-                         (const float*)h->l_x0, (float*)h->l_xuy, (float*)h->delta_V, h->status, h->N, h->batch, 0.0f,
-                         nullptr, nullptr};
-      frc = ilqr_launch_fused<float>(h->stream, h->model.kind, h->n, h->m, ilqr_args<float>(h, false, false, 1, 0.0), la, ba, fa);
-    }
-    if (frc) return fail(ALTRO_HIP_ERR_HIP, "fused iLQR kernel launch failed");
-    h->backward_done = true;
-    if (async) {   // the caller polls; altro_hip_ilqr_wait finishes the bookkeeping
-      h->async_pending = true;
-      h->forward_done = true;
-      h->solve_done = true;
-      return 0;
-    }
-    int c4[4];
-    HIP_TRY(hipMemcpyAsync(c4, h->i_counters, sizeof(c4), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    sweeps = c4[3];
-    running = c4[1];
-    if (clk) {
-      std::vector<unsigned long long> hc((size_t)clk_groups * ILQR_FUSED_PHASES);
-      (void)hipMemcpy(hc.data(), clk, hc.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-      (void)hipFree(clk);
-      static const char* names[ILQR_FUSED_PHASES] = {"hessians", "backward", "pre:roll", "pre:points", "pre:sums", "ls logic+select",
-                                                     "ls:roll", "ls:points", "ls:sums", "re-expand", "stationarity+accept", "duals+gradients"};
-      int slow = 0;
-      unsigned long long slow_t = 0;
-      std::vector<double> mean(ILQR_FUSED_PHASES, 0.0);
-      for (int g = 0; g < clk_groups; ++g) {
-        unsigned long long tot = 0;
-        for (int p = 0; p < ILQR_FUSED_PHASES; ++p) { tot += hc[(size_t)g * ILQR_FUSED_PHASES + p]; mean[p] += (double)hc[(size_t)g * ILQR_FUSED_PHASES + p]; }
-        if (tot > slow_t) { slow_t = tot; slow = g; }
-      }
-      std::fprintf(stderr, "[altro_hip] fused solve phase clock, us (mean over %d workgroups | slowest workgroup %d), %d sweeps max\n", clk_groups, slow, sweeps);
-      for (int p = 0; p < ILQR_FUSED_PHASES; ++p)
-        std::fprintf(stderr, "  %-22s %10.1f | %10.1f\n", names[p], mean[p] / clk_groups * 0.01, (double)hc[(size_t)slow * ILQR_FUSED_PHASES + p] * 0.01);
-      std::fprintf(stderr, "  %-22s %10s | %10.1f\n", "total", "", (double)slow_t * 0.01);
-    }
-    iter0 = running > 0 ? fused_sweeps : o.iterations_max;
-  }
-  bool hessians_ready = false;   // the previous sweep's last expansion left the cost Hessians of this one
-  // ---- the launch-sequenced loop, with the host running AHEAD of the device's verdicts -------------------------------------------
-  // Every kernel of a sweep masks itself (running / active / the line search's own state), so a launch made for problems that
-  // turn out not to need it is a no-op.  The host therefore does not wait for a count before it enqueues what follows when the
-  // solve's own history says the work will be needed: the next line-search round goes out before the previous round's count is
-  // read (as many rounds ahead as the last sweep took), and from the second sweep on the next sweep's head goes out before
-  // the count of problems still running is read.  A verdict that says "nobody" stops the enqueueing; what is already queued runs
-  // on empty masks.  The stream never drains inside a solve, and no memset or copy rides on it (counter slots, above).  Results
-  // are those of the wait-then-launch loop bit for bit: the same kernels see the same masks in the same order.
-  // (ALTRO_HIP_NO_RUNAHEAD: wait for every verdict before enqueueing on -- the comparison the tests hold this against)
-  const char* nra = std::getenv("ALTRO_HIP_NO_RUNAHEAD");
-  const bool run_ahead = nra == nullptr || std::atoi(nra) == 0;
-  if (iter0 < o.iterations_max)   // the one memset of the solve: every slot but the one-launch kernel's starts from zero
-    HIP_TRY(hipMemsetAsync(h->i_counters + 8, 0, (size_t)(kCounterSlots - 1) * 8 * sizeof(int), h->stream));
-  // Plan MFMA16, diagonal cost, bound-type blocks only: the Hessian blocks differ from sweep to sweep on their diagonal alone, so
-  // after this solve's first (full) Hessian expansion the later ones store 16 values per knot point instead of 158 (EXPAND_DIAG)
-  bool hessian_stored = false;
-  const int diag_mode = (h->plan == ALTRO_HIP_PLAN_MFMA16 && al && !h->cost_dense && h->al_all_sel && std::getenv("ALTRO_HIP_NO_EXPAND_DIAG") == nullptr) ? EXPAND_DIAG : 0;
-  const int stop_at = o.stop_when_running_at_most > 0 ? o.stop_when_running_at_most : 0;
-  int pend_finish = -1;          // slot of the previous sweep's ILK_FINISH_ITER whose count has not been read yet
-  bool multi_sweep = false;      // a second sweep was needed: from now on the next sweep's head is enqueued ahead
-  int rounds_last = 0;           // line-search rounds the previous sweep needed (beyond the dual / first evaluation)
-  bool stop = false;
-  for (int iter = iter0; iter < o.iterations_max && !stop; ++iter) {
-    la.iter = iter;
-    if (ilqr_launch_loop(h->stream, ILK_MARK_RUNNING, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
-    if (al && !hessians_ready) {                                // CalcExpansions: cost Hessians (solver.cpp:448)
-      rc = ilqr_run(h, IK_EXPAND, false, true, 0, 0.0, EXPAND_HESSIAN | (hessian_stored ? diag_mode : 0));
-      if (rc) return rc;
-      hessian_stored = true;
-    }
-    rc = launch_backward(h, 0.0);                               // BackwardPass (reg = 0, solver.cpp:363)
-    if (rc) return rc;
-    h->backward_done = true;
-    for (int attempt = 0; attempt < o.reg_retry_max; ++attempt) {   // extension: repeat failed problems with more reg
-      const int sr = counted(ILK_REG_RETRY);
-      if (sr < 0) return ALTRO_HIP_ERR_HIP;
-      int again = 0;
-      if ((rc = verdict(sr, 2, &again))) return rc;
-      if (again == 0) break;
-      total_reg_retries += again;
-      rc = launch_backward(h, 0.0);
-      if (rc) return rc;
-    }
-    if (o.reg_retry_max > 0 && ilqr_launch_loop(h->stream, ILK_MARK_RUNNING, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
-    // ForwardPass: phi(0), then the line search (solver.cpp:237-271).  While the running problems leave half of the
-    // chip idle, the first step the search will ask for (alpha0 = 1, known in advance) rides in the same launch as
-    // phi(0) -- phi, phi' and the trajectory go to spare row / buffer 0 -- and ILK_LS_BEGIN consumes it at once.
-    bool refreshed = false;
-    bool pre = !dual && spec_all_on && !h->spec_no_memory && spec_waves(running, 2) <= spec_capacity;
-    if (pre && !ensure_spares(h, 1, spare_each)) {   // an optimisation only: carry on one step per launch
-      h->spec_no_memory = true;
-      pre = false;
-    }
-    h->spec_trials = pre ? 2 : 1; h->spec_pre = pre ? 1 : 0;
-    // (mode 1 on IK_MERIT2: the matrix-core form of the two-trial evaluation, wave_merit2_mfma_kernel -- unconstrained problems,
-    //  fp64 records.  Opt-in, ALTRO_HIP_MERIT2_MFMA=1: correct to 1e-12 but, as built, 0.99 ms where the LDS-broadcast form
-    //  takes 0.86 on C1 -- 222 registers, two waves per SIMD under a chain of 13 dependent-issue MFMAs per knot point;
-    //  DESIGN.md 4.11)
-    const char* mm = std::getenv("ALTRO_HIP_MERIT2_MFMA");
-    const bool merit_mfma = mm != nullptr && std::atoi(mm) != 0;
-    // (mode 2: the same evaluation with the broadcasts on the VALU's DPP path and two problems per wave,
-    //  kernels/ilqr_merit2_dpp.hip -- with or without constraint blocks, bit-identical; ALTRO_HIP_MERIT2_DPP=0 keeps the LDS form)
-    const char* md = std::getenv("ALTRO_HIP_MERIT2_DPP");
-    const bool merit_dpp = md == nullptr || std::atoi(md) != 0;
-    const int merit2_mode = (merit_mfma && !al && h->dtype == ALTRO_HIP_F64) ? 1 : merit_dpp ? 2 : 0;
-    rc = dual ? ilqr_run(h, IK_MERIT2, true, true, 1, 0.0, merit2_mode)
-              : ilqr_run(h, IK_MERIT, true, true, 1, 0.0);
-    h->spec_trials = 1; h->spec_pre = 0;
-    if (rc) return rc;
-    int sweep_merit_launches = 1;
-    la.spec_pre = (pre || dual) ? 1 : 0;
-    la.spec_flip = dual ? 1 : 0; la.stat_done = h->i_stat_done; la.stat_inline = h->dtype == ALTRO_HIP_F64 ? 1 : 0;
-    int prev = counted(ILK_LS_BEGIN);      // the slot whose [0] says whether another evaluation is needed
-    if (prev < 0) return ALTRO_HIP_ERR_HIP;
-    la.spec_pre = 0; la.spec_flip = 0;
-    if (dual) {
-      // searches that ended WITHOUT the first step (phi' too small, not a descent direction): their candidate is the alpha = 0
-      // evaluation's, redone by the single-step kernel for them alone -- launched on their mask whether or not there are any
-      // (counted only when there were: the verdict is read with the first round's)
-      int* keep = h->i_active;
-      h->i_active = h->i_spec_refresh;
-      rc = ilqr_run(h, IK_MERIT, true, true, 1, 0.0);
-      h->i_active = keep;
-      if (rc) return rc;
-    } else if (pre) {
-      rc = ilqr_run(h, IK_SPEC_SELECT, false, false, 0, 0.0);
-      if (rc) return rc;
-      refreshed = true;
-    } else {
-      // The first trial step is launched without asking the device whether any problem needs it: the masks make it
-      // a no-op when none does, and it saves one host read-back per sweep (these loops are latency-bound).
-      rc = ilqr_run(h, IK_MERIT, true, true, 1, 0.0);
-      if (rc) return rc;
-      ++sweep_merit_launches;
-      prev = counted(ILK_LS_FEED);
-      if (prev < 0) return ALTRO_HIP_ERR_HIP;
-    }
-    const int begin_slot = dual ? prev : -1;
-    // the previous sweep's verdict, now that this sweep's head keeps the device busy
-    if (pend_finish >= 0) {
-      int still = 0;
-      if ((rc = verdict(pend_finish, 1, &still))) return rc;
-      pend_finish = -1;
-      ++sweeps;                                   // (the previous sweep)
-      if (still == 0) { stop = true; break; }     // nobody was running: what this sweep enqueued ran on empty masks
-      running = still;
-    }
-    int searching = -1;            // the last count read (the speculation width follows it)
-    int rounds = 0;
-    for (int guard = 0; guard < 64; ++guard) {
-      const bool ahead = run_ahead && rounds < rounds_last;    // history says this round will be needed: enqueue it first
-      if (!ahead) {
-        if ((rc = verdict(prev, 0, &searching))) return rc;
-        if (searching == 0) break;
-      }
-      // Speculative backtracking: once the problems still searching leave most of the chip idle, one launch
-      // evaluates the next 2, 4 or 8 steps of the (known) sequence alpha beta^j for each of them; the feed
-      // kernel consumes them in order, so every decision is the sequential one (kernels/ilqr_types.h).
-      const int width_for = searching > 0 ? searching : running;
-      int trials = 1;
-      if (spec_on && !h->spec_no_memory)
-        while (trials < trials_cap && spec_waves(width_for, trials * 2) <= spec_capacity) trials *= 2;   // as wide as leaves the launch within the capacity
-      // plan MFMA16's rounds in the DPP form evaluate two trials per problem in the lanes one trial would leave idle
-      // (kernels/ilqr_merit2_dpp.hip): the second step of the known sequence rides along whatever the occupancy
-      if (spec_on && !lane_plan && !h->spec_no_memory && trials < 2 && merit_rounds_dpp) trials = 2;
-      if (trials > 1 && !ensure_spares(h, trials_cap - 1, spare_each)) {
-        while (trials > 1 && trials - 1 > h->spare_count) trials /= 2;   // as wide as the spares there are
-        if (trials == 1 && h->spare_count == 0) h->spec_no_memory = true;
-      }
-      const bool spec = trials > 1;
-      h->spec_trials = trials;
-      la.spec_trials = h->spec_trials;
-      rc = ilqr_run(h, IK_MERIT, true, true, 1, 0.0);
-      if (rc) return rc;
-      const int sf = counted(ILK_LS_FEED);
-      if (sf < 0) return ALTRO_HIP_ERR_HIP;
-      if (spec) {
-        rc = ilqr_run(h, IK_SPEC_SELECT, false, false, 0, 0.0);
-        if (rc) return rc;
-      }
-      h->spec_trials = 1;
-      la.spec_trials = 1;
-      if (ahead) {
-        if ((rc = verdict(prev, 0, &searching))) return rc;
-        if (searching == 0) break;      // the round just enqueued was not needed: it ran on empty masks (not counted)
-      }
-      ++sweep_merit_launches; ++rounds;
-      if (spec) refreshed = true;
-      prev = sf;
-    }
-    rounds_last = rounds;
-    if (begin_slot >= 0) {   // (the verdicts of ILK_LS_BEGIN's launch are in: it was waited for above)
-      int redone = 0;
-      if ((rc = verdict(begin_slot, 3, &redone))) return rc;
-      if (redone > 0) ++sweep_merit_launches;
-    }
-    total_merit_launches += sweep_merit_launches;
-    if (refreshed) {   // steps accepted from a speculative trial carry no phi' pass: redo their expansion (what the
-                       // derivative pass of a sequential trial would have left behind)
-      int* keep = h->i_active;
-      h->i_active = h->i_spec_refresh;
-      rc = ilqr_run(h, IK_EXPAND, false, true, 0, 0.0, EXPAND_GRADIENT);
-      h->i_active = keep;
-      if (rc) return rc;
-    }
-    // convergence criteria on the accepted candidate, then make it the nominal (solver.cpp:459-469)
-    if (ilqr_launch_loop(h->stream, ILK_MARK_RUNNING, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
-    {   // (dual: only the problems whose step was not the one the two-trial pass evaluated -- the skip mask; most waves leave at once)
-      h->stat_skip = dual ? h->i_stat_done : nullptr;
-      rc = ilqr_run(h, IK_STATIONARITY, false, true, 0, 0.0);
-      h->stat_skip = nullptr;
-    }
-    if (!rc) rc = ilqr_run(h, IK_ACCEPT, false, true, 0, 0.0);
-    if (rc) return rc;
-    const int fin = counted(ILK_FINISH_ITER);
-    if (fin < 0) return ALTRO_HIP_ERR_HIP;
-    if (al) {   // DualUpdate, PenaltyUpdate, refreshed gradients for the problems that asked (solver.cpp:470-489)
-      // (plan MFMA16, DPP forms: ONE pass over the constraint rows does the dual update, the gradients and the next sweep's
-      //  Hessians -- EXPAND_DUAL | EXPAND_NEXT -- and PenaltyUpdate's bookkeeping follows it)
-      const char* ed0 = std::getenv("ALTRO_HIP_EXPAND_DPP");
-      const char* ar0 = std::getenv("ALTRO_HIP_ALROWS_DPP");
-      const bool fused_end = !lane_plan && !generic_plan && !(ed0 != nullptr && std::atoi(ed0) == 0) && !(ar0 != nullptr && std::atoi(ar0) == 0);
-      if (fused_end) {
-        h->expand_penalty_scaling = o.penalty_scaling; h->expand_penalty_max = o.penalty_max;
-        rc = ilqr_run(h, IK_EXPAND, false, true, 0, 0.0, EXPAND_GRADIENT | EXPAND_HESSIAN | EXPAND_NEXT | EXPAND_DUAL | (hessian_stored ? diag_mode : 0));
-        if (rc) return rc;
-        if (ilqr_launch_loop(h->stream, ILK_PENALTY_UPDATE, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
-        hessians_ready = true;
-      } else {
-        rc = ilqr_run(h, IK_DUAL, false, false, 0, 0.0);
-        if (rc) return rc;
-        if (ilqr_launch_loop(h->stream, ILK_PENALTY_UPDATE, la)) return fail(ALTRO_HIP_ERR_HIP, "iLQR loop kernel launch failed");
-        // ... and, in the same pass over the constraint rows, the cost Hessians the NEXT sweep's CalcExpansions would form:
-        // nothing they depend on (trajectory, duals, penalties) changes between here and there
-        // (plan MFMA16, DPP form: gradient for the problems whose duals changed, Hessians for every problem still running)
-        const char* ed = std::getenv("ALTRO_HIP_EXPAND_DPP");
-        const bool merged = !lane_plan && !generic_plan && !(ed != nullptr && std::atoi(ed) == 0);
-        rc = ilqr_run(h, IK_EXPAND, false, true, 0, 0.0, merged ? (EXPAND_GRADIENT | EXPAND_HESSIAN | EXPAND_NEXT | (hessian_stored ? diag_mode : 0)) : EXPAND_GRADIENT);
-        if (rc) return rc;
-        hessians_ready = merged;
-      }
-    }
-    // how many problems still run: read now -- or, once the solve has shown that it takes several sweeps, after the next sweep's
-    // head has been enqueued
-    if (run_ahead && multi_sweep && iter + 1 < o.iterations_max && stop_at == 0) {
-      pend_finish = fin;
-      continue;
-    }
-    int still = 0;
-    if ((rc = verdict(fin, 1, &still))) return rc;
-    ++sweeps;
-    if (still <= stop_at) break;   // (stop_at = 0: nobody runs any more; > 0: altro_hip_solve_options::stop_when_running_at_most)
-    running = still;
-    multi_sweep = true;
-  }
-  if (pend_finish >= 0) {   // (the last sweep the iteration limit allowed)
-    int still = 0;
-    if ((rc = verdict(pend_finish, 1, &still))) return rc;
-    ++sweeps;
-  }
-  h->forward_done = true;
-  h->solve_done = true;
-  HIP_TRY(hipStreamSynchronize(h->stream));   // (iterations_max <= 0 reaches this point with kernels still in flight)
-  if (results && (rc = ilqr_gather_results(h, results))) return rc;
-  h->last_sweeps = sweeps;
-  h->last_merit_launches = total_merit_launches;
-  return 0;
-}
+// altro_hip_ilqr_solve: capi_solve.hip
 
 void altro_hip_default_solve_options(altro_hip_solve_options* o) {
   if (!o) return;

@@ -470,6 +470,17 @@ int rtc_tile_launch(altro_hip_batch* h, int which, const IlqrWaveArgs<double>& a
 
 // the sweep launchers (capi_tvlqr.hip), also used by the iLQR loop
 int replan_empty_handle(altro_hip_batch* h, int plan);   // capi_core.hip
+// capi_ilqr.hip, for the solve loop in capi_solve.hip
+int al_upload(altro_hip_batch* h);
+int ilqr_check(altro_hip_batch* h, bool need_guess);
+int ilqr_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int want_deriv, double alpha_const,
+             int mode = EXPAND_GRADIENT | EXPAND_HESSIAN);
+template <typename T>
+IlqrArgs<T> ilqr_args(altro_hip_batch* h, bool use_alpha, bool use_active, int want_deriv, double alpha_const);
+int spec_trials_cap(const altro_hip_batch* h);
+bool ensure_spares(altro_hip_batch* h, int count, size_t bytes_each);
+void merit_split_prepare(altro_hip_batch* h);
+int ilqr_gather_results(altro_hip_batch* h, altro_hip_solve_result* results);
 int launch_backward(altro_hip_batch* h, double reg);
 int launch_forward(altro_hip_batch* h);
 bool mfma16_forward_is_x4(const altro_hip_batch* h);   // the forward sweep runs four problems per wave (pure fp32)

@@ -174,28 +174,13 @@ int launch_backward(altro_hip_batch* h, double reg) {
     else if (sq || !(h->flags & ALTRO_HIP_F32_PURE)) mfma16_launch_backward<float>(h, reg, sq);   // fp32 storage, fp64 tiles
     else {   // opt-in: pure fp32 on v_mfma_f32_16x16x4_f32
       auto a = mfma16_args<float>(h, reg);
-      // four problems per wave (kernels/tvlqr_mfma16_f32x4.hip) whenever the batch allows it; the one-problem kernel
-      // stays for ragged batches and, under ALTRO_HIP_F32_PURE_V1, for A/B measurements
-      static const bool v1 = std::getenv("ALTRO_HIP_F32_PURE_V1") != nullptr;
-      if (h->batch % 4 == 0 && !v1) {
+      // four problems per wave (kernels/tvlqr_mfma16_f32x4.hip) whenever the batch allows it; the one-problem kernel stays for
+      // batches that are not whole quads.  Ring depth 2, two waves per SIMD: measured on C4 against (1,2) (1,3) (3,1) (3,2) (4,1) --
+      // 3.40 ms against 4.1-4.4 (profiles/r02g_c4_quad_variants.txt); the other instantiations left with round 5's clean-up
+      if (h->batch % 4 == 0) {
         const dim3 grid(mf_grid(h->batch / 4));
-        // (ring depth, waves per SIMD): measured on C4 (profiles/r02g_c4_quad_variants.txt: 3.40 ms for (2, 2), 4.1-4.4 ms for
-        // the others and for the one-problem kernel); ALTRO_HIP_F32X4 = "DW" overrides
-        static const int variant = std::getenv("ALTRO_HIP_F32X4") ? std::atoi(std::getenv("ALTRO_HIP_F32X4")) : 22;
-#define MFQ_LAUNCH(D, W)                                                                                               \
-  do {                                                                                                                 \
-    if (a.has_f) PROF_LAUNCH((mfma16_backward_f32x4_kernel<true, D, W>), grid, dim3(64), 0, h->stream, a);       \
-    else PROF_LAUNCH((mfma16_backward_f32x4_kernel<false, D, W>), grid, dim3(64), 0, h->stream, a);              \
-  } while (0)
-        switch (variant) {
-          case 13: MFQ_LAUNCH(1, 3); break;
-          case 12: MFQ_LAUNCH(1, 2); break;
-          case 32: MFQ_LAUNCH(3, 2); break;
-          case 31: MFQ_LAUNCH(3, 1); break;
-          case 41: MFQ_LAUNCH(4, 1); break;
-          default: MFQ_LAUNCH(2, 2); break;
-        }
-#undef MFQ_LAUNCH
+        if (a.has_f) PROF_LAUNCH((mfma16_backward_f32x4_kernel<true, 2, 2>), grid, dim3(64), 0, h->stream, a);
+        else PROF_LAUNCH((mfma16_backward_f32x4_kernel<false, 2, 2>), grid, dim3(64), 0, h->stream, a);
       } else if (a.has_f) PROF_LAUNCH((mfma16_backward_f32_kernel<true, 3>), dim3(mf_grid(h->batch)), dim3(64), 0, h->stream, a);
       else PROF_LAUNCH((mfma16_backward_f32_kernel<false, 3>), dim3(mf_grid(h->batch)), dim3(64), 0, h->stream, a);
     }
@@ -228,8 +213,7 @@ int launch_backward(altro_hip_batch* h, double reg) {
 
 // the pure-fp32 forward sweep with four problems per wave: fp32 records, fp32 arithmetic asked for, a batch of whole quads
 bool mfma16_forward_is_x4(const altro_hip_batch* h) {
-  static const bool v1 = std::getenv("ALTRO_HIP_F32_PURE_FWD_V1") != nullptr;   // A/B: the one-problem fp64-arithmetic kernel
-  return h->plan == ALTRO_HIP_PLAN_MFMA16 && h->dtype == ALTRO_HIP_F32 && (h->flags & ALTRO_HIP_F32_PURE) && h->batch % 4 == 0 && !v1;
+  return h->plan == ALTRO_HIP_PLAN_MFMA16 && h->dtype == ALTRO_HIP_F32 && (h->flags & ALTRO_HIP_F32_PURE) && h->batch % 4 == 0;
 }
 
 int launch_forward(altro_hip_batch* h) {
@@ -243,20 +227,9 @@ int launch_forward(altro_hip_batch* h) {
       auto a = mfma16_args<float>(h, 0.0);
       if (mfma16_forward_is_x4(h)) {   // pure fp32, four problems per wave (kernels/tvlqr_mfma16_fwd_f32x4.hip)
         const dim3 grid(mf_grid(h->batch / 4));
-        // (ring depth, waves per SIMD): measured on C4 on two boxes (profiles/r03e_ / r03f_c4_fwd_variants.txt): (2, 2) 2.47 / 2.375 ms,
-        // (3, 2) 2.43 / 2.405, (4, 2) 2.49 / 2.39, (1, 4) 2.63 / 2.44, (2, 4) 2.61 / 2.42 (spills), the one-problem kernel
-        // 2.84 / 2.81; ALTRO_HIP_F32X4_FWD = "DW" overrides (tools/c4_fwd_ab.sh)
-        static const int variant = std::getenv("ALTRO_HIP_F32X4_FWD") ? std::atoi(std::getenv("ALTRO_HIP_F32X4_FWD")) : 22;
-        switch (variant) {
-          case 14: PROF_LAUNCH((mfma16_forward_f32x4_kernel<1, 4>), grid, dim3(64), 0, h->stream, a); break;
-          case 34: PROF_LAUNCH((mfma16_forward_f32x4_kernel<3, 4>), grid, dim3(64), 0, h->stream, a); break;
-          case 32: PROF_LAUNCH((mfma16_forward_f32x4_kernel<3, 2>), grid, dim3(64), 0, h->stream, a); break;
-          case 42: PROF_LAUNCH((mfma16_forward_f32x4_kernel<4, 2>), grid, dim3(64), 0, h->stream, a); break;
-          case 24: PROF_LAUNCH((mfma16_forward_f32x4_kernel<2, 4>), grid, dim3(64), 0, h->stream, a); break;
-          case 23: PROF_LAUNCH((mfma16_forward_f32x4_kernel<2, 3>), grid, dim3(64), 0, h->stream, a); break;
-          case 33: PROF_LAUNCH((mfma16_forward_f32x4_kernel<3, 3>), grid, dim3(64), 0, h->stream, a); break;
-          default: PROF_LAUNCH((mfma16_forward_f32x4_kernel<2, 2>), grid, dim3(64), 0, h->stream, a); break;
-        }
+        // ring depth 2, two waves per SIMD: measured on C4 on two boxes against seven other (depth, waves) pairs and the one-problem
+        // kernel (profiles/r03e_ / r03f_c4_fwd_variants.txt: 2.47 / 2.375 ms; the others 2.39-2.84)
+        PROF_LAUNCH((mfma16_forward_f32x4_kernel<2, 2>), grid, dim3(64), 0, h->stream, a);
       } else {
         mfma16_launch_forward<float>(h, a);
       }

@@ -65,12 +65,9 @@ static int wave_launch(hipStream_t stream, int which, const IlqrWaveArgs<S>& a) 
       if (a.cost_dense && a.al.enabled && !a.al.has_soc) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, true, true, true, 0, false>), dim3(mf_grid((a.batch + 1) / 2)), b64, gsh, stream, a);
       else if (a.cost_dense && a.al.enabled) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, true, true, true>), dim3(mf_grid((a.batch + 1) / 2)), b64, gsh, stream, a);
       else if (a.cost_dense) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, false, true, true>), dim3(mf_grid((a.batch + 1) / 2)), b64, gsh, stream, a);
-      else if (a.mode == 2 && a.al.enabled && !a.al.has_soc) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, true, true, false, 0, false>), dim3(mf_grid((a.batch + 1) / 2)), b64, gsh, stream, a);
-      else if (a.mode == 2 && a.al.enabled) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, true, true>), dim3(mf_grid((a.batch + 1) / 2)), b64, gsh, stream, a);
-      else if (a.mode == 2) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, false, true>), dim3(mf_grid((a.batch + 1) / 2)), b64, gsh, stream, a);   // two problems per wave
-      else if (a.al.enabled) hipLaunchKernelGGL((wave_merit2_kernel<S, true>), waves, b64, 0, stream, a);
-      else if (sizeof(S) == 8 && a.mode == 1) hipLaunchKernelGGL((wave_merit2_mfma_kernel<S>), waves, b64, 0, stream, a);   // mode 1: asked for by altro_hip_ilqr_solve
-      else hipLaunchKernelGGL((wave_merit2_kernel<S, false>), waves, b64, 0, stream, a);
+      else if (a.al.enabled && !a.al.has_soc) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, true, true, false, 0, false>), dim3(mf_grid((a.batch + 1) / 2)), b64, gsh, stream, a);
+      else if (a.al.enabled) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, true, true>), dim3(mf_grid((a.batch + 1) / 2)), b64, gsh, stream, a);
+      else hipLaunchKernelGGL((wave_merit_dpp_kernel<S, false, true>), dim3(mf_grid((a.batch + 1) / 2)), b64, gsh, stream, a);   // two problems per wave
       break;
     case IK_SPEC_SELECT: hipLaunchKernelGGL(wave_spec_select_kernel<S>, dim3(a.batch), b64, 0, stream, a); break;
     case IK_STATIONARITY:

@@ -652,435 +652,15 @@ __global__ __launch_bounds__(64) void wave_merit_kernel(IlqrWaveArgs<S> a) {
   }
 }
 
-// phi(0) AND the line search's first step alpha0 = 1 (linesearch.cpp: the search always starts there) in ONE pass over
-// the records: the two evaluations of SolverImpl::MeritFunction (solver.cpp:273-355) that every sweep makes stream the
-// same DYN / OUT / nominal / cost-parameter records, so "trial 0" (alpha = a.alpha[b], 0 in the solve loop) and "trial 1"
-// (alpha = 1) ride the same loads and the same LDS image -- each lane forms its row product against both trials' vectors
-// (interleaved in LDS: one 16-byte broadcast read per pair).  Expressions and accumulation order per trial are those of
-// wave_merit_kernel.  Outputs: phi / dphi rows 0 and 1; the candidate trajectory x_, u_, y_ and the expansion lx, lu
-// are TRIAL 1's (IlqrLoopArgs::spec_flip: the step that is nearly always accepted needs no copy and no second pass).
-// For fp64 storage the kernel also leaves trial 1's stationarity (solver.cpp:207-222, with a one-knot-point lag:
-// |lx_k + A_k^T y_{k+1} - y_k| needs the NEXT step's y, so the previous record image, gradient and y stay in LDS)
-// and feasibility (solver.cpp:224-231) in the control block -- the values wave_stationarity_kernel would compute from
-// the stored candidate, without its two further passes over DYN.
-// sum over the 32 lanes of this lane's half of the wave: offsets 16 .. 1 of the butterfly wave_sum runs over 64 lanes (whose
-// first step, offset 32, only ever adds the exact zeros of the other half: the order of the additions that matter is kept)
+// (The two-trial evaluation -- phi(0) and the line search's first step from one pass over the records -- lives in
+// kernels/ilqr_merit2_dpp.hip: wave_merit_dpp_kernel<.., DUAL>.  Its LDS form and its matrix-core form, which round 3 built on the way
+// there and kept as comparisons (0.86 / 0.99 ms against 0.70-0.75 on C1), were removed in round 5; HISTORY.md has their story.)
+// sum over the 32 lanes of this lane's half of the wave: offsets 16 .. 1 of the butterfly wave_sum runs over 64 lanes (whose first
+// step, offset 32, only ever adds the exact zeros of the other half: the order of the additions that matter is kept)
 __device__ __forceinline__ double half_sum(double v) {
 #pragma unroll
   for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
-}
-
-// Lane roles: ONE TRIAL PER HALF WAVE.  Half h = lane / 32 evaluates trial h (0: alpha = a.alpha[b], 1: alpha = 1); within a
-// half, r = lane % 32:
-//   r  0..11 : row r of Z = [A B]        -> x+[r], dx+/dalpha[r], state cost terms, lx[r]
-//   r 16..19 : row r - 16 of Kt = [K|-d] -> u, du/dalpha, input cost terms                     (lu: lanes r 12..15, like the
-//   r 12..15, 20..27 : rows 0..3, 4..11 of [P | p] -> y                                          single-trial kernel's 12..15)
-// i.e. the single-trial kernel's lanes 0..11 / 16..19 keep their places inside a half, so the per-trial sums are taken in
-// its order.  Each lane reads ITS trial's vectors (8-byte broadcast reads): 36 LDS reads per lane and knot point for both
-// trials together, where the first version of this kernel (every lane against both trials' interleaved vectors) needed 36
-// at twice the width -- the kernel is bound by the LDS pipe, not by HBM.
-template <typename S, bool AL>
-__global__ __launch_bounds__(64) void wave_merit2_kernel(IlqrWaveArgs<S> a) {
-  constexpr int DEPTH = 2;                          // also the image ping-pong: parity of k == dd
-  constexpr bool kStat = sizeof(S) == 8;            // stored values == computed values only without a rounding store
-  __shared__ double img[2][MW_IMG + 4];
-  __shared__ double vec[2][24], das[2][12], us[2][4], dus[2][4];   // [trial]: x | dx, dx/dalpha, u, du/dalpha
-  __shared__ double jv[2][AL_MAXC * AL_MAXP];
-  __shared__ double crec[2][28], qrec[2][16], yN[12], lxN[12];
-  const int b = mf_problem(blockIdx.x, a.batch), lane = threadIdx.x;
-  if (b >= a.batch) return;
-  if (a.active && !a.active[b]) return;
-  const int N = a.N;
-  const int h = lane >> 5, r = lane & 31;           // trial, role
-  const double alpha = h ? 1.0 : (a.alpha ? a.alpha[b] : a.alpha_const);
-  S* __restrict__ candb = a.cand + (size_t)b * a.xuy_bs;
-  constexpr bool al = AL;
-  const double rho = al ? a.prob[b].rho : 1.0;
-  const bool is_x = r < 12, is_u = (r >= 16 && r < 20), is_y = (r >= 12 && r < 16) || (r >= 20 && r < 28);
-  const bool cand = h == 1;                         // trial 1 writes the candidate trajectory and the expansion
-  const int i = is_x ? r : (r < 16 ? r - 12 : (r < 20 ? 11 : (r < 28 ? r - 16 : 11)));   // row of Z / of [P | p]
-  const int ia = is_u ? r - 16 : 3;                 // row of Kt
-  int ra[13];
-#pragma unroll
-  for (int j = 0; j < 12; ++j)
-    ra[j] = is_x ? i * MW_ZLD + j : is_u ? MW_OUT0 + ia * 13 + j : MW_OUT0 + MF_OFF_P + mf_sym(i, j);
-  ra[12] = is_x ? i * MW_ZLD + 12 : is_u ? MW_OUT0 + ia * 13 + 12 : MW_OUT0 + MF_OFF_p + i;
-  const double* const vrow = is_x ? &vec[h][0] : &vec[h][12];   // rows of Z multiply x, the others dx
-  const int l27 = lane < 28 ? lane : 27;
-  const int sub = lane & 15;
-  const S* __restrict__ dynb = a.dyn + (size_t)b * a.dyn_bs;
-  const S* __restrict__ outb = a.out + (size_t)b * a.out_bs;
-  const S* __restrict__ nomb = a.nom + (size_t)b * MF_NOM;
-  const S* __restrict__ cpb = a.costp + (size_t)b * MF_COSTP;
-  const size_t nom_ks = (size_t)a.batch * MF_NOM, cp_ks = (size_t)a.batch * MF_COSTP;
-  double x = (double)a.x0[(size_t)b * 12 + (is_x ? r : 11)];
-  double dxda = 0.0;
-  double J = 0.0, Jal = 0.0, dJ = 0.0, viol = 0.0, res = 0.0;   // (Jal: the AL rows' cost shares, summed apart like the
-                                                                 //  single-trial kernel's lanes 48..55 do)
-  MeritWaveRegs ring[DEPTH];
-#pragma unroll
-  for (int dd = 0; dd < DEPTH; ++dd) {
-    const size_t kk = dd < N ? dd : N - 1;
-    merit_wave_load<S>(ring[dd], dynb + kk * a.dyn_ks, outb + kk * a.out_ks, nomb + kk * nom_ks, cpb + kk * cp_ks, lane);
-  }
-  const int Npad = ((N + DEPTH - 1) / DEPTH) * DEPTH;
-  for (int k0 = 0; k0 < Npad; k0 += DEPTH) {
-#pragma unroll
-   for (int dd = 0; dd < DEPTH; ++dd) {
-    const int k = k0 + dd;
-    const bool live = k < N;
-    const int kc = live ? k : N - 1;
-    double* const L = img[dd];
-    // (no barrier here: the image, the candidate record and the gradient are double-buffered, and every lane has passed
-    //  the last barrier of the previous step before anything single-buffered is rewritten)
-    merit_wave_stage(ring[dd], L, lane);
-    if (is_x) {   // (ring.nm is the nominal record's element lane % 16 = r)
-      vec[h][r] = x; vec[h][12 + r] = x - ring[dd].nm; das[h][r] = dxda;
-      if (cand) crec[dd][r] = x;
-    }
-    {
-      const size_t kn = (k + DEPTH < N) ? k + DEPTH : N - 1;
-      merit_wave_load<S>(ring[dd], dynb + kn * a.dyn_ks, outb + kn * a.out_ks, nomb + kn * nom_ks, cpb + kn * cp_ks, lane);
-    }
-    __syncthreads();
-    // this lane's row (of Z, of Kt or of [P | p]) times x (rows of Z) or dx (the others), and times dx/dalpha
-    double acc = 0.0, acc2 = 0.0;
-#pragma unroll
-    for (int j = 0; j < 12; ++j) {
-      const double rj = L[ra[j]];
-      acc += rj * vrow[j];
-      acc2 += rj * das[h][j];
-    }
-    const double aff = L[ra[12]];          // -d (rows of Kt), p (rows of [P | p]), B[.][0] (rows of Z)
-    if (is_u) {   // u_ = u + (-K dx + alpha d) ; du_da = -K dx_da + d        (Kt = [K | -d])
-      const double d = -aff;
-      const double uval = L[MW_NOM0 + 12 + ia] + (-acc + alpha * d);
-      const double duval = -acc2 + d;
-      us[h][ia] = uval; dus[h][ia] = duval;
-      if (cand) crec[dd][24 + ia] = uval;
-      const double Rd = L[MW_CP0 + 12 + ia], rr = L[MW_CP0 + 28 + ia];
-      if (live) J += 0.5 * (uval * (Rd * uval)) + rr * uval;
-    }
-    if (is_y && cand) crec[dd][12 + i] = acc + aff;      // y_ = P dx + p
-    __syncthreads();
-    double xn = 0.0, dxn = 0.0;
-    if (is_x) {   // x+ = A x + B u + f ; dx+/da = A dx_da + B du_da ; state cost
-      double s2 = 0.0, t2 = 0.0;
-#pragma unroll
-      for (int cc = 0; cc < 4; ++cc) { const double bic = L[i * MW_ZLD + 12 + cc]; s2 += bic * us[h][cc]; t2 += bic * dus[h][cc]; }
-      xn = (acc + s2) + L[MW_F0 + i];
-      dxn = acc2 + t2;
-      const double Qd = L[MW_CP0 + i], q = L[MW_CP0 + 16 + i];
-      if (live) {
-        J += 0.5 * (x * (Qd * x)) + q * x;
-        if (r == 0) J += L[MW_CP0 + 32];
-      }
-    }
-    if (kStat && lane >= 48 && live && k >= 1) {   // stationarity at knot point k - 1 now that y_k is known (trial 1's lanes 48..63)
-      const double* const Lp = img[dd ^ 1];
-      double sy = 0.0;
-#pragma unroll
-      for (int rr = 0; rr < 12; ++rr) sy += Lp[rr * MW_ZLD + sub] * crec[dd][12 + rr];
-      const double g = qrec[dd ^ 1][sub] + sy;
-      res = fmax(res, fabs(sub < 12 ? g - crec[dd ^ 1][12 + sub] : g));
-    }
-    if (al) {
-      // both trials' constraint rows at once: lanes r = 16..23 of each half own the rows of their trial (trial 1's are
-      // lanes 48..55, where the single-trial kernel has them); the feasibility that counts is the candidate's (trial 1)
-      double Ja = 0.0, vv = 0.0;
-      wave_al_rows<S, 16>(a.al, kc, b, a.batch, &vec[h][0], &us[h][0], false, rho, r, jv[h], nullptr, nullptr, Ja, vv, false);
-      if (live) Jal += Ja;
-      if (cand && live) viol = fmax(viol, vv);   // (live: a padding step's point is not on the trajectory)
-    }
-    __syncthreads();
-    if (r < 16) {   // lx (r 0..11) and lu (r 12..15) with the AL terms; dphi
-      const int e = r;
-      const double pt = e < 12 ? x : us[h][e - 12];
-      double l = L[MW_CP0 + e] * pt + L[MW_CP0 + 16 + e];       // costp: Qd | Rd | q | r line up with [x; u]
-      if (al) l -= wave_al_col<S>(a.al, kc, e, jv[h]);
-      if (cand) qrec[dd][e] = l;
-      if (live) dJ += l * (e < 12 ? dxda : dus[h][e - 12]);
-    }
-    __syncthreads();
-    {   // one coalesced store of trial 1's candidate record and of its [lx lu]
-      S* c = candb + (size_t)(live ? k : N) * a.xuy_ks;
-      c[l27] = (S)crec[dd][l27];
-      S* ci = a.cin + (size_t)b * a.cin_bs + (size_t)kc * a.cin_ks;
-      const double qv = qrec[dd][sub];
-      if (live) ci[MF_OFF_QR + sub] = (S)qv;
-    }
-    if (is_x && live) { x = xn; dxda = dxn; }
-   }
-  }
-  __syncthreads();
-  {   // terminal knot point (solver.cpp:319-332), both trials
-    const S* nm = a.nom + ((size_t)N * a.batch + b) * MF_NOM;
-    const S* cp = a.costp + ((size_t)N * a.batch + b) * MF_COSTP;
-    const S* on = a.outn + (size_t)b * MF_TERM;
-    S* c = candb + (size_t)N * a.xuy_ks;
-    if (is_u && cand) c[24 + ia] = S(0);
-    if (is_x) {
-      vec[h][r] = x; vec[h][12 + r] = x - (double)nm[r];
-      if (cand) c[r] = (S)x;
-      const double Qd = (double)cp[i], q = (double)cp[16 + i];
-      J += 0.5 * (x * (Qd * x)) + q * x;
-      if (r == 0) J += (double)cp[32];
-    }
-    __syncthreads();
-    if (al) {
-      double Ja = 0.0, vv = 0.0;
-      wave_al_rows<S, 16>(a.al, N, b, a.batch, &vec[h][0], &us[h][0], true, rho, r, jv[h], nullptr, nullptr, Ja, vv, false);
-      Jal += Ja;
-      if (cand) viol = fmax(viol, vv);
-    }
-    if (is_y && cand) {
-      double sacc = 0.0;
-#pragma unroll
-      for (int j = 0; j < 12; ++j) sacc += (double)on[i * 13 + j] * vec[1][12 + j];
-      const double y = sacc + (double)on[i * 13 + 12];
-      c[12 + i] = (S)y;
-      yN[i] = y;
-    }
-    __syncthreads();
-    if (is_x) {
-      double lx = (double)cp[i] * x + (double)cp[16 + i];
-      if (al) lx -= wave_al_col<S>(a.al, N, i, jv[h]);
-      if (cand) { a.term[(size_t)b * MF_TERM + 144 + i] = (S)lx; lxN[i] = lx; }
-      dJ += lx * dxda;
-    }
-    if (kStat) {
-      __syncthreads();
-      const int pl = (N - 1) & 1;      // the last LIVE step's buffers (a padding step writes the other parity)
-      if (lane >= 48) {
-        double sy = 0.0;
-#pragma unroll
-        for (int rr = 0; rr < 12; ++rr) sy += img[pl][rr * MW_ZLD + sub] * yN[rr];
-        const double g = qrec[pl][sub] + sy;
-        res = fmax(res, fabs(sub < 12 ? g - crec[pl][12 + sub] : g));
-      }
-      if (cand && is_x) res = fmax(res, fabs(lxN[r] - yN[r]));
-    }
-  }
-  const double phi = half_sum(J + Jal), dphi = half_sum(dJ);   // (J + Jal: the 64-lane butterfly's first step, lane l + lane l + 32)
-  if (kStat) { res = wave_max(res); if (al) viol = wave_max(viol); }
-  if (r == 0) {
-    a.phi[(size_t)h * a.batch + b] = phi;
-    a.dphi[(size_t)h * a.batch + b] = dphi;
-  }
-  if (lane == 0) {
-    if (al) a.prob[b].rho_est = rho;
-    if (kStat) { a.prob[b].stationarity = res; a.prob[b].feasibility = viol; }
-  }
-}
-
-// ---- the same two-trial evaluation on the matrix cores ------------------------------------------------------------------------
-// wave_merit2_kernel is bound by the LDS pipe, and what it moves through LDS is operand broadcast: every lane re-reads the
-// vectors x, dx, dx/dalpha its row multiplies.  MFMA removes exactly that (the backward sweep's reason to use it).  Here the
-// state of both trials and their sensitivities are four COLUMNS of the 16 x 16 B operand of v_mfma_f64_16x16x4 --
-//     column 0: [x; u] of trial 0      column 2: d[x; u]/dalpha of trial 0
-//     column 1: [x; u] of trial 1      column 3: d[x; u]/dalpha of trial 1          (columns 4..15: zero)
-// -- with [x; u] in the rows: lane (g, t) = (lane / 16, lane % 16) holds row 4 c + g of column t in register c (c = 0..2: x,
-// c = 3: u).  The accumulator layout of the instruction (register r <-> row g + 4 r, column t) IS this B-operand layout, so
-//     K dx           (A operand: the rows of Kt)                                            3 MFMA
-//     Z [x; u]       (A operand: Z read transposed from the LDS image)  -> the next state   4 MFMA
-//     P dx           (A operand: P gathered from its packed triangle)   -> y                3 MFMA
-//     Z^T y+         (A operand: Z's own fragment registers, one knot point late)  -> the stationarity residual   3 MFMA
-// hand their results to the next product in registers: the recursion never goes through LDS.  Sums are taken in the MFMA's
-// order, not in wave_merit_kernel's: results agree to rounding (1e-12 relative asserted), not bit for bit.  Unconstrained
-// problems, fp64 records (the default for those); everything else runs wave_merit2_kernel.
-typedef double mw_f64x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ mw_f64x4 mw_mfma(double a, double b, mw_f64x4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
-__device__ __forceinline__ double mw_from_lane_plus2(double v) { return __shfl_down(v, 2, 64); }
-
-template <typename S>
-__global__ __launch_bounds__(64) void wave_merit2_mfma_kernel(IlqrWaveArgs<S> a) {
-  constexpr int DEPTH = 2;
-  __shared__ double img[2][MW_IMG + 4];
-  __shared__ double crec[2][28], qrec[2][16];
-  const int b = mf_problem(blockIdx.x, a.batch), lane = threadIdx.x;
-  if (b >= a.batch) return;
-  if (a.active && !a.active[b]) return;
-  const int N = a.N;
-  const int g = lane >> 4, t = lane & 15;
-  const bool xcol = t < 2;                      // a column that holds a trial's [x; u] (2, 3: its sensitivities)
-  const bool live_col = t < 4;
-  const bool cand = t == 1;                     // trial 1 writes the candidate trajectory and the expansion
-  const double alpha = (t == 0) ? (a.alpha ? a.alpha[b] : a.alpha_const) : 1.0;
-  S* __restrict__ candb = a.cand + (size_t)b * a.xuy_bs;
-  const int tr = t < 12 ? t : 11;               // row of Z / of [P | p] this lane supplies as A operand (rows 12..15: zeroed)
-  const int ta = t < 4 ? t : 3;                 // row of Kt
-  int aZ[4], aK[3], aP[3];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) aZ[c] = tr * MW_ZLD + 4 * c + g;
-#pragma unroll
-  for (int c = 0; c < 3; ++c) { aK[c] = MW_OUT0 + ta * 13 + 4 * c + g; aP[c] = MW_OUT0 + MF_OFF_P + mf_sym(tr, 4 * c + g); }
-  const int l27 = lane < 28 ? lane : 27;
-  const S* __restrict__ dynb = a.dyn + (size_t)b * a.dyn_bs;
-  const S* __restrict__ outb = a.out + (size_t)b * a.out_bs;
-  const S* __restrict__ nomb = a.nom + (size_t)b * MF_NOM;
-  const S* __restrict__ cpb = a.costp + (size_t)b * MF_COSTP;
-  const size_t nom_ks = (size_t)a.batch * MF_NOM, cp_ks = (size_t)a.batch * MF_COSTP;
-  // the state: V[c] = row 4 c + g of this lane's column; columns 0, 1 start at x0, the sensitivities at 0
-  double V[3];
-#pragma unroll
-  for (int c = 0; c < 3; ++c) V[c] = xcol ? (double)a.x0[(size_t)b * 12 + 4 * c + g] : 0.0;
-  double J = 0.0, dJ = 0.0, res = 0.0;
-  double lxp[3] = {0.0, 0.0, 0.0}, lup = 0.0, yp[3] = {0.0, 0.0, 0.0}, zprev[3] = {0.0, 0.0, 0.0};   // knot point k - 1 (the lag)
-  MeritWaveRegs ring[DEPTH];
-#pragma unroll
-  for (int dd = 0; dd < DEPTH; ++dd) {
-    const size_t kk = dd < N ? dd : N - 1;
-    merit_wave_load<S>(ring[dd], dynb + kk * a.dyn_ks, outb + kk * a.out_ks, nomb + kk * nom_ks, cpb + kk * cp_ks, lane);
-  }
-  const int Npad = ((N + DEPTH - 1) / DEPTH) * DEPTH;
-  for (int k0 = 0; k0 < Npad; k0 += DEPTH) {
-#pragma unroll
-   for (int dd = 0; dd < DEPTH; ++dd) {
-    const int k = k0 + dd;
-    const bool live = k < N;
-    const int kc = live ? k : N - 1;
-    double* const L = img[dd];
-    merit_wave_stage(ring[dd], L, lane);
-    double zf[3];                               // Z_k in fragment order: lane (g, t) holds Z[4 c + g][t] = (Z^T)[t][4 c + g]
-#pragma unroll
-    for (int c = 0; c < 3; ++c) zf[c] = ring[dd].z[c];
-    {
-      const size_t kn = (k + DEPTH < N) ? k + DEPTH : N - 1;
-      merit_wave_load<S>(ring[dd], dynb + kn * a.dyn_ks, outb + kn * a.out_ks, nomb + kn * nom_ks, cpb + kn * cp_ks, lane);
-    }
-    __syncthreads();
-    // dx = x - x_nominal in the trial columns; the sensitivity columns go through unchanged
-    double W[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) W[c] = V[c] - (xcol ? L[MW_NOM0 + 4 * c + g] : 0.0);
-    // K dx | K dx/dalpha: rows 0..3 of the product = register 0 of lane (g, t)
-    mw_f64x4 DK = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int c = 0; c < 3; ++c) DK = mw_mfma(t < 4 ? L[aK[c]] : 0.0, W[c], DK);
-    const double d = L[MW_OUT0 + g * 13 + 12] * -1.0;      // d[g] = -Kt[g][12]
-    // u_ = u + (-K dx + alpha d) ; du_da = -K dx_da + d
-    const double U = xcol ? L[MW_NOM0 + 12 + g] + (-DK[0] + alpha * d) : (live_col ? -DK[0] + d : 0.0);
-    // y_ = P dx + p  (P dx/dalpha in the sensitivity columns is not needed, it rides along)
-    mw_f64x4 DY = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int c = 0; c < 3; ++c) DY = mw_mfma(t < 12 ? L[aP[c]] : 0.0, W[c], DY);
-    double y[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) y[c] = DY[c] + L[MW_OUT0 + MF_OFF_p + 4 * c + g];
-    // costs and their gradient at (x_k, u_k), in the trial columns
-    double lx[3], lu;
-    {
-      double Jk = 0.0;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const double Qd = L[MW_CP0 + 4 * c + g], q = L[MW_CP0 + 16 + 4 * c + g];
-        Jk += 0.5 * (V[c] * (Qd * V[c])) + q * V[c];
-        lx[c] = Qd * V[c] + q;
-      }
-      const double Rd = L[MW_CP0 + 12 + g], rr = L[MW_CP0 + 28 + g];
-      Jk += 0.5 * (U * (Rd * U)) + rr * U;
-      lu = Rd * U + rr;
-      if (g == 0) Jk += L[MW_CP0 + 32];
-      if (live && xcol) J += Jk;
-      // dphi: the sensitivities of trial t sit two columns to the right
-      double dk = lu * mw_from_lane_plus2(U);
-#pragma unroll
-      for (int c = 0; c < 3; ++c) dk += lx[c] * mw_from_lane_plus2(V[c]);
-      if (live && xcol) dJ += dk;
-    }
-    // stationarity at knot point k - 1 now that y_k is known: Z_{k-1}^T y_k in fragment registers, trial 1's column
-    if (k >= 1 && live) {
-      mw_f64x4 DS = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int c = 0; c < 3; ++c) DS = mw_mfma(zprev[c], y[c], DS);
-      if (cand) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) res = fmax(res, fabs((lxp[c] + DS[c]) - yp[c]));
-        res = fmax(res, fabs(lup + DS[3]));
-      }
-    }
-    // the candidate record x_ | y_ | u_ and [lx lu] of trial 1, gathered for one coalesced store each
-    if (cand) {
-#pragma unroll
-      for (int c = 0; c < 3; ++c) { crec[dd][4 * c + g] = V[c]; crec[dd][12 + 4 * c + g] = y[c]; qrec[dd][4 * c + g] = lx[c]; }
-      crec[dd][24 + g] = U;
-      qrec[dd][12 + g] = lu;
-    }
-    if (live) {
-#pragma unroll
-      for (int c = 0; c < 3; ++c) { lxp[c] = lx[c]; yp[c] = y[c]; zprev[c] = zf[c]; }
-      lup = lu;
-    }
-    // the next state: Z [x; u] (+ f in the trial columns)
-    mw_f64x4 DX = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int c = 0; c < 3; ++c) DX = mw_mfma(t < 12 ? L[aZ[c]] : 0.0, V[c], DX);
-    DX = mw_mfma(t < 12 ? L[aZ[3]] : 0.0, U, DX);
-    if (live) {
-#pragma unroll
-      for (int c = 0; c < 3; ++c) V[c] = DX[c] + (xcol ? L[MW_F0 + 4 * c + g] : 0.0);
-    }
-    __syncthreads();
-    {
-      S* c = candb + (size_t)(live ? k : N) * a.xuy_ks;
-      c[l27] = (S)crec[dd][l27];
-      S* ci = a.cin + (size_t)b * a.cin_bs + (size_t)kc * a.cin_ks;
-      const double qv = qrec[dd][t];
-      if (live) ci[MF_OFF_QR + t] = (S)qv;
-    }
-   }
-  }
-  {   // terminal knot point (solver.cpp:319-332), both trials
-    const S* nm = a.nom + ((size_t)N * a.batch + b) * MF_NOM;
-    const S* cp = a.costp + ((size_t)N * a.batch + b) * MF_COSTP;
-    const S* on = a.outn + (size_t)b * MF_TERM;
-    S* cN = candb + (size_t)N * a.xuy_ks;
-    double W[3], lxN[3];
-    {
-      double Jk = 0.0, dk = 0.0;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        W[c] = V[c] - (xcol ? (double)nm[4 * c + g] : 0.0);
-        const double Qd = (double)cp[4 * c + g], q = (double)cp[16 + 4 * c + g];
-        Jk += 0.5 * (V[c] * (Qd * V[c])) + q * V[c];
-        lxN[c] = Qd * V[c] + q;
-        dk += lxN[c] * mw_from_lane_plus2(V[c]);
-      }
-      if (g == 0) Jk += (double)cp[32];
-      if (xcol) { J += Jk; dJ += dk; }
-    }
-    mw_f64x4 DY = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int c = 0; c < 3; ++c) DY = mw_mfma(t < 12 ? (double)on[tr * 13 + 4 * c + g] : 0.0, W[c], DY);
-    double yN[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) yN[c] = DY[c] + (double)on[(4 * c + g) * 13 + 12];
-    mw_f64x4 DS = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int c = 0; c < 3; ++c) DS = mw_mfma(zprev[c], yN[c], DS);
-    if (cand) {
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        res = fmax(res, fabs((lxp[c] + DS[c]) - yp[c]));
-        res = fmax(res, fabs(lxN[c] - yN[c]));
-        cN[4 * c + g] = (S)V[c];
-        cN[12 + 4 * c + g] = (S)yN[c];
-        a.term[(size_t)b * MF_TERM + 144 + 4 * c + g] = (S)lxN[c];
-      }
-      res = fmax(res, fabs(lup + DS[3]));
-      cN[24 + g] = S(0);
-    }
-  }
-  // per-column sums over the four lane groups; columns 0 and 1 are the trials
-  J += __shfl_xor(J, 16, 64); J += __shfl_xor(J, 32, 64);
-  dJ += __shfl_xor(dJ, 16, 64); dJ += __shfl_xor(dJ, 32, 64);
-  res = wave_max(res);
-  if (lane < 2) {
-    a.phi[(size_t)lane * a.batch + b] = J;
-    a.dphi[(size_t)lane * a.batch + b] = dJ;
-  }
-  if (lane == 0) { a.prob[b].stationarity = res; a.prob[b].feasibility = 0.0; }
 }
 
 // Stationarity (solver.cpp:207-222): max_k |lx + A^T y+ - y|, max_k |lu + B^T y+|

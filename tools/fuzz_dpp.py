@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 import altro_amd  # noqa: E402
 from tests import problems  # noqa: E402
 
-SWITCHES = ("ALTRO_HIP_MERIT2_DPP", "ALTRO_HIP_MERIT_DPP", "ALTRO_HIP_EXPAND_DPP", "ALTRO_HIP_ALROWS_DPP")
+SWITCHES = ("ALTRO_HIP_MERIT_DPP", "ALTRO_HIP_EXPAND_DPP", "ALTRO_HIP_ALROWS_DPP")
 KEYS = ("status", "iterations", "dual_updates", "phi", "stationarity", "feasibility", "alpha", "penalty")
 
 
