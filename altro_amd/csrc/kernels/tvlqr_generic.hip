@@ -58,6 +58,10 @@ struct GenericArgs {
 };
 
 // C(mr x nc) = beta*C + alpha * op(A) op(B); operands column-major in LDS (or global for B/A reads).
+// The sum over k is taken in index order, one product at a time (the CPU path's order); the OPERANDS of four consecutive terms are
+// fetched together first: the trip count is a run-time value, the loop is not unrolled by the compiler, and with one fetch per
+// iteration every term paid a full LDS (or global) round trip (round 5: plan GENERIC's (13, 4) sweep 6.6 -> 5.25 ms, (14, 7) 12.9 -> 10.7,
+// the seam's (20, 8) call 605 -> 475 us, (12, 4) 250 -> 225; same bits).
 template <typename T>
 __device__ __forceinline__ void wave_gemm(int lane, int ta, int tb, int mr, int nc, int kd, T alpha,
                                           const T* A, int lda, const T* B, int ldb, T beta, T* C,
@@ -65,20 +69,41 @@ __device__ __forceinline__ void wave_gemm(int lane, int ta, int tb, int mr, int 
   const int total = mr * nc;
   for (int e = lane; e < total; e += 64) {
     const int i = e % mr, j = e / mr;
+    const T* pa = ta ? A + i * lda : A + i;
+    const T* pb = tb ? B + j : B + j * ldb;
+    const int sa = ta ? 1 : lda, sb = tb ? ldb : 1;
     T s = T(0);
-    for (int k = 0; k < kd; ++k) {
-      const T a = ta ? A[k + i * lda] : A[i + k * lda];
-      const T b = tb ? B[j + k * ldb] : B[k + j * ldb];
-      s += a * b;
+    int k = 0;
+    for (; k + 4 <= kd; k += 4) {
+      const T a0 = pa[(k + 0) * sa], a1 = pa[(k + 1) * sa], a2 = pa[(k + 2) * sa], a3 = pa[(k + 3) * sa];
+      const T b0 = pb[(k + 0) * sb], b1 = pb[(k + 1) * sb], b2 = pb[(k + 2) * sb], b3 = pb[(k + 3) * sb];
+      s += a0 * b0;
+      s += a1 * b1;
+      s += a2 * b2;
+      s += a3 * b3;
     }
+    for (; k < kd; ++k) s += pa[k * sa] * pb[k * sb];
     const T c0 = (beta == T(0)) ? T(0) : beta * C[i + j * ldc];
     C[i + j * ldc] = c0 + alpha * s;
   }
 }
 
+// dst[0 .. count) <- src: four elements per lane in flight (a copy from global memory pays one round trip per 256 elements, not per 64)
 template <typename T>
 __device__ __forceinline__ void wave_copy(int lane, T* dst, const T* src, int count) {
-  for (int e = lane; e < count; e += 64) dst[e] = src[e];
+  for (int e0 = 0; e0 < count; e0 += 256) {
+    T v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = e0 + lane + 64 * q;
+      v[q] = e < count ? src[e] : T(0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = e0 + lane + 64 * q;
+      if (e < count) dst[e] = v[q];
+    }
+  }
 }
 
 // BIG = false: the knot point's blocks live in LDS (what fits 64 KB: n, m up to ~32 in fp64).  BIG = true: the same code on a
@@ -292,6 +317,23 @@ inline size_t generic_backward_lds_bytes(int nm, int mm) {
   return el * sizeof(T) + 64;
 }
 
+// sum_j M[i + j ld] v[j], j = 0 .. cnt-1, in index order; four matrix entries (global memory) and vector entries (LDS) fetched at a time
+template <typename T>
+__device__ __forceinline__ T gen_row_dot(const T* M, int ld, const T* v, int cnt) {
+  T s = T(0);
+  int j = 0;
+  for (; j + 4 <= cnt; j += 4) {
+    const T a0 = M[(j + 0) * ld], a1 = M[(j + 1) * ld], a2 = M[(j + 2) * ld], a3 = M[(j + 3) * ld];
+    const T b0 = v[j], b1 = v[j + 1], b2 = v[j + 2], b3 = v[j + 3];
+    s += a0 * b0;
+    s += a1 * b1;
+    s += a2 * b2;
+    s += a3 * b3;
+  }
+  for (; j < cnt; ++j) s += M[j * ld] * v[j];
+  return s;
+}
+
 // tvlqr_ForwardPass (tvlqr.cpp:197-248): x_0 = x0; u = d - K x; x+ = f + A x + B u; y = P x + p.
 template <typename T>
 __global__ __launch_bounds__(64) void generic_forward_kernel(GenericArgs<T> a) {
@@ -315,8 +357,7 @@ __global__ __launch_bounds__(64) void generic_forward_kernel(GenericArgs<T> a) {
     const T* K = GPTR(G_K, k);
     const T* d = GPTR(G_d, k);
     for (int i = lane; i < m; i += 64) {  // u = d - K x
-      T s = T(0);
-      for (int j = 0; j < n; ++j) s += K[i + j * m] * sx[j];
+      const T s = gen_row_dot<T>(K + i, m, sx, n);
       su[i] = d[i] + T(-1) * s;
     }
     if (a.want_y) {  // y = P x + p   (lanes m.. take it so it overlaps the u chain)
@@ -324,18 +365,15 @@ __global__ __launch_bounds__(64) void generic_forward_kernel(GenericArgs<T> a) {
       const T* p = GPTR(G_p, k);
       T* y = GPTR(G_y, k);
       for (int i = lane; i < n; i += 64) {
-        T s = T(0);
-        for (int j = 0; j < n; ++j) s += P[i + j * n] * sx[j];
+        const T s = gen_row_dot<T>(P + i, n, sx, n);
         y[i] = (T(0) + s) + p[i];
       }
     }
     __syncthreads();
     for (int i = lane; i < n2; i += 64) {  // x+ = f + A x + B u
-      T s = T(0);
-      for (int j = 0; j < n; ++j) s += A[i + j * n2] * sx[j];
+      const T s = gen_row_dot<T>(A + i, n2, sx, n);
       T v = f[i] + s;
-      T s2 = T(0);
-      for (int j = 0; j < m; ++j) s2 += B[i + j * n2] * su[j];
+      const T s2 = gen_row_dot<T>(B + i, n2, su, m);
       sxn[i] = v + s2;
     }
     wave_copy(lane, GPTR(G_u, k), (const T*)su, m);
@@ -350,8 +388,7 @@ __global__ __launch_bounds__(64) void generic_forward_kernel(GenericArgs<T> a) {
     const T* p = GPTR(G_p, N);
     T* y = GPTR(G_y, N);
     for (int i = lane; i < n; i += 64) {
-      T s = T(0);
-      for (int j = 0; j < n; ++j) s += P[i + j * n] * sx[j];
+      const T s = gen_row_dot<T>(P + i, n, sx, n);
       y[i] = (T(0) + s) + p[i];
     }
   }
