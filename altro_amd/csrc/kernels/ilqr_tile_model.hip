@@ -6,7 +6,8 @@
 // The point [x; u] of a (problem, trial) lives in the registers of one row of 16 lanes (lane j < 12: x_j, lane 12 + i: u_i).
 // One step:
 //   * every lane gathers the whole [x; u] (16 DPP moves) and evaluates the continuous model itself -- the same instructions
-//     in every lane, so one evaluation's worth of issue per wave -- at (x, u) and at the midpoint; lane j keeps x+_j;
+//     in every lane, so one evaluation's worth of issue per wave -- at (x, u) and at the midpoint; lane j keeps x+_j.  What a
+//     model can share over the row it does: MODEL_QUADROTOR takes ONE sincos per lane and evaluation (tile_quad_trig);
 //   * for the expansion lane j keeps ROW j of the two continuous Jacobians J0 = [df/dx df/du](x, u), Jm = (...)(xm, u) and forms
 //     row j of Z = [A B],  A = I + h Jm_x (I + h/2 J0_x),  B = h (Jm_x h/2 J0_u + Jm_u):  the products  sum_i Jm[j][i] J0[i][c]
 //     are 16 chains of 12 `v_fmac_f64_dpp row_newbcast` (lane i holds row i of J0) -- nothing crosses LDS.
@@ -41,43 +42,72 @@ __device__ __forceinline__ void tile_pick_row(const double (&J)[192], int jr, do
   }
 }
 
+// MODEL_QUADROTOR's trigonometry once per ROW: lane 3, 4, 5 hold phi, theta, psi, every lane takes sin / cos of ONE number (the
+// other lanes of 0) and the six results reach the row by DPP -- a third of the library calls of quadrotor_trig, same values.
+__device__ __forceinline__ QuadTrig<double> tile_quad_trig(double own) {
+  double s, c;
+  sincos_hd<double>(own, &s, &c);
+  QuadTrig<double> t;
+  asm volatile("s_nop 4\n"
+               "v_mov_b64_dpp %0, %6" MD_BC(3) "v_mov_b64_dpp %1, %7" MD_BC(3) "v_mov_b64_dpp %2, %6" MD_BC(4) "v_mov_b64_dpp %3, %7" MD_BC(4)
+               "v_mov_b64_dpp %4, %6" MD_BC(5) "v_mov_b64_dpp %5, %7" MD_BC(5)
+      : "=&v"(t.sp), "=&v"(t.cp), "=&v"(t.st), "=&v"(t.ct), "=&v"(t.ss), "=&v"(t.cs)
+      : "v"(s), "v"(c));
+  t.ict = 1.0 / t.ct;
+  return t;
+}
+
+// The continuous model at (x, u), every lane the whole of it; `jr` is the lane's row (for the models that share work over the row).
+template <int MK, bool JAC>
+__device__ __forceinline__ void tile_cont(const ModelParams& mp, const double* x, const double* u, int jr, double* xdot, double* J) {
+  using M = DiscreteModel<MK, 12, 4, double>;
+  if constexpr (MK == MODEL_QUADROTOR) {
+    const double own = jr == 3 ? x[3] : (jr == 4 ? x[4] : (jr == 5 ? x[5] : 0.0));
+    const QuadTrig<double> t = tile_quad_trig(own);
+    quadrotor_f_from<double>(t, x, u, xdot);
+    if constexpr (JAC) quadrotor_J_from<double>(t, x, u, J);
+  } else {
+    if constexpr (JAC) M::cont_fJ(mp, x, u, xdot, J);
+    else M::cont_f(mp, x, u, xdot);
+  }
+}
+
 // One explicit-midpoint step of model MK from the row's registers: lane j < 12 gets x+_j and, with JAC, row j of Z = [A B] of the
 // step (lanes 12..15 compute along as row 11 and must not use either).  Must be called by every lane of the row.
 template <int MK, bool JAC>
 __device__ __forceinline__ void tile_model_step(const ModelParams& mp, double w, int jr, double& xnext, double (&zrow)[16]) {
-  using M = DiscreteModel<MK, 12, 4, double>;
   double z[16];
   md_gather16(w, z);
   const double h = (double)mp.h, h2 = (double)(mp.h / 2);     // (h / 2 in float arithmetic, like the reference's harness)
   double k1[12], xm[12], k2[12];
   if constexpr (JAC) {
     double J0[192], Jm[192], j0[16], jm[16];
-    M::cont_fJ(mp, z, z + 12, k1, J0);
+    tile_cont<MK, true>(mp, z, z + 12, jr, k1, J0);
     tile_pick_row(J0, jr, j0);
 #pragma unroll
     for (int i = 0; i < 12; ++i) xm[i] = z[i] + h2 * k1[i];
-    M::cont_fJ(mp, xm, z + 12, k2, Jm);
+    tile_cont<MK, true>(mp, xm, z + 12, jr, k2, Jm);
     tile_pick_row(Jm, jr, jm);
     double jm12[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) jm12[i] = jm[i];
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
-      double s = 0.0;
-      md_col12(s, j0[c], jm12);                         // sum_i Jm[j][i] J0[i][c]
+      double s = 0.0;                                   // sum_i Jm[j][i] J0[i][c]; a column of J0 that is zero in every row (the
+      if (!(__builtin_constant_p(j0[c]) && j0[c] == 0.0)) md_col12(s, j0[c], jm12);   // picks folded to the constant) needs no chain
       if (c < 12) zrow[c] = ((jr == c) ? 1.0 : 0.0) + h * (jm[c] + h2 * s);
       else zrow[c] = h * (h2 * s + jm[c]);
     }
   } else {
-    M::cont_f(mp, z, z + 12, k1);
+    tile_cont<MK, false>(mp, z, z + 12, jr, k1, nullptr);
 #pragma unroll
     for (int i = 0; i < 12; ++i) xm[i] = z[i] + h2 * k1[i];
-    M::cont_f(mp, xm, z + 12, k2);
+    tile_cont<MK, false>(mp, xm, z + 12, jr, k2, nullptr);
   }
-  double xj = 0.0, kj = 0.0;
+  double kj = 0.0;
 #pragma unroll
-  for (int i = 0; i < 12; ++i) { xj = (jr == i) ? z[i] : xj; kj = (jr == i) ? k2[i] : kj; }
-  xnext = xj + h * kj;
+  for (int i = 0; i < 12; ++i) kj = (jr == i) ? k2[i] : kj;
+  xnext = w + h * kj;                                   // (w is x_j in the lanes that keep the result)
 }
 
 // SolverImpl::OpenLoopRollout (solver.cpp:116-131) with a device model: x_0 = x0, x_{k+1} = F(x_k, u_k) on the candidate

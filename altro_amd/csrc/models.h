@@ -197,38 +197,43 @@ ALTRO_HD void bicycle_fJ(const ModelParams& mp, const T* x, const T* u, T* xdot,
 // on the device at the shape BASELINE.json calls "quadrotor-sized".  Same equations as oracle/models_oracle.c (written apart):
 //   x = [p (3) | roll phi, pitch theta, yaw psi | v (3, world) | omega (3, body)],  u = [thrust F | torques tau (3)]
 //   pdot = v ;  [phi; theta; psi]' = W(phi, theta) omega ;  vdot = -g e3 + F / mass R e3 ;  omegadot = I^-1 (tau - omega x I omega)
+// sin / cos of the three Euler angles and 1 / cos(theta): the only transcendental calls and the only division of one evaluation
+// (the inertias divide as multiplications by their reciprocals).  The tile plan forms this once per row of 16 lanes
+// (kernels/ilqr_tile_model.hip: lane 3, 4, 5 take phi, theta, psi and the row shares the results by DPP).
 template <typename T>
-struct QuadTrig { T sp, cp, st, ct, ss, cs; };
+struct QuadTrig { T sp, cp, st, ct, ss, cs, ict; };
 template <typename T>
 ALTRO_HD QuadTrig<T> quadrotor_trig(const T* x) {
   QuadTrig<T> t;
   sincos_hd<T>(x[3], &t.sp, &t.cp);
   sincos_hd<T>(x[4], &t.st, &t.ct);
   sincos_hd<T>(x[5], &t.ss, &t.cs);
+  t.ict = T(1) / t.ct;
   return t;
 }
 constexpr double kQuadMass = 0.5, kQuadG = 9.81, kQuadIx = 0.0023, kQuadIy = 0.0023, kQuadIz = 0.004;
+constexpr double kQuadRMass = 1.0 / kQuadMass, kQuadRIx = 1.0 / kQuadIx, kQuadRIy = 1.0 / kQuadIy, kQuadRIz = 1.0 / kQuadIz;
 template <typename T>
 ALTRO_HD void quadrotor_f_from(const QuadTrig<T>& t, const T* x, const T* u, T* xd) {
-  const T tt = t.st / t.ct;
+  const T tt = t.st * t.ict;
   const T wx = x[9], wy = x[10], wz = x[11];
   xd[0] = x[6]; xd[1] = x[7]; xd[2] = x[8];
   xd[3] = wx + t.sp * tt * wy + t.cp * tt * wz;
   xd[4] = t.cp * wy - t.sp * wz;
-  xd[5] = (t.sp * wy + t.cp * wz) / t.ct;
-  const T a = u[0] / T(kQuadMass);
+  xd[5] = (t.sp * wy + t.cp * wz) * t.ict;
+  const T a = u[0] * T(kQuadRMass);
   xd[6] = a * (t.cp * t.st * t.cs + t.sp * t.ss);
   xd[7] = a * (t.cp * t.st * t.ss - t.sp * t.cs);
   xd[8] = a * (t.cp * t.ct) - T(kQuadG);
-  xd[9] = (u[1] - T(kQuadIz - kQuadIy) * wy * wz) / T(kQuadIx);
-  xd[10] = (u[2] - T(kQuadIx - kQuadIz) * wz * wx) / T(kQuadIy);
-  xd[11] = (u[3] - T(kQuadIy - kQuadIx) * wx * wy) / T(kQuadIz);
+  xd[9] = (u[1] - T(kQuadIz - kQuadIy) * wy * wz) * T(kQuadRIx);
+  xd[10] = (u[2] - T(kQuadIx - kQuadIz) * wz * wx) * T(kQuadRIy);
+  xd[11] = (u[3] - T(kQuadIy - kQuadIx) * wx * wy) * T(kQuadRIz);
 }
 template <typename T>
 ALTRO_HD void quadrotor_J_from(const QuadTrig<T>& t, const T* x, const T* u, T* J) {   // 12 x 16, column-major
 #pragma unroll
   for (int e = 0; e < 192; ++e) J[e] = T(0);   // (unrolled: the array must dissolve into registers / constants where it is used)
-  const T tt = t.st / t.ct, sec2 = T(1) / (t.ct * t.ct);
+  const T tt = t.st * t.ict, sec2 = t.ict * t.ict;
   const T wx = x[9], wy = x[10], wz = x[11];
   J[0 + 6 * 12] = T(1); J[1 + 7 * 12] = T(1); J[2 + 8 * 12] = T(1);
   J[3 + 3 * 12] = t.cp * tt * wy - t.sp * tt * wz;
@@ -236,24 +241,24 @@ ALTRO_HD void quadrotor_J_from(const QuadTrig<T>& t, const T* x, const T* u, T* 
   J[3 + 9 * 12] = T(1); J[3 + 10 * 12] = t.sp * tt; J[3 + 11 * 12] = t.cp * tt;
   J[4 + 3 * 12] = -t.sp * wy - t.cp * wz;
   J[4 + 10 * 12] = t.cp; J[4 + 11 * 12] = -t.sp;
-  J[5 + 3 * 12] = (t.cp * wy - t.sp * wz) / t.ct;
+  J[5 + 3 * 12] = (t.cp * wy - t.sp * wz) * t.ict;
   J[5 + 4 * 12] = (t.sp * wy + t.cp * wz) * t.st * sec2;
-  J[5 + 10 * 12] = t.sp / t.ct; J[5 + 11 * 12] = t.cp / t.ct;
-  const T a = u[0] / T(kQuadMass);
+  J[5 + 10 * 12] = t.sp * t.ict; J[5 + 11 * 12] = t.cp * t.ict;
+  const T a = u[0] * T(kQuadRMass);
   J[6 + 3 * 12] = a * (-t.sp * t.st * t.cs + t.cp * t.ss);
   J[6 + 4 * 12] = a * (t.cp * t.ct * t.cs);
   J[6 + 5 * 12] = a * (-t.cp * t.st * t.ss + t.sp * t.cs);
-  J[6 + 12 * 12] = (t.cp * t.st * t.cs + t.sp * t.ss) / T(kQuadMass);
+  J[6 + 12 * 12] = (t.cp * t.st * t.cs + t.sp * t.ss) * T(kQuadRMass);
   J[7 + 3 * 12] = a * (-t.sp * t.st * t.ss - t.cp * t.cs);
   J[7 + 4 * 12] = a * (t.cp * t.ct * t.ss);
   J[7 + 5 * 12] = a * (t.cp * t.st * t.cs + t.sp * t.ss);
-  J[7 + 12 * 12] = (t.cp * t.st * t.ss - t.sp * t.cs) / T(kQuadMass);
+  J[7 + 12 * 12] = (t.cp * t.st * t.ss - t.sp * t.cs) * T(kQuadRMass);
   J[8 + 3 * 12] = a * (-t.sp * t.ct);
   J[8 + 4 * 12] = a * (-t.cp * t.st);
-  J[8 + 12 * 12] = (t.cp * t.ct) / T(kQuadMass);
-  J[9 + 10 * 12] = -T(kQuadIz - kQuadIy) * wz / T(kQuadIx); J[9 + 11 * 12] = -T(kQuadIz - kQuadIy) * wy / T(kQuadIx); J[9 + 13 * 12] = T(1) / T(kQuadIx);
-  J[10 + 9 * 12] = -T(kQuadIx - kQuadIz) * wz / T(kQuadIy); J[10 + 11 * 12] = -T(kQuadIx - kQuadIz) * wx / T(kQuadIy); J[10 + 14 * 12] = T(1) / T(kQuadIy);
-  J[11 + 9 * 12] = -T(kQuadIy - kQuadIx) * wy / T(kQuadIz); J[11 + 10 * 12] = -T(kQuadIy - kQuadIx) * wx / T(kQuadIz); J[11 + 15 * 12] = T(1) / T(kQuadIz);
+  J[8 + 12 * 12] = (t.cp * t.ct) * T(kQuadRMass);
+  J[9 + 10 * 12] = T(-(kQuadIz - kQuadIy) * kQuadRIx) * wz; J[9 + 11 * 12] = T(-(kQuadIz - kQuadIy) * kQuadRIx) * wy; J[9 + 13 * 12] = T(kQuadRIx);
+  J[10 + 9 * 12] = T(-(kQuadIx - kQuadIz) * kQuadRIy) * wz; J[10 + 11 * 12] = T(-(kQuadIx - kQuadIz) * kQuadRIy) * wx; J[10 + 14 * 12] = T(kQuadRIy);
+  J[11 + 9 * 12] = T(-(kQuadIy - kQuadIx) * kQuadRIz) * wy; J[11 + 10 * 12] = T(-(kQuadIy - kQuadIx) * kQuadRIz) * wx; J[11 + 15 * 12] = T(kQuadRIz);
 }
 
 #if defined(ALTRO_HIP_USER_MODEL) && defined(ALTRO_HIP_TILE_N)
