@@ -57,6 +57,14 @@ struct GenericArgs {
   int64_t ws_stride = 0;     // elements between consecutive problems' work blocks (>= generic_backward_lds_bytes / sizeof(T))
 };
 
+// e -> (e % d, e / d) for 0 <= e < 2^22, d > 0, rd ~ 1 / d: a float product and a fix-up instead of the integer division sequence
+__device__ __forceinline__ void split_index(int e, int d, float rd, int& r, int& q) {
+  q = (int)((float)e * rd);
+  r = e - q * d;
+  if (r < 0) { r += d; --q; }
+  else if (r >= d) { r -= d; ++q; }
+}
+
 // C(mr x nc) = beta*C + alpha * op(A) op(B); operands column-major in LDS (or global for B/A reads).
 // The sum over k is taken in index order, one product at a time (the CPU path's order); the OPERANDS of four consecutive terms are
 // fetched together first: the trip count is a run-time value, the loop is not unrolled by the compiler, and with one fetch per
@@ -67,8 +75,10 @@ __device__ __forceinline__ void wave_gemm(int lane, int ta, int tb, int mr, int 
                                           const T* A, int lda, const T* B, int ldb, T beta, T* C,
                                           int ldc) {
   const int total = mr * nc;
+  const float rmr = __builtin_amdgcn_rcpf((float)mr);
   for (int e = lane; e < total; e += 64) {
-    const int i = e % mr, j = e / mr;
+    int i, j;
+    split_index(e, mr, rmr, i, j);
     const T* pa = ta ? A + i * lda : A + i;
     const T* pb = tb ? B + j : B + j * ldb;
     const int sa = ta ? 1 : lda, sb = tb ? ldb : 1;
@@ -106,6 +116,147 @@ __device__ __forceinline__ void wave_copy(int lane, T* dst, const T* src, int co
   }
 }
 
+// sum_i a[i] b[i], i = 0 .. cnt-1, in index order, four operand pairs fetched at a time
+template <typename T>
+__device__ __forceinline__ T gen_dot(const T* a, const T* b, int cnt) {
+  T s = T(0);
+  int j = 0;
+  for (; j + 4 <= cnt; j += 4) {
+    const T a0 = a[j], a1 = a[j + 1], a2 = a[j + 2], a3 = a[j + 3];
+    const T b0 = b[j], b1 = b[j + 1], b2 = b[j + 2], b3 = b[j + 3];
+    s += a0 * b0;
+    s += a1 * b1;
+    s += a2 * b2;
+    s += a3 * b3;
+  }
+  for (; j < cnt; ++j) s += a[j] * b[j];
+  return s;
+}
+
+// ---- the gain solve of small input dimensions in registers --------------------------------------------------------------------------
+// Quu + reg I = L L^T (unblocked lower Cholesky, Eigen's llt_inplace order: fail when a pivot is <= 0) for m <= M with L in the
+// registers of EVERY lane (the same instructions wave-wide: the cost of one lane doing it, without the LDS round trip per entry
+// that one lane walking the matrix in LDS pays), then one right-hand side per lane against those registers.
+#define GEN_TRI(i, j) ((i) * ((i) + 1) / 2 + (j))
+template <typename T, int M>
+__device__ __forceinline__ int chol_regs(const T* sL, int m, T (&L)[M * (M + 1) / 2]) {
+#pragma unroll
+  for (int i = 0; i < M; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j) L[GEN_TRI(i, j)] = i < m ? sL[i + j * m] : (i == j ? T(1) : T(0));
+  int fail = 0;
+#pragma unroll
+  for (int kk = 0; kk < M; ++kk) {
+    if (kk < m && !fail) {
+      T x = L[GEN_TRI(kk, kk)];
+#pragma unroll
+      for (int j = 0; j < kk; ++j) x -= L[GEN_TRI(kk, j)] * L[GEN_TRI(kk, j)];
+      if (x <= T(0)) {
+        fail = 1;
+      } else {
+        x = sqrt(x);
+        L[GEN_TRI(kk, kk)] = x;
+#pragma unroll
+        for (int i = kk + 1; i < M; ++i) {
+          if (i < m) {
+            T s = L[GEN_TRI(i, kk)];
+#pragma unroll
+            for (int j = 0; j < kk; ++j) s -= L[GEN_TRI(i, j)] * L[GEN_TRI(kk, j)];
+            L[GEN_TRI(i, kk)] = s / x;
+          }
+        }
+      }
+    }
+  }
+  return fail;
+}
+template <typename T, int M>
+__device__ __forceinline__ void solve_regs(const T (&L)[M * (M + 1) / 2], int m, T* rhs) {
+  T v[M];
+#pragma unroll
+  for (int i = 0; i < M; ++i) v[i] = i < m ? rhs[i] : T(0);
+#pragma unroll
+  for (int i = 0; i < M; ++i) {
+    if (i < m) {
+      T s = v[i];
+#pragma unroll
+      for (int j = 0; j < i; ++j) s -= L[GEN_TRI(i, j)] * v[j];
+      v[i] = s / L[GEN_TRI(i, i)];
+    }
+  }
+#pragma unroll
+  for (int i = M - 1; i >= 0; --i) {
+    if (i < m) {
+      T s = v[i];
+#pragma unroll
+      for (int j = i + 1; j < M; ++j) {
+        if (j < m) s -= L[GEN_TRI(j, i)] * v[j];
+      }
+      v[i] = s / L[GEN_TRI(i, i)];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < M; ++i) {
+    if (i < m) rhs[i] = v[i];
+  }
+}
+// x - sum_j a[j sa] b[j sb], j = 0 .. cnt-1, one product at a time in index order; four operand pairs fetched at a time
+template <typename T>
+__device__ __forceinline__ T gen_dot_sub(T x, const T* a, int sa, const T* b, int sb, int cnt) {
+  int j = 0;
+  for (; j + 4 <= cnt; j += 4) {
+    const T a0 = a[(j + 0) * sa], a1 = a[(j + 1) * sa], a2 = a[(j + 2) * sa], a3 = a[(j + 3) * sa];
+    const T b0 = b[(j + 0) * sb], b1 = b[(j + 1) * sb], b2 = b[(j + 2) * sb], b3 = b[(j + 3) * sb];
+    x -= a0 * b0;
+    x -= a1 * b1;
+    x -= a2 * b2;
+    x -= a3 * b3;
+  }
+  for (; j < cnt; ++j) x -= a[j * sa] * b[j * sb];
+  return x;
+}
+
+// m > 4: the same factorisation column by column with the rows below the pivot spread over the lanes (every lane forms the pivot
+// itself: same addresses, same instructions), then one right-hand side per lane against the factor in the work image.
+template <typename T>
+__device__ __forceinline__ int gain_solve_lanes(int lane, T* sL, T* sK, T* sd, int n, int m) {
+  for (int kk = 0; kk < m; ++kk) {
+    T x = gen_dot_sub<T>(sL[kk + kk * m], sL + kk, m, sL + kk, m, kk);
+    if (x <= T(0)) return 1;                           // (uniform)
+    x = sqrt(x);
+    for (int i = kk + 1 + lane; i < m; i += 64) {
+      const T sv = gen_dot_sub<T>(sL[i + kk * m], sL + i, m, sL + kk, m, kk);
+      sL[i + kk * m] = sv / x;
+    }
+    if (lane == 0) sL[kk + kk * m] = x;
+    __syncthreads();
+  }
+  for (int c = lane; c < n + 1; c += 64) {
+    T* rhs = (c < n) ? (sK + c * m) : sd;
+    for (int i = 0; i < m; ++i) rhs[i] = gen_dot_sub<T>(rhs[i], sL + i, m, rhs, 1, i) / sL[i + i * m];
+    for (int i = m - 1; i >= 0; --i) rhs[i] = gen_dot_sub<T>(rhs[i], sL + (i + 1) + i * m, 1, rhs + i + 1, 1, m - 1 - i) / sL[i + i * m];
+  }
+  return 0;
+}
+
+template <typename T, int M>
+__device__ __forceinline__ int gain_solve_regs(int lane, T* sL, T* sK, T* sd, int n, int m, bool keep_factor) {
+  T L[M * (M + 1) / 2];
+  const int fail = chol_regs<T, M>(sL, m, L);
+  __syncthreads();                                     // (every lane has read the matrix before lane 0 writes the factor over it)
+  if (keep_factor && lane == 0) {                      // Quu_tmp of the reference holds the factor (as far as it got)
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+      for (int j = 0; j <= i; ++j) {
+        if (i < m) sL[i + j * m] = L[GEN_TRI(i, j)];
+      }
+  }
+  if (fail) return 1;
+  for (int c = lane; c < n + 1; c += 64) solve_regs<T, M>(L, m, (c < n) ? (sK + c * m) : sd);
+  return 0;
+}
+
 // BIG = false: the knot point's blocks live in LDS (what fits 64 KB: n, m up to ~32 in fp64).  BIG = true: the same code on a
 // per-problem work block in GLOBAL memory (args.ws) -- any dimensions, as the reference takes them (tvlqr.cpp:92-121 sizes every
 // block from nx[k], nu[k]); slow (every operand is a cached global load), which is the point: refusing n = 33 is worse.  A workgroup
@@ -119,8 +270,8 @@ __global__ __launch_bounds__(64) void generic_backward_kernel(GenericArgs<T> a) 
   T* smem = BIG ? a.ws + (int64_t)b * a.ws_stride : reinterpret_cast<T*>(smem_raw);
   const int nm = a.nmax, mm = a.mmax;
   // LDS carve
-  T* sP = smem;                 // P_{k+1}     nm*nm
-  T* sp = sP + nm * nm;         // p_{k+1}     nm
+  T* sP = smem;                 // P_{k+1}, then P_k in its place     nm*nm
+  T* sp = sP + nm * nm;         // p_{k+1}, then p_k                  nm
   T* sA = sp + nm;              // A_k         nm*nm
   T* sB = sA + nm * nm;         // B_k         nm*mm
   T* sf = sB + nm * mm;         // f_k         nm
@@ -135,11 +286,7 @@ __global__ __launch_bounds__(64) void generic_backward_kernel(GenericArgs<T> a) 
   T* sL = st + nm;              // Quu_tmp mm*mm
   T* sK = sL + mm * mm;         // mm*nm
   T* sd = sK + mm * nm;         // mm
-  T* sPk = sd + mm;             // P_k nm*nm
-  T* spk = sPk + nm * nm;       // p_k nm
-  T* sw = spk + nm;             // Qu_tmp mm
-  int* s_failp = reinterpret_cast<int*>(sw + mm);  // keep ALL LDS in the one dynamic array
-#define s_fail (*s_failp)
+  T* sw = sd + mm;              // Qu_tmp mm
 
 #define GPTR(arr, k) (a.base[arr] + (int64_t)b * a.bstride[arr] + a.off[(int64_t)(k) * G_NUM + arr])
   const int N = a.N;
@@ -158,7 +305,6 @@ __global__ __launch_bounds__(64) void generic_backward_kernel(GenericArgs<T> a) 
     wave_copy(lane, GPTR(G_P, N), (const T*)sP, n * n);
     wave_copy(lane, GPTR(G_p, N), (const T*)sp, n);
   }
-  if (lane == 0) s_fail = 0;
   __syncthreads();
 
   for (int k = N - 1; k >= 0; --k) {
@@ -198,26 +344,16 @@ __global__ __launch_bounds__(64) void generic_backward_kernel(GenericArgs<T> a) 
     // gains (tvlqr.cpp:155-166)
     wave_copy(lane, sK, (const T*)sQux, m * n);
     for (int e = lane; e < m; e += 64) sd[e] = -sQu[e];
-    for (int e = lane; e < m * m; e += 64) sL[e] = sQuu[e] + ((e % m == e / m) ? a.reg : T(0));
-    __syncthreads();
-    if (lane == 0) {  // unblocked lower Cholesky, fail when the pivot is <= 0 (Eigen llt_inplace)
-      int fail = 0;
-      for (int kk = 0; kk < m && !fail; ++kk) {
-        T x = sL[kk + kk * m];
-        for (int j = 0; j < kk; ++j) x -= sL[kk + j * m] * sL[kk + j * m];
-        if (x <= T(0)) { fail = 1; break; }
-        x = sqrt(x);
-        sL[kk + kk * m] = x;
-        for (int i = kk + 1; i < m; ++i) {
-          T s = sL[i + kk * m];
-          for (int j = 0; j < kk; ++j) s -= sL[i + j * m] * sL[kk + j * m];
-          sL[i + kk * m] = s / x;
-        }
-      }
-      s_fail = fail;
+    {
+      const float rmf = __builtin_amdgcn_rcpf((float)(m > 0 ? m : 1));
+      for (int e = lane; e < m * m; e += 64) { int i, j; split_index(e, m, rmf, i, j); sL[e] = sQuu[e] + ((i == j) ? a.reg : T(0)); }
     }
     __syncthreads();
-    if (s_fail) {  // tvlqr.cpp:162-164: return k, leaving K_k = Qux, d_k = -Qu unsolved
+    // Quu + reg I = L L^T (fail when a pivot is <= 0: Eigen's llt_inplace) and solveInPlace, one right-hand side per lane
+    // (columns of K, then d): in registers for m <= 4, spread over the lanes beyond
+    const int failed = m <= 4 ? gain_solve_regs<T, 4>(lane, sL, sK, sd, n, m, a.store_q == 2) : gain_solve_lanes<T>(lane, sL, sK, sd, n, m);
+    __syncthreads();
+    if (failed) {  // tvlqr.cpp:162-164: return k, leaving K_k = Qux, d_k = -Qu unsolved
       wave_copy(lane, GPTR(G_K, k), (const T*)sK, m * n);
       wave_copy(lane, GPTR(G_d, k), (const T*)sd, m);
       if (a.store_q) {
@@ -240,43 +376,34 @@ __global__ __launch_bounds__(64) void generic_backward_kernel(GenericArgs<T> a) 
       }
       return;
     }
-    // solveInPlace: one right-hand side per lane (columns of K, then d)
-    for (int c = lane; c < n + 1; c += 64) {
-      T* rhs = (c < n) ? (sK + c * m) : sd;
-      for (int i = 0; i < m; ++i) {
-        T s = rhs[i];
-        for (int j = 0; j < i; ++j) s -= sL[i + j * m] * rhs[j];
-        rhs[i] = s / sL[i + i * m];
-      }
-      for (int i = m - 1; i >= 0; --i) {
-        T s = rhs[i];
-        for (int j = i + 1; j < m; ++j) s -= sL[j + i * m] * rhs[j];
-        rhs[i] = s / sL[i + i * m];
-      }
-    }
-    __syncthreads();
     // cost-to-go (tvlqr.cpp:173-186)
     wave_gemm<T>(lane, 0, 0, m, n, m, T(1), sQuu, m, sK, m, T(0), sT2, m);  // Qux_tmp = Quu K
     wave_gemm<T>(lane, 1, 0, n, n, m, T(1), sK, m, sQux, m, T(0), sT1, n);  // Qxx_tmp = K^T Qux
-    wave_copy(lane, sPk, (const T*)sQxx, n * n);
-    wave_copy(lane, spk, (const T*)sQx, n);
+    wave_copy(lane, sP, (const T*)sQxx, n * n);         // P_{k+1}, p_{k+1} are dead from here: P_k, p_k are built in their place
+    wave_copy(lane, sp, (const T*)sQx, n);
     wave_gemm<T>(lane, 0, 0, m, 1, m, T(1), sQuu, m, sd, m, T(0), sw, m);   // Qu_tmp = Quu d (:189)
     if (a.store_q == 2) wave_gemm<T>(lane, 1, 0, n, 1, m, T(1), sK, m, sQu, m, T(0), st, n);  // Qx_tmp = K^T Qu (:176)
     __syncthreads();
-    wave_gemm<T>(lane, 1, 0, n, n, m, T(1), sT2, m, sK, m, T(1), sPk, n);   // P += (Quu K)^T K
+    wave_gemm<T>(lane, 1, 0, n, n, m, T(1), sT2, m, sK, m, T(1), sP, n);    // P += (Quu K)^T K
     __syncthreads();
-    for (int e = lane; e < n * n; e += 64) sPk[e] -= sT1[e];                // P -= K^T Qux
+    {   // P -= K^T Qux; P -= (K^T Qux)^T: the same lane owns the element in both statements
+      const float rn = __builtin_amdgcn_rcpf((float)n);
+      for (int e = lane; e < n * n; e += 64) {
+        int i, j;
+        split_index(e, n, rn, i, j);
+        T v = sP[e];
+        v -= sT1[e];
+        v -= sT1[j + i * n];
+        sP[e] = v;
+      }
+    }
+    wave_gemm<T>(lane, 1, 0, n, 1, m, T(-1), sT2, m, sd, m, T(1), sp, n);   // p -= (Quu K)^T d
     __syncthreads();
-    for (int e = lane; e < n * n; e += 64) sPk[e] -= sT1[(e / n) + (e % n) * n];  // P -= (..)^T
-    wave_gemm<T>(lane, 1, 0, n, 1, m, T(-1), sT2, m, sd, m, T(1), spk, n);  // p -= (Quu K)^T d
+    wave_gemm<T>(lane, 1, 0, n, 1, m, T(-1), sK, m, sQu, m, T(1), sp, n);   // p -= K^T Qu
     __syncthreads();
-    wave_gemm<T>(lane, 1, 0, n, 1, m, T(-1), sK, m, sQu, m, T(1), spk, n);  // p -= K^T Qu
-    __syncthreads();
-    wave_gemm<T>(lane, 1, 0, n, 1, m, T(1), sQux, m, sd, m, T(1), spk, n);  // p += Qux^T d
+    wave_gemm<T>(lane, 1, 0, n, 1, m, T(1), sQux, m, sd, m, T(1), sp, n);   // p += Qux^T d
     if (lane == 0) {  // tvlqr.cpp:189-191
-      T s0 = T(0), s1 = T(0);
-      for (int i = 0; i < m; ++i) s0 += sd[i] * sQu[i];
-      for (int i = 0; i < m; ++i) s1 += sd[i] * sw[i];
+      const T s0 = gen_dot<T>(sd, sQu, m), s1 = gen_dot<T>(sd, sw, m);
       dv0 += s0;
       dv1 += T(0.5) * s1;
     }
@@ -284,8 +411,8 @@ __global__ __launch_bounds__(64) void generic_backward_kernel(GenericArgs<T> a) 
     // write the knot point's results, roll P_k -> P_{k+1}
     wave_copy(lane, GPTR(G_K, k), (const T*)sK, m * n);
     wave_copy(lane, GPTR(G_d, k), (const T*)sd, m);
-    wave_copy(lane, GPTR(G_P, k), (const T*)sPk, n * n);
-    wave_copy(lane, GPTR(G_p, k), (const T*)spk, n);
+    wave_copy(lane, GPTR(G_P, k), (const T*)sP, n * n);
+    wave_copy(lane, GPTR(G_p, k), (const T*)sp, n);
     if (a.store_q) {
       wave_copy(lane, GPTR(G_Qxx, k), (const T*)sQxx, n * n);
       wave_copy(lane, GPTR(G_Quu, k), (const T*)sQuu, m * m);
@@ -300,8 +427,6 @@ __global__ __launch_bounds__(64) void generic_backward_kernel(GenericArgs<T> a) 
       wave_copy(lane, GPTR(G_Qx_tmp, k), (const T*)st, n);
       wave_copy(lane, GPTR(G_Qu_tmp, k), (const T*)sw, m);
     }
-    wave_copy(lane, sP, (const T*)sPk, n * n);
-    wave_copy(lane, sp, (const T*)spk, n);
     __syncthreads();
   }
   if (lane == 0) {
@@ -313,7 +438,7 @@ __global__ __launch_bounds__(64) void generic_backward_kernel(GenericArgs<T> a) 
 
 template <typename T>
 inline size_t generic_backward_lds_bytes(int nm, int mm) {
-  size_t el = (size_t)5 * nm * nm + (size_t)4 * nm * mm + (size_t)2 * mm * mm + (size_t)6 * nm + (size_t)3 * mm;
+  size_t el = (size_t)4 * nm * nm + (size_t)4 * nm * mm + (size_t)2 * mm * mm + (size_t)5 * nm + (size_t)3 * mm;   // (the carve of generic_backward_kernel)
   return el * sizeof(T) + 64;
 }
 
@@ -393,7 +518,6 @@ __global__ __launch_bounds__(64) void generic_forward_kernel(GenericArgs<T> a) {
     }
   }
 #undef GPTR
-#undef s_fail
 }
 
 ALTRO_FP_REGION_END   // back to the including translation unit's own mode (fp_contract.h)
