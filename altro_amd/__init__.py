@@ -245,8 +245,9 @@ class Batch:
 
     @classmethod
     def with_dims(cls, nx, nu, batch, dtype=F64, flags=0, device=0, stream=None):
-        """altro_hip_batch_create_dims: per-knot-point dimensions nx[0..N], nu[0..N-1] (plan GENERIC, TVLQR sweeps).  Bulk arrays
-        are flat per problem, [batch, sum_k block_k]; `get` returns them like that (split with `offsets`)."""
+        """altro_hip_batch_create_dims: per-knot-point dimensions nx[0..N], nu[0..N-1] (plan GENERIC: the TVLQR sweeps and the iLQR
+        loop -- set_dynamics / set_quadratic_cost / set_initial_state / set_input_guess / add_linear_constraint / ilqr_solve ...).
+        Bulk arrays are flat per problem, [batch, sum_k block_k]; `get` / `get_nominal` return them like that."""
         self = cls.__new__(cls)
         self.L = lib()
         self.nx = np.ascontiguousarray(nx, dtype=np.int32); self.nu = np.ascontiguousarray(nu, dtype=np.int32)
@@ -405,7 +406,10 @@ class Batch:
         return out
 
     def get_nominal(self):
-        x = np.zeros((self.batch, self.N + 1, self.n)); u = np.zeros((self.batch, self.N, self.m))
+        if getattr(self, "nx", None) is not None:   # per-knot-point dimensions: packed [batch, sum nx], [batch, sum nu]
+            x = np.zeros((self.batch, self._ragged_len("x"))); u = np.zeros((self.batch, self._ragged_len("u")))
+        else:
+            x = np.zeros((self.batch, self.N + 1, self.n)); u = np.zeros((self.batch, self.N, self.m))
         _check(self.L.altro_hip_get_nominal(self.h, x.ctypes.data_as(C.c_void_p), u.ctypes.data_as(C.c_void_p)))
         return x, u
 
@@ -426,8 +430,10 @@ class Batch:
                                                     int(k_stride_zero), int(batch_stride_zero)))
 
     def get_knot(self, k, want_u=True):
-        x = np.zeros((self.batch, self.n))
-        u = np.zeros((self.batch, self.m)) if (want_u and k < self.N) else None
+        nk = self.n if getattr(self, "nx", None) is None else int(self.nx[k])
+        mk = self.m if getattr(self, "nx", None) is None or k >= self.N else int(self.nu[k])
+        x = np.zeros((self.batch, nk))
+        u = np.zeros((self.batch, mk)) if (want_u and k < self.N) else None
         _check(self.L.altro_hip_get_knot(self.h, int(k), x.ctypes.data_as(C.c_void_p),
                                          u.ctypes.data_as(C.c_void_p) if u is not None else None))
         return x, u

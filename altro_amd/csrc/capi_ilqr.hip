@@ -30,6 +30,11 @@ int al_upload_typed(altro_hip_batch* h) {
   for (size_t i = 0; i < h->al_defs.size(); ++i) {
     const AlDef& d0 = h->al_defs[i];
     G_off_dev[i] = (int)G.size();
+    if (h->ragged) {   // per-knot-point dimensions (plan GENERIC): the block as given, p x (nx[k] + nu[k]) of its knot points
+      G.resize(G.size() + (size_t)d0.p * d0.w, (T)0);
+      for (size_t e = 0; e < (size_t)d0.p * d0.w; ++e) G[(size_t)G_off_dev[i] + e] = (T)h->al_G[(size_t)d0.G_off + e];
+      continue;
+    }
     G.resize(G.size() + (size_t)d0.p * w_dev, (T)0);
     for (int e = 0; e < w_log; ++e)
       for (int r = 0; r < d0.p; ++r) G[(size_t)G_off_dev[i] + r + (size_t)dev_col(e) * d0.p] = (T)h->al_G[(size_t)d0.G_off + r + (size_t)e * d0.p];
@@ -264,7 +269,18 @@ int wave_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int
   if (rc) return fail(ALTRO_HIP_ERR_HIP, "iLQR kernel launch failed");
   return 0;
 }
-// plan GENERIC: any (n, m) up to 32, dynamics as data, quadratic cost, linear constraint blocks (kernels/ilqr_generic.hip)
+// one problem's length of the dense arrays of plan GENERIC's iLQR loop (nominal trajectory, the cost's own blocks): the sum of the
+// knot points' blocks, whatever their dimensions
+struct GenSizes { int64_t sx, su, sQ, sR, sH; };
+GenSizes gen_sizes(const altro_hip_batch* h) {
+  GenSizes z{0, 0, 0, 0, 0};
+  for (int k = 0; k <= h->N; ++k) {
+    const int64_t nk = h->ragged ? h->nxv[k] : h->n, mk = k < h->N ? (h->ragged ? h->nuv[k] : h->m) : 0;
+    z.sx += nk; z.su += mk; z.sQ += nk * nk; z.sR += mk * mk; z.sH += mk * nk;
+  }
+  return z;
+}
+// plan GENERIC: any (n_k, m_k) up to 32, dynamics as data, quadratic cost, linear constraint blocks (kernels/ilqr_generic.hip)
 template <typename T>
 int gen_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int want_deriv, double alpha_const, int mode) {
   const int n = h->n, m = h->m, N = h->N;
@@ -285,6 +301,9 @@ int gen_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int 
   a.alpha = use_alpha ? h->i_alpha : nullptr; a.active = use_active ? h->i_active : nullptr; a.alpha_const = alpha_const;
   a.phi = h->i_phi; a.dphi = h->i_dphi; a.prob = h->i_prob;
   a.N = N; a.n = n; a.m = m; a.batch = h->batch; a.want_derivative = want_deriv; a.mode = mode;
+  a.off = h->g_off; a.nx = h->g_nx; a.nu = h->g_nu;
+  const GenSizes gs = gen_sizes(h);
+  a.sx = gs.sx; a.su = gs.su; a.sQ = gs.sQ; a.sR = gs.sR; a.sH = gs.sH;
   a.al.knots = h->al_d_knots; a.al.G = (const T*)h->al_d_G; a.al.g = (const T*)h->al_d_g; a.al.z = (T*)h->al_d_z;
   a.al.enabled = h->al_defs.empty() ? 0 : 1;
   a.al.uniform = h->al_uniform; a.al.rows_per_knot = h->al_rows_per_knot; a.al.N = h->N; a.al.G_count = h->al_G_count;
@@ -329,13 +348,14 @@ int generic_cost_def(altro_hip_batch* h, const double* Q, const double* R, const
   const int n = h->n, m = h->m, N = h->N;
   const int nkx = kz ? 2 : N + 1, nku = kz ? 1 : N;
   const size_t B = h->batch, E = h->esz;
+  const GenSizes gs = gen_sizes(h);
   int rc = 0;
   {   // every array has its own guard: a failed allocation in the middle leaves the later pointers null and the next call retries them
     // (one `if (!h->g_cQ)` around all eight skipped the retry and handed null arrays to the kernels)
     struct { void** p; size_t bytes; bool zero; } want[] = {
-        {&h->g_cQ, B * (N + 1) * n * n * E, false}, {&h->g_cR, B * N * m * m * E, false}, {&h->g_cH, B * N * m * n * E, false},
-        {&h->g_cq, B * (N + 1) * n * E, false},     {&h->g_cr, B * N * m * E, false},     {&h->g_cc, B * (N + 1) * E, false},
-        {&h->g_xn, B * (N + 1) * n * E, true},      {&h->g_un, B * N * m * E, true}};
+        {&h->g_cQ, B * gs.sQ * E, false}, {&h->g_cR, B * gs.sR * E, false}, {&h->g_cH, B * gs.sH * E, false},
+        {&h->g_cq, B * gs.sx * E, false}, {&h->g_cr, B * gs.su * E, false}, {&h->g_cc, B * (N + 1) * E, false},
+        {&h->g_xn, B * gs.sx * E, true},  {&h->g_un, B * gs.su * E, true}};
     for (auto& w : want) {
       if (*w.p) continue;
       if ((rc = dmalloc(h, w.p, w.bytes))) return rc;
@@ -351,6 +371,20 @@ int generic_cost_def(altro_hip_batch* h, const double* Q, const double* R, const
       r_ = aos_set<T>(h, (T*)dst + (size_t)N * blk, (int64_t)nk_total * blk, (int64_t)blk, src, blk, 1, 1, bz, nk_host, (kz ? 1 : N) * blk);
     return r_;
   };
+  if (h->ragged) {   // per-knot-point dimensions: the caller's packed [b][k][block_k] arrays are the device layout, one block per problem
+    if (kz) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "k_stride_zero needs uniform dimensions");
+    auto whole = [&](void* dst, int64_t len, const double* src) -> int {
+      if (!src) { HIP_TRY(hipMemsetAsync(dst, 0, B * len * E, h->stream)); return 0; }
+      return aos_set<T>(h, (T*)dst, len, len, src, (int)len, 1, 0, bz);
+    };
+    rc = whole(h->g_cQ, gs.sQ, Q);
+    if (!rc) rc = whole(h->g_cR, gs.sR, R);
+    if (!rc) rc = whole(h->g_cH, gs.sH, H);
+    if (!rc) rc = whole(h->g_cq, gs.sx, q);
+    if (!rc) rc = whole(h->g_cr, gs.su, r);
+    if (!rc) rc = whole(h->g_cc, N + 1, c);
+    return rc;
+  }
   rc = put(h->g_cQ, n * n, N + 1, Q, nkx, true);
   if (!rc) rc = put(h->g_cR, m * m, N, R, nku, false);
   if (!rc) rc = put(h->g_cH, m * n, N, H, nku, false);
@@ -368,7 +402,7 @@ int generic_cost(altro_hip_batch* h, const double* Q, const double* R, const dou
   return rc;
 }
 int ilqr_check(altro_hip_batch* h, bool need_guess) {
-  int rc = loop_entry(h);
+  int rc = loop_entry(h, true);
   if (rc) return rc;
   if (h->plan == ALTRO_HIP_PLAN_MFMA16) {   // dynamics are data (altro_hip_set_dynamics) or a device model of the tile plan
     if (!h->dyn_set && !h->model_set)
@@ -546,11 +580,11 @@ int altro_hip_set_quadratic_cost(altro_hip_batch* h, const double* Q, const doub
   // ALTROSolver::SetQuadraticCost (altro_solver.cpp:118-136) -> KnotPointData::SetQuadraticCost (knotpoint_data.cpp:64-85) for the
   // device iLQR loop: the cost 1/2 x'Qx + 1/2 u'Ru + u'Hx + q'x + r'u + c per knot point, stored dense and evaluated as
   // CalcOriginalCost / Gradient / Hessian do (knotpoint_data.cpp:624-634, :659-668, :691-698).
-  int rc = loop_entry(h);
+  int rc = loop_entry(h, true);
   if (rc) return rc;
   h->expansion_current = false;
   if (!Q || !R || !H || !q || !r) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "Q, R, H, q, r are required (c may be NULL: zero)");
-  if (h->plan == ALTRO_HIP_PLAN_GENERIC) return generic_cost(h, Q, R, H, q, r, c, kz, bz);
+  if (h->plan == ALTRO_HIP_PLAN_GENERIC) return generic_cost(h, Q, R, H, q, r, c, kz, bz);   // (per-knot-point dimensions: packed arrays)
   const int n = h->n, m = h->m, N = h->N;
   const int nkx = kz ? 2 : N + 1, nku = kz ? 1 : N;
   const size_t Ez = h->esz;
@@ -646,12 +680,17 @@ int altro_hip_set_quadratic_cost(altro_hip_batch* h, const double* Q, const doub
 
 int altro_hip_set_input_guess(altro_hip_batch* h, const double* u, int kz, int bz) {
   // ALTROSolver::SetInput (altro_solver.cpp:242-251): writes the CANDIDATE inputs u_
-  int rc = loop_entry(h);
+  int rc = loop_entry(h, true);
   if (rc) return rc;
   h->expansion_current = false;
   if (!u) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "u == NULL");
   const int n = h->n, m = h->m, N = h->N;
   if (h->plan == ALTRO_HIP_PLAN_GENERIC) {   // candidate inputs: the forward sweep's u array, reference layout
+    if (h->ragged) {   // one packed block per problem
+      if (kz) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "k_stride_zero needs uniform dimensions");
+      const int len = (int)h->g_bstride[G_u];
+      rc = h->dtype == ALTRO_HIP_F64 ? generic_set<double>(h, G_u, u, len, 1, 0, bz) : generic_set<float>(h, G_u, u, len, 1, 0, bz);
+    } else
     rc = h->dtype == ALTRO_HIP_F64 ? generic_set<double>(h, G_u, u, m, N, kz, bz) : generic_set<float>(h, G_u, u, m, N, kz, bz);
     if (!rc) h->guess_set = true;
     return rc;
@@ -672,12 +711,17 @@ int altro_hip_set_input_guess(altro_hip_batch* h, const double* u, int kz, int b
 
 int altro_hip_set_state_guess(altro_hip_batch* h, const double* x, int kz, int bz) {
   // ALTROSolver::SetState (altro_solver.cpp:229-240): writes the CANDIDATE states x_
-  int rc = loop_entry(h);
+  int rc = loop_entry(h, true);
   if (rc) return rc;
   h->expansion_current = false;
   if (!x) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "x == NULL");
   const int n = h->n, m = h->m, N = h->N;
   const bool f64 = h->dtype == ALTRO_HIP_F64;
+  if (h->plan == ALTRO_HIP_PLAN_GENERIC && h->ragged) {   // one packed block per problem
+    if (kz) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "k_stride_zero needs uniform dimensions");
+    const int len = (int)h->g_bstride[G_x];
+    return f64 ? generic_set<double>(h, G_x, x, len, 1, 0, bz) : generic_set<float>(h, G_x, x, len, 1, 0, bz);
+  }
   if (h->plan == ALTRO_HIP_PLAN_GENERIC)
     return f64 ? generic_set<double>(h, G_x, x, n, N + 1, kz, bz) : generic_set<float>(h, G_x, x, n, N + 1, kz, bz);
   if (h->plan == ALTRO_HIP_PLAN_MFMA16)
@@ -752,6 +796,8 @@ int altro_hip_feasibility(altro_hip_batch* h, double* out) {
 // ---- MPC receding-horizon operations on the resident batch -----------------
 int altro_hip_shift_trajectory(altro_hip_batch* h) {
   int rc = ilqr_check(h, true);
+  if (!rc && h->ragged)   // (the reference's ShiftTrajectory copies knot point k + 1 into k: meaningful between equal dimensions only)
+    rc = fail(ALTRO_HIP_ERR_UNSUPPORTED, "altro_hip_shift_trajectory needs uniform dimensions");
   if (!rc) rc = ilqr_run(h, IK_SHIFT, false, false, 0, 0.0);
   return rc;
 }
@@ -833,8 +879,8 @@ int altro_hip_update_linear_costs(altro_hip_batch* h, const double* q, const dou
 }
 int altro_hip_get_knot(altro_hip_batch* h, int k, double* x, double* u) {
   // ALTROSolver::GetState / GetInput (altro_solver.cpp:323-347) of one knot point for the whole batch:
-  // x [batch][n], u [batch][m] (u must be NULL at k = N)
-  int rc = loop_entry(h);
+  // x [batch][n], u [batch][m] (u must be NULL at k = N); per-knot-point dimensions: [batch][nx[k]], [batch][nu[k]]
+  int rc = loop_entry(h, true);
   if (rc) return rc;
   const int n = h->n, m = h->m, N = h->N;
   if (k < 0 || k > N) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "knot point %d outside [0, %d] (ErrorCodes::BadIndex)", k, N);
@@ -852,6 +898,22 @@ int altro_hip_get_knot(altro_hip_batch* h, int k, double* x, double* u) {
       rc = h->dtype == ALTRO_HIP_F64
                ? aos_get<double>(h, u, (const double*)h->m_nom + (size_t)k * B * MF_NOM + 12, MF_NOM, B * MF_NOM, m, 1)
                : aos_get<float>(h, u, (const float*)h->m_nom + (size_t)k * B * MF_NOM + 12, MF_NOM, B * MF_NOM, m, 1);
+    return rc;
+  }
+  if (h->plan == ALTRO_HIP_PLAN_GENERIC && h->ragged) {
+    if (!h->g_xn) return fail(ALTRO_HIP_ERR_NOT_SET, "no cost has been set for the iLQR loop");
+    const GenSizes gs = gen_sizes(h);
+    int64_t ox = 0, ou = 0;
+    for (int j = 0; j < k; ++j) { ox += h->nxv[j]; ou += h->nuv[j]; }
+    const int nk = h->nxv[k], mk = k < N ? h->nuv[k] : 0;
+    if (x) {
+      rc = h->dtype == ALTRO_HIP_F64 ? aos_get<double>(h, x, (const double*)h->g_xn + ox, gs.sx, nk, nk, 1)
+                                     : aos_get<float>(h, x, (const float*)h->g_xn + ox, gs.sx, nk, nk, 1);
+      if (rc) return rc;
+    }
+    if (u)
+      rc = h->dtype == ALTRO_HIP_F64 ? aos_get<double>(h, u, (const double*)h->g_un + ou, gs.su, mk, mk, 1)
+                                     : aos_get<float>(h, u, (const float*)h->g_un + ou, gs.su, mk, mk, 1);
     return rc;
   }
   if (h->plan == ALTRO_HIP_PLAN_GENERIC) {
@@ -882,7 +944,7 @@ int altro_hip_get_knot(altro_hip_batch* h, int k, double* x, double* u) {
 int altro_hip_add_linear_constraint(altro_hip_batch* h, int k_first, int k_last, int cone, int p, const double* G,
                                     const double* g, int g_per_problem) {
   // ALTROSolver::SetConstraint (altro_solver.cpp:175-215) for c(x,u) = G [x;u] - g
-  int rc = loop_entry(h);
+  int rc = loop_entry(h, true);
   if (rc) return rc;
   h->expansion_current = false;
   if (!G || !g) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "G and g are required");
@@ -901,8 +963,16 @@ int altro_hip_add_linear_constraint(altro_hip_batch* h, int k_first, int k_last,
     if (h->al_knots[k].ncon >= cmax)
       return fail(ALTRO_HIP_ERR_UNSUPPORTED, "at most %d constraint blocks per knot point on this plan (k = %d)%s", cmax, k,
                   gen ? "" : ": ALTRO_HIP_PLAN_GENERIC takes 8");
-  const int w = h->n + h->m;
-  AlDef d{cone, p, g_per_problem ? 1 : 0, (int)h->al_G.size(), 0};
+  int w = h->n + h->m;
+  if (h->ragged) {   // G is p x (nx[k] + nu[k]): every knot point of the range must have the dimensions of the first (the terminal one: its nx)
+    const int nk = h->nxv[k_first], mk = k_first < h->N ? h->nuv[k_first] : h->m;
+    for (int k = k_first; k <= k_last; ++k)
+      if (h->nxv[k] != nk || (k < h->N && h->nuv[k] != mk))
+        return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "knot points %d and %d differ in dimension: one constraint block takes one [x; u] size "
+                                                "(register it per range, like ALTROSolver::SetConstraint per index)", k_first, k);
+    w = nk + mk;
+  }
+  AlDef d{cone, p, g_per_problem ? 1 : 0, (int)h->al_G.size(), 0, 0, w};
   h->al_G.insert(h->al_G.end(), G, G + (size_t)p * w);
   h->al_g.emplace_back(g, g + (size_t)p * (g_per_problem ? h->batch : 1));
   const int id = (int)h->al_defs.size();
@@ -931,7 +1001,7 @@ int altro_hip_add_user_constraint(altro_hip_batch* h, int k_first, int k_last, i
   return rc;
 }
 int altro_hip_clear_constraints(altro_hip_batch* h) {
-  int rc = loop_entry(h);
+  int rc = loop_entry(h, true);
   if (rc) return rc;
   h->expansion_current = false;
   h->al_defs.clear(); h->al_G.clear(); h->al_g.clear();
@@ -941,7 +1011,7 @@ int altro_hip_clear_constraints(altro_hip_batch* h) {
 }
 int altro_hip_reset_duals(altro_hip_batch* h, double penalty) {
   // duals back to zero and every constraint's penalty to `penalty` (what a fresh Initialize leaves: 1)
-  int rc = loop_entry(h);
+  int rc = loop_entry(h, true);
   if (rc) return rc;
   h->expansion_current = false;
   if (!(penalty > 0.0)) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "penalty must be positive");
@@ -957,7 +1027,7 @@ int altro_hip_reset_duals(altro_hip_batch* h, double penalty) {
 }
 int altro_hip_get_duals(altro_hip_batch* h, int k, int slot, double* z) {
   // duals of constraint block `slot` of knot point k, [batch][p]
-  int rc = loop_entry(h);
+  int rc = loop_entry(h, true);
   if (rc) return rc;
   if ((rc = al_upload(h))) return rc;
   if (k < 0 || k > h->N || slot < 0 || slot >= h->al_knots[k].ncon || !z)
@@ -1015,7 +1085,7 @@ int altro_hip_ilqr_poll(altro_hip_batch* h, int* n_done, const altro_hip_poll_re
   return 0;
 }
 int altro_hip_ilqr_wait(altro_hip_batch* h, altro_hip_solve_result* results) {
-  int rc = loop_entry(h);
+  int rc = loop_entry(h, true);
   if (rc) return rc;
   if (!h->poll_host) return fail(ALTRO_HIP_ERR_NOT_SET, "altro_hip_ilqr_solve_async has not been called");
   HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1056,9 +1126,22 @@ int altro_hip_last_solve_counts(const altro_hip_batch* h, int* sweeps, int* meri
   return 0;
 }
 int altro_hip_get_nominal(altro_hip_batch* h, double* x, double* u) {
-  int rc = loop_entry(h);
+  int rc = loop_entry(h, true);
   if (rc) return rc;
   const int n = h->n, m = h->m, N = h->N;
+  if (h->plan == ALTRO_HIP_PLAN_GENERIC && h->ragged) {   // per-knot-point dimensions: packed [batch][sum nx], [batch][sum nu]
+    if (!h->g_xn) return fail(ALTRO_HIP_ERR_NOT_SET, "no cost has been set for the iLQR loop");
+    const GenSizes gs = gen_sizes(h);
+    if (x) {
+      rc = h->dtype == ALTRO_HIP_F64 ? aos_get<double>(h, x, (const double*)h->g_xn, gs.sx, gs.sx, (int)gs.sx, 1)
+                                     : aos_get<float>(h, x, (const float*)h->g_xn, gs.sx, gs.sx, (int)gs.sx, 1);
+      if (rc) return rc;
+    }
+    if (u)
+      rc = h->dtype == ALTRO_HIP_F64 ? aos_get<double>(h, u, (const double*)h->g_un, gs.su, gs.su, (int)gs.su, 1)
+                                     : aos_get<float>(h, u, (const float*)h->g_un, gs.su, gs.su, (int)gs.su, 1);
+    return rc;
+  }
   if (h->plan == ALTRO_HIP_PLAN_MFMA16) {
     if (!h->m_nom) return fail(ALTRO_HIP_ERR_NOT_SET, "altro_hip_set_tracking_cost has not been called");
     const int64_t B = h->batch;

@@ -26,6 +26,7 @@ struct AlDef {
   int G_off;       // into the G pool (elements)
   int64_t g_off;   // into the g pool (elements): [p] shared, or [p][batch]
   int user;        // 0: c = G [x;u] - g;  id + 1: rows and Jacobian come from the caller's run-time compiled source
+  int w = 0;       // columns of G as given: n + m of the handle, or nx[k] + nu[k] of the block's knot points (per-knot-point dimensions)
 };
 struct AlKnot {          // everything a kernel needs about knot point k in ONE wave-uniform record
   int ncon;

@@ -1,4 +1,6 @@
-// ilqr_generic.hip -- the iLQR loop around the TVLQR sweep for plan GENERIC: any (n, m) up to 32, dynamics given as DATA
+// ilqr_generic.hip -- the iLQR loop around the TVLQR sweep for plan GENERIC: any (n_k, m_k) up to 32 -- per-knot-point dimensions
+// included, like ALTROSolver::SetDimension(n, m, k_start, k_stop) (altro_solver.cpp:26-47): every block is found through the sweep's
+// offset table (generic_arrays.h) and sized by nx[k], nu[k] -- dynamics given as DATA
 // (x+ = A_k x + B_k u + f_k: the reference's SetLinearDynamics path, knotpoint_data.cpp:123-142, :406-419, :710-719) and a
 // quadratic cost (tracking or dense).  The correctness-first companion of kernels/ilqr_mfma16.hip for the shapes the tile plan
 // does not cover (n > 12 or m > 4): one wavefront per problem, vectors exchanged through LDS, the blocks read from the
@@ -14,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "generic_arrays.h"
 #include "ilqr_types.h"
 #include "al_lane.hip"   // soc_projection / soc_jacobian / soc_hessian
 
@@ -33,9 +36,14 @@ struct IlqrGenArgs {
   const T* x0; int64_t x0_stride;
   const double* alpha; const int* active; double alpha_const;
   double* phi; double* dphi; IlqrProb* prob;
-  int N, n, m, batch, want_derivative, mode;
+  int N, n, m, batch, want_derivative, mode;                        // n, m: the LARGEST state / input dimension along the horizon
+  const int64_t* off;                                               // [(N + 1) * G_NUM]: the sweep's offset table (generic_arrays.h)
+  const int *nx, *nu;                                               // [N + 1] dimensions of knot point k
+  int64_t sx, su, sQ, sR, sH;                                       // one problem's length of xn | cq, un | cr, cQ, cR, cH (cc: N + 1)
   AlTable<T> al;                                                    // constraint blocks (G: p x (n + m), column-major)
 };
+
+#define GOFF(arr, k) (a.off[(int64_t)(k) * G_NUM + (arr)])
 
 __device__ __forceinline__ double gen_wave_sum(double v) {
 #pragma unroll
@@ -160,35 +168,35 @@ __global__ __launch_bounds__(64) void generic_rollout_kernel(IlqrGenArgs<T> a) {
   __shared__ double xs[GEN_MAX], us[GEN_MAX];
   const int b = blockIdx.x, lane = threadIdx.x;
   if (a.active && !a.active[b]) return;
-  const int n = a.n, m = a.m, N = a.N;
-  const int i = lane < n ? lane : 0;
-  double x = (double)a.x0[(int64_t)b * a.x0_stride + i];
+  const int N = a.N;
+  double x = (double)a.x0[(int64_t)b * a.x0_stride + (lane < a.nx[0] ? lane : 0)];
   for (int k = 0; k < N; ++k) {
+    const int n = a.nx[k], m = a.nu[k], n2 = a.nx[k + 1];
     __syncthreads();
-    if (lane < n) { xs[lane] = x; a.x[(int64_t)b * a.x_bs + (int64_t)k * n + lane] = (T)x; }
-    if (lane < m) us[lane] = (double)a.u[(int64_t)b * a.u_bs + (int64_t)k * m + lane];
+    if (lane < n) { xs[lane] = x; a.x[(int64_t)b * a.x_bs + GOFF(G_x, k) + lane] = (T)x; }
+    if (lane < m) us[lane] = (double)a.u[(int64_t)b * a.u_bs + GOFF(G_u, k) + lane];
     __syncthreads();
-    const T* Ak = a.A + (int64_t)b * a.A_bs + (int64_t)k * n * n;
-    const T* Bk = a.B + (int64_t)b * a.B_bs + (int64_t)k * n * m;
+    const int i = lane < n2 ? lane : 0;                  // row of x_{k+1} (A_k is n2 x n, B_k n2 x m)
+    const T* Ak = a.A + (int64_t)b * a.A_bs + GOFF(G_A, k);
+    const T* Bk = a.B + (int64_t)b * a.B_bs + GOFF(G_B, k);
     double s = 0.0, s2 = 0.0;
-    for (int j = 0; j < n; ++j) s += (double)Ak[i + j * n] * xs[j];
-    for (int j = 0; j < m; ++j) s2 += (double)Bk[i + j * n] * us[j];
-    x = (s + s2) + (double)a.f[(int64_t)b * a.f_bs + (int64_t)k * n + i];
+    for (int j = 0; j < n; ++j) s += (double)Ak[i + j * n2] * xs[j];
+    for (int j = 0; j < m; ++j) s2 += (double)Bk[i + j * n2] * us[j];
+    x = (s + s2) + (double)a.f[(int64_t)b * a.f_bs + GOFF(G_f, k) + i];
   }
-  if (lane < n) a.x[(int64_t)b * a.x_bs + (int64_t)N * n + lane] = (T)x;
+  if (lane < a.nx[N]) a.x[(int64_t)b * a.x_bs + GOFF(G_x, N) + lane] = (T)x;
 }
 
 // nominal <- candidate (x, u)
 template <typename T>
 __global__ void generic_accept_kernel(IlqrGenArgs<T> a) {
-  const int n = a.n, m = a.m, N = a.N;
-  const int64_t per = (int64_t)(N + 1) * n + (int64_t)N * m, total = per * a.batch;
+  const int64_t per = a.sx + a.su, total = per * a.batch;
   for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
     const int b = (int)(t / per);
     const int64_t e = t % per;
     if (a.active && !a.active[b]) continue;
-    if (e < (int64_t)(N + 1) * n) a.xn[(int64_t)b * (N + 1) * n + e] = a.x[(int64_t)b * a.x_bs + e];
-    else a.un[(int64_t)b * N * m + (e - (int64_t)(N + 1) * n)] = a.u[(int64_t)b * a.u_bs + (e - (int64_t)(N + 1) * n)];
+    if (e < a.sx) a.xn[(int64_t)b * a.sx + e] = a.x[(int64_t)b * a.x_bs + e];
+    else a.un[(int64_t)b * a.su + (e - a.sx)] = a.u[(int64_t)b * a.u_bs + (e - a.sx)];
   }
 }
 
@@ -197,7 +205,7 @@ __global__ void generic_accept_kernel(IlqrGenArgs<T> a) {
 //   EXPAND_HESSIAN : lxx = Q, luu = R, lux = H (knotpoint_data.cpp:691-698) into its Q / R / H -- a copy of the cost's own blocks
 template <typename T>
 __global__ void generic_expand_kernel(IlqrGenArgs<T> a) {
-  const int n = a.n, m = a.m, N = a.N, w = n + m;
+  const int N = a.N, w = a.n + a.m;                      // threads per knot point: the largest [x; u]; e < a.n: state row e, else input row e - a.n
   const bool grad = (a.mode & EXPAND_GRADIENT) != 0, hess = (a.mode & EXPAND_HESSIAN) != 0;
   const int64_t total = (int64_t)a.batch * (N + 1) * w;
   for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
@@ -206,46 +214,43 @@ __global__ void generic_expand_kernel(IlqrGenArgs<T> a) {
     const int b = (int)(t / ((int64_t)w * (N + 1)));
     if (a.active && !a.active[b]) continue;
     const bool terminal = k == N;
-    if (terminal && e >= n) continue;
-    const T* xk = a.x + (int64_t)b * a.x_bs + (int64_t)k * n;
-    const T* uk = a.u + (int64_t)b * a.u_bs + (int64_t)k * m;
+    const int n = a.nx[k], m = terminal ? 0 : a.nu[k];
+    const bool isx = e < a.n;
+    const int i = isx ? e : e - a.n;
+    if (isx ? i >= n : i >= m) continue;
+    const T* xk = a.x + (int64_t)b * a.x_bs + GOFF(G_x, k);
+    const T* uk = a.u + (int64_t)b * a.u_bs + GOFF(G_u, k);
+    const T* Qk = a.cQ + (int64_t)b * a.sQ + GOFF(G_Q, k);
+    const T* Rk = a.cR + (int64_t)b * a.sR + GOFF(G_R, k);
+    const T* Hk = a.cH + (int64_t)b * a.sH + GOFF(G_H, k);
     if (grad) {
       double s;
-      if (e < n) {
-        const T* Qk = a.cQ + ((int64_t)b * (N + 1) + k) * n * n;
+      if (isx) {
         s = 0.0;
-        for (int j = 0; j < n; ++j) s += (double)Qk[e + j * n] * (double)xk[j];
-        s += (double)a.cq[((int64_t)b * (N + 1) + k) * n + e];
+        for (int j = 0; j < n; ++j) s += (double)Qk[i + j * n] * (double)xk[j];
+        s += (double)a.cq[(int64_t)b * a.sx + GOFF(G_q, k) + i];
         if (!terminal) {
-          const T* Hk = a.cH + ((int64_t)b * N + k) * m * n;
           double t2 = 0.0;
-          for (int i = 0; i < m; ++i) t2 += (double)Hk[i + e * m] * (double)uk[i];
+          for (int r = 0; r < m; ++r) t2 += (double)Hk[r + i * m] * (double)uk[r];
           s += t2;
         }
-        a.q[(int64_t)b * a.q_bs + (int64_t)k * n + e] = (T)s;
+        a.q[(int64_t)b * a.q_bs + GOFF(G_q, k) + i] = (T)s;
       } else {
-        const int i = e - n;
-        const T* Rk = a.cR + ((int64_t)b * N + k) * m * m;
-        const T* Hk = a.cH + ((int64_t)b * N + k) * m * n;
         s = 0.0;
         for (int j = 0; j < m; ++j) s += (double)Rk[i + j * m] * (double)uk[j];
-        s += (double)a.cr[((int64_t)b * N + k) * m + i];
+        s += (double)a.cr[(int64_t)b * a.su + GOFF(G_r, k) + i];
         double t2 = 0.0;
         for (int j = 0; j < n; ++j) t2 += (double)Hk[i + j * m] * (double)xk[j];
         s += t2;
-        a.r[(int64_t)b * a.r_bs + (int64_t)k * m + i] = (T)s;
+        a.r[(int64_t)b * a.r_bs + GOFF(G_r, k) + i] = (T)s;
       }
     }
     if (hess) {
-      if (e < n) {
-        const T* Qk = a.cQ + ((int64_t)b * (N + 1) + k) * n * n;
-        for (int j = 0; j < n; ++j) a.Q[(int64_t)b * a.Q_bs + (int64_t)k * n * n + e + j * n] = Qk[e + j * n];
+      if (isx) {
+        for (int j = 0; j < n; ++j) a.Q[(int64_t)b * a.Q_bs + GOFF(G_Q, k) + i + j * n] = Qk[i + j * n];
       } else {
-        const int i = e - n;
-        const T* Rk = a.cR + ((int64_t)b * N + k) * m * m;
-        const T* Hk = a.cH + ((int64_t)b * N + k) * m * n;
-        for (int j = 0; j < m; ++j) a.R[(int64_t)b * a.R_bs + (int64_t)k * m * m + i + j * m] = Rk[i + j * m];
-        for (int j = 0; j < n; ++j) a.H[(int64_t)b * a.H_bs + (int64_t)k * m * n + i + j * m] = Hk[i + j * m];
+        for (int j = 0; j < m; ++j) a.R[(int64_t)b * a.R_bs + GOFF(G_R, k) + i + j * m] = Rk[i + j * m];
+        for (int j = 0; j < n; ++j) a.H[(int64_t)b * a.H_bs + GOFF(G_H, k) + i + j * m] = Hk[i + j * m];
       }
     }
   }
@@ -258,37 +263,38 @@ __global__ __launch_bounds__(64) void generic_merit_kernel(IlqrGenArgs<T> a) {
   __shared__ double xs[GEN_MAX], dxs[GEN_MAX], das[GEN_MAX], us[GEN_MAX], dus[GEN_MAX], jv[GEN_AL_JV];
   const int b = blockIdx.x, lane = threadIdx.x;
   if (a.active && !a.active[b]) return;
-  const int n = a.n, m = a.m, N = a.N;
+  const int N = a.N;
   const bool al = a.al.enabled != 0;
   const double rho = al ? a.prob[b].rho : 1.0;
   double viol = 0.0;
   const double alpha = a.alpha ? a.alpha[b] : a.alpha_const;
   const bool deriv = a.want_derivative != 0;
-  const bool isx = lane < n, isu = lane >= 32 && lane - 32 < m;
-  const int i = isx ? lane : 0, iu = isu ? lane - 32 : 0;
-  double x = (double)a.x0[(int64_t)b * a.x0_stride + i], dxda = 0.0;
+  double x = (double)a.x0[(int64_t)b * a.x0_stride + (lane < a.nx[0] ? lane : 0)], dxda = 0.0;
   double J = 0.0, dJ = 0.0;
   for (int k = 0; k < N; ++k) {
+    const int n = a.nx[k], m = a.nu[k], n2 = a.nx[k + 1];
+    const bool isx = lane < n, isu = lane >= 32 && lane - 32 < m;
+    const int i = isx ? lane : 0, iu = isu ? lane - 32 : 0;
     __syncthreads();
     if (isx) {
-      xs[lane] = x; dxs[lane] = x - (double)a.xn[((int64_t)b * (N + 1) + k) * n + lane]; das[lane] = dxda;
-      a.x[(int64_t)b * a.x_bs + (int64_t)k * n + lane] = (T)x;
+      xs[lane] = x; dxs[lane] = x - (double)a.xn[(int64_t)b * a.sx + GOFF(G_x, k) + lane]; das[lane] = dxda;
+      a.x[(int64_t)b * a.x_bs + GOFF(G_x, k) + lane] = (T)x;
     }
     __syncthreads();
     if (isu) {   // u_ = u + (-K dx + alpha d) ; du_da = -K dx_da + d
-      const T* Kk = a.K + (int64_t)b * a.K_bs + (int64_t)k * m * n;
+      const T* Kk = a.K + (int64_t)b * a.K_bs + GOFF(G_K, k);
       double s = 0.0, s2 = 0.0;
       for (int j = 0; j < n; ++j) { const double kj = (double)Kk[iu + j * m]; s += kj * dxs[j]; s2 += kj * das[j]; }
-      const double dk = (double)a.d[(int64_t)b * a.d_bs + (int64_t)k * m + iu];
-      const double uv = (double)a.un[((int64_t)b * N + k) * m + iu] + (-s + alpha * dk);
+      const double dk = (double)a.d[(int64_t)b * a.d_bs + GOFF(G_d, k) + iu];
+      const double uv = (double)a.un[(int64_t)b * a.su + GOFF(G_u, k) + iu] + (-s + alpha * dk);
       us[iu] = uv; dus[iu] = -s2 + dk;
-      a.u[(int64_t)b * a.u_bs + (int64_t)k * m + iu] = (T)uv;
+      a.u[(int64_t)b * a.u_bs + GOFF(G_u, k) + iu] = (T)uv;
     }
     if (isx) {   // y_ = P dx + p
-      const T* Pk = a.P + (int64_t)b * a.P_bs + (int64_t)k * n * n;
+      const T* Pk = a.P + (int64_t)b * a.P_bs + GOFF(G_P, k);
       double s = 0.0;
       for (int j = 0; j < n; ++j) s += (double)Pk[i + j * n] * dxs[j];
-      a.y[(int64_t)b * a.y_bs + (int64_t)k * n + i] = (T)(s + (double)a.p[(int64_t)b * a.p_bs + (int64_t)k * n + i]);
+      a.y[(int64_t)b * a.y_bs + GOFF(G_y, k) + i] = (T)(s + (double)a.p[(int64_t)b * a.p_bs + GOFF(G_p, k) + i]);
     }
     __syncthreads();
     if (al) {   // the constraint rows' cost shares at the candidate point; (J^T z_proj) for the gradient below
@@ -297,61 +303,66 @@ __global__ __launch_bounds__(64) void generic_merit_kernel(IlqrGenArgs<T> a) {
       J += Jal;
       __syncthreads();
     }
-    const T* Qk = a.cQ + ((int64_t)b * (N + 1) + k) * n * n;
-    const T* Rk = a.cR + ((int64_t)b * N + k) * m * m;
-    const T* Hk = a.cH + ((int64_t)b * N + k) * m * n;
-    double xn = 0.0, dxn = 0.0;
-    if (isx) {   // state row: cost share, lx, next state
+    const T* Qk = a.cQ + (int64_t)b * a.sQ + GOFF(G_Q, k);
+    const T* Rk = a.cR + (int64_t)b * a.sR + GOFF(G_R, k);
+    const T* Hk = a.cH + (int64_t)b * a.sH + GOFF(G_H, k);
+    if (isx) {   // state row: cost share, lx
       double qx = 0.0, htu = 0.0;
       for (int j = 0; j < n; ++j) qx += (double)Qk[i + j * n] * xs[j];
       for (int j = 0; j < m; ++j) htu += (double)Hk[j + i * m] * us[j];
-      const double ql = (double)a.cq[((int64_t)b * (N + 1) + k) * n + i];
+      const double ql = (double)a.cq[(int64_t)b * a.sx + GOFF(G_q, k) + i];
       J += x * (0.5 * qx + ql);
       if (lane == 0) J += (double)a.cc[(int64_t)b * (N + 1) + k];
       double lx = (qx + htu) + ql;
       if (al && deriv) lx -= gen_al_col<T>(a.al, k, i, jv);
-      if (deriv) { dJ += lx * dxda; a.q[(int64_t)b * a.q_bs + (int64_t)k * n + i] = (T)lx; }
-      const T* Ak = a.A + (int64_t)b * a.A_bs + (int64_t)k * n * n;
-      const T* Bk = a.B + (int64_t)b * a.B_bs + (int64_t)k * n * m;
+      if (deriv) { dJ += lx * dxda; a.q[(int64_t)b * a.q_bs + GOFF(G_q, k) + i] = (T)lx; }
+    }
+    double xn = 0.0, dxn = 0.0;
+    if (lane < n2) {   // row of the next state: A_k is n2 x n, B_k n2 x m
+      const T* Ak = a.A + (int64_t)b * a.A_bs + GOFF(G_A, k);
+      const T* Bk = a.B + (int64_t)b * a.B_bs + GOFF(G_B, k);
       double s = 0.0, s2 = 0.0, t = 0.0, t2 = 0.0;
-      for (int j = 0; j < n; ++j) { const double aj = (double)Ak[i + j * n]; s += aj * xs[j]; t += aj * das[j]; }
-      for (int j = 0; j < m; ++j) { const double bj = (double)Bk[i + j * n]; s2 += bj * us[j]; t2 += bj * dus[j]; }
-      xn = (s + s2) + (double)a.f[(int64_t)b * a.f_bs + (int64_t)k * n + i];
+      for (int j = 0; j < n; ++j) { const double aj = (double)Ak[lane + j * n2]; s += aj * xs[j]; t += aj * das[j]; }
+      for (int j = 0; j < m; ++j) { const double bj = (double)Bk[lane + j * n2]; s2 += bj * us[j]; t2 += bj * dus[j]; }
+      xn = (s + s2) + (double)a.f[(int64_t)b * a.f_bs + GOFF(G_f, k) + lane];
       dxn = t + t2;
     }
     if (isu) {   // input row: cost share (with the cross term u'Hx), lu
       double ru = 0.0, hx = 0.0;
       for (int j = 0; j < m; ++j) ru += (double)Rk[iu + j * m] * us[j];
       for (int j = 0; j < n; ++j) hx += (double)Hk[iu + j * m] * xs[j];
-      const double rl = (double)a.cr[((int64_t)b * N + k) * m + iu];
+      const double rl = (double)a.cr[(int64_t)b * a.su + GOFF(G_r, k) + iu];
       const double uv = us[iu];
       J += uv * ((0.5 * ru + rl) + hx);
       double lu = (ru + hx) + rl;
       if (al && deriv) lu -= gen_al_col<T>(a.al, k, n + iu, jv);
-      if (deriv) { dJ += lu * dus[iu]; a.r[(int64_t)b * a.r_bs + (int64_t)k * m + iu] = (T)lu; }
+      if (deriv) { dJ += lu * dus[iu]; a.r[(int64_t)b * a.r_bs + GOFF(G_r, k) + iu] = (T)lu; }
     }
-    if (isx) { x = xn; dxda = dxn; }
+    x = xn; dxda = dxn;                                  // (lanes past n2 carry zeros)
   }
   __syncthreads();
   {   // terminal knot point (solver.cpp:319-332)
-    if (isx) { xs[lane] = x; dxs[lane] = x - (double)a.xn[((int64_t)b * (N + 1) + N) * n + lane]; a.x[(int64_t)b * a.x_bs + (int64_t)N * n + lane] = (T)x; }
+    const int n = a.nx[N];
+    const bool isx = lane < n;
+    const int i = isx ? lane : 0;
+    if (isx) { xs[lane] = x; dxs[lane] = x - (double)a.xn[(int64_t)b * a.sx + GOFF(G_x, N) + lane]; a.x[(int64_t)b * a.x_bs + GOFF(G_x, N) + lane] = (T)x; }
     __syncthreads();
     if (al) {
-      gen_al_rows<T>(a.al, N, b, a.batch, n, m, xs, us, true, rho, lane, jv, nullptr, nullptr, nullptr, J, viol, false);
+      gen_al_rows<T>(a.al, N, b, a.batch, n, 0, xs, us, true, rho, lane, jv, nullptr, nullptr, nullptr, J, viol, false);
       __syncthreads();
     }
     if (isx) {
-      const T* Qk = a.cQ + ((int64_t)b * (N + 1) + N) * n * n;
-      const T* Pk = a.P + (int64_t)b * a.P_bs + (int64_t)N * n * n;
+      const T* Qk = a.cQ + (int64_t)b * a.sQ + GOFF(G_Q, N);
+      const T* Pk = a.P + (int64_t)b * a.P_bs + GOFF(G_P, N);
       double qx = 0.0, s = 0.0;
       for (int j = 0; j < n; ++j) { qx += (double)Qk[i + j * n] * xs[j]; s += (double)Pk[i + j * n] * dxs[j]; }
-      const double ql = (double)a.cq[((int64_t)b * (N + 1) + N) * n + i];
+      const double ql = (double)a.cq[(int64_t)b * a.sx + GOFF(G_q, N) + i];
       J += x * (0.5 * qx + ql);
       if (lane == 0) J += (double)a.cc[(int64_t)b * (N + 1) + N];
-      a.y[(int64_t)b * a.y_bs + (int64_t)N * n + i] = (T)(s + (double)a.p[(int64_t)b * a.p_bs + (int64_t)N * n + i]);
+      a.y[(int64_t)b * a.y_bs + GOFF(G_y, N) + i] = (T)(s + (double)a.p[(int64_t)b * a.p_bs + GOFF(G_p, N) + i]);
       double lx = qx + ql;
       if (al && deriv) lx -= gen_al_col<T>(a.al, N, i, jv);
-      if (deriv) { dJ += lx * dxda; a.q[(int64_t)b * a.q_bs + (int64_t)N * n + i] = (T)lx; }
+      if (deriv) { dJ += lx * dxda; a.q[(int64_t)b * a.q_bs + GOFF(G_q, N) + i] = (T)lx; }
     }
   }
   const double phi = gen_wave_sum(J), dphi = gen_wave_sum(dJ);
@@ -368,36 +379,38 @@ __global__ __launch_bounds__(64) void generic_stationarity_kernel(IlqrGenArgs<T>
   __shared__ double yn[GEN_MAX];
   const int b = blockIdx.x, lane = threadIdx.x;
   if (a.active && !a.active[b]) return;
-  const int n = a.n, m = a.m, N = a.N;
-  const bool isx = lane < n, isu = lane >= 32 && lane - 32 < m;
-  const int j = isx ? lane : (isu ? lane - 32 : 0);
+  const int N = a.N;
   double res = 0.0;
   for (int k = 0; k < N; ++k) {
+    const int n = a.nx[k], m = a.nu[k], n2 = a.nx[k + 1];
+    const bool isx = lane < n, isu = lane >= 32 && lane - 32 < m;
+    const int j = isx ? lane : (isu ? lane - 32 : 0);
     __syncthreads();
-    if (lane < n) yn[lane] = (double)a.y[(int64_t)b * a.y_bs + (int64_t)(k + 1) * n + lane];
+    if (lane < n2) yn[lane] = (double)a.y[(int64_t)b * a.y_bs + GOFF(G_y, k + 1) + lane];
     __syncthreads();
     if (isx) {
-      const T* Ak = a.A + (int64_t)b * a.A_bs + (int64_t)k * n * n;
+      const T* Ak = a.A + (int64_t)b * a.A_bs + GOFF(G_A, k);
       double s = 0.0;
-      for (int i = 0; i < n; ++i) s += (double)Ak[i + j * n] * yn[i];
-      res = fmax(res, fabs(((double)a.q[(int64_t)b * a.q_bs + (int64_t)k * n + j] + s) - (double)a.y[(int64_t)b * a.y_bs + (int64_t)k * n + j]));
+      for (int i = 0; i < n2; ++i) s += (double)Ak[i + j * n2] * yn[i];
+      res = fmax(res, fabs(((double)a.q[(int64_t)b * a.q_bs + GOFF(G_q, k) + j] + s) - (double)a.y[(int64_t)b * a.y_bs + GOFF(G_y, k) + j]));
     } else if (isu) {
-      const T* Bk = a.B + (int64_t)b * a.B_bs + (int64_t)k * n * m;
+      const T* Bk = a.B + (int64_t)b * a.B_bs + GOFF(G_B, k);
       double s = 0.0;
-      for (int i = 0; i < n; ++i) s += (double)Bk[i + j * n] * yn[i];
-      res = fmax(res, fabs((double)a.r[(int64_t)b * a.r_bs + (int64_t)k * m + j] + s));
+      for (int i = 0; i < n2; ++i) s += (double)Bk[i + j * n2] * yn[i];
+      res = fmax(res, fabs((double)a.r[(int64_t)b * a.r_bs + GOFF(G_r, k) + j] + s));
     }
   }
-  if (isx) res = fmax(res, fabs((double)a.q[(int64_t)b * a.q_bs + (int64_t)N * n + j] - (double)a.y[(int64_t)b * a.y_bs + (int64_t)N * n + j]));
+  if (lane < a.nx[N]) res = fmax(res, fabs((double)a.q[(int64_t)b * a.q_bs + GOFF(G_q, N) + lane] - (double)a.y[(int64_t)b * a.y_bs + GOFF(G_y, N) + lane]));
   res = gen_wave_max(res);
   double viol = 0.0;   // Feasibility (solver.cpp:224-231) of the candidate trajectory
   if (a.al.enabled) {
     __shared__ double xs[GEN_MAX], us[GEN_MAX], jv[GEN_AL_JV];
     const double rho = a.prob[b].rho;
     for (int k = 0; k <= N; ++k) {
+      const int n = a.nx[k], m = k < N ? a.nu[k] : 0;
       __syncthreads();
-      if (lane < n) xs[lane] = (double)a.x[(int64_t)b * a.x_bs + (int64_t)k * n + lane];
-      if (lane >= 32 && lane - 32 < m) us[lane - 32] = k < N ? (double)a.u[(int64_t)b * a.u_bs + (int64_t)k * m + lane - 32] : 0.0;
+      if (lane < n) xs[lane] = (double)a.x[(int64_t)b * a.x_bs + GOFF(G_x, k) + lane];
+      if (lane >= 32 && lane - 32 < m) us[lane - 32] = (double)a.u[(int64_t)b * a.u_bs + GOFF(G_u, k) + lane - 32];
       __syncthreads();
       double cost = 0.0;
       gen_al_rows<T>(a.al, k, b, a.batch, n, m, xs, us, k == N, rho, lane, jv, nullptr, nullptr, nullptr, cost, viol, false);
@@ -416,45 +429,46 @@ __global__ __launch_bounds__(64) void generic_expand_al_kernel(IlqrGenArgs<T> a)
   const int lane = threadIdx.x;
   const int64_t wk = blockIdx.x;
   const int b = (int)(wk % a.batch), k = (int)(wk / a.batch);
-  const int n = a.n, m = a.m, N = a.N, w = n + m;
+  const int N = a.N;
   if (k > N) return;
   if (a.active && !a.active[b]) return;
   const bool terminal = k == N;
+  const int n = a.nx[k], m = terminal ? 0 : a.nu[k], w = n + m;
   const bool grad = (a.mode & EXPAND_GRADIENT) != 0, hess = (a.mode & EXPAND_HESSIAN) != 0;
-  if (lane < n) xs[lane] = (double)a.x[(int64_t)b * a.x_bs + (int64_t)k * n + lane];
-  if (lane >= 32 && lane - 32 < m) us[lane - 32] = terminal ? 0.0 : (double)a.u[(int64_t)b * a.u_bs + (int64_t)k * m + lane - 32];
+  if (lane < n) xs[lane] = (double)a.x[(int64_t)b * a.x_bs + GOFF(G_x, k) + lane];
+  if (lane >= 32 && lane - 32 < m) us[lane - 32] = (double)a.u[(int64_t)b * a.u_bs + GOFF(G_u, k) + lane - 32];
   __syncthreads();
   {
     double cost = 0.0, viol = 0.0;
     gen_al_rows<T>(a.al, k, b, a.batch, n, m, xs, us, terminal, a.prob[b].rho_est, lane, jv, jd, Jm, Hm, cost, viol, false);
   }
   __syncthreads();
-  const T* Qk = a.cQ + ((int64_t)b * (N + 1) + k) * n * n;
-  const T* Rk = terminal ? nullptr : a.cR + ((int64_t)b * N + k) * m * m;
-  const T* Hk = terminal ? nullptr : a.cH + ((int64_t)b * N + k) * m * n;
+  const T* Qk = a.cQ + (int64_t)b * a.sQ + GOFF(G_Q, k);
+  const T* Rk = terminal ? nullptr : a.cR + (int64_t)b * a.sR + GOFF(G_R, k);
+  const T* Hk = terminal ? nullptr : a.cH + (int64_t)b * a.sH + GOFF(G_H, k);
   if (grad) {
     if (lane < n) {
       const int e = lane;
       double s = 0.0;
       for (int j = 0; j < n; ++j) s += (double)Qk[e + j * n] * xs[j];
-      s += (double)a.cq[((int64_t)b * (N + 1) + k) * n + e];
+      s += (double)a.cq[(int64_t)b * a.sx + GOFF(G_q, k) + e];
       if (!terminal) {
         double t2 = 0.0;
         for (int i = 0; i < m; ++i) t2 += (double)Hk[i + e * m] * us[i];
         s += t2;
       }
       s -= gen_al_col<T>(a.al, k, e, jv);
-      a.q[(int64_t)b * a.q_bs + (int64_t)k * n + e] = (T)s;
+      a.q[(int64_t)b * a.q_bs + GOFF(G_q, k) + e] = (T)s;
     } else if (!terminal && lane >= 32 && lane - 32 < m) {
       const int i = lane - 32;
       double s = 0.0;
       for (int j = 0; j < m; ++j) s += (double)Rk[i + j * m] * us[j];
-      s += (double)a.cr[((int64_t)b * N + k) * m + i];
+      s += (double)a.cr[(int64_t)b * a.su + GOFF(G_r, k) + i];
       double t2 = 0.0;
       for (int j = 0; j < n; ++j) t2 += (double)Hk[i + j * m] * xs[j];
       s += t2;
       s -= gen_al_col<T>(a.al, k, n + i, jv);
-      a.r[(int64_t)b * a.r_bs + (int64_t)k * m + i] = (T)s;
+      a.r[(int64_t)b * a.r_bs + GOFF(G_r, k) + i] = (T)s;
     }
   }
   if (hess) {
@@ -491,9 +505,9 @@ __global__ __launch_bounds__(64) void generic_expand_al_kernel(IlqrGenArgs<T> a)
         }
       }
       v += rho * s;
-      if (r < n) a.Q[(int64_t)b * a.Q_bs + (int64_t)k * n * n + r + cc * n] = (T)v;
-      else if (cc < n) a.H[(int64_t)b * a.H_bs + (int64_t)k * m * n + (r - n) + cc * m] = (T)v;
-      else a.R[(int64_t)b * a.R_bs + (int64_t)k * m * m + (r - n) + (cc - n) * m] = (T)v;
+      if (r < n) a.Q[(int64_t)b * a.Q_bs + GOFF(G_Q, k) + r + cc * n] = (T)v;
+      else if (cc < n) a.H[(int64_t)b * a.H_bs + GOFF(G_H, k) + (r - n) + cc * m] = (T)v;
+      else a.R[(int64_t)b * a.R_bs + GOFF(G_R, k) + (r - n) + (cc - n) * m] = (T)v;
     }
   }
 }
@@ -505,12 +519,13 @@ __global__ __launch_bounds__(64) void generic_dual_update_kernel(IlqrGenArgs<T> 
   const int lane = threadIdx.x;
   const int64_t wk = blockIdx.x;
   const int b = (int)(wk % a.batch), k = (int)(wk / a.batch);
-  const int n = a.n, m = a.m, N = a.N;
+  const int N = a.N;
   if (k > N || !a.al.enabled) return;
   if (!a.prob[b].dual) return;
   const bool terminal = k == N;
-  if (lane < n) xs[lane] = (double)a.x[(int64_t)b * a.x_bs + (int64_t)k * n + lane];
-  if (lane >= 32 && lane - 32 < m) us[lane - 32] = terminal ? 0.0 : (double)a.u[(int64_t)b * a.u_bs + (int64_t)k * m + lane - 32];
+  const int n = a.nx[k], m = terminal ? 0 : a.nu[k];
+  if (lane < n) xs[lane] = (double)a.x[(int64_t)b * a.x_bs + GOFF(G_x, k) + lane];
+  if (lane >= 32 && lane - 32 < m) us[lane - 32] = (double)a.u[(int64_t)b * a.u_bs + GOFF(G_u, k) + lane - 32];
   __syncthreads();
   double cost = 0.0, viol = 0.0;
   gen_al_rows<T>(a.al, k, b, a.batch, n, m, xs, us, terminal, a.prob[b].rho_est, lane, jv, nullptr, nullptr, nullptr, cost, viol, true);
@@ -533,6 +548,8 @@ __global__ void generic_shift_kernel(IlqrGenArgs<T> a) {
     }
   }
 }
+
+#undef GOFF
 
 template <typename T>
 int ilqr_generic_launch(hipStream_t stream, int which, const IlqrGenArgs<T>& a);   // ilqr_launch_generic.hip

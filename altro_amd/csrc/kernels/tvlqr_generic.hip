@@ -17,6 +17,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "generic_arrays.h"
+
 namespace altro_hip {
 
 // Bit-parity with the CPU oracle: no a*b+c -> fma fusion anywhere in this file.
@@ -25,14 +27,7 @@ ALTRO_FP_REGION_OFF
 constexpr size_t kGenericLdsLimit = 64 * 1024;   // dynamic LDS a launch gets without asking for more; beyond it plan GENERIC works in global memory
 constexpr int kGenericMaxDim = 256;              // n, m accepted by plan GENERIC (a bound on the work blocks, not of the algorithm)
 
-enum GArr {
-  G_A = 0, G_B, G_f, G_Q, G_R, G_H, G_q, G_r,      // inputs
-  G_K, G_d, G_P, G_p,                              // outputs
-  G_Qxx, G_Quu, G_Qux, G_Qx, G_Qu,                 // optional outputs
-  G_Qxx_tmp, G_Quu_tmp, G_Qux_tmp, G_Qx_tmp, G_Qu_tmp,  // the reference's scratch blocks (store_q == 2)
-  G_x, G_u, G_y,                                   // forward outputs
-  G_NUM
-};
+// (enum GArr: kernels/generic_arrays.h)
 
 template <typename T>
 struct GenericArgs {

@@ -135,10 +135,17 @@ int altro_hip_batch_create(altro_hip_batch** out, int horizon_N, int n, int m, i
                            int dtype, int plan, unsigned flags, int device, void* stream);
 /* The same with PER-KNOT-POINT dimensions nx[0..N], nu[0..N-1] (ALTROSolver::SetDimension per range, altro_solver.cpp:26-47; the
  * kernel boundary takes nx[k], nu[k] throughout, tvlqr.cpp:65-248: A_k is nx[k+1] x nx[k], B_k nx[k+1] x nu[k], K_k nu[k] x nx[k]).
- * Plan GENERIC, every dimension in [1, 32].  Such a handle serves the TVLQR sweeps -- altro_hip_set_dynamics / _set_cost /
- * _set_initial_state, altro_hip_backward / _forward_ltv / _sweep, the getters, the statistics -- with every bulk array packed
- * [b][k][block_k] (block_k column-major with knot point k's own dimensions: the reference's per-knot-point blocks end to end);
- * k_stride_zero is refused, batch_stride_zero works; the iLQR-loop calls need uniform dimensions and say so.                     */
+ * Plan GENERIC.  Such a handle serves
+ *   - the TVLQR sweeps (every dimension in [1, 256]): altro_hip_set_dynamics / _set_cost / _set_initial_state, altro_hip_backward /
+ *     _forward_ltv / _sweep, the getters, the statistics;
+ *   - the iLQR loop (every dimension in [1, 32]): altro_hip_set_quadratic_cost, _set_input_guess, _set_state_guess,
+ *     _add_linear_constraint (G is p x (nx[k] + nu[k]); the knot points of one block must share their dimensions -- register it per
+ *     range, like ALTROSolver::SetConstraint per index), altro_hip_open_loop_rollout / _merit / _expand / _accept / _stationarity,
+ *     altro_hip_ilqr_solve, altro_hip_get_nominal / _get_knot (x: nx[k], u: nu[k] entries);
+ * with every bulk array packed [b][k][block_k] (block_k column-major with knot point k's own dimensions: the reference's per-knot-
+ * point blocks end to end; c is [b][N + 1]).  k_stride_zero is refused, batch_stride_zero works.  The calls whose arguments or
+ * meaning need ONE dimension say so: altro_hip_set_tracking_cost (give the dense blocks), _update_linear_costs, _shift_trajectory,
+ * the device models.                                                                                                              */
 int altro_hip_batch_create_dims(altro_hip_batch** out, int horizon_N, const int* nx, const int* nu, int batch, int dtype,
                                 unsigned flags, int device, void* stream);
 void altro_hip_batch_destroy(altro_hip_batch* h);
