@@ -965,7 +965,7 @@ int altro_hip_add_linear_constraint(altro_hip_batch* h, int k_first, int k_last,
                   gen ? "" : ": ALTRO_HIP_PLAN_GENERIC takes 8");
   int w = h->n + h->m;
   if (h->ragged) {   // G is p x (nx[k] + nu[k]): every knot point of the range must have the dimensions of the first (the terminal one: its nx)
-    const int nk = h->nxv[k_first], mk = k_first < h->N ? h->nuv[k_first] : h->m;
+    const int nk = h->nxv[k_first], mk = k_first < h->N ? h->nuv[k_first] : 0;   // (a block of the terminal knot point alone: p x nx[N])
     for (int k = k_first; k <= k_last; ++k)
       if (h->nxv[k] != nk || (k < h->N && h->nuv[k] != mk))
         return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "knot points %d and %d differ in dimension: one constraint block takes one [x; u] size "

@@ -139,8 +139,8 @@ int altro_hip_batch_create(altro_hip_batch** out, int horizon_N, int n, int m, i
  *   - the TVLQR sweeps (every dimension in [1, 256]): altro_hip_set_dynamics / _set_cost / _set_initial_state, altro_hip_backward /
  *     _forward_ltv / _sweep, the getters, the statistics;
  *   - the iLQR loop (every dimension in [1, 32]): altro_hip_set_quadratic_cost, _set_input_guess, _set_state_guess,
- *     _add_linear_constraint (G is p x (nx[k] + nu[k]); the knot points of one block must share their dimensions -- register it per
- *     range, like ALTROSolver::SetConstraint per index), altro_hip_open_loop_rollout / _merit / _expand / _accept / _stationarity,
+ *     _add_linear_constraint (G is p x (nx[k] + nu[k]), p x nx[N] for a block of the terminal knot point alone; the knot points of
+ *     one block must share their dimensions -- register it per range, like ALTROSolver::SetConstraint per index), altro_hip_open_loop_rollout / _merit / _expand / _accept / _stationarity,
  *     altro_hip_ilqr_solve, altro_hip_get_nominal / _get_knot (x: nx[k], u: nu[k] entries);
  * with every bulk array packed [b][k][block_k] (block_k column-major with knot point k's own dimensions: the reference's per-knot-
  * point blocks end to end; c is [b][N + 1]).  k_stride_zero is refused, batch_stride_zero works.  The calls whose arguments or

@@ -9,11 +9,15 @@ point padded to (max nx, max nu) with states that stay at zero (zero rows / colu
 function, hence the same line-search decisions; the padded entries of its iterates are zero.  Tolerances: merit phi 1e-11, phi'
 1e-9, candidate trajectories 1e-10 (sums reduced over the wave on the device), whole solves: same status and iterations,
 trajectories 1e-8."""
+import os
+import tempfile
+
 import numpy as np
 import pytest
 
 import altro_amd
 from oracle import oracle
+from tests import cpp_build
 from tests import problems
 
 pytestmark = pytest.mark.gpu
@@ -64,7 +68,7 @@ def make_hip(p, batch, bounds):
     bt.set_initial_state(p["x0"])
     bt.set_input_guess(packed(p["u0"]))
     for (k0, k1, G, g) in bounds:
-        bt.add_linear_constraint(k0, k1, altro_amd.CONE_INEQUALITY, G, g)
+        bt.add_linear_constraint(k0, k1, altro_amd.CONE_EQUALITY if k0 == N else altro_amd.CONE_INEQUALITY, G, g)
     return bt
 
 
@@ -92,9 +96,9 @@ def make_oracle(p, b, bounds):
     s.L.oracle_ilqr_set_initial_state(s.h, np.ascontiguousarray(x0))
     for (k0, k1, G, g) in bounds:
         for k in range(k0, k1 + 1):
-            n, m = NX[k], NU[k]
+            n, m = NX[k], (NU[k] if k < N else 0)
             Gp = np.zeros((G.shape[0], NMAX + MMAX)); Gp[:, :n] = G[:, :n]; Gp[:, NMAX:NMAX + m] = G[:, n:n + m]
-            s.add_linear_constraint(k, oracle.CONE_INEQUALITY, Gp, g)
+            s.add_linear_constraint(k, oracle.CONE_EQUALITY if k == N else oracle.CONE_INEQUALITY, Gp, g)
     s.L.oracle_ilqr_initialize(s.h)
     for k in range(N):
         u = np.zeros(MMAX); u[:NU[k]] = p["u0"][k][b]
@@ -125,6 +129,12 @@ def input_bounds():
     G = np.zeros((1, 4 + 1)); G[0, 4] = 1.0
     out.append((7, 7, G, np.array([0.1])))
     return out
+
+
+def terminal_pin():
+    """x_N[0] = 0.3, x_N[2] = -0.2: an EQUALITY block of the terminal knot point alone (G is p x nx[N])."""
+    G = np.zeros((2, NX[N])); G[0, 0] = 1.0; G[1, 2] = 1.0
+    return (N, N, G, np.array([0.3, -0.2]))
 
 
 def test_merit_and_stationarity_with_varying_dimensions():
@@ -159,7 +169,7 @@ def test_merit_and_stationarity_with_varying_dimensions():
 def test_whole_solves_with_varying_dimensions(constrained):
     batch = 9
     p = make_problem(batch, seed=977)
-    bounds = input_bounds() if constrained else []
+    bounds = input_bounds() + [terminal_pin()] if constrained else []
     bt = make_hip(p, batch, bounds)
     res = bt.ilqr_solve(iterations_max=60, tol_stationarity=1e-4, penalty_initial=1.0, penalty_scaling=10.0)
     assert (res["status"] == 0).all(), res["status"]
@@ -171,6 +181,8 @@ def test_whole_solves_with_varying_dimensions(constrained):
         for k in range(2, 6):
             assert np.abs(u[:, off_u[k]:off_u[k + 1]]).max() <= 0.25 + 1e-4
         assert (res["iterations"] > 2).all()          # the bounds bind: more than the LQ problem's sweeps
+        off_x = np.concatenate([[0], np.cumsum(NX)])
+        assert np.abs(x[:, off_x[N] + 0] - 0.3).max() < 1e-4 and np.abs(x[:, off_x[N] + 2] + 0.2).max() < 1e-4
     else:
         assert (res["iterations"] <= 3).all()
     for b in (0, 4, 8):
@@ -184,6 +196,48 @@ def test_whole_solves_with_varying_dimensions(constrained):
         np.testing.assert_allclose(u[b], unpad_u(s.get("u")), rtol=1e-7, atol=1e-7)
         off_x = np.concatenate([[0], np.cumsum(NX)])
         np.testing.assert_allclose(x3[b], x[b, off_x[3]:off_x[4]], rtol=0, atol=0)
+
+
+def test_cpp_altro_solver_with_varying_dimensions():
+    """The same problem through the C++ ALTROSolver (include/altro/altro.hpp): SetDimension / SetExplicitDynamics / SetQuadraticCost per
+    knot point, host callbacks, every backward sweep through tvlqr_BackwardPass with per-knot-point nx, nu on the GPU.  Against the
+    batched ABI on the same problem (1e-9: both run plan GENERIC's sweep, the host loop sums in index order, the device loop over the
+    wave) and the oracle on the padded one."""
+    batch = 3
+    p = make_problem(batch, seed=977)
+    b = 1
+    col = lambda M: " ".join(repr(float(v)) for v in np.asarray(M).T.reshape(-1))     # column-major
+    vec = lambda v: " ".join(repr(float(x)) for x in np.asarray(v).reshape(-1))
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "problem.txt")
+        with open(path, "w") as f:
+            f.write("%d\n%s\n%s\n" % (N, " ".join(map(str, NX)), " ".join(map(str, NU))))
+            for k in range(N):
+                f.write("\n".join([col(p["A"][k][b]), col(p["B"][k][b]), vec(p["f"][k][b]), col(p["R"][k][b]), col(p["H"][k][b]),
+                                   vec(p["r"][k][b])]) + "\n")
+            for k in range(N + 1):
+                f.write("%s\n%s\n%r\n" % (col(p["Q"][k][b]), vec(p["q"][k][b]), float(p["c"][b, k])))
+            f.write(vec(p["x0"][b]) + "\n")
+            for k in range(N):
+                f.write(vec(p["u0"][k][b]) + "\n")
+        rc, out, err = cpp_build.run("altro_varying_dims_test", args=[path], timeout=300)
+    assert rc == 0 and out.strip().endswith("OK"), out[-1500:] + err[-1500:]
+    lines = out.splitlines()
+    head = [l for l in lines if l.startswith("status ")][0].split()
+    status, iters = int(head[1]), int(head[3])
+    xs = np.array([float(v) for v in [l for l in lines if l.startswith("x ")][0].split()[1:]])
+    us = np.array([float(v) for v in [l for l in lines if l.startswith("u ")][0].split()[1:]])
+    bt = make_hip(p, batch, [])
+    res = bt.ilqr_solve(iterations_max=60, tol_stationarity=1e-4)
+    x, u = bt.get_nominal()
+    assert status == 0 and res["status"][b] == 0 and iters == res["iterations"][b]
+    np.testing.assert_allclose(xs, x[b], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(us, u[b], rtol=1e-8, atol=1e-8)
+    s = make_oracle(p, b, [])
+    s.L.oracle_ilqr_set_options(s.h, 60, 1e-4, 1e-4, 1e-8, 0)
+    ostatus, oiters, _ = s.solve()
+    assert ostatus == 0 and oiters == iters
+    np.testing.assert_allclose(xs, unpad_x(s.get("x")), rtol=1e-8, atol=1e-8)
 
 
 def test_calls_that_need_one_dimension_say_so():
