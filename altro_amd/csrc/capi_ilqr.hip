@@ -280,7 +280,7 @@ GenSizes gen_sizes(const altro_hip_batch* h) {
   }
   return z;
 }
-// plan GENERIC: any (n_k, m_k) up to 32, dynamics as data, quadratic cost, linear constraint blocks (kernels/ilqr_generic.hip)
+// plan GENERIC: any (n_k, m_k) up to 64, dynamics as data, quadratic cost, linear constraint blocks (kernels/ilqr_generic.hip)
 template <typename T>
 int gen_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int want_deriv, double alpha_const, int mode) {
   const int n = h->n, m = h->m, N = h->N;
@@ -407,10 +407,10 @@ int ilqr_check(altro_hip_batch* h, bool need_guess) {
   if (h->plan == ALTRO_HIP_PLAN_MFMA16) {   // dynamics are data (altro_hip_set_dynamics) or a device model of the tile plan
     if (!h->dyn_set && !h->model_set)
       return fail(ALTRO_HIP_ERR_NOT_SET, "neither altro_hip_set_dynamics nor altro_hip_set_model has been called");
-  } else if (h->plan == ALTRO_HIP_PLAN_GENERIC) {   // any (n, m) up to 32: dynamics as data, a quadratic cost
-    if (h->n > 32 || h->m > 32)
+  } else if (h->plan == ALTRO_HIP_PLAN_GENERIC) {   // any (n, m) up to 64: dynamics as data, a quadratic cost
+    if (h->n > 64 || h->m > 64)
       return fail(ALTRO_HIP_ERR_UNSUPPORTED, "the iLQR loop of plan GENERIC gives one lane to every state row and one to every input row: "
-                                             "n, m <= 32 (got %d, %d); the TVLQR sweeps (altro_hip_backward / _forward_ltv / _sweep) take any size", h->n, h->m);
+                                             "n, m <= 64 (got %d, %d); the TVLQR sweeps (altro_hip_backward / _forward_ltv / _sweep) take any size", h->n, h->m);
     if (!h->dyn_set) return fail(ALTRO_HIP_ERR_NOT_SET, "altro_hip_set_dynamics has not been called");
   } else if (!h->model_set) {
     return fail(ALTRO_HIP_ERR_NOT_SET, "altro_hip_set_model has not been called (plan LANE runs device models; for dynamics given as "

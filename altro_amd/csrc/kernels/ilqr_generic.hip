@@ -1,4 +1,4 @@
-// ilqr_generic.hip -- the iLQR loop around the TVLQR sweep for plan GENERIC: any (n_k, m_k) up to 32 -- per-knot-point dimensions
+// ilqr_generic.hip -- the iLQR loop around the TVLQR sweep for plan GENERIC: any (n_k, m_k) up to 64 -- per-knot-point dimensions
 // included, like ALTROSolver::SetDimension(n, m, k_start, k_stop) (altro_solver.cpp:26-47): every block is found through the sweep's
 // offset table (generic_arrays.h) and sized by nx[k], nu[k] -- dynamics given as DATA
 // (x+ = A_k x + B_k u + f_k: the reference's SetLinearDynamics path, knotpoint_data.cpp:123-142, :406-419, :710-719) and a
@@ -22,7 +22,10 @@
 
 namespace altro_hip {
 
-constexpr int GEN_MAX = 32;   // n, m <= 32: lanes 0..31 own state rows, lanes 32..63 input rows
+constexpr int GEN_MAX = 64;   // n, m <= 64: one lane per state row, one per input row
+// Which lanes own the input rows: lanes 32.. while every dimension is <= 32 (state rows in lanes 0..31: the two kinds of row run side
+// by side), lanes 0.. beyond (a lane then owns a state row AND an input row and does one after the other).
+#define GEN_UBASE(a) (((a).n <= 32 && (a).m <= 32) ? 32 : 0)
 
 template <typename T>
 struct IlqrGenArgs {
@@ -273,8 +276,9 @@ __global__ __launch_bounds__(64) void generic_merit_kernel(IlqrGenArgs<T> a) {
   double J = 0.0, dJ = 0.0;
   for (int k = 0; k < N; ++k) {
     const int n = a.nx[k], m = a.nu[k], n2 = a.nx[k + 1];
-    const bool isx = lane < n, isu = lane >= 32 && lane - 32 < m;
-    const int i = isx ? lane : 0, iu = isu ? lane - 32 : 0;
+    const int ub = GEN_UBASE(a);
+    const bool isx = lane < n, isu = lane >= ub && lane - ub < m;
+    const int i = isx ? lane : 0, iu = isu ? lane - ub : 0;
     __syncthreads();
     if (isx) {
       xs[lane] = x; dxs[lane] = x - (double)a.xn[(int64_t)b * a.sx + GOFF(G_x, k) + lane]; das[lane] = dxda;
@@ -383,8 +387,9 @@ __global__ __launch_bounds__(64) void generic_stationarity_kernel(IlqrGenArgs<T>
   double res = 0.0;
   for (int k = 0; k < N; ++k) {
     const int n = a.nx[k], m = a.nu[k], n2 = a.nx[k + 1];
-    const bool isx = lane < n, isu = lane >= 32 && lane - 32 < m;
-    const int j = isx ? lane : (isu ? lane - 32 : 0);
+    const int ub = GEN_UBASE(a);
+    const bool isx = lane < n, isu = lane >= ub && lane - ub < m;
+    const int j = lane, ju = isu ? lane - ub : 0;
     __syncthreads();
     if (lane < n2) yn[lane] = (double)a.y[(int64_t)b * a.y_bs + GOFF(G_y, k + 1) + lane];
     __syncthreads();
@@ -393,11 +398,12 @@ __global__ __launch_bounds__(64) void generic_stationarity_kernel(IlqrGenArgs<T>
       double s = 0.0;
       for (int i = 0; i < n2; ++i) s += (double)Ak[i + j * n2] * yn[i];
       res = fmax(res, fabs(((double)a.q[(int64_t)b * a.q_bs + GOFF(G_q, k) + j] + s) - (double)a.y[(int64_t)b * a.y_bs + GOFF(G_y, k) + j]));
-    } else if (isu) {
+    }
+    if (isu) {
       const T* Bk = a.B + (int64_t)b * a.B_bs + GOFF(G_B, k);
       double s = 0.0;
-      for (int i = 0; i < n2; ++i) s += (double)Bk[i + j * n2] * yn[i];
-      res = fmax(res, fabs((double)a.r[(int64_t)b * a.r_bs + GOFF(G_r, k) + j] + s));
+      for (int i = 0; i < n2; ++i) s += (double)Bk[i + ju * n2] * yn[i];
+      res = fmax(res, fabs((double)a.r[(int64_t)b * a.r_bs + GOFF(G_r, k) + ju] + s));
     }
   }
   if (lane < a.nx[N]) res = fmax(res, fabs((double)a.q[(int64_t)b * a.q_bs + GOFF(G_q, N) + lane] - (double)a.y[(int64_t)b * a.y_bs + GOFF(G_y, N) + lane]));
@@ -410,7 +416,7 @@ __global__ __launch_bounds__(64) void generic_stationarity_kernel(IlqrGenArgs<T>
       const int n = a.nx[k], m = k < N ? a.nu[k] : 0;
       __syncthreads();
       if (lane < n) xs[lane] = (double)a.x[(int64_t)b * a.x_bs + GOFF(G_x, k) + lane];
-      if (lane >= 32 && lane - 32 < m) us[lane - 32] = (double)a.u[(int64_t)b * a.u_bs + GOFF(G_u, k) + lane - 32];
+      if (lane < m) us[lane] = (double)a.u[(int64_t)b * a.u_bs + GOFF(G_u, k) + lane];
       __syncthreads();
       double cost = 0.0;
       gen_al_rows<T>(a.al, k, b, a.batch, n, m, xs, us, k == N, rho, lane, jv, nullptr, nullptr, nullptr, cost, viol, false);
@@ -436,7 +442,7 @@ __global__ __launch_bounds__(64) void generic_expand_al_kernel(IlqrGenArgs<T> a)
   const int n = a.nx[k], m = terminal ? 0 : a.nu[k], w = n + m;
   const bool grad = (a.mode & EXPAND_GRADIENT) != 0, hess = (a.mode & EXPAND_HESSIAN) != 0;
   if (lane < n) xs[lane] = (double)a.x[(int64_t)b * a.x_bs + GOFF(G_x, k) + lane];
-  if (lane >= 32 && lane - 32 < m) us[lane - 32] = (double)a.u[(int64_t)b * a.u_bs + GOFF(G_u, k) + lane - 32];
+  if (lane < m) us[lane] = (double)a.u[(int64_t)b * a.u_bs + GOFF(G_u, k) + lane];
   __syncthreads();
   {
     double cost = 0.0, viol = 0.0;
@@ -459,8 +465,10 @@ __global__ __launch_bounds__(64) void generic_expand_al_kernel(IlqrGenArgs<T> a)
       }
       s -= gen_al_col<T>(a.al, k, e, jv);
       a.q[(int64_t)b * a.q_bs + GOFF(G_q, k) + e] = (T)s;
-    } else if (!terminal && lane >= 32 && lane - 32 < m) {
-      const int i = lane - 32;
+    }
+    const int ub = GEN_UBASE(a);
+    if (!terminal && lane >= ub && lane - ub < m) {
+      const int i = lane - ub;
       double s = 0.0;
       for (int j = 0; j < m; ++j) s += (double)Rk[i + j * m] * us[j];
       s += (double)a.cr[(int64_t)b * a.su + GOFF(G_r, k) + i];
@@ -525,7 +533,7 @@ __global__ __launch_bounds__(64) void generic_dual_update_kernel(IlqrGenArgs<T> 
   const bool terminal = k == N;
   const int n = a.nx[k], m = terminal ? 0 : a.nu[k];
   if (lane < n) xs[lane] = (double)a.x[(int64_t)b * a.x_bs + GOFF(G_x, k) + lane];
-  if (lane >= 32 && lane - 32 < m) us[lane - 32] = (double)a.u[(int64_t)b * a.u_bs + GOFF(G_u, k) + lane - 32];
+  if (lane < m) us[lane] = (double)a.u[(int64_t)b * a.u_bs + GOFF(G_u, k) + lane];
   __syncthreads();
   double cost = 0.0, viol = 0.0;
   gen_al_rows<T>(a.al, k, b, a.batch, n, m, xs, us, terminal, a.prob[b].rho_est, lane, jv, nullptr, nullptr, nullptr, cost, viol, true);
@@ -550,6 +558,7 @@ __global__ void generic_shift_kernel(IlqrGenArgs<T> a) {
 }
 
 #undef GOFF
+#undef GEN_UBASE
 
 template <typename T>
 int ilqr_generic_launch(hipStream_t stream, int which, const IlqrGenArgs<T>& a);   // ilqr_launch_generic.hip

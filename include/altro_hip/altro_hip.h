@@ -84,12 +84,12 @@ typedef enum altro_hip_error {
  * whole 5 x 5 / 6 x 6 blocks is a long single-wave chain and the zero-padded tile is up to 2.7 x faster -> MFMA16 (such a handle moves
  * to LANE by itself when altro_hip_set_model names a compiled-in model only LANE carries, provided nothing else was set on it yet);
  * other n <= 12, m <= 4 -> MFMA16 (padded); anything larger (<= 256) -> GENERIC (the TVLQR sweep for any size; the iLQR loop for
- * n, m <= 32 with dynamics given as data, a quadratic cost and linear constraint blocks in every cone, kernels/ilqr_generic.hip:
+ * n, m <= 64 with dynamics given as data, a quadratic cost and linear constraint blocks in every cone, kernels/ilqr_generic.hip:
  * correctness first; no device models, no regularisation retry). */
 typedef enum altro_hip_plan {
   ALTRO_HIP_PLAN_AUTO = 0,
   ALTRO_HIP_PLAN_GENERIC = 1, /* wave-per-problem, any (n, m) <= 256: blocks staged in LDS, or (past ~32) worked on in global memory;
-                                 the iLQR loop of this plan: n, m <= 32                            */
+                                 the iLQR loop of this plan: n, m <= 64                            */
   ALTRO_HIP_PLAN_MFMA16 = 2,  /* wave-per-problem, 16x16x4 MFMA tiles: (n, m) = (12, 4), and any n <= 12,
                                  m <= 4 on zero-padded records (same results, the (12, 4) cost)        */
   ALTRO_HIP_PLAN_LANE = 3     /* lane-per-problem, batch structure-of-arrays, n <= 6 and m <= 3         */
@@ -138,7 +138,7 @@ int altro_hip_batch_create(altro_hip_batch** out, int horizon_N, int n, int m, i
  * Plan GENERIC.  Such a handle serves
  *   - the TVLQR sweeps (every dimension in [1, 256]): altro_hip_set_dynamics / _set_cost / _set_initial_state, altro_hip_backward /
  *     _forward_ltv / _sweep, the getters, the statistics;
- *   - the iLQR loop (every dimension in [1, 32]): altro_hip_set_quadratic_cost, _set_input_guess, _set_state_guess,
+ *   - the iLQR loop (every dimension in [1, 64]): altro_hip_set_quadratic_cost, _set_input_guess, _set_state_guess,
  *     _add_linear_constraint (G is p x (nx[k] + nu[k]), p x nx[N] for a block of the terminal knot point alone; the knot points of
  *     one block must share their dimensions -- register it per range, like ALTROSolver::SetConstraint per index), altro_hip_open_loop_rollout / _merit / _expand / _accept / _stationarity,
  *     altro_hip_ilqr_solve, altro_hip_get_nominal / _get_knot (x: nx[k], u: nu[k] entries);
@@ -201,7 +201,7 @@ int altro_hip_get_qblocks(altro_hip_batch* h, double* qblocks);
 
 
 /* ---- the iLQR loop around the sweep ------------------------------------------------------------------
- * Plan GENERIC (n or m beyond the tile, up to 32): dynamics are DATA, tracking or dense quadratic cost, MPC operations; one wave per
+ * Plan GENERIC (n or m beyond the tile, up to 64): dynamics are DATA, tracking or dense quadratic cost, MPC operations; one wave per
  * problem (kernels/ilqr_generic.hip), linear constraint blocks in every cone (round 4).  Device models and the regularisation retry:
  * plans LANE / MFMA16.
  * Plan LANE (n <= 6: BASELINE.json configs[2], [3]): nonlinear dynamics from a compiled-in device model
@@ -284,7 +284,7 @@ int altro_hip_get_expansion(altro_hip_batch* h, double* A, double* B, double* lx
  *   plans LANE, MFMA16 2 blocks per knot point, p <= 8 (SOC: p <= 4), 16 blocks per handle (the blocks ride fixed lanes / registers of
  *                      the fast kernels); rows of one cone can be stacked into one block.
  * Returns the block id (>= 0) or a negative error.  Duals and penalties live on the device per problem and,
- * like the reference's, persist from one solve to the next (warm-started MPC) until reset.  Every plan (GENERIC: n, m <= 32,
+ * like the reference's, persist from one solve to the next (warm-started MPC) until reset.  Every plan (GENERIC: n, m <= 64,
  * one wave per knot point).                                                                              */
 int altro_hip_add_linear_constraint(altro_hip_batch* h, int k_first, int k_last, int cone, int p,
                                     const double* G, const double* g, int g_per_problem);

@@ -1,4 +1,4 @@
-"""The iLQR loop on plan GENERIC (missing #3): shapes beyond the (12, 4) tile -- any n, m up to 32 -- with dynamics
+"""The iLQR loop on plan GENERIC (missing #3): shapes beyond the (12, 4) tile -- any n, m up to 64 -- with dynamics
 given as data and a quadratic cost (tracking or dense), through kernels/ilqr_generic.hip, against the oracle's restatement of
 SolverImpl with ORACLE_DYN_LINEAR.  Correctness-first plan: one wave per problem, sums reduced over the wave -- results agree to
 rounding (merit phi 1e-11, phi' 1e-9, candidates 1e-10; whole LQ solves: same status / iterations, trajectories 1e-9)."""
@@ -49,7 +49,8 @@ def make_oracle(p, b, N, n, m, dense):
     return s
 
 
-@pytest.mark.parametrize("n,m,dense", [(16, 5, False), (16, 5, True), (13, 4, True), (32, 8, False), (12, 6, True)])
+@pytest.mark.parametrize("n,m,dense", [(16, 5, False), (16, 5, True), (13, 4, True), (32, 8, False), (12, 6, True), (48, 12, True),
+                                       (10, 33, True)])
 def test_merit_expansion_stationarity_generic(n, m, dense):
     N, batch = 14, 7
     p, bt = make(batch, N, n, m, dense)
@@ -80,7 +81,8 @@ def test_merit_expansion_stationarity_generic(n, m, dense):
 
 
 @pytest.mark.parametrize("n,m,dense,dtype", [(16, 5, False, altro_amd.F64), (20, 7, True, altro_amd.F64), (32, 8, True, altro_amd.F64),
-                                              (16, 5, True, altro_amd.F32)])
+                                              (16, 5, True, altro_amd.F32), (40, 10, True, altro_amd.F64), (64, 16, False, altro_amd.F64),
+                                              (20, 40, True, altro_amd.F64)])   # (past 32 a lane owns a state row AND an input row)
 def test_whole_lq_solves_generic(n, m, dense, dtype):
     """Whole solves of an LQ problem (alpha = 1, <= 3 sweeps) on plan GENERIC; MPC operations on the resident batch afterwards
     (UpdateLinearCosts, SetInitialState, ShiftTrajectory: bicycle_test.cpp:302-337's pattern) and a second solve."""
@@ -197,15 +199,15 @@ def test_generic_plan_says_what_it_does_not_do():
     bt = altro_amd.Batch(10, 16, 5, 4)
     with pytest.raises(altro_amd.AltroHipError):
         bt.set_model(altro_amd.MODEL_BICYCLE, 0.1)
-    # dimensions past 32: the TVLQR sweeps run (tests/test_gpu_parity.py::test_generic_random), the iLQR loop says why it does not
-    N, n, m, batch = 5, 40, 10, 2
+    # dimensions past 64: the TVLQR sweeps run (tests/test_gpu_parity.py::test_generic_random), the iLQR loop says why it does not
+    N, n, m, batch = 5, 80, 10, 2
     p = problems.ilqr12x4_problem(batch, N, True, n=n, m=m)
     big = altro_amd.Batch(N, n, m, batch)
     assert big.plan == altro_amd.PLAN_GENERIC
     big.set_dynamics(p["A"], p["B"], p["f"])
     big.set_tracking_cost(p["Qd"], p["Rd"], p["xref"], p["uref"])
     big.set_initial_state(p["x0"]); big.set_input_guess(p["u0"])
-    with pytest.raises(altro_amd.AltroHipError, match="n, m <= 32"):
+    with pytest.raises(altro_amd.AltroHipError, match="n, m <= 64"):
         big.ilqr_solve(iterations_max=3)
 
 
