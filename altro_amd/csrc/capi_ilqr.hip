@@ -461,7 +461,7 @@ int altro_hip_set_tracking_cost(altro_hip_batch* h, const double* Qd, const doub
                                 const double* uref, int kz, int bz) {
   // ALTROSolver::SetLQRCost (altro_solver.cpp:138-172): q = -Q xref, r = -R uref,
   // c = 1/2 xref'Q xref (+ 1/2 uref'R uref for k < N) -> KnotPointData::SetDiagonalCost
-  int rc = loop_entry(h);
+  int rc = loop_entry(h, true);
   if (rc) return rc;
   h->expansion_current = false;
   if (h->plan != ALTRO_HIP_PLAN_LANE && h->plan != ALTRO_HIP_PLAN_MFMA16 && h->plan != ALTRO_HIP_PLAN_GENERIC)
@@ -470,6 +470,40 @@ int altro_hip_set_tracking_cost(altro_hip_batch* h, const double* Qd, const doub
   if (h->dev_ptrs)
     return fail(ALTRO_HIP_ERR_UNSUPPORTED, "altro_hip_set_tracking_cost forms q = -Q xref on the host: pass host arrays "
                                            "(altro_hip_set_pointer_mode(h, 0))");
+  if (h->ragged) {   // per-knot-point dimensions: Qd, xref [b][sum nx], Rd, uref [b][sum nu] -> the dense blocks the loop of plan GENERIC evaluates
+    if (kz) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "k_stride_zero needs uniform dimensions");
+    const int N = h->N, nb = bz ? 1 : h->batch;
+    const GenSizes gs = gen_sizes(h);
+    std::vector<double> Q((size_t)nb * gs.sQ, 0.0), R((size_t)nb * gs.sR, 0.0), H((size_t)nb * gs.sH, 0.0), q((size_t)nb * gs.sx),
+        r((size_t)nb * gs.su), c((size_t)nb * (N + 1));
+    for (int b = 0; b < nb; ++b) {
+      int64_t ox = 0, ou = 0, oQ = 0, oR = 0;
+      for (int k = 0; k <= N; ++k) {
+        const int nk = h->nxv[k], mk = k < N ? h->nuv[k] : 0;
+        const double *Q_ = Qd + (size_t)b * gs.sx + ox, *x_ = xref + (size_t)b * gs.sx + ox;
+        double cc = 0.0;
+        for (int i = 0; i < nk; ++i) {
+          Q[(size_t)b * gs.sQ + oQ + i + (size_t)i * nk] = Q_[i];
+          q[(size_t)b * gs.sx + ox + i] = -(Q_[i] * x_[i]);
+          cc += x_[i] * Q_[i] * x_[i];
+        }
+        cc *= 0.5;
+        if (k < N) {
+          const double *R_ = Rd + (size_t)b * gs.su + ou, *u_ = uref + (size_t)b * gs.su + ou;
+          double cu = 0.0;
+          for (int i = 0; i < mk; ++i) {
+            R[(size_t)b * gs.sR + oR + i + (size_t)i * mk] = R_[i];
+            r[(size_t)b * gs.su + ou + i] = -(R_[i] * u_[i]);
+            cu += u_[i] * R_[i] * u_[i];
+          }
+          cc += 0.5 * cu;
+        }
+        c[(size_t)b * (N + 1) + k] = cc;
+        ox += nk; ou += mk; oQ += (int64_t)nk * nk; oR += (int64_t)mk * mk;
+      }
+    }
+    return generic_cost(h, Q.data(), R.data(), H.data(), q.data(), r.data(), c.data(), 0, bz);
+  }
   const int n = h->n, m = h->m, N = h->N;
   const int nb = bz ? 1 : h->batch, nkx = kz ? 2 : N + 1, nku = kz ? 1 : N;
   const int E = 2 * n + 2 * m + 1;
@@ -805,7 +839,7 @@ int altro_hip_update_linear_costs(altro_hip_batch* h, const double* q, const dou
                                   int k_first, int k_last, int kz, int bz) {
   // ALTROSolver::UpdateLinearCosts (altro_solver.cpp:266-281) -> KnotPointData::UpdateLinearCosts
   // (knotpoint_data.cpp:193-226) for knot points k_first..k_last (inclusive) of every problem
-  int rc = loop_entry(h);
+  int rc = loop_entry(h, true);
   if (rc) return rc;
   h->expansion_current = false;
   if (!h->lqr_cost_set) return fail(ALTRO_HIP_ERR_NOT_SET, "no quadratic cost to update (ErrorCodes::CostNotQuadratic)");
@@ -816,6 +850,23 @@ int altro_hip_update_linear_costs(altro_hip_batch* h, const double* q, const dou
     return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "cannot update linear input costs at the terminal knot point "
                                             "(ErrorCodes::InvalidOptAtTerminalKnotPoint)");
   const int nk = k_last - k_first + 1;
+  if (h->plan == ALTRO_HIP_PLAN_GENERIC && h->ragged) {   // per-knot-point dimensions: q [b][sum over the range of nx[k]], r likewise, c [b][nk]
+    if (kz) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "k_stride_zero needs uniform dimensions");
+    const GenSizes gs = gen_sizes(h);
+    int64_t ox = 0, ou = 0, lx = 0, lu = 0;
+    for (int k = 0; k < k_first; ++k) { ox += h->nxv[k]; ou += h->nuv[k]; }
+    for (int k = k_first; k <= k_last; ++k) { lx += h->nxv[k]; if (k < N) lu += h->nuv[k]; }
+    auto put = [&](void* base, int64_t at, int64_t bs, const double* src, int64_t len) -> int {
+      if (!src || len <= 0) return 0;
+      char* dst = (char*)base + (size_t)at * h->esz;
+      return h->dtype == ALTRO_HIP_F64 ? aos_set<double>(h, (double*)dst, bs, bs, src, (int)len, 1, 0, bz)
+                                       : aos_set<float>(h, (float*)dst, bs, bs, src, (int)len, 1, 0, bz);
+    };
+    rc = put(h->g_cq, ox, gs.sx, q, lx);
+    if (!rc) rc = put(h->g_cr, ou, gs.su, r, lu);
+    if (!rc) rc = put(h->g_cc, k_first, N + 1, c, nk);
+    return rc;
+  }
   if (h->plan == ALTRO_HIP_PLAN_GENERIC) {   // the cost's own q, r, c blocks (dense [b][k][block])
     auto put = [&](void* base, int blk, int nk_total, const double* src, int nkp) -> int {
       if (!src || nkp <= 0) return 0;

@@ -195,15 +195,15 @@ inline int check(altro_hip_batch* h) {
 
 // entry of the iLQR-loop family of calls.  A handle with per-knot-point dimensions (altro_hip_batch_create_dims; the reference's
 // ALTROSolver::SetDimension(n, m, k_start, k_stop), altro_solver.cpp:26-47) runs the loop of plan GENERIC, whose kernels walk the
-// sweep's offset table; the calls whose arguments or meaning need ONE dimension (a tracking cost broadcast over the horizon, the
-// receding-horizon shift, device models) say so.
+// sweep's offset table; the calls whose meaning needs ONE dimension (the receding-horizon shift, device models) say so.
 inline int loop_entry(altro_hip_batch* h, bool takes_varying_dims = false) {
   int rc = check(h);
   if (rc) return rc;
   if (h->ragged && !takes_varying_dims)
     return fail(ALTRO_HIP_ERR_UNSUPPORTED, "this call needs uniform dimensions; a handle with per-knot-point dimensions (altro_hip_batch_create_dims) "
-                                           "takes altro_hip_set_dynamics / _set_quadratic_cost / _set_initial_state / _set_input_guess / _set_state_guess / "
-                                           "_add_linear_constraint, the iLQR loop calls and their getters, all with packed [batch][k][block_k] arrays");
+                                           "takes altro_hip_set_dynamics / _set_quadratic_cost / _set_tracking_cost / _update_linear_costs / _set_initial_state / "
+                                           "_set_input_guess / _set_state_guess / _add_linear_constraint, the iLQR loop calls and their getters, all with packed "
+                                           "[batch][k][block_k] arrays");
   return 0;
 }
 

@@ -143,9 +143,9 @@ int altro_hip_batch_create(altro_hip_batch** out, int horizon_N, int n, int m, i
  *     one block must share their dimensions -- register it per range, like ALTROSolver::SetConstraint per index), altro_hip_open_loop_rollout / _merit / _expand / _accept / _stationarity,
  *     altro_hip_ilqr_solve, altro_hip_get_nominal / _get_knot (x: nx[k], u: nu[k] entries);
  * with every bulk array packed [b][k][block_k] (block_k column-major with knot point k's own dimensions: the reference's per-knot-
- * point blocks end to end; c is [b][N + 1]).  k_stride_zero is refused, batch_stride_zero works.  The calls whose arguments or
- * meaning need ONE dimension say so: altro_hip_set_tracking_cost (give the dense blocks), _update_linear_costs, _shift_trajectory,
- * the device models.                                                                                                              */
+ * point blocks end to end; c is [b][N + 1]; altro_hip_set_tracking_cost takes Qd, xref [b][sum nx], Rd, uref [b][sum nu];
+ * altro_hip_update_linear_costs takes the blocks of its range end to end).  k_stride_zero is refused, batch_stride_zero works.  The
+ * calls whose meaning needs ONE dimension say so: altro_hip_shift_trajectory, the device models.                                  */
 int altro_hip_batch_create_dims(altro_hip_batch** out, int horizon_N, const int* nx, const int* nu, int batch, int dtype,
                                 unsigned flags, int device, void* stream);
 void altro_hip_batch_destroy(altro_hip_batch* h);

@@ -155,5 +155,5 @@ def test_what_a_ragged_handle_refuses():
     with pytest.raises(altro_amd.AltroHipError, match="uniform dimensions"):
         bt.set_input_guess(np.zeros((1, 1, 2)), k_stride_zero=True, batch_stride_zero=True)
     with pytest.raises(altro_amd.AltroHipError, match="uniform dimensions"):   # (the iLQR loop itself runs: tests/test_gpu_ragged_ilqr.py)
-        bt.update_linear_costs(np.zeros((4, 1, 3)), None, None, 0, 0)
+        bt.set_model(altro_amd.MODEL_PENDULUM, 0.05)
     bt.close()

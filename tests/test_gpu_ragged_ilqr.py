@@ -240,10 +240,56 @@ def test_cpp_altro_solver_with_varying_dimensions():
     np.testing.assert_allclose(xs, unpad_x(s.get("x")), rtol=1e-8, atol=1e-8)
 
 
+def test_tracking_cost_and_linear_cost_update_with_varying_dimensions():
+    """altro_hip_set_tracking_cost (ALTROSolver::SetLQRCost, altro_solver.cpp:138-172) and altro_hip_update_linear_costs
+    (UpdateLinearCosts, altro_solver.cpp:266-281) with packed per-knot-point arrays: the same iterates as the dense blocks they stand for."""
+    batch = 4
+    p = make_problem(batch, seed=55)
+    Qd = [1.0 + problems.uniform01((batch, NX[k]), 700 + k) for k in range(N + 1)]
+    Rd = [0.1 + 0.2 * problems.uniform01((batch, NU[k]), 800 + k) for k in range(N)]
+    xref = [0.5 * problems.normal((batch, NX[k]), 900 + k) for k in range(N + 1)]
+    uref = [0.2 * problems.normal((batch, NU[k]), 950 + k) for k in range(N)]
+
+    def build(tracking, q_override=None):
+        bt = altro_amd.Batch.with_dims(NX, NU, batch)
+        bt.set_dynamics(packed(p["A"]), packed(p["B"]), packed(p["f"]))
+        if tracking:
+            bt.set_tracking_cost(packed(Qd), packed(Rd), packed(xref), packed(uref))
+        else:
+            Q = [np.stack([np.diag(Qd[k][b]) for b in range(batch)]) for k in range(N + 1)]
+            R = [np.stack([np.diag(Rd[k][b]) for b in range(batch)]) for k in range(N)]
+            H = [np.zeros((batch, NU[k], NX[k])) for k in range(N)]
+            q = [-(Qd[k] * xref[k]) for k in range(N + 1)] if q_override is None else q_override
+            r = [-(Rd[k] * uref[k]) for k in range(N)]
+            c = np.stack([0.5 * (xref[k] * Qd[k] * xref[k]).sum(1) + (0.5 * (uref[k] * Rd[k] * uref[k]).sum(1) if k < N else 0.0)
+                          for k in range(N + 1)], axis=1)
+            bt.set_quadratic_cost(packed(Q), packed(R), packed(H), packed(q), packed(r), c)
+        bt.set_initial_state(p["x0"]); bt.set_input_guess(packed(p["u0"]))
+        return bt
+    bt, bd = build(True), build(False)
+    r1, r2 = bt.ilqr_solve(iterations_max=20, tol_stationarity=1e-6), bd.ilqr_solve(iterations_max=20, tol_stationarity=1e-6)
+    assert (r1["status"] == 0).all() and np.array_equal(r1["iterations"], r2["iterations"])
+    (x1, u1), (x2, u2) = bt.get_nominal(), bd.get_nominal()
+    np.testing.assert_allclose(x1, x2, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(u1, u2, rtol=1e-12, atol=1e-12)
+    # new linear state costs on knot points 3..7 (7 and 4 states): the packed range
+    qn = [-(Qd[k] * (xref[k] + 0.3)) for k in range(N + 1)]
+    bt.update_linear_costs(packed(qn[3:8]), None, None, 3, 7)
+    bt.set_input_guess(packed(p["u0"]))
+    r3 = bt.ilqr_solve(iterations_max=20, tol_stationarity=1e-6)
+    q_all = [-(Qd[k] * xref[k]) for k in range(N + 1)]
+    q_all[3:8] = qn[3:8]
+    be = build(False, q_all)
+    r4 = be.ilqr_solve(iterations_max=20, tol_stationarity=1e-6)
+    assert (r3["status"] == 0).all() and np.array_equal(r3["iterations"], r4["iterations"])
+    np.testing.assert_allclose(bt.get_nominal()[0], be.get_nominal()[0], rtol=1e-12, atol=1e-12)
+    assert np.abs(bt.get_nominal()[0] - x1).max() > 1e-3       # (the update moved the solution)
+
+
 def test_calls_that_need_one_dimension_say_so():
     bt = altro_amd.Batch.with_dims(NX, NU, 2)
     with pytest.raises(altro_amd.AltroHipError, match="uniform dimensions"):
-        bt.set_tracking_cost(np.ones((2, N + 1, NMAX)), np.ones((2, N, MMAX)), np.zeros((2, N + 1, NMAX)), np.zeros((2, N, MMAX)))
+        bt.set_model(altro_amd.MODEL_BICYCLE, 0.1)
     G = np.zeros((1, 5 + 2)); G[0, 5] = 1.0
     with pytest.raises(altro_amd.AltroHipError, match="differ in dimension"):
         bt.add_linear_constraint(0, 2, altro_amd.CONE_INEQUALITY, G, np.array([1.0]))     # k = 2 has three inputs
