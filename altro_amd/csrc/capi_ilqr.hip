@@ -412,6 +412,9 @@ int ilqr_check(altro_hip_batch* h, bool need_guess) {
       return fail(ALTRO_HIP_ERR_UNSUPPORTED, "the iLQR loop of plan GENERIC gives one lane to every state row and one to every input row: "
                                              "n, m <= 64 (got %d, %d); the TVLQR sweeps (altro_hip_backward / _forward_ltv / _sweep) take any size", h->n, h->m);
     if (!h->dyn_set) return fail(ALTRO_HIP_ERR_NOT_SET, "altro_hip_set_dynamics has not been called");
+    if (h->ragged && h->is_diag)   // (a diagonal altro_hip_set_cost re-lays the sweep's Q / R offsets, which the loop's dense blocks share)
+      return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "per-knot-point dimensions: the iLQR loop works on the dense blocks of altro_hip_set_quadratic_cost / "
+                                              "_set_tracking_cost; a later altro_hip_set_cost(is_diag = 1) re-laid them -- set the loop's cost again");
   } else if (!h->model_set) {
     return fail(ALTRO_HIP_ERR_NOT_SET, "altro_hip_set_model has not been called (plan LANE runs device models; for dynamics given as "
                                        "data -- altro_hip_set_dynamics -- create the handle with ALTRO_HIP_PLAN_MFMA16)");
