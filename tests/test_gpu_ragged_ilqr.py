@@ -80,7 +80,8 @@ def make_oracle(p, b, bounds):
         Ak = np.zeros((NMAX, NMAX)); Ak[:n2, :n] = p["A"][k][b]
         Bk = np.zeros((NMAX, MMAX)); Bk[:n2, :m] = p["B"][k][b]
         A[k] = Ak.T.reshape(-1); B[k] = Bk.T.reshape(-1); f[k, :n2] = p["f"][k][b]
-    s.L.oracle_ilqr_set_linear_dynamics(s.h, np.ascontiguousarray(A), np.ascontiguousarray(B), np.ascontiguousarray(f).ctypes.data)
+    fc = np.ascontiguousarray(f)
+    s.L.oracle_ilqr_set_linear_dynamics(s.h, np.ascontiguousarray(A), np.ascontiguousarray(B), fc.ctypes.data)
     for k in range(N + 1):
         n = NX[k]
         Q = np.zeros((NMAX, NMAX)); Q[:n, :n] = p["Q"][k][b]
@@ -89,9 +90,9 @@ def make_oracle(p, b, bounds):
         if k < N:
             m = NU[k]
             R[:m, :m] = p["R"][k][b]; H[:m, :n] = p["H"][k][b]; r[:m] = p["r"][k][b]
-        s.L.oracle_ilqr_set_quadratic_cost(s.h, k, np.ascontiguousarray(Q.T.reshape(-1)), np.ascontiguousarray(R.T.reshape(-1)).ctypes.data,
-                                           np.ascontiguousarray(H.T.reshape(-1)).ctypes.data, np.ascontiguousarray(q),
-                                           np.ascontiguousarray(r).ctypes.data, float(p["c"][b, k]))
+        Rc, Hc, rc_ = np.ascontiguousarray(R.T.reshape(-1)), np.ascontiguousarray(H.T.reshape(-1)), np.ascontiguousarray(r)   # (kept alive over the call)
+        s.L.oracle_ilqr_set_quadratic_cost(s.h, k, np.ascontiguousarray(Q.T.reshape(-1)), Rc.ctypes.data, Hc.ctypes.data, np.ascontiguousarray(q),
+                                           rc_.ctypes.data, float(p["c"][b, k]))
     x0 = np.zeros(NMAX); x0[:NX[0]] = p["x0"][b]
     s.L.oracle_ilqr_set_initial_state(s.h, np.ascontiguousarray(x0))
     for (k0, k1, G, g) in bounds:
@@ -238,6 +239,51 @@ def test_cpp_altro_solver_with_varying_dimensions():
     ostatus, oiters, _ = s.solve()
     assert ostatus == 0 and oiters == iters
     np.testing.assert_allclose(xs, unpad_x(s.get("x")), rtol=1e-8, atol=1e-8)
+
+
+@pytest.mark.parametrize("seed,lo,hi,mhi,dtype", [(1, 1, 9, 4, altro_amd.F64), (2, 2, 12, 6, altro_amd.F64), (3, 20, 40, 35, altro_amd.F64),
+                                                  (4, 3, 10, 5, altro_amd.F32)])
+def test_random_dimension_sequences(seed, lo, hi, mhi, dtype, monkeypatch):
+    """Seeded random nx[k] in [lo, hi], nu[k] in [1, mhi] (case 3: past 32, where a lane owns a state row and an input row):
+    merit, candidates and whole LQ solves against the padded oracle."""
+    import sys
+    me = sys.modules[__name__]
+    rs = np.random.RandomState(seed)
+    Nn = 9
+    nx = rs.randint(lo, hi + 1, size=Nn + 1); nu = rs.randint(1, mhi + 1, size=Nn)
+    for name, val in (("NX", nx), ("NU", nu), ("N", Nn), ("NMAX", int(nx.max())), ("MMAX", int(nu.max()))):
+        monkeypatch.setattr(me, name, val)
+    batch = 3
+    p = make_problem(batch, seed=1000 + seed)
+    f32 = dtype == altro_amd.F32
+    bt = altro_amd.Batch.with_dims(NX, NU, batch, dtype=dtype)
+    bt.set_dynamics(packed(p["A"]), packed(p["B"]), packed(p["f"]))
+    bt.set_quadratic_cost(packed(p["Q"]), packed(p["R"]), packed(p["H"]), packed(p["q"]), packed(p["r"]), p["c"])
+    bt.set_initial_state(p["x0"]); bt.set_input_guess(packed(p["u0"]))
+    bt.open_loop_rollout(); bt.accept(); bt.expand(); bt.backward()
+    assert (bt.get("status") == -1).all()
+    phi, dphi = bt.merit(np.full(batch, 0.7))
+    xc = bt.get("x")
+    res = bt.ilqr_solve(iterations_max=10, tol_stationarity=1e-2 if f32 else 1e-4)
+    assert (res["status"] == 0).all() and (res["iterations"] <= 3).all()
+    x, u = bt.get_nominal()
+    for b in range(batch):
+        s = make_oracle(p, b, [])
+        s.L.oracle_ilqr_open_loop_rollout(s.h); s.L.oracle_ilqr_copy_trajectory(s.h)
+        s.L.oracle_ilqr_calc_dynamics_expansions(s.h); s.L.oracle_ilqr_calc_cost_gradient(s.h)
+        s.L.oracle_ilqr_calc_expansions(s.h)
+        assert s.L.oracle_ilqr_backward_pass(s.h) == -1
+        p_ref, dp_ref = s.merit(0.7)
+        assert abs(phi[b] - p_ref) <= (2e-4 if f32 else 1e-11) * max(1.0, abs(p_ref)), (b, phi[b], p_ref)
+        assert abs(dphi[b] - dp_ref) <= (2e-3 if f32 else 1e-9) * max(1.0, abs(dp_ref)), (b, dphi[b], dp_ref)
+        np.testing.assert_allclose(xc[b], unpad_x(s.get("x_cand")), rtol=2e-4 if f32 else 1e-10, atol=2e-4 if f32 else 1e-10)
+        s2 = make_oracle(p, b, [])
+        s2.L.oracle_ilqr_set_options(s2.h, 10, 1e-4, 1e-4, 1e-8, 0)
+        status, iters, _ = s2.solve()
+        assert status == 0 and (f32 or iters == res["iterations"][b])
+        tol = 5e-4 if f32 else 1e-8
+        np.testing.assert_allclose(x[b], unpad_x(s2.get("x")), rtol=tol, atol=tol)
+        np.testing.assert_allclose(u[b], unpad_u(s2.get("u")), rtol=10 * tol, atol=10 * tol)
 
 
 def test_tracking_cost_and_linear_cost_update_with_varying_dimensions():
