@@ -17,6 +17,7 @@ PLAN_AUTO, PLAN_GENERIC, PLAN_MFMA16, PLAN_LANE = 0, 1, 2, 3
 STORE_QBLOCKS = 0x1
 LANE_FUSED = 0x4   # plan LANE: FMA-fused TVLQR kernels (not bit-identical to the CPU path, ~20 % faster at small batch)
 F32_PURE = 0x2   # ALTRO_HIP_F32 on plan MFMA16: backward sweep in pure fp32 (v_mfma_f32_16x16x4_f32)
+GENERIC_MATRIX_CORES = 0x8   # plan GENERIC, fp64: the backward sweep's products on the matrix cores (equal to rounding, not bit for bit)
 TVLQR_SUCCESS = -1
 
 # every symbol include/altro_hip/altro_hip.h declares (tests check the .so exports all of them)

@@ -115,6 +115,9 @@ static int batch_create_impl(altro_hip_batch** out, int N, int n, int m, int bat
   h->N = N; h->n = n; h->m = m; h->batch = batch; h->dtype = dtype; h->plan = plan;
   h->flags = flags; h->device = device; h->auto_plan = was_auto; h->user_stream = stream != nullptr;
   if (nx_k) { h->ragged = true; h->nxv.assign(nx_k, nx_k + N + 1); h->nuv.assign(nu_k, nu_k + N); }
+  // plan GENERIC's products on the matrix cores: only when asked for (the plan's default is the CPU path's sums bit for bit: whole
+  // AL-iLQR solves then take the oracle's line-search decisions, which sums that differ in the last bits do not always do)
+  h->g_mfma = plan == ALTRO_HIP_PLAN_GENERIC && dtype == ALTRO_HIP_F64 && (flags & ALTRO_HIP_GENERIC_MATRIX_CORES) != 0;
   h->esz = dtype == ALTRO_HIP_F64 ? 8 : 4;
   if (stream) { h->stream = (hipStream_t)stream; }
   else {

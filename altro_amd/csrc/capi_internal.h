@@ -62,6 +62,7 @@ struct altro_hip_batch {
   // plan GENERIC: reference layout on the device
   void* g_arr[G_NUM] = {};
   int64_t g_bstride[G_NUM] = {};
+  bool g_mfma = false;                       // plan GENERIC, fp64: the backward sweep's products on the matrix cores (ALTRO_HIP_GENERIC_MATRIX_CORES)
   bool ragged = false;                       // per-knot-point dimensions (altro_hip_batch_create_dims): plan GENERIC, TVLQR sweeps only
   std::vector<int> nxv, nuv;                 // nx[0..N], nu[0..N-1] of a ragged handle (n, m hold the maxima)
   int64_t* g_off = nullptr;

@@ -197,7 +197,10 @@ int launch_backward(altro_hip_batch* h, double reg) {
     if (h->dtype == ALTRO_HIP_F64) {
       auto a = generic_args<double>(h, reg);
       a.ws = (double*)h->g_ws; a.ws_stride = (int64_t)((lds + 15) / 16 * 16 / sizeof(double));
-      if (big) PROF_LAUNCH((generic_backward_kernel<double, true>), dim3(h->batch), dim3(64), 0, h->stream, a);
+      if (h->g_mfma) {   // the products on the matrix cores (ALTRO_HIP_GENERIC_MATRIX_CORES; plan AUTO's choice for shapes past the tile)
+        if (big) PROF_LAUNCH((generic_backward_kernel<double, true, true>), dim3(h->batch), dim3(64), 0, h->stream, a);
+        else PROF_LAUNCH((generic_backward_kernel<double, false, true>), dim3(h->batch), dim3(64), lds, h->stream, a);
+      } else if (big) PROF_LAUNCH((generic_backward_kernel<double, true>), dim3(h->batch), dim3(64), 0, h->stream, a);
       else PROF_LAUNCH((generic_backward_kernel<double, false>), dim3(h->batch), dim3(64), lds, h->stream, a);
     } else {
       auto a = generic_args<float>(h, reg);

@@ -93,6 +93,51 @@ __device__ __forceinline__ void wave_gemm(int lane, int ta, int tb, int mr, int 
   }
 }
 
+// The same product on the matrix cores (plan GENERIC with ALTRO_HIP_GENERIC_MATRIX_CORES; fp64): 16 x 16 output tiles, four terms per
+// v_mfma_f64_16x16x4.  Lane l = (g = l / 16, j = l % 16) feeds A[row j][term g] and B[term g][column j] of the tile and receives
+// rows g, g + 4, g + 8, g + 12 of column j; entries past the blocks' own dimensions are fed as zeros, so any (mr, nc, kd) takes
+// ceil(mr / 16) ceil(nc / 16) ceil(kd / 4) instructions with two LDS reads each -- against mr nc kd / 64 multiply-add pairs with four
+// reads per pair in wave_gemm.  The sums are the matrix pipe's (fused, its own order): results agree with wave_gemm's to rounding,
+// not bit for bit, which is why the plan's default and the tvlqr_* drop-in keep wave_gemm.
+typedef double gen_f64x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void wave_gemm_mfma(int lane, int ta, int tb, int mr, int nc, int kd, double alpha, const double* A, int lda,
+                                               const double* B, int ldb, double beta, double* C, int ldc) {
+  const int j = lane & 15, g = lane >> 4;
+  const int ai = ta ? lda : 1, ak = ta ? 1 : lda;      // op(A)(i, k) = A[i ai + k ak]
+  const int bk = tb ? ldb : 1, bj = tb ? 1 : ldb;      // op(B)(k, c) = B[k bk + c bj]
+  for (int j0 = 0; j0 < nc; j0 += 16) {
+    for (int i0 = 0; i0 < mr; i0 += 16) {
+      gen_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+      const bool arow = i0 + j < mr, bcol = j0 + j < nc;
+      const double* pa = A + (i0 + j) * ai + g * ak;
+      const double* pb = B + (j0 + j) * bj + g * bk;
+      for (int k0 = 0; k0 < kd; k0 += 4) {
+        const bool kin = k0 + g < kd;
+        const double av = (arow && kin) ? pa[k0 * ak] : 0.0;
+        const double bv = (bcol && kin) ? pb[k0 * bk] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+      }
+      if (bcol) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = i0 + g + 4 * r;
+          if (row < mr) {
+            double* c = C + row + (j0 + j) * ldc;
+            const double c0 = (beta == 0.0) ? 0.0 : beta * *c;
+            *c = c0 + alpha * acc[r];
+          }
+        }
+      }
+    }
+  }
+}
+template <typename T, bool MF>
+__device__ __forceinline__ void wave_gemm_sel(int lane, int ta, int tb, int mr, int nc, int kd, T alpha, const T* A, int lda, const T* B,
+                                              int ldb, T beta, T* C, int ldc) {
+  if constexpr (MF && sizeof(T) == 8) wave_gemm_mfma(lane, ta, tb, mr, nc, kd, alpha, A, lda, B, ldb, beta, C, ldc);
+  else wave_gemm<T>(lane, ta, tb, mr, nc, kd, alpha, A, lda, B, ldb, beta, C, ldc);
+}
+
 // dst[0 .. count) <- src: four elements per lane in flight (a copy from global memory pays one round trip per 256 elements, not per 64)
 template <typename T>
 __device__ __forceinline__ void wave_copy(int lane, T* dst, const T* src, int count) {
@@ -256,8 +301,8 @@ __device__ __forceinline__ int gain_solve_regs(int lane, T* sL, T* sK, T* sd, in
 // per-problem work block in GLOBAL memory (args.ws) -- any dimensions, as the reference takes them (tvlqr.cpp:92-121 sizes every
 // block from nx[k], nu[k]); slow (every operand is a cached global load), which is the point: refusing n = 33 is worse.  A workgroup
 // is one wave and __syncthreads() orders its global accesses at workgroup scope, so the phases stay as they are.
-template <typename T, bool BIG = false>
-__global__ __launch_bounds__(64) void generic_backward_kernel(GenericArgs<T> a) {
+template <typename T, bool BIG = false, bool MF = false>
+__global__ __launch_bounds__(64, (MF && !BIG) ? 4 : 1) void generic_backward_kernel(GenericArgs<T> a) {   // (MF in LDS: 128 registers, four waves per SIMD -- 4096 problems resident)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int lane = threadIdx.x;
   const int b = blockIdx.x;
@@ -324,17 +369,17 @@ __global__ __launch_bounds__(64) void generic_backward_kernel(GenericArgs<T> a) 
     wave_copy(lane, sQu, (const T*)GPTR(G_r, k), m);
     __syncthreads();
     // Qxx_tmp = A^T P' ; Qux_tmp = B^T P' ; Qx_tmp = p' + P' f     (tvlqr.cpp:135,139,147-148)
-    wave_gemm<T>(lane, 1, 0, n, n2, n2, T(1), sA, n2, sP, n2, T(0), sT1, n);
-    wave_gemm<T>(lane, 1, 0, m, n2, n2, T(1), sB, n2, sP, n2, T(0), sT2, m);
+    wave_gemm_sel<T, MF>(lane, 1, 0, n, n2, n2, T(1), sA, n2, sP, n2, T(0), sT1, n);
+    wave_gemm_sel<T, MF>(lane, 1, 0, m, n2, n2, T(1), sB, n2, sP, n2, T(0), sT2, m);
     wave_copy(lane, st, (const T*)sp, n2);
     __syncthreads();
-    wave_gemm<T>(lane, 0, 0, n2, 1, n2, T(1), sP, n2, sf, n2, T(1), st, n2);
-    wave_gemm<T>(lane, 0, 0, n, n, n2, T(1), sT1, n, sA, n2, T(1), sQxx, n);   // :136
-    wave_gemm<T>(lane, 0, 0, m, m, n2, T(1), sT2, m, sB, n2, T(1), sQuu, m);   // :140
-    wave_gemm<T>(lane, 0, 0, m, n, n2, T(1), sT2, m, sA, n2, T(1), sQux, m);   // :143
+    wave_gemm_sel<T, MF>(lane, 0, 0, n2, 1, n2, T(1), sP, n2, sf, n2, T(1), st, n2);
+    wave_gemm_sel<T, MF>(lane, 0, 0, n, n, n2, T(1), sT1, n, sA, n2, T(1), sQxx, n);   // :136
+    wave_gemm_sel<T, MF>(lane, 0, 0, m, m, n2, T(1), sT2, m, sB, n2, T(1), sQuu, m);   // :140
+    wave_gemm_sel<T, MF>(lane, 0, 0, m, n, n2, T(1), sT2, m, sA, n2, T(1), sQux, m);   // :143
     __syncthreads();
-    wave_gemm<T>(lane, 1, 0, n, 1, n2, T(1), sA, n2, st, n2, T(1), sQx, n);    // :149-150
-    wave_gemm<T>(lane, 1, 0, m, 1, n2, T(1), sB, n2, st, n2, T(1), sQu, m);    // :151-152
+    wave_gemm_sel<T, MF>(lane, 1, 0, n, 1, n2, T(1), sA, n2, st, n2, T(1), sQx, n);    // :149-150
+    wave_gemm_sel<T, MF>(lane, 1, 0, m, 1, n2, T(1), sB, n2, st, n2, T(1), sQu, m);    // :151-152
     __syncthreads();
     // gains (tvlqr.cpp:155-166)
     wave_copy(lane, sK, (const T*)sQux, m * n);
@@ -372,14 +417,14 @@ __global__ __launch_bounds__(64) void generic_backward_kernel(GenericArgs<T> a) 
       return;
     }
     // cost-to-go (tvlqr.cpp:173-186)
-    wave_gemm<T>(lane, 0, 0, m, n, m, T(1), sQuu, m, sK, m, T(0), sT2, m);  // Qux_tmp = Quu K
-    wave_gemm<T>(lane, 1, 0, n, n, m, T(1), sK, m, sQux, m, T(0), sT1, n);  // Qxx_tmp = K^T Qux
+    wave_gemm_sel<T, MF>(lane, 0, 0, m, n, m, T(1), sQuu, m, sK, m, T(0), sT2, m);  // Qux_tmp = Quu K
+    wave_gemm_sel<T, MF>(lane, 1, 0, n, n, m, T(1), sK, m, sQux, m, T(0), sT1, n);  // Qxx_tmp = K^T Qux
     wave_copy(lane, sP, (const T*)sQxx, n * n);         // P_{k+1}, p_{k+1} are dead from here: P_k, p_k are built in their place
     wave_copy(lane, sp, (const T*)sQx, n);
-    wave_gemm<T>(lane, 0, 0, m, 1, m, T(1), sQuu, m, sd, m, T(0), sw, m);   // Qu_tmp = Quu d (:189)
-    if (a.store_q == 2) wave_gemm<T>(lane, 1, 0, n, 1, m, T(1), sK, m, sQu, m, T(0), st, n);  // Qx_tmp = K^T Qu (:176)
+    wave_gemm_sel<T, MF>(lane, 0, 0, m, 1, m, T(1), sQuu, m, sd, m, T(0), sw, m);   // Qu_tmp = Quu d (:189)
+    if (a.store_q == 2) wave_gemm_sel<T, MF>(lane, 1, 0, n, 1, m, T(1), sK, m, sQu, m, T(0), st, n);  // Qx_tmp = K^T Qu (:176)
     __syncthreads();
-    wave_gemm<T>(lane, 1, 0, n, n, m, T(1), sT2, m, sK, m, T(1), sP, n);    // P += (Quu K)^T K
+    wave_gemm_sel<T, MF>(lane, 1, 0, n, n, m, T(1), sT2, m, sK, m, T(1), sP, n);    // P += (Quu K)^T K
     __syncthreads();
     {   // P -= K^T Qux; P -= (K^T Qux)^T: the same lane owns the element in both statements
       const float rn = __builtin_amdgcn_rcpf((float)n);
@@ -392,11 +437,11 @@ __global__ __launch_bounds__(64) void generic_backward_kernel(GenericArgs<T> a) 
         sP[e] = v;
       }
     }
-    wave_gemm<T>(lane, 1, 0, n, 1, m, T(-1), sT2, m, sd, m, T(1), sp, n);   // p -= (Quu K)^T d
+    wave_gemm_sel<T, MF>(lane, 1, 0, n, 1, m, T(-1), sT2, m, sd, m, T(1), sp, n);   // p -= (Quu K)^T d
     __syncthreads();
-    wave_gemm<T>(lane, 1, 0, n, 1, m, T(-1), sK, m, sQu, m, T(1), sp, n);   // p -= K^T Qu
+    wave_gemm_sel<T, MF>(lane, 1, 0, n, 1, m, T(-1), sK, m, sQu, m, T(1), sp, n);   // p -= K^T Qu
     __syncthreads();
-    wave_gemm<T>(lane, 1, 0, n, 1, m, T(1), sQux, m, sd, m, T(1), sp, n);   // p += Qux^T d
+    wave_gemm_sel<T, MF>(lane, 1, 0, n, 1, m, T(1), sQux, m, sd, m, T(1), sp, n);   // p += Qux^T d
     if (lane == 0) {  // tvlqr.cpp:189-191
       const T s0 = gen_dot<T>(sd, sQu, m), s1 = gen_dot<T>(sd, sw, m);
       dv0 += s0;

@@ -101,6 +101,11 @@ typedef enum altro_hip_plan {
                                         v_mfma_f32_16x16x4_f32 (cost-to-go carried in fp32: ~5e-4 relative).
                                         Default for F32 is fp32 storage with fp64 tile arithmetic (2e-5): on
                                         MI355X both are bound by the same fp32 record traffic */
+#define ALTRO_HIP_GENERIC_MATRIX_CORES 0x8u /* plan GENERIC, fp64: the backward sweep's products as v_mfma_f64_16x16x4 tiles (any
+                                      * n, m, per-knot-point dimensions included) instead of one multiply-add at a time in the CPU
+                                      * path's order: 1.0-1.7 x faster from n = 14 up, results equal to rounding
+                                      * (1e-12) instead of bit for bit -- a whole AL-iLQR solve may then take a line-search decision
+                                      * differently from the CPU path.  Off unless given; the tvlqr_* drop-in is always exact.      */
 
 #define ALTRO_HIP_LANE_FUSED 0x4u    /* plan LANE: let the TVLQR kernels fuse a * b + c into one FMA.  Default off: the
                                         unfused kernels repeat the CPU path operation for operation and give

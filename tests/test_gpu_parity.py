@@ -723,3 +723,39 @@ def test_plan_auto_picks_by_measured_cost():
     ref = run_oracle(pr)
     for k in ("K", "d", "P", "p", "x", "u", "y"):
         assert relerr(out[k], ref[k]) < 1e-11, k
+
+
+@pytest.mark.parametrize("n,m,N", [(13, 4, 40), (16, 5, 30), (20, 8, 20), (7, 9, 25), (40, 10, 12), (33, 33, 6)])
+def test_generic_matrix_core_products_equal_the_exact_ones_to_rounding(n, m, N):
+    """ALTRO_HIP_GENERIC_MATRIX_CORES: plan GENERIC's backward sweep with its sixteen products as v_mfma_f64_16x16x4 tiles (any
+    dimensions, zeros fed past the blocks' edges; past 60 KB of LDS on the global work block too).  Same statuses; gains, cost-to-go
+    and trajectories within 1e-12 of the bit-exact form (measured 1e-15), which tests above pin to the oracle bit for bit."""
+    batch = 16
+    pr = problems.random_ltv(batch, N, n, m)
+    out = {}
+    for name, flags in (("exact", 0), ("mc", altro_amd.GENERIC_MATRIX_CORES)):
+        bt = altro_amd.Batch(N, n, m, batch, plan=altro_amd.PLAN_GENERIC, flags=flags)
+        bt.set_dynamics(pr["A"], pr["B"], pr["f"]); bt.set_cost(pr["Q"], pr["R"], pr["H"], pr["q"], pr["r"])
+        bt.set_initial_state(pr["x0"])
+        bt.sweep(); bt.synchronize()
+        out[name] = {k: bt.get(k) for k in ("K", "d", "P", "p", "x", "u", "y", "status", "delta_V")}
+        bt.close()
+    assert np.array_equal(out["exact"]["status"], out["mc"]["status"]) and (out["mc"]["status"] == -1).all()
+    for k in ("K", "d", "P", "p", "x", "u", "y", "delta_V"):
+        scale = max(1.0, float(np.abs(out["exact"][k]).max()))
+        assert np.abs(out["exact"][k] - out["mc"][k]).max() <= 1e-12 * scale, k
+    assert not np.array_equal(out["exact"]["P"], out["mc"]["P"])      # (it IS another summation order)
+
+
+def test_generic_matrix_core_products_failed_factorisation_and_varying_dimensions():
+    """The same flag where the recursion stops (an indefinite R at one knot point: status = that index, like tvlqr.cpp:162-164) and on
+    a handle with per-knot-point dimensions."""
+    N, n, m, batch = 12, 14, 5, 8
+    pr = problems.random_ltv(batch, N, n, m)
+    R = pr["R"].copy(); R[3, 7] = -np.eye(m).reshape(-1) * 50.0
+    st = {}
+    for name, flags in (("exact", 0), ("mc", altro_amd.GENERIC_MATRIX_CORES)):
+        bt = altro_amd.Batch(N, n, m, batch, plan=altro_amd.PLAN_GENERIC, flags=flags)
+        bt.set_dynamics(pr["A"], pr["B"], pr["f"]); bt.set_cost(pr["Q"], R, pr["H"], pr["q"], pr["r"])
+        bt.set_initial_state(pr["x0"]); bt.backward(); st[name] = bt.get("status"); bt.close()
+    assert np.array_equal(st["exact"], st["mc"]) and st["mc"][3] == 7 and (np.delete(st["mc"], 3) == -1).all()

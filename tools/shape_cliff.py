@@ -15,9 +15,9 @@ from tests import problems  # noqa: E402
 PLAN = {1: "GENERIC", 2: "MFMA16", 3: "LANE"}
 
 
-def sweep_ms(N, n, m, batch, plan):
+def sweep_ms(N, n, m, batch, plan, flags=0):
     pr = problems.random_ltv(64, N, n, m)
-    bt = altro_amd.Batch(N, n, m, batch, plan=plan)
+    bt = altro_amd.Batch(N, n, m, batch, plan=plan, flags=flags)
     bt.set_host_batch(64) if bt.plan != altro_amd.PLAN_GENERIC else None
     if bt.plan == altro_amd.PLAN_GENERIC:
         pr = {k: (np.tile(v, (batch // 64,) + (1,) * (v.ndim - 1)) if isinstance(v, np.ndarray) else v) for k, v in pr.items()}
@@ -43,8 +43,8 @@ def main():
     batches = [int(b) for b in sys.argv[1:]] or [4096]
     for batch in batches:
         print("# sweep (backward + forward) ms, N = %d, batch = %d, fp64, random LTV problems; every plan that takes the shape" % (N, batch))
-        print("%-8s %-8s %10s %10s %10s %10s %8s" % ("(n, m)", "AUTO ->", "AUTO ms", "LANE ms", "MFMA16 ms", "GENERIC ms", "worst/AUTO"))
-        shapes = [(16, 4), (14, 7), (13, 4), (12, 4), (12, 3), (11, 4), (10, 4), (8, 2), (7, 3), (6, 3), (6, 2), (6, 1), (5, 3), (5, 2), (5, 1),
+        print("%-8s %-8s %10s %10s %10s %10s %10s %8s" % ("(n, m)", "AUTO ->", "AUTO ms", "LANE ms", "MFMA16 ms", "GENERIC ms", "GEN+MC ms", "worst/AUTO"))
+        shapes = [(28, 4), (24, 8), (20, 8), (16, 4), (14, 7), (13, 4), (12, 4), (12, 3), (11, 4), (10, 4), (8, 2), (7, 3), (6, 3), (6, 2), (6, 1), (5, 3), (5, 2), (5, 1),
                   (4, 3), (4, 2), (4, 1), (3, 3), (3, 2), (2, 1), (1, 1)]
         for (n, m) in shapes:
             if batch > 8192 and (n > 12 or m > 4):
@@ -54,9 +54,11 @@ def main():
             for name, plan, ok in (("LANE", altro_amd.PLAN_LANE, n <= 6 and m <= 3), ("MFMA16", altro_amd.PLAN_MFMA16, n <= 12 and m <= 4),
                                    ("GENERIC", altro_amd.PLAN_GENERIC, batch <= 8192)):
                 row[name] = sweep_ms(N, n, m, batch, plan)[0] if ok else None
+            # plan GENERIC with its products on the matrix cores (ALTRO_HIP_GENERIC_MATRIX_CORES: equal to rounding, not bit for bit; opt-in)
+            mc = sweep_ms(N, n, m, batch, altro_amd.PLAN_GENERIC, altro_amd.GENERIC_MATRIX_CORES)[0] if (batch <= 8192 and (n > 12 or m > 4)) else None
             f = lambda v: ("%10.3f" % v) if v is not None else "%10s" % "-"
             best = min([v for v in row.values() if v is not None] + [a])
-            print("%-8s %-8s %10.3f %s %s %s %8.2f" % ("(%d, %d)" % (n, m), PLAN[used], a, f(row["LANE"]), f(row["MFMA16"]), f(row["GENERIC"]), a / best))
+            print("%-8s %-8s %10.3f %s %s %s %s %8.2f" % ("(%d, %d)" % (n, m), PLAN[used], a, f(row["LANE"]), f(row["MFMA16"]), f(row["GENERIC"]), f(mc), a / best))
 
 
 if __name__ == "__main__":
