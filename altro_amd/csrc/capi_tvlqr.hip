@@ -240,13 +240,17 @@ int launch_forward(altro_hip_batch* h) {
   } else if (h->plan == ALTRO_HIP_PLAN_LANE) {
     return h->dtype == ALTRO_HIP_F64 ? lane_launch<double>(h, false, 0.0) : lane_launch<float>(h, false, 0.0);
   } else if (h->dtype == ALTRO_HIP_F64) {
+    // the knot point's blocks staged in LDS and fetched a knot point ahead while sixteen waves still fit a CU (10 KB each: measured at
+    // 4096 problems, (13, 4) 1.53 -> 1.21 ms, (16, 4) 1.62 -> 1.27, but (24, 8) at 13 KB 2.37 -> 3.58); else rows from global memory
     auto a = generic_args<double>(h, 0.0);
-    size_t lds = (size_t)(2 * h->n + h->m) * sizeof(double) + 64;
-    PROF_LAUNCH(generic_forward_kernel<double>, dim3(h->batch), dim3(64), lds, h->stream, a);
+    const size_t staged = generic_forward_lds_bytes(h->n, h->m, a.want_y, sizeof(double));
+    if (staged <= kGenericForwardStageLimit) PROF_LAUNCH((generic_forward_kernel<double, true>), dim3(h->batch), dim3(64), staged, h->stream, a);
+    else PROF_LAUNCH((generic_forward_kernel<double, false>), dim3(h->batch), dim3(64), (size_t)(2 * h->n + h->m) * sizeof(double) + 64, h->stream, a);
   } else {
     auto a = generic_args<float>(h, 0.0);
-    size_t lds = (size_t)(2 * h->n + h->m) * sizeof(float) + 64;
-    PROF_LAUNCH(generic_forward_kernel<float>, dim3(h->batch), dim3(64), lds, h->stream, a);
+    const size_t staged = generic_forward_lds_bytes(h->n, h->m, a.want_y, sizeof(float));
+    if (staged <= kGenericForwardStageLimit) PROF_LAUNCH((generic_forward_kernel<float, true>), dim3(h->batch), dim3(64), staged, h->stream, a);
+    else PROF_LAUNCH((generic_forward_kernel<float, false>), dim3(h->batch), dim3(64), (size_t)(2 * h->n + h->m) * sizeof(float) + 64, h->stream, a);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "forward launch: %s", hipGetErrorString(e));

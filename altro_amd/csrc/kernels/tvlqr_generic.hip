@@ -25,6 +25,7 @@ namespace altro_hip {
 ALTRO_FP_REGION_OFF
 
 constexpr size_t kGenericLdsLimit = 64 * 1024;   // dynamic LDS a launch gets without asking for more; beyond it plan GENERIC works in global memory
+constexpr size_t kGenericForwardStageLimit = 10 * 1024;   // batched forward sweep: stage the knot point in LDS up to this much per problem (sixteen waves per CU)
 constexpr int kGenericMaxDim = 256;              // n, m accepted by plan GENERIC (a bound on the work blocks, not of the algorithm)
 
 // (enum GArr: kernels/generic_arrays.h)
@@ -499,47 +500,110 @@ __device__ __forceinline__ T gen_row_dot(const T* M, int ld, const T* v, int cnt
   return s;
 }
 
+// CAP x 64 elements of a block ride in registers from one knot point to the next; what is past that is copied at the point of use
+template <typename T, int CAP>
+__device__ __forceinline__ void reg_fetch(T (&v)[CAP], const T* src, int count, int lane) {
+#pragma unroll
+  for (int c = 0; c < CAP; ++c) {
+    const int e = lane + 64 * c;
+    v[c] = e < count ? src[e] : T(0);
+  }
+}
+template <typename T, int CAP>
+__device__ __forceinline__ void reg_put(T* dst, const T (&v)[CAP], const T* src, int count, int lane) {
+#pragma unroll
+  for (int c = 0; c < CAP; ++c) {
+    const int e = lane + 64 * c;
+    if (e < count) dst[e] = v[c];
+  }
+  if (count > 64 * CAP) wave_copy(lane, dst + 64 * CAP, src + 64 * CAP, count - 64 * CAP);
+}
+
+inline size_t generic_forward_lds_bytes(int nm, int mm, int want_y, size_t esz) {   // STAGE = true
+  size_t el = (size_t)3 * nm + mm + (size_t)nm * nm + (size_t)2 * nm * mm + nm + mm + (want_y ? (size_t)nm * nm + nm : 0);
+  return el * esz + 64;
+}
+
 // tvlqr_ForwardPass (tvlqr.cpp:197-248): x_0 = x0; u = d - K x; x+ = f + A x + B u; y = P x + p.
-template <typename T>
+// STAGE = true (what fits LDS): the knot point's K, d, A, B, f (P, p) are staged in LDS by coalesced loads and those of knot point
+// k + 1 are fetched into registers while knot point k is worked on -- the rollout is one chain of dependent rows, and with the rows
+// read from global memory term by term every knot point waited four to eight round trips ((13, 4), 4096 problems: forward sweep
+// 1.53 ms; sums and their order unchanged).  STAGE = false: the rows straight from global memory (any size).
+template <typename T, bool STAGE = false>
 __global__ __launch_bounds__(64) void generic_forward_kernel(GenericArgs<T> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* smem = reinterpret_cast<T*>(smem_raw);
   const int lane = threadIdx.x;
   const int b = blockIdx.x;
   if (b >= a.batch) return;
+  const int nm = a.nmax, mm = a.mmax;
   T* sx = smem;            // x_k
-  T* su = sx + a.nmax;     // u_k
-  T* sxn = su + a.mmax;    // x_{k+1}
+  T* su = sx + nm;         // u_k
+  T* sxn = su + mm;        // x_{k+1}
+  T* sA = sxn + nm;        // STAGE: A_k, B_k, f_k, K_k, d_k (, P_k, p_k)
+  T* sB = sA + nm * nm;
+  T* sf = sB + nm * mm;
+  T* sK = sf + nm;
+  T* sd = sK + mm * nm;
+  T* sPm = sd + mm;
+  T* spv = sPm + nm * nm;
+#define GPTR(arr, k) (a.base[arr] + (int64_t)b * a.bstride[arr] + a.off[(int64_t)(k) * G_NUM + arr])
   const int N = a.N;
+  struct { T A[4], B[2], f[1], K[2], d[1], P[4], p[1]; } kr;
+  auto fetch_knot = [&](int k) {
+    const int n = a.nx[k], m = a.nu[k], n2 = a.nx[k + 1];
+    reg_fetch<T, 4>(kr.A, (const T*)GPTR(G_A, k), n2 * n, lane);
+    reg_fetch<T, 2>(kr.B, (const T*)GPTR(G_B, k), n2 * m, lane);
+    reg_fetch<T, 1>(kr.f, (const T*)GPTR(G_f, k), n2, lane);
+    reg_fetch<T, 2>(kr.K, (const T*)GPTR(G_K, k), m * n, lane);
+    reg_fetch<T, 1>(kr.d, (const T*)GPTR(G_d, k), m, lane);
+    if (a.want_y) {
+      reg_fetch<T, 4>(kr.P, (const T*)GPTR(G_P, k), n * n, lane);
+      reg_fetch<T, 1>(kr.p, (const T*)GPTR(G_p, k), n, lane);
+    }
+  };
+  if (STAGE && N > 0) fetch_knot(0);
   wave_copy(lane, sx, a.x0 + (int64_t)b * a.x0_stride, a.nx[0]);
   __syncthreads();
   wave_copy(lane, GPTR(G_x, 0), (const T*)sx, a.nx[0]);
   for (int k = 0; k < N; ++k) {
     const int n = a.nx[k], m = a.nu[k], n2 = a.nx[k + 1];
-    const T* A = GPTR(G_A, k);
-    const T* B = GPTR(G_B, k);
-    const T* f = GPTR(G_f, k);
-    const T* K = GPTR(G_K, k);
-    const T* d = GPTR(G_d, k);
-    for (int i = lane; i < m; i += 64) {  // u = d - K x
-      const T s = gen_row_dot<T>(K + i, m, sx, n);
-      su[i] = d[i] + T(-1) * s;
-    }
-    if (a.want_y) {  // y = P x + p   (lanes m.. take it so it overlaps the u chain)
-      const T* P = GPTR(G_P, k);
-      const T* p = GPTR(G_p, k);
-      T* y = GPTR(G_y, k);
-      for (int i = lane; i < n; i += 64) {
-        const T s = gen_row_dot<T>(P + i, n, sx, n);
-        y[i] = (T(0) + s) + p[i];
+    // the knot point's rows against x, u (both call sites inline it: the LDS blocks keep ds_read, the global ones global_load)
+    auto step = [&](const T* A, const T* B, const T* f, const T* K, const T* d, const T* P, const T* p) {
+      for (int i = lane; i < m; i += 64) {  // u = d - K x
+        const T s = gen_row_dot<T>(K + i, m, sx, n);
+        su[i] = d[i] + T(-1) * s;
       }
-    }
-    __syncthreads();
-    for (int i = lane; i < n2; i += 64) {  // x+ = f + A x + B u
-      const T s = gen_row_dot<T>(A + i, n2, sx, n);
-      T v = f[i] + s;
-      const T s2 = gen_row_dot<T>(B + i, n2, su, m);
-      sxn[i] = v + s2;
+      if (a.want_y) {  // y = P x + p   (lanes m.. take it so it overlaps the u chain)
+        T* y = GPTR(G_y, k);
+        for (int i = lane; i < n; i += 64) {
+          const T s = gen_row_dot<T>(P + i, n, sx, n);
+          y[i] = (T(0) + s) + p[i];
+        }
+      }
+      __syncthreads();
+      for (int i = lane; i < n2; i += 64) {  // x+ = f + A x + B u
+        const T s = gen_row_dot<T>(A + i, n2, sx, n);
+        T v = f[i] + s;
+        const T s2 = gen_row_dot<T>(B + i, n2, su, m);
+        sxn[i] = v + s2;
+      }
+    };
+    if (STAGE) {
+      reg_put<T, 4>(sA, kr.A, (const T*)GPTR(G_A, k), n2 * n, lane);
+      reg_put<T, 2>(sB, kr.B, (const T*)GPTR(G_B, k), n2 * m, lane);
+      reg_put<T, 1>(sf, kr.f, (const T*)GPTR(G_f, k), n2, lane);
+      reg_put<T, 2>(sK, kr.K, (const T*)GPTR(G_K, k), m * n, lane);
+      reg_put<T, 1>(sd, kr.d, (const T*)GPTR(G_d, k), m, lane);
+      if (a.want_y) {
+        reg_put<T, 4>(sPm, kr.P, (const T*)GPTR(G_P, k), n * n, lane);
+        reg_put<T, 1>(spv, kr.p, (const T*)GPTR(G_p, k), n, lane);
+      }
+      if (k + 1 < N) fetch_knot(k + 1);                // in flight until the next iteration stores them
+      __syncthreads();
+      step(sA, sB, sf, sK, sd, sPm, spv);
+    } else {
+      step(GPTR(G_A, k), GPTR(G_B, k), GPTR(G_f, k), GPTR(G_K, k), GPTR(G_d, k), GPTR(G_P, k), GPTR(G_p, k));
     }
     wave_copy(lane, GPTR(G_u, k), (const T*)su, m);
     __syncthreads();

@@ -518,8 +518,9 @@ int tvlqr_ForwardPass(const int* nx, const int* nu, int num_horizon, const lqr_f
   memcpy(hs + L.total - 4 - L.xstage, x0, sizeof(double) * nx[0]);
   if (hipMemcpyAsync(w.dev, hs, (size_t)L.group_end[2] * sizeof(double), hipMemcpyHostToDevice, w.stream) != hipSuccess) return TVLQR_NO_DEVICE;
   GenericArgs<double> a = make_args(w, L, 0.0, false, y ? 1 : 0, L.group_end[2]);
-  const size_t lds = (size_t)(2 * a.nmax + a.mmax) * sizeof(double) + 64;
-  hipLaunchKernelGGL(generic_forward_kernel<double>, dim3(1), dim3(64), lds, w.stream, a);
+  const size_t staged = generic_forward_lds_bytes(a.nmax, a.mmax, a.want_y, sizeof(double));
+  if (staged <= kGenericLdsLimit) hipLaunchKernelGGL((generic_forward_kernel<double, true>), dim3(1), dim3(64), staged, w.stream, a);
+  else hipLaunchKernelGGL((generic_forward_kernel<double, false>), dim3(1), dim3(64), (size_t)(2 * a.nmax + a.mmax) * sizeof(double) + 64, w.stream, a);
   if (hipGetLastError() != hipSuccess) return TVLQR_NO_DEVICE;
   if (hipStreamSynchronize(w.stream) != hipSuccess) return TVLQR_NO_DEVICE;
   for (int k = 0; k <= N; ++k) {
