@@ -298,12 +298,32 @@ __device__ __forceinline__ int gain_solve_regs(int lane, T* sL, T* sK, T* sd, in
   return 0;
 }
 
+// A block on its way from global memory to the work image: CAP x 64 elements in registers (every block of a knot point is fetched
+// before the first is stored: one round trip for the knot point instead of one per block); what is past that is copied at the point of use
+template <typename T, int CAP>
+__device__ __forceinline__ void reg_fetch(T (&v)[CAP], const T* src, int count, int lane) {
+#pragma unroll
+  for (int c = 0; c < CAP; ++c) {
+    const int e = lane + 64 * c;
+    v[c] = e < count ? src[e] : T(0);
+  }
+}
+template <typename T, int CAP>
+__device__ __forceinline__ void reg_put(T* dst, const T (&v)[CAP], const T* src, int count, int lane) {
+#pragma unroll
+  for (int c = 0; c < CAP; ++c) {
+    const int e = lane + 64 * c;
+    if (e < count) dst[e] = v[c];
+  }
+  if (count > 64 * CAP) wave_copy(lane, dst + 64 * CAP, src + 64 * CAP, count - 64 * CAP);
+}
+
 // BIG = false: the knot point's blocks live in LDS (what fits 64 KB: n, m up to ~32 in fp64).  BIG = true: the same code on a
 // per-problem work block in GLOBAL memory (args.ws) -- any dimensions, as the reference takes them (tvlqr.cpp:92-121 sizes every
 // block from nx[k], nu[k]); slow (every operand is a cached global load), which is the point: refusing n = 33 is worse.  A workgroup
 // is one wave and __syncthreads() orders its global accesses at workgroup scope, so the phases stay as they are.
 template <typename T, bool BIG = false, bool MF = false>
-__global__ __launch_bounds__(64, (MF && !BIG) ? 4 : 1) void generic_backward_kernel(GenericArgs<T> a) {   // (MF in LDS: 128 registers, four waves per SIMD -- 4096 problems resident)
+__global__ __launch_bounds__(64, BIG ? 1 : 4) void generic_backward_kernel(GenericArgs<T> a) {   // (in LDS: 128 registers, four waves per SIMD -- 4096 problems resident)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int lane = threadIdx.x;
   const int b = blockIdx.x;
@@ -350,24 +370,46 @@ __global__ __launch_bounds__(64, (MF && !BIG) ? 4 : 1) void generic_backward_ker
 
   for (int k = N - 1; k >= 0; --k) {
     const int n = a.nx[k], m = a.nu[k], n2 = a.nx[k + 1];
-    // stage the knot point
-    wave_copy(lane, sA, (const T*)GPTR(G_A, k), n2 * n);
-    wave_copy(lane, sB, (const T*)GPTR(G_B, k), n2 * m);
-    if (a.no_f) { for (int e = lane; e < n2; e += 64) sf[e] = T(0); }   // the iLQR loop's expansion carries no affine term (knotpoint_data.cpp:416)
-    else wave_copy(lane, sf, (const T*)GPTR(G_f, k), n2);
-    if (a.is_diag) {  // tvlqr.cpp:125-128
-      const T* Qd = GPTR(G_Q, k);
-      const T* Rd = GPTR(G_R, k);
-      for (int e = lane; e < n * n; e += 64) sQxx[e] = (e % n == e / n) ? Qd[e % n] : T(0);
-      for (int e = lane; e < m * m; e += 64) sQuu[e] = (e % m == e / m) ? Rd[e % m] : T(0);
-      for (int e = lane; e < m * n; e += 64) sQux[e] = T(0);
-    } else {  // tvlqr.cpp:129-133
-      wave_copy(lane, sQxx, (const T*)GPTR(G_Q, k), n * n);
-      wave_copy(lane, sQuu, (const T*)GPTR(G_R, k), m * m);
-      wave_copy(lane, sQux, (const T*)GPTR(G_H, k), m * n);
+    // stage the knot point: all its blocks fetched, then all stored (a lone wave otherwise waits a global round trip per block: 5-8
+    // thousand cycles of 37 per knot point at (13, 4), 17 of 57 with 4096 waves in flight)
+    {   // (two batches: all eight at once is one round trip less but 32 registers more than the rest of the kernel needs -- three waves per SIMD)
+      T rA[4], rB[2], rf[1], rq[1], rr[1];
+      const T *gA = GPTR(G_A, k), *gB = GPTR(G_B, k), *gf = GPTR(G_f, k), *gq = GPTR(G_q, k), *gr = GPTR(G_r, k);
+      reg_fetch<T, 4>(rA, gA, n2 * n, lane);
+      reg_fetch<T, 2>(rB, gB, n2 * m, lane);
+      if (!a.no_f) reg_fetch<T, 1>(rf, gf, n2, lane);
+      reg_fetch<T, 1>(rq, gq, n, lane);
+      reg_fetch<T, 1>(rr, gr, m, lane);
+      reg_put<T, 4>(sA, rA, gA, n2 * n, lane);
+      reg_put<T, 2>(sB, rB, gB, n2 * m, lane);
+      if (a.no_f) { for (int e = lane; e < n2; e += 64) sf[e] = T(0); }   // the iLQR loop's expansion carries no affine term (knotpoint_data.cpp:416)
+      else reg_put<T, 1>(sf, rf, gf, n2, lane);
+      reg_put<T, 1>(sQx, rq, gq, n, lane);
+      reg_put<T, 1>(sQu, rr, gr, m, lane);
     }
-    wave_copy(lane, sQx, (const T*)GPTR(G_q, k), n);
-    wave_copy(lane, sQu, (const T*)GPTR(G_r, k), m);
+    {
+      T rQ[4], rR[1], rH[2];
+      const T *gQ = GPTR(G_Q, k), *gR = GPTR(G_R, k), *gH = GPTR(G_H, k);
+      const int cQ = a.is_diag ? n : n * n, cR = a.is_diag ? m : m * m;
+      reg_fetch<T, 4>(rQ, gQ, cQ, lane);
+      reg_fetch<T, 1>(rR, gR, cR, lane);
+      if (!a.is_diag) reg_fetch<T, 2>(rH, gH, m * n, lane);
+      if (a.is_diag) {  // tvlqr.cpp:125-128: the diagonals through the scratch blocks, then spread
+        reg_put<T, 4>(sT1, rQ, gQ, n, lane);
+        reg_put<T, 1>(sT2, rR, gR, m, lane);
+      } else {  // tvlqr.cpp:129-133
+        reg_put<T, 4>(sQxx, rQ, gQ, n * n, lane);
+        reg_put<T, 1>(sQuu, rR, gR, m * m, lane);
+        reg_put<T, 2>(sQux, rH, gH, m * n, lane);
+      }
+    }
+    if (a.is_diag) {
+      __syncthreads();
+      const float rn = __builtin_amdgcn_rcpf((float)n), rmf = __builtin_amdgcn_rcpf((float)(m > 0 ? m : 1));
+      for (int e = lane; e < n * n; e += 64) { int i, j; split_index(e, n, rn, i, j); sQxx[e] = (i == j) ? sT1[i] : T(0); }
+      for (int e = lane; e < m * m; e += 64) { int i, j; split_index(e, m, rmf, i, j); sQuu[e] = (i == j) ? sT2[i] : T(0); }
+      for (int e = lane; e < m * n; e += 64) sQux[e] = T(0);
+    }
     __syncthreads();
     // Qxx_tmp = A^T P' ; Qux_tmp = B^T P' ; Qx_tmp = p' + P' f     (tvlqr.cpp:135,139,147-148)
     wave_gemm_sel<T, MF>(lane, 1, 0, n, n2, n2, T(1), sA, n2, sP, n2, T(0), sT1, n);
@@ -498,25 +540,6 @@ __device__ __forceinline__ T gen_row_dot(const T* M, int ld, const T* v, int cnt
   }
   for (; j < cnt; ++j) s += M[j * ld] * v[j];
   return s;
-}
-
-// CAP x 64 elements of a block ride in registers from one knot point to the next; what is past that is copied at the point of use
-template <typename T, int CAP>
-__device__ __forceinline__ void reg_fetch(T (&v)[CAP], const T* src, int count, int lane) {
-#pragma unroll
-  for (int c = 0; c < CAP; ++c) {
-    const int e = lane + 64 * c;
-    v[c] = e < count ? src[e] : T(0);
-  }
-}
-template <typename T, int CAP>
-__device__ __forceinline__ void reg_put(T* dst, const T (&v)[CAP], const T* src, int count, int lane) {
-#pragma unroll
-  for (int c = 0; c < CAP; ++c) {
-    const int e = lane + 64 * c;
-    if (e < count) dst[e] = v[c];
-  }
-  if (count > 64 * CAP) wave_copy(lane, dst + 64 * CAP, src + 64 * CAP, count - 64 * CAP);
 }
 
 inline size_t generic_forward_lds_bytes(int nm, int mm, int want_y, size_t esz) {   // STAGE = true
