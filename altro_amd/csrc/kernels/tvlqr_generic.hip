@@ -139,6 +139,54 @@ __device__ __forceinline__ void wave_gemm_sel(int lane, int ta, int tb, int mr, 
   else wave_gemm<T>(lane, ta, tb, mr, nc, kd, alpha, A, lda, B, ldb, beta, C, ldc);
 }
 
+// Two products with the same number of terms and alpha = 1 in ONE pass when their outputs fit the wave together (lanes 0 .. c1-1 the
+// first, c1 .. c1+c2-1 the second): a pass costs a lone wave ~1000 cycles whatever it computes, and a knot point has several products
+// of a dozen outputs.  Each output's sum is wave_gemm's, term by term.  More than 64 outputs together: one after the other.
+template <typename T>
+struct GemmOp { int ta, tb, mr, nc; const T* A; int lda; const T* B; int ldb; T beta; T* C; int ldc; };
+template <typename T>
+__device__ __forceinline__ void wave_gemm_pair(int lane, int kd, const GemmOp<T>& o1, const GemmOp<T>& o2) {
+  const int c1 = o1.mr * o1.nc, c2 = o2.mr * o2.nc;
+  if (c1 + c2 > 64) {
+    wave_gemm<T>(lane, o1.ta, o1.tb, o1.mr, o1.nc, kd, T(1), o1.A, o1.lda, o1.B, o1.ldb, o1.beta, o1.C, o1.ldc);
+    wave_gemm<T>(lane, o2.ta, o2.tb, o2.mr, o2.nc, kd, T(1), o2.A, o2.lda, o2.B, o2.ldb, o2.beta, o2.C, o2.ldc);
+    return;
+  }
+  if (lane >= c1 + c2) return;
+  const bool w2 = lane >= c1;
+  const int e = w2 ? lane - c1 : lane;
+  const int mr = w2 ? o2.mr : o1.mr;
+  int i, j;
+  split_index(e, mr, __builtin_amdgcn_rcpf((float)mr), i, j);
+  const T* pa = w2 ? (o2.ta ? o2.A + i * o2.lda : o2.A + i) : (o1.ta ? o1.A + i * o1.lda : o1.A + i);
+  const T* pb = w2 ? (o2.tb ? o2.B + j : o2.B + j * o2.ldb) : (o1.tb ? o1.B + j : o1.B + j * o1.ldb);
+  const int sa = w2 ? (o2.ta ? 1 : o2.lda) : (o1.ta ? 1 : o1.lda), sb = w2 ? (o2.tb ? o2.ldb : 1) : (o1.tb ? o1.ldb : 1);
+  T* pc = w2 ? o2.C + i + j * o2.ldc : o1.C + i + j * o1.ldc;
+  const T beta = w2 ? o2.beta : o1.beta;
+  T s = T(0);
+  int k = 0;
+  for (; k + 4 <= kd; k += 4) {
+    const T a0 = pa[(k + 0) * sa], a1 = pa[(k + 1) * sa], a2 = pa[(k + 2) * sa], a3 = pa[(k + 3) * sa];
+    const T b0 = pb[(k + 0) * sb], b1 = pb[(k + 1) * sb], b2 = pb[(k + 2) * sb], b3 = pb[(k + 3) * sb];
+    s += a0 * b0;
+    s += a1 * b1;
+    s += a2 * b2;
+    s += a3 * b3;
+  }
+  for (; k < kd; ++k) s += pa[k * sa] * pb[k * sb];
+  const T c0 = (beta == T(0)) ? T(0) : beta * *pc;
+  *pc = c0 + T(1) * s;
+}
+template <typename T, bool MF>
+__device__ __forceinline__ void wave_gemm_pair_sel(int lane, int kd, const GemmOp<T>& o1, const GemmOp<T>& o2) {
+  if constexpr (MF && sizeof(T) == 8) {
+    wave_gemm_mfma(lane, o1.ta, o1.tb, o1.mr, o1.nc, kd, 1.0, o1.A, o1.lda, o1.B, o1.ldb, o1.beta, o1.C, o1.ldc);
+    wave_gemm_mfma(lane, o2.ta, o2.tb, o2.mr, o2.nc, kd, 1.0, o2.A, o2.lda, o2.B, o2.ldb, o2.beta, o2.C, o2.ldc);
+  } else {
+    wave_gemm_pair<T>(lane, kd, o1, o2);
+  }
+}
+
 // dst[0 .. count) <- src: four elements per lane in flight (a copy from global memory pays one round trip per 256 elements, not per 64)
 template <typename T>
 __device__ __forceinline__ void wave_copy(int lane, T* dst, const T* src, int count) {
@@ -416,13 +464,13 @@ __global__ __launch_bounds__(64, BIG ? 1 : 4) void generic_backward_kernel(Gener
     wave_gemm_sel<T, MF>(lane, 1, 0, m, n2, n2, T(1), sB, n2, sP, n2, T(0), sT2, m);
     wave_copy(lane, st, (const T*)sp, n2);
     __syncthreads();
-    wave_gemm_sel<T, MF>(lane, 0, 0, n2, 1, n2, T(1), sP, n2, sf, n2, T(1), st, n2);
+    wave_gemm_pair_sel<T, MF>(lane, n2, GemmOp<T>{0, 0, n2, 1, sP, n2, sf, n2, T(1), st, n2},     // Qx_tmp += P' f
+                              GemmOp<T>{0, 0, m, m, sT2, m, sB, n2, T(1), sQuu, m});        // Quu += Qux_tmp B   (:140)
     wave_gemm_sel<T, MF>(lane, 0, 0, n, n, n2, T(1), sT1, n, sA, n2, T(1), sQxx, n);   // :136
-    wave_gemm_sel<T, MF>(lane, 0, 0, m, m, n2, T(1), sT2, m, sB, n2, T(1), sQuu, m);   // :140
     wave_gemm_sel<T, MF>(lane, 0, 0, m, n, n2, T(1), sT2, m, sA, n2, T(1), sQux, m);   // :143
     __syncthreads();
-    wave_gemm_sel<T, MF>(lane, 1, 0, n, 1, n2, T(1), sA, n2, st, n2, T(1), sQx, n);    // :149-150
-    wave_gemm_sel<T, MF>(lane, 1, 0, m, 1, n2, T(1), sB, n2, st, n2, T(1), sQu, m);    // :151-152
+    wave_gemm_pair_sel<T, MF>(lane, n2, GemmOp<T>{1, 0, n, 1, sA, n2, st, n2, T(1), sQx, n},      // Qx += A^T Qx_tmp   (:149-150)
+                              GemmOp<T>{1, 0, m, 1, sB, n2, st, n2, T(1), sQu, m});       // Qu += B^T Qx_tmp   (:151-152)
     __syncthreads();
     // gains (tvlqr.cpp:155-166)
     wave_copy(lane, sK, (const T*)sQux, m * n);
@@ -460,11 +508,11 @@ __global__ __launch_bounds__(64, BIG ? 1 : 4) void generic_backward_kernel(Gener
       return;
     }
     // cost-to-go (tvlqr.cpp:173-186)
-    wave_gemm_sel<T, MF>(lane, 0, 0, m, n, m, T(1), sQuu, m, sK, m, T(0), sT2, m);  // Qux_tmp = Quu K
+    wave_gemm_pair_sel<T, MF>(lane, m, GemmOp<T>{0, 0, m, n, sQuu, m, sK, m, T(0), sT2, m},       // Qux_tmp = Quu K
+                              GemmOp<T>{0, 0, m, 1, sQuu, m, sd, m, T(0), sw, m});        // Qu_tmp = Quu d     (:189)
     wave_gemm_sel<T, MF>(lane, 1, 0, n, n, m, T(1), sK, m, sQux, m, T(0), sT1, n);  // Qxx_tmp = K^T Qux
     wave_copy(lane, sP, (const T*)sQxx, n * n);         // P_{k+1}, p_{k+1} are dead from here: P_k, p_k are built in their place
     wave_copy(lane, sp, (const T*)sQx, n);
-    wave_gemm_sel<T, MF>(lane, 0, 0, m, 1, m, T(1), sQuu, m, sd, m, T(0), sw, m);   // Qu_tmp = Quu d (:189)
     if (a.store_q == 2) wave_gemm_sel<T, MF>(lane, 1, 0, n, 1, m, T(1), sK, m, sQu, m, T(0), st, n);  // Qx_tmp = K^T Qu (:176)
     __syncthreads();
     wave_gemm_sel<T, MF>(lane, 1, 0, n, n, m, T(1), sT2, m, sK, m, T(1), sP, n);    // P += (Quu K)^T K
@@ -480,11 +528,22 @@ __global__ __launch_bounds__(64, BIG ? 1 : 4) void generic_backward_kernel(Gener
         sP[e] = v;
       }
     }
-    wave_gemm_sel<T, MF>(lane, 1, 0, n, 1, m, T(-1), sT2, m, sd, m, T(1), sp, n);   // p -= (Quu K)^T d
-    __syncthreads();
-    wave_gemm_sel<T, MF>(lane, 1, 0, n, 1, m, T(-1), sK, m, sQu, m, T(1), sp, n);   // p -= K^T Qu
-    __syncthreads();
-    wave_gemm_sel<T, MF>(lane, 1, 0, n, 1, m, T(1), sQux, m, sd, m, T(1), sp, n);   // p += Qux^T d
+    if constexpr (MF && sizeof(T) == 8) {
+      wave_gemm_sel<T, MF>(lane, 1, 0, n, 1, m, T(-1), sT2, m, sd, m, T(1), sp, n);   // p -= (Quu K)^T d
+      __syncthreads();
+      wave_gemm_sel<T, MF>(lane, 1, 0, n, 1, m, T(-1), sK, m, sQu, m, T(1), sp, n);   // p -= K^T Qu
+      __syncthreads();
+      wave_gemm_sel<T, MF>(lane, 1, 0, n, 1, m, T(1), sQux, m, sd, m, T(1), sp, n);   // p += Qux^T d
+    } else {   // the three statements in one pass: a lane owns p_i in all of them, and forms its three sums side by side
+      for (int i = lane; i < n; i += 64) {
+        const T s1 = gen_dot<T>(sT2 + i * m, sd, m), s2 = gen_dot<T>(sK + i * m, sQu, m), s3 = gen_dot<T>(sQux + i * m, sd, m);
+        T v = sp[i];
+        v = T(1) * v + T(-1) * s1;                       // p -= (Quu K)^T d
+        v = T(1) * v + T(-1) * s2;                       // p -= K^T Qu
+        v = T(1) * v + T(1) * s3;                        // p += Qux^T d
+        sp[i] = v;
+      }
+    }
     if (lane == 0) {  // tvlqr.cpp:189-191
       const T s0 = gen_dot<T>(sd, sQu, m), s1 = gen_dot<T>(sd, sw, m);
       dv0 += s0;
