@@ -747,9 +747,9 @@ def test_generic_matrix_core_products_equal_the_exact_ones_to_rounding(n, m, N):
     assert not np.array_equal(out["exact"]["P"], out["mc"]["P"])      # (it IS another summation order)
 
 
-def test_generic_matrix_core_products_failed_factorisation_and_varying_dimensions():
-    """The same flag where the recursion stops (an indefinite R at one knot point: status = that index, like tvlqr.cpp:162-164) and on
-    a handle with per-knot-point dimensions."""
+def test_generic_matrix_core_products_failed_factorisation():
+    """The same flag where the recursion stops (an indefinite R at one knot point: status = that index, like tvlqr.cpp:162-164).
+    (Per-knot-point dimensions: tests/test_gpu_ragged.py.)"""
     N, n, m, batch = 12, 14, 5, 8
     pr = problems.random_ltv(batch, N, n, m)
     R = pr["R"].copy(); R[3, 7] = -np.eye(m).reshape(-1) * 50.0

@@ -124,6 +124,28 @@ def test_sweeps_with_per_knot_point_dimensions_are_bit_identical_to_the_oracle(w
     bt.close()
 
 
+@pytest.mark.parametrize("is_diag", [False, True])
+def test_matrix_core_products_with_per_knot_point_dimensions(is_diag):
+    """ALTRO_HIP_GENERIC_MATRIX_CORES on a handle with per-knot-point dimensions: the tiles are fed zeros past every block's own edges,
+    so the changing shapes need nothing special; equal to the bit-exact form to 1e-12."""
+    nx, nu = DIMS["mixed"]
+    batch = 11
+    p = make(nx, nu, batch, is_diag, seed=333)
+    got = {}
+    for name, flags in (("exact", 0), ("mc", altro_amd.GENERIC_MATRIX_CORES)):
+        bt = altro_amd.Batch.with_dims(nx, nu, batch, flags=flags)
+        bt.set_dynamics(p["A"], p["B"], p["f"])
+        bt.set_cost(p["Q"], p["R"], p["H"], p["q"], p["r"], is_diag=is_diag)
+        bt.set_initial_state(p["x0"])
+        bt.sweep()
+        got[name] = {k: bt.get(k) for k in ("K", "d", "P", "p", "x", "u", "y", "delta_V", "status")}
+        bt.close()
+    assert np.array_equal(got["exact"]["status"], got["mc"]["status"])
+    for k in ("K", "d", "P", "p", "x", "u", "y", "delta_V"):
+        scale = max(1.0, float(np.abs(got["exact"][k]).max()))
+        assert np.abs(got["exact"][k] - got["mc"][k]).max() <= 1e-12 * scale, k
+
+
 def test_fp32_handle_and_shared_problem():
     """fp32 storage (2e-4 relative) and batch_stride_zero (one problem's arrays for the whole batch)"""
     nx, nu = DIMS["mixed"]
