@@ -48,6 +48,54 @@ struct IlqrGenArgs {
 
 #define GOFF(arr, k) (a.off[(int64_t)(k) * G_NUM + (arr)])
 
+// sum_j M[j ld] v[j], j = 0 .. cnt-1, in index order (M: a row or a column of a block in global memory, v in LDS); EIGHT matrix entries
+// are fetched before the first product -- with one load per term a lane waited a global round trip per term, and a knot point's rows
+// are chains of a dozen (the merit pass of plan GENERIC at (13, 4), 4096 problems: 3.6 ms, longer than the backward sweep).
+template <typename T>
+__device__ __forceinline__ double gen_gdot(const T* M, int ld, const double* v, int cnt) {
+  double s = 0.0;
+  int j = 0;
+  for (; j + 8 <= cnt; j += 8) {
+    T mv[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) mv[q] = M[(j + q) * ld];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s += (double)mv[q] * v[j + q];
+  }
+  if (j + 4 <= cnt) {
+    T mv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) mv[q] = M[(j + q) * ld];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s += (double)mv[q] * v[j + q];
+    j += 4;
+  }
+  for (; j < cnt; ++j) s += (double)M[j * ld] * v[j];
+  return s;
+}
+// the same for two vectors at once: s = sum_j M[j ld] v[j], t = sum_j M[j ld] w[j]
+template <typename T>
+__device__ __forceinline__ void gen_gdot2(const T* M, int ld, const double* v, const double* w, int cnt, double& s, double& t) {
+  s = 0.0; t = 0.0;
+  int j = 0;
+  for (; j + 8 <= cnt; j += 8) {
+    T mv[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) mv[q] = M[(j + q) * ld];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const double e = (double)mv[q]; s += e * v[j + q]; t += e * w[j + q]; }
+  }
+  if (j + 4 <= cnt) {
+    T mv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) mv[q] = M[(j + q) * ld];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const double e = (double)mv[q]; s += e * v[j + q]; t += e * w[j + q]; }
+    j += 4;
+  }
+  for (; j < cnt; ++j) { const double e = (double)M[j * ld]; s += e * v[j]; t += e * w[j]; }
+}
+
 __device__ __forceinline__ double gen_wave_sum(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -182,9 +230,7 @@ __global__ __launch_bounds__(64) void generic_rollout_kernel(IlqrGenArgs<T> a) {
     const int i = lane < n2 ? lane : 0;                  // row of x_{k+1} (A_k is n2 x n, B_k n2 x m)
     const T* Ak = a.A + (int64_t)b * a.A_bs + GOFF(G_A, k);
     const T* Bk = a.B + (int64_t)b * a.B_bs + GOFF(G_B, k);
-    double s = 0.0, s2 = 0.0;
-    for (int j = 0; j < n; ++j) s += (double)Ak[i + j * n2] * xs[j];
-    for (int j = 0; j < m; ++j) s2 += (double)Bk[i + j * n2] * us[j];
+    const double s = gen_gdot<T>(Ak + i, n2, xs, n), s2 = gen_gdot<T>(Bk + i, n2, us, m);
     x = (s + s2) + (double)a.f[(int64_t)b * a.f_bs + GOFF(G_f, k) + i];
   }
   if (lane < a.nx[N]) a.x[(int64_t)b * a.x_bs + GOFF(G_x, N) + lane] = (T)x;
@@ -262,7 +308,7 @@ __global__ void generic_expand_kernel(IlqrGenArgs<T> a) {
 // MeritFunction (solver.cpp:273-355): closed-loop rollout with step alpha, total cost phi and -- when asked -- the directional
 // derivative phi' with the refreshed lx, lu.  Lanes 0..31: state rows, lanes 32..63: input rows.
 template <typename T>
-__global__ __launch_bounds__(64) void generic_merit_kernel(IlqrGenArgs<T> a) {
+__global__ __launch_bounds__(64, 4) void generic_merit_kernel(IlqrGenArgs<T> a) {
   __shared__ double xs[GEN_MAX], dxs[GEN_MAX], das[GEN_MAX], us[GEN_MAX], dus[GEN_MAX], jv[GEN_AL_JV];
   const int b = blockIdx.x, lane = threadIdx.x;
   if (a.active && !a.active[b]) return;
@@ -287,8 +333,8 @@ __global__ __launch_bounds__(64) void generic_merit_kernel(IlqrGenArgs<T> a) {
     __syncthreads();
     if (isu) {   // u_ = u + (-K dx + alpha d) ; du_da = -K dx_da + d
       const T* Kk = a.K + (int64_t)b * a.K_bs + GOFF(G_K, k);
-      double s = 0.0, s2 = 0.0;
-      for (int j = 0; j < n; ++j) { const double kj = (double)Kk[iu + j * m]; s += kj * dxs[j]; s2 += kj * das[j]; }
+      double s, s2;
+      gen_gdot2<T>(Kk + iu, m, dxs, das, n, s, s2);
       const double dk = (double)a.d[(int64_t)b * a.d_bs + GOFF(G_d, k) + iu];
       const double uv = (double)a.un[(int64_t)b * a.su + GOFF(G_u, k) + iu] + (-s + alpha * dk);
       us[iu] = uv; dus[iu] = -s2 + dk;
@@ -296,8 +342,7 @@ __global__ __launch_bounds__(64) void generic_merit_kernel(IlqrGenArgs<T> a) {
     }
     if (isx) {   // y_ = P dx + p
       const T* Pk = a.P + (int64_t)b * a.P_bs + GOFF(G_P, k);
-      double s = 0.0;
-      for (int j = 0; j < n; ++j) s += (double)Pk[i + j * n] * dxs[j];
+      const double s = gen_gdot<T>(Pk + i, n, dxs, n);
       a.y[(int64_t)b * a.y_bs + GOFF(G_y, k) + i] = (T)(s + (double)a.p[(int64_t)b * a.p_bs + GOFF(G_p, k) + i]);
     }
     __syncthreads();
@@ -311,9 +356,7 @@ __global__ __launch_bounds__(64) void generic_merit_kernel(IlqrGenArgs<T> a) {
     const T* Rk = a.cR + (int64_t)b * a.sR + GOFF(G_R, k);
     const T* Hk = a.cH + (int64_t)b * a.sH + GOFF(G_H, k);
     if (isx) {   // state row: cost share, lx
-      double qx = 0.0, htu = 0.0;
-      for (int j = 0; j < n; ++j) qx += (double)Qk[i + j * n] * xs[j];
-      for (int j = 0; j < m; ++j) htu += (double)Hk[j + i * m] * us[j];
+      const double qx = gen_gdot<T>(Qk + i, n, xs, n), htu = gen_gdot<T>(Hk + i * m, 1, us, m);
       const double ql = (double)a.cq[(int64_t)b * a.sx + GOFF(G_q, k) + i];
       J += x * (0.5 * qx + ql);
       if (lane == 0) J += (double)a.cc[(int64_t)b * (N + 1) + k];
@@ -325,16 +368,14 @@ __global__ __launch_bounds__(64) void generic_merit_kernel(IlqrGenArgs<T> a) {
     if (lane < n2) {   // row of the next state: A_k is n2 x n, B_k n2 x m
       const T* Ak = a.A + (int64_t)b * a.A_bs + GOFF(G_A, k);
       const T* Bk = a.B + (int64_t)b * a.B_bs + GOFF(G_B, k);
-      double s = 0.0, s2 = 0.0, t = 0.0, t2 = 0.0;
-      for (int j = 0; j < n; ++j) { const double aj = (double)Ak[lane + j * n2]; s += aj * xs[j]; t += aj * das[j]; }
-      for (int j = 0; j < m; ++j) { const double bj = (double)Bk[lane + j * n2]; s2 += bj * us[j]; t2 += bj * dus[j]; }
+      double s, s2, t, t2;
+      gen_gdot2<T>(Ak + lane, n2, xs, das, n, s, t);
+      gen_gdot2<T>(Bk + lane, n2, us, dus, m, s2, t2);
       xn = (s + s2) + (double)a.f[(int64_t)b * a.f_bs + GOFF(G_f, k) + lane];
       dxn = t + t2;
     }
     if (isu) {   // input row: cost share (with the cross term u'Hx), lu
-      double ru = 0.0, hx = 0.0;
-      for (int j = 0; j < m; ++j) ru += (double)Rk[iu + j * m] * us[j];
-      for (int j = 0; j < n; ++j) hx += (double)Hk[iu + j * m] * xs[j];
+      const double ru = gen_gdot<T>(Rk + iu, m, us, m), hx = gen_gdot<T>(Hk + iu, m, xs, n);
       const double rl = (double)a.cr[(int64_t)b * a.su + GOFF(G_r, k) + iu];
       const double uv = us[iu];
       J += uv * ((0.5 * ru + rl) + hx);
@@ -358,8 +399,7 @@ __global__ __launch_bounds__(64) void generic_merit_kernel(IlqrGenArgs<T> a) {
     if (isx) {
       const T* Qk = a.cQ + (int64_t)b * a.sQ + GOFF(G_Q, N);
       const T* Pk = a.P + (int64_t)b * a.P_bs + GOFF(G_P, N);
-      double qx = 0.0, s = 0.0;
-      for (int j = 0; j < n; ++j) { qx += (double)Qk[i + j * n] * xs[j]; s += (double)Pk[i + j * n] * dxs[j]; }
+      const double qx = gen_gdot<T>(Qk + i, n, xs, n), s = gen_gdot<T>(Pk + i, n, dxs, n);
       const double ql = (double)a.cq[(int64_t)b * a.sx + GOFF(G_q, N) + i];
       J += x * (0.5 * qx + ql);
       if (lane == 0) J += (double)a.cc[(int64_t)b * (N + 1) + N];
@@ -395,14 +435,12 @@ __global__ __launch_bounds__(64) void generic_stationarity_kernel(IlqrGenArgs<T>
     __syncthreads();
     if (isx) {
       const T* Ak = a.A + (int64_t)b * a.A_bs + GOFF(G_A, k);
-      double s = 0.0;
-      for (int i = 0; i < n2; ++i) s += (double)Ak[i + j * n2] * yn[i];
+      const double s = gen_gdot<T>(Ak + j * n2, 1, yn, n2);
       res = fmax(res, fabs(((double)a.q[(int64_t)b * a.q_bs + GOFF(G_q, k) + j] + s) - (double)a.y[(int64_t)b * a.y_bs + GOFF(G_y, k) + j]));
     }
     if (isu) {
       const T* Bk = a.B + (int64_t)b * a.B_bs + GOFF(G_B, k);
-      double s = 0.0;
-      for (int i = 0; i < n2; ++i) s += (double)Bk[i + ju * n2] * yn[i];
+      const double s = gen_gdot<T>(Bk + ju * n2, 1, yn, n2);
       res = fmax(res, fabs((double)a.r[(int64_t)b * a.r_bs + GOFF(G_r, k) + ju] + s));
     }
   }
@@ -455,26 +493,18 @@ __global__ __launch_bounds__(64) void generic_expand_al_kernel(IlqrGenArgs<T> a)
   if (grad) {
     if (lane < n) {
       const int e = lane;
-      double s = 0.0;
-      for (int j = 0; j < n; ++j) s += (double)Qk[e + j * n] * xs[j];
+      double s = gen_gdot<T>(Qk + e, n, xs, n);
       s += (double)a.cq[(int64_t)b * a.sx + GOFF(G_q, k) + e];
-      if (!terminal) {
-        double t2 = 0.0;
-        for (int i = 0; i < m; ++i) t2 += (double)Hk[i + e * m] * us[i];
-        s += t2;
-      }
+      if (!terminal) s += gen_gdot<T>(Hk + e * m, 1, us, m);
       s -= gen_al_col<T>(a.al, k, e, jv);
       a.q[(int64_t)b * a.q_bs + GOFF(G_q, k) + e] = (T)s;
     }
     const int ub = GEN_UBASE(a);
     if (!terminal && lane >= ub && lane - ub < m) {
       const int i = lane - ub;
-      double s = 0.0;
-      for (int j = 0; j < m; ++j) s += (double)Rk[i + j * m] * us[j];
+      double s = gen_gdot<T>(Rk + i, m, us, m);
       s += (double)a.cr[(int64_t)b * a.su + GOFF(G_r, k) + i];
-      double t2 = 0.0;
-      for (int j = 0; j < n; ++j) t2 += (double)Hk[i + j * m] * xs[j];
-      s += t2;
+      s += gen_gdot<T>(Hk + i, m, xs, n);
       s -= gen_al_col<T>(a.al, k, n + i, jv);
       a.r[(int64_t)b * a.r_bs + GOFF(G_r, k) + i] = (T)s;
     }
