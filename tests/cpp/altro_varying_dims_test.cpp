@@ -3,7 +3,9 @@
 // way a user of the reference would -- one SetDimension / SetExplicitDynamics / SetQuadraticCost per knot point.  Every backward
 // sweep runs on the GPU through tvlqr_BackwardPass with the nx[k], nu[k] the reference hands it (tvlqr.cpp:65-248).
 //
-//   altro_varying_dims_test.bin <problem.txt>
+//   altro_varying_dims_test.bin <problem.txt> [constrained]
+// constrained: |u_i| <= 0.25 where the input has three entries, u_0 <= 0.1 where it has one (INEQUALITY blocks, SetConstraint per knot
+// point with that knot point's own n + m columns), x_N[0] = 0.3 and x_N[2] = -0.2 (an EQUALITY block at the terminal knot point).
 // problem.txt: N, then nx[0..N], nu[0..N-1], then per k < N: A_k (nx[k+1] x nx[k] column-major), B_k, f_k, R_k, H_k (nu x nx), r_k;
 // per k <= N: Q_k, q_k, c_k; then x0 and u0_k.  Prints: status, iterations, then x_0 .. x_N and u_0 .. u_(N-1), one value per token.
 // tests/test_gpu_ragged_ilqr.py compares them with the batched ABI on the same problem and with the oracle on the padded one.
@@ -78,6 +80,31 @@ int main(int argc, char** argv) {
     std::vector<double> Rn((size_t)m * m, 0.0), Hn((size_t)m * n, 0.0), rn(m, 0.0);
     for (int i = 0; i < m; ++i) Rn[i + i * m] = 1.0;
     ok(solver.SetQuadraticCost(n, m, Q[N].data(), Rn.data(), Hn.data(), q[N].data(), rn.data(), c[N], N));
+  }
+  const bool constrained = argc > 2;
+  if (constrained) {
+    for (int k = 0; k < N; ++k) {
+      const int n = nx[k], m = nu[k];
+      if (m == 3) {
+        auto con = [n](a_float* c, const a_float*, const a_float* u) { for (int i = 0; i < 3; ++i) { c[i] = u[i] - 0.25; c[3 + i] = -u[i] - 0.25; } };
+        auto jac = [n](a_float* J, const a_float*, const a_float*) {     // 6 x (n + 3) column-major
+          for (int e = 0; e < 6 * (n + 3); ++e) J[e] = 0.0;
+          for (int i = 0; i < 3; ++i) { J[i + (n + i) * 6] = 1.0; J[3 + i + (n + i) * 6] = -1.0; }
+        };
+        ok(solver.SetConstraint(con, jac, 6, ConstraintType::INEQUALITY, "input box", k));
+      } else if (m == 1) {
+        auto con = [](a_float* c, const a_float*, const a_float* u) { c[0] = u[0] - 0.1; };
+        auto jac = [n](a_float* J, const a_float*, const a_float*) { for (int e = 0; e < n + 1; ++e) J[e] = 0.0; J[n] = 1.0; };
+        ok(solver.SetConstraint(con, jac, 1, ConstraintType::INEQUALITY, "input bound", k));
+      }
+    }
+    const int n = nx[N], m = nu[N - 1];
+    auto con = [](a_float* c, const a_float* x, const a_float*) { c[0] = x[0] - 0.3; c[1] = x[2] + 0.2; };
+    auto jac = [n, m](a_float* J, const a_float*, const a_float*) {       // 2 x (n + m) column-major
+      for (int e = 0; e < 2 * (n + m); ++e) J[e] = 0.0;
+      J[0 + 0 * 2] = 1.0; J[1 + 2 * 2] = 1.0;
+    };
+    ok(solver.SetConstraint(con, jac, 2, ConstraintType::EQUALITY, "goal", N));
   }
   ok(solver.SetInitialState(x0.data(), nx[0]));
   ok(solver.Initialize());
