@@ -243,3 +243,34 @@ def test_input_guess_before_the_cost_is_kept(dense):
     assert np.array_equal(ra["iterations"], rb["iterations"])
     xa, ua = a.get_nominal(); xb, ub = b.get_nominal()
     np.testing.assert_array_equal(xa, xb); np.testing.assert_array_equal(ua, ub)
+
+
+def test_whole_solves_with_the_matrix_core_products():
+    """ALTRO_HIP_GENERIC_MATRIX_CORES through the iLQR loop (unconstrained LQ problems: one exact step): statuses and iterations of the
+    bit-exact form, trajectories to 1e-10; a constrained problem converges to the same solution (1e-6), whatever path it takes."""
+    N, n, m, batch = 18, 20, 7, 9
+    p = problems.ilqr12x4_problem(batch, N, True, n=n, m=m)
+    p.update(problems.quadratic_cost(batch, N, n, m))
+    out = {}
+    for name, flags in (("exact", 0), ("mc", altro_amd.GENERIC_MATRIX_CORES)):
+        for constrained in (False, True):
+            bt = altro_amd.Batch(N, n, m, batch, plan=altro_amd.PLAN_GENERIC, flags=flags)
+            bt.set_dynamics(p["A"], p["B"], p["f"])
+            bt.set_quadratic_cost(p["Q"], p["R"], p["H"], p["q"], p["r"], p["c"])
+            bt.set_initial_state(p["x0"]); bt.set_input_guess(p["u0"])
+            if constrained:
+                G = np.zeros((2 * m, n + m)); G[:m, n:] = np.eye(m); G[m:, n:] = -np.eye(m)
+                bt.add_linear_constraint(0, N - 1, altro_amd.CONE_INEQUALITY, G, np.full(2 * m, 0.3))
+            res = bt.ilqr_solve(iterations_max=60, tol_stationarity=1e-5, penalty_initial=1.0, penalty_scaling=10.0)
+            out[(name, constrained)] = (res, bt.get_nominal())
+            bt.close()
+    (re, (xe, ue)), (rm, (xm, um)) = out[("exact", False)], out[("mc", False)]
+    assert (re["status"] == 0).all() and np.array_equal(re["status"], rm["status"]) and np.array_equal(re["iterations"], rm["iterations"])
+    np.testing.assert_allclose(xm, xe, rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(um, ue, rtol=1e-9, atol=1e-9)
+    (re, (xe, ue)), (rm, (xm, um)) = out[("exact", True)], out[("mc", True)]
+    both = (re["status"] == 0) & (rm["status"] == 0)             # (one of the nine runs out of iterations in either form)
+    assert both.sum() >= batch - 2 and (re["status"] == 0).sum() == (rm["status"] == 0).sum()
+    np.testing.assert_allclose(xm[both], xe[both], rtol=0, atol=2e-4)   # (both within the solver's tolerances of one solution)
+    np.testing.assert_allclose(um[both], ue[both], rtol=0, atol=2e-3)
+    assert np.abs(um[both]).max() <= 0.3 + 2e-4
