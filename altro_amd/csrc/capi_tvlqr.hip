@@ -187,25 +187,39 @@ int launch_backward(altro_hip_batch* h, double reg) {
   } else if (h->plan == ALTRO_HIP_PLAN_LANE) {
     return h->dtype == ALTRO_HIP_F64 ? lane_launch<double>(h, true, reg) : lane_launch<float>(h, true, reg);
   } else {
-    // blocks beyond 64 KB of LDS per problem (n, m past ~32 in fp64): the same kernel on a per-problem work block in global memory
-    const size_t lds = h->dtype == ALTRO_HIP_F64 ? generic_backward_lds_bytes<double>(h->n, h->m) : generic_backward_lds_bytes<float>(h->n, h->m);
+    // the knot point's blocks in LDS while they fit; the form without a block for Qxx ("late Q", 3 n^2 instead of 4 n^2 elements) where
+    // that keeps more problems on a CU than the batch otherwise gets, or keeps the blocks in LDS at all; past that the same kernel on a
+    // per-problem work block in global memory (n, m beyond ~37 in fp64)
+    const bool f64 = h->dtype == ALTRO_HIP_F64;
+    const size_t lds4 = f64 ? generic_backward_lds_bytes<double>(h->n, h->m) : generic_backward_lds_bytes<float>(h->n, h->m);
+    const size_t lds3 = f64 ? generic_backward_lds_bytes<double>(h->n, h->m, true) : generic_backward_lds_bytes<float>(h->n, h->m, true);
+    const auto per_cu = [](size_t lds) { return (int)std::min<size_t>(16, (160 * 1024) / std::max<size_t>(lds, 1)); };   // (16: four waves per SIMD by registers)
+    const int cus = 256;
+    bool late_q = lds4 > kGenericLdsLimit ? lds3 <= kGenericLdsLimit
+                                          : (per_cu(lds3) > per_cu(lds4) && (int64_t)h->batch > (int64_t)cus * per_cu(lds4));
+    if (std::getenv("ALTRO_HIP_GENERIC_LATE_Q")) late_q = std::atoi(std::getenv("ALTRO_HIP_GENERIC_LATE_Q")) != 0 && lds3 <= kGenericLdsLimit;
+    const size_t lds = late_q ? lds3 : lds4;
     const bool big = lds > kGenericLdsLimit;
     if (big && !h->g_ws) {
       int rc = dmalloc(h, &h->g_ws, (size_t)h->batch * ((lds + 15) / 16 * 16));
       if (rc) return rc;
     }
-    if (h->dtype == ALTRO_HIP_F64) {
+    if (f64) {
       auto a = generic_args<double>(h, reg);
       a.ws = (double*)h->g_ws; a.ws_stride = (int64_t)((lds + 15) / 16 * 16 / sizeof(double));
-      if (h->g_mfma) {   // the products on the matrix cores (ALTRO_HIP_GENERIC_MATRIX_CORES; plan AUTO's choice for shapes past the tile)
-        if (big) PROF_LAUNCH((generic_backward_kernel<double, true, true>), dim3(h->batch), dim3(64), 0, h->stream, a);
-        else PROF_LAUNCH((generic_backward_kernel<double, false, true>), dim3(h->batch), dim3(64), lds, h->stream, a);
-      } else if (big) PROF_LAUNCH((generic_backward_kernel<double, true>), dim3(h->batch), dim3(64), 0, h->stream, a);
-      else PROF_LAUNCH((generic_backward_kernel<double, false>), dim3(h->batch), dim3(64), lds, h->stream, a);
+      const dim3 grid(h->batch), blk(64);
+      if (h->g_mfma) {   // the products on the matrix cores (ALTRO_HIP_GENERIC_MATRIX_CORES)
+        if (big) PROF_LAUNCH((generic_backward_kernel<double, true, true>), grid, blk, 0, h->stream, a);
+        else if (late_q) PROF_LAUNCH((generic_backward_kernel<double, false, true, true>), grid, blk, lds, h->stream, a);
+        else PROF_LAUNCH((generic_backward_kernel<double, false, true>), grid, blk, lds, h->stream, a);
+      } else if (big) PROF_LAUNCH((generic_backward_kernel<double, true>), grid, blk, 0, h->stream, a);
+      else if (late_q) PROF_LAUNCH((generic_backward_kernel<double, false, false, true>), grid, blk, lds, h->stream, a);
+      else PROF_LAUNCH((generic_backward_kernel<double, false>), grid, blk, lds, h->stream, a);
     } else {
       auto a = generic_args<float>(h, reg);
       a.ws = (float*)h->g_ws; a.ws_stride = (int64_t)((lds + 15) / 16 * 16 / sizeof(float));
       if (big) PROF_LAUNCH((generic_backward_kernel<float, true>), dim3(h->batch), dim3(64), 0, h->stream, a);
+      else if (late_q) PROF_LAUNCH((generic_backward_kernel<float, false, false, true>), dim3(h->batch), dim3(64), lds, h->stream, a);
       else PROF_LAUNCH((generic_backward_kernel<float, false>), dim3(h->batch), dim3(64), lds, h->stream, a);
     }
   }

@@ -370,7 +370,10 @@ __device__ __forceinline__ void reg_put(T* dst, const T (&v)[CAP], const T* src,
 // per-problem work block in GLOBAL memory (args.ws) -- any dimensions, as the reference takes them (tvlqr.cpp:92-121 sizes every
 // block from nx[k], nu[k]); slow (every operand is a cached global load), which is the point: refusing n = 33 is worse.  A workgroup
 // is one wave and __syncthreads() orders its global accesses at workgroup scope, so the phases stay as they are.
-template <typename T, bool BIG = false, bool MF = false>
+// LQ ("late Q"): Qxx has no block of its own -- Q_k is brought in AFTER the products with P' (which then includes Qx_tmp += P' f), into
+// the block P' leaves, and Qxx, then P_k, are built there: 3 n^2 + .. elements instead of 4 n^2 + .., for the shapes and batches where
+// that puts more problems on a CU (the launch decides; same sums, one global round trip in the middle of the knot point).
+template <typename T, bool BIG = false, bool MF = false, bool LQ = false>
 __global__ __launch_bounds__(64, BIG ? 1 : 4) void generic_backward_kernel(GenericArgs<T> a) {   // (in LDS: 128 registers, four waves per SIMD -- 4096 problems resident)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int lane = threadIdx.x;
@@ -384,8 +387,8 @@ __global__ __launch_bounds__(64, BIG ? 1 : 4) void generic_backward_kernel(Gener
   T* sA = sp + nm;              // A_k         nm*nm
   T* sB = sA + nm * nm;         // B_k         nm*mm
   T* sf = sB + nm * mm;         // f_k         nm
-  T* sQxx = sf + nm;            // nm*nm
-  T* sQuu = sQxx + nm * nm;     // mm*mm
+  T* sQxx = LQ ? sP : sf + nm;  // nm*nm (LQ: the block of P')
+  T* sQuu = LQ ? sf + nm : sQxx + nm * nm;     // mm*mm
   T* sQux = sQuu + mm * mm;     // mm*nm
   T* sQx = sQux + mm * nm;      // nm
   T* sQu = sQx + nm;            // mm
@@ -439,14 +442,14 @@ __global__ __launch_bounds__(64, BIG ? 1 : 4) void generic_backward_kernel(Gener
       T rQ[4], rR[1], rH[2];
       const T *gQ = GPTR(G_Q, k), *gR = GPTR(G_R, k), *gH = GPTR(G_H, k);
       const int cQ = a.is_diag ? n : n * n, cR = a.is_diag ? m : m * m;
-      reg_fetch<T, 4>(rQ, gQ, cQ, lane);
+      if (!LQ || a.is_diag) reg_fetch<T, 4>(rQ, gQ, cQ, lane);
       reg_fetch<T, 1>(rR, gR, cR, lane);
       if (!a.is_diag) reg_fetch<T, 2>(rH, gH, m * n, lane);
-      if (a.is_diag) {  // tvlqr.cpp:125-128: the diagonals through the scratch blocks, then spread
-        reg_put<T, 4>(sT1, rQ, gQ, n, lane);
+      if (a.is_diag) {  // tvlqr.cpp:125-128: the diagonals through scratch blocks, then spread (LQ: Q's waits in K's block)
+        reg_put<T, 4>(LQ ? sK : sT1, rQ, gQ, n, lane);
         reg_put<T, 1>(sT2, rR, gR, m, lane);
       } else {  // tvlqr.cpp:129-133
-        reg_put<T, 4>(sQxx, rQ, gQ, n * n, lane);
+        if (!LQ) reg_put<T, 4>(sQxx, rQ, gQ, n * n, lane);
         reg_put<T, 1>(sQuu, rR, gR, m * m, lane);
         reg_put<T, 2>(sQux, rH, gH, m * n, lane);
       }
@@ -454,7 +457,8 @@ __global__ __launch_bounds__(64, BIG ? 1 : 4) void generic_backward_kernel(Gener
     if (a.is_diag) {
       __syncthreads();
       const float rn = __builtin_amdgcn_rcpf((float)n), rmf = __builtin_amdgcn_rcpf((float)(m > 0 ? m : 1));
-      for (int e = lane; e < n * n; e += 64) { int i, j; split_index(e, n, rn, i, j); sQxx[e] = (i == j) ? sT1[i] : T(0); }
+      if (!LQ)
+        for (int e = lane; e < n * n; e += 64) { int i, j; split_index(e, n, rn, i, j); sQxx[e] = (i == j) ? sT1[i] : T(0); }
       for (int e = lane; e < m * m; e += 64) { int i, j; split_index(e, m, rmf, i, j); sQuu[e] = (i == j) ? sT2[i] : T(0); }
       for (int e = lane; e < m * n; e += 64) sQux[e] = T(0);
     }
@@ -463,12 +467,26 @@ __global__ __launch_bounds__(64, BIG ? 1 : 4) void generic_backward_kernel(Gener
     wave_gemm_sel<T, MF>(lane, 1, 0, n, n2, n2, T(1), sA, n2, sP, n2, T(0), sT1, n);
     wave_gemm_sel<T, MF>(lane, 1, 0, m, n2, n2, T(1), sB, n2, sP, n2, T(0), sT2, m);
     wave_copy(lane, st, (const T*)sp, n2);
+    if (LQ) {   // the last use of P': Qx_tmp += P' f; then Q_k into its block
+      __syncthreads();
+      wave_gemm_sel<T, MF>(lane, 0, 0, n2, 1, n2, T(1), sP, n2, sf, n2, T(1), st, n2);
+      __syncthreads();
+      if (a.is_diag) {
+        const float rn = __builtin_amdgcn_rcpf((float)n);
+        for (int e = lane; e < n * n; e += 64) { int i, j; split_index(e, n, rn, i, j); sQxx[e] = (i == j) ? sK[i] : T(0); }
+      } else {
+        wave_copy(lane, sQxx, (const T*)GPTR(G_Q, k), n * n);
+      }
+    }
     __syncthreads();
+    if (LQ) wave_gemm_sel<T, MF>(lane, 0, 0, m, m, n2, T(1), sT2, m, sB, n2, T(1), sQuu, m);        // Quu += Qux_tmp B   (:140)
+    else
     wave_gemm_pair_sel<T, MF>(lane, n2, GemmOp<T>{0, 0, n2, 1, sP, n2, sf, n2, T(1), st, n2},     // Qx_tmp += P' f
                               GemmOp<T>{0, 0, m, m, sT2, m, sB, n2, T(1), sQuu, m});        // Quu += Qux_tmp B   (:140)
     wave_gemm_sel<T, MF>(lane, 0, 0, n, n, n2, T(1), sT1, n, sA, n2, T(1), sQxx, n);   // :136
     wave_gemm_sel<T, MF>(lane, 0, 0, m, n, n2, T(1), sT2, m, sA, n2, T(1), sQux, m);   // :143
     __syncthreads();
+    if (LQ && a.store_q) wave_copy(lane, GPTR(G_Qxx, k), (const T*)sQxx, n * n);   // (Qxx goes out now: P_k is built over it)
     wave_gemm_pair_sel<T, MF>(lane, n2, GemmOp<T>{1, 0, n, 1, sA, n2, st, n2, T(1), sQx, n},      // Qx += A^T Qx_tmp   (:149-150)
                               GemmOp<T>{1, 0, m, 1, sB, n2, st, n2, T(1), sQu, m});       // Qu += B^T Qx_tmp   (:151-152)
     __syncthreads();
@@ -488,7 +506,7 @@ __global__ __launch_bounds__(64, BIG ? 1 : 4) void generic_backward_kernel(Gener
       wave_copy(lane, GPTR(G_K, k), (const T*)sK, m * n);
       wave_copy(lane, GPTR(G_d, k), (const T*)sd, m);
       if (a.store_q) {
-        wave_copy(lane, GPTR(G_Qxx, k), (const T*)sQxx, n * n);
+        if (!LQ) wave_copy(lane, GPTR(G_Qxx, k), (const T*)sQxx, n * n);
         wave_copy(lane, GPTR(G_Quu, k), (const T*)sQuu, m * m);
         wave_copy(lane, GPTR(G_Qux, k), (const T*)sQux, m * n);
         wave_copy(lane, GPTR(G_Qx, k), (const T*)sQx, n);
@@ -511,7 +529,7 @@ __global__ __launch_bounds__(64, BIG ? 1 : 4) void generic_backward_kernel(Gener
     wave_gemm_pair_sel<T, MF>(lane, m, GemmOp<T>{0, 0, m, n, sQuu, m, sK, m, T(0), sT2, m},       // Qux_tmp = Quu K
                               GemmOp<T>{0, 0, m, 1, sQuu, m, sd, m, T(0), sw, m});        // Qu_tmp = Quu d     (:189)
     wave_gemm_sel<T, MF>(lane, 1, 0, n, n, m, T(1), sK, m, sQux, m, T(0), sT1, n);  // Qxx_tmp = K^T Qux
-    wave_copy(lane, sP, (const T*)sQxx, n * n);         // P_{k+1}, p_{k+1} are dead from here: P_k, p_k are built in their place
+    if (!LQ) wave_copy(lane, sP, (const T*)sQxx, n * n);   // P_{k+1}, p_{k+1} are dead from here: P_k, p_k are built in their place
     wave_copy(lane, sp, (const T*)sQx, n);
     if (a.store_q == 2) wave_gemm_sel<T, MF>(lane, 1, 0, n, 1, m, T(1), sK, m, sQu, m, T(0), st, n);  // Qx_tmp = K^T Qu (:176)
     __syncthreads();
@@ -556,7 +574,7 @@ __global__ __launch_bounds__(64, BIG ? 1 : 4) void generic_backward_kernel(Gener
     wave_copy(lane, GPTR(G_P, k), (const T*)sP, n * n);
     wave_copy(lane, GPTR(G_p, k), (const T*)sp, n);
     if (a.store_q) {
-      wave_copy(lane, GPTR(G_Qxx, k), (const T*)sQxx, n * n);
+      if (!LQ) wave_copy(lane, GPTR(G_Qxx, k), (const T*)sQxx, n * n);
       wave_copy(lane, GPTR(G_Quu, k), (const T*)sQuu, m * m);
       wave_copy(lane, GPTR(G_Qux, k), (const T*)sQux, m * n);
       wave_copy(lane, GPTR(G_Qx, k), (const T*)sQx, n);
@@ -579,8 +597,8 @@ __global__ __launch_bounds__(64, BIG ? 1 : 4) void generic_backward_kernel(Gener
 }
 
 template <typename T>
-inline size_t generic_backward_lds_bytes(int nm, int mm) {
-  size_t el = (size_t)4 * nm * nm + (size_t)4 * nm * mm + (size_t)2 * mm * mm + (size_t)5 * nm + (size_t)3 * mm;   // (the carve of generic_backward_kernel)
+inline size_t generic_backward_lds_bytes(int nm, int mm, bool late_q = false) {
+  size_t el = (size_t)(late_q ? 3 : 4) * nm * nm + (size_t)4 * nm * mm + (size_t)2 * mm * mm + (size_t)5 * nm + (size_t)3 * mm;   // (the carve of generic_backward_kernel)
   return el * sizeof(T) + 64;
 }
 
