@@ -434,8 +434,12 @@ int tvlqr_BackwardPass(const int* nx, const int* nu, int num_horizon, const lqr_
   }
   if (hipMemcpyAsync(w.dev, hs, (size_t)L.group_end[1] * sizeof(double), hipMemcpyHostToDevice, w.stream) != hipSuccess) return TVLQR_NO_DEVICE;
   GenericArgs<double> a = make_args(w, L, reg, is_diag, 0, L.group_end[1]);
-  const size_t lds = generic_backward_lds_bytes<double>(a.nmax, a.mmax);
-  if (lds > kGenericLdsLimit) {
+  const size_t lds4 = generic_backward_lds_bytes<double>(a.nmax, a.mmax), lds3 = generic_backward_lds_bytes<double>(a.nmax, a.mmax, true);
+  const bool late_q = lds4 > kGenericLdsLimit && lds3 <= kGenericLdsLimit;   // (the form without a block for Qxx keeps n up to ~37 in LDS)
+  const size_t lds = late_q ? lds3 : lds4;
+  if (late_q) {
+    hipLaunchKernelGGL((generic_backward_kernel<double, false, false, true>), dim3(1), dim3(64), lds, w.stream, a);
+  } else if (lds > kGenericLdsLimit) {
     if (w.big_bytes < lds) {
       if (w.big) (void)hipFree(w.big);
       w.big = nullptr; w.big_bytes = 0;

@@ -36,6 +36,11 @@ constexpr int N = 5;
 const int kNx[N + 1] = {48, 48, 40, 40, 36, 33};
 const int kNu[N] = {10, 12, 9, 33, 7};
 #define DIMS_TEXT "nx = 48..33, nu = 7..33"
+#elif defined(MID_DIMS)   // just past 32: the blocks stay in LDS in the form without a block for Qxx ("late Q")
+constexpr int N = 6;
+const int kNx[N + 1] = {35, 36, 34, 33, 36, 30, 35};
+const int kNu[N] = {3, 5, 2, 6, 4, 5};
+#define DIMS_TEXT "nx = 30..36, nu = 2..6"
 #else
 constexpr int N = 9;
 const int kNx[N + 1] = {6, 6, 5, 5, 5, 4, 3, 3, 2, 2};

@@ -53,6 +53,20 @@ def test_tvlqr_dropin_dimensions_past_32_match_the_oracle():
     assert out.count("bit-identical") == 4
 
 
+def test_tvlqr_dropin_dimensions_just_past_32_stay_in_lds():
+    """nx = 30..36 per knot point: the blocks of the largest knot point are past 60 KB of LDS in the usual carve and inside it without a
+    block for Qxx (generic_backward_kernel<double, false, false, true>, "late Q"): the same bits as the oracle, scratch blocks included."""
+    import os
+    from oracle import oracle
+    oracle.lib()
+    libdir = os.path.dirname(oracle._LIB)
+    rc, out, err = cpp_build.run("tvlqr_dropin_varying_test", defines=["MID_DIMS"], out_name="tvlqr_dropin_mid_test",
+                                 extra_link=["-L" + libdir, "-l:" + os.path.basename(oracle._LIB), "-Wl,-rpath," + libdir])
+    print(out)
+    assert rc == 0 and out.strip().endswith("OK"), out + err
+    assert out.count("bit-identical") == 4
+
+
 def test_altro_solver_cpp_api_integration():
     """test/double_integrator_test.cpp + test/pendulum_test.cpp + test/altro_api.cpp re-authored against
     include/altro/altro.hpp: iteration counts 3 / 5 / 9, pendulum end state, error ladder."""
