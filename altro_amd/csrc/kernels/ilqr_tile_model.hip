@@ -10,7 +10,8 @@
 //     model can share over the row it does: MODEL_QUADROTOR takes ONE sincos per lane and evaluation (tile_quad_trig);
 //   * for the expansion lane j keeps ROW j of the two continuous Jacobians J0 = [df/dx df/du](x, u), Jm = (...)(xm, u) and forms
 //     row j of Z = [A B],  A = I + h Jm_x (I + h/2 J0_x),  B = h (Jm_x h/2 J0_u + Jm_u):  the products  sum_i Jm[j][i] J0[i][c]
-//     are 16 chains of 12 `v_fmac_f64_dpp row_newbcast` (lane i holds row i of J0) -- nothing crosses LDS.
+//     are sums over the NONZERO entries of J0, which every lane holds whole (it evaluated the model itself) -- nothing crosses LDS,
+//     nothing is broadcast; the lane picks its row of Jm only.
 // wave_merit_dpp_kernel<.., MK> (ilqr_merit2_dpp.hip) calls tile_model_step at every knot point and leaves the rows in the DYN
 // records for the next backward sweep; here are the two kernels around it: the open-loop rollout and the expansion of a stored
 // trajectory (the head of Solve, and the re-expansion after a speculative line-search step).
@@ -81,20 +82,20 @@ __device__ __forceinline__ void tile_model_step(const ModelParams& mp, double w,
   const double h = (double)mp.h, h2 = (double)(mp.h / 2);     // (h / 2 in float arithmetic, like the reference's harness)
   double k1[12], xm[12], k2[12];
   if constexpr (JAC) {
-    double J0[192], Jm[192], j0[16], jm[16];
+    double J0[192], Jm[192], jm[16];
     tile_cont<MK, true>(mp, z, z + 12, jr, k1, J0);
-    tile_pick_row(J0, jr, j0);
 #pragma unroll
     for (int i = 0; i < 12; ++i) xm[i] = z[i] + h2 * k1[i];
     tile_cont<MK, true>(mp, xm, z + 12, jr, k2, Jm);
-    tile_pick_row(Jm, jr, jm);
-    double jm12[12];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) jm12[i] = jm[i];
+    tile_pick_row(Jm, jr, jm);                          // the lane's row of Jm; J0 it holds whole (every lane evaluated it)
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
-      double s = 0.0;                                   // sum_i Jm[j][i] J0[i][c]; a column of J0 that is zero in every row (the
-      if (!(__builtin_constant_p(j0[c]) && j0[c] == 0.0)) md_col12(s, j0[c], jm12);   // picks folded to the constant) needs no chain
+      double s = 0.0;                                   // sum_i Jm[j][i] J0[i][c], without the terms whose J0[i][c] is a structural zero of the
+#pragma unroll                                          // model (the quadrotor keeps 38 of 192); fused like the DPP chain this replaces
+      for (int i = 0; i < 12; ++i) {
+        if (__builtin_constant_p(J0[i + 12 * c]) && J0[i + 12 * c] == 0.0) continue;
+        s = __builtin_fma(J0[i + 12 * c], jm[i], s);
+      }
       if (c < 12) zrow[c] = ((jr == c) ? 1.0 : 0.0) + h * (jm[c] + h2 * s);
       else zrow[c] = h * (h2 * s + jm[c]);
     }
