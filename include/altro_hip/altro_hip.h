@@ -103,7 +103,7 @@ typedef enum altro_hip_plan {
                                         MI355X both are bound by the same fp32 record traffic */
 #define ALTRO_HIP_GENERIC_MATRIX_CORES 0x8u /* plan GENERIC, fp64: the backward sweep's products as v_mfma_f64_16x16x4 tiles (any
                                       * n, m, per-knot-point dimensions included) instead of one multiply-add at a time in the CPU
-                                      * path's order: 1.0-1.7 x faster from n = 14 up, results equal to rounding
+                                      * path's order: 1.0-1.9 x faster from n = 14 up, results equal to rounding
                                       * (1e-12) instead of bit for bit -- a whole AL-iLQR solve may then take a line-search decision
                                       * differently from the CPU path.  Off unless given; the tvlqr_* drop-in is always exact.      */
 
