@@ -307,9 +307,29 @@ __global__ void generic_expand_kernel(IlqrGenArgs<T> a) {
 
 // MeritFunction (solver.cpp:273-355): closed-loop rollout with step alpha, total cost phi and -- when asked -- the directional
 // derivative phi' with the refreshed lx, lu.  Lanes 0..31: state rows, lanes 32..63: input rows.
-template <typename T>
+// STAGE: the knot point's seven matrices (K, P, Q, R, H, A, B) are copied into LDS first -- coalesced, all loads of a batch issued before its
+// stores, two batches -- and the rows read from there: two global round trips per knot point instead of one per eight terms of every row
+// (eight to ten per knot point at (13, 4)).  The launch stages while sixteen waves still fit a CU.  Dynamic LDS: [jv (with constraint
+// blocks)] [the staged matrices].
+template <typename T, int CAP>
+__device__ __forceinline__ void gen_fetch(T (&v)[CAP], const T* src, int count, int lane) {
+#pragma unroll
+  for (int c = 0; c < CAP; ++c) { const int e = lane + 64 * c; v[c] = e < count ? src[e] : T(0); }
+}
+template <typename T, int CAP>
+__device__ __forceinline__ void gen_put(T* dst, const T (&v)[CAP], const T* src, int count, int lane) {
+#pragma unroll
+  for (int c = 0; c < CAP; ++c) { const int e = lane + 64 * c; if (e < count) dst[e] = v[c]; }
+  for (int e = 64 * CAP + lane; e < count; e += 64) dst[e] = src[e];
+}
+inline size_t generic_merit_stage_elems(int n, int m) { return (size_t)3 * n * n + (size_t)3 * n * m + (size_t)m * m; }
+
+template <typename T, bool STAGE>
 __global__ __launch_bounds__(64, 4) void generic_merit_kernel(IlqrGenArgs<T> a) {
-  __shared__ double xs[GEN_MAX], dxs[GEN_MAX], das[GEN_MAX], us[GEN_MAX], dus[GEN_MAX], jv[GEN_AL_JV];
+  __shared__ double xs[GEN_MAX], dxs[GEN_MAX], das[GEN_MAX], us[GEN_MAX], dus[GEN_MAX];
+  extern __shared__ __attribute__((aligned(16))) unsigned char gen_dyn[];
+  double* const jv = reinterpret_cast<double*>(gen_dyn);                                   // [GEN_AL_JV] when there are constraint blocks
+  T* const stg = reinterpret_cast<T*>(gen_dyn + (a.al.enabled ? GEN_AL_JV * sizeof(double) : 0));
   const int b = blockIdx.x, lane = threadIdx.x;
   if (a.active && !a.active[b]) return;
   const int N = a.N;
@@ -325,14 +345,32 @@ __global__ __launch_bounds__(64, 4) void generic_merit_kernel(IlqrGenArgs<T> a) 
     const int ub = GEN_UBASE(a);
     const bool isx = lane < n, isu = lane >= ub && lane - ub < m;
     const int i = isx ? lane : 0, iu = isu ? lane - ub : 0;
-    __syncthreads();
+    const T* gK = a.K + (int64_t)b * a.K_bs + GOFF(G_K, k);
+    const T* gP = a.P + (int64_t)b * a.P_bs + GOFF(G_P, k);
+    const T* gQ = a.cQ + (int64_t)b * a.sQ + GOFF(G_Q, k);
+    const T* gR = a.cR + (int64_t)b * a.sR + GOFF(G_R, k);
+    const T* gH = a.cH + (int64_t)b * a.sH + GOFF(G_H, k);
+    const T* gA = a.A + (int64_t)b * a.A_bs + GOFF(G_A, k);
+    const T* gB = a.B + (int64_t)b * a.B_bs + GOFF(G_B, k);
+    T* const sK = stg; T* const sP = sK + m * n; T* const sQ = sP + n * n; T* const sR = sQ + n * n; T* const sH = sR + m * m;
+    T* const sA = sH + m * n; T* const sB = sA + n2 * n;
+    __syncthreads();                                     // (the previous knot point's rows are read: the staged blocks may be overwritten)
+    if (STAGE) {
+      { T rK[2], rP[4], rQ[4];
+        gen_fetch<T, 2>(rK, gK, m * n, lane); gen_fetch<T, 4>(rP, gP, n * n, lane); gen_fetch<T, 4>(rQ, gQ, n * n, lane);
+        gen_put<T, 2>(sK, rK, gK, m * n, lane); gen_put<T, 4>(sP, rP, gP, n * n, lane); gen_put<T, 4>(sQ, rQ, gQ, n * n, lane); }
+      { T rR[1], rH[2], rA[4], rB[2];
+        gen_fetch<T, 1>(rR, gR, m * m, lane); gen_fetch<T, 2>(rH, gH, m * n, lane); gen_fetch<T, 4>(rA, gA, n2 * n, lane); gen_fetch<T, 2>(rB, gB, n2 * m, lane);
+        gen_put<T, 1>(sR, rR, gR, m * m, lane); gen_put<T, 2>(sH, rH, gH, m * n, lane); gen_put<T, 4>(sA, rA, gA, n2 * n, lane); gen_put<T, 2>(sB, rB, gB, n2 * m, lane); }
+    }
+    // the knot point's rows (both call sites inline it: the staged blocks keep ds_read, the global ones global_load)
+    auto knot = [&](const T* Kk, const T* Pk, const T* Qk, const T* Rk, const T* Hk, const T* Ak, const T* Bk) {
     if (isx) {
       xs[lane] = x; dxs[lane] = x - (double)a.xn[(int64_t)b * a.sx + GOFF(G_x, k) + lane]; das[lane] = dxda;
       a.x[(int64_t)b * a.x_bs + GOFF(G_x, k) + lane] = (T)x;
     }
     __syncthreads();
     if (isu) {   // u_ = u + (-K dx + alpha d) ; du_da = -K dx_da + d
-      const T* Kk = a.K + (int64_t)b * a.K_bs + GOFF(G_K, k);
       double s, s2;
       gen_gdot2<T>(Kk + iu, m, dxs, das, n, s, s2);
       const double dk = (double)a.d[(int64_t)b * a.d_bs + GOFF(G_d, k) + iu];
@@ -341,7 +379,6 @@ __global__ __launch_bounds__(64, 4) void generic_merit_kernel(IlqrGenArgs<T> a) 
       a.u[(int64_t)b * a.u_bs + GOFF(G_u, k) + iu] = (T)uv;
     }
     if (isx) {   // y_ = P dx + p
-      const T* Pk = a.P + (int64_t)b * a.P_bs + GOFF(G_P, k);
       const double s = gen_gdot<T>(Pk + i, n, dxs, n);
       a.y[(int64_t)b * a.y_bs + GOFF(G_y, k) + i] = (T)(s + (double)a.p[(int64_t)b * a.p_bs + GOFF(G_p, k) + i]);
     }
@@ -352,9 +389,6 @@ __global__ __launch_bounds__(64, 4) void generic_merit_kernel(IlqrGenArgs<T> a) 
       J += Jal;
       __syncthreads();
     }
-    const T* Qk = a.cQ + (int64_t)b * a.sQ + GOFF(G_Q, k);
-    const T* Rk = a.cR + (int64_t)b * a.sR + GOFF(G_R, k);
-    const T* Hk = a.cH + (int64_t)b * a.sH + GOFF(G_H, k);
     if (isx) {   // state row: cost share, lx
       const double qx = gen_gdot<T>(Qk + i, n, xs, n), htu = gen_gdot<T>(Hk + i * m, 1, us, m);
       const double ql = (double)a.cq[(int64_t)b * a.sx + GOFF(G_q, k) + i];
@@ -366,8 +400,6 @@ __global__ __launch_bounds__(64, 4) void generic_merit_kernel(IlqrGenArgs<T> a) 
     }
     double xn = 0.0, dxn = 0.0;
     if (lane < n2) {   // row of the next state: A_k is n2 x n, B_k n2 x m
-      const T* Ak = a.A + (int64_t)b * a.A_bs + GOFF(G_A, k);
-      const T* Bk = a.B + (int64_t)b * a.B_bs + GOFF(G_B, k);
       double s, s2, t, t2;
       gen_gdot2<T>(Ak + lane, n2, xs, das, n, s, t);
       gen_gdot2<T>(Bk + lane, n2, us, dus, m, s2, t2);
@@ -384,6 +416,9 @@ __global__ __launch_bounds__(64, 4) void generic_merit_kernel(IlqrGenArgs<T> a) 
       if (deriv) { dJ += lu * dus[iu]; a.r[(int64_t)b * a.r_bs + GOFF(G_r, k) + iu] = (T)lu; }
     }
     x = xn; dxda = dxn;                                  // (lanes past n2 carry zeros)
+    };
+    if (STAGE) knot(sK, sP, sQ, sR, sH, sA, sB);
+    else knot(gK, gP, gQ, gR, gH, gA, gB);
   }
   __syncthreads();
   {   // terminal knot point (solver.cpp:319-332)
