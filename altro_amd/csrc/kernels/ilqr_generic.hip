@@ -73,6 +73,21 @@ __device__ __forceinline__ double gen_gdot(const T* M, int ld, const double* v, 
   for (; j < cnt; ++j) s += (double)M[j * ld] * v[j];
   return s;
 }
+// the same with the vector in global memory too (the expansion's one-thread-per-entry kernel)
+template <typename T>
+__device__ __forceinline__ double gen_gdot_gg(const T* M, int ld, const T* v, int cnt) {
+  double s = 0.0;
+  int j = 0;
+  for (; j + 8 <= cnt; j += 8) {
+    T mv[8], vv[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { mv[q] = M[(j + q) * ld]; vv[q] = v[j + q]; }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s += (double)mv[q] * (double)vv[q];
+  }
+  for (; j < cnt; ++j) s += (double)M[j * ld] * (double)v[j];
+  return s;
+}
 // the same for two vectors at once: s = sum_j M[j ld] v[j], t = sum_j M[j ld] w[j]
 template <typename T>
 __device__ __forceinline__ void gen_gdot2(const T* M, int ld, const double* v, const double* w, int cnt, double& s, double& t) {
@@ -275,22 +290,14 @@ __global__ void generic_expand_kernel(IlqrGenArgs<T> a) {
     if (grad) {
       double s;
       if (isx) {
-        s = 0.0;
-        for (int j = 0; j < n; ++j) s += (double)Qk[i + j * n] * (double)xk[j];
+        s = gen_gdot_gg<T>(Qk + i, n, xk, n);
         s += (double)a.cq[(int64_t)b * a.sx + GOFF(G_q, k) + i];
-        if (!terminal) {
-          double t2 = 0.0;
-          for (int r = 0; r < m; ++r) t2 += (double)Hk[r + i * m] * (double)uk[r];
-          s += t2;
-        }
+        if (!terminal) s += gen_gdot_gg<T>(Hk + i * m, 1, uk, m);
         a.q[(int64_t)b * a.q_bs + GOFF(G_q, k) + i] = (T)s;
       } else {
-        s = 0.0;
-        for (int j = 0; j < m; ++j) s += (double)Rk[i + j * m] * (double)uk[j];
+        s = gen_gdot_gg<T>(Rk + i, m, uk, m);
         s += (double)a.cr[(int64_t)b * a.su + GOFF(G_r, k) + i];
-        double t2 = 0.0;
-        for (int j = 0; j < n; ++j) t2 += (double)Hk[i + j * m] * (double)xk[j];
-        s += t2;
+        s += gen_gdot_gg<T>(Hk + i, m, xk, n);
         a.r[(int64_t)b * a.r_bs + GOFF(G_r, k) + i] = (T)s;
       }
     }
