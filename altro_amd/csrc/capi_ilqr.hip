@@ -254,6 +254,17 @@ int wave_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int
   a.spec_stride = (int64_t)h->batch * (h->N + 1) * 28;
   a.ls_beta = h->spec_beta; a.ls_max_iters = h->spec_max_iters;
   a.skip = which == IK_STATIONARITY ? h->stat_skip : nullptr;
+  if constexpr (sizeof(S) == 8) {   // affine line-search trials (capi_solve.hip switches them on for a solve): dynamics as data only
+    if (h->aff_enabled && !h->model_set) {
+      if (h->aff_store && (which == IK_MERIT2 || which == IK_MERIT)) {   // the sweep's phi(0) evaluation leaves base + sensitivity behind
+        a.sens = (double*)h->i_sens; a.sens_alpha = (double*)h->i_sens_alpha;
+      } else if (which == IK_MERIT && h->aff_round && a.mode >= 2 && !a.spec_pre) {
+        a.sens = (double*)h->i_sens; a.sens_alpha = (double*)h->i_sens_alpha;
+        a.aff = 1; a.aff_part = (double*)h->i_aff_part; a.aff_on = (int*)h->i_aff_on;
+        HIP_TRY(hipMemsetAsync(h->i_aff_on, 0, (size_t)ILQR_SPEC_TRIALS * h->batch * sizeof(int), h->stream));
+      }
+    }
+  }
   if (h->model_set && h->model.kind == MODEL_USER) {   // the caller's own model, compiled at run time (capi_rtc.hip): fp64 handles only
     if constexpr (sizeof(S) == 8) {
       if (which == IK_ROLLOUT || which == IK_MERIT || which == IK_MERIT2) return rtc_tile_launch(h, which, a);

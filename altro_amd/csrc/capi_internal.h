@@ -62,6 +62,10 @@ struct altro_hip_batch {
   // plan GENERIC: reference layout on the device
   void* g_arr[G_NUM] = {};
   int64_t g_bstride[G_NUM] = {};
+  // affine line-search trials (plan MFMA16, dynamics as data, fp64: kernels/ilqr_merit2_dpp.hip AFF): buffers, and the two switches the
+  // solve loop sets -- on for this solve / this launch is a line-search round
+  void *i_sens = nullptr, *i_sens_alpha = nullptr, *i_aff_part = nullptr, *i_aff_on = nullptr;
+  bool aff_enabled = false, aff_round = false, aff_store = false;   // (aff_store: this launch is the sweep's phi(0) evaluation)
   bool g_mfma = false;                       // plan GENERIC, fp64: the backward sweep's products on the matrix cores (ALTRO_HIP_GENERIC_MATRIX_CORES)
   bool ragged = false;                       // per-knot-point dimensions (altro_hip_batch_create_dims): plan GENERIC, TVLQR sweeps only
   std::vector<int> nxv, nuv;                 // nx[0..N], nu[0..N-1] of a ragged handle (n, m hold the maxima)

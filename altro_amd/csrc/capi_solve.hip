@@ -53,6 +53,7 @@ struct SolveRun {
   ~SolveRun() {   // whatever path leaves the solve: no speculation state, mask or swapped pointer survives it
     h->bwd_active = nullptr; h->bwd_reg = nullptr; h->stat_skip = nullptr;
     h->spec_trials = 1; h->spec_pre = 0;
+    h->aff_round = false; h->aff_enabled = false; h->aff_store = false;
     h->i_active = active0;
   }
 
@@ -147,6 +148,18 @@ int SolveRun::configure(const altro_hip_solve_options* opts) {
   // after this solve's first (full) Hessian expansion the later ones store 16 values per knot point instead of 158 (EXPAND_DIAG)
   diag_mode = (h->plan == ALTRO_HIP_PLAN_MFMA16 && al && !h->cost_dense && h->al_all_sel) ? EXPAND_DIAG : 0;
   running = h->batch;
+  // Affine line-search trials (kernels/ilqr_merit2_dpp.hip, AFF): plan MFMA16, dynamics as data, fp64, the two-trial first pass (which
+  // (the sweep's phi(0) evaluation leaves the base trajectory and its sensitivity behind).  ALTRO_HIP_AFFINE=0 keeps every trial a rollout.
+  h->aff_enabled = h->plan == ALTRO_HIP_PLAN_MFMA16 && h->dtype == ALTRO_HIP_F64 && !h->model_set && merit_rounds_dpp && !env_off("ALTRO_HIP_AFFINE");
+  h->aff_round = false; h->aff_store = false;
+  if (h->aff_enabled && !h->i_sens) {
+    const size_t B = h->batch, chunks = (h->N + 15) / 16;
+    int rc = dmalloc(h, &h->i_sens, B * (h->N + 1) * 24 * sizeof(double));
+    if (!rc) rc = dmalloc(h, &h->i_sens_alpha, B * sizeof(double));
+    if (!rc) rc = dmalloc(h, &h->i_aff_part, chunks * ILQR_SPEC_TRIALS * B * 2 * sizeof(double));
+    if (!rc) rc = dmalloc(h, &h->i_aff_on, (size_t)ILQR_SPEC_TRIALS * B * sizeof(int));
+    if (rc) { h->aff_enabled = false; (void)hipGetLastError(); }   // an optimisation only
+  }
   return 0;
 }
 
@@ -335,7 +348,9 @@ int SolveRun::first_evaluation(int* prev_slot, int* begin_slot, int* launches, b
   h->spec_trials = pre ? 2 : 1; h->spec_pre = pre ? 1 : 0;
   // (IK_MERIT2, mode 2: the two-trial evaluation with the broadcasts on the VALU's DPP path and two problems per wave,
   //  kernels/ilqr_merit2_dpp.hip -- with or without constraint blocks)
+  h->aff_store = true;                               // (phi(0): the base of the sweep's affine trials)
   int rc = dual ? ilqr_run(h, IK_MERIT2, true, true, 1, 0.0, 2) : ilqr_run(h, IK_MERIT, true, true, 1, 0.0);
+  h->aff_store = false;
   h->spec_trials = 1; h->spec_pre = 0;
   if (rc) return rc;
   *launches = 1;
@@ -359,6 +374,7 @@ int SolveRun::first_evaluation(int* prev_slot, int* begin_slot, int* launches, b
   } else {
     // The first trial step is launched without asking the device whether any problem needs it: the masks make it a no-op when
     // none does, and it saves one host read-back per sweep (these loops are latency-bound).
+    // (a rollout like the two-trial pass's second row: the first step is the same bits whichever way the sweep's head runs)
     if ((rc = ilqr_run(h, IK_MERIT, true, true, 1, 0.0))) return rc;
     ++*launches;
     prev = counted(ILK_LS_FEED);
@@ -396,7 +412,10 @@ int SolveRun::search_rounds(int* prev_slot, int rounds_last, int* rounds_out, in
     const bool spec = trials > 1;
     h->spec_trials = trials;
     la.spec_trials = h->spec_trials;
-    if ((rc = ilqr_run(h, IK_MERIT, true, true, 1, 0.0))) return rc;
+    h->aff_round = true;                             // (dynamics as data: the trials of a round are sums over independent knot points)
+    rc = ilqr_run(h, IK_MERIT, true, true, 1, 0.0);
+    h->aff_round = false;
+    if (rc) return rc;
     const int sf = counted(ILK_LS_FEED);
     if (sf < 0) return ALTRO_HIP_ERR_HIP;
     if (spec && (rc = ilqr_run(h, IK_SPEC_SELECT, false, false, 0, 0.0))) return rc;

@@ -44,6 +44,24 @@ static int wave_launch(hipStream_t stream, int which, const IlqrWaveArgs<S>& a) 
       else hipLaunchKernelGGL(wave_dual_update_kernel<S>, dim3((unsigned)((int64_t)a.batch * (a.N + 1))), b64, 0, stream, a);
       break;
     case IK_MERIT:
+      if constexpr (sizeof(S) == 8) {
+        if (a.aff) {   // affine trials (dynamics as data): a chunk of knot points per wave, then the chunks' shares added up
+          const int chunks = (a.N + MD_AFF_CHUNK - 1) / MD_AFF_CHUNK;
+          const dim3 grid(mf_grid((a.batch + 1) / 2), ((a.spec_trials > 1 ? a.spec_trials : 1) + 1) / 2, chunks);
+          if (a.cost_dense) {
+            if (a.al.enabled && !a.al.has_soc) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, true, false, true, 0, false, true>), grid, b64, gsh, stream, a);
+            else if (a.al.enabled) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, true, false, true, 0, true, true>), grid, b64, gsh, stream, a);
+            else hipLaunchKernelGGL((wave_merit_dpp_kernel<S, false, false, true, 0, true, true>), grid, b64, gsh, stream, a);
+          } else {
+            if (a.al.enabled && !a.al.has_soc) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, true, false, false, 0, false, true>), grid, b64, gsh, stream, a);
+            else if (a.al.enabled) hipLaunchKernelGGL((wave_merit_dpp_kernel<S, true, false, false, 0, true, true>), grid, b64, gsh, stream, a);
+            else hipLaunchKernelGGL((wave_merit_dpp_kernel<S, false, false, false, 0, true, true>), grid, b64, gsh, stream, a);
+          }
+          const int64_t tot = (int64_t)ILQR_SPEC_TRIALS * a.batch;
+          hipLaunchKernelGGL(wave_aff_reduce_kernel<S>, dim3((unsigned)((tot + 255) / 256)), b256, 0, stream, a, chunks);
+          break;
+        }
+      }
       // the DPP form: two problems per wave, two trials per problem (kernels/ilqr_merit2_dpp.hip).  (With constraint blocks and
       // ONE trial per problem its second rows idle; while the constraint Jacobians came from global memory the LDS form won
       // those rounds on long horizons.  With G in LDS and the duals fetched a step ahead the DPP form wins them too -- C1 + input

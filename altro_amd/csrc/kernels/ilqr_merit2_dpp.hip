@@ -336,8 +336,20 @@ namespace altro_hip {
 // from the row's registers and, where phi' is wanted, forms row j of Z = [A B] at the point (tile_model_step,
 // ilqr_tile_model.hip); a pass that stores the expansion leaves those rows in the DYN records for the next backward sweep
 // (what KnotPointData::CalcDynamicsExpansion leaves in A_, B_: knotpoint_data.cpp:406-419).  Z and f are then not loaded.
-template <typename S, bool AL, bool DUAL, bool DENSE = false, int MK = 0, bool SOC = true>
+// AFF ("affine trials", dynamics as data only): with x+ = A x + B u + f the closed-loop rollout is affine in the step --
+//     x_k(alpha) = x_k(alpha_b) + (alpha - alpha_b) s_k ,   s_k = dx_k / dalpha  (the same for every alpha)
+// -- so once the sweep's phi(0) evaluation has left x_k(alpha_b) and s_k behind (IlqrWaveArgs::sens; alpha_b = 0), every
+// further trial is a sum over knot points that do not depend on each other: the wave takes MD_AFF_CHUNK knot points (blockIdx.z),
+// forms x_k(alpha) from the two stored vectors instead of from the step before, does everything else this kernel does at a knot
+// point -- u_, y_, cost share, constraint rows, gradient, phi' share, the candidate record -- except the product with Z = [A B],
+// and leaves its share of phi / phi' in IlqrWaveArgs::aff_part; wave_aff_reduce_kernel adds the shares in chunk order.  A
+// line-search round then costs a chunk's walk (16 knot points) instead of the horizon's (256 for C1: 0.36 ms however few problems
+// search).  The trial points equal the rollout's to rounding (1e-13), not bit for bit -- like everything on this plan.
+constexpr int MD_AFF_CHUNK = 16;                    // even (the image ping-pong is the parity of k)
+template <typename S, bool AL, bool DUAL, bool DENSE = false, int MK = 0, bool SOC = true, bool AFF = false>
 __global__ __launch_bounds__(64, ((MK != 0 || (AL && DENSE && sizeof(S) == 8)) ? 1 : 2)) void wave_merit_dpp_kernel(IlqrWaveArgs<S> a) {
+  static_assert(!AFF || (!DUAL && MK == 0), "affine trials: the single-trial rounds of dynamics given as data");
+  constexpr bool NOZ = MK != 0 || AFF;              // Z and f are neither loaded nor staged
   constexpr int DEPTH = 2;                          // also the image ping-pong: parity of k == dd
   constexpr bool kStat = sizeof(S) == 8;            // stored values == computed values only without a rounding store
   constexpr int IMG = DENSE ? MD_IMG_DENSE : MD_IMG;
@@ -415,31 +427,51 @@ __global__ __launch_bounds__(64, ((MK != 0 || (AL && DENSE && sizeof(S) == 8)) ?
     for (int c = 0; c < 16; ++c)
       rw[c] = MD_CP0 + (isx ? (c < 12 ? MF_OFF_Q + mf_sym(j, c) : MF_OFF_HR + (c - 12) * 16 + j) : MF_OFF_HR + (j - 12) * 16 + c);
   }
+  // AFF: this wave's knot points kb .. ke - 1 (the last chunk also takes the terminal knot point)
+  const int kb = AFF ? (int)blockIdx.z * MD_AFF_CHUNK : 0;
+  const int ke = AFF ? (kb + MD_AFF_CHUNK < N ? kb + MD_AFF_CHUNK : N) : N;
+  const double dalpha = AFF ? alpha - a.sens_alpha[b] : 0.0;
+  const double* const sensb = AFF || a.sens ? a.sens + (size_t)b * 24 : nullptr;   // [k][b][24]: x_k(alpha_b) 12 | s_k 12
+  const size_t sens_ks = (size_t)a.batch * 24;
+  // the row that leaves the base trajectory and its sensitivity behind: the sweep's phi(0) evaluation (trial 0 of the pass the host marks)
+  const bool sens_out = !AFF && a.sens != nullptr && wr && (DUAL ? h == 0 : (row_on && trial == 0));
+  if (sens_out && j == 0) a.sens_alpha[b] = alpha;
   double x = isx ? (double)a.x0[(size_t)b * 12 + j] : 0.0;
   double dxda = 0.0;
   double J = 0.0, Jal = 0.0, dJ = 0.0, res = 0.0, viol = 0.0;   // (Jal: the constraint rows' cost shares, lanes 0..7)
   double jvr[AL_MAXC] = {0.0, 0.0};
   double zg[AL_MAXC][2] = {{0.0, 0.0}, {0.0, 0.0}};   // (z_i, g_i) of the knot point in hand
-  if (al) { alp_knot<S>(a.al, 0, kc_s); kn_s = kc_s; alp_fetch<S>(a.al, kc_s, 0, b, a.batch, j, zg); }
+  if (al) {
+    alp_knot<S>(a.al, al_uni ? 0 : kb, kc_s); kn_s = kc_s;
+    alp_fetch<S>(a.al, kc_s, al_uni ? kb * a.al.rows_per_knot : 0, b, a.batch, j, zg);
+  }
   double lprev = 0.0, yprev = 0.0;                  // gradient and y of knot point k - 1 (the stationarity's lag)
   MeritPairRegs<DENSE> ring[DEPTH];
+  double rxb[DEPTH] = {0.0, 0.0}, rsv[DEPTH] = {0.0, 0.0};   // AFF: x_k(alpha_b)_j and s_k_j of the knot points in the ring
 #pragma unroll
   for (int dd = 0; dd < DEPTH; ++dd) {
-    const size_t kk = dd < N ? dd : N - 1;
-    merit_pair_load<S, DENSE, MK != 0>(ring[dd], dynb + kk * a.dyn_ks, outb + kk * a.out_ks, nomb + kk * nom_ks, cpb + kk * cp_ks, hl);
+    const size_t kk = kb + dd < ke ? kb + dd : ke - 1;
+    merit_pair_load<S, DENSE, NOZ>(ring[dd], dynb + kk * a.dyn_ks, outb + kk * a.out_ks, nomb + kk * nom_ks, cpb + kk * cp_ks, hl);
+    if constexpr (AFF) { rxb[dd] = sensb[kk * sens_ks + jr]; rsv[dd] = sensb[kk * sens_ks + 12 + jr]; }
   }
-  const int Npad = ((N + DEPTH - 1) / DEPTH) * DEPTH;
-  for (int k0 = 0; k0 < Npad; k0 += DEPTH) {
+  const int Npad = ((ke - kb + DEPTH - 1) / DEPTH) * DEPTH;
+  for (int k0 = kb; k0 < kb + Npad; k0 += DEPTH) {
 #pragma unroll
    for (int dd = 0; dd < DEPTH; ++dd) {
     const int k = k0 + dd;
-    const bool live = k < N;
-    const int kc = live ? k : N - 1;
+    const bool live = k < ke;
+    const int kc = live ? k : ke - 1;
     double* const L = img[dd][slot];
-    merit_pair_stage<DENSE, MK != 0>(ring[dd], L, hl);
+    merit_pair_stage<DENSE, NOZ>(ring[dd], L, hl);
+    if constexpr (AFF) { x = isx ? rxb[dd] + dalpha * rsv[dd] : 0.0; dxda = isx ? rsv[dd] : 0.0; }   // x_k(alpha), dx_k / dalpha
     {
-      const size_t kn = (k + DEPTH < N) ? k + DEPTH : N - 1;
-      merit_pair_load<S, DENSE, MK != 0>(ring[dd], dynb + kn * a.dyn_ks, outb + kn * a.out_ks, nomb + kn * nom_ks, cpb + kn * cp_ks, hl);
+      const size_t kn = (k + DEPTH < ke) ? k + DEPTH : ke - 1;
+      merit_pair_load<S, DENSE, NOZ>(ring[dd], dynb + kn * a.dyn_ks, outb + kn * a.out_ks, nomb + kn * nom_ks, cpb + kn * cp_ks, hl);
+      if constexpr (AFF) { rxb[dd] = sensb[kn * sens_ks + jr]; rsv[dd] = sensb[kn * sens_ks + 12 + jr]; }
+    }
+    if (sens_out && live && isx) {                    // (x, dxda: this knot point's, before the step below moves them on)
+      double* sp_ = const_cast<double*>(sensb) + (size_t)k * sens_ks;
+      sp_[j] = x; sp_[12 + j] = dxda;
     }
     __syncthreads();
     // (1) rows of [P | p] and of Kt against dx and dx/dalpha
@@ -489,7 +521,11 @@ __global__ __launch_bounds__(64, ((MK != 0 || (AL && DENSE && sizeof(S) == 8)) ?
     double cR[16];
     double zacc = 0.0, zacc2 = 0.0, s2 = 0.0, t2 = 0.0;
     double xn;
-    if constexpr (MK != 0) {   // a device model: x+ = F(x, u), and row j of Z = [A B] at (x, u) where phi' is wanted
+    if constexpr (AFF) {       // the next knot point's state comes from the stored pair, not from this step
+      xn = 0.0;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) cR[c] = 0.0;
+    } else if constexpr (MK != 0) {   // a device model: x+ = F(x, u), and row j of Z = [A B] at (x, u) where phi' is wanted
       if (DUAL || deriv) {
         tile_model_step<MK, true>(a.mp, w, jr, xn, cR);
       } else {
@@ -547,7 +583,15 @@ __global__ __launch_bounds__(64, ((MK != 0 || (AL && DENSE && sizeof(S) == 8)) ?
     if (live) { lprev = l; yprev = y; if (isx) { x = xn; dxda = dxn; } }
    }
   }
-  {   // terminal knot point (solver.cpp:319-332), both trials
+  if (!AFF || ke == N) {   // terminal knot point (solver.cpp:319-332), both trials (AFF: the last chunk's)
+    if constexpr (AFF) {
+      const double xb = sensb[(size_t)N * sens_ks + jr], sv = sensb[(size_t)N * sens_ks + 12 + jr];
+      x = isx ? xb + dalpha * sv : 0.0; dxda = isx ? sv : 0.0;
+    }
+    if (sens_out && isx) {
+      double* sp_ = const_cast<double*>(sensb) + (size_t)N * sens_ks;
+      sp_[j] = x; sp_[12 + j] = dxda;
+    }
     const S* nm = a.nom + ((size_t)N * a.batch + b) * MF_NOM;
     const S* on = a.outn + (size_t)b * MF_TERM;
     S* c = candb + (size_t)N * a.xuy_ks;
@@ -657,11 +701,34 @@ __global__ __launch_bounds__(64, ((MK != 0 || (AL && DENSE && sizeof(S) == 8)) ?
       const double phi = wave_sum(red[0][q][lane]), dphi = wave_sum(red[1][q][lane]);
       const int tq = 2 * (int)blockIdx.y + (q & 1), bs = 2 * pr + (q >> 1);
       if (lane == 0 && ((on_mask >> (16 * q)) & 1ull)) {
-        a.phi[(size_t)tq * a.batch + bs] = phi;
-        if (a.want_derivative != 0 && (tq == 0 || a.spec_pre)) a.dphi[(size_t)tq * a.batch + bs] = dphi;
+        if constexpr (AFF) {   // this chunk's share; chunk 0 says that (trial, problem) is being evaluated
+          double* pt = a.aff_part + (((size_t)blockIdx.z * ILQR_SPEC_TRIALS + tq) * a.batch + bs) * 2;
+          pt[0] = phi; pt[1] = dphi;
+          if (blockIdx.z == 0) a.aff_on[(size_t)tq * a.batch + bs] = 1;
+        } else {
+          a.phi[(size_t)tq * a.batch + bs] = phi;
+          if (a.want_derivative != 0 && (tq == 0 || a.spec_pre)) a.dphi[(size_t)tq * a.batch + bs] = dphi;
+        }
       }
     }
-    if (al && j == 0 && row_on) a.prob[b].rho_est = rho;
+    if (al && j == 0 && row_on && (!AFF || blockIdx.z == 0)) a.prob[b].rho_est = rho;
+  }
+}
+
+// phi / phi' of the affine trials: the chunks' shares added in chunk order (one thread per (trial, problem))
+template <typename S>
+__global__ void wave_aff_reduce_kernel(IlqrWaveArgs<S> a, int chunks) {
+  const int64_t total = (int64_t)ILQR_SPEC_TRIALS * a.batch;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    if (!a.aff_on[t]) continue;
+    const int tq = (int)(t / a.batch);
+    double phi = 0.0, dphi = 0.0;
+    for (int c = 0; c < chunks; ++c) {
+      const double* pt = a.aff_part + ((size_t)c * ILQR_SPEC_TRIALS * a.batch + t) * 2;
+      phi += pt[0]; dphi += pt[1];
+    }
+    a.phi[t] = phi;
+    if (a.want_derivative != 0 && tq == 0) a.dphi[t] = dphi;
   }
 }
 

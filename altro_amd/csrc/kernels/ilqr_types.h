@@ -159,6 +159,13 @@ struct IlqrWaveArgs {
   // A device model instead of dynamics given as data (altro_hip_set_model on plan MFMA16, kernels/ilqr_tile_model.hip): the
   // rollout and the merit evaluation step the model, the expansion writes Z = [A B] into the DYN records (mp.kind != MODEL_LINEAR)
   ModelParams mp{MODEL_LINEAR, 0.0f, 0, 2.7, 1.5};
+  // Affine line-search trials (dynamics as data, kernels/ilqr_merit2_dpp.hip: AFF): the base trajectory and its sensitivity the first
+  // pass of a sweep leaves behind, the step it was taken at, the chunks' shares of phi / phi' and which (trial, problem) is evaluated
+  double* sens = nullptr;                    // [k][b][24]: x_k(alpha_b) 12 | dx_k / dalpha 12      (k = 0 .. N)
+  double* sens_alpha = nullptr;              // [b]: alpha_b
+  double* aff_part = nullptr;                // [chunk][ILQR_SPEC_TRIALS][b][2]
+  int* aff_on = nullptr;                     // [ILQR_SPEC_TRIALS][b]
+  int aff = 0;                               // IK_MERIT: launch the affine form
 };
 constexpr int MF_COSTD_C = 78;    // the constant term c inside a dense cost record (the first pad slot of the COST layout)
 constexpr int ROLLOUT_INIT = 4;   // wave_rollout_kernel also writes the nominal record and the cost gradient (the head of

@@ -18,6 +18,13 @@ pytestmark = pytest.mark.gpu
 n, m = 12, 4
 
 
+@pytest.fixture(autouse=True)
+def rollout_trials(monkeypatch):
+    """This module holds the kernel FORMS against each other bit for bit (two-trial pass vs sequence, row layout vs LDS form); the
+    line-search rounds' affine evaluation (tests/test_gpu_affine.py) exists in the row layout only, so here every trial is a rollout."""
+    monkeypatch.setenv("ALTRO_HIP_AFFINE", "0")
+
+
 def _solve(p, N, blocks, dual, dtype=altro_amd.F64, **kw):
     batch = p["x0"].shape[0]
     bt = altro_amd.Batch(N, n, m, batch, dtype=dtype)
