@@ -260,8 +260,7 @@ int wave_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int
         a.sens = (double*)h->i_sens; a.sens_alpha = (double*)h->i_sens_alpha;
       } else if (which == IK_MERIT && h->aff_round && a.mode >= 2 && !a.spec_pre) {
         a.sens = (double*)h->i_sens; a.sens_alpha = (double*)h->i_sens_alpha;
-        a.aff = 1; a.aff_part = (double*)h->i_aff_part; a.aff_on = (int*)h->i_aff_on;
-        HIP_TRY(hipMemsetAsync(h->i_aff_on, 0, (size_t)ILQR_SPEC_TRIALS * h->batch * sizeof(int), h->stream));
+        a.aff = 1; a.aff_part = (double*)h->i_aff_part; a.aff_on = (int*)h->i_aff_on;   // (flags: zero when allocated, cleared again by the reduction)
       }
     }
   }

@@ -158,6 +158,7 @@ int SolveRun::configure(const altro_hip_solve_options* opts) {
     if (!rc) rc = dmalloc(h, &h->i_sens_alpha, B * sizeof(double));
     if (!rc) rc = dmalloc(h, &h->i_aff_part, chunks * ILQR_SPEC_TRIALS * B * 2 * sizeof(double));
     if (!rc) rc = dmalloc(h, &h->i_aff_on, (size_t)ILQR_SPEC_TRIALS * B * sizeof(int));
+    if (!rc && hipMemsetAsync(h->i_aff_on, 0, (size_t)ILQR_SPEC_TRIALS * B * sizeof(int), h->stream) != hipSuccess) rc = 1;
     if (rc) { h->aff_enabled = false; (void)hipGetLastError(); }   // an optimisation only
   }
   return 0;

@@ -721,6 +721,7 @@ __global__ void wave_aff_reduce_kernel(IlqrWaveArgs<S> a, int chunks) {
   const int64_t total = (int64_t)ILQR_SPEC_TRIALS * a.batch;
   for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
     if (!a.aff_on[t]) continue;
+    a.aff_on[t] = 0;                                  // (consumed: the next round finds the flags clear)
     const int tq = (int)(t / a.batch);
     double phi = 0.0, dphi = 0.0;
     for (int c = 0; c < chunks; ++c) {
