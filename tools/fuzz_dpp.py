@@ -16,6 +16,7 @@ import altro_amd  # noqa: E402
 from tests import problems  # noqa: E402
 
 SWITCHES = ("ALTRO_HIP_MERIT_DPP", "ALTRO_HIP_EXPAND_DPP", "ALTRO_HIP_ALROWS_DPP")
+os.environ["ALTRO_HIP_AFFINE"] = "0"   # the kernel FORMS against each other: every line-search trial a rollout in both (the affine rounds exist in the row layout only)
 KEYS = ("status", "iterations", "dual_updates", "phi", "stationarity", "feasibility", "alpha", "penalty")
 
 
