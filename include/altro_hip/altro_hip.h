@@ -358,7 +358,11 @@ void altro_hip_default_solve_options(altro_hip_solve_options* opts);
  * evaluated speculatively -- the first step (alpha = 1) in the launch that evaluates phi(0), the backtracking steps
  * alpha beta^j several per launch -- and consumed by the search in its own order: every result is bit-identical to
  * the one-step-per-launch sequence, only altro_hip_last_solve_counts' merit_launches drops.  Setting the environment
- * variable ALTRO_HIP_NO_SPECULATION (any value) restores one step per launch. */
+ * variable ALTRO_HIP_NO_SPECULATION (any value) restores one step per launch.
+ * Plan MFMA16, fp64, dynamics given as data: the closed-loop rollout of SolverImpl::MeritFunction (solver.cpp:273-355) is affine in
+ * the step, x_k(alpha) = x_k(0) + alpha dx_k/dalpha, so the line-search rounds after a sweep's first step evaluate the knot points
+ * independently from that pair instead of rolling out again (16 per wavefront; a round then costs the same whatever the horizon).
+ * Their trial points equal the rollout's to rounding (1e-13), as everything on this plan does; ALTRO_HIP_AFFINE=0 keeps rollouts. */
 int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts,
                          altro_hip_solve_result* results);
 int altro_hip_last_solve_counts(const altro_hip_batch* h, int* sweeps, int* merit_launches);
