@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libaltro_hip.so")
 
 F64, F32 = 0, 1
-PLAN_AUTO, PLAN_GENERIC, PLAN_MFMA16, PLAN_LANE = 0, 1, 2, 3
+PLAN_AUTO, PLAN_GENERIC, PLAN_MFMA16, PLAN_LANE, PLAN_MFMA32 = 0, 1, 2, 3, 4
 STORE_QBLOCKS = 0x1
 LANE_FUSED = 0x4   # plan LANE: FMA-fused TVLQR kernels (not bit-identical to the CPU path, ~20 % faster at small batch)
 F32_PURE = 0x2   # ALTRO_HIP_F32 on plan MFMA16: backward sweep in pure fp32 (v_mfma_f32_16x16x4_f32)

@@ -104,6 +104,19 @@ static int batch_create_impl(altro_hip_batch** out, int N, int n, int m, int bat
     plan = (n == 12 && m == 4) ? ALTRO_HIP_PLAN_MFMA16
            : (lane_supported(n, m) && !small_tile) ? ALTRO_HIP_PLAN_LANE : (mfma_ok ? ALTRO_HIP_PLAN_MFMA16 : ALTRO_HIP_PLAN_GENERIC);
   }
+  // Plan MFMA32 (kernels/tvlqr_tile32.hip): the TVLQR pair on 2 x 2 matrix-core tiles for 12 < n <= 31, m <= 8, n + m <= 32 (and
+  // n <= 12 with 4 < m <= 8), fp64, uniform dimensions -- on plan GENERIC's arrays, so it is that plan with other sweep kernels.
+  bool tile32 = false;
+  if (plan == ALTRO_HIP_PLAN_MFMA32) {
+    if (!tile32_supported(n, m) || dtype != ALTRO_HIP_F64 || nx_k)
+      return fail(ALTRO_HIP_ERR_UNSUPPORTED, "plan MFMA32 takes fp64 problems with n <= 31, m <= 8, n + m <= 32 past the (12, 4) tile and uniform "
+                                             "dimensions (got n = %d, m = %d, dtype %d)", n, m, dtype);
+    tile32 = true;
+    plan = ALTRO_HIP_PLAN_GENERIC;
+  } else if (was_auto && plan == ALTRO_HIP_PLAN_GENERIC && !nx_k && dtype == ALTRO_HIP_F64 && tile32_supported(n, m) &&
+             !(flags & (ALTRO_HIP_STORE_QBLOCKS | ALTRO_HIP_GENERIC_MATRIX_CORES))) {
+    tile32 = true;
+  }
   if (plan == ALTRO_HIP_PLAN_MFMA16 && !mfma_ok)
     return fail(ALTRO_HIP_ERR_UNSUPPORTED, "plan MFMA16 needs n <= 12 and m <= 4 (got %d, %d)", n, m);
   if (plan == ALTRO_HIP_PLAN_LANE && !lane_supported(n, m))
@@ -118,6 +131,7 @@ static int batch_create_impl(altro_hip_batch** out, int N, int n, int m, int bat
   // plan GENERIC's products on the matrix cores: only when asked for (the plan's default is the CPU path's sums bit for bit: whole
   // AL-iLQR solves then take the oracle's line-search decisions, which sums that differ in the last bits do not always do)
   h->g_mfma = plan == ALTRO_HIP_PLAN_GENERIC && dtype == ALTRO_HIP_F64 && (flags & ALTRO_HIP_GENERIC_MATRIX_CORES) != 0;
+  h->g_tile = tile32;
   h->esz = dtype == ALTRO_HIP_F64 ? 8 : 4;
   if (stream) { h->stream = (hipStream_t)stream; }
   else {
@@ -310,7 +324,7 @@ void altro_hip_batch_destroy(altro_hip_batch* h) {
   delete h;
 }
 
-int altro_hip_batch_plan(const altro_hip_batch* h) { return h ? h->plan : ALTRO_HIP_ERR_BAD_ARGUMENT; }
+int altro_hip_batch_plan(const altro_hip_batch* h) { return h ? (h->g_tile ? (int)ALTRO_HIP_PLAN_MFMA32 : h->plan) : ALTRO_HIP_ERR_BAD_ARGUMENT; }
 size_t altro_hip_batch_device_bytes(const altro_hip_batch* h) { return h ? h->device_bytes : 0; }
 
 int altro_hip_set_dynamics(altro_hip_batch* h, const double* A, const double* B, const double* f,

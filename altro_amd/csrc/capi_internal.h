@@ -66,6 +66,7 @@ struct altro_hip_batch {
   // solve loop sets -- on for this solve / this launch is a line-search round
   void *i_sens = nullptr, *i_sens_alpha = nullptr, *i_aff_part = nullptr, *i_aff_on = nullptr;
   bool aff_enabled = false, aff_round = false, aff_store = false;   // (aff_store: this launch is the sweep's phi(0) evaluation)
+  bool g_tile = false;                       // plan MFMA32: plan GENERIC's arrays, the sweeps of kernels/tvlqr_tile32.hip (capi_tile32.hip)
   bool g_mfma = false;                       // plan GENERIC, fp64: the backward sweep's products on the matrix cores (ALTRO_HIP_GENERIC_MATRIX_CORES)
   bool ragged = false;                       // per-knot-point dimensions (altro_hip_batch_create_dims): plan GENERIC, TVLQR sweeps only
   std::vector<int> nxv, nuv;                 // nx[0..N], nu[0..N-1] of a ragged handle (n, m hold the maxima)
@@ -491,6 +492,9 @@ bool ensure_spares(altro_hip_batch* h, int count, size_t bytes_each);
 void merit_split_prepare(altro_hip_batch* h);
 int ilqr_gather_results(altro_hip_batch* h, altro_hip_solve_result* results);
 int launch_backward(altro_hip_batch* h, double reg);
+bool tile32_supported(int n, int m);                        // capi_tile32.hip: plan MFMA32
+int tile32_launch_backward(altro_hip_batch* h, double reg);
+int tile32_launch_forward(altro_hip_batch* h);
 int launch_forward(altro_hip_batch* h);
 bool mfma16_forward_is_x4(const altro_hip_batch* h);   // the forward sweep runs four problems per wave (pure fp32)
 

@@ -1,0 +1,102 @@
+// capi_tile32.hip -- plan MFMA32's sweep launchers: which instantiation of kernels/tvlqr_tile32.hip a shape runs.
+// (A translation unit of its own: the instantiations compile beside the other plans' kernels.)
+#include "capi_internal.h"
+
+#include "kernels/tvlqr_tile32.hip"
+
+using namespace altro_hip;
+using namespace altro_hip::capi;
+
+#define PROF_LAUNCH(kernel, grid, block, lds, stream, ...) \
+  hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, h->launch_ev0, h->launch_ev1, 0, __VA_ARGS__)
+
+namespace {
+
+Tile32Args tile32_args(altro_hip_batch* h, double reg) {
+  Tile32Args a{};
+  auto P = [&](int arr) { return (double*)h->g_arr[arr]; };
+  a.A = P(G_A); a.B = P(G_B); a.f = P(G_f); a.Q = P(G_Q); a.R = P(G_R); a.H = P(G_H); a.q = P(G_q); a.r = P(G_r);
+  a.K = P(G_K); a.d = P(G_d); a.P = P(G_P); a.p = P(G_p);
+  a.bsA = h->g_bstride[G_A]; a.bsB = h->g_bstride[G_B]; a.bsf = h->g_bstride[G_f]; a.bsQ = h->g_bstride[G_Q];
+  a.bsR = h->g_bstride[G_R]; a.bsH = h->g_bstride[G_H]; a.bsq = h->g_bstride[G_q]; a.bsr = h->g_bstride[G_r];
+  a.bsK = h->g_bstride[G_K]; a.bsd = h->g_bstride[G_d]; a.bsP = h->g_bstride[G_P]; a.bsp = h->g_bstride[G_p];
+  a.x = P(G_x); a.u = P(G_u); a.y = P(G_y);
+  a.bsx = h->g_bstride[G_x]; a.bsu = h->g_bstride[G_u]; a.bsy = h->g_bstride[G_y];
+  a.x0 = (const double*)h->x0;
+  a.delta_V = (double*)h->delta_V; a.status = h->status;
+  a.N = h->N; a.batch = h->batch; a.n = h->n; a.m = h->m;
+  a.reg = reg;
+  a.no_f = (h->ilqr_linear || !h->has_f) ? 1 : 0;
+  a.active = h->bwd_active; a.reg_pp = h->bwd_reg;
+  a.L = tile32_lds_layout(h->n, h->m);
+  return a;
+}
+
+// waves per SIMD the LDS image leaves room for (160 KB per CU, four SIMDs), capped at W
+int waves_by_lds(size_t lds_bytes, int W) {
+  const int per_cu = (int)((160u * 1024u) / std::max<size_t>(lds_bytes, 1));
+  return std::max(1, std::min(W, per_cu / 4));
+}
+
+template <int KC, int T1, int TC, int MC>
+int backward_launch(altro_hip_batch* h, const Tile32Args& a) {
+  const size_t lds = (size_t)a.L.total * sizeof(double);
+  const dim3 grid(mf_grid(h->batch)), blk(64);
+  // the register budget follows the occupancy LDS allows anyway: small shapes keep four waves per SIMD's worth of registers
+  auto go = [&](auto kernel) -> int {
+    if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "plan MFMA32: %zu bytes of LDS refused: %s", lds, hipGetErrorString(e));
+    }
+    PROF_LAUNCH(kernel, grid, blk, lds, h->stream, a);
+    return 0;
+  };
+  return go(tile32_backward_kernel<KC, T1, TC, MC, 2>);
+}
+
+template <int KC, int MC>
+int forward_launch(altro_hip_batch* h, const Tile32Args& a) {
+  const Tile32FwdLds L = tile32_fwd_lds_layout(a.n, a.m);
+  const size_t lds = (size_t)L.total * sizeof(double);
+  PROF_LAUNCH((tile32_forward_kernel<KC, MC, 2>), dim3(mf_grid(h->batch)), dim3(64), lds, h->stream, a);
+  return 0;
+}
+
+}  // namespace
+
+namespace altro_hip {
+namespace capi {
+
+bool tile32_supported(int n, int m) {
+  return n >= 5 && n <= T32_MAX_N && m >= 1 && m <= T32_MAX_M && n + m <= 32 && !(n <= 12 && m <= 4);
+}
+
+int tile32_launch_backward(altro_hip_batch* h, double reg) {
+  const Tile32Args a = tile32_args(h, reg);
+  const int kc = (h->n + 3) / 4, t1 = (h->n + 1 + 15) / 16, tc = (h->n + h->m + 15) / 16, mc = (h->m + 3) / 4;
+#define T32_CASE(KC_, T1_, TC_, MC_) \
+  if (kc == KC_ && t1 == T1_ && tc == TC_ && mc == MC_) return backward_launch<KC_, T1_, TC_, MC_>(h, a);
+  T32_CASE(2, 1, 1, 2) T32_CASE(3, 1, 1, 2)
+  T32_CASE(3, 1, 2, 2)
+  T32_CASE(4, 1, 1, 1) T32_CASE(4, 1, 2, 1) T32_CASE(4, 1, 2, 2)
+  T32_CASE(4, 2, 2, 1) T32_CASE(4, 2, 2, 2)
+  T32_CASE(5, 2, 2, 1) T32_CASE(5, 2, 2, 2)
+  T32_CASE(6, 2, 2, 1) T32_CASE(6, 2, 2, 2)
+  T32_CASE(7, 2, 2, 1) T32_CASE(7, 2, 2, 2)
+  T32_CASE(8, 2, 2, 1)
+#undef T32_CASE
+  return fail(ALTRO_HIP_ERR_UNSUPPORTED, "plan MFMA32 has no kernel for (n, m) = (%d, %d)", h->n, h->m);
+}
+
+int tile32_launch_forward(altro_hip_batch* h) {
+  const Tile32Args a = tile32_args(h, 0.0);
+  const int kc = (h->n + 3) / 4, mc = (h->m + 3) / 4;
+#define T32_CASE(KC_, MC_) if (kc == KC_ && mc == MC_) return forward_launch<KC_, MC_>(h, a);
+  T32_CASE(2, 2) T32_CASE(3, 2) T32_CASE(4, 1) T32_CASE(4, 2) T32_CASE(5, 1) T32_CASE(5, 2) T32_CASE(6, 1) T32_CASE(6, 2)
+  T32_CASE(7, 1) T32_CASE(7, 2) T32_CASE(8, 1)
+#undef T32_CASE
+  return fail(ALTRO_HIP_ERR_UNSUPPORTED, "plan MFMA32 has no forward kernel for (n, m) = (%d, %d)", h->n, h->m);
+}
+
+}  // namespace capi
+}  // namespace altro_hip

@@ -186,6 +186,9 @@ int launch_backward(altro_hip_batch* h, double reg) {
     }
   } else if (h->plan == ALTRO_HIP_PLAN_LANE) {
     return h->dtype == ALTRO_HIP_F64 ? lane_launch<double>(h, true, reg) : lane_launch<float>(h, true, reg);
+  } else if (h->g_tile && !h->is_diag) {   // plan MFMA32 (a diagonal cost keeps its diagonals packed: plan GENERIC's own kernel reads those)
+    int rc = tile32_launch_backward(h, reg);
+    if (rc) return rc;
   } else {
     // the knot point's blocks in LDS while they fit; the form without a block for Qxx ("late Q", 3 n^2 instead of 4 n^2 elements) where
     // that keeps more problems on a CU than the batch otherwise gets, or keeps the blocks in LDS at all; past that the same kernel on a
@@ -253,6 +256,9 @@ int launch_forward(altro_hip_batch* h) {
     }
   } else if (h->plan == ALTRO_HIP_PLAN_LANE) {
     return h->dtype == ALTRO_HIP_F64 ? lane_launch<double>(h, false, 0.0) : lane_launch<float>(h, false, 0.0);
+  } else if (h->g_tile) {
+    int rc = tile32_launch_forward(h);
+    if (rc) return rc;
   } else if (h->dtype == ALTRO_HIP_F64) {
     // the knot point's blocks staged in LDS and fetched a knot point ahead while sixteen waves still fit a CU (10 KB each: measured at
     // 4096 problems, (13, 4) 1.53 -> 1.21 ms, (16, 4) 1.62 -> 1.27, but (24, 8) at 13 KB 2.37 -> 3.58); else rows from global memory

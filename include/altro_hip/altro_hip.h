@@ -92,7 +92,10 @@ typedef enum altro_hip_plan {
                                  the iLQR loop of this plan: n, m <= 64                            */
   ALTRO_HIP_PLAN_MFMA16 = 2,  /* wave-per-problem, 16x16x4 MFMA tiles: (n, m) = (12, 4), and any n <= 12,
                                  m <= 4 on zero-padded records (same results, the (12, 4) cost)        */
-  ALTRO_HIP_PLAN_LANE = 3     /* lane-per-problem, batch structure-of-arrays, n <= 6 and m <= 3         */
+  ALTRO_HIP_PLAN_LANE = 3,    /* lane-per-problem, batch structure-of-arrays, n <= 6 and m <= 3         */
+  ALTRO_HIP_PLAN_MFMA32 = 4   /* wave-per-problem, 2 x 2 tiles of v_mfma_f64_16x16x4 (kernels/tvlqr_tile32.hip): fp64, uniform dimensions,
+                                 12 < n <= 31, m <= 8, n + m <= 32 (and n <= 12 with 4 < m <= 8).  Plan GENERIC's arrays and iLQR loop with
+                                 matrix-core sweeps: K, d within 1e-8 of the CPU path (measured 1e-13), not bit for bit            */
 } altro_hip_plan;
 
 /* create flags */
