@@ -1,8 +1,6 @@
 // capi_tile32.hip -- plan MFMA32's sweep launchers: which instantiation of kernels/tvlqr_tile32.hip a shape runs.
 // (A translation unit of its own: the instantiations compile beside the other plans' kernels.)
-#include "capi_internal.h"
-
-#include "kernels/tvlqr_tile32.hip"
+#include "capi_tile32.h"
 
 using namespace altro_hip;
 using namespace altro_hip::capi;
@@ -32,28 +30,6 @@ Tile32Args tile32_args(altro_hip_batch* h, double reg) {
   return a;
 }
 
-// waves per SIMD the LDS image leaves room for (160 KB per CU, four SIMDs), capped at W
-int waves_by_lds(size_t lds_bytes, int W) {
-  const int per_cu = (int)((160u * 1024u) / std::max<size_t>(lds_bytes, 1));
-  return std::max(1, std::min(W, per_cu / 4));
-}
-
-template <int KC, int T1, int TC, int MC>
-int backward_launch(altro_hip_batch* h, const Tile32Args& a) {
-  const size_t lds = (size_t)a.L.total * sizeof(double);
-  const dim3 grid(mf_grid(h->batch)), blk(64);
-  // the register budget follows the occupancy LDS allows anyway: small shapes keep four waves per SIMD's worth of registers
-  auto go = [&](auto kernel) -> int {
-    if (lds > 64 * 1024) {
-      hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "plan MFMA32: %zu bytes of LDS refused: %s", lds, hipGetErrorString(e));
-    }
-    PROF_LAUNCH(kernel, grid, blk, lds, h->stream, a);
-    return 0;
-  };
-  return go(tile32_backward_kernel<KC, T1, TC, MC, 2>);
-}
-
 template <int KC, int MC>
 int forward_launch(altro_hip_batch* h, const Tile32Args& a) {
   const Tile32FwdLds L = tile32_fwd_lds_layout(a.n, a.m);
@@ -67,25 +43,20 @@ int forward_launch(altro_hip_batch* h, const Tile32Args& a) {
 namespace altro_hip {
 namespace capi {
 
-bool tile32_supported(int n, int m) {
-  return n >= 5 && n <= T32_MAX_N && m >= 1 && m <= T32_MAX_M && n + m <= 32 && !(n <= 12 && m <= 4);
-}
+bool tile32_supported(int n, int m) { return tile32_shape_ok(n, m); }
 
 int tile32_launch_backward(altro_hip_batch* h, double reg) {
   const Tile32Args a = tile32_args(h, reg);
-  const int kc = (h->n + 3) / 4, t1 = (h->n + 1 + 15) / 16, tc = (h->n + h->m + 15) / 16, mc = (h->m + 3) / 4;
-#define T32_CASE(KC_, T1_, TC_, MC_) \
-  if (kc == KC_ && t1 == T1_ && tc == TC_ && mc == MC_) return backward_launch<KC_, T1_, TC_, MC_>(h, a);
-  T32_CASE(2, 1, 1, 2) T32_CASE(3, 1, 1, 2)
-  T32_CASE(3, 1, 2, 2)
-  T32_CASE(4, 1, 1, 1) T32_CASE(4, 1, 2, 1) T32_CASE(4, 1, 2, 2)
-  T32_CASE(4, 2, 2, 1) T32_CASE(4, 2, 2, 2)
-  T32_CASE(5, 2, 2, 1) T32_CASE(5, 2, 2, 2)
-  T32_CASE(6, 2, 2, 1) T32_CASE(6, 2, 2, 2)
-  T32_CASE(7, 2, 2, 1) T32_CASE(7, 2, 2, 2)
-  T32_CASE(8, 2, 2, 1)
-#undef T32_CASE
-  return fail(ALTRO_HIP_ERR_UNSUPPORTED, "plan MFMA32 has no kernel for (n, m) = (%d, %d)", h->n, h->m);
+  switch (h->n & 7) {
+    case 0: return tile32_backward_unit0(h, a);
+    case 1: return tile32_backward_unit1(h, a);
+    case 2: return tile32_backward_unit2(h, a);
+    case 3: return tile32_backward_unit3(h, a);
+    case 4: return tile32_backward_unit4(h, a);
+    case 5: return tile32_backward_unit5(h, a);
+    case 6: return tile32_backward_unit6(h, a);
+    default: return tile32_backward_unit7(h, a);
+  }
 }
 
 int tile32_launch_forward(altro_hip_batch* h) {

@@ -53,9 +53,9 @@ struct Tile32Lds {
   int cst;    // 0.0, 1.0
   int total;
 };
-inline __host__ __device__ Tile32Lds tile32_lds_layout(int n, int m) {
+constexpr __host__ __device__ Tile32Lds tile32_lds_layout(int n, int m) {
   const int kc = (n + 3) / 4, mp = 4 * ((m + 3) / 4), nz = n + m, kz = (nz + 3) / 4;
-  Tile32Lds L;
+  Tile32Lds L{};
   L.ldz = 2 * ((2 * kc) | 1);   // 2 x odd >= 4 kc
   L.ldc = 2 * ((2 * kz) | 1);
   L.ldp = (n + 1) | 1;
@@ -63,7 +63,8 @@ inline __host__ __device__ Tile32Lds tile32_lds_layout(int n, int m) {
   L.z = at;   at += L.ldz * nz;
   L.s = at;   at += mp * T32_SLD;
   const int cin = L.ldc * nz + 32, pex = (n + 4) * L.ldp;   // (+32 / +3 rows: tile reads past the blocks stay inside the region)
-  L.c = at;   at += cin > pex ? cin : pex;
+  const int park = m > 4 ? (n >= 16 ? 768 : 256) : 0;      // m > 4: G's tiles wait here while the 8 x 8 factor has the registers
+  L.c = at;   at += (cin > pex ? cin : pex) > park ? (cin > pex ? cin : pex) : park;
   L.f = at;   at += 32;
   L.qr = at;  at += 32;
   L.gv = at;  at += 40;   // (column n of Qt reads gv[n .. n + MP - 1]: past n + m they are zeros)
@@ -134,17 +135,7 @@ struct T32Buf {
 // dozen integer operations beside 22-60 matrix-core instructions -- because hoisted out of the loop (which the compiler does with
 // anything loop-invariant) those addresses alone overflow the register file of the larger instantiations.
 // ------------------------------------------------------------------------------------------------------------------------
-constexpr int t32_count_cols(int KC, int len) {   // loads that cover `len` columns of length n, worst n of the class 4 KC - 3 .. 4 KC
-  int w = 1;
-  for (int n = 4 * KC - 3; n <= 4 * KC; ++n) {
-    if (n < 1) continue;
-    const int cpi = 64 / n, use = len < 0 ? n : len;
-    const int c = (use + cpi - 1) / cpi;
-    if (c > w) w = c;
-  }
-  return w;
-}
-constexpr int t32_count_h(int KC, int MC) { return (4 * KC + 64 / (4 * MC) - 1) / (64 / (4 * MC)); }
+constexpr int t32_count_cols(int len, int cols) { return (cols + 64 / len - 1) / (64 / len); }   // loads that cover `cols` columns of length `len`
 
 struct T32Lanes { int j, g; };
 __device__ __forceinline__ T32Lanes t32_launder(int j, int g) {   // the same values, opaque to loop-invariant code motion
@@ -152,14 +143,19 @@ __device__ __forceinline__ T32Lanes t32_launder(int j, int g) {   // the same va
   return T32Lanes{j, g};
 }
 
-template <int KC, int T1, int TC, int MC, int WPS>
+// NS, MS: n and m, compile-time constants -- every address, mask and stride below folds, and a knot point's integer work shrinks from
+// ~500 vector instructions (the first, run-time-shape form of this kernel: issue-bound at 0.34 of the HBM roofline) to under 100.
+// One instantiation per shape (capi_tile32_*.hip).  LAUNDER: recompute the lane-dependent addresses every knot point instead of
+// keeping them in registers (the m > 4 shapes, whose 8 x 8 factor needs the registers).
+template <int NS, int MS, int WPS, bool LAUNDER>
 __global__ __launch_bounds__(64, WPS) void tile32_backward_kernel(Tile32Args a) {
-  static_assert(T1 <= TC && TC <= 2 && MC <= 2 && KC <= 8, "tile counts");
+  constexpr int KC = (NS + 3) / 4, T1 = (NS + 16) / 16, TC = (NS + MS + 15) / 16, MC = (MS + 3) / 4;
+  static_assert(NS >= 1 && NS <= T32_MAX_N && MS >= 1 && MS <= T32_MAX_M && NS + MS <= 32, "shape");
   extern __shared__ __attribute__((aligned(16))) double lds[];
   constexpr int MP = 4 * MC;
-  constexpr int NA = t32_count_cols(KC, -1);       // loads per n x n block
-  constexpr int NB = t32_count_cols(KC, 4 * MC);   // ... per n x m block (columns of length n)
-  constexpr int NH = t32_count_h(KC, MC);          // ... per m x n block (columns of length m)
+  constexpr int NA = t32_count_cols(NS, NS);       // loads per n x n block
+  constexpr int NB = t32_count_cols(NS, MS);       // ... per n x m block (columns of length n)
+  constexpr int NH = t32_count_cols(MS, NS);       // ... per m x n block (columns of length m)
   constexpr int NGT = TC == 1 ? 1 : 3;             // lower block triangle: (0,0), (1,0), (1,1)
   constexpr int NPT = T1 == 1 ? 1 : 3;
   constexpr int TI[3] = {0, 1, 1}, TJ[3] = {0, 0, 1};
@@ -168,9 +164,10 @@ __global__ __launch_bounds__(64, WPS) void tile32_backward_kernel(Tile32Args a) 
   const int b = mf_problem(blockIdx.x, a.batch);
   if (b >= a.batch) return;
   if (a.active && !a.active[b]) return;   // wave-uniform: the problem has stopped, its outputs stay
-  const int n = a.n, m = a.m, nz = n + m, N = a.N, nn = n * n, nm = n * m;
-  const Tile32Lds L = a.L;
-  const int ZERO = L.cst;
+  constexpr int n = NS, m = MS, nz = n + m, nn = n * n, nm = n * m;
+  const int N = a.N;
+  constexpr Tile32Lds L = tile32_lds_layout(NS, MS);
+  constexpr int ZERO = L.cst;
 
   for (int e = lane; e < L.total; e += 64) lds[e] = 0.0;
   __syncthreads();
@@ -180,14 +177,13 @@ __global__ __launch_bounds__(64, WPS) void tile32_backward_kernel(Tile32Args a) 
       bQ(a.Q + (int64_t)b * a.bsQ), bR(a.R + (int64_t)b * a.bsR), bH(a.H + (int64_t)b * a.bsH), bq(a.q + (int64_t)b * a.bsq),
       br(a.r + (int64_t)b * a.bsr), bK(a.K + (int64_t)b * a.bsK), bd(a.d + (int64_t)b * a.bsd), bP(a.P + (int64_t)b * a.bsP),
       bp(a.p + (int64_t)b * a.bsp);
-  const unsigned sA = (unsigned)nn * 8u, sB = (unsigned)nm * 8u, sv = (unsigned)n * 8u, sR = (unsigned)(m * m) * 8u, sr = (unsigned)m * 8u;
+  constexpr unsigned sA = (unsigned)nn * 8u, sB = (unsigned)nm * 8u, sv = (unsigned)n * 8u, sR = (unsigned)(m * m) * 8u, sr = (unsigned)m * 8u;
 
   // column groups: cpi columns of length n per load (A, Q, B), cph columns of length m (H)
-  const int cpi = 64 / n, cph = 64 / m;
-  const int lrow = lane % n, lcol = lane / n;      // this lane's entry of a group of columns of length n
-  const int hrow = lane % m, hcol = lane / m;      // ... of length m
-  const bool lin = lane < cpi * n, hin = lane < cph * m;
-  const int tn = n >> 4;   // the tile column that holds column n
+  constexpr int cpi = 64 / n, cph = 64 / m;
+  int lrow = lane % n, lcol = lane / n;            // this lane's entry of a group of columns of length n
+  int hrow = lane % m, hcol = lane / m;            // ... of length m
+  constexpr int tn = n >> 4;   // the tile column that holds column n
 
   // ---- terminal cost-to-go: P_N = Q_N, p_N = q_N (tvlqr.cpp:81-90) -----------------------------------------------------------
   double Pt[KC][T1];
@@ -206,18 +202,27 @@ __global__ __launch_bounds__(64, WPS) void tile32_backward_kernel(Tile32Args a) 
       }
   }
 
-  struct Knot { double a[NA], b[NB], q[NA], h[NH], r, s; };
-  auto fetch = [&](Knot& kn, int k) {
-    const unsigned uk = (unsigned)k, cstep = (unsigned)(cpi * n) * 8u, hstep = (unsigned)(cph * m) * 8u;
-    const unsigned lv = (unsigned)lane * 8u;
+  // The next knot point is fetched in two halves, each while nothing else needs its registers: A | B at the top of a step (they
+  // become the Z image at its end), Q | H | R | f | q | r after the step's factorisation and solves (they become the C image after
+  // the NEXT step's first product) -- the solves are where the registers are scarce.
+  struct KnotZ { double a[NA], b[NB]; };
+  struct KnotC { double q[NA], h[NH], r, s; };
+  auto fetch_z = [&](KnotZ& kn, int k) {
+    if (LAUNDER) asm volatile("" : "+v"(lrow), "+v"(lcol));   // (no hoisting of the masks below: see the head comment)
+    const bool lin = lcol < cpi;
+    const unsigned uk = (unsigned)k, cstep = (unsigned)(cpi * n) * 8u, lv = (unsigned)(lcol * n + lrow) * 8u;
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const unsigned v = (lin && i * cpi + lcol < n) ? lv : T32_OOB;
-      kn.a[i] = bA.ld(v, uk * sA + (unsigned)i * cstep);
-      kn.q[i] = bQ.ld(v, uk * sA + (unsigned)i * cstep);
-    }
+    for (int i = 0; i < NA; ++i) kn.a[i] = bA.ld((lin && i * cpi + lcol < n) ? lv : T32_OOB, uk * sA + (unsigned)i * cstep);
 #pragma unroll
     for (int i = 0; i < NB; ++i) kn.b[i] = bB.ld((lin && i * cpi + lcol < m) ? lv : T32_OOB, uk * sB + (unsigned)i * cstep);
+  };
+  auto fetch_c = [&](KnotC& kn, int k) {
+    if (LAUNDER) asm volatile("" : "+v"(lrow), "+v"(lcol), "+v"(hrow), "+v"(hcol));
+    const int lane = lcol * n + lrow;
+    const bool lin = lcol < cpi, hin = hcol < cph;
+    const unsigned uk = (unsigned)k, cstep = (unsigned)(cpi * n) * 8u, hstep = (unsigned)(cph * m) * 8u, lv = (unsigned)lane * 8u;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) kn.q[i] = bQ.ld((lin && i * cpi + lcol < n) ? lv : T32_OOB, uk * sA + (unsigned)i * cstep);
 #pragma unroll
     for (int i = 0; i < NH; ++i) kn.h[i] = bH.ld((hin && i * cph + hcol < n) ? lv : T32_OOB, uk * sB + (unsigned)i * hstep);
     kn.r = bR.ld(lane < m * m ? lv : T32_OOB, uk * sR);
@@ -227,17 +232,24 @@ __global__ __launch_bounds__(64, WPS) void tile32_backward_kernel(Tile32Args a) 
     kn.s = bF.ld(of, uk * sv) + bq.ld(oq, uk * sv) + br.ld(orr, uk * sr);
   };
   // the images: Z = [A B] at leading dimension ldz; C = [Q .; H R] at ldc (rows 0..n-1 Q, n..n+m-1 H | R)
-  auto stage = [&](const Knot& kn) {
-    const int zl = L.z + lcol * L.ldz + lrow, cl = L.c + lcol * L.ldc + lrow;
+  auto stage_z = [&](const KnotZ& kn) {
+    if (LAUNDER) asm volatile("" : "+v"(lrow), "+v"(lcol));
+    const bool lin = lcol < cpi;
+    const int zl = L.z + lcol * L.ldz + lrow;
 #pragma unroll
-    for (int i = 0; i < NA; ++i)
-      if (lin && i * cpi + lcol < n) { lds[zl + i * cpi * L.ldz] = kn.a[i]; lds[cl + i * cpi * L.ldc] = kn.q[i]; }
+    for (int i = 0; i < NA; ++i) if (lin && i * cpi + lcol < n) lds[zl + i * cpi * L.ldz] = kn.a[i];
 #pragma unroll
-    for (int i = 0; i < NB; ++i)
-      if (lin && i * cpi + lcol < m) lds[zl + (n + i * cpi) * L.ldz] = kn.b[i];
+    for (int i = 0; i < NB; ++i) if (lin && i * cpi + lcol < m) lds[zl + (n + i * cpi) * L.ldz] = kn.b[i];
+  };
+  auto stage_c = [&](const KnotC& kn) {
+    if (LAUNDER) asm volatile("" : "+v"(lrow), "+v"(lcol), "+v"(hrow), "+v"(hcol));
+    const int lane = lcol * n + lrow;
+    const bool lin = lcol < cpi, hin = hcol < cph;
+    const int cl = L.c + lcol * L.ldc + lrow;
 #pragma unroll
-    for (int i = 0; i < NH; ++i)
-      if (hin && i * cph + hcol < n) lds[L.c + (i * cph + hcol) * L.ldc + n + hrow] = kn.h[i];
+    for (int i = 0; i < NA; ++i) if (lin && i * cpi + lcol < n) lds[cl + i * cpi * L.ldc] = kn.q[i];
+#pragma unroll
+    for (int i = 0; i < NH; ++i) if (hin && i * cph + hcol < n) lds[L.c + (i * cph + hcol) * L.ldc + n + hrow] = kn.h[i];
     if (lane < m * m) lds[L.c + (n + hcol) * L.ldc + n + hrow] = kn.r;
     const int sml = lane < n ? (a.no_f ? -1 : L.f + lane) : lane < 2 * n ? L.qr + (lane - n) : lane < 2 * n + m ? L.qr + lane - n : -1;
     if (sml >= 0) lds[sml] = kn.s;
@@ -247,15 +259,17 @@ __global__ __launch_bounds__(64, WPS) void tile32_backward_kernel(Tile32Args a) 
   int fail_k = -1;
   const double reg = a.reg_pp ? a.reg_pp[b] : a.reg;
 
-  Knot nxt;
-  fetch(nxt, N - 1);
+  KnotZ nz_;
+  KnotC nc_;
+  fetch_c(nc_, N - 1);
+  fetch_z(nz_, N - 1);
   __syncthreads();
-  stage(nxt);
+  stage_z(nz_);
   __syncthreads();
 
   for (int k = N - 1; k >= 0; --k) {
-    fetch(nxt, k > 0 ? k - 1 : 0);   // the next knot point while this one computes (k == 0 re-reads block 0: harmless)
-    const T32Lanes ln = t32_launder(lane & 15, lane >> 4);
+    fetch_z(nz_, k > 0 ? k - 1 : 0);   // the next knot point while this one computes (k == 0 re-reads block 0: harmless)
+    const T32Lanes ln = LAUNDER ? t32_launder(lane & 15, lane >> 4) : T32Lanes{lane & 15, lane >> 4};
     const int j = ln.j, g = ln.g;
 
     // ---- D1 = [P' | t]^T Z -------------------------------------------------------------------------------------------------
@@ -278,6 +292,10 @@ __global__ __launch_bounds__(64, WPS) void tile32_backward_kernel(Tile32Args a) 
         for (int c = 0; c < KC; ++c) acc = t32_mfma(Pt[c][tr], z[c][tc], acc);
         D1[tr][tc] = acc;
       }
+    // ---- this knot point's cost blocks (requested in the middle of the previous step) become the C image ----------------------
+    __syncthreads();   // (the exchange tile that overlays it was read back a step ago; the barrier orders those reads before these writes)
+    stage_c(nc_);
+    __syncthreads();
     // ---- G = [Q H^T; H R] + Z^T D1 (terms 4 c .. 4 c + 3 = register c & 3 of row tile c >> 2; rows past n - 1 of Z are zero) ------
     // the entries right of Quu and below it start from whatever the image holds there: nobody uses them
     t32_f64x4 G[NGT];
@@ -322,25 +340,13 @@ __global__ __launch_bounds__(64, WPS) void tile32_backward_kernel(Tile32Args a) 
     }
     __syncthreads();
 
-    // what the registers of the new [P p; p^T .] start from: G's own entry, but Qx in column n and in row n
-    t32_f64x4 Pn[NPT];
+    // (m > 4: the 8 x 8 factor below needs G's registers -- its entries wait in LDS, accumulator layout, where the C image was)
+    constexpr bool PARK = MC == 2;
+    if (PARK) {
 #pragma unroll
-    for (int t = 0; t < NPT; ++t) {
-      const int col = 16 * TJ[t] + j;
+      for (int t = 0; t < NPT; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 16 * TI[t] + 4 * r + g;
-        double v = G[t][r];
-        if (TJ[t] == T1 - 1 || T1 == 1) {   // column n lives in the last tile column
-          const double qx = lds[L.gv + (row < n ? row : n)];
-          v = (col == n) ? qx : v;
-        }
-        if (TI[t] == T1 - 1 || T1 == 1) {   // row n in the last tile row
-          const double qx = lds[L.gv + (col < n ? col : n)];
-          v = (row == n) ? qx : v;
-        }
-        Pn[t][r] = v;
-      }
+        for (int r = 0; r < 4; ++r) lds[L.c + (4 * t + r) * 64 + lane] = G[t][r];
     }
 
     // ---- Cholesky of Quu + reg I (lower; a pivot <= 0 fails: tvlqr.cpp:159-164); reciprocal pivots only; unit diagonal past m -----
@@ -383,6 +389,8 @@ __global__ __launch_bounds__(64, WPS) void tile32_backward_kernel(Tile32Args a) 
 #pragma unroll
       for (int aa = 0; aa < MP; ++aa) rhs[aa] = lds[rbase + aa * rstep];
 #pragma unroll
+      for (int c = 0; c < MC; ++c) qm[c][t] = t32_pick4(rhs[4 * c], rhs[4 * c + 1], rhs[4 * c + 2], rhs[4 * c + 3], g);
+#pragma unroll
       for (int aa = 0; aa < MP; ++aa) {
         double s = rhs[aa];
 #pragma unroll
@@ -399,7 +407,6 @@ __global__ __launch_bounds__(64, WPS) void tile32_backward_kernel(Tile32Args a) 
 #pragma unroll
       for (int c = 0; c < MC; ++c) {
         km[c][t] = t32_pick4(kt[4 * c], kt[4 * c + 1], kt[4 * c + 2], kt[4 * c + 3], g);
-        qm[c][t] = t32_pick4(rhs[4 * c], rhs[4 * c + 1], rhs[4 * c + 2], rhs[4 * c + 3], g);
         // row 4 c + g of the unregularised Quu (tvlqr.cpp:174), the entries right of the diagonal from their mirror images
         const int ar = 4 * c + g;
         double s = 0.0;
@@ -426,6 +433,28 @@ __global__ __launch_bounds__(64, WPS) void tile32_backward_kernel(Tile32Args a) 
       }
       dv0 = alive ? dv0 + s0 : dv0;
       dv1 = alive ? dv1 + s1 : dv1;
+    }
+
+    fetch_c(nc_, k > 0 ? k - 1 : 0);   // the next knot point's cost blocks, now that the solves' registers are free
+    // what the registers of the new [P p; p^T .] start from: G's own entry, but Qx in column n and in row n
+    t32_f64x4 Pn[NPT];
+#pragma unroll
+    for (int t = 0; t < NPT; ++t) {
+      const int col = 16 * TJ[t] + j;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * TI[t] + 4 * r + g;
+        double v = PARK ? lds[L.c + (4 * t + r) * 64 + lane] : G[t][r];
+        if (TJ[t] == T1 - 1 || T1 == 1) {   // column n lives in the last tile column
+          const double qx = lds[L.gv + (row < n ? row : n)];
+          v = (col == n) ? qx : v;
+        }
+        if (TI[t] == T1 - 1 || T1 == 1) {   // row n in the last tile row
+          const double qx = lds[L.gv + (col < n ? col : n)];
+          v = (row == n) ? qx : v;
+        }
+        Pn[t][r] = v;
+      }
     }
 
     // ---- [P p; p^T .] += Kt^T W - Qt^T Kt ---------------------------------------------------------------------------------
@@ -489,7 +518,7 @@ __global__ __launch_bounds__(64, WPS) void tile32_backward_kernel(Tile32Args a) 
 
     // ---- the next knot point's images ------------------------------------------------------------------------------------------
     __syncthreads();
-    stage(nxt);
+    stage_z(nz_);
     __syncthreads();
   }
   {
