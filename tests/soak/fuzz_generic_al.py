@@ -26,7 +26,7 @@ for it in range(cases):
     p = problems.ilqr12x4_problem(batch, N, True, n=n, m=m)
     if dense:
         p.update(problems.quadratic_cost(batch, N, n, m))
-    bt = altro_amd.Batch(N, n, m, batch)
+    bt = altro_amd.Batch(N, n, m, batch, plan=altro_amd.PLAN_GENERIC)
     assert bt.plan == altro_amd.PLAN_GENERIC
     bt.set_dynamics(p["A"], p["B"], p["f"])
     if dense:

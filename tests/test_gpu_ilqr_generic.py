@@ -16,7 +16,7 @@ def make(batch, N, n, m, dense, with_f=True):
     p = problems.ilqr12x4_problem(batch, N, with_f, n=n, m=m)      # random LTV dynamics + tracking cost of any shape
     if dense:
         p.update(problems.quadratic_cost(batch, N, n, m))
-    bt = altro_amd.Batch(N, n, m, batch)
+    bt = altro_amd.Batch(N, n, m, batch, plan=altro_amd.PLAN_GENERIC)   # (the bit-for-bit plan by name: AUTO gives these shapes plan MFMA32, tests/test_gpu_tile32.py)
     assert bt.plan == altro_amd.PLAN_GENERIC
     bt.set_dynamics(p["A"], p["B"], p["f"])
     if dense:
@@ -90,7 +90,7 @@ def test_whole_lq_solves_generic(n, m, dense, dtype):
     p = problems.ilqr12x4_problem(batch, N, True, n=n, m=m)
     if dense:
         p.update(problems.quadratic_cost(batch, N, n, m))
-    bt = altro_amd.Batch(N, n, m, batch, dtype=dtype)
+    bt = altro_amd.Batch(N, n, m, batch, dtype=dtype, plan=altro_amd.PLAN_GENERIC)
     assert bt.plan == altro_amd.PLAN_GENERIC
     bt.set_dynamics(p["A"], p["B"], p["f"])
     if dense:
@@ -196,13 +196,13 @@ def test_constrained_solves_generic(n, m, dense, soc, backtracking):
 
 
 def test_generic_plan_says_what_it_does_not_do():
-    bt = altro_amd.Batch(10, 16, 5, 4)
+    bt = altro_amd.Batch(10, 16, 5, 4, plan=altro_amd.PLAN_GENERIC)
     with pytest.raises(altro_amd.AltroHipError):
         bt.set_model(altro_amd.MODEL_BICYCLE, 0.1)
     # dimensions past 64: the TVLQR sweeps run (tests/test_gpu_parity.py::test_generic_random), the iLQR loop says why it does not
     N, n, m, batch = 5, 80, 10, 2
     p = problems.ilqr12x4_problem(batch, N, True, n=n, m=m)
-    big = altro_amd.Batch(N, n, m, batch)
+    big = altro_amd.Batch(N, n, m, batch, plan=altro_amd.PLAN_GENERIC)
     assert big.plan == altro_amd.PLAN_GENERIC
     big.set_dynamics(p["A"], p["B"], p["f"])
     big.set_tracking_cost(p["Qd"], p["Rd"], p["xref"], p["uref"])
@@ -221,7 +221,7 @@ def test_input_guess_before_the_cost_is_kept(dense):
         p.update(problems.quadratic_cost(batch, N, n, m))
 
     def build(guess_first):
-        bt = altro_amd.Batch(N, n, m, batch)
+        bt = altro_amd.Batch(N, n, m, batch, plan=altro_amd.PLAN_GENERIC)
         assert bt.plan == altro_amd.PLAN_GENERIC
         bt.set_dynamics(p["A"], p["B"], p["f"])
         bt.set_initial_state(p["x0"])

@@ -12,17 +12,18 @@ sys.path.insert(0, ROOT)
 import altro_amd  # noqa: E402
 from tests import problems  # noqa: E402
 
-PLAN = {1: "GENERIC", 2: "MFMA16", 3: "LANE"}
+PLAN = {1: "GENERIC", 2: "MFMA16", 3: "LANE", 4: "MFMA32"}
 
 
 def sweep_ms(N, n, m, batch, plan, flags=0):
     pr = problems.random_ltv(64, N, n, m)
     bt = altro_amd.Batch(N, n, m, batch, plan=plan, flags=flags)
-    bt.set_host_batch(64) if bt.plan != altro_amd.PLAN_GENERIC else None
-    if bt.plan == altro_amd.PLAN_GENERIC:
+    generic_arrays = bt.plan in (altro_amd.PLAN_GENERIC, altro_amd.PLAN_MFMA32)    # (no host-batch tiling on plan GENERIC's arrays)
+    bt.set_host_batch(64) if not generic_arrays else None
+    if generic_arrays:
         pr = {k: (np.tile(v, (batch // 64,) + (1,) * (v.ndim - 1)) if isinstance(v, np.ndarray) else v) for k, v in pr.items()}
     bt.set_dynamics(pr["A"], pr["B"], pr["f"]); bt.set_cost(pr["Q"], pr["R"], pr["H"], pr["q"], pr["r"])
-    bt.set_host_batch(0) if bt.plan != altro_amd.PLAN_GENERIC else None
+    bt.set_host_batch(0) if not generic_arrays else None
     bt.set_initial_state(np.tile(pr["x0"][:64], (batch // 64, 1)))
     for _ in range(3):
         bt.sweep()
@@ -44,7 +45,8 @@ def main():
     for batch in batches:
         print("# sweep (backward + forward) ms, N = %d, batch = %d, fp64, random LTV problems; every plan that takes the shape" % (N, batch))
         print("%-8s %-8s %10s %10s %10s %10s %10s %8s" % ("(n, m)", "AUTO ->", "AUTO ms", "LANE ms", "MFMA16 ms", "GENERIC ms", "GEN+MC ms", "worst/AUTO"))
-        shapes = [(28, 4), (24, 8), (20, 8), (16, 4), (14, 7), (13, 4), (12, 4), (12, 3), (11, 4), (10, 4), (8, 2), (7, 3), (6, 3), (6, 2), (6, 1), (5, 3), (5, 2), (5, 1),
+        shapes = [(31, 1), (30, 2), (28, 4), (26, 6), (24, 8), (24, 4), (22, 6), (20, 8), (20, 4), (18, 6), (17, 4), (16, 8), (16, 4), (15, 4), (14, 7), (14, 4), (13, 5), (13, 4), (13, 1),
+                  (12, 8), (12, 5), (10, 6), (8, 8), (6, 6), (5, 5), (12, 4), (12, 3), (11, 4), (10, 4), (8, 2), (7, 3), (6, 3), (6, 2), (6, 1), (5, 3), (5, 2), (5, 1),
                   (4, 3), (4, 2), (4, 1), (3, 3), (3, 2), (2, 1), (1, 1)]
         for (n, m) in shapes:
             if batch > 8192 and (n > 12 or m > 4):
