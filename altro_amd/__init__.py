@@ -37,7 +37,7 @@ C_ABI_SYMBOLS = [
     "altro_hip_set_input_guess", "altro_hip_set_state_guess",
     "altro_hip_open_loop_rollout", "altro_hip_accept", "altro_hip_expand", "altro_hip_merit",
     "altro_hip_stationarity", "altro_hip_get_nominal", "altro_hip_get_expansion",
-    "altro_hip_default_solve_options", "altro_hip_ilqr_solve", "altro_hip_last_solve_counts",
+    "altro_hip_default_solve_options", "altro_hip_set_forms", "altro_hip_get_forms", "altro_hip_ilqr_solve", "altro_hip_last_solve_counts",
     "altro_hip_ilqr_solve_async", "altro_hip_ilqr_poll", "altro_hip_ilqr_wait",
     "altro_hip_linesearch_host",
     "altro_hip_add_linear_constraint", "altro_hip_add_user_constraint", "altro_hip_clear_constraints", "altro_hip_reset_duals",
@@ -46,6 +46,41 @@ C_ABI_SYMBOLS = [
     "altro_hip_set_pointer_mode",
 ]
 CONE_EQUALITY, CONE_IDENTITY, CONE_INEQUALITY, CONE_SOC = 0, 1, 2, 3   # ConstraintType, typedefs.hpp:29-34
+
+# altro_hip_solve_options::forms / altro_hip_set_forms (ALTRO_HIP_FORM_*): how a solve is executed.  The C library reads no environment
+# for these any more (version 300); THIS binding still translates the variables the test-suite and the tools set (forms_from_env), so
+# that one process can alternate forms between calls.
+FORM_NO_SPECULATION, FORM_NO_RUNAHEAD, FORM_NO_MERIT2, FORM_MERIT_LDS, FORM_MERIT_DPP_ALWAYS = 0x1, 0x2, 0x4, 0x8, 0x10
+FORM_EXPAND_LDS, FORM_ALROWS_LDS, FORM_ROLLOUT_ROUNDS, FORM_SEQUENCED, FORM_MERIT_ONE_LAUNCH = 0x20, 0x40, 0x80, 0x100, 0x200
+FORM_LANE_QUAD_OFF, FORM_LANE_QUAD_ON, FORM_GENERIC_LATE_Q_OFF, FORM_GENERIC_LATE_Q_ON, FORM_FUSED_CLOCK = 0x400, 0x800, 0x1000, 0x2000, 0x4000
+
+
+def forms_from_env():
+    """The ALTRO_HIP_* comparison switches of the environment as ALTRO_HIP_FORM_* bits (what the library itself read up to version 200)."""
+    e = os.environ
+    off = lambda name: e.get(name) is not None and e[name].strip() not in ("",) and _atoi(e[name]) == 0
+    f = 0
+    if "ALTRO_HIP_NO_SPECULATION" in e: f |= FORM_NO_SPECULATION
+    if "ALTRO_HIP_NO_RUNAHEAD" in e and not off("ALTRO_HIP_NO_RUNAHEAD"): f |= FORM_NO_RUNAHEAD
+    if off("ALTRO_HIP_MERIT2"): f |= FORM_NO_MERIT2
+    if off("ALTRO_HIP_MERIT_DPP"): f |= FORM_MERIT_LDS
+    elif e.get("ALTRO_HIP_MERIT_DPP") is not None and _atoi(e["ALTRO_HIP_MERIT_DPP"]) == 2: f |= FORM_MERIT_DPP_ALWAYS
+    if off("ALTRO_HIP_EXPAND_DPP"): f |= FORM_EXPAND_LDS
+    if off("ALTRO_HIP_ALROWS_DPP"): f |= FORM_ALROWS_LDS
+    if off("ALTRO_HIP_AFFINE"): f |= FORM_ROLLOUT_ROUNDS
+    if off("ALTRO_HIP_FUSED") or "ALTRO_HIP_NO_FUSED" in e: f |= FORM_SEQUENCED
+    if off("ALTRO_HIP_MERIT_SPLIT"): f |= FORM_MERIT_ONE_LAUNCH
+    if "ALTRO_HIP_LANE_QUAD" in e: f |= FORM_LANE_QUAD_OFF if _atoi(e["ALTRO_HIP_LANE_QUAD"]) == 0 else FORM_LANE_QUAD_ON
+    if "ALTRO_HIP_GENERIC_LATE_Q" in e: f |= FORM_GENERIC_LATE_Q_OFF if _atoi(e["ALTRO_HIP_GENERIC_LATE_Q"]) == 0 else FORM_GENERIC_LATE_Q_ON
+    if "ALTRO_HIP_FUSED_CLOCK" in e: f |= FORM_FUSED_CLOCK
+    return f
+
+
+def _atoi(text):
+    try:
+        return int(text.strip() or 0)
+    except ValueError:
+        return 0
 
 MODEL_LINEAR, MODEL_DOUBLE_INTEGRATOR, MODEL_PENDULUM, MODEL_BICYCLE, MODEL_USER, MODEL_QUADROTOR = 0, 1, 2, 3, 4, 5
 MERIT_FN = C.CFUNCTYPE(None, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p)
@@ -57,7 +92,8 @@ class SolveOptions(C.Structure):
                 ("use_backtracking_linesearch", C.c_int), ("penalty_initial", C.c_double),
                 ("penalty_scaling", C.c_double), ("penalty_max", C.c_double), ("reg_initial", C.c_double),
                 ("reg_retry_max", C.c_int), ("reg_scale", C.c_double), ("reg_min", C.c_double),
-                ("reg_max", C.c_double), ("stop_when_running_at_most", C.c_int)]
+                ("reg_max", C.c_double), ("stop_when_running_at_most", C.c_int),
+                ("forms", C.c_uint), ("fused_sweeps", C.c_int), ("decision_margin", C.c_double)]   # version 300
 
 
 class SolveResult(C.Structure):
@@ -188,6 +224,9 @@ def lib():
         L.altro_hip_get_knot.argtypes = [vp, i, vp, vp]
         L.altro_hip_default_solve_options.argtypes = [C.POINTER(SolveOptions)]
         L.altro_hip_default_solve_options.restype = None
+        L.altro_hip_set_forms.argtypes = [vp, C.c_uint]
+        L.altro_hip_get_forms.argtypes = [vp]
+        L.altro_hip_get_forms.restype = C.c_uint
         L.altro_hip_ilqr_solve.argtypes = [vp, C.POINTER(SolveOptions), vp]
         L.altro_hip_last_solve_counts.argtypes = [vp, C.POINTER(i), C.POINTER(i)]
         L.altro_hip_ilqr_solve_async.argtypes = [vp, C.POINTER(SolveOptions)]
@@ -297,12 +336,15 @@ class Batch:
         _check(self.L.altro_hip_set_initial_state(self.h, pa, int(batch_stride_zero)))
 
     def backward(self, reg=0.0):
+        self._sync_forms()
         _check(self.L.altro_hip_backward(self.h, float(reg)))
 
     def forward_ltv(self):
+        self._sync_forms()
         _check(self.L.altro_hip_forward_ltv(self.h))
 
     def sweep(self, reg=0.0):
+        self._sync_forms()
         _check(self.L.altro_hip_sweep(self.h, float(reg)))
 
     def synchronize(self):
@@ -383,15 +425,19 @@ class Batch:
         _check(self.L.altro_hip_set_state_guess(self.h, pa, int(k_stride_zero), int(batch_stride_zero)))
 
     def open_loop_rollout(self):
+        self._sync_forms()
         _check(self.L.altro_hip_open_loop_rollout(self.h))
 
     def accept(self):
+        self._sync_forms()
         _check(self.L.altro_hip_accept(self.h))
 
     def expand(self):
+        self._sync_forms()
         _check(self.L.altro_hip_expand(self.h))
 
     def merit(self, alpha, derivative=True):
+        self._sync_forms()
         phi = np.zeros(self.batch); dphi = np.zeros(self.batch)
         if np.isscalar(alpha):
             a = np.array([float(alpha)]); uniform = 1
@@ -402,6 +448,7 @@ class Batch:
         return phi, (dphi if derivative else None)
 
     def stationarity(self):
+        self._sync_forms()
         out = np.zeros(self.batch)
         _check(self.L.altro_hip_stationarity(self.h, out.ctypes.data_as(C.c_void_p)))
         return out
@@ -474,6 +521,7 @@ class Batch:
         return out
 
     def feasibility(self):
+        self._sync_forms()
         out = np.zeros(self.batch)
         _check(self.L.altro_hip_feasibility(self.h, out.ctypes.data_as(C.c_void_p)))
         return out
@@ -481,9 +529,16 @@ class Batch:
     def _solve_options(self, iterations_max=200, tol_stationarity=1e-4, tol_meritfun_gradient=1e-8,
                        use_backtracking=False, tol_primal_feasibility=1e-4, penalty_initial=1.0, penalty_scaling=10.0,
                        penalty_max=1e8, reg_initial=0.0, reg_retry_max=0, reg_scale=10.0, reg_min=1e-6, reg_max=1e8,
-                       stop_when_running_at_most=0):
+                       stop_when_running_at_most=0, forms=0, fused_sweeps=None, decision_margin=None):
+        self._sync_forms()
         o = SolveOptions()
         self.L.altro_hip_default_solve_options(C.byref(o))
+        o.forms = int(forms)
+        if fused_sweeps is None and "ALTRO_HIP_FUSED_SWEEPS" in os.environ:
+            fused_sweeps = max(1, _atoi(os.environ["ALTRO_HIP_FUSED_SWEEPS"]))
+        o.fused_sweeps = int(fused_sweeps or 0)
+        if decision_margin is not None:
+            o.decision_margin = float(decision_margin)
         o.tol_primal_feasibility = tol_primal_feasibility
         o.penalty_initial, o.penalty_scaling, o.penalty_max = penalty_initial, penalty_scaling, penalty_max
         o.reg_initial, o.reg_retry_max, o.reg_scale = reg_initial, reg_retry_max, reg_scale
@@ -492,6 +547,17 @@ class Batch:
         o.iterations_max, o.tol_stationarity = iterations_max, tol_stationarity
         o.tol_meritfun_gradient, o.use_backtracking_linesearch = tol_meritfun_gradient, int(use_backtracking)
         return o
+
+    def set_forms(self, forms):
+        """altro_hip_set_forms: ALTRO_HIP_FORM_* bits every later call on this handle runs with (OR-ed with the environment's, see forms_from_env)."""
+        self._forms_user = int(forms)
+        self._sync_forms()
+
+    def _sync_forms(self):
+        want = getattr(self, "_forms_user", 0) | forms_from_env()
+        if want != getattr(self, "_forms_set", 0):
+            _check(self.L.altro_hip_set_forms(self.h, want))
+            self._forms_set = want
 
     @staticmethod
     def _results(rec, sweeps, merit_launches):

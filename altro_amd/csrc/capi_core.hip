@@ -100,7 +100,8 @@ static int batch_create_impl(altro_hip_batch** out, int N, int n, int m, int bat
     // costs the (12, 4) sweep whatever the shape and grows linearly past 4096 problems.  Hence: n >= 5 with m >= 2 rides the padded tile
     // up to 6144 problems ((6, 3): 8192), LANE beyond.  A LANE-only compiled-in device model arriving later moves the (still empty)
     // handle to LANE (altro_hip_set_model).
-    const bool small_tile = lane_supported(n, m) && dtype == ALTRO_HIP_F64 && n >= 5 && m >= 2 && batch <= ((n == 6 && m == 3) ? 8192 : 6144);
+    const bool small_tile = lane_supported(n, m) && dtype == ALTRO_HIP_F64 && n >= 5 && m >= 2 && batch <= ((n == 6 && m == 3) ? 8192 : 6144) &&
+                            !(flags & ALTRO_HIP_LANE_FUSED);   // (a flag only plan LANE honours keeps the handle there: ADVICE r5)
     plan = (n == 12 && m == 4) ? ALTRO_HIP_PLAN_MFMA16
            : (lane_supported(n, m) && !small_tile) ? ALTRO_HIP_PLAN_LANE : (mfma_ok ? ALTRO_HIP_PLAN_MFMA16 : ALTRO_HIP_PLAN_GENERIC);
   }
@@ -267,17 +268,31 @@ namespace altro_hip { namespace capi {
 // A handle created with ALTRO_HIP_PLAN_AUTO that nothing has been set on yet becomes a handle of `plan` in place (same address):
 // a fresh handle is created and the two exchange their contents.
 int replan_empty_handle(altro_hip_batch* h, int plan) {
-  if (!h->auto_plan || h->dyn_set || h->cost_set || h->x0_set || h->model_set || h->lqr_cost_set || h->guess_set || !h->al_defs.empty())
-    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "this handle runs plan %d; create it with plan %d (or call altro_hip_set_model before anything else "
-                                           "on a handle created with ALTRO_HIP_PLAN_AUTO)", h->plan, plan);
+  // "empty": nothing but the initial state (kept on the host for exactly this move) and configuration calls has reached the handle
+  if (!h->auto_plan || h->dyn_set || h->cost_set || h->model_set || h->lqr_cost_set || h->guess_set || !h->al_defs.empty() ||
+      (h->x0_set && h->x0_host.empty()))
+    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "this handle runs plan %d; create it with plan %d (or call altro_hip_set_model before the dynamics, the cost, "
+                                           "a guess or a constraint block reach a handle created with ALTRO_HIP_PLAN_AUTO)", h->plan, plan);
   altro_hip_batch* fresh = nullptr;
   int rc = batch_create_impl(&fresh, h->N, h->n, h->m, h->batch, h->dtype, plan, h->flags, h->device, h->user_stream ? (void*)h->stream : nullptr,
                              nullptr, nullptr);
   if (rc) return rc;
+  // what configuration calls set before the move stays set (pointer mode, host-batch tiling, forms, profiling)
+  fresh->dev_ptrs = h->dev_ptrs; fresh->host_batch = h->host_batch; fresh->forms = h->forms;
+  const int prof = h->prof;
+  std::vector<double> x0 = std::move(h->x0_host);
+  const int x0_bz = h->x0_host_bz;
   std::swap(*h, *fresh);
   h->auto_plan = false;
   altro_hip_batch_destroy(fresh);   // (the old buffers; a caller-supplied stream is shared and not destroyed: own_stream is false on both)
-  return 0;
+  if (prof && (rc = altro_hip_profile_enable(h, prof))) return rc;
+  if (!x0.empty()) {
+    const bool dp = h->dev_ptrs;
+    h->dev_ptrs = false;
+    rc = altro_hip_set_initial_state(h, x0.data(), x0_bz);
+    h->dev_ptrs = dp;
+  }
+  return rc;
 }
 } }
 }  // extern "C++"
@@ -529,7 +544,17 @@ int altro_hip_set_initial_state(altro_hip_batch* h, const double* x0, int bz) {
     rc = h->dtype == ALTRO_HIP_F64
              ? lane_pack<double>(h, (double*)h->l_x0, h->n, x0, h->n, 0, 0, 1, 0, 1, 1, bz)
              : lane_pack<float>(h, (float*)h->l_x0, h->n, x0, h->n, 0, 0, 1, 0, 1, 1, bz);
-  if (!rc) h->x0_set = true;
+  if (!rc) {
+    h->x0_set = true;
+    // a handle that may still move to another plan (altro_hip_set_model on an ALTRO_HIP_PLAN_AUTO handle) keeps the initial state
+    // on the host, so that "x0 first, model second" works like "model first" (host pointers only: a device array is the caller's)
+    h->x0_host.clear();
+    if (h->auto_plan && !h->dev_ptrs && !h->ragged) {
+      h->x0_host.assign(x0, x0 + (size_t)(bz ? 1 : (h->host_batch > 0 && h->host_batch < h->batch ? h->host_batch : h->batch)) * n0);
+      h->x0_host_bz = bz;
+      if (!bz && h->host_batch > 0 && h->host_batch < h->batch) h->x0_host.clear();   // (tiled upload: not kept)
+    }
+  }
   return rc;
 }
 

@@ -196,8 +196,7 @@ bool ensure_spares(altro_hip_batch* h, int count, size_t bytes_each) {
 // The buffers of the three-launch merit evaluation (first use).  No memory for them: the one-launch kernel, for good.
 void merit_split_prepare(altro_hip_batch* h) {
   if (h->merit_split >= 0) return;
-  const char* e = std::getenv("ALTRO_HIP_MERIT_SPLIT");
-  h->merit_split = (e && std::atoi(e) == 0) ? 0 : 1;
+  h->merit_split = form(h, ALTRO_HIP_FORM_MERIT_ONE_LAUNCH) ? 0 : 1;
   if (!h->merit_split) return;
   const size_t jk = (size_t)spec_trials_cap(h) * (h->N + 1) * h->batch * h->esz;
   const size_t jac = ((size_t)h->N * (h->n * h->n + h->n * h->m + h->n + h->m) + h->n) * h->batch * h->esz;
@@ -224,23 +223,16 @@ int wave_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int
   a.al.uniform = h->al_uniform; a.al.rows_per_knot = h->al_rows_per_knot; a.al.N = h->N; a.al.G_count = h->al_G_count; a.al.has_soc = h->al_has_soc; a.al.all_sel = h->al_all_sel; a.al.Gpad = (decltype(a.al.Gpad))h->al_d_Gpad; a.al.Gpad_count = h->al_Gpad_count;
   a.mode = mode;
   a.penalty_scaling = h->expand_penalty_scaling; a.penalty_max = h->expand_penalty_max;
-  if (which == IK_STATIONARITY || which == IK_DUAL) {   // constraint rows in the DPP form unless ALTRO_HIP_ALROWS_DPP=0
-    const char* e = std::getenv("ALTRO_HIP_ALROWS_DPP");
-    a.mode = (e != nullptr && std::atoi(e) == 0) ? 0 : STAT_NO_FEAS;
-  }
-  if (which == IK_EXPAND) {
-    const char* e = std::getenv("ALTRO_HIP_EXPAND_DPP");
-    if (e != nullptr && std::atoi(e) == 0 && !h->cost_dense) a.mode |= EXPAND_LDS;   // (the dense cost lives in the row-layout kernels only)
-  }
+  if (which == IK_STATIONARITY || which == IK_DUAL)   // constraint rows in the DPP form unless ALTRO_HIP_FORM_ALROWS_LDS
+    a.mode = form(h, ALTRO_HIP_FORM_ALROWS_LDS) ? 0 : STAT_NO_FEAS;
+  if (which == IK_EXPAND && form(h, ALTRO_HIP_FORM_EXPAND_LDS) && !h->cost_dense) a.mode |= EXPAND_LDS;   // (the dense cost lives in the row-layout kernels only)
   a.costd = (const S*)h->m_costd; a.costd_term = (const S*)h->m_costd_term; a.cost_dense = h->cost_dense ? 1 : 0;
   if (h->model_set) {   // a device model: the dynamics expansion rides with every gradient expansion of a stored trajectory
     a.mp = h->model;    // (not with the end-of-sweep refresh, EXPAND_NEXT: the merit pass that made the candidate left Z already)
     if (which == IK_EXPAND && (a.mode & EXPAND_GRADIENT) && !(a.mode & EXPAND_NEXT)) a.mode |= EXPAND_DYN;
   }
-  if (which == IK_MERIT) {   // a line-search round: the DPP form of the merit evaluation unless ALTRO_HIP_MERIT_DPP=0 keeps the LDS form
-    const char* e = std::getenv("ALTRO_HIP_MERIT_DPP");
-    a.mode = e == nullptr ? 2 : std::atoi(e) == 0 ? 0 : std::atoi(e) == 2 ? 3 : 2;   // (2: the DPP form whatever the launcher's rule)
-  }
+  if (which == IK_MERIT)   // a line-search round: the DPP form of the merit evaluation unless ALTRO_HIP_FORM_MERIT_LDS keeps the LDS form
+    a.mode = form(h, ALTRO_HIP_FORM_MERIT_LDS) ? 0 : form(h, ALTRO_HIP_FORM_MERIT_DPP_ALWAYS) ? 3 : 2;   // (3: the DPP form whatever the launcher's rule)
   a.dyn = (const S*)h->m_in; a.dyn_bs = h->m_st.in_bs; a.dyn_ks = h->m_st.in_ks;
   a.cin = (S*)h->m_cin; a.cin_bs = h->m_st.cin_bs; a.cin_ks = h->m_st.cin_ks;
   a.term = (S*)h->m_term; a.out = (const S*)h->m_out; a.out_bs = h->m_st.out_bs; a.out_ks = h->m_st.out_ks;
@@ -1182,7 +1174,27 @@ void altro_hip_default_solve_options(altro_hip_solve_options* o) {
   o->reg_min = 1e-6;
   o->reg_max = 1e8;
   o->stop_when_running_at_most = 0;   // (extension: every problem to its own end)
+  o->forms = 0;
+  o->fused_sweeps = 0;
+  o->decision_margin = 1e-9;
 }
+int altro_hip_set_forms(altro_hip_batch* h, unsigned forms) {
+  int rc = check(h);
+  if (rc) return rc;
+  if ((forms & ALTRO_HIP_FORM_LANE_QUAD_OFF) && (forms & ALTRO_HIP_FORM_LANE_QUAD_ON))
+    return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "ALTRO_HIP_FORM_LANE_QUAD_OFF and _ON exclude each other");
+  if ((forms & ALTRO_HIP_FORM_GENERIC_LATE_Q_OFF) && (forms & ALTRO_HIP_FORM_GENERIC_LATE_Q_ON))
+    return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "ALTRO_HIP_FORM_GENERIC_LATE_Q_OFF and _ON exclude each other");
+  if (((h->forms ^ forms) & ALTRO_HIP_FORM_MERIT_ONE_LAUNCH) && h->merit_split >= 0) {   // decided at the first evaluation: decide again
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->i_merit_jk) { (void)hipFree(h->i_merit_jk); h->i_merit_jk = nullptr; }
+    if (h->i_spec_jac) { (void)hipFree(h->i_spec_jac); h->i_spec_jac = nullptr; }
+    h->merit_split = -1;
+  }
+  h->forms = forms;
+  return 0;
+}
+unsigned altro_hip_get_forms(const altro_hip_batch* h) { return h ? h->forms : 0u; }
 int altro_hip_last_solve_counts(const altro_hip_batch* h, int* sweeps, int* merit_launches) {
   if (!h) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "null handle");
   if (sweeps) *sweeps = h->last_sweeps;

@@ -48,6 +48,7 @@ using namespace altro_hip;   // internal header: the handle below names the kern
 struct altro_hip_batch {
   int N = 0, n = 0, m = 0, batch = 0, dtype = 0, plan = 0, device = 0;
   unsigned flags = 0;
+  unsigned forms = 0;     // ALTRO_HIP_FORM_* bits of the handle (altro_hip_set_forms); a solve ORs its options' bits in for its duration
   hipStream_t stream = nullptr;
   bool own_stream = false;
   size_t esz = 8;  // element size on the device
@@ -65,6 +66,7 @@ struct altro_hip_batch {
   // affine line-search trials (plan MFMA16, dynamics as data, fp64: kernels/ilqr_merit2_dpp.hip AFF): buffers, and the two switches the
   // solve loop sets -- on for this solve / this launch is a line-search round
   void *i_sens = nullptr, *i_sens_alpha = nullptr, *i_aff_part = nullptr, *i_aff_on = nullptr;
+  bool aff_failed = false;                   // the buffers could not be had once: no retry on this handle
   bool aff_enabled = false, aff_round = false, aff_store = false;   // (aff_store: this launch is the sweep's phi(0) evaluation)
   bool g_tile = false;                       // plan MFMA32: plan GENERIC's arrays, the sweeps of kernels/tvlqr_tile32.hip (capi_tile32.hip)
   bool g_mfma = false;                       // plan GENERIC, fp64: the backward sweep's products on the matrix cores (ALTRO_HIP_GENERIC_MATRIX_CORES)
@@ -118,6 +120,8 @@ struct altro_hip_batch {
   int spec_max_iters = 25;        // need to reproduce the state machine's step sequence)
   ModelParams model{MODEL_LINEAR, 0.0f, 0, 2.7, 1.5};
   bool model_set = false, lqr_cost_set = false, guess_set = false;
+  std::vector<double> x0_host;    // the initial state as given, while the handle may still move to another plan (replan_empty_handle)
+  int x0_host_bz = 0;
   bool auto_plan = false;         // created with ALTRO_HIP_PLAN_AUTO (the plan may still move to LANE when a LANE-only device model arrives)
   bool user_stream = false;
   // augmented-Lagrangian constraint blocks (plan LANE): host mirrors + device tables, uploaded lazily
@@ -180,6 +184,8 @@ struct altro_hip_batch {
 
 namespace altro_hip {
 namespace capi {
+
+inline bool form(const altro_hip_batch* h, unsigned bit) { return (h->forms & bit) != 0; }
 
 inline int dmalloc(altro_hip_batch* h, void** p, size_t bytes) {
   hipError_t e = hipMalloc(p, bytes ? bytes : 16);

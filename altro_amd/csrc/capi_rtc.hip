@@ -413,6 +413,13 @@ int altro_hip_set_model_source(altro_hip_batch* h, const char* source, float tim
     return fail(ALTRO_HIP_ERR_UNSUPPORTED, "run-time compiled models run on plans LANE (n <= 6, m <= 3) and MFMA16 (n <= 12, m <= 4); this "
                                            "handle is on plan %d with (n, m) = (%d, %d)", h->plan, h->n, h->m);
   HIP_TRY(hipSetDevice(h->device));
+  if (h->plan == ALTRO_HIP_PLAN_MFMA16 && h->auto_plan && lane_supported(h->n, h->m)) {
+    // nonlinear constraint blocks from source are plan LANE's: an ALTRO_HIP_PLAN_AUTO handle that rides the padded tile only because
+    // of its batch size moves there while it is still empty
+    const std::string probe(source);
+    if ((defines_function(probe, "altro_user_constraint") || defines_function(probe, "altro_user_constraint_jacobian")) &&
+        (rc = replan_empty_handle(h, ALTRO_HIP_PLAN_LANE))) return rc;
+  }
   if (h->plan == ALTRO_HIP_PLAN_MFMA16) {   // the tile plan's row-layout kernels around the caller's model (kernels/ilqr_tile_model.hip)
     if (h->dtype != ALTRO_HIP_F64)
       return fail(ALTRO_HIP_ERR_UNSUPPORTED, "device models on plan MFMA16 run on fp64 records (create the handle with ALTRO_HIP_F64)");

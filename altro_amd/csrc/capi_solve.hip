@@ -23,11 +23,6 @@ using namespace altro_hip::capi;
 
 namespace {
 
-bool env_off(const char* name) {   // NAME=0 switches a default form off (the comparison forms the tests and tools hold the defaults against)
-  const char* e = std::getenv(name);
-  return e != nullptr && std::atoi(e) == 0;
-}
-
 struct SolveRun {
   altro_hip_batch* h;
   altro_hip_solve_options o;
@@ -48,13 +43,15 @@ struct SolveRun {
   bool hessian_stored = false;
   int diag_mode = 0;
   int* active0 = nullptr;
+  unsigned forms0 = 0;            // the handle's own forms (the solve's are OR-ed in for its duration)
 
-  explicit SolveRun(altro_hip_batch* h_) : h(h_), active0(h_->i_active) {}
+  explicit SolveRun(altro_hip_batch* h_) : h(h_), active0(h_->i_active), forms0(h_->forms) {}
   ~SolveRun() {   // whatever path leaves the solve: no speculation state, mask or swapped pointer survives it
     h->bwd_active = nullptr; h->bwd_reg = nullptr; h->stat_skip = nullptr;
     h->spec_trials = 1; h->spec_pre = 0;
     h->aff_round = false; h->aff_enabled = false; h->aff_store = false;
     h->i_active = active0;
+    h->forms = forms0;
   }
 
   int loop(int which) {
@@ -109,6 +106,7 @@ struct SolveRun {
 int SolveRun::configure(const altro_hip_solve_options* opts) {
   if (opts) o = *opts;
   else altro_hip_default_solve_options(&o);
+  h->forms = forms0 | o.forms;
   la.prob = h->i_prob; la.alpha = h->i_alpha; la.active = h->i_active; la.phi = h->i_phi; la.dphi = h->i_dphi;
   la.counters = h->i_counters; la.batch = h->batch; la.iter = 0; la.iterations_max = o.iterations_max;
   la.tol_stationarity = o.tol_stationarity; la.tol_meritfun_gradient = o.tol_meritfun_gradient;
@@ -136,30 +134,41 @@ int SolveRun::configure(const altro_hip_solve_options* opts) {
   spare_each = (size_t)cand_elems * h->esz;   // one spare candidate trajectory
   trials_cap = spec_trials_cap(h);
   // speculative backtracking: how much of the chip the searching problems occupy, and how much there is
-  spec_all_on = std::getenv("ALTRO_HIP_NO_SPECULATION") == nullptr && !generic_plan;   // (plan GENERIC evaluates one step per launch)
+  spec_all_on = !form(h, ALTRO_HIP_FORM_NO_SPECULATION) && !generic_plan;   // (plan GENERIC evaluates one step per launch)
   spec_on = o.use_backtracking_linesearch != 0 && spec_all_on;
-  merit_rounds_dpp = !env_off("ALTRO_HIP_MERIT_DPP") || h->cost_dense || h->model_set;   // (a dense cost, a device model: row-layout kernels only)
+  merit_rounds_dpp = !form(h, ALTRO_HIP_FORM_MERIT_LDS) || h->cost_dense || h->model_set;   // (a dense cost, a device model: row-layout kernels only)
   spec_capacity = lane_plan ? 512 : (merit_rounds_dpp ? 2048 : 4096);   // two waves per CU (LANE: latency-bound; more slow each other down) / four per SIMD (MFMA16)
-  run_ahead = std::getenv("ALTRO_HIP_NO_RUNAHEAD") == nullptr || env_off("ALTRO_HIP_NO_RUNAHEAD");
+  run_ahead = !form(h, ALTRO_HIP_FORM_NO_RUNAHEAD);
   // Plan MFMA16: phi(0) and the line search's first step from one pass over the records, the candidate's stationarity / feasibility
-  // from that same pass.  ALTRO_HIP_MERIT2=0 keeps the one-evaluation-per-launch sequence (the comparison the tests hold this against).
-  dual = h->plan == ALTRO_HIP_PLAN_MFMA16 && std::getenv("ALTRO_HIP_NO_SPECULATION") == nullptr && !env_off("ALTRO_HIP_MERIT2");
+  // from that same pass.  ALTRO_HIP_FORM_NO_MERIT2 keeps the one-evaluation-per-launch sequence (the comparison the tests hold this against).
+  dual = h->plan == ALTRO_HIP_PLAN_MFMA16 && !form(h, ALTRO_HIP_FORM_NO_SPECULATION) && !form(h, ALTRO_HIP_FORM_NO_MERIT2);
   // Plan MFMA16, diagonal cost, bound-type blocks only: the Hessian blocks differ from sweep to sweep on their diagonal alone, so
   // after this solve's first (full) Hessian expansion the later ones store 16 values per knot point instead of 158 (EXPAND_DIAG)
   diag_mode = (h->plan == ALTRO_HIP_PLAN_MFMA16 && al && !h->cost_dense && h->al_all_sel) ? EXPAND_DIAG : 0;
   running = h->batch;
-  // Affine line-search trials (kernels/ilqr_merit2_dpp.hip, AFF): plan MFMA16, dynamics as data, fp64, the two-trial first pass (which
-  // (the sweep's phi(0) evaluation leaves the base trajectory and its sensitivity behind).  ALTRO_HIP_AFFINE=0 keeps every trial a rollout.
-  h->aff_enabled = h->plan == ALTRO_HIP_PLAN_MFMA16 && h->dtype == ALTRO_HIP_F64 && !h->model_set && merit_rounds_dpp && !env_off("ALTRO_HIP_AFFINE");
+  // Affine line-search trials (kernels/ilqr_merit2_dpp.hip, AFF): plan MFMA16, dynamics as data, fp64; the sweep's phi(0) evaluation
+  // leaves the base trajectory and its sensitivity behind.  ALTRO_HIP_FORM_ROLLOUT_ROUNDS keeps every trial a rollout.
+  h->aff_enabled = h->plan == ALTRO_HIP_PLAN_MFMA16 && h->dtype == ALTRO_HIP_F64 && !h->model_set && merit_rounds_dpp &&
+                   !form(h, ALTRO_HIP_FORM_ROLLOUT_ROUNDS) && !h->aff_failed;
   h->aff_round = false; h->aff_store = false;
-  if (h->aff_enabled && !h->i_sens) {
+  if (h->aff_enabled && !(h->i_sens && h->i_sens_alpha && h->i_aff_part && h->i_aff_on)) {
+    // all four buffers or none: a partial allocation is released and remembered, so that no later solve of this handle
+    // finds a null pointer behind a non-null one or retries a multi-gigabyte hipMalloc; the sensitivity buffer (192 B per knot point
+    // and problem) is only taken while it stays below a quarter of what the handle already holds -- an optimisation must not be what
+    // runs a large batch out of memory
     const size_t B = h->batch, chunks = (h->N + 15) / 16;
-    int rc = dmalloc(h, &h->i_sens, B * (h->N + 1) * 24 * sizeof(double));
+    const size_t sens_bytes = B * (h->N + 1) * 24 * sizeof(double);
+    int rc = sens_bytes > h->device_bytes / 4 + (size_t(64) << 20) ? 1 : 0;
+    if (!rc) rc = dmalloc(h, &h->i_sens, sens_bytes);
     if (!rc) rc = dmalloc(h, &h->i_sens_alpha, B * sizeof(double));
     if (!rc) rc = dmalloc(h, &h->i_aff_part, chunks * ILQR_SPEC_TRIALS * B * 2 * sizeof(double));
     if (!rc) rc = dmalloc(h, &h->i_aff_on, (size_t)ILQR_SPEC_TRIALS * B * sizeof(int));
     if (!rc && hipMemsetAsync(h->i_aff_on, 0, (size_t)ILQR_SPEC_TRIALS * B * sizeof(int), h->stream) != hipSuccess) rc = 1;
-    if (rc) { h->aff_enabled = false; (void)hipGetLastError(); }   // an optimisation only
+    if (rc) {   // an optimisation only: this handle's rounds stay rollouts
+      for (void** q : {&h->i_sens, &h->i_sens_alpha, &h->i_aff_part, &h->i_aff_on}) { if (*q) (void)hipFree(*q); *q = nullptr; }
+      h->aff_enabled = false; h->aff_failed = true;
+      (void)hipGetLastError();
+    }
   }
   return 0;
 }
@@ -183,8 +192,8 @@ int SolveRun::ensure_counters() {
 
 // Plan LANE: whole solves run in ONE launch -- a workgroup of four (eight) waves per 8 / 16 / 32 problems sequencing itself with no
 // host in between (kernels/ilqr_fused.hip) -- bit-identical to the launch-sequenced loop (tests/test_gpu_fused.py,
-// tools/fuzz_fused.py).  ALTRO_HIP_FUSED=1 / =0 forces one or the other (ALTRO_HIP_NO_FUSED, any value, = the latter);
-// ALTRO_HIP_FUSED_SWEEPS=n hands the problems still running after n sweeps over to the loop (a test hook: the hand-over is exact at
+// tools/fuzz_fused.py).  ALTRO_HIP_FORM_SEQUENCED forces the latter;
+// altro_hip_solve_options::fused_sweeps = n hands the problems still running after n sweeps over to the loop (a test hook: the hand-over is exact at
 // any sweep).  POLICY: fused wherever the kernel exists.  Measured on MI355X (tools/solve_batches.py, profiles/r02p_solve_batches.txt;
 // bicycle + steering bound, N = 50, median wall ms fused / sequenced): backtracking search 5.5 / 7.4 at 256 problems, 20 / 31 at 2048,
 // 24 / 44 at 8192, 76 / 173 at 65536; cubic search 25 / 33, 28 / 61, 36 / 106, 99 / 316; pendulum, 8192 problems: 2.4 / 4.1, 2.6 / 4.3.
@@ -196,14 +205,11 @@ int SolveRun::choose_path() {
                          !(h->flags & ALTRO_HIP_LANE_FUSED) && h->model.kind != MODEL_USER &&   // (run-time models: sequenced loop)
                          !h->cost_dense &&   // (the one-launch kernel is instantiated for the diagonal cost: a dense one runs sequenced)
                          o.stop_when_running_at_most <= 0;   // (the batch-level early return is the sequenced loop's)
-  bool fused_want = true;
-  if (const char* e = std::getenv("ALTRO_HIP_FUSED")) fused_want = std::atoi(e) != 0;
-  if (std::getenv("ALTRO_HIP_NO_FUSED") != nullptr) fused_want = false;
-  fused = fused_can && fused_want;
+  fused = fused_can && !form(h, ALTRO_HIP_FORM_SEQUENCED);
   if (fused && !ensure_spares(h, 3, spare_each))   // the waves' speculative steps (at most four per evaluation) need three
     fused = false;                                 // spare trajectories; without them THIS solve runs the sequenced loop
   if (async) {   // results while the solve runs: only the one-launch path can publish them
-    if (!fused || std::getenv("ALTRO_HIP_FUSED_SWEEPS") != nullptr)
+    if (!fused || o.fused_sweeps > 0)
       return fail(ALTRO_HIP_ERR_UNSUPPORTED, "altro_hip_ilqr_solve_async needs the one-launch solve kernel (plan LANE with a compiled-in "
                                              "device model, default environment); use altro_hip_ilqr_solve");
     const size_t bytes = (size_t)h->batch * sizeof(IlqrPollRec);
@@ -261,7 +267,7 @@ static void print_fused_clock(const std::vector<unsigned long long>& hc, int clk
 
 int SolveRun::run_fused() {
   int fused_sweeps = o.iterations_max;
-  if (const char* e = std::getenv("ALTRO_HIP_FUSED_SWEEPS")) fused_sweeps = std::max(1, std::min(o.iterations_max, std::atoi(e)));
+  if (o.fused_sweeps > 0) fused_sweeps = std::max(1, std::min(o.iterations_max, o.fused_sweeps));
   HIP_TRY(hipMemsetAsync(h->i_counters, 0, 4 * sizeof(int), h->stream));
   IlqrFusedArgs fa{0, fused_sweeps, o.reg_retry_max, reg_on ? 1 : 0, h->i_counters, nullptr, fused_prologue ? 1 : 0};
   if (async) {
@@ -273,7 +279,7 @@ int SolveRun::run_fused() {
   const int clk_G = ilqr_fused_group(h->batch);
   const int clk_groups = (h->batch + clk_G - 1) / clk_G;
   unsigned long long* clk = nullptr;     // ALTRO_HIP_FUSED_CLOCK: per-phase time of the kernel, printed to stderr (a tuning aid)
-  if (std::getenv("ALTRO_HIP_FUSED_CLOCK") != nullptr && !async) {   // (an async solve returns before the clock could be read or freed)
+  if (form(h, ALTRO_HIP_FORM_FUSED_CLOCK) && !async) {   // (an async solve returns before the clock could be read or freed)
     const size_t bytes = (size_t)clk_groups * ILQR_FUSED_PHASES * sizeof(unsigned long long);
     if (hipMalloc((void**)&clk, bytes) == hipSuccess) { (void)hipMemsetAsync(clk, 0, bytes, h->stream); fa.clk = clk; }
   }
@@ -462,7 +468,7 @@ int SolveRun::outer_update() {
   // plan MFMA16, DPP forms: ONE pass over the constraint rows does the dual update, the gradients and the next sweep's Hessians
   // (EXPAND_DUAL | EXPAND_NEXT), and PenaltyUpdate's bookkeeping follows it
   const bool tile = !lane_plan && !generic_plan;
-  const bool expand_dpp = !env_off("ALTRO_HIP_EXPAND_DPP"), alrows_dpp = !env_off("ALTRO_HIP_ALROWS_DPP");
+  const bool expand_dpp = !form(h, ALTRO_HIP_FORM_EXPAND_LDS), alrows_dpp = !form(h, ALTRO_HIP_FORM_ALROWS_LDS);
   int rc;
   if (tile && expand_dpp && alrows_dpp) {
     h->expand_penalty_scaling = o.penalty_scaling; h->expand_penalty_max = o.penalty_max;

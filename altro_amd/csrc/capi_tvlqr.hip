@@ -30,9 +30,8 @@ int lane_launch(altro_hip_batch* h, bool backward, double reg) {
   // 16384, 0.56 / 0.44 at 32768, 1.10 / 0.84 at 65536; (2, 1) 0.10 / 0.12, 0.11 / 0.12, 0.16 / 0.14, 0.31 / 0.25, 0.60 / 0.49.
   // The quad form shortens the chain of one wave (what bounds small batches); once every SIMD has its waves the sweep is
   // HBM-bound and the lane-per-problem form's 512-byte runs stream better than the quad's four 128-byte segments.
-  // ALTRO_HIP_LANE_QUAD=0 / 1 forces one or the other.
-  const char* qe = std::getenv("ALTRO_HIP_LANE_QUAD");
-  const bool quad_on = qe ? std::atoi(qe) != 0 : h->batch <= 12288;
+  // ALTRO_HIP_FORM_LANE_QUAD_OFF / _ON forces one or the other.
+  const bool quad_on = form(h, ALTRO_HIP_FORM_LANE_QUAD_ON) ? true : form(h, ALTRO_HIP_FORM_LANE_QUAD_OFF) ? false : h->batch <= 12288;
   const bool q42 = h->n == 4 && h->m == 2, q21 = h->n == 2 && h->m == 1;
   if (backward) h->bwd_quad = quad_on && (q42 || q21);
   if (!backward) h->fwd_quad = quad_on && q42;
@@ -200,7 +199,8 @@ int launch_backward(altro_hip_batch* h, double reg) {
     const int cus = 256;
     bool late_q = lds4 > kGenericLdsLimit ? lds3 <= kGenericLdsLimit
                                           : (per_cu(lds3) > per_cu(lds4) && (int64_t)h->batch > (int64_t)cus * per_cu(lds4));
-    if (std::getenv("ALTRO_HIP_GENERIC_LATE_Q")) late_q = std::atoi(std::getenv("ALTRO_HIP_GENERIC_LATE_Q")) != 0 && lds3 <= kGenericLdsLimit;
+    if (form(h, ALTRO_HIP_FORM_GENERIC_LATE_Q_ON)) late_q = lds3 <= kGenericLdsLimit;
+    else if (form(h, ALTRO_HIP_FORM_GENERIC_LATE_Q_OFF)) late_q = false;
     const size_t lds = late_q ? lds3 : lds4;
     const bool big = lds > kGenericLdsLimit;
     if (big && !h->g_ws) {

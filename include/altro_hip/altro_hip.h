@@ -59,7 +59,7 @@
 extern "C" {
 #endif
 
-#define ALTRO_HIP_VERSION 200
+#define ALTRO_HIP_VERSION 300
 #define ALTRO_HIP_TVLQR_SUCCESS (-1) /* tvlqr.h:11 */
 
 typedef struct altro_hip_batch altro_hip_batch; /* opaque handle */
@@ -79,13 +79,19 @@ typedef enum altro_hip_error {
   ALTRO_HIP_ERR_OUT_OF_MEMORY = -6
 } altro_hip_error;
 
-/* Which kernel family a handle runs.  AUTO picks by measured sweep cost (tools/shape_cliff.py, profiles/r05i_shape_cliff*.txt):
+/* Which kernel family a handle runs.  AUTO picks by measured sweep cost (tools/shape_cliff.py, profiles/r06b_shape_cliff.txt):
  * (12, 4) -> MFMA16; n <= 6, m <= 3 -> LANE, except n >= 5 with m >= 2 below 6144 problems ((6, 3): 8192), where a lane carrying
  * whole 5 x 5 / 6 x 6 blocks is a long single-wave chain and the zero-padded tile is up to 2.7 x faster -> MFMA16 (such a handle moves
  * to LANE by itself when altro_hip_set_model names a compiled-in model only LANE carries, provided nothing else was set on it yet);
- * other n <= 12, m <= 4 -> MFMA16 (padded); anything larger (<= 256) -> GENERIC (the TVLQR sweep for any size; the iLQR loop for
- * n, m <= 64 with dynamics given as data, a quadratic cost and linear constraint blocks in every cone, kernels/ilqr_generic.hip:
- * correctness first; no device models, no regularisation retry). */
+ * other n <= 12, m <= 4 -> MFMA16 (padded); fp64 problems with uniform dimensions, n <= 31, m <= 8, n + m <= 32 past that tile ->
+ * MFMA32 (the same arrays and iLQR loop as GENERIC, the sweeps on 2 x 2 matrix-core tiles: 3-6 x faster than GENERIC); anything else
+ * (<= 256) -> GENERIC (the TVLQR sweep for any size; the iLQR loop for n, m <= 64 with dynamics given as data, a quadratic cost and
+ * linear constraint blocks in every cone, kernels/ilqr_generic.hip: correctness first; no device models, no regularisation retry).
+ * What AUTO does NOT promise is the CPU path's bits: plans LANE and GENERIC repeat it operation for operation (bit-identical K, d, P,
+ * p), the matrix-core plans MFMA16 / MFMA32 agree with it to rounding (K, d within 1e-8 absolute, measured 1e-13).  A caller that
+ * needs the bits names ALTRO_HIP_PLAN_LANE / ALTRO_HIP_PLAN_GENERIC; one that passes a flag only plan LANE honours
+ * (ALTRO_HIP_LANE_FUSED) stays on LANE under AUTO.  altro_hip_ilqr_solve_async needs plan LANE with a compiled-in device model
+ * (altro_hip_set_model on an AUTO handle moves it there while nothing but the initial state has been set). */
 typedef enum altro_hip_plan {
   ALTRO_HIP_PLAN_AUTO = 0,
   ALTRO_HIP_PLAN_GENERIC = 1, /* wave-per-problem, any (n, m) <= 256: blocks staged in LDS, or (past ~32) worked on in global memory;
@@ -343,7 +349,40 @@ typedef struct altro_hip_solve_options { /* AltroOptions, solver_options.hpp:16-
    * the full solve.  Honoured by the launch-sequenced loop (plans MFMA16 and GENERIC; plan LANE runs that loop instead of its
    * one-launch kernel when k > 0).  Default 0: solve every problem to its own end, like the reference.                        */
   int stop_when_running_at_most;
+  /* ---- version 300 ----
+   * HOW the solve is executed: ALTRO_HIP_FORM_* bits, OR-ed with the handle's (altro_hip_set_forms).  0 = the defaults.  These were
+   * process-environment switches (ALTRO_HIP_AFFINE, _NO_SPECULATION, _MERIT2, ...) until version 200: what changes iterates -- even
+   * in the last bits -- belongs to the call, not to the process.                                                                   */
+  unsigned forms;
+  /* plan LANE: hand the problems still running after this many sweeps of the one-launch solve kernel over to the launch-sequenced
+   * loop (the hand-over is exact at any sweep: a test hook).  0: the one-launch kernel runs every sweep.                         */
+  int fused_sweeps;
+  /* The decision guard of the affine line-search rounds (plan MFMA16, dynamics as data): a trial whose phi, phi' fall
+   * within this RELATIVE margin of a line-search decision boundary (Armijo, curvature, the interval tests of linesearch.cpp:37-351,
+   * the thresholds of cubicspline.c) is evaluated again as a rollout (SolverImpl::MeritFunction's own order, solver.cpp:285-316)
+   * and decided on that.  Default 1e-9 (the two forms agree to 1e-13); 0 switches the guard off.                                 */
+  double decision_margin;
 } altro_hip_solve_options;
+/* altro_hip_solve_options::forms / altro_hip_set_forms.  Bit-for-bit equal to the default unless said otherwise. */
+#define ALTRO_HIP_FORM_NO_SPECULATION 0x0001u    /* one line-search step per launch (no two-trial pass, no speculative backtracking steps) */
+#define ALTRO_HIP_FORM_NO_RUNAHEAD 0x0002u       /* the host waits for every verdict before it enqueues on                    */
+#define ALTRO_HIP_FORM_NO_MERIT2 0x0004u         /* plan MFMA16: phi(0) and the first step in separate launches                             */
+#define ALTRO_HIP_FORM_MERIT_LDS 0x0008u         /* plan MFMA16: line-search rounds / altro_hip_merit in the LDS form (equal to rounding)   */
+#define ALTRO_HIP_FORM_MERIT_DPP_ALWAYS 0x0010u  /* ... in the row-layout form whatever the launcher's rule                                 */
+#define ALTRO_HIP_FORM_EXPAND_LDS 0x0020u        /* plan MFMA16: the LDS form of the expansion                                              */
+#define ALTRO_HIP_FORM_ALROWS_LDS 0x0040u        /* plan MFMA16: dual update / feasibility in the LDS form                                  */
+#define ALTRO_HIP_FORM_ROLLOUT_ROUNDS 0x0080u    /* plan MFMA16: every line-search trial a rollout, no affine rounds (equal to rounding, 1e-13;
+                                                    the reference's own evaluation order)                                                    */
+#define ALTRO_HIP_FORM_SEQUENCED 0x0100u         /* plan LANE: the launch-sequenced loop instead of the one-launch solve kernel             */
+#define ALTRO_HIP_FORM_MERIT_ONE_LAUNCH 0x0200u  /* plan LANE: MeritFunction in one launch instead of three                                 */
+#define ALTRO_HIP_FORM_LANE_QUAD_OFF 0x0400u     /* plan LANE, (4, 2) / (2, 1): one lane per problem whatever the batch                     */
+#define ALTRO_HIP_FORM_LANE_QUAD_ON 0x0800u      /* ... four lanes per problem whatever the batch                                           */
+#define ALTRO_HIP_FORM_GENERIC_LATE_Q_OFF 0x1000u /* plan GENERIC: the backward kernel with a block for Qxx whatever the occupancy rule     */
+#define ALTRO_HIP_FORM_GENERIC_LATE_Q_ON 0x2000u
+#define ALTRO_HIP_FORM_FUSED_CLOCK 0x4000u       /* plan LANE: per-phase clock of the one-launch kernel on stderr (a tuning aid)            */
+/* forms of a HANDLE: what altro_hip_merit / _expand / _sweep and every solve on it run with (a solve ORs its options' bits in) */
+int altro_hip_set_forms(altro_hip_batch* h, unsigned forms);
+unsigned altro_hip_get_forms(const altro_hip_batch* h);
 typedef struct altro_hip_solve_result { /* AltroStats per problem, solver_stats.hpp:14-25 */
   int status;     /* SolveStatus: 0 Success, 1 Unsolved, 2 MaxIterations (typedefs.hpp:19-27)        */
   int iterations; /* solver.cpp:506                                                                  */
@@ -360,12 +399,14 @@ void altro_hip_default_solve_options(altro_hip_solve_options* opts);
  * While the problems still searching leave part of the GPU idle, line-search steps that are known in advance are
  * evaluated speculatively -- the first step (alpha = 1) in the launch that evaluates phi(0), the backtracking steps
  * alpha beta^j several per launch -- and consumed by the search in its own order: every result is bit-identical to
- * the one-step-per-launch sequence, only altro_hip_last_solve_counts' merit_launches drops.  Setting the environment
- * variable ALTRO_HIP_NO_SPECULATION (any value) restores one step per launch.
+ * the one-step-per-launch sequence, only altro_hip_last_solve_counts' merit_launches drops.  ALTRO_HIP_FORM_NO_SPECULATION
+ * restores one step per launch.
  * Plan MFMA16, fp64, dynamics given as data: the closed-loop rollout of SolverImpl::MeritFunction (solver.cpp:273-355) is affine in
  * the step, x_k(alpha) = x_k(0) + alpha dx_k/dalpha, so the line-search rounds after a sweep's first step evaluate the knot points
  * independently from that pair instead of rolling out again (16 per wavefront; a round then costs the same whatever the horizon).
- * Their trial points equal the rollout's to rounding (1e-13), as everything on this plan does; ALTRO_HIP_AFFINE=0 keeps rollouts. */
+ * Their trial points equal the rollout's to rounding (1e-13), as everything on this plan does; a trial whose values fall within
+ * altro_hip_solve_options::decision_margin of a line-search decision is evaluated again as a rollout and decided on that, so the
+ * search takes the rollout form's decisions; ALTRO_HIP_FORM_ROLLOUT_ROUNDS keeps every trial a rollout.                          */
 int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts,
                          altro_hip_solve_result* results);
 int altro_hip_last_solve_counts(const altro_hip_batch* h, int* sweeps, int* merit_launches);

@@ -25,7 +25,7 @@ def test_library_builds_and_exports_header_symbols():
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, missing
     assert sorted(altro_amd.C_ABI_SYMBOLS) == names
-    assert L.altro_hip_version() == 200
+    assert L.altro_hip_version() == 300
 
 
 def test_no_cpu_fallback_without_device():
