@@ -53,6 +53,7 @@ CONE_EQUALITY, CONE_IDENTITY, CONE_INEQUALITY, CONE_SOC = 0, 1, 2, 3   # Constra
 FORM_NO_SPECULATION, FORM_NO_RUNAHEAD, FORM_NO_MERIT2, FORM_MERIT_LDS, FORM_MERIT_DPP_ALWAYS = 0x1, 0x2, 0x4, 0x8, 0x10
 FORM_EXPAND_LDS, FORM_ALROWS_LDS, FORM_ROLLOUT_ROUNDS, FORM_SEQUENCED, FORM_MERIT_ONE_LAUNCH = 0x20, 0x40, 0x80, 0x100, 0x200
 FORM_LANE_QUAD_OFF, FORM_LANE_QUAD_ON, FORM_GENERIC_LATE_Q_OFF, FORM_GENERIC_LATE_Q_ON, FORM_FUSED_CLOCK = 0x400, 0x800, 0x1000, 0x2000, 0x4000
+FORM_AFFINE_EXACT = 0x8000
 
 
 def forms_from_env():
@@ -73,6 +74,7 @@ def forms_from_env():
     if "ALTRO_HIP_LANE_QUAD" in e: f |= FORM_LANE_QUAD_OFF if _atoi(e["ALTRO_HIP_LANE_QUAD"]) == 0 else FORM_LANE_QUAD_ON
     if "ALTRO_HIP_GENERIC_LATE_Q" in e: f |= FORM_GENERIC_LATE_Q_OFF if _atoi(e["ALTRO_HIP_GENERIC_LATE_Q"]) == 0 else FORM_GENERIC_LATE_Q_ON
     if "ALTRO_HIP_FUSED_CLOCK" in e: f |= FORM_FUSED_CLOCK
+    if "ALTRO_HIP_AFFINE_EXACT" in e: f |= FORM_AFFINE_EXACT
     return f
 
 

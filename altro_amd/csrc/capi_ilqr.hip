@@ -1176,7 +1176,7 @@ void altro_hip_default_solve_options(altro_hip_solve_options* o) {
   o->stop_when_running_at_most = 0;   // (extension: every problem to its own end)
   o->forms = 0;
   o->fused_sweeps = 0;
-  o->decision_margin = 1e-9;
+  o->decision_margin = 0.0;   // (the guard of the affine rounds is opt-in: it costs more than the rounds save -- altro_hip.h)
 }
 int altro_hip_set_forms(altro_hip_batch* h, unsigned forms) {
   int rc = check(h);

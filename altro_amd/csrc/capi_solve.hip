@@ -32,6 +32,8 @@ struct SolveRun {
   bool fused = false, fused_prologue = false;
   bool dual = false;              // plan MFMA16: phi(0) and the first step in one pass (IK_MERIT2)
   bool spec_all_on = false, spec_on = false, merit_rounds_dpp = true, run_ahead = true;
+  bool guard_on = false;          // affine rounds with the decision guard (altro_hip_solve_options::decision_margin > 0)
+  int guarded_total = 0;          // trials the guard sent back for a rollout evaluation
   size_t spare_each = 0;
   int trials_cap = 1;
   int64_t spec_capacity = 512;
@@ -170,6 +172,12 @@ int SolveRun::configure(const altro_hip_solve_options* opts) {
       (void)hipGetLastError();
     }
   }
+  guard_on = h->aff_enabled && o.decision_margin > 0.0;
+  la.guard = guard_on ? h->i_guard : nullptr;
+  la.active_exact = guard_on ? h->i_active_exact : nullptr;
+  la.decision_margin = guard_on ? o.decision_margin : 0.0;
+  la.aff_fed = 0;
+  la.aff_exact = (guard_on && form(h, ALTRO_HIP_FORM_AFFINE_EXACT)) ? 1 : 0;
   return 0;
 }
 
@@ -399,11 +407,13 @@ int SolveRun::search_rounds(int* prev_slot, int rounds_last, int* rounds_out, in
   int prev = *prev_slot, rc = 0;
   int searching = -1;            // the last count read (the speculation width follows it)
   int rounds = 0;
+  int guarded_last = 0;          // problems the last feed read sent to the rollout launch (the sweep's first feed: none)
   for (int guard = 0; guard < 64; ++guard) {
     const bool ahead = run_ahead && rounds < rounds_last;    // history says this round will be needed: enqueue it first
     if (!ahead) {
       if ((rc = verdict(prev, 0, &searching))) return rc;
       if (searching == 0) break;
+      if (guard_on && rounds > 0) { if ((rc = verdict(prev, 5, &guarded_last))) return rc; guarded_total += guarded_last; }
     }
     const int width_for = searching > 0 ? searching : running;
     int trials = 1;
@@ -423,7 +433,19 @@ int SolveRun::search_rounds(int* prev_slot, int rounds_last, int* rounds_out, in
     rc = ilqr_run(h, IK_MERIT, true, true, 1, 0.0);
     h->aff_round = false;
     if (rc) return rc;
+    // The decision guard: the trials the last feed would not decide on affine values (IlqrLoopArgs::guard) are evaluated as rollouts,
+    // on their own mask.  Not launched when the last verdict read says there are none (the first round of a sweep never has any);
+    // launched blind when the host runs ahead of the verdicts -- an empty mask makes it a no-op.
+    if (guard_on && rounds > 0 && (ahead || guarded_last != 0)) {
+      int* keep = h->i_active;
+      h->i_active = h->i_active_exact;
+      rc = ilqr_run(h, IK_MERIT, true, true, 1, 0.0);
+      h->i_active = keep;
+      if (rc) return rc;
+    }
+    la.aff_fed = h->aff_enabled ? 1 : 0;
     const int sf = counted(ILK_LS_FEED);
+    la.aff_fed = 0;
     if (sf < 0) return ALTRO_HIP_ERR_HIP;
     if (spec && (rc = ilqr_run(h, IK_SPEC_SELECT, false, false, 0, 0.0))) return rc;
     h->spec_trials = 1;
@@ -431,6 +453,7 @@ int SolveRun::search_rounds(int* prev_slot, int rounds_last, int* rounds_out, in
     if (ahead) {
       if ((rc = verdict(prev, 0, &searching))) return rc;
       if (searching == 0) break;      // the round just enqueued was not needed: it ran on empty masks (not counted)
+      if (guard_on && rounds > 0) { if ((rc = verdict(prev, 5, &guarded_last))) return rc; guarded_total += guarded_last; }
     }
     ++*launches; ++rounds;
     if (spec) *refreshed = true;

@@ -63,7 +63,7 @@ __global__ void ilqr_ls_begin_kernel(IlqrLoopArgs a) {
 // after merit(alpha[b]): advance every searching problem's state machine
 __global__ void ilqr_ls_feed_kernel(IlqrLoopArgs a) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b < a.batch && ilqr_ls_feed_body(a, b)) atomicAdd(&a.counters[0], 1);
+  if (b < a.batch && ilqr_ls_feed_body<true>(a, b)) atomicAdd(&a.counters[0], 1);
   ilqr_publish_counters(a);
 }
 

@@ -120,6 +120,7 @@ __device__ __forceinline__ bool ilqr_ls_begin_body(const IlqrLoopArgs& a, int b)
   IlqrProb& p = a.prob[b];
   a.spec_sel[b] = 0;
   a.spec_refresh[b] = 0;
+  if (a.guard) { a.guard[b] = 0; a.active_exact[b] = 0; }   // (null in the one-launch kernel's arguments)
   if (!p.running) { a.active[b] = 0; return false; }
   bool need = ilqr_ls_begin_logic(p, a.ls, a.tol_meritfun_gradient, a.phi[b], a.dphi[b]);
   // Fused first trial (IlqrLoopArgs::spec_pre): the merit launch that produced phi(0) also evaluated the first step
@@ -145,9 +146,67 @@ __device__ __forceinline__ bool ilqr_ls_begin_body(const IlqrLoopArgs& a, int b)
 }
 
 // after merit(alpha[b]): advance the state machine of problem b; returns whether it needs another evaluation
+// GUARD: with the decision guard of the affine rounds compiled in (the launch-sequenced loop's kernel; the one-launch solve kernel of
+// plan LANE has no affine rounds and keeps the function it had)
+template <bool GUARD = false>
 __device__ __forceinline__ bool ilqr_ls_feed_body(const IlqrLoopArgs& a, int b) {
   IlqrProb& p = a.prob[b];
-  if (!p.running || !p.evaluating) { a.active[b] = 0; a.spec_sel[b] = 0; return false; }
+  if (!p.running || !p.evaluating) { a.active[b] = 0; a.spec_sel[b] = 0; if (GUARD && a.guard) a.active_exact[b] = 0; return false; }
+  // Affine rounds (IlqrLoopArgs::guard; plan MFMA16, dynamics as data).  The values of an affine trial equal the rollout's to rounding
+  // only.  The decision guard (decision_margin > 0): a trial whose feed is not robust against that margin (linesearch_sm.h:
+  // ls_feed_is_robust) stays pending (guard = 1) and is evaluated again as a rollout by the next round, on the mask active_exact.
+  // aff_exact (ALTRO_HIP_FORM_AFFINE_EXACT) goes all the way: the search uses affine values for nothing but robust decisions --
+  //   * a trial whose VALUES the search would keep is evaluated again as well: a rejected zoom or extrapolation step enters the bracket
+  //     the next interpolation is taken from (a rejected cubic first guess does not: linesearch.cpp goes on from the first step's
+  //     values; the backtracking sequence alpha beta^j is fixed in advance);
+  //   * a search that ENDS on an affine trial is finalised (guard = 2): one rollout evaluation of the step it ended on writes the
+  //     candidate trajectory, its expansion and the final merit values
+  // -- and every step length, candidate and decision is the rollout form's bit for bit (tools/fuzz_affine.py: 0 of 5617 problems
+  // differ, |dx| = 0), at the price of a rollout per accepted step: slower than plain rollout rounds, a checking form.
+  if (GUARD && a.guard) {
+    const int gs = a.guard[b];
+    a.guard[b] = 0; a.active_exact[b] = 0;
+    if (gs == 2) {   // the rollout evaluation of the step the search ended on
+      p.ls.phi = a.phi[b]; p.ls.dphi = a.dphi[b];
+      p.evaluating = 0; a.active[b] = 0; a.spec_sel[b] = 0;
+      ilqr_ls_end_logic(p);
+      return false;
+    }
+    if (gs == 0 && a.aff_fed && a.decision_margin > 0.0) {
+      for (int j = 0; j < a.spec_trials; ++j) {
+        const int stage0 = p.ls.stage;
+        LsState t;
+        bool need = false;
+        const bool robust = ls_feed_is_robust(p.ls, a.ls, a.phi[(size_t)j * a.batch + b], j == 0 ? a.dphi[b] : 0.0, a.decision_margin, &t, &need);
+        const bool keeps_values = a.aff_exact && need && !(stage0 == LS_STAGE_CUBIC || t.stage == LS_STAGE_BACKTRACK);
+        if (!robust || keeps_values) {   // this trial again, as a rollout
+          a.guard[b] = 1; a.active_exact[b] = 1; a.active[b] = 0; a.spec_sel[b] = 0;
+          a.alpha[b] = p.ls.alpha;
+          atomicAdd(&a.counters[5], 1);
+          return true;
+        }
+        p.ls = t;
+        if (!need && a.aff_exact) {      // ended on an affine trial: finalise on a rollout of that step
+          a.guard[b] = 2; a.active_exact[b] = 1; a.active[b] = 0; a.spec_sel[b] = 0;
+          a.alpha[b] = p.ls.alpha;
+          atomicAdd(&a.counters[5], 1);
+          return true;
+        }
+        if (!need) {                     // (the margin guard alone: the search ends on the affine trial like an unguarded one)
+          a.spec_sel[b] = j;
+          if (j > 0) a.spec_refresh[b] = 1;
+          p.evaluating = 0; a.active[b] = 0;
+          ilqr_ls_end_logic(p);
+          return false;
+        }
+        // the next trial of this launch exists only along the backtracking sequence (see below)
+        if (!((stage0 == LS_STAGE_BACKTRACK || stage0 == LS_STAGE_CUBIC) && p.ls.stage == LS_STAGE_BACKTRACK)) break;
+      }
+      a.alpha[b] = p.ls.alpha;
+      a.active[b] = 1; a.spec_sel[b] = 0;
+      return true;
+    }
+  }
   // Speculative backtracking: the merit launch also evaluated alpha beta^j, j = 1 .. spec_trials - 1, for the problems
   // that were in the backtracking stage or about to enter it (cubic first guess pending).  Feeding them in order
   // reproduces the sequential search exactly; "need" after trial j - 1 is precisely the condition under which trial j

@@ -107,6 +107,15 @@ struct IlqrLoopArgs {
   int spec_flip = 0;
   int stat_inline = 0;
   int* stat_done = nullptr;   // [batch]
+  // The decision guard of the affine line-search rounds (linesearch_sm.h: ls_feed_is_robust).  ILK_LS_FEED with aff_fed = 1 consumes
+  // values an affine round produced: a trial whose turn is not robust against `decision_margin` is NOT fed -- guard[b] = 1, the problem
+  // leaves `active` and enters `active_exact`, the next round's rollout launch (on that mask) evaluates the same step in the
+  // reference's order, and the feed after it takes those values as they are.  counters[5] counts the problems so marked.
+  int* guard = nullptr;          // [batch]
+  int* active_exact = nullptr;   // [batch]
+  int aff_fed = 0;
+  int aff_exact = 0;             // ALTRO_HIP_FORM_AFFINE_EXACT: see ilqr_ls_feed_body
+  double decision_margin = 0.0;
   int batch;
   int iter;
   int iterations_max;

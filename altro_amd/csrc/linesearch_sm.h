@@ -53,12 +53,18 @@ struct LsState {
 
 namespace ls_detail {
 constexpr double kTol = 1e-6;   // LINESEARCH_TOL, cubicspline.c:10
+// Which way a comparison went, folded into a running code of the turns one feed takes (null: not recorded -- every existing caller;
+// the recorder is how ls_feed_is_robust tells two feeds that took the same turns from two that did not).
+ALTRO_LS_HD bool brc(int* br, bool c) {
+  if (br) *br = *br * 31 + (c ? 2 : 1);
+  return c;
+}
 
 // cubic through two points with slopes; returns false when the abscissae coincide (cubicspline.c:18-42)
 ALTRO_LS_HD bool spline2(double x1, double y1, double d1, double x2, double y2, double d2, double* x0,
-                         double* b, double* c, double* d) {
+                         double* b, double* c, double* d, int* br = nullptr) {
   const double delta = x2 - x1;
-  if (fabs(delta) < kTol) return false;
+  if (brc(br, fabs(delta) < kTol)) return false;
   *x0 = x1;
   *b = d1;
   *c = 3 * (y2 - y1) / (delta * delta) - (d2 + 2 * d1) / delta;
@@ -66,26 +72,26 @@ ALTRO_LS_HD bool spline2(double x1, double y1, double d1, double x2, double y2, 
   return true;
 }
 // minimiser of a + b t + c t^2 + d t^3 about x0 (cubicspline.c:111-181, :229-246)
-ALTRO_LS_HD bool argmin(double x0, double b, double c, double d, double* xmin) {
-  const bool quad = fabs(d) < kTol;
+ALTRO_LS_HD bool argmin(double x0, double b, double c, double d, double* xmin, int* br = nullptr) {
+  const bool quad = brc(br, fabs(d) < kTol);
   if (quad) {
-    if (fabs(c) < kTol) return false;
-    if (c <= 0) return false;
+    if (brc(br, fabs(c) < kTol)) return false;
+    if (brc(br, c <= 0)) return false;
     *xmin = -b / (2 * c) + x0;
     return true;
   }
   const double qa = 3 * d, qb = 2 * c, qc = b;
-  if (fabs(qa) < kTol) return false;
+  if (brc(br, fabs(qa) < kTol)) return false;
   const double s2 = qb * qb - 4 * qa * qc;
   double s;
-  if (fabs(s2) < kTol) s = 0.0;
-  else if (s2 < 0) return false;
+  if (brc(br, fabs(s2) < kTol)) s = 0.0;
+  else if (brc(br, s2 < 0)) return false;
   else s = sqrt(s2);
   const double d1 = (-qb + s) / (2 * qa), d2 = (-qb - s) / (2 * qa);
   const double curv1 = 2 * c + 6 * d * d1, curv2 = 2 * c + 6 * d * d2;
-  if (fabs(curv1) < kTol && fabs(curv2) < kTol) return false;
-  if (curv1 > 0 && curv2 < 0) { *xmin = d1 + x0; return true; }
-  if (curv1 < 0 && curv2 > 0) { *xmin = d2 + x0; return true; }
+  if (brc(br, fabs(curv1) < kTol && fabs(curv2) < kTol)) return false;
+  if (brc(br, curv1 > 0 && curv2 < 0)) { *xmin = d1 + x0; return true; }
+  if (brc(br, curv1 < 0 && curv2 > 0)) { *xmin = d2 + x0; return true; }
   return false;
 }
 
@@ -107,22 +113,22 @@ ALTRO_LS_HD bool run_top(LsState& s, const LsOptions& o, double alpha) {   // he
   return request(s, LS_STAGE_RUN, alpha, 1);
 }
 
-ALTRO_LS_HD bool zoom_top(LsState& s, const LsOptions& o, double last_alpha) {   // head of Zoom's loop
+ALTRO_LS_HD bool zoom_top(LsState& s, const LsOptions& o, double last_alpha, int* br = nullptr) {   // head of Zoom's loop
   if (s.zoom_iter >= o.max_iters) {
     s.status = LS_MAX_ITERATIONS;
     return finish(s, last_alpha);
   }
-  if (fabs(s.alo - s.ahi) < o.min_interval_size)
+  if (brc(br, fabs(s.alo - s.ahi) < o.min_interval_size))
     return request(s, LS_STAGE_ZOOM_MID, (s.alo + s.ahi) / 2.0, 1);
   double x0, b, c, d, a = 0.0;
   bool ok = false;
-  if (spline2(s.alo, s.phi_lo, s.dphi_lo, s.ahi, s.phi_hi, s.dphi_hi, &x0, &b, &c, &d))
-    ok = argmin(x0, b, c, d, &a) && isfinite(a);
-  if (!ok) a = (s.alo + s.ahi) / 2;
+  if (spline2(s.alo, s.phi_lo, s.dphi_lo, s.ahi, s.phi_hi, s.dphi_hi, &x0, &b, &c, &d, br))
+    ok = argmin(x0, b, c, d, &a, br) && isfinite(a);
+  if (!brc(br, ok)) a = (s.alo + s.ahi) / 2;
   return request(s, LS_STAGE_ZOOM, a, 1);
 }
 ALTRO_LS_HD bool zoom_begin(LsState& s, const LsOptions& o, double alo, double ahi, double phi_lo,
-                            double dphi_lo, double phi_hi, double dphi_hi) {
+                            double dphi_lo, double phi_hi, double dphi_hi, int* br = nullptr) {
   if (!isfinite(alo) || !isfinite(ahi)) {
     s.status = LS_GOT_NONFINITE_STEP_SIZE;
     return finish(s, 0.0);
@@ -130,7 +136,7 @@ ALTRO_LS_HD bool zoom_begin(LsState& s, const LsOptions& o, double alo, double a
   s.alo = alo; s.ahi = ahi;
   s.phi_lo = phi_lo; s.dphi_lo = dphi_lo; s.phi_hi = phi_hi; s.dphi_hi = dphi_hi;
   s.zoom_iter = s.n_iters + 1;
-  return zoom_top(s, o, alo);
+  return zoom_top(s, o, alo, br);
 }
 
 ALTRO_LS_HD bool bt_top(LsState& s, const LsOptions& o, double alpha) {
@@ -139,7 +145,7 @@ ALTRO_LS_HD bool bt_top(LsState& s, const LsOptions& o, double alpha) {
 }
 
 // Run's loop body after the (optional) cubic first guess: alpha/phi/dphi are the FIRST evaluation's
-ALTRO_LS_HD bool run_rest(LsState& s, const LsOptions& o, double alpha, double phi, double dphi) {
+ALTRO_LS_HD bool run_rest(LsState& s, const LsOptions& o, double alpha, double phi, double dphi, int* br = nullptr) {
   const bool suff = phi <= s.phi0 + o.c1 * alpha * s.dphi0;
   const bool not_decreasing = phi >= s.phi_prev;
   const bool wolfe = fabs(dphi) <= -o.c2 * s.dphi0;
@@ -147,9 +153,9 @@ ALTRO_LS_HD bool run_rest(LsState& s, const LsOptions& o, double alpha, double p
     s.bt_iter = 1;
     return bt_top(s, o, s.alpha0 * o.beta_decrease);
   }
-  if (!suff || (s.iter > 0 && not_decreasing))
-    return zoom_begin(s, o, s.alpha_prev, alpha, s.phi_prev, s.dphi_prev, phi, dphi);
-  if (dphi >= 0) return zoom_begin(s, o, alpha, s.alpha_prev, phi, dphi, s.phi_prev, s.dphi_prev);
+  if (brc(br, !suff || (s.iter > 0 && not_decreasing)))
+    return zoom_begin(s, o, s.alpha_prev, alpha, s.phi_prev, s.dphi_prev, phi, dphi, br);
+  if (brc(br, dphi >= 0)) return zoom_begin(s, o, alpha, s.alpha_prev, phi, dphi, s.phi_prev, s.dphi_prev, br);
   s.alpha_prev = alpha;
   double next = alpha * o.beta_increase;
   if (next > o.alpha_max) {
@@ -157,7 +163,7 @@ ALTRO_LS_HD bool run_rest(LsState& s, const LsOptions& o, double alpha, double p
     if (s.hit_max_alpha) {
       s.status = LS_HIT_MAX_STEPSIZE;
       s.sufficient_decrease = suff;
-      s.curvature = wolfe;
+      s.curvature = brc(br, wolfe);
       return finish(s, next);
     }
     s.hit_max_alpha = 1;
@@ -184,7 +190,7 @@ ALTRO_LS_HD bool ls_begin(LsState& s, const LsOptions& o, double alpha0, double 
 
 // Feed the merit value (and derivative, when s.want_derivative) at s.alpha.  Returns true when
 // another evaluation (of the new s.alpha) is needed; false when the search is over (s.alpha = result).
-ALTRO_LS_HD bool ls_feed(LsState& s, const LsOptions& o, double phi, double dphi) {
+ALTRO_LS_HD bool ls_feed(LsState& s, const LsOptions& o, double phi, double dphi, int* br = nullptr) {
   using namespace ls_detail;
   const double alpha = s.alpha;
   switch (s.stage) {
@@ -192,37 +198,37 @@ ALTRO_LS_HD bool ls_feed(LsState& s, const LsOptions& o, double phi, double dphi
       s.phi = phi; s.dphi = dphi;
       const bool suff = phi <= s.phi0 + o.c1 * alpha * s.dphi0;
       const bool wolfe = fabs(dphi) <= -o.c2 * s.dphi0;
-      if (suff && wolfe) {
+      if (brc(br, suff && wolfe)) {
         s.sufficient_decrease = 1; s.curvature = 1; s.status = LS_MINIMUM_FOUND;
         return finish(s, alpha);
       }
       if (s.iter == 0 && o.try_cubic_first) {
         double x0, b, c, d, ac = 0.0;
         bool ok = false;
-        if (spline2(0, s.phi0, s.dphi0, alpha, phi, dphi, &x0, &b, &c, &d))
-          ok = argmin(x0, b, c, d, &ac) && isfinite(ac);
-        if (ok) {
+        if (spline2(0, s.phi0, s.dphi0, alpha, phi, dphi, &x0, &b, &c, &d, br))
+          ok = argmin(x0, b, c, d, &ac, br) && isfinite(ac);
+        if (brc(br, ok)) {
           s.alpha_first = alpha; s.phi_first = phi; s.dphi_first = dphi;
           s.iter += 1;
           return request(s, LS_STAGE_CUBIC, ac, 1);
         }
       }
-      return run_rest(s, o, alpha, phi, dphi);
+      return run_rest(s, o, alpha, phi, dphi, br);
     }
     case LS_STAGE_CUBIC: {
       const bool suff = phi <= s.phi0 + o.c1 * alpha * s.dphi0;
       const bool wolfe = fabs(dphi) <= -o.c2 * s.dphi0;
-      if (suff && wolfe) {
+      if (brc(br, suff && wolfe)) {
         s.phi = phi; s.dphi = dphi;
         s.sufficient_decrease = 1; s.curvature = 1; s.status = LS_MINIMUM_FOUND;
         return finish(s, alpha);
       }
-      return run_rest(s, o, s.alpha_first, s.phi_first, s.dphi_first);
+      return run_rest(s, o, s.alpha_first, s.phi_first, s.dphi_first, br);
     }
     case LS_STAGE_ZOOM_MID: {
       s.phi = phi; s.dphi = dphi;
-      s.sufficient_decrease = phi <= s.phi0 + o.c1 * alpha * s.dphi0;
-      s.curvature = fabs(dphi) <= -o.c2 * s.dphi0;
+      s.sufficient_decrease = brc(br, phi <= s.phi0 + o.c1 * alpha * s.dphi0);
+      s.curvature = brc(br, fabs(dphi) <= -o.c2 * s.dphi0);
       s.status = (s.sufficient_decrease && s.curvature) ? LS_MINIMUM_FOUND : LS_WINDOW_TOO_SMALL;
       return finish(s, alpha);
     }
@@ -231,22 +237,22 @@ ALTRO_LS_HD bool ls_feed(LsState& s, const LsOptions& o, double phi, double dphi
       const bool suff = phi <= s.phi0 + o.c1 * alpha * s.dphi0;
       const bool higher = phi > s.phi_lo;
       const bool curv = fabs(dphi) <= -o.c2 * s.dphi0;
-      if (suff && curv) {
+      if (brc(br, suff && curv)) {
         s.sufficient_decrease = 1; s.curvature = 1; s.status = LS_MINIMUM_FOUND;
         return finish(s, alpha);
       }
-      if (!suff || higher) {
+      if (brc(br, !suff || higher)) {
         s.ahi = alpha; s.phi_hi = phi; s.dphi_hi = dphi;
       } else {
-        if (dphi * (s.ahi - s.alo) <= 0) { s.ahi = s.alo; s.phi_hi = s.phi_lo; s.dphi_hi = s.dphi_lo; }
+        if (brc(br, dphi * (s.ahi - s.alo) <= 0)) { s.ahi = s.alo; s.phi_hi = s.phi_lo; s.dphi_hi = s.dphi_lo; }
         s.alo = alpha; s.phi_lo = phi; s.dphi_lo = dphi;
       }
       s.zoom_iter += 1;
-      return zoom_top(s, o, alpha);
+      return zoom_top(s, o, alpha, br);
     }
     case LS_STAGE_BACKTRACK: {
       s.phi = phi;
-      if (phi <= s.phi0 + o.c1 * alpha * s.dphi0) {
+      if (brc(br, phi <= s.phi0 + o.c1 * alpha * s.dphi0)) {
         s.sufficient_decrease = 1; s.curvature = 1; s.status = LS_MINIMUM_FOUND;
         return finish(s, alpha);
       }
@@ -256,6 +262,31 @@ ALTRO_LS_HD bool ls_feed(LsState& s, const LsOptions& o, double phi, double dphi
     default:
       return false;
   }
+}
+
+// The decision guard of evaluation forms that agree with the reference's only to rounding (the affine line-search rounds of plan
+// MFMA16).  Would the search take the same turns if phi, phi' were off by a relative `margin`?  The state machine is run
+// on copies of the state with the values pushed to the four corners of that box, each recording which way every comparison went
+// (ls_detail::brc): Armijo, curvature, the bracket updates of linesearch.cpp:233-351, the degenerate-spline thresholds of
+// cubicspline.c:18-42, :111-181 -- whatever the feed meets, without restating one of them here.  Same turns at every corner: the
+// decision does not hang on the last bits.  False: evaluate this trial again in the reference's own order (a rollout) and feed that.
+// `fed` (optional): the state after the feed, `need`: what that feed returned.
+ALTRO_LS_HD bool ls_feed_is_robust(const LsState& s, const LsOptions& o, double phi, double dphi, double margin, LsState* fed = nullptr,
+                                   bool* need_out = nullptr) {
+  const double dp = margin * (fabs(phi) + fabs(s.phi0)), dd = margin * (fabs(dphi) + fabs(s.dphi0));
+  LsState ref = s;
+  int turns = 7;
+  const bool need = ls_feed(ref, o, phi, dphi, &turns);
+  if (fed) *fed = ref;
+  if (need_out) *need_out = need;
+  if (!(margin > 0.0)) return true;
+  for (int c = 0; c < 4; ++c) {
+    LsState t = s;
+    int tc = 7;
+    const bool nd = ls_feed(t, o, phi + ((c & 1) ? dp : -dp), dphi + ((c & 2) ? dd : -dd), &tc);
+    if (nd != need || tc != turns || t.stage != ref.stage || t.status != ref.status) return false;
+  }
+  return true;
 }
 
 }  // namespace altro_hip

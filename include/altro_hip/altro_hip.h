@@ -357,10 +357,15 @@ typedef struct altro_hip_solve_options { /* AltroOptions, solver_options.hpp:16-
   /* plan LANE: hand the problems still running after this many sweeps of the one-launch solve kernel over to the launch-sequenced
    * loop (the hand-over is exact at any sweep: a test hook).  0: the one-launch kernel runs every sweep.                         */
   int fused_sweeps;
-  /* The decision guard of the affine line-search rounds (plan MFMA16, dynamics as data): a trial whose phi, phi' fall
-   * within this RELATIVE margin of a line-search decision boundary (Armijo, curvature, the interval tests of linesearch.cpp:37-351,
-   * the thresholds of cubicspline.c) is evaluated again as a rollout (SolverImpl::MeritFunction's own order, solver.cpp:285-316)
-   * and decided on that.  Default 1e-9 (the two forms agree to 1e-13); 0 switches the guard off.                                 */
+  /* The decision guard of the affine line-search rounds (plan MFMA16, dynamics as data), opt-in: with a margin > 0 a trial
+   * whose phi, phi' would turn the search another way if they were off by that RELATIVE margin -- any comparison of
+   * linesearch.cpp:37-351 and cubicspline.c, found by running the state machine at the corners of the box (linesearch_sm.h:
+   * ls_feed_is_robust) -- is evaluated again as a rollout (SolverImpl::MeritFunction's own order, solver.cpp:285-316) and decided on
+   * that.  With ALTRO_HIP_FORM_AFFINE_EXACT on top, values the search would KEEP and steps it ACCEPTS are evaluated as rollouts too,
+   * and the solve is the rollout form's bit for bit (tools/fuzz_affine.py: 0 of 5617 problems differ, |dx| = 0).  Default 0 = off,
+   * because a batch pays for it: some problem of 4096 is at a boundary in nearly every round, every such round then carries a rollout
+   * launch, and the constrained C1 solve goes from 43 ms to 84 ms -- slower than ALTRO_HIP_FORM_ROLLOUT_ROUNDS (70 ms), which is the
+   * form to ask for when the reference's own evaluation order matters more than the time.                                           */
   double decision_margin;
 } altro_hip_solve_options;
 /* altro_hip_solve_options::forms / altro_hip_set_forms.  Bit-for-bit equal to the default unless said otherwise. */
@@ -379,6 +384,8 @@ typedef struct altro_hip_solve_options { /* AltroOptions, solver_options.hpp:16-
 #define ALTRO_HIP_FORM_LANE_QUAD_ON 0x0800u      /* ... four lanes per problem whatever the batch                                           */
 #define ALTRO_HIP_FORM_GENERIC_LATE_Q_OFF 0x1000u /* plan GENERIC: the backward kernel with a block for Qxx whatever the occupancy rule     */
 #define ALTRO_HIP_FORM_GENERIC_LATE_Q_ON 0x2000u
+#define ALTRO_HIP_FORM_AFFINE_EXACT 0x8000u      /* plan MFMA16: affine rounds used for robust decisions only -- kept values and accepted steps are
+                                                    evaluated as rollouts: the rollout form's results bit for bit, slower than ROLLOUT_ROUNDS (a checking form) */
 #define ALTRO_HIP_FORM_FUSED_CLOCK 0x4000u       /* plan LANE: per-phase clock of the one-launch kernel on stderr (a tuning aid)            */
 /* forms of a HANDLE: what altro_hip_merit / _expand / _sweep and every solve on it run with (a solve ORs its options' bits in) */
 int altro_hip_set_forms(altro_hip_batch* h, unsigned forms);
@@ -404,9 +411,11 @@ void altro_hip_default_solve_options(altro_hip_solve_options* opts);
  * Plan MFMA16, fp64, dynamics given as data: the closed-loop rollout of SolverImpl::MeritFunction (solver.cpp:273-355) is affine in
  * the step, x_k(alpha) = x_k(0) + alpha dx_k/dalpha, so the line-search rounds after a sweep's first step evaluate the knot points
  * independently from that pair instead of rolling out again (16 per wavefront; a round then costs the same whatever the horizon).
- * Their trial points equal the rollout's to rounding (1e-13), as everything on this plan does; a trial whose values fall within
- * altro_hip_solve_options::decision_margin of a line-search decision is evaluated again as a rollout and decided on that, so the
- * search takes the rollout form's decisions; ALTRO_HIP_FORM_ROLLOUT_ROUNDS keeps every trial a rollout.                          */
+ * Their trial points equal the rollout's to rounding (1e-13), as everything on this plan does: a search whose decision sits on a
+ * boundary at that level may turn another way (tools/fuzz_affine.py: 25 of 5617 random constrained problems -- all of them problems
+ * whose search FAILS in one of the two forms after 13-37 sweeps -- end with another status or iteration count; the converged rest
+ * within 5e-10).  ALTRO_HIP_FORM_ROLLOUT_ROUNDS keeps every trial a rollout; altro_hip_solve_options::decision_margin and
+ * ALTRO_HIP_FORM_AFFINE_EXACT are the guarded forms (slower than either).                                                        */
 int altro_hip_ilqr_solve(altro_hip_batch* h, const altro_hip_solve_options* opts,
                          altro_hip_solve_result* results);
 int altro_hip_last_solve_counts(const altro_hip_batch* h, int* sweeps, int* merit_launches);

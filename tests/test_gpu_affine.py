@@ -19,12 +19,13 @@ from tests import problems
 pytestmark = pytest.mark.gpu
 
 
-def _solve(p, N, blocks, affine, **kw):
+def _solve(p, N, blocks, affine, forms=0, **kw):
     old = os.environ.get("ALTRO_HIP_AFFINE")
     os.environ["ALTRO_HIP_AFFINE"] = "1" if affine else "0"
     try:
         batch = p["x0"].shape[0]
         bt = altro_amd.Batch(N, 12, 4, batch)
+        bt.set_forms(forms)
         bt.set_dynamics(p["A"], p["B"], p["f"])
         if "Q" in p:
             bt.set_quadratic_cost(p["Q"], p["R"], p["H"], p["q"], p["r"], p["c"])
@@ -83,3 +84,45 @@ def test_unconstrained_and_soc_problems():
     both = (a["status"] == 0) & (b["status"] == 0)
     assert both.sum() >= batch - 1 and np.array_equal(a["iterations"][both], b["iterations"][both])
     np.testing.assert_allclose(a["x"][both], b["x"][both], rtol=1e-8, atol=1e-8)
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_affine_rounds_used_for_robust_decisions_only_are_the_rollout_form_bit_for_bit(seed):
+    """ALTRO_HIP_FORM_AFFINE_EXACT + decision_margin: the affine values decide only where the decision does not hang
+    on their last bits (the state machine run at the corners of the margin box: linesearch_sm.h, ls_feed_is_robust); a trial whose
+    values the search would keep, and the step it ends on, are evaluated as rollouts.  Then every step length, candidate and decision
+    is the rollout form's: statuses, iteration counts, dual updates AND trajectories equal bit for bit -- on random constrained
+    problems of tools/fuzz_affine.py's kind, both line searches, non-converging problems included."""
+    from tools.fuzz_dpp import blocks_for
+    rng = np.random.default_rng(seed)
+    total = 0
+    for c in range(12):
+        n, m = 12, 4
+        N = int(rng.integers(3, 70)); batch = int(rng.integers(2, 60))
+        p = problems.ilqr12x4_problem(batch, N, bool(rng.integers(0, 2)), n=n, m=m)
+        blocks = blocks_for(rng, N, n, m)
+        kw = dict(iterations_max=int(rng.integers(3, 40)), use_backtracking=bool(rng.integers(0, 2)), penalty_initial=1.0, penalty_scaling=10.0)
+        a = _solve(p, N, blocks, True, forms=altro_amd.FORM_AFFINE_EXACT, decision_margin=1e-9, **kw)
+        b = _solve(p, N, blocks, False, **kw)
+        for key in ("status", "iterations", "dual_updates", "x", "u", "alpha", "phi", "stationarity", "feasibility"):
+            assert np.array_equal(a[key], b[key]), (c, key)
+        total += batch
+    assert total > 100
+
+
+def test_margin_guard_sends_borderline_trials_to_the_rollout_form():
+    """decision_margin alone: trials whose turn is not robust are evaluated again as rollouts (more merit launches than the unguarded
+    rounds take), everything else as in the unguarded form; the converged problems agree with the rollout form's to rounding."""
+    N, batch = 37, 60
+    p = problems.ilqr12x4_problem(batch, N, True)
+    blocks = problems.ilqr12x4_constraint_blocks(N)
+    kw = dict(iterations_max=40, penalty_initial=1.0, penalty_scaling=10.0)
+    g = _solve(p, N, blocks, True, decision_margin=1e-9, **kw)
+    a = _solve(p, N, blocks, True, **kw)
+    b = _solve(p, N, blocks, False, **kw)
+    assert g["merit_launches"] >= a["merit_launches"]
+    both = (g["status"] == 0) & (b["status"] == 0)
+    assert both.sum() >= batch // 2
+    same = both & (g["iterations"] == b["iterations"])
+    assert same.sum() >= both.sum() - max(1, batch // 20)
+    np.testing.assert_allclose(g["x"][same], b["x"][same], rtol=1e-7, atol=1e-7)

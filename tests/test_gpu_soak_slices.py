@@ -1,0 +1,80 @@
+"""Seeded slices of the long-running oracle comparisons of tests/soak/ and tools/ ("the oracle comparisons that
+find differences are outside the driver's view").  Each test runs one of those scripts for a few seconds on a fixed seed and holds its
+summary line to a stated count; the scripts' full runs and what their differing problems are is in tests/soak/README.md.
+
+What the counts mean.  The device's sums are taken in another order than the CPU path's (wave-order reductions, matrix-core products):
+values agree to 1e-12 .. 1e-15, and a line search that sits ON a decision boundary at that level -- in practice: a problem that does
+not converge in either implementation -- may take its turn a sweep earlier or later.  So the statement per slice is: every problem
+that converges does so with the oracle's iteration count and trajectory, and the number of problems that end differently is the small
+number stated (zero on these seeds unless said otherwise)."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run(script, *args, env=None):
+    e = dict(os.environ)
+    e["PYTHONPATH"] = ROOT + os.pathsep + e.get("PYTHONPATH", "")
+    for k in ("ALTRO_HIP_AFFINE", "ALTRO_HIP_AFFINE_EXACT", "FUZZ_MARGIN"):
+        e.pop(k, None)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, script)] + [str(a) for a in args], cwd=ROOT, env=e, capture_output=True, text=True,
+                       timeout=600)
+    print(r.stdout[-3000:])
+    return r
+
+
+def test_slice_plan_generic_constrained_solves_against_the_oracle():
+    """fuzz_generic_al.py: whole AL-iLQR solves on plan GENERIC, random shapes up to (24, 8), constraint blocks in every cone."""
+    r = run("tests/soak/fuzz_generic_al.py", 24, 7)
+    m = re.search(r"(\d+) of (\d+) cases differ", r.stdout)
+    assert m, r.stdout[-2000:] + r.stderr[-2000:]
+    assert int(m.group(2)) == 24 and int(m.group(1)) == 0
+
+
+def test_slice_per_knot_point_dimensions_against_the_oracle():
+    """fuzz_ragged_ilqr.py: (AL-)iLQR solves with per-knot-point dimensions against the oracle on the zero-padded uniform problem."""
+    r = run("tests/soak/fuzz_ragged_ilqr.py", 12, 3)
+    m = re.search(r"(\d+) of (\d+) cases differ", r.stdout)
+    assert m, r.stdout[-2000:] + r.stderr[-2000:]
+    assert int(m.group(2)) == 12 and int(m.group(1)) <= 1
+
+
+def test_slice_tile_constrained_solves_against_the_oracle_in_both_forms_of_the_rounds():
+    """fuzz_tile_al_oracle.py: constrained (12, 4) solves on plan MFMA16, every problem against the oracle, with affine and with
+    rollout line-search rounds."""
+    r = run("tests/soak/fuzz_tile_al_oracle.py", 8, 1)
+    got = dict((name, (int(a), int(b), float(c))) for name, a, b, c in
+               re.findall(r"(affine|rollout) rounds: (\d+) of (\d+) problems end with another status / iteration count than the oracle; converged rest within ([0-9.e+-]+)", r.stdout))
+    assert set(got) == {"affine", "rollout"}, r.stdout[-2000:] + r.stderr[-2000:]
+    assert got["rollout"][0] == 0 and got["affine"][0] <= 1
+    assert got["rollout"][1] >= 60 and got["rollout"][2] < 1e-9 and got["affine"][2] < 1e-9
+
+
+def test_slice_affine_rounds_against_rollout_rounds():
+    """tools/fuzz_affine.py: the affine rounds against the rollout rounds on random constrained batches -- unguarded (a handful of
+    non-converging problems may end a sweep apart), and as ALTRO_HIP_FORM_AFFINE_EXACT with a decision margin (bit for bit)."""
+    r = run("tools/fuzz_affine.py", 40, 11)
+    m = re.search(r"(\d+) of (\d+) problems end with another status / iteration count; largest \|x_affine - x_rollout\| among the converged rest ([0-9.e+-]+)", r.stdout)
+    assert m, r.stdout[-2000:] + r.stderr[-2000:]
+    # (this seed: 9 of 1538, every one of them a problem whose search fails or runs out of sweeps in at least one of the two forms)
+    assert int(m.group(2)) > 1000 and int(m.group(1)) <= int(m.group(2)) // 100 and float(m.group(3)) < 1e-8
+    for a_st, b_st in re.findall(r"affine status (\d) after \d+ iterations, rollout status (\d) after", r.stdout):
+        assert not (a_st == "0" and b_st == "0")
+    r = run("tools/fuzz_affine.py", 40, 11, env={"ALTRO_HIP_AFFINE_EXACT": "1", "FUZZ_MARGIN": "1e-9"})
+    m = re.search(r"(\d+) of (\d+) problems end with another status / iteration count; largest \|x_affine - x_rollout\| among the converged rest ([0-9.e+-]+)", r.stdout)
+    assert m, r.stdout[-2000:] + r.stderr[-2000:]
+    assert int(m.group(1)) == 0 and float(m.group(3)) == 0.0
+
+
+def test_slice_tile_sweeps_against_the_oracle():
+    """fuzz_mfma16.py: plan MFMA16's TVLQR sweeps on random shapes / horizons / batches."""
+    r = run("tests/soak/fuzz_mfma16.py", 3)
+    assert r.returncode == 0 and "ok, worst relative error" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -42,6 +42,8 @@ def main():
         p = problems.ilqr12x4_problem(batch, N, bool(rng.integers(0, 2)), n=n, m=m)
         blocks = blocks_for(rng, N, n, m)
         kw = dict(iterations_max=int(rng.integers(3, 40)), use_backtracking=bool(rng.integers(0, 2)), penalty_initial=1.0, penalty_scaling=10.0)
+        if "FUZZ_MARGIN" in os.environ:
+            kw["decision_margin"] = float(os.environ["FUZZ_MARGIN"])
         a = solve(p, N, n, m, blocks, True, kw)
         b = solve(p, N, n, m, blocks, False, kw)
         same = (a["status"] == b["status"]) & (a["iterations"] == b["iterations"])
@@ -49,6 +51,8 @@ def main():
         d = float(np.abs(a["x"][conv] - b["x"][conv]).max()) if conv.any() else 0.0
         worst = max(worst, d)
         problems_total += batch; problems_off += int((~same).sum())
+        for i in np.nonzero(~same)[0]:
+            print("      problem %d: affine status %d after %d iterations, rollout status %d after %d" % (i, a["status"][i], a["iterations"][i], b["status"][i], b["iterations"][i]), flush=True)
         print("%s case %3d: (n, m) = (%2d, %d) N = %2d batch = %2d blocks %d backtracking %d sweeps %d merit launches %d / %d: %d of %d problems differ; |dx| %.1e"
               % ("ok " if same.all() else "off", c, n, m, N, batch, len(blocks), kw["use_backtracking"], a["sweeps"], a["merit_launches"],
                  b["merit_launches"], int((~same).sum()), batch, d), flush=True)
