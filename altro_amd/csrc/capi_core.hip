@@ -712,6 +712,7 @@ int altro_hip_profile_get(altro_hip_batch* h, int slot, int* launches, double* t
                                       {"mfma16_backward_kernel", "mfma16_forward_kernel"},
                                       {"lane_backward_kernel", "lane_forward_kernel"}};
     *kernel_name = names[h->plan == ALTRO_HIP_PLAN_MFMA16 ? 1 : (h->plan == ALTRO_HIP_PLAN_LANE ? 2 : 0)][slot];
+    if (h->g_tile && !(slot == 0 && h->is_diag)) *kernel_name = slot == 0 ? "tile32_backward_kernel" : "tile32_forward_kernel";
     if (slot == 0 && h->plan == ALTRO_HIP_PLAN_LANE && h->bwd_quad) *kernel_name = h->n == 4 ? "quad_backward_kernel" : "quad2_backward_kernel";
     if (slot == 1 && h->plan == ALTRO_HIP_PLAN_LANE && h->fwd_quad) *kernel_name = "quad_forward_kernel";
     if (slot == 1 && mfma16_forward_is_x4(h)) *kernel_name = "mfma16_forward_f32x4_kernel";

@@ -574,6 +574,21 @@ def other_config_entry(key, device, steps, torch, cpu_seconds=2.0, live=None):
             t_solve = time.perf_counter() - t1
         out["full_solve"] = {"ms": t_solve * 1e3, "sweeps": int(res["sweeps"]), "converged": int((res["status"] == 0).sum()),
                              "mean_iterations": float(res["iterations"].mean())}
+        # A batched solve lasts as long as its slowest problem: the same solve again, returning once at most 0.1 % of the batch still
+        # runs (altro_hip_solve_options::stop_when_running_at_most; every problem that stopped on its own has the full solve's result
+        # bit for bit) -- the time an MPC caller that can use each problem as it finishes actually waits for 99.9 % of them
+        if c3:
+            bt.reset_duals(1.0)
+        set_guess()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        r9 = bt.ilqr_solve(iterations_max=80, use_backtracking=c3, stop_when_running_at_most=max(1, batch // 1000))
+        torch.cuda.synchronize()
+        out["full_solve"]["ms_to_p999"] = (time.perf_counter() - t1) * 1e3
+        out["full_solve"]["sweeps_to_p999"] = int(r9["sweeps"])
+        out["full_solve"]["stragglers"] = ("the %d sweeps after the first %d serve at most %d problems: one wave's dependent chain per sweep whatever "
+                                           "rides it (tools/c3_small_batches.py: 0.24 ms per sweep at 64 problems, 0.31 at 8192, 0.99 at 65536)"
+                                           % (int(res["sweeps"]) - int(r9["sweeps"]), int(r9["sweeps"]), max(1, batch // 1000)))
     bt.close()
     if cfg != "c4" and batch <= 8192:
         # What bit-identity with the CPU path costs at this latency-bound size: the same sweeps with ALTRO_HIP_LANE_FUSED (the kernels
@@ -598,6 +613,53 @@ def other_config_entry(key, device, steps, torch, cpu_seconds=2.0, live=None):
                                          "backward_frac": bytes_b / (ms0 / max(nl0, 1) * 1e-3) / 8e12}
     if cpu_seconds > 0:
         out["cpu_baseline"] = cpu_sweep_rate(N, n, m, cpu_seconds, " (the GPU line: fp32)" if cfg == "c4" else "")
+        out["vs_cpu_single_thread"] = out["value"] / out["cpu_baseline"]["value"]
+    out["seconds_total"] = time.perf_counter() - t_setup
+    return out
+
+
+def mfma32_entry(n, m, device, steps, torch, cpu_seconds=2.0, N=128, batch=4096):
+    """Plan MFMA32 (kernels/tvlqr_tile32.hip): the TVLQR sweep of a shape one step past the (12, 4) tile -- (13, 4), a quaternion
+    quadrotor's dimensions, and (28, 4) -- at the shape-cliff table's size (4096 problems x 128 knot points, random LTV problems,
+    fp64, time-varying storage), with the roofline fraction of both sweep kernels.  The arrays are plan GENERIC's full blocks, so
+    algorithmic bytes = the bytes that move."""
+    from tests import problems
+    t_setup = time.perf_counter()
+    pr = problems.random_ltv(16, N, n, m)
+    rep = lambda a: np.ascontiguousarray(np.tile(a, (batch // 16,) + (1,) * (a.ndim - 1)))
+    bt = altro_amd.Batch(N, n, m, batch, device=device)
+    assert bt.plan == altro_amd.PLAN_MFMA32
+    bt.set_dynamics(rep(pr["A"]), rep(pr["B"]), rep(pr["f"]))
+    bt.set_cost(rep(pr["Q"]), rep(pr["R"]), rep(pr["H"]), rep(pr["q"]), rep(pr["r"]))
+    bt.set_initial_state(rep(pr["x0"]))
+    for _ in range(3):
+        bt.sweep()
+    bt.profile(2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        bt.sweep()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kern = {}
+    for slot in (0, 1):
+        nl, ms, name = bt.profile_get(slot)
+        kern[slot] = {"name": name, "launches": nl, "avg_ms": ms / max(nl, 1)}
+    bt.profile(0)
+    assert (bt.get("status") == -1).all()
+    bytes_b, bytes_f = bt.algorithmic_bytes(0), bt.algorithmic_bytes(1)
+    bt.close()
+    out = {"workload": "TVLQR sweep of random LTV problems, (n, m) = (%d, %d): plan MFMA32, 2 x 2 tiles of v_mfma_f64_16x16x4" % (n, m),
+           "horizon_N": N, "n": n, "m": m, "batch": batch, "dtype": "f64", "steps": steps, "ms_per_step": elapsed / steps * 1e3,
+           "value": batch * steps / elapsed, "unit": "problem-sweeps/s", "kernels": {}}
+    for slot, key, by in ((0, "roofline", bytes_b), (1, "roofline_forward", bytes_f)):
+        dur = kern[slot]["avg_ms"] * 1e-3
+        out["kernels"][kern[slot]["name"]] = dict(kern[slot], algorithmic_GB=by / 1e9, GBps=by / dur / 1e9)
+        out[key] = {"bound": "hbm", "kernel": kern[slot]["name"], "achieved": by / dur / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": by / dur / 1e9 / HBM_PEAK_GBS, "duration_ms": dur * 1e3, "traffic": None,
+                    "traffic_source": "full n x n blocks in HBM: the algorithmic bytes are the bytes the kernel requests (profiles/r06*_tile32_pmc.txt)"}
+    if cpu_seconds > 0:
+        out["cpu_baseline"] = cpu_sweep_rate(N, n, m, cpu_seconds)
         out["vs_cpu_single_thread"] = out["value"] / out["cpu_baseline"]["value"]
     out["seconds_total"] = time.perf_counter() - t_setup
     return out
@@ -852,6 +914,11 @@ def main():
                                                  live=live_other.get(key))
             except Exception as e:   # noqa: BLE001 -- an extra must never take the metric's own line down
                 others[key] = {"error": str(e)}
+        for (n_, m_) in ((13, 4), (28, 4)):   # plan MFMA32: the shapes one step past the tile (round 6)
+            try:
+                others["mfma32_%dx%d" % (n_, m_)] = mfma32_entry(n_, m_, local_rank, args.other_steps, torch, 0.0 if args.no_cpu_baseline else 2.0)
+            except Exception as e:   # noqa: BLE001
+                others["mfma32_%dx%d" % (n_, m_)] = {"error": str(e)}
     else:
         bytes_keep = (bt.algorithmic_bytes(0), bt.algorithmic_bytes(1))
 
