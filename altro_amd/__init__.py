@@ -84,7 +84,7 @@ def _atoi(text):
     except ValueError:
         return 0
 
-MODEL_LINEAR, MODEL_DOUBLE_INTEGRATOR, MODEL_PENDULUM, MODEL_BICYCLE, MODEL_USER, MODEL_QUADROTOR = 0, 1, 2, 3, 4, 5
+MODEL_LINEAR, MODEL_DOUBLE_INTEGRATOR, MODEL_PENDULUM, MODEL_BICYCLE, MODEL_USER, MODEL_QUADROTOR, MODEL_QUADROTOR13 = 0, 1, 2, 3, 4, 5, 6
 MERIT_FN = C.CFUNCTYPE(None, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p)
 
 

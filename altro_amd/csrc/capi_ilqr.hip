@@ -311,6 +311,22 @@ int gen_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int 
   a.al.uniform = h->al_uniform; a.al.rows_per_knot = h->al_rows_per_knot; a.al.N = h->N; a.al.G_count = h->al_G_count;
   a.al.has_soc = h->al_has_soc; a.al.all_sel = h->al_all_sel; a.al.Gpad = nullptr; a.al.Gpad_count = 0;
   a.al.big = h->al_d_big;
+  if (h->model_set) {   // a device model: the dynamics expansion rides with every gradient expansion of a stored trajectory
+    a.mp = h->model;
+    if (which == IK_EXPAND && (a.mode & EXPAND_GRADIENT)) a.mode |= EXPAND_DYN;
+  }
+  if constexpr (sizeof(T) == 8) {
+    if (h->model_set && h->model.kind == MODEL_USER) {   // the caller's own model, compiled at run time (capi_rtc.hip)
+      if (which == IK_ROLLOUT || which == IK_MERIT) return rtc_gen_launch(h, which, a);
+      if (which == IK_EXPAND) {   // the cost's expansion from the library's kernel (the model kind it sees is not one it steps), then A_k, B_k
+        IlqrGenArgs<T> ac = a;
+        ac.mp.kind = MODEL_LINEAR;
+        const int rc0 = ilqr_generic_launch<T>(h->stream, which, ac);
+        if (rc0) return fail(ALTRO_HIP_ERR_HIP, "iLQR kernel launch failed");
+        return (a.mode & EXPAND_DYN) ? rtc_gen_launch(h, which, a) : 0;
+      }
+    }
+  }
   const int rc = ilqr_generic_launch<T>(h->stream, which, a);
   if (rc == 1) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "operation %d is not available on plan GENERIC", which);
   if (rc) return fail(ALTRO_HIP_ERR_HIP, "iLQR kernel launch failed");
@@ -446,6 +462,21 @@ int altro_hip_set_model(altro_hip_batch* h, int model, float timestep, int bicyc
   if (h->plan == ALTRO_HIP_PLAN_MFMA16 && !ilqr_tile_model_supported(model, h->n, h->m) && ilqr_supported(model, h->n, h->m) &&
       lane_supported(h->n, h->m)) {
     if ((rc = replan_empty_handle(h, ALTRO_HIP_PLAN_LANE))) return rc;
+  }
+  if (h->plan == ALTRO_HIP_PLAN_GENERIC) {   // plans GENERIC / MFMA32: the model steps inside that plan's loop kernels (kernels/ilqr_generic.hip)
+    if (h->ragged) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "device models need uniform dimensions");
+    if (!ilqr_generic_model_supported(model, h->n, h->m))
+      return fail(ALTRO_HIP_ERR_UNSUPPORTED, "no device model %d for plan %d with (n, m) = (%d, %d): plans GENERIC / MFMA32 carry "
+                                             "ALTRO_HIP_MODEL_QUADROTOR13 at (13, 4)", model, altro_hip_batch_plan(h), h->n, h->m);
+    if (h->dtype != ALTRO_HIP_F64) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "device models on plans GENERIC / MFMA32 run on fp64 handles");
+    h->model = ModelParams{model, timestep, 0, 2.7, 1.5};
+    h->model_set = true;
+    // A_k, B_k are the EXPANSION's from now on (written by the expansion / merit kernels), f = 0
+    HIP_TRY(hipMemsetAsync(h->g_arr[G_f], 0, (size_t)h->batch * h->g_bstride[G_f] * h->esz, h->stream));
+    HIP_TRY(hipMemsetAsync(h->g_arr[G_A], 0, (size_t)h->batch * h->g_bstride[G_A] * h->esz, h->stream));
+    HIP_TRY(hipMemsetAsync(h->g_arr[G_B], 0, (size_t)h->batch * h->g_bstride[G_B] * h->esz, h->stream));
+    h->dyn_set = true; h->has_f = 0;
+    return 0;
   }
   const bool tile = h->plan == ALTRO_HIP_PLAN_MFMA16 && ilqr_tile_model_supported(model, h->n, h->m);   // kernels/ilqr_tile_model.hip
   if (tile && h->dtype != ALTRO_HIP_F64)

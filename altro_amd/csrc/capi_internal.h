@@ -484,6 +484,7 @@ enum RtcKernel { RTC_ROLLOUT = 0, RTC_ACCEPT, RTC_EXPAND, RTC_MERIT, RTC_MERIT_R
 template <typename T>
 int rtc_launch(altro_hip_batch* h, int which, const IlqrArgs<T>& a);
 int rtc_tile_launch(altro_hip_batch* h, int which, const IlqrWaveArgs<double>& a);   // plan MFMA16: the model kernels of a caller's source
+int rtc_gen_launch(altro_hip_batch* h, int which, const IlqrGenArgs<double>& a);     // plans GENERIC / MFMA32: likewise
 
 // the sweep launchers (capi_tvlqr.hip), also used by the iLQR loop
 int replan_empty_handle(altro_hip_batch* h, int plan);   // capi_core.hip

@@ -48,6 +48,9 @@ ALTRO_EMBED(altro_rtc_src_mfma16_layout, "kernels/mfma16_layout.h")
 ALTRO_EMBED(altro_rtc_src_ilqr_mfma16, "kernels/ilqr_mfma16.hip")
 ALTRO_EMBED(altro_rtc_src_merit2_dpp, "kernels/ilqr_merit2_dpp.hip")
 ALTRO_EMBED(altro_rtc_src_tile_model, "kernels/ilqr_tile_model.hip")
+// ... and of plan GENERIC's loop kernels (a caller's model on plans GENERIC / MFMA32)
+ALTRO_EMBED(altro_rtc_src_generic_arrays, "kernels/generic_arrays.h")
+ALTRO_EMBED(altro_rtc_src_ilqr_generic, "kernels/ilqr_generic.hip")
 
 namespace {
 
@@ -325,6 +328,112 @@ static int rtc_tile_module_for(altro_hip_batch* h, int al, int dense, RtcTileMod
   return 0;
 }
 
+// ---- the same for plans GENERIC / MFMA32: the caller's model inside that plan's loop kernels (kernels/ilqr_generic.hip) ----------------
+// Three kernels per (source, n, m): the open-loop rollout, the dynamics expansion and the merit evaluation.
+enum RtcGenKernel { RTG_ROLLOUT = 0, RTG_EXPAND_DYN, RTG_MERIT, RTG_NUM };
+struct RtcGenModule {
+  hipModule_t module = nullptr;
+  hipFunction_t fn[RTG_NUM] = {};
+};
+static int rtc_gen_module_for(altro_hip_batch* h, RtcGenModule** out) {
+  *out = nullptr;
+  static std::mutex mu;
+  static std::map<std::string, RtcGenModule*> cache;
+  const std::string& user_src = h->rtc_source;
+  const std::string key = std::to_string(h->device) + "|" + std::to_string(h->n) + "|" + std::to_string(h->m) + "|" + user_src;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = cache.find(key);
+  if (it != cache.end()) { *out = it->second; return 0; }
+  const Hiprtc* R;
+  int rc = hiprtc_api(&R);
+  if (rc) return rc;
+  const std::string nm = std::to_string(h->n) + ", " + std::to_string(h->m);
+  std::string exprs[RTG_NUM];
+  exprs[RTG_ROLLOUT] = "altro_hip::generic_model_rollout_kernel<double, altro_hip::MODEL_USER, " + nm + ">";
+  exprs[RTG_EXPAND_DYN] = "altro_hip::generic_model_expand_dyn_kernel<double, altro_hip::MODEL_USER, " + nm + ">";
+  exprs[RTG_MERIT] = "altro_hip::generic_merit_kernel<double, false, altro_hip::MODEL_USER, " + nm + ">";
+  std::string src = "#define ALTRO_HIP_USER_MODEL 1\n";
+  src += "#include \"rtc_compat.h\"\n#include \"fp_contract.h\"\nALTRO_FP_REGION_ON\n";
+  src += "#line 1 \"user_model\"\n" + user_src + "\nALTRO_FP_REGION_END\n#include \"kernels/ilqr_generic.hip\"\nnamespace altro_hip {\n";
+  for (int w = 0; w < RTG_NUM; ++w) {
+    std::string e = exprs[w];
+    for (size_t p; (p = e.find("altro_hip::")) != std::string::npos;) e.erase(p, std::strlen("altro_hip::"));
+    src += "template __global__ void " + e + "(IlqrGenArgs<double>);\n";
+  }
+  src += "}\n";
+  const char* hdr_src[] = {altro_rtc_src_rtc_compat, altro_rtc_src_fp_contract, altro_rtc_src_models, altro_rtc_src_linesearch,
+                           altro_rtc_src_ilqr_types, altro_rtc_src_al_types, altro_rtc_src_al_lane, altro_rtc_src_tvlqr_lane,
+                           altro_rtc_src_lane_body, altro_rtc_src_quad_body, altro_rtc_src_quad2_body, altro_rtc_src_generic_arrays,
+                           altro_rtc_src_ilqr_generic};
+  const char* hdr_name[] = {"rtc_compat.h", "fp_contract.h", "models.h", "linesearch_sm.h", "kernels/ilqr_types.h", "kernels/al_types.h",
+                            "kernels/al_lane.hip", "kernels/tvlqr_lane.hip", "kernels/tvlqr_lane_body.inc", "kernels/tvlqr_quad_body.inc",
+                            "kernels/tvlqr_quad2_body.inc", "kernels/generic_arrays.h", "kernels/ilqr_generic.hip"};
+  hiprtcProgram prog = nullptr;
+  hiprtcResult rr = R->CreateProgram(&prog, src.c_str(), "altro_user_generic_model.hip", 13, hdr_src, hdr_name);
+  if (rr != HIPRTC_SUCCESS) return fail(ALTRO_HIP_ERR_HIP, "hiprtcCreateProgram: %s", R->GetErrorString(rr));
+  for (int w = 0; w < RTG_NUM; ++w) R->AddNameExpression(prog, exprs[w].c_str());
+  hipDeviceProp_t prop;
+  std::string arch = "--offload-arch=gfx950";
+  if (hipGetDeviceProperties(&prop, h->device) == hipSuccess) arch = std::string("--offload-arch=") + prop.gcnArchName;
+  const char* opts[] = {arch.c_str(), "-O3", "-std=c++17"};
+  rr = R->CompileProgram(prog, 3, opts);
+  if (rr != HIPRTC_SUCCESS) {
+    size_t ls = 0;
+    R->GetProgramLogSize(prog, &ls);
+    std::string log(ls, '\0');
+    if (ls) R->GetProgramLog(prog, &log[0]);
+    if (log.size() > 1800) log.resize(1800);
+    R->DestroyProgram(&prog);
+    return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "the model source does not compile for plan GENERIC's loop (hiprtc: %s):\n%s", R->GetErrorString(rr), log.c_str());
+  }
+  size_t cs = 0;
+  R->GetCodeSize(prog, &cs);
+  std::vector<char> code(cs);
+  R->GetCode(prog, code.data());
+  RtcGenModule* m = new RtcGenModule();
+  if (const hipError_t le = hipModuleLoadData(&m->module, code.data()); le != hipSuccess) {
+    R->DestroyProgram(&prog);
+    delete m;
+    return fail(ALTRO_HIP_ERR_HIP, "hipModuleLoadData of the compiled model failed: %s", hipGetErrorString(le));
+  }
+  for (int w = 0; w < RTG_NUM; ++w) {
+    const char* lowered = nullptr;
+    if (R->GetLoweredName(prog, exprs[w].c_str(), &lowered) != HIPRTC_SUCCESS || !lowered ||
+        hipModuleGetFunction(&m->fn[w], m->module, lowered) != hipSuccess) {
+      rc = fail(ALTRO_HIP_ERR_HIP, "kernel %s missing from the compiled model", exprs[w].c_str());
+      R->DestroyProgram(&prog);
+      (void)hipModuleUnload(m->module);
+      delete m;
+      return rc;
+    }
+  }
+  R->DestroyProgram(&prog);
+  cache[key] = m;
+  *out = m;
+  return 0;
+}
+// A model kernel of plan GENERIC's loop from the handle's run-time module: the grids of ilqr_launch_generic.hip.  (IK_EXPAND: the
+// dynamics expansion only -- the caller has launched the cost's.)
+int rtc_gen_launch(altro_hip_batch* h, int which, const IlqrGenArgs<double>& a) {
+  if (h->rtc_source.empty()) return fail(ALTRO_HIP_ERR_NOT_SET, "altro_hip_set_model_source has not been called");
+  RtcGenModule* mod = nullptr;
+  int rc = rtc_gen_module_for(h, &mod);
+  if (rc) return rc;
+  IlqrGenArgs<double> args = a;
+  void* params[] = {&args};
+  auto go = [&](int w, unsigned gx, unsigned lds) -> int {
+    const hipError_t e = hipModuleLaunchKernel(mod->fn[w], gx, 1, 1, 64, 1, 1, lds, h->stream, params, nullptr);
+    if (e != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "launch of the run-time compiled kernel %d of plan GENERIC's loop failed: %s", w, hipGetErrorString(e));
+    return 0;
+  };
+  switch (which) {
+    case IK_ROLLOUT: return go(RTG_ROLLOUT, (unsigned)((a.batch + 63) / 64), 0);
+    case IK_EXPAND: return go(RTG_EXPAND_DYN, (unsigned)(((int64_t)a.batch * a.N + 63) / 64), 0);
+    case IK_MERIT: return go(RTG_MERIT, (unsigned)a.batch, a.al.enabled ? (unsigned)(GEN_AL_JV * sizeof(double)) : 0u);
+    default: return fail(ALTRO_HIP_ERR_UNSUPPORTED, "operation %d has no run-time compiled kernel on this plan", which);
+  }
+}
+
 // A model kernel of plan MFMA16's loop from the handle's run-time module: the grids of ilqr_launch_mfma16_model.hip.
 int rtc_tile_launch(altro_hip_batch* h, int which, const IlqrWaveArgs<double>& a) {
   if (h->rtc_source.empty()) return fail(ALTRO_HIP_ERR_NOT_SET, "altro_hip_set_model_source has not been called");
@@ -409,10 +518,29 @@ int altro_hip_set_model_source(altro_hip_batch* h, const char* source, float tim
   h->expansion_current = false;
   if (!source) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "source == NULL");
   if (!(timestep > 0.0f)) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "time step must be positive (ErrorCodes::TimestepNotPositive)");
-  if (h->plan != ALTRO_HIP_PLAN_LANE && h->plan != ALTRO_HIP_PLAN_MFMA16)
-    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "run-time compiled models run on plans LANE (n <= 6, m <= 3) and MFMA16 (n <= 12, m <= 4); this "
-                                           "handle is on plan %d with (n, m) = (%d, %d)", h->plan, h->n, h->m);
   HIP_TRY(hipSetDevice(h->device));
+  if (h->plan == ALTRO_HIP_PLAN_GENERIC) {   // plans GENERIC / MFMA32: the caller's model inside that plan's loop kernels (any n, m <= 32)
+    if (h->ragged) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "device models need uniform dimensions");
+    if (h->dtype != ALTRO_HIP_F64) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "device models on plans GENERIC / MFMA32 run on fp64 handles");
+    if (h->n > 32 || h->m > 32)
+      return fail(ALTRO_HIP_ERR_UNSUPPORTED, "run-time compiled models on plan GENERIC take n, m <= 32 (got %d, %d)", h->n, h->m);
+    const std::string gsrc(source);
+    if (defines_function(gsrc, "altro_user_constraint") || defines_function(gsrc, "altro_user_constraint_jacobian"))
+      return fail(ALTRO_HIP_ERR_UNSUPPORTED, "nonlinear constraint blocks from source are a plan LANE feature; this plan takes the model's two "
+                                             "functions and linear blocks (altro_hip_add_linear_constraint)");
+    h->rtc_source = gsrc;
+    h->model = ModelParams{MODEL_USER, timestep, 0, 2.7, 1.5};
+    RtcGenModule* gm = nullptr;   // compile now: a source that does not build must fail HERE, with the compiler's log
+    if ((rc = rtc_gen_module_for(h, &gm))) { h->rtc_source.clear(); h->model = ModelParams{MODEL_LINEAR, 0.0f, 0, 2.7, 1.5}; return rc; }
+    h->model_set = true; h->rtc_has_constraints = false;
+    HIP_TRY(hipMemsetAsync(h->g_arr[G_f], 0, (size_t)h->batch * h->g_bstride[G_f] * h->esz, h->stream));
+    HIP_TRY(hipMemsetAsync(h->g_arr[G_A], 0, (size_t)h->batch * h->g_bstride[G_A] * h->esz, h->stream));
+    HIP_TRY(hipMemsetAsync(h->g_arr[G_B], 0, (size_t)h->batch * h->g_bstride[G_B] * h->esz, h->stream));
+    h->dyn_set = true; h->has_f = 0;
+    return 0;
+  }
+  if (h->plan != ALTRO_HIP_PLAN_LANE && h->plan != ALTRO_HIP_PLAN_MFMA16)
+    return fail(ALTRO_HIP_ERR_UNSUPPORTED, "unknown plan %d", h->plan);
   if (h->plan == ALTRO_HIP_PLAN_MFMA16 && h->auto_plan && lane_supported(h->n, h->m)) {
     // nonlinear constraint blocks from source are plan LANE's: an ALTRO_HIP_PLAN_AUTO handle that rides the padded tile only because
     // of its batch size moves there while it is still empty

@@ -7,9 +7,37 @@
 
 namespace altro_hip {
 
+bool ilqr_generic_model_supported(int kind, int n, int m) { return kind == MODEL_QUADROTOR13 && n == 13 && m == 4; }
+
+// the kernels that step a compiled-in device model (fp64 handles); everything else of the loop is the data form's
+template <int MK, int MN, int MM>
+static int gen_launch_model(hipStream_t stream, int which, const IlqrGenArgs<double>& a) {
+  const dim3 waves(a.batch), b64(64), b256(256);
+  switch (which) {
+    case IK_ROLLOUT:
+      hipLaunchKernelGGL((generic_model_rollout_kernel<double, MK, MN, MM>), dim3((a.batch + 63) / 64), b64, 0, stream, a);
+      break;
+    case IK_MERIT: {
+      const size_t jv = a.al.enabled ? (size_t)GEN_AL_JV * sizeof(double) : 0;
+      hipLaunchKernelGGL((generic_merit_kernel<double, false, MK, MN, MM>), waves, b64, jv, stream, a);
+      break;
+    }
+    case IK_EXPAND: {   // after the cost expansion (the caller launched it): A_k, B_k at the candidate trajectory
+      const int64_t tot = (int64_t)a.batch * a.N;
+      hipLaunchKernelGGL((generic_model_expand_dyn_kernel<double, MK, MN, MM>), dim3((unsigned)((tot + 63) / 64)), b64, 0, stream, a);
+      break;
+    }
+    default: return 1;
+  }
+  return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
 template <typename T>
 static int gen_launch(hipStream_t stream, int which, const IlqrGenArgs<T>& a) {
   const dim3 waves(a.batch), b64(64), b256(256);
+  if constexpr (sizeof(T) == 8) {
+    if (a.mp.kind == MODEL_QUADROTOR13 && (which == IK_ROLLOUT || which == IK_MERIT)) return gen_launch_model<MODEL_QUADROTOR13, 13, 4>(stream, which, a);
+  }
   const int64_t flat_n = (int64_t)a.batch * (a.N + 1) * (a.n + a.m);
   const dim3 flat((unsigned)std::min<int64_t>((flat_n + 255) / 256, 1 << 20));
   switch (which) {
@@ -18,6 +46,10 @@ static int gen_launch(hipStream_t stream, int which, const IlqrGenArgs<T>& a) {
     case IK_EXPAND:
       if (a.al.enabled) hipLaunchKernelGGL(generic_expand_al_kernel<T>, dim3((unsigned)((int64_t)a.batch * (a.N + 1))), b64, 0, stream, a);
       else hipLaunchKernelGGL(generic_expand_kernel<T>, flat, b256, 0, stream, a);
+      if constexpr (sizeof(T) == 8) {
+        if (a.mp.kind == MODEL_QUADROTOR13 && (a.mode & EXPAND_DYN) && hipGetLastError() == hipSuccess)
+          return gen_launch_model<MODEL_QUADROTOR13, 13, 4>(stream, IK_EXPAND, a);
+      }
       break;
     case IK_DUAL: hipLaunchKernelGGL(generic_dual_update_kernel<T>, dim3((unsigned)((int64_t)a.batch * (a.N + 1))), b64, 0, stream, a); break;
     case IK_MERIT: {   // the knot point's matrices staged in LDS while sixteen waves still fit a CU (10 KB each, the kernel's own 2.5 KB included)

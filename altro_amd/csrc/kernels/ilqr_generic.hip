@@ -13,8 +13,7 @@
 // The line search, convergence logic and sweep sequencing are the plan-independent kernels of ilqr_loop_kernels.hip.
 // Sums are taken per lane and reduced over the wave: results agree with the oracle to rounding (1e-12 relative), not bit for bit.
 #pragma once
-#include <hip/hip_runtime.h>
-#include <stdint.h>
+#include "../rtc_compat.h"   // (also compiled at run time around a caller's model: capi_rtc.hip)
 
 #include "generic_arrays.h"
 #include "ilqr_types.h"
@@ -44,6 +43,9 @@ struct IlqrGenArgs {
   const int *nx, *nu;                                               // [N + 1] dimensions of knot point k
   int64_t sx, su, sQ, sR, sH;                                       // one problem's length of xn | cq, un | cr, cQ, cR, cH (cc: N + 1)
   AlTable<T> al;                                                    // constraint blocks (G: p x (n + m), column-major)
+  // a device model instead of dynamics given as data (altro_hip_set_model on plans GENERIC / MFMA32): the rollout and the merit
+  // evaluation step the model (explicit midpoint, test_utils.cpp:84-132), the expansion writes A_k, B_k into the sweep's arrays
+  ModelParams mp{MODEL_LINEAR, 0.0f, 0, 2.7, 1.5};
 };
 
 #define GOFF(arr, k) (a.off[(int64_t)(k) * G_NUM + (arr)])
@@ -331,9 +333,14 @@ __device__ __forceinline__ void gen_put(T* dst, const T (&v)[CAP], const T* src,
 }
 inline size_t generic_merit_stage_elems(int n, int m) { return (size_t)3 * n * n + (size_t)3 * n * m + (size_t)m * m; }
 
-template <typename T, bool STAGE>
+// MK != 0: a compiled-in device model of MN states and MM inputs (models.h) in the place of x+ = A x + B u + f: lane 0 evaluates the
+// continuous model and its Jacobian at (x, u) and at the midpoint, the state rows form their rows of A_k = I + h Am (I + h/2 A0),
+// B_k = h (Am h/2 B0 + Bm) (the chain rule of test_utils.cpp:113-129, in oracle/models_oracle.c's order) from LDS, store them into the
+// sweep's arrays (MeritFunction with derivative refreshes the dynamics expansion: solver.cpp:300-305) and take phi' through them.
+template <typename T, bool STAGE, int MK = 0, int MN = 1, int MM = 1>
 __global__ __launch_bounds__(64, 4) void generic_merit_kernel(IlqrGenArgs<T> a) {
   __shared__ double xs[GEN_MAX], dxs[GEN_MAX], das[GEN_MAX], us[GEN_MAX], dus[GEN_MAX];
+  __shared__ double md_xn[MK ? MN : 1], md_J0[MK ? MN * (MN + MM) : 1], md_Jm[MK ? MN * (MN + MM) : 1];
   extern __shared__ __attribute__((aligned(16))) unsigned char gen_dyn[];
   double* const jv = reinterpret_cast<double*>(gen_dyn);                                   // [GEN_AL_JV] when there are constraint blocks
   T* const stg = reinterpret_cast<T*>(gen_dyn + (a.al.enabled ? GEN_AL_JV * sizeof(double) : 0));
@@ -406,12 +413,58 @@ __global__ __launch_bounds__(64, 4) void generic_merit_kernel(IlqrGenArgs<T> a) 
       if (deriv) { dJ += lx * dxda; a.q[(int64_t)b * a.q_bs + GOFF(G_q, k) + i] = (T)lx; }
     }
     double xn = 0.0, dxn = 0.0;
+    if constexpr (MK == 0) {
     if (lane < n2) {   // row of the next state: A_k is n2 x n, B_k n2 x m
       double s, s2, t, t2;
       gen_gdot2<T>(Ak + lane, n2, xs, das, n, s, t);
       gen_gdot2<T>(Bk + lane, n2, us, dus, m, s2, t2);
       xn = (s + s2) + (double)a.f[(int64_t)b * a.f_bs + GOFF(G_f, k) + lane];
       dxn = t + t2;
+    }
+    } else {
+      using M = DiscreteModel<MK, MN, MM, double>;
+      const float h = a.mp.h;
+      if (lane == 0) {   // the model at (x, u) and at the midpoint
+        double xl[MN], ul[MM], k1[MN], xm[MN], k2[MN];
+        for (int e = 0; e < MN; ++e) xl[e] = xs[e];
+        for (int e = 0; e < MM; ++e) ul[e] = us[e];
+        if (deriv) {
+          double J0[MN * (MN + MM)], Jm[MN * (MN + MM)];
+          M::cont_fJ(a.mp, xl, ul, k1, J0);
+          for (int e = 0; e < MN; ++e) xm[e] = xl[e] + (double)(h / 2) * k1[e];
+          M::cont_fJ(a.mp, xm, ul, k2, Jm);
+          for (int e = 0; e < MN * (MN + MM); ++e) { md_J0[e] = J0[e]; md_Jm[e] = Jm[e]; }
+        } else {
+          M::cont_f(a.mp, xl, ul, k1);
+          for (int e = 0; e < MN; ++e) xm[e] = xl[e] + (double)(h / 2) * k1[e];
+          M::cont_f(a.mp, xm, ul, k2);
+        }
+        for (int e = 0; e < MN; ++e) md_xn[e] = xl[e] + (double)h * k2[e];
+      }
+      __syncthreads();
+      if (lane < MN) {
+        xn = md_xn[lane];
+        if (deriv) {   // row `lane` of A_k and B_k, stored and applied
+          T* Aw = const_cast<T*>(Ak); T* Bw = const_cast<T*>(Bk);
+          const double* A0 = md_J0; const double* B0 = md_J0 + MN * MN; const double* Am = md_Jm; const double* Bm = md_Jm + MN * MN;
+          double t = 0.0;
+          for (int jc = 0; jc < MN; ++jc) {
+            double sm = 0.0;
+            for (int kk = 0; kk < MN; ++kk) sm += ((double)h * Am[lane + kk * MN]) * ((kk == jc ? 1.0 : 0.0) + (double)(h / 2) * A0[kk + jc * MN]);
+            const double av = (lane == jc ? 1.0 : 0.0) + sm;
+            Aw[lane + jc * MN] = (T)av;
+            t += av * das[jc];
+          }
+          for (int jc = 0; jc < MM; ++jc) {
+            double sm = 0.0;
+            for (int kk = 0; kk < MN; ++kk) sm += (Am[lane + kk * MN] * (double)(h / 2)) * B0[kk + jc * MN];
+            const double bv = (double)h * (sm + Bm[lane + jc * MN]);
+            Bw[lane + jc * MN] = (T)bv;
+            t += bv * dus[jc];
+          }
+          dxn = t;
+        }
+      }
     }
     if (isu) {   // input row: cost share (with the cross term u'Hx), lu
       const double ru = gen_gdot<T>(Rk + iu, m, us, m), hx = gen_gdot<T>(Hk + iu, m, xs, n);
@@ -611,6 +664,44 @@ __global__ __launch_bounds__(64) void generic_dual_update_kernel(IlqrGenArgs<T> 
   gen_al_rows<T>(a.al, k, b, a.batch, n, m, xs, us, terminal, a.prob[b].rho_est, lane, jv, nullptr, nullptr, nullptr, cost, viol, true);
 }
 
+// ---- device models on plan GENERIC: open-loop rollout and dynamics expansion -------------------------------------------------------
+// SolverImpl::OpenLoopRollout (solver.cpp:116-131) with a model: one thread per problem steps x_{k+1} = model(x_k, u_k)
+template <typename T, int MK, int MN, int MM>
+__global__ void generic_model_rollout_kernel(IlqrGenArgs<T> a) {
+  using M = DiscreteModel<MK, MN, MM, double>;
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.batch) return;
+  if (a.active && !a.active[b]) return;
+  double x[MN], u[MM], xn[MN];
+  for (int e = 0; e < MN; ++e) x[e] = (double)a.x0[(int64_t)b * a.x0_stride + e];
+  T* xo = a.x + (int64_t)b * a.x_bs;
+  const T* ui = a.u + (int64_t)b * a.u_bs;
+  for (int k = 0; k < a.N; ++k) {
+    for (int e = 0; e < MN; ++e) xo[(int64_t)k * MN + e] = (T)x[e];
+    for (int e = 0; e < MM; ++e) u[e] = (double)ui[(int64_t)k * MM + e];
+    M::dynamics(a.mp, x, u, xn);
+    for (int e = 0; e < MN; ++e) x[e] = xn[e];
+  }
+  for (int e = 0; e < MN; ++e) xo[(int64_t)a.N * MN + e] = (T)x[e];
+}
+// KnotPointData::CalcDynamicsExpansion (knotpoint_data.cpp:406-419) at the candidate trajectory: one thread per (problem, knot point)
+template <typename T, int MK, int MN, int MM>
+__global__ void generic_model_expand_dyn_kernel(IlqrGenArgs<T> a) {
+  using M = DiscreteModel<MK, MN, MM, double>;
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t >= (int64_t)a.batch * a.N) return;
+  const int b = (int)(t / a.N), k = (int)(t % a.N);
+  if (a.active && !a.active[b]) return;
+  double x[MN], u[MM], A[MN * MN], B[MN * MM];
+  for (int e = 0; e < MN; ++e) x[e] = (double)a.x[(int64_t)b * a.x_bs + (int64_t)k * MN + e];
+  for (int e = 0; e < MM; ++e) u[e] = (double)a.u[(int64_t)b * a.u_bs + (int64_t)k * MM + e];
+  M::jacobian(a.mp, x, u, A, B);
+  T* Ao = const_cast<T*>(a.A) + (int64_t)b * a.A_bs + (int64_t)k * MN * MN;
+  T* Bo = const_cast<T*>(a.B) + (int64_t)b * a.B_bs + (int64_t)k * MN * MM;
+  for (int e = 0; e < MN * MN; ++e) Ao[e] = (T)A[e];
+  for (int e = 0; e < MN * MM; ++e) Bo[e] = (T)B[e];
+}
+
 // ALTROSolver::ShiftTrajectory (altro_solver.cpp:283-293) on the candidate trajectory
 template <typename T>
 __global__ void generic_shift_kernel(IlqrGenArgs<T> a) {
@@ -634,5 +725,6 @@ __global__ void generic_shift_kernel(IlqrGenArgs<T> a) {
 
 template <typename T>
 int ilqr_generic_launch(hipStream_t stream, int which, const IlqrGenArgs<T>& a);   // ilqr_launch_generic.hip
+bool ilqr_generic_model_supported(int kind, int n, int m);                           // compiled-in device models of plans GENERIC / MFMA32
 
 }  // namespace altro_hip

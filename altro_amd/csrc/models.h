@@ -29,7 +29,8 @@ namespace altro_hip {
 
 enum ModelKind { MODEL_LINEAR = 0, MODEL_DOUBLE_INTEGRATOR = 1, MODEL_PENDULUM = 2, MODEL_BICYCLE = 3,
                  MODEL_USER = 4 /* altro_hip_set_model_source: the caller's own continuous dynamics, compiled at run time */,
-                 MODEL_QUADROTOR = 5 /* 12 states, 4 inputs: the nonlinear model of the (12, 4) tile plan (not a reference model) */ };
+                 MODEL_QUADROTOR = 5 /* 12 states, 4 inputs: the nonlinear model of the (12, 4) tile plan (not a reference model) */,
+                 MODEL_QUADROTOR13 = 6 /* 13 states (quaternion attitude), 4 inputs: the compiled-in model of plans GENERIC / MFMA32 */ };
 
 struct ModelParams {
   int kind;
@@ -291,6 +292,55 @@ ALTRO_HD void altro_tile_user_J(const T* x, const T* u, T* J) {
 }
 #endif
 
+// ---- quadrotor, 13 states (unit-quaternion attitude), 4 inputs ---------------------------------------------------------------
+// The same rigid body with the attitude as a quaternion q = (qw, qx, qy, qz): the state dimension one past the (12, 4) tile, the
+// compiled-in device model of plan GENERIC's iLQR loop (and plan MFMA32's, which shares it).  Same equations as
+// oracle/models_oracle.c (written apart; pinned there by central differences):
+//   x = [p (3) | q (4) | v (3, world) | omega (3, body)],  u = [thrust F | torques tau (3)]
+//   pdot = v ;  qdot = 1/2 q (x) [0; omega] ;  vdot = -g e3 + F / mass R(q) e3 ;  omegadot = I^-1 (tau - omega x I omega)
+// Polynomial: no transcendental call and no division in an evaluation.
+template <typename T>
+ALTRO_HD void quadrotor13_f(const T* x, const T* u, T* xd) {
+  const T qw = x[3], qx = x[4], qy = x[5], qz = x[6];
+  const T wx = x[10], wy = x[11], wz = x[12];
+  xd[0] = x[7]; xd[1] = x[8]; xd[2] = x[9];
+  xd[3] = T(0.5) * (-qx * wx - qy * wy - qz * wz);
+  xd[4] = T(0.5) * (qw * wx + qy * wz - qz * wy);
+  xd[5] = T(0.5) * (qw * wy - qx * wz + qz * wx);
+  xd[6] = T(0.5) * (qw * wz + qx * wy - qy * wx);
+  const T a = u[0] * T(kQuadRMass);
+  xd[7] = a * (T(2) * (qx * qz + qw * qy));
+  xd[8] = a * (T(2) * (qy * qz - qw * qx));
+  xd[9] = a * (T(1) - T(2) * (qx * qx + qy * qy)) - T(kQuadG);
+  xd[10] = (u[1] - T(kQuadIz - kQuadIy) * wy * wz) * T(kQuadRIx);
+  xd[11] = (u[2] - T(kQuadIx - kQuadIz) * wz * wx) * T(kQuadRIy);
+  xd[12] = (u[3] - T(kQuadIy - kQuadIx) * wx * wy) * T(kQuadRIz);
+}
+template <typename T>
+ALTRO_HD void quadrotor13_J(const T* x, const T* u, T* J) {   // 13 x 17, column-major
+  constexpr int n = 13;
+  for (int e = 0; e < 13 * 17; ++e) J[e] = T(0);
+  const T qw = x[3], qx = x[4], qy = x[5], qz = x[6];
+  const T wx = x[10], wy = x[11], wz = x[12];
+#define QJ(i, j) J[(i) + (j) * n]
+  QJ(0, 7) = T(1); QJ(1, 8) = T(1); QJ(2, 9) = T(1);
+  QJ(3, 4) = T(-0.5) * wx; QJ(3, 5) = T(-0.5) * wy; QJ(3, 6) = T(-0.5) * wz; QJ(3, 10) = T(-0.5) * qx; QJ(3, 11) = T(-0.5) * qy; QJ(3, 12) = T(-0.5) * qz;
+  QJ(4, 3) = T(0.5) * wx; QJ(4, 5) = T(0.5) * wz; QJ(4, 6) = T(-0.5) * wy; QJ(4, 10) = T(0.5) * qw; QJ(4, 11) = T(-0.5) * qz; QJ(4, 12) = T(0.5) * qy;
+  QJ(5, 3) = T(0.5) * wy; QJ(5, 4) = T(-0.5) * wz; QJ(5, 6) = T(0.5) * wx; QJ(5, 10) = T(0.5) * qz; QJ(5, 11) = T(0.5) * qw; QJ(5, 12) = T(-0.5) * qx;
+  QJ(6, 3) = T(0.5) * wz; QJ(6, 4) = T(0.5) * wy; QJ(6, 5) = T(-0.5) * wx; QJ(6, 10) = T(-0.5) * qy; QJ(6, 11) = T(0.5) * qx; QJ(6, 12) = T(0.5) * qw;
+  const T a = u[0] * T(kQuadRMass);
+  QJ(7, 3) = T(2) * a * qy; QJ(7, 4) = T(2) * a * qz; QJ(7, 5) = T(2) * a * qw; QJ(7, 6) = T(2) * a * qx;
+  QJ(7, 13) = T(2) * (qx * qz + qw * qy) * T(kQuadRMass);
+  QJ(8, 3) = T(-2) * a * qx; QJ(8, 4) = T(-2) * a * qw; QJ(8, 5) = T(2) * a * qz; QJ(8, 6) = T(2) * a * qy;
+  QJ(8, 13) = T(2) * (qy * qz - qw * qx) * T(kQuadRMass);
+  QJ(9, 4) = T(-4) * a * qx; QJ(9, 5) = T(-4) * a * qy;
+  QJ(9, 13) = (T(1) - T(2) * (qx * qx + qy * qy)) * T(kQuadRMass);
+  QJ(10, 11) = -T(kQuadIz - kQuadIy) * wz * T(kQuadRIx); QJ(10, 12) = -T(kQuadIz - kQuadIy) * wy * T(kQuadRIx); QJ(10, 14) = T(kQuadRIx);
+  QJ(11, 10) = -T(kQuadIx - kQuadIz) * wz * T(kQuadRIy); QJ(11, 12) = -T(kQuadIx - kQuadIz) * wx * T(kQuadRIy); QJ(11, 15) = T(kQuadRIy);
+  QJ(12, 10) = -T(kQuadIy - kQuadIx) * wy * T(kQuadRIz); QJ(12, 11) = -T(kQuadIy - kQuadIx) * wx * T(kQuadRIz); QJ(12, 16) = T(kQuadRIz);
+#undef QJ
+}
+
 // ---- discrete models -------------------------------------------------------------------------------
 // KIND is a compile-time ModelKind; n, m the dimensions (double integrator: dim = n/2, the first m
 // axes are actuated -- m == dim is the reference's model, m < dim the C1 variant of SURVEY.md 8d).
@@ -311,6 +361,7 @@ struct DiscreteModel {
     else if (KIND == MODEL_USER) altro_user_dynamics<T>(x, u, xdot);
 #endif
     else if (KIND == MODEL_QUADROTOR) quadrotor_f_from<T>(quadrotor_trig<T>(x), x, u, xdot);
+    else if (KIND == MODEL_QUADROTOR13) quadrotor13_f<T>(x, u, xdot);
     else bicycle_f<T>(mp, x, u, xdot);
   }
   static ALTRO_HD void cont_J(const ModelParams& mp, const T* x, const T* u, T* J) {
@@ -321,6 +372,7 @@ struct DiscreteModel {
     else if (KIND == MODEL_USER) altro_user_jacobian<T>(x, u, J);
 #endif
     else if (KIND == MODEL_QUADROTOR) quadrotor_J_from<T>(quadrotor_trig<T>(x), x, u, J);
+    else if (KIND == MODEL_QUADROTOR13) quadrotor13_J<T>(x, u, J);
     else bicycle_J<T>(mp, x, u, J);
   }
 
@@ -336,6 +388,7 @@ struct DiscreteModel {
       quadrotor_J_from<T>(t, x, u, J);
       return;
     }
+    if (KIND == MODEL_QUADROTOR13) { quadrotor13_f<T>(x, u, xdot); quadrotor13_J<T>(x, u, J); return; }
     if (KIND == MODEL_PENDULUM) {   // one sincos for f (sin) and J (cos)
       const T l = T(0.5), g = T(9.81), b = T(0.1), mm = T(1.0) * l * l;
       T sn, cs;

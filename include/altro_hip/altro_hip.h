@@ -130,7 +130,8 @@ typedef enum altro_hip_model {
   ALTRO_HIP_MODEL_PENDULUM = 2,          /* test_utils.cpp:43-82 + midpoint :84-132               */
   ALTRO_HIP_MODEL_BICYCLE = 3,           /* test_utils.cpp:134-238 + midpoint                     */
   ALTRO_HIP_MODEL_USER = 4,              /* set by altro_hip_set_model_source (not a value to pass) */
-  ALTRO_HIP_MODEL_QUADROTOR = 5          /* 12 states, 4 inputs, plan MFMA16 (csrc/models.h) + midpoint; not a reference model */
+  ALTRO_HIP_MODEL_QUADROTOR = 5,         /* 12 states, 4 inputs, plan MFMA16 (csrc/models.h) + midpoint; not a reference model */
+  ALTRO_HIP_MODEL_QUADROTOR13 = 6        /* 13 states (quaternion attitude), 4 inputs, plans GENERIC / MFMA32 + midpoint; not a reference model */
 } altro_hip_model;
 
 /* ---- library ------------------------------------------------------------------------------- */

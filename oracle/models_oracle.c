@@ -21,6 +21,7 @@
 #define ORACLE_MODEL_PENDULUM 1
 #define ORACLE_MODEL_BICYCLE 2
 #define ORACLE_MODEL_QUADROTOR 3   /* NOT from the reference: this repo's own 12-state test model, see below */
+#define ORACLE_MODEL_QUADROTOR13 4 /* ... and its 13-state quaternion form (round 6: a shape past the (12, 4) tile) */
 
 /* ---- double integrator (test_utils.cpp:18-41) ---------------------------------- */
 void oracle_di_dynamics(double* xnext, const double* x, const double* u, float h, int dim) {
@@ -253,6 +254,57 @@ void oracle_quadrotor_jacobian(double* jac, const double* x, const double* u) {
 #undef J
 }
 
+/* ---- quadrotor, 13 states (unit-quaternion attitude), 4 inputs -------------------------------------------------------
+ * NOT a model of the reference either: the same rigid body with the attitude as a quaternion q = (qw, qx, qy, qz) -- the state
+ * dimension one past the (12, 4) tile that round 6's plan MFMA32 and the device models of plan GENERIC are exercised on.
+ *   x = [p (3) | q (4) | v (3, world) | omega (3, body)],  u = [thrust F | torques tau (3)]
+ *   pdot = v ;  qdot = 1/2 q (x) [0; omega] ;  vdot = -g e3 + F/mass R(q) e3 ;  omegadot = I^-1 (tau - omega x I omega)
+ * R(q) e3 in its polynomial form (no normalisation: f is smooth everywhere, and its Jacobian is checked against central
+ * differences in tests/test_oracle_kat.py).                                                                              */
+void oracle_quadrotor13_dynamics(double* xd, const double* x, const double* u) {
+  const double qw = x[3], qx = x[4], qy = x[5], qz = x[6];
+  const double wx = x[10], wy = x[11], wz = x[12];
+  xd[0] = x[7]; xd[1] = x[8]; xd[2] = x[9];
+  xd[3] = 0.5 * (-qx * wx - qy * wy - qz * wz);
+  xd[4] = 0.5 * (qw * wx + qy * wz - qz * wy);
+  xd[5] = 0.5 * (qw * wy - qx * wz + qz * wx);
+  xd[6] = 0.5 * (qw * wz + qx * wy - qy * wx);
+  const double a = u[0] / QUAD_MASS;
+  xd[7] = a * (2.0 * (qx * qz + qw * qy));
+  xd[8] = a * (2.0 * (qy * qz - qw * qx));
+  xd[9] = a * (1.0 - 2.0 * (qx * qx + qy * qy)) - QUAD_G;
+  xd[10] = (u[1] - (QUAD_IZ - QUAD_IY) * wy * wz) / QUAD_IX;
+  xd[11] = (u[2] - (QUAD_IX - QUAD_IZ) * wz * wx) / QUAD_IY;
+  xd[12] = (u[3] - (QUAD_IY - QUAD_IX) * wx * wy) / QUAD_IZ;
+}
+/* jac (13 x 17) column-major = [df/dx df/du] */
+void oracle_quadrotor13_jacobian(double* jac, const double* x, const double* u) {
+  const int n = 13;
+  memset(jac, 0, sizeof(double) * 13 * 17);
+#define J(i, j) jac[(i) + (j) * n]
+  const double qw = x[3], qx = x[4], qy = x[5], qz = x[6];
+  const double wx = x[10], wy = x[11], wz = x[12];
+  J(0, 7) = 1.0; J(1, 8) = 1.0; J(2, 9) = 1.0;
+  /* quaternion kinematics */
+  J(3, 4) = -0.5 * wx; J(3, 5) = -0.5 * wy; J(3, 6) = -0.5 * wz; J(3, 10) = -0.5 * qx; J(3, 11) = -0.5 * qy; J(3, 12) = -0.5 * qz;
+  J(4, 3) = 0.5 * wx; J(4, 5) = 0.5 * wz; J(4, 6) = -0.5 * wy; J(4, 10) = 0.5 * qw; J(4, 11) = -0.5 * qz; J(4, 12) = 0.5 * qy;
+  J(5, 3) = 0.5 * wy; J(5, 4) = -0.5 * wz; J(5, 6) = 0.5 * wx; J(5, 10) = 0.5 * qz; J(5, 11) = 0.5 * qw; J(5, 12) = -0.5 * qx;
+  J(6, 3) = 0.5 * wz; J(6, 4) = 0.5 * wy; J(6, 5) = -0.5 * wx; J(6, 10) = -0.5 * qy; J(6, 11) = 0.5 * qx; J(6, 12) = 0.5 * qw;
+  /* translational acceleration */
+  const double a = u[0] / QUAD_MASS;
+  J(7, 3) = 2.0 * a * qy; J(7, 4) = 2.0 * a * qz; J(7, 5) = 2.0 * a * qw; J(7, 6) = 2.0 * a * qx;
+  J(7, 13) = 2.0 * (qx * qz + qw * qy) / QUAD_MASS;
+  J(8, 3) = -2.0 * a * qx; J(8, 4) = -2.0 * a * qw; J(8, 5) = 2.0 * a * qz; J(8, 6) = 2.0 * a * qy;
+  J(8, 13) = 2.0 * (qy * qz - qw * qx) / QUAD_MASS;
+  J(9, 4) = -4.0 * a * qx; J(9, 5) = -4.0 * a * qy;
+  J(9, 13) = (1.0 - 2.0 * (qx * qx + qy * qy)) / QUAD_MASS;
+  /* body rates */
+  J(10, 11) = -(QUAD_IZ - QUAD_IY) * wz / QUAD_IX; J(10, 12) = -(QUAD_IZ - QUAD_IY) * wy / QUAD_IX; J(10, 14) = 1.0 / QUAD_IX;
+  J(11, 10) = -(QUAD_IX - QUAD_IZ) * wz / QUAD_IY; J(11, 12) = -(QUAD_IX - QUAD_IZ) * wx / QUAD_IY; J(11, 15) = 1.0 / QUAD_IY;
+  J(12, 10) = -(QUAD_IY - QUAD_IX) * wy / QUAD_IZ; J(12, 11) = -(QUAD_IY - QUAD_IX) * wx / QUAD_IZ; J(12, 16) = 1.0 / QUAD_IZ;
+#undef J
+}
+
 /* ---- generic continuous-model dispatch + midpoint rule (test_utils.cpp:84-132) --- */
 typedef struct {
   int kind;            /* ORACLE_MODEL_* */
@@ -266,11 +318,13 @@ typedef struct {
 static void cont_dyn(const oracle_model* mdl, double* xdot, const double* x, const double* u) {
   if (mdl->kind == ORACLE_MODEL_PENDULUM) oracle_pendulum_dynamics(xdot, x, u);
   else if (mdl->kind == ORACLE_MODEL_QUADROTOR) oracle_quadrotor_dynamics(xdot, x, u);
+  else if (mdl->kind == ORACLE_MODEL_QUADROTOR13) oracle_quadrotor13_dynamics(xdot, x, u);
   else oracle_bicycle_dynamics(&mdl->bike, xdot, x, u);
 }
 static void cont_jac(const oracle_model* mdl, double* jac, const double* x, const double* u) {
   if (mdl->kind == ORACLE_MODEL_PENDULUM) oracle_pendulum_jacobian(jac, x, u);
   else if (mdl->kind == ORACLE_MODEL_QUADROTOR) oracle_quadrotor_jacobian(jac, x, u);
+  else if (mdl->kind == ORACLE_MODEL_QUADROTOR13) oracle_quadrotor13_jacobian(jac, x, u);
   else oracle_bicycle_jacobian(&mdl->bike, jac, x, u);
 }
 
@@ -279,6 +333,7 @@ void oracle_model_dims(const oracle_model* mdl, int* n, int* m) {
     case ORACLE_MODEL_DOUBLE_INTEGRATOR: *n = 2 * mdl->dim; *m = mdl->dim; break;
     case ORACLE_MODEL_PENDULUM: *n = 2; *m = 1; break;
     case ORACLE_MODEL_QUADROTOR: *n = 12; *m = 4; break;
+    case ORACLE_MODEL_QUADROTOR13: *n = 13; *m = 4; break;
     default: *n = 4; *m = 2; break;
   }
 }

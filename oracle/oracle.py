@@ -162,7 +162,7 @@ class Model(C.Structure):
     _fields_ = [("kind", C.c_int), ("dim", C.c_int), ("bike", Bicycle)]
 
 
-MODEL_DI, MODEL_PENDULUM, MODEL_BICYCLE, MODEL_QUADROTOR = 0, 1, 2, 3
+MODEL_DI, MODEL_PENDULUM, MODEL_BICYCLE, MODEL_QUADROTOR, MODEL_QUADROTOR13 = 0, 1, 2, 3, 4
 DYN_LINEAR, DYN_MODEL = 0, 1
 COST_QUADRATIC, COST_DIAGONAL = 0, 1
 CONE_EQUALITY, CONE_IDENTITY, CONE_INEQUALITY, CONE_SOC = 0, 1, 2, 3

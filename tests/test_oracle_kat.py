@@ -579,3 +579,52 @@ def test_quadrotor_test_model_jacobian_by_central_differences():
     out = np.zeros(12)
     L.oracle_discrete_dynamics(C.byref(mdl), out, hover_x, hover_u, h)
     assert np.abs(out - hover_x).max() < 1e-15
+
+
+def test_quaternion_quadrotor_test_model_jacobian_by_central_differences():
+    """The 13-state quaternion quadrotor (oracle/models_oracle.c, round 6): the state dimension one past the (12, 4) tile.  Like its
+    12-state sibling nothing of the reference pins it, so its analytic Jacobian is held to central differences of its own dynamics,
+    continuous and discretised (midpoint rule + chain rule, test_utils.cpp:84-132); hover with the identity attitude is a fixed
+    point, and the quaternion's norm changes only at second order in the step (qdot is orthogonal to q)."""
+    import ctypes as C
+    L = oracle.lib()
+    L.oracle_quadrotor13_dynamics.argtypes = [C.c_void_p] * 3
+    L.oracle_quadrotor13_jacobian.argtypes = [C.c_void_p] * 3
+    rng = np.random.default_rng(13)
+    mdl = oracle.make_model(oracle.MODEL_QUADROTOR13)
+    h = np.float32(0.02)
+    n, w = 13, 17
+    for trial in range(5):
+        x = rng.normal(size=n) * 0.4
+        x[3:7] = np.array([1.0, 0.0, 0.0, 0.0]) + 0.3 * rng.normal(size=4)
+        x[3:7] /= np.linalg.norm(x[3:7])
+        u = np.array([0.5 * 9.81, 0.0, 0.0, 0.0]) + rng.normal(size=4) * np.array([1.0, 0.01, 0.01, 0.01])
+
+        def f(z):
+            out = np.zeros(n)
+            xx, uu = np.ascontiguousarray(z[:n]), np.ascontiguousarray(z[n:])
+            L.oracle_quadrotor13_dynamics(out.ctypes.data, xx.ctypes.data, uu.ctypes.data)
+            return out
+
+        def F(z):
+            out = np.zeros(n)
+            L.oracle_discrete_dynamics(C.byref(mdl), out, np.ascontiguousarray(z[:n]), np.ascontiguousarray(z[n:]), h)
+            return out
+        z = np.concatenate([x, u])
+        J = np.zeros(n * w)
+        L.oracle_quadrotor13_jacobian(J.ctypes.data, x.ctypes.data, u.ctypes.data)
+        Jd = np.zeros(n * w)
+        L.oracle_discrete_jacobian(C.byref(mdl), Jd, x, u, h)
+        for (fun, Jan) in ((f, J.reshape(w, n).T), (F, Jd.reshape(w, n).T)):
+            num = np.zeros((n, w))
+            for c in range(w):
+                e = np.zeros(w); e[c] = 1e-6 * max(1.0, abs(z[c]))
+                num[:, c] = (fun(z + e) - fun(z - e)) / (2 * e[c])
+            assert np.abs(num - Jan).max() <= 2e-7 * max(1.0, np.abs(Jan).max()), (trial, np.abs(num - Jan).max())
+        assert abs(np.dot(f(z)[3:7], x[3:7])) < 1e-15                       # qdot is orthogonal to q
+        assert abs(np.linalg.norm(F(z)[3:7]) - 1.0) < 5e-3
+    hover_x = np.zeros(n); hover_x[:3] = [1.0, -2.0, 3.0]; hover_x[3] = 1.0
+    hover_u = np.array([0.5 * 9.81, 0, 0, 0.0])
+    out = np.zeros(n)
+    L.oracle_discrete_dynamics(C.byref(mdl), out, hover_x, hover_u, h)
+    assert np.abs(out - hover_x).max() < 1e-15
