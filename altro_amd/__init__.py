@@ -54,6 +54,7 @@ FORM_NO_SPECULATION, FORM_NO_RUNAHEAD, FORM_NO_MERIT2, FORM_MERIT_LDS, FORM_MERI
 FORM_EXPAND_LDS, FORM_ALROWS_LDS, FORM_ROLLOUT_ROUNDS, FORM_SEQUENCED, FORM_MERIT_ONE_LAUNCH = 0x20, 0x40, 0x80, 0x100, 0x200
 FORM_LANE_QUAD_OFF, FORM_LANE_QUAD_ON, FORM_GENERIC_LATE_Q_OFF, FORM_GENERIC_LATE_Q_ON, FORM_FUSED_CLOCK = 0x400, 0x800, 0x1000, 0x2000, 0x4000
 FORM_AFFINE_EXACT = 0x8000
+FORM_NO_COMPACTION = 0x10000
 
 
 def forms_from_env():
@@ -75,6 +76,7 @@ def forms_from_env():
     if "ALTRO_HIP_GENERIC_LATE_Q" in e: f |= FORM_GENERIC_LATE_Q_OFF if _atoi(e["ALTRO_HIP_GENERIC_LATE_Q"]) == 0 else FORM_GENERIC_LATE_Q_ON
     if "ALTRO_HIP_FUSED_CLOCK" in e: f |= FORM_FUSED_CLOCK
     if "ALTRO_HIP_AFFINE_EXACT" in e: f |= FORM_AFFINE_EXACT
+    if "ALTRO_HIP_NO_COMPACTION" in e: f |= FORM_NO_COMPACTION
     return f
 
 
@@ -537,7 +539,7 @@ class Batch:
         self.L.altro_hip_default_solve_options(C.byref(o))
         o.forms = int(forms)
         if fused_sweeps is None and "ALTRO_HIP_FUSED_SWEEPS" in os.environ:
-            fused_sweeps = max(1, _atoi(os.environ["ALTRO_HIP_FUSED_SWEEPS"]))
+            fused_sweeps = _atoi(os.environ["ALTRO_HIP_FUSED_SWEEPS"]) or 1
         o.fused_sweeps = int(fused_sweeps or 0)
         if decision_margin is not None:
             o.decision_margin = float(decision_margin)

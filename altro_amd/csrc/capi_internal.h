@@ -103,6 +103,8 @@ struct altro_hip_batch {
   int spare_count = 0;            // spare candidate trajectories i_cand_spec holds (sized to the path in use, see spec_trials_cap)
   int spare_failed = 0;           // > 0: an allocation of this many spares failed on this handle (no retry at this size or above)
   int *i_spec_sel = nullptr, *i_spec_refresh = nullptr;
+  int* i_fused_list = nullptr;   // straggler compaction of the one-launch solve (capi_solve.hip): [3][batch] = run flags, two lists
+  int fused_resident = 0;        // workgroups of the one-launch kernel the device holds at once (0: not asked yet)
   int *i_guard = nullptr, *i_active_exact = nullptr;   // the decision guard of the affine rounds (IlqrLoopArgs::guard, ::active_exact)
   int* i_stat_done = nullptr;     // plan MFMA16's dual merit evaluation (IlqrLoopArgs::stat_done)
   const int* stat_skip = nullptr; // set while a solve's IK_STATIONARITY launches may skip those problems

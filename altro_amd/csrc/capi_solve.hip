@@ -23,6 +23,8 @@ using namespace altro_hip::capi;
 
 namespace {
 
+constexpr int kFusedFirstChunk = 5;   // sweeps of the one-launch solve before its still-running problems are listed (run_fused)
+
 struct SolveRun {
   altro_hip_batch* h;
   altro_hip_solve_options o;
@@ -273,11 +275,43 @@ static void print_fused_clock(const std::vector<unsigned long long>& hc, int clk
   std::fprintf(stderr, "  %-22s %10s | %10.1f\n", "total", "", (double)slow_t * 0.01);
 }
 
+// Straggler compaction.  The kernel is one launch of (batch / G) workgroups, each of which stays on its CU until
+// ITS problems have stopped.  While the batch fits the chip (one workgroup per CU: up to 8192 problems) that is all a straggler costs --
+// its own four waves.  A larger batch queues behind them: workgroups are dealt to CUs as these come free, a CU that drew a workgroup
+// with a non-converging problem serves nobody else for iterations_max sweeps, and a straggler in a late workgroup starts its
+// iterations_max sweeps late.  So a solve of more than four workgroups per CU runs its first kFusedFirstChunk sweeps as one launch,
+// which hands back which slots still run (IlqrFusedArgs::run_flags); ilqr_list_running_kernel lists them in order, dealt round-robin
+// to as many workgroups as the chip holds (ilqr_list_layout: a workgroup waits for the slowest line search among its problems, so the
+// list is spread thin, not packed), and the rest of the sweeps are ONE launch over that list (IlqrFusedArgs::list: slot s serves
+// problem list[s]).  Per problem it is the same code on the same data whichever slot it rides in: status, iterations and iterates
+// are the single launch's bit for bit (tests/test_gpu_fused.py, tools/fuzz_fused.py).
+// MEASURED (tools/compaction_times.py, C3 bicycles, 80 sweeps): 65536 problems 72 -> 60..66 ms; 32768 problems 42 -> 46 (hence the
+// four-workgroups-per-CU rule).  What the tail of such a solve costs is NOT idle lanes or queueing but each straggler's own chain:
+// 0.25 ms per sweep for the slowest of 17 stragglers (8192 problems), 0.52 for the slowest of 276 (65536) -- and every further
+// re-listing is a barrier at which all wait for the slowest (chunks of 8 sweeps: +5 ms at 8192 problems, chunks of 2: +10 ms).
+// altro_hip_solve_options::fused_sweeps = -n (a test hook like its positive form): re-list after every n sweeps whatever the batch.
+// ALTRO_HIP_FORM_NO_COMPACTION: the single launch.
 int SolveRun::run_fused() {
-  int fused_sweeps = o.iterations_max;
-  if (o.fused_sweeps > 0) fused_sweeps = std::max(1, std::min(o.iterations_max, o.fused_sweeps));
-  HIP_TRY(hipMemsetAsync(h->i_counters, 0, 4 * sizeof(int), h->stream));
-  IlqrFusedArgs fa{0, fused_sweeps, o.reg_retry_max, reg_on ? 1 : 0, h->i_counters, nullptr, fused_prologue ? 1 : 0};
+  int budget = o.iterations_max;
+  if (o.fused_sweeps > 0) budget = std::max(1, std::min(o.iterations_max, o.fused_sweeps));
+  const bool clock_on = form(h, ALTRO_HIP_FORM_FUSED_CLOCK) && !async;   // (an async solve returns before the clock could be read or freed)
+  if (!h->fused_resident) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || cus <= 0) { (void)hipGetLastError(); cus = 256; }
+    h->fused_resident = cus;   // (four waves of up to 512 registers each: one workgroup per CU)
+  }
+  const bool hook = o.fused_sweeps < 0;
+  auto groups_of = [](int count) { const int G = ilqr_fused_group(count); return (count + G - 1) / G; };
+  bool compact = !async && !clock_on && !form(h, ALTRO_HIP_FORM_NO_COMPACTION) && (hook || groups_of(h->batch) > 4 * h->fused_resident);
+  // (slots of a listed launch: the problems rounded up to whole workgroups, or `resident` thin workgroups of up to 32)
+  const size_t list_cap = (size_t)h->batch + 32 * (size_t)h->fused_resident + 32;
+  if (compact && !h->i_fused_list && dmalloc(h, (void**)&h->i_fused_list, 3 * list_cap * sizeof(int))) {
+    (void)hipGetLastError();
+    compact = false;   // an optimisation only
+  }
+  int* const flags = h->i_fused_list;
+  int* const lists[2] = {h->i_fused_list ? h->i_fused_list + list_cap : nullptr, h->i_fused_list ? h->i_fused_list + 2 * list_cap : nullptr};
+  IlqrFusedArgs fa{0, budget, o.reg_retry_max, reg_on ? 1 : 0, h->i_counters, nullptr, fused_prologue ? 1 : 0};
   if (async) {
     void *dp = nullptr, *dc = nullptr;
     HIP_TRY(hipHostGetDevicePointer(&dp, h->poll_host, 0));
@@ -286,43 +320,66 @@ int SolveRun::run_fused() {
   }
   const int clk_G = ilqr_fused_group(h->batch);
   const int clk_groups = (h->batch + clk_G - 1) / clk_G;
-  unsigned long long* clk = nullptr;     // ALTRO_HIP_FUSED_CLOCK: per-phase time of the kernel, printed to stderr (a tuning aid)
-  if (form(h, ALTRO_HIP_FORM_FUSED_CLOCK) && !async) {   // (an async solve returns before the clock could be read or freed)
+  unsigned long long* clk = nullptr;     // ALTRO_HIP_FORM_FUSED_CLOCK: per-phase time of the kernel, printed to stderr (a tuning aid)
+  if (clock_on) {
     const size_t bytes = (size_t)clk_groups * ILQR_FUSED_PHASES * sizeof(unsigned long long);
     if (hipMalloc((void**)&clk, bytes) == hipSuccess) { (void)hipMemsetAsync(clk, 0, bytes, h->stream); fa.clk = clk; }
   }
-  int frc;
-  if (h->dtype == ALTRO_HIP_F64) {
-    LaneArgs<double> ba{(const double*)h->l_in, (const double*)h->l_term, (double*)h->l_out, (double*)h->l_outn,
-                        (const double*)h->l_x0, (double*)h->l_xuy, (double*)h->delta_V, h->status, h->N, h->batch, 0.0,
-                        nullptr, nullptr};
-    frc = ilqr_launch_fused<double>(h->stream, h->model.kind, h->n, h->m, ilqr_args<double>(h, false, false, 1, 0.0), la, ba, fa);
-  } else {
-    LaneArgs<float> ba{(const float*)h->l_in, (const float*)h->l_term, (float*)h->l_out, (float*)h->l_outn,
-                       (const float*)h->l_x0, (float*)h->l_xuy, (float*)h->delta_V, h->status, h->N, h->batch, 0.0f,
-                       nullptr, nullptr};
-    frc = ilqr_launch_fused<float>(h->stream, h->model.kind, h->n, h->m, ilqr_args<float>(h, false, false, 1, 0.0), la, ba, fa);
+  int done = 0, slots = h->batch, groups = groups_of(h->batch), pp = 0;
+  sweeps = 0;
+  for (;;) {
+    int chunk = budget - done;
+    if (compact) {
+      if (hook) chunk = std::min(chunk, -o.fused_sweeps);
+      else if (done == 0) chunk = std::min(chunk, kFusedFirstChunk);   // (then ONE listed launch for the rest)
+    }
+    const bool last = done + chunk >= budget;
+    HIP_TRY(hipMemsetAsync(h->i_counters, 0, 4 * sizeof(int), h->stream));
+    fa.first_iter = done; fa.max_sweeps = chunk;
+    fa.prologue = (done == 0 && fused_prologue) ? 1 : 0;
+    fa.run_flags = (compact && !last) ? flags : nullptr;
+    int frc;
+    if (h->dtype == ALTRO_HIP_F64) {
+      LaneArgs<double> ba{(const double*)h->l_in, (const double*)h->l_term, (double*)h->l_out, (double*)h->l_outn,
+                          (const double*)h->l_x0, (double*)h->l_xuy, (double*)h->delta_V, h->status, h->N, h->batch, 0.0,
+                          nullptr, nullptr};
+      frc = ilqr_launch_fused<double>(h->stream, h->model.kind, h->n, h->m, ilqr_args<double>(h, false, false, 1, 0.0), la, ba, fa);
+    } else {
+      LaneArgs<float> ba{(const float*)h->l_in, (const float*)h->l_term, (float*)h->l_out, (float*)h->l_outn,
+                         (const float*)h->l_x0, (float*)h->l_xuy, (float*)h->delta_V, h->status, h->N, h->batch, 0.0f,
+                         nullptr, nullptr};
+      frc = ilqr_launch_fused<float>(h->stream, h->model.kind, h->n, h->m, ilqr_args<float>(h, false, false, 1, 0.0), la, ba, fa);
+    }
+    if (frc) { if (clk) (void)hipFree(clk); return fail(ALTRO_HIP_ERR_HIP, "fused iLQR kernel launch failed"); }
+    h->backward_done = true;
+    if (async) {   // the caller polls; altro_hip_ilqr_wait finishes the bookkeeping
+      h->async_pending = true;
+      h->forward_done = true;
+      h->solve_done = true;
+      return 0;
+    }
+    if (fa.run_flags && ilqr_launch_list_running(h->stream, flags, fa.list, slots, lists[pp], h->fused_resident)) {
+      if (clk) (void)hipFree(clk);
+      return fail(ALTRO_HIP_ERR_HIP, "list kernel launch failed");
+    }
+    int c4[4];
+    HIP_TRY(hipMemcpyAsync(c4, h->i_counters, sizeof(c4), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    sweeps += c4[3];
+    running = c4[1];
+    done += chunk;
+    if (running == 0 || last) break;
+    ilqr_list_layout(running, h->fused_resident, &fa.group, &groups);   // (what ilqr_list_running_kernel laid the list out for)
+    fa.list = lists[pp]; fa.list_count = slots = fa.group * groups;
+    pp ^= 1;
   }
-  if (frc) return fail(ALTRO_HIP_ERR_HIP, "fused iLQR kernel launch failed");
-  h->backward_done = true;
-  if (async) {   // the caller polls; altro_hip_ilqr_wait finishes the bookkeeping
-    h->async_pending = true;
-    h->forward_done = true;
-    h->solve_done = true;
-    return 0;
-  }
-  int c4[4];
-  HIP_TRY(hipMemcpyAsync(c4, h->i_counters, sizeof(c4), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  sweeps = c4[3];
-  running = c4[1];
   if (clk) {
     std::vector<unsigned long long> hc((size_t)clk_groups * ILQR_FUSED_PHASES);
     (void)hipMemcpy(hc.data(), clk, hc.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
     (void)hipFree(clk);
     print_fused_clock(hc, clk_groups, sweeps);
   }
-  iter0 = running > 0 ? fused_sweeps : o.iterations_max;
+  iter0 = running > 0 ? budget : o.iterations_max;
   return 0;
 }
 

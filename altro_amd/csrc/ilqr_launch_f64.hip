@@ -72,6 +72,11 @@ int ilqr_launch_results(hipStream_t stream, const IlqrProb* prob, IlqrResult* ou
   return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 
+int ilqr_launch_list_running(hipStream_t stream, const int* flags, const int* list_in, int count_in, int* list_out, int resident) {
+  hipLaunchKernelGGL(ilqr_list_running_kernel, dim3(1), dim3(1024), 0, stream, flags, list_in, count_in, list_out, resident);
+  return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
 int ilqr_launch_loop(hipStream_t stream, int which, const IlqrLoopArgs& a) {
   const dim3 gb((a.batch + 255) / 256), bb(256);
   switch (which) {

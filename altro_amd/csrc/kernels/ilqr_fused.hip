@@ -52,18 +52,29 @@ __global__ __launch_bounds__((64 * ilqr_fused_waves<n, T>())) void ilqr_fused_sw
   constexpr int KS = 64 / G;                  // knot points a wave takes at once in the (problem, knot point)-parallel steps
   constexpr bool QUAD = (n == 4 && m == 2) || (n == 2 && m == 1);   // four lanes per problem: tvlqr_quad_body.inc, tvlqr_quad2_body.inc
   // workgroup -> problems: contiguous runs per XCD like the sweep kernels' waves (tvlqr_lane_body.inc)
-  const int nwg = (a.batch + G - 1) / G, chk = (nwg + 7) / 8;
+  // A LISTED launch (fa.list: the problems still running after an earlier launch, capi_solve.hip) serves slot s = problem list[s]
+  // (-1: an empty slot; a workgroup's first slot is never empty).  Every address below is `base + lane offset`, and a listed
+  // launch takes base = 0, lane offset = the problem's own index -- the same functions on the same per-problem data, so nothing
+  // a problem computes depends on which slot it rides in.
+  const bool listed = fa.list != nullptr;
+  const int slots = listed ? fa.list_count : a.batch;
+  const int nwg = (slots + G - 1) / G, chk = (nwg + 7) / 8;
   const int wg = (int)((blockIdx.x & 7) * chk + (blockIdx.x >> 3));
   if (wg >= nwg) return;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), t = threadIdx.x & 63;   // (w: provably wave-uniform)
   const int pt = t % G, ks = t / G;           // lane = (problem slot, knot-point slot)
-  const int64_t b0 = (int64_t)wg * G;
-  const int64_t b = b0 + pt;
+  const int64_t s0 = (int64_t)wg * G;         // the workgroup's first slot
+  const bool in_range = s0 + pt < slots;
+  const int listed_b = listed ? fa.list[in_range ? s0 + pt : s0] : 0;
+  const bool valid = in_range && listed_b >= 0;
+  const int64_t b0 = listed ? 0 : s0;         // base problem of the workgroup's addresses
+  // (lanes past the batch / on an empty slot never dereference their problem: they carry the workgroup's first one)
+  const int64_t b = listed ? (int64_t)(valid ? listed_b : fa.list[s0]) : (valid ? s0 + pt : s0);
+  const int pl = (int)(b - b0);               // this lane's problem relative to the base
   const int64_t B = a.batch;
-  const bool valid = b < B;
-  const int bi = (int)(valid ? b : b0);           // (lanes past the batch never dereference it)
+  const int bi = (int)b;
   const int N = a.N;
-  const uint32_t lane = (uint32_t)pt * (uint32_t)sizeof(T);
+  const uint32_t lane = (uint32_t)pl * (uint32_t)sizeof(T);
   const uint32_t rowB = (uint32_t)B * (uint32_t)sizeof(T);
   const bool al = a.al.enabled != 0;
   const bool serial = ks == 0 && valid;           // the lanes of a wave that run a lane-per-problem chain
@@ -85,7 +96,9 @@ __global__ __launch_bounds__((64 * ilqr_fused_waves<n, T>())) void ilqr_fused_sw
   // stragglers per workgroup for most of the sweeps -- gets the whole wave per problem there (memory accesses are then one
   // cache line per lane: irrelevant for a handful of problems).  The serial chains keep the fixed lane <-> problem mapping.
   __shared__ int s_list[G];
+  __shared__ int s_prob[G];                       // slot -> problem
   __shared__ int s_na;
+  if (w == 0 && ks == 0) s_prob[pt] = valid ? bi : -1;
   int KSd = KS, ksd = ks, bik = bi;
   int64_t bk = b;
   bool validk = valid;
@@ -101,16 +114,20 @@ __global__ __launch_bounds__((64 * ilqr_fused_waves<n, T>())) void ilqr_fused_sw
     if constexpr (QUAD) {
       if (w < (G + 15) / 16) {
         const int q = 16 * w + (t >> 2);
-        const int64_t bq = b0 + q;
-        if (q < G && bq < B && (retry ? s_again[q] != 0 : la.active[bq] != 0)) {
-          const T rg = (retry || fa.use_reg) ? (T)la.reg[bq] : T(0);
-          if constexpr (n == 4) (void)quad_backward_wave<m, T>(ba, b0 + 16 * w, t, rg);
-          else (void)quad2_backward_wave<T>(ba, b0 + 16 * w, t, rg);
+        const int64_t bq = q < G ? s_prob[q] : -1;
+        if (bq >= 0) {
+          if (retry ? s_again[q] != 0 : la.active[bq] != 0) {
+            const T rg = (retry || fa.use_reg) ? (T)la.reg[bq] : T(0);
+            // (unlisted: the wave's base is its first problem, lane offsets 0 .. 15 as in quad_backward_kernel)
+            const int64_t bw = listed ? 0 : s0 + 16 * w;
+            if constexpr (n == 4) (void)quad_backward_quad<m, T>(ba, bw, (int)(bq - bw), t & 3, rg);
+            else (void)quad2_backward_quad<T>(ba, bw, (int)(bq - bw), t & 3, rg);
+          }
         }
       }
     } else {
       if (lead && (retry ? s_again[pt] != 0 : la.active[bi] != 0))
-        (void)lane_backward_lane<n, m, T>(ba, b0, pt, (retry || fa.use_reg) ? (T)la.reg[bi] : T(0));
+        (void)lane_backward_lane<n, m, T>(ba, b0, pl, (retry || fa.use_reg) ? (T)la.reg[bi] : T(0));
     }
   };
   // One merit launch of the sequenced loop (ilqr_launch_kernel, IK_MERIT) inside the workgroup: the rollouts of the
@@ -205,7 +222,7 @@ __global__ __launch_bounds__((64 * ilqr_fused_waves<n, T>())) void ilqr_fused_sw
       const int slot = t & (Gd - 1);
       ksd = t >> __builtin_ctz(Gd);
       validk = slot < na;
-      bik = validk ? (int)b0 + s_list[slot] : (int)b0;
+      bik = s_prob[validk ? s_list[slot] : 0];
       bk = bik;
     }
     // CalcExpansions: the cost Hessians change only through the constraints' terms (solver.cpp:448)
@@ -329,7 +346,9 @@ __global__ __launch_bounds__((64 * ilqr_fused_waves<n, T>())) void ilqr_fused_sw
   }
 #undef FUSED_FOR_K
   // hand-back: how many problems the launch leaves running, how many sweeps its slowest workgroup took
-  const int still = __syncthreads_count(lead && la.prob[bi].running != 0);
+  const bool runs_on = lead && la.prob[bi].running != 0;
+  if (fa.run_flags && w == 0 && ks == 0 && in_range) fa.run_flags[s0 + pt] = runs_on ? 1 : 0;
+  const int still = __syncthreads_count(runs_on);
   if (threadIdx.x == 0) {
     if (still) atomicAdd(&fa.counters[1], still);
     atomicMax(&fa.counters[3], sweeps);

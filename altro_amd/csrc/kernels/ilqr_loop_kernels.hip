@@ -16,6 +16,40 @@ __global__ void ilqr_results_kernel(const IlqrProb* __restrict__ prob, IlqrResul
   out[b] = ilqr_result_of(prob[b]);
 }
 
+// Straggler compaction of the one-launch solve (capi_solve.hip, run_fused): the still-running problems of a launch, listed in
+// order and dealt round-robin to the workgroups of the next one (ilqr_list_layout).  One workgroup: every thread counts the set
+// flags of its contiguous run of slots, an LDS scan places the runs.
+__global__ __launch_bounds__(1024) void ilqr_list_running_kernel(const int* __restrict__ flags, const int* __restrict__ list_in,
+                                                                 int count_in, int* __restrict__ list_out, int resident) {
+  __shared__ int s_sum[1024];
+  const int tid = (int)threadIdx.x;
+  const int per = (count_in + 1023) / 1024;
+  const int lo = tid * per < count_in ? tid * per : count_in;
+  const int hi = lo + per < count_in ? lo + per : count_in;
+  int c = 0;
+  for (int i = lo; i < hi; ++i) c += flags[i] != 0 ? 1 : 0;
+  s_sum[tid] = c;
+  __syncthreads();
+  for (int step = 1; step < 1024; step <<= 1) {   // inclusive scan
+    const int v = tid >= step ? s_sum[tid - step] : 0;
+    __syncthreads();
+    s_sum[tid] += v;
+    __syncthreads();
+  }
+  const int total = s_sum[1023];
+  if (total == 0) return;
+  int group, groups;
+  ilqr_list_layout(total, resident, &group, &groups);
+  for (int i = tid; i < group * groups; i += 1024) list_out[i] = -1;
+  __syncthreads();
+  int pos = s_sum[tid] - c;
+  for (int i = lo; i < hi; ++i)
+    if (flags[i] != 0) {
+      list_out[(pos % groups) * group + pos / groups] = list_in ? list_in[i] : i;
+      ++pos;
+    }
+}
+
 // The counters of a counting kernel, handed to the host without a copy on the stream: the block that finishes last (a ticket in
 // counters[7]) stores counters[0..6] into the launch's slot of host-mapped memory; the host reads it after the event it recorded
 // behind the launch.  Called by every thread of the kernel (no early exits before it).

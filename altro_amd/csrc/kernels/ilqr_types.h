@@ -225,6 +225,12 @@ struct IlqrFusedArgs {
                       //    accept, first expansion, SetPenalty -- what the host enqueues as five launches otherwise
   IlqrPollRec* poll = nullptr;   // optional [batch], pinned host memory: results published while the launch still runs
   int* poll_count = nullptr;     // optional, pinned: number of records published so far
+  // straggler compaction (capi_solve.hip, run_fused): the launch serves the `list_count` problems list[0 .. list_count) -- slot s of
+  // the grid is problem list[s] -- instead of the whole batch; run_flags[s] = 1 at hand-back when slot s is still running
+  const int* list = nullptr;     // [list_count] problem per slot, -1 = empty (never a workgroup's first slot)
+  int list_count = 0;            // slots = workgroups x `group`
+  int group = 0;                 // problems per workgroup of a listed launch (8 / 16 / 32)
+  int* run_flags = nullptr;
 };
 template <typename T, int G>   // G problems per workgroup: one translation unit each (ilqr_fused_unit.inc)
 int ilqr_launch_fused_g(hipStream_t stream, int kind, int n, int m, const IlqrArgs<T>& a, const IlqrLoopArgs& la,
@@ -235,7 +241,7 @@ inline int ilqr_fused_group(int batch) { return batch <= 8 * 256 ? 8 : batch <= 
 template <typename T>
 inline int ilqr_launch_fused(hipStream_t stream, int kind, int n, int m, const IlqrArgs<T>& a, const IlqrLoopArgs& la,
                              const LaneArgs<T>& ba, const IlqrFusedArgs& fa) {
-  const int G = ilqr_fused_group(a.batch);
+  const int G = fa.list ? fa.group : ilqr_fused_group(a.batch);
   return G == 8    ? ilqr_launch_fused_g<T, 8>(stream, kind, n, m, a, la, ba, fa)
          : G == 16 ? ilqr_launch_fused_g<T, 16>(stream, kind, n, m, a, la, ba, fa)
                    : ilqr_launch_fused_g<T, 32>(stream, kind, n, m, a, la, ba, fa);
@@ -246,5 +252,17 @@ template <typename T>
 int ilqr_launch_kernel(hipStream_t stream, int which, int kind, int n, int m, const IlqrArgs<T>& a);
 int ilqr_launch_loop(hipStream_t stream, int which, const IlqrLoopArgs& a);
 int ilqr_launch_results(hipStream_t stream, const IlqrProb* prob, IlqrResult* out, int batch);
+// Straggler compaction of the one-launch solve: `count` problems on a device that holds `resident` workgroups at once -- problems
+// per workgroup and the number of workgroups, spread as thin as the device allows (a workgroup waits for the slowest line search
+// among its problems, and its knot-point-parallel steps share four waves)
+__host__ __device__ inline void ilqr_list_layout(int count, int resident, int* group, int* groups) {
+  const int G = count <= 8 * resident ? 8 : count <= 16 * resident ? 16 : 32;
+  *group = G;
+  *groups = count <= G * resident ? (count < resident ? count : resident) : (count + G - 1) / G;
+}
+// The problems of list_in[0 .. count_in) (list_in == nullptr: of 0 .. count_in) whose run flag is set, in order, dealt round-robin
+// to the workgroups of ilqr_list_layout(their number, resident): the i-th goes to list_out[(i % groups) * group + i / groups],
+// the other slots are -1.
+int ilqr_launch_list_running(hipStream_t stream, const int* flags, const int* list_in, int count_in, int* list_out, int resident);
 
 }  // namespace altro_hip

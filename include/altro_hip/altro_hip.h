@@ -356,7 +356,9 @@ typedef struct altro_hip_solve_options { /* AltroOptions, solver_options.hpp:16-
    * in the last bits -- belongs to the call, not to the process.                                                                   */
   unsigned forms;
   /* plan LANE: hand the problems still running after this many sweeps of the one-launch solve kernel over to the launch-sequenced
-   * loop (the hand-over is exact at any sweep: a test hook).  0: the one-launch kernel runs every sweep.                         */
+   * loop (the hand-over is exact at any sweep: a test hook).  0: the one-launch kernel runs every sweep.  -n: the one-launch solve
+   * re-lists its still-running problems after every n sweeps whatever the batch size (the straggler compaction of batches beyond
+   * one workgroup per compute unit, forced: a test hook too -- results are those of the single launch bit for bit).             */
   int fused_sweeps;
   /* The decision guard of the affine line-search rounds (plan MFMA16, dynamics as data), opt-in: with a margin > 0 a trial
    * whose phi, phi' would turn the search another way if they were off by that RELATIVE margin -- any comparison of
@@ -388,6 +390,8 @@ typedef struct altro_hip_solve_options { /* AltroOptions, solver_options.hpp:16-
 #define ALTRO_HIP_FORM_AFFINE_EXACT 0x8000u      /* plan MFMA16: affine rounds used for robust decisions only -- kept values and accepted steps are
                                                     evaluated as rollouts: the rollout form's results bit for bit, slower than ROLLOUT_ROUNDS (a checking form) */
 #define ALTRO_HIP_FORM_FUSED_CLOCK 0x4000u       /* plan LANE: per-phase clock of the one-launch kernel on stderr (a tuning aid)            */
+#define ALTRO_HIP_FORM_NO_COMPACTION 0x10000u    /* plan LANE: the one-launch solve of a batch beyond one workgroup per compute unit stays ONE
+                                                    launch (default: chunks of sweeps over the list of still-running problems)              */
 /* forms of a HANDLE: what altro_hip_merit / _expand / _sweep and every solve on it run with (a solve ORs its options' bits in) */
 int altro_hip_set_forms(altro_hip_batch* h, unsigned forms);
 unsigned altro_hip_get_forms(const altro_hip_batch* h);

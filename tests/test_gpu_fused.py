@@ -198,3 +198,50 @@ def test_fused_six_state_double_integrator():
         _same(seq, fused)
         _same(seq, hand)
         assert int(fused[0]["merit_launches"]) == 0
+
+
+# ---- straggler compaction (capi_solve.hip, run_fused): chunks of sweeps over the list of still-running problems --------------------
+@pytest.mark.parametrize("name,make,opts,chunk", [
+    # all three workgroup sizes of a LISTED launch: the list after the first chunk holds > 4096, > 2048, <= 2048 problems
+    ("bicycle + steering bound, backtracking, 6000 problems, chunks of 1", _bicycle(6000, spread=1.2), dict(iterations_max=30, use_backtracking=True), 1),
+    ("bicycle + steering bound, cubic, 3000 problems, chunks of 2", _bicycle(3000, spread=1.0), dict(iterations_max=30), 2),
+    ("bicycle, chunks of 3, ragged batch", _bicycle(777), dict(iterations_max=40, use_backtracking=True), 3),
+    ("pendulum (four lanes per problem, eight waves), chunks of 2", _pendulum(2500), dict(iterations_max=30), 2),
+    ("double integrator, second-order cone, chunks of 1", _di_cones("soc", 70), dict(iterations_max=30, penalty_scaling=100.0), 1),
+])
+def test_listed_launches_are_the_single_launch_bit_for_bit(name, make, opts, chunk):
+    one = _solve(make, {"ALTRO_HIP_FUSED": "1"}, forms=altro_amd.FORM_NO_COMPACTION, **opts)
+    chunks = _solve(make, {"ALTRO_HIP_FUSED": "1", "ALTRO_HIP_FUSED_SWEEPS": str(-chunk)}, **opts)
+    _same(one, chunks)
+    assert int(chunks[0]["merit_launches"]) == 0     # (no hand-over to the sequenced loop happened)
+    one[5].close(); chunks[5].close()
+
+
+def test_listed_launches_with_the_regularisation_retry():
+    N, n, m, batch = 10, 4, 2, 300
+
+    def make():
+        bt = altro_amd.Batch(N, n, m, batch)
+        bt.set_model(altro_amd.MODEL_DOUBLE_INTEGRATOR, np.float32(0.5))
+        R = np.where(np.arange(batch)[:, None, None] % 3 == 0, -0.5, 1e-2) * np.ones((batch, 1, m))   # every third problem needs the retry
+        bt.set_tracking_cost(np.ones((batch, 2, n)), R, np.zeros((batch, 2, n)), np.zeros((batch, 1, m)), k_stride_zero=True)
+        bt.set_initial_state(np.tile([1.0, 2.0, 0.0, 0.0], (batch, 1)) + 0.01 * np.arange(batch)[:, None])
+        bt.set_input_guess(np.zeros((1, 1, m)), k_stride_zero=True, batch_stride_zero=True)
+        return bt
+    opts = dict(iterations_max=6, reg_retry_max=5, reg_min=0.01, reg_scale=10.0)
+    one = _solve(make, {"ALTRO_HIP_FUSED": "1"}, forms=altro_amd.FORM_NO_COMPACTION, **opts)
+    chunks = _solve(make, {"ALTRO_HIP_FUSED": "1", "ALTRO_HIP_FUSED_SWEEPS": "-1"}, **opts)
+    _same(one, chunks)
+    assert (chunks[0]["reg_retries"] >= 1).any()
+    one[5].close(); chunks[5].close()
+
+
+def test_a_batch_beyond_four_workgroups_per_compute_unit_compacts_by_itself():
+    """40000 bicycles: 1250 workgroups of 32 -- the default solve runs its first sweeps, then the rest over the list of problems still
+    running; the results are the single launch's."""
+    make = _bicycle(40000, N=20, spread=1.0)
+    opts = dict(iterations_max=40, use_backtracking=True)
+    one = _solve(make, {}, forms=altro_amd.FORM_NO_COMPACTION, **opts)
+    auto = _solve(make, {}, **opts)
+    _same(one, auto)
+    one[5].close(); auto[5].close()

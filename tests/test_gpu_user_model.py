@@ -158,9 +158,9 @@ def test_a_source_that_does_not_compile_says_why():
     with pytest.raises(altro_amd.AltroHipError) as e:
         bt.set_model_source("template <typename T> __device__ void altro_user_dynamics(const T* x, const T* u, T* xdot) { xdot[0] = y; }", 0.1)
     assert "error" in str(e.value) and "user_model" in str(e.value)
-    big = altro_amd.Batch(10, 20, 4, 4)
+    big = altro_amd.Batch(10, 20, 4, 4, dtype=altro_amd.F32)
     with pytest.raises(altro_amd.AltroHipError):
-        big.set_model_source(PENDULUM_SRC, 0.1)       # plan GENERIC: dynamics as data only
+        big.set_model_source(PENDULUM_SRC, 0.1)       # plans GENERIC / MFMA32 take models on fp64 handles (tests/test_gpu_generic_model.py)
     f32 = altro_amd.Batch(10, 12, 4, 4, dtype=altro_amd.F32)
     with pytest.raises(altro_amd.AltroHipError):
         f32.set_model_source(PENDULUM_SRC, 0.1)       # plan MFMA16 takes models on fp64 records (tests/test_gpu_tile_model.py)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Soak: the fused solve kernel against the launch-sequenced loop, bit for bit, over random shapes -- model, horizon,
 batch (all three workgroup sizes, ragged tails), line search, element type, constraints on / off, regularisation retry,
-hand-over after a random number of fused sweeps.    python tools/fuzz_fused.py [cases] [seed]"""
+hand-over after a random number of fused sweeps, listed launches over the still-running problems after
+every few sweeps (the straggler compaction, forced).    python tools/fuzz_fused.py [cases] [seed]"""
 import os
 import sys
 
@@ -19,7 +20,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
 def make_case():
     model = rng.choice(["pendulum", "bicycle", "di2", "di4", "di6"])
     N = int(rng.integers(1, 70))
-    batch = int(rng.choice([1, 7, 33, 64, 65, 200, 777, 2048, 2049, 3000, 4097, 6000]))
+    batch = int(rng.choice([1, 7, 33, 64, 65, 200, 777, 2048, 2049, 3000, 4097, 6000, 9000]))
     dtype = altro_amd.F32 if rng.random() < 0.25 else altro_amd.F64
     constrained = bool(rng.random() < 0.6)
     spread = float(rng.uniform(0.1, 1.5))
@@ -77,8 +78,12 @@ for c in range(CASES):
     seq = _solve(make, {"ALTRO_HIP_NO_FUSED": "1"}, **opts)
     fused = _solve(make, {"ALTRO_HIP_FUSED": "1"}, **opts)
     hand = _solve(make, {"ALTRO_HIP_FUSED": "1", "ALTRO_HIP_FUSED_SWEEPS": str(int(rng.integers(1, 6)))}, **opts)
+    listed = _solve(make, {"ALTRO_HIP_FUSED": "1", "ALTRO_HIP_FUSED_SWEEPS": str(-int(rng.integers(1, 5)))}, **opts)   # straggler compaction, forced
     _same(seq, fused)
     _same(seq, hand)
+    _same(seq, listed)
+    for r in (seq, fused, hand, listed):
+        r[5].close()
     st = np.asarray(fused[0]["status"])
     print("%-46s %-70s sweeps %3d  converged %d/%d" % (name, str(opts), int(fused[0]["sweeps"]), int((st == 0).sum()), len(st)))
 print("ok: %d cases bit-identical" % CASES)
