@@ -45,18 +45,21 @@ namespace capi {
 
 bool tile32_supported(int n, int m) { return tile32_shape_ok(n, m); }
 
-int tile32_launch_backward(altro_hip_batch* h, double reg) {
-  const Tile32Args a = tile32_args(h, reg);
-  switch (h->n & 7) {
-    case 0: return tile32_backward_unit0(h, a);
-    case 1: return tile32_backward_unit1(h, a);
-    case 2: return tile32_backward_unit2(h, a);
-    case 3: return tile32_backward_unit3(h, a);
-    case 4: return tile32_backward_unit4(h, a);
-    case 5: return tile32_backward_unit5(h, a);
-    case 6: return tile32_backward_unit6(h, a);
-    default: return tile32_backward_unit7(h, a);
+int tile32_backward_dispatch(const Tile32Launch& at, const Tile32Args& a) {
+  switch (a.n & 7) {
+    case 0: return tile32_backward_unit0(at, a);
+    case 1: return tile32_backward_unit1(at, a);
+    case 2: return tile32_backward_unit2(at, a);
+    case 3: return tile32_backward_unit3(at, a);
+    case 4: return tile32_backward_unit4(at, a);
+    case 5: return tile32_backward_unit5(at, a);
+    case 6: return tile32_backward_unit6(at, a);
+    default: return tile32_backward_unit7(at, a);
   }
+}
+
+int tile32_launch_backward(altro_hip_batch* h, double reg) {
+  return tile32_backward_dispatch(Tile32Launch{h->stream, h->launch_ev0, h->launch_ev1}, tile32_args(h, reg));
 }
 
 int tile32_launch_forward(altro_hip_batch* h) {

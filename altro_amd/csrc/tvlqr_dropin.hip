@@ -12,6 +12,7 @@
 
 #include "kernels/tvlqr_generic.hip"
 #include "kernels/tvlqr_lane.hip"   // plan LANE's sweeps: a single small problem rides one lane (four for (4, 2) and (2, 1))
+#include "capi_tile32.h"            // plan MFMA32's backward kernel: a single larger problem rides the matrix cores
 
 using namespace altro_hip;
 
@@ -392,6 +393,173 @@ int fast_backward(Workspace& w, const Layout& L, int n, int m, int N, const doub
   return status == TVLQR_SUCCESS ? 0 : 1;   // a failed factorisation: the GENERIC path reproduces the reference's early return
 }
 
+// ---- fast path for ONE problem with uniform dimensions on the matrix cores (7 <= n <= 31, m <= 8, n + m <= 32) ---------------------
+// The single-wave GENERIC kernel takes 14 us per knot point at (12, 4) and 40 at (20, 8); plan MFMA32's backward kernel
+// (kernels/tvlqr_tile32.hip: 2 x 2 tiles of v_mfma_f64_16x16x4, one wave per problem) takes 2 - 4.  So: the inputs staged as a batch
+// of ONE in plan GENERIC's array layout ([k][block]), that kernel (K, d, P, p, delta_V, status into device memory), then ONE more
+// launch -- a wave per knot point, nothing serial -- forms what the seam's signature carries besides (Qxx, Quu, Qux, Qx, Qu and
+// the final contents of their scratch twins, tvlqr.cpp:125-191) from the inputs and the sweep's P, p, K, d in the index order of the
+// GENERIC kernel, and writes everything into the mapped pinned arena at the GENERIC layout's offsets.  The sweep's sums run in the
+// matrix cores' order, not the oracle's: K, d, P, p agree with the GENERIC path to ~1e-13 relative (tests/cpp/tvlqr_dropin_tile_test.cpp
+// holds 1e-9), not bit for bit as the two other paths do.  A failed factorisation repeats the call on the GENERIC path.
+ALTRO_FP_REGION_OFF
+__global__ __launch_bounds__(64) void dropin_qblocks_wave_kernel(Tile32Args a, double reg, double* __restrict__ host,
+                                                                const int64_t* __restrict__ off, int64_t total) {
+  extern __shared__ double sm[];
+  const int n = a.n, m = a.m, N = a.N, k = (int)blockIdx.x, t = (int)threadIdx.x;
+  auto at = [&](int arr) -> double* { return host + off[(size_t)k * G_NUM + arr]; };
+  if (k == N) {
+    double* Ph = at(G_P); double* ph = at(G_p);
+    for (int e = t; e < n * n; e += 64) Ph[e] = a.P[(size_t)N * n * n + e];
+    for (int e = t; e < n; e += 64) ph[e] = a.p[(size_t)N * n + e];
+    if (t == 0) {
+      host[total - 4] = a.delta_V[0]; host[total - 3] = a.delta_V[1];
+      *reinterpret_cast<int*>(host + total - 2) = a.status[0];
+    }
+    return;
+  }
+  double* A = sm;               // n x n
+  double* Bm = A + n * n;       // n x m
+  double* Pn = Bm + n * m;      // n x n   P_{k+1}
+  double* T1 = Pn + n * n;      // n x n   A^T P'
+  double* T2 = T1 + n * n;      // m x n   B^T P'
+  double* Qxx = T2 + m * n;     // n x n
+  double* Qux = Qxx + n * n;    // m x n
+  double* Quu = Qux + m * n;    // m x m
+  double* Kk = Quu + m * m;     // m x n
+  double* L = Kk + m * n;       // m x m
+  double* f = L + m * m;        // n
+  double* tt = f + n;           // n       p' + P' f
+  double* Qx = tt + n;          // n
+  double* Qu = Qx + n;          // m
+  double* dk = Qu + m;          // m
+  for (int e = t; e < n * n; e += 64) {
+    A[e] = a.A[(size_t)k * n * n + e];
+    Pn[e] = a.P[(size_t)(k + 1) * n * n + e];
+    Qxx[e] = a.Q[(size_t)k * n * n + e];
+  }
+  for (int e = t; e < n * m; e += 64) {
+    Bm[e] = a.B[(size_t)k * n * m + e];
+    Qux[e] = a.H[(size_t)k * n * m + e];
+    Kk[e] = a.K[(size_t)k * n * m + e];
+  }
+  for (int e = t; e < m * m; e += 64) Quu[e] = a.R[(size_t)k * m * m + e];
+  for (int e = t; e < n; e += 64) { f[e] = a.f[(size_t)k * n + e]; Qx[e] = a.q[(size_t)k * n + e]; }
+  for (int e = t; e < m; e += 64) { Qu[e] = a.r[(size_t)k * m + e]; dk[e] = a.d[(size_t)k * m + e]; }
+  __syncthreads();
+  // the expressions of the GENERIC kernel / lane_backward_step: index-ordered dot products, no contraction
+  for (int e = t; e < n * n; e += 64) { const int i = e % n, j = e / n; double s = 0.0; for (int c = 0; c < n; ++c) s += A[c + i * n] * Pn[c + j * n]; T1[e] = 0.0 + s; }
+  for (int e = t; e < m * n; e += 64) { const int i = e % m, j = e / m; double s = 0.0; for (int c = 0; c < n; ++c) s += Bm[c + i * n] * Pn[c + j * n]; T2[e] = 0.0 + s; }
+  for (int i = t; i < n; i += 64) { double s = 0.0; for (int c = 0; c < n; ++c) s += Pn[i + c * n] * f[c]; tt[i] = a.p[(size_t)(k + 1) * n + i] + s; }
+  __syncthreads();
+  for (int e = t; e < n * n; e += 64) { const int i = e % n, j = e / n; double s = 0.0; for (int c = 0; c < n; ++c) s += T1[i + c * n] * A[c + j * n]; Qxx[e] = Qxx[e] + s; }
+  for (int e = t; e < m * m; e += 64) { const int i = e % m, j = e / m; double s = 0.0; for (int c = 0; c < n; ++c) s += T2[i + c * m] * Bm[c + j * n]; Quu[e] = Quu[e] + s; }
+  for (int e = t; e < m * n; e += 64) { const int i = e % m, j = e / m; double s = 0.0; for (int c = 0; c < n; ++c) s += T2[i + c * m] * A[c + j * n]; Qux[e] = Qux[e] + s; }
+  for (int i = t; i < n; i += 64) { double s = 0.0; for (int c = 0; c < n; ++c) s += A[c + i * n] * tt[c]; Qx[i] = Qx[i] + s; }
+  for (int i = t; i < m; i += 64) { double s = 0.0; for (int c = 0; c < n; ++c) s += Bm[c + i * n] * tt[c]; Qu[i] = Qu[i] + s; }
+  __syncthreads();
+  // the scratch twins as the reference leaves them: chol(Quu + reg I) in place, Quu K, K^T Qux, K^T Qu, Quu d
+  for (int e = t; e < m * m; e += 64) L[e] = Quu[e] + ((e % m == e / m) ? reg : 0.0);
+  __syncthreads();
+  if (t == 0)
+    for (int c = 0; c < m; ++c) {
+      double x = L[c + c * m];
+      for (int j = 0; j < c; ++j) x -= L[c + j * m] * L[c + j * m];
+      x = sqrt(x);
+      L[c + c * m] = x;
+      for (int i = c + 1; i < m; ++i) {
+        double s = L[i + c * m];
+        for (int j = 0; j < c; ++j) s -= L[i + j * m] * L[c + j * m];
+        L[i + c * m] = s / x;
+      }
+    }
+  double* h;
+  h = at(G_Qux_tmp); for (int e = t; e < m * n; e += 64) { const int i = e % m, j = e / m; double s = 0.0; for (int c = 0; c < m; ++c) s += Quu[i + c * m] * Kk[c + j * m]; h[e] = 0.0 + s; }
+  h = at(G_Qxx_tmp); for (int e = t; e < n * n; e += 64) { const int i = e % n, j = e / n; double s = 0.0; for (int c = 0; c < m; ++c) s += Kk[c + i * m] * Qux[c + j * m]; h[e] = 0.0 + s; }
+  h = at(G_Qx_tmp); for (int i = t; i < n; i += 64) { double s = 0.0; for (int c = 0; c < m; ++c) s += Kk[c + i * m] * Qu[c]; h[i] = 0.0 + s; }
+  h = at(G_Qu_tmp); for (int i = t; i < m; i += 64) { double s = 0.0; for (int c = 0; c < m; ++c) s += Quu[i + c * m] * dk[c]; h[i] = 0.0 + s; }
+  h = at(G_K); for (int e = t; e < m * n; e += 64) h[e] = Kk[e];
+  h = at(G_d); for (int e = t; e < m; e += 64) h[e] = dk[e];
+  h = at(G_P); for (int e = t; e < n * n; e += 64) h[e] = a.P[(size_t)k * n * n + e];
+  h = at(G_p); for (int e = t; e < n; e += 64) h[e] = a.p[(size_t)k * n + e];
+  h = at(G_Qxx); for (int e = t; e < n * n; e += 64) h[e] = Qxx[e];
+  h = at(G_Quu); for (int e = t; e < m * m; e += 64) h[e] = Quu[e];
+  h = at(G_Qux); for (int e = t; e < m * n; e += 64) h[e] = Qux[e];
+  h = at(G_Qx); for (int e = t; e < n; e += 64) h[e] = Qx[e];
+  h = at(G_Qu); for (int e = t; e < m; e += 64) h[e] = Qu[e];
+  __syncthreads();
+  h = at(G_Quu_tmp); for (int e = t; e < m * m; e += 64) h[e] = L[e];
+}
+ALTRO_FP_REGION_END
+
+bool tile_shape(const int* nx, const int* nu, int N, int* n_out, int* m_out) {
+  if (N < 1) return false;
+  const int n = nx[0], m = nu[0];
+  if (!capi::tile32_kernel_ok(n, m)) return false;
+  for (int k = 0; k <= N; ++k)
+    if (nx[k] != n || (k < N && nu[k] != m)) return false;
+  *n_out = n; *m_out = m;
+  return true;
+}
+
+// returns 0 when the path ran to completion (outputs and status in the pinned arena w.host), 1 to fall back
+int tile_backward(Workspace& w, const Layout& L, int n, int m, int N, const double* const* A, const double* const* B,
+                  const double* const* f, const double* const* Q, const double* const* R, const double* const* H,
+                  const double* const* q, const double* const* r, double reg, bool is_diag) {
+  if (std::getenv("ALTRO_TVLQR_DROPIN_GENERIC") != nullptr) return 1;   // A/B hook: always the GENERIC kernel
+  const size_t nn = (size_t)n * n, nm = (size_t)n * m, mm = (size_t)m * m;
+  // inputs, one copy: A | B | f | Q | R | H | q | r ; outputs on the device behind them: K | d | P | p | delta_V, status
+  const size_t oA = 0, oB = oA + N * nn, of = oB + N * nm, oQ = of + (size_t)N * n, oR = oQ + (N + 1) * nn, oH = oR + N * mm,
+               oq = oH + N * nm, orr = oq + (size_t)(N + 1) * n, in_elems = orr + (size_t)N * m;
+  const size_t oK = (in_elems + 1) & ~size_t(1), od = oK + N * nm, oP = od + (size_t)N * m, op = oP + (N + 1) * nn,
+               odv = op + (size_t)(N + 1) * n, total = odv + 4;
+  FastWs& fw = g_fast;
+  if (fw.elems < total) {
+    if (fw.dev) (void)hipFree(fw.dev);
+    if (fw.host) (void)hipHostFree(fw.host);
+    fw.dev = nullptr; fw.host = nullptr; fw.elems = 0;
+    if (hipMalloc(&fw.dev, total * sizeof(double)) != hipSuccess) { fw.dev = nullptr; return 1; }
+    if (hipHostMalloc((void**)&fw.host, total * sizeof(double) + 64, hipHostMallocDefault) != hipSuccess) {
+      (void)hipFree(fw.dev); fw.dev = nullptr; fw.host = nullptr; return 1;
+    }
+    fw.elems = total;
+  }
+  auto put = [](double* dst, const double* src, size_t cnt) {
+    if (src) memcpy(dst, src, sizeof(double) * cnt);
+    else memset(dst, 0, sizeof(double) * cnt);
+  };
+  auto put_sym = [&](double* dst, const double* src, int dim) {   // a diagonal block (is_diag) expanded to the dense one
+    if (!is_diag) { put(dst, src, (size_t)dim * dim); return; }
+    memset(dst, 0, sizeof(double) * dim * dim);
+    for (int i = 0; i < dim; ++i) dst[i + (size_t)i * dim] = src[i];
+  };
+  double* hs = fw.host;
+  for (int k = 0; k < N; ++k) {
+    put(hs + oA + k * nn, A[k], nn); put(hs + oB + k * nm, B[k], nm); put(hs + of + (size_t)k * n, f[k], n);
+    put_sym(hs + oQ + k * nn, Q[k], n); put_sym(hs + oR + k * mm, R[k], m);
+    put(hs + oH + k * nm, is_diag ? nullptr : H[k], nm);
+    put(hs + oq + (size_t)k * n, q[k], n); put(hs + orr + (size_t)k * m, r[k], m);
+  }
+  put_sym(hs + oQ + N * nn, Q[N], n); put(hs + oq + (size_t)N * n, q[N], n);
+  double* dv = fw.dev;
+  if (hipMemcpyAsync(dv, hs, in_elems * sizeof(double), hipMemcpyHostToDevice, w.stream) != hipSuccess) return 1;
+  Tile32Args a{};
+  a.A = dv + oA; a.B = dv + oB; a.f = dv + of; a.Q = dv + oQ; a.R = dv + oR; a.H = dv + oH; a.q = dv + oq; a.r = dv + orr;
+  a.K = dv + oK; a.d = dv + od; a.P = dv + oP; a.p = dv + op;
+  a.delta_V = dv + odv; a.status = reinterpret_cast<int*>(dv + odv + 2);
+  a.N = N; a.batch = 1; a.n = n; a.m = m; a.reg = reg; a.no_f = 0;
+  a.L = tile32_lds_layout(n, m);
+  if (capi::tile32_backward_dispatch(capi::Tile32Launch{w.stream, nullptr, nullptr}, a) || hipGetLastError() != hipSuccess) return 1;
+  const size_t lds = (4 * nn + 4 * nm + 2 * mm + 4 * (size_t)n + 2 * (size_t)m) * sizeof(double);
+  hipLaunchKernelGGL(dropin_qblocks_wave_kernel, dim3(N + 1), dim3(64), lds, w.stream, a, reg, w.host_dev, (const int64_t*)w.dev_off,
+                     (int64_t)L.total);
+  if (hipGetLastError() != hipSuccess) return 1;
+  if (hipStreamSynchronize(w.stream) != hipSuccess) return 1;
+  int status;
+  memcpy(&status, w.host + L.total - 2, sizeof(int));
+  return status == TVLQR_SUCCESS ? 0 : 1;   // a failed factorisation: the GENERIC path reproduces the reference's early return
+}
+
 }  // namespace
 
 int tvlqr_BackwardPass(const int* nx, const int* nu, int num_horizon, const lqr_float* const* A,
@@ -411,7 +579,8 @@ int tvlqr_BackwardPass(const int* nx, const int* nu, int num_horizon, const lqr_
   if (prepare(w, L, nx, nu)) return TVLQR_NO_DEVICE;
   double* hs = w.host;
   int fn = 0, fm = 0;
-  const bool fast = fast_shape(nx, nu, N, &fn, &fm) && fast_backward(w, L, fn, fm, N, A, B, f, Q, R, H, q, r, reg, is_diag) == 0;
+  const bool fast = (fast_shape(nx, nu, N, &fn, &fm) && fast_backward(w, L, fn, fm, N, A, B, f, Q, R, H, q, r, reg, is_diag) == 0) ||
+                    (tile_shape(nx, nu, N, &fn, &fm) && tile_backward(w, L, fn, fm, N, A, B, f, Q, R, H, q, r, reg, is_diag) == 0);
   auto put = [&](int arr, int k, const double* src, int64_t cnt) {
     if (!cnt) return;
     if (src) memcpy(hs + L.off[(size_t)k * G_NUM + arr], src, sizeof(double) * cnt);

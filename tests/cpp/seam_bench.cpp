@@ -83,7 +83,7 @@ double micros(F fn, int reps) {
 }  // namespace
 
 int main() {
-  const int shapes[][3] = {{10, 4, 2}, {50, 4, 2}, {10, 12, 4}, {10, 20, 8}};
+  const int shapes[][3] = {{10, 4, 2}, {50, 4, 2}, {10, 12, 4}, {10, 20, 8}, {50, 28, 4}};
   std::printf("{\"what\": \"median microseconds of ONE tvlqr_BackwardPass call (reference signature, include/tvlqr/tvlqr.h): the GPU seam -- one small "
               "problem, one wavefront, pinned staging, one wait -- against the CPU port of the same function (oracle/tvlqr_oracle.c, this host, "
               "one thread)\", \"shapes\": [");

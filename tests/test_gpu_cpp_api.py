@@ -21,6 +21,16 @@ def test_tvlqr_dropin_fast_path_equals_the_generic_path():
     assert rc == 0 and out.strip().endswith("OK"), out + err
 
 
+def test_tvlqr_dropin_matrix_core_path_agrees_with_the_generic_path():
+    """One problem with uniform dimensions 7 <= n <= 31, m <= 8 runs plan MFMA32's backward kernel for a batch of one + a
+    wave-per-knot-point kernel for the Q-blocks and their scratch twins: every array of the reference's signature against the
+    GENERIC path's to 1e-9 relative (the sums run in the matrix cores' order), twelve shapes, dense / diagonal costs, reg, and the
+    failure convention (handed back to the GENERIC kernel: bit for bit)."""
+    rc, out, err = cpp_build.run("tvlqr_dropin_tile_test")
+    print(out[-300:])
+    assert rc == 0 and out.strip().endswith("OK"), out + err
+
+
 def test_tvlqr_dropin_per_knot_point_dimensions_match_the_oracle():
     """tvlqr.cpp:65-248 takes nx[k], nu[k] per knot point; the reference's own tests pass uniform ones only.  A random problem with
     a state dimension that shrinks 6 -> 2 along the horizon and an input dimension that changes every step (tests/cpp/

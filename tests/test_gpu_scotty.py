@@ -90,7 +90,18 @@ def test_cpp_altro_solver_reproduces_the_references_saved_mpc_run():
             for x, u in zip(x_ref, u_ref):
                 f.write(" ".join(repr(float(v)) for v in list(x) + list(u)) + "\n")
         rc, out, errtxt = cpp_build.run("bicycle_mpc_test", args=[path, NSIM], timeout=900)
+        # the same program with the three tvlqr_* entry points bound to the CPU oracle (tests/cpp/tvlqr_cpu_seam.cpp interposes
+        # libaltro_hip.so's definitions): what the seam replaces, timed on this host beside it
+        from oracle import oracle as _oracle
+        _oracle.lib()
+        odir = os.path.join(cpp_build.ROOT, "oracle", "_build")
+        rc_cpu, out_cpu, err_cpu = cpp_build.run("bicycle_mpc_test", extra_sources=["tests/cpp/tvlqr_cpu_seam.cpp"],
+                                                 extra_link=["-L" + odir, "-loracle", "-Wl,-rpath," + odir], args=[path, NSIM], timeout=900,
+                                                 out_name="bicycle_mpc_test_cpu_seam")
     assert rc == 0 and out.strip().endswith("OK"), out[-2000:] + errtxt[-2000:]
+    assert rc_cpu == 0 and out_cpu.strip().endswith("OK"), out_cpu[-2000:] + err_cpu[-2000:]
+    rows_cpu = [l.split() for l in out_cpu.splitlines() if l.startswith("step ")]
+    rate_cpu = [l for l in out_cpu.splitlines() if l.startswith("Average rate")][0]
     rows = [l.split() for l in out.splitlines() if l.startswith("step ")]
     assert len(rows) == NSIM
     iters = np.array([int(r[3]) for r in rows]); status = np.array([int(r[5]) for r in rows])
@@ -99,8 +110,12 @@ def test_cpp_altro_solver_reproduces_the_references_saved_mpc_run():
     rate = [l for l in out.splitlines() if l.startswith("Average rate")][0]
     same = int((iters == exp["solve_iters"]).sum())
     ex, eu = np.abs(xs - exp["state_trajectory"][1:]).max(), np.abs(us - exp["input_trajectory"]).max()
-    print("scotty through ALTROSolver: solve_iters equal %d / %d, max |x - x_file| %.3g, max |u - u_file| %.3g; %s"
-          % (same, NSIM, ex, eu, rate))
+    print("scotty through ALTROSolver: solve_iters equal %d / %d, max |x - x_file| %.3g, max |u - u_file| %.3g; %s through the GPU seam; "
+          "%s with the backward sweeps on this host's CPU (oracle port, one thread)" % (same, NSIM, ex, eu, rate, rate_cpu))
+    # the seam changes where the sweep runs, not what the solver does: same iteration counts, same inputs
+    assert [r[3] for r in rows_cpu] == [r[3] for r in rows]
+    us_cpu = np.array([[float(v) for v in r[7:9]] for r in rows_cpu])
+    assert np.abs(us_cpu - us).max() < 1e-9
     assert (status == 0).all()
     # host callbacks (glibc trigonometry) + the device backward sweep in the oracle's operation order
     assert same == NSIM, np.flatnonzero(iters != exp["solve_iters"])
