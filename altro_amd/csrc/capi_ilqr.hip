@@ -25,10 +25,27 @@ int al_upload_typed(altro_hip_batch* h) {
   const bool tile = h->plan == ALTRO_HIP_PLAN_MFMA16;
   const int w_log = h->n + h->m, w_dev = tile ? MF_N + MF_M : w_log;
   auto dev_col = [&](int e) { return (tile && e >= h->n) ? MF_N + (e - h->n) : e; };
+  // Plan MFMA16 lays a block out over SLOTS of at most AL_MAXP rows (al_types.h: AL_TILE_MAXC): rows 8 s .. 8 s + 7 of a block in the
+  // zero / identity / orthant cones are a block of their own (those cones project row by row, cones.cpp:13-38) with the same duals
+  // in the same place; a second-order-cone block (p <= AL_MAXSOC) is one slot.  slot_base[i]: first slot definition of block i.
+  auto nslots = [&](const AlDef& d) { return (tile && d.cone != CONE_SOC) ? (d.p + AL_MAXP - 1) / AL_MAXP : 1; };
+  std::vector<int> slot_base(h->al_defs.size() + 1, 0);
+  for (size_t i = 0; i < h->al_defs.size(); ++i) slot_base[i + 1] = slot_base[i] + nslots(h->al_defs[i]);
   std::vector<T> G;
-  std::vector<int> G_off_dev(h->al_defs.size(), 0);
+  std::vector<int> G_off_dev(tile ? (size_t)slot_base.back() : h->al_defs.size(), 0);   // plan MFMA16: per slot definition
   for (size_t i = 0; i < h->al_defs.size(); ++i) {
     const AlDef& d0 = h->al_defs[i];
+    if (tile) {   // every slot its own ps x 16 column-major matrix (the LDS-form kernels address a slot like a block)
+      for (int sl = 0; sl < nslots(d0); ++sl) {
+        const int r0 = sl * AL_MAXP, ps = std::min(d0.p - r0, AL_MAXP);
+        const size_t off = G.size();
+        G_off_dev[(size_t)slot_base[i] + sl] = (int)off;
+        G.resize(off + (size_t)ps * w_dev, (T)0);
+        for (int e = 0; e < w_log; ++e)
+          for (int r = 0; r < ps; ++r) G[off + r + (size_t)dev_col(e) * ps] = (T)h->al_G[(size_t)d0.G_off + (r0 + r) + (size_t)e * d0.p];
+      }
+      continue;
+    }
     G_off_dev[i] = (int)G.size();
     if (h->ragged) {   // per-knot-point dimensions (plan GENERIC): the block as given, p x (nx[k] + nu[k]) of its knot points
       G.resize(G.size() + (size_t)d0.p * d0.w, (T)0);
@@ -39,15 +56,16 @@ int al_upload_typed(altro_hip_batch* h) {
     for (int e = 0; e < w_log; ++e)
       for (int r = 0; r < d0.p; ++r) G[(size_t)G_off_dev[i] + r + (size_t)dev_col(e) * d0.p] = (T)h->al_G[(size_t)d0.G_off + r + (size_t)e * d0.p];
   }
-  std::vector<T> Gpad;   // the same blocks zero-padded for the row-layout kernels (al_types.h: AL_GP_DEF)
+  std::vector<T> Gpad;   // the same slots zero-padded for the row-layout kernels (al_types.h: AL_GP_DEF)
   if (tile) {
-    Gpad.assign(h->al_defs.size() * (size_t)AL_GP_DEF, (T)0);
+    Gpad.assign((size_t)slot_base.back() * (size_t)AL_GP_DEF, (T)0);
     for (size_t i = 0; i < h->al_defs.size(); ++i) {
       const AlDef& d0 = h->al_defs[i];
       if (d0.user) continue;
       for (int e = 0; e < w_log; ++e)
-        for (int r = 0; r < d0.p && r < AL_MAXP; ++r)
-          Gpad[i * (size_t)AL_GP_DEF + (size_t)r * AL_GP_LD + dev_col(e)] = (T)h->al_G[(size_t)d0.G_off + r + (size_t)e * d0.p];
+        for (int r = 0; r < d0.p; ++r)
+          Gpad[(size_t)(slot_base[i] + r / AL_MAXP) * AL_GP_DEF + (size_t)(r % AL_MAXP) * AL_GP_LD + dev_col(e)] =
+              (T)h->al_G[(size_t)d0.G_off + r + (size_t)e * d0.p];
     }
   }
   std::vector<T> g;
@@ -69,34 +87,47 @@ int al_upload_typed(altro_hip_batch* h) {
   const bool gen = h->plan == ALTRO_HIP_PLAN_GENERIC;
   std::vector<AlKnotBig> big = h->al_knots;
   std::vector<AlKnot> knots(gen ? 0 : big.size(), AlKnot{});
+  int max_ncon = 0;
   for (size_t k = 0; k < big.size(); ++k) {
     AlKnotBig& bk = big[k];
+    int ns = 0;   // slots of knot point k so far (plans LANE: one per block)
     for (int j = 0; j < bk.ncon; ++j) {
       const AlDef& d = defs[bk.def[j]];
       bk.z_off[j] = rows; rows += d.p;
-      bk.cone[j] = d.cone; bk.p[j] = d.p; bk.g_per_problem[j] = d.g_per_problem; bk.G_off[j] = G_off_dev[bk.def[j]]; bk.g_off[j] = d.g_off;
+      bk.cone[j] = d.cone; bk.p[j] = d.p; bk.g_per_problem[j] = d.g_per_problem; bk.G_off[j] = tile ? G_off_dev[slot_base[bk.def[j]]] : G_off_dev[bk.def[j]];
+      bk.g_off[j] = d.g_off;
       if (gen) continue;
       AlKnot& kn = knots[k];
-      kn.ncon = bk.ncon; kn.def[j] = bk.def[j];
-      kn.z_off[j] = bk.z_off[j];
-      kn.cone[j] = d.cone; kn.p[j] = d.p; kn.g_per_problem[j] = d.g_per_problem; kn.G_off[j] = G_off_dev[kn.def[j]]; kn.g_off[j] = d.g_off;
-      kn.user[j] = d.user;
-      kn.Gp_off[j] = kn.def[j] * AL_GP_DEF;
-      // bound-type block: every row of G is +-e_idx
-      const int w = h->n + h->m;
-      bool sel = d.cone != CONE_SOC;
-      for (int r = 0; r < d.p && sel; ++r) {
-        int nz = 0, at = -1;
-        for (int e = 0; e < w; ++e) {
-          const double v = h->al_G[(size_t)d.G_off + r + (size_t)e * d.p];
-          if (v != 0.0) { ++nz; at = e; if (v != 1.0 && v != -1.0) sel = false; }
+      for (int sl = 0; sl < nslots(d); ++sl, ++ns) {
+        if (ns >= (tile ? AL_TILE_MAXC : AL_MAXC))   // (altro_hip_add_linear_constraint counted the slots: not reached)
+          return fail(ALTRO_HIP_ERR_UNSUPPORTED, "knot point %d: more constraint rows than the plan's table holds", (int)k);
+        const int r0 = sl * AL_MAXP, ps = tile ? std::min(d.p - r0, d.cone == CONE_SOC ? d.p : AL_MAXP) : d.p;
+        kn.def[ns] = bk.def[j];
+        kn.z_off[ns] = bk.z_off[j] + r0;
+        kn.cone[ns] = d.cone; kn.p[ns] = ps; kn.g_per_problem[ns] = d.g_per_problem;
+        kn.G_off[ns] = tile ? G_off_dev[(size_t)slot_base[bk.def[j]] + sl] : G_off_dev[bk.def[j]];
+        kn.g_off[ns] = d.g_off + (d.g_per_problem ? (int64_t)r0 * B : (int64_t)r0);   // g is [p] or [p][batch]: row r0 on
+        kn.user[ns] = d.user;
+        kn.Gp_off[ns] = tile ? (slot_base[bk.def[j]] + sl) * AL_GP_DEF : 0;
+        // bound-type slot: every row of G is +-e_idx
+        const int w = h->n + h->m;
+        bool sel = d.cone != CONE_SOC;
+        for (int r = 0; r < ps && sel; ++r) {
+          int nz = 0, at = -1;
+          for (int e = 0; e < w; ++e) {
+            const double v = h->al_G[(size_t)d.G_off + (r0 + r) + (size_t)e * d.p];
+            if (v != 0.0) { ++nz; at = e; if (v != 1.0 && v != -1.0) sel = false; }
+          }
+          if (nz != 1) sel = false;
+          else kn.sidx[ns][r] = h->al_G[(size_t)d.G_off + (r0 + r) + (size_t)at * d.p] > 0 ? dev_col(at) + 1 : -(dev_col(at) + 1);
         }
-        if (nz != 1) sel = false;
-        else kn.sidx[j][r] = h->al_G[(size_t)d.G_off + r + (size_t)at * d.p] > 0 ? dev_col(at) + 1 : -(dev_col(at) + 1);
+        kn.sel[ns] = sel ? 1 : 0;
       }
-      kn.sel[j] = sel ? 1 : 0;
+      kn.ncon = ns;
     }
+    max_ncon = std::max(max_ncon, gen ? bk.ncon : ns);
   }
+  h->al_max_ncon = max_ncon;
   h->al_rows = rows;
   if (h->plan == ALTRO_HIP_PLAN_LANE && (uint64_t)rows * (uint64_t)B * sizeof(T) >= (1ull << 31))
     return fail(ALTRO_HIP_ERR_UNSUPPORTED, "plan LANE: %d dual rows x batch %d exceed the 2 GiB buffer window; split the batch", rows, h->batch);
@@ -152,7 +183,7 @@ IlqrArgs<T> ilqr_args(altro_hip_batch* h, bool use_alpha, bool use_active, int w
   IlqrArgs<T> a;
   a.al.knots = h->al_d_knots; a.al.G = (const T*)h->al_d_G; a.al.g = (const T*)h->al_d_g;
   a.al.z = (T*)h->al_d_z; a.al.enabled = h->al_defs.empty() ? 0 : 1;
-  a.al.uniform = h->al_uniform; a.al.rows_per_knot = h->al_rows_per_knot; a.al.N = h->N; a.al.G_count = h->al_G_count; a.al.has_soc = h->al_has_soc; a.al.all_sel = h->al_all_sel; a.al.Gpad = (decltype(a.al.Gpad))h->al_d_Gpad; a.al.Gpad_count = h->al_Gpad_count;
+  a.al.uniform = h->al_uniform; a.al.rows_per_knot = h->al_rows_per_knot; a.al.N = h->N; a.al.G_count = h->al_G_count; a.al.has_soc = h->al_has_soc; a.al.all_sel = h->al_all_sel; a.al.Gpad = (decltype(a.al.Gpad))h->al_d_Gpad; a.al.Gpad_count = h->al_Gpad_count; a.al.max_ncon = h->al_max_ncon;
   a.mode = EXPAND_GRADIENT | EXPAND_HESSIAN;
   a.in = (T*)h->l_in; a.term = (T*)h->l_term; a.out = (const T*)h->l_out; a.outn = (const T*)h->l_outn;
   a.nom = (T*)h->l_nom; a.cand = (T*)h->l_xuy; a.x0 = (const T*)h->l_x0;
@@ -220,7 +251,7 @@ int wave_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int
   IlqrWaveArgs<S> a;
   a.al.knots = h->al_d_knots; a.al.G = (const S*)h->al_d_G; a.al.g = (const S*)h->al_d_g; a.al.z = (S*)h->al_d_z;
   a.al.enabled = h->al_defs.empty() ? 0 : 1;
-  a.al.uniform = h->al_uniform; a.al.rows_per_knot = h->al_rows_per_knot; a.al.N = h->N; a.al.G_count = h->al_G_count; a.al.has_soc = h->al_has_soc; a.al.all_sel = h->al_all_sel; a.al.Gpad = (decltype(a.al.Gpad))h->al_d_Gpad; a.al.Gpad_count = h->al_Gpad_count;
+  a.al.uniform = h->al_uniform; a.al.rows_per_knot = h->al_rows_per_knot; a.al.N = h->N; a.al.G_count = h->al_G_count; a.al.has_soc = h->al_has_soc; a.al.all_sel = h->al_all_sel; a.al.Gpad = (decltype(a.al.Gpad))h->al_d_Gpad; a.al.Gpad_count = h->al_Gpad_count; a.al.max_ncon = h->al_max_ncon;
   a.mode = mode;
   a.penalty_scaling = h->expand_penalty_scaling; a.penalty_max = h->expand_penalty_max;
   if (which == IK_STATIONARITY || which == IK_DUAL)   // constraint rows in the DPP form unless ALTRO_HIP_FORM_ALROWS_LDS
@@ -1036,20 +1067,39 @@ int altro_hip_add_linear_constraint(altro_hip_batch* h, int k_first, int k_last,
   h->expansion_current = false;
   if (!G || !g) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "G and g are required");
   if (cone < CONE_EQUALITY || cone > CONE_SOC) return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "unknown cone %d", cone);
-  // capacities (stated in altro_hip.h): plan GENERIC loops over the blocks with one lane per row, plans LANE / MFMA16 unroll two blocks
-  const bool gen = h->plan == ALTRO_HIP_PLAN_GENERIC;
-  const int pmax = cone == CONE_SOC ? AL_MAXSOC : (gen ? GEN_MAXP : AL_MAXP);
-  const int cmax = gen ? GEN_MAXC : AL_MAXC, dmax = gen ? GEN_MAXDEF : AL_MAXDEF;
+  // capacities (stated in altro_hip.h): plan GENERIC loops over the blocks with one lane per row, plan LANE unrolls two blocks, plan
+  // MFMA16 lays the rows out over slots of eight (kernels/al_types.h: AL_TILE_MAXC)
+  const bool gen = h->plan == ALTRO_HIP_PLAN_GENERIC, tile = h->plan == ALTRO_HIP_PLAN_MFMA16;
+  const int tile_slots = h->dtype == ALTRO_HIP_F64 ? AL_TILE_MAXC : AL_MAXC;   // (fp32 records: the two-slot kernels only)
+  const int pmax = cone == CONE_SOC ? AL_MAXSOC : (gen ? GEN_MAXP : tile ? tile_slots * AL_MAXP : AL_MAXP);
+  const int cmax = gen ? GEN_MAXC : AL_MAXC, dmax = gen ? GEN_MAXDEF : tile ? AL_TILE_MAXSLOTDEF : AL_MAXDEF;
   if (p < 1 || p > pmax)
     return fail(ALTRO_HIP_ERR_UNSUPPORTED, "constraint dimension %d outside [1, %d]%s", p, pmax,
                 gen || cone == CONE_SOC ? "" : " on this plan (ALTRO_HIP_PLAN_GENERIC takes up to 64 rows per block and 8 blocks per knot point)");
   if (k_first < 0 || k_last > h->N || k_first > k_last)
     return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "knot point range [%d, %d] outside [0, %d] (ErrorCodes::BadIndex)", k_first, k_last, h->N);
-  if ((int)h->al_defs.size() >= dmax) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "at most %d constraint blocks", dmax);
-  for (int k = k_first; k <= k_last; ++k)
-    if (h->al_knots[k].ncon >= cmax)
-      return fail(ALTRO_HIP_ERR_UNSUPPORTED, "at most %d constraint blocks per knot point on this plan (k = %d)%s", cmax, k,
-                  gen ? "" : ": ALTRO_HIP_PLAN_GENERIC takes 8");
+  auto slots_of = [&](int cn, int rows) { return cn == CONE_SOC ? 1 : (rows + AL_MAXP - 1) / AL_MAXP; };
+  if (tile) {   // slots: per knot point and per handle
+    int defslots = slots_of(cone, p);
+    for (const AlDef& d0 : h->al_defs) defslots += slots_of(d0.cone, d0.p);
+    if (defslots > AL_TILE_MAXSLOTDEF)
+      return fail(ALTRO_HIP_ERR_UNSUPPORTED, "at most %d constraint slots (blocks, counted in units of %d rows) per handle on this plan: "
+                                             "ALTRO_HIP_PLAN_GENERIC takes 64 blocks", AL_TILE_MAXSLOTDEF, AL_MAXP);
+    for (int k = k_first; k <= k_last; ++k) {
+      int used = slots_of(cone, p);
+      for (int j = 0; j < h->al_knots[k].ncon; ++j) { const AlDef& d0 = h->al_defs[h->al_knots[k].def[j]]; used += slots_of(d0.cone, d0.p); }
+      if (used > tile_slots)
+        return fail(ALTRO_HIP_ERR_UNSUPPORTED, "at most %d constraint slots of %d rows per knot point on this plan (k = %d would need %d; a block "
+                                               "takes ceil(p / %d) of them, a second-order cone one): ALTRO_HIP_PLAN_GENERIC takes 8 blocks of 64 rows",
+                    tile_slots, AL_MAXP, k, used, AL_MAXP);
+    }
+  } else {
+    if ((int)h->al_defs.size() >= dmax) return fail(ALTRO_HIP_ERR_UNSUPPORTED, "at most %d constraint blocks", dmax);
+    for (int k = k_first; k <= k_last; ++k)
+      if (h->al_knots[k].ncon >= cmax)
+        return fail(ALTRO_HIP_ERR_UNSUPPORTED, "at most %d constraint blocks per knot point on this plan (k = %d)%s", cmax, k,
+                    gen ? "" : ": ALTRO_HIP_PLAN_GENERIC takes 8");
+  }
   int w = h->n + h->m;
   if (h->ragged) {   // G is p x (nx[k] + nu[k]): every knot point of the range must have the dimensions of the first (the terminal one: its nx)
     const int nk = h->nxv[k_first], mk = k_first < h->N ? h->nuv[k_first] : 0;   // (a block of the terminal knot point alone: p x nx[N])

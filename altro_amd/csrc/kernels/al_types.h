@@ -5,8 +5,16 @@
 
 namespace altro_hip {
 
-constexpr int AL_MAXC = 2;     // constraint blocks per knot point
-constexpr int AL_MAXP = 8;     // rows per zero / identity / orthant block
+constexpr int AL_MAXC = 2;     // constraint blocks per knot point on plan LANE (its kernels unroll two)
+constexpr int AL_MAXP = 8;     // rows per zero / identity / orthant block (plan LANE); rows per SLOT on plan MFMA16
+// Plan MFMA16 (round 6): a knot point's record holds up to AL_TILE_MAXC SLOTS of at most AL_MAXP rows.  A caller's block in the zero /
+// identity / orthant cones with more rows than a slot is laid out over consecutive slots by the host (those cones project row by row:
+// cones.cpp:13-38, so rows 8s .. 8s + 7 of a block ARE a block of their own with the same duals in the same place); a second-order-cone
+// block takes one slot.  6 x 8 = 48 rows per knot point: e.g. an input box (8 rows) and a state box (24) on a (12, 4) problem with two
+// slots to spare.  The row-layout kernels loop over the slots a knot point has; the merit kernel, which carries per-slot values in
+// registers across the ring of knot points, is instantiated for 2 and for AL_TILE_MAXC slots (AlTable::max_ncon picks).
+constexpr int AL_TILE_MAXC = 6;
+constexpr int AL_TILE_MAXSLOTDEF = 32;   // distinct slots per handle on plan MFMA16 (their padded Jacobians sit in the merit kernel's LDS: 32 x 1296 B)
 constexpr int AL_MAXSOC = 4;   // rows per second-order-cone block
 constexpr int AL_MAXDEF = 16;  // distinct blocks per handle
 // AlTable::Gpad: every block as 9 rows x 16 tile columns, rows padded to 18 (16-byte aligned, eight lanes reading one column hit
@@ -29,20 +37,20 @@ struct AlDef {
   int w = 0;       // columns of G as given: n + m of the handle, or nx[k] + nu[k] of the block's knot points (per-knot-point dimensions)
 };
 struct AlKnot {          // everything a kernel needs about knot point k in ONE wave-uniform record
-  int ncon;
-  int def[AL_MAXC];
-  int z_off[AL_MAXC];   // first row of this block's dual in z[rows][batch]
-  int cone[AL_MAXC], p[AL_MAXC], g_per_problem[AL_MAXC], G_off[AL_MAXC];
-  int64_t g_off[AL_MAXC];
+  int ncon;               // plan LANE: blocks (<= AL_MAXC); plan MFMA16: slots (<= AL_TILE_MAXC)
+  int def[AL_TILE_MAXC];
+  int z_off[AL_TILE_MAXC];   // first row of this block's dual in z[rows][batch]
+  int cone[AL_TILE_MAXC], p[AL_TILE_MAXC], g_per_problem[AL_TILE_MAXC], G_off[AL_TILE_MAXC];
+  int64_t g_off[AL_TILE_MAXC];
   // Bound-type blocks: every row of G is +-e_idx (control / state bounds, goal pins -- most constraints of an MPC
   // problem).  sel != 0 marks such a block; sidx[row] = +(idx + 1) or -(idx + 1).  The kernels then skip G.
-  int sel[AL_MAXC];
-  int sidx[AL_MAXC][AL_MAXP];
+  int sel[AL_TILE_MAXC];
+  int sidx[AL_TILE_MAXC][AL_MAXP];
   // id + 1 of a block whose value c(x, u) and Jacobian dc/d[x;u] the caller's source computes (altro_hip_add_user_constraint:
   // ALTROSolver::SetConstraint with a general callback pair, altro_solver.cpp:192-223); 0 for c = G [x;u] - g
-  int user[AL_MAXC];
-  // the block's Jacobian in the zero-padded pool AlTable::Gpad (plan MFMA16's row-layout kernels): def index * AL_GP_DEF
-  int Gp_off[AL_MAXC];
+  int user[AL_TILE_MAXC];
+  // the slot's Jacobian in the zero-padded pool AlTable::Gpad (plan MFMA16's row-layout kernels): slot definition index * AL_GP_DEF
+  int Gp_off[AL_TILE_MAXC];
 };
 struct AlKnotBig {       // the host's record of a knot point on every plan, and plan GENERIC's device table entry
   int ncon;
@@ -68,6 +76,7 @@ struct AlTable {
   int Gpad_count;        // its elements
   int all_sel;           // every block is bound-type (AlKnot::sel): the Gauss-Newton blocks are diagonal
   int has_soc;           // some block is a second-order cone (kernels instantiated without the cone's code serve handles that have none)
+  int max_ncon = 0;      // most blocks / slots any knot point has (plan MFMA16: above AL_MAXC the merit kernel's wide instantiation runs)
 };
 #define ALTRO_CONST_AS __attribute__((address_space(4)))
 // table entry and dual-row shift for knot point k

@@ -160,11 +160,11 @@ __device__ __forceinline__ void md_gather4(double v, double (&o)[4]) {
 // (DU: DualUpdate, knotpoint_data.cpp:503-510 -- the projected dual becomes the dual; `store`: this row has a problem of its own)
 template <typename S, bool DU = false, bool SOC = true>
 __device__ __forceinline__ void dpp_al_rows(const AlTable<S>& t, int k, int b, int64_t B, double w, bool terminal, double rho_est, int j,
-                                            double (&jvr)[AL_MAXC], double& cost, double& viol, bool store = false) {
+                                            double (&jvr)[AL_TILE_MAXC], double& cost, double& viol, bool store = false) {
   int zshift;
   const AlKnot ALTRO_CONST_AS& kn = al_knot<S>(t, k, zshift);
 #pragma unroll
-  for (int c = 0; c < AL_MAXC; ++c) {
+  for (int c = 0; c < AL_TILE_MAXC; ++c) {
     jvr[c] = 0.0;
     if (c >= kn.ncon) continue;                     // (wave-uniform: the table is the handle's)
     const int p = kn.p[c], cone = kn.cone[c];
@@ -232,25 +232,27 @@ __device__ __forceinline__ void dpp_al_rows(const AlTable<S>& t, int k, int b, i
 //   cost share + 0, violation max(., 0), J^T z_proj = 0).
 // Same values, same expressions, same order of the sums as dpp_al_rows (and as wave_al_rows / wave_al_col of the LDS form):
 // bit-identical (tests/test_gpu_merit2.py).
+// (NC: the slots the instantiation carries -- AL_MAXC = 2, today's kernels register for register, or AL_TILE_MAXC; al_types.h)
+template <int NC>
 struct AlpKnot {
-  int ncon, p[AL_MAXC], cone[AL_MAXC], gp_off[AL_MAXC], z_off[AL_MAXC], gpp[AL_MAXC];
-  int64_t g_off[AL_MAXC];
+  int ncon, p[NC], cone[NC], gp_off[NC], z_off[NC], gpp[NC];
+  int64_t g_off[NC];
 };
-template <typename S>
-__device__ __forceinline__ void alp_knot(const AlTable<S>& t, int k, AlpKnot& s) {
+template <typename S, int NC>
+__device__ __forceinline__ void alp_knot(const AlTable<S>& t, int k, AlpKnot<NC>& s) {
   const AlKnot ALTRO_CONST_AS& kn = *(const AlKnot ALTRO_CONST_AS*)(t.knots + k);
   s.ncon = kn.ncon;
 #pragma unroll
-  for (int c = 0; c < AL_MAXC; ++c) {
+  for (int c = 0; c < NC; ++c) {
     s.p[c] = kn.p[c]; s.cone[c] = kn.cone[c]; s.gp_off[c] = kn.Gp_off[c]; s.z_off[c] = kn.z_off[c]; s.gpp[c] = kn.g_per_problem[c];
     s.g_off[c] = kn.g_off[c];
   }
 }
 // (z_i, g_i) of the knot point whose entry is s (zshift: al_knot's, for uniform tables)
-template <typename S>
-__device__ __forceinline__ void alp_fetch(const AlTable<S>& t, const AlpKnot& s, int zshift, int b, int64_t B, int j, double (&zg)[AL_MAXC][2]) {
+template <typename S, int NC>
+__device__ __forceinline__ void alp_fetch(const AlTable<S>& t, const AlpKnot<NC>& s, int zshift, int b, int64_t B, int j, double (&zg)[NC][2]) {
 #pragma unroll
-  for (int c = 0; c < AL_MAXC; ++c) {
+  for (int c = 0; c < NC; ++c) {
     zg[c][0] = 0.0; zg[c][1] = 0.0;
     if (c >= s.ncon) continue;
     const bool rl = j < s.p[c];
@@ -260,11 +262,11 @@ __device__ __forceinline__ void alp_fetch(const AlTable<S>& t, const AlpKnot& s,
   }
 }
 // rowb: min(lane of the row, 8) * AL_GP_LD;  pre: this knot point's (z_i, g_i)
-template <bool SOC>
-__device__ __forceinline__ void alp_rows(const AlpKnot& s, double w, double rho_est, int j, int rowb, double (&jvr)[AL_MAXC], double& cost,
-                                         double& viol, const double* Gp, const double (&pre)[AL_MAXC][2]) {
+template <bool SOC, int NC>
+__device__ __forceinline__ void alp_rows(const AlpKnot<NC>& s, double w, double rho_est, int j, int rowb, double (&jvr)[NC], double& cost,
+                                         double& viol, const double* Gp, const double (&pre)[NC][2]) {
 #pragma unroll
-  for (int c = 0; c < AL_MAXC; ++c) {
+  for (int c = 0; c < NC; ++c) {
     jvr[c] = 0.0;
     if (c >= s.ncon) continue;                      // (wave-uniform)
     const int p = s.p[c], cone = s.cone[c];
@@ -306,10 +308,11 @@ __device__ __forceinline__ void alp_rows(const AlpKnot& s, double w, double rho_
     }
   }
 }
-__device__ __forceinline__ double alp_col(const AlpKnot& s, int j, const double (&jvr)[AL_MAXC], const double* Gp) {
+template <int NC>
+__device__ __forceinline__ double alp_col(const AlpKnot<NC>& s, int j, const double (&jvr)[NC], const double* Gp) {
   double sum = 0.0;
 #pragma unroll
-  for (int c = 0; c < AL_MAXC; ++c) {
+  for (int c = 0; c < NC; ++c) {
     if (c >= s.ncon) continue;
     const double* Gc = Gp + s.gp_off[c] + j;
     double cC[8];
@@ -346,8 +349,9 @@ namespace altro_hip {
 // line-search round then costs a chunk's walk (16 knot points) instead of the horizon's (256 for C1: 0.36 ms however few problems
 // search).  The trial points equal the rollout's to rounding (1e-13), not bit for bit -- like everything on this plan.
 constexpr int MD_AFF_CHUNK = 16;                    // even (the image ping-pong is the parity of k)
-template <typename S, bool AL, bool DUAL, bool DENSE = false, int MK = 0, bool SOC = true, bool AFF = false>
-__global__ __launch_bounds__(64, ((MK != 0 || (AL && DENSE && sizeof(S) == 8)) ? 1 : 2)) void wave_merit_dpp_kernel(IlqrWaveArgs<S> a) {
+template <typename S, bool AL, bool DUAL, bool DENSE = false, int MK = 0, bool SOC = true, bool AFF = false, int NC = AL_MAXC>
+__global__ __launch_bounds__(64, ((MK != 0 || (AL && DENSE && sizeof(S) == 8) || NC > 4) ? 1 : 2)) void wave_merit_dpp_kernel(IlqrWaveArgs<S> a) {
+  static_assert(NC >= AL_MAXC && NC <= AL_TILE_MAXC, "two to AL_TILE_MAXC slots per knot point");
   static_assert(!AFF || (!DUAL && MK == 0), "affine trials: the single-trial rounds of dynamics given as data");
   constexpr bool NOZ = MK != 0 || AFF;              // Z and f are neither loaded nor staged
   constexpr int DEPTH = 2;                          // also the image ping-pong: parity of k == dd
@@ -405,7 +409,7 @@ __global__ __launch_bounds__(64, ((MK != 0 || (AL && DENSE && sizeof(S) == 8)) ?
     for (int e = lane; e < a.al.Gpad_count; e += 64) Gdyn[e] = (double)a.al.Gpad[e];
   const bool al_uni = al && a.al.uniform != 0;
   const int rowb = (j < 8 ? j : 8) * AL_GP_LD;
-  AlpKnot kc_s, kn_s;                               // the table entries of the knot point in hand and of the next (scalar registers)
+  AlpKnot<NC> kc_s, kn_s;                           // the table entries of the knot point in hand and of the next (scalar registers)
   const bool isx = j < 12;
   const bool cand = DUAL ? (h == 1 && wr) : row_on; // DUAL: trial 1 writes the candidate trajectory and the expansion
   const bool wqr = DUAL ? cand : (row_on && deriv && store);
@@ -439,11 +443,11 @@ __global__ __launch_bounds__(64, ((MK != 0 || (AL && DENSE && sizeof(S) == 8)) ?
   double x = isx ? (double)a.x0[(size_t)b * 12 + j] : 0.0;
   double dxda = 0.0;
   double J = 0.0, Jal = 0.0, dJ = 0.0, res = 0.0, viol = 0.0;   // (Jal: the constraint rows' cost shares, lanes 0..7)
-  double jvr[AL_MAXC] = {0.0, 0.0};
-  double zg[AL_MAXC][2] = {{0.0, 0.0}, {0.0, 0.0}};   // (z_i, g_i) of the knot point in hand
+  double jvr[NC] = {0.0, 0.0};
+  double zg[NC][2] = {{0.0, 0.0}, {0.0, 0.0}};   // (z_i, g_i) of the knot point in hand
   if (al) {
-    alp_knot<S>(a.al, al_uni ? 0 : kb, kc_s); kn_s = kc_s;
-    alp_fetch<S>(a.al, kc_s, al_uni ? kb * a.al.rows_per_knot : 0, b, a.batch, j, zg);
+    alp_knot<S, NC>(a.al, al_uni ? 0 : kb, kc_s); kn_s = kc_s;
+    alp_fetch<S, NC>(a.al, kc_s, al_uni ? kb * a.al.rows_per_knot : 0, b, a.batch, j, zg);
   }
   double lprev = 0.0, yprev = 0.0;                  // gradient and y of knot point k - 1 (the stationarity's lag)
   MeritPairRegs<DENSE> ring[DEPTH];
@@ -493,16 +497,24 @@ __global__ __launch_bounds__(64, ((MK != 0 || (AL && DENSE && sizeof(S) == 8)) ?
     if (al) {   // both trials' constraint rows at the candidate point [x; u]; the feasibility that counts is trial 1's
       double Ja = 0.0, vv = 0.0;
       if (live) {
-        double zgn[AL_MAXC][2];
-        if (k + 1 >= N) alp_knot<S>(a.al, N, kn_s);           // (k + 1 <= N: the terminal knot point's too)
-        else if (!al_uni) alp_knot<S>(a.al, k + 1, kn_s);
-        alp_fetch<S>(a.al, kn_s, (al_uni && k + 1 < N) ? (k + 1) * a.al.rows_per_knot : 0, b, a.batch, j, zgn);
-        alp_rows<SOC>(kc_s, w, rho, j, rowb, jvr, Ja, vv, Gdyn, zg);
+        if (k + 1 >= N) alp_knot<S, NC>(a.al, N, kn_s);           // (k + 1 <= N: the terminal knot point's too)
+        else if (!al_uni) alp_knot<S, NC>(a.al, k + 1, kn_s);
+        if constexpr (NC > AL_MAXC) {
+          // the wide tables: the next knot point's (z_i, g_i) are asked for AFTER this one's have been used, into the same registers --
+          // the loads then have the rest of this step and the head of the next to land in, and four slots cost 16 registers less
+          // than with a second set (what keeps the four-slot instantiation at two waves per SIMD without spills; six slots run one)
+          alp_rows<SOC, NC>(kc_s, w, rho, j, rowb, jvr, Ja, vv, Gdyn, zg);
+          alp_fetch<S, NC>(a.al, kn_s, (al_uni && k + 1 < N) ? (k + 1) * a.al.rows_per_knot : 0, b, a.batch, j, zg);
+        } else {
+          double zgn[NC][2];
+          alp_fetch<S, NC>(a.al, kn_s, (al_uni && k + 1 < N) ? (k + 1) * a.al.rows_per_knot : 0, b, a.batch, j, zgn);
+          alp_rows<SOC, NC>(kc_s, w, rho, j, rowb, jvr, Ja, vv, Gdyn, zg);
 #pragma unroll
-        for (int c = 0; c < AL_MAXC; ++c) { zg[c][0] = zgn[c][0]; zg[c][1] = zgn[c][1]; }
+          for (int c = 0; c < NC; ++c) { zg[c][0] = zgn[c][0]; zg[c][1] = zgn[c][1]; }
+        }
         Jal += Ja;
       } else {
-        alp_rows<SOC>(kc_s, w, rho, j, rowb, jvr, Ja, vv, Gdyn, zg);   // a padding step: discarded
+        alp_rows<SOC, NC>(kc_s, w, rho, j, rowb, jvr, Ja, vv, Gdyn, zg);   // a padding step: discarded
       }
       if (cand && live) viol = fmax(viol, vv);               // (live: a padding step's point is not on the trajectory)
     }
@@ -619,10 +631,10 @@ __global__ __launch_bounds__(64, ((MK != 0 || (AL && DENSE && sizeof(S) == 8)) ?
     if (al) {
       double Ja = 0.0, vv = 0.0;
       if constexpr (DUAL) {
-        alp_rows<SOC>(kc_s, isx ? x : 0.0, rho, j, rowb, jvr, Ja, vv, Gdyn, zg);
+        alp_rows<SOC, NC>(kc_s, isx ? x : 0.0, rho, j, rowb, jvr, Ja, vv, Gdyn, zg);
         Jal += Ja;
       } else {   // (wave_merit_kernel adds the terminal blocks' shares to its running sum one by one)
-        alp_rows<SOC>(kc_s, isx ? x : 0.0, rho, j, rowb, jvr, Jal, vv, Gdyn, zg);
+        alp_rows<SOC, NC>(kc_s, isx ? x : 0.0, rho, j, rowb, jvr, Jal, vv, Gdyn, zg);
       }
       if (cand) viol = fmax(viol, vv);
     }
@@ -783,7 +795,8 @@ __device__ __forceinline__ void md_cross_rows(double (&tile)[16], const double (
 // BOUNDS: every block of the handle is bound-type (rows +-e_idx: AlTable::all_sel) and the cost is diagonal -- the Hessian blocks
 // are then diagonal: diag(Qd, Rd) + rho * (active rows per variable).  No 16 x 16 tile is formed; and once a solve has stored the
 // full blocks, later expansions store the diagonal only (EXPAND_DIAG: what is off it cannot have changed).
-template <typename S, bool DENSE = false, bool BOUNDS = false>
+// NC: the constraint slots of a knot point the instantiation loops over (AL_MAXC, or AL_TILE_MAXC: ilqr_launch_mfma16_wide.hip)
+template <typename S, bool DENSE = false, bool BOUNDS = false, int NC = AL_MAXC>
 __global__ __launch_bounds__(64) void wave_expand_dpp_kernel(IlqrWaveArgs<S> a) {
   static_assert(!(DENSE && BOUNDS), "the diagonal form is the diagonal cost's");
   const int lane = threadIdx.x, j = lane & 15;
@@ -847,7 +860,7 @@ __global__ __launch_bounds__(64) void wave_expand_dpp_kernel(IlqrWaveArgs<S> a) 
   double scol = 0.0;
   bool tile_counts = true;
 #pragma unroll
-  for (int cidx = 0; cidx < AL_MAXC; ++cidx) {
+  for (int cidx = 0; cidx < NC; ++cidx) {
     if (cidx >= kn.ncon) continue;
     const int p = kn.p[cidx], cone = kn.cone[cidx];
     // row min(j, 8) and column j of the block from the zero-padded pool (al_types.h: AL_GP_DEF; rows >= p are zero, and at the
@@ -855,13 +868,35 @@ __global__ __launch_bounds__(64) void wave_expand_dpp_kernel(IlqrWaveArgs<S> a) 
     const S* Gp = a.al.Gpad + kn.Gp_off[cidx];
     const bool rl = j < p;
     const int jr = rl ? j : 0;
-    double cG[16], cC[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { const md_d2 v = md_ld<S>(Gp + (j < 8 ? j : 8) * AL_GP_LD, e); cG[2 * e] = v[0]; cG[2 * e + 1] = v[1]; }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) cC[i] = (double)Gp[i * AL_GP_LD + j];
+    double cC[8];
     double sacc = 0.0;
-    md_chain16(sacc, w, cG);
+    if constexpr (BOUNDS) {
+      // every row of the slot is +-e_idx (AlKnot::sidx, scalar registers): nothing of G is loaded.  Row i's value is +-w_idx -- the
+      // 16-term chain would add that one product to fifteen exact zeros -- fetched from lane idx of this lane's row of sixteen; column
+      // j's entries are the signs of the rows that select j.  (The pool's loads were what bound this kernel: 16 vector loads per slot
+      // and wave through the CU's one texture path -- C1 with an input box and a state box, four slots: 1.0 ms; like this: see DESIGN.)
+      int sx = 0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int si = kn.sidx[cidx][i];                       // (rows >= p: never read -- i < p below)
+        if (i < p) {
+          if (j == i) sx = si;
+          cC[i] = (j == (si < 0 ? -si : si) - 1) ? (si < 0 ? -1.0 : 1.0) : 0.0;
+        } else {
+          cC[i] = 0.0;
+        }
+      }
+      const int idx = (sx < 0 ? -sx : sx) - 1;                 // (lanes without a row: sx = 0, idx = -1 -> their own lane, value unused)
+      const double wsel = __shfl(w, idx < 0 ? j : idx, 16);
+      sacc = (sx == 0) ? 0.0 : (sx < 0 ? -wsel : wsel);
+    } else {
+      double cG[16];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const md_d2 v = md_ld<S>(Gp + (j < 8 ? j : 8) * AL_GP_LD, e); cG[2 * e] = v[0]; cG[2 * e + 1] = v[1]; }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) cC[i] = (double)Gp[i * AL_GP_LD + j];
+      md_chain16(sacc, w, cG);
+    }
     const double gi = rl ? (kn.g_per_problem[cidx] ? (double)a.al.g[kn.g_off[cidx] + (int64_t)jr * a.batch + b] : (double)a.al.g[kn.g_off[cidx] + jr]) : 0.0;
     const double val = sacc - gi;
     S* const zp_ = a.al.z + (int64_t)(kn.z_off[cidx] + zshift + jr) * a.batch + b;
@@ -1012,7 +1047,7 @@ __global__ __launch_bounds__(64) void wave_dual_update_dpp_kernel(IlqrWaveArgs<S
   const bool terminal = k == a.N;
   const S* c = a.cand + (size_t)b * a.xuy_bs + (size_t)k * a.xuy_ks;
   const double w = j < 12 ? (double)c[j] : (terminal ? 0.0 : (double)c[12 + j]);
-  double jvr[AL_MAXC], cost = 0.0, viol = 0.0;
+  double jvr[AL_TILE_MAXC], cost = 0.0, viol = 0.0;
   dpp_al_rows<S, true>(a.al, k, b, a.batch, w, terminal, a.prob[b].rho_est, j, jvr, cost, viol, on);
 }
 // One wave per (four problems, knot point), like the dual update; the maximum over the knot points is an atomic maximum on the
@@ -1033,7 +1068,7 @@ __global__ __launch_bounds__(64) void wave_feasibility_dpp_kernel(IlqrWaveArgs<S
   const bool terminal = k == a.N;
   const S* c = a.cand + (size_t)b * a.xuy_bs + (size_t)k * a.xuy_ks;
   const double w = j < 12 ? (double)c[j] : (terminal ? 0.0 : (double)c[12 + j]);
-  double jvr[AL_MAXC], cost = 0.0, viol = 0.0;
+  double jvr[AL_TILE_MAXC], cost = 0.0, viol = 0.0;
   dpp_al_rows<S>(a.al, k, b, a.batch, w, terminal, a.prob[b].rho, j, jvr, cost, viol);
 #pragma unroll
   for (int o = 8; o > 0; o >>= 1) viol = fmax(viol, __shfl_xor(viol, o, 64));

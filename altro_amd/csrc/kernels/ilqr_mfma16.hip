@@ -62,7 +62,7 @@ __device__ __forceinline__ void wave_al_rows(const AlTable<S>& t, int k, int b, 
   const int i = lane - ROW0;
   const bool row_lane = (i >= 0 && i < AL_MAXP);
 #pragma unroll
-  for (int c = 0; c < AL_MAXC; ++c) {
+  for (int c = 0; c < AL_TILE_MAXC; ++c) {
     const bool has = c < kn.ncon;
     const int p = has ? kn.p[c] : 0, cone = has ? kn.cone[c] : CONE_IDENTITY;
     const S* G = t.G + (has ? kn.G_off[c] : 0);
@@ -148,7 +148,7 @@ __device__ __forceinline__ double wave_al_col(const AlTable<S>& t, int k, int e,
   const AlKnot ALTRO_CONST_AS& kn = al_knot<S>(t, k, zshift);
   double s = 0.0;
 #pragma unroll
-  for (int c = 0; c < AL_MAXC; ++c)
+  for (int c = 0; c < AL_TILE_MAXC; ++c)
     if (c < kn.ncon) {
       const int p = kn.p[c];
       const S* G = t.G + kn.G_off[c];
@@ -325,7 +325,7 @@ __global__ void wave_expand_grad_dense_kernel(IlqrWaveArgs<S> a) {
 //                    set by altro_hip_set_tracking_cost stay as they are.
 template <typename S>
 __global__ __launch_bounds__(64) void wave_expand_kernel(IlqrWaveArgs<S> a) {
-  __shared__ double xs[12], us[4], jv[AL_MAXC * AL_MAXP], Jm[AL_MAXC * 64], Hm[AL_MAXC * 16];
+  __shared__ double xs[12], us[4], jv[AL_TILE_MAXC * AL_MAXP], Jm[AL_TILE_MAXC * 64], Hm[AL_TILE_MAXC * 16];
   const int lane = threadIdx.x;
   const int64_t wk = blockIdx.x;
   const int b = (int)(wk % a.batch), k = (int)(wk / a.batch);
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(64) void wave_expand_kernel(IlqrWaveArgs<S> a) {
 // DualUpdate (knotpoint_data.cpp:503-510) for the problems whose sweep asked for it, one wave per (problem, knot point)
 template <typename S>
 __global__ __launch_bounds__(64) void wave_dual_update_kernel(IlqrWaveArgs<S> a) {
-  __shared__ double xs[12], us[4], jv[AL_MAXC * AL_MAXP], Jm[AL_MAXC * 64], Hm[AL_MAXC * 16];
+  __shared__ double xs[12], us[4], jv[AL_TILE_MAXC * AL_MAXP], Jm[AL_TILE_MAXC * 64], Hm[AL_TILE_MAXC * 16];
   const int lane = threadIdx.x;
   const int64_t wk = blockIdx.x;
   const int b = (int)(wk % a.batch), k = (int)(wk / a.batch);
@@ -473,7 +473,7 @@ template <typename S, bool AL>
 __global__ __launch_bounds__(64) void wave_merit_kernel(IlqrWaveArgs<S> a) {
   constexpr int DEPTH = 2;
   __shared__ double img[MW_IMG + 4];
-  __shared__ double vec[24], das[12], us[4], dus[4], jv[AL_MAXC * AL_MAXP];   // vec = x | dx
+  __shared__ double vec[24], das[12], us[4], dus[4], jv[AL_TILE_MAXC * AL_MAXP];   // vec = x | dx
   double* const xs = vec;
   double* const dxs = vec + 12;
   __shared__ double crec[28], qrec[16];     // candidate record x | y | u and [lx lu], gathered for one coalesced store
@@ -693,7 +693,7 @@ __global__ __launch_bounds__(64) void wave_stationarity_kernel(IlqrWaveArgs<S> a
   double viol = 0.0;
   const bool feas_here = (a.mode & STAT_NO_FEAS) == 0;
   if (a.al.enabled && feas_here) {
-    __shared__ double xs[12], us[4], jv[AL_MAXC * AL_MAXP], Jm[AL_MAXC * 64], Hm[AL_MAXC * 16];
+    __shared__ double xs[12], us[4], jv[AL_TILE_MAXC * AL_MAXP], Jm[AL_TILE_MAXC * 64], Hm[AL_TILE_MAXC * 16];
     const double rho = a.prob[b].rho;
     for (int k = 0; k <= N; ++k) {
       const S* c = a.cand + (size_t)b * a.xuy_bs + (size_t)k * a.xuy_ks;

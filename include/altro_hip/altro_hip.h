@@ -294,10 +294,15 @@ int altro_hip_get_expansion(altro_hip_batch* h, double* A, double* B, double* lx
  * 3 SECOND_ORDER_CONE (||c[0:p-1]|| <= c[p-1]).
  * Capacity (the reference appends constraints without limit, knotpoint_data.cpp:155-161; going past a limit here is an error that
  * names it, never a truncation):
- *   plan GENERIC       8 blocks per knot point, p <= 64 rows per block (SOC: p <= 4), 64 blocks per handle -- e.g. a (12, 4) problem
- *                      with an input box (8 rows), a state box (24 rows) and more; create the handle with ALTRO_HIP_PLAN_GENERIC;
- *   plans LANE, MFMA16 2 blocks per knot point, p <= 8 (SOC: p <= 4), 16 blocks per handle (the blocks ride fixed lanes / registers of
- *                      the fast kernels); rows of one cone can be stacked into one block.
+ *   plan GENERIC       8 blocks per knot point, p <= 64 rows per block (SOC: p <= 4), 64 blocks per handle;
+ *   plan MFMA16        (the (12, 4) tile, fp64) 6 SLOTS of 8 rows per knot point -- a block in the zero / identity / orthant cones
+ *                      takes ceil(p / 8) consecutive slots (p <= 48: those cones project row by row, so the host lays the rows out;
+ *                      duals stay [p] per block), a second-order cone (p <= 4) one -- and 32 slots per handle: e.g. an input box
+ *                      (8 rows) and a state box (24 rows) at every knot point with two slots to spare.  Knot points with up to 2 / 4 /
+ *                      6 slots run the merit kernel's 2- / 4- / 6-slot instantiation (the last at one wave per SIMD: C1 with both
+ *                      boxes solves in 1.27 x the time of the input box alone).  fp32 records: 2 slots;
+ *   plan LANE          2 blocks per knot point, p <= 8 (SOC: p <= 4), 16 blocks per handle (the blocks ride registers of the
+ *                      lane-per-problem kernels); rows of one cone can be stacked into one block.
  * Returns the block id (>= 0) or a negative error.  Duals and penalties live on the device per problem and,
  * like the reference's, persist from one solve to the next (warm-started MPC) until reset.  Every plan (GENERIC: n, m <= 64,
  * one wave per knot point).                                                                              */

@@ -2,7 +2,10 @@
 """C1 (BASELINE.json configs[1]: N = 256, n = 12, m = 4, 4096 problems) as whole iLQR solves on plan MFMA16: wall time per
 altro_hip_ilqr_solve (host clock, stream drained), for A/B runs (ALTRO_HIP_MERIT2=0/1) and for rocprofv3 --kernel-trace.
 
-    python tools/c1_solve.py [solves] [batch] [horizon] [--al] [--alternate=ENV_SWITCH]
+    python tools/c1_solve.py [solves] [batch] [horizon] [--al] [--boxes] [--generic] [--alternate=ENV_SWITCH]
+
+--boxes: the input box of --al AND a state box |x| <= 1.2 (24 rows) at every running knot point -- four of plan MFMA16's six slots
+(kernels/al_types.h); --generic: the same problem on plan GENERIC (where it had to live up to round 5).
 """
 import os
 import sys
@@ -21,10 +24,11 @@ def main():
     solves = int(args[0]) if len(args) > 0 else 9
     batch = int(args[1]) if len(args) > 1 else 4096
     N = int(args[2]) if len(args) > 2 else 256
-    al = "--al" in sys.argv
+    boxes = "--boxes" in sys.argv
+    al = "--al" in sys.argv or boxes
     n, m = 12, 4
     one = problems.c1_double_integrator(1, N=N)
-    bt = altro_amd.Batch(N, n, m, batch)
+    bt = altro_amd.Batch(N, n, m, batch, plan=altro_amd.PLAN_GENERIC if "--generic" in sys.argv else altro_amd.PLAN_AUTO)
     bt.set_dynamics(one["A"][0, :1], one["B"][0, :1], None, k_stride_zero=True, batch_stride_zero=True)
     bt.set_tracking_cost(np.stack([np.ones(n), 100.0 * np.ones(n)]), np.full((1, m), 1e-2), np.zeros((2, n)), np.zeros((1, m)),
                          k_stride_zero=True, batch_stride_zero=True)
@@ -32,6 +36,9 @@ def main():
     if al:   # input bounds as an INEQUALITY block: the AL path of the same shape
         G = np.zeros((2 * m, n + m)); G[:m, n:] = np.eye(m); G[m:, n:] = -np.eye(m)
         bt.add_linear_constraint(0, N - 1, altro_amd.CONE_INEQUALITY, G, np.full(2 * m, 2.0))
+    if boxes:
+        Gx = np.zeros((2 * n, n + m)); Gx[:n, :n] = np.eye(n); Gx[n:, :n] = -np.eye(n)
+        bt.add_linear_constraint(int(os.environ.get("C1_XBOX_K0", "0")), N - 1, altro_amd.CONE_INEQUALITY, Gx, np.full(2 * n, float(os.environ.get("C1_XBOX", "1.2"))))
     alternate = [a.split("=")[1] for a in sys.argv if a.startswith("--alternate=")]   # an environment switch flipped 1 / 0 per solve
     ts = []
     for i in range(solves + 1):
@@ -48,7 +55,7 @@ def main():
     ts = sorted(ts[1:])
     print("C1 solve%s, %d problems, N = %d, ALTRO_HIP_MERIT2=%s: median %.3f ms (min %.3f, max %.3f) over %d solves; sweeps %d, "
           "merit launches %d, converged %d, max stationarity %.2e"
-          % (" + input bounds" if al else "", batch, N, os.environ.get("ALTRO_HIP_MERIT2", "unset"), ts[len(ts) // 2], ts[0], ts[-1],
+          % ((" + input box + state box, plan %d" % bt.plan) if boxes else " + input bounds" if al else "", batch, N, os.environ.get("ALTRO_HIP_MERIT2", "unset"), ts[len(ts) // 2], ts[0], ts[-1],
              len(ts), res["sweeps"], res["merit_launches"], int((res["status"] == 0).sum()), float(np.abs(res["stationarity"]).max())))
     bt.close()
 
