@@ -392,6 +392,7 @@ ErrorCodes SolverImpl::Initialize() {
   tab(pQuxt, &Knot::Qux_t); tab(pQxt, &Knot::Qx_t); tab(pQut, &Knot::Qu_t);
   tab(px, &Knot::x_); tab(pu, &Knot::u_); tab(py, &Knot::y_);
   for (int k = 0; k <= N; ++k) { nx[k] = data[k].n; nu[k] = data[k].m; }
+  (void)tvlqr_hip_warmup(nx.data(), nu.data(), N);   // device, kernels and workspace now, not in the first Solve (a missing device shows in Solve)
   initialized = true;
   return ErrorCodes::NoError;
 }

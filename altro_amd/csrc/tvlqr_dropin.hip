@@ -7,6 +7,10 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+
 #include <cstring>
 #include <vector>
 
@@ -73,6 +77,31 @@ struct Workspace {
 };
 thread_local Workspace g_ws;
 
+// ALTRO_TVLQR_DROPIN_STATS=1: where a tvlqr_BackwardPass call spends its time -- layout + workspace, staging + launches + the wait,
+// the scatter into the caller's blocks -- summed over the process and printed at exit (tests/test_gpu_scotty.py shows it).
+struct SeamStats {
+  bool on = std::getenv("ALTRO_TVLQR_DROPIN_STATS") != nullptr;
+  double us[3] = {0, 0, 0};
+  long calls = 0;
+  ~SeamStats() {
+    if (on && calls)
+      std::fprintf(stderr, "tvlqr_BackwardPass seam: %ld calls, per call %.1f us layout + workspace, %.1f us staging + launches + wait, "
+                           "%.1f us scatter\n", calls, us[0] / calls, us[1] / calls, us[2] / calls);
+  }
+};
+SeamStats g_seam_stats;
+struct SeamClock {
+  std::chrono::steady_clock::time_point t;
+  SeamClock() { if (g_seam_stats.on) t = std::chrono::steady_clock::now(); }
+  void lap(int i) {
+    if (!g_seam_stats.on) return;
+    const auto now = std::chrono::steady_clock::now();
+    g_seam_stats.us[i] += std::chrono::duration<double, std::micro>(now - t).count();
+    t = now;
+    if (i == 2) ++g_seam_stats.calls;
+  }
+};
+
 bool have_device() {
   int c = 0;
   return hipGetDeviceCount(&c) == hipSuccess && c > 0;
@@ -114,7 +143,7 @@ int64_t block_size(int arr, int n, int m, int n2, bool is_diag) {
 
 // Arena order: [A B f of every k] [Q R H q r of every k] [K d P p of every k] [everything else] [x0 | delta_V | status].
 // The backward pass's inputs are the first two groups, the forward pass's the first three: one contiguous copy each.
-Layout make_layout(const int* nx, const int* nu, int N, bool is_diag) {
+Layout build_layout(const int* nx, const int* nu, int N, bool is_diag) {
   Layout L;
   L.N = N;
   L.off.assign((size_t)(N + 1) * G_NUM, 0);
@@ -139,6 +168,29 @@ Layout make_layout(const int* nx, const int* nu, int N, bool is_diag) {
   L.xstage = std::max(32, (L.nmax + 3) & ~3);
   L.total = cur + L.xstage + 4;   // + x0 staging + delta_V[2] (+pad) at the end
   return L;
+}
+
+// A solver calls the seam with the same dimensions sweep after sweep: the layout of the last call is kept per thread and found
+// again by comparing the dimension arrays (N = 30, (4, 2): building it took 48 of a call's 140 us -- the clock of
+// ALTRO_TVLQR_DROPIN_STATS through tests/cpp/bicycle_mpc_test.cpp).
+struct LayoutCache {
+  Layout L;
+  std::vector<int> nx, nu;
+  bool is_diag = false, valid = false;
+};
+thread_local LayoutCache g_layout[2];   // [0]: the backward pass's, [1]: the forward pass's (always dense)
+const Layout& make_layout(const int* nx, const int* nu, int N, bool is_diag, int slot = 0) {
+  LayoutCache& c = g_layout[slot];
+  if (c.valid && c.L.N == N && c.is_diag == is_diag && std::memcmp(c.nx.data(), nx, sizeof(int) * (size_t)(N + 1)) == 0 &&
+      (N == 0 || std::memcmp(c.nu.data(), nu, sizeof(int) * (size_t)N) == 0))
+    return c.L;
+  c.valid = false;
+  c.L = build_layout(nx, nu, N, is_diag);
+  c.nx.assign(nx, nx + N + 1);
+  c.nu.assign(nu, nu + N);
+  c.is_diag = is_diag;
+  c.valid = true;
+  return c.L;
 }
 
 int prepare(Workspace& w, const Layout& L, const int* nx, const int* nu) {
@@ -168,12 +220,15 @@ int prepare(Workspace& w, const Layout& L, const int* nx, const int* nu) {
     w.table_k = (size_t)(N + 1);
     w.off.clear(); w.dims.clear();
   }
-  std::vector<int> dims((size_t)(N + 1) * 2, 0);
-  for (int k = 0; k <= N; ++k) {
-    dims[k] = nx[k];
-    dims[(size_t)(N + 1) + k] = (k < N) ? nu[k] : 0;
-  }
-  if (dims != w.dims || L.off != w.off) {   // a new layout: upload its tables (the usual call finds them in place)
+  bool same = w.dims.size() == (size_t)(N + 1) * 2 && w.off.size() == L.off.size();
+  for (int k = 0; k <= N && same; ++k) same = w.dims[k] == nx[k] && w.dims[(size_t)(N + 1) + k] == ((k < N) ? nu[k] : 0);
+  if (same) same = std::memcmp(w.off.data(), L.off.data(), L.off.size() * sizeof(int64_t)) == 0;
+  if (!same) {
+    std::vector<int> dims((size_t)(N + 1) * 2, 0);
+    for (int k = 0; k <= N; ++k) {
+      dims[k] = nx[k];
+      dims[(size_t)(N + 1) + k] = (k < N) ? nu[k] : 0;
+    }   // a new layout: upload its tables (the usual call finds them in place)
     w.off.clear(); w.dims.clear();
     if (hipMemcpy(w.dev_off, L.off.data(), L.off.size() * sizeof(int64_t), hipMemcpyHostToDevice) != hipSuccess) return -1;
     if (hipMemcpy(w.dev_dims, dims.data(), dims.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return -1;
@@ -365,6 +420,8 @@ int fast_backward(Workspace& w, const Layout& L, int n, int m, int N, const doub
   double* d_outn = d_out + (size_t)N * e_out;
   double* d_dv = d_outn + e_term;
   int* d_status = reinterpret_cast<int*>(d_dv + 2);
+  // (Measured and not kept: the kernel reading its records from the pinned staging itself, no copy enqueued -- the single wave then
+  //  waits on the bus at every knot point: 85 -> 101-107 us per call at N = 30, (4, 2); profiles/r06g_scotty_seam.txt.)
   if (hipMemcpyAsync(d_in, fw.host, in_elems * sizeof(double), hipMemcpyHostToDevice, w.stream) != hipSuccess) return 1;
   LaneArgs<double> a{d_in, d_term, d_out, d_outn, nullptr, nullptr, d_dv, d_status, N, 1, reg, nullptr, nullptr};
   bool done = false;
@@ -574,10 +631,12 @@ int tvlqr_BackwardPass(const int* nx, const int* nu, int num_horizon, const lqr_
   if (!have_device()) return TVLQR_NO_DEVICE;
   const int N = num_horizon;
   if (!dims_supported(nx, nu, N)) return TVLQR_UNSUPPORTED_SIZE;
+  SeamClock clk;
   Workspace& w = g_ws;
-  const Layout L = make_layout(nx, nu, N, is_diag);
+  const Layout& L = make_layout(nx, nu, N, is_diag, 0);
   if (prepare(w, L, nx, nu)) return TVLQR_NO_DEVICE;
   double* hs = w.host;
+  clk.lap(0);
   int fn = 0, fm = 0;
   const bool fast = (fast_shape(nx, nu, N, &fn, &fm) && fast_backward(w, L, fn, fm, N, A, B, f, Q, R, H, q, r, reg, is_diag) == 0) ||
                     (tile_shape(nx, nu, N, &fn, &fm) && tile_backward(w, L, fn, fm, N, A, B, f, Q, R, H, q, r, reg, is_diag) == 0);
@@ -623,6 +682,7 @@ int tvlqr_BackwardPass(const int* nx, const int* nu, int num_horizon, const lqr_
   if (hipGetLastError() != hipSuccess) return TVLQR_NO_DEVICE;
   if (hipStreamSynchronize(w.stream) != hipSuccess) return TVLQR_NO_DEVICE;
   }
+  clk.lap(1);
   int status;
   memcpy(&status, hs + L.total - 2, sizeof(int));
   auto get = [&](int arr, int k, double* dst, int64_t cnt) {
@@ -654,7 +714,42 @@ int tvlqr_BackwardPass(const int* nx, const int* nu, int num_horizon, const lqr_
   }
   delta_V[0] = hs[L.total - 4];
   delta_V[1] = hs[L.total - 3];
+  clk.lap(2);
   return status;
+}
+
+// One throw-away backward pass on blocks of this shape (A = B = 0, Q = R = I): device initialisation, the code object's load, the
+// workspace, the pinned arenas and the layout tables happen here instead of inside the caller's first timed sweep
+// (SolverImpl::Initialize calls it: a 200-step MPC run of 0.17 s spent a third of its time there).  Uniform dimensions run the dense
+// form a solver uses; per-knot-point dimensions the diagonal form (one buffer of ones serves every block size).
+int tvlqr_hip_warmup(const int* nx, const int* nu, int num_horizon) {
+  if (!have_device()) return TVLQR_NO_DEVICE;
+  const int N = num_horizon;
+  if (N < 1 || !dims_supported(nx, nu, N)) return TVLQR_UNSUPPORTED_SIZE;
+  int nmax = 0, mmax = 0;
+  for (int k = 0; k <= N; ++k) { nmax = std::max(nmax, nx[k]); if (k < N) mmax = std::max(mmax, nu[k]); }
+  bool uniform = true;
+  for (int k = 0; k <= N && uniform; ++k) uniform = nx[k] == nmax && (k == N || nu[k] == mmax);
+  const size_t nn = (size_t)nmax * nmax, nm = (size_t)nmax * mmax, mm = (size_t)mmax * mmax;
+  std::vector<double> zero(std::max({nn, nm, mm, (size_t)1}), 0.0), In(nn, 0.0), Im(mm, 0.0), ones((size_t)std::max(nmax, mmax) + 1, 1.0);
+  for (int i = 0; i < nmax; ++i) In[(size_t)i * nmax + i] = 1.0;
+  for (int i = 0; i < mmax; ++i) Im[(size_t)i * mmax + i] = 1.0;
+  std::vector<const double*> pz(N + 1, zero.data()), pQ(N + 1, uniform ? In.data() : ones.data()), pR(N + 1, uniform ? Im.data() : ones.data());
+  const size_t each[14] = {nm, (size_t)mmax, nn, (size_t)nmax, nn, mm, nm, (size_t)nmax, (size_t)mmax, nn, mm, nm, (size_t)nmax, (size_t)mmax};
+  size_t tot = 0;
+  for (size_t e : each) tot += e;
+  std::vector<double> out((size_t)(N + 1) * tot + 1, 0.0);
+  std::vector<double*> slots[14];
+  double* cur = out.data();
+  for (int i = 0; i < 14; ++i) {
+    slots[i].assign(N + 1, nullptr);
+    for (int k = 0; k <= N; ++k) { slots[i][k] = cur; cur += each[i]; }
+  }
+  double dv[2];
+  return tvlqr_BackwardPass(nx, nu, N, pz.data(), pz.data(), pz.data(), pQ.data(), pR.data(), pz.data(), pz.data(), pz.data(), 0.0,
+                            slots[0].data(), slots[1].data(), slots[2].data(), slots[3].data(), dv, slots[4].data(), slots[5].data(),
+                            slots[6].data(), slots[7].data(), slots[8].data(), slots[9].data(), slots[10].data(), slots[11].data(),
+                            slots[12].data(), slots[13].data(), false, !uniform);
 }
 
 int tvlqr_ForwardPass(const int* nx, const int* nu, int num_horizon, const lqr_float* const* A,
@@ -665,7 +760,7 @@ int tvlqr_ForwardPass(const int* nx, const int* nu, int num_horizon, const lqr_f
   const int N = num_horizon;
   if (!dims_supported(nx, nu, N)) return TVLQR_UNSUPPORTED_SIZE;
   Workspace& w = g_ws;
-  const Layout L = make_layout(nx, nu, N, false);
+  const Layout& L = make_layout(nx, nu, N, false, 1);
   if (prepare(w, L, nx, nu)) return TVLQR_NO_DEVICE;
   double* hs = w.host;
   auto put = [&](int arr, int k, const double* src, int64_t cnt) {

@@ -77,3 +77,8 @@ int tvlqr_ForwardPass(
     tvlqr_blocks_out x,                                      /* [N+1] states           */
     tvlqr_blocks_out u,                                      /* [N]   inputs           */
     tvlqr_blocks_out y);                                     /* [N+1] co-states        */
+
+/* This library only (the reference has nothing to warm up): one throw-away backward pass on blocks of this shape, so that device
+ * initialisation, the kernels' load and the workspace allocation do not land in the caller's first sweep.  ALTROSolver::Initialize
+ * calls it.  Returns TVLQR_SUCCESS, TVLQR_NO_DEVICE or TVLQR_UNSUPPORTED_SIZE. */
+int tvlqr_hip_warmup(const int *nx, const int *nu, int num_horizon);
