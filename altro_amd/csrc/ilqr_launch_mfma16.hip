@@ -16,7 +16,7 @@ static int wave_launch(hipStream_t stream, int which, const IlqrWaveArgs<S>& a) 
   const dim3 flat((unsigned)std::min<int64_t>((flat_n + 255) / 256, 1 << 20));
   // more than two constraint slots at some knot point: the merit kernel's wide instantiation (ilqr_launch_mfma16_wide.hip)
   if ((which == IK_MERIT || which == IK_MERIT2) && a.al.enabled && a.al.max_ncon > AL_MAXC)
-    return a.al.max_ncon <= 4 ? ilqr_wave_launch_wide<S, 4>(stream, which, a) : ilqr_wave_launch_wide<S, AL_TILE_MAXC>(stream, which, a);
+    return ilqr_wave_launch_wide<S>(stream, which, a);
   if (a.mp.kind != MODEL_LINEAR) {   // a device model instead of dynamics as data: kernels/ilqr_tile_model.hip
     if (which == IK_ROLLOUT || which == IK_MERIT || which == IK_MERIT2) return ilqr_wave_launch_model<S>(stream, which, a);
     if (which == IK_EXPAND && (a.mode & EXPAND_DYN)) {
@@ -29,7 +29,7 @@ static int wave_launch(hipStream_t stream, int which, const IlqrWaveArgs<S>& a) 
     case IK_ACCEPT: hipLaunchKernelGGL(wave_accept_kernel<S>, flat, b256, 0, stream, a); break;
     case IK_EXPAND:
       if (a.al.enabled && a.al.max_ncon > AL_MAXC)
-        return a.al.max_ncon <= 4 ? ilqr_wave_launch_wide<S, 4>(stream, IK_EXPAND, a) : ilqr_wave_launch_wide<S, AL_TILE_MAXC>(stream, IK_EXPAND, a);
+        return ilqr_wave_launch_wide<S>(stream, IK_EXPAND, a);
       if (a.cost_dense) {   // the dense quadratic cost: row-layout kernels only (capi_ilqr.hip keeps EXPAND_LDS off)
         const int64_t blocks = ((int64_t)a.batch * (a.N + 1) * 16 + 255) / 256;
         if (a.al.enabled) hipLaunchKernelGGL((wave_expand_dpp_kernel<S, true>), dim3((unsigned)((int64_t)((a.batch + 3) / 4) * (a.N + 1))), b64, 0, stream, a);

@@ -1,9 +1,10 @@
 // Kernel instantiations of plan MFMA16's merit and expansion passes for handles with more than AL_MAXC constraint slots at a knot
 // point (kernels/al_types.h: AL_TILE_MAXC slots of AL_MAXP rows -- an input box AND a state box on a (12, 4) problem): the
-// NC = ALTRO_WIDE_SLOTS instantiations of wave_merit_dpp_kernel and wave_expand_dpp_kernel.  Included by ilqr_launch_mfma16_wide4.hip
-// (four slots: the merit kernel still fits two waves per SIMD -- measured, C1 + input box + state box: the two-trial pass 1.04 ms
-// against 2.4-2.5 ms for the six-slot instantiation, which either spills or runs one wave per SIMD) and _wide6.hip, translation units
-// of their own: the two-slot kernels of ilqr_launch_mfma16.hip stay what they were, register for register.
+// NC = AL_TILE_MAXC instantiations of wave_merit_dpp_kernel and wave_expand_dpp_kernel.  A translation unit of their own: the two-slot
+// kernels of ilqr_launch_mfma16.hip stay what they were, register for register.  (What keeps the six-slot merit kernel at two waves
+// per SIMD without spills -- 251 registers -- is in kernels/ilqr_merit2_dpp.hip: one set of (z, g) registers, asked for after use,
+// and the gradient's column sums taken with the rows.  Before those two changes: one wave per SIMD or 64-114 spilled registers,
+// the two-trial pass of C1 + input box + state box 2.4-2.5 ms; a four-slot instantiation 1.04 ms)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -17,9 +18,9 @@ namespace altro_hip {
 
 // 0 ok, 1 = no such kernel, 2 = launch error
 template <>
-int ilqr_wave_launch_wide<double, ALTRO_WIDE_SLOTS>(hipStream_t stream, int which, const IlqrWaveArgs<double>& a) {
+int ilqr_wave_launch_wide<double>(hipStream_t stream, int which, const IlqrWaveArgs<double>& a) {
   using S = double;
-  constexpr int W = ALTRO_WIDE_SLOTS;
+  constexpr int W = AL_TILE_MAXC;
   const dim3 b64(64);
   const unsigned gsh = (unsigned)a.al.Gpad_count * 8u;   // the padded constraint Jacobians in dynamic LDS
   const int trials = a.spec_trials > 1 ? a.spec_trials : 1;
@@ -76,6 +77,6 @@ int ilqr_wave_launch_wide<double, ALTRO_WIDE_SLOTS>(hipStream_t stream, int whic
 }
 // (fp32 records: the wide form is not instantiated -- altro_hip_add_linear_constraint says so when a block would need it)
 template <>
-int ilqr_wave_launch_wide<float, ALTRO_WIDE_SLOTS>(hipStream_t, int, const IlqrWaveArgs<float>&) { return 1; }
+int ilqr_wave_launch_wide<float>(hipStream_t, int, const IlqrWaveArgs<float>&) { return 1; }
 
 }  // namespace altro_hip

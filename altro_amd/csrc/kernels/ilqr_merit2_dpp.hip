@@ -262,12 +262,17 @@ __device__ __forceinline__ void alp_fetch(const AlTable<S>& t, const AlpKnot<NC>
   }
 }
 // rowb: min(lane of the row, 8) * AL_GP_LD;  pre: this knot point's (z_i, g_i)
-template <bool SOC, int NC>
-__device__ __forceinline__ void alp_rows(const AlpKnot<NC>& s, double w, double rho_est, int j, int rowb, double (&jvr)[NC], double& cost,
-                                         double& viol, const double* Gp, const double (&pre)[NC][2]) {
+// FUSE (the wide tables): the gradient's column sum  sum_c sum_i G_c[i][jcol] (J^T z_proj)_i  is taken here, slot by slot, right after a
+// slot's rows -- alp_col's sum in alp_col's order, so the same bits -- and (J^T z_proj)_i is not kept per slot: six slots cost 12
+// registers less, which is what lets the six-slot instantiation run two waves per SIMD.  jvr is then a single scratch value.
+template <bool SOC, int NC, bool FUSE = false>
+__device__ __forceinline__ void alp_rows(const AlpKnot<NC>& s, double w, double rho_est, int j, int rowb, double (&jvr)[FUSE ? 1 : NC], double& cost,
+                                         double& viol, const double* Gp, const double (&pre)[NC][2], int jcol = 0, double* colsum = nullptr) {
+  if constexpr (FUSE) *colsum = 0.0;
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
-    jvr[c] = 0.0;
+    double& jv = jvr[FUSE ? 0 : c];
+    jv = 0.0;
     if (c >= s.ncon) continue;                      // (wave-uniform)
     const int p = s.p[c], cone = s.cone[c];
     const md_d2* Gr = reinterpret_cast<const md_d2*>(Gp + s.gp_off[c] + rowb);
@@ -284,7 +289,7 @@ __device__ __forceinline__ void alp_rows(const AlpKnot<NC>& s, double w, double 
       if (cone == CONE_EQUALITY) { zp = ze; mkv = 1.0; viol = fmax(viol, fabs(val)); }
       else if (cone == CONE_INEQUALITY) { zp = fmin(0.0, ze); mkv = (ze <= 0.0) ? 1.0 : 0.0; viol = fmax(viol, fabs(fmin(0.0, val) - val)); }
       cost += zp * zp / (2.0 * rho_est);
-      jvr[c] = mkv * zp;
+      jv = mkv * zp;
     } else {
       double valv[AL_MAXSOC], zev[AL_MAXSOC], zpv[AL_MAXSOC], pv[AL_MAXSOC];
       md_gather4(val, valv);
@@ -303,8 +308,15 @@ __device__ __forceinline__ void alp_rows(const AlpKnot<NC>& s, double w, double 
         double sj = 0.0;
 #pragma unroll
         for (int q = 0; q < AL_MAXSOC; ++q) sj += Jc[q + r * AL_MAXSOC] * zpv[q];     // (J^T z_proj)_r
-        if (r < p && j == r) jvr[c] = sj;
+        if (r < p && j == r) jv = sj;
       }
+    }
+    if constexpr (FUSE) {                             // alp_col's chain for this slot
+      const double* Gc = Gp + s.gp_off[c] + jcol;
+      double cC[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) cC[i] = Gc[i * AL_GP_LD];
+      md_chain8(*colsum, jv, cC);
     }
   }
 }
@@ -350,7 +362,7 @@ namespace altro_hip {
 // search).  The trial points equal the rollout's to rounding (1e-13), not bit for bit -- like everything on this plan.
 constexpr int MD_AFF_CHUNK = 16;                    // even (the image ping-pong is the parity of k)
 template <typename S, bool AL, bool DUAL, bool DENSE = false, int MK = 0, bool SOC = true, bool AFF = false, int NC = AL_MAXC>
-__global__ __launch_bounds__(64, ((MK != 0 || (AL && DENSE && sizeof(S) == 8) || NC > 4) ? 1 : 2)) void wave_merit_dpp_kernel(IlqrWaveArgs<S> a) {
+__global__ __launch_bounds__(64, ((MK != 0 || (AL && DENSE && sizeof(S) == 8)) ? 1 : 2)) void wave_merit_dpp_kernel(IlqrWaveArgs<S> a) {
   static_assert(NC >= AL_MAXC && NC <= AL_TILE_MAXC, "two to AL_TILE_MAXC slots per knot point");
   static_assert(!AFF || (!DUAL && MK == 0), "affine trials: the single-trial rounds of dynamics given as data");
   constexpr bool NOZ = MK != 0 || AFF;              // Z and f are neither loaded nor staged
@@ -443,7 +455,9 @@ __global__ __launch_bounds__(64, ((MK != 0 || (AL && DENSE && sizeof(S) == 8) ||
   double x = isx ? (double)a.x0[(size_t)b * 12 + j] : 0.0;
   double dxda = 0.0;
   double J = 0.0, Jal = 0.0, dJ = 0.0, res = 0.0, viol = 0.0;   // (Jal: the constraint rows' cost shares, lanes 0..7)
-  double jvr[NC] = {0.0, 0.0};
+  constexpr bool FUSE = NC > AL_MAXC;               // the wide tables: the gradient's column sums are taken with the rows (alp_rows)
+  double jvr[FUSE ? 1 : NC] = {0.0};
+  double colsum = 0.0;
   double zg[NC][2] = {{0.0, 0.0}, {0.0, 0.0}};   // (z_i, g_i) of the knot point in hand
   if (al) {
     alp_knot<S, NC>(a.al, al_uni ? 0 : kb, kc_s); kn_s = kc_s;
@@ -500,10 +514,10 @@ __global__ __launch_bounds__(64, ((MK != 0 || (AL && DENSE && sizeof(S) == 8) ||
         if (k + 1 >= N) alp_knot<S, NC>(a.al, N, kn_s);           // (k + 1 <= N: the terminal knot point's too)
         else if (!al_uni) alp_knot<S, NC>(a.al, k + 1, kn_s);
         if constexpr (NC > AL_MAXC) {
-          // the wide tables: the next knot point's (z_i, g_i) are asked for AFTER this one's have been used, into the same registers --
-          // the loads then have the rest of this step and the head of the next to land in, and four slots cost 16 registers less
-          // than with a second set (what keeps the four-slot instantiation at two waves per SIMD without spills; six slots run one)
-          alp_rows<SOC, NC>(kc_s, w, rho, j, rowb, jvr, Ja, vv, Gdyn, zg);
+          // the wide table: the next knot point's (z_i, g_i) are asked for AFTER this one's have been used, into the same registers --
+          // the loads then have the rest of this step and the head of the next to land in, and six slots cost 24 registers less
+          // than with a second set (with alp_rows' FUSE: the six-slot instantiation at two waves per SIMD, no spills)
+          alp_rows<SOC, NC, FUSE>(kc_s, w, rho, j, rowb, jvr, Ja, vv, Gdyn, zg, j, &colsum);
           alp_fetch<S, NC>(a.al, kn_s, (al_uni && k + 1 < N) ? (k + 1) * a.al.rows_per_knot : 0, b, a.batch, j, zg);
         } else {
           double zgn[NC][2];
@@ -514,7 +528,7 @@ __global__ __launch_bounds__(64, ((MK != 0 || (AL && DENSE && sizeof(S) == 8) ||
         }
         Jal += Ja;
       } else {
-        alp_rows<SOC, NC>(kc_s, w, rho, j, rowb, jvr, Ja, vv, Gdyn, zg);   // a padding step: discarded
+        alp_rows<SOC, NC, FUSE>(kc_s, w, rho, j, rowb, jvr, Ja, vv, Gdyn, zg, j, &colsum);   // a padding step: discarded
       }
       if (cand && live) viol = fmax(viol, vv);               // (live: a padding step's point is not on the trajectory)
     }
@@ -584,7 +598,11 @@ __global__ __launch_bounds__(64, ((MK != 0 || (AL && DENSE && sizeof(S) == 8) ||
       //  forms this gradient from its own loads, where it is)
       l = __builtin_fma(cq, w, cl);
     }
-    if (al) { l -= alp_col(kc_s, j, jvr, Gdyn); if (live) kc_s = kn_s; }
+    if (al) {
+      if constexpr (FUSE) l -= colsum;
+      else l -= alp_col(kc_s, j, jvr, Gdyn);
+      if (live) kc_s = kn_s;
+    }
     if (live) dJ += l * dw;
     if (cand) {   // trial 1's candidate record x | y | u and its [lx lu]
       S* c = candb + (size_t)(live ? k : N) * a.xuy_ks;
@@ -631,10 +649,10 @@ __global__ __launch_bounds__(64, ((MK != 0 || (AL && DENSE && sizeof(S) == 8) ||
     if (al) {
       double Ja = 0.0, vv = 0.0;
       if constexpr (DUAL) {
-        alp_rows<SOC, NC>(kc_s, isx ? x : 0.0, rho, j, rowb, jvr, Ja, vv, Gdyn, zg);
+        alp_rows<SOC, NC, FUSE>(kc_s, isx ? x : 0.0, rho, j, rowb, jvr, Ja, vv, Gdyn, zg, jr, &colsum);
         Jal += Ja;
       } else {   // (wave_merit_kernel adds the terminal blocks' shares to its running sum one by one)
-        alp_rows<SOC, NC>(kc_s, isx ? x : 0.0, rho, j, rowb, jvr, Jal, vv, Gdyn, zg);
+        alp_rows<SOC, NC, FUSE>(kc_s, isx ? x : 0.0, rho, j, rowb, jvr, Jal, vv, Gdyn, zg, jr, &colsum);
       }
       if (cand) viol = fmax(viol, vv);
     }
@@ -645,7 +663,10 @@ __global__ __launch_bounds__(64, ((MK != 0 || (AL && DENSE && sizeof(S) == 8) ||
     md_rows12(sacc, unused, dxN, dxda, cP);
     const double yN = sacc + cP[12];
     double lx = DENSE ? gN + q : __builtin_fma(Qd, x, q);
-    if (al) lx -= alp_col(kc_s, jr, jvr, Gdyn);
+    if (al) {
+      if constexpr (FUSE) lx -= colsum;
+      else lx -= alp_col(kc_s, jr, jvr, Gdyn);
+    }
     if (isx) dJ += lx * dxda;
     if (cand) {
       if (isx) {

@@ -186,8 +186,8 @@ template <typename S>
 int ilqr_wave_launch_model(hipStream_t stream, int which, const IlqrWaveArgs<S>& a);    // ilqr_launch_mfma16_model.hip (a.mp.kind)
 bool ilqr_tile_model_supported(int kind, int n, int m);                                 // device models of the (12, 4) tile plan
 // the merit passes of a handle with more than AL_MAXC constraint slots at some knot point (al_types.h: AL_TILE_MAXC; fp64 records)
-template <typename S, int SLOTS>
-int ilqr_wave_launch_wide(hipStream_t stream, int which, const IlqrWaveArgs<S>& a);     // ilqr_launch_mfma16_wide{4,6}.hip
+template <typename S>
+int ilqr_wave_launch_wide(hipStream_t stream, int which, const IlqrWaveArgs<S>& a);     // ilqr_launch_mfma16_wide.hip
 
 // Speculative backtracking: most trials one merit launch evaluates (the host picks 1, 2, 4 or 8 by how idle the chip is)
 constexpr int ILQR_SPEC_TRIALS = 8;
