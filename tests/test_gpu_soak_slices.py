@@ -78,3 +78,19 @@ def test_slice_tile_sweeps_against_the_oracle():
     """fuzz_mfma16.py: plan MFMA16's TVLQR sweeps on random shapes / horizons / batches."""
     r = run("tests/soak/fuzz_mfma16.py", 3)
     assert r.returncode == 0 and "ok, worst relative error" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_slice_six_slot_tables_against_the_oracle_and_plan_generic():
+    """fuzz_tile_slots.py (round 6): random constraint tables on plan MFMA16's six-slot knot-point records -- blocks of 1..48 rows laid
+    out over slots, cones, ragged knot-point ranges, per-problem right-hand sides -- as whole solves against the oracle in both forms
+    of the line-search rounds, and the merit / expansion / feasibility kernels against plan GENERIC's on the same problem.
+    (This seed: one problem of case 2 with affine rounds, one of case 3 with rollout rounds -- batches in which 2 of 8 and 1 of 5
+    problems converge at all -- end a sweep apart from the oracle; the full run's counts are in tests/soak/README.md.)"""
+    r = run("tests/soak/fuzz_tile_slots.py", 10, 5)
+    got = dict((name, (int(a), int(b), float(c))) for name, a, b, c in
+               re.findall(r"(affine|rollout) rounds: (\d+) of (\d+) problems end with another status / iteration count than the oracle; converged rest within ([0-9.e+-]+)", r.stdout))
+    assert set(got) == {"affine", "rollout"}, r.stdout[-2000:] + r.stderr[-2000:]
+    assert got["rollout"][0] <= 1 and got["affine"][0] <= 1
+    assert got["rollout"][1] >= 80 and got["rollout"][2] < 1e-9 and got["affine"][2] < 1e-9
+    m = re.search(r"kernels against plan GENERIC: worst relative difference ([0-9.e+-]+)", r.stdout)
+    assert m and float(m.group(1)) < 1e-12
