@@ -55,6 +55,7 @@ FORM_EXPAND_LDS, FORM_ALROWS_LDS, FORM_ROLLOUT_ROUNDS, FORM_SEQUENCED, FORM_MERI
 FORM_LANE_QUAD_OFF, FORM_LANE_QUAD_ON, FORM_GENERIC_LATE_Q_OFF, FORM_GENERIC_LATE_Q_ON, FORM_FUSED_CLOCK = 0x400, 0x800, 0x1000, 0x2000, 0x4000
 FORM_AFFINE_EXACT = 0x8000
 FORM_NO_COMPACTION = 0x10000
+FORM_GENERIC_MERIT_LDS = 0x20000
 
 
 def forms_from_env():

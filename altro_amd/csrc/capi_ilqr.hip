@@ -128,6 +128,8 @@ int al_upload_typed(altro_hip_batch* h) {
     max_ncon = std::max(max_ncon, gen ? bk.ncon : ns);
   }
   h->al_max_ncon = max_ncon;
+  h->al_row32_ok = true;   // (kernels/ilqr_row32.hip: a lane position per row, the row-wise cones)
+  for (const AlDef& d : defs) if (d.cone == CONE_SOC || d.p > 32 || d.user) h->al_row32_ok = false;
   h->al_rows = rows;
   if (h->plan == ALTRO_HIP_PLAN_LANE && (uint64_t)rows * (uint64_t)B * sizeof(T) >= (1ull << 31))
     return fail(ALTRO_HIP_ERR_UNSUPPORTED, "plan LANE: %d dual rows x batch %d exceed the 2 GiB buffer window; split the batch", rows, h->batch);
@@ -342,6 +344,10 @@ int gen_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int 
   a.al.uniform = h->al_uniform; a.al.rows_per_knot = h->al_rows_per_knot; a.al.N = h->N; a.al.G_count = h->al_G_count;
   a.al.has_soc = h->al_has_soc; a.al.all_sel = h->al_all_sel; a.al.Gpad = nullptr; a.al.Gpad_count = 0;
   a.al.big = h->al_d_big;
+  // MeritFunction in the row layout of kernels/ilqr_row32.hip: plan MFMA32's shapes (also on a handle created as plan GENERIC), fp64,
+  // dynamics as data, every constraint block in a row-wise cone with at most 32 rows
+  a.row32 = (sizeof(T) == 8 && !h->ragged && !h->model_set && tile32_supported(n, m) &&
+             !form(h, ALTRO_HIP_FORM_GENERIC_MERIT_LDS) && (h->al_defs.empty() || h->al_row32_ok)) ? 1 : 0;
   if (h->model_set) {   // a device model: the dynamics expansion rides with every gradient expansion of a stored trajectory
     a.mp = h->model;
     if (which == IK_EXPAND && (a.mode & EXPAND_GRADIENT)) a.mode |= EXPAND_DYN;

@@ -7,6 +7,24 @@
 
 namespace altro_hip {
 
+// the row-layout merit kernels, eight translation units by n mod 8 (row32_unit.inc)
+int row32_merit_unit0(hipStream_t, const IlqrGenArgs<double>&); int row32_merit_unit1(hipStream_t, const IlqrGenArgs<double>&);
+int row32_merit_unit2(hipStream_t, const IlqrGenArgs<double>&); int row32_merit_unit3(hipStream_t, const IlqrGenArgs<double>&);
+int row32_merit_unit4(hipStream_t, const IlqrGenArgs<double>&); int row32_merit_unit5(hipStream_t, const IlqrGenArgs<double>&);
+int row32_merit_unit6(hipStream_t, const IlqrGenArgs<double>&); int row32_merit_unit7(hipStream_t, const IlqrGenArgs<double>&);
+static int row32_merit_dispatch(hipStream_t stream, const IlqrGenArgs<double>& a) {
+  switch (a.n & 7) {
+    case 0: return row32_merit_unit0(stream, a);
+    case 1: return row32_merit_unit1(stream, a);
+    case 2: return row32_merit_unit2(stream, a);
+    case 3: return row32_merit_unit3(stream, a);
+    case 4: return row32_merit_unit4(stream, a);
+    case 5: return row32_merit_unit5(stream, a);
+    case 6: return row32_merit_unit6(stream, a);
+    default: return row32_merit_unit7(stream, a);
+  }
+}
+
 bool ilqr_generic_model_supported(int kind, int n, int m) { return kind == MODEL_QUADROTOR13 && n == 13 && m == 4; }
 
 // the kernels that step a compiled-in device model (fp64 handles); everything else of the loop is the data form's
@@ -53,6 +71,12 @@ static int gen_launch(hipStream_t stream, int which, const IlqrGenArgs<T>& a) {
       break;
     case IK_DUAL: hipLaunchKernelGGL(generic_dual_update_kernel<T>, dim3((unsigned)((int64_t)a.batch * (a.N + 1))), b64, 0, stream, a); break;
     case IK_MERIT: {   // the knot point's matrices staged in LDS while sixteen waves still fit a CU (10 KB each, the kernel's own 2.5 KB included)
+      if constexpr (sizeof(T) == 8) {
+        if (a.row32) {   // plan MFMA32's shapes: two problems per wave in the row layout, one kernel per shape (kernels/ilqr_row32.hip)
+          const int rc = row32_merit_dispatch(stream, a);
+          if (rc != 1) return rc;   // (1: no kernel for this shape -- the LDS form below)
+        }
+      }
       const size_t jv = a.al.enabled ? (size_t)GEN_AL_JV * sizeof(double) : 0;
       const size_t stage = generic_merit_stage_elems(a.n, a.m) * sizeof(T);
       if (2560 + jv + stage <= 10 * 1024) hipLaunchKernelGGL((generic_merit_kernel<T, true>), waves, b64, jv + stage, stream, a);

@@ -46,6 +46,9 @@ struct IlqrGenArgs {
   // a device model instead of dynamics given as data (altro_hip_set_model on plans GENERIC / MFMA32): the rollout and the merit
   // evaluation step the model (explicit midpoint, test_utils.cpp:84-132), the expansion writes A_k, B_k into the sweep's arrays
   ModelParams mp{MODEL_LINEAR, 0.0f, 0, 2.7, 1.5};
+  // uniform n <= 31, m <= 8, n + m <= 32, fp64, dynamics as data, constraint blocks (if any) of at most 32 rows in the row-wise cones:
+  // MeritFunction runs kernels/ilqr_row32.hip's kernel (the host decides: capi_ilqr.hip)
+  int row32 = 0;
 };
 
 #define GOFF(arr, k) (a.off[(int64_t)(k) * G_NUM + (arr)])

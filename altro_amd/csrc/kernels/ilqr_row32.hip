@@ -1,0 +1,451 @@
+// kernels/ilqr_row32.hip -- MeritFunction (solver.cpp:273-355) for plan MFMA32's shapes (uniform n <= 31, m <= 8, n + m <= 32 past the
+// (12, 4) tile) in a ROW LAYOUT of 32 lanes per problem, on plan GENERIC's arrays (reference layout on the device, generic_arrays.h):
+// a drop-in for generic_merit_kernel, which stays the kernel of every other case (per-knot-point dimensions, other shapes, device
+// models, fp32, second-order cones, blocks of more than 32 rows) and the form this one is compared with (tests/test_gpu_row32.py).
+//
+// Why: after round 6 gave these shapes a matrix-core TVLQR pair, a whole solve at (13, 4) spent half to three quarters of its time in
+// generic_merit_kernel -- one wave per problem, every vector through LDS, four to five barriers and a dozen dependent global round
+// trips per knot point: 1.87 ms per evaluation at 4096 problems x 128 knot points where the backward sweep takes 0.72
+// (profiles/r06h_solve_13_4.txt).  The (12, 4) tile's answer (kernels/ilqr_merit2_dpp.hip) carries over:
+//   * a problem lives in HALF a wave: lane position q = lane % 32 holds x_q (q < n) or u_e at q = 31 - e (inputs from the top down:
+//     their positions do not depend on n); two problems per wave;
+//   * a vector of 32 positions is two registers per lane -- positions 0..15 and 16..31 as seen from BOTH rows of 16 lanes of the half
+//     (one cross-row exchange per vector and knot point) -- so every product against it is a chain of `v_fmac_f64_dpp ... row_newbcast`
+//     instructions with the lane's own row of coefficients; input lanes ride the same instructions with rows of K, [H R] where state
+//     lanes have rows of P, [A B], [Q H^T];
+//   * a knot point's seven matrices go from HBM to an image in LDS verbatim (column-major blocks as they lie: 256-byte runs per half
+//     wave and load, fetched one knot point ahead into a ring of registers), and "coefficient j of every lane's row" is then a
+//     conflict-free ds_read_b64 -- no barriers: one wave is the whole workgroup, its LDS operations execute in order;
+//   * n and m are COMPILE-TIME (one instantiation per shape, like plan MFMA32's backward kernel: row32_unit.inc): the chains have
+//     exactly n and m terms, the ring exactly the registers the shape needs, no select or branch asks how large the problem is.  (The
+//     first form of this kernel took n, m at run time: 1500 instructions per knot point, a third of them moving spilled scalars, and
+//     ran at generic_merit_kernel's speed: profiles/r06i_row32_runtime_shape.txt.)
+// Every sum is taken in generic_merit_kernel's order with its expressions, the final sums over its 64-entry arrangement (state rows
+// at 0..31, input rows at 32..63) with its butterfly: the tests hold the results to 1e-13 relative against that kernel and report
+// whether they are bit-identical; whole solves are held to the oracle like plan GENERIC's.
+#pragma once
+
+namespace altro_hip {
+
+typedef __attribute__((address_space(3))) double r32_lds_t;   // (an explicit LDS pointer: a generic one becomes flat loads on some paths)
+
+#define R32_DPP " row_mask:0xf bank_mask:0xf\n"
+// CNT (1..4) terms of two sums against the same coefficients: acc += bc_L(v) c, acc2 += bc_L(v2) c for lanes L0, L0 + DL, ... of the
+// row of 16.  (Hazards: see ilqr_merit2_dpp.hip -- every block starts with `s_nop 4`, accumulators are early-clobber, `volatile`
+// keeps a block where the whole wave executes it.)
+template <int L0, int DL, int CNT>
+__device__ __forceinline__ void r32_two(double& acc, double& acc2, double v, double v2, const double (&c)[4]) {
+  static_assert(CNT >= 1 && CNT <= 4 && L0 >= 0 && L0 <= 15 && L0 + DL * (CNT - 1) >= 0 && L0 + DL * (CNT - 1) <= 15, "a row of 16 lanes");
+#define R32_T2(C, L) "v_fmac_f64_dpp %0, %2, %" #C " row_newbcast:%" #L R32_DPP "v_fmac_f64_dpp %1, %3, %" #C " row_newbcast:%" #L R32_DPP
+  if constexpr (CNT == 4)
+    asm volatile("s_nop 4\n" R32_T2(4, 8) R32_T2(5, 9) R32_T2(6, 10) R32_T2(7, 11)
+                 : "+&v"(acc), "+&v"(acc2)
+                 : "v"(v), "v"(v2), "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "n"(L0), "n"(L0 + DL), "n"(L0 + 2 * DL), "n"(L0 + 3 * DL));
+  else if constexpr (CNT == 3)
+    asm volatile("s_nop 4\n" R32_T2(4, 7) R32_T2(5, 8) R32_T2(6, 9)
+                 : "+&v"(acc), "+&v"(acc2)
+                 : "v"(v), "v"(v2), "v"(c[0]), "v"(c[1]), "v"(c[2]), "n"(L0), "n"(L0 + DL), "n"(L0 + 2 * DL));
+  else if constexpr (CNT == 2)
+    asm volatile("s_nop 4\n" R32_T2(4, 6) R32_T2(5, 7) : "+&v"(acc), "+&v"(acc2) : "v"(v), "v"(v2), "v"(c[0]), "v"(c[1]), "n"(L0), "n"(L0 + DL));
+  else
+    asm volatile("s_nop 4\n" R32_T2(4, 5) : "+&v"(acc), "+&v"(acc2) : "v"(v), "v"(v2), "v"(c[0]), "n"(L0));
+#undef R32_T2
+}
+template <int L0, int DL, int CNT>
+__device__ __forceinline__ void r32_one(double& acc, double v, const double (&c)[4]) {
+  static_assert(CNT >= 1 && CNT <= 4 && L0 >= 0 && L0 <= 15 && L0 + DL * (CNT - 1) >= 0 && L0 + DL * (CNT - 1) <= 15, "a row of 16 lanes");
+#define R32_T1(C, L) "v_fmac_f64_dpp %0, %1, %" #C " row_newbcast:%" #L R32_DPP
+  if constexpr (CNT == 4)
+    asm volatile("s_nop 4\n" R32_T1(2, 6) R32_T1(3, 7) R32_T1(4, 8) R32_T1(5, 9)
+                 : "+&v"(acc)
+                 : "v"(v), "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "n"(L0), "n"(L0 + DL), "n"(L0 + 2 * DL), "n"(L0 + 3 * DL));
+  else if constexpr (CNT == 3)
+    asm volatile("s_nop 4\n" R32_T1(2, 5) R32_T1(3, 6) R32_T1(4, 7)
+                 : "+&v"(acc) : "v"(v), "v"(c[0]), "v"(c[1]), "v"(c[2]), "n"(L0), "n"(L0 + DL), "n"(L0 + 2 * DL));
+  else if constexpr (CNT == 2)
+    asm volatile("s_nop 4\n" R32_T1(2, 4) R32_T1(3, 5) : "+&v"(acc) : "v"(v), "v"(c[0]), "v"(c[1]), "n"(L0), "n"(L0 + DL));
+  else
+    asm volatile("s_nop 4\n" R32_T1(2, 3) : "+&v"(acc) : "v"(v), "v"(c[0]), "n"(L0));
+#undef R32_T1
+}
+
+// a vector of the half's 32 positions as the two registers the chains read: positions 0..15 (lo) and 16..31 (hi) in both rows
+struct R32Vec { double lo, hi; };
+__device__ __forceinline__ R32Vec r32_spread(double v, bool upper_row) {
+  const double o = __shfl_xor(v, 16, 64);
+  return R32Vec{upper_row ? o : v, upper_row ? v : o};
+}
+
+// ---- chains with the coefficients in LDS: coefficient j of this lane's row at L[at + j * stride] (at, stride: the lane's) ----------
+// Four coefficients are read a block ahead of the block being summed.  A lane without a row reads from its `at` (somewhere inside the
+// image) and sums what it finds: nobody looks at its sums, and no chain broadcasts from its position -- the same instructions for
+// every lane, not one select.
+template <int CNT>
+__device__ __forceinline__ void r32_read4(double (&c)[4], const r32_lds_t* L, int& at, int stride) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+    if (t < CNT) { c[t] = L[at]; at += stride; }
+}
+// positions 0 .. CNT-1 from the bottom (states), ascending, two vectors
+template <int CNT, int J0 = 0>
+__device__ __forceinline__ void r32_lo2(double& acc, double& acc2, const R32Vec& v, const R32Vec& v2, const r32_lds_t* L, int& at, int stride,
+                                        double (&cur)[4]) {
+  if constexpr (J0 < CNT) {
+    constexpr int here = CNT - J0 < 4 ? CNT - J0 : 4;
+    constexpr int next = CNT - J0 - 4 < 4 ? CNT - J0 - 4 : 4;
+    double nxt[4] = {0.0, 0.0, 0.0, 0.0};
+    if constexpr (next > 0) r32_read4<next>(nxt, L, at, stride);
+    if constexpr (J0 < 16) r32_two<J0, 1, here>(acc, acc2, v.lo, v2.lo, cur);
+    else r32_two<J0 - 16, 1, here>(acc, acc2, v.hi, v2.hi, cur);
+    if constexpr (next > 0) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) cur[t] = nxt[t];
+      r32_lo2<CNT, J0 + 4>(acc, acc2, v, v2, L, at, stride, cur);
+    }
+  }
+}
+template <int CNT, int J0 = 0>
+__device__ __forceinline__ void r32_lo1(double& acc, const R32Vec& v, const r32_lds_t* L, int& at, int stride, double (&cur)[4]) {
+  if constexpr (J0 < CNT) {
+    constexpr int here = CNT - J0 < 4 ? CNT - J0 : 4;
+    constexpr int next = CNT - J0 - 4 < 4 ? CNT - J0 - 4 : 4;
+    double nxt[4] = {0.0, 0.0, 0.0, 0.0};
+    if constexpr (next > 0) r32_read4<next>(nxt, L, at, stride);
+    if constexpr (J0 < 16) r32_one<J0, 1, here>(acc, v.lo, cur);
+    else r32_one<J0 - 16, 1, here>(acc, v.hi, cur);
+    if constexpr (next > 0) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) cur[t] = nxt[t];
+      r32_lo1<CNT, J0 + 4>(acc, v, L, at, stride, cur);
+    }
+  }
+}
+template <int CNT>
+__device__ __forceinline__ void r32_states2(double& acc, double& acc2, const R32Vec& v, const R32Vec& v2, const r32_lds_t* L, int at, int stride) {
+  double cur[4] = {0.0, 0.0, 0.0, 0.0};
+  r32_read4<(CNT < 4 ? CNT : 4)>(cur, L, at, stride);
+  r32_lo2<CNT>(acc, acc2, v, v2, L, at, stride, cur);
+}
+template <int CNT>
+__device__ __forceinline__ void r32_states1(double& acc, const R32Vec& v, const r32_lds_t* L, int at, int stride) {
+  double cur[4] = {0.0, 0.0, 0.0, 0.0};
+  r32_read4<(CNT < 4 ? CNT : 4)>(cur, L, at, stride);
+  r32_lo1<CNT>(acc, v, L, at, stride, cur);
+}
+// the input positions e = 0 .. CNT-1 (position 31 - e: lane 15 - e of the upper row), ascending e
+template <int CNT>
+__device__ __forceinline__ void r32_in2(double& acc, double& acc2, const R32Vec& v, const R32Vec& v2, const r32_lds_t* L, int at, int stride) {
+  double c[4] = {0.0, 0.0, 0.0, 0.0};
+  r32_read4<(CNT < 4 ? CNT : 4)>(c, L, at, stride);
+  r32_two<15, -1, (CNT < 4 ? CNT : 4)>(acc, acc2, v.hi, v2.hi, c);
+  if constexpr (CNT > 4) {
+    r32_read4<CNT - 4>(c, L, at, stride);
+    r32_two<11, -1, CNT - 4>(acc, acc2, v.hi, v2.hi, c);
+  }
+}
+template <int CNT>
+__device__ __forceinline__ void r32_in1(double& acc, const R32Vec& v, const r32_lds_t* L, int at, int stride) {
+  double c[4] = {0.0, 0.0, 0.0, 0.0};
+  r32_read4<(CNT < 4 ? CNT : 4)>(c, L, at, stride);
+  r32_one<15, -1, (CNT < 4 ? CNT : 4)>(acc, v.hi, c);
+  if constexpr (CNT > 4) {
+    r32_read4<CNT - 4>(c, L, at, stride);
+    r32_one<11, -1, CNT - 4>(acc, v.hi, c);
+  }
+}
+
+// ---- a block of a knot point on its way from HBM to the image: the PAIR of elements 2 (q + 32 t), + 1 in lane position q of the
+// problem's half -- each half a 512-byte run per load (16 bytes per lane; with 8 the texture path was the busiest unit of the kernel:
+// 74 %, 19 cache accesses per load instruction).  The address is a wave-uniform base (the wave's first problem, moved on by scalar
+// adds) plus the lane's 32-bit offset (the half's problem and the pair): one offset register per array instead of a pointer.
+typedef double r32_d2 __attribute__((ext_vector_type(2), aligned(8)));   // (blocks start on 8-byte boundaries: 169 doubles per knot point at n = 13)
+template <int COUNT>
+struct R32Block {
+  static constexpr int PAIRS = (COUNT + 1) / 2, T = (PAIRS + 31) / 32;
+  r32_d2 r[T];
+  // g: the block of the wave's first problem; lane_off: elements from there to this lane's first pair (the half's problem included)
+  template <typename S>
+  __device__ __forceinline__ void fetch(const S* g, int lane_off, int q) {
+    static_assert(sizeof(S) == 8, "fp64 records");
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const int e0 = 2 * (q + 32 * t);
+      if constexpr (COUNT < 2) {
+        r[t] = r32_d2{(double)g[lane_off - 2 * q], 0.0};
+      } else if (64 * (t + 1) <= COUNT) {
+        r[t] = *reinterpret_cast<const r32_d2*>(g + lane_off + 64 * t);
+      } else {   // the last run: past the block's end its last pair again (put() takes what belongs to it)
+        const int back = e0 + 1 < COUNT ? 0 : e0 - (COUNT - 2);
+        r[t] = *reinterpret_cast<const r32_d2*>(g + lane_off + 64 * t - back);
+      }
+    }
+  }
+  __device__ __forceinline__ void put(r32_lds_t* L, int q) const {
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const int e0 = 2 * (q + 32 * t);
+      if constexpr (COUNT < 2) {
+        if (q == 0) L[0] = r[t][0];
+      } else if (64 * (t + 1) <= COUNT) {
+        L[e0] = r[t][0]; L[e0 + 1] = r[t][1];
+      } else if (e0 + 1 < COUNT) {
+        L[e0] = r[t][0]; L[e0 + 1] = r[t][1];
+      } else if (e0 < COUNT) {                          // (an odd count's last element: the fetched pair is (COUNT - 2, COUNT - 1))
+        L[e0] = r[t][1];
+      }
+    }
+  }
+};
+
+// ---- constraint blocks in this layout (gen_al_rows / gen_al_col of ilqr_generic.hip: zero / identity / orthant blocks of up to 32 rows) ----
+// Lane position r owns row r of EVERY block of the knot point: c_r = G_r [x; u] - g_r is one more chain over the positions (its
+// coefficients the lane's row of G in global memory -- the blocks are the handle's, a few KB that stay in L2 --, column e of the
+// caller's [x; u] order); the projected dual, the cost share and (J^T z_proj)_r stay in the lane.  The gradient's column sums
+// sum_c sum_i G_c[i][col] (J^T z_proj)_i  are chains over the ROWS (positions 0..p-1) against the lane's own column of G, taken block
+// by block right after the block's rows -- gen_al_col's sum in gen_al_col's order.
+template <typename T, int CNT, bool TOP, int J0 = 0>
+__device__ __forceinline__ void r32_g1(double& acc, const R32Vec& w, const T* g, int64_t stride) {
+  if constexpr (J0 < CNT) {
+    constexpr int here = CNT - J0 < 4 ? CNT - J0 : 4;
+    double c[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int t = 0; t < here; ++t) c[t] = (double)g[(int64_t)(J0 + t) * stride];
+    if constexpr (TOP) r32_one<15 - J0, -1, here>(acc, w.hi, c);          // inputs e = J0.. at positions 31 - e
+    else if constexpr (J0 < 16) r32_one<J0, 1, here>(acc, w.lo, c);       // states j = J0.. at positions j
+    else r32_one<J0 - 16, 1, here>(acc, w.hi, c);
+    r32_g1<T, CNT, TOP, J0 + 4>(acc, w, g, stride);
+  }
+}
+// the column sums run over p <= 32 rows: blocks of four skipped (wave-uniformly) past p
+template <typename T, int J0 = 0>
+__device__ __forceinline__ void r32_gcol(double& acc, const R32Vec& jv, const T* g, int p) {
+  if constexpr (J0 < 32) {
+    if (J0 < p) {
+      double c[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) c[t] = (double)g[J0 + t < p ? J0 + t : p - 1];   // (past p: a real entry against (J^T z_proj) = 0: an exact zero)
+      if constexpr (J0 < 16) r32_one<J0, 1, 4>(acc, jv.lo, c);
+      else r32_one<J0 - 16, 1, 4>(acc, jv.hi, c);
+      r32_gcol<T, J0 + 4>(acc, jv, g, p);
+    }
+  }
+}
+template <typename T, int NX, int NU>
+__device__ __forceinline__ void r32_al(const AlTable<T>& t, int k, int b, int64_t B, const R32Vec& w, bool terminal, double rho_est, int q, bool upper_row,
+                                       bool want_col, int col, bool has_col, double& cost, double& viol, double& colsum) {
+  int zshift;
+  const AlKnotBig ALTRO_CONST_AS& kn = gen_knot<T>(t, k, zshift);
+  const int ncon = kn.ncon;
+  colsum = 0.0;
+#pragma unroll 1
+  for (int c = 0; c < ncon; ++c) {                      // (wave-uniform trip count; nothing is carried per block but the two sums)
+    const int p = kn.p[c], cone = kn.cone[c];
+    const T* G = t.G + kn.G_off[c];
+    const bool rl = q < p;
+    double s = 0.0;
+    r32_g1<T, NX, false>(s, w, G + (rl ? q : 0), p);
+    if (!terminal) r32_g1<T, NU, true>(s, w, G + (rl ? q : 0) + (int64_t)NX * p, p);
+    double jv = 0.0;
+    if (rl) {
+      const double gi = kn.g_per_problem[c] ? (double)t.g[kn.g_off[c] + (int64_t)q * B + b] : (double)t.g[kn.g_off[c] + q];
+      const double val = s - gi;
+      const double ze = (double)t.z[(int64_t)(kn.z_off[c] + zshift + q) * B + b] - rho_est * val;
+      double zp = 0.0, mkv = 0.0;
+      if (cone == CONE_EQUALITY) { zp = ze; mkv = 1.0; viol = fmax(viol, fabs(val)); }
+      else if (cone == CONE_INEQUALITY) { zp = fmin(0.0, ze); mkv = (ze <= 0.0) ? 1.0 : 0.0; viol = fmax(viol, fabs(fmin(0.0, val) - val)); }
+      cost += zp * zp / (2.0 * rho_est);
+      jv = mkv * zp;
+    }
+    if (want_col) {                                     // (wave-uniform)
+      const R32Vec jvv = r32_spread(jv, upper_row);
+      r32_gcol<T>(colsum, jvv, G + (int64_t)(has_col ? col : 0) * p, p);   // (rows 0..p-1 sit at positions 0..p-1, like states)
+    }
+  }
+}
+
+constexpr int r32_image_doubles(int n, int m) { return ((3 * n * n + 3 * n * m + m * m + 1) & ~1); }
+
+// two problems per wave: lanes 0..31 problem 2 pr, lanes 32..63 problem 2 pr + 1
+template <typename T, int NX, int NU, int WPS>
+__global__ __launch_bounds__(64, WPS) void row32_merit_kernel(IlqrGenArgs<T> a) {
+  static_assert(NX >= 1 && NU >= 1 && NU <= 8 && NX + NU <= 32, "a problem's [x; u] fits half a wave, the inputs its top eight positions");
+  constexpr int NN = NX * NX, NM = NX * NU, MM = NU * NU;
+  constexpr int oP = 0, oK = NN, oA = oK + NM, oB = oA + NN, oQ = oB + NM, oH = oQ + NN, oR = oH + NM, IMG = r32_image_doubles(NX, NU);
+  __shared__ double red[2][2][64];                    // [phi | phi'][half][generic_merit_kernel's lane arrangement]
+  __shared__ double img[2][IMG];                      // [half][P | K | A | B | Q | H | R], every block column-major as in HBM
+  const int lane = threadIdx.x, half = lane >> 5, q = lane & 31;
+  const bool upper_row = (lane & 16) != 0;
+  const int b_own = 2 * (int)blockIdx.x + half, b_oth = 2 * (int)blockIdx.x + (1 - half);
+  const bool ok_own = b_own < a.batch && !(a.active && !a.active[b_own]);
+  const bool ok_oth = b_oth < a.batch && !(a.active && !a.active[b_oth]);
+  if (!ok_own && !ok_oth) return;                     // (the same two answers in every lane)
+  const int b = ok_own ? b_own : b_oth;               // a half without a problem shadows the other one and stores nothing
+  const bool wr = ok_own;
+  const int N = a.N;
+  const bool isx = q < NX, isu = q >= 32 - NU, has = isx || isu;
+  const int iu = isu ? 31 - q : 0, ix = isx ? q : 0;
+  const bool al = a.al.enabled != 0;
+  const double rho = al ? a.prob[b].rho : 1.0;
+  double viol = 0.0;
+  const double alpha = a.alpha ? a.alpha[b] : a.alpha_const;
+  const bool deriv = a.want_derivative != 0;
+  const r32_lds_t* const L = (const r32_lds_t*)&img[half][0];
+  r32_lds_t* const Lw = (r32_lds_t*)&img[half][0];
+  // uniform dimensions: knot point k's block of an array starts k strides after knot point 0's (the offset table's rows 0 and 1 say
+  // both).  Per lane: one pointer per array, moved on by the stride after every knot point.
+  const int64_t* off0 = a.off;
+  const int64_t* off1 = a.off + (N > 1 ? G_NUM : 0);
+#define R32_STRIDE(arr) (off1[arr] - off0[arr])
+  const int b0 = 2 * (int)blockIdx.x, hb = b - b0;    // the wave's first problem; this half's problem relative to it (0 or 1)
+  const T* gP = a.P + (int64_t)b0 * a.P_bs + off0[G_P];   const int64_t sP = R32_STRIDE(G_P);   const int vP = hb * (int)a.P_bs + 2 * q;
+  const T* gK = a.K + (int64_t)b0 * a.K_bs + off0[G_K];   const int64_t sK = R32_STRIDE(G_K);   const int vK = hb * (int)a.K_bs + 2 * q;
+  const T* gA = a.A + (int64_t)b0 * a.A_bs + off0[G_A];   const int64_t sA = R32_STRIDE(G_A);   const int vA = hb * (int)a.A_bs + 2 * q;
+  const T* gB = a.B + (int64_t)b0 * a.B_bs + off0[G_B];   const int64_t sB = R32_STRIDE(G_B);   const int vB = hb * (int)a.B_bs + 2 * q;
+  const T* gQ = a.cQ + (int64_t)b0 * a.sQ + off0[G_Q];    const int64_t sQ = R32_STRIDE(G_Q);   const int vQ = hb * (int)a.sQ + 2 * q;
+  const T* gH = a.cH + (int64_t)b0 * a.sH + off0[G_H];    const int64_t sH = R32_STRIDE(G_H);   const int vH = hb * (int)a.sH + 2 * q;
+  const T* gR = a.cR + (int64_t)b0 * a.sR + off0[G_R];    const int64_t sR = R32_STRIDE(G_R);   const int vR = hb * (int)a.sR + 2 * q;
+  // the vectors: this lane's entry (state lanes: row ix, input lanes: row iu)
+  const T* gxn = a.xn + (int64_t)b * a.sx + off0[G_x] + ix;  const int64_t sx_ = R32_STRIDE(G_x);
+  T* gx = a.x + (int64_t)b * a.x_bs + off0[G_x] + ix;
+  T* gy = a.y + (int64_t)b * a.y_bs + off0[G_y] + ix;        const int64_t sy_ = R32_STRIDE(G_y);
+  const T* gp = a.p + (int64_t)b * a.p_bs + off0[G_p] + ix;  const int64_t sp_ = R32_STRIDE(G_p);
+  const T* gf = a.f + (int64_t)b * a.f_bs + off0[G_f] + ix;  const int64_t sf_ = R32_STRIDE(G_f);
+  const T* gcq = a.cq + (int64_t)b * a.sx + off0[G_q] + ix;  const int64_t sq_ = R32_STRIDE(G_q);
+  T* glx = a.q + (int64_t)b * a.q_bs + off0[G_q] + ix;
+  const T* gd = a.d + (int64_t)b * a.d_bs + off0[G_d] + iu;  const int64_t sd_ = R32_STRIDE(G_d);
+  const T* gun = a.un + (int64_t)b * a.su + off0[G_u] + iu;  const int64_t su_ = R32_STRIDE(G_u);
+  T* gu = a.u + (int64_t)b * a.u_bs + off0[G_u] + iu;
+  const T* gcr = a.cr + (int64_t)b * a.su + off0[G_r] + iu;  const int64_t sr_ = R32_STRIDE(G_r);
+  T* glu = a.r + (int64_t)b * a.r_bs + off0[G_r] + iu;
+  const T* gcc = a.cc + (int64_t)b * (N + 1);
+#undef R32_STRIDE
+  double x = isx ? (double)a.x0[(int64_t)b * a.x0_stride + q] : 0.0, dxda = 0.0;
+  double J0 = 0.0, J1 = 0.0, dJ = 0.0;                // J0: this position's constraint rows and state row; J1: its input row
+  R32Block<NN> rP, rA, rQ;
+  R32Block<NM> rK, rB, rH;
+  R32Block<MM> rR;
+  double vxn, vp, vf, vcq, vd = 0.0, vun = 0.0, vcr = 0.0, vcc;   // the knot point's entries of the vectors, fetched with the matrices
+  auto fetch = [&]() {
+    rP.fetch(gP, vP, q); rK.fetch(gK, vK, q); rA.fetch(gA, vA, q); rB.fetch(gB, vB, q); rQ.fetch(gQ, vQ, q); rH.fetch(gH, vH, q); rR.fetch(gR, vR, q);
+    vxn = (double)*gxn; vp = (double)*gp; vf = (double)*gf; vcq = (double)*gcq;
+    vd = (double)*gd; vun = (double)*gun; vcr = (double)*gcr;   // (every lane: lanes without an input row read row 0's and do not use it)
+  };
+  fetch();
+  vcc = (double)gcc[0];
+  for (int k = 0; k < N; ++k) {
+    // this knot point's matrices into the image (every read of the last one's has been issued), the next one's on their way.
+    // One wave: the LDS pipe executes its writes before the reads that follow, for all lanes -- nothing to wait for (a __syncthreads
+    // would wait for the loads just issued: the whole round trip, every knot point); the compiler only has to keep the order.
+    rP.put(Lw + oP, q); rK.put(Lw + oK, q); rA.put(Lw + oA, q); rB.put(Lw + oB, q); rQ.put(Lw + oQ, q); rH.put(Lw + oH, q); rR.put(Lw + oR, q);
+    const double xnom = vxn, pk = vp, fk = vf, ql = vcq, dk = vd, unom = vun, rl = vcr, ck = vcc;
+    if (k + 1 < N) {
+      gP += sP; gK += sK; gA += sA; gB += sB; gQ += sQ; gH += sH; gR += sR;
+      gxn += sx_; gp += sp_; gf += sf_; gcq += sq_; gd += sd_; gun += su_; gcr += sr_;
+      fetch();
+      vcc = (double)gcc[k + 1];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const double dx = isx ? x - xnom : 0.0;
+    if (isx && wr) *gx = (T)x;
+    const R32Vec vdx = r32_spread(dx, upper_row), vda = r32_spread(isx ? dxda : 0.0, upper_row);
+    // rows of P (state lanes) / K (input lanes) against dx and dx/dalpha
+    double s = 0.0, s2 = 0.0;
+    r32_states2<NX>(s, s2, vdx, vda, L, isx ? oP + ix : oK + iu, isx ? NX : NU);
+    double uv = 0.0, du = 0.0;
+    if (isu) {   // u_ = u + (-K dx + alpha d) ; du_da = -K dx_da + d
+      uv = unom + (-s + alpha * dk);
+      du = -s2 + dk;
+      if (wr) *gu = (T)uv;
+    }
+    if (isx && wr) *gy = (T)(s + pk);                   // y_ = P dx + p
+    const R32Vec vw = r32_spread(isx ? x : uv, upper_row), vdw = r32_spread(isx ? dxda : du, upper_row);
+    // rows of [A B] (state lanes) / [H R] (input lanes) against [x; u] and its sensitivity
+    double sA_ = 0.0, tA = 0.0, sBv = 0.0, tB = 0.0;
+    r32_states2<NX>(sA_, tA, vw, vdw, L, isx ? oA + ix : oH + iu, isx ? NX : NU);
+    r32_in2<NU>(sBv, tB, vw, vdw, L, isx ? oB + ix : oR + iu, isx ? NX : NU);
+    double alcol = 0.0;
+    if (al) {   // the constraint rows' cost shares at the candidate point and the gradient's column sums
+      double Jal = 0.0;
+      r32_al<T, NX, NU>(a.al, k, b, a.batch, vw, false, rho, q, upper_row, deriv, isx ? ix : NX + iu, has, Jal, viol, alcol);
+      J0 += Jal;
+    }
+    // rows of [Q H^T] (state lanes) against [x; u]
+    double qx = 0.0, htu = 0.0;
+    r32_states1<NX>(qx, vw, L, oQ + ix, NX);
+    r32_in1<NU>(htu, vw, L, oH + ix * NU, 1);
+    double lxu = 0.0;
+    if (isx) {   // state row: cost share, lx
+      J0 += x * (0.5 * qx + ql);
+      if (q == 0) J0 += ck;
+      lxu = (qx + htu) + ql;
+    }
+    if (isu) {   // input row: cost share (with the cross term u'Hx), lu
+      const double ru = sBv, hx = sA_;
+      J1 += uv * ((0.5 * ru + rl) + hx);
+      lxu = (ru + hx) + rl;
+    }
+    if (al && deriv && has) lxu -= alcol;
+    if (deriv) {
+      if (isx) { dJ += lxu * dxda; if (wr) *glx = (T)lxu; }
+      if (isu) { dJ += lxu * du; if (wr) *glu = (T)lxu; }
+    }
+    if (isx) {   // next state (uniform dimensions: n2 = n)
+      const double xn = (sA_ + sBv) + fk;
+      dxda = tA + tB;
+      x = xn;
+    }
+    gx += sx_; gy += sy_; glx += sq_; gu += su_; glu += sr_;
+  }
+#define GOFFN(arr) (a.off[(int64_t)N * G_NUM + (arr)])
+  {   // terminal knot point (solver.cpp:319-332): Q_N and P_N through the image's slots of Q and P
+    R32Block<NN> rQn, rPn;
+    rQn.fetch(a.cQ + (int64_t)b0 * a.sQ + GOFFN(G_Q), vQ, q);
+    rPn.fetch(a.P + (int64_t)b0 * a.P_bs + GOFFN(G_P), vP, q);
+    const double xnom = isx ? (double)a.xn[(int64_t)b * a.sx + GOFFN(G_x) + ix] : 0.0;
+    rQn.put(Lw + oQ, q); rPn.put(Lw + oP, q);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const double dx = isx ? x - xnom : 0.0;
+    if (isx && wr) a.x[(int64_t)b * a.x_bs + GOFFN(G_x) + ix] = (T)x;
+    const R32Vec vx = r32_spread(isx ? x : 0.0, upper_row), vdx = r32_spread(dx, upper_row);
+    double alcol = 0.0;
+    if (al) r32_al<T, NX, NU>(a.al, N, b, a.batch, vx, true, rho, q, upper_row, deriv, ix, isx, J0, viol, alcol);
+    double qx = 0.0, s = 0.0;
+    r32_states1<NX>(qx, vx, L, oQ + ix, NX);
+    r32_states1<NX>(s, vdx, L, oP + ix, NX);
+    if (isx) {
+      const double ql = (double)a.cq[(int64_t)b * a.sx + GOFFN(G_q) + ix];
+      J0 += x * (0.5 * qx + ql);
+      if (q == 0) J0 += (double)a.cc[(int64_t)b * (N + 1) + N];
+      if (wr) a.y[(int64_t)b * a.y_bs + GOFFN(G_y) + ix] = (T)(s + (double)a.p[(int64_t)b * a.p_bs + GOFFN(G_p) + ix]);
+      double lx = qx + ql;
+      if (al && deriv) lx -= alcol;
+      if (deriv) { dJ += lx * dxda; if (wr) a.q[(int64_t)b * a.q_bs + GOFFN(G_q) + ix] = (T)lx; }
+    }
+  }
+#undef GOFFN
+  // the sums over generic_merit_kernel's arrangement: entry r < 32 what its lane r held (constraint row r and state row r), entry
+  // 32 + e its input lane e
+  for (int e = lane; e < 2 * 2 * 64; e += 64) (&red[0][0][0])[e] = 0.0;
+  __syncthreads();
+  red[0][half][q] = J0;
+  red[1][half][q] = isx ? dJ : 0.0;
+  __syncthreads();
+  if (isu) { red[0][half][32 + iu] = J1; red[1][half][32 + iu] = dJ; }
+  __syncthreads();
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh) {
+    const double phi = gen_wave_sum(red[0][hh][lane]), dphi = gen_wave_sum(red[1][hh][lane]);
+    const int bs = 2 * (int)blockIdx.x + hh;
+    if (lane == 0 && (hh == 0 ? ok_own : ok_oth)) {    // (lane 0 sits in half 0: its own problem is hh = 0)
+      a.phi[bs] = phi;
+      if (deriv) a.dphi[bs] = dphi;
+      if (al) a.prob[bs].rho_est = a.prob[bs].rho;
+    }
+  }
+}
+
+}  // namespace altro_hip

@@ -397,6 +397,8 @@ typedef struct altro_hip_solve_options { /* AltroOptions, solver_options.hpp:16-
 #define ALTRO_HIP_FORM_FUSED_CLOCK 0x4000u       /* plan LANE: per-phase clock of the one-launch kernel on stderr (a tuning aid)            */
 #define ALTRO_HIP_FORM_NO_COMPACTION 0x10000u    /* plan LANE: the one-launch solve of a batch beyond one workgroup per compute unit stays ONE
                                                     launch (default: chunks of sweeps over the list of still-running problems)              */
+#define ALTRO_HIP_FORM_GENERIC_MERIT_LDS 0x20000u /* plans GENERIC / MFMA32: MeritFunction by the wave-per-problem LDS kernel also where the
+                                                    row-layout one runs (uniform n <= 31, m <= 8, n + m <= 32: kernels/ilqr_row32.hip)        */
 /* forms of a HANDLE: what altro_hip_merit / _expand / _sweep and every solve on it run with (a solve ORs its options' bits in) */
 int altro_hip_set_forms(altro_hip_batch* h, unsigned forms);
 unsigned altro_hip_get_forms(const altro_hip_batch* h);
