@@ -17,7 +17,7 @@ template <typename T>
 int al_upload_typed(altro_hip_batch* h) {
   const int64_t B = h->batch;
   h->al_Gpad_count = 0;
-  for (void** p : {(void**)&h->al_d_knots, (void**)&h->al_d_big, &h->al_d_G, &h->al_d_Gpad, &h->al_d_g, &h->al_d_z})
+  for (void** p : {(void**)&h->al_d_knots, (void**)&h->al_d_big, (void**)&h->al_d_gsel, &h->al_d_G, &h->al_d_Gpad, &h->al_d_g, &h->al_d_z})
     if (*p) { (void)hipFree(*p); *p = nullptr; }
   if (h->al_defs.empty()) { h->al_rows = 0; return 0; }
   // G on the device: p x (n + m) column-major as given on plan LANE; on plan MFMA16 p x 16 in the tile's own column order
@@ -128,6 +128,29 @@ int al_upload_typed(altro_hip_batch* h) {
     max_ncon = std::max(max_ncon, gen ? bk.ncon : ns);
   }
   h->al_max_ncon = max_ncon;
+  if (gen && !h->ragged) {   // plan GENERIC: which blocks are bound-type (AlTable::gsel; the expansion's Gauss-Newton term is then diagonal)
+    std::vector<int> gsel(defs.size() * (size_t)(1 + GEN_MAXP), 0);
+    const int wn = h->n + h->m;
+    for (size_t i = 0; i < defs.size(); ++i) {
+      const AlDef& d = defs[i];
+      bool sel = d.cone != CONE_SOC && !d.user && d.p <= GEN_MAXP;
+      for (int r = 0; r < d.p && sel; ++r) {
+        int nz = 0, at = -1;
+        for (int e = 0; e < wn; ++e) {
+          const double v = h->al_G[(size_t)d.G_off + r + (size_t)e * d.p];
+          if (v != 0.0) { ++nz; at = e; if (v != 1.0 && v != -1.0) sel = false; }
+        }
+        if (nz != 1) sel = false;
+        else gsel[i * (size_t)(1 + GEN_MAXP) + 1 + r] = at;
+      }
+      gsel[i * (size_t)(1 + GEN_MAXP)] = sel ? 1 : 0;
+    }
+    if (!gsel.empty()) {
+      int rcg = dmalloc(h, (void**)&h->al_d_gsel, gsel.size() * sizeof(int));
+      if (rcg) return rcg;
+      HIP_TRY(hipMemcpy(h->al_d_gsel, gsel.data(), gsel.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+  }
   h->al_row32_ok = true;   // (kernels/ilqr_row32.hip: a lane position per row, the row-wise cones)
   for (const AlDef& d : defs) if (d.cone == CONE_SOC || d.p > 32 || d.user) h->al_row32_ok = false;
   h->al_rows = rows;
@@ -343,7 +366,7 @@ int gen_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int 
   a.al.enabled = h->al_defs.empty() ? 0 : 1;
   a.al.uniform = h->al_uniform; a.al.rows_per_knot = h->al_rows_per_knot; a.al.N = h->N; a.al.G_count = h->al_G_count;
   a.al.has_soc = h->al_has_soc; a.al.all_sel = h->al_all_sel; a.al.Gpad = nullptr; a.al.Gpad_count = 0;
-  a.al.big = h->al_d_big;
+  a.al.big = h->al_d_big; a.al.gsel = h->al_d_gsel;
   // MeritFunction in the row layout of kernels/ilqr_row32.hip: plan MFMA32's shapes (also on a handle created as plan GENERIC), fp64,
   // dynamics as data, every constraint block in a row-wise cone with at most 32 rows
   a.row32 = (sizeof(T) == 8 && !h->ragged && !h->model_set && tile32_supported(n, m) &&

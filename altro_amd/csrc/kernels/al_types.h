@@ -76,6 +76,9 @@ struct AlTable {
   int Gpad_count;        // its elements
   int all_sel;           // every block is bound-type (AlKnot::sel): the Gauss-Newton blocks are diagonal
   int has_soc;           // some block is a second-order cone (kernels instantiated without the cone's code serve handles that have none)
+  // plan GENERIC: per block definition [1 + GEN_MAXP] ints -- [0] != 0: every row of G is +-e_idx (a bound-type block: the Gauss-Newton
+  // term of such a block is diagonal), [1 + i] = idx of row i (device column order) -- or null
+  const int* gsel = nullptr;
   int max_ncon = 0;      // most blocks / slots any knot point has (plan MFMA16: above AL_MAXC the merit kernel's wide instantiation runs)
 };
 #define ALTRO_CONST_AS __attribute__((address_space(4)))
