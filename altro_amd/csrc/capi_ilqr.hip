@@ -141,7 +141,7 @@ int al_upload_typed(altro_hip_batch* h) {
           if (v != 0.0) { ++nz; at = e; if (v != 1.0 && v != -1.0) sel = false; }
         }
         if (nz != 1) sel = false;
-        else gsel[i * (size_t)(1 + GEN_MAXP) + 1 + r] = at;
+        else gsel[i * (size_t)(1 + GEN_MAXP) + 1 + r] = h->al_G[(size_t)d.G_off + r + (size_t)at * d.p] > 0 ? at + 1 : -(at + 1);
       }
       gsel[i * (size_t)(1 + GEN_MAXP)] = sel ? 1 : 0;
     }

@@ -77,7 +77,7 @@ struct AlTable {
   int all_sel;           // every block is bound-type (AlKnot::sel): the Gauss-Newton blocks are diagonal
   int has_soc;           // some block is a second-order cone (kernels instantiated without the cone's code serve handles that have none)
   // plan GENERIC: per block definition [1 + GEN_MAXP] ints -- [0] != 0: every row of G is +-e_idx (a bound-type block: the Gauss-Newton
-  // term of such a block is diagonal), [1 + i] = idx of row i (device column order) -- or null
+  // term of such a block is diagonal), [1 + i] = +(idx + 1) / -(idx + 1) for row i = +e_idx / -e_idx (the caller's column order) -- or null
   const int* gsel = nullptr;
   int max_ncon = 0;      // most blocks / slots any knot point has (plan MFMA16: above AL_MAXC the merit kernel's wide instantiation runs)
 };

@@ -156,11 +156,20 @@ __device__ __forceinline__ void gen_al_rows(const AlTable<T>& t, int k, int b, i
     jv[c * GEN_MAXP + i] = 0.0;
     if (jd) jd[c * GEN_MAXP + i] = 0.0;
     if (Jm && i < AL_MAXSOC * AL_MAXSOC) { Jm[c * 16 + i] = 0.0; Hm[c * 16 + i] = 0.0; }
+    // (a bound-type block -- AlTable::gsel: every row +-e_idx -- adds one product to exact zeros: that product alone, no walk over G)
+    const int* sd = t.gsel ? t.gsel + (int64_t)kn.def[c] * (1 + GEN_MAXP) : nullptr;
+    const bool bsel = sd && sd[0];
     auto value = [&](int r) -> double {
       double s = 0.0;
-      for (int e = 0; e < n; ++e) s += (double)G[r + e * p] * xs[e];
-      if (!terminal)
-        for (int e = 0; e < m; ++e) s += (double)G[r + (n + e) * p] * us[e];
+      if (bsel) {
+        const int se = sd[1 + r], e = (se < 0 ? -se : se) - 1;
+        if (e < n) s += (double)G[r + e * p] * xs[e];
+        else if (!terminal) s += (double)G[r + e * p] * us[e - n];
+      } else {
+        for (int e = 0; e < n; ++e) s += (double)G[r + e * p] * xs[e];
+        if (!terminal)
+          for (int e = 0; e < m; ++e) s += (double)G[r + (n + e) * p] * us[e];
+      }
       const double gi = kn.g_per_problem[c] ? (double)t.g[kn.g_off[c] + (int64_t)r * B + b] : (double)t.g[kn.g_off[c] + r];
       return s - gi;
     };
@@ -228,7 +237,13 @@ __device__ __forceinline__ double gen_al_col(const AlTable<T>& t, int k, int e, 
   for (int c = 0; c < ncon; ++c) {
     const int p = kn.p[c];
     const T* G = t.G + kn.G_off[c];
-    for (int i = 0; i < p; ++i) s += (double)G[i + e * p] * w[c * GEN_MAXP + i];
+    const int* sd = t.gsel ? t.gsel + (int64_t)kn.def[c] * (1 + GEN_MAXP) : nullptr;
+    if (sd && sd[0]) {   // bound-type: the rows that select column e (the others would add exact zeros)
+      for (int i = 0; i < p; ++i)
+        if (sd[1 + i] == e + 1 || sd[1 + i] == -(e + 1)) s += (double)G[i + e * p] * w[c * GEN_MAXP + i];
+    } else {
+      for (int i = 0; i < p; ++i) s += (double)G[i + e * p] * w[c * GEN_MAXP + i];
+    }
   }
   return s;
 }
@@ -626,10 +641,10 @@ __global__ __launch_bounds__(64) void generic_expand_al_kernel(IlqrGenArgs<T> a)
           // a bound-type block (every row +-e_idx: input and state boxes, pins -- most constraints of an MPC problem): (J G)^T (J G) is
           // diagonal, entry idx = the sum of J_ii^2 over the rows that select idx -- the general loop below adds exactly these terms and
           // exact zeros, at two loads of G per row and entry (16 loads for each of the 289 entries of a (13, 4) knot point with an input
-          // box: the texture path bound this kernel at 1.3 - 3.1 ms per launch, profiles/r06j_solve_13_4_4096_128_3___bounds.txt)
+          // box: the texture path bound this kernel at 1.3 - 3.1 ms per launch, profiles/r06h_solve_13_4_bounds_before_row32.txt)
           if (r == cc)
             for (int i = 0; i < p; ++i)
-              if (sd[1 + i] == r) { const double jii = jd[cidx * GEN_MAXP + i]; s += (jii * 1.0) * (jii * 1.0); }
+              if (sd[1 + i] == r + 1 || sd[1 + i] == -(r + 1)) { const double jii = jd[cidx * GEN_MAXP + i]; s += (jii * 1.0) * (jii * 1.0); }
         } else if (kn.cone[cidx] != CONE_SOC) {   // diagonal projection Jacobian: (J G)_(i r) = J_ii G_ir
           for (int i = 0; i < p; ++i) {
             const double jii = jd[cidx * GEN_MAXP + i];

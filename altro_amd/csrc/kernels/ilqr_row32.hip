@@ -6,7 +6,7 @@
 // Why: after round 6 gave these shapes a matrix-core TVLQR pair, a whole solve at (13, 4) spent half to three quarters of its time in
 // generic_merit_kernel -- one wave per problem, every vector through LDS, four to five barriers and a dozen dependent global round
 // trips per knot point: 1.87 ms per evaluation at 4096 problems x 128 knot points where the backward sweep takes 0.72
-// (profiles/r06h_solve_13_4.txt).  The (12, 4) tile's answer (kernels/ilqr_merit2_dpp.hip) carries over:
+// (profiles/r06h_solve_13_4_before_row32.txt).  The (12, 4) tile's answer (kernels/ilqr_merit2_dpp.hip) carries over:
 //   * a problem lives in HALF a wave: lane position q = lane % 32 holds x_q (q < n) or u_e at q = 31 - e (inputs from the top down:
 //     their positions do not depend on n); two problems per wave;
 //   * a vector of 32 positions is two registers per lane -- positions 0..15 and 16..31 as seen from BOTH rows of 16 lanes of the half
@@ -230,9 +230,27 @@ __device__ __forceinline__ void r32_gcol(double& acc, const R32Vec& jv, const T*
     }
   }
 }
+// (bound-type blocks -- AlTable::gsel: every row +-e_idx -- load nothing of G: a row's value is +-[x; u]_idx, fetched from the lane
+//  that holds it; a column's coefficients are the signs of the rows that select it, compared out of the table's scalars)
+template <int J0 = 0>
+__device__ __forceinline__ void r32_selcol(double& acc, const R32Vec& jv, const int* sd, int p, int col1) {
+  if constexpr (J0 < 32) {
+    if (J0 < p) {
+      double c[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int se = sd[1 + (J0 + t < p ? J0 + t : p - 1)];   // (wave-uniform: a scalar load)
+        c[t] = (J0 + t < p && se == col1) ? 1.0 : ((J0 + t < p && se == -col1) ? -1.0 : 0.0);
+      }
+      if constexpr (J0 < 16) r32_one<J0, 1, 4>(acc, jv.lo, c);
+      else r32_one<J0 - 16, 1, 4>(acc, jv.hi, c);
+      r32_selcol<J0 + 4>(acc, jv, sd, p, col1);
+    }
+  }
+}
 template <typename T, int NX, int NU>
-__device__ __forceinline__ void r32_al(const AlTable<T>& t, int k, int b, int64_t B, const R32Vec& w, bool terminal, double rho_est, int q, bool upper_row,
-                                       bool want_col, int col, bool has_col, double& cost, double& viol, double& colsum) {
+__device__ __forceinline__ void r32_al(const AlTable<T>& t, int k, int b, int64_t B, const R32Vec& w, double wv, bool terminal, double rho_est, int q,
+                                       bool upper_row, bool want_col, int col, bool has_col, double& cost, double& viol, double& colsum) {
   int zshift;
   const AlKnotBig ALTRO_CONST_AS& kn = gen_knot<T>(t, k, zshift);
   const int ncon = kn.ncon;
@@ -242,9 +260,17 @@ __device__ __forceinline__ void r32_al(const AlTable<T>& t, int k, int b, int64_
     const int p = kn.p[c], cone = kn.cone[c];
     const T* G = t.G + kn.G_off[c];
     const bool rl = q < p;
+    const int* sd = t.gsel ? t.gsel + (int64_t)kn.def[c] * (1 + GEN_MAXP) : nullptr;
+    const bool bsel = sd && sd[0];                      // (wave-uniform)
     double s = 0.0;
-    r32_g1<T, NX, false>(s, w, G + (rl ? q : 0), p);
-    if (!terminal) r32_g1<T, NU, true>(s, w, G + (rl ? q : 0) + (int64_t)NX * p, p);
+    if (bsel) {
+      const int se = rl ? sd[1 + q] : 1, e = (se < 0 ? -se : se) - 1;
+      const double wsel = __shfl(wv, e < NX ? e : 31 - (e - NX), 32);   // (this half's lane that holds [x; u]_e)
+      if (e < NX || !terminal) s = se < 0 ? -wsel : wsel;
+    } else {
+      r32_g1<T, NX, false>(s, w, G + (rl ? q : 0), p);
+      if (!terminal) r32_g1<T, NU, true>(s, w, G + (rl ? q : 0) + (int64_t)NX * p, p);
+    }
     double jv = 0.0;
     if (rl) {
       const double gi = kn.g_per_problem[c] ? (double)t.g[kn.g_off[c] + (int64_t)q * B + b] : (double)t.g[kn.g_off[c] + q];
@@ -258,7 +284,8 @@ __device__ __forceinline__ void r32_al(const AlTable<T>& t, int k, int b, int64_
     }
     if (want_col) {                                     // (wave-uniform)
       const R32Vec jvv = r32_spread(jv, upper_row);
-      r32_gcol<T>(colsum, jvv, G + (int64_t)(has_col ? col : 0) * p, p);   // (rows 0..p-1 sit at positions 0..p-1, like states)
+      if (bsel) r32_selcol(colsum, jvv, sd, p, has_col ? col + 1 : 0);
+      else r32_gcol<T>(colsum, jvv, G + (int64_t)(has_col ? col : 0) * p, p);   // (rows 0..p-1 sit at positions 0..p-1, like states)
     }
   }
 }
@@ -368,7 +395,7 @@ __global__ __launch_bounds__(64, WPS) void row32_merit_kernel(IlqrGenArgs<T> a) 
     double alcol = 0.0;
     if (al) {   // the constraint rows' cost shares at the candidate point and the gradient's column sums
       double Jal = 0.0;
-      r32_al<T, NX, NU>(a.al, k, b, a.batch, vw, false, rho, q, upper_row, deriv, isx ? ix : NX + iu, has, Jal, viol, alcol);
+      r32_al<T, NX, NU>(a.al, k, b, a.batch, vw, isx ? x : uv, false, rho, q, upper_row, deriv, isx ? ix : NX + iu, has, Jal, viol, alcol);
       J0 += Jal;
     }
     // rows of [Q H^T] (state lanes) against [x; u]
@@ -412,7 +439,7 @@ __global__ __launch_bounds__(64, WPS) void row32_merit_kernel(IlqrGenArgs<T> a) 
     if (isx && wr) a.x[(int64_t)b * a.x_bs + GOFFN(G_x) + ix] = (T)x;
     const R32Vec vx = r32_spread(isx ? x : 0.0, upper_row), vdx = r32_spread(dx, upper_row);
     double alcol = 0.0;
-    if (al) r32_al<T, NX, NU>(a.al, N, b, a.batch, vx, true, rho, q, upper_row, deriv, ix, isx, J0, viol, alcol);
+    if (al) r32_al<T, NX, NU>(a.al, N, b, a.batch, vx, isx ? x : 0.0, true, rho, q, upper_row, deriv, ix, isx, J0, viol, alcol);
     double qx = 0.0, s = 0.0;
     r32_states1<NX>(qx, vx, L, oQ + ix, NX);
     r32_states1<NX>(s, vdx, L, oP + ix, NX);

@@ -662,6 +662,45 @@ def mfma32_entry(n, m, device, steps, torch, cpu_seconds=2.0, N=128, batch=4096)
     assert (bt.get("status") == -1).all()
     bytes_b, bytes_f = bt.algorithmic_bytes(0), bt.algorithmic_bytes(1)
     bt.close()
+    # the iLQR loop on the same shape (tools/solve_shapes.py's problems, 16 of them tiled): one MeritFunction evaluation with derivative
+    # (kernels/ilqr_row32.hip; "lds": plan GENERIC's wave-per-problem kernel it replaced on these shapes) and whole solves, without and
+    # with an input box -- host clock, stream drained
+    ilqr = {}
+    try:
+        pl = problems.ilqr12x4_problem(16, N, True, n=n, m=m)
+        G = np.zeros((2 * m, n + m)); G[:m, n:] = np.eye(m); G[m:, n:] = -np.eye(m)
+        for key, forms in (("row_layout", 0), ("lds", altro_amd.FORM_GENERIC_MERIT_LDS)):
+            b2 = altro_amd.Batch(N, n, m, batch, device=device)
+            b2.set_forms(forms)
+            b2.set_dynamics(rep(pl["A"]), rep(pl["B"]), rep(pl["f"]))
+            b2.set_tracking_cost(rep(pl["Qd"]), rep(pl["Rd"]), rep(pl["xref"]), rep(pl["uref"]))
+            b2.set_initial_state(rep(pl["x0"])); b2.set_input_guess(rep(pl["u0"]))
+            b2.open_loop_rollout(); b2.accept(); b2.expand(); b2.backward()
+            ts = []
+            for _ in range(6):
+                torch.cuda.synchronize(); t1 = time.perf_counter()
+                b2.merit(1.0); b2.synchronize()
+                ts.append((time.perf_counter() - t1) * 1e3)
+            e = {"merit_with_derivative_ms": sorted(ts[1:])[len(ts[1:]) // 2]}
+            if key == "row_layout":
+                for tag, bounds in (("solve", False), ("solve_input_box", True)):
+                    if bounds:
+                        b2.add_linear_constraint(0, N - 1, altro_amd.CONE_INEQUALITY, G, np.full(2 * m, 0.5))
+                    t2 = []
+                    for _ in range(3):
+                        b2.set_input_guess(rep(pl["u0"]))
+                        if bounds:
+                            b2.reset_duals(1.0)
+                        b2.synchronize(); t1 = time.perf_counter()
+                        res = b2.ilqr_solve(iterations_max=40)
+                        b2.synchronize()
+                        t2.append((time.perf_counter() - t1) * 1e3)
+                    e[tag] = {"ms": sorted(t2[1:])[0], "sweeps": int(res["sweeps"]), "merit_launches": int(res["merit_launches"]),
+                              "converged": int((res["status"] == 0).sum())}
+            ilqr[key] = e
+            b2.close()
+    except Exception as ex:  # noqa: BLE001
+        ilqr["error"] = str(ex)
     out = {"workload": "TVLQR sweep of random LTV problems, (n, m) = (%d, %d): plan MFMA32, 2 x 2 tiles of v_mfma_f64_16x16x4" % (n, m),
            "horizon_N": N, "n": n, "m": m, "batch": batch, "dtype": "f64", "steps": steps, "ms_per_step": elapsed / steps * 1e3,
            "value": batch * steps / elapsed, "unit": "problem-sweeps/s", "kernels": {}}
@@ -674,6 +713,7 @@ def mfma32_entry(n, m, device, steps, torch, cpu_seconds=2.0, N=128, batch=4096)
     if cpu_seconds > 0:
         out["cpu_baseline"] = cpu_sweep_rate(N, n, m, cpu_seconds)
         out["vs_cpu_single_thread"] = out["value"] / out["cpu_baseline"]["value"]
+    out["ilqr_loop"] = ilqr
     out["seconds_total"] = time.perf_counter() - t_setup
     return out
 
