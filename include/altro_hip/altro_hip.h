@@ -101,7 +101,8 @@ typedef enum altro_hip_plan {
   ALTRO_HIP_PLAN_LANE = 3,    /* lane-per-problem, batch structure-of-arrays, n <= 6 and m <= 3         */
   ALTRO_HIP_PLAN_MFMA32 = 4   /* wave-per-problem, 2 x 2 tiles of v_mfma_f64_16x16x4 (kernels/tvlqr_tile32.hip): fp64, uniform dimensions,
                                  12 < n <= 31, m <= 8, n + m <= 32 (and n <= 12 with 4 < m <= 8).  Plan GENERIC's arrays and iLQR loop with
-                                 matrix-core sweeps: K, d within 1e-8 of the CPU path (measured 1e-13), not bit for bit            */
+                                 matrix-core sweeps: K, d within 1e-8 of the CPU path (measured 1e-13), not bit for bit.  MeritFunction
+                                 runs a row-layout kernel per shape (kernels/ilqr_row32.hip: plan GENERIC's values)      */
 } altro_hip_plan;
 
 /* create flags */
