@@ -81,10 +81,17 @@ def main():
 
     add("C1 (12,4) N=256 x4096 fp64", line["roofline"])
     add("C1", line.get("roofline_forward"))
-    lane_inst = lambda oc, rl: f"<{oc['n']}, {oc['m']}" if rl and rl["kernel"].startswith("lane_") else None
+    def lane_inst(oc, rl):   # the template arguments that tell a shape's instantiation from its neighbours' in the summary
+        if not rl:
+            return None
+        if rl["kernel"].startswith("lane_") or rl["kernel"].startswith("tile32_backward"):
+            return f"<{oc['n']}, {oc['m']}"
+        if rl["kernel"].startswith("tile32_forward"):
+            return f"<{(oc['n'] + 3) // 4}, {(oc['m'] + 3) // 4}"
+        return None
     for key, oc in line["config"].get("other_configs", {}).items():
         label = {"c2": "C2 (2,1) N=100 x8192", "c3_8192": "C3 (4,2) N=50 x8192", "c3_65536": "C3 (4,2) N=50 x65536",
-                 "c4": "C4 (12,4) N=512 x16384 fp32"}.get(key, key)
+                 "c4": "C4 (12,4) N=512 x16384 fp32", "mfma32_13x4": "plan MFMA32 (13,4) N=128 x4096", "mfma32_28x4": "plan MFMA32 (28,4) N=128 x4096"}.get(key, key)
         add(label, oc.get("roofline"), lane_inst(oc, oc.get("roofline")))
         add(label, oc.get("roofline_forward"), lane_inst(oc, oc.get("roofline_forward")))
 
