@@ -128,6 +128,7 @@ int al_upload_typed(altro_hip_batch* h) {
     max_ncon = std::max(max_ncon, gen ? bk.ncon : ns);
   }
   h->al_max_ncon = max_ncon;
+  h->al_all_gsel = gen && !h->ragged && !defs.empty();
   if (gen && !h->ragged) {   // plan GENERIC: which blocks are bound-type (AlTable::gsel; the expansion's Gauss-Newton term is then diagonal)
     std::vector<int> gsel(defs.size() * (size_t)(1 + GEN_MAXP), 0);
     const int wn = h->n + h->m;
@@ -144,6 +145,7 @@ int al_upload_typed(altro_hip_batch* h) {
         else gsel[i * (size_t)(1 + GEN_MAXP) + 1 + r] = h->al_G[(size_t)d.G_off + r + (size_t)at * d.p] > 0 ? at + 1 : -(at + 1);
       }
       gsel[i * (size_t)(1 + GEN_MAXP)] = sel ? 1 : 0;
+      if (!sel) h->al_all_gsel = false;
     }
     if (!gsel.empty()) {
       int rcg = dmalloc(h, (void**)&h->al_d_gsel, gsel.size() * sizeof(int));

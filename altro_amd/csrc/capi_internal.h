@@ -140,6 +140,7 @@ struct altro_hip_batch {
   void *al_d_G = nullptr, *al_d_g = nullptr, *al_d_z = nullptr;
   void* al_d_Gpad = nullptr;                 // AlTable::Gpad (plan MFMA16)
   int al_Gpad_count = 0;
+  bool al_all_gsel = false;              // plan GENERIC: every block is bound-type (the Hessian blocks change on their diagonals only)
   int* al_d_gsel = nullptr;              // plan GENERIC: AlTable::gsel (bound-type blocks)
   bool al_row32_ok = false;              // every block fits kernels/ilqr_row32.hip (row-wise cone, <= 32 rows)
   int al_max_ncon = 0;                   // most blocks (plan MFMA16: slots, al_types.h) any knot point has

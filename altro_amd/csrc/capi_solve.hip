@@ -148,7 +148,10 @@ int SolveRun::configure(const altro_hip_solve_options* opts) {
   dual = h->plan == ALTRO_HIP_PLAN_MFMA16 && !form(h, ALTRO_HIP_FORM_NO_SPECULATION) && !form(h, ALTRO_HIP_FORM_NO_MERIT2);
   // Plan MFMA16, diagonal cost, bound-type blocks only: the Hessian blocks differ from sweep to sweep on their diagonal alone, so
   // after this solve's first (full) Hessian expansion the later ones store 16 values per knot point instead of 158 (EXPAND_DIAG)
-  diag_mode = (h->plan == ALTRO_HIP_PLAN_MFMA16 && al && !h->cost_dense && h->al_all_sel) ? EXPAND_DIAG : 0;
+  // (plan GENERIC / MFMA32, every block bound-type -- AlTable::gsel --: the constraints touch the Hessian blocks' diagonals only,
+  //  whatever the cost's own blocks are: generic_expand_al_kernel then rewrites n + m entries per knot point instead of (n + m)^2)
+  diag_mode = ((h->plan == ALTRO_HIP_PLAN_MFMA16 && al && !h->cost_dense && h->al_all_sel) ||
+               (h->plan == ALTRO_HIP_PLAN_GENERIC && al && !h->ragged && h->al_all_gsel)) ? EXPAND_DIAG : 0;
   running = h->batch;
   // Affine line-search trials (kernels/ilqr_merit2_dpp.hip, AFF): plan MFMA16, dynamics as data, fp64; the sweep's phi(0) evaluation
   // leaves the base trajectory and its sensitivity behind.  ALTRO_HIP_FORM_ROLLOUT_ROUNDS keeps every trial a rollout.

@@ -627,7 +627,10 @@ __global__ __launch_bounds__(64) void generic_expand_al_kernel(IlqrGenArgs<T> a)
     int zshift;
     const AlKnotBig ALTRO_CONST_AS& kn = gen_knot<T>(a.al, k, zshift);
     const int wt = terminal ? n : w;
-    for (int t = lane; t < wt * wt; t += 64) {
+    // EXPAND_DIAG (the host: every block of the handle is bound-type, and this solve has stored the full blocks once): what is off the
+    // diagonal cannot have changed -- the diagonal's wt entries only
+    const bool diag_only = (a.mode & EXPAND_DIAG) != 0;
+    for (int t = diag_only ? lane * (wt + 1) : lane; t < wt * wt; t += diag_only ? 64 * (wt + 1) : 64) {
       const int r = t % wt, cc = t / wt;          // entry (r, cc) of the (n + m) x (n + m) block, column-major walk
       if (r < n && cc >= n) continue;             // the lux^T block is not stored
       double v = r < n ? (double)Qk[r + cc * n] : (cc < n ? (double)Hk[(r - n) + cc * m] : (double)Rk[(r - n) + (cc - n) * m]);
