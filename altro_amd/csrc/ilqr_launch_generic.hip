@@ -8,20 +8,20 @@
 namespace altro_hip {
 
 // the row-layout merit kernels, eight translation units by n mod 8 (row32_unit.inc)
-int row32_merit_unit0(hipStream_t, const IlqrGenArgs<double>&); int row32_merit_unit1(hipStream_t, const IlqrGenArgs<double>&);
-int row32_merit_unit2(hipStream_t, const IlqrGenArgs<double>&); int row32_merit_unit3(hipStream_t, const IlqrGenArgs<double>&);
-int row32_merit_unit4(hipStream_t, const IlqrGenArgs<double>&); int row32_merit_unit5(hipStream_t, const IlqrGenArgs<double>&);
-int row32_merit_unit6(hipStream_t, const IlqrGenArgs<double>&); int row32_merit_unit7(hipStream_t, const IlqrGenArgs<double>&);
-static int row32_merit_dispatch(hipStream_t stream, const IlqrGenArgs<double>& a) {
+int row32_merit_unit0(hipStream_t, const IlqrGenArgs<double>&, bool); int row32_merit_unit1(hipStream_t, const IlqrGenArgs<double>&, bool);
+int row32_merit_unit2(hipStream_t, const IlqrGenArgs<double>&, bool); int row32_merit_unit3(hipStream_t, const IlqrGenArgs<double>&, bool);
+int row32_merit_unit4(hipStream_t, const IlqrGenArgs<double>&, bool); int row32_merit_unit5(hipStream_t, const IlqrGenArgs<double>&, bool);
+int row32_merit_unit6(hipStream_t, const IlqrGenArgs<double>&, bool); int row32_merit_unit7(hipStream_t, const IlqrGenArgs<double>&, bool);
+static int row32_merit_dispatch(hipStream_t stream, const IlqrGenArgs<double>& a, bool stat = false) {
   switch (a.n & 7) {
-    case 0: return row32_merit_unit0(stream, a);
-    case 1: return row32_merit_unit1(stream, a);
-    case 2: return row32_merit_unit2(stream, a);
-    case 3: return row32_merit_unit3(stream, a);
-    case 4: return row32_merit_unit4(stream, a);
-    case 5: return row32_merit_unit5(stream, a);
-    case 6: return row32_merit_unit6(stream, a);
-    default: return row32_merit_unit7(stream, a);
+    case 0: return row32_merit_unit0(stream, a, stat);
+    case 1: return row32_merit_unit1(stream, a, stat);
+    case 2: return row32_merit_unit2(stream, a, stat);
+    case 3: return row32_merit_unit3(stream, a, stat);
+    case 4: return row32_merit_unit4(stream, a, stat);
+    case 5: return row32_merit_unit5(stream, a, stat);
+    case 6: return row32_merit_unit6(stream, a, stat);
+    default: return row32_merit_unit7(stream, a, stat);
   }
 }
 
@@ -83,7 +83,15 @@ static int gen_launch(hipStream_t stream, int which, const IlqrGenArgs<T>& a) {
       else hipLaunchKernelGGL((generic_merit_kernel<T, false>), waves, b64, jv, stream, a);
       break;
     }
-    case IK_STATIONARITY: hipLaunchKernelGGL(generic_stationarity_kernel<T>, waves, b64, 0, stream, a); break;
+    case IK_STATIONARITY:
+      if constexpr (sizeof(T) == 8) {
+        if (a.row32) {   // (kernels/ilqr_row32.hip: row32_stationarity_kernel)
+          const int rc = row32_merit_dispatch(stream, a, true);
+          if (rc != 1) return rc;
+        }
+      }
+      hipLaunchKernelGGL(generic_stationarity_kernel<T>, waves, b64, 0, stream, a);
+      break;
     case IK_SHIFT: hipLaunchKernelGGL(generic_shift_kernel<T>, dim3((unsigned)(((int64_t)a.batch * (a.n + a.m) + 255) / 256)), b256, 0, stream, a); break;
     default: return 1;
   }

@@ -475,4 +475,80 @@ __global__ __launch_bounds__(64, WPS) void row32_merit_kernel(IlqrGenArgs<T> a) 
   }
 }
 
+// ---- Stationarity and Feasibility (solver.cpp:207-231) of the candidate trajectory in the same layout: generic_stationarity_kernel's
+// values (maxima: no order to keep).  Lane j's product A_k^T y_{k+1} (B_k^T y_{k+1} in the input lanes) runs down COLUMN j of the
+// block -- in global memory a dozen cache lines per load instruction, in the image a conflict-free read at stride one.
+template <typename T, int NX, int NU, int WPS>
+__global__ __launch_bounds__(64, WPS) void row32_stationarity_kernel(IlqrGenArgs<T> a) {
+  constexpr int NN = NX * NX, NM = NX * NU, oA = 0, oB = NN, IMG = (NN + NM + 1) & ~1;
+  __shared__ double img[2][IMG];
+  const int lane = threadIdx.x, half = lane >> 5, q = lane & 31;
+  const bool upper_row = (lane & 16) != 0;
+  const int b0 = 2 * (int)blockIdx.x;
+  const int b_own = b0 + half, b_oth = b0 + (1 - half);
+  const bool ok_own = b_own < a.batch && !(a.active && !a.active[b_own]);
+  const bool ok_oth = b_oth < a.batch && !(a.active && !a.active[b_oth]);
+  if (!ok_own && !ok_oth) return;
+  const int b = ok_own ? b_own : b_oth, hb = b - b0;
+  const int N = a.N;
+  const bool isx = q < NX, isu = q >= 32 - NU, has = isx || isu;
+  const int iu = isu ? 31 - q : 0, ix = isx ? q : 0;
+  const bool al = a.al.enabled != 0;
+  const r32_lds_t* const L = (const r32_lds_t*)&img[half][0];
+  r32_lds_t* const Lw = (r32_lds_t*)&img[half][0];
+  const int64_t* off0 = a.off;
+  const int64_t* off1 = a.off + (N > 1 ? G_NUM : 0);
+#define R32_STRIDE(arr) (off1[arr] - off0[arr])
+  const T* gA = a.A + (int64_t)b0 * a.A_bs + off0[G_A];   const int64_t sA = R32_STRIDE(G_A);   const int vA = hb * (int)a.A_bs + 2 * q;
+  const T* gB = a.B + (int64_t)b0 * a.B_bs + off0[G_B];   const int64_t sB = R32_STRIDE(G_B);   const int vB = hb * (int)a.B_bs + 2 * q;
+  const T* gy = a.y + (int64_t)b * a.y_bs + off0[G_y] + ix;    const int64_t sy_ = R32_STRIDE(G_y);
+  const T* glx = a.q + (int64_t)b * a.q_bs + off0[G_q] + ix;   const int64_t sq_ = R32_STRIDE(G_q);
+  const T* glu = a.r + (int64_t)b * a.r_bs + off0[G_r] + iu;   const int64_t sr_ = R32_STRIDE(G_r);
+  const T* gx = a.x + (int64_t)b * a.x_bs + off0[G_x] + ix;    const int64_t sx_ = R32_STRIDE(G_x);
+  const T* gu = a.u + (int64_t)b * a.u_bs + off0[G_u] + iu;    const int64_t su_ = R32_STRIDE(G_u);
+#undef R32_STRIDE
+  const double rho = al ? a.prob[b].rho : 1.0;
+  double res = 0.0, viol = 0.0;
+  R32Block<NN> rA;
+  R32Block<NM> rB;
+  rA.fetch(gA, vA, q); rB.fetch(gB, vB, q);
+  double yk = (double)*gy;                               // y_k (state lanes), carried from knot point to knot point
+  for (int k = 0; k < N; ++k) {
+    rA.put(Lw + oA, q); rB.put(Lw + oB, q);
+    gy += sy_;
+    const double yn = (double)*gy, lx = (double)*glx, lu = (double)*glu;
+    double xv = 0.0, uv = 0.0;
+    if (al) { xv = (double)*gx; uv = (double)*gu; }
+    if (k + 1 < N) { gA += sA; gB += sB; rA.fetch(gA, vA, q); rB.fetch(gB, vB, q); }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const R32Vec vy = r32_spread(isx ? yn : 0.0, upper_row);
+    double s = 0.0;
+    r32_states1<NX>(s, vy, L, isx ? oA + ix * NX : oB + iu * NX, 1);
+    if (isx) res = fmax(res, fabs((lx + s) - yk));
+    if (isu) res = fmax(res, fabs(lu + s));
+    if (al) {
+      const double wv = isx ? xv : (isu ? uv : 0.0);
+      const R32Vec vw = r32_spread(wv, upper_row);
+      double cost = 0.0, colsum = 0.0;
+      r32_al<T, NX, NU>(a.al, k, b, a.batch, vw, wv, false, rho, q, upper_row, false, 0, false, cost, viol, colsum);
+    }
+    yk = yn;
+    glx += sq_; glu += sr_; gx += sx_; gu += su_;
+  }
+  if (isx) res = fmax(res, fabs((double)*glx - yk));     // terminal: |lx_N - y_N|   (glx, yk stand at knot point N)
+  if (al) {
+    const double wv = isx ? (double)*gx : 0.0;
+    const R32Vec vw = r32_spread(wv, upper_row);
+    double cost = 0.0, colsum = 0.0;
+    r32_al<T, NX, NU>(a.al, N, b, a.batch, vw, wv, true, rho, q, upper_row, false, 0, false, cost, viol, colsum);
+  }
+  (void)has;
+  // the maxima over the half's 32 lanes
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) { res = fmax(res, __shfl_xor(res, o, 64)); viol = fmax(viol, __shfl_xor(viol, o, 64)); }
+  if (q == 0 && ok_own) { a.prob[b].stationarity = res; a.prob[b].feasibility = viol; }
+}
+
 }  // namespace altro_hip

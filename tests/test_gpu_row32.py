@@ -64,6 +64,9 @@ def evaluate(bt, batch):
         if deriv:
             _, _, lx, lu = bt.get_expansion()
             out["lx_" + name] = lx.copy(); out["lu_" + name] = lu.copy()
+            # Stationarity / Feasibility of that candidate (solver.cpp:207-231): row32_stationarity_kernel against generic_stationarity_kernel
+            out["stat_" + name] = np.asarray(bt.stationarity(), dtype=np.float64).copy()
+            out["feas_" + name] = bt.feasibility().copy()
     return out
 
 
