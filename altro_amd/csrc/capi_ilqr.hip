@@ -340,6 +340,12 @@ GenSizes gen_sizes(const altro_hip_batch* h) {
   }
   return z;
 }
+// the loop kernels of kernels/ilqr_row32.hip serve this handle: plan MFMA32's shapes (also on a handle created as plan GENERIC), fp64,
+// uniform dimensions, dynamics as data, every constraint block in a row-wise cone with at most 32 rows
+bool row32_eligible(const altro_hip_batch* h) {
+  return h->plan == ALTRO_HIP_PLAN_GENERIC && h->dtype == ALTRO_HIP_F64 && !h->ragged && !h->model_set && tile32_supported(h->n, h->m) &&
+         !form(h, ALTRO_HIP_FORM_GENERIC_MERIT_LDS) && (h->al_defs.empty() || h->al_row32_ok);
+}
 // plan GENERIC: any (n_k, m_k) up to 64, dynamics as data, quadratic cost, linear constraint blocks (kernels/ilqr_generic.hip)
 template <typename T>
 int gen_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int want_deriv, double alpha_const, int mode) {
@@ -371,8 +377,7 @@ int gen_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int 
   a.al.big = h->al_d_big; a.al.gsel = h->al_d_gsel;
   // MeritFunction in the row layout of kernels/ilqr_row32.hip: plan MFMA32's shapes (also on a handle created as plan GENERIC), fp64,
   // dynamics as data, every constraint block in a row-wise cone with at most 32 rows
-  a.row32 = (sizeof(T) == 8 && !h->ragged && !h->model_set && tile32_supported(n, m) &&
-             !form(h, ALTRO_HIP_FORM_GENERIC_MERIT_LDS) && (h->al_defs.empty() || h->al_row32_ok)) ? 1 : 0;
+  a.row32 = (sizeof(T) == 8 && row32_eligible(h)) ? 1 : 0;
   if (h->model_set) {   // a device model: the dynamics expansion rides with every gradient expansion of a stored trajectory
     a.mp = h->model;
     if (which == IK_EXPAND && (a.mode & EXPAND_GRADIENT)) a.mode |= EXPAND_DYN;

@@ -250,6 +250,8 @@ int SolveRun::prologue() {
   if (rc) return rc;
   if (dual && !al && !h->cost_dense && !h->model_set) {   // (ROLLOUT_INIT: linear dynamics as data, the diagonal cost's gradient: one pass)
     rc = ilqr_run(h, IK_ROLLOUT, false, false, 0, 0.0, ROLLOUT_INIT);
+  } else if (!al && row32_eligible(h)) {   // plan MFMA32's shapes: rollout, CopyTrajectory and the first expansion in one pass (row32_rollout_init_kernel)
+    rc = ilqr_run(h, IK_ROLLOUT, false, false, 0, 0.0, ROLLOUT_INIT);
   } else {
     rc = ilqr_run(h, IK_ROLLOUT, false, false, 0, 0.0);
     if (!rc) rc = ilqr_run(h, IK_ACCEPT, false, false, 0, 0.0);

@@ -8,20 +8,20 @@
 namespace altro_hip {
 
 // the row-layout merit kernels, eight translation units by n mod 8 (row32_unit.inc)
-int row32_merit_unit0(hipStream_t, const IlqrGenArgs<double>&, bool); int row32_merit_unit1(hipStream_t, const IlqrGenArgs<double>&, bool);
-int row32_merit_unit2(hipStream_t, const IlqrGenArgs<double>&, bool); int row32_merit_unit3(hipStream_t, const IlqrGenArgs<double>&, bool);
-int row32_merit_unit4(hipStream_t, const IlqrGenArgs<double>&, bool); int row32_merit_unit5(hipStream_t, const IlqrGenArgs<double>&, bool);
-int row32_merit_unit6(hipStream_t, const IlqrGenArgs<double>&, bool); int row32_merit_unit7(hipStream_t, const IlqrGenArgs<double>&, bool);
-static int row32_merit_dispatch(hipStream_t stream, const IlqrGenArgs<double>& a, bool stat = false) {
+int row32_merit_unit0(hipStream_t, const IlqrGenArgs<double>&, int); int row32_merit_unit1(hipStream_t, const IlqrGenArgs<double>&, int);
+int row32_merit_unit2(hipStream_t, const IlqrGenArgs<double>&, int); int row32_merit_unit3(hipStream_t, const IlqrGenArgs<double>&, int);
+int row32_merit_unit4(hipStream_t, const IlqrGenArgs<double>&, int); int row32_merit_unit5(hipStream_t, const IlqrGenArgs<double>&, int);
+int row32_merit_unit6(hipStream_t, const IlqrGenArgs<double>&, int); int row32_merit_unit7(hipStream_t, const IlqrGenArgs<double>&, int);
+static int row32_merit_dispatch(hipStream_t stream, const IlqrGenArgs<double>& a, int kind = 0) {
   switch (a.n & 7) {
-    case 0: return row32_merit_unit0(stream, a, stat);
-    case 1: return row32_merit_unit1(stream, a, stat);
-    case 2: return row32_merit_unit2(stream, a, stat);
-    case 3: return row32_merit_unit3(stream, a, stat);
-    case 4: return row32_merit_unit4(stream, a, stat);
-    case 5: return row32_merit_unit5(stream, a, stat);
-    case 6: return row32_merit_unit6(stream, a, stat);
-    default: return row32_merit_unit7(stream, a, stat);
+    case 0: return row32_merit_unit0(stream, a, kind);
+    case 1: return row32_merit_unit1(stream, a, kind);
+    case 2: return row32_merit_unit2(stream, a, kind);
+    case 3: return row32_merit_unit3(stream, a, kind);
+    case 4: return row32_merit_unit4(stream, a, kind);
+    case 5: return row32_merit_unit5(stream, a, kind);
+    case 6: return row32_merit_unit6(stream, a, kind);
+    default: return row32_merit_unit7(stream, a, kind);
   }
 }
 
@@ -59,7 +59,14 @@ static int gen_launch(hipStream_t stream, int which, const IlqrGenArgs<T>& a) {
   const int64_t flat_n = (int64_t)a.batch * (a.N + 1) * (a.n + a.m);
   const dim3 flat((unsigned)std::min<int64_t>((flat_n + 255) / 256, 1 << 20));
   switch (which) {
-    case IK_ROLLOUT: hipLaunchKernelGGL(generic_rollout_kernel<T>, waves, b64, 0, stream, a); break;
+    case IK_ROLLOUT:
+      if constexpr (sizeof(T) == 8) {
+        // ROLLOUT_INIT (the host asks for it only where it applies: capi_solve.hip): rollout + CopyTrajectory + the first expansion of
+        // an unconstrained problem in one pass of the row layout (kernels/ilqr_row32.hip: row32_rollout_init_kernel)
+        if (a.row32 && (a.mode & ROLLOUT_INIT)) return row32_merit_dispatch(stream, a, 2) == 0 ? 0 : 2;
+      }
+      hipLaunchKernelGGL(generic_rollout_kernel<T>, waves, b64, 0, stream, a);
+      break;
     case IK_ACCEPT: hipLaunchKernelGGL(generic_accept_kernel<T>, flat, b256, 0, stream, a); break;
     case IK_EXPAND:
       if (a.al.enabled) hipLaunchKernelGGL(generic_expand_al_kernel<T>, dim3((unsigned)((int64_t)a.batch * (a.N + 1))), b64, 0, stream, a);
@@ -86,7 +93,7 @@ static int gen_launch(hipStream_t stream, int which, const IlqrGenArgs<T>& a) {
     case IK_STATIONARITY:
       if constexpr (sizeof(T) == 8) {
         if (a.row32) {   // (kernels/ilqr_row32.hip: row32_stationarity_kernel)
-          const int rc = row32_merit_dispatch(stream, a, true);
+          const int rc = row32_merit_dispatch(stream, a, 1);
           if (rc != 1) return rc;
         }
       }

@@ -180,6 +180,23 @@ struct R32Block {
       }
     }
   }
+  // the same pairs back to global memory (a copy of the block: the fetch's address pattern with stores)
+  template <typename S>
+  __device__ __forceinline__ void store(S* g, int lane_off, int q) const {
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const int e0 = 2 * (q + 32 * t);
+      if constexpr (COUNT < 2) {
+        if (q == 0) g[lane_off] = (S)r[t][0];
+      } else if (64 * (t + 1) <= COUNT) {
+        *reinterpret_cast<r32_d2*>(g + lane_off + 64 * t) = r[t];
+      } else if (e0 + 1 < COUNT) {
+        *reinterpret_cast<r32_d2*>(g + lane_off + 64 * t) = r[t];
+      } else if (e0 < COUNT) {
+        g[lane_off + 64 * t] = (S)r[t][1];
+      }
+    }
+  }
   __device__ __forceinline__ void put(r32_lds_t* L, int q) const {
 #pragma unroll
     for (int t = 0; t < T; ++t) {
@@ -549,6 +566,110 @@ __global__ __launch_bounds__(64, WPS) void row32_stationarity_kernel(IlqrGenArgs
 #pragma unroll
   for (int o = 16; o > 0; o >>= 1) { res = fmax(res, __shfl_xor(res, o, 64)); viol = fmax(viol, __shfl_xor(viol, o, 64)); }
   if (q == 0 && ok_own) { a.prob[b].stationarity = res; a.prob[b].feasibility = viol; }
+}
+
+// ---- the head of Solve for an unconstrained problem (solver.cpp:420-434) in one pass: OpenLoopRollout (generic_rollout_kernel),
+// CopyTrajectory (generic_accept_kernel) and the first expansion (generic_expand_kernel: gradient and the cost's Hessian blocks) --
+// their values, in their expressions' order.  The knot point's A, B, Q, H, R pass through the image like the merit kernel's; the
+// Hessian blocks are written back out of the very registers they were fetched into.
+template <typename T, int NX, int NU, int WPS>
+__global__ __launch_bounds__(64, WPS) void row32_rollout_init_kernel(IlqrGenArgs<T> a) {
+  constexpr int NN = NX * NX, NM = NX * NU, MM = NU * NU;
+  constexpr int oA = 0, oB = NN, oQ = oB + NM, oH = oQ + NN, oR = oH + NM, IMG = (oR + MM + 1) & ~1;
+  __shared__ double img[2][IMG];
+  const int lane = threadIdx.x, half = lane >> 5, q = lane & 31;
+  const bool upper_row = (lane & 16) != 0;
+  const int b0 = 2 * (int)blockIdx.x;
+  const int b_own = b0 + half, b_oth = b0 + (1 - half);
+  const bool ok_own = b_own < a.batch && !(a.active && !a.active[b_own]);
+  const bool ok_oth = b_oth < a.batch && !(a.active && !a.active[b_oth]);
+  if (!ok_own && !ok_oth) return;
+  const int b = ok_own ? b_own : b_oth, hb = b - b0;
+  const bool wr = ok_own;
+  const int N = a.N;
+  const bool isx = q < NX, isu = q >= 32 - NU;
+  const int iu = isu ? 31 - q : 0, ix = isx ? q : 0;
+  const r32_lds_t* const L = (const r32_lds_t*)&img[half][0];
+  r32_lds_t* const Lw = (r32_lds_t*)&img[half][0];
+  const int64_t* off0 = a.off;
+  const int64_t* off1 = a.off + (N > 1 ? G_NUM : 0);
+#define R32_STRIDE(arr) (off1[arr] - off0[arr])
+  const T* gA = a.A + (int64_t)b0 * a.A_bs + off0[G_A];   const int64_t sA = R32_STRIDE(G_A);   const int vA = hb * (int)a.A_bs + 2 * q;
+  const T* gB = a.B + (int64_t)b0 * a.B_bs + off0[G_B];   const int64_t sB = R32_STRIDE(G_B);   const int vB = hb * (int)a.B_bs + 2 * q;
+  const T* gQ = a.cQ + (int64_t)b0 * a.sQ + off0[G_Q];    const int64_t sQ = R32_STRIDE(G_Q);   const int vQ = hb * (int)a.sQ + 2 * q;
+  const T* gH = a.cH + (int64_t)b0 * a.sH + off0[G_H];    const int64_t sH = R32_STRIDE(G_H);   const int vH = hb * (int)a.sH + 2 * q;
+  const T* gR = a.cR + (int64_t)b0 * a.sR + off0[G_R];    const int64_t sR = R32_STRIDE(G_R);   const int vR = hb * (int)a.sR + 2 * q;
+  // where the Hessian blocks go (the sweep's Q / R / H: same block sizes, their own problem strides)
+  T* dQ = a.Q + (int64_t)b0 * a.Q_bs + off0[G_Q];   const int wQ = hb * (int)a.Q_bs + 2 * q;
+  T* dH = a.H + (int64_t)b0 * a.H_bs + off0[G_H];   const int wH = hb * (int)a.H_bs + 2 * q;
+  T* dR = a.R + (int64_t)b0 * a.R_bs + off0[G_R];   const int wR = hb * (int)a.R_bs + 2 * q;
+  const T* gf = a.f + (int64_t)b * a.f_bs + off0[G_f] + ix;   const int64_t sf_ = R32_STRIDE(G_f);
+  const T* gcq = a.cq + (int64_t)b * a.sx + off0[G_q] + ix;   const int64_t sq_ = R32_STRIDE(G_q);
+  const T* gcr = a.cr + (int64_t)b * a.su + off0[G_r] + iu;   const int64_t sr_ = R32_STRIDE(G_r);
+  T* gx = a.x + (int64_t)b * a.x_bs + off0[G_x] + ix;         const int64_t sx_ = R32_STRIDE(G_x);
+  T* gxn = a.xn + (int64_t)b * a.sx + off0[G_x] + ix;
+  const T* gu = a.u + (int64_t)b * a.u_bs + off0[G_u] + iu;   const int64_t su_ = R32_STRIDE(G_u);
+  T* gun = a.un + (int64_t)b * a.su + off0[G_u] + iu;
+  T* glx = a.q + (int64_t)b * a.q_bs + off0[G_q] + ix;
+  T* glu = a.r + (int64_t)b * a.r_bs + off0[G_r] + iu;
+#undef R32_STRIDE
+  double x = isx ? (double)a.x0[(int64_t)b * a.x0_stride + q] : 0.0;
+  R32Block<NN> rA, rQ;
+  R32Block<NM> rB, rH;
+  R32Block<MM> rR;
+  double vf, vcq, vcr, vu;
+  auto fetch = [&]() {
+    rA.fetch(gA, vA, q); rB.fetch(gB, vB, q); rQ.fetch(gQ, vQ, q); rH.fetch(gH, vH, q); rR.fetch(gR, vR, q);
+    vf = (double)*gf; vcq = (double)*gcq; vcr = (double)*gcr; vu = (double)*gu;
+  };
+  fetch();
+  for (int k = 0; k < N; ++k) {
+    rA.put(Lw + oA, q); rB.put(Lw + oB, q); rQ.put(Lw + oQ, q); rH.put(Lw + oH, q); rR.put(Lw + oR, q);
+    if (wr) { rQ.store(dQ, wQ, q); rH.store(dH, wH, q); rR.store(dR, wR, q); }     // CalcCostHessian: the cost's own blocks
+    const double fk = vf, ql = vcq, rl = vcr, uv = isu ? vu : 0.0;
+    if (k + 1 < N) {
+      gA += sA; gB += sB; gQ += sQ; gH += sH; gR += sR; gf += sf_; gcq += sq_; gcr += sr_; gu += su_;
+      fetch();
+    }
+    dQ += sQ; dH += sH; dR += sR;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (wr) {
+      if (isx) { *gx = (T)x; *gxn = (T)x; }
+      if (isu) *gun = (T)uv;
+    }
+    const R32Vec vw = r32_spread(isx ? x : uv, upper_row);
+    // rows of [A B] (state lanes) / [H R] (input lanes) against [x; u]
+    double sA_ = 0.0, sBv = 0.0;
+    r32_states1<NX>(sA_, vw, L, isx ? oA + ix : oH + iu, isx ? NX : NU);
+    r32_in1<NU>(sBv, vw, L, isx ? oB + ix : oR + iu, isx ? NX : NU);
+    // rows of [Q H^T] (state lanes)
+    double qx = 0.0, htu = 0.0;
+    r32_states1<NX>(qx, vw, L, oQ + ix, NX);
+    r32_in1<NU>(htu, vw, L, oH + ix * NU, 1);
+    if (wr) {   // generic_expand_kernel's sums: (Q x + q) + H^T u  |  (R u + r) + H x
+      if (isx) *glx = (T)((qx + ql) + htu);
+      if (isu) *glu = (T)((sBv + rl) + sA_);
+    }
+    if (isx) x = (sA_ + sBv) + fk;
+    gx += sx_; gxn += sx_; gun += su_; glx += sq_; glu += sr_;
+  }
+  {   // terminal knot point
+    R32Block<NN> rQn;
+    rQn.fetch(a.cQ + (int64_t)b0 * a.sQ + a.off[(int64_t)N * G_NUM + G_Q], vQ, q);
+    const double ql = (double)a.cq[(int64_t)b * a.sx + a.off[(int64_t)N * G_NUM + G_q] + ix];
+    rQn.put(Lw + oQ, q);
+    if (wr) rQn.store(a.Q + (int64_t)b0 * a.Q_bs + a.off[(int64_t)N * G_NUM + G_Q], wQ, q);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (wr && isx) { *gx = (T)x; *gxn = (T)x; }
+    const R32Vec vx = r32_spread(isx ? x : 0.0, upper_row);
+    double qx = 0.0;
+    r32_states1<NX>(qx, vx, L, oQ + ix, NX);
+    if (wr && isx) *glx = (T)(qx + ql);
+  }
 }
 
 }  // namespace altro_hip

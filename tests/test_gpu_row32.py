@@ -152,3 +152,30 @@ def test_whole_solves_on_the_row_layout_equal_the_oracle(n, m, dense):
         np.testing.assert_allclose(x[b], s.get("x"), rtol=1e-7, atol=1e-7)
         np.testing.assert_allclose(u[b], s.get("u"), rtol=1e-6, atol=1e-6)
     assert nconv >= 1
+
+
+@pytest.mark.parametrize("n,m,dense", [(13, 4, False), (17, 3, True), (24, 8, False), (31, 1, True), (5, 8, False)])
+def test_unconstrained_solves_are_the_lds_forms_bit_for_bit(n, m, dense):
+    """Without constraint blocks a solve on these shapes runs row32_rollout_init_kernel (rollout + CopyTrajectory + first expansion in
+    one pass), the row-layout merit kernel and row32_stationarity_kernel where ALTRO_HIP_FORM_GENERIC_MERIT_LDS runs plan GENERIC's five
+    kernels: the same values, so the same iterates -- nominal trajectory, gains, expansion and statistics array_equal -- and the
+    oracle's iteration count."""
+    N, batch = 11, 5
+    p = problem(batch, N, n, m, dense)
+    out = {}
+    for name, forms in (("row", 0), ("lds", altro_amd.FORM_GENERIC_MERIT_LDS)):
+        bt = build(p, N, n, m, batch, dense, forms)
+        res = bt.ilqr_solve(iterations_max=20)
+        x, u = bt.get_nominal()
+        _, _, lx, lu = bt.get_expansion()
+        out[name] = dict(status=res["status"].copy(), iterations=res["iterations"].copy(), x=x.copy(), u=u.copy(), K=bt.get("K").copy(), d=bt.get("d").copy(),
+                         lx=lx.copy(), lu=lu.copy(), stat=res["stationarity"].copy(), cost=res["cost"].copy() if "cost" in res else np.zeros(1))
+        bt.close()
+    for key in out["row"]:
+        assert np.array_equal(out["row"][key], out["lds"][key]), key
+    assert (out["row"]["status"] == 0).all()
+    s = make_oracle(p, 0, N, n, m, dense)
+    s.L.oracle_ilqr_set_options(s.h, 20, 1e-4, 1e-4, 1e-8, 0)
+    status, iters, _ = s.solve()
+    assert status == 0 and iters == out["row"]["iterations"][0]
+    np.testing.assert_allclose(out["row"]["x"][0], s.get("x"), rtol=1e-9, atol=1e-9)
