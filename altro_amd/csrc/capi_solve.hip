@@ -145,7 +145,8 @@ int SolveRun::configure(const altro_hip_solve_options* opts) {
   run_ahead = !form(h, ALTRO_HIP_FORM_NO_RUNAHEAD);
   // Plan MFMA16: phi(0) and the line search's first step from one pass over the records, the candidate's stationarity / feasibility
   // from that same pass.  ALTRO_HIP_FORM_NO_MERIT2 keeps the one-evaluation-per-launch sequence (the comparison the tests hold this against).
-  dual = h->plan == ALTRO_HIP_PLAN_MFMA16 && !form(h, ALTRO_HIP_FORM_NO_SPECULATION) && !form(h, ALTRO_HIP_FORM_NO_MERIT2);
+  // (round 6: also where kernels/ilqr_row32.hip serves the handle -- plan MFMA32's shapes: its merit kernel has a two-trial form)
+  dual = (h->plan == ALTRO_HIP_PLAN_MFMA16 || row32_eligible(h)) && !form(h, ALTRO_HIP_FORM_NO_SPECULATION) && !form(h, ALTRO_HIP_FORM_NO_MERIT2);
   // Plan MFMA16, diagonal cost, bound-type blocks only: the Hessian blocks differ from sweep to sweep on their diagonal alone, so
   // after this solve's first (full) Hessian expansion the later ones store 16 values per knot point instead of 158 (EXPAND_DIAG)
   // (plan GENERIC / MFMA32, every block bound-type -- AlTable::gsel --: the constraints touch the Hessian blocks' diagonals only,
@@ -432,7 +433,8 @@ int SolveRun::first_evaluation(int* prev_slot, int* begin_slot, int* launches, b
   if (rc) return rc;
   *launches = 1;
   la.spec_pre = (pre || dual) ? 1 : 0;
-  la.spec_flip = dual ? 1 : 0; la.stat_done = h->i_stat_done; la.stat_inline = h->dtype == ALTRO_HIP_F64 ? 1 : 0;
+  la.spec_flip = dual ? 1 : 0; la.stat_done = h->i_stat_done;
+  la.stat_inline = (h->plan == ALTRO_HIP_PLAN_MFMA16 && h->dtype == ALTRO_HIP_F64) ? 1 : 0;   // (the tile's two-trial pass also takes the candidate's stationarity)
   int prev = counted(ILK_LS_BEGIN);      // the slot whose [0] says whether another evaluation is needed
   if (prev < 0) return ALTRO_HIP_ERR_HIP;
   la.spec_pre = 0; la.spec_flip = 0;

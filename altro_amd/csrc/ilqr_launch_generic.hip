@@ -90,6 +90,11 @@ static int gen_launch(hipStream_t stream, int which, const IlqrGenArgs<T>& a) {
       else hipLaunchKernelGGL((generic_merit_kernel<T, false>), waves, b64, jv, stream, a);
       break;
     }
+    case IK_MERIT2:   // phi(0) and the line search's first step in one pass: the row layout's shapes only (the host asks where it applies)
+      if constexpr (sizeof(T) == 8) {
+        if (a.row32) return row32_merit_dispatch(stream, a, 3) == 0 ? 0 : 2;
+      }
+      return 1;
     case IK_STATIONARITY:
       if constexpr (sizeof(T) == 8) {
         if (a.row32) {   // (kernels/ilqr_row32.hip: row32_stationarity_kernel)

@@ -159,9 +159,10 @@ __device__ __forceinline__ void r32_in1(double& acc, const R32Vec& v, const r32_
 // 74 %, 19 cache accesses per load instruction).  The address is a wave-uniform base (the wave's first problem, moved on by scalar
 // adds) plus the lane's 32-bit offset (the half's problem and the pair): one offset register per array instead of a pointer.
 typedef double r32_d2 __attribute__((ext_vector_type(2), aligned(8)));   // (blocks start on 8-byte boundaries: 169 doubles per knot point at n = 13)
-template <int COUNT>
+// LANES: the lanes that share the block's runs -- 32 (a half wave per problem) or 64 (one problem per wave: the two-trial pass)
+template <int COUNT, int LANES = 32>
 struct R32Block {
-  static constexpr int PAIRS = (COUNT + 1) / 2, T = (PAIRS + 31) / 32;
+  static constexpr int PAIRS = (COUNT + 1) / 2, T = (PAIRS + LANES - 1) / LANES;
   r32_d2 r[T];
   // g: the block of the wave's first problem; lane_off: elements from there to this lane's first pair (the half's problem included)
   template <typename S>
@@ -169,14 +170,14 @@ struct R32Block {
     static_assert(sizeof(S) == 8, "fp64 records");
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-      const int e0 = 2 * (q + 32 * t);
+      const int e0 = 2 * (q + LANES * t);
       if constexpr (COUNT < 2) {
         r[t] = r32_d2{(double)g[lane_off - 2 * q], 0.0};
-      } else if (64 * (t + 1) <= COUNT) {
-        r[t] = *reinterpret_cast<const r32_d2*>(g + lane_off + 64 * t);
+      } else if (2 * LANES * (t + 1) <= COUNT) {
+        r[t] = *reinterpret_cast<const r32_d2*>(g + lane_off + 2 * LANES * t);
       } else {   // the last run: past the block's end its last pair again (put() takes what belongs to it)
         const int back = e0 + 1 < COUNT ? 0 : e0 - (COUNT - 2);
-        r[t] = *reinterpret_cast<const r32_d2*>(g + lane_off + 64 * t - back);
+        r[t] = *reinterpret_cast<const r32_d2*>(g + lane_off + 2 * LANES * t - back);
       }
     }
   }
@@ -185,25 +186,25 @@ struct R32Block {
   __device__ __forceinline__ void store(S* g, int lane_off, int q) const {
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-      const int e0 = 2 * (q + 32 * t);
+      const int e0 = 2 * (q + LANES * t);
       if constexpr (COUNT < 2) {
         if (q == 0) g[lane_off] = (S)r[t][0];
-      } else if (64 * (t + 1) <= COUNT) {
-        *reinterpret_cast<r32_d2*>(g + lane_off + 64 * t) = r[t];
+      } else if (2 * LANES * (t + 1) <= COUNT) {
+        *reinterpret_cast<r32_d2*>(g + lane_off + 2 * LANES * t) = r[t];
       } else if (e0 + 1 < COUNT) {
-        *reinterpret_cast<r32_d2*>(g + lane_off + 64 * t) = r[t];
+        *reinterpret_cast<r32_d2*>(g + lane_off + 2 * LANES * t) = r[t];
       } else if (e0 < COUNT) {
-        g[lane_off + 64 * t] = (S)r[t][1];
+        g[lane_off + 2 * LANES * t] = (S)r[t][1];
       }
     }
   }
   __device__ __forceinline__ void put(r32_lds_t* L, int q) const {
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-      const int e0 = 2 * (q + 32 * t);
+      const int e0 = 2 * (q + LANES * t);
       if constexpr (COUNT < 2) {
         if (q == 0) L[0] = r[t][0];
-      } else if (64 * (t + 1) <= COUNT) {
+      } else if (2 * LANES * (t + 1) <= COUNT) {
         L[e0] = r[t][0]; L[e0 + 1] = r[t][1];
       } else if (e0 + 1 < COUNT) {
         L[e0] = r[t][0]; L[e0 + 1] = r[t][1];
@@ -310,44 +311,51 @@ __device__ __forceinline__ void r32_al(const AlTable<T>& t, int k, int b, int64_
 constexpr int r32_image_doubles(int n, int m) { return ((3 * n * n + 3 * n * m + m * m + 1) & ~1); }
 
 // two problems per wave: lanes 0..31 problem 2 pr, lanes 32..63 problem 2 pr + 1
-template <typename T, int NX, int NU, int WPS>
+// DUAL (the sweep's first evaluation, IK_MERIT2): ONE problem per wave, its two halves the two evaluations ForwardPass starts with --
+// phi(0) at alpha = a.alpha[b] in half 0 and the line search's first step alpha = 1 in half 1 (solver.cpp:241-252) -- sharing one
+// image: the knot point's matrices are fetched once, by all 64 lanes.  Half 1 writes the candidate trajectory and the expansion (what
+// the second of two launches would have left behind), both halves their phi / phi' (rows 0 and 1 of IlqrGenArgs::phi / dphi); per
+// half the single-trial kernel's instructions on the same data, so the same values.
+template <typename T, int NX, int NU, int WPS, bool DUAL = false>
 __global__ __launch_bounds__(64, WPS) void row32_merit_kernel(IlqrGenArgs<T> a) {
   static_assert(NX >= 1 && NU >= 1 && NU <= 8 && NX + NU <= 32, "a problem's [x; u] fits half a wave, the inputs its top eight positions");
   constexpr int NN = NX * NX, NM = NX * NU, MM = NU * NU;
   constexpr int oP = 0, oK = NN, oA = oK + NM, oB = oA + NN, oQ = oB + NM, oH = oQ + NN, oR = oH + NM, IMG = r32_image_doubles(NX, NU);
+  constexpr int LN = DUAL ? 64 : 32;                  // lanes that share a block's runs
   __shared__ double red[2][2][64];                    // [phi | phi'][half][generic_merit_kernel's lane arrangement]
-  __shared__ double img[2][IMG];                      // [half][P | K | A | B | Q | H | R], every block column-major as in HBM
+  __shared__ double img[DUAL ? 1 : 2][IMG];           // [half][P | K | A | B | Q | H | R], every block column-major as in HBM
   const int lane = threadIdx.x, half = lane >> 5, q = lane & 31;
+  const int ql = DUAL ? lane : q;                     // this lane's place among the lanes that fetch a block
   const bool upper_row = (lane & 16) != 0;
-  const int b_own = 2 * (int)blockIdx.x + half, b_oth = 2 * (int)blockIdx.x + (1 - half);
+  const int b_own = DUAL ? (int)blockIdx.x : 2 * (int)blockIdx.x + half, b_oth = DUAL ? (int)blockIdx.x : 2 * (int)blockIdx.x + (1 - half);
   const bool ok_own = b_own < a.batch && !(a.active && !a.active[b_own]);
   const bool ok_oth = b_oth < a.batch && !(a.active && !a.active[b_oth]);
   if (!ok_own && !ok_oth) return;                     // (the same two answers in every lane)
   const int b = ok_own ? b_own : b_oth;               // a half without a problem shadows the other one and stores nothing
-  const bool wr = ok_own;
+  const bool wr = DUAL ? half == 1 : ok_own;          // (DUAL: the first step's half writes the candidate and the expansion)
   const int N = a.N;
   const bool isx = q < NX, isu = q >= 32 - NU, has = isx || isu;
   const int iu = isu ? 31 - q : 0, ix = isx ? q : 0;
   const bool al = a.al.enabled != 0;
   const double rho = al ? a.prob[b].rho : 1.0;
   double viol = 0.0;
-  const double alpha = a.alpha ? a.alpha[b] : a.alpha_const;
+  const double alpha = (DUAL && half == 1) ? 1.0 : (a.alpha ? a.alpha[b] : a.alpha_const);
   const bool deriv = a.want_derivative != 0;
-  const r32_lds_t* const L = (const r32_lds_t*)&img[half][0];
-  r32_lds_t* const Lw = (r32_lds_t*)&img[half][0];
+  const r32_lds_t* const L = (const r32_lds_t*)&img[DUAL ? 0 : half][0];
+  r32_lds_t* const Lw = (r32_lds_t*)&img[DUAL ? 0 : half][0];
   // uniform dimensions: knot point k's block of an array starts k strides after knot point 0's (the offset table's rows 0 and 1 say
   // both).  Per lane: one pointer per array, moved on by the stride after every knot point.
   const int64_t* off0 = a.off;
   const int64_t* off1 = a.off + (N > 1 ? G_NUM : 0);
 #define R32_STRIDE(arr) (off1[arr] - off0[arr])
-  const int b0 = 2 * (int)blockIdx.x, hb = b - b0;    // the wave's first problem; this half's problem relative to it (0 or 1)
-  const T* gP = a.P + (int64_t)b0 * a.P_bs + off0[G_P];   const int64_t sP = R32_STRIDE(G_P);   const int vP = hb * (int)a.P_bs + 2 * q;
-  const T* gK = a.K + (int64_t)b0 * a.K_bs + off0[G_K];   const int64_t sK = R32_STRIDE(G_K);   const int vK = hb * (int)a.K_bs + 2 * q;
-  const T* gA = a.A + (int64_t)b0 * a.A_bs + off0[G_A];   const int64_t sA = R32_STRIDE(G_A);   const int vA = hb * (int)a.A_bs + 2 * q;
-  const T* gB = a.B + (int64_t)b0 * a.B_bs + off0[G_B];   const int64_t sB = R32_STRIDE(G_B);   const int vB = hb * (int)a.B_bs + 2 * q;
-  const T* gQ = a.cQ + (int64_t)b0 * a.sQ + off0[G_Q];    const int64_t sQ = R32_STRIDE(G_Q);   const int vQ = hb * (int)a.sQ + 2 * q;
-  const T* gH = a.cH + (int64_t)b0 * a.sH + off0[G_H];    const int64_t sH = R32_STRIDE(G_H);   const int vH = hb * (int)a.sH + 2 * q;
-  const T* gR = a.cR + (int64_t)b0 * a.sR + off0[G_R];    const int64_t sR = R32_STRIDE(G_R);   const int vR = hb * (int)a.sR + 2 * q;
+  const int b0 = DUAL ? b : 2 * (int)blockIdx.x, hb = b - b0;   // the wave's first problem; this half's problem relative to it (0 or 1)
+  const T* gP = a.P + (int64_t)b0 * a.P_bs + off0[G_P];   const int64_t sP = R32_STRIDE(G_P);   const int vP = hb * (int)a.P_bs + 2 * ql;
+  const T* gK = a.K + (int64_t)b0 * a.K_bs + off0[G_K];   const int64_t sK = R32_STRIDE(G_K);   const int vK = hb * (int)a.K_bs + 2 * ql;
+  const T* gA = a.A + (int64_t)b0 * a.A_bs + off0[G_A];   const int64_t sA = R32_STRIDE(G_A);   const int vA = hb * (int)a.A_bs + 2 * ql;
+  const T* gB = a.B + (int64_t)b0 * a.B_bs + off0[G_B];   const int64_t sB = R32_STRIDE(G_B);   const int vB = hb * (int)a.B_bs + 2 * ql;
+  const T* gQ = a.cQ + (int64_t)b0 * a.sQ + off0[G_Q];    const int64_t sQ = R32_STRIDE(G_Q);   const int vQ = hb * (int)a.sQ + 2 * ql;
+  const T* gH = a.cH + (int64_t)b0 * a.sH + off0[G_H];    const int64_t sH = R32_STRIDE(G_H);   const int vH = hb * (int)a.sH + 2 * ql;
+  const T* gR = a.cR + (int64_t)b0 * a.sR + off0[G_R];    const int64_t sR = R32_STRIDE(G_R);   const int vR = hb * (int)a.sR + 2 * ql;
   // the vectors: this lane's entry (state lanes: row ix, input lanes: row iu)
   const T* gxn = a.xn + (int64_t)b * a.sx + off0[G_x] + ix;  const int64_t sx_ = R32_STRIDE(G_x);
   T* gx = a.x + (int64_t)b * a.x_bs + off0[G_x] + ix;
@@ -365,12 +373,12 @@ __global__ __launch_bounds__(64, WPS) void row32_merit_kernel(IlqrGenArgs<T> a) 
 #undef R32_STRIDE
   double x = isx ? (double)a.x0[(int64_t)b * a.x0_stride + q] : 0.0, dxda = 0.0;
   double J0 = 0.0, J1 = 0.0, dJ = 0.0;                // J0: this position's constraint rows and state row; J1: its input row
-  R32Block<NN> rP, rA, rQ;
-  R32Block<NM> rK, rB, rH;
-  R32Block<MM> rR;
+  R32Block<NN, LN> rP, rA, rQ;
+  R32Block<NM, LN> rK, rB, rH;
+  R32Block<MM, LN> rR;
   double vxn, vp, vf, vcq, vd = 0.0, vun = 0.0, vcr = 0.0, vcc;   // the knot point's entries of the vectors, fetched with the matrices
   auto fetch = [&]() {
-    rP.fetch(gP, vP, q); rK.fetch(gK, vK, q); rA.fetch(gA, vA, q); rB.fetch(gB, vB, q); rQ.fetch(gQ, vQ, q); rH.fetch(gH, vH, q); rR.fetch(gR, vR, q);
+    rP.fetch(gP, vP, ql); rK.fetch(gK, vK, ql); rA.fetch(gA, vA, ql); rB.fetch(gB, vB, ql); rQ.fetch(gQ, vQ, ql); rH.fetch(gH, vH, ql); rR.fetch(gR, vR, ql);
     vxn = (double)*gxn; vp = (double)*gp; vf = (double)*gf; vcq = (double)*gcq;
     vd = (double)*gd; vun = (double)*gun; vcr = (double)*gcr;   // (every lane: lanes without an input row read row 0's and do not use it)
   };
@@ -380,7 +388,7 @@ __global__ __launch_bounds__(64, WPS) void row32_merit_kernel(IlqrGenArgs<T> a) 
     // this knot point's matrices into the image (every read of the last one's has been issued), the next one's on their way.
     // One wave: the LDS pipe executes its writes before the reads that follow, for all lanes -- nothing to wait for (a __syncthreads
     // would wait for the loads just issued: the whole round trip, every knot point); the compiler only has to keep the order.
-    rP.put(Lw + oP, q); rK.put(Lw + oK, q); rA.put(Lw + oA, q); rB.put(Lw + oB, q); rQ.put(Lw + oQ, q); rH.put(Lw + oH, q); rR.put(Lw + oR, q);
+    rP.put(Lw + oP, ql); rK.put(Lw + oK, ql); rA.put(Lw + oA, ql); rB.put(Lw + oB, ql); rQ.put(Lw + oQ, ql); rH.put(Lw + oH, ql); rR.put(Lw + oR, ql);
     const double xnom = vxn, pk = vp, fk = vf, ql = vcq, dk = vd, unom = vun, rl = vcr, ck = vcc;
     if (k + 1 < N) {
       gP += sP; gK += sK; gA += sA; gB += sB; gQ += sQ; gH += sH; gR += sR;
@@ -444,11 +452,11 @@ __global__ __launch_bounds__(64, WPS) void row32_merit_kernel(IlqrGenArgs<T> a) 
   }
 #define GOFFN(arr) (a.off[(int64_t)N * G_NUM + (arr)])
   {   // terminal knot point (solver.cpp:319-332): Q_N and P_N through the image's slots of Q and P
-    R32Block<NN> rQn, rPn;
-    rQn.fetch(a.cQ + (int64_t)b0 * a.sQ + GOFFN(G_Q), vQ, q);
-    rPn.fetch(a.P + (int64_t)b0 * a.P_bs + GOFFN(G_P), vP, q);
+    R32Block<NN, LN> rQn, rPn;
+    rQn.fetch(a.cQ + (int64_t)b0 * a.sQ + GOFFN(G_Q), vQ, ql);
+    rPn.fetch(a.P + (int64_t)b0 * a.P_bs + GOFFN(G_P), vP, ql);
     const double xnom = isx ? (double)a.xn[(int64_t)b * a.sx + GOFFN(G_x) + ix] : 0.0;
-    rQn.put(Lw + oQ, q); rPn.put(Lw + oP, q);
+    rQn.put(Lw + oQ, ql); rPn.put(Lw + oP, ql);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -483,11 +491,19 @@ __global__ __launch_bounds__(64, WPS) void row32_merit_kernel(IlqrGenArgs<T> a) 
 #pragma unroll
   for (int hh = 0; hh < 2; ++hh) {
     const double phi = gen_wave_sum(red[0][hh][lane]), dphi = gen_wave_sum(red[1][hh][lane]);
-    const int bs = 2 * (int)blockIdx.x + hh;
-    if (lane == 0 && (hh == 0 ? ok_own : ok_oth)) {    // (lane 0 sits in half 0: its own problem is hh = 0)
-      a.phi[bs] = phi;
-      if (deriv) a.dphi[bs] = dphi;
-      if (al) a.prob[bs].rho_est = a.prob[bs].rho;
+    if constexpr (DUAL) {                               // row hh of phi / dphi: evaluation hh of this wave's problem
+      if (lane == 0) {
+        a.phi[(size_t)hh * a.batch + b] = phi;
+        if (deriv) a.dphi[(size_t)hh * a.batch + b] = dphi;
+        if (al && hh == 0) a.prob[b].rho_est = a.prob[b].rho;
+      }
+    } else {
+      const int bs = 2 * (int)blockIdx.x + hh;
+      if (lane == 0 && (hh == 0 ? ok_own : ok_oth)) {  // (lane 0 sits in half 0: its own problem is hh = 0)
+        a.phi[bs] = phi;
+        if (deriv) a.dphi[bs] = dphi;
+        if (al) a.prob[bs].rho_est = a.prob[bs].rho;
+      }
     }
   }
 }
