@@ -69,6 +69,14 @@ static int gen_launch(hipStream_t stream, int which, const IlqrGenArgs<T>& a) {
       break;
     case IK_ACCEPT: hipLaunchKernelGGL(generic_accept_kernel<T>, flat, b256, 0, stream, a); break;
     case IK_EXPAND:
+      if constexpr (sizeof(T) == 8) {
+        // constraint blocks on plan MFMA32's shapes: the gradient and the DIAGONAL form of the Hessian (EXPAND_DIAG: the host has seen
+        // that every block is bound-type and that the full blocks are stored) as a walk of the row layout (row32_expand_kernel)
+        if (a.al.enabled && a.row32 && (!(a.mode & EXPAND_HESSIAN) || (a.mode & EXPAND_DIAG)) && !(a.mode & EXPAND_DYN)) {
+          const int rc = row32_merit_dispatch(stream, a, 4);
+          if (rc != 1) return rc;
+        }
+      }
       if (a.al.enabled) hipLaunchKernelGGL(generic_expand_al_kernel<T>, dim3((unsigned)((int64_t)a.batch * (a.N + 1))), b64, 0, stream, a);
       else hipLaunchKernelGGL(generic_expand_kernel<T>, flat, b256, 0, stream, a);
       if constexpr (sizeof(T) == 8) {

@@ -266,13 +266,34 @@ __device__ __forceinline__ void r32_selcol(double& acc, const R32Vec& jv, const 
     }
   }
 }
+// the same walk with coefficient 1 wherever a row selects the column, whatever its sign: sum_i [row i selects col] v_i
+template <int J0 = 0>
+__device__ __forceinline__ void r32_selcount(double& acc, const R32Vec& v, const int* sd, int p, int col1) {
+  if constexpr (J0 < 32) {
+    if (J0 < p) {
+      double c[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int se = sd[1 + (J0 + t < p ? J0 + t : p - 1)];
+        c[t] = (J0 + t < p && (se == col1 || se == -col1)) ? 1.0 : 0.0;
+      }
+      if constexpr (J0 < 16) r32_one<J0, 1, 4>(acc, v.lo, c);
+      else r32_one<J0 - 16, 1, 4>(acc, v.hi, c);
+      r32_selcount<J0 + 4>(acc, v, sd, p, col1);
+    }
+  }
+}
+// diag (or null): the diagonal Gauss-Newton term of this lane's variable, sum over the bound-type blocks' rows that select it of J_ii^2
+// (the host asks for it only when every block is bound-type: EXPAND_DIAG)
 template <typename T, int NX, int NU>
 __device__ __forceinline__ void r32_al(const AlTable<T>& t, int k, int b, int64_t B, const R32Vec& w, double wv, bool terminal, double rho_est, int q,
-                                       bool upper_row, bool want_col, int col, bool has_col, double& cost, double& viol, double& colsum) {
+                                       bool upper_row, bool want_col, int col, bool has_col, double& cost, double& viol, double& colsum,
+                                       double& diag, bool want_diag) {
   int zshift;
   const AlKnotBig ALTRO_CONST_AS& kn = gen_knot<T>(t, k, zshift);
   const int ncon = kn.ncon;
   colsum = 0.0;
+  diag = 0.0;
 #pragma unroll 1
   for (int c = 0; c < ncon; ++c) {                      // (wave-uniform trip count; nothing is carried per block but the two sums)
     const int p = kn.p[c], cone = kn.cone[c];
@@ -289,7 +310,7 @@ __device__ __forceinline__ void r32_al(const AlTable<T>& t, int k, int b, int64_
       r32_g1<T, NX, false>(s, w, G + (rl ? q : 0), p);
       if (!terminal) r32_g1<T, NU, true>(s, w, G + (rl ? q : 0) + (int64_t)NX * p, p);
     }
-    double jv = 0.0;
+    double jv = 0.0, jd2 = 0.0;
     if (rl) {
       const double gi = kn.g_per_problem[c] ? (double)t.g[kn.g_off[c] + (int64_t)q * B + b] : (double)t.g[kn.g_off[c] + q];
       const double val = s - gi;
@@ -299,6 +320,11 @@ __device__ __forceinline__ void r32_al(const AlTable<T>& t, int k, int b, int64_
       else if (cone == CONE_INEQUALITY) { zp = fmin(0.0, ze); mkv = (ze <= 0.0) ? 1.0 : 0.0; viol = fmax(viol, fabs(fmin(0.0, val) - val)); }
       cost += zp * zp / (2.0 * rho_est);
       jv = mkv * zp;
+      jd2 = (mkv * 1.0) * (mkv * 1.0);
+    }
+    if (want_diag && bsel) {                            // (wave-uniform)
+      const R32Vec jdv = r32_spread(jd2, upper_row);
+      r32_selcount(diag, jdv, sd, p, has_col ? col + 1 : 0);
     }
     if (want_col) {                                     // (wave-uniform)
       const R32Vec jvv = r32_spread(jv, upper_row);
@@ -338,7 +364,7 @@ __global__ __launch_bounds__(64, WPS) void row32_merit_kernel(IlqrGenArgs<T> a) 
   const int iu = isu ? 31 - q : 0, ix = isx ? q : 0;
   const bool al = a.al.enabled != 0;
   const double rho = al ? a.prob[b].rho : 1.0;
-  double viol = 0.0;
+  double viol = 0.0, r32_nodiag = 0.0;
   const double alpha = (DUAL && half == 1) ? 1.0 : (a.alpha ? a.alpha[b] : a.alpha_const);
   const bool deriv = a.want_derivative != 0;
   const r32_lds_t* const L = (const r32_lds_t*)&img[DUAL ? 0 : half][0];
@@ -420,7 +446,7 @@ __global__ __launch_bounds__(64, WPS) void row32_merit_kernel(IlqrGenArgs<T> a) 
     double alcol = 0.0;
     if (al) {   // the constraint rows' cost shares at the candidate point and the gradient's column sums
       double Jal = 0.0;
-      r32_al<T, NX, NU>(a.al, k, b, a.batch, vw, isx ? x : uv, false, rho, q, upper_row, deriv, isx ? ix : NX + iu, has, Jal, viol, alcol);
+      r32_al<T, NX, NU>(a.al, k, b, a.batch, vw, isx ? x : uv, false, rho, q, upper_row, deriv, isx ? ix : NX + iu, has, Jal, viol, alcol, r32_nodiag, false);
       J0 += Jal;
     }
     // rows of [Q H^T] (state lanes) against [x; u]
@@ -464,7 +490,7 @@ __global__ __launch_bounds__(64, WPS) void row32_merit_kernel(IlqrGenArgs<T> a) 
     if (isx && wr) a.x[(int64_t)b * a.x_bs + GOFFN(G_x) + ix] = (T)x;
     const R32Vec vx = r32_spread(isx ? x : 0.0, upper_row), vdx = r32_spread(dx, upper_row);
     double alcol = 0.0;
-    if (al) r32_al<T, NX, NU>(a.al, N, b, a.batch, vx, isx ? x : 0.0, true, rho, q, upper_row, deriv, ix, isx, J0, viol, alcol);
+    if (al) r32_al<T, NX, NU>(a.al, N, b, a.batch, vx, isx ? x : 0.0, true, rho, q, upper_row, deriv, ix, isx, J0, viol, alcol, r32_nodiag, false);
     double qx = 0.0, s = 0.0;
     r32_states1<NX>(qx, vx, L, oQ + ix, NX);
     r32_states1<NX>(s, vdx, L, oP + ix, NX);
@@ -541,7 +567,7 @@ __global__ __launch_bounds__(64, WPS) void row32_stationarity_kernel(IlqrGenArgs
   const T* gu = a.u + (int64_t)b * a.u_bs + off0[G_u] + iu;    const int64_t su_ = R32_STRIDE(G_u);
 #undef R32_STRIDE
   const double rho = al ? a.prob[b].rho : 1.0;
-  double res = 0.0, viol = 0.0;
+  double res = 0.0, viol = 0.0, r32_nodiag = 0.0;
   R32Block<NN> rA;
   R32Block<NM> rB;
   rA.fetch(gA, vA, q); rB.fetch(gB, vB, q);
@@ -565,7 +591,7 @@ __global__ __launch_bounds__(64, WPS) void row32_stationarity_kernel(IlqrGenArgs
       const double wv = isx ? xv : (isu ? uv : 0.0);
       const R32Vec vw = r32_spread(wv, upper_row);
       double cost = 0.0, colsum = 0.0;
-      r32_al<T, NX, NU>(a.al, k, b, a.batch, vw, wv, false, rho, q, upper_row, false, 0, false, cost, viol, colsum);
+      r32_al<T, NX, NU>(a.al, k, b, a.batch, vw, wv, false, rho, q, upper_row, false, 0, false, cost, viol, colsum, r32_nodiag, false);
     }
     yk = yn;
     glx += sq_; glu += sr_; gx += sx_; gu += su_;
@@ -575,7 +601,7 @@ __global__ __launch_bounds__(64, WPS) void row32_stationarity_kernel(IlqrGenArgs
     const double wv = isx ? (double)*gx : 0.0;
     const R32Vec vw = r32_spread(wv, upper_row);
     double cost = 0.0, colsum = 0.0;
-    r32_al<T, NX, NU>(a.al, N, b, a.batch, vw, wv, true, rho, q, upper_row, false, 0, false, cost, viol, colsum);
+    r32_al<T, NX, NU>(a.al, N, b, a.batch, vw, wv, true, rho, q, upper_row, false, 0, false, cost, viol, colsum, r32_nodiag, false);
   }
   (void)has;
   // the maxima over the half's 32 lanes
@@ -685,6 +711,116 @@ __global__ __launch_bounds__(64, WPS) void row32_rollout_init_kernel(IlqrGenArgs
     double qx = 0.0;
     r32_states1<NX>(qx, vx, L, oQ + ix, NX);
     if (wr && isx) *glx = (T)(qx + ql);
+  }
+}
+
+constexpr int R32_EXPAND_CHUNK = 16;
+// ---- the expansion with constraint blocks (generic_expand_al_kernel: one wave per (problem, knot point), every gradient entry a walk
+// over a row in global memory) as a walk of the row layout over a problem's knot points: EXPAND_GRADIENT -- lx, lu with the AL terms
+// (knotpoint_data.cpp:583-595), that kernel's sums ((Q x + q) + H^T u - G^T J^T z_proj) -- and EXPAND_HESSIAN in its diagonal form
+// (EXPAND_DIAG: every block bound-type; cost entry + rho * the selecting rows' J_ii^2).  The full Hessian stays that kernel's.
+template <typename T, int NX, int NU, int WPS>
+__global__ __launch_bounds__(64, WPS) void row32_expand_kernel(IlqrGenArgs<T> a) {
+  constexpr int NN = NX * NX, NM = NX * NU, MM = NU * NU;
+  constexpr int oQ = 0, oH = NN, oR = oH + NM, IMG = (oR + MM + 1) & ~1;
+  __shared__ double img[2][IMG];
+  const int lane = threadIdx.x, half = lane >> 5, q = lane & 31;
+  const bool upper_row = (lane & 16) != 0;
+  const int b0 = 2 * (int)blockIdx.x;
+  const int b_own = b0 + half, b_oth = b0 + (1 - half);
+  const bool ok_own = b_own < a.batch && !(a.active && !a.active[b_own]);
+  const bool ok_oth = b_oth < a.batch && !(a.active && !a.active[b_oth]);
+  if (!ok_own && !ok_oth) return;
+  const int b = ok_own ? b_own : b_oth, hb = b - b0;
+  const bool wr = ok_own;
+  const int N = a.N;
+  const bool grad = (a.mode & EXPAND_GRADIENT) != 0, hess = (a.mode & EXPAND_HESSIAN) != 0;
+  const bool isx = q < NX, isu = q >= 32 - NU, has = isx || isu;
+  const int iu = isu ? 31 - q : 0, ix = isx ? q : 0;
+  const r32_lds_t* const L = (const r32_lds_t*)&img[half][0];
+  r32_lds_t* const Lw = (r32_lds_t*)&img[half][0];
+  const int64_t* off0 = a.off;
+  const int64_t* off1 = a.off + (N > 1 ? G_NUM : 0);
+#define R32_STRIDE(arr) (off1[arr] - off0[arr])
+  const T* gQ = a.cQ + (int64_t)b0 * a.sQ + off0[G_Q];    const int64_t sQ = R32_STRIDE(G_Q);   const int vQ = hb * (int)a.sQ + 2 * q;
+  const T* gH = a.cH + (int64_t)b0 * a.sH + off0[G_H];    const int64_t sH = R32_STRIDE(G_H);   const int vH = hb * (int)a.sH + 2 * q;
+  const T* gR = a.cR + (int64_t)b0 * a.sR + off0[G_R];    const int64_t sR = R32_STRIDE(G_R);   const int vR = hb * (int)a.sR + 2 * q;
+  // the diagonal entries this lane owns: Q(ix, ix) / R(iu, iu) of the cost, and where they go in the sweep's blocks
+  const T* cQd = a.cQ + (int64_t)b * a.sQ + off0[G_Q] + ix + (int64_t)ix * NX;
+  const T* cRd = a.cR + (int64_t)b * a.sR + off0[G_R] + iu + (int64_t)iu * NU;
+  T* dQd = a.Q + (int64_t)b * a.Q_bs + off0[G_Q] + ix + (int64_t)ix * NX;
+  T* dRd = a.R + (int64_t)b * a.R_bs + off0[G_R] + iu + (int64_t)iu * NU;
+  const T* gcq = a.cq + (int64_t)b * a.sx + off0[G_q] + ix;   const int64_t sq_ = R32_STRIDE(G_q);
+  const T* gcr = a.cr + (int64_t)b * a.su + off0[G_r] + iu;   const int64_t sr_ = R32_STRIDE(G_r);
+  const T* gx = a.x + (int64_t)b * a.x_bs + off0[G_x] + ix;   const int64_t sx_ = R32_STRIDE(G_x);
+  const T* gu = a.u + (int64_t)b * a.u_bs + off0[G_u] + iu;   const int64_t su_ = R32_STRIDE(G_u);
+  T* glx = a.q + (int64_t)b * a.q_bs + off0[G_q] + ix;
+  T* glu = a.r + (int64_t)b * a.r_bs + off0[G_r] + iu;
+#undef R32_STRIDE
+  const double rho = a.prob[b].rho, rho_est = a.prob[b].rho_est;
+  // the knot points are independent here: blockIdx.y takes R32_EXPAND_CHUNK of them (the last chunk the terminal one too), so that a
+  // launch is 8 x as many waves walking an eighth of the horizon each (one walk of 128 knot points: 0.41 ms whatever the batch)
+  const int kb = (int)blockIdx.y * R32_EXPAND_CHUNK, ke = kb + R32_EXPAND_CHUNK < N ? kb + R32_EXPAND_CHUNK : N;
+  gQ += kb * sQ; gH += kb * sH; gR += kb * sR;
+  cQd += kb * sQ; cRd += kb * sR; dQd += kb * sQ; dRd += kb * sR;
+  gcq += kb * sq_; gcr += kb * sr_; gx += kb * sx_; gu += kb * su_; glx += kb * sq_; glu += kb * sr_;
+  R32Block<NN> rQ;
+  R32Block<NM> rH;
+  R32Block<MM> rR;
+  if (grad) { rQ.fetch(gQ, vQ, q); rH.fetch(gH, vH, q); rR.fetch(gR, vR, q); }
+  for (int k = kb; k < ke; ++k) {
+    const double xv = (double)*gx, uv0 = (double)*gu;
+    double ql = 0.0, rl = 0.0, cqd = 0.0, crd = 0.0;
+    if (grad) {
+      rQ.put(Lw + oQ, q); rH.put(Lw + oH, q); rR.put(Lw + oR, q);
+      ql = (double)*gcq; rl = (double)*gcr;
+      if (k + 1 < ke) { gQ += sQ; gH += sH; gR += sR; rQ.fetch(gQ, vQ, q); rH.fetch(gH, vH, q); rR.fetch(gR, vR, q); }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (hess) { cqd = (double)*cQd; crd = (double)*cRd; }
+    const double wv = isx ? xv : (isu ? uv0 : 0.0);
+    const R32Vec vw = r32_spread(wv, upper_row);
+    double cost = 0.0, viol = 0.0, alcol = 0.0, dg = 0.0;
+    r32_al<T, NX, NU>(a.al, k, b, a.batch, vw, wv, false, rho_est, q, upper_row, grad, isx ? ix : NX + iu, has, cost, viol, alcol, dg, hess);
+    if (grad) {
+      double s1 = 0.0, s2 = 0.0;     // state lanes: Q x, H^T u;  input lanes: H x, R u
+      r32_states1<NX>(s1, vw, L, isx ? oQ + ix : oH + iu, isx ? NX : NU);
+      r32_in1<NU>(s2, vw, L, isx ? oH + ix * NU : oR + iu, isx ? 1 : NU);
+      if (wr) {
+        if (isx) *glx = (T)(((s1 + ql) + s2) - alcol);
+        if (isu) *glu = (T)(((s2 + rl) + s1) - alcol);
+      }
+    }
+    if (hess && wr) {
+      if (isx) { double v = cqd; v += rho * dg; *dQd = (T)v; }
+      if (isu) { double v = crd; v += rho * dg; *dRd = (T)v; }
+    }
+    gx += sx_; gu += su_; gcq += sq_; gcr += sr_; glx += sq_; glu += sr_;
+    cQd += sQ; cRd += sR; dQd += sQ; dRd += sR;
+  }
+  if (ke == N) {   // terminal knot point (the last chunk's): states only
+    const int64_t oNQ = a.off[(int64_t)N * G_NUM + G_Q];
+    R32Block<NN> rQn;
+    if (grad) { rQn.fetch(a.cQ + (int64_t)b0 * a.sQ + oNQ, vQ, q); rQn.put(Lw + oQ, q); }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const double xv = isx ? (double)*gx : 0.0;
+    const R32Vec vx = r32_spread(xv, upper_row);
+    double cost = 0.0, viol = 0.0, alcol = 0.0, dg = 0.0;
+    r32_al<T, NX, NU>(a.al, N, b, a.batch, vx, xv, true, rho_est, q, upper_row, grad, ix, isx, cost, viol, alcol, dg, hess);
+    if (grad) {
+      double s1 = 0.0;
+      r32_states1<NX>(s1, vx, L, oQ + ix, NX);
+      if (wr && isx) *glx = (T)((s1 + (double)*gcq) - alcol);
+    }
+    if (hess && wr && isx) {
+      double v = (double)a.cQ[(int64_t)b * a.sQ + oNQ + ix + (int64_t)ix * NX];
+      v += rho * dg;
+      a.Q[(int64_t)b * a.Q_bs + oNQ + ix + (int64_t)ix * NX] = (T)v;
+    }
   }
 }
 
