@@ -325,7 +325,7 @@ void altro_hip_batch_destroy(altro_hip_batch* h) {
                   h->m_qblk, h->m_trash, h->g_off, h->g_nx, h->g_nu, h->stage,
                   h->l_in, h->l_term, h->l_out, h->l_outn, h->l_xuy, h->l_x0,
                   h->l_nom, h->l_cost, h->g_ws, h->i_prob, h->i_alpha, h->i_phi, h->i_dphi, h->i_active, h->i_counters,
-                  h->al_d_knots, h->al_d_big, h->al_d_gsel, h->al_d_G, h->al_d_Gpad, h->al_d_g, h->al_d_z, h->i_reg, h->m_nom, h->m_costp,
+                  h->al_d_knots, h->al_d_big, h->al_d_gsel, h->g_stat_part, h->al_d_G, h->al_d_Gpad, h->al_d_g, h->al_d_z, h->i_reg, h->m_nom, h->m_costp,
                   h->i_cand_spec, h->i_spec_sel, h->i_spec_refresh, h->i_fused_list, h->i_guard, h->i_active_exact, h->i_stat_done, h->st_partial, h->st_red, h->i_merit_jk, h->i_spec_jac, h->i_results,
                   h->m_costd, h->m_costd_term, h->l_costq, h->i_sens, h->i_sens_alpha, h->i_aff_part, h->i_aff_on, h->g_xn, h->g_un, h->g_cQ, h->g_cR, h->g_cH, h->g_cq, h->g_cr, h->g_cc};
   for (void* p : ptrs) if (p) (void)hipFree(p);

@@ -378,6 +378,15 @@ int gen_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int 
   // MeritFunction in the row layout of kernels/ilqr_row32.hip: plan MFMA32's shapes (also on a handle created as plan GENERIC), fp64,
   // dynamics as data, every constraint block in a row-wise cone with at most 32 rows
   a.row32 = (sizeof(T) == 8 && row32_eligible(h)) ? 1 : 0;
+  if (a.row32 && which == IK_STATIONARITY && N > 32) {   // the stationarity walk in chunks of 32 knot points: their maxima meet here
+    const size_t need = (size_t)((N + 31) / 32) * h->batch * 2 * sizeof(double);
+    if (h->g_stat_part_bytes < need) {
+      if (h->g_stat_part) { (void)hipFree(h->g_stat_part); h->g_stat_part = nullptr; h->g_stat_part_bytes = 0; }
+      if (hipMalloc((void**)&h->g_stat_part, need) == hipSuccess) h->g_stat_part_bytes = need;
+      else { (void)hipGetLastError(); h->g_stat_part = nullptr; }   // (an optimisation only: one chunk then)
+    }
+    a.stat_part = h->g_stat_part;
+  }
   if (h->model_set) {   // a device model: the dynamics expansion rides with every gradient expansion of a stored trajectory
     a.mp = h->model;
     if (which == IK_EXPAND && (a.mode & EXPAND_GRADIENT)) a.mode |= EXPAND_DYN;

@@ -141,6 +141,7 @@ struct altro_hip_batch {
   void* al_d_Gpad = nullptr;                 // AlTable::Gpad (plan MFMA16)
   int al_Gpad_count = 0;
   bool al_all_gsel = false;              // plan GENERIC: every block is bound-type (the Hessian blocks change on their diagonals only)
+  double* g_stat_part = nullptr; size_t g_stat_part_bytes = 0;   // row32_stationarity_kernel's per-chunk maxima (capi_ilqr.hip: gen_run)
   int* al_d_gsel = nullptr;              // plan GENERIC: AlTable::gsel (bound-type blocks)
   bool al_row32_ok = false;              // every block fits kernels/ilqr_row32.hip (row-wise cone, <= 32 rows)
   int al_max_ncon = 0;                   // most blocks (plan MFMA16: slots, al_types.h) any knot point has

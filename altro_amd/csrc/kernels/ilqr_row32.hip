@@ -537,6 +537,7 @@ __global__ __launch_bounds__(64, WPS) void row32_merit_kernel(IlqrGenArgs<T> a) 
 // ---- Stationarity and Feasibility (solver.cpp:207-231) of the candidate trajectory in the same layout: generic_stationarity_kernel's
 // values (maxima: no order to keep).  Lane j's product A_k^T y_{k+1} (B_k^T y_{k+1} in the input lanes) runs down COLUMN j of the
 // block -- in global memory a dozen cache lines per load instruction, in the image a conflict-free read at stride one.
+constexpr int R32_STAT_CHUNK = 32;
 template <typename T, int NX, int NU, int WPS>
 __global__ __launch_bounds__(64, WPS) void row32_stationarity_kernel(IlqrGenArgs<T> a) {
   constexpr int NN = NX * NX, NM = NX * NU, oA = 0, oB = NN, IMG = (NN + NM + 1) & ~1;
@@ -568,17 +569,21 @@ __global__ __launch_bounds__(64, WPS) void row32_stationarity_kernel(IlqrGenArgs
 #undef R32_STRIDE
   const double rho = al ? a.prob[b].rho : 1.0;
   double res = 0.0, viol = 0.0, r32_nodiag = 0.0;
+  // the knot points are independent (maxima): blockIdx.y takes R32_STAT_CHUNK of them, the last chunk the terminal one too; with more
+  // than one chunk the halves' maxima go to IlqrGenArgs::stat_part and row32_stat_reduce_kernel takes the maximum over the chunks
+  const int kb = (int)blockIdx.y * R32_STAT_CHUNK, ke = (gridDim.y == 1 || kb + R32_STAT_CHUNK >= N) ? N : kb + R32_STAT_CHUNK;
+  gA += kb * sA; gB += kb * sB; gy += kb * sy_; glx += kb * sq_; glu += kb * sr_; gx += kb * sx_; gu += kb * su_;
   R32Block<NN> rA;
   R32Block<NM> rB;
   rA.fetch(gA, vA, q); rB.fetch(gB, vB, q);
   double yk = (double)*gy;                               // y_k (state lanes), carried from knot point to knot point
-  for (int k = 0; k < N; ++k) {
+  for (int k = kb; k < ke; ++k) {
     rA.put(Lw + oA, q); rB.put(Lw + oB, q);
     gy += sy_;
     const double yn = (double)*gy, lx = (double)*glx, lu = (double)*glu;
     double xv = 0.0, uv = 0.0;
     if (al) { xv = (double)*gx; uv = (double)*gu; }
-    if (k + 1 < N) { gA += sA; gB += sB; rA.fetch(gA, vA, q); rB.fetch(gB, vB, q); }
+    if (k + 1 < ke) { gA += sA; gB += sB; rA.fetch(gA, vA, q); rB.fetch(gB, vB, q); }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -596,8 +601,8 @@ __global__ __launch_bounds__(64, WPS) void row32_stationarity_kernel(IlqrGenArgs
     yk = yn;
     glx += sq_; glu += sr_; gx += sx_; gu += su_;
   }
-  if (isx) res = fmax(res, fabs((double)*glx - yk));     // terminal: |lx_N - y_N|   (glx, yk stand at knot point N)
-  if (al) {
+  if (ke == N && isx) res = fmax(res, fabs((double)*glx - yk));     // terminal: |lx_N - y_N|   (glx, yk stand at knot point N)
+  if (ke == N && al) {
     const double wv = isx ? (double)*gx : 0.0;
     const R32Vec vw = r32_spread(wv, upper_row);
     double cost = 0.0, colsum = 0.0;
@@ -607,7 +612,22 @@ __global__ __launch_bounds__(64, WPS) void row32_stationarity_kernel(IlqrGenArgs
   // the maxima over the half's 32 lanes
 #pragma unroll
   for (int o = 16; o > 0; o >>= 1) { res = fmax(res, __shfl_xor(res, o, 64)); viol = fmax(viol, __shfl_xor(viol, o, 64)); }
-  if (q == 0 && ok_own) { a.prob[b].stationarity = res; a.prob[b].feasibility = viol; }
+  if (q == 0 && ok_own) {
+    if (gridDim.y == 1) { a.prob[b].stationarity = res; a.prob[b].feasibility = viol; }
+    else { double* pt = a.stat_part + ((size_t)blockIdx.y * a.batch + b) * 2; pt[0] = res; pt[1] = viol; }
+  }
+}
+// the maximum over the chunks (one thread per problem; the same problems the chunks' waves ran for)
+template <typename T>
+__global__ void row32_stat_reduce_kernel(IlqrGenArgs<T> a, int chunks) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.batch || (a.active && !a.active[b])) return;
+  double res = 0.0, viol = 0.0;
+  for (int c = 0; c < chunks; ++c) {
+    const double* pt = a.stat_part + ((size_t)c * a.batch + b) * 2;
+    res = fmax(res, pt[0]); viol = fmax(viol, pt[1]);
+  }
+  a.prob[b].stationarity = res; a.prob[b].feasibility = viol;
 }
 
 // ---- the head of Solve for an unconstrained problem (solver.cpp:420-434) in one pass: OpenLoopRollout (generic_rollout_kernel),

@@ -179,3 +179,29 @@ def test_unconstrained_solves_are_the_lds_forms_bit_for_bit(n, m, dense):
     status, iters, _ = s.solve()
     assert status == 0 and iters == out["row"]["iterations"][0]
     np.testing.assert_allclose(out["row"]["x"][0], s.get("x"), rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("constrained", [False, True])
+def test_long_horizons_walk_in_chunks(constrained):
+    """N = 70: the stationarity kernel walks the horizon in chunks of 32 knot points (their maxima meet in row32_stat_reduce_kernel), the
+    constrained expansion in chunks of 16 -- against the LDS forms: stationarity, feasibility and a whole solve."""
+    N, n, m, batch = 70, 13, 4, 5
+    p = problem(batch, N, n, m, False)
+    blocks = blocks_for(N, n, m, 7) if constrained else ()
+    out = {}
+    for name, forms in (("row", 0), ("lds", altro_amd.FORM_GENERIC_MERIT_LDS)):
+        bt = build(p, N, n, m, batch, False, forms, blocks)
+        res = evaluate(bt, batch)
+        r = bt.ilqr_solve(iterations_max=40, penalty_initial=1.0, penalty_scaling=10.0)
+        res["status"] = r["status"].copy(); res["iterations"] = r["iterations"].copy(); res["x"] = bt.get_nominal()[0].copy()
+        res["stationarity"] = r["stationarity"].copy()
+        out[name] = res
+        bt.close()
+    for key in out["row"]:
+        a, b = out["row"][key], out["lds"][key]
+        if key in ("x",):
+            np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-9, err_msg=key)
+        elif key in ("status", "iterations"):
+            assert np.array_equal(a, b), key
+        else:
+            np.testing.assert_allclose(a, b, rtol=1e-13, atol=1e-13 * max(1.0, float(np.abs(b).max())), err_msg=key)
