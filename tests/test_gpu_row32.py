@@ -205,3 +205,22 @@ def test_long_horizons_walk_in_chunks(constrained):
             assert np.array_equal(a, b), key
         else:
             np.testing.assert_allclose(a, b, rtol=1e-13, atol=1e-13 * max(1.0, float(np.abs(b).max())), err_msg=key)
+
+
+def test_a_handle_created_as_plan_generic_runs_the_same_kernels():
+    """The row-layout kernels serve plan MFMA32's shapes on plan GENERIC's arrays -- also on a handle created with ALTRO_HIP_PLAN_GENERIC
+    (whose TVLQR sweeps stay plan GENERIC's own, bit-identical to the CPU path): evaluations and a constrained solve against the LDS form."""
+    N, n, m, batch = 15, 14, 7, 4
+    p = problem(batch, N, n, m, True)
+    blocks = blocks_for(N, n, m, 9)
+    out = {}
+    for name, forms in (("row", 0), ("lds", altro_amd.FORM_GENERIC_MERIT_LDS)):
+        bt = build(p, N, n, m, batch, True, forms, blocks, plan=altro_amd.PLAN_GENERIC)
+        assert bt.plan == altro_amd.PLAN_GENERIC
+        res = evaluate(bt, batch)
+        r = bt.ilqr_solve(iterations_max=30, penalty_initial=1.0, penalty_scaling=10.0)
+        res["status"] = r["status"].copy(); res["iterations"] = r["iterations"].copy(); res["xsol"] = bt.get_nominal()[0].copy()
+        out[name] = res
+        bt.close()
+    for key in out["row"]:
+        assert np.array_equal(out["row"][key], out["lds"][key]), key
