@@ -443,16 +443,18 @@ __global__ __launch_bounds__(64, 4) void generic_merit_kernel(IlqrGenArgs<T> a) 
     } else {
       using M = DiscreteModel<MK, MN, MM, double>;
       const float h = a.mp.h;
+      if (deriv) {   // the two Jacobians zeroed by the whole wave (the evaluating lane then stores what its model knows to be nonzero)
+        for (int e = lane; e < MN * (MN + MM); e += 64) { md_J0[e] = 0.0; md_Jm[e] = 0.0; }
+        __syncthreads();
+      }
       if (lane == 0) {   // the model at (x, u) and at the midpoint
         double xl[MN], ul[MM], k1[MN], xm[MN], k2[MN];
         for (int e = 0; e < MN; ++e) xl[e] = xs[e];
         for (int e = 0; e < MM; ++e) ul[e] = us[e];
-        if (deriv) {
-          double J0[MN * (MN + MM)], Jm[MN * (MN + MM)];
-          M::cont_fJ(a.mp, xl, ul, k1, J0);
+        if (deriv) {   // (the Jacobians are written where the rows are formed from -- two local arrays of n (n + m) doubles lived in scratch memory)
+          M::cont_fJ_zeroed(a.mp, xl, ul, k1, md_J0);
           for (int e = 0; e < MN; ++e) xm[e] = xl[e] + (double)(h / 2) * k1[e];
-          M::cont_fJ(a.mp, xm, ul, k2, Jm);
-          for (int e = 0; e < MN * (MN + MM); ++e) { md_J0[e] = J0[e]; md_Jm[e] = Jm[e]; }
+          M::cont_fJ_zeroed(a.mp, xm, ul, k2, md_Jm);
         } else {
           M::cont_f(a.mp, xl, ul, k1);
           for (int e = 0; e < MN; ++e) xm[e] = xl[e] + (double)(h / 2) * k1[e];

@@ -316,10 +316,12 @@ ALTRO_HD void quadrotor13_f(const T* x, const T* u, T* xd) {
   xd[11] = (u[2] - T(kQuadIx - kQuadIz) * wz * wx) * T(kQuadRIy);
   xd[12] = (u[3] - T(kQuadIy - kQuadIx) * wx * wy) * T(kQuadRIz);
 }
-template <typename T>
+// (ZERO = false: the caller has zeroed J -- plan GENERIC's merit kernel does it with all its lanes, the evaluating lane stores the 46 nonzeros)
+template <typename T, bool ZERO = true>
 ALTRO_HD void quadrotor13_J(const T* x, const T* u, T* J) {   // 13 x 17, column-major
   constexpr int n = 13;
-  for (int e = 0; e < 13 * 17; ++e) J[e] = T(0);
+  if (ZERO)
+    for (int e = 0; e < 13 * 17; ++e) J[e] = T(0);
   const T qw = x[3], qx = x[4], qy = x[5], qz = x[6];
   const T wx = x[10], wy = x[11], wz = x[12];
 #define QJ(i, j) J[(i) + (j) * n]
@@ -376,6 +378,11 @@ struct DiscreteModel {
     else bicycle_J<T>(mp, x, u, J);
   }
 
+  // the same into a J the caller has zeroed (models that know their zeros skip them; the others fill every entry anyway)
+  static ALTRO_HD void cont_fJ_zeroed(const ModelParams& mp, const T* x, const T* u, T* xdot, T* J) {
+    if (KIND == MODEL_QUADROTOR13) { quadrotor13_f<T>(x, u, xdot); quadrotor13_J<T, false>(x, u, J); return; }
+    cont_fJ(mp, x, u, xdot, J);
+  }
   static ALTRO_HD void cont_fJ(const ModelParams& mp, const T* x, const T* u, T* xdot, T* J) {
 #if defined(ALTRO_HIP_USER_MODEL) && defined(ALTRO_HIP_TILE_N)
     if (KIND == MODEL_USER) { altro_tile_user_f<T>(x, u, xdot); altro_tile_user_J<T>(x, u, J); return; }
