@@ -346,6 +346,11 @@ bool row32_eligible(const altro_hip_batch* h) {
   return h->plan == ALTRO_HIP_PLAN_GENERIC && h->dtype == ALTRO_HIP_F64 && !h->ragged && !h->model_set && tile32_supported(h->n, h->m) &&
          !form(h, ALTRO_HIP_FORM_GENERIC_MERIT_LDS) && (h->al_defs.empty() || h->al_row32_ok);
 }
+// the same with a compiled-in device model (row32_model.hip has the kernels: ilqr_generic_model_supported's models)
+bool row32_model_eligible(const altro_hip_batch* h) {
+  return h->plan == ALTRO_HIP_PLAN_GENERIC && h->dtype == ALTRO_HIP_F64 && !h->ragged && h->model_set && tile32_supported(h->n, h->m) &&
+         !form(h, ALTRO_HIP_FORM_GENERIC_MERIT_LDS) && (h->al_defs.empty() || h->al_row32_ok);
+}
 // plan GENERIC: any (n_k, m_k) up to 64, dynamics as data, quadratic cost, linear constraint blocks (kernels/ilqr_generic.hip)
 template <typename T>
 int gen_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int want_deriv, double alpha_const, int mode) {
@@ -378,7 +383,8 @@ int gen_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int 
   // MeritFunction in the row layout of kernels/ilqr_row32.hip: plan MFMA32's shapes (also on a handle created as plan GENERIC), fp64,
   // dynamics as data, every constraint block in a row-wise cone with at most 32 rows
   a.row32 = (sizeof(T) == 8 && row32_eligible(h)) ? 1 : 0;
-  if (a.row32 && which == IK_STATIONARITY && N > 32) {   // the stationarity walk in chunks of 32 knot points: their maxima meet here
+  a.row32m = (sizeof(T) == 8 && row32_model_eligible(h)) ? 1 : 0;
+  if ((a.row32 || a.row32m) && which == IK_STATIONARITY && N > 32) {   // the stationarity walk in chunks of 32 knot points: their maxima meet here
     const size_t need = (size_t)((N + 31) / 32) * h->batch * 2 * sizeof(double);
     if (h->g_stat_part_bytes < need) {
       if (h->g_stat_part) { (void)hipFree(h->g_stat_part); h->g_stat_part = nullptr; h->g_stat_part_bytes = 0; }

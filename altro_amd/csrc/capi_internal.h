@@ -508,6 +508,7 @@ void merit_split_prepare(altro_hip_batch* h);
 int ilqr_gather_results(altro_hip_batch* h, altro_hip_solve_result* results);
 int launch_backward(altro_hip_batch* h, double reg);
 bool row32_eligible(const altro_hip_batch* h);             // capi_ilqr.hip: kernels/ilqr_row32.hip serves the handle
+bool row32_model_eligible(const altro_hip_batch* h);
 bool tile32_supported(int n, int m);                        // capi_tile32.hip: plan MFMA32
 int tile32_launch_backward(altro_hip_batch* h, double reg);
 int tile32_launch_forward(altro_hip_batch* h);

@@ -25,6 +25,8 @@ static int row32_merit_dispatch(hipStream_t stream, const IlqrGenArgs<double>& a
   }
 }
 
+int row32_model_launch(hipStream_t, const IlqrGenArgs<double>&, int);   // row32_model.hip
+
 bool ilqr_generic_model_supported(int kind, int n, int m) { return kind == MODEL_QUADROTOR13 && n == 13 && m == 4; }
 
 // the kernels that step a compiled-in device model (fp64 handles); everything else of the loop is the data form's
@@ -36,11 +38,19 @@ static int gen_launch_model(hipStream_t stream, int which, const IlqrGenArgs<dou
       hipLaunchKernelGGL((generic_model_rollout_kernel<double, MK, MN, MM>), dim3((a.batch + 63) / 64), b64, 0, stream, a);
       break;
     case IK_MERIT: {
+      if (a.row32m) {   // two problems per wave in the row layout, every lane evaluating the model (kernels/ilqr_row32.hip: r32_model_step)
+        const int rc = row32_model_launch(stream, a, 0);
+        if (rc != 1) return rc;
+      }
       const size_t jv = a.al.enabled ? (size_t)GEN_AL_JV * sizeof(double) : 0;
       hipLaunchKernelGGL((generic_merit_kernel<double, false, MK, MN, MM>), waves, b64, jv, stream, a);
       break;
     }
     case IK_EXPAND: {   // after the cost expansion (the caller launched it): A_k, B_k at the candidate trajectory
+      if (a.row32m) {
+        const int rc = row32_model_launch(stream, a, 5);
+        if (rc != 1) return rc;
+      }
       const int64_t tot = (int64_t)a.batch * a.N;
       hipLaunchKernelGGL((generic_model_expand_dyn_kernel<double, MK, MN, MM>), dim3((unsigned)((tot + 63) / 64)), b64, 0, stream, a);
       break;
@@ -105,7 +115,7 @@ static int gen_launch(hipStream_t stream, int which, const IlqrGenArgs<T>& a) {
       return 1;
     case IK_STATIONARITY:
       if constexpr (sizeof(T) == 8) {
-        if (a.row32) {   // (kernels/ilqr_row32.hip: row32_stationarity_kernel)
+        if (a.row32 || a.row32m) {   // (kernels/ilqr_row32.hip: row32_stationarity_kernel -- it reads A_k, B_k wherever they came from)
           const int rc = row32_merit_dispatch(stream, a, 1);
           if (rc != 1) return rc;
         }

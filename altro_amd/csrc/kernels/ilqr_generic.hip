@@ -49,6 +49,7 @@ struct IlqrGenArgs {
   // uniform n <= 31, m <= 8, n + m <= 32, fp64, dynamics as data, constraint blocks (if any) of at most 32 rows in the row-wise cones:
   // MeritFunction runs kernels/ilqr_row32.hip's kernel (the host decides: capi_ilqr.hip)
   int row32 = 0;
+  int row32m = 0;                                       // a device model's handle on those shapes: MeritFunction in the row layout too (row32_model.hip)
   double* stat_part = nullptr;                          // row32_stationarity_kernel's per-chunk maxima [chunk][b][2], or null (one chunk)
 };
 

@@ -334,6 +334,105 @@ __device__ __forceinline__ void r32_al(const AlTable<T>& t, int k, int b, int64_
   }
 }
 
+// ---- a compiled-in device model (models.h) in this layout: generic_merit_kernel<.., MK>'s values (there lane 0 evaluates the model and
+// its two Jacobians for the wave, through LDS; the rows of A_k = I + h Am (I + h/2 A0), B_k = h (Am h/2 B0 + Bm) are 13 x 17 inner
+// loops of 13 terms per lane: 94 % of a quadrotor NMPC step, profiles/r06o_quad13_nmpc_4096.txt) the way the (12, 4) tile steps its
+// models (kernels/ilqr_tile_model.hip): every lane gathers the half's [x; u] (32 DPP moves) and evaluates the continuous model itself
+// -- the same instructions in every lane: one evaluation's issue per wave, for two problems --, keeps row `ix` of the midpoint Jacobian
+// and sums over the terms whose factor in the first Jacobian is not a structural zero of the model (a skipped term is (h Am) * (0 + h/2
+// * 0) = +-0 added to a sum that starts at +0: the sums, in generic_merit_kernel's order with its expressions, keep their bits).
+// lanes L0, L0 + DL, ... (CNT of them, 1..4) of the row of 16, to every lane of the row
+template <int L0, int DL, int CNT>
+__device__ __forceinline__ void r32_gather4(double v, double* o) {
+  static_assert(CNT >= 1 && CNT <= 4 && L0 >= 0 && L0 <= 15 && L0 + DL * (CNT - 1) >= 0 && L0 + DL * (CNT - 1) <= 15, "a row of 16 lanes");
+#define R32_MV(O, L) "v_mov_b64_dpp %" #O ", %" #L R32_DPP
+  if constexpr (CNT == 4)
+    asm volatile("s_nop 4\n" "v_mov_b64_dpp %0, %4 row_newbcast:%5" R32_DPP "v_mov_b64_dpp %1, %4 row_newbcast:%6" R32_DPP
+                 "v_mov_b64_dpp %2, %4 row_newbcast:%7" R32_DPP "v_mov_b64_dpp %3, %4 row_newbcast:%8" R32_DPP
+                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]) : "v"(v), "n"(L0), "n"(L0 + DL), "n"(L0 + 2 * DL), "n"(L0 + 3 * DL));
+  else if constexpr (CNT == 3)
+    asm volatile("s_nop 4\n" "v_mov_b64_dpp %0, %3 row_newbcast:%4" R32_DPP "v_mov_b64_dpp %1, %3 row_newbcast:%5" R32_DPP
+                 "v_mov_b64_dpp %2, %3 row_newbcast:%6" R32_DPP
+                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]) : "v"(v), "n"(L0), "n"(L0 + DL), "n"(L0 + 2 * DL));
+  else if constexpr (CNT == 2)
+    asm volatile("s_nop 4\n" "v_mov_b64_dpp %0, %2 row_newbcast:%3" R32_DPP "v_mov_b64_dpp %1, %2 row_newbcast:%4" R32_DPP
+                 : "=&v"(o[0]), "=&v"(o[1]) : "v"(v), "n"(L0), "n"(L0 + DL));
+  else
+    asm volatile("s_nop 4\n" "v_mov_b64_dpp %0, %1 row_newbcast:%2" R32_DPP : "=&v"(o[0]) : "v"(v), "n"(L0));
+#undef R32_MV
+}
+// the states (positions 0 .. NX-1) and the inputs (position 31 - e) of a vector, whole, in every lane of the half
+template <int NX, int NU, int J0 = 0>
+__device__ __forceinline__ void r32_gather_states(const R32Vec& v, double* xl) {
+  if constexpr (J0 < NX) {
+    constexpr int here = NX - J0 < 4 ? NX - J0 : 4;
+    constexpr int stop = (J0 < 16 && J0 + here > 16) ? 16 - J0 : here;   // (a block does not straddle the rows of 16)
+    if constexpr (J0 < 16) r32_gather4<J0, 1, stop>(v.lo, xl + J0);
+    else r32_gather4<J0 - 16, 1, stop>(v.hi, xl + J0);
+    r32_gather_states<NX, NU, J0 + stop>(v, xl);
+  }
+}
+template <int NU>
+__device__ __forceinline__ void r32_gather_inputs(const R32Vec& v, double* ul) {
+  r32_gather4<15, -1, (NU < 4 ? NU : 4)>(v.hi, ul);
+  if constexpr (NU > 4) r32_gather4<11, -1, NU - 4>(v.hi, ul + 4);
+}
+// One explicit-midpoint step (test_utils.cpp:84-132) from the half's [x; u] (vw: states at positions 0.., input e at 31 - e): state
+// lane ix gets x+_ix and, with JAC, row ix of [A_k B_k] (lanes without a state compute row 0 along and must not use it).
+template <int MK, int NX, int NU, bool JAC>
+__device__ __forceinline__ void r32_model_step(const ModelParams& mp, const R32Vec& vw, double own, int ix, double& xnext, double (&zrow)[NX + NU]) {
+  using M = DiscreteModel<MK, NX, NU, double>;
+  double xl[NX], ul[NU], k1[NX], xm[NX], k2[NX];
+  r32_gather_states<NX, NU>(vw, xl);
+  r32_gather_inputs<NU>(vw, ul);
+  const float h = mp.h;
+  if constexpr (JAC) {
+    double J0[NX * (NX + NU)], Jm[NX * (NX + NU)], jm[NX + NU];
+    M::cont_fJ(mp, xl, ul, k1, J0);
+#pragma unroll
+    for (int e = 0; e < NX; ++e) xm[e] = xl[e] + (double)(h / 2) * k1[e];
+    M::cont_fJ(mp, xm, ul, k2, Jm);
+#pragma unroll
+    for (int c = 0; c < NX + NU; ++c) {                 // the lane's row of Jm: a select per entry that is not the same constant in every row
+      double v = 0.0;
+#pragma unroll
+      for (int r = 0; r < NX; ++r) v = (ix == r) ? Jm[r + NX * c] : v;
+      jm[c] = v;
+    }
+#pragma unroll
+    for (int jc = 0; jc < NX; ++jc) {
+      double sm = 0.0;
+#pragma unroll
+      for (int kk = 0; kk < NX; ++kk) {
+        const double a0 = J0[kk + jc * NX];
+        if (kk != jc && __builtin_constant_p(a0) && a0 == 0.0) continue;
+        sm += ((double)h * jm[kk]) * ((kk == jc ? 1.0 : 0.0) + (double)(h / 2) * a0);
+      }
+      zrow[jc] = (ix == jc ? 1.0 : 0.0) + sm;
+    }
+#pragma unroll
+    for (int jc = 0; jc < NU; ++jc) {
+      double sm = 0.0;
+#pragma unroll
+      for (int kk = 0; kk < NX; ++kk) {
+        const double b0 = J0[kk + (NX + jc) * NX];
+        if (__builtin_constant_p(b0) && b0 == 0.0) continue;
+        sm += (jm[kk] * (double)(h / 2)) * b0;
+      }
+      zrow[NX + jc] = (double)h * (sm + jm[NX + jc]);
+    }
+  } else {
+    M::cont_f(mp, xl, ul, k1);
+#pragma unroll
+    for (int e = 0; e < NX; ++e) xm[e] = xl[e] + (double)(h / 2) * k1[e];
+    M::cont_f(mp, xm, ul, k2);
+  }
+  double kj = 0.0;
+#pragma unroll
+  for (int r = 0; r < NX; ++r) kj = (ix == r) ? k2[r] : kj;
+  xnext = own + (double)h * kj;
+}
+
 constexpr int r32_image_doubles(int n, int m) { return ((3 * n * n + 3 * n * m + m * m + 1) & ~1); }
 
 // two problems per wave: lanes 0..31 problem 2 pr, lanes 32..63 problem 2 pr + 1
@@ -342,7 +441,11 @@ constexpr int r32_image_doubles(int n, int m) { return ((3 * n * n + 3 * n * m +
 // image: the knot point's matrices are fetched once, by all 64 lanes.  Half 1 writes the candidate trajectory and the expansion (what
 // the second of two launches would have left behind), both halves their phi / phi' (rows 0 and 1 of IlqrGenArgs::phi / dphi); per
 // half the single-trial kernel's instructions on the same data, so the same values.
-template <typename T, int NX, int NU, int WPS, bool DUAL = false>
+// MK != 0: a compiled-in device model of NX states and NU inputs in the place of x+ = A x + B u + f (generic_merit_kernel<.., MK>): the
+// blocks A_k, B_k are not fetched but formed (r32_model_step), written into their slots of the image -- the sensitivity's chain runs
+// over them as it does over fetched ones -- and, with the derivative, stored into the sweep's arrays for the backward pass
+// (MeritFunction with derivative refreshes the dynamics expansion: solver.cpp:300-305).
+template <typename T, int NX, int NU, int WPS, bool DUAL = false, int MK = 0>
 __global__ __launch_bounds__(64, WPS) void row32_merit_kernel(IlqrGenArgs<T> a) {
   static_assert(NX >= 1 && NU >= 1 && NU <= 8 && NX + NU <= 32, "a problem's [x; u] fits half a wave, the inputs its top eight positions");
   constexpr int NN = NX * NX, NM = NX * NU, MM = NU * NU;
@@ -396,6 +499,8 @@ __global__ __launch_bounds__(64, WPS) void row32_merit_kernel(IlqrGenArgs<T> a) 
   const T* gcr = a.cr + (int64_t)b * a.su + off0[G_r] + iu;  const int64_t sr_ = R32_STRIDE(G_r);
   T* glu = a.r + (int64_t)b * a.r_bs + off0[G_r] + iu;
   const T* gcc = a.cc + (int64_t)b * (N + 1);
+  T* gAw = const_cast<T*>(a.A) + (int64_t)b * a.A_bs + off0[G_A] + ix;   // (MK: this lane's row of A_k, B_k in the sweep's arrays)
+  T* gBw = const_cast<T*>(a.B) + (int64_t)b * a.B_bs + off0[G_B] + ix;
 #undef R32_STRIDE
   double x = isx ? (double)a.x0[(int64_t)b * a.x0_stride + q] : 0.0, dxda = 0.0;
   double J0 = 0.0, J1 = 0.0, dJ = 0.0;                // J0: this position's constraint rows and state row; J1: its input row
@@ -404,8 +509,10 @@ __global__ __launch_bounds__(64, WPS) void row32_merit_kernel(IlqrGenArgs<T> a) 
   R32Block<MM, LN> rR;
   double vxn, vp, vf, vcq, vd = 0.0, vun = 0.0, vcr = 0.0, vcc;   // the knot point's entries of the vectors, fetched with the matrices
   auto fetch = [&]() {
-    rP.fetch(gP, vP, ql); rK.fetch(gK, vK, ql); rA.fetch(gA, vA, ql); rB.fetch(gB, vB, ql); rQ.fetch(gQ, vQ, ql); rH.fetch(gH, vH, ql); rR.fetch(gR, vR, ql);
-    vxn = (double)*gxn; vp = (double)*gp; vf = (double)*gf; vcq = (double)*gcq;
+    rP.fetch(gP, vP, ql); rK.fetch(gK, vK, ql); rQ.fetch(gQ, vQ, ql); rH.fetch(gH, vH, ql); rR.fetch(gR, vR, ql);
+    if constexpr (MK == 0) { rA.fetch(gA, vA, ql); rB.fetch(gB, vB, ql); vf = (double)*gf; }
+    else vf = 0.0;
+    vxn = (double)*gxn; vp = (double)*gp; vcq = (double)*gcq;
     vd = (double)*gd; vun = (double)*gun; vcr = (double)*gcr;   // (every lane: lanes without an input row read row 0's and do not use it)
   };
   fetch();
@@ -414,7 +521,8 @@ __global__ __launch_bounds__(64, WPS) void row32_merit_kernel(IlqrGenArgs<T> a) 
     // this knot point's matrices into the image (every read of the last one's has been issued), the next one's on their way.
     // One wave: the LDS pipe executes its writes before the reads that follow, for all lanes -- nothing to wait for (a __syncthreads
     // would wait for the loads just issued: the whole round trip, every knot point); the compiler only has to keep the order.
-    rP.put(Lw + oP, ql); rK.put(Lw + oK, ql); rA.put(Lw + oA, ql); rB.put(Lw + oB, ql); rQ.put(Lw + oQ, ql); rH.put(Lw + oH, ql); rR.put(Lw + oR, ql);
+    rP.put(Lw + oP, ql); rK.put(Lw + oK, ql); rQ.put(Lw + oQ, ql); rH.put(Lw + oH, ql); rR.put(Lw + oR, ql);
+    if constexpr (MK == 0) { rA.put(Lw + oA, ql); rB.put(Lw + oB, ql); }
     const double xnom = vxn, pk = vp, fk = vf, ql = vcq, dk = vd, unom = vun, rl = vcr, ck = vcc;
     if (k + 1 < N) {
       gP += sP; gK += sK; gA += sA; gB += sB; gQ += sQ; gH += sH; gR += sR;
@@ -439,10 +547,38 @@ __global__ __launch_bounds__(64, WPS) void row32_merit_kernel(IlqrGenArgs<T> a) 
     }
     if (isx && wr) *gy = (T)(s + pk);                   // y_ = P dx + p
     const R32Vec vw = r32_spread(isx ? x : uv, upper_row), vdw = r32_spread(isx ? dxda : du, upper_row);
-    // rows of [A B] (state lanes) / [H R] (input lanes) against [x; u] and its sensitivity
+    double xmodel = 0.0;
+    if constexpr (MK != 0) {   // the model at this knot point's [x; u]; with the derivative the state lanes' rows of [A_k B_k] into the image
+      if (deriv) {
+        double zrow[NX + NU];
+        r32_model_step<MK, NX, NU, true>(a.mp, vw, x, ix, xmodel, zrow);
+        if (isx) {
+#pragma unroll
+          for (int c = 0; c < NX; ++c) Lw[oA + ix + c * NX] = zrow[c];
+#pragma unroll
+          for (int c = 0; c < NU; ++c) Lw[oB + ix + c * NX] = zrow[NX + c];
+          if (wr) {   // (a column per store instruction: the half's state lanes write NX consecutive entries)
+#pragma unroll
+            for (int c = 0; c < NX; ++c) gAw[c * NX] = (T)zrow[c];
+#pragma unroll
+            for (int c = 0; c < NU; ++c) gBw[c * NX] = (T)zrow[NX + c];
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      } else {
+        double unused[NX + NU];
+        r32_model_step<MK, NX, NU, false>(a.mp, vw, x, ix, xmodel, unused);
+      }
+      gAw += sA; gBw += sB;
+    }
+    // rows of [A B] (state lanes) / [H R] (input lanes) against [x; u] and its sensitivity (MK: one sum over A's then B's terms, like
+    // generic_merit_kernel's; without the derivative the state lanes' coefficients are whatever the image holds and nobody reads the sums)
     double sA_ = 0.0, tA = 0.0, sBv = 0.0, tB = 0.0;
     r32_states2<NX>(sA_, tA, vw, vdw, L, isx ? oA + ix : oH + iu, isx ? NX : NU);
-    r32_in2<NU>(sBv, tB, vw, vdw, L, isx ? oB + ix : oR + iu, isx ? NX : NU);
+    if constexpr (MK == 0) r32_in2<NU>(sBv, tB, vw, vdw, L, isx ? oB + ix : oR + iu, isx ? NX : NU);
+    else r32_in2<NU>(sBv, tA, vw, vdw, L, isx ? oB + ix : oR + iu, isx ? NX : NU);
     double alcol = 0.0;
     if (al) {   // the constraint rows' cost shares at the candidate point and the gradient's column sums
       double Jal = 0.0;
@@ -470,8 +606,8 @@ __global__ __launch_bounds__(64, WPS) void row32_merit_kernel(IlqrGenArgs<T> a) 
       if (isu) { dJ += lxu * du; if (wr) *glu = (T)lxu; }
     }
     if (isx) {   // next state (uniform dimensions: n2 = n)
-      const double xn = (sA_ + sBv) + fk;
-      dxda = tA + tB;
+      const double xn = MK != 0 ? xmodel : (sA_ + sBv) + fk;
+      dxda = MK != 0 ? tA : tA + tB;
       x = xn;
     }
     gx += sx_; gy += sy_; glx += sq_; gu += su_; glu += sr_;
@@ -531,6 +667,36 @@ __global__ __launch_bounds__(64, WPS) void row32_merit_kernel(IlqrGenArgs<T> a) 
         if (al) a.prob[bs].rho_est = a.prob[bs].rho;
       }
     }
+  }
+}
+
+// ---- CalcDynamicsExpansion (knotpoint_data.cpp:406-419) of a stored candidate trajectory with a device model: A_k, B_k at every
+// (problem, knot point), half a wave each (generic_model_expand_dyn_kernel: a thread each, its 13 x 17 Jacobians in scratch memory --
+// 1.0 ms for 4096 vehicles x 30 knot points, once per solve).  r32_model_step's rows: jacobian()'s expressions (models.h).
+template <typename T, int NX, int NU, int MK>
+__global__ __launch_bounds__(64, 1) void row32_expand_dyn_kernel(IlqrGenArgs<T> a) {
+  const int lane = threadIdx.x, half = lane >> 5, q = lane & 31;
+  const bool upper_row = (lane & 16) != 0;
+  const int64_t tot = (int64_t)a.batch * a.N;
+  const int64_t t_own = 2 * (int64_t)blockIdx.x + half, t_oth = 2 * (int64_t)blockIdx.x + (1 - half);
+  const bool ok_own = t_own < tot && !(a.active && !a.active[(int)(t_own / a.N)]);
+  const bool ok_oth = t_oth < tot && !(a.active && !a.active[(int)(t_oth / a.N)]);
+  if (!ok_own && !ok_oth) return;
+  const int64_t t = ok_own ? t_own : t_oth;           // a half without a pair shadows the other one and stores nothing
+  const int b = (int)(t / a.N), k = (int)(t % a.N);
+  const bool isx = q < NX, isu = q >= 32 - NU;
+  const int ix = isx ? q : 0, iu = isu ? 31 - q : 0;
+  const double w = isx ? (double)a.x[(int64_t)b * a.x_bs + (int64_t)k * NX + ix] : (isu ? (double)a.u[(int64_t)b * a.u_bs + (int64_t)k * NU + iu] : 0.0);
+  const R32Vec vw = r32_spread(w, upper_row);
+  double xn, zrow[NX + NU];
+  r32_model_step<MK, NX, NU, true>(a.mp, vw, w, ix, xn, zrow);
+  if (ok_own && isx) {
+    T* Ao = const_cast<T*>(a.A) + (int64_t)b * a.A_bs + (int64_t)k * NX * NX + ix;
+    T* Bo = const_cast<T*>(a.B) + (int64_t)b * a.B_bs + (int64_t)k * NX * NU + ix;
+#pragma unroll
+    for (int c = 0; c < NX; ++c) Ao[c * NX] = (T)zrow[c];
+#pragma unroll
+    for (int c = 0; c < NU; ++c) Bo[c * NX] = (T)zrow[NX + c];
   }
 }
 

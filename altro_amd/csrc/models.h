@@ -320,8 +320,10 @@ ALTRO_HD void quadrotor13_f(const T* x, const T* u, T* xd) {
 template <typename T, bool ZERO = true>
 ALTRO_HD void quadrotor13_J(const T* x, const T* u, T* J) {   // 13 x 17, column-major
   constexpr int n = 13;
-  if (ZERO)
+  if (ZERO) {
+#pragma unroll
     for (int e = 0; e < 13 * 17; ++e) J[e] = T(0);
+  }
   const T qw = x[3], qx = x[4], qy = x[5], qz = x[6];
   const T wx = x[10], wy = x[11], wz = x[12];
 #define QJ(i, j) J[(i) + (j) * n]

@@ -330,3 +330,53 @@ def test_a_sixteen_state_model_from_source():
                 assert np.abs(fd - col).max() < 1e-6, (b, k, c)
     res = bt.ilqr_solve(iterations_max=60, tol_stationarity=1e-3)
     assert (res["status"] == 0).sum() >= batch - 2 and res["iterations"].max() < 60
+
+
+@pytest.mark.parametrize("constrained", [False, True])
+def test_row_layout_model_merit_equals_the_lds_form(constrained):
+    """MeritFunction with the compiled-in model in the row layout (kernels/ilqr_row32.hip: r32_model_step -- every lane evaluates the
+    model, two problems per wave) against generic_merit_kernel<.., MK> (lane 0 evaluates it for a wave of one problem:
+    ALTRO_HIP_FORM_GENERIC_MERIT_LDS): the same sums in the same order -- the first expansion's A_k, B_k, phi, phi', the candidate, the refreshed A_k, B_k, the
+    stored gradient at 1e-13 relative (the printout says whether they are bit-identical), with and without the derivative, odd batch;
+    whole solves with the same status and iteration count."""
+    batch = 7
+    c = make_case(batch, seed=3)
+    Gb = np.zeros((2, n + m)); Gb[0, n] = 1.0; Gb[1, n] = -1.0
+    blocks = [(0, N - 1, altro_amd.CONE_INEQUALITY, Gb, np.array([1.1 * HOVER[0], -0.8 * HOVER[0]]))] if constrained else []
+    out = {}
+    for name, forms in (("row", 0), ("lds", altro_amd.FORM_GENERIC_MERIT_LDS)):
+        bt = make_hip(c, altro_amd.PLAN_MFMA32)
+        bt.set_forms(forms)
+        for (k0, k1, cone, G, g) in blocks:
+            bt.add_linear_constraint(k0, k1, cone, G, g)
+        bt.open_loop_rollout(); bt.accept(); bt.expand()
+        r = {}
+        r["A_expand"], r["B_expand"] = (v.copy() for v in bt.get_expansion()[:2])   # (row32_expand_dyn_kernel / generic_model_expand_dyn_kernel)
+        bt.backward()
+        assert (bt.get("status") == -1).all()
+        for tag, alphas, deriv in (("a", np.linspace(0.05, 1.0, batch), True), ("zero", np.zeros(batch), True), ("noderiv", np.full(batch, 0.5), False)):
+            phi, dphi = bt.merit(alphas, derivative=deriv)
+            r["phi_" + tag] = phi.copy()
+            r["x_" + tag] = bt.get("x").copy(); r["u_" + tag] = bt.get("u").copy(); r["y_" + tag] = bt.get("y").copy()
+            if deriv:
+                r["dphi_" + tag] = dphi.copy()
+                A, B, lx, lu = bt.get_expansion()
+                r["A_" + tag] = A.copy(); r["B_" + tag] = B.copy(); r["lx_" + tag] = lx.copy(); r["lu_" + tag] = lu.copy()
+                r["stat_" + tag] = np.asarray(bt.stationarity(), dtype=np.float64).copy()
+        res = bt.ilqr_solve(iterations_max=50, tol_stationarity=1e-3, penalty_initial=1.0, penalty_scaling=10.0)
+        r["solve_status"] = res["status"].copy(); r["solve_iterations"] = res["iterations"].copy()
+        r["solve_x"] = bt.get_nominal()[0].copy()
+        out[name] = r
+        bt.close()
+    exact = 0
+    for key in out["row"]:
+        a, b = out["row"][key], out["lds"][key]
+        if key in ("solve_status", "solve_iterations"):
+            assert np.array_equal(a, b), (key, a, b)
+        elif key == "solve_x":
+            np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-9)
+        else:
+            np.testing.assert_allclose(a, b, rtol=1e-13, atol=1e-13 * max(1.0, float(np.abs(b).max())), err_msg=key)
+        exact += int(np.array_equal(a, b))
+    assert (out["row"]["solve_status"] == 0).sum() >= batch - 2
+    print("row-layout model merit == LDS form bit for bit in %d of %d quantities%s" % (exact, len(out["row"]), " (thrust bound)" if constrained else ""))
