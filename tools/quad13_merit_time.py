@@ -31,4 +31,4 @@ for deriv in (True, False):
         bt.synchronize(); t0 = time.perf_counter()
         bt.merit(alphas, derivative=deriv)
         bt.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
-    print("R32_XP=%s forms %#x: %d vehicles, N = %d, merit with derivative %s: %.3f ms (host clock, best of 5)" % (os.environ.get("R32_XP", "0"), forms, batch, N, deriv, min(ts)))
+    print("forms %#x: %d vehicles, N = %d, merit with derivative %s: %.3f ms (host clock, best of 5)" % (forms, batch, N, deriv, min(ts)))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""What a batched NMPC step of 13-state quaternion quadrotors costs on plan MFMA32 (device model in plan GENERIC's loop kernels: lane 0
-steps the model): tests/test_gpu_generic_model.py's case at a given batch, warm receding-horizon steps timed on the host clock.
+"""What a batched NMPC step of 13-state quaternion quadrotors costs on plan MFMA32 (device model in the row-layout loop kernels of
+kernels/ilqr_row32.hip): tests/test_gpu_generic_model.py's case at a given batch, warm receding-horizon steps timed on the host clock.
 
     python tools/quad13_nmpc_time.py [batch] [steps]
 """
