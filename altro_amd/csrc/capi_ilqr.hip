@@ -349,7 +349,8 @@ bool row32_eligible(const altro_hip_batch* h) {
 // the same with a compiled-in device model (row32_model.hip has the kernels: ilqr_generic_model_supported's models)
 bool row32_model_eligible(const altro_hip_batch* h) {
   return h->plan == ALTRO_HIP_PLAN_GENERIC && h->dtype == ALTRO_HIP_F64 && !h->ragged && h->model_set && tile32_supported(h->n, h->m) &&
-         !form(h, ALTRO_HIP_FORM_GENERIC_MERIT_LDS) && (h->al_defs.empty() || h->al_row32_ok);
+         ilqr_generic_model_supported(h->model.kind, h->n, h->m) && !form(h, ALTRO_HIP_FORM_GENERIC_MERIT_LDS) &&
+         (h->al_defs.empty() || h->al_row32_ok);
 }
 // plan GENERIC: any (n_k, m_k) up to 64, dynamics as data, quadratic cost, linear constraint blocks (kernels/ilqr_generic.hip)
 template <typename T>

@@ -146,7 +146,7 @@ int SolveRun::configure(const altro_hip_solve_options* opts) {
   // Plan MFMA16: phi(0) and the line search's first step from one pass over the records, the candidate's stationarity / feasibility
   // from that same pass.  ALTRO_HIP_FORM_NO_MERIT2 keeps the one-evaluation-per-launch sequence (the comparison the tests hold this against).
   // (round 6: also where kernels/ilqr_row32.hip serves the handle -- plan MFMA32's shapes: its merit kernel has a two-trial form)
-  dual = (h->plan == ALTRO_HIP_PLAN_MFMA16 || row32_eligible(h)) && !form(h, ALTRO_HIP_FORM_NO_SPECULATION) && !form(h, ALTRO_HIP_FORM_NO_MERIT2);
+  dual = (h->plan == ALTRO_HIP_PLAN_MFMA16 || row32_eligible(h) || row32_model_eligible(h)) && !form(h, ALTRO_HIP_FORM_NO_SPECULATION) && !form(h, ALTRO_HIP_FORM_NO_MERIT2);
   // Plan MFMA16, diagonal cost, bound-type blocks only: the Hessian blocks differ from sweep to sweep on their diagonal alone, so
   // after this solve's first (full) Hessian expansion the later ones store 16 values per knot point instead of 158 (EXPAND_DIAG)
   // (plan GENERIC / MFMA32, every block bound-type -- AlTable::gsel --: the constraints touch the Hessian blocks' diagonals only,

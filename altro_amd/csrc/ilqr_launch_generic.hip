@@ -111,6 +111,7 @@ static int gen_launch(hipStream_t stream, int which, const IlqrGenArgs<T>& a) {
     case IK_MERIT2:   // phi(0) and the line search's first step in one pass: the row layout's shapes only (the host asks where it applies)
       if constexpr (sizeof(T) == 8) {
         if (a.row32) return row32_merit_dispatch(stream, a, 3) == 0 ? 0 : 2;
+        if (a.row32m) return row32_model_launch(stream, a, 3) == 0 ? 0 : 2;
       }
       return 1;
     case IK_STATIONARITY:

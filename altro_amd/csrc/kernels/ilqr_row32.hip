@@ -452,7 +452,10 @@ __global__ __launch_bounds__(64, WPS) void row32_merit_kernel(IlqrGenArgs<T> a) 
   constexpr int oP = 0, oK = NN, oA = oK + NM, oB = oA + NN, oQ = oB + NM, oH = oQ + NN, oR = oH + NM, IMG = r32_image_doubles(NX, NU);
   constexpr int LN = DUAL ? 64 : 32;                  // lanes that share a block's runs
   __shared__ double red[2][2][64];                    // [phi | phi'][half][generic_merit_kernel's lane arrangement]
-  __shared__ double img[DUAL ? 1 : 2][IMG];           // [half][P | K | A | B | Q | H | R], every block column-major as in HBM
+  // [half][P | K | A | B | Q | H | R], every block column-major as in HBM.  (DUAL with a model: the two trials share the fetched blocks
+  // but each forms its own A_k, B_k -- two more A | B slots behind the image, one per half.)
+  constexpr int IMGX = IMG + ((DUAL && MK != 0) ? 2 * (NN + NM) : 0);
+  __shared__ double img[DUAL ? 1 : 2][IMGX];
   const int lane = threadIdx.x, half = lane >> 5, q = lane & 31;
   const int ql = DUAL ? lane : q;                     // this lane's place among the lanes that fetch a block
   const bool upper_row = (lane & 16) != 0;
@@ -470,6 +473,7 @@ __global__ __launch_bounds__(64, WPS) void row32_merit_kernel(IlqrGenArgs<T> a) 
   double viol = 0.0, r32_nodiag = 0.0;
   const double alpha = (DUAL && half == 1) ? 1.0 : (a.alpha ? a.alpha[b] : a.alpha_const);
   const bool deriv = a.want_derivative != 0;
+  const int oAm = (DUAL && MK != 0) ? IMG + half * (NN + NM) : oA, oBm = oAm + NN;   // where this half's rows of A_k, B_k live
   const r32_lds_t* const L = (const r32_lds_t*)&img[DUAL ? 0 : half][0];
   r32_lds_t* const Lw = (r32_lds_t*)&img[DUAL ? 0 : half][0];
   // uniform dimensions: knot point k's block of an array starts k strides after knot point 0's (the offset table's rows 0 and 1 say
@@ -554,9 +558,9 @@ __global__ __launch_bounds__(64, WPS) void row32_merit_kernel(IlqrGenArgs<T> a) 
         r32_model_step<MK, NX, NU, true>(a.mp, vw, x, ix, xmodel, zrow);
         if (isx) {
 #pragma unroll
-          for (int c = 0; c < NX; ++c) Lw[oA + ix + c * NX] = zrow[c];
+          for (int c = 0; c < NX; ++c) Lw[oAm + ix + c * NX] = zrow[c];
 #pragma unroll
-          for (int c = 0; c < NU; ++c) Lw[oB + ix + c * NX] = zrow[NX + c];
+          for (int c = 0; c < NU; ++c) Lw[oBm + ix + c * NX] = zrow[NX + c];
           if (wr) {   // (a column per store instruction: the half's state lanes write NX consecutive entries)
 #pragma unroll
             for (int c = 0; c < NX; ++c) gAw[c * NX] = (T)zrow[c];
@@ -576,9 +580,9 @@ __global__ __launch_bounds__(64, WPS) void row32_merit_kernel(IlqrGenArgs<T> a) 
     // rows of [A B] (state lanes) / [H R] (input lanes) against [x; u] and its sensitivity (MK: one sum over A's then B's terms, like
     // generic_merit_kernel's; without the derivative the state lanes' coefficients are whatever the image holds and nobody reads the sums)
     double sA_ = 0.0, tA = 0.0, sBv = 0.0, tB = 0.0;
-    r32_states2<NX>(sA_, tA, vw, vdw, L, isx ? oA + ix : oH + iu, isx ? NX : NU);
+    r32_states2<NX>(sA_, tA, vw, vdw, L, isx ? oAm + ix : oH + iu, isx ? NX : NU);
     if constexpr (MK == 0) r32_in2<NU>(sBv, tB, vw, vdw, L, isx ? oB + ix : oR + iu, isx ? NX : NU);
-    else r32_in2<NU>(sBv, tA, vw, vdw, L, isx ? oB + ix : oR + iu, isx ? NX : NU);
+    else r32_in2<NU>(sBv, tA, vw, vdw, L, isx ? oBm + ix : oR + iu, isx ? NX : NU);
     double alcol = 0.0;
     if (al) {   // the constraint rows' cost shares at the candidate point and the gradient's column sums
       double Jal = 0.0;
