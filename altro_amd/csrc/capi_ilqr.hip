@@ -1123,11 +1123,12 @@ int altro_hip_add_linear_constraint(altro_hip_batch* h, int k_first, int k_last,
   // MFMA16 lays the rows out over slots of eight (kernels/al_types.h: AL_TILE_MAXC)
   const bool gen = h->plan == ALTRO_HIP_PLAN_GENERIC, tile = h->plan == ALTRO_HIP_PLAN_MFMA16;
   const int tile_slots = h->dtype == ALTRO_HIP_F64 ? AL_TILE_MAXC : AL_MAXC;   // (fp32 records: the two-slot kernels only)
-  const int pmax = cone == CONE_SOC ? AL_MAXSOC : (gen ? GEN_MAXP : tile ? tile_slots * AL_MAXP : AL_MAXP);
+  const int pmax = cone == CONE_SOC ? (gen ? GEN_MAXSOC : AL_MAXSOC) : (gen ? GEN_MAXP : tile ? tile_slots * AL_MAXP : AL_MAXP);
   const int cmax = gen ? GEN_MAXC : AL_MAXC, dmax = gen ? GEN_MAXDEF : tile ? AL_TILE_MAXSLOTDEF : AL_MAXDEF;
   if (p < 1 || p > pmax)
     return fail(ALTRO_HIP_ERR_UNSUPPORTED, "constraint dimension %d outside [1, %d]%s", p, pmax,
-                gen || cone == CONE_SOC ? "" : " on this plan (ALTRO_HIP_PLAN_GENERIC takes up to 64 rows per block and 8 blocks per knot point)");
+                gen ? "" : cone == CONE_SOC ? " on this plan (ALTRO_HIP_PLAN_GENERIC takes second-order cones of up to 32 rows)"
+                                            : " on this plan (ALTRO_HIP_PLAN_GENERIC takes up to 64 rows per block and 8 blocks per knot point)");
   if (k_first < 0 || k_last > h->N || k_first > k_last)
     return fail(ALTRO_HIP_ERR_BAD_ARGUMENT, "knot point range [%d, %d] outside [0, %d] (ErrorCodes::BadIndex)", k_first, k_last, h->N);
   auto slots_of = [&](int cn, int rows) { return cn == CONE_SOC ? 1 : (rows + AL_MAXP - 1) / AL_MAXP; };

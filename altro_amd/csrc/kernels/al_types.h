@@ -15,7 +15,7 @@ constexpr int AL_MAXP = 8;     // rows per zero / identity / orthant block (plan
 // registers across the ring of knot points, is instantiated for 2 and for AL_TILE_MAXC slots (AlTable::max_ncon picks).
 constexpr int AL_TILE_MAXC = 6;
 constexpr int AL_TILE_MAXSLOTDEF = 32;   // distinct slots per handle on plan MFMA16 (their padded Jacobians sit in the merit kernel's LDS: 32 x 1296 B)
-constexpr int AL_MAXSOC = 4;   // rows per second-order-cone block
+constexpr int AL_MAXSOC = 4;   // rows per second-order-cone block (plans LANE / MFMA16; plan GENERIC: up to GEN_MAXSOC)
 constexpr int AL_MAXDEF = 16;  // distinct blocks per handle
 // AlTable::Gpad: every block as 9 rows x 16 tile columns, rows padded to 18 (16-byte aligned, eight lanes reading one column hit
 // eight bank groups): rows >= p and row 8 are zero, so a lane reads `its` row (min(lane, 8)) or any column without a select
@@ -24,6 +24,7 @@ constexpr int AL_GP_LD = 18, AL_GP_DEF = 9 * AL_GP_LD;
 // Plan GENERIC has its own, larger table (kernels/ilqr_generic.hip loops over the blocks instead of unrolling two of them, one lane per
 // row): the reference takes any number of constraints of any dimension per knot point (knotpoint_data.hpp:16, knotpoint_data.cpp:155-161)
 constexpr int GEN_MAXC = 8;     // constraint blocks per knot point on plan GENERIC
+constexpr int GEN_MAXSOC = 32;  // rows per second-order-cone block on plan GENERIC (one lane per row; cones.cpp:13-123 takes any dimension)
 constexpr int GEN_MAXP = 64;    // rows per zero / identity / orthant block on plan GENERIC: one lane each, so up to n + m = 64
 constexpr int GEN_MAXDEF = 64;  // distinct blocks per handle on plan GENERIC
 

@@ -135,7 +135,7 @@ __device__ __forceinline__ double gen_wave_max(double v) {
 // any dimension, knotpoint_data.cpp:155-161).  Lane i owns row i of EVERY block of knot point k -- value c_i = G_i [x; u] - g_i,
 // estimated / projected dual, AL cost share, violation -- and publishes to LDS, for the lanes that own gradient / Hessian entries,
 //   jv[c * GEN_MAXP + i] = (J^T z_proj)_i     jd[c * GEN_MAXP + i] = J_ii  (the projection Jacobian of those cones is diagonal)
-// A second-order-cone block (p <= AL_MAXSOC) is evaluated whole by lane 0: Jm[c * 16 + i * 4 + r] = J_ir, Hm[c * 16 + i * 4 + r] its curvature.
+// A second-order-cone block of p <= AL_MAXSOC rows is evaluated whole by lane 0 (one of more rows, up to GEN_MAXSOC, lane per row: below): Jm[c * 16 + i * 4 + r] = J_ir, Hm[c * 16 + i * 4 + r] its curvature.
 // xs / us: the point, in LDS (us ignored at the terminal knot point).  Must be called by all lanes; no barrier inside.
 constexpr int GEN_AL_JV = GEN_MAXC * GEN_MAXP, GEN_AL_SOC = GEN_MAXC * AL_MAXSOC * AL_MAXSOC;
 template <typename T>
@@ -187,6 +187,44 @@ __device__ __forceinline__ void gen_al_rows(const AlTable<T>& t, int k, int b, i
         jv[c * GEN_MAXP + i] = mkv * zp;
         if (jd) jd[c * GEN_MAXP + i] = mkv;
         if (dual_update) *zp_ = (T)zp;
+      }
+    } else if (p > AL_MAXSOC) {
+      // A second-order cone of more than AL_MAXSOC rows (p <= GEN_MAXSOC; cones.cpp:13-123 in any dimension): lane i owns row i, the
+      // norms and inner products are wave sums (every lane of the wave is here: no branch around the shuffles).  Outside the cone, with
+      // a = |v|, u = v / a, t = s / a:  P(v, s) = (a + s)/2 (u, 1),  J = 1/2 [(1 + t) I - t u u^T, u; u^T, 1]  (symmetric),
+      // d2/dx2 [b^T P] = 1/(2a) [kappa (I - u u^T) - t (w u^T + u w^T), w; w^T, 0] with gamma = u^T b_v, w = b_v - gamma u,
+      // kappa = b_s - t gamma (al_lane.hip: soc_jacobian / soc_hessian, the same closed forms written out per entry).  For the expansion
+      // the structure is published instead of the p x p matrices: jd[c GEN_MAXP + i] = u_i, jd[c GEN_MAXP + GEN_MAXSOC + i] = w_i,
+      // Jm[c 16 + 0..3] = {region (0 below, 1 inside, 2 outside), t, kappa, 1/(2a)}.
+      const int nn = p - 1;
+      const bool row = i < p, vrow = i < nn;
+      const double val = row ? value(i) : 0.0;
+      T* zp_ = t.z + (int64_t)(kn.z_off[c] + zshift + (row ? i : 0)) * B + b;
+      const double ze = row ? (double)*zp_ - rho_est * val : 0.0;
+      const double az = sqrt(gen_wave_sum(vrow ? ze * ze : 0.0)), sz = __shfl(ze, nn, 64);
+      const double av = sqrt(gen_wave_sum(vrow ? val * val : 0.0)), sv = __shfl(val, nn, 64);
+      const int region = az <= -sz ? 0 : (az <= sz ? 1 : 2);
+      double zp = 0.0, pv = 0.0;
+      if (region == 1) zp = ze;
+      else if (region == 2) { const double cf = 0.5 * (1.0 + sz / az); zp = vrow ? cf * ze : (i == nn ? cf * az : 0.0); }
+      if (av <= -sv) pv = 0.0;
+      else if (av <= sv) pv = val;
+      else { const double cf = 0.5 * (1.0 + sv / av); pv = vrow ? cf * val : (i == nn ? cf * av : 0.0); }
+      if (row) { cost += zp * zp / (2.0 * rho_est); viol = fmax(viol, fabs(pv - val)); }
+      // (J^T z_proj)_i
+      const double inv_a = region == 2 ? 1.0 / az : 0.0, tt = sz * inv_a;
+      const double u = vrow ? ze * inv_a : 0.0;
+      const double gamma = gen_wave_sum(u * zp), zps = __shfl(zp, nn, 64);
+      double sj = 0.0;
+      if (region == 1) sj = zp;
+      else if (region == 2) sj = vrow ? 0.5 * (((1.0 + tt) * zp - tt * u * gamma) + u * zps) : (i == nn ? 0.5 * (gamma + zps) : 0.0);
+      if (row) {
+        jv[c * GEN_MAXP + i] = sj;
+        if (dual_update) *zp_ = (T)zp;
+      }
+      if (Jm) {
+        if (i < GEN_MAXSOC) { jd[c * GEN_MAXP + i] = u; jd[c * GEN_MAXP + GEN_MAXSOC + i] = vrow ? zp - gamma * u : 0.0; }
+        if (i == 0) { Jm[c * 16 + 0] = (double)region; Jm[c * 16 + 1] = tt; Jm[c * 16 + 2] = zps - tt * gamma; Jm[c * 16 + 3] = 0.5 * inv_a; }
       }
     } else if (i == 0) {
       double val[AL_MAXSOC], ze[AL_MAXSOC], zp[AL_MAXSOC], pv[AL_MAXSOC];
@@ -656,6 +694,34 @@ __global__ __launch_bounds__(64) void generic_expand_al_kernel(IlqrGenArgs<T> a)
           for (int i = 0; i < p; ++i) {
             const double jii = jd[cidx * GEN_MAXP + i];
             s += (jii * (double)G[i + r * p]) * (jii * (double)G[i + cc * p]);
+          }
+        } else if (p > AL_MAXSOC) {   // a cone of many rows: the structure gen_al_rows published (region, t, kappa, 1/(2a); u, w)
+          const int region = (int)Jc[0];
+          if (region == 1) {                        // inside: J = I, no curvature
+            for (int i = 0; i < p; ++i) s += (double)G[i + r * p] * (double)G[i + cc * p];
+          } else if (region == 2) {
+            const double tt = Jc[1], kappa = Jc[2], half = Jc[3];
+            const double* uu = jd + cidx * GEN_MAXP;
+            const double* ww = uu + GEN_MAXSOC;
+            const int nn = p - 1;
+            double du_r = 0.0, du_c = 0.0, dw_c = 0.0;
+            for (int i = 0; i < nn; ++i) {
+              const double gr = (double)G[i + r * p], gc = (double)G[i + cc * p];
+              du_r += uu[i] * gr; du_c += uu[i] * gc; dw_c += ww[i] * gc;
+            }
+            const double gs_r = (double)G[nn + r * p], gs_c = (double)G[nn + cc * p];
+            double t1 = 0.0, t2 = 0.0;
+            for (int i = 0; i < nn; ++i) {
+              const double gr = (double)G[i + r * p], gc = (double)G[i + cc * p];
+              const double jr = 0.5 * (((1.0 + tt) * gr - tt * uu[i] * du_r) + uu[i] * gs_r);     // (J G)_(i r)
+              const double jc = 0.5 * (((1.0 + tt) * gc - tt * uu[i] * du_c) + uu[i] * gs_c);
+              t1 += jr * jc;
+              const double hc = half * ((kappa * (gc - uu[i] * du_c) - tt * (ww[i] * du_c + uu[i] * dw_c)) + ww[i] * gs_c);   // (H G)_(i cc)
+              t2 += gr * hc;
+            }
+            t1 += (0.5 * (du_r + gs_r)) * (0.5 * (du_c + gs_c));
+            t2 += gs_r * (half * dw_c);
+            s += t1 + t2;
           }
         } else {
           for (int i = 0; i < p; ++i) {

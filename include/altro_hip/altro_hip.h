@@ -295,7 +295,9 @@ int altro_hip_get_expansion(altro_hip_batch* h, double* A, double* B, double* lx
  * 3 SECOND_ORDER_CONE (||c[0:p-1]|| <= c[p-1]).
  * Capacity (the reference appends constraints without limit, knotpoint_data.cpp:155-161; going past a limit here is an error that
  * names it, never a truncation):
- *   plan GENERIC       8 blocks per knot point, p <= 64 rows per block (SOC: p <= 4), 64 blocks per handle;
+ *   plan GENERIC       (and plan MFMA32, which shares its loop) 8 blocks per knot point, p <= 64 rows per block, a second-order cone
+ *                      p <= 32 (one lane per row; the projection's Jacobian and curvature applied from their closed forms), 64 blocks
+ *                      per handle;
  *   plan MFMA16        (the (12, 4) tile, fp64) 6 SLOTS of 8 rows per knot point -- a block in the zero / identity / orthant cones
  *                      takes ceil(p / 8) consecutive slots (p <= 48: those cones project row by row, so the host lays the rows out;
  *                      duals stay [p] per block), a second-order cone (p <= 4) one -- and 32 slots per handle: e.g. an input box

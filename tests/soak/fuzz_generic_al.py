@@ -3,7 +3,10 @@
 right-hand sides, terminal blocks, both line searches) against the oracle's restatement of SolverImpl, problem by problem: status,
 iterations, dual updates; trajectories where both converged.
 
-    python tests/soak/fuzz_generic_al.py [cases] [seed]
+    python tests/soak/fuzz_generic_al.py [cases] [seed] [--big-soc]
+
+--big-soc: second-order cones of 2 .. 12 rows (over all inputs and some states; GEN_MAXSOC = 32 on this plan) instead of 2 .. 4 -- another
+random stream than the default's, whose counts tests/soak/README.md quotes.
 """
 import os
 import sys
@@ -15,8 +18,10 @@ import altro_amd  # noqa: E402
 from oracle import oracle  # noqa: E402
 from tests import problems  # noqa: E402
 
-cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+BIG_SOC = "--big-soc" in sys.argv
+argv = [a for a in sys.argv if not a.startswith("--")]
+cases = int(argv[1]) if len(argv) > 1 else 30
+rng = np.random.default_rng(int(argv[2]) if len(argv) > 2 else 0)
 bad = 0
 for it in range(cases):
     n = int(rng.integers(13, 25)) if rng.random() < 0.7 else int(rng.integers(5, 13))
@@ -39,7 +44,7 @@ for it in range(cases):
     used = np.zeros(N + 1, dtype=int)
     for _ in range(int(rng.integers(1, 4))):
         cone = int(rng.choice([altro_amd.CONE_EQUALITY, altro_amd.CONE_INEQUALITY, altro_amd.CONE_INEQUALITY, altro_amd.CONE_SOC]))
-        pp = int(rng.integers(2, 5)) if cone == altro_amd.CONE_SOC else int(rng.integers(1, 9 if cone != altro_amd.CONE_EQUALITY else 3))
+        pp = int(rng.integers(2, 13 if BIG_SOC else 5)) if cone == altro_amd.CONE_SOC else int(rng.integers(1, 9 if cone != altro_amd.CONE_EQUALITY else 3))
         k0 = int(rng.integers(0, N + 1)); k1 = int(rng.integers(k0, N + 1))
         if rng.random() < 0.5:
             k0, k1 = 0, N - 1
@@ -53,7 +58,10 @@ for it in range(cases):
             g = np.full(pp, 0.4)
         elif cone == altro_amd.CONE_SOC:
             for r in range(pp - 1):
-                G[r, n + r % m] = 1.0
+                if r < m or not BIG_SOC:
+                    G[r, n + r % m] = 1.0
+                else:
+                    G[r, (r - m) % n] = 0.2                         # (rows past the inputs: states, scaled down)
             g = np.zeros(pp); g[-1] = -0.5
         else:
             G = 0.3 * rng.standard_normal((pp, w)); g = 0.5 + 0.2 * rng.random(pp)

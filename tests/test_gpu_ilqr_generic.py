@@ -195,6 +195,92 @@ def test_constrained_solves_generic(n, m, dense, soc, backtracking):
     bt.close()
 
 
+def _input_cone(N, n, m):
+    """||u|| <= 0.4 over ALL inputs: (u; 0.4) in the cone, p = m + 1 rows."""
+    Gu = np.zeros((m + 1, n + m)); Gu[np.arange(m), n + np.arange(m)] = 1.0
+    return (0, N - 1, altro_amd.CONE_SOC, Gu, np.concatenate([np.zeros(m), [-0.4]]))
+
+
+def _fresh(p, N, n, m, batch, dense, plan, blocks):
+    bt = altro_amd.Batch(N, n, m, batch, plan=plan)
+    bt.set_dynamics(p["A"], p["B"], p["f"])
+    if dense:
+        bt.set_quadratic_cost(p["Q"], p["R"], p["H"], p["q"], p["r"], p["c"])
+    else:
+        bt.set_tracking_cost(p["Qd"], p["Rd"], p["xref"], p["uref"])
+    bt.set_initial_state(p["x0"]); bt.set_input_guess(p["u0"])
+    for (k0, k1, cone, G, g) in blocks:
+        bt.add_linear_constraint(k0, k1, cone, G, g)
+    return bt
+
+
+@pytest.mark.parametrize("n,m,dense,which,plan", [(14, 5, False, "inputs", altro_amd.PLAN_GENERIC), (16, 6, True, "terminal", altro_amd.PLAN_GENERIC),
+                                                   (13, 4, False, "terminal", altro_amd.PLAN_AUTO), (20, 8, False, "dense", altro_amd.PLAN_GENERIC)])
+def test_second_order_cones_of_many_rows(n, m, dense, which, plan):
+    """VERDICT r5 item 4's second half: cones of 5 .. 12 rows on plans GENERIC / MFMA32 (one lane per row, the projection's Jacobian and
+    curvature applied from their closed forms: gen_al_rows, generic_expand_al_kernel; cones.cpp:13-123 takes any dimension) -- whole
+    AL-iLQR solves against the oracle, EVERY problem of the batch: status, iterations, trajectories; the input bound holds and binds;
+    the cone's duals lie inside the (self-dual) cone.  `terminal`: + a cone over the first eight states at k = N (p = 9); `dense`: + a
+    cone of twelve rows with a dense G and offsets at 1 <= k < N (two cones at a knot point) -- both bounds placed to bind on the
+    solution that has the input cone alone."""
+    N, batch = 14, 7
+    w = n + m
+    p, bt0 = make(batch, N, n, m, dense)
+    bt0.close()
+    blocks = [_input_cone(N, n, m)]
+    bt0 = _fresh(p, N, n, m, batch, dense, plan, blocks)
+    r0 = bt0.ilqr_solve(iterations_max=60, penalty_initial=1.0, penalty_scaling=10.0)
+    x0s, u0s = bt0.get_nominal()
+    bt0.close()
+    assert (r0["status"] == 0).sum() >= batch - 1
+    if which == "terminal":
+        Gx = np.zeros((9, w)); Gx[np.arange(8), np.arange(8)] = 1.0
+        blocks.append((N, N, altro_amd.CONE_SOC, Gx, np.concatenate([np.zeros(8), [-0.85 * float(np.linalg.norm(x0s[:, N, :8], axis=1).max())]])))
+    if which == "dense":
+        rng = np.random.default_rng(7 * n + m)
+        Gd = np.zeros((12, w)); Gd[:11] = rng.normal(size=(11, w)) * (rng.random((11, w)) < 0.4)
+        gd = np.concatenate([0.05 * rng.normal(size=11), [0.0]])
+        v = np.einsum("rw,bkw->bkr", Gd[:11], np.concatenate([x0s[:, 1:N], u0s[:, 1:N]], axis=2)) - gd[:11]
+        gd[11] = -0.85 * float(np.linalg.norm(v, axis=2).max())
+        blocks.append((1, N - 1, altro_amd.CONE_SOC, Gd, gd))
+    assert max(G.shape[0] for (_, _, _, G, _) in blocks) > 4
+    bt = _fresh(p, N, n, m, batch, dense, plan, blocks)
+    assert bt.plan == (altro_amd.PLAN_MFMA32 if plan == altro_amd.PLAN_AUTO else plan)
+    res = bt.ilqr_solve(iterations_max=60, penalty_initial=1.0, penalty_scaling=10.0)
+    x, u = bt.get_nominal()
+    nconv = nbind = 0
+    for b in range(batch):
+        s = make_oracle(p, b, N, n, m, dense)
+        for (k0, k1, cone, G, g) in blocks:
+            for k in range(k0, k1 + 1):
+                s.add_linear_constraint(k, cone, G, g)
+        s.L.oracle_ilqr_initialize(s.h)
+        for k in range(N):
+            s.L.oracle_ilqr_set_input(s.h, k, np.ascontiguousarray(p["u0"][b, k]))
+        s.set_penalty(1.0, 10.0)
+        s.L.oracle_ilqr_set_options(s.h, 60, 1e-4, 1e-4, 1e-8, 0)
+        status, iters, log = s.solve()
+        assert res["status"][b] == status and res["iterations"][b] == iters, (b, res["status"][b], status, res["iterations"][b], iters)
+        if status != 0:
+            continue
+        nconv += 1
+        np.testing.assert_allclose(x[b], s.get("x"), rtol=1e-7, atol=1e-7)
+        np.testing.assert_allclose(u[b], s.get("u"), rtol=1e-6, atol=1e-6)
+        nrm = np.linalg.norm(u[b], axis=1)
+        assert nrm.max() <= 0.4 + 5e-4
+        nbind += int(nrm.max() >= 0.4 - 5e-4)
+    assert nconv >= batch - 2
+    assert nbind >= 1                                  # the cone binds somewhere: its duals moved
+    pz = blocks[0][3].shape[0]
+    z = bt.get_duals(0, 0, pz)
+    assert z.shape == (batch, pz) and (np.linalg.norm(z[:, :-1], axis=1) <= z[:, -1] * (1 + 1e-12) + 1e-9).all()   # z in the cone
+    assert np.abs(z).max() > 0.0
+    if which != "inputs":                              # the second cone moved the solution: it is not the input cone's alone
+        assert np.abs(x - x0s).max() > 1e-3
+    assert (res["dual_updates"] > 0).all()
+    bt.close()
+
+
 def test_generic_plan_says_what_it_does_not_do():
     bt = altro_amd.Batch(10, 16, 5, 4, plan=altro_amd.PLAN_GENERIC)
     with pytest.raises(altro_amd.AltroHipError):
