@@ -18,6 +18,7 @@
 
 #include "../linesearch_sm.h"
 #include "cones.hpp"
+#include "altro_hip/altro_hip.h"
 #include "tvlqr/tvlqr.h"
 
 namespace altro {
@@ -50,6 +51,8 @@ struct Constraint {
   std::string label;
   Vec val, jac, hess, v, z, z_est, z_proj, proj_jvp, proj_jac, proj_hess, jac_tmp;
   double rho = 1.0;
+  bool linear = false;   // SetLinearConstraint: G (dim x (n + m), column-major) and g kept for the device loop
+  Vec G, g;
 };
 
 struct Knot {
@@ -59,7 +62,7 @@ struct Knot {
   float h = 0.0f;
   bool initialized = false;
   // dynamics
-  bool dyn_set = false, dyn_linear = false;
+  bool dyn_set = false, dyn_linear = false, dyn_device = false;   // (dyn_device: SetDeviceModel -- no host callbacks)
   ExplicitDynamicsFunction dyn;
   ExplicitDynamicsJacobian dyn_jac;
   Vec jac, affine;
@@ -359,6 +362,12 @@ class SolverImpl {
   double phi0 = 0, dphi0 = 0, phi = 0, dphi = 0, rho = 1.0, delta_V[2] = {0, 0};
   int ls_iters = 0;
   int backward_status = TVLQR_SUCCESS;
+  // SetDeviceModel: the compiled-in model and the resident batch of one that Solve() runs on
+  int device_model = -1, device_frame = 0;
+  double device_length = 2.7, device_lr = 1.5;
+  altro_hip_batch* dev = nullptr;
+  ~SolverImpl() { if (dev) altro_hip_batch_destroy(dev); }
+  ErrorCodes DeviceSolve();
   // pointer tables handed to the tvlqr_* kernel boundary (solver.cpp:63-106)
   std::vector<double*> pA, pB, pf, plxx, pluu, plux, plx, plu, pK, pd, pP, pp, pQxx, pQuu, pQux, pQx, pQu, pQxxt,
       pQuut, pQuxt, pQxt, pQut, px, pu, py;
@@ -604,6 +613,89 @@ ErrorCodes SolverImpl::Solve() {   // solver.cpp:414-511
   return ErrorCodes::NoError;
 }
 
+// SolverImpl::Solve (solver.cpp:414-511) on the device for a solver with SetDeviceModel: the problem as data into a resident
+// altro_hip batch of one (created at the first Solve, kept), altro_hip_ilqr_solve, the iterate back.  Everything the device loop
+// computes is the batched path's (tests/test_gpu_ilqr*.py hold it to the oracle); this function only moves the problem across.
+ErrorCodes SolverImpl::DeviceSolve() {
+  const auto t_start = std::chrono::steady_clock::now();
+  stats.status = SolveStatus::Unsolved;
+  const int n = data[0].n, m = data[0].m;
+  for (int k = 0; k <= N; ++k) {
+    const Knot& kp = data[k];
+    if (kp.n != n || (k < N && (kp.m != m || kp.h != data[0].h)))
+      return ALTRO_THROW("SetDeviceModel: the device loop takes one state / input dimension and one time step", ErrorCodes::DimensionMismatch);
+    if (kp.cost_kind == CostKind::Generic)
+      return ALTRO_THROW("SetDeviceModel: costs must be set as data (SetDiagonalCost / SetQuadraticCost / SetLQRCost)", ErrorCodes::CostNotQuadratic);
+    for (const auto& cn : kp.cons)
+      if (!cn.linear) return ALTRO_THROW("SetDeviceModel: constraints must be given as data (SetLinearConstraint)", ErrorCodes::InvalidPointer);
+  }
+  auto hip_fail = [&](const char* what) {
+    std::fprintf(stderr, "altro: %s failed on the device: %s (the device path has no CPU fallback)\n", what, altro_hip_last_error());
+    stats.solve_time = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start);
+    return ErrorCodes::BackwardPassFailed;
+  };
+  const bool fresh = dev == nullptr;
+  if (fresh) {
+    if (altro_hip_batch_create(&dev, N, n, m, 1, ALTRO_HIP_F64, ALTRO_HIP_PLAN_AUTO, 0, 0, nullptr)) { dev = nullptr; return hip_fail("altro_hip_batch_create"); }
+    if (altro_hip_set_model(dev, device_model, data[0].h, device_frame, device_length, device_lr)) return hip_fail("altro_hip_set_model");
+  }
+  // the cost, dense (a diagonal cost is its diagonal): [N+1][n*n], [N][m*m], [N][m*n], [N+1][n], [N][m], [N+1]
+  std::vector<double> Q((size_t)(N + 1) * n * n, 0.0), R((size_t)N * m * m, 0.0), H((size_t)N * m * n, 0.0), q((size_t)(N + 1) * n, 0.0),
+      r((size_t)N * m, 0.0), c(N + 1, 0.0);
+  for (int k = 0; k <= N; ++k) {
+    const Knot& kp = data[k];
+    const bool diag = kp.cost_kind == CostKind::Diagonal;
+    for (int j = 0; j < n; ++j)
+      for (int i = 0; i < n; ++i) Q[(size_t)k * n * n + i + (size_t)j * n] = diag ? (i == j ? kp.Q[i] : 0.0) : kp.Q[i + (size_t)j * n];
+    std::copy(kp.q.begin(), kp.q.begin() + n, q.begin() + (size_t)k * n);
+    c[k] = kp.c;
+    if (k == N) break;
+    for (int j = 0; j < m; ++j)
+      for (int i = 0; i < m; ++i) R[(size_t)k * m * m + i + (size_t)j * m] = diag ? (i == j ? kp.R[i] : 0.0) : kp.R[i + (size_t)j * m];
+    if (!diag) std::copy(kp.H.begin(), kp.H.begin() + (size_t)m * n, H.begin() + (size_t)k * m * n);
+    std::copy(kp.r.begin(), kp.r.begin() + m, r.begin() + (size_t)k * m);
+  }
+  if (altro_hip_set_quadratic_cost(dev, Q.data(), R.data(), H.data(), q.data(), r.data(), c.data(), 0, 0)) return hip_fail("altro_hip_set_quadratic_cost");
+  if (fresh) {   // constraint blocks are fixed at Initialize(): once (their duals then persist from Solve to Solve, like the host loop's)
+    for (int k = 0; k <= N; ++k)
+      for (const auto& cn : data[k].cons)
+        if (altro_hip_add_linear_constraint(dev, k, k, (int)cn.type, cn.dim, cn.G.data(), cn.g.data(), 0) < 0) return hip_fail("altro_hip_add_linear_constraint");
+  }   // (a later Solve keeps the duals and restarts the penalty, as the host loop does: solver.cpp:429)
+  std::vector<double> u0((size_t)N * m);
+  for (int k = 0; k < N; ++k) std::copy(data[k].u_.begin(), data[k].u_.begin() + m, u0.begin() + (size_t)k * m);
+  if (altro_hip_set_initial_state(dev, data[0].x_.data(), 0)) return hip_fail("altro_hip_set_initial_state");
+  if (altro_hip_set_input_guess(dev, u0.data(), 0, 0)) return hip_fail("altro_hip_set_input_guess");
+  altro_hip_solve_options o;
+  altro_hip_default_solve_options(&o);
+  o.iterations_max = opts.iterations_max;
+  o.tol_stationarity = opts.tol_stationarity;
+  o.tol_primal_feasibility = opts.tol_primal_feasibility;
+  o.tol_meritfun_gradient = opts.tol_meritfun_gradient;
+  o.use_backtracking_linesearch = opts.use_backtracking_linesearch != 0.0 ? 1 : 0;
+  o.penalty_initial = opts.penalty_initial; o.penalty_scaling = opts.penalty_scaling; o.penalty_max = opts.penalty_max;
+  altro_hip_solve_result res;
+  if (altro_hip_ilqr_solve(dev, &o, &res)) return hip_fail("altro_hip_ilqr_solve");
+  std::vector<double> xs((size_t)(N + 1) * n), us((size_t)N * m);
+  if (altro_hip_get_nominal(dev, xs.data(), us.data())) return hip_fail("altro_hip_get_nominal");
+  for (int k = 0; k <= N; ++k) {
+    Knot& kp = data[k];
+    std::copy(xs.begin() + (size_t)k * n, xs.begin() + (size_t)(k + 1) * n, kp.x.begin());
+    kp.x_ = kp.x;
+    if (k == N) break;
+    std::copy(us.begin() + (size_t)k * m, us.begin() + (size_t)(k + 1) * m, kp.u.begin());
+    std::copy(kp.u.begin(), kp.u.begin() + m, kp.u_.begin());
+  }
+  stats.status = res.status == 0 ? SolveStatus::Success : (res.status == 2 ? SolveStatus::MaxIterations : SolveStatus::Unsolved);
+  stats.iterations = res.iterations;
+  stats.stationarity = res.stationarity;
+  stats.primal_feasibility = res.primal_feasibility;
+  stats.objective_value = res.final_phi;
+  phi = res.final_phi;
+  rho = res.penalty;
+  stats.solve_time = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start);
+  return ErrorCodes::NoError;
+}
+
 // ---- ALTROSolver: validation + forwarding (altro_solver.cpp) ------------------------------------------
 ALTROSolver::ALTROSolver(int horizon_length) : solver_(std::make_unique<SolverImpl>(horizon_length)) {}
 ALTROSolver::ALTROSolver(ALTROSolver&& other) = default;
@@ -756,6 +848,61 @@ ErrorCodes ALTROSolver::SetConstraint(ConstraintFunction cfun, ConstraintJacobia
   }
   return ErrorCodes::NoError;
 }
+ErrorCodes ALTROSolver::SetDeviceModel(int altro_hip_model, int bicycle_frame, double bicycle_length, double bicycle_lr) {
+  if (IsInitialized()) return ALTRO_THROW("Cannot set the dynamics: Solver Already Initialized.", ErrorCodes::SolverAlreadyInitialized);
+  const int N = GetHorizonLength();
+  ErrorCodes err = AssertDimensionsAreSet(0, N, "Cannot set the device model");
+  if (err != ErrorCodes::NoError) return err;
+  if (altro_hip_model < 0) return ALTRO_THROW("SetDeviceModel: unknown model", ErrorCodes::InvalidPointer);
+  for (int k = 0; k < N; ++k) {
+    Knot& kp = solver_->data[k];
+    kp.dyn = nullptr; kp.dyn_jac = nullptr;
+    kp.dyn_set = true; kp.dyn_linear = false; kp.dyn_device = true;
+  }
+  solver_->device_model = altro_hip_model; solver_->device_frame = bicycle_frame;
+  solver_->device_length = bicycle_length; solver_->device_lr = bicycle_lr;
+  return ErrorCodes::NoError;
+}
+ErrorCodes ALTROSolver::SetLinearConstraint(const a_float* G, const a_float* g, int dim, ConstraintType type, std::string label, int k_start,
+                                            int k_stop, std::vector<ConstraintIndex>* con_inds) {
+  if (!G || !g) return ALTRO_THROW("SetLinearConstraint: G and g are required", ErrorCodes::InvalidPointer);
+  ErrorCodes err = CheckKnotPointIndices(k_start, k_stop, LastIndexMode::Inclusive);
+  if (err != ErrorCodes::NoError) return err;
+  err = AssertDimensionsAreSet(k_start, k_stop, "Cannot set constraint");
+  if (err != ErrorCodes::NoError) return err;
+  if (dim <= 0) return ALTRO_THROW("Got a non-positive constraint dimension", ErrorCodes::InvalidConstraintDim);
+  const int N = GetHorizonLength();
+  for (int k = k_start; k < k_stop; ++k) {
+    const int n = GetStateDim(k), m = k == N ? 0 : GetInputDim(k), w = n + m;
+    if (n != GetStateDim(k_start) || m != (k_start == N ? 0 : GetInputDim(k_start)))
+      return ALTRO_THROW("SetLinearConstraint: the knot points of one call must share their dimensions", ErrorCodes::DimensionMismatch);
+    Vec Gk(G, G + (size_t)dim * w), gk(g, g + dim);
+    const int wh = n + std::max(m, 1);      // the host record's Jacobian width (a terminal knot point keeps one input column)
+    auto fun = [Gk, gk, dim, n, m](a_float* c, const a_float* x, const a_float* u) {
+      for (int i = 0; i < dim; ++i) {
+        double s = 0.0;
+        for (int e = 0; e < n; ++e) s += Gk[i + (size_t)e * dim] * x[e];
+        for (int e = 0; e < m; ++e) s += Gk[i + (size_t)(n + e) * dim] * u[e];
+        c[i] = s - gk[i];
+      }
+    };
+    auto jac = [Gk, dim, w, wh](a_float* J, const a_float* x, const a_float* u) {
+      (void)x; (void)u;
+      std::fill(J, J + (size_t)dim * wh, 0.0);
+      std::copy(Gk.begin(), Gk.begin() + (size_t)dim * w, J);
+    };
+    std::vector<ConstraintIndex> one;
+    err = SetConstraint(fun, jac, dim, type, (k_stop - k_start != 1) ? label + "_" + std::to_string(k) : label, k, k + 1, &one);
+    if (err != ErrorCodes::NoError) return err;
+    Constraint& cn = solver_->data[k].cons.back();
+    cn.linear = true; cn.G = Gk; cn.g = gk;
+    if (m == 0) {   // the device takes G as dim x (n + m) of the HANDLE's dimensions: zero input columns at the terminal knot point
+      cn.G.resize((size_t)dim * (n + GetInputDim(0)), 0.0);
+    }
+    if (con_inds) con_inds->insert(con_inds->end(), one.begin(), one.end());
+  }
+  return ErrorCodes::NoError;
+}
 bool ALTROSolver::IsInitialized() const { return solver_->initialized; }
 ErrorCodes ALTROSolver::Initialize() {
   AssertDimensionsAreSet(0, GetHorizonLength(), "Cannot initialize solver");
@@ -777,6 +924,7 @@ ErrorCodes ALTROSolver::SetInput(const a_float* u, int m, int k_start, int k_sto
 }
 ErrorCodes ALTROSolver::OpenLoopRollout() {
   if (!IsInitialized()) return ErrorCodes::SolverNotInitialized;
+  if (solver_->device_model >= 0) return ALTRO_THROW("OpenLoopRollout: a device model has no host callbacks (the rollout happens inside Solve)", ErrorCodes::DynamicsFunNotSet);
   solver_->OpenLoopRollout();
   return ErrorCodes::NoError;
 }
@@ -806,7 +954,8 @@ void ALTROSolver::SetOptions(const AltroOptions& opts) { solver_->opts = opts; }
 AltroOptions& ALTROSolver::GetOptions() { return solver_->opts; }
 const AltroOptions& ALTROSolver::GetOptions() const { return solver_->opts; }
 SolveStatus ALTROSolver::Solve() {
-  solver_->Solve();
+  if (solver_->device_model >= 0) solver_->DeviceSolve();
+  else solver_->Solve();
   return solver_->stats.status;
 }
 SolveStatus ALTROSolver::GetStatus() const { return solver_->stats.status; }

@@ -61,6 +61,20 @@ class ALTROSolver {
   ErrorCodes SetConstraint(ConstraintFunction constraint_function, ConstraintJacobian constraint_jacobian, int dim,
                            ConstraintType constraint_type, std::string label, int k_start, int k_stop = 0,
                            std::vector<ConstraintIndex>* con_inds = nullptr);
+  // ---- extensions (not in the reference): the whole Solve on the device -------------------------------
+  // A compiled-in device model (ALTRO_HIP_MODEL_* of include/altro_hip/altro_hip.h: double integrator, pendulum, bicycle, the
+  // quadrotors) in the place of SetExplicitDynamics' host callbacks, for every knot point, discretised with the explicit midpoint
+  // rule at SetTimeStep's step.  Solve() of such a solver runs SolverImpl::Solve (solver.cpp:414-511) on the device --
+  // altro_hip_ilqr_solve on a resident batch of one, one host round trip per Solve instead of two per sweep -- and leaves states,
+  // inputs, status, iterations and the final objective where the getters look.  It needs what a device loop can hold: uniform
+  // dimensions and time step, costs set as data (SetDiagonalCost / SetQuadraticCost / SetLQRCost), constraints given as data
+  // (SetLinearConstraint below; a callback pair cannot run on the device).  OpenLoopRollout of such a solver returns
+  // DynamicsFunNotSet: there is no host model to evaluate.  `bicycle_*`: MODEL_BICYCLE's reference frame / length / lr.
+  ErrorCodes SetDeviceModel(int altro_hip_model, int bicycle_frame = 0, double bicycle_length = 2.7, double bicycle_lr = 1.5);
+  // c(x, u) = G [x; u] - g in `constraint_type`'s cone at k_start <= k < k_stop: SetConstraint with the callback pair made here
+  // (G is (dim, n + m) column-major, (dim, n) for the terminal knot point alone; both are copied), and the data kept for the device.
+  ErrorCodes SetLinearConstraint(const a_float* G, const a_float* g, int dim, ConstraintType constraint_type, std::string label,
+                                 int k_start, int k_stop = 0, std::vector<ConstraintIndex>* con_inds = nullptr);
   bool IsInitialized() const;
 
   // ---- initialization and initial guess ------------------------------------------------------------

@@ -301,6 +301,64 @@ static void test_pendulum(bool constrained) {
   }
 }
 
+// ALTROSolver::SetDeviceModel (an extension: VERDICT r5 item 7): the pendulum problems above with the compiled-in device model in the
+// place of the callback pair -- Solve() runs SolverImpl::Solve on the device (altro_hip_ilqr_solve, batch of one) -- against the
+// callback solver, whose loop runs on the host with the sweeps on the device: same status, the same iteration count, the same
+// trajectory (both evaluate test_utils.cpp:43-132's equations; the sums differ in order only), the goal constraint given as data
+// (SetLinearConstraint) in both.  A second Solve from the solution is a warm start in both.
+#include "altro_hip/altro_hip.h"
+static void test_pendulum_device_model(bool constrained) {
+  std::printf("[pendulum] device model, %s\n", constrained ? "goal constrained" : "unconstrained");
+  const int n = 2, m = 1, N = constrained ? 20 : 50;
+  const float tf = constrained ? 2.0f : 3.0f;
+  const float h = (float)(tf / static_cast<double>(N));
+  std::vector<double> Qd(n, 1e-2), Rd(m, 1e-3), Qdf(n, 1.0), x0(n, 0.0), xf = {M_PI, 0.0}, uf(m, 0.0);
+  std::vector<double> traj[2];
+  int iters[2] = {0, 0}, iters2[2] = {0, 0};
+  SolveStatus st[2];
+  for (int dev = 0; dev < 2; ++dev) {
+    ALTROSolver s(N);
+    EXPECT(s.SetDimension(n, m, 0, LastIndex) == ErrorCodes::NoError);
+    EXPECT(s.SetTimeStep(h, 0, LastIndex) == ErrorCodes::NoError);
+    if (dev) EXPECT(s.SetDeviceModel(ALTRO_HIP_MODEL_PENDULUM) == ErrorCodes::NoError);
+    else EXPECT(s.SetExplicitDynamics(pend_dyn, pend_jac, 0, LastIndex) == ErrorCodes::NoError);
+    EXPECT(s.SetLQRCost(n, m, Qd.data(), Rd.data(), xf.data(), uf.data(), 0, N) == ErrorCodes::NoError);
+    EXPECT(s.SetLQRCost(n, m, Qdf.data(), Rd.data(), xf.data(), uf.data(), N) == ErrorCodes::NoError);
+    EXPECT(s.SetInitialState(x0.data(), n) == ErrorCodes::NoError);
+    if (constrained) {
+      const double G[4] = {1, 0, 0, 1};   // x_N - xf = 0
+      EXPECT(s.SetLinearConstraint(G, xf.data(), n, ConstraintType::EQUALITY, "Goal constraint", N, N + 1) == ErrorCodes::NoError);
+    }
+    EXPECT(s.Initialize() == ErrorCodes::NoError);
+    std::vector<double> u0(m, 0.1);
+    s.SetInput(u0.data(), m, 0, LastIndex);
+    AltroOptions o; o.iterations_max = constrained ? 100 : 20;
+    s.SetOptions(o);
+    if (dev) EXPECT(s.OpenLoopRollout() == ErrorCodes::DynamicsFunNotSet);
+    st[dev] = s.Solve();
+    iters[dev] = s.GetIterations();
+    traj[dev].resize((size_t)(N + 1) * n + (size_t)N * m);
+    for (int k = 0; k <= N; ++k) s.GetState(traj[dev].data() + (size_t)k * n, k);
+    for (int k = 0; k < N; ++k) s.GetInput(traj[dev].data() + (size_t)(N + 1) * n + (size_t)k * m, k);
+    std::printf("   %s: status %d, iterations %d, objective %.10g, solve %.3f ms\n", dev ? "device model  " : "host callbacks", (int)st[dev], iters[dev],
+                (double)s.GetFinalObjective(), (double)s.GetSolveTimeMs());
+    s.Solve();                               // from the solution: converged at once
+    iters2[dev] = s.GetIterations();
+    std::printf("      warm re-solve: %d iteration(s), %.3f ms\n", iters2[dev], (double)s.GetSolveTimeMs());
+  }
+  EXPECT(st[0] == SolveStatus::Success && st[1] == SolveStatus::Success);
+  EXPECT(iters[0] == iters[1]);
+  EXPECT(iters2[0] == iters2[1] && iters2[1] <= 2);
+  const double dd = dist(traj[0], traj[1]);
+  std::printf("   |trajectory(device model) - trajectory(host callbacks)| = %.3e, warm re-solve: %d iteration(s)\n", dd, iters2[1]);
+  EXPECT(dd < 1e-7);
+  if (!constrained) {
+    const std::vector<double> xN_expected = {3.12099917161669, 0.0011966258762942175};   // pendulum_test.cpp:45-115
+    std::vector<double> xN(traj[1].begin() + (size_t)N * n, traj[1].begin() + (size_t)(N + 1) * n);
+    EXPECT(dist(xN, xN_expected) < 1e-5);
+  }
+}
+
 // ALTROSolver::SetQuadraticCost (altro_solver.cpp:118-136) -- a DENSE cost with a cross term,
 // 1/2 x'Qx + 1/2 u'Ru + u'Hx + q'x + r'u + c, on the double integrator (with and without the goal constraint).  The blocks are
 // small closed forms so that tests/test_gpu_cpp_api.py can hand the very same numbers to the oracle
@@ -359,6 +417,8 @@ int main() {
   test_di_soc();
   test_pendulum(false);
   test_pendulum(true);
+  test_pendulum_device_model(false);
+  test_pendulum_device_model(true);
   if (failures) { std::printf("%d EXPECTATION(S) FAILED\n", failures); return 1; }
   std::printf("OK\n");
   return 0;
