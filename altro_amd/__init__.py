@@ -33,7 +33,7 @@ C_ABI_SYMBOLS = [
     "altro_hip_comm_destroy", "altro_hip_comm_rank", "altro_hip_comm_world", "altro_hip_comm_device", "altro_hip_stats_allreduce", "altro_hip_stats_allreduce_multi",
     "altro_hip_profile_enable", "altro_hip_profile_reset",
     "altro_hip_profile_get", "altro_hip_profile_get_range", "altro_hip_profile_dropped", "altro_hip_algorithmic_bytes",
-    "altro_hip_set_model", "altro_hip_set_model_source", "altro_hip_set_tracking_cost", "altro_hip_set_quadratic_cost",
+    "altro_hip_set_model", "altro_hip_set_model_source", "altro_hip_model_row_layout", "altro_hip_set_tracking_cost", "altro_hip_set_quadratic_cost",
     "altro_hip_set_input_guess", "altro_hip_set_state_guess",
     "altro_hip_open_loop_rollout", "altro_hip_accept", "altro_hip_expand", "altro_hip_merit",
     "altro_hip_stationarity", "altro_hip_get_nominal", "altro_hip_get_expansion",
@@ -207,6 +207,7 @@ def lib():
         L.altro_hip_algorithmic_bytes.restype = d
         L.altro_hip_set_model.argtypes = [vp, i, C.c_float, i, d, d]
         L.altro_hip_set_model_source.argtypes = [vp, C.c_char_p, C.c_float]
+        L.altro_hip_model_row_layout.argtypes = [vp]
         L.altro_hip_set_tracking_cost.argtypes = [vp, vp, vp, vp, vp, i, i]
         L.altro_hip_set_quadratic_cost.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i]
         L.altro_hip_set_input_guess.argtypes = [vp, vp, i, i]
@@ -440,6 +441,11 @@ class Batch:
     def expand(self):
         self._sync_forms()
         _check(self.L.altro_hip_expand(self.h))
+
+    def model_row_layout(self):
+        """Whether the handle's device model runs the row-layout model kernels (plans GENERIC / MFMA32; altro_hip_model_row_layout)."""
+        self._sync_forms()
+        return bool(self.L.altro_hip_model_row_layout(self.h))
 
     def merit(self, alpha, derivative=True):
         self._sync_forms()

@@ -349,7 +349,8 @@ bool row32_eligible(const altro_hip_batch* h) {
 // the same with a compiled-in device model (row32_model.hip has the kernels: ilqr_generic_model_supported's models)
 bool row32_model_eligible(const altro_hip_batch* h) {
   return h->plan == ALTRO_HIP_PLAN_GENERIC && h->dtype == ALTRO_HIP_F64 && !h->ragged && h->model_set && tile32_supported(h->n, h->m) &&
-         ilqr_generic_model_supported(h->model.kind, h->n, h->m) && !form(h, ALTRO_HIP_FORM_GENERIC_MERIT_LDS) &&
+         (ilqr_generic_model_supported(h->model.kind, h->n, h->m) || (h->model.kind == MODEL_USER && h->rtc_row32_ok)) &&
+         !form(h, ALTRO_HIP_FORM_GENERIC_MERIT_LDS) &&
          (h->al_defs.empty() || h->al_row32_ok);
 }
 // plan GENERIC: any (n_k, m_k) up to 64, dynamics as data, quadratic cost, linear constraint blocks (kernels/ilqr_generic.hip)
@@ -400,7 +401,7 @@ int gen_run(altro_hip_batch* h, int which, bool use_alpha, bool use_active, int 
   }
   if constexpr (sizeof(T) == 8) {
     if (h->model_set && h->model.kind == MODEL_USER) {   // the caller's own model, compiled at run time (capi_rtc.hip)
-      if (which == IK_ROLLOUT || which == IK_MERIT) return rtc_gen_launch(h, which, a);
+      if (which == IK_ROLLOUT || which == IK_MERIT || (which == IK_MERIT2 && a.row32m)) return rtc_gen_launch(h, which, a);
       if (which == IK_EXPAND) {   // the cost's expansion from the library's kernel (the model kind it sees is not one it steps), then A_k, B_k
         IlqrGenArgs<T> ac = a;
         ac.mp.kind = MODEL_LINEAR;

@@ -95,6 +95,7 @@ struct altro_hip_batch {
   // altro_hip_ilqr_solve_async / _poll / _wait: pinned records the fused kernel publishes into while it runs
   void* poll_host = nullptr; int* poll_count_host = nullptr;
   bool async_request = false, async_pending = false;
+  bool rtc_row32_ok = false;          // plans GENERIC / MFMA32: the source's row-layout kernels compiled without scratch memory (capi_rtc.hip)
   bool rtc_has_constraints = false;   // ... whose source also defines altro_user_constraint / _jacobian
   void* rtc = nullptr;            // run-time compiled model (capi_rtc.hip: RtcModule, shared through a per-process cache)
   std::string rtc_source;         // ... its source, and the cost kind (IlqrArgs::cost_kind) its cost-reading kernels were instantiated for

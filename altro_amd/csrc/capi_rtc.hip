@@ -51,6 +51,7 @@ ALTRO_EMBED(altro_rtc_src_tile_model, "kernels/ilqr_tile_model.hip")
 // ... and of plan GENERIC's loop kernels (a caller's model on plans GENERIC / MFMA32)
 ALTRO_EMBED(altro_rtc_src_generic_arrays, "kernels/generic_arrays.h")
 ALTRO_EMBED(altro_rtc_src_ilqr_generic, "kernels/ilqr_generic.hip")
+ALTRO_EMBED(altro_rtc_src_ilqr_row32, "kernels/ilqr_row32.hip")
 
 namespace {
 
@@ -330,11 +331,18 @@ static int rtc_tile_module_for(altro_hip_batch* h, int al, int dense, RtcTileMod
 
 // ---- the same for plans GENERIC / MFMA32: the caller's model inside that plan's loop kernels (kernels/ilqr_generic.hip) ----------------
 // Three kernels per (source, n, m): the open-loop rollout, the dynamics expansion and the merit evaluation.
-enum RtcGenKernel { RTG_ROLLOUT = 0, RTG_EXPAND_DYN, RTG_MERIT, RTG_NUM };
+// On plan MFMA32's shapes three more: the merit kernel, its two-trial pass and the dynamics expansion in the row layout
+// (kernels/ilqr_row32.hip: every lane evaluates the caller's model; r32_model_step).  They are USED when they compiled without scratch
+// memory (row_ok): a Jacobian the compiler cannot keep in registers -- a dense one of many states, a loop it cannot unroll -- makes
+// that formulation spill, and a spilling wave of that kernel waits for its reloads behind the prefetch (3.4 x slower
+// than without); the wave-per-problem kernels above are the form for such models.
+enum RtcGenKernel { RTG_ROLLOUT = 0, RTG_EXPAND_DYN, RTG_MERIT, RTG_NUM, RTG_ROW_MERIT = RTG_NUM, RTG_ROW_MERIT2, RTG_ROW_EXPAND_DYN, RTG_NUM_ROW };
 struct RtcGenModule {
   hipModule_t module = nullptr;
-  hipFunction_t fn[RTG_NUM] = {};
+  hipFunction_t fn[RTG_NUM_ROW] = {};
+  bool row_ok = false;
 };
+constexpr int RTG_ROW_SCRATCH_MAX = 256;   // bytes of private segment per lane a row-layout kernel may use and still be chosen
 static int rtc_gen_module_for(altro_hip_batch* h, RtcGenModule** out) {
   *out = nullptr;
   static std::mutex mu;
@@ -348,14 +356,21 @@ static int rtc_gen_module_for(altro_hip_batch* h, RtcGenModule** out) {
   int rc = hiprtc_api(&R);
   if (rc) return rc;
   const std::string nm = std::to_string(h->n) + ", " + std::to_string(h->m);
-  std::string exprs[RTG_NUM];
+  const bool row_shape = tile32_supported(h->n, h->m);
+  const int nk = row_shape ? (int)RTG_NUM_ROW : (int)RTG_NUM;
+  std::string exprs[RTG_NUM_ROW];
+  exprs[RTG_ROW_MERIT] = "altro_hip::row32_merit_kernel<double, " + nm + ", 1, false, altro_hip::MODEL_USER>";
+  exprs[RTG_ROW_MERIT2] = "altro_hip::row32_merit_kernel<double, " + nm + ", 1, true, altro_hip::MODEL_USER>";
+  exprs[RTG_ROW_EXPAND_DYN] = "altro_hip::row32_expand_dyn_kernel<double, " + nm + ", altro_hip::MODEL_USER>";
   exprs[RTG_ROLLOUT] = "altro_hip::generic_model_rollout_kernel<double, altro_hip::MODEL_USER, " + nm + ">";
   exprs[RTG_EXPAND_DYN] = "altro_hip::generic_model_expand_dyn_kernel<double, altro_hip::MODEL_USER, " + nm + ">";
   exprs[RTG_MERIT] = "altro_hip::generic_merit_kernel<double, false, altro_hip::MODEL_USER, " + nm + ">";
   std::string src = "#define ALTRO_HIP_USER_MODEL 1\n";
   src += "#include \"rtc_compat.h\"\n#include \"fp_contract.h\"\nALTRO_FP_REGION_ON\n";
-  src += "#line 1 \"user_model\"\n" + user_src + "\nALTRO_FP_REGION_END\n#include \"kernels/ilqr_generic.hip\"\nnamespace altro_hip {\n";
-  for (int w = 0; w < RTG_NUM; ++w) {
+  src += "#line 1 \"user_model\"\n" + user_src + "\nALTRO_FP_REGION_END\n#include \"kernels/ilqr_generic.hip\"\n";
+  if (row_shape) src += "#include \"kernels/ilqr_row32.hip\"\n";
+  src += "namespace altro_hip {\n";
+  for (int w = 0; w < nk; ++w) {
     std::string e = exprs[w];
     for (size_t p; (p = e.find("altro_hip::")) != std::string::npos;) e.erase(p, std::strlen("altro_hip::"));
     src += "template __global__ void " + e + "(IlqrGenArgs<double>);\n";
@@ -364,19 +379,22 @@ static int rtc_gen_module_for(altro_hip_batch* h, RtcGenModule** out) {
   const char* hdr_src[] = {altro_rtc_src_rtc_compat, altro_rtc_src_fp_contract, altro_rtc_src_models, altro_rtc_src_linesearch,
                            altro_rtc_src_ilqr_types, altro_rtc_src_al_types, altro_rtc_src_al_lane, altro_rtc_src_tvlqr_lane,
                            altro_rtc_src_lane_body, altro_rtc_src_quad_body, altro_rtc_src_quad2_body, altro_rtc_src_generic_arrays,
-                           altro_rtc_src_ilqr_generic};
+                           altro_rtc_src_ilqr_generic, altro_rtc_src_ilqr_row32};
   const char* hdr_name[] = {"rtc_compat.h", "fp_contract.h", "models.h", "linesearch_sm.h", "kernels/ilqr_types.h", "kernels/al_types.h",
                             "kernels/al_lane.hip", "kernels/tvlqr_lane.hip", "kernels/tvlqr_lane_body.inc", "kernels/tvlqr_quad_body.inc",
-                            "kernels/tvlqr_quad2_body.inc", "kernels/generic_arrays.h", "kernels/ilqr_generic.hip"};
+                            "kernels/tvlqr_quad2_body.inc", "kernels/generic_arrays.h", "kernels/ilqr_generic.hip", "kernels/ilqr_row32.hip"};
   hiprtcProgram prog = nullptr;
-  hiprtcResult rr = R->CreateProgram(&prog, src.c_str(), "altro_user_generic_model.hip", 13, hdr_src, hdr_name);
+  hiprtcResult rr = R->CreateProgram(&prog, src.c_str(), "altro_user_generic_model.hip", 14, hdr_src, hdr_name);
   if (rr != HIPRTC_SUCCESS) return fail(ALTRO_HIP_ERR_HIP, "hiprtcCreateProgram: %s", R->GetErrorString(rr));
-  for (int w = 0; w < RTG_NUM; ++w) R->AddNameExpression(prog, exprs[w].c_str());
+  for (int w = 0; w < nk; ++w) R->AddNameExpression(prog, exprs[w].c_str());
   hipDeviceProp_t prop;
   std::string arch = "--offload-arch=gfx950";
   if (hipGetDeviceProperties(&prop, h->device) == hipSuccess) arch = std::string("--offload-arch=") + prop.gcnArchName;
-  const char* opts[] = {arch.c_str(), "-O3", "-std=c++17"};
-  rr = R->CompileProgram(prog, 3, opts);
+  // (-unroll-threshold: the row-layout kernels find a Jacobian's structural zeros with __builtin_constant_p, which the compiler
+  //  resolves right after its EARLY full-unroll pass -- a caller's `for (e < n (n + m)) J[e] = 0` must be unrolled by then, and at
+  //  the default threshold it is only unrolled later: every entry then counts as a nonzero and the kernel spills 585 registers)
+  const char* opts[] = {arch.c_str(), "-O3", "-std=c++17", "-mllvm", "-unroll-threshold=5000"};
+  rr = R->CompileProgram(prog, row_shape ? 5 : 3, opts);
   if (rr != HIPRTC_SUCCESS) {
     size_t ls = 0;
     R->GetProgramLogSize(prog, &ls);
@@ -396,7 +414,7 @@ static int rtc_gen_module_for(altro_hip_batch* h, RtcGenModule** out) {
     delete m;
     return fail(ALTRO_HIP_ERR_HIP, "hipModuleLoadData of the compiled model failed: %s", hipGetErrorString(le));
   }
-  for (int w = 0; w < RTG_NUM; ++w) {
+  for (int w = 0; w < nk; ++w) {
     const char* lowered = nullptr;
     if (R->GetLoweredName(prog, exprs[w].c_str(), &lowered) != HIPRTC_SUCCESS || !lowered ||
         hipModuleGetFunction(&m->fn[w], m->module, lowered) != hipSuccess) {
@@ -408,6 +426,14 @@ static int rtc_gen_module_for(altro_hip_batch* h, RtcGenModule** out) {
     }
   }
   R->DestroyProgram(&prog);
+  if (row_shape) {   // the row-layout kernels are chosen when none of them spills (see RtcGenKernel)
+    m->row_ok = true;
+    for (int w = RTG_ROW_MERIT; w < RTG_NUM_ROW; ++w) {
+      int scratch = 0;
+      if (hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, m->fn[w]) != hipSuccess) { (void)hipGetLastError(); scratch = 1 << 30; }
+      if (scratch > RTG_ROW_SCRATCH_MAX) m->row_ok = false;
+    }
+  }
   cache[key] = m;
   *out = m;
   return 0;
@@ -426,10 +452,18 @@ int rtc_gen_launch(altro_hip_batch* h, int which, const IlqrGenArgs<double>& a) 
     if (e != hipSuccess) return fail(ALTRO_HIP_ERR_HIP, "launch of the run-time compiled kernel %d of plan GENERIC's loop failed: %s", w, hipGetErrorString(e));
     return 0;
   };
+  const bool row = a.row32m && mod->row_ok;   // (the host set row32m knowing row_ok: row32_model_eligible)
   switch (which) {
     case IK_ROLLOUT: return go(RTG_ROLLOUT, (unsigned)((a.batch + 63) / 64), 0);
-    case IK_EXPAND: return go(RTG_EXPAND_DYN, (unsigned)(((int64_t)a.batch * a.N + 63) / 64), 0);
-    case IK_MERIT: return go(RTG_MERIT, (unsigned)a.batch, a.al.enabled ? (unsigned)(GEN_AL_JV * sizeof(double)) : 0u);
+    case IK_EXPAND:
+      if (row) return go(RTG_ROW_EXPAND_DYN, (unsigned)(((int64_t)a.batch * a.N + 1) / 2), 0);
+      return go(RTG_EXPAND_DYN, (unsigned)(((int64_t)a.batch * a.N + 63) / 64), 0);
+    case IK_MERIT2:
+      if (row) return go(RTG_ROW_MERIT2, (unsigned)a.batch, 0);
+      return fail(ALTRO_HIP_ERR_UNSUPPORTED, "the two-trial pass has no run-time compiled kernel for this model");
+    case IK_MERIT:
+      if (row) return go(RTG_ROW_MERIT, (unsigned)((a.batch + 1) / 2), 0);
+      return go(RTG_MERIT, (unsigned)a.batch, a.al.enabled ? (unsigned)(GEN_AL_JV * sizeof(double)) : 0u);
     default: return fail(ALTRO_HIP_ERR_UNSUPPORTED, "operation %d has no run-time compiled kernel on this plan", which);
   }
 }
@@ -533,6 +567,7 @@ int altro_hip_set_model_source(altro_hip_batch* h, const char* source, float tim
     RtcGenModule* gm = nullptr;   // compile now: a source that does not build must fail HERE, with the compiler's log
     if ((rc = rtc_gen_module_for(h, &gm))) { h->rtc_source.clear(); h->model = ModelParams{MODEL_LINEAR, 0.0f, 0, 2.7, 1.5}; return rc; }
     h->model_set = true; h->rtc_has_constraints = false;
+    h->rtc_row32_ok = gm->row_ok;
     HIP_TRY(hipMemsetAsync(h->g_arr[G_f], 0, (size_t)h->batch * h->g_bstride[G_f] * h->esz, h->stream));
     HIP_TRY(hipMemsetAsync(h->g_arr[G_A], 0, (size_t)h->batch * h->g_bstride[G_A] * h->esz, h->stream));
     HIP_TRY(hipMemsetAsync(h->g_arr[G_B], 0, (size_t)h->batch * h->g_bstride[G_B] * h->esz, h->stream));
@@ -578,5 +613,7 @@ int altro_hip_set_model_source(altro_hip_batch* h, const char* source, float tim
   h->model_set = true;
   return 0;
 }
+
+int altro_hip_model_row_layout(const altro_hip_batch* h) { return (h && row32_model_eligible(h)) ? 1 : 0; }
 
 }  // extern "C"

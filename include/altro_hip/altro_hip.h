@@ -246,6 +246,12 @@ int altro_hip_set_model(altro_hip_batch* h, int model, float timestep, int bicyc
  * ALTRO_HIP_ERR_BAD_ARGUMENT with the compiler's log in altro_hip_last_error().  Whole solves of such a handle run on the
  * launch-sequenced loop.                                                                                              */
 int altro_hip_set_model_source(altro_hip_batch* h, const char* source, float timestep);
+/* Plans GENERIC / MFMA32: 1 when the handle's device model (compiled in, or the caller's source) runs the loop's ROW-LAYOUT model kernels
+ * (kernels/ilqr_row32.hip: two problems per wave, every lane evaluates the model -- plan MFMA32's shapes), 0 when it runs the
+ * wave-per-problem ones.  A model from source gets the row layout when hiprtc compiled those kernels without scratch memory (a sparse
+ * Jacobian written entry by entry does; a dense one of many states, or one filled by loops the compiler cannot unroll, does not) --
+ * same results either way (the sums are taken in the same order), about 3 x the speed.  0 on other plans.                         */
+int altro_hip_model_row_layout(const altro_hip_batch* h);
 /* ALTROSolver::SetConstraint with a general (nonlinear) callback pair (altro_solver.cpp:192-223, typedefs.hpp:41-53): when
  * the source above also defines
  *     template <typename T> __device__ void altro_user_constraint(int id, const T* x, const T* u, T* c);            // c[p]

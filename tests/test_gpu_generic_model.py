@@ -243,6 +243,9 @@ def test_a_callers_own_model_from_source_solves_like_the_compiled_in_one(plan):
             bt.set_model_source(QUADROTOR13_SRC, H)
         else:
             bt.set_model(altro_amd.MODEL_QUADROTOR13, H)
+        # plan MFMA32: both models on the row-layout kernels (the source's Jacobian is written entry by entry: hiprtc keeps it in
+        # registers, so its row-layout kernels are chosen -- altro_hip_model_row_layout); plan GENERIC by name: the same kernels
+        assert bt.model_row_layout()
         bt.set_tracking_cost(np.stack([c["Qd"], c["Qfd"]]), c["Rd"][None], np.stack([c["xref"], c["xref"]]), c["uref"][None],
                              k_stride_zero=True, batch_stride_zero=True)
         bt.set_initial_state(c["x0"])
@@ -330,6 +333,19 @@ def test_a_sixteen_state_model_from_source():
                 assert np.abs(fd - col).max() < 1e-6, (b, k, c)
     res = bt.ilqr_solve(iterations_max=60, tol_stationarity=1e-3)
     assert (res["status"] == 0).sum() >= batch - 2 and res["iterations"].max() < 60
+    # whichever model kernels the source got (the row layout when hiprtc kept its Jacobian in registers: altro_hip_model_row_layout),
+    # the wave-per-problem form takes the same iterations to the same trajectory
+    print("the (16, 5) chain from source runs the %s model kernels" % ("row-layout" if bt.model_row_layout() else "wave-per-problem"))
+    b2 = altro_amd.Batch(NN, nn, mm, batch)
+    b2.set_forms(altro_amd.FORM_GENERIC_MERIT_LDS)
+    b2.set_model_source(CHAIN_SRC, h)
+    assert not b2.model_row_layout()
+    b2.set_tracking_cost(np.stack([np.ones(nn), 10.0 * np.ones(nn)]), np.full((1, mm), 0.1), np.zeros((2, nn)), np.zeros((1, mm)),
+                         k_stride_zero=True, batch_stride_zero=True)
+    b2.set_initial_state(x0); b2.set_input_guess(u0)
+    r2 = b2.ilqr_solve(iterations_max=60, tol_stationarity=1e-3)
+    assert np.array_equal(res["status"], r2["status"]) and np.array_equal(res["iterations"], r2["iterations"])
+    np.testing.assert_allclose(bt.get_nominal()[0], b2.get_nominal()[0], rtol=1e-9, atol=1e-9)
 
 
 @pytest.mark.parametrize("constrained", [False, True])
