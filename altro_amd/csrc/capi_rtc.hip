@@ -291,8 +291,11 @@ static int rtc_tile_module_for(altro_hip_batch* h, int al, int dense, RtcTileMod
   hipDeviceProp_t prop;
   std::string arch = "--offload-arch=gfx950";
   if (hipGetDeviceProperties(&prop, h->device) == hipSuccess) arch = std::string("--offload-arch=") + prop.gcnArchName;
-  const char* opts[] = {arch.c_str(), "-O3", "-std=c++17"};
-  rr = R->CompileProgram(prog, 3, opts);
+  // (-unroll-threshold: tile_model_step finds the Jacobian's structural zeros with __builtin_constant_p, resolved right after the
+  //  compiler's early full-unroll pass -- the caller's zero fill must be unrolled by then, or all 192 entries count as nonzeros: the
+  //  merit kernels then spill 240-330 registers to scratch; see rtc_gen_module_for)
+  const char* opts[] = {arch.c_str(), "-O3", "-std=c++17", "-mllvm", "-unroll-threshold=5000"};
+  rr = R->CompileProgram(prog, 5, opts);
   if (rr != HIPRTC_SUCCESS) {
     size_t ls = 0;
     R->GetProgramLogSize(prog, &ls);

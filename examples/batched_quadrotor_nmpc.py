@@ -38,9 +38,11 @@ def plant(x, u, h):   # explicit midpoint, like the solver's discretisation (tes
 
 
 def main():
-    batch = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 50
-    sweeps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+    argv = [a for a in sys.argv if not a.startswith("--")]
+    batch = int(argv[1]) if len(argv) > 1 else 4096
+    steps = int(argv[2]) if len(argv) > 2 else 50
+    sweeps = int(argv[3]) if len(argv) > 3 else 3
+    from_source = "--source" in sys.argv          # the same model handed over as HIP source (altro_hip_set_model_source: hiprtc)
     N, n, m, h = 40, 12, 4, 0.02
     hover = np.array([MASS * GRAV, 0.0, 0.0, 0.0])
     Qd = np.concatenate([np.full(3, 4.0), np.full(3, 1.0), np.full(3, 0.5), np.full(3, 0.1)])
@@ -54,7 +56,11 @@ def main():
 
     bt = altro_amd.Batch(N, n, m, batch)
     assert bt.plan == altro_amd.PLAN_MFMA16
-    bt.set_model(altro_amd.MODEL_QUADROTOR, np.float32(h))
+    if from_source:
+        from tests.test_gpu_tile_model import QUADROTOR_SRC
+        bt.set_model_source(QUADROTOR_SRC, np.float32(h))
+    else:
+        bt.set_model(altro_amd.MODEL_QUADROTOR, np.float32(h))
     xref = np.stack([goal(k * h) for k in range(N + 1)])
     Q = np.tile(Qd, (1, N + 1, 1)); Q[0, N] *= 10.0
     bt.set_tracking_cost(Q, np.tile(Rd, (1, N, 1)), xref[None], np.tile(hover, (1, N, 1)), batch_stride_zero=True)
