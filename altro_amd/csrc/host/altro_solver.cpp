@@ -663,7 +663,8 @@ ErrorCodes SolverImpl::DeviceSolve() {
   }   // (a later Solve keeps the duals and restarts the penalty, as the host loop does: solver.cpp:429)
   std::vector<double> u0((size_t)N * m);
   for (int k = 0; k < N; ++k) std::copy(data[k].u_.begin(), data[k].u_.begin() + m, u0.begin() + (size_t)k * m);
-  if (altro_hip_set_initial_state(dev, data[0].x_.data(), 0)) return hip_fail("altro_hip_set_initial_state");
+  if ((int)initial_state.size() != n) return ALTRO_THROW("SetDeviceModel: the initial state is not set", ErrorCodes::DimensionMismatch);
+  if (altro_hip_set_initial_state(dev, initial_state.data(), 0)) return hip_fail("altro_hip_set_initial_state");   // (OpenLoopRollout's x_0: solver.cpp:119)
   if (altro_hip_set_input_guess(dev, u0.data(), 0, 0)) return hip_fail("altro_hip_set_input_guess");
   altro_hip_solve_options o;
   altro_hip_default_solve_options(&o);

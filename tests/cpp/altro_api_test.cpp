@@ -313,6 +313,7 @@ static void test_pendulum_device_model(bool constrained) {
   const float tf = constrained ? 2.0f : 3.0f;
   const float h = (float)(tf / static_cast<double>(N));
   std::vector<double> Qd(n, 1e-2), Rd(m, 1e-3), Qdf(n, 1.0), x0(n, 0.0), xf = {M_PI, 0.0}, uf(m, 0.0);
+  if (constrained) x0 = {0.3, -0.2};       // (a start away from the origin: SetInitialState must reach the device)
   std::vector<double> traj[2];
   int iters[2] = {0, 0}, iters2[2] = {0, 0};
   SolveStatus st[2];
