@@ -39,6 +39,19 @@ def test_slice_plan_generic_constrained_solves_against_the_oracle():
     assert int(m.group(2)) == 24 and int(m.group(1)) == 0
 
 
+def test_slice_plan_generic_second_order_cones_of_many_rows_against_the_oracle():
+    """fuzz_generic_al.py --big-soc: the same with second-order cones of 2 .. 12 rows among the blocks (plan GENERIC's lane-per-row cone,
+    round 6).  This seed: 1 of 24 cases differs -- a problem that converges in neither implementation stops at another sweep; no problem
+    that both solve ends differently."""
+    r = run("tests/soak/fuzz_generic_al.py", 24, 3, "--big-soc")
+    m = re.search(r"(\d+) of (\d+) cases differ", r.stdout)
+    assert m, r.stdout[-2000:] + r.stderr[-2000:]
+    assert int(m.group(2)) == 24 and int(m.group(1)) <= 1
+    assert len(re.findall(r"cones \[[^\]]*3[^\]]*\]", r.stdout)) >= 8          # (cases with a cone in them)
+    for a_st, b_st in re.findall(r"device status (\d) iterations \d+, oracle (\d) \d+", r.stdout):
+        assert not (a_st == "0" and b_st == "0")
+
+
 def test_slice_per_knot_point_dimensions_against_the_oracle():
     """fuzz_ragged_ilqr.py: (AL-)iLQR solves with per-knot-point dimensions against the oracle on the zero-padded uniform problem."""
     r = run("tests/soak/fuzz_ragged_ilqr.py", 12, 3)
