@@ -25,7 +25,8 @@ def main():
     batch = int(args[1]) if len(args) > 1 else 4096
     N = int(args[2]) if len(args) > 2 else 256
     boxes = "--boxes" in sys.argv
-    al = "--al" in sys.argv or boxes
+    soc = "--soc" in sys.argv                     # ||u[:3]|| <= 2 as a second-order cone instead of the input box (+ the state box with --boxes)
+    al = "--al" in sys.argv or boxes or soc
     n, m = 12, 4
     one = problems.c1_double_integrator(1, N=N)
     bt = altro_amd.Batch(N, n, m, batch, plan=altro_amd.PLAN_GENERIC if "--generic" in sys.argv else altro_amd.PLAN_AUTO)
@@ -33,7 +34,10 @@ def main():
     bt.set_tracking_cost(np.stack([np.ones(n), 100.0 * np.ones(n)]), np.full((1, m), 1e-2), np.zeros((2, n)), np.zeros((1, m)),
                          k_stride_zero=True, batch_stride_zero=True)
     bt.set_initial_state(2.0 * problems.uniform01((batch, n), 21) - 1.0)
-    if al:   # input bounds as an INEQUALITY block: the AL path of the same shape
+    if soc:
+        Gs = np.zeros((4, n + m)); Gs[0, n] = Gs[1, n + 1] = Gs[2, n + 2] = 1.0
+        bt.add_linear_constraint(0, N - 1, altro_amd.CONE_SOC, Gs, np.array([0.0, 0.0, 0.0, -2.0]))
+    elif al:   # input bounds as an INEQUALITY block: the AL path of the same shape
         G = np.zeros((2 * m, n + m)); G[:m, n:] = np.eye(m); G[m:, n:] = -np.eye(m)
         bt.add_linear_constraint(0, N - 1, altro_amd.CONE_INEQUALITY, G, np.full(2 * m, 2.0))
     if boxes:
@@ -55,7 +59,7 @@ def main():
     ts = sorted(ts[1:])
     print("C1 solve%s, %d problems, N = %d, ALTRO_HIP_MERIT2=%s: median %.3f ms (min %.3f, max %.3f) over %d solves; sweeps %d, "
           "merit launches %d, converged %d, max stationarity %.2e"
-          % ((" + input box + state box, plan %d" % bt.plan) if boxes else " + input bounds" if al else "", batch, N, os.environ.get("ALTRO_HIP_MERIT2", "unset"), ts[len(ts) // 2], ts[0], ts[-1],
+          % ((" + %s + state box, plan %d" % ("input cone" if soc else "input box", bt.plan)) if boxes else " + input cone" if soc else " + input bounds" if al else "", batch, N, os.environ.get("ALTRO_HIP_MERIT2", "unset"), ts[len(ts) // 2], ts[0], ts[-1],
              len(ts), res["sweeps"], res["merit_launches"], int((res["status"] == 0).sum()), float(np.abs(res["stationarity"]).max())))
     bt.close()
 
