@@ -657,9 +657,20 @@ ErrorCodes SolverImpl::DeviceSolve() {
   }
   if (altro_hip_set_quadratic_cost(dev, Q.data(), R.data(), H.data(), q.data(), r.data(), c.data(), 0, 0)) return hip_fail("altro_hip_set_quadratic_cost");
   if (fresh) {   // constraint blocks are fixed at Initialize(): once (their duals then persist from Solve to Solve, like the host loop's)
+    // runs of knot points with the same block become ONE block over the range (the device holds a handful of block definitions per
+    // handle, include/altro_hip/altro_hip.h: an input bound set for 0 <= k < N is one definition, not N)
+    struct Run { int k0, k1; const Constraint* cn; };
+    std::vector<Run> runs;
     for (int k = 0; k <= N; ++k)
-      for (const auto& cn : data[k].cons)
-        if (altro_hip_add_linear_constraint(dev, k, k, (int)cn.type, cn.dim, cn.G.data(), cn.g.data(), 0) < 0) return hip_fail("altro_hip_add_linear_constraint");
+      for (const auto& cn : data[k].cons) {
+        bool joined = false;
+        for (auto& r : runs)
+          if (r.k1 == k - 1 && r.cn->type == cn.type && r.cn->dim == cn.dim && r.cn->G == cn.G && r.cn->g == cn.g) { r.k1 = k; joined = true; break; }
+        if (!joined) runs.push_back(Run{k, k, &cn});
+      }
+    for (const auto& r : runs)
+      if (altro_hip_add_linear_constraint(dev, r.k0, r.k1, (int)r.cn->type, r.cn->dim, r.cn->G.data(), r.cn->g.data(), 0) < 0)
+        return hip_fail("altro_hip_add_linear_constraint");
   }   // (a later Solve keeps the duals and restarts the penalty, as the host loop does: solver.cpp:429)
   std::vector<double> u0((size_t)N * m);
   for (int k = 0; k < N; ++k) std::copy(data[k].u_.begin(), data[k].u_.begin() + m, u0.begin() + (size_t)k * m);

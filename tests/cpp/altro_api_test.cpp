@@ -360,6 +360,46 @@ static void test_pendulum_device_model(bool constrained) {
   }
 }
 
+// double_integrator_test.cpp's goal + control-bound problem (test_di_bounds above) with the device model and the constraints as data:
+// the bound is registered for 0 <= k < N in one call -- ONE block definition on the device, not N -- and the solve takes the callback
+// solver's five iterations to the same inputs.
+static void test_di_bounds_device_model() {
+  std::printf("[double integrator] device model, goal + control bounds as data (SetLinearConstraint)\n");
+  DIProblem p; p.x0 = {2.0, 2.0, 0.0, 0.0};
+  const double ub = 1.0;
+  double Gb[4 * 6] = {0}, gb[4] = {ub, ub, ub, ub}, Gg[4 * 4] = {0};
+  for (int i = 0; i < 2; ++i) { Gb[i + (4 + i) * 4] = 1.0; Gb[(i + 2) + (4 + i) * 4] = -1.0; }   // u - ub <= 0, -u - ub <= 0
+  for (int i = 0; i < 4; ++i) Gg[i + i * 4] = 1.0;
+  std::vector<double> u0s[2];
+  int iters[2] = {0, 0};
+  for (int dev = 0; dev < 2; ++dev) {
+    ALTROSolver s(p.N);
+    EXPECT(s.SetDimension(p.n, p.m, 0, LastIndex) == ErrorCodes::NoError);
+    EXPECT(s.SetTimeStep(p.h, 0, LastIndex) == ErrorCodes::NoError);
+    if (dev) EXPECT(s.SetDeviceModel(ALTRO_HIP_MODEL_DOUBLE_INTEGRATOR) == ErrorCodes::NoError);
+    else EXPECT(s.SetExplicitDynamics(di_dyn, di_jac, 0, LastIndex) == ErrorCodes::NoError);
+    EXPECT(s.SetLQRCost(p.n, p.m, p.Q.data(), p.R.data(), p.xf.data(), p.uf.data(), 0, LastIndex) == ErrorCodes::NoError);
+    EXPECT(s.SetInitialState(p.x0.data(), p.n) == ErrorCodes::NoError);
+    EXPECT(s.SetLinearConstraint(Gg, p.xf.data(), p.n, ConstraintType::EQUALITY, "Goal constraint", p.N, 0) == ErrorCodes::NoError);
+    EXPECT(s.SetLinearConstraint(Gb, gb, 4, ConstraintType::INEQUALITY, "Control bounds", 0, p.N) == ErrorCodes::NoError);
+    EXPECT(s.Initialize() == ErrorCodes::NoError);
+    di_guess(s, p);
+    AltroOptions o; o.penalty_initial = 100; o.penalty_scaling = 100;
+    s.SetOptions(o);
+    EXPECT(s.Solve() == SolveStatus::Success);
+    iters[dev] = s.GetIterations();
+    std::vector<double> xN(4);
+    s.GetState(xN.data(), p.N);
+    u0s[dev].resize((size_t)p.N * p.m);
+    for (int k = 0; k < p.N; ++k) s.GetInput(u0s[dev].data() + (size_t)k * p.m, k);
+    std::printf("   %s: iterations = %d, dist = %.3e, u0 = (%.6f, %.6f)\n", dev ? "device model  " : "host callbacks", iters[dev], dist(xN, p.xf), u0s[dev][0], u0s[dev][1]);
+    EXPECT(dist(xN, p.xf) < 1e-4);
+    EXPECT(std::fabs(u0s[dev][0] + ub) < 1e-4 && std::fabs(u0s[dev][1] + ub) < 1e-4);
+  }
+  EXPECT(iters[0] == 5 && iters[1] == 5);                 // double_integrator_test.cpp's count
+  EXPECT(dist(u0s[0], u0s[1]) < 1e-9);
+}
+
 // ALTROSolver::SetQuadraticCost (altro_solver.cpp:118-136) -- a DENSE cost with a cross term,
 // 1/2 x'Qx + 1/2 u'Ru + u'Hx + q'x + r'u + c, on the double integrator (with and without the goal constraint).  The blocks are
 // small closed forms so that tests/test_gpu_cpp_api.py can hand the very same numbers to the oracle
@@ -420,6 +460,7 @@ int main() {
   test_pendulum(true);
   test_pendulum_device_model(false);
   test_pendulum_device_model(true);
+  test_di_bounds_device_model();
   if (failures) { std::printf("%d EXPECTATION(S) FAILED\n", failures); return 1; }
   std::printf("OK\n");
   return 0;
