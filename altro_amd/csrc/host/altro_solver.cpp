@@ -655,7 +655,31 @@ ErrorCodes SolverImpl::DeviceSolve() {
     if (!diag) std::copy(kp.H.begin(), kp.H.begin() + (size_t)m * n, H.begin() + (size_t)k * m * n);
     std::copy(kp.r.begin(), kp.r.begin() + m, r.begin() + (size_t)k * m);
   }
-  if (altro_hip_set_quadratic_cost(dev, Q.data(), R.data(), H.data(), q.data(), r.data(), c.data(), 0, 0)) return hip_fail("altro_hip_set_quadratic_cost");
+  // A diagonal cost with no zero weight is SetLQRCost's tracking form 1/2 (x - xref)' Q (x - xref) + ... (altro_solver.cpp:138-172) up to a
+  // constant: handed over as such, the small plans run their whole solve in ONE launch (plan LANE's fused kernel) instead of the
+  // launch sequence the dense cost takes.  The constant (c_k - 1/2 xref' Q xref - 1/2 uref' R uref, summed) goes back into the objective.
+  bool tracking = true;
+  for (int k = 0; k <= N && tracking; ++k) {
+    const Knot& kp = data[k];
+    if (kp.cost_kind != CostKind::Diagonal) tracking = false;
+    for (int i = 0; i < n && tracking; ++i) if (kp.Q[i] == 0.0) tracking = false;
+    for (int i = 0; i < m && tracking && k < N; ++i) if (kp.R[i] == 0.0) tracking = false;
+  }
+  double objective_offset = 0.0;
+  if (tracking) {
+    std::vector<double> Qd((size_t)(N + 1) * n), Rd((size_t)N * m), xr((size_t)(N + 1) * n), ur((size_t)N * m);
+    for (int k = 0; k <= N; ++k) {
+      const Knot& kp = data[k];
+      double ct = 0.0;
+      for (int i = 0; i < n; ++i) { Qd[(size_t)k * n + i] = kp.Q[i]; xr[(size_t)k * n + i] = -kp.q[i] / kp.Q[i]; ct += 0.5 * xr[(size_t)k * n + i] * kp.Q[i] * xr[(size_t)k * n + i]; }
+      if (k < N)
+        for (int i = 0; i < m; ++i) { Rd[(size_t)k * m + i] = kp.R[i]; ur[(size_t)k * m + i] = -kp.r[i] / kp.R[i]; ct += 0.5 * ur[(size_t)k * m + i] * kp.R[i] * ur[(size_t)k * m + i]; }
+      objective_offset += kp.c - ct;
+    }
+    if (altro_hip_set_tracking_cost(dev, Qd.data(), Rd.data(), xr.data(), ur.data(), 0, 0)) return hip_fail("altro_hip_set_tracking_cost");
+  } else if (altro_hip_set_quadratic_cost(dev, Q.data(), R.data(), H.data(), q.data(), r.data(), c.data(), 0, 0)) {
+    return hip_fail("altro_hip_set_quadratic_cost");
+  }
   if (fresh) {   // constraint blocks are fixed at Initialize(): once (their duals then persist from Solve to Solve, like the host loop's)
     // runs of knot points with the same block become ONE block over the range (the device holds a handful of block definitions per
     // handle, include/altro_hip/altro_hip.h: an input bound set for 0 <= k < N is one definition, not N)
@@ -701,8 +725,8 @@ ErrorCodes SolverImpl::DeviceSolve() {
   stats.iterations = res.iterations;
   stats.stationarity = res.stationarity;
   stats.primal_feasibility = res.primal_feasibility;
-  stats.objective_value = res.final_phi;
-  phi = res.final_phi;
+  stats.objective_value = res.final_phi + objective_offset;
+  phi = stats.objective_value;
   rho = res.penalty;
   stats.solve_time = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start);
   return ErrorCodes::NoError;
