@@ -17,6 +17,7 @@
 
 #include "altro/altro.hpp"
 
+#include "altro_hip/altro_hip.h"
 using namespace altro;
 
 namespace {
@@ -104,7 +105,11 @@ int main(int argc, char** argv) {
   auto ok = [&bad](ErrorCodes e) { if (e != ErrorCodes::NoError) ++bad; };
   ALTROSolver solver(N);
   ok(solver.SetDimension(n, m));
+#ifdef DEVICE_MODEL   // the whole Solve on the device (ALTROSolver::SetDeviceModel: altro_hip_ilqr_solve on a resident batch of one)
+  ok(solver.SetDeviceModel(ALTRO_HIP_MODEL_BICYCLE, 0, kLength, kRear));
+#else
   ok(solver.SetExplicitDynamics(step, step_jac));
+#endif
   ok(solver.SetTimeStep(h));
   for (int k = 0; k <= N; ++k) ok(solver.SetLQRCost(n, m, Qd, Rd, &xr[k * n], &ur[k * m], k));
   const double delta_max = 60 * M_PI / 180.0;
@@ -114,7 +119,18 @@ int main(int argc, char** argv) {
     J[0 + 3 * 2] = 1.0;
     J[1 + 3 * 2] = -1.0;
   };
+#ifdef DEVICE_MODEL
+  (void)con; (void)con_jac;
+  {
+    double G[2 * (n + m)] = {0}, Gt[2 * n] = {0};
+    const double g[2] = {delta_max, delta_max};
+    G[0 + 3 * 2] = 1.0; G[1 + 3 * 2] = -1.0; Gt[0 + 3 * 2] = 1.0; Gt[1 + 3 * 2] = -1.0;
+    ok(solver.SetLinearConstraint(G, g, 2, ConstraintType::INEQUALITY, "steering angle bound", 0, N));
+    ok(solver.SetLinearConstraint(Gt, g, 2, ConstraintType::INEQUALITY, "steering angle bound", N, N + 1));
+  }
+#else
   ok(solver.SetConstraint(con, con_jac, 2, ConstraintType::INEQUALITY, "steering angle bound", 0, N + 1));
+#endif
   ok(solver.SetInitialState(&xr[0], n));
   ok(solver.Initialize());
   const double u0[m] = {ur[0], 0.0};

@@ -121,3 +121,30 @@ def test_cpp_altro_solver_reproduces_the_references_saved_mpc_run():
     assert same == NSIM, np.flatnonzero(iters != exp["solve_iters"])
     assert ex < 1e-9 and eu < 1e-9
     np.testing.assert_allclose(err, exp["tracking_error"], rtol=0, atol=1e-9)
+
+
+def test_cpp_altro_solver_with_a_device_model_reproduces_the_references_saved_mpc_run():
+    """The same program with ALTROSolver::SetDeviceModel(ALTRO_HIP_MODEL_BICYCLE) + SetLinearConstraint in the place of the callback
+    pairs (tests/cpp/bicycle_mpc_test.cpp, -DDEVICE_MODEL): every Solve() of the 200-step run is altro_hip_ilqr_solve on a resident batch of
+    one, warm-started through the class's UpdateLinearCosts / SetInitialState / ShiftTrajectory -- the file's iteration counts, states
+    and inputs."""
+    x_ref, u_ref, exp = problems.scotty()
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "scotty.txt")
+        with open(path, "w") as f:
+            f.write("%d\n" % len(x_ref))
+            for x, u in zip(x_ref, u_ref):
+                f.write(" ".join(repr(float(v)) for v in list(x) + list(u)) + "\n")
+        rc, out, errtxt = cpp_build.run("bicycle_mpc_test", args=[path, NSIM], timeout=900, defines=["DEVICE_MODEL"], out_name="bicycle_mpc_test_device_model")
+    assert rc == 0 and out.strip().endswith("OK"), out[-2000:] + errtxt[-2000:]
+    rows = [l.split() for l in out.splitlines() if l.startswith("step ")]
+    assert len(rows) == NSIM
+    iters = np.array([int(r[3]) for r in rows]); status = np.array([int(r[5]) for r in rows])
+    us = np.array([[float(v) for v in r[7:9]] for r in rows]); xs = np.array([[float(v) for v in r[10:14]] for r in rows])
+    rate = [l for l in out.splitlines() if l.startswith("Average rate")][0]
+    same = int((iters == exp["solve_iters"]).sum())
+    ex, eu = np.abs(xs - exp["state_trajectory"][1:]).max(), np.abs(us - exp["input_trajectory"]).max()
+    print("scotty through ALTROSolver::SetDeviceModel: solve_iters equal %d / %d, max |x - x_file| %.3g, max |u - u_file| %.3g; %s" % (same, NSIM, ex, eu, rate))
+    assert (status == 0).all()
+    assert same == NSIM, np.flatnonzero(iters != exp["solve_iters"])
+    assert ex < 1e-8 and eu < 1e-8
