@@ -630,6 +630,50 @@ def other_config_entry(key, device, steps, torch, cpu_seconds=2.0, live=None):
     return out
 
 
+def quad13_nmpc_entry(device, torch, batch=4096, N=30, steps=6):
+    """config.other_configs.quad13_nmpc (round 6): nonlinear dynamics past the (12, 4) tile -- a batched receding-horizon NMPC of
+    13-state quaternion quadrotors on plan MFMA32, the compiled-in device model in the row-layout loop kernels
+    (kernels/ilqr_row32.hip: r32_model_step), warm steps timed on the host clock around altro_hip_ilqr_solve."""
+    import time
+
+    import altro_amd
+    n, m, h = 13, 4, np.float32(0.02)
+    hover = np.array([0.5 * 9.81, 0.0, 0.0, 0.0])
+    rng = np.random.default_rng(7)
+    x0 = np.zeros((batch, n))
+    x0[:, :3] = 0.8 * rng.standard_normal((batch, 3))
+    q = np.concatenate([np.ones((batch, 1)), 0.12 * rng.standard_normal((batch, 3))], axis=1)
+    x0[:, 3:7] = q / np.linalg.norm(q, axis=1, keepdims=True)
+    x0[:, 7:10] = 0.3 * rng.standard_normal((batch, 3)); x0[:, 10:] = 0.2 * rng.standard_normal((batch, 3))
+    xref = np.zeros(n); xref[3] = 1.0
+    Qd = np.concatenate([np.full(3, 2.0), np.full(4, 1.0), np.full(3, 0.5), np.full(3, 0.1)])
+    Rd = np.array([0.05, 20.0, 20.0, 20.0])
+    bt = altro_amd.Batch(N, n, m, batch, device=device)
+    try:
+        bt.set_model(altro_amd.MODEL_QUADROTOR13, h)
+        bt.set_tracking_cost(np.stack([Qd, 20.0 * Qd]), Rd[None], np.stack([xref, xref]), hover[None], k_stride_zero=True, batch_stride_zero=True)
+        bt.set_initial_state(x0)
+        bt.set_input_guess(hover[None, None], k_stride_zero=True, batch_stride_zero=True)
+        res = bt.ilqr_solve(iterations_max=40, tol_stationarity=1e-3)
+        first = {"sweeps": int(res["sweeps"]), "converged": int((res["status"] == 0).sum())}
+        ts, sw, it = [], [], []
+        for _ in range(steps):
+            x1, _u = bt.get_knot(1)
+            bt.set_initial_state(x1)
+            bt.shift_trajectory()
+            bt.synchronize(); t0 = time.perf_counter()
+            res = bt.ilqr_solve(iterations_max=40, tol_stationarity=1e-3)
+            bt.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
+            sw.append(int(res["sweeps"])); it.append(float(res["iterations"].mean()))
+        med = sorted(ts)[len(ts) // 2]
+        return {"workload": "batched NMPC of %d 13-state quaternion quadrotors (MODEL_QUADROTOR13), N = %d, h = 0.02, warm receding-horizon steps" % (batch, N),
+                "plan": int(bt.plan), "model_kernels": "row layout" if bt.model_row_layout() else "wave per problem",
+                "ms_per_step_median": med, "ms_per_step": ts, "sweeps": sw, "mean_iterations": it, "first_solve": first,
+                "vehicle_steps_per_s": batch / (med * 1e-3)}
+    finally:
+        bt.close()
+
+
 def mfma32_entry(n, m, device, steps, torch, cpu_seconds=2.0, N=128, batch=4096):
     """Plan MFMA32 (kernels/tvlqr_tile32.hip): the TVLQR sweep of a shape one step past the (12, 4) tile -- (13, 4), a quaternion
     quadrotor's dimensions, and (28, 4) -- at the shape-cliff table's size (4096 problems x 128 knot points, random LTV problems,
@@ -972,6 +1016,10 @@ def main():
                 others["mfma32_%dx%d" % (n_, m_)] = mfma32_entry(n_, m_, local_rank, args.other_steps, torch, 0.0 if args.no_cpu_baseline else 2.0)
             except Exception as e:   # noqa: BLE001
                 others["mfma32_%dx%d" % (n_, m_)] = {"error": str(e)}
+        try:   # nonlinear dynamics past the tile: the device model in the row-layout loop kernels (round 6)
+            others["quad13_nmpc"] = quad13_nmpc_entry(local_rank, torch)
+        except Exception as e:   # noqa: BLE001
+            others["quad13_nmpc"] = {"error": str(e)}
     else:
         bytes_keep = (bt.algorithmic_bytes(0), bt.algorithmic_bytes(1))
 
