@@ -80,6 +80,8 @@ class BatchSolver {
   }
   // SetExplicitDynamics with the caller's own continuous model as HIP source, compiled at run time (altro_hip_set_model_source)
   void SetModelSource(const char* source, float timestep) { Check(altro_hip_set_model_source(h_, source, timestep)); }
+  // whether the device model runs the loop's row-layout model kernels (plans GENERIC / MFMA32; altro_hip_model_row_layout)
+  bool ModelRowLayout() const { return altro_hip_model_row_layout(h_) != 0; }
   void SetInitialState(const double* x0, bool shared_over_batch = false) {
     Check(altro_hip_set_initial_state(h_, x0, shared_over_batch));
   }
