@@ -396,3 +396,71 @@ def test_row_layout_model_merit_equals_the_lds_form(constrained):
         exact += int(np.array_equal(a, b))
     assert (out["row"]["solve_status"] == 0).sum() >= batch - 2
     print("row-layout model merit == LDS form bit for bit in %d of %d quantities%s" % (exact, len(out["row"]), " (thrust bound)" if constrained else ""))
+
+
+DENSE_SRC = r"""
+// fourteen states, five inputs, every state coupled to every other: xdot_i = -x_i + 0.1 sum_j sin(x_j - x_i) + (i < 5 ? u_i : 0)
+template <typename T>
+__device__ void altro_user_dynamics(const T* x, const T* u, T* xd) {
+  for (int i = 0; i < 14; ++i) {
+    T s = T(0);
+    for (int j = 0; j < 14; ++j) s += sin(x[j] - x[i]);
+    xd[i] = -x[i] + T(0.1) * s + (i < 5 ? u[i] : T(0));
+  }
+}
+template <typename T>
+__device__ void altro_user_jacobian(const T* x, const T* u, T* J) {
+  const int n = 14;
+  for (int e = 0; e < 14 * 19; ++e) J[e] = T(0);
+  for (int i = 0; i < 14; ++i) {
+    T d = T(0);
+    for (int j = 0; j < 14; ++j) {
+      const T c = T(0.1) * cos(x[j] - x[i]);
+      if (j != i) { J[i + j * n] = c; d += c; }
+    }
+    J[i + i * n] = T(-1) - d;
+    if (i < 5) J[i + (14 + i) * n] = T(1);
+  }
+}
+"""
+
+
+def test_a_dense_model_from_source_keeps_the_wave_per_problem_kernels():
+    """The row-layout model kernels keep the whole first Jacobian in every lane's registers; a DENSE one of fourteen states does not fit
+    (hiprtc's kernels for it use scratch memory), so altro_hip_set_model_source leaves such a source on the wave-per-problem kernels --
+    altro_hip_model_row_layout says so -- and the solve is what it was: A_k, B_k against central differences of numpy's midpoint rule,
+    whole solves converge."""
+    nn, mm, NN, batch = 14, 5, 20, 12
+    h = np.float32(0.05)
+
+    def f(x, u):
+        d = x[..., None, :] - x[..., :, None]                       # d[i, j] = x_j - x_i
+        xd = -x + 0.1 * np.sin(d).sum(axis=-1)
+        xd[..., :5] += u
+        return xd
+
+    def step(x, u):
+        return x + float(h) * f(x + float(np.float32(h / 2)) * f(x, u), u)
+    rng = np.random.default_rng(11)
+    x0 = 0.6 * rng.standard_normal((batch, nn)); u0 = 0.2 * rng.standard_normal((batch, NN, mm))
+    bt = altro_amd.Batch(NN, nn, mm, batch)
+    assert bt.plan == altro_amd.PLAN_MFMA32
+    bt.set_model_source(DENSE_SRC, h)
+    assert not bt.model_row_layout()
+    bt.set_tracking_cost(np.stack([np.ones(nn), 10.0 * np.ones(nn)]), np.full((1, mm), 0.1), np.zeros((2, nn)), np.zeros((1, mm)),
+                         k_stride_zero=True, batch_stride_zero=True)
+    bt.set_initial_state(x0); bt.set_input_guess(u0)
+    bt.open_loop_rollout(); bt.accept(); bt.expand()
+    xr = bt.get("x").reshape(batch, NN + 1, nn)
+    A, B, _, _ = bt.get_expansion()
+    for b in (0, 7):
+        for k in (0, NN - 1):
+            Ak, Bk = A[b, k].reshape(nn, nn).T, B[b, k].reshape(mm, nn).T
+            for c in range(nn + mm):
+                e = np.zeros(nn + mm); e[c] = 1e-6
+                fd = (step(xr[b, k] + e[:nn], u0[b, k] + e[nn:]) - step(xr[b, k] - e[:nn], u0[b, k] - e[nn:])) / 2e-6
+                col = Ak[:, c] if c < nn else Bk[:, c - nn]
+                assert np.abs(fd - col).max() < 1e-6, (b, k, c)
+    res = bt.ilqr_solve(iterations_max=60, tol_stationarity=1e-3)
+    assert (res["status"] == 0).sum() >= batch - 1
+    bt.close()
